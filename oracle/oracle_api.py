@@ -1,0 +1,66 @@
+"""ctypes access to the oracle (oracle/_build/libx265oracle*.so) - TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package never does (tests/test_no_oracle_in_product.py enforces it).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_libs = {}
+
+
+def host_has_avx2() -> bool:
+    try:
+        return " avx2 " in open("/proc/cpuinfo").read().replace("\n", " ")
+    except OSError:
+        return False
+
+
+def lib(avx2: bool = False) -> ctypes.CDLL:
+    key = bool(avx2)
+    if key not in _libs:
+        name = "libx265oracle_avx2.so" if avx2 else "libx265oracle.so"
+        path = os.path.join(_HERE, "_build", name)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle oracle` (or __graft_entry__.build())")
+        _libs[key] = ctypes.CDLL(path)
+    return _libs[key]
+
+
+def me_fullsearch(depth, fenc, fenc_stride, fenc_org, fref, fref_stride, fref_org, width, height, rng,
+                  ctu_begin, ctu_end, cost_x, cost_y, want_surf=True, want_best=True, levels=(0, 1, 2, 3),
+                  nthreads=0, avx2=False):
+    """Run the CPU restatement of the exhaustive search on padded host planes (numpy).
+    Returns (surf list, best list) with the same layouts as the HIP ABI (full-frame sized arrays;
+    only CTUs [ctu_begin, ctu_end) are filled)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_me_fullsearch_d{depth}")
+    nctu = (width // 64) * (height // 64)
+    nc = 2 * rng + 1
+    pus = (64, 16, 4, 1)
+    surf = [None] * 4
+    best = [None] * 4
+    sp = (ctypes.c_void_p * 4)()
+    bp = (ctypes.c_void_p * 4)()
+    for l in levels:
+        if want_surf:
+            surf[l] = np.zeros(nctu * nc * nc * pus[l], dtype=np.int32)
+            sp[l] = surf[l].ctypes.data
+        if want_best:
+            best[l] = np.full(nctu * pus[l], 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+            bp[l] = best[l].ctypes.data
+    es = fenc.itemsize
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_ssize_t,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    cx = np.ascontiguousarray(cost_x, dtype=np.uint16)
+    cy = np.ascontiguousarray(cost_y, dtype=np.uint16)
+    fn(fenc.ctypes.data + fenc_org * es, fenc_stride, fref.ctypes.data + fref_org * es, fref_stride,
+       width, height, rng, ctu_begin, ctu_end, ctypes.addressof(sp), ctypes.addressof(bp),
+       cx.ctypes.data, cy.ctypes.data, nthreads)
+    return surf, best

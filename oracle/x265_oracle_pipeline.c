@@ -1,0 +1,117 @@
+/* oracle/x265_oracle_pipeline.c
+ *
+ * TEST INFRASTRUCTURE - NOT PRODUCT CODE (same rules as x265_oracle.c).
+ *
+ * CPU restatement of how the reference's CALLERS drive the primitives for the batched stages of
+ * the frame pipeline, written against the oracle table only (so it is "the reference's CPU path":
+ * per-PU calls of pu[].sad / sad_x4 exactly as motion.cpp issues them).  Used by tests as the
+ * checker for the HIP batch kernels and by bench.py's cpu_baseline leg (OpenMP over CTUs).
+ *
+ * Stage: exhaustive integer motion search.  Follows MotionEstimate::setSourcePU
+ * (source/encoder/motion.cpp:189-222: the PU is copied into a FENC_STRIDE=64 buffer) and the
+ * X265_FULL_SEARCH loop (motion.cpp:1397-1445: raster scan of the mv window, sad_x4 on groups of
+ * four consecutive x positions, plain sad for the remainder, COPY2_IF_LT = strict less-than), with
+ * the search window centred on the PU (mvp = 0) and bcost starting at "infinity".
+ */
+#ifndef X265HIP_DEPTH
+#error "compile with -DX265HIP_DEPTH=8|10|12"
+#endif
+#include "x265hip_table.h"
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef x265hip_pixel pixel;
+#define CAT_(a, b)   a##b
+#define CAT(a, b)    CAT_(a, b)
+#define EXPORT(name) CAT(CAT(name, _d), X265HIP_DEPTH)
+
+void EXPORT(x265oracle_setup_primitives)(x265hip_EncoderPrimitives* p);
+
+/* z-order index -> (x, y) in units of the PU size inside the CTU */
+static void zorder_xy(int z, int* x, int* y)
+{
+    *x = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4);
+    *y = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+}
+
+static const int kLevelSize[4] = { 8, 16, 32, 64 };
+static const int kLevelPU[4] = { X265HIP_LUMA_8x8, X265HIP_LUMA_16x16, X265HIP_LUMA_32x32, X265HIP_LUMA_64x64 };
+
+/* surf[l] : int32 [ctu][mvy][mvx][pu]   best[l] : uint64 [ctu][pu] = cost << 32 | (mvyi * NC + mvxi)
+ * Any of the 8 output pointers may be NULL.  Processes CTUs [ctuBegin, ctuEnd). Returns 0. */
+int EXPORT(x265oracle_me_fullsearch)(const pixel* fenc, intptr_t fencStride, const pixel* fref, intptr_t frefStride,
+                                     int width, int height, int range, int ctuBegin, int ctuEnd,
+                                     int32_t** surf, uint64_t** best, const uint16_t* costX, const uint16_t* costY,
+                                     int nthreads)
+{
+    static x265hip_EncoderPrimitives prim;
+    static int ready = 0;
+    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    const int ctusW = width / 64;
+    const int NC = 2 * range + 1;
+    (void)height;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int ctu = ctuBegin; ctu < ctuEnd; ctu++)
+    {
+        const int cx = (ctu % ctusW) * 64, cy = (ctu / ctusW) * 64;
+        pixel fencPU[64 * 64] __attribute__((aligned(64)));
+        for (int l = 0; l < 4; l++)
+        {
+            if (!(surf && surf[l]) && !(best && best[l]))
+                continue;
+            const int n = kLevelSize[l], npu = (64 / n) * (64 / n);
+            const struct x265hip_PU* pu = &prim.pu[kLevelPU[l]];
+            for (int z = 0; z < npu; z++)
+            {
+                int bx, by;
+                zorder_xy(z, &bx, &by);
+                const int px = cx + bx * n, py = cy + by * n;
+                /* setSourcePU: private copy at stride 64 */
+                pu->copy_pp(fencPU, 64, fenc + (intptr_t)py * fencStride + px, fencStride);
+                const pixel* refPU = fref + (intptr_t)py * frefStride + px;
+                uint32_t bcost = 0xFFFFFFFFu; uint32_t bidx = 0xFFFFFFFFu;
+                for (int my = -range; my <= range; my++)
+                {
+                    for (int mx = -range; mx <= range; )
+                    {
+                        int32_t costs[4];
+                        int cnt;
+                        const pixel* base = refPU + (intptr_t)my * frefStride + mx;
+                        if (mx + 3 <= range)
+                        {
+                            pu->sad_x4(fencPU, base, base + 1, base + 2, base + 3, frefStride, costs);
+                            cnt = 4;
+                        }
+                        else
+                        {
+                            costs[0] = pu->sad(fencPU, 64, base, frefStride);
+                            cnt = 1;
+                        }
+                        for (int k = 0; k < cnt; k++, mx++)
+                        {
+                            const int xi = mx + range, yi = my + range;
+                            if (surf && surf[l])
+                                surf[l][(((size_t)ctu * NC + yi) * NC + xi) * npu + z] = costs[k];
+                            if (best && best[l])
+                            {
+                                const uint32_t c = (uint32_t)costs[k] + costX[xi] + costY[yi];
+                                if (c < bcost) { bcost = c; bidx = (uint32_t)(yi * NC + xi); }
+                            }
+                        }
+                    }
+                }
+                if (best && best[l])
+                    best[l][(size_t)ctu * npu + z] = ((uint64_t)bcost << 32) | bidx;
+            }
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,85 @@
+"""GPU parity: CTU-tiled exhaustive motion search (x265hip_me_fullsearch) vs the oracle's
+restatement of the reference full search (motion.cpp:1397-1445 over pu[].sad / sad_x4)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+pkg = importlib.import_module("x265-yuuki-asuna_amd")
+F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_api
+    return oracle_api
+
+
+def _run(width, height, rng, depth, seed, extreme=None):
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=seed)
+    y0, y1 = clip[0][0], clip[1][0]
+    if extreme == "flat":
+        y0 = np.zeros_like(y0); y1 = np.full_like(y1, (1 << depth) - 1)
+    cur, ref = P.DevicePicture(y1, dev), P.DevicePicture(y0, dev)
+    ms = P.MotionSearch(cur.w64, cur.h64, rng, depth, dev)
+    ms.run(cur, ref)
+    torch.cuda.synchronize()
+    O = _oracle()
+    nctu = ms.nctu
+    surf, best = O.me_fullsearch(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org,
+                                 cur.w64, cur.h64, rng, 0, nctu, ms.cost_host, ms.cost_host)
+    for l in range(4):
+        g = ms.surf[l].cpu().numpy()
+        assert np.array_equal(g, surf[l]), f"surface level {l} differs ({np.count_nonzero(g != surf[l])} of {g.size})"
+        gb = ms.best[l].cpu().numpy().view(np.uint64)
+        assert np.array_equal(gb, best[l]), f"best level {l} differs"
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_me_small_range(depth):
+    _run(128, 128, 8, depth, seed=1)
+
+
+def test_me_non_ctu_multiple_picture():
+    _run(200, 136, 12, 8, seed=2)       # padded to 256x192 like the reference's whole-CTU allocation
+
+
+def test_me_extremes():
+    _run(128, 64, 5, 8, seed=3, extreme="flat")   # all-min vs all-max (TestBench cases [1]/[2])
+    _run(64, 64, 5, 10, seed=3, extreme="flat")
+
+
+def test_me_default_merange_one_ctu_row():
+    _run(256, 64, 57, 8, seed=4)        # the reference's default merange (param.cpp:198)
+
+
+def test_me_hierarchy_property_full_size():
+    """Size-independent property at a BASELINE size (1080p): every parent SAD equals the sum of its four
+    children at the same mv, and the best key is <= every candidate's key."""
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(1920, 1080, 2, depth=8, seed=5)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    ms = P.MotionSearch(cur.w64, cur.h64, 16, 8, dev)
+    ms.run(cur, ref)
+    torch.cuda.synchronize()
+    nmv = ms.nctu * ms.nc * ms.nc
+    for l in range(3):
+        child = ms.surf[l].view(nmv, P.LEVEL_PUS[l] // 4, 4).sum(dim=2)
+        parent = ms.surf[l + 1].view(nmv, P.LEVEL_PUS[l + 1])
+        assert torch.equal(child, parent)
+    # spot-check one CTU against the oracle at full picture size
+    O = _oracle()
+    ctu = 257
+    surf, best = O.me_fullsearch(8, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org,
+                                 cur.w64, cur.h64, 16, ctu, ctu + 1, ms.cost_host, ms.cost_host)
+    per = ms.nc * ms.nc * 64
+    assert np.array_equal(ms.surf[0][ctu * per:(ctu + 1) * per].cpu().numpy(), surf[0][ctu * per:(ctu + 1) * per])
+    assert np.array_equal(ms.best[3][ctu:ctu + 1].cpu().numpy().view(np.uint64), best[3][ctu:ctu + 1])

@@ -1,0 +1,100 @@
+// runtime.hip - process-level state of libx265hip.so: device selection, error text.
+// There is deliberately no CPU fallback here: if HIP cannot give us a gfx950 device every
+// entry point returns X265HIP_ENODEV and x265hip_last_error() says why.
+#include "common.h"
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+namespace x265hip {
+
+static thread_local char t_err[512] = "";
+static std::once_flag g_initOnce;
+static int g_initRc = X265HIP_ENODEV;
+static int g_device = -1;
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what)
+{
+    if (e == hipSuccess)
+        return 0;
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return X265HIP_ENODEV;
+}
+
+static void do_init(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+    {
+        set_error("no HIP device available (hipGetDeviceCount: %s, count %d); libx265hip has no CPU fallback",
+                  hipGetErrorString(e), n);
+        g_initRc = X265HIP_ENODEV;
+        return;
+    }
+    if (device < 0 || device >= n)
+        device = 0;
+    hipDeviceProp_t prop;
+    if (check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) { g_initRc = X265HIP_ENODEV; return; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    {
+        set_error("device %d is %s; this library only carries gfx950 (MI355X) code objects", device, prop.gcnArchName);
+        g_initRc = X265HIP_ENODEV;
+        return;
+    }
+    g_device = device;
+    g_initRc = 0;
+}
+
+int ensure_device()
+{
+    std::call_once(g_initOnce, do_init, -1);
+    if (g_initRc)
+    {
+        if (!t_err[0])
+            set_error("libx265hip: no usable gfx950 device (initialisation failed earlier)");
+        return g_initRc;
+    }
+    return 0;
+}
+
+} // namespace x265hip
+
+using namespace x265hip;
+
+extern "C" {
+
+const char* x265hip_version(void) { return "x265hip 0.1 (gfx950, x265 3.5 EncoderPrimitives ABI, X265_BUILD 199)"; }
+
+const char* x265hip_last_error(void) { return t_err; }
+
+int x265hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int x265hip_init(int device)
+{
+    std::call_once(g_initOnce, do_init, device);
+    if (g_initRc)
+        return g_initRc;
+    /* a host process that already picked a device through another runtime user (torch) keeps it:
+     * we launch on whatever device is current for the calling thread */
+    return 0;
+}
+
+} // extern "C"

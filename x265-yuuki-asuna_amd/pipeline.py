@@ -1,0 +1,93 @@
+"""Frame pipeline driver (tier T2 of SURVEY.md section 7): issues the encoder's block-primitive
+work for whole frames as batched HIP launches, everything resident in HBM.
+
+It is NOT an HEVC encoder: it runs the data-parallel stages the reference's callers
+(motion.cpp / search.cpp / quant.cpp / framefilter.cpp) spend their time in, in the same
+dependency order, through the C ABI of libx265hip.so, and produces integer results (SAD surfaces,
+motion vectors, ...) that the tests compare bit-for-bit with the oracle.
+
+Stages implemented so far
+  ME   exhaustive integer motion search for every 8x8..64x64 PU of every CTU
+       (x265hip_me_fullsearch; reference caller motion.cpp:1397-1445, primitives pu[].sad/sad_x4)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import frames as F
+from . import hipabi
+
+LEVEL_SIZES = (8, 16, 32, 64)
+LEVEL_PUS = (64, 16, 4, 1)
+
+
+class DevicePicture:
+    """A padded picture plane in HBM (layout: frames.padded_dims)."""
+
+    def __init__(self, img: np.ndarray, device):
+        import torch
+        buf, self.stride, self.org, self.w64, self.h64 = F.pad_plane(img)
+        self.depth = 8 if img.dtype == np.uint8 else 10
+        if img.dtype == np.uint8:
+            self.t = torch.from_numpy(buf).to(device)
+        else:
+            self.t = torch.from_numpy(buf.view(np.int16)).to(device)   # torch has no uint16 arithmetic; raw bits only
+        self.host = buf
+
+
+class MotionSearch:
+    """Owns the output buffers of the ME stage for one picture size."""
+
+    def __init__(self, w64, h64, rng, depth, device, want_surf=True, want_best=True, lam=4.0, levels=(0, 1, 2, 3)):
+        import torch
+        self.w64, self.h64, self.range, self.depth = w64, h64, rng, depth
+        self.nctu = (w64 // 64) * (h64 // 64)
+        self.nc = 2 * rng + 1
+        self.levels = levels
+        self.surf = [None] * 4
+        self.best = [None] * 4
+        for l in levels:
+            if want_surf:
+                self.surf[l] = torch.empty(self.nctu * self.nc * self.nc * LEVEL_PUS[l], dtype=torch.int32, device=device)
+            if want_best:
+                self.best[l] = torch.empty(self.nctu * LEVEL_PUS[l], dtype=torch.int64, device=device)
+        cost = F.mv_cost_table(rng, lam)
+        self.cost_host = cost
+        self.cost_x = torch.from_numpy(cost.view(np.int16)).to(device)
+        self.cost_y = self.cost_x.clone()
+
+    def surface_bytes(self):
+        return sum(t.numel() * 4 for t in self.surf if t is not None)
+
+    def algorithmic_bytes(self, bpp=1):
+        """SURVEY.md section 8(d), batched full-window SAD: per PU (W*H + (W+2R)(H+2R))*bpp read +
+        4*(2R+1)^2 written when the surface is produced (8 bytes per PU when only the minimum is)."""
+        r = self.range
+        total = 0
+        for l in self.levels:
+            n = LEVEL_SIZES[l]
+            npu = self.nctu * LEVEL_PUS[l]
+            rd = (n * n + (n + 2 * r) * (n + 2 * r)) * bpp
+            wr = 4 * self.nc * self.nc if self.surf[l] is not None else 8
+            total += npu * (rd + wr)
+        return total
+
+    def run(self, cur: DevicePicture, ref: DevicePicture):
+        for l in self.levels:
+            if self.best[l] is not None:
+                hipabi.me_best_reset(self.best[l])
+        hipabi.me_fullsearch(self.depth, self.w64, self.h64, self.range,
+                             cur.t, cur.stride, ref.t, ref.stride,
+                             surf=self.surf, best=self.best, cost_x=self.cost_x, cost_y=self.cost_y,
+                             fenc_off=cur.org, fref_off=ref.org)
+
+    def checksum(self):
+        """Order-independent digest of the stage outputs (sum of best keys / surface sums)."""
+        import torch
+        out = {}
+        for l in self.levels:
+            if self.best[l] is not None:
+                out[f"best{LEVEL_SIZES[l]}"] = int(self.best[l].sum().item())
+            if self.surf[l] is not None:
+                out[f"surf{LEVEL_SIZES[l]}"] = int(self.surf[l].sum(dtype=torch.int64).item())
+        return out
