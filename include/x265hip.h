@@ -32,6 +32,7 @@
 extern "C" {
 #endif
 
+#define X265HIP_ME_PUS_PER_CTU 85  /* 64 + 16 + 4 + 1 */
 #define X265HIP_OK            0
 #define X265HIP_ENODEV       -1   /* no HIP device / runtime error (see x265hip_last_error) */
 #define X265HIP_EINVAL       -2   /* bad argument (size, depth, alignment, NULL) */
@@ -76,11 +77,13 @@ int x265hip_pixelcmp_batch(int kind, int depth, int w, int h,
  *   fenc, fref : luma planes, (0,0) pixel pointers; fref must have >= range + 8 valid pixels of
  *                margin on every side (reference picyuv.cpp:87-114 guarantees 96 / 80).
  *   width, height : multiples of 64 (the reference allocates whole CTUs).
- *   surf[l]    : optional SAD surfaces, l = 0..3 for 8x8, 16x16, 32x32, 64x64:
- *                int32 [ctu][mvy][mvx][pu], pu in z-order inside the CTU (64 / 16 / 4 / 1 per CTU).
- *   best[l]    : optional per-PU minimum of (sad + cost_x[mvx] + cost_y[mvy]):
- *                uint64 [ctu][pu] = cost << 32 | (mvy_index * (2*range+1) + mvx_index); must be
- *                pre-set to all-ones by the caller (x265hip_me_best_reset).
+ *   surf       : optional SAD surfaces, int32 [ctu][mvy][mvx][85]: one 85-int record per motion
+ *                vector holding every PU of the CTU - [0,64) the 8x8 PUs, [64,80) the 16x16, [80,84)
+ *                the 32x32, [84] the 64x64, each group in z-order inside the CTU.
+ *   best       : optional per-PU minimum of (sad + cost_x[mvx] + cost_y[mvy]), uint64 [ctu][85] (same
+ *                PU order) = cost << 32 | (mvy_index * (2*range+1) + mvx_index); must be pre-set to
+ *                all-ones by the caller (x265hip_me_best_reset).  Ties resolve to the smallest raster
+ *                index, i.e. the reference's scan order with its strict '<'.
  *   cost_x/y   : uint16 [2*range+1] mv bit-cost tables built on the host (bitcost.cpp:51-55).
  */
 typedef struct x265hip_me_params
@@ -90,8 +93,8 @@ typedef struct x265hip_me_params
     int range;
     const void* fenc;  intptr_t fenc_stride;
     const void* fref;  intptr_t fref_stride;
-    int32_t*  surf[4];
-    uint64_t* best[4];
+    int32_t*  surf;
+    uint64_t* best;
     const uint16_t* cost_x;
     const uint16_t* cost_y;
 } x265hip_me_params;

@@ -36,31 +36,23 @@ def me_fullsearch(depth, fenc, fenc_stride, fenc_org, fref, fref_stride, fref_or
                   ctu_begin, ctu_end, cost_x, cost_y, want_surf=True, want_best=True, levels=(0, 1, 2, 3),
                   nthreads=0, avx2=False):
     """Run the CPU restatement of the exhaustive search on padded host planes (numpy).
-    Returns (surf list, best list) with the same layouts as the HIP ABI (full-frame sized arrays;
-    only CTUs [ctu_begin, ctu_end) are filled)."""
+    Returns (surf, best) with the same layouts as the HIP ABI (int32 [ctu][mvy][mvx][85] and uint64
+    [ctu][85]; full-frame sized arrays, only CTUs [ctu_begin, ctu_end) are filled)."""
     L = lib(avx2)
     fn = getattr(L, f"x265oracle_me_fullsearch_d{depth}")
     nctu = (width // 64) * (height // 64)
     nc = 2 * rng + 1
-    pus = (64, 16, 4, 1)
-    surf = [None] * 4
-    best = [None] * 4
-    sp = (ctypes.c_void_p * 4)()
-    bp = (ctypes.c_void_p * 4)()
-    for l in levels:
-        if want_surf:
-            surf[l] = np.zeros(nctu * nc * nc * pus[l], dtype=np.int32)
-            sp[l] = surf[l].ctypes.data
-        if want_best:
-            best[l] = np.full(nctu * pus[l], 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
-            bp[l] = best[l].ctypes.data
+    surf = np.zeros(nctu * nc * nc * 85, dtype=np.int32) if want_surf else None
+    best = np.full(nctu * 85, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64) if want_best else None
+    mask = sum(1 << l for l in levels)
     es = fenc.itemsize
     fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_ssize_t,
                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     cx = np.ascontiguousarray(cost_x, dtype=np.uint16)
     cy = np.ascontiguousarray(cost_y, dtype=np.uint16)
     fn(fenc.ctypes.data + fenc_org * es, fenc_stride, fref.ctypes.data + fref_org * es, fref_stride,
-       width, height, rng, ctu_begin, ctu_end, ctypes.addressof(sp), ctypes.addressof(bp),
-       cx.ctypes.data, cy.ctypes.data, nthreads)
+       width, height, rng, ctu_begin, ctu_end,
+       surf.ctypes.data if surf is not None else None, best.ctypes.data if best is not None else None,
+       cx.ctypes.data, cy.ctypes.data, mask, nthreads)
     return surf, best

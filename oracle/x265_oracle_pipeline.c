@@ -41,13 +41,16 @@ static void zorder_xy(int z, int* x, int* y)
 
 static const int kLevelSize[4] = { 8, 16, 32, 64 };
 static const int kLevelPU[4] = { X265HIP_LUMA_8x8, X265HIP_LUMA_16x16, X265HIP_LUMA_32x32, X265HIP_LUMA_64x64 };
+static const int kLevelBase[4] = { 0, 64, 80, 84 };   /* position of each PU level inside the 85-entry CTU record */
+#define PUS_PER_CTU 85
 
-/* surf[l] : int32 [ctu][mvy][mvx][pu]   best[l] : uint64 [ctu][pu] = cost << 32 | (mvyi * NC + mvxi)
- * Any of the 8 output pointers may be NULL.  Processes CTUs [ctuBegin, ctuEnd). Returns 0. */
+/* surf : int32 [ctu][mvy][mvx][85]   best : uint64 [ctu][85] = cost << 32 | (mvyi * NC + mvxi)
+ * (record = 64 8x8 PUs, 16 16x16, 4 32x32, 1 64x64, each group in z-order; same layout as the HIP ABI).
+ * Either output may be NULL; levelMask selects PU levels (bit l).  Processes CTUs [ctuBegin, ctuEnd). */
 int EXPORT(x265oracle_me_fullsearch)(const pixel* fenc, intptr_t fencStride, const pixel* fref, intptr_t frefStride,
                                      int width, int height, int range, int ctuBegin, int ctuEnd,
-                                     int32_t** surf, uint64_t** best, const uint16_t* costX, const uint16_t* costY,
-                                     int nthreads)
+                                     int32_t* surf, uint64_t* best, const uint16_t* costX, const uint16_t* costY,
+                                     int levelMask, int nthreads)
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
@@ -65,7 +68,7 @@ int EXPORT(x265oracle_me_fullsearch)(const pixel* fenc, intptr_t fencStride, con
         pixel fencPU[64 * 64] __attribute__((aligned(64)));
         for (int l = 0; l < 4; l++)
         {
-            if (!(surf && surf[l]) && !(best && best[l]))
+            if (!(levelMask & (1 << l)) || (!surf && !best))
                 continue;
             const int n = kLevelSize[l], npu = (64 / n) * (64 / n);
             const struct x265hip_PU* pu = &prim.pu[kLevelPU[l]];
@@ -98,9 +101,9 @@ int EXPORT(x265oracle_me_fullsearch)(const pixel* fenc, intptr_t fencStride, con
                         for (int k = 0; k < cnt; k++, mx++)
                         {
                             const int xi = mx + range, yi = my + range;
-                            if (surf && surf[l])
-                                surf[l][(((size_t)ctu * NC + yi) * NC + xi) * npu + z] = costs[k];
-                            if (best && best[l])
+                            if (surf)
+                                surf[(((size_t)ctu * NC + yi) * NC + xi) * PUS_PER_CTU + kLevelBase[l] + z] = costs[k];
+                            if (best)
                             {
                                 const uint32_t c = (uint32_t)costs[k] + costX[xi] + costY[yi];
                                 if (c < bcost) { bcost = c; bidx = (uint32_t)(yi * NC + xi); }
@@ -108,8 +111,8 @@ int EXPORT(x265oracle_me_fullsearch)(const pixel* fenc, intptr_t fencStride, con
                         }
                     }
                 }
-                if (best && best[l])
-                    best[l][(size_t)ctu * npu + z] = ((uint64_t)bcost << 32) | bidx;
+                if (best)
+                    best[(size_t)ctu * PUS_PER_CTU + kLevelBase[l] + z] = ((uint64_t)bcost << 32) | bidx;
             }
         }
     }

@@ -35,11 +35,10 @@ def _run(width, height, rng, depth, seed, extreme=None):
     nctu = ms.nctu
     surf, best = O.me_fullsearch(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org,
                                  cur.w64, cur.h64, rng, 0, nctu, ms.cost_host, ms.cost_host)
-    for l in range(4):
-        g = ms.surf[l].cpu().numpy()
-        assert np.array_equal(g, surf[l]), f"surface level {l} differs ({np.count_nonzero(g != surf[l])} of {g.size})"
-        gb = ms.best[l].cpu().numpy().view(np.uint64)
-        assert np.array_equal(gb, best[l]), f"best level {l} differs"
+    g = ms.surf.cpu().numpy()
+    assert np.array_equal(g, surf), f"SAD surface differs ({np.count_nonzero(g != surf)} of {g.size})"
+    gb = ms.best.cpu().numpy().view(np.uint64)
+    assert np.array_equal(gb, best), f"best differs ({np.count_nonzero(gb != best)} of {gb.size})"
 
 
 @pytest.mark.parametrize("depth", [8, 10])
@@ -72,14 +71,14 @@ def test_me_hierarchy_property_full_size():
     torch.cuda.synchronize()
     nmv = ms.nctu * ms.nc * ms.nc
     for l in range(3):
-        child = ms.surf[l].view(nmv, P.LEVEL_PUS[l] // 4, 4).sum(dim=2)
-        parent = ms.surf[l + 1].view(nmv, P.LEVEL_PUS[l + 1])
+        child = ms.level_view(l)[0].reshape(nmv, P.LEVEL_PUS[l] // 4, 4).sum(dim=2)
+        parent = ms.level_view(l + 1)[0]
         assert torch.equal(child, parent)
     # spot-check one CTU against the oracle at full picture size
     O = _oracle()
     ctu = 257
     surf, best = O.me_fullsearch(8, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org,
                                  cur.w64, cur.h64, 16, ctu, ctu + 1, ms.cost_host, ms.cost_host)
-    per = ms.nc * ms.nc * 64
-    assert np.array_equal(ms.surf[0][ctu * per:(ctu + 1) * per].cpu().numpy(), surf[0][ctu * per:(ctu + 1) * per])
-    assert np.array_equal(ms.best[3][ctu:ctu + 1].cpu().numpy().view(np.uint64), best[3][ctu:ctu + 1])
+    per = ms.nc * ms.nc * 85
+    assert np.array_equal(ms.surf[ctu * per:(ctu + 1) * per].cpu().numpy(), surf[ctu * per:(ctu + 1) * per])
+    assert np.array_equal(ms.best[ctu * 85:(ctu + 1) * 85].cpu().numpy().view(np.uint64), best[ctu * 85:(ctu + 1) * 85])

@@ -1,0 +1,74 @@
+// Micro-benchmark: issue rate of the packed-SAD VALU instructions on gfx950 (cycles per wave-instruction
+// per SIMD), to size the motion-search kernels.  One workgroup of 256 threads per CU (1 wave / SIMD)
+// and 4 waves / SIMD variants.  Build: hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+#define N_ITERS 4096
+#define UNROLL 32
+
+template <int OP>
+__global__ void k(uint32_t* out, uint32_t seed)
+{
+    uint32_t a[8], b = seed + threadIdx.x;
+    unsigned long long q[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a[i] = seed * (i + 1) + threadIdx.x; q[i] = a[i]; }
+    long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < N_ITERS; it++)
+    {
+#pragma unroll
+        for (int u = 0; u < UNROLL / 8; u++)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+                if (OP == 0) a[i] = __builtin_amdgcn_sad_u8(a[(i + 1) & 7] | 1, b, a[i]);
+                if (OP == 1) a[i] = __builtin_amdgcn_sad_u16(a[(i + 1) & 7] | 1, b, a[i]);
+                if (OP == 2) q[i] = __builtin_amdgcn_qsad_pk_u16_u8(q[(i + 1) & 7] | 1, b, q[i]);
+                if (OP == 3) a[i] = a[i] + (a[(i + 1) & 7] ^ b);                         // v_xad / plain VALU baseline
+                if (OP == 4) a[i] = __builtin_amdgcn_alignbit(a[(i + 1) & 7], a[i], b);
+                if (OP == 5) a[i] = __builtin_amdgcn_sad_hi_u8(a[(i + 1) & 7] | 1, b, a[i]);
+                if (OP == 6) a[i] = __builtin_amdgcn_msad_u8(a[(i + 1) & 7] | 1, b, a[i]);
+                if (OP == 7) a[i] = __builtin_amdgcn_update_dpp(0, (int)a[(i + 1) & 7], 0xB1, 0xF, 0xF, true) + a[i];
+            }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r += a[i] + (uint32_t)q[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (uint32_t)(t1 - t0);
+}
+
+template <int OP> void run(const char* name, int threads)
+{
+    uint32_t* d; hipMalloc(&d, 256 * 1024 * 4 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, dim3(256), dim3(threads), 0, 0, d, 12345u);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, dim3(256), dim3(threads), 0, 0, d, 12345u);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    uint32_t cyc; hipMemcpy(&cyc, d, 4, hipMemcpyDeviceToHost);
+    double instr_per_wave = (double)N_ITERS * UNROLL;
+    int waves_per_simd = threads / 256;
+    printf("%-22s threads/WG %4d: %.2f s_memtime-cycles per instr per wave; wall %.3f ms -> %.2f ns/instr/SIMD-slot\n",
+           name, threads, cyc / instr_per_wave, ms, ms * 1e6 / (instr_per_wave * waves_per_simd));
+    hipFree(d);
+}
+
+int main()
+{
+    for (int th : {256, 1024})
+    {
+        if (th == 256) {
+            run<0>("v_sad_u8", 256); run<1>("v_sad_u16", 256); run<2>("v_qsad_pk_u16_u8", 256); run<3>("v_add+xor (2 ops)", 256);
+            run<4>("v_alignbit", 256); run<5>("v_sad_hi_u8", 256); run<6>("v_msad_u8", 256); run<7>("dpp add", 256);
+        } else {
+            run<0>("v_sad_u8", 1024); run<1>("v_sad_u16", 1024); run<2>("v_qsad_pk_u16_u8", 1024); run<3>("v_add+xor (2 ops)", 1024);
+            run<4>("v_alignbit", 1024); run<5>("v_sad_hi_u8", 1024); run<6>("v_msad_u8", 1024); run<7>("dpp add", 1024);
+        }
+    }
+    return 0;
+}

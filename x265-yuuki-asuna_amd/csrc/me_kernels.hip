@@ -14,8 +14,8 @@
 //     vertical displacements it overlaps, so each lane keeps a ring of 8 running SADs: 3 LDS dwords
 //     (12 B) + 2 v_alignbit feed 16 v_sad_u8 - register reuse keeps LDS at ~1/5 of its bandwidth;
 //   * every row step completes one mv: 8x8 SADs are summed to 16x16 (DPP quad_perm), 32x32 (DPP
-//     row_ror) and 64x64 (v_readlane) without touching LDS, written as [ctu][mvy][mvx][pu] so a
-//     wavefront stores 256 contiguous bytes, and/or folded into a per-PU running minimum of
+//     row_ror) and 64x64 (v_readlane) without touching LDS, written as one 85-int record per mv
+//     ([ctu][mvy][mvx][64 + 16 + 4 + 1]) so a wavefront stores 340 contiguous bytes, and/or folded into a per-PU running minimum of
 //     (cost << 32 | raster index) that is merged across wavefronts with one 64-bit atomicMin.
 #include "common.h"
 
@@ -29,9 +29,10 @@ struct MEArgs
     const uint8_t* fref;  long frefStrideB;
     int ctusW;
     int range;            // R
-    int rowBytes;         // LDS row pitch (multiple of 4, odd number of dwords)
-    int32_t*  surf[4];
-    unsigned long long* best[4];
+    int rowBytes;         // LDS row pitch in bytes (multiple of 128: see lds_row_off)
+    int payloadDw;        // dwords copied per window row
+    int32_t*  surf;              // [ctu][mvy][mvx][85]
+    unsigned long long* best;     // [ctu][85]
     const uint16_t* costX;
     const uint16_t* costY;
 };
@@ -47,8 +48,23 @@ template <typename Px> struct MECfg;
 template <> struct MECfg<uint8_t>  { static constexpr int DWPR = 2; static constexpr int NLD = 3; };   // dwords per 8-px row; dwords loaded
 template <> struct MECfg<uint16_t> { static constexpr int DWPR = 4; static constexpr int NLD = 5; };
 
-template <typename Px, bool SURF, bool BEST>
-__global__ void __launch_bounds__(1024) me_ctu_kernel(MEArgs a)
+// LDS row placement.  A half-wave reads, for one window row step, dwords by*8*pitch + bx*DWPR + c
+// (by = 0..3 block rows, bx = 0..7).  With the pitch a multiple of 32 dwords the four block rows
+// would collide on the same banks, so every group of 8 window rows is skewed by {0,1,16,17} dwords
+// (u8: the 8 bx values occupy the even banks 0..14, so the four skews tile all 32 banks conflict-free).
+__device__ __forceinline__ int lds_skew_bytes(int rowGroup)
+{
+    const int g = rowGroup & 3;
+    return ((g & 1) + ((g & 2) << 3)) * 4;                // 0, 1, 16, 17 dwords
+}
+__device__ __forceinline__ int lds_row_off(int r, int pitchBytes)
+{
+    return r * pitchBytes + lds_skew_bytes(r >> 3);
+}
+
+// PITCH = LDS row pitch in bytes as a compile-time constant (ds_read offsets become immediates).
+template <typename Px, bool SURF, bool BEST, int PITCH>
+__global__ void __launch_bounds__(1024, SURF ? 4 : 8) me_ctu_kernel(MEArgs a)
 {
     constexpr int BPP  = PxInfo<Px>::BPP;
     constexpr int DWPR = MECfg<Px>::DWPR;
@@ -63,16 +79,17 @@ __global__ void __launch_bounds__(1024) me_ctu_kernel(MEArgs a)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
+    constexpr int pitch = PITCH;
 
     // ---- stage the search window: aligned dword copy of each row -------------------------------
     const uint8_t* g0 = a.fref + (long)(cy - R) * a.frefStrideB + (long)(cx - R) * BPP;
     const int adj = (int)((uintptr_t)g0 & 3);           // identical for every row (stride % 4 == 0)
     const uint8_t* g0a = g0 - adj;
-    const int rowDw = a.rowBytes >> 2;
+    const int rowDw = a.payloadDw;
     for (int r = wave; r < rows; r += nwaves)
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(g0a + (long)r * a.frefStrideB);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(win + r * a.rowBytes);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(win + lds_row_off(r, pitch));
         for (int c = lane; c < rowDw; c += 64)
             dst[c] = src[c];
     }
@@ -92,107 +109,141 @@ __global__ void __launch_bounds__(1024) me_ctu_kernel(MEArgs a)
     __syncthreads();
 
     unsigned long long bk8 = ~0ull, bk16 = ~0ull, bk32 = ~0ull, bk64 = ~0ull;
+    // which upper-level value this lane writes into the 85-int record (see the SURF store below)
+    const bool uMask = (lane & 3) == 0 || (lane & 15) == 1 || lane == 2;
+    const int uSel = (lane & 3) == 0 ? 0 : ((lane & 15) == 1 ? 1 : 2);
+    const int uOff = uSel == 0 ? 64 + (lane >> 2) : (uSel == 1 ? 80 + (lane >> 4) : 84);
 
-    const int T = 2 * R + 8;                  // window rows a lane walks through
+    const int T = 2 * R + 8;                  // window rows a lane walks through (always even, >= 10)
     for (int mvxi = wave; mvxi < NC; mvxi += nwaves)
     {
         const int xb = adj + (bx * 8 + mvxi) * BPP;                 // byte column inside the LDS row
         const int sh = __builtin_amdgcn_readfirstlane((xb & 3) * 8); // wave-uniform (bx*8*BPP % 4 == 0)
-        const uint8_t* rp = win + (by * 8) * a.rowBytes + (xb & ~3);
+        const int colB = xb & ~3;
         const uint32_t cxv = BEST ? a.costX[mvxi] : 0;
+        const long e0 = (long)ctu * NC * NC + mvxi;                 // mv index of row 0 of this column
 
         uint32_t acc[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) acc[i] = 0;
 
-        // 8 window rows per call; FIRST = the warm-up rows where displacement index m = t - j < 0
-        auto rows8 = [&](auto firstTag, const int t0)
+        // rows of one 8-row block share a skew: address = blockBase(t0) + p * pitch (p immediate)
+        const uint8_t* colBase = win + (by * 8) * pitch + colB;
+        auto block_base = [&](const int t0) { return colBase + t0 * pitch + lds_skew_bytes(by + (t0 >> 3)); };
+        auto ldpair = [&](uint32_t (&d)[2][NLD], const uint8_t* bb, const int p)
         {
-            constexpr bool FIRST = decltype(firstTag)::value;
 #pragma unroll
-            for (int p = 0; p < 8; p++)
+            for (int q = 0; q < 2; q++)
             {
-                const int t = t0 + p;
-                if (FIRST || t < T)     // wave-uniform
-                {
-                    const uint32_t* lp = reinterpret_cast<const uint32_t*>(rp + t * a.rowBytes);
-                    uint32_t d[NLD];
+                const uint32_t* lp = reinterpret_cast<const uint32_t*>(bb + (p + q) * pitch);
 #pragma unroll
-                    for (int k = 0; k < NLD; k++) d[k] = lp[k];
-                    uint32_t rr[DWPR];
-#pragma unroll
-                    for (int k = 0; k < DWPR; k++) rr[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
-
-                    // window row t meets source row j at vertical displacement index m = t - j
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                    {
-                        if (FIRST && j > p) continue;
-                        uint32_t v = acc[(p - j) & 7];
-#pragma unroll
-                        for (int k = 0; k < DWPR; k++) v = sad_dw<Px>(F[j][k], rr[k], v);
-                        acc[(p - j) & 7] = v;
-                    }
-
-                    if (!FIRST || p == 7)
-                    {
-                        const int m = t - 7;                      // completed displacement row
-                        const int slot = (p + 1) & 7;
-                        const int s8 = (int)acc[slot];
-                        acc[slot] = 0;
-                        const int s16 = quad_sum(s8);
-                        const int s32 = row_sum_of_quads(s16);
-                        const int s64 = wave_sum_of_rows(s32);
-                        const size_t o = ((size_t)ctu * NC + m) * NC + mvxi;
-                        if (SURF)
-                        {
-                            if (a.surf[0]) a.surf[0][o * 64 + lane] = s8;
-                            if (a.surf[1] && (lane & 3) == 0) a.surf[1][o * 16 + (lane >> 2)] = s16;
-                            if (a.surf[2] && (lane & 15) == 0) a.surf[2][o * 4 + (lane >> 4)] = s32;
-                            if (a.surf[3] && lane == 0) a.surf[3][o] = s64;
-                        }
-                        if (BEST)
-                        {
-                            const uint32_t mvc = cxv + a.costY[m];
-                            const uint32_t idx = (uint32_t)(m * NC + mvxi);
-                            const unsigned long long k8 = ((unsigned long long)((uint32_t)s8 + mvc) << 32) | idx;
-                            const unsigned long long k16 = ((unsigned long long)((uint32_t)s16 + mvc) << 32) | idx;
-                            const unsigned long long k32 = ((unsigned long long)((uint32_t)s32 + mvc) << 32) | idx;
-                            const unsigned long long k64 = ((unsigned long long)((uint32_t)s64 + mvc) << 32) | idx;
-                            bk8 = k8 < bk8 ? k8 : bk8;
-                            bk16 = k16 < bk16 ? k16 : bk16;
-                            bk32 = k32 < bk32 ? k32 : bk32;
-                            bk64 = k64 < bk64 ? k64 : bk64;
-                        }
-                    }
-                }
+                for (int k = 0; k < NLD; k++) d[q][k] = lp[k];
             }
         };
-        rows8(std::true_type{}, 0);                      // T >= 10 always, the first 8 rows exist
-        for (int t0 = 8; t0 < T; t0 += 8)
-            rows8(std::false_type{}, t0);
+        auto align_pair = [&](uint32_t (&rr)[2][DWPR], const uint32_t (&d)[2][NLD])
+        {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int k = 0; k < DWPR; k++) rr[q][k] = __builtin_amdgcn_alignbit(d[q][k + 1], d[q][k], sh);
+        };
+        // software pipeline over PAIRS of window rows: rr = aligned pixels of the pair being consumed,
+        // d = raw dwords of the next pair, requested from LDS before the SAD work of the current pair
+        uint32_t rr[2][DWPR], d[2][NLD];
+        ldpair(d, block_base(0), 0);
+        align_pair(rr, d);
+
+        // 8 window rows per call.  FIRST: warm-up rows (displacement index m = t - j < 0 is skipped,
+        // only the last row completes an mv).  NROWS < 8 only for the final partial block.
+        auto rows8 = [&](auto firstTag, auto nrowsTag, const int t0)
+        {
+            constexpr bool FIRST = decltype(firstTag)::value;
+            constexpr int NROWS = decltype(nrowsTag)::value;
+            const uint8_t* bb = block_base(t0);
+            const uint8_t* bn = block_base(t0 + 8);
+#pragma unroll
+            for (int p = 0; p < NROWS; p++)
+            {
+                if ((p & 1) == 0)                                   // LDS has 2 spare rows past the window
+                {
+                    if (p + 2 < 8) ldpair(d, bb, p + 2); else ldpair(d, bn, 0);
+                }
+                // window row t meets source row j at vertical displacement index m = t - j
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                {
+                    if (FIRST && j > p) continue;
+                    uint32_t v = acc[(p - j) & 7];
+#pragma unroll
+                    for (int k = 0; k < DWPR; k++) v = sad_dw<Px>(F[j][k], rr[p & 1][k], v);
+                    acc[(p - j) & 7] = v;
+                }
+
+                if (!FIRST || p == 7)
+                {
+                    const int m = t0 + p - 7;                 // completed displacement row
+                    const int slot = (p + 1) & 7;
+                    const int s8 = (int)acc[slot];
+                    acc[slot] = 0;
+                    const int s16 = quad_sum(s8);
+                    const int s32 = row_sum_of_quads(s16);
+                    const int s64 = wave_sum_of_rows(s32);
+                    if (SURF)
+                    {
+                        // uniform record address (scalar math), per-lane constant offsets inside the record
+                        int32_t* rec = a.surf + (e0 + (long)m * NC) * 85;
+                        rec[lane] = s8;
+                        // the 21 upper-level values leave in ONE masked store: lane 4q -> 16x16 PU q,
+                        // lane 16r+1 -> 32x32 PU r, lane 2 -> the 64x64 PU
+                        const int vU = uSel == 0 ? s16 : (uSel == 1 ? s32 : s64);
+                        if (uMask) rec[uOff] = vU;
+                    }
+                    if (BEST)
+                    {
+                        const uint32_t mvc = cxv + a.costY[m];
+                        const uint32_t idx = (uint32_t)(m * NC + mvxi);
+                        const unsigned long long k8 = ((unsigned long long)((uint32_t)s8 + mvc) << 32) | idx;
+                        const unsigned long long k16 = ((unsigned long long)((uint32_t)s16 + mvc) << 32) | idx;
+                        const unsigned long long k32 = ((unsigned long long)((uint32_t)s32 + mvc) << 32) | idx;
+                        const unsigned long long k64 = ((unsigned long long)((uint32_t)s64 + mvc) << 32) | idx;
+                        bk8 = k8 < bk8 ? k8 : bk8;
+                        bk16 = k16 < bk16 ? k16 : bk16;
+                        bk32 = k32 < bk32 ? k32 : bk32;
+                        bk64 = k64 < bk64 ? k64 : bk64;
+                    }
+                }
+                if (p & 1) align_pair(rr, d);
+            }
+        };
+        using I8 = std::integral_constant<int, 8>;
+        rows8(std::true_type{}, I8{}, 0);                       // T >= 10: the first 8 rows always exist
+        int t0 = 8;
+        for (; t0 + 8 <= T; t0 += 8)
+            rows8(std::false_type{}, I8{}, t0);
+        switch (T - t0)                                         // T is even: 0, 2, 4 or 6 rows left
+        {
+        case 2: rows8(std::false_type{}, std::integral_constant<int, 2>{}, t0); break;
+        case 4: rows8(std::false_type{}, std::integral_constant<int, 4>{}, t0); break;
+        case 6: rows8(std::false_type{}, std::integral_constant<int, 6>{}, t0); break;
+        default: break;
+        }
     }
 
     if (BEST)
     {
-        if (a.best[0]) atomicMin(&a.best[0][(size_t)ctu * 64 + lane], bk8);
-        if (a.best[1] && (lane & 3) == 0) atomicMin(&a.best[1][(size_t)ctu * 16 + (lane >> 2)], bk16);
-        if (a.best[2] && (lane & 15) == 0) atomicMin(&a.best[2][(size_t)ctu * 4 + (lane >> 4)], bk32);
-        if (a.best[3] && lane == 0) atomicMin(&a.best[3][ctu], bk64);
+        unsigned long long* rec = a.best + (size_t)ctu * 85;
+        atomicMin(&rec[lane], bk8);
+        if ((lane & 3) == 0) atomicMin(&rec[64 + (lane >> 2)], bk16);
+        if ((lane & 15) == 0) atomicMin(&rec[80 + (lane >> 4)], bk32);
+        if (lane == 0) atomicMin(&rec[84], bk64);
     }
 }
 
-// number of wavefronts per workgroup: prefer an exact divisor of the column count (no idle tail)
+// wavefronts per workgroup: as many as the column count keeps busy (16 = 1024 threads max); the
+// columns are dealt round-robin, so the idle tail is at most one column per wavefront.
 static int pick_waves(int ncols)
 {
-    int bestW = 16, bestWaste = 1 << 30;
-    for (int w = 16; w >= 4; w--)
-    {
-        int waste = ((ncols + w - 1) / w) * w - ncols;
-        if (waste * bestW < bestWaste * w) { bestWaste = waste; bestW = w; }   // compare waste fraction
-        if (waste == 0) { bestW = w; break; }
-    }
-    return bestW;
+    return ncols >= 16 ? 16 : (ncols < 4 ? 4 : ncols);
 }
 
 template <typename Px>
@@ -204,24 +255,26 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     a.fref = (const uint8_t*)p->fref;  a.frefStrideB = (long)p->fref_stride * BPP;
     a.ctusW = p->width / 64;
     a.range = p->range;
-    int rowBytes = (3 + (56 + 2 * p->range) * BPP + 4 * MECfg<Px>::NLD + 3) & ~3;
-    if (((rowBytes >> 2) & 1) == 0) rowBytes += 4;            // odd dword pitch spreads rows over LDS banks
-    a.rowBytes = rowBytes;
-    bool anySurf = false, anyBest = false;
-    for (int l = 0; l < 4; l++)
-    {
-        a.surf[l] = p->surf[l]; a.best[l] = (unsigned long long*)p->best[l];
-        anySurf |= p->surf[l] != nullptr; anyBest |= p->best[l] != nullptr;
-    }
+    const int payload = (3 + (56 + 2 * p->range) * BPP + 4 * MECfg<Px>::NLD + 3) >> 2;   // dwords actually read per row
+    a.payloadDw = payload;
+    int pitchDw = 64;                                          // power-of-two pitch >= payload + max skew (17 dwords)
+    while (pitchDw < payload + 17) pitchDw <<= 1;
+    a.rowBytes = pitchDw * 4;
+    a.surf = p->surf; a.best = (unsigned long long*)p->best;
+    const bool anySurf = p->surf != nullptr, anyBest = p->best != nullptr;
     a.costX = p->cost_x; a.costY = p->cost_y;
     const int nctu = a.ctusW * (p->height / 64);
-    const size_t lds = (size_t)rowBytes * (64 + 2 * p->range);
+    const size_t lds = (size_t)a.rowBytes * (64 + 2 * p->range + 2);     // + 2 rows the pipeline may prefetch past the window
     if (lds > 160 * 1024) { set_error("me_fullsearch: range %d needs %zu B of LDS (> 160 KiB)", p->range, lds); return X265HIP_EINVAL; }
     const int nw = pick_waves(2 * p->range + 1);
     dim3 grid(nctu), block(nw * 64);
+#define LAUNCH_P(SF, BS, PT) do { \
+        if (lds > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_kernel<Px, SF, BS, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((me_ctu_kernel<Px, SF, BS, PT>), grid, block, lds, s, a); } while (0)
 #define LAUNCH(SF, BS) do { \
-        if (lds > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_kernel<Px, SF, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((me_ctu_kernel<Px, SF, BS>), grid, block, lds, s, a); } while (0)
+        if (a.rowBytes == 256) LAUNCH_P(SF, BS, 256); else if (a.rowBytes == 512) LAUNCH_P(SF, BS, 512); \
+        else if (a.rowBytes == 1024) LAUNCH_P(SF, BS, 1024); \
+        else { set_error("me_fullsearch: range %d needs an LDS row pitch of %d bytes (unsupported)", p->range, a.rowBytes); return X265HIP_EINVAL; } } while (0)
     if (anySurf && anyBest) LAUNCH(true, true);
     else if (anySurf) LAUNCH(true, false);
     else LAUNCH(false, true);
@@ -253,9 +306,8 @@ extern "C" int x265hip_me_fullsearch(const x265hip_me_params* p, void* stream)
     const int bpp = p->depth == 8 ? 1 : 2;
     if (((p->fenc_stride * bpp) & 3) || ((p->fref_stride * bpp) & 3) || ((uintptr_t)p->fenc & 3))
     { set_error("me_fullsearch: plane strides must be multiples of 4 bytes and fenc 4-byte aligned"); return X265HIP_EINVAL; }
-    bool anyOut = false, anyBest = false;
-    for (int l = 0; l < 4; l++) { anyOut |= p->surf[l] || p->best[l]; anyBest |= p->best[l] != nullptr; }
-    if (!anyOut) { set_error("me_fullsearch: no output requested"); return X265HIP_EINVAL; }
+    const bool anyBest = p->best != nullptr;
+    if (!p->surf && !p->best) { set_error("me_fullsearch: no output requested"); return X265HIP_EINVAL; }
     if (anyBest && (!p->cost_x || !p->cost_y)) { set_error("me_fullsearch: best[] needs cost_x / cost_y"); return X265HIP_EINVAL; }
     if (p->depth == 8) return launch_me<uint8_t>(p, (hipStream_t)stream);
     return launch_me<uint16_t>(p, (hipStream_t)stream);

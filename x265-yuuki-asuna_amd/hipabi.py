@@ -27,7 +27,7 @@ class MEParams(ctypes.Structure):
         ("depth", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int), ("range", ctypes.c_int),
         ("fenc", ctypes.c_void_p), ("fenc_stride", ctypes.c_ssize_t),
         ("fref", ctypes.c_void_p), ("fref_stride", ctypes.c_ssize_t),
-        ("surf", ctypes.c_void_p * 4), ("best", ctypes.c_void_p * 4),
+        ("surf", ctypes.c_void_p), ("best", ctypes.c_void_p),
         ("cost_x", ctypes.c_void_p), ("cost_y", ctypes.c_void_p),
     ]
 
@@ -77,7 +77,7 @@ def _p(t):
 
 
 def me_fullsearch(depth, width, height, rng, fenc, fenc_stride, fref, fref_stride,
-                  surf=(None, None, None, None), best=(None, None, None, None), cost_x=None, cost_y=None,
+                  surf=None, best=None, cost_x=None, cost_y=None,
                   fenc_off=0, fref_off=0, stream=None):
     """fenc/fref: torch tensors holding the planes; *_off = element offset of pixel (0,0)."""
     es = 1 if depth == 8 else 2
@@ -85,9 +85,7 @@ def me_fullsearch(depth, width, height, rng, fenc, fenc_stride, fref, fref_strid
     p.depth, p.width, p.height, p.range = depth, width, height, rng
     p.fenc, p.fenc_stride = fenc.data_ptr() + fenc_off * es, fenc_stride
     p.fref, p.fref_stride = fref.data_ptr() + fref_off * es, fref_stride
-    for i in range(4):
-        p.surf[i] = _p(surf[i])
-        p.best[i] = _p(best[i])
+    p.surf, p.best = _p(surf), _p(best)
     p.cost_x, p.cost_y = _p(cost_x), _p(cost_y)
     s = current_stream() if stream is None else stream
     check(lib().x265hip_me_fullsearch(ctypes.byref(p), s), "x265hip_me_fullsearch")

@@ -19,6 +19,8 @@ from . import hipabi
 
 LEVEL_SIZES = (8, 16, 32, 64)
 LEVEL_PUS = (64, 16, 4, 1)
+LEVEL_BASE = (0, 64, 80, 84)
+PUS_PER_CTU = 85
 
 
 class DevicePicture:
@@ -36,58 +38,65 @@ class DevicePicture:
 
 
 class MotionSearch:
-    """Owns the output buffers of the ME stage for one picture size."""
+    """Owns the output buffers of the ME stage for one picture size.
 
-    def __init__(self, w64, h64, rng, depth, device, want_surf=True, want_best=True, lam=4.0, levels=(0, 1, 2, 3)):
+    surf : int32 [ctu][mvy][mvx][85]  (85 = 64 8x8 + 16 16x16 + 4 32x32 + 1 64x64 PUs, z-order)
+    best : int64 [ctu][85]            cost << 32 | raster mv index
+    """
+
+    def __init__(self, w64, h64, rng, depth, device, want_surf=True, want_best=True, lam=4.0):
         import torch
         self.w64, self.h64, self.range, self.depth = w64, h64, rng, depth
         self.nctu = (w64 // 64) * (h64 // 64)
         self.nc = 2 * rng + 1
-        self.levels = levels
-        self.surf = [None] * 4
-        self.best = [None] * 4
-        for l in levels:
-            if want_surf:
-                self.surf[l] = torch.empty(self.nctu * self.nc * self.nc * LEVEL_PUS[l], dtype=torch.int32, device=device)
-            if want_best:
-                self.best[l] = torch.empty(self.nctu * LEVEL_PUS[l], dtype=torch.int64, device=device)
+        self.surf = torch.empty(self.nctu * self.nc * self.nc * PUS_PER_CTU, dtype=torch.int32, device=device) if want_surf else None
+        self.best = torch.empty(self.nctu * PUS_PER_CTU, dtype=torch.int64, device=device) if want_best else None
         cost = F.mv_cost_table(rng, lam)
         self.cost_host = cost
         self.cost_x = torch.from_numpy(cost.view(np.int16)).to(device)
         self.cost_y = self.cost_x.clone()
-
-    def surface_bytes(self):
-        return sum(t.numel() * 4 for t in self.surf if t is not None)
 
     def algorithmic_bytes(self, bpp=1):
         """SURVEY.md section 8(d), batched full-window SAD: per PU (W*H + (W+2R)(H+2R))*bpp read +
         4*(2R+1)^2 written when the surface is produced (8 bytes per PU when only the minimum is)."""
         r = self.range
         total = 0
-        for l in self.levels:
+        for l in range(4):
             n = LEVEL_SIZES[l]
             npu = self.nctu * LEVEL_PUS[l]
             rd = (n * n + (n + 2 * r) * (n + 2 * r)) * bpp
-            wr = 4 * self.nc * self.nc if self.surf[l] is not None else 8
+            wr = 4 * self.nc * self.nc if self.surf is not None else 8
             total += npu * (rd + wr)
         return total
 
+    def hbm_floor_bytes(self, bpp=1):
+        """What one launch must move through HBM at minimum: both pictures once + the outputs."""
+        pix = self.w64 * self.h64 * bpp * 2
+        out = self.surf.numel() * 4 if self.surf is not None else 0
+        out += self.best.numel() * 8 if self.best is not None else 0
+        return pix + out
+
     def run(self, cur: DevicePicture, ref: DevicePicture):
-        for l in self.levels:
-            if self.best[l] is not None:
-                hipabi.me_best_reset(self.best[l])
+        if self.best is not None:
+            hipabi.me_best_reset(self.best)
         hipabi.me_fullsearch(self.depth, self.w64, self.h64, self.range,
                              cur.t, cur.stride, ref.t, ref.stride,
                              surf=self.surf, best=self.best, cost_x=self.cost_x, cost_y=self.cost_y,
                              fenc_off=cur.org, fref_off=ref.org)
 
+    def level_view(self, level):
+        """(surface view [nmv, npu], best view [nctu, npu]) of one PU level."""
+        b, n = LEVEL_BASE[level], LEVEL_PUS[level]
+        sv = self.surf.view(-1, PUS_PER_CTU)[:, b:b + n] if self.surf is not None else None
+        bv = self.best.view(-1, PUS_PER_CTU)[:, b:b + n] if self.best is not None else None
+        return sv, bv
+
     def checksum(self):
-        """Order-independent digest of the stage outputs (sum of best keys / surface sums)."""
+        """Order-independent digest of the stage outputs."""
         import torch
         out = {}
-        for l in self.levels:
-            if self.best[l] is not None:
-                out[f"best{LEVEL_SIZES[l]}"] = int(self.best[l].sum().item())
-            if self.surf[l] is not None:
-                out[f"surf{LEVEL_SIZES[l]}"] = int(self.surf[l].sum(dtype=torch.int64).item())
+        if self.best is not None:
+            out["best"] = int(self.best.sum().item())
+        if self.surf is not None:
+            out["surf"] = int(self.surf.sum(dtype=torch.int64).item())
         return out
