@@ -101,6 +101,92 @@ typedef struct x265hip_me_params
 int x265hip_me_fullsearch(const x265hip_me_params* p, void* stream);
 int x265hip_me_best_reset(uint64_t* best, size_t count, void* stream);
 
+/* ------------------------------------------------------------------ generic job-list entry points
+ * Every remaining family evaluates `njobs` independent blocks of one size per launch.  An operand
+ * is a device plane (base pointer + element stride); a job carries up to four element offsets into
+ * the operand planes plus four integer arguments.  `jobs` is a DEVICE array. */
+typedef struct x265hip_plane { void* base; intptr_t stride; } x265hip_plane;
+typedef struct x265hip_job { int64_t off[4]; int32_t arg[4]; } x265hip_job;
+
+/* Sub-pel interpolation (reference ipfilter.cpp:79-369; taps constants.cpp:250-268).
+ * taps = 8 (luma, coeffIdx 0..3) or 4 (chroma, 0..7).  src = plane 0 (off[0]), dst = plane 1 (off[1]).
+ *   HPP/VPP: pixel->pixel  arg[0]=coeffIdx            HPS: pixel->int16 arg[0]=coeffIdx arg[1]=isRowExt
+ *   VPS: pixel->int16       VSP: int16->pixel          VSS: int16->int16
+ *   HVPP: pixel->pixel arg[0]=idxX arg[1]=idxY (hps with row extension + vsp, ipfilter.cpp:362-369)
+ *   P2S: pixel->int16 (ipfilter.cpp:40-57) */
+enum x265hip_interp_kind
+{
+    X265HIP_IP_HPP = 0, X265HIP_IP_HPS, X265HIP_IP_VPP, X265HIP_IP_VPS, X265HIP_IP_VSP, X265HIP_IP_VSS,
+    X265HIP_IP_HVPP, X265HIP_IP_P2S
+};
+int x265hip_interp_batch(int kind, int depth, int taps, int w, int h, x265hip_plane src, x265hip_plane dst,
+                         const x265hip_job* jobs, int njobs, void* stream);
+
+/* Transforms (reference dct.cpp:43-610, lowpassdct.cpp:34-113).  n = 4, 8, 16, 32.
+ *   DCT / DST4 / LOWPASS: src plane 0 = int16 residual with stride (off[0]); dst plane 1 = n*n contiguous
+ *   int16 per job at off[1].   IDCT / IDST4: src plane 0 = n*n contiguous (off[0]); dst plane 1 strided (off[1]).
+ * use_mfma != 0 selects the int8-limb MFMA kernels for n = 16 / 32 (bit-identical results). */
+enum x265hip_tr_kind { X265HIP_TR_DCT = 0, X265HIP_TR_IDCT, X265HIP_TR_DST4, X265HIP_TR_IDST4, X265HIP_TR_LOWPASS_DCT };
+int x265hip_transform_batch(int kind, int depth, int n, x265hip_plane src, x265hip_plane dst,
+                            const x265hip_job* jobs, int njobs, int use_mfma, void* stream);
+
+/* Quantisation family (reference dct.cpp:612-755).  All operands are contiguous per job; planes give the
+ * base pointers (stride unused).  arg[] meanings follow the reference signatures:
+ *   QUANT   : p0 coef(int16) p1 quantCoeff(int32) p2 deltaU(int32 out) p3 qCoef(int16 out); arg = {qBits, add, numCoeff}
+ *   NQUANT  : p0 coef p1 quantCoeff p3 qCoef(out); arg = {qBits, add, numCoeff}
+ *   DEQUANT_NORMAL : p0 quantCoef(int16) p3 coef(int16 out); arg = {num, scale, shift}
+ *   DEQUANT_SCALING: p0 quantCoef p1 deQuantCoef(int32) p3 coef(out); arg = {num, per, shift}
+ *   DENOISE : p0 dctCoef(int16 in/out) p1 resSum(uint32 in/out) p2 offset(uint16); arg = {numCoeff}
+ *   COUNT_NONZERO : p0 coef; arg = {numCoeff}       COPY_CNT: p0 residual (strided, stride = plane stride) p3 coeff out; arg = {n}
+ * result[i] (uint32, may be NULL for void kinds) = numSig / count. */
+enum x265hip_quant_kind
+{
+    X265HIP_Q_QUANT = 0, X265HIP_Q_NQUANT, X265HIP_Q_DEQUANT_NORMAL, X265HIP_Q_DEQUANT_SCALING, X265HIP_Q_DENOISE,
+    X265HIP_Q_COUNT_NONZERO, X265HIP_Q_COPY_CNT
+};
+int x265hip_quant_batch(int kind, const x265hip_plane planes[4], const x265hip_job* jobs, int njobs,
+                        uint32_t* result, void* stream);
+
+/* Intra prediction (reference intrapred.cpp:31-234).  n = 4, 8, 16, 32.
+ *   PRED   : plane 0 = neighbour buffers (off[0] -> srcPix[0], layout [0]=top-left, [1..2n]=above,
+ *            [2n+1..4n]=left), plane 1 = dst (off[1], strided); arg = {dirMode 0..34, bFilter}
+ *   FILTER : plane 0 = samples (off[0]), plane 1 = filtered out (off[1])
+ *   ALLANGS: plane 0 = refPix (off[0]) and filtPix (off[2]), plane 1 = dest 33*n*n (off[1]); arg = {bLuma} */
+enum x265hip_intra_kind { X265HIP_INTRA_PRED = 0, X265HIP_INTRA_FILTER, X265HIP_INTRA_ALLANGS };
+int x265hip_intra_batch(int kind, int depth, int n, x265hip_plane src, x265hip_plane dst,
+                        const x265hip_job* jobs, int njobs, void* stream);
+
+/* Element-wise block operations (reference pixel.cpp:393-602,759-862).  Operand planes / offsets:
+ *   COPY_PP/PS/SP/SS: dst=p0 src=p1           SUB_PS: dst(int16)=p0 a=p1 b=p2      ADD_PS: dst(pixel)=p0 a(pixel)=p1 r(int16)=p2
+ *   ADDAVG: dst(pixel)=p0 a(int16)=p1 b(int16)=p2   PIXELAVG: dst=p0 a=p1 b=p2      BLOCKFILL: dst(int16)=p0 arg[0]=val
+ *   CPY2DTO1D_SHL/SHR: dst contiguous=p0 src strided=p1 arg[0]=shift   CPY1DTO2D_SHL/SHR: dst strided=p0 src contiguous=p1
+ *   TRANSPOSE: dst contiguous=p0 src=p1       WEIGHT_PP: dst=p0 src=p1 arg={w0, round, shift, offset}
+ *   WEIGHT_SP: dst(pixel)=p0 src(int16)=p1 arg={w0, round, shift, offset}
+ *   SCALE1D_128TO64: dst=p0 src=p1 (w=h=0)    SCALE2D_64TO32: dst=p0 src=p1
+ *   SSE_SS (int16,int16), SSD_S (int16), VAR (pixel): reductions, result in `result` (uint64 per job) */
+enum x265hip_blockop_kind
+{
+    X265HIP_OP_COPY_PP = 0, X265HIP_OP_COPY_PS, X265HIP_OP_COPY_SP, X265HIP_OP_COPY_SS, X265HIP_OP_SUB_PS, X265HIP_OP_ADD_PS,
+    X265HIP_OP_ADDAVG, X265HIP_OP_PIXELAVG, X265HIP_OP_BLOCKFILL, X265HIP_OP_CPY2DTO1D_SHL, X265HIP_OP_CPY2DTO1D_SHR,
+    X265HIP_OP_CPY1DTO2D_SHL, X265HIP_OP_CPY1DTO2D_SHR, X265HIP_OP_TRANSPOSE, X265HIP_OP_WEIGHT_PP, X265HIP_OP_WEIGHT_SP,
+    X265HIP_OP_SCALE1D_128TO64, X265HIP_OP_SCALE2D_64TO32, X265HIP_OP_SSE_SS, X265HIP_OP_SSD_S, X265HIP_OP_VAR
+};
+int x265hip_blockop_batch(int op, int depth, int w, int h, const x265hip_plane planes[3],
+                          const x265hip_job* jobs, int njobs, uint64_t* result, void* stream);
+
+/* Loop-filter family: SAO apply / statistics, deblocking edge filters, sign, SEA integrals, ADS.
+ * (reference loopfilter.cpp:39-180, encoder/sao.cpp:1762-1925, encoder/framefilter.cpp:39-140,
+ * pixel.cpp:121-165).  Operand conventions are documented with each kind in csrc/loopfilter_kernels.hip;
+ * the table layer is their main client in this round. */
+enum x265hip_lf_kind
+{
+    X265HIP_LF_SIGN = 0, X265HIP_LF_SAO_E0, X265HIP_LF_SAO_E1, X265HIP_LF_SAO_E1_2ROWS, X265HIP_LF_SAO_E2, X265HIP_LF_SAO_E3,
+    X265HIP_LF_SAO_B0, X265HIP_LF_STATS_BO, X265HIP_LF_STATS_E0, X265HIP_LF_STATS_E1, X265HIP_LF_STATS_E2, X265HIP_LF_STATS_E3,
+    X265HIP_LF_DEBLOCK_LUMA_STRONG, X265HIP_LF_DEBLOCK_CHROMA, X265HIP_LF_INTEGRAL_H, X265HIP_LF_INTEGRAL_V, X265HIP_LF_ADS
+};
+int x265hip_loopfilter_batch(int kind, int depth, const x265hip_plane planes[4], const x265hip_job* jobs, int njobs,
+                             uint32_t* result, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,10 @@
 // Install order for a real encoder (reference primitives.cpp:248-282): let the host fill its own
 // C table first (setupCPrimitives + setupAliasPrimitives), then call x265hip_setup_primitives() on
 // it BEFORE x265_encoder_open(); slots we do not implement keep the host's entries.
+//
+// Every stub: pack the operands the reference function would touch (including filter aprons and
+// carried sign buffers) into the calling thread's pinned staging buffer, one H2D copy, the batch
+// kernel on a single job, one D2H copy, scatter the outputs back with the caller's strides.
 #ifndef X265HIP_DEPTH
 #error "compile with -DX265HIP_DEPTH=8|10|12"
 #endif
@@ -19,6 +23,14 @@ typedef x265hip_pixel pixel;
 typedef x265hip_sse_t sse_t;
 constexpr int D = X265HIP_DEPTH;
 constexpr int ES = sizeof(pixel);
+
+// upload a single job record (after all other inputs) and return its device pointer
+static const x265hip_job* put_job(ThreadStage& st, const x265hip_job& jb)
+{
+    const size_t o = st.in1d(&jb, sizeof(jb));
+    return st.dptr<const x265hip_job>(o);
+}
+static x265hip_plane plane(ThreadStage& st, size_t off, intptr_t stride) { x265hip_plane p = { st.dptr<void>(off), stride }; return p; }
 
 // ---------------------------------------------------------------- pixel-compare family
 static uint64_t cmp_one(int kind, int w, int h, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
@@ -34,15 +46,10 @@ static uint64_t cmp_one(int kind, int w, int h, const pixel* a, intptr_t sa, con
     st.download(oo, 8);
     return *st.hptr<uint64_t>(oo);
 }
-
 template <int KIND, int W, int H> static int cmp_stub(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
-{
-    return (int)cmp_one(KIND, W, H, a, sa, b, sb);
-}
+{ return (int)cmp_one(KIND, W, H, a, sa, b, sb); }
 template <int W, int H> static sse_t sse_stub(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
-{
-    return (sse_t)cmp_one(X265HIP_CMP_SSE_PP, W, H, a, sa, b, sb);
-}
+{ return (sse_t)cmp_one(X265HIP_CMP_SSE_PP, W, H, a, sa, b, sb); }
 
 // sad_x3 / sad_x4 (pixel.cpp:74-119): one fenc block at the fixed FENC_STRIDE 64, N refs sharing a stride
 template <int W, int H, int N> static void sad_xn(const pixel* fenc, const pixel* const* refs, intptr_t rs, int32_t* res)
@@ -56,8 +63,7 @@ template <int W, int H, int N> static void sad_xn(const pixel* fenc, const pixel
         const size_t o = st.in2d(refs[i], rs, W, H, ES);
         if (!i) ob = o;
     }
-    // in2d pads every block start to 64 bytes: the job step is the padded block pitch
-    const size_t pitch = (((size_t)W * H * ES) + 63) & ~(size_t)63;
+    const size_t pitch = (((size_t)W * H * ES) + 63) & ~(size_t)63;   // in2d starts every block on a 64-byte boundary
     const size_t oo = st.alloc(8 * N);
     st.upload();
     st.require(x265hip_pixelcmp_batch(X265HIP_CMP_SAD, D, W, H, st.dptr<void>(oa), W, nullptr, 0,
@@ -67,18 +73,535 @@ template <int W, int H, int N> static void sad_xn(const pixel* fenc, const pixel
     for (int i = 0; i < N; i++) res[i] = (int32_t)st.hptr<uint64_t>(oo)[i];
 }
 template <int W, int H> static void sad_x3_stub(const pixel* f, const pixel* r0, const pixel* r1, const pixel* r2, intptr_t rs, int32_t* res)
-{
-    const pixel* r[3] = { r0, r1, r2 };
-    sad_xn<W, H, 3>(f, r, rs, res);
-}
+{ const pixel* r[3] = { r0, r1, r2 }; sad_xn<W, H, 3>(f, r, rs, res); }
 template <int W, int H> static void sad_x4_stub(const pixel* f, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rs, int32_t* res)
+{ const pixel* r[4] = { r0, r1, r2, r3 }; sad_xn<W, H, 4>(f, r, rs, res); }
+
+// ---------------------------------------------------------------- interpolation family
+template <int KIND, int N, int W, int H, typename S, typename Dt>
+static void ip_core(const S* src, intptr_t ss, Dt* dst, intptr_t ds, int a0, int a1)
 {
-    const pixel* r[4] = { r0, r1, r2, r3 };
-    sad_xn<W, H, 4>(f, r, rs, res);
+    constexpr bool horiz = KIND == X265HIP_IP_HPP || KIND == X265HIP_IP_HPS || KIND == X265HIP_IP_HVPP;
+    constexpr bool vert = KIND == X265HIP_IP_VPP || KIND == X265HIP_IP_VPS || KIND == X265HIP_IP_VSP || KIND == X265HIP_IP_VSS || KIND == X265HIP_IP_HVPP;
+    const bool ext = (KIND == X265HIP_IP_HPS && a1) || vert;
+    const int ax = (horiz && KIND != X265HIP_IP_P2S) ? N / 2 - 1 : 0, ay = ext ? N / 2 - 1 : 0;
+    const int tw = W + (ax ? N - 1 : 0), th = H + (ay ? N - 1 : 0);
+    const int oh = (KIND == X265HIP_IP_HPS && a1) ? H + N - 1 : H;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t oa = st.in2d(src - (intptr_t)ay * ss - ax, ss, tw, th, sizeof(S));
+    x265hip_job jb = {};
+    jb.off[0] = (int64_t)ay * tw + ax; jb.arg[0] = a0; jb.arg[1] = a1;
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t od = st.alloc((size_t)W * oh * sizeof(Dt));
+    st.upload();
+    st.require(x265hip_interp_batch(KIND, D, N, W, H, plane(st, oa, tw), plane(st, od, W), dj, 1, st.stream), "interp");
+    st.download(od, (size_t)W * oh * sizeof(Dt));
+    st.out2d(od, dst, ds, W, oh, sizeof(Dt));
+}
+template <int N, int W, int H> static void hpp_stub(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int idx) { ip_core<X265HIP_IP_HPP, N, W, H>(s, ss, d, ds, idx, 0); }
+template <int N, int W, int H> static void hps_stub(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int idx, int ext) { ip_core<X265HIP_IP_HPS, N, W, H>(s, ss, d, ds, idx, ext); }
+template <int N, int W, int H> static void vpp_stub(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int idx) { ip_core<X265HIP_IP_VPP, N, W, H>(s, ss, d, ds, idx, 0); }
+template <int N, int W, int H> static void vps_stub(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int idx) { ip_core<X265HIP_IP_VPS, N, W, H>(s, ss, d, ds, idx, 0); }
+template <int N, int W, int H> static void vsp_stub(const int16_t* s, intptr_t ss, pixel* d, intptr_t ds, int idx) { ip_core<X265HIP_IP_VSP, N, W, H>(s, ss, d, ds, idx, 0); }
+template <int N, int W, int H> static void vss_stub(const int16_t* s, intptr_t ss, int16_t* d, intptr_t ds, int idx) { ip_core<X265HIP_IP_VSS, N, W, H>(s, ss, d, ds, idx, 0); }
+template <int N, int W, int H> static void hvpp_stub(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int ix, int iy) { ip_core<X265HIP_IP_HVPP, N, W, H>(s, ss, d, ds, ix, iy); }
+template <int W, int H> static void p2s_stub(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds) { ip_core<X265HIP_IP_P2S, 8, W, H>(s, ss, d, ds, 0, 0); }
+
+// ---------------------------------------------------------------- transforms
+template <int KIND, int N> static void fwd_tr_stub(const int16_t* src, int16_t* dst, intptr_t srcStride)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t oa = st.in2d(src, srcStride, N, N, 2);
+    x265hip_job jb = {};
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t od = st.alloc(N * N * 2);
+    st.upload();
+    st.require(x265hip_transform_batch(KIND, D, N, plane(st, oa, N), plane(st, od, N), dj, 1, N >= 16, st.stream), "transform");
+    st.download(od, N * N * 2);
+    memcpy(dst, st.hptr<int16_t>(od), N * N * 2);
+}
+template <int KIND, int N> static void inv_tr_stub(const int16_t* src, int16_t* dst, intptr_t dstStride)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t oa = st.in1d(src, N * N * 2);
+    x265hip_job jb = {};
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t od = st.alloc(N * N * 2);
+    st.upload();
+    st.require(x265hip_transform_batch(KIND, D, N, plane(st, oa, N), plane(st, od, N), dj, 1, N >= 16, st.stream), "inverse transform");
+    st.download(od, N * N * 2);
+    st.out2d(od, dst, dstStride, N, N, 2);
+}
+
+// ---------------------------------------------------------------- quantisation
+static uint32_t quant_stub(const int16_t* coef, const int32_t* quantCoeff, int32_t* deltaU, int16_t* qCoef, int qBits, int add, int numCoeff)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(coef, numCoeff * 2), o1 = st.in1d(quantCoeff, numCoeff * 4);
+    x265hip_job jb = {}; jb.arg[0] = qBits; jb.arg[1] = add; jb.arg[2] = numCoeff;
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t o2 = st.alloc(numCoeff * 4), o3 = st.alloc(numCoeff * 2), orr = st.alloc(4);
+    st.upload();
+    const x265hip_plane pl[4] = { plane(st, o0, 0), plane(st, o1, 0), plane(st, o2, 0), plane(st, o3, 0) };
+    st.require(x265hip_quant_batch(X265HIP_Q_QUANT, pl, dj, 1, st.dptr<uint32_t>(orr), st.stream), "quant");
+    st.download(o2, orr + 4 - o2);
+    memcpy(deltaU, st.hptr<void>(o2), numCoeff * 4);
+    memcpy(qCoef, st.hptr<void>(o3), numCoeff * 2);
+    return *st.hptr<uint32_t>(orr);
+}
+static uint32_t nquant_stub(const int16_t* coef, const int32_t* quantCoeff, int16_t* qCoef, int qBits, int add, int numCoeff)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(coef, numCoeff * 2), o1 = st.in1d(quantCoeff, numCoeff * 4);
+    x265hip_job jb = {}; jb.arg[0] = qBits; jb.arg[1] = add; jb.arg[2] = numCoeff;
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t o3 = st.alloc(numCoeff * 2), orr = st.alloc(4);
+    st.upload();
+    const x265hip_plane pl[4] = { plane(st, o0, 0), plane(st, o1, 0), plane(st, o3, 0), plane(st, o3, 0) };
+    st.require(x265hip_quant_batch(X265HIP_Q_NQUANT, pl, dj, 1, st.dptr<uint32_t>(orr), st.stream), "nquant");
+    st.download(o3, orr + 4 - o3);
+    memcpy(qCoef, st.hptr<void>(o3), numCoeff * 2);
+    return *st.hptr<uint32_t>(orr);
+}
+static void dequant_normal_stub(const int16_t* quantCoef, int16_t* coef, int num, int scale, int shift)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(quantCoef, num * 2);
+    x265hip_job jb = {}; jb.arg[0] = num; jb.arg[1] = scale; jb.arg[2] = shift;
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t o3 = st.alloc(num * 2);
+    st.upload();
+    const x265hip_plane pl[4] = { plane(st, o0, 0), plane(st, o0, 0), plane(st, o3, 0), plane(st, o3, 0) };
+    st.require(x265hip_quant_batch(X265HIP_Q_DEQUANT_NORMAL, pl, dj, 1, nullptr, st.stream), "dequant_normal");
+    st.download(o3, num * 2);
+    memcpy(coef, st.hptr<void>(o3), num * 2);
+}
+static void dequant_scaling_stub(const int16_t* quantCoef, const int32_t* deQuantCoef, int16_t* coef, int num, int per, int shift)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(quantCoef, num * 2), o1 = st.in1d(deQuantCoef, num * 4);
+    x265hip_job jb = {}; jb.arg[0] = num; jb.arg[1] = per; jb.arg[2] = shift;
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t o3 = st.alloc(num * 2);
+    st.upload();
+    const x265hip_plane pl[4] = { plane(st, o0, 0), plane(st, o1, 0), plane(st, o3, 0), plane(st, o3, 0) };
+    st.require(x265hip_quant_batch(X265HIP_Q_DEQUANT_SCALING, pl, dj, 1, nullptr, st.stream), "dequant_scaling");
+    st.download(o3, num * 2);
+    memcpy(coef, st.hptr<void>(o3), num * 2);
+}
+static void denoise_stub(int16_t* dctCoef, uint32_t* resSum, const uint16_t* offset, int numCoeff)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(dctCoef, numCoeff * 2), o1 = st.in1d(resSum, numCoeff * 4), o2 = st.in1d(offset, numCoeff * 2);
+    x265hip_job jb = {}; jb.arg[0] = numCoeff;
+    const x265hip_job* dj = put_job(st, jb);
+    st.upload();
+    const x265hip_plane pl[4] = { plane(st, o0, 0), plane(st, o1, 0), plane(st, o2, 0), plane(st, o2, 0) };
+    st.require(x265hip_quant_batch(X265HIP_Q_DENOISE, pl, dj, 1, nullptr, st.stream), "denoiseDct");
+    st.download(o0, o1 + (size_t)numCoeff * 4 - o0);
+    memcpy(dctCoef, st.hptr<void>(o0), numCoeff * 2);
+    memcpy(resSum, st.hptr<void>(o1), numCoeff * 4);
+}
+template <int N> static int count_nonzero_stub(const int16_t* q)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(q, N * N * 2);
+    x265hip_job jb = {}; jb.arg[0] = N * N;
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t orr = st.alloc(4);
+    st.upload();
+    const x265hip_plane pl[4] = { plane(st, o0, 0), plane(st, o0, 0), plane(st, o0, 0), plane(st, o0, 0) };
+    st.require(x265hip_quant_batch(X265HIP_Q_COUNT_NONZERO, pl, dj, 1, st.dptr<uint32_t>(orr), st.stream), "count_nonzero");
+    st.download(orr, 4);
+    return (int)*st.hptr<uint32_t>(orr);
+}
+template <int N> static uint32_t copy_cnt_stub(int16_t* coeff, const int16_t* residual, intptr_t resiStride)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in2d(residual, resiStride, N, N, 2);
+    x265hip_job jb = {}; jb.arg[0] = N;
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t o3 = st.alloc(N * N * 2), orr = st.alloc(4);
+    st.upload();
+    const x265hip_plane pl[4] = { plane(st, o0, N), plane(st, o0, 0), plane(st, o0, 0), plane(st, o3, 0) };
+    st.require(x265hip_quant_batch(X265HIP_Q_COPY_CNT, pl, dj, 1, st.dptr<uint32_t>(orr), st.stream), "copy_cnt");
+    st.download(o3, orr + 4 - o3);
+    memcpy(coeff, st.hptr<void>(o3), N * N * 2);
+    return *st.hptr<uint32_t>(orr);
+}
+
+// ---------------------------------------------------------------- intra prediction
+template <int N> static void intra_pred_stub(pixel* dst, intptr_t dstStride, const pixel* srcPix, int dirMode, int bFilter)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(srcPix, (4 * N + 1) * ES);
+    x265hip_job jb = {}; jb.arg[0] = dirMode; jb.arg[1] = bFilter;
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t od = st.alloc(N * N * ES);
+    st.upload();
+    st.require(x265hip_intra_batch(X265HIP_INTRA_PRED, D, N, plane(st, o0, 0), plane(st, od, N), dj, 1, st.stream), "intra_pred");
+    st.download(od, N * N * ES);
+    st.out2d(od, dst, dstStride, N, N, ES);
+}
+template <int N> static void intra_filter_stub(const pixel* references, pixel* filtered)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(references, (4 * N + 1) * ES);
+    x265hip_job jb = {};
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t od = st.alloc((4 * N + 1) * ES);
+    st.upload();
+    st.require(x265hip_intra_batch(X265HIP_INTRA_FILTER, D, N, plane(st, o0, 0), plane(st, od, 0), dj, 1, st.stream), "intra_filter");
+    st.download(od, (4 * N + 1) * ES);
+    memcpy(filtered, st.hptr<void>(od), (4 * N + 1) * ES);
+}
+template <int N> static void intra_allangs_stub(pixel* dest, pixel* refPix, pixel* filtPix, int bLuma)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(refPix, (4 * N + 1) * ES), o1 = st.in1d(filtPix, (4 * N + 1) * ES);
+    x265hip_job jb = {}; jb.off[2] = (int64_t)((o1 - o0) / ES); jb.arg[0] = bLuma;
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t od = st.alloc(33 * N * N * ES);
+    st.upload();
+    st.require(x265hip_intra_batch(X265HIP_INTRA_ALLANGS, D, N, plane(st, o0, 0), plane(st, od, N), dj, 1, st.stream), "intra_allangs");
+    st.download(od, 33 * N * N * ES);
+    memcpy(dest, st.hptr<void>(od), 33 * N * N * ES);
+}
+
+// ---------------------------------------------------------------- element-wise block ops
+// generic: up to two strided inputs, one output (strided or contiguous)
+template <typename T0, typename T1, typename T2>
+static void op_core(int op, int w, int h, T0* dst, intptr_t ds, bool dstContig, const T1* s1, intptr_t ss1, bool s1Contig,
+                    const T2* s2, intptr_t ss2, const int args[4])
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    size_t o1 = 0, o2 = 0;
+    if (s1) o1 = s1Contig ? st.in1d(s1, (size_t)w * h * sizeof(T1)) : st.in2d(s1, ss1, w, h, sizeof(T1));
+    if (s2) o2 = st.in2d(s2, ss2, w, h, sizeof(T2));
+    x265hip_job jb = {};
+    for (int i = 0; i < 4; i++) jb.arg[i] = args ? args[i] : 0;
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t od = st.alloc((size_t)w * h * sizeof(T0));
+    st.upload();
+    const x265hip_plane pl[3] = { plane(st, od, w), plane(st, o1, w), plane(st, o2, w) };
+    st.require(x265hip_blockop_batch(op, D, w, h, pl, dj, 1, nullptr, st.stream), "blockop");
+    st.download(od, (size_t)w * h * sizeof(T0));
+    if (dstContig) memcpy(dst, st.hptr<void>(od), (size_t)w * h * sizeof(T0));
+    else st.out2d(od, dst, ds, w, h, sizeof(T0));
+}
+template <int W, int H> static void copy_pp_stub(pixel* d, intptr_t ds, const pixel* s, intptr_t ss) { op_core<pixel, pixel, pixel>(X265HIP_OP_COPY_PP, W, H, d, ds, false, s, ss, false, nullptr, 0, nullptr); }
+template <int W, int H> static void copy_ps_stub(int16_t* d, intptr_t ds, const pixel* s, intptr_t ss) { op_core<int16_t, pixel, pixel>(X265HIP_OP_COPY_PS, W, H, d, ds, false, s, ss, false, nullptr, 0, nullptr); }
+template <int W, int H> static void copy_sp_stub(pixel* d, intptr_t ds, const int16_t* s, intptr_t ss) { op_core<pixel, int16_t, pixel>(X265HIP_OP_COPY_SP, W, H, d, ds, false, s, ss, false, nullptr, 0, nullptr); }
+template <int W, int H> static void copy_ss_stub(int16_t* d, intptr_t ds, const int16_t* s, intptr_t ss) { op_core<int16_t, int16_t, pixel>(X265HIP_OP_COPY_SS, W, H, d, ds, false, s, ss, false, nullptr, 0, nullptr); }
+template <int W, int H> static void sub_ps_stub(int16_t* d, intptr_t ds, const pixel* a, const pixel* b, intptr_t sa, intptr_t sb) { op_core<int16_t, pixel, pixel>(X265HIP_OP_SUB_PS, W, H, d, ds, false, a, sa, false, b, sb, nullptr); }
+template <int W, int H> static void add_ps_stub(pixel* d, intptr_t ds, const pixel* a, const int16_t* r, intptr_t sa, intptr_t sr) { op_core<pixel, pixel, int16_t>(X265HIP_OP_ADD_PS, W, H, d, ds, false, a, sa, false, r, sr, nullptr); }
+template <int W, int H> static void addavg_stub(const int16_t* a, const int16_t* b, pixel* d, intptr_t sa, intptr_t sb, intptr_t ds) { op_core<pixel, int16_t, int16_t>(X265HIP_OP_ADDAVG, W, H, d, ds, false, a, sa, false, b, sb, nullptr); }
+template <int W, int H> static void pixelavg_stub(pixel* d, intptr_t ds, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb, int) { op_core<pixel, pixel, pixel>(X265HIP_OP_PIXELAVG, W, H, d, ds, false, a, sa, false, b, sb, nullptr); }
+template <int N> static void calcresidual_stub(const pixel* fenc, const pixel* pred, int16_t* resi, intptr_t stride) { op_core<int16_t, pixel, pixel>(X265HIP_OP_SUB_PS, N, N, resi, stride, false, fenc, stride, false, pred, stride, nullptr); }
+template <int N> static void blockfill_stub(int16_t* d, intptr_t ds, int16_t v) { const int a[4] = { v, 0, 0, 0 }; op_core<int16_t, pixel, pixel>(X265HIP_OP_BLOCKFILL, N, N, d, ds, false, nullptr, 0, false, nullptr, 0, a); }
+template <int N> static void cpy2d1d_shl_stub(int16_t* d, const int16_t* s, intptr_t ss, int sh) { const int a[4] = { sh, 0, 0, 0 }; op_core<int16_t, int16_t, pixel>(X265HIP_OP_CPY2DTO1D_SHL, N, N, d, 0, true, s, ss, false, nullptr, 0, a); }
+template <int N> static void cpy2d1d_shr_stub(int16_t* d, const int16_t* s, intptr_t ss, int sh) { const int a[4] = { sh, 0, 0, 0 }; op_core<int16_t, int16_t, pixel>(X265HIP_OP_CPY2DTO1D_SHR, N, N, d, 0, true, s, ss, false, nullptr, 0, a); }
+template <int N> static void cpy1d2d_shl_stub(int16_t* d, const int16_t* s, intptr_t ds, int sh) { const int a[4] = { sh, 0, 0, 0 }; op_core<int16_t, int16_t, pixel>(X265HIP_OP_CPY1DTO2D_SHL, N, N, d, ds, false, s, 0, true, nullptr, 0, a); }
+template <int N> static void cpy1d2d_shr_stub(int16_t* d, const int16_t* s, intptr_t ds, int sh) { const int a[4] = { sh, 0, 0, 0 }; op_core<int16_t, int16_t, pixel>(X265HIP_OP_CPY1DTO2D_SHR, N, N, d, ds, false, s, 0, true, nullptr, 0, a); }
+template <int N> static void transpose_stub(pixel* d, const pixel* s, intptr_t ss) { op_core<pixel, pixel, pixel>(X265HIP_OP_TRANSPOSE, N, N, d, 0, true, s, ss, false, nullptr, 0, nullptr); }
+static void weight_pp_stub(const pixel* src, pixel* dst, intptr_t stride, int width, int height, int w0, int round, int shift, int offset)
+{ const int a[4] = { w0, round, shift, offset }; op_core<pixel, pixel, pixel>(X265HIP_OP_WEIGHT_PP, width, height, dst, stride, false, src, stride, false, nullptr, 0, a); }
+static void weight_sp_stub(const int16_t* src, pixel* dst, intptr_t srcStride, intptr_t dstStride, int width, int height, int w0, int round, int shift, int offset)
+{ const int a[4] = { w0, round, shift, offset }; op_core<pixel, int16_t, pixel>(X265HIP_OP_WEIGHT_SP, width, height, dst, dstStride, false, src, srcStride, false, nullptr, 0, a); }
+
+static void scale1d_stub(pixel* dst, const pixel* src)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o1 = st.in1d(src, 256 * ES);
+    x265hip_job jb = {};
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t od = st.alloc(128 * ES);
+    st.upload();
+    const x265hip_plane pl[3] = { plane(st, od, 0), plane(st, o1, 0), plane(st, o1, 0) };
+    st.require(x265hip_blockop_batch(X265HIP_OP_SCALE1D_128TO64, D, 0, 0, pl, dj, 1, nullptr, st.stream), "scale1D");
+    st.download(od, 128 * ES);
+    memcpy(dst, st.hptr<void>(od), 128 * ES);
+}
+static void scale2d_stub(pixel* dst, const pixel* src, intptr_t stride)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o1 = st.in2d(src, stride, 64, 64, ES);
+    x265hip_job jb = {};
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t od = st.alloc(32 * 32 * ES);
+    st.upload();
+    const x265hip_plane pl[3] = { plane(st, od, 0), plane(st, o1, 64), plane(st, o1, 64) };
+    st.require(x265hip_blockop_batch(X265HIP_OP_SCALE2D_64TO32, D, 0, 0, pl, dj, 1, nullptr, st.stream), "scale2D");
+    st.download(od, 32 * 32 * ES);
+    memcpy(dst, st.hptr<void>(od), 32 * 32 * ES);
+}
+// reductions: sse_ss, ssd_s, var
+template <typename T> static uint64_t reduce_core(int op, int n, const T* a, intptr_t sa, const T* b, intptr_t sb)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in2d(a, sa, n, n, sizeof(T));
+    const size_t o1 = b ? st.in2d(b, sb, n, n, sizeof(T)) : o0;
+    x265hip_job jb = {};
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t orr = st.alloc(8);
+    st.upload();
+    const x265hip_plane pl[3] = { plane(st, o0, n), plane(st, o1, n), plane(st, o1, n) };
+    st.require(x265hip_blockop_batch(op, D, n, n, pl, dj, 1, st.dptr<uint64_t>(orr), st.stream), "block reduction");
+    st.download(orr, 8);
+    return *st.hptr<uint64_t>(orr);
+}
+template <int N> static sse_t sse_ss_stub(const int16_t* a, intptr_t sa, const int16_t* b, intptr_t sb) { return (sse_t)reduce_core<int16_t>(X265HIP_OP_SSE_SS, N, a, sa, b, sb); }
+template <int N> static sse_t ssd_s_stub(const int16_t* a, intptr_t sa) { return (sse_t)reduce_core<int16_t>(X265HIP_OP_SSD_S, N, a, sa, nullptr, 0); }
+template <int N> static uint64_t var_stub(const pixel* p, intptr_t s) { return reduce_core<pixel>(X265HIP_OP_VAR, N, p, s, nullptr, 0); }
+
+// ---------------------------------------------------------------- loop filter family
+static void lf_run(ThreadStage& st, int kind, const size_t o[4], const intptr_t strides[4], const x265hip_job& jb, uint32_t* dres)
+{
+    const x265hip_job* dj = put_job(st, jb);
+    st.upload();
+    const x265hip_plane pl[4] = { plane(st, o[0], strides[0]), plane(st, o[1], strides[1]), plane(st, o[2], strides[2]), plane(st, o[3], strides[3]) };
+    st.require(x265hip_loopfilter_batch(kind, D, pl, dj, 1, dres, st.stream), "loopfilter");
+}
+static void sign_stub(int8_t* dst, const pixel* src1, const pixel* src2, const int endX)
+{
+    if (endX <= 0) return;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o1 = st.in1d(src1, endX * ES), o2 = st.in1d(src2, endX * ES), od = st.in1d(dst, endX);
+    const size_t o[4] = { od, o1, o2, o2 }; const intptr_t s[4] = { 0, 0, 0, 0 };
+    x265hip_job jb = {}; jb.arg[0] = endX;
+    lf_run(st, X265HIP_LF_SIGN, o, s, jb, nullptr);
+    st.download(od, endX);
+    memcpy(dst, st.hptr<void>(od), endX);
+}
+// stage `rows` rows of rec with `left`/`right` extra columns; returns offset and sets *org to the element offset of rec[0]
+static size_t stage_rec(ThreadStage& st, const pixel* rec, intptr_t stride, int width, int rows, int left, int right, int rowsAbove, int* tw, int* org)
+{
+    *tw = width + left + right;
+    *org = rowsAbove * *tw + left;
+    return st.in2d(rec - (intptr_t)rowsAbove * stride - left, stride, *tw, rows + rowsAbove, ES);
+}
+static void unstage_rec(ThreadStage& st, size_t off, int tw, int org, pixel* rec, intptr_t stride, int width, int rows)
+{
+    st.download(off, (size_t)(org + (rows - 1) * tw + width) * ES);
+    const pixel* s = st.hptr<pixel>(off) + org;
+    for (int y = 0; y < rows; y++) memcpy(rec + (intptr_t)y * stride, s + (size_t)y * tw, (size_t)width * ES);
+}
+static void sao_e0_stub(pixel* rec, int8_t* offsetEo, int width, int8_t* signLeft, intptr_t stride)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    int tw, org;
+    const size_t orec = stage_rec(st, rec, stride, width, 2, 1, 1, 0, &tw, &org);
+    const size_t oo = st.in1d(offsetEo, 5), osl = st.in1d(signLeft, 2);
+    const size_t o[4] = { orec, oo, osl, osl }; const intptr_t s[4] = { tw, 0, 0, 0 };
+    x265hip_job jb = {}; jb.off[0] = org; jb.arg[0] = width;
+    lf_run(st, X265HIP_LF_SAO_E0, o, s, jb, nullptr);
+    unstage_rec(st, orec, tw, org, rec, stride, width, 2);
+}
+template <int ROWS> static void sao_e1_stub(pixel* rec, int8_t* upBuff1, int8_t* offsetEo, intptr_t stride, int width)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    int tw, org;
+    const size_t orec = stage_rec(st, rec, stride, width, ROWS + 1, 0, 0, 0, &tw, &org);
+    const size_t oo = st.in1d(offsetEo, 5), oup = st.in1d(upBuff1, width);
+    const size_t o[4] = { orec, oo, oup, oup }; const intptr_t s[4] = { tw, 0, 0, 0 };
+    x265hip_job jb = {}; jb.off[0] = org; jb.arg[0] = width;
+    lf_run(st, ROWS == 1 ? X265HIP_LF_SAO_E1 : X265HIP_LF_SAO_E1_2ROWS, o, s, jb, nullptr);
+    st.download(orec, oup + width - orec);
+    const pixel* r = st.hptr<pixel>(orec);
+    for (int y = 0; y < ROWS; y++) memcpy(rec + (intptr_t)y * stride, r + (size_t)y * tw, (size_t)width * ES);
+    memcpy(upBuff1, st.hptr<void>(oup), width);
+}
+static void sao_e2_stub(pixel* rec, int8_t* bufft, int8_t* buff1, int8_t* offsetEo, int width, intptr_t stride)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    int tw, org;
+    const size_t orec = stage_rec(st, rec, stride, width, 2, 0, 1, 0, &tw, &org);
+    const size_t oo = st.in1d(offsetEo, 5), ob1 = st.in1d(buff1, width), obt = st.in1d(bufft, width + 1);
+    const size_t o[4] = { orec, oo, ob1, obt }; const intptr_t s[4] = { tw, 0, 0, 0 };
+    x265hip_job jb = {}; jb.off[0] = org; jb.arg[0] = width;
+    lf_run(st, X265HIP_LF_SAO_E2, o, s, jb, nullptr);
+    st.download(orec, obt + width + 1 - orec);
+    memcpy(rec, st.hptr<pixel>(orec), (size_t)width * ES);
+    memcpy(bufft + 1, st.hptr<int8_t>(obt) + 1, width);
+}
+static void sao_e3_stub(pixel* rec, int8_t* upBuff1, int8_t* offsetEo, intptr_t stride, int startX, int endX)
+{
+    if (endX - startX < 2) return;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    // rows 0 and 1, columns [startX, endX]; the sign buffer is touched on [startX, endX-1]
+    const int width = endX - startX;
+    int tw, org;
+    const size_t orec = stage_rec(st, rec + startX, stride, width, 2, 0, 0, 0, &tw, &org);
+    const size_t oo = st.in1d(offsetEo, 5), oup = st.in1d(upBuff1 + startX, width);
+    const size_t o[4] = { orec, oo, oup, oup }; const intptr_t s[4] = { tw, 0, 0, 0 };
+    x265hip_job jb = {}; jb.off[0] = org; jb.arg[0] = 0; jb.arg[1] = width;
+    lf_run(st, X265HIP_LF_SAO_E3, o, s, jb, nullptr);
+    st.download(orec, oup + width - orec);
+    memcpy(rec + startX + 1, st.hptr<pixel>(orec) + 1, (size_t)(width - 1) * ES);
+    memcpy(upBuff1 + startX, st.hptr<int8_t>(oup), width - 1);
+}
+static void sao_b0_stub(pixel* rec, const int8_t* offsetBo, int ctuWidth, int ctuHeight, intptr_t stride)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    int tw, org;
+    const size_t orec = stage_rec(st, rec, stride, ctuWidth, ctuHeight, 0, 0, 0, &tw, &org);
+    const size_t oo = st.in1d(offsetBo, 32);
+    const size_t o[4] = { orec, oo, oo, oo }; const intptr_t s[4] = { tw, 0, 0, 0 };
+    x265hip_job jb = {}; jb.off[0] = org; jb.arg[0] = ctuWidth; jb.arg[1] = ctuHeight;
+    lf_run(st, X265HIP_LF_SAO_B0, o, s, jb, nullptr);
+    unstage_rec(st, orec, tw, org, rec, stride, ctuWidth, ctuHeight);
+}
+// SAO statistics: stage the rec neighbourhood each class reads (one column left/right, one row below, one row above
+// is never read: row 0 uses the carried buffer), the 64-stride diff block, the carried sign buffers and the stats/count arrays.
+static void sao_stats(int kind, const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* upBuff1, int8_t* upBufft,
+                      int endX, int endY, int32_t* stats, int32_t* count)
+{
+    if (endX <= 0 || endY <= 0) return;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const int bins = kind == X265HIP_LF_STATS_BO ? 32 : 5;
+    int tw, org;
+    const size_t orec = stage_rec(st, rec, stride, endX, endY + 1, 1, 1, 0, &tw, &org);
+    const size_t odiff = st.in2d(diff, 64, endX, endY, 2);
+    // carried buffers: E3 writes index -1, E2 writes index endX -> stage [-1, endX]
+    const size_t oup = upBuff1 ? st.in1d(upBuff1 - 1, endX + 2) : orec;
+    const size_t out_ = upBufft ? st.in1d(upBufft - 1, endX + 2) : oup;
+    int32_t packed[64] = { 0 };
+    memcpy(packed, stats, bins * 4); memcpy(packed + 32, count, bins * 4);
+    const size_t ores = st.in1d(packed, sizeof(packed));
+    const size_t o[4] = { odiff, orec, oup, out_ }; const intptr_t s[4] = { endX, tw, 0, 0 };   // diff packed at pitch endX
+    x265hip_job jb = {}; jb.off[1] = org; jb.off[2] = 1; jb.off[3] = 1; jb.arg[0] = endX; jb.arg[1] = endY;
+    lf_run(st, kind, o, s, jb, st.dptr<uint32_t>(ores));
+    st.download(oup, ores + sizeof(packed) - oup);
+    const int32_t* r = st.hptr<int32_t>(ores);
+    memcpy(stats, r, bins * 4); memcpy(count, r + 32, bins * 4);
+    if (kind == X265HIP_LF_STATS_E1) memcpy(upBuff1, st.hptr<int8_t>(oup) + 1, endX);
+    if (kind == X265HIP_LF_STATS_E3) memcpy(upBuff1 - 1, st.hptr<int8_t>(oup), endX + 1);
+    if (kind == X265HIP_LF_STATS_E2)
+    {
+        memcpy(upBufft, st.hptr<int8_t>(out_) + 1, endX + 1);
+        if (endY >= 2) memcpy(upBuff1, st.hptr<int8_t>(oup) + 1, endX + 1);
+    }
+}
+static void stats_bo_stub(const int16_t* diff, const pixel* rec, intptr_t stride, int endX, int endY, int32_t* stats, int32_t* count)
+{ sao_stats(X265HIP_LF_STATS_BO, diff, rec, stride, nullptr, nullptr, endX, endY, stats, count); }
+static void stats_e0_stub(const int16_t* diff, const pixel* rec, intptr_t stride, int endX, int endY, int32_t* stats, int32_t* count)
+{ sao_stats(X265HIP_LF_STATS_E0, diff, rec, stride, nullptr, nullptr, endX, endY, stats, count); }
+static void stats_e1_stub(const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* up, int endX, int endY, int32_t* stats, int32_t* count)
+{ sao_stats(X265HIP_LF_STATS_E1, diff, rec, stride, up, nullptr, endX, endY, stats, count); }
+static void stats_e2_stub(const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* up, int8_t* upt, int endX, int endY, int32_t* stats, int32_t* count)
+{ sao_stats(X265HIP_LF_STATS_E2, diff, rec, stride, up, upt, endX, endY, stats, count); }
+static void stats_e3_stub(const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* up, int endX, int endY, int32_t* stats, int32_t* count)
+{ sao_stats(X265HIP_LF_STATS_E3, diff, rec, stride, up, nullptr, endX, endY, stats, count); }
+
+// deblocking: 4 lines x 8 (luma) / 4 (chroma) samples across the edge
+template <bool CHROMA> static void deblock_core(pixel* src, intptr_t srcStep, intptr_t offset, int32_t a2, int32_t a3, int32_t maskQ)
+{
+    // gather the 4 x 8 neighbourhood into a dense [line][tap] block (tap stride 1, line stride 8)
+    ThreadStage& st = thread_stage();
+    st.begin();
+    pixel blk[4 * 8];
+    for (int l = 0; l < 4; l++)
+        for (int t = -4; t < 4; t++)
+            blk[l * 8 + t + 4] = (CHROMA && (t < -2 || t > 1)) ? (pixel)0 : src[l * srcStep + t * offset];
+    const size_t ob = st.in1d(blk, sizeof(blk));
+    const size_t o[4] = { ob, ob, ob, ob }; const intptr_t s[4] = { 0, 0, 0, 0 };
+    x265hip_job jb = {}; jb.off[0] = 4; jb.arg[0] = 8; jb.arg[1] = 1; jb.arg[2] = a2; jb.arg[3] = a3;
+    if (CHROMA) { jb.off[2] = a3; jb.off[3] = maskQ; }
+    lf_run(st, CHROMA ? X265HIP_LF_DEBLOCK_CHROMA : X265HIP_LF_DEBLOCK_LUMA_STRONG, o, s, jb, nullptr);
+    st.download(ob, sizeof(blk));
+    const pixel* r = st.hptr<pixel>(ob);
+    const int lo = CHROMA ? -1 : -3, hi = CHROMA ? 0 : 2;
+    for (int l = 0; l < 4; l++)
+        for (int t = lo; t <= hi; t++)
+            src[l * srcStep + t * offset] = r[l * 8 + t + 4];
+}
+static void deblock_luma_stub(pixel* src, intptr_t srcStep, intptr_t offset, int32_t tcP, int32_t tcQ) { deblock_core<false>(src, srcStep, offset, tcP, tcQ, 0); }
+static void deblock_chroma_stub(pixel* src, intptr_t srcStep, intptr_t offset, int32_t tc, int32_t maskP, int32_t maskQ) { deblock_core<true>(src, srcStep, offset, tc, maskP, maskQ); }
+
+template <int N> static void integral_h_stub(uint32_t* sum, pixel* pix, intptr_t stride)
+{
+    if (stride <= N) return;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const int cnt = (int)stride - N;
+    const size_t oabove = st.in1d(sum - stride, (size_t)cnt * 4);
+    const size_t opix = st.in1d(pix, (size_t)stride * ES);
+    // sum row sits `cnt` elements after the staged row above: tell the kernel stride = cnt for the sum plane
+    const size_t osum = st.alloc((size_t)cnt * 4);
+    (void)osum;
+    // kernel: sum[x] = v + sum[x - strideArg]; use strideArg = distance between the two staged rows
+    const intptr_t dist = (intptr_t)((osum - oabove) / 4);
+    const size_t o[4] = { osum, opix, opix, opix }; const intptr_t s[4] = { 0, 0, 0, 0 };
+    x265hip_job jb = {}; jb.arg[0] = (int)dist; jb.arg[1] = N; jb.arg[2] = cnt;
+    lf_run(st, X265HIP_LF_INTEGRAL_H, o, s, jb, nullptr);
+    st.download(osum, (size_t)cnt * 4);
+    memcpy(sum, st.hptr<void>(osum), (size_t)cnt * 4);
+}
+template <int N> static void integral_v_stub(uint32_t* sum, intptr_t stride)
+{
+    if (stride <= 0) return;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(sum, (size_t)stride * 4);
+    const size_t oN = st.in1d(sum + (intptr_t)N * stride, (size_t)stride * 4);
+    const intptr_t dist = (intptr_t)((oN - o0) / 4);           // kernel reads sum[x + N * strideArg]
+    const size_t o[4] = { o0, o0, o0, o0 }; const intptr_t s[4] = { 0, 0, 0, 0 };
+    x265hip_job jb = {}; jb.arg[0] = (int)dist; jb.arg[1] = 1; jb.arg[2] = (int)stride;
+    lf_run(st, X265HIP_LF_INTEGRAL_V, o, s, jb, nullptr);
+    st.download(o0, (size_t)stride * 4);
+    memcpy(sum, st.hptr<void>(o0), (size_t)stride * 4);
+}
+template <int LX, int NSUM> static int ads_stub(int* encDC, uint32_t* sums, int delta, uint16_t* costMvX, int16_t* mvs, int width, int thresh)
+{
+    if (width <= 0) return 0;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const int span = width + (NSUM == 4 ? delta + (LX >> 1) : (NSUM == 2 ? delta : 0));
+    const size_t os = st.in1d(sums, (size_t)span * 4), oc = st.in1d(costMvX, (size_t)width * 2), oe = st.in1d(encDC, 16);
+    x265hip_job jb = {}; jb.arg[0] = delta; jb.arg[1] = width; jb.arg[2] = thresh; jb.arg[3] = LX | (NSUM << 16);
+    const x265hip_job* dj = put_job(st, jb);
+    const size_t om = st.alloc((size_t)width * 2), orr = st.alloc(4);
+    st.upload();
+    const x265hip_plane pl[4] = { plane(st, os, 0), plane(st, oc, 0), plane(st, om, 0), plane(st, oe, 0) };
+    st.require(x265hip_loopfilter_batch(X265HIP_LF_ADS, D, pl, dj, 1, st.dptr<uint32_t>(orr), st.stream), "ads");
+    st.download(om, orr + 4 - om);
+    const int n = (int)*st.hptr<uint32_t>(orr);
+    memcpy(mvs, st.hptr<void>(om), (size_t)n * 2);
+    return n;
 }
 
 #define PU_LIST(X) X(4,4) X(8,8) X(16,16) X(32,32) X(64,64) X(8,4) X(4,8) X(16,8) X(8,16) X(32,16) X(16,32) \
     X(64,32) X(32,64) X(16,12) X(12,16) X(16,4) X(4,16) X(32,24) X(24,32) X(32,8) X(8,32) X(64,48) X(48,64) X(64,16) X(16,64)
+
+// ADS variant per PU (pixel.cpp:1105-1129)
+template <int W, int H> struct AdsN { static constexpr int v = 4; };
+#define ADSN(W, H, N) template <> struct AdsN<W, H> { static constexpr int v = N; };
+ADSN(4,4,1) ADSN(8,8,1) ADSN(8,4,2) ADSN(4,8,2) ADSN(16,8,2) ADSN(8,16,2) ADSN(16,12,1) ADSN(12,16,1) ADSN(16,4,1) ADSN(4,16,1)
+ADSN(32,16,2) ADSN(16,32,2) ADSN(64,32,2) ADSN(32,64,2)
 
 } // namespace
 
@@ -89,24 +612,72 @@ int CAT(setup_primitives_d, X265HIP_DEPTH)(x265hip_EncoderPrimitives* p)
 {
     int n = 0;
 #define SET(slot, fn) do { (slot) = (fn); n++; } while (0)
+#define SET2(slot, fn) do { SET((slot)[0], fn); SET((slot)[1], fn); } while (0)
 
 #define SET_PU(W, H) { auto& u = p->pu[X265HIP_LUMA_##W##x##H]; \
     SET(u.sad, (cmp_stub<X265HIP_CMP_SAD, W, H>)); SET(u.sad_x3, (sad_x3_stub<W, H>)); SET(u.sad_x4, (sad_x4_stub<W, H>)); \
-    SET(u.satd, (cmp_stub<X265HIP_CMP_SATD, W, H>)); }
+    SET(u.ads, (ads_stub<W, AdsN<W, H>::v>)); SET(u.satd, (cmp_stub<X265HIP_CMP_SATD, W, H>)); \
+    SET(u.luma_hpp, (hpp_stub<8, W, H>)); SET(u.luma_hps, (hps_stub<8, W, H>)); SET(u.luma_vpp, (vpp_stub<8, W, H>)); \
+    SET(u.luma_vps, (vps_stub<8, W, H>)); SET(u.luma_vsp, (vsp_stub<8, W, H>)); SET(u.luma_vss, (vss_stub<8, W, H>)); \
+    SET(u.luma_hvpp, (hvpp_stub<8, W, H>)); SET2(u.pixelavg_pp, (pixelavg_stub<W, H>)); SET2(u.addAvg, (addavg_stub<W, H>)); \
+    SET(u.copy_pp, (copy_pp_stub<W, H>)); SET2(u.convert_p2s, (p2s_stub<W, H>)); }
     PU_LIST(SET_PU)
 
 #define SET_CU(I, N) { auto& c = p->cu[I]; \
-    SET(c.sa8d, (cmp_stub<X265HIP_CMP_SA8D, N, N>)); SET(c.sse_pp, (sse_stub<N, N>)); SET(c.psy_cost_pp, (cmp_stub<X265HIP_CMP_PSY_COST, N, N>)); }
+    SET2(c.calcresidual, (calcresidual_stub<N>)); SET(c.sub_ps, (sub_ps_stub<N, N>)); SET2(c.add_ps, (add_ps_stub<N, N>)); \
+    SET2(c.blockfill_s, (blockfill_stub<N>)); SET(c.cpy2Dto1D_shl, (cpy2d1d_shl_stub<N>)); SET(c.cpy2Dto1D_shr, (cpy2d1d_shr_stub<N>)); \
+    SET2(c.cpy1Dto2D_shl, (cpy1d2d_shl_stub<N>)); SET(c.cpy1Dto2D_shr, (cpy1d2d_shr_stub<N>)); \
+    SET(c.copy_sp, (copy_sp_stub<N, N>)); SET(c.copy_ps, (copy_ps_stub<N, N>)); SET(c.copy_ss, (copy_ss_stub<N, N>)); SET(c.copy_pp, (copy_pp_stub<N, N>)); \
+    SET(c.var, (var_stub<N>)); SET(c.sse_pp, (sse_stub<N, N>)); SET(c.sse_ss, (sse_ss_stub<N>)); SET(c.psy_cost_pp, (cmp_stub<X265HIP_CMP_PSY_COST, N, N>)); \
+    SET2(c.ssd_s, (ssd_s_stub<N>)); SET(c.sa8d, (cmp_stub<X265HIP_CMP_SA8D, N, N>)); SET(c.transpose, (transpose_stub<N>)); }
     SET_CU(0, 4) SET_CU(1, 8) SET_CU(2, 16) SET_CU(3, 32) SET_CU(4, 64)
 
-    // chroma satd: same kernels on the chroma block size, only where the reference has a function
-    // (NULL when the chroma PU is not a multiple of 4x4: primitives.h:398, pixel.cpp:1200-1226,1279-1305)
-#define SET_CSATD(CSP, W, H, CW, CH) if (((CW) % 4 == 0) && ((CH) % 4 == 0)) SET(p->chroma[CSP].pu[X265HIP_LUMA_##W##x##H].satd, (cmp_stub<X265HIP_CMP_SATD, ((CW) % 4 || (CH) % 4) ? 4 : (CW), ((CW) % 4 || (CH) % 4) ? 4 : (CH)>));
-#define SET_C420(W, H) SET_CSATD(1, W, H, W / 2, H / 2)
-#define SET_C422(W, H) SET_CSATD(2, W, H, W / 2, H)
-#define SET_C444(W, H) SET_CSATD(3, W, H, W, H)
+#define SET_TU(I, N) { auto& c = p->cu[I]; \
+    SET(c.dct, (fwd_tr_stub<X265HIP_TR_DCT, N>)); SET(c.idct, (inv_tr_stub<X265HIP_TR_IDCT, N>)); \
+    SET(c.copy_cnt, (copy_cnt_stub<N>)); SET(c.count_nonzero, (count_nonzero_stub<N>)); \
+    SET(c.intra_filter, (intra_filter_stub<N>)); SET(c.intra_pred_allangs, (intra_allangs_stub<N>)); \
+    for (int m = 0; m < 35; m++) SET(c.intra_pred[m], (intra_pred_stub<N>)); }
+    SET_TU(0, 4) SET_TU(1, 8) SET_TU(2, 16) SET_TU(3, 32)
+    SET(p->cu[1].lowpass_dct, (fwd_tr_stub<X265HIP_TR_LOWPASS_DCT, 8>));
+    SET(p->cu[2].lowpass_dct, (fwd_tr_stub<X265HIP_TR_LOWPASS_DCT, 16>));
+    SET(p->cu[3].lowpass_dct, (fwd_tr_stub<X265HIP_TR_LOWPASS_DCT, 32>));
+
+    SET(p->dst4x4, (fwd_tr_stub<X265HIP_TR_DST4, 4>)); SET(p->idst4x4, (inv_tr_stub<X265HIP_TR_IDST4, 4>));
+    SET(p->quant, quant_stub); SET(p->nquant, nquant_stub); SET(p->dequant_scaling, dequant_scaling_stub);
+    SET(p->dequant_normal, dequant_normal_stub); SET(p->denoiseDct, denoise_stub);
+    SET2(p->scale1D_128to64, scale1d_stub); SET(p->scale2D_64to32, scale2d_stub);
+    SET(p->sign, sign_stub); SET(p->saoCuOrgE0, sao_e0_stub); SET(p->saoCuOrgE1, (sao_e1_stub<1>)); SET(p->saoCuOrgE1_2Rows, (sao_e1_stub<2>));
+    SET2(p->saoCuOrgE2, sao_e2_stub); SET2(p->saoCuOrgE3, sao_e3_stub); SET(p->saoCuOrgB0, sao_b0_stub);
+    SET(p->saoCuStatsBO, stats_bo_stub); SET(p->saoCuStatsE0, stats_e0_stub); SET(p->saoCuStatsE1, stats_e1_stub);
+    SET(p->saoCuStatsE2, stats_e2_stub); SET(p->saoCuStatsE3, stats_e3_stub);
+    SET(p->weight_sp, weight_sp_stub); SET(p->weight_pp, weight_pp_stub);
+    SET2(p->pelFilterLumaStrong, deblock_luma_stub); SET2(p->pelFilterChroma, deblock_chroma_stub);
+#define SET_INTEG(I, N) SET(p->integral_initv[I], (integral_v_stub<N>)); SET(p->integral_inith[I], (integral_h_stub<N>));
+    SET_INTEG(0, 4) SET_INTEG(1, 8) SET_INTEG(2, 12) SET_INTEG(3, 16) SET_INTEG(4, 24) SET_INTEG(5, 32)
+
+    // ---- chroma tables (indexed by the LUMA enum; primitives.h:77-79,393-428) ----
+    // satd only where the reference has a function (multiple of 4x4: pixel.cpp:1200-1226,1279-1305); 4:2:0 2x2 has
+    // no interpolation / p2s (ipfilter.cpp:416-521)
+#define OKSZ(CW, CH) (((CW) % 4 == 0) && ((CH) % 4 == 0))
+#define SAFE(V, CW, CH) (OKSZ(CW, CH) ? (V) : 4)
+#define SET_CPU(CSP, W, H, CW, CH) { auto& u = p->chroma[CSP].pu[X265HIP_LUMA_##W##x##H]; \
+    if (OKSZ(CW, CH)) SET(u.satd, (cmp_stub<X265HIP_CMP_SATD, SAFE(CW, CW, CH), SAFE(CH, CW, CH)>)); \
+    if (!((CW) == 2 && (CH) == 2)) { \
+        SET(u.filter_vpp, (vpp_stub<4, CW, CH>)); SET(u.filter_vps, (vps_stub<4, CW, CH>)); SET(u.filter_vsp, (vsp_stub<4, CW, CH>)); \
+        SET(u.filter_vss, (vss_stub<4, CW, CH>)); SET(u.filter_hpp, (hpp_stub<4, CW, CH>)); SET(u.filter_hps, (hps_stub<4, CW, CH>)); \
+        SET2(u.p2s, (p2s_stub<CW, CH>)); } \
+    SET2(u.addAvg, (addavg_stub<CW, CH>)); SET(u.copy_pp, (copy_pp_stub<CW, CH>)); }
+#define SET_C420(W, H) SET_CPU(1, W, H, W / 2, H / 2)
+#define SET_C422(W, H) SET_CPU(2, W, H, W / 2, H)
+#define SET_C444(W, H) SET_CPU(3, W, H, W, H)
     PU_LIST(SET_C420) PU_LIST(SET_C422) PU_LIST(SET_C444)
 
+#define SET_CCU(CSP, I, CW, CH) { auto& c = p->chroma[CSP].cu[I]; \
+    SET(c.sub_ps, (sub_ps_stub<CW, CH>)); SET2(c.add_ps, (add_ps_stub<CW, CH>)); SET(c.copy_ps, (copy_ps_stub<CW, CH>)); \
+    SET(c.copy_sp, (copy_sp_stub<CW, CH>)); SET(c.copy_ss, (copy_ss_stub<CW, CH>)); SET(c.copy_pp, (copy_pp_stub<CW, CH>)); }
+    SET_CCU(1, 0, 2, 2) SET_CCU(1, 1, 4, 4) SET_CCU(1, 2, 8, 8) SET_CCU(1, 3, 16, 16) SET_CCU(1, 4, 32, 32)
+    SET_CCU(2, 0, 2, 4) SET_CCU(2, 1, 4, 8) SET_CCU(2, 2, 8, 16) SET_CCU(2, 3, 16, 32) SET_CCU(2, 4, 32, 64)
+    SET_CCU(3, 0, 4, 4) SET_CCU(3, 1, 8, 8) SET_CCU(3, 2, 16, 16) SET_CCU(3, 3, 32, 32) SET_CCU(3, 4, 64, 64)
     // chroma CU costs (pixel.cpp:1243-1246,1322-1325; primitives.cpp:184-208)
     SET(p->chroma[1].cu[1].sa8d, (cmp_stub<X265HIP_CMP_SATD, 4, 4>)); SET(p->chroma[1].cu[2].sa8d, (cmp_stub<X265HIP_CMP_SA8D, 8, 8>));
     SET(p->chroma[1].cu[3].sa8d, (cmp_stub<X265HIP_CMP_SA8D, 16, 16>)); SET(p->chroma[1].cu[4].sa8d, (cmp_stub<X265HIP_CMP_SA8D, 32, 32>));

@@ -1,0 +1,387 @@
+// transform_kernels.hip - batched HEVC integer transforms on gfx950.
+//
+// Reference semantics (source/common/dct.cpp): forward dct4/8/16/32_c :459-525 = two passes of
+//   out[k][j] = (int16)((sum_i M[k][i] * in[j][i] + add) >> shift)   (partialButterflyN :83-240,:418-440 are
+//   an exact refactoring of this product; the store TRUNCATES to int16 without clipping), shifts
+//   log2N-1+depth-8 then log2N+6; inverse idct* :544-610 = two passes of
+//   out[j][k] = clip16((sum_i M[i][k] * in[i][j] + add) >> shift), shifts 7 then 12-(depth-8);
+//   DST-VII 4x4 :43-81,:442-457,:527-542; lowpass approximations lowpassdct.cpp:34-113.
+// M is the standard's 32-point matrix (constants.cpp:270-344), generated here from its 31 distinct
+// magnitudes by the cosine symmetries.
+//
+// Two implementations, bit-identical:
+//   * VALU: one thread per output coefficient, operands in LDS (all sizes; default for 4x4 / 8x8);
+//   * MFMA: 16x16 / 32x32 as int8 matrix products on the matrix cores.  int16 inputs are biased to
+//     unsigned and split into two 8-bit limbs re-centred to signed (x = 256*hi + lo + 128 with
+//     hi, lo in [-128,127]); M * x = 256 * (M*hi) + (M*lo) + 128 * rowsum(M), every partial sum fits
+//     int32 exactly, so the rounding shift sees the same integer as the reference.
+#include "common.h"
+
+namespace x265hip {
+
+struct DctMat
+{
+    int8_t m[32][32];
+    constexpr DctMat() : m{}
+    {
+        constexpr int basis[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67,
+                                    64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+        for (int k = 0; k < 32; k++)
+            for (int n = 0; n < 32; n++)
+            {
+                const int q = (k * (2 * n + 1)) & 127;
+                int v = 0;
+                if (q <= 32) v = basis[q];
+                else if (q <= 64) v = -basis[64 - q];
+                else if (q <= 96) v = -basis[q - 64];
+                else v = basis[128 - q];
+                m[k][n] = (int8_t)v;
+            }
+    }
+};
+__constant__ DctMat kT = DctMat();
+__constant__ int8_t kDst[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };
+
+struct TrArgs
+{
+    const int16_t* src; long srcStride;
+    int16_t* dst; long dstStride;
+    const x265hip_job* jobs;
+    int njobs, depth;
+};
+
+__device__ __forceinline__ int clip16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+// coefficient (row k, column n) of the N-point matrix; DST uses its own 4x4 matrix
+template <int N, bool DST> __device__ __forceinline__ int coef(int k, int n) { return DST ? kDst[k][n] : kT.m[k * (32 / N)][n]; }
+
+// KIND: 0 forward, 1 inverse.  JPB jobs per block (small transforms share a workgroup).
+template <int N, int KIND, bool DST>
+__global__ void __launch_bounds__(256) transform_valu_kernel(TrArgs a)
+{
+    constexpr int NN = N * N;
+    constexpr int JPB = NN >= 256 ? 1 : 256 / NN;
+    constexpr int LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
+    __shared__ int16_t bufA[JPB * NN], bufB[JPB * NN];
+    const int tid = threadIdx.x;
+    const int jl = NN >= 256 ? 0 : tid / NN;                 // job slot inside the block
+    const int e0 = NN >= 256 ? tid : tid - jl * NN;          // first element handled by this thread
+    const long job = (long)blockIdx.x * JPB + jl;
+    const bool live = job < a.njobs;
+    const x265hip_job jb = a.jobs[live ? job : 0];
+    const int16_t* src = a.src + jb.off[0];
+    int16_t* dst = a.dst + jb.off[1];
+    int16_t* A = bufA + jl * NN;
+    int16_t* B = bufB + jl * NN;
+
+    if (KIND == 0)
+    {
+        for (int e = e0; e < NN; e += 256)
+        {
+            const int y = e / N, x = e % N;
+            A[e] = live ? src[(long)y * a.srcStride + x] : (int16_t)0;
+        }
+        __syncthreads();
+        const int sh1 = (DST ? 1 : LOG2N - 1) + a.depth - 8, sh2 = DST ? 8 : LOG2N + 6;
+        for (int e = e0; e < NN; e += 256)
+        {
+            const int k = e / N, j = e % N;
+            int acc = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) acc += coef<N, DST>(k, i) * (int)A[j * N + i];
+            B[k * N + j] = (int16_t)((acc + (1 << (sh1 - 1))) >> sh1);
+        }
+        __syncthreads();
+        for (int e = e0; e < NN; e += 256)
+        {
+            const int k = e / N, j = e % N;
+            int acc = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) acc += coef<N, DST>(k, i) * (int)B[j * N + i];
+            if (live) dst[k * N + j] = (int16_t)((acc + (1 << (sh2 - 1))) >> sh2);
+        }
+    }
+    else
+    {
+        for (int e = e0; e < NN; e += 256) A[e] = live ? src[e] : (int16_t)0;
+        __syncthreads();
+        const int sh2 = 12 - (a.depth - 8);
+        for (int e = e0; e < NN; e += 256)
+        {
+            const int j = e / N, k = e % N;
+            int acc = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) acc += coef<N, DST>(i, k) * (int)A[i * N + j];
+            B[j * N + k] = (int16_t)clip16((acc + 64) >> 7);
+        }
+        __syncthreads();
+        for (int e = e0; e < NN; e += 256)
+        {
+            const int j = e / N, k = e % N;
+            int acc = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) acc += coef<N, DST>(i, k) * (int)B[i * N + j];
+            if (live) dst[(long)j * a.dstStride + k] = (int16_t)clip16((acc + (1 << (sh2 - 1))) >> sh2);
+        }
+    }
+}
+
+// lowpass_dct (lowpassdct.cpp:34-113): 2x2 average -> half-size DCT into the top-left quadrant,
+// zeros elsewhere, DC replaced by a scaled sum of the (int16-truncated) 2x2 sums.
+template <int N>
+__global__ void __launch_bounds__(256) lowpass_kernel(TrArgs a)
+{
+    constexpr int H = N / 2, HH = H * H;
+    constexpr int LOG2H = H == 4 ? 2 : (H == 8 ? 3 : 4);
+    __shared__ int16_t A[HH], B[HH];
+    __shared__ int total;
+    const int tid = threadIdx.x;
+    const x265hip_job jb = a.jobs[blockIdx.x];
+    const int16_t* src = a.src + jb.off[0];
+    int16_t* dst = a.dst + jb.off[1];
+    if (tid == 0) total = 0;
+    __syncthreads();
+    int part = 0;
+    for (int e = tid; e < HH; e += 256)
+    {
+        const int i = e / H, j = e % H;
+        const int16_t* p = src + (long)(2 * i) * a.srcStride + 2 * j;
+        const int16_t s4 = (int16_t)((int)p[0] + p[1] + p[a.srcStride] + p[a.srcStride + 1]);
+        A[e] = (int16_t)(s4 >> 2);
+        part += s4;
+    }
+    atomicAdd(&total, part);
+    for (int e = tid; e < N * N; e += 256) dst[e] = 0;
+    __syncthreads();
+    const int sh1 = LOG2H - 1 + a.depth - 8, sh2 = LOG2H + 6;
+    for (int e = tid; e < HH; e += 256)
+    {
+        const int k = e / H, j = e % H;
+        int acc = 0;
+#pragma unroll
+        for (int i = 0; i < H; i++) acc += coef<H, false>(k, i) * (int)A[j * H + i];
+        B[k * H + j] = (int16_t)((acc + (1 << (sh1 - 1))) >> sh1);
+    }
+    __syncthreads();
+    for (int e = tid; e < HH; e += 256)
+    {
+        const int k = e / H, j = e % H;
+        int acc = 0;
+#pragma unroll
+        for (int i = 0; i < H; i++) acc += coef<H, false>(k, i) * (int)B[j * H + i];
+        int16_t v = (int16_t)((acc + (1 << (sh2 - 1))) >> sh2);
+        if (e == 0)
+        {
+            const int t32 = total;
+            if (N == 8) v = (int16_t)((int)(int16_t)t32 << 1);       // int16_t running sum in the reference
+            else if (N == 16) v = (int16_t)(t32 >> 1);
+            else v = (int16_t)(t32 >> 3);
+        }
+        dst[k * N + j] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------ MFMA path
+// One wavefront per TU.  N = 32: one v_mfma_i32_32x32x32_i8 per limb; N = 16: v_mfma_i32_16x16x64_i8 would
+// need K = 64, so the 16-point product is zero-padded to K = 32 inside the 32x32x32 shape?  No - the
+// 16x16 case uses v_mfma_i32_16x16x64_i8 with the K range [16,64) fed zeros.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// Operand fragment layouts (gfx950, 8-bit types): 32x32x32 - lane l supplies A[row = l & 31][k = 16*(l >> 5) + 0..15]
+// and B[k = 16*(l >> 5) + 0..15][col = l & 31]; C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5).
+// 16x16x64 - A[row = l & 15][k = 16*(l >> 4) + 0..15], B[k = 16*(l >> 4) + 0..15][col = l & 15];
+// C/D: col = l & 15, row = 4*(l >> 4) + r.
+template <int N> struct Mfma;
+template <> struct Mfma<32>
+{
+    typedef v16i Acc;
+    static constexpr int NACC = 16;
+    static __device__ __forceinline__ Acc run(v4i a, v4i b, Acc c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+    static __device__ __forceinline__ int col(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int kbase(int lane) { return 16 * (lane >> 5); }
+    static __device__ __forceinline__ int mn(int lane) { return lane & 31; }
+};
+template <> struct Mfma<16>
+{
+    typedef v4i Acc;
+    static constexpr int NACC = 4;
+    static __device__ __forceinline__ Acc run(v4i a, v4i b, Acc c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+    static __device__ __forceinline__ int col(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int kbase(int lane) { return 16 * (lane >> 4); }     // 0,16,32,48: only 0 is inside K = 16
+    static __device__ __forceinline__ int mn(int lane) { return lane & 15; }
+};
+
+__device__ __forceinline__ int pack4(int b0, int b1, int b2, int b3)
+{
+    return (b0 & 0xff) | ((b1 & 0xff) << 8) | ((b2 & 0xff) << 16) | ((uint32_t)(b3 & 0xff) << 24);
+}
+
+// P = Mop x X where Mop is the transform matrix (FWD: M[k][i]; INV: M^T, i.e. Mop[k][i] = M[i][k]) and
+// X[i][col] comes from LDS as int16 via xsrc(i, col).  Returns the exact int32 products in C/D layout.
+template <int N, bool INV, typename XF>
+__device__ __forceinline__ typename Mfma<N>::Acc mfma_stage(int lane, XF xsrc)
+{
+    typedef Mfma<N> MF;
+    const int kb = MF::kbase(lane), rn = MF::mn(lane);
+    int aw[4], hw[4], lw[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        int ab[4], hb[4], lb[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+        {
+            const int k = kb + 4 * q + t;
+            if (k < N)
+            {
+                ab[t] = INV ? kT.m[k * (32 / N)][rn] : kT.m[rn * (32 / N)][k];
+                const int u = (int)xsrc(k, rn) + 32768;           // bias to unsigned 16 bit
+                hb[t] = (u >> 8) - 128;
+                lb[t] = (u & 0xff) - 128;
+            }
+            else { ab[t] = 0; hb[t] = 0; lb[t] = 0; }
+        }
+        aw[q] = pack4(ab[0], ab[1], ab[2], ab[3]);
+        hw[q] = pack4(hb[0], hb[1], hb[2], hb[3]);
+        lw[q] = pack4(lb[0], lb[1], lb[2], lb[3]);
+    }
+    const v4i A = { aw[0], aw[1], aw[2], aw[3] };
+    const v4i Bh = { hw[0], hw[1], hw[2], hw[3] };
+    const v4i Bl = { lw[0], lw[1], lw[2], lw[3] };
+    typename MF::Acc zero = {};
+    typename MF::Acc ph = MF::run(A, Bh, zero);
+    typename MF::Acc pl = MF::run(A, Bl, zero);
+    typename MF::Acc out;
+#pragma unroll
+    for (int r = 0; r < MF::NACC; r++)
+    {
+        // + 128 * sum_i Mop[row][i]: only the DC basis row (forward) / is data independent; computed exactly
+        const int rowIdx = MF::row(lane, r);
+        int rs = 0;
+        if (!INV) rs = rowIdx == 0 ? 64 * N : 0;                    // rows 1.. of the DCT matrix sum to zero
+        out[r] = ph[r] * 256 + pl[r] + 128 * rs;
+    }
+    return out;
+}
+
+// column sums of M (needed for the inverse: Mop = M^T so "row sums" of Mop are column sums of M)
+__device__ __forceinline__ int col_sum(int N, int k)
+{
+    int s = 0;
+    for (int i = 0; i < N; i++) s += kT.m[i * (32 / N)][k];
+    return s;
+}
+
+template <int N, int KIND>
+__global__ void __launch_bounds__(64) transform_mfma_kernel(TrArgs a)
+{
+    typedef Mfma<N> MF;
+    constexpr int NN = N * N;
+    constexpr int LOG2N = N == 16 ? 4 : 5;
+    __shared__ int16_t A[NN], B[NN];
+    __shared__ int csum[32];
+    const int lane = threadIdx.x;
+    const x265hip_job jb = a.jobs[blockIdx.x];
+    const int16_t* src = a.src + jb.off[0];
+    int16_t* dst = a.dst + jb.off[1];
+    if (KIND == 1 && lane < N) csum[lane] = col_sum(N, lane);
+
+    if (KIND == 0)
+    {
+        for (int e = lane; e < NN; e += 64) A[e] = src[(long)(e / N) * a.srcStride + (e % N)];
+        __syncthreads();
+        const int sh1 = LOG2N - 1 + a.depth - 8, sh2 = LOG2N + 6;
+        // stage 1: P[k][j] = sum_i M[k][i] * in[j][i]  -> X[i][col=j] = A[j*N + i]
+        typename MF::Acc p = mfma_stage<N, false>(lane, [&](int i, int j) { return A[j * N + i]; });
+#pragma unroll
+        for (int r = 0; r < MF::NACC; r++)
+            B[MF::row(lane, r) * N + MF::col(lane)] = (int16_t)((p[r] + (1 << (sh1 - 1))) >> sh1);
+        __syncthreads();
+        p = mfma_stage<N, false>(lane, [&](int i, int j) { return B[j * N + i]; });
+#pragma unroll
+        for (int r = 0; r < MF::NACC; r++)
+            dst[MF::row(lane, r) * N + MF::col(lane)] = (int16_t)((p[r] + (1 << (sh2 - 1))) >> sh2);
+    }
+    else
+    {
+        for (int e = lane; e < NN; e += 64) A[e] = src[e];
+        __syncthreads();
+        const int sh2 = 12 - (a.depth - 8);
+        // stage 1: P[k][j] = sum_i M[i][k] * in[i][j]; stored transposed: out[j][k]
+        typename MF::Acc p = mfma_stage<N, true>(lane, [&](int i, int j) { return A[i * N + j]; });
+#pragma unroll
+        for (int r = 0; r < MF::NACC; r++)
+        {
+            const int k = MF::row(lane, r), j = MF::col(lane);
+            B[j * N + k] = (int16_t)clip16((p[r] + 128 * csum[k] + 64) >> 7);
+        }
+        __syncthreads();
+        p = mfma_stage<N, true>(lane, [&](int i, int j) { return B[i * N + j]; });
+#pragma unroll
+        for (int r = 0; r < MF::NACC; r++)
+        {
+            const int k = MF::row(lane, r), j = MF::col(lane);
+            dst[(long)j * a.dstStride + k] = (int16_t)clip16((p[r] + 128 * csum[k] + (1 << (sh2 - 1))) >> sh2);
+        }
+    }
+}
+
+template <int N, int KIND, bool DST> static int launch_valu(const TrArgs& a, hipStream_t s)
+{
+    constexpr int JPB = N * N >= 256 ? 1 : 256 / (N * N);
+    hipLaunchKernelGGL((transform_valu_kernel<N, KIND, DST>), dim3((a.njobs + JPB - 1) / JPB), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <int N, int KIND> static int launch_mfma(const TrArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL((transform_mfma_kernel<N, KIND>), dim3(a.njobs), dim3(64), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+} // namespace x265hip
+
+using namespace x265hip;
+
+extern "C" int x265hip_transform_batch(int kind, int depth, int n, x265hip_plane src, x265hip_plane dst,
+                                       const x265hip_job* jobs, int njobs, int use_mfma, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!src.base || !dst.base || !jobs || njobs < 0) { set_error("transform_batch: NULL operand"); return X265HIP_EINVAL; }
+    if (njobs == 0) return 0;
+    if (depth != 8 && depth != 10 && depth != 12) { set_error("transform_batch: depth %d", depth); return X265HIP_EINVAL; }
+    TrArgs a;
+    a.src = (const int16_t*)src.base; a.srcStride = src.stride; a.dst = (int16_t*)dst.base; a.dstStride = dst.stride;
+    a.jobs = jobs; a.njobs = njobs; a.depth = depth;
+    hipStream_t s = (hipStream_t)stream;
+    switch (kind)
+    {
+    case X265HIP_TR_DST4:  if (n != 4) break; return launch_valu<4, 0, true>(a, s);
+    case X265HIP_TR_IDST4: if (n != 4) break; return launch_valu<4, 1, true>(a, s);
+    case X265HIP_TR_DCT:
+        if (n == 4) return launch_valu<4, 0, false>(a, s);
+        if (n == 8) return launch_valu<8, 0, false>(a, s);
+        if (n == 16) return use_mfma ? launch_mfma<16, 0>(a, s) : launch_valu<16, 0, false>(a, s);
+        if (n == 32) return use_mfma ? launch_mfma<32, 0>(a, s) : launch_valu<32, 0, false>(a, s);
+        break;
+    case X265HIP_TR_IDCT:
+        if (n == 4) return launch_valu<4, 1, false>(a, s);
+        if (n == 8) return launch_valu<8, 1, false>(a, s);
+        if (n == 16) return use_mfma ? launch_mfma<16, 1>(a, s) : launch_valu<16, 1, false>(a, s);
+        if (n == 32) return use_mfma ? launch_mfma<32, 1>(a, s) : launch_valu<32, 1, false>(a, s);
+        break;
+    case X265HIP_TR_LOWPASS_DCT:
+        if (n == 8) { hipLaunchKernelGGL((lowpass_kernel<8>), dim3(njobs), dim3(256), 0, s, a); X265HIP_TRY(hipGetLastError()); return 0; }
+        if (n == 16) { hipLaunchKernelGGL((lowpass_kernel<16>), dim3(njobs), dim3(256), 0, s, a); X265HIP_TRY(hipGetLastError()); return 0; }
+        if (n == 32) { hipLaunchKernelGGL((lowpass_kernel<32>), dim3(njobs), dim3(256), 0, s, a); X265HIP_TRY(hipGetLastError()); return 0; }
+        break;
+    default: break;
+    }
+    set_error("transform_batch: kind %d with n = %d is not a transform of the reference", kind, n);
+    return X265HIP_EINVAL;
+}
