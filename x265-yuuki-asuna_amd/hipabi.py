@@ -96,6 +96,91 @@ def me_best_reset(best, stream=None):
     check(lib().x265hip_me_best_reset(best.data_ptr(), best.numel(), s), "x265hip_me_best_reset")
 
 
+# ------------------------------------------------------------------ generic job-list entry points
+class Plane(ctypes.Structure):
+    _fields_ = [("base", ctypes.c_void_p), ("stride", ctypes.c_ssize_t)]
+
+
+IP_HPP, IP_HPS, IP_VPP, IP_VPS, IP_VSP, IP_VSS, IP_HVPP, IP_P2S = range(8)
+TR_DCT, TR_IDCT, TR_DST4, TR_IDST4, TR_LOWPASS_DCT = range(5)
+Q_QUANT, Q_NQUANT, Q_DEQUANT_NORMAL, Q_DEQUANT_SCALING, Q_DENOISE, Q_COUNT_NONZERO, Q_COPY_CNT = range(7)
+INTRA_PRED, INTRA_FILTER, INTRA_ALLANGS = range(3)
+(OP_COPY_PP, OP_COPY_PS, OP_COPY_SP, OP_COPY_SS, OP_SUB_PS, OP_ADD_PS, OP_ADDAVG, OP_PIXELAVG, OP_BLOCKFILL,
+ OP_CPY2DTO1D_SHL, OP_CPY2DTO1D_SHR, OP_CPY1DTO2D_SHL, OP_CPY1DTO2D_SHR, OP_TRANSPOSE, OP_WEIGHT_PP, OP_WEIGHT_SP,
+ OP_SCALE1D_128TO64, OP_SCALE2D_64TO32, OP_SSE_SS, OP_SSD_S, OP_VAR) = range(21)
+
+
+def job_dtype():
+    import numpy as np
+    return np.dtype([("off", "<i8", 4), ("arg", "<i4", 4)])
+
+
+def make_jobs(entries, device):
+    """entries: iterable of (offsets[<=4], args[<=4]) -> device tensor of x265hip_job records."""
+    import numpy as np
+    import torch
+    entries = list(entries)
+    arr = np.zeros(len(entries), dtype=job_dtype())
+    for i, (offs, args) in enumerate(entries):
+        arr["off"][i, :len(offs)] = offs
+        arr["arg"][i, :len(args)] = args
+    return torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(device)
+
+
+def plane(t, stride=0, elem_off=0, elem_size=None):
+    es = t.element_size() if elem_size is None else elem_size
+    return Plane(t.data_ptr() + elem_off * es if t is not None else None, stride)
+
+
+def _planes(ps, n):
+    arr = (Plane * n)()
+    for i in range(n):
+        arr[i] = ps[i] if i < len(ps) and ps[i] is not None else Plane(None, 0)
+    return arr
+
+
+def interp_batch(kind, depth, taps, w, h, src, dst, jobs, njobs, stream=None):
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_interp_batch
+    f.argtypes = [ctypes.c_int] * 5 + [Plane, Plane, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    check(f(kind, depth, taps, w, h, src, dst, jobs.data_ptr(), njobs, s), "x265hip_interp_batch")
+
+
+def transform_batch(kind, depth, n, src, dst, jobs, njobs, use_mfma=0, stream=None):
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_transform_batch
+    f.argtypes = [ctypes.c_int] * 3 + [Plane, Plane, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    check(f(kind, depth, n, src, dst, jobs.data_ptr(), njobs, use_mfma, s), "x265hip_transform_batch")
+
+
+def quant_batch(kind, planes, jobs, njobs, result=None, stream=None):
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_quant_batch
+    f.argtypes = [ctypes.c_int, ctypes.POINTER(Plane), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    check(f(kind, _planes(planes, 4), jobs.data_ptr(), njobs, _p(result), s), "x265hip_quant_batch")
+
+
+def intra_batch(kind, depth, n, src, dst, jobs, njobs, stream=None):
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_intra_batch
+    f.argtypes = [ctypes.c_int] * 3 + [Plane, Plane, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    check(f(kind, depth, n, src, dst, jobs.data_ptr(), njobs, s), "x265hip_intra_batch")
+
+
+def blockop_batch(op, depth, w, h, planes, jobs, njobs, result=None, stream=None):
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_blockop_batch
+    f.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(Plane), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    check(f(op, depth, w, h, _planes(planes, 3), jobs.data_ptr(), njobs, _p(result), s), "x265hip_blockop_batch")
+
+
+def loopfilter_batch(kind, depth, planes, jobs, njobs, result=None, stream=None):
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_loopfilter_batch
+    f.argtypes = [ctypes.c_int] * 2 + [ctypes.POINTER(Plane), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    check(f(kind, depth, _planes(planes, 4), jobs.data_ptr(), njobs, _p(result), s), "x265hip_loopfilter_batch")
+
+
 def pixelcmp_batch(kind, depth, w, h, a, a_stride, b, b_stride, njobs, out,
                    a_off=None, a_step=0, b_off=None, b_step=0, a_base=0, b_base=0, stream=None):
     es = 1 if depth == 8 else 2
