@@ -427,9 +427,12 @@ def _cmp_intra_pred(fa, fb, path, depth, rng, case):
     for bf in (0, 1):
         ds = int(rng.integers(n, n + 40))
         outs = []
+        # the planar / DC slots ignore dirMode (intrapred.cpp:70,88) and callers pass other values there:
+        # the reference harness calls the DC slot with dirMode 0 (intrapredharness.cpp:62)
+        arg_mode = mode if mode >= 2 else (0 if mode == 1 else int(rng.integers(0, 35)))
         for f in (fa, fb):
             d = out2d(n, n, ds, pix_dtype(depth), 0x33)
-            f(d.p, d.stride, ptr(s, 16), mode, bf)
+            f(d.p, d.stride, ptr(s, 16), arg_mode, bf)
             outs.append(d.data)
         res.append((f"dst(bFilter={bf})", outs[0], outs[1]))
     return res

@@ -241,8 +241,11 @@ template <int N> static uint32_t copy_cnt_stub(int16_t* coeff, const int16_t* re
 }
 
 // ---------------------------------------------------------------- intra prediction
-template <int N> static void intra_pred_stub(pixel* dst, intptr_t dstStride, const pixel* srcPix, int dirMode, int bFilter)
+// SLOT: 0 = planar slot, 1 = DC slot (both IGNORE the dirMode argument, intrapred.cpp:70,88 - callers do pass
+// other values there), 2 = angular slots (mode taken from the argument)
+template <int N, int SLOT> static void intra_pred_stub(pixel* dst, intptr_t dstStride, const pixel* srcPix, int dirMode, int bFilter)
 {
+    if (SLOT < 2) dirMode = SLOT;
     ThreadStage& st = thread_stage();
     st.begin();
     const size_t o0 = st.in1d(srcPix, (4 * N + 1) * ES);
@@ -636,7 +639,8 @@ int CAT(setup_primitives_d, X265HIP_DEPTH)(x265hip_EncoderPrimitives* p)
     SET(c.dct, (fwd_tr_stub<X265HIP_TR_DCT, N>)); SET(c.idct, (inv_tr_stub<X265HIP_TR_IDCT, N>)); \
     SET(c.copy_cnt, (copy_cnt_stub<N>)); SET(c.count_nonzero, (count_nonzero_stub<N>)); \
     SET(c.intra_filter, (intra_filter_stub<N>)); SET(c.intra_pred_allangs, (intra_allangs_stub<N>)); \
-    for (int m = 0; m < 35; m++) SET(c.intra_pred[m], (intra_pred_stub<N>)); }
+    SET(c.intra_pred[0], (intra_pred_stub<N, 0>)); SET(c.intra_pred[1], (intra_pred_stub<N, 1>)); \
+    for (int m = 2; m < 35; m++) SET(c.intra_pred[m], (intra_pred_stub<N, 2>)); }
     SET_TU(0, 4) SET_TU(1, 8) SET_TU(2, 16) SET_TU(3, 32)
     SET(p->cu[1].lowpass_dct, (fwd_tr_stub<X265HIP_TR_LOWPASS_DCT, 8>));
     SET(p->cu[2].lowpass_dct, (fwd_tr_stub<X265HIP_TR_LOWPASS_DCT, 16>));
