@@ -98,6 +98,7 @@ def main():
     ref_pic.__dict__.update(ref.__dict__)
     ref_pic.t = ref_plane
 
+    fp = P.FrameParallel(rank, world)
     ev = []
 
     def step(i, timed):
@@ -109,13 +110,8 @@ def main():
         if timed:
             e1.record()
             ev.append((e0, e1))
-        if world > 1:
-            # frame-parallel hand-off: the last rank's newest picture becomes everyone's next reference
-            if rank == world - 1:
-                ref_plane.copy_(cur.t)
-            dist.broadcast(ref_plane, src=world - 1)
-        else:
-            ref_plane.copy_(cur.t)
+        # frame-parallel hand-off: the last rank's newest picture becomes everyone's next reference
+        fp.exchange(ref_plane, cur.t)
 
     for i in range(args.warmup):
         step(i, False)

@@ -100,3 +100,30 @@ class MotionSearch:
         if self.surf is not None:
             out["surf"] = int(self.surf.sum(dtype=torch.int64).item())
         return out
+
+
+class FrameParallel:
+    """Frame-parallel sharding across GPUs: rank r encodes frame step*world + r.
+    All frames of a step search in the same reference picture - the newest picture of the previous step,
+    owned by the last rank - so the only data-path exchange is a one-to-many broadcast of that picture,
+    issued where the reference raises m_reconRowFlag (encoder/framefilter.cpp:664).  Works on any
+    torch.distributed backend (RCCL on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, rank: int, world: int):
+        self.rank, self.world = rank, world
+
+    def frame_index(self, step: int) -> int:
+        return step * self.world + self.rank
+
+    def reference_owner(self) -> int:
+        return self.world - 1
+
+    def exchange(self, ref_plane, newest_plane):
+        """ref_plane <- the reference owner's newest picture (in place on every rank)."""
+        if self.world == 1:
+            ref_plane.copy_(newest_plane)
+            return
+        import torch.distributed as dist
+        if self.rank == self.reference_owner():
+            ref_plane.copy_(newest_plane)
+        dist.broadcast(ref_plane, src=self.reference_owner())
