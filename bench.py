@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--range", type=int, default=57)          # reference default merange (param.cpp:198)
-    ap.add_argument("--mode", default="surface+best", choices=["surface+best", "surface", "best"])
+    ap.add_argument("--mode", default="surface", choices=["surface+best", "surface", "best"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -74,12 +74,14 @@ int x265hip_pixelcmp_batch(int kind, int depth, int w, int h,
  * then summed hierarchically into the 16x16 / 32x32 / 64x64 PUs (SAD is additive, so every level
  * equals pu[LUMA_NxN].sad on the same pixels).
  *
- *   fenc, fref : luma planes, (0,0) pixel pointers; fref must have >= range + 8 valid pixels of
+ *   fenc, fref : luma planes, (0,0) pixel pointers; fref must have >= range + 12 valid pixels of
  *                margin on every side (reference picyuv.cpp:87-114 guarantees 96 / 80).
  *   width, height : multiples of 64 (the reference allocates whole CTUs).
- *   surf       : optional SAD surfaces, int32 [ctu][mvy][mvx][85]: one 85-int record per motion
- *                vector holding every PU of the CTU - [0,64) the 8x8 PUs, [64,80) the 16x16, [80,84)
- *                the 32x32, [84] the 64x64, each group in z-order inside the CTU.
+ *   surf       : optional SAD surfaces, int32 [ctu][mvy][(2*range+1+3)/4][85][4]: for every motion-vector
+ *                row, columns are stored in groups of 4 (the last group padded, pad values unspecified); a
+ *                group holds, for each of the 85 PUs of the CTU, the 4 SADs of its 4 columns - exactly the
+ *                res[4] a sad_x4 call on those 4 horizontal displacements returns (motion.cpp:1415-1430).
+ *                PU order: [0,64) 8x8, [64,80) 16x16, [80,84) 32x32, [84] 64x64, each level in z-order.
  *   best       : optional per-PU minimum of (sad + cost_x[mvx] + cost_y[mvy]), uint64 [ctu][85] (same
  *                PU order) = cost << 32 | (mvy_index * (2*range+1) + mvx_index); must be pre-set to
  *                all-ones by the caller (x265hip_me_best_reset).  Ties resolve to the smallest raster

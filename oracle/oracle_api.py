@@ -36,13 +36,14 @@ def me_fullsearch(depth, fenc, fenc_stride, fenc_org, fref, fref_stride, fref_or
                   ctu_begin, ctu_end, cost_x, cost_y, want_surf=True, want_best=True, levels=(0, 1, 2, 3),
                   nthreads=0, avx2=False):
     """Run the CPU restatement of the exhaustive search on padded host planes (numpy).
-    Returns (surf, best) with the same layouts as the HIP ABI (int32 [ctu][mvy][mvx][85] and uint64
+    Returns (surf, best) with the same layouts as the HIP ABI (int32 [ctu][mvy][mvx/4][85][4] and uint64
     [ctu][85]; full-frame sized arrays, only CTUs [ctu_begin, ctu_end) are filled)."""
     L = lib(avx2)
     fn = getattr(L, f"x265oracle_me_fullsearch_d{depth}")
     nctu = (width // 64) * (height // 64)
     nc = 2 * rng + 1
-    surf = np.zeros(nctu * nc * nc * 85, dtype=np.int32) if want_surf else None
+    ng = (nc + 3) // 4
+    surf = np.zeros(nctu * nc * ng * 340, dtype=np.int32) if want_surf else None
     best = np.full(nctu * 85, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64) if want_best else None
     mask = sum(1 << l for l in levels)
     es = fenc.itemsize

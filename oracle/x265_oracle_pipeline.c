@@ -44,8 +44,9 @@ static const int kLevelPU[4] = { X265HIP_LUMA_8x8, X265HIP_LUMA_16x16, X265HIP_L
 static const int kLevelBase[4] = { 0, 64, 80, 84 };   /* position of each PU level inside the 85-entry CTU record */
 #define PUS_PER_CTU 85
 
-/* surf : int32 [ctu][mvy][mvx][85]   best : uint64 [ctu][85] = cost << 32 | (mvyi * NC + mvxi)
- * (record = 64 8x8 PUs, 16 16x16, 4 32x32, 1 64x64, each group in z-order; same layout as the HIP ABI).
+/* surf : int32 [ctu][mvy][mvx/4][85][4]   best : uint64 [ctu][85] = cost << 32 | (mvyi * NC + mvxi)
+ * (85 = 64 8x8 PUs, 16 16x16, 4 32x32, 1 64x64, each level in z-order; mv columns are stored in groups of 4,
+ * the last group padded; same layout as the HIP ABI).
  * Either output may be NULL; levelMask selects PU levels (bit l).  Processes CTUs [ctuBegin, ctuEnd). */
 int EXPORT(x265oracle_me_fullsearch)(const pixel* fenc, intptr_t fencStride, const pixel* fref, intptr_t frefStride,
                                      int width, int height, int range, int ctuBegin, int ctuEnd,
@@ -57,6 +58,7 @@ int EXPORT(x265oracle_me_fullsearch)(const pixel* fenc, intptr_t fencStride, con
     if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
     const int ctusW = width / 64;
     const int NC = 2 * range + 1;
+    const int NG = (NC + 3) >> 2;
     (void)height;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -102,7 +104,7 @@ int EXPORT(x265oracle_me_fullsearch)(const pixel* fenc, intptr_t fencStride, con
                         {
                             const int xi = mx + range, yi = my + range;
                             if (surf)
-                                surf[(((size_t)ctu * NC + yi) * NC + xi) * PUS_PER_CTU + kLevelBase[l] + z] = costs[k];
+                                surf[((((size_t)ctu * NC + yi) * NG + (xi >> 2)) * PUS_PER_CTU + kLevelBase[l] + z) * 4 + (xi & 3)] = costs[k];
                             if (best)
                             {
                                 const uint32_t c = (uint32_t)costs[k] + costX[xi] + costY[yi];

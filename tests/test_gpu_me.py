@@ -20,6 +20,12 @@ def _oracle():
     return oracle_api
 
 
+def _valid(surf, ms):
+    """[ctu*mvy, mvx, 85] view of a surface buffer with the pad column of the last group dropped."""
+    v = surf.reshape(ms.nctu * ms.nc, ms.ng, 85, 4).transpose(0, 1, 3, 2).reshape(ms.nctu * ms.nc, ms.ng * 4, 85)
+    return v[:, :ms.nc, :]
+
+
 def _run(width, height, rng, depth, seed, extreme=None):
     import torch
     dev = torch.device("cuda:0")
@@ -35,8 +41,9 @@ def _run(width, height, rng, depth, seed, extreme=None):
     nctu = ms.nctu
     surf, best = O.me_fullsearch(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org,
                                  cur.w64, cur.h64, rng, 0, nctu, ms.cost_host, ms.cost_host)
-    g = ms.surf.cpu().numpy()
-    assert np.array_equal(g, surf), f"SAD surface differs ({np.count_nonzero(g != surf)} of {g.size})"
+    g = _valid(ms.surf.cpu().numpy(), ms)
+    e = _valid(surf, ms)
+    assert np.array_equal(g, e), f"SAD surface differs ({np.count_nonzero(g != e)} of {g.size})"
     gb = ms.best.cpu().numpy().view(np.uint64)
     assert np.array_equal(gb, best), f"best differs ({np.count_nonzero(gb != best)} of {gb.size})"
 
@@ -79,6 +86,6 @@ def test_me_hierarchy_property_full_size():
     ctu = 257
     surf, best = O.me_fullsearch(8, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org,
                                  cur.w64, cur.h64, 16, ctu, ctu + 1, ms.cost_host, ms.cost_host)
-    per = ms.nc * ms.nc * 85
-    assert np.array_equal(ms.surf[ctu * per:(ctu + 1) * per].cpu().numpy(), surf[ctu * per:(ctu + 1) * per])
+    rows = slice(ctu * ms.nc, (ctu + 1) * ms.nc)
+    assert np.array_equal(_valid(ms.surf.cpu().numpy(), ms)[rows], _valid(surf, ms)[rows])
     assert np.array_equal(ms.best[ctu * 85:(ctu + 1) * 85].cpu().numpy().view(np.uint64), best[ctu * 85:(ctu + 1) * 85])

@@ -40,7 +40,8 @@ class DevicePicture:
 class MotionSearch:
     """Owns the output buffers of the ME stage for one picture size.
 
-    surf : int32 [ctu][mvy][mvx][85]  (85 = 64 8x8 + 16 16x16 + 4 32x32 + 1 64x64 PUs, z-order)
+    surf : int32 [ctu][mvy][mvx/4][85][4]  (85 = 64 8x8 + 16 16x16 + 4 32x32 + 1 64x64 PUs, z-order;
+           mv columns in groups of 4, last group padded - the pad column holds unspecified values)
     best : int64 [ctu][85]            cost << 32 | raster mv index
     """
 
@@ -49,7 +50,8 @@ class MotionSearch:
         self.w64, self.h64, self.range, self.depth = w64, h64, rng, depth
         self.nctu = (w64 // 64) * (h64 // 64)
         self.nc = 2 * rng + 1
-        self.surf = torch.empty(self.nctu * self.nc * self.nc * PUS_PER_CTU, dtype=torch.int32, device=device) if want_surf else None
+        self.ng = (self.nc + 3) // 4
+        self.surf = torch.zeros(self.nctu * self.nc * self.ng * PUS_PER_CTU * 4, dtype=torch.int32, device=device) if want_surf else None
         self.best = torch.empty(self.nctu * PUS_PER_CTU, dtype=torch.int64, device=device) if want_best else None
         cost = F.mv_cost_table(rng, lam)
         self.cost_host = cost
@@ -87,7 +89,10 @@ class MotionSearch:
     def level_view(self, level):
         """(surface view [nmv, npu], best view [nctu, npu]) of one PU level."""
         b, n = LEVEL_BASE[level], LEVEL_PUS[level]
-        sv = self.surf.view(-1, PUS_PER_CTU)[:, b:b + n] if self.surf is not None else None
+        sv = None
+        if self.surf is not None:      # [ctu*mvy, group, pu, col] -> [ctu*mvy, mvx, pu] with the pad column dropped
+            g = self.surf.view(self.nctu * self.nc, self.ng, PUS_PER_CTU, 4)[:, :, b:b + n, :]
+            sv = g.permute(0, 1, 3, 2).reshape(self.nctu * self.nc, self.ng * 4, n)[:, :self.nc, :].reshape(-1, n)
         bv = self.best.view(-1, PUS_PER_CTU)[:, b:b + n] if self.best is not None else None
         return sv, bv
 
@@ -98,7 +103,7 @@ class MotionSearch:
         if self.best is not None:
             out["best"] = int(self.best.sum().item())
         if self.surf is not None:
-            out["surf"] = int(self.surf.sum(dtype=torch.int64).item())
+            out["surf"] = int(sum(self.level_view(l)[0].sum(dtype=torch.int64).item() for l in range(4)))
         return out
 
 
