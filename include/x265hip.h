@@ -103,6 +103,28 @@ typedef struct x265hip_me_params
 int x265hip_me_fullsearch(const x265hip_me_params* p, void* stream);
 int x265hip_me_best_reset(uint64_t* best, size_t count, void* stream);
 
+/* Sub-pel refinement of every PU's integer motion vector (the caller loop of SURVEY section 8(f) item 1,
+ * reference MotionEstimate::motionEstimate, motion.cpp:1448-1561 + subpelCompare :1571-1664, luma):
+ * square1 half-pel then quarter-pel iterations per the SubpelWorkload row `subme` (motion.cpp:48-58),
+ * candidates measured with luma_hpp / luma_vpp / luma_hvpp + sad / satd, strict '<' updates.
+ *   best_in : uint64 [ctu][85] from x265hip_me_fullsearch (cost << 32 | raster mv index)
+ *   cost_q  : uint16 cost of a quarter-pel mv component, indexed by q + qoff (q in [-4*range-8, 4*range+8])
+ *   out     : per PU { int32 cost; int16 qmvx; int16 qmvy }, [ctu][85]
+ * fref needs >= range + 12 valid pixels of margin (8-tap apron around the +-1.5 pixel drift). */
+typedef struct x265hip_subpel_params
+{
+    int depth;
+    int width, height;
+    int range;
+    int subme;                      /* 0..7, row of the reference's workload[] table */
+    const void* fenc;  intptr_t fenc_stride;
+    const void* fref;  intptr_t fref_stride;
+    const uint64_t* best_in;
+    const uint16_t* cost_q;  int qoff;
+    void* out;
+} x265hip_subpel_params;
+int x265hip_subpel_refine(const x265hip_subpel_params* p, void* stream);
+
 /* ------------------------------------------------------------------ generic job-list entry points
  * Every remaining family evaluates `njobs` independent blocks of one size per launch.  An operand
  * is a device plane (base pointer + element stride); a job carries up to four element offsets into

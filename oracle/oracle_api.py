@@ -57,3 +57,21 @@ def me_fullsearch(depth, fenc, fenc_stride, fenc_org, fref, fref_stride, fref_or
        surf.ctypes.data if surf is not None else None, best.ctypes.data if best is not None else None,
        cx.ctypes.data, cy.ctypes.data, mask, nthreads)
     return surf, best
+
+
+def subpel_refine(depth, fenc, fenc_stride, fenc_org, fref, fref_stride, fref_org, width, height, rng,
+                  ctu_begin, ctu_end, best_in, cost_q, qoff, subme, nthreads=0, avx2=False):
+    """CPU restatement of the sub-pel refinement stage; returns int32 [nctu*85, 2] = {cost, qx | qy << 16}."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_subpel_refine_d{depth}")
+    nctu = (width // 64) * (height // 64)
+    out = np.zeros((nctu * 85, 2), dtype=np.int32)
+    es = fenc.itemsize
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_ssize_t,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    b = np.ascontiguousarray(best_in, dtype=np.uint64)
+    cq = np.ascontiguousarray(cost_q, dtype=np.uint16)
+    fn(fenc.ctypes.data + fenc_org * es, fenc_stride, fref.ctypes.data + fref_org * es, fref_stride,
+       width, height, rng, ctu_begin, ctu_end, b.ctypes.data, cq.ctypes.data, qoff, subme, out.ctypes.data, nthreads)
+    return out

@@ -120,3 +120,118 @@ int EXPORT(x265oracle_me_fullsearch)(const pixel* fenc, intptr_t fencStride, con
     }
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * Stage: sub-pel refinement of every PU's integer motion vector.
+ * Follows MotionEstimate::motionEstimate after the integer search (source/encoder/motion.cpp:1448-1561,
+ * non-lowres branch) and MotionEstimate::subpelCompare (:1571-1664, luma part: bChromaSATD is off for
+ * subpelRefine <= 2): square1 half-pel then quarter-pel iterations with the SubpelWorkload table (:48-58),
+ * COPY2_IF_LT strict-less updates, candidates measured by luma_hpp / luma_vpp / luma_hvpp into a
+ * blockwidth-stride buffer + sad or satd against the 64-stride source copy.
+ *
+ *   bestIn  : uint64 [ctu][85] from the integer stage (cost << 32 | mvyi * NC + mvxi)
+ *   costQ   : uint16 quarter-pel mv component cost, indexed by q + qoff  (q = qpel displacement)
+ *   out     : per PU { int32 cost; int16 qmvx; int16 qmvy }  (8 bytes, [ctu][85])
+ */
+typedef struct { int hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd; } SubpelWorkload;
+static const SubpelWorkload kWorkload[8] = {
+    { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+    { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+static const int kSquare1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+
+typedef struct { int32_t cost; int16_t qx, qy; } SubpelOut;
+
+static int subpel_compare(const struct x265hip_PU* pu, const pixel* fencPU, const pixel* refPU, intptr_t refStride,
+                          int qx, int qy, int n, int useSatd, pixel* subpelbuf)
+{
+    const pixel* fref = refPU + (qx >> 2) + (intptr_t)(qy >> 2) * refStride;
+    const int xFrac = qx & 3, yFrac = qy & 3;
+    x265hip_pixelcmp_t cmp = useSatd ? pu->satd : pu->sad;
+    if (!(xFrac | yFrac))
+        return cmp(fencPU, 64, fref, refStride);
+    if (!yFrac) pu->luma_hpp(fref, refStride, subpelbuf, n, xFrac);
+    else if (!xFrac) pu->luma_vpp(fref, refStride, subpelbuf, n, yFrac);
+    else pu->luma_hvpp(fref, refStride, subpelbuf, n, xFrac, yFrac);
+    return cmp(fencPU, 64, subpelbuf, n);
+}
+
+int EXPORT(x265oracle_subpel_refine)(const pixel* fenc, intptr_t fencStride, const pixel* fref, intptr_t frefStride,
+                                     int width, int height, int range, int ctuBegin, int ctuEnd,
+                                     const uint64_t* bestIn, const uint16_t* costQ, int qoff, int subme,
+                                     void* outv, int nthreads)
+{
+    static x265hip_EncoderPrimitives prim;
+    static int ready = 0;
+    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    SubpelOut* out = (SubpelOut*)outv;
+    const int ctusW = width / 64;
+    const int NC = 2 * range + 1;
+    const SubpelWorkload wl = kWorkload[subme];
+    (void)height;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int ctu = ctuBegin; ctu < ctuEnd; ctu++)
+    {
+        const int cx = (ctu % ctusW) * 64, cy = (ctu / ctusW) * 64;
+        pixel fencPU[64 * 64] __attribute__((aligned(64)));
+        pixel subpelbuf[64 * 64] __attribute__((aligned(64)));
+        for (int l = 0; l < 4; l++)
+        {
+            const int n = kLevelSize[l], npu = (64 / n) * (64 / n);
+            const struct x265hip_PU* pu = &prim.pu[kLevelPU[l]];
+            for (int z = 0; z < npu; z++)
+            {
+                int bx, by;
+                zorder_xy(z, &bx, &by);
+                const int px = cx + bx * n, py = cy + by * n;
+                pu->copy_pp(fencPU, 64, fenc + (intptr_t)py * fencStride + px, fencStride);
+                const pixel* refPU = fref + (intptr_t)py * frefStride + px;
+                const uint64_t key = bestIn[(size_t)ctu * PUS_PER_CTU + kLevelBase[l] + z];
+                const int idx = (int)(key & 0xffffffffu);
+                int bcost = (int)(key >> 32);
+                int bx4 = ((idx % NC) - range) * 4, by4 = ((idx / NC) - range) * 4;      /* bmv.toQPel() */
+#define MVCOST(qx, qy) ((int)costQ[(qx) + qoff] + (int)costQ[(qy) + qoff])
+                if (!bcost)
+                    bcost = MVCOST(bx4, by4);
+                else
+                {
+                    int hpelSatd = wl.hpel_satd;
+                    if (hpelSatd)
+                        bcost = subpel_compare(pu, fencPU, refPU, frefStride, bx4, by4, n, 1, subpelbuf) + MVCOST(bx4, by4);
+                    for (int iter = 0; iter < wl.hpel_iters; iter++)
+                    {
+                        int bdir = 0;
+                        for (int i = 1; i <= wl.hpel_dirs; i++)
+                        {
+                            const int qx = bx4 + kSquare1[i][0] * 2, qy = by4 + kSquare1[i][1] * 2;
+                            const int cost = subpel_compare(pu, fencPU, refPU, frefStride, qx, qy, n, hpelSatd, subpelbuf) + MVCOST(qx, qy);
+                            if (cost < bcost) { bcost = cost; bdir = i; }
+                        }
+                        if (bdir) { bx4 += kSquare1[bdir][0] * 2; by4 += kSquare1[bdir][1] * 2; }
+                        else break;
+                    }
+                    if (!hpelSatd)
+                        bcost = subpel_compare(pu, fencPU, refPU, frefStride, bx4, by4, n, 1, subpelbuf) + MVCOST(bx4, by4);
+                    for (int iter = 0; iter < wl.qpel_iters; iter++)
+                    {
+                        int bdir = 0;
+                        for (int i = 1; i <= wl.qpel_dirs; i++)
+                        {
+                            const int qx = bx4 + kSquare1[i][0], qy = by4 + kSquare1[i][1];
+                            const int cost = subpel_compare(pu, fencPU, refPU, frefStride, qx, qy, n, 1, subpelbuf) + MVCOST(qx, qy);
+                            if (cost < bcost) { bcost = cost; bdir = i; }
+                        }
+                        if (bdir) { bx4 += kSquare1[bdir][0]; by4 += kSquare1[bdir][1]; }
+                        else break;
+                    }
+                }
+#undef MVCOST
+                SubpelOut* o = &out[(size_t)ctu * PUS_PER_CTU + kLevelBase[l] + z];
+                o->cost = bcost; o->qx = (int16_t)bx4; o->qy = (int16_t)by4;
+            }
+        }
+    }
+    return 0;
+}

@@ -81,6 +81,18 @@ def write_y4m(path: str, frames, width: int, height: int, depth: int = 8, fps: i
                 f.write(np.ascontiguousarray(pl).astype("<u2" if depth > 8 else np.uint8).tobytes())
 
 
+def qpel_cost_table(rng_r: int, lam: float = 4.0):
+    """uint16 bit-cost of a QUARTER-pel mv component q in [-4R-8, 4R+8] (index q + qoff), same formula as
+    mv_cost_table; the integer-search table is its every-4th entry.  Returns (table, qoff)."""
+    qoff = 4 * rng_r + 8
+    q = np.arange(-qoff, qoff + 1)
+    i = np.abs(q).astype(np.float32)
+    bits = (np.log(i + np.float32(1.0)) * np.float32(2.0) / np.log(np.float32(2.0)) + np.float32(1.718)).astype(np.float32)
+    bits[i == 0] = np.float32(0.718)
+    cost = np.minimum(bits * np.float32(lam) + np.float32(0.5), np.float32(32767.0))
+    return cost.astype(np.uint16), qoff
+
+
 def mv_cost_table(rng_r: int, lam: float = 4.0):
     """uint16 bit-cost of an integer mv component in [-R, R], the reference's formula
     (source/encoder/bitcost.cpp:51-55,103-118: s_bitsizes[i] = log2(i+1)*2 + 1.718 in float,

@@ -32,6 +32,16 @@ class MEParams(ctypes.Structure):
     ]
 
 
+class SubpelParams(ctypes.Structure):
+    _fields_ = [
+        ("depth", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int), ("range", ctypes.c_int),
+        ("subme", ctypes.c_int),
+        ("fenc", ctypes.c_void_p), ("fenc_stride", ctypes.c_ssize_t),
+        ("fref", ctypes.c_void_p), ("fref_stride", ctypes.c_ssize_t),
+        ("best_in", ctypes.c_void_p), ("cost_q", ctypes.c_void_p), ("qoff", ctypes.c_int), ("out", ctypes.c_void_p),
+    ]
+
+
 def lib() -> ctypes.CDLL:
     """Load libx265hip.so (built in-tree by __graft_entry__.build()); fail loudly if absent."""
     global _lib
@@ -89,6 +99,20 @@ def me_fullsearch(depth, width, height, rng, fenc, fenc_stride, fref, fref_strid
     p.cost_x, p.cost_y = _p(cost_x), _p(cost_y)
     s = current_stream() if stream is None else stream
     check(lib().x265hip_me_fullsearch(ctypes.byref(p), s), "x265hip_me_fullsearch")
+
+
+def subpel_refine(depth, width, height, rng, subme, fenc, fenc_stride, fref, fref_stride, best_in, cost_q, qoff, out,
+                  fenc_off=0, fref_off=0, stream=None):
+    es = 1 if depth == 8 else 2
+    p = SubpelParams()
+    p.depth, p.width, p.height, p.range, p.subme = depth, width, height, rng, subme
+    p.fenc, p.fenc_stride = fenc.data_ptr() + fenc_off * es, fenc_stride
+    p.fref, p.fref_stride = fref.data_ptr() + fref_off * es, fref_stride
+    p.best_in, p.cost_q, p.qoff, p.out = best_in.data_ptr(), cost_q.data_ptr(), qoff, out.data_ptr()
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_subpel_refine
+    f.argtypes = [ctypes.POINTER(SubpelParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_subpel_refine")
 
 
 def me_best_reset(best, stream=None):

@@ -107,6 +107,28 @@ class MotionSearch:
         return out
 
 
+class SubpelRefine:
+    """Stage 2: sub-pel refinement of the ME stage's best integer mv for all 85 PUs of every CTU
+    (x265hip_subpel_refine; reference caller motion.cpp:1448-1664).  Output int32 [ctu*85][2] =
+    {cost, qmvx | qmvy << 16}."""
+
+    def __init__(self, ms: MotionSearch, subme: int, device, lam=4.0):
+        import torch
+        self.ms, self.subme = ms, subme
+        cq, self.qoff = F.qpel_cost_table(ms.range, lam)
+        self.cost_q_host = cq
+        self.cost_q = torch.from_numpy(cq.view(np.int16)).to(device)
+        self.out = torch.zeros(ms.nctu * PUS_PER_CTU * 2, dtype=torch.int32, device=device)
+
+    def run(self, cur: DevicePicture, ref: DevicePicture):
+        ms = self.ms
+        hipabi.subpel_refine(ms.depth, ms.w64, ms.h64, ms.range, self.subme, cur.t, cur.stride, ref.t, ref.stride,
+                             ms.best, self.cost_q, self.qoff, self.out, fenc_off=cur.org, fref_off=ref.org)
+
+    def checksum(self):
+        return {"subpel": int(self.out.to(dtype=__import__("torch").int64).sum().item())}
+
+
 class FrameParallel:
     """Frame-parallel sharding across GPUs: rank r encodes frame step*world + r.
     All frames of a step search in the same reference picture - the newest picture of the previous step,
