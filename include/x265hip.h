@@ -125,6 +125,30 @@ typedef struct x265hip_subpel_params
 } x265hip_subpel_params;
 int x265hip_subpel_refine(const x265hip_subpel_params* p, void* stream);
 
+/* Fused inter prediction + residual coding round trip of every NxN block (N = 8 << level, level 0..2), the
+ * caller sequence of SURVEY section 8(f) item 2: Predict::predInterLumaPixel (predict.cpp:245-265),
+ * calcresidual, Quant::transformNxN without RDOQ / sign hiding (quant.cpp:397-480, flat scaling lists),
+ * Quant::invtransformNxN incl. the DC-only shortcut (quant.cpp:543-605), add_ps / copy_pp, sse_pp.
+ *   mv      : int32 [ctu*85][2] from x265hip_subpel_refine ({cost, qmvx | qmvy << 16}); block z of the level uses
+ *             entry base(level) + z (base = 0, 64, 80)
+ *   qp      : scaled luma QP (per = qp / 6, rem = qp % 6); intra_slice selects the 171/85 rounding offset
+ *   recon   : reconstructed luma plane, same geometry as fenc (margins are not written)
+ *   levels  : int16 [ctu][blocks][N*N] quantised coefficients   num_sig : uint32 [ctu][blocks]
+ *   dist    : uint64 [ctu][blocks] sse_pp(fenc, recon) */
+typedef struct x265hip_recon_params
+{
+    int depth;
+    int width, height;
+    int level;
+    int qp, intra_slice;
+    const void* fenc;  intptr_t fenc_stride;
+    const void* fref;  intptr_t fref_stride;
+    void* recon;       intptr_t recon_stride;
+    const void* mv;
+    int16_t* levels; uint32_t* num_sig; uint64_t* dist;
+} x265hip_recon_params;
+int x265hip_inter_recon(const x265hip_recon_params* p, void* stream);
+
 /* ------------------------------------------------------------------ generic job-list entry points
  * Every remaining family evaluates `njobs` independent blocks of one size per launch.  An operand
  * is a device plane (base pointer + element stride); a job carries up to four element offsets into

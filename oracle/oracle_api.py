@@ -75,3 +75,28 @@ def subpel_refine(depth, fenc, fenc_stride, fenc_org, fref, fref_stride, fref_or
     fn(fenc.ctypes.data + fenc_org * es, fenc_stride, fref.ctypes.data + fref_org * es, fref_stride,
        width, height, rng, ctu_begin, ctu_end, b.ctypes.data, cq.ctypes.data, qoff, subme, out.ctypes.data, nthreads)
     return out
+
+
+def inter_recon(depth, fenc, fenc_stride, fenc_org, fref, fref_stride, fref_org, width, height, level, mv, qp,
+                intra_slice=0, ctu_begin=0, ctu_end=None, nthreads=0, avx2=False):
+    """CPU restatement of the fused prediction + residual round trip.  Returns (recon plane, levels, num_sig, dist)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_inter_recon_d{depth}")
+    nctu = (width // 64) * (height // 64)
+    if ctu_end is None:
+        ctu_end = nctu
+    n = 8 << level
+    nblk = (64 // n) ** 2
+    recon = np.zeros_like(fenc)
+    levels = np.zeros(nctu * nblk * n * n, dtype=np.int16)
+    num_sig = np.zeros(nctu * nblk, dtype=np.uint32)
+    dist = np.zeros(nctu * nblk, dtype=np.uint64)
+    es = fenc.itemsize
+    m = np.ascontiguousarray(mv, dtype=np.int32)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_ssize_t,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    fn(fenc.ctypes.data + fenc_org * es, fenc_stride, fref.ctypes.data + fref_org * es, fref_stride,
+       recon.ctypes.data + fenc_org * es, fenc_stride, width, height, level, m.ctypes.data, qp, intra_slice,
+       levels.ctypes.data, num_sig.ctypes.data, dist.ctypes.data, ctu_begin, ctu_end, nthreads)
+    return recon, levels, num_sig, dist

@@ -1,0 +1,123 @@
+/* oracle/x265_oracle_pipeline2.c
+ *
+ * TEST INFRASTRUCTURE - NOT PRODUCT CODE (same rules as x265_oracle.c).
+ *
+ * Stage: inter prediction + residual coding round trip of one square PU/TU per block.
+ * Restates, on top of the oracle's primitive table, the call sequence of
+ *   Predict::predInterLumaPixel        (source/common/predict.cpp:245-265: copy_pp / luma_hpp / luma_vpp / luma_hvpp),
+ *   calcresidual                        (source/encoder/search.cpp:357 / pixel.cpp:471-483),
+ *   Quant::transformNxN, non-RDOQ path  (source/common/quant.cpp:397-480: dct, quant with flat scaling
+ *                                        s_quantScales[rem] (scalinglist.cpp:129,386), qbits = 14 + per + transformShift,
+ *                                        add = (I ? 171 : 85) << (qbits - 9); sign hiding off),
+ *   Quant::invtransformNxN              (quant.cpp:543-605: dequant_normal with s_invQuantScales[rem] << per,
+ *                                        the DC-only blockfill shortcut :586-598, else idct),
+ *   add_ps / copy when no coefficient survives, and sse_pp (search.cpp:367-375).
+ */
+#ifndef X265HIP_DEPTH
+#error "compile with -DX265HIP_DEPTH=8|10|12"
+#endif
+#include "x265hip_table.h"
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef x265hip_pixel pixel;
+#define CAT_(a, b)   a##b
+#define CAT(a, b)    CAT_(a, b)
+#define EXPORT(name) CAT(CAT(name, _d), X265HIP_DEPTH)
+
+void EXPORT(x265oracle_setup_primitives)(x265hip_EncoderPrimitives* p);
+
+static const int kQuantScales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };   /* scalinglist.cpp:129 */
+static const int kInvQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                  /* scalinglist.cpp:130 */
+static const int kLvlBase[4] = { 0, 64, 80, 84 };
+
+static void zxy(int z, int* x, int* y)
+{
+    *x = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4);
+    *y = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+}
+
+/* level: 0..2 -> 8x8, 16x16, 32x32 blocks.  mv: int32 [ctu*85][2] = {cost, qx | qy << 16} from the sub-pel stage.
+ * Outputs: recon plane (same geometry as fenc), levels int16 [ctu][npu][n*n], numSig uint32 [ctu][npu],
+ * dist uint64 [ctu][npu]. */
+int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const pixel* fref, intptr_t frefStride,
+                                   pixel* recon, intptr_t reconStride, int width, int height, int level,
+                                   const int32_t* mv, int qp, int isIntraSlice,
+                                   int16_t* levels, uint32_t* numSigOut, uint64_t* distOut,
+                                   int ctuBegin, int ctuEnd, int nthreads)
+{
+    static x265hip_EncoderPrimitives prim;
+    static int ready = 0;
+    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    const int ctusW = width / 64;
+    const int n = 8 << level, log2n = 3 + level, npu = (64 / n) * (64 / n);
+    const int puIdx = level == 0 ? X265HIP_LUMA_8x8 : (level == 1 ? X265HIP_LUMA_16x16 : X265HIP_LUMA_32x32);
+    const struct x265hip_PU* pu = &prim.pu[puIdx];
+    const struct x265hip_CU* cu = &prim.cu[log2n - 2];
+    const int per = qp / 6, rem = qp % 6;
+    const int transformShift = 15 - X265HIP_DEPTH - log2n;
+    const int qbits = 14 + per + transformShift;
+    const int add = (isIntraSlice ? 171 : 85) << (qbits - 9);
+    const int dqShift = 20 - 14 - transformShift;
+    const int dqScale = kInvQuantScales[rem] << per;
+    (void)height;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int ctu = ctuBegin; ctu < ctuEnd; ctu++)
+    {
+        const int cx = (ctu % ctusW) * 64, cy = (ctu / ctusW) * 64;
+        pixel pred[64 * 64] __attribute__((aligned(64)));
+        int16_t resi[64 * 64] __attribute__((aligned(64)));
+        int16_t coef[32 * 32] __attribute__((aligned(64)));
+        int32_t quantCoeff[32 * 32] __attribute__((aligned(64)));
+        int32_t deltaU[32 * 32];
+        for (int i = 0; i < n * n; i++) quantCoeff[i] = kQuantScales[rem];
+        for (int z = 0; z < npu; z++)
+        {
+            int bx, by;
+            zxy(z, &bx, &by);
+            const int px = cx + bx * n, py = cy + by * n;
+            const int32_t packed = mv[((size_t)ctu * 85 + kLvlBase[level] + z) * 2 + 1];
+            const int qx = (int16_t)(packed & 0xffff), qy = (int16_t)(packed >> 16);
+            const pixel* src = fref + (intptr_t)(py + (qy >> 2)) * frefStride + px + (qx >> 2);
+            const pixel* fe = fenc + (intptr_t)py * fencStride + px;
+            pixel* rec = recon + (intptr_t)py * reconStride + px;
+            const int xf = qx & 3, yf = qy & 3;
+            /* predInterLumaPixel */
+            if (!(xf | yf)) pu->copy_pp(pred, 64, src, frefStride);
+            else if (!yf) pu->luma_hpp(src, frefStride, pred, 64, xf);
+            else if (!xf) pu->luma_vpp(src, frefStride, pred, 64, yf);
+            else pu->luma_hvpp(src, frefStride, pred, 64, xf, yf);
+            /* residual, transform, quantisation */
+            cu->sub_ps(resi, 64, fe, pred, fencStride, 64);
+            cu->dct(resi, coef, 64);
+            int16_t* q = levels + ((size_t)ctu * npu + z) * n * n;
+            const uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
+            numSigOut[(size_t)ctu * npu + z] = numSig;
+            if (numSig)
+            {
+                prim.dequant_normal(q, coef, n * n, dqScale, dqShift);
+                if (numSig == 1 && q[0] != 0)
+                {
+                    const int shift_2nd = 12 - (X265HIP_DEPTH - 8) - 3;
+                    const int dc = ((((coef[0] * (64 >> 6) + 1) >> 1) * (64 >> 3)) + (1 << (shift_2nd - 1))) >> shift_2nd;
+                    cu->blockfill_s[0](resi, 64, (int16_t)dc);
+                }
+                else
+                    cu->idct(coef, resi, 64);
+                cu->add_ps[0](rec, reconStride, pred, resi, 64, 64);
+            }
+            else
+                cu->copy_pp(rec, reconStride, pred, 64);
+            distOut[(size_t)ctu * npu + z] = (uint64_t)cu->sse_pp(fe, fencStride, rec, reconStride);
+        }
+    }
+    return 0;
+}

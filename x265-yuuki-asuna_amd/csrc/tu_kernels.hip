@@ -1,0 +1,284 @@
+// tu_kernels.hip - fused inter prediction + residual coding round trip per square block, on gfx950.
+//
+// One launch performs, for every NxN block of every CTU (N = 8, 16, 32), the primitive sequence the
+// reference issues from Predict::predInterLumaPixel (source/common/predict.cpp:245-265), Search's residual
+// path (source/encoder/search.cpp:357-375), Quant::transformNxN non-RDOQ (source/common/quant.cpp:397-480)
+// and Quant::invtransformNxN (:543-605):
+//     luma_hvpp|hpp|vpp|copy_pp -> calcresidual -> dct -> quant (flat scaling) -> dequant_normal
+//     -> DC-only blockfill shortcut | idct -> add_ps | copy_pp -> sse_pp
+// with every intermediate held in LDS: per block HBM sees the source block, the (N+7)^2 reference patch,
+// the quantised levels and the reconstructed block - nothing else (the primitive-by-primitive form moves
+// ~9x that).  This is SURVEY section 8(f) item 2.  Arithmetic per primitive: ipfilter.cpp:79-369,
+// dct.cpp:83-240,242-416,612-634,664-686, pixel.cpp:167-186,471-483,828-840.
+#include "common.h"
+
+namespace x265hip {
+
+struct DctMatrix
+{
+    int8_t m[32][32];
+    constexpr DctMatrix() : m{}
+    {
+        constexpr int basis[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67,
+                                    64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+        for (int k = 0; k < 32; k++)
+            for (int n = 0; n < 32; n++)
+            {
+                const int q = (k * (2 * n + 1)) & 127;
+                int v = 0;
+                if (q <= 32) v = basis[q];
+                else if (q <= 64) v = -basis[64 - q];
+                else if (q <= 96) v = -basis[q - 64];
+                else v = basis[128 - q];
+                m[k][n] = (int8_t)v;
+            }
+    }
+};
+static __constant__ DctMatrix kTu = DctMatrix();
+static __constant__ int16_t kTuTaps[4][8] = {
+    { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+    { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+static __constant__ int kTuQuantScales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };   // scalinglist.cpp:129
+static __constant__ int kTuInvQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                  // scalinglist.cpp:130
+
+struct TuArgs
+{
+    const uint8_t* fenc; long fencStrideB;
+    const uint8_t* fref; long frefStrideB;
+    uint8_t* recon; long reconStrideB;
+    int ctusW, depth, level;
+    const int2* mv;                 // [ctu*85] {cost, qx | qy << 16}
+    int qp, intraSlice;
+    int16_t* levels; uint32_t* numSig; unsigned long long* dist;
+};
+
+__device__ __forceinline__ int tu_clip16(int v, int maxVal) { const int16_t s = (int16_t)v; return s < 0 ? 0 : (s > maxVal ? maxVal : s); }
+__device__ __forceinline__ int tu_sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+template <typename Px, int N>
+__global__ void __launch_bounds__(256) inter_recon_kernel(TuArgs a)
+{
+    constexpr int NN = N * N, LOG2N = N == 8 ? 3 : (N == 16 ? 4 : 5), PW = N + 7, PP = N + 8;
+    constexpr int BPP = sizeof(Px);
+    __shared__ int16_t patch[PW * PP];
+    __shared__ int16_t immed[PW * N];
+    __shared__ int16_t pred[NN], fe[NN], A[NN], B[NN];
+    __shared__ unsigned long long red[4];
+    __shared__ int sNumSig;
+
+    const int npu = (64 / N) * (64 / N);
+    const int lbase = N == 8 ? 0 : (N == 16 ? 64 : 80);
+    const int ctu = blockIdx.x / npu, z = blockIdx.x - ctu * npu;
+    const int bxz = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), byz = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+    const int px = (ctu % a.ctusW) * 64 + bxz * N, py = (ctu / a.ctusW) * 64 + byz * N;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int maxVal = (1 << a.depth) - 1, headRoom = 14 - a.depth;
+
+    const int packed = a.mv[(size_t)ctu * 85 + lbase + z].y;
+    const int qx = (int16_t)(packed & 0xffff), qy = (int16_t)(packed >> 16);
+    const int xf = qx & 3, yf = qy & 3;
+
+    // ---- stage source block + reference patch (3 left/top, 4 right/bottom apron) --------------------
+    {
+        const Px* f = reinterpret_cast<const Px*>(a.fenc + (long)py * a.fencStrideB) + px;
+        const long fst = a.fencStrideB / BPP;
+        for (int i = tid; i < NN; i += nth) { const int y = i >> LOG2N, x = i & (N - 1); fe[i] = (int16_t)f[y * fst + x]; }
+        const Px* r = reinterpret_cast<const Px*>(a.fref + (long)(py + (qy >> 2) - 3) * a.frefStrideB) + (px + (qx >> 2) - 3);
+        const long rst = a.frefStrideB / BPP;
+        for (int i = tid; i < PW * PW; i += nth) { const int y = i / PW, x = i - y * PW; patch[y * PP + x] = (int16_t)r[y * rst + x]; }
+        if (tid == 0) sNumSig = 0;
+    }
+    __syncthreads();
+
+    // ---- predInterLumaPixel ----------------------------------------------------------------------------
+    if (xf && yf)
+    {
+        const int shiftPS = 6 - headRoom, offPS = -(8192 << shiftPS);
+        for (int i = tid; i < PW * N; i += nth)
+        {
+            const int y = i >> LOG2N, x = i & (N - 1);
+            int s = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) s += (int)patch[y * PP + x + t] * kTuTaps[xf][t];
+            immed[i] = (int16_t)((s + offPS) >> shiftPS);
+        }
+        __syncthreads();
+        const int shiftSP = 6 + headRoom, offSP = (1 << (shiftSP - 1)) + (8192 << 6);
+        for (int i = tid; i < NN; i += nth)
+        {
+            const int y = i >> LOG2N, x = i & (N - 1);
+            int s = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) s += (int)immed[(y + t) * N + x] * kTuTaps[yf][t];
+            pred[i] = (int16_t)tu_clip16((s + offSP) >> shiftSP, maxVal);
+        }
+    }
+    else
+    {
+        for (int i = tid; i < NN; i += nth)
+        {
+            const int y = i >> LOG2N, x = i & (N - 1);
+            int v;
+            if (!(xf | yf)) v = patch[(y + 3) * PP + x + 3];
+            else
+            {
+                int s = 0;
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                    s += (int)(xf ? patch[(y + 3) * PP + x + t] : patch[(y + t) * PP + x + 3]) * kTuTaps[xf ? xf : yf][t];
+                v = tu_clip16((s + 32) >> 6, maxVal);
+            }
+            pred[i] = (int16_t)v;
+        }
+    }
+    __syncthreads();
+
+    // ---- residual + forward transform (two passes, int16-truncating stores) -------------------------------
+    for (int i = tid; i < NN; i += nth) A[i] = (int16_t)((int)fe[i] - (int)pred[i]);
+    __syncthreads();
+    const int sh1 = LOG2N - 1 + a.depth - 8, sh2 = LOG2N + 6;
+    for (int e = tid; e < NN; e += nth)
+    {
+        const int k = e >> LOG2N, j = e & (N - 1);
+        int acc = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) acc += kTu.m[k * (32 / N)][i] * (int)A[j * N + i];
+        B[k * N + j] = (int16_t)((acc + (1 << (sh1 - 1))) >> sh1);
+    }
+    __syncthreads();
+    // ---- second pass fused with quant (quant.cpp:462-469, dct.cpp:664-686) ----------------------------------
+    const int per = a.qp / 6, rem = a.qp - per * 6;
+    const int transformShift = 15 - a.depth - LOG2N;
+    const int qbits = 14 + per + transformShift;
+    const int qadd = (a.intraSlice ? 171 : 85) << (qbits - 9);
+    const int qscale = kTuQuantScales[rem];
+    int16_t* lv = a.levels + ((size_t)ctu * npu + z) * NN;
+    int nz = 0;
+    for (int e = tid; e < NN; e += nth)
+    {
+        const int k = e >> LOG2N, j = e & (N - 1);
+        int acc = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) acc += kTu.m[k * (32 / N)][i] * (int)B[j * N + i];
+        const int c = (int16_t)((acc + (1 << (sh2 - 1))) >> sh2);
+        const int t = abs(c) * qscale;
+        int level = (t + qadd) >> qbits;
+        nz += level != 0;
+        if (c < 0) level = -level;
+        level = tu_sat16(level);
+        A[e] = (int16_t)level;            // A is free again: quantised levels
+        lv[e] = (int16_t)level;
+    }
+    nz = group_sum<64>(nz);
+    if ((tid & 63) == 0 && nz) atomicAdd(&sNumSig, nz);
+    __syncthreads();
+    const int numSig = sNumSig;
+    if (tid == 0) a.numSig[(size_t)ctu * npu + z] = (uint32_t)numSig;
+
+    // ---- inverse path --------------------------------------------------------------------------------------
+    Px* rec = reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px;
+    const long cst = a.reconStrideB / BPP;
+    unsigned long long part = 0;
+    if (numSig)
+    {
+        const int dqShift = 20 - 14 - transformShift, dqAdd = 1 << (dqShift - 1);
+        const int dqScale = kTuInvQuantScales[rem] << per;
+        if (numSig == 1 && A[0] != 0)
+        {
+            // DC-only shortcut (quant.cpp:586-598)
+            const int deq = tu_sat16(((int)A[0] * dqScale + dqAdd) >> dqShift);
+            const int shift2 = 12 - (a.depth - 8) - 3;
+            const int dc = (int16_t)(((((deq + 1) >> 1) * 8) + (1 << (shift2 - 1))) >> shift2);
+            for (int i = tid; i < NN; i += nth)
+            {
+                const int y = i >> LOG2N, x = i & (N - 1);
+                const int v = clip3(0, maxVal, (int)pred[i] + dc);
+                rec[y * cst + x] = (Px)v;
+                const int d = (int)fe[i] - v;
+                part += (unsigned)(d * d);
+            }
+        }
+        else
+        {
+            for (int i = tid; i < NN; i += nth) B[i] = (int16_t)tu_sat16(((int)A[i] * dqScale + dqAdd) >> dqShift);
+            __syncthreads();
+            for (int e = tid; e < NN; e += nth)
+            {
+                const int j = e >> LOG2N, k = e & (N - 1);
+                int acc = 0;
+#pragma unroll
+                for (int i = 0; i < N; i++) acc += kTu.m[i * (32 / N)][k] * (int)B[i * N + j];
+                A[j * N + k] = (int16_t)tu_sat16((acc + 64) >> 7);
+            }
+            __syncthreads();
+            const int shI = 12 - (a.depth - 8);
+            for (int e = tid; e < NN; e += nth)
+            {
+                const int j = e >> LOG2N, k = e & (N - 1);
+                int acc = 0;
+#pragma unroll
+                for (int i = 0; i < N; i++) acc += kTu.m[i * (32 / N)][k] * (int)A[i * N + j];
+                const int r = tu_sat16((acc + (1 << (shI - 1))) >> shI);
+                const int v = clip3(0, maxVal, (int)pred[e] + r);
+                rec[j * cst + k] = (Px)v;
+                const int d = (int)fe[e] - v;
+                part += (unsigned)(d * d);
+            }
+        }
+    }
+    else
+    {
+        for (int i = tid; i < NN; i += nth)
+        {
+            const int y = i >> LOG2N, x = i & (N - 1);
+            const int v = pred[i];
+            rec[y * cst + x] = (Px)v;
+            const int d = (int)fe[i] - v;
+            part += (unsigned)(d * d);
+        }
+    }
+    part = group_sum<64>(part);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0)
+    {
+        unsigned long long t = 0;
+        for (int i = 0; i < (nth >> 6); i++) t += red[i];
+        a.dist[(size_t)ctu * npu + z] = t;
+    }
+}
+
+} // namespace x265hip
+
+using namespace x265hip;
+
+extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->fenc || !p->fref || !p->recon || !p->mv || !p->levels || !p->num_sig || !p->dist)
+    { set_error("inter_recon: NULL operand"); return X265HIP_EINVAL; }
+    if ((p->width & 63) || (p->height & 63) || p->width <= 0 || p->height <= 0) { set_error("inter_recon: width/height must be multiples of 64"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("inter_recon: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->level < 0 || p->level > 2) { set_error("inter_recon: level %d (0..2 = 8x8, 16x16, 32x32)", p->level); return X265HIP_EINVAL; }
+    if (p->qp < 0 || p->qp > 51 + 6 * (p->depth - 8)) { set_error("inter_recon: qp %d out of range", p->qp); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    TuArgs a;
+    a.fenc = (const uint8_t*)p->fenc; a.fencStrideB = (long)p->fenc_stride * bpp;
+    a.fref = (const uint8_t*)p->fref; a.frefStrideB = (long)p->fref_stride * bpp;
+    a.recon = (uint8_t*)p->recon; a.reconStrideB = (long)p->recon_stride * bpp;
+    a.ctusW = p->width / 64; a.depth = p->depth; a.level = p->level;
+    a.mv = (const int2*)p->mv; a.qp = p->qp; a.intraSlice = p->intra_slice;
+    a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
+    const int nctu = a.ctusW * (p->height / 64);
+    const int npu = 64 >> (2 * p->level);
+    hipStream_t s = (hipStream_t)stream;
+#define GO(PX) do { \
+        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 8>), dim3(nctu * npu), dim3(64), 0, s, a); \
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 16>), dim3(nctu * npu), dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((inter_recon_kernel<PX, 32>), dim3(nctu * npu), dim3(256), 0, s, a); } while (0)
+    if (p->depth == 8) GO(uint8_t); else GO(uint16_t);
+#undef GO
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
