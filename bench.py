@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py - frame-pipeline throughput of the MI355X block-primitive path.
+"""bench.py - closed-loop frame-pipeline throughput of the MI355X block-primitive path.
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" = one 1080p frame (BASELINE.json configs[1]: 1920x1080 8-bit, allocated as 1920x1088 whole
-CTUs like the reference) through the batched stages of x265-yuuki-asuna_amd/pipeline.py, all inputs
-resident in HBM.  With N GPUs the job is frame-parallel (one frame per GPU per step, weak scaling);
-the only data-path exchange is the one-to-many broadcast of the newest reference picture (RCCL), the
-seam where the reference raises m_reconRowFlag (framefilter.cpp:664).
+A "step" = one 1920x1080 8-bit frame (BASELINE.json configs[1] picture size; allocated as 1920x1088 whole CTUs
+like the reference) through the batched stages of the frame pipeline, everything resident in HBM:
+
+    ME   exhaustive +-57 search, all 85 PUs of every CTU: SAD surfaces (sad_x4 layout) + best mv
+    SUB  sub-pel refinement of every PU (subme 2)
+    REC  32x32 prediction + residual DCT / quant / dequant / iDCT / reconstruction + SSE (MC + TU round trip)
+    EXT  border extension; the reconstruction is the next frame's reference (closed loop)
+
+With N GPUs the job is frame-parallel (one frame per GPU per step, weak scaling); the only data-path exchange is
+the one-to-many broadcast of the newest reconstructed reference (RCCL), the seam where the reference raises
+m_reconRowFlag (framefilter.cpp:664).  Every stage is parity-tested bit-exact against the oracle (tests/ -m gpu).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     - dominant kernel (CTU motion search): algorithmic bytes per launch
-                 / HIP-event-measured launch time, vs 8 TB/s HBM
-  cpu_baseline - the oracle's restatement of the same stage on the host cores (bounded sample).
+  roofline     - dominant kernel (ME surface kernel): algorithmic bytes per launch /
+                 HIP-event launch time vs 8 TB/s; `traffic` = HBM bytes from the committed rocprofv3 PMC passes
+  stages_ms    - HIP-event time of each stage (a separate, untimed pass)
+  cpu_baseline - the oracle's restatement of the same pipeline on the host cores (bounded CTU sample).
 """
 import argparse
 import importlib
@@ -30,32 +37,49 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(F, P, clip, rng_r, target_s=15.0):
-    """Time the oracle (CPU restatement, AVX2 build when the host has AVX2) on a bounded number of
-    CTUs of the same workload, all host cores via OpenMP."""
+def cpu_baseline(F, clip, rng_r, subme, level, qp, target_s=15.0):
+    """The oracle chain (CPU restatement, AVX2 build when the host has AVX2) for one frame on a bounded number
+    of CTUs, all host cores via OpenMP: exhaustive search (best mv) -> sub-pel -> prediction/residual round trip."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_api as O          # cpu_baseline leg only
     avx2 = O.host_has_avx2()
-    cur_buf, stride, org, w64, h64 = F.pad_plane(clip[1][0])
-    ref_buf = F.pad_plane(clip[0][0])[0]
+    cur, stride, org, w64, h64 = F.pad_plane(clip[1][0])
+    ref = F.pad_plane(clip[0][0])[0]
     cost = F.mv_cost_table(rng_r)
+    cq, qoff = F.qpel_cost_table(rng_r)
     nctu = (w64 // 64) * (h64 // 64)
     cores = os.cpu_count() or 1
 
     def run(n):
         t = time.perf_counter()
-        O.me_fullsearch(8, cur_buf, stride, org, ref_buf, stride, org, w64, h64, rng_r, 0, n,
-                        cost, cost, want_surf=False, want_best=True, nthreads=cores, avx2=avx2)
+        _, best = O.me_fullsearch(8, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, cost, cost,
+                                  want_surf=False, want_best=True, nthreads=cores, avx2=avx2)
+        mv = O.subpel_refine(8, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, best, cq, qoff, subme,
+                             nthreads=cores, avx2=avx2)
+        O.inter_recon(8, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp, ctu_begin=0, ctu_end=n,
+                      nthreads=cores, avx2=avx2)
         return time.perf_counter() - t
 
     probe = min(nctu, max(cores, 8))
     t_probe = run(probe)
     n = int(min(nctu, max(probe, probe * target_s / max(t_probe, 1e-3))))
-    t = run(n)
-    fps = (n / nctu) / t
-    return {"value": round(fps, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of {nctu} CTUs of one 1080p frame, exhaustive +-{rng_r} search, best-mv only, "
+    reps, t = 0, 0.0
+    while t < target_s * 0.66 and reps < 64:      # ~10-15 s of wall time: repeat the (sub-)frame if one pass is shorter
+        t += run(n)
+        reps += 1
+    return {"value": round(reps * (n / nctu) / t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x {n} of {nctu} CTUs of a 1080p frame through the same stages (search keeps only the best mv), "
                       f"oracle C ({'-march=x86-64-v3' if avx2 else 'generic x86-64'}) with OpenMP over CTUs, {t:.1f} s"}
+
+
+def load_traffic(width, height, rng_r):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        e = t.get(f"me_surface_{width}x{height}_r{rng_r}")
+        return (e["fetch_bytes"] + e["write_bytes"], e["source"]) if e else (None, None)
+    except (OSError, ValueError, KeyError):
+        return None, None
 
 
 def main():
@@ -66,7 +90,10 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--range", type=int, default=57)          # reference default merange (param.cpp:198)
-    ap.add_argument("--mode", default="surface", choices=["surface+best", "surface", "best"])
+    ap.add_argument("--subme", type=int, default=2)           # preset medium (param.cpp presets)
+    ap.add_argument("--level", type=int, default=2)           # 32x32 blocks in the reconstruction stage
+    ap.add_argument("--qp", type=int, default=27)
+    ap.add_argument("--no-surface", action="store_true", help="ME keeps only the best mv (no SAD surfaces)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -86,42 +113,34 @@ def main():
 
     F = importlib.import_module("x265-yuuki-asuna_amd.frames")
     P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+    S = importlib.import_module("x265-yuuki-asuna_amd.stages")
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
 
     nclip = 4
     clip = F.synth_clip(args.width, args.height, nclip, depth=8, seed=265 + rank)
     pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
-    ms = P.MotionSearch(pics[0].w64, pics[0].h64, args.range, 8, dev,
-                        want_surf="surface" in args.mode, want_best="best" in args.mode)
-    ref = pics[0]
-    ref_plane = ref.t.clone()                        # the reference picture every rank searches in
+    pipe = S.FramePipeline(pics[0].w64, pics[0].h64, 8, dev, rng=args.range, subme=args.subme, level=args.level,
+                           qp=args.qp, want_surf=not args.no_surface)
     ref_pic = P.DevicePicture.__new__(P.DevicePicture)
-    ref_pic.__dict__.update(ref.__dict__)
-    ref_pic.t = ref_plane
-
+    ref_pic.__dict__.update(pics[0].__dict__)
+    ref_pic.t = pics[0].t.clone()                    # the reference every rank searches in (starts as frame 0)
     fp = P.FrameParallel(rank, world)
-    ev = []
 
-    def step(i, timed):
+    def step(i):
         cur = pics[1 + i % (nclip - 1)]
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        ms.run(cur, ref_pic)
-        if timed:
-            e1.record()
-            ev.append((e0, e1))
-        # frame-parallel hand-off: the last rank's newest picture becomes everyone's next reference
-        fp.exchange(ref_plane, cur.t)
+        rec = pipe.run(cur, ref_pic)
+        # frame-parallel hand-off: the last rank's reconstruction becomes everyone's next reference
+        fp.exchange(ref_pic.t, rec)
 
     for i in range(args.warmup):
-        step(i, False)
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, True)
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -131,29 +150,61 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    csum = pipe.checksum()
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
-    alg_bytes = ms.algorithmic_bytes(bpp=1)
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    csum = ms.checksum()
+    # ---- untimed pass: HIP-event time of every stage (events on the stream the kernels are launched on) ----
+    ms, sp, rc = pipe.ms, pipe.sp, pipe.rc
+    cur = pics[1]
+    names = ["me_surface", "me_best", "subpel", "recon", "border"]
+    acc = {k: [] for k in names}
+    for _ in range(5):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        marks[0].record()
+        if ms.surf is not None:
+            A.me_fullsearch(8, ms.w64, ms.h64, ms.range, cur.t, cur.stride, ref_pic.t, ref_pic.stride, surf=ms.surf,
+                            fenc_off=cur.org, fref_off=ref_pic.org)
+        marks[1].record()
+        A.me_best_reset(ms.best)
+        A.me_fullsearch(8, ms.w64, ms.h64, ms.range, cur.t, cur.stride, ref_pic.t, ref_pic.stride, best=ms.best,
+                        cost_x=ms.cost_x, cost_y=ms.cost_y, fenc_off=cur.org, fref_off=ref_pic.org)
+        marks[2].record()
+        sp.run(cur, ref_pic)
+        marks[3].record()
+        rc.run(cur, ref_pic, pipe.recon, sp.out)
+        marks[4].record()
+        S.extend_border(pipe.recon, cur)
+        marks[5].record()
+        torch.cuda.synchronize()
+        for j, k in enumerate(names):
+            acc[k].append(marks[j].elapsed_time(marks[j + 1]))
+    stages = {k: round(float(np.median(v)), 4) for k, v in acc.items()}
 
     if rank == 0:
         fps = world * args.steps / dt
+        surf_mode = ms.surf is not None
+        dom = "me_surface" if surf_mode else "me_best"
+        alg_bytes = ms.algorithmic_bytes(bpp=1)
+        achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9
+        traffic, tsrc = load_traffic(args.width, args.height, args.range) if surf_mode else (None, None)
         out = {
             "metric": "encoded fps + bit-exact check, 4K preset=slow, 1/2/4/8 MI355X vs host AVX2",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.width}x{args.height} 8-bit (BASELINE configs[1] picture size), frame pipeline stages: "
-                                   f"ME exhaustive +-{args.range} for every 8x8/16x16/32x32/64x64 PU ({args.mode})",
+            "config": {"workload": f"{args.width}x{args.height} 8-bit (BASELINE configs[1] picture size) closed-loop frame pipeline: "
+                                   f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({'SAD surfaces + ' if surf_mode else ''}best mv) -> "
+                                   f"sub-pel subme={args.subme} -> {8 << args.level}x{8 << args.level} prediction + DCT/quant/recon qp {args.qp} -> "
+                                   f"border extension -> next reference; pipeline throughput, not HEVC encoded fps",
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world}",
                        "ctus_per_frame": ms.nctu, "checksum": csum},
-            "roofline": {"bound": "hbm", "kernel": "me_ctu_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(kern_ms, 4)},
+            "stages_ms": stages,
+            "roofline": {"bound": "hbm", "kernel": "me_ctu_q_kernel<surf>" if surf_mode else "me_ctu_q_kernel<best>",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": stages[dom]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(F, P, clip, args.range)
+            out["cpu_baseline"] = cpu_baseline(F, clip, args.range, args.subme, args.level, args.qp)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

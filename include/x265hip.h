@@ -149,6 +149,11 @@ typedef struct x265hip_recon_params
 } x265hip_recon_params;
 int x265hip_inter_recon(const x265hip_recon_params* p, void* stream);
 
+/* Picture border extension (reference extendPicBorder, pixel.cpp:1027-1041 = extendRowBorder slot,
+ * ipfilter.cpp:59-77, + top/bottom row replication): `pic` points at pixel (0,0) of a plane that has
+ * margin_x columns / margin_y rows of padding on every side. */
+int x265hip_extend_border(void* pic, intptr_t stride, int width, int height, int margin_x, int margin_y, int depth, void* stream);
+
 /* ------------------------------------------------------------------ generic job-list entry points
  * Every remaining family evaluates `njobs` independent blocks of one size per launch.  An operand
  * is a device plane (base pointer + element stride); a job carries up to four element offsets into

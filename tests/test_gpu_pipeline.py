@@ -1,0 +1,59 @@
+"""GPU parity of the closed-loop frame pipeline (ME -> sub-pel -> prediction/residual round trip -> border
+extension -> next reference) against the same chain of oracle stages, frame by frame."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+S = importlib.import_module("x265-yuuki-asuna_amd.stages")
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_api
+    return oracle_api
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_closed_loop_three_frames(depth):
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    R, subme, level, qp = 12, 2, 2, 24 + 12 * (depth == 10)
+    clip = F.synth_clip(192, 128, 4, depth=depth, seed=61)
+    pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
+    fp = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=R, subme=subme, level=level, qp=qp, want_surf=False)
+    ref_dev = P.DevicePicture(clip[0][0], dev)             # frame 0 is the first reference as-is
+    ref_host = ref_dev.host.copy()
+    cost = F.mv_cost_table(R)
+    cq, qoff = F.qpel_cost_table(R)
+    for k in (1, 2, 3):
+        cur = pics[k]
+        rec = fp.run(cur, ref_dev)
+        torch.cuda.synchronize()
+        # oracle chain on the host
+        _, best = O.me_fullsearch(depth, cur.host, cur.stride, cur.org, ref_host, cur.stride, cur.org, cur.w64, cur.h64, R,
+                                  0, fp.ms.nctu, cost, cost, want_surf=False)
+        mv = O.subpel_refine(depth, cur.host, cur.stride, cur.org, ref_host, cur.stride, cur.org, cur.w64, cur.h64, R,
+                             0, fp.ms.nctu, best, cq, qoff, subme)
+        erec, elev, ens, edist = O.inter_recon(depth, cur.host, cur.stride, cur.org, ref_host, cur.stride, cur.org,
+                                               cur.w64, cur.h64, level, mv, qp)
+        inner = erec[F.MARGIN_Y:F.MARGIN_Y + cur.h64, F.MARGIN_X:F.MARGIN_X + cur.w64]
+        erec = np.pad(inner, ((F.MARGIN_Y, F.MARGIN_Y), (F.MARGIN_X, F.MARGIN_X)), mode="edge")   # extendPicBorder
+        grec = rec.cpu().numpy().view(cur.host.dtype).reshape(cur.host.shape)
+        assert np.array_equal(fp.ms.best.cpu().numpy().view(np.uint64), best), f"frame {k}: integer mvs differ"
+        assert np.array_equal(fp.sp.out.cpu().numpy().reshape(-1, 2), mv), f"frame {k}: sub-pel mvs differ"
+        assert np.array_equal(fp.rc.levels.cpu().numpy(), elev), f"frame {k}: levels differ"
+        assert np.array_equal(grec, erec), f"frame {k}: reconstruction (with borders) differs"
+        # the reconstruction becomes the reference of the next frame on both sides
+        ref_host = erec
+        ref_dev = P.DevicePicture.__new__(P.DevicePicture)
+        ref_dev.__dict__.update(cur.__dict__)
+        ref_dev.t = rec.clone()
+        ref_dev.host = erec

@@ -471,9 +471,14 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     {
         // 8-bit fast path (v_qsad_pk_u16_u8); 2 * range + 75 bytes of window row must fit the 256-byte pitch
 #define LAUNCH_Q(SF, BS) hipLaunchKernelGGL((me_ctu_q_kernel<SF, BS, 256>), grid, dim3(pick_waves((2 * p->range + 4) / 4) * 64), lds, s, a)
-        if (anySurf && anyBest) LAUNCH_Q(true, true);
-        else if (anySurf) LAUNCH_Q(true, false);
-        else LAUNCH_Q(false, true);
+        // Both outputs: two clean launches (surfaces, then minima).  The fused <true, true> instantiation needs
+        // ~200 VGPRs and spills at the 128 a 16-wave workgroup allows - measured slower than this pair.
+        if (anySurf && anyBest && getenv("X265HIP_ME_FUSED")) LAUNCH_Q(true, true);
+        else
+        {
+            if (anySurf) LAUNCH_Q(true, false);
+            if (anyBest) LAUNCH_Q(false, true);
+        }
 #undef LAUNCH_Q
     }
     else if (anySurf && anyBest) LAUNCH(true, true);

@@ -59,3 +59,49 @@ class InterRecon:
         import torch
         return {"levels": int(self.levels.to(torch.int64).sum().item()), "num_sig": int(self.num_sig.sum().item()),
                 "dist": int(self.dist.sum().item())}
+
+
+def extend_border(plane, pic: DevicePicture, stream=None):
+    """Replicate the picture edges into the margins of `plane` (same geometry as `pic`), on device."""
+    from . import frames as F
+    es = 1 if pic.depth == 8 else 2
+    s = hipabi.current_stream() if stream is None else stream
+    f = hipabi.lib().x265hip_extend_border
+    f.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    hipabi.check(f(plane.data_ptr() + pic.org * es, pic.stride, pic.w64, pic.h64, F.MARGIN_X, F.MARGIN_Y, pic.depth, s),
+                 "x265hip_extend_border")
+
+
+class FramePipeline:
+    """Closed-loop frame pipeline: every frame is searched in, predicted from and reconstructed against the
+    RECONSTRUCTION of the previous frame (like the reference's P-frame chain), all on device:
+        ME (exhaustive, SAD surfaces and/or best mv) -> sub-pel refinement -> prediction + residual round trip
+        (NxN blocks) -> border extension -> the reconstruction becomes the next reference."""
+
+    def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True):
+        import torch
+        from .pipeline import MotionSearch, SubpelRefine
+        self.depth = depth
+        self.ms = MotionSearch(w64, h64, rng, depth, device, want_surf=want_surf, want_best=True)
+        self.sp = SubpelRefine(self.ms, subme, device)
+        self.rc = InterRecon(self.ms.nctu, w64, h64, depth, level, qp, device)
+        self.recon = None
+
+    def run(self, cur: DevicePicture, ref: DevicePicture):
+        """ref.t is the current reference plane (extended borders); returns the plane holding the new reconstruction."""
+        import torch
+        if self.recon is None:
+            self.recon = torch.zeros_like(cur.t)
+        self.ms.run(cur, ref)
+        self.sp.run(cur, ref)
+        self.rc.run(cur, ref, self.recon, self.sp.out)
+        extend_border(self.recon, cur)
+        return self.recon
+
+    def checksum(self):
+        import torch
+        out = {}
+        out.update(self.sp.checksum())
+        out.update(self.rc.checksum())
+        out["recon"] = int(self.recon.view(torch.uint8).to(torch.int64).sum().item())
+        return out
