@@ -76,7 +76,7 @@ def load_traffic(width, height, rng_r):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json)."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        e = t.get(f"me_surface_{width}x{height}_r{rng_r}")
+        e = t.get(f"me_{width}x{height}_r{rng_r}")
         return (e["fetch_bytes"] + e["write_bytes"], e["source"]) if e else (None, None)
     except (OSError, ValueError, KeyError):
         return None, None
@@ -155,25 +155,19 @@ def main():
     # ---- untimed pass: HIP-event time of every stage (events on the stream the kernels are launched on) ----
     ms, sp, rc = pipe.ms, pipe.sp, pipe.rc
     cur = pics[1]
-    names = ["me_surface", "me_best", "subpel", "recon", "border"]
+    names = ["me", "subpel", "recon", "border"]
     acc = {k: [] for k in names}
     for _ in range(5):
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         marks[0].record()
-        if ms.surf is not None:
-            A.me_fullsearch(8, ms.w64, ms.h64, ms.range, cur.t, cur.stride, ref_pic.t, ref_pic.stride, surf=ms.surf,
-                            fenc_off=cur.org, fref_off=ref_pic.org)
+        ms.run(cur, ref_pic)                      # minima reset + ONE fused launch: SAD surfaces and best mv
         marks[1].record()
-        A.me_best_reset(ms.best)
-        A.me_fullsearch(8, ms.w64, ms.h64, ms.range, cur.t, cur.stride, ref_pic.t, ref_pic.stride, best=ms.best,
-                        cost_x=ms.cost_x, cost_y=ms.cost_y, fenc_off=cur.org, fref_off=ref_pic.org)
-        marks[2].record()
         sp.run(cur, ref_pic)
-        marks[3].record()
+        marks[2].record()
         rc.run(cur, ref_pic, pipe.recon, sp.out)
-        marks[4].record()
+        marks[3].record()
         S.extend_border(pipe.recon, cur)
-        marks[5].record()
+        marks[4].record()
         torch.cuda.synchronize()
         for j, k in enumerate(names):
             acc[k].append(marks[j].elapsed_time(marks[j + 1]))
@@ -182,7 +176,7 @@ def main():
     if rank == 0:
         fps = world * args.steps / dt
         surf_mode = ms.surf is not None
-        dom = "me_surface" if surf_mode else "me_best"
+        dom = "me"
         alg_bytes = ms.algorithmic_bytes(bpp=1)
         achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9
         traffic, tsrc = load_traffic(args.width, args.height, args.range) if surf_mode else (None, None)
@@ -198,7 +192,7 @@ def main():
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world}",
                        "ctus_per_frame": ms.nctu, "checksum": csum},
             "stages_ms": stages,
-            "roofline": {"bound": "hbm", "kernel": "me_ctu_q_kernel<surf>" if surf_mode else "me_ctu_q_kernel<best>",
+            "roofline": {"bound": "hbm", "kernel": "me_ctu_q_kernel<surf,best>" if surf_mode else "me_ctu_q_kernel<best>",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": stages[dom]},

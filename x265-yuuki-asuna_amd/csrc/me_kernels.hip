@@ -248,11 +248,11 @@ __global__ void __launch_bounds__(1024, SURF ? 4 : 8) me_ctu_kernel(MEArgs a)
 // The window is staged so that LDS byte 0 of a row is window column 0 (unaligned global dword loads),
 // which makes column group g start on LDS dword 2*bx + g for every CTU.
 template <bool SURF, bool BEST, int PITCH>
-__global__ void __launch_bounds__(1024, 4) me_ctu_q_kernel(MEArgs a)
+__global__ void __launch_bounds__(SURF && BEST ? 512 : 1024, SURF && BEST ? 2 : 4) me_ctu_q_kernel(MEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t win[];
     typedef unsigned long long u64;
-    constexpr bool PIPE = !(SURF && BEST);      // the fused variant trades the LDS software pipeline for registers
+    constexpr bool PIPE = true;
 
     const int R = a.range;
     const int NC = 2 * R + 1;
@@ -470,14 +470,16 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     if (sizeof(Px) == 1 && a.rowBytes == 256 && !p_generic)
     {
         // 8-bit fast path (v_qsad_pk_u16_u8); 2 * range + 75 bytes of window row must fit the 256-byte pitch
-#define LAUNCH_Q(SF, BS) hipLaunchKernelGGL((me_ctu_q_kernel<SF, BS, 256>), grid, dim3(pick_waves((2 * p->range + 4) / 4) * 64), lds, s, a)
-        // Both outputs: two clean launches (surfaces, then minima).  The fused <true, true> instantiation needs
-        // ~200 VGPRs and spills at the 128 a 16-wave workgroup allows - measured slower than this pair.
-        if (anySurf && anyBest && getenv("X265HIP_ME_FUSED")) LAUNCH_Q(true, true);
+#define LAUNCH_Q(SF, BS, MAXW) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > (MAXW)) nwq = (MAXW); \
+        hipLaunchKernelGGL((me_ctu_q_kernel<SF, BS, 256>), grid, dim3(nwq * 64), lds, s, a); } while (0)
+        // Both outputs: ONE fused launch.  It needs ~180 VGPRs, so its workgroup is 8 wavefronts (2 per SIMD,
+        // 256-VGPR budget) instead of 16; the qsad chains carry enough ILP to keep the VALU busy at that occupancy.
+        // X265HIP_ME_SPLIT forces the older surfaces-then-minima pair of launches (A/B measurements).
+        if (anySurf && anyBest && !getenv("X265HIP_ME_SPLIT")) LAUNCH_Q(true, true, 8);
         else
         {
-            if (anySurf) LAUNCH_Q(true, false);
-            if (anyBest) LAUNCH_Q(false, true);
+            if (anySurf) LAUNCH_Q(true, false, 16);
+            if (anyBest) LAUNCH_Q(false, true, 16);
         }
 #undef LAUNCH_Q
     }

@@ -7,12 +7,12 @@
 // pu[].satd against the PU source copy).  Interpolation arithmetic: source/common/ipfilter.cpp:79-118,
 // :164-203, :120-162 + :319-369 (hps with row extension then vertical sp), SATD source/common/pixel.cpp:210-297.
 //
-// Mapping: one workgroup per PU.  The PU source block and the reference patch around the integer motion
-// vector (+-3 pixels of drift + 8-tap apron) are staged in LDS once; every candidate of an iteration
-// (4 or 8 directions) is evaluated concurrently, one thread per (candidate, 4x4 tile): the thread
+// Mapping: one workgroup per (CTU, PU level).  The CTU source block and, per PU, the reference patch around its
+// integer motion vector (+-3 pixels of drift + 8-tap apron) are staged in LDS once; every candidate of an
+// iteration (4 or 8 directions) of every PU is evaluated concurrently, one thread per (PU, candidate, 4x4 tile): the thread
 // interpolates its 16 samples straight from the LDS patch (hv: 11 horizontally filtered rows kept in
 // registers), takes the 4x4 Hadamard (or SAD) in registers and adds its partial cost to an LDS bin.  The
-// serial decision loop of the reference then runs redundantly in every thread on the reduced costs, so no
+// serial decision loop of the reference then runs in one thread per PU on the reduced costs, so no
 // host round trip sits between the candidates - this is SURVEY section 8(f) item 1 for the sub-pel part.
 #include "common.h"
 
@@ -23,7 +23,6 @@ struct SubpelArgs
     const uint8_t* fenc; long fencStrideB;
     const uint8_t* fref; long frefStrideB;
     int ctusW, range, depth;
-    int level;                       // 0..3 -> 8, 16, 32, 64
     const unsigned long long* bestIn;
     const uint16_t* costQ; int qoff;
     int hpelIters, hpelDirs, qpelIters, qpelDirs, hpelSatd;
@@ -36,7 +35,6 @@ __constant__ int16_t kSpLumaTaps[4][8] = {
 __constant__ int kSpSquare1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
 
 constexpr int SP_MARGIN = 7;                        // patch origin = integer mv - 7: 3 px of drift + 3 px of left apron + 1
-constexpr int SP_PITCH = 64 + 2 * SP_MARGIN + 2;    // 80 int16 per LDS row
 
 __device__ __forceinline__ int sp_clip16(int v, int maxVal)
 {
@@ -44,49 +42,72 @@ __device__ __forceinline__ int sp_clip16(int v, int maxVal)
     return s < 0 ? 0 : (s > maxVal ? maxVal : s);
 }
 
+// One workgroup per (CTU, PU level): ALL PUs of the level are refined together, so every evaluation round has
+// npu * ndirs * tiles = 1024 (4 directions) or 2048 (8) independent (PU, candidate, 4x4 tile) items for the 256
+// threads whatever the PU size.  Per-PU state (best cost / mv, alive flag, candidate costs) lives in LDS; the
+// round structure of the reference loop is uniform, PUs that stop early simply contribute no items.
 template <typename Px>
 __global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
 {
-    __shared__ int16_t patch[(64 + 2 * SP_MARGIN + 2) * SP_PITCH];
-    __shared__ int16_t src[64 * 64];
-    __shared__ int costs[9];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smemRaw[];
+    Px* smem = reinterpret_cast<Px*>(smemRaw);
+    __shared__ int sCost[64][9];
+    __shared__ int sB[64], sQx[64], sQy[64], sIx[64], sIy[64], sAlive[64];
     constexpr int BPP = sizeof(Px);
 
-    const int n = 8 << a.level, npu = (64 / n) * (64 / n);
-    const int lbase = a.level == 0 ? 0 : (a.level == 1 ? 64 : (a.level == 2 ? 80 : 84));
-    const int ctu = blockIdx.x / npu, z = blockIdx.x - ctu * npu;
-    const int bxz = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), byz = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
-    const int px = (ctu % a.ctusW) * 64 + bxz * n, py = (ctu / a.ctusW) * 64 + byz * n;
+    const int level = blockIdx.y;                          // all four PU levels of a CTU run concurrently
+    const int n = 8 << level, npu = 64 >> (2 * level);
+    const int lbase = level == 0 ? 0 : (level == 1 ? 64 : (level == 2 ? 80 : 84));
+    const int ctu = blockIdx.x;
+    const int cx = (ctu % a.ctusW) * 64, cy = (ctu / a.ctusW) * 64;
     const int tid = threadIdx.x, nth = blockDim.x;
     const int R = a.range, NC = 2 * R + 1;
     const int maxVal = (1 << a.depth) - 1, headRoom = 14 - a.depth;
+    const int pw = n + 2 * SP_MARGIN + 1;                  // patch width = height
+    const int psz = pw * pw;
+    Px* src = smem;                                   // 64 x 64 source CTU (all PUs of the level tile it)
+    Px* patches = smem + 64 * 64;                     // npu patches of pw x pw
 
-    const unsigned long long key = a.bestIn[(size_t)ctu * 85 + lbase + z];
-    const int idx = (int)(key & 0xffffffffu);
-    int bcost = (int)(key >> 32);
-    const int imx = (idx % NC) - R, imy = (idx / NC) - R;                      // integer mv
-    int bqx = imx * 4, bqy = imy * 4;
-
-    // ---- stage source block and reference patch ------------------------------------------------------
-    const int pw = n + 2 * SP_MARGIN + 1;                                        // columns / rows of the patch actually used
+    if (tid < npu)
     {
-        const Px* fe = reinterpret_cast<const Px*>(a.fenc + (long)py * a.fencStrideB) + px;
+        const unsigned long long key = a.bestIn[(size_t)ctu * 85 + lbase + tid];
+        const int idx = (int)(key & 0xffffffffu);
+        const int imx = (idx % NC) - R, imy = (idx / NC) - R;
+        sIx[tid] = imx; sIy[tid] = imy;
+        sQx[tid] = imx * 4; sQy[tid] = imy * 4;
+        const int c = (int)(key >> 32);
+        sB[tid] = c;
+        sAlive[tid] = c != 0;                              // zero residual: skip refinement (motion.cpp:1464-1469)
+    }
+    {
+        const Px* fe = reinterpret_cast<const Px*>(a.fenc + (long)cy * a.fencStrideB) + cx;
         const long fst = a.fencStrideB / BPP;
-        for (int i = tid; i < n * n; i += nth) { const int y = i / n, x = i - y * n; src[y * 64 + x] = (int16_t)fe[y * fst + x]; }
-        const Px* rf = reinterpret_cast<const Px*>(a.fref + (long)(py + imy - SP_MARGIN) * a.frefStrideB) + (px + imx - SP_MARGIN);
+        for (int i = tid; i < 64 * 64; i += nth) src[i] = fe[(i >> 6) * fst + (i & 63)];
+    }
+    __syncthreads();
+    {
         const long rst = a.frefStrideB / BPP;
-        for (int i = tid; i < pw * pw; i += nth) { const int y = i / pw, x = i - y * pw; patch[y * SP_PITCH + x] = (int16_t)rf[y * rst + x]; }
+        for (int i = tid; i < npu * psz; i += nth)
+        {
+            const int pu = i / psz, r = i - pu * psz, y = r / pw, x = r - y * pw;
+            const int bxz = (pu & 1) | ((pu >> 1) & 2) | ((pu >> 2) & 4), byz = ((pu >> 1) & 1) | ((pu >> 2) & 2) | ((pu >> 3) & 4);
+            const Px* rf = reinterpret_cast<const Px*>(a.fref) + (long)(cy + byz * n + sIy[pu] - SP_MARGIN + y) * rst
+                           + (cx + bxz * n + sIx[pu] - SP_MARGIN + x);
+            patches[i] = rf[0];
+        }
     }
     __syncthreads();
 
-    const int tpr = n >> 2, ntiles = tpr * tpr;
-    const int tshift = a.level * 2 + 2;                                          // log2(ntiles)
+    const int tpr = n >> 2;
+    const int tshift = level * 2 + 2;                      // log2(tiles per PU)
+    const int ntiles = 1 << tshift;
 
-    // cost of one candidate for one 4x4 tile; (qx, qy) = absolute qpel mv
-    auto tile_cost = [&](const int qx, const int qy, const int tile, const bool useSatd) -> int
+    auto tile_cost = [&](const int pu, const int qx, const int qy, const int tile, const bool useSatd) -> int
     {
+        const Px* patch = patches + pu * psz;
+        const int bxz = (pu & 1) | ((pu >> 1) & 2) | ((pu >> 2) & 4), byz = ((pu >> 1) & 1) | ((pu >> 2) & 2) | ((pu >> 3) & 4);
         const int ty = tile / tpr, tx = tile - ty * tpr;
-        const int ox = (qx >> 2) - imx + SP_MARGIN + tx * 4, oy = (qy >> 2) - imy + SP_MARGIN + ty * 4;   // patch coords of the tile's full-pel sample
+        const int ox = (qx >> 2) - sIx[pu] + SP_MARGIN + tx * 4, oy = (qy >> 2) - sIy[pu] + SP_MARGIN + ty * 4;
         const int xf = qx & 3, yf = qy & 3;
         int d[4][4];
         if (!(xf | yf))
@@ -94,33 +115,43 @@ __global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
 #pragma unroll
             for (int y = 0; y < 4; y++)
 #pragma unroll
-                for (int x = 0; x < 4; x++) d[y][x] = patch[(oy + y) * SP_PITCH + ox + x];
+                for (int x = 0; x < 4; x++) d[y][x] = patch[(oy + y) * pw + ox + x];
         }
         else if (!yf)
         {
 #pragma unroll
             for (int y = 0; y < 4; y++)
+            {
+                int in[11];
+#pragma unroll
+                for (int t = 0; t < 11; t++) in[t] = patch[(oy + y) * pw + ox + t - 3];
 #pragma unroll
                 for (int x = 0; x < 4; x++)
                 {
                     int s = 0;
 #pragma unroll
-                    for (int t = 0; t < 8; t++) s += (int)patch[(oy + y) * SP_PITCH + ox + x + t - 3] * kSpLumaTaps[xf][t];
+                    for (int t = 0; t < 8; t++) s += in[x + t] * kSpLumaTaps[xf][t];
                     d[y][x] = sp_clip16((s + 32) >> 6, maxVal);
                 }
+            }
         }
         else if (!xf)
         {
 #pragma unroll
-            for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++)
+            {
+                int in[11];
 #pragma unroll
-                for (int x = 0; x < 4; x++)
+                for (int t = 0; t < 11; t++) in[t] = patch[(oy + t - 3) * pw + ox + x];
+#pragma unroll
+                for (int y = 0; y < 4; y++)
                 {
                     int s = 0;
 #pragma unroll
-                    for (int t = 0; t < 8; t++) s += (int)patch[(oy + y + t - 3) * SP_PITCH + ox + x] * kSpLumaTaps[yf][t];
+                    for (int t = 0; t < 8; t++) s += in[y + t] * kSpLumaTaps[yf][t];
                     d[y][x] = sp_clip16((s + 32) >> 6, maxVal);
                 }
+            }
         }
         else
         {
@@ -129,14 +160,19 @@ __global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
             int16_t im[11][4];
 #pragma unroll
             for (int r = 0; r < 11; r++)
+            {
+                int in[11];
+#pragma unroll
+                for (int t = 0; t < 11; t++) in[t] = patch[(oy + r - 3) * pw + ox + t - 3];
 #pragma unroll
                 for (int x = 0; x < 4; x++)
                 {
                     int s = 0;
 #pragma unroll
-                    for (int t = 0; t < 8; t++) s += (int)patch[(oy + r - 3) * SP_PITCH + ox + x + t - 3] * kSpLumaTaps[xf][t];
+                    for (int t = 0; t < 8; t++) s += in[x + t] * kSpLumaTaps[xf][t];
                     im[r][x] = (int16_t)((s + offPS) >> shiftPS);
                 }
+            }
 #pragma unroll
             for (int y = 0; y < 4; y++)
 #pragma unroll
@@ -148,10 +184,11 @@ __global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
                     d[y][x] = sp_clip16((s + offSP) >> shiftSP, maxVal);
                 }
         }
+        const Px* sp = src + (byz * n + ty * 4) * 64 + bxz * n + tx * 4;
 #pragma unroll
         for (int y = 0; y < 4; y++)
 #pragma unroll
-            for (int x = 0; x < 4; x++) d[y][x] = (int)src[(ty * 4 + y) * 64 + tx * 4 + x] - d[y][x];
+            for (int x = 0; x < 4; x++) d[y][x] = (int)sp[y * 64 + x] - d[y][x];
         int acc = 0;
         if (!useSatd)
         {
@@ -177,58 +214,70 @@ __global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
         return acc >> 1;
     };
 
-    // evaluate candidates base + square1[first..last] * step concurrently; results in costs[first..last]
+    // PU state: 0 = zero residual at the integer mv, refinement skipped (motion.cpp:1464-1469); 1 = searching;
+    // 2 = the current phase ended for this PU (the reference's `break`), waiting for the next phase.
+    // evaluate(): for every searching PU, candidates best + square1[first..last] * step -> sCost[pu][first..last]
     auto evaluate = [&](const int first, const int last, const int step, const bool useSatd)
     {
-        if (tid < 9) costs[tid] = 0;
+        for (int i = tid; i < 64 * 9; i += nth) (&sCost[0][0])[i] = 0;
         __syncthreads();
-        const int ncand = last - first + 1;
-        for (int it = tid; it < (ncand << tshift); it += nth)
+        const int perPu = (last - first + 1) << tshift;
+        for (int it = tid; it < npu * perPu; it += nth)
         {
-            const int c = first + (it >> tshift), tile = it & (ntiles - 1);
-            const int qx = bqx + kSpSquare1[c][0] * step, qy = bqy + kSpSquare1[c][1] * step;
-            atomicAdd(&costs[c], tile_cost(qx, qy, tile, useSatd));
+            const int pu = it / perPu, r = it - pu * perPu;
+            if (sAlive[pu] != 1) continue;
+            const int c = first + (r >> tshift), tile = r & (ntiles - 1);
+            atomicAdd(&sCost[pu][c], tile_cost(pu, sQx[pu] + kSpSquare1[c][0] * step, sQy[pu] + kSpSquare1[c][1] * step, tile, useSatd));
         }
         __syncthreads();
     };
     auto mvcost = [&](const int qx, const int qy) { return (int)a.costQ[qx + a.qoff] + (int)a.costQ[qy + a.qoff]; };
-
-    if (!bcost)
-        bcost = mvcost(bqx, bqy);
-    else
+    // one iteration's decision for PU `tid` (COPY2_IF_LT: strict less, first direction wins; motion.cpp:1520-1531)
+    auto decide = [&](const int ndirs, const int step)
     {
-        const bool hs = a.hpelSatd != 0;
-        if (hs) { evaluate(0, 0, 0, true); bcost = costs[0] + mvcost(bqx, bqy); __syncthreads(); }
-        for (int iter = 0; iter < a.hpelIters; iter++)
+        if (tid < npu && sAlive[tid] == 1)
         {
-            evaluate(1, a.hpelDirs, 2, hs);
-            int bdir = 0;
-            for (int i = 1; i <= a.hpelDirs; i++)
+            int bcost = sB[tid], bdir = 0;
+            const int qx0 = sQx[tid], qy0 = sQy[tid];
+            for (int i = 1; i <= ndirs; i++)
             {
-                const int c = costs[i] + mvcost(bqx + kSpSquare1[i][0] * 2, bqy + kSpSquare1[i][1] * 2);
+                const int c = sCost[tid][i] + mvcost(qx0 + kSpSquare1[i][0] * step, qy0 + kSpSquare1[i][1] * step);
                 if (c < bcost) { bcost = c; bdir = i; }
             }
-            __syncthreads();
-            if (bdir) { bqx += kSpSquare1[bdir][0] * 2; bqy += kSpSquare1[bdir][1] * 2; }
-            else break;
+            sB[tid] = bcost;
+            if (bdir) { sQx[tid] = qx0 + kSpSquare1[bdir][0] * step; sQy[tid] = qy0 + kSpSquare1[bdir][1] * step; }
+            else sAlive[tid] = 2;
         }
-        if (!hs) { evaluate(0, 0, 0, true); bcost = costs[0] + mvcost(bqx, bqy); __syncthreads(); }
-        for (int iter = 0; iter < a.qpelIters; iter++)
-        {
-            evaluate(1, a.qpelDirs, 1, true);
-            int bdir = 0;
-            for (int i = 1; i <= a.qpelDirs; i++)
-            {
-                const int c = costs[i] + mvcost(bqx + kSpSquare1[i][0], bqy + kSpSquare1[i][1]);
-                if (c < bcost) { bcost = c; bdir = i; }
-            }
-            __syncthreads();
-            if (bdir) { bqx += kSpSquare1[bdir][0]; bqy += kSpSquare1[bdir][1]; }
-            else break;
-        }
+        __syncthreads();
+    };
+    auto remeasure = [&]()          // SATD of the current best replaces the SAD-based cost
+    {
+        evaluate(0, 0, 0, true);
+        if (tid < npu && sAlive[tid] == 1) sB[tid] = sCost[tid][0] + mvcost(sQx[tid], sQy[tid]);
+        __syncthreads();
+    };
+
+    const bool hs = a.hpelSatd != 0;
+    if (hs) remeasure();
+    for (int iter = 0; iter < a.hpelIters; iter++)
+    {
+        evaluate(1, a.hpelDirs, 2, hs);
+        decide(a.hpelDirs, 2);
     }
-    if (tid == 0)
-        a.out[(size_t)ctu * 85 + lbase + z] = make_int2(bcost, (bqx & 0xffff) | (bqy << 16));
+    if (tid < npu && sAlive[tid] == 2) sAlive[tid] = 1;          // next phase: every refined PU searches again
+    __syncthreads();
+    if (!hs) remeasure();
+    for (int iter = 0; iter < a.qpelIters; iter++)
+    {
+        evaluate(1, a.qpelDirs, 1, true);
+        decide(a.qpelDirs, 1);
+    }
+    if (tid < npu)
+    {
+        int bcost = sB[tid];
+        if (sAlive[tid] == 0) bcost = mvcost(sQx[tid], sQy[tid]);     // zero-residual PUs return the mv cost only
+        a.out[(size_t)ctu * 85 + lbase + tid] = make_int2(bcost, (sQx[tid] & 0xffff) | (sQy[tid] << 16));
+    }
 }
 
 } // namespace x265hip
@@ -255,13 +304,17 @@ extern "C" int x265hip_subpel_refine(const x265hip_subpel_params* p, void* strea
     a.out = (int2*)p->out;
     const int nctu = a.ctusW * (p->height / 64);
     hipStream_t s = (hipStream_t)stream;
-    for (int level = 0; level < 4; level++)
+    // one launch: grid.y = PU level; LDS sized for level 0 (64 patches of 23 x 23), the largest
+    const int pw0 = 8 + 2 * SP_MARGIN + 1;
+    const size_t lds = (size_t)(64 * 64 + 64 * pw0 * pw0) * bpp;
+    static_assert(64 * (8 + 15) * (8 + 15) >= 1 * (64 + 15) * (64 + 15) && 64 * 23 * 23 >= 16 * 31 * 31 && 64 * 23 * 23 >= 4 * 47 * 47, "level 0 is the largest");
+    if (p->depth == 8)
+        hipLaunchKernelGGL(subpel_refine_kernel<uint8_t>, dim3(nctu, 4), dim3(256), lds, s, a);
+    else
     {
-        a.level = level;
-        const int npu = 64 >> (2 * level);
-        const int threads = level == 0 ? 64 : (level == 1 ? 128 : 256);
-        if (p->depth == 8) hipLaunchKernelGGL(subpel_refine_kernel<uint8_t>, dim3(nctu * npu), dim3(threads), 0, s, a);
-        else hipLaunchKernelGGL(subpel_refine_kernel<uint16_t>, dim3(nctu * npu), dim3(threads), 0, s, a);
+        static bool attr = false;
+        if (!attr) { X265HIP_TRY(hipFuncSetAttribute((const void*)subpel_refine_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        hipLaunchKernelGGL(subpel_refine_kernel<uint16_t>, dim3(nctu, 4), dim3(256), lds, s, a);
     }
     X265HIP_TRY(hipGetLastError());
     return 0;
