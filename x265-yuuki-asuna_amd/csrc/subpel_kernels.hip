@@ -42,72 +42,85 @@ __device__ __forceinline__ int sp_clip16(int v, int maxVal)
     return s < 0 ? 0 : (s > maxVal ? maxVal : s);
 }
 
-// One workgroup per (CTU, PU level): ALL PUs of the level are refined together, so every evaluation round has
-// npu * ndirs * tiles = 1024 (4 directions) or 2048 (8) independent (PU, candidate, 4x4 tile) items for the 256
-// threads whatever the PU size.  Per-PU state (best cost / mv, alive flag, candidate costs) lives in LDS; the
-// round structure of the reference loop is uniform, PUs that stop early simply contribute no items.
-template <typename Px>
-__global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
+struct SpShared                                     // per-PU search state of one workgroup
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smemRaw[];
-    Px* smem = reinterpret_cast<Px*>(smemRaw);
-    __shared__ int sCost[64][9];
-    __shared__ int sB[64], sQx[64], sQy[64], sIx[64], sIy[64], sAlive[64];
-    constexpr int BPP = sizeof(Px);
+    int cost[64][9];
+    int best[64], qx[64], qy[64], ix[64], iy[64], state[64];
+};
 
-    const int level = blockIdx.y;                          // all four PU levels of a CTU run concurrently
-    const int n = 8 << level, npu = 64 >> (2 * level);
-    const int lbase = level == 0 ? 0 : (level == 1 ? 64 : (level == 2 ? 80 : 84));
+template <typename Px, int LEVEL> struct SpGeom
+{
+    static constexpr int BPP = sizeof(Px);
+    static constexpr int N = 8 << LEVEL, NPU = 64 >> (2 * LEVEL);
+    static constexpr int TSHIFT = 2 * LEVEL + 2, NTILES = 1 << TSHIFT, TPR = N >> 2;   // 4x4 tiles per PU; NPU * NTILES = 256
+    static constexpr int PW = N + 2 * SP_MARGIN + 1;                                     // patch width = height (pixels)
+    static constexpr int PITCH = BPP == 1 ? (PW + 3) & ~3 : (PW + 1) & ~1;               // row pitch in pixels, dword multiple
+    static constexpr int DWR = PITCH * BPP / 4;                                          // dwords per patch row
+    static constexpr int PSZ = PW * PITCH;
+    static constexpr int LBASE = LEVEL == 0 ? 0 : (LEVEL == 1 ? 64 : (LEVEL == 2 ? 80 : 84));
+};
+
+// One workgroup = one (CTU, PU level): 256 threads, thread t owns 4x4 tile (t % NTILES) of PU (t / NTILES) for the
+// whole search, its 16 source pixels in registers.  Each pass of an evaluation round handles ONE candidate for
+// all PUs, so a wavefront mostly runs a single interpolation case.
+template <typename Px, int LEVEL>
+__device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemRaw, SpShared& sh)
+{
+    typedef SpGeom<Px, LEVEL> G;
+    constexpr int BPP = G::BPP, N = G::N, NPU = G::NPU, PW = G::PW, PITCH = G::PITCH;
+    Px* patches = reinterpret_cast<Px*>(smemRaw);
+
     const int ctu = blockIdx.x;
     const int cx = (ctu % a.ctusW) * 64, cy = (ctu / a.ctusW) * 64;
-    const int tid = threadIdx.x, nth = blockDim.x;
+    const int tid = threadIdx.x;
     const int R = a.range, NC = 2 * R + 1;
     const int maxVal = (1 << a.depth) - 1, headRoom = 14 - a.depth;
-    const int pw = n + 2 * SP_MARGIN + 1;                  // patch width = height
-    const int psz = pw * pw;
-    Px* src = smem;                                   // 64 x 64 source CTU (all PUs of the level tile it)
-    Px* patches = smem + 64 * 64;                     // npu patches of pw x pw
 
-    if (tid < npu)
+    if (tid < NPU)
     {
-        const unsigned long long key = a.bestIn[(size_t)ctu * 85 + lbase + tid];
+        const unsigned long long key = a.bestIn[(size_t)ctu * 85 + G::LBASE + tid];
         const int idx = (int)(key & 0xffffffffu);
         const int imx = (idx % NC) - R, imy = (idx / NC) - R;
-        sIx[tid] = imx; sIy[tid] = imy;
-        sQx[tid] = imx * 4; sQy[tid] = imy * 4;
+        sh.ix[tid] = imx; sh.iy[tid] = imy;
+        sh.qx[tid] = imx * 4; sh.qy[tid] = imy * 4;
         const int c = (int)(key >> 32);
-        sB[tid] = c;
-        sAlive[tid] = c != 0;                              // zero residual: skip refinement (motion.cpp:1464-1469)
+        sh.best[tid] = c;
+        sh.state[tid] = c != 0;                            // zero residual: skip refinement (motion.cpp:1464-1469)
     }
+    const int pu = tid >> G::TSHIFT, tile = tid & (G::NTILES - 1);
+    const int bxz = (pu & 1) | ((pu >> 1) & 2) | ((pu >> 2) & 4), byz = ((pu >> 1) & 1) | ((pu >> 2) & 2) | ((pu >> 3) & 4);
+    const int ty = tile / G::TPR, tx = tile % G::TPR;
+    int src[4][4];
     {
-        const Px* fe = reinterpret_cast<const Px*>(a.fenc + (long)cy * a.fencStrideB) + cx;
+        const Px* fe = reinterpret_cast<const Px*>(a.fenc + (long)(cy + byz * N + ty * 4) * a.fencStrideB) + (cx + bxz * N + tx * 4);
         const long fst = a.fencStrideB / BPP;
-        for (int i = tid; i < 64 * 64; i += nth) src[i] = fe[(i >> 6) * fst + (i & 63)];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) src[y][x] = fe[y * fst + x];
     }
     __syncthreads();
-    {
-        const long rst = a.frefStrideB / BPP;
-        for (int i = tid; i < npu * psz; i += nth)
+    {   // stage every PU's reference patch, one (possibly unaligned) dword per item
+        constexpr int ITEMS = NPU * PW * G::DWR;
+        uint32_t* pdw = reinterpret_cast<uint32_t*>(smemRaw);
+#pragma unroll 4
+        for (int i = tid; i < ITEMS; i += 256)
         {
-            const int pu = i / psz, r = i - pu * psz, y = r / pw, x = r - y * pw;
-            const int bxz = (pu & 1) | ((pu >> 1) & 2) | ((pu >> 2) & 4), byz = ((pu >> 1) & 1) | ((pu >> 2) & 2) | ((pu >> 3) & 4);
-            const Px* rf = reinterpret_cast<const Px*>(a.fref) + (long)(cy + byz * n + sIy[pu] - SP_MARGIN + y) * rst
-                           + (cx + bxz * n + sIx[pu] - SP_MARGIN + x);
-            patches[i] = rf[0];
+            const int q = i / (PW * G::DWR), r = i % (PW * G::DWR), y = r / G::DWR, c = r % G::DWR;
+            const int qbx = (q & 1) | ((q >> 1) & 2) | ((q >> 2) & 4), qby = ((q >> 1) & 1) | ((q >> 2) & 2) | ((q >> 3) & 4);
+            const uint8_t* rf = a.fref + (long)(cy + qby * N + sh.iy[q] - SP_MARGIN + y) * a.frefStrideB
+                                + (long)(cx + qbx * N + sh.ix[q] - SP_MARGIN) * BPP + 4 * c;
+            pdw[i] = ld_u32(rf);
         }
     }
     __syncthreads();
 
-    const int tpr = n >> 2;
-    const int tshift = level * 2 + 2;                      // log2(tiles per PU)
-    const int ntiles = 1 << tshift;
+    const Px* patch = patches + pu * G::PSZ;
+    const int pox = SP_MARGIN + tx * 4 - sh.ix[pu], poy = SP_MARGIN + ty * 4 - sh.iy[pu];
 
-    auto tile_cost = [&](const int pu, const int qx, const int qy, const int tile, const bool useSatd) -> int
+    auto tile_cost = [&](const int qx, const int qy, const bool useSatd) -> int
     {
-        const Px* patch = patches + pu * psz;
-        const int bxz = (pu & 1) | ((pu >> 1) & 2) | ((pu >> 2) & 4), byz = ((pu >> 1) & 1) | ((pu >> 2) & 2) | ((pu >> 3) & 4);
-        const int ty = tile / tpr, tx = tile - ty * tpr;
-        const int ox = (qx >> 2) - sIx[pu] + SP_MARGIN + tx * 4, oy = (qy >> 2) - sIy[pu] + SP_MARGIN + ty * 4;
+        const int ox = (qx >> 2) + pox, oy = (qy >> 2) + poy;
         const int xf = qx & 3, yf = qy & 3;
         int d[4][4];
         if (!(xf | yf))
@@ -115,7 +128,7 @@ __global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
 #pragma unroll
             for (int y = 0; y < 4; y++)
 #pragma unroll
-                for (int x = 0; x < 4; x++) d[y][x] = patch[(oy + y) * pw + ox + x];
+                for (int x = 0; x < 4; x++) d[y][x] = patch[(oy + y) * PITCH + ox + x];
         }
         else if (!yf)
         {
@@ -124,7 +137,7 @@ __global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
             {
                 int in[11];
 #pragma unroll
-                for (int t = 0; t < 11; t++) in[t] = patch[(oy + y) * pw + ox + t - 3];
+                for (int t = 0; t < 11; t++) in[t] = patch[(oy + y) * PITCH + ox + t - 3];
 #pragma unroll
                 for (int x = 0; x < 4; x++)
                 {
@@ -142,7 +155,7 @@ __global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
             {
                 int in[11];
 #pragma unroll
-                for (int t = 0; t < 11; t++) in[t] = patch[(oy + t - 3) * pw + ox + x];
+                for (int t = 0; t < 11; t++) in[t] = patch[(oy + t - 3) * PITCH + ox + x];
 #pragma unroll
                 for (int y = 0; y < 4; y++)
                 {
@@ -157,38 +170,43 @@ __global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
         {
             const int shiftPS = 6 - headRoom, offPS = -(8192 << shiftPS);
             const int shiftSP = 6 + headRoom, offSP = (1 << (shiftSP - 1)) + (8192 << 6);
-            int16_t im[11][4];
+            int ch[8], cv[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) { ch[t] = kSpLumaTaps[xf][t]; cv[t] = kSpLumaTaps[yf][t]; }
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) d[y][x] = offSP;
+            // stream the 11 horizontally filtered rows through the 4 x 4 vertical accumulators: the 16-bit
+            // intermediate row r feeds output row y with tap r - y
 #pragma unroll
             for (int r = 0; r < 11; r++)
             {
                 int in[11];
 #pragma unroll
-                for (int t = 0; t < 11; t++) in[t] = patch[(oy + r - 3) * pw + ox + t - 3];
+                for (int t = 0; t < 11; t++) in[t] = patch[(oy + r - 3) * PITCH + ox + t - 3];
 #pragma unroll
                 for (int x = 0; x < 4; x++)
                 {
-                    int s = 0;
+                    int s = offPS;
 #pragma unroll
-                    for (int t = 0; t < 8; t++) s += in[x + t] * kSpLumaTaps[xf][t];
-                    im[r][x] = (int16_t)((s + offPS) >> shiftPS);
+                    for (int t = 0; t < 8; t++) s += in[x + t] * ch[t];
+                    const int im = (int)(int16_t)(s >> shiftPS);
+#pragma unroll
+                    for (int y = 0; y < 4; y++)
+                        if (r - y >= 0 && r - y < 8) d[y][x] += im * cv[r - y];
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int y = 0; y < 4; y++)
 #pragma unroll
-                for (int x = 0; x < 4; x++)
-                {
-                    int s = 0;
-#pragma unroll
-                    for (int t = 0; t < 8; t++) s += (int)im[y + t][x] * kSpLumaTaps[yf][t];
-                    d[y][x] = sp_clip16((s + offSP) >> shiftSP, maxVal);
-                }
+                for (int x = 0; x < 4; x++) d[y][x] = sp_clip16(d[y][x] >> shiftSP, maxVal);
         }
-        const Px* sp = src + (byz * n + ty * 4) * 64 + bxz * n + tx * 4;
 #pragma unroll
         for (int y = 0; y < 4; y++)
 #pragma unroll
-            for (int x = 0; x < 4; x++) d[y][x] = (int)sp[y * 64 + x] - d[y][x];
+            for (int x = 0; x < 4; x++) d[y][x] = src[y][x] - d[y][x];
         int acc = 0;
         if (!useSatd)
         {
@@ -214,69 +232,84 @@ __global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
         return acc >> 1;
     };
 
-    // PU state: 0 = zero residual at the integer mv, refinement skipped (motion.cpp:1464-1469); 1 = searching;
-    // 2 = the current phase ended for this PU (the reference's `break`), waiting for the next phase.
-    // evaluate(): for every searching PU, candidates best + square1[first..last] * step -> sCost[pu][first..last]
-    auto evaluate = [&](const int first, const int last, const int step, const bool useSatd)
-    {
-        for (int i = tid; i < 64 * 9; i += nth) (&sCost[0][0])[i] = 0;
-        __syncthreads();
-        const int perPu = (last - first + 1) << tshift;
-        for (int it = tid; it < npu * perPu; it += nth)
-        {
-            const int pu = it / perPu, r = it - pu * perPu;
-            if (sAlive[pu] != 1) continue;
-            const int c = first + (r >> tshift), tile = r & (ntiles - 1);
-            atomicAdd(&sCost[pu][c], tile_cost(pu, sQx[pu] + kSpSquare1[c][0] * step, sQy[pu] + kSpSquare1[c][1] * step, tile, useSatd));
-        }
-        __syncthreads();
-    };
     auto mvcost = [&](const int qx, const int qy) { return (int)a.costQ[qx + a.qoff] + (int)a.costQ[qy + a.qoff]; };
-    // one iteration's decision for PU `tid` (COPY2_IF_LT: strict less, first direction wins; motion.cpp:1520-1531)
-    auto decide = [&](const int ndirs, const int step)
-    {
-        if (tid < npu && sAlive[tid] == 1)
-        {
-            int bcost = sB[tid], bdir = 0;
-            const int qx0 = sQx[tid], qy0 = sQy[tid];
-            for (int i = 1; i <= ndirs; i++)
-            {
-                const int c = sCost[tid][i] + mvcost(qx0 + kSpSquare1[i][0] * step, qy0 + kSpSquare1[i][1] * step);
-                if (c < bcost) { bcost = c; bdir = i; }
-            }
-            sB[tid] = bcost;
-            if (bdir) { sQx[tid] = qx0 + kSpSquare1[bdir][0] * step; sQy[tid] = qy0 + kSpSquare1[bdir][1] * step; }
-            else sAlive[tid] = 2;
-        }
-        __syncthreads();
-    };
-    auto remeasure = [&]()          // SATD of the current best replaces the SAD-based cost
-    {
-        evaluate(0, 0, 0, true);
-        if (tid < npu && sAlive[tid] == 1) sB[tid] = sCost[tid][0] + mvcost(sQx[tid], sQy[tid]);
-        __syncthreads();
-    };
 
+    // PU state: 0 = zero residual at the integer mv, refinement skipped; 1 = searching; 2 = the current phase
+    // ended for this PU (the reference's `break`), waiting for the next phase.
+    // The reference's sequence [SATD re-measure if hpelSatd] hpel iterations [re-measure otherwise] qpel iterations
+    // is run as one loop of rounds so the interpolation code exists once.
     const bool hs = a.hpelSatd != 0;
-    if (hs) remeasure();
-    for (int iter = 0; iter < a.hpelIters; iter++)
+    const int nH = a.hpelIters, remAt = hs ? 0 : nH, total = 1 + nH + a.qpelIters;
+    if (G::NTILES == 256) { if (tid < 9) sh.cost[0][tid] = 0; __syncthreads(); }
+    for (int rd = 0; rd < total; rd++)
     {
-        evaluate(1, a.hpelDirs, 2, hs);
-        decide(a.hpelDirs, 2);
+        const bool isRem = rd == remAt;
+        const bool isQ = rd > nH;
+        if (rd == nH + (hs ? 1 : 0))
+        {
+            if (tid < NPU && sh.state[tid] == 2) sh.state[tid] = 1;      // next phase: every refined PU searches again
+            __syncthreads();
+        }
+        const int first = isRem ? 0 : 1, last = isRem ? 0 : (isQ ? a.qpelDirs : a.hpelDirs);
+        const int step = isRem ? 0 : (isQ ? 1 : 2);
+        const bool useSatd = isRem || isQ || hs;
+        // evaluate: for every searching PU, candidates best + square1[first..last] * step -> sh.cost[pu][first..last]
+        {
+            const bool on = sh.state[pu] == 1;
+            const int qx0 = sh.qx[pu], qy0 = sh.qy[pu];
+            for (int c = first; c <= last; c++)
+            {
+                int v = on ? tile_cost(qx0 + kSpSquare1[c][0] * step, qy0 + kSpSquare1[c][1] * step, useSatd) : 0;
+                // sum over the PU's NTILES consecutive threads (all lanes take part)
+                v = quad_sum(v);
+                if (G::NTILES >= 16) v = row_sum_of_quads(v);
+                if (G::NTILES >= 64) v = wave_sum_of_rows(v);
+                if (G::NTILES == 256) { if ((tid & 63) == 0) atomicAdd(&sh.cost[pu][c], v); }
+                else if ((tile & (G::NTILES < 64 ? G::NTILES - 1 : 63)) == 0) sh.cost[pu][c] = v;
+            }
+            __syncthreads();
+        }
+        if (tid < NPU && sh.state[tid] == 1)
+        {
+            const int qx0 = sh.qx[tid], qy0 = sh.qy[tid];
+            if (isRem)
+                sh.best[tid] = sh.cost[tid][0] + mvcost(qx0, qy0);      // SATD of the current best replaces the SAD-based cost
+            else
+            {
+                // COPY2_IF_LT: strict less, first direction wins (motion.cpp:1520-1531)
+                int bcost = sh.best[tid], bdir = 0;
+                for (int i = 1; i <= last; i++)
+                {
+                    const int c = sh.cost[tid][i] + mvcost(qx0 + kSpSquare1[i][0] * step, qy0 + kSpSquare1[i][1] * step);
+                    if (c < bcost) { bcost = c; bdir = i; }
+                }
+                sh.best[tid] = bcost;
+                if (bdir) { sh.qx[tid] = qx0 + kSpSquare1[bdir][0] * step; sh.qy[tid] = qy0 + kSpSquare1[bdir][1] * step; }
+                else sh.state[tid] = 2;
+            }
+        }
+        if (G::NTILES == 256) { __syncthreads(); if (tid < 9) sh.cost[0][tid] = 0; }     // the 64x64 PU accumulates across wavefronts
+        __syncthreads();
     }
-    if (tid < npu && sAlive[tid] == 2) sAlive[tid] = 1;          // next phase: every refined PU searches again
-    __syncthreads();
-    if (!hs) remeasure();
-    for (int iter = 0; iter < a.qpelIters; iter++)
+    if (tid < NPU)
     {
-        evaluate(1, a.qpelDirs, 1, true);
-        decide(a.qpelDirs, 1);
+        int bcost = sh.best[tid];
+        if (sh.state[tid] == 0) bcost = mvcost(sh.qx[tid], sh.qy[tid]);     // zero-residual PUs return the mv cost only
+        a.out[(size_t)ctu * 85 + G::LBASE + tid] = make_int2(bcost, (sh.qx[tid] & 0xffff) | (sh.qy[tid] << 16));
     }
-    if (tid < npu)
+}
+
+template <typename Px>
+__global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smemRaw[];
+    __shared__ SpShared sh;
+    switch (blockIdx.y)                                   // all four PU levels of a CTU run concurrently
     {
-        int bcost = sB[tid];
-        if (sAlive[tid] == 0) bcost = mvcost(sQx[tid], sQy[tid]);     // zero-residual PUs return the mv cost only
-        a.out[(size_t)ctu * 85 + lbase + tid] = make_int2(bcost, (sQx[tid] & 0xffff) | (sQy[tid] << 16));
+    case 0: subpel_level<Px, 0>(a, smemRaw, sh); break;
+    case 1: subpel_level<Px, 1>(a, smemRaw, sh); break;
+    case 2: subpel_level<Px, 2>(a, smemRaw, sh); break;
+    default: subpel_level<Px, 3>(a, smemRaw, sh); break;
     }
 }
 
@@ -304,10 +337,12 @@ extern "C" int x265hip_subpel_refine(const x265hip_subpel_params* p, void* strea
     a.out = (int2*)p->out;
     const int nctu = a.ctusW * (p->height / 64);
     hipStream_t s = (hipStream_t)stream;
-    // one launch: grid.y = PU level; LDS sized for level 0 (64 patches of 23 x 23), the largest
-    const int pw0 = 8 + 2 * SP_MARGIN + 1;
-    const size_t lds = (size_t)(64 * 64 + 64 * pw0 * pw0) * bpp;
-    static_assert(64 * (8 + 15) * (8 + 15) >= 1 * (64 + 15) * (64 + 15) && 64 * 23 * 23 >= 16 * 31 * 31 && 64 * 23 * 23 >= 4 * 47 * 47, "level 0 is the largest");
+    // one launch: grid.y = PU level; LDS sized for level 0 (64 patches of 23 rows), the largest
+    const size_t lds = (size_t)(bpp == 1 ? SpGeom<uint8_t, 0>::PSZ : SpGeom<uint16_t, 0>::PSZ) * 64 * bpp;
+    static_assert(SpGeom<uint8_t, 0>::PSZ * 64 >= SpGeom<uint8_t, 1>::PSZ * 16 && SpGeom<uint8_t, 0>::PSZ * 64 >= SpGeom<uint8_t, 2>::PSZ * 4
+                  && SpGeom<uint8_t, 0>::PSZ * 64 >= SpGeom<uint8_t, 3>::PSZ, "level 0 is the largest");
+    static_assert(SpGeom<uint16_t, 0>::PSZ * 64 >= SpGeom<uint16_t, 1>::PSZ * 16 && SpGeom<uint16_t, 0>::PSZ * 64 >= SpGeom<uint16_t, 2>::PSZ * 4
+                  && SpGeom<uint16_t, 0>::PSZ * 64 >= SpGeom<uint16_t, 3>::PSZ, "level 0 is the largest");
     if (p->depth == 8)
         hipLaunchKernelGGL(subpel_refine_kernel<uint8_t>, dim3(nctu, 4), dim3(256), lds, s, a);
     else
