@@ -72,11 +72,11 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, target_s=15.0):
                       f"oracle C ({'-march=x86-64-v3' if avx2 else 'generic x86-64'}) with OpenMP over CTUs, {t:.1f} s"}
 
 
-def load_traffic(width, height, rng_r):
+def load_traffic(width, height, rng_r, fmt):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json)."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        e = t.get(f"me_{width}x{height}_r{rng_r}")
+        e = t.get(f"me_{fmt}_{width}x{height}_r{rng_r}")
         return (e["fetch_bytes"] + e["write_bytes"], e["source"]) if e else (None, None)
     except (OSError, ValueError, KeyError):
         return None, None
@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--level", type=int, default=2)           # 32x32 blocks in the reconstruction stage
     ap.add_argument("--qp", type=int, default=27)
     ap.add_argument("--no-surface", action="store_true", help="ME keeps only the best mv (no SAD surfaces)")
+    ap.add_argument("--surf-format", choices=["packed", "i32"], default="packed",
+                    help="SAD surface records: packed = u16 for the 8x8/16x16 levels (X265HIP_SURF_PACKED), i32 = all int32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -120,7 +122,7 @@ def main():
     clip = F.synth_clip(args.width, args.height, nclip, depth=8, seed=265 + rank)
     pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, 8, dev, rng=args.range, subme=args.subme, level=args.level,
-                           qp=args.qp, want_surf=not args.no_surface)
+                           qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed")
     ref_pic = P.DevicePicture.__new__(P.DevicePicture)
     ref_pic.__dict__.update(pics[0].__dict__)
     ref_pic.t = pics[0].t.clone()                    # the reference every rank searches in (starts as frame 0)
@@ -162,7 +164,8 @@ def main():
         A.me_best_reset(ms.best)                  # 4 us fill, outside the timed kernel
         marks[0].record()
         A.me_fullsearch(8, ms.w64, ms.h64, ms.range, cur.t, cur.stride, ref_pic.t, ref_pic.stride, surf=ms.surf, best=ms.best,
-                        cost_x=ms.cost_x, cost_y=ms.cost_y, fenc_off=cur.org, fref_off=ref_pic.org)   # ONE fused launch
+                        cost_x=ms.cost_x, cost_y=ms.cost_y, fenc_off=cur.org, fref_off=ref_pic.org,
+                        surf_format=A.SURF_PACKED if ms.packed else A.SURF_I32)                      # ONE fused launch
         marks[1].record()
         sp.run(cur, ref_pic)
         marks[2].record()
@@ -181,14 +184,14 @@ def main():
         dom = "me"
         alg_bytes = ms.algorithmic_bytes(bpp=1)
         achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9
-        traffic, tsrc = load_traffic(args.width, args.height, args.range) if surf_mode else (None, None)
+        traffic, tsrc = load_traffic(args.width, args.height, args.range, args.surf_format) if surf_mode else (None, None)
         out = {
             "metric": "encoded fps + bit-exact check, 4K preset=slow, 1/2/4/8 MI355X vs host AVX2",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.width}x{args.height} 8-bit (BASELINE configs[1] picture size) closed-loop frame pipeline: "
-                                   f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({'SAD surfaces + ' if surf_mode else ''}best mv) -> "
+                                   f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + args.surf_format + ' records) + ') if surf_mode else ''}best mv) -> "
                                    f"sub-pel subme={args.subme} -> {8 << args.level}x{8 << args.level} prediction + DCT/quant/recon qp {args.qp} -> "
                                    f"border extension -> next reference; pipeline throughput, not HEVC encoded fps",
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world}",
@@ -197,7 +200,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "me_ctu_q_kernel<surf,best>" if surf_mode else "me_ctu_q_kernel<best>",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": stages[dom]},
+                         "algorithmic_bytes_per_launch": alg_bytes, "output_bytes_per_launch": ms.hbm_floor_bytes(1),
+                         "launch_ms": stages[dom]},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F, clip, args.range, args.subme, args.level, args.qp)

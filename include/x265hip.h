@@ -82,6 +82,10 @@ int x265hip_pixelcmp_batch(int kind, int depth, int w, int h,
  *                group holds, for each of the 85 PUs of the CTU, the 4 SADs of its 4 columns - exactly the
  *                res[4] a sad_x4 call on those 4 horizontal displacements returns (motion.cpp:1415-1430).
  *                PU order: [0,64) 8x8, [64,80) 16x16, [80,84) 32x32, [84] 64x64, each level in z-order.
+ *   surf_format: X265HIP_SURF_I32 (default, any depth): the layout above, 1360 bytes per group.
+ *                X265HIP_SURF_PACKED (8-bit only): 720 bytes per (ctu, mvy, group) -
+ *                uint16 [64][4] 8x8 SADs (<= 16320), uint16 [16][4] 16x16 SADs (<= 65280), int32 [4][4] 32x32,
+ *                int32 [1][4] 64x64; same values, 47 % fewer bytes through HBM (the search is write-bound).
  *   best       : optional per-PU minimum of (sad + cost_x[mvx] + cost_y[mvy]), uint64 [ctu][85] (same
  *                PU order) = cost << 32 | (mvy_index * (2*range+1) + mvx_index); must be pre-set to
  *                all-ones by the caller (x265hip_me_best_reset).  Ties resolve to the smallest raster
@@ -99,7 +103,11 @@ typedef struct x265hip_me_params
     uint64_t* best;
     const uint16_t* cost_x;
     const uint16_t* cost_y;
+    int surf_format;                /* X265HIP_SURF_* */
 } x265hip_me_params;
+enum { X265HIP_SURF_I32 = 0, X265HIP_SURF_PACKED = 1 };
+#define X265HIP_SURF_GROUP_BYTES_I32    1360
+#define X265HIP_SURF_GROUP_BYTES_PACKED 720
 int x265hip_me_fullsearch(const x265hip_me_params* p, void* stream);
 int x265hip_me_best_reset(uint64_t* best, size_t count, void* stream);
 

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 pkg = importlib.import_module("x265-yuuki-asuna_amd")
 F = importlib.import_module("x265-yuuki-asuna_amd.frames")
 P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
 
 
 def _oracle():
@@ -26,7 +27,7 @@ def _valid(surf, ms):
     return v[:, :ms.nc, :]
 
 
-def _run(width, height, rng, depth, seed, extreme=None):
+def _run(width, height, rng, depth, seed, extreme=None, packed=False):
     import torch
     dev = torch.device("cuda:0")
     clip = F.synth_clip(width, height, 2, depth=depth, seed=seed)
@@ -34,16 +35,23 @@ def _run(width, height, rng, depth, seed, extreme=None):
     if extreme == "flat":
         y0 = np.zeros_like(y0); y1 = np.full_like(y1, (1 << depth) - 1)
     cur, ref = P.DevicePicture(y1, dev), P.DevicePicture(y0, dev)
-    ms = P.MotionSearch(cur.w64, cur.h64, rng, depth, dev)
+    ms = P.MotionSearch(cur.w64, cur.h64, rng, depth, dev, packed=packed)
     ms.run(cur, ref)
     torch.cuda.synchronize()
     O = _oracle()
     nctu = ms.nctu
     surf, best = O.me_fullsearch(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org,
                                  cur.w64, cur.h64, rng, 0, nctu, ms.cost_host, ms.cost_host)
-    g = _valid(ms.surf.cpu().numpy(), ms)
     e = _valid(surf, ms)
-    assert np.array_equal(g, e), f"SAD surface differs ({np.count_nonzero(g != e)} of {g.size})"
+    if packed:      # X265HIP_SURF_PACKED: same values, u16 records for the 8x8 / 16x16 levels
+        assert ms.surf.numel() * 4 == nctu * ms.nc * ms.ng * 720
+        for level in range(4):
+            b, n = P.LEVEL_BASE[level], P.LEVEL_PUS[level]
+            g = ms.level_view(level)[0].cpu().numpy()
+            assert np.array_equal(g, e[:, :, b:b + n].reshape(-1, n)), f"packed surface level {level} differs"
+    else:
+        g = _valid(ms.surf.cpu().numpy(), ms)
+        assert np.array_equal(g, e), f"SAD surface differs ({np.count_nonzero(g != e)} of {g.size})"
     gb = ms.best.cpu().numpy().view(np.uint64)
     assert np.array_equal(gb, best), f"best differs ({np.count_nonzero(gb != best)} of {gb.size})"
 
@@ -60,6 +68,23 @@ def test_me_non_ctu_multiple_picture():
 def test_me_extremes():
     _run(128, 64, 5, 8, seed=3, extreme="flat")   # all-min vs all-max (TestBench cases [1]/[2])
     _run(64, 64, 5, 10, seed=3, extreme="flat")
+
+
+def test_me_packed_surface_format():
+    _run(128, 128, 8, 8, seed=1, packed=True)
+    _run(200, 136, 12, 8, seed=2, packed=True)
+    _run(128, 64, 5, 8, seed=3, extreme="flat", packed=True)     # 16x16 SAD = 65280: the u16 maximum
+    _run(256, 64, 57, 8, seed=4, packed=True)
+
+
+def test_me_packed_surface_rejected_for_high_bit_depth():
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(64, 64, 2, depth=10, seed=7)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    ms = P.MotionSearch(cur.w64, cur.h64, 4, 10, dev, packed=True)
+    with pytest.raises(A.X265HipError):
+        ms.run(cur, ref)
 
 
 def test_me_default_merange_one_ctu_row():

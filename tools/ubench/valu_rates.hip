@@ -31,6 +31,18 @@ __global__ void k(uint32_t* out, uint32_t seed)
                 if (OP == 5) a[i] = __builtin_amdgcn_sad_hi_u8(a[(i + 1) & 7] | 1, b, a[i]);
                 if (OP == 6) a[i] = __builtin_amdgcn_msad_u8(a[(i + 1) & 7] | 1, b, a[i]);
                 if (OP == 7) a[i] = __builtin_amdgcn_update_dpp(0, (int)a[(i + 1) & 7], 0xB1, 0xF, 0xF, true) + a[i];
+                if (OP == 8) a[i] = __builtin_amdgcn_sdot4((int)a[(i + 1) & 7], (int)b, (int)a[i], false);
+                if (OP == 9) { typedef short v2s __attribute__((ext_vector_type(2)));
+                               a[i] = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a[(i + 1) & 7]), __builtin_bit_cast(v2s, b), (int)a[i], false); }
+                if (OP == 10) a[i] = __mul24((int)a[(i + 1) & 7], (int)b) + a[i];      // v_mad_i32_i24
+                if (OP == 11) a[i] = __builtin_amdgcn_alignbyte(a[(i + 1) & 7], a[i], b);
+                if (OP == 12) a[i] = __builtin_amdgcn_perm(a[(i + 1) & 7], a[i], b);
+                if (OP == 13) a[i] = a[(i + 1) & 7] * b + a[i];                                          // v_mad_u64_u32 / v_mul_lo_u32 + add
+                if (OP == 14) { typedef short v2s __attribute__((ext_vector_type(2)));
+                                v2s x = __builtin_bit_cast(v2s, a[(i + 1) & 7]), y = __builtin_bit_cast(v2s, b), z = __builtin_bit_cast(v2s, a[i]);
+                                a[i] = __builtin_bit_cast(uint32_t, (v2s)(x * y + z)); }                  // v_pk_mad_i16
+                if (OP == 15) a[i] = __builtin_amdgcn_udot4(a[(i + 1) & 7], b, a[i], false);
+                if (OP == 16) a[i] = a[i] + a[(i + 1) & 7] + b;                                          // v_add3_u32
             }
     }
     long long t1 = __builtin_readcyclecounter();
@@ -65,9 +77,13 @@ int main()
         if (th == 256) {
             run<0>("v_sad_u8", 256); run<1>("v_sad_u16", 256); run<2>("v_qsad_pk_u16_u8", 256); run<3>("v_add+xor (2 ops)", 256);
             run<4>("v_alignbit", 256); run<5>("v_sad_hi_u8", 256); run<6>("v_msad_u8", 256); run<7>("dpp add", 256);
+            run<8>("v_dot4_i32_i8", 256); run<9>("v_dot2_i32_i16", 256); run<10>("v_mad_i32_i24", 256); run<11>("v_alignbyte", 256);
+            run<12>("v_perm_b32", 256); run<13>("mul_lo_u32 + add", 256); run<14>("v_pk_mad_i16", 256); run<15>("v_dot4_u32_u8", 256); run<16>("v_add3_u32", 256);
         } else {
             run<0>("v_sad_u8", 1024); run<1>("v_sad_u16", 1024); run<2>("v_qsad_pk_u16_u8", 1024); run<3>("v_add+xor (2 ops)", 1024);
             run<4>("v_alignbit", 1024); run<5>("v_sad_hi_u8", 1024); run<6>("v_msad_u8", 1024); run<7>("dpp add", 1024);
+            run<8>("v_dot4_i32_i8", 1024); run<9>("v_dot2_i32_i16", 1024); run<10>("v_mad_i32_i24", 1024); run<11>("v_alignbyte", 1024);
+            run<12>("v_perm_b32", 1024); run<13>("mul_lo_u32 + add", 1024); run<14>("v_pk_mad_i16", 1024); run<15>("v_dot4_u32_u8", 1024); run<16>("v_add3_u32", 1024);
         }
     }
     return 0;

@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(1024, SURF ? 4 : 8) me_ctu_kernel(MEArgs a)
 // GROUP of 4 mv columns; the 8-deep ring holds 4 packed u16 SADs per slot (an 8x8 SAD is <= 16320).
 // The window is staged so that LDS byte 0 of a row is window column 0 (unaligned global dword loads),
 // which makes column group g start on LDS dword 2*bx + g for every CTU.
-template <bool SURF, bool BEST, int PITCH>
+template <bool SURF, bool BEST, int PITCH, bool PACKED = false>
 __global__ void __launch_bounds__(SURF && BEST ? 512 : 1024, SURF && BEST ? 2 : 4) me_ctu_q_kernel(MEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t win[];
@@ -284,12 +284,17 @@ __global__ void __launch_bounds__(SURF && BEST ? 512 : 1024, SURF && BEST ? 2 : 
     }
     __syncthreads();
 
-    u64 bk8 = ~0ull, bkU = ~0ull;       // running minima: this lane's 8x8 PU, and the ONE upper-level PU it owns (uSel/uOff)
-    // upper-level writers: lane 4q -> 16x16 PU q, lane 16r+1 -> 32x32 PU r, lane 50 (row 3) -> the 64x64 PU
-    const bool uMask = (lane & 3) == 0 || (lane & 15) == 1 || lane == 50;
-    const int uSel = (lane & 3) == 0 ? 0 : ((lane & 15) == 1 ? 1 : 2);
-    const int uOff = uSel == 0 ? 64 + (lane >> 2) : (uSel == 1 ? 80 + (lane >> 4) : 84);
-    const int m16 = uSel == 0 ? -1 : 0, m32 = uSel == 1 ? -1 : 0, m64 = uSel == 2 ? -1 : 0;
+    // Upper PU levels are reduced "transposed": after the packed quad sums, lane (q = lane >> 2, k = lane & 3) keeps
+    // column k of 16x16 PU q; row_ror adds give column k of 32x32 PU (lane >> 4) in every lane of the row, and two
+    // v_permlane{16,32}_swap adds (gfx950) give column k of the 64x64 PU in every lane.  So 84 upper values live in 3
+    // VGPRs, the 16x16 level is one fully coalesced dword store, and every lane folds a single column per level.
+    u64 bk8 = ~0ull, bk16 = ~0ull, bk32 = ~0ull, bk64 = ~0ull;
+    const int kcol = lane & 3;
+    const uint32_t selK = 0x0c0c0000u | (uint32_t)((2 * kcol + 1) << 8) | (uint32_t)(2 * kcol);   // v_perm: u16 #kcol of {qhi, qlo}
+    // one masked dword store covers the 32x32 level (lanes with (lane & 15) < 4) and the 64x64 level (lanes 52..55)
+    const bool is64 = lane >= 52 && lane < 56;
+    const bool uMask = (lane & 15) < 4 || is64;
+    const int uOffDw = is64 ? 84 * 4 + kcol : (80 + (lane >> 4)) * 4 + kcol;
 
     const int T = 2 * R + 8;
     for (int g = wave; g < NG; g += nwaves)
@@ -305,11 +310,13 @@ __global__ void __launch_bounds__(SURF && BEST ? 512 : 1024, SURF && BEST ? 2 : 
                 d[q][0] = lp[0]; d[q][1] = lp[1]; d[q][2] = lp[2];
             }
         };
-        uint32_t cxv[4] = { 0, 0, 0, 0 };
+        uint32_t cxk4[4] = { 0, 0, 0, 0 }, cxL = 0;      // (costX << 2 | k) per column; this lane's own column cost
         if (BEST)
         {
 #pragma unroll
-            for (int k = 0; k < 4; k++) cxv[k] = 4 * g + k < NC ? (uint32_t)a.costX[4 * g + k] : 0x10000000u;   // pad column never wins
+            for (int k = 0; k < 4; k++)
+                cxk4[k] = ((4 * g + k < NC ? (uint32_t)a.costX[4 * g + k] : 0x08000000u) << 2) | (uint32_t)k;   // pad column never wins
+            cxL = 4 * g + kcol < NC ? (uint32_t)a.costX[4 * g + kcol] : 0x08000000u;
         }
         u64 acc[8];
 #pragma unroll
@@ -352,50 +359,58 @@ __global__ void __launch_bounds__(SURF && BEST ? 512 : 1024, SURF && BEST ? 2 : 
                     const uint32_t lo = (uint32_t)A, hi = (uint32_t)(A >> 32);      // columns {0,1} and {2,3}, u16 each
                     // 16x16 = quad sums, still packed (<= 65280 per half: no carry between the halves)
                     const uint32_t qlo = (uint32_t)quad_sum((int)lo), qhi = (uint32_t)quad_sum((int)hi);
-                    int s8[4] = { (int)(lo & 0xffff), (int)(lo >> 16), (int)(hi & 0xffff), (int)(hi >> 16) };
-                    int s16[4] = { (int)(qlo & 0xffff), (int)(qlo >> 16), (int)(qhi & 0xffff), (int)(qhi >> 16) };
-                    int s32[4], s64[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                    {
-                        s32[k] = row_sum_of_quads(s16[k]);
-                        // 64x64: fold the four 16-lane rows with row_bcast; complete in row 3 (lanes 48..63)
-                        int v = s32[k];
-                        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
-                        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
-                        s64[k] = v;
-                    }
-                    // every lane keeps exactly one upper-level value per column: lane 4q the 16x16 PU q, lane 16r+1
-                    // the 32x32 PU r, lane 50 the 64x64 PU (other lanes carry a copy nobody reads)
-                    int sU[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) sU[k] = (s16[k] & m16) | (s32[k] & m32) | (s64[k] & m64);   // branch-free select
+                    const int s8[4] = { (int)(lo & 0xffff), (int)(lo >> 16), (int)(hi & 0xffff), (int)(hi >> 16) };
+                    const int v16 = (int)__builtin_amdgcn_perm(qhi, qlo, selK);      // column kcol of 16x16 PU (lane >> 2)
+                    const int v32 = row_sum_of_quads(v16);                           // column kcol of 32x32 PU (lane >> 4)
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    v2u sw = __builtin_amdgcn_permlane16_swap((unsigned)v32, (unsigned)v32, false, false);
+                    const unsigned h64 = sw.x + sw.y;                                // rows {0,1} / {2,3}
+                    sw = __builtin_amdgcn_permlane32_swap(h64, h64, false, false);
+                    const int v64 = (int)(sw.x + sw.y);                              // column kcol of the 64x64 PU
                     if (SURF)
                     {
                         typedef int v4i __attribute__((ext_vector_type(4)));
-                        v4i* grp = reinterpret_cast<v4i*>(a.surf + (((long)ctu * NC + m) * NG + g) * 340);
-                        const v4i v8 = { s8[0], s8[1], s8[2], s8[3] };
-                        grp[lane] = v8;                                             // 1 KiB per wavefront store
-                        const v4i vU = { sU[0], sU[1], sU[2], sU[3] };
-                        if (uMask) grp[uOff] = vU;
+                        // wave-uniform group base kept in SGPRs; lanes add a 32-bit byte offset (saddr addressing)
+                        const u64 gofs = (u64)((((long)ctu * NC + m) * NG + g) * (PACKED ? 180 : 340)) * 4;
+                        const u64 gsc = ((u64)__builtin_amdgcn_readfirstlane((uint32_t)(gofs >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)gofs);
+                        char* grp = reinterpret_cast<char*>(a.surf) + gsc;
+                        if (PACKED)
+                        {
+                            // the accumulators already ARE the u16[4] records of the 8x8 level
+                            typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+                            const v2u32 v8 = { lo, hi };
+                            *reinterpret_cast<v2u32*>(grp + (uint32_t)(lane * 8)) = v8;                        // 512 B per wavefront
+                            *reinterpret_cast<uint16_t*>(grp + (uint32_t)(512 + lane * 2)) = (uint16_t)v16;    // 16x16 level, 128 B
+                            if (uMask) *reinterpret_cast<int*>(grp + (uint32_t)(640 - 320 * 4 + uOffDw * 4)) = is64 ? v64 : v32;
+                        }
+                        else
+                        {
+                            const v4i v8 = { s8[0], s8[1], s8[2], s8[3] };
+                            *reinterpret_cast<v4i*>(grp + (uint32_t)(lane * 16)) = v8;             // 1 KiB per wavefront store
+                            *reinterpret_cast<int*>(grp + (uint32_t)(1024 + lane * 4)) = v16;      // records 64..79, 256 contiguous bytes
+                            if (uMask) *reinterpret_cast<int*>(grp + (uint32_t)(uOffDw * 4)) = is64 ? v64 : v32;
+                        }
                     }
                     if (BEST)
                     {
                         const uint32_t cy_ = a.costY[m];
                         const uint32_t ibase = (uint32_t)(m * NC + 4 * g);
-                        auto fold = [&](const int (&s)[4], u64& bk)
-                        {
-                            uint32_t kmin = 0xffffffffu;
-#pragma unroll
-                            for (int k = 0; k < 4; k++)
-                            {
-                                const uint32_t key = (((uint32_t)s[k] + cxv[k] + cy_) << 2) | (uint32_t)k;   // cost < 2^28
-                                kmin = key < kmin ? key : kmin;
-                            }
-                            const u64 key64 = ((u64)(kmin >> 2) << 32) | (ibase + (kmin & 3));
-                            bk = key64 < bk ? key64 : bk;
-                        };
-                        fold(s8, bk8); fold(sU, bkU);
+                        {   // 8x8: min over the 4 columns of (sad << 2) + (costX << 2 | k); costY is common, added after
+                            const uint32_t k0 = ((uint32_t)s8[0] << 2) + cxk4[0], k1 = ((uint32_t)s8[1] << 2) + cxk4[1];
+                            const uint32_t k2 = ((uint32_t)s8[2] << 2) + cxk4[2], k3 = ((uint32_t)s8[3] << 2) + cxk4[3];
+                            uint32_t kmin = k0 < k1 ? k0 : k1;
+                            kmin = k2 < kmin ? k2 : kmin;
+                            kmin = k3 < kmin ? k3 : kmin;
+                            const u64 key64 = ((u64)((kmin >> 2) + cy_) << 32) | (ibase + (kmin & 3));
+                            bk8 = key64 < bk8 ? key64 : bk8;
+                        }
+                        const uint32_t cxy = cxL + cy_, idxL = ibase + (uint32_t)kcol;
+                        const u64 k16 = ((u64)((uint32_t)v16 + cxy) << 32) | idxL;
+                        const u64 k32 = ((u64)((uint32_t)v32 + cxy) << 32) | idxL;
+                        const u64 k64 = ((u64)((uint32_t)v64 + cxy) << 32) | idxL;
+                        bk16 = k16 < bk16 ? k16 : bk16;
+                        bk32 = k32 < bk32 ? k32 : bk32;
+                        bk64 = k64 < bk64 ? k64 : bk64;
                     }
                 }
                 if (PIPE && (p & 1))
@@ -426,7 +441,9 @@ __global__ void __launch_bounds__(SURF && BEST ? 512 : 1024, SURF && BEST ? 2 : 
     {
         u64* rec = a.best + (size_t)ctu * 85;
         atomicMin(&rec[lane], bk8);
-        if (uMask) atomicMin(&rec[uOff], bkU);
+        atomicMin(&rec[64 + (lane >> 2)], bk16);           // the 4 column lanes of a 16x16 PU merge here
+        if ((lane & 15) < 4) atomicMin(&rec[80 + (lane >> 4)], bk32);
+        if (lane < 4) atomicMin(&rec[84], bk64);
     }
 }
 
@@ -454,6 +471,7 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     a.rowBytes = pitchDw * 4;
     a.surf = p->surf; a.best = (unsigned long long*)p->best;
     const bool anySurf = p->surf != nullptr, anyBest = p->best != nullptr;
+    const bool packed = anySurf && p->surf_format == X265HIP_SURF_PACKED;
     a.costX = p->cost_x; a.costY = p->cost_y;
     const int nctu = a.ctusW * (p->height / 64);
     const size_t lds = (size_t)a.rowBytes * (64 + 2 * p->range + 2);     // + 2 rows the pipeline may prefetch past the window
@@ -471,8 +489,9 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     {
         // 8-bit fast path (v_qsad_pk_u16_u8); 2 * range + 75 bytes of window row must fit the 256-byte pitch
 #define LAUNCH_Q(SF, BS, MAXW) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > (MAXW)) nwq = (MAXW); \
-        hipLaunchKernelGGL((me_ctu_q_kernel<SF, BS, 256>), grid, dim3(nwq * 64), lds, s, a); } while (0)
-        // Both outputs: ONE fused launch.  It needs ~180 VGPRs, so its workgroup is 8 wavefronts (2 per SIMD,
+        if (packed) hipLaunchKernelGGL((me_ctu_q_kernel<SF, BS, 256, SF>), grid, dim3(nwq * 64), lds, s, a); \
+        else hipLaunchKernelGGL((me_ctu_q_kernel<SF, BS, 256, false>), grid, dim3(nwq * 64), lds, s, a); } while (0)
+        // Both outputs: ONE fused launch.  It needs ~170 VGPRs, so its workgroup is 8 wavefronts (2 per SIMD,
         // 256-VGPR budget) instead of 16; the qsad chains carry enough ILP to keep the VALU busy at that occupancy.
         // X265HIP_ME_SPLIT forces the older surfaces-then-minima pair of launches (A/B measurements).
         if (anySurf && anyBest && !getenv("X265HIP_ME_SPLIT")) LAUNCH_Q(true, true, 8);
@@ -483,6 +502,7 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
         }
 #undef LAUNCH_Q
     }
+    else if (packed) { set_error("me_fullsearch: X265HIP_SURF_PACKED needs depth 8 and 2 * range + 75 <= 256"); return X265HIP_EINVAL; }
     else if (anySurf && anyBest) LAUNCH(true, true);
     else if (anySurf) LAUNCH(true, false);
     else LAUNCH(false, true);
@@ -516,6 +536,7 @@ extern "C" int x265hip_me_fullsearch(const x265hip_me_params* p, void* stream)
     { set_error("me_fullsearch: plane strides must be multiples of 4 bytes and fenc 4-byte aligned"); return X265HIP_EINVAL; }
     const bool anyBest = p->best != nullptr;
     if (!p->surf && !p->best) { set_error("me_fullsearch: no output requested"); return X265HIP_EINVAL; }
+    if (p->surf_format != X265HIP_SURF_I32 && p->surf_format != X265HIP_SURF_PACKED) { set_error("me_fullsearch: surf_format %d", p->surf_format); return X265HIP_EINVAL; }
     if (anyBest && (!p->cost_x || !p->cost_y)) { set_error("me_fullsearch: best[] needs cost_x / cost_y"); return X265HIP_EINVAL; }
     if (p->depth == 8) return launch_me<uint8_t>(p, (hipStream_t)stream);
     return launch_me<uint16_t>(p, (hipStream_t)stream);

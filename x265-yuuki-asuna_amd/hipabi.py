@@ -29,7 +29,12 @@ class MEParams(ctypes.Structure):
         ("fref", ctypes.c_void_p), ("fref_stride", ctypes.c_ssize_t),
         ("surf", ctypes.c_void_p), ("best", ctypes.c_void_p),
         ("cost_x", ctypes.c_void_p), ("cost_y", ctypes.c_void_p),
+        ("surf_format", ctypes.c_int),
     ]
+
+
+SURF_I32, SURF_PACKED = 0, 1
+SURF_GROUP_BYTES_I32, SURF_GROUP_BYTES_PACKED = 1360, 720
 
 
 class SubpelParams(ctypes.Structure):
@@ -88,10 +93,11 @@ def _p(t):
 
 def me_fullsearch(depth, width, height, rng, fenc, fenc_stride, fref, fref_stride,
                   surf=None, best=None, cost_x=None, cost_y=None,
-                  fenc_off=0, fref_off=0, stream=None):
+                  fenc_off=0, fref_off=0, stream=None, surf_format=SURF_I32):
     """fenc/fref: torch tensors holding the planes; *_off = element offset of pixel (0,0)."""
     es = 1 if depth == 8 else 2
     p = MEParams()
+    p.surf_format = surf_format
     p.depth, p.width, p.height, p.range = depth, width, height, rng
     p.fenc, p.fenc_stride = fenc.data_ptr() + fenc_off * es, fenc_stride
     p.fref, p.fref_stride = fref.data_ptr() + fref_off * es, fref_stride

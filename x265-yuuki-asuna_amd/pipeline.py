@@ -41,17 +41,20 @@ class MotionSearch:
     """Owns the output buffers of the ME stage for one picture size.
 
     surf : int32 [ctu][mvy][mvx/4][85][4]  (85 = 64 8x8 + 16 16x16 + 4 32x32 + 1 64x64 PUs, z-order;
-           mv columns in groups of 4, last group padded - the pad column holds unspecified values)
+           mv columns in groups of 4, last group padded - the pad column holds unspecified values);
+           packed=True (8-bit): 720-byte groups, uint16 for the 8x8 / 16x16 levels (X265HIP_SURF_PACKED)
     best : int64 [ctu][85]            cost << 32 | raster mv index
     """
 
-    def __init__(self, w64, h64, rng, depth, device, want_surf=True, want_best=True, lam=4.0):
+    def __init__(self, w64, h64, rng, depth, device, want_surf=True, want_best=True, lam=4.0, packed=False):
         import torch
         self.w64, self.h64, self.range, self.depth = w64, h64, rng, depth
         self.nctu = (w64 // 64) * (h64 // 64)
         self.nc = 2 * rng + 1
         self.ng = (self.nc + 3) // 4
-        self.surf = torch.zeros(self.nctu * self.nc * self.ng * PUS_PER_CTU * 4, dtype=torch.int32, device=device) if want_surf else None
+        self.packed = bool(packed and want_surf)
+        self.group_bytes = hipabi.SURF_GROUP_BYTES_PACKED if self.packed else hipabi.SURF_GROUP_BYTES_I32
+        self.surf = torch.zeros(self.nctu * self.nc * self.ng * self.group_bytes // 4, dtype=torch.int32, device=device) if want_surf else None
         self.best = torch.empty(self.nctu * PUS_PER_CTU, dtype=torch.int64, device=device) if want_best else None
         cost = F.mv_cost_table(rng, lam)
         self.cost_host = cost
@@ -84,14 +87,26 @@ class MotionSearch:
         hipabi.me_fullsearch(self.depth, self.w64, self.h64, self.range,
                              cur.t, cur.stride, ref.t, ref.stride,
                              surf=self.surf, best=self.best, cost_x=self.cost_x, cost_y=self.cost_y,
-                             fenc_off=cur.org, fref_off=ref.org)
+                             fenc_off=cur.org, fref_off=ref.org,
+                             surf_format=hipabi.SURF_PACKED if self.packed else hipabi.SURF_I32)
 
     def level_view(self, level):
         """(surface view [nmv, npu], best view [nctu, npu]) of one PU level."""
         b, n = LEVEL_BASE[level], LEVEL_PUS[level]
         sv = None
         if self.surf is not None:      # [ctu*mvy, group, pu, col] -> [ctu*mvy, mvx, pu] with the pad column dropped
-            g = self.surf.view(self.nctu * self.nc, self.ng, PUS_PER_CTU, 4)[:, :, b:b + n, :]
+            if self.packed:
+                import torch
+                raw = self.surf.view(torch.uint8).view(self.nctu * self.nc, self.ng, self.group_bytes)
+                if level < 2:          # uint16 records at byte 0 (8x8) / 512 (16x16)
+                    o = 0 if level == 0 else 512
+                    g = raw[:, :, o:o + n * 8].contiguous().view(torch.int16).to(torch.int32) & 0xffff
+                else:                  # int32 records at byte 640 (32x32) / 704 (64x64)
+                    o = 640 if level == 2 else 704
+                    g = raw[:, :, o:o + n * 16].contiguous().view(torch.int32)
+                g = g.view(self.nctu * self.nc, self.ng, n, 4)
+            else:
+                g = self.surf.view(self.nctu * self.nc, self.ng, PUS_PER_CTU, 4)[:, :, b:b + n, :]
             sv = g.permute(0, 1, 3, 2).reshape(self.nctu * self.nc, self.ng * 4, n)[:, :self.nc, :].reshape(-1, n)
         bv = self.best.view(-1, PUS_PER_CTU)[:, b:b + n] if self.best is not None else None
         return sv, bv

@@ -78,11 +78,11 @@ class FramePipeline:
         ME (exhaustive, SAD surfaces and/or best mv) -> sub-pel refinement -> prediction + residual round trip
         (NxN blocks) -> border extension -> the reconstruction becomes the next reference."""
 
-    def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True):
+    def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False):
         import torch
         from .pipeline import MotionSearch, SubpelRefine
         self.depth = depth
-        self.ms = MotionSearch(w64, h64, rng, depth, device, want_surf=want_surf, want_best=True)
+        self.ms = MotionSearch(w64, h64, rng, depth, device, want_surf=want_surf, want_best=True, packed=packed)
         self.sp = SubpelRefine(self.ms, subme, device)
         self.rc = InterRecon(self.ms.nctu, w64, h64, depth, level, qp, device)
         self.recon = None
