@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(1024, SURF ? 4 : 8) me_ctu_kernel(MEArgs a)
 // The window is staged so that LDS byte 0 of a row is window column 0 (unaligned global dword loads),
 // which makes column group g start on LDS dword 2*bx + g for every CTU.
 template <bool SURF, bool BEST, int PITCH, bool PACKED = false>
-__global__ void __launch_bounds__(SURF && BEST ? 512 : 1024, SURF && BEST ? 2 : 4) me_ctu_q_kernel(MEArgs a)
+__global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 4) me_ctu_q_kernel(MEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t win[];
     typedef unsigned long long u64;
@@ -310,13 +310,18 @@ __global__ void __launch_bounds__(SURF && BEST ? 512 : 1024, SURF && BEST ? 2 : 
                 d[q][0] = lp[0]; d[q][1] = lp[1]; d[q][2] = lp[2];
             }
         };
+        // Row-local 32-bit keys: inside one column group only the row m varies, so `cost << 10 | m << 2 | k` (8x8,
+        // cost < 2^17) and `cost << 8 | m` (upper levels, cost < 2^22; m < 256) order candidates exactly like
+        // (cost, raster index); they are widened and merged into the 64-bit running minima once per group.
+        // Pad columns (>= 2R+1) get a cost offset no real candidate reaches.
         uint32_t cxk4[4] = { 0, 0, 0, 0 }, cxL = 0;      // (costX << 2 | k) per column; this lane's own column cost
+        uint32_t r8 = 0xffffffffu, r16 = 0xffffffffu, r32 = 0xffffffffu, r64 = 0xffffffffu;
         if (BEST)
         {
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                cxk4[k] = ((4 * g + k < NC ? (uint32_t)a.costX[4 * g + k] : 0x08000000u) << 2) | (uint32_t)k;   // pad column never wins
-            cxL = 4 * g + kcol < NC ? (uint32_t)a.costX[4 * g + kcol] : 0x08000000u;
+                cxk4[k] = ((4 * g + k < NC ? (uint32_t)a.costX[4 * g + k] : (1u << 20)) << 2) | (uint32_t)k;
+            cxL = 4 * g + kcol < NC ? (uint32_t)a.costX[4 * g + kcol] : (1u << 23);
         }
         u64 acc[8];
 #pragma unroll
@@ -394,23 +399,24 @@ __global__ void __launch_bounds__(SURF && BEST ? 512 : 1024, SURF && BEST ? 2 : 
                     if (BEST)
                     {
                         const uint32_t cy_ = a.costY[m];
-                        const uint32_t ibase = (uint32_t)(m * NC + 4 * g);
-                        {   // 8x8: min over the 4 columns of (sad << 2) + (costX << 2 | k); costY is common, added after
+                        {   // 8x8: min over the 4 columns of (sad << 2) + (costX << 2 | k); costY is common to the row
                             const uint32_t k0 = ((uint32_t)s8[0] << 2) + cxk4[0], k1 = ((uint32_t)s8[1] << 2) + cxk4[1];
                             const uint32_t k2 = ((uint32_t)s8[2] << 2) + cxk4[2], k3 = ((uint32_t)s8[3] << 2) + cxk4[3];
                             uint32_t kmin = k0 < k1 ? k0 : k1;
                             kmin = k2 < kmin ? k2 : kmin;
                             kmin = k3 < kmin ? k3 : kmin;
-                            const u64 key64 = ((u64)((kmin >> 2) + cy_) << 32) | (ibase + (kmin & 3));
-                            bk8 = key64 < bk8 ? key64 : bk8;
+                            const uint32_t rowc = (cy_ << 10) | ((uint32_t)m << 2);
+                            uint32_t key = ((kmin & ~3u) << 8) + rowc;                   // cost << 10 | m << 2
+                            key = (key & ~3u) | (kmin & 3u);                             // | k  (v_bfi)
+                            r8 = key < r8 ? key : r8;
                         }
-                        const uint32_t cxy = cxL + cy_, idxL = ibase + (uint32_t)kcol;
-                        const u64 k16 = ((u64)((uint32_t)v16 + cxy) << 32) | idxL;
-                        const u64 k32 = ((u64)((uint32_t)v32 + cxy) << 32) | idxL;
-                        const u64 k64 = ((u64)((uint32_t)v64 + cxy) << 32) | idxL;
-                        bk16 = k16 < bk16 ? k16 : bk16;
-                        bk32 = k32 < bk32 ? k32 : bk32;
-                        bk64 = k64 < bk64 ? k64 : bk64;
+                        const uint32_t cxy = cxL + cy_;
+                        const uint32_t k16 = (((uint32_t)v16 + cxy) << 8) | (uint32_t)m;
+                        const uint32_t k32 = (((uint32_t)v32 + cxy) << 8) | (uint32_t)m;
+                        const uint32_t k64 = (((uint32_t)v64 + cxy) << 8) | (uint32_t)m;
+                        r16 = k16 < r16 ? k16 : r16;
+                        r32 = k32 < r32 ? k32 : r32;
+                        r64 = k64 < r64 ? k64 : r64;
                     }
                 }
                 if (PIPE && (p & 1))
@@ -434,6 +440,16 @@ __global__ void __launch_bounds__(SURF && BEST ? 512 : 1024, SURF && BEST ? 2 : 
         case 4: rows8(std::false_type{}, std::integral_constant<int, 4>{}, t0); break;
         case 6: rows8(std::false_type{}, std::integral_constant<int, 6>{}, t0); break;
         default: break;
+        }
+        if (BEST)
+        {   // widen the group's row-local keys to cost << 32 | raster index and merge
+            const u64 w8 = ((u64)(r8 >> 10) << 32) | (uint32_t)(((r8 >> 2) & 255u) * NC + 4 * g + (r8 & 3u));
+            bk8 = w8 < bk8 ? w8 : bk8;
+            auto widen = [&](const uint32_t r) { return ((u64)(r >> 8) << 32) | (uint32_t)((r & 255u) * NC + 4 * g + kcol); };
+            const u64 w16 = widen(r16), w32 = widen(r32), w64 = widen(r64);
+            bk16 = w16 < bk16 ? w16 : bk16;
+            bk32 = w32 < bk32 ? w32 : bk32;
+            bk64 = w64 < bk64 ? w64 : bk64;
         }
     }
 
@@ -494,7 +510,7 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
         // Both outputs: ONE fused launch.  It needs ~170 VGPRs, so its workgroup is 8 wavefronts (2 per SIMD,
         // 256-VGPR budget) instead of 16; the qsad chains carry enough ILP to keep the VALU busy at that occupancy.
         // X265HIP_ME_SPLIT forces the older surfaces-then-minima pair of launches (A/B measurements).
-        if (anySurf && anyBest && !getenv("X265HIP_ME_SPLIT")) LAUNCH_Q(true, true, 8);
+        if (anySurf && anyBest && !getenv("X265HIP_ME_SPLIT")) LAUNCH_Q(true, true, 12);
         else
         {
             if (anySurf) LAUNCH_Q(true, false, 16);
