@@ -48,7 +48,7 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, target_s=15.0):
     cost = F.mv_cost_table(rng_r)
     cq, qoff = F.qpel_cost_table(rng_r)
     nctu = (w64 // 64) * (h64 // 64)
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
 
     def run(n):
         t = time.perf_counter()
@@ -69,7 +69,21 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, target_s=15.0):
         reps += 1
     return {"value": round(reps * (n / nctu) / t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{reps} x {n} of {nctu} CTUs of a 1080p frame through the same stages (search keeps only the best mv), "
-                      f"oracle C ({'-march=x86-64-v3' if avx2 else 'generic x86-64'}) with OpenMP over CTUs, {t:.1f} s"}
+                      f"oracle C ({'-march=x86-64-v3' if avx2 else 'generic x86-64'}) with OpenMP over CTUs on {cores} threads "
+                      f"(the container's CPU quota; {os.cpu_count()} hardware threads visible), {t:.1f} s"}
+
+
+def effective_cpus():
+    """CPUs this process may actually use: scheduler affinity capped by the cgroup CPU quota (cpu.max) - more OpenMP
+    threads than that only get throttled."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def load_traffic(width, height, rng_r, fmt):

@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
-"""Per-family throughput of the batch-layer kernels on one MI355X (inputs resident in HBM).
+"""Per-family throughput of the batch-layer kernels on one MI355X, with the CPU path timed beside each
+(primitive level).
 
-For every family: N blocks per launch, HIP-event time per launch, algorithmic bytes per block as defined in
-SURVEY.md section 8(d), achieved GB/s and the fraction of the 8 TB/s HBM peak; for the MFMA transforms also
-int8 TOPS (4*N^3 MACs per block incl. the two 8-bit limbs) against the 5 POPS dense int8 peak.
-Prints a table; `> profiles/rNN_prims.txt` keeps it."""
+For every family: N blocks per launch (inputs resident in HBM), HIP-event time per launch, algorithmic bytes per block
+as defined in SURVEY.md section 8(d), achieved GB/s and the fraction of the 8 TB/s HBM peak.  The CPU columns run the
+SAME job list through (a) the real reference C primitive from oracle/_ref (when that build travelled to this box) and
+(b) the oracle's AVX2-compiled restatement, OpenMP over jobs on all host cores (oracle/x265_oracle_bench.c).
+For the MFMA transforms also int8 TOPS (4*N^3 MACs per block x 2 limbs) against the 5 POPS dense int8 peak.
+
+    python tools/bench_prims.py > profiles/rNN_prims.txt
+"""
+import ctypes
 import importlib
 import os
 import sys
@@ -13,10 +19,20 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+spec = importlib.import_module("x265-yuuki-asuna_amd.table_spec")
+import harness as H  # noqa: E402  (TEST INFRASTRUCTURE: table loaders for the CPU columns)
 
 HBM = 8000.0
 I8_PEAK_TOPS = 5000.0
+(SIG_PIXELCMP, SIG_SAD_X4, SIG_FILTER, SIG_FILTER_HPS, SIG_FILTER_HV, SIG_P2S, SIG_DCT, SIG_QUANT, SIG_NQUANT,
+ SIG_DEQUANT_NORMAL, SIG_INTRA_PRED, SIG_INTRA_ALLANGS, SIG_COPY, SIG_SUB_PS, SIG_ADD_PS, SIG_ADDAVG, SIG_SAO_E0,
+ SIG_SAO_B0, SIG_DEBLOCK_LUMA, SIG_VAR, SIG_CALCRES) = range(21)
+
+
+class BPlane(ctypes.Structure):
+    _fields_ = [("base", ctypes.c_void_p), ("stride", ctypes.c_ssize_t), ("elem", ctypes.c_int)]
 
 
 def timeit(fn, iters=10):
@@ -32,73 +48,242 @@ def timeit(fn, iters=10):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def row(name, njobs, t, bytes_per_job, extra=""):
-    gbs = njobs * bytes_per_job / t / 1e9
-    print(f"{name:44s} {njobs:9d} {t * 1e6:10.1f} {bytes_per_job:9d} {gbs:10.1f} {gbs / HBM:7.3f} {extra}")
+def jobs_np(n, offs=(), args=()):
+    """offs / args: sequences of scalars or length-n arrays -> numpy array of x265hip_job records."""
+    arr = np.zeros(n, dtype=A.job_dtype())
+    for k, o in enumerate(offs):
+        arr["off"][:, k] = o
+    for k, a in enumerate(args):
+        arr["arg"][:, k] = a
+    return arr
+
+
+def to_dev(a, dev):
+    import torch
+    if a.dtype == np.uint16:
+        a = a.view(np.int16)
+    if a.dtype == np.uint32:
+        a = a.view(np.int32)
+    return torch.from_numpy(a).to(dev)
+
+
+def jobs_dev(arr, dev):
+    import torch
+    return torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(dev)
+
+
+class CPU:
+    """The CPU columns: the reference build's table (if present) and the oracle's AVX2 flavour, timed by
+    x265oracle_time_jobs over the same job list."""
+
+    def __init__(self):
+        self.lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libx265oracle_avx2.so"))
+        self.lib.x265oracle_time_jobs.restype = ctypes.c_double
+        self.lib.x265oracle_time_jobs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        sys.path.insert(0, ROOT)
+        from bench import effective_cpus
+        self.threads = effective_cpus()        # cgroup CPU quota, not the socket's thread count
+        self.port = H.load_oracle(8, ROOT, avx2=True)
+        self.ref = H.load_reference(8, ROOT)
+
+    def time(self, table, path, sig, planes, jobs, reps=2):
+        fn = table.ptr(path)
+        if not fn:
+            return None
+        pl = (BPlane * 4)()
+        keep = []
+        for i, (arr, stride) in enumerate(planes):
+            if arr is None:
+                continue
+            arr = arr.copy()                 # in-place primitives must not disturb the GPU's input
+            keep.append(arr)
+            pl[i] = BPlane(arr.ctypes.data, stride, arr.itemsize)
+        j = np.ascontiguousarray(jobs)
+        t1 = self.lib.x265oracle_time_jobs(fn, sig, ctypes.byref(pl), j.ctypes.data, len(j), 1, self.threads, None)
+        reps = int(min(200, max(3, 0.25 / max(t1, 1e-6))))            # ~0.25 s of CPU work per measurement
+        return self.lib.x265oracle_time_jobs(fn, sig, ctypes.byref(pl), j.ctypes.data, len(j), reps, self.threads, None)
+
+
+def pu_index(w, h):
+    return next(i for i in range(25) if spec.pu_dims(i) == (w, h))
+
+
+HEADER = (f"{'kernel (8-bit unless noted)':40s} {'blocks':>8s} {'GPU us':>9s} {'B/blk':>7s} {'GPU GB/s':>9s} {'frac':>6s} "
+          f"{'ref-C GB/s':>10s} {'port GB/s':>10s} {'GPU/CPU':>8s}  notes")
+
+
+def report(cpu, name, n, t_gpu, bpj, path, sig, planes, jobs, extra=""):
+    gbs = n * bpj / t_gpu / 1e9
+    cols = []
+    best = None
+    for tab in (cpu.ref, cpu.port):
+        t = cpu.time(tab, path, sig, planes, jobs) if tab is not None else None
+        cols.append(f"{n * bpj / t / 1e9:10.1f}" if t else f"{'-':>10s}")
+        if t and (best is None or t < best):
+            best = t
+    ratio = f"{best / t_gpu:8.1f}" if best else f"{'-':>8s}"
+    print(f"{name:40s} {n:8d} {t_gpu * 1e6:9.1f} {bpj:7d} {gbs:9.1f} {gbs / HBM:6.3f} {cols[0]} {cols[1]} {ratio}  {extra}", flush=True)
 
 
 def main():
     import torch
     dev = "cuda:0"
     rng = np.random.default_rng(5)
-    print(f"{'kernel (8-bit unless noted)':44s} {'blocks':>9s} {'us/launch':>10s} {'B/block':>9s} {'GB/s':>10s} {'frac':>7s}")
+    cpu = CPU()
+    print(f"# host CPU columns: {cpu.threads} OpenMP threads (= the container's CPU quota; {os.cpu_count()} hardware threads visible); ref-C = real reference C primitives (oracle/_ref, g++ -O2, "
+          f"{'present' if cpu.ref is not None else 'ABSENT on this box'}); port = oracle restatement, gcc -O3 -march=x86-64-v3")
+    print(HEADER)
 
-    # ---- pixel compare on a 4K frame: random candidate positions (fenc blocks at stride 64 like motion.cpp) ----
     W, Hh, st = 3840, 2176, 4032
-    ref = torch.from_numpy(rng.integers(0, 256, size=st * (Hh + 160), dtype=np.uint8)).to(dev)
-    for kind, name in ((A.CMP_SAD, "sad"), (A.CMP_SATD, "satd"), (A.CMP_SA8D, "sa8d")):
+    ref_h = rng.integers(0, 256, size=st * (Hh + 160), dtype=np.uint8)
+    ref_d = to_dev(ref_h, dev)
+
+    # ---- a1 / a4 / a5 / a6: block compare on a 4K plane, random candidate positions, fenc blocks at stride 64 ----
+    for kind, name, grp in ((A.CMP_SAD, "sad", "pu"), (A.CMP_SATD, "satd", "pu"), (A.CMP_SA8D, "sa8d", "cu"),
+                            (A.CMP_SSE_PP, "sse_pp", "cu"), (A.CMP_PSY_COST, "psy_cost_pp", "cu")):
         for w in (8, 16, 32, 64):
-            if kind == A.CMP_SA8D and w < 8:
+            if name in ("sse_pp", "psy_cost_pp") and w not in (16, 32):
                 continue
-            n = 1 << 20 if w <= 16 else 1 << 18
-            fenc = torch.from_numpy(rng.integers(0, 256, size=n * 64 + 64 * 64, dtype=np.uint8)).to(dev)
-            aoff = torch.arange(n, dtype=torch.int64, device=dev) * 64 % (n * 64 - 64 * 64)
-            boff = torch.from_numpy((rng.integers(80, Hh - 80, size=n) * st + rng.integers(96, W - 96, size=n)).astype(np.int64)).to(dev)
+            n = 1 << 18 if w <= 16 else 1 << 16
+            fenc_h = rng.integers(0, 256, size=n * 64 + 64 * 64, dtype=np.uint8)
+            aoff = (np.arange(n, dtype=np.int64) * 64) % (n * 64 - 64 * 64)
+            boff = (rng.integers(80, Hh - 80, size=n) * st + rng.integers(96, W - 96, size=n)).astype(np.int64)
+            fenc_d, ao, bo = to_dev(fenc_h, dev), to_dev(aoff, dev), to_dev(boff, dev)
             out = torch.zeros(n, dtype=torch.int64, device=dev)
-            t = timeit(lambda: A.pixelcmp_batch(kind, 8, w, w, fenc, 64, ref, st, n, out, a_off=aoff, b_off=boff))
-            row(f"pixelcmp {name} {w}x{w}", n, t, 2 * w * w + 8)
+            t = timeit(lambda: A.pixelcmp_batch(kind, 8, w, w, fenc_d, 64, ref_d, st, n, out, a_off=ao, b_off=bo))
+            path = f"pu[{pu_index(w, w)}].{name}" if grp == "pu" else f"cu[{int(np.log2(w)) - 2}].{name}"
+            report(cpu, f"{name} {w}x{w}", n, t, 2 * w * w + 8, path, SIG_PIXELCMP, [(fenc_h, 64), (ref_h, st)],
+                   jobs_np(n, (aoff, boff)), "random positions: each row of a block is its own DRAM sector" if w == 8 and name == "sad" else "")
 
-    # ---- interpolation: hvpp 16x16 / 64x64 luma ----
+    # ---- a11: interpolation ----
+    def interp_case(kind, kname, slot, sig, w, taps, dst_dtype, src_short=False, bpj=None):
+        n = 1 << 16 if w <= 16 else 1 << 14
+        src_h = ref_h if not src_short else rng.integers(-8192, 8192, size=st * (Hh + 160)).astype(np.int16)
+        src_d = ref_d if not src_short else to_dev(src_h, dev)
+        off0 = (rng.integers(80, Hh - 80, size=n) * st + rng.integers(96, W - 96, size=n)).astype(np.int64)
+        rows = w + (taps - 1 if kind == A.IP_HPS else 0)
+        off1 = np.arange(n, dtype=np.int64) * w * rows
+        nidx = 4 if taps == 8 else 8
+        a0, a1 = rng.integers(1, nidx, size=n), (np.ones(n, np.int64) if kind == A.IP_HPS else rng.integers(1, nidx, size=n))
+        jb = jobs_np(n, (off0, off1), (a0, a1))
+        jd = jobs_dev(jb, dev)
+        dst_h = np.zeros(n * w * rows, dtype=dst_dtype)
+        dst_d = to_dev(dst_h, dev)
+        t = timeit(lambda: A.interp_batch(kind, 8, taps, w, w, A.plane(src_d, st), A.plane(dst_d, w), jd, n))
+        pu = pu_index(w, w) if taps == 8 else pu_index(2 * w, 2 * w)
+        path = f"pu[{pu}].{slot}" if taps == 8 else f"chroma[1].pu[{pu}].{slot}"
+        es, ed = src_h.itemsize, dst_h.itemsize
+        if bpj is None:
+            ap = taps - 1
+            hor = kind in (A.IP_HPP, A.IP_HPS, A.IP_HVPP)
+            ver = kind in (A.IP_VPP, A.IP_VPS, A.IP_VSP, A.IP_VSS, A.IP_HVPP) or kind == A.IP_HPS
+            bpj = (w + (ap if hor else 0)) * (w + (ap if ver else 0)) * es + w * rows * ed
+        report(cpu, f"{'luma' if taps == 8 else 'chroma'} {kname} {w}x{w}", n, t, bpj, path, sig,
+               [(src_h, st), (dst_h, w)], jb)
+
     for w in (16, 64):
-        n = 1 << 18 if w == 16 else 1 << 15
-        jobs = A.make_jobs([([int(y) * st + int(x), j * w * w], [int(ix), int(iy)]) for j, (y, x, ix, iy) in
-                            enumerate(zip(rng.integers(80, Hh - 80, size=n), rng.integers(96, W - 96, size=n),
-                                          rng.integers(1, 4, size=n), rng.integers(1, 4, size=n)))], dev)
-        dst = torch.zeros(n * w * w, dtype=torch.uint8, device=dev)
-        t = timeit(lambda: A.interp_batch(A.IP_HVPP, 8, 8, w, w, A.plane(ref, st), A.plane(dst, w), jobs, n))
-        row(f"interp luma_hvpp {w}x{w}", n, t, (w + 7) * (w + 7) + w * w)
+        interp_case(A.IP_HPP, "hpp", "luma_hpp", SIG_FILTER, w, 8, np.uint8)
+        interp_case(A.IP_VPP, "vpp", "luma_vpp", SIG_FILTER, w, 8, np.uint8)
+        interp_case(A.IP_HVPP, "hvpp", "luma_hvpp", SIG_FILTER_HV, w, 8, np.uint8)
+    interp_case(A.IP_HPS, "hps(+rows)", "luma_hps", SIG_FILTER_HPS, 16, 8, np.int16)
+    interp_case(A.IP_VSP, "vsp", "luma_vsp", SIG_FILTER, 16, 8, np.uint8, src_short=True)
+    interp_case(A.IP_VSS, "vss", "luma_vss", SIG_FILTER, 16, 8, np.int16, src_short=True)
+    interp_case(A.IP_HPP, "hpp", "filter_hpp", SIG_FILTER, 8, 4, np.uint8)
+    interp_case(A.IP_VPP, "vpp", "filter_vpp", SIG_FILTER, 8, 4, np.uint8)
+    interp_case(A.IP_P2S, "p2s", "convert_p2s[0]", SIG_P2S, 32, 8, np.int16, bpj=32 * 32 * 3)
 
-    # ---- transforms: VALU vs MFMA ----
-    for n_ in (16, 32):
-        nb = 1 << 17
-        src = torch.from_numpy(rng.integers(-255, 256, size=nb * n_ * n_, dtype=np.int16)).to(dev)
-        dst = torch.zeros(nb * n_ * n_, dtype=torch.int16, device=dev)
-        jobs = A.make_jobs([([j * n_ * n_, j * n_ * n_], []) for j in range(nb)], dev)
+    # ---- a7: transforms, VALU vs MFMA ----
+    for n_ in (4, 8, 16, 32):
+        nb = 1 << 16
+        src_h = rng.integers(-255, 256, size=nb * n_ * n_, dtype=np.int16)
+        dst_h = np.zeros(nb * n_ * n_, np.int16)
+        src_d, dst_d = to_dev(src_h, dev), to_dev(dst_h, dev)
+        off = np.arange(nb, dtype=np.int64) * n_ * n_
         for kind, kname in ((A.TR_DCT, "dct"), (A.TR_IDCT, "idct")):
-            for mf in (0, 1):
-                t = timeit(lambda: A.transform_batch(kind, 8, n_, A.plane(src, n_), A.plane(dst, n_), jobs, nb, mf))
+            jb = jobs_np(nb, (off, off), (0, 0, 0, 1 if kind == A.TR_IDCT else 0))
+            jd = jobs_dev(jb, dev)
+            for mf in ((0, 1) if n_ >= 16 else (0,)):
+                t = timeit(lambda: A.transform_batch(kind, 8, n_, A.plane(src_d, n_), A.plane(dst_d, n_), jd, nb, mf))
                 tops = nb * 4 * n_ ** 3 * 2 / t / 1e12
-                extra = f"int8 {tops:7.1f} TOPS = {tops / I8_PEAK_TOPS:.3f} of dense peak" if mf else "VALU"
-                row(f"transform {kname}{n_} {'mfma' if mf else 'valu'}", nb, t, 2 * n_ * n_ * 2, extra)
+                extra = f"MFMA int8 limbs: {tops:6.1f} TOPS = {tops / I8_PEAK_TOPS:.3f} of dense peak" if mf else "VALU"
+                report(cpu, f"{kname}{n_} {'mfma' if mf else 'valu'}", nb, t, 2 * n_ * n_ * 2, f"cu[{int(np.log2(n_)) - 2}].{kname}",
+                       SIG_DCT, [(src_h, n_), (dst_h, n_)], jb, extra)
 
-    # ---- quant 32x32 ----
-    nb, n2 = 1 << 16, 1024
-    coef = torch.from_numpy(rng.integers(-255, 256, size=nb * n2, dtype=np.int16)).to(dev)
-    qc = torch.from_numpy(rng.integers(1, 256, size=nb * n2).astype(np.int32)).to(dev)
-    du = torch.zeros(nb * n2, dtype=torch.int32, device=dev)
-    qo = torch.zeros(nb * n2, dtype=torch.int16, device=dev)
+    # ---- a8: quant family, 32x32 ----
+    nb, n2 = 1 << 15, 1024
+    coef_h = rng.integers(-255, 256, size=nb * n2, dtype=np.int16)
+    qc_h = rng.integers(1, 256, size=nb * n2).astype(np.int32)
+    du_h, qo_h = np.zeros(nb * n2, np.int32), np.zeros(nb * n2, np.int16)
+    coef_d, qc_d, du_d, qo_d = (to_dev(x, dev) for x in (coef_h, qc_h, du_h, qo_h))
     res = torch.zeros(nb, dtype=torch.int32, device=dev)
-    jobs = A.make_jobs([([j * n2] * 4, [17, 85 << 8, n2]) for j in range(nb)], dev)
-    t = timeit(lambda: A.quant_batch(A.Q_QUANT, [A.plane(coef), A.plane(qc), A.plane(du), A.plane(qo)], jobs, nb, res))
-    row("quant 32x32", nb, t, n2 * (2 + 4) * 2)
+    off = np.arange(nb, dtype=np.int64) * n2
+    jb = jobs_np(nb, (off, off, off, off), (17, 85 << 8, n2))
+    jd = jobs_dev(jb, dev)
+    planes_d = [A.plane(coef_d), A.plane(qc_d), A.plane(du_d), A.plane(qo_d)]
+    planes_h = [(coef_h, 0), (qc_h, 0), (du_h, 0), (qo_h, 0)]
+    t = timeit(lambda: A.quant_batch(A.Q_QUANT, planes_d, jd, nb, res))
+    report(cpu, "quant 32x32", nb, t, n2 * (2 + 4) * 2, "quant", SIG_QUANT, planes_h, jb)
+    t = timeit(lambda: A.quant_batch(A.Q_NQUANT, planes_d, jd, nb, res))
+    report(cpu, "nquant 32x32", nb, t, n2 * (2 + 4) + n2 * 2, "nquant", SIG_NQUANT, planes_h, jb)
+    jb2 = jobs_np(nb, (off, off, off, off), (n2, 40, 5))
+    jd2 = jobs_dev(jb2, dev)
+    t = timeit(lambda: A.quant_batch(A.Q_DEQUANT_NORMAL, planes_d, jd2, nb, res))
+    report(cpu, "dequant_normal 32x32", nb, t, n2 * 4, "dequant_normal", SIG_DEQUANT_NORMAL, planes_h, jb2)
 
-    # ---- intra 16x16, all 35 modes ----
-    ntu = 1 << 13
-    nbuf = torch.from_numpy(rng.integers(0, 256, size=ntu * 80, dtype=np.uint8)).to(dev)
-    dsti = torch.zeros(ntu * 35 * 256, dtype=torch.uint8, device=dev)
-    jobs = A.make_jobs([([t_ * 80, (t_ * 35 + m) * 256], [m, 1]) for t_ in range(ntu) for m in range(35)], dev)
-    t = timeit(lambda: A.intra_batch(A.INTRA_PRED, 8, 16, A.plane(nbuf), A.plane(dsti, 16), jobs, ntu * 35))
-    row("intra_pred 16x16 (35 modes per TU)", ntu * 35, t, 65 + 256)
+    # ---- a12: intra prediction, all 35 modes per TU ----
+    for n_ in (8, 16, 32):
+        ntu = 1 << 11
+        nb_h = rng.integers(0, 256, size=ntu * 160, dtype=np.uint8)
+        dst_h = np.zeros(ntu * 35 * n_ * n_, np.uint8)
+        nb_d, dst_d = to_dev(nb_h, dev), to_dev(dst_h, dev)
+        tu = np.repeat(np.arange(ntu, dtype=np.int64), 35)
+        mode = np.tile(np.arange(35, dtype=np.int64), ntu)
+        jb = jobs_np(ntu * 35, (tu * 160, (tu * 35 + mode) * n_ * n_), (mode, 1))
+        jd = jobs_dev(jb, dev)
+        jb_cpu = jobs_np(ntu * 35, (tu * 160, (tu * 35 + mode) * n_ * n_), (np.maximum(mode, 2), 1))   # an angular slot only takes angular modes
+        t = timeit(lambda: A.intra_batch(A.INTRA_PRED, 8, n_, A.plane(nb_d), A.plane(dst_d, n_), jd, ntu * 35))
+        # one CPU job list per mode class is not needed: slot [mode] differs, time the angular slot 10 on all jobs
+        report(cpu, f"intra_pred {n_}x{n_} (35 modes/TU)", ntu * 35, t, 4 * n_ + 1 + n_ * n_, f"cu[{int(np.log2(n_)) - 2}].intra_pred[10]",
+               SIG_INTRA_PRED, [(nb_h, 0), (dst_h, n_)], jb_cpu, "CPU column: the angular slot on every job")
+
+    # ---- a10: element-wise block ops, 32x32 ----
+    nb, w = 1 << 15, 32
+    pa_h = rng.integers(0, 256, size=nb * w * w, dtype=np.uint8)
+    pb_h = rng.integers(0, 256, size=nb * w * w, dtype=np.uint8)
+    s_h = rng.integers(-255, 256, size=nb * w * w, dtype=np.int16)
+    s2_h = rng.integers(-8000, 8000, size=nb * w * w).astype(np.int16)
+    pa_d, pb_d, s_d, s2_d = (to_dev(x, dev) for x in (pa_h, pb_h, s_h, s2_h))
+    off = np.arange(nb, dtype=np.int64) * w * w
+    jb = jobs_np(nb, (off, off, off))
+    jd = jobs_dev(jb, dev)
+    pu32 = pu_index(32, 32)
+    cases = [
+        ("copy_pp 32x32", A.OP_COPY_PP, [(pa_d, pa_h), (pb_d, pb_h), None], f"pu[{pu32}].copy_pp", SIG_COPY, 2 * w * w),
+        ("sub_ps 32x32", A.OP_SUB_PS, [(s_d, s_h), (pa_d, pa_h), (pb_d, pb_h)], "cu[3].sub_ps", SIG_SUB_PS, 4 * w * w),
+        ("add_ps 32x32", A.OP_ADD_PS, [(pa_d, pa_h), (pb_d, pb_h), (s_d, s_h)], "cu[3].add_ps[0]", SIG_ADD_PS, 4 * w * w),
+        ("addAvg 32x32", A.OP_ADDAVG, [(pa_d, pa_h), (s2_d, s2_h), (s_d, s_h)], f"pu[{pu32}].addAvg[0]", SIG_ADDAVG, 5 * w * w),
+    ]
+    for name, op, pls, path, sig, bpj in cases:
+        pd = [A.plane(p[0], w) if p else None for p in pls]
+        t = timeit(lambda: A.blockop_batch(op, 8, w, w, pd, jd, nb))
+        report(cpu, name, nb, t, bpj, path, sig, [(p[1], w) if p else (None, 0) for p in pls], jb)
+
+    # ---- a13 / a14: SAO band offset on 64x64 CTUs, strong luma deblocking edges ----
+    nb = 1 << 13
+    rec_h = rng.integers(0, 256, size=nb * 64 * 64, dtype=np.uint8)
+    offs_h = rng.integers(-7, 8, size=32).astype(np.int8)
+    rec_d, offs_d = to_dev(rec_h, dev), to_dev(offs_h, dev)
+    jb = jobs_np(nb, (np.arange(nb, dtype=np.int64) * 4096, 0), (64, 64))
+    jd = jobs_dev(jb, dev)
+    t = timeit(lambda: A.loopfilter_batch(A.LF_SAO_B0, 8, [A.plane(rec_d, 64), A.plane(offs_d)], jd, nb))
+    report(cpu, "saoCuOrgB0 64x64", nb, t, 2 * 4096, "saoCuOrgB0", SIG_SAO_B0, [(rec_h, 64), (offs_h, 0)], jb)
+    ne = 1 << 18
+    edge = (rng.integers(8, Hh - 8, size=ne) * st + rng.integers(8, W - 8, size=ne)).astype(np.int64)
+    jb = jobs_np(ne, (edge,), (st, 1, 3, 3))           # vertical edge: 4 lines down the plane, taps along x
+    jd = jobs_dev(jb, dev)
+    t = timeit(lambda: A.loopfilter_batch(A.LF_DEBLOCK_LUMA_STRONG, 8, [A.plane(ref_d, st)], jd, ne))
+    report(cpu, "pelFilterLumaStrong (4 lines)", ne, t, 4 * 8 + 4 * 6, "pelFilterLumaStrong[0]", SIG_DEBLOCK_LUMA, [(ref_h, st)], jb)
 
 
 if __name__ == "__main__":

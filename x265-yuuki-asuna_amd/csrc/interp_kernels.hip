@@ -12,6 +12,7 @@
 #include "common.h"
 
 #include <type_traits>
+#include <cstdlib>
 
 namespace x265hip {
 
@@ -160,11 +161,245 @@ __global__ void __launch_bounds__(256) interp_kernel(IPArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path (block width a multiple of 4, every kind but P2S): no LDS, no barriers.  A thread owns a strip of
+// 4 pixels x STRIP_ROWS rows of one job; a 256-thread workgroup carries as many jobs as fit, so small blocks
+// (8x8 chroma: 2 strips) do not pay one workgroup launch each.  Arithmetic is packed:
+//   horizontal, 8-bit pixels : v_dot4_i32_i8 on (pixel - 128) bytes - the bias 128 * sum(taps) = 8192 is the
+//                              accumulator's start value; the 4 shifted windows of a row come from 3 dwords by
+//                              v_alignbyte
+//   horizontal, 16-bit pixels: v_dot2_i32_i16 on pixel pairs (odd windows by v_alignbyte 2)
+//   vertical (all sources)   : v_dot2_i32_i16 on (row r, row r+1) pairs built with one v_perm_b32 per pixel from
+//                              two row dwords (bytes zero-extended, halfwords as they are, or the 14-bit
+//                              horizontal intermediates of the hv kind, which never leave registers)
+// Both give exact int32 sums, so the rounding code below is the same as the generic kernel's.
+__constant__ uint32_t kLumaDot4[4][2] = {          // taps as 4 signed bytes: {c0..c3}, {c4..c7}
+    { 0x40000000u, 0x00000000u }, { 0x3af604ffu, 0x0001fb11u }, { 0x28f504ffu, 0xff04f528u }, { 0x11fb0100u, 0xff04f63au } };
+__constant__ uint32_t kChromaDot4[8] = {
+    0x00004000u, 0xfe0a3afeu, 0xfe1036fcu, 0xfc1c2efau, 0xfc2424fcu, 0xfa2e1cfcu, 0xfc3610feu, 0xfe3a0afeu };
+
+template <int N> __device__ __forceinline__ uint32_t tap_pair(int idx, int j)          // (c[2j], c[2j+1]) as int16 x 2
+{
+    const int a = tap<N>(idx, 2 * j), b = tap<N>(idx, 2 * j + 1);
+    return ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+}
+
+typedef short v2i16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2i16, a), __builtin_bit_cast(v2i16, b), c, false);
+}
+
+constexpr int STRIP_ROWS = 8;
+
+template <typename Px, int KIND, int N>
+__global__ void __launch_bounds__(256) interp_strip_kernel(IPArgs a, int njobs, int stripsPerJob, int jobsPerWg)
+{
+    constexpr bool SRC_SHORT = KIND == X265HIP_IP_VSP || KIND == X265HIP_IP_VSS;
+    constexpr bool DST_SHORT = KIND == X265HIP_IP_HPS || KIND == X265HIP_IP_VPS || KIND == X265HIP_IP_VSS;
+    constexpr bool HORIZ = KIND == X265HIP_IP_HPP || KIND == X265HIP_IP_HPS || KIND == X265HIP_IP_HVPP;
+    constexpr bool VERT = !HORIZ || KIND == X265HIP_IP_HVPP;
+    typedef typename std::conditional<SRC_SHORT, int16_t, Px>::type S;
+    typedef typename std::conditional<DST_SHORT, int16_t, Px>::type Dt;
+    constexpr int SB = sizeof(S);
+    constexpr int HALF = N / 2 - 1;
+    constexpr int NSRC = STRIP_ROWS + (VERT ? N - 1 : 0);           // source rows a strip touches
+
+    const int jw = threadIdx.x / stripsPerJob;
+    const int strip = threadIdx.x - jw * stripsPerJob;
+    const int job = blockIdx.x * jobsPerWg + jw;
+    if (jw >= jobsPerWg || job >= njobs) return;
+    const x265hip_job jb = a.jobs[job];
+    const int w = a.w, depth = a.depth;
+    const bool rowExt = KIND == X265HIP_IP_HPS && jb.arg[1] != 0;
+    const int hEff = a.h + (rowExt ? N - 1 : 0);                     // rows this job writes
+    const int spr = w >> 2;
+    const int sy = (strip / spr) * STRIP_ROWS, sx = (strip - (strip / spr) * spr) * 4;
+    const int nr = hEff - sy < STRIP_ROWS ? hEff - sy : STRIP_ROWS;
+    const int maxVal = (1 << depth) - 1, headRoom = IF_PREC - depth;
+    const int idx0 = jb.arg[0], idx1 = jb.arg[1];
+
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(reinterpret_cast<const S*>(a.src) + jb.off[0]);
+    const long ssB = a.srcStride * SB;
+    // first source row / column this strip reads
+    const long row0 = sy - ((VERT || rowExt) ? HALF : 0);
+    const uint8_t* sp = src + row0 * ssB + (long)(sx - (HORIZ ? HALF : 0)) * SB;
+    const int lastRow = (VERT ? nr + N - 2 : nr - 1);               // rows past it are clamped (never stored)
+
+    // ---- stage 1: per source row, the 4 samples of the strip (vertical kinds) or the 4 horizontal sums ----
+    int hsum[HORIZ ? NSRC : 1][4];
+    uint32_t raw[(!HORIZ) ? NSRC : 1][2];
+    if (HORIZ)
+    {
+        uint32_t c03 = 0, c47 = 0, cp[4] = { 0, 0, 0, 0 };
+        if (sizeof(Px) == 1) { c03 = N == 8 ? kLumaDot4[idx0][0] : kChromaDot4[idx0]; c47 = N == 8 ? kLumaDot4[idx0][1] : 0; }
+        else
+        {
+#pragma unroll
+            for (int j = 0; j < N / 2; j++) cp[j] = tap_pair<N>(idx0, j);
+        }
+#pragma unroll
+        for (int r = 0; r < NSRC; r++)
+        {
+            const uint8_t* rp = sp + (long)(r < lastRow ? r : lastRow) * ssB;
+            if (sizeof(Px) == 1)
+            {
+                uint32_t w0 = ld_u32(rp) ^ 0x80808080u, w1 = ld_u32(rp + 4) ^ 0x80808080u, w2 = N == 8 ? ld_u32(rp + 8) ^ 0x80808080u : 0;
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    const uint32_t lo = x ? __builtin_amdgcn_alignbyte(w1, w0, x) : w0;
+                    int sacc = __builtin_amdgcn_sdot4((int)lo, (int)c03, 8192, false);
+                    if (N == 8)
+                    {
+                        const uint32_t hi = x ? __builtin_amdgcn_alignbyte(w2, w1, x) : w1;
+                        sacc = __builtin_amdgcn_sdot4((int)hi, (int)c47, sacc, false);
+                    }
+                    hsum[r][x] = sacc;
+                }
+            }
+            else
+            {
+                // N + 3 samples = (N + 4) / 2 dwords: even windows are the dwords themselves, odd ones are shifted by one sample
+                constexpr int ND = (N + 4) / 2;
+                uint32_t d[ND];
+#pragma unroll
+                for (int k = 0; k < ND; k++) d[k] = ld_u32(rp + 4 * k);
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    int sacc = 0;
+#pragma unroll
+                    for (int j = 0; j < N / 2; j++)
+                    {
+                        const int k = (x >> 1) + j;
+                        const uint32_t pr = (x & 1) ? __builtin_amdgcn_alignbyte(d[k + 1], d[k], 2) : d[k];
+                        sacc = dot2(pr, cp[j], sacc);
+                    }
+                    hsum[r][x] = sacc;
+                }
+            }
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int r = 0; r < NSRC; r++)
+        {
+            const uint8_t* rp = sp + (long)(r < lastRow ? r : lastRow) * ssB;
+            raw[r][0] = ld_u32(rp);
+            raw[r][1] = SB == 2 ? ld_u32(rp + 4) : 0;
+        }
+    }
+
+    // ---- stage 2: finish the row (horizontal kinds) or run the vertical taps over row pairs ----
+    Dt* dst = reinterpret_cast<Dt*>(a.dst) + jb.off[1] + (long)sy * a.dstStride + sx;
+    auto store4 = [&](const int y, const int (&v)[4])
+    {
+        uint8_t* dp = reinterpret_cast<uint8_t*>(dst + (long)y * a.dstStride);
+        if (sizeof(Dt) == 1)
+            *reinterpret_cast<u32_unaligned*>(dp) = (uint32_t)(v[0] & 0xff) | ((uint32_t)(v[1] & 0xff) << 8) | ((uint32_t)(v[2] & 0xff) << 16) | ((uint32_t)v[3] << 24);
+        else
+        {
+            *reinterpret_cast<u32_unaligned*>(dp) = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
+            *reinterpret_cast<u32_unaligned*>(dp + 4) = ((uint32_t)v[2] & 0xffffu) | ((uint32_t)v[3] << 16);
+        }
+    };
+    if (KIND == X265HIP_IP_HPP || KIND == X265HIP_IP_HPS)
+    {
+        const int shiftPS = IF_FPREC - headRoom, offPS = -(IF_OFFS << shiftPS);
+#pragma unroll
+        for (int y = 0; y < STRIP_ROWS; y++)
+        {
+            if (y >= nr) break;
+            int v[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                v[x] = KIND == X265HIP_IP_HPP ? clip_val16((hsum[y][x] + (1 << (IF_FPREC - 1))) >> IF_FPREC, maxVal)
+                                              : (int)(int16_t)((hsum[y][x] + offPS) >> shiftPS);
+            store4(y, v);
+        }
+        return;
+    }
+    // vertical taps
+    const int idxV = KIND == X265HIP_IP_HVPP ? idx1 : idx0;
+    uint32_t cv[N / 2];
+#pragma unroll
+    for (int j = 0; j < N / 2; j++) cv[j] = tap_pair<N>(idxV, j);
+    uint32_t pairs[NSRC - 1][4];                                     // (row r, row r + 1) at each of the 4 columns
+    if (KIND == X265HIP_IP_HVPP)
+    {
+        const int shiftPS = IF_FPREC - headRoom, offPS = -(IF_OFFS << shiftPS);
+        int im[NSRC][4];
+#pragma unroll
+        for (int r = 0; r < NSRC; r++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) im[r][x] = (hsum[r][x] + offPS) >> shiftPS;
+#pragma unroll
+        for (int r = 0; r < NSRC - 1; r++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) pairs[r][x] = __builtin_amdgcn_perm((uint32_t)im[r + 1][x], (uint32_t)im[r][x], 0x05040100u);
+    }
+    else
+    {
+#pragma unroll
+        for (int r = 0; r < NSRC - 1; r++)
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                if (SB == 1)     // byte x of both rows, zero-extended to halfwords
+                    pairs[r][x] = __builtin_amdgcn_perm(raw[r + 1][0], raw[r][0], 0x0c000c00u | (uint32_t)x | ((uint32_t)(4 + x) << 16));
+                else             // halfword x of both rows
+                    pairs[r][x] = __builtin_amdgcn_perm(raw[r + 1][x >> 1], raw[r][x >> 1], (x & 1) ? 0x07060302u : 0x05040100u);
+            }
+    }
+#pragma unroll
+    for (int y = 0; y < STRIP_ROWS; y++)
+    {
+        if (y >= nr) break;
+        int v[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+        {
+            int sum = 0;
+#pragma unroll
+            for (int j = 0; j < N / 2; j++) sum = dot2(pairs[y + 2 * j][x], cv[j], sum);
+            if (KIND == X265HIP_IP_VPP)
+                v[x] = clip_val16((sum + (1 << (IF_FPREC - 1))) >> IF_FPREC, maxVal);
+            else if (KIND == X265HIP_IP_VPS)
+            {
+                const int shift = IF_FPREC - headRoom;
+                v[x] = (int)(int16_t)((sum - (IF_OFFS << shift)) >> shift);
+            }
+            else if (KIND == X265HIP_IP_VSS)
+                v[x] = (int)(int16_t)(sum >> IF_FPREC);
+            else                                                      // VSP and the second stage of HVPP
+            {
+                const int shift = IF_FPREC + headRoom;
+                v[x] = clip_val16((sum + (1 << (shift - 1)) + (IF_OFFS << IF_FPREC)) >> shift, maxVal);
+            }
+        }
+        store4(y, v);
+    }
+}
+
+template <typename Px, int KIND, int N>
+static void launch_strip(const IPArgs& a, int njobs, hipStream_t s)
+{
+    const int hEffMax = a.h + (KIND == X265HIP_IP_HPS ? N - 1 : 0);
+    const int spj = (a.w >> 2) * ((hEffMax + STRIP_ROWS - 1) / STRIP_ROWS);          // <= 16 * 9 = 144
+    const int jpw = 256 / spj > 0 ? 256 / spj : 1;
+    const int threads = ((spj * jpw + 63) / 64) * 64;
+    hipLaunchKernelGGL((interp_strip_kernel<Px, KIND, N>), dim3((njobs + jpw - 1) / jpw), dim3(threads), 0, s, a, njobs, spj, jpw);
+}
+
 template <typename Px, int N>
 static int launch_ip(int kind, const IPArgs& a, int njobs, hipStream_t s)
 {
     const int threads = a.w * a.h <= 256 ? 64 : 256;
-#define CASE(K) case K: hipLaunchKernelGGL((interp_kernel<Px, K, N>), dim3(njobs), dim3(threads), 0, s, a); break;
+    const bool strip = (a.w & 3) == 0 && kind != X265HIP_IP_P2S && !getenv("X265HIP_INTERP_GENERIC");
+#define CASE(K) case K: if (strip && K != X265HIP_IP_P2S) launch_strip<Px, K == X265HIP_IP_P2S ? X265HIP_IP_HPP : K, N>(a, njobs, s); \
+                        else hipLaunchKernelGGL((interp_kernel<Px, K, N>), dim3(njobs), dim3(threads), 0, s, a); break;
     switch (kind)
     {
         CASE(X265HIP_IP_HPP) CASE(X265HIP_IP_HPS) CASE(X265HIP_IP_VPP) CASE(X265HIP_IP_VPS)

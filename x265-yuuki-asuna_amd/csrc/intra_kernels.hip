@@ -10,6 +10,8 @@
 // projected reference line) live in LDS, one thread per predicted sample.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace x265hip {
 
 __constant__ int8_t kAngle[17] = { -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
@@ -167,6 +169,169 @@ __global__ void __launch_bounds__(256) intra_kernel(IntraArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path for PRED and ALLANGS: a thread owns 4 horizontally adjacent output samples (one dword / two dword
+// store), a 256-thread workgroup carries 256 / (N*N/4) candidates (64 for 4x4 ... 1 for 32x32).  Per candidate the
+// neighbours are staged in LDS and the angular reference line (main arm, corner and - for negative angles - the
+// samples projected from the side arm, intrapred.cpp:150-160) is laid out once, so a predicted sample is two LDS
+// reads and one interpolation.  Horizontal modes read the swapped arms and write transposed, as index arithmetic.
+struct IntraMode
+{
+    int hor, angle, inv, mainBase, sideBase;
+};
+__device__ __forceinline__ IntraMode intra_mode(int mode, int n2)
+{
+    IntraMode m;
+    m.hor = mode < 18;
+    const int aoff = m.hor ? 10 - mode : mode - 26;
+    m.angle = mode >= 2 ? kAngle[8 + aoff] : 0;
+    m.inv = (mode >= 2 && m.angle < 0) ? kInvAngle[-aoff - 1] : 0;
+    m.mainBase = m.hor ? n2 : 0;
+    m.sideBase = m.hor ? 0 : n2;
+    return m;
+}
+
+template <typename Px, int KIND>
+__global__ void __launch_bounds__(256) intra_quad_kernel(IntraArgs a, int njobs, int log2tpj)
+{
+    constexpr bool ALL = KIND == X265HIP_INTRA_ALLANGS;
+    __shared__ Px nbs[64 * 20];                 // jobsPerWg * (4n + 4) samples: 64 * 20 (n = 4) ... 1 * 132 (n = 32)
+    __shared__ Px nbf[ALL ? 64 * 20 : 1];       // the filtered neighbours of ALLANGS
+    __shared__ Px lines[64 * 16];               // jobsPerWg * (3n + 4): 64 * 16 ... 1 * 100
+    __shared__ int dcSum[64];
+    const int tid = threadIdx.x;
+    const int n = a.n, log2n = a.log2n, n2 = 2 * n, cnt = 4 * n + 1, pitch = 4 * n + 4, lpitch = 3 * n + 4;
+    const int tpj = 1 << log2tpj, jpw = 256 >> log2tpj;
+    const int jw = tid >> log2tpj, q = tid & (tpj - 1);
+    const int job = blockIdx.x * jpw + jw;
+    const bool live = job < njobs;
+    x265hip_job jb;
+    if (live) jb = a.jobs[job];
+    if (tid < 64) dcSum[tid] = 0;
+    __syncthreads();
+    Px* nb0 = nbs + jw * pitch;
+    Px* nbF = ALL ? nbf + jw * pitch : nb0;
+    Px* line = lines + jw * lpitch + n;          // line[k], k in [-n, 2n]
+    if (live)
+    {
+        const Px* sp = reinterpret_cast<const Px*>(a.src) + jb.off[0];
+        int part = 0;
+        for (int k = q; k < cnt; k += tpj)
+        {
+            const Px v = sp[k];
+            nb0[k] = v;
+            if (ALL) nbF[k] = (reinterpret_cast<const Px*>(a.src) + jb.off[2])[k];
+            else if ((k >= 1 && k <= n) || (k >= n2 + 1 && k <= n2 + n)) part += (int)v;
+        }
+        if (!ALL && jb.arg[0] == 1) atomicAdd(&dcSum[jw], part);
+    }
+    __syncthreads();
+    const int qpr = n >> 2;
+    const int y = q >> (log2n - 2), x0 = (q & (qpr - 1)) * 4;
+    const int maxVal = (1 << a.depth) - 1;
+    Px* d = live ? reinterpret_cast<Px*>(a.dst) + jb.off[1] : nullptr;
+    auto put4 = [&](Px* p, const int (&v)[4])
+    {
+        if (sizeof(Px) == 1)
+            *reinterpret_cast<u32_unaligned*>(p) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+        else
+        {
+            reinterpret_cast<u32_unaligned*>(p)[0] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+            reinterpret_cast<u32_unaligned*>(p)[1] = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+        }
+    };
+    // lay out the reference line of `mode` from neighbour set nb (all threads of the candidate), then predict 4 samples
+    auto build_line = [&](const Px* nb, const IntraMode& m)
+    {
+        const int lowest = (n * m.angle) >> 5;                    // most negative index read (0 for angle >= 0)
+        for (int e = q; e < 3 * n + 2; e += tpj)
+        {
+            const int k = e - n;
+            Px v = 0;
+            if (k >= 0) v = k < n2 ? nb[m.mainBase + 1 + k] : nb[m.mainBase + n2];      // line[2n] is only ever weighted by 0
+            else if (k == -1) v = nb[0];
+            else if (k >= lowest) v = nb[m.sideBase + ((128 + (-1 - k) * m.inv) >> 8)];
+            line[k] = v;
+        }
+    };
+    auto angular4 = [&](const Px* nb, const IntraMode& m, const int bFilter, const bool flip, int (&v)[4])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int r = flip ? x0 + k : y, c = flip ? y : x0 + k;
+            if (m.angle == 0)
+            {
+                int t = nb[m.mainBase + 1 + c];
+                if (bFilter && c == 0)
+                {
+                    const int16_t f = (int16_t)(nb[m.mainBase + 1] + (((int)nb[m.sideBase + 1 + r] - (int)nb[0]) >> 1));
+                    t = f < 0 ? 0 : (f > maxVal ? maxVal : f);
+                }
+                v[k] = t;
+            }
+            else
+            {
+                const int pos = (r + 1) * m.angle, off = pos >> 5, frac = pos & 31;
+                v[k] = ((32 - frac) * (int)line[off + c] + frac * (int)line[off + c + 1] + 16) >> 5;
+            }
+        }
+    };
+    if (!ALL)
+    {
+        const int mode = live ? jb.arg[0] : 0, bFilter = live ? jb.arg[1] : 0;
+        const IntraMode m = intra_mode(mode, n2);
+        if (live && mode >= 2 && m.angle != 0) build_line(nb0, m);
+        __syncthreads();
+        if (!live) return;
+        int v[4];
+        if (mode == 0)
+        {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int x = x0 + k;
+                v[k] = ((n - 1 - x) * nb0[n2 + 1 + y] + (n - 1 - y) * nb0[1 + x] + (x + 1) * nb0[1 + n] + (y + 1) * nb0[n2 + 1 + n] + n) >> (log2n + 1);
+            }
+        }
+        else if (mode == 1)
+        {
+            const int dc = (dcSum[jw] + n) / n2;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int x = x0 + k;
+                int t = dc;
+                if (bFilter)
+                {
+                    if (x == 0 && y == 0) t = (nb0[1] + nb0[n2 + 1] + 2 * dc + 2) >> 2;
+                    else if (y == 0) t = (nb0[1 + x] + 3 * dc + 2) >> 2;
+                    else if (x == 0) t = (nb0[n2 + 1 + y] + 3 * dc + 2) >> 2;
+                }
+                v[k] = t;
+            }
+        }
+        else
+            angular4(nb0, m, bFilter, m.hor != 0, v);
+        put4(d + (long)y * a.dstStride + x0, v);
+        return;
+    }
+    for (int mode = 2; mode <= 34; mode++)
+    {
+        const Px* nb = (kIntraFilterFlags[mode] & n) ? nbF : nb0;
+        const IntraMode m = intra_mode(mode, n2);
+        if (live && m.angle != 0) build_line(nb, m);
+        __syncthreads();
+        if (live)
+        {
+            int v[4];
+            angular4(nb, m, jb.arg[0], false, v);                  // all-angs keeps the horizontal modes transposed
+            put4(d + (long)(mode - 2) * n * n + y * n + x0, v);
+        }
+        __syncthreads();                                            // the line is rebuilt for the next mode
+    }
+}
+
 } // namespace x265hip
 
 using namespace x265hip;
@@ -185,10 +350,14 @@ extern "C" int x265hip_intra_batch(int kind, int depth, int n, x265hip_plane src
     a.jobs = jobs; a.n = n; a.log2n = n == 4 ? 2 : (n == 8 ? 3 : (n == 16 ? 4 : 5)); a.depth = depth;
     const int threads = n * n <= 64 ? 64 : 256;
     hipStream_t s = (hipStream_t)stream;
+    const int log2tpj = 2 * a.log2n - 2, jpw = 256 >> log2tpj, wgs = (njobs + jpw - 1) / jpw;      // fast path geometry
+    const bool generic = getenv("X265HIP_INTRA_GENERIC") != nullptr;                 // A/B switch: one workgroup per candidate
 #define GO(PX) do { switch (kind) { \
-        case X265HIP_INTRA_PRED:    hipLaunchKernelGGL((intra_kernel<PX, X265HIP_INTRA_PRED>), dim3(njobs), dim3(threads), 0, s, a); break; \
+        case X265HIP_INTRA_PRED:    if (generic) hipLaunchKernelGGL((intra_kernel<PX, X265HIP_INTRA_PRED>), dim3(njobs), dim3(threads), 0, s, a); \
+                                    else hipLaunchKernelGGL((intra_quad_kernel<PX, X265HIP_INTRA_PRED>), dim3(wgs), dim3(256), 0, s, a, njobs, log2tpj); break; \
         case X265HIP_INTRA_FILTER:  hipLaunchKernelGGL((intra_kernel<PX, X265HIP_INTRA_FILTER>), dim3(njobs), dim3(threads), 0, s, a); break; \
-        case X265HIP_INTRA_ALLANGS: hipLaunchKernelGGL((intra_kernel<PX, X265HIP_INTRA_ALLANGS>), dim3(njobs), dim3(threads), 0, s, a); break; \
+        case X265HIP_INTRA_ALLANGS: if (generic) hipLaunchKernelGGL((intra_kernel<PX, X265HIP_INTRA_ALLANGS>), dim3(njobs), dim3(threads), 0, s, a); \
+                                    else hipLaunchKernelGGL((intra_quad_kernel<PX, X265HIP_INTRA_ALLANGS>), dim3(wgs), dim3(256), 0, s, a, njobs, log2tpj); break; \
         default: set_error("intra_batch: unknown kind %d", kind); return X265HIP_EINVAL; } } while (0)
     if (depth == 8) GO(uint8_t); else GO(uint16_t);
 #undef GO

@@ -13,6 +13,9 @@
 // producing kernels, the table layer uses them one block at a time.
 #include "common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace x265hip {
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
@@ -252,9 +255,107 @@ __global__ void __launch_bounds__(256) blockop_kernel(OpArgs a)
     }
 }
 
+// Fast path for the streaming ops when the width is a multiple of 4: a thread moves 4 samples per step with dword
+// accesses (unaligned addresses are fine on gfx950), and small blocks share a 256-thread workgroup.
+template <typename T> __device__ __forceinline__ void ld4(const T* p, int (&v)[4])
+{
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(p);
+    if (sizeof(T) == 1)
+    {
+        const uint32_t w = ld_u32(b);
+        v[0] = w & 0xff; v[1] = (w >> 8) & 0xff; v[2] = (w >> 16) & 0xff; v[3] = w >> 24;
+    }
+    else
+    {
+        const uint32_t w0 = ld_u32(b), w1 = ld_u32(b + 4);
+        const bool sgn = std::is_signed<T>::value;
+        v[0] = sgn ? (int)(int16_t)w0 : (int)(w0 & 0xffff); v[1] = sgn ? (int)w0 >> 16 : (int)(w0 >> 16);
+        v[2] = sgn ? (int)(int16_t)w1 : (int)(w1 & 0xffff); v[3] = sgn ? (int)w1 >> 16 : (int)(w1 >> 16);
+    }
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const int (&v)[4])
+{
+    uint8_t* b = reinterpret_cast<uint8_t*>(p);
+    if (sizeof(T) == 1)
+        *reinterpret_cast<u32_unaligned*>(b) = (uint32_t)(v[0] & 0xff) | ((uint32_t)(v[1] & 0xff) << 8) | ((uint32_t)(v[2] & 0xff) << 16) | ((uint32_t)v[3] << 24);
+    else
+    {
+        reinterpret_cast<u32_unaligned*>(b)[0] = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
+        reinterpret_cast<u32_unaligned*>(b)[1] = ((uint32_t)v[2] & 0xffffu) | ((uint32_t)v[3] << 16);
+    }
+}
+
+template <typename Px, int OP>
+__global__ void __launch_bounds__(256) blockop_quad_kernel(OpArgs a, int njobs, int threadsPerJob, int jobsPerWg)
+{
+    const int jw = threadIdx.x / threadsPerJob, t = threadIdx.x - jw * threadsPerJob;
+    const int job = blockIdx.x * jobsPerWg + jw;
+    if (jw >= jobsPerWg || job >= njobs) return;
+    const x265hip_job jb = a.jobs[job];
+    const int qpr = a.w >> 2, nq = qpr * a.h;
+    const int maxVal = (1 << a.depth) - 1;
+    const long s0 = a.p[0].stride, s1 = a.p[1].stride, s2 = a.p[2].stride;
+    for (int q = t; q < nq; q += threadsPerJob)
+    {
+        const int y = q / qpr, x = (q - y * qpr) * 4;
+        int u[4], v[4], r[4];
+        switch (OP)
+        {
+        case X265HIP_OP_COPY_PP: ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, r); st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
+        case X265HIP_OP_COPY_PS: ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, r); st4((int16_t*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
+        case X265HIP_OP_COPY_SP: ld4((const int16_t*)a.p[1].base + jb.off[1] + y * s1 + x, r); st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
+        case X265HIP_OP_COPY_SS: ld4((const int16_t*)a.p[1].base + jb.off[1] + y * s1 + x, r); st4((int16_t*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
+        case X265HIP_OP_SUB_PS:
+            ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, u); ld4((const Px*)a.p[2].base + jb.off[2] + y * s2 + x, v);
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = u[k] - v[k];
+            st4((int16_t*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
+        case X265HIP_OP_ADD_PS:
+            ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, u); ld4((const int16_t*)a.p[2].base + jb.off[2] + y * s2 + x, v);
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = clip3(0, maxVal, u[k] + v[k]);
+            st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
+        case X265HIP_OP_ADDAVG:
+        {
+            const int shift = 14 + 1 - a.depth, offset = (1 << (shift - 1)) + 2 * 8192;
+            ld4((const int16_t*)a.p[1].base + jb.off[1] + y * s1 + x, u); ld4((const int16_t*)a.p[2].base + jb.off[2] + y * s2 + x, v);
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = clip3(0, maxVal, (u[k] + v[k] + offset) >> shift);
+            st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
+        }
+        case X265HIP_OP_PIXELAVG:
+            ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, u); ld4((const Px*)a.p[2].base + jb.off[2] + y * s2 + x, v);
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = (u[k] + v[k] + 1) >> 1;
+            st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
+        default: break;
+        }
+    }
+}
+
+template <typename Px, int OP> static void launch_quad(const OpArgs& a, int njobs, hipStream_t s)
+{
+    const int nq = (a.w >> 2) * a.h;
+    int tpj = 1;
+    while (tpj < nq && tpj < 256) tpj <<= 1;                   // threads per job: power of two, <= 256
+    const int jpw = 256 / tpj;
+    hipLaunchKernelGGL((blockop_quad_kernel<Px, OP>), dim3((njobs + jpw - 1) / jpw), dim3(256), 0, s, a, njobs, tpj, jpw);
+}
+
 template <typename Px> static int launch_op(int op, const OpArgs& a, int njobs, hipStream_t s)
 {
     const int threads = (a.w * a.h <= 256 && op < X265HIP_OP_SCALE1D_128TO64) ? 64 : 256;
+    if ((a.w & 3) == 0 && !getenv("X265HIP_BLOCKOP_GENERIC"))
+    {
+#define QUAD(K) case K: launch_quad<Px, K>(a, njobs, s); X265HIP_TRY(hipGetLastError()); return 0;
+        switch (op)
+        {
+            QUAD(X265HIP_OP_COPY_PP) QUAD(X265HIP_OP_COPY_PS) QUAD(X265HIP_OP_COPY_SP) QUAD(X265HIP_OP_COPY_SS) QUAD(X265HIP_OP_SUB_PS)
+            QUAD(X265HIP_OP_ADD_PS) QUAD(X265HIP_OP_ADDAVG) QUAD(X265HIP_OP_PIXELAVG)
+        default: break;
+        }
+#undef QUAD
+    }
 #define CASE(K) case K: hipLaunchKernelGGL((blockop_kernel<Px, K>), dim3(njobs), dim3(threads), 0, s, a); break;
     switch (op)
     {

@@ -17,6 +17,8 @@
 //     int32 exactly, so the rounding shift sees the same integer as the reference.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace x265hip {
 
 struct DctMat
@@ -336,9 +338,170 @@ template <int N, int KIND, bool DST> static int launch_valu(const TrArgs& a, hip
     X265HIP_TRY(hipGetLastError());
     return 0;
 }
+// ------------------------------------------------------------------------------------ MFMA path, streaming form
+// Same arithmetic as transform_mfma_kernel (kept above as the readable reference of the limb identities), organised
+// for throughput: a wavefront loops over TUs with the transform-matrix fragment and the bias constants in
+// registers; forward stage-1 operands are the TU's rows read straight from global memory (16 consecutive int16 per
+// lane), the limb split is two v_perm_b32 + one v_xor per four samples (x = 256 * hi + lo with hi the signed high
+// byte as it stands and lo - 128 the low byte with its top bit flipped), and the only LDS traffic is the 32 x 32
+// transpose between the two passes (and in front of the inverse's first pass, whose contraction runs down columns).
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(2))) u32x4_a2;
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+
+// 16 consecutive int16 (8 dwords) -> high-byte and (low-byte - 128) fragments
+__device__ __forceinline__ void split_limbs(const uint32_t (&d)[8], v4i& hi, v4i& lo)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        hi[q] = (int)__builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x07050301u);
+        lo[q] = (int)(__builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x06040200u) ^ 0x80808080u);
+    }
+}
+
+template <int N, int KIND>
+__global__ void __launch_bounds__(256) transform_mfma_stream_kernel(TrArgs a)
+{
+    typedef Mfma<N> MF;
+    constexpr int NN = N * N;
+    constexpr int LOG2N = N == 16 ? 4 : 5;
+    constexpr bool INV = KIND == 1;
+    __shared__ __attribute__((aligned(16))) int16_t lds[4][NN];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int16_t* T = lds[wave];
+    const int kb = MF::kbase(lane), rn = MF::mn(lane);
+    const bool kvalid = kb < N;                                    // 16x16x64: only the first K block is real
+
+    // transform-matrix fragment (the A operand of both passes) and the data-independent bias of each accumulator row
+    v4i Afrag = { 0, 0, 0, 0 };
+    if (kvalid)
+    {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            int b[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+            {
+                const int k = kb + 4 * q + t;
+                b[t] = INV ? kT.m[k * (32 / N)][rn] : kT.m[rn * (32 / N)][k];
+            }
+            Afrag[q] = pack4(b[0], b[1], b[2], b[3]);
+        }
+    }
+    int bias[MF::NACC];
+#pragma unroll
+    for (int r = 0; r < MF::NACC; r++)
+    {
+        const int row = MF::row(lane, r);
+        int rs = 0;
+        if (INV) { for (int i = 0; i < N; i++) rs += kT.m[i * (32 / N)][row]; }
+        else rs = row == 0 ? 64 * N : 0;
+        bias[r] = 128 * rs;
+    }
+    const int shF1 = LOG2N - 1 + a.depth - 8, shF2 = LOG2N + 6, shI2 = 12 - (a.depth - 8);
+
+    auto product = [&](const uint32_t (&d)[8], int (&out)[MF::NACC])
+    {
+        v4i hi = { 0, 0, 0, 0 }, lo = { 0, 0, 0, 0 };
+        if (kvalid) split_limbs(d, hi, lo);
+        typename MF::Acc zero = {};
+        const typename MF::Acc ph = MF::run(Afrag, hi, zero);
+        const typename MF::Acc pl = MF::run(Afrag, lo, zero);
+#pragma unroll
+        for (int r = 0; r < MF::NACC; r++) out[r] = ph[r] * 256 + pl[r] + bias[r];
+    };
+    // read T[row rn][kb .. kb + 15] (one transposed operand row) as 8 dwords
+    auto lds_row = [&](uint32_t (&d)[8])
+    {
+        if (kvalid)
+        {
+            const u32x4* p = reinterpret_cast<const u32x4*>(T + rn * N + kb);
+            const u32x4 v0 = p[0], v1 = p[1];
+            d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+        }
+    };
+
+    const int nwaves = gridDim.x * 4;
+    for (int job = blockIdx.x * 4 + wave; job < a.njobs; job += nwaves)
+    {
+        const x265hip_job jb = a.jobs[job];
+        const int16_t* src = a.src + jb.off[0];
+        int16_t* dst = a.dst + jb.off[1];
+        uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        int p[MF::NACC];
+        if (!INV)
+        {
+            // pass 1: P[k][j] = sum_i M[k][i] * in[j][i]: lane (column j = rn) supplies in[j][kb .. kb + 15]
+            if (kvalid)
+            {
+                const u32x4_a2* g = reinterpret_cast<const u32x4_a2*>(src + (long)rn * a.srcStride + kb);
+                const u32x4_a2 v0 = g[0], v1 = g[1];
+                d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+            }
+            product(d, p);
+            // T[k][j] = (int16)((P + add) >> shift): the operand rows of pass 2 (contraction over j)
+#pragma unroll
+            for (int r = 0; r < MF::NACC; r++)
+                T[MF::row(lane, r) * N + MF::col(lane)] = (int16_t)((p[r] + (1 << (shF1 - 1))) >> shF1);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): this wave's LDS writes have landed
+            lds_row(d);
+            product(d, p);
+#pragma unroll
+            for (int r = 0; r < MF::NACC; r++)
+                dst[MF::row(lane, r) * N + MF::col(lane)] = (int16_t)((p[r] + (1 << (shF2 - 1))) >> shF2);
+        }
+        else
+        {
+            // pass 1 contracts over the ROWS of the coefficient block: lane (column j = rn) gathers in[kb .. kb + 15][j];
+            // across the lanes of a row group every one of the 16 loads is a contiguous 2 * N byte run
+            if (kvalid)
+            {
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                {
+                    const uint32_t e0 = (uint16_t)src[(kb + 2 * q) * N + rn], e1 = (uint16_t)src[(kb + 2 * q + 1) * N + rn];
+                    d[q] = e0 | (e1 << 16);
+                }
+            }
+            product(d, p);                                          // P[k][j], lane: column j, rows k
+            __builtin_amdgcn_wave_barrier();
+            // out1[j][k] = clip16((P + 64) >> 7); pass 2 contracts over j for fixed k: T[k][j]
+#pragma unroll
+            for (int r = 0; r < MF::NACC; r++)
+                T[MF::row(lane, r) * N + MF::col(lane)] = (int16_t)clip16((p[r] + 64) >> 7);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            lds_row(d);
+            product(d, p);                                          // P2[k2][k] = sum_j M[j][k2] * out1[j][k]: lane column k, rows k2
+            // a lane's accumulator rows come in runs of 4 consecutive k: one 8-byte store per run
+#pragma unroll
+            for (int g = 0; g < MF::NACC / 4; g++)
+            {
+                int v[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = clip16((p[4 * g + t] + (1 << (shI2 - 1))) >> shI2);
+                uint8_t* dp = reinterpret_cast<uint8_t*>(dst + (long)MF::col(lane) * a.dstStride + MF::row(lane, 4 * g));
+                reinterpret_cast<u32_unaligned*>(dp)[0] = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
+                reinterpret_cast<u32_unaligned*>(dp)[1] = ((uint32_t)v[2] & 0xffffu) | ((uint32_t)v[3] << 16);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                            // T is rewritten by the next TU
+    }
+}
+
 template <int N, int KIND> static int launch_mfma(const TrArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL((transform_mfma_kernel<N, KIND>), dim3(a.njobs), dim3(64), 0, s, a);
+    if (getenv("X265HIP_MFMA_SIMPLE"))                              // A/B switch: one wavefront + one workgroup per TU
+        hipLaunchKernelGGL((transform_mfma_kernel<N, KIND>), dim3(a.njobs), dim3(64), 0, s, a);
+    else
+    {
+        int wgs = (a.njobs + 3) / 4;
+        if (wgs > 256 * 8) wgs = 256 * 8;
+        hipLaunchKernelGGL((transform_mfma_stream_kernel<N, KIND>), dim3(wgs), dim3(256), 0, s, a);
+    }
     X265HIP_TRY(hipGetLastError());
     return 0;
 }

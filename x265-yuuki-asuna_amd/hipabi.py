@@ -138,6 +138,8 @@ INTRA_PRED, INTRA_FILTER, INTRA_ALLANGS = range(3)
 (OP_COPY_PP, OP_COPY_PS, OP_COPY_SP, OP_COPY_SS, OP_SUB_PS, OP_ADD_PS, OP_ADDAVG, OP_PIXELAVG, OP_BLOCKFILL,
  OP_CPY2DTO1D_SHL, OP_CPY2DTO1D_SHR, OP_CPY1DTO2D_SHL, OP_CPY1DTO2D_SHR, OP_TRANSPOSE, OP_WEIGHT_PP, OP_WEIGHT_SP,
  OP_SCALE1D_128TO64, OP_SCALE2D_64TO32, OP_SSE_SS, OP_SSD_S, OP_VAR) = range(21)
+(LF_SIGN, LF_SAO_E0, LF_SAO_E1, LF_SAO_E1_2ROWS, LF_SAO_E2, LF_SAO_E3, LF_SAO_B0, LF_STATS_BO, LF_STATS_E0, LF_STATS_E1,
+ LF_STATS_E2, LF_STATS_E3, LF_DEBLOCK_LUMA_STRONG, LF_DEBLOCK_CHROMA, LF_INTEGRAL_H, LF_INTEGRAL_V, LF_ADS) = range(17)
 
 
 def job_dtype():
