@@ -4,11 +4,13 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" = one 1920x1080 8-bit frame (BASELINE.json configs[1] picture size; allocated as 1920x1088 whole CTUs
-like the reference) through the batched stages of the frame pipeline, everything resident in HBM:
+A "step" = one 3840x2160 8-bit frame (BASELINE.json `metric`: "4K preset=slow" = configs[2]; allocated as
+3840x2176 whole CTUs like the reference; --width/--height select the other picture sizes) through the batched stages of
+the frame pipeline, everything resident in HBM:
 
-    ME   exhaustive +-57 search, all 85 PUs of every CTU: SAD surfaces (sad_x4 layout) + best mv
-    SUB  sub-pel refinement of every PU (subme 2)
+    ME   exhaustive +-57 search (the reference's default merange), all 85 PUs of every CTU: SAD surfaces
+         (sad_x4 grouping) + best mv, one launch
+    SUB  sub-pel refinement of every PU (subme 3 = preset slow)
     REC  32x32 prediction + residual DCT / quant / dequant / iDCT / reconstruction + SSE (MC + TU round trip)
     EXT  border extension; the reconstruction is the next frame's reference (closed loop)
 
@@ -68,7 +70,7 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, target_s=15.0):
         t += run(n)
         reps += 1
     return {"value": round(reps * (n / nctu) / t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x {n} of {nctu} CTUs of a 1080p frame through the same stages (search keeps only the best mv), "
+            "sample": f"{reps} x {n} of {nctu} CTUs of the same {clip[0][0].shape[1]}x{clip[0][0].shape[0]} frame through the same stages (search keeps only the best mv), "
                       f"oracle C ({'-march=x86-64-v3' if avx2 else 'generic x86-64'}) with OpenMP over CTUs on {cores} threads "
                       f"(the container's CPU quota; {os.cpu_count()} hardware threads visible), {t:.1f} s"}
 
@@ -101,10 +103,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=3840)      # BASELINE metric: "4K preset=slow" = configs[2]
+    ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--range", type=int, default=57)          # reference default merange (param.cpp:198)
-    ap.add_argument("--subme", type=int, default=2)           # preset medium (param.cpp presets)
+    ap.add_argument("--subme", type=int, default=3)           # preset slow (param.cpp:397-539); medium = 2
     ap.add_argument("--level", type=int, default=2)           # 32x32 blocks in the reconstruction stage
     ap.add_argument("--qp", type=int, default=27)
     ap.add_argument("--no-surface", action="store_true", help="ME keeps only the best mv (no SAD surfaces)")
@@ -204,7 +206,7 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.width}x{args.height} 8-bit (BASELINE configs[1] picture size) closed-loop frame pipeline: "
+            "config": {"workload": f"{args.width}x{args.height} 8-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: "
                                    f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + args.surf_format + ' records) + ') if surf_mode else ''}best mv) -> "
                                    f"sub-pel subme={args.subme} -> {8 << args.level}x{8 << args.level} prediction + DCT/quant/recon qp {args.qp} -> "
                                    f"border extension -> next reference; pipeline throughput, not HEVC encoded fps",
