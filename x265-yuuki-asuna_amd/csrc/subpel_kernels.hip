@@ -118,6 +118,50 @@ __device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemR
     const Px* patch = patches + pu * G::PSZ;
     const int pox = SP_MARGIN + tx * 4 - sh.ix[pu], poy = SP_MARGIN + ty * 4 - sh.iy[pu];
 
+    // Packed interpolation of the thread's 4 x 4 tile out of the LDS patch (same identities as csrc/interp_kernels.hip):
+    // horizontal taps by v_dot4_i32_i8 on (pixel - 128) bytes (8-bit) or v_dot2_i32_i16 on pixel pairs (16-bit), vertical
+    // taps by v_dot2_i32_i16 on (row r, row r + 1) pairs built with v_perm_b32; all sums are the exact int32 values.
+    typedef short v2i16 __attribute__((ext_vector_type(2)));
+    auto dot2 = [](const uint32_t x, const uint32_t y, const int c) -> int
+    { return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2i16, x), __builtin_bit_cast(v2i16, y), c, false); };
+    auto sel3 = [](const int f, const uint32_t a1, const uint32_t a2, const uint32_t a3) -> uint32_t { return f == 1 ? a1 : (f == 2 ? a2 : a3); };
+    const uint8_t* pbytes = reinterpret_cast<const uint8_t*>(patch);
+    // 4 horizontal sums (no rounding) of the row whose sample (ox - 3) sits at byte pointer rp
+    auto hrow = [&](const uint8_t* rp, const int xf, int (&out)[4])
+    {
+        if (BPP == 1)
+        {
+            const uint32_t c03 = sel3(xf, 0x3af604ffu, 0x28f504ffu, 0x11fb0100u), c47 = sel3(xf, 0x0001fb11u, 0xff04f528u, 0xff04f63au);
+            const uint32_t w0 = ld_u32(rp) ^ 0x80808080u, w1 = ld_u32(rp + 4) ^ 0x80808080u, w2 = ld_u32(rp + 8) ^ 0x80808080u;
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                const uint32_t lo = x ? __builtin_amdgcn_alignbyte(w1, w0, x) : w0, hi = x ? __builtin_amdgcn_alignbyte(w2, w1, x) : w1;
+                out[x] = __builtin_amdgcn_sdot4((int)hi, (int)c47, __builtin_amdgcn_sdot4((int)lo, (int)c03, 8192, false), false);
+            }
+        }
+        else
+        {
+            // taps as int16 pairs (c0,c1) (c2,c3) (c4,c5) (c6,c7)
+            const uint32_t cp[4] = { sel3(xf, 0x0004ffffu, 0x0004ffffu, 0x00010000u), sel3(xf, 0x003afff6u, 0x0028fff5u, 0x0011fffbu),
+                                     sel3(xf, 0xfffb0011u, 0xfff50028u, 0xfff6003au), sel3(xf, 0x00000001u, 0xffff0004u, 0xffff0004u) };
+            uint32_t dd[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) dd[k] = ld_u32(rp + 4 * k);
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                int sacc = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    const int k = (x >> 1) + j;
+                    sacc = dot2((x & 1) ? __builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 2) : dd[k], cp[j], sacc);
+                }
+                out[x] = sacc;
+            }
+        }
+    };
     auto tile_cost = [&](const int qx, const int qy, const bool useSatd) -> int
     {
         const int ox = (qx >> 2) + pox, oy = (qy >> 2) + poy;
@@ -135,73 +179,62 @@ __device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemR
 #pragma unroll
             for (int y = 0; y < 4; y++)
             {
-                int in[11];
+                int hs[4];
+                hrow(pbytes + ((oy + y) * PITCH + ox - 3) * BPP, xf, hs);
 #pragma unroll
-                for (int t = 0; t < 11; t++) in[t] = patch[(oy + y) * PITCH + ox + t - 3];
-#pragma unroll
-                for (int x = 0; x < 4; x++)
-                {
-                    int s = 0;
-#pragma unroll
-                    for (int t = 0; t < 8; t++) s += in[x + t] * kSpLumaTaps[xf][t];
-                    d[y][x] = sp_clip16((s + 32) >> 6, maxVal);
-                }
-            }
-        }
-        else if (!xf)
-        {
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-            {
-                int in[11];
-#pragma unroll
-                for (int t = 0; t < 11; t++) in[t] = patch[(oy + t - 3) * PITCH + ox + x];
-#pragma unroll
-                for (int y = 0; y < 4; y++)
-                {
-                    int s = 0;
-#pragma unroll
-                    for (int t = 0; t < 8; t++) s += in[y + t] * kSpLumaTaps[yf][t];
-                    d[y][x] = sp_clip16((s + 32) >> 6, maxVal);
-                }
+                for (int x = 0; x < 4; x++) d[y][x] = sp_clip16((hs[x] + 32) >> 6, maxVal);
             }
         }
         else
         {
             const int shiftPS = 6 - headRoom, offPS = -(8192 << shiftPS);
             const int shiftSP = 6 + headRoom, offSP = (1 << (shiftSP - 1)) + (8192 << 6);
-            int ch[8], cv[8];
-#pragma unroll
-            for (int t = 0; t < 8; t++) { ch[t] = kSpLumaTaps[xf][t]; cv[t] = kSpLumaTaps[yf][t]; }
-#pragma unroll
-            for (int y = 0; y < 4; y++)
-#pragma unroll
-                for (int x = 0; x < 4; x++) d[y][x] = offSP;
-            // stream the 11 horizontally filtered rows through the 4 x 4 vertical accumulators: the 16-bit
-            // intermediate row r feeds output row y with tap r - y
-#pragma unroll
-            for (int r = 0; r < 11; r++)
+            const uint32_t cv[4] = { sel3(yf, 0x0004ffffu, 0x0004ffffu, 0x00010000u), sel3(yf, 0x003afff6u, 0x0028fff5u, 0x0011fffbu),
+                                     sel3(yf, 0xfffb0011u, 0xfff50028u, 0xfff6003au), sel3(yf, 0x00000001u, 0xffff0004u, 0xffff0004u) };
+            uint32_t pairs[10][4];                           // (row r, row r + 1) at the 4 columns, rows oy - 3 .. oy + 7
+            if (!xf)
             {
-                int in[11];
+                uint32_t raw[11][2];
 #pragma unroll
-                for (int t = 0; t < 11; t++) in[t] = patch[(oy + r - 3) * PITCH + ox + t - 3];
-#pragma unroll
-                for (int x = 0; x < 4; x++)
+                for (int t = 0; t < 11; t++)
                 {
-                    int s = offPS;
-#pragma unroll
-                    for (int t = 0; t < 8; t++) s += in[x + t] * ch[t];
-                    const int im = (int)(int16_t)(s >> shiftPS);
-#pragma unroll
-                    for (int y = 0; y < 4; y++)
-                        if (r - y >= 0 && r - y < 8) d[y][x] += im * cv[r - y];
+                    const uint8_t* rp = pbytes + ((oy + t - 3) * PITCH + ox) * BPP;
+                    raw[t][0] = ld_u32(rp);
+                    raw[t][1] = BPP == 2 ? ld_u32(rp + 4) : 0;
                 }
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 10; t++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++)
+                        pairs[t][x] = BPP == 1 ? __builtin_amdgcn_perm(raw[t + 1][0], raw[t][0], 0x0c000c00u | (uint32_t)x | ((uint32_t)(4 + x) << 16))
+                                               : __builtin_amdgcn_perm(raw[t + 1][x >> 1], raw[t][x >> 1], (x & 1) ? 0x07060302u : 0x05040100u);
+            }
+            else
+            {
+                int im[11][4];
+#pragma unroll
+                for (int t = 0; t < 11; t++)
+                {
+                    int hs[4];
+                    hrow(pbytes + ((oy + t - 3) * PITCH + ox - 3) * BPP, xf, hs);
+#pragma unroll
+                    for (int x = 0; x < 4; x++) im[t][x] = (hs[x] + offPS) >> shiftPS;
+                }
+#pragma unroll
+                for (int t = 0; t < 10; t++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) pairs[t][x] = __builtin_amdgcn_perm((uint32_t)im[t + 1][x], (uint32_t)im[t][x], 0x05040100u);
             }
 #pragma unroll
             for (int y = 0; y < 4; y++)
 #pragma unroll
-                for (int x = 0; x < 4; x++) d[y][x] = sp_clip16(d[y][x] >> shiftSP, maxVal);
+                for (int x = 0; x < 4; x++)
+                {
+                    int sum = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sum = dot2(pairs[y + 2 * j][x], cv[j], sum);
+                    d[y][x] = xf ? sp_clip16((sum + offSP) >> shiftSP, maxVal) : sp_clip16((sum + 32) >> 6, maxVal);
+                }
         }
 #pragma unroll
         for (int y = 0; y < 4; y++)
