@@ -87,6 +87,12 @@ def test_me_packed_surface_rejected_for_high_bit_depth():
         ms.run(cur, ref)
 
 
+def test_me_10bit_column_group_kernel():
+    _run(128, 128, 16, 10, seed=11)     # 512-byte LDS pitch
+    _run(256, 64, 57, 10, seed=12)      # the reference's default merange
+    _run(64, 64, 20, 10, seed=13, extreme="flat")
+
+
 def test_me_default_merange_one_ctu_row():
     _run(256, 64, 57, 8, seed=4)        # the reference's default merange (param.cpp:198)
 

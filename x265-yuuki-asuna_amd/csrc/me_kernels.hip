@@ -463,6 +463,179 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 10-bit fast path: the column-group organisation of me_ctu_q_kernel for 16-bit pixels.  There is no packed
+// multi-displacement SAD for 16-bit samples, so the core is v_sad_u16 (2 pixels, 8.8 cycles): a wavefront owns 4 mv
+// columns, each window row is 6 dwords (12 pixels: even columns read pixel pairs as stored, odd columns through
+// v_alignbit 16) feeding 8 ring slots x 4 columns x 4 dwords = 128 v_sad_u16; the emission (transposed upper levels,
+// 16-byte group stores, row-local 32-bit keys) is the 8-bit kernel's.  Key widths hold for depth <= 10
+// (64x64 SAD + mv cost < 2^23); 12-bit pictures use the generic kernel.
+template <bool SURF, bool BEST, int PITCH>
+__global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 4) me_ctu_w_kernel(MEArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t win[];
+    typedef unsigned long long u64;
+
+    const int R = a.range;
+    const int NC = 2 * R + 1;
+    const int NG = (NC + 3) >> 2;
+    const int rows = 64 + 2 * R;
+    const int ctu = blockIdx.x;
+    const int cx = (ctu % a.ctusW) * 64, cy = (ctu / a.ctusW) * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    constexpr int pitch = PITCH;
+
+    const uint8_t* g0 = a.fref + (long)(cy - R) * a.frefStrideB + (long)(cx - R) * 2;
+    const int rowDw = a.payloadDw;
+    for (int r = wave; r < rows; r += nwaves)
+    {
+        const uint8_t* src = g0 + (long)r * a.frefStrideB;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(win + lds_row_off(r, pitch));
+        for (int c = lane; c < rowDw; c += 64)
+            dst[c] = ld_u32(src + 4 * c);
+    }
+    int bx, by;
+    zorder_xy(lane, bx, by);
+    uint32_t F[8][4];
+    {
+        const uint8_t* fe = a.fenc + (long)(cy + by * 8) * a.fencStrideB + (long)(cx + bx * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) F[j][k] = ld_u32(fe + (long)j * a.fencStrideB + 4 * k);
+    }
+    __syncthreads();
+
+    u64 bk8 = ~0ull, bk16 = ~0ull, bk32 = ~0ull, bk64 = ~0ull;
+    const int kcol = lane & 3;
+    const bool is64 = lane >= 52 && lane < 56;
+    const bool uMask = (lane & 15) < 4 || is64;
+    const int uOffDw = is64 ? 84 * 4 + kcol : (80 + (lane >> 4)) * 4 + kcol;
+
+    const int T = 2 * R + 8;
+    for (int g = wave; g < NG; g += nwaves)
+    {
+        const uint8_t* colBase = win + (by * 8) * pitch + (bx * 8 + 4 * g) * 2;
+        uint32_t cxk4[4] = { 0, 0, 0, 0 }, cxL = 0;
+        uint32_t r8 = 0xffffffffu, r16 = 0xffffffffu, r32 = 0xffffffffu, r64 = 0xffffffffu;
+        if (BEST)
+        {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                cxk4[k] = ((4 * g + k < NC ? (uint32_t)a.costX[4 * g + k] : (1u << 20)) << 2) | (uint32_t)k;
+            cxL = 4 * g + kcol < NC ? (uint32_t)a.costX[4 * g + kcol] : (1u << 23);
+        }
+        uint32_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[i][k] = 0;
+
+        auto row_step = [&](auto firstTag, const int t0, const int p)
+        {
+            constexpr bool FIRST = decltype(firstTag)::value;
+            const int t = t0 + p;
+            const uint32_t* lp = reinterpret_cast<const uint32_t*>(colBase + t * pitch + lds_skew_bytes(by + (t >> 3)));
+            uint32_t d[6], e[5];
+#pragma unroll
+            for (int k = 0; k < 6; k++) d[k] = lp[k];
+#pragma unroll
+            for (int k = 0; k < 5; k++) e[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], 16);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+            {
+                if (FIRST && j > p) continue;
+                const int slot = (p - j) & 7;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    acc[slot][0] = __builtin_amdgcn_sad_u16(d[k], F[j][k], acc[slot][0]);
+                    acc[slot][1] = __builtin_amdgcn_sad_u16(e[k], F[j][k], acc[slot][1]);
+                    acc[slot][2] = __builtin_amdgcn_sad_u16(d[k + 1], F[j][k], acc[slot][2]);
+                    acc[slot][3] = __builtin_amdgcn_sad_u16(e[k + 1], F[j][k], acc[slot][3]);
+                }
+            }
+            if (!FIRST || p == 7)
+            {
+                const int m = t - 7;
+                const int slot = (p + 1) & 7;
+                int s8[4], s16[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { s8[k] = (int)acc[slot][k]; acc[slot][k] = 0; s16[k] = quad_sum(s8[k]); }
+                const int v16 = kcol == 0 ? s16[0] : (kcol == 1 ? s16[1] : (kcol == 2 ? s16[2] : s16[3]));   // column kcol of 16x16 PU (lane >> 2)
+                const int v32 = row_sum_of_quads(v16);
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                v2u sw = __builtin_amdgcn_permlane16_swap((unsigned)v32, (unsigned)v32, false, false);
+                const unsigned h64 = sw.x + sw.y;
+                sw = __builtin_amdgcn_permlane32_swap(h64, h64, false, false);
+                const int v64 = (int)(sw.x + sw.y);
+                if (SURF)
+                {
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    const u64 gofs = (u64)((((long)ctu * NC + m) * NG + g) * 340) * 4;
+                    const u64 gsc = ((u64)__builtin_amdgcn_readfirstlane((uint32_t)(gofs >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)gofs);
+                    char* grp = reinterpret_cast<char*>(a.surf) + gsc;
+                    const v4i v8 = { s8[0], s8[1], s8[2], s8[3] };
+                    *reinterpret_cast<v4i*>(grp + (uint32_t)(lane * 16)) = v8;
+                    *reinterpret_cast<int*>(grp + (uint32_t)(1024 + lane * 4)) = v16;
+                    if (uMask) *reinterpret_cast<int*>(grp + (uint32_t)(uOffDw * 4)) = is64 ? v64 : v32;
+                }
+                if (BEST)
+                {
+                    const uint32_t cy_ = a.costY[m];
+                    {
+                        const uint32_t k0 = ((uint32_t)s8[0] << 2) + cxk4[0], k1 = ((uint32_t)s8[1] << 2) + cxk4[1];
+                        const uint32_t k2 = ((uint32_t)s8[2] << 2) + cxk4[2], k3 = ((uint32_t)s8[3] << 2) + cxk4[3];
+                        uint32_t kmin = k0 < k1 ? k0 : k1;
+                        kmin = k2 < kmin ? k2 : kmin;
+                        kmin = k3 < kmin ? k3 : kmin;
+                        const uint32_t rowc = (cy_ << 10) | ((uint32_t)m << 2);
+                        uint32_t key = ((kmin & ~3u) << 8) + rowc;
+                        key = (key & ~3u) | (kmin & 3u);
+                        r8 = key < r8 ? key : r8;
+                    }
+                    const uint32_t cxy = cxL + cy_;
+                    const uint32_t k16 = (((uint32_t)v16 + cxy) << 8) | (uint32_t)m;
+                    const uint32_t k32 = (((uint32_t)v32 + cxy) << 8) | (uint32_t)m;
+                    const uint32_t k64 = (((uint32_t)v64 + cxy) << 8) | (uint32_t)m;
+                    r16 = k16 < r16 ? k16 : r16;
+                    r32 = k32 < r32 ? k32 : r32;
+                    r64 = k64 < r64 ? k64 : r64;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int p = 0; p < 8; p++) row_step(std::true_type{}, 0, p);
+        for (int t0 = 8; t0 < T; t0 += 8)
+        {
+#pragma unroll
+            for (int p = 0; p < 8; p++)
+                if (t0 + p < T) row_step(std::false_type{}, t0, p);
+        }
+        if (BEST)
+        {
+            const u64 w8 = ((u64)(r8 >> 10) << 32) | (uint32_t)(((r8 >> 2) & 255u) * NC + 4 * g + (r8 & 3u));
+            bk8 = w8 < bk8 ? w8 : bk8;
+            auto widen = [&](const uint32_t r) { return ((u64)(r >> 8) << 32) | (uint32_t)((r & 255u) * NC + 4 * g + kcol); };
+            const u64 w16 = widen(r16), w32 = widen(r32), w64 = widen(r64);
+            bk16 = w16 < bk16 ? w16 : bk16;
+            bk32 = w32 < bk32 ? w32 : bk32;
+            bk64 = w64 < bk64 ? w64 : bk64;
+        }
+    }
+    if (BEST)
+    {
+        u64* rec = a.best + (size_t)ctu * 85;
+        atomicMin(&rec[lane], bk8);
+        atomicMin(&rec[64 + (lane >> 2)], bk16);
+        if ((lane & 15) < 4) atomicMin(&rec[80 + (lane >> 4)], bk32);
+        if (lane < 4) atomicMin(&rec[84], bk64);
+    }
+}
+
 // wavefronts per workgroup: as many as the column count keeps busy (16 = 1024 threads max); the
 // columns are dealt round-robin, so the idle tail is at most one column per wavefront.
 static int pick_waves(int ncols)
@@ -519,6 +692,25 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
 #undef LAUNCH_Q
     }
     else if (packed) { set_error("me_fullsearch: X265HIP_SURF_PACKED needs depth 8 and 2 * range + 75 <= 256"); return X265HIP_EINVAL; }
+    else if (sizeof(Px) == 2 && p->depth <= 10 && (a.rowBytes == 512 || a.rowBytes == 256) && !p_generic)
+    {
+        // 10-bit fast path (column groups, v_sad_u16); 2 * (2 * range + 76) bytes of window row must fit the 512-byte pitch
+        const int plw = (3 + (56 + 2 * p->range) * 2 + 4 * 6 + 3) >> 2;                 // the group kernel reads 6 dwords per row
+        a.payloadDw = plw > a.payloadDw ? plw : a.payloadDw;
+        if (a.payloadDw + 17 > a.rowBytes / 4) { set_error("me_fullsearch: internal: window row does not fit the LDS pitch"); return X265HIP_EINVAL; }
+#define LAUNCH_W(SF, BS, MAXW) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > (MAXW)) nwq = (MAXW); \
+        if (a.rowBytes == 256) hipLaunchKernelGGL((me_ctu_w_kernel<SF, BS, 256>), grid, dim3(nwq * 64), lds, s, a); \
+        else { \
+            if (lds > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_w_kernel<SF, BS, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((me_ctu_w_kernel<SF, BS, 512>), grid, dim3(nwq * 64), lds, s, a); } } while (0)
+        if (anySurf && anyBest && !getenv("X265HIP_ME_SPLIT")) LAUNCH_W(true, true, 12);
+        else
+        {
+            if (anySurf) LAUNCH_W(true, false, 16);
+            if (anyBest) LAUNCH_W(false, true, 16);
+        }
+#undef LAUNCH_W
+    }
     else if (anySurf && anyBest) LAUNCH(true, true);
     else if (anySurf) LAUNCH(true, false);
     else LAUNCH(false, true);
