@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(F, clip, rng_r, subme, level, qp, target_s=15.0):
+def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0):
     """The oracle chain (CPU restatement, AVX2 build when the host has AVX2) for one frame on a bounded number
     of CTUs, all host cores via OpenMP: exhaustive search (best mv) -> sub-pel -> prediction/residual round trip."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -54,11 +54,11 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, target_s=15.0):
 
     def run(n):
         t = time.perf_counter()
-        _, best = O.me_fullsearch(8, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, cost, cost,
+        _, best = O.me_fullsearch(depth, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, cost, cost,
                                   want_surf=False, want_best=True, nthreads=cores, avx2=avx2)
-        mv = O.subpel_refine(8, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, best, cq, qoff, subme,
+        mv = O.subpel_refine(depth, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, best, cq, qoff, subme,
                              nthreads=cores, avx2=avx2)
-        O.inter_recon(8, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp, ctu_begin=0, ctu_end=n,
+        O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp, ctu_begin=0, ctu_end=n,
                       nthreads=cores, avx2=avx2)
         return time.perf_counter() - t
 
@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--subme", type=int, default=3)           # preset slow (param.cpp:397-539); medium = 2
     ap.add_argument("--level", type=int, default=2)           # 32x32 blocks in the reconstruction stage
     ap.add_argument("--qp", type=int, default=27)
+    ap.add_argument("--depth", type=int, default=8, choices=[8, 10], help="10 = the Main10 configurations (configs[3], [4])")
     ap.add_argument("--no-surface", action="store_true", help="ME keeps only the best mv (no SAD surfaces)")
     ap.add_argument("--surf-format", choices=["packed", "i32"], default="packed",
                     help="SAD surface records: packed = u16 for the 8x8/16x16 levels (X265HIP_SURF_PACKED), i32 = all int32")
@@ -135,10 +136,10 @@ def main():
     A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
 
     nclip = 4
-    clip = F.synth_clip(args.width, args.height, nclip, depth=8, seed=265 + rank)
+    clip = F.synth_clip(args.width, args.height, nclip, depth=args.depth, seed=265 + rank)
     pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
-    pipe = S.FramePipeline(pics[0].w64, pics[0].h64, 8, dev, rng=args.range, subme=args.subme, level=args.level,
-                           qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed")
+    pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
+                           qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed" and args.depth == 8)
     ref_pic = P.DevicePicture.__new__(P.DevicePicture)
     ref_pic.__dict__.update(pics[0].__dict__)
     ref_pic.t = pics[0].t.clone()                    # the reference every rank searches in (starts as frame 0)
@@ -179,7 +180,7 @@ def main():
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         A.me_best_reset(ms.best)                  # 4 us fill, outside the timed kernel
         marks[0].record()
-        A.me_fullsearch(8, ms.w64, ms.h64, ms.range, cur.t, cur.stride, ref_pic.t, ref_pic.stride, surf=ms.surf, best=ms.best,
+        A.me_fullsearch(args.depth, ms.w64, ms.h64, ms.range, cur.t, cur.stride, ref_pic.t, ref_pic.stride, surf=ms.surf, best=ms.best,
                         cost_x=ms.cost_x, cost_y=ms.cost_y, fenc_off=cur.org, fref_off=ref_pic.org,
                         surf_format=A.SURF_PACKED if ms.packed else A.SURF_I32)                      # ONE fused launch
         marks[1].record()
@@ -198,29 +199,29 @@ def main():
         fps = world * args.steps / dt
         surf_mode = ms.surf is not None
         dom = "me"
-        alg_bytes = ms.algorithmic_bytes(bpp=1)
+        alg_bytes = ms.algorithmic_bytes(bpp=1 if args.depth == 8 else 2)
         achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9
-        traffic, tsrc = load_traffic(args.width, args.height, args.range, args.surf_format) if surf_mode else (None, None)
+        traffic, tsrc = load_traffic(args.width, args.height, args.range, ('packed' if ms.packed else 'i32') + ('' if args.depth == 8 else '_d10')) if surf_mode else (None, None)
         out = {
             "metric": "encoded fps + bit-exact check, 4K preset=slow, 1/2/4/8 MI355X vs host AVX2",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.width}x{args.height} 8-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: "
-                                   f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + args.surf_format + ' records) + ') if surf_mode else ''}best mv) -> "
+            "vs_baseline": None, "dtype": "u8" if args.depth == 8 else "u16", "data": "synthetic",
+            "config": {"workload": f"{args.width}x{args.height} {args.depth}-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: "
+                                   f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + ('packed' if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
                                    f"sub-pel subme={args.subme} -> {8 << args.level}x{8 << args.level} prediction + DCT/quant/recon qp {args.qp} -> "
                                    f"border extension -> next reference; pipeline throughput, not HEVC encoded fps",
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world}",
                        "ctus_per_frame": ms.nctu, "checksum": csum},
             "stages_ms": stages,
-            "roofline": {"bound": "hbm", "kernel": "me_ctu_q_kernel<surf,best>" if surf_mode else "me_ctu_q_kernel<best>",
+            "roofline": {"bound": "hbm", "kernel": ("me_ctu_q_kernel" if args.depth == 8 else "me_ctu_w_kernel") + ("<surf,best>" if surf_mode else "<best>"),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                         "algorithmic_bytes_per_launch": alg_bytes, "output_bytes_per_launch": ms.hbm_floor_bytes(1),
+                         "algorithmic_bytes_per_launch": alg_bytes, "output_bytes_per_launch": ms.hbm_floor_bytes(1 if args.depth == 8 else 2),
                          "launch_ms": stages[dom]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(F, clip, args.range, args.subme, args.level, args.qp)
+            out["cpu_baseline"] = cpu_baseline(F, clip, args.range, args.subme, args.level, args.qp, depth=args.depth)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
