@@ -127,10 +127,19 @@ def report(cpu, name, n, t_gpu, bpj, path, sig, planes, jobs, extra=""):
 
 
 def main():
+    import argparse
     import torch
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="comma-separated families to run: compare,interp,transform,quant,intra,blockop,loopfilter")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU columns (profiling runs)")
+    args = ap.parse_args()
+    want = set(x for x in args.only.split(",") if x)
+    on = lambda fam: not want or fam in want
     dev = "cuda:0"
     rng = np.random.default_rng(5)
     cpu = CPU()
+    if args.no_cpu:
+        cpu.ref = cpu.port = None
     print(f"# host CPU columns: {cpu.threads} OpenMP threads (= the container's CPU quota; {os.cpu_count()} hardware threads visible); ref-C = real reference C primitives (oracle/_ref, g++ -O2, "
           f"{'present' if cpu.ref is not None else 'ABSENT on this box'}); port = oracle restatement, gcc -O3 -march=x86-64-v3")
     print(HEADER)
@@ -140,7 +149,7 @@ def main():
     ref_d = to_dev(ref_h, dev)
 
     # ---- a1 / a4 / a5 / a6: block compare on a 4K plane, random candidate positions, fenc blocks at stride 64 ----
-    for kind, name, grp in ((A.CMP_SAD, "sad", "pu"), (A.CMP_SATD, "satd", "pu"), (A.CMP_SA8D, "sa8d", "cu"),
+    for kind, name, grp in () if not on("compare") else ((A.CMP_SAD, "sad", "pu"), (A.CMP_SATD, "satd", "pu"), (A.CMP_SA8D, "sa8d", "cu"),
                             (A.CMP_SSE_PP, "sse_pp", "cu"), (A.CMP_PSY_COST, "psy_cost_pp", "cu")):
         for w in (8, 16, 32, 64):
             if name in ("sse_pp", "psy_cost_pp") and w not in (16, 32):
@@ -182,19 +191,20 @@ def main():
         report(cpu, f"{'luma' if taps == 8 else 'chroma'} {kname} {w}x{w}", n, t, bpj, path, sig,
                [(src_h, st), (dst_h, w)], jb)
 
-    for w in (16, 64):
+    for w in (16, 64) if on("interp") else ():
         interp_case(A.IP_HPP, "hpp", "luma_hpp", SIG_FILTER, w, 8, np.uint8)
         interp_case(A.IP_VPP, "vpp", "luma_vpp", SIG_FILTER, w, 8, np.uint8)
         interp_case(A.IP_HVPP, "hvpp", "luma_hvpp", SIG_FILTER_HV, w, 8, np.uint8)
-    interp_case(A.IP_HPS, "hps(+rows)", "luma_hps", SIG_FILTER_HPS, 16, 8, np.int16)
-    interp_case(A.IP_VSP, "vsp", "luma_vsp", SIG_FILTER, 16, 8, np.uint8, src_short=True)
-    interp_case(A.IP_VSS, "vss", "luma_vss", SIG_FILTER, 16, 8, np.int16, src_short=True)
-    interp_case(A.IP_HPP, "hpp", "filter_hpp", SIG_FILTER, 8, 4, np.uint8)
-    interp_case(A.IP_VPP, "vpp", "filter_vpp", SIG_FILTER, 8, 4, np.uint8)
-    interp_case(A.IP_P2S, "p2s", "convert_p2s[0]", SIG_P2S, 32, 8, np.int16, bpj=32 * 32 * 3)
+    if on("interp"):
+        interp_case(A.IP_HPS, "hps(+rows)", "luma_hps", SIG_FILTER_HPS, 16, 8, np.int16)
+        interp_case(A.IP_VSP, "vsp", "luma_vsp", SIG_FILTER, 16, 8, np.uint8, src_short=True)
+        interp_case(A.IP_VSS, "vss", "luma_vss", SIG_FILTER, 16, 8, np.int16, src_short=True)
+        interp_case(A.IP_HPP, "hpp", "filter_hpp", SIG_FILTER, 8, 4, np.uint8)
+        interp_case(A.IP_VPP, "vpp", "filter_vpp", SIG_FILTER, 8, 4, np.uint8)
+        interp_case(A.IP_P2S, "p2s", "convert_p2s[0]", SIG_P2S, 32, 8, np.int16, bpj=32 * 32 * 3)
 
     # ---- a7: transforms, VALU vs MFMA ----
-    for n_ in (4, 8, 16, 32):
+    for n_ in (4, 8, 16, 32) if on("transform") else ():
         nb = 1 << 16
         src_h = rng.integers(-255, 256, size=nb * n_ * n_, dtype=np.int16)
         dst_h = np.zeros(nb * n_ * n_, np.int16)
@@ -211,6 +221,8 @@ def main():
                        SIG_DCT, [(src_h, n_), (dst_h, n_)], jb, extra)
 
     # ---- a8: quant family, 32x32 ----
+    if not (on("quant") or on("intra") or on("blockop") or on("loopfilter")):
+        return
     nb, n2 = 1 << 15, 1024
     coef_h = rng.integers(-255, 256, size=nb * n2, dtype=np.int16)
     qc_h = rng.integers(1, 256, size=nb * n2).astype(np.int32)
