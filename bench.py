@@ -8,6 +8,8 @@ A "step" = one 3840x2160 8-bit frame (BASELINE.json `metric`: "4K preset=slow" =
 3840x2176 whole CTUs like the reference; --width/--height select the other picture sizes) through the batched stages of
 the frame pipeline, everything resident in HBM:
 
+    LA   lookahead preparation of the source picture: four half-resolution planes + border extension, intra cost
+         estimate of every 8x8 lowres block (Lowres::init / lowresIntraEstimate)
     ME   exhaustive +-57 search (the reference's default merange), all 85 PUs of every CTU: SAD surfaces
          (sad_x4 grouping) + best mv, one launch
     SUB  sub-pel refinement of every PU (subme 3 = preset slow)
@@ -52,8 +54,15 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0):
     nctu = (w64 // 64) * (h64 // 64)
     cores = effective_cpus()
 
+    lw, lh = ((clip[0][0].shape[1] // 2 + 7) >> 3) * 8, ((clip[0][0].shape[0] // 2 + 7) >> 3) * 8
+    lstride = (lw + 2 * F.MARGIN_X + 31) & ~31
+
     def run(n):
         t = time.perf_counter()
+        if n == nctu:       # the lookahead stage is per picture: include it with whole-frame samples
+            lp = O.lowres_init(depth, cur, stride, org, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lh + 2 * F.MARGIN_Y, lw, lh,
+                               F.MARGIN_X, F.MARGIN_Y, avx2=avx2)
+            O.lowres_intra(depth, lp[0], lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lw // 8, lh // 8, 5, nthreads=cores, avx2=avx2)
         _, best = O.me_fullsearch(depth, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, cost, cost,
                                   want_surf=False, want_best=True, nthreads=cores, avx2=avx2)
         mv = O.subpel_refine(depth, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, best, cq, qoff, subme,
@@ -139,7 +148,8 @@ def main():
     clip = F.synth_clip(args.width, args.height, nclip, depth=args.depth, seed=265 + rank)
     pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
-                           qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed" and args.depth == 8)
+                           qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed" and args.depth == 8,
+                           lookahead=(args.width, args.height))
     ref_pic = P.DevicePicture.__new__(P.DevicePicture)
     ref_pic.__dict__.update(pics[0].__dict__)
     ref_pic.t = pics[0].t.clone()                    # the reference every rank searches in (starts as frame 0)
@@ -174,10 +184,14 @@ def main():
     # ---- untimed pass: HIP-event time of every stage (events on the stream the kernels are launched on) ----
     ms, sp, rc = pipe.ms, pipe.sp, pipe.rc
     cur = pics[1]
-    names = ["me", "subpel", "recon", "border"]
+    names = ["lookahead", "me", "subpel", "recon", "border"]
     acc = {k: [] for k in names}
     for _ in range(5):
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        lk, lk2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        lk.record()
+        pipe.la.run(cur)                          # half-resolution planes + intra cost estimate of the source picture
+        lk2.record()
         A.me_best_reset(ms.best)                  # 4 us fill, outside the timed kernel
         marks[0].record()
         A.me_fullsearch(args.depth, ms.w64, ms.h64, ms.range, cur.t, cur.stride, ref_pic.t, ref_pic.stride, surf=ms.surf, best=ms.best,
@@ -191,7 +205,8 @@ def main():
         S.extend_border(pipe.recon, cur)
         marks[4].record()
         torch.cuda.synchronize()
-        for j, k in enumerate(names):
+        acc["lookahead"].append(lk.elapsed_time(lk2))
+        for j, k in enumerate(names[1:]):
             acc[k].append(marks[j].elapsed_time(marks[j + 1]))
     stages = {k: round(float(np.median(v)), 4) for k, v in acc.items()}
 
@@ -207,7 +222,7 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8" if args.depth == 8 else "u16", "data": "synthetic",
-            "config": {"workload": f"{args.width}x{args.height} {args.depth}-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: "
+            "config": {"workload": f"{args.width}x{args.height} {args.depth}-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: lookahead lowres planes + intra estimate -> "
                                    f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + ('packed' if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
                                    f"sub-pel subme={args.subme} -> {8 << args.level}x{8 << args.level} prediction + DCT/quant/recon qp {args.qp} -> "
                                    f"border extension -> next reference; pipeline throughput, not HEVC encoded fps",

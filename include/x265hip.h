@@ -162,6 +162,34 @@ int x265hip_inter_recon(const x265hip_recon_params* p, void* stream);
  * margin_x columns / margin_y rows of padding on every side. */
 int x265hip_extend_border(void* pic, intptr_t stride, int width, int height, int margin_x, int margin_y, int depth, void* stream);
 
+/* ---- lookahead picture preparation and intra cost estimate (the intra half) ----
+ * x265hip_lowres_init = Lowres::init's pixel work (lowres.cpp:294-306): frameInitLowres (pixel.cpp:604-629) into the four
+ *   half-resolution planes (full-pel, H, V, HV phase) followed by extendPicBorder of each.  `src` = pixel (0,0) of the padded
+ *   full-resolution luma plane (it is read up to 2 * lines + 1 rows / 2 * width + 1 columns, i.e. into its margin when the
+ *   lowres size was rounded up to whole 8x8 blocks); plane[i] = pixel (0,0) of lowres plane i, all with `stride` and
+ *   margin_x / margin_y pixels of padding.  width / lines: lowres size, multiples of 8.
+ * x265hip_lowres_intra = LookaheadTLD::lowresIntraEstimate's per-block work (slicetype.cpp:696-772) on lowres plane 0:
+ *   intra_cost int32 / intra_mode uint8 / lowres_costs uint16 per 8x8 block in raster order; intra_penalty =
+ *   5 * (int)x265_lambda_tab[X265_LOOKAHEAD_QP] is computed by the host (constants.cpp double table). */
+typedef struct x265hip_lowres_init_params
+{
+    int depth;
+    const void* src; intptr_t src_stride;
+    void* plane[4]; intptr_t stride;
+    int width, lines;
+    int margin_x, margin_y;
+} x265hip_lowres_init_params;
+int x265hip_lowres_init(const x265hip_lowres_init_params* p, void* stream);
+typedef struct x265hip_lowres_intra_params
+{
+    int depth;
+    const void* plane; intptr_t stride;
+    int width_in_cu, height_in_cu;
+    int intra_penalty;
+    int32_t* intra_cost; uint8_t* intra_mode; uint16_t* lowres_costs;
+} x265hip_lowres_intra_params;
+int x265hip_lowres_intra(const x265hip_lowres_intra_params* p, void* stream);
+
 /* ------------------------------------------------------------------ generic job-list entry points
  * Every remaining family evaluates `njobs` independent blocks of one size per launch.  An operand
  * is a device plane (base pointer + element stride); a job carries up to four element offsets into

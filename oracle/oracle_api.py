@@ -100,3 +100,27 @@ def inter_recon(depth, fenc, fenc_stride, fenc_org, fref, fref_stride, fref_org,
        recon.ctypes.data + fenc_org * es, fenc_stride, width, height, level, m.ctypes.data, qp, intra_slice,
        levels.ctypes.data, num_sig.ctypes.data, dist.ctypes.data, ctu_begin, ctu_end, nthreads)
     return recon, levels, num_sig, dist
+
+
+def lowres_init(depth, src, src_stride, src_org, stride, org, rows, width, lines, margin_x, margin_y, avx2=False):
+    """CPU restatement of Lowres::init's pixel work.  Returns the four padded lowres planes (flat arrays of rows * stride)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_lowres_init_d{depth}")
+    planes = [np.zeros(rows * stride, dtype=src.dtype) for _ in range(4)]
+    es = src.itemsize
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t] + [ctypes.c_void_p] * 4 + [ctypes.c_ssize_t] + [ctypes.c_int] * 4
+    fn(src.ctypes.data + src_org * es, src_stride, *[p.ctypes.data + org * es for p in planes], stride, width, lines, margin_x, margin_y)
+    return planes
+
+
+def lowres_intra(depth, plane, stride, org, width_in_cu, height_in_cu, intra_penalty, nthreads=0, avx2=False):
+    """CPU restatement of LookaheadTLD::lowresIntraEstimate's per-block work.  Returns (intra_cost, intra_mode, lowres_costs)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_lowres_intra_d{depth}")
+    n = width_in_cu * height_in_cu
+    cost, mode, lc = np.zeros(n, np.int32), np.zeros(n, np.uint8), np.zeros(n, np.uint16)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                   ctypes.c_void_p, ctypes.c_int]
+    fn(plane.ctypes.data + org * plane.itemsize, stride, width_in_cu, height_in_cu, intra_penalty, cost.ctypes.data, mode.ctypes.data,
+       lc.ctypes.data, nthreads)
+    return cost, mode, lc

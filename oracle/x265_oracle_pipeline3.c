@@ -1,0 +1,139 @@
+/* oracle/x265_oracle_pipeline3.c
+ *
+ * TEST INFRASTRUCTURE - NOT PRODUCT CODE (same rules as x265_oracle.c).
+ *
+ * Stage: lookahead picture preparation and intra cost estimate (the intra half).
+ * Restates, on top of the oracle's primitive table, the call sequences of
+ *   Lowres::init          (source/common/lowres.cpp:294-306: frameInitLowres into the four half-resolution planes,
+ *                          then extendPicBorder of each, pixel.cpp:1027-1041) and
+ *   LookaheadTLD::lowresIntraEstimate (source/encoder/slicetype.cpp:696-772: per 8x8 block - copy_pp, neighbour
+ *                          collection from the padded plane, intra_filter, DC / planar / coarse-to-fine angular scan
+ *                          with intra_pred[] + satd 8x8, COPY2_IF_LT order, + intraPenalty + lowresPenalty).
+ * AQ weighting and the row / frame cost sums that follow in the reference are host bookkeeping and not restated.
+ */
+#ifndef X265HIP_DEPTH
+#error "compile with -DX265HIP_DEPTH=8|10|12"
+#endif
+#include "x265hip_table.h"
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef x265hip_pixel pixel;
+#define CAT_(a, b)   a##b
+#define CAT(a, b)    CAT_(a, b)
+#define EXPORT(name) CAT(CAT(name, _d), X265HIP_DEPTH)
+
+void EXPORT(x265oracle_setup_primitives)(x265hip_EncoderPrimitives* p);
+void EXPORT(x265oracle_setup_host_primitives)(x265hip_EncoderPrimitives* p);
+
+#define LOWRES_CU     8            /* common.h X265_LOWRES_CU_SIZE */
+#define LOWRES_CU_L2  3
+#define COST_MAX      (1 << 28)    /* motion.h:103 */
+#define LOWRES_COST_MASK ((1 << 14) - 1)
+
+static x265hip_EncoderPrimitives prim;
+static int ready;
+static void init(void)
+{
+    if (ready) return;
+    EXPORT(x265oracle_setup_primitives)(&prim);
+    EXPORT(x265oracle_setup_host_primitives)(&prim);
+    ready = 1;
+}
+
+static const uint8_t kFilterFlags[35] = {        /* constants.cpp:561 g_intraFilterFlags */
+    0x38, 0x00,
+    0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30,
+    0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30,
+    0x38 };
+
+/* pixel.cpp:1027-1041 extendPicBorder: left/right columns of every row, then whole rows above / below */
+static void extend_pic_border(pixel* pic, intptr_t stride, int width, int height, int marginX, int marginY)
+{
+    for (int y = 0; y < height; y++)
+    {
+        pixel* row = pic + y * stride;
+        for (int x = 0; x < marginX; x++) { row[-marginX + x] = row[0]; row[width + x] = row[width - 1]; }
+    }
+    pixel* top = pic - marginX;
+    for (int y = 0; y < marginY; y++) memcpy(top - (y + 1) * stride, top, (size_t)(width + 2 * marginX) * sizeof(pixel));
+    pixel* bot = pic + (height - 1) * stride - marginX;
+    for (int y = 0; y < marginY; y++) memcpy(bot + (y + 1) * stride, bot, (size_t)(width + 2 * marginX) * sizeof(pixel));
+}
+
+/* src: full-resolution padded plane ((0,0) pointer); planes[4]: (0,0) pointers of the four lowres planes, all with
+ * `lumaStride` and margins of marginX / marginY pixels; width / lines: lowres size (multiples of 8). */
+void EXPORT(x265oracle_lowres_init)(const pixel* src, intptr_t srcStride, pixel* p0, pixel* ph, pixel* pv, pixel* pc,
+                                    intptr_t lumaStride, int width, int lines, int marginX, int marginY)
+{
+    init();
+    prim.frameInitLowres(src, p0, ph, pv, pc, srcStride, lumaStride, width, lines);
+    extend_pic_border(p0, lumaStride, width, lines, marginX, marginY);
+    extend_pic_border(ph, lumaStride, width, lines, marginX, marginY);
+    extend_pic_border(pv, lumaStride, width, lines, marginX, marginY);
+    extend_pic_border(pc, lumaStride, width, lines, marginX, marginY);
+}
+
+/* plane: lowres plane 0 ((0,0) pointer, padded).  Outputs per 8x8 block, raster order: intraCost (int32), intraMode
+ * (uint8), lowresCosts (uint16 = min(cost, LOWRES_COST_MASK)). */
+void EXPORT(x265oracle_lowres_intra)(const pixel* plane, intptr_t stride, int widthInCU, int heightInCU, int intraPenalty,
+                                     int32_t* intraCost, uint8_t* intraMode, uint16_t* lowresCosts, int nthreads)
+{
+    init();
+    const int cuSize = LOWRES_CU, cuSize2 = 2 * LOWRES_CU, sizeIdx = LOWRES_CU_L2 - 2;
+    const int lowresPenalty = 4;
+    x265hip_pixelcmp_t satd = prim.pu[sizeIdx].satd;          /* pu[1] = LUMA_8x8 (slicetype.cpp:710) */
+    const int planar = cuSize >= 8;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+    for (int cuXY = 0; cuXY < widthInCU * heightInCU; cuXY++)
+    {
+        const int cuX = cuXY % widthInCU, cuY = cuXY / widthInCU;
+        pixel prediction[LOWRES_CU * LOWRES_CU], fencIntra[LOWRES_CU * LOWRES_CU];
+        pixel neighbours[2][LOWRES_CU * 4 + 1];
+        pixel* samples = neighbours[0];
+        pixel* filtered = neighbours[1];
+        const pixel* pixCur = plane + cuSize * cuX + (intptr_t)cuSize * cuY * stride;
+        prim.cu[sizeIdx].copy_pp(fencIntra, cuSize, pixCur, stride);
+        pixCur -= stride + 1;
+        memcpy(samples, pixCur, (2 * cuSize + 1) * sizeof(pixel));
+        for (int i = 1; i <= 2 * cuSize; i++) samples[cuSize2 + i] = pixCur[i * stride];
+        prim.cu[sizeIdx].intra_filter(samples, filtered);
+
+        int cost, icost = COST_MAX;
+        uint32_t ilowmode = 0;
+        prim.cu[sizeIdx].intra_pred[1](prediction, cuSize, samples, 0, cuSize <= 16);
+        cost = satd(fencIntra, cuSize, prediction, cuSize);
+        if (cost < icost) { icost = cost; ilowmode = 1; }
+        prim.cu[sizeIdx].intra_pred[0](prediction, cuSize, neighbours[planar], 0, 0);
+        cost = satd(fencIntra, cuSize, prediction, cuSize);
+        if (cost < icost) { icost = cost; ilowmode = 0; }
+
+        int acost = COST_MAX;
+        uint32_t alowmode = 4;
+#define TRY(M) do { const uint32_t mode_ = (M); const int filter = !!(kFilterFlags[mode_] & cuSize); \
+        prim.cu[sizeIdx].intra_pred[mode_](prediction, cuSize, neighbours[filter], (int)mode_, cuSize <= 16); \
+        cost = satd(fencIntra, cuSize, prediction, cuSize); \
+        if (cost < acost) { acost = cost; alowmode = mode_; } } while (0)
+        for (uint32_t mode = 5; mode < 35; mode += 5) TRY(mode);
+        for (uint32_t dist = 2; dist >= 1; dist--)
+        {
+            const uint32_t minusmode = alowmode - dist, plusmode = alowmode + dist;
+            TRY(minusmode);
+            TRY(plusmode);
+        }
+#undef TRY
+        if (acost < icost) { icost = acost; ilowmode = alowmode; }
+        icost += intraPenalty + lowresPenalty;
+        lowresCosts[cuXY] = (uint16_t)(icost < LOWRES_COST_MASK ? icost : LOWRES_COST_MASK);
+        intraCost[cuXY] = icost;
+        intraMode[cuXY] = (uint8_t)ilowmode;
+    }
+}

@@ -1,0 +1,290 @@
+// lookahead_kernels.hip - lookahead picture preparation and intra cost estimate on gfx950
+// (the intra half).
+//
+// Reference semantics:
+//   Lowres::init (source/common/lowres.cpp:294-306): primitives.frameInitLowres (frame_init_lowres_core,
+//     source/common/pixel.cpp:604-629) fills the four half-resolution planes - full-pel, H, V and HV phase, every
+//     sample the rounded average of two rounded vertical averages - and extendPicBorder pads each of them;
+//   LookaheadTLD::lowresIntraEstimate (source/encoder/slicetype.cpp:696-772): per 8x8 block of lowres plane 0 -
+//     neighbours read from the padded plane, intra_filter (intrapred.cpp:31-51), DC / planar / angular predictions
+//     (intrapred.cpp:53-204) scored with satd 8x8 (pixel.cpp:239-297), modes scanned 5,10..30 then +-2, +-1 around
+//     the best angle, COPY2_IF_LT (strict <) order, + intraPenalty + lowresPenalty.
+//
+// Mapping: lowres_init - a thread produces 4 horizontally adjacent samples of all four planes from a 3 x 12 source
+// patch (dword loads).  lowres_intra - one thread per 4x4 tile, four threads (one DPP quad) per 8x8 block, 64 blocks per
+// workgroup; the block's 33 + 33 neighbour samples live in LDS, every candidate mode is predicted sample by sample in
+// registers (closed form of the reference's projected reference line), Hadamard-transformed per tile and summed over
+// the quad; the data-dependent mode scan runs per quad without divergence because the mode only enters as data.
+#include "common.h"
+
+namespace x265hip {
+
+__constant__ int8_t kLaAngle[17] = { -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+__constant__ int16_t kLaInvAngle[8] = { 4096, 1638, 910, 630, 482, 390, 315, 256 };
+__constant__ uint8_t kLaFilterFlags[35] = {
+    0x38, 0x00,
+    0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30,
+    0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30,
+    0x38 };
+
+struct LowresInitArgs
+{
+    const uint8_t* src; long srcStrideB;
+    uint8_t* dst[4]; long dstStrideB;
+    int width, lines;                 // lowres size
+};
+
+__device__ __forceinline__ int la_avg(int a, int b) { return (a + b + 1) >> 1; }
+
+template <typename Px>
+__global__ void __launch_bounds__(256) lowres_init_kernel(LowresInitArgs a)
+{
+    constexpr int BPP = sizeof(Px);
+    const int qpr = a.width >> 2;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= qpr * a.lines) return;
+    const int y = q / qpr, x0 = (q - y * qpr) * 4;
+    // rows 2y, 2y+1, 2y+2 of the source, samples 2*x0 .. 2*x0 + 8
+    int s[3][9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+    {
+        const uint8_t* rp = a.src + (long)(2 * y + r) * a.srcStrideB + (long)(2 * x0) * BPP;
+        if (BPP == 1)
+        {
+            const uint32_t w0 = ld_u32(rp), w1 = ld_u32(rp + 4), w2 = ld_u32(rp + 8);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { s[r][k] = (w0 >> (8 * k)) & 0xff; s[r][4 + k] = (w1 >> (8 * k)) & 0xff; }
+            s[r][8] = w2 & 0xff;
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+            {
+                const uint32_t w = ld_u32(rp + 4 * k);
+                s[r][2 * k] = w & 0xffff;
+                if (2 * k + 1 < 9) s[r][2 * k + 1] = w >> 16;
+            }
+        }
+    }
+    int v01[9], v12[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { v01[k] = la_avg(s[0][k], s[1][k]); v12[k] = la_avg(s[1][k], s[2][k]); }
+    int o[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        o[0][k] = la_avg(v01[2 * k], v01[2 * k + 1]);
+        o[1][k] = la_avg(v01[2 * k + 1], v01[2 * k + 2]);
+        o[2][k] = la_avg(v12[2 * k], v12[2 * k + 1]);
+        o[3][k] = la_avg(v12[2 * k + 1], v12[2 * k + 2]);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 4; pl++)
+    {
+        uint8_t* dp = a.dst[pl] + (long)y * a.dstStrideB + (long)x0 * BPP;
+        if (BPP == 1)
+            *reinterpret_cast<u32_unaligned*>(dp) = (uint32_t)o[pl][0] | ((uint32_t)o[pl][1] << 8) | ((uint32_t)o[pl][2] << 16) | ((uint32_t)o[pl][3] << 24);
+        else
+        {
+            reinterpret_cast<u32_unaligned*>(dp)[0] = (uint32_t)o[pl][0] | ((uint32_t)o[pl][1] << 16);
+            reinterpret_cast<u32_unaligned*>(dp)[1] = (uint32_t)o[pl][2] | ((uint32_t)o[pl][3] << 16);
+        }
+    }
+}
+
+struct LowresIntraArgs
+{
+    const uint8_t* plane; long strideB;
+    int widthInCU, heightInCU, depth, intraPenalty;
+    int* intraCost; uint8_t* intraMode; uint16_t* lowresCosts;
+};
+
+// One predicted sample of an 8x8 block (n = 8): the reference's per-mode code in closed form.
+template <typename Px>
+__device__ __forceinline__ int la_sample(const Px* nb, int mode, int dc, int maxVal, int x, int y)
+{
+    constexpr int n = 8, n2 = 16;
+    if (mode == 0)
+        return ((n - 1 - x) * nb[n2 + 1 + y] + (n - 1 - y) * nb[1 + x] + (x + 1) * nb[1 + n] + (y + 1) * nb[n2 + 1 + n] + n) >> 4;
+    if (mode == 1)       // DC with edge filter (bFilter = cuSize <= 16)
+    {
+        if (x == 0 && y == 0) return (nb[1] + nb[n2 + 1] + 2 * dc + 2) >> 2;
+        if (y == 0) return (nb[1 + x] + 3 * dc + 2) >> 2;
+        if (x == 0) return (nb[n2 + 1 + y] + 3 * dc + 2) >> 2;
+        return dc;
+    }
+    const bool hor = mode < 18;
+    const int r = hor ? x : y, c = hor ? y : x;                      // horizontal modes predict the transpose
+    const int mainBase = hor ? n2 : 0, sideBase = hor ? 0 : n2;
+    const int aoff = hor ? 10 - mode : mode - 26;
+    const int angle = kLaAngle[8 + aoff];
+    if (angle == 0)
+    {
+        int v = nb[mainBase + 1 + c];
+        if (c == 0)                                                  // bFilter
+        {
+            const int16_t t = (int16_t)(nb[mainBase + 1] + (((int)nb[sideBase + 1 + r] - (int)nb[0]) >> 1));
+            v = t < 0 ? 0 : (t > maxVal ? maxVal : t);
+        }
+        return v;
+    }
+    const int inv = angle < 0 ? kLaInvAngle[-aoff - 1] : 0;
+    auto ref = [&](const int k) -> int
+    {
+        if (k >= 0) return nb[mainBase + 1 + k];
+        if (k == -1) return nb[0];
+        return nb[sideBase + ((128 + (-1 - k) * inv) >> 8)];
+    };
+    const int pos = (r + 1) * angle, off = pos >> 5, frac = pos & 31;
+    const int p0 = ref(off + c);
+    if (!frac) return p0;
+    return ((32 - frac) * p0 + frac * ref(off + c + 1) + 16) >> 5;
+}
+
+template <typename Px>
+__global__ void __launch_bounds__(256) lowres_intra_kernel(LowresIntraArgs a)
+{
+    constexpr int BPP = sizeof(Px);
+    __shared__ Px nbS[64][36], nbF[64][36];
+    const int tid = threadIdx.x;
+    const int bw = tid >> 2, tile = tid & 3;                         // block within the workgroup, 4x4 tile within the block
+    const int ncu = a.widthInCU * a.heightInCU;
+    const int cuXY = blockIdx.x * 64 + bw;
+    const bool live = cuXY < ncu;
+    const int cuX = live ? cuXY % a.widthInCU : 0, cuY = live ? cuXY / a.widthInCU : 0;
+    const Px* pix = reinterpret_cast<const Px*>(a.plane + (long)(8 * cuY) * a.strideB) + 8 * cuX;
+    const long st = a.strideB / BPP;
+    const int maxVal = (1 << a.depth) - 1;
+
+    // neighbours: [0] corner, [1..16] above + above-right, [17..32] left + below-left (slicetype.cpp:725-729)
+    for (int k = tile; k < 33; k += 4)
+        nbS[bw][k] = k <= 16 ? pix[-st - 1 + k] : pix[-1 + (long)(k - 17) * st];
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    for (int i = tile; i < 33; i += 4)                              // intra_filter, intrapred.cpp:31-51
+    {
+        const Px* s = nbS[bw];
+        int v;
+        if (i == 0) v = (2 * s[0] + s[1] + s[17] + 2) >> 2;
+        else if (i == 16 || i == 32) v = s[i];
+        else if (i == 17) v = (2 * s[17] + s[0] + s[18] + 2) >> 2;
+        else if (i == 1) v = (2 * s[1] + s[0] + s[2] + 2) >> 2;
+        else v = (2 * s[i] + s[i - 1] + s[i + 1] + 2) >> 2;
+        nbF[bw][i] = (Px)v;
+    }
+    __syncthreads();
+
+    // this thread's 4x4 source tile
+    const int tx = (tile & 1) * 4, ty = (tile >> 1) * 4;
+    int src[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) src[y][x] = pix[(long)(ty + y) * st + tx + x];
+    int dcSum = 8;
+    for (int i = 0; i < 8; i++) dcSum += nbS[bw][1 + i] + nbS[bw][17 + i];
+    const int dc = dcSum / 16;
+
+    auto mode_cost = [&](const int mode, const Px* nb) -> int
+    {
+        int d[4][4];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) d[y][x] = src[y][x] - la_sample<Px>(nb, mode, dc, maxVal, tx + x, ty + y);
+        int t4[4][4], acc = 0;
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            const int s0 = d[y][0] + d[y][1], s1 = d[y][0] - d[y][1], s2 = d[y][2] + d[y][3], s3 = d[y][2] - d[y][3];
+            t4[y][0] = s0 + s2; t4[y][1] = s1 + s3; t4[y][2] = s0 - s2; t4[y][3] = s1 - s3;
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+        {
+            const int s0 = t4[0][x] + t4[1][x], s1 = t4[0][x] - t4[1][x], s2 = t4[2][x] + t4[3][x], s3 = t4[2][x] - t4[3][x];
+            acc += abs(s0 + s2) + abs(s1 + s3) + abs(s0 - s2) + abs(s1 - s3);
+        }
+        return quad_sum(acc >> 1);                                   // every 4x4 abs-sum is even; 8x8 satd = sum of its four tiles
+    };
+    auto nb_for = [&](const int mode) -> const Px* { return (kLaFilterFlags[mode] & 8) ? nbF[bw] : nbS[bw]; };
+
+    int icost = 1 << 28, ilow = 0;
+    int cost = mode_cost(1, nbS[bw]);
+    if (cost < icost) { icost = cost; ilow = 1; }
+    cost = mode_cost(0, nbF[bw]);                                    // planar uses the filtered set when cuSize >= 8
+    if (cost < icost) { icost = cost; ilow = 0; }
+    int acost = 1 << 28, alow = 4;
+    for (int mode = 5; mode < 35; mode += 5)
+    {
+        cost = mode_cost(mode, nb_for(mode));
+        if (cost < acost) { acost = cost; alow = mode; }
+    }
+    for (int dist = 2; dist >= 1; dist--)
+    {
+        const int minusmode = alow - dist, plusmode = alow + dist;
+        cost = mode_cost(minusmode, nb_for(minusmode));
+        if (cost < acost) { acost = cost; alow = minusmode; }
+        cost = mode_cost(plusmode, nb_for(plusmode));
+        if (cost < acost) { acost = cost; alow = plusmode; }
+    }
+    if (acost < icost) { icost = acost; ilow = alow; }
+    icost += a.intraPenalty + 4;
+    if (live && tile == 0)
+    {
+        a.intraCost[cuXY] = icost;
+        a.intraMode[cuXY] = (uint8_t)ilow;
+        a.lowresCosts[cuXY] = (uint16_t)(icost < 16383 ? icost : 16383);
+    }
+}
+
+} // namespace x265hip
+
+using namespace x265hip;
+
+extern "C" int x265hip_lowres_init(const x265hip_lowres_init_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->src || !p->plane[0] || !p->plane[1] || !p->plane[2] || !p->plane[3]) { set_error("lowres_init: NULL plane"); return X265HIP_EINVAL; }
+    if (p->width <= 0 || p->lines <= 0 || (p->width & 7) || (p->lines & 7)) { set_error("lowres_init: lowres size %dx%d must be positive multiples of 8", p->width, p->lines); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("lowres_init: depth %d", p->depth); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    LowresInitArgs a;
+    a.src = (const uint8_t*)p->src; a.srcStrideB = (long)p->src_stride * bpp;
+    for (int i = 0; i < 4; i++) a.dst[i] = (uint8_t*)p->plane[i];
+    a.dstStrideB = (long)p->stride * bpp; a.width = p->width; a.lines = p->lines;
+    const int quads = (p->width >> 2) * p->lines;
+    hipStream_t s = (hipStream_t)stream;
+    if (bpp == 1) hipLaunchKernelGGL(lowres_init_kernel<uint8_t>, dim3((quads + 255) / 256), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lowres_init_kernel<uint16_t>, dim3((quads + 255) / 256), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    for (int i = 0; i < 4; i++)
+    {
+        rc = x265hip_extend_border(p->plane[i], p->stride, p->width, p->lines, p->margin_x, p->margin_y, p->depth, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int x265hip_lowres_intra(const x265hip_lowres_intra_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->plane || !p->intra_cost || !p->intra_mode || !p->lowres_costs) { set_error("lowres_intra: NULL operand"); return X265HIP_EINVAL; }
+    if (p->width_in_cu <= 0 || p->height_in_cu <= 0) { set_error("lowres_intra: empty picture"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("lowres_intra: depth %d", p->depth); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    LowresIntraArgs a;
+    a.plane = (const uint8_t*)p->plane; a.strideB = (long)p->stride * bpp;
+    a.widthInCU = p->width_in_cu; a.heightInCU = p->height_in_cu; a.depth = p->depth; a.intraPenalty = p->intra_penalty;
+    a.intraCost = p->intra_cost; a.intraMode = p->intra_mode; a.lowresCosts = p->lowres_costs;
+    const int ncu = p->width_in_cu * p->height_in_cu;
+    hipStream_t s = (hipStream_t)stream;
+    if (bpp == 1) hipLaunchKernelGGL(lowres_intra_kernel<uint8_t>, dim3((ncu + 63) / 64), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lowres_intra_kernel<uint16_t>, dim3((ncu + 63) / 64), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -47,6 +47,18 @@ class SubpelParams(ctypes.Structure):
     ]
 
 
+class LowresInitParams(ctypes.Structure):
+    _fields_ = [("depth", ctypes.c_int), ("src", ctypes.c_void_p), ("src_stride", ctypes.c_ssize_t),
+                ("plane", ctypes.c_void_p * 4), ("stride", ctypes.c_ssize_t),
+                ("width", ctypes.c_int), ("lines", ctypes.c_int), ("margin_x", ctypes.c_int), ("margin_y", ctypes.c_int)]
+
+
+class LowresIntraParams(ctypes.Structure):
+    _fields_ = [("depth", ctypes.c_int), ("plane", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),
+                ("width_in_cu", ctypes.c_int), ("height_in_cu", ctypes.c_int), ("intra_penalty", ctypes.c_int),
+                ("intra_cost", ctypes.c_void_p), ("intra_mode", ctypes.c_void_p), ("lowres_costs", ctypes.c_void_p)]
+
+
 def lib() -> ctypes.CDLL:
     """Load libx265hip.so (built in-tree by __graft_entry__.build()); fail loudly if absent."""
     global _lib
@@ -119,6 +131,33 @@ def subpel_refine(depth, width, height, rng, subme, fenc, fenc_stride, fref, fre
     f = lib().x265hip_subpel_refine
     f.argtypes = [ctypes.POINTER(SubpelParams), ctypes.c_void_p]
     check(f(ctypes.byref(p), s), "x265hip_subpel_refine")
+
+
+def lowres_init(depth, src, src_stride, src_off, planes, stride, org, width, lines, margin_x, margin_y, stream=None):
+    """src: padded full-resolution plane tensor (src_off = element offset of pixel (0,0)); planes: 4 tensors of the lowres
+    geometry (org = element offset of their pixel (0,0))."""
+    es = 1 if depth == 8 else 2
+    p = LowresInitParams()
+    p.depth, p.src, p.src_stride = depth, src.data_ptr() + src_off * es, src_stride
+    for i in range(4):
+        p.plane[i] = planes[i].data_ptr() + org * es
+    p.stride, p.width, p.lines, p.margin_x, p.margin_y = stride, width, lines, margin_x, margin_y
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_lowres_init
+    f.argtypes = [ctypes.POINTER(LowresInitParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_lowres_init")
+
+
+def lowres_intra(depth, plane, stride, org, width_in_cu, height_in_cu, intra_penalty, intra_cost, intra_mode, lowres_costs, stream=None):
+    es = 1 if depth == 8 else 2
+    p = LowresIntraParams()
+    p.depth, p.plane, p.stride = depth, plane.data_ptr() + org * es, stride
+    p.width_in_cu, p.height_in_cu, p.intra_penalty = width_in_cu, height_in_cu, intra_penalty
+    p.intra_cost, p.intra_mode, p.lowres_costs = intra_cost.data_ptr(), intra_mode.data_ptr(), lowres_costs.data_ptr()
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_lowres_intra
+    f.argtypes = [ctypes.POINTER(LowresIntraParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_lowres_intra")
 
 
 def me_best_reset(best, stream=None):

@@ -72,19 +72,56 @@ def extend_border(plane, pic: DevicePicture, stream=None):
                  "x265hip_extend_border")
 
 
+class Lookahead:
+    """Lookahead picture preparation + intra cost estimate on device (x265hip_lowres_init / x265hip_lowres_intra; reference
+    Lowres::init lowres.cpp:294-306 and LookaheadTLD::lowresIntraEstimate slicetype.cpp:696-772).  Geometry follows
+    Lowres::create (lowres.cpp:50-72): half resolution rounded up to whole 8x8 blocks, the full-resolution margins; the
+    row stride is sized for the ROUNDED width so the right margin never runs into the next row (the reference sizes it
+    from the unrounded width - a layout choice, not a result)."""
+
+    def __init__(self, width, height, depth, device, intra_penalty=5):
+        import torch
+        from . import frames as F
+        self.depth, self.penalty = depth, intra_penalty
+        self.wcu, self.hcu = (width // 2 + 7) >> 3, (height // 2 + 7) >> 3
+        self.width, self.lines = self.wcu * 8, self.hcu * 8
+        self.mx, self.my = F.MARGIN_X, F.MARGIN_Y
+        self.stride = (self.width + 2 * self.mx + 31) & ~31
+        self.org = self.stride * self.my + self.mx
+        dt = torch.uint8 if depth == 8 else torch.int16
+        self.planes = [torch.zeros(self.stride * (self.lines + 2 * self.my), dtype=dt, device=device) for _ in range(4)]
+        n = self.wcu * self.hcu
+        self.intra_cost = torch.zeros(n, dtype=torch.int32, device=device)
+        self.intra_mode = torch.zeros(n, dtype=torch.uint8, device=device)
+        self.lowres_costs = torch.zeros(n, dtype=torch.int16, device=device)
+
+    def run(self, pic: DevicePicture):
+        hipabi.lowres_init(self.depth, pic.t, pic.stride, pic.org, self.planes, self.stride, self.org,
+                           self.width, self.lines, self.mx, self.my)
+        hipabi.lowres_intra(self.depth, self.planes[0], self.stride, self.org, self.wcu, self.hcu, self.penalty,
+                            self.intra_cost, self.intra_mode, self.lowres_costs)
+
+    def checksum(self):
+        import torch
+        return {"intra_cost": int(self.intra_cost.sum(dtype=torch.int64).item()), "intra_mode": int(self.intra_mode.sum(dtype=torch.int64).item())}
+
+
 class FramePipeline:
     """Closed-loop frame pipeline: every frame is searched in, predicted from and reconstructed against the
     RECONSTRUCTION of the previous frame (like the reference's P-frame chain), all on device:
         ME (exhaustive, SAD surfaces and/or best mv) -> sub-pel refinement -> prediction + residual round trip
-        (NxN blocks) -> border extension -> the reconstruction becomes the next reference."""
+        (NxN blocks) -> border extension -> the reconstruction becomes the next reference.
+    With lookahead=(width, height) the source picture also goes through the lookahead stage (half-resolution planes + intra
+    cost estimate per 8x8 block), which only depends on the source."""
 
-    def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False):
+    def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False, lookahead=None):
         import torch
         from .pipeline import MotionSearch, SubpelRefine
         self.depth = depth
         self.ms = MotionSearch(w64, h64, rng, depth, device, want_surf=want_surf, want_best=True, packed=packed)
         self.sp = SubpelRefine(self.ms, subme, device)
         self.rc = InterRecon(self.ms.nctu, w64, h64, depth, level, qp, device)
+        self.la = Lookahead(lookahead[0], lookahead[1], depth, device) if lookahead else None
         self.recon = None
 
     def run(self, cur: DevicePicture, ref: DevicePicture):
@@ -92,6 +129,8 @@ class FramePipeline:
         import torch
         if self.recon is None:
             self.recon = torch.zeros_like(cur.t)
+        if self.la is not None:
+            self.la.run(cur)
         self.ms.run(cur, ref)
         self.sp.run(cur, ref)
         self.rc.run(cur, ref, self.recon, self.sp.out)
@@ -103,5 +142,7 @@ class FramePipeline:
         out = {}
         out.update(self.sp.checksum())
         out.update(self.rc.checksum())
+        if self.la is not None:
+            out.update(self.la.checksum())
         out["recon"] = int(self.recon.view(torch.uint8).to(torch.int64).sum().item())
         return out
