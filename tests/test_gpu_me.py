@@ -120,3 +120,36 @@ def test_me_hierarchy_property_full_size():
     rows = slice(ctu * ms.nc, (ctu + 1) * ms.nc)
     assert np.array_equal(_valid(ms.surf.cpu().numpy(), ms)[rows], _valid(surf, ms)[rows])
     assert np.array_equal(ms.best[ctu * 85:(ctu + 1) * 85].cpu().numpy().view(np.uint64), best[ctu * 85:(ctu + 1) * 85])
+
+
+def test_me_4k_default_config_properties():
+    """BASELINE configs[2] size (3840x2160, merange 57, packed records), through size-independent properties:
+    every parent SAD = sum of its four children at the same mv; best = min over the surface of (sad + mv cost, raster
+    index) for every PU of every CTU; three CTUs spot-checked against the oracle at full picture size."""
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(3840, 2160, 2, depth=8, seed=9)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    ms = P.MotionSearch(cur.w64, cur.h64, 57, 8, dev, packed=True)
+    ms.run(cur, ref)
+    torch.cuda.synchronize()
+    nmv = ms.nctu * ms.nc * ms.nc
+    cost = torch.from_numpy(ms.cost_host.astype(np.int64)).to(dev)
+    mvcost = (cost[:, None] + cost[None, :]).reshape(1, ms.nc * ms.nc, 1)            # [mvy * nc + mvx]
+    idx = torch.arange(ms.nc * ms.nc, device=dev, dtype=torch.int64).reshape(1, -1, 1)
+    views = [ms.level_view(l)[0] for l in range(4)]
+    for l in range(3):
+        child = views[l].reshape(nmv, P.LEVEL_PUS[l] // 4, 4).sum(dim=2)
+        assert torch.equal(child, views[l + 1]), f"level {l + 1} is not the sum of its children"
+    for l in range(4):
+        n = P.LEVEL_PUS[l]
+        key = ((views[l].reshape(ms.nctu, ms.nc * ms.nc, n).to(torch.int64) + mvcost) << 32) | idx
+        want = key.min(dim=1).values
+        got = ms.level_view(l)[1]
+        assert torch.equal(got, want), f"best of level {l} is not the surface minimum"
+        del key, want
+    O = _oracle()
+    for ctu in (0, 1017, ms.nctu - 1):
+        _, best = O.me_fullsearch(8, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org,
+                                  cur.w64, cur.h64, 57, ctu, ctu + 1, ms.cost_host, ms.cost_host, want_surf=False)
+        assert np.array_equal(ms.best[ctu * 85:(ctu + 1) * 85].cpu().numpy().view(np.uint64), best[ctu * 85:(ctu + 1) * 85])
