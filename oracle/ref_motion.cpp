@@ -1,0 +1,71 @@
+/* oracle/ref_motion.cpp - TEST INFRASTRUCTURE, never part of the product path.
+ *
+ * C-ABI window onto the REAL reference motion search: builds an x265::MotionEstimate object (encoder/motion.cpp)
+ * over caller-owned padded luma planes and runs MotionEstimate::motionEstimate() - integer search pattern + sub-pel
+ * refinement - exactly as the lookahead / --pme callers do through the luma-only setSourcePU overload
+ * (motion.cpp:171-196).  Compiled by oracle/Makefile into oracle/_ref/libx265ref<depth>.so; the tests use it to pin the
+ * oracle's restatement of the search drivers and of the sub-pel refinement against the reference itself.
+ */
+#include "common.h"
+#include "primitives.h"
+#include "lowres.h"
+#include "motion.h"
+#include "mv.h"
+
+#include <cstring>
+
+using namespace X265_NS;
+
+extern "C" void x265ref_encoder_table_reset_c(void);
+
+struct x265ref_me_job
+{
+    int32_t px, py;            /* PU position in the picture */
+    int32_t w, h;              /* PU size (a reference partition size) */
+    int32_t qmvpx, qmvpy;      /* quarter-pel motion vector predictor */
+    int32_t out_qmvx, out_qmvy, out_cost;
+};
+
+extern "C" {
+
+/* fenc / fref: pixel (0,0) of padded planes with the same stride.  method: X265_*_SEARCH (x265.h), subme 0..7,
+ * qp selects the BitCost lambda table (bitcost.cpp:40-58).  mvmin / mvmax: integer-pel search bounds applied to every job.
+ * Returns the number of jobs run. */
+int x265ref_motion_estimate(const void* fenc, const void* fref, intptr_t stride, int method, int subme, int merange, int qp,
+                            int mvminx, int mvminy, int mvmaxx, int mvmaxy, x265ref_me_job* jobs, int njobs)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }   /* MotionEstimate reads the global table */
+    MotionEstimate me;
+    me.init(X265_CSP_I400);
+    me.setQP(qp);
+    ReferencePlanes ref;
+    ref.fpelPlane[0] = (pixel*)fref;
+    ref.lumaStride = stride;
+    ref.isLowres = false;
+    ref.isWeighted = false;
+    const MV mvmin(mvminx, mvminy), mvmax(mvmaxx, mvmaxy);
+    for (int i = 0; i < njobs; i++)
+    {
+        x265ref_me_job& j = jobs[i];
+        const intptr_t offset = (intptr_t)j.py * stride + j.px;
+        me.setSourcePU((pixel*)fenc, stride, offset, j.w, j.h, method, method, method, subme);
+        MV out(0, 0);
+        const MV qmvp(j.qmvpx, j.qmvpy);
+        j.out_cost = me.motionEstimate(&ref, mvmin, mvmax, qmvp, 0, NULL, merange, out, 1);
+        j.out_qmvx = out.x;
+        j.out_qmvy = out.y;
+    }
+    return njobs;
+}
+
+/* the u16 cost of a quarter-pel mv difference for `qp` (index d + 2 * BC_MAX_MV), for tests that want the exact table */
+uint16_t x265ref_mvcost_entry(int qp, int d)
+{
+    BitCost bc;
+    bc.setQP(qp);
+    bc.setMVP(MV(0, 0));
+    return bc.mvcost(MV(d, 0)) - bc.mvcost(MV(0, 0)) + bc.mvcost(MV(0, 0)) / 2;   /* mvcost(d,0) = cost[d] + cost[0] */
+}
+
+} // extern "C"

@@ -1,0 +1,71 @@
+"""Pin the oracle's search + sub-pel chain against the REAL reference class: x265::MotionEstimate::motionEstimate()
+(encoder/motion.cpp:739-1561) run through oracle/ref_motion.cpp on the same padded planes, --me full, every PU of every
+CTU, several sub-pel levels.  The oracle side is exactly what the GPU parity tests compare the HIP kernels with
+(oracle_api.me_fullsearch -> subpel_refine), so GPU == oracle == reference for integer search + sub-pel refinement.
+
+The BitCost table of the reference at QP 24 (8-bit) / QP 12... is lambda = 4.0 (constants.cpp lambda tables), the value
+frames.mv_cost_table() uses, and the predictor is (0,0), so both sides price a motion vector identically."""
+import ctypes
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+
+X265_FULL_SEARCH = 5          # x265.h:492-497
+
+
+class Job(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("px", "py", "w", "h", "qmvpx", "qmvpy", "out_qmvx", "out_qmvy", "out_cost")]
+
+
+def _ref(depth):
+    path = os.path.join(ROOT, "oracle", "_ref", f"libx265ref{depth}.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    lib = ctypes.CDLL(path)
+    if not hasattr(lib, "x265ref_motion_estimate"):
+        pytest.skip("oracle/_ref predates ref_motion.cpp")
+    lib.x265ref_motion_estimate.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_int]
+    return lib
+
+
+def _zxy(z):
+    return (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)
+
+
+@pytest.mark.parametrize("depth,width,height,rng,seed", [(8, 128, 128, 8, 21), (8, 192, 64, 12, 22), (10, 128, 64, 6, 23)])
+def test_fullsearch_subpel_chain_equals_reference_motion_estimate(depth, width, height, rng, seed):
+    import oracle_api as O
+    lib = _ref(depth)
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=seed)
+    cur, stride, org, w64, h64 = F.pad_plane(clip[1][0])
+    ref = F.pad_plane(clip[0][0])[0]
+    cost = F.mv_cost_table(rng)
+    cq, qoff = F.qpel_cost_table(rng)
+    nctu = (w64 // 64) * (h64 // 64)
+    es = cur.itemsize
+    qp = 24 if depth == 8 else 12         # lambda 4.0 in the reference's table for this bit depth
+    _, best = O.me_fullsearch(depth, cur, stride, org, ref, stride, org, w64, h64, rng, 0, nctu, cost, cost, want_surf=False)
+    for subme in (0, 1, 2, 3, 5, 7):
+        mv = O.subpel_refine(depth, cur, stride, org, ref, stride, org, w64, h64, rng, 0, nctu, best, cq, qoff, subme).reshape(-1, 2)
+        jobs = (Job * (nctu * 85))()
+        for ctu in range(nctu):
+            cx, cy = (ctu % (w64 // 64)) * 64, (ctu // (w64 // 64)) * 64
+            for base, n, size in ((0, 64, 8), (64, 16, 16), (80, 4, 32), (84, 1, 64)):
+                for z in range(n):
+                    bx, by = _zxy(z)
+                    j = jobs[ctu * 85 + base + z]
+                    j.px, j.py, j.w, j.h, j.qmvpx, j.qmvpy = cx + bx * size, cy + by * size, size, size, 0, 0
+        lib.x265ref_motion_estimate(cur.ctypes.data + org * es, ref.ctypes.data + org * es, stride, X265_FULL_SEARCH, subme, rng, qp,
+                                    -rng, -rng, rng, rng, jobs, nctu * 85)
+        got = np.array([(j.out_cost, j.out_qmvx, j.out_qmvy) for j in jobs], dtype=np.int64)
+        q = mv[:, 1].astype(np.int64)
+        exp = np.stack([mv[:, 0].astype(np.int64), ((q & 0xffff) ^ 0x8000) - 0x8000, q >> 16], axis=1)
+        bad = np.nonzero((got != exp).any(axis=1))[0]
+        assert bad.size == 0, f"subme {subme}: {bad.size} of {len(got)} PUs differ, first {bad[:3]}: ref {got[bad[:3]]} oracle {exp[bad[:3]]}"
