@@ -1,0 +1,423 @@
+/* oracle/x265_oracle_search.c
+ *
+ * TEST INFRASTRUCTURE - NOT PRODUCT CODE (same rules as x265_oracle.c).
+ *
+ * Restatement of MotionEstimate::motionEstimate (source/encoder/motion.cpp:739-1561) for one PU and a general
+ * quarter-pel predictor, luma only, no extra candidates: the predictor / zero-mv start (:772-799), the integer search
+ * patterns DIA (:827-850), HEX (:852-948 incl. the square refine), STAR (:1138-1240 + StarPatternSearch :362-604,
+ * including the raster refinement's `tmv << 3` cost quirk at :1196) and FULL (:1397-1445), the choice between the
+ * search result and the measured predictor (:1452-1458), the zero-residual shortcut (:1464-1469) and the sub-pel
+ * refinement (:1508-1561) with subpelCompare (:1571-1613).  UMH and SEA are not restated.
+ * Pinned against the real class through oracle/ref_motion.cpp (tests/test_oracle_me_vs_reference.py).
+ */
+#ifndef X265HIP_DEPTH
+#error "compile with -DX265HIP_DEPTH=8|10|12"
+#endif
+#include "x265hip_table.h"
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef x265hip_pixel pixel;
+#define CAT_(a, b)   a##b
+#define CAT(a, b)    CAT_(a, b)
+#define EXPORT(name) CAT(CAT(name, _d), X265HIP_DEPTH)
+
+void EXPORT(x265oracle_setup_primitives)(x265hip_EncoderPrimitives* p);
+
+enum { ME_DIA = 0, ME_HEX = 1, ME_UMH = 2, ME_STAR = 3, ME_SEA = 4, ME_FULL = 5 };     /* x265.h:492-497 */
+
+typedef struct { int32_t px, py, w, h, qmvpx, qmvpy, out_qmvx, out_qmvy, out_cost; } me_job;
+typedef struct { int x, y; } mv_t;
+
+typedef struct { int hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd; } workload_t;
+static const workload_t kWorkload[8] = {          /* motion.cpp:48-58 */
+    { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+    { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+static const mv_t kHex2[8] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
+static const uint8_t kMod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+static const mv_t kSquare1[9] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+static const mv_t kOffsets[16] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
+                                   { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
+static const int kPuDims[25][2] = {
+    { 4, 4 }, { 8, 8 }, { 16, 16 }, { 32, 32 }, { 64, 64 }, { 8, 4 }, { 4, 8 }, { 16, 8 }, { 8, 16 }, { 32, 16 }, { 16, 32 },
+    { 64, 32 }, { 32, 64 }, { 16, 12 }, { 12, 16 }, { 16, 4 }, { 4, 16 }, { 32, 24 }, { 24, 32 }, { 32, 8 }, { 8, 32 },
+    { 64, 48 }, { 48, 64 }, { 64, 16 }, { 16, 64 } };
+
+typedef struct
+{
+    const struct x265hip_PU* pu;
+    pixel fenc[64 * 64];              /* the PU source at stride 64 (motion.cpp:193) */
+    const pixel* fref;                /* reference sample under the PU's top-left corner */
+    intptr_t stride;
+    int w;
+    const uint16_t* cost;             /* cost[q]: bit cost of a quarter-pel mv DIFFERENCE component q (index 0 = zero) */
+    int mvpx, mvpy;
+    mv_t mvmin, mvmax;
+} me_ctx;
+
+static inline int mvcost_q(const me_ctx* c, int qx, int qy) { return c->cost[qx - c->mvpx] + c->cost[qy - c->mvpy]; }
+static inline int sad_at(const me_ctx* c, int mx, int my) { return c->pu->sad(c->fenc, 64, c->fref + mx + (intptr_t)my * c->stride, c->stride); }
+static inline int cost_mv(const me_ctx* c, int mx, int my) { return sad_at(c, mx, my) + mvcost_q(c, mx * 4, my * 4); }
+static inline int in_range(const me_ctx* c, int x, int y) { return x >= c->mvmin.x && x <= c->mvmax.x && y >= c->mvmin.y && y <= c->mvmax.y; }
+
+/* motion.cpp:1571-1613 */
+static int subpel_compare(const me_ctx* c, int qx, int qy, int useSatd)
+{
+    const pixel* fref = c->fref + (qx >> 2) + (intptr_t)(qy >> 2) * c->stride;
+    const int xf = qx & 3, yf = qy & 3;
+    x265hip_pixelcmp_t cmp = useSatd ? c->pu->satd : c->pu->sad;
+    if (!(xf | yf)) return cmp(c->fenc, 64, fref, c->stride);
+    pixel buf[64 * 64];
+    if (!yf) c->pu->luma_hpp(fref, c->stride, buf, c->w, xf);
+    else if (!xf) c->pu->luma_vpp(fref, c->stride, buf, c->w, yf);
+    else c->pu->luma_hvpp(fref, c->stride, buf, c->w, xf, yf);
+    return cmp(c->fenc, 64, buf, c->w);
+}
+
+/* motion.cpp:362-604; point numbers and distances as in the reference's diagrams */
+static void star_pattern(const me_ctx* c, mv_t* bmv, int* bcost, int* bPointNr, int* bDistance, int earlyExitIters, int merange)
+{
+    const mv_t omv = *bmv;
+    int saved = *bcost, rounds = 0;
+#define PT(MX, MY, P, D) do { const int cost_ = cost_mv(c, (MX), (MY)); \
+        if (cost_ < *bcost) { *bcost = cost_; bmv->x = (MX); bmv->y = (MY); *bPointNr = (P); *bDistance = (D); } } while (0)
+    {
+        const int dist = 1;
+        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        /* inside the bounds the reference scores the same four points with one sad_x4 in this order */
+        if (top >= c->mvmin.y) PT(omv.x, top, 2, dist);
+        if (left >= c->mvmin.x) PT(left, omv.y, 4, dist);
+        if (right <= c->mvmax.x) PT(right, omv.y, 5, dist);
+        if (bottom <= c->mvmax.y) PT(omv.x, bottom, 7, dist);
+        if (*bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+    for (int dist = 2; dist <= 8; dist <<= 1)
+    {
+        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        const int top2 = omv.y - (dist >> 1), bottom2 = omv.y + (dist >> 1), left2 = omv.x - (dist >> 1), right2 = omv.x + (dist >> 1);
+        saved = *bcost;
+        if (top >= c->mvmin.y && left >= c->mvmin.x && right <= c->mvmax.x && bottom <= c->mvmax.y)
+        {
+            /* the x4 order differs from the per-point order of the border branch (:448-455 vs :459-500) */
+            PT(omv.x, top, 2, dist); PT(left2, top2, 1, dist >> 1); PT(right2, top2, 3, dist >> 1); PT(left, omv.y, 4, dist);
+            PT(right, omv.y, 5, dist); PT(left2, bottom2, 6, dist >> 1); PT(right2, bottom2, 8, dist >> 1); PT(omv.x, bottom, 7, dist);
+        }
+        else
+        {
+            if (top >= c->mvmin.y) PT(omv.x, top, 2, dist);
+            if (top2 >= c->mvmin.y)
+            {
+                if (left2 >= c->mvmin.x) PT(left2, top2, 1, dist >> 1);
+                if (right2 <= c->mvmax.x) PT(right2, top2, 3, dist >> 1);
+            }
+            if (left >= c->mvmin.x) PT(left, omv.y, 4, dist);
+            if (right <= c->mvmax.x) PT(right, omv.y, 5, dist);
+            if (bottom2 <= c->mvmax.y)
+            {
+                if (left2 >= c->mvmin.x) PT(left2, bottom2, 6, dist >> 1);
+                if (right2 <= c->mvmax.x) PT(right2, bottom2, 8, dist >> 1);
+            }
+            if (bottom <= c->mvmax.y) PT(omv.x, bottom, 7, dist);
+        }
+        if (*bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+    for (int dist = 16; dist <= (int)(int16_t)merange; dist <<= 1)
+    {
+        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        saved = *bcost;
+        if (top >= c->mvmin.y && left >= c->mvmin.x && right <= c->mvmax.x && bottom <= c->mvmax.y)
+        {
+            PT(omv.x, top, 0, dist); PT(left, omv.y, 0, dist); PT(right, omv.y, 0, dist); PT(omv.x, bottom, 0, dist);
+            for (int index = 1; index < 4; index++)
+            {
+                const int posYT = top + (dist >> 2) * index, posYB = bottom - (dist >> 2) * index;
+                const int posXL = omv.x - (dist >> 2) * index, posXR = omv.x + (dist >> 2) * index;
+                PT(posXL, posYT, 0, dist); PT(posXR, posYT, 0, dist); PT(posXL, posYB, 0, dist); PT(posXR, posYB, 0, dist);
+            }
+        }
+        else
+        {
+            if (top >= c->mvmin.y) PT(omv.x, top, 0, dist);
+            if (left >= c->mvmin.x) PT(left, omv.y, 0, dist);
+            if (right <= c->mvmax.x) PT(right, omv.y, 0, dist);
+            if (bottom <= c->mvmax.y) PT(omv.x, bottom, 0, dist);
+            for (int index = 1; index < 4; index++)
+            {
+                const int posYT = top + (dist >> 2) * index, posYB = bottom - (dist >> 2) * index;
+                const int posXL = omv.x - (dist >> 2) * index, posXR = omv.x + (dist >> 2) * index;
+                if (posYT >= c->mvmin.y)
+                {
+                    if (posXL >= c->mvmin.x) PT(posXL, posYT, 0, dist);
+                    if (posXR <= c->mvmax.x) PT(posXR, posYT, 0, dist);
+                }
+                if (posYB <= c->mvmax.y)
+                {
+                    if (posXL >= c->mvmin.x) PT(posXL, posYB, 0, dist);
+                    if (posXR <= c->mvmax.x) PT(posXR, posYB, 0, dist);
+                }
+            }
+        }
+        if (*bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+#undef PT
+}
+
+static int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static int motion_estimate_one(me_ctx* c, int method, int subme, int merange, int* outQx, int* outQy)
+{
+    const int qminx = c->mvmin.x * 4, qminy = c->mvmin.y * 4, qmaxx = c->mvmax.x * 4, qmaxy = c->mvmax.y * 4;
+    /* measure the clipped quarter-pel predictor (:772-781), re-measure its full-pel rounding (:783-787), try mv 0 (:789-799) */
+    int pmvx = clip3(qminx, qmaxx, c->mvpx), pmvy = clip3(qminy, qmaxy, c->mvpy);
+    const int bestprex = pmvx, bestprey = pmvy;
+    const int bprecost = subpel_compare(c, pmvx, pmvy, 0);
+    mv_t bmv = { (pmvx + 2) >> 2, (pmvy + 2) >> 2 };
+    int bcost = bprecost;
+    if ((pmvx | pmvy) & 3) bcost = cost_mv(c, bmv.x, bmv.y);
+    if (pmvx | pmvy)
+    {
+        const int cost = sad_at(c, 0, 0) + mvcost_q(c, 0, 0);
+        if (cost < bcost)
+        {
+            bcost = cost;
+            bmv.x = 0;
+            const int zy = 0 < c->mvmax.y ? 0 : c->mvmax.y;
+            bmv.y = zy > c->mvmin.y ? zy : c->mvmin.y;
+        }
+    }
+    int costs[4];
+    switch (method)
+    {
+    case ME_DIA:
+    {
+        bcost <<= 4;
+        int i = merange;
+        do
+        {
+            costs[0] = cost_mv(c, bmv.x, bmv.y - 1); costs[1] = cost_mv(c, bmv.x, bmv.y + 1);
+            costs[2] = cost_mv(c, bmv.x - 1, bmv.y); costs[3] = cost_mv(c, bmv.x + 1, bmv.y);
+            if ((bmv.y - 1 >= c->mvmin.y) & (bmv.y - 1 <= c->mvmax.y)) { if ((costs[0] << 4) + 1 < bcost) bcost = (costs[0] << 4) + 1; }
+            if ((bmv.y + 1 >= c->mvmin.y) & (bmv.y + 1 <= c->mvmax.y)) { if ((costs[1] << 4) + 3 < bcost) bcost = (costs[1] << 4) + 3; }
+            if ((costs[2] << 4) + 4 < bcost) bcost = (costs[2] << 4) + 4;
+            if ((costs[3] << 4) + 12 < bcost) bcost = (costs[3] << 4) + 12;
+            if (!(bcost & 15)) break;
+            bmv.x -= (int)((uint32_t)bcost << 28) >> 30;       /* the direction packed in the low 4 bits */
+            bmv.y -= (int)((uint32_t)bcost << 30) >> 30;
+            bcost &= ~15;
+        }
+        while (--i && in_range(c, bmv.x, bmv.y));
+        bcost >>= 4;
+        break;
+    }
+    case ME_HEX:
+    {
+        /* first full hexagon: six points in two groups of three; out-of-range rows are scored but not accepted */
+#define X3(D0, D1, D2) do { costs[0] = cost_mv(c, bmv.x + (D0).x, bmv.y + (D0).y); costs[1] = cost_mv(c, bmv.x + (D1).x, bmv.y + (D1).y); \
+                            costs[2] = cost_mv(c, bmv.x + (D2).x, bmv.y + (D2).y); } while (0)
+#define YOK(DY) ((bmv.y + (DY) >= c->mvmin.y) & (bmv.y + (DY) <= c->mvmax.y))
+#define LT(V) do { if ((V) < bcost) bcost = (V); } while (0)
+        { const mv_t a = { -2, 0 }, b = { -1, 2 }, d = { 1, 2 }; X3(a, b, d); }
+        bcost <<= 3;
+        if (YOK(0)) LT((costs[0] << 3) + 2);
+        if (YOK(2)) { LT((costs[1] << 3) + 3); LT((costs[2] << 3) + 4); }
+        { const mv_t a = { 2, 0 }, b = { 1, -2 }, d = { -1, -2 }; X3(a, b, d); }
+        if (YOK(0)) LT((costs[0] << 3) + 5);
+        if (YOK(-2)) { LT((costs[1] << 3) + 6); LT((costs[2] << 3) + 7); }
+        if (bcost & 7)
+        {
+            int dir = (bcost & 7) - 2;
+            if (YOK(kHex2[dir + 1].y))
+            {
+                bmv.x += kHex2[dir + 1].x; bmv.y += kHex2[dir + 1].y;
+                /* half hexagons that do not overlap the previous iteration */
+                for (int i = (merange >> 1) - 1; i > 0 && in_range(c, bmv.x, bmv.y); i--)
+                {
+                    X3(kHex2[dir + 0], kHex2[dir + 1], kHex2[dir + 2]);
+                    bcost &= ~7;
+                    if (YOK(kHex2[dir + 0].y)) LT((costs[0] << 3) + 1);
+                    if (YOK(kHex2[dir + 1].y)) LT((costs[1] << 3) + 2);
+                    if (YOK(kHex2[dir + 2].y)) LT((costs[2] << 3) + 3);
+                    if (!(bcost & 7)) break;
+                    dir += (bcost & 7) - 2;
+                    dir = kMod6m1[dir + 1];
+                    bmv.x += kHex2[dir + 1].x; bmv.y += kHex2[dir + 1].y;
+                }
+            }
+        }
+        bcost >>= 3;
+        /* square refine */
+        int dir = 0;
+        costs[0] = cost_mv(c, bmv.x, bmv.y - 1); costs[1] = cost_mv(c, bmv.x, bmv.y + 1);
+        costs[2] = cost_mv(c, bmv.x - 1, bmv.y); costs[3] = cost_mv(c, bmv.x + 1, bmv.y);
+        if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 1; }
+        if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 2; }
+        if (costs[2] < bcost) { bcost = costs[2]; dir = 3; }
+        if (costs[3] < bcost) { bcost = costs[3]; dir = 4; }
+        costs[0] = cost_mv(c, bmv.x - 1, bmv.y - 1); costs[1] = cost_mv(c, bmv.x - 1, bmv.y + 1);
+        costs[2] = cost_mv(c, bmv.x + 1, bmv.y - 1); costs[3] = cost_mv(c, bmv.x + 1, bmv.y + 1);
+        if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 5; }
+        if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 6; }
+        if (YOK(-1) && costs[2] < bcost) { bcost = costs[2]; dir = 7; }
+        if (YOK(1) && costs[3] < bcost) { bcost = costs[3]; dir = 8; }
+        bmv.x += kSquare1[dir].x; bmv.y += kSquare1[dir].y;
+#undef X3
+#undef YOK
+#undef LT
+        break;
+    }
+    case ME_STAR:
+    {
+        int bPointNr = 0, bDistance = 0;
+        star_pattern(c, &bmv, &bcost, &bPointNr, &bDistance, 3, merange);
+        int done = 0;
+        if (bDistance == 1)
+        {
+            if (bPointNr)
+            {
+                const int saved = bcost;
+                const mv_t m1 = { bmv.x + kOffsets[(bPointNr - 1) * 2].x, bmv.y + kOffsets[(bPointNr - 1) * 2].y };
+                const mv_t m2 = { bmv.x + kOffsets[(bPointNr - 1) * 2 + 1].x, bmv.y + kOffsets[(bPointNr - 1) * 2 + 1].y };
+                if (in_range(c, m1.x, m1.y)) { const int cost = cost_mv(c, m1.x, m1.y); if (cost < bcost) { bcost = cost; bmv = m1; } }
+                if (in_range(c, m2.x, m2.y)) { const int cost = cost_mv(c, m2.x, m2.y); if (cost < bcost) { bcost = cost; bmv = m2; } }
+                if (bcost == saved) done = 1;
+            }
+            else done = 1;
+        }
+        if (done) break;
+        const int RasterDistance = 5;
+        if (bDistance > RasterDistance)
+        {
+            for (int ty = c->mvmin.y; ty <= c->mvmax.y; ty += RasterDistance)
+                for (int tx = c->mvmin.x; tx <= c->mvmax.x; tx += RasterDistance)
+                {
+                    if (tx + RasterDistance * 3 <= c->mvmax.x)
+                    {
+                        for (int k = 0; k < 4; k++, tx += (k < 4 ? RasterDistance : 0))
+                        {
+                            /* the fourth candidate of every sad_x4 group is priced with mvcost(tmv << 3) (:1196) */
+                            const int cost = sad_at(c, tx, ty) + (k == 3 ? mvcost_q(c, tx * 8, ty * 8) : mvcost_q(c, tx * 4, ty * 4));
+                            if (cost < bcost) { bcost = cost; bmv.x = tx; bmv.y = ty; }
+                        }
+                    }
+                    else
+                    {
+                        const int cost = cost_mv(c, tx, ty);
+                        if (cost < bcost) { bcost = cost; bmv.x = tx; bmv.y = ty; }
+                    }
+                }
+        }
+        while (bDistance > 0)
+        {
+            bDistance = 0;
+            bPointNr = 0;
+            star_pattern(c, &bmv, &bcost, &bPointNr, &bDistance, 32, merange);
+            if (bDistance == 1)
+            {
+                if (!bPointNr) break;
+                const mv_t m1 = { bmv.x + kOffsets[(bPointNr - 1) * 2].x, bmv.y + kOffsets[(bPointNr - 1) * 2].y };
+                const mv_t m2 = { bmv.x + kOffsets[(bPointNr - 1) * 2 + 1].x, bmv.y + kOffsets[(bPointNr - 1) * 2 + 1].y };
+                if (in_range(c, m1.x, m1.y)) { const int cost = cost_mv(c, m1.x, m1.y); if (cost < bcost) { bcost = cost; bmv = m1; } }
+                if (in_range(c, m2.x, m2.y)) { const int cost = cost_mv(c, m2.x, m2.y); if (cost < bcost) { bcost = cost; bmv = m2; } }
+                break;
+            }
+        }
+        break;
+    }
+    case ME_FULL:
+        for (int ty = c->mvmin.y; ty <= c->mvmax.y; ty++)
+            for (int tx = c->mvmin.x; tx <= c->mvmax.x; tx++)
+            {
+                const int cost = cost_mv(c, tx, ty);
+                if (cost < bcost) { bcost = cost; bmv.x = tx; bmv.y = ty; }
+            }
+        break;
+    default:
+        return -1;
+    }
+
+    int bx, by;
+    if (bprecost < bcost) { bx = bestprex; by = bestprey; bcost = bprecost; }
+    else { bx = bmv.x * 4; by = bmv.y * 4; }
+    const workload_t wl = kWorkload[subme];
+    if (!bcost)
+        bcost = mvcost_q(c, bx, by);
+    else
+    {
+        int hpelSatd = wl.hpel_satd;
+        if (hpelSatd) bcost = subpel_compare(c, bx, by, 1) + mvcost_q(c, bx, by);
+        for (int iter = 0; iter < wl.hpel_iters; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= wl.hpel_dirs; i++)
+            {
+                const int qx = bx + kSquare1[i].x * 2, qy = by + kSquare1[i].y * 2;
+                if ((qy < qminy) | (qy > qmaxy)) continue;
+                const int cost = subpel_compare(c, qx, qy, hpelSatd) + mvcost_q(c, qx, qy);
+                if (cost < bcost) { bcost = cost; bdir = i; }
+            }
+            if (bdir) { bx += kSquare1[bdir].x * 2; by += kSquare1[bdir].y * 2; }
+            else break;
+        }
+        if (!hpelSatd) bcost = subpel_compare(c, bx, by, 1) + mvcost_q(c, bx, by);
+        for (int iter = 0; iter < wl.qpel_iters; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= wl.qpel_dirs; i++)
+            {
+                const int qx = bx + kSquare1[i].x, qy = by + kSquare1[i].y;
+                if ((qy < qminy) | (qy > qmaxy)) continue;
+                const int cost = subpel_compare(c, qx, qy, 1) + mvcost_q(c, qx, qy);
+                if (cost < bcost) { bcost = cost; bdir = i; }
+            }
+            if (bdir) { bx += kSquare1[bdir].x; by += kSquare1[bdir].y; }
+            else break;
+        }
+    }
+    *outQx = bx; *outQy = by;
+    return bcost;
+}
+
+/* fenc / fref: pixel (0,0) of padded planes of equal stride.  cost: uint16 table, cost[q] for q in [-qoff, qoff]
+ * (pointer to the q = 0 entry is cost + qoff).  Runs every job; returns 0, or -1 for an unsupported method / PU size. */
+int EXPORT(x265oracle_motion_estimate)(const pixel* fenc, const pixel* fref, intptr_t stride, int method, int subme, int merange,
+                                       const uint16_t* cost, int qoff, int mvminx, int mvminy, int mvmaxx, int mvmaxy,
+                                       me_job* jobs, int njobs, int nthreads)
+{
+    static x265hip_EncoderPrimitives prim;
+    static int ready = 0;
+    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    if (subme < 0 || subme > 7) return -1;
+    int rc = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int i = 0; i < njobs; i++)
+    {
+        me_job* j = &jobs[i];
+        int part = -1;
+        for (int k = 1; k < 25; k++) if (kPuDims[k][0] == j->w && kPuDims[k][1] == j->h) part = k;
+        if (part < 0) { rc = -1; continue; }
+        me_ctx c;
+        c.pu = &prim.pu[part];
+        c.stride = stride; c.w = j->w;
+        c.fref = fref + j->px + (intptr_t)j->py * stride;
+        c.pu->copy_pp(c.fenc, 64, fenc + j->px + (intptr_t)j->py * stride, stride);
+        c.cost = cost + qoff;
+        c.mvpx = j->qmvpx; c.mvpy = j->qmvpy;
+        c.mvmin.x = mvminx; c.mvmin.y = mvminy; c.mvmax.x = mvmaxx; c.mvmax.y = mvmaxy;
+        int qx = 0, qy = 0;
+        const int cst = motion_estimate_one(&c, method, subme, merange, &qx, &qy);
+        if (cst < 0) { rc = -1; continue; }
+        j->out_cost = cst; j->out_qmvx = qx; j->out_qmvy = qy;
+    }
+    return rc;
+}

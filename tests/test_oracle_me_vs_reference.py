@@ -69,3 +69,65 @@ def test_fullsearch_subpel_chain_equals_reference_motion_estimate(depth, width, 
         exp = np.stack([mv[:, 0].astype(np.int64), ((q & 0xffff) ^ 0x8000) - 0x8000, q >> 16], axis=1)
         bad = np.nonzero((got != exp).any(axis=1))[0]
         assert bad.size == 0, f"subme {subme}: {bad.size} of {len(got)} PUs differ, first {bad[:3]}: ref {got[bad[:3]]} oracle {exp[bad[:3]]}"
+
+
+ALL_PU_DIMS = [(8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (4, 8), (16, 8), (8, 16), (32, 16), (16, 32), (64, 32), (32, 64), (16, 12),
+               (12, 16), (16, 4), (4, 16), (32, 24), (24, 32), (32, 8), (8, 32), (64, 48), (48, 64), (64, 16), (16, 64)]
+METHODS = {"dia": 0, "hex": 1, "star": 3, "full": 5}          # x265.h:492-497
+
+
+def random_me_jobs(rng, n, width, height):
+    jobs = (Job * n)()
+    for j in jobs:
+        w, h = ALL_PU_DIMS[int(rng.integers(0, len(ALL_PU_DIMS)))]
+        j.px, j.py = int(rng.integers(0, (width - w) // 4 + 1)) * 4, int(rng.integers(0, (height - h) // 4 + 1)) * 4
+        j.w, j.h = w, h
+        if rng.integers(0, 4):                                     # mostly a non-zero, usually fractional predictor
+            j.qmvpx, j.qmvpy = int(rng.integers(-40, 41)), int(rng.integers(-40, 41))
+    return jobs
+
+
+def copy_jobs(jobs):
+    out = (Job * len(jobs))()
+    ctypes.memmove(out, jobs, ctypes.sizeof(jobs))
+    return out
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("method", ["dia", "hex", "star", "full"])
+def test_search_driver_restatement_equals_reference_motion_estimate(depth, method):
+    """oracle/x265_oracle_search.c (predictor start, DIA / HEX / STAR / FULL patterns, predictor-vs-search choice, sub-pel
+    refinement) against the real MotionEstimate::motionEstimate: random PU sizes (all 24 inter partitions), positions,
+    quarter-pel predictors, search bounds, merange and every sub-pel level."""
+    lib = _ref(depth)
+    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libx265oracle.so"))
+    f = getattr(orc, f"x265oracle_motion_estimate_d{depth}")
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + \
+                 [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    width, height = 256, 192
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=31)
+    cur, stride, org, _, _ = F.pad_plane(clip[1][0])
+    ref = F.pad_plane(clip[0][0])[0]
+    es = cur.itemsize
+    rng = np.random.default_rng([7, depth, METHODS[method]])
+    qp = 24 if depth == 8 else 12
+    total = 0
+    for subme in range(8):
+        for merange in ((4, 16, 57) if method != "full" else (6,)):
+            bound = merange if method == "full" else 57
+            cq, qoff = F.qpel_cost_table(bound, qmax=8 * 64 + 300)
+            mn, mx = (-bound, -bound), (bound, bound)
+            if rng.integers(0, 3) == 0:                            # tight, asymmetric bounds exercise the border branches
+                mn = (-int(rng.integers(3, 20)), -int(rng.integers(3, 20)))
+                mx = (int(rng.integers(3, 20)), int(rng.integers(3, 20)))
+            ja = random_me_jobs(rng, 40, width, height)
+            jb = copy_jobs(ja)
+            lib.x265ref_motion_estimate(cur.ctypes.data + org * es, ref.ctypes.data + org * es, stride, METHODS[method], subme, merange, qp,
+                                        mn[0], mn[1], mx[0], mx[1], ja, len(ja))
+            assert f(cur.ctypes.data + org * es, ref.ctypes.data + org * es, stride, METHODS[method], subme, merange, cq.ctypes.data, qoff,
+                     mn[0], mn[1], mx[0], mx[1], jb, len(jb), 1) == 0
+            for a, b in zip(ja, jb):
+                assert (a.out_cost, a.out_qmvx, a.out_qmvy) == (b.out_cost, b.out_qmvx, b.out_qmvy), \
+                    f"{method} subme {subme} merange {merange} PU {(a.px, a.py, a.w, a.h)} mvp {(a.qmvpx, a.qmvpy)} bounds {mn}..{mx}"
+                total += 1
+    assert total >= 300

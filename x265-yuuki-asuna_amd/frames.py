@@ -81,10 +81,11 @@ def write_y4m(path: str, frames, width: int, height: int, depth: int = 8, fps: i
                 f.write(np.ascontiguousarray(pl).astype("<u2" if depth > 8 else np.uint8).tobytes())
 
 
-def qpel_cost_table(rng_r: int, lam: float = 4.0):
+def qpel_cost_table(rng_r: int, lam: float = 4.0, qmax: int = 0):
     """uint16 bit-cost of a QUARTER-pel mv component q in [-4R-8, 4R+8] (index q + qoff), same formula as
-    mv_cost_table; the integer-search table is its every-4th entry.  Returns (table, qoff)."""
-    qoff = 4 * rng_r + 8
+    mv_cost_table; the integer-search table is its every-4th entry.  qmax widens the table (the search drivers index
+    it with mv - predictor differences and, for one STAR candidate, with 8x the integer mv).  Returns (table, qoff)."""
+    qoff = max(4 * rng_r + 8, qmax)
     q = np.arange(-qoff, qoff + 1)
     i = np.abs(q).astype(np.float32)
     bits = (np.log(i + np.float32(1.0)) * np.float32(2.0) / np.log(np.float32(2.0)) + np.float32(1.718)).astype(np.float32)
