@@ -162,6 +162,35 @@ int x265hip_inter_recon(const x265hip_recon_params* p, void* stream);
  * margin_x columns / margin_y rows of padding on every side. */
 int x265hip_extend_border(void* pic, intptr_t stride, int width, int height, int margin_x, int margin_y, int depth, void* stream);
 
+/* ---- motion search drivers: MotionEstimate::motionEstimate for a list of PUs ----
+ * One job = one prediction unit of one reference picture: position, size (any of the reference's 24 inter partitions,
+ * primitives.h:41-55 minus 4x4), quarter-pel predictor.  For every job the kernel reproduces motionEstimate() with no extra
+ * candidates (encoder/motion.cpp:739-1561): predictor / zero start, the integer pattern `method` (X265_DIA_SEARCH,
+ * X265_HEX_SEARCH, X265_STAR_SEARCH, X265_FULL_SEARCH of x265.h:492-497; UMH and SEA are rejected), the predictor-vs-search
+ * choice and the sub-pel refinement level `subme`; out_qmv / out_cost are its outQMv and return value.
+ *   fenc, fref : pixel (0,0) of the padded source / reference luma planes; fref needs mvmax + 8 valid pixels of margin
+ *   cost_q     : uint16 bit cost of a quarter-pel mv DIFFERENCE component, cost_q[qoff + d] (BitCost::s_costs, built on the
+ *                host, bitcost.cpp:40-58); d ranges over mv - predictor and, for one STAR raster candidate, 8 x mv - predictor
+ *   mvmin/mvmax: integer-pel search bounds applied to every job */
+enum { X265HIP_ME_DIA = 0, X265HIP_ME_HEX = 1, X265HIP_ME_UMH = 2, X265HIP_ME_STAR = 3, X265HIP_ME_SEA = 4, X265HIP_ME_FULL = 5 };
+typedef struct x265hip_me_search_job
+{
+    int32_t px, py, w, h;
+    int32_t qmvpx, qmvpy;
+    int32_t out_qmvx, out_qmvy, out_cost;
+} x265hip_me_search_job;
+typedef struct x265hip_me_search_params
+{
+    int depth;
+    const void* fenc;  intptr_t fenc_stride;
+    const void* fref;  intptr_t fref_stride;
+    int method, subme, merange;
+    const uint16_t* cost_q;  int qoff;
+    int mvmin_x, mvmin_y, mvmax_x, mvmax_y;
+    x265hip_me_search_job* jobs;  int njobs;      /* DEVICE array, results written in place */
+} x265hip_me_search_params;
+int x265hip_me_search(const x265hip_me_search_params* p, void* stream);
+
 /* ---- lookahead picture preparation and intra cost estimate (the intra half) ----
  * x265hip_lowres_init = Lowres::init's pixel work (lowres.cpp:294-306): frameInitLowres (pixel.cpp:604-629) into the four
  *   half-resolution planes (full-pel, H, V, HV phase) followed by extendPicBorder of each.  `src` = pixel (0,0) of the padded

@@ -1,0 +1,96 @@
+"""GPU parity: the motion search drivers (x265hip_me_search) vs the oracle's restatement of
+MotionEstimate::motionEstimate (oracle/x265_oracle_search.c), which tests/test_oracle_me_vs_reference.py pins against the
+real reference class - so GPU == oracle == x265 for predictor start, DIA / HEX / STAR / FULL and the sub-pel refinement."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+
+ALL_PU_DIMS = [(8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (4, 8), (16, 8), (8, 16), (32, 16), (16, 32), (64, 32), (32, 64), (16, 12),
+               (12, 16), (16, 4), (4, 16), (32, 24), (24, 32), (32, 8), (8, 32), (64, 48), (48, 64), (64, 16), (16, 64)]
+METHODS = {"dia": A.ME_DIA, "hex": A.ME_HEX, "star": A.ME_STAR, "full": A.ME_FULL}
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_api
+    return oracle_api
+
+
+def _jobs(rng, n, width, height, zero_mvp=False):
+    jobs = np.zeros(n, dtype=A.me_search_job_dtype())
+    for j in jobs:
+        w, h = ALL_PU_DIMS[int(rng.integers(0, len(ALL_PU_DIMS)))]
+        j["px"], j["py"] = int(rng.integers(0, (width - w) // 4 + 1)) * 4, int(rng.integers(0, (height - h) // 4 + 1)) * 4
+        j["w"], j["h"] = w, h
+        if not zero_mvp and rng.integers(0, 4):
+            j["qmvpx"], j["qmvpy"] = int(rng.integers(-40, 41)), int(rng.integers(-40, 41))
+    return jobs
+
+
+def _check(depth, method, width, height, seed, njobs, submes, meranges, extreme=None):
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=seed)
+    y0, y1 = clip[0][0], clip[1][0]
+    if extreme == "flat":
+        y0 = np.zeros_like(y0); y1 = np.full_like(y1, (1 << depth) - 1)
+    cur, ref = P.DevicePicture(y1, dev), P.DevicePicture(y0, dev)
+    rng = np.random.default_rng([seed, depth, METHODS[method]])
+    for subme in submes:
+        for merange in meranges:
+            bound = merange if method == "full" else 57
+            cq, qoff = F.qpel_cost_table(bound, qmax=8 * 64 + 300)
+            cq_d = torch.from_numpy(cq.view(np.int16)).to(dev)
+            mn, mx = (-bound, -bound), (bound, bound)
+            if rng.integers(0, 3) == 0:
+                mn = (-int(rng.integers(3, 20)), -int(rng.integers(3, 20)))
+                mx = (int(rng.integers(3, 20)), int(rng.integers(3, 20)))
+            jobs = _jobs(rng, njobs, width, height)
+            exp = O.motion_estimate(depth, cur.host, ref.host, cur.stride, cur.org, METHODS[method], subme, merange, cq, qoff, mn, mx, jobs)
+            jd = torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy()).to(dev)
+            A.me_search(depth, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, METHODS[method], subme, merange, cq_d, qoff, mn, mx, jd, njobs)
+            torch.cuda.synchronize()
+            got = jd.cpu().numpy().view(A.me_search_job_dtype())
+            for f in ("out_cost", "out_qmvx", "out_qmvy"):
+                bad = np.nonzero(got[f] != exp[f])[0]
+                assert bad.size == 0, (f"{method} depth {depth} subme {subme} merange {merange} bounds {mn}..{mx}: {f} differs for {bad.size} of {njobs} "
+                                       f"jobs, first {jobs[bad[0]]}: got {got[bad[0]]} expected {exp[bad[0]]}")
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("method", ["dia", "hex", "star"])
+def test_pattern_search_all_partitions(depth, method):
+    _check(depth, method, 256, 192, seed=41, njobs=64, submes=(0, 2, 3, 5, 7), meranges=(4, 16, 57))
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_full_search_driver(depth):
+    _check(depth, "full", 192, 128, seed=42, njobs=32, submes=(1, 3), meranges=(6,))
+
+
+def test_search_extremes():
+    _check(8, "hex", 128, 128, seed=43, njobs=32, submes=(2,), meranges=(16,), extreme="flat")
+    _check(8, "star", 128, 128, seed=43, njobs=32, submes=(3,), meranges=(57,), extreme="flat")
+
+
+def test_unimplemented_methods_are_rejected():
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(64, 64, 2, depth=8, seed=1)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    cq, qoff = F.qpel_cost_table(8, qmax=400)
+    cq_d = torch.from_numpy(cq.view(np.int16)).to(dev)
+    jd = torch.zeros(36, dtype=torch.uint8, device=dev)
+    for m in (A.ME_UMH, A.ME_SEA):
+        with pytest.raises(A.X265HipError):
+            A.me_search(8, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, m, 2, 16, cq_d, qoff, (-8, -8), (8, 8), jd, 1)

@@ -1,0 +1,455 @@
+// search_kernels.hip - MotionEstimate::motionEstimate for a list of PUs on gfx950 (SURVEY.md section 8(f) item 1:
+// the search DRIVERS as device code, next to the pixels, instead of a host loop issuing one SAD per candidate).
+//
+// Reference semantics (source/encoder/motion.cpp): predictor / zero-mv start :772-799 (bprecost is the SAD at the clipped
+// quarter-pel predictor WITHOUT its mv cost), integer patterns DIA :827-850, HEX :852-948 (incl. square refine), STAR
+// :1138-1240 with StarPatternSearch :362-604 (point numbering, early exit after 3 / 32 idle rounds, two-point refinement,
+// raster refinement whose fourth candidate is priced with mvcost(tmv << 3), :1196) and FULL :1397-1445; predictor-vs-search
+// choice :1452-1458; zero-residual shortcut :1464-1469; sub-pel refinement :1508-1561 over subpelCompare :1571-1613
+// (luma_hpp / luma_vpp / luma_hvpp + sad / satd).  mv costs come from the caller's table, indexed by the quarter-pel
+// difference to the predictor (bitcost.h:45).  UMH and SEA are not implemented (the entry point rejects them).
+//
+// Mapping: one wavefront per PU.  The PU is cut into 4x4 tiles dealt round-robin to the lanes (64x64: 4 tiles per lane), the
+// source tiles stay packed in registers; a candidate is scored by every lane on its tiles (v_sad_u8 / v_sad_u16 against
+// unaligned reference dwords, or packed dot4/dot2 interpolation + 4x4 Hadamard for fractional positions, tile_interp.h) and
+// summed across the wavefront with DPP, so the score is wave-uniform and the reference's serial decision code runs unchanged,
+// once per wavefront, with no divergence.
+#include "tile_interp.h"
+
+namespace x265hip {
+
+struct SearchArgs
+{
+    const uint8_t* fenc; long fencStrideB;
+    const uint8_t* fref; long frefStrideB;
+    const uint16_t* cost;            // cost[q]: pointer to the q = 0 entry
+    x265hip_me_search_job* jobs; int njobs;
+    int depth, method, subme, merange;
+    int mvminx, mvminy, mvmaxx, mvmaxy;
+};
+
+struct SMv { int x, y; };
+
+__constant__ SMv kSHex2[8] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
+__constant__ unsigned char kSMod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+__constant__ SMv kSSquare1[9] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+__constant__ SMv kSOffsets[16] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
+                                   { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
+__constant__ int kSWorkload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+                                      { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+
+__device__ __forceinline__ int wave_total(int v)
+{
+    return __builtin_amdgcn_readfirstlane(wave_sum_of_rows(row_sum(v)));
+}
+
+template <typename Px>
+struct PuEval
+{
+    static constexpr int BPP = sizeof(Px);
+    static constexpr int DW = BPP;                 // dwords per 4-sample tile row
+    const uint8_t* refOrg[4];                       // reference byte address under each of the lane's tiles (mv 0)
+    uint32_t src[4][4][DW];                         // the lane's source tiles, packed
+    bool have[4];
+    long strideB;
+    int depth;
+    const uint16_t* cost;
+    int mvpx, mvpy;
+    SMv mvmin, mvmax;
+
+    __device__ __forceinline__ int mvcost_q(int qx, int qy) const { return (int)cost[qx - mvpx] + (int)cost[qy - mvpy]; }
+    __device__ __forceinline__ bool in_range(int x, int y) const { return x >= mvmin.x && x <= mvmax.x && y >= mvmin.y && y <= mvmax.y; }
+
+    // SAD of the PU at integer displacement (mx, my)
+    __device__ __forceinline__ int sad_at(int mx, int my) const
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            if (!have[k]) continue;
+            const uint8_t* rp = refOrg[k] + (long)my * strideB + (long)mx * BPP;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < DW; q++)
+                    acc = sad_dw<Px>(ld_u32(rp + r * strideB + 4 * q), src[k][r][q], acc);
+        }
+        return wave_total((int)acc);
+    }
+    __device__ __forceinline__ int cost_mv(int mx, int my) const { return sad_at(mx, my) + mvcost_q(mx * 4, my * 4); }
+
+    // subpelCompare: SAD or SATD of the PU at quarter-pel displacement (qx, qy)
+    __device__ __forceinline__ int cmp_q(int qx, int qy, bool useSatd) const
+    {
+        if (!((qx | qy) & 3) && !useSatd) return sad_at(qx >> 2, qy >> 2);
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            if (!have[k]) continue;
+            int d[4][4];
+            tile_predict<BPP>(refOrg[k] + (long)(qy >> 2) * strideB + (long)(qx >> 2) * BPP, strideB, qx & 3, qy & 3, depth, d);
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    const int s = BPP == 1 ? (int)((src[k][y][0] >> (8 * x)) & 0xff) : (int)((src[k][y][x >> 1] >> (16 * (x & 1))) & 0xffff);
+                    d[y][x] = s - d[y][x];
+                }
+            if (useSatd) acc += tile_satd4(d);
+            else
+            {
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) acc += abs(d[y][x]);
+            }
+        }
+        return wave_total(acc);
+    }
+};
+
+template <typename Px>
+__device__ __forceinline__ void star_pattern(const PuEval<Px>& c, SMv& bmv, int& bcost, int& bPointNr, int& bDistance, int earlyExitIters, int merange)
+{
+    const SMv omv = bmv;
+    int saved = bcost, rounds = 0;
+#define PT(MX, MY, P, D) do { const int mx_ = (MX), my_ = (MY); const int cost_ = c.cost_mv(mx_, my_); \
+        if (cost_ < bcost) { bcost = cost_; bmv.x = mx_; bmv.y = my_; bPointNr = (P); bDistance = (D); } } while (0)
+    {
+        const int top = omv.y - 1, bottom = omv.y + 1, left = omv.x - 1, right = omv.x + 1;
+        if (top >= c.mvmin.y) PT(omv.x, top, 2, 1);
+        if (left >= c.mvmin.x) PT(left, omv.y, 4, 1);
+        if (right <= c.mvmax.x) PT(right, omv.y, 5, 1);
+        if (bottom <= c.mvmax.y) PT(omv.x, bottom, 7, 1);
+        if (bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+    for (int dist = 2; dist <= 8; dist <<= 1)
+    {
+        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        const int hd = dist >> 1;
+        const int top2 = omv.y - hd, bottom2 = omv.y + hd, left2 = omv.x - hd, right2 = omv.x + hd;
+        saved = bcost;
+        if (top >= c.mvmin.y && left >= c.mvmin.x && right <= c.mvmax.x && bottom <= c.mvmax.y)
+        {
+            PT(omv.x, top, 2, dist); PT(left2, top2, 1, hd); PT(right2, top2, 3, hd); PT(left, omv.y, 4, dist);
+            PT(right, omv.y, 5, dist); PT(left2, bottom2, 6, hd); PT(right2, bottom2, 8, hd); PT(omv.x, bottom, 7, dist);
+        }
+        else
+        {
+            if (top >= c.mvmin.y) PT(omv.x, top, 2, dist);
+            if (top2 >= c.mvmin.y)
+            {
+                if (left2 >= c.mvmin.x) PT(left2, top2, 1, hd);
+                if (right2 <= c.mvmax.x) PT(right2, top2, 3, hd);
+            }
+            if (left >= c.mvmin.x) PT(left, omv.y, 4, dist);
+            if (right <= c.mvmax.x) PT(right, omv.y, 5, dist);
+            if (bottom2 <= c.mvmax.y)
+            {
+                if (left2 >= c.mvmin.x) PT(left2, bottom2, 6, hd);
+                if (right2 <= c.mvmax.x) PT(right2, bottom2, 8, hd);
+            }
+            if (bottom <= c.mvmax.y) PT(omv.x, bottom, 7, dist);
+        }
+        if (bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+    for (int dist = 16; dist <= (int)(int16_t)merange; dist <<= 1)
+    {
+        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        const int qd = dist >> 2;
+        saved = bcost;
+        const bool inside = top >= c.mvmin.y && left >= c.mvmin.x && right <= c.mvmax.x && bottom <= c.mvmax.y;
+        if (inside || top >= c.mvmin.y) PT(omv.x, top, 0, dist);
+        if (inside || left >= c.mvmin.x) PT(left, omv.y, 0, dist);
+        if (inside || right <= c.mvmax.x) PT(right, omv.y, 0, dist);
+        if (inside || bottom <= c.mvmax.y) PT(omv.x, bottom, 0, dist);
+        for (int index = 1; index < 4; index++)
+        {
+            const int posYT = top + qd * index, posYB = bottom - qd * index, posXL = omv.x - qd * index, posXR = omv.x + qd * index;
+            if (inside || posYT >= c.mvmin.y)
+            {
+                if (inside || posXL >= c.mvmin.x) PT(posXL, posYT, 0, dist);
+                if (inside || posXR <= c.mvmax.x) PT(posXR, posYT, 0, dist);
+            }
+            if (inside || posYB <= c.mvmax.y)
+            {
+                if (inside || posXL >= c.mvmin.x) PT(posXL, posYB, 0, dist);
+                if (inside || posXR <= c.mvmax.x) PT(posXR, posYB, 0, dist);
+            }
+        }
+        if (bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+#undef PT
+}
+
+__device__ __forceinline__ int s_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <typename Px>
+__global__ void __launch_bounds__(256) me_search_kernel(SearchArgs a)
+{
+    constexpr int BPP = sizeof(Px);
+    const int lane = threadIdx.x & 63;
+    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (job >= a.njobs) return;                                   // whole wavefronts leave together
+    x265hip_me_search_job jb = a.jobs[job];
+    PuEval<Px> c;
+    c.strideB = a.frefStrideB; c.depth = a.depth; c.cost = a.cost;
+    c.mvpx = jb.qmvpx; c.mvpy = jb.qmvpy;
+    c.mvmin.x = a.mvminx; c.mvmin.y = a.mvminy; c.mvmax.x = a.mvmaxx; c.mvmax.y = a.mvmaxy;
+    const int tilesX = jb.w >> 2, ntiles = tilesX * (jb.h >> 2);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const int t = lane + 64 * k;
+        c.have[k] = t < ntiles;
+        const int ty = c.have[k] ? t / tilesX : 0, tx = c.have[k] ? t - ty * tilesX : 0;
+        const uint8_t* fe = a.fenc + (long)(jb.py + ty * 4) * a.fencStrideB + (long)(jb.px + tx * 4) * BPP;
+        c.refOrg[k] = a.fref + (long)(jb.py + ty * 4) * a.frefStrideB + (long)(jb.px + tx * 4) * BPP;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int q = 0; q < BPP; q++) c.src[k][r][q] = c.have[k] ? ld_u32(fe + r * a.fencStrideB + 4 * q) : 0;
+    }
+    const int merange = a.merange;
+    const int qminx = c.mvmin.x * 4, qminy = c.mvmin.y * 4, qmaxx = c.mvmax.x * 4, qmaxy = c.mvmax.y * 4;
+    const int pmvx = s_clip3(qminx, qmaxx, c.mvpx), pmvy = s_clip3(qminy, qmaxy, c.mvpy);
+    const int bprecost = c.cmp_q(pmvx, pmvy, false);
+    SMv bmv = { (pmvx + 2) >> 2, (pmvy + 2) >> 2 };
+    int bcost = bprecost;
+    if ((pmvx | pmvy) & 3) bcost = c.cost_mv(bmv.x, bmv.y);
+    if (pmvx | pmvy)
+    {
+        const int cost = c.sad_at(0, 0) + c.mvcost_q(0, 0);
+        if (cost < bcost)
+        {
+            bcost = cost;
+            bmv.x = 0;
+            const int zy = 0 < c.mvmax.y ? 0 : c.mvmax.y;
+            bmv.y = zy > c.mvmin.y ? zy : c.mvmin.y;
+        }
+    }
+    int costs[4];
+#define YOK(DY) ((bmv.y + (DY) >= c.mvmin.y) & (bmv.y + (DY) <= c.mvmax.y))
+#define LT(V) do { const int v_ = (V); if (v_ < bcost) bcost = v_; } while (0)
+    if (a.method == 0)              // X265_DIA_SEARCH
+    {
+        bcost <<= 4;
+        int i = merange;
+        do
+        {
+            costs[0] = c.cost_mv(bmv.x, bmv.y - 1); costs[1] = c.cost_mv(bmv.x, bmv.y + 1);
+            costs[2] = c.cost_mv(bmv.x - 1, bmv.y); costs[3] = c.cost_mv(bmv.x + 1, bmv.y);
+            if (YOK(-1)) LT((costs[0] << 4) + 1);
+            if (YOK(1)) LT((costs[1] << 4) + 3);
+            LT((costs[2] << 4) + 4);
+            LT((costs[3] << 4) + 12);
+            if (!(bcost & 15)) break;
+            bmv.x -= (int)((uint32_t)bcost << 28) >> 30;
+            bmv.y -= (int)((uint32_t)bcost << 30) >> 30;
+            bcost &= ~15;
+        }
+        while (--i && c.in_range(bmv.x, bmv.y));
+        bcost >>= 4;
+    }
+    else if (a.method == 1)         // X265_HEX_SEARCH
+    {
+#define X3(D0X, D0Y, D1X, D1Y, D2X, D2Y) do { costs[0] = c.cost_mv(bmv.x + (D0X), bmv.y + (D0Y)); costs[1] = c.cost_mv(bmv.x + (D1X), bmv.y + (D1Y)); \
+                                              costs[2] = c.cost_mv(bmv.x + (D2X), bmv.y + (D2Y)); } while (0)
+        X3(-2, 0, -1, 2, 1, 2);
+        bcost <<= 3;
+        if (YOK(0)) LT((costs[0] << 3) + 2);
+        if (YOK(2)) { LT((costs[1] << 3) + 3); LT((costs[2] << 3) + 4); }
+        X3(2, 0, 1, -2, -1, -2);
+        if (YOK(0)) LT((costs[0] << 3) + 5);
+        if (YOK(-2)) { LT((costs[1] << 3) + 6); LT((costs[2] << 3) + 7); }
+        if (bcost & 7)
+        {
+            int dir = (bcost & 7) - 2;
+            if (YOK(kSHex2[dir + 1].y))
+            {
+                bmv.x += kSHex2[dir + 1].x; bmv.y += kSHex2[dir + 1].y;
+                for (int i = (merange >> 1) - 1; i > 0 && c.in_range(bmv.x, bmv.y); i--)
+                {
+                    X3(kSHex2[dir + 0].x, kSHex2[dir + 0].y, kSHex2[dir + 1].x, kSHex2[dir + 1].y, kSHex2[dir + 2].x, kSHex2[dir + 2].y);
+                    bcost &= ~7;
+                    if (YOK(kSHex2[dir + 0].y)) LT((costs[0] << 3) + 1);
+                    if (YOK(kSHex2[dir + 1].y)) LT((costs[1] << 3) + 2);
+                    if (YOK(kSHex2[dir + 2].y)) LT((costs[2] << 3) + 3);
+                    if (!(bcost & 7)) break;
+                    dir += (bcost & 7) - 2;
+                    dir = kSMod6m1[dir + 1];
+                    bmv.x += kSHex2[dir + 1].x; bmv.y += kSHex2[dir + 1].y;
+                }
+            }
+        }
+        bcost >>= 3;
+        int dir = 0;
+        costs[0] = c.cost_mv(bmv.x, bmv.y - 1); costs[1] = c.cost_mv(bmv.x, bmv.y + 1);
+        costs[2] = c.cost_mv(bmv.x - 1, bmv.y); costs[3] = c.cost_mv(bmv.x + 1, bmv.y);
+        if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 1; }
+        if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 2; }
+        if (costs[2] < bcost) { bcost = costs[2]; dir = 3; }
+        if (costs[3] < bcost) { bcost = costs[3]; dir = 4; }
+        costs[0] = c.cost_mv(bmv.x - 1, bmv.y - 1); costs[1] = c.cost_mv(bmv.x - 1, bmv.y + 1);
+        costs[2] = c.cost_mv(bmv.x + 1, bmv.y - 1); costs[3] = c.cost_mv(bmv.x + 1, bmv.y + 1);
+        if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 5; }
+        if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 6; }
+        if (YOK(-1) && costs[2] < bcost) { bcost = costs[2]; dir = 7; }
+        if (YOK(1) && costs[3] < bcost) { bcost = costs[3]; dir = 8; }
+        bmv.x += kSSquare1[dir].x; bmv.y += kSSquare1[dir].y;
+#undef X3
+    }
+    else if (a.method == 3)         // X265_STAR_SEARCH
+    {
+        int bPointNr = 0, bDistance = 0;
+        star_pattern<Px>(c, bmv, bcost, bPointNr, bDistance, 3, merange);
+        bool done = false;
+        auto two_points = [&]()
+        {
+            const SMv m1 = { bmv.x + kSOffsets[(bPointNr - 1) * 2].x, bmv.y + kSOffsets[(bPointNr - 1) * 2].y };
+            const SMv m2 = { bmv.x + kSOffsets[(bPointNr - 1) * 2 + 1].x, bmv.y + kSOffsets[(bPointNr - 1) * 2 + 1].y };
+            if (c.in_range(m1.x, m1.y)) { const int cost = c.cost_mv(m1.x, m1.y); if (cost < bcost) { bcost = cost; bmv = m1; } }
+            if (c.in_range(m2.x, m2.y)) { const int cost = c.cost_mv(m2.x, m2.y); if (cost < bcost) { bcost = cost; bmv = m2; } }
+        };
+        if (bDistance == 1)
+        {
+            if (bPointNr)
+            {
+                const int saved = bcost;
+                two_points();
+                if (bcost == saved) done = true;
+            }
+            else done = true;
+        }
+        if (!done)
+        {
+            const int RasterDistance = 5;
+            if (bDistance > RasterDistance)
+            {
+                for (int ty = c.mvmin.y; ty <= c.mvmax.y; ty += RasterDistance)
+                    for (int tx = c.mvmin.x; tx <= c.mvmax.x; tx += RasterDistance)
+                    {
+                        if (tx + RasterDistance * 3 <= c.mvmax.x)
+                        {
+                            for (int k = 0; k < 4; k++)
+                            {
+                                const int cost = c.sad_at(tx, ty) + (k == 3 ? c.mvcost_q(tx * 8, ty * 8) : c.mvcost_q(tx * 4, ty * 4));
+                                if (cost < bcost) { bcost = cost; bmv.x = tx; bmv.y = ty; }
+                                if (k < 3) tx += RasterDistance;
+                            }
+                        }
+                        else
+                        {
+                            const int cost = c.cost_mv(tx, ty);
+                            if (cost < bcost) { bcost = cost; bmv.x = tx; bmv.y = ty; }
+                        }
+                    }
+            }
+            while (bDistance > 0)
+            {
+                bDistance = 0;
+                bPointNr = 0;
+                star_pattern<Px>(c, bmv, bcost, bPointNr, bDistance, 32, merange);
+                if (bDistance == 1)
+                {
+                    if (bPointNr) two_points();
+                    break;
+                }
+            }
+        }
+    }
+    else                            // X265_FULL_SEARCH
+    {
+        for (int ty = c.mvmin.y; ty <= c.mvmax.y; ty++)
+            for (int tx = c.mvmin.x; tx <= c.mvmax.x; tx++)
+            {
+                const int cost = c.cost_mv(tx, ty);
+                if (cost < bcost) { bcost = cost; bmv.x = tx; bmv.y = ty; }
+            }
+    }
+#undef YOK
+#undef LT
+
+    int bx, by;
+    if (bprecost < bcost) { bx = pmvx; by = pmvy; bcost = bprecost; }
+    else { bx = bmv.x * 4; by = bmv.y * 4; }
+    const int hpelIters = kSWorkload[a.subme][0], hpelDirs = kSWorkload[a.subme][1], qpelIters = kSWorkload[a.subme][2],
+              qpelDirs = kSWorkload[a.subme][3];
+    const bool hpelSatd = kSWorkload[a.subme][4] != 0;
+    if (!bcost)
+        bcost = c.mvcost_q(bx, by);
+    else
+    {
+        if (hpelSatd) bcost = c.cmp_q(bx, by, true) + c.mvcost_q(bx, by);
+        for (int iter = 0; iter < hpelIters; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= hpelDirs; i++)
+            {
+                const int qx = bx + kSSquare1[i].x * 2, qy = by + kSSquare1[i].y * 2;
+                if ((qy < qminy) | (qy > qmaxy)) continue;
+                const int cost = c.cmp_q(qx, qy, hpelSatd) + c.mvcost_q(qx, qy);
+                if (cost < bcost) { bcost = cost; bdir = i; }
+            }
+            if (bdir) { bx += kSSquare1[bdir].x * 2; by += kSSquare1[bdir].y * 2; }
+            else break;
+        }
+        if (!hpelSatd) bcost = c.cmp_q(bx, by, true) + c.mvcost_q(bx, by);
+        for (int iter = 0; iter < qpelIters; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= qpelDirs; i++)
+            {
+                const int qx = bx + kSSquare1[i].x, qy = by + kSSquare1[i].y;
+                if ((qy < qminy) | (qy > qmaxy)) continue;
+                const int cost = c.cmp_q(qx, qy, true) + c.mvcost_q(qx, qy);
+                if (cost < bcost) { bcost = cost; bdir = i; }
+            }
+            if (bdir) { bx += kSSquare1[bdir].x; by += kSSquare1[bdir].y; }
+            else break;
+        }
+    }
+    if (lane == 0)
+    {
+        a.jobs[job].out_qmvx = bx;
+        a.jobs[job].out_qmvy = by;
+        a.jobs[job].out_cost = bcost;
+    }
+}
+
+} // namespace x265hip
+
+using namespace x265hip;
+
+extern "C" int x265hip_me_search(const x265hip_me_search_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->fenc || !p->fref || !p->cost_q || !p->jobs) { set_error("me_search: NULL operand"); return X265HIP_EINVAL; }
+    if (p->njobs < 0) { set_error("me_search: njobs %d", p->njobs); return X265HIP_EINVAL; }
+    if (p->njobs == 0) return 0;
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("me_search: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->method != X265HIP_ME_DIA && p->method != X265HIP_ME_HEX && p->method != X265HIP_ME_STAR && p->method != X265HIP_ME_FULL)
+    { set_error("me_search: search method %d is not implemented (DIA, HEX, STAR, FULL are)", p->method); return X265HIP_EINVAL; }
+    if (p->subme < 0 || p->subme > 7) { set_error("me_search: subme %d out of [0,7]", p->subme); return X265HIP_EINVAL; }
+    if (p->mvmin_x > p->mvmax_x || p->mvmin_y > p->mvmax_y) { set_error("me_search: empty mv range"); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    SearchArgs a;
+    a.fenc = (const uint8_t*)p->fenc; a.fencStrideB = (long)p->fenc_stride * bpp;
+    a.fref = (const uint8_t*)p->fref; a.frefStrideB = (long)p->fref_stride * bpp;
+    a.cost = p->cost_q + p->qoff; a.jobs = p->jobs; a.njobs = p->njobs;
+    a.depth = p->depth; a.method = p->method; a.subme = p->subme; a.merange = p->merange;
+    a.mvminx = p->mvmin_x; a.mvminy = p->mvmin_y; a.mvmaxx = p->mvmax_x; a.mvmaxy = p->mvmax_y;
+    hipStream_t s = (hipStream_t)stream;
+    const int wgs = (p->njobs + 3) / 4;
+    if (bpp == 1) hipLaunchKernelGGL(me_search_kernel<uint8_t>, dim3(wgs), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(me_search_kernel<uint16_t>, dim3(wgs), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -59,6 +59,27 @@ class LowresIntraParams(ctypes.Structure):
                 ("intra_cost", ctypes.c_void_p), ("intra_mode", ctypes.c_void_p), ("lowres_costs", ctypes.c_void_p)]
 
 
+class MESearchJob(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("px", "py", "w", "h", "qmvpx", "qmvpy", "out_qmvx", "out_qmvy", "out_cost")]
+
+
+class MESearchParams(ctypes.Structure):
+    _fields_ = [("depth", ctypes.c_int), ("fenc", ctypes.c_void_p), ("fenc_stride", ctypes.c_ssize_t),
+                ("fref", ctypes.c_void_p), ("fref_stride", ctypes.c_ssize_t),
+                ("method", ctypes.c_int), ("subme", ctypes.c_int), ("merange", ctypes.c_int),
+                ("cost_q", ctypes.c_void_p), ("qoff", ctypes.c_int),
+                ("mvmin_x", ctypes.c_int), ("mvmin_y", ctypes.c_int), ("mvmax_x", ctypes.c_int), ("mvmax_y", ctypes.c_int),
+                ("jobs", ctypes.c_void_p), ("njobs", ctypes.c_int)]
+
+
+ME_DIA, ME_HEX, ME_UMH, ME_STAR, ME_SEA, ME_FULL = range(6)
+
+
+def me_search_job_dtype():
+    import numpy as np
+    return np.dtype([(n, "<i4") for n in ("px", "py", "w", "h", "qmvpx", "qmvpy", "out_qmvx", "out_qmvy", "out_cost")])
+
+
 def lib() -> ctypes.CDLL:
     """Load libx265hip.so (built in-tree by __graft_entry__.build()); fail loudly if absent."""
     global _lib
@@ -158,6 +179,24 @@ def lowres_intra(depth, plane, stride, org, width_in_cu, height_in_cu, intra_pen
     f = lib().x265hip_lowres_intra
     f.argtypes = [ctypes.POINTER(LowresIntraParams), ctypes.c_void_p]
     check(f(ctypes.byref(p), s), "x265hip_lowres_intra")
+
+
+def me_search(depth, fenc, fenc_stride, fenc_off, fref, fref_stride, fref_off, method, subme, merange, cost_q, qoff,
+              mvmin, mvmax, jobs, njobs, stream=None):
+    """jobs: device uint8 tensor holding njobs x265hip_me_search_job records (me_search_job_dtype), updated in place."""
+    es = 1 if depth == 8 else 2
+    p = MESearchParams()
+    p.depth = depth
+    p.fenc, p.fenc_stride = fenc.data_ptr() + fenc_off * es, fenc_stride
+    p.fref, p.fref_stride = fref.data_ptr() + fref_off * es, fref_stride
+    p.method, p.subme, p.merange = method, subme, merange
+    p.cost_q, p.qoff = cost_q.data_ptr(), qoff
+    p.mvmin_x, p.mvmin_y, p.mvmax_x, p.mvmax_y = mvmin[0], mvmin[1], mvmax[0], mvmax[1]
+    p.jobs, p.njobs = jobs.data_ptr(), njobs
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_me_search
+    f.argtypes = [ctypes.POINTER(MESearchParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_me_search")
 
 
 def me_best_reset(best, stream=None):
