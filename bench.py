@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--no-surface", action="store_true", help="ME keeps only the best mv (no SAD surfaces)")
     ap.add_argument("--surf-format", choices=["packed", "i32"], default="packed",
                     help="SAD surface records: packed = u16 for the 8x8/16x16 levels (X265HIP_SURF_PACKED), i32 = all int32")
+    ap.add_argument("--search", choices=["full", "dia", "hex", "star"], default="full",
+                    help="full = exhaustive search (SAD surfaces + best mv) + sub-pel stage; dia/hex/star = the reference's pattern "
+                         "searches run by the device-side search driver (x265hip_me_search), predictor (0,0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -149,7 +152,7 @@ def main():
     pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
                            qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed" and args.depth == 8,
-                           lookahead=(args.width, args.height))
+                           lookahead=(args.width, args.height), search=args.search)
     ref_pic = P.DevicePicture.__new__(P.DevicePicture)
     ref_pic.__dict__.update(pics[0].__dict__)
     ref_pic.t = pics[0].t.clone()                    # the reference every rank searches in (starts as frame 0)
@@ -192,15 +195,23 @@ def main():
         lk.record()
         pipe.la.run(cur)                          # half-resolution planes + intra cost estimate of the source picture
         lk2.record()
-        A.me_best_reset(ms.best)                  # 4 us fill, outside the timed kernel
-        marks[0].record()
-        A.me_fullsearch(args.depth, ms.w64, ms.h64, ms.range, cur.t, cur.stride, ref_pic.t, ref_pic.stride, surf=ms.surf, best=ms.best,
-                        cost_x=ms.cost_x, cost_y=ms.cost_y, fenc_off=cur.org, fref_off=ref_pic.org,
-                        surf_format=A.SURF_PACKED if ms.packed else A.SURF_I32)                      # ONE fused launch
-        marks[1].record()
-        sp.run(cur, ref_pic)
-        marks[2].record()
-        rc.run(cur, ref_pic, pipe.recon, sp.out)
+        if pipe.ps is not None:
+            marks[0].record()
+            pipe.ps.run(cur, ref_pic)             # pattern search + sub-pel for every PU, one launch
+            marks[1].record()
+            marks[2].record()
+            mv_out = pipe.ps.out
+        else:
+            A.me_best_reset(ms.best)                  # 4 us fill, outside the timed kernel
+            marks[0].record()
+            A.me_fullsearch(args.depth, ms.w64, ms.h64, ms.range, cur.t, cur.stride, ref_pic.t, ref_pic.stride, surf=ms.surf, best=ms.best,
+                            cost_x=ms.cost_x, cost_y=ms.cost_y, fenc_off=cur.org, fref_off=ref_pic.org,
+                            surf_format=A.SURF_PACKED if ms.packed else A.SURF_I32)                      # ONE fused launch
+            marks[1].record()
+            sp.run(cur, ref_pic)
+            marks[2].record()
+            mv_out = sp.out
+        rc.run(cur, ref_pic, pipe.recon, mv_out)
         marks[3].record()
         S.extend_border(pipe.recon, cur)
         marks[4].record()
@@ -222,14 +233,17 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8" if args.depth == 8 else "u16", "data": "synthetic",
-            "config": {"workload": f"{args.width}x{args.height} {args.depth}-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: lookahead lowres planes + intra estimate -> "
-                                   f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + ('packed' if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
-                                   f"sub-pel subme={args.subme} -> {8 << args.level}x{8 << args.level} prediction + DCT/quant/recon qp {args.qp} -> "
+            "config": {"workload": f"{args.width}x{args.height} {args.depth}-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: lookahead lowres planes + intra estimate -> " +
+                                   (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + ('packed' if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
+                                    f"sub-pel subme={args.subme} -> " if args.search == "full" else
+                                    f"{args.search} search driver (motionEstimate, merange {args.range}, subme {args.subme}, predictor 0) for all 85 PUs/CTU -> ") +
+                                   f"{8 << args.level}x{8 << args.level} prediction + DCT/quant/recon qp {args.qp} -> "
                                    f"border extension -> next reference; pipeline throughput, not HEVC encoded fps",
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world}",
                        "ctus_per_frame": ms.nctu, "checksum": csum},
             "stages_ms": stages,
-            "roofline": {"bound": "hbm", "kernel": ("me_ctu_q_kernel" if args.depth == 8 else "me_ctu_w_kernel") + ("<surf,best>" if surf_mode else "<best>"),
+            "roofline": {"bound": "hbm", "kernel": "me_search_kernel" if args.search != "full" else
+                                   ("me_ctu_q_kernel" if args.depth == 8 else "me_ctu_w_kernel") + ("<surf,best>" if surf_mode else "<best>"),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                          "algorithmic_bytes_per_launch": alg_bytes, "output_bytes_per_launch": ms.hbm_floor_bytes(1 if args.depth == 8 else 2),

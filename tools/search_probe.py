@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Throughput probe of x265hip_me_search: every 8x8..64x64 PU of every CTU of a frame, predictor (0,0)."""
+import importlib, sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+dev = torch.device("cuda:0")
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
+clip = F.synth_clip(W, H, 2, depth=8, seed=5)
+cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+jobs = []
+for cy in range(0, cur.h64, 64):
+    for cx in range(0, cur.w64, 64):
+        for n in (8, 16, 32, 64):
+            for y in range(0, 64, n):
+                for x in range(0, 64, n):
+                    jobs.append((cx + x, cy + y, n, n, 0, 0, 0, 0, 0))
+jn = np.array(jobs, dtype=A.me_search_job_dtype())
+jd = torch.from_numpy(jn.view(np.uint8).reshape(-1).copy()).to(dev)
+cq, qoff = F.qpel_cost_table(57, qmax=8 * 64 + 300)
+cq_d = torch.from_numpy(cq.view(np.int16)).to(dev)
+for name, m in (("dia", A.ME_DIA), ("hex", A.ME_HEX), ("star", A.ME_STAR)):
+    for subme in (2, 3):
+        f = lambda: A.me_search(8, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, m, subme, 57, cq_d, qoff, (-57, -57), (57, 57), jd, len(jn))
+        f(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3): f()
+        e1.record(); torch.cuda.synchronize()
+        print(f"{W}x{H} {name} subme {subme}: {len(jn)} PUs, {e0.elapsed_time(e1) / 3:.3f} ms")

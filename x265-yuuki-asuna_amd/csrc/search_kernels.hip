@@ -9,11 +9,14 @@
 // (luma_hpp / luma_vpp / luma_hvpp + sad / satd).  mv costs come from the caller's table, indexed by the quarter-pel
 // difference to the predictor (bitcost.h:45).  UMH and SEA are not implemented (the entry point rejects them).
 //
-// Mapping: one wavefront per PU.  The PU is cut into 4x4 tiles dealt round-robin to the lanes (64x64: 4 tiles per lane), the
-// source tiles stay packed in registers; a candidate is scored by every lane on its tiles (v_sad_u8 / v_sad_u16 against
-// unaligned reference dwords, or packed dot4/dot2 interpolation + 4x4 Hadamard for fractional positions, tile_interp.h) and
-// summed across the wavefront with DPP, so the score is wave-uniform and the reference's serial decision code runs unchanged,
-// once per wavefront, with no divergence.
+// Mapping: a lane GROUP per PU - a DPP quad (4 lanes) for PUs of up to 8 tiles of 4x4 (8x8, 8x4, 16x8 ...), a 16-lane row up
+// to 32 tiles (16x16 ... 32x16), the whole wavefront above (32x32 ... 64x64: 4 tiles per lane).  The source tiles stay packed
+// in registers; a candidate is scored by every lane of the group on its tiles (v_sad_u8 / v_sad_u16 against unaligned reference
+// dwords, or packed dot4/dot2 interpolation + 4x4 Hadamard for fractional positions, tile_interp.h) and summed across the group
+// with DPP, so every lane of a group holds the same score and runs the reference's serial decision code redundantly; groups of
+// one wavefront follow their own decisions through ordinary SIMT divergence (the instruction stream is the same, only the
+// motion vectors differ).  A wavefront takes 16 consecutive jobs: the small ones together, the medium ones four at a time,
+// the large ones one after the other - any job order is correct, jobs sorted by size run fastest.
 #include "tile_interp.h"
 
 namespace x265hip {
@@ -38,19 +41,22 @@ __constant__ SMv kSOffsets[16] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, 
 __constant__ int kSWorkload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
                                       { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
 
-__device__ __forceinline__ int wave_total(int v)
+// sum over the G lanes of a group, result in every lane of the group
+template <int G> __device__ __forceinline__ int group_total(int v)
 {
-    return __builtin_amdgcn_readfirstlane(wave_sum_of_rows(row_sum(v)));
+    if (G == 4) return quad_sum(v);
+    if (G == 16) return row_sum(v);
+    return wave_sum_of_rows(row_sum(v));
 }
 
-template <typename Px>
+template <typename Px, int G, int T>
 struct PuEval
 {
     static constexpr int BPP = sizeof(Px);
     static constexpr int DW = BPP;                 // dwords per 4-sample tile row
-    const uint8_t* refOrg[4];                       // reference byte address under each of the lane's tiles (mv 0)
-    uint32_t src[4][4][DW];                         // the lane's source tiles, packed
-    bool have[4];
+    const uint8_t* refOrg[T];                       // reference byte address under each of the lane's tiles (mv 0)
+    uint32_t src[T][4][DW];                         // the lane's source tiles, packed
+    bool have[T];
     long strideB;
     int depth;
     const uint16_t* cost;
@@ -65,7 +71,7 @@ struct PuEval
     {
         uint32_t acc = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < T; k++)
         {
             if (!have[k]) continue;
             const uint8_t* rp = refOrg[k] + (long)my * strideB + (long)mx * BPP;
@@ -75,9 +81,36 @@ struct PuEval
                 for (int q = 0; q < DW; q++)
                     acc = sad_dw<Px>(ld_u32(rp + r * strideB + 4 * q), src[k][r][q], acc);
         }
-        return wave_total((int)acc);
+        return group_total<G>((int)acc);
     }
     __device__ __forceinline__ int cost_mv(int mx, int my) const { return sad_at(mx, my) + mvcost_q(mx * 4, my * 4); }
+
+    // N candidates at once (the reference's sad_x3 / sad_x4 groups): all reference loads are issued before the first
+    // reduction, so one memory round trip serves the group
+    template <int N>
+    __device__ __forceinline__ void cost_mv_n(const int (&mx)[N], const int (&my)[N], int (&out)[N]) const
+    {
+        uint32_t acc[N];
+#pragma unroll
+        for (int n = 0; n < N; n++) acc[n] = 0;
+#pragma unroll
+        for (int k = 0; k < T; k++)
+        {
+            if (!have[k]) continue;
+#pragma unroll
+            for (int n = 0; n < N; n++)
+            {
+                const uint8_t* rp = refOrg[k] + (long)my[n] * strideB + (long)mx[n] * BPP;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int q = 0; q < DW; q++)
+                        acc[n] = sad_dw<Px>(ld_u32(rp + r * strideB + 4 * q), src[k][r][q], acc[n]);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < N; n++) out[n] = group_total<G>((int)acc[n]) + mvcost_q(mx[n] * 4, my[n] * 4);
+    }
 
     // subpelCompare: SAD or SATD of the PU at quarter-pel displacement (qx, qy)
     __device__ __forceinline__ int cmp_q(int qx, int qy, bool useSatd) const
@@ -85,7 +118,7 @@ struct PuEval
         if (!((qx | qy) & 3) && !useSatd) return sad_at(qx >> 2, qy >> 2);
         int acc = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < T; k++)
         {
             if (!have[k]) continue;
             int d[4][4];
@@ -107,12 +140,12 @@ struct PuEval
                     for (int x = 0; x < 4; x++) acc += abs(d[y][x]);
             }
         }
-        return wave_total(acc);
+        return group_total<G>(acc);
     }
 };
 
-template <typename Px>
-__device__ __forceinline__ void star_pattern(const PuEval<Px>& c, SMv& bmv, int& bcost, int& bPointNr, int& bDistance, int earlyExitIters, int merange)
+template <typename Px, int G, int T>
+__device__ __forceinline__ void star_pattern(const PuEval<Px, G, T>& c, SMv& bmv, int& bcost, int& bPointNr, int& bDistance, int earlyExitIters, int merange)
 {
     const SMv omv = bmv;
     int saved = bcost, rounds = 0;
@@ -120,10 +153,22 @@ __device__ __forceinline__ void star_pattern(const PuEval<Px>& c, SMv& bmv, int&
         if (cost_ < bcost) { bcost = cost_; bmv.x = mx_; bmv.y = my_; bPointNr = (P); bDistance = (D); } } while (0)
     {
         const int top = omv.y - 1, bottom = omv.y + 1, left = omv.x - 1, right = omv.x + 1;
+        if (top >= c.mvmin.y && left >= c.mvmin.x && right <= c.mvmax.x && bottom <= c.mvmax.y)
+        {
+            const int mxs[4] = { omv.x, left, right, omv.x }, mys[4] = { top, omv.y, omv.y, bottom }, pts[4] = { 2, 4, 5, 7 };
+            int cs[4];
+            c.template cost_mv_n<4>(mxs, mys, cs);
+#pragma unroll
+            for (int n = 0; n < 4; n++)
+                if (cs[n] < bcost) { bcost = cs[n]; bmv.x = mxs[n]; bmv.y = mys[n]; bPointNr = pts[n]; bDistance = 1; }
+        }
+        else
+        {
         if (top >= c.mvmin.y) PT(omv.x, top, 2, 1);
         if (left >= c.mvmin.x) PT(left, omv.y, 4, 1);
         if (right <= c.mvmax.x) PT(right, omv.y, 5, 1);
         if (bottom <= c.mvmax.y) PT(omv.x, bottom, 7, 1);
+        }
         if (bcost < saved) rounds = 0;
         else if (++rounds >= earlyExitIters) return;
     }
@@ -135,8 +180,14 @@ __device__ __forceinline__ void star_pattern(const PuEval<Px>& c, SMv& bmv, int&
         saved = bcost;
         if (top >= c.mvmin.y && left >= c.mvmin.x && right <= c.mvmax.x && bottom <= c.mvmax.y)
         {
-            PT(omv.x, top, 2, dist); PT(left2, top2, 1, hd); PT(right2, top2, 3, hd); PT(left, omv.y, 4, dist);
-            PT(right, omv.y, 5, dist); PT(left2, bottom2, 6, hd); PT(right2, bottom2, 8, hd); PT(omv.x, bottom, 7, dist);
+            const int mxs[8] = { omv.x, left2, right2, left, right, left2, right2, omv.x };
+            const int mys[8] = { top, top2, top2, omv.y, omv.y, bottom2, bottom2, bottom };
+            const int pts[8] = { 2, 1, 3, 4, 5, 6, 8, 7 };
+            int cs[8];
+            c.template cost_mv_n<8>(mxs, mys, cs);
+#pragma unroll
+            for (int n = 0; n < 8; n++)
+                if (cs[n] < bcost) { bcost = cs[n]; bmv.x = mxs[n]; bmv.y = mys[n]; bPointNr = pts[n]; bDistance = (pts[n] == 1 || pts[n] == 3 || pts[n] == 6 || pts[n] == 8) ? hd : dist; }
         }
         else
         {
@@ -164,6 +215,33 @@ __device__ __forceinline__ void star_pattern(const PuEval<Px>& c, SMv& bmv, int&
         const int qd = dist >> 2;
         saved = bcost;
         const bool inside = top >= c.mvmin.y && left >= c.mvmin.x && right <= c.mvmax.x && bottom <= c.mvmax.y;
+        if (inside)
+        {
+            // 16 points in the reference's order: the four axis points, then for index 1..3 (XL,YT) (XR,YT) (XL,YB) (XR,YB)
+            int mxs[16], mys[16];
+            mxs[0] = omv.x; mys[0] = top; mxs[1] = left; mys[1] = omv.y; mxs[2] = right; mys[2] = omv.y; mxs[3] = omv.x; mys[3] = bottom;
+#pragma unroll
+            for (int index = 1; index < 4; index++)
+            {
+                const int posYT = top + qd * index, posYB = bottom - qd * index, posXL = omv.x - qd * index, posXR = omv.x + qd * index;
+                mxs[4 * index + 0] = posXL; mys[4 * index + 0] = posYT; mxs[4 * index + 1] = posXR; mys[4 * index + 1] = posYT;
+                mxs[4 * index + 2] = posXL; mys[4 * index + 2] = posYB; mxs[4 * index + 3] = posXR; mys[4 * index + 3] = posYB;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; half++)
+            {
+                int bx8[8], by8[8], cs[8];
+#pragma unroll
+                for (int n = 0; n < 8; n++) { bx8[n] = mxs[8 * half + n]; by8[n] = mys[8 * half + n]; }
+                c.template cost_mv_n<8>(bx8, by8, cs);
+#pragma unroll
+                for (int n = 0; n < 8; n++)
+                    if (cs[n] < bcost) { bcost = cs[n]; bmv.x = bx8[n]; bmv.y = by8[n]; bPointNr = 0; bDistance = dist; }
+            }
+            if (bcost < saved) rounds = 0;
+            else if (++rounds >= earlyExitIters) return;
+            continue;
+        }
         if (inside || top >= c.mvmin.y) PT(omv.x, top, 0, dist);
         if (inside || left >= c.mvmin.x) PT(left, omv.y, 0, dist);
         if (inside || right <= c.mvmax.x) PT(right, omv.y, 0, dist);
@@ -190,23 +268,22 @@ __device__ __forceinline__ void star_pattern(const PuEval<Px>& c, SMv& bmv, int&
 
 __device__ __forceinline__ int s_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 
-template <typename Px>
-__global__ void __launch_bounds__(256) me_search_kernel(SearchArgs a)
+// One PU per lane group: `job` is the group's job (every lane of the group passes the same value).
+template <typename Px, int G, int T>
+__device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
 {
     constexpr int BPP = sizeof(Px);
-    const int lane = threadIdx.x & 63;
-    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (job >= a.njobs) return;                                   // whole wavefronts leave together
+    const int gl = threadIdx.x & (G - 1);                         // lane inside the group
     x265hip_me_search_job jb = a.jobs[job];
-    PuEval<Px> c;
+    PuEval<Px, G, T> c;
     c.strideB = a.frefStrideB; c.depth = a.depth; c.cost = a.cost;
     c.mvpx = jb.qmvpx; c.mvpy = jb.qmvpy;
     c.mvmin.x = a.mvminx; c.mvmin.y = a.mvminy; c.mvmax.x = a.mvmaxx; c.mvmax.y = a.mvmaxy;
     const int tilesX = jb.w >> 2, ntiles = tilesX * (jb.h >> 2);
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < T; k++)
     {
-        const int t = lane + 64 * k;
+        const int t = gl + G * k;
         c.have[k] = t < ntiles;
         const int ty = c.have[k] ? t / tilesX : 0, tx = c.have[k] ? t - ty * tilesX : 0;
         const uint8_t* fe = a.fenc + (long)(jb.py + ty * 4) * a.fencStrideB + (long)(jb.px + tx * 4) * BPP;
@@ -243,8 +320,7 @@ __global__ void __launch_bounds__(256) me_search_kernel(SearchArgs a)
         int i = merange;
         do
         {
-            costs[0] = c.cost_mv(bmv.x, bmv.y - 1); costs[1] = c.cost_mv(bmv.x, bmv.y + 1);
-            costs[2] = c.cost_mv(bmv.x - 1, bmv.y); costs[3] = c.cost_mv(bmv.x + 1, bmv.y);
+            { const int mxs[4] = { bmv.x, bmv.x, bmv.x - 1, bmv.x + 1 }, mys[4] = { bmv.y - 1, bmv.y + 1, bmv.y, bmv.y }; c.template cost_mv_n<4>(mxs, mys, costs); }
             if (YOK(-1)) LT((costs[0] << 4) + 1);
             if (YOK(1)) LT((costs[1] << 4) + 3);
             LT((costs[2] << 4) + 4);
@@ -259,8 +335,8 @@ __global__ void __launch_bounds__(256) me_search_kernel(SearchArgs a)
     }
     else if (a.method == 1)         // X265_HEX_SEARCH
     {
-#define X3(D0X, D0Y, D1X, D1Y, D2X, D2Y) do { costs[0] = c.cost_mv(bmv.x + (D0X), bmv.y + (D0Y)); costs[1] = c.cost_mv(bmv.x + (D1X), bmv.y + (D1Y)); \
-                                              costs[2] = c.cost_mv(bmv.x + (D2X), bmv.y + (D2Y)); } while (0)
+#define X3(D0X, D0Y, D1X, D1Y, D2X, D2Y) do { const int mxs_[3] = { bmv.x + (D0X), bmv.x + (D1X), bmv.x + (D2X) }, mys_[3] = { bmv.y + (D0Y), bmv.y + (D1Y), bmv.y + (D2Y) }; \
+                                              int cs_[3]; c.template cost_mv_n<3>(mxs_, mys_, cs_); costs[0] = cs_[0]; costs[1] = cs_[1]; costs[2] = cs_[2]; } while (0)
         X3(-2, 0, -1, 2, 1, 2);
         bcost <<= 3;
         if (YOK(0)) LT((costs[0] << 3) + 2);
@@ -290,14 +366,12 @@ __global__ void __launch_bounds__(256) me_search_kernel(SearchArgs a)
         }
         bcost >>= 3;
         int dir = 0;
-        costs[0] = c.cost_mv(bmv.x, bmv.y - 1); costs[1] = c.cost_mv(bmv.x, bmv.y + 1);
-        costs[2] = c.cost_mv(bmv.x - 1, bmv.y); costs[3] = c.cost_mv(bmv.x + 1, bmv.y);
+        { const int mxs[4] = { bmv.x, bmv.x, bmv.x - 1, bmv.x + 1 }, mys[4] = { bmv.y - 1, bmv.y + 1, bmv.y, bmv.y }; c.template cost_mv_n<4>(mxs, mys, costs); }
         if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 1; }
         if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 2; }
         if (costs[2] < bcost) { bcost = costs[2]; dir = 3; }
         if (costs[3] < bcost) { bcost = costs[3]; dir = 4; }
-        costs[0] = c.cost_mv(bmv.x - 1, bmv.y - 1); costs[1] = c.cost_mv(bmv.x - 1, bmv.y + 1);
-        costs[2] = c.cost_mv(bmv.x + 1, bmv.y - 1); costs[3] = c.cost_mv(bmv.x + 1, bmv.y + 1);
+        { const int mxs[4] = { bmv.x - 1, bmv.x - 1, bmv.x + 1, bmv.x + 1 }, mys[4] = { bmv.y - 1, bmv.y + 1, bmv.y - 1, bmv.y + 1 }; c.template cost_mv_n<4>(mxs, mys, costs); }
         if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 5; }
         if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 6; }
         if (YOK(-1) && costs[2] < bcost) { bcost = costs[2]; dir = 7; }
@@ -308,7 +382,7 @@ __global__ void __launch_bounds__(256) me_search_kernel(SearchArgs a)
     else if (a.method == 3)         // X265_STAR_SEARCH
     {
         int bPointNr = 0, bDistance = 0;
-        star_pattern<Px>(c, bmv, bcost, bPointNr, bDistance, 3, merange);
+        star_pattern<Px, G, T>(c, bmv, bcost, bPointNr, bDistance, 3, merange);
         bool done = false;
         auto two_points = [&]()
         {
@@ -355,7 +429,7 @@ __global__ void __launch_bounds__(256) me_search_kernel(SearchArgs a)
             {
                 bDistance = 0;
                 bPointNr = 0;
-                star_pattern<Px>(c, bmv, bcost, bPointNr, bDistance, 32, merange);
+                star_pattern<Px, G, T>(c, bmv, bcost, bPointNr, bDistance, 32, merange);
                 if (bDistance == 1)
                 {
                     if (bPointNr) two_points();
@@ -415,11 +489,63 @@ __global__ void __launch_bounds__(256) me_search_kernel(SearchArgs a)
             else break;
         }
     }
-    if (lane == 0)
+    if (gl == 0)
     {
         a.jobs[job].out_qmvx = bx;
         a.jobs[job].out_qmvy = by;
         a.jobs[job].out_cost = bcost;
+    }
+}
+
+// size class of a job: 0 = quad (<= 8 tiles), 1 = 16-lane row (<= 32 tiles), 2 = whole wavefront
+__device__ __forceinline__ int job_class(const x265hip_me_search_job& j)
+{
+    const int nt = (j.w >> 2) * (j.h >> 2);
+    return nt <= 8 ? 0 : (nt <= 32 ? 1 : 2);
+}
+
+template <typename Px>
+__global__ void __launch_bounds__(256) me_search_kernel(SearchArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int first = wave * 16;                                  // this wavefront's 16 consecutive jobs
+    if (first >= a.njobs) return;
+    // classes of the 16 jobs, one per lane 0..15, shared through ballots
+    int cls = 3;
+    if (lane < 16 && first + lane < a.njobs) cls = job_class(a.jobs[first + lane]);
+    const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+    // small PUs: quad q takes job q
+    {
+        const int q = lane >> 2;
+        if ((m0 >> q) & 1) search_job<Px, 4, 2>(a, first + q);
+    }
+    // medium PUs: four at a time, one per 16-lane row
+    {
+        unsigned long long m = m1;
+        while (m)
+        {
+            int mine = -1;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+            {
+                if (!m) break;
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if ((lane >> 4) == r) mine = j;
+            }
+            if (mine >= 0) search_job<Px, 16, 2>(a, first + mine);
+        }
+    }
+    // large PUs: the whole wavefront, one after the other
+    {
+        unsigned long long m = m2;
+        while (m)
+        {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            search_job<Px, 64, 4>(a, first + j);
+        }
     }
 }
 
@@ -447,7 +573,7 @@ extern "C" int x265hip_me_search(const x265hip_me_search_params* p, void* stream
     a.depth = p->depth; a.method = p->method; a.subme = p->subme; a.merange = p->merange;
     a.mvminx = p->mvmin_x; a.mvminy = p->mvmin_y; a.mvmaxx = p->mvmax_x; a.mvmaxy = p->mvmax_y;
     hipStream_t s = (hipStream_t)stream;
-    const int wgs = (p->njobs + 3) / 4;
+    const int wgs = (p->njobs + 63) / 64;                          // 4 wavefronts x 16 jobs per workgroup
     if (bpp == 1) hipLaunchKernelGGL(me_search_kernel<uint8_t>, dim3(wgs), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(me_search_kernel<uint16_t>, dim3(wgs), dim3(256), 0, s, a);
     X265HIP_TRY(hipGetLastError());

@@ -106,6 +106,45 @@ class Lookahead:
         return {"intra_cost": int(self.intra_cost.sum(dtype=torch.int64).item()), "intra_mode": int(self.intra_mode.sum(dtype=torch.int64).item())}
 
 
+class PatternSearch:
+    """Motion search drivers for every 8x8..64x64 PU of every CTU (x265hip_me_search; reference
+    MotionEstimate::motionEstimate, motion.cpp:739-1561) with predictor (0,0): integer pattern + sub-pel refinement in
+    one launch.  Output has SubpelRefine's layout: int32 [ctu*85][2] = {cost, qmvx | qmvy << 16}."""
+
+    def __init__(self, w64, h64, depth, method, subme, merange, device, lam=4.0):
+        import numpy as np
+        import torch
+        from . import frames as F
+        self.depth, self.method, self.subme, self.merange = depth, method, subme, merange
+        jobs = []
+        for cy in range(0, h64, 64):
+            for cx in range(0, w64, 64):
+                for n in (8, 16, 32, 64):
+                    npu = (64 // n) ** 2
+                    for z in range(npu):
+                        bx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)
+                        by = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)
+                        jobs.append((cx + bx * n, cy + by * n, n, n, 0, 0, 0, 0, 0))
+        self.njobs = len(jobs)
+        arr = np.array(jobs, dtype=hipabi.me_search_job_dtype())
+        self.jobs = torch.from_numpy(arr.view(np.int32).reshape(-1, 9).copy()).to(device)
+        cq, self.qoff = F.qpel_cost_table(merange, lam, qmax=8 * (merange + 8) + 64)
+        self.cost_q = torch.from_numpy(cq.view(np.int16)).to(device)
+        self.out = torch.zeros(self.njobs * 2, dtype=torch.int32, device=device)
+
+    def run(self, cur: DevicePicture, ref: DevicePicture):
+        r = self.merange
+        hipabi.me_search(self.depth, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, self.method, self.subme, r,
+                         self.cost_q, self.qoff, (-r, -r), (r, r), self.jobs, self.njobs)
+        o = self.out.view(-1, 2)
+        o[:, 0] = self.jobs[:, 8]
+        o[:, 1] = (self.jobs[:, 6] & 0xffff) | (self.jobs[:, 7] << 16)
+
+    def checksum(self):
+        import torch
+        return {"subpel": int(self.out.to(dtype=torch.int64).sum().item())}
+
+
 class FramePipeline:
     """Closed-loop frame pipeline: every frame is searched in, predicted from and reconstructed against the
     RECONSTRUCTION of the previous frame (like the reference's P-frame chain), all on device:
@@ -114,12 +153,18 @@ class FramePipeline:
     With lookahead=(width, height) the source picture also goes through the lookahead stage (half-resolution planes + intra
     cost estimate per 8x8 block), which only depends on the source."""
 
-    def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False, lookahead=None):
+    def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False, lookahead=None,
+                 search="full"):
         import torch
         from .pipeline import MotionSearch, SubpelRefine
         self.depth = depth
-        self.ms = MotionSearch(w64, h64, rng, depth, device, want_surf=want_surf, want_best=True, packed=packed)
+        self.ms = MotionSearch(w64, h64, rng, depth, device, want_surf=want_surf and search == "full", want_best=True, packed=packed)
         self.sp = SubpelRefine(self.ms, subme, device)
+        # search != "full": the pattern-search drivers replace the exhaustive search + sub-pel pair
+        self.ps = None
+        if search != "full":
+            method = {"dia": hipabi.ME_DIA, "hex": hipabi.ME_HEX, "star": hipabi.ME_STAR}[search]
+            self.ps = PatternSearch(w64, h64, depth, method, subme, rng, device)
         self.rc = InterRecon(self.ms.nctu, w64, h64, depth, level, qp, device)
         self.la = Lookahead(lookahead[0], lookahead[1], depth, device) if lookahead else None
         self.recon = None
@@ -131,16 +176,21 @@ class FramePipeline:
             self.recon = torch.zeros_like(cur.t)
         if self.la is not None:
             self.la.run(cur)
-        self.ms.run(cur, ref)
-        self.sp.run(cur, ref)
-        self.rc.run(cur, ref, self.recon, self.sp.out)
+        if self.ps is not None:
+            self.ps.run(cur, ref)
+            mv = self.ps.out
+        else:
+            self.ms.run(cur, ref)
+            self.sp.run(cur, ref)
+            mv = self.sp.out
+        self.rc.run(cur, ref, self.recon, mv)
         extend_border(self.recon, cur)
         return self.recon
 
     def checksum(self):
         import torch
         out = {}
-        out.update(self.sp.checksum())
+        out.update(self.ps.checksum() if self.ps is not None else self.sp.checksum())
         out.update(self.rc.checksum())
         if self.la is not None:
             out.update(self.la.checksum())
