@@ -131,3 +131,39 @@ def test_search_driver_restatement_equals_reference_motion_estimate(depth, metho
                     f"{method} subme {subme} merange {merange} PU {(a.px, a.py, a.w, a.h)} mvp {(a.qmvpx, a.qmvpy)} bounds {mn}..{mx}"
                 total += 1
     assert total >= 300
+
+
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 192, 144), (10, 128, 128)])
+def test_lookahead_restatement_equals_reference_classes(depth, width, height):
+    """oracle/x265_oracle_pipeline3.c against the real Lowres::init + LookaheadTLD::lowresIntraEstimate
+    (oracle/ref_lookahead.cpp): the four half-resolution planes including their extended borders, intraCost, intraMode
+    and lowresCosts of every 8x8 block."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_lowres_intra"):
+        pytest.skip("oracle/_ref predates ref_lookahead.cpp")
+    y = F.synth_clip(width, height, 1, depth=depth, seed=77)[0][0]
+    src, stride, org, w64, h64 = F.pad_plane(y)
+    wcu, hcu = (width // 2 + 7) >> 3, (height // 2 + 7) >> 3
+    lw, lh = wcu * 8, hcu * 8
+    geo = (ctypes.c_int * 5)()
+    rstride = (width // 2 + 2 * F.MARGIN_X + 31) & ~31                  # Lowres::create, lowres.cpp:59-61
+    rows = lh + 2 * F.MARGIN_Y
+    rplanes = [np.zeros(rstride * rows, dtype=y.dtype) for _ in range(4)]
+    rcost, rmode, rlc = np.zeros(wcu * hcu, np.int32), np.zeros(wcu * hcu, np.uint8), np.zeros(wcu * hcu, np.uint16)
+    lib.x265ref_lowres_intra.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_void_p] * 7
+    rc = lib.x265ref_lowres_intra(src.ctypes.data, width, height, geo, *[p.ctypes.data for p in rplanes],
+                                  rcost.ctypes.data, rmode.ctypes.data, rlc.ctypes.data)
+    assert rc == 0
+    assert tuple(geo) == (lw, lh, rstride, wcu, hcu)
+    penalty = 5 if depth == 8 else 80          # 5 * (int)x265_lambda_tab[X265_LOOKAHEAD_QP]: 1.0 (8-bit, QP 12) / 16.0 (10-bit, QP 24)
+    lorg = rstride * F.MARGIN_Y + F.MARGIN_X
+    planes = O.lowres_init(depth, src, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    for i in range(4):
+        a = planes[i].reshape(rows, rstride)[:, :lw + 2 * F.MARGIN_X]
+        b = rplanes[i].reshape(rows, rstride)[:, :lw + 2 * F.MARGIN_X]
+        if lw + 2 * F.MARGIN_X > rstride:      # rounded-up width: the reference's right margin runs into the next row (lowres.cpp:59-66)
+            a, b = a[:, :F.MARGIN_X + lw], b[:, :F.MARGIN_X + lw]
+        assert np.array_equal(a, b), f"lowres plane {i} differs from Lowres::init"
+    cost, mode, lc = O.lowres_intra(depth, planes[0], rstride, lorg, wcu, hcu, penalty)
+    assert np.array_equal(cost, rcost) and np.array_equal(mode, rmode) and np.array_equal(lc, rlc)
