@@ -188,6 +188,8 @@ typedef struct x265hip_me_search_params
     const uint16_t* cost_q;  int qoff;
     int mvmin_x, mvmin_y, mvmax_x, mvmax_y;
     x265hip_me_search_job* jobs;  int njobs;      /* DEVICE array, results written in place */
+    const int32_t* mvc;                           /* optional DEVICE int32 [njobs][12][2]: motionEstimate's extra quarter-pel */
+    const int32_t* num_mvc;                       /* candidates mvc[] (at most 12, search.cpp:2094) and their count per job */
 } x265hip_me_search_params;
 int x265hip_me_search(const x265hip_me_search_params* p, void* stream);
 

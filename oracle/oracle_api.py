@@ -126,18 +126,22 @@ def lowres_intra(depth, plane, stride, org, width_in_cu, height_in_cu, intra_pen
     return cost, mode, lc
 
 
-def motion_estimate(depth, fenc, fref, stride, org, method, subme, merange, cost_q, qoff, mvmin, mvmax, jobs, nthreads=0, avx2=False):
+def motion_estimate(depth, fenc, fref, stride, org, method, subme, merange, cost_q, qoff, mvmin, mvmax, jobs, nthreads=0, avx2=False,
+                    mvc=None, num_mvc=None):
     """CPU restatement of MotionEstimate::motionEstimate over a job array (numpy structured array with the fields of
     x265hip_me_search_job); results are written into a copy that is returned."""
     L = lib(avx2)
-    fn = getattr(L, f"x265oracle_motion_estimate_d{depth}")
+    fn = getattr(L, f"x265oracle_motion_estimate_mvc_d{depth}")
     fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + \
-                  [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+                  [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    mv = np.ascontiguousarray(mvc, dtype=np.int32) if mvc is not None else None
+    nm = np.ascontiguousarray(num_mvc, dtype=np.int32) if num_mvc is not None else None
     out = np.ascontiguousarray(jobs).copy()
     cq = np.ascontiguousarray(cost_q, dtype=np.uint16)
     es = fenc.itemsize
     rc = fn(fenc.ctypes.data + org * es, fref.ctypes.data + org * es, stride, method, subme, merange, cq.ctypes.data, qoff,
-            mvmin[0], mvmin[1], mvmax[0], mvmax[1], out.ctypes.data, len(out), nthreads)
+            mvmin[0], mvmin[1], mvmax[0], mvmax[1], out.ctypes.data, len(out), nthreads,
+            mv.ctypes.data if mv is not None else None, nm.ctypes.data if nm is not None else None)
     if rc:
         raise RuntimeError("x265oracle_motion_estimate: unsupported method or PU size")
     return out

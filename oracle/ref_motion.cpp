@@ -31,8 +31,9 @@ extern "C" {
 /* fenc / fref: pixel (0,0) of padded planes with the same stride.  method: X265_*_SEARCH (x265.h), subme 0..7,
  * qp selects the BitCost lambda table (bitcost.cpp:40-58).  mvmin / mvmax: integer-pel search bounds applied to every job.
  * Returns the number of jobs run. */
-int x265ref_motion_estimate(const void* fenc, const void* fref, intptr_t stride, int method, int subme, int merange, int qp,
-                            int mvminx, int mvminy, int mvmaxx, int mvmaxy, x265ref_me_job* jobs, int njobs)
+int x265ref_motion_estimate_mvc(const void* fenc, const void* fref, intptr_t stride, int method, int subme, int merange, int qp,
+                                int mvminx, int mvminy, int mvmaxx, int mvmaxy, x265ref_me_job* jobs, int njobs,
+                                const int32_t* mvc /* [njobs][12][2] quarter-pel, or NULL */, const int32_t* numMvc /* [njobs] */)
 {
     static bool tableReady = false;
     if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }   /* MotionEstimate reads the global table */
@@ -52,11 +53,20 @@ int x265ref_motion_estimate(const void* fenc, const void* fref, intptr_t stride,
         me.setSourcePU((pixel*)fenc, stride, offset, j.w, j.h, method, method, method, subme);
         MV out(0, 0);
         const MV qmvp(j.qmvpx, j.qmvpy);
-        j.out_cost = me.motionEstimate(&ref, mvmin, mvmax, qmvp, 0, NULL, merange, out, 1);
+        MV cand[12];
+        const int nc = (mvc && numMvc) ? numMvc[i] : 0;
+        for (int k = 0; k < nc; k++) cand[k] = MV(mvc[(i * 12 + k) * 2], mvc[(i * 12 + k) * 2 + 1]);
+        j.out_cost = me.motionEstimate(&ref, mvmin, mvmax, qmvp, nc, cand, merange, out, 1);
         j.out_qmvx = out.x;
         j.out_qmvy = out.y;
     }
     return njobs;
+}
+
+int x265ref_motion_estimate(const void* fenc, const void* fref, intptr_t stride, int method, int subme, int merange, int qp,
+                            int mvminx, int mvminy, int mvmaxx, int mvmaxy, x265ref_me_job* jobs, int njobs)
+{
+    return x265ref_motion_estimate_mvc(fenc, fref, stride, method, subme, merange, qp, mvminx, mvminy, mvmaxx, mvmaxy, jobs, njobs, NULL, NULL);
 }
 
 /* the u16 cost of a quarter-pel mv difference for `qp` (index d + 2 * BC_MAX_MV), for tests that want the exact table */

@@ -172,13 +172,13 @@ static void star_pattern(const me_ctx* c, mv_t* bmv, int* bcost, int* bPointNr, 
 
 static int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 
-static int motion_estimate_one(me_ctx* c, int method, int subme, int merange, int* outQx, int* outQy)
+static int motion_estimate_one(me_ctx* c, int method, int subme, int merange, const int32_t* mvc, int numMvc, int* outQx, int* outQy)
 {
     const int qminx = c->mvmin.x * 4, qminy = c->mvmin.y * 4, qmaxx = c->mvmax.x * 4, qmaxy = c->mvmax.y * 4;
     /* measure the clipped quarter-pel predictor (:772-781), re-measure its full-pel rounding (:783-787), try mv 0 (:789-799) */
     int pmvx = clip3(qminx, qmaxx, c->mvpx), pmvy = clip3(qminy, qmaxy, c->mvpy);
-    const int bestprex = pmvx, bestprey = pmvy;
-    const int bprecost = subpel_compare(c, pmvx, pmvy, 0);
+    int bestprex = pmvx, bestprey = pmvy;
+    int bprecost = subpel_compare(c, pmvx, pmvy, 0);
     mv_t bmv = { (pmvx + 2) >> 2, (pmvy + 2) >> 2 };
     int bcost = bprecost;
     if ((pmvx | pmvy) & 3) bcost = cost_mv(c, bmv.x, bmv.y);
@@ -191,6 +191,16 @@ static int motion_estimate_one(me_ctx* c, int method, int subme, int merange, in
             bmv.x = 0;
             const int zy = 0 < c->mvmax.y ? 0 : c->mvmax.y;
             bmv.y = zy > c->mvmin.y ? zy : c->mvmin.y;
+        }
+    }
+    /* extra quarter-pel candidates (:800-812): SAD + mv cost against the measured predictor, not against the search start */
+    for (int i = 0; i < numMvc; i++)
+    {
+        const int mx = clip3(qminx, qmaxx, mvc[2 * i]), my = clip3(qminy, qmaxy, mvc[2 * i + 1]);
+        if ((mx | my) && (mx != pmvx || my != pmvy) && (mx != bestprex || my != bestprey))
+        {
+            const int cost = subpel_compare(c, mx, my, 0) + mvcost_q(c, mx, my);
+            if (cost < bprecost) { bprecost = cost; bestprex = mx; bestprey = my; }
         }
     }
     int costs[4];
@@ -387,9 +397,22 @@ static int motion_estimate_one(me_ctx* c, int method, int subme, int merange, in
 
 /* fenc / fref: pixel (0,0) of padded planes of equal stride.  cost: uint16 table, cost[q] for q in [-qoff, qoff]
  * (pointer to the q = 0 entry is cost + qoff).  Runs every job; returns 0, or -1 for an unsupported method / PU size. */
+int EXPORT(x265oracle_motion_estimate_mvc)(const pixel* fenc, const pixel* fref, intptr_t stride, int method, int subme, int merange,
+                                           const uint16_t* cost, int qoff, int mvminx, int mvminy, int mvmaxx, int mvmaxy,
+                                           me_job* jobs, int njobs, int nthreads, const int32_t* mvc, const int32_t* numMvc);
+
 int EXPORT(x265oracle_motion_estimate)(const pixel* fenc, const pixel* fref, intptr_t stride, int method, int subme, int merange,
                                        const uint16_t* cost, int qoff, int mvminx, int mvminy, int mvmaxx, int mvmaxy,
                                        me_job* jobs, int njobs, int nthreads)
+{
+    return EXPORT(x265oracle_motion_estimate_mvc)(fenc, fref, stride, method, subme, merange, cost, qoff, mvminx, mvminy, mvmaxx, mvmaxy,
+                                                  jobs, njobs, nthreads, NULL, NULL);
+}
+
+/* mvc: optional int32 [njobs][12][2] quarter-pel candidates, numMvc: int32 [njobs] (the reference passes at most 12, search.cpp:2094) */
+int EXPORT(x265oracle_motion_estimate_mvc)(const pixel* fenc, const pixel* fref, intptr_t stride, int method, int subme, int merange,
+                                           const uint16_t* cost, int qoff, int mvminx, int mvminy, int mvmaxx, int mvmaxy,
+                                           me_job* jobs, int njobs, int nthreads, const int32_t* mvc, const int32_t* numMvc)
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
@@ -415,7 +438,7 @@ int EXPORT(x265oracle_motion_estimate)(const pixel* fenc, const pixel* fref, int
         c.mvpx = j->qmvpx; c.mvpy = j->qmvpy;
         c.mvmin.x = mvminx; c.mvmin.y = mvminy; c.mvmax.x = mvmaxx; c.mvmax.y = mvmaxy;
         int qx = 0, qy = 0;
-        const int cst = motion_estimate_one(&c, method, subme, merange, &qx, &qy);
+        const int cst = motion_estimate_one(&c, method, subme, merange, mvc ? mvc + (size_t)i * 24 : NULL, (mvc && numMvc) ? numMvc[i] : 0, &qx, &qy);
         if (cst < 0) { rc = -1; continue; }
         j->out_cost = cst; j->out_qmvx = qx; j->out_qmvy = qy;
     }

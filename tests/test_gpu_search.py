@@ -94,3 +94,32 @@ def test_unimplemented_methods_are_rejected():
     for m in (A.ME_UMH, A.ME_SEA):
         with pytest.raises(A.X265HipError):
             A.me_search(8, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, m, 2, 16, cq_d, qoff, (-8, -8), (8, 8), jd, 1)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_search_with_extra_candidates(depth):
+    """mvc[] candidates of motionEstimate (motion.cpp:800-812), 0..12 per job."""
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    width, height = 256, 192
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=44)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    rng = np.random.default_rng([44, depth])
+    cq, qoff = F.qpel_cost_table(57, qmax=8 * 64 + 300)
+    cq_d = torch.from_numpy(cq.view(np.int16)).to(dev)
+    for method in ("hex", "star"):
+        n = 64
+        jobs = _jobs(rng, n, width, height)
+        num = rng.integers(0, 13, size=n).astype(np.int32)
+        mvc = rng.integers(-60, 61, size=(n, 12, 2)).astype(np.int32)
+        mvc[::7, 0] = 0
+        exp = O.motion_estimate(depth, cur.host, ref.host, cur.stride, cur.org, METHODS[method], 3, 16, cq, qoff, (-57, -57), (57, 57), jobs,
+                                mvc=mvc, num_mvc=num)
+        jd = torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy()).to(dev)
+        A.me_search(depth, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, METHODS[method], 3, 16, cq_d, qoff, (-57, -57), (57, 57), jd, n,
+                    mvc=torch.from_numpy(mvc).to(dev), num_mvc=torch.from_numpy(num).to(dev))
+        torch.cuda.synchronize()
+        got = jd.cpu().numpy().view(A.me_search_job_dtype())
+        for f in ("out_cost", "out_qmvx", "out_qmvy"):
+            assert np.array_equal(got[f], exp[f]), f"{method}: {f} differs with extra candidates"

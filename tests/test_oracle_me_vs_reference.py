@@ -167,3 +167,42 @@ def test_lookahead_restatement_equals_reference_classes(depth, width, height):
         assert np.array_equal(a, b), f"lowres plane {i} differs from Lowres::init"
     cost, mode, lc = O.lowres_intra(depth, planes[0], rstride, lorg, wcu, hcu, penalty)
     assert np.array_equal(cost, rcost) and np.array_equal(mode, rmode) and np.array_equal(lc, rlc)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_search_driver_with_extra_candidates_equals_reference(depth):
+    """motionEstimate's mvc[] candidates (motion.cpp:800-812: measured with SAD + mv cost against the predictor's cost, skipping
+    zero / predictor / current-best duplicates), up to the 12 the encoder passes (search.cpp:2094)."""
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_motion_estimate_mvc"):
+        pytest.skip("oracle/_ref predates the mvc entry point")
+    lib.x265ref_motion_estimate_mvc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t] + [ctypes.c_int] * 8 + \
+                                                [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libx265oracle.so"))
+    f = getattr(orc, f"x265oracle_motion_estimate_mvc_d{depth}")
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + \
+                 [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    width, height = 256, 192
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=33)
+    cur, stride, org, _, _ = F.pad_plane(clip[1][0])
+    ref = F.pad_plane(clip[0][0])[0]
+    es = cur.itemsize
+    rng = np.random.default_rng([9, depth])
+    qp = 24 if depth == 8 else 12
+    cq, qoff = F.qpel_cost_table(57, qmax=8 * 64 + 300)
+    for method in (1, 3):
+        for subme in (1, 2, 5):
+            n = 48
+            ja = random_me_jobs(rng, n, width, height)
+            jb = copy_jobs(ja)
+            num = rng.integers(0, 13, size=n).astype(np.int32)
+            mvc = rng.integers(-60, 61, size=(n, 12, 2)).astype(np.int32)
+            mvc[rng.integers(0, n, size=8), 0] = 0                                      # some zero / duplicate candidates
+            for i in range(0, n, 5):
+                mvc[i, 1] = (ja[i].qmvpx, ja[i].qmvpy)
+            lib.x265ref_motion_estimate_mvc(cur.ctypes.data + org * es, ref.ctypes.data + org * es, stride, method, subme, 16, qp,
+                                            -57, -57, 57, 57, ja, n, mvc.ctypes.data, num.ctypes.data)
+            assert f(cur.ctypes.data + org * es, ref.ctypes.data + org * es, stride, method, subme, 16, cq.ctypes.data, qoff,
+                     -57, -57, 57, 57, jb, n, 1, mvc.ctypes.data, num.ctypes.data) == 0
+            for a, b in zip(ja, jb):
+                assert (a.out_cost, a.out_qmvx, a.out_qmvy) == (b.out_cost, b.out_qmvx, b.out_qmvy)

@@ -29,6 +29,7 @@ struct SearchArgs
     x265hip_me_search_job* jobs; int njobs;
     int depth, method, subme, merange;
     int mvminx, mvminy, mvmaxx, mvmaxy;
+    const int32_t* mvc; const int32_t* numMvc;      // optional [njobs][12][2] quarter-pel candidates / [njobs]
 };
 
 struct SMv { int x, y; };
@@ -296,7 +297,8 @@ __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
     const int merange = a.merange;
     const int qminx = c.mvmin.x * 4, qminy = c.mvmin.y * 4, qmaxx = c.mvmax.x * 4, qmaxy = c.mvmax.y * 4;
     const int pmvx = s_clip3(qminx, qmaxx, c.mvpx), pmvy = s_clip3(qminy, qmaxy, c.mvpy);
-    const int bprecost = c.cmp_q(pmvx, pmvy, false);
+    int bprecost = c.cmp_q(pmvx, pmvy, false);
+    int bestprex = pmvx, bestprey = pmvy;
     SMv bmv = { (pmvx + 2) >> 2, (pmvy + 2) >> 2 };
     int bcost = bprecost;
     if ((pmvx | pmvy) & 3) bcost = c.cost_mv(bmv.x, bmv.y);
@@ -309,6 +311,17 @@ __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
             bmv.x = 0;
             const int zy = 0 < c.mvmax.y ? 0 : c.mvmax.y;
             bmv.y = zy > c.mvmin.y ? zy : c.mvmin.y;
+        }
+    }
+    // extra quarter-pel candidates (motion.cpp:800-812) compete with the measured predictor
+    const int numMvc = (a.mvc && a.numMvc) ? a.numMvc[job] : 0;
+    for (int i = 0; i < numMvc; i++)
+    {
+        const int mx = s_clip3(qminx, qmaxx, a.mvc[(job * 12 + i) * 2]), my = s_clip3(qminy, qmaxy, a.mvc[(job * 12 + i) * 2 + 1]);
+        if ((mx | my) && (mx != pmvx || my != pmvy) && (mx != bestprex || my != bestprey))
+        {
+            const int cost = c.cmp_q(mx, my, false) + c.mvcost_q(mx, my);
+            if (cost < bprecost) { bprecost = cost; bestprex = mx; bestprey = my; }
         }
     }
     int costs[4];
@@ -451,7 +464,7 @@ __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
 #undef LT
 
     int bx, by;
-    if (bprecost < bcost) { bx = pmvx; by = pmvy; bcost = bprecost; }
+    if (bprecost < bcost) { bx = bestprex; by = bestprey; bcost = bprecost; }
     else { bx = bmv.x * 4; by = bmv.y * 4; }
     const int hpelIters = kSWorkload[a.subme][0], hpelDirs = kSWorkload[a.subme][1], qpelIters = kSWorkload[a.subme][2],
               qpelDirs = kSWorkload[a.subme][3];
@@ -572,6 +585,7 @@ extern "C" int x265hip_me_search(const x265hip_me_search_params* p, void* stream
     a.cost = p->cost_q + p->qoff; a.jobs = p->jobs; a.njobs = p->njobs;
     a.depth = p->depth; a.method = p->method; a.subme = p->subme; a.merange = p->merange;
     a.mvminx = p->mvmin_x; a.mvminy = p->mvmin_y; a.mvmaxx = p->mvmax_x; a.mvmaxy = p->mvmax_y;
+    a.mvc = p->mvc; a.numMvc = p->num_mvc;
     hipStream_t s = (hipStream_t)stream;
     const int wgs = (p->njobs + 63) / 64;                          // 4 wavefronts x 16 jobs per workgroup
     if (bpp == 1) hipLaunchKernelGGL(me_search_kernel<uint8_t>, dim3(wgs), dim3(256), 0, s, a);

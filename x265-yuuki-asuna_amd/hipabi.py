@@ -69,7 +69,7 @@ class MESearchParams(ctypes.Structure):
                 ("method", ctypes.c_int), ("subme", ctypes.c_int), ("merange", ctypes.c_int),
                 ("cost_q", ctypes.c_void_p), ("qoff", ctypes.c_int),
                 ("mvmin_x", ctypes.c_int), ("mvmin_y", ctypes.c_int), ("mvmax_x", ctypes.c_int), ("mvmax_y", ctypes.c_int),
-                ("jobs", ctypes.c_void_p), ("njobs", ctypes.c_int)]
+                ("jobs", ctypes.c_void_p), ("njobs", ctypes.c_int), ("mvc", ctypes.c_void_p), ("num_mvc", ctypes.c_void_p)]
 
 
 ME_DIA, ME_HEX, ME_UMH, ME_STAR, ME_SEA, ME_FULL = range(6)
@@ -182,8 +182,9 @@ def lowres_intra(depth, plane, stride, org, width_in_cu, height_in_cu, intra_pen
 
 
 def me_search(depth, fenc, fenc_stride, fenc_off, fref, fref_stride, fref_off, method, subme, merange, cost_q, qoff,
-              mvmin, mvmax, jobs, njobs, stream=None):
-    """jobs: device uint8 tensor holding njobs x265hip_me_search_job records (me_search_job_dtype), updated in place."""
+              mvmin, mvmax, jobs, njobs, stream=None, mvc=None, num_mvc=None):
+    """jobs: device uint8 tensor holding njobs x265hip_me_search_job records (me_search_job_dtype), updated in place.
+    mvc / num_mvc: optional device int32 tensors [njobs][12][2] / [njobs] (motionEstimate's extra candidates)."""
     es = 1 if depth == 8 else 2
     p = MESearchParams()
     p.depth = depth
@@ -193,6 +194,7 @@ def me_search(depth, fenc, fenc_stride, fenc_off, fref, fref_stride, fref_off, m
     p.cost_q, p.qoff = cost_q.data_ptr(), qoff
     p.mvmin_x, p.mvmin_y, p.mvmax_x, p.mvmax_y = mvmin[0], mvmin[1], mvmax[0], mvmax[1]
     p.jobs, p.njobs = jobs.data_ptr(), njobs
+    p.mvc, p.num_mvc = _p(mvc), _p(num_mvc)
     s = current_stream() if stream is None else stream
     f = lib().x265hip_me_search
     f.argtypes = [ctypes.POINTER(MESearchParams), ctypes.c_void_p]
