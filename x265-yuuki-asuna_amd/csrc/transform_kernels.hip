@@ -16,6 +16,7 @@
 //     hi, lo in [-128,127]); M * x = 256 * (M*hi) + (M*lo) + 128 * rowsum(M), every partial sum fits
 //     int32 exactly, so the rounding shift sees the same integer as the reference.
 #include "common.h"
+#include "mfma_dct.h"
 
 #include <cstdlib>
 
@@ -187,40 +188,6 @@ __global__ void __launch_bounds__(256) lowpass_kernel(TrArgs a)
 // One wavefront per TU.  N = 32: one v_mfma_i32_32x32x32_i8 per limb; N = 16: v_mfma_i32_16x16x64_i8 would
 // need K = 64, so the 16-point product is zero-padded to K = 32 inside the 32x32x32 shape?  No - the
 // 16x16 case uses v_mfma_i32_16x16x64_i8 with the K range [16,64) fed zeros.
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-
-// Operand fragment layouts (gfx950, 8-bit types): 32x32x32 - lane l supplies A[row = l & 31][k = 16*(l >> 5) + 0..15]
-// and B[k = 16*(l >> 5) + 0..15][col = l & 31]; C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5).
-// 16x16x64 - A[row = l & 15][k = 16*(l >> 4) + 0..15], B[k = 16*(l >> 4) + 0..15][col = l & 15];
-// C/D: col = l & 15, row = 4*(l >> 4) + r.
-template <int N> struct Mfma;
-template <> struct Mfma<32>
-{
-    typedef v16i Acc;
-    static constexpr int NACC = 16;
-    static __device__ __forceinline__ Acc run(v4i a, v4i b, Acc c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-    static __device__ __forceinline__ int col(int lane) { return lane & 31; }
-    static __device__ __forceinline__ int kbase(int lane) { return 16 * (lane >> 5); }
-    static __device__ __forceinline__ int mn(int lane) { return lane & 31; }
-};
-template <> struct Mfma<16>
-{
-    typedef v4i Acc;
-    static constexpr int NACC = 4;
-    static __device__ __forceinline__ Acc run(v4i a, v4i b, Acc c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
-    static __device__ __forceinline__ int col(int lane) { return lane & 15; }
-    static __device__ __forceinline__ int kbase(int lane) { return 16 * (lane >> 4); }     // 0,16,32,48: only 0 is inside K = 16
-    static __device__ __forceinline__ int mn(int lane) { return lane & 15; }
-};
-
-__device__ __forceinline__ int pack4(int b0, int b1, int b2, int b3)
-{
-    return (b0 & 0xff) | ((b1 & 0xff) << 8) | ((b2 & 0xff) << 16) | ((uint32_t)(b3 & 0xff) << 24);
-}
-
 // P = Mop x X where Mop is the transform matrix (FWD: M[k][i]; INV: M^T, i.e. Mop[k][i] = M[i][k]) and
 // X[i][col] comes from LDS as int16 via xsrc(i, col).  Returns the exact int32 products in C/D layout.
 template <int N, bool INV, typename XF>
@@ -345,20 +312,6 @@ template <int N, int KIND, bool DST> static int launch_valu(const TrArgs& a, hip
 // lane), the limb split is two v_perm_b32 + one v_xor per four samples (x = 256 * hi + lo with hi the signed high
 // byte as it stands and lo - 128 the low byte with its top bit flipped), and the only LDS traffic is the 32 x 32
 // transpose between the two passes (and in front of the inverse's first pass, whose contraction runs down columns).
-typedef uint32_t __attribute__((ext_vector_type(4), aligned(2))) u32x4_a2;
-typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
-
-// 16 consecutive int16 (8 dwords) -> high-byte and (low-byte - 128) fragments
-__device__ __forceinline__ void split_limbs(const uint32_t (&d)[8], v4i& hi, v4i& lo)
-{
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-    {
-        hi[q] = (int)__builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x07050301u);
-        lo[q] = (int)(__builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x06040200u) ^ 0x80808080u);
-    }
-}
-
 template <int N, int KIND>
 __global__ void __launch_bounds__(256) transform_mfma_stream_kernel(TrArgs a)
 {

@@ -11,6 +11,7 @@
 // ~9x that).  This is SURVEY section 8(f) item 2.  Arithmetic per primitive: ipfilter.cpp:79-369,
 // dct.cpp:83-240,242-416,612-634,664-686, pixel.cpp:167-186,471-483,828-840.
 #include "common.h"
+#include "mfma_dct.h"
 
 namespace x265hip {
 
@@ -137,6 +138,65 @@ __global__ void __launch_bounds__(256) inter_recon_kernel(TuArgs a)
     for (int i = tid; i < NN; i += nth) A[i] = (int16_t)((int)fe[i] - (int)pred[i]);
     __syncthreads();
     const int sh1 = LOG2N - 1 + a.depth - 8, sh2 = LOG2N + 6;
+    const int per = a.qp / 6, rem = a.qp - per * 6;
+    const int transformShift = 15 - a.depth - LOG2N;
+    const int qbits = 14 + per + transformShift;
+    const int qadd = (a.intraSlice ? 171 : 85) << (qbits - 9);
+    const int qscale = kTuQuantScales[rem];
+    int16_t* lv = a.levels + ((size_t)ctu * npu + z) * NN;
+    int nz = 0;
+    constexpr bool USE_MFMA = N >= 16;           // the 16 / 32 point transforms are dense matrix products: matrix cores
+    const int lane = tid & 63, wave = tid >> 6;
+    auto matrix = [](int r, int c) { return (int)kTu.m[r][c]; };
+    // 16 consecutive int16 of an LDS row (forward operands) / 16 samples down a column (inverse operands)
+    auto lds_row16 = [&](const int16_t* base, uint32_t (&d)[8])
+    {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(base);
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = q[k];
+    };
+    auto lds_col16 = [&](const int16_t* base, uint32_t (&d)[8])
+    {
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = (uint32_t)(uint16_t)base[(2 * k) * N] | ((uint32_t)(uint16_t)base[(2 * k + 1) * N] << 16);
+    };
+    if constexpr (USE_MFMA)
+    {
+        if (wave == 0)
+        {
+            typedef Mfma<N> MF;
+            DctOperand<N, false> fw;
+            fw.init(lane, matrix);
+            const int kb = MF::kbase(lane), rn = MF::mn(lane);
+            uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            int p[MF::NACC];
+            // pass 1: P[k][j] = sum_i M[k][i] * resid[j][i]
+            if (fw.kvalid) lds_row16(A + rn * N + kb, d);
+            fw.product(d, p);
+#pragma unroll
+            for (int r = 0; r < MF::NACC; r++) B[MF::row(lane, r) * N + MF::col(lane)] = (int16_t)((p[r] + (1 << (sh1 - 1))) >> sh1);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            // pass 2 fused with quant (quant.cpp:462-469, dct.cpp:664-686)
+            if (fw.kvalid) lds_row16(B + rn * N + kb, d);
+            fw.product(d, p);
+#pragma unroll
+            for (int r = 0; r < MF::NACC; r++)
+            {
+                const int e = MF::row(lane, r) * N + MF::col(lane);
+                const int c = (int16_t)((p[r] + (1 << (sh2 - 1))) >> sh2);
+                const int t = abs(c) * qscale;
+                int level = (t + qadd) >> qbits;
+                nz += level != 0;
+                if (c < 0) level = -level;
+                level = tu_sat16(level);
+                A[e] = (int16_t)level;            // A is free again: quantised levels
+                lv[e] = (int16_t)level;
+            }
+        }
+    }
+    else
+    {
     for (int e = tid; e < NN; e += nth)
     {
         const int k = e >> LOG2N, j = e & (N - 1);
@@ -147,13 +207,6 @@ __global__ void __launch_bounds__(256) inter_recon_kernel(TuArgs a)
     }
     __syncthreads();
     // ---- second pass fused with quant (quant.cpp:462-469, dct.cpp:664-686) ----------------------------------
-    const int per = a.qp / 6, rem = a.qp - per * 6;
-    const int transformShift = 15 - a.depth - LOG2N;
-    const int qbits = 14 + per + transformShift;
-    const int qadd = (a.intraSlice ? 171 : 85) << (qbits - 9);
-    const int qscale = kTuQuantScales[rem];
-    int16_t* lv = a.levels + ((size_t)ctu * npu + z) * NN;
-    int nz = 0;
     for (int e = tid; e < NN; e += nth)
     {
         const int k = e >> LOG2N, j = e & (N - 1);
@@ -168,6 +221,7 @@ __global__ void __launch_bounds__(256) inter_recon_kernel(TuArgs a)
         level = tu_sat16(level);
         A[e] = (int16_t)level;            // A is free again: quantised levels
         lv[e] = (int16_t)level;
+    }
     }
     nz = group_sum<64>(nz);
     if ((tid & 63) == 0 && nz) atomicAdd(&sNumSig, nz);
@@ -202,6 +256,41 @@ __global__ void __launch_bounds__(256) inter_recon_kernel(TuArgs a)
         {
             for (int i = tid; i < NN; i += nth) B[i] = (int16_t)tu_sat16(((int)A[i] * dqScale + dqAdd) >> dqShift);
             __syncthreads();
+            const int shI = 12 - (a.depth - 8);
+            if constexpr (USE_MFMA)
+            {
+                if (wave == 0)
+                {
+                    typedef Mfma<N> MF;
+                    DctOperand<N, true> iv;
+                    iv.init(lane, matrix);
+                    const int kb = MF::kbase(lane), rn = MF::mn(lane);
+                    uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+                    int p[MF::NACC];
+                    // pass 1: P[k][j] = sum_i M[i][k] * deq[i][j]  (contraction down the columns), stored as out1[j][k]
+                    if (iv.kvalid) lds_col16(B + kb * N + rn, d);
+                    iv.product(d, p);
+#pragma unroll
+                    for (int r = 0; r < MF::NACC; r++) A[MF::col(lane) * N + MF::row(lane, r)] = (int16_t)tu_sat16((p[r] + 64) >> 7);
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    // pass 2: r[j][k] = sum_i M[i][k] * out1[i][j]
+                    if (iv.kvalid) lds_col16(A + kb * N + rn, d);
+                    iv.product(d, p);
+#pragma unroll
+                    for (int r = 0; r < MF::NACC; r++)
+                    {
+                        const int j = MF::col(lane), k = MF::row(lane, r);
+                        const int res = tu_sat16((p[r] + (1 << (shI - 1))) >> shI);
+                        const int v = clip3(0, maxVal, (int)pred[j * N + k] + res);
+                        rec[j * cst + k] = (Px)v;
+                        const int dd = (int)fe[j * N + k] - v;
+                        part += (unsigned)(dd * dd);
+                    }
+                }
+            }
+            else
+            {
             for (int e = tid; e < NN; e += nth)
             {
                 const int j = e >> LOG2N, k = e & (N - 1);
@@ -211,7 +300,6 @@ __global__ void __launch_bounds__(256) inter_recon_kernel(TuArgs a)
                 A[j * N + k] = (int16_t)tu_sat16((acc + 64) >> 7);
             }
             __syncthreads();
-            const int shI = 12 - (a.depth - 8);
             for (int e = tid; e < NN; e += nth)
             {
                 const int j = e >> LOG2N, k = e & (N - 1);
@@ -223,6 +311,7 @@ __global__ void __launch_bounds__(256) inter_recon_kernel(TuArgs a)
                 rec[j * cst + k] = (Px)v;
                 const int d = (int)fe[e] - v;
                 part += (unsigned)(d * d);
+            }
             }
         }
     }
