@@ -22,6 +22,13 @@ jn = np.array(jobs, dtype=A.me_search_job_dtype())
 jd = torch.from_numpy(jn.view(np.uint8).reshape(-1).copy()).to(dev)
 cq, qoff = F.qpel_cost_table(57, qmax=8 * 64 + 300)
 cq_d = torch.from_numpy(cq.view(np.int16)).to(dev)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import oracle_api as O            # CPU column only (the oracle restatement of motionEstimate, OpenMP over PUs)
+import time
+from bench import effective_cpus
+threads = effective_cpus()
+print(f"# x265hip_me_search: every 8x8..64x64 PU of every CTU, predictor (0,0), merange 57; CPU column = oracle/x265_oracle_search.c "
+      f"(-march=x86-64-v3) on {threads} threads (container CPU quota) over a sample of the same jobs")
 for name, m in (("dia", A.ME_DIA), ("hex", A.ME_HEX), ("star", A.ME_STAR)):
     for subme in (2, 3):
         f = lambda: A.me_search(8, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, m, subme, 57, cq_d, qoff, (-57, -57), (57, 57), jd, len(jn))
@@ -30,4 +37,10 @@ for name, m in (("dia", A.ME_DIA), ("hex", A.ME_HEX), ("star", A.ME_STAR)):
         e0.record()
         for _ in range(3): f()
         e1.record(); torch.cuda.synchronize()
-        print(f"{W}x{H} {name} subme {subme}: {len(jn)} PUs, {e0.elapsed_time(e1) / 3:.3f} ms")
+        t_gpu = e0.elapsed_time(e1) / 3
+        ns = min(len(jn), 85 * 64)                                   # 64 CTUs' worth of PUs on the CPU
+        t0 = time.perf_counter()
+        O.motion_estimate(8, cur.host, ref.host, cur.stride, cur.org, m, subme, 57, cq, qoff, (-57, -57), (57, 57), jn[:ns], nthreads=threads, avx2=O.host_has_avx2())
+        t_cpu = (time.perf_counter() - t0) * len(jn) / ns
+        print(f"{W}x{H} {name:4s} subme {subme}: {len(jn)} PUs, GPU {t_gpu:.3f} ms ({len(jn) / t_gpu / 1e3:.1f} M PU/s), "
+              f"CPU {t_cpu * 1e3:.1f} ms extrapolated from {ns} PUs ({threads} threads) -> GPU/CPU {t_cpu * 1e3 / t_gpu:.0f}x")
