@@ -126,7 +126,20 @@ def main():
                     help="full = exhaustive search (SAD surfaces + best mv) + sub-pel stage; dia/hex/star = the reference's pattern "
                          "searches run by the device-side search driver (x265hip_me_search), predictor (0,0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--prims", action="store_true",
+                    help="instead of the pipeline line, print the per-family table of the batch-layer kernels with the CPU paths timed beside "
+                         "them (tools/bench_prims.py: bench.py's cpu_baseline leg at primitive level)")
+    ap.add_argument("--search-probe", action="store_true",
+                    help="instead of the pipeline line, time the search drivers over every PU of a frame with the CPU restatement beside "
+                         "them (tools/search_probe.py)")
+    args, rest = ap.parse_known_args()
+    if args.prims or args.search_probe:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        sys.argv = [sys.argv[0]] + rest + ([str(args.width), str(args.height)] if args.search_probe else [])
+        mod = importlib.import_module("bench_prims" if args.prims else "search_probe")
+        if hasattr(mod, "main"):
+            mod.main()
+        return
 
     import torch
     import torch.distributed as dist

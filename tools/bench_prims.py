@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Per-family throughput of the batch-layer kernels on one MI355X, with the CPU path timed beside each
+"""[bench.py --prims: the primitive-level part of bench.py's cpu_baseline leg - the only place besides tests/ and smoke() that
+loads oracle/, and only to time the CPU path beside the kernels]
+
+Per-family throughput of the batch-layer kernels on one MI355X, with the CPU path timed beside each
 (primitive level).
 
 For every family: N blocks per launch (inputs resident in HBM), HIP-event time per launch, algorithmic bytes per block

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Throughput probe of x265hip_me_search: every 8x8..64x64 PU of every CTU of a frame, predictor (0,0)."""
+"""[bench.py --search-probe: the primitive-level part of bench.py's cpu_baseline leg - the only place besides tests/ and smoke() that
+loads oracle/, and only to time the CPU path beside the kernels]
+
+Throughput probe of x265hip_me_search: every 8x8..64x64 PU of every CTU of a frame, predictor (0,0)."""
 import importlib, sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
