@@ -14,7 +14,8 @@ the frame pipeline, everything resident in HBM:
          (sad_x4 grouping) + best mv, one launch
     SUB  sub-pel refinement of every PU (subme 3 = preset slow)
     REC  32x32 prediction + residual DCT / quant / dequant / iDCT / reconstruction + SSE (MC + TU round trip)
-    EXT  border extension; the reconstruction is the next frame's reference (closed loop)
+    DBK  in-loop luma deblocking of the reconstruction (boundary strengths from the mvs / coded flags, edge filters)
+    EXT  border extension; the filtered reconstruction is the next frame's reference (closed loop)
 
 With N GPUs the job is frame-parallel (one frame per GPU per step, weak scaling); the only data-path exchange is
 the one-to-many broadcast of the newest reconstructed reference (RCCL), the seam where the reference raises
@@ -67,8 +68,11 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0):
                                   want_surf=False, want_best=True, nthreads=cores, avx2=avx2)
         mv = O.subpel_refine(depth, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, best, cq, qoff, subme,
                              nthreads=cores, avx2=avx2)
-        O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp, ctu_begin=0, ctu_end=n,
-                      nthreads=cores, avx2=avx2)
+        rec, _, ns, _ = O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp, ctu_begin=0, ctu_end=n,
+                                      nthreads=cores, avx2=avx2)
+        if n == nctu:       # per-picture stage, single-threaded in the restatement
+            bv, bh = O.deblock_bs_inter(depth, w64, h64, level, mv, ns, avx2=avx2)
+            O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, qp, avx2=avx2)
         return time.perf_counter() - t
 
     probe = min(nctu, max(cores, 8))
@@ -165,7 +169,7 @@ def main():
     pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
                            qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed" and args.depth == 8,
-                           lookahead=(args.width, args.height), search=args.search)
+                           lookahead=(args.width, args.height), search=args.search, deblock=True)
     ref_pic = P.DevicePicture.__new__(P.DevicePicture)
     ref_pic.__dict__.update(pics[0].__dict__)
     ref_pic.t = pics[0].t.clone()                    # the reference every rank searches in (starts as frame 0)
@@ -200,10 +204,10 @@ def main():
     # ---- untimed pass: HIP-event time of every stage (events on the stream the kernels are launched on) ----
     ms, sp, rc = pipe.ms, pipe.sp, pipe.rc
     cur = pics[1]
-    names = ["lookahead", "me", "subpel", "recon", "border"]
+    names = ["lookahead", "me", "subpel", "recon", "deblock", "border"]
     acc = {k: [] for k in names}
     for _ in range(5):
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
         lk, lk2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         lk.record()
         pipe.la.run(cur)                          # half-resolution planes + intra cost estimate of the source picture
@@ -226,8 +230,10 @@ def main():
             mv_out = sp.out
         rc.run(cur, ref_pic, pipe.recon, mv_out)
         marks[3].record()
-        S.extend_border(pipe.recon, cur)
+        pipe.db.run(pipe.recon, cur, mv_out, rc.num_sig)      # boundary strengths + vertical / horizontal edge passes
         marks[4].record()
+        S.extend_border(pipe.recon, cur)
+        marks[5].record()
         torch.cuda.synchronize()
         acc["lookahead"].append(lk.elapsed_time(lk2))
         for j, k in enumerate(names[1:]):
@@ -250,7 +256,7 @@ def main():
                                    (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + ('packed' if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
                                     f"sub-pel subme={args.subme} -> " if args.search == "full" else
                                     f"{args.search} search driver (motionEstimate, merange {args.range}, subme {args.subme}, predictor 0) for all 85 PUs/CTU -> ") +
-                                   f"{8 << args.level}x{8 << args.level} prediction + DCT/quant/recon qp {args.qp} -> "
+                                   f"{8 << args.level}x{8 << args.level} prediction + DCT/quant/recon qp {args.qp} -> luma deblocking -> "
                                    f"border extension -> next reference; pipeline throughput, not HEVC encoded fps",
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world}",
                        "ctus_per_frame": ms.nctu, "checksum": csum},

@@ -193,6 +193,32 @@ typedef struct x265hip_me_search_params
 } x265hip_me_search_params;
 int x265hip_me_search(const x265hip_me_search_params* p, void* stream);
 
+/* ---- in-loop deblocking of a device-resident luma reconstruction (deblocking half) ----
+ * x265hip_deblock_bs_inter = Deblock::getBoundaryStrength (deblock.cpp:191-215) for a P picture with one reference cut into
+ *   square inter blocks of 8 << level samples: inputs are the sub-pel stage's mv array (int32 [ctu*85][2], z-order) and the
+ *   reconstruction stage's num_sig (uint32 [ctu][blocks]); outputs bs_ver uint8 [height/4][width/8] (4-row unit u of the
+ *   vertical edge at x = 8 * ex) and bs_hor uint8 [height/8][width/4].  Picture borders get Bs 0.
+ * x265hip_deblock_luma = Deblock::edgeFilterLuma (deblock.cpp:317-415) over the whole picture, vertical edges then horizontal
+ *   edges, in place: rec = pixel (0,0).  Any Bs maps may be supplied (Bs 2 = intra edges).  qp_map (int8 [height/8][width/8])
+ *   overrides the uniform qp; the offsets are the PPS's deblockingFilter{Beta,Tc}OffsetDiv2. */
+typedef struct x265hip_deblock_bs_params
+{
+    int width, height, level;
+    const int32_t* mv; const uint32_t* num_sig;
+    uint8_t* bs_ver; uint8_t* bs_hor;
+} x265hip_deblock_bs_params;
+int x265hip_deblock_bs_inter(const x265hip_deblock_bs_params* p, void* stream);
+typedef struct x265hip_deblock_params
+{
+    int depth;
+    void* rec; intptr_t stride;
+    int width, height;
+    const uint8_t* bs_ver; const uint8_t* bs_hor;
+    int qp; const int8_t* qp_map;
+    int beta_offset_div2, tc_offset_div2;
+} x265hip_deblock_params;
+int x265hip_deblock_luma(const x265hip_deblock_params* p, void* stream);
+
 /* ---- lookahead picture preparation and intra cost estimate (the intra half) ----
  * x265hip_lowres_init = Lowres::init's pixel work (lowres.cpp:294-306): frameInitLowres (pixel.cpp:604-629) into the four
  *   half-resolution planes (full-pel, H, V, HV phase) followed by extendPicBorder of each.  `src` = pixel (0,0) of the padded

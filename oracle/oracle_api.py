@@ -145,3 +145,29 @@ def motion_estimate(depth, fenc, fref, stride, org, method, subme, merange, cost
     if rc:
         raise RuntimeError("x265oracle_motion_estimate: unsupported method or PU size")
     return out
+
+
+def deblock_bs_inter(depth, width, height, level, mv, num_sig, avx2=False):
+    """CPU restatement of getBoundaryStrength for a picture of square inter blocks.  Returns (bs_ver, bs_hor)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_deblock_bs_inter_d{depth}")
+    bv = np.zeros((height // 4) * (width // 8), np.uint8)
+    bh = np.zeros((height // 8) * (width // 4), np.uint8)
+    m = np.ascontiguousarray(mv, dtype=np.int32)
+    ns = np.ascontiguousarray(num_sig, dtype=np.uint32)
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    fn(width, height, level, m.ctypes.data, ns.ctypes.data, bv.ctypes.data, bh.ctypes.data)
+    return bv, bh
+
+
+def deblock_luma(depth, rec, stride, org, width, height, bs_ver, bs_hor, qp, qp_map=None, beta_offset_div2=0, tc_offset_div2=0, avx2=False):
+    """CPU restatement of edgeFilterLuma over a picture; returns the filtered copy of `rec` (padded plane)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_deblock_luma_d{depth}")
+    out = rec.copy()
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    qm = np.ascontiguousarray(qp_map, dtype=np.int8) if qp_map is not None else None
+    fn(out.ctypes.data + org * out.itemsize, stride, width, height, bs_ver.ctypes.data, bs_hor.ctypes.data, qp,
+       qm.ctypes.data if qm is not None else None, beta_offset_div2, tc_offset_div2)
+    return out

@@ -1,0 +1,151 @@
+/* oracle/x265_oracle_pipeline4.c
+ *
+ * TEST INFRASTRUCTURE - NOT PRODUCT CODE (same rules as x265_oracle.c).
+ *
+ * Stage: in-loop deblocking of the luma reconstruction (deblocking half).
+ * Restates, on top of the oracle's primitive table,
+ *   Deblock::getBoundaryStrength for P pictures with one reference (source/common/deblock.cpp:191-215: Bs 1 when either side
+ *     has coded luma coefficients on a transform edge or the motion vectors differ by >= 4 quarter-pels in x or y, else 0;
+ *     picture borders are not filtered, :46-70) for a picture cut into square inter blocks of one size, and
+ *   Deblock::edgeFilterLuma (:317-415): per 4-sample edge unit beta / tc from the average QP (tables :499-509), the dE /
+ *     strong-filter decisions (calcDP / calcDQ / useStrongFiltering :249-265), primitives.pelFilterLumaStrong
+ *     (loopfilter.cpp:140-159) or the normal filter pelFilterLuma (:278-315);
+ *   all vertical edges of the picture, then all horizontal edges (deblockCTU order, framefilter.cpp; edges of one direction
+ *   do not interact: they lie 8 samples apart and a filter changes at most 3 samples per side).
+ */
+#ifndef X265HIP_DEPTH
+#error "compile with -DX265HIP_DEPTH=8|10|12"
+#endif
+#include "x265hip_table.h"
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef x265hip_pixel pixel;
+#define DEPTH        X265HIP_DEPTH
+#define CAT_(a, b)   a##b
+#define CAT(a, b)    CAT_(a, b)
+#define EXPORT(name) CAT(CAT(name, _d), X265HIP_DEPTH)
+
+void EXPORT(x265oracle_setup_primitives)(x265hip_EncoderPrimitives* p);
+
+static const uint8_t kTc[54] = {            /* H.265 table 8-12 (deblock.cpp:499-503) */
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2,
+    2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
+static const uint8_t kBeta[52] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17,
+    18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64 };
+
+static int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+static pixel clip_px(int v) { return (pixel)clip3(0, (1 << DEPTH) - 1, v); }
+static int iabs(int v) { return v < 0 ? -v : v; }
+
+/* Bs maps of a picture made of n x n inter blocks (n = 8 << level), z-order inside each 64x64 CTU like the other stages:
+ * mv = int32 [ctu*85][2] {cost, qx | qy << 16}, numSig = uint32 [ctu][npu].
+ * bsVer: uint8 [height/4][width/8] (unit r of the vertical edge at x = 8 * ex), bsHor: uint8 [height/8][width/4]. */
+void EXPORT(x265oracle_deblock_bs_inter)(int width, int height, int level, const int32_t* mv, const uint32_t* numSig,
+                                         uint8_t* bsVer, uint8_t* bsHor)
+{
+    const int n = 8 << level, npu = (64 / n) * (64 / n), ctusW = width / 64;
+    const int lbase = level == 0 ? 0 : (level == 1 ? 64 : (level == 2 ? 80 : 84));
+    memset(bsVer, 0, (size_t)(height / 4) * (width / 8));
+    memset(bsHor, 0, (size_t)(height / 8) * (width / 4));
+#define BLK(X, Y, MVX, MVY, CBF) do { \
+        const int ctu_ = ((Y) / 64) * ctusW + (X) / 64, bx_ = ((X) & 63) / n, by_ = ((Y) & 63) / n; \
+        int z_ = 0; for (int b_ = 0; b_ < 3; b_++) z_ |= (((bx_ >> b_) & 1) << (2 * b_)) | (((by_ >> b_) & 1) << (2 * b_ + 1)); \
+        const int32_t pk_ = mv[((size_t)ctu_ * 85 + lbase + z_) * 2 + 1]; \
+        MVX = (int16_t)(pk_ & 0xffff); MVY = (int16_t)(pk_ >> 16); CBF = numSig[(size_t)ctu_ * npu + z_] != 0; } while (0)
+    for (int y = 0; y < height; y += 4)
+        for (int x = n; x < width; x += n)            /* vertical block edges; x = 0 is the picture border */
+        {
+            int px, py, pc, qx, qy, qc;
+            BLK(x - 1, y, px, py, pc); BLK(x, y, qx, qy, qc);
+            bsVer[(size_t)(y / 4) * (width / 8) + x / 8] = (pc || qc) ? 1 : ((iabs(qx - px) >= 4 || iabs(qy - py) >= 4) ? 1 : 0);
+        }
+    for (int y = n; y < height; y += n)
+        for (int x = 0; x < width; x += 4)
+        {
+            int px, py, pc, qx, qy, qc;
+            BLK(x, y - 1, px, py, pc); BLK(x, y, qx, qy, qc);
+            bsHor[(size_t)(y / 8) * (width / 4) + x / 4] = (pc || qc) ? 1 : ((iabs(qx - px) >= 4 || iabs(qy - py) >= 4) ? 1 : 0);
+        }
+#undef BLK
+}
+
+static void filter_unit(const x265hip_EncoderPrimitives* prim, pixel* src, intptr_t srcStep, intptr_t offset, int dir, int bs, int qp,
+                        int betaOffset, int tcOffset)
+{
+    const int shift = DEPTH - 8;
+    const int beta = kBeta[clip3(0, 51, qp + betaOffset)] << shift;
+#define DP(S) iabs((int)(S)[-offset * 3] - 2 * (int)(S)[-offset * 2] + (int)(S)[-offset])
+#define DQ(S) iabs((int)(S)[0] - 2 * (int)(S)[offset] + (int)(S)[offset * 2])
+    const int dp0 = DP(src), dq0 = DQ(src), dp3 = DP(src + srcStep * 3), dq3 = DQ(src + srcStep * 3);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3, d = d0 + d3;
+    if (d >= beta) return;
+    const int tc = kTc[clip3(0, 53, qp + 2 * (bs - 1) + tcOffset)] << shift;
+#define STRONG(S) (iabs((int)(S)[-offset * 4] - (int)(S)[-offset]) + iabs((int)(S)[offset * 3] - (int)(S)[0]) < (beta >> 3) && \
+                   iabs((int)(S)[-offset] - (int)(S)[0]) < ((tc * 5 + 1) >> 1))
+    const int sw = 2 * d0 < (beta >> 2) && 2 * d3 < (beta >> 2) && STRONG(src) && STRONG(src + srcStep * 3);
+    if (sw)
+    {
+        prim->pelFilterLumaStrong[dir](src, srcStep, offset, 2 * tc, 2 * tc);
+        return;
+    }
+    const int sideThreshold = (beta + (beta >> 1)) >> 3;
+    const int maskP1 = (dp0 + dp3) < sideThreshold, maskQ1 = (dq0 + dq3) < sideThreshold;
+    const int thrCut = tc * 10, tc2 = tc >> 1;
+    for (int i = 0; i < 4; i++, src += srcStep)
+    {
+        const int m4 = src[0], m3 = src[-offset], m5 = src[offset], m2 = src[-offset * 2];
+        int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+        if (iabs(delta) < thrCut)
+        {
+            delta = clip3(-tc, tc, delta);
+            src[-offset] = clip_px(m3 + delta);
+            src[0] = clip_px(m4 - delta);
+            if (maskP1)
+            {
+                const int m1 = src[-offset * 3];
+                src[-offset * 2] = clip_px(m2 + clip3(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)));
+            }
+            if (maskQ1)
+            {
+                const int m6 = src[offset * 2];
+                src[offset] = clip_px(m5 + clip3(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)));
+            }
+        }
+    }
+#undef DP
+#undef DQ
+#undef STRONG
+}
+
+/* rec: pixel (0,0) of the reconstruction (filtered in place).  qpMap: optional int8 [height/8][width/8] (QP of every 8x8 block;
+ * the unit's QP is the rounded mean of its two sides), else the uniform `qp`. */
+void EXPORT(x265oracle_deblock_luma)(pixel* rec, intptr_t stride, int width, int height, const uint8_t* bsVer, const uint8_t* bsHor,
+                                     int qp, const int8_t* qpMap, int betaOffsetDiv2, int tcOffsetDiv2)
+{
+    static x265hip_EncoderPrimitives prim;
+    static int ready = 0;
+    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    const int bo = betaOffsetDiv2 * 2, to = tcOffsetDiv2 * 2, w8 = width / 8;
+    for (int ex = 1; ex < width / 8; ex++)                 /* EDGE_VER: offset 1, srcStep stride */
+        for (int u = 0; u < height / 4; u++)
+        {
+            const int bs = bsVer[(size_t)u * (width / 8) + ex];
+            if (!bs) continue;
+            const int by = (u * 4) / 8;
+            const int q = qpMap ? (qpMap[by * w8 + ex - 1] + qpMap[by * w8 + ex] + 1) >> 1 : qp;
+            filter_unit(&prim, rec + (intptr_t)(u * 4) * stride + ex * 8, stride, 1, 0, bs, q, bo, to);
+        }
+    for (int ey = 1; ey < height / 8; ey++)                /* EDGE_HOR: offset stride, srcStep 1 */
+        for (int u = 0; u < width / 4; u++)
+        {
+            const int bs = bsHor[(size_t)ey * (width / 4) + u];
+            if (!bs) continue;
+            const int bx = (u * 4) / 8;
+            const int q = qpMap ? (qpMap[(ey - 1) * w8 + bx] + qpMap[ey * w8 + bx] + 1) >> 1 : qp;
+            filter_unit(&prim, rec + (intptr_t)(ey * 8) * stride + u * 4, 1, stride, 1, bs, q, bo, to);
+        }
+}

@@ -20,15 +20,15 @@ def _oracle():
     return oracle_api
 
 
-@pytest.mark.parametrize("depth", [8, 10])
-def test_closed_loop_three_frames(depth):
+@pytest.mark.parametrize("depth,deblock", [(8, False), (10, False), (8, True), (10, True)])
+def test_closed_loop_three_frames(depth, deblock):
     import torch
     dev = torch.device("cuda:0")
     O = _oracle()
-    R, subme, level, qp = 12, 2, 2, 24 + 12 * (depth == 10)
+    R, subme, level, qp = 12, 2, 2, (30 if deblock else 24) + 12 * (depth == 10)
     clip = F.synth_clip(192, 128, 4, depth=depth, seed=61)
     pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
-    fp = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=R, subme=subme, level=level, qp=qp, want_surf=False)
+    fp = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=R, subme=subme, level=level, qp=qp, want_surf=False, deblock=deblock)
     ref_dev = P.DevicePicture(clip[0][0], dev)             # frame 0 is the first reference as-is
     ref_host = ref_dev.host.copy()
     cost = F.mv_cost_table(R)
@@ -44,6 +44,9 @@ def test_closed_loop_three_frames(depth):
                              0, fp.ms.nctu, best, cq, qoff, subme)
         erec, elev, ens, edist = O.inter_recon(depth, cur.host, cur.stride, cur.org, ref_host, cur.stride, cur.org,
                                                cur.w64, cur.h64, level, mv, qp)
+        if deblock:         # the in-loop filter runs on the reconstruction before it becomes a reference
+            bv, bh = O.deblock_bs_inter(depth, cur.w64, cur.h64, level, mv, ens)
+            erec = O.deblock_luma(depth, erec.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64, bv, bh, qp).reshape(erec.shape)
         inner = erec[F.MARGIN_Y:F.MARGIN_Y + cur.h64, F.MARGIN_X:F.MARGIN_X + cur.w64]
         erec = np.pad(inner, ((F.MARGIN_Y, F.MARGIN_Y), (F.MARGIN_X, F.MARGIN_X)), mode="edge")   # extendPicBorder
         grec = rec.cpu().numpy().view(cur.host.dtype).reshape(cur.host.shape)

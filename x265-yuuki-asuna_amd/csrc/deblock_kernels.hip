@@ -1,0 +1,206 @@
+// deblock_kernels.hip - in-loop deblocking of a device-resident luma reconstruction on gfx950
+// (the deblocking half: the reconstruction stays on the GPU that hands it on as a reference).
+//
+// Reference semantics (source/common/deblock.cpp): Deblock::getBoundaryStrength :191-215 for P pictures with one reference
+// (Bs 1 when either side of a transform edge has coded luma coefficients or the motion vectors differ by >= 4 quarter-pels,
+// else 0; picture borders are not filtered, bsCuEdge :46-70); Deblock::edgeFilterLuma :317-415 - per 4-sample unit of an
+// edge: beta / tc from the mean QP of the two sides (tables :499-509 = H.265 table 8-12), dE and the strong-filter decision
+// (calcDP / calcDQ / useStrongFiltering :249-265), then primitives.pelFilterLumaStrong (loopfilter.cpp:140-159) or the
+// file-static normal filter pelFilterLuma (:278-315).  All vertical edges of the picture are filtered before all horizontal
+// edges; edges of one direction lie 8 samples apart and a filter changes at most 3 samples per side, so a pass is one
+// launch with one thread per 4-sample unit and no ordering inside it.
+#include "common.h"
+
+namespace x265hip {
+
+__constant__ unsigned char kDbTc[54] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2,
+    2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
+__constant__ unsigned char kDbBeta[52] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17,
+    18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64 };
+
+struct BsArgs
+{
+    int width, height, level;
+    const int2* mv; const uint32_t* numSig;
+    uint8_t* bsVer; uint8_t* bsHor;
+};
+
+__device__ __forceinline__ void db_block(const BsArgs& a, int x, int y, int& mvx, int& mvy, int& cbf)
+{
+    const int n = 8 << a.level, npu = 64 >> (2 * a.level), ctusW = a.width >> 6;
+    const int lbase = a.level == 0 ? 0 : (a.level == 1 ? 64 : (a.level == 2 ? 80 : 84));
+    const int ctu = (y >> 6) * ctusW + (x >> 6), bx = (x & 63) / n, by = (y & 63) / n;
+    const int z = (bx & 1) | ((by & 1) << 1) | ((bx & 2) << 1) | ((by & 2) << 2) | ((bx & 4) << 2) | ((by & 4) << 3);
+    const int pk = a.mv[(size_t)ctu * 85 + lbase + z].y;
+    mvx = (int16_t)(pk & 0xffff); mvy = (int16_t)(pk >> 16);
+    cbf = a.numSig[(size_t)ctu * npu + z] != 0;
+}
+
+// one thread per 4-sample unit of the 8x8 edge grid, both directions in one launch (blockIdx.y = direction)
+__global__ void __launch_bounds__(256) deblock_bs_inter_kernel(BsArgs a)
+{
+    const int n = 8 << a.level;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.y == 0)
+    {
+        const int w8 = a.width >> 3, total = (a.height >> 2) * w8;
+        if (i >= total) return;
+        const int u = i / w8, ex = i - u * w8, x = ex * 8, y = u * 4;
+        int bs = 0;
+        if (x > 0 && (x % n) == 0)
+        {
+            int px, py, pc, qx, qy, qc;
+            db_block(a, x - 1, y, px, py, pc); db_block(a, x, y, qx, qy, qc);
+            bs = (pc || qc) ? 1 : ((abs(qx - px) >= 4 || abs(qy - py) >= 4) ? 1 : 0);
+        }
+        a.bsVer[i] = (uint8_t)bs;
+    }
+    else
+    {
+        const int w4 = a.width >> 2, total = (a.height >> 3) * w4;
+        if (i >= total) return;
+        const int ey = i / w4, u = i - ey * w4, x = u * 4, y = ey * 8;
+        int bs = 0;
+        if (y > 0 && (y % n) == 0)
+        {
+            int px, py, pc, qx, qy, qc;
+            db_block(a, x, y - 1, px, py, pc); db_block(a, x, y, qx, qy, qc);
+            bs = (pc || qc) ? 1 : ((abs(qx - px) >= 4 || abs(qy - py) >= 4) ? 1 : 0);
+        }
+        a.bsHor[i] = (uint8_t)bs;
+    }
+}
+
+struct DbArgs
+{
+    uint8_t* rec; long strideB;
+    int width, height, depth;
+    const uint8_t* bs; const int8_t* qpMap;
+    int qp, betaOffset, tcOffset;
+};
+
+// DIR 0: vertical edges (taps along x, 4 rows per unit); DIR 1: horizontal edges (taps along y, 4 columns per unit)
+template <typename Px, int DIR>
+__global__ void __launch_bounds__(256) deblock_luma_kernel(DbArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w8 = a.width >> 3, w4 = a.width >> 2;
+    const int total = DIR == 0 ? (a.height >> 2) * w8 : (a.height >> 3) * w4;
+    if (i >= total) return;
+    const int bs = a.bs[i];
+    if (!bs) return;
+    const long st = a.strideB / (long)sizeof(Px);
+    int x, y, qp = a.qp;
+    if (DIR == 0)
+    {
+        const int u = i / w8, ex = i - u * w8;
+        x = ex * 8; y = u * 4;
+        if (a.qpMap) qp = (a.qpMap[(y >> 3) * w8 + ex - 1] + a.qpMap[(y >> 3) * w8 + ex] + 1) >> 1;
+    }
+    else
+    {
+        const int ey = i / w4, u = i - ey * w4;
+        x = u * 4; y = ey * 8;
+        if (a.qpMap) qp = (a.qpMap[(ey - 1) * w8 + (x >> 3)] + a.qpMap[ey * w8 + (x >> 3)] + 1) >> 1;
+    }
+    Px* src = reinterpret_cast<Px*>(a.rec) + (long)y * st + x;
+    const long offset = DIR == 0 ? 1 : st, srcStep = DIR == 0 ? st : 1;
+    const int shift = a.depth - 8, maxVal = (1 << a.depth) - 1;
+    // the unit's 4 lines x 8 taps
+    int m[4][8];
+#pragma unroll
+    for (int l = 0; l < 4; l++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) m[l][t] = src[l * srcStep + (t - 4) * offset];
+    const int beta = (int)kDbBeta[clip3(0, 51, qp + a.betaOffset)] << shift;
+    auto dP = [&](int l) { return abs(m[l][1] - 2 * m[l][2] + m[l][3]); };
+    auto dQ = [&](int l) { return abs(m[l][4] - 2 * m[l][5] + m[l][6]); };
+    const int dp0 = dP(0), dq0 = dQ(0), dp3 = dP(3), dq3 = dQ(3);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    if (d0 + d3 >= beta) return;
+    const int tc = (int)kDbTc[clip3(0, 53, qp + 2 * (bs - 1) + a.tcOffset)] << shift;
+    auto strongLine = [&](int l) { return abs(m[l][0] - m[l][3]) + abs(m[l][7] - m[l][4]) < (beta >> 3) && abs(m[l][3] - m[l][4]) < ((tc * 5 + 1) >> 1); };
+    const bool sw = 2 * d0 < (beta >> 2) && 2 * d3 < (beta >> 2) && strongLine(0) && strongLine(3);
+    if (sw)
+    {
+        const int t2 = 2 * tc;
+#pragma unroll
+        for (int l = 0; l < 4; l++)
+        {
+            const int m0 = m[l][0], m1 = m[l][1], m2 = m[l][2], m3 = m[l][3], m4 = m[l][4], m5 = m[l][5], m6 = m[l][6], m7 = m[l][7];
+            Px* p = src + l * srcStep;
+            p[-3 * offset] = (Px)(clip3(-t2, t2, ((2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3) - m1) + m1);
+            p[-2 * offset] = (Px)(clip3(-t2, t2, ((m1 + m2 + m3 + m4 + 2) >> 2) - m2) + m2);
+            p[-offset]     = (Px)(clip3(-t2, t2, ((m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3) - m3) + m3);
+            p[0]           = (Px)(clip3(-t2, t2, ((m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3) - m4) + m4);
+            p[offset]      = (Px)(clip3(-t2, t2, ((m3 + m4 + m5 + m6 + 2) >> 2) - m5) + m5);
+            p[2 * offset]  = (Px)(clip3(-t2, t2, ((m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3) - m6) + m6);
+        }
+        return;
+    }
+    const int sideThreshold = (beta + (beta >> 1)) >> 3;
+    const bool maskP1 = dp0 + dp3 < sideThreshold, maskQ1 = dq0 + dq3 < sideThreshold;
+    const int thrCut = tc * 10, tc2 = tc >> 1;
+#pragma unroll
+    for (int l = 0; l < 4; l++)
+    {
+        const int m1 = m[l][1], m2 = m[l][2], m3 = m[l][3], m4 = m[l][4], m5 = m[l][5], m6 = m[l][6];
+        int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+        if (abs(delta) >= thrCut) continue;
+        delta = clip3(-tc, tc, delta);
+        Px* p = src + l * srcStep;
+        p[-offset] = (Px)clip3(0, maxVal, m3 + delta);
+        p[0] = (Px)clip3(0, maxVal, m4 - delta);
+        if (maskP1) p[-2 * offset] = (Px)clip3(0, maxVal, m2 + clip3(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)));
+        if (maskQ1) p[offset] = (Px)clip3(0, maxVal, m5 + clip3(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)));
+    }
+}
+
+} // namespace x265hip
+
+using namespace x265hip;
+
+extern "C" int x265hip_deblock_bs_inter(const x265hip_deblock_bs_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->mv || !p->num_sig || !p->bs_ver || !p->bs_hor) { set_error("deblock_bs_inter: NULL operand"); return X265HIP_EINVAL; }
+    if ((p->width & 63) || (p->height & 63) || p->width <= 0 || p->height <= 0) { set_error("deblock_bs_inter: width/height must be multiples of 64"); return X265HIP_EINVAL; }
+    if (p->level < 0 || p->level > 3) { set_error("deblock_bs_inter: level %d", p->level); return X265HIP_EINVAL; }
+    BsArgs a;
+    a.width = p->width; a.height = p->height; a.level = p->level;
+    a.mv = (const int2*)p->mv; a.numSig = p->num_sig; a.bsVer = p->bs_ver; a.bsHor = p->bs_hor;
+    const int nv = (p->height >> 2) * (p->width >> 3), nh = (p->height >> 3) * (p->width >> 2);
+    const int n = nv > nh ? nv : nh;
+    hipLaunchKernelGGL(deblock_bs_inter_kernel, dim3((n + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x265hip_deblock_luma(const x265hip_deblock_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->rec || !p->bs_ver || !p->bs_hor) { set_error("deblock_luma: NULL operand"); return X265HIP_EINVAL; }
+    if ((p->width & 7) || (p->height & 7) || p->width <= 0 || p->height <= 0) { set_error("deblock_luma: width/height must be multiples of 8"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("deblock_luma: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->beta_offset_div2 < -6 || p->beta_offset_div2 > 6 || p->tc_offset_div2 < -6 || p->tc_offset_div2 > 6)
+    { set_error("deblock_luma: beta / tc offsets out of [-6, 6]"); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    DbArgs a;
+    a.rec = (uint8_t*)p->rec; a.strideB = (long)p->stride * bpp;
+    a.width = p->width; a.height = p->height; a.depth = p->depth;
+    a.qpMap = p->qp_map; a.qp = p->qp; a.betaOffset = p->beta_offset_div2 * 2; a.tcOffset = p->tc_offset_div2 * 2;
+    hipStream_t s = (hipStream_t)stream;
+    const int nv = (p->height >> 2) * (p->width >> 3), nh = (p->height >> 3) * (p->width >> 2);
+    a.bs = p->bs_ver;
+    if (bpp == 1) hipLaunchKernelGGL((deblock_luma_kernel<uint8_t, 0>), dim3((nv + 255) / 256), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((deblock_luma_kernel<uint16_t, 0>), dim3((nv + 255) / 256), dim3(256), 0, s, a);
+    a.bs = p->bs_hor;
+    if (bpp == 1) hipLaunchKernelGGL((deblock_luma_kernel<uint8_t, 1>), dim3((nh + 255) / 256), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((deblock_luma_kernel<uint16_t, 1>), dim3((nh + 255) / 256), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}

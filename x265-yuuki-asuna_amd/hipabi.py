@@ -80,6 +80,17 @@ def me_search_job_dtype():
     return np.dtype([(n, "<i4") for n in ("px", "py", "w", "h", "qmvpx", "qmvpy", "out_qmvx", "out_qmvy", "out_cost")])
 
 
+class DeblockBsParams(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int), ("height", ctypes.c_int), ("level", ctypes.c_int),
+                ("mv", ctypes.c_void_p), ("num_sig", ctypes.c_void_p), ("bs_ver", ctypes.c_void_p), ("bs_hor", ctypes.c_void_p)]
+
+
+class DeblockParams(ctypes.Structure):
+    _fields_ = [("depth", ctypes.c_int), ("rec", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),
+                ("width", ctypes.c_int), ("height", ctypes.c_int), ("bs_ver", ctypes.c_void_p), ("bs_hor", ctypes.c_void_p),
+                ("qp", ctypes.c_int), ("qp_map", ctypes.c_void_p), ("beta_offset_div2", ctypes.c_int), ("tc_offset_div2", ctypes.c_int)]
+
+
 def lib() -> ctypes.CDLL:
     """Load libx265hip.so (built in-tree by __graft_entry__.build()); fail loudly if absent."""
     global _lib
@@ -199,6 +210,28 @@ def me_search(depth, fenc, fenc_stride, fenc_off, fref, fref_stride, fref_off, m
     f = lib().x265hip_me_search
     f.argtypes = [ctypes.POINTER(MESearchParams), ctypes.c_void_p]
     check(f(ctypes.byref(p), s), "x265hip_me_search")
+
+
+def deblock_bs_inter(width, height, level, mv, num_sig, bs_ver, bs_hor, stream=None):
+    p = DeblockBsParams()
+    p.width, p.height, p.level = width, height, level
+    p.mv, p.num_sig, p.bs_ver, p.bs_hor = mv.data_ptr(), num_sig.data_ptr(), bs_ver.data_ptr(), bs_hor.data_ptr()
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_deblock_bs_inter
+    f.argtypes = [ctypes.POINTER(DeblockBsParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_deblock_bs_inter")
+
+
+def deblock_luma(depth, rec, stride, org, width, height, bs_ver, bs_hor, qp, qp_map=None, beta_offset_div2=0, tc_offset_div2=0, stream=None):
+    es = 1 if depth == 8 else 2
+    p = DeblockParams()
+    p.depth, p.rec, p.stride, p.width, p.height = depth, rec.data_ptr() + org * es, stride, width, height
+    p.bs_ver, p.bs_hor, p.qp, p.qp_map = bs_ver.data_ptr(), bs_hor.data_ptr(), qp, _p(qp_map)
+    p.beta_offset_div2, p.tc_offset_div2 = beta_offset_div2, tc_offset_div2
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_deblock_luma
+    f.argtypes = [ctypes.POINTER(DeblockParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_deblock_luma")
 
 
 def me_best_reset(best, stream=None):

@@ -72,6 +72,21 @@ def extend_border(plane, pic: DevicePicture, stream=None):
                  "x265hip_extend_border")
 
 
+class Deblock:
+    """In-loop deblocking of the luma reconstruction on device (x265hip_deblock_bs_inter + x265hip_deblock_luma; reference
+    Deblock::getBoundaryStrength / edgeFilterLuma, deblock.cpp:191-215, 317-415) for the reconstruction stage's block grid."""
+
+    def __init__(self, w64, h64, depth, level, qp, device):
+        import torch
+        self.w64, self.h64, self.depth, self.level, self.qp = w64, h64, depth, level, qp
+        self.bs_ver = torch.zeros((h64 // 4) * (w64 // 8), dtype=torch.uint8, device=device)
+        self.bs_hor = torch.zeros((h64 // 8) * (w64 // 4), dtype=torch.uint8, device=device)
+
+    def run(self, plane, pic: DevicePicture, mv, num_sig):
+        hipabi.deblock_bs_inter(self.w64, self.h64, self.level, mv, num_sig, self.bs_ver, self.bs_hor)
+        hipabi.deblock_luma(self.depth, plane, pic.stride, pic.org, self.w64, self.h64, self.bs_ver, self.bs_hor, self.qp)
+
+
 class Lookahead:
     """Lookahead picture preparation + intra cost estimate on device (x265hip_lowres_init / x265hip_lowres_intra; reference
     Lowres::init lowres.cpp:294-306 and LookaheadTLD::lowresIntraEstimate slicetype.cpp:696-772).  Geometry follows
@@ -154,7 +169,7 @@ class FramePipeline:
     cost estimate per 8x8 block), which only depends on the source."""
 
     def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False, lookahead=None,
-                 search="full"):
+                 search="full", deblock=False):
         import torch
         from .pipeline import MotionSearch, SubpelRefine
         self.depth = depth
@@ -167,6 +182,7 @@ class FramePipeline:
             self.ps = PatternSearch(w64, h64, depth, method, subme, rng, device)
         self.rc = InterRecon(self.ms.nctu, w64, h64, depth, level, qp, device)
         self.la = Lookahead(lookahead[0], lookahead[1], depth, device) if lookahead else None
+        self.db = Deblock(w64, h64, depth, level, qp, device) if deblock else None
         self.recon = None
 
     def run(self, cur: DevicePicture, ref: DevicePicture):
@@ -184,6 +200,8 @@ class FramePipeline:
             self.sp.run(cur, ref)
             mv = self.sp.out
         self.rc.run(cur, ref, self.recon, mv)
+        if self.db is not None:
+            self.db.run(self.recon, cur, mv, self.rc.num_sig)
         extend_border(self.recon, cur)
         return self.recon
 
