@@ -254,6 +254,24 @@ int x265hip_lowres_intra(const x265hip_lowres_intra_params* p, void* stream);
 typedef struct x265hip_plane { void* base; intptr_t stride; } x265hip_plane;
 typedef struct x265hip_job { int64_t off[4]; int32_t arg[4]; } x265hip_job;
 
+/* Intra TU candidate set - the pixel work of Search::codeIntraLumaQT for a list of (TU, mode) candidates
+ * (encoder/search.cpp:335-373): Predict::predIntraLumaAng (predict.cpp:579-588), calcresidual, Quant::transformNxN (non-RDOQ,
+ * flat scaling; DST-VII for the 4x4 luma TU), Quant::invtransformNxN, add_ps / copy_pp, sse_pp.  One job per candidate:
+ *   off[0] source block (elements into fenc), off[1] unfiltered / off[2] filtered neighbour arrays ([0] corner, [1..2n] above,
+ *   [2n+1..4n] left; elements into nb), off[3] the candidate's reconstruction block (elements into recon); arg[0] = mode 0..34.
+ * Outputs per job: levels int16 [n*n], num_sig, dist (SSE source vs reconstruction).  Bit costs stay with the host. */
+typedef struct x265hip_intra_recon_params
+{
+    int depth, n;
+    const void* fenc;  intptr_t fenc_stride;
+    const void* nb;
+    void* recon;       intptr_t recon_stride;
+    int qp, intra_slice;
+    const x265hip_job* jobs;  int njobs;
+    int16_t* levels; uint32_t* num_sig; uint64_t* dist;
+} x265hip_intra_recon_params;
+int x265hip_intra_recon_batch(const x265hip_intra_recon_params* p, void* stream);
+
 /* Sub-pel interpolation (reference ipfilter.cpp:79-369; taps constants.cpp:250-268).
  * taps = 8 (luma, coeffIdx 0..3) or 4 (chroma, 0..7).  src = plane 0 (off[0]), dst = plane 1 (off[1]).
  *   HPP/VPP: pixel->pixel  arg[0]=coeffIdx            HPS: pixel->int16 arg[0]=coeffIdx arg[1]=isRowExt

@@ -171,3 +171,23 @@ def deblock_luma(depth, rec, stride, org, width, height, bs_ver, bs_hor, qp, qp_
     fn(out.ctypes.data + org * out.itemsize, stride, width, height, bs_ver.ctypes.data, bs_hor.ctypes.data, qp,
        qm.ctypes.data if qm is not None else None, beta_offset_div2, tc_offset_div2)
     return out
+
+
+def intra_recon(depth, n, fenc, fenc_stride, nb, recon_len, recon_stride, qp, intra_slice, jobs, nthreads=0, avx2=False):
+    """CPU restatement of the intra TU candidate set (search.cpp:335-373 through the oracle primitives).
+    jobs: numpy records {off[4], arg[4]}.  Returns (recon flat array, levels, num_sig, dist)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_intra_recon_d{depth}")
+    njobs = len(jobs)
+    recon = np.zeros(recon_len, dtype=fenc.dtype)
+    levels = np.zeros(njobs * n * n, dtype=np.int16)
+    num_sig = np.zeros(njobs, dtype=np.uint32)
+    dist = np.zeros(njobs, dtype=np.uint64)
+    j = np.ascontiguousarray(jobs)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    rc = fn(fenc.ctypes.data, fenc_stride, nb.ctypes.data, recon.ctypes.data, recon_stride, n, qp, intra_slice,
+            j.ctypes.data, njobs, levels.ctypes.data, num_sig.ctypes.data, dist.ctypes.data, nthreads)
+    assert rc == 0
+    return recon, levels, num_sig, dist

@@ -121,3 +121,81 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
     }
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Intra TU candidate set: the pixel work of Search::codeIntraLumaQT for one (TU, mode) candidate
+ * (source/encoder/search.cpp:335-373): Predict::predIntraLumaAng (predict.cpp:579-588: filtered neighbours per
+ * g_intraFilterFlags & size, edge filter for sizes <= 16), calcresidual, Quant::transformNxN (DST for the 4x4 luma
+ * intra TU, quant.cpp:426-431), Quant::invtransformNxN (no DC shortcut under DST, quant.cpp:583-603), add_ps / copy_pp
+ * into the candidate's reconstruction, sse_pp.  Bit costs (CABAC) stay with the host.
+ * jobs: { off[0] fenc block, off[1] unfiltered neighbours, off[2] filtered neighbours, off[3] reconstruction block;
+ *         arg[0] intra mode 0..34 } with element offsets into fenc / nb / recon. */
+typedef struct { int64_t off[4]; int32_t arg[4]; } intra_job;
+static const uint8_t kIntraFilterFlags[35] = {
+    0x38, 0x00,
+    0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30,
+    0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30,
+    0x38 };
+
+int EXPORT(x265oracle_intra_recon)(const pixel* fenc, intptr_t fencStride, const pixel* nb, pixel* recon, intptr_t reconStride,
+                                   int n, int qp, int isIntraSlice, const intra_job* jobs, int njobs,
+                                   int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads)
+{
+    static x265hip_EncoderPrimitives prim;
+    static int ready = 0;
+    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    const int log2n = n == 4 ? 2 : (n == 8 ? 3 : (n == 16 ? 4 : 5));
+    if ((1 << log2n) != n) return -1;
+    const struct x265hip_CU* cu = &prim.cu[log2n - 2];
+    const int useDST = n == 4;
+    const int per = qp / 6, rem = qp % 6;
+    const int transformShift = 15 - X265HIP_DEPTH - log2n;
+    const int qbits = 14 + per + transformShift;
+    const int add = (isIntraSlice ? 171 : 85) << (qbits - 9);
+    const int dqShift = 20 - 14 - transformShift;
+    const int dqScale = kInvQuantScales[rem] << per;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 16)
+#endif
+    for (int j = 0; j < njobs; j++)
+    {
+        pixel pred[32 * 32] __attribute__((aligned(64)));
+        int16_t resi[32 * 32] __attribute__((aligned(64)));
+        int16_t coef[32 * 32] __attribute__((aligned(64)));
+        int32_t quantCoeff[32 * 32] __attribute__((aligned(64)));
+        int32_t deltaU[32 * 32];
+        for (int i = 0; i < n * n; i++) quantCoeff[i] = kQuantScales[rem];
+        const intra_job* jb = &jobs[j];
+        const int mode = jb->arg[0];
+        const pixel* fe = fenc + jb->off[0];
+        pixel* rec = recon + jb->off[3];
+        const int filter = !!(kIntraFilterFlags[mode] & n);
+        cu->intra_pred[mode](pred, n, nb + (filter ? jb->off[2] : jb->off[1]), mode, log2n <= 4);
+        /* calcresidual assumes one stride for fenc / pred / residual (search.cpp:357); restate it for separate strides */
+        for (int y = 0; y < n; y++)
+            for (int x = 0; x < n; x++) resi[y * n + x] = (int16_t)((int)fe[y * fencStride + x] - (int)pred[y * n + x]);
+        if (useDST) prim.dst4x4(resi, coef, n);
+        else cu->dct(resi, coef, n);
+        int16_t* q = levels + (size_t)j * n * n;
+        const uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
+        numSigOut[j] = numSig;
+        if (numSig)
+        {
+            prim.dequant_normal(q, coef, n * n, dqScale, dqShift);
+            if (numSig == 1 && q[0] != 0 && !useDST)
+            {
+                const int shift_2nd = 12 - (X265HIP_DEPTH - 8) - 3;
+                const int dc = ((((coef[0] * (64 >> 6) + 1) >> 1) * (64 >> 3)) + (1 << (shift_2nd - 1))) >> shift_2nd;
+                cu->blockfill_s[0](resi, n, (int16_t)dc);
+            }
+            else if (useDST) prim.idst4x4(coef, resi, n);
+            else cu->idct(coef, resi, n);
+            cu->add_ps[0](rec, reconStride, pred, resi, n, n);
+        }
+        else
+            cu->copy_pp(rec, reconStride, pred, n);
+        distOut[j] = (uint64_t)cu->sse_pp(rec, reconStride, fe, fencStride);
+    }
+    return 0;
+}

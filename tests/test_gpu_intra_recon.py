@@ -1,0 +1,94 @@
+"""GPU parity: the intra TU candidate set (x265hip_intra_recon_batch) vs the oracle's restatement of Search::codeIntraLumaQT's
+pixel work (search.cpp:335-373: predIntraLumaAng, calcresidual, transformNxN / DST-VII for 4x4, invtransformNxN, add_ps / copy_pp,
+sse_pp) driven through the oracle primitives."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+H = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_api
+    return oracle_api
+
+
+def _smooth(a):
+    """[1 2 1] smoothing along the left-bottom .. corner .. above-right path (any filtered contents exercise the stage the same
+    way; the filter primitive has its own parity test)."""
+    n4 = len(a) - 1
+    n2 = n4 // 2
+    path = np.concatenate([a[n4:n2:-1], a[0:1], a[1:n2 + 1]]).astype(np.int32)
+    f = path.copy()
+    f[1:-1] = (path[:-2] + 2 * path[1:-1] + path[2:] + 2) >> 2
+    out = a.copy()
+    out[n4:n2:-1] = f[:n2]
+    out[0] = f[n2]
+    out[1:n2 + 1] = f[n2 + 1:]
+    return out
+
+
+@pytest.mark.parametrize("depth,n,qp,islice", [(8, 4, 22, 1), (8, 8, 27, 1), (8, 16, 32, 0), (8, 32, 22, 1), (8, 32, 44, 0),
+                                               (10, 4, 30, 0), (10, 8, 12, 1), (10, 16, 24, 1), (10, 32, 37, 1), (8, 16, 0, 1)])
+def test_intra_recon_matches_oracle(depth, n, qp, islice):
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng([61, depth, n, qp])
+    dt = np.uint8 if depth == 8 else np.uint16
+    pmax = (1 << depth) - 1
+    ntu = 24
+    # source: smooth texture + noise so that some candidates quantise to nothing, some to DC only, most to many levels
+    W = n * ntu
+    yy, xx = np.mgrid[0:n, 0:W]
+    src = np.clip(np.rint((0.5 + 0.35 * np.sin(xx / 9.0) * np.cos(yy / 5.0)) * pmax + rng.normal(0, 3.0 * (1 << (depth - 8)), (n, W))), 0, pmax).astype(dt)
+    src[:, :n] = src[0, 0]                                      # a flat TU: DC / empty residuals
+    fenc_stride = W + 16
+    fenc = np.zeros((n, fenc_stride), dtype=dt)
+    fenc[:, :W] = src
+    nbw = 4 * n + 1
+    nb = np.zeros((ntu, 2, nbw + 3), dtype=dt)                  # odd record size: unaligned neighbour rows
+    for t in range(ntu):
+        base = int(src[:, t * n:(t + 1) * n].mean())
+        a = np.clip(base + rng.integers(-12 << (depth - 8), 13 << (depth - 8), nbw), 0, pmax).astype(dt)
+        if t == 0:
+            a[:] = src[0, 0]
+        nb[t, 0, :nbw] = a
+        nb[t, 1, :nbw] = _smooth(a)
+    jobs = np.zeros(ntu * 35, dtype=H.job_dtype())
+    recon_stride = n + 5
+    for t in range(ntu):
+        for m in range(35):
+            j = t * 35 + m
+            jobs["off"][j] = (t * n, (t * 2) * (nbw + 3), (t * 2 + 1) * (nbw + 3), j * n * recon_stride)
+            jobs["arg"][j, 0] = m
+    njobs = len(jobs)
+    recon_len = njobs * n * recon_stride
+    O = _oracle()
+    erec, elev, ens, edist = O.intra_recon(depth, n, fenc.reshape(-1), fenc_stride, nb.reshape(-1), recon_len, recon_stride, qp, islice, jobs)
+
+    d_fenc = torch.from_numpy(fenc.reshape(-1).view(np.uint8)).to(dev)
+    d_nb = torch.from_numpy(nb.reshape(-1).view(np.uint8)).to(dev)
+    d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(dev)
+    d_rec = torch.zeros(recon_len * dt().itemsize, dtype=torch.uint8, device=dev)
+    d_lev = torch.full((njobs * n * n,), 0x5a5a, dtype=torch.int16, device=dev)
+    d_ns = torch.zeros(njobs, dtype=torch.int32, device=dev)
+    d_dist = torch.zeros(njobs, dtype=torch.int64, device=dev)
+    H.intra_recon_batch(depth, n, d_fenc, fenc_stride, d_nb, d_rec, recon_stride, qp, islice, d_jobs, njobs, d_lev, d_ns, d_dist)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ns.cpu().numpy().view(np.uint32), ens), "numSig differs"
+    assert np.array_equal(d_lev.cpu().numpy(), elev), "quantised levels differ"
+    grec = d_rec.cpu().numpy().view(dt)
+    # only the n x n block of each candidate is defined (the row padding of recon_stride stays untouched on both sides)
+    assert np.array_equal(grec, erec), f"recon differs at {np.count_nonzero(grec != erec)} samples"
+    assert np.array_equal(d_dist.cpu().numpy().view(np.uint64), edist), "SSE differs"
+    # every branch of the inverse path must be hit somewhere in the case set
+    if qp in (22, 27, 12):
+        assert (ens > 1).any()
+    if qp == 44:
+        assert (ens == 0).any()

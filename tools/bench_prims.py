@@ -133,7 +133,7 @@ def main():
     import argparse
     import torch
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="", help="comma-separated families to run: compare,interp,transform,quant,intra,blockop,loopfilter")
+    ap.add_argument("--only", default="", help="comma-separated families to run: compare,interp,transform,quant,intra,intratu,blockop,loopfilter")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU columns (profiling runs)")
     args = ap.parse_args()
     want = set(x for x in args.only.split(",") if x)
@@ -224,7 +224,7 @@ def main():
                        SIG_DCT, [(src_h, n_), (dst_h, n_)], jb, extra)
 
     # ---- a8: quant family, 32x32 ----
-    if not (on("quant") or on("intra") or on("blockop") or on("loopfilter")):
+    if not (on("quant") or on("intra") or on("intratu") or on("blockop") or on("loopfilter")):
         return
     nb, n2 = 1 << 15, 1024
     coef_h = rng.integers(-255, 256, size=nb * n2, dtype=np.int16)
@@ -261,6 +261,39 @@ def main():
         # one CPU job list per mode class is not needed: slot [mode] differs, time the angular slot 10 on all jobs
         report(cpu, f"intra_pred {n_}x{n_} (35 modes/TU)", ntu * 35, t, 4 * n_ + 1 + n_ * n_, f"cu[{int(np.log2(n_)) - 2}].intra_pred[10]",
                SIG_INTRA_PRED, [(nb_h, 0), (dst_h, n_)], jb_cpu, "CPU column: the angular slot on every job")
+
+    # ---- (f)-2: the intra TU candidate set - prediction + residual round trip of every (TU, mode) candidate in one launch ----
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_api as O  # noqa: E402  (bench.py's cpu_baseline leg)
+    import time
+    for n_ in (4, 8, 16, 32) if on("intratu") else ():
+        ntu = {4: 1 << 13, 8: 1 << 12, 16: 1 << 11, 32: 1 << 9}[n_]
+        nbw = 4 * n_ + 1
+        fe_h = rng.integers(0, 256, size=ntu * n_ * n_, dtype=np.uint8)
+        nb_h = np.clip(128 + rng.integers(-20, 21, size=ntu * 2 * nbw), 0, 255).astype(np.uint8)
+        tu = np.repeat(np.arange(ntu, dtype=np.int64), 35)
+        mode = np.tile(np.arange(35, dtype=np.int64), ntu)
+        jb = jobs_np(ntu * 35, (tu * n_ * n_, tu * 2 * nbw, (tu * 2 + 1) * nbw, (tu * 35 + mode) * n_ * n_), (mode,))
+        nj = ntu * 35
+        fe_d, nb_d, jd = to_dev(fe_h, dev), to_dev(nb_h, dev), jobs_dev(jb, dev)
+        rec_d = torch.zeros(nj * n_ * n_, dtype=torch.uint8, device=dev)
+        lev_d = torch.zeros(nj * n_ * n_, dtype=torch.int16, device=dev)
+        ns_d = torch.zeros(nj, dtype=torch.int32, device=dev)
+        di_d = torch.zeros(nj, dtype=torch.int64, device=dev)
+        t = timeit(lambda: A.intra_recon_batch(8, n_, fe_d, n_, nb_d, rec_d, n_, 27, 1, jd, nj, lev_d, ns_d, di_d))
+        bpj = n_ * n_ * 3 + 2 * nbw + 12                 # recon + levels written, neighbours read; the source block is shared by 35 jobs
+        col = f"{'-':>10s}"
+        ratio = f"{'-':>8s}"
+        if cpu.port is not None:
+            samp = min(nj, 35 * 256)
+            O.intra_recon(8, n_, fe_h, n_, nb_h, samp * n_ * n_, n_, 27, 1, jb[:samp], nthreads=cpu.threads, avx2=True)
+            t0 = time.perf_counter()
+            O.intra_recon(8, n_, fe_h, n_, nb_h, samp * n_ * n_, n_, 27, 1, jb[:samp], nthreads=cpu.threads, avx2=True)
+            tc = (time.perf_counter() - t0) * nj / samp
+            col, ratio = f"{nj * bpj / tc / 1e9:10.1f}", f"{tc / t:8.1f}"
+        gbs = nj * bpj / t / 1e9
+        print(f"{f'intra TU candidates {n_}x{n_} (35 modes)':40s} {nj:8d} {t * 1e6:9.1f} {bpj:7d} {gbs:9.1f} {gbs / HBM:6.3f} {'-':>10s} {col} {ratio}  "
+              f"pred+DCT/DST+quant+dequant+IDCT+recon+SSE per job; CPU column = oracle restatement on a {35 * 256}-job sample", flush=True)
 
     # ---- a10: element-wise block ops, 32x32 ----
     nb, w = 1 << 15, 32

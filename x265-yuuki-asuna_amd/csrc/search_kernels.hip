@@ -55,10 +55,11 @@ struct PuEval
 {
     static constexpr int BPP = sizeof(Px);
     static constexpr int DW = BPP;                 // dwords per 4-sample tile row
-    const uint8_t* refOrg[T];                       // reference byte address under each of the lane's tiles (mv 0)
+    const uint8_t* base;                            // wave-uniform: reference plane origin minus kBias bytes
+    uint32_t refOrg[T];                             // byte offset from `base` of the reference under each of the lane's tiles (mv 0)
     uint32_t src[T][4][DW];                         // the lane's source tiles, packed
     bool have[T];
-    long strideB;
+    int strideB;
     int depth;
     const uint16_t* cost;
     int mvpx, mvpy;
@@ -75,12 +76,12 @@ struct PuEval
         for (int k = 0; k < T; k++)
         {
             if (!have[k]) continue;
-            const uint8_t* rp = refOrg[k] + (long)my * strideB + (long)mx * BPP;
+            const uint32_t ro = refOrg[k] + (uint32_t)(my * strideB + mx * BPP);
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
                 for (int q = 0; q < DW; q++)
-                    acc = sad_dw<Px>(ld_u32(rp + r * strideB + 4 * q), src[k][r][q], acc);
+                    acc = sad_dw<Px>(ld_u32(base + (ro + (uint32_t)(r * strideB + 4 * q))), src[k][r][q], acc);
         }
         return group_total<G>((int)acc);
     }
@@ -101,13 +102,15 @@ struct PuEval
 #pragma unroll
             for (int n = 0; n < N; n++)
             {
-                const uint8_t* rp = refOrg[k] + (long)my[n] * strideB + (long)mx[n] * BPP;
+                const uint32_t ro = refOrg[k] + (uint32_t)(my[n] * strideB + mx[n] * BPP);
 #pragma unroll
                 for (int r = 0; r < 4; r++)
 #pragma unroll
                     for (int q = 0; q < DW; q++)
-                        acc[n] = sad_dw<Px>(ld_u32(rp + r * strideB + 4 * q), src[k][r][q], acc[n]);
+                        acc[n] = sad_dw<Px>(ld_u32(base + (ro + (uint32_t)(r * strideB + 4 * q))), src[k][r][q], acc[n]);
             }
+            // at most 64 dwords in flight per lane: larger groups go one tile at a time
+            if (N * T * 4 * DW > 64) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int n = 0; n < N; n++) out[n] = group_total<G>((int)acc[n]) + mvcost_q(mx[n] * 4, my[n] * 4);
@@ -123,7 +126,7 @@ struct PuEval
         {
             if (!have[k]) continue;
             int d[4][4];
-            tile_predict<BPP>(refOrg[k] + (long)(qy >> 2) * strideB + (long)(qx >> 2) * BPP, strideB, qx & 3, qy & 3, depth, d);
+            tile_predict<BPP>(base + (refOrg[k] + (uint32_t)((qy >> 2) * strideB + (qx >> 2) * BPP)), (long)strideB, qx & 3, qy & 3, depth, d);
 #pragma unroll
             for (int y = 0; y < 4; y++)
 #pragma unroll
@@ -140,131 +143,80 @@ struct PuEval
 #pragma unroll
                     for (int x = 0; x < 4; x++) acc += abs(d[y][x]);
             }
+            __builtin_amdgcn_sched_barrier(0);        // one tile's interpolation at a time: bounds the register footprint
         }
         return group_total<G>(acc);
     }
 };
 
+// Point i of one StarPatternSearch round (motion.cpp:362-604) as offsets from the round's origin, in the reference's
+// evaluation order, with its point number and distance.  dist 1: the 4 axis neighbours; dist 2..8: 8 points (axis at dist,
+// diagonals at dist / 2); dist >= 16: 16 points on the diamond of radius dist.
+__constant__ signed char kStarBx[8] = { 0, -1, 1, -1, 1, -1, 1, 0 }, kStarBy[8] = { -1, -1, -1, 0, 0, 1, 1, 1 };
+__constant__ unsigned char kStarBhalf[8] = { 0, 1, 1, 0, 0, 1, 1, 0 }, kStarBpt[8] = { 2, 1, 3, 4, 5, 6, 8, 7 };
+__constant__ signed char kStarAx[4] = { 0, -1, 1, 0 }, kStarAy[4] = { -1, 0, 0, 1 };
+__constant__ unsigned char kStarApt[4] = { 2, 4, 5, 7 };
+
+__device__ __forceinline__ void star_point(int dist, int i, int& dx, int& dy, int& pt, int& d)
+{
+    if (dist == 1) { dx = kStarAx[i]; dy = kStarAy[i]; pt = kStarApt[i]; d = 1; return; }
+    if (dist <= 8)
+    {
+        const int m = kStarBhalf[i] ? dist >> 1 : dist;
+        dx = kStarBx[i] * m; dy = kStarBy[i] * m; pt = kStarBpt[i]; d = m;
+        return;
+    }
+    pt = 0; d = dist;
+    if (i < 4) { dx = kStarAx[i] * dist; dy = kStarAy[i] * dist; return; }
+    const int step = (dist >> 2) * (i >> 2), q = i & 3;
+    dx = (q & 1) ? step : -step;
+    dy = q < 2 ? -dist + step : dist - step;
+}
+
+// motion.cpp:362-604.  Inside the search bounds a round is scored in groups (the reference's sad_x4 calls, same order) with
+// the loads of a group in flight together; a round that touches the bounds is scored point by point with the reference's
+// directional border tests.
 template <typename Px, int G, int T>
 __device__ __forceinline__ void star_pattern(const PuEval<Px, G, T>& c, SMv& bmv, int& bcost, int& bPointNr, int& bDistance, int earlyExitIters, int merange)
 {
     const SMv omv = bmv;
-    int saved = bcost, rounds = 0;
-#define PT(MX, MY, P, D) do { const int mx_ = (MX), my_ = (MY); const int cost_ = c.cost_mv(mx_, my_); \
-        if (cost_ < bcost) { bcost = cost_; bmv.x = mx_; bmv.y = my_; bPointNr = (P); bDistance = (D); } } while (0)
+    int rounds = 0;
+    for (int dist = 1; dist <= 8 || dist <= (int)(int16_t)merange; dist <<= 1)
     {
-        const int top = omv.y - 1, bottom = omv.y + 1, left = omv.x - 1, right = omv.x + 1;
-        if (top >= c.mvmin.y && left >= c.mvmin.x && right <= c.mvmax.x && bottom <= c.mvmax.y)
-        {
-            const int mxs[4] = { omv.x, left, right, omv.x }, mys[4] = { top, omv.y, omv.y, bottom }, pts[4] = { 2, 4, 5, 7 };
-            int cs[4];
-            c.template cost_mv_n<4>(mxs, mys, cs);
-#pragma unroll
-            for (int n = 0; n < 4; n++)
-                if (cs[n] < bcost) { bcost = cs[n]; bmv.x = mxs[n]; bmv.y = mys[n]; bPointNr = pts[n]; bDistance = 1; }
-        }
-        else
-        {
-        if (top >= c.mvmin.y) PT(omv.x, top, 2, 1);
-        if (left >= c.mvmin.x) PT(left, omv.y, 4, 1);
-        if (right <= c.mvmax.x) PT(right, omv.y, 5, 1);
-        if (bottom <= c.mvmax.y) PT(omv.x, bottom, 7, 1);
-        }
-        if (bcost < saved) rounds = 0;
-        else if (++rounds >= earlyExitIters) return;
-    }
-    for (int dist = 2; dist <= 8; dist <<= 1)
-    {
-        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
-        const int hd = dist >> 1;
-        const int top2 = omv.y - hd, bottom2 = omv.y + hd, left2 = omv.x - hd, right2 = omv.x + hd;
-        saved = bcost;
-        if (top >= c.mvmin.y && left >= c.mvmin.x && right <= c.mvmax.x && bottom <= c.mvmax.y)
-        {
-            const int mxs[8] = { omv.x, left2, right2, left, right, left2, right2, omv.x };
-            const int mys[8] = { top, top2, top2, omv.y, omv.y, bottom2, bottom2, bottom };
-            const int pts[8] = { 2, 1, 3, 4, 5, 6, 8, 7 };
-            int cs[8];
-            c.template cost_mv_n<8>(mxs, mys, cs);
-#pragma unroll
-            for (int n = 0; n < 8; n++)
-                if (cs[n] < bcost) { bcost = cs[n]; bmv.x = mxs[n]; bmv.y = mys[n]; bPointNr = pts[n]; bDistance = (pts[n] == 1 || pts[n] == 3 || pts[n] == 6 || pts[n] == 8) ? hd : dist; }
-        }
-        else
-        {
-            if (top >= c.mvmin.y) PT(omv.x, top, 2, dist);
-            if (top2 >= c.mvmin.y)
-            {
-                if (left2 >= c.mvmin.x) PT(left2, top2, 1, hd);
-                if (right2 <= c.mvmax.x) PT(right2, top2, 3, hd);
-            }
-            if (left >= c.mvmin.x) PT(left, omv.y, 4, dist);
-            if (right <= c.mvmax.x) PT(right, omv.y, 5, dist);
-            if (bottom2 <= c.mvmax.y)
-            {
-                if (left2 >= c.mvmin.x) PT(left2, bottom2, 6, hd);
-                if (right2 <= c.mvmax.x) PT(right2, bottom2, 8, hd);
-            }
-            if (bottom <= c.mvmax.y) PT(omv.x, bottom, 7, dist);
-        }
-        if (bcost < saved) rounds = 0;
-        else if (++rounds >= earlyExitIters) return;
-    }
-    for (int dist = 16; dist <= (int)(int16_t)merange; dist <<= 1)
-    {
-        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
-        const int qd = dist >> 2;
-        saved = bcost;
-        const bool inside = top >= c.mvmin.y && left >= c.mvmin.x && right <= c.mvmax.x && bottom <= c.mvmax.y;
+        const int npts = dist == 1 ? 4 : (dist <= 8 ? 8 : 16);
+        const bool inside = omv.y - dist >= c.mvmin.y && omv.x - dist >= c.mvmin.x && omv.x + dist <= c.mvmax.x && omv.y + dist <= c.mvmax.y;
+        const int saved = bcost;
         if (inside)
         {
-            // 16 points in the reference's order: the four axis points, then for index 1..3 (XL,YT) (XR,YT) (XL,YB) (XR,YB)
-            int mxs[16], mys[16];
-            mxs[0] = omv.x; mys[0] = top; mxs[1] = left; mys[1] = omv.y; mxs[2] = right; mys[2] = omv.y; mxs[3] = omv.x; mys[3] = bottom;
-#pragma unroll
-            for (int index = 1; index < 4; index++)
+            constexpr int NB = 4;                             // the reference's sad_x4 groups, same order
+#pragma unroll 1
+            for (int base = 0; base < npts; base += NB)
             {
-                const int posYT = top + qd * index, posYB = bottom - qd * index, posXL = omv.x - qd * index, posXR = omv.x + qd * index;
-                mxs[4 * index + 0] = posXL; mys[4 * index + 0] = posYT; mxs[4 * index + 1] = posXR; mys[4 * index + 1] = posYT;
-                mxs[4 * index + 2] = posXL; mys[4 * index + 2] = posYB; mxs[4 * index + 3] = posXR; mys[4 * index + 3] = posYB;
+                int mxs[NB], mys[NB], pts[NB], ds[NB], cs[NB];
+#pragma unroll
+                for (int n = 0; n < NB; n++) { int dx, dy; star_point(dist, base + n, dx, dy, pts[n], ds[n]); mxs[n] = omv.x + dx; mys[n] = omv.y + dy; }
+                c.template cost_mv_n<NB>(mxs, mys, cs);
+#pragma unroll
+                for (int n = 0; n < NB; n++)
+                    if (cs[n] < bcost) { bcost = cs[n]; bmv.x = mxs[n]; bmv.y = mys[n]; bPointNr = pts[n]; bDistance = ds[n]; }
             }
-#pragma unroll
-            for (int half = 0; half < 2; half++)
-            {
-                int bx8[8], by8[8], cs[8];
-#pragma unroll
-                for (int n = 0; n < 8; n++) { bx8[n] = mxs[8 * half + n]; by8[n] = mys[8 * half + n]; }
-                c.template cost_mv_n<8>(bx8, by8, cs);
-#pragma unroll
-                for (int n = 0; n < 8; n++)
-                    if (cs[n] < bcost) { bcost = cs[n]; bmv.x = bx8[n]; bmv.y = by8[n]; bPointNr = 0; bDistance = dist; }
-            }
-            if (bcost < saved) rounds = 0;
-            else if (++rounds >= earlyExitIters) return;
-            continue;
         }
-        if (inside || top >= c.mvmin.y) PT(omv.x, top, 0, dist);
-        if (inside || left >= c.mvmin.x) PT(left, omv.y, 0, dist);
-        if (inside || right <= c.mvmax.x) PT(right, omv.y, 0, dist);
-        if (inside || bottom <= c.mvmax.y) PT(omv.x, bottom, 0, dist);
-        for (int index = 1; index < 4; index++)
+        else
         {
-            const int posYT = top + qd * index, posYB = bottom - qd * index, posXL = omv.x - qd * index, posXR = omv.x + qd * index;
-            if (inside || posYT >= c.mvmin.y)
+            for (int i = 0; i < npts; i++)
             {
-                if (inside || posXL >= c.mvmin.x) PT(posXL, posYT, 0, dist);
-                if (inside || posXR <= c.mvmax.x) PT(posXR, posYT, 0, dist);
-            }
-            if (inside || posYB <= c.mvmax.y)
-            {
-                if (inside || posXL >= c.mvmin.x) PT(posXL, posYB, 0, dist);
-                if (inside || posXR <= c.mvmax.x) PT(posXR, posYB, 0, dist);
+                int dx, dy, pt, d;
+                star_point(dist, i, dx, dy, pt, d);
+                const int mx = omv.x + dx, my = omv.y + dy;
+                // the reference tests a point only against the bound(s) it moves towards
+                if ((dx < 0 && mx < c.mvmin.x) || (dx > 0 && mx > c.mvmax.x) || (dy < 0 && my < c.mvmin.y) || (dy > 0 && my > c.mvmax.y)) continue;
+                const int cost = c.cost_mv(mx, my);
+                if (cost < bcost) { bcost = cost; bmv.x = mx; bmv.y = my; bPointNr = pt; bDistance = d; }
             }
         }
         if (bcost < saved) rounds = 0;
         else if (++rounds >= earlyExitIters) return;
     }
-#undef PT
 }
 
 __device__ __forceinline__ int s_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -277,7 +229,10 @@ __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
     const int gl = threadIdx.x & (G - 1);                         // lane inside the group
     x265hip_me_search_job jb = a.jobs[job];
     PuEval<Px, G, T> c;
-    c.strideB = a.frefStrideB; c.depth = a.depth; c.cost = a.cost;
+    // 32-bit lane offsets from one scalar base: the loads take the saddr form and the address math stays in 32 bits
+    constexpr uint32_t kBias = 1u << 30;
+    c.base = a.fref - kBias;
+    c.strideB = (int)a.frefStrideB; c.depth = a.depth; c.cost = a.cost;
     c.mvpx = jb.qmvpx; c.mvpy = jb.qmvpy;
     c.mvmin.x = a.mvminx; c.mvmin.y = a.mvminy; c.mvmax.x = a.mvmaxx; c.mvmax.y = a.mvmaxy;
     const int tilesX = jb.w >> 2, ntiles = tilesX * (jb.h >> 2);
@@ -288,7 +243,7 @@ __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
         c.have[k] = t < ntiles;
         const int ty = c.have[k] ? t / tilesX : 0, tx = c.have[k] ? t - ty * tilesX : 0;
         const uint8_t* fe = a.fenc + (long)(jb.py + ty * 4) * a.fencStrideB + (long)(jb.px + tx * 4) * BPP;
-        c.refOrg[k] = a.fref + (long)(jb.py + ty * 4) * a.frefStrideB + (long)(jb.px + tx * 4) * BPP;
+        c.refOrg[k] = kBias + (uint32_t)((jb.py + ty * 4) * c.strideB + (jb.px + tx * 4) * BPP);
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -392,11 +347,9 @@ __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
         bmv.x += kSSquare1[dir].x; bmv.y += kSSquare1[dir].y;
 #undef X3
     }
-    else if (a.method == 3)         // X265_STAR_SEARCH
+    else if (a.method == 3)         // X265_STAR_SEARCH (motion.cpp:1138-1240), one StarPatternSearch call site for both phases
     {
         int bPointNr = 0, bDistance = 0;
-        star_pattern<Px, G, T>(c, bmv, bcost, bPointNr, bDistance, 3, merange);
-        bool done = false;
         auto two_points = [&]()
         {
             const SMv m1 = { bmv.x + kSOffsets[(bPointNr - 1) * 2].x, bmv.y + kSOffsets[(bPointNr - 1) * 2].y };
@@ -404,51 +357,49 @@ __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
             if (c.in_range(m1.x, m1.y)) { const int cost = c.cost_mv(m1.x, m1.y); if (cost < bcost) { bcost = cost; bmv = m1; } }
             if (c.in_range(m2.x, m2.y)) { const int cost = c.cost_mv(m2.x, m2.y); if (cost < bcost) { bcost = cost; bmv = m2; } }
         };
-        if (bDistance == 1)
+        for (int iter = 0;; iter = 1)
         {
-            if (bPointNr)
+            if (iter) { bDistance = 0; bPointNr = 0; }
+            star_pattern<Px, G, T>(c, bmv, bcost, bPointNr, bDistance, iter ? 32 : 3, merange);
+            if (iter == 0)
             {
-                const int saved = bcost;
-                two_points();
-                if (bcost == saved) done = true;
-            }
-            else done = true;
-        }
-        if (!done)
-        {
-            const int RasterDistance = 5;
-            if (bDistance > RasterDistance)
-            {
-                for (int ty = c.mvmin.y; ty <= c.mvmax.y; ty += RasterDistance)
-                    for (int tx = c.mvmin.x; tx <= c.mvmax.x; tx += RasterDistance)
-                    {
-                        if (tx + RasterDistance * 3 <= c.mvmax.x)
-                        {
-                            for (int k = 0; k < 4; k++)
-                            {
-                                const int cost = c.sad_at(tx, ty) + (k == 3 ? c.mvcost_q(tx * 8, ty * 8) : c.mvcost_q(tx * 4, ty * 4));
-                                if (cost < bcost) { bcost = cost; bmv.x = tx; bmv.y = ty; }
-                                if (k < 3) tx += RasterDistance;
-                            }
-                        }
-                        else
-                        {
-                            const int cost = c.cost_mv(tx, ty);
-                            if (cost < bcost) { bcost = cost; bmv.x = tx; bmv.y = ty; }
-                        }
-                    }
-            }
-            while (bDistance > 0)
-            {
-                bDistance = 0;
-                bPointNr = 0;
-                star_pattern<Px, G, T>(c, bmv, bcost, bPointNr, bDistance, 32, merange);
                 if (bDistance == 1)
                 {
-                    if (bPointNr) two_points();
-                    break;
+                    if (!bPointNr) break;
+                    const int saved = bcost;
+                    two_points();
+                    if (bcost == saved) break;
                 }
+                const int RasterDistance = 5;
+                if (bDistance > RasterDistance)
+                {
+                    for (int ty = c.mvmin.y; ty <= c.mvmax.y; ty += RasterDistance)
+                        for (int tx = c.mvmin.x; tx <= c.mvmax.x; tx += RasterDistance)
+                        {
+                            if (tx + RasterDistance * 3 <= c.mvmax.x)
+                            {
+                                // one sad_x4 group; its fourth candidate is priced with mvcost(tmv << 3) (:1196)
+                                const int mxs[4] = { tx, tx + RasterDistance, tx + 2 * RasterDistance, tx + 3 * RasterDistance }, mys[4] = { ty, ty, ty, ty };
+                                int cs[4];
+                                c.template cost_mv_n<4>(mxs, mys, cs);
+                                cs[3] += c.mvcost_q(mxs[3] * 8, ty * 8) - c.mvcost_q(mxs[3] * 4, ty * 4);
+#pragma unroll
+                                for (int k = 0; k < 4; k++)
+                                    if (cs[k] < bcost) { bcost = cs[k]; bmv.x = mxs[k]; bmv.y = ty; }
+                                tx += 3 * RasterDistance;
+                            }
+                            else
+                            {
+                                const int cost = c.cost_mv(tx, ty);
+                                if (cost < bcost) { bcost = cost; bmv.x = tx; bmv.y = ty; }
+                            }
+                        }
+                }
+                if (!(bDistance > 0)) break;
+                continue;
             }
+            if (bDistance == 1) { if (bPointNr) two_points(); break; }
+            if (!(bDistance > 0)) break;
         }
     }
     else                            // X265_FULL_SEARCH
@@ -518,7 +469,7 @@ __device__ __forceinline__ int job_class(const x265hip_me_search_job& j)
 }
 
 template <typename Px>
-__global__ void __launch_bounds__(256) me_search_kernel(SearchArgs a)
+__global__ void __launch_bounds__(256, 3) me_search_kernel(SearchArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -12,6 +12,7 @@
 // dct.cpp:83-240,242-416,612-634,664-686, pixel.cpp:167-186,471-483,828-840.
 #include "common.h"
 #include "mfma_dct.h"
+#include "intra_sample.h"
 
 namespace x265hip {
 
@@ -36,6 +37,7 @@ struct DctMatrix
     }
 };
 static __constant__ DctMatrix kTu = DctMatrix();
+static __constant__ int8_t kTuDst[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };   // dct.cpp:43-81
 static __constant__ int16_t kTuTaps[4][8] = {
     { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
     { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
@@ -55,6 +57,241 @@ struct TuArgs
 
 __device__ __forceinline__ int tu_clip16(int v, int maxVal) { const int16_t s = (int16_t)v; return s < 0 ? 0 : (s > maxVal ? maxVal : s); }
 __device__ __forceinline__ int tu_sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+// The transform-coding round trip of one N x N block whose prediction (pred) and source (fe) already sit in LDS:
+// residual -> forward transform -> quant -> dequant -> (DC shortcut | inverse transform) -> reconstruction -> SSE.
+// DST selects the 4x4 DST-VII of intra luma TUs (quant.cpp:426-431, no DC shortcut :583).  Every thread of the workgroup
+// calls it; A / B are N*N int16 scratch, red / sNumSig reduction scratch (sNumSig must be 0 on entry).
+template <int N, bool DST> __device__ __forceinline__ int tu_mat(int k, int i) { return DST ? (int)kTuDst[k][i] : (int)kTu.m[k * (32 / N)][i]; }
+
+// The MFMA operands of the 16 / 32 point transforms (matrix fragments + biases of wave 0's lanes); empty below 16.  A
+// persistent workgroup builds them once and reuses them for every block it processes.
+template <int N, bool USE> struct TuOps { __device__ __forceinline__ void init(int) {} };
+template <int N> struct TuOps<N, true>
+{
+    DctOperand<N, false> fw;
+    DctOperand<N, true> iv;
+    __device__ __forceinline__ void init(int lane)
+    {
+        auto matrix = [](int r, int c) { return (int)kTu.m[r][c]; };
+        fw.init(lane, matrix);
+        iv.init(lane, matrix);
+    }
+};
+template <int N, bool DST> using TuOpsFor = TuOps<N, (N >= 16 && !DST)>;
+
+template <typename Px, int N, bool DST, bool LAZY = false>
+__device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int16_t* pred, const int16_t* fe, int16_t* A, int16_t* B, unsigned long long* red, int& sNumSig,
+                                         int depth, int qp, int intraSlice, int16_t* lvOut, uint32_t* numSigOut, unsigned long long* distOut,
+                                         Px* rec, long cst)
+{
+    constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int maxVal = (1 << depth) - 1;
+    // ---- residual + forward transform (two passes, int16-truncating stores) -------------------------------
+    for (int i = tid; i < NN; i += nth) A[i] = (int16_t)((int)fe[i] - (int)pred[i]);
+    __syncthreads();
+    const int sh1 = LOG2N - 1 + depth - 8, sh2 = LOG2N + 6;
+    const int per = qp / 6, rem = qp - per * 6;
+    const int transformShift = 15 - depth - LOG2N;
+    const int qbits = 14 + per + transformShift;
+    const int qadd = (intraSlice ? 171 : 85) << (qbits - 9);
+    const int qscale = kTuQuantScales[rem];
+    int16_t* lv = lvOut;
+    int nz = 0;
+    constexpr bool USE_MFMA = N >= 16 && !DST;           // the 16 / 32 point transforms are dense matrix products: matrix cores
+    const int lane = tid & 63, wave = tid >> 6;
+    // 16 consecutive int16 of an LDS row (forward operands) / 16 samples down a column (inverse operands)
+    auto lds_row16 = [&](const int16_t* base, uint32_t (&d)[8])
+    {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(base);
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = q[k];
+    };
+    auto lds_col16 = [&](const int16_t* base, uint32_t (&d)[8])
+    {
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = (uint32_t)(uint16_t)base[(2 * k) * N] | ((uint32_t)(uint16_t)base[(2 * k + 1) * N] << 16);
+    };
+    if constexpr (USE_MFMA)
+    {
+        if (wave == 0)
+        {
+            typedef Mfma<N> MF;
+            // LAZY: a one-block workgroup builds each operand where it is used (short live ranges) instead of up front
+            auto matrix = [](int r, int c) { return (int)kTu.m[r][c]; };
+            DctOperand<N, false> fwL;
+            if constexpr (LAZY) fwL.init(lane, matrix);
+            const DctOperand<N, false>& fw = LAZY ? fwL : ops.fw;
+            const int kb = MF::kbase(lane), rn = MF::mn(lane);
+            uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            int p[MF::NACC];
+            // pass 1: P[k][j] = sum_i M[k][i] * resid[j][i]
+            if (fw.kvalid) lds_row16(A + rn * N + kb, d);
+            fw.product(d, p);
+#pragma unroll
+            for (int r = 0; r < MF::NACC; r++) B[MF::row(lane, r) * N + MF::col(lane)] = (int16_t)((p[r] + (1 << (sh1 - 1))) >> sh1);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            // pass 2 fused with quant (quant.cpp:462-469, dct.cpp:664-686)
+            if (fw.kvalid) lds_row16(B + rn * N + kb, d);
+            fw.product(d, p);
+#pragma unroll
+            for (int r = 0; r < MF::NACC; r++)
+            {
+                const int e = MF::row(lane, r) * N + MF::col(lane);
+                const int c = (int16_t)((p[r] + (1 << (sh2 - 1))) >> sh2);
+                const int t = abs(c) * qscale;
+                int level = (t + qadd) >> qbits;
+                nz += level != 0;
+                if (c < 0) level = -level;
+                level = tu_sat16(level);
+                A[e] = (int16_t)level;            // A is free again: quantised levels
+                lv[e] = (int16_t)level;
+            }
+        }
+    }
+    else
+    {
+    for (int e = tid; e < NN; e += nth)
+    {
+        const int k = e >> LOG2N, j = e & (N - 1);
+        int acc = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) acc += tu_mat<N, DST>(k, i) * (int)A[j * N + i];
+        B[k * N + j] = (int16_t)((acc + (1 << (sh1 - 1))) >> sh1);
+    }
+    __syncthreads();
+    // ---- second pass fused with quant (quant.cpp:462-469, dct.cpp:664-686) ----------------------------------
+    for (int e = tid; e < NN; e += nth)
+    {
+        const int k = e >> LOG2N, j = e & (N - 1);
+        int acc = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) acc += tu_mat<N, DST>(k, i) * (int)B[j * N + i];
+        const int c = (int16_t)((acc + (1 << (sh2 - 1))) >> sh2);
+        const int t = abs(c) * qscale;
+        int level = (t + qadd) >> qbits;
+        nz += level != 0;
+        if (c < 0) level = -level;
+        level = tu_sat16(level);
+        A[e] = (int16_t)level;            // A is free again: quantised levels
+        lv[e] = (int16_t)level;
+    }
+    }
+    nz = group_sum<64>(nz);
+    if ((tid & 63) == 0 && nz) atomicAdd(&sNumSig, nz);
+    __syncthreads();
+    const int numSig = sNumSig;
+    if (tid == 0) *numSigOut = (uint32_t)numSig;
+
+    // ---- inverse path --------------------------------------------------------------------------------------
+    unsigned long long part = 0;
+    if (numSig)
+    {
+        const int dqShift = 20 - 14 - transformShift, dqAdd = 1 << (dqShift - 1);
+        const int dqScale = kTuInvQuantScales[rem] << per;
+        if (numSig == 1 && A[0] != 0 && !DST)
+        {
+            // DC-only shortcut (quant.cpp:586-598)
+            const int deq = tu_sat16(((int)A[0] * dqScale + dqAdd) >> dqShift);
+            const int shift2 = 12 - (depth - 8) - 3;
+            const int dc = (int16_t)(((((deq + 1) >> 1) * 8) + (1 << (shift2 - 1))) >> shift2);
+            for (int i = tid; i < NN; i += nth)
+            {
+                const int y = i >> LOG2N, x = i & (N - 1);
+                const int v = clip3(0, maxVal, (int)pred[i] + dc);
+                rec[y * cst + x] = (Px)v;
+                const int d = (int)fe[i] - v;
+                part += (unsigned)(d * d);
+            }
+        }
+        else
+        {
+            for (int i = tid; i < NN; i += nth) B[i] = (int16_t)tu_sat16(((int)A[i] * dqScale + dqAdd) >> dqShift);
+            __syncthreads();
+            const int shI = 12 - (depth - 8);
+            if constexpr (USE_MFMA)
+            {
+                if (wave == 0)
+                {
+                    typedef Mfma<N> MF;
+                    auto matrix = [](int r, int c) { return (int)kTu.m[r][c]; };
+                    DctOperand<N, true> ivL;
+                    if constexpr (LAZY) ivL.init(lane, matrix);
+                    const DctOperand<N, true>& iv = LAZY ? ivL : ops.iv;
+                    const int kb = MF::kbase(lane), rn = MF::mn(lane);
+                    uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+                    int p[MF::NACC];
+                    // pass 1: P[k][j] = sum_i M[i][k] * deq[i][j]  (contraction down the columns), stored as out1[j][k]
+                    if (iv.kvalid) lds_col16(B + kb * N + rn, d);
+                    iv.product(d, p);
+#pragma unroll
+                    for (int r = 0; r < MF::NACC; r++) A[MF::col(lane) * N + MF::row(lane, r)] = (int16_t)tu_sat16((p[r] + 64) >> 7);
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    // pass 2: r[j][k] = sum_i M[i][k] * out1[i][j]
+                    if (iv.kvalid) lds_col16(A + kb * N + rn, d);
+                    iv.product(d, p);
+#pragma unroll
+                    for (int r = 0; r < MF::NACC; r++)
+                    {
+                        const int j = MF::col(lane), k = MF::row(lane, r);
+                        const int res = tu_sat16((p[r] + (1 << (shI - 1))) >> shI);
+                        const int v = clip3(0, maxVal, (int)pred[j * N + k] + res);
+                        rec[j * cst + k] = (Px)v;
+                        const int dd = (int)fe[j * N + k] - v;
+                        part += (unsigned)(dd * dd);
+                    }
+                }
+            }
+            else
+            {
+            for (int e = tid; e < NN; e += nth)
+            {
+                const int j = e >> LOG2N, k = e & (N - 1);
+                int acc = 0;
+#pragma unroll
+                for (int i = 0; i < N; i++) acc += tu_mat<N, DST>(i, k) * (int)B[i * N + j];
+                A[j * N + k] = (int16_t)tu_sat16((acc + 64) >> 7);
+            }
+            __syncthreads();
+            for (int e = tid; e < NN; e += nth)
+            {
+                const int j = e >> LOG2N, k = e & (N - 1);
+                int acc = 0;
+#pragma unroll
+                for (int i = 0; i < N; i++) acc += tu_mat<N, DST>(i, k) * (int)A[i * N + j];
+                const int r = tu_sat16((acc + (1 << (shI - 1))) >> shI);
+                const int v = clip3(0, maxVal, (int)pred[e] + r);
+                rec[j * cst + k] = (Px)v;
+                const int d = (int)fe[e] - v;
+                part += (unsigned)(d * d);
+            }
+            }
+        }
+    }
+    else
+    {
+        for (int i = tid; i < NN; i += nth)
+        {
+            const int y = i >> LOG2N, x = i & (N - 1);
+            const int v = pred[i];
+            rec[y * cst + x] = (Px)v;
+            const int d = (int)fe[i] - v;
+            part += (unsigned)(d * d);
+        }
+    }
+    part = group_sum<64>(part);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0)
+    {
+        unsigned long long t = 0;
+        for (int i = 0; i < (nth >> 6); i++) t += red[i];
+        *distOut = t;
+    }
+}
 
 template <typename Px, int N>
 __global__ void __launch_bounds__(256) inter_recon_kernel(TuArgs a)
@@ -134,206 +371,71 @@ __global__ void __launch_bounds__(256) inter_recon_kernel(TuArgs a)
     }
     __syncthreads();
 
-    // ---- residual + forward transform (two passes, int16-truncating stores) -------------------------------
-    for (int i = tid; i < NN; i += nth) A[i] = (int16_t)((int)fe[i] - (int)pred[i]);
-    __syncthreads();
-    const int sh1 = LOG2N - 1 + a.depth - 8, sh2 = LOG2N + 6;
-    const int per = a.qp / 6, rem = a.qp - per * 6;
-    const int transformShift = 15 - a.depth - LOG2N;
-    const int qbits = 14 + per + transformShift;
-    const int qadd = (a.intraSlice ? 171 : 85) << (qbits - 9);
-    const int qscale = kTuQuantScales[rem];
-    int16_t* lv = a.levels + ((size_t)ctu * npu + z) * NN;
-    int nz = 0;
-    constexpr bool USE_MFMA = N >= 16;           // the 16 / 32 point transforms are dense matrix products: matrix cores
-    const int lane = tid & 63, wave = tid >> 6;
-    auto matrix = [](int r, int c) { return (int)kTu.m[r][c]; };
-    // 16 consecutive int16 of an LDS row (forward operands) / 16 samples down a column (inverse operands)
-    auto lds_row16 = [&](const int16_t* base, uint32_t (&d)[8])
-    {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(base);
-#pragma unroll
-        for (int k = 0; k < 8; k++) d[k] = q[k];
-    };
-    auto lds_col16 = [&](const int16_t* base, uint32_t (&d)[8])
-    {
-#pragma unroll
-        for (int k = 0; k < 8; k++) d[k] = (uint32_t)(uint16_t)base[(2 * k) * N] | ((uint32_t)(uint16_t)base[(2 * k + 1) * N] << 16);
-    };
-    if constexpr (USE_MFMA)
-    {
-        if (wave == 0)
-        {
-            typedef Mfma<N> MF;
-            DctOperand<N, false> fw;
-            fw.init(lane, matrix);
-            const int kb = MF::kbase(lane), rn = MF::mn(lane);
-            uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-            int p[MF::NACC];
-            // pass 1: P[k][j] = sum_i M[k][i] * resid[j][i]
-            if (fw.kvalid) lds_row16(A + rn * N + kb, d);
-            fw.product(d, p);
-#pragma unroll
-            for (int r = 0; r < MF::NACC; r++) B[MF::row(lane, r) * N + MF::col(lane)] = (int16_t)((p[r] + (1 << (sh1 - 1))) >> sh1);
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            // pass 2 fused with quant (quant.cpp:462-469, dct.cpp:664-686)
-            if (fw.kvalid) lds_row16(B + rn * N + kb, d);
-            fw.product(d, p);
-#pragma unroll
-            for (int r = 0; r < MF::NACC; r++)
-            {
-                const int e = MF::row(lane, r) * N + MF::col(lane);
-                const int c = (int16_t)((p[r] + (1 << (sh2 - 1))) >> sh2);
-                const int t = abs(c) * qscale;
-                int level = (t + qadd) >> qbits;
-                nz += level != 0;
-                if (c < 0) level = -level;
-                level = tu_sat16(level);
-                A[e] = (int16_t)level;            // A is free again: quantised levels
-                lv[e] = (int16_t)level;
-            }
-        }
-    }
-    else
-    {
-    for (int e = tid; e < NN; e += nth)
-    {
-        const int k = e >> LOG2N, j = e & (N - 1);
-        int acc = 0;
-#pragma unroll
-        for (int i = 0; i < N; i++) acc += kTu.m[k * (32 / N)][i] * (int)A[j * N + i];
-        B[k * N + j] = (int16_t)((acc + (1 << (sh1 - 1))) >> sh1);
-    }
-    __syncthreads();
-    // ---- second pass fused with quant (quant.cpp:462-469, dct.cpp:664-686) ----------------------------------
-    for (int e = tid; e < NN; e += nth)
-    {
-        const int k = e >> LOG2N, j = e & (N - 1);
-        int acc = 0;
-#pragma unroll
-        for (int i = 0; i < N; i++) acc += kTu.m[k * (32 / N)][i] * (int)B[j * N + i];
-        const int c = (int16_t)((acc + (1 << (sh2 - 1))) >> sh2);
-        const int t = abs(c) * qscale;
-        int level = (t + qadd) >> qbits;
-        nz += level != 0;
-        if (c < 0) level = -level;
-        level = tu_sat16(level);
-        A[e] = (int16_t)level;            // A is free again: quantised levels
-        lv[e] = (int16_t)level;
-    }
-    }
-    nz = group_sum<64>(nz);
-    if ((tid & 63) == 0 && nz) atomicAdd(&sNumSig, nz);
-    __syncthreads();
-    const int numSig = sNumSig;
-    if (tid == 0) a.numSig[(size_t)ctu * npu + z] = (uint32_t)numSig;
+    TuOpsFor<N, false> ops;          // unused: built lazily inside
+    tu_chain<Px, N, false, true>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
+                           a.levels + ((size_t)ctu * npu + z) * NN, &a.numSig[(size_t)ctu * npu + z], &a.dist[(size_t)ctu * npu + z],
+                           reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP);
+}
 
-    // ---- inverse path --------------------------------------------------------------------------------------
-    Px* rec = reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px;
-    const long cst = a.reconStrideB / BPP;
-    unsigned long long part = 0;
-    if (numSig)
+// ------------------------------------------------------------------------------------------------
+// Intra TU candidate set (Search::codeIntraLumaQT's pixel work, search.cpp:335-373): one workgroup per (TU, mode) job -
+// Predict::predIntraLumaAng (predict.cpp:579-588: filtered neighbours per g_intraFilterFlags & size, edge filter for
+// sizes <= 16) computed sample by sample into LDS, then the same transform-coding round trip as the inter kernel (DST-VII
+// for 4x4).  The candidate's reconstruction goes to its own block of the recon plane, so a host can evaluate many modes of
+// many TUs in one launch and keep the winner.
+struct IntraTuArgs
+{
+    const uint8_t* fenc; long fencStrideB;
+    const uint8_t* nb;
+    uint8_t* recon; long reconStrideB;
+    const x265hip_job* jobs; int njobs;
+    int depth, qp, intraSlice;
+    int16_t* levels; uint32_t* numSig; unsigned long long* dist;
+};
+
+template <typename Px, int N>
+__global__ void __launch_bounds__(64, (N == 4 ? 8 : (N == 8 ? 5 : (N == 16 ? 4 : 2)))) intra_recon_kernel(IntraTuArgs a)
+{
+    constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
+    constexpr int BPP = sizeof(Px);
+    __shared__ int16_t nbS[4 * N + 4];
+    __shared__ int16_t pred[NN], fe[NN], A[NN], B[NN];
+    __shared__ unsigned long long red[4];
+    __shared__ int sNumSig;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int maxVal = (1 << a.depth) - 1;
+    TuOpsFor<N, N == 4> ops;
+    ops.init(tid & 63);
+    // a persistent single-wavefront workgroup: the operands above are built once, the barriers below are wave-local
+    for (int job = blockIdx.x; job < a.njobs; job += gridDim.x)
     {
-        const int dqShift = 20 - 14 - transformShift, dqAdd = 1 << (dqShift - 1);
-        const int dqScale = kTuInvQuantScales[rem] << per;
-        if (numSig == 1 && A[0] != 0)
+        const x265hip_job jb = a.jobs[job];
+        const int mode = jb.arg[0];
+        const bool filtered = (kIsFilterFlags[mode] & N) != 0;
+        const Px* nbp = reinterpret_cast<const Px*>(a.nb) + (filtered ? jb.off[2] : jb.off[1]);
+        for (int i = tid; i < 4 * N + 1; i += nth) nbS[i] = (int16_t)nbp[i];
         {
-            // DC-only shortcut (quant.cpp:586-598)
-            const int deq = tu_sat16(((int)A[0] * dqScale + dqAdd) >> dqShift);
-            const int shift2 = 12 - (a.depth - 8) - 3;
-            const int dc = (int16_t)(((((deq + 1) >> 1) * 8) + (1 << (shift2 - 1))) >> shift2);
-            for (int i = tid; i < NN; i += nth)
-            {
-                const int y = i >> LOG2N, x = i & (N - 1);
-                const int v = clip3(0, maxVal, (int)pred[i] + dc);
-                rec[y * cst + x] = (Px)v;
-                const int d = (int)fe[i] - v;
-                part += (unsigned)(d * d);
-            }
+            const Px* f = reinterpret_cast<const Px*>(a.fenc) + jb.off[0];
+            const long fst = a.fencStrideB / BPP;
+            for (int i = tid; i < NN; i += nth) { const int y = i >> LOG2N, x = i & (N - 1); fe[i] = (int16_t)f[y * fst + x]; }
         }
-        else
-        {
-            for (int i = tid; i < NN; i += nth) B[i] = (int16_t)tu_sat16(((int)A[i] * dqScale + dqAdd) >> dqShift);
-            __syncthreads();
-            const int shI = 12 - (a.depth - 8);
-            if constexpr (USE_MFMA)
-            {
-                if (wave == 0)
-                {
-                    typedef Mfma<N> MF;
-                    DctOperand<N, true> iv;
-                    iv.init(lane, matrix);
-                    const int kb = MF::kbase(lane), rn = MF::mn(lane);
-                    uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-                    int p[MF::NACC];
-                    // pass 1: P[k][j] = sum_i M[i][k] * deq[i][j]  (contraction down the columns), stored as out1[j][k]
-                    if (iv.kvalid) lds_col16(B + kb * N + rn, d);
-                    iv.product(d, p);
-#pragma unroll
-                    for (int r = 0; r < MF::NACC; r++) A[MF::col(lane) * N + MF::row(lane, r)] = (int16_t)tu_sat16((p[r] + 64) >> 7);
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    // pass 2: r[j][k] = sum_i M[i][k] * out1[i][j]
-                    if (iv.kvalid) lds_col16(A + kb * N + rn, d);
-                    iv.product(d, p);
-#pragma unroll
-                    for (int r = 0; r < MF::NACC; r++)
-                    {
-                        const int j = MF::col(lane), k = MF::row(lane, r);
-                        const int res = tu_sat16((p[r] + (1 << (shI - 1))) >> shI);
-                        const int v = clip3(0, maxVal, (int)pred[j * N + k] + res);
-                        rec[j * cst + k] = (Px)v;
-                        const int dd = (int)fe[j * N + k] - v;
-                        part += (unsigned)(dd * dd);
-                    }
-                }
-            }
-            else
-            {
-            for (int e = tid; e < NN; e += nth)
-            {
-                const int j = e >> LOG2N, k = e & (N - 1);
-                int acc = 0;
-#pragma unroll
-                for (int i = 0; i < N; i++) acc += kTu.m[i * (32 / N)][k] * (int)B[i * N + j];
-                A[j * N + k] = (int16_t)tu_sat16((acc + 64) >> 7);
-            }
-            __syncthreads();
-            for (int e = tid; e < NN; e += nth)
-            {
-                const int j = e >> LOG2N, k = e & (N - 1);
-                int acc = 0;
-#pragma unroll
-                for (int i = 0; i < N; i++) acc += kTu.m[i * (32 / N)][k] * (int)A[i * N + j];
-                const int r = tu_sat16((acc + (1 << (shI - 1))) >> shI);
-                const int v = clip3(0, maxVal, (int)pred[e] + r);
-                rec[j * cst + k] = (Px)v;
-                const int d = (int)fe[e] - v;
-                part += (unsigned)(d * d);
-            }
-            }
-        }
-    }
-    else
-    {
+        if (tid == 0) sNumSig = 0;
+        __syncthreads();
+        // dcVal (intrapred.cpp:95-110): every lane sums a slice of the 2N neighbours, the wavefront adds them up
+        int part = 0;
+        for (int i = tid; i < 2 * N; i += nth) part += i < N ? nbS[1 + i] : nbS[2 * N + 1 + (i - N)];
+        const int dc = (group_sum<64>(part) + N) / (2 * N);
+        const int bFilter = LOG2N <= 4;
         for (int i = tid; i < NN; i += nth)
         {
             const int y = i >> LOG2N, x = i & (N - 1);
-            const int v = pred[i];
-            rec[y * cst + x] = (Px)v;
-            const int d = (int)fe[i] - v;
-            part += (unsigned)(d * d);
+            pred[i] = (int16_t)intra_sample(nbS, N, LOG2N, mode, bFilter, dc, maxVal, x, y);
         }
-    }
-    part = group_sum<64>(part);
-    if ((tid & 63) == 0) red[tid >> 6] = part;
-    __syncthreads();
-    if (tid == 0)
-    {
-        unsigned long long t = 0;
-        for (int i = 0; i < (nth >> 6); i++) t += red[i];
-        a.dist[(size_t)ctu * npu + z] = t;
+        __syncthreads();
+        tu_chain<Px, N, N == 4>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
+                                a.levels + (size_t)job * NN, &a.numSig[job], &a.dist[job],
+                                reinterpret_cast<Px*>(a.recon) + jb.off[3], a.reconStrideB / BPP);
+        __syncthreads();
     }
 }
 
@@ -368,6 +470,46 @@ extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
         else hipLaunchKernelGGL((inter_recon_kernel<PX, 32>), dim3(nctu * npu), dim3(256), 0, s, a); } while (0)
     if (p->depth == 8) GO(uint8_t); else GO(uint16_t);
 #undef GO
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x265hip_intra_recon_batch(const x265hip_intra_recon_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->fenc || !p->nb || !p->recon || !p->jobs || !p->levels || !p->num_sig || !p->dist) { set_error("intra_recon_batch: NULL operand"); return X265HIP_EINVAL; }
+    if (p->njobs < 0) { set_error("intra_recon_batch: njobs %d", p->njobs); return X265HIP_EINVAL; }
+    if (p->njobs == 0) return 0;
+    if (p->n != 4 && p->n != 8 && p->n != 16 && p->n != 32) { set_error("intra_recon_batch: TU size %d", p->n); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("intra_recon_batch: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->qp < 0 || p->qp > 51 + 6 * (p->depth - 8)) { set_error("intra_recon_batch: qp %d out of range", p->qp); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    IntraTuArgs a;
+    a.fenc = (const uint8_t*)p->fenc; a.fencStrideB = (long)p->fenc_stride * bpp;
+    a.nb = (const uint8_t*)p->nb;
+    a.recon = (uint8_t*)p->recon; a.reconStrideB = (long)p->recon_stride * bpp;
+    a.jobs = p->jobs; a.njobs = p->njobs; a.depth = p->depth; a.qp = p->qp; a.intraSlice = p->intra_slice;
+    a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
+    hipStream_t s = (hipStream_t)stream;
+    // 16 / 32: persistent single-wavefront workgroups, exactly one resident set (a second partial round would double the time);
+    // 4 / 8: nothing to amortise, one workgroup per job
+    auto resident = [&](const void* fn)
+    {
+        int dev = 0, cus = 256, per = 8;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, 64, 0) != hipSuccess || per < 1) per = 8;
+        const long r = (long)cus * per;
+        return (int)(p->njobs < r ? p->njobs : r);
+    };
+#define GOI(PX) do { \
+        if (p->n == 4) hipLaunchKernelGGL((intra_recon_kernel<PX, 4>), dim3(p->njobs), dim3(64), 0, s, a); \
+        else if (p->n == 8) hipLaunchKernelGGL((intra_recon_kernel<PX, 8>), dim3(p->njobs), dim3(64), 0, s, a); \
+        else if (p->n == 16) hipLaunchKernelGGL((intra_recon_kernel<PX, 16>), dim3(resident((const void*)intra_recon_kernel<PX, 16>)), dim3(64), 0, s, a); \
+        else hipLaunchKernelGGL((intra_recon_kernel<PX, 32>), dim3(resident((const void*)intra_recon_kernel<PX, 32>)), dim3(64), 0, s, a); } while (0)
+    if (p->depth == 8) GOI(uint8_t); else GOI(uint16_t);
+#undef GOI
     X265HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -284,6 +284,32 @@ def _planes(ps, n):
     return arr
 
 
+class IntraReconParams(ctypes.Structure):
+    """x265hip_intra_recon_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("n", ctypes.c_int),
+                ("fenc", ctypes.c_void_p), ("fenc_stride", ctypes.c_ssize_t),
+                ("nb", ctypes.c_void_p),
+                ("recon", ctypes.c_void_p), ("recon_stride", ctypes.c_ssize_t),
+                ("qp", ctypes.c_int), ("intra_slice", ctypes.c_int),
+                ("jobs", ctypes.c_void_p), ("njobs", ctypes.c_int),
+                ("levels", ctypes.c_void_p), ("num_sig", ctypes.c_void_p), ("dist", ctypes.c_void_p)]
+
+
+def intra_recon_batch(depth, n, fenc, fenc_stride, nb, recon, recon_stride, qp, intra_slice, jobs, njobs,
+                      levels, num_sig, dist, stream=None):
+    """Intra TU candidate set (search.cpp:335-373): one (TU, mode) candidate per job, see include/x265hip.h."""
+    p = IntraReconParams()
+    p.depth, p.n = depth, n
+    p.fenc, p.fenc_stride, p.nb = fenc.data_ptr(), fenc_stride, nb.data_ptr()
+    p.recon, p.recon_stride = recon.data_ptr(), recon_stride
+    p.qp, p.intra_slice, p.jobs, p.njobs = qp, intra_slice, jobs.data_ptr(), njobs
+    p.levels, p.num_sig, p.dist = levels.data_ptr(), num_sig.data_ptr(), dist.data_ptr()
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_intra_recon_batch
+    f.argtypes = [ctypes.POINTER(IntraReconParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_intra_recon_batch")
+
+
 def interp_batch(kind, depth, taps, w, h, src, dst, jobs, njobs, stream=None):
     s = current_stream() if stream is None else stream
     f = lib().x265hip_interp_batch
