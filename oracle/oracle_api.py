@@ -191,3 +191,24 @@ def intra_recon(depth, n, fenc, fenc_stride, nb, recon_len, recon_stride, qp, in
             j.ctypes.data, njobs, levels.ctypes.data, num_sig.ctypes.data, dist.ctypes.data, nthreads)
     assert rc == 0
     return recon, levels, num_sig, dist
+
+
+def lowres_cost(depth, cur, ref_planes, stride, org, width_in_cu, height_in_cu, cost_q, qoff, intra_cost, inv_qscale=None, avx2=False):
+    """CPU restatement of CostEstimateGroup::estimateFrameCost for a P picture (slicetype.cpp:3189-3388).  cur: the current
+    picture's plane 0; ref_planes: the reference's four planes (flat arrays, pixel (0,0) at element `org`).
+    Returns (mvs int32 [n, 2], mv_costs, lowres_costs, row_satds, frame int64 [3] = costEst, costEstAq, intraMbs)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_lowres_cost_d{depth}")
+    n = width_in_cu * height_in_cu
+    mvs, mvc = np.zeros((n, 2), np.int32), np.zeros(n, np.int32)
+    lc, rows, frame = np.zeros(n, np.uint16), np.zeros(height_in_cu, np.int32), np.zeros(3, np.int64)
+    es = cur.itemsize
+    cq = np.ascontiguousarray(cost_q, dtype=np.uint16)
+    ic = np.ascontiguousarray(intra_cost, dtype=np.int32)
+    iq = None if inv_qscale is None else np.ascontiguousarray(inv_qscale, dtype=np.int32)
+    fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7
+    rc = fn(cur.ctypes.data + org * es, *[p.ctypes.data + org * es for p in ref_planes], stride, width_in_cu, height_in_cu,
+            cq.ctypes.data, qoff, ic.ctypes.data, None if iq is None else iq.ctypes.data, mvs.ctypes.data, mvc.ctypes.data,
+            lc.ctypes.data, rows.ctypes.data, frame.ctypes.data)
+    assert rc == 0
+    return mvs, mvc, lc, rows, frame

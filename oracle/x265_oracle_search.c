@@ -58,6 +58,7 @@ typedef struct
     const uint16_t* cost;             /* cost[q]: bit cost of a quarter-pel mv DIFFERENCE component q (index 0 = zero) */
     int mvpx, mvpy;
     mv_t mvmin, mvmax;
+    const pixel* lowres[4];           /* lowres references only: the four half-pel phase planes under the block (else lowres[0] = NULL) */
 } me_ctx;
 
 static inline int mvcost_q(const me_ctx* c, int qx, int qy) { return c->cost[qx - c->mvpx] + c->cost[qy - c->mvpy]; }
@@ -77,6 +78,25 @@ static int subpel_compare(const me_ctx* c, int qx, int qy, int useSatd)
     else if (!xf) c->pu->luma_vpp(fref, c->stride, buf, c->w, yf);
     else c->pu->luma_hvpp(fref, c->stride, buf, c->w, xf, yf);
     return cmp(c->fenc, 64, buf, c->w);
+}
+
+/* lowres.h:95-121 (ReferencePlanes::lowresQPelCost): half-pel positions read a phase plane, quarter-pel positions average two */
+static int lowres_qpel_cost(const me_ctx* c, int qx, int qy, int useSatd)
+{
+    x265hip_pixelcmp_t cmp = useSatd ? c->pu->satd : c->pu->sad;
+    if ((qx | qy) & 1)
+    {
+        pixel buf[8 * 8] __attribute__((aligned(16)));
+        const int hpelA = (qy & 2) | ((qx & 2) >> 1);
+        const pixel* frefA = c->lowres[hpelA] + (qx >> 2) + (intptr_t)(qy >> 2) * c->stride;
+        const int qmvx = qx + (qx & 1), qmvy = qy + (qy & 1);
+        const int hpelB = (qmvy & 2) | ((qmvx & 2) >> 1);
+        const pixel* frefB = c->lowres[hpelB] + (qmvx >> 2) + (intptr_t)(qmvy >> 2) * c->stride;
+        c->pu->pixelavg_pp[0](buf, 8, frefA, c->stride, frefB, c->stride, 32);
+        return cmp(c->fenc, 64, buf, 8);
+    }
+    const int hpel = (qy & 2) | ((qx & 2) >> 1);
+    return cmp(c->fenc, 64, c->lowres[hpel] + (qx >> 2) + (intptr_t)(qy >> 2) * c->stride, c->stride);
 }
 
 /* motion.cpp:362-604; point numbers and distances as in the reference's diagrams */
@@ -178,7 +198,7 @@ static int motion_estimate_one(me_ctx* c, int method, int subme, int merange, co
     /* measure the clipped quarter-pel predictor (:772-781), re-measure its full-pel rounding (:783-787), try mv 0 (:789-799) */
     int pmvx = clip3(qminx, qmaxx, c->mvpx), pmvy = clip3(qminy, qmaxy, c->mvpy);
     int bestprex = pmvx, bestprey = pmvy;
-    int bprecost = subpel_compare(c, pmvx, pmvy, 0);
+    int bprecost = c->lowres[0] ? lowres_qpel_cost(c, pmvx, pmvy, 0) /* :775-776 */ : subpel_compare(c, pmvx, pmvy, 0);
     mv_t bmv = { (pmvx + 2) >> 2, (pmvy + 2) >> 2 };
     int bcost = bprecost;
     if ((pmvx | pmvy) & 3) bcost = cost_mv(c, bmv.x, bmv.y);
@@ -359,6 +379,29 @@ static int motion_estimate_one(me_ctx* c, int method, int subme, int merange, co
     const workload_t wl = kWorkload[subme];
     if (!bcost)
         bcost = mvcost_q(c, bx, by);
+    else if (c->lowres[0])
+    {
+        /* motion.cpp:1471-1503: one half-pel round on SAD, re-measure on SATD, one quarter-pel round on SATD */
+        int bdir = 0;
+        for (int i = 1; i <= wl.hpel_dirs; i++)
+        {
+            const int qx = bx + kSquare1[i].x * 2, qy = by + kSquare1[i].y * 2;
+            if ((qy < qminy) | (qy > qmaxy)) continue;
+            const int cost = lowres_qpel_cost(c, qx, qy, 0) + mvcost_q(c, qx, qy);
+            if (cost < bcost) { bcost = cost; bdir = i; }
+        }
+        bx += kSquare1[bdir].x * 2; by += kSquare1[bdir].y * 2;
+        bcost = lowres_qpel_cost(c, bx, by, 1) + mvcost_q(c, bx, by);
+        bdir = 0;
+        for (int i = 1; i <= wl.qpel_dirs; i++)
+        {
+            const int qx = bx + kSquare1[i].x, qy = by + kSquare1[i].y;
+            if ((qy < qminy) | (qy > qmaxy)) continue;
+            const int cost = lowres_qpel_cost(c, qx, qy, 1) + mvcost_q(c, qx, qy);
+            if (cost < bcost) { bcost = cost; bdir = i; }
+        }
+        bx += kSquare1[bdir].x; by += kSquare1[bdir].y;
+    }
     else
     {
         int hpelSatd = wl.hpel_satd;
@@ -437,10 +480,97 @@ int EXPORT(x265oracle_motion_estimate_mvc)(const pixel* fenc, const pixel* fref,
         c.cost = cost + qoff;
         c.mvpx = j->qmvpx; c.mvpy = j->qmvpy;
         c.mvmin.x = mvminx; c.mvmin.y = mvminy; c.mvmax.x = mvmaxx; c.mvmax.y = mvmaxy;
+        c.lowres[0] = c.lowres[1] = c.lowres[2] = c.lowres[3] = NULL;
         int qx = 0, qy = 0;
         const int cst = motion_estimate_one(&c, method, subme, merange, mvc ? mvc + (size_t)i * 24 : NULL, (mvc && numMvc) ? numMvc[i] : 0, &qx, &qy);
         if (cst < 0) { rc = -1; continue; }
         j->out_cost = cst; j->out_qmvx = qx; j->out_qmvy = qy;
     }
     return rc;
+}
+
+
+/* CostEstimateGroup::estimateFrameCost + estimateCUCost for a P picture (b == p1, one list, no HME, no weighted reference):
+ * slicetype.cpp:3189-3198 (reverse raster order) and :3216-3388.  Every 8x8 block of the half-resolution picture: the mvs of the
+ * already finished right / lower neighbours are tried as predictors (SATD at lowresMC, :3284-3301), HEX search with merange 16
+ * and subpelRefine 1 against the reference's four phase planes (:3307), + lowresPenalty, intra wins if cheaper (:3346-3356);
+ * frame sums over the non-edge blocks.
+ *   cur: pixel (0,0) of the current picture's plane 0; ref0..3: pixel (0,0) of the reference's four planes (same stride).
+ *   intraCost: LookaheadTLD::lowresIntraEstimate's output for the current picture; invQscale: fenc->invQscaleFactor or NULL.
+ * Outputs: mvs int32 [n][2] (quarter-pel), mvCosts int32 [n], lowresCosts uint16 [n], rowSatds int32 [heightInCU],
+ * frame int64 [3] = { costEst, costEstAq, intraMbs }.  Serial by construction (each block needs its neighbours' mvs). */
+int EXPORT(x265oracle_lowres_cost)(const pixel* cur, const pixel* ref0, const pixel* ref1, const pixel* ref2, const pixel* ref3, intptr_t stride,
+                                   int widthInCU, int heightInCU, const uint16_t* cost, int qoff, const int32_t* intraCost,
+                                   const int32_t* invQscale, int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds,
+                                   int64_t* frame)
+{
+    static x265hip_EncoderPrimitives prim;
+    static int ready = 0;
+    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    int part = -1;
+    for (int k = 0; k < 25; k++) if (kPuDims[k][0] == 8 && kPuDims[k][1] == 8) part = k;
+    const pixel* planes[4] = { ref0, ref1, ref2, ref3 };
+    const int cuSize = 8, lowresPenalty = 4, merange = 16;
+    int64_t costEst = 0, costEstAq = 0, intraMbs = 0;
+    for (int cuY = heightInCU - 1; cuY >= 0; cuY--)
+    {
+        const int lastRow = cuY == heightInCU - 1;
+        rowSatds[cuY] = 0;
+        for (int cuX = widthInCU - 1; cuX >= 0; cuX--)
+        {
+            const int cuXY = cuX + cuY * widthInCU;
+            const intptr_t pelOffset = cuSize * cuX + cuSize * cuY * stride;
+            me_ctx c;
+            c.pu = &prim.pu[part];
+            c.stride = stride; c.w = 8;
+            c.pu->copy_pp(c.fenc, 64, cur + pelOffset, stride);
+            c.cost = cost + qoff;
+            for (int i = 0; i < 4; i++) c.lowres[i] = planes[i] + pelOffset;
+            c.fref = c.lowres[0];
+            c.mvmin.x = -cuX * cuSize - 8; c.mvmin.y = -cuY * cuSize - 8;
+            c.mvmax.x = (widthInCU - cuX - 1) * cuSize + 8; c.mvmax.y = (heightInCU - cuY - 1) * cuSize + 8;
+            /* reverse-order mv prediction (:3266-3282) */
+            int numc = 0, mvc[4][2];
+            const int32_t* fencMV = mvs + 2 * cuXY;
+#define MVC(IDX) do { mvc[numc][0] = fencMV[2 * (IDX)]; mvc[numc][1] = fencMV[2 * (IDX) + 1]; numc++; } while (0)
+            if (cuX < widthInCU - 1) MVC(1);
+            if (!lastRow)
+            {
+                MVC(widthInCU);
+                if (cuX > 0) MVC(widthInCU - 1);
+                if (cuX < widthInCU - 1) MVC(widthInCU + 1);
+            }
+#undef MVC
+            int mvpx = 0, mvpy = 0;
+            if (numc)
+            {
+                int mvpcost = 0x7fffffff;
+                for (int idx = 0; idx < numc; idx++)
+                {
+                    /* bufSATD over lowresMC's prediction = the SATD flavour of lowresQPelCost (lowres.h:66-93) */
+                    const int cst = lowres_qpel_cost(&c, mvc[idx][0], mvc[idx][1], 1);
+                    if (cst < mvpcost) { mvpcost = cst; mvpx = mvc[idx][0]; mvpy = mvc[idx][1]; }
+                }
+            }
+            c.mvpx = mvpx; c.mvpy = mvpy;
+            int qx = 0, qy = 0;
+            const int fencCost = motion_estimate_one(&c, ME_HEX, 1, merange, NULL, 0, &qx, &qy);
+            mvs[2 * cuXY] = qx; mvs[2 * cuXY + 1] = qy;
+            mvCosts[cuXY] = fencCost;
+            int bcost = fencCost, listused = 1;
+            bcost += lowresPenalty;
+            if (intraCost[cuXY] < bcost) { bcost = intraCost[cuXY]; listused = 0; }
+            const int bFrameScoreCU = (cuX > 0 && cuX < widthInCU - 1 && cuY > 0 && cuY < heightInCU - 1) || widthInCU <= 2 || heightInCU <= 2;
+            const int bcostAq = (bFrameScoreCU && invQscale) ? ((bcost * invQscale[cuXY] + 128) >> 8) : bcost;
+            if (bFrameScoreCU)
+            {
+                costEst += bcost; costEstAq += bcostAq;
+                if (!listused) intraMbs++;
+            }
+            rowSatds[cuY] += bcostAq;
+            lowresCosts[cuXY] = (uint16_t)((bcost < 0x3fff ? bcost : 0x3fff) | (listused << 14));
+        }
+    }
+    frame[0] = costEst; frame[1] = costEstAq; frame[2] = intraMbs;
+    return 0;
 }

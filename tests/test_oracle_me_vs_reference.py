@@ -169,6 +169,50 @@ def test_lookahead_restatement_equals_reference_classes(depth, width, height):
     assert np.array_equal(cost, rcost) and np.array_equal(mode, rmode) and np.array_equal(lc, rlc)
 
 
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 208, 144), (10, 192, 128)])
+def test_lowres_frame_cost_restatement_equals_reference_classes(depth, width, height):
+    """oracle/x265_oracle_search.c::x265oracle_lowres_cost against the real CostEstimateGroup::singleCost(0, 1, 1)
+    (oracle/ref_lookahead.cpp): the lookahead's P-frame cost estimate - neighbour-mv predictors, HEX search on the four
+    half-pel phase planes, intra competition - mv, mv cost and lowresCosts of every 8x8 block, rowSatds, costEst, intraMbs."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_lowres_cost"):
+        pytest.skip("oracle/_ref predates x265ref_lowres_cost")
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=91)
+    rng = np.random.default_rng([13, depth, width])
+    y0 = clip[0][0]
+    # the current picture: the reference shifted by a global motion plus local differences, so that mvs, intra wins and
+    # zero-residual blocks all occur
+    y1 = np.roll(y0, (3, -5), axis=(0, 1)).copy()
+    y1[: height // 3] = clip[1][0][: height // 3]
+    y1[-32:, -64:] = y0[-32:, -64:]
+    noise = rng.integers(-2, 3, size=y1.shape) << (depth - 8)
+    y1[:, : width // 2] = np.clip(y1[:, : width // 2].astype(np.int32) + noise[:, : width // 2], 0, (1 << depth) - 1).astype(y1.dtype)
+    cur, stride, org, w64, h64 = F.pad_plane(y1)
+    ref = F.pad_plane(y0)[0]
+    wcu, hcu = (width // 2 + 7) >> 3, (height // 2 + 7) >> 3
+    lw, lh = wcu * 8, hcu * 8
+    n = wcu * hcu
+    rmv, rmc, rlc = np.zeros((n, 2), np.int32), np.zeros(n, np.int32), np.zeros(n, np.uint16)
+    rrows, rframe = np.zeros(hcu, np.int32), np.zeros(4, np.int64)
+    lib.x265ref_lowres_cost.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
+    assert lib.x265ref_lowres_cost(cur.ctypes.data, ref.ctypes.data, width, height, rmv.ctypes.data, rmc.ctypes.data,
+                                   rlc.ctypes.data, rrows.ctypes.data, rframe.ctypes.data) == 0
+    rstride = (width // 2 + 2 * F.MARGIN_X + 31) & ~31
+    rows = lh + 2 * F.MARGIN_Y
+    lorg = rstride * F.MARGIN_Y + F.MARGIN_X
+    cplanes = O.lowres_init(depth, cur, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    rplanes = O.lowres_init(depth, ref, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    lam = 1.0 if depth == 8 else 16.0            # x265_lambda_tab[X265_LOOKAHEAD_QP]
+    icost, _, _ = O.lowres_intra(depth, cplanes[0], rstride, lorg, wcu, hcu, 5 * int(lam))
+    cq, qoff = F.qpel_cost_table(16, lam=lam, qmax=4 * (max(lw, lh) + 64))
+    mvs, mvc, lc, rws, frame = O.lowres_cost(depth, cplanes[0], rplanes, rstride, lorg, wcu, hcu, cq, qoff, icost)
+    assert np.array_equal(mvs, rmv), f"mvs differ at {np.flatnonzero((mvs != rmv).any(axis=1))[:8]}"
+    assert np.array_equal(mvc, rmc) and np.array_equal(lc, rlc) and np.array_equal(rws, rrows)
+    assert (frame[0], frame[1], frame[2]) == (rframe[1], rframe[2], rframe[3]) and rframe[0] == rframe[1]
+    assert (mvs != 0).any() and ((lc >> 14) == 0).any() and ((lc >> 14) == 1).any()
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_search_driver_with_extra_candidates_equals_reference(depth):
     """motionEstimate's mvc[] candidates (motion.cpp:800-812: measured with SAD + mv cost against the predictor's cost, skipping
