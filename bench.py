@@ -136,11 +136,14 @@ def main():
     ap.add_argument("--search-probe", action="store_true",
                     help="instead of the pipeline line, time the search drivers over every PU of a frame with the CPU restatement beside "
                          "them (tools/search_probe.py)")
+    ap.add_argument("--lookahead-probe", action="store_true",
+                    help="instead of the pipeline line, time the lookahead P-frame cost estimate (x265hip_lowres_cost) for one picture and "
+                         "for batches of independent pictures on separate streams, CPU restatement beside it (tools/lookahead_probe.py)")
     args, rest = ap.parse_known_args()
-    if args.prims or args.search_probe:
+    if args.prims or args.search_probe or args.lookahead_probe:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
-        sys.argv = [sys.argv[0]] + rest + ([str(args.width), str(args.height)] if args.search_probe else [])
-        mod = importlib.import_module("bench_prims" if args.prims else "search_probe")
+        sys.argv = [sys.argv[0]] + rest + ([] if args.prims else [str(args.width), str(args.height)])
+        mod = importlib.import_module("bench_prims" if args.prims else ("search_probe" if args.search_probe else "lookahead_probe"))
         if hasattr(mod, "main"):
             mod.main()
         return

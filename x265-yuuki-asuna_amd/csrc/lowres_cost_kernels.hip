@@ -1,0 +1,313 @@
+// lowres_cost_kernels.hip - the lookahead's P-frame cost estimate on gfx950 (the motion half).
+//
+// Reference semantics: CostEstimateGroup::estimateFrameCost / estimateCUCost for b == p1 (encoder/slicetype.cpp:3189-3198,
+// 3216-3388) over MotionEstimate::motionEstimate's lowres flavour (encoder/motion.cpp:775-776 predictor measure, HEX :852-948,
+// :1452-1469, sub-pel :1471-1503) and ReferencePlanes::lowresQPelCost / lowresMC (common/lowres.h:66-121: half-pel positions
+// read one of the four phase planes, quarter-pel positions average two with pixelavg_pp).
+//
+// Every 8x8 block needs the final mvs of its right neighbour and of three blocks of the row below, so a picture is a wavefront:
+// row r (counted from the bottom) works on block W-1-(t-2r) at step t.  One workgroup walks it in lockstep - a DPP quad per row
+// (lane = one 4x4 tile of the block), one barrier per step, mvs exchanged through the output array with workgroup-scope accesses.
+// The step time is the latency of one HEX search, so a single picture cannot fill the chip: callers batch independent pictures
+// (frame-parallel encoding has them) on separate streams.
+#include "pu_eval.h"
+
+namespace x265hip {
+
+struct LowresCostArgs
+{
+    const x265hip_lowres_cost_pair* pairs;     // device copy, one per workgroup
+    int strideB, W, H, depth;
+    const uint16_t* cost;
+};
+struct LowresPairArgs
+{
+    const uint8_t* cur; const uint8_t* ref[4];
+    const int32_t* intraCost; const int32_t* invQscale;
+    unsigned long long* mvs; int32_t* mvCosts; uint16_t* lowresCosts; int32_t* rowSatds; long long* frame;
+};
+
+// the four phase planes, biased like PuEval::base; passed by value so that they stay in registers
+struct PhasePlanes { const uint8_t *p0, *p1, *p2, *p3; };
+
+template <typename Px>
+struct LowresPu
+{
+    static constexpr int BPP = sizeof(Px);
+    PuEval<Px, 4, 1> c;
+
+    static __device__ __forceinline__ const uint8_t* plane(const PhasePlanes pp, int h) { return h == 0 ? pp.p0 : (h == 1 ? pp.p1 : (h == 2 ? pp.p2 : pp.p3)); }
+    __device__ __forceinline__ void load_tile(const uint8_t* base, uint32_t off, int (&p)[4][4]) const
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const uint8_t* rp = base + (off + (uint32_t)(r * c.strideB));
+            if (BPP == 1)
+            {
+                const uint32_t w = ld_u32(rp);
+#pragma unroll
+                for (int x = 0; x < 4; x++) p[r][x] = (int)((w >> (8 * x)) & 0xff);
+            }
+            else
+            {
+                const uint32_t w0 = ld_u32(rp), w1 = ld_u32(rp + 4);
+                p[r][0] = (int)(w0 & 0xffff); p[r][1] = (int)(w0 >> 16); p[r][2] = (int)(w1 & 0xffff); p[r][3] = (int)(w1 >> 16);
+            }
+        }
+    }
+    // lowresQPelCost (lowres.h:95-121) with sad or satd; also lowresMC + bufSATD (:66-93, slicetype.cpp:3293-3295)
+    __device__ __forceinline__ int qpel_cost(const PhasePlanes pp, int qx, int qy, bool useSatd) const
+    {
+        int p[4][4];
+        const int hA = (qy & 2) | ((qx & 2) >> 1);
+        load_tile(plane(pp, hA), c.refOrg[0] + (uint32_t)((qy >> 2) * c.strideB + (qx >> 2) * BPP), p);
+        if ((qx | qy) & 1)
+        {
+            int pb[4][4];
+            const int qx2 = qx + (qx & 1), qy2 = qy + (qy & 1);
+            const int hB = (qy2 & 2) | ((qx2 & 2) >> 1);
+            load_tile(plane(pp, hB), c.refOrg[0] + (uint32_t)((qy2 >> 2) * c.strideB + (qx2 >> 2) * BPP), pb);
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) p[y][x] = (p[y][x] + pb[y][x] + 1) >> 1;          // pixelavg_pp, weight 32
+        }
+        int acc = 0;
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                const int s = BPP == 1 ? (int)((c.src[0][y][0] >> (8 * x)) & 0xff) : (int)((c.src[0][y][x >> 1] >> (16 * (x & 1))) & 0xffff);
+                p[y][x] = s - p[y][x];
+            }
+        if (useSatd) acc = tile_satd4(p);
+        else
+        {
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) acc += abs(p[y][x]);
+        }
+        return quad_sum(acc);
+    }
+};
+
+// MotionEstimate::motionEstimate, lowres flavour, HEX, merange 16, subpelRefine 1, no extra candidates
+template <typename Px>
+__device__ __forceinline__ int lowres_motion_estimate(const LowresPu<Px>& L, const PhasePlanes pp, int& outx, int& outy)
+{
+    const PuEval<Px, 4, 1>& c = L.c;
+    const int qminx = c.mvmin.x * 4, qminy = c.mvmin.y * 4, qmaxx = c.mvmax.x * 4, qmaxy = c.mvmax.y * 4;
+    const int pmvx = s_clip3(qminx, qmaxx, c.mvpx), pmvy = s_clip3(qminy, qmaxy, c.mvpy);
+    // the three start measures are independent: issue them together (one memory round trip), then decide in the reference's order
+    SMv bmv = { (pmvx + 2) >> 2, (pmvy + 2) >> 2 };
+    const int bprecost = L.qpel_cost(pp, pmvx, pmvy, false);
+    const int roundedCost = c.cost_mv(bmv.x, bmv.y);
+    const int zeroCost = c.sad_at(0, 0) + c.mvcost_q(0, 0);
+    int bcost = bprecost;
+    if ((pmvx | pmvy) & 3) bcost = roundedCost;
+    if (pmvx | pmvy)
+    {
+        const int cost = zeroCost;
+        if (cost < bcost)
+        {
+            bcost = cost;
+            bmv.x = 0;
+            const int zy = 0 < c.mvmax.y ? 0 : c.mvmax.y;
+            bmv.y = zy > c.mvmin.y ? zy : c.mvmin.y;
+        }
+    }
+    hex_search<Px, 4, 1>(c, bmv, bcost, 16);
+    int bx, by;
+    if (bprecost < bcost) { bx = pmvx; by = pmvy; bcost = bprecost; }
+    else { bx = bmv.x * 4; by = bmv.y * 4; }
+    if (!bcost)
+        bcost = c.mvcost_q(bx, by);
+    else
+    {
+        // each round scores its four directions (workload[1]: 4 half-pel, 4 quarter-pel) together, then picks in order
+        int bdir = 0, cs[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int qx = bx + kSSquare1[i + 1].x * 2, qy = by + kSSquare1[i + 1].y * 2;
+            cs[i] = L.qpel_cost(pp, qx, qy, false) + c.mvcost_q(qx, qy);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int qy = by + kSSquare1[i + 1].y * 2;
+            if ((qy < qminy) | (qy > qmaxy)) continue;
+            if (cs[i] < bcost) { bcost = cs[i]; bdir = i + 1; }
+        }
+        bx += kSSquare1[bdir].x * 2; by += kSSquare1[bdir].y * 2;
+        bcost = L.qpel_cost(pp, bx, by, true) + c.mvcost_q(bx, by);
+        bdir = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int qx = bx + kSSquare1[i + 1].x, qy = by + kSSquare1[i + 1].y;
+            cs[i] = L.qpel_cost(pp, qx, qy, true) + c.mvcost_q(qx, qy);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int qy = by + kSSquare1[i + 1].y;
+            if ((qy < qminy) | (qy > qmaxy)) continue;
+            if (cs[i] < bcost) { bcost = cs[i]; bdir = i + 1; }
+        }
+        bx += kSSquare1[bdir].x; by += kSSquare1[bdir].y;
+    }
+    outx = bx; outy = by;
+    return bcost;
+}
+
+template <typename Px>
+__global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
+{
+    LowresPairArgs a;
+    {
+        const x265hip_lowres_cost_pair pr = g.pairs[blockIdx.x];
+        a.cur = (const uint8_t*)pr.cur;
+        a.ref[0] = (const uint8_t*)pr.ref[0]; a.ref[1] = (const uint8_t*)pr.ref[1]; a.ref[2] = (const uint8_t*)pr.ref[2]; a.ref[3] = (const uint8_t*)pr.ref[3];
+        a.intraCost = pr.intra_cost; a.invQscale = pr.inv_qscale;
+        a.mvs = (unsigned long long*)pr.mvs; a.mvCosts = pr.mv_costs; a.lowresCosts = pr.lowres_costs; a.rowSatds = pr.row_satds;
+        a.frame = (long long*)pr.frame;
+    }
+    constexpr int BPP = sizeof(Px);
+    constexpr uint32_t kBias = 1u << 30;
+    const int Q = blockDim.x >> 2;                    // rows in flight: one quad each
+    const int q = threadIdx.x >> 2, l = threadIdx.x & 3;
+    const int tx = l & 1, ty = l >> 1;
+    const int W = g.W, H = g.H;
+    const int steps = W + 2 * (H - 1);
+    __shared__ long long sFrame[3];
+    if (threadIdx.x < 3) sFrame[threadIdx.x] = 0;
+    __syncthreads();
+    long long costEst = 0, costEstAq = 0;
+    int intraMbs = 0, rowSatd = 0;
+    int rightx = 0, righty = 0;                       // the finished block to the right (this quad's previous result)
+    LowresPu<Px> L;
+    L.c.base = a.ref[0] - kBias;
+    const PhasePlanes pp = { a.ref[0] - kBias, a.ref[1] - kBias, a.ref[2] - kBias, a.ref[3] - kBias };
+    L.c.strideB = g.strideB; L.c.depth = g.depth; L.c.cost = g.cost;
+    L.c.have[0] = true;
+    for (int t = 0; t < steps; t++)
+    {
+        // quad q walks rows q, q + Q, q + 2Q ... (counted from the bottom); W <= 2Q keeps at most one of them active per step
+        int ry = -1, cuX = 0;
+        if (t >= 2 * q)
+        {
+            const int k = (t - 2 * q) / (2 * Q), r = q + k * Q, dx = t - 2 * r;
+            if (r < H && dx < W) { ry = r; cuX = W - 1 - dx; }
+        }
+        if (ry >= 0)
+        {
+            const int cuY = H - 1 - ry, cuXY = cuX + cuY * W;
+            const uint32_t pel = (uint32_t)((cuY * 8 + ty * 4) * g.strideB + (cuX * 8 + tx * 4) * BPP);
+            L.c.refOrg[0] = kBias + pel;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int d = 0; d < BPP; d++) L.c.src[0][r][d] = ld_u32(a.cur + (pel + (uint32_t)(r * g.strideB + 4 * d)));
+            L.c.mvmin.x = -cuX * 8 - 8; L.c.mvmin.y = -cuY * 8 - 8;
+            L.c.mvmax.x = (W - cuX - 1) * 8 + 8; L.c.mvmax.y = (H - cuY - 1) * 8 + 8;
+            // reverse-order mv prediction (:3266-3301): right, below, below-left, below-right; the cheapest SATD wins (strict <)
+            // The (up to) four finished neighbours are fetched and scored together; invalid ones score a dummy position that
+            // the selection below skips.
+            const bool vR = cuX < W - 1, vB = ry > 0, vBL = vB && cuX > 0, vBR = vB && cuX < W - 1;
+            auto finished = [&](bool valid, int idx, int& mx, int& my)
+            {
+                const unsigned long long v = __hip_atomic_load(&a.mvs[valid ? idx : cuXY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                mx = valid ? (int)(uint32_t)v : 0; my = valid ? (int)(uint32_t)(v >> 32) : 0;
+            };
+            int cx[4], cy[4], cc[4];
+            cx[0] = vR ? rightx : 0; cy[0] = vR ? righty : 0;
+            finished(vB, cuXY + W, cx[1], cy[1]);
+            finished(vBL, cuXY + W - 1, cx[2], cy[2]);
+            finished(vBR, cuXY + W + 1, cx[3], cy[3]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) cc[i] = L.qpel_cost(pp, cx[i], cy[i], true);
+            const bool cv[4] = { vR, vB, vBL, vBR };
+            int mvpx = 0, mvpy = 0, mvpcost = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (cv[i] && cc[i] < mvpcost) { mvpcost = cc[i]; mvpx = cx[i]; mvpy = cy[i]; }
+            L.c.mvpx = mvpx; L.c.mvpy = mvpy;
+            int qx, qy;
+            const int fencCost = lowres_motion_estimate<Px>(L, pp, qx, qy);
+            rightx = qx; righty = qy;
+            int bcost = fencCost + 4, listused = 1;                                 // lowresPenalty
+            const int ic = a.intraCost[cuXY];
+            if (ic < bcost) { bcost = ic; listused = 0; }
+            const bool scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+            const int bcostAq = (scored && a.invQscale) ? ((bcost * a.invQscale[cuXY] + 128) >> 8) : bcost;
+            if (scored) { costEst += bcost; costEstAq += bcostAq; intraMbs += !listused; }
+            if (cuX == W - 1) rowSatd = 0;
+            rowSatd += bcostAq;
+            if (l == 0)
+            {
+                __hip_atomic_store(&a.mvs[cuXY], (unsigned long long)(uint32_t)qx | ((unsigned long long)(uint32_t)qy << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                a.mvCosts[cuXY] = fencCost;
+                a.lowresCosts[cuXY] = (uint16_t)((bcost < 0x3fff ? bcost : 0x3fff) | (listused << 14));
+                if (cuX == 0) a.rowSatds[cuY] = rowSatd;
+            }
+        }
+        // the exchange stays inside one workgroup (one CU, one L1 / L2): the barrier's workgroup-scope fence is all it needs - an
+        // agent-scope fence would write the L2 back every step
+        __syncthreads();
+    }
+    if (l == 0)
+    {
+        atomicAdd((unsigned long long*)&sFrame[0], (unsigned long long)costEst);
+        atomicAdd((unsigned long long*)&sFrame[1], (unsigned long long)costEstAq);
+        atomicAdd((unsigned long long*)&sFrame[2], (unsigned long long)intraMbs);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) a.frame[threadIdx.x] = sFrame[threadIdx.x];
+}
+
+} // namespace x265hip
+
+using namespace x265hip;
+
+extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->cost_q || !p->pairs) { set_error("lowres_cost: NULL operand"); return X265HIP_EINVAL; }
+    if (p->npairs < 0) { set_error("lowres_cost: npairs %d", p->npairs); return X265HIP_EINVAL; }
+    if (p->npairs == 0) return 0;
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("lowres_cost: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->width_in_cu <= 0 || p->height_in_cu <= 0) { set_error("lowres_cost: empty picture"); return X265HIP_EINVAL; }
+    for (int i = 0; i < p->npairs; i++)
+    {
+        const x265hip_lowres_cost_pair& q = p->pairs[i];
+        if (!q.cur || !q.ref[0] || !q.ref[1] || !q.ref[2] || !q.ref[3] || !q.intra_cost || !q.mvs || !q.mv_costs || !q.lowres_costs || !q.row_satds || !q.frame)
+        { set_error("lowres_cost: NULL operand in pair %d", i); return X265HIP_EINVAL; }
+        if (((uintptr_t)q.mvs) & 7) { set_error("lowres_cost: mvs of pair %d must be 8-byte aligned", i); return X265HIP_EINVAL; }
+    }
+    int quads = (p->height_in_cu + 15) & ~15;
+    if (quads > 256) quads = 256;
+    if (p->width_in_cu > 2 * quads) { set_error("lowres_cost: %d blocks per row need more than %d rows in flight", p->width_in_cu, quads); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    hipStream_t s = (hipStream_t)stream;
+    // the pair table travels in stream order: allocated, filled, used and released on `s`
+    x265hip_lowres_cost_pair* dpairs = nullptr;
+    const size_t bytes = sizeof(x265hip_lowres_cost_pair) * (size_t)p->npairs;
+    X265HIP_TRY(hipMallocAsync((void**)&dpairs, bytes, s));
+    X265HIP_TRY(hipMemcpyAsync(dpairs, p->pairs, bytes, hipMemcpyHostToDevice, s));
+    LowresCostArgs a;
+    a.pairs = dpairs;
+    a.strideB = (int)(p->stride * bpp);
+    a.W = p->width_in_cu; a.H = p->height_in_cu; a.depth = p->depth;
+    a.cost = p->cost_q + p->qoff;
+    if (bpp == 1) hipLaunchKernelGGL(lowres_cost_kernel<uint8_t>, dim3(p->npairs), dim3(quads * 4), 0, s, a);
+    else hipLaunchKernelGGL(lowres_cost_kernel<uint16_t>, dim3(p->npairs), dim3(quads * 4), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    X265HIP_TRY(hipFreeAsync(dpairs, s));
+    return 0;
+}

@@ -1,0 +1,182 @@
+// pu_eval.h - a PU held by a lane group (quad / 16-lane row / wavefront) and scored candidate by candidate: shared by the search
+// drivers (search_kernels.hip) and the lookahead cost estimate (lowres_cost_kernels.hip).
+#pragma once
+#include "tile_interp.h"
+
+namespace x265hip {
+
+struct SMv { int x, y; };
+
+static __constant__ SMv kSHex2[8] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
+static __constant__ unsigned char kSMod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+static __constant__ SMv kSSquare1[9] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+static __constant__ SMv kSOffsets[16] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
+                                   { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
+static __constant__ int kSWorkload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+                                      { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+
+// sum over the G lanes of a group, result in every lane of the group
+template <int G> __device__ __forceinline__ int group_total(int v)
+{
+    if (G == 4) return quad_sum(v);
+    if (G == 16) return row_sum(v);
+    return wave_sum_of_rows(row_sum(v));
+}
+
+template <typename Px, int G, int T>
+struct PuEval
+{
+    static constexpr int BPP = sizeof(Px);
+    static constexpr int DW = BPP;                 // dwords per 4-sample tile row
+    const uint8_t* base;                            // wave-uniform: reference plane origin minus kBias bytes
+    uint32_t refOrg[T];                             // byte offset from `base` of the reference under each of the lane's tiles (mv 0)
+    uint32_t src[T][4][DW];                         // the lane's source tiles, packed
+    bool have[T];
+    int strideB;
+    int depth;
+    const uint16_t* cost;
+    int mvpx, mvpy;
+    SMv mvmin, mvmax;
+
+    __device__ __forceinline__ int mvcost_q(int qx, int qy) const { return (int)cost[qx - mvpx] + (int)cost[qy - mvpy]; }
+    __device__ __forceinline__ bool in_range(int x, int y) const { return x >= mvmin.x && x <= mvmax.x && y >= mvmin.y && y <= mvmax.y; }
+
+    // SAD of the PU at integer displacement (mx, my)
+    __device__ __forceinline__ int sad_at(int mx, int my) const
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < T; k++)
+        {
+            if (!have[k]) continue;
+            const uint32_t ro = refOrg[k] + (uint32_t)(my * strideB + mx * BPP);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < DW; q++)
+                    acc = sad_dw<Px>(ld_u32(base + (ro + (uint32_t)(r * strideB + 4 * q))), src[k][r][q], acc);
+        }
+        return group_total<G>((int)acc);
+    }
+    __device__ __forceinline__ int cost_mv(int mx, int my) const { return sad_at(mx, my) + mvcost_q(mx * 4, my * 4); }
+
+    // N candidates at once (the reference's sad_x3 / sad_x4 groups): all reference loads are issued before the first
+    // reduction, so one memory round trip serves the group
+    template <int N>
+    __device__ __forceinline__ void cost_mv_n(const int (&mx)[N], const int (&my)[N], int (&out)[N]) const
+    {
+        uint32_t acc[N];
+#pragma unroll
+        for (int n = 0; n < N; n++) acc[n] = 0;
+#pragma unroll
+        for (int k = 0; k < T; k++)
+        {
+            if (!have[k]) continue;
+#pragma unroll
+            for (int n = 0; n < N; n++)
+            {
+                const uint32_t ro = refOrg[k] + (uint32_t)(my[n] * strideB + mx[n] * BPP);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int q = 0; q < DW; q++)
+                        acc[n] = sad_dw<Px>(ld_u32(base + (ro + (uint32_t)(r * strideB + 4 * q))), src[k][r][q], acc[n]);
+            }
+            // at most 64 dwords in flight per lane: larger groups go one tile at a time
+            if (N * T * 4 * DW > 64) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int n = 0; n < N; n++) out[n] = group_total<G>((int)acc[n]) + mvcost_q(mx[n] * 4, my[n] * 4);
+    }
+
+    // subpelCompare: SAD or SATD of the PU at quarter-pel displacement (qx, qy)
+    __device__ __forceinline__ int cmp_q(int qx, int qy, bool useSatd) const
+    {
+        if (!((qx | qy) & 3) && !useSatd) return sad_at(qx >> 2, qy >> 2);
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < T; k++)
+        {
+            if (!have[k]) continue;
+            int d[4][4];
+            tile_predict<BPP>(base + (refOrg[k] + (uint32_t)((qy >> 2) * strideB + (qx >> 2) * BPP)), (long)strideB, qx & 3, qy & 3, depth, d);
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    const int s = BPP == 1 ? (int)((src[k][y][0] >> (8 * x)) & 0xff) : (int)((src[k][y][x >> 1] >> (16 * (x & 1))) & 0xffff);
+                    d[y][x] = s - d[y][x];
+                }
+            if (useSatd) acc += tile_satd4(d);
+            else
+            {
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) acc += abs(d[y][x]);
+            }
+            __builtin_amdgcn_sched_barrier(0);        // one tile's interpolation at a time: bounds the register footprint
+        }
+        return group_total<G>(acc);
+    }
+};
+
+
+__device__ __forceinline__ int s_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// X265_HEX_SEARCH (motion.cpp:852-948): first hexagon, directional half-hexagon walk, square refine
+template <typename Px, int G, int T>
+__device__ __forceinline__ void hex_search(const PuEval<Px, G, T>& c, SMv& bmv, int& bcost, int merange)
+{
+    int costs[4];
+#define YOK(DY) ((bmv.y + (DY) >= c.mvmin.y) & (bmv.y + (DY) <= c.mvmax.y))
+#define LT(V) do { const int v_ = (V); if (v_ < bcost) bcost = v_; } while (0)
+#define X3(D0X, D0Y, D1X, D1Y, D2X, D2Y) do { const int mxs_[3] = { bmv.x + (D0X), bmv.x + (D1X), bmv.x + (D2X) }, mys_[3] = { bmv.y + (D0Y), bmv.y + (D1Y), bmv.y + (D2Y) }; \
+                                              int cs_[3]; c.template cost_mv_n<3>(mxs_, mys_, cs_); costs[0] = cs_[0]; costs[1] = cs_[1]; costs[2] = cs_[2]; } while (0)
+        X3(-2, 0, -1, 2, 1, 2);
+        bcost <<= 3;
+        if (YOK(0)) LT((costs[0] << 3) + 2);
+        if (YOK(2)) { LT((costs[1] << 3) + 3); LT((costs[2] << 3) + 4); }
+        X3(2, 0, 1, -2, -1, -2);
+        if (YOK(0)) LT((costs[0] << 3) + 5);
+        if (YOK(-2)) { LT((costs[1] << 3) + 6); LT((costs[2] << 3) + 7); }
+        if (bcost & 7)
+        {
+            int dir = (bcost & 7) - 2;
+            if (YOK(kSHex2[dir + 1].y))
+            {
+                bmv.x += kSHex2[dir + 1].x; bmv.y += kSHex2[dir + 1].y;
+                for (int i = (merange >> 1) - 1; i > 0 && c.in_range(bmv.x, bmv.y); i--)
+                {
+                    X3(kSHex2[dir + 0].x, kSHex2[dir + 0].y, kSHex2[dir + 1].x, kSHex2[dir + 1].y, kSHex2[dir + 2].x, kSHex2[dir + 2].y);
+                    bcost &= ~7;
+                    if (YOK(kSHex2[dir + 0].y)) LT((costs[0] << 3) + 1);
+                    if (YOK(kSHex2[dir + 1].y)) LT((costs[1] << 3) + 2);
+                    if (YOK(kSHex2[dir + 2].y)) LT((costs[2] << 3) + 3);
+                    if (!(bcost & 7)) break;
+                    dir += (bcost & 7) - 2;
+                    dir = kSMod6m1[dir + 1];
+                    bmv.x += kSHex2[dir + 1].x; bmv.y += kSHex2[dir + 1].y;
+                }
+            }
+        }
+        bcost >>= 3;
+        int dir = 0;
+        { const int mxs[4] = { bmv.x, bmv.x, bmv.x - 1, bmv.x + 1 }, mys[4] = { bmv.y - 1, bmv.y + 1, bmv.y, bmv.y }; c.template cost_mv_n<4>(mxs, mys, costs); }
+        if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 1; }
+        if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 2; }
+        if (costs[2] < bcost) { bcost = costs[2]; dir = 3; }
+        if (costs[3] < bcost) { bcost = costs[3]; dir = 4; }
+        { const int mxs[4] = { bmv.x - 1, bmv.x - 1, bmv.x + 1, bmv.x + 1 }, mys[4] = { bmv.y - 1, bmv.y + 1, bmv.y - 1, bmv.y + 1 }; c.template cost_mv_n<4>(mxs, mys, costs); }
+        if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 5; }
+        if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 6; }
+        if (YOK(-1) && costs[2] < bcost) { bcost = costs[2]; dir = 7; }
+        if (YOK(1) && costs[3] < bcost) { bcost = costs[3]; dir = 8; }
+        bmv.x += kSSquare1[dir].x; bmv.y += kSSquare1[dir].y;
+#undef X3
+#undef YOK
+#undef LT
+}
+
+} // namespace x265hip

@@ -121,6 +121,40 @@ class Lookahead:
         return {"intra_cost": int(self.intra_cost.sum(dtype=torch.int64).item()), "intra_mode": int(self.intra_mode.sum(dtype=torch.int64).item())}
 
 
+class LookaheadCost:
+    """The lookahead's P-frame cost estimate of a prepared picture against a prepared reference (x265hip_lowres_cost; reference
+    CostEstimateGroup::estimateFrameCost / estimateCUCost, slicetype.cpp:3189-3388).  `lam` is x265_lambda_tab[X265_LOOKAHEAD_QP]
+    (1.0 for 8-bit, 16.0 for 10-bit); the mv cost table is built on the host like BitCost's (bitcost.cpp:51-55,103-118)."""
+
+    def __init__(self, la: Lookahead, device, lam=None):
+        import numpy as np
+        import torch
+        from . import frames as F
+        self.depth = la.depth
+        lam = (1.0 if la.depth == 8 else (16.0 if la.depth == 10 else 64.0)) if lam is None else lam
+        cq, self.qoff = F.qpel_cost_table(16, lam=lam, qmax=4 * (max(la.width, la.lines) + 64))
+        self.cost_q = torch.from_numpy(cq.view(np.int16)).to(device)
+        n = la.wcu * la.hcu
+        self.mvs = torch.zeros(n * 2, dtype=torch.int32, device=device)
+        self.mv_costs = torch.zeros(n, dtype=torch.int32, device=device)
+        self.lowres_costs = torch.zeros(n, dtype=torch.int16, device=device)
+        self.row_satds = torch.zeros(la.hcu, dtype=torch.int32, device=device)
+        self.frame = torch.zeros(3, dtype=torch.int64, device=device)
+
+    def pair(self, cur: Lookahead, ref: Lookahead):
+        return hipabi.lowres_cost_pair(self.depth, cur.org, cur.planes[0], ref.planes, cur.intra_cost, self.mvs, self.mv_costs,
+                                       self.lowres_costs, self.row_satds, self.frame)
+
+    def run(self, cur: Lookahead, ref: Lookahead, stream=None):
+        hipabi.lowres_cost(self.depth, cur.stride, cur.wcu, cur.hcu, self.cost_q, self.qoff, [self.pair(cur, ref)], stream=stream)
+
+    @staticmethod
+    def run_batch(stages, curs, refs, stream=None):
+        """One launch for many independent pictures of one geometry (one workgroup each)."""
+        s0, c0 = stages[0], curs[0]
+        hipabi.lowres_cost(s0.depth, c0.stride, c0.wcu, c0.hcu, s0.cost_q, s0.qoff, [s.pair(c, r) for s, c, r in zip(stages, curs, refs)], stream=stream)
+
+
 class PatternSearch:
     """Motion search drivers for every 8x8..64x64 PU of every CTU (x265hip_me_search; reference
     MotionEstimate::motionEstimate, motion.cpp:739-1561) with predictor (0,0): integer pattern + sub-pel refinement in
