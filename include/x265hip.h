@@ -193,8 +193,9 @@ typedef struct x265hip_me_search_params
 } x265hip_me_search_params;
 int x265hip_me_search(const x265hip_me_search_params* p, void* stream);
 
-/* Lookahead P-frame cost estimate - CostEstimateGroup::estimateFrameCost + estimateCUCost for b == p1 (one list, no HME, no
- * weighted reference; encoder/slicetype.cpp:3189-3198,3216-3388): every 8x8 block of the half-resolution picture, in the
+/* Lookahead frame cost estimate - CostEstimateGroup::estimateFrameCost + estimateCUCost (no HME, no weighted reference;
+ * encoder/slicetype.cpp:3115-3213,3216-3388) for P pictures (one list, intra competes) and B pictures (two lists, skip shortcut
+ * :3311-3315, the two bi-directional candidates :3322-3343, score scaling :3203-3204): every 8x8 block of the half-resolution picture, in the
  * reference's reverse raster order, tries the final mvs of its right / lower neighbours as predictors (SATD at lowresMC,
  * :3284-3301), runs MotionEstimate::motionEstimate in its lowres flavour (HEX, merange 16, subpelRefine 1, quarter-pel positions
  * from the four half-pel phase planes: motion.cpp:775,1471-1503, lowres.h:66-121), adds lowresPenalty and lets the intra cost win
@@ -203,17 +204,23 @@ int x265hip_me_search(const x265hip_me_search_params* p, void* stream);
  *   cur: pixel (0,0) of the current picture's plane 0; ref[0..3]: pixel (0,0) of the reference's planes (lowres_init's outputs);
  *   intra_cost: x265hip_lowres_intra's output for the current picture; inv_qscale: optional (fenc->invQscaleFactor) or NULL.
  * Outputs: mvs int32 [n][2] quarter-pel (lowresMvs), mv_costs int32 [n] (lowresMvCosts), lowres_costs uint16 [n]
- * (cost | listused << 14), row_satds int32 [height_in_cu], frame int64 [3] = { costEst, costEstAq, intraMbs }.
+ * (cost | listused << 14), row_satds int32 [height_in_cu], frame int64 [4] = { costEst, costEstAq, intraMbs, score }.
+ * All pairs of one call are P or all are B.
  * A call takes `npairs` independent (current, reference) pairs of one geometry - `pairs` is a HOST array, copied to the device in
  * stream order - and runs one workgroup per pair.
  * Limit: width_in_cu <= 2 * min(256, height_in_cu rounded up to 16), i.e. any picture up to 8192 x 8192. */
 typedef struct x265hip_lowres_cost_pair
 {
     const void* cur;
-    const void* ref[4];
+    const void* ref[4];                             /* list 0 */
+    const void* ref1[4];                            /* list 1: a B picture (b < p1); all NULL for a P picture */
     const int32_t* intra_cost;
     const int32_t* inv_qscale;
-    int32_t* mvs;  int32_t* mv_costs;  uint16_t* lowres_costs;  int32_t* row_satds;  int64_t* frame;
+    int32_t* mvs;   int32_t* mv_costs;              /* list 0 */
+    int32_t* mvs1;  int32_t* mv_costs1;             /* list 1 */
+    int32_t do_search[2];                           /* estimateFrameCost's bDoSearch: 0 keeps the list's given mvs / mv_costs */
+    uint16_t* lowres_costs;  int32_t* row_satds;
+    int64_t* frame;                                 /* [4] = costEst (unscaled sum), costEstAq, intraMbs, score */
 } x265hip_lowres_cost_pair;
 typedef struct x265hip_lowres_cost_params
 {
@@ -221,6 +228,7 @@ typedef struct x265hip_lowres_cost_params
     intptr_t stride;
     int width_in_cu, height_in_cu;
     const uint16_t* cost_q;  int qoff;
+    int bframe_bias;                                /* param->bFrameBias: B score = costEst * 100 / (130 + bias) */
     const x265hip_lowres_cost_pair* pairs;  int npairs;
 } x265hip_lowres_cost_params;
 int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* stream);

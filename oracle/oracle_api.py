@@ -193,22 +193,32 @@ def intra_recon(depth, n, fenc, fenc_stride, nb, recon_len, recon_stride, qp, in
     return recon, levels, num_sig, dist
 
 
-def lowres_cost(depth, cur, ref_planes, stride, org, width_in_cu, height_in_cu, cost_q, qoff, intra_cost, inv_qscale=None, avx2=False):
-    """CPU restatement of CostEstimateGroup::estimateFrameCost for a P picture (slicetype.cpp:3189-3388).  cur: the current
-    picture's plane 0; ref_planes: the reference's four planes (flat arrays, pixel (0,0) at element `org`).
-    Returns (mvs int32 [n, 2], mv_costs, lowres_costs, row_satds, frame int64 [3] = costEst, costEstAq, intraMbs)."""
+def lowres_cost(depth, cur, ref_planes, stride, org, width_in_cu, height_in_cu, cost_q, qoff, intra_cost, inv_qscale=None, avx2=False,
+                ref1_planes=None, do_search=(1, 1), bframe_bias=0, mvs_in=None, mv_costs_in=None):
+    """CPU restatement of CostEstimateGroup::estimateFrameCost (slicetype.cpp:3115-3388) for a P picture (ref1_planes None) or a B
+    picture.  cur: the current picture's plane 0; ref_planes / ref1_planes: the list-0 / list-1 reference's four planes (flat arrays,
+    pixel (0,0) at element `org`).  P: returns (mvs int32 [n, 2], mv_costs, lowres_costs, row_satds, frame int64 [3] = costEst,
+    costEstAq, intraMbs).  B: returns ((mvs0, mvs1), (mv_costs0, mv_costs1), lowres_costs, row_satds, frame int64 [4] with the
+    returned score last)."""
     L = lib(avx2)
     fn = getattr(L, f"x265oracle_lowres_cost_d{depth}")
     n = width_in_cu * height_in_cu
-    mvs, mvc = np.zeros((n, 2), np.int32), np.zeros(n, np.int32)
-    lc, rows, frame = np.zeros(n, np.uint16), np.zeros(height_in_cu, np.int32), np.zeros(3, np.int64)
+    mvs = [np.zeros((n, 2), np.int32) if mvs_in is None or mvs_in[i] is None else np.ascontiguousarray(mvs_in[i], np.int32).copy() for i in range(2)]
+    mvc = [np.zeros(n, np.int32) if mv_costs_in is None or mv_costs_in[i] is None else np.ascontiguousarray(mv_costs_in[i], np.int32).copy() for i in range(2)]
+    lc, rows, frame = np.zeros(n, np.uint16), np.zeros(height_in_cu, np.int32), np.zeros(4, np.int64)
     es = cur.itemsize
     cq = np.ascontiguousarray(cost_q, dtype=np.uint16)
     ic = np.ascontiguousarray(intra_cost, dtype=np.int32)
     iq = None if inv_qscale is None else np.ascontiguousarray(inv_qscale, dtype=np.int32)
-    fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7
-    rc = fn(cur.ctypes.data + org * es, *[p.ctypes.data + org * es for p in ref_planes], stride, width_in_cu, height_in_cu,
-            cq.ctypes.data, qoff, ic.ctypes.data, None if iq is None else iq.ctypes.data, mvs.ctypes.data, mvc.ctypes.data,
+    r0 = (ctypes.c_void_p * 4)(*[p.ctypes.data + org * es for p in ref_planes])
+    r1 = None if ref1_planes is None else (ctypes.c_void_p * 4)(*[p.ctypes.data + org * es for p in ref1_planes])
+    ds = (ctypes.c_int * 2)(*do_search)
+    fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7
+    rc = fn(cur.ctypes.data + org * es, r0, r1, stride, width_in_cu, height_in_cu, cq.ctypes.data, qoff, ic.ctypes.data,
+            None if iq is None else iq.ctypes.data, ds, bframe_bias, mvs[0].ctypes.data, mvc[0].ctypes.data, mvs[1].ctypes.data, mvc[1].ctypes.data,
             lc.ctypes.data, rows.ctypes.data, frame.ctypes.data)
     assert rc == 0
-    return mvs, mvc, lc, rows, frame
+    if ref1_planes is None:
+        return mvs[0], mvc[0], lc, rows, frame[:3]
+    return (mvs[0], mvs[1]), (mvc[0], mvc[1]), lc, rows, frame

@@ -135,4 +135,67 @@ int x265ref_lowres_cost(const void* curPlane, const void* refPlane, int width, i
     return 0;
 }
 
+/* The REAL CostEstimateGroup::singleCost(0, 2, 1) for a B picture `cur` between `ref0` (list 0) and `ref1` (list 1): same set-up
+ * as x265ref_lowres_cost.  Outputs per 8x8 block: mvs0 / mvs1 int32 [n][2], mvCosts0 / mvCosts1 int32 [n], lowresCosts uint16 [n];
+ * rowSatds int32 [rows]; frame int64 [4] = { returned score, costEst (as stored: already scaled), costEstAq, intraMbs }. */
+int x265ref_lowres_cost_b(const void* curPlane, const void* ref0Plane, const void* ref1Plane, int width, int height,
+                          int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1, uint16_t* lowresCosts, int32_t* rowSatds,
+                          int64_t* frame)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width;
+    param->sourceHeight = height;
+    param->internalCsp = X265_CSP_I400;
+    param->maxCUSize = 64;
+    param->rc.aqMode = 0;
+    param->rc.hevcAq = 0;
+    param->bAQMotion = 0;
+    param->bEnableHME = 0;
+    param->bEnableWeightedPred = 0;
+    param->bEnableWeightedBiPred = 0;
+    param->lookaheadSlices = 0;
+    const int h64 = (height + 63) / 64 * 64;
+    PicYuv pics[3];
+    Lowres lrs[3];
+    const void* srcs[3] = { ref0Plane, curPlane, ref1Plane };
+    const uint32_t qgSize = 32;
+    for (int i = 0; i < 3; i++)
+    {
+        pics[i].m_param = param;
+        if (!pics[i].create(param, true)) return -1;
+        memcpy(pics[i].m_picOrg[0] - pics[i].m_lumaMarginY * pics[i].m_stride - pics[i].m_lumaMarginX, srcs[i],
+               sizeof(pixel) * pics[i].m_stride * (h64 + 2 * pics[i].m_lumaMarginY));
+        memset((void*)&lrs[i], 0, sizeof(Lowres));
+        if (!lrs[i].create(param, &pics[i], qgSize)) return -2;
+        lrs[i].init(&pics[i], i);
+    }
+    Lookahead la(param, NULL);
+    if (!la.create()) return -3;
+    la.m_tld[0].lowresIntraEstimate(lrs[1], qgSize);
+    Lowres* frames[3] = { &lrs[0], &lrs[1], &lrs[2] };
+    CostEstimateGroup estGroup(la, frames);
+    frame[0] = estGroup.singleCost(0, 2, 1);
+    Lowres& fenc = lrs[1];
+    const int ncu = fenc.maxBlocksInRow * fenc.maxBlocksInCol;
+    for (int i = 0; i < ncu; i++)
+    {
+        mvs0[2 * i] = fenc.lowresMvs[0][1][i].x; mvs0[2 * i + 1] = fenc.lowresMvs[0][1][i].y;
+        mvs1[2 * i] = fenc.lowresMvs[1][1][i].x; mvs1[2 * i + 1] = fenc.lowresMvs[1][1][i].y;
+        mvCosts0[i] = fenc.lowresMvCosts[0][1][i];
+        mvCosts1[i] = fenc.lowresMvCosts[1][1][i];
+        lowresCosts[i] = fenc.lowresCosts[1][1][i];
+    }
+    for (int y = 0; y < fenc.maxBlocksInCol; y++) rowSatds[y] = fenc.rowSatds[1][1][y];
+    frame[1] = fenc.costEst[1][1];
+    frame[2] = fenc.costEstAq[1][1];
+    frame[3] = fenc.intraMbs[1];
+    la.destroy();
+    for (int i = 0; i < 3; i++) { lrs[i].destroy(); pics[i].destroy(); }
+    x265_param_free(param);
+    return 0;
+}
+
 } // extern "C"

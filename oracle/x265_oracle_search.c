@@ -490,26 +490,51 @@ int EXPORT(x265oracle_motion_estimate_mvc)(const pixel* fenc, const pixel* fref,
 }
 
 
-/* CostEstimateGroup::estimateFrameCost + estimateCUCost for a P picture (b == p1, one list, no HME, no weighted reference):
- * slicetype.cpp:3189-3198 (reverse raster order) and :3216-3388.  Every 8x8 block of the half-resolution picture: the mvs of the
- * already finished right / lower neighbours are tried as predictors (SATD at lowresMC, :3284-3301), HEX search with merange 16
- * and subpelRefine 1 against the reference's four phase planes (:3307), + lowresPenalty, intra wins if cheaper (:3346-3356);
- * frame sums over the non-edge blocks.
- *   cur: pixel (0,0) of the current picture's plane 0; ref0..3: pixel (0,0) of the reference's four planes (same stride).
+/* lowres.h:66-93 (ReferencePlanes::lowresMC): the prediction itself - a pointer into a phase plane, or the average of two in buf */
+static const pixel* lowres_mc(const me_ctx* c, int qx, int qy, pixel* buf, intptr_t* outStride)
+{
+    if ((qx | qy) & 1)
+    {
+        const int hpelA = (qy & 2) | ((qx & 2) >> 1);
+        const pixel* frefA = c->lowres[hpelA] + (qx >> 2) + (intptr_t)(qy >> 2) * c->stride;
+        const int qmvx = qx + (qx & 1), qmvy = qy + (qy & 1);
+        const int hpelB = (qmvy & 2) | ((qmvx & 2) >> 1);
+        const pixel* frefB = c->lowres[hpelB] + (qmvx >> 2) + (intptr_t)(qmvy >> 2) * c->stride;
+        c->pu->pixelavg_pp[0](buf, *outStride, frefA, c->stride, frefB, c->stride, 32);
+        return buf;
+    }
+    *outStride = c->stride;
+    const int hpel = (qy & 2) | ((qx & 2) >> 1);
+    return c->lowres[hpel] + (qx >> 2) + (intptr_t)(qy >> 2) * c->stride;
+}
+
+/* CostEstimateGroup::estimateFrameCost + estimateCUCost (slicetype.cpp:3115-3213, 3216-3388; reverse raster order :3189-3198) for
+ * a P picture (refs1 == NULL: b == p1, one list, intra competes) or a B picture (two lists + the two bi-directional candidates,
+ * :3322-3343); no HME, no weighted reference.  Every 8x8 block of the half-resolution picture: per searched list the mvs of the
+ * already finished right / lower neighbours are tried as predictors (SATD at lowresMC, :3284-3301, which also yields the B
+ * picture's skipCost), HEX search with merange 16 and subpelRefine 1 against the reference's four phase planes (:3307), skip
+ * shortcut (:3311-3315); then + lowresPenalty and, for P, intra wins if cheaper (:3346-3356); frame sums over the non-edge blocks.
+ *   cur: pixel (0,0) of the current picture's plane 0; refs0 / refs1: pixel (0,0) of the four planes of the list-0 / list-1
+ *   reference (same stride); doSearch[i] == 0 keeps list i's mvs / mvCosts as given (estimateFrameCost's bDoSearch, :3125-3127).
  *   intraCost: LookaheadTLD::lowresIntraEstimate's output for the current picture; invQscale: fenc->invQscaleFactor or NULL.
- * Outputs: mvs int32 [n][2] (quarter-pel), mvCosts int32 [n], lowresCosts uint16 [n], rowSatds int32 [heightInCU],
- * frame int64 [3] = { costEst, costEstAq, intraMbs }.  Serial by construction (each block needs its neighbours' mvs). */
-int EXPORT(x265oracle_lowres_cost)(const pixel* cur, const pixel* ref0, const pixel* ref1, const pixel* ref2, const pixel* ref3, intptr_t stride,
+ * Outputs: mvs0/1 int32 [n][2] (quarter-pel), mvCosts0/1 int32 [n], lowresCosts uint16 [n], rowSatds int32 [heightInCU],
+ * frame int64 [4] = { costEst as accumulated, costEstAq, intraMbs, the returned score (costEst * 100 / (130 + bFrameBias) for B) }.
+ * Serial by construction (each block needs its neighbours' mvs). */
+int EXPORT(x265oracle_lowres_cost)(const pixel* cur, const pixel* const* refs0, const pixel* const* refs1, intptr_t stride,
                                    int widthInCU, int heightInCU, const uint16_t* cost, int qoff, const int32_t* intraCost,
-                                   const int32_t* invQscale, int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds,
-                                   int64_t* frame)
+                                   const int32_t* invQscale, const int* doSearch, int bFrameBias,
+                                   int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
+                                   uint16_t* lowresCosts, int32_t* rowSatds, int64_t* frame)
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
     if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
     int part = -1;
     for (int k = 0; k < 25; k++) if (kPuDims[k][0] == 8 && kPuDims[k][1] == 8) part = k;
-    const pixel* planes[4] = { ref0, ref1, ref2, ref3 };
+    const int bBidir = refs1 != NULL;
+    const pixel* const* refs[2] = { refs0, refs1 };
+    int32_t* mvsL[2] = { mvs0, mvs1 };
+    int32_t* mvCostsL[2] = { mvCosts0, mvCosts1 };
     const int cuSize = 8, lowresPenalty = 4, merange = 16;
     int64_t costEst = 0, costEstAq = 0, intraMbs = 0;
     for (int cuY = heightInCU - 1; cuY >= 0; cuY--)
@@ -525,52 +550,86 @@ int EXPORT(x265oracle_lowres_cost)(const pixel* cur, const pixel* ref0, const pi
             c.stride = stride; c.w = 8;
             c.pu->copy_pp(c.fenc, 64, cur + pelOffset, stride);
             c.cost = cost + qoff;
-            for (int i = 0; i < 4; i++) c.lowres[i] = planes[i] + pelOffset;
-            c.fref = c.lowres[0];
             c.mvmin.x = -cuX * cuSize - 8; c.mvmin.y = -cuY * cuSize - 8;
             c.mvmax.x = (widthInCU - cuX - 1) * cuSize + 8; c.mvmax.y = (heightInCU - cuY - 1) * cuSize + 8;
-            /* reverse-order mv prediction (:3266-3282) */
-            int numc = 0, mvc[4][2];
-            const int32_t* fencMV = mvs + 2 * cuXY;
-#define MVC(IDX) do { mvc[numc][0] = fencMV[2 * (IDX)]; mvc[numc][1] = fencMV[2 * (IDX) + 1]; numc++; } while (0)
-            if (cuX < widthInCU - 1) MVC(1);
-            if (!lastRow)
+            int bcost = 1 << 28, listused = 0;                        /* MotionEstimate::COST_MAX (motion.h:65) */
+            for (int i = 0; i < 1 + bBidir; i++)
             {
-                MVC(widthInCU);
-                if (cuX > 0) MVC(widthInCU - 1);
-                if (cuX < widthInCU - 1) MVC(widthInCU + 1);
-            }
-#undef MVC
-            int mvpx = 0, mvpy = 0;
-            if (numc)
-            {
-                int mvpcost = 0x7fffffff;
-                for (int idx = 0; idx < numc; idx++)
+                int32_t* fencMV = mvsL[i] + 2 * cuXY;
+                int skipCost = 0x7fffffff;
+                if (!doSearch[i])
                 {
-                    /* bufSATD over lowresMC's prediction = the SATD flavour of lowresQPelCost (lowres.h:66-93) */
-                    const int cst = lowres_qpel_cost(&c, mvc[idx][0], mvc[idx][1], 1);
-                    if (cst < mvpcost) { mvpcost = cst; mvpx = mvc[idx][0]; mvpy = mvc[idx][1]; }
+                    if (mvCostsL[i][cuXY] < bcost) { bcost = mvCostsL[i][cuXY]; listused = i + 1; }
+                    continue;
                 }
+                for (int k = 0; k < 4; k++) c.lowres[k] = refs[i][k] + pelOffset;
+                c.fref = c.lowres[0];
+                /* reverse-order mv prediction (:3266-3282) */
+                int numc = 0, mvc[4][2];
+#define MVC(IDX) do { mvc[numc][0] = fencMV[2 * (IDX)]; mvc[numc][1] = fencMV[2 * (IDX) + 1]; numc++; } while (0)
+                if (cuX < widthInCU - 1) MVC(1);
+                if (!lastRow)
+                {
+                    MVC(widthInCU);
+                    if (cuX > 0) MVC(widthInCU - 1);
+                    if (cuX < widthInCU - 1) MVC(widthInCU + 1);
+                }
+#undef MVC
+                int mvpx = 0, mvpy = 0;
+                if (numc)
+                {
+                    int mvpcost = 1 << 28;                          /* MotionEstimate::COST_MAX */
+                    for (int idx = 0; idx < numc; idx++)
+                    {
+                        /* bufSATD over lowresMC's prediction = the SATD flavour of lowresQPelCost */
+                        const int cst = lowres_qpel_cost(&c, mvc[idx][0], mvc[idx][1], 1);
+                        if (cst < mvpcost) { mvpcost = cst; mvpx = mvc[idx][0]; mvpy = mvc[idx][1]; }
+                        /* :3297-3299: while the best predictor so far is the zero mv, remember the cost just measured */
+                        if (!(mvpx | mvpy) && bBidir) skipCost = cst;
+                    }
+                }
+                c.mvpx = mvpx; c.mvpy = mvpy;
+                int qx = 0, qy = 0;
+                int fencCost = motion_estimate_one(&c, ME_HEX, 1, merange, NULL, 0, &qx, &qy);
+                if (skipCost < 64 && skipCost < fencCost && bBidir) { fencCost = skipCost; qx = qy = 0; }
+                fencMV[0] = qx; fencMV[1] = qy;
+                mvCostsL[i][cuXY] = fencCost;
+                if (fencCost < bcost) { bcost = fencCost; listused = i + 1; }
             }
-            c.mvpx = mvpx; c.mvpy = mvpy;
-            int qx = 0, qy = 0;
-            const int fencCost = motion_estimate_one(&c, ME_HEX, 1, merange, NULL, 0, &qx, &qy);
-            mvs[2 * cuXY] = qx; mvs[2 * cuXY + 1] = qy;
-            mvCosts[cuXY] = fencCost;
-            int bcost = fencCost, listused = 1;
-            bcost += lowresPenalty;
-            if (intraCost[cuXY] < bcost) { bcost = intraCost[cuXY]; listused = 0; }
+            if (bBidir)
+            {
+                /* avg(l0-mv, l1-mv) candidate, then the co-located one (:3322-3343) */
+                pixel buf0[64], buf1[64], avg[64];
+                intptr_t st0 = 8, st1 = 8;
+                for (int k = 0; k < 4; k++) c.lowres[k] = refs0[k] + pelOffset;
+                const pixel* src0 = lowres_mc(&c, mvs0[2 * cuXY], mvs0[2 * cuXY + 1], buf0, &st0);
+                for (int k = 0; k < 4; k++) c.lowres[k] = refs1[k] + pelOffset;
+                const pixel* src1 = lowres_mc(&c, mvs1[2 * cuXY], mvs1[2 * cuXY + 1], buf1, &st1);
+                c.pu->pixelavg_pp[0](avg, 8, src0, st0, src1, st1, 32);
+                int bicost = c.pu->satd(c.fenc, 64, avg, 8);
+                if (bicost < bcost) { bcost = bicost; listused = 3; }
+                c.pu->pixelavg_pp[0](avg, 8, refs0[0] + pelOffset, stride, refs1[0] + pelOffset, stride, 32);
+                bicost = c.pu->satd(c.fenc, 64, avg, 8);
+                if (bicost < bcost) { bcost = bicost; listused = 3; }
+                bcost += lowresPenalty;
+            }
+            else
+            {
+                bcost += lowresPenalty;
+                if (intraCost[cuXY] < bcost) { bcost = intraCost[cuXY]; listused = 0; }
+            }
             const int bFrameScoreCU = (cuX > 0 && cuX < widthInCU - 1 && cuY > 0 && cuY < heightInCU - 1) || widthInCU <= 2 || heightInCU <= 2;
             const int bcostAq = (bFrameScoreCU && invQscale) ? ((bcost * invQscale[cuXY] + 128) >> 8) : bcost;
             if (bFrameScoreCU)
             {
                 costEst += bcost; costEstAq += bcostAq;
-                if (!listused) intraMbs++;
+                if (!listused && !bBidir) intraMbs++;
             }
             rowSatds[cuY] += bcostAq;
             lowresCosts[cuXY] = (uint16_t)((bcost < 0x3fff ? bcost : 0x3fff) | (listused << 14));
         }
     }
     frame[0] = costEst; frame[1] = costEstAq; frame[2] = intraMbs;
+    frame[3] = bBidir ? costEst * 100 / (130 + bFrameBias) : costEst;
     return 0;
 }

@@ -57,9 +57,58 @@ def test_lowres_cost_matches_oracle(depth, width, height):
     assert np.array_equal(st.mv_costs.cpu().numpy(), mvc)
     assert np.array_equal(st.lowres_costs.cpu().numpy().view(np.uint16), lcost)
     assert np.array_equal(st.row_satds.cpu().numpy(), rows)
-    assert np.array_equal(st.frame.cpu().numpy(), frame)
+    assert np.array_equal(st.frame.cpu().numpy()[:3], frame) and st.frame.cpu().numpy()[3] == frame[0]
     if width >= 192:
         assert (mvs != 0).any() and ((lcost >> 14) == 0).any() and ((lcost >> 14) == 1).any()
+
+
+@pytest.mark.parametrize("depth,width,height,bias", [(8, 256, 128, 0), (8, 208, 144, 20), (10, 192, 128, 0), (8, 1280, 720, 0)])
+def test_lowres_b_cost_matches_oracle(depth, width, height, bias):
+    """B pictures: two lists, the skip shortcut, the two bi-directional candidates and the scaled score; then a second estimate
+    that reuses list 0 (bDoSearch[0] == false)."""
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(width, height, 3, depth=depth, seed=92)
+    rng = np.random.default_rng([18, depth, width])
+    y0, y2 = clip[0][0], clip[2][0]
+    y1 = np.roll(y0, (2, -3), axis=(0, 1)).copy()
+    y1[: height // 3] = np.roll(y2, (-1, 2), axis=(0, 1))[: height // 3]
+    y1[-32:, -64:] = y0[-32:, -64:]
+    y1[-64:-32, :64] = ((y0[-64:-32, :64].astype(np.int32) + y2[-64:-32, :64] + 1) >> 1).astype(y1.dtype)
+    noise = rng.integers(-1, 2, size=y1.shape) << (depth - 8)
+    y1[:, width // 2:] = np.clip(y1[:, width // 2:].astype(np.int32) + noise[:, width // 2:], 0, (1 << depth) - 1).astype(y1.dtype)
+    pics = [P.DevicePicture(y, dev) for y in (y1, y0, y2)]
+    las = [S.Lookahead(width, height, depth, dev, intra_penalty=5 if depth == 8 else 80) for _ in range(3)]
+    for la, pic in zip(las, pics):
+        la.run(pic)
+    lc, l0, l1 = las
+    st = S.LookaheadCost(lc, dev, bidir=True)
+    st.run(lc, l0, l1, bframe_bias=bias)
+    torch.cuda.synchronize()
+    O = _oracle()
+    dt = y1.dtype
+    cp = lc.planes[0].cpu().numpy().view(dt)
+    r0 = [p.cpu().numpy().view(dt) for p in l0.planes]
+    r1 = [p.cpu().numpy().view(dt) for p in l1.planes]
+    cq = st.cost_q.cpu().numpy().view(np.uint16)
+    ic = lc.intra_cost.cpu().numpy()
+    mvs, mvc, lcost, rows, frame = O.lowres_cost(depth, cp, r0, lc.stride, lc.org, lc.wcu, lc.hcu, cq, st.qoff, ic, ref1_planes=r1, bframe_bias=bias)
+    g0, g1 = st.mvs.cpu().numpy().reshape(-1, 2), st.mvs1.cpu().numpy().reshape(-1, 2)
+    assert np.array_equal(g0, mvs[0]) and np.array_equal(g1, mvs[1]), "mvs differ"
+    assert np.array_equal(st.mv_costs.cpu().numpy(), mvc[0]) and np.array_equal(st.mv_costs1.cpu().numpy(), mvc[1])
+    assert np.array_equal(st.lowres_costs.cpu().numpy().view(np.uint16), lcost)
+    assert np.array_equal(st.row_satds.cpu().numpy(), rows)
+    assert np.array_equal(st.frame.cpu().numpy(), frame)
+    used = lcost >> 14
+    assert (used == 1).any() and (used == 2).any() and (used == 3).any()
+    # second estimate of the same picture against another list-1 reference: list 0 is not searched again
+    keep0, keepc0 = g0.copy(), st.mv_costs.cpu().numpy().copy()
+    st.run(lc, l0, l0, do_search=(0, 1), bframe_bias=bias)
+    torch.cuda.synchronize()
+    mvs2, mvc2, lcost2, rows2, frame2 = O.lowres_cost(depth, cp, r0, lc.stride, lc.org, lc.wcu, lc.hcu, cq, st.qoff, ic, ref1_planes=r0,
+                                                      bframe_bias=bias, do_search=(0, 1), mvs_in=(keep0, None), mv_costs_in=(keepc0, None))
+    assert np.array_equal(st.mvs.cpu().numpy().reshape(-1, 2), keep0) and np.array_equal(st.mvs1.cpu().numpy().reshape(-1, 2), mvs2[1])
+    assert np.array_equal(st.lowres_costs.cpu().numpy().view(np.uint16), lcost2) and np.array_equal(st.frame.cpu().numpy(), frame2)
 
 
 def test_lowres_cost_rejects_bad_geometry():

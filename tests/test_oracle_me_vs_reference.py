@@ -213,6 +213,53 @@ def test_lowres_frame_cost_restatement_equals_reference_classes(depth, width, he
     assert (mvs != 0).any() and ((lc >> 14) == 0).any() and ((lc >> 14) == 1).any()
 
 
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 208, 144), (10, 192, 128)])
+def test_lowres_b_frame_cost_restatement_equals_reference_classes(depth, width, height):
+    """The B-picture flavour (two lists, skip shortcut, the two bi-directional candidates, the 100 / (130 + bias) score scaling)
+    against the real CostEstimateGroup::singleCost(0, 2, 1)."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_lowres_cost_b"):
+        pytest.skip("oracle/_ref predates x265ref_lowres_cost_b")
+    clip = F.synth_clip(width, height, 3, depth=depth, seed=92)
+    rng = np.random.default_rng([14, depth, width])
+    y0, y2 = clip[0][0], clip[2][0]
+    y1 = np.roll(y0, (2, -3), axis=(0, 1)).copy()
+    y1[: height // 3] = np.roll(y2, (-1, 2), axis=(0, 1))[: height // 3]
+    y1[-32:, -64:] = y0[-32:, -64:]                                        # zero-residual blocks (skip shortcut)
+    y1[-64:-32, :64] = ((y0[-64:-32, :64].astype(np.int32) + y2[-64:-32, :64] + 1) >> 1).astype(y1.dtype)   # bi-directional wins
+    noise = rng.integers(-1, 2, size=y1.shape) << (depth - 8)
+    y1[:, width // 2:] = np.clip(y1[:, width // 2:].astype(np.int32) + noise[:, width // 2:], 0, (1 << depth) - 1).astype(y1.dtype)
+    cur, stride, org, w64, h64 = F.pad_plane(y1)
+    r0, r1 = F.pad_plane(y0)[0], F.pad_plane(y2)[0]
+    wcu, hcu = (width // 2 + 7) >> 3, (height // 2 + 7) >> 3
+    lw, lh = wcu * 8, hcu * 8
+    n = wcu * hcu
+    rmv = [np.zeros((n, 2), np.int32) for _ in range(2)]
+    rmc = [np.zeros(n, np.int32) for _ in range(2)]
+    rlc, rrows, rframe = np.zeros(n, np.uint16), np.zeros(hcu, np.int32), np.zeros(4, np.int64)
+    lib.x265ref_lowres_cost_b.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 7
+    assert lib.x265ref_lowres_cost_b(cur.ctypes.data, r0.ctypes.data, r1.ctypes.data, width, height, rmv[0].ctypes.data, rmc[0].ctypes.data,
+                                     rmv[1].ctypes.data, rmc[1].ctypes.data, rlc.ctypes.data, rrows.ctypes.data, rframe.ctypes.data) == 0
+    rstride = (width // 2 + 2 * F.MARGIN_X + 31) & ~31
+    rows = lh + 2 * F.MARGIN_Y
+    lorg = rstride * F.MARGIN_Y + F.MARGIN_X
+    cplanes = O.lowres_init(depth, cur, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    p0 = O.lowres_init(depth, r0, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    p1 = O.lowres_init(depth, r1, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    lam = 1.0 if depth == 8 else 16.0
+    icost, _, _ = O.lowres_intra(depth, cplanes[0], rstride, lorg, wcu, hcu, 5 * int(lam))
+    cq, qoff = F.qpel_cost_table(16, lam=lam, qmax=4 * (max(lw, lh) + 64))
+    mvs, mvc, lc, rws, frame = O.lowres_cost(depth, cplanes[0], p0, rstride, lorg, wcu, hcu, cq, qoff, icost, ref1_planes=p1)
+    for i in range(2):
+        assert np.array_equal(mvs[i], rmv[i]), f"list {i} mvs differ at {np.flatnonzero((mvs[i] != rmv[i]).any(axis=1))[:8]}"
+        assert np.array_equal(mvc[i], rmc[i])
+    assert np.array_equal(lc, rlc) and np.array_equal(rws, rrows)
+    assert frame[3] == rframe[0] == rframe[1] and frame[1] == rframe[2] and rframe[3] == 0
+    used = lc >> 14
+    assert (used == 1).any() and (used == 2).any() and (used == 3).any()
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_search_driver_with_extra_candidates_equals_reference(depth):
     """motionEstimate's mvc[] candidates (motion.cpp:800-812: measured with SAD + mv cost against the predictor's cost, skipping

@@ -49,5 +49,5 @@ res = O.lowres_cost(8, cp, rp, lc.stride, lc.org, lc.wcu, lc.hcu, cq, stages[0].
 tc = time.perf_counter() - t0
 thr = effective_cpus()
 print(f"CPU one picture pair on one thread: {tc * 1e3:.1f} ms -> {1 / tc:.1f} pairs/s per thread, {thr / tc:.1f} pairs/s if {thr} threads each take a picture")
-assert np.array_equal(stages[0].frame.cpu().numpy(), res[4]), "GPU and CPU frame costs differ"
+assert np.array_equal(stages[0].frame.cpu().numpy()[:3], res[4]), "GPU and CPU frame costs differ"
 print(f"frame cost (costEst, costEstAq, intraMbs) = {res[4].tolist()} on both")

@@ -17,14 +17,8 @@ namespace x265hip {
 struct LowresCostArgs
 {
     const x265hip_lowres_cost_pair* pairs;     // device copy, one per workgroup
-    int strideB, W, H, depth;
+    int strideB, W, H, depth, bFrameBias;
     const uint16_t* cost;
-};
-struct LowresPairArgs
-{
-    const uint8_t* cur; const uint8_t* ref[4];
-    const int32_t* intraCost; const int32_t* invQscale;
-    unsigned long long* mvs; int32_t* mvCosts; uint16_t* lowresCosts; int32_t* rowSatds; long long* frame;
 };
 
 // the four phase planes, biased like PuEval::base; passed by value so that they stay in registers
@@ -56,10 +50,9 @@ struct LowresPu
             }
         }
     }
-    // lowresQPelCost (lowres.h:95-121) with sad or satd; also lowresMC + bufSATD (:66-93, slicetype.cpp:3293-3295)
-    __device__ __forceinline__ int qpel_cost(const PhasePlanes pp, int qx, int qy, bool useSatd) const
+    // lowresMC (lowres.h:66-93): this lane's 4x4 tile of the prediction at quarter-pel (qx, qy)
+    __device__ __forceinline__ void predict(const PhasePlanes pp, int qx, int qy, int (&p)[4][4]) const
     {
-        int p[4][4];
         const int hA = (qy & 2) | ((qx & 2) >> 1);
         load_tile(plane(pp, hA), c.refOrg[0] + (uint32_t)((qy >> 2) * c.strideB + (qx >> 2) * BPP), p);
         if ((qx | qy) & 1)
@@ -73,6 +66,10 @@ struct LowresPu
 #pragma unroll
                 for (int x = 0; x < 4; x++) p[y][x] = (p[y][x] + pb[y][x] + 1) >> 1;          // pixelavg_pp, weight 32
         }
+    }
+    // sad / satd of the block against a prediction held tile by tile
+    __device__ __forceinline__ int score(int (&p)[4][4], bool useSatd) const
+    {
         int acc = 0;
 #pragma unroll
         for (int y = 0; y < 4; y++)
@@ -91,6 +88,13 @@ struct LowresPu
                 for (int x = 0; x < 4; x++) acc += abs(p[y][x]);
         }
         return quad_sum(acc);
+    }
+    // lowresQPelCost (lowres.h:95-121) with sad or satd; also lowresMC + bufSATD (slicetype.cpp:3293-3295)
+    __device__ __forceinline__ int qpel_cost(const PhasePlanes pp, int qx, int qy, bool useSatd) const
+    {
+        int p[4][4];
+        predict(pp, qx, qy, p);
+        return score(p, useSatd);
     }
 };
 
@@ -164,20 +168,16 @@ __device__ __forceinline__ int lowres_motion_estimate(const LowresPu<Px>& L, con
     return bcost;
 }
 
-template <typename Px>
+template <typename Px, bool BIDIR>
 __global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
 {
-    LowresPairArgs a;
-    {
-        const x265hip_lowres_cost_pair pr = g.pairs[blockIdx.x];
-        a.cur = (const uint8_t*)pr.cur;
-        a.ref[0] = (const uint8_t*)pr.ref[0]; a.ref[1] = (const uint8_t*)pr.ref[1]; a.ref[2] = (const uint8_t*)pr.ref[2]; a.ref[3] = (const uint8_t*)pr.ref[3];
-        a.intraCost = pr.intra_cost; a.invQscale = pr.inv_qscale;
-        a.mvs = (unsigned long long*)pr.mvs; a.mvCosts = pr.mv_costs; a.lowresCosts = pr.lowres_costs; a.rowSatds = pr.row_satds;
-        a.frame = (long long*)pr.frame;
-    }
+    const x265hip_lowres_cost_pair pr = g.pairs[blockIdx.x];
+    const uint8_t* cur = (const uint8_t*)pr.cur;
+    unsigned long long* mvsL[2] = { (unsigned long long*)pr.mvs, (unsigned long long*)pr.mvs1 };
+    int32_t* mvCostsL[2] = { pr.mv_costs, pr.mv_costs1 };
     constexpr int BPP = sizeof(Px);
     constexpr uint32_t kBias = 1u << 30;
+    constexpr int NL = BIDIR ? 2 : 1;
     const int Q = blockDim.x >> 2;                    // rows in flight: one quad each
     const int q = threadIdx.x >> 2, l = threadIdx.x & 3;
     const int tx = l & 1, ty = l >> 1;
@@ -188,10 +188,10 @@ __global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
     __syncthreads();
     long long costEst = 0, costEstAq = 0;
     int intraMbs = 0, rowSatd = 0;
-    int rightx = 0, righty = 0;                       // the finished block to the right (this quad's previous result)
+    int rightx[2] = { 0, 0 }, righty[2] = { 0, 0 };   // per list: the finished block to the right (this quad's previous result)
     LowresPu<Px> L;
-    L.c.base = a.ref[0] - kBias;
-    const PhasePlanes pp = { a.ref[0] - kBias, a.ref[1] - kBias, a.ref[2] - kBias, a.ref[3] - kBias };
+    const PhasePlanes pp0 = { (const uint8_t*)pr.ref[0] - kBias, (const uint8_t*)pr.ref[1] - kBias, (const uint8_t*)pr.ref[2] - kBias, (const uint8_t*)pr.ref[3] - kBias };
+    const PhasePlanes pp1 = BIDIR ? PhasePlanes{ (const uint8_t*)pr.ref1[0] - kBias, (const uint8_t*)pr.ref1[1] - kBias, (const uint8_t*)pr.ref1[2] - kBias, (const uint8_t*)pr.ref1[3] - kBias } : pp0;
     L.c.strideB = g.strideB; L.c.depth = g.depth; L.c.cost = g.cost;
     L.c.have[0] = true;
     for (int t = 0; t < steps; t++)
@@ -211,49 +211,104 @@ __global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int d = 0; d < BPP; d++) L.c.src[0][r][d] = ld_u32(a.cur + (pel + (uint32_t)(r * g.strideB + 4 * d)));
+                for (int d = 0; d < BPP; d++) L.c.src[0][r][d] = ld_u32(cur + (pel + (uint32_t)(r * g.strideB + 4 * d)));
             L.c.mvmin.x = -cuX * 8 - 8; L.c.mvmin.y = -cuY * 8 - 8;
             L.c.mvmax.x = (W - cuX - 1) * 8 + 8; L.c.mvmax.y = (H - cuY - 1) * 8 + 8;
-            // reverse-order mv prediction (:3266-3301): right, below, below-left, below-right; the cheapest SATD wins (strict <)
-            // The (up to) four finished neighbours are fetched and scored together; invalid ones score a dummy position that
-            // the selection below skips.
-            const bool vR = cuX < W - 1, vB = ry > 0, vBL = vB && cuX > 0, vBR = vB && cuX < W - 1;
-            auto finished = [&](bool valid, int idx, int& mx, int& my)
+            int bcost = 1 << 28, listused = 0;                                     // MotionEstimate::COST_MAX
+            int lmx[2] = { 0, 0 }, lmy[2] = { 0, 0 };
+#pragma unroll
+            for (int li = 0; li < NL; li++)
             {
-                const unsigned long long v = __hip_atomic_load(&a.mvs[valid ? idx : cuXY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                mx = valid ? (int)(uint32_t)v : 0; my = valid ? (int)(uint32_t)(v >> 32) : 0;
-            };
-            int cx[4], cy[4], cc[4];
-            cx[0] = vR ? rightx : 0; cy[0] = vR ? righty : 0;
-            finished(vB, cuXY + W, cx[1], cy[1]);
-            finished(vBL, cuXY + W - 1, cx[2], cy[2]);
-            finished(vBR, cuXY + W + 1, cx[3], cy[3]);
+                const PhasePlanes pp = li ? pp1 : pp0;
+                unsigned long long* mvA = mvsL[li];
+                int fencCost, qx, qy;
+                if (!pr.do_search[li])
+                {
+                    // estimateFrameCost's bDoSearch == false: this list was searched by an earlier estimate, its results stand
+                    fencCost = mvCostsL[li][cuXY];
+                    const unsigned long long v = mvA[cuXY];
+                    qx = (int)(uint32_t)v; qy = (int)(uint32_t)(v >> 32);
+                }
+                else
+                {
+                    L.c.base = pp.p0;
+                    // reverse-order mv prediction (:3266-3301): right, below, below-left, below-right; the cheapest SATD wins
+                    // (strict <).  The (up to) four finished neighbours are fetched and scored together; invalid ones score a
+                    // dummy position that the selection below skips.
+                    const bool vR = cuX < W - 1, vB = ry > 0, vBL = vB && cuX > 0, vBR = vB && cuX < W - 1;
+                    auto finished = [&](bool valid, int idx, int& mx, int& my)
+                    {
+                        const unsigned long long v = __hip_atomic_load(&mvA[valid ? idx : cuXY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        mx = valid ? (int)(uint32_t)v : 0; my = valid ? (int)(uint32_t)(v >> 32) : 0;
+                    };
+                    int cx[4], cy[4], cc[4];
+                    cx[0] = vR ? rightx[li] : 0; cy[0] = vR ? righty[li] : 0;
+                    finished(vB, cuXY + W, cx[1], cy[1]);
+                    finished(vBL, cuXY + W - 1, cx[2], cy[2]);
+                    finished(vBR, cuXY + W + 1, cx[3], cy[3]);
 #pragma unroll
-            for (int i = 0; i < 4; i++) cc[i] = L.qpel_cost(pp, cx[i], cy[i], true);
-            const bool cv[4] = { vR, vB, vBL, vBR };
-            int mvpx = 0, mvpy = 0, mvpcost = 0x7fffffff;
+                    for (int i = 0; i < 4; i++) cc[i] = L.qpel_cost(pp, cx[i], cy[i], true);
+                    const bool cv[4] = { vR, vB, vBL, vBR };
+                    int mvpx = 0, mvpy = 0, mvpcost = 1 << 28, skipCost = 0x7fffffff;
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (cv[i] && cc[i] < mvpcost) { mvpcost = cc[i]; mvpx = cx[i]; mvpy = cy[i]; }
-            L.c.mvpx = mvpx; L.c.mvpy = mvpy;
-            int qx, qy;
-            const int fencCost = lowres_motion_estimate<Px>(L, pp, qx, qy);
-            rightx = qx; righty = qy;
-            int bcost = fencCost + 4, listused = 1;                                 // lowresPenalty
-            const int ic = a.intraCost[cuXY];
-            if (ic < bcost) { bcost = ic; listused = 0; }
+                    for (int i = 0; i < 4; i++)
+                        if (cv[i])
+                        {
+                            if (cc[i] < mvpcost) { mvpcost = cc[i]; mvpx = cx[i]; mvpy = cy[i]; }
+                            // :3297-3299: while the best predictor so far is the zero mv, remember the cost just measured
+                            if (BIDIR && !(mvpx | mvpy)) skipCost = cc[i];
+                        }
+                    L.c.mvpx = mvpx; L.c.mvpy = mvpy;
+                    fencCost = lowres_motion_estimate<Px>(L, pp, qx, qy);
+                    if (BIDIR && skipCost < 64 && skipCost < fencCost) { fencCost = skipCost; qx = qy = 0; }       // :3311-3315
+                    rightx[li] = qx; righty[li] = qy;
+                    if (l == 0)
+                    {
+                        __hip_atomic_store(&mvA[cuXY], (unsigned long long)(uint32_t)qx | ((unsigned long long)(uint32_t)qy << 32),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        mvCostsL[li][cuXY] = fencCost;
+                    }
+                }
+                lmx[li] = qx; lmy[li] = qy;
+                if (fencCost < bcost) { bcost = fencCost; listused = li + 1; }
+            }
+            if (BIDIR)
+            {
+                // avg(l0-mv, l1-mv), then the co-located average (:3322-3343)
+                int p0[4][4], p1[4][4];
+                L.predict(pp0, lmx[0], lmy[0], p0);
+                L.predict(pp1, lmx[1], lmy[1], p1);
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) p0[y][x] = (p0[y][x] + p1[y][x] + 1) >> 1;
+                int bicost = L.score(p0, true);
+                if (bicost < bcost) { bcost = bicost; listused = 3; }
+                L.predict(pp0, 0, 0, p0);
+                L.predict(pp1, 0, 0, p1);
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) p0[y][x] = (p0[y][x] + p1[y][x] + 1) >> 1;
+                bicost = L.score(p0, true);
+                if (bicost < bcost) { bcost = bicost; listused = 3; }
+                bcost += 4;                                                        // lowresPenalty
+            }
+            else
+            {
+                bcost += 4;
+                const int ic = pr.intra_cost[cuXY];
+                if (ic < bcost) { bcost = ic; listused = 0; }
+            }
             const bool scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
-            const int bcostAq = (scored && a.invQscale) ? ((bcost * a.invQscale[cuXY] + 128) >> 8) : bcost;
-            if (scored) { costEst += bcost; costEstAq += bcostAq; intraMbs += !listused; }
+            const int bcostAq = (scored && pr.inv_qscale) ? ((bcost * pr.inv_qscale[cuXY] + 128) >> 8) : bcost;
+            if (scored) { costEst += bcost; costEstAq += bcostAq; intraMbs += (!BIDIR && !listused); }
             if (cuX == W - 1) rowSatd = 0;
             rowSatd += bcostAq;
             if (l == 0)
             {
-                __hip_atomic_store(&a.mvs[cuXY], (unsigned long long)(uint32_t)qx | ((unsigned long long)(uint32_t)qy << 32),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                a.mvCosts[cuXY] = fencCost;
-                a.lowresCosts[cuXY] = (uint16_t)((bcost < 0x3fff ? bcost : 0x3fff) | (listused << 14));
-                if (cuX == 0) a.rowSatds[cuY] = rowSatd;
+                pr.lowres_costs[cuXY] = (uint16_t)((bcost < 0x3fff ? bcost : 0x3fff) | (listused << 14));
+                if (cuX == 0) pr.row_satds[cuY] = rowSatd;
             }
         }
         // the exchange stays inside one workgroup (one CU, one L1 / L2): the barrier's workgroup-scope fence is all it needs - an
@@ -267,7 +322,8 @@ __global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
         atomicAdd((unsigned long long*)&sFrame[2], (unsigned long long)intraMbs);
     }
     __syncthreads();
-    if (threadIdx.x < 3) a.frame[threadIdx.x] = sFrame[threadIdx.x];
+    if (threadIdx.x < 3) pr.frame[threadIdx.x] = sFrame[threadIdx.x];
+    if (threadIdx.x == 0) pr.frame[3] = BIDIR ? sFrame[0] * 100 / (130 + g.bFrameBias) : sFrame[0];      // estimateFrameCost's score (:3201-3204)
 }
 
 } // namespace x265hip
@@ -283,12 +339,17 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     if (p->npairs == 0) return 0;
     if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("lowres_cost: depth %d", p->depth); return X265HIP_EINVAL; }
     if (p->width_in_cu <= 0 || p->height_in_cu <= 0) { set_error("lowres_cost: empty picture"); return X265HIP_EINVAL; }
+    bool bidir = false;
     for (int i = 0; i < p->npairs; i++)
     {
         const x265hip_lowres_cost_pair& q = p->pairs[i];
         if (!q.cur || !q.ref[0] || !q.ref[1] || !q.ref[2] || !q.ref[3] || !q.intra_cost || !q.mvs || !q.mv_costs || !q.lowres_costs || !q.row_satds || !q.frame)
         { set_error("lowres_cost: NULL operand in pair %d", i); return X265HIP_EINVAL; }
-        if (((uintptr_t)q.mvs) & 7) { set_error("lowres_cost: mvs of pair %d must be 8-byte aligned", i); return X265HIP_EINVAL; }
+        const bool b = q.ref1[0] != nullptr;
+        if (i == 0) bidir = b;
+        if (b != bidir) { set_error("lowres_cost: pair %d mixes P and B pictures in one call", i); return X265HIP_EINVAL; }
+        if (b && (!q.ref1[1] || !q.ref1[2] || !q.ref1[3] || !q.mvs1 || !q.mv_costs1)) { set_error("lowres_cost: NULL list-1 operand in pair %d", i); return X265HIP_EINVAL; }
+        if ((((uintptr_t)q.mvs) & 7) || (b && (((uintptr_t)q.mvs1) & 7))) { set_error("lowres_cost: mvs of pair %d must be 8-byte aligned", i); return X265HIP_EINVAL; }
     }
     int quads = (p->height_in_cu + 15) & ~15;
     if (quads > 256) quads = 256;
@@ -305,8 +366,11 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     a.strideB = (int)(p->stride * bpp);
     a.W = p->width_in_cu; a.H = p->height_in_cu; a.depth = p->depth;
     a.cost = p->cost_q + p->qoff;
-    if (bpp == 1) hipLaunchKernelGGL(lowres_cost_kernel<uint8_t>, dim3(p->npairs), dim3(quads * 4), 0, s, a);
-    else hipLaunchKernelGGL(lowres_cost_kernel<uint16_t>, dim3(p->npairs), dim3(quads * 4), 0, s, a);
+    a.bFrameBias = p->bframe_bias;
+    if (bpp == 1 && !bidir) hipLaunchKernelGGL((lowres_cost_kernel<uint8_t, false>), dim3(p->npairs), dim3(quads * 4), 0, s, a);
+    else if (bpp == 1) hipLaunchKernelGGL((lowres_cost_kernel<uint8_t, true>), dim3(p->npairs), dim3(quads * 4), 0, s, a);
+    else if (!bidir) hipLaunchKernelGGL((lowres_cost_kernel<uint16_t, false>), dim3(p->npairs), dim3(quads * 4), 0, s, a);
+    else hipLaunchKernelGGL((lowres_cost_kernel<uint16_t, true>), dim3(p->npairs), dim3(quads * 4), 0, s, a);
     X265HIP_TRY(hipGetLastError());
     X265HIP_TRY(hipFreeAsync(dpairs, s));
     return 0;

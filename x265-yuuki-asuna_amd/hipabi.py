@@ -61,15 +61,18 @@ class LowresIntraParams(ctypes.Structure):
 
 class LowresCostPair(ctypes.Structure):
     """x265hip_lowres_cost_pair (include/x265hip.h)."""
-    _fields_ = [("cur", ctypes.c_void_p), ("ref", ctypes.c_void_p * 4), ("intra_cost", ctypes.c_void_p), ("inv_qscale", ctypes.c_void_p),
-                ("mvs", ctypes.c_void_p), ("mv_costs", ctypes.c_void_p), ("lowres_costs", ctypes.c_void_p),
-                ("row_satds", ctypes.c_void_p), ("frame", ctypes.c_void_p)]
+    _fields_ = [("cur", ctypes.c_void_p), ("ref", ctypes.c_void_p * 4), ("ref1", ctypes.c_void_p * 4),
+                ("intra_cost", ctypes.c_void_p), ("inv_qscale", ctypes.c_void_p),
+                ("mvs", ctypes.c_void_p), ("mv_costs", ctypes.c_void_p), ("mvs1", ctypes.c_void_p), ("mv_costs1", ctypes.c_void_p),
+                ("do_search", ctypes.c_int32 * 2),
+                ("lowres_costs", ctypes.c_void_p), ("row_satds", ctypes.c_void_p), ("frame", ctypes.c_void_p)]
 
 
 class LowresCostParams(ctypes.Structure):
     """x265hip_lowres_cost_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("stride", ctypes.c_ssize_t), ("width_in_cu", ctypes.c_int), ("height_in_cu", ctypes.c_int),
-                ("cost_q", ctypes.c_void_p), ("qoff", ctypes.c_int), ("pairs", ctypes.POINTER(LowresCostPair)), ("npairs", ctypes.c_int)]
+                ("cost_q", ctypes.c_void_p), ("qoff", ctypes.c_int), ("bframe_bias", ctypes.c_int),
+                ("pairs", ctypes.POINTER(LowresCostPair)), ("npairs", ctypes.c_int)]
 
 
 class MESearchJob(ctypes.Structure):
@@ -205,27 +208,30 @@ def lowres_intra(depth, plane, stride, org, width_in_cu, height_in_cu, intra_pen
     check(f(ctypes.byref(p), s), "x265hip_lowres_intra")
 
 
-def lowres_cost_pair(depth, org, cur, ref_planes, intra_cost, mvs, mv_costs, lowres_costs, row_satds, frame, inv_qscale=None):
-    """One (current, reference) pair for lowres_cost: cur = the current picture's plane 0, ref_planes = the reference's four phase
-    planes (pixel (0,0) at element `org` of each tensor)."""
+def lowres_cost_pair(depth, org, cur, ref_planes, intra_cost, mvs, mv_costs, lowres_costs, row_satds, frame, inv_qscale=None,
+                     ref1_planes=None, mvs1=None, mv_costs1=None, do_search=(1, 1)):
+    """One picture for lowres_cost: cur = the current picture's plane 0, ref_planes = the list-0 reference's four phase planes
+    (pixel (0,0) at element `org` of each tensor); ref1_planes / mvs1 / mv_costs1 = list 1 of a B picture."""
     es = 1 if depth == 8 else 2
     q = LowresCostPair()
     q.cur = cur.data_ptr() + org * es
     for i in range(4):
         q.ref[i] = ref_planes[i].data_ptr() + org * es
+        q.ref1[i] = None if ref1_planes is None else ref1_planes[i].data_ptr() + org * es
     q.intra_cost, q.inv_qscale = intra_cost.data_ptr(), _p(inv_qscale)
-    q.mvs, q.mv_costs, q.lowres_costs = mvs.data_ptr(), mv_costs.data_ptr(), lowres_costs.data_ptr()
-    q.row_satds, q.frame = row_satds.data_ptr(), frame.data_ptr()
+    q.mvs, q.mv_costs, q.mvs1, q.mv_costs1 = mvs.data_ptr(), mv_costs.data_ptr(), _p(mvs1), _p(mv_costs1)
+    q.do_search[0], q.do_search[1] = do_search
+    q.lowres_costs, q.row_satds, q.frame = lowres_costs.data_ptr(), row_satds.data_ptr(), frame.data_ptr()
     return q
 
 
-def lowres_cost(depth, stride, width_in_cu, height_in_cu, cost_q, qoff, pairs, stream=None):
-    """Lookahead P-frame cost estimate (estimateFrameCost, slicetype.cpp:3189-3388) of a batch of independent picture pairs of
-    one geometry; pairs: list of LowresCostPair (lowres_cost_pair)."""
+def lowres_cost(depth, stride, width_in_cu, height_in_cu, cost_q, qoff, pairs, bframe_bias=0, stream=None):
+    """Lookahead frame cost estimate (estimateFrameCost, slicetype.cpp:3115-3388) of a batch of independent pictures of one
+    geometry and one kind (all P or all B); pairs: list of LowresCostPair (lowres_cost_pair)."""
     arr = (LowresCostPair * len(pairs))(*pairs)
     p = LowresCostParams()
     p.depth, p.stride, p.width_in_cu, p.height_in_cu = depth, stride, width_in_cu, height_in_cu
-    p.cost_q, p.qoff, p.pairs, p.npairs = cost_q.data_ptr(), qoff, arr, len(pairs)
+    p.cost_q, p.qoff, p.bframe_bias, p.pairs, p.npairs = cost_q.data_ptr(), qoff, bframe_bias, arr, len(pairs)
     s = current_stream() if stream is None else stream
     f = lib().x265hip_lowres_cost
     f.argtypes = [ctypes.POINTER(LowresCostParams), ctypes.c_void_p]

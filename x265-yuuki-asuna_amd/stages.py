@@ -122,37 +122,45 @@ class Lookahead:
 
 
 class LookaheadCost:
-    """The lookahead's P-frame cost estimate of a prepared picture against a prepared reference (x265hip_lowres_cost; reference
-    CostEstimateGroup::estimateFrameCost / estimateCUCost, slicetype.cpp:3189-3388).  `lam` is x265_lambda_tab[X265_LOOKAHEAD_QP]
-    (1.0 for 8-bit, 16.0 for 10-bit); the mv cost table is built on the host like BitCost's (bitcost.cpp:51-55,103-118)."""
+    """The lookahead's frame cost estimate of a prepared picture against one (P) or two (B) prepared references
+    (x265hip_lowres_cost; reference CostEstimateGroup::estimateFrameCost / estimateCUCost, slicetype.cpp:3115-3388).  `lam` is
+    x265_lambda_tab[X265_LOOKAHEAD_QP] (1.0 for 8-bit, 16.0 for 10-bit); the mv cost table is built on the host like BitCost's
+    (bitcost.cpp:51-55,103-118)."""
 
-    def __init__(self, la: Lookahead, device, lam=None):
+    def __init__(self, la: Lookahead, device, lam=None, bidir=False):
         import numpy as np
         import torch
         from . import frames as F
-        self.depth = la.depth
+        self.depth, self.bidir = la.depth, bidir
         lam = (1.0 if la.depth == 8 else (16.0 if la.depth == 10 else 64.0)) if lam is None else lam
         cq, self.qoff = F.qpel_cost_table(16, lam=lam, qmax=4 * (max(la.width, la.lines) + 64))
         self.cost_q = torch.from_numpy(cq.view(np.int16)).to(device)
         n = la.wcu * la.hcu
         self.mvs = torch.zeros(n * 2, dtype=torch.int32, device=device)
         self.mv_costs = torch.zeros(n, dtype=torch.int32, device=device)
+        self.mvs1 = torch.zeros(n * 2, dtype=torch.int32, device=device) if bidir else None
+        self.mv_costs1 = torch.zeros(n, dtype=torch.int32, device=device) if bidir else None
         self.lowres_costs = torch.zeros(n, dtype=torch.int16, device=device)
         self.row_satds = torch.zeros(la.hcu, dtype=torch.int32, device=device)
-        self.frame = torch.zeros(3, dtype=torch.int64, device=device)
+        self.frame = torch.zeros(4, dtype=torch.int64, device=device)
 
-    def pair(self, cur: Lookahead, ref: Lookahead):
+    def pair(self, cur: Lookahead, ref: Lookahead, ref1: Lookahead = None, do_search=(1, 1)):
         return hipabi.lowres_cost_pair(self.depth, cur.org, cur.planes[0], ref.planes, cur.intra_cost, self.mvs, self.mv_costs,
-                                       self.lowres_costs, self.row_satds, self.frame)
+                                       self.lowres_costs, self.row_satds, self.frame,
+                                       ref1_planes=None if ref1 is None else ref1.planes, mvs1=self.mvs1, mv_costs1=self.mv_costs1,
+                                       do_search=do_search)
 
-    def run(self, cur: Lookahead, ref: Lookahead, stream=None):
-        hipabi.lowres_cost(self.depth, cur.stride, cur.wcu, cur.hcu, self.cost_q, self.qoff, [self.pair(cur, ref)], stream=stream)
+    def run(self, cur: Lookahead, ref: Lookahead, ref1: Lookahead = None, do_search=(1, 1), bframe_bias=0, stream=None):
+        hipabi.lowres_cost(self.depth, cur.stride, cur.wcu, cur.hcu, self.cost_q, self.qoff, [self.pair(cur, ref, ref1, do_search)],
+                           bframe_bias=bframe_bias, stream=stream)
 
     @staticmethod
-    def run_batch(stages, curs, refs, stream=None):
-        """One launch for many independent pictures of one geometry (one workgroup each)."""
+    def run_batch(stages, curs, refs, refs1=None, bframe_bias=0, stream=None):
+        """One launch for many independent pictures of one geometry and kind (one workgroup each)."""
         s0, c0 = stages[0], curs[0]
-        hipabi.lowres_cost(s0.depth, c0.stride, c0.wcu, c0.hcu, s0.cost_q, s0.qoff, [s.pair(c, r) for s, c, r in zip(stages, curs, refs)], stream=stream)
+        refs1 = [None] * len(stages) if refs1 is None else refs1
+        hipabi.lowres_cost(s0.depth, c0.stride, c0.wcu, c0.hcu, s0.cost_q, s0.qoff,
+                           [s.pair(c, r, r1) for s, c, r, r1 in zip(stages, curs, refs, refs1)], bframe_bias=bframe_bias, stream=stream)
 
 
 class PatternSearch:
