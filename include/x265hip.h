@@ -287,6 +287,33 @@ typedef struct x265hip_lowres_intra_params
 } x265hip_lowres_intra_params;
 int x265hip_lowres_intra(const x265hip_lowres_intra_params* p, void* stream);
 
+/* Sample adaptive offset of the deblocked luma picture - the two pixel passes of encoder/sao.cpp; the rate-distortion choice of
+ * the parameters between them (rdoSaoUnitCu, sao.cpp:1225-1605) stays with the host.
+ * x265hip_sao_stats: SAO::calcSaoStatsCTU (sao.cpp:735-917) for every 64x64 CTU (bSaoNonDeblocked = 0, bLimitSAO = 0, one slice):
+ *   count / offset_org int32 [numCtu][5][32] = samples and sum of (source - deblocked) per type (EO_0, EO_1, EO_2, EO_3, BO) and
+ *   class (edge classes 0..4, bands 0..31), over the reference's sub-rectangles of each CTU.
+ * x265hip_sao_apply: SAO::generateLumaOffsets + applyPixelOffsets (sao.cpp:572-630, 274-570) for every CTU, out of place:
+ *   ctu_params int32 [numCtu][7] (DEVICE) = { typeIdx (-1 off, 0..3 EO, 4 BO), bandPos, offset[4], mergeLeft (informational: a
+ *   merged CTU carries the values it inherited) }.  width / height need not be multiples of 64; planes are padded pictures. */
+typedef struct x265hip_sao_stats_params
+{
+    int depth;
+    const void* fenc;  intptr_t fenc_stride;
+    const void* rec;   intptr_t rec_stride;
+    int width, height;
+    int32_t* count;  int32_t* offset_org;
+} x265hip_sao_stats_params;
+int x265hip_sao_stats(const x265hip_sao_stats_params* p, void* stream);
+typedef struct x265hip_sao_apply_params
+{
+    int depth;
+    const void* src;  intptr_t src_stride;
+    void* dst;        intptr_t dst_stride;
+    int width, height;
+    const int32_t* ctu_params;
+} x265hip_sao_apply_params;
+int x265hip_sao_apply(const x265hip_sao_apply_params* p, void* stream);
+
 /* ------------------------------------------------------------------ generic job-list entry points
  * Every remaining family evaluates `njobs` independent blocks of one size per launch.  An operand
  * is a device plane (base pointer + element stride); a job carries up to four element offsets into

@@ -1,0 +1,146 @@
+/* oracle/ref_sao.cpp - TEST INFRASTRUCTURE, never part of the product path.
+ *
+ * C-ABI window onto the REAL reference SAO class (encoder/sao.cpp): builds a Frame / FrameData / CUData skeleton around
+ * caller-supplied source and deblocked luma planes and runs SAO::calcSaoStatsCTU (sao.cpp:735-917) for every CTU, then
+ * SAO::generateLumaOffsets / applyPixelOffsets (sao.cpp:572-630, 274-570) CTU by CTU in raster order with the above-row
+ * buffer filled the way FrameFilter::ParallelFilter::copySaoAboveRef does (framefilter.cpp:300-322: from the not yet
+ * offset picture).  The tests use it to pin oracle/x265_oracle_pipeline4.c's SAO restatement.
+ */
+#include "common.h"
+#include "primitives.h"
+#include "picyuv.h"
+#include "frame.h"
+#include "framedata.h"
+#include "cudata.h"
+#include "slice.h"
+#include "sao.h"
+#include "x265.h"
+
+#include <cstring>
+#include <vector>
+
+using namespace X265_NS;
+
+extern "C" void x265ref_encoder_table_reset_c(void);
+
+namespace {
+struct SaoProbe : public SAO
+{
+    using SAO::m_count;
+    using SAO::m_offsetOrg;
+    using SAO::m_tmpU;
+};
+}
+
+extern "C" {
+
+/* fencPlane / recPlane: ALLOCATION STARTS of padded luma planes with the reference's PicYuv geometry (as x265ref_lowres_intra);
+ * recPlane holds the deblocked picture on entry and the sample-adaptive-offset picture on return.
+ * params: int32 [numCtu][7] = { typeIdx (-1 none, 0..3 EO, 4 BO), bandPos, offset[4], mergeLeft (0 / 1: take the left CTU's
+ * offsets through SAO_MERGE_LEFT instead of re-deriving them) }.
+ * count / offsetOrg: int32 [numCtu][5][32] = SAO::m_count[0] / m_offsetOrg[0] after calcSaoStatsCTU(addr, 0). */
+int x265ref_sao(const void* fencPlane, void* recPlane, int width, int height, const int32_t* params, int32_t* count, int32_t* offsetOrg)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width;
+    param->sourceHeight = height;
+    param->internalCsp = X265_CSP_I400;
+    param->maxCUSize = 64;
+    param->maxLog2CUSize = 6;
+    param->unitSizeDepth = 4;
+    param->num4x4Partitions = 256;
+    param->bEnableSAO = 1;
+    param->bSaoNonDeblocked = 0;
+    param->bLimitSAO = 0;
+    SPS sps;
+    memset((void*)&sps, 0, sizeof(sps));
+    sps.numCuInWidth = (width + 63) / 64;
+    sps.numCuInHeight = (height + 63) / 64;
+    sps.numCUsInFrame = sps.numCuInWidth * sps.numCuInHeight;
+    const int numCtu = sps.numCUsInFrame;
+    const int h64 = sps.numCuInHeight * 64;
+
+    Frame frame;
+    frame.m_param = param;
+    PicYuv fenc, recon;
+    PicYuv* pics[2] = { &fenc, &recon };
+    const void* srcs[2] = { fencPlane, recPlane };
+    for (int i = 0; i < 2; i++)
+    {
+        pics[i]->m_param = param;
+        if (!pics[i]->create(param, true) || !pics[i]->createOffsets(sps)) return -1;
+        memcpy(pics[i]->m_picOrg[0] - pics[i]->m_lumaMarginY * pics[i]->m_stride - pics[i]->m_lumaMarginX, srcs[i],
+               sizeof(pixel) * pics[i]->m_stride * (h64 + 2 * pics[i]->m_lumaMarginY));
+    }
+    frame.m_fencPic = &fenc;
+    frame.m_reconPic = &recon;
+    FrameData encData;
+    Slice slice;
+    slice.m_sps = &sps;
+    slice.m_param = param;
+    slice.m_sliceType = P_SLICE;
+    encData.m_param = param;
+    encData.m_slice = &slice;
+    encData.m_reconPic = &recon;
+    std::vector<CUData> ctus(numCtu);
+    encData.m_picCTU = ctus.data();
+    for (int a = 0; a < numCtu; a++)
+    {
+        const int row = a / sps.numCuInWidth, col = a % sps.numCuInWidth;
+        ctus[a].m_encData = &encData;
+        ctus[a].m_slice = &slice;
+        ctus[a].m_cuAddr = a;
+        ctus[a].m_cuPelX = col * 64;
+        ctus[a].m_cuPelY = row * 64;
+        ctus[a].m_bFirstRowInSlice = row == 0;
+        ctus[a].m_bLastRowInSlice = row == (int)sps.numCuInHeight - 1;
+    }
+    frame.m_encData = &encData;
+
+    SaoProbe sao;
+    if (!sao.create(param, 1)) return -2;
+    sao.m_frame = &frame;
+    for (int a = 0; a < numCtu; a++)
+    {
+        sao.resetStats();
+        sao.calcSaoStatsCTU(a, 0);
+        memcpy(count + (size_t)a * 5 * 32, sao.m_count[0], sizeof(int32_t) * 5 * 32);
+        memcpy(offsetOrg + (size_t)a * 5 * 32, sao.m_offsetOrg[0], sizeof(int32_t) * 5 * 32);
+    }
+
+    /* apply: the above-row reference comes from the picture before any offset was applied */
+    const intptr_t stride = recon.m_stride;
+    std::vector<pixel> pristine(recon.m_picOrg[0], recon.m_picOrg[0] + stride * h64);
+    std::vector<SaoCtuParam> cp(numCtu);
+    for (int a = 0; a < numCtu; a++)
+    {
+        const int32_t* p = params + (size_t)a * 7;
+        cp[a].reset();
+        cp[a].typeIdx = p[0];
+        cp[a].bandPos = p[1];
+        for (int i = 0; i < 4; i++) cp[a].offset[i] = p[2 + i];
+        cp[a].mergeMode = p[6] ? SAO_MERGE_LEFT : SAO_MERGE_NONE;
+    }
+    for (int row = 0; row < (int)sps.numCuInHeight; row++)
+    {
+        const pixel* above = pristine.data() + (row == 0 ? 0 : (intptr_t)(row * 64 - 1) * stride);
+        memcpy(sao.m_tmpU[0], above, sizeof(pixel) * sps.numCuInWidth * 64);
+        for (int col = 0; col < (int)sps.numCuInWidth; col++)
+            sao.generateLumaOffsets(cp.data(), row, col);
+    }
+    memcpy(recPlane, recon.m_picOrg[0] - recon.m_lumaMarginY * recon.m_stride - recon.m_lumaMarginX,
+           sizeof(pixel) * recon.m_stride * (h64 + 2 * recon.m_lumaMarginY));
+
+    /* the skeleton borrows stack objects: detach them before the destructors run */
+    frame.m_fencPic = NULL; frame.m_reconPic = NULL; frame.m_encData = NULL;
+    encData.m_picCTU = NULL; encData.m_slice = NULL;
+    sao.destroy(1);
+    fenc.destroy(); recon.destroy();
+    x265_param_free(param);
+    return 0;
+}
+
+} // extern "C"

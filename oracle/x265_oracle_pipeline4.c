@@ -149,3 +149,133 @@ void EXPORT(x265oracle_deblock_luma)(pixel* rec, intptr_t stride, int width, int
             filter_unit(&prim, rec + (intptr_t)(ey * 8) * stride + u * 4, 1, stride, 1, bs, q, bo, to);
         }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Stage: sample adaptive offset of the deblocked luma picture (SAO half) - the two pixel passes;
+ * the rate-distortion choice of the parameters between them (sao.cpp:1225-1605, entropy-coder bit counts) stays host work.
+ *
+ *   x265oracle_sao_stats: SAO::calcSaoStatsCTU (encoder/sao.cpp:735-917) for every CTU, luma, bSaoNonDeblocked = 0, bLimitSAO = 0,
+ *     one slice: difference source - deblocked, then the oracle's saoCuStatsBO / E0 / E1 / E2 / E3 primitives over the reference's
+ *     sub-rectangles (the right 5 columns and bottom 4 rows of a CTU wait for the neighbour CTU's deblocking, so they are left
+ *     out unless the CTU touches the picture edge; E0 leaves the bottom 4 rows out even there, :835).
+ *   x265oracle_sao_apply: SAO::generateLumaOffsets + applyPixelOffsets (:572-630, :274-570) for every CTU.  The reference works
+ *     in place but classifies against saved copies of the not yet offset neighbours (m_tmpU / m_tmpL1, framefilter.cpp:300-322),
+ *     which is an out-of-place filter: dst = src + offset[class(src neighbourhood)].  Edge classes: sign(c - a) + sign(c - b) + 2
+ *     mapped through s_eoTable = { 1, 2, 0, 3, 4 } (sao.cpp:67) to offset[] with offset[0] = 0; picture-border samples without both
+ *     neighbours keep their value; band offset: offset[(c >> (depth - 5)) - bandPos mod 32] for the 4 bands from bandPos.
+ * stats layout: int32 [numCtu][5][32] with type order EO_0, EO_1, EO_2, EO_3, BO (sao.h:36-44).
+ * params layout: int32 [numCtu][7] = { typeIdx (-1 = off), bandPos, offset[4], mergeLeft (ignored here: merged CTUs carry the
+ * left CTU's values, as rdoSaoUnitCu copies them) }. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int sao_sign(int x) { return (x > 0) - (x < 0); }
+
+int EXPORT(x265oracle_sao_stats)(const pixel* fenc, const pixel* rec, intptr_t stride, int picWidth, int picHeight,
+                                 int32_t* count, int32_t* offsetOrg, int nthreads)
+{
+    static x265hip_EncoderPrimitives prim;
+    static int ready = 0;
+    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    const int ctusW = (picWidth + 63) / 64, ctusH = (picHeight + 63) / 64;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+    for (int addr = 0; addr < ctusW * ctusH; addr++)
+    {
+        const int lpelx = (addr % ctusW) * 64, tpely = (addr / ctusW) * 64;
+        const int rpelx = lpelx + 64 < picWidth ? lpelx + 64 : picWidth, bpely = tpely + 64 < picHeight ? tpely + 64 : picHeight;
+        const int ctuWidth = rpelx - lpelx, ctuHeight = bpely - tpely;
+        const int aboveUnavail = !tpely;
+        const pixel* fenc0 = fenc + lpelx + (intptr_t)tpely * stride;
+        const pixel* rec0 = rec + lpelx + (intptr_t)tpely * stride;
+        int32_t* cnt = count + (size_t)addr * 5 * 32;
+        int32_t* org = offsetOrg + (size_t)addr * 5 * 32;
+        memset(cnt, 0, sizeof(int32_t) * 5 * 32);
+        memset(org, 0, sizeof(int32_t) * 5 * 32);
+        int16_t diff[64 * 64] __attribute__((aligned(32)));
+        int8_t upStore[2 * (64 + 32)], *upBuff1 = upStore + 16, *upBufft = upBuff1 + (64 + 32);
+        for (int y = 0; y < ctuHeight; y++)
+            for (int x = 0; x < ctuWidth; x++) diff[y * 64 + x] = (int16_t)((int)fenc0[y * stride + x] - (int)rec0[y * stride + x]);
+        const int skipB = 4, skipR = 5;
+        const int atRight = rpelx == picWidth, atBottom = bpely == picHeight;
+        /* band offset: everything already deblocked */
+        prim.saoCuStatsBO(diff, rec0, stride, atRight ? ctuWidth : ctuWidth - skipR, atBottom ? ctuHeight : ctuHeight - skipB, org + 4 * 32, cnt + 4 * 32);
+        /* EO_0 (horizontal) */
+        {
+            const int startX = !lpelx, endX = atRight ? ctuWidth - 1 : ctuWidth - skipR;
+            prim.saoCuStatsE0(diff + startX, rec0 + startX, stride, endX - startX, ctuHeight - skipB, org + 0 * 32, cnt + 0 * 32);
+        }
+        /* EO_1 (vertical) */
+        {
+            const int startY = aboveUnavail, endX = atRight ? ctuWidth : ctuWidth - skipR, endY = atBottom ? ctuHeight - 1 : ctuHeight - skipB;
+            const pixel* r = rec0 + startY * stride;
+            prim.sign(upBuff1, r, r - stride, ctuWidth);
+            prim.saoCuStatsE1(diff + startY * 64, rec0 + startY * stride, stride, upBuff1, endX, endY - startY, org + 1 * 32, cnt + 1 * 32);
+        }
+        /* EO_2 (135 degrees) and EO_3 (45 degrees) */
+        {
+            const int startX = !lpelx, endX = atRight ? ctuWidth - 1 : ctuWidth - skipR;
+            const int startY = aboveUnavail, endY = atBottom ? ctuHeight - 1 : ctuHeight - skipB;
+            const pixel* r = rec0 + startY * stride;
+            prim.sign(upBuff1, r + startX, r + startX - stride - 1, endX - startX);
+            prim.saoCuStatsE2(diff + startX + startY * 64, rec0 + startX + startY * stride, stride, upBuff1, upBufft, endX - startX, endY - startY,
+                              org + 2 * 32, cnt + 2 * 32);
+            prim.sign(upBuff1, r + startX - 1, r + startX - 1 - stride + 1, endX - startX + 1);
+            prim.saoCuStatsE3(diff + startX + startY * 64, rec0 + startX + startY * stride, stride, upBuff1 + 1, endX - startX, endY - startY,
+                              org + 3 * 32, cnt + 3 * 32);
+        }
+    }
+    return 0;
+}
+
+int EXPORT(x265oracle_sao_apply)(const pixel* src, pixel* dst, intptr_t stride, int picWidth, int picHeight, const int32_t* params, int nthreads)
+{
+    static const int kEoTable[5] = { 1, 2, 0, 3, 4 };
+    const int ctusW = (picWidth + 63) / 64, ctusH = (picHeight + 63) / 64;
+    const int maxVal = (1 << DEPTH) - 1, boShift = DEPTH - 5;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+    for (int addr = 0; addr < ctusW * ctusH; addr++)
+    {
+        const int32_t* p = params + (size_t)addr * 7;
+        const int typeIdx = p[0], bandPos = p[1];
+        const int lpelx = (addr % ctusW) * 64, tpely = (addr / ctusW) * 64;
+        const int rpelx = lpelx + 64 < picWidth ? lpelx + 64 : picWidth, bpely = tpely + 64 < picHeight ? tpely + 64 : picHeight;
+        int offsetEo[5], offsetBo[32];
+        {
+            int off[5] = { 0, p[2], p[3], p[4], p[5] };
+            for (int e = 0; e < 5; e++) offsetEo[e] = (int8_t)off[kEoTable[e]];
+            memset(offsetBo, 0, sizeof(offsetBo));
+            for (int i = 0; i < 4; i++) offsetBo[(bandPos + i) & 31] = (int8_t)p[2 + i];
+        }
+        /* neighbour steps of the four edge classes */
+        static const int kDx[4] = { 1, 0, 1, -1 }, kDy[4] = { 0, 1, 1, 1 };
+        for (int y = tpely; y < bpely; y++)
+            for (int x = lpelx; x < rpelx; x++)
+            {
+                const pixel* c = src + x + (intptr_t)y * stride;
+                int v = *c;
+                if (typeIdx == 4)
+                    v = clip3(0, maxVal, v + offsetBo[v >> boShift]);
+                else if (typeIdx >= 0)
+                {
+                    const int dx = kDx[typeIdx], dy = kDy[typeIdx];
+                    /* a sample is classified only when both neighbours lie inside the picture (startX / endX / startY / endY) */
+                    const int okx = !dx || (x > 0 && x < picWidth - 1), oky = !dy || (y > 0 && y < picHeight - 1);
+                    if (okx && oky)
+                    {
+                        const int a = c[-dx - dy * stride], b = c[dx + dy * stride];
+                        const int edgeType = sao_sign(v - a) + sao_sign(v - b) + 2;
+                        v = clip3(0, maxVal, v + offsetEo[edgeType]);
+                    }
+                }
+                dst[x + (intptr_t)y * stride] = (pixel)v;
+            }
+    }
+    return 0;
+}

@@ -1,0 +1,64 @@
+"""GPU parity: the SAO pixel passes (x265hip_sao_stats / x265hip_sao_apply) vs the oracle's restatement of SAO::calcSaoStatsCTU and
+SAO::generateLumaOffsets / applyPixelOffsets (sao.cpp:735-917, 572-630, 274-570), which tests/test_oracle_me_vs_reference.py pins
+against the real SAO class."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+H = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_api
+    return oracle_api
+
+
+def _case(depth, width, height, seed):
+    from test_oracle_me_vs_reference import sao_case
+    return sao_case(depth, width, height, seed)
+
+
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 200, 150), (10, 192, 136), (8, 64, 64), (8, 1920, 1080), (10, 832, 480), (8, 70, 66)])
+def test_sao_passes_match_oracle(depth, width, height):
+    import torch
+    dev = torch.device("cuda:0")
+    y, rec, params = _case(depth, width, height, 6)
+    fenc, stride, org, w64, h64 = F.pad_plane(y)
+    recp = F.pad_plane(rec)[0]
+    nctu = params.shape[0]
+    dt = y.dtype
+    d_f = torch.from_numpy(fenc.view(np.uint8).reshape(-1)).to(dev)
+    d_r = torch.from_numpy(recp.view(np.uint8).reshape(-1)).to(dev)
+    d_cnt = torch.full((nctu * 160,), -1, dtype=torch.int32, device=dev)
+    d_off = torch.full((nctu * 160,), -1, dtype=torch.int32, device=dev)
+    H.sao_stats(depth, d_f, stride, org, d_r, stride, org, width, height, d_cnt, d_off)
+    d_out = d_r.clone()
+    d_par = torch.from_numpy(params.reshape(-1)).to(dev)
+    H.sao_apply(depth, d_r, stride, org, d_out, stride, org, width, height, d_par)
+    torch.cuda.synchronize()
+    O = _oracle()
+    cnt, off = O.sao_stats(depth, fenc, recp, stride, org, width, height)
+    gc, go = d_cnt.cpu().numpy().reshape(nctu, 5, 32), d_off.cpu().numpy().reshape(nctu, 5, 32)
+    assert np.array_equal(gc, cnt), f"count differs in CTU/type {np.argwhere((gc != cnt).any(axis=2))[:6].tolist()}"
+    assert np.array_equal(go, off), f"offsetOrg differs in CTU/type {np.argwhere((go != off).any(axis=2))[:6].tolist()}"
+    out = O.sao_apply(depth, recp, stride, org, width, height, params)
+    gout = d_out.cpu().numpy().view(dt).reshape(out.shape)
+    assert np.array_equal(gout, out), f"{np.count_nonzero(gout != out)} samples differ"
+    assert (out != recp).any() and cnt[:, :4, :5].sum() > 0 and cnt[:, 4].sum() > 0
+
+
+def test_sao_apply_refuses_in_place():
+    import torch
+    dev = torch.device("cuda:0")
+    t = torch.zeros(1 << 16, dtype=torch.uint8, device=dev)
+    par = torch.zeros(7, dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError):
+        H.sao_apply(8, t, 256, 0, t, 256, 0, 64, 64, par)

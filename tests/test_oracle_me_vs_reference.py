@@ -260,6 +260,56 @@ def test_lowres_b_frame_cost_restatement_equals_reference_classes(depth, width, 
     assert (used == 1).any() and (used == 2).any() and (used == 3).any()
 
 
+def sao_case(depth, width, height, seed):
+    """Source / deblocked-like pair and random per-CTU SAO parameters (all five types, off, merge-left runs)."""
+    rng = np.random.default_rng([21, depth, width, seed])
+    y = F.synth_clip(width, height, 1, depth=depth, seed=seed)[0][0]
+    sm = (y.astype(np.int32) * 2 + np.roll(y, 1, axis=1) + np.roll(y, 1, axis=0) + 2) >> 2
+    rec = np.clip(sm + (rng.integers(-3, 4, size=y.shape) << (depth - 8)), 0, (1 << depth) - 1).astype(y.dtype)
+    rec[: height // 4, : width // 4] = y[: height // 4, : width // 4]                    # zero differences
+    rec[-9:, -70:] = (1 << depth) - 1                                                     # clipping at the top of the range
+    nctu = ((width + 63) // 64) * ((height + 63) // 64)
+    cw = (width + 63) // 64
+    lim = 7 if depth == 8 else 31
+    params = np.zeros((nctu, 7), np.int32)
+    params[:, 0] = rng.integers(-1, 5, size=nctu)
+    params[:, 1] = rng.integers(0, 32, size=nctu)
+    params[:, 2:6] = rng.integers(-lim, lim + 1, size=(nctu, 4))
+    for a in range(nctu):
+        if a % cw and rng.random() < 0.3:
+            params[a] = params[a - 1]
+            params[a, 6] = 1
+    return y, rec, params
+
+
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 200, 150), (10, 192, 136), (8, 64, 64)])
+def test_sao_restatement_equals_reference_class(depth, width, height):
+    """oracle/x265_oracle_pipeline4.c's SAO passes against the real SAO class (oracle/ref_sao.cpp): calcSaoStatsCTU's count /
+    offsetOrg of every CTU, type and class, and the picture after generateLumaOffsets over all CTUs - including pictures that
+    are not a multiple of the CTU size, merge-left CTUs and clipping."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_sao"):
+        pytest.skip("oracle/_ref predates ref_sao.cpp")
+    y, rec, params = sao_case(depth, width, height, 5)
+    fenc, stride, org, w64, h64 = F.pad_plane(y)
+    recp = F.pad_plane(rec)[0]
+    nctu = params.shape[0]
+    rcnt, roff = np.zeros((nctu, 5, 32), np.int32), np.zeros((nctu, 5, 32), np.int32)
+    rout = recp.copy()
+    lib.x265ref_sao.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.x265ref_sao(fenc.ctypes.data, rout.ctypes.data, width, height, params.ctypes.data, rcnt.ctypes.data, roff.ctypes.data) == 0
+    cnt, off = O.sao_stats(depth, fenc, recp, stride, org, width, height)
+    assert np.array_equal(cnt, rcnt), f"count differs in CTU/type {np.argwhere((cnt != rcnt).any(axis=2))[:6].tolist()}"
+    assert np.array_equal(off, roff), f"offsetOrg differs in CTU/type {np.argwhere((off != roff).any(axis=2))[:6].tolist()}"
+    out = O.sao_apply(depth, recp, stride, org, width, height, params)
+    rows = out.size // stride
+    a = out.reshape(rows, stride)[org // stride: org // stride + height, org % stride: org % stride + width]
+    b = rout.reshape(rows, stride)[org // stride: org // stride + height, org % stride: org % stride + width]
+    assert np.array_equal(a, b), f"{np.count_nonzero(a != b)} samples differ, first at {np.argwhere(a != b)[:4].tolist()}"
+    assert (a != recp.reshape(rows, stride)[org // stride: org // stride + height, org % stride: org % stride + width]).any()
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_search_driver_with_extra_candidates_equals_reference(depth):
     """motionEstimate's mvc[] candidates (motion.cpp:800-812: measured with SAD + mv cost against the predictor's cost, skipping

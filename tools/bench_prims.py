@@ -133,7 +133,7 @@ def main():
     import argparse
     import torch
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="", help="comma-separated families to run: compare,interp,transform,quant,intra,intratu,blockop,loopfilter")
+    ap.add_argument("--only", default="", help="comma-separated families to run: compare,interp,transform,quant,intra,intratu,blockop,loopfilter,sao")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU columns (profiling runs)")
     args = ap.parse_args()
     want = set(x for x in args.only.split(",") if x)
@@ -224,7 +224,7 @@ def main():
                        SIG_DCT, [(src_h, n_), (dst_h, n_)], jb, extra)
 
     # ---- a8: quant family, 32x32 ----
-    if not (on("quant") or on("intra") or on("intratu") or on("blockop") or on("loopfilter")):
+    if not (on("quant") or on("intra") or on("intratu") or on("blockop") or on("loopfilter") or on("sao")):
         return
     nb, n2 = 1 << 15, 1024
     coef_h = rng.integers(-255, 256, size=nb * n2, dtype=np.int16)
@@ -332,6 +332,40 @@ def main():
     jd = jobs_dev(jb, dev)
     t = timeit(lambda: A.loopfilter_batch(A.LF_DEBLOCK_LUMA_STRONG, 8, [A.plane(ref_d, st)], jd, ne))
     report(cpu, "pelFilterLumaStrong (4 lines)", ne, t, 4 * 8 + 4 * 6, "pelFilterLumaStrong[0]", SIG_DEBLOCK_LUMA, [(ref_h, st)], jb)
+
+    # ---- (f)-4: frame-level SAO passes on a 4K picture (statistics for every CTU / type / class; offsets applied out of place) ----
+    if on("loopfilter") or on("sao"):
+        import time
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_api as O  # noqa: E402  (bench.py's cpu_baseline leg)
+        F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+        sw, sh = 3840, 2160
+        yv = F.synth_clip(sw, sh, 1, depth=8, seed=3)[0][0]
+        rc = np.clip(yv.astype(np.int32) + rng.integers(-3, 4, size=yv.shape), 0, 255).astype(np.uint8)
+        fp, fst, forg, _, _ = F.pad_plane(yv)
+        rp = F.pad_plane(rc)[0]
+        nctu = ((sw + 63) // 64) * ((sh + 63) // 64)
+        par = np.zeros((nctu, 7), np.int32)
+        par[:, 0] = rng.integers(0, 5, size=nctu); par[:, 1] = rng.integers(0, 32, size=nctu); par[:, 2:6] = rng.integers(-7, 8, size=(nctu, 4))
+        d_f, d_r = to_dev(fp.reshape(-1), dev), to_dev(rp.reshape(-1), dev)
+        d_o = d_r.clone()
+        d_c = torch.zeros(nctu * 160, dtype=torch.int32, device=dev)
+        d_s = torch.zeros(nctu * 160, dtype=torch.int32, device=dev)
+        d_p = torch.from_numpy(par.reshape(-1)).to(dev)
+        for name, fn, bpp, cpu_fn in (
+                ("sao stats 4K frame (5 types/CTU)", lambda: A.sao_stats(8, d_f, fst, forg, d_r, fst, forg, sw, sh, d_c, d_s), 2,
+                 lambda: O.sao_stats(8, fp, rp, fst, forg, sw, sh, nthreads=cpu.threads, avx2=True)),
+                ("sao apply 4K frame", lambda: A.sao_apply(8, d_r, fst, forg, d_o, fst, forg, sw, sh, d_p), 2,
+                 lambda: O.sao_apply(8, rp, fst, forg, sw, sh, par, nthreads=cpu.threads, avx2=True))):
+            t = timeit(fn)
+            col, ratio = f"{'-':>10s}", f"{'-':>8s}"
+            if cpu.port is not None:
+                cpu_fn()
+                t0 = time.perf_counter(); cpu_fn(); tc = time.perf_counter() - t0
+                col, ratio = f"{sw * sh * bpp / tc / 1e9:10.1f}", f"{tc / t:8.1f}"
+            gbs = sw * sh * bpp / t / 1e9
+            print(f"{name:40s} {nctu:8d} {t * 1e6:9.1f} {4096 * bpp:7d} {gbs:9.1f} {gbs / HBM:6.3f} {'-':>10s} {col} {ratio}  "
+                  f"CTUs; bytes = the two planes touched once; CPU column = oracle restatement on {cpu.threads} threads", flush=True)
 
 
 if __name__ == "__main__":

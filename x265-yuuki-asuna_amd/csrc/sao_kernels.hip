@@ -1,0 +1,238 @@
+// sao_kernels.hip - sample adaptive offset of the device-resident deblocked luma picture (SAO half):
+// the two pixel passes.  The rate-distortion choice of the parameters between them (sao.cpp:1225-1605, entropy-coder bit counts
+// over ~100 numbers per CTU) stays with the host.
+//
+// Reference semantics: SAO::calcSaoStatsCTU (encoder/sao.cpp:735-917; saoCuStatsBO / E0..E3, common/loopfilter.cpp) - per CTU,
+// type and class the number of samples and the sum of (source - deblocked) - and SAO::generateLumaOffsets / applyPixelOffsets
+// (sao.cpp:572-630, 274-570), which filter in place against saved copies of the not yet offset neighbours, i.e. out of place.
+// Edge class of a sample c with neighbours a, b along the direction: s_eoTable[sign(c - a) + sign(c - b) + 2], table { 1, 2, 0,
+// 3, 4 } (sao.cpp:67); band = c >> (depth - 5).
+//
+// Statistics: one workgroup per CTU; the deblocked 66x66 neighbourhood is staged in LDS once, a thread walks 16 samples of a
+// row with a sliding 3x3 window and keeps the 4 x 5 edge accumulators packed (count << 20 | biased sum) in registers; the 32
+// bands go through per-wavefront LDS histograms.  HBM traffic is the two planes read once: 2 samples per pixel.
+#include "common.h"
+
+namespace x265hip {
+
+struct SaoStatsArgs
+{
+    const uint8_t* fenc; long fencStrideB;
+    const uint8_t* rec; long recStrideB;
+    int width, height, depth, ctusW;
+    int32_t* count; int32_t* offsetOrg;
+};
+
+__device__ __forceinline__ int sao_sign(int x) { return (x > 0) - (x < 0); }
+
+template <typename Px>
+__global__ void __launch_bounds__(256) sao_stats_kernel(SaoStatsArgs a)
+{
+    constexpr int BPP = sizeof(Px);
+    constexpr int LW = 68;                                   // LDS row pitch of the 66-wide neighbourhood
+    __shared__ uint16_t sRec[66 * LW];
+    __shared__ int sBo[4][2][32];
+    __shared__ int sEo[2][20];
+    const int tid = threadIdx.x;
+    const int addr = blockIdx.x;
+    const int lpelx = (addr % a.ctusW) * 64, tpely = (addr / a.ctusW) * 64;
+    const int rpelx = min(lpelx + 64, a.width), bpely = min(tpely + 64, a.height);
+    const int ctuW = rpelx - lpelx, ctuH = bpely - tpely;
+    const bool atRight = rpelx == a.width, atBottom = bpely == a.height;
+    // the reference's sub-rectangles (sao.cpp:806-915): the right 5 columns / bottom 4 rows wait for the neighbour's deblocking
+    const int boEndX = atRight ? ctuW : ctuW - 5, boEndY = atBottom ? ctuH : ctuH - 4;
+    const int startX = !lpelx, endX0 = atRight ? ctuW - 1 : ctuW - 5;
+    const int startY = !tpely, endY1 = atBottom ? ctuH - 1 : ctuH - 4;
+    const int e0EndY = ctuH - 4, e1EndX = boEndX;
+    for (int i = tid; i < 4 * 2 * 32; i += 256) (&sBo[0][0][0])[i] = 0;
+    if (tid < 40) (&sEo[0][0])[tid] = 0;
+    // stage rows -1..64, columns -1..64 of the deblocked picture (the planes are padded, so the border reads are legal)
+    const Px* rec = reinterpret_cast<const Px*>(a.rec) + lpelx + (long)tpely * (a.recStrideB / BPP);
+    const long rst = a.recStrideB / BPP;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < 66; r += 4)
+        for (int c = lane; c < 66; c += 64)
+            sRec[r * LW + c] = (uint16_t)rec[(long)(r - 1) * rst + (c - 1)];
+    __syncthreads();
+    // a thread owns 16 consecutive samples of one row (four threads per row)
+    const int y = tid >> 2, x0 = (tid & 3) * 16;
+    const Px* fe = reinterpret_cast<const Px*>(a.fenc) + lpelx + (long)(tpely + y) * (a.fencStrideB / BPP);
+    const int bias = 1 << a.depth, boShift = a.depth - 5;
+    uint32_t acc[4][5];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[t][k] = 0;
+    if (y < ctuH)
+    {
+        // sliding window along the row: w[r][0..2] = columns x-1, x, x+1 of rows y-1, y, y+1 (LDS coordinates are shifted by one)
+        int w[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) { w[r][1] = sRec[(y + r) * LW + x0]; w[r][2] = sRec[(y + r) * LW + x0 + 1]; }
+        const bool yE0 = y < e0EndY, yE1 = y >= startY && y < endY1, yBo = y < boEndY;
+        // s_eoTable = { 1, 2, 0, 3, 4 }: class of edgeType e
+        auto cls = [](int e) { return e == 0 ? 1 : (e == 1 ? 2 : (e == 2 ? 0 : e)); };
+#pragma unroll 4
+        for (int i = 0; i < 16; i++)
+        {
+            const int x = x0 + i;
+#pragma unroll
+            for (int r = 0; r < 3; r++) { w[r][0] = w[r][1]; w[r][1] = w[r][2]; w[r][2] = sRec[(y + r) * LW + x + 2]; }
+            if (x >= ctuW) break;
+            const int c = w[1][1];
+            const int d = (int)fe[x] - c;
+            const uint32_t unit = (1u << 20) | (uint32_t)(d + bias);
+            const bool xE = x >= startX && x < endX0;
+            const int sc_l = sao_sign(c - w[1][0]), sc_r = sao_sign(c - w[1][2]);
+            const int sc_u = sao_sign(c - w[0][1]), sc_d = sao_sign(c - w[2][1]);
+            const int sc_ul = sao_sign(c - w[0][0]), sc_dr = sao_sign(c - w[2][2]);
+            const int sc_ur = sao_sign(c - w[0][2]), sc_dl = sao_sign(c - w[2][0]);
+            const int k0 = (xE && yE0) ? cls(sc_l + sc_r + 2) : 7;
+            const int k1 = (x < e1EndX && yE1) ? cls(sc_u + sc_d + 2) : 7;
+            const int k2 = (xE && yE1) ? cls(sc_ul + sc_dr + 2) : 7;
+            const int k3 = (xE && yE1) ? cls(sc_ur + sc_dl + 2) : 7;
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+            {
+                acc[0][k] += k0 == k ? unit : 0u;
+                acc[1][k] += k1 == k ? unit : 0u;
+                acc[2][k] += k2 == k ? unit : 0u;
+                acc[3][k] += k3 == k ? unit : 0u;
+            }
+            if (yBo && x < boEndX)
+            {
+                const int band = c >> boShift;
+                atomicAdd(&sBo[wave][0][band], 1);
+                atomicAdd(&sBo[wave][1][band], d);
+            }
+        }
+    }
+    // unpack, reduce over the wavefront, then over the workgroup
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+        {
+            const int cnt = (int)(acc[t][k] >> 20);
+            const int sum = (int)(acc[t][k] & 0xfffffu) - cnt * bias;
+            const int cw = group_sum<64>(cnt), sw = group_sum<64>(sum);
+            if ((tid & 63) == 0 && cw) { atomicAdd(&sEo[0][t * 5 + k], cw); atomicAdd(&sEo[1][t * 5 + k], sw); }
+        }
+    __syncthreads();
+    int32_t* cnt = a.count + (size_t)addr * 160;
+    int32_t* org = a.offsetOrg + (size_t)addr * 160;
+    if (tid < 160)
+    {
+        const int t = tid >> 5, k = tid & 31;
+        int c = 0, s = 0;
+        if (t < 4) { if (k < 5) { c = sEo[0][t * 5 + k]; s = sEo[1][t * 5 + k]; } }
+        else
+        {
+#pragma unroll
+            for (int w4 = 0; w4 < 4; w4++) { c += sBo[w4][0][k]; s += sBo[w4][1][k]; }
+        }
+        cnt[tid] = c; org[tid] = s;
+    }
+}
+
+struct SaoApplyArgs
+{
+    const uint8_t* src; long srcStrideB;
+    uint8_t* dst; long dstStrideB;
+    int width, height, depth, ctusW;
+    const int32_t* params;
+};
+
+template <typename Px>
+__global__ void __launch_bounds__(256) sao_apply_kernel(SaoApplyArgs a)
+{
+    constexpr int BPP = sizeof(Px);
+    const int tid = threadIdx.x, addr = blockIdx.x;
+    const int lpelx = (addr % a.ctusW) * 64, tpely = (addr / a.ctusW) * 64;
+    const int32_t* p = a.params + (size_t)addr * 7;
+    const int typeIdx = p[0], bandPos = p[1];
+    const int o0 = (int8_t)p[2], o1 = (int8_t)p[3], o2 = (int8_t)p[4], o3 = (int8_t)p[5];
+    const int maxVal = (1 << a.depth) - 1, boShift = a.depth - 5;
+    const long sst = a.srcStrideB / BPP, dst_st = a.dstStrideB / BPP;
+    const Px* src = reinterpret_cast<const Px*>(a.src);
+    Px* dst = reinterpret_cast<Px*>(a.dst);
+    // a lane owns one column (unit-stride loads and stores across the wavefront), a wavefront every fourth row
+    const int x = lpelx + (tid & 63);
+    if (x >= a.width) return;
+    // neighbour step of the edge classes: EO_0 horizontal, EO_1 vertical, EO_2 135 degrees, EO_3 45 degrees
+    const int dx = typeIdx == 1 ? 0 : (typeIdx == 3 ? -1 : 1), dy = typeIdx == 0 ? 0 : 1;
+    const bool okx = !dx || (x > 0 && x < a.width - 1);
+    for (int i = 0; i < 16; i++)
+    {
+        const int y = tpely + (tid >> 6) + 4 * i;
+        if (y >= a.height) break;
+        const bool oky = !dy || (y > 0 && y < a.height - 1);
+        const Px* c = src + x + (long)y * sst;
+        int v = *c;
+        if (typeIdx == 4)
+        {
+            const int k = ((v >> boShift) - bandPos) & 31;                  // offset[i] sits on band (bandPos + i) mod 32
+            const int off = k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : (k == 3 ? o3 : 0)));
+            v = clip3(0, maxVal, v + off);
+        }
+        else if (typeIdx >= 0)
+        {
+            if (okx && oky)
+            {
+                const int na = c[-dx - dy * sst], nb = c[dx + dy * sst];
+                const int e = sao_sign(v - na) + sao_sign(v - nb) + 2;
+                // offsetEo[e] = offset[s_eoTable[e]] with offset[] = { 0, o0, o1, o2, o3 }, s_eoTable = { 1, 2, 0, 3, 4 }
+                const int off = e == 0 ? o0 : (e == 1 ? o1 : (e == 2 ? 0 : (e == 3 ? o2 : o3)));
+                v = clip3(0, maxVal, v + off);
+            }
+        }
+        dst[x + (long)y * dst_st] = (Px)v;
+    }
+}
+
+} // namespace x265hip
+
+using namespace x265hip;
+
+extern "C" int x265hip_sao_stats(const x265hip_sao_stats_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->fenc || !p->rec || !p->count || !p->offset_org) { set_error("sao_stats: NULL operand"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("sao_stats: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->width <= 0 || p->height <= 0) { set_error("sao_stats: empty picture"); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    SaoStatsArgs a;
+    a.fenc = (const uint8_t*)p->fenc; a.fencStrideB = (long)p->fenc_stride * bpp;
+    a.rec = (const uint8_t*)p->rec; a.recStrideB = (long)p->rec_stride * bpp;
+    a.width = p->width; a.height = p->height; a.depth = p->depth; a.ctusW = (p->width + 63) / 64;
+    a.count = p->count; a.offsetOrg = p->offset_org;
+    const int nctu = a.ctusW * ((p->height + 63) / 64);
+    hipStream_t s = (hipStream_t)stream;
+    if (bpp == 1) hipLaunchKernelGGL(sao_stats_kernel<uint8_t>, dim3(nctu), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(sao_stats_kernel<uint16_t>, dim3(nctu), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x265hip_sao_apply(const x265hip_sao_apply_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->src || !p->dst || !p->ctu_params) { set_error("sao_apply: NULL operand"); return X265HIP_EINVAL; }
+    if (p->src == p->dst) { set_error("sao_apply: the filter is out of place (a sample is classified against unfiltered neighbours)"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("sao_apply: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->width <= 0 || p->height <= 0) { set_error("sao_apply: empty picture"); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    SaoApplyArgs a;
+    a.src = (const uint8_t*)p->src; a.srcStrideB = (long)p->src_stride * bpp;
+    a.dst = (uint8_t*)p->dst; a.dstStrideB = (long)p->dst_stride * bpp;
+    a.width = p->width; a.height = p->height; a.depth = p->depth; a.ctusW = (p->width + 63) / 64;
+    a.params = p->ctu_params;
+    const int nctu = a.ctusW * ((p->height + 63) / 64);
+    hipStream_t s = (hipStream_t)stream;
+    if (bpp == 1) hipLaunchKernelGGL(sao_apply_kernel<uint8_t>, dim3(nctu), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(sao_apply_kernel<uint16_t>, dim3(nctu), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}

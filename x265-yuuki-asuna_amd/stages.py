@@ -87,6 +87,26 @@ class Deblock:
         hipabi.deblock_luma(self.depth, plane, pic.stride, pic.org, self.w64, self.h64, self.bs_ver, self.bs_hor, self.qp)
 
 
+class Sao:
+    """Sample adaptive offset of the deblocked luma picture: the two pixel passes on device (x265hip_sao_stats /
+    x265hip_sao_apply; reference SAO::calcSaoStatsCTU sao.cpp:735-917 and generateLumaOffsets / applyPixelOffsets :572-630,
+    :274-570).  The parameter choice between them (rdoSaoUnitCu, entropy-coder bit counts) is host work: `stats()` fills
+    count / offset_org [numCtu, 5, 32]; `apply(params)` takes int32 [numCtu, 7] = typeIdx, bandPos, offset[4], mergeLeft."""
+
+    def __init__(self, width, height, depth, device):
+        import torch
+        self.width, self.height, self.depth = width, height, depth
+        self.nctu = ((width + 63) // 64) * ((height + 63) // 64)
+        self.count = torch.zeros(self.nctu * 160, dtype=torch.int32, device=device)
+        self.offset_org = torch.zeros(self.nctu * 160, dtype=torch.int32, device=device)
+
+    def stats(self, src: DevicePicture, rec, rec_stride, rec_org):
+        hipabi.sao_stats(self.depth, src.t, src.stride, src.org, rec, rec_stride, rec_org, self.width, self.height, self.count, self.offset_org)
+
+    def apply(self, rec, rec_stride, rec_org, out, params):
+        hipabi.sao_apply(self.depth, rec, rec_stride, rec_org, out, rec_stride, rec_org, self.width, self.height, params)
+
+
 class Lookahead:
     """Lookahead picture preparation + intra cost estimate on device (x265hip_lowres_init / x265hip_lowres_intra; reference
     Lowres::init lowres.cpp:294-306 and LookaheadTLD::lowresIntraEstimate slicetype.cpp:696-772).  Geometry follows
