@@ -15,6 +15,8 @@ the frame pipeline, everything resident in HBM:
     SUB  sub-pel refinement of every PU (subme 3 = preset slow)
     REC  32x32 prediction + residual DCT / quant / dequant / iDCT / reconstruction + SSE (MC + TU round trip)
     DBK  in-loop luma deblocking of the reconstruction (boundary strengths from the mvs / coded flags, edge filters)
+    SAO  sample-adaptive-offset statistics of the deblocked reconstruction for every CTU, type and class (calcSaoStatsCTU;
+         the parameter decision and therefore the offsets themselves are host work)
     EXT  border extension; the filtered reconstruction is the next frame's reference (closed loop)
 
 With N GPUs the job is frame-parallel (one frame per GPU per step, weak scaling); the only data-path exchange is
@@ -72,7 +74,8 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0):
                                       nthreads=cores, avx2=avx2)
         if n == nctu:       # per-picture stage, single-threaded in the restatement
             bv, bh = O.deblock_bs_inter(depth, w64, h64, level, mv, ns, avx2=avx2)
-            O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, qp, avx2=avx2)
+            dbk = O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, qp, avx2=avx2)
+            O.sao_stats(depth, cur.reshape(-1), dbk.reshape(-1), stride, org, w64, h64, nthreads=cores, avx2=avx2)
         return time.perf_counter() - t
 
     probe = min(nctu, max(cores, 8))
@@ -172,7 +175,7 @@ def main():
     pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
                            qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed" and args.depth == 8,
-                           lookahead=(args.width, args.height), search=args.search, deblock=True)
+                           lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True)
     ref_pic = P.DevicePicture.__new__(P.DevicePicture)
     ref_pic.__dict__.update(pics[0].__dict__)
     ref_pic.t = pics[0].t.clone()                    # the reference every rank searches in (starts as frame 0)
@@ -207,10 +210,10 @@ def main():
     # ---- untimed pass: HIP-event time of every stage (events on the stream the kernels are launched on) ----
     ms, sp, rc = pipe.ms, pipe.sp, pipe.rc
     cur = pics[1]
-    names = ["lookahead", "me", "subpel", "recon", "deblock", "border"]
+    names = ["lookahead", "me", "subpel", "recon", "deblock", "sao_stats", "border"]
     acc = {k: [] for k in names}
     for _ in range(5):
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
         lk, lk2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         lk.record()
         pipe.la.run(cur)                          # half-resolution planes + intra cost estimate of the source picture
@@ -235,8 +238,10 @@ def main():
         marks[3].record()
         pipe.db.run(pipe.recon, cur, mv_out, rc.num_sig)      # boundary strengths + vertical / horizontal edge passes
         marks[4].record()
-        S.extend_border(pipe.recon, cur)
+        pipe.sao.stats(cur, pipe.recon, cur.stride, cur.org)
         marks[5].record()
+        S.extend_border(pipe.recon, cur)
+        marks[6].record()
         torch.cuda.synchronize()
         acc["lookahead"].append(lk.elapsed_time(lk2))
         for j, k in enumerate(names[1:]):
@@ -259,7 +264,7 @@ def main():
                                    (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + ('packed' if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
                                     f"sub-pel subme={args.subme} -> " if args.search == "full" else
                                     f"{args.search} search driver (motionEstimate, merange {args.range}, subme {args.subme}, predictor 0) for all 85 PUs/CTU -> ") +
-                                   f"{8 << args.level}x{8 << args.level} prediction + DCT/quant/recon qp {args.qp} -> luma deblocking -> "
+                                   f"{8 << args.level}x{8 << args.level} prediction + DCT/quant/recon qp {args.qp} -> luma deblocking -> SAO statistics -> "
                                    f"border extension -> next reference; pipeline throughput, not HEVC encoded fps",
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world}",
                        "ctus_per_frame": ms.nctu, "checksum": csum},

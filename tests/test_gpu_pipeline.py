@@ -28,7 +28,7 @@ def test_closed_loop_three_frames(depth, deblock):
     R, subme, level, qp = 12, 2, 2, (30 if deblock else 24) + 12 * (depth == 10)
     clip = F.synth_clip(192, 128, 4, depth=depth, seed=61)
     pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
-    fp = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=R, subme=subme, level=level, qp=qp, want_surf=False, deblock=deblock)
+    fp = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=R, subme=subme, level=level, qp=qp, want_surf=False, deblock=deblock, sao=deblock)
     ref_dev = P.DevicePicture(clip[0][0], dev)             # frame 0 is the first reference as-is
     ref_host = ref_dev.host.copy()
     cost = F.mv_cost_table(R)
@@ -47,6 +47,10 @@ def test_closed_loop_three_frames(depth, deblock):
         if deblock:         # the in-loop filter runs on the reconstruction before it becomes a reference
             bv, bh = O.deblock_bs_inter(depth, cur.w64, cur.h64, level, mv, ens)
             erec = O.deblock_luma(depth, erec.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64, bv, bh, qp).reshape(erec.shape)
+        if deblock:         # SAO statistics of the filtered reconstruction against the source
+            ecnt, eoff = O.sao_stats(depth, cur.host.reshape(-1), erec.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64)
+            assert np.array_equal(fp.sao.count.cpu().numpy().reshape(ecnt.shape), ecnt), f"frame {k}: SAO counts differ"
+            assert np.array_equal(fp.sao.offset_org.cpu().numpy().reshape(eoff.shape), eoff), f"frame {k}: SAO offset sums differ"
         inner = erec[F.MARGIN_Y:F.MARGIN_Y + cur.h64, F.MARGIN_X:F.MARGIN_X + cur.w64]
         erec = np.pad(inner, ((F.MARGIN_Y, F.MARGIN_Y), (F.MARGIN_X, F.MARGIN_X)), mode="edge")   # extendPicBorder
         grec = rec.cpu().numpy().view(cur.host.dtype).reshape(cur.host.shape)

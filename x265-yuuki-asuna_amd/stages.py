@@ -231,7 +231,7 @@ class FramePipeline:
     cost estimate per 8x8 block), which only depends on the source."""
 
     def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False, lookahead=None,
-                 search="full", deblock=False):
+                 search="full", deblock=False, sao=False):
         import torch
         from .pipeline import MotionSearch, SubpelRefine
         self.depth = depth
@@ -245,6 +245,8 @@ class FramePipeline:
         self.rc = InterRecon(self.ms.nctu, w64, h64, depth, level, qp, device)
         self.la = Lookahead(lookahead[0], lookahead[1], depth, device) if lookahead else None
         self.db = Deblock(w64, h64, depth, level, qp, device) if deblock else None
+        # SAO statistics of the deblocked reconstruction (what rdoSaoUnitCu reads); the offsets themselves are the host's decision
+        self.sao = Sao(w64, h64, depth, device) if sao else None
         self.recon = None
 
     def run(self, cur: DevicePicture, ref: DevicePicture):
@@ -264,6 +266,8 @@ class FramePipeline:
         self.rc.run(cur, ref, self.recon, mv)
         if self.db is not None:
             self.db.run(self.recon, cur, mv, self.rc.num_sig)
+        if self.sao is not None:
+            self.sao.stats(cur, self.recon, cur.stride, cur.org)
         extend_border(self.recon, cur)
         return self.recon
 
@@ -274,5 +278,8 @@ class FramePipeline:
         out.update(self.rc.checksum())
         if self.la is not None:
             out.update(self.la.checksum())
+        if self.sao is not None:
+            out["sao_count"] = int(self.sao.count.sum(dtype=torch.int64).item())
+            out["sao_offset_org"] = int(self.sao.offset_org.sum(dtype=torch.int64).item())
         out["recon"] = int(self.recon.view(torch.uint8).to(torch.int64).sum().item())
         return out
