@@ -21,7 +21,7 @@ def _oracle():
     return oracle_api
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", [8, 10, 12])
 @pytest.mark.parametrize("level", [0, 1, 2])
 def test_deblock_after_reconstruction(depth, level):
     """The real use: boundary strengths from the sub-pel / reconstruction stages' outputs, then the filter, on a

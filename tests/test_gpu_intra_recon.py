@@ -35,7 +35,8 @@ def _smooth(a):
 
 
 @pytest.mark.parametrize("depth,n,qp,islice", [(8, 4, 22, 1), (8, 8, 27, 1), (8, 16, 32, 0), (8, 32, 22, 1), (8, 32, 44, 0),
-                                               (10, 4, 30, 0), (10, 8, 12, 1), (10, 16, 24, 1), (10, 32, 37, 1), (8, 16, 0, 1)])
+                                               (10, 4, 30, 0), (10, 8, 12, 1), (10, 16, 24, 1), (10, 32, 37, 1), (8, 16, 0, 1),
+                                               (12, 4, 40, 1), (12, 16, 33, 0), (12, 32, 50, 1)])
 def test_intra_recon_matches_oracle(depth, n, qp, islice):
     import torch
     dev = torch.device("cuda:0")

@@ -33,7 +33,7 @@ def _pair(width, height, depth, seed):
     return y1, y0
 
 
-@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 208, 144), (10, 192, 128), (8, 1920, 1080), (10, 640, 360), (8, 48, 32)])
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 208, 144), (10, 192, 128), (8, 1920, 1080), (10, 640, 360), (8, 48, 32), (12, 208, 144)])
 def test_lowres_cost_matches_oracle(depth, width, height):
     import torch
     dev = torch.device("cuda:0")
@@ -62,7 +62,7 @@ def test_lowres_cost_matches_oracle(depth, width, height):
         assert (mvs != 0).any() and ((lcost >> 14) == 0).any() and ((lcost >> 14) == 1).any()
 
 
-@pytest.mark.parametrize("depth,width,height,bias", [(8, 256, 128, 0), (8, 208, 144, 20), (10, 192, 128, 0), (8, 1280, 720, 0)])
+@pytest.mark.parametrize("depth,width,height,bias", [(8, 256, 128, 0), (8, 208, 144, 20), (10, 192, 128, 0), (8, 1280, 720, 0), (12, 192, 128, 0)])
 def test_lowres_b_cost_matches_oracle(depth, width, height, bias):
     """B pictures: two lists, the skip shortcut, the two bi-directional candidates and the scaled score; then a second estimate
     that reuses list 0 (bDoSearch[0] == false)."""

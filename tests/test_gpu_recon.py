@@ -20,7 +20,7 @@ def _oracle():
     return oracle_api
 
 
-@pytest.mark.parametrize("depth,level,qp", [(8, 2, 22), (8, 1, 30), (8, 0, 12), (8, 2, 45), (10, 2, 34), (10, 1, 20), (8, 2, 0)])
+@pytest.mark.parametrize("depth,level,qp", [(8, 2, 22), (8, 1, 30), (8, 0, 12), (8, 2, 45), (10, 2, 34), (10, 1, 20), (8, 2, 0), (12, 2, 40), (12, 0, 30)])
 def test_inter_recon_matches_oracle(depth, level, qp):
     import torch
     dev = torch.device("cuda:0")

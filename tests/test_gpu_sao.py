@@ -26,7 +26,7 @@ def _case(depth, width, height, seed):
     return sao_case(depth, width, height, seed)
 
 
-@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 200, 150), (10, 192, 136), (8, 64, 64), (8, 1920, 1080), (10, 832, 480), (8, 70, 66)])
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 200, 150), (10, 192, 136), (8, 64, 64), (8, 1920, 1080), (10, 832, 480), (8, 70, 66), (12, 200, 150)])
 def test_sao_passes_match_oracle(depth, width, height):
     import torch
     dev = torch.device("cuda:0")
