@@ -60,7 +60,7 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0):
     lw, lh = ((clip[0][0].shape[1] // 2 + 7) >> 3) * 8, ((clip[0][0].shape[0] // 2 + 7) >> 3) * 8
     lstride = (lw + 2 * F.MARGIN_X + 31) & ~31
 
-    def run(n):
+    def run(n, cores=cores):
         t = time.perf_counter()
         if n == nctu:       # the lookahead stage is per picture: include it with whole-frame samples
             lp = O.lowres_init(depth, cur, stride, org, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lh + 2 * F.MARGIN_Y, lw, lh,
@@ -85,7 +85,11 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0):
     while t < target_s * 0.66 and reps < 64:      # ~10-15 s of wall time: repeat the (sub-)frame if one pass is shorter
         t += run(n)
         reps += 1
+    # the same chain on ONE thread (SURVEY 8(d) asks for both figures): a short CTU sample, per-picture stages left out
+    n1 = min(nctu - 1, 8)
+    t1 = run(n1, 1)
     return {"value": round(reps * (n / nctu) / t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "one_thread_value": round((n1 / nctu) / t1, 5),
             "sample": f"{reps} x {n} of {nctu} CTUs of the same {clip[0][0].shape[1]}x{clip[0][0].shape[0]} frame through the same stages (search keeps only the best mv), "
                       f"oracle C ({'-march=x86-64-v3' if avx2 else 'generic x86-64'}) with OpenMP over CTUs on {cores} threads "
                       f"(the container's CPU quota; {os.cpu_count()} hardware threads visible), {t:.1f} s"}
