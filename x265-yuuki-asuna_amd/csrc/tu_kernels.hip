@@ -394,7 +394,7 @@ struct IntraTuArgs
 };
 
 template <typename Px, int N>
-__global__ void __launch_bounds__(64, (N == 4 ? 8 : (N == 8 ? 5 : (N == 16 ? 4 : 2)))) intra_recon_kernel(IntraTuArgs a)
+__global__ void __launch_bounds__(N <= 8 ? 256 : 64) intra_recon_kernel(IntraTuArgs a)
 {
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
     constexpr int BPP = sizeof(Px);
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(64, (N == 4 ? 8 : (N == 8 ? 5 : (N == 16 ? 4 :
     TuOpsFor<N, N == 4> ops;
     ops.init(tid & 63);
     // a persistent single-wavefront workgroup: the operands above are built once, the barriers below are wave-local
-    for (int job = blockIdx.x; job < a.njobs; job += gridDim.x)
+    auto do_job = [&](const int job)
     {
         const x265hip_job jb = a.jobs[job];
         const int mode = jb.arg[0];
@@ -436,7 +436,11 @@ __global__ void __launch_bounds__(64, (N == 4 ? 8 : (N == 8 ? 5 : (N == 16 ? 4 :
                                 a.levels + (size_t)job * NN, &a.numSig[job], &a.dist[job],
                                 reinterpret_cast<Px*>(a.recon) + jb.off[3], a.reconStrideB / BPP);
         __syncthreads();
-    }
+    };
+    // 4 / 8: one candidate per workgroup; 16 / 32: persistent, the MFMA operands above are reused
+    if constexpr (N <= 8) do_job(blockIdx.x);
+    else
+        for (int job = blockIdx.x; job < a.njobs; job += gridDim.x) do_job(job);
 }
 
 } // namespace x265hip
