@@ -9,7 +9,8 @@ A "step" = one 3840x2160 8-bit frame (BASELINE.json `metric`: "4K preset=slow" =
 the frame pipeline, everything resident in HBM:
 
     LA   lookahead preparation of the source picture: four half-resolution planes + border extension, intra cost
-         estimate of every 8x8 lowres block (Lowres::init / lowresIntraEstimate)
+         estimate of every 8x8 lowres block (Lowres::init / lowresIntraEstimate); the P-frame cost estimate against the
+         previous picture (estimateFrameCost) runs ahead on a side stream, --lookahead-batch pictures per launch
     ME   exhaustive +-57 search (the reference's default merange), all 85 PUs of every CTU: SAD surfaces
          (sad_x4 grouping) + best mv, one launch
     SUB  sub-pel refinement of every PU (subme 3 = preset slow)
@@ -65,7 +66,12 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0):
         if n == nctu:       # the lookahead stage is per picture: include it with whole-frame samples
             lp = O.lowres_init(depth, cur, stride, org, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lh + 2 * F.MARGIN_Y, lw, lh,
                                F.MARGIN_X, F.MARGIN_Y, avx2=avx2)
-            O.lowres_intra(depth, lp[0], lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lw // 8, lh // 8, 5, nthreads=cores, avx2=avx2)
+            ic, _, _ = O.lowres_intra(depth, lp[0], lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lw // 8, lh // 8, 5, nthreads=cores, avx2=avx2)
+            # the frame cost estimate against the previous picture is serial per picture (the reference spreads pictures over threads)
+            lq, lqoff = F.qpel_cost_table(16, lam=1.0 if depth == 8 else 16.0, qmax=4 * (max(lw, lh) + 64))
+            lpr = O.lowres_init(depth, ref, stride, org, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lh + 2 * F.MARGIN_Y, lw, lh,
+                                F.MARGIN_X, F.MARGIN_Y, avx2=avx2)
+            O.lowres_cost(depth, lp[0], lpr, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lw // 8, lh // 8, lq, lqoff, ic, avx2=avx2)
         _, best = O.me_fullsearch(depth, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, cost, cost,
                                   want_surf=False, want_best=True, nthreads=cores, avx2=avx2)
         mv = O.subpel_refine(depth, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, best, cq, qoff, subme,
@@ -136,6 +142,8 @@ def main():
     ap.add_argument("--search", choices=["full", "dia", "hex", "star"], default="full",
                     help="full = exhaustive search (SAD surfaces + best mv) + sub-pel stage; dia/hex/star = the reference's pattern "
                          "searches run by the device-side search driver (x265hip_me_search), predictor (0,0)")
+    ap.add_argument("--lookahead-batch", type=int, default=0,
+                    help="pictures per launch of the lookahead's P-frame cost estimate, which runs ahead on a side stream (0 = stage off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prims", action="store_true",
                     help="instead of the pipeline line, print the per-family table of the batch-layer kernels with the CPU paths timed beside "
@@ -179,7 +187,7 @@ def main():
     pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
                            qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed" and args.depth == 8,
-                           lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True)
+                           lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True, lookahead_cost_batch=args.lookahead_batch)
     ref_pic = P.DevicePicture.__new__(P.DevicePicture)
     ref_pic.__dict__.update(pics[0].__dict__)
     ref_pic.t = pics[0].t.clone()                    # the reference every rank searches in (starts as frame 0)
@@ -193,6 +201,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    pipe.launch_lookahead_costs()                    # no lookahead work of the warm-up frames leaks into the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -200,6 +209,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    pipe.launch_lookahead_costs()                    # flush the incomplete batch: all K pictures are scored inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -251,6 +261,20 @@ def main():
         for j, k in enumerate(names[1:]):
             acc[k].append(marks[j].elapsed_time(marks[j + 1]))
     stages = {k: round(float(np.median(v)), 4) for k, v in acc.items()}
+    if pipe.lcb:
+        # the lookahead's cost estimate: one launch scores `lookahead_batch` pictures on its own stream, overlapped with the stages above
+        b = pipe.lcb
+        side = torch.cuda.Stream()
+        tms = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            S.LookaheadCost.run_batch(pipe.lc[:b], [pipe.ring[(j + 1) % len(pipe.ring)] for j in range(b)], [pipe.ring[j % len(pipe.ring)] for j in range(b)],
+                                      stream=side.cuda_stream)
+            e1.record(side)
+            torch.cuda.synchronize()
+            tms.append(e0.elapsed_time(e1))
+        stages["lookahead_cost_launch_of_%d (side stream, overlapped)" % b] = round(float(np.median(tms)), 4)
 
     if rank == 0:
         fps = world * args.steps / dt
@@ -264,7 +288,7 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8" if args.depth == 8 else "u16", "data": "synthetic",
-            "config": {"workload": f"{args.width}x{args.height} {args.depth}-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: lookahead lowres planes + intra estimate -> " +
+            "config": {"workload": f"{args.width}x{args.height} {args.depth}-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: lookahead lowres planes + intra estimate (+ P-frame cost estimate vs the previous picture, " + (f"{args.lookahead_batch} pictures per launch on a side stream" if args.lookahead_batch else "off") + ") -> " +
                                    (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + ('packed' if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
                                     f"sub-pel subme={args.subme} -> " if args.search == "full" else
                                     f"{args.search} search driver (motionEstimate, merange {args.range}, subme {args.subme}, predictor 0) for all 85 PUs/CTU -> ") +

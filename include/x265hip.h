@@ -230,6 +230,8 @@ typedef struct x265hip_lowres_cost_params
     const uint16_t* cost_q;  int qoff;
     int bframe_bias;                                /* param->bFrameBias: B score = costEst * 100 / (130 + bias) */
     const x265hip_lowres_cost_pair* pairs;  int npairs;
+    int pairs_on_device;                            /* 0: `pairs` is host memory (copied in stream order, may block the caller);
+                                                       1 / 2: `pairs` already is a device array of P (1) / B (2) pictures (no allocation, no copy, no validation) */
 } x265hip_lowres_cost_params;
 int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* stream);
 

@@ -64,3 +64,48 @@ def test_closed_loop_three_frames(depth, deblock):
         ref_dev.__dict__.update(cur.__dict__)
         ref_dev.t = rec.clone()
         ref_dev.host = erec
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_lookahead_costs_run_ahead_in_batches(depth):
+    """FramePipeline(lookahead_cost_batch=2): the lookahead's P-frame cost estimates are launched two pictures at a time on a side
+    stream over a ring of prepared pictures; every (picture, previous picture) pair must equal the oracle's estimate."""
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    W, Hh = 192, 128
+    clip = F.synth_clip(W, Hh, 8, depth=depth, seed=63)
+    pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
+    fp = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=8, subme=1, level=2, qp=30, want_surf=False, lookahead=(W, Hh),
+                         lookahead_cost_batch=2)
+    dt = clip[0][0].dtype
+    planes = []                                             # host copies of the prepared pictures, frame by frame
+
+    def expect(k):
+        la = fp.ring[0]
+        cq = fp.lc[0].cost_q.cpu().numpy().view(np.uint16)
+        cur_planes, ref_planes, icost = planes[k][0], planes[k - 1][0], planes[k][1]
+        return O.lowres_cost(depth, cur_planes[0], ref_planes, la.stride, la.org, la.wcu, la.hcu, cq, fp.lc[0].qoff, icost)
+
+    checked = 0
+    ref = pics[0]
+    for k in range(7):
+        n_before = len(fp.pending)
+        fp.run(pics[k], ref)
+        torch.cuda.synchronize()
+        planes.append(([p.cpu().numpy().view(dt).copy() for p in fp.la.planes], fp.la.intra_cost.cpu().numpy().copy()))
+        if k and n_before + 1 == 2:                         # this frame completed a batch: frames k-1 and k were scored
+            for i, kk in enumerate((k - 1, k)):
+                mvs, mvc, lcost, rows, frame = expect(kk)
+                st = fp.lc[i]
+                assert np.array_equal(st.mvs.cpu().numpy().reshape(-1, 2), mvs), f"frame {kk}: lookahead mvs differ"
+                assert np.array_equal(st.lowres_costs.cpu().numpy().view(np.uint16), lcost) and np.array_equal(st.frame.cpu().numpy()[:3], frame)
+                checked += 1
+    assert checked == 6 and not fp.pending
+    fp.run(pics[7], ref)
+    assert len(fp.pending) == 1
+    fp.launch_lookahead_costs()                             # flush the incomplete batch
+    torch.cuda.synchronize()
+    planes.append(([p.cpu().numpy().view(dt).copy() for p in fp.la.planes], fp.la.intra_cost.cpu().numpy().copy()))
+    mvs, mvc, lcost, rows, frame = expect(7)
+    assert np.array_equal(fp.lc[0].mvs.cpu().numpy().reshape(-1, 2), mvs) and np.array_equal(fp.lc[0].frame.cpu().numpy()[:3], frame)

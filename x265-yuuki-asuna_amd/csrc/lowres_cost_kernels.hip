@@ -340,6 +340,8 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("lowres_cost: depth %d", p->depth); return X265HIP_EINVAL; }
     if (p->width_in_cu <= 0 || p->height_in_cu <= 0) { set_error("lowres_cost: empty picture"); return X265HIP_EINVAL; }
     bool bidir = false;
+    if (p->pairs_on_device) bidir = p->pairs_on_device == 2;
+    else
     for (int i = 0; i < p->npairs; i++)
     {
         const x265hip_lowres_cost_pair& q = p->pairs[i];
@@ -359,8 +361,12 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     // the pair table travels in stream order: allocated, filled, used and released on `s`
     x265hip_lowres_cost_pair* dpairs = nullptr;
     const size_t bytes = sizeof(x265hip_lowres_cost_pair) * (size_t)p->npairs;
-    X265HIP_TRY(hipMallocAsync((void**)&dpairs, bytes, s));
-    X265HIP_TRY(hipMemcpyAsync(dpairs, p->pairs, bytes, hipMemcpyHostToDevice, s));
+    if (p->pairs_on_device) dpairs = const_cast<x265hip_lowres_cost_pair*>(p->pairs);
+    else
+    {
+        X265HIP_TRY(hipMallocAsync((void**)&dpairs, bytes, s));
+        X265HIP_TRY(hipMemcpyAsync(dpairs, p->pairs, bytes, hipMemcpyHostToDevice, s));
+    }
     LowresCostArgs a;
     a.pairs = dpairs;
     a.strideB = (int)(p->stride * bpp);
@@ -372,6 +378,6 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     else if (!bidir) hipLaunchKernelGGL((lowres_cost_kernel<uint16_t, false>), dim3(p->npairs), dim3(quads * 4), 0, s, a);
     else hipLaunchKernelGGL((lowres_cost_kernel<uint16_t, true>), dim3(p->npairs), dim3(quads * 4), 0, s, a);
     X265HIP_TRY(hipGetLastError());
-    X265HIP_TRY(hipFreeAsync(dpairs, s));
+    if (!p->pairs_on_device) X265HIP_TRY(hipFreeAsync(dpairs, s));
     return 0;
 }

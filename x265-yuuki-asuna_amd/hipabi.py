@@ -72,7 +72,7 @@ class LowresCostParams(ctypes.Structure):
     """x265hip_lowres_cost_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("stride", ctypes.c_ssize_t), ("width_in_cu", ctypes.c_int), ("height_in_cu", ctypes.c_int),
                 ("cost_q", ctypes.c_void_p), ("qoff", ctypes.c_int), ("bframe_bias", ctypes.c_int),
-                ("pairs", ctypes.POINTER(LowresCostPair)), ("npairs", ctypes.c_int)]
+                ("pairs", ctypes.POINTER(LowresCostPair)), ("npairs", ctypes.c_int), ("pairs_on_device", ctypes.c_int)]
 
 
 class MESearchJob(ctypes.Structure):
@@ -225,13 +225,35 @@ def lowres_cost_pair(depth, org, cur, ref_planes, intra_cost, mvs, mv_costs, low
     return q
 
 
-def lowres_cost(depth, stride, width_in_cu, height_in_cu, cost_q, qoff, pairs, bframe_bias=0, stream=None):
-    """Lookahead frame cost estimate (estimateFrameCost, slicetype.cpp:3115-3388) of a batch of independent pictures of one
-    geometry and one kind (all P or all B); pairs: list of LowresCostPair (lowres_cost_pair)."""
+def lowres_cost_table(pairs, device, stream=None):
+    """Upload a list of LowresCostPair once (pinned staging, non-blocking copy on `stream`): returns (device tensor, staging tensor,
+    kind) for lowres_cost(..., device_table=...).  Keep both tensors alive until the launch has run."""
+    import numpy as np
+    import torch
     arr = (LowresCostPair * len(pairs))(*pairs)
+    host = torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy()).pin_memory()
+    if stream is not None:
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            dev = host.to(device, non_blocking=True)
+    else:
+        dev = host.to(device, non_blocking=True)
+    return dev, host, (2 if pairs[0].ref1[0] else 1)
+
+
+def lowres_cost(depth, stride, width_in_cu, height_in_cu, cost_q, qoff, pairs, bframe_bias=0, stream=None, device_table=None):
+    """Lookahead frame cost estimate (estimateFrameCost, slicetype.cpp:3115-3388) of a batch of independent pictures of one
+    geometry and one kind (all P or all B); pairs: list of LowresCostPair (lowres_cost_pair), or None with
+    device_table = lowres_cost_table(...) for a table that already sits on the device (no host-side blocking)."""
     p = LowresCostParams()
     p.depth, p.stride, p.width_in_cu, p.height_in_cu = depth, stride, width_in_cu, height_in_cu
-    p.cost_q, p.qoff, p.bframe_bias, p.pairs, p.npairs = cost_q.data_ptr(), qoff, bframe_bias, arr, len(pairs)
+    p.cost_q, p.qoff, p.bframe_bias = cost_q.data_ptr(), qoff, bframe_bias
+    if device_table is not None:
+        dev, _, kind = device_table
+        p.pairs = ctypes.cast(ctypes.c_void_p(dev.data_ptr()), ctypes.POINTER(LowresCostPair))
+        p.npairs, p.pairs_on_device = dev.numel() // ctypes.sizeof(LowresCostPair), kind
+    else:
+        arr = (LowresCostPair * len(pairs))(*pairs)
+        p.pairs, p.npairs, p.pairs_on_device = arr, len(pairs), 0
     s = current_stream() if stream is None else stream
     f = lib().x265hip_lowres_cost
     f.argtypes = [ctypes.POINTER(LowresCostParams), ctypes.c_void_p]

@@ -175,12 +175,19 @@ class LookaheadCost:
                            bframe_bias=bframe_bias, stream=stream)
 
     @staticmethod
-    def run_batch(stages, curs, refs, refs1=None, bframe_bias=0, stream=None):
-        """One launch for many independent pictures of one geometry and kind (one workgroup each)."""
+    def run_batch(stages, curs, refs, refs1=None, bframe_bias=0, stream=None, device_table=None):
+        """One launch for many independent pictures of one geometry and kind (one workgroup each).  device_table: a table made by
+        `table()` for exactly these operands - the launch then involves no host-to-device copy."""
         s0, c0 = stages[0], curs[0]
         refs1 = [None] * len(stages) if refs1 is None else refs1
-        hipabi.lowres_cost(s0.depth, c0.stride, c0.wcu, c0.hcu, s0.cost_q, s0.qoff,
-                           [s.pair(c, r, r1) for s, c, r, r1 in zip(stages, curs, refs, refs1)], bframe_bias=bframe_bias, stream=stream)
+        pairs = None if device_table is not None else [s.pair(c, r, r1) for s, c, r, r1 in zip(stages, curs, refs, refs1)]
+        hipabi.lowres_cost(s0.depth, c0.stride, c0.wcu, c0.hcu, s0.cost_q, s0.qoff, pairs, bframe_bias=bframe_bias, stream=stream,
+                           device_table=device_table)
+
+    @staticmethod
+    def table(stages, curs, refs, device, refs1=None, stream=None):
+        refs1 = [None] * len(stages) if refs1 is None else refs1
+        return hipabi.lowres_cost_table([s.pair(c, r, r1) for s, c, r, r1 in zip(stages, curs, refs, refs1)], device, stream=stream)
 
 
 class PatternSearch:
@@ -231,7 +238,7 @@ class FramePipeline:
     cost estimate per 8x8 block), which only depends on the source."""
 
     def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False, lookahead=None,
-                 search="full", deblock=False, sao=False):
+                 search="full", deblock=False, sao=False, lookahead_cost_batch=0):
         import torch
         from .pipeline import MotionSearch, SubpelRefine
         self.depth = depth
@@ -244,6 +251,21 @@ class FramePipeline:
             self.ps = PatternSearch(w64, h64, depth, method, subme, rng, device)
         self.rc = InterRecon(self.ms.nctu, w64, h64, depth, level, qp, device)
         self.la = Lookahead(lookahead[0], lookahead[1], depth, device) if lookahead else None
+        # The lookahead's P-frame cost estimate runs AHEAD of the encode like the reference's lookahead thread: every
+        # `lookahead_cost_batch` frames one launch on a side stream scores that many (picture, previous picture) pairs.  The
+        # prepared pictures live in a ring so that a slot is only rewritten after the launches that read it.
+        self.lcb = lookahead_cost_batch if lookahead else 0
+        if self.lcb:
+            self.ring = [self.la] + [Lookahead(lookahead[0], lookahead[1], depth, device) for _ in range(2 * self.lcb)]
+            self.lc = [LookaheadCost(self.la, device) for _ in range(self.lcb)]
+            self.side = torch.cuda.Stream(device=device)
+            self.frame_no, self.pending, self.read_done = 0, [], {}
+            # the operand tables of the launches repeat with the ring: upload each once, up front for the full batches
+            self.device, self.tables = device, {}
+            nring = len(self.ring)
+            for j in range(nring):
+                self._table(tuple(((j * self.lcb + 1 + i) % nring, (j * self.lcb + i) % nring) for i in range(self.lcb)))
+            torch.cuda.synchronize()
         self.db = Deblock(w64, h64, depth, level, qp, device) if deblock else None
         # SAO statistics of the deblocked reconstruction (what rdoSaoUnitCu reads); the offsets themselves are the host's decision
         self.sao = Sao(w64, h64, depth, device) if sao else None
@@ -254,7 +276,18 @@ class FramePipeline:
         import torch
         if self.recon is None:
             self.recon = torch.zeros_like(cur.t)
-        if self.la is not None:
+        if self.lcb:
+            slot = self.frame_no % len(self.ring)
+            if slot in self.read_done:                       # the cost launches that read this slot must be through
+                torch.cuda.current_stream().wait_event(self.read_done.pop(slot))
+            self.la = self.ring[slot]
+            self.la.run(cur)
+            if self.frame_no:
+                self.pending.append((slot, (self.frame_no - 1) % len(self.ring)))
+            self.frame_no += 1
+            if len(self.pending) == self.lcb:
+                self.launch_lookahead_costs()
+        elif self.la is not None:
             self.la.run(cur)
         if self.ps is not None:
             self.ps.run(cur, ref)
@@ -271,9 +304,35 @@ class FramePipeline:
         extend_border(self.recon, cur)
         return self.recon
 
+    def _table(self, key):
+        if key not in self.tables:
+            n = len(key)
+            self.tables[key] = LookaheadCost.table(self.lc[:n], [self.ring[c] for c, _ in key], [self.ring[r] for _, r in key], self.device)
+        return self.tables[key]
+
+    def launch_lookahead_costs(self):
+        """Score the pending (picture, previous picture) pairs in one launch on the side stream."""
+        import torch
+        if not self.lcb or not self.pending:
+            return
+        ready = torch.cuda.Event()
+        ready.record()                                       # the pictures were prepared on the current stream
+        self.side.wait_event(ready)
+        n = len(self.pending)
+        LookaheadCost.run_batch(self.lc[:n], [self.ring[c] for c, _ in self.pending], [self.ring[r] for _, r in self.pending],
+                                stream=self.side.cuda_stream, device_table=self._table(tuple(self.pending)))
+        done = torch.cuda.Event()
+        done.record(self.side)
+        for c, r in self.pending:
+            self.read_done[c] = done
+            self.read_done[r] = done
+        self.pending = []
+
     def checksum(self):
         import torch
         out = {}
+        if self.lcb:
+            out["lookahead_cost"] = int(sum(int(s.frame[0].item()) for s in self.lc))
         out.update(self.ps.checksum() if self.ps is not None else self.sp.checksum())
         out.update(self.rc.checksum())
         if self.la is not None:
