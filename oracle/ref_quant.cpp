@@ -1,0 +1,104 @@
+/* oracle/ref_quant.cpp - TEST INFRASTRUCTURE, never part of the product path.
+ *
+ * C-ABI window onto the REAL reference transform-coding round trip: Quant::transformNxN (common/quant.cpp:397-480, the non-RDOQ
+ * branch with the flat scaling list, sign hiding off) followed by Quant::invtransformNxN (:543-605) for a list of residual blocks.
+ * The tests use it to pin the residual half of oracle/x265_oracle_pipeline2.c's inter / intra TU stages.
+ */
+#include "common.h"
+#include "primitives.h"
+#include "frame.h"
+#include "framedata.h"
+#include "cudata.h"
+#include "slice.h"
+#include "quant.h"
+#include "scalinglist.h"
+#include "entropy.h"
+#include "x265.h"
+
+#include <cstring>
+#include <vector>
+
+using namespace X265_NS;
+
+extern "C" void x265ref_encoder_table_reset_c(void);
+
+extern "C" {
+
+/* resi: int16 [njobs][n*n] residual blocks (stride n).  qpScaled: the QP the quantiser works with (qp + QP_BD_OFFSET, what the
+ * device stages take).  intraCU: the CU's prediction mode (4x4 intra luma uses DST-VII); intraSlice: I slice (rounding 171 vs 85).
+ * Outputs: levels int16 [njobs][n*n], numSig uint32 [njobs], resiOut int16 [njobs][n*n] (zero when numSig == 0, as the callers
+ * skip the inverse transform then).  Returns 0 on success. */
+int x265ref_tu_roundtrip(const int16_t* resi, int n, int qpScaled, int intraCU, int intraSlice, int njobs,
+                         int16_t* levels, uint32_t* numSig, int16_t* resiOut)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
+    const int log2n = n == 4 ? 2 : (n == 8 ? 3 : (n == 16 ? 4 : (n == 32 ? 5 : 0)));
+    if (!log2n) return -10;
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = 64;
+    param->sourceHeight = 64;
+    param->internalCsp = X265_CSP_I400;
+    param->maxCUSize = 64;
+    param->minCUSize = 8;
+    param->maxLog2CUSize = 6;
+    param->unitSizeDepth = 4;
+    param->num4x4Partitions = 256;
+    param->rdoqLevel = 0;
+    param->bLossless = 0;
+    SPS sps;
+    memset((void*)&sps, 0, sizeof(sps));
+    sps.numCuInWidth = sps.numCuInHeight = sps.numCUsInFrame = 1;
+    sps.numPartInCUSize = 16;
+    sps.numPartitions = 256;
+    sps.quadtreeTULog2MaxSize = 5;
+    PPS pps;
+    memset((void*)&pps, 0, sizeof(pps));
+    pps.bSignHideEnabled = 0;
+    Frame frame;
+    frame.m_param = param;
+    FrameData encData;
+    Slice slice;
+    slice.m_sps = &sps;
+    slice.m_pps = &pps;
+    slice.m_param = param;
+    slice.m_sliceType = intraSlice ? I_SLICE : P_SLICE;
+    encData.m_param = param;
+    encData.m_slice = &slice;
+    CUData ctu;
+    encData.m_picCTU = &ctu;
+    frame.m_encData = &encData;
+    CUDataMemPool pool;
+    if (!pool.create(0, param->internalCsp, 1, *param)) return -2;
+    ctu.initialize(pool, 0, *param, 0);
+    ctu.initCTU(frame, 0, qpScaled - QP_BD_OFFSET, 1, 1, 1);
+    for (int p = 0; p < 256; p++) ctu.m_predMode[p] = intraCU ? MODE_INTRA : MODE_INTER;
+
+    ScalingList scalingList;
+    if (!scalingList.init()) return -3;
+    scalingList.m_bEnabled = false;
+    scalingList.setupQuantMatrices(param->internalCsp);
+    Entropy entropy;
+    Quant quant;
+    if (!quant.init(0.0, scalingList, entropy)) return -4;
+    quant.setQPforQuant(ctu, qpScaled - QP_BD_OFFSET);
+
+    std::vector<pixel> fencDummy(n * n, 0);
+    for (int j = 0; j < njobs; j++)
+    {
+        int16_t* lv = levels + (size_t)j * n * n;
+        int16_t* out = resiOut + (size_t)j * n * n;
+        const uint32_t ns = quant.transformNxN(ctu, fencDummy.data(), n, resi + (size_t)j * n * n, n, lv, log2n, TEXT_LUMA, 0, false);
+        numSig[j] = ns;
+        memset(out, 0, sizeof(int16_t) * n * n);
+        if (ns) quant.invtransformNxN(ctu, out, n, lv, log2n, TEXT_LUMA, !!intraCU, false, ns);
+    }
+    frame.m_encData = NULL;
+    encData.m_picCTU = NULL; encData.m_slice = NULL;
+    pool.destroy();
+    x265_param_free(param);
+    return 0;
+}
+
+} // extern "C"

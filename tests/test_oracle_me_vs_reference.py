@@ -310,6 +310,111 @@ def test_sao_restatement_equals_reference_class(depth, width, height):
     assert (a != recp.reshape(rows, stride)[org // stride: org // stride + height, org % stride: org % stride + width]).any()
 
 
+@pytest.mark.parametrize("depth,level,qp,offs", [(8, 2, 32, (0, 0)), (8, 1, 30, (0, 0)), (8, 0, 27, (2, -1)), (10, 2, 44, (0, 0)), (10, 1, 36, (-2, 3))])
+def test_deblock_restatement_equals_reference_class(depth, level, qp, offs):
+    """oracle/x265_oracle_pipeline4.c's boundary strengths + luma edge filter against the real Deblock::deblockCTU
+    (oracle/ref_deblock.cpp) on a reconstruction the oracle chain itself produced (search -> sub-pel -> prediction / residual round
+    trip), cut into 2Nx2N inter CUs of one size with the chain's mvs and coded flags: the filtered picture must be identical."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_deblock"):
+        pytest.skip("oracle/_ref predates ref_deblock.cpp")
+    R, subme = 8, 2
+    clip = F.synth_clip(192, 128, 2, depth=depth, seed=71 + level)
+    cur, stride, org, w64, h64 = F.pad_plane(clip[1][0])
+    ref = F.pad_plane(clip[0][0])[0]
+    nctu = (w64 // 64) * (h64 // 64)
+    cost = F.mv_cost_table(R)
+    cq, qoff = F.qpel_cost_table(R)
+    _, best = O.me_fullsearch(depth, cur, stride, org, ref, stride, org, w64, h64, R, 0, nctu, cost, cost, want_surf=False)
+    mv = O.subpel_refine(depth, cur, stride, org, ref, stride, org, w64, h64, R, 0, nctu, best, cq, qoff, subme)
+    rec, _, ns, _ = O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp)
+    bv, bh = O.deblock_bs_inter(depth, w64, h64, level, mv, ns)
+    exp = O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, qp, beta_offset_div2=offs[0], tc_offset_div2=offs[1])
+    got = np.ascontiguousarray(rec.reshape(-1)).copy()
+    m = np.ascontiguousarray(mv, dtype=np.int32)
+    n = np.ascontiguousarray(ns, dtype=np.uint32)
+    lib.x265ref_deblock.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 3
+    assert lib.x265ref_deblock(got.ctypes.data, w64, h64, level, m.ctypes.data, n.ctypes.data, qp, offs[0], offs[1]) == 0
+    assert np.array_equal(got, exp.reshape(-1)), f"{np.count_nonzero(got != exp.reshape(-1))} samples differ"
+    assert np.count_nonzero(exp.reshape(-1) != rec.reshape(-1)) > 50 and bv.any() and bh.any()
+
+
+@pytest.mark.parametrize("depth,n,qp,islice", [(8, 4, 24, 1), (8, 4, 30, 0), (8, 8, 27, 1), (8, 16, 33, 0), (8, 32, 22, 1), (8, 32, 45, 0),
+                                               (10, 4, 36, 1), (10, 16, 40, 1), (10, 32, 30, 0)])
+def test_intra_tu_round_trip_equals_reference_quant_class(depth, n, qp, islice):
+    """The residual half of the intra TU stage (oracle/x265_oracle_pipeline2.c::x265oracle_intra_recon) against the real
+    Quant::transformNxN + Quant::invtransformNxN (oracle/ref_quant.cpp): DC prediction from flat neighbours makes the prediction a
+    constant, so levels, numSig and the reconstruction can be compared block by block (DST-VII for 4x4, DC shortcut, empty blocks)."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_tu_roundtrip"):
+        pytest.skip("oracle/_ref predates ref_quant.cpp")
+    rng = np.random.default_rng([31, depth, n, qp])
+    dt = np.uint8 if depth == 8 else np.uint16
+    pmax, v = (1 << depth) - 1, 1 << (depth - 1)
+    ntu = 40
+    W = n * ntu
+    yy, xx = np.mgrid[0:n, 0:W]
+    amp = np.repeat(rng.choice([0.0, 0.02, 0.2, 0.45], size=ntu), n)[None, :]
+    src = np.clip(np.rint(v + amp * pmax * np.sin(xx / 3.0 + yy / 2.0) + rng.normal(0, 1.5 * (1 << (depth - 8)), (n, W))), 0, pmax).astype(dt)
+    src[:, :n] = v                                           # an empty residual
+    src[:, n:2 * n] = v + (3 << (depth - 8))                 # a DC-only residual
+    nbw = 4 * n + 1
+    nb = np.full(2 * nbw, v, dtype=dt)
+    jobs = np.zeros(ntu, dtype=np.dtype([("off", "<i8", 4), ("arg", "<i4", 4)]))
+    for t in range(ntu):
+        jobs["off"][t] = (t * n, 0, nbw, t * n * n)
+        jobs["arg"][t, 0] = 1                                # DC mode
+    rec, lev, ns, _ = O.intra_recon(depth, n, src.reshape(-1), W, nb, ntu * n * n, n, qp, islice, jobs)
+    resi = np.stack([src[:, t * n:(t + 1) * n].astype(np.int16) - v for t in range(ntu)]).reshape(-1)
+    rlev, rns, rout = np.zeros(ntu * n * n, np.int16), np.zeros(ntu, np.uint32), np.zeros(ntu * n * n, np.int16)
+    lib.x265ref_tu_roundtrip.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3
+    assert lib.x265ref_tu_roundtrip(resi.ctypes.data, n, qp, 1, islice, ntu, rlev.ctypes.data, rns.ctypes.data, rout.ctypes.data) == 0
+    assert np.array_equal(ns, rns) and np.array_equal(lev, rlev)
+    assert np.array_equal(rec.astype(np.int32), np.clip(v + rout.astype(np.int32), 0, pmax))
+    assert (rns == 0).any() and (rns > 1).any()
+
+
+@pytest.mark.parametrize("depth,level,qp", [(8, 2, 30), (8, 0, 24), (10, 1, 38)])
+def test_inter_tu_round_trip_equals_reference_quant_class(depth, level, qp):
+    """Same for the inter TU stage (x265oracle_inter_recon) with zero motion, where the prediction is the reference picture itself."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_tu_roundtrip"):
+        pytest.skip("oracle/_ref predates ref_quant.cpp")
+    clip = F.synth_clip(128, 64, 2, depth=depth, seed=81)
+    cur, stride, org, w64, h64 = F.pad_plane(clip[1][0])
+    ref = F.pad_plane(clip[0][0])[0]
+    nctu = (w64 // 64) * (h64 // 64)
+    n = 8 << level
+    nblk = (64 // n) ** 2
+    mv = np.zeros((nctu * 85, 2), np.int32)
+    rec, lev, ns, _ = O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp)
+    rows = cur.size // stride
+    c2, r2, o2 = cur.reshape(rows, stride), ref.reshape(rows, stride), rec.reshape(rows, stride)
+    y0, x0 = org // stride, org % stride
+    resi, pos = [], []
+    for ctu in range(nctu):
+        for z in range(nblk):
+            bx = sum(((z >> (2 * b)) & 1) << b for b in range(3))
+            by = sum(((z >> (2 * b + 1)) & 1) << b for b in range(3))
+            y, x = y0 + (ctu // (w64 // 64)) * 64 + by * n, x0 + (ctu % (w64 // 64)) * 64 + bx * n
+            resi.append(c2[y:y + n, x:x + n].astype(np.int16) - r2[y:y + n, x:x + n].astype(np.int16))
+            pos.append((y, x))
+    resi = np.ascontiguousarray(np.stack(resi).reshape(-1))
+    nj = len(pos)
+    rlev, rns, rout = np.zeros(nj * n * n, np.int16), np.zeros(nj, np.uint32), np.zeros(nj * n * n, np.int16)
+    lib.x265ref_tu_roundtrip.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3
+    assert lib.x265ref_tu_roundtrip(resi.ctypes.data, n, qp, 0, 0, nj, rlev.ctypes.data, rns.ctypes.data, rout.ctypes.data) == 0
+    assert np.array_equal(ns.reshape(-1), rns) and np.array_equal(lev, rlev)
+    pmax = (1 << depth) - 1
+    for j, (y, x) in enumerate(pos):
+        exp = np.clip(r2[y:y + n, x:x + n].astype(np.int32) + rout[j * n * n:(j + 1) * n * n].reshape(n, n), 0, pmax)
+        assert np.array_equal(o2[y:y + n, x:x + n].astype(np.int32), exp), f"block {j} reconstruction differs"
+    assert (rns > 1).any()
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_search_driver_with_extra_candidates_equals_reference(depth):
     """motionEstimate's mvc[] candidates (motion.cpp:800-812: measured with SAD + mv cost against the predictor's cost, skipping
