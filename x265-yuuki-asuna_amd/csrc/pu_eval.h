@@ -134,13 +134,19 @@ __device__ __forceinline__ void hex_search(const PuEval<Px, G, T>& c, SMv& bmv, 
 #define LT(V) do { const int v_ = (V); if (v_ < bcost) bcost = v_; } while (0)
 #define X3(D0X, D0Y, D1X, D1Y, D2X, D2Y) do { const int mxs_[3] = { bmv.x + (D0X), bmv.x + (D1X), bmv.x + (D2X) }, mys_[3] = { bmv.y + (D0Y), bmv.y + (D1Y), bmv.y + (D2Y) }; \
                                               int cs_[3]; c.template cost_mv_n<3>(mxs_, mys_, cs_); costs[0] = cs_[0]; costs[1] = cs_[1]; costs[2] = cs_[2]; } while (0)
-        X3(-2, 0, -1, 2, 1, 2);
-        bcost <<= 3;
-        if (YOK(0)) LT((costs[0] << 3) + 2);
-        if (YOK(2)) { LT((costs[1] << 3) + 3); LT((costs[2] << 3) + 4); }
-        X3(2, 0, 1, -2, -1, -2);
-        if (YOK(0)) LT((costs[0] << 3) + 5);
-        if (YOK(-2)) { LT((costs[1] << 3) + 6); LT((costs[2] << 3) + 7); }
+        // the six points of the first hexagon are independent of each other: one group, one memory round trip; the decisions
+        // are then taken in the reference's order (two COST_MV_X3 calls, motion.cpp:868-885)
+        {
+            const int mxs_[6] = { bmv.x - 2, bmv.x - 1, bmv.x + 1, bmv.x + 2, bmv.x + 1, bmv.x - 1 };
+            const int mys_[6] = { bmv.y, bmv.y + 2, bmv.y + 2, bmv.y, bmv.y - 2, bmv.y - 2 };
+            int cs_[6];
+            c.template cost_mv_n<6>(mxs_, mys_, cs_);
+            bcost <<= 3;
+            if (YOK(0)) LT((cs_[0] << 3) + 2);
+            if (YOK(2)) { LT((cs_[1] << 3) + 3); LT((cs_[2] << 3) + 4); }
+            if (YOK(0)) LT((cs_[3] << 3) + 5);
+            if (YOK(-2)) { LT((cs_[4] << 3) + 6); LT((cs_[5] << 3) + 7); }
+        }
         if (bcost & 7)
         {
             int dir = (bcost & 7) - 2;
@@ -163,16 +169,21 @@ __device__ __forceinline__ void hex_search(const PuEval<Px, G, T>& c, SMv& bmv, 
         }
         bcost >>= 3;
         int dir = 0;
-        { const int mxs[4] = { bmv.x, bmv.x, bmv.x - 1, bmv.x + 1 }, mys[4] = { bmv.y - 1, bmv.y + 1, bmv.y, bmv.y }; c.template cost_mv_n<4>(mxs, mys, costs); }
-        if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 1; }
-        if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 2; }
-        if (costs[2] < bcost) { bcost = costs[2]; dir = 3; }
-        if (costs[3] < bcost) { bcost = costs[3]; dir = 4; }
-        { const int mxs[4] = { bmv.x - 1, bmv.x - 1, bmv.x + 1, bmv.x + 1 }, mys[4] = { bmv.y - 1, bmv.y + 1, bmv.y - 1, bmv.y + 1 }; c.template cost_mv_n<4>(mxs, mys, costs); }
-        if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 5; }
-        if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 6; }
-        if (YOK(-1) && costs[2] < bcost) { bcost = costs[2]; dir = 7; }
-        if (YOK(1) && costs[3] < bcost) { bcost = costs[3]; dir = 8; }
+        {
+            // square refine (:927-947): the eight neighbours of the final hexagon centre in one group, accepted in the reference's order
+            const int mxs[8] = { bmv.x, bmv.x, bmv.x - 1, bmv.x + 1, bmv.x - 1, bmv.x - 1, bmv.x + 1, bmv.x + 1 };
+            const int mys[8] = { bmv.y - 1, bmv.y + 1, bmv.y, bmv.y, bmv.y - 1, bmv.y + 1, bmv.y - 1, bmv.y + 1 };
+            int cs8[8];
+            c.template cost_mv_n<8>(mxs, mys, cs8);
+            if (YOK(-1) && cs8[0] < bcost) { bcost = cs8[0]; dir = 1; }
+            if (YOK(1) && cs8[1] < bcost) { bcost = cs8[1]; dir = 2; }
+            if (cs8[2] < bcost) { bcost = cs8[2]; dir = 3; }
+            if (cs8[3] < bcost) { bcost = cs8[3]; dir = 4; }
+            if (YOK(-1) && cs8[4] < bcost) { bcost = cs8[4]; dir = 5; }
+            if (YOK(1) && cs8[5] < bcost) { bcost = cs8[5]; dir = 6; }
+            if (YOK(-1) && cs8[6] < bcost) { bcost = cs8[6]; dir = 7; }
+            if (YOK(1) && cs8[7] < bcost) { bcost = cs8[7]; dir = 8; }
+        }
         bmv.x += kSSquare1[dir].x; bmv.y += kSSquare1[dir].y;
 #undef X3
 #undef YOK
