@@ -289,7 +289,8 @@ typedef struct x265hip_lowres_intra_params
 } x265hip_lowres_intra_params;
 int x265hip_lowres_intra(const x265hip_lowres_intra_params* p, void* stream);
 
-/* Sample adaptive offset of the deblocked luma picture - the two pixel passes of encoder/sao.cpp; the rate-distortion choice of
+/* Sample adaptive offset of a deblocked plane (luma, or a chroma plane through ctu_width / ctu_height / plane_offset) - the two
+ * pixel passes of encoder/sao.cpp; the rate-distortion choice of
  * the parameters between them (rdoSaoUnitCu, sao.cpp:1225-1605) stays with the host.
  * x265hip_sao_stats: SAO::calcSaoStatsCTU (sao.cpp:735-917) for every 64x64 CTU (bSaoNonDeblocked = 0, bLimitSAO = 0, one slice):
  *   count / offset_org int32 [numCtu][5][32] = samples and sum of (source - deblocked) per type (EO_0, EO_1, EO_2, EO_3, BO) and
@@ -304,6 +305,8 @@ typedef struct x265hip_sao_stats_params
     const void* rec;   intptr_t rec_stride;
     int width, height;
     int32_t* count;  int32_t* offset_org;
+    int ctu_width, ctu_height;     /* the CTU's footprint in this plane; 0 = 64 (luma).  4:2:0 chroma: 32 x 32 with the plane's own width / height */
+    int plane_offset;              /* the reference's plane_offset (sao.cpp:782): 0 luma, 2 chroma */
 } x265hip_sao_stats_params;
 int x265hip_sao_stats(const x265hip_sao_stats_params* p, void* stream);
 typedef struct x265hip_sao_apply_params
@@ -313,6 +316,7 @@ typedef struct x265hip_sao_apply_params
     void* dst;        intptr_t dst_stride;
     int width, height;
     const int32_t* ctu_params;
+    int ctu_width, ctu_height;     /* as in x265hip_sao_stats_params */
 } x265hip_sao_apply_params;
 int x265hip_sao_apply(const x265hip_sao_apply_params* p, void* stream);
 

@@ -224,27 +224,28 @@ def lowres_cost(depth, cur, ref_planes, stride, org, width_in_cu, height_in_cu, 
     return (mvs[0], mvs[1]), (mvc[0], mvc[1]), lc, rows, frame
 
 
-def sao_stats(depth, fenc, rec, stride, org, width, height, nthreads=0, avx2=False):
+def sao_stats(depth, fenc, rec, stride, org, width, height, nthreads=0, avx2=False, ctu=(64, 64), plane_offset=0):
     """CPU restatement of SAO::calcSaoStatsCTU (sao.cpp:735-917) for every CTU of the luma plane.
     Returns (count, offset_org), int32 [numCtu, 5, 32] each (type order EO_0..EO_3, BO)."""
     L = lib(avx2)
-    fn = getattr(L, f"x265oracle_sao_stats_d{depth}")
-    nctu = ((width + 63) // 64) * ((height + 63) // 64)
+    fn = getattr(L, f"x265oracle_sao_stats_plane_d{depth}")
+    nctu = ((width + ctu[0] - 1) // ctu[0]) * ((height + ctu[1] - 1) // ctu[1])
     cnt, off = np.zeros((nctu, 5, 32), np.int32), np.zeros((nctu, 5, 32), np.int32)
     es = fenc.itemsize
-    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-    assert fn(fenc.ctypes.data + org * es, rec.ctypes.data + org * es, stride, width, height, cnt.ctypes.data, off.ctypes.data, nthreads) == 0
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    assert fn(fenc.ctypes.data + org * es, rec.ctypes.data + org * es, stride, width, height, ctu[0], ctu[1], plane_offset,
+              cnt.ctypes.data, off.ctypes.data, nthreads) == 0
     return cnt, off
 
 
-def sao_apply(depth, src, stride, org, width, height, params, nthreads=0, avx2=False):
+def sao_apply(depth, src, stride, org, width, height, params, nthreads=0, avx2=False, ctu=(64, 64)):
     """CPU restatement of SAO::generateLumaOffsets / applyPixelOffsets (sao.cpp:572-630, 274-570) for every CTU; params int32
     [numCtu, 7] = typeIdx, bandPos, offset[4], mergeLeft.  Returns the offset picture (a copy of src outside the picture area)."""
     L = lib(avx2)
-    fn = getattr(L, f"x265oracle_sao_apply_d{depth}")
+    fn = getattr(L, f"x265oracle_sao_apply_plane_d{depth}")
     dst = src.copy()
     es = src.itemsize
     pr = np.ascontiguousarray(params, dtype=np.int32)
-    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
-    assert fn(src.ctypes.data + org * es, dst.ctypes.data + org * es, stride, width, height, pr.ctypes.data, nthreads) == 0
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
+    assert fn(src.ctypes.data + org * es, dst.ctypes.data + org * es, stride, width, height, ctu[0], ctu[1], pr.ctypes.data, nthreads) == 0
     return dst

@@ -143,4 +143,126 @@ int x265ref_sao(const void* fencPlane, void* recPlane, int width, int height, co
     return 0;
 }
 
+/* The chroma planes of a 4:2:0 picture through the same real class: calcSaoStatsCTU(addr, 1 / 2) and generateChromaOffsets.
+ * fencC / recC: [2] pointers to UNPADDED (width / 2) x (height / 2) planes (Cb, Cr); recC is replaced by the offset planes.
+ * params: [2] pointers to int32 [numCtu][7] as in x265ref_sao (the reference applies Cb's typeIdx to Cr as well, sao.cpp:723: pass
+ * the same type for both, as the encoder's decision always does).  count / offsetOrg: [2] pointers to int32 [numCtu][5][32]. */
+int x265ref_sao_chroma(const void* const* fencC, void* const* recC, int width, int height, const int32_t* const* params,
+                       int32_t* const* count, int32_t* const* offsetOrg)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width;
+    param->sourceHeight = height;
+    param->internalCsp = X265_CSP_I420;
+    param->maxCUSize = 64;
+    param->maxLog2CUSize = 6;
+    param->unitSizeDepth = 4;
+    param->num4x4Partitions = 256;
+    param->bEnableSAO = 1;
+    param->bSaoNonDeblocked = 0;
+    param->bLimitSAO = 0;
+    SPS sps;
+    memset((void*)&sps, 0, sizeof(sps));
+    sps.numCuInWidth = (width + 63) / 64;
+    sps.numCuInHeight = (height + 63) / 64;
+    sps.numCUsInFrame = sps.numCuInWidth * sps.numCuInHeight;
+    const int numCtu = sps.numCUsInFrame;
+    const int cw = width / 2, ch = height / 2;
+
+    Frame frame;
+    frame.m_param = param;
+    PicYuv fenc, recon;
+    PicYuv* pics[2] = { &fenc, &recon };
+    for (int i = 0; i < 2; i++)
+    {
+        pics[i]->m_param = param;
+        if (!pics[i]->create(param, true) || !pics[i]->createOffsets(sps)) return -1;
+        for (int c = 0; c < 2; c++)
+        {
+            const pixel* src = (const pixel*)(i ? recC[c] : fencC[c]);
+            for (int y = 0; y < ch; y++)
+                memcpy(pics[i]->m_picOrg[1 + c] + (intptr_t)y * pics[i]->m_strideC, src + (size_t)y * cw, sizeof(pixel) * cw);
+        }
+    }
+    frame.m_fencPic = &fenc;
+    frame.m_reconPic = &recon;
+    FrameData encData;
+    Slice slice;
+    slice.m_sps = &sps;
+    slice.m_param = param;
+    slice.m_sliceType = P_SLICE;
+    encData.m_param = param;
+    encData.m_slice = &slice;
+    encData.m_reconPic = &recon;
+    std::vector<CUData> ctus(numCtu);
+    encData.m_picCTU = ctus.data();
+    for (int a = 0; a < numCtu; a++)
+    {
+        const int row = a / sps.numCuInWidth, col = a % sps.numCuInWidth;
+        ctus[a].m_encData = &encData;
+        ctus[a].m_slice = &slice;
+        ctus[a].m_cuAddr = a;
+        ctus[a].m_cuPelX = col * 64;
+        ctus[a].m_cuPelY = row * 64;
+        ctus[a].m_bFirstRowInSlice = row == 0;
+        ctus[a].m_bLastRowInSlice = row == (int)sps.numCuInHeight - 1;
+    }
+    frame.m_encData = &encData;
+
+    SaoProbe sao;
+    if (!sao.create(param, 1)) return -2;
+    sao.m_frame = &frame;
+    for (int a = 0; a < numCtu; a++)
+        for (int c = 0; c < 2; c++)
+        {
+            sao.resetStats();
+            sao.calcSaoStatsCTU(a, 1 + c);
+            memcpy(count[c] + (size_t)a * 5 * 32, sao.m_count[1 + c], sizeof(int32_t) * 5 * 32);
+            memcpy(offsetOrg[c] + (size_t)a * 5 * 32, sao.m_offsetOrg[1 + c], sizeof(int32_t) * 5 * 32);
+        }
+
+    const intptr_t strideC = recon.m_strideC;
+    const int h32 = sps.numCuInHeight * 32;
+    std::vector<pixel> pristine[2];
+    std::vector<SaoCtuParam> cp[3];
+    for (int c = 0; c < 3; c++) cp[c].resize(numCtu);
+    for (int c = 0; c < 2; c++)
+    {
+        pristine[c].assign(recon.m_picOrg[1 + c], recon.m_picOrg[1 + c] + strideC * h32);
+        for (int a = 0; a < numCtu; a++)
+        {
+            const int32_t* p = params[c] + (size_t)a * 7;
+            cp[1 + c][a].reset();
+            cp[1 + c][a].typeIdx = p[0];
+            cp[1 + c][a].bandPos = p[1];
+            for (int i = 0; i < 4; i++) cp[1 + c][a].offset[i] = p[2 + i];
+            cp[1 + c][a].mergeMode = p[6] ? SAO_MERGE_LEFT : SAO_MERGE_NONE;
+        }
+    }
+    SaoCtuParam* cps[3] = { cp[0].data(), cp[1].data(), cp[2].data() };
+    for (int row = 0; row < (int)sps.numCuInHeight; row++)
+    {
+        for (int c = 0; c < 2; c++)
+        {
+            const pixel* above = pristine[c].data() + (row == 0 ? 0 : (intptr_t)(row * 32 - 1) * strideC);
+            memcpy(sao.m_tmpU[1 + c], above, sizeof(pixel) * sps.numCuInWidth * 32);
+        }
+        for (int col = 0; col < (int)sps.numCuInWidth; col++)
+            sao.generateChromaOffsets(cps, row, col);
+    }
+    for (int c = 0; c < 2; c++)
+        for (int y = 0; y < ch; y++)
+            memcpy((pixel*)recC[c] + (size_t)y * cw, recon.m_picOrg[1 + c] + (intptr_t)y * strideC, sizeof(pixel) * cw);
+
+    frame.m_fencPic = NULL; frame.m_reconPic = NULL; frame.m_encData = NULL;
+    encData.m_picCTU = NULL; encData.m_slice = NULL;
+    sao.destroy(1);
+    fenc.destroy(); recon.destroy();
+    x265_param_free(param);
+    return 0;
+}
+
 } // extern "C"

@@ -172,21 +172,31 @@ void EXPORT(x265oracle_deblock_luma)(pixel* rec, intptr_t stride, int width, int
 
 static int sao_sign(int x) { return (x > 0) - (x < 0); }
 
+int EXPORT(x265oracle_sao_stats_plane)(const pixel* fenc, const pixel* rec, intptr_t stride, int picWidth, int picHeight,
+                                       int ctuW, int ctuH, int planeOffset, int32_t* count, int32_t* offsetOrg, int nthreads);
 int EXPORT(x265oracle_sao_stats)(const pixel* fenc, const pixel* rec, intptr_t stride, int picWidth, int picHeight,
                                  int32_t* count, int32_t* offsetOrg, int nthreads)
+{
+    return EXPORT(x265oracle_sao_stats_plane)(fenc, rec, stride, picWidth, picHeight, 64, 64, 0, count, offsetOrg, nthreads);
+}
+
+/* Any plane: ctuW x ctuH = the CTU's footprint in this plane (64x64 luma, 32x32 for 4:2:0 chroma), picWidth / picHeight the plane's
+ * size, planeOffset = the reference's plane_offset (0 luma, 2 chroma: chroma deblocking reaches fewer samples, sao.cpp:782). */
+int EXPORT(x265oracle_sao_stats_plane)(const pixel* fenc, const pixel* rec, intptr_t stride, int picWidth, int picHeight,
+                                       int ctuW, int ctuH, int planeOffset, int32_t* count, int32_t* offsetOrg, int nthreads)
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
     if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
-    const int ctusW = (picWidth + 63) / 64, ctusH = (picHeight + 63) / 64;
+    const int ctusW = (picWidth + ctuW - 1) / ctuW, ctusH = (picHeight + ctuH - 1) / ctuH;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel for schedule(dynamic, 4)
 #endif
     for (int addr = 0; addr < ctusW * ctusH; addr++)
     {
-        const int lpelx = (addr % ctusW) * 64, tpely = (addr / ctusW) * 64;
-        const int rpelx = lpelx + 64 < picWidth ? lpelx + 64 : picWidth, bpely = tpely + 64 < picHeight ? tpely + 64 : picHeight;
+        const int lpelx = (addr % ctusW) * ctuW, tpely = (addr / ctusW) * ctuH;
+        const int rpelx = lpelx + ctuW < picWidth ? lpelx + ctuW : picWidth, bpely = tpely + ctuH < picHeight ? tpely + ctuH : picHeight;
         const int ctuWidth = rpelx - lpelx, ctuHeight = bpely - tpely;
         const int aboveUnavail = !tpely;
         const pixel* fenc0 = fenc + lpelx + (intptr_t)tpely * stride;
@@ -199,7 +209,7 @@ int EXPORT(x265oracle_sao_stats)(const pixel* fenc, const pixel* rec, intptr_t s
         int8_t upStore[2 * (64 + 32)], *upBuff1 = upStore + 16, *upBufft = upBuff1 + (64 + 32);
         for (int y = 0; y < ctuHeight; y++)
             for (int x = 0; x < ctuWidth; x++) diff[y * 64 + x] = (int16_t)((int)fenc0[y * stride + x] - (int)rec0[y * stride + x]);
-        const int skipB = 4, skipR = 5;
+        const int skipB = 4 - planeOffset, skipR = 5 - planeOffset;
         const int atRight = rpelx == picWidth, atBottom = bpely == picHeight;
         /* band offset: everything already deblocked */
         prim.saoCuStatsBO(diff, rec0, stride, atRight ? ctuWidth : ctuWidth - skipR, atBottom ? ctuHeight : ctuHeight - skipB, org + 4 * 32, cnt + 4 * 32);
@@ -231,10 +241,18 @@ int EXPORT(x265oracle_sao_stats)(const pixel* fenc, const pixel* rec, intptr_t s
     return 0;
 }
 
+int EXPORT(x265oracle_sao_apply_plane)(const pixel* src, pixel* dst, intptr_t stride, int picWidth, int picHeight, int ctuW, int ctuH,
+                                       const int32_t* params, int nthreads);
 int EXPORT(x265oracle_sao_apply)(const pixel* src, pixel* dst, intptr_t stride, int picWidth, int picHeight, const int32_t* params, int nthreads)
 {
+    return EXPORT(x265oracle_sao_apply_plane)(src, dst, stride, picWidth, picHeight, 64, 64, params, nthreads);
+}
+
+int EXPORT(x265oracle_sao_apply_plane)(const pixel* src, pixel* dst, intptr_t stride, int picWidth, int picHeight, int ctuW, int ctuH,
+                                       const int32_t* params, int nthreads)
+{
     static const int kEoTable[5] = { 1, 2, 0, 3, 4 };
-    const int ctusW = (picWidth + 63) / 64, ctusH = (picHeight + 63) / 64;
+    const int ctusW = (picWidth + ctuW - 1) / ctuW, ctusH = (picHeight + ctuH - 1) / ctuH;
     const int maxVal = (1 << DEPTH) - 1, boShift = DEPTH - 5;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -244,8 +262,8 @@ int EXPORT(x265oracle_sao_apply)(const pixel* src, pixel* dst, intptr_t stride, 
     {
         const int32_t* p = params + (size_t)addr * 7;
         const int typeIdx = p[0], bandPos = p[1];
-        const int lpelx = (addr % ctusW) * 64, tpely = (addr / ctusW) * 64;
-        const int rpelx = lpelx + 64 < picWidth ? lpelx + 64 : picWidth, bpely = tpely + 64 < picHeight ? tpely + 64 : picHeight;
+        const int lpelx = (addr % ctusW) * ctuW, tpely = (addr / ctusW) * ctuH;
+        const int rpelx = lpelx + ctuW < picWidth ? lpelx + ctuW : picWidth, bpely = tpely + ctuH < picHeight ? tpely + ctuH : picHeight;
         int offsetEo[5], offsetBo[32];
         {
             int off[5] = { 0, p[2], p[3], p[4], p[5] };

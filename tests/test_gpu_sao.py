@@ -55,6 +55,33 @@ def test_sao_passes_match_oracle(depth, width, height):
     assert (out != recp).any() and cnt[:, :4, :5].sum() > 0 and cnt[:, 4].sum() > 0
 
 
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 200, 152), (10, 192, 136), (8, 1920, 1080)])
+def test_sao_chroma_planes_match_oracle(depth, width, height):
+    """The chroma planes of a 4:2:0 picture: 32x32 CTU footprint, plane_offset 2."""
+    import torch
+    from test_oracle_me_vs_reference import sao_chroma_case, pad_any
+    dev = torch.device("cuda:0")
+    src, rec, params = sao_chroma_case(depth, width, height, 8)
+    cw, ch = width // 2, height // 2
+    nctu = params[0].shape[0]
+    O = _oracle()
+    for c in range(2):
+        fp, st, og = pad_any(src[c])
+        rp = pad_any(rec[c])[0]
+        d_f = torch.from_numpy(fp.view(np.uint8)).to(dev)
+        d_r = torch.from_numpy(rp.view(np.uint8)).to(dev)
+        d_cnt = torch.full((nctu * 160,), -1, dtype=torch.int32, device=dev)
+        d_off = torch.full((nctu * 160,), -1, dtype=torch.int32, device=dev)
+        H.sao_stats(depth, d_f, st, og, d_r, st, og, cw, ch, d_cnt, d_off, ctu=(32, 32), plane_offset=2)
+        d_out = d_r.clone()
+        H.sao_apply(depth, d_r, st, og, d_out, st, og, cw, ch, torch.from_numpy(params[c].reshape(-1)).to(dev), ctu=(32, 32))
+        torch.cuda.synchronize()
+        cnt, off = O.sao_stats(depth, fp, rp, st, og, cw, ch, ctu=(32, 32), plane_offset=2)
+        assert np.array_equal(d_cnt.cpu().numpy().reshape(cnt.shape), cnt) and np.array_equal(d_off.cpu().numpy().reshape(off.shape), off)
+        out = O.sao_apply(depth, rp, st, og, cw, ch, params[c], ctu=(32, 32))
+        assert np.array_equal(d_out.cpu().numpy().view(rp.dtype), out)
+
+
 def test_sao_apply_refuses_in_place():
     import torch
     dev = torch.device("cuda:0")

@@ -415,6 +415,64 @@ def test_inter_tu_round_trip_equals_reference_quant_class(depth, level, qp):
     assert (rns > 1).any()
 
 
+def pad_any(img, margin=32):
+    """A plane of any size inside `margin` zero samples: (flat buffer, stride, element offset of sample (0, 0))."""
+    h, w = img.shape
+    buf = np.zeros((h + 2 * margin, w + 2 * margin), dtype=img.dtype)
+    buf[margin:margin + h, margin:margin + w] = img
+    return np.ascontiguousarray(buf).reshape(-1), w + 2 * margin, margin * (w + 2 * margin) + margin
+
+
+def sao_chroma_case(depth, width, height, seed):
+    """Cb / Cr source and deblocked-like planes of a 4:2:0 picture + per-CTU parameters (both planes share the type)."""
+    rng = np.random.default_rng([23, depth, width, seed])
+    cw, ch = width // 2, height // 2
+    clip = F.synth_clip(width, height, 1, depth=depth, seed=seed)[0]
+    nctu = ((width + 63) // 64) * ((height + 63) // 64)
+    lim = 7 if depth == 8 else 31
+    src, rec, params = [], [], []
+    typ = rng.integers(-1, 5, size=nctu)
+    for c in (1, 2):
+        y = clip[c][:ch, :cw]
+        sm = (y.astype(np.int32) * 2 + np.roll(y, 1, axis=1) + np.roll(y, 1, axis=0) + 2) >> 2
+        r = np.clip(sm + (rng.integers(-3, 4, size=y.shape) << (depth - 8)), 0, (1 << depth) - 1).astype(y.dtype)
+        p = np.zeros((nctu, 7), np.int32)
+        p[:, 0] = typ
+        p[:, 1] = rng.integers(0, 32, size=nctu)
+        p[:, 2:6] = rng.integers(-lim, lim + 1, size=(nctu, 4))
+        src.append(np.ascontiguousarray(y)); rec.append(np.ascontiguousarray(r)); params.append(p)
+    return src, rec, params
+
+
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 200, 152), (10, 192, 136)])
+def test_sao_chroma_restatement_equals_reference_class(depth, width, height):
+    """The same SAO passes on the chroma planes of a 4:2:0 picture (32x32 CTU footprint, plane_offset 2) against the real class:
+    calcSaoStatsCTU(addr, 1 / 2) and generateChromaOffsets."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_sao_chroma"):
+        pytest.skip("oracle/_ref predates x265ref_sao_chroma")
+    src, rec, params = sao_chroma_case(depth, width, height, 7)
+    cw, ch = width // 2, height // 2
+    nctu = params[0].shape[0]
+    rcnt = [np.zeros((nctu, 5, 32), np.int32) for _ in range(2)]
+    roff = [np.zeros((nctu, 5, 32), np.int32) for _ in range(2)]
+    rout = [r.copy() for r in rec]
+    arr = lambda xs: (ctypes.c_void_p * 2)(*[x.ctypes.data for x in xs])
+    lib.x265ref_sao_chroma.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.x265ref_sao_chroma(arr(src), arr(rout), width, height, arr(params), arr(rcnt), arr(roff)) == 0
+    for c in range(2):
+        fp, st, og = pad_any(src[c])
+        rp = pad_any(rec[c])[0]
+        cnt, off = O.sao_stats(depth, fp, rp, st, og, cw, ch, ctu=(32, 32), plane_offset=2)
+        assert np.array_equal(cnt, rcnt[c]), f"plane {c + 1}: count differs in CTU/type {np.argwhere((cnt != rcnt[c]).any(axis=2))[:6].tolist()}"
+        assert np.array_equal(off, roff[c]), f"plane {c + 1}: offsetOrg differs"
+        out = O.sao_apply(depth, rp, st, og, cw, ch, params[c], ctu=(32, 32))
+        got = out.reshape(-1, st)[32:32 + ch, 32:32 + cw]
+        assert np.array_equal(got, rout[c]), f"plane {c + 1}: {np.count_nonzero(got != rout[c])} samples differ"
+        assert (got != rec[c]).any() and cnt[:, :4, :5].sum() > 0
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_search_driver_with_extra_candidates_equals_reference(depth):
     """motionEstimate's mvc[] candidates (motion.cpp:800-812: measured with SAD + mv cost against the predictor's cost, skipping

@@ -20,6 +20,7 @@ struct SaoStatsArgs
     const uint8_t* fenc; long fencStrideB;
     const uint8_t* rec; long recStrideB;
     int width, height, depth, ctusW;
+    int ctuW, ctuH, planeOffset;      // the CTU's footprint in this plane (64x64 luma, 32x32 4:2:0 chroma) and the reference's plane_offset
     int32_t* count; int32_t* offsetOrg;
 };
 
@@ -35,23 +36,25 @@ __global__ void __launch_bounds__(256) sao_stats_kernel(SaoStatsArgs a)
     __shared__ int sEo[2][20];
     const int tid = threadIdx.x;
     const int addr = blockIdx.x;
-    const int lpelx = (addr % a.ctusW) * 64, tpely = (addr / a.ctusW) * 64;
-    const int rpelx = min(lpelx + 64, a.width), bpely = min(tpely + 64, a.height);
+    const int lpelx = (addr % a.ctusW) * a.ctuW, tpely = (addr / a.ctusW) * a.ctuH;
+    const int rpelx = min(lpelx + a.ctuW, a.width), bpely = min(tpely + a.ctuH, a.height);
     const int ctuW = rpelx - lpelx, ctuH = bpely - tpely;
     const bool atRight = rpelx == a.width, atBottom = bpely == a.height;
-    // the reference's sub-rectangles (sao.cpp:806-915): the right 5 columns / bottom 4 rows wait for the neighbour's deblocking
-    const int boEndX = atRight ? ctuW : ctuW - 5, boEndY = atBottom ? ctuH : ctuH - 4;
-    const int startX = !lpelx, endX0 = atRight ? ctuW - 1 : ctuW - 5;
-    const int startY = !tpely, endY1 = atBottom ? ctuH - 1 : ctuH - 4;
-    const int e0EndY = ctuH - 4, e1EndX = boEndX;
+    // the reference's sub-rectangles (sao.cpp:806-915): the right 5 columns / bottom 4 rows (3 / 2 for chroma) wait for the
+    // neighbour's deblocking
+    const int skipR = 5 - a.planeOffset, skipB = 4 - a.planeOffset;
+    const int boEndX = atRight ? ctuW : ctuW - skipR, boEndY = atBottom ? ctuH : ctuH - skipB;
+    const int startX = !lpelx, endX0 = atRight ? ctuW - 1 : ctuW - skipR;
+    const int startY = !tpely, endY1 = atBottom ? ctuH - 1 : ctuH - skipB;
+    const int e0EndY = ctuH - skipB, e1EndX = boEndX;
     for (int i = tid; i < 4 * 2 * 32; i += 256) (&sBo[0][0][0])[i] = 0;
     if (tid < 40) (&sEo[0][0])[tid] = 0;
-    // stage rows -1..64, columns -1..64 of the deblocked picture (the planes are padded, so the border reads are legal)
+    // stage rows -1..ctuH, columns -1..ctuW of the deblocked picture (the planes are padded, so the border reads are legal)
     const Px* rec = reinterpret_cast<const Px*>(a.rec) + lpelx + (long)tpely * (a.recStrideB / BPP);
     const long rst = a.recStrideB / BPP;
     const int lane = tid & 63, wave = tid >> 6;
-    for (int r = wave; r < 66; r += 4)
-        for (int c = lane; c < 66; c += 64)
+    for (int r = wave; r < a.ctuH + 2; r += 4)
+        for (int c = lane; c < a.ctuW + 2; c += 64)
             sRec[r * LW + c] = (uint16_t)rec[(long)(r - 1) * rst + (c - 1)];
     __syncthreads();
     // a thread owns 16 consecutive samples of one row (four threads per row)
@@ -139,7 +142,7 @@ struct SaoApplyArgs
 {
     const uint8_t* src; long srcStrideB;
     uint8_t* dst; long dstStrideB;
-    int width, height, depth, ctusW;
+    int width, height, depth, ctusW, ctuW, ctuH;
     const int32_t* params;
 };
 
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(256) sao_apply_kernel(SaoApplyArgs a)
 {
     constexpr int BPP = sizeof(Px);
     const int tid = threadIdx.x, addr = blockIdx.x;
-    const int lpelx = (addr % a.ctusW) * 64, tpely = (addr / a.ctusW) * 64;
+    const int lpelx = (addr % a.ctusW) * a.ctuW, tpely = (addr / a.ctusW) * a.ctuH;
     const int32_t* p = a.params + (size_t)addr * 7;
     const int typeIdx = p[0], bandPos = p[1];
     const int o0 = (int8_t)p[2], o1 = (int8_t)p[3], o2 = (int8_t)p[4], o3 = (int8_t)p[5];
@@ -158,14 +161,14 @@ __global__ void __launch_bounds__(256) sao_apply_kernel(SaoApplyArgs a)
     Px* dst = reinterpret_cast<Px*>(a.dst);
     // a lane owns one column (unit-stride loads and stores across the wavefront), a wavefront every fourth row
     const int x = lpelx + (tid & 63);
-    if (x >= a.width) return;
+    if ((tid & 63) >= a.ctuW || x >= a.width) return;
     // neighbour step of the edge classes: EO_0 horizontal, EO_1 vertical, EO_2 135 degrees, EO_3 45 degrees
     const int dx = typeIdx == 1 ? 0 : (typeIdx == 3 ? -1 : 1), dy = typeIdx == 0 ? 0 : 1;
     const bool okx = !dx || (x > 0 && x < a.width - 1);
     for (int i = 0; i < 16; i++)
     {
-        const int y = tpely + (tid >> 6) + 4 * i;
-        if (y >= a.height) break;
+        const int yl = (tid >> 6) + 4 * i, y = tpely + yl;
+        if (yl >= a.ctuH || y >= a.height) break;
         const bool oky = !dy || (y > 0 && y < a.height - 1);
         const Px* c = src + x + (long)y * sst;
         int v = *c;
@@ -205,9 +208,12 @@ extern "C" int x265hip_sao_stats(const x265hip_sao_stats_params* p, void* stream
     SaoStatsArgs a;
     a.fenc = (const uint8_t*)p->fenc; a.fencStrideB = (long)p->fenc_stride * bpp;
     a.rec = (const uint8_t*)p->rec; a.recStrideB = (long)p->rec_stride * bpp;
-    a.width = p->width; a.height = p->height; a.depth = p->depth; a.ctusW = (p->width + 63) / 64;
+    a.ctuW = p->ctu_width ? p->ctu_width : 64; a.ctuH = p->ctu_height ? p->ctu_height : 64; a.planeOffset = p->plane_offset;
+    if (a.ctuW < 8 || a.ctuW > 64 || a.ctuH < 8 || a.ctuH > 64 || a.planeOffset < 0 || a.planeOffset > 2)
+    { set_error("sao_stats: CTU footprint %d x %d / plane_offset %d", a.ctuW, a.ctuH, a.planeOffset); return X265HIP_EINVAL; }
+    a.width = p->width; a.height = p->height; a.depth = p->depth; a.ctusW = (p->width + a.ctuW - 1) / a.ctuW;
     a.count = p->count; a.offsetOrg = p->offset_org;
-    const int nctu = a.ctusW * ((p->height + 63) / 64);
+    const int nctu = a.ctusW * ((p->height + a.ctuH - 1) / a.ctuH);
     hipStream_t s = (hipStream_t)stream;
     if (bpp == 1) hipLaunchKernelGGL(sao_stats_kernel<uint8_t>, dim3(nctu), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(sao_stats_kernel<uint16_t>, dim3(nctu), dim3(256), 0, s, a);
@@ -227,9 +233,11 @@ extern "C" int x265hip_sao_apply(const x265hip_sao_apply_params* p, void* stream
     SaoApplyArgs a;
     a.src = (const uint8_t*)p->src; a.srcStrideB = (long)p->src_stride * bpp;
     a.dst = (uint8_t*)p->dst; a.dstStrideB = (long)p->dst_stride * bpp;
-    a.width = p->width; a.height = p->height; a.depth = p->depth; a.ctusW = (p->width + 63) / 64;
+    a.ctuW = p->ctu_width ? p->ctu_width : 64; a.ctuH = p->ctu_height ? p->ctu_height : 64;
+    if (a.ctuW < 8 || a.ctuW > 64 || a.ctuH < 8 || a.ctuH > 64) { set_error("sao_apply: CTU footprint %d x %d", a.ctuW, a.ctuH); return X265HIP_EINVAL; }
+    a.width = p->width; a.height = p->height; a.depth = p->depth; a.ctusW = (p->width + a.ctuW - 1) / a.ctuW;
     a.params = p->ctu_params;
-    const int nctu = a.ctusW * ((p->height + 63) / 64);
+    const int nctu = a.ctusW * ((p->height + a.ctuH - 1) / a.ctuH);
     hipStream_t s = (hipStream_t)stream;
     if (bpp == 1) hipLaunchKernelGGL(sao_apply_kernel<uint8_t>, dim3(nctu), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(sao_apply_kernel<uint16_t>, dim3(nctu), dim3(256), 0, s, a);

@@ -306,36 +306,40 @@ class SaoStatsParams(ctypes.Structure):
     """x265hip_sao_stats_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("fenc", ctypes.c_void_p), ("fenc_stride", ctypes.c_ssize_t),
                 ("rec", ctypes.c_void_p), ("rec_stride", ctypes.c_ssize_t), ("width", ctypes.c_int), ("height", ctypes.c_int),
-                ("count", ctypes.c_void_p), ("offset_org", ctypes.c_void_p)]
+                ("count", ctypes.c_void_p), ("offset_org", ctypes.c_void_p),
+                ("ctu_width", ctypes.c_int), ("ctu_height", ctypes.c_int), ("plane_offset", ctypes.c_int)]
 
 
 class SaoApplyParams(ctypes.Structure):
     """x265hip_sao_apply_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("src", ctypes.c_void_p), ("src_stride", ctypes.c_ssize_t),
                 ("dst", ctypes.c_void_p), ("dst_stride", ctypes.c_ssize_t), ("width", ctypes.c_int), ("height", ctypes.c_int),
-                ("ctu_params", ctypes.c_void_p)]
+                ("ctu_params", ctypes.c_void_p), ("ctu_width", ctypes.c_int), ("ctu_height", ctypes.c_int)]
 
 
-def sao_stats(depth, fenc, fenc_stride, fenc_org, rec, rec_stride, rec_org, width, height, count, offset_org, stream=None):
+def sao_stats(depth, fenc, fenc_stride, fenc_org, rec, rec_stride, rec_org, width, height, count, offset_org, stream=None, ctu=(0, 0),
+              plane_offset=0):
     """SAO::calcSaoStatsCTU for every CTU: count / offset_org int32 [numCtu * 5 * 32] device tensors."""
     es = 1 if depth == 8 else 2
     p = SaoStatsParams()
     p.depth, p.fenc, p.fenc_stride = depth, fenc.data_ptr() + fenc_org * es, fenc_stride
     p.rec, p.rec_stride, p.width, p.height = rec.data_ptr() + rec_org * es, rec_stride, width, height
     p.count, p.offset_org = count.data_ptr(), offset_org.data_ptr()
+    p.ctu_width, p.ctu_height, p.plane_offset = ctu[0], ctu[1], plane_offset
     s = current_stream() if stream is None else stream
     f = lib().x265hip_sao_stats
     f.argtypes = [ctypes.POINTER(SaoStatsParams), ctypes.c_void_p]
     check(f(ctypes.byref(p), s), "x265hip_sao_stats")
 
 
-def sao_apply(depth, src, src_stride, src_org, dst, dst_stride, dst_org, width, height, ctu_params, stream=None):
+def sao_apply(depth, src, src_stride, src_org, dst, dst_stride, dst_org, width, height, ctu_params, stream=None, ctu=(0, 0)):
     """SAO::generateLumaOffsets / applyPixelOffsets for every CTU, out of place; ctu_params: int32 [numCtu * 7] device tensor."""
     es = 1 if depth == 8 else 2
     p = SaoApplyParams()
     p.depth, p.src, p.src_stride = depth, src.data_ptr() + src_org * es, src_stride
     p.dst, p.dst_stride, p.width, p.height = dst.data_ptr() + dst_org * es, dst_stride, width, height
     p.ctu_params = ctu_params.data_ptr()
+    p.ctu_width, p.ctu_height = ctu
     s = current_stream() if stream is None else stream
     f = lib().x265hip_sao_apply
     f.argtypes = [ctypes.POINTER(SaoApplyParams), ctypes.c_void_p]
