@@ -15,8 +15,8 @@
 // dwords, or packed dot4/dot2 interpolation + 4x4 Hadamard for fractional positions, tile_interp.h) and summed across the group
 // with DPP, so every lane of a group holds the same score and runs the reference's serial decision code redundantly; groups of
 // one wavefront follow their own decisions through ordinary SIMT divergence (the instruction stream is the same, only the
-// motion vectors differ).  A wavefront takes 16 consecutive jobs: the small ones together, the medium ones four at a time,
-// the large ones one after the other - any job order is correct, jobs sorted by size run fastest.
+// motion vectors differ).  A wavefront takes 16 consecutive jobs: the small ones together, the medium ones four at a time; the
+// large ones are queued and run by a second kernel with a wavefront each - any job order is correct.
 #include "pu_eval.h"
 
 namespace x265hip {
@@ -30,6 +30,7 @@ struct SearchArgs
     int depth, method, subme, merange;
     int mvminx, mvminy, mvmaxx, mvmaxy;
     const int32_t* mvc; const int32_t* numMvc;      // optional [njobs][12][2] quarter-pel candidates / [njobs]
+    int* largeCount; int* largeQueue;               // jobs of more than 32 tiles, collected by the first kernel for the second
 };
 
 // Point i of one StarPatternSearch round (motion.cpp:362-604) as offsets from the round's origin, in the reference's
@@ -340,16 +341,24 @@ __global__ void __launch_bounds__(256, 3) me_search_kernel(SearchArgs a)
             if (mine >= 0) search_job<Px, 16, 2>(a, first + mine);
         }
     }
-    // large PUs: the whole wavefront, one after the other
+    // large PUs need the whole wavefront: they are queued for the second kernel, which gives each of them a wavefront of its own
+    // (sixteen of them one after the other in this wavefront would leave most of the chip idle)
+    if (m2)
     {
-        unsigned long long m = m2;
-        while (m)
-        {
-            const int j = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            search_job<Px, 64, 4>(a, first + j);
-        }
+        const int n = __popcll(m2);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.largeCount, n);
+        base = __shfl(base, 0, 64);
+        if (cls == 2) a.largeQueue[base + __popcll(m2 & ((1ull << lane) - 1))] = first + lane;
     }
+}
+
+template <typename Px>
+__global__ void __launch_bounds__(256, 3) me_search_large_kernel(SearchArgs a)
+{
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= *a.largeCount) return;
+    search_job<Px, 64, 4>(a, a.largeQueue[w]);
 }
 
 } // namespace x265hip
@@ -377,9 +386,25 @@ extern "C" int x265hip_me_search(const x265hip_me_search_params* p, void* stream
     a.mvminx = p->mvmin_x; a.mvminy = p->mvmin_y; a.mvmaxx = p->mvmax_x; a.mvmaxy = p->mvmax_y;
     a.mvc = p->mvc; a.numMvc = p->num_mvc;
     hipStream_t s = (hipStream_t)stream;
+    // stream-ordered scratch: [0] = number of large jobs, [1..] = their indices
+    int* scratch = nullptr;
+    X265HIP_TRY(hipMallocAsync((void**)&scratch, sizeof(int) * ((size_t)p->njobs + 1), s));
+    X265HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(int), s));
+    a.largeCount = scratch; a.largeQueue = scratch + 1;
     const int wgs = (p->njobs + 63) / 64;                          // 4 wavefronts x 16 jobs per workgroup
-    if (bpp == 1) hipLaunchKernelGGL(me_search_kernel<uint8_t>, dim3(wgs), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(me_search_kernel<uint16_t>, dim3(wgs), dim3(256), 0, s, a);
+    // the second grid covers the worst case (every job large): surplus wavefronts leave at once
+    const int wgsLarge = (p->njobs + 3) / 4;
+    if (bpp == 1)
+    {
+        hipLaunchKernelGGL(me_search_kernel<uint8_t>, dim3(wgs), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(me_search_large_kernel<uint8_t>, dim3(wgsLarge), dim3(256), 0, s, a);
+    }
+    else
+    {
+        hipLaunchKernelGGL(me_search_kernel<uint16_t>, dim3(wgs), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(me_search_large_kernel<uint16_t>, dim3(wgsLarge), dim3(256), 0, s, a);
+    }
     X265HIP_TRY(hipGetLastError());
+    X265HIP_TRY(hipFreeAsync(scratch, s));
     return 0;
 }
