@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""[test infrastructure, like tests/: uses oracle/ only as the checker]
+"""[test infrastructure: uses oracle/ only as the checker; not collected by pytest - run it by hand on a GPU box]
 
 Randomised soak of the device stages against the oracle: many seeds / sizes / parameter draws per stage for a time budget.
-Usage on a GPU box:  python tools/soak.py [seconds]   -> one line per stage with the number of cases, non-zero exit on a mismatch."""
+Usage on a GPU box:  python tests/soak.py [seconds]   -> one line per stage with the number of cases, non-zero exit on a mismatch."""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
