@@ -80,7 +80,7 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0):
                                       nthreads=cores, avx2=avx2)
         if n == nctu:       # per-picture stage, single-threaded in the restatement
             bv, bh = O.deblock_bs_inter(depth, w64, h64, level, mv, ns, avx2=avx2)
-            dbk = O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, qp, avx2=avx2)
+            dbk = O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, max(qp - 6 * (depth - 8), 0), avx2=avx2)
             O.sao_stats(depth, cur.reshape(-1), dbk.reshape(-1), stride, org, w64, h64, nthreads=cores, avx2=avx2)
         return time.perf_counter() - t
 

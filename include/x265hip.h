@@ -248,6 +248,7 @@ typedef struct x265hip_deblock_bs_params
     int width, height, level;
     const int32_t* mv; const uint32_t* num_sig;
     uint8_t* bs_ver; uint8_t* bs_hor;
+    const uint8_t* intra;          /* optional uint8 [ctu][blocks]: non-zero = intra CU, its edges get Bs 2 (deblock.cpp:198-199) */
 } x265hip_deblock_bs_params;
 int x265hip_deblock_bs_inter(const x265hip_deblock_bs_params* p, void* stream);
 typedef struct x265hip_deblock_params
@@ -260,6 +261,20 @@ typedef struct x265hip_deblock_params
     int beta_offset_div2, tc_offset_div2;
 } x265hip_deblock_params;
 int x265hip_deblock_luma(const x265hip_deblock_params* p, void* stream);
+/* x265hip_deblock_chroma = Deblock::edgeFilterChroma (deblock.cpp:417-497) + pelFilterChroma (loopfilter.cpp:160-180) for the Cb / Cr
+ *   planes of a 4:2:0 picture, in place: only Bs 2 units on the 8-sample chroma grid (luma multiples of 16) are filtered; tc from the
+ *   mean QP + the plane's PPS offset through the chroma QP mapping (constants.cpp:346-350).  cb / cr = sample (0,0), stride in
+ *   samples; width / height = LUMA size (multiples of 16); bs maps / qp_map as above; qp = the CUs' m_qp (0..51). */
+typedef struct x265hip_deblock_chroma_params
+{
+    int depth;
+    void* cb; void* cr; intptr_t stride;
+    int width, height;
+    const uint8_t* bs_ver; const uint8_t* bs_hor;
+    int qp; const int8_t* qp_map;
+    int cb_qp_offset, cr_qp_offset, tc_offset_div2;
+} x265hip_deblock_chroma_params;
+int x265hip_deblock_chroma(const x265hip_deblock_chroma_params* p, void* stream);
 
 /* ---- lookahead picture preparation and intra cost estimate (the intra half) ----
  * x265hip_lowres_init = Lowres::init's pixel work (lowres.cpp:294-306): frameInitLowres (pixel.cpp:604-629) into the four

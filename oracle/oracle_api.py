@@ -147,17 +147,35 @@ def motion_estimate(depth, fenc, fref, stride, org, method, subme, merange, cost
     return out
 
 
-def deblock_bs_inter(depth, width, height, level, mv, num_sig, avx2=False):
-    """CPU restatement of getBoundaryStrength for a picture of square inter blocks.  Returns (bs_ver, bs_hor)."""
+def deblock_bs_inter(depth, width, height, level, mv, num_sig, avx2=False, intra=None):
+    """CPU restatement of getBoundaryStrength for a picture of square blocks (intra: optional uint8 flags per block, Bs 2 on their
+    edges).  Returns (bs_ver, bs_hor)."""
     L = lib(avx2)
-    fn = getattr(L, f"x265oracle_deblock_bs_inter_d{depth}")
+    fn = getattr(L, f"x265oracle_deblock_bs_d{depth}")
     bv = np.zeros((height // 4) * (width // 8), np.uint8)
     bh = np.zeros((height // 8) * (width // 4), np.uint8)
     m = np.ascontiguousarray(mv, dtype=np.int32)
     ns = np.ascontiguousarray(num_sig, dtype=np.uint32)
-    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    fn(width, height, level, m.ctypes.data, ns.ctypes.data, bv.ctypes.data, bh.ctypes.data)
+    it = None if intra is None else np.ascontiguousarray(intra, dtype=np.uint8)
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    fn(width, height, level, m.ctypes.data, ns.ctypes.data, None if it is None else it.ctypes.data, bv.ctypes.data, bh.ctypes.data)
     return bv, bh
+
+
+def deblock_chroma(depth, cb, cr, stride_c, org_c, width, height, bs_ver, bs_hor, qp, qp_map=None, cb_qp_offset=0, cr_qp_offset=0,
+                   tc_offset_div2=0, avx2=False):
+    """CPU restatement of edgeFilterChroma over the two chroma planes of a 4:2:0 picture (width / height = luma size); returns the
+    filtered copies of cb, cr (flat padded planes, sample (0,0) at element org_c)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_deblock_chroma_d{depth}")
+    ob, orr = cb.copy(), cr.copy()
+    es = cb.itemsize
+    qm = None if qp_map is None else np.ascontiguousarray(qp_map, dtype=np.int8)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    fn(ob.ctypes.data + org_c * es, orr.ctypes.data + org_c * es, stride_c, width, height, bs_ver.ctypes.data, bs_hor.ctypes.data, qp,
+       None if qm is None else qm.ctypes.data, cb_qp_offset, cr_qp_offset, tc_offset_div2)
+    return ob, orr
 
 
 def deblock_luma(depth, rec, stride, org, width, height, bs_ver, bs_hor, qp, qp_map=None, beta_offset_div2=0, tc_offset_div2=0, avx2=False):

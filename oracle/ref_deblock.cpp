@@ -27,8 +27,20 @@ extern "C" {
 /* recPlane: ALLOCATION START of a padded luma plane (reference PicYuv geometry, width / height multiples of 64), filtered in place.
  * level 0..2 = 8x8 / 16x16 / 32x32 blocks; mv: int32 [numCtu * 85][2] = { cost, qx | qy << 16 } (the sub-pel stage's records, the
  * level's blocks in z-order at offsets 0 / 64 / 80); numSig: uint32 [numCtu][blocks per CTU].  Returns 0 on success. */
+int x265ref_deblock420(void* recPlane, void* cbPlane, void* crPlane, int width, int height, int level, const int32_t* mv,
+                       const uint32_t* numSig, const uint8_t* intra, int qp, int betaOffsetDiv2, int tcOffsetDiv2, int cbQpOffset, int crQpOffset);
+
 int x265ref_deblock(void* recPlane, int width, int height, int level, const int32_t* mv, const uint32_t* numSig, int qp,
                     int betaOffsetDiv2, int tcOffsetDiv2)
+{
+    return x265ref_deblock420(recPlane, NULL, NULL, width, height, level, mv, numSig, NULL, qp, betaOffsetDiv2, tcOffsetDiv2, 0, 0);
+}
+
+/* The general form: cbPlane / crPlane = UNPADDED (width / 2) x (height / 2) chroma planes of a 4:2:0 picture (NULL: luma only),
+ * filtered in place; intra: optional uint8 [numCtu][blocks per CTU], non-zero = the block is an intra CU (Bs 2 on its edges, the
+ * only edges the chroma filter touches); cbQpOffset / crQpOffset = pps->chromaQpOffset[]. */
+int x265ref_deblock420(void* recPlane, void* cbPlane, void* crPlane, int width, int height, int level, const int32_t* mv,
+                       const uint32_t* numSig, const uint8_t* intra, int qp, int betaOffsetDiv2, int tcOffsetDiv2, int cbQpOffset, int crQpOffset)
 {
     static bool tableReady = false;
     if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
@@ -37,7 +49,7 @@ int x265ref_deblock(void* recPlane, int width, int height, int level, const int3
     x265_param_default(param);
     param->sourceWidth = width;
     param->sourceHeight = height;
-    param->internalCsp = X265_CSP_I400;
+    param->internalCsp = cbPlane ? X265_CSP_I420 : X265_CSP_I400;
     param->maxCUSize = 64;
     param->minCUSize = 8;
     param->maxLog2CUSize = 6;
@@ -59,6 +71,8 @@ int x265ref_deblock(void* recPlane, int width, int height, int level, const int3
     pps.deblockingFilterBetaOffsetDiv2 = betaOffsetDiv2;
     pps.deblockingFilterTcOffsetDiv2 = tcOffsetDiv2;
     pps.bTransquantBypassEnabled = 0;
+    pps.chromaQpOffset[0] = cbQpOffset;
+    pps.chromaQpOffset[1] = crQpOffset;
     const int numCtu = sps.numCUsInFrame;
 
     PicYuv recon;
@@ -67,6 +81,12 @@ int x265ref_deblock(void* recPlane, int width, int height, int level, const int3
     const size_t planeBytes = sizeof(pixel) * recon.m_stride * (height + 2 * recon.m_lumaMarginY);
     pixel* planeStart = recon.m_picOrg[0] - recon.m_lumaMarginY * recon.m_stride - recon.m_lumaMarginX;
     memcpy(planeStart, recPlane, planeBytes);
+    void* chroma[2] = { cbPlane, crPlane };
+    const int cw = width / 2, ch = height / 2;
+    if (cbPlane)
+        for (int c = 0; c < 2; c++)
+            for (int y = 0; y < ch; y++)
+                memcpy(recon.m_picOrg[1 + c] + (intptr_t)y * recon.m_strideC, (const pixel*)chroma[c] + (size_t)y * cw, sizeof(pixel) * cw);
 
     Frame frame, refFrame;
     frame.m_param = param;
@@ -99,7 +119,7 @@ int x265ref_deblock(void* recPlane, int width, int height, int level, const int3
         {
             const int z = p / partsPerBlock;
             const int32_t pk = mv[((size_t)a * 85 + lbase + z) * 2 + 1];
-            ctus[a].m_predMode[p] = MODE_INTER;
+            ctus[a].m_predMode[p] = (intra && intra[(size_t)a * npu + z]) ? MODE_INTRA : MODE_INTER;
             ctus[a].m_cuDepth[p] = (uint8_t)depth;
             ctus[a].m_log2CUSize[p] = (uint8_t)log2n;
             ctus[a].m_partSize[p] = SIZE_2Nx2N;
@@ -116,6 +136,10 @@ int x265ref_deblock(void* recPlane, int width, int height, int level, const int3
     for (int a = 0; a < numCtu; a++) deblock.deblockCTU(&ctus[a], geoms[0], Deblock::EDGE_VER);
     for (int a = 0; a < numCtu; a++) deblock.deblockCTU(&ctus[a], geoms[0], Deblock::EDGE_HOR);
     memcpy(recPlane, planeStart, planeBytes);
+    if (cbPlane)
+        for (int c = 0; c < 2; c++)
+            for (int y = 0; y < ch; y++)
+                memcpy((pixel*)chroma[c] + (size_t)y * cw, recon.m_picOrg[1 + c] + (intptr_t)y * recon.m_strideC, sizeof(pixel) * cw);
 
     frame.m_reconPic = NULL; frame.m_encData = NULL;
     encData.m_picCTU = NULL; encData.m_slice = NULL;

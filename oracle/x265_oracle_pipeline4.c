@@ -44,8 +44,18 @@ static int iabs(int v) { return v < 0 ? -v : v; }
 /* Bs maps of a picture made of n x n inter blocks (n = 8 << level), z-order inside each 64x64 CTU like the other stages:
  * mv = int32 [ctu*85][2] {cost, qx | qy << 16}, numSig = uint32 [ctu][npu].
  * bsVer: uint8 [height/4][width/8] (unit r of the vertical edge at x = 8 * ex), bsHor: uint8 [height/8][width/4]. */
+void EXPORT(x265oracle_deblock_bs)(int width, int height, int level, const int32_t* mv, const uint32_t* numSig, const uint8_t* intra,
+                                   uint8_t* bsVer, uint8_t* bsHor);
 void EXPORT(x265oracle_deblock_bs_inter)(int width, int height, int level, const int32_t* mv, const uint32_t* numSig,
                                          uint8_t* bsVer, uint8_t* bsHor)
+{
+    EXPORT(x265oracle_deblock_bs)(width, height, level, mv, numSig, NULL, bsVer, bsHor);
+}
+
+/* intra: optional uint8 [ctu][npu], non-zero = the block is an intra CU: an edge with an intra block on either side gets Bs 2
+ * (deblock.cpp:198-199). */
+void EXPORT(x265oracle_deblock_bs)(int width, int height, int level, const int32_t* mv, const uint32_t* numSig, const uint8_t* intra,
+                                   uint8_t* bsVer, uint8_t* bsHor)
 {
     const int n = 8 << level, npu = (64 / n) * (64 / n), ctusW = width / 64;
     const int lbase = level == 0 ? 0 : (level == 1 ? 64 : (level == 2 ? 80 : 84));
@@ -55,20 +65,20 @@ void EXPORT(x265oracle_deblock_bs_inter)(int width, int height, int level, const
         const int ctu_ = ((Y) / 64) * ctusW + (X) / 64, bx_ = ((X) & 63) / n, by_ = ((Y) & 63) / n; \
         int z_ = 0; for (int b_ = 0; b_ < 3; b_++) z_ |= (((bx_ >> b_) & 1) << (2 * b_)) | (((by_ >> b_) & 1) << (2 * b_ + 1)); \
         const int32_t pk_ = mv[((size_t)ctu_ * 85 + lbase + z_) * 2 + 1]; \
-        MVX = (int16_t)(pk_ & 0xffff); MVY = (int16_t)(pk_ >> 16); CBF = numSig[(size_t)ctu_ * npu + z_] != 0; } while (0)
+        MVX = (int16_t)(pk_ & 0xffff); MVY = (int16_t)(pk_ >> 16); CBF = (numSig[(size_t)ctu_ * npu + z_] != 0) | ((intra && intra[(size_t)ctu_ * npu + z_]) ? 2 : 0); } while (0)
     for (int y = 0; y < height; y += 4)
         for (int x = n; x < width; x += n)            /* vertical block edges; x = 0 is the picture border */
         {
             int px, py, pc, qx, qy, qc;
             BLK(x - 1, y, px, py, pc); BLK(x, y, qx, qy, qc);
-            bsVer[(size_t)(y / 4) * (width / 8) + x / 8] = (pc || qc) ? 1 : ((iabs(qx - px) >= 4 || iabs(qy - py) >= 4) ? 1 : 0);
+            bsVer[(size_t)(y / 4) * (width / 8) + x / 8] = ((pc | qc) & 2) ? 2 : ((pc || qc) ? 1 : ((iabs(qx - px) >= 4 || iabs(qy - py) >= 4) ? 1 : 0));
         }
     for (int y = n; y < height; y += n)
         for (int x = 0; x < width; x += 4)
         {
             int px, py, pc, qx, qy, qc;
             BLK(x, y - 1, px, py, pc); BLK(x, y, qx, qy, qc);
-            bsHor[(size_t)(y / 8) * (width / 4) + x / 4] = (pc || qc) ? 1 : ((iabs(qx - px) >= 4 || iabs(qy - py) >= 4) ? 1 : 0);
+            bsHor[(size_t)(y / 8) * (width / 4) + x / 4] = ((pc | qc) & 2) ? 2 : ((pc || qc) ? 1 : ((iabs(qx - px) >= 4 || iabs(qy - py) >= 4) ? 1 : 0));
         }
 #undef BLK
 }
@@ -148,6 +158,46 @@ void EXPORT(x265oracle_deblock_luma)(pixel* rec, intptr_t stride, int width, int
             const int q = qpMap ? (qpMap[(ey - 1) * w8 + bx] + qpMap[ey * w8 + bx] + 1) >> 1 : qp;
             filter_unit(&prim, rec + (intptr_t)(ey * 8) * stride + u * 4, 1, stride, 1, bs, q, bo, to);
         }
+}
+
+/* Deblock::edgeFilterChroma (deblock.cpp:417-497) for the two chroma planes of a 4:2:0 picture: only edges with Bs 2 (an intra
+ * block on either side) on the 8-sample chroma grid (luma positions that are multiples of 16, deblock.cpp:104-113) are filtered,
+ * 4 chroma lines per unit with the Bs of the luma unit they start at; tc from the mean QP + the plane's PPS offset through the
+ * chroma QP mapping table (constants.cpp:346-350) at index qp + DEFAULT_INTRA_TC_OFFSET (2) + tcOffset; the filter is
+ * primitives.pelFilterChroma (loopfilter.cpp:160-180).  cb / cr: sample (0,0) of the planes, strideC their stride; width / height:
+ * LUMA size; bs maps and qpMap as for x265oracle_deblock_luma.  Vertical edges first, then horizontal. */
+static const uint8_t kChromaScale[70] = {
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 33, 33, 34, 34, 35,
+    35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51 };
+
+void EXPORT(x265oracle_deblock_chroma)(pixel* cb, pixel* cr, intptr_t strideC, int width, int height, const uint8_t* bsVer, const uint8_t* bsHor,
+                                       int qp, const int8_t* qpMap, int cbQpOffset, int crQpOffset, int tcOffsetDiv2)
+{
+    static x265hip_EncoderPrimitives prim;
+    static int ready = 0;
+    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    pixel* planes[2] = { cb, cr };
+    const int offs[2] = { cbQpOffset, crQpOffset };
+    const int to = tcOffsetDiv2 * 2, w8 = width / 8;
+    for (int dir = 0; dir < 2; dir++)
+        for (int e = 1; e < (dir ? height : width) / 16; e++)          /* edges at luma 16 * e */
+            for (int cu = 0; cu < (dir ? width : height) / 8; cu++)   /* chroma units of 4 lines = 8 luma lines along the edge */
+            {
+                const int bs = dir ? bsHor[(size_t)(2 * e) * (width / 4) + 2 * cu] : bsVer[(size_t)(2 * cu) * w8 + 2 * e];
+                if (bs <= 1) continue;
+                int qpA = qp;
+                if (qpMap)
+                    qpA = dir ? (qpMap[(2 * e - 1) * w8 + cu] + qpMap[(2 * e) * w8 + cu] + 1) >> 1
+                              : (qpMap[cu * w8 + 2 * e - 1] + qpMap[cu * w8 + 2 * e] + 1) >> 1;
+                for (int c = 0; c < 2; c++)
+                {
+                    int q = qpA + offs[c];
+                    if (q >= 30) q = kChromaScale[q];
+                    const int tc = kTc[clip3(0, 53, q + 2 + to)] << (DEPTH - 8);
+                    pixel* src = dir ? planes[c] + (intptr_t)(8 * e) * strideC + 4 * cu : planes[c] + (intptr_t)(4 * cu) * strideC + 8 * e;
+                    prim.pelFilterChroma[dir](src, dir ? 1 : strideC, dir ? strideC : 1, tc, -1, -1);
+                }
+            }
 }
 
 /* ---------------------------------------------------------------------------------------------------------------------------

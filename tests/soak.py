@@ -96,7 +96,7 @@ def soak_pipeline(rng):
     mv = O.subpel_refine(depth, cur.host, cur.stride, cur.org, ref.host, cur.stride, cur.org, cur.w64, cur.h64, R, 0, fp.ms.nctu, best, cq, qoff, subme)
     erec, elev, ens, _ = O.inter_recon(depth, cur.host, cur.stride, cur.org, ref.host, cur.stride, cur.org, cur.w64, cur.h64, level, mv, qp)
     bv, bh = O.deblock_bs_inter(depth, cur.w64, cur.h64, level, mv, ens)
-    erec = O.deblock_luma(depth, erec.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64, bv, bh, qp).reshape(erec.shape)
+    erec = O.deblock_luma(depth, erec.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64, bv, bh, max(qp - 6 * (depth - 8), 0)).reshape(erec.shape)
     ecnt, eoff = O.sao_stats(depth, cur.host.reshape(-1), erec.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64)
     assert np.array_equal(fp.sp.out.cpu().numpy().reshape(-1, 2), mv) and np.array_equal(fp.rc.levels.cpu().numpy(), elev)
     inner = erec[F.MARGIN_Y:F.MARGIN_Y + cur.h64, F.MARGIN_X:F.MARGIN_X + cur.w64]

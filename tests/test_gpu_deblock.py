@@ -82,3 +82,57 @@ def test_deblock_random_strengths_qp_map_and_offsets(depth):
             exp = O.deblock_luma(depth, pic.host, pic.stride, pic.org, pic.w64, pic.h64, bv, bh, 30, qp_map=qmap, beta_offset_div2=bo, tc_offset_div2=to)
             got = plane.cpu().numpy().view(pic.host.dtype)
             assert np.array_equal(got, exp), f"{kind} offsets {(bo, to)}: {np.count_nonzero(got != exp)} samples differ"
+
+
+@pytest.mark.parametrize("depth,level,qp,cq", [(8, 2, 32, (0, 0)), (8, 1, 36, (3, -4)), (8, 0, 30, (-2, 6)), (10, 1, 33, (1, 1)), (12, 2, 40, (0, 5))])
+def test_deblock_with_intra_blocks_and_chroma(depth, level, qp, cq):
+    """Mixed intra / inter 4:2:0 pictures: Bs 2 on intra CU edges (luma tc index + the only edges the chroma filter touches), Cb / Cr
+    planes filtered on the 8-sample chroma grid with the chroma QP mapping; vs the oracle restatement pinned against the real class."""
+    import torch
+    H = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    clip = F.synth_clip(256, 192, 2, depth=depth, seed=57 + level)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    pipe = S.FramePipeline(cur.w64, cur.h64, depth, dev, rng=8, subme=2, level=level, qp=qp + 6 * (depth - 8), want_surf=False)
+    rec = pipe.run(cur, ref)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng([43, depth, level])
+    nctu, npu = pipe.ms.nctu, (64 >> (3 + level)) ** 2
+    intra = (rng.random((nctu, npu)) < 0.3).astype(np.uint8)
+    qmap = rng.integers(max(qp - 6, 0), min(qp + 7, 52), size=(cur.h64 // 8) * (cur.w64 // 8)).astype(np.int8)
+    cw, ch = cur.w64 // 2, cur.h64 // 2
+    dt = cur.host.dtype
+    margin = 16
+    cst, corg = cw + 2 * margin, margin * (cw + 2 * margin) + margin
+    planes = []
+    for c in (1, 2):
+        pl = np.zeros((ch + 2 * margin, cst), dtype=dt)
+        src = clip[1][c]
+        steps = rng.integers(-6, 7, size=(ch // 8, cw // 8)) << (depth - 8)
+        body = np.zeros((ch, cw), np.int32)
+        body[:src.shape[0], :src.shape[1]] = src
+        body[src.shape[0]:, :] = body[src.shape[0] - 1]
+        body[:, src.shape[1]:] = body[:, src.shape[1] - 1:src.shape[1]]
+        pl[margin:margin + ch, margin:margin + cw] = np.clip(body + np.kron(steps, np.ones((8, 8), np.int32)), 0, (1 << depth) - 1)
+        planes.append(np.ascontiguousarray(pl).reshape(-1))
+    mv_h = pipe.sp.out.cpu().numpy()
+    ns_h = pipe.rc.num_sig.cpu().numpy().view(np.uint32)
+    rec_h = rec.cpu().numpy().view(dt).copy()
+    bv, bh = O.deblock_bs_inter(depth, cur.w64, cur.h64, level, mv_h, ns_h, intra=intra)
+    exp_y = O.deblock_luma(depth, rec_h, cur.stride, cur.org, cur.w64, cur.h64, bv, bh, qp, qp_map=qmap, tc_offset_div2=1)
+    exp_cb, exp_cr = O.deblock_chroma(depth, planes[0], planes[1], cst, corg, cur.w64, cur.h64, bv, bh, qp, qp_map=qmap, cb_qp_offset=cq[0],
+                                      cr_qp_offset=cq[1], tc_offset_div2=1)
+    d_bv = torch.zeros(bv.size, dtype=torch.uint8, device=dev)
+    d_bh = torch.zeros(bh.size, dtype=torch.uint8, device=dev)
+    H.deblock_bs_inter(cur.w64, cur.h64, level, pipe.sp.out, pipe.rc.num_sig, d_bv, d_bh, intra=torch.from_numpy(intra.reshape(-1)).to(dev))
+    d_q = torch.from_numpy(qmap).to(dev)
+    H.deblock_luma(depth, rec, cur.stride, cur.org, cur.w64, cur.h64, d_bv, d_bh, qp, qp_map=d_q, tc_offset_div2=1)
+    d_cb = torch.from_numpy(planes[0].view(np.uint8)).to(dev)
+    d_cr = torch.from_numpy(planes[1].view(np.uint8)).to(dev)
+    H.deblock_chroma(depth, d_cb, d_cr, cst, corg, cur.w64, cur.h64, d_bv, d_bh, qp, qp_map=d_q, cb_qp_offset=cq[0], cr_qp_offset=cq[1], tc_offset_div2=1)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_bv.cpu().numpy(), bv) and np.array_equal(d_bh.cpu().numpy(), bh) and (bv == 2).any() and (bh == 2).any()
+    assert np.array_equal(rec.cpu().numpy().view(dt), exp_y), "luma differs"
+    assert np.array_equal(d_cb.cpu().numpy().view(dt), exp_cb) and np.array_equal(d_cr.cpu().numpy().view(dt), exp_cr), "chroma differs"
+    assert np.count_nonzero(exp_cb != planes[0]) > 20

@@ -46,7 +46,7 @@ def test_closed_loop_three_frames(depth, deblock):
                                                cur.w64, cur.h64, level, mv, qp)
         if deblock:         # the in-loop filter runs on the reconstruction before it becomes a reference
             bv, bh = O.deblock_bs_inter(depth, cur.w64, cur.h64, level, mv, ens)
-            erec = O.deblock_luma(depth, erec.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64, bv, bh, qp).reshape(erec.shape)
+            erec = O.deblock_luma(depth, erec.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64, bv, bh, max(qp - 6 * (depth - 8), 0)).reshape(erec.shape)
         if deblock:         # SAO statistics of the filtered reconstruction against the source
             ecnt, eoff = O.sao_stats(depth, cur.host.reshape(-1), erec.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64)
             assert np.array_equal(fp.sao.count.cpu().numpy().reshape(ecnt.shape), ecnt), f"frame {k}: SAO counts differ"

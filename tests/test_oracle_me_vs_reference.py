@@ -340,6 +340,58 @@ def test_deblock_restatement_equals_reference_class(depth, level, qp, offs):
     assert np.count_nonzero(exp.reshape(-1) != rec.reshape(-1)) > 50 and bv.any() and bh.any()
 
 
+@pytest.mark.parametrize("depth,level,qp,offs,cq", [(8, 2, 32, (0, 0), (0, 0)), (8, 1, 36, (1, -2), (3, -4)), (8, 0, 30, (0, 0), (-2, 6)), (10, 1, 33, (0, 2), (1, 1))])
+def test_deblock_with_intra_blocks_and_chroma_equals_reference_class(depth, level, qp, offs, cq):
+    """Mixed intra / inter pictures in 4:2:0: Bs 2 on the edges of intra CUs, luma filtered with the Bs-2 tc, and the chroma planes
+    (edgeFilterChroma: Bs 2 edges on the 8-sample chroma grid, chroma QP mapping, PPS chroma offsets) - against the real class."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_deblock420"):
+        pytest.skip("oracle/_ref predates x265ref_deblock420")
+    R, subme = 8, 2
+    clip = F.synth_clip(192, 128, 2, depth=depth, seed=75 + level)
+    cur, stride, org, w64, h64 = F.pad_plane(clip[1][0])
+    ref = F.pad_plane(clip[0][0])[0]
+    nctu = (w64 // 64) * (h64 // 64)
+    cost = F.mv_cost_table(R)
+    cqt, qoff = F.qpel_cost_table(R)
+    _, best = O.me_fullsearch(depth, cur, stride, org, ref, stride, org, w64, h64, R, 0, nctu, cost, cost, want_surf=False)
+    mv = O.subpel_refine(depth, cur, stride, org, ref, stride, org, w64, h64, R, 0, nctu, best, cqt, qoff, subme)
+    rec, _, ns, _ = O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp + 6 * (depth - 8))
+    rng = np.random.default_rng([41, depth, level])
+    npu = (64 >> (3 + level)) ** 2
+    intra = (rng.random((nctu, npu)) < 0.3).astype(np.uint8)
+    # chroma planes of the reconstruction: the clip's chroma with coding-like steps at 8-sample boundaries
+    cw, ch = w64 // 2, h64 // 2
+    chroma = []
+    for c in (1, 2):
+        pl = np.zeros((ch, cw), dtype=cur.dtype)
+        src = clip[1][c]
+        pl[:src.shape[0], :src.shape[1]] = src
+        pl[src.shape[0]:, :] = pl[src.shape[0] - 1]
+        pl[:, src.shape[1]:] = pl[:, src.shape[1] - 1:src.shape[1]]
+        steps = rng.integers(-6, 7, size=(ch // 8, cw // 8)) << (depth - 8)
+        pl = np.clip(pl.astype(np.int32) + np.kron(steps, np.ones((8, 8), np.int32)), 0, (1 << depth) - 1).astype(cur.dtype)
+        chroma.append(np.ascontiguousarray(pl))
+    bv, bh = O.deblock_bs_inter(depth, w64, h64, level, mv, ns, intra=intra)
+    assert (bv == 2).any() and (bh == 2).any()
+    exp_y = O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, qp, beta_offset_div2=offs[0], tc_offset_div2=offs[1])
+    pads = [pad_any(c, margin=16) for c in chroma]
+    exp_cb, exp_cr = O.deblock_chroma(depth, pads[0][0], pads[1][0], pads[0][1], pads[0][2], w64, h64, bv, bh, qp, cb_qp_offset=cq[0],
+                                      cr_qp_offset=cq[1], tc_offset_div2=offs[1])
+    got_y = np.ascontiguousarray(rec.reshape(-1)).copy()
+    got_c = [c.copy() for c in chroma]
+    m, n = np.ascontiguousarray(mv, dtype=np.int32), np.ascontiguousarray(ns, dtype=np.uint32)
+    lib.x265ref_deblock420.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5
+    assert lib.x265ref_deblock420(got_y.ctypes.data, got_c[0].ctypes.data, got_c[1].ctypes.data, w64, h64, level, m.ctypes.data, n.ctypes.data,
+                                  intra.ctypes.data, qp, offs[0], offs[1], cq[0], cq[1]) == 0
+    assert np.array_equal(got_y, exp_y.reshape(-1)), f"luma: {np.count_nonzero(got_y != exp_y.reshape(-1))} samples differ"
+    for c, (exp, name) in enumerate(((exp_cb, "Cb"), (exp_cr, "Cr"))):
+        e2 = exp.reshape(-1, pads[c][1])[16:16 + ch, 16:16 + cw]
+        assert np.array_equal(got_c[c], e2), f"{name}: {np.count_nonzero(got_c[c] != e2)} samples differ"
+        assert np.count_nonzero(e2 != chroma[c]) > 20
+
+
 @pytest.mark.parametrize("depth,n,qp,islice", [(8, 4, 24, 1), (8, 4, 30, 0), (8, 8, 27, 1), (8, 16, 33, 0), (8, 32, 22, 1), (8, 32, 45, 0),
                                                (10, 4, 36, 1), (10, 16, 40, 1), (10, 32, 30, 0)])
 def test_intra_tu_round_trip_equals_reference_quant_class(depth, n, qp, islice):

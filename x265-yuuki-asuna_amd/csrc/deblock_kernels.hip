@@ -23,7 +23,7 @@ __constant__ unsigned char kDbBeta[52] = {
 struct BsArgs
 {
     int width, height, level;
-    const int2* mv; const uint32_t* numSig;
+    const int2* mv; const uint32_t* numSig; const uint8_t* intra;
     uint8_t* bsVer; uint8_t* bsHor;
 };
 
@@ -35,7 +35,8 @@ __device__ __forceinline__ void db_block(const BsArgs& a, int x, int y, int& mvx
     const int z = (bx & 1) | ((by & 1) << 1) | ((bx & 2) << 1) | ((by & 2) << 2) | ((bx & 4) << 2) | ((by & 4) << 3);
     const int pk = a.mv[(size_t)ctu * 85 + lbase + z].y;
     mvx = (int16_t)(pk & 0xffff); mvy = (int16_t)(pk >> 16);
-    cbf = a.numSig[(size_t)ctu * npu + z] != 0;
+    // bit 0: coded coefficients, bit 1: intra CU (Bs 2 on its edges, deblock.cpp:198-199)
+    cbf = (a.numSig[(size_t)ctu * npu + z] != 0) | ((a.intra && a.intra[(size_t)ctu * npu + z]) ? 2 : 0);
 }
 
 // one thread per 4-sample unit of the 8x8 edge grid, both directions in one launch (blockIdx.y = direction)
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(256) deblock_bs_inter_kernel(BsArgs a)
         {
             int px, py, pc, qx, qy, qc;
             db_block(a, x - 1, y, px, py, pc); db_block(a, x, y, qx, qy, qc);
-            bs = (pc || qc) ? 1 : ((abs(qx - px) >= 4 || abs(qy - py) >= 4) ? 1 : 0);
+            bs = ((pc | qc) & 2) ? 2 : ((pc || qc) ? 1 : ((abs(qx - px) >= 4 || abs(qy - py) >= 4) ? 1 : 0));
         }
         a.bsVer[i] = (uint8_t)bs;
     }
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(256) deblock_bs_inter_kernel(BsArgs a)
         {
             int px, py, pc, qx, qy, qc;
             db_block(a, x, y - 1, px, py, pc); db_block(a, x, y, qx, qy, qc);
-            bs = (pc || qc) ? 1 : ((abs(qx - px) >= 4 || abs(qy - py) >= 4) ? 1 : 0);
+            bs = ((pc | qc) & 2) ? 2 : ((pc || qc) ? 1 : ((abs(qx - px) >= 4 || abs(qy - py) >= 4) ? 1 : 0));
         }
         a.bsHor[i] = (uint8_t)bs;
     }
@@ -158,6 +159,53 @@ __global__ void __launch_bounds__(256) deblock_luma_kernel(DbArgs a)
     }
 }
 
+// Deblock::edgeFilterChroma (deblock.cpp:417-497) + pelFilterChroma (loopfilter.cpp:160-180) for one chroma plane of a 4:2:0 picture:
+// a thread per 4-line chroma unit of an edge on the 8-sample chroma grid (luma multiples of 16); only Bs 2 units are filtered.
+struct DbChromaArgs
+{
+    uint8_t* plane; long strideB;
+    int width, height, depth;                  // LUMA size
+    const uint8_t* bs; const int8_t* qpMap;
+    int qp, qpOffset, tcOffset;
+};
+
+__constant__ uint8_t kDbChromaScale[70] = {
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 33, 33, 34, 34, 35,
+    35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51 };
+
+template <typename Px, int DIR>
+__global__ void __launch_bounds__(256) deblock_chroma_kernel(DbChromaArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w8 = a.width >> 3, w4 = a.width >> 2;
+    const int nEdges = (DIR == 0 ? a.width : a.height) >> 4, nUnits = (DIR == 0 ? a.height : a.width) >> 3;
+    if (i >= nEdges * nUnits) return;
+    const int e = i / nUnits, cu = i - e * nUnits;
+    if (e == 0) return;                                     // the picture border is not an edge
+    const int bs = DIR == 0 ? a.bs[(2 * cu) * w8 + 2 * e] : a.bs[(size_t)(2 * e) * w4 + 2 * cu];
+    if (bs <= 1) return;
+    int qp = a.qp;
+    if (a.qpMap)
+        qp = DIR == 0 ? (a.qpMap[cu * w8 + 2 * e - 1] + a.qpMap[cu * w8 + 2 * e] + 1) >> 1
+                      : (a.qpMap[(2 * e - 1) * w8 + cu] + a.qpMap[(2 * e) * w8 + cu] + 1) >> 1;
+    qp += a.qpOffset;
+    if (qp >= 30) qp = kDbChromaScale[qp];
+    const int tc = (int)kDbTc[clip3(0, 53, qp + 2 + a.tcOffset)] << (a.depth - 8);
+    const int maxVal = (1 << a.depth) - 1;
+    const long st = a.strideB / (long)sizeof(Px);
+    Px* src = reinterpret_cast<Px*>(a.plane) + (DIR == 0 ? (long)(4 * cu) * st + 8 * e : (long)(8 * e) * st + 4 * cu);
+    const long offset = DIR == 0 ? 1 : st, srcStep = DIR == 0 ? st : 1;
+#pragma unroll
+    for (int l = 0; l < 4; l++)
+    {
+        Px* p = src + l * srcStep;
+        const int m2 = p[-2 * offset], m3 = p[-offset], m4 = p[0], m5 = p[offset];
+        const int delta = clip3(-tc, tc, (((m4 - m3) * 4) + m2 - m5 + 4) >> 3);
+        p[-offset] = (Px)clip3(0, maxVal, m3 + delta);
+        p[0] = (Px)clip3(0, maxVal, m4 - delta);
+    }
+}
+
 } // namespace x265hip
 
 using namespace x265hip;
@@ -174,6 +222,7 @@ extern "C" int x265hip_deblock_bs_inter(const x265hip_deblock_bs_params* p, void
     a.mv = (const int2*)p->mv; a.numSig = p->num_sig; a.bsVer = p->bs_ver; a.bsHor = p->bs_hor;
     const int nv = (p->height >> 2) * (p->width >> 3), nh = (p->height >> 3) * (p->width >> 2);
     const int n = nv > nh ? nv : nh;
+    a.intra = p->intra;
     hipLaunchKernelGGL(deblock_bs_inter_kernel, dim3((n + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, a);
     X265HIP_TRY(hipGetLastError());
     return 0;
@@ -201,6 +250,39 @@ extern "C" int x265hip_deblock_luma(const x265hip_deblock_params* p, void* strea
     a.bs = p->bs_hor;
     if (bpp == 1) hipLaunchKernelGGL((deblock_luma_kernel<uint8_t, 1>), dim3((nh + 255) / 256), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((deblock_luma_kernel<uint16_t, 1>), dim3((nh + 255) / 256), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x265hip_deblock_chroma(const x265hip_deblock_chroma_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->cb || !p->cr || !p->bs_ver || !p->bs_hor) { set_error("deblock_chroma: NULL operand"); return X265HIP_EINVAL; }
+    if ((p->width & 15) || (p->height & 15) || p->width <= 0 || p->height <= 0) { set_error("deblock_chroma: width/height must be multiples of 16"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("deblock_chroma: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->tc_offset_div2 < -6 || p->tc_offset_div2 > 6 || p->cb_qp_offset < -12 || p->cb_qp_offset > 12 || p->cr_qp_offset < -12 || p->cr_qp_offset > 12)
+    { set_error("deblock_chroma: tc / chroma QP offsets out of range"); return X265HIP_EINVAL; }
+    if (p->qp < 0 || p->qp > 51) { set_error("deblock_chroma: qp %d out of [0, 51]", p->qp); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    hipStream_t s = (hipStream_t)stream;
+    DbChromaArgs a;
+    a.strideB = (long)p->stride * bpp;
+    a.width = p->width; a.height = p->height; a.depth = p->depth;
+    a.qpMap = p->qp_map; a.qp = p->qp; a.tcOffset = p->tc_offset_div2 * 2;
+    const int nv = (p->width >> 4) * (p->height >> 3), nh = (p->height >> 4) * (p->width >> 3);
+    for (int dir = 0; dir < 2; dir++)
+        for (int c = 0; c < 2; c++)
+        {
+            a.plane = (uint8_t*)(c ? p->cr : p->cb);
+            a.qpOffset = c ? p->cr_qp_offset : p->cb_qp_offset;
+            a.bs = dir ? p->bs_hor : p->bs_ver;
+            const int n = dir ? nh : nv;
+            if (bpp == 1 && dir == 0) hipLaunchKernelGGL((deblock_chroma_kernel<uint8_t, 0>), dim3((n + 255) / 256), dim3(256), 0, s, a);
+            else if (bpp == 1) hipLaunchKernelGGL((deblock_chroma_kernel<uint8_t, 1>), dim3((n + 255) / 256), dim3(256), 0, s, a);
+            else if (dir == 0) hipLaunchKernelGGL((deblock_chroma_kernel<uint16_t, 0>), dim3((n + 255) / 256), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((deblock_chroma_kernel<uint16_t, 1>), dim3((n + 255) / 256), dim3(256), 0, s, a);
+        }
     X265HIP_TRY(hipGetLastError());
     return 0;
 }

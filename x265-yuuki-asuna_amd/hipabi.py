@@ -98,7 +98,16 @@ def me_search_job_dtype():
 
 class DeblockBsParams(ctypes.Structure):
     _fields_ = [("width", ctypes.c_int), ("height", ctypes.c_int), ("level", ctypes.c_int),
-                ("mv", ctypes.c_void_p), ("num_sig", ctypes.c_void_p), ("bs_ver", ctypes.c_void_p), ("bs_hor", ctypes.c_void_p)]
+                ("mv", ctypes.c_void_p), ("num_sig", ctypes.c_void_p), ("bs_ver", ctypes.c_void_p), ("bs_hor", ctypes.c_void_p),
+                ("intra", ctypes.c_void_p)]
+
+
+class DeblockChromaParams(ctypes.Structure):
+    """x265hip_deblock_chroma_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("cb", ctypes.c_void_p), ("cr", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),
+                ("width", ctypes.c_int), ("height", ctypes.c_int), ("bs_ver", ctypes.c_void_p), ("bs_hor", ctypes.c_void_p),
+                ("qp", ctypes.c_int), ("qp_map", ctypes.c_void_p),
+                ("cb_qp_offset", ctypes.c_int), ("cr_qp_offset", ctypes.c_int), ("tc_offset_div2", ctypes.c_int)]
 
 
 class DeblockParams(ctypes.Structure):
@@ -280,14 +289,31 @@ def me_search(depth, fenc, fenc_stride, fenc_off, fref, fref_stride, fref_off, m
     check(f(ctypes.byref(p), s), "x265hip_me_search")
 
 
-def deblock_bs_inter(width, height, level, mv, num_sig, bs_ver, bs_hor, stream=None):
+def deblock_bs_inter(width, height, level, mv, num_sig, bs_ver, bs_hor, stream=None, intra=None):
     p = DeblockBsParams()
     p.width, p.height, p.level = width, height, level
     p.mv, p.num_sig, p.bs_ver, p.bs_hor = mv.data_ptr(), num_sig.data_ptr(), bs_ver.data_ptr(), bs_hor.data_ptr()
+    p.intra = _p(intra)
     s = current_stream() if stream is None else stream
     f = lib().x265hip_deblock_bs_inter
     f.argtypes = [ctypes.POINTER(DeblockBsParams), ctypes.c_void_p]
     check(f(ctypes.byref(p), s), "x265hip_deblock_bs_inter")
+
+
+def deblock_chroma(depth, cb, cr, stride, org, width, height, bs_ver, bs_hor, qp, qp_map=None, cb_qp_offset=0, cr_qp_offset=0,
+                   tc_offset_div2=0, stream=None):
+    """edgeFilterChroma over the Cb / Cr planes of a 4:2:0 picture in place (width / height = luma size; org = element offset of
+    sample (0,0) in both plane tensors)."""
+    es = 1 if depth == 8 else 2
+    p = DeblockChromaParams()
+    p.depth, p.cb, p.cr, p.stride = depth, cb.data_ptr() + org * es, cr.data_ptr() + org * es, stride
+    p.width, p.height, p.bs_ver, p.bs_hor = width, height, bs_ver.data_ptr(), bs_hor.data_ptr()
+    p.qp, p.qp_map = qp, _p(qp_map)
+    p.cb_qp_offset, p.cr_qp_offset, p.tc_offset_div2 = cb_qp_offset, cr_qp_offset, tc_offset_div2
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_deblock_chroma
+    f.argtypes = [ctypes.POINTER(DeblockChromaParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_deblock_chroma")
 
 
 def deblock_luma(depth, rec, stride, org, width, height, bs_ver, bs_hor, qp, qp_map=None, beta_offset_div2=0, tc_offset_div2=0, stream=None):

@@ -266,7 +266,9 @@ class FramePipeline:
             for j in range(nring):
                 self._table(tuple(((j * self.lcb + 1 + i) % nring, (j * self.lcb + i) % nring) for i in range(self.lcb)))
             torch.cuda.synchronize()
-        self.db = Deblock(w64, h64, depth, level, qp, device) if deblock else None
+        # `qp` is the quantiser's QP (qp + QP_BD_OFFSET, what transformNxN works with); the deblocking tables are indexed with the
+        # CU's own QP (m_qp, 0..51)
+        self.db = Deblock(w64, h64, depth, level, max(qp - 6 * (depth - 8), 0), device) if deblock else None
         # SAO statistics of the deblocked reconstruction (what rdoSaoUnitCu reads); the offsets themselves are the host's decision
         self.sao = Sao(w64, h64, depth, device) if sao else None
         self.recon = None
