@@ -14,6 +14,8 @@ P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
 S = importlib.import_module("x265-yuuki-asuna_amd.stages")
 A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
 import test_gpu_search as TS
+import test_gpu_deblock as TD
+import test_gpu_intra_recon as TI
 from test_oracle_me_vs_reference import sao_case
 
 dev = torch.device("cuda:0")
@@ -105,7 +107,17 @@ def soak_pipeline(rng):
     assert np.array_equal(fp.sao.count.cpu().numpy().reshape(ecnt.shape), ecnt) and np.array_equal(fp.sao.offset_org.cpu().numpy().reshape(eoff.shape), eoff)
 
 
-stages = [("search drivers", soak_search), ("lookahead cost (P/B)", soak_lowres), ("sao passes", soak_sao), ("frame pipeline", soak_pipeline)]
+def soak_deblock(rng):
+    depth = int(rng.choice([8, 10, 12]))
+    TD.test_deblock_with_intra_blocks_and_chroma(depth, int(rng.integers(0, 3)), int(rng.integers(26, 48)), (int(rng.integers(-6, 7)), int(rng.integers(-6, 7))))
+
+
+def soak_intra_tu(rng):
+    depth = int(rng.choice([8, 10, 12]))
+    TI.test_intra_recon_matches_oracle(depth, int(rng.choice([4, 8, 16, 32])), int(rng.integers(0, 52)) + 6 * (depth - 8), int(rng.integers(0, 2)))
+
+
+stages = [("deblocking (intra / chroma)", soak_deblock), ("intra TU candidates", soak_intra_tu), ("search drivers", soak_search), ("lookahead cost (P/B)", soak_lowres), ("sao passes", soak_sao), ("frame pipeline", soak_pipeline)]
 counts = {n: 0 for n, _ in stages}
 t0 = time.time()
 fail = 0
