@@ -285,61 +285,89 @@ template <typename T> __device__ __forceinline__ void st4(T* p, const int (&v)[4
     }
 }
 
+// An element-wise block operation on 4 consecutive samples at (x, y) of the job's block, in two halves so that a thread can have the
+// loads of several quads in flight before its first store (source and destination may alias as far as the compiler knows)
 template <typename Px, int OP>
+__device__ __forceinline__ void blockop_load(const OpArgs& a, const x265hip_job& jb, int x, int y, int (&u)[4], int (&v)[4])
+{
+    const long s1 = a.p[1].stride, s2 = a.p[2].stride;
+    switch (OP)
+    {
+    case X265HIP_OP_COPY_PP: case X265HIP_OP_COPY_PS: ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, u); break;
+    case X265HIP_OP_COPY_SP: case X265HIP_OP_COPY_SS: ld4((const int16_t*)a.p[1].base + jb.off[1] + y * s1 + x, u); break;
+    case X265HIP_OP_SUB_PS: case X265HIP_OP_PIXELAVG:
+        ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, u); ld4((const Px*)a.p[2].base + jb.off[2] + y * s2 + x, v); break;
+    case X265HIP_OP_ADD_PS:
+        ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, u); ld4((const int16_t*)a.p[2].base + jb.off[2] + y * s2 + x, v); break;
+    case X265HIP_OP_ADDAVG:
+        ld4((const int16_t*)a.p[1].base + jb.off[1] + y * s1 + x, u); ld4((const int16_t*)a.p[2].base + jb.off[2] + y * s2 + x, v); break;
+    default: break;
+    }
+}
+
+template <typename Px, int OP>
+__device__ __forceinline__ void blockop_store(const OpArgs& a, const x265hip_job& jb, int x, int y, int maxVal, const int (&u)[4], const int (&v)[4])
+{
+    const long s0 = a.p[0].stride;
+    int r[4];
+    switch (OP)
+    {
+    case X265HIP_OP_COPY_PP: case X265HIP_OP_COPY_SP: st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, u); break;
+    case X265HIP_OP_COPY_PS: case X265HIP_OP_COPY_SS: st4((int16_t*)a.p[0].base + jb.off[0] + y * s0 + x, u); break;
+    case X265HIP_OP_SUB_PS:
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = u[k] - v[k];
+        st4((int16_t*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
+    case X265HIP_OP_ADD_PS:
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = clip3(0, maxVal, u[k] + v[k]);
+        st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
+    case X265HIP_OP_ADDAVG:
+    {
+        const int shift = 14 + 1 - a.depth, offset = (1 << (shift - 1)) + 2 * 8192;
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = clip3(0, maxVal, (u[k] + v[k] + offset) >> shift);
+        st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
+    }
+    case X265HIP_OP_PIXELAVG:
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = (u[k] + v[k] + 1) >> 1;
+        st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
+    default: break;
+    }
+}
+
+// QPT quads (of 4 samples) per thread and step: 4 for blocks whose width is a multiple of 16 (16 consecutive samples per thread, the
+// four quads' loads in flight together), else 1
+template <typename Px, int OP, int QPT>
 __global__ void __launch_bounds__(256) blockop_quad_kernel(OpArgs a, int njobs, int threadsPerJob, int jobsPerWg)
 {
     const int jw = threadIdx.x / threadsPerJob, t = threadIdx.x - jw * threadsPerJob;
     const int job = blockIdx.x * jobsPerWg + jw;
     if (jw >= jobsPerWg || job >= njobs) return;
     const x265hip_job jb = a.jobs[job];
-    const int qpr = a.w >> 2, nq = qpr * a.h;
+    const int gpr = (a.w >> 2) / QPT, ng = gpr * a.h;          // groups of QPT quads per row / per block
     const int maxVal = (1 << a.depth) - 1;
-    const long s0 = a.p[0].stride, s1 = a.p[1].stride, s2 = a.p[2].stride;
-    for (int q = t; q < nq; q += threadsPerJob)
+    for (int g = t; g < ng; g += threadsPerJob)
     {
-        const int y = q / qpr, x = (q - y * qpr) * 4;
-        int u[4], v[4], r[4];
-        switch (OP)
-        {
-        case X265HIP_OP_COPY_PP: ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, r); st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
-        case X265HIP_OP_COPY_PS: ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, r); st4((int16_t*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
-        case X265HIP_OP_COPY_SP: ld4((const int16_t*)a.p[1].base + jb.off[1] + y * s1 + x, r); st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
-        case X265HIP_OP_COPY_SS: ld4((const int16_t*)a.p[1].base + jb.off[1] + y * s1 + x, r); st4((int16_t*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
-        case X265HIP_OP_SUB_PS:
-            ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, u); ld4((const Px*)a.p[2].base + jb.off[2] + y * s2 + x, v);
+        const int y = g / gpr, x = (g - y * gpr) * 4 * QPT;
+        int u[QPT][4], v[QPT][4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = u[k] - v[k];
-            st4((int16_t*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
-        case X265HIP_OP_ADD_PS:
-            ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, u); ld4((const int16_t*)a.p[2].base + jb.off[2] + y * s2 + x, v);
+        for (int k = 0; k < QPT; k++) blockop_load<Px, OP>(a, jb, x + 4 * k, y, u[k], v[k]);
 #pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = clip3(0, maxVal, u[k] + v[k]);
-            st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
-        case X265HIP_OP_ADDAVG:
-        {
-            const int shift = 14 + 1 - a.depth, offset = (1 << (shift - 1)) + 2 * 8192;
-            ld4((const int16_t*)a.p[1].base + jb.off[1] + y * s1 + x, u); ld4((const int16_t*)a.p[2].base + jb.off[2] + y * s2 + x, v);
-#pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = clip3(0, maxVal, (u[k] + v[k] + offset) >> shift);
-            st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
-        }
-        case X265HIP_OP_PIXELAVG:
-            ld4((const Px*)a.p[1].base + jb.off[1] + y * s1 + x, u); ld4((const Px*)a.p[2].base + jb.off[2] + y * s2 + x, v);
-#pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = (u[k] + v[k] + 1) >> 1;
-            st4((Px*)a.p[0].base + jb.off[0] + y * s0 + x, r); break;
-        default: break;
-        }
+        for (int k = 0; k < QPT; k++) blockop_store<Px, OP>(a, jb, x + 4 * k, y, maxVal, u[k], v[k]);
     }
 }
 
 template <typename Px, int OP> static void launch_quad(const OpArgs& a, int njobs, hipStream_t s)
 {
-    const int nq = (a.w >> 2) * a.h;
+    const bool wide = (a.w & 15) == 0;
+    const int ng = (a.w >> 2) * a.h / (wide ? 4 : 1);
     int tpj = 1;
-    while (tpj < nq && tpj < 256) tpj <<= 1;                   // threads per job: power of two, <= 256
+    while (tpj < ng && tpj < 256) tpj <<= 1;                   // threads per job: power of two, <= 256
     const int jpw = 256 / tpj;
-    hipLaunchKernelGGL((blockop_quad_kernel<Px, OP>), dim3((njobs + jpw - 1) / jpw), dim3(256), 0, s, a, njobs, tpj, jpw);
+    if (wide) hipLaunchKernelGGL((blockop_quad_kernel<Px, OP, 4>), dim3((njobs + jpw - 1) / jpw), dim3(256), 0, s, a, njobs, tpj, jpw);
+    else hipLaunchKernelGGL((blockop_quad_kernel<Px, OP, 1>), dim3((njobs + jpw - 1) / jpw), dim3(256), 0, s, a, njobs, tpj, jpw);
 }
 
 template <typename Px> static int launch_op(int op, const OpArgs& a, int njobs, hipStream_t s)
