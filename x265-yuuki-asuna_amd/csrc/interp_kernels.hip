@@ -65,6 +65,34 @@ __global__ void __launch_bounds__(256) interp_kernel(IPArgs a)
 
     if (KIND == X265HIP_IP_P2S)
     {
+        if ((w & 3) == 0)
+        {
+            // 4 samples per thread and step: one packed source dword (two for 16-bit pixels), two packed int16 destination dwords
+            const int qpr = w >> 2;
+            for (int q = tid; q < qpr * h; q += nth)
+            {
+                const int y = q / qpr, x = (q - y * qpr) * 4;
+                const uint8_t* sp = reinterpret_cast<const uint8_t*>(src + (long)y * a.srcStride + x);
+                int c[4];
+                if (sizeof(S) == 1)
+                {
+                    const uint32_t v = ld_u32(sp);
+                    c[0] = v & 0xff; c[1] = (v >> 8) & 0xff; c[2] = (v >> 16) & 0xff; c[3] = v >> 24;
+                }
+                else
+                {
+                    const uint32_t v0 = ld_u32(sp), v1 = ld_u32(sp + 4);
+                    c[0] = v0 & 0xffff; c[1] = v0 >> 16; c[2] = v1 & 0xffff; c[3] = v1 >> 16;
+                }
+                uint32_t r[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) r[k] = (uint32_t)(uint16_t)(int16_t)((int16_t)(c[k] << headRoom) - (int16_t)IF_OFFS);
+                uint8_t* dp = reinterpret_cast<uint8_t*>(dst + (long)y * a.dstStride + x);
+                *reinterpret_cast<u32_unaligned*>(dp) = r[0] | (r[1] << 16);
+                *reinterpret_cast<u32_unaligned*>(dp + 4) = r[2] | (r[3] << 16);
+            }
+            return;
+        }
         for (int i = tid; i < w * h; i += nth)
         {
             const int y = i / w, x = i - y * w;

@@ -221,11 +221,46 @@ __global__ void __launch_bounds__(256) lf_kernel(LfArgs a)
         const int8_t* offs = (const int8_t*)a.p[1].base + jb.off[1];
         const int w = jb.arg[0], h = jb.arg[1], sh = a.depth - 5;
         const long st = a.p[0].stride;
+        __shared__ int sOff[32];                       // the 32 band offsets: one global read per workgroup instead of one per sample
+        if (tid < 32) sOff[tid] = offs[tid];
+        __syncthreads();
+        if ((w & 3) == 0)
+        {
+            // 4 samples per thread and step through packed dwords
+            const int qpr = w >> 2;
+            for (int q = tid; q < qpr * h; q += nth)
+            {
+                const int y = q / qpr, x = (q - y * qpr) * 4;
+                uint8_t* p = reinterpret_cast<uint8_t*>(rec + y * st + x);
+                if (sizeof(Px) == 1)
+                {
+                    const uint32_t v = ld_u32(p);
+                    uint32_t r = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        const int c = (v >> (8 * k)) & 0xff;
+                        r |= (uint32_t)clip3(0, maxVal, c + sOff[c >> sh]) << (8 * k);
+                    }
+                    *reinterpret_cast<u32_unaligned*>(p) = r;
+                }
+                else
+                {
+                    const uint32_t v0 = ld_u32(p), v1 = ld_u32(p + 4);
+                    const int c0 = v0 & 0xffff, c1 = v0 >> 16, c2 = v1 & 0xffff, c3 = v1 >> 16;
+                    const uint32_t r0 = (uint32_t)clip3(0, maxVal, c0 + sOff[c0 >> sh]) | ((uint32_t)clip3(0, maxVal, c1 + sOff[c1 >> sh]) << 16);
+                    const uint32_t r1 = (uint32_t)clip3(0, maxVal, c2 + sOff[c2 >> sh]) | ((uint32_t)clip3(0, maxVal, c3 + sOff[c3 >> sh]) << 16);
+                    *reinterpret_cast<u32_unaligned*>(p) = r0;
+                    *reinterpret_cast<u32_unaligned*>(p + 4) = r1;
+                }
+            }
+            return;
+        }
         for (int i = tid; i < w * h; i += nth)
         {
             const int y = i / w, x = i - y * w;
             const int c = rec[y * st + x];
-            rec[y * st + x] = (Px)clip3(0, maxVal, c + offs[c >> sh]);
+            rec[y * st + x] = (Px)clip3(0, maxVal, c + sOff[c >> sh]);
         }
         return;
     }
