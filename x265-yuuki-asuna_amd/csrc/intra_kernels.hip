@@ -192,7 +192,7 @@ __device__ __forceinline__ IntraMode intra_mode(int mode, int n2)
 }
 
 template <typename Px, int KIND>
-__global__ void __launch_bounds__(256) intra_quad_kernel(IntraArgs a, int njobs, int log2tpj)
+__global__ void __launch_bounds__(256) intra_quad_kernel(IntraArgs a, int njobs, int log2tpj, int quadsPerThread)
 {
     constexpr bool ALL = KIND == X265HIP_INTRA_ALLANGS;
     __shared__ Px nbs[64 * 20];                 // jobsPerWg * (4n + 4) samples: 64 * 20 (n = 4) ... 1 * 132 (n = 32)
@@ -227,7 +227,9 @@ __global__ void __launch_bounds__(256) intra_quad_kernel(IntraArgs a, int njobs,
     }
     __syncthreads();
     const int qpr = n >> 2;
-    const int y = q >> (log2n - 2), x0 = (q & (qpr - 1)) * 4;
+    // a thread predicts `quadsPerThread` row-quads (4 samples each): quad index q, q + tpj, ... (fewer, fatter workgroups for the big blocks)
+    int y = q >> (log2n - 2), x0 = (q & (qpr - 1)) * 4;
+    auto set_quad = [&](int r) { const int qq = q + r * tpj; y = qq >> (log2n - 2); x0 = (qq & (qpr - 1)) * 4; };
     const int maxVal = (1 << a.depth) - 1;
     Px* d = live ? reinterpret_cast<Px*>(a.dst) + jb.off[1] : nullptr;
     auto put4 = [&](Px* p, const int (&v)[4])
@@ -284,6 +286,9 @@ __global__ void __launch_bounds__(256) intra_quad_kernel(IntraArgs a, int njobs,
         if (live && mode >= 2 && m.angle != 0) build_line(nb0, m);
         __syncthreads();
         if (!live) return;
+        for (int rq = 0; rq < quadsPerThread; rq++)
+        {
+        set_quad(rq);
         int v[4];
         if (mode == 0)
         {
@@ -314,6 +319,7 @@ __global__ void __launch_bounds__(256) intra_quad_kernel(IntraArgs a, int njobs,
         else
             angular4(nb0, m, bFilter, m.hor != 0, v);
         put4(d + (long)y * a.dstStride + x0, v);
+        }
         return;
     }
     for (int mode = 2; mode <= 34; mode++)
@@ -323,11 +329,13 @@ __global__ void __launch_bounds__(256) intra_quad_kernel(IntraArgs a, int njobs,
         if (live && m.angle != 0) build_line(nb, m);
         __syncthreads();
         if (live)
-        {
-            int v[4];
-            angular4(nb, m, jb.arg[0], false, v);                  // all-angs keeps the horizontal modes transposed
-            put4(d + (long)(mode - 2) * n * n + y * n + x0, v);
-        }
+            for (int rq = 0; rq < quadsPerThread; rq++)
+            {
+                set_quad(rq);
+                int v[4];
+                angular4(nb, m, jb.arg[0], false, v);              // all-angs keeps the horizontal modes transposed
+                put4(d + (long)(mode - 2) * n * n + y * n + x0, v);
+            }
         __syncthreads();                                            // the line is rebuilt for the next mode
     }
 }
@@ -350,14 +358,17 @@ extern "C" int x265hip_intra_batch(int kind, int depth, int n, x265hip_plane src
     a.jobs = jobs; a.n = n; a.log2n = n == 4 ? 2 : (n == 8 ? 3 : (n == 16 ? 4 : 5)); a.depth = depth;
     const int threads = n * n <= 64 ? 64 : 256;
     hipStream_t s = (hipStream_t)stream;
-    const int log2tpj = 2 * a.log2n - 2, jpw = 256 >> log2tpj, wgs = (njobs + jpw - 1) / jpw;      // fast path geometry
+    // fast path geometry: a thread per row-quad for 4x4 / 8x8, four row-quads per thread for 16x16 / 32x32 (the LDS arrays hold the
+    // neighbours of up to 64 / 16 / 16 / 4 candidates)
+    const int qpt = n >= 16 ? 4 : 1;
+    const int log2tpj = 2 * a.log2n - 2 - (qpt == 4 ? 2 : 0), jpw = 256 >> log2tpj, wgs = (njobs + jpw - 1) / jpw;
     const bool generic = getenv("X265HIP_INTRA_GENERIC") != nullptr;                 // A/B switch: one workgroup per candidate
 #define GO(PX) do { switch (kind) { \
         case X265HIP_INTRA_PRED:    if (generic) hipLaunchKernelGGL((intra_kernel<PX, X265HIP_INTRA_PRED>), dim3(njobs), dim3(threads), 0, s, a); \
-                                    else hipLaunchKernelGGL((intra_quad_kernel<PX, X265HIP_INTRA_PRED>), dim3(wgs), dim3(256), 0, s, a, njobs, log2tpj); break; \
+                                    else hipLaunchKernelGGL((intra_quad_kernel<PX, X265HIP_INTRA_PRED>), dim3(wgs), dim3(256), 0, s, a, njobs, log2tpj, qpt); break; \
         case X265HIP_INTRA_FILTER:  hipLaunchKernelGGL((intra_kernel<PX, X265HIP_INTRA_FILTER>), dim3(njobs), dim3(threads), 0, s, a); break; \
         case X265HIP_INTRA_ALLANGS: if (generic) hipLaunchKernelGGL((intra_kernel<PX, X265HIP_INTRA_ALLANGS>), dim3(njobs), dim3(threads), 0, s, a); \
-                                    else hipLaunchKernelGGL((intra_quad_kernel<PX, X265HIP_INTRA_ALLANGS>), dim3(wgs), dim3(256), 0, s, a, njobs, log2tpj); break; \
+                                    else hipLaunchKernelGGL((intra_quad_kernel<PX, X265HIP_INTRA_ALLANGS>), dim3(wgs), dim3(256), 0, s, a, njobs, log2tpj, qpt); break; \
         default: set_error("intra_batch: unknown kind %d", kind); return X265HIP_EINVAL; } } while (0)
     if (depth == 8) GO(uint8_t); else GO(uint16_t);
 #undef GO
