@@ -50,17 +50,43 @@ __global__ void __launch_bounds__(256) quant_kernel(QArgs a)
         int32_t* deltaU = KIND == X265HIP_Q_QUANT ? (int32_t*)a.p[2].base + jb.off[2] : nullptr;
         int16_t* q = (int16_t*)a.p[3].base + jb.off[3];
         const int qBits = jb.arg[0], add = jb.arg[1], n = jb.arg[2];
-        for (int i = tid; i < n; i += 256)
+        auto one = [&](int c, int qcv, int& du, int& lv)
         {
-            const int c = coef[i];
-            const int t = iabs(c) * qc[i];
+            const int t = iabs(c) * qcv;
             int level = (t + add) >> qBits;
-            if (KIND == X265HIP_Q_QUANT) deltaU[i] = (t - (level << qBits)) >> (qBits - 8);
+            du = (t - (level << qBits)) >> (qBits - 8);
             cnt += level != 0;
             if (c < 0) level = -level;
             level = clip3(-32768, 32767, level);
-            q[i] = (int16_t)(KIND == X265HIP_Q_QUANT ? level : iabs(level));
+            lv = KIND == X265HIP_Q_QUANT ? level : iabs(level);
+        };
+        if ((n & 3) == 0)
+        {
+            // 4 coefficients per thread and step: packed int16 dwords in and out, 4 int32 scaling factors
+            for (int i = tid * 4; i < n; i += 1024)
+            {
+                const uint32_t c01 = ld_u32(coef + i), c23 = ld_u32(coef + i + 2);
+                const int c[4] = { (int16_t)(c01 & 0xffff), (int16_t)(c01 >> 16), (int16_t)(c23 & 0xffff), (int16_t)(c23 >> 16) };
+                int qv[4], du[4], lv[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) qv[k] = (int)ld_u32(qc + i + k);
+#pragma unroll
+                for (int k = 0; k < 4; k++) one(c[k], qv[k], du[k], lv[k]);
+                if (KIND == X265HIP_Q_QUANT)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) *reinterpret_cast<u32_unaligned*>(deltaU + i + k) = (uint32_t)du[k];
+                *reinterpret_cast<u32_unaligned*>(q + i) = ((uint32_t)lv[0] & 0xffffu) | ((uint32_t)lv[1] << 16);
+                *reinterpret_cast<u32_unaligned*>(q + i + 2) = ((uint32_t)lv[2] & 0xffffu) | ((uint32_t)lv[3] << 16);
+            }
         }
+        else
+            for (int i = tid; i < n; i += 256)
+            {
+                int du, lv;
+                one(coef[i], qc[i], du, lv);
+                if (KIND == X265HIP_Q_QUANT) deltaU[i] = du;
+                q[i] = (int16_t)lv;
+            }
     }
     else if (KIND == X265HIP_Q_DEQUANT_NORMAL)
     {
@@ -68,7 +94,17 @@ __global__ void __launch_bounds__(256) quant_kernel(QArgs a)
         int16_t* coef = (int16_t*)a.p[3].base + jb.off[3];
         const int n = jb.arg[0], scale = jb.arg[1], shift = jb.arg[2];
         const int add = 1 << (shift - 1);
-        for (int i = tid; i < n; i += 256) coef[i] = (int16_t)clip3(-32768, 32767, ((int)q[i] * scale + add) >> shift);
+        auto deq = [&](int v) { return clip3(-32768, 32767, (v * scale + add) >> shift); };
+        if ((n & 3) == 0)
+            for (int i = tid * 4; i < n; i += 1024)
+            {
+                const uint32_t a01 = ld_u32(q + i), a23 = ld_u32(q + i + 2);
+                const int r0 = deq((int16_t)(a01 & 0xffff)), r1 = deq((int16_t)(a01 >> 16)), r2 = deq((int16_t)(a23 & 0xffff)), r3 = deq((int16_t)(a23 >> 16));
+                *reinterpret_cast<u32_unaligned*>(coef + i) = ((uint32_t)r0 & 0xffffu) | ((uint32_t)r1 << 16);
+                *reinterpret_cast<u32_unaligned*>(coef + i + 2) = ((uint32_t)r2 & 0xffffu) | ((uint32_t)r3 << 16);
+            }
+        else
+            for (int i = tid; i < n; i += 256) coef[i] = (int16_t)deq((int)q[i]);
     }
     else if (KIND == X265HIP_Q_DEQUANT_SCALING)
     {
