@@ -294,7 +294,7 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
 }
 
 template <typename Px, int N>
-__global__ void __launch_bounds__(256) inter_recon_kernel(TuArgs a)
+__global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs a, int nblocks)
 {
     constexpr int NN = N * N, LOG2N = N == 8 ? 3 : (N == 16 ? 4 : 5), PW = N + 7, PP = N + 8;
     constexpr int BPP = sizeof(Px);
@@ -306,11 +306,17 @@ __global__ void __launch_bounds__(256) inter_recon_kernel(TuArgs a)
 
     const int npu = (64 / N) * (64 / N);
     const int lbase = N == 8 ? 0 : (N == 16 ? 64 : 80);
-    const int ctu = blockIdx.x / npu, z = blockIdx.x - ctu * npu;
-    const int bxz = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), byz = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
-    const int px = (ctu % a.ctusW) * 64 + bxz * N, py = (ctu / a.ctusW) * 64 + byz * N;
     const int tid = threadIdx.x, nth = blockDim.x;
     const int maxVal = (1 << a.depth) - 1, headRoom = 14 - a.depth;
+    // 16 / 32: a persistent single-wavefront workgroup walks blocks blockIdx.x, + gridDim.x, ... with the MFMA operands of the
+    // transforms built once (its barriers are wave-local); 8: one block per workgroup
+    TuOpsFor<N, false> ops;
+    ops.init(tid & 63);
+    auto do_block = [&](const int blk)
+    {
+    const int ctu = blk / npu, z = blk - ctu * npu;
+    const int bxz = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), byz = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+    const int px = (ctu % a.ctusW) * 64 + bxz * N, py = (ctu / a.ctusW) * 64 + byz * N;
 
     const int packed = a.mv[(size_t)ctu * 85 + lbase + z].y;
     const int qx = (int16_t)(packed & 0xffff), qy = (int16_t)(packed >> 16);
@@ -371,10 +377,15 @@ __global__ void __launch_bounds__(256) inter_recon_kernel(TuArgs a)
     }
     __syncthreads();
 
-    TuOpsFor<N, false> ops;          // unused: built lazily inside
-    tu_chain<Px, N, false, true>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
+    tu_chain<Px, N, false>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
                            a.levels + ((size_t)ctu * npu + z) * NN, &a.numSig[(size_t)ctu * npu + z], &a.dist[(size_t)ctu * npu + z],
                            reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP);
+    __syncthreads();
+    };
+    if constexpr (N >= 16)
+        for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) do_block(blk);
+    else
+        do_block(blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -468,10 +479,20 @@ extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
     const int nctu = a.ctusW * (p->height / 64);
     const int npu = 64 >> (2 * p->level);
     hipStream_t s = (hipStream_t)stream;
+    const int nblocks = nctu * npu;
+    auto resident = [&](const void* fn)
+    {
+        int dev = 0, cus = 256, per = 8;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, 64, 0) != hipSuccess || per < 1) per = 8;
+        const long r = (long)cus * per;
+        return (int)(nblocks < r ? nblocks : r);
+    };
 #define GO(PX) do { \
-        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 8>), dim3(nctu * npu), dim3(64), 0, s, a); \
-        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 16>), dim3(nctu * npu), dim3(256), 0, s, a); \
-        else hipLaunchKernelGGL((inter_recon_kernel<PX, 32>), dim3(nctu * npu), dim3(256), 0, s, a); } while (0)
+        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 8>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 16>), dim3(resident((const void*)inter_recon_kernel<PX, 16>)), dim3(64), 0, s, a, nblocks); \
+        else hipLaunchKernelGGL((inter_recon_kernel<PX, 32>), dim3(resident((const void*)inter_recon_kernel<PX, 32>)), dim3(64), 0, s, a, nblocks); } while (0)
     if (p->depth == 8) GO(uint8_t); else GO(uint16_t);
 #undef GO
     X265HIP_TRY(hipGetLastError());
