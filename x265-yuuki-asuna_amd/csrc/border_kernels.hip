@@ -10,19 +10,57 @@
 
 namespace x265hip {
 
-template <typename Px>
-__global__ void __launch_bounds__(256) extend_border_kernel(Px* pic, long stride, int width, int height, int marginX, int marginY)
+struct BorderArgs
 {
-    const int pw = width + 2 * marginX, ph = height + 2 * marginY;
-    // threads walk the padded plane row-major and skip the interior
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)pw * ph; i += (long)gridDim.x * blockDim.x)
+    void* pic[4];                     // up to four planes of one geometry (blockIdx.y selects)
+    long stride;
+    int width, height, marginX, marginY;
+};
+
+// Only the margin is walked: first the bands above and below the picture (full padded width), then the left / right bands of the
+// picture rows.
+template <typename Px>
+__global__ void __launch_bounds__(256) extend_border_kernel(BorderArgs a)
+{
+    Px* pic = reinterpret_cast<Px*>(a.pic[blockIdx.y]);
+    const int width = a.width, height = a.height, marginX = a.marginX, marginY = a.marginY;
+    const int pw = width + 2 * marginX, sideW = 2 * marginX;
+    const long nBands = (long)pw * 2 * marginY, nSides = (long)height * sideW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nBands + nSides; i += (long)gridDim.x * blockDim.x)
     {
-        const int y = (int)(i / pw) - marginY, x = (int)(i % pw) - marginX;
-        if (x >= 0 && x < width && y >= 0 && y < height)
-            continue;
+        int x, y;
+        if (i < nBands)
+        {
+            const int r = (int)(i / pw);
+            x = (int)(i - (long)r * pw) - marginX;
+            y = r < marginY ? r - marginY : height + (r - marginY);
+        }
+        else
+        {
+            const long j = i - nBands;
+            y = (int)(j / sideW);
+            const int k = (int)(j - (long)y * sideW);
+            x = k < marginX ? k - marginX : width + (k - marginX);
+        }
         const int sx = x < 0 ? 0 : (x >= width ? width - 1 : x), sy = y < 0 ? 0 : (y >= height ? height - 1 : y);
-        pic[(long)y * stride + x] = pic[(long)sy * stride + sx];
+        pic[(long)y * a.stride + x] = pic[(long)sy * a.stride + sx];
     }
+}
+
+// nplanes planes of one geometry in one launch (the four lookahead planes)
+int extend_borders(void* const* pics, int nplanes, intptr_t stride, int width, int height, int margin_x, int margin_y, int depth, hipStream_t s)
+{
+    BorderArgs a;
+    for (int i = 0; i < 4; i++) a.pic[i] = i < nplanes ? pics[i] : nullptr;
+    a.stride = (long)stride; a.width = width; a.height = height; a.marginX = margin_x; a.marginY = margin_y;
+    const long total = (long)(width + 2 * margin_x) * 2 * margin_y + (long)height * 2 * margin_x;
+    if (total <= 0) return 0;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (depth == 8) hipLaunchKernelGGL(extend_border_kernel<uint8_t>, dim3(blocks, nplanes), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(extend_border_kernel<uint16_t>, dim3(blocks, nplanes), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 } // namespace x265hip
@@ -35,11 +73,6 @@ extern "C" int x265hip_extend_border(void* pic, intptr_t stride, int width, int 
     if (rc) return rc;
     if (!pic || width <= 0 || height <= 0 || margin_x < 0 || margin_y < 0) { set_error("extend_border: bad argument"); return X265HIP_EINVAL; }
     if (depth != 8 && depth != 10 && depth != 12) { set_error("extend_border: depth %d", depth); return X265HIP_EINVAL; }
-    const long total = (long)(width + 2 * margin_x) * (height + 2 * margin_y);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    if (depth == 8) hipLaunchKernelGGL(extend_border_kernel<uint8_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (uint8_t*)pic, (long)stride, width, height, margin_x, margin_y);
-    else hipLaunchKernelGGL(extend_border_kernel<uint16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)pic, (long)stride, width, height, margin_x, margin_y);
-    X265HIP_TRY(hipGetLastError());
-    return 0;
+    void* pics[1] = { pic };
+    return extend_borders(pics, 1, stride, width, height, margin_x, margin_y, depth, (hipStream_t)stream);
 }

@@ -242,6 +242,8 @@ __global__ void __launch_bounds__(256) lowres_intra_kernel(LowresIntraArgs a)
 
 } // namespace x265hip
 
+namespace x265hip { int extend_borders(void* const* pics, int nplanes, intptr_t stride, int width, int height, int margin_x, int margin_y, int depth, hipStream_t s); }
+
 using namespace x265hip;
 
 extern "C" int x265hip_lowres_init(const x265hip_lowres_init_params* p, void* stream)
@@ -261,12 +263,7 @@ extern "C" int x265hip_lowres_init(const x265hip_lowres_init_params* p, void* st
     if (bpp == 1) hipLaunchKernelGGL(lowres_init_kernel<uint8_t>, dim3((quads + 255) / 256), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(lowres_init_kernel<uint16_t>, dim3((quads + 255) / 256), dim3(256), 0, s, a);
     X265HIP_TRY(hipGetLastError());
-    for (int i = 0; i < 4; i++)
-    {
-        rc = x265hip_extend_border(p->plane[i], p->stride, p->width, p->lines, p->margin_x, p->margin_y, p->depth, stream);
-        if (rc) return rc;
-    }
-    return 0;
+    return extend_borders(p->plane, 4, p->stride, p->width, p->lines, p->margin_x, p->margin_y, p->depth, s);      // the four planes in one launch
 }
 
 extern "C" int x265hip_lowres_intra(const x265hip_lowres_intra_params* p, void* stream)
