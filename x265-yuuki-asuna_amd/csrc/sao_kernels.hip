@@ -24,7 +24,7 @@ struct SaoStatsArgs
     int32_t* count; int32_t* offsetOrg;
 };
 
-__device__ __forceinline__ int sao_sign(int x) { return (x > 0) - (x < 0); }
+__device__ __forceinline__ int sao_sign(int x) { return max(-1, min(1, x)); }      // one v_med3_i32
 
 template <typename Px>
 __global__ void __launch_bounds__(256) sao_stats_kernel(SaoStatsArgs a)
@@ -53,9 +53,21 @@ __global__ void __launch_bounds__(256) sao_stats_kernel(SaoStatsArgs a)
     const Px* rec = reinterpret_cast<const Px*>(a.rec) + lpelx + (long)tpely * (a.recStrideB / BPP);
     const long rst = a.recStrideB / BPP;
     const int lane = tid & 63, wave = tid >> 6;
-    for (int r = wave; r < a.ctuH + 2; r += 4)
-        for (int c = lane; c < a.ctuW + 2; c += 64)
-            sRec[r * LW + c] = (uint16_t)rec[(long)(r - 1) * rst + (c - 1)];
+    {
+        // packed loads: a thread fetches 4 samples (one dword, two for 16-bit pixels) of a staged row at a time
+        const int qpr = (a.ctuW + 2 + 3) >> 2, nq = qpr * (a.ctuH + 2);
+        for (int i = tid; i < nq; i += 256)
+        {
+            const int r = i / qpr, c = (i - r * qpr) * 4;
+            const uint8_t* sp = reinterpret_cast<const uint8_t*>(rec + (long)(r - 1) * rst + (c - 1));
+            uint32_t v[4];
+            if (BPP == 1) { const uint32_t w = ld_u32(sp); v[0] = w & 0xff; v[1] = (w >> 8) & 0xff; v[2] = (w >> 16) & 0xff; v[3] = w >> 24; }
+            else { const uint32_t w0 = ld_u32(sp), w1 = ld_u32(sp + 4); v[0] = w0 & 0xffff; v[1] = w0 >> 16; v[2] = w1 & 0xffff; v[3] = w1 >> 16; }
+            uint32_t* d = reinterpret_cast<uint32_t*>(&sRec[r * LW + c]);        // LW and c are multiples of 4: dword aligned
+            d[0] = v[0] | (v[1] << 16);
+            d[1] = v[2] | (v[3] << 16);
+        }
+    }
     __syncthreads();
     // a thread owns 16 consecutive samples of one row (four threads per row)
     const int y = tid >> 2, x0 = (tid & 3) * 16;
@@ -73,9 +85,21 @@ __global__ void __launch_bounds__(256) sao_stats_kernel(SaoStatsArgs a)
 #pragma unroll
         for (int r = 0; r < 3; r++) { w[r][1] = sRec[(y + r) * LW + x0]; w[r][2] = sRec[(y + r) * LW + x0 + 1]; }
         const bool yE0 = y < e0EndY, yE1 = y >= startY && y < endY1, yBo = y < boEndY;
+        // the thread's 16 source samples, fetched as dwords up front (a partial CTU reads into the padded margin)
+        int fev[16];
+        {
+            const uint8_t* fp = reinterpret_cast<const uint8_t*>(fe + x0);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                if (BPP == 1) { const uint32_t w4 = ld_u32(fp + 4 * k); fev[4 * k] = w4 & 0xff; fev[4 * k + 1] = (w4 >> 8) & 0xff; fev[4 * k + 2] = (w4 >> 16) & 0xff; fev[4 * k + 3] = w4 >> 24; }
+                else { const uint32_t w0 = ld_u32(fp + 8 * k), w1 = ld_u32(fp + 8 * k + 4); fev[4 * k] = w0 & 0xffff; fev[4 * k + 1] = w0 >> 16; fev[4 * k + 2] = w1 & 0xffff; fev[4 * k + 3] = w1 >> 16; }
+            }
+        }
         // s_eoTable = { 1, 2, 0, 3, 4 }: class of edgeType e
-        auto cls = [](int e) { return e == 0 ? 1 : (e == 1 ? 2 : (e == 2 ? 0 : e)); };
-#pragma unroll 4
+        auto cls = [](int e) { return (0x43021 >> (4 * e)) & 7; };                // nibble e of 0x43021
+        int runBand = 0, runCnt = 0, runSum = 0;
+#pragma unroll
         for (int i = 0; i < 16; i++)
         {
             const int x = x0 + i;
@@ -83,7 +107,7 @@ __global__ void __launch_bounds__(256) sao_stats_kernel(SaoStatsArgs a)
             for (int r = 0; r < 3; r++) { w[r][0] = w[r][1]; w[r][1] = w[r][2]; w[r][2] = sRec[(y + r) * LW + x + 2]; }
             if (x >= ctuW) break;
             const int c = w[1][1];
-            const int d = (int)fe[x] - c;
+            const int d = fev[i] - c;
             const uint32_t unit = (1u << 20) | (uint32_t)(d + bias);
             const bool xE = x >= startX && x < endX0;
             const int sc_l = sao_sign(c - w[1][0]), sc_r = sao_sign(c - w[1][2]);
@@ -104,11 +128,17 @@ __global__ void __launch_bounds__(256) sao_stats_kernel(SaoStatsArgs a)
             }
             if (yBo && x < boEndX)
             {
+                // neighbouring samples mostly share a band: accumulate the run in registers, touch the LDS histogram on a change
                 const int band = c >> boShift;
-                atomicAdd(&sBo[wave][0][band], 1);
-                atomicAdd(&sBo[wave][1][band], d);
+                if (band != runBand)
+                {
+                    if (runCnt) { atomicAdd(&sBo[wave][0][runBand], runCnt); atomicAdd(&sBo[wave][1][runBand], runSum); }
+                    runBand = band; runCnt = 0; runSum = 0;
+                }
+                runCnt++; runSum += d;
             }
         }
+        if (runCnt) { atomicAdd(&sBo[wave][0][runBand], runCnt); atomicAdd(&sBo[wave][1][runBand], runSum); }
     }
     // unpack, reduce over the wavefront, then over the workgroup
 #pragma unroll
