@@ -90,6 +90,14 @@ template <int G, typename T> __device__ __forceinline__ T group_sum(T v)
     return v;
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup i runs on XCD i % 8) and every XCD has its own L2: hand each XCD a
+// contiguous eighth of the index range, so that neighbouring CTUs (shared reference rows and search-window overlap) meet in one L2.
+__device__ __forceinline__ int xcd_swizzle(int i, int n)
+{
+    const int per = n >> 3;
+    return i < (per << 3) ? (i & 7) * per + (i >> 3) : i;
+}
+
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 #endif  // __HIPCC__
 

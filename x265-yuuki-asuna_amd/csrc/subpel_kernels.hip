@@ -70,7 +70,7 @@ __device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemR
     constexpr int BPP = G::BPP, N = G::N, NPU = G::NPU, PW = G::PW, PITCH = G::PITCH;
     Px* patches = reinterpret_cast<Px*>(smemRaw);
 
-    const int ctu = blockIdx.x;
+    const int ctu = xcd_swizzle(blockIdx.x, gridDim.x);
     const int cx = (ctu % a.ctusW) * 64, cy = (ctu / a.ctusW) * 64;
     const int tid = threadIdx.x;
     const int R = a.range, NC = 2 * R + 1;
