@@ -2,7 +2,7 @@
 """[test infrastructure: uses oracle/ only as the checker; not collected by pytest - run it by hand on a GPU box]
 
 Randomised soak of the device stages against the oracle: many seeds / sizes / parameter draws per stage for a time budget.
-Usage on a GPU box:  python tests/soak.py [seconds]   -> one line per stage with the number of cases, non-zero exit on a mismatch."""
+Usage on a GPU box:  python tests/soak.py [seconds [master seed]]   -> one line per stage with the number of cases, non-zero exit on a mismatch."""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +20,7 @@ from test_oracle_me_vs_reference import sao_case
 
 dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-master = np.random.default_rng(20260927)
+master = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260927)
 
 
 def soak_search(rng):
