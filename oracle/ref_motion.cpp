@@ -36,7 +36,7 @@ int x265ref_motion_estimate_mvc(const void* fenc, const void* fref, intptr_t str
                                 const int32_t* mvc /* [njobs][12][2] quarter-pel, or NULL */, const int32_t* numMvc /* [njobs] */)
 {
     static bool tableReady = false;
-    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }   /* MotionEstimate reads the global table */
+    if (!tableReady) { x265ref_encoder_table_reset_c(); MotionEstimate::initScales(); tableReady = true; }   /* MotionEstimate reads the global table; Encoder::Encoder() calls initScales (encoder.cpp:123: the SAD_THRESH scales of UMH) */
     MotionEstimate me;
     me.init(X265_CSP_I400);
     me.setQP(qp);

@@ -54,7 +54,7 @@ typedef struct
     pixel fenc[64 * 64];              /* the PU source at stride 64 (motion.cpp:193) */
     const pixel* fref;                /* reference sample under the PU's top-left corner */
     intptr_t stride;
-    int w;
+    int w, h;
     const uint16_t* cost;             /* cost[q]: bit cost of a quarter-pel mv DIFFERENCE component q (index 0 = zero) */
     int mvpx, mvpy;
     mv_t mvmin, mvmax;
@@ -190,6 +190,195 @@ static void star_pattern(const me_ctx* c, mv_t* bmv, int* bcost, int* bPointNr, 
 #undef PT
 }
 
+/* X265_HEX_SEARCH (motion.cpp:847-942, also the tail of UMH through `goto me_hex2`): hexagon of radius 2, half-hexagon walk,
+ * square refine */
+static void hex_refine(const me_ctx* c, mv_t* pbmv, int* pbcost, int merange)
+{
+    mv_t bmv = *pbmv;
+    int bcost = *pbcost;
+    int costs[4];
+        /* first full hexagon: six points in two groups of three; out-of-range rows are scored but not accepted */
+#define X3(D0, D1, D2) do { costs[0] = cost_mv(c, bmv.x + (D0).x, bmv.y + (D0).y); costs[1] = cost_mv(c, bmv.x + (D1).x, bmv.y + (D1).y); \
+                            costs[2] = cost_mv(c, bmv.x + (D2).x, bmv.y + (D2).y); } while (0)
+#define YOK(DY) ((bmv.y + (DY) >= c->mvmin.y) & (bmv.y + (DY) <= c->mvmax.y))
+#define LT(V) do { if ((V) < bcost) bcost = (V); } while (0)
+        { const mv_t a = { -2, 0 }, b = { -1, 2 }, d = { 1, 2 }; X3(a, b, d); }
+        bcost <<= 3;
+        if (YOK(0)) LT((costs[0] << 3) + 2);
+        if (YOK(2)) { LT((costs[1] << 3) + 3); LT((costs[2] << 3) + 4); }
+        { const mv_t a = { 2, 0 }, b = { 1, -2 }, d = { -1, -2 }; X3(a, b, d); }
+        if (YOK(0)) LT((costs[0] << 3) + 5);
+        if (YOK(-2)) { LT((costs[1] << 3) + 6); LT((costs[2] << 3) + 7); }
+        if (bcost & 7)
+        {
+            int dir = (bcost & 7) - 2;
+            if (YOK(kHex2[dir + 1].y))
+            {
+                bmv.x += kHex2[dir + 1].x; bmv.y += kHex2[dir + 1].y;
+                /* half hexagons that do not overlap the previous iteration */
+                for (int i = (merange >> 1) - 1; i > 0 && in_range(c, bmv.x, bmv.y); i--)
+                {
+                    X3(kHex2[dir + 0], kHex2[dir + 1], kHex2[dir + 2]);
+                    bcost &= ~7;
+                    if (YOK(kHex2[dir + 0].y)) LT((costs[0] << 3) + 1);
+                    if (YOK(kHex2[dir + 1].y)) LT((costs[1] << 3) + 2);
+                    if (YOK(kHex2[dir + 2].y)) LT((costs[2] << 3) + 3);
+                    if (!(bcost & 7)) break;
+                    dir += (bcost & 7) - 2;
+                    dir = kMod6m1[dir + 1];
+                    bmv.x += kHex2[dir + 1].x; bmv.y += kHex2[dir + 1].y;
+                }
+            }
+        }
+        bcost >>= 3;
+        /* square refine */
+        int dir = 0;
+        costs[0] = cost_mv(c, bmv.x, bmv.y - 1); costs[1] = cost_mv(c, bmv.x, bmv.y + 1);
+        costs[2] = cost_mv(c, bmv.x - 1, bmv.y); costs[3] = cost_mv(c, bmv.x + 1, bmv.y);
+        if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 1; }
+        if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 2; }
+        if (costs[2] < bcost) { bcost = costs[2]; dir = 3; }
+        if (costs[3] < bcost) { bcost = costs[3]; dir = 4; }
+        costs[0] = cost_mv(c, bmv.x - 1, bmv.y - 1); costs[1] = cost_mv(c, bmv.x - 1, bmv.y + 1);
+        costs[2] = cost_mv(c, bmv.x + 1, bmv.y - 1); costs[3] = cost_mv(c, bmv.x + 1, bmv.y + 1);
+        if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 5; }
+        if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 6; }
+        if (YOK(-1) && costs[2] < bcost) { bcost = costs[2]; dir = 7; }
+        if (YOK(1) && costs[3] < bcost) { bcost = costs[3]; dir = 8; }
+        bmv.x += kSquare1[dir].x; bmv.y += kSquare1[dir].y;
+#undef X3
+#undef YOK
+#undef LT
+    *pbmv = bmv; *pbcost = bcost;
+}
+
+/* motion.cpp:61,123-150: SAD_THRESH(v) = bcost < (v >> 4) * sizeScale[part], sizeScale = (H * H) >> 4 */
+static int sad_thresh(int bcost, int v, int h) { return bcost < ((v >> 4) * ((h * h) >> 4)); }
+
+static const mv_t kHex4[16] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },
+                                { -4, 0 }, { 4, 0 }, { -4, 1 }, { 4, 1 }, { -4, 2 }, { 4, 2 }, { -2, 3 }, { 2, 3 } };
+
+/* X265_UMH_SEARCH (motion.cpp:946-1130); pmv = the clipped predictor rounded to full-pel.  Upstream quirks kept: COST_MV_X4 only tests the candidate's y against the search range (:295-302); the hexagon
+ * grid's fast path tests omv.y + dy with the UNscaled hex4 offset (:1087 MIN_MV) and keeps its winner in a packed dx * 16 + (dy & 15);
+ * with mv candidates the range is rescaled by range_mul[mvd_ctx][sad_ctx] (:982-1040) and that range also drives the final
+ * hexagon refinement. */
+static void umh_search(const me_ctx* c, mv_t* pbmv, int* pbcost, int merange, int pmvx, int pmvy, int h, int is64,
+                       const int32_t* mvc, int numMvc)
+{
+    mv_t bmv = *pbmv, omv;
+    int bcost = *pbcost;
+    int costs[16];
+#define X4(M0X, M0Y, M1X, M1Y, M2X, M2Y, M3X, M3Y) do { \
+        const int dx_[4] = { (M0X), (M1X), (M2X), (M3X) }, dy_[4] = { (M0Y), (M1Y), (M2Y), (M3Y) }; \
+        for (int k_ = 0; k_ < 4; k_++) costs[k_] = cost_mv(c, omv.x + dx_[k_], omv.y + dy_[k_]); \
+        for (int k_ = 0; k_ < 4; k_++) \
+            if ((omv.y + dy_[k_] >= c->mvmin.y) & (omv.y + dy_[k_] <= c->mvmax.y)) \
+                if (costs[k_] < bcost) { bcost = costs[k_]; bmv.x = omv.x + dx_[k_]; bmv.y = omv.y + dy_[k_]; } } while (0)
+#define ONE(MX, MY) do { const int cost_ = cost_mv(c, (MX), (MY)); if (cost_ < bcost) { bcost = cost_; bmv.x = (MX); bmv.y = (MY); } } while (0)
+#define DIA1(MX, MY) do { omv.x = (MX); omv.y = (MY); X4(0, -1, 0, 1, -1, 0, 1, 0); } while (0)
+#define CROSS(START, XMAX, YMAX) do { \
+        int16_t i_ = (int16_t)(START); \
+        const int xm_ = (XMAX), ym_ = (YMAX); \
+        int lim_ = c->mvmax.x - omv.x < omv.x - c->mvmin.x ? c->mvmax.x - omv.x : omv.x - c->mvmin.x; \
+        if (xm_ <= lim_) for (; i_ < xm_ - 2; i_ += 4) X4(i_, 0, -i_, 0, i_ + 2, 0, -i_ - 2, 0); \
+        for (; i_ < xm_; i_ += 2) { if (omv.x + i_ <= c->mvmax.x) ONE(omv.x + i_, omv.y); if (omv.x - i_ >= c->mvmin.x) ONE(omv.x - i_, omv.y); } \
+        i_ = (int16_t)(START); \
+        lim_ = c->mvmax.y - omv.y < omv.y - c->mvmin.y ? c->mvmax.y - omv.y : omv.y - c->mvmin.y; \
+        if (ym_ <= lim_) for (; i_ < ym_ - 2; i_ += 4) X4(0, i_, 0, -i_, 0, i_ + 2, 0, -i_ - 2); \
+        for (; i_ < ym_; i_ += 2) { if (omv.y + i_ <= c->mvmax.y) ONE(omv.x, omv.y + i_); if (omv.y - i_ >= c->mvmin.y) ONE(omv.x, omv.y - i_); } } while (0)
+    int16_t cross_start = 1;
+    /* refine predictors */
+    omv = bmv;
+    const int ucost1 = bcost;
+    DIA1(pmvx, pmvy);
+    if (pmvx | pmvy) DIA1(0, 0);
+    const int ucost2 = bcost;
+    if ((bmv.x | bmv.y) && (bmv.x != pmvx || bmv.y != pmvy)) DIA1(bmv.x, bmv.y);
+    if (bcost == ucost2) cross_start = 3;
+    /* early termination */
+    omv = bmv;
+    int done = 0;
+    if (bcost == ucost2 && sad_thresh(bcost, 2000, h))
+    {
+        X4(0, -2, -1, -1, 1, -1, -2, 0);
+        X4(2, 0, -1, 1, 1, 1, 0, 2);
+        if (bcost == ucost1 && sad_thresh(bcost, 500, h)) done = 1;
+        else if (bcost == ucost2)
+        {
+            const int16_t range = (int16_t)((merange >> 1) | 1);
+            CROSS(3, range, range);
+            X4(-1, -2, 1, -2, -2, -1, 2, -1);
+            X4(-2, 1, 2, 1, -1, 2, 1, 2);
+            if (bcost == ucost2) done = 1;
+            else cross_start = (int16_t)(range + 2);
+        }
+    }
+    if (!done)
+    {
+        /* adaptive search range based on the agreement of the mv candidates (:982-1040) */
+        if (numMvc)
+        {
+            static const uint8_t range_mul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
+            int mvd, denom = 1;
+            if (numMvc == 1)
+                mvd = is64 ? 25 : abs(c->mvpx - mvc[0]) + abs(c->mvpy - mvc[1]);
+            else
+            {
+                denom = numMvc - 1;
+                mvd = 0;
+                if (!is64) { mvd = abs(c->mvpx - mvc[0]) + abs(c->mvpy - mvc[1]); denom++; }
+                for (int i = 0; i < numMvc - 1; i++) mvd += abs(mvc[2 * i] - mvc[2 * i + 2]) + abs(mvc[2 * i + 1] - mvc[2 * i + 3]);
+            }
+            const int sad_ctx = sad_thresh(bcost, 1000, h) ? 0 : sad_thresh(bcost, 2000, h) ? 1 : sad_thresh(bcost, 4000, h) ? 2 : 3;
+            const int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+            merange = (merange * range_mul[mvd_ctx][sad_ctx]) >> 2;
+        }
+        CROSS(cross_start, merange, merange >> 1);
+        X4(-2, -2, -2, 2, 2, -2, 2, 2);
+        /* hexagon grid */
+        omv = bmv;
+        uint16_t i = 1;
+        do
+        {
+            int m = c->mvmax.x - omv.x;
+            if (omv.x - c->mvmin.x < m) m = omv.x - c->mvmin.x;
+            if (c->mvmax.y - omv.y < m) m = c->mvmax.y - omv.y;
+            if (omv.y - c->mvmin.y < m) m = omv.y - c->mvmin.y;
+            if (4 * i > m)
+            {
+                for (int j = 0; j < 16; j++)
+                {
+                    const int mx = omv.x + kHex4[j].x * i, my = omv.y + kHex4[j].y * i;
+                    if (in_range(c, mx, my)) ONE(mx, my);
+                }
+            }
+            else
+            {
+                int16_t dir = 0;
+                /* the reference's sad_x4 order (:1075-1078): k = 0..15 */
+                static const int8_t ox[16] = { 0, 0, -2, 2, -4, 4, -4, 4, -4, 4, -4, 4, -4, 4, -2, 2 };
+                static const int8_t oy[16] = { -4, 4, -3, -3, -2, -2, -1, -1, 0, 0, 1, 1, 2, 2, 3, 3 };
+                for (int k = 0; k < 16; k++) costs[k] = cost_mv(c, omv.x + ox[k] * i, omv.y + oy[k] * i);
+                for (int k = 0; k < 16; k++)
+                    if ((omv.y + oy[k] >= c->mvmin.y) & (omv.y + oy[k] <= c->mvmax.y))      /* unscaled dy: upstream */
+                        if (costs[k] < bcost) { bcost = costs[k]; dir = (int16_t)(ox[k] * 16 + (oy[k] & 15)); }
+                if (dir)
+                {
+                    bmv.x = omv.x + i * (dir >> 4);
+                    bmv.y = omv.y + i * ((int)((uint32_t)(int)dir << 28) >> 28);
+                }
+            }
+        }
+        while (++i <= merange >> 2);
+        if (in_range(c, bmv.x, bmv.y)) hex_refine(c, &bmv, &bcost, merange);
+    }
+#undef X4
+#undef ONE
+#undef DIA1
+#undef CROSS
+    *pbmv = bmv; *pbcost = bcost;
+}
+
 static int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 
 static int motion_estimate_one(me_ctx* c, int method, int subme, int merange, const int32_t* mvc, int numMvc, int* outQx, int* outQy)
@@ -248,61 +437,12 @@ static int motion_estimate_one(me_ctx* c, int method, int subme, int merange, co
         break;
     }
     case ME_HEX:
-    {
-        /* first full hexagon: six points in two groups of three; out-of-range rows are scored but not accepted */
-#define X3(D0, D1, D2) do { costs[0] = cost_mv(c, bmv.x + (D0).x, bmv.y + (D0).y); costs[1] = cost_mv(c, bmv.x + (D1).x, bmv.y + (D1).y); \
-                            costs[2] = cost_mv(c, bmv.x + (D2).x, bmv.y + (D2).y); } while (0)
-#define YOK(DY) ((bmv.y + (DY) >= c->mvmin.y) & (bmv.y + (DY) <= c->mvmax.y))
-#define LT(V) do { if ((V) < bcost) bcost = (V); } while (0)
-        { const mv_t a = { -2, 0 }, b = { -1, 2 }, d = { 1, 2 }; X3(a, b, d); }
-        bcost <<= 3;
-        if (YOK(0)) LT((costs[0] << 3) + 2);
-        if (YOK(2)) { LT((costs[1] << 3) + 3); LT((costs[2] << 3) + 4); }
-        { const mv_t a = { 2, 0 }, b = { 1, -2 }, d = { -1, -2 }; X3(a, b, d); }
-        if (YOK(0)) LT((costs[0] << 3) + 5);
-        if (YOK(-2)) { LT((costs[1] << 3) + 6); LT((costs[2] << 3) + 7); }
-        if (bcost & 7)
-        {
-            int dir = (bcost & 7) - 2;
-            if (YOK(kHex2[dir + 1].y))
-            {
-                bmv.x += kHex2[dir + 1].x; bmv.y += kHex2[dir + 1].y;
-                /* half hexagons that do not overlap the previous iteration */
-                for (int i = (merange >> 1) - 1; i > 0 && in_range(c, bmv.x, bmv.y); i--)
-                {
-                    X3(kHex2[dir + 0], kHex2[dir + 1], kHex2[dir + 2]);
-                    bcost &= ~7;
-                    if (YOK(kHex2[dir + 0].y)) LT((costs[0] << 3) + 1);
-                    if (YOK(kHex2[dir + 1].y)) LT((costs[1] << 3) + 2);
-                    if (YOK(kHex2[dir + 2].y)) LT((costs[2] << 3) + 3);
-                    if (!(bcost & 7)) break;
-                    dir += (bcost & 7) - 2;
-                    dir = kMod6m1[dir + 1];
-                    bmv.x += kHex2[dir + 1].x; bmv.y += kHex2[dir + 1].y;
-                }
-            }
-        }
-        bcost >>= 3;
-        /* square refine */
-        int dir = 0;
-        costs[0] = cost_mv(c, bmv.x, bmv.y - 1); costs[1] = cost_mv(c, bmv.x, bmv.y + 1);
-        costs[2] = cost_mv(c, bmv.x - 1, bmv.y); costs[3] = cost_mv(c, bmv.x + 1, bmv.y);
-        if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 1; }
-        if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 2; }
-        if (costs[2] < bcost) { bcost = costs[2]; dir = 3; }
-        if (costs[3] < bcost) { bcost = costs[3]; dir = 4; }
-        costs[0] = cost_mv(c, bmv.x - 1, bmv.y - 1); costs[1] = cost_mv(c, bmv.x - 1, bmv.y + 1);
-        costs[2] = cost_mv(c, bmv.x + 1, bmv.y - 1); costs[3] = cost_mv(c, bmv.x + 1, bmv.y + 1);
-        if (YOK(-1) && costs[0] < bcost) { bcost = costs[0]; dir = 5; }
-        if (YOK(1) && costs[1] < bcost) { bcost = costs[1]; dir = 6; }
-        if (YOK(-1) && costs[2] < bcost) { bcost = costs[2]; dir = 7; }
-        if (YOK(1) && costs[3] < bcost) { bcost = costs[3]; dir = 8; }
-        bmv.x += kSquare1[dir].x; bmv.y += kSquare1[dir].y;
-#undef X3
-#undef YOK
-#undef LT
+        hex_refine(c, &bmv, &bcost, merange);
         break;
-    }
+    case ME_UMH:
+        /* pmv = pmv.roundToFPel() before the switch (motion.cpp:814) */
+        umh_search(c, &bmv, &bcost, merange, (pmvx + 2) >> 2, (pmvy + 2) >> 2, c->h, c->w == 64 && c->h == 64, mvc, numMvc);
+        break;
     case ME_STAR:
     {
         int bPointNr = 0, bDistance = 0;
@@ -474,7 +614,7 @@ int EXPORT(x265oracle_motion_estimate_mvc)(const pixel* fenc, const pixel* fref,
         if (part < 0) { rc = -1; continue; }
         me_ctx c;
         c.pu = &prim.pu[part];
-        c.stride = stride; c.w = j->w;
+        c.stride = stride; c.w = j->w; c.h = j->h;
         c.fref = fref + j->px + (intptr_t)j->py * stride;
         c.pu->copy_pp(c.fenc, 64, fenc + j->px + (intptr_t)j->py * stride, stride);
         c.cost = cost + qoff;
@@ -547,7 +687,7 @@ int EXPORT(x265oracle_lowres_cost)(const pixel* cur, const pixel* const* refs0, 
             const intptr_t pelOffset = cuSize * cuX + cuSize * cuY * stride;
             me_ctx c;
             c.pu = &prim.pu[part];
-            c.stride = stride; c.w = 8;
+            c.stride = stride; c.w = 8; c.h = 8;
             c.pu->copy_pp(c.fenc, 64, cur + pelOffset, stride);
             c.cost = cost + qoff;
             c.mvmin.x = -cuX * cuSize - 8; c.mvmin.y = -cuY * cuSize - 8;

@@ -25,7 +25,7 @@ master = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 202609
 
 def soak_search(rng):
     depth = int(rng.choice([8, 10, 12]))
-    method = str(rng.choice(["dia", "hex", "star", "full"]))
+    method = str(rng.choice(["dia", "hex", "umh", "star", "full"]))
     w, h = int(rng.choice([128, 192, 320])), int(rng.choice([128, 192]))
     TS._check(depth, method, w, h, int(rng.integers(1, 1 << 30)), 96 if method != "full" else 24, [int(rng.integers(0, 8))],
               [int(rng.choice([4, 8])) if method == "full" else int(rng.choice([8, 16, 32, 57]))])

@@ -73,7 +73,7 @@ def test_fullsearch_subpel_chain_equals_reference_motion_estimate(depth, width, 
 
 ALL_PU_DIMS = [(8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (4, 8), (16, 8), (8, 16), (32, 16), (16, 32), (64, 32), (32, 64), (16, 12),
                (12, 16), (16, 4), (4, 16), (32, 24), (24, 32), (32, 8), (8, 32), (64, 48), (48, 64), (64, 16), (16, 64)]
-METHODS = {"dia": 0, "hex": 1, "star": 3, "full": 5}          # x265.h:492-497
+METHODS = {"dia": 0, "hex": 1, "umh": 2, "star": 3, "full": 5}          # x265.h:492-497
 
 
 def random_me_jobs(rng, n, width, height):
@@ -94,7 +94,7 @@ def copy_jobs(jobs):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
-@pytest.mark.parametrize("method", ["dia", "hex", "star", "full"])
+@pytest.mark.parametrize("method", ["dia", "hex", "umh", "star", "full"])
 def test_search_driver_restatement_equals_reference_motion_estimate(depth, method):
     """oracle/x265_oracle_search.c (predictor start, DIA / HEX / STAR / FULL patterns, predictor-vs-search choice, sub-pel
     refinement) against the real MotionEstimate::motionEstimate: random PU sizes (all 24 inter partitions), positions,
@@ -546,7 +546,7 @@ def test_search_driver_with_extra_candidates_equals_reference(depth):
     rng = np.random.default_rng([9, depth])
     qp = 24 if depth == 8 else 12
     cq, qoff = F.qpel_cost_table(57, qmax=8 * 64 + 300)
-    for method in (1, 3):
+    for method in (1, 2, 3):
         for subme in (1, 2, 5):
             n = 48
             ja = random_me_jobs(rng, n, width, height)

@@ -32,7 +32,7 @@ from bench import effective_cpus
 threads = effective_cpus()
 print(f"# x265hip_me_search: every 8x8..64x64 PU of every CTU, predictor (0,0), merange 57; CPU column = oracle/x265_oracle_search.c "
       f"(-march=x86-64-v3) on {threads} threads (container CPU quota) over a sample of the same jobs")
-for name, m in (("dia", A.ME_DIA), ("hex", A.ME_HEX), ("star", A.ME_STAR)):
+for name, m in (("dia", A.ME_DIA), ("hex", A.ME_HEX), ("umh", A.ME_UMH), ("star", A.ME_STAR)):
     for subme in (2, 3):
         f = lambda: A.me_search(8, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, m, subme, 57, cq_d, qoff, (-57, -57), (57, 57), jd, len(jn))
         f(); torch.cuda.synchronize()

@@ -6,8 +6,8 @@
 // :1138-1240 with StarPatternSearch :362-604 (point numbering, early exit after 3 / 32 idle rounds, two-point refinement,
 // raster refinement whose fourth candidate is priced with mvcost(tmv << 3), :1196) and FULL :1397-1445; predictor-vs-search
 // choice :1452-1458; zero-residual shortcut :1464-1469; sub-pel refinement :1508-1561 over subpelCompare :1571-1613
-// (luma_hpp / luma_vpp / luma_hvpp + sad / satd).  mv costs come from the caller's table, indexed by the quarter-pel
-// difference to the predictor (bitcost.h:45).  UMH and SEA are not implemented (the entry point rejects them).
+// (luma_hpp / luma_vpp / luma_hvpp + sad / satd); UMH :946-1130.  mv costs come from the caller's table, indexed by the quarter-pel
+// difference to the predictor (bitcost.h:45).  SEA is not implemented (the entry point rejects it).
 //
 // Mapping: a lane GROUP per PU - a DPP quad (4 lanes) for PUs of up to 8 tiles of 4x4 (8x8, 8x4, 16x8 ...), a 16-lane row up
 // to 32 tiles (16x16 ... 32x16), the whole wavefront above (32x32 ... 64x64: 4 tiles per lane).  The source tiles stay packed
@@ -103,6 +103,134 @@ __device__ __forceinline__ void star_pattern(const PuEval<Px, G, T>& c, SMv& bmv
     }
 }
 
+// X265_UMH_SEARCH (motion.cpp:946-1130): predictor diamonds, early termination on the SAD_THRESH scales (:61, :123-150), cross and
+// octagon probes, optional range adaptation from the mv candidates (:982-1040), the 16-point hexagon grid, then the radius-2 hexagon
+// refinement of X265_HEX_SEARCH.  Upstream behaviour kept: COST_MV_X4 only tests a candidate's y against the search range (:295-302);
+// the hexagon grid's fast path tests omv.y + dy with the UNscaled offset (:1087).
+__constant__ signed char kUmhHexX[16] = { 0, 0, -2, 2, -4, 4, -4, 4, -4, 4, -4, 4, -4, 4, -2, 2 };
+__constant__ signed char kUmhHexY[16] = { -4, 4, -3, -3, -2, -2, -1, -1, 0, 0, 1, 1, 2, 2, 3, 3 };
+__constant__ unsigned char kUmhRangeMul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
+
+template <typename Px, int G, int T>
+__device__ __forceinline__ void umh_search(const PuEval<Px, G, T>& c, SMv& bmv, int& bcost, int merange, const int pmvx, const int pmvy,
+                                           const int h, const bool is64, const int32_t* mvc, const int numMvc)
+{
+    SMv omv = bmv;
+    auto thresh = [&](int v) { return bcost < ((v >> 4) * ((h * h) >> 4)); };
+    auto x4 = [&](int d0x, int d0y, int d1x, int d1y, int d2x, int d2y, int d3x, int d3y)
+    {
+        const int mxs[4] = { omv.x + d0x, omv.x + d1x, omv.x + d2x, omv.x + d3x }, mys[4] = { omv.y + d0y, omv.y + d1y, omv.y + d2y, omv.y + d3y };
+        int cs[4];
+        c.template cost_mv_n<4>(mxs, mys, cs);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((mys[k] >= c.mvmin.y) & (mys[k] <= c.mvmax.y))
+                if (cs[k] < bcost) { bcost = cs[k]; bmv.x = mxs[k]; bmv.y = mys[k]; }
+    };
+    auto one = [&](int mx, int my) { const int cost = c.cost_mv(mx, my); if (cost < bcost) { bcost = cost; bmv.x = mx; bmv.y = my; } };
+    auto dia1 = [&](int mx, int my) { omv.x = mx; omv.y = my; x4(0, -1, 0, 1, -1, 0, 1, 0); };
+    auto cross = [&](int start, int xmax, int ymax)
+    {
+        int i = (int16_t)start;
+        if (xmax <= min(c.mvmax.x - omv.x, omv.x - c.mvmin.x))
+            for (; i < xmax - 2; i += 4) x4(i, 0, -i, 0, i + 2, 0, -i - 2, 0);
+        for (; i < xmax; i += 2)
+        {
+            if (omv.x + i <= c.mvmax.x) one(omv.x + i, omv.y);
+            if (omv.x - i >= c.mvmin.x) one(omv.x - i, omv.y);
+        }
+        i = (int16_t)start;
+        if (ymax <= min(c.mvmax.y - omv.y, omv.y - c.mvmin.y))
+            for (; i < ymax - 2; i += 4) x4(0, i, 0, -i, 0, i + 2, 0, -i - 2);
+        for (; i < ymax; i += 2)
+        {
+            if (omv.y + i <= c.mvmax.y) one(omv.x, omv.y + i);
+            if (omv.y - i >= c.mvmin.y) one(omv.x, omv.y - i);
+        }
+    };
+    int crossStart = 1;
+    const int ucost1 = bcost;
+    dia1(pmvx, pmvy);
+    if (pmvx | pmvy) dia1(0, 0);
+    const int ucost2 = bcost;
+    if ((bmv.x | bmv.y) && (bmv.x != pmvx || bmv.y != pmvy)) dia1(bmv.x, bmv.y);
+    if (bcost == ucost2) crossStart = 3;
+    omv = bmv;
+    if (bcost == ucost2 && thresh(2000))
+    {
+        x4(0, -2, -1, -1, 1, -1, -2, 0);
+        x4(2, 0, -1, 1, 1, 1, 0, 2);
+        if (bcost == ucost1 && thresh(500)) return;
+        if (bcost == ucost2)
+        {
+            const int range = (int16_t)((merange >> 1) | 1);
+            cross(3, range, range);
+            x4(-1, -2, 1, -2, -2, -1, 2, -1);
+            x4(-2, 1, 2, 1, -1, 2, 1, 2);
+            if (bcost == ucost2) return;
+            crossStart = (int16_t)(range + 2);
+        }
+    }
+    if (numMvc)
+    {
+        int mvd, denom = 1;
+        if (numMvc == 1)
+            mvd = is64 ? 25 : abs(c.mvpx - mvc[0]) + abs(c.mvpy - mvc[1]);
+        else
+        {
+            denom = numMvc - 1;
+            mvd = 0;
+            if (!is64) { mvd = abs(c.mvpx - mvc[0]) + abs(c.mvpy - mvc[1]); denom++; }
+            for (int i = 0; i < numMvc - 1; i++) mvd += abs(mvc[2 * i] - mvc[2 * i + 2]) + abs(mvc[2 * i + 1] - mvc[2 * i + 3]);
+        }
+        const int sadCtx = thresh(1000) ? 0 : (thresh(2000) ? 1 : (thresh(4000) ? 2 : 3));
+        const int mvdCtx = mvd < 10 * denom ? 0 : (mvd < 20 * denom ? 1 : (mvd < 40 * denom ? 2 : 3));
+        merange = (merange * kUmhRangeMul[mvdCtx][sadCtx]) >> 2;
+    }
+    cross(crossStart, merange, merange >> 1);
+    x4(-2, -2, -2, 2, 2, -2, 2, 2);
+    omv = bmv;
+    int i = 1;
+    do
+    {
+        const int m = min(min(c.mvmax.x - omv.x, omv.x - c.mvmin.x), min(c.mvmax.y - omv.y, omv.y - c.mvmin.y));
+        if (4 * i > m)
+        {
+            for (int j = 0; j < 16; j++)
+            {
+                const int mx = omv.x + kUmhHexX[j] * i, my = omv.y + kUmhHexY[j] * i;
+                if (c.in_range(mx, my)) one(mx, my);
+            }
+        }
+        else
+        {
+            int dir = 0;
+#pragma unroll 1
+            for (int g4 = 0; g4 < 16; g4 += 4)                        // the reference's four sad_x4 groups, same order
+            {
+                int mxs[4], mys[4], cs[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { mxs[k] = omv.x + kUmhHexX[g4 + k] * i; mys[k] = omv.y + kUmhHexY[g4 + k] * i; }
+                c.template cost_mv_n<4>(mxs, mys, cs);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const int dy = kUmhHexY[g4 + k];
+                    if ((omv.y + dy >= c.mvmin.y) & (omv.y + dy <= c.mvmax.y))
+                        if (cs[k] < bcost) { bcost = cs[k]; dir = (int16_t)(kUmhHexX[g4 + k] * 16 + (dy & 15)); }
+                }
+            }
+            if (dir)
+            {
+                bmv.x = omv.x + i * (dir >> 4);
+                bmv.y = omv.y + i * ((int)((uint32_t)dir << 28) >> 28);
+            }
+        }
+    }
+    while (++i <= (merange >> 2));
+    if (c.in_range(bmv.x, bmv.y)) hex_search<Px, G, T>(c, bmv, bcost, merange);
+}
+
 // One PU per lane group: `job` is the group's job (every lane of the group passes the same value).
 template <typename Px, int G, int T>
 __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
@@ -186,6 +314,11 @@ __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
     else if (a.method == 1)         // X265_HEX_SEARCH
     {
         hex_search<Px, G, T>(c, bmv, bcost, merange);
+    }
+    else if (a.method == 2)         // X265_UMH_SEARCH; pmv is rounded to full-pel before the pattern switch (motion.cpp:814)
+    {
+        umh_search<Px, G, T>(c, bmv, bcost, merange, (pmvx + 2) >> 2, (pmvy + 2) >> 2, jb.h, jb.w == 64 && jb.h == 64,
+                             a.mvc ? a.mvc + (size_t)job * 24 : nullptr, numMvc);
     }
     else if (a.method == 3)         // X265_STAR_SEARCH (motion.cpp:1138-1240), one StarPatternSearch call site for both phases
     {
@@ -373,8 +506,8 @@ extern "C" int x265hip_me_search(const x265hip_me_search_params* p, void* stream
     if (p->njobs < 0) { set_error("me_search: njobs %d", p->njobs); return X265HIP_EINVAL; }
     if (p->njobs == 0) return 0;
     if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("me_search: depth %d", p->depth); return X265HIP_EINVAL; }
-    if (p->method != X265HIP_ME_DIA && p->method != X265HIP_ME_HEX && p->method != X265HIP_ME_STAR && p->method != X265HIP_ME_FULL)
-    { set_error("me_search: search method %d is not implemented (DIA, HEX, STAR, FULL are)", p->method); return X265HIP_EINVAL; }
+    if (p->method != X265HIP_ME_DIA && p->method != X265HIP_ME_HEX && p->method != X265HIP_ME_UMH && p->method != X265HIP_ME_STAR && p->method != X265HIP_ME_FULL)
+    { set_error("me_search: search method %d is not implemented (DIA, HEX, UMH, STAR, FULL are; SEA needs integral planes)", p->method); return X265HIP_EINVAL; }
     if (p->subme < 0 || p->subme > 7) { set_error("me_search: subme %d out of [0,7]", p->subme); return X265HIP_EINVAL; }
     if (p->mvmin_x > p->mvmax_x || p->mvmin_y > p->mvmax_y) { set_error("me_search: empty mv range"); return X265HIP_EINVAL; }
     const int bpp = p->depth == 8 ? 1 : 2;

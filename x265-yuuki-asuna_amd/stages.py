@@ -247,7 +247,7 @@ class FramePipeline:
         # search != "full": the pattern-search drivers replace the exhaustive search + sub-pel pair
         self.ps = None
         if search != "full":
-            method = {"dia": hipabi.ME_DIA, "hex": hipabi.ME_HEX, "star": hipabi.ME_STAR}[search]
+            method = {"dia": hipabi.ME_DIA, "hex": hipabi.ME_HEX, "umh": hipabi.ME_UMH, "star": hipabi.ME_STAR}[search]
             self.ps = PatternSearch(w64, h64, depth, method, subme, rng, device)
         self.rc = InterRecon(self.ms.nctu, w64, h64, depth, level, qp, device)
         self.la = Lookahead(lookahead[0], lookahead[1], depth, device) if lookahead else None
