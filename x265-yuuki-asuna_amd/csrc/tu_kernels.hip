@@ -80,7 +80,7 @@ template <int N> struct TuOps<N, true>
 };
 template <int N, bool DST> using TuOpsFor = TuOps<N, (N >= 16 && !DST)>;
 
-template <typename Px, int N, bool DST, bool LAZY = false>
+template <typename Px, int N, bool DST>
 __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int16_t* pred, const int16_t* fe, int16_t* A, int16_t* B, unsigned long long* red, int& sNumSig,
                                          int depth, int qp, int intraSlice, int16_t* lvOut, uint32_t* numSigOut, unsigned long long* distOut,
                                          Px* rec, long cst)
@@ -118,11 +118,7 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
         if (wave == 0)
         {
             typedef Mfma<N> MF;
-            // LAZY: a one-block workgroup builds each operand where it is used (short live ranges) instead of up front
-            auto matrix = [](int r, int c) { return (int)kTu.m[r][c]; };
-            DctOperand<N, false> fwL;
-            if constexpr (LAZY) fwL.init(lane, matrix);
-            const DctOperand<N, false>& fw = LAZY ? fwL : ops.fw;
+            const DctOperand<N, false>& fw = ops.fw;
             const int kb = MF::kbase(lane), rn = MF::mn(lane);
             uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
             int p[MF::NACC];
@@ -216,10 +212,7 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
                 if (wave == 0)
                 {
                     typedef Mfma<N> MF;
-                    auto matrix = [](int r, int c) { return (int)kTu.m[r][c]; };
-                    DctOperand<N, true> ivL;
-                    if constexpr (LAZY) ivL.init(lane, matrix);
-                    const DctOperand<N, true>& iv = LAZY ? ivL : ops.iv;
+                    const DctOperand<N, true>& iv = ops.iv;
                     const int kb = MF::kbase(lane), rn = MF::mn(lane);
                     uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
                     int p[MF::NACC];
