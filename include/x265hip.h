@@ -164,8 +164,8 @@ int x265hip_extend_border(void* pic, intptr_t stride, int width, int height, int
 
 /* ---- motion search drivers: MotionEstimate::motionEstimate for a list of PUs ----
  * One job = one prediction unit of one reference picture: position, size (any of the reference's 24 inter partitions,
- * primitives.h:41-55 minus 4x4), quarter-pel predictor.  For every job the kernel reproduces motionEstimate() with no extra
- * candidates (encoder/motion.cpp:739-1561): predictor / zero start, the integer pattern `method` (X265_DIA_SEARCH,
+ * primitives.h:41-55 minus 4x4), quarter-pel predictor.  For every job the kernels reproduce motionEstimate() with the optional
+ * extra candidates mvc[] (encoder/motion.cpp:739-1561; UMH also sizes its range from them, :982-1040): predictor / zero start, the integer pattern `method` (X265_DIA_SEARCH,
  * X265_HEX_SEARCH, X265_UMH_SEARCH, X265_STAR_SEARCH, X265_FULL_SEARCH of x265.h:492-497; SEA is rejected), the predictor-vs-search
  * choice and the sub-pel refinement level `subme`; out_qmv / out_cost are its outQMv and return value.
  *   fenc, fref : pixel (0,0) of the padded source / reference luma planes; fref needs mvmax + 8 valid pixels of margin
