@@ -156,6 +156,11 @@ typedef struct x265hip_recon_params
     int16_t* levels; uint32_t* num_sig; uint64_t* dist;
 } x265hip_recon_params;
 int x265hip_inter_recon(const x265hip_recon_params* p, void* stream);
+/* One chroma plane of the same stage for 4:2:0 pictures (Predict::predInterChromaPixel, predict.cpp:304-351, + the same residual
+ * round trip on (n/2) x (n/2) blocks; DCT also for 4x4): fenc / fref / recon = sample (0,0) of the chroma planes with their
+ * strides, width / height = LUMA size, mv = the luma stage's records, qp = the plane's quantiser QP (chroma QP mapping and PPS /
+ * slice offsets applied by the caller, + QP_BD_OFFSET); levels hold (n/2)^2 entries per block. */
+int x265hip_inter_recon_chroma(const x265hip_recon_params* p, void* stream);
 
 /* Picture border extension (reference extendPicBorder, pixel.cpp:1027-1041 = extendRowBorder slot,
  * ipfilter.cpp:59-77, + top/bottom row replication): `pic` points at pixel (0,0) of a plane that has

@@ -267,3 +267,25 @@ def sao_apply(depth, src, stride, org, width, height, params, nthreads=0, avx2=F
     fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int]
     assert fn(src.ctypes.data + org * es, dst.ctypes.data + org * es, stride, width, height, ctu[0], ctu[1], pr.ctypes.data, nthreads) == 0
     return dst
+
+
+def inter_recon_chroma(depth, fenc, fref, stride, org, width, height, level, mv, qp, intra_slice=0, nthreads=0, avx2=False):
+    """CPU restatement of the chroma half of the inter TU stage for one plane of a 4:2:0 picture (flat padded planes, sample (0,0) at
+    element `org`; width / height = luma size).  Returns (recon plane, levels, num_sig, dist)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_inter_recon_chroma_d{depth}")
+    nctu = (width // 64) * (height // 64)
+    nc = 4 << level
+    nblk = (32 // nc) ** 2
+    recon = np.zeros_like(fenc)
+    levels = np.zeros(nctu * nblk * nc * nc, dtype=np.int16)
+    num_sig = np.zeros(nctu * nblk, dtype=np.uint32)
+    dist = np.zeros(nctu * nblk, dtype=np.uint64)
+    es = fenc.itemsize
+    m = np.ascontiguousarray(mv, dtype=np.int32)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_ssize_t,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    assert fn(fenc.ctypes.data + org * es, stride, fref.ctypes.data + org * es, stride, recon.ctypes.data + org * es, stride,
+              width, height, level, m.ctypes.data, qp, intra_slice, levels.ctypes.data, num_sig.ctypes.data, dist.ctypes.data, nthreads) == 0
+    return recon, levels, num_sig, dist

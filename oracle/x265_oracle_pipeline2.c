@@ -122,6 +122,89 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
     return 0;
 }
 
+/* One chroma plane of the same stage for 4:2:0 pictures: Predict::predInterChromaPixel (predict.cpp:304-351: the luma mv in 1/8
+ * chroma samples, 4-tap filters - copy_pp / filter_hpp / filter_vpp / filter_hps (+3 rows) + filter_vsp of the chroma table) and
+ * the residual round trip on (n/2) x (n/2) blocks (DCT also for 4x4: DST-VII is intra luma only).  fenc / fref / recon: sample
+ * (0,0) of the chroma planes; width / height: LUMA size; qp: the plane's quantiser QP (chroma mapping and offsets applied by the
+ * caller, + QP_BD_OFFSET).  Outputs as x265oracle_inter_recon with (n/2)^2 levels per block. */
+int EXPORT(x265oracle_inter_recon_chroma)(const pixel* fenc, intptr_t fencStride, const pixel* fref, intptr_t frefStride,
+                                          pixel* recon, intptr_t reconStride, int width, int height, int level,
+                                          const int32_t* mv, int qp, int isIntraSlice,
+                                          int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads)
+{
+    static x265hip_EncoderPrimitives prim;
+    static int ready = 0;
+    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    const int ctusW = width / 64, nctu = ctusW * (height / 64);
+    const int n = 8 << level, nc = n >> 1, log2nc = 2 + level, npu = (64 / n) * (64 / n);
+    const int puIdx = level == 0 ? X265HIP_LUMA_8x8 : (level == 1 ? X265HIP_LUMA_16x16 : X265HIP_LUMA_32x32);
+    const struct x265hip_PUChroma* pu = &prim.chroma[1].pu[puIdx];       /* X265_CSP_I420 */
+    const struct x265hip_CU* cu = &prim.cu[log2nc - 2];
+    const int per = qp / 6, rem = qp % 6;
+    const int transformShift = 15 - X265HIP_DEPTH - log2nc;
+    const int qbits = 14 + per + transformShift;
+    const int add = (isIntraSlice ? 171 : 85) << (qbits - 9);
+    const int dqShift = 20 - 14 - transformShift;
+    const int dqScale = kInvQuantScales[rem] << per;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int ctu = 0; ctu < nctu; ctu++)
+    {
+        const int cx = (ctu % ctusW) * 32, cy = (ctu / ctusW) * 32;
+        pixel pred[32 * 32] __attribute__((aligned(64)));
+        int16_t resi[32 * 32] __attribute__((aligned(64)));
+        int16_t coef[16 * 16] __attribute__((aligned(64)));
+        int16_t immed[32 * (32 + 3)] __attribute__((aligned(64)));
+        int32_t quantCoeff[16 * 16] __attribute__((aligned(64)));
+        int32_t deltaU[16 * 16];
+        for (int i = 0; i < nc * nc; i++) quantCoeff[i] = kQuantScales[rem];
+        for (int z = 0; z < npu; z++)
+        {
+            int bx, by;
+            zxy(z, &bx, &by);
+            const int px = cx + bx * nc, py = cy + by * nc;
+            const int32_t packed = mv[((size_t)ctu * 85 + kLvlBase[level] + z) * 2 + 1];
+            const int qx = (int16_t)(packed & 0xffff), qy = (int16_t)(packed >> 16);       /* 1/4 luma = 1/8 chroma samples */
+            const pixel* src = fref + (intptr_t)(py + (qy >> 3)) * frefStride + px + (qx >> 3);
+            const pixel* fe = fenc + (intptr_t)py * fencStride + px;
+            pixel* rec = recon + (intptr_t)py * reconStride + px;
+            const int xf = qx & 7, yf = qy & 7;
+            if (!(xf | yf)) pu->copy_pp(pred, 32, src, frefStride);
+            else if (!yf) pu->filter_hpp(src, frefStride, pred, 32, xf);
+            else if (!xf) pu->filter_vpp(src, frefStride, pred, 32, yf);
+            else
+            {
+                pu->filter_hps(src, frefStride, immed, nc, xf, 1);
+                pu->filter_vsp(immed + 1 * nc, nc, pred, 32, yf);
+            }
+            cu->sub_ps(resi, 32, fe, pred, fencStride, 32);
+            cu->dct(resi, coef, 32);
+            int16_t* q = levels + ((size_t)ctu * npu + z) * nc * nc;
+            const uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, nc * nc);
+            numSigOut[(size_t)ctu * npu + z] = numSig;
+            if (numSig)
+            {
+                prim.dequant_normal(q, coef, nc * nc, dqScale, dqShift);
+                if (numSig == 1 && q[0] != 0)
+                {
+                    const int shift_2nd = 12 - (X265HIP_DEPTH - 8) - 3;
+                    const int dc = ((((coef[0] * (64 >> 6) + 1) >> 1) * (64 >> 3)) + (1 << (shift_2nd - 1))) >> shift_2nd;
+                    cu->blockfill_s[0](resi, 32, (int16_t)dc);
+                }
+                else
+                    cu->idct(coef, resi, 32);
+                cu->add_ps[0](rec, reconStride, pred, resi, 32, 32);
+            }
+            else
+                cu->copy_pp(rec, reconStride, pred, 32);
+            distOut[(size_t)ctu * npu + z] = (uint64_t)cu->sse_pp(fe, fencStride, rec, reconStride);
+        }
+    }
+    return 0;
+}
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Intra TU candidate set: the pixel work of Search::codeIntraLumaQT for one (TU, mode) candidate
  * (source/encoder/search.cpp:335-373): Predict::predIntraLumaAng (predict.cpp:579-588: filtered neighbours per

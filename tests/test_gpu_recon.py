@@ -52,3 +52,54 @@ def test_inter_recon_matches_oracle(depth, level, qp):
         assert (ens > 1).any()
     if qp == 45:
         assert (ens == 0).any()
+
+
+@pytest.mark.parametrize("depth,level,qp", [(8, 2, 24), (8, 1, 30), (8, 0, 20), (10, 2, 36), (10, 0, 30), (12, 1, 44)])
+def test_inter_recon_chroma_matches_oracle(depth, level, qp):
+    """The chroma planes of a 4:2:0 picture through the same stage: 1/8-sample 4-tap prediction from the luma mvs, residual round
+    trip on half-size blocks (4x4 ... 16x16)."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng([53, depth, level])
+    W, Hh = 256, 128
+    clip = F.synth_clip(W, Hh, 2, depth=depth, seed=60 + level)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    ms = P.MotionSearch(cur.w64, cur.h64, 8, depth, dev, want_surf=False)
+    ms.run(cur, ref)
+    sp = P.SubpelRefine(ms, 3, dev)
+    sp.run(cur, ref)
+    torch.cuda.synchronize()
+    mv = sp.out.cpu().numpy().reshape(-1, 2).copy()
+    # spread the mvs so that every 1/8 phase and the integer / h-only / v-only paths occur
+    q = mv[:, 1]
+    jit = rng.integers(-9, 10, size=(q.size, 2))
+    qx = (((q & 0xffff) ^ 0x8000) - 0x8000) + jit[:, 0]
+    qy = (q >> 16) + jit[:, 1]
+    qx[::5] &= ~7; qy[::7] &= ~7
+    mv[:, 1] = (qx & 0xffff) | (qy << 16)
+    d_mv = torch.from_numpy(mv.reshape(-1)).to(dev)
+    cw, ch, margin = cur.w64 // 2, cur.h64 // 2, 24
+    stride = cw + 2 * margin
+    org = margin * stride + margin
+    O = _oracle()
+    dt = cur.host.dtype
+    for c in (1, 2):
+        planes = []
+        for k in (1, 0):                                      # current, reference
+            src = clip[k][c]
+            body = np.zeros((ch, cw), dt)
+            body[:src.shape[0], :src.shape[1]] = src
+            planes.append(np.ascontiguousarray(np.pad(body, margin, mode="edge")).reshape(-1))
+        fenc_h, fref_h = planes
+        st = S.InterReconChroma(ms.nctu, cur.w64, cur.h64, depth, level, qp, dev)
+        d_f = torch.from_numpy(fenc_h.view(np.uint8)).to(dev)
+        d_r = torch.from_numpy(fref_h.view(np.uint8)).to(dev)
+        d_o = torch.zeros_like(d_f)
+        st.run(d_f, d_r, d_o, stride, org, d_mv)
+        torch.cuda.synchronize()
+        erec, elev, ens, edist = O.inter_recon_chroma(depth, fenc_h, fref_h, stride, org, cur.w64, cur.h64, level, mv, qp)
+        assert np.array_equal(st.num_sig.cpu().numpy().view(np.uint32), ens), f"plane {c}: numSig differs"
+        assert np.array_equal(st.levels.cpu().numpy(), elev), f"plane {c}: levels differ"
+        assert np.array_equal(d_o.cpu().numpy().view(dt), erec), f"plane {c}: reconstruction differs"
+        assert np.array_equal(st.dist.cpu().numpy().view(np.uint64), edist), f"plane {c}: SSE differs"
+        assert (ens > 0).any()

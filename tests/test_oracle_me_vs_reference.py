@@ -525,6 +525,48 @@ def test_sao_chroma_restatement_equals_reference_class(depth, width, height):
         assert (got != rec[c]).any() and cnt[:, :4, :5].sum() > 0
 
 
+@pytest.mark.parametrize("depth,level,qp", [(8, 0, 26), (8, 2, 32), (10, 1, 40)])
+def test_chroma_inter_tu_round_trip_equals_reference_quant_class(depth, level, qp):
+    """The chroma flavour of the inter TU stage (x265oracle_inter_recon_chroma, half-size blocks incl. the 4x4 DCT) with zero motion
+    against the real Quant class: levels, numSig and reconstruction block by block."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_tu_roundtrip"):
+        pytest.skip("oracle/_ref predates ref_quant.cpp")
+    clip = F.synth_clip(128, 64, 2, depth=depth, seed=83)
+    w64, h64 = 128, 64
+    cw, ch, margin = w64 // 2, h64 // 2, 16
+    dt = clip[0][0].dtype
+    mk = lambda src: np.ascontiguousarray(np.pad(src[:ch, :cw], margin, mode="edge")).reshape(-1)
+    cur, ref = mk(clip[1][1]), mk(clip[0][1])
+    stride, org = cw + 2 * margin, margin * (cw + 2 * margin) + margin
+    nctu = (w64 // 64) * (h64 // 64)
+    nc = 4 << level
+    nblk = (32 // nc) ** 2
+    mv = np.zeros((nctu * 85, 2), np.int32)
+    rec, lev, ns, _ = O.inter_recon_chroma(depth, cur, ref, stride, org, w64, h64, level, mv, qp)
+    c2, r2, o2 = cur.reshape(-1, stride), ref.reshape(-1, stride), rec.reshape(-1, stride)
+    resi, pos = [], []
+    for ctu in range(nctu):
+        for z in range(nblk):
+            bx = sum(((z >> (2 * b)) & 1) << b for b in range(3))
+            by = sum(((z >> (2 * b + 1)) & 1) << b for b in range(3))
+            y, x = margin + (ctu // (w64 // 64)) * 32 + by * nc, margin + (ctu % (w64 // 64)) * 32 + bx * nc
+            resi.append(c2[y:y + nc, x:x + nc].astype(np.int16) - r2[y:y + nc, x:x + nc].astype(np.int16))
+            pos.append((y, x))
+    resi = np.ascontiguousarray(np.stack(resi).reshape(-1))
+    nj = len(pos)
+    rlev, rns, rout = np.zeros(nj * nc * nc, np.int16), np.zeros(nj, np.uint32), np.zeros(nj * nc * nc, np.int16)
+    lib.x265ref_tu_roundtrip.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3
+    assert lib.x265ref_tu_roundtrip(resi.ctypes.data, nc, qp, 0, 0, nj, rlev.ctypes.data, rns.ctypes.data, rout.ctypes.data) == 0
+    assert np.array_equal(ns.reshape(-1), rns) and np.array_equal(lev, rlev)
+    pmax = (1 << depth) - 1
+    for j, (y, x) in enumerate(pos):
+        exp = np.clip(r2[y:y + nc, x:x + nc].astype(np.int32) + rout[j * nc * nc:(j + 1) * nc * nc].reshape(nc, nc), 0, pmax)
+        assert np.array_equal(o2[y:y + nc, x:x + nc].astype(np.int32), exp), f"block {j} reconstruction differs"
+    assert (rns > 0).any()
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_search_driver_with_extra_candidates_equals_reference(depth):
     """motionEstimate's mvc[] candidates (motion.cpp:800-812: measured with SAD + mv cost against the predictor's cost, skipping

@@ -41,6 +41,8 @@ static __constant__ int8_t kTuDst[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74
 static __constant__ int16_t kTuTaps[4][8] = {
     { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
     { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+static __constant__ int16_t kTuChromaTaps[8][4] = {                                      // constants.cpp:258-268
+    { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 }, { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
 static __constant__ int kTuQuantScales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };   // scalinglist.cpp:129
 static __constant__ int kTuInvQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                  // scalinglist.cpp:130
 
@@ -286,10 +288,14 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
     }
 }
 
-template <typename Px, int N>
+// CHROMA: one chroma plane of a 4:2:0 picture - N is the chroma block size (half the luma block), the mv counts 1/8 samples and
+// the filters are the 4-tap chroma set (Predict::predInterChromaPixel, predict.cpp:304-351)
+template <typename Px, int N, bool CHROMA>
 __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs a, int nblocks)
 {
-    constexpr int NN = N * N, LOG2N = N == 8 ? 3 : (N == 16 ? 4 : 5), PW = N + 7, PP = N + 8;
+    constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
+    constexpr int TAPS = CHROMA ? 4 : 8, APRON = TAPS / 2 - 1, PW = N + TAPS - 1, PP = PW + 1;
+    constexpr int NL = CHROMA ? 2 * N : N, CTU = CHROMA ? 32 : 64, MVSH = CHROMA ? 3 : 2, MVMASK = CHROMA ? 7 : 3;
     constexpr int BPP = sizeof(Px);
     __shared__ int16_t patch[PW * PP];
     __shared__ int16_t immed[PW * N];
@@ -297,10 +303,11 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs 
     __shared__ unsigned long long red[4];
     __shared__ int sNumSig;
 
-    const int npu = (64 / N) * (64 / N);
-    const int lbase = N == 8 ? 0 : (N == 16 ? 64 : 80);
+    const int npu = (64 / NL) * (64 / NL);
+    const int lbase = NL == 8 ? 0 : (NL == 16 ? 64 : 80);
     const int tid = threadIdx.x, nth = blockDim.x;
     const int maxVal = (1 << a.depth) - 1, headRoom = 14 - a.depth;
+    auto tap = [](int f, int t) { return CHROMA ? (int)kTuChromaTaps[f][t] : (int)kTuTaps[f][t]; };
     // 16 / 32: a persistent single-wavefront workgroup walks blocks blockIdx.x, + gridDim.x, ... with the MFMA operands of the
     // transforms built once (its barriers are wave-local); 8: one block per workgroup
     TuOpsFor<N, false> ops;
@@ -309,18 +316,18 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs 
     {
     const int ctu = blk / npu, z = blk - ctu * npu;
     const int bxz = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), byz = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
-    const int px = (ctu % a.ctusW) * 64 + bxz * N, py = (ctu / a.ctusW) * 64 + byz * N;
+    const int px = (ctu % a.ctusW) * CTU + bxz * N, py = (ctu / a.ctusW) * CTU + byz * N;
 
     const int packed = a.mv[(size_t)ctu * 85 + lbase + z].y;
     const int qx = (int16_t)(packed & 0xffff), qy = (int16_t)(packed >> 16);
-    const int xf = qx & 3, yf = qy & 3;
+    const int xf = qx & MVMASK, yf = qy & MVMASK;
 
-    // ---- stage source block + reference patch (3 left/top, 4 right/bottom apron) --------------------
+    // ---- stage source block + reference patch (TAPS/2 - 1 left/top, TAPS/2 right/bottom apron) --------------------
     {
         const Px* f = reinterpret_cast<const Px*>(a.fenc + (long)py * a.fencStrideB) + px;
         const long fst = a.fencStrideB / BPP;
         for (int i = tid; i < NN; i += nth) { const int y = i >> LOG2N, x = i & (N - 1); fe[i] = (int16_t)f[y * fst + x]; }
-        const Px* r = reinterpret_cast<const Px*>(a.fref + (long)(py + (qy >> 2) - 3) * a.frefStrideB) + (px + (qx >> 2) - 3);
+        const Px* r = reinterpret_cast<const Px*>(a.fref + (long)(py + (qy >> MVSH) - APRON) * a.frefStrideB) + (px + (qx >> MVSH) - APRON);
         const long rst = a.frefStrideB / BPP;
         for (int i = tid; i < PW * PW; i += nth) { const int y = i / PW, x = i - y * PW; patch[y * PP + x] = (int16_t)r[y * rst + x]; }
         if (tid == 0) sNumSig = 0;
@@ -336,7 +343,7 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs 
             const int y = i >> LOG2N, x = i & (N - 1);
             int s = 0;
 #pragma unroll
-            for (int t = 0; t < 8; t++) s += (int)patch[y * PP + x + t] * kTuTaps[xf][t];
+            for (int t = 0; t < TAPS; t++) s += (int)patch[y * PP + x + t] * tap(xf, t);
             immed[i] = (int16_t)((s + offPS) >> shiftPS);
         }
         __syncthreads();
@@ -346,7 +353,7 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs 
             const int y = i >> LOG2N, x = i & (N - 1);
             int s = 0;
 #pragma unroll
-            for (int t = 0; t < 8; t++) s += (int)immed[(y + t) * N + x] * kTuTaps[yf][t];
+            for (int t = 0; t < TAPS; t++) s += (int)immed[(y + t) * N + x] * tap(yf, t);
             pred[i] = (int16_t)tu_clip16((s + offSP) >> shiftSP, maxVal);
         }
     }
@@ -356,13 +363,13 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs 
         {
             const int y = i >> LOG2N, x = i & (N - 1);
             int v;
-            if (!(xf | yf)) v = patch[(y + 3) * PP + x + 3];
+            if (!(xf | yf)) v = patch[(y + APRON) * PP + x + APRON];
             else
             {
                 int s = 0;
 #pragma unroll
-                for (int t = 0; t < 8; t++)
-                    s += (int)(xf ? patch[(y + 3) * PP + x + t] : patch[(y + t) * PP + x + 3]) * kTuTaps[xf ? xf : yf][t];
+                for (int t = 0; t < TAPS; t++)
+                    s += (int)(xf ? patch[(y + APRON) * PP + x + t] : patch[(y + t) * PP + x + APRON]) * tap(xf ? xf : yf, t);
                 v = tu_clip16((s + 32) >> 6, maxVal);
             }
             pred[i] = (int16_t)v;
@@ -483,11 +490,51 @@ extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
         return (int)(nblocks < r ? nblocks : r);
     };
 #define GO(PX) do { \
-        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 8>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
-        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 16>), dim3(resident((const void*)inter_recon_kernel<PX, 16>)), dim3(64), 0, s, a, nblocks); \
-        else hipLaunchKernelGGL((inter_recon_kernel<PX, 32>), dim3(resident((const void*)inter_recon_kernel<PX, 32>)), dim3(64), 0, s, a, nblocks); } while (0)
+        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 8, false>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 16, false>), dim3(resident((const void*)inter_recon_kernel<PX, 16, false>)), dim3(64), 0, s, a, nblocks); \
+        else hipLaunchKernelGGL((inter_recon_kernel<PX, 32, false>), dim3(resident((const void*)inter_recon_kernel<PX, 32, false>)), dim3(64), 0, s, a, nblocks); } while (0)
     if (p->depth == 8) GO(uint8_t); else GO(uint16_t);
 #undef GO
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x265hip_inter_recon_chroma(const x265hip_recon_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->fenc || !p->fref || !p->recon || !p->mv || !p->levels || !p->num_sig || !p->dist)
+    { set_error("inter_recon_chroma: NULL operand"); return X265HIP_EINVAL; }
+    if ((p->width & 63) || (p->height & 63) || p->width <= 0 || p->height <= 0) { set_error("inter_recon_chroma: width/height (luma) must be multiples of 64"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("inter_recon_chroma: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->level < 0 || p->level > 2) { set_error("inter_recon_chroma: level %d (0..2 = 8x8, 16x16, 32x32 luma blocks)", p->level); return X265HIP_EINVAL; }
+    if (p->qp < 0 || p->qp > 51 + 6 * (p->depth - 8)) { set_error("inter_recon_chroma: qp %d out of range", p->qp); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    TuArgs a;
+    a.fenc = (const uint8_t*)p->fenc; a.fencStrideB = (long)p->fenc_stride * bpp;
+    a.fref = (const uint8_t*)p->fref; a.frefStrideB = (long)p->fref_stride * bpp;
+    a.recon = (uint8_t*)p->recon; a.reconStrideB = (long)p->recon_stride * bpp;
+    a.ctusW = p->width / 64; a.depth = p->depth; a.level = p->level;
+    a.mv = (const int2*)p->mv; a.qp = p->qp; a.intraSlice = p->intra_slice;
+    a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
+    const int nctu = a.ctusW * (p->height / 64);
+    const int nblocks = nctu * (64 >> (2 * p->level));
+    hipStream_t s = (hipStream_t)stream;
+    auto resident = [&](const void* fn)
+    {
+        int dev = 0, cus = 256, per = 8;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, 64, 0) != hipSuccess || per < 1) per = 8;
+        const long r = (long)cus * per;
+        return (int)(nblocks < r ? nblocks : r);
+    };
+#define GOC(PX) do { \
+        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 4, true>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 8, true>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
+        else hipLaunchKernelGGL((inter_recon_kernel<PX, 16, true>), dim3(resident((const void*)inter_recon_kernel<PX, 16, true>)), dim3(64), 0, s, a, nblocks); } while (0)
+    if (p->depth == 8) GOC(uint8_t); else GOC(uint16_t);
+#undef GOC
     X265HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -61,6 +61,34 @@ class InterRecon:
                 "dist": int(self.dist.sum().item())}
 
 
+class InterReconChroma:
+    """The same stage for one chroma plane of a 4:2:0 picture (x265hip_inter_recon_chroma; reference predInterChromaPixel,
+    predict.cpp:304-351, + the residual round trip on half-size blocks).  Planes are flat device tensors with `stride` samples per
+    row and sample (0,0) at element `org`; `qp` is the plane's quantiser QP (chroma mapping / offsets applied by the caller)."""
+
+    def __init__(self, nctu, w64, h64, depth, level, qp, device, intra_slice=0):
+        import torch
+        self.nctu, self.w64, self.h64, self.depth, self.level, self.qp, self.intra = nctu, w64, h64, depth, level, qp, intra_slice
+        self.n = 4 << level
+        self.nblk = (32 // self.n) ** 2
+        self.levels = torch.zeros(nctu * self.nblk * self.n * self.n, dtype=torch.int16, device=device)
+        self.num_sig = torch.zeros(nctu * self.nblk, dtype=torch.int32, device=device)
+        self.dist = torch.zeros(nctu * self.nblk, dtype=torch.int64, device=device)
+
+    def run(self, fenc, fref, recon, stride, org, mv, stream=None):
+        es = 1 if self.depth == 8 else 2
+        p = ReconParams()
+        p.depth, p.width, p.height, p.level, p.qp, p.intra_slice = self.depth, self.w64, self.h64, self.level, self.qp, self.intra
+        p.fenc, p.fenc_stride = fenc.data_ptr() + org * es, stride
+        p.fref, p.fref_stride = fref.data_ptr() + org * es, stride
+        p.recon, p.recon_stride = recon.data_ptr() + org * es, stride
+        p.mv, p.levels, p.num_sig, p.dist = mv.data_ptr(), self.levels.data_ptr(), self.num_sig.data_ptr(), self.dist.data_ptr()
+        s = hipabi.current_stream() if stream is None else stream
+        f = hipabi.lib().x265hip_inter_recon_chroma
+        f.argtypes = [ctypes.POINTER(ReconParams), ctypes.c_void_p]
+        hipabi.check(f(ctypes.byref(p), s), "x265hip_inter_recon_chroma")
+
+
 def extend_border(plane, pic: DevicePicture, stream=None):
     """Replicate the picture edges into the margins of `plane` (same geometry as `pic`), on device."""
     from . import frames as F
