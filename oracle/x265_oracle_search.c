@@ -8,7 +8,7 @@
  * including the raster refinement's `tmv << 3` cost quirk at :1196) and FULL (:1397-1445), the choice between the
  * search result and the measured predictor (:1452-1458), the zero-residual shortcut (:1464-1469) and the sub-pel
  * refinement (:1508-1561) with subpelCompare (:1571-1613).  UMH and SEA are not restated.
- * Pinned against the real class through oracle/ref_motion.cpp (tests/test_oracle_me_vs_reference.py).
+ * Pinned against the real class through oracle/ref_motion.cpp (tests/test_oracle_classes_vs_reference.py).
  */
 #ifndef X265HIP_DEPTH
 #error "compile with -DX265HIP_DEPTH=8|10|12"

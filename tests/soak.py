@@ -16,7 +16,7 @@ A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
 import test_gpu_search as TS
 import test_gpu_deblock as TD
 import test_gpu_intra_recon as TI
-from test_oracle_me_vs_reference import sao_case
+from test_oracle_classes_vs_reference import sao_case
 
 dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0

@@ -1,5 +1,5 @@
 """GPU parity: the lookahead P-frame cost estimate (x265hip_lowres_cost) vs the oracle's restatement of
-CostEstimateGroup::estimateFrameCost / estimateCUCost (slicetype.cpp:3189-3388), which tests/test_oracle_me_vs_reference.py pins
+CostEstimateGroup::estimateFrameCost / estimateCUCost (slicetype.cpp:3189-3388), which tests/test_oracle_classes_vs_reference.py pins
 against the real reference classes."""
 import importlib
 import os

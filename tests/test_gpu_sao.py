@@ -1,5 +1,5 @@
 """GPU parity: the SAO pixel passes (x265hip_sao_stats / x265hip_sao_apply) vs the oracle's restatement of SAO::calcSaoStatsCTU and
-SAO::generateLumaOffsets / applyPixelOffsets (sao.cpp:735-917, 572-630, 274-570), which tests/test_oracle_me_vs_reference.py pins
+SAO::generateLumaOffsets / applyPixelOffsets (sao.cpp:735-917, 572-630, 274-570), which tests/test_oracle_classes_vs_reference.py pins
 against the real SAO class."""
 import importlib
 import os
@@ -22,7 +22,7 @@ def _oracle():
 
 
 def _case(depth, width, height, seed):
-    from test_oracle_me_vs_reference import sao_case
+    from test_oracle_classes_vs_reference import sao_case
     return sao_case(depth, width, height, seed)
 
 
@@ -59,7 +59,7 @@ def test_sao_passes_match_oracle(depth, width, height):
 def test_sao_chroma_planes_match_oracle(depth, width, height):
     """The chroma planes of a 4:2:0 picture: 32x32 CTU footprint, plane_offset 2."""
     import torch
-    from test_oracle_me_vs_reference import sao_chroma_case, pad_any
+    from test_oracle_classes_vs_reference import sao_chroma_case, pad_any
     dev = torch.device("cuda:0")
     src, rec, params = sao_chroma_case(depth, width, height, 8)
     cw, ch = width // 2, height // 2

@@ -1,5 +1,5 @@
 """GPU parity: the motion search drivers (x265hip_me_search) vs the oracle's restatement of
-MotionEstimate::motionEstimate (oracle/x265_oracle_search.c), which tests/test_oracle_me_vs_reference.py pins against the
+MotionEstimate::motionEstimate (oracle/x265_oracle_search.c), which tests/test_oracle_classes_vs_reference.py pins against the
 real reference class - so GPU == oracle == x265 for predictor start, DIA / HEX / STAR / FULL and the sub-pel refinement."""
 import importlib
 import os
