@@ -161,6 +161,17 @@ int x265hip_inter_recon(const x265hip_recon_params* p, void* stream);
  * strides, width / height = LUMA size, mv = the luma stage's records, qp = the plane's quantiser QP (chroma QP mapping and PPS /
  * slice offsets applied by the caller, + QP_BD_OFFSET); levels hold (n/2)^2 entries per block. */
 int x265hip_inter_recon_chroma(const x265hip_recon_params* p, void* stream);
+/* Bi-predictive flavour (B pictures, luma): Predict::motionCompensation without weighted prediction (predict.cpp:168-243).  base =
+ * the uni-directional parameters with fref / mv = list 0 (both references share fref_stride); dir = uint8 [ctu][blocks]: 1 = list 0
+ * only, 2 = list 1 only, 3 = predInterLumaShort of both lists combined by addAvg; NULL = all 3. */
+typedef struct x265hip_recon_bi_params
+{
+    x265hip_recon_params base;
+    const void* fref1;
+    const int32_t* mv1;
+    const uint8_t* dir;
+} x265hip_recon_bi_params;
+int x265hip_inter_recon_bi(const x265hip_recon_bi_params* p, void* stream);
 
 /* Picture border extension (reference extendPicBorder, pixel.cpp:1027-1041 = extendRowBorder slot,
  * ipfilter.cpp:59-77, + top/bottom row replication): `pic` points at pixel (0,0) of a plane that has

@@ -122,6 +122,108 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
     return 0;
 }
 
+/* The same stage with bi-prediction (B pictures): per block `dir` = 1 (list 0 only), 2 (list 1 only) or 3 (both): Predict::
+ * motionCompensation (predict.cpp:168-243, no weighted prediction): uni-directional blocks as above; bi-directional blocks take
+ * predInterLumaShort of each list (:267-304: convert_p2s / luma_hps / luma_vps / luma_hps with row extension + luma_vss) and
+ * combine them with addAvg (pixel.cpp: (a + b + offset) >> shift at 14-bit intermediate precision).  mv0 / mv1: the two lists'
+ * records in the sub-pel stage's format; dir: uint8 [ctu][npu] or NULL (all 3). */
+int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, const pixel* fref0, const pixel* fref1, intptr_t frefStride,
+                                      pixel* recon, intptr_t reconStride, int width, int height, int level,
+                                      const int32_t* mv0, const int32_t* mv1, const uint8_t* dir, int qp, int isIntraSlice,
+                                      int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads)
+{
+    static x265hip_EncoderPrimitives prim;
+    static int ready = 0;
+    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    const int ctusW = width / 64, nctu = ctusW * (height / 64);
+    const int n = 8 << level, log2n = 3 + level, npu = (64 / n) * (64 / n);
+    const int puIdx = level == 0 ? X265HIP_LUMA_8x8 : (level == 1 ? X265HIP_LUMA_16x16 : X265HIP_LUMA_32x32);
+    const struct x265hip_PU* pu = &prim.pu[puIdx];
+    const struct x265hip_CU* cu = &prim.cu[log2n - 2];
+    const int per = qp / 6, rem = qp % 6;
+    const int transformShift = 15 - X265HIP_DEPTH - log2n;
+    const int qbits = 14 + per + transformShift;
+    const int add = (isIntraSlice ? 171 : 85) << (qbits - 9);
+    const int dqShift = 20 - 14 - transformShift;
+    const int dqScale = kInvQuantScales[rem] << per;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int ctu = 0; ctu < nctu; ctu++)
+    {
+        const int cx = (ctu % ctusW) * 64, cy = (ctu / ctusW) * 64;
+        pixel pred[64 * 64] __attribute__((aligned(64)));
+        int16_t ps[2][64 * 64] __attribute__((aligned(64)));
+        int16_t immed[64 * (64 + 7)] __attribute__((aligned(64)));
+        int16_t resi[64 * 64] __attribute__((aligned(64)));
+        int16_t coef[32 * 32] __attribute__((aligned(64)));
+        int32_t quantCoeff[32 * 32] __attribute__((aligned(64)));
+        int32_t deltaU[32 * 32];
+        for (int i = 0; i < n * n; i++) quantCoeff[i] = kQuantScales[rem];
+        for (int z = 0; z < npu; z++)
+        {
+            int bx, by;
+            zxy(z, &bx, &by);
+            const int px = cx + bx * n, py = cy + by * n;
+            const int d = dir ? dir[(size_t)ctu * npu + z] : 3;
+            const pixel* fe = fenc + (intptr_t)py * fencStride + px;
+            pixel* rec = recon + (intptr_t)py * reconStride + px;
+            for (int l = 0; l < 2; l++)
+            {
+                if (!(d & (1 << l))) continue;
+                const int32_t packed = (l ? mv1 : mv0)[((size_t)ctu * 85 + kLvlBase[level] + z) * 2 + 1];
+                const int qx = (int16_t)(packed & 0xffff), qy = (int16_t)(packed >> 16);
+                const pixel* src = (l ? fref1 : fref0) + (intptr_t)(py + (qy >> 2)) * frefStride + px + (qx >> 2);
+                const int xf = qx & 3, yf = qy & 3;
+                if (d != 3)
+                {
+                    /* predInterLumaPixel */
+                    if (!(xf | yf)) pu->copy_pp(pred, 64, src, frefStride);
+                    else if (!yf) pu->luma_hpp(src, frefStride, pred, 64, xf);
+                    else if (!xf) pu->luma_vpp(src, frefStride, pred, 64, yf);
+                    else pu->luma_hvpp(src, frefStride, pred, 64, xf, yf);
+                }
+                else
+                {
+                    /* predInterLumaShort */
+                    if (!(xf | yf)) pu->convert_p2s[0](src, frefStride, ps[l], 64);
+                    else if (!yf) pu->luma_hps(src, frefStride, ps[l], 64, xf, 0);
+                    else if (!xf) pu->luma_vps(src, frefStride, ps[l], 64, yf);
+                    else
+                    {
+                        pu->luma_hps(src, frefStride, immed, n, xf, 1);
+                        pu->luma_vss(immed + 3 * n, n, ps[l], 64, yf);
+                    }
+                }
+            }
+            if (d == 3) pu->addAvg[0](ps[0], ps[1], pred, 64, 64, 64);
+            cu->sub_ps(resi, 64, fe, pred, fencStride, 64);
+            cu->dct(resi, coef, 64);
+            int16_t* q = levels + ((size_t)ctu * npu + z) * n * n;
+            const uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
+            numSigOut[(size_t)ctu * npu + z] = numSig;
+            if (numSig)
+            {
+                prim.dequant_normal(q, coef, n * n, dqScale, dqShift);
+                if (numSig == 1 && q[0] != 0)
+                {
+                    const int shift_2nd = 12 - (X265HIP_DEPTH - 8) - 3;
+                    const int dc = ((((coef[0] * (64 >> 6) + 1) >> 1) * (64 >> 3)) + (1 << (shift_2nd - 1))) >> shift_2nd;
+                    cu->blockfill_s[0](resi, 64, (int16_t)dc);
+                }
+                else
+                    cu->idct(coef, resi, 64);
+                cu->add_ps[0](rec, reconStride, pred, resi, 64, 64);
+            }
+            else
+                cu->copy_pp(rec, reconStride, pred, 64);
+            distOut[(size_t)ctu * npu + z] = (uint64_t)cu->sse_pp(fe, fencStride, rec, reconStride);
+        }
+    }
+    return 0;
+}
+
 /* One chroma plane of the same stage for 4:2:0 pictures: Predict::predInterChromaPixel (predict.cpp:304-351: the luma mv in 1/8
  * chroma samples, 4-tap filters - copy_pp / filter_hpp / filter_vpp / filter_hps (+3 rows) + filter_vsp of the chroma table) and
  * the residual round trip on (n/2) x (n/2) blocks (DCT also for 4x4: DST-VII is intra luma only).  fenc / fref / recon: sample

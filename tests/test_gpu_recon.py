@@ -103,3 +103,36 @@ def test_inter_recon_chroma_matches_oracle(depth, level, qp):
         assert np.array_equal(d_o.cpu().numpy().view(dt), erec), f"plane {c}: reconstruction differs"
         assert np.array_equal(st.dist.cpu().numpy().view(np.uint64), edist), f"plane {c}: SSE differs"
         assert (ens > 0).any()
+
+
+@pytest.mark.parametrize("depth,level,qp", [(8, 2, 26), (8, 1, 30), (8, 0, 22), (10, 2, 38), (12, 1, 46)])
+def test_inter_recon_bi_matches_oracle(depth, level, qp):
+    """B pictures: per block list 0, list 1 or both (predInterLumaShort of each list + addAvg), every fractional phase combination."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng([55, depth, level])
+    clip = F.synth_clip(256, 128, 3, depth=depth, seed=64 + level)
+    cur, r0, r1 = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev), P.DevicePicture(clip[2][0], dev)
+    nctu = (cur.w64 // 64) * (cur.h64 // 64)
+    mvs = []
+    for _ in range(2):
+        qx, qy = rng.integers(-30, 31, size=nctu * 85), rng.integers(-30, 31, size=nctu * 85)
+        qx[::4] &= ~3; qy[::3] &= ~3                           # integer / h-only / v-only phases too
+        m = np.zeros((nctu * 85, 2), np.int32)
+        m[:, 1] = (qx & 0xffff) | (qy << 16)
+        mvs.append(m)
+    nblk = (64 >> (3 + level)) ** 2
+    dirs = rng.integers(1, 4, size=nctu * nblk).astype(np.uint8)
+    st = S.InterReconBi(nctu, cur.w64, cur.h64, depth, level, qp, dev)
+    recon = torch.zeros_like(cur.t)
+    st.run(cur, r0, r1, recon, torch.from_numpy(mvs[0].reshape(-1)).to(dev), torch.from_numpy(mvs[1].reshape(-1)).to(dev),
+           dir_flags=torch.from_numpy(dirs).to(dev))
+    torch.cuda.synchronize()
+    O = _oracle()
+    erec, elev, ens, edist = O.inter_recon_bi(depth, cur.host.reshape(-1), cur.stride, cur.org, r0.host.reshape(-1), r1.host.reshape(-1),
+                                              cur.w64, cur.h64, level, mvs[0], mvs[1], qp, dir_flags=dirs)
+    assert np.array_equal(st.num_sig.cpu().numpy().view(np.uint32), ens), "numSig differs"
+    assert np.array_equal(st.levels.cpu().numpy(), elev), "levels differ"
+    assert np.array_equal(recon.cpu().numpy().view(cur.host.dtype).reshape(-1), erec.reshape(-1)), "reconstruction differs"
+    assert np.array_equal(st.dist.cpu().numpy().view(np.uint64), edist), "SSE differs"
+    assert (dirs == 3).any() and (dirs == 1).any() and (dirs == 2).any()

@@ -388,6 +388,124 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs 
         do_block(blockIdx.x);
 }
 
+// Bi-predictive flavour of the inter stage (B pictures; Predict::motionCompensation, predict.cpp:168-243 without weighted prediction):
+// dir 1 / 2 = one list as above, dir 3 = predInterLumaShort of both lists (convert_p2s / luma_hps / luma_vps / luma_hps + luma_vss at
+// 14-bit intermediate precision, :267-304) combined by addAvg.
+struct TuBiArgs
+{
+    TuArgs t;                          // t.fref / t.mv = list 0
+    const uint8_t* fref1; const int2* mv1;
+    const uint8_t* dir;                // [ctu][npu]: 1, 2 or 3; NULL = all 3
+};
+
+template <typename Px, int N>
+__global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBiArgs b, int nblocks)
+{
+    const TuArgs& a = b.t;
+    constexpr int NN = N * N, LOG2N = N == 8 ? 3 : (N == 16 ? 4 : 5), PW = N + 7, PP = N + 8;
+    constexpr int BPP = sizeof(Px);
+    __shared__ int16_t patch[PW * PP];
+    __shared__ int16_t immed[PW * N];
+    __shared__ int16_t pred[NN], ps0[NN], fe[NN], A[NN], B[NN];
+    __shared__ unsigned long long red[4];
+    __shared__ int sNumSig;
+    const int npu = (64 / N) * (64 / N);
+    const int lbase = N == 8 ? 0 : (N == 16 ? 64 : 80);
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int maxVal = (1 << a.depth) - 1, headRoom = 14 - a.depth;
+    TuOpsFor<N, false> ops;
+    ops.init(tid & 63);
+    auto do_block = [&](const int blk)
+    {
+        const int ctu = blk / npu, z = blk - ctu * npu;
+        const int bxz = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), byz = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+        const int px = (ctu % a.ctusW) * 64 + bxz * N, py = (ctu / a.ctusW) * 64 + byz * N;
+        const int d = b.dir ? b.dir[blk] : 3;
+        {
+            const Px* f = reinterpret_cast<const Px*>(a.fenc + (long)py * a.fencStrideB) + px;
+            const long fst = a.fencStrideB / BPP;
+            for (int i = tid; i < NN; i += nth) { const int y = i >> LOG2N, x = i & (N - 1); fe[i] = (int16_t)f[y * fst + x]; }
+            if (tid == 0) sNumSig = 0;
+        }
+        for (int l = 0; l < 2; l++)
+        {
+            if (!(d & (1 << l))) continue;                              // uniform over the workgroup
+            const int packed = (l ? b.mv1 : a.mv)[(size_t)ctu * 85 + lbase + z].y;
+            const int qx = (int16_t)(packed & 0xffff), qy = (int16_t)(packed >> 16);
+            const int xf = qx & 3, yf = qy & 3;
+            __syncthreads();                                            // the patch of the other list is no longer read
+            {
+                const uint8_t* plane = l ? b.fref1 : a.fref;
+                const Px* r = reinterpret_cast<const Px*>(plane + (long)(py + (qy >> 2) - 3) * a.frefStrideB) + (px + (qx >> 2) - 3);
+                const long rst = a.frefStrideB / BPP;
+                for (int i = tid; i < PW * PW; i += nth) { const int y = i / PW, x = i - y * PW; patch[y * PP + x] = (int16_t)r[y * rst + x]; }
+            }
+            __syncthreads();
+            int16_t* out = (d == 3 && l == 0) ? ps0 : pred;            // list 0's short prediction waits in ps0
+            const bool shortOut = d == 3;
+            const int shiftPS = 6 - headRoom, offPS = -(8192 << shiftPS);
+            if (xf && yf)
+            {
+                for (int i = tid; i < PW * N; i += nth)
+                {
+                    const int y = i >> LOG2N, x = i & (N - 1);
+                    int s = 0;
+#pragma unroll
+                    for (int t = 0; t < 8; t++) s += (int)patch[y * PP + x + t] * kTuTaps[xf][t];
+                    immed[i] = (int16_t)((s + offPS) >> shiftPS);
+                }
+                __syncthreads();
+                const int shiftSP = 6 + headRoom, offSP = (1 << (shiftSP - 1)) + (8192 << 6);
+                for (int i = tid; i < NN; i += nth)
+                {
+                    const int y = i >> LOG2N, x = i & (N - 1);
+                    int s = 0;
+#pragma unroll
+                    for (int t = 0; t < 8; t++) s += (int)immed[(y + t) * N + x] * kTuTaps[yf][t];
+                    out[i] = shortOut ? (int16_t)(s >> 6) : (int16_t)tu_clip16((s + offSP) >> shiftSP, maxVal);      // luma_vss : luma_vsp
+                }
+            }
+            else
+            {
+                for (int i = tid; i < NN; i += nth)
+                {
+                    const int y = i >> LOG2N, x = i & (N - 1);
+                    int v;
+                    if (!(xf | yf))
+                    {
+                        const int c = patch[(y + 3) * PP + x + 3];
+                        v = shortOut ? (int16_t)((c << headRoom) - 8192) : c;                                         // convert_p2s : copy_pp
+                    }
+                    else
+                    {
+                        int s = 0;
+#pragma unroll
+                        for (int t = 0; t < 8; t++)
+                            s += (int)(xf ? patch[(y + 3) * PP + x + t] : patch[(y + t) * PP + x + 3]) * kTuTaps[xf ? xf : yf][t];
+                        v = shortOut ? (int16_t)((s + offPS) >> shiftPS) : tu_clip16((s + 32) >> 6, maxVal);           // luma_hps / vps : hpp / vpp
+                    }
+                    out[i] = (int16_t)v;
+                }
+            }
+        }
+        __syncthreads();
+        if (d == 3)
+        {
+            const int shiftAvg = 15 - a.depth, offAvg = (1 << (shiftAvg - 1)) + 2 * 8192;                              // addAvg
+            for (int i = tid; i < NN; i += nth) pred[i] = (int16_t)clip3(0, maxVal, ((int)ps0[i] + (int)pred[i] + offAvg) >> shiftAvg);
+            __syncthreads();
+        }
+        tu_chain<Px, N, false>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
+                               a.levels + ((size_t)ctu * npu + z) * NN, &a.numSig[(size_t)ctu * npu + z], &a.dist[(size_t)ctu * npu + z],
+                               reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP);
+        __syncthreads();
+    };
+    if constexpr (N >= 16)
+        for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) do_block(blk);
+    else
+        do_block(blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Intra TU candidate set (Search::codeIntraLumaQT's pixel work, search.cpp:335-373): one workgroup per (TU, mode) job -
 // Predict::predIntraLumaAng (predict.cpp:579-588: filtered neighbours per g_intraFilterFlags & size, edge filter for
@@ -495,6 +613,49 @@ extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
         else hipLaunchKernelGGL((inter_recon_kernel<PX, 32, false>), dim3(resident((const void*)inter_recon_kernel<PX, 32, false>)), dim3(64), 0, s, a, nblocks); } while (0)
     if (p->depth == 8) GO(uint8_t); else GO(uint16_t);
 #undef GO
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x265hip_inter_recon_bi(const x265hip_recon_bi_params* q, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!q) { set_error("inter_recon_bi: NULL operand"); return X265HIP_EINVAL; }
+    const x265hip_recon_params* p = &q->base;
+    if (!p->fenc || !p->fref || !q->fref1 || !p->recon || !p->mv || !q->mv1 || !p->levels || !p->num_sig || !p->dist)
+    { set_error("inter_recon_bi: NULL operand"); return X265HIP_EINVAL; }
+    if ((p->width & 63) || (p->height & 63) || p->width <= 0 || p->height <= 0) { set_error("inter_recon_bi: width/height must be multiples of 64"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("inter_recon_bi: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->level < 0 || p->level > 2) { set_error("inter_recon_bi: level %d (0..2 = 8x8, 16x16, 32x32)", p->level); return X265HIP_EINVAL; }
+    if (p->qp < 0 || p->qp > 51 + 6 * (p->depth - 8)) { set_error("inter_recon_bi: qp %d out of range", p->qp); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    TuBiArgs b;
+    TuArgs& a = b.t;
+    a.fenc = (const uint8_t*)p->fenc; a.fencStrideB = (long)p->fenc_stride * bpp;
+    a.fref = (const uint8_t*)p->fref; a.frefStrideB = (long)p->fref_stride * bpp;
+    a.recon = (uint8_t*)p->recon; a.reconStrideB = (long)p->recon_stride * bpp;
+    a.ctusW = p->width / 64; a.depth = p->depth; a.level = p->level;
+    a.mv = (const int2*)p->mv; a.qp = p->qp; a.intraSlice = p->intra_slice;
+    a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
+    b.fref1 = (const uint8_t*)q->fref1; b.mv1 = (const int2*)q->mv1; b.dir = q->dir;
+    const int nblocks = a.ctusW * (p->height / 64) * (64 >> (2 * p->level));
+    hipStream_t s = (hipStream_t)stream;
+    auto resident = [&](const void* fn)
+    {
+        int dev = 0, cus = 256, per = 8;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, 64, 0) != hipSuccess || per < 1) per = 8;
+        const long r = (long)cus * per;
+        return (int)(nblocks < r ? nblocks : r);
+    };
+#define GOB(PX) do { \
+        if (p->level == 0) hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 8>), dim3(nblocks), dim3(64), 0, s, b, nblocks); \
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 16>), dim3(resident((const void*)inter_recon_bi_kernel<PX, 16>)), dim3(64), 0, s, b, nblocks); \
+        else hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 32>), dim3(resident((const void*)inter_recon_bi_kernel<PX, 32>)), dim3(64), 0, s, b, nblocks); } while (0)
+    if (p->depth == 8) GOB(uint8_t); else GOB(uint16_t);
+#undef GOB
     X265HIP_TRY(hipGetLastError());
     return 0;
 }

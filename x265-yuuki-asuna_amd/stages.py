@@ -61,6 +61,32 @@ class InterRecon:
                 "dist": int(self.dist.sum().item())}
 
 
+class ReconBiParams(ctypes.Structure):
+    """x265hip_recon_bi_params (include/x265hip.h)."""
+    _fields_ = [("base", ReconParams), ("fref1", ctypes.c_void_p), ("mv1", ctypes.c_void_p), ("dir", ctypes.c_void_p)]
+
+
+class InterReconBi(InterRecon):
+    """The inter TU stage for B pictures (x265hip_inter_recon_bi): per block list 0, list 1 or the average of both
+    (predInterLumaShort + addAvg, predict.cpp:168-304)."""
+
+    def run(self, cur: DevicePicture, ref0: DevicePicture, ref1: DevicePicture, recon_plane, mv0, mv1, dir_flags=None, stream=None):
+        es = 1 if self.depth == 8 else 2
+        q = ReconBiParams()
+        p = q.base
+        p.depth, p.width, p.height, p.level, p.qp, p.intra_slice = self.depth, self.w64, self.h64, self.level, self.qp, self.intra
+        p.fenc, p.fenc_stride = cur.t.data_ptr() + cur.org * es, cur.stride
+        p.fref, p.fref_stride = ref0.t.data_ptr() + ref0.org * es, ref0.stride
+        p.recon, p.recon_stride = recon_plane.data_ptr() + cur.org * es, cur.stride
+        p.mv, p.levels, p.num_sig, p.dist = mv0.data_ptr(), self.levels.data_ptr(), self.num_sig.data_ptr(), self.dist.data_ptr()
+        q.fref1, q.mv1 = ref1.t.data_ptr() + ref1.org * es, mv1.data_ptr()
+        q.dir = None if dir_flags is None else dir_flags.data_ptr()
+        s = hipabi.current_stream() if stream is None else stream
+        f = hipabi.lib().x265hip_inter_recon_bi
+        f.argtypes = [ctypes.POINTER(ReconBiParams), ctypes.c_void_p]
+        hipabi.check(f(ctypes.byref(q), s), "x265hip_inter_recon_bi")
+
+
 class InterReconChroma:
     """The same stage for one chroma plane of a 4:2:0 picture (x265hip_inter_recon_chroma; reference predInterChromaPixel,
     predict.cpp:304-351, + the residual round trip on half-size blocks).  Planes are flat device tensors with `stride` samples per
