@@ -265,6 +265,12 @@ typedef struct x265hip_deblock_bs_params
     const int32_t* mv; const uint32_t* num_sig;
     uint8_t* bs_ver; uint8_t* bs_hor;
     const uint8_t* intra;          /* optional uint8 [ctu][blocks]: non-zero = intra CU, its edges get Bs 2 (deblock.cpp:198-199) */
+    /* Several reference pictures / B pictures (deblock.cpp:217-247); all zero / NULL = one list-0 picture for every block.
+     * ref0 / ref1: optional int8 [ctu][blocks], the reference PICTURE id of the block's list-0 / list-1 prediction (equal ids =
+     * the same picture, whichever list it came from; -1 = list unused, its mv reads as zero).  mv1: list-1 records laid out like
+     * mv.  slice_b != 0 selects the B-picture comparison of (ref0, ref1) x (mv, mv1). */
+    int slice_b;
+    const int32_t* mv1; const int8_t* ref0; const int8_t* ref1;
 } x265hip_deblock_bs_params;
 int x265hip_deblock_bs_inter(const x265hip_deblock_bs_params* p, void* stream);
 typedef struct x265hip_deblock_params

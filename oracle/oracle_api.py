@@ -162,6 +162,25 @@ def deblock_bs_inter(depth, width, height, level, mv, num_sig, avx2=False, intra
     return bv, bh
 
 
+def deblock_bs_b(depth, width, height, level, mv0, mv1, ref0, ref1, num_sig, slice_b=True, intra=None, avx2=False):
+    """CPU restatement of the whole of getBoundaryStrength (deblock.cpp:191-247): per block a reference picture id per list
+    (int8, -1 = list unused) and an mv record array per list; slice_b selects the B-picture comparison.  Returns (bs_ver, bs_hor)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_deblock_bs_b_d{depth}")
+    bv = np.zeros((height // 4) * (width // 8), np.uint8)
+    bh = np.zeros((height // 8) * (width // 4), np.uint8)
+    m0 = np.ascontiguousarray(mv0, dtype=np.int32)
+    m1 = None if mv1 is None else np.ascontiguousarray(mv1, dtype=np.int32)
+    r0 = None if ref0 is None else np.ascontiguousarray(ref0, dtype=np.int8)
+    r1 = None if ref1 is None else np.ascontiguousarray(ref1, dtype=np.int8)
+    ns = np.ascontiguousarray(num_sig, dtype=np.uint32)
+    it = None if intra is None else np.ascontiguousarray(intra, dtype=np.uint8)
+    ptr = lambda a: None if a is None else a.ctypes.data
+    fn.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 8
+    fn(width, height, level, int(bool(slice_b)), ptr(m0), ptr(m1), ptr(r0), ptr(r1), ptr(ns), ptr(it), bv.ctypes.data, bh.ctypes.data)
+    return bv, bh
+
+
 def deblock_chroma(depth, cb, cr, stride_c, org_c, width, height, bs_ver, bs_hor, qp, qp_map=None, cb_qp_offset=0, cr_qp_offset=0,
                    tc_offset_div2=0, avx2=False):
     """CPU restatement of edgeFilterChroma over the two chroma planes of a 4:2:0 picture (width / height = luma size); returns the

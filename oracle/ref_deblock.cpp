@@ -29,6 +29,9 @@ extern "C" {
  * level's blocks in z-order at offsets 0 / 64 / 80); numSig: uint32 [numCtu][blocks per CTU].  Returns 0 on success. */
 int x265ref_deblock420(void* recPlane, void* cbPlane, void* crPlane, int width, int height, int level, const int32_t* mv,
                        const uint32_t* numSig, const uint8_t* intra, int qp, int betaOffsetDiv2, int tcOffsetDiv2, int cbQpOffset, int crQpOffset);
+int x265ref_deblock_b(void* recPlane, int width, int height, int level, int sliceB, const int32_t* mv0, const int32_t* mv1,
+                      const int8_t* ref0, const int8_t* ref1, const uint32_t* numSig, const uint8_t* intra, int qp,
+                      int betaOffsetDiv2, int tcOffsetDiv2);
 
 int x265ref_deblock(void* recPlane, int width, int height, int level, const int32_t* mv, const uint32_t* numSig, int qp,
                     int betaOffsetDiv2, int tcOffsetDiv2)
@@ -39,8 +42,29 @@ int x265ref_deblock(void* recPlane, int width, int height, int level, const int3
 /* The general form: cbPlane / crPlane = UNPADDED (width / 2) x (height / 2) chroma planes of a 4:2:0 picture (NULL: luma only),
  * filtered in place; intra: optional uint8 [numCtu][blocks per CTU], non-zero = the block is an intra CU (Bs 2 on its edges, the
  * only edges the chroma filter touches); cbQpOffset / crQpOffset = pps->chromaQpOffset[]. */
+static int deblock_core(void* recPlane, void* cbPlane, void* crPlane, int width, int height, int level, const int32_t* mv,
+                        const uint32_t* numSig, const uint8_t* intra, int qp, int betaOffsetDiv2, int tcOffsetDiv2, int cbQpOffset, int crQpOffset,
+                        int sliceB, const int32_t* mv1, const int8_t* ref0, const int8_t* ref1);
+
 int x265ref_deblock420(void* recPlane, void* cbPlane, void* crPlane, int width, int height, int level, const int32_t* mv,
                        const uint32_t* numSig, const uint8_t* intra, int qp, int betaOffsetDiv2, int tcOffsetDiv2, int cbQpOffset, int crQpOffset)
+{
+    return deblock_core(recPlane, cbPlane, crPlane, width, height, level, mv, numSig, intra, qp, betaOffsetDiv2, tcOffsetDiv2, cbQpOffset, crQpOffset,
+                        0, NULL, NULL, NULL);
+}
+
+/* Pictures with several references / B pictures (luma): ref0 / ref1 = int8 [numCtu][blocks] reference PICTURE ids (0..3, -1 = list
+ * unused; equal ids denote the same picture in either list), mv1 = list-1 records; sliceB selects B_SLICE. */
+int x265ref_deblock_b(void* recPlane, int width, int height, int level, int sliceB, const int32_t* mv0, const int32_t* mv1,
+                      const int8_t* ref0, const int8_t* ref1, const uint32_t* numSig, const uint8_t* intra, int qp,
+                      int betaOffsetDiv2, int tcOffsetDiv2)
+{
+    return deblock_core(recPlane, NULL, NULL, width, height, level, mv0, numSig, intra, qp, betaOffsetDiv2, tcOffsetDiv2, 0, 0, sliceB, mv1, ref0, ref1);
+}
+
+static int deblock_core(void* recPlane, void* cbPlane, void* crPlane, int width, int height, int level, const int32_t* mv,
+                        const uint32_t* numSig, const uint8_t* intra, int qp, int betaOffsetDiv2, int tcOffsetDiv2, int cbQpOffset, int crQpOffset,
+                        int sliceB, const int32_t* mv1, const int8_t* ref0, const int8_t* ref1)
 {
     static bool tableReady = false;
     if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
@@ -88,7 +112,7 @@ int x265ref_deblock420(void* recPlane, void* cbPlane, void* crPlane, int width, 
             for (int y = 0; y < ch; y++)
                 memcpy(recon.m_picOrg[1 + c] + (intptr_t)y * recon.m_strideC, (const pixel*)chroma[c] + (size_t)y * cw, sizeof(pixel) * cw);
 
-    Frame frame, refFrame;
+    Frame frame, refFrames[4];
     frame.m_param = param;
     frame.m_reconPic = &recon;
     FrameData encData;
@@ -96,8 +120,9 @@ int x265ref_deblock420(void* recPlane, void* cbPlane, void* crPlane, int width, 
     slice.m_sps = &sps;
     slice.m_pps = &pps;
     slice.m_param = param;
-    slice.m_sliceType = P_SLICE;
-    slice.m_refFrameList[0][0] = &refFrame;
+    slice.m_sliceType = sliceB ? B_SLICE : P_SLICE;
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < 4; i++) slice.m_refFrameList[l][i] = &refFrames[i];       /* refIdx = picture id in both lists */
     encData.m_param = param;
     encData.m_slice = &slice;
     encData.m_reconPic = &recon;
@@ -126,7 +151,13 @@ int x265ref_deblock420(void* recPlane, void* cbPlane, void* crPlane, int width, 
             ctus[a].m_tuDepth[p] = 0;
             ctus[a].m_cbf[0][p] = numSig[(size_t)a * npu + z] ? 1 : 0;
             ctus[a].m_mv[0][p] = MV((int16_t)(pk & 0xffff), (int16_t)(pk >> 16));
-            ctus[a].m_refIdx[0][p] = 0;
+            ctus[a].m_refIdx[0][p] = ref0 ? ref0[(size_t)a * npu + z] : 0;
+            if (mv1)
+            {
+                const int32_t pk1 = mv1[((size_t)a * 85 + lbase + z) * 2 + 1];
+                ctus[a].m_mv[1][p] = MV((int16_t)(pk1 & 0xffff), (int16_t)(pk1 >> 16));
+            }
+            ctus[a].m_refIdx[1][p] = ref1 ? ref1[(size_t)a * npu + z] : -1;
             ctus[a].m_qp[p] = (int8_t)qp;
         }
     }

@@ -160,6 +160,69 @@ void EXPORT(x265oracle_deblock_luma)(pixel* rec, intptr_t stride, int width, int
         }
 }
 
+/* Deblock::getBoundaryStrength in full (deblock.cpp:191-247): pictures with several references and B pictures.  Per block and list
+ * a reference PICTURE id (int8, -1 = list unused; equal ids = the same picture, whichever list they come from) and an mv record
+ * array per list; intra as above.  P logic (isInterP on both sides): Bs 1 when the list-0 pictures differ or the mvs differ by >= 4;
+ * B logic: the four-way comparison of (ref0, ref1) x (mv0, mv1) of :231-246. */
+static int bs_motion(int sliceB, int rp0, int rp1, int rq0, int rq1, const int* mp0, const int* mp1, const int* mq0, const int* mq1)
+{
+    static const int zero[2] = { 0, 0 };
+    if (rp0 < 0) mp0 = zero;
+    if (rq0 < 0) mq0 = zero;
+#define FAR(A, B) (iabs((A)[0] - (B)[0]) >= 4 || iabs((A)[1] - (B)[1]) >= 4)
+    if (!sliceB) return (rp0 != rq0 || FAR(mq0, mp0)) ? 1 : 0;
+    if (rp1 < 0) mp1 = zero;
+    if (rq1 < 0) mq1 = zero;
+    if ((rp0 == rq0 && rp1 == rq1) || (rp0 == rq1 && rp1 == rq0))
+    {
+        if (rp0 != rp1)
+        {
+            if (rp0 == rq0) return (FAR(mq0, mp0) || FAR(mq1, mp1)) ? 1 : 0;
+            return (FAR(mq1, mp0) || FAR(mq0, mp1)) ? 1 : 0;
+        }
+        return ((FAR(mq0, mp0) || FAR(mq1, mp1)) && (FAR(mq1, mp0) || FAR(mq0, mp1))) ? 1 : 0;
+    }
+    return 1;
+#undef FAR
+}
+
+void EXPORT(x265oracle_deblock_bs_b)(int width, int height, int level, int sliceB, const int32_t* mv0, const int32_t* mv1,
+                                     const int8_t* ref0, const int8_t* ref1, const uint32_t* numSig, const uint8_t* intra,
+                                     uint8_t* bsVer, uint8_t* bsHor)
+{
+    const int n = 8 << level, npu = (64 / n) * (64 / n), ctusW = width / 64;
+    const int lbase = level == 0 ? 0 : (level == 1 ? 64 : (level == 2 ? 80 : 84));
+    memset(bsVer, 0, (size_t)(height / 4) * (width / 8));
+    memset(bsHor, 0, (size_t)(height / 8) * (width / 4));
+    for (int dir = 0; dir < 2; dir++)
+        for (int y = dir ? n : 0; y < height; y += dir ? n : 4)
+            for (int x = dir ? 0 : n; x < width; x += dir ? 4 : n)
+            {
+                int blk[2], m0[2][2], m1[2][2], r0[2], r1[2], cbf[2], in[2];
+                for (int s2 = 0; s2 < 2; s2++)                              /* s2 = 0: P side, 1: Q side */
+                {
+                    const int xx = dir ? x : x - 1 + s2, yy = dir ? y - 1 + s2 : y;
+                    const int ctu = (yy / 64) * ctusW + xx / 64, bx = (xx & 63) / n, by = (yy & 63) / n;
+                    int z = 0;
+                    for (int b = 0; b < 3; b++) z |= (((bx >> b) & 1) << (2 * b)) | (((by >> b) & 1) << (2 * b + 1));
+                    blk[s2] = ctu * npu + z;
+                    const int32_t p0 = mv0[((size_t)ctu * 85 + lbase + z) * 2 + 1], p1 = mv1 ? mv1[((size_t)ctu * 85 + lbase + z) * 2 + 1] : 0;
+                    m0[s2][0] = (int16_t)(p0 & 0xffff); m0[s2][1] = (int16_t)(p0 >> 16);
+                    m1[s2][0] = (int16_t)(p1 & 0xffff); m1[s2][1] = (int16_t)(p1 >> 16);
+                    r0[s2] = ref0 ? ref0[blk[s2]] : 0;
+                    r1[s2] = ref1 ? ref1[blk[s2]] : -1;
+                    cbf[s2] = numSig[blk[s2]] != 0;
+                    in[s2] = intra && intra[blk[s2]];
+                }
+                int bs;
+                if (in[0] || in[1]) bs = 2;
+                else if (cbf[0] || cbf[1]) bs = 1;
+                else bs = bs_motion(sliceB, r0[0], r1[0], r0[1], r1[1], m0[0], m1[0], m0[1], m1[1]);
+                if (dir) bsHor[(size_t)(y / 8) * (width / 4) + x / 4] = (uint8_t)bs;
+                else bsVer[(size_t)(y / 4) * (width / 8) + x / 8] = (uint8_t)bs;
+            }
+}
+
 /* Deblock::edgeFilterChroma (deblock.cpp:417-497) for the two chroma planes of a 4:2:0 picture: only edges with Bs 2 (an intra
  * block on either side) on the 8-sample chroma grid (luma positions that are multiples of 16, deblock.cpp:104-113) are filtered,
  * 4 chroma lines per unit with the Bs of the luma unit they start at; tc from the mean QP + the plane's PPS offset through the

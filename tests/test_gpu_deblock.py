@@ -136,3 +136,56 @@ def test_deblock_with_intra_blocks_and_chroma(depth, level, qp, cq):
     assert np.array_equal(rec.cpu().numpy().view(dt), exp_y), "luma differs"
     assert np.array_equal(d_cb.cpu().numpy().view(dt), exp_cb) and np.array_equal(d_cr.cpu().numpy().view(dt), exp_cr), "chroma differs"
     assert np.count_nonzero(exp_cb != planes[0]) > 20
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3])
+@pytest.mark.parametrize("slice_b,lists", [(1, "both"), (1, "noref1"), (0, "both"), (0, "ref0only"), (1, "none")])
+def test_boundary_strengths_multi_reference_and_b_pictures(level, slice_b, lists):
+    """getBoundaryStrength in full (deblock.cpp:217-247): reference picture ids per list, list-1 mvs, the B-picture four-way
+    comparison - random coherent motion fields over a 1024x576 picture against the oracle restatement (pinned against the real
+    Deblock class in tests/test_oracle_classes_vs_reference.py), every optional operand combination of the ABI."""
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    w, h = 1024, 576
+    nctu, npu = (w // 64) * (h // 64), (64 >> (3 + level)) ** 2
+    rng = np.random.default_rng([47, level, slice_b, len(lists)])
+
+    def field():
+        m = np.zeros((nctu * 85, 2), np.int32)
+        x = rng.integers(-3, 4, size=nctu * 85) * 8 + rng.integers(-4, 5, size=nctu * 85) * (rng.random(nctu * 85) < 0.5)
+        y = rng.integers(-2, 3, size=nctu * 85) * 8 + rng.integers(-4, 5, size=nctu * 85) * (rng.random(nctu * 85) < 0.5)
+        m[:, 0] = rng.integers(0, 1 << 20, size=nctu * 85)
+        m[:, 1] = (x & 0xffff) | (y << 16)
+        return m
+
+    mv0, mv1 = field(), field()
+    same = rng.random(nctu * 85) < 0.4
+    mv1[same] = mv0[same]
+    combos = np.array([(0, 1), (1, 0), (0, 0), (0, -1), (-1, 0), (1, 1), (2, 1), (-1, 2)], dtype=np.int8)
+    pick = rng.choice(len(combos), size=(nctu, npu), p=[0.3, 0.2, 0.2, 0.1, 0.05, 0.05, 0.05, 0.05])
+    ref0, ref1 = np.ascontiguousarray(combos[pick, 0]), np.ascontiguousarray(combos[pick, 1])
+    if not slice_b:
+        ref0 = np.maximum(ref0, 0)
+    if lists == "noref1":
+        ref1 = None
+    elif lists == "ref0only":
+        ref1, mv1 = None, None
+    elif lists == "none":
+        ref0, ref1, mv1 = None, None, None
+    ns = (rng.random((nctu, npu)) < 0.1).astype(np.uint32) * 3
+    intra = (rng.random((nctu, npu)) < 0.05).astype(np.uint8)
+    bv, bh = O.deblock_bs_b(8, w, h, level, mv0, mv1, ref0, ref1, ns, slice_b=slice_b, intra=intra)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)
+    d_bv = torch.full((bv.size,), 9, dtype=torch.uint8, device=dev)
+    d_bh = torch.full((bh.size,), 9, dtype=torch.uint8, device=dev)
+    A.deblock_bs_inter(w, h, level, t(mv0), t(ns), d_bv, d_bh, intra=t(intra), slice_b=slice_b, mv1=t(mv1), ref0=t(ref0), ref1=t(ref1))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_bv.cpu().numpy(), bv), f"vertical: {np.count_nonzero(d_bv.cpu().numpy() != bv)} units differ"
+    assert np.array_equal(d_bh.cpu().numpy(), bh), f"horizontal: {np.count_nonzero(d_bh.cpu().numpy() != bh)} units differ"
+    if level < 3:
+        both = np.concatenate([bv, bh])
+        assert (both == 0).any() and (both == 1).any() and (both == 2).any()
+    if lists == "none" and not slice_b:
+        pv, ph = O.deblock_bs_inter(8, w, h, level, mv0, ns, intra=intra)
+        assert np.array_equal(pv, bv) and np.array_equal(ph, bh)          # the single-reference form is the special case

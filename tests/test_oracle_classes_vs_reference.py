@@ -392,6 +392,65 @@ def test_deblock_with_intra_blocks_and_chroma_equals_reference_class(depth, leve
         assert np.count_nonzero(e2 != chroma[c]) > 20
 
 
+def motion_field_case(depth, level, seed, qp):
+    """A reconstruction from the oracle chain plus a random two-list motion field for it: list-1 mvs a small perturbation of the
+    list-0 ones (so both sides of the 4-quarter-sample threshold occur), reference picture ids in -1..2 per list (at least one list
+    used), sparse coded flags so that most edges are decided by the motion comparison."""
+    import oracle_api as O
+    R, subme = 8, 2
+    clip = F.synth_clip(192, 128, 2, depth=depth, seed=seed)
+    cur, stride, org, w64, h64 = F.pad_plane(clip[1][0])
+    ref = F.pad_plane(clip[0][0])[0]
+    nctu = (w64 // 64) * (h64 // 64)
+    cost = F.mv_cost_table(R)
+    cqt, qoff = F.qpel_cost_table(R)
+    _, best = O.me_fullsearch(depth, cur, stride, org, ref, stride, org, w64, h64, R, 0, nctu, cost, cost, want_surf=False)
+    mv0 = O.subpel_refine(depth, cur, stride, org, ref, stride, org, w64, h64, R, 0, nctu, best, cqt, qoff, subme)
+    rec, _, ns, _ = O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv0, qp + 6 * (depth - 8))
+    rng = np.random.default_rng([43, depth, level, seed])
+    npu = (64 >> (3 + level)) ** 2
+    mv0 = np.ascontiguousarray(mv0, dtype=np.int32).reshape(-1, 2).copy()
+    # neighbouring blocks often share a vector in real pictures: quantise the field so that equal / near-equal pairs are common
+    qx = ((mv0[:, 1] << 16 >> 16) // 8) * 8
+    qy = ((mv0[:, 1] >> 16) // 8) * 8
+    d = rng.integers(-4, 5, size=(len(mv0), 2))
+    mv1 = mv0.copy()
+    mv0[:, 1] = (qx & 0xffff) | (qy << 16)
+    mv1[:, 1] = ((qx + d[:, 0]) & 0xffff) | ((qy + d[:, 1]) << 16)
+    combos = np.array([(0, 1), (1, 0), (0, 0), (0, -1), (-1, 0), (1, 1), (2, 1), (-1, 2)], dtype=np.int8)   # few pictures: every branch of :231-246 occurs
+    pick = rng.choice(len(combos), size=(nctu, npu), p=[0.3, 0.2, 0.2, 0.1, 0.05, 0.05, 0.05, 0.05])
+    ref0, ref1 = np.ascontiguousarray(combos[pick, 0]), np.ascontiguousarray(combos[pick, 1])
+    ns = (np.asarray(ns).reshape(nctu, npu) * (rng.random((nctu, npu)) < 0.15)).astype(np.uint32)
+    intra = (rng.random((nctu, npu)) < 0.05).astype(np.uint8)
+    return rec, stride, org, w64, h64, mv0, mv1, ref0, ref1, ns, intra
+
+
+@pytest.mark.parametrize("depth,level,slice_b,qp", [(8, 0, 1, 30), (8, 1, 1, 34), (8, 2, 1, 28), (8, 0, 0, 32), (8, 1, 0, 30), (10, 0, 1, 33), (10, 1, 0, 36)])
+def test_deblock_b_picture_boundary_strengths_equal_reference_class(depth, level, slice_b, qp):
+    """getBoundaryStrength in full (deblock.cpp:217-247): several reference pictures per list and the B-picture four-way comparison
+    of (ref0, ref1) x (mv0, mv1) - the restatement's Bs maps + luma filter against the real Deblock::deblockCTU with B_SLICE /
+    P_SLICE, distinct Frame objects per picture id, m_refIdx / m_mv of both lists filled."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_deblock_b"):
+        pytest.skip("oracle/_ref predates x265ref_deblock_b")
+    rec, stride, org, w64, h64, mv0, mv1, ref0, ref1, ns, intra = motion_field_case(depth, level, 81 + level, qp)
+    if not slice_b:
+        ref0 = np.maximum(ref0, 0)                      # P pictures: every inter block uses list 0
+    bv, bh = O.deblock_bs_b(depth, w64, h64, level, mv0, mv1, ref0, ref1, ns, slice_b=slice_b, intra=intra)
+    both = np.concatenate([bv, bh])
+    assert (both == 0).any() and (both == 1).any() and (both == 2).any()
+    exp = O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, qp)
+    got = np.ascontiguousarray(rec.reshape(-1)).copy()
+    lib.x265ref_deblock_b.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3
+    assert lib.x265ref_deblock_b(got.ctypes.data, w64, h64, level, slice_b, mv0.ctypes.data, mv1.ctypes.data, ref0.ctypes.data, ref1.ctypes.data,
+                                 ns.ctypes.data, intra.ctypes.data, qp, 0, 0) == 0
+    assert np.array_equal(got, exp.reshape(-1)), f"{np.count_nonzero(got != exp.reshape(-1))} samples differ"
+    # the motion comparison matters: the P-only single-reference rule gives different maps on this field
+    pv, ph = O.deblock_bs_inter(depth, w64, h64, level, mv0, ns, intra=intra)
+    assert not (np.array_equal(pv, bv) and np.array_equal(ph, bh))
+
+
 @pytest.mark.parametrize("depth,n,qp,islice", [(8, 4, 24, 1), (8, 4, 30, 0), (8, 8, 27, 1), (8, 16, 33, 0), (8, 32, 22, 1), (8, 32, 45, 0),
                                                (10, 4, 36, 1), (10, 16, 40, 1), (10, 32, 30, 0)])
 def test_intra_tu_round_trip_equals_reference_quant_class(depth, n, qp, islice):

@@ -22,21 +22,52 @@ __constant__ unsigned char kDbBeta[52] = {
 
 struct BsArgs
 {
-    int width, height, level;
-    const int2* mv; const uint32_t* numSig; const uint8_t* intra;
+    int width, height, level, sliceB;
+    const int2* mv; const int2* mv1; const int8_t* ref0; const int8_t* ref1;
+    const uint32_t* numSig; const uint8_t* intra;
     uint8_t* bsVer; uint8_t* bsHor;
 };
 
-__device__ __forceinline__ void db_block(const BsArgs& a, int x, int y, int& mvx, int& mvy, int& cbf)
+// what getBoundaryStrength reads of the block on one side of an edge
+struct BsSide
+{
+    int mx0, my0, mx1, my1;     // list-0 / list-1 mv, quarter samples (zero when the list is unused, deblock.cpp:213-214,225-226)
+    int r0, r1;                 // reference picture id per list, -1 = unused
+    int flags;                  // bit 0: coded coefficients, bit 1: intra CU (Bs 2 on its edges, deblock.cpp:198-199)
+};
+
+__device__ __forceinline__ BsSide db_block(const BsArgs& a, int x, int y)
 {
     const int n = 8 << a.level, npu = 64 >> (2 * a.level), ctusW = a.width >> 6;
     const int lbase = a.level == 0 ? 0 : (a.level == 1 ? 64 : (a.level == 2 ? 80 : 84));
     const int ctu = (y >> 6) * ctusW + (x >> 6), bx = (x & 63) / n, by = (y & 63) / n;
     const int z = (bx & 1) | ((by & 1) << 1) | ((bx & 2) << 1) | ((by & 2) << 2) | ((bx & 4) << 2) | ((by & 4) << 3);
-    const int pk = a.mv[(size_t)ctu * 85 + lbase + z].y;
-    mvx = (int16_t)(pk & 0xffff); mvy = (int16_t)(pk >> 16);
-    // bit 0: coded coefficients, bit 1: intra CU (Bs 2 on its edges, deblock.cpp:198-199)
-    cbf = (a.numSig[(size_t)ctu * npu + z] != 0) | ((a.intra && a.intra[(size_t)ctu * npu + z]) ? 2 : 0);
+    const size_t blk = (size_t)ctu * npu + z, rec = (size_t)ctu * 85 + lbase + z;
+    BsSide s;
+    s.r0 = a.ref0 ? a.ref0[blk] : 0;
+    s.r1 = a.ref1 ? a.ref1[blk] : -1;
+    const int pk0 = s.r0 >= 0 ? a.mv[rec].y : 0;
+    const int pk1 = (s.r1 >= 0 && a.mv1) ? a.mv1[rec].y : 0;
+    s.mx0 = (int16_t)(pk0 & 0xffff); s.my0 = pk0 >> 16;
+    s.mx1 = (int16_t)(pk1 & 0xffff); s.my1 = pk1 >> 16;
+    s.flags = (a.numSig[blk] != 0) | ((a.intra && a.intra[blk]) ? 2 : 0);
+    return s;
+}
+
+__device__ __forceinline__ bool db_far(int ax, int ay, int bx, int by) { return abs(ax - bx) >= 4 || abs(ay - by) >= 4; }
+
+// Deblock::getBoundaryStrength (deblock.cpp:191-247) for the edge between blocks P and Q
+__device__ __forceinline__ int db_strength(const BsArgs& a, const BsSide& p, const BsSide& q)
+{
+    if ((p.flags | q.flags) & 2) return 2;
+    if (p.flags | q.flags) return 1;
+    const bool f00 = db_far(q.mx0, q.my0, p.mx0, p.my0);
+    if (!a.sliceB) return (p.r0 != q.r0 || f00) ? 1 : 0;
+    if (!((p.r0 == q.r0 && p.r1 == q.r1) || (p.r0 == q.r1 && p.r1 == q.r0))) return 1;
+    const bool f11 = db_far(q.mx1, q.my1, p.mx1, p.my1);
+    const bool f10 = db_far(q.mx1, q.my1, p.mx0, p.my0), f01 = db_far(q.mx0, q.my0, p.mx1, p.my1);
+    if (p.r0 != p.r1) return (p.r0 == q.r0 ? (f00 || f11) : (f10 || f01)) ? 1 : 0;
+    return ((f00 || f11) && (f10 || f01)) ? 1 : 0;
 }
 
 // one thread per 4-sample unit of the 8x8 edge grid, both directions in one launch (blockIdx.y = direction)
@@ -50,12 +81,7 @@ __global__ void __launch_bounds__(256) deblock_bs_inter_kernel(BsArgs a)
         if (i >= total) return;
         const int u = i / w8, ex = i - u * w8, x = ex * 8, y = u * 4;
         int bs = 0;
-        if (x > 0 && (x % n) == 0)
-        {
-            int px, py, pc, qx, qy, qc;
-            db_block(a, x - 1, y, px, py, pc); db_block(a, x, y, qx, qy, qc);
-            bs = ((pc | qc) & 2) ? 2 : ((pc || qc) ? 1 : ((abs(qx - px) >= 4 || abs(qy - py) >= 4) ? 1 : 0));
-        }
+        if (x > 0 && (x % n) == 0) bs = db_strength(a, db_block(a, x - 1, y), db_block(a, x, y));
         a.bsVer[i] = (uint8_t)bs;
     }
     else
@@ -64,12 +90,7 @@ __global__ void __launch_bounds__(256) deblock_bs_inter_kernel(BsArgs a)
         if (i >= total) return;
         const int ey = i / w4, u = i - ey * w4, x = u * 4, y = ey * 8;
         int bs = 0;
-        if (y > 0 && (y % n) == 0)
-        {
-            int px, py, pc, qx, qy, qc;
-            db_block(a, x, y - 1, px, py, pc); db_block(a, x, y, qx, qy, qc);
-            bs = ((pc | qc) & 2) ? 2 : ((pc || qc) ? 1 : ((abs(qx - px) >= 4 || abs(qy - py) >= 4) ? 1 : 0));
-        }
+        if (y > 0 && (y % n) == 0) bs = db_strength(a, db_block(a, x, y - 1), db_block(a, x, y));
         a.bsHor[i] = (uint8_t)bs;
     }
 }
@@ -223,6 +244,8 @@ extern "C" int x265hip_deblock_bs_inter(const x265hip_deblock_bs_params* p, void
     const int nv = (p->height >> 2) * (p->width >> 3), nh = (p->height >> 3) * (p->width >> 2);
     const int n = nv > nh ? nv : nh;
     a.intra = p->intra;
+    a.sliceB = p->slice_b; a.mv1 = (const int2*)p->mv1; a.ref0 = p->ref0; a.ref1 = p->ref1;
+    if (p->slice_b && p->ref1 && !p->mv1) { set_error("deblock_bs_inter: ref1 without mv1"); return X265HIP_EINVAL; }
     hipLaunchKernelGGL(deblock_bs_inter_kernel, dim3((n + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, a);
     X265HIP_TRY(hipGetLastError());
     return 0;

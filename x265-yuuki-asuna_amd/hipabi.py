@@ -99,7 +99,8 @@ def me_search_job_dtype():
 class DeblockBsParams(ctypes.Structure):
     _fields_ = [("width", ctypes.c_int), ("height", ctypes.c_int), ("level", ctypes.c_int),
                 ("mv", ctypes.c_void_p), ("num_sig", ctypes.c_void_p), ("bs_ver", ctypes.c_void_p), ("bs_hor", ctypes.c_void_p),
-                ("intra", ctypes.c_void_p)]
+                ("intra", ctypes.c_void_p),
+                ("slice_b", ctypes.c_int), ("mv1", ctypes.c_void_p), ("ref0", ctypes.c_void_p), ("ref1", ctypes.c_void_p)]
 
 
 class DeblockChromaParams(ctypes.Structure):
@@ -289,11 +290,15 @@ def me_search(depth, fenc, fenc_stride, fenc_off, fref, fref_stride, fref_off, m
     check(f(ctypes.byref(p), s), "x265hip_me_search")
 
 
-def deblock_bs_inter(width, height, level, mv, num_sig, bs_ver, bs_hor, stream=None, intra=None):
+def deblock_bs_inter(width, height, level, mv, num_sig, bs_ver, bs_hor, stream=None, intra=None, slice_b=False, mv1=None, ref0=None,
+                     ref1=None):
+    """Boundary strengths of a picture of square blocks.  ref0 / ref1 (int8 picture ids per block), mv1 and slice_b describe pictures
+    with several references / B pictures (deblock.cpp:217-247); left out = one list-0 reference."""
     p = DeblockBsParams()
     p.width, p.height, p.level = width, height, level
     p.mv, p.num_sig, p.bs_ver, p.bs_hor = mv.data_ptr(), num_sig.data_ptr(), bs_ver.data_ptr(), bs_hor.data_ptr()
     p.intra = _p(intra)
+    p.slice_b, p.mv1, p.ref0, p.ref1 = int(bool(slice_b)), _p(mv1), _p(ref0), _p(ref1)
     s = current_stream() if stream is None else stream
     f = lib().x265hip_deblock_bs_inter
     f.argtypes = [ctypes.POINTER(DeblockBsParams), ctypes.c_void_p]
