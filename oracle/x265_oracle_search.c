@@ -381,6 +381,137 @@ static void umh_search(const me_ctx* c, mv_t* pbmv, int* pbcost, int merange, in
 
 static int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* ---- X265_SEA (motion.cpp:1241-1395).  The reference keeps twelve "integral planes" per reference picture
+ * (framefilter.cpp:716-823 with the integral_init*h / *v primitives): plane value at (x, y) = the sum of the bw x bh block of
+ * reference samples whose top-left corner is (x, y), for (bw, bh) in the order below.  Here the block sums are taken straight
+ * from the reference samples; the pin test builds the planes with the real primitives. */
+static const int kSeaPlaneDims[12][2] = { { 32, 32 }, { 32, 24 }, { 32, 8 }, { 24, 32 }, { 16, 16 }, { 16, 12 }, { 16, 4 }, { 12, 16 },
+                                          { 8, 32 }, { 8, 8 }, { 4, 16 }, { 4, 4 } };     /* framedata.h:171 */
+
+typedef struct
+{
+    int nAds;                 /* terms of the ADS sum: the PU's ads_x1 / ads_x2 / ads_x4 (pixel.cpp:1105-1129) */
+    int plane;                /* index into kSeaPlaneDims */
+    int offX[4], offY[4];     /* position of each term's block sum relative to the candidate */
+    int encDC[4];
+} sea_plan;
+
+/* the choices motion.cpp:1258-1364 makes for a w x h PU; -1 for the sizes whose DC terms read source samples outside the PU
+ * (8x4, 4x8, 32x8, 8x32: fenc + deltaX / deltaY lies beyond the block that setSourcePU copied) */
+static int sea_make_plan(const me_ctx* c, sea_plan* p)
+{
+    const int w = c->w, h = c->h;
+    if ((w == 8 && h == 4) || (w == 4 && h == 8) || (w == 32 && h == 8) || (w == 8 && h == 32) || (w == 4 && h == 4)) return -1;
+    const int vertical = h == 2 * w, horizontal = w == 2 * h, square = w == h;
+    const int smallRect = (w == 16 && h == 12) || (w == 12 && h == 16) || (w == 16 && h == 4) || (w == 4 && h == 16);
+    const int asymVertical = !square && !vertical && w < h;
+    const int deltaX = w <= 8 ? w : w >> 1, deltaY = h <= 8 ? h : h >> 1;
+    int tw, th;                                                     /* the block size the source DCs are taken over (:1283-1303) */
+    if (vertical) { tw = w; th = h >> 1; }
+    else if (horizontal) { tw = w >> 1; th = h; }
+    else if (!square) { tw = smallRect ? w : w >> 1; th = smallRect ? h : h >> 1; }
+    else { tw = w <= 8 ? w : w >> 1; th = w <= 8 ? h : h >> 1; }
+    p->nAds = (square ? w <= 8 : smallRect) ? 1 : ((vertical || horizontal) ? 2 : 4);
+    int bw, bh;                                                     /* :1315-1347, keyed on deltaX / deltaY only */
+    switch (deltaX)
+    {
+    case 32: bw = 32; bh = (deltaY % 24 == 0) ? 24 : (deltaY == 8 ? 8 : 32); break;
+    case 24: bw = 24; bh = 32; break;
+    case 16: bw = 16; bh = (deltaY % 12 == 0) ? 12 : (deltaY == 4 ? 4 : 16); break;
+    case 12: bw = 12; bh = 16; break;
+    case 8: bw = 8; bh = deltaY == 32 ? 32 : 8; break;
+    case 4: bw = 4; bh = deltaY == 16 ? 16 : 4; break;
+    default: bw = 4; bh = 4; break;
+    }
+    p->plane = -1;
+    for (int k = 0; k < 12; k++) if (kSeaPlaneDims[k][0] == bw && kSeaPlaneDims[k][1] == bh) p->plane = k;
+    int dc[4];
+    for (int k = 0; k < 4; k++)
+    {
+        dc[k] = 0;
+        const int ox = (k & 1) ? deltaX : 0, oy = (k & 2) ? deltaY : 0;
+        if (ox + tw > w || oy + th > h) continue;                   /* never used by the ADS variant of a supported size */
+        for (int y = 0; y < th; y++)
+            for (int x = 0; x < tw; x++) dc[k] += c->fenc[(oy + y) * 64 + ox + x];
+    }
+    /* `delta` of the ads call: deltaY rows for squares, vertical and asymmetric-vertical PUs (:1349-1355), deltaY SAMPLES along the
+     * row for the asymmetric-horizontal ones (they are missing from that list), deltaX samples for horizontal PUs (:1360-1361) */
+    const int rows = square || vertical || asymVertical;
+    const int dx = horizontal ? deltaX : (rows ? 0 : deltaY), dy = (!horizontal && rows) ? deltaY : 0;
+    memset(p->offX, 0, sizeof(p->offX)); memset(p->offY, 0, sizeof(p->offY));
+    if (p->nAds == 4)
+    {
+        p->offX[1] = w >> 1;                                        /* ads_x4<lx, ly>: sums[lx >> 1] with the WHOLE PU's lx */
+        p->offX[2] = dx; p->offY[2] = dy;
+        p->offX[3] = dx + (w >> 1); p->offY[3] = dy;
+        memcpy(p->encDC, dc, sizeof(dc));
+    }
+    else if (p->nAds == 2)
+    {
+        p->offX[1] = dx; p->offY[1] = dy;
+        p->encDC[0] = dc[0]; p->encDC[1] = vertical ? dc[2] : dc[1];    /* :1357-1358 */
+    }
+    else p->encDC[0] = dc[0];
+    return 0;
+}
+
+static int sea_block_sum(const me_ctx* c, int plane, int x, int y)
+{
+    const pixel* r = c->fref + x + (intptr_t)y * c->stride;
+    int s = 0;
+    for (int j = 0; j < kSeaPlaneDims[plane][1]; j++, r += c->stride)
+        for (int i = 0; i < kSeaPlaneDims[plane][0]; i++) s += r[i];
+    return s;
+}
+
+/* The row loop (:1366-1391).  Three different mv-cost expressions meet here: the ADS filter adds the ordinary x cost
+ * (fpelCostMvX), the sad_x3 groups add m_cost[4x - 2 * qmvp.x] (p_cost_mvx is m_cost_mvx, itself already offset by the
+ * predictor, offset again) and no y cost, the row's y cost is m_cost[y - 2 * qmvp.y] << 2 (a full-pel y indexing the quarter-pel
+ * table), and the 0-2 candidates left over after the groups of three use the ordinary mvcost. */
+static int sea_search(const me_ctx* c, mv_t* pbmv, int* pbcost, int merange)
+{
+    sea_plan p;
+    if (sea_make_plan(c, &p)) return -1;
+    mv_t bmv = *pbmv;
+    int bcost = *pbcost;
+    const int ox = bmv.x, oy = bmv.y;
+    const int minX = ox - merange > c->mvmin.x ? ox - merange : c->mvmin.x, minY = oy - merange > c->mvmin.y ? oy - merange : c->mvmin.y;
+    const int maxX = ox + merange < c->mvmax.x ? ox + merange : c->mvmax.x, maxY = oy + merange < c->mvmax.y ? oy + merange : c->mvmax.y;
+    const int width = (maxX - minX + 3) & ~3;                       /* up to three candidates beyond maxX are examined */
+    int16_t list[4 * 64 + 8];
+    for (int ty = minY; ty <= maxY; ty++)
+    {
+        const int ycost = c->cost[ty - 2 * c->mvpy] << 2;
+        if (bcost <= ycost) continue;
+        bcost -= ycost;
+        int n = 0;
+        for (int i = 0; i < width; i++)
+        {
+            const int x = minX + i;
+            int ads = c->cost[4 * x - c->mvpx];
+            for (int k = 0; k < p.nAds; k++) ads += abs(p.encDC[k] - sea_block_sum(c, p.plane, x + p.offX[k], ty + p.offY[k]));
+            if (ads < bcost) list[n++] = (int16_t)i;
+        }
+        int i = 0;
+        for (; i < n - 2; i += 3)
+            for (int k = 0; k < 3; k++)
+            {
+                const int x = minX + list[i + k];
+                const int cost = sad_at(c, x, ty) + c->cost[4 * x - 2 * c->mvpx];
+                if (cost < bcost) { bcost = cost; bmv.x = x; bmv.y = ty; }
+            }
+        bcost += ycost;
+        for (; i < n; i++)
+        {
+            const int x = minX + list[i];
+            const int cost = cost_mv(c, x, ty);
+            if (cost < bcost) { bcost = cost; bmv.x = x; bmv.y = ty; }
+        }
+    }
+    *pbmv = bmv; *pbcost = bcost;
+    return 0;
+}
+
 static int motion_estimate_one(me_ctx* c, int method, int subme, int merange, const int32_t* mvc, int numMvc, int* outQx, int* outQy)
 {
     const int qminx = c->mvmin.x * 4, qminy = c->mvmin.y * 4, qmaxx = c->mvmax.x * 4, qmaxy = c->mvmax.y * 4;
@@ -501,6 +632,9 @@ static int motion_estimate_one(me_ctx* c, int method, int subme, int merange, co
         }
         break;
     }
+    case ME_SEA:
+        if (sea_search(c, &bmv, &bcost, merange)) return -1;
+        break;
     case ME_FULL:
         for (int ty = c->mvmin.y; ty <= c->mvmax.y; ty++)
             for (int tx = c->mvmin.x; tx <= c->mvmax.x; tx++)

@@ -133,6 +133,58 @@ def test_search_driver_restatement_equals_reference_motion_estimate(depth, metho
     assert total >= 300
 
 
+SEA_UNSUPPORTED = {(8, 4), (4, 8), (32, 8), (8, 32)}      # their DC terms read source samples outside the PU (motion.cpp:1259-1260,1305)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_sea_search_restatement_equals_reference_motion_estimate(depth):
+    """X265_SEA (motion.cpp:1241-1395): the restatement takes its block sums straight from the reference samples; the real class
+    gets the twelve integral planes built by the library's own integral_init primitives the way FrameFilter does.  Every
+    supported PU size (the ADS variant, plane and offsets differ per size - including the sizes whose plane does not match
+    their DC block), random predictors, bounds, merange and sub-pel levels."""
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_motion_estimate_sea"):
+        pytest.skip("oracle/_ref predates the SEA entry point")
+    lib.x265ref_motion_estimate_sea.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t] + [ctypes.c_int] * 11 + [ctypes.c_void_p, ctypes.c_int]
+    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libx265oracle.so"))
+    f = getattr(orc, f"x265oracle_motion_estimate_d{depth}")
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + \
+                 [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    width, height = 256, 192
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=37)
+    cur, stride, org, w64, h64 = F.pad_plane(clip[1][0])
+    ref = F.pad_plane(clip[0][0])[0]
+    es = cur.itemsize
+    rng = np.random.default_rng([11, depth])
+    qp = 24 if depth == 8 else 12
+    cq, qoff = F.qpel_cost_table(57, qmax=8 * 64 + 300)
+    seen, moved = set(), 0
+    for subme in (0, 1, 2, 3, 5, 7):
+        for merange in (5, 16, 40):
+            mn, mx = (-44, -44), (44, 44)
+            if rng.integers(0, 3) == 0:
+                mn = (-int(rng.integers(3, 20)), -int(rng.integers(3, 20)))
+                mx = (int(rng.integers(3, 20)), int(rng.integers(3, 20)))
+            ja = random_me_jobs(rng, 60, width, height)
+            keep = [j for j in ja if (j.w, j.h) not in SEA_UNSUPPORTED]
+            ja = (Job * len(keep))(*keep)
+            jb = copy_jobs(ja)
+            assert lib.x265ref_motion_estimate_sea(cur.ctypes.data + org * es, ref.ctypes.data + org * es, stride, w64, h64, F.MARGIN_X, F.MARGIN_Y,
+                                                   subme, merange, qp, mn[0], mn[1], mx[0], mx[1], ja, len(ja)) == len(ja)
+            assert f(cur.ctypes.data + org * es, ref.ctypes.data + org * es, stride, 4, subme, merange, cq.ctypes.data, qoff,
+                     mn[0], mn[1], mx[0], mx[1], jb, len(jb), 1) == 0
+            for a, b in zip(ja, jb):
+                assert (a.out_cost, a.out_qmvx, a.out_qmvy) == (b.out_cost, b.out_qmvx, b.out_qmvy), \
+                    f"subme {subme} merange {merange} PU {(a.px, a.py, a.w, a.h)} mvp {(a.qmvpx, a.qmvpy)} bounds {mn}..{mx}"
+                seen.add((a.w, a.h))
+                moved += (a.out_qmvx, a.out_qmvy) != (0, 0)
+    assert len(seen) == len(ALL_PU_DIMS) - len(SEA_UNSUPPORTED) and moved > 300
+    # the unsupported sizes are refused, not approximated
+    bad = (Job * 1)()
+    bad[0].w, bad[0].h = 32, 8
+    assert f(cur.ctypes.data + org * es, ref.ctypes.data + org * es, stride, 4, 2, 8, cq.ctypes.data, qoff, -8, -8, 8, 8, bad, 1, 1) != 0
+
+
 @pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 192, 144), (10, 128, 128)])
 def test_lookahead_restatement_equals_reference_classes(depth, width, height):
     """oracle/x265_oracle_pipeline3.c against the real Lowres::init + LookaheadTLD::lowresIntraEstimate
