@@ -182,7 +182,8 @@ int x265hip_extend_border(void* pic, intptr_t stride, int width, int height, int
  * One job = one prediction unit of one reference picture: position, size (any of the reference's 24 inter partitions,
  * primitives.h:41-55 minus 4x4), quarter-pel predictor.  For every job the kernels reproduce motionEstimate() with the optional
  * extra candidates mvc[] (encoder/motion.cpp:739-1561; UMH also sizes its range from them, :982-1040): predictor / zero start, the integer pattern `method` (X265_DIA_SEARCH,
- * X265_HEX_SEARCH, X265_UMH_SEARCH, X265_STAR_SEARCH, X265_FULL_SEARCH of x265.h:492-497; SEA is rejected), the predictor-vs-search
+ * X265_HEX_SEARCH, X265_UMH_SEARCH, X265_STAR_SEARCH, X265_SEA, X265_FULL_SEARCH of x265.h:492-497; SEA needs `integral` and
+ * refuses, with out_cost = -1, the four PU sizes whose DC terms the reference reads from outside the PU: 8x4, 4x8, 32x8, 8x32), the predictor-vs-search
  * choice and the sub-pel refinement level `subme`; out_qmv / out_cost are its outQMv and return value.
  *   fenc, fref : pixel (0,0) of the padded source / reference luma planes; fref needs mvmax + 8 valid pixels of margin
  *   cost_q     : uint16 bit cost of a quarter-pel mv DIFFERENCE component, cost_q[qoff + d] (BitCost::s_costs, built on the
@@ -206,8 +207,26 @@ typedef struct x265hip_me_search_params
     x265hip_me_search_job* jobs;  int njobs;      /* DEVICE array, results written in place */
     const int32_t* mvc;                           /* optional DEVICE int32 [njobs][12][2]: motionEstimate's extra quarter-pel */
     const int32_t* num_mvc;                       /* candidates mvc[] (at most 12, search.cpp:2094) and their count per job */
+    /* X265_SEA only: the reference picture's twelve block-sum planes (x265hip_sea_integral), DEVICE uint32 pointers to the entry of
+     * sample (0,0), stride = fref_stride; only the planes the job sizes select are read (motion.cpp:1315-1347) */
+    const uint32_t* integral[12];
 } x265hip_me_search_params;
 int x265hip_me_search(const x265hip_me_search_params* p, void* stream);
+
+/* x265hip_sea_integral = the integral section of FrameFilter::processPostRow (encoder/framefilter.cpp:716-823) with the
+ *   integral_init*h / *v primitives (:39-140) for one reference picture: planes[k](x, y) = sum of the bw x bh block of samples whose
+ *   top-left corner is (x, y), (bw, bh) = 32x32, 32x24, 32x8, 24x32, 16x16, 16x12, 16x4, 12x16, 8x32, 8x8, 4x16, 4x4 (framedata.h:171),
+ *   for -margin_x <= x <= width + margin_x - bw and -margin_y <= y <= height + margin_y - bh (the reference leaves row -margin_y
+ *   and the last rows unset; a search window must stay inside either way).  ref = sample (0,0) of the padded plane; planes[k] =
+ *   DEVICE pointer to the entry of sample (0,0) in a uint32 plane of the same stride and margins, NULL = not wanted. */
+typedef struct x265hip_sea_integral_params
+{
+    int depth;
+    const void* ref; intptr_t stride;
+    int width, height, margin_x, margin_y;
+    uint32_t* planes[12];
+} x265hip_sea_integral_params;
+int x265hip_sea_integral(const x265hip_sea_integral_params* p, void* stream);
 
 /* Lookahead frame cost estimate - CostEstimateGroup::estimateFrameCost + estimateCUCost (no HME, no weighted reference;
  * encoder/slicetype.cpp:3115-3213,3216-3388) for P pictures (one list, intra competes) and B pictures (two lists, skip shortcut

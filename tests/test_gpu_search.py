@@ -83,6 +83,72 @@ def test_search_extremes():
     _check(8, "star", 128, 128, seed=43, njobs=32, submes=(3,), meranges=(57,), extreme="flat")
 
 
+SEA_UNSUPPORTED = {(8, 4), (4, 8), (32, 8), (8, 32)}
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_sea_block_sum_planes(depth):
+    """x265hip_sea_integral: each of the twelve planes holds, at (x, y), the sum of the bw x bh block of the padded reference whose
+    corner is (x, y) - what the reference's integral_init primitives leave there (the oracle's SEA restatement, pinned against
+    the real class fed with planes from those primitives, takes exactly these sums)."""
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(200, 136, 1, depth=depth, seed=48)
+    ref = P.DevicePicture(clip[0][0], dev)
+    planes, org = A.sea_integral(depth, ref.t, ref.stride, ref.org, ref.w64, ref.h64, F.MARGIN_X, F.MARGIN_Y)
+    torch.cuda.synchronize()
+    host = ref.host.astype(np.int64)
+    rows = host.shape[0]
+    cs = np.zeros((rows + 1, ref.stride + 1), np.int64)
+    cs[1:, 1:] = host.cumsum(0).cumsum(1)
+    got = planes.cpu().numpy().view(np.uint32).reshape(12, rows, ref.stride)
+    for k, (bw, bh) in enumerate(A.SEA_PLANE_DIMS):
+        exp = cs[bh:, bw:] - cs[:-bh, bw:] - cs[bh:, :-bw] + cs[:-bh, :-bw]          # rows - bh + 1 x stride - bw + 1 corners
+        vw = ref.w64 + 2 * F.MARGIN_X - bw + 1
+        assert np.array_equal(got[k, :rows - bh + 1, :vw], exp[:, :vw]), f"plane {k} ({bw}x{bh}) differs"
+        assert not got[k, rows - bh + 1:, :].any()                                       # nothing written outside the valid corners
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_sea_search_driver(depth):
+    """X265_SEA through the device planes: every supported PU size, random predictors / bounds / merange / sub-pel levels against
+    the oracle restatement (pinned against the real MotionEstimate with real integral planes); the four sizes whose DC terms the
+    reference reads from outside the PU come back refused (out_cost -1)."""
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    width, height = 256, 192
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=49)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    integral = A.sea_integral(depth, ref.t, ref.stride, ref.org, ref.w64, ref.h64, F.MARGIN_X, F.MARGIN_Y)
+    rng = np.random.default_rng([49, depth])
+    cq, qoff = F.qpel_cost_table(57, qmax=8 * 64 + 300)
+    cq_d = torch.from_numpy(cq.view(np.int16)).to(dev)
+    seen, moved = set(), 0
+    for subme in (0, 2, 3, 5, 7):
+        for merange in (5, 16, 40):
+            mn, mx = (-44, -44), (44, 44)
+            if rng.integers(0, 3) == 0:
+                mn = (-int(rng.integers(3, 20)), -int(rng.integers(3, 20)))
+                mx = (int(rng.integers(3, 20)), int(rng.integers(3, 20)))
+            jobs = _jobs(rng, 96, width, height)
+            ok = np.array([(int(j["w"]), int(j["h"])) not in SEA_UNSUPPORTED for j in jobs])
+            exp = O.motion_estimate(depth, cur.host, ref.host, cur.stride, cur.org, A.ME_SEA, subme, merange, cq, qoff, mn, mx, jobs[ok])
+            jd = torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy()).to(dev)
+            A.me_search(depth, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, A.ME_SEA, subme, merange, cq_d, qoff, mn, mx, jd, len(jobs),
+                        integral=integral)
+            torch.cuda.synchronize()
+            got = jd.cpu().numpy().view(A.me_search_job_dtype())
+            assert (got["out_cost"][~ok] == -1).all()
+            for f in ("out_cost", "out_qmvx", "out_qmvy"):
+                bad = np.nonzero(got[f][ok] != exp[f])[0]
+                assert bad.size == 0, (f"sea depth {depth} subme {subme} merange {merange} bounds {mn}..{mx}: {f} differs for {bad.size} jobs, "
+                                       f"first {jobs[ok][bad[0]]}: got {got[ok][bad[0]]} expected {exp[bad[0]]}")
+            seen |= {(int(j["w"]), int(j["h"])) for j in jobs[ok]}
+            moved += int(np.count_nonzero(exp["out_qmvx"] | exp["out_qmvy"]))
+    assert len(seen) == len(ALL_PU_DIMS) - len(SEA_UNSUPPORTED) and moved > 500
+
+
 def test_unimplemented_methods_are_rejected():
     import torch
     dev = torch.device("cuda:0")

@@ -63,7 +63,7 @@ struct PuEval
     // N candidates at once (the reference's sad_x3 / sad_x4 groups): all reference loads are issued before the first
     // reduction, so one memory round trip serves the group
     template <int N>
-    __device__ __forceinline__ void cost_mv_n(const int (&mx)[N], const int (&my)[N], int (&out)[N]) const
+    __device__ __forceinline__ void sad_n(const int (&mx)[N], const int (&my)[N], int (&out)[N]) const
     {
         uint32_t acc[N];
 #pragma unroll
@@ -86,7 +86,14 @@ struct PuEval
             if (N * T * 4 * DW > 64) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int n = 0; n < N; n++) out[n] = group_total<G>((int)acc[n]) + mvcost_q(mx[n] * 4, my[n] * 4);
+        for (int n = 0; n < N; n++) out[n] = group_total<G>((int)acc[n]);
+    }
+    template <int N>
+    __device__ __forceinline__ void cost_mv_n(const int (&mx)[N], const int (&my)[N], int (&out)[N]) const
+    {
+        sad_n<N>(mx, my, out);
+#pragma unroll
+        for (int n = 0; n < N; n++) out[n] += mvcost_q(mx[n] * 4, my[n] * 4);
     }
 
     // subpelCompare: SAD or SATD of the PU at quarter-pel displacement (qx, qy)

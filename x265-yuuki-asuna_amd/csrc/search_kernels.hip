@@ -31,6 +31,7 @@ struct SearchArgs
     int mvminx, mvminy, mvmaxx, mvmaxy;
     const int32_t* mvc; const int32_t* numMvc;      // optional [njobs][12][2] quarter-pel candidates / [njobs]
     int* largeCount; int* largeQueue;               // jobs of more than 32 tiles, collected by the first kernel for the second
+    const uint32_t* integral[12];                   // X265_SEA: block-sum planes of the reference, entry of sample (0,0)
 };
 
 // Point i of one StarPatternSearch round (motion.cpp:362-604) as offsets from the round's origin, in the reference's
@@ -232,7 +233,141 @@ __device__ __forceinline__ void umh_search(const PuEval<Px, G, T>& c, SMv& bmv, 
 }
 
 // One PU per lane group: `job` is the group's job (every lane of the group passes the same value).
+// the group's lanes that voted true, bit i = lane i of the group (the lanes of a group are always active together)
+template <int G> __device__ __forceinline__ unsigned long long group_ballot(bool v)
+{
+    const unsigned long long m = __ballot(v);
+    if (G == 64) return m;
+    return (m >> (threadIdx.x & 63 & ~(G - 1))) & ((1ull << G) - 1);
+}
+
+// X265_SEA (motion.cpp:1241-1395): row by row, the ADS filter - sum over the PU's 1 / 2 / 4 DC terms of |source DC - block sum of
+// the reference| plus the x cost, against the best cost so far - selects the candidates whose SAD is then measured.  The G lanes
+// of the group take G consecutive candidates of the row through the filter at a time; the survivors are measured in the
+// reference's order and grouping (threes through sad_x3 with a y-less cost, the 0-2 left over with the ordinary cost), because
+// the two cost expressions differ and the result depends on which one a candidate meets.  Which ADS variant, which plane and
+// which offsets a PU size gets - including the sizes where they do not match the DC blocks - follows :1258-1364 literally.
+// Returns false for the PU sizes whose DC terms lie outside the PU.
 template <typename Px, int G, int T>
+__device__ __forceinline__ bool sea_search(const PuEval<Px, G, T>& c, const SearchArgs& a, const x265hip_me_search_job& jb, SMv& bmv, int& bcost,
+                                           const int merange)
+{
+    constexpr int BPP = sizeof(Px);
+    const int gl = threadIdx.x & (G - 1);
+    const int w = jb.w, h = jb.h;
+    if ((w == 8 && h == 4) || (w == 4 && h == 8) || (w == 32 && h == 8) || (w == 8 && h == 32)) return false;
+    const bool vertical = h == 2 * w, horizontal = w == 2 * h, square = w == h;
+    const bool smallRect = (w == 16 && h == 12) || (w == 12 && h == 16) || (w == 16 && h == 4) || (w == 4 && h == 16);
+    const bool asymVertical = !square && !vertical && w < h;
+    const int deltaX = w <= 8 ? w : w >> 1, deltaY = h <= 8 ? h : h >> 1;
+    int tw, th;                                                     // the block the source DCs are taken over (:1283-1303)
+    if (vertical) { tw = w; th = h >> 1; }
+    else if (horizontal) { tw = w >> 1; th = h; }
+    else if (!square) { tw = smallRect ? w : w >> 1; th = smallRect ? h : h >> 1; }
+    else { tw = w <= 8 ? w : w >> 1; th = w <= 8 ? h : h >> 1; }
+    const int nAds = (square ? w <= 8 : smallRect) ? 1 : ((vertical || horizontal) ? 2 : 4);      // pixel.cpp:1105-1129
+    int plane;                                                      // :1315-1347, keyed on deltaX / deltaY only
+    switch (deltaX)
+    {
+    case 32: plane = (deltaY % 24 == 0) ? 1 : (deltaY == 8 ? 2 : 0); break;
+    case 24: plane = 3; break;
+    case 16: plane = (deltaY % 12 == 0) ? 5 : (deltaY == 4 ? 6 : 4); break;
+    case 12: plane = 7; break;
+    case 8: plane = deltaY == 32 ? 8 : 9; break;
+    case 4: plane = deltaY == 16 ? 10 : 11; break;
+    default: plane = 11; break;
+    }
+    // source DCs: every lane adds the tiles it holds to the blocks they fall into (sad_x4 against zeros, :1305-1311)
+    int dc[4] = { 0, 0, 0, 0 };
+    const int tilesX = w >> 2;
+#pragma unroll
+    for (int k = 0; k < T; k++)
+    {
+        if (!c.have[k]) continue;
+        const int t = gl + G * k, ty = t / tilesX, x = (t - ty * tilesX) * 4, y = ty * 4;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int q = 0; q < BPP; q++) sum = sad_dw<Px>(c.src[k][r][q], 0u, sum);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int ox = (q & 1) ? deltaX : 0, oy = (q & 2) ? deltaY : 0;
+            if (x >= ox && x < ox + tw && y >= oy && y < oy + th) dc[q] += (int)sum;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) dc[q] = group_total<G>(dc[q]);
+    // `delta` of the ads call: deltaY rows for squares, vertical and asymmetric-vertical PUs (:1349-1355), deltaY SAMPLES along the
+    // row for the asymmetric-horizontal ones (missing from that list), deltaX samples for horizontal PUs (:1360-1361)
+    const int ps = c.strideB / BPP;
+    const bool rows = square || vertical || asymVertical;
+    const int delta = horizontal ? deltaX : (rows ? deltaY * ps : deltaY);
+    int off1, off2 = 0, off3 = 0, enc1;
+    if (nAds == 4) { off1 = w >> 1; off2 = delta; off3 = delta + (w >> 1); enc1 = dc[1]; }
+    else { off1 = delta; enc1 = vertical ? dc[2] : dc[1]; }           // :1357-1358
+    const uint32_t* pl = a.integral[plane] + (long)jb.py * ps + jb.px;
+    const int minX = max(bmv.x - merange, c.mvmin.x), minY = max(bmv.y - merange, c.mvmin.y);
+    const int maxX = min(bmv.x + merange, c.mvmax.x), maxY = min(bmv.y + merange, c.mvmax.y);
+    const int width = (maxX - minX + 3) & ~3;                       // up to three candidates beyond maxX are examined
+    for (int ty = minY; ty <= maxY; ty++)
+    {
+        // three mv-cost expressions meet here: the filter adds the ordinary x cost; the threes add m_cost[4x - 2 qmvp.x] and no y
+        // cost; the row's y cost is m_cost[y - 2 qmvp.y] << 2; the left-over candidates use the ordinary mvcost (:1247-1248,1369,304-306)
+        const int ycost = (int)c.cost[ty - 2 * c.mvpy] << 2;
+        if (bcost <= ycost) continue;
+        const int thr = bcost - ycost;                              // the filter's threshold for the whole row
+        int cur = thr;
+        int pend0 = 0, pend1 = 0, np = 0;
+        const uint32_t* row = pl + (long)ty * ps;
+#pragma unroll 1
+        for (int i0 = 0; i0 < width; i0 += G)
+        {
+            const int i = i0 + gl;
+            bool pass = false;
+            if (i < width)
+            {
+                const int x = minX + i;
+                const uint32_t* sp = row + x;
+                int ads = (int)c.cost[4 * x - c.mvpx] + abs(dc[0] - (int)sp[0]);
+                if (nAds >= 2) ads += abs(enc1 - (int)sp[off1]);
+                if (nAds == 4) ads += abs(dc[2] - (int)sp[off2]) + abs(dc[3] - (int)sp[off3]);
+                pass = ads < thr;
+            }
+            unsigned long long m = group_ballot<G>(pass);
+#pragma unroll 1
+            while (m)
+            {
+                const int x = minX + i0 + __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (np == 0) { pend0 = x; np = 1; }
+                else if (np == 1) { pend1 = x; np = 2; }
+                else
+                {
+                    const int xs[3] = { pend0, pend1, x }, ys[3] = { ty, ty, ty };
+                    int sads[3];
+                    c.template sad_n<3>(xs, ys, sads);
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                    {
+                        const int cost = sads[k] + (int)c.cost[4 * xs[k] - 2 * c.mvpx];
+                        if (cost < cur) { cur = cost; bmv.x = xs[k]; bmv.y = ty; }
+                    }
+                    np = 0;
+                }
+            }
+        }
+        bcost = cur + ycost;
+        if (np >= 1) { const int cost = c.cost_mv(pend0, ty); if (cost < bcost) { bcost = cost; bmv.x = pend0; bmv.y = ty; } }
+        if (np == 2) { const int cost = c.cost_mv(pend1, ty); if (cost < bcost) { bcost = cost; bmv.x = pend1; bmv.y = ty; } }
+    }
+    return true;
+}
+
+// SEA: the kernels are instantiated twice, with only the SEA pattern or with all the others (the pattern code shares a register
+// budget; SEA's row loop would push the 16-bit wavefront-per-PU kernel into scratch)
+template <typename Px, int G, int T, bool SEA>
 __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
 {
     constexpr int BPP = sizeof(Px);
@@ -292,7 +427,15 @@ __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
     int costs[4];
 #define YOK(DY) ((bmv.y + (DY) >= c.mvmin.y) & (bmv.y + (DY) <= c.mvmax.y))
 #define LT(V) do { const int v_ = (V); if (v_ < bcost) bcost = v_; } while (0)
-    if (a.method == 0)              // X265_DIA_SEARCH
+    if constexpr (SEA)              // X265_SEA
+    {
+        if (!sea_search(c, a, jb, bmv, bcost, merange))
+        {
+            if (gl == 0) { a.jobs[job].out_qmvx = 0; a.jobs[job].out_qmvy = 0; a.jobs[job].out_cost = -1; }
+            return;
+        }
+    }
+    else if (a.method == 0)         // X265_DIA_SEARCH
     {
         bcost <<= 4;
         int i = merange;
@@ -441,7 +584,7 @@ __device__ __forceinline__ int job_class(const x265hip_me_search_job& j)
     return nt <= 8 ? 0 : (nt <= 32 ? 1 : 2);
 }
 
-template <typename Px>
+template <typename Px, bool SEA>
 __global__ void __launch_bounds__(256, 3) me_search_kernel(SearchArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -455,7 +598,7 @@ __global__ void __launch_bounds__(256, 3) me_search_kernel(SearchArgs a)
     // small PUs: quad q takes job q
     {
         const int q = lane >> 2;
-        if ((m0 >> q) & 1) search_job<Px, 4, 2>(a, first + q);
+        if ((m0 >> q) & 1) search_job<Px, 4, 2, SEA>(a, first + q);
     }
     // medium PUs: four at a time, one per 16-lane row
     {
@@ -471,7 +614,7 @@ __global__ void __launch_bounds__(256, 3) me_search_kernel(SearchArgs a)
                 m &= m - 1;
                 if ((lane >> 4) == r) mine = j;
             }
-            if (mine >= 0) search_job<Px, 16, 2>(a, first + mine);
+            if (mine >= 0) search_job<Px, 16, 2, SEA>(a, first + mine);
         }
     }
     // large PUs need the whole wavefront: they are queued for the second kernel, which gives each of them a wavefront of its own
@@ -486,12 +629,12 @@ __global__ void __launch_bounds__(256, 3) me_search_kernel(SearchArgs a)
     }
 }
 
-template <typename Px>
+template <typename Px, bool SEA>
 __global__ void __launch_bounds__(256, 3) me_search_large_kernel(SearchArgs a)
 {
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= *a.largeCount) return;
-    search_job<Px, 64, 4>(a, a.largeQueue[w]);
+    search_job<Px, 64, 4, SEA>(a, a.largeQueue[w]);
 }
 
 } // namespace x265hip
@@ -506,8 +649,10 @@ extern "C" int x265hip_me_search(const x265hip_me_search_params* p, void* stream
     if (p->njobs < 0) { set_error("me_search: njobs %d", p->njobs); return X265HIP_EINVAL; }
     if (p->njobs == 0) return 0;
     if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("me_search: depth %d", p->depth); return X265HIP_EINVAL; }
-    if (p->method != X265HIP_ME_DIA && p->method != X265HIP_ME_HEX && p->method != X265HIP_ME_UMH && p->method != X265HIP_ME_STAR && p->method != X265HIP_ME_FULL)
-    { set_error("me_search: search method %d is not implemented (DIA, HEX, UMH, STAR, FULL are; SEA needs integral planes)", p->method); return X265HIP_EINVAL; }
+    if (p->method < X265HIP_ME_DIA || p->method > X265HIP_ME_FULL) { set_error("me_search: unknown search method %d", p->method); return X265HIP_EINVAL; }
+    if (p->method == X265HIP_ME_SEA)
+        for (int k = 0; k < 12; k++)
+            if (!p->integral[k]) { set_error("me_search: X265_SEA needs the twelve block-sum planes (x265hip_sea_integral); integral[%d] is NULL", k); return X265HIP_EINVAL; }
     if (p->subme < 0 || p->subme > 7) { set_error("me_search: subme %d out of [0,7]", p->subme); return X265HIP_EINVAL; }
     if (p->mvmin_x > p->mvmax_x || p->mvmin_y > p->mvmax_y) { set_error("me_search: empty mv range"); return X265HIP_EINVAL; }
     const int bpp = p->depth == 8 ? 1 : 2;
@@ -518,6 +663,7 @@ extern "C" int x265hip_me_search(const x265hip_me_search_params* p, void* stream
     a.depth = p->depth; a.method = p->method; a.subme = p->subme; a.merange = p->merange;
     a.mvminx = p->mvmin_x; a.mvminy = p->mvmin_y; a.mvmaxx = p->mvmax_x; a.mvmaxy = p->mvmax_y;
     a.mvc = p->mvc; a.numMvc = p->num_mvc;
+    for (int k = 0; k < 12; k++) a.integral[k] = p->integral[k];
     hipStream_t s = (hipStream_t)stream;
     // stream-ordered scratch: [0] = number of large jobs, [1..] = their indices
     int* scratch = nullptr;
@@ -527,16 +673,13 @@ extern "C" int x265hip_me_search(const x265hip_me_search_params* p, void* stream
     const int wgs = (p->njobs + 63) / 64;                          // 4 wavefronts x 16 jobs per workgroup
     // the second grid covers the worst case (every job large): surplus wavefronts leave at once
     const int wgsLarge = (p->njobs + 3) / 4;
-    if (bpp == 1)
-    {
-        hipLaunchKernelGGL(me_search_kernel<uint8_t>, dim3(wgs), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(me_search_large_kernel<uint8_t>, dim3(wgsLarge), dim3(256), 0, s, a);
-    }
-    else
-    {
-        hipLaunchKernelGGL(me_search_kernel<uint16_t>, dim3(wgs), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(me_search_large_kernel<uint16_t>, dim3(wgsLarge), dim3(256), 0, s, a);
-    }
+    const bool sea = p->method == X265HIP_ME_SEA;
+#define LAUNCH_SEARCH(PX, SEA) do { \
+        hipLaunchKernelGGL((me_search_kernel<PX, SEA>), dim3(wgs), dim3(256), 0, s, a); \
+        hipLaunchKernelGGL((me_search_large_kernel<PX, SEA>), dim3(wgsLarge), dim3(256), 0, s, a); } while (0)
+    if (bpp == 1) { if (sea) LAUNCH_SEARCH(uint8_t, true); else LAUNCH_SEARCH(uint8_t, false); }
+    else { if (sea) LAUNCH_SEARCH(uint16_t, true); else LAUNCH_SEARCH(uint16_t, false); }
+#undef LAUNCH_SEARCH
     X265HIP_TRY(hipGetLastError());
     X265HIP_TRY(hipFreeAsync(scratch, s));
     return 0;

@@ -85,7 +85,18 @@ class MESearchParams(ctypes.Structure):
                 ("method", ctypes.c_int), ("subme", ctypes.c_int), ("merange", ctypes.c_int),
                 ("cost_q", ctypes.c_void_p), ("qoff", ctypes.c_int),
                 ("mvmin_x", ctypes.c_int), ("mvmin_y", ctypes.c_int), ("mvmax_x", ctypes.c_int), ("mvmax_y", ctypes.c_int),
-                ("jobs", ctypes.c_void_p), ("njobs", ctypes.c_int), ("mvc", ctypes.c_void_p), ("num_mvc", ctypes.c_void_p)]
+                ("jobs", ctypes.c_void_p), ("njobs", ctypes.c_int), ("mvc", ctypes.c_void_p), ("num_mvc", ctypes.c_void_p),
+                ("integral", ctypes.c_void_p * 12)]
+
+
+class SeaIntegralParams(ctypes.Structure):
+    """x265hip_sea_integral_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("ref", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),
+                ("width", ctypes.c_int), ("height", ctypes.c_int), ("margin_x", ctypes.c_int), ("margin_y", ctypes.c_int),
+                ("planes", ctypes.c_void_p * 12)]
+
+
+SEA_PLANE_DIMS = ((32, 32), (32, 24), (32, 8), (24, 32), (16, 16), (16, 12), (16, 4), (12, 16), (8, 32), (8, 8), (4, 16), (4, 4))   # framedata.h:171
 
 
 ME_DIA, ME_HEX, ME_UMH, ME_STAR, ME_SEA, ME_FULL = range(6)
@@ -271,9 +282,10 @@ def lowres_cost(depth, stride, width_in_cu, height_in_cu, cost_q, qoff, pairs, b
 
 
 def me_search(depth, fenc, fenc_stride, fenc_off, fref, fref_stride, fref_off, method, subme, merange, cost_q, qoff,
-              mvmin, mvmax, jobs, njobs, stream=None, mvc=None, num_mvc=None):
+              mvmin, mvmax, jobs, njobs, stream=None, mvc=None, num_mvc=None, integral=None):
     """jobs: device uint8 tensor holding njobs x265hip_me_search_job records (me_search_job_dtype), updated in place.
-    mvc / num_mvc: optional device int32 tensors [njobs][12][2] / [njobs] (motionEstimate's extra candidates)."""
+    mvc / num_mvc: optional device int32 tensors [njobs][12][2] / [njobs] (motionEstimate's extra candidates).
+    integral: X265_SEA only - the reference's block-sum planes, a (planes tensor, org) pair from sea_integral()."""
     es = 1 if depth == 8 else 2
     p = MESearchParams()
     p.depth = depth
@@ -284,10 +296,33 @@ def me_search(depth, fenc, fenc_stride, fenc_off, fref, fref_stride, fref_off, m
     p.mvmin_x, p.mvmin_y, p.mvmax_x, p.mvmax_y = mvmin[0], mvmin[1], mvmax[0], mvmax[1]
     p.jobs, p.njobs = jobs.data_ptr(), njobs
     p.mvc, p.num_mvc = _p(mvc), _p(num_mvc)
+    if integral is not None:
+        planes, org = integral
+        for k in range(12):
+            p.integral[k] = planes[k].data_ptr() + org * 4
     s = current_stream() if stream is None else stream
     f = lib().x265hip_me_search
     f.argtypes = [ctypes.POINTER(MESearchParams), ctypes.c_void_p]
     check(f(ctypes.byref(p), s), "x265hip_me_search")
+
+
+def sea_integral(depth, ref, stride, org, width, height, margin_x, margin_y, planes=None, stream=None):
+    """The twelve block-sum planes of a padded reference picture (x265hip_sea_integral): returns (planes, org) with planes a
+    uint32 device tensor [12][rows * stride] laid out like the picture (entry of sample (0,0) at element org)."""
+    import torch
+    es = 1 if depth == 8 else 2
+    if planes is None:
+        planes = torch.zeros((12, ref.numel() * ref.element_size() // es), dtype=torch.int32, device=ref.device)
+    p = SeaIntegralParams()
+    p.depth, p.ref, p.stride = depth, ref.data_ptr() + org * es, stride
+    p.width, p.height, p.margin_x, p.margin_y = width, height, margin_x, margin_y
+    for k in range(12):
+        p.planes[k] = planes[k].data_ptr() + org * 4
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_sea_integral
+    f.argtypes = [ctypes.POINTER(SeaIntegralParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_sea_integral")
+    return planes, org
 
 
 def deblock_bs_inter(width, height, level, mv, num_sig, bs_ver, bs_hor, stream=None, intra=None, slice_b=False, mv1=None, ref0=None,
