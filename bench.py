@@ -139,8 +139,8 @@ def main():
     ap.add_argument("--no-surface", action="store_true", help="ME keeps only the best mv (no SAD surfaces)")
     ap.add_argument("--surf-format", choices=["packed", "i32"], default="packed",
                     help="SAD surface records: packed = u16 for the 8x8/16x16 levels (X265HIP_SURF_PACKED), i32 = all int32")
-    ap.add_argument("--search", choices=["full", "dia", "hex", "umh", "star"], default="full",
-                    help="full = exhaustive search (SAD surfaces + best mv) + sub-pel stage; dia/hex/umh/star = the reference's pattern "
+    ap.add_argument("--search", choices=["full", "dia", "hex", "umh", "star", "sea"], default="full",
+                    help="full = exhaustive search (SAD surfaces + best mv) + sub-pel stage; dia/hex/umh/star/sea = the reference's pattern "
                          "searches run by the device-side search driver (x265hip_me_search), predictor (0,0)")
     ap.add_argument("--lookahead-batch", type=int, default=0,
                     help="pictures per launch of the lookahead's P-frame cost estimate, which runs ahead on a side stream (0 = stage off)")

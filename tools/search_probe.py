@@ -32,9 +32,20 @@ from bench import effective_cpus
 threads = effective_cpus()
 print(f"# x265hip_me_search: every 8x8..64x64 PU of every CTU, predictor (0,0), merange 57; CPU column = oracle/x265_oracle_search.c "
       f"(-march=x86-64-v3) on {threads} threads (container CPU quota) over a sample of the same jobs")
-for name, m in (("dia", A.ME_DIA), ("hex", A.ME_HEX), ("umh", A.ME_UMH), ("star", A.ME_STAR)):
+integral = A.sea_integral(8, ref.t, ref.stride, ref.org, ref.w64, ref.h64, F.MARGIN_X, F.MARGIN_Y)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(3): A.sea_integral(8, ref.t, ref.stride, ref.org, ref.w64, ref.h64, F.MARGIN_X, F.MARGIN_Y, planes=integral[0])
+e1.record(); torch.cuda.synchronize()
+print(f"{W}x{H} x265hip_sea_integral (twelve block-sum planes of one reference): {e0.elapsed_time(e1) / 3:.3f} ms")
+only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+for name, m in (("dia", A.ME_DIA), ("hex", A.ME_HEX), ("umh", A.ME_UMH), ("star", A.ME_STAR), ("sea", A.ME_SEA)):
+    if only and name not in only:
+        continue
     for subme in (2, 3):
-        f = lambda: A.me_search(8, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, m, subme, 57, cq_d, qoff, (-57, -57), (57, 57), jd, len(jn))
+        f = lambda: A.me_search(8, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, m, subme, 57, cq_d, qoff, (-57, -57), (57, 57), jd, len(jn),
+                                integral=integral if m == A.ME_SEA else None)
         f(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

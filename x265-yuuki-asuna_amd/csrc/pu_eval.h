@@ -61,7 +61,7 @@ struct PuEval
     __device__ __forceinline__ int cost_mv(int mx, int my) const { return sad_at(mx, my) + mvcost_q(mx * 4, my * 4); }
 
     // N candidates at once (the reference's sad_x3 / sad_x4 groups): all reference loads are issued before the first
-    // reduction, so one memory round trip serves the group
+    // reduction, so one memory round trip serves the group.  sad_n: the bare SADs (SEA adds its own cost terms); cost_mv_n: SAD + mvcost
     template <int N>
     __device__ __forceinline__ void sad_n(const int (&mx)[N], const int (&my)[N], int (&out)[N]) const
     {
@@ -91,9 +91,27 @@ struct PuEval
     template <int N>
     __device__ __forceinline__ void cost_mv_n(const int (&mx)[N], const int (&my)[N], int (&out)[N]) const
     {
-        sad_n<N>(mx, my, out);
+        uint32_t acc[N];
 #pragma unroll
-        for (int n = 0; n < N; n++) out[n] += mvcost_q(mx[n] * 4, my[n] * 4);
+        for (int n = 0; n < N; n++) acc[n] = 0;
+#pragma unroll
+        for (int k = 0; k < T; k++)
+        {
+            if (!have[k]) continue;
+#pragma unroll
+            for (int n = 0; n < N; n++)
+            {
+                const uint32_t ro = refOrg[k] + (uint32_t)(my[n] * strideB + mx[n] * BPP);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int q = 0; q < DW; q++)
+                        acc[n] = sad_dw<Px>(ld_u32(base + (ro + (uint32_t)(r * strideB + 4 * q))), src[k][r][q], acc[n]);
+            }
+            if (N * T * 4 * DW > 64) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int n = 0; n < N; n++) out[n] = group_total<G>((int)acc[n]) + mvcost_q(mx[n] * 4, my[n] * 4);
     }
 
     // subpelCompare: SAD or SATD of the PU at quarter-pel displacement (qx, qy)

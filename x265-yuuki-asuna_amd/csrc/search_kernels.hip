@@ -233,6 +233,8 @@ __device__ __forceinline__ void umh_search(const PuEval<Px, G, T>& c, SMv& bmv, 
 }
 
 // One PU per lane group: `job` is the group's job (every lane of the group passes the same value).
+constexpr int kSeaListLen = 128;      // candidates per SEA row: 2 * merange + 4 <= 128
+
 // the group's lanes that voted true, bit i = lane i of the group (the lanes of a group are always active together)
 template <int G> __device__ __forceinline__ unsigned long long group_ballot(bool v)
 {
@@ -311,6 +313,8 @@ __device__ __forceinline__ bool sea_search(const PuEval<Px, G, T>& c, const Sear
     const int minX = max(bmv.x - merange, c.mvmin.x), minY = max(bmv.y - merange, c.mvmin.y);
     const int maxX = min(bmv.x + merange, c.mvmax.x), maxY = min(bmv.y + merange, c.mvmax.y);
     const int width = (maxX - minX + 3) & ~3;                       // up to three candidates beyond maxX are examined
+    __shared__ short seaLists[256 / 4][kSeaListLen];                // one survivor list per lane group of the workgroup
+    short* list = seaLists[(threadIdx.x / G) * (G / 4)];
     for (int ty = minY; ty <= maxY; ty++)
     {
         // three mv-cost expressions meet here: the filter adds the ordinary x cost; the threes add m_cost[4x - 2 qmvp.x] and no y
@@ -319,48 +323,77 @@ __device__ __forceinline__ bool sea_search(const PuEval<Px, G, T>& c, const Sear
         if (bcost <= ycost) continue;
         const int thr = bcost - ycost;                              // the filter's threshold for the whole row
         int cur = thr;
-        int pend0 = 0, pend1 = 0, np = 0;
         const uint32_t* row = pl + (long)ty * ps;
+        // the filter: G x U consecutive candidates per step (independent plane reads, issued together); the survivors' column
+        // numbers go to the group's list in LDS in ascending order - the reference's mvs[] scratch array
+        constexpr int U = G == 4 ? 8 : (G == 16 ? 2 : 1);
+        int n = 0;
 #pragma unroll 1
-        for (int i0 = 0; i0 < width; i0 += G)
+        for (int i0 = 0; i0 < width; i0 += G * U)
         {
-            const int i = i0 + gl;
-            bool pass = false;
-            if (i < width)
-            {
-                const int x = minX + i;
-                const uint32_t* sp = row + x;
-                int ads = (int)c.cost[4 * x - c.mvpx] + abs(dc[0] - (int)sp[0]);
-                if (nAds >= 2) ads += abs(enc1 - (int)sp[off1]);
-                if (nAds == 4) ads += abs(dc[2] - (int)sp[off2]) + abs(dc[3] - (int)sp[off3]);
-                pass = ads < thr;
-            }
-            unsigned long long m = group_ballot<G>(pass);
-#pragma unroll 1
-            while (m)
-            {
-                const int x = minX + i0 + __ffsll((long long)m) - 1;
-                m &= m - 1;
-                if (np == 0) { pend0 = x; np = 1; }
-                else if (np == 1) { pend1 = x; np = 2; }
-                else
-                {
-                    const int xs[3] = { pend0, pend1, x }, ys[3] = { ty, ty, ty };
-                    int sads[3];
-                    c.template sad_n<3>(xs, ys, sads);
+            bool pass[U];
 #pragma unroll
-                    for (int k = 0; k < 3; k++)
-                    {
-                        const int cost = sads[k] + (int)c.cost[4 * xs[k] - 2 * c.mvpx];
-                        if (cost < cur) { cur = cost; bmv.x = xs[k]; bmv.y = ty; }
-                    }
-                    np = 0;
+            for (int u = 0; u < U; u++)
+            {
+                const int i = i0 + u * G + gl;
+                pass[u] = false;
+                if (i < width)
+                {
+                    const int x = minX + i;
+                    const uint32_t* sp = row + x;
+                    int ads = (int)c.cost[4 * x - c.mvpx] + abs(dc[0] - (int)sp[0]);
+                    if (nAds >= 2) ads += abs(enc1 - (int)sp[off1]);
+                    if (nAds == 4) ads += abs(dc[2] - (int)sp[off2]) + abs(dc[3] - (int)sp[off3]);
+                    pass[u] = ads < thr;
                 }
             }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+            {
+                const unsigned long long m = group_ballot<G>(pass[u]);
+                if (pass[u]) list[n + __popcll(m & ((1ull << gl) - 1))] = (short)(minX + i0 + u * G + gl);
+                n += __popcll(m);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // the list is read back by the lanes of the same wavefront
+        // the threes (sad_x3 with the y-less cost), two at a time so that six SADs share a memory round trip
+        int i = 0;
+#pragma unroll 1
+        for (; i + 6 <= n; i += 6)
+        {
+            int xs[6], ys[6], sads[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { xs[k] = list[i + k]; ys[k] = ty; }
+            c.template sad_n<6>(xs, ys, sads);
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+            {
+                const int cost = sads[k] + (int)c.cost[4 * xs[k] - 2 * c.mvpx];
+                if (cost < cur) { cur = cost; bmv.x = xs[k]; bmv.y = ty; }
+            }
+        }
+        if (i + 3 <= n)
+        {
+            int xs[3], ys[3], sads[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { xs[k] = list[i + k]; ys[k] = ty; }
+            c.template sad_n<3>(xs, ys, sads);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+            {
+                const int cost = sads[k] + (int)c.cost[4 * xs[k] - 2 * c.mvpx];
+                if (cost < cur) { cur = cost; bmv.x = xs[k]; bmv.y = ty; }
+            }
+            i += 3;
         }
         bcost = cur + ycost;
-        if (np >= 1) { const int cost = c.cost_mv(pend0, ty); if (cost < bcost) { bcost = cost; bmv.x = pend0; bmv.y = ty; } }
-        if (np == 2) { const int cost = c.cost_mv(pend1, ty); if (cost < bcost) { bcost = cost; bmv.x = pend1; bmv.y = ty; } }
+        for (; i < n; i++)                                          // the 0-2 left over: ordinary cost against the restored bcost
+        {
+            const int x = list[i];
+            const int cost = c.cost_mv(x, ty);
+            if (cost < bcost) { bcost = cost; bmv.x = x; bmv.y = ty; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // before the next row overwrites the list
     }
     return true;
 }
@@ -650,6 +683,7 @@ extern "C" int x265hip_me_search(const x265hip_me_search_params* p, void* stream
     if (p->njobs == 0) return 0;
     if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("me_search: depth %d", p->depth); return X265HIP_EINVAL; }
     if (p->method < X265HIP_ME_DIA || p->method > X265HIP_ME_FULL) { set_error("me_search: unknown search method %d", p->method); return X265HIP_EINVAL; }
+    if (p->method == X265HIP_ME_SEA && (p->merange < 0 || 2 * p->merange + 4 > 128)) { set_error("me_search: X265_SEA merange %d out of [0,62]", p->merange); return X265HIP_EINVAL; }
     if (p->method == X265HIP_ME_SEA)
         for (int k = 0; k < 12; k++)
             if (!p->integral[k]) { set_error("me_search: X265_SEA needs the twelve block-sum planes (x265hip_sea_integral); integral[%d] is NULL", k); return X265HIP_EINVAL; }

@@ -269,11 +269,18 @@ class PatternSearch:
         cq, self.qoff = F.qpel_cost_table(merange, lam, qmax=8 * (merange + 8) + 64)
         self.cost_q = torch.from_numpy(cq.view(np.int16)).to(device)
         self.out = torch.zeros(self.njobs * 2, dtype=torch.int32, device=device)
+        self.w64, self.h64, self.planes = w64, h64, None
 
     def run(self, cur: DevicePicture, ref: DevicePicture):
+        from . import frames as F
         r = self.merange
+        integral = None
+        if self.method == hipabi.ME_SEA:
+            # the reference picture's block-sum planes, rebuilt per reference like FrameFilter does after reconstruction
+            integral = hipabi.sea_integral(self.depth, ref.t, ref.stride, ref.org, self.w64, self.h64, F.MARGIN_X, F.MARGIN_Y, planes=self.planes)
+            self.planes = integral[0]
         hipabi.me_search(self.depth, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, self.method, self.subme, r,
-                         self.cost_q, self.qoff, (-r, -r), (r, r), self.jobs, self.njobs)
+                         self.cost_q, self.qoff, (-r, -r), (r, r), self.jobs, self.njobs, integral=integral)
         o = self.out.view(-1, 2)
         o[:, 0] = self.jobs[:, 8]
         o[:, 1] = (self.jobs[:, 6] & 0xffff) | (self.jobs[:, 7] << 16)
@@ -301,7 +308,7 @@ class FramePipeline:
         # search != "full": the pattern-search drivers replace the exhaustive search + sub-pel pair
         self.ps = None
         if search != "full":
-            method = {"dia": hipabi.ME_DIA, "hex": hipabi.ME_HEX, "umh": hipabi.ME_UMH, "star": hipabi.ME_STAR}[search]
+            method = {"dia": hipabi.ME_DIA, "hex": hipabi.ME_HEX, "umh": hipabi.ME_UMH, "star": hipabi.ME_STAR, "sea": hipabi.ME_SEA}[search]
             self.ps = PatternSearch(w64, h64, depth, method, subme, rng, device)
         self.rc = InterRecon(self.ms.nctu, w64, h64, depth, level, qp, device)
         self.la = Lookahead(lookahead[0], lookahead[1], depth, device) if lookahead else None
