@@ -398,6 +398,11 @@ typedef struct x265hip_intra_recon_params
     int qp, intra_slice;
     const x265hip_job* jobs;  int njobs;
     int16_t* levels; uint32_t* num_sig; uint64_t* dist;
+    /* non-zero: the 4:2:0 chroma flavour (Search::codeIntraChromaQt's pixel work, search.cpp:899-930) - Predict::predIntraChromaAng
+     * (predict.cpp:590-598) predicts from the UNFILTERED neighbours (off[2] is not read) with bFilter = 0, the 4x4 TU takes the DCT
+     * (useDST needs TEXT_LUMA, quant.cpp:426,583); fenc / nb / recon are the chroma plane's, n = 4..32, qp = the chroma QP the
+     * host mapped (Quant::setChromaQP) + QP_BD_OFFSET */
+    int chroma;
 } x265hip_intra_recon_params;
 int x265hip_intra_recon_batch(const x265hip_intra_recon_params* p, void* stream);
 

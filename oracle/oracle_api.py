@@ -210,11 +210,12 @@ def deblock_luma(depth, rec, stride, org, width, height, bs_ver, bs_hor, qp, qp_
     return out
 
 
-def intra_recon(depth, n, fenc, fenc_stride, nb, recon_len, recon_stride, qp, intra_slice, jobs, nthreads=0, avx2=False):
-    """CPU restatement of the intra TU candidate set (search.cpp:335-373 through the oracle primitives).
+def intra_recon(depth, n, fenc, fenc_stride, nb, recon_len, recon_stride, qp, intra_slice, jobs, nthreads=0, avx2=False, chroma=False):
+    """CPU restatement of the intra TU candidate set (search.cpp:335-373 through the oracle primitives); chroma=True: the 4:2:0
+    chroma flavour (predIntraChromaAng: unfiltered neighbours, no edge smoothing; DCT for 4x4).
     jobs: numpy records {off[4], arg[4]}.  Returns (recon flat array, levels, num_sig, dist)."""
     L = lib(avx2)
-    fn = getattr(L, f"x265oracle_intra_recon_d{depth}")
+    fn = getattr(L, f"x265oracle_intra_recon{'_chroma' if chroma else ''}_d{depth}")
     njobs = len(jobs)
     recon = np.zeros(recon_len, dtype=fenc.dtype)
     levels = np.zeros(njobs * n * n, dtype=np.int16)

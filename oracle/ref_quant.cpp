@@ -22,14 +22,33 @@ using namespace X265_NS;
 
 extern "C" void x265ref_encoder_table_reset_c(void);
 
+namespace { struct QuantProbe : public Quant { using Quant::setChromaQP; }; }     /* setChromaQP is protected (quant.h:153) */
+
 extern "C" {
 
 /* resi: int16 [njobs][n*n] residual blocks (stride n).  qpScaled: the QP the quantiser works with (qp + QP_BD_OFFSET, what the
  * device stages take).  intraCU: the CU's prediction mode (4x4 intra luma uses DST-VII); intraSlice: I slice (rounding 171 vs 85).
  * Outputs: levels int16 [njobs][n*n], numSig uint32 [njobs], resiOut int16 [njobs][n*n] (zero when numSig == 0, as the callers
  * skip the inverse transform then).  Returns 0 on success. */
+static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intraCU, int intraSlice, int njobs,
+                             int16_t* levels, uint32_t* numSig, int16_t* resiOut, TextType ttype);
+
 int x265ref_tu_roundtrip(const int16_t* resi, int n, int qpScaled, int intraCU, int intraSlice, int njobs,
                          int16_t* levels, uint32_t* numSig, int16_t* resiOut)
+{
+    return tu_roundtrip_core(resi, n, qpScaled, intraCU, intraSlice, njobs, levels, numSig, resiOut, TEXT_LUMA);
+}
+
+/* the same with TEXT_CHROMA_U blocks (no DST for the 4x4 intra TU); qpScaled is the chroma QP + QP_BD_OFFSET the quantiser is
+ * to work with: Quant::setChromaQP stores it per text type, here the CU's QP is simply set to it */
+int x265ref_tu_roundtrip_chroma(const int16_t* resi, int n, int qpScaled, int intraCU, int intraSlice, int njobs,
+                                int16_t* levels, uint32_t* numSig, int16_t* resiOut)
+{
+    return tu_roundtrip_core(resi, n, qpScaled, intraCU, intraSlice, njobs, levels, numSig, resiOut, TEXT_CHROMA_U);
+}
+
+static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intraCU, int intraSlice, int njobs,
+                             int16_t* levels, uint32_t* numSig, int16_t* resiOut, TextType ttype)
 {
     static bool tableReady = false;
     if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
@@ -80,19 +99,21 @@ int x265ref_tu_roundtrip(const int16_t* resi, int n, int qpScaled, int intraCU, 
     scalingList.m_bEnabled = false;
     scalingList.setupQuantMatrices(param->internalCsp);
     Entropy entropy;
-    Quant quant;
+    QuantProbe quant;
     if (!quant.init(0.0, scalingList, entropy)) return -4;
     quant.setQPforQuant(ctu, qpScaled - QP_BD_OFFSET);
+    if (ttype != TEXT_LUMA)          /* the I400 CTU above leaves the chroma QPs unset; chFmt 4:4:4 = no mapping table: the caller passes the mapped QP */
+        quant.setChromaQP(qpScaled - QP_BD_OFFSET, ttype, X265_CSP_I444);
 
     std::vector<pixel> fencDummy(n * n, 0);
     for (int j = 0; j < njobs; j++)
     {
         int16_t* lv = levels + (size_t)j * n * n;
         int16_t* out = resiOut + (size_t)j * n * n;
-        const uint32_t ns = quant.transformNxN(ctu, fencDummy.data(), n, resi + (size_t)j * n * n, n, lv, log2n, TEXT_LUMA, 0, false);
+        const uint32_t ns = quant.transformNxN(ctu, fencDummy.data(), n, resi + (size_t)j * n * n, n, lv, log2n, ttype, 0, false);
         numSig[j] = ns;
         memset(out, 0, sizeof(int16_t) * n * n);
-        if (ns) quant.invtransformNxN(ctu, out, n, lv, log2n, TEXT_LUMA, !!intraCU, false, ns);
+        if (ns) quant.invtransformNxN(ctu, out, n, lv, log2n, ttype, !!intraCU, false, ns);
     }
     frame.m_encData = NULL;
     encData.m_picCTU = NULL; encData.m_slice = NULL;

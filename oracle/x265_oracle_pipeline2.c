@@ -322,9 +322,31 @@ static const uint8_t kIntraFilterFlags[35] = {
     0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30,
     0x38 };
 
+static int intra_recon_core(const pixel* fenc, intptr_t fencStride, const pixel* nb, pixel* recon, intptr_t reconStride,
+                            int n, int qp, int isIntraSlice, const intra_job* jobs, int njobs,
+                            int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads, int chroma);
+
 int EXPORT(x265oracle_intra_recon)(const pixel* fenc, intptr_t fencStride, const pixel* nb, pixel* recon, intptr_t reconStride,
                                    int n, int qp, int isIntraSlice, const intra_job* jobs, int njobs,
                                    int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads)
+{
+    return intra_recon_core(fenc, fencStride, nb, recon, reconStride, n, qp, isIntraSlice, jobs, njobs, levels, numSigOut, distOut, nthreads, 0);
+}
+
+/* The chroma flavour for 4:2:0 (Search::codeIntraChromaQt's pixel work, search.cpp:899-930): Predict::predIntraChromaAng
+ * (predict.cpp:590-598) always predicts from the UNFILTERED neighbours with bFilter = 0 (no DC / vertical / horizontal edge
+ * smoothing), and the 4x4 TU uses the DCT (useDST needs TEXT_LUMA, quant.cpp:426,583).  qp = the chroma QP the host mapped
+ * (Quant::setChromaQP, + QP_BD_OFFSET); fenc / nb / recon are the chroma plane's. */
+int EXPORT(x265oracle_intra_recon_chroma)(const pixel* fenc, intptr_t fencStride, const pixel* nb, pixel* recon, intptr_t reconStride,
+                                          int n, int qp, int isIntraSlice, const intra_job* jobs, int njobs,
+                                          int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads)
+{
+    return intra_recon_core(fenc, fencStride, nb, recon, reconStride, n, qp, isIntraSlice, jobs, njobs, levels, numSigOut, distOut, nthreads, 1);
+}
+
+static int intra_recon_core(const pixel* fenc, intptr_t fencStride, const pixel* nb, pixel* recon, intptr_t reconStride,
+                            int n, int qp, int isIntraSlice, const intra_job* jobs, int njobs,
+                            int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads, int chroma)
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
@@ -332,7 +354,7 @@ int EXPORT(x265oracle_intra_recon)(const pixel* fenc, intptr_t fencStride, const
     const int log2n = n == 4 ? 2 : (n == 8 ? 3 : (n == 16 ? 4 : 5));
     if ((1 << log2n) != n) return -1;
     const struct x265hip_CU* cu = &prim.cu[log2n - 2];
-    const int useDST = n == 4;
+    const int useDST = n == 4 && !chroma;
     const int per = qp / 6, rem = qp % 6;
     const int transformShift = 15 - X265HIP_DEPTH - log2n;
     const int qbits = 14 + per + transformShift;
@@ -355,8 +377,8 @@ int EXPORT(x265oracle_intra_recon)(const pixel* fenc, intptr_t fencStride, const
         const int mode = jb->arg[0];
         const pixel* fe = fenc + jb->off[0];
         pixel* rec = recon + jb->off[3];
-        const int filter = !!(kIntraFilterFlags[mode] & n);
-        cu->intra_pred[mode](pred, n, nb + (filter ? jb->off[2] : jb->off[1]), mode, log2n <= 4);
+        const int filter = !chroma && (kIntraFilterFlags[mode] & n);
+        cu->intra_pred[mode](pred, n, nb + (filter ? jb->off[2] : jb->off[1]), mode, chroma ? 0 : log2n <= 4);
         /* calcresidual assumes one stride for fenc / pred / residual (search.cpp:357); restate it for separate strides */
         for (int y = 0; y < n; y++)
             for (int x = 0; x < n; x++) resi[y * n + x] = (int16_t)((int)fe[y * fencStride + x] - (int)pred[y * n + x]);

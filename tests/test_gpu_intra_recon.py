@@ -37,7 +37,10 @@ def _smooth(a):
 @pytest.mark.parametrize("depth,n,qp,islice", [(8, 4, 22, 1), (8, 8, 27, 1), (8, 16, 32, 0), (8, 32, 22, 1), (8, 32, 44, 0),
                                                (10, 4, 30, 0), (10, 8, 12, 1), (10, 16, 24, 1), (10, 32, 37, 1), (8, 16, 0, 1),
                                                (12, 4, 40, 1), (12, 16, 33, 0), (12, 32, 50, 1)])
-def test_intra_recon_matches_oracle(depth, n, qp, islice):
+@pytest.mark.parametrize("chroma", [False, True])
+def test_intra_recon_matches_oracle(depth, n, qp, islice, chroma):
+    """chroma: the 4:2:0 chroma flavour (predIntraChromaAng: unfiltered neighbours, bFilter 0; DCT for 4x4 - the oracle side of both
+    flavours is pinned against the real Quant / the table primitive in tests/test_oracle_classes_vs_reference.py)."""
     import torch
     dev = torch.device("cuda:0")
     rng = np.random.default_rng([61, depth, n, qp])
@@ -71,7 +74,7 @@ def test_intra_recon_matches_oracle(depth, n, qp, islice):
     njobs = len(jobs)
     recon_len = njobs * n * recon_stride
     O = _oracle()
-    erec, elev, ens, edist = O.intra_recon(depth, n, fenc.reshape(-1), fenc_stride, nb.reshape(-1), recon_len, recon_stride, qp, islice, jobs)
+    erec, elev, ens, edist = O.intra_recon(depth, n, fenc.reshape(-1), fenc_stride, nb.reshape(-1), recon_len, recon_stride, qp, islice, jobs, chroma=chroma)
 
     d_fenc = torch.from_numpy(fenc.reshape(-1).view(np.uint8)).to(dev)
     d_nb = torch.from_numpy(nb.reshape(-1).view(np.uint8)).to(dev)
@@ -80,7 +83,7 @@ def test_intra_recon_matches_oracle(depth, n, qp, islice):
     d_lev = torch.full((njobs * n * n,), 0x5a5a, dtype=torch.int16, device=dev)
     d_ns = torch.zeros(njobs, dtype=torch.int32, device=dev)
     d_dist = torch.zeros(njobs, dtype=torch.int64, device=dev)
-    H.intra_recon_batch(depth, n, d_fenc, fenc_stride, d_nb, d_rec, recon_stride, qp, islice, d_jobs, njobs, d_lev, d_ns, d_dist)
+    H.intra_recon_batch(depth, n, d_fenc, fenc_stride, d_nb, d_rec, recon_stride, qp, islice, d_jobs, njobs, d_lev, d_ns, d_dist, chroma=chroma)
     torch.cuda.synchronize()
     assert np.array_equal(d_ns.cpu().numpy().view(np.uint32), ens), "numSig differs"
     assert np.array_equal(d_lev.cpu().numpy(), elev), "quantised levels differ"
@@ -93,3 +96,6 @@ def test_intra_recon_matches_oracle(depth, n, qp, islice):
         assert (ens > 1).any()
     if qp == 44:
         assert (ens == 0).any()
+    if chroma and n <= 16:                                      # the two flavours really differ (edge smoothing / filtered neighbours / DST)
+        other = O.intra_recon(depth, n, fenc.reshape(-1), fenc_stride, nb.reshape(-1), recon_len, recon_stride, qp, islice, jobs)[0]
+        assert not np.array_equal(other, erec)

@@ -503,16 +503,20 @@ def test_deblock_b_picture_boundary_strengths_equal_reference_class(depth, level
     assert not (np.array_equal(pv, bv) and np.array_equal(ph, bh))
 
 
+@pytest.mark.parametrize("chroma", [False, True])
 @pytest.mark.parametrize("depth,n,qp,islice", [(8, 4, 24, 1), (8, 4, 30, 0), (8, 8, 27, 1), (8, 16, 33, 0), (8, 32, 22, 1), (8, 32, 45, 0),
                                                (10, 4, 36, 1), (10, 16, 40, 1), (10, 32, 30, 0)])
-def test_intra_tu_round_trip_equals_reference_quant_class(depth, n, qp, islice):
+def test_intra_tu_round_trip_equals_reference_quant_class(depth, n, qp, islice, chroma):
     """The residual half of the intra TU stage (oracle/x265_oracle_pipeline2.c::x265oracle_intra_recon) against the real
     Quant::transformNxN + Quant::invtransformNxN (oracle/ref_quant.cpp): DC prediction from flat neighbours makes the prediction a
-    constant, so levels, numSig and the reconstruction can be compared block by block (DST-VII for 4x4, DC shortcut, empty blocks)."""
+    constant, so levels, numSig and the reconstruction can be compared block by block (DST-VII for 4x4, DC shortcut, empty blocks).
+    chroma: the 4:2:0 chroma flavour (x265oracle_intra_recon_chroma) against the same class with TEXT_CHROMA_U - the 4x4 TU takes
+    the DCT there."""
     import oracle_api as O
     lib = _ref(depth)
-    if not hasattr(lib, "x265ref_tu_roundtrip"):
-        pytest.skip("oracle/_ref predates ref_quant.cpp")
+    entry = "x265ref_tu_roundtrip_chroma" if chroma else "x265ref_tu_roundtrip"
+    if not hasattr(lib, entry):
+        pytest.skip("oracle/_ref predates " + entry)
     rng = np.random.default_rng([31, depth, n, qp])
     dt = np.uint8 if depth == 8 else np.uint16
     pmax, v = (1 << depth) - 1, 1 << (depth - 1)
@@ -529,14 +533,44 @@ def test_intra_tu_round_trip_equals_reference_quant_class(depth, n, qp, islice):
     for t in range(ntu):
         jobs["off"][t] = (t * n, 0, nbw, t * n * n)
         jobs["arg"][t, 0] = 1                                # DC mode
-    rec, lev, ns, _ = O.intra_recon(depth, n, src.reshape(-1), W, nb, ntu * n * n, n, qp, islice, jobs)
+    rec, lev, ns, _ = O.intra_recon(depth, n, src.reshape(-1), W, nb, ntu * n * n, n, qp, islice, jobs, chroma=chroma)
     resi = np.stack([src[:, t * n:(t + 1) * n].astype(np.int16) - v for t in range(ntu)]).reshape(-1)
     rlev, rns, rout = np.zeros(ntu * n * n, np.int16), np.zeros(ntu, np.uint32), np.zeros(ntu * n * n, np.int16)
-    lib.x265ref_tu_roundtrip.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3
-    assert lib.x265ref_tu_roundtrip(resi.ctypes.data, n, qp, 1, islice, ntu, rlev.ctypes.data, rns.ctypes.data, rout.ctypes.data) == 0
+    fn = getattr(lib, entry)
+    fn.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3
+    assert fn(resi.ctypes.data, n, qp, 1, islice, ntu, rlev.ctypes.data, rns.ctypes.data, rout.ctypes.data) == 0
     assert np.array_equal(ns, rns) and np.array_equal(lev, rlev)
     assert np.array_equal(rec.astype(np.int32), np.clip(v + rout.astype(np.int32), 0, pmax))
     assert (rns == 0).any() and (rns > 1).any()
+    if n == 4:                                               # the transform really differs between the two flavours at 4x4
+        other = O.intra_recon(depth, n, src.reshape(-1), W, nb, ntu * n * n, n, qp, islice, jobs, chroma=not chroma)[1]
+        assert not np.array_equal(other, lev)
+
+
+@pytest.mark.parametrize("depth,n", [(8, 4), (8, 8), (8, 16), (8, 32), (10, 8)])
+def test_chroma_intra_prediction_uses_unfiltered_neighbours_without_edge_smoothing(depth, n, repo_root):
+    """Predict::predIntraChromaAng (predict.cpp:590-598, 4:2:0): intra_pred[mode](dst, stride, intraNeighbourBuf[0], mode, 0) - the
+    chroma flavour's prediction (recovered from a lossless-enough candidate: source == prediction gives an empty residual and the
+    reconstruction IS the prediction) equals the table primitive called that way, for every mode."""
+    import oracle_api as O
+    rng = np.random.default_rng([33, depth, n])
+    dt = np.uint8 if depth == 8 else np.uint16
+    pmax = (1 << depth) - 1
+    nbw = 4 * n + 1
+    unf = rng.integers(0, pmax + 1, size=nbw).astype(dt)
+    flt = rng.integers(0, pmax + 1, size=nbw).astype(dt)      # a decoy: the chroma flavour must never read it
+    nb = np.concatenate([unf, flt])
+    import harness as H
+    orc = H.load_oracle(depth, repo_root)
+    ci = {4: 0, 8: 1, 16: 2, 32: 3}[n]
+    for mode in range(35):
+        src = np.zeros((n, n), dtype=dt)
+        orc.fn(f"cu[{ci}].intra_pred[{mode}]")(H.ptr(src), n, H.ptr(unf), mode, 0)
+        jobs = np.zeros(1, dtype=np.dtype([("off", "<i8", 4), ("arg", "<i4", 4)]))
+        jobs["off"][0] = (0, 0, nbw, 0)
+        jobs["arg"][0, 0] = mode
+        rec, lev, ns, dist = O.intra_recon(depth, n, src.reshape(-1), n, nb, n * n, n, 30, 1, jobs, chroma=True)
+        assert ns[0] == 0 and dist[0] == 0 and np.array_equal(rec.reshape(n, n), src), f"mode {mode}"
 
 
 @pytest.mark.parametrize("depth,level,qp", [(8, 2, 30), (8, 0, 24), (10, 1, 38)])

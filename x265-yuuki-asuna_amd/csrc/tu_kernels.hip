@@ -520,9 +520,11 @@ struct IntraTuArgs
     const x265hip_job* jobs; int njobs;
     int depth, qp, intraSlice;
     int16_t* levels; uint32_t* numSig; unsigned long long* dist;
+    int chroma;             // predIntraChromaAng (predict.cpp:590-598): unfiltered neighbours, no edge smoothing
 };
 
-template <typename Px, int N>
+// DST: the 4x4 intra LUMA TU (chroma 4x4 takes the DCT)
+template <typename Px, int N, bool DST>
 __global__ void __launch_bounds__(N <= 8 ? 256 : 64) intra_recon_kernel(IntraTuArgs a)
 {
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
@@ -533,14 +535,14 @@ __global__ void __launch_bounds__(N <= 8 ? 256 : 64) intra_recon_kernel(IntraTuA
     __shared__ int sNumSig;
     const int tid = threadIdx.x, nth = blockDim.x;
     const int maxVal = (1 << a.depth) - 1;
-    TuOpsFor<N, N == 4> ops;
+    TuOpsFor<N, DST> ops;
     ops.init(tid & 63);
     // a persistent single-wavefront workgroup: the operands above are built once, the barriers below are wave-local
     auto do_job = [&](const int job)
     {
         const x265hip_job jb = a.jobs[job];
         const int mode = jb.arg[0];
-        const bool filtered = (kIsFilterFlags[mode] & N) != 0;
+        const bool filtered = !a.chroma && (kIsFilterFlags[mode] & N) != 0;
         const Px* nbp = reinterpret_cast<const Px*>(a.nb) + (filtered ? jb.off[2] : jb.off[1]);
         for (int i = tid; i < 4 * N + 1; i += nth) nbS[i] = (int16_t)nbp[i];
         {
@@ -554,16 +556,16 @@ __global__ void __launch_bounds__(N <= 8 ? 256 : 64) intra_recon_kernel(IntraTuA
         int part = 0;
         for (int i = tid; i < 2 * N; i += nth) part += i < N ? nbS[1 + i] : nbS[2 * N + 1 + (i - N)];
         const int dc = (group_sum<64>(part) + N) / (2 * N);
-        const int bFilter = LOG2N <= 4;
+        const int bFilter = !a.chroma && LOG2N <= 4;
         for (int i = tid; i < NN; i += nth)
         {
             const int y = i >> LOG2N, x = i & (N - 1);
             pred[i] = (int16_t)intra_sample(nbS, N, LOG2N, mode, bFilter, dc, maxVal, x, y);
         }
         __syncthreads();
-        tu_chain<Px, N, N == 4>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
-                                a.levels + (size_t)job * NN, &a.numSig[job], &a.dist[job],
-                                reinterpret_cast<Px*>(a.recon) + jb.off[3], a.reconStrideB / BPP);
+        tu_chain<Px, N, DST>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
+                             a.levels + (size_t)job * NN, &a.numSig[job], &a.dist[job],
+                             reinterpret_cast<Px*>(a.recon) + jb.off[3], a.reconStrideB / BPP);
         __syncthreads();
     };
     // 4 / 8: one candidate per workgroup; 16 / 32: persistent, the MFMA operands above are reused
@@ -715,7 +717,7 @@ extern "C" int x265hip_intra_recon_batch(const x265hip_intra_recon_params* p, vo
     a.fenc = (const uint8_t*)p->fenc; a.fencStrideB = (long)p->fenc_stride * bpp;
     a.nb = (const uint8_t*)p->nb;
     a.recon = (uint8_t*)p->recon; a.reconStrideB = (long)p->recon_stride * bpp;
-    a.jobs = p->jobs; a.njobs = p->njobs; a.depth = p->depth; a.qp = p->qp; a.intraSlice = p->intra_slice;
+    a.jobs = p->jobs; a.njobs = p->njobs; a.depth = p->depth; a.qp = p->qp; a.intraSlice = p->intra_slice; a.chroma = p->chroma != 0;
     a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
     hipStream_t s = (hipStream_t)stream;
     // 16 / 32: persistent single-wavefront workgroups, exactly one resident set (a second partial round would double the time);
@@ -730,10 +732,11 @@ extern "C" int x265hip_intra_recon_batch(const x265hip_intra_recon_params* p, vo
         return (int)(p->njobs < r ? p->njobs : r);
     };
 #define GOI(PX) do { \
-        if (p->n == 4) hipLaunchKernelGGL((intra_recon_kernel<PX, 4>), dim3(p->njobs), dim3(64), 0, s, a); \
-        else if (p->n == 8) hipLaunchKernelGGL((intra_recon_kernel<PX, 8>), dim3(p->njobs), dim3(64), 0, s, a); \
-        else if (p->n == 16) hipLaunchKernelGGL((intra_recon_kernel<PX, 16>), dim3(resident((const void*)intra_recon_kernel<PX, 16>)), dim3(64), 0, s, a); \
-        else hipLaunchKernelGGL((intra_recon_kernel<PX, 32>), dim3(resident((const void*)intra_recon_kernel<PX, 32>)), dim3(64), 0, s, a); } while (0)
+        if (p->n == 4 && !p->chroma) hipLaunchKernelGGL((intra_recon_kernel<PX, 4, true>), dim3(p->njobs), dim3(64), 0, s, a); \
+        else if (p->n == 4) hipLaunchKernelGGL((intra_recon_kernel<PX, 4, false>), dim3(p->njobs), dim3(64), 0, s, a); \
+        else if (p->n == 8) hipLaunchKernelGGL((intra_recon_kernel<PX, 8, false>), dim3(p->njobs), dim3(64), 0, s, a); \
+        else if (p->n == 16) hipLaunchKernelGGL((intra_recon_kernel<PX, 16, false>), dim3(resident((const void*)intra_recon_kernel<PX, 16, false>)), dim3(64), 0, s, a); \
+        else hipLaunchKernelGGL((intra_recon_kernel<PX, 32, false>), dim3(resident((const void*)intra_recon_kernel<PX, 32, false>)), dim3(64), 0, s, a); } while (0)
     if (p->depth == 8) GOI(uint8_t); else GOI(uint16_t);
 #undef GOI
     X265HIP_TRY(hipGetLastError());

@@ -470,14 +470,15 @@ class IntraReconParams(ctypes.Structure):
                 ("recon", ctypes.c_void_p), ("recon_stride", ctypes.c_ssize_t),
                 ("qp", ctypes.c_int), ("intra_slice", ctypes.c_int),
                 ("jobs", ctypes.c_void_p), ("njobs", ctypes.c_int),
-                ("levels", ctypes.c_void_p), ("num_sig", ctypes.c_void_p), ("dist", ctypes.c_void_p)]
+                ("levels", ctypes.c_void_p), ("num_sig", ctypes.c_void_p), ("dist", ctypes.c_void_p), ("chroma", ctypes.c_int)]
 
 
 def intra_recon_batch(depth, n, fenc, fenc_stride, nb, recon, recon_stride, qp, intra_slice, jobs, njobs,
-                      levels, num_sig, dist, stream=None):
-    """Intra TU candidate set (search.cpp:335-373): one (TU, mode) candidate per job, see include/x265hip.h."""
+                      levels, num_sig, dist, stream=None, chroma=False):
+    """Intra TU candidate set (search.cpp:335-373): one (TU, mode) candidate per job, see include/x265hip.h.
+    chroma=True: the 4:2:0 chroma flavour (unfiltered neighbours, no edge smoothing, DCT for 4x4)."""
     p = IntraReconParams()
-    p.depth, p.n = depth, n
+    p.depth, p.n, p.chroma = depth, n, int(bool(chroma))
     p.fenc, p.fenc_stride, p.nb = fenc.data_ptr(), fenc_stride, nb.data_ptr()
     p.recon, p.recon_stride = recon.data_ptr(), recon_stride
     p.qp, p.intra_slice, p.jobs, p.njobs = qp, intra_slice, jobs.data_ptr(), njobs
