@@ -126,6 +126,42 @@ def lowres_intra(depth, plane, stride, org, width_in_cu, height_in_cu, intra_pen
     return cost, mode, lc
 
 
+def lowres_weight_cost(depth, fenc, ref, stride, org, width, lines, intra_cost, weight, avx2=False):
+    """CPU restatement of LookaheadTLD::weightCostLuma: weight = None (unweighted) or (scale, denom, offset)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_lowres_weight_cost_d{depth}")
+    fn.restype = ctypes.c_uint32
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 4
+    ic = np.ascontiguousarray(intra_cost, dtype=np.int32)
+    es = fenc.itemsize
+    w = (0, 0, 0, 0) if weight is None else (1,) + tuple(int(v) for v in weight)
+    return int(fn(fenc.ctypes.data + org * es, ref.ctypes.data + org * es, stride, width, lines, ic.ctypes.data, *w))
+
+
+def weights_analyse(depth, fenc, ref, stride, org, width, lines, intra_cost, wp_ssd, wp_sum, avx2=False):
+    """CPU restatement of LookaheadTLD::weightsAnalyse.  wp_ssd / wp_sum: (current, reference).  Returns (weight or None, minscore,
+    origscore) with weight = (scale, denom, offset)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_weights_analyse_d{depth}")
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4
+    ic = np.ascontiguousarray(intra_cost, dtype=np.int32)
+    ssd, sm = np.asarray(wp_ssd, dtype=np.uint64), np.asarray(wp_sum, dtype=np.uint64)
+    out = np.zeros(6, np.int64)
+    es = fenc.itemsize
+    fn(fenc.ctypes.data + org * es, ref.ctypes.data + org * es, stride, width, lines, ic.ctypes.data, ssd.ctypes.data, sm.ctypes.data, out.ctypes.data)
+    return (tuple(int(v) for v in out[1:4]) if out[0] else None), int(out[4]), int(out[5])
+
+
+def weight_plane(depth, plane, weight):
+    """primitives.weight_pp over a whole buffer the way weightsAnalyse applies the chosen weight (slicetype.cpp:943-952)."""
+    scale, denom, offset = weight
+    corr = 14 - depth
+    rnd = ((1 << (denom - 1)) if denom else 0) << corr
+    v = (scale * (plane.astype(np.int64) << corr) + rnd) >> (denom + corr)
+    return np.clip(v + (offset << (depth - 8)), 0, (1 << depth) - 1).astype(plane.dtype)
+
+
 def motion_estimate(depth, fenc, fref, stride, org, method, subme, merange, cost_q, qoff, mvmin, mvmax, jobs, nthreads=0, avx2=False,
                     mvc=None, num_mvc=None):
     """CPU restatement of MotionEstimate::motionEstimate over a job array (numpy structured array with the fields of

@@ -198,4 +198,64 @@ int x265ref_lowres_cost_b(const void* curPlane, const void* ref0Plane, const voi
     return 0;
 }
 
+
+/* The REAL LookaheadTLD::weightsAnalyse(fenc, ref) (encoder/slicetype.cpp:860-957) for a current picture / reference pair (planes as
+ * in x265ref_lowres_intra; the reference is frame 0, the current picture frame 1).  wpSsd / wpSum: wp_ssd[0] / wp_sum[0] of the
+ * current picture ([0]) and of the reference ([1]) - normally left in Lowres by the adaptive-quantisation pass.
+ * Outputs: out[0] = weightedRef.isWeighted; weighted: the four weighted planes' whole padded buffers (only meaningful when
+ * out[0]); intraCost (int32 per 8x8 block) as computed by lowresIntraEstimate on the current picture.  Returns 0 on success. */
+int x265ref_weights_analyse(const void* curPlane, const void* refPlane, int width, int height, const uint64_t* wpSsd, const uint64_t* wpSum,
+                            int32_t* out, void* w0, void* w1, void* w2, void* w3, int32_t* intraCost)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width;
+    param->sourceHeight = height;
+    param->internalCsp = X265_CSP_I400;
+    param->maxCUSize = 64;
+    param->rc.aqMode = 0;
+    param->rc.hevcAq = 0;
+    param->bAQMotion = 0;
+    param->bEnableHME = 0;
+    const int h64 = (height + 63) / 64 * 64;
+    PicYuv pics[2];
+    Lowres lrs[2];
+    const void* srcs[2] = { refPlane, curPlane };
+    const uint32_t qgSize = 32;
+    for (int i = 0; i < 2; i++)
+    {
+        pics[i].m_param = param;
+        if (!pics[i].create(param, true)) return -1;
+        memcpy(pics[i].m_picOrg[0] - pics[i].m_lumaMarginY * pics[i].m_stride - pics[i].m_lumaMarginX, srcs[i],
+               sizeof(pixel) * pics[i].m_stride * (h64 + 2 * pics[i].m_lumaMarginY));
+        memset((void*)&lrs[i], 0, sizeof(Lowres));
+        if (!lrs[i].create(param, &pics[i], qgSize)) return -2;
+        lrs[i].init(&pics[i], i);
+        lrs[i].wp_ssd[0] = wpSsd[1 - i];
+        lrs[i].wp_sum[0] = wpSum[1 - i];
+    }
+    Lowres& fenc = lrs[1];
+    Lowres& ref = lrs[0];
+    {
+        LookaheadTLD tld;
+        tld.init(fenc.maxBlocksInRow, fenc.maxBlocksInCol, fenc.maxBlocksInRow * fenc.maxBlocksInCol);
+        tld.lowresIntraEstimate(fenc, qgSize);
+        memcpy(intraCost, fenc.intraCost, sizeof(int32_t) * fenc.maxBlocksInRow * fenc.maxBlocksInCol);
+        tld.weightsAnalyse(fenc, ref);
+        const ReferencePlanes& wr = fenc.weightedRef[1];
+        out[0] = wr.isWeighted ? 1 : 0;
+        if (tld.wbuffer[0])
+        {
+            const size_t planesize = fenc.buffer[1] - fenc.buffer[0];
+            void* outs[4] = { w0, w1, w2, w3 };
+            for (int i = 0; i < 4; i++) memcpy(outs[i], tld.wbuffer[i], planesize * sizeof(pixel));
+        }
+    }
+    for (int i = 0; i < 2; i++) { lrs[i].destroy(); pics[i].destroy(); }
+    x265_param_free(param);
+    return 0;
+}
+
 } // extern "C"

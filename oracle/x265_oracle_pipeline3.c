@@ -137,3 +137,88 @@ void EXPORT(x265oracle_lowres_intra)(const pixel* plane, intptr_t stride, int wi
         intraMode[cuXY] = (uint8_t)ilowmode;
     }
 }
+
+/* ================================================================ weighted-reference analysis of the lookahead
+ * LookaheadTLD::weightCostLuma (slicetype.cpp:807-841): the reference picture's plane 0 weighted by (scale, denom, offset)
+ * through primitives.weight_pp - with the 14-bit intermediate of the interpolation filters: round << (14 - depth), shift
+ * denom + (14 - depth), offset << (depth - 8) - then the 8x8 SATD against the current picture, block by block, each capped by
+ * the block's intra cost.  fenc / ref: sample (0,0) of the lowres planes 0 (the reference weights the whole padded buffer; only
+ * the blocks' samples matter, which may reach up to 7 samples into the padding); intraCost: int32 [blocks]. */
+uint32_t EXPORT(x265oracle_lowres_weight_cost)(const pixel* fenc, const pixel* ref, intptr_t stride, int width, int lines,
+                                               const int32_t* intraCost, int present, int scale, int denom, int inputOffset)
+{
+    init();
+    const int correction = 14 - X265HIP_DEPTH;
+    const int offset = inputOffset << (X265HIP_DEPTH - 8), round = denom ? 1 << (denom - 1) : 0;
+    uint32_t cost = 0;
+    int mb = 0;
+    pixel wbuf[8 * 16] __attribute__((aligned(64)));
+    for (int y = 0; y < lines; y += 8)
+        for (int x = 0; x < width; x += 8, mb++)
+        {
+            const pixel* src = ref + (intptr_t)y * stride + x;
+            intptr_t sstride = stride;
+            if (present)
+            {
+                /* weight_pp works on rows of 16: weight a 16-wide strip, use its left half */
+                pixel strip[8 * 16];
+                for (int r = 0; r < 8; r++)
+                    for (int c = 0; c < 16; c++) strip[r * 16 + c] = c < 8 ? src[r * stride + c] : 0;
+                prim.weight_pp(strip, wbuf, 16, 16, 8, scale, round << correction, denom + correction, offset);
+                src = wbuf; sstride = 16;
+            }
+            const int satd = prim.pu[X265HIP_LUMA_8x8].satd(src, sstride, fenc + (intptr_t)y * stride + x, stride);
+            cost += (uint32_t)(satd < intraCost[mb] ? satd : intraCost[mb]);
+        }
+    return cost;
+}
+
+/* LookaheadTLD::weightsAnalyse (slicetype.cpp:860-957) for one (current, reference) pair: the float arithmetic exactly as written
+ * there (C float: sqrtf, the mean through two divisions, (int)(x + 0.5f)).  wpSsd / wpSum: the pictures' wp_ssd[0] / wp_sum[0]
+ * (luma statistics the adaptive-quantisation pass leaves in Lowres, lowres.h:220-221), [0] = current, [1] = reference.
+ * out[0] = 1 when a weight is chosen (weightedRef.isWeighted), out[1..3] = scale, denom, offset (input offset, 8-bit domain),
+ * out[4] / out[5] = minscore / origscore (0 when the early exits were taken). */
+#include <math.h>
+void EXPORT(x265oracle_weights_analyse)(const pixel* fenc, const pixel* ref, intptr_t stride, int width, int lines, const int32_t* intraCost,
+                                        const uint64_t* wpSsd, const uint64_t* wpSum, int64_t* out)
+{
+    static const float epsilon = 1.f / 128.f;
+    memset(out, 0, 6 * sizeof(int64_t));
+    float guessScale, fencMean, refMean;
+    if (wpSsd[0] && wpSsd[1]) guessScale = sqrtf((float)wpSsd[0] / wpSsd[1]);
+    else guessScale = 1.0f;
+    fencMean = (float)wpSum[0] / (lines * width) / (1 << (X265HIP_DEPTH - 8));
+    refMean = (float)wpSum[1] / (lines * width) / (1 << (X265HIP_DEPTH - 8));
+    if (fabsf(refMean - fencMean) < 0.5f && fabsf(1.f - guessScale) < epsilon) return;
+    /* WeightParam::setFromWeightAndOffset(w, 0, 7, true) (slice.h:306-318): halve an even weight while the denominator lasts, clamp to 127 */
+    int w = (int)(guessScale * 128 + 0.5f), mindenom = 7;
+    while (mindenom > 0 && (w > 127)) { mindenom--; w >>= 1; }
+    int minscale = w < 127 ? w : 127, minoff = 0, found = 0;
+    unsigned int minscore, origscore;
+    /* wp.wtPresent is still 0 here (:866): the first score is the UNWEIGHTED cost, the yardstick of the 0.998 test below */
+    origscore = minscore = EXPORT(x265oracle_lowres_weight_cost)(fenc, ref, stride, width, lines, intraCost, 0, minscale, mindenom, 0);
+    out[4] = minscore; out[5] = origscore;
+    if (!minscore) return;
+    int curScale = minscale;
+    int curOffset = (int)(fencMean - refMean * curScale / (1 << mindenom) + 0.5f);
+    if (curOffset < -128 || curOffset > 127)
+    {
+        curOffset = curOffset < -128 ? -128 : (curOffset > 127 ? 127 : curOffset);
+        curScale = (int)((1 << mindenom) * (fencMean - curOffset) / refMean + 0.5f);
+        curScale = curScale < 0 ? 0 : (curScale > 127 ? 127 : curScale);
+    }
+    const unsigned int s = EXPORT(x265oracle_lowres_weight_cost)(fenc, ref, stride, width, lines, intraCost, 1, curScale, mindenom, curOffset);
+    if (s < minscore) { minscore = s; minscale = curScale; minoff = curOffset; found = 1; }
+    if (mindenom > 0 && !(minscale & 1))
+    {
+        int idx = 0;
+        if (!minscale) idx = 32;                                     /* CTZ(0): tzcnt's answer */
+        else while (!((minscale >> idx) & 1)) idx++;
+        const int shift = idx < mindenom ? idx : mindenom;
+        mindenom -= shift;
+        minscale >>= shift;
+    }
+    out[4] = minscore;
+    if (!found || (minscale == 1 << mindenom && minoff == 0) || (float)minscore / origscore > 0.998f) return;
+    out[0] = 1; out[1] = minscale; out[2] = mindenom; out[3] = minoff;
+}

@@ -312,6 +312,70 @@ def test_lowres_b_frame_cost_restatement_equals_reference_classes(depth, width, 
     assert (used == 1).any() and (used == 2).any() and (used == 3).any()
 
 
+def fade_pair(depth, width, height, gain, lift, seed):
+    """A reference picture and a current picture that is the same scene (static but for a little noise: weightCostLuma compares at
+    zero motion) with a fade applied (gain, lift)."""
+    clip = F.synth_clip(width, height, 1, depth=depth, seed=seed)
+    y0 = clip[0][0]
+    pmax = (1 << depth) - 1
+    noise = np.random.default_rng(seed).integers(-1, 2, size=y0.shape) * (1 << (depth - 8))
+    y1 = np.clip(np.rint(y0.astype(np.float64) * gain + lift * (1 << (depth - 8))) + noise, 0, pmax).astype(y0.dtype)
+    return y0, y1
+
+
+def lowres_stats(plane, rows, stride, lorg, lw, lh):
+    """wp_sum / wp_ssd of a picture, taken over its lowres plane 0 (so that the means weightsAnalyse derives from them are the
+    plane's): sum, and sum of squares minus sum^2 / n (lowres.h:220)."""
+    a = plane.reshape(rows, stride)[lorg // stride: lorg // stride + lh, lorg % stride: lorg % stride + lw].astype(np.int64)
+    sm = int(a.sum())
+    return int((a * a).sum()) - sm * sm // a.size, sm
+
+
+@pytest.mark.parametrize("depth,width,height,gain,lift", [(8, 256, 128, 0.75, 6), (8, 208, 144, 1.0, 0), (8, 256, 128, 1.3, -20), (8, 192, 128, 0.5, 40),
+                                                        (8, 256, 144, 1.0, 9), (10, 192, 128, 0.8, 12), (10, 256, 128, 1.15, -6), (8, 192, 128, 0.25, 150)])
+def test_weighted_reference_analysis_equals_reference_class(depth, width, height, gain, lift):
+    """LookaheadTLD::weightsAnalyse + weightCostLuma (slicetype.cpp:807-957) - the float guess (scale from the variance ratio, offset
+    from the means), the two scored candidates, the denominator reduction, the 0.998 acceptance test and the weighting of the four
+    lowres planes - restatement against the real class on fades of different strength (accepted, rejected, early exit, clamped
+    offset)."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_weights_analyse"):
+        pytest.skip("oracle/_ref predates x265ref_weights_analyse")
+    y0, y1 = fade_pair(depth, width, height, gain, lift, seed=93)
+    cur, stride, org, w64, h64 = F.pad_plane(y1)
+    ref = F.pad_plane(y0)[0]
+    wcu, hcu = (width // 2 + 7) >> 3, (height // 2 + 7) >> 3
+    lw, lh = wcu * 8, hcu * 8
+    rstride = (width // 2 + 2 * F.MARGIN_X + 31) & ~31
+    rows = lh + 2 * F.MARGIN_Y
+    lorg = rstride * F.MARGIN_Y + F.MARGIN_X
+    cplanes = O.lowres_init(depth, cur, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    rplanes = O.lowres_init(depth, ref, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    st = [lowres_stats(cplanes[0], rows, rstride, lorg, lw, lh), lowres_stats(rplanes[0], rows, rstride, lorg, lw, lh)]
+    ssd = np.array([st[0][0], st[1][0]], np.uint64)
+    sm = np.array([st[0][1], st[1][1]], np.uint64)
+    out = np.zeros(4, np.int32)
+    wpl = [np.zeros(rstride * rows, dtype=y0.dtype) for _ in range(4)]
+    ricost = np.zeros(wcu * hcu, np.int32)
+    lib.x265ref_weights_analyse.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8
+    assert lib.x265ref_weights_analyse(cur.ctypes.data, ref.ctypes.data, width, height, ssd.ctypes.data, sm.ctypes.data, out.ctypes.data,
+                                       *[p.ctypes.data for p in wpl], ricost.ctypes.data) == 0
+    lam = 1.0 if depth == 8 else 16.0
+    icost, _, _ = O.lowres_intra(depth, cplanes[0], rstride, lorg, wcu, hcu, 5 * int(lam))
+    assert np.array_equal(icost, ricost)
+    weight, minscore, origscore = O.weights_analyse(depth, cplanes[0], rplanes[0], rstride, lorg, lw, lh, icost, ssd, sm)
+    assert (weight is not None) == bool(out[0]), f"weighted: restatement {weight} (scores {minscore} / {origscore}), reference {out[0]}"
+    expect_weighted = not (gain == 1.0 and abs(lift) < 1)
+    assert (weight is not None) == expect_weighted
+    if weight is not None:
+        assert minscore < origscore
+        for i in range(4):
+            a = O.weight_plane(depth, rplanes[i], weight).reshape(rows, rstride)[:, :F.MARGIN_X + lw]
+            b = wpl[i].reshape(rows, rstride)[:, :F.MARGIN_X + lw]
+            assert np.array_equal(a, b), f"weighted plane {i} differs ({weight})"
+
+
 def sao_case(depth, width, height, seed):
     """Source / deblocked-like pair and random per-CTU SAO parameters (all five types, off, merge-left runs)."""
     rng = np.random.default_rng([21, depth, width, seed])
