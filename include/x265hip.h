@@ -345,6 +345,34 @@ typedef struct x265hip_lowres_intra_params
 } x265hip_lowres_intra_params;
 int x265hip_lowres_intra(const x265hip_lowres_intra_params* p, void* stream);
 
+/* Weighted-reference analysis of the lookahead - the pixel work of LookaheadTLD::weightsAnalyse (encoder/slicetype.cpp:860-957).
+ * x265hip_lowres_weight_cost = LookaheadTLD::weightCostLuma (:807-841) for up to four candidate weights in one launch: the
+ *   reference's lowres plane 0 weighted like primitives.weight_pp (pixel.cpp:518-543, 14-bit intermediate: round << (14 - depth),
+ *   shift denom + (14 - depth), offset << (depth - 8)) - without materialising the weighted plane - then the 8x8 SATD against the
+ *   current picture's plane, each block capped by its intra cost.  cand[i] = { present, scale, log2 denom, offset }; present = 0
+ *   scores the unweighted reference (what weightsAnalyse measures first).  cost: DEVICE uint32 [ncand], overwritten.
+ * x265hip_lowres_weight_apply = the weighting of the reference's four lowres buffers once a weight is accepted (:943-952):
+ *   src[i] / dst[i] = ALLOCATION START of plane i, rows x stride samples each.
+ * The float guess between the calls (variance ratio, means, the 0.998 acceptance test) is host logic: stages.py WeightAnalysis. */
+typedef struct x265hip_lowres_weight_cost_params
+{
+    int depth;
+    const void* fenc; const void* ref; intptr_t stride;      /* sample (0,0) of the two planes 0 */
+    int width, lines;                                        /* the lowres picture (blocks may reach 7 samples into the padding) */
+    const int32_t* intra_cost;                               /* DEVICE int32 [ceil(lines/8) * ceil(width/8)] */
+    int ncand; int cand[4][4];
+    uint32_t* cost;
+} x265hip_lowres_weight_cost_params;
+int x265hip_lowres_weight_cost(const x265hip_lowres_weight_cost_params* p, void* stream);
+typedef struct x265hip_lowres_weight_apply_params
+{
+    int depth;
+    const void* src[4]; void* dst[4];
+    intptr_t stride; int rows;
+    int scale, denom, offset;
+} x265hip_lowres_weight_apply_params;
+int x265hip_lowres_weight_apply(const x265hip_lowres_weight_apply_params* p, void* stream);
+
 /* Sample adaptive offset of a deblocked plane (luma, or a chroma plane through ctu_width / ctu_height / plane_offset) - the two
  * pixel passes of encoder/sao.cpp; the rate-distortion choice of
  * the parameters between them (rdoSaoUnitCu, sao.cpp:1225-1605) stays with the host.

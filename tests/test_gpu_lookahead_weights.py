@@ -1,0 +1,85 @@
+"""GPU parity: the lookahead's weighted-reference analysis (x265hip_lowres_weight_cost / x265hip_lowres_weight_apply + the host-side
+float guess of stages.WeightAnalysis) vs the oracle's restatement of LookaheadTLD::weightCostLuma / weightsAnalyse
+(oracle/x265_oracle_pipeline3.c), which tests/test_oracle_classes_vs_reference.py pins against the real LookaheadTLD."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+S = importlib.import_module("x265-yuuki-asuna_amd.stages")
+A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_api
+    return oracle_api
+
+
+def _fade(depth, width, height, gain, lift, seed):
+    y0 = F.synth_clip(width, height, 1, depth=depth, seed=seed)[0][0]
+    pmax = (1 << depth) - 1
+    noise = np.random.default_rng(seed).integers(-1, 2, size=y0.shape) * (1 << (depth - 8))
+    y1 = np.clip(np.rint(y0.astype(np.float64) * gain + lift * (1 << (depth - 8))) + noise, 0, pmax).astype(y0.dtype)
+    return y0, y1
+
+
+def _stats(plane, la):
+    a = plane.reshape(-1, la.stride)[la.my:la.my + la.lines, la.mx:la.mx + la.width].astype(np.int64)
+    sm = int(a.sum())
+    return int((a * a).sum()) - sm * sm // a.size, sm
+
+
+@pytest.mark.parametrize("depth,width,height,gain,lift", [(8, 512, 256, 0.75, 6), (8, 416, 288, 1.0, 0), (8, 512, 256, 1.3, -20), (8, 384, 256, 0.5, 40),
+                                                        (8, 512, 288, 1.0, 9), (10, 384, 256, 0.8, 12), (10, 512, 256, 1.15, -6), (8, 384, 256, 0.25, 150)])
+def test_weight_analysis_matches_oracle(depth, width, height, gain, lift):
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    y0, y1 = _fade(depth, width, height, gain, lift, seed=95)
+    cur_pic, ref_pic = P.DevicePicture(y1, dev), P.DevicePicture(y0, dev)
+    cur, ref = S.Lookahead(width, height, depth, dev, intra_penalty=5 if depth == 8 else 80), S.Lookahead(width, height, depth, dev)
+    cur.run(cur_pic); ref.run(ref_pic)
+    torch.cuda.synchronize()
+    dt = y0.dtype
+    cpl = [p.cpu().numpy().view(dt) for p in cur.planes]
+    rpl = [p.cpu().numpy().view(dt) for p in ref.planes]
+    icost = cur.intra_cost.cpu().numpy()
+    ssd_c, sum_c = _stats(cpl[0], cur)
+    ssd_r, sum_r = _stats(rpl[0], ref)
+    # the cost kernel alone, four candidates in one launch (unweighted, identity weight, two real ones)
+    cands = [None, (64, 6, 0), (3, 2, 6), (83, 6, -19)]
+    cost = torch.full((4,), -1, dtype=torch.int32, device=dev)
+    A.lowres_weight_cost(depth, cur.planes[0], ref.planes[0], cur.stride, cur.org, cur.width, cur.lines, cur.intra_cost, cands, cost)
+    torch.cuda.synchronize()
+    exp = [O.lowres_weight_cost(depth, cpl[0], rpl[0], cur.stride, cur.org, cur.width, cur.lines, icost, c) for c in cands]
+    assert cost.cpu().numpy().view(np.uint32).tolist() == exp
+    assert exp[0] == exp[1]                                             # scale 64 / 2^6, offset 0 is the identity
+    # the whole analysis
+    wa = S.WeightAnalysis(cur, dev)
+    got = wa.analyse(cur, ref, (ssd_c, ssd_r), (sum_c, sum_r))
+    torch.cuda.synchronize()
+    want = O.weights_analyse(depth, cpl[0], rpl[0], cur.stride, cur.org, cur.width, cur.lines, icost, (ssd_c, ssd_r), (sum_c, sum_r))
+    assert got == want, f"analysis: device {got}, oracle {want}"
+    assert (want[0] is not None) == (not (gain == 1.0 and lift == 0))
+    if want[0] is not None:
+        for i in range(4):
+            assert np.array_equal(wa.weighted[i].cpu().numpy().view(dt), O.weight_plane(depth, rpl[i], want[0])), f"weighted plane {i} differs"
+
+
+def test_weight_cost_rejects_bad_candidates():
+    import torch
+    dev = torch.device("cuda:0")
+    y0, y1 = _fade(8, 128, 128, 0.9, 3, seed=96)
+    la = S.Lookahead(128, 128, 8, dev)
+    la.run(P.DevicePicture(y1, dev))
+    cost = torch.zeros(4, dtype=torch.int32, device=dev)
+    for bad in ([(200, 6, 0)], [(64, 9, 0)], [(64, 6, 300)], []):
+        with pytest.raises(A.X265HipError):
+            A.lowres_weight_cost(8, la.planes[0], la.planes[0], la.stride, la.org, la.width, la.lines, la.intra_cost, bad, cost)

@@ -16,6 +16,7 @@
 // registers (closed form of the reference's projected reference line), Hadamard-transformed per tile and summed over
 // the quad; the data-dependent mode scan runs per quad without divergence because the mode only enters as data.
 #include "common.h"
+#include "tile_interp.h"
 
 namespace x265hip {
 
@@ -240,6 +241,81 @@ __global__ void __launch_bounds__(256) lowres_intra_kernel(LowresIntraArgs a)
     }
 }
 
+// ---- weighted-reference analysis (LookaheadTLD::weightCostLuma / weightsAnalyse, slicetype.cpp:807-957)
+struct WeightCostArgs
+{
+    const uint8_t* fenc; const uint8_t* ref; long strideB;
+    int width, lines, depth;
+    const int32_t* intraCost;
+    int cand[4][4];
+    uint32_t* cost;
+};
+
+// primitives.weight_pp's arithmetic for one sample (pixel.cpp:535-536)
+__device__ __forceinline__ int weight_sample(int v, int scale, int round, int shift, int offset, int correction, int maxVal)
+{
+    const int val = (int)(int16_t)(v << correction);
+    return clip3(0, maxVal, ((scale * val + round) >> shift) + offset);
+}
+
+// one thread per 8x8 block, blockIdx.y = candidate weight: weighted reference vs source through four 4x4 Hadamards (satd8 = two
+// satd_8x4, each the two half sums of a 4x4 pair, pixel.cpp:239-297), capped by the block's intra cost, summed per candidate
+template <typename Px>
+__global__ void __launch_bounds__(256) lowres_weight_cost_kernel(WeightCostArgs a)
+{
+    const int bw = (a.width + 7) >> 3, nblk = bw * ((a.lines + 7) >> 3);
+    const int mb = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    int v = 0;
+    if (mb < nblk)
+    {
+        const int by = mb / bw, bx = mb - by * bw;
+        const int present = a.cand[c][0], scale = a.cand[c][1], denom = a.cand[c][2];
+        const int correction = 14 - a.depth, maxVal = (1 << a.depth) - 1;
+        const int offset = a.cand[c][3] << (a.depth - 8), round = (denom ? 1 << (denom - 1) : 0) << correction, shift = denom + correction;
+        const Px* f = reinterpret_cast<const Px*>(a.fenc + (long)(by * 8) * a.strideB) + bx * 8;
+        const Px* r = reinterpret_cast<const Px*>(a.ref + (long)(by * 8) * a.strideB) + bx * 8;
+        const long st = a.strideB / (long)sizeof(Px);
+        int satd = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+        {
+            int d[4][4];
+            const int ox = (t & 1) * 4, oy = (t >> 1) * 4;
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    int rv = (int)r[(oy + y) * st + ox + x];
+                    if (present) rv = weight_sample(rv, scale, round, shift, offset, correction, maxVal);
+                    d[y][x] = rv - (int)f[(oy + y) * st + ox + x];
+                }
+            satd += tile_satd4(d);
+        }
+        v = min(satd, a.intraCost[mb]);
+    }
+    v = group_sum<64>(v);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&a.cost[c], (uint32_t)v);
+}
+
+struct WeightApplyArgs
+{
+    const uint8_t* src[4]; uint8_t* dst[4];
+    long n; int depth, scale, denom, offset;
+};
+
+template <typename Px>
+__global__ void __launch_bounds__(256) lowres_weight_apply_kernel(WeightApplyArgs a)
+{
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= a.n) return;
+    const int correction = 14 - a.depth, maxVal = (1 << a.depth) - 1;
+    const int offset = a.offset << (a.depth - 8), round = (a.denom ? 1 << (a.denom - 1) : 0) << correction, shift = a.denom + correction;
+    const Px* s = reinterpret_cast<const Px*>(a.src[blockIdx.y]);
+    Px* d = reinterpret_cast<Px*>(a.dst[blockIdx.y]);
+    d[i] = (Px)weight_sample((int)s[i], a.scale, round, shift, offset, correction, maxVal);
+}
+
 } // namespace x265hip
 
 namespace x265hip { int extend_borders(void* const* pics, int nplanes, intptr_t stride, int width, int height, int margin_x, int margin_y, int depth, hipStream_t s); }
@@ -282,6 +358,51 @@ extern "C" int x265hip_lowres_intra(const x265hip_lowres_intra_params* p, void* 
     hipStream_t s = (hipStream_t)stream;
     if (bpp == 1) hipLaunchKernelGGL(lowres_intra_kernel<uint8_t>, dim3((ncu + 63) / 64), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(lowres_intra_kernel<uint16_t>, dim3((ncu + 63) / 64), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x265hip_lowres_weight_cost(const x265hip_lowres_weight_cost_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->fenc || !p->ref || !p->intra_cost || !p->cost) { set_error("lowres_weight_cost: NULL operand"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("lowres_weight_cost: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->width <= 0 || p->lines <= 0) { set_error("lowres_weight_cost: empty picture"); return X265HIP_EINVAL; }
+    if (p->ncand < 1 || p->ncand > 4) { set_error("lowres_weight_cost: ncand %d out of [1,4]", p->ncand); return X265HIP_EINVAL; }
+    for (int i = 0; i < p->ncand; i++)
+        if (p->cand[i][0] && (p->cand[i][1] < 0 || p->cand[i][1] > 127 || p->cand[i][2] < 0 || p->cand[i][2] > 7 || p->cand[i][3] < -128 || p->cand[i][3] > 127))
+        { set_error("lowres_weight_cost: candidate %d {scale %d, denom %d, offset %d} out of range", i, p->cand[i][1], p->cand[i][2], p->cand[i][3]); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    WeightCostArgs a;
+    a.fenc = (const uint8_t*)p->fenc; a.ref = (const uint8_t*)p->ref; a.strideB = (long)p->stride * bpp;
+    a.width = p->width; a.lines = p->lines; a.depth = p->depth; a.intraCost = p->intra_cost; a.cost = p->cost;
+    for (int i = 0; i < 4; i++) for (int k = 0; k < 4; k++) a.cand[i][k] = p->cand[i][k];
+    hipStream_t s = (hipStream_t)stream;
+    X265HIP_TRY(hipMemsetAsync(p->cost, 0, sizeof(uint32_t) * p->ncand, s));
+    const int nblk = ((p->width + 7) >> 3) * ((p->lines + 7) >> 3);
+    if (bpp == 1) hipLaunchKernelGGL(lowres_weight_cost_kernel<uint8_t>, dim3((nblk + 255) / 256, p->ncand), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lowres_weight_cost_kernel<uint16_t>, dim3((nblk + 255) / 256, p->ncand), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x265hip_lowres_weight_apply(const x265hip_lowres_weight_apply_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p) { set_error("lowres_weight_apply: NULL operand"); return X265HIP_EINVAL; }
+    for (int i = 0; i < 4; i++) if (!p->src[i] || !p->dst[i]) { set_error("lowres_weight_apply: NULL plane %d", i); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("lowres_weight_apply: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->stride <= 0 || p->rows <= 0) { set_error("lowres_weight_apply: empty plane"); return X265HIP_EINVAL; }
+    if (p->scale < 0 || p->scale > 127 || p->denom < 0 || p->denom > 7 || p->offset < -128 || p->offset > 127) { set_error("lowres_weight_apply: weight out of range"); return X265HIP_EINVAL; }
+    WeightApplyArgs a;
+    for (int i = 0; i < 4; i++) { a.src[i] = (const uint8_t*)p->src[i]; a.dst[i] = (uint8_t*)p->dst[i]; }
+    a.n = (long)p->stride * p->rows; a.depth = p->depth; a.scale = p->scale; a.denom = p->denom; a.offset = p->offset;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = (unsigned)((a.n + 255) / 256);
+    if (p->depth == 8) hipLaunchKernelGGL(lowres_weight_apply_kernel<uint8_t>, dim3(g, 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lowres_weight_apply_kernel<uint16_t>, dim3(g, 4), dim3(256), 0, s, a);
     X265HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -306,6 +306,51 @@ def me_search(depth, fenc, fenc_stride, fenc_off, fref, fref_stride, fref_off, m
     check(f(ctypes.byref(p), s), "x265hip_me_search")
 
 
+class LowresWeightCostParams(ctypes.Structure):
+    """x265hip_lowres_weight_cost_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("fenc", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),
+                ("width", ctypes.c_int), ("lines", ctypes.c_int), ("intra_cost", ctypes.c_void_p),
+                ("ncand", ctypes.c_int), ("cand", (ctypes.c_int * 4) * 4), ("cost", ctypes.c_void_p)]
+
+
+class LowresWeightApplyParams(ctypes.Structure):
+    """x265hip_lowres_weight_apply_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("src", ctypes.c_void_p * 4), ("dst", ctypes.c_void_p * 4),
+                ("stride", ctypes.c_ssize_t), ("rows", ctypes.c_int),
+                ("scale", ctypes.c_int), ("denom", ctypes.c_int), ("offset", ctypes.c_int)]
+
+
+def lowres_weight_cost(depth, fenc, ref, stride, org, width, lines, intra_cost, cands, cost, stream=None):
+    """LookaheadTLD::weightCostLuma for up to four candidate weights: cands = [None | (scale, denom, offset)], cost = device int32
+    tensor [len(cands)] (uint32 bits), overwritten."""
+    es = 1 if depth == 8 else 2
+    p = LowresWeightCostParams()
+    p.depth, p.stride, p.width, p.lines = depth, stride, width, lines
+    p.fenc, p.ref = fenc.data_ptr() + org * es, ref.data_ptr() + org * es
+    p.intra_cost, p.cost, p.ncand = intra_cost.data_ptr(), cost.data_ptr(), len(cands)
+    for i, c in enumerate(cands):
+        vals = (0, 0, 0, 0) if c is None else (1, int(c[0]), int(c[1]), int(c[2]))
+        for k in range(4):
+            p.cand[i][k] = vals[k]
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_lowres_weight_cost
+    f.argtypes = [ctypes.POINTER(LowresWeightCostParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_lowres_weight_cost")
+
+
+def lowres_weight_apply(depth, src_planes, dst_planes, stride, rows, weight, stream=None):
+    """weight_pp over the four whole lowres buffers (allocation start, rows x stride samples) with weight = (scale, denom, offset)."""
+    p = LowresWeightApplyParams()
+    p.depth, p.stride, p.rows = depth, stride, rows
+    p.scale, p.denom, p.offset = int(weight[0]), int(weight[1]), int(weight[2])
+    for i in range(4):
+        p.src[i], p.dst[i] = src_planes[i].data_ptr(), dst_planes[i].data_ptr()
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_lowres_weight_apply
+    f.argtypes = [ctypes.POINTER(LowresWeightApplyParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_lowres_weight_apply")
+
+
 def sea_integral(depth, ref, stride, org, width, height, margin_x, margin_y, planes=None, stream=None):
     """The twelve block-sum planes of a padded reference picture (x265hip_sea_integral): returns (planes, org) with planes a
     uint32 device tensor [12][rows * stride] laid out like the picture (entry of sample (0,0) at element org)."""

@@ -195,6 +195,67 @@ class Lookahead:
         return {"intra_cost": int(self.intra_cost.sum(dtype=torch.int64).item()), "intra_mode": int(self.intra_mode.sum(dtype=torch.int64).item())}
 
 
+class WeightAnalysis:
+    """Weighted-reference analysis of a prepared picture against a prepared reference - LookaheadTLD::weightsAnalyse
+    (slicetype.cpp:860-957).  The pixel work runs on the device (x265hip_lowres_weight_cost scores the unweighted reference and the
+    offset candidate in ONE launch - the second candidate does not depend on the first score -, x265hip_lowres_weight_apply weights
+    the four planes); the float guess in between is evaluated here in single precision, operation by operation as the reference
+    writes it.  wp_ssd / wp_sum are the pictures' luma statistics (Lowres::wp_ssd[0] / wp_sum[0], left there by the reference's
+    adaptive-quantisation pass)."""
+
+    def __init__(self, la: Lookahead, device):
+        import torch
+        self.la, self.depth = la, la.depth
+        self.cost = torch.zeros(4, dtype=torch.int32, device=device)
+        self.weighted = [torch.zeros_like(p) for p in la.planes]          # the reference's wbuffer[0..3]
+
+    def analyse(self, cur: Lookahead, ref: Lookahead, wp_ssd, wp_sum):
+        """wp_ssd / wp_sum: (current, reference).  Returns (weight or None, minscore, origscore); with a weight, self.weighted holds
+        the weighted reference planes (weightedRef.isWeighted)."""
+        import numpy as np
+        f32 = np.float32
+        depth = self.depth
+        guess = np.sqrt(f32(int(wp_ssd[0])) / f32(int(wp_ssd[1]))) if (wp_ssd[0] and wp_ssd[1]) else f32(1.0)
+        npx = f32(cur.lines * cur.width)
+        fenc_mean = f32(int(wp_sum[0])) / npx / f32(1 << (depth - 8))
+        ref_mean = f32(int(wp_sum[1])) / npx / f32(1 << (depth - 8))
+        if abs(ref_mean - fenc_mean) < f32(0.5) and abs(f32(1.0) - guess) < f32(1.0 / 128.0):
+            return None, 0, 0
+        # WeightParam::setFromWeightAndOffset(w, 0, 7, true), slice.h:304-316
+        w, mindenom = int(guess * f32(128) + f32(0.5)), 7
+        while mindenom > 0 and w > 127:
+            mindenom -= 1
+            w >>= 1
+        minscale, minoff, found = min(w, 127), 0, False
+        cur_scale = minscale
+        cur_off = int(fenc_mean - ref_mean * f32(cur_scale) / f32(1 << mindenom) + f32(0.5))
+        if cur_off < -128 or cur_off > 127:
+            cur_off = max(-128, min(127, cur_off))
+            cur_scale = int(f32(1 << mindenom) * (fenc_mean - f32(cur_off)) / ref_mean + f32(0.5))
+            cur_scale = max(0, min(127, cur_scale))
+        # origscore: wp.wtPresent is still 0 at :907 - the UNWEIGHTED cost; then the offset candidate (:925)
+        hipabi.lowres_weight_cost(depth, cur.planes[0], ref.planes[0], cur.stride, cur.org, cur.width, cur.lines, cur.intra_cost,
+                                  [None, (cur_scale, mindenom, cur_off)], self.cost)
+        scores = self.cost[:2].cpu().numpy().view(np.uint32)
+        origscore = minscore = int(scores[0])
+        if not minscore:
+            return None, minscore, origscore
+        s = int(scores[1])
+        if s < minscore:
+            minscore, minscale, minoff, found = s, cur_scale, cur_off, True
+        if mindenom > 0 and not (minscale & 1):
+            idx = 32 if not minscale else (minscale & -minscale).bit_length() - 1        # CTZ
+            shift = min(idx, mindenom)
+            mindenom -= shift
+            minscale >>= shift
+        if (not found) or (minscale == 1 << mindenom and minoff == 0) or f32(minscore) / f32(origscore) > f32(0.998):
+            return None, minscore, origscore
+        weight = (minscale, mindenom, minoff)
+        rows = cur.lines + 2 * cur.my
+        hipabi.lowres_weight_apply(depth, ref.planes, self.weighted, cur.stride, rows, weight)
+        return weight, minscore, origscore
+
+
 class LookaheadCost:
     """The lookahead's frame cost estimate of a prepared picture against one (P) or two (B) prepared references
     (x265hip_lowres_cost; reference CostEstimateGroup::estimateFrameCost / estimateCUCost, slicetype.cpp:3115-3388).  `lam` is
