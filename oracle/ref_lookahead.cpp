@@ -77,8 +77,28 @@ int x265ref_lowres_intra(const void* plane, int width, int height, int* geometry
  * frame cost estimate with a pool-less Lookahead (no cooperative slices, no HME, no weighted prediction, no AQ).
  * Outputs per 8x8 block: mvs int32 [n][2], mvCosts int32 [n], lowresCosts uint16 [n]; rowSatds int32 [rows];
  * frame int64 [4] = { returned score, costEst, costEstAq, intraMbs }.  Returns 0 on success. */
+static int lowres_cost_core(const void* curPlane, const void* refPlane, int width, int height,
+                            int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int64_t* frame,
+                            const uint64_t* wpSsd, const uint64_t* wpSum, int32_t* isWeighted);
+
 int x265ref_lowres_cost(const void* curPlane, const void* refPlane, int width, int height,
                         int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int64_t* frame)
+{
+    return lowres_cost_core(curPlane, refPlane, width, height, mvs, mvCosts, lowresCosts, rowSatds, frame, NULL, NULL, NULL);
+}
+
+/* The same with --weightp: estimateFrameCost runs weightsAnalyse first (slicetype.cpp:3136-3138) and, when it accepts a weight,
+ * searches the WEIGHTED reference planes (:3222,3267).  wpSsd / wpSum: wp_ssd[0] / wp_sum[0] of the current picture ([0]) and the
+ * reference ([1]); *isWeighted receives weightedRef.isWeighted. */
+int x265ref_lowres_cost_weightp(const void* curPlane, const void* refPlane, int width, int height, const uint64_t* wpSsd, const uint64_t* wpSum,
+                                int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int64_t* frame, int32_t* isWeighted)
+{
+    return lowres_cost_core(curPlane, refPlane, width, height, mvs, mvCosts, lowresCosts, rowSatds, frame, wpSsd, wpSum, isWeighted);
+}
+
+static int lowres_cost_core(const void* curPlane, const void* refPlane, int width, int height,
+                            int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int64_t* frame,
+                            const uint64_t* wpSsd, const uint64_t* wpSum, int32_t* isWeighted)
 {
     static bool tableReady = false;
     if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
@@ -92,7 +112,7 @@ int x265ref_lowres_cost(const void* curPlane, const void* refPlane, int width, i
     param->rc.hevcAq = 0;
     param->bAQMotion = 0;
     param->bEnableHME = 0;
-    param->bEnableWeightedPred = 0;
+    param->bEnableWeightedPred = wpSsd ? 1 : 0;
     param->bEnableWeightedBiPred = 0;
     param->lookaheadSlices = 0;
     const int h64 = (height + 63) / 64 * 64;
@@ -109,6 +129,7 @@ int x265ref_lowres_cost(const void* curPlane, const void* refPlane, int width, i
         memset((void*)&lrs[i], 0, sizeof(Lowres));
         if (!lrs[i].create(param, &pics[i], qgSize)) return -2;
         lrs[i].init(&pics[i], i);
+        if (wpSsd) { lrs[i].wp_ssd[0] = wpSsd[1 - i]; lrs[i].wp_sum[0] = wpSum[1 - i]; }
     }
     Lookahead la(param, NULL);
     if (!la.create()) return -3;
@@ -129,6 +150,7 @@ int x265ref_lowres_cost(const void* curPlane, const void* refPlane, int width, i
     frame[1] = fenc.costEst[1][0];
     frame[2] = fenc.costEstAq[1][0];
     frame[3] = fenc.intraMbs[1];
+    if (isWeighted) *isWeighted = fenc.weightedRef[1].isWeighted ? 1 : 0;
     la.destroy();
     for (int i = 0; i < 2; i++) { lrs[i].destroy(); pics[i].destroy(); }
     x265_param_free(param);

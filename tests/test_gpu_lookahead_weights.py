@@ -73,6 +73,41 @@ def test_weight_analysis_matches_oracle(depth, width, height, gain, lift):
             assert np.array_equal(wa.weighted[i].cpu().numpy().view(dt), O.weight_plane(depth, rpl[i], want[0])), f"weighted plane {i} differs"
 
 
+@pytest.mark.parametrize("depth,width,height,gain,lift", [(8, 512, 256, 0.75, 6), (10, 384, 256, 1.2, -10)])
+def test_weighted_p_frame_cost_matches_oracle(depth, width, height, gain, lift):
+    """--weightp end to end on the device: analysis -> weighted planes -> the frame cost estimate searching them (the oracle chain
+    is pinned against the real CostEstimateGroup::singleCost with bEnableWeightedPred)."""
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    y0, y1 = _fade(depth, width, height, gain, lift, seed=98)
+    y1 = np.roll(y1, (2, -2), axis=(0, 1)).copy()
+    cur, ref = S.Lookahead(width, height, depth, dev, intra_penalty=5 if depth == 8 else 80), S.Lookahead(width, height, depth, dev)
+    cur.run(P.DevicePicture(y1, dev)); ref.run(P.DevicePicture(y0, dev))
+    torch.cuda.synchronize()
+    dt = y0.dtype
+    cp = cur.planes[0].cpu().numpy().view(dt)
+    rpl = [p.cpu().numpy().view(dt) for p in ref.planes]
+    ssd_c, sum_c = _stats(cp, cur)
+    ssd_r, sum_r = _stats(rpl[0], ref)
+    wa = S.WeightAnalysis(cur, dev)
+    weight, _, _ = wa.analyse(cur, ref, (ssd_c, ssd_r), (sum_c, sum_r))
+    assert weight is not None
+    st = S.LookaheadCost(cur, dev)
+    st.run(cur, wa.weighted_ref)
+    torch.cuda.synchronize()
+    icost = cur.intra_cost.cpu().numpy()
+    assert weight == O.weights_analyse(depth, cp, rpl[0], cur.stride, cur.org, cur.width, cur.lines, icost, (ssd_c, ssd_r), (sum_c, sum_r))[0]
+    wpl = [O.weight_plane(depth, p, weight) for p in rpl]
+    cq = st.cost_q.cpu().numpy().view(np.uint16)
+    mvs, mvc, lcost, rows, frame = O.lowres_cost(depth, cp, wpl, cur.stride, cur.org, cur.wcu, cur.hcu, cq, st.qoff, icost)
+    assert np.array_equal(st.mvs.cpu().numpy().reshape(-1, 2), mvs) and np.array_equal(st.mv_costs.cpu().numpy(), mvc)
+    assert np.array_equal(st.lowres_costs.cpu().numpy().view(np.uint16), lcost) and np.array_equal(st.row_satds.cpu().numpy(), rows)
+    assert np.array_equal(st.frame.cpu().numpy()[:3], frame)
+    plain = O.lowres_cost(depth, cp, rpl, cur.stride, cur.org, cur.wcu, cur.hcu, cq, st.qoff, icost)
+    assert plain[4][0] != frame[0]
+
+
 def test_weight_cost_rejects_bad_candidates():
     import torch
     dev = torch.device("cuda:0")

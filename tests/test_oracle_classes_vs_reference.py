@@ -376,6 +376,49 @@ def test_weighted_reference_analysis_equals_reference_class(depth, width, height
             assert np.array_equal(a, b), f"weighted plane {i} differs ({weight})"
 
 
+@pytest.mark.parametrize("depth,width,height,gain,lift", [(8, 256, 128, 0.75, 6), (8, 208, 144, 1.2, -12), (10, 192, 128, 0.8, 10), (8, 256, 128, 1.0, 0)])
+def test_weighted_p_frame_cost_equals_reference_classes(depth, width, height, gain, lift):
+    """--weightp in the lookahead, end to end: the real CostEstimateGroup::singleCost with bEnableWeightedPred runs weightsAnalyse and
+    searches the weighted planes (slicetype.cpp:3136-3138,3222,3267); the restatement chains weights_analyse -> weight_plane ->
+    lowres_cost with the weighted planes as the reference.  A fade with a small global motion (and the no-fade control)."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_lowres_cost_weightp"):
+        pytest.skip("oracle/_ref predates x265ref_lowres_cost_weightp")
+    y0, y1 = fade_pair(depth, width, height, gain, lift, seed=97)
+    y1 = np.roll(y1, (2, -2), axis=(0, 1)).copy()
+    cur, stride, org, w64, h64 = F.pad_plane(y1)
+    ref = F.pad_plane(y0)[0]
+    wcu, hcu = (width // 2 + 7) >> 3, (height // 2 + 7) >> 3
+    lw, lh = wcu * 8, hcu * 8
+    n = wcu * hcu
+    rstride = (width // 2 + 2 * F.MARGIN_X + 31) & ~31
+    rows = lh + 2 * F.MARGIN_Y
+    lorg = rstride * F.MARGIN_Y + F.MARGIN_X
+    cplanes = O.lowres_init(depth, cur, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    rplanes = O.lowres_init(depth, ref, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    st = [lowres_stats(cplanes[0], rows, rstride, lorg, lw, lh), lowres_stats(rplanes[0], rows, rstride, lorg, lw, lh)]
+    ssd, sm = np.array([st[0][0], st[1][0]], np.uint64), np.array([st[0][1], st[1][1]], np.uint64)
+    rmv, rmc, rlc = np.zeros((n, 2), np.int32), np.zeros(n, np.int32), np.zeros(n, np.uint16)
+    rrows, rframe, rw = np.zeros(hcu, np.int32), np.zeros(4, np.int64), np.zeros(1, np.int32)
+    lib.x265ref_lowres_cost_weightp.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8
+    assert lib.x265ref_lowres_cost_weightp(cur.ctypes.data, ref.ctypes.data, width, height, ssd.ctypes.data, sm.ctypes.data, rmv.ctypes.data,
+                                           rmc.ctypes.data, rlc.ctypes.data, rrows.ctypes.data, rframe.ctypes.data, rw.ctypes.data) == 0
+    lam = 1.0 if depth == 8 else 16.0
+    icost, _, _ = O.lowres_intra(depth, cplanes[0], rstride, lorg, wcu, hcu, 5 * int(lam))
+    weight, _, _ = O.weights_analyse(depth, cplanes[0], rplanes[0], rstride, lorg, lw, lh, icost, ssd, sm)
+    assert (weight is not None) == bool(rw[0]) == (gain != 1.0)
+    search_planes = rplanes if weight is None else [O.weight_plane(depth, p, weight) for p in rplanes]
+    cq, qoff = F.qpel_cost_table(16, lam=lam, qmax=4 * (max(lw, lh) + 64))
+    mvs, mvc, lc, rws, frame = O.lowres_cost(depth, cplanes[0], search_planes, rstride, lorg, wcu, hcu, cq, qoff, icost)
+    assert np.array_equal(mvs, rmv), f"mvs differ at {np.flatnonzero((mvs != rmv).any(axis=1))[:8]}"
+    assert np.array_equal(mvc, rmc) and np.array_equal(lc, rlc) and np.array_equal(rws, rrows)
+    assert (frame[0], frame[1], frame[2]) == (rframe[1], rframe[2], rframe[3])
+    if weight is not None:                                   # the weighting matters: the unweighted search gives another answer
+        plain = O.lowres_cost(depth, cplanes[0], rplanes, rstride, lorg, wcu, hcu, cq, qoff, icost)
+        assert plain[4][0] != frame[0]
+
+
 def sao_case(depth, width, height, seed):
     """Source / deblocked-like pair and random per-CTU SAO parameters (all five types, off, merge-left runs)."""
     rng = np.random.default_rng([21, depth, width, seed])

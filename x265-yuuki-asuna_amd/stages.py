@@ -209,6 +209,14 @@ class WeightAnalysis:
         self.cost = torch.zeros(4, dtype=torch.int32, device=device)
         self.weighted = [torch.zeros_like(p) for p in la.planes]          # the reference's wbuffer[0..3]
 
+    @property
+    def weighted_ref(self):
+        """The weighted planes in the shape LookaheadCost takes a reference in: estimateFrameCost searches them instead of the
+        reference's own planes once a weight is accepted (wfref0, slicetype.cpp:3222,3267; P pictures - the bi-directional
+        candidates of B pictures keep the unweighted planes, :3328)."""
+        from types import SimpleNamespace
+        return SimpleNamespace(planes=self.weighted)
+
     def analyse(self, cur: Lookahead, ref: Lookahead, wp_ssd, wp_sum):
         """wp_ssd / wp_sum: (current, reference).  Returns (weight or None, minscore, origscore); with a weight, self.weighted holds
         the weighted reference planes (weightedRef.isWeighted)."""
