@@ -126,6 +126,24 @@ def lowres_intra(depth, plane, stride, org, width_in_cu, height_in_cu, intra_pen
     return cost, mode, lc
 
 
+def aq_frame(depth, y, stride, org, width, height, cb=None, cr=None, stride_c=0, org_c=0, qg_size=16, aq_mode=2, aq_strength=1.0, weightp=True,
+             avx2=False):
+    """CPU restatement of LookaheadTLD::calcAdaptiveQuantFrame.  y / cb / cr: padded planes (flat arrays, sample (0,0) at org / org_c).
+    Returns (energy uint32 [blocks], qp_aq_offset float64 [blocks], inv_qscale int32 [blocks], wp_sum uint64 [3], wp_ssd uint64 [3])."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_aq_frame_d{depth}")
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_ssize_t] * 2 + [ctypes.c_int] * 4 + [ctypes.c_double, ctypes.c_int] + [ctypes.c_void_p] * 5
+    n = ((width + qg_size - 1) // qg_size) * ((height + qg_size - 1) // qg_size)
+    energy, qp, inv = np.zeros(n, np.uint32), np.zeros(n, np.float64), np.zeros(n, np.int32)
+    sm, ssd = np.zeros(3, np.uint64), np.zeros(3, np.uint64)
+    es = y.itemsize
+    fn(y.ctypes.data + org * es, None if cb is None else cb.ctypes.data + org_c * es, None if cr is None else cr.ctypes.data + org_c * es,
+       stride, stride_c, width, height, qg_size, aq_mode, float(aq_strength), int(bool(weightp)),
+       energy.ctypes.data, qp.ctypes.data, inv.ctypes.data, sm.ctypes.data, ssd.ctypes.data)
+    return energy, qp, inv, sm, ssd
+
+
 def lowres_weight_cost(depth, fenc, ref, stride, org, width, lines, intra_cost, weight, avx2=False):
     """CPU restatement of LookaheadTLD::weightCostLuma: weight = None (unweighted) or (scale, denom, offset)."""
     L = lib(avx2)

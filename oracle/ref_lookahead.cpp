@@ -9,6 +9,7 @@
 #include "primitives.h"
 #include "picyuv.h"
 #include "lowres.h"
+#include "frame.h"
 #include "slicetype.h"
 #include "x265.h"
 
@@ -278,6 +279,79 @@ int x265ref_weights_analyse(const void* curPlane, const void* refPlane, int widt
     for (int i = 0; i < 2; i++) { lrs[i].destroy(); pics[i].destroy(); }
     x265_param_free(param);
     return 0;
+}
+
+
+/* The REAL LookaheadTLD::calcAdaptiveQuantFrame (encoder/slicetype.cpp:439-694) on one picture.  yPlane: allocation start of the
+ * padded luma plane (as in x265ref_lowres_intra); cb / cr: compact (width / 2) x (height / 2) chroma planes or NULL for 4:0:0 (then
+ * width and height should be multiples of the block size: no chroma padding is synthesised).  aqMode 0..3, hevcAq off.
+ * Outputs per qgSize x qgSize block (row-major): qpAqOffset (double), invQscale (int32); wpSum / wpSsd [3] as left in Lowres. */
+int x265ref_aq_frame(const void* yPlane, const void* cb, const void* cr, int width, int height, int qgSize, int aqMode, double aqStrength,
+                     int weightp, double* qpAqOffset, int32_t* invQscale, uint64_t* wpSum, uint64_t* wpSsd, int32_t* numBlocks)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width;
+    param->sourceHeight = height;
+    param->internalCsp = cb ? X265_CSP_I420 : X265_CSP_I400;
+    param->maxCUSize = 64;
+    param->rc.aqMode = aqMode;
+    param->rc.aqStrength = aqStrength;
+    param->rc.hevcAq = 0;
+    param->rc.qgSize = qgSize;
+    param->rc.cuTree = 0;
+    param->rc.bStatRead = 0;
+    param->bAQMotion = 0;
+    param->bEnableHME = 0;
+    param->bHDR10Opt = 0;
+    param->bDynamicRefine = 0;
+    param->bEnableFades = 0;
+    param->bEnableWeightedPred = weightp;
+    param->bEnableWeightedBiPred = 0;
+    PicYuv pic;
+    pic.m_param = param;
+    if (!pic.create(param, true)) return -1;
+    const int h64 = (height + 63) / 64 * 64;
+    memcpy(pic.m_picOrg[0] - pic.m_lumaMarginY * pic.m_stride - pic.m_lumaMarginX, yPlane,
+           sizeof(pixel) * pic.m_stride * (h64 + 2 * pic.m_lumaMarginY));
+    if (cb)
+    {
+        const void* cs[2] = { cb, cr };
+        for (int c = 0; c < 2; c++)
+            for (int y = 0; y < height / 2; y++)
+                memcpy(pic.m_picOrg[1 + c] + (intptr_t)y * pic.m_strideC, (const pixel*)cs[c] + (size_t)y * (width / 2), sizeof(pixel) * (width / 2));
+    }
+    int rc = 0;
+    {
+        Frame frame;
+        frame.m_param = param;
+        frame.m_fencPic = &pic;
+        frame.m_quantOffsets = NULL;
+        memset((void*)&frame.m_lowres, 0, sizeof(Lowres));
+        if (!frame.m_lowres.create(param, &pic, qgSize)) rc = -2;
+        else
+        {
+            LookaheadTLD tld;
+            tld.init(frame.m_lowres.maxBlocksInRow, frame.m_lowres.maxBlocksInCol, frame.m_lowres.maxBlocksInRow * frame.m_lowres.maxBlocksInCol);
+            tld.calcAdaptiveQuantFrame(&frame, param);
+            const int n = qgSize == 8 ? frame.m_lowres.maxBlocksInRowFullRes * frame.m_lowres.maxBlocksInColFullRes
+                                      : frame.m_lowres.maxBlocksInRow * frame.m_lowres.maxBlocksInCol;
+            *numBlocks = n;
+            if (frame.m_lowres.qpAqOffset)
+            {
+                memcpy(qpAqOffset, frame.m_lowres.qpAqOffset, sizeof(double) * n);
+                for (int i = 0; i < n; i++) invQscale[i] = frame.m_lowres.invQscaleFactor[i];
+            }
+            for (int i = 0; i < 3; i++) { wpSum[i] = frame.m_lowres.wp_sum[i]; wpSsd[i] = frame.m_lowres.wp_ssd[i]; }
+            frame.m_lowres.destroy();
+        }
+        frame.m_fencPic = NULL;
+    }
+    pic.destroy();
+    x265_param_free(param);
+    return rc;
 }
 
 } // extern "C"

@@ -222,3 +222,104 @@ void EXPORT(x265oracle_weights_analyse)(const pixel* fenc, const pixel* ref, int
     if (!found || (minscale == 1 << mindenom && minoff == 0) || (float)minscore / origscore > 0.998f) return;
     out[0] = 1; out[1] = minscale; out[2] = mindenom; out[3] = minoff;
 }
+
+/* ================================================================ adaptive quantisation pass of the lookahead
+ * LookaheadTLD::calcAdaptiveQuantFrame (slicetype.cpp:439-694) without hevcAq / edge mode / HDR10 / per-block quant offsets:
+ * the AC energy of every qgSize x qgSize block (acEnergyCu :256-275: cu[].var of the luma block plus, for 4:2:0, of the two half-size
+ * chroma blocks; energy = ssd - (sum^2 >> shift), and every call adds the block's sum / ssd to the picture's wp_sum / wp_ssd), the
+ * QP offset per block in double precision (AQ modes 1-3, :508-632) with invQscaleFactor = x265_exp2fix8(offset) (common.cpp:96-103),
+ * and the final wp_ssd normalisation (:662-675) when weighted prediction is on.
+ * y / cb / cr: sample (0,0) of padded planes (cb = NULL: 4:0:0); blocks run over [0, width) x [0, height) in steps of qgSize and may
+ * reach into the padding.  energy: uint32 per block; qpAqOffset: double per block; invQscale: int32 per block. */
+static uint32_t aq_block_energy(const pixel* src, intptr_t stride, int n, int shift, uint64_t* wpSum, uint64_t* wpSsd)
+{
+    uint32_t sum = 0, sqr = 0;
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) { const uint32_t v = src[y * stride + x]; sum += v; sqr += v * v; }
+    *wpSum += sum; *wpSsd += sqr;
+    return sqr - (uint32_t)(((uint64_t)sum * sum) >> shift);
+}
+
+static int exp2fix8(double x)
+{
+    static uint8_t lut[64];
+    static int lutReady = 0;
+    if (!lutReady) { for (int i = 0; i < 64; i++) lut[i] = (uint8_t)((pow(2.0, i / 64.0) - 1.0) * 256.0 + 0.5); lutReady = 1; }   /* x265_exp2_lut, constants.cpp:552 */
+    const int i = (int)(x * (-64.f / 6.f) + 512.5f);
+    if (i < 0) return 0;
+    if (i > 1023) return 0xffff;
+    return (lut[i & 63] + 256) << (i >> 6) >> 8;
+}
+
+void EXPORT(x265oracle_aq_frame)(const pixel* y, const pixel* cb, const pixel* cr, intptr_t stride, intptr_t strideC, int width, int height,
+                                 int qgSize, int aqMode, double aqStrength, int weightp,
+                                 uint32_t* energy, double* qpAqOffset, int32_t* invQscale, uint64_t* wpSum, uint64_t* wpSsd)
+{
+    const int inc = qgSize == 8 ? 8 : 16, lshift = qgSize == 8 ? 6 : 8, cshift = qgSize == 8 ? 4 : 6;
+    const float modeOneConst = qgSize == 8 ? 11.427f : 14.427f, modeTwoConst = qgSize == 8 ? 8.f : 11.f;
+    const int bw = (width + inc - 1) / inc, bh = (height + inc - 1) / inc, blockCount = bw * bh;
+    for (int i = 0; i < 3; i++) wpSum[i] = wpSsd[i] = 0;
+#define ENERGY(BX, BY) (aq_block_energy(y + (BX) + (intptr_t)(BY) * stride, stride, inc, lshift, &wpSum[0], &wpSsd[0]) + \
+        (cb ? aq_block_energy(cb + ((BX) >> 1) + (intptr_t)((BY) >> 1) * strideC, strideC, inc >> 1, cshift, &wpSum[1], &wpSsd[1]) + \
+              aq_block_energy(cr + ((BX) >> 1) + (intptr_t)((BY) >> 1) * strideC, strideC, inc >> 1, cshift, &wpSum[2], &wpSsd[2]) : 0u))
+    if (aqMode == 0 || aqStrength == 0)
+    {
+        for (int i = 0; i < blockCount; i++) { qpAqOffset[i] = 0; invQscale[i] = 256; }
+        if (weightp)
+            for (int by = 0, i = 0; by < height; by += inc)
+                for (int bx = 0; bx < width; bx += inc, i++) energy[i] = ENERGY(bx, by);
+    }
+    else
+    {
+        double avg_adj_pow2 = 0, avg_adj = 0, qp_adj = 0, bias_strength = 0.f, strength = 0.f;
+        if (aqMode == 2 || aqMode == 3)
+        {
+            const double bit_depth_correction = 1.f / (1 << (2 * (X265HIP_DEPTH - 8)));
+            for (int by = 0, i = 0; by < height; by += inc)
+                for (int bx = 0; bx < width; bx += inc, i++)
+                {
+                    energy[i] = ENERGY(bx, by);
+                    qp_adj = pow(energy[i] * bit_depth_correction + 1, 0.1);
+                    qpAqOffset[i] = qp_adj;
+                    avg_adj += qp_adj;
+                    avg_adj_pow2 += qp_adj * qp_adj;
+                }
+            avg_adj /= blockCount;
+            avg_adj_pow2 /= blockCount;
+            strength = aqStrength * avg_adj;
+            avg_adj = avg_adj - 0.5f * (avg_adj_pow2 - modeTwoConst) / avg_adj;
+            bias_strength = aqStrength;
+        }
+        else
+            strength = aqStrength * 1.0397f;
+        for (int by = 0, i = 0; by < height; by += inc)
+            for (int bx = 0; bx < width; bx += inc, i++)
+            {
+                if (aqMode == 3)
+                {
+                    qp_adj = qpAqOffset[i];
+                    qp_adj = strength * (qp_adj - avg_adj) + bias_strength * (1.f - modeTwoConst / (qp_adj * qp_adj));
+                }
+                else if (aqMode == 2)
+                {
+                    qp_adj = qpAqOffset[i];
+                    qp_adj = strength * (qp_adj - avg_adj);
+                }
+                else
+                {
+                    energy[i] = ENERGY(bx, by);
+                    qp_adj = strength * (log2((double)(energy[i] > 1 ? energy[i] : 1)) - (modeOneConst + 2 * (X265HIP_DEPTH - 8)));
+                }
+                qpAqOffset[i] = qp_adj;
+                invQscale[i] = exp2fix8(qp_adj);
+            }
+    }
+#undef ENERGY
+    if (weightp)
+    {
+        const int maxCol = ((width + 8) >> 4) << 4, maxRow = ((height + 8) >> 4) << 4;
+        const int w[3] = { maxCol, maxCol >> 1, maxCol >> 1 }, h[3] = { maxRow, maxRow >> 1, maxRow >> 1 };
+        for (int i = 0; i < 3; i++)
+            wpSsd[i] = wpSsd[i] - (wpSum[i] * wpSum[i] + (uint64_t)(w[i] * h[i]) / 2) / (uint64_t)(w[i] * h[i]);
+    }
+}

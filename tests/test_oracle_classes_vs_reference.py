@@ -419,6 +419,40 @@ def test_weighted_p_frame_cost_equals_reference_classes(depth, width, height, ga
         assert plain[4][0] != frame[0]
 
 
+@pytest.mark.parametrize("depth,width,height,qg,mode,strength,chroma", [(8, 256, 128, 16, 2, 1.0, True), (8, 256, 128, 16, 1, 1.0, True), (8, 208, 144, 16, 3, 0.8, True),
+                                                                    (8, 256, 128, 8, 2, 1.0, True), (8, 192, 128, 8, 1, 1.5, True), (8, 250, 138, 16, 2, 1.0, False),
+                                                                    (10, 192, 128, 16, 2, 1.0, True), (10, 192, 128, 16, 1, 0.6, False), (8, 256, 128, 16, 0, 1.0, True)])
+def test_adaptive_quant_pass_equals_reference_class(depth, width, height, qg, mode, strength, chroma):
+    """LookaheadTLD::calcAdaptiveQuantFrame (slicetype.cpp:439-694): block energies through cu[].var (luma + 4:2:0 chroma), the
+    double-precision QP offsets of AQ modes 1-3, invQscaleFactor through x265_exp2fix8, and the wp_sum / wp_ssd statistics the
+    weight analysis reads - restatement against the real class."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_aq_frame"):
+        pytest.skip("oracle/_ref predates x265ref_aq_frame")
+    clip = F.synth_clip(width, height, 1, depth=depth, seed=99)
+    yimg, cbimg, crimg = clip[0]
+    yp, stride, org, w64, h64 = F.pad_plane(yimg)
+    cpad = [pad_any(np.ascontiguousarray(c), margin=16) for c in (cbimg, crimg)] if chroma else None
+    n = ((width + qg - 1) // qg) * ((height + qg - 1) // qg)
+    rqp, rinv = np.zeros(4 * n + 64, np.float64), np.zeros(4 * n + 64, np.int32)
+    rsum, rssd, rn = np.zeros(3, np.uint64), np.zeros(3, np.uint64), np.zeros(1, np.int32)
+    lib.x265ref_aq_frame.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_double, ctypes.c_int] + [ctypes.c_void_p] * 5
+    cbc, crc = (np.ascontiguousarray(cbimg), np.ascontiguousarray(crimg)) if chroma else (None, None)
+    assert lib.x265ref_aq_frame(yp.ctypes.data, None if cbc is None else cbc.ctypes.data, None if crc is None else crc.ctypes.data, width, height,
+                                qg, mode, strength, 1, rqp.ctypes.data, rinv.ctypes.data, rsum.ctypes.data, rssd.ctypes.data, rn.ctypes.data) == 0
+    assert rn[0] == n
+    if chroma:
+        energy, qp, inv, sm, ssd = O.aq_frame(depth, yp, stride, org, width, height, cpad[0][0], cpad[1][0], cpad[0][1], cpad[0][2], qg, mode, strength, True)
+    else:
+        energy, qp, inv, sm, ssd = O.aq_frame(depth, yp, stride, org, width, height, qg_size=qg, aq_mode=mode, aq_strength=strength, weightp=True)
+    assert np.array_equal(sm, rsum) and np.array_equal(ssd, rssd), f"wp statistics: {sm} {ssd} vs {rsum} {rssd}"
+    if mode:
+        assert np.array_equal(qp, rqp[:n]), f"{np.count_nonzero(qp != rqp[:n])} QP offsets differ (max {np.abs(qp - rqp[:n]).max()})"
+        assert np.array_equal(inv, rinv[:n])
+        assert len(np.unique(inv)) > 4
+
+
 def sao_case(depth, width, height, seed):
     """Source / deblocked-like pair and random per-CTU SAO parameters (all five types, off, merge-left runs)."""
     rng = np.random.default_rng([21, depth, width, seed])
