@@ -364,6 +364,23 @@ typedef struct x265hip_lowres_weight_cost_params
     uint32_t* cost;
 } x265hip_lowres_weight_cost_params;
 int x265hip_lowres_weight_cost(const x265hip_lowres_weight_cost_params* p, void* stream);
+/* x265hip_aq_energy = the pixel work of LookaheadTLD::calcAdaptiveQuantFrame (encoder/slicetype.cpp:439-694): acEnergyCu (:256-275)
+ *   for every qg_size x qg_size block of the source picture - cu[].var of the luma block plus, for 4:2:0, of the two half-size chroma
+ *   blocks; energy = ssd - (sum^2 >> shift) per plane, added up - and the picture totals every acEnergyCu call accumulates into
+ *   Lowres::wp_sum / wp_ssd.  The double-precision QP offsets of the AQ modes, x265_exp2fix8 and the final wp_ssd normalisation
+ *   (:508-632, :662-675) are host logic: stages.AdaptiveQuant.
+ *   y / cb / cr: sample (0,0) of padded planes (cb = cr = NULL: 4:0:0); blocks run over [0, width) x [0, height) in steps of qg_size
+ *   (16 or 8) and may reach into the padding.  energy: DEVICE uint32 [blocks], row-major; wp: DEVICE uint64 [6] =
+ *   { sum Y, Cb, Cr, ssd Y, Cb, Cr } raw totals, overwritten. */
+typedef struct x265hip_aq_energy_params
+{
+    int depth;
+    const void* y; const void* cb; const void* cr;
+    intptr_t stride, stride_c;
+    int width, height, qg_size;
+    uint32_t* energy; uint64_t* wp;
+} x265hip_aq_energy_params;
+int x265hip_aq_energy(const x265hip_aq_energy_params* p, void* stream);
 typedef struct x265hip_lowres_weight_apply_params
 {
     int depth;

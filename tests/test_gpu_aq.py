@@ -1,0 +1,66 @@
+"""GPU parity: the adaptive-quantisation pass (x265hip_aq_energy + the host-side double-precision offsets of stages.AdaptiveQuant) vs
+the oracle's restatement of LookaheadTLD::calcAdaptiveQuantFrame (oracle/x265_oracle_pipeline3.c), which
+tests/test_oracle_classes_vs_reference.py pins against the real class."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+S = importlib.import_module("x265-yuuki-asuna_amd.stages")
+A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_api
+    return oracle_api
+
+
+def _pad(img, margin=16):
+    h, w = img.shape
+    buf = np.pad(img, margin, mode="edge")
+    return np.ascontiguousarray(buf).reshape(-1), w + 2 * margin, margin * (w + 2 * margin) + margin
+
+
+@pytest.mark.parametrize("depth,width,height,qg,mode,strength,chroma", [(8, 640, 360, 16, 2, 1.0, True), (8, 640, 360, 16, 1, 1.0, True), (8, 416, 240, 16, 3, 0.8, True),
+                                                                    (8, 640, 352, 8, 2, 1.0, True), (8, 250, 138, 16, 2, 1.0, False), (10, 384, 256, 16, 2, 1.0, True),
+                                                                    (10, 384, 256, 8, 1, 0.6, False), (8, 3840, 2160, 16, 2, 1.0, True), (8, 256, 128, 16, 0, 1.0, True)])
+def test_aq_pass_matches_oracle(depth, width, height, qg, mode, strength, chroma):
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    yimg, cbimg, crimg = F.synth_clip(width, height, 1, depth=depth, seed=101)[0]
+    pic = P.DevicePicture(yimg, dev)
+    kw, okw = {}, {}
+    if chroma:
+        cpad = [_pad(np.ascontiguousarray(c)) for c in (cbimg, crimg)]
+        to_dev = lambda a: torch.from_numpy(a.view(np.uint8) if depth == 8 else a.view(np.int16)).to(dev)
+        kw = dict(cb=to_dev(cpad[0][0]), cr=to_dev(cpad[1][0]), stride_c=cpad[0][1], org_c=cpad[0][2])
+        okw = dict(cb=cpad[0][0], cr=cpad[1][0], stride_c=cpad[0][1], org_c=cpad[0][2])
+    aq = S.AdaptiveQuant(width, height, depth, dev, qg_size=qg, aq_mode=mode, aq_strength=strength, weightp=True)
+    qp, inv, wp_sum, wp_ssd = aq.run(pic, **kw)
+    energy, eqp, einv, esum, essd = O.aq_frame(depth, pic.host.reshape(-1), pic.stride, pic.org, width, height, qg_size=qg, aq_mode=mode,
+                                               aq_strength=strength, weightp=True, **okw)
+    assert np.array_equal(aq.energy.cpu().numpy().view(np.uint32), energy), "block energies differ"
+    assert wp_sum == [int(v) for v in esum] and wp_ssd == [int(v) for v in essd], "wp statistics differ"
+    assert np.array_equal(qp, eqp), f"{np.count_nonzero(qp != eqp)} QP offsets differ"
+    assert np.array_equal(inv, einv)
+    if mode:
+        assert len(np.unique(inv)) > 4
+
+
+def test_aq_energy_rejects_bad_arguments():
+    import torch
+    dev = torch.device("cuda:0")
+    pic = P.DevicePicture(F.synth_clip(64, 64, 1, depth=8, seed=1)[0][0], dev)
+    energy, wp = torch.zeros(64, dtype=torch.int32, device=dev), torch.zeros(6, dtype=torch.int64, device=dev)
+    with pytest.raises(A.X265HipError):
+        A.aq_energy(8, pic.t, pic.stride, pic.org, 64, 64, 32, energy, wp)
+    with pytest.raises(A.X265HipError):
+        A.aq_energy(8, pic.t, pic.stride, pic.org, 64, 64, 16, energy, wp, cb=pic.t)

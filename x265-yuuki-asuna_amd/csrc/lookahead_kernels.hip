@@ -298,6 +298,66 @@ __global__ void __launch_bounds__(256) lowres_weight_cost_kernel(WeightCostArgs 
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&a.cost[c], (uint32_t)v);
 }
 
+// ---- adaptive-quantisation pass: block energies + picture statistics (acEnergyCu, slicetype.cpp:48-82,256-275)
+struct AqArgs
+{
+    const uint8_t* y; const uint8_t* cb; const uint8_t* cr;
+    long strideB, strideCB;
+    int width, height, inc;
+    uint32_t* energy; unsigned long long* wp;
+};
+
+// 16 lanes per block, one luma row each (the first inc / 2 lanes also take a row of each chroma block); DPP row sums give the
+// block's sum / sum of squares per plane, a wavefront sum and six atomics per wavefront the picture totals
+template <typename Px>
+__global__ void __launch_bounds__(256) aq_energy_kernel(AqArgs a)
+{
+    const int inc = a.inc, bw = (a.width + inc - 1) / inc, nblk = bw * ((a.height + inc - 1) / inc);
+    const int blk = (blockIdx.x * 256 + threadIdx.x) >> 4, row = threadIdx.x & 15;
+    uint32_t sum[3] = { 0, 0, 0 }, sqr[3] = { 0, 0, 0 };
+    if (blk < nblk)
+    {
+        const int by = blk / bw, bx = blk - by * bw;
+        if (row < inc)
+        {
+            const Px* p = reinterpret_cast<const Px*>(a.y + (long)(by * inc + row) * a.strideB) + bx * inc;
+            for (int x = 0; x < inc; x++) { const uint32_t v = p[x]; sum[0] += v; sqr[0] += v * v; }
+        }
+        if (a.cb && row < (inc >> 1))
+        {
+            const int ci = inc >> 1;
+            const Px* pb = reinterpret_cast<const Px*>(a.cb + (long)(by * ci + row) * a.strideCB) + bx * ci;
+            const Px* pr = reinterpret_cast<const Px*>(a.cr + (long)(by * ci + row) * a.strideCB) + bx * ci;
+            for (int x = 0; x < ci; x++)
+            {
+                const uint32_t u = pb[x], v = pr[x];
+                sum[1] += u; sqr[1] += u * u; sum[2] += v; sqr[2] += v * v;
+            }
+        }
+    }
+    const int lshift = inc == 8 ? 6 : 8, cshift = inc == 8 ? 4 : 6;
+    uint32_t energy = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+    {
+        sum[c] = (uint32_t)group_sum<16>((int)sum[c]);
+        sqr[c] = (uint32_t)group_sum<16>((int)sqr[c]);
+        if (c == 0 || a.cb) energy += sqr[c] - (uint32_t)(((unsigned long long)sum[c] * sum[c]) >> (c ? cshift : lshift));
+    }
+    if (blk < nblk && row == 0) a.energy[blk] = energy;
+    // picture totals: one lane per block contributes, summed over the wavefront's four blocks
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+    {
+        const long long s = group_sum<64>((long long)(row == 0 ? sum[c] : 0u)), q = group_sum<64>((long long)(row == 0 ? sqr[c] : 0u));
+        if ((threadIdx.x & 63) == 0 && (c == 0 || a.cb))
+        {
+            atomicAdd(&a.wp[c], (unsigned long long)s);
+            atomicAdd(&a.wp[3 + c], (unsigned long long)q);
+        }
+    }
+}
+
 struct WeightApplyArgs
 {
     const uint8_t* src[4]; uint8_t* dst[4];
@@ -403,6 +463,30 @@ extern "C" int x265hip_lowres_weight_apply(const x265hip_lowres_weight_apply_par
     const unsigned g = (unsigned)((a.n + 255) / 256);
     if (p->depth == 8) hipLaunchKernelGGL(lowres_weight_apply_kernel<uint8_t>, dim3(g, 4), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(lowres_weight_apply_kernel<uint16_t>, dim3(g, 4), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x265hip_aq_energy(const x265hip_aq_energy_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->y || !p->energy || !p->wp) { set_error("aq_energy: NULL operand"); return X265HIP_EINVAL; }
+    if ((p->cb == NULL) != (p->cr == NULL)) { set_error("aq_energy: cb and cr go together"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("aq_energy: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->qg_size != 16 && p->qg_size != 8) { set_error("aq_energy: qg_size %d (16 or 8; the larger groups read the 16x16 energies)", p->qg_size); return X265HIP_EINVAL; }
+    if (p->width <= 0 || p->height <= 0) { set_error("aq_energy: empty picture"); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    AqArgs a;
+    a.y = (const uint8_t*)p->y; a.cb = (const uint8_t*)p->cb; a.cr = (const uint8_t*)p->cr;
+    a.strideB = (long)p->stride * bpp; a.strideCB = (long)p->stride_c * bpp;
+    a.width = p->width; a.height = p->height; a.inc = p->qg_size; a.energy = p->energy; a.wp = (unsigned long long*)p->wp;
+    hipStream_t s = (hipStream_t)stream;
+    X265HIP_TRY(hipMemsetAsync(p->wp, 0, sizeof(uint64_t) * 6, s));
+    const int nblk = ((p->width + a.inc - 1) / a.inc) * ((p->height + a.inc - 1) / a.inc);
+    const unsigned g = (unsigned)(((long)nblk * 16 + 255) / 256);
+    if (bpp == 1) hipLaunchKernelGGL(aq_energy_kernel<uint8_t>, dim3(g), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(aq_energy_kernel<uint16_t>, dim3(g), dim3(256), 0, s, a);
     X265HIP_TRY(hipGetLastError());
     return 0;
 }

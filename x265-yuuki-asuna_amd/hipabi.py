@@ -306,6 +306,30 @@ def me_search(depth, fenc, fenc_stride, fenc_off, fref, fref_stride, fref_off, m
     check(f(ctypes.byref(p), s), "x265hip_me_search")
 
 
+class AqEnergyParams(ctypes.Structure):
+    """x265hip_aq_energy_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("y", ctypes.c_void_p), ("cb", ctypes.c_void_p), ("cr", ctypes.c_void_p),
+                ("stride", ctypes.c_ssize_t), ("stride_c", ctypes.c_ssize_t),
+                ("width", ctypes.c_int), ("height", ctypes.c_int), ("qg_size", ctypes.c_int),
+                ("energy", ctypes.c_void_p), ("wp", ctypes.c_void_p)]
+
+
+def aq_energy(depth, y, stride, org, width, height, qg_size, energy, wp, cb=None, cr=None, stride_c=0, org_c=0, stream=None):
+    """acEnergyCu for every qg_size x qg_size block + the wp_sum / wp_ssd raw totals (x265hip_aq_energy).  energy: device int32 tensor
+    [blocks] (uint32 bits); wp: device int64 tensor [6]."""
+    es = 1 if depth == 8 else 2
+    p = AqEnergyParams()
+    p.depth, p.stride, p.stride_c, p.width, p.height, p.qg_size = depth, stride, stride_c, width, height, qg_size
+    p.y = y.data_ptr() + org * es
+    p.cb = None if cb is None else cb.data_ptr() + org_c * es
+    p.cr = None if cr is None else cr.data_ptr() + org_c * es
+    p.energy, p.wp = energy.data_ptr(), wp.data_ptr()
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_aq_energy
+    f.argtypes = [ctypes.POINTER(AqEnergyParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_aq_energy")
+
+
 class LowresWeightCostParams(ctypes.Structure):
     """x265hip_lowres_weight_cost_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("fenc", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),
