@@ -256,6 +256,9 @@ typedef struct x265hip_lowres_cost_pair
     int32_t do_search[2];                           /* estimateFrameCost's bDoSearch: 0 keeps the list's given mvs / mv_costs */
     uint16_t* lowres_costs;  int32_t* row_satds;
     int64_t* frame;                                 /* [4] = costEst (unscaled sum), costEstAq, intraMbs, score */
+    const void* ref_bi[4];                          /* --weightp on a B picture: ref[] = the WEIGHTED list-0 planes (search, predictor
+                                                       candidates, skip cost: slicetype.cpp:3222,3267), ref_bi[] = the unweighted ones,
+                                                       which the two bi-directional candidates keep (:3328); all NULL = ref[] */
 } x265hip_lowres_cost_pair;
 typedef struct x265hip_lowres_cost_params
 {

@@ -286,14 +286,15 @@ def intra_recon(depth, n, fenc, fenc_stride, nb, recon_len, recon_stride, qp, in
 
 
 def lowres_cost(depth, cur, ref_planes, stride, org, width_in_cu, height_in_cu, cost_q, qoff, intra_cost, inv_qscale=None, avx2=False,
-                ref1_planes=None, do_search=(1, 1), bframe_bias=0, mvs_in=None, mv_costs_in=None):
+                ref1_planes=None, do_search=(1, 1), bframe_bias=0, mvs_in=None, mv_costs_in=None, ref_bi_planes=None):
     """CPU restatement of CostEstimateGroup::estimateFrameCost (slicetype.cpp:3115-3388) for a P picture (ref1_planes None) or a B
     picture.  cur: the current picture's plane 0; ref_planes / ref1_planes: the list-0 / list-1 reference's four planes (flat arrays,
     pixel (0,0) at element `org`).  P: returns (mvs int32 [n, 2], mv_costs, lowres_costs, row_satds, frame int64 [3] = costEst,
     costEstAq, intraMbs).  B: returns ((mvs0, mvs1), (mv_costs0, mv_costs1), lowres_costs, row_satds, frame int64 [4] with the
-    returned score last)."""
+    returned score last).  ref_bi_planes: --weightp for B pictures - ref_planes are then the weighted list-0 planes, ref_bi_planes the
+    unweighted ones the bi-directional candidates keep."""
     L = lib(avx2)
-    fn = getattr(L, f"x265oracle_lowres_cost_d{depth}")
+    fn = getattr(L, f"x265oracle_lowres_cost_wp_d{depth}")
     n = width_in_cu * height_in_cu
     mvs = [np.zeros((n, 2), np.int32) if mvs_in is None or mvs_in[i] is None else np.ascontiguousarray(mvs_in[i], np.int32).copy() for i in range(2)]
     mvc = [np.zeros(n, np.int32) if mv_costs_in is None or mv_costs_in[i] is None else np.ascontiguousarray(mv_costs_in[i], np.int32).copy() for i in range(2)]
@@ -304,12 +305,13 @@ def lowres_cost(depth, cur, ref_planes, stride, org, width_in_cu, height_in_cu, 
     iq = None if inv_qscale is None else np.ascontiguousarray(inv_qscale, dtype=np.int32)
     r0 = (ctypes.c_void_p * 4)(*[p.ctypes.data + org * es for p in ref_planes])
     r1 = None if ref1_planes is None else (ctypes.c_void_p * 4)(*[p.ctypes.data + org * es for p in ref1_planes])
+    rb = None if ref_bi_planes is None else (ctypes.c_void_p * 4)(*[p.ctypes.data + org * es for p in ref_bi_planes])
     ds = (ctypes.c_int * 2)(*do_search)
     fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                            ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7
+                                            ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 8
     rc = fn(cur.ctypes.data + org * es, r0, r1, stride, width_in_cu, height_in_cu, cq.ctypes.data, qoff, ic.ctypes.data,
             None if iq is None else iq.ctypes.data, ds, bframe_bias, mvs[0].ctypes.data, mvc[0].ctypes.data, mvs[1].ctypes.data, mvc[1].ctypes.data,
-            lc.ctypes.data, rows.ctypes.data, frame.ctypes.data)
+            lc.ctypes.data, rows.ctypes.data, frame.ctypes.data, rb)
     assert rc == 0
     if ref1_planes is None:
         return mvs[0], mvc[0], lc, rows, frame[:3]

@@ -161,9 +161,31 @@ static int lowres_cost_core(const void* curPlane, const void* refPlane, int widt
 /* The REAL CostEstimateGroup::singleCost(0, 2, 1) for a B picture `cur` between `ref0` (list 0) and `ref1` (list 1): same set-up
  * as x265ref_lowres_cost.  Outputs per 8x8 block: mvs0 / mvs1 int32 [n][2], mvCosts0 / mvCosts1 int32 [n], lowresCosts uint16 [n];
  * rowSatds int32 [rows]; frame int64 [4] = { returned score, costEst (as stored: already scaled), costEstAq, intraMbs }. */
+static int lowres_cost_b_core(const void* curPlane, const void* ref0Plane, const void* ref1Plane, int width, int height,
+                              int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1, uint16_t* lowresCosts, int32_t* rowSatds,
+                              int64_t* frame, const uint64_t* wpSsd, const uint64_t* wpSum, int32_t* isWeighted);
+
 int x265ref_lowres_cost_b(const void* curPlane, const void* ref0Plane, const void* ref1Plane, int width, int height,
                           int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1, uint16_t* lowresCosts, int32_t* rowSatds,
                           int64_t* frame)
+{
+    return lowres_cost_b_core(curPlane, ref0Plane, ref1Plane, width, height, mvs0, mvCosts0, mvs1, mvCosts1, lowresCosts, rowSatds, frame, NULL, NULL, NULL);
+}
+
+/* B picture with --weightp: the list-0 search (predictor candidates, skip cost, motionEstimate) runs on the weighted list-0 planes,
+ * the two bi-directional candidates keep the unweighted ones (slicetype.cpp:3222,3267,3328).  wpSsd / wpSum: current picture ([0]) and
+ * the list-0 reference ([1]). */
+int x265ref_lowres_cost_b_weightp(const void* curPlane, const void* ref0Plane, const void* ref1Plane, int width, int height,
+                                  const uint64_t* wpSsd, const uint64_t* wpSum,
+                                  int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1, uint16_t* lowresCosts, int32_t* rowSatds,
+                                  int64_t* frame, int32_t* isWeighted)
+{
+    return lowres_cost_b_core(curPlane, ref0Plane, ref1Plane, width, height, mvs0, mvCosts0, mvs1, mvCosts1, lowresCosts, rowSatds, frame, wpSsd, wpSum, isWeighted);
+}
+
+static int lowres_cost_b_core(const void* curPlane, const void* ref0Plane, const void* ref1Plane, int width, int height,
+                              int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1, uint16_t* lowresCosts, int32_t* rowSatds,
+                              int64_t* frame, const uint64_t* wpSsd, const uint64_t* wpSum, int32_t* isWeighted)
 {
     static bool tableReady = false;
     if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
@@ -177,7 +199,7 @@ int x265ref_lowres_cost_b(const void* curPlane, const void* ref0Plane, const voi
     param->rc.hevcAq = 0;
     param->bAQMotion = 0;
     param->bEnableHME = 0;
-    param->bEnableWeightedPred = 0;
+    param->bEnableWeightedPred = wpSsd ? 1 : 0;
     param->bEnableWeightedBiPred = 0;
     param->lookaheadSlices = 0;
     const int h64 = (height + 63) / 64 * 64;
@@ -195,6 +217,7 @@ int x265ref_lowres_cost_b(const void* curPlane, const void* ref0Plane, const voi
         if (!lrs[i].create(param, &pics[i], qgSize)) return -2;
         lrs[i].init(&pics[i], i);
     }
+    if (wpSsd) { lrs[1].wp_ssd[0] = wpSsd[0]; lrs[1].wp_sum[0] = wpSum[0]; lrs[0].wp_ssd[0] = wpSsd[1]; lrs[0].wp_sum[0] = wpSum[1]; }
     Lookahead la(param, NULL);
     if (!la.create()) return -3;
     la.m_tld[0].lowresIntraEstimate(lrs[1], qgSize);
@@ -215,6 +238,7 @@ int x265ref_lowres_cost_b(const void* curPlane, const void* ref0Plane, const voi
     frame[1] = fenc.costEst[1][1];
     frame[2] = fenc.costEstAq[1][1];
     frame[3] = fenc.intraMbs[1];
+    if (isWeighted) *isWeighted = fenc.weightedRef[1].isWeighted ? 1 : 0;
     la.destroy();
     for (int i = 0; i < 3; i++) { lrs[i].destroy(); pics[i].destroy(); }
     x265_param_free(param);

@@ -794,12 +794,31 @@ static const pixel* lowres_mc(const me_ctx* c, int qx, int qy, pixel* buf, intpt
  * Outputs: mvs0/1 int32 [n][2] (quarter-pel), mvCosts0/1 int32 [n], lowresCosts uint16 [n], rowSatds int32 [heightInCU],
  * frame int64 [4] = { costEst as accumulated, costEstAq, intraMbs, the returned score (costEst * 100 / (130 + bFrameBias) for B) }.
  * Serial by construction (each block needs its neighbours' mvs). */
+int EXPORT(x265oracle_lowres_cost_wp)(const pixel* cur, const pixel* const* refs0, const pixel* const* refs1, intptr_t stride,
+                                      int widthInCU, int heightInCU, const uint16_t* cost, int qoff, const int32_t* intraCost,
+                                      const int32_t* invQscale, const int* doSearch, int bFrameBias,
+                                      int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
+                                      uint16_t* lowresCosts, int32_t* rowSatds, int64_t* frame, const pixel* const* refs0Bi);
+
 int EXPORT(x265oracle_lowres_cost)(const pixel* cur, const pixel* const* refs0, const pixel* const* refs1, intptr_t stride,
                                    int widthInCU, int heightInCU, const uint16_t* cost, int qoff, const int32_t* intraCost,
                                    const int32_t* invQscale, const int* doSearch, int bFrameBias,
                                    int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
                                    uint16_t* lowresCosts, int32_t* rowSatds, int64_t* frame)
 {
+    return EXPORT(x265oracle_lowres_cost_wp)(cur, refs0, refs1, stride, widthInCU, heightInCU, cost, qoff, intraCost, invQscale, doSearch, bFrameBias,
+                                             mvs0, mvCosts0, mvs1, mvCosts1, lowresCosts, rowSatds, frame, NULL);
+}
+
+/* --weightp: refs0 are then the WEIGHTED list-0 planes (what the list-0 search, its predictor candidates and the skip cost see,
+ * slicetype.cpp:3222,3267) and refs0Bi the unweighted ones, which the two bi-directional candidates keep using (:3328); NULL = refs0 */
+int EXPORT(x265oracle_lowres_cost_wp)(const pixel* cur, const pixel* const* refs0, const pixel* const* refs1, intptr_t stride,
+                                      int widthInCU, int heightInCU, const uint16_t* cost, int qoff, const int32_t* intraCost,
+                                      const int32_t* invQscale, const int* doSearch, int bFrameBias,
+                                      int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
+                                      uint16_t* lowresCosts, int32_t* rowSatds, int64_t* frame, const pixel* const* refs0Bi)
+{
+    if (!refs0Bi) refs0Bi = refs0;
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
     if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
@@ -875,14 +894,14 @@ int EXPORT(x265oracle_lowres_cost)(const pixel* cur, const pixel* const* refs0, 
                 /* avg(l0-mv, l1-mv) candidate, then the co-located one (:3322-3343) */
                 pixel buf0[64], buf1[64], avg[64];
                 intptr_t st0 = 8, st1 = 8;
-                for (int k = 0; k < 4; k++) c.lowres[k] = refs0[k] + pelOffset;
+                for (int k = 0; k < 4; k++) c.lowres[k] = refs0Bi[k] + pelOffset;
                 const pixel* src0 = lowres_mc(&c, mvs0[2 * cuXY], mvs0[2 * cuXY + 1], buf0, &st0);
                 for (int k = 0; k < 4; k++) c.lowres[k] = refs1[k] + pelOffset;
                 const pixel* src1 = lowres_mc(&c, mvs1[2 * cuXY], mvs1[2 * cuXY + 1], buf1, &st1);
                 c.pu->pixelavg_pp[0](avg, 8, src0, st0, src1, st1, 32);
                 int bicost = c.pu->satd(c.fenc, 64, avg, 8);
                 if (bicost < bcost) { bcost = bicost; listused = 3; }
-                c.pu->pixelavg_pp[0](avg, 8, refs0[0] + pelOffset, stride, refs1[0] + pelOffset, stride, 32);
+                c.pu->pixelavg_pp[0](avg, 8, refs0Bi[0] + pelOffset, stride, refs1[0] + pelOffset, stride, 32);
                 bicost = c.pu->satd(c.fenc, 64, avg, 8);
                 if (bicost < bcost) { bcost = bicost; listused = 3; }
                 bcost += lowresPenalty;

@@ -108,6 +108,43 @@ def test_weighted_p_frame_cost_matches_oracle(depth, width, height, gain, lift):
     assert plain[4][0] != frame[0]
 
 
+@pytest.mark.parametrize("depth,width,height,gain,lift", [(8, 512, 256, 0.8, 8), (10, 384, 256, 0.7, 12)])
+def test_weighted_b_frame_cost_matches_oracle(depth, width, height, gain, lift):
+    """--weightp on a B picture: weighted list-0 planes for the search, the unweighted ones for the bi-directional candidates."""
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    y0, y1 = _fade(depth, width, height, gain, lift, seed=104)
+    y1 = np.roll(y1, (2, -2), axis=(0, 1)).copy()
+    y2 = np.roll(y1, (-2, 4), axis=(0, 1)).copy()
+    y1[-64:-32, :64] = ((y0[-64:-32, :64].astype(np.int32) + y2[-64:-32, :64] + 1) >> 1).astype(y1.dtype)
+    cur, l0, l1 = (S.Lookahead(width, height, depth, dev, intra_penalty=5 if depth == 8 else 80) for _ in range(3))
+    cur.run(P.DevicePicture(y1, dev)); l0.run(P.DevicePicture(y0, dev)); l1.run(P.DevicePicture(y2, dev))
+    torch.cuda.synchronize()
+    dt = y0.dtype
+    cp = cur.planes[0].cpu().numpy().view(dt)
+    p0 = [p.cpu().numpy().view(dt) for p in l0.planes]
+    p1 = [p.cpu().numpy().view(dt) for p in l1.planes]
+    ssd_c, sum_c = _stats(cp, cur)
+    ssd_r, sum_r = _stats(p0[0], l0)
+    wa = S.WeightAnalysis(cur, dev)
+    weight, _, _ = wa.analyse(cur, l0, (ssd_c, ssd_r), (sum_c, sum_r))
+    assert weight is not None
+    st = S.LookaheadCost(cur, dev, bidir=True)
+    st.run(cur, wa.weighted_ref, l1, ref_bi=l0)
+    torch.cuda.synchronize()
+    icost = cur.intra_cost.cpu().numpy()
+    w0 = [O.weight_plane(depth, p, weight) for p in p0]
+    cq = st.cost_q.cpu().numpy().view(np.uint16)
+    mvs, mvc, lcost, rows, frame = O.lowres_cost(depth, cp, w0, cur.stride, cur.org, cur.wcu, cur.hcu, cq, st.qoff, icost, ref1_planes=p1, ref_bi_planes=p0)
+    assert np.array_equal(st.mvs.cpu().numpy().reshape(-1, 2), mvs[0]) and np.array_equal(st.mvs1.cpu().numpy().reshape(-1, 2), mvs[1])
+    assert np.array_equal(st.mv_costs.cpu().numpy(), mvc[0]) and np.array_equal(st.mv_costs1.cpu().numpy(), mvc[1])
+    assert np.array_equal(st.lowres_costs.cpu().numpy().view(np.uint16), lcost) and np.array_equal(st.row_satds.cpu().numpy(), rows)
+    assert np.array_equal(st.frame.cpu().numpy(), frame)
+    allw = O.lowres_cost(depth, cp, w0, cur.stride, cur.org, cur.wcu, cur.hcu, cq, st.qoff, icost, ref1_planes=p1)
+    assert not np.array_equal(allw[2], lcost)                       # the unweighted planes of the bi-directional candidates matter here
+
+
 def test_weight_cost_rejects_bad_candidates():
     import torch
     dev = torch.device("cuda:0")

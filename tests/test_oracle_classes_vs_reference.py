@@ -453,6 +453,57 @@ def test_adaptive_quant_pass_equals_reference_class(depth, width, height, qg, mo
         assert len(np.unique(inv)) > 4
 
 
+@pytest.mark.parametrize("depth,width,height,gain,lift", [(8, 256, 128, 0.8, 8), (8, 208, 144, 0.7, 10), (10, 192, 128, 0.7, 12)])
+def test_weighted_b_frame_cost_equals_reference_classes(depth, width, height, gain, lift):
+    """--weightp on a B picture: the list-0 search (predictor candidates, skip cost, motionEstimate) sees the weighted list-0 planes,
+    the two bi-directional candidates the unweighted ones (slicetype.cpp:3222,3267,3328) - against the real singleCost(0, 2, 1) with
+    bEnableWeightedPred.  List 0 is a brighter / darker version of the scene, list 1 the scene itself."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_lowres_cost_b_weightp"):
+        pytest.skip("oracle/_ref predates x265ref_lowres_cost_b_weightp")
+    y0, y1 = fade_pair(depth, width, height, gain, lift, seed=103)            # y0: list-0 reference, y1: current (faded y0)
+    y1 = np.roll(y1, (2, -2), axis=(0, 1)).copy()
+    y2 = np.roll(y1, (-2, 4), axis=(0, 1)).copy()                             # list 1: the current scene, moved
+    y1[-64:-32, :64] = ((y0[-64:-32, :64].astype(np.int32) + y2[-64:-32, :64] + 1) >> 1).astype(y1.dtype)
+    cur, stride, org, w64, h64 = F.pad_plane(y1)
+    r0, r1 = F.pad_plane(y0)[0], F.pad_plane(y2)[0]
+    wcu, hcu = (width // 2 + 7) >> 3, (height // 2 + 7) >> 3
+    lw, lh = wcu * 8, hcu * 8
+    n = wcu * hcu
+    rstride = (width // 2 + 2 * F.MARGIN_X + 31) & ~31
+    rows = lh + 2 * F.MARGIN_Y
+    lorg = rstride * F.MARGIN_Y + F.MARGIN_X
+    cplanes = O.lowres_init(depth, cur, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    p0 = O.lowres_init(depth, r0, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    p1 = O.lowres_init(depth, r1, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
+    st = [lowres_stats(cplanes[0], rows, rstride, lorg, lw, lh), lowres_stats(p0[0], rows, rstride, lorg, lw, lh)]
+    ssd, sm = np.array([st[0][0], st[1][0]], np.uint64), np.array([st[0][1], st[1][1]], np.uint64)
+    rmv = [np.zeros((n, 2), np.int32) for _ in range(2)]
+    rmc = [np.zeros(n, np.int32) for _ in range(2)]
+    rlc, rrows, rframe, rw = np.zeros(n, np.uint16), np.zeros(hcu, np.int32), np.zeros(4, np.int64), np.zeros(1, np.int32)
+    lib.x265ref_lowres_cost_b_weightp.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 10
+    assert lib.x265ref_lowres_cost_b_weightp(cur.ctypes.data, r0.ctypes.data, r1.ctypes.data, width, height, ssd.ctypes.data, sm.ctypes.data,
+                                             rmv[0].ctypes.data, rmc[0].ctypes.data, rmv[1].ctypes.data, rmc[1].ctypes.data, rlc.ctypes.data,
+                                             rrows.ctypes.data, rframe.ctypes.data, rw.ctypes.data) == 0
+    lam = 1.0 if depth == 8 else 16.0
+    icost, _, _ = O.lowres_intra(depth, cplanes[0], rstride, lorg, wcu, hcu, 5 * int(lam))
+    weight, _, _ = O.weights_analyse(depth, cplanes[0], p0[0], rstride, lorg, lw, lh, icost, ssd, sm)
+    assert weight is not None and rw[0] == 1
+    w0 = [O.weight_plane(depth, p, weight) for p in p0]
+    cq, qoff = F.qpel_cost_table(16, lam=lam, qmax=4 * (max(lw, lh) + 64))
+    mvs, mvc, lc, rws, frame = O.lowres_cost(depth, cplanes[0], w0, rstride, lorg, wcu, hcu, cq, qoff, icost, ref1_planes=p1, ref_bi_planes=p0)
+    for i in range(2):
+        assert np.array_equal(mvs[i], rmv[i]), f"list {i} mvs differ at {np.flatnonzero((mvs[i] != rmv[i]).any(axis=1))[:8]}"
+        assert np.array_equal(mvc[i], rmc[i])
+    assert np.array_equal(lc, rlc) and np.array_equal(rws, rrows)
+    assert frame[3] == rframe[0] == rframe[1] and frame[1] == rframe[2]
+    # both distinctions matter on this content: weighted planes for the search, unweighted for the bi-directional candidates
+    allw = O.lowres_cost(depth, cplanes[0], w0, rstride, lorg, wcu, hcu, cq, qoff, icost, ref1_planes=p1)
+    plain = O.lowres_cost(depth, cplanes[0], p0, rstride, lorg, wcu, hcu, cq, qoff, icost, ref1_planes=p1)
+    assert not np.array_equal(allw[2], lc) and not np.array_equal(plain[2], lc)
+
+
 def sao_case(depth, width, height, seed):
     """Source / deblocked-like pair and random per-CTU SAO parameters (all five types, off, merge-left runs)."""
     rng = np.random.default_rng([21, depth, width, seed])

@@ -192,6 +192,8 @@ __global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
     LowresPu<Px> L;
     const PhasePlanes pp0 = { (const uint8_t*)pr.ref[0] - kBias, (const uint8_t*)pr.ref[1] - kBias, (const uint8_t*)pr.ref[2] - kBias, (const uint8_t*)pr.ref[3] - kBias };
     const PhasePlanes pp1 = BIDIR ? PhasePlanes{ (const uint8_t*)pr.ref1[0] - kBias, (const uint8_t*)pr.ref1[1] - kBias, (const uint8_t*)pr.ref1[2] - kBias, (const uint8_t*)pr.ref1[3] - kBias } : pp0;
+    // --weightp: the bi-directional candidates keep the unweighted list-0 planes (slicetype.cpp:3328)
+    const PhasePlanes ppB = (BIDIR && pr.ref_bi[0]) ? PhasePlanes{ (const uint8_t*)pr.ref_bi[0] - kBias, (const uint8_t*)pr.ref_bi[1] - kBias, (const uint8_t*)pr.ref_bi[2] - kBias, (const uint8_t*)pr.ref_bi[3] - kBias } : pp0;
     L.c.strideB = g.strideB; L.c.depth = g.depth; L.c.cost = g.cost;
     L.c.have[0] = true;
     for (int t = 0; t < steps; t++)
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
             {
                 // avg(l0-mv, l1-mv), then the co-located average (:3322-3343)
                 int p0[4][4], p1[4][4];
-                L.predict(pp0, lmx[0], lmy[0], p0);
+                L.predict(ppB, lmx[0], lmy[0], p0);
                 L.predict(pp1, lmx[1], lmy[1], p1);
 #pragma unroll
                 for (int y = 0; y < 4; y++)
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
                     for (int x = 0; x < 4; x++) p0[y][x] = (p0[y][x] + p1[y][x] + 1) >> 1;
                 int bicost = L.score(p0, true);
                 if (bicost < bcost) { bcost = bicost; listused = 3; }
-                L.predict(pp0, 0, 0, p0);
+                L.predict(ppB, 0, 0, p0);
                 L.predict(pp1, 0, 0, p1);
 #pragma unroll
                 for (int y = 0; y < 4; y++)
@@ -351,6 +353,7 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
         if (i == 0) bidir = b;
         if (b != bidir) { set_error("lowres_cost: pair %d mixes P and B pictures in one call", i); return X265HIP_EINVAL; }
         if (b && (!q.ref1[1] || !q.ref1[2] || !q.ref1[3] || !q.mvs1 || !q.mv_costs1)) { set_error("lowres_cost: NULL list-1 operand in pair %d", i); return X265HIP_EINVAL; }
+        if (q.ref_bi[0] && (!b || !q.ref_bi[1] || !q.ref_bi[2] || !q.ref_bi[3])) { set_error("lowres_cost: ref_bi needs a B picture and four planes (pair %d)", i); return X265HIP_EINVAL; }
         if ((((uintptr_t)q.mvs) & 7) || (b && (((uintptr_t)q.mvs1) & 7))) { set_error("lowres_cost: mvs of pair %d must be 8-byte aligned", i); return X265HIP_EINVAL; }
     }
     int quads = (p->height_in_cu + 15) & ~15;

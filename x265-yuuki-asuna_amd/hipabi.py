@@ -65,7 +65,8 @@ class LowresCostPair(ctypes.Structure):
                 ("intra_cost", ctypes.c_void_p), ("inv_qscale", ctypes.c_void_p),
                 ("mvs", ctypes.c_void_p), ("mv_costs", ctypes.c_void_p), ("mvs1", ctypes.c_void_p), ("mv_costs1", ctypes.c_void_p),
                 ("do_search", ctypes.c_int32 * 2),
-                ("lowres_costs", ctypes.c_void_p), ("row_satds", ctypes.c_void_p), ("frame", ctypes.c_void_p)]
+                ("lowres_costs", ctypes.c_void_p), ("row_satds", ctypes.c_void_p), ("frame", ctypes.c_void_p),
+                ("ref_bi", ctypes.c_void_p * 4)]
 
 
 class LowresCostParams(ctypes.Structure):
@@ -230,8 +231,8 @@ def lowres_intra(depth, plane, stride, org, width_in_cu, height_in_cu, intra_pen
 
 
 def lowres_cost_pair(depth, org, cur, ref_planes, intra_cost, mvs, mv_costs, lowres_costs, row_satds, frame, inv_qscale=None,
-                     ref1_planes=None, mvs1=None, mv_costs1=None, do_search=(1, 1)):
-    """One picture for lowres_cost: cur = the current picture's plane 0, ref_planes = the list-0 reference's four phase planes
+                     ref1_planes=None, mvs1=None, mv_costs1=None, do_search=(1, 1), ref_bi_planes=None):
+    """One picture for lowres_cost (ref_bi_planes: --weightp on a B picture - ref_planes weighted, ref_bi_planes the unweighted list 0): cur = the current picture's plane 0, ref_planes = the list-0 reference's four phase planes
     (pixel (0,0) at element `org` of each tensor); ref1_planes / mvs1 / mv_costs1 = list 1 of a B picture."""
     es = 1 if depth == 8 else 2
     q = LowresCostPair()
@@ -239,6 +240,7 @@ def lowres_cost_pair(depth, org, cur, ref_planes, intra_cost, mvs, mv_costs, low
     for i in range(4):
         q.ref[i] = ref_planes[i].data_ptr() + org * es
         q.ref1[i] = None if ref1_planes is None else ref1_planes[i].data_ptr() + org * es
+        q.ref_bi[i] = None if ref_bi_planes is None else ref_bi_planes[i].data_ptr() + org * es
     q.intra_cost, q.inv_qscale = intra_cost.data_ptr(), _p(inv_qscale)
     q.mvs, q.mv_costs, q.mvs1, q.mv_costs1 = mvs.data_ptr(), mv_costs.data_ptr(), _p(mvs1), _p(mv_costs1)
     q.do_search[0], q.do_search[1] = do_search

@@ -364,14 +364,16 @@ class LookaheadCost:
         self.row_satds = torch.zeros(la.hcu, dtype=torch.int32, device=device)
         self.frame = torch.zeros(4, dtype=torch.int64, device=device)
 
-    def pair(self, cur: Lookahead, ref: Lookahead, ref1: Lookahead = None, do_search=(1, 1)):
+    def pair(self, cur: Lookahead, ref: Lookahead, ref1: Lookahead = None, do_search=(1, 1), ref_bi: Lookahead = None):
+        """ref_bi: --weightp on a B picture - `ref` then carries the weighted list-0 planes (WeightAnalysis.weighted_ref) and ref_bi the
+        reference's own planes, which the bi-directional candidates keep (slicetype.cpp:3328)."""
         return hipabi.lowres_cost_pair(self.depth, cur.org, cur.planes[0], ref.planes, cur.intra_cost, self.mvs, self.mv_costs,
                                        self.lowres_costs, self.row_satds, self.frame,
                                        ref1_planes=None if ref1 is None else ref1.planes, mvs1=self.mvs1, mv_costs1=self.mv_costs1,
-                                       do_search=do_search)
+                                       do_search=do_search, ref_bi_planes=None if ref_bi is None else ref_bi.planes)
 
-    def run(self, cur: Lookahead, ref: Lookahead, ref1: Lookahead = None, do_search=(1, 1), bframe_bias=0, stream=None):
-        hipabi.lowres_cost(self.depth, cur.stride, cur.wcu, cur.hcu, self.cost_q, self.qoff, [self.pair(cur, ref, ref1, do_search)],
+    def run(self, cur: Lookahead, ref: Lookahead, ref1: Lookahead = None, do_search=(1, 1), bframe_bias=0, stream=None, ref_bi: Lookahead = None):
+        hipabi.lowres_cost(self.depth, cur.stride, cur.wcu, cur.hcu, self.cost_q, self.qoff, [self.pair(cur, ref, ref1, do_search, ref_bi)],
                            bframe_bias=bframe_bias, stream=stream)
 
     @staticmethod
