@@ -384,6 +384,21 @@ typedef struct x265hip_aq_energy_params
     uint32_t* energy; uint64_t* wp;
 } x265hip_aq_energy_params;
 int x265hip_aq_energy(const x265hip_aq_energy_params* p, void* stream);
+/* x265hip_aq_offsets - HOST-side companion (no device work, host pointers): the double-precision part of calcAdaptiveQuantFrame
+ *   (slicetype.cpp:508-632) for AQ modes 1-3 from the block energies - pow(energy * c + 1, 0.1) with the frame-average correction
+ *   (modes 2, 3; the bias term of mode 3), log2 (mode 1), the reference's float constants and summation order, through the C
+ *   library's pow / log2 as the reference does - and invQscaleFactor = x265_exp2fix8(offset) (common.cpp:96-103).  aq_mode 0 or
+ *   aq_strength 0: offsets 0, factors 256. */
+typedef struct x265hip_aq_offsets_params
+{
+    int depth, qg_size, aq_mode;
+    double aq_strength;
+    int nblocks;
+    const uint32_t* energy;          /* HOST uint32 [nblocks] */
+    double* qp_aq_offset;            /* HOST double [nblocks] */
+    int32_t* inv_qscale;             /* HOST int32 [nblocks] */
+} x265hip_aq_offsets_params;
+int x265hip_aq_offsets(const x265hip_aq_offsets_params* p);
 typedef struct x265hip_lowres_weight_apply_params
 {
     int depth;

@@ -51,3 +51,36 @@ thr = effective_cpus()
 print(f"CPU one picture pair on one thread: {tc * 1e3:.1f} ms -> {1 / tc:.1f} pairs/s per thread, {thr / tc:.1f} pairs/s if {thr} threads each take a picture")
 assert np.array_equal(stages[0].frame.cpu().numpy()[:3], res[4]), "GPU and CPU frame costs differ"
 print(f"frame cost (costEst, costEstAq, intraMbs) = {res[4].tolist()} on both")
+
+# ---- the other lookahead stages of the same picture: adaptive-quantisation energies, weighted-reference analysis
+def timed(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+yimg, cbimg, crimg = clip[1]
+pad = lambda a: np.ascontiguousarray(np.pad(a, 16, mode="edge"))
+cbp, crp = pad(cbimg), pad(crimg)
+d_cb, d_cr = torch.from_numpy(cbp.reshape(-1)).to(dev), torch.from_numpy(crp.reshape(-1)).to(dev)
+aq = S.AdaptiveQuant(W, H, 8, dev, qg_size=16, aq_mode=2)
+t_aq = timed(lambda: A.aq_energy(8, cur.t, cur.stride, cur.org, W, H, 16, aq.energy, aq.wp, d_cb, d_cr, cbp.shape[1], 16 * cbp.shape[1] + 16))
+px = W * H * 3 // 2
+print(f"x265hip_aq_energy (16x16 blocks, 4:2:0): {t_aq * 1e3:.1f} us per picture -> {px / t_aq / 1e6:.1f} GB/s of source samples")
+t0 = time.perf_counter(); qp, inv, wsum, wssd = aq.run(cur, d_cb, d_cr, cbp.shape[1], 16 * cbp.shape[1] + 16); t_host = time.perf_counter() - t0
+e_ref = O.aq_frame(8, cur.host.reshape(-1), cur.stride, cur.org, W, H, cbp.reshape(-1), crp.reshape(-1), cbp.shape[1], 16 * cbp.shape[1] + 16, 16, 2, 1.0, True)
+assert np.array_equal(qp, e_ref[1]) and np.array_equal(inv, e_ref[2]), "AQ offsets differ from the CPU restatement"
+t0 = time.perf_counter(); O.aq_frame(8, cur.host.reshape(-1), cur.stride, cur.org, W, H, cbp.reshape(-1), crp.reshape(-1), cbp.shape[1], 16 * cbp.shape[1] + 16, 16, 2, 1.0, True); tc = time.perf_counter() - t0
+print(f"stages.AdaptiveQuant.run (launch, copy back, {len(qp)} double-precision offsets on the host): {t_host * 1e3:.1f} ms; CPU restatement of the whole pass (one thread): {tc * 1e3:.1f} ms")
+cost = torch.zeros(4, dtype=torch.int32, device=dev)
+cands = [None, (60, 6, 3), (3, 2, 6), (83, 6, -19)]
+t_w = timed(lambda: A.lowres_weight_cost(8, lc.planes[0], lr.planes[0], lc.stride, lc.org, lc.width, lc.lines, lc.intra_cost, cands, cost))
+t0 = time.perf_counter(); ec = [O.lowres_weight_cost(8, cp, rp[0], lc.stride, lc.org, lc.width, lc.lines, ic, c) for c in cands]; tc = time.perf_counter() - t0
+assert cost.cpu().numpy().view(np.uint32).tolist() == ec
+print(f"x265hip_lowres_weight_cost (4 candidate weights, {lc.wcu * lc.hcu} blocks each): {t_w * 1e3:.1f} us per launch; CPU restatement (one thread): {tc * 1e3:.1f} ms")
+wa = S.WeightAnalysis(lc, dev)
+t_a = timed(lambda: A.lowres_weight_apply(8, lr.planes, wa.weighted, lc.stride, lc.lines + 2 * lc.my, (60, 6, 3)))
+print(f"x265hip_lowres_weight_apply (four planes): {t_a * 1e3:.1f} us -> {2 * 4 * lr.planes[0].numel() / t_a / 1e6:.1f} GB/s read + written")

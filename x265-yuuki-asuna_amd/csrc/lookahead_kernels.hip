@@ -304,7 +304,7 @@ struct AqArgs
     const uint8_t* y; const uint8_t* cb; const uint8_t* cr;
     long strideB, strideCB;
     int width, height, inc;
-    uint32_t* energy; unsigned long long* wp;
+    uint32_t* energy; unsigned long long* slots;       // [64][6] partial picture totals
 };
 
 // 16 lanes per block, one luma row each (the first inc / 2 lanes also take a row of each chroma block); DPP row sums give the
@@ -345,17 +345,26 @@ __global__ void __launch_bounds__(256) aq_energy_kernel(AqArgs a)
         if (c == 0 || a.cb) energy += sqr[c] - (uint32_t)(((unsigned long long)sum[c] * sum[c]) >> (c ? cshift : lshift));
     }
     if (blk < nblk && row == 0) a.energy[blk] = energy;
-    // picture totals: one lane per block contributes, summed over the wavefront's four blocks
+    // picture totals: one lane per block contributes; wavefront sums meet in LDS, the workgroup adds its six totals to one of 64
+    // slots (a single set of counters serialises ~50 000 atomics on six addresses: 0.6 ms per 4K picture)
+    __shared__ unsigned long long part[4][6];
 #pragma unroll
     for (int c = 0; c < 3; c++)
     {
         const long long s = group_sum<64>((long long)(row == 0 ? sum[c] : 0u)), q = group_sum<64>((long long)(row == 0 ? sqr[c] : 0u));
-        if ((threadIdx.x & 63) == 0 && (c == 0 || a.cb))
-        {
-            atomicAdd(&a.wp[c], (unsigned long long)s);
-            atomicAdd(&a.wp[3 + c], (unsigned long long)q);
-        }
+        if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][c] = (unsigned long long)s; part[threadIdx.x >> 6][3 + c] = (unsigned long long)q; }
     }
+    __syncthreads();
+    if (threadIdx.x < 6 && (a.cb || threadIdx.x % 3 == 0))
+        atomicAdd(&a.slots[(blockIdx.x & 63) * 6 + threadIdx.x], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+__global__ void aq_totals_kernel(const unsigned long long* slots, unsigned long long* wp)
+{
+    if (threadIdx.x >= 6) return;
+    unsigned long long t = 0;
+    for (int i = 0; i < 64; i++) t += slots[i * 6 + threadIdx.x];
+    wp[threadIdx.x] = t;
 }
 
 struct WeightApplyArgs
@@ -480,13 +489,82 @@ extern "C" int x265hip_aq_energy(const x265hip_aq_energy_params* p, void* stream
     AqArgs a;
     a.y = (const uint8_t*)p->y; a.cb = (const uint8_t*)p->cb; a.cr = (const uint8_t*)p->cr;
     a.strideB = (long)p->stride * bpp; a.strideCB = (long)p->stride_c * bpp;
-    a.width = p->width; a.height = p->height; a.inc = p->qg_size; a.energy = p->energy; a.wp = (unsigned long long*)p->wp;
+    a.width = p->width; a.height = p->height; a.inc = p->qg_size; a.energy = p->energy;
     hipStream_t s = (hipStream_t)stream;
-    X265HIP_TRY(hipMemsetAsync(p->wp, 0, sizeof(uint64_t) * 6, s));
+    unsigned long long* slots = nullptr;
+    X265HIP_TRY(hipMallocAsync((void**)&slots, sizeof(unsigned long long) * 64 * 6, s));
+    X265HIP_TRY(hipMemsetAsync(slots, 0, sizeof(unsigned long long) * 64 * 6, s));
+    a.slots = slots;
     const int nblk = ((p->width + a.inc - 1) / a.inc) * ((p->height + a.inc - 1) / a.inc);
     const unsigned g = (unsigned)(((long)nblk * 16 + 255) / 256);
     if (bpp == 1) hipLaunchKernelGGL(aq_energy_kernel<uint8_t>, dim3(g), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(aq_energy_kernel<uint16_t>, dim3(g), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(aq_totals_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)slots, (unsigned long long*)p->wp);
+    X265HIP_TRY(hipFreeAsync(slots, s));
     X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- host side of the adaptive-quantisation pass (slicetype.cpp:508-632, common.cpp:96-103)
+#include <cmath>
+static int aq_exp2fix8(double x)
+{
+    static uint8_t lut[64];
+    static bool ready = false;
+    if (!ready) { for (int i = 0; i < 64; i++) lut[i] = (uint8_t)((std::pow(2.0, i / 64.0) - 1.0) * 256.0 + 0.5); ready = true; }   // x265_exp2_lut
+    const int i = (int)(x * (-64.f / 6.f) + 512.5f);
+    if (i < 0) return 0;
+    if (i > 1023) return 0xffff;
+    return (lut[i & 63] + 256) << (i >> 6) >> 8;
+}
+
+extern "C" int x265hip_aq_offsets(const x265hip_aq_offsets_params* p)
+{
+    if (!p || !p->energy || !p->qp_aq_offset || !p->inv_qscale) { set_error("aq_offsets: NULL operand"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("aq_offsets: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->qg_size != 16 && p->qg_size != 8) { set_error("aq_offsets: qg_size %d", p->qg_size); return X265HIP_EINVAL; }
+    if (p->aq_mode < 0 || p->aq_mode > 3) { set_error("aq_offsets: aq_mode %d (0..3; the edge mode and hevcAq are not covered)", p->aq_mode); return X265HIP_EINVAL; }
+    if (p->nblocks <= 0) { set_error("aq_offsets: nblocks %d", p->nblocks); return X265HIP_EINVAL; }
+    const int n = p->nblocks;
+    double* qp = p->qp_aq_offset;
+    if (p->aq_mode == 0 || p->aq_strength == 0)
+    {
+        for (int i = 0; i < n; i++) { qp[i] = 0; p->inv_qscale[i] = 256; }
+        return 0;
+    }
+    const float modeOneConst = p->qg_size == 8 ? 11.427f : 14.427f, modeTwoConst = p->qg_size == 8 ? 8.f : 11.f;
+    double avg_adj_pow2 = 0, avg_adj = 0, qp_adj = 0, bias_strength = 0.f, strength = 0.f;
+    if (p->aq_mode == 2 || p->aq_mode == 3)
+    {
+        const double bit_depth_correction = 1.f / (1 << (2 * (p->depth - 8)));
+        for (int i = 0; i < n; i++)
+        {
+            qp_adj = std::pow(p->energy[i] * bit_depth_correction + 1, 0.1);
+            qp[i] = qp_adj;
+            avg_adj += qp_adj;
+            avg_adj_pow2 += qp_adj * qp_adj;
+        }
+        avg_adj /= n;
+        avg_adj_pow2 /= n;
+        strength = p->aq_strength * avg_adj;
+        avg_adj = avg_adj - 0.5f * (avg_adj_pow2 - modeTwoConst) / avg_adj;
+        bias_strength = p->aq_strength;
+    }
+    else
+        strength = p->aq_strength * 1.0397f;
+    for (int i = 0; i < n; i++)
+    {
+        if (p->aq_mode == 3)
+        {
+            qp_adj = qp[i];
+            qp_adj = strength * (qp_adj - avg_adj) + bias_strength * (1.f - modeTwoConst / (qp_adj * qp_adj));
+        }
+        else if (p->aq_mode == 2)
+            qp_adj = strength * (qp[i] - avg_adj);
+        else
+            qp_adj = strength * (std::log2((double)(p->energy[i] > 1 ? p->energy[i] : 1)) - (modeOneConst + 2 * (p->depth - 8)));
+        qp[i] = qp_adj;
+        p->inv_qscale[i] = aq_exp2fix8(qp_adj);
+    }
     return 0;
 }

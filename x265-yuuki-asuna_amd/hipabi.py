@@ -332,6 +332,26 @@ def aq_energy(depth, y, stride, org, width, height, qg_size, energy, wp, cb=None
     check(f(ctypes.byref(p), s), "x265hip_aq_energy")
 
 
+class AqOffsetsParams(ctypes.Structure):
+    """x265hip_aq_offsets_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("qg_size", ctypes.c_int), ("aq_mode", ctypes.c_int), ("aq_strength", ctypes.c_double),
+                ("nblocks", ctypes.c_int), ("energy", ctypes.c_void_p), ("qp_aq_offset", ctypes.c_void_p), ("inv_qscale", ctypes.c_void_p)]
+
+
+def aq_offsets(depth, qg_size, aq_mode, aq_strength, energy):
+    """Host side of the AQ pass (x265hip_aq_offsets): energy = numpy uint32 [blocks]; returns (qp_aq_offset float64, inv_qscale int32)."""
+    import numpy as np
+    e = np.ascontiguousarray(energy, dtype=np.uint32)
+    qp, inv = np.zeros(len(e), np.float64), np.zeros(len(e), np.int32)
+    p = AqOffsetsParams()
+    p.depth, p.qg_size, p.aq_mode, p.aq_strength, p.nblocks = depth, qg_size, aq_mode, float(aq_strength), len(e)
+    p.energy, p.qp_aq_offset, p.inv_qscale = e.ctypes.data, qp.ctypes.data, inv.ctypes.data
+    f = lib().x265hip_aq_offsets
+    f.argtypes = [ctypes.POINTER(AqOffsetsParams)]
+    check(f(ctypes.byref(p)), "x265hip_aq_offsets")
+    return qp, inv
+
+
 class LowresWeightCostParams(ctypes.Structure):
     """x265hip_lowres_weight_cost_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("fenc", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),

@@ -199,9 +199,7 @@ class AdaptiveQuant:
     """The adaptive-quantisation pass of the lookahead - LookaheadTLD::calcAdaptiveQuantFrame (slicetype.cpp:439-694; AQ modes 0-3,
     no hevcAq / edge mode / HDR10 / per-block quant offsets).  The pixel work (every block's AC energy through the var primitive, the
     picture's wp_sum / wp_ssd totals) is one device launch (x265hip_aq_energy); the QP offsets are the reference's double-precision
-    expressions evaluated on the host with the C library's pow / log2 (math.pow / math.log2 are libm's), x265_exp2fix8 included."""
-
-    _lut = None
+    expressions, evaluated by the library's host-side x265hip_aq_offsets through the C library's pow / log2 like the reference."""
 
     def __init__(self, width, height, depth, device, qg_size=16, aq_mode=2, aq_strength=1.0, weightp=True):
         import torch
@@ -211,61 +209,17 @@ class AdaptiveQuant:
         self.energy = torch.zeros(self.bw * self.bh, dtype=torch.int32, device=device)
         self.wp = torch.zeros(6, dtype=torch.int64, device=device)
 
-    @classmethod
-    def exp2fix8(cls, x):
-        """x265_exp2fix8 (common.cpp:96-103) with x265_exp2_lut (constants.cpp:552) = round((2^(i/64) - 1) * 256)."""
-        import numpy as np
-        if cls._lut is None:
-            cls._lut = [int((2.0 ** (i / 64.0) - 1.0) * 256.0 + 0.5) for i in range(64)]
-        i = int(x * float(np.float32(-64.0) / np.float32(6.0)) + 512.5)
-        if i < 0:
-            return 0
-        if i > 1023:
-            return 0xffff
-        return ((cls._lut[i & 63] + 256) << (i >> 6)) >> 8
-
     def run(self, y: DevicePicture, cb=None, cr=None, stride_c=0, org_c=0):
         """y: the source luma picture; cb / cr: device chroma planes (4:2:0) or None.  Returns (qp_aq_offset float64 [blocks],
         inv_qscale int32 [blocks], wp_sum [3], wp_ssd [3]) as Lowres holds them afterwards."""
-        import math
         import numpy as np
         hipabi.aq_energy(self.depth, y.t, y.stride, y.org, self.width, self.height, self.qg, self.energy, self.wp, cb, cr, stride_c, org_c)
         energy = self.energy.cpu().numpy().view(np.uint32)
         wp = self.wp.cpu().numpy().view(np.uint64)
-        n, depth = len(energy), self.depth
-        f32 = lambda v: float(np.float32(v))
-        m1 = np.float32(11.427 if self.qg == 8 else 14.427)
-        m2 = f32(8.0 if self.qg == 8 else 11.0)
-        qp = np.zeros(n, np.float64)
-        inv = np.full(n, 256, np.int32)
-        if self.mode and self.strength != 0:
-            if self.mode in (2, 3):
-                corr = float(np.float32(1.0) / np.float32(1 << (2 * (depth - 8))))
-                adj = [math.pow(int(e) * corr + 1, 0.1) for e in energy]
-                avg = avg2 = 0.0
-                for a in adj:                                        # the reference accumulates block by block: keep its summation order
-                    avg += a
-                    avg2 += a * a
-                avg /= n
-                avg2 /= n
-                strength = self.strength * avg
-                avg = avg - 0.5 * (avg2 - m2) / avg
-                for i, a in enumerate(adj):
-                    q = strength * (a - avg)
-                    if self.mode == 3:
-                        q += self.strength * (1.0 - m2 / (a * a))
-                    qp[i] = q
-                    inv[i] = self.exp2fix8(q)
-            else:
-                strength = self.strength * f32(1.0397)
-                base = float(m1 + np.float32(2 * (depth - 8)))
-                for i, e in enumerate(energy):
-                    q = strength * (math.log2(float(max(int(e), 1))) - base)
-                    qp[i] = q
-                    inv[i] = self.exp2fix8(q)
+        qp, inv = hipabi.aq_offsets(self.depth, self.qg, self.mode, self.strength, energy)
         wp_sum = [int(v) for v in wp[:3]]
         wp_ssd = [int(v) for v in wp[3:]]
-        if self.weightp:                                             # :662-675
+        if self.weightp:                                             # the final normalisation, slicetype.cpp:662-675
             col, row = ((self.width + 8) >> 4) << 4, ((self.height + 8) >> 4) << 4
             dims = [col * row, (col >> 1) * (row >> 1), (col >> 1) * (row >> 1)]
             wp_ssd = [(wp_ssd[i] - (wp_sum[i] * wp_sum[i] + dims[i] // 2) // dims[i]) & 0xffffffffffffffff for i in range(3)]
