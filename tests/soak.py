@@ -16,6 +16,8 @@ A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
 import test_gpu_search as TS
 import test_gpu_deblock as TD
 import test_gpu_intra_recon as TI
+import test_gpu_aq as TA
+import test_gpu_lookahead_weights as TW
 from test_oracle_classes_vs_reference import sao_case
 
 dev = torch.device("cuda:0")
@@ -114,10 +116,36 @@ def soak_deblock(rng):
 
 def soak_intra_tu(rng):
     depth = int(rng.choice([8, 10, 12]))
-    TI.test_intra_recon_matches_oracle(depth, int(rng.choice([4, 8, 16, 32])), int(rng.integers(0, 52)) + 6 * (depth - 8), int(rng.integers(0, 2)))
+    TI.test_intra_recon_matches_oracle(depth, int(rng.choice([4, 8, 16, 32])), int(rng.integers(0, 52)) + 6 * (depth - 8), int(rng.integers(0, 2)),
+                                       bool(rng.integers(0, 2)))
 
 
-stages = [("deblocking (intra / chroma)", soak_deblock), ("intra TU candidates", soak_intra_tu), ("search drivers", soak_search), ("lookahead cost (P/B)", soak_lowres), ("sao passes", soak_sao), ("frame pipeline", soak_pipeline)]
+def soak_sea(rng):
+    depth = int(rng.choice([8, 10, 12]))
+    TS._check_sea(depth, int(rng.choice([192, 256, 320])), int(rng.choice([192, 256])), int(rng.integers(1, 1 << 30)), 64,
+                  [int(rng.integers(0, 8))], [int(rng.choice([4, 9, 16, 33, 40]))])
+
+
+def soak_bs(rng):
+    TD.test_boundary_strengths_multi_reference_and_b_pictures(int(rng.integers(0, 4)), int(rng.integers(0, 2)), str(rng.choice(["both", "noref1", "none"])), seed=int(rng.integers(1, 1 << 30)))
+
+
+def soak_aq(rng):
+    depth = int(rng.choice([8, 10]))
+    qg = int(rng.choice([16, 8]))
+    w, h = int(rng.choice([128, 250, 416, 640])), int(rng.choice([96, 138, 240]))
+    chroma = bool(rng.integers(0, 2)) and w % 16 == 0 and h % 16 == 0
+    TA.test_aq_pass_matches_oracle(depth, w, h, qg, int(rng.integers(1, 4)), float(rng.choice([0.5, 1.0, 1.7])), chroma, seed=int(rng.integers(1, 1 << 30)))
+
+
+def soak_weights(rng):
+    depth = int(rng.choice([8, 10]))
+    gain, lift = float(rng.choice([0.3, 0.6, 0.8, 0.95, 1.1, 1.4])), int(rng.integers(-40, 60))
+    TW.test_weight_analysis_matches_oracle(depth, int(rng.choice([256, 384, 512])), int(rng.choice([128, 256])), gain, lift, seed=int(rng.integers(1, 1 << 30)), check_expectation=False)
+
+
+stages = [("SEA search", soak_sea), ("boundary strengths (multi-ref / B)", soak_bs), ("adaptive quantisation", soak_aq), ("weight analysis", soak_weights),
+          ("deblocking (intra / chroma)", soak_deblock), ("intra TU candidates", soak_intra_tu), ("search drivers", soak_search), ("lookahead cost (P/B)", soak_lowres), ("sao passes", soak_sao), ("frame pipeline", soak_pipeline)]
 counts = {n: 0 for n, _ in stages}
 t0 = time.time()
 fail = 0

@@ -31,11 +31,11 @@ def _pad(img, margin=16):
 @pytest.mark.parametrize("depth,width,height,qg,mode,strength,chroma", [(8, 640, 360, 16, 2, 1.0, True), (8, 640, 360, 16, 1, 1.0, True), (8, 416, 240, 16, 3, 0.8, True),
                                                                     (8, 640, 352, 8, 2, 1.0, True), (8, 250, 138, 16, 2, 1.0, False), (10, 384, 256, 16, 2, 1.0, True),
                                                                     (10, 384, 256, 8, 1, 0.6, False), (8, 3840, 2160, 16, 2, 1.0, True), (8, 256, 128, 16, 0, 1.0, True)])
-def test_aq_pass_matches_oracle(depth, width, height, qg, mode, strength, chroma):
+def test_aq_pass_matches_oracle(depth, width, height, qg, mode, strength, chroma, seed=101):
     import torch
     dev = torch.device("cuda:0")
     O = _oracle()
-    yimg, cbimg, crimg = F.synth_clip(width, height, 1, depth=depth, seed=101)[0]
+    yimg, cbimg, crimg = F.synth_clip(width, height, 1, depth=depth, seed=seed)[0]
     pic = P.DevicePicture(yimg, dev)
     kw, okw = {}, {}
     if chroma:

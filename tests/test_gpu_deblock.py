@@ -140,7 +140,7 @@ def test_deblock_with_intra_blocks_and_chroma(depth, level, qp, cq):
 
 @pytest.mark.parametrize("level", [0, 1, 2, 3])
 @pytest.mark.parametrize("slice_b,lists", [(1, "both"), (1, "noref1"), (0, "both"), (0, "ref0only"), (1, "none")])
-def test_boundary_strengths_multi_reference_and_b_pictures(level, slice_b, lists):
+def test_boundary_strengths_multi_reference_and_b_pictures(level, slice_b, lists, seed=0):
     """getBoundaryStrength in full (deblock.cpp:217-247): reference picture ids per list, list-1 mvs, the B-picture four-way
     comparison - random coherent motion fields over a 1024x576 picture against the oracle restatement (pinned against the real
     Deblock class in tests/test_oracle_classes_vs_reference.py), every optional operand combination of the ABI."""
@@ -149,7 +149,7 @@ def test_boundary_strengths_multi_reference_and_b_pictures(level, slice_b, lists
     O = _oracle()
     w, h = 1024, 576
     nctu, npu = (w // 64) * (h // 64), (64 >> (3 + level)) ** 2
-    rng = np.random.default_rng([47, level, slice_b, len(lists)])
+    rng = np.random.default_rng([47, level, slice_b, len(lists), seed])
 
     def field():
         m = np.zeros((nctu * 85, 2), np.int32)

@@ -109,29 +109,25 @@ def test_sea_block_sum_planes(depth):
         assert not got[k, rows - bh + 1:, :].any()                                       # nothing written outside the valid corners
 
 
-@pytest.mark.parametrize("depth", [8, 10])
-def test_sea_search_driver(depth):
-    """X265_SEA through the device planes: every supported PU size, random predictors / bounds / merange / sub-pel levels against
-    the oracle restatement (pinned against the real MotionEstimate with real integral planes); the four sizes whose DC terms the
-    reference reads from outside the PU come back refused (out_cost -1)."""
+def _check_sea(depth, width, height, seed, njobs, submes, meranges):
+    """X265_SEA through the device planes against the oracle restatement; returns (PU sizes seen, jobs whose mv moved)."""
     import torch
     dev = torch.device("cuda:0")
     O = _oracle()
-    width, height = 256, 192
-    clip = F.synth_clip(width, height, 2, depth=depth, seed=49)
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=seed)
     cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
     integral = A.sea_integral(depth, ref.t, ref.stride, ref.org, ref.w64, ref.h64, F.MARGIN_X, F.MARGIN_Y)
-    rng = np.random.default_rng([49, depth])
+    rng = np.random.default_rng([seed, depth])
     cq, qoff = F.qpel_cost_table(57, qmax=8 * 64 + 300)
     cq_d = torch.from_numpy(cq.view(np.int16)).to(dev)
     seen, moved = set(), 0
-    for subme in (0, 2, 3, 5, 7):
-        for merange in (5, 16, 40):
+    for subme in submes:
+        for merange in meranges:
             mn, mx = (-44, -44), (44, 44)
             if rng.integers(0, 3) == 0:
                 mn = (-int(rng.integers(3, 20)), -int(rng.integers(3, 20)))
                 mx = (int(rng.integers(3, 20)), int(rng.integers(3, 20)))
-            jobs = _jobs(rng, 96, width, height)
+            jobs = _jobs(rng, njobs, width, height)
             ok = np.array([(int(j["w"]), int(j["h"])) not in SEA_UNSUPPORTED for j in jobs])
             exp = O.motion_estimate(depth, cur.host, ref.host, cur.stride, cur.org, A.ME_SEA, subme, merange, cq, qoff, mn, mx, jobs[ok])
             jd = torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy()).to(dev)
@@ -146,6 +142,15 @@ def test_sea_search_driver(depth):
                                        f"first {jobs[ok][bad[0]]}: got {got[ok][bad[0]]} expected {exp[bad[0]]}")
             seen |= {(int(j["w"]), int(j["h"])) for j in jobs[ok]}
             moved += int(np.count_nonzero(exp["out_qmvx"] | exp["out_qmvy"]))
+    return seen, moved
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_sea_search_driver(depth):
+    """X265_SEA through the device planes: every supported PU size, random predictors / bounds / merange / sub-pel levels against
+    the oracle restatement (pinned against the real MotionEstimate with real integral planes); the four sizes whose DC terms the
+    reference reads from outside the PU come back refused (out_cost -1)."""
+    seen, moved = _check_sea(depth, 256, 192, 49, 96, (0, 2, 3, 5, 7), (5, 16, 40))
     assert len(seen) == len(ALL_PU_DIMS) - len(SEA_UNSUPPORTED) and moved > 500
 
 
