@@ -126,6 +126,25 @@ def lowres_intra(depth, plane, stride, org, width_in_cu, height_in_cu, intra_pen
     return cost, mode, lc
 
 
+def cutree_propagate(depth, width_in_cu, height_in_cu, propagate_in, intra_cost, lowres_costs, inv_qscale, mvs0, mvs1, fps_factor, bipred_weight,
+                     ref_cost0, ref_cost1=None, avx2=False):
+    """CPU restatement of Lookahead::estimateCUPropagate + primitives.propagateCost.  Returns the updated copies (ref_cost0, ref_cost1)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_cutree_propagate_d{depth}")
+    fn.restype = None
+    fn.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    pi = None if propagate_in is None else np.ascontiguousarray(propagate_in, np.uint16)
+    ic, lc, iq = np.ascontiguousarray(intra_cost, np.int32), np.ascontiguousarray(lowres_costs, np.uint16), np.ascontiguousarray(inv_qscale, np.int32)
+    m0 = np.ascontiguousarray(mvs0, np.int32)
+    m1 = None if mvs1 is None else np.ascontiguousarray(mvs1, np.int32)
+    r0 = np.ascontiguousarray(ref_cost0, np.uint16).copy()
+    r1 = None if ref_cost1 is None else np.ascontiguousarray(ref_cost1, np.uint16).copy()
+    ptr = lambda a: None if a is None else a.ctypes.data
+    fn(width_in_cu, height_in_cu, ptr(pi), ic.ctypes.data, lc.ctypes.data, iq.ctypes.data, m0.ctypes.data, ptr(m1), float(fps_factor), int(bipred_weight),
+       r0.ctypes.data, ptr(r1))
+    return r0, r1
+
+
 def aq_frame(depth, y, stride, org, width, height, cb=None, cr=None, stride_c=0, org_c=0, qg_size=16, aq_mode=2, aq_strength=1.0, weightp=True,
              avx2=False):
     """CPU restatement of LookaheadTLD::calcAdaptiveQuantFrame.  y / cb / cr: padded planes (flat arrays, sample (0,0) at org / org_c).

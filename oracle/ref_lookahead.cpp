@@ -378,4 +378,91 @@ int x265ref_aq_frame(const void* yPlane, const void* cb, const void* cr, int wid
     return rc;
 }
 
+
+namespace { struct LookaheadProbe : public Lookahead
+{
+    LookaheadProbe(x265_param* p, ThreadPool* t) : Lookahead(p, t) {}
+    using Lookahead::estimateCUPropagate;            /* protected in the class (slicetype.h:196) */
+}; }
+
+/* One cuTree propagation step with the REAL Lookahead::estimateCUPropagate (encoder/slicetype.cpp:2641-2753).  Three pictures:
+ * ref0 (frame 0), cur (frame 1), ref1 (frame 2; NULL = a P picture, p1 = b = 1).  The real singleCost fills lowresMvs / lowresCosts of
+ * the current picture first; then propagateCost of the three pictures is set from the caller (propCur NULL = not referenced),
+ * invQscaleFactor of the current picture from invQscale, and estimateCUPropagate(frames, averageDuration, 0, p1, 1, referenced) runs.
+ * Outputs: the inputs the step read (intraCost, lowresCosts, mvs0, mvs1) and the references' propagateCost afterwards. */
+int x265ref_cutree_propagate(const void* curPlane, const void* ref0Plane, const void* ref1Plane, int width, int height,
+                             const int32_t* invQscale, const uint16_t* propCur, uint16_t* propRef0, uint16_t* propRef1,
+                             int fpsNum, int fpsDenom, double averageDuration, int weightedBiPred,
+                             int32_t* intraCost, uint16_t* lowresCosts, int32_t* mvs0, int32_t* mvs1)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
+    const int nf = ref1Plane ? 3 : 2, p1 = ref1Plane ? 2 : 1;
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width;
+    param->sourceHeight = height;
+    param->internalCsp = X265_CSP_I400;
+    param->maxCUSize = 64;
+    param->rc.aqMode = 2;                       /* Lowres::create allocates invQscaleFactor only with AQ on */
+    param->rc.hevcAq = 0;
+    param->rc.qgSize = 32;
+    param->rc.vbvBufferSize = 0;
+    param->bAQMotion = 0;
+    param->bEnableHME = 0;
+    param->bEnableWeightedPred = 0;
+    param->bEnableWeightedBiPred = weightedBiPred;
+    param->lookaheadSlices = 0;
+    param->fpsNum = fpsNum;
+    param->fpsDenom = fpsDenom;
+    const int h64 = (height + 63) / 64 * 64;
+    PicYuv pics[3];
+    Lowres lrs[3];
+    const void* srcs[3] = { ref0Plane, curPlane, ref1Plane };
+    const uint32_t qgSize = 32;
+    for (int i = 0; i < nf; i++)
+    {
+        pics[i].m_param = param;
+        if (!pics[i].create(param, true)) return -1;
+        memcpy(pics[i].m_picOrg[0] - pics[i].m_lumaMarginY * pics[i].m_stride - pics[i].m_lumaMarginX, srcs[i],
+               sizeof(pixel) * pics[i].m_stride * (h64 + 2 * pics[i].m_lumaMarginY));
+        memset((void*)&lrs[i], 0, sizeof(Lowres));
+        if (!lrs[i].create(param, &pics[i], qgSize)) return -2;
+        lrs[i].init(&pics[i], i);
+    }
+    Lowres& fenc = lrs[1];
+    const int ncu = fenc.maxBlocksInRow * fenc.maxBlocksInCol;
+    for (int i = 0; i < nf; i++)
+        for (int k = 0; k < ncu; k++) lrs[i].invQscaleFactor[k] = i == 1 ? invQscale[k] : 256;
+    int rc = 0;
+    {
+        LookaheadProbe la(param, NULL);
+        if (!la.create()) rc = -3;
+        else
+        {
+            la.m_tld[0].lowresIntraEstimate(fenc, qgSize);
+            Lowres* frames[3] = { &lrs[0], &lrs[1], nf == 3 ? &lrs[2] : NULL };
+            CostEstimateGroup estGroup(la, frames);
+            estGroup.singleCost(0, p1, 1);
+            for (int k = 0; k < ncu; k++)
+            {
+                intraCost[k] = fenc.intraCost[k];
+                lowresCosts[k] = fenc.lowresCosts[1][p1 - 1][k];
+                mvs0[2 * k] = fenc.lowresMvs[0][1][k].x; mvs0[2 * k + 1] = fenc.lowresMvs[0][1][k].y;
+                if (nf == 3) { mvs1[2 * k] = fenc.lowresMvs[1][1][k].x; mvs1[2 * k + 1] = fenc.lowresMvs[1][1][k].y; }
+            }
+            memcpy(lrs[0].propagateCost, propRef0, sizeof(uint16_t) * ncu);
+            if (nf == 3) memcpy(lrs[2].propagateCost, propRef1, sizeof(uint16_t) * ncu);
+            if (propCur) memcpy(fenc.propagateCost, propCur, sizeof(uint16_t) * ncu);
+            la.estimateCUPropagate(frames, averageDuration, 0, p1, 1, propCur ? 1 : 0);
+            memcpy(propRef0, lrs[0].propagateCost, sizeof(uint16_t) * ncu);
+            if (nf == 3) memcpy(propRef1, lrs[2].propagateCost, sizeof(uint16_t) * ncu);
+            la.destroy();
+        }
+    }
+    for (int i = 0; i < nf; i++) { lrs[i].destroy(); pics[i].destroy(); }
+    x265_param_free(param);
+    return rc;
+}
+
 } // extern "C"

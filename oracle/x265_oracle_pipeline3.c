@@ -323,3 +323,55 @@ void EXPORT(x265oracle_aq_frame)(const pixel* y, const pixel* cb, const pixel* c
             wpSsd[i] = wpSsd[i] - (wpSum[i] * wpSum[i] + (uint64_t)(w[i] * h[i]) / 2) / (uint64_t)(w[i] * h[i]);
     }
 }
+
+/* ================================================================ cuTree: one propagation step
+ * Lookahead::estimateCUPropagate (slicetype.cpp:2641-2753) with primitives.propagateCost (pixel.cpp:914-940): every 8x8 lowres block
+ * of picture b passes on  (propagateIn + intraCost * invQscale * fpsFactor / 256) * (intraCost - min(intraCost, interCost)) / intraCost
+ * (double arithmetic, + 0.5, truncated) to the blocks its motion vectors point at in the list-0 / list-1 reference, split bilinearly
+ * over the four blocks the displaced block overlaps (weights in 1/32 block units, blocks outside the picture dropped), halved by the
+ * bi-prediction weights when both lists are used; the references' propagateCost accumulate with saturation at 65535.
+ * propagateIn: uint16 [h][w] = frames[b]->propagateCost, or NULL for a non-referenced picture (zeros); mvs0 / mvs1: int32 [n][2];
+ * lowresCosts: uint16 [n] (cost | lists used << 14); refCost0 / refCost1: uint16 [n], updated in place (refCost1 may be NULL for P). */
+void EXPORT(x265oracle_cutree_propagate)(int widthInCU, int heightInCU, const uint16_t* propagateIn, const int32_t* intraCost,
+                                         const uint16_t* lowresCosts, const int32_t* invQscale, const int32_t* mvs0, const int32_t* mvs1,
+                                         double fpsFactor, int bipredWeight, uint16_t* refCost0, uint16_t* refCost1)
+{
+    const double fps = fpsFactor / 256;
+    const int32_t bipredWeights[2] = { bipredWeight, 64 - bipredWeight };
+    uint16_t* refCosts[2] = { refCost0, refCost1 };
+    const int32_t* mvsL[2] = { mvs0, mvs1 };
+#define CLIP_ADD(S, X) (S) = (uint16_t)((int32_t)(S) + (X) < 65535 ? (int32_t)(S) + (X) : 65535)
+    for (int blocky = 0; blocky < heightInCU; blocky++)
+        for (int blockx = 0; blockx < widthInCU; blockx++)
+        {
+            const int cuIndex = blocky * widthInCU + blockx;
+            const int intra = intraCost[cuIndex];
+            const int inter0 = lowresCosts[cuIndex] & LOWRES_COST_MASK, inter = intra < inter0 ? intra : inter0;
+            const double propagateIntra = intra * invQscale[cuIndex];
+            const double amount = (double)(propagateIn ? propagateIn[cuIndex] : 0) + propagateIntra * fps;
+            const double r = amount * (double)(intra - inter) / (double)intra + 0.5;
+            const int32_t propagate_amount = (r == r && r < 2147483648.0 && r > -2147483649.0) ? (int32_t)r : INT32_MIN;   /* cvttsd2si's answer for NaN / overflow */
+            if (propagate_amount <= 0) continue;
+            const int32_t lists_used = lowresCosts[cuIndex] >> 14;
+            for (int list = 0; list < 2; list++)
+            {
+                if (!((lists_used >> list) & 1)) continue;
+                int32_t listamount = propagate_amount;
+                if (lists_used == 3) listamount = (listamount * bipredWeights[list] + 32) >> 6;
+                int32_t x = mvsL[list][2 * cuIndex], y = mvsL[list][2 * cuIndex + 1];
+                uint16_t* rc = refCosts[list];
+                if (!x && !y) { CLIP_ADD(rc[cuIndex], listamount); continue; }
+                const int32_t cux = (x >> 5) + blockx, cuy = (y >> 5) + blocky;
+                const int32_t idx0 = cux + cuy * widthInCU;
+                x &= 31; y &= 31;
+                const int32_t w[4] = { (32 - y) * (32 - x), (32 - y) * x, y * (32 - x), y * x };
+                for (int k = 0; k < 4; k++)
+                {
+                    const int32_t tx = cux + (k & 1), ty = cuy + (k >> 1);
+                    if (tx < 0 || ty < 0 || tx >= widthInCU || ty >= heightInCU) continue;      /* :2722-2741: each target checked on its own */
+                    CLIP_ADD(rc[idx0 + (k & 1) + (k >> 1) * widthInCU], (listamount * w[k] + 512) >> 10);
+                }
+            }
+        }
+#undef CLIP_ADD
+}

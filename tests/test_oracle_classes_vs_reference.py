@@ -504,6 +504,58 @@ def test_weighted_b_frame_cost_equals_reference_classes(depth, width, height, ga
     assert not np.array_equal(allw[2], lc) and not np.array_equal(plain[2], lc)
 
 
+def clip_duration(f):
+    return min(max(f, 0.01), 1.0)          # CLIP_DURATION, ratecontrol.h:44-47
+
+
+@pytest.mark.parametrize("depth,width,height,bframe,referenced,wbp,avg", [(8, 256, 128, False, True, 0, 1 / 30), (8, 256, 128, True, True, 0, 1 / 24),
+                                                                         (8, 208, 144, True, False, 1, 1 / 30), (10, 192, 128, True, True, 1, 1 / 60),
+                                                                         (8, 320, 192, False, False, 0, 0.5)])
+def test_cutree_propagation_step_equals_reference_class(depth, width, height, bframe, referenced, wbp, avg):
+    """Lookahead::estimateCUPropagate + primitives.propagateCost (slicetype.cpp:2641-2753, pixel.cpp:914-940): the real class runs on
+    the motion vectors / costs its own singleCost produced; the restatement gets those same inputs and must leave the same
+    propagateCost in the references (bilinear split over four blocks, picture-border drops, bi-prediction weights, saturation)."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_cutree_propagate"):
+        pytest.skip("oracle/_ref predates x265ref_cutree_propagate")
+    clip = F.synth_clip(width, height, 3, depth=depth, seed=105)
+    rng = np.random.default_rng([15, depth, width, int(bframe)])
+    y0, y2 = clip[0][0], clip[2][0]
+    y1 = np.roll(y0, (5, -9), axis=(0, 1)).copy()
+    y1[: height // 3] = np.roll(y2, (-7, 12), axis=(0, 1))[: height // 3]
+    y1[-32:, -64:] = y0[-32:, -64:]
+    y1[-64:-32, :64] = ((y0[-64:-32, :64].astype(np.int32) + y2[-64:-32, :64] + 1) >> 1).astype(y1.dtype)
+    cur = F.pad_plane(y1)[0]
+    r0, r1 = F.pad_plane(y0)[0], F.pad_plane(y2)[0]
+    wcu, hcu = (width // 2 + 7) >> 3, (height // 2 + 7) >> 3
+    n = wcu * hcu
+    invq = rng.integers(128, 513, size=n).astype(np.int32)
+    prop_cur = rng.integers(0, 30000, size=n).astype(np.uint16) if referenced else None
+    pr0 = rng.integers(0, 65536, size=n).astype(np.uint16)
+    pr0[::3] = 65533                                                       # a third of the blocks are about to saturate
+    pr1 = rng.integers(0, 40000, size=n).astype(np.uint16)
+    g0, g1 = pr0.copy(), pr1.copy()
+    icost, lcost = np.zeros(n, np.int32), np.zeros(n, np.uint16)
+    mv0, mv1 = np.zeros((n, 2), np.int32), np.zeros((n, 2), np.int32)
+    lib.x265ref_cutree_propagate.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4 + \
+                                           [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int] + [ctypes.c_void_p] * 4
+    assert lib.x265ref_cutree_propagate(cur.ctypes.data, r0.ctypes.data, r1.ctypes.data if bframe else None, width, height, invq.ctypes.data,
+                                        None if prop_cur is None else prop_cur.ctypes.data, g0.ctypes.data, g1.ctypes.data, 30, 1, avg, wbp,
+                                        icost.ctypes.data, lcost.ctypes.data, mv0.ctypes.data, mv1.ctypes.data) == 0
+    fps_factor = clip_duration(1 / 30) / clip_duration(avg)
+    # distScaleFactor / bipredWeight (slicetype.cpp:2644-2646) for b - p0 = 1, p1 - p0 = 2 (B) or 1 (P)
+    span = 2 if bframe else 1
+    dist_scale = ((1 << 8) + (span >> 1)) // span
+    bipred = 64 - (dist_scale >> 2) if wbp else 32
+    e0, e1 = O.cutree_propagate(depth, wcu, hcu, prop_cur, icost, lcost, invq, mv0, mv1 if bframe else None, fps_factor, bipred, pr0, pr1 if bframe else None)
+    assert np.array_equal(e0, g0), f"list-0 reference: {np.count_nonzero(e0 != g0)} blocks differ"
+    if bframe:
+        assert np.array_equal(e1, g1), f"list-1 reference: {np.count_nonzero(e1 != g1)} blocks differ"
+        assert (lcost >> 14 == 3).any()
+    assert (g0 != pr0).any() and (g0 == 65535).any() and (mv0 != 0).any()
+
+
 def sao_case(depth, width, height, seed):
     """Source / deblocked-like pair and random per-CTU SAO parameters (all five types, off, merge-left runs)."""
     rng = np.random.default_rng([21, depth, width, seed])
