@@ -399,6 +399,27 @@ typedef struct x265hip_aq_offsets_params
     int32_t* inv_qscale;             /* HOST int32 [nblocks] */
 } x265hip_aq_offsets_params;
 int x265hip_aq_offsets(const x265hip_aq_offsets_params* p);
+/* x265hip_cutree_propagate = one cuTree propagation step, Lookahead::estimateCUPropagate (encoder/slicetype.cpp:2641-2753) with
+ *   primitives.propagateCost (pixel.cpp:914-940): every 8x8 lowres block of picture b passes on
+ *   (propagate_in + intra_cost * inv_qscale * fps_factor / 256) * (intra - min(intra, inter)) / intra   (double arithmetic, exactly as
+ *   the reference's C: no fused multiply-add) to the blocks its mvs point at in the list-0 / list-1 reference - split bilinearly over
+ *   four blocks, targets outside the picture dropped, weighted by bipred_weight / 64 when both lists are used - and the references'
+ *   propagateCost accumulate with saturation at 65535 (saturating sums of non-negative terms do not depend on the order: the
+ *   kernel adds into 64-bit counters and clamps once).  Amounts are assumed below 2^21, as in any real encode: beyond that the
+ *   reference's own int32 products `listamount * weight` overflow (:2704-2716) and its result depends on the block order.
+ *   All arrays DEVICE, one entry per 8x8 block, row-major: propagate_in uint16 (NULL: a non-referenced picture, zeros), intra_cost
+ *   int32, lowres_costs uint16 (cost | lists used << 14), inv_qscale int32, mvs0 / mvs1 int32 [n][2] (x265hip_lowres_cost's outputs;
+ *   mvs1 / ref_cost1 NULL for a P picture), ref_cost0 / ref_cost1 uint16, updated in place. */
+typedef struct x265hip_cutree_propagate_params
+{
+    int width_in_cu, height_in_cu;
+    const uint16_t* propagate_in; const int32_t* intra_cost; const uint16_t* lowres_costs; const int32_t* inv_qscale;
+    const int32_t* mvs0; const int32_t* mvs1;
+    double fps_factor;               /* CLIP_DURATION(fpsDenom / fpsNum) / CLIP_DURATION(averageDuration), slicetype.cpp:2654 */
+    int bipred_weight;               /* 32, or 64 - (distScaleFactor >> 2) with --weightb (:2644-2646) */
+    uint16_t* ref_cost0; uint16_t* ref_cost1;
+} x265hip_cutree_propagate_params;
+int x265hip_cutree_propagate(const x265hip_cutree_propagate_params* p, void* stream);
 typedef struct x265hip_lowres_weight_apply_params
 {
     int depth;

@@ -367,6 +367,67 @@ __global__ void aq_totals_kernel(const unsigned long long* slots, unsigned long 
     wp[threadIdx.x] = t;
 }
 
+// ---- cuTree: one propagation step (Lookahead::estimateCUPropagate, slicetype.cpp:2641-2753; propagateCost, pixel.cpp:914-940)
+struct CuTreeArgs
+{
+    int w, h;
+    const uint16_t* propagateIn; const int32_t* intraCost; const uint16_t* lowresCosts; const int32_t* invQscale;
+    const int32_t* mvs[2];
+    double fps;                                     // fpsFactor / 256
+    int bipred[2];
+    unsigned long long* acc[2];                     // 64-bit sums per target block and list
+    uint16_t* refCost[2];
+};
+
+// a thread per source block: the amount in double precision with separate multiply / add / divide roundings (__dmul_rn & co. are
+// never contracted into FMAs: the reference's C is not), then up to four atomic adds per list
+__global__ void __launch_bounds__(256) cutree_scatter_kernel(CuTreeArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.w * a.h) return;
+    const int blocky = i / a.w, blockx = i - blocky * a.w;
+    const int intra = a.intraCost[i];
+    const int lc = a.lowresCosts[i];
+    const int inter = min(intra, lc & 0x3fff);
+    const double propagateIntra = (double)(intra * a.invQscale[i]);
+    const double amount = __dadd_rn((double)(a.propagateIn ? (int)a.propagateIn[i] : 0), __dmul_rn(propagateIntra, a.fps));
+    const double r = __dadd_rn(__ddiv_rn(__dmul_rn(amount, (double)(intra - inter)), (double)intra), 0.5);
+    if (!(r >= 1.0) || r >= 2147483648.0) return;   // (int)r <= 0, NaN (intra cost 0) or out of int range: nothing is passed on
+    const int amountI = (int)r;
+    const int lists = lc >> 14;
+#pragma unroll
+    for (int list = 0; list < 2; list++)
+    {
+        if (!((lists >> list) & 1)) continue;
+        int listamount = amountI;
+        if (lists == 3) listamount = (listamount * a.bipred[list] + 32) >> 6;
+        int x = a.mvs[list][2 * i], y = a.mvs[list][2 * i + 1];
+        unsigned long long* acc = a.acc[list];
+        if (!x && !y) { atomicAdd(&acc[i], (unsigned long long)listamount); continue; }
+        const int cux = (x >> 5) + blockx, cuy = (y >> 5) + blocky;
+        x &= 31; y &= 31;
+        const int wgt[4] = { (32 - y) * (32 - x), (32 - y) * x, y * (32 - x), y * x };
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int tx = cux + (k & 1), ty = cuy + (k >> 1);
+            if (tx < 0 || ty < 0 || tx >= a.w || ty >= a.h) continue;
+            const int v = (listamount * wgt[k] + 512) >> 10;
+            if (v > 0) atomicAdd(&acc[ty * a.w + tx], (unsigned long long)v);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) cutree_finish_kernel(CuTreeArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.w * a.h) return;
+    uint16_t* rc = a.refCost[blockIdx.y];
+    if (!rc) return;
+    const unsigned long long t = (unsigned long long)rc[i] + a.acc[blockIdx.y][i];
+    rc[i] = (uint16_t)(t < 65535ull ? t : 65535ull);
+}
+
 struct WeightApplyArgs
 {
     const uint8_t* src[4]; uint8_t* dst[4];
@@ -566,5 +627,34 @@ extern "C" int x265hip_aq_offsets(const x265hip_aq_offsets_params* p)
         qp[i] = qp_adj;
         p->inv_qscale[i] = aq_exp2fix8(qp_adj);
     }
+    return 0;
+}
+
+extern "C" int x265hip_cutree_propagate(const x265hip_cutree_propagate_params* p, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->intra_cost || !p->lowres_costs || !p->inv_qscale || !p->mvs0 || !p->ref_cost0) { set_error("cutree_propagate: NULL operand"); return X265HIP_EINVAL; }
+    if ((p->mvs1 == NULL) != (p->ref_cost1 == NULL)) { set_error("cutree_propagate: mvs1 and ref_cost1 go together"); return X265HIP_EINVAL; }
+    if (p->width_in_cu <= 0 || p->height_in_cu <= 0) { set_error("cutree_propagate: empty picture"); return X265HIP_EINVAL; }
+    if (p->bipred_weight < 0 || p->bipred_weight > 64) { set_error("cutree_propagate: bipred_weight %d", p->bipred_weight); return X265HIP_EINVAL; }
+    const size_t n = (size_t)p->width_in_cu * p->height_in_cu;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* acc = nullptr;
+    X265HIP_TRY(hipMallocAsync((void**)&acc, sizeof(unsigned long long) * 2 * n, s));
+    X265HIP_TRY(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * 2 * n, s));
+    CuTreeArgs a;
+    a.w = p->width_in_cu; a.h = p->height_in_cu;
+    a.propagateIn = p->propagate_in; a.intraCost = p->intra_cost; a.lowresCosts = p->lowres_costs; a.invQscale = p->inv_qscale;
+    a.mvs[0] = p->mvs0; a.mvs[1] = p->mvs1 ? p->mvs1 : p->mvs0;      // a P picture never uses list 1 (lists used is 0 or 1)
+    a.fps = p->fps_factor / 256;
+    a.bipred[0] = p->bipred_weight; a.bipred[1] = 64 - p->bipred_weight;
+    a.acc[0] = acc; a.acc[1] = acc + n;
+    a.refCost[0] = p->ref_cost0; a.refCost[1] = p->ref_cost1;
+    const unsigned g = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(cutree_scatter_kernel, dim3(g), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(cutree_finish_kernel, dim3(g, 2), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    X265HIP_TRY(hipFreeAsync(acc, s));
     return 0;
 }

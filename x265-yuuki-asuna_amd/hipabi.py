@@ -352,6 +352,29 @@ def aq_offsets(depth, qg_size, aq_mode, aq_strength, energy):
     return qp, inv
 
 
+class CuTreePropagateParams(ctypes.Structure):
+    """x265hip_cutree_propagate_params (include/x265hip.h)."""
+    _fields_ = [("width_in_cu", ctypes.c_int), ("height_in_cu", ctypes.c_int),
+                ("propagate_in", ctypes.c_void_p), ("intra_cost", ctypes.c_void_p), ("lowres_costs", ctypes.c_void_p), ("inv_qscale", ctypes.c_void_p),
+                ("mvs0", ctypes.c_void_p), ("mvs1", ctypes.c_void_p), ("fps_factor", ctypes.c_double), ("bipred_weight", ctypes.c_int),
+                ("ref_cost0", ctypes.c_void_p), ("ref_cost1", ctypes.c_void_p)]
+
+
+def cutree_propagate(width_in_cu, height_in_cu, propagate_in, intra_cost, lowres_costs, inv_qscale, mvs0, mvs1, fps_factor, bipred_weight,
+                     ref_cost0, ref_cost1=None, stream=None):
+    """One cuTree propagation step (x265hip_cutree_propagate); device tensors, ref_cost0 / ref_cost1 (int16 tensors holding uint16 bits)
+    updated in place."""
+    p = CuTreePropagateParams()
+    p.width_in_cu, p.height_in_cu = width_in_cu, height_in_cu
+    p.propagate_in, p.intra_cost, p.lowres_costs, p.inv_qscale = _p(propagate_in), intra_cost.data_ptr(), lowres_costs.data_ptr(), inv_qscale.data_ptr()
+    p.mvs0, p.mvs1, p.fps_factor, p.bipred_weight = mvs0.data_ptr(), _p(mvs1), float(fps_factor), int(bipred_weight)
+    p.ref_cost0, p.ref_cost1 = ref_cost0.data_ptr(), _p(ref_cost1)
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_cutree_propagate
+    f.argtypes = [ctypes.POINTER(CuTreePropagateParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_cutree_propagate")
+
+
 class LowresWeightCostParams(ctypes.Structure):
     """x265hip_lowres_weight_cost_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("fenc", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),
