@@ -420,6 +420,21 @@ typedef struct x265hip_cutree_propagate_params
     uint16_t* ref_cost0; uint16_t* ref_cost1;
 } x265hip_cutree_propagate_params;
 int x265hip_cutree_propagate(const x265hip_cutree_propagate_params* p, void* stream);
+/* x265hip_cutree_finish - HOST-side companion of the propagation step (no device work, host pointers): Lookahead::cuTreeFinish
+ *   (slicetype.cpp:2889-2937; quantisation groups of 16 or more, hevcAq off) - the propagated cost of every 8x8 lowres block becomes
+ *   qp_cutree_offset = qp_aq_offset - strength * (log2(intra + propagate) - log2(intra) + weight_delta), intra = (intra_cost *
+ *   inv_qscale + 128) >> 8, propagate = (propagate_cost * fps_factor_q8 + 128) >> 8; blocks whose scaled intra cost is 0 keep their
+ *   value.  fps_factor_q8 = (int)(CLIP_DURATION(averageDuration) / CLIP_DURATION(fpsDenom / fpsNum) * 256); strength = 5.0 * (1.0 -
+ *   qCompress) (:989); weight_delta = 1 - weightedCostDelta[ref0Distance - 1] when that is positive, else 0. */
+typedef struct x265hip_cutree_finish_params
+{
+    int nblocks;
+    const int32_t* intra_cost; const int32_t* inv_qscale; const uint16_t* propagate_cost; const double* qp_aq_offset;   /* HOST */
+    int fps_factor_q8;
+    double weight_delta, strength;
+    double* qp_cutree_offset;                                                                                        /* HOST, in place */
+} x265hip_cutree_finish_params;
+int x265hip_cutree_finish(const x265hip_cutree_finish_params* p);
 typedef struct x265hip_lowres_weight_apply_params
 {
     int depth;

@@ -145,6 +145,19 @@ def cutree_propagate(depth, width_in_cu, height_in_cu, propagate_in, intra_cost,
     return r0, r1
 
 
+def cutree_finish(depth, intra_cost, inv_qscale, propagate_cost, qp_aq_offset, fps_factor_q8, weight_delta, strength, qp_cutree_offset, avx2=False):
+    """CPU restatement of Lookahead::cuTreeFinish (qgSize >= 16, hevcAq off).  Returns the updated copy of qp_cutree_offset."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_cutree_finish_d{depth}")
+    fn.restype = None
+    fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+    ic, iq = np.ascontiguousarray(intra_cost, np.int32), np.ascontiguousarray(inv_qscale, np.int32)
+    pc, qa = np.ascontiguousarray(propagate_cost, np.uint16), np.ascontiguousarray(qp_aq_offset, np.float64)
+    out = np.ascontiguousarray(qp_cutree_offset, np.float64).copy()
+    fn(len(ic), ic.ctypes.data, iq.ctypes.data, pc.ctypes.data, qa.ctypes.data, int(fps_factor_q8), float(weight_delta), float(strength), out.ctypes.data)
+    return out
+
+
 def aq_frame(depth, y, stride, org, width, height, cb=None, cr=None, stride_c=0, org_c=0, qg_size=16, aq_mode=2, aq_strength=1.0, weightp=True,
              avx2=False):
     """CPU restatement of LookaheadTLD::calcAdaptiveQuantFrame.  y / cb / cr: padded planes (flat arrays, sample (0,0) at org / org_c).

@@ -383,6 +383,7 @@ namespace { struct LookaheadProbe : public Lookahead
 {
     LookaheadProbe(x265_param* p, ThreadPool* t) : Lookahead(p, t) {}
     using Lookahead::estimateCUPropagate;            /* protected in the class (slicetype.h:196) */
+    using Lookahead::cuTreeFinish;
 }; }
 
 /* One cuTree propagation step with the REAL Lookahead::estimateCUPropagate (encoder/slicetype.cpp:2641-2753).  Three pictures:
@@ -463,6 +464,61 @@ int x265ref_cutree_propagate(const void* curPlane, const void* ref0Plane, const 
     for (int i = 0; i < nf; i++) { lrs[i].destroy(); pics[i].destroy(); }
     x265_param_free(param);
     return rc;
+}
+
+
+/* The REAL Lookahead::cuTreeFinish (encoder/slicetype.cpp:2889-2937) on caller-supplied per-block arrays of a width x height picture
+ * (qgSize 32, hevcAq off): qpCuTreeOffset is preset to `preset` and updated in place. */
+int x265ref_cutree_finish(int width, int height, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* propagateCost,
+                          const double* qpAqOffset, int fpsNum, int fpsDenom, double averageDuration, double qCompress,
+                          int ref0Distance, double weightedCostDelta, double* qpCuTreeOffset)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width;
+    param->sourceHeight = height;
+    param->internalCsp = X265_CSP_I400;
+    param->maxCUSize = 64;
+    param->rc.aqMode = 2;
+    param->rc.hevcAq = 0;
+    param->rc.qgSize = 32;
+    param->rc.qCompress = qCompress;
+    param->bEnableHME = 0;
+    param->fpsNum = fpsNum;
+    param->fpsDenom = fpsDenom;
+    PicYuv pic;
+    pic.m_param = param;
+    if (!pic.create(param, true)) return -1;
+    Lowres lr;
+    memset((void*)&lr, 0, sizeof(Lowres));
+    if (!lr.create(param, &pic, 32)) return -2;
+    const int ncu = lr.maxBlocksInRow * lr.maxBlocksInCol;
+    int rc = 0;
+    {
+        LookaheadProbe la(param, NULL);
+        if (!la.create()) rc = -3;
+        else
+        {
+            for (int k = 0; k < ncu; k++)
+            {
+                lr.intraCost[k] = intraCost[k];
+                lr.invQscaleFactor[k] = invQscale[k];
+                lr.propagateCost[k] = propagateCost[k];
+                lr.qpAqOffset[k] = qpAqOffset[k];
+                lr.qpCuTreeOffset[k] = qpCuTreeOffset[k];
+            }
+            if (ref0Distance) lr.weightedCostDelta[ref0Distance - 1] = weightedCostDelta;
+            la.cuTreeFinish(&lr, averageDuration, ref0Distance);
+            for (int k = 0; k < ncu; k++) qpCuTreeOffset[k] = lr.qpCuTreeOffset[k];
+            la.destroy();
+        }
+    }
+    lr.destroy();
+    pic.destroy();
+    x265_param_free(param);
+    return rc ? rc : ncu;
 }
 
 } // extern "C"

@@ -375,3 +375,22 @@ void EXPORT(x265oracle_cutree_propagate)(int widthInCU, int heightInCU, const ui
         }
 #undef CLIP_ADD
 }
+
+/* Lookahead::cuTreeFinish (slicetype.cpp:2889-2937, quantisation groups of 16 or more, hevcAq off): the propagated cost of every
+ * 8x8 lowres block becomes a QP offset, qpCuTreeOffset = qpAqOffset - strength * (log2(intra + propagate) - log2(intra) + weightDelta)
+ * with intra = (intraCost * invQscale + 128) >> 8 and propagate = (propagateCost * fpsFactorQ8 + 128) >> 8; blocks whose scaled intra
+ * cost is 0 keep their value.  fpsFactorQ8 = (int)(CLIP_DURATION(averageDuration) / CLIP_DURATION(fpsDenom / fpsNum) * 256);
+ * strength = m_cuTreeStrength = 5.0 * (1.0 - qCompress) (:989); weightDelta = 1 - weightedCostDelta[ref0Distance - 1] when that is
+ * positive, else 0. */
+void EXPORT(x265oracle_cutree_finish)(int n, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* propagateCost,
+                                      const double* qpAqOffset, int fpsFactorQ8, double weightDelta, double strength, double* qpCuTreeOffset)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const int intracost = (intraCost[i] * invQscale[i] + 128) >> 8;
+        if (!intracost) continue;
+        const int propagate = (propagateCost[i] * fpsFactorQ8 + 128) >> 8;
+        const double log2_ratio = log2((double)(intracost + propagate)) - log2((double)intracost) + weightDelta;
+        qpCuTreeOffset[i] = qpAqOffset[i] - strength * log2_ratio;
+    }
+}

@@ -556,6 +556,41 @@ def test_cutree_propagation_step_equals_reference_class(depth, width, height, bf
     assert (g0 != pr0).any() and (g0 == 65535).any() and (mv0 != 0).any()
 
 
+@pytest.mark.parametrize("width,height,avg,qcomp,dist,wdelta", [(256, 128, 1 / 30, 0.6, 0, 0.0), (416, 240, 1 / 24, 0.6, 1, 0.4), (256, 144, 0.2, 0.8, 2, 0.0),
+                                                              (640, 360, 1 / 60, 0.5, 1, 1.0)])
+def test_cutree_finish_equals_reference_class(width, height, avg, qcomp, dist, wdelta):
+    """Lookahead::cuTreeFinish (slicetype.cpp:2889-2937): the restatement AND the library's host-side entry x265hip_cutree_finish
+    against the real class on random per-block arrays (zero intra costs, saturated propagate costs, the weighted-cost delta)."""
+    import importlib
+    import oracle_api as O
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    lib = _ref(8)
+    if not hasattr(lib, "x265ref_cutree_finish"):
+        pytest.skip("oracle/_ref predates x265ref_cutree_finish")
+    rng = np.random.default_rng([17, width, height])
+    n = ((width // 2 + 7) >> 3) * ((height // 2 + 7) >> 3)
+    intra = rng.integers(0, 9000, size=n).astype(np.int32)
+    intra[rng.random(n) < 0.05] = 0
+    invq = rng.integers(64, 1024, size=n).astype(np.int32)
+    prop = rng.integers(0, 65536, size=n).astype(np.uint16)
+    prop[::5] = 65535
+    qpaq = rng.normal(0, 2, size=n)
+    preset = rng.normal(0, 1, size=n)
+    got = preset.copy()
+    lib.x265ref_cutree_finish.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                                                                                  ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
+    assert lib.x265ref_cutree_finish(width, height, intra.ctypes.data, invq.ctypes.data, prop.ctypes.data, qpaq.ctypes.data, 30, 1, avg, qcomp, dist, wdelta,
+                                     got.ctypes.data) == n
+    fps_q8 = int(clip_duration(avg) / clip_duration(1 / 30) * 256)
+    weight_delta = (1.0 - wdelta) if (dist and wdelta > 0) else 0.0
+    strength = 5.0 * (1.0 - qcomp)
+    exp = O.cutree_finish(8, intra, invq, prop, qpaq, fps_q8, weight_delta, strength, preset)
+    assert np.array_equal(exp, got), f"{np.count_nonzero(exp != got)} offsets differ from the real class"
+    mine = A.cutree_finish(intra, invq, prop, qpaq, fps_q8, weight_delta, strength, preset)
+    assert np.array_equal(mine, got), f"{np.count_nonzero(mine != got)} offsets of the library entry differ from the real class"
+    assert (got == preset).any() and (got != preset).any()
+
+
 def sao_case(depth, width, height, seed):
     """Source / deblocked-like pair and random per-CTU SAO parameters (all five types, off, merge-left runs)."""
     rng = np.random.default_rng([21, depth, width, seed])

@@ -658,3 +658,19 @@ extern "C" int x265hip_cutree_propagate(const x265hip_cutree_propagate_params* p
     X265HIP_TRY(hipFreeAsync(acc, s));
     return 0;
 }
+
+// ---- host side of the cuTree step (Lookahead::cuTreeFinish, slicetype.cpp:2889-2937)
+extern "C" int x265hip_cutree_finish(const x265hip_cutree_finish_params* p)
+{
+    if (!p || !p->intra_cost || !p->inv_qscale || !p->propagate_cost || !p->qp_aq_offset || !p->qp_cutree_offset) { set_error("cutree_finish: NULL operand"); return X265HIP_EINVAL; }
+    if (p->nblocks <= 0) { set_error("cutree_finish: nblocks %d", p->nblocks); return X265HIP_EINVAL; }
+    for (int i = 0; i < p->nblocks; i++)
+    {
+        const int intracost = (p->intra_cost[i] * p->inv_qscale[i] + 128) >> 8;
+        if (!intracost) continue;
+        const int propagate = (p->propagate_cost[i] * p->fps_factor_q8 + 128) >> 8;
+        const double log2_ratio = std::log2((double)(intracost + propagate)) - std::log2((double)intracost) + p->weight_delta;
+        p->qp_cutree_offset[i] = p->qp_aq_offset[i] - p->strength * log2_ratio;
+    }
+    return 0;
+}

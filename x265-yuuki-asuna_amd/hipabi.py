@@ -375,6 +375,29 @@ def cutree_propagate(width_in_cu, height_in_cu, propagate_in, intra_cost, lowres
     check(f(ctypes.byref(p), s), "x265hip_cutree_propagate")
 
 
+class CuTreeFinishParams(ctypes.Structure):
+    """x265hip_cutree_finish_params (include/x265hip.h)."""
+    _fields_ = [("nblocks", ctypes.c_int), ("intra_cost", ctypes.c_void_p), ("inv_qscale", ctypes.c_void_p), ("propagate_cost", ctypes.c_void_p),
+                ("qp_aq_offset", ctypes.c_void_p), ("fps_factor_q8", ctypes.c_int), ("weight_delta", ctypes.c_double), ("strength", ctypes.c_double),
+                ("qp_cutree_offset", ctypes.c_void_p)]
+
+
+def cutree_finish(intra_cost, inv_qscale, propagate_cost, qp_aq_offset, fps_factor_q8, weight_delta, strength, qp_cutree_offset):
+    """Host side of the cuTree step (x265hip_cutree_finish): numpy arrays; returns the updated copy of qp_cutree_offset."""
+    import numpy as np
+    ic, iq = np.ascontiguousarray(intra_cost, np.int32), np.ascontiguousarray(inv_qscale, np.int32)
+    pc, qa = np.ascontiguousarray(propagate_cost, np.uint16), np.ascontiguousarray(qp_aq_offset, np.float64)
+    out = np.ascontiguousarray(qp_cutree_offset, np.float64).copy()
+    p = CuTreeFinishParams()
+    p.nblocks, p.fps_factor_q8, p.weight_delta, p.strength = len(ic), int(fps_factor_q8), float(weight_delta), float(strength)
+    p.intra_cost, p.inv_qscale, p.propagate_cost, p.qp_aq_offset = ic.ctypes.data, iq.ctypes.data, pc.ctypes.data, qa.ctypes.data
+    p.qp_cutree_offset = out.ctypes.data
+    f = lib().x265hip_cutree_finish
+    f.argtypes = [ctypes.POINTER(CuTreeFinishParams)]
+    check(f(ctypes.byref(p)), "x265hip_cutree_finish")
+    return out
+
+
 class LowresWeightCostParams(ctypes.Structure):
     """x265hip_lowres_weight_cost_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("fenc", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),
