@@ -43,3 +43,46 @@ def test_product_never_references_oracle(repo_root):
     import subprocess
     deps = subprocess.run(["ldd", A.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in deps
+
+
+def test_ctypes_structures_match_the_c_header(repo_root, tmp_path):
+    """Every ctypes mirror in hipabi.py has the size and the field offsets of its struct in include/x265hip.h, as gcc lays it out:
+    a field added on one side only would silently shift everything behind it."""
+    import ctypes
+    import importlib
+    import subprocess
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    S = importlib.import_module("x265-yuuki-asuna_amd.stages")
+    pairs = {"x265hip_me_params": A.MEParams, "x265hip_subpel_params": A.SubpelParams, "x265hip_lowres_init_params": A.LowresInitParams,
+             "x265hip_lowres_intra_params": A.LowresIntraParams, "x265hip_lowres_cost_pair": A.LowresCostPair,
+             "x265hip_lowres_cost_params": A.LowresCostParams, "x265hip_me_search_job": A.MESearchJob, "x265hip_me_search_params": A.MESearchParams,
+             "x265hip_sea_integral_params": A.SeaIntegralParams, "x265hip_deblock_bs_params": A.DeblockBsParams,
+             "x265hip_deblock_chroma_params": A.DeblockChromaParams, "x265hip_deblock_params": A.DeblockParams,
+             "x265hip_aq_energy_params": A.AqEnergyParams, "x265hip_aq_offsets_params": A.AqOffsetsParams,
+             "x265hip_cutree_propagate_params": A.CuTreePropagateParams, "x265hip_cutree_finish_params": A.CuTreeFinishParams,
+             "x265hip_lowres_weight_cost_params": A.LowresWeightCostParams, "x265hip_lowres_weight_apply_params": A.LowresWeightApplyParams,
+             "x265hip_sao_stats_params": A.SaoStatsParams, "x265hip_sao_apply_params": A.SaoApplyParams, "x265hip_plane": A.Plane,
+             "x265hip_intra_recon_params": A.IntraReconParams}
+    for extra, cname in (("ReconParams", "x265hip_recon_params"), ("ReconBiParams", "x265hip_recon_bi_params")):
+        cls = getattr(A, extra, None) or getattr(S, extra, None)
+        if cls is not None and isinstance(cls, type) and issubclass(cls, ctypes.Structure):
+            pairs[cname] = cls
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "x265hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} . %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(repo_root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        cname, fname, val = line.split()
+        cls = pairs[cname]
+        expect = ctypes.sizeof(cls) if fname == "." else getattr(cls, fname).offset
+        assert int(val) == expect, f"{cname}.{fname}: C says {val}, ctypes says {expect}"
+        seen += 1
+    assert seen > 150
