@@ -435,6 +435,16 @@ typedef struct x265hip_cutree_finish_params
     double* qp_cutree_offset;                                                                                        /* HOST, in place */
 } x265hip_cutree_finish_params;
 int x265hip_cutree_finish(const x265hip_cutree_finish_params* p);
+/* x265hip_frame_cost_recalculate - HOST-side: Lookahead::frameCostRecalculate (slicetype.cpp:2941-3011; P pictures, quantisation groups
+ *   of 16 or more, hevcAq off) - the frame cost after cuTree changed the quantisers: every block's lowres cost (low 14 bits of
+ *   lowres_costs) scaled by x265_exp2fix8(qp_cutree_offset), summed per row into row_satds and over the interior blocks into *score. */
+typedef struct x265hip_frame_cost_recalculate_params
+{
+    int width_in_cu, height_in_cu;
+    const uint16_t* lowres_costs; const double* qp_cutree_offset;      /* HOST */
+    int32_t* row_satds; int64_t* score;                                /* HOST outputs */
+} x265hip_frame_cost_recalculate_params;
+int x265hip_frame_cost_recalculate(const x265hip_frame_cost_recalculate_params* p);
 typedef struct x265hip_lowres_weight_apply_params
 {
     int depth;

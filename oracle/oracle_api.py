@@ -158,6 +158,17 @@ def cutree_finish(depth, intra_cost, inv_qscale, propagate_cost, qp_aq_offset, f
     return out
 
 
+def frame_cost_recalculate(depth, width_in_cu, height_in_cu, lowres_costs, qp_cutree_offset, avx2=False):
+    """CPU restatement of Lookahead::frameCostRecalculate (P pictures).  Returns (score, row_satds)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_frame_cost_recalculate_d{depth}")
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lc, qp = np.ascontiguousarray(lowres_costs, np.uint16), np.ascontiguousarray(qp_cutree_offset, np.float64)
+    rows = np.zeros(height_in_cu, np.int32)
+    return int(fn(width_in_cu, height_in_cu, lc.ctypes.data, qp.ctypes.data, rows.ctypes.data)), rows
+
+
 def aq_frame(depth, y, stride, org, width, height, cb=None, cr=None, stride_c=0, org_c=0, qg_size=16, aq_mode=2, aq_strength=1.0, weightp=True,
              avx2=False):
     """CPU restatement of LookaheadTLD::calcAdaptiveQuantFrame.  y / cb / cr: padded planes (flat arrays, sample (0,0) at org / org_c).

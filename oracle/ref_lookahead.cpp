@@ -384,6 +384,7 @@ namespace { struct LookaheadProbe : public Lookahead
     LookaheadProbe(x265_param* p, ThreadPool* t) : Lookahead(p, t) {}
     using Lookahead::estimateCUPropagate;            /* protected in the class (slicetype.h:196) */
     using Lookahead::cuTreeFinish;
+    using Lookahead::frameCostRecalculate;
 }; }
 
 /* One cuTree propagation step with the REAL Lookahead::estimateCUPropagate (encoder/slicetype.cpp:2641-2753).  Three pictures:
@@ -516,6 +517,55 @@ int x265ref_cutree_finish(int width, int height, const int32_t* intraCost, const
         }
     }
     lr.destroy();
+    pic.destroy();
+    x265_param_free(param);
+    return rc ? rc : ncu;
+}
+
+
+/* The REAL Lookahead::frameCostRecalculate(frames, 0, 1, 1) (encoder/slicetype.cpp:2941-3011) for a P picture of a width x height
+ * source whose lowresCosts[1][0] and qpCuTreeOffset are supplied by the caller; rowSatds receives rowSatds[1][0].  Returns the score
+ * through *score. */
+int x265ref_frame_cost_recalculate(int width, int height, const uint16_t* lowresCosts, const double* qpCuTreeOffset, int32_t* rowSatds, int64_t* score)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width;
+    param->sourceHeight = height;
+    param->internalCsp = X265_CSP_I400;
+    param->maxCUSize = 64;
+    param->rc.aqMode = 2;
+    param->rc.hevcAq = 0;
+    param->rc.qgSize = 32;
+    param->bEnableHME = 0;
+    PicYuv pic;
+    pic.m_param = param;
+    if (!pic.create(param, true)) return -1;
+    Lowres lrs[2];
+    for (int i = 0; i < 2; i++)
+    {
+        memset((void*)&lrs[i], 0, sizeof(Lowres));
+        if (!lrs[i].create(param, &pic, 32)) return -2;
+    }
+    Lowres& fenc = lrs[1];
+    fenc.sliceType = X265_TYPE_P;
+    const int ncu = fenc.maxBlocksInRow * fenc.maxBlocksInCol;
+    int rc = 0;
+    {
+        LookaheadProbe la(param, NULL);
+        if (!la.create()) rc = -3;
+        else
+        {
+            for (int k = 0; k < ncu; k++) { fenc.lowresCosts[1][0][k] = lowresCosts[k]; fenc.qpCuTreeOffset[k] = qpCuTreeOffset[k]; }
+            Lowres* frames[2] = { &lrs[0], &lrs[1] };
+            *score = la.frameCostRecalculate(frames, 0, 1, 1);
+            for (int y = 0; y < fenc.maxBlocksInCol; y++) rowSatds[y] = fenc.rowSatds[1][0][y];
+            la.destroy();
+        }
+    }
+    for (int i = 0; i < 2; i++) lrs[i].destroy();
     pic.destroy();
     x265_param_free(param);
     return rc ? rc : ncu;

@@ -394,3 +394,25 @@ void EXPORT(x265oracle_cutree_finish)(int n, const int32_t* intraCost, const int
         qpCuTreeOffset[i] = qpAqOffset[i] - strength * log2_ratio;
     }
 }
+
+/* Lookahead::frameCostRecalculate (slicetype.cpp:2941-3011; P pictures, quantisation groups of 16 or more, hevcAq off): the frame
+ * cost after cuTree changed the quantisers - every block's lowres cost scaled by x265_exp2fix8(qpCuTreeOffset), summed per row into
+ * rowSatds and over the interior blocks (all blocks when the picture is at most two blocks wide or high) into the returned score. */
+int64_t EXPORT(x265oracle_frame_cost_recalculate)(int widthInCU, int heightInCU, const uint16_t* lowresCosts, const double* qpCuTreeOffset,
+                                                  int32_t* rowSatds)
+{
+    int64_t score = 0;
+    for (int cuy = heightInCU - 1; cuy >= 0; cuy--)
+    {
+        rowSatds[cuy] = 0;
+        for (int cux = widthInCU - 1; cux >= 0; cux--)
+        {
+            const int cuxy = cux + cuy * widthInCU;
+            int cuCost = lowresCosts[cuxy] & LOWRES_COST_MASK;
+            cuCost = (cuCost * exp2fix8(qpCuTreeOffset[cuxy]) + 128) >> 8;
+            rowSatds[cuy] += cuCost;
+            if ((cuy > 0 && cuy < heightInCU - 1 && cux > 0 && cux < widthInCU - 1) || widthInCU <= 2 || heightInCU <= 2) score += cuCost;
+        }
+    }
+    return score;
+}

@@ -591,6 +591,31 @@ def test_cutree_finish_equals_reference_class(width, height, avg, qcomp, dist, w
     assert (got == preset).any() and (got != preset).any()
 
 
+@pytest.mark.parametrize("width,height", [(256, 128), (416, 240), (48, 32), (32, 160), (1280, 720)])
+def test_frame_cost_recalculate_equals_reference_class(width, height):
+    """Lookahead::frameCostRecalculate (slicetype.cpp:2941-3011, P pictures): the restatement and the library's host-side entry
+    against the real class (row sums, interior-only score, the at-most-two-blocks rule, x265_exp2fix8's clamps)."""
+    import importlib
+    import oracle_api as O
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    lib = _ref(8)
+    if not hasattr(lib, "x265ref_frame_cost_recalculate"):
+        pytest.skip("oracle/_ref predates x265ref_frame_cost_recalculate")
+    rng = np.random.default_rng([19, width, height])
+    wcu, hcu = (width // 2 + 7) >> 3, (height // 2 + 7) >> 3
+    n = wcu * hcu
+    lc = (rng.integers(0, 16384, size=n) | (rng.integers(0, 4, size=n) << 14)).astype(np.uint16)
+    qp = rng.normal(0, 3, size=n)
+    qp[::11] = 60.0; qp[5::13] = -60.0                                # beyond both clamps of x265_exp2fix8
+    rrows, rscore = np.zeros(hcu, np.int32), np.zeros(1, np.int64)
+    lib.x265ref_frame_cost_recalculate.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4
+    assert lib.x265ref_frame_cost_recalculate(width, height, lc.ctypes.data, qp.ctypes.data, rrows.ctypes.data, rscore.ctypes.data) == n
+    score, rows = O.frame_cost_recalculate(8, wcu, hcu, lc, qp)
+    assert score == int(rscore[0]) and np.array_equal(rows, rrows)
+    score2, rows2 = A.frame_cost_recalculate(wcu, hcu, lc, qp)
+    assert score2 == int(rscore[0]) and np.array_equal(rows2, rrows)
+
+
 def sao_case(depth, width, height, seed):
     """Source / deblocked-like pair and random per-CTU SAO parameters (all five types, off, merge-left runs)."""
     rng = np.random.default_rng([21, depth, width, seed])

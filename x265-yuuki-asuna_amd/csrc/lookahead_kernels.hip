@@ -674,3 +674,25 @@ extern "C" int x265hip_cutree_finish(const x265hip_cutree_finish_params* p)
     }
     return 0;
 }
+
+extern "C" int x265hip_frame_cost_recalculate(const x265hip_frame_cost_recalculate_params* p)
+{
+    if (!p || !p->lowres_costs || !p->qp_cutree_offset || !p->row_satds || !p->score) { set_error("frame_cost_recalculate: NULL operand"); return X265HIP_EINVAL; }
+    if (p->width_in_cu <= 0 || p->height_in_cu <= 0) { set_error("frame_cost_recalculate: empty picture"); return X265HIP_EINVAL; }
+    const int w = p->width_in_cu, h = p->height_in_cu;
+    int64_t score = 0;
+    for (int cuy = h - 1; cuy >= 0; cuy--)
+    {
+        int row = 0;
+        for (int cux = w - 1; cux >= 0; cux--)
+        {
+            const int cuxy = cux + cuy * w;
+            const int cuCost = ((p->lowres_costs[cuxy] & 0x3fff) * aq_exp2fix8(p->qp_cutree_offset[cuxy]) + 128) >> 8;
+            row += cuCost;
+            if ((cuy > 0 && cuy < h - 1 && cux > 0 && cux < w - 1) || w <= 2 || h <= 2) score += cuCost;
+        }
+        p->row_satds[cuy] = row;
+    }
+    *p->score = score;
+    return 0;
+}

@@ -398,6 +398,26 @@ def cutree_finish(intra_cost, inv_qscale, propagate_cost, qp_aq_offset, fps_fact
     return out
 
 
+class FrameCostRecalculateParams(ctypes.Structure):
+    """x265hip_frame_cost_recalculate_params (include/x265hip.h)."""
+    _fields_ = [("width_in_cu", ctypes.c_int), ("height_in_cu", ctypes.c_int), ("lowres_costs", ctypes.c_void_p), ("qp_cutree_offset", ctypes.c_void_p),
+                ("row_satds", ctypes.c_void_p), ("score", ctypes.c_void_p)]
+
+
+def frame_cost_recalculate(width_in_cu, height_in_cu, lowres_costs, qp_cutree_offset):
+    """Host side (x265hip_frame_cost_recalculate): numpy arrays in; returns (score, row_satds int32 [height_in_cu])."""
+    import numpy as np
+    lc, qp = np.ascontiguousarray(lowres_costs, np.uint16), np.ascontiguousarray(qp_cutree_offset, np.float64)
+    rows, score = np.zeros(height_in_cu, np.int32), np.zeros(1, np.int64)
+    p = FrameCostRecalculateParams()
+    p.width_in_cu, p.height_in_cu = width_in_cu, height_in_cu
+    p.lowres_costs, p.qp_cutree_offset, p.row_satds, p.score = lc.ctypes.data, qp.ctypes.data, rows.ctypes.data, score.ctypes.data
+    f = lib().x265hip_frame_cost_recalculate
+    f.argtypes = [ctypes.POINTER(FrameCostRecalculateParams)]
+    check(f(ctypes.byref(p)), "x265hip_frame_cost_recalculate")
+    return int(score[0]), rows
+
+
 class LowresWeightCostParams(ctypes.Structure):
     """x265hip_lowres_weight_cost_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("fenc", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),
