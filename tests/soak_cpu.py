@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""[test infrastructure; not collected by pytest - run by hand where /root/reference has been built into oracle/_ref]
+
+Randomised CPU soak of the newest oracle restatements against the REAL reference classes: the pin tests of
+tests/test_oracle_classes_vs_reference.py with fresh seeds / parameters for a time budget.
+Usage:  python tests/soak_cpu.py [seconds [master seed]]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import test_oracle_classes_vs_reference as T
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+master = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260927)
+
+
+def s_sea(r): T.test_sea_search_restatement_equals_reference_motion_estimate(int(r.choice([8, 10])), seed=int(r.integers(1, 1 << 30)))
+def s_cutree(r):
+    b = bool(r.integers(0, 2))
+    T.test_cutree_propagation_step_equals_reference_class(int(r.choice([8, 10])), int(r.choice([192, 256, 320])), int(r.choice([128, 192])), b, bool(r.integers(0, 2)),
+                                                          int(r.integers(0, 2)), float(r.choice([1 / 60, 1 / 30, 1 / 24, 0.2])), seed=int(r.integers(1, 1 << 30)))
+def s_weights(r):
+    T.test_weighted_reference_analysis_equals_reference_class(int(r.choice([8, 10])), int(r.choice([192, 256])), int(r.choice([128, 144])),
+                                                              float(r.choice([0.3, 0.6, 0.8, 0.95, 1.1, 1.4])), int(r.integers(-40, 60)),
+                                                              seed=int(r.integers(1, 1 << 30)), check_expectation=False)
+def s_aq(r):
+    qg = int(r.choice([16, 8]))
+    T.test_adaptive_quant_pass_equals_reference_class(int(r.choice([8, 10])), int(r.choice([192, 256, 320])), int(r.choice([128, 176])), qg, int(r.integers(1, 4)),
+                                                      float(r.choice([0.5, 1.0, 1.7])), bool(r.integers(0, 2)), seed=int(r.integers(1, 1 << 30)))
+def s_bs(r):
+    T.test_deblock_b_picture_boundary_strengths_equal_reference_class(int(r.choice([8, 10])), int(r.integers(0, 3)), int(r.integers(0, 2)), int(r.integers(26, 40)),
+                                                                      seed=int(r.integers(1, 1 << 30)), check_coverage=False)
+
+stages = [("SEA search", s_sea), ("cuTree step", s_cutree), ("weight analysis", s_weights), ("adaptive quantisation", s_aq), ("boundary strengths (B)", s_bs)]
+counts = {n: 0 for n, _ in stages}
+t0, fail = time.time(), 0
+while time.time() - t0 < budget and not fail:
+    for name, fn in stages:
+        seed = int(master.integers(1, 1 << 31))
+        try:
+            fn(np.random.default_rng(seed))
+            counts[name] += 1
+        except AssertionError as e:
+            print(f"MISMATCH in {name} (case seed {seed}): {str(e)[:400]}", flush=True)
+            fail = 1
+            break
+for n, c in counts.items():
+    print(f"{n}: {c} randomised cases matched the real reference class")
+print(f"cpu soak {'FAILED' if fail else 'ok'} after {time.time() - t0:.0f} s")
+sys.exit(fail)

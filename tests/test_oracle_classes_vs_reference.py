@@ -137,7 +137,7 @@ SEA_UNSUPPORTED = {(8, 4), (4, 8), (32, 8), (8, 32)}      # their DC terms read 
 
 
 @pytest.mark.parametrize("depth", [8, 10])
-def test_sea_search_restatement_equals_reference_motion_estimate(depth):
+def test_sea_search_restatement_equals_reference_motion_estimate(depth, seed=37):
     """X265_SEA (motion.cpp:1241-1395): the restatement takes its block sums straight from the reference samples; the real class
     gets the twelve integral planes built by the library's own integral_init primitives the way FrameFilter does.  Every
     supported PU size (the ADS variant, plane and offsets differ per size - including the sizes whose plane does not match
@@ -151,11 +151,11 @@ def test_sea_search_restatement_equals_reference_motion_estimate(depth):
     f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + \
                  [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     width, height = 256, 192
-    clip = F.synth_clip(width, height, 2, depth=depth, seed=37)
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=seed)
     cur, stride, org, w64, h64 = F.pad_plane(clip[1][0])
     ref = F.pad_plane(clip[0][0])[0]
     es = cur.itemsize
-    rng = np.random.default_rng([11, depth])
+    rng = np.random.default_rng([11, depth, seed])
     qp = 24 if depth == 8 else 12
     cq, qoff = F.qpel_cost_table(57, qmax=8 * 64 + 300)
     seen, moved = set(), 0
@@ -333,7 +333,7 @@ def lowres_stats(plane, rows, stride, lorg, lw, lh):
 
 @pytest.mark.parametrize("depth,width,height,gain,lift", [(8, 256, 128, 0.75, 6), (8, 208, 144, 1.0, 0), (8, 256, 128, 1.3, -20), (8, 192, 128, 0.5, 40),
                                                         (8, 256, 144, 1.0, 9), (10, 192, 128, 0.8, 12), (10, 256, 128, 1.15, -6), (8, 192, 128, 0.25, 150)])
-def test_weighted_reference_analysis_equals_reference_class(depth, width, height, gain, lift):
+def test_weighted_reference_analysis_equals_reference_class(depth, width, height, gain, lift, seed=93, check_expectation=True):
     """LookaheadTLD::weightsAnalyse + weightCostLuma (slicetype.cpp:807-957) - the float guess (scale from the variance ratio, offset
     from the means), the two scored candidates, the denominator reduction, the 0.998 acceptance test and the weighting of the four
     lowres planes - restatement against the real class on fades of different strength (accepted, rejected, early exit, clamped
@@ -342,7 +342,7 @@ def test_weighted_reference_analysis_equals_reference_class(depth, width, height
     lib = _ref(depth)
     if not hasattr(lib, "x265ref_weights_analyse"):
         pytest.skip("oracle/_ref predates x265ref_weights_analyse")
-    y0, y1 = fade_pair(depth, width, height, gain, lift, seed=93)
+    y0, y1 = fade_pair(depth, width, height, gain, lift, seed=seed)
     cur, stride, org, w64, h64 = F.pad_plane(y1)
     ref = F.pad_plane(y0)[0]
     wcu, hcu = (width // 2 + 7) >> 3, (height // 2 + 7) >> 3
@@ -367,7 +367,7 @@ def test_weighted_reference_analysis_equals_reference_class(depth, width, height
     weight, minscore, origscore = O.weights_analyse(depth, cplanes[0], rplanes[0], rstride, lorg, lw, lh, icost, ssd, sm)
     assert (weight is not None) == bool(out[0]), f"weighted: restatement {weight} (scores {minscore} / {origscore}), reference {out[0]}"
     expect_weighted = not (gain == 1.0 and abs(lift) < 1)
-    assert (weight is not None) == expect_weighted
+    assert not check_expectation or (weight is not None) == expect_weighted
     if weight is not None:
         assert minscore < origscore
         for i in range(4):
@@ -422,7 +422,7 @@ def test_weighted_p_frame_cost_equals_reference_classes(depth, width, height, ga
 @pytest.mark.parametrize("depth,width,height,qg,mode,strength,chroma", [(8, 256, 128, 16, 2, 1.0, True), (8, 256, 128, 16, 1, 1.0, True), (8, 208, 144, 16, 3, 0.8, True),
                                                                     (8, 256, 128, 8, 2, 1.0, True), (8, 192, 128, 8, 1, 1.5, True), (8, 250, 138, 16, 2, 1.0, False),
                                                                     (10, 192, 128, 16, 2, 1.0, True), (10, 192, 128, 16, 1, 0.6, False), (8, 256, 128, 16, 0, 1.0, True)])
-def test_adaptive_quant_pass_equals_reference_class(depth, width, height, qg, mode, strength, chroma):
+def test_adaptive_quant_pass_equals_reference_class(depth, width, height, qg, mode, strength, chroma, seed=99):
     """LookaheadTLD::calcAdaptiveQuantFrame (slicetype.cpp:439-694): block energies through cu[].var (luma + 4:2:0 chroma), the
     double-precision QP offsets of AQ modes 1-3, invQscaleFactor through x265_exp2fix8, and the wp_sum / wp_ssd statistics the
     weight analysis reads - restatement against the real class."""
@@ -430,7 +430,7 @@ def test_adaptive_quant_pass_equals_reference_class(depth, width, height, qg, mo
     lib = _ref(depth)
     if not hasattr(lib, "x265ref_aq_frame"):
         pytest.skip("oracle/_ref predates x265ref_aq_frame")
-    clip = F.synth_clip(width, height, 1, depth=depth, seed=99)
+    clip = F.synth_clip(width, height, 1, depth=depth, seed=seed)
     yimg, cbimg, crimg = clip[0]
     yp, stride, org, w64, h64 = F.pad_plane(yimg)
     cpad = [pad_any(np.ascontiguousarray(c), margin=16) for c in (cbimg, crimg)] if chroma else None
@@ -511,7 +511,7 @@ def clip_duration(f):
 @pytest.mark.parametrize("depth,width,height,bframe,referenced,wbp,avg", [(8, 256, 128, False, True, 0, 1 / 30), (8, 256, 128, True, True, 0, 1 / 24),
                                                                          (8, 208, 144, True, False, 1, 1 / 30), (10, 192, 128, True, True, 1, 1 / 60),
                                                                          (8, 320, 192, False, False, 0, 0.5)])
-def test_cutree_propagation_step_equals_reference_class(depth, width, height, bframe, referenced, wbp, avg):
+def test_cutree_propagation_step_equals_reference_class(depth, width, height, bframe, referenced, wbp, avg, seed=105):
     """Lookahead::estimateCUPropagate + primitives.propagateCost (slicetype.cpp:2641-2753, pixel.cpp:914-940): the real class runs on
     the motion vectors / costs its own singleCost produced; the restatement gets those same inputs and must leave the same
     propagateCost in the references (bilinear split over four blocks, picture-border drops, bi-prediction weights, saturation)."""
@@ -519,8 +519,8 @@ def test_cutree_propagation_step_equals_reference_class(depth, width, height, bf
     lib = _ref(depth)
     if not hasattr(lib, "x265ref_cutree_propagate"):
         pytest.skip("oracle/_ref predates x265ref_cutree_propagate")
-    clip = F.synth_clip(width, height, 3, depth=depth, seed=105)
-    rng = np.random.default_rng([15, depth, width, int(bframe)])
+    clip = F.synth_clip(width, height, 3, depth=depth, seed=seed)
+    rng = np.random.default_rng([15, depth, width, int(bframe), seed])
     y0, y2 = clip[0][0], clip[2][0]
     y1 = np.roll(y0, (5, -9), axis=(0, 1)).copy()
     y1[: height // 3] = np.roll(y2, (-7, 12), axis=(0, 1))[: height // 3]
@@ -782,7 +782,7 @@ def motion_field_case(depth, level, seed, qp):
 
 
 @pytest.mark.parametrize("depth,level,slice_b,qp", [(8, 0, 1, 30), (8, 1, 1, 34), (8, 2, 1, 28), (8, 0, 0, 32), (8, 1, 0, 30), (10, 0, 1, 33), (10, 1, 0, 36)])
-def test_deblock_b_picture_boundary_strengths_equal_reference_class(depth, level, slice_b, qp):
+def test_deblock_b_picture_boundary_strengths_equal_reference_class(depth, level, slice_b, qp, seed=None, check_coverage=True):
     """getBoundaryStrength in full (deblock.cpp:217-247): several reference pictures per list and the B-picture four-way comparison
     of (ref0, ref1) x (mv0, mv1) - the restatement's Bs maps + luma filter against the real Deblock::deblockCTU with B_SLICE /
     P_SLICE, distinct Frame objects per picture id, m_refIdx / m_mv of both lists filled."""
@@ -790,12 +790,12 @@ def test_deblock_b_picture_boundary_strengths_equal_reference_class(depth, level
     lib = _ref(depth)
     if not hasattr(lib, "x265ref_deblock_b"):
         pytest.skip("oracle/_ref predates x265ref_deblock_b")
-    rec, stride, org, w64, h64, mv0, mv1, ref0, ref1, ns, intra = motion_field_case(depth, level, 81 + level, qp)
+    rec, stride, org, w64, h64, mv0, mv1, ref0, ref1, ns, intra = motion_field_case(depth, level, 81 + level if seed is None else seed, qp)
     if not slice_b:
         ref0 = np.maximum(ref0, 0)                      # P pictures: every inter block uses list 0
     bv, bh = O.deblock_bs_b(depth, w64, h64, level, mv0, mv1, ref0, ref1, ns, slice_b=slice_b, intra=intra)
     both = np.concatenate([bv, bh])
-    assert (both == 0).any() and (both == 1).any() and (both == 2).any()
+    assert not check_coverage or ((both == 0).any() and (both == 1).any() and (both == 2).any())
     exp = O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, qp)
     got = np.ascontiguousarray(rec.reshape(-1)).copy()
     lib.x265ref_deblock_b.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3
@@ -804,7 +804,7 @@ def test_deblock_b_picture_boundary_strengths_equal_reference_class(depth, level
     assert np.array_equal(got, exp.reshape(-1)), f"{np.count_nonzero(got != exp.reshape(-1))} samples differ"
     # the motion comparison matters: the P-only single-reference rule gives different maps on this field
     pv, ph = O.deblock_bs_inter(depth, w64, h64, level, mv0, ns, intra=intra)
-    assert not (np.array_equal(pv, bv) and np.array_equal(ph, bh))
+    assert not check_coverage or not (np.array_equal(pv, bv) and np.array_equal(ph, bh))
 
 
 @pytest.mark.parametrize("chroma", [False, True])
