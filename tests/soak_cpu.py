@@ -31,7 +31,13 @@ def s_bs(r):
     T.test_deblock_b_picture_boundary_strengths_equal_reference_class(int(r.choice([8, 10])), int(r.integers(0, 3)), int(r.integers(0, 2)), int(r.integers(26, 40)),
                                                                       seed=int(r.integers(1, 1 << 30)), check_coverage=False)
 
-stages = [("SEA search", s_sea), ("cuTree step", s_cutree), ("weight analysis", s_weights), ("adaptive quantisation", s_aq), ("boundary strengths (B)", s_bs)]
+def s_search(r):
+    T.test_search_driver_restatement_equals_reference_motion_estimate(int(r.choice([8, 10])), str(r.choice(["dia", "hex", "umh", "star"])), seed=int(r.integers(1, 1 << 30)))
+def s_lowres(r):
+    fn = T.test_lowres_b_frame_cost_restatement_equals_reference_classes if r.integers(0, 2) else T.test_lowres_frame_cost_restatement_equals_reference_classes
+    fn(int(r.choice([8, 10])), int(r.choice([192, 208, 256])), int(r.choice([128, 144])), seed=int(r.integers(1, 1 << 30)), check_coverage=False)
+
+stages = [("search drivers (DIA / HEX / UMH / STAR)", s_search), ("lookahead frame cost (P / B)", s_lowres), ("SEA search", s_sea), ("cuTree step", s_cutree), ("weight analysis", s_weights), ("adaptive quantisation", s_aq), ("boundary strengths (B)", s_bs)]
 counts = {n: 0 for n, _ in stages}
 t0, fail = time.time(), 0
 while time.time() - t0 < budget and not fail:

@@ -95,7 +95,7 @@ def copy_jobs(jobs):
 
 @pytest.mark.parametrize("depth", [8, 10])
 @pytest.mark.parametrize("method", ["dia", "hex", "umh", "star", "full"])
-def test_search_driver_restatement_equals_reference_motion_estimate(depth, method):
+def test_search_driver_restatement_equals_reference_motion_estimate(depth, method, seed=31):
     """oracle/x265_oracle_search.c (predictor start, DIA / HEX / STAR / FULL patterns, predictor-vs-search choice, sub-pel
     refinement) against the real MotionEstimate::motionEstimate: random PU sizes (all 24 inter partitions), positions,
     quarter-pel predictors, search bounds, merange and every sub-pel level."""
@@ -105,11 +105,11 @@ def test_search_driver_restatement_equals_reference_motion_estimate(depth, metho
     f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + \
                  [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     width, height = 256, 192
-    clip = F.synth_clip(width, height, 2, depth=depth, seed=31)
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=seed)
     cur, stride, org, _, _ = F.pad_plane(clip[1][0])
     ref = F.pad_plane(clip[0][0])[0]
     es = cur.itemsize
-    rng = np.random.default_rng([7, depth, METHODS[method]])
+    rng = np.random.default_rng([7, depth, METHODS[method], seed])
     qp = 24 if depth == 8 else 12
     total = 0
     for subme in range(8):
@@ -222,7 +222,7 @@ def test_lookahead_restatement_equals_reference_classes(depth, width, height):
 
 
 @pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 208, 144), (10, 192, 128)])
-def test_lowres_frame_cost_restatement_equals_reference_classes(depth, width, height):
+def test_lowres_frame_cost_restatement_equals_reference_classes(depth, width, height, seed=91, check_coverage=True):
     """oracle/x265_oracle_search.c::x265oracle_lowres_cost against the real CostEstimateGroup::singleCost(0, 1, 1)
     (oracle/ref_lookahead.cpp): the lookahead's P-frame cost estimate - neighbour-mv predictors, HEX search on the four
     half-pel phase planes, intra competition - mv, mv cost and lowresCosts of every 8x8 block, rowSatds, costEst, intraMbs."""
@@ -230,8 +230,8 @@ def test_lowres_frame_cost_restatement_equals_reference_classes(depth, width, he
     lib = _ref(depth)
     if not hasattr(lib, "x265ref_lowres_cost"):
         pytest.skip("oracle/_ref predates x265ref_lowres_cost")
-    clip = F.synth_clip(width, height, 2, depth=depth, seed=91)
-    rng = np.random.default_rng([13, depth, width])
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=seed)
+    rng = np.random.default_rng([13, depth, width, seed])
     y0 = clip[0][0]
     # the current picture: the reference shifted by a global motion plus local differences, so that mvs, intra wins and
     # zero-residual blocks all occur
@@ -262,19 +262,19 @@ def test_lowres_frame_cost_restatement_equals_reference_classes(depth, width, he
     assert np.array_equal(mvs, rmv), f"mvs differ at {np.flatnonzero((mvs != rmv).any(axis=1))[:8]}"
     assert np.array_equal(mvc, rmc) and np.array_equal(lc, rlc) and np.array_equal(rws, rrows)
     assert (frame[0], frame[1], frame[2]) == (rframe[1], rframe[2], rframe[3]) and rframe[0] == rframe[1]
-    assert (mvs != 0).any() and ((lc >> 14) == 0).any() and ((lc >> 14) == 1).any()
+    assert not check_coverage or ((mvs != 0).any() and ((lc >> 14) == 0).any() and ((lc >> 14) == 1).any())
 
 
 @pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 208, 144), (10, 192, 128)])
-def test_lowres_b_frame_cost_restatement_equals_reference_classes(depth, width, height):
+def test_lowres_b_frame_cost_restatement_equals_reference_classes(depth, width, height, seed=92, check_coverage=True):
     """The B-picture flavour (two lists, skip shortcut, the two bi-directional candidates, the 100 / (130 + bias) score scaling)
     against the real CostEstimateGroup::singleCost(0, 2, 1)."""
     import oracle_api as O
     lib = _ref(depth)
     if not hasattr(lib, "x265ref_lowres_cost_b"):
         pytest.skip("oracle/_ref predates x265ref_lowres_cost_b")
-    clip = F.synth_clip(width, height, 3, depth=depth, seed=92)
-    rng = np.random.default_rng([14, depth, width])
+    clip = F.synth_clip(width, height, 3, depth=depth, seed=seed)
+    rng = np.random.default_rng([14, depth, width, seed])
     y0, y2 = clip[0][0], clip[2][0]
     y1 = np.roll(y0, (2, -3), axis=(0, 1)).copy()
     y1[: height // 3] = np.roll(y2, (-1, 2), axis=(0, 1))[: height // 3]
@@ -309,7 +309,7 @@ def test_lowres_b_frame_cost_restatement_equals_reference_classes(depth, width, 
     assert np.array_equal(lc, rlc) and np.array_equal(rws, rrows)
     assert frame[3] == rframe[0] == rframe[1] and frame[1] == rframe[2] and rframe[3] == 0
     used = lc >> 14
-    assert (used == 1).any() and (used == 2).any() and (used == 3).any()
+    assert not check_coverage or ((used == 1).any() and (used == 2).any() and (used == 3).any())
 
 
 def fade_pair(depth, width, height, gain, lift, seed):
