@@ -41,7 +41,7 @@ extern "C" {
 const char* x265hip_version(void);
 const char* x265hip_last_error(void);          /* thread-local text of the last failure */
 int         x265hip_device_count(void);
-int         x265hip_init(int device);          /* select device, create per-process state */
+int         x265hip_init(int device);          /* device >= 0: validate (gfx950) and hipSetDevice() it for the calling thread; -1: validate the thread's current device and keep it */
 
 /* ------------------------------------------------------------------ 1. table layer */
 /* Overwrite the GPU-backed slots of an EncoderPrimitives-layout table (18240 bytes, see

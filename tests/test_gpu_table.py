@@ -48,3 +48,34 @@ def test_table_rejects_bad_arguments():
     assert L.x265hip_setup_primitives(ctypes.byref(mem), 100, 8) < 0
     assert L.x265hip_setup_primitives(ctypes.byref(mem), spec.TABLE_BYTES, 9) < 0
     assert L.x265hip_setup_primitives(None, spec.TABLE_BYTES, 8) < 0
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_whole_plane_weight_pp_on_a_fresh_thread(depth, repo_root):
+    """The reference calls weight_pp on whole lowres planes (slicetype.cpp:821,956: stride x paddedLines,
+    ~680 KB at 1080p, ~2.4 MB at 4K).  A fresh host thread starts with 1 MiB of staging, so the output
+    allocation regrows (moves) the staging buffers after the job record was packed: the record's device
+    address must be resolved after the last allocation (round-1 advisor finding)."""
+    import threading
+    import numpy as np
+    orc = H.load_oracle(depth, repo_root)
+    hip, _ = load_hip_table(depth)
+    rng = np.random.default_rng(77 + depth)
+    w, h, st = 1088, 700, 1120                      # 784 000 samples: > 512 KiB in, > 1 MiB with the output
+    src = H.pixels(rng, "random", depth, w, h, st)
+    corr = 14 - depth
+    args = (37, (1 << (corr + 5)) & ~((1 << corr) - 1), corr + 6, -9)
+    outs, errs = [], []
+
+    def work(tab):
+        try:
+            d = H.out2d(w, h, st, H.pix_dtype(depth), 0x33)
+            tab.fn("weight_pp")(src.p, d.p, st, w, h, *args)
+            outs.append(d.data)
+        except Exception as e:              # pragma: no cover
+            errs.append(e)
+    for tab in (orc, hip):
+        t = threading.Thread(target=work, args=(tab,))
+        t.start(); t.join()
+    assert not errs and len(outs) == 2
+    assert np.array_equal(outs[0], outs[1])

@@ -23,7 +23,7 @@ template <> struct PxInfo<uint16_t> { static constexpr int BPP = 2; static const
 // ---------------------------------------------------------------- host-side error plumbing
 void set_error(const char* fmt, ...);
 int  check_hip(hipError_t e, const char* what);   // 0 or X265HIP_ENODEV with last-error text
-int  ensure_device();                             // lazy x265hip_init(0)
+int  ensure_device();                             // lazy x265hip_init(-1): validates the calling thread's current device
 
 #define X265HIP_TRY(expr) do { int _rc = ::x265hip::check_hip((expr), #expr); if (_rc) return _rc; } while (0)
 

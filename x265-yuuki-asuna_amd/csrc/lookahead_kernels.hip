@@ -568,11 +568,15 @@ extern "C" int x265hip_aq_energy(const x265hip_aq_energy_params* p, void* stream
 
 // ---- host side of the adaptive-quantisation pass (slicetype.cpp:508-632, common.cpp:96-103)
 #include <cmath>
+struct AqExp2Lut
+{
+    uint8_t v[64];
+    AqExp2Lut() { for (int i = 0; i < 64; i++) v[i] = (uint8_t)((std::pow(2.0, i / 64.0) - 1.0) * 256.0 + 0.5); }   // x265_exp2_lut
+};
 static int aq_exp2fix8(double x)
 {
-    static uint8_t lut[64];
-    static bool ready = false;
-    if (!ready) { for (int i = 0; i < 64; i++) lut[i] = (uint8_t)((std::pow(2.0, i / 64.0) - 1.0) * 256.0 + 0.5); ready = true; }   // x265_exp2_lut
+    static const AqExp2Lut table;          // C++11 magic static: initialised once, thread-safe (lookahead workers call concurrently)
+    const uint8_t* lut = table.v;
     const int i = (int)(x * (-64.f / 6.f) + 512.5f);
     if (i < 0) return 0;
     if (i > 1023) return 0xffff;

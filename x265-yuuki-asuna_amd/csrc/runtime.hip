@@ -43,7 +43,13 @@ static void do_init(int device)
         g_initRc = X265HIP_ENODEV;
         return;
     }
-    if (device < 0 || device >= n)
+    if (device >= n)
+    {
+        set_error("x265hip_init: device %d requested, %d present", device, n);
+        g_initRc = X265HIP_EINVAL;
+        return;
+    }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess)      // lazy init: validate the calling thread's current device
         device = 0;
     hipDeviceProp_t prop;
     if (check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) { g_initRc = X265HIP_ENODEV; return; }
@@ -92,8 +98,24 @@ int x265hip_init(int device)
     std::call_once(g_initOnce, do_init, device);
     if (g_initRc)
         return g_initRc;
-    /* a host process that already picked a device through another runtime user (torch) keeps it:
-     * we launch on whatever device is current for the calling thread */
+    /* device >= 0: make it the calling thread's current device (every launch, hipMallocAsync and staging
+     * buffer of this library goes to the current device of the thread that calls in); device < 0: keep
+     * whatever the host process selected (e.g. torch.cuda.set_device) - it was validated as gfx950 above.
+     * A second init that names ANOTHER device is honoured per thread after the same arch check. */
+    if (device >= 0)
+    {
+        if (device != g_device)
+        {
+            hipDeviceProp_t prop;
+            if (check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) return X265HIP_ENODEV;
+            if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            {
+                set_error("device %d is %s; this library only carries gfx950 (MI355X) code objects", device, prop.gcnArchName);
+                return X265HIP_ENODEV;
+            }
+        }
+        if (check_hip(hipSetDevice(device), "hipSetDevice")) return X265HIP_ENODEV;
+    }
     return 0;
 }
 

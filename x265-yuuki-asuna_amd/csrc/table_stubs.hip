@@ -24,11 +24,18 @@ typedef x265hip_sse_t sse_t;
 constexpr int D = X265HIP_DEPTH;
 constexpr int ES = sizeof(pixel);
 
-// upload a single job record (after all other inputs) and return its device pointer
-static const x265hip_job* put_job(ThreadStage& st, const x265hip_job& jb)
+// pack a single job record and return a reference that resolves to its DEVICE pointer only when it is
+// handed to the launch: a later st.alloc() may regrow (and move) the staging buffers, so no device
+// address may be taken before the last alloc of a call.
+struct JobRef
 {
-    const size_t o = st.in1d(&jb, sizeof(jb));
-    return st.dptr<const x265hip_job>(o);
+    const ThreadStage* st; size_t off;
+    operator const x265hip_job*() const { return st->dptr<const x265hip_job>(off); }
+};
+static JobRef put_job(ThreadStage& st, const x265hip_job& jb)
+{
+    const JobRef r = { &st, st.in1d(&jb, sizeof(jb)) };
+    return r;
 }
 static x265hip_plane plane(ThreadStage& st, size_t off, intptr_t stride) { x265hip_plane p = { st.dptr<void>(off), stride }; return p; }
 
@@ -92,7 +99,7 @@ static void ip_core(const S* src, intptr_t ss, Dt* dst, intptr_t ds, int a0, int
     const size_t oa = st.in2d(src - (intptr_t)ay * ss - ax, ss, tw, th, sizeof(S));
     x265hip_job jb = {};
     jb.off[0] = (int64_t)ay * tw + ax; jb.arg[0] = a0; jb.arg[1] = a1;
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t od = st.alloc((size_t)W * oh * sizeof(Dt));
     st.upload();
     st.require(x265hip_interp_batch(KIND, D, N, W, H, plane(st, oa, tw), plane(st, od, W), dj, 1, st.stream), "interp");
@@ -115,7 +122,7 @@ template <int KIND, int N> static void fwd_tr_stub(const int16_t* src, int16_t* 
     st.begin();
     const size_t oa = st.in2d(src, srcStride, N, N, 2);
     x265hip_job jb = {};
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t od = st.alloc(N * N * 2);
     st.upload();
     st.require(x265hip_transform_batch(KIND, D, N, plane(st, oa, N), plane(st, od, N), dj, 1, N >= 16, st.stream), "transform");
@@ -128,7 +135,7 @@ template <int KIND, int N> static void inv_tr_stub(const int16_t* src, int16_t* 
     st.begin();
     const size_t oa = st.in1d(src, N * N * 2);
     x265hip_job jb = {};
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t od = st.alloc(N * N * 2);
     st.upload();
     st.require(x265hip_transform_batch(KIND, D, N, plane(st, oa, N), plane(st, od, N), dj, 1, N >= 16, st.stream), "inverse transform");
@@ -143,7 +150,7 @@ static uint32_t quant_stub(const int16_t* coef, const int32_t* quantCoeff, int32
     st.begin();
     const size_t o0 = st.in1d(coef, numCoeff * 2), o1 = st.in1d(quantCoeff, numCoeff * 4);
     x265hip_job jb = {}; jb.arg[0] = qBits; jb.arg[1] = add; jb.arg[2] = numCoeff;
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t o2 = st.alloc(numCoeff * 4), o3 = st.alloc(numCoeff * 2), orr = st.alloc(4);
     st.upload();
     const x265hip_plane pl[4] = { plane(st, o0, 0), plane(st, o1, 0), plane(st, o2, 0), plane(st, o3, 0) };
@@ -159,7 +166,7 @@ static uint32_t nquant_stub(const int16_t* coef, const int32_t* quantCoeff, int1
     st.begin();
     const size_t o0 = st.in1d(coef, numCoeff * 2), o1 = st.in1d(quantCoeff, numCoeff * 4);
     x265hip_job jb = {}; jb.arg[0] = qBits; jb.arg[1] = add; jb.arg[2] = numCoeff;
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t o3 = st.alloc(numCoeff * 2), orr = st.alloc(4);
     st.upload();
     const x265hip_plane pl[4] = { plane(st, o0, 0), plane(st, o1, 0), plane(st, o3, 0), plane(st, o3, 0) };
@@ -174,7 +181,7 @@ static void dequant_normal_stub(const int16_t* quantCoef, int16_t* coef, int num
     st.begin();
     const size_t o0 = st.in1d(quantCoef, num * 2);
     x265hip_job jb = {}; jb.arg[0] = num; jb.arg[1] = scale; jb.arg[2] = shift;
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t o3 = st.alloc(num * 2);
     st.upload();
     const x265hip_plane pl[4] = { plane(st, o0, 0), plane(st, o0, 0), plane(st, o3, 0), plane(st, o3, 0) };
@@ -188,7 +195,7 @@ static void dequant_scaling_stub(const int16_t* quantCoef, const int32_t* deQuan
     st.begin();
     const size_t o0 = st.in1d(quantCoef, num * 2), o1 = st.in1d(deQuantCoef, num * 4);
     x265hip_job jb = {}; jb.arg[0] = num; jb.arg[1] = per; jb.arg[2] = shift;
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t o3 = st.alloc(num * 2);
     st.upload();
     const x265hip_plane pl[4] = { plane(st, o0, 0), plane(st, o1, 0), plane(st, o3, 0), plane(st, o3, 0) };
@@ -202,7 +209,7 @@ static void denoise_stub(int16_t* dctCoef, uint32_t* resSum, const uint16_t* off
     st.begin();
     const size_t o0 = st.in1d(dctCoef, numCoeff * 2), o1 = st.in1d(resSum, numCoeff * 4), o2 = st.in1d(offset, numCoeff * 2);
     x265hip_job jb = {}; jb.arg[0] = numCoeff;
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     st.upload();
     const x265hip_plane pl[4] = { plane(st, o0, 0), plane(st, o1, 0), plane(st, o2, 0), plane(st, o2, 0) };
     st.require(x265hip_quant_batch(X265HIP_Q_DENOISE, pl, dj, 1, nullptr, st.stream), "denoiseDct");
@@ -216,7 +223,7 @@ template <int N> static int count_nonzero_stub(const int16_t* q)
     st.begin();
     const size_t o0 = st.in1d(q, N * N * 2);
     x265hip_job jb = {}; jb.arg[0] = N * N;
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t orr = st.alloc(4);
     st.upload();
     const x265hip_plane pl[4] = { plane(st, o0, 0), plane(st, o0, 0), plane(st, o0, 0), plane(st, o0, 0) };
@@ -230,7 +237,7 @@ template <int N> static uint32_t copy_cnt_stub(int16_t* coeff, const int16_t* re
     st.begin();
     const size_t o0 = st.in2d(residual, resiStride, N, N, 2);
     x265hip_job jb = {}; jb.arg[0] = N;
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t o3 = st.alloc(N * N * 2), orr = st.alloc(4);
     st.upload();
     const x265hip_plane pl[4] = { plane(st, o0, N), plane(st, o0, 0), plane(st, o0, 0), plane(st, o3, 0) };
@@ -250,7 +257,7 @@ template <int N, int SLOT> static void intra_pred_stub(pixel* dst, intptr_t dstS
     st.begin();
     const size_t o0 = st.in1d(srcPix, (4 * N + 1) * ES);
     x265hip_job jb = {}; jb.arg[0] = dirMode; jb.arg[1] = bFilter;
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t od = st.alloc(N * N * ES);
     st.upload();
     st.require(x265hip_intra_batch(X265HIP_INTRA_PRED, D, N, plane(st, o0, 0), plane(st, od, N), dj, 1, st.stream), "intra_pred");
@@ -263,7 +270,7 @@ template <int N> static void intra_filter_stub(const pixel* references, pixel* f
     st.begin();
     const size_t o0 = st.in1d(references, (4 * N + 1) * ES);
     x265hip_job jb = {};
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t od = st.alloc((4 * N + 1) * ES);
     st.upload();
     st.require(x265hip_intra_batch(X265HIP_INTRA_FILTER, D, N, plane(st, o0, 0), plane(st, od, 0), dj, 1, st.stream), "intra_filter");
@@ -276,7 +283,7 @@ template <int N> static void intra_allangs_stub(pixel* dest, pixel* refPix, pixe
     st.begin();
     const size_t o0 = st.in1d(refPix, (4 * N + 1) * ES), o1 = st.in1d(filtPix, (4 * N + 1) * ES);
     x265hip_job jb = {}; jb.off[2] = (int64_t)((o1 - o0) / ES); jb.arg[0] = bLuma;
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t od = st.alloc(33 * N * N * ES);
     st.upload();
     st.require(x265hip_intra_batch(X265HIP_INTRA_ALLANGS, D, N, plane(st, o0, 0), plane(st, od, N), dj, 1, st.stream), "intra_allangs");
@@ -297,7 +304,7 @@ static void op_core(int op, int w, int h, T0* dst, intptr_t ds, bool dstContig, 
     if (s2) o2 = st.in2d(s2, ss2, w, h, sizeof(T2));
     x265hip_job jb = {};
     for (int i = 0; i < 4; i++) jb.arg[i] = args ? args[i] : 0;
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t od = st.alloc((size_t)w * h * sizeof(T0));
     st.upload();
     const x265hip_plane pl[3] = { plane(st, od, w), plane(st, o1, w), plane(st, o2, w) };
@@ -332,7 +339,7 @@ static void scale1d_stub(pixel* dst, const pixel* src)
     st.begin();
     const size_t o1 = st.in1d(src, 256 * ES);
     x265hip_job jb = {};
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t od = st.alloc(128 * ES);
     st.upload();
     const x265hip_plane pl[3] = { plane(st, od, 0), plane(st, o1, 0), plane(st, o1, 0) };
@@ -346,7 +353,7 @@ static void scale2d_stub(pixel* dst, const pixel* src, intptr_t stride)
     st.begin();
     const size_t o1 = st.in2d(src, stride, 64, 64, ES);
     x265hip_job jb = {};
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t od = st.alloc(32 * 32 * ES);
     st.upload();
     const x265hip_plane pl[3] = { plane(st, od, 0), plane(st, o1, 64), plane(st, o1, 64) };
@@ -362,7 +369,7 @@ template <typename T> static uint64_t reduce_core(int op, int n, const T* a, int
     const size_t o0 = st.in2d(a, sa, n, n, sizeof(T));
     const size_t o1 = b ? st.in2d(b, sb, n, n, sizeof(T)) : o0;
     x265hip_job jb = {};
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t orr = st.alloc(8);
     st.upload();
     const x265hip_plane pl[3] = { plane(st, o0, n), plane(st, o1, n), plane(st, o1, n) };
@@ -375,10 +382,12 @@ template <int N> static sse_t ssd_s_stub(const int16_t* a, intptr_t sa) { return
 template <int N> static uint64_t var_stub(const pixel* p, intptr_t s) { return reduce_core<pixel>(X265HIP_OP_VAR, N, p, s, nullptr, 0); }
 
 // ---------------------------------------------------------------- loop filter family
-static void lf_run(ThreadStage& st, int kind, const size_t o[4], const intptr_t strides[4], const x265hip_job& jb, uint32_t* dres)
+static constexpr size_t NO_RESULT = ~(size_t)0;
+static void lf_run(ThreadStage& st, int kind, const size_t o[4], const intptr_t strides[4], const x265hip_job& jb, size_t ores)
 {
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);     // last alloc of the call: device addresses are taken below
     st.upload();
+    uint32_t* dres = ores == NO_RESULT ? nullptr : st.dptr<uint32_t>(ores);
     const x265hip_plane pl[4] = { plane(st, o[0], strides[0]), plane(st, o[1], strides[1]), plane(st, o[2], strides[2]), plane(st, o[3], strides[3]) };
     st.require(x265hip_loopfilter_batch(kind, D, pl, dj, 1, dres, st.stream), "loopfilter");
 }
@@ -390,7 +399,7 @@ static void sign_stub(int8_t* dst, const pixel* src1, const pixel* src2, const i
     const size_t o1 = st.in1d(src1, endX * ES), o2 = st.in1d(src2, endX * ES), od = st.in1d(dst, endX);
     const size_t o[4] = { od, o1, o2, o2 }; const intptr_t s[4] = { 0, 0, 0, 0 };
     x265hip_job jb = {}; jb.arg[0] = endX;
-    lf_run(st, X265HIP_LF_SIGN, o, s, jb, nullptr);
+    lf_run(st, X265HIP_LF_SIGN, o, s, jb, NO_RESULT);
     st.download(od, endX);
     memcpy(dst, st.hptr<void>(od), endX);
 }
@@ -416,7 +425,7 @@ static void sao_e0_stub(pixel* rec, int8_t* offsetEo, int width, int8_t* signLef
     const size_t oo = st.in1d(offsetEo, 5), osl = st.in1d(signLeft, 2);
     const size_t o[4] = { orec, oo, osl, osl }; const intptr_t s[4] = { tw, 0, 0, 0 };
     x265hip_job jb = {}; jb.off[0] = org; jb.arg[0] = width;
-    lf_run(st, X265HIP_LF_SAO_E0, o, s, jb, nullptr);
+    lf_run(st, X265HIP_LF_SAO_E0, o, s, jb, NO_RESULT);
     unstage_rec(st, orec, tw, org, rec, stride, width, 2);
 }
 template <int ROWS> static void sao_e1_stub(pixel* rec, int8_t* upBuff1, int8_t* offsetEo, intptr_t stride, int width)
@@ -428,7 +437,7 @@ template <int ROWS> static void sao_e1_stub(pixel* rec, int8_t* upBuff1, int8_t*
     const size_t oo = st.in1d(offsetEo, 5), oup = st.in1d(upBuff1, width);
     const size_t o[4] = { orec, oo, oup, oup }; const intptr_t s[4] = { tw, 0, 0, 0 };
     x265hip_job jb = {}; jb.off[0] = org; jb.arg[0] = width;
-    lf_run(st, ROWS == 1 ? X265HIP_LF_SAO_E1 : X265HIP_LF_SAO_E1_2ROWS, o, s, jb, nullptr);
+    lf_run(st, ROWS == 1 ? X265HIP_LF_SAO_E1 : X265HIP_LF_SAO_E1_2ROWS, o, s, jb, NO_RESULT);
     st.download(orec, oup + width - orec);
     const pixel* r = st.hptr<pixel>(orec);
     for (int y = 0; y < ROWS; y++) memcpy(rec + (intptr_t)y * stride, r + (size_t)y * tw, (size_t)width * ES);
@@ -443,7 +452,7 @@ static void sao_e2_stub(pixel* rec, int8_t* bufft, int8_t* buff1, int8_t* offset
     const size_t oo = st.in1d(offsetEo, 5), ob1 = st.in1d(buff1, width), obt = st.in1d(bufft, width + 1);
     const size_t o[4] = { orec, oo, ob1, obt }; const intptr_t s[4] = { tw, 0, 0, 0 };
     x265hip_job jb = {}; jb.off[0] = org; jb.arg[0] = width;
-    lf_run(st, X265HIP_LF_SAO_E2, o, s, jb, nullptr);
+    lf_run(st, X265HIP_LF_SAO_E2, o, s, jb, NO_RESULT);
     st.download(orec, obt + width + 1 - orec);
     memcpy(rec, st.hptr<pixel>(orec), (size_t)width * ES);
     memcpy(bufft + 1, st.hptr<int8_t>(obt) + 1, width);
@@ -460,7 +469,7 @@ static void sao_e3_stub(pixel* rec, int8_t* upBuff1, int8_t* offsetEo, intptr_t 
     const size_t oo = st.in1d(offsetEo, 5), oup = st.in1d(upBuff1 + startX, width);
     const size_t o[4] = { orec, oo, oup, oup }; const intptr_t s[4] = { tw, 0, 0, 0 };
     x265hip_job jb = {}; jb.off[0] = org; jb.arg[0] = 0; jb.arg[1] = width;
-    lf_run(st, X265HIP_LF_SAO_E3, o, s, jb, nullptr);
+    lf_run(st, X265HIP_LF_SAO_E3, o, s, jb, NO_RESULT);
     st.download(orec, oup + width - orec);
     memcpy(rec + startX + 1, st.hptr<pixel>(orec) + 1, (size_t)(width - 1) * ES);
     memcpy(upBuff1 + startX, st.hptr<int8_t>(oup), width - 1);
@@ -474,7 +483,7 @@ static void sao_b0_stub(pixel* rec, const int8_t* offsetBo, int ctuWidth, int ct
     const size_t oo = st.in1d(offsetBo, 32);
     const size_t o[4] = { orec, oo, oo, oo }; const intptr_t s[4] = { tw, 0, 0, 0 };
     x265hip_job jb = {}; jb.off[0] = org; jb.arg[0] = ctuWidth; jb.arg[1] = ctuHeight;
-    lf_run(st, X265HIP_LF_SAO_B0, o, s, jb, nullptr);
+    lf_run(st, X265HIP_LF_SAO_B0, o, s, jb, NO_RESULT);
     unstage_rec(st, orec, tw, org, rec, stride, ctuWidth, ctuHeight);
 }
 // SAO statistics: stage the rec neighbourhood each class reads (one column left/right, one row below, one row above
@@ -497,7 +506,7 @@ static void sao_stats(int kind, const int16_t* diff, const pixel* rec, intptr_t 
     const size_t ores = st.in1d(packed, sizeof(packed));
     const size_t o[4] = { odiff, orec, oup, out_ }; const intptr_t s[4] = { endX, tw, 0, 0 };   // diff packed at pitch endX
     x265hip_job jb = {}; jb.off[1] = org; jb.off[2] = 1; jb.off[3] = 1; jb.arg[0] = endX; jb.arg[1] = endY;
-    lf_run(st, kind, o, s, jb, st.dptr<uint32_t>(ores));
+    lf_run(st, kind, o, s, jb, ores);
     st.download(oup, ores + sizeof(packed) - oup);
     const int32_t* r = st.hptr<int32_t>(ores);
     memcpy(stats, r, bins * 4); memcpy(count, r + 32, bins * 4);
@@ -534,7 +543,7 @@ template <bool CHROMA> static void deblock_core(pixel* src, intptr_t srcStep, in
     const size_t o[4] = { ob, ob, ob, ob }; const intptr_t s[4] = { 0, 0, 0, 0 };
     x265hip_job jb = {}; jb.off[0] = 4; jb.arg[0] = 8; jb.arg[1] = 1; jb.arg[2] = a2; jb.arg[3] = a3;
     if (CHROMA) { jb.off[2] = a3; jb.off[3] = maskQ; }
-    lf_run(st, CHROMA ? X265HIP_LF_DEBLOCK_CHROMA : X265HIP_LF_DEBLOCK_LUMA_STRONG, o, s, jb, nullptr);
+    lf_run(st, CHROMA ? X265HIP_LF_DEBLOCK_CHROMA : X265HIP_LF_DEBLOCK_LUMA_STRONG, o, s, jb, NO_RESULT);
     st.download(ob, sizeof(blk));
     const pixel* r = st.hptr<pixel>(ob);
     const int lo = CHROMA ? -1 : -3, hi = CHROMA ? 0 : 2;
@@ -560,7 +569,7 @@ template <int N> static void integral_h_stub(uint32_t* sum, pixel* pix, intptr_t
     const intptr_t dist = (intptr_t)((osum - oabove) / 4);
     const size_t o[4] = { osum, opix, opix, opix }; const intptr_t s[4] = { 0, 0, 0, 0 };
     x265hip_job jb = {}; jb.arg[0] = (int)dist; jb.arg[1] = N; jb.arg[2] = cnt;
-    lf_run(st, X265HIP_LF_INTEGRAL_H, o, s, jb, nullptr);
+    lf_run(st, X265HIP_LF_INTEGRAL_H, o, s, jb, NO_RESULT);
     st.download(osum, (size_t)cnt * 4);
     memcpy(sum, st.hptr<void>(osum), (size_t)cnt * 4);
 }
@@ -574,7 +583,7 @@ template <int N> static void integral_v_stub(uint32_t* sum, intptr_t stride)
     const intptr_t dist = (intptr_t)((oN - o0) / 4);           // kernel reads sum[x + N * strideArg]
     const size_t o[4] = { o0, o0, o0, o0 }; const intptr_t s[4] = { 0, 0, 0, 0 };
     x265hip_job jb = {}; jb.arg[0] = (int)dist; jb.arg[1] = 1; jb.arg[2] = (int)stride;
-    lf_run(st, X265HIP_LF_INTEGRAL_V, o, s, jb, nullptr);
+    lf_run(st, X265HIP_LF_INTEGRAL_V, o, s, jb, NO_RESULT);
     st.download(o0, (size_t)stride * 4);
     memcpy(sum, st.hptr<void>(o0), (size_t)stride * 4);
 }
@@ -586,7 +595,7 @@ template <int LX, int NSUM> static int ads_stub(int* encDC, uint32_t* sums, int 
     const int span = width + (NSUM == 4 ? delta + (LX >> 1) : (NSUM == 2 ? delta : 0));
     const size_t os = st.in1d(sums, (size_t)span * 4), oc = st.in1d(costMvX, (size_t)width * 2), oe = st.in1d(encDC, 16);
     x265hip_job jb = {}; jb.arg[0] = delta; jb.arg[1] = width; jb.arg[2] = thresh; jb.arg[3] = LX | (NSUM << 16);
-    const x265hip_job* dj = put_job(st, jb);
+    const JobRef dj = put_job(st, jb);
     const size_t om = st.alloc((size_t)width * 2), orr = st.alloc(4);
     st.upload();
     const x265hip_plane pl[4] = { plane(st, os, 0), plane(st, oc, 0), plane(st, om, 0), plane(st, oe, 0) };

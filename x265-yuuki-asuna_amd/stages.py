@@ -222,7 +222,8 @@ class AdaptiveQuant:
         if self.weightp:                                             # the final normalisation, slicetype.cpp:662-675
             col, row = ((self.width + 8) >> 4) << 4, ((self.height + 8) >> 4) << 4
             dims = [col * row, (col >> 1) * (row >> 1), (col >> 1) * (row >> 1)]
-            wp_ssd = [(wp_ssd[i] - (wp_sum[i] * wp_sum[i] + dims[i] // 2) // dims[i]) & 0xffffffffffffffff for i in range(3)]
+            m64 = 0xffffffffffffffff                                 # `sum * sum` wraps in uint64_t in the reference (bright 4K 10/12-bit)
+            wp_ssd = [(wp_ssd[i] - ((wp_sum[i] * wp_sum[i] + dims[i] // 2) & m64) // dims[i]) & m64 for i in range(3)]
         return qp, inv, wp_sum, wp_ssd
 
 
