@@ -45,60 +45,125 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0):
-    """The oracle chain (CPU restatement, AVX2 build when the host has AVX2) for one frame on a bounded number
-    of CTUs, all host cores via OpenMP: exhaustive search (best mv) -> sub-pel -> prediction/residual round trip."""
+def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2):
+    """The oracle's restatement (CPU; checker + cpu_baseline leg only) of one frame of the pipeline - clip[1] searched in
+    clip[0] - on the first n CTUs.  n == all CTUs also runs the per-picture stages (lookahead, deblocking, SAO statistics)
+    and returns every stage output for the bit-exact comparison with the device pipeline.  Returns (seconds, outputs)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle_api as O          # cpu_baseline leg only
-    avx2 = O.host_has_avx2()
+    import oracle_api as O          # cpu_baseline / bit-exact checker leg only
     cur, stride, org, w64, h64 = F.pad_plane(clip[1][0])
     ref = F.pad_plane(clip[0][0])[0]
     cost = F.mv_cost_table(rng_r)
     cq, qoff = F.qpel_cost_table(rng_r)
     nctu = (w64 // 64) * (h64 // 64)
-    cores = effective_cpus()
-
     lw, lh = ((clip[0][0].shape[1] // 2 + 7) >> 3) * 8, ((clip[0][0].shape[0] // 2 + 7) >> 3) * 8
     lstride = (lw + 2 * F.MARGIN_X + 31) & ~31
+    out = {}
+    t = time.perf_counter()
+    if n == nctu:       # the lookahead stage is per picture: include it with whole-frame samples
+        lp = O.lowres_init(depth, cur, stride, org, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lh + 2 * F.MARGIN_Y, lw, lh,
+                           F.MARGIN_X, F.MARGIN_Y, avx2=avx2)
+        ic, im, lc = O.lowres_intra(depth, lp[0], lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lw // 8, lh // 8, 5, nthreads=cores, avx2=avx2)
+        # the frame cost estimate against the previous picture is serial per picture (the reference spreads pictures over threads)
+        lq, lqoff = F.qpel_cost_table(16, lam=1.0 if depth == 8 else 16.0, qmax=4 * (max(lw, lh) + 64))
+        lpr = O.lowres_init(depth, ref, stride, org, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lh + 2 * F.MARGIN_Y, lw, lh,
+                            F.MARGIN_X, F.MARGIN_Y, avx2=avx2)
+        O.lowres_cost(depth, lp[0], lpr, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lw // 8, lh // 8, lq, lqoff, ic, avx2=avx2)
+        out.update({"lowres_plane%d" % i: lp[i] for i in range(4)})
+        out.update({"intra_cost": ic, "intra_mode": im, "lowres_costs": lc})
+    _, best = O.me_fullsearch(depth, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, cost, cost,
+                              want_surf=False, want_best=True, nthreads=cores, avx2=avx2)
+    mv = O.subpel_refine(depth, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, best, cq, qoff, subme,
+                         nthreads=cores, avx2=avx2)
+    rec, lev, ns, dist = O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp, ctu_begin=0, ctu_end=n,
+                                       nthreads=cores, avx2=avx2)
+    if n == nctu:       # per-picture stages, single-threaded in the restatement
+        bv, bh = O.deblock_bs_inter(depth, w64, h64, level, mv, ns, avx2=avx2)
+        dbk = O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, max(qp - 6 * (depth - 8), 0), avx2=avx2)
+        cnt, off = O.sao_stats(depth, cur.reshape(-1), dbk.reshape(-1), stride, org, w64, h64, nthreads=cores, avx2=avx2)
+        dt = time.perf_counter() - t
+        dbk = dbk.reshape(rec.shape)
+        inner = dbk[F.MARGIN_Y:F.MARGIN_Y + h64, F.MARGIN_X:F.MARGIN_X + w64]
+        out.update({"me_best": best, "subpel_mv": mv, "levels": lev, "num_sig": ns, "dist": dist, "sao_count": cnt, "sao_offset_org": off,
+                    "recon": np.pad(inner, ((F.MARGIN_Y, F.MARGIN_Y), (F.MARGIN_X, F.MARGIN_X)), mode="edge")})   # extendPicBorder
+        return dt, out
+    return time.perf_counter() - t, out
 
-    def run(n, cores=cores):
-        t = time.perf_counter()
-        if n == nctu:       # the lookahead stage is per picture: include it with whole-frame samples
-            lp = O.lowres_init(depth, cur, stride, org, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lh + 2 * F.MARGIN_Y, lw, lh,
-                               F.MARGIN_X, F.MARGIN_Y, avx2=avx2)
-            ic, _, _ = O.lowres_intra(depth, lp[0], lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lw // 8, lh // 8, 5, nthreads=cores, avx2=avx2)
-            # the frame cost estimate against the previous picture is serial per picture (the reference spreads pictures over threads)
-            lq, lqoff = F.qpel_cost_table(16, lam=1.0 if depth == 8 else 16.0, qmax=4 * (max(lw, lh) + 64))
-            lpr = O.lowres_init(depth, ref, stride, org, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lh + 2 * F.MARGIN_Y, lw, lh,
-                                F.MARGIN_X, F.MARGIN_Y, avx2=avx2)
-            O.lowres_cost(depth, lp[0], lpr, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lw // 8, lh // 8, lq, lqoff, ic, avx2=avx2)
-        _, best = O.me_fullsearch(depth, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, cost, cost,
-                                  want_surf=False, want_best=True, nthreads=cores, avx2=avx2)
-        mv = O.subpel_refine(depth, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, best, cq, qoff, subme,
-                             nthreads=cores, avx2=avx2)
-        rec, _, ns, _ = O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp, ctu_begin=0, ctu_end=n,
-                                      nthreads=cores, avx2=avx2)
-        if n == nctu:       # per-picture stage, single-threaded in the restatement
-            bv, bh = O.deblock_bs_inter(depth, w64, h64, level, mv, ns, avx2=avx2)
-            dbk = O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, max(qp - 6 * (depth - 8), 0), avx2=avx2)
-            O.sao_stats(depth, cur.reshape(-1), dbk.reshape(-1), stride, org, w64, h64, nthreads=cores, avx2=avx2)
-        return time.perf_counter() - t
 
-    probe = min(nctu, max(cores, 8))
-    t_probe = run(probe)
-    n = int(min(nctu, max(probe, probe * target_s / max(t_probe, 1e-3))))
-    reps, t = 0, 0.0
+def device_outputs(pipe, cur, ref):
+    """One frame of the device pipeline (cur searched in ref) with every stage output copied to the host."""
+    import torch
+    rec = pipe.run(cur, ref)
+    torch.cuda.synchronize()
+    dt = cur.host.dtype
+    out = {"lowres_plane%d" % i: pipe.la.planes[i].cpu().numpy().view(dt) for i in range(4)}
+    out.update({"intra_cost": pipe.la.intra_cost.cpu().numpy(), "intra_mode": pipe.la.intra_mode.cpu().numpy(),
+                "lowres_costs": pipe.la.lowres_costs.cpu().numpy().view(np.uint16),
+                "me_best": pipe.ms.best.cpu().numpy().view(np.uint64), "subpel_mv": pipe.sp.out.cpu().numpy().reshape(-1, 2),
+                "levels": pipe.rc.levels.cpu().numpy(), "num_sig": pipe.rc.num_sig.cpu().numpy(), "dist": pipe.rc.dist.cpu().numpy(),
+                "sao_count": pipe.sao.count.cpu().numpy(), "sao_offset_org": pipe.sao.offset_org.cpu().numpy(),
+                "recon": rec.cpu().numpy().view(dt).reshape(cur.host.shape)})
+    return out
+
+
+def compare_outputs(dev_out, cpu_out):
+    """Bit-exact comparison, stage by stage.  Returns {"ok": bool, "stages": {name: "equal" | "<k> of <n> values differ"}}."""
+    stages, ok = {}, True
+    for k, e in cpu_out.items():
+        g = np.asarray(dev_out[k]).reshape(-1)
+        e = np.asarray(e).reshape(-1)
+        if g.dtype != e.dtype:
+            g, e = g.astype(np.int64), e.astype(np.int64)
+        if g.shape == e.shape and np.array_equal(g, e):
+            stages[k] = "equal"
+        else:
+            ok = False
+            stages[k] = "shape %s vs %s" % (g.shape, e.shape) if g.shape != e.shape else "%d of %d values differ" % (int(np.count_nonzero(g != e)), e.size)
+    return {"ok": ok, "stages": stages, "values_compared": int(sum(np.asarray(v).size for v in cpu_out.values()))}
+
+
+def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0, dev_out=None):
+    """The oracle chain (CPU restatement, AVX2 build when the host has AVX2) for one frame, all host cores via OpenMP:
+    lookahead -> exhaustive search (best mv) -> sub-pel -> prediction/residual round trip -> deblocking -> SAO statistics.
+    Timed on whole frames when one fits the budget, else on a bounded CTU sample; with dev_out (the device pipeline's outputs
+    for the same frame pair) ONE whole-frame pass is also compared with them bit for bit.  Returns (cpu_baseline, bit_exact)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_api as O          # cpu_baseline leg only
+    avx2 = O.host_has_avx2()
+    w64, h64 = F.pad_plane(clip[1][0])[3:5]
+    nctu = (w64 // 64) * (h64 // 64)
+    cores = effective_cpus()
+
+    def run(n, c=cores):
+        return oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, c, avx2)
+
+    bit_exact = None
+    reps, t, n = 0, 0.0, nctu
+    if dev_out is not None:                          # the whole frame once: timed AND compared
+        t, cpu_out = run(nctu)
+        reps = 1
+        bit_exact = compare_outputs(dev_out, cpu_out)
+        bit_exact["ctus"] = nctu
+        bit_exact["what"] = ("device pipeline == oracle chain (C restatement, pinned against the real reference) for one whole frame "
+                             "searched in the previous source frame: lookahead planes / intra costs, integer mvs, sub-pel mvs, levels, "
+                             "numSig, SSE, deblocked + border-extended reconstruction, SAO statistics")
+    else:
+        probe = min(nctu, max(cores, 8))
+        t_probe, _ = run(probe)
+        n = int(min(nctu, max(probe, probe * target_s / max(t_probe, 1e-3))))
     while t < target_s * 0.66 and reps < 64:      # ~10-15 s of wall time: repeat the (sub-)frame if one pass is shorter
-        t += run(n)
+        t += run(n)[0]
         reps += 1
     # the same chain on ONE thread (SURVEY 8(d) asks for both figures): a short CTU sample, per-picture stages left out
     n1 = min(nctu - 1, 8)
-    t1 = run(n1, 1)
-    return {"value": round(reps * (n / nctu) / t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+    t1, _ = run(n1, 1)
+    base = {"value": round(reps * (n / nctu) / t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "one_thread_value": round((n1 / nctu) / t1, 5),
             "sample": f"{reps} x {n} of {nctu} CTUs of the same {clip[0][0].shape[1]}x{clip[0][0].shape[0]} frame through the same stages (search keeps only the best mv), "
                       f"oracle C ({'-march=x86-64-v3' if avx2 else 'generic x86-64'}) with OpenMP over CTUs on {cores} threads "
-                      f"(the container's CPU quota; {os.cpu_count()} hardware threads visible), {t:.1f} s"}
+                      f"(the container's CPU quota; {os.cpu_count()} hardware threads visible), {t:.1f} s; an EXHAUSTIVE +-{rng_r} search on the CPU is "
+                      f"not what x265 runs at preset slow - the real reference encoder is timed by `bench.py --encoder` (profiles/)"}
+    return base, bit_exact
 
 
 def effective_cpus():
@@ -145,6 +210,7 @@ def main():
     ap.add_argument("--lookahead-batch", type=int, default=0,
                     help="pictures per launch of the lookahead's P-frame cost estimate, which runs ahead on a side stream (0 = stage off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the bit-exact comparison of one whole frame with the oracle chain")
     ap.add_argument("--prims", action="store_true",
                     help="instead of the pipeline line, print the per-family table of the batch-layer kernels with the CPU paths timed beside "
                          "them (tools/bench_prims.py: bench.py's cpu_baseline leg at primitive level)")
@@ -304,9 +370,19 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "output_bytes_per_launch": ms.hbm_floor_bytes(1 if args.depth == 8 else 2),
                          "launch_ms": stages[dom]},
         }
+        bit_exact = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(F, clip, args.range, args.subme, args.level, args.qp, depth=args.depth)
+            dev_out = None
+            if args.search == "full" and not args.no_verify:      # one more (untimed) frame: clip[1] searched in the SOURCE clip[0]
+                dev_out = device_outputs(pipe, pics[1], pics[0])
+            out["cpu_baseline"], bit_exact = cpu_baseline(F, clip, args.range, args.subme, args.level, args.qp, depth=args.depth, dev_out=dev_out)
+            if bit_exact is not None:
+                out["bit_exact"] = bit_exact["ok"]
+                out["bit_exact_detail"] = bit_exact
         print(json.dumps(out))
+        if bit_exact is not None and not bit_exact["ok"]:
+            sys.stderr.write("bench.py: device pipeline differs from the oracle chain: %s\n" % json.dumps(bit_exact["stages"]))
+            sys.exit(3)
     if world > 1:
         dist.destroy_process_group()
 

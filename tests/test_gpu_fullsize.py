@@ -1,0 +1,160 @@
+"""GPU parity at BASELINE.json's FULL picture sizes, all five configurations' dimensions and bit depths:
+
+  configs[2]  3840x2160  8-bit   whole frame, every stage, against the oracle chain (the same code bench.py's `bit_exact` runs)
+  configs[3]  3840x2160 10-bit   the same, plus the ME surface properties (int32 records)
+  configs[4]  7680x4320 10-bit   ME surface properties over all 8160 CTUs; CTU samples (first / middle / last rows) of
+                                 search -> sub-pel -> reconstruction against the oracle; deblocking + SAO statistics of the
+                                 WHOLE picture against the oracle fed with the device's own reconstruction
+
+Size-independent properties (task statement (3)): every parent SAD is the sum of its four children at the same
+displacement; the best key of every PU is the minimum of (SAD + mv cost) << 32 | raster index over its surface."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+S = importlib.import_module("x265-yuuki-asuna_amd.stages")
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_api
+    return oracle_api
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def _surface_properties(ms, dev, chunk=256):
+    """Hierarchy + minimum properties of an int32-record surface buffer, CTU chunk by CTU chunk."""
+    import torch
+    assert not ms.packed
+    nc, ng = ms.nc, ms.ng
+    cost = torch.from_numpy(ms.cost_host.astype(np.int64)).to(dev)
+    mvcost = (cost[:, None] + cost[None, :]).reshape(1, nc * nc, 1)
+    idx = torch.arange(nc * nc, device=dev, dtype=torch.int64).reshape(1, -1, 1)
+    per_ctu = nc * ng * 340                                      # int32 words per CTU
+    best = ms.best.view(-1, P.PUS_PER_CTU)
+    for c0 in range(0, ms.nctu, chunk):
+        c1 = min(ms.nctu, c0 + chunk)
+        n = c1 - c0
+        g = ms.surf[c0 * per_ctu:c1 * per_ctu].view(n * nc, ng, P.PUS_PER_CTU, 4)
+        v = g.permute(0, 1, 3, 2).reshape(n * nc, ng * 4, P.PUS_PER_CTU)[:, :nc, :].reshape(n, nc * nc, P.PUS_PER_CTU)
+        for l in range(3):
+            b, k = P.LEVEL_BASE[l], P.LEVEL_PUS[l]
+            child = v[:, :, b:b + k].reshape(n, nc * nc, k // 4, 4).sum(dim=3)
+            pb, pk = P.LEVEL_BASE[l + 1], P.LEVEL_PUS[l + 1]
+            assert torch.equal(child, v[:, :, pb:pb + pk]), f"CTUs {c0}..{c1}: level {l + 1} is not the sum of its children"
+        key = ((v.to(torch.int64) + mvcost) << 32) | idx
+        want = key.min(dim=1).values
+        assert torch.equal(best[c0:c1], want), f"CTUs {c0}..{c1}: best is not the surface minimum"
+        del key, want, v
+
+
+def _spot_check_ctus(ms, cur, ref, depth, rng, ctus):
+    O = _oracle()
+    for ctu in ctus:
+        _, best = O.me_fullsearch(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org,
+                                  cur.w64, cur.h64, rng, ctu, ctu + 1, ms.cost_host, ms.cost_host, want_surf=False)
+        assert np.array_equal(ms.best[ctu * 85:(ctu + 1) * 85].cpu().numpy().view(np.uint64), best[ctu * 85:(ctu + 1) * 85]), f"CTU {ctu}"
+
+
+@pytest.mark.parametrize("width,height", [(3840, 2160), (7680, 4320)])
+def test_me_10bit_full_size_properties(width, height):
+    """configs[3] / configs[4] picture sizes, 10-bit, merange 57: surface properties over every CTU + oracle spot checks."""
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(width, height, 2, depth=10, seed=19)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    ms = P.MotionSearch(cur.w64, cur.h64, 57, 10, dev)
+    ms.run(cur, ref)
+    torch.cuda.synchronize()
+    _surface_properties(ms, dev)
+    _spot_check_ctus(ms, cur, ref, 10, 57, (0, ms.nctu // 2 + 7, ms.nctu - 1))
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_whole_4k_frame_every_stage_equals_oracle_chain(depth):
+    """configs[2] (8-bit) / configs[3] (10-bit) at full size with the bench's own settings (merange 57, subme 3, 32x32 blocks):
+    lookahead, integer mvs, sub-pel mvs, levels, numSig, SSE, deblocked + extended reconstruction, SAO statistics - all CTUs."""
+    import torch
+    B = _bench()
+    O = _oracle()
+    dev = torch.device("cuda:0")
+    w, h, qp = 3840, 2160, 27 + 12 * (depth == 10)
+    clip = F.synth_clip(w, h, 2, depth=depth, seed=265)
+    pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
+    pipe = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=57, subme=3, level=2, qp=qp, want_surf=True, packed=depth == 8,
+                           lookahead=(w, h), deblock=True, sao=True)
+    dev_out = B.device_outputs(pipe, pics[1], pics[0])
+    _, cpu_out = B.oracle_chain(F, clip, 57, 3, 2, qp, depth, pipe.ms.nctu, B.effective_cpus(), O.host_has_avx2())
+    res = B.compare_outputs(dev_out, cpu_out)
+    assert res["ok"], res["stages"]
+    assert res["values_compared"] > 30_000_000
+    assert int(dev_out["num_sig"].sum()) > 0 and len(np.unique(dev_out["subpel_mv"][:, 1])) > 8      # not a degenerate frame
+
+
+def test_8k_10bit_ctu_samples_and_whole_picture_loop_filters():
+    """configs[4] size: the oracle's exhaustive search is too slow for 8160 CTUs, so search -> sub-pel -> reconstruction are compared
+    on three CTU runs (top rows, middle, bottom rows), and the per-picture stages (boundary strengths, deblocking, SAO statistics)
+    on the whole picture with the oracle fed by the device's own motion vectors / reconstruction."""
+    import torch
+    O = _oracle()
+    dev = torch.device("cuda:0")
+    depth, w, h, R, subme, level, qp = 10, 7680, 4320, 57, 3, 2, 39
+    clip = F.synth_clip(w, h, 2, depth=depth, seed=31)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    ms = P.MotionSearch(cur.w64, cur.h64, R, depth, dev, want_surf=False)
+    sp = P.SubpelRefine(ms, subme, dev)
+    rc = S.InterRecon(ms.nctu, cur.w64, cur.h64, depth, level, qp, dev)
+    db = S.Deblock(cur.w64, cur.h64, depth, level, max(qp - 6 * (depth - 8), 0), dev)
+    sao = S.Sao(cur.w64, cur.h64, depth, dev)
+    recon = torch.zeros_like(cur.t)
+    ms.run(cur, ref); sp.run(cur, ref); rc.run(cur, ref, recon, sp.out)
+    torch.cuda.synchronize()
+    pre = recon.cpu().numpy().view(np.uint16).reshape(cur.host.shape).copy()
+    db.run(recon, cur, sp.out, rc.num_sig)
+    sao.stats(cur, recon, cur.stride, cur.org)
+    torch.cuda.synchronize()
+    g_best = ms.best.cpu().numpy().view(np.uint64)
+    g_mv = sp.out.cpu().numpy().reshape(-1, 2)
+    g_lev, g_ns, g_dist = rc.levels.cpu().numpy(), rc.num_sig.cpu().numpy(), rc.dist.cpu().numpy()
+    cost, (cq, qoff) = F.mv_cost_table(R), F.qpel_cost_table(R)
+    nthreads = _bench().effective_cpus()
+    ctus_w = cur.w64 // 64
+    n = 2 * nthreads
+    nb, bs = (64 // (8 << level)) ** 2, (8 << level) ** 2
+    for c0 in (0, (ms.nctu // 2 // ctus_w) * ctus_w + ctus_w // 2, ms.nctu - n):
+        c1 = c0 + n
+        _, best = O.me_fullsearch(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, R, c0, c1, cost, cost,
+                                  want_surf=False, nthreads=nthreads)
+        assert np.array_equal(g_best[c0 * 85:c1 * 85], best[c0 * 85:c1 * 85]), f"CTUs {c0}..{c1}: integer mvs differ"
+        mv = O.subpel_refine(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, R, c0, c1, best, cq, qoff, subme,
+                             nthreads=nthreads)
+        assert np.array_equal(g_mv[c0 * 85:c1 * 85], mv[c0 * 85:c1 * 85]), f"CTUs {c0}..{c1}: sub-pel mvs differ"
+        erec, elev, ens, edist = O.inter_recon(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, level, mv, qp,
+                                               ctu_begin=c0, ctu_end=c1, nthreads=nthreads)
+        assert np.array_equal(g_lev[c0 * nb * bs:c1 * nb * bs], elev[c0 * nb * bs:c1 * nb * bs]), f"CTUs {c0}..{c1}: levels differ"
+        assert np.array_equal(g_ns[c0 * nb:c1 * nb], ens[c0 * nb:c1 * nb].astype(g_ns.dtype)) and \
+            np.array_equal(g_dist[c0 * nb:c1 * nb].astype(np.uint64), edist[c0 * nb:c1 * nb])
+        for c in range(c0, c1):
+            y, x = F.MARGIN_Y + 64 * (c // ctus_w), F.MARGIN_X + 64 * (c % ctus_w)
+            assert np.array_equal(pre[y:y + 64, x:x + 64], erec[y:y + 64, x:x + 64]), f"CTU {c}: reconstruction differs"
+    # whole-picture loop filters on the device's own reconstruction
+    bv, bh = O.deblock_bs_inter(depth, cur.w64, cur.h64, level, g_mv, g_ns.astype(np.uint32))
+    assert np.array_equal(db.bs_ver.cpu().numpy(), bv.reshape(-1)) and np.array_equal(db.bs_hor.cpu().numpy(), bh.reshape(-1))
+    edbk = O.deblock_luma(depth, pre.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64, bv, bh, max(qp - 6 * (depth - 8), 0))
+    assert np.array_equal(recon.cpu().numpy().view(np.uint16), edbk.reshape(-1)), "8K deblocked picture differs"
+    ecnt, eoff = O.sao_stats(depth, cur.host.reshape(-1), edbk.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64, nthreads=nthreads)
+    assert np.array_equal(sao.count.cpu().numpy().reshape(ecnt.shape), ecnt) and np.array_equal(sao.offset_org.cpu().numpy().reshape(eoff.shape), eoff)
+    assert int(np.count_nonzero(edbk.reshape(-1) != pre.reshape(-1))) > 1000          # the filter really ran

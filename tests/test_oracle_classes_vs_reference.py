@@ -39,7 +39,7 @@ def _zxy(z):
     return (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)
 
 
-@pytest.mark.parametrize("depth,width,height,rng,seed", [(8, 128, 128, 8, 21), (8, 192, 64, 12, 22), (10, 128, 64, 6, 23)])
+@pytest.mark.parametrize("depth,width,height,rng,seed", [(8, 128, 128, 8, 21), (8, 192, 64, 12, 22), (10, 128, 64, 6, 23), (12, 128, 64, 6, 24)])
 def test_fullsearch_subpel_chain_equals_reference_motion_estimate(depth, width, height, rng, seed):
     import oracle_api as O
     lib = _ref(depth)
@@ -50,7 +50,7 @@ def test_fullsearch_subpel_chain_equals_reference_motion_estimate(depth, width, 
     cq, qoff = F.qpel_cost_table(rng)
     nctu = (w64 // 64) * (h64 // 64)
     es = cur.itemsize
-    qp = 24 if depth == 8 else 12         # lambda 4.0 in the reference's table for this bit depth
+    qp = {8: 24, 10: 12, 12: 0}[depth]     # lambda 4.0 in the reference's table for this bit depth (constants.cpp:31-150)
     _, best = O.me_fullsearch(depth, cur, stride, org, ref, stride, org, w64, h64, rng, 0, nctu, cost, cost, want_surf=False)
     for subme in (0, 1, 2, 3, 5, 7):
         mv = O.subpel_refine(depth, cur, stride, org, ref, stride, org, w64, h64, rng, 0, nctu, best, cq, qoff, subme).reshape(-1, 2)
@@ -110,7 +110,7 @@ def test_search_driver_restatement_equals_reference_motion_estimate(depth, metho
     ref = F.pad_plane(clip[0][0])[0]
     es = cur.itemsize
     rng = np.random.default_rng([7, depth, METHODS[method], seed])
-    qp = 24 if depth == 8 else 12
+    qp = {8: 24, 10: 12, 12: 0}[depth]
     total = 0
     for subme in range(8):
         for merange in ((4, 16, 57) if method != "full" else (6,)):
@@ -156,7 +156,7 @@ def test_sea_search_restatement_equals_reference_motion_estimate(depth, seed=37)
     ref = F.pad_plane(clip[0][0])[0]
     es = cur.itemsize
     rng = np.random.default_rng([11, depth, seed])
-    qp = 24 if depth == 8 else 12
+    qp = {8: 24, 10: 12, 12: 0}[depth]
     cq, qoff = F.qpel_cost_table(57, qmax=8 * 64 + 300)
     seen, moved = set(), 0
     for subme in (0, 1, 2, 3, 5, 7):
@@ -185,7 +185,7 @@ def test_sea_search_restatement_equals_reference_motion_estimate(depth, seed=37)
     assert f(cur.ctypes.data + org * es, ref.ctypes.data + org * es, stride, 4, 2, 8, cq.ctypes.data, qoff, -8, -8, 8, 8, bad, 1, 1) != 0
 
 
-@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 192, 144), (10, 128, 128)])
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 192, 144), (10, 128, 128), (12, 128, 128)])
 def test_lookahead_restatement_equals_reference_classes(depth, width, height):
     """oracle/x265_oracle_pipeline3.c against the real Lowres::init + LookaheadTLD::lowresIntraEstimate
     (oracle/ref_lookahead.cpp): the four half-resolution planes including their extended borders, intraCost, intraMode
@@ -208,7 +208,7 @@ def test_lookahead_restatement_equals_reference_classes(depth, width, height):
                                   rcost.ctypes.data, rmode.ctypes.data, rlc.ctypes.data)
     assert rc == 0
     assert tuple(geo) == (lw, lh, rstride, wcu, hcu)
-    penalty = 5 if depth == 8 else 80          # 5 * (int)x265_lambda_tab[X265_LOOKAHEAD_QP]: 1.0 (8-bit, QP 12) / 16.0 (10-bit, QP 24)
+    penalty = {8: 5, 10: 80, 12: 1280}[depth]  # 5 * (int)x265_lambda_tab[X265_LOOKAHEAD_QP]: 1.0 (8-bit, QP 12) / 16.0 (10-bit, QP 24) / 256.0 (12-bit, QP 36)
     lorg = rstride * F.MARGIN_Y + F.MARGIN_X
     planes = O.lowres_init(depth, src, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
     for i in range(4):
@@ -255,7 +255,7 @@ def test_lowres_frame_cost_restatement_equals_reference_classes(depth, width, he
     lorg = rstride * F.MARGIN_Y + F.MARGIN_X
     cplanes = O.lowres_init(depth, cur, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
     rplanes = O.lowres_init(depth, ref, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
-    lam = 1.0 if depth == 8 else 16.0            # x265_lambda_tab[X265_LOOKAHEAD_QP]
+    lam = {8: 1.0, 10: 16.0, 12: 256.0}[depth]    # x265_lambda_tab[X265_LOOKAHEAD_QP]
     icost, _, _ = O.lowres_intra(depth, cplanes[0], rstride, lorg, wcu, hcu, 5 * int(lam))
     cq, qoff = F.qpel_cost_table(16, lam=lam, qmax=4 * (max(lw, lh) + 64))
     mvs, mvc, lc, rws, frame = O.lowres_cost(depth, cplanes[0], rplanes, rstride, lorg, wcu, hcu, cq, qoff, icost)
@@ -299,7 +299,7 @@ def test_lowres_b_frame_cost_restatement_equals_reference_classes(depth, width, 
     cplanes = O.lowres_init(depth, cur, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
     p0 = O.lowres_init(depth, r0, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
     p1 = O.lowres_init(depth, r1, stride, org, rstride, lorg, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y)
-    lam = 1.0 if depth == 8 else 16.0
+    lam = {8: 1.0, 10: 16.0, 12: 256.0}[depth]
     icost, _, _ = O.lowres_intra(depth, cplanes[0], rstride, lorg, wcu, hcu, 5 * int(lam))
     cq, qoff = F.qpel_cost_table(16, lam=lam, qmax=4 * (max(lw, lh) + 64))
     mvs, mvc, lc, rws, frame = O.lowres_cost(depth, cplanes[0], p0, rstride, lorg, wcu, hcu, cq, qoff, icost, ref1_planes=p1)
@@ -361,7 +361,7 @@ def test_weighted_reference_analysis_equals_reference_class(depth, width, height
     lib.x265ref_weights_analyse.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8
     assert lib.x265ref_weights_analyse(cur.ctypes.data, ref.ctypes.data, width, height, ssd.ctypes.data, sm.ctypes.data, out.ctypes.data,
                                        *[p.ctypes.data for p in wpl], ricost.ctypes.data) == 0
-    lam = 1.0 if depth == 8 else 16.0
+    lam = {8: 1.0, 10: 16.0, 12: 256.0}[depth]
     icost, _, _ = O.lowres_intra(depth, cplanes[0], rstride, lorg, wcu, hcu, 5 * int(lam))
     assert np.array_equal(icost, ricost)
     weight, minscore, origscore = O.weights_analyse(depth, cplanes[0], rplanes[0], rstride, lorg, lw, lh, icost, ssd, sm)
@@ -404,7 +404,7 @@ def test_weighted_p_frame_cost_equals_reference_classes(depth, width, height, ga
     lib.x265ref_lowres_cost_weightp.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8
     assert lib.x265ref_lowres_cost_weightp(cur.ctypes.data, ref.ctypes.data, width, height, ssd.ctypes.data, sm.ctypes.data, rmv.ctypes.data,
                                            rmc.ctypes.data, rlc.ctypes.data, rrows.ctypes.data, rframe.ctypes.data, rw.ctypes.data) == 0
-    lam = 1.0 if depth == 8 else 16.0
+    lam = {8: 1.0, 10: 16.0, 12: 256.0}[depth]
     icost, _, _ = O.lowres_intra(depth, cplanes[0], rstride, lorg, wcu, hcu, 5 * int(lam))
     weight, _, _ = O.weights_analyse(depth, cplanes[0], rplanes[0], rstride, lorg, lw, lh, icost, ssd, sm)
     assert (weight is not None) == bool(rw[0]) == (gain != 1.0)
@@ -486,7 +486,7 @@ def test_weighted_b_frame_cost_equals_reference_classes(depth, width, height, ga
     assert lib.x265ref_lowres_cost_b_weightp(cur.ctypes.data, r0.ctypes.data, r1.ctypes.data, width, height, ssd.ctypes.data, sm.ctypes.data,
                                              rmv[0].ctypes.data, rmc[0].ctypes.data, rmv[1].ctypes.data, rmc[1].ctypes.data, rlc.ctypes.data,
                                              rrows.ctypes.data, rframe.ctypes.data, rw.ctypes.data) == 0
-    lam = 1.0 if depth == 8 else 16.0
+    lam = {8: 1.0, 10: 16.0, 12: 256.0}[depth]
     icost, _, _ = O.lowres_intra(depth, cplanes[0], rstride, lorg, wcu, hcu, 5 * int(lam))
     weight, _, _ = O.weights_analyse(depth, cplanes[0], p0[0], rstride, lorg, lw, lh, icost, ssd, sm)
     assert weight is not None and rw[0] == 1
@@ -638,7 +638,7 @@ def sao_case(depth, width, height, seed):
     return y, rec, params
 
 
-@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 200, 150), (10, 192, 136), (8, 64, 64)])
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (8, 200, 150), (10, 192, 136), (8, 64, 64), (12, 192, 136)])
 def test_sao_restatement_equals_reference_class(depth, width, height):
     """oracle/x265_oracle_pipeline4.c's SAO passes against the real SAO class (oracle/ref_sao.cpp): calcSaoStatsCTU's count /
     offsetOrg of every CTU, type and class, and the picture after generateLumaOffsets over all CTUs - including pictures that
@@ -666,7 +666,7 @@ def test_sao_restatement_equals_reference_class(depth, width, height):
     assert (a != recp.reshape(rows, stride)[org // stride: org // stride + height, org % stride: org % stride + width]).any()
 
 
-@pytest.mark.parametrize("depth,level,qp,offs", [(8, 2, 32, (0, 0)), (8, 1, 30, (0, 0)), (8, 0, 27, (2, -1)), (10, 2, 44, (0, 0)), (10, 1, 36, (-2, 3))])
+@pytest.mark.parametrize("depth,level,qp,offs", [(8, 2, 32, (0, 0)), (8, 1, 30, (0, 0)), (8, 0, 27, (2, -1)), (10, 2, 44, (0, 0)), (10, 1, 36, (-2, 3)), (12, 1, 40, (1, -1))])
 def test_deblock_restatement_equals_reference_class(depth, level, qp, offs):
     """oracle/x265_oracle_pipeline4.c's boundary strengths + luma edge filter against the real Deblock::deblockCTU
     (oracle/ref_deblock.cpp) on a reconstruction the oracle chain itself produced (search -> sub-pel -> prediction / residual round
@@ -877,7 +877,7 @@ def test_chroma_intra_prediction_uses_unfiltered_neighbours_without_edge_smoothi
         assert ns[0] == 0 and dist[0] == 0 and np.array_equal(rec.reshape(n, n), src), f"mode {mode}"
 
 
-@pytest.mark.parametrize("depth,level,qp", [(8, 2, 30), (8, 0, 24), (10, 1, 38)])
+@pytest.mark.parametrize("depth,level,qp", [(8, 2, 30), (8, 0, 24), (10, 1, 38), (12, 1, 50)])
 def test_inter_tu_round_trip_equals_reference_quant_class(depth, level, qp):
     """Same for the inter TU stage (x265oracle_inter_recon) with zero motion, where the prediction is the reference picture itself."""
     import oracle_api as O
@@ -974,7 +974,7 @@ def test_sao_chroma_restatement_equals_reference_class(depth, width, height):
         assert (got != rec[c]).any() and cnt[:, :4, :5].sum() > 0
 
 
-@pytest.mark.parametrize("depth,level,qp", [(8, 0, 26), (8, 2, 32), (10, 1, 40)])
+@pytest.mark.parametrize("depth,level,qp", [(8, 0, 26), (8, 2, 32), (10, 1, 40), (12, 1, 52)])
 def test_chroma_inter_tu_round_trip_equals_reference_quant_class(depth, level, qp):
     """The chroma flavour of the inter TU stage (x265oracle_inter_recon_chroma, half-size blocks incl. the 4x4 DCT) with zero motion
     against the real Quant class: levels, numSig and reconstruction block by block."""
@@ -1035,7 +1035,7 @@ def test_search_driver_with_extra_candidates_equals_reference(depth):
     ref = F.pad_plane(clip[0][0])[0]
     es = cur.itemsize
     rng = np.random.default_rng([9, depth])
-    qp = 24 if depth == 8 else 12
+    qp = {8: 24, 10: 12, 12: 0}[depth]
     cq, qoff = F.qpel_cost_table(57, qmax=8 * 64 + 300)
     for method in (1, 2, 3):
         for subme in (1, 2, 5):

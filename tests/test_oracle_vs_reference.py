@@ -10,7 +10,7 @@ import harness as H
 import harness_host  # noqa: F401  (registers the handlers of the host-side slots)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", [8, 10, 12])
 def test_oracle_matches_reference_all_slots(depth, repo_root):
     ref = H.load_reference(depth, repo_root)
     if ref is None:
@@ -21,7 +21,7 @@ def test_oracle_matches_reference_all_slots(depth, repo_root):
     assert not fails, "\n".join(fails[:50])
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", [8, 10, 12])
 def test_null_pattern_matches_reference(depth, repo_root):
     """Exactly the slots the reference's cprim populates (setupCPrimitives + setupAliasPrimitives), all 2280 checked."""
     ref = H.load_reference(depth, repo_root)

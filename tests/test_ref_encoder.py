@@ -69,7 +69,7 @@ def oracle_filler(depth, root):
     return cb, orc
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", [8, 10, 12])
 @pytest.mark.parametrize("preset", ["ultrafast", "medium", "slow"])
 def test_oracle_table_gives_reference_bitstream(depth, preset, repo_root):
     lib = ref_lib(depth, repo_root)
