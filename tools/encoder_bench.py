@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Encoder-level measurement, SURVEY.md section 8(d)(iii) / tier T3: the REAL reference encoder (oracle/_ref/libx265ref<depth>.so =
+x265 3.5 compiled from /root/reference by oracle/Makefile, C primitives, no asm - nasm is not in the image) on the synthetic clip of
+each BASELINE.json configuration, once per primitive-table flavour:
+
+    c      the reference's own C table (setupCPrimitives + aliases)            -> the host-CPU baseline, kind "reference"
+    hip    1816 slots served by libx265hip.so's per-call stubs (table layer)   -> drop-in, byte-identical, launch-bound
+    seam   C table + the stage-level seam (oracle/ref_seam.cpp): MotionEstimate::motionEstimate replays its integer search on the
+           SAD surfaces one x265hip_me_fullsearch launch per (picture, reference) produced (batch layer)
+
+fps = frames / seconds of the encode loop (what encoder.cpp:2708 prints), bitstreams compared by md5 (--no-info, CRF, fixed
+frame threads: SURVEY section 4 determinism rules).  Used by `bench.py --encoder`; test infrastructure, not product code.
+
+  python tools/encoder_bench.py [--configs cfg1,cfg2,cfg3] [--frames N] [--tables c,hip,seam] [--budget-s S]
+"""
+import argparse
+import ctypes
+import hashlib
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs -> (width, height, depth, preset, extra options, default frame count for the C table)
+CONFIGS = {
+    "cfg1": dict(width=1280, height=720, depth=8, preset="ultrafast", opts=[("keyint", "1")], frames=8,
+                 name="configs[0]: 720p 8-bit --preset ultrafast --keyint 1"),
+    "cfg2": dict(width=1920, height=1080, depth=8, preset="medium", opts=[], frames=6,
+                 name="configs[1]: 1080p 8-bit --preset medium"),
+    "cfg3": dict(width=3840, height=2160, depth=8, preset="slow", opts=[("me", "star")], frames=4,
+                 name="configs[2]: 2160p 8-bit --preset slow --me star"),
+    "cfg4": dict(width=3840, height=2160, depth=10, preset="slower", opts=[], frames=3,
+                 name="configs[3]: 2160p 10-bit --preset slower (one GPU's share of the frame-parallel job)"),
+}
+FILL = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int)
+
+
+def ref_lib(depth):
+    path = os.path.join(ROOT, "oracle", "_ref", f"libx265ref{depth}.so")
+    if not os.path.exists(path):
+        raise SystemExit(f"{path} missing: the real-reference build (make -C oracle ref) only exists where /root/reference does; "
+                         "the built .so travels to the GPU box with the snapshot")
+    lib = ctypes.CDLL(path)
+    lib.x265ref_encode.restype = ctypes.c_long
+    lib.x265ref_encode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
+                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long,
+                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    return lib
+
+
+def encode(lib, yuv, w, h, nframes, preset, opts, filler=None):
+    out = np.zeros(64 << 20, np.uint8)
+    arr = (ctypes.c_char_p * (2 * len(opts)))()
+    for i, (k, v) in enumerate(opts):
+        arr[2 * i] = k.encode()
+        arr[2 * i + 1] = v.encode() if v is not None else None
+    sec, filled = ctypes.c_double(), ctypes.c_int()
+    n = lib.x265ref_encode(yuv.ctypes.data, w, h, nframes, preset.encode(), arr, len(opts), filler,
+                           out.ctypes.data, out.size, ctypes.byref(sec), ctypes.byref(filled))
+    if n <= 0:
+        raise RuntimeError(f"reference encode failed ({n})")
+    return hashlib.md5(out[:n].tobytes()).hexdigest(), int(n), sec.value, filled.value
+
+
+def effective_cpus():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sys.stderr):
+    F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+    cfg = CONFIGS[key]
+    w, h, depth = cfg["width"], cfg["height"], cfg["depth"]
+    n = frames or cfg["frames"]
+    cores = effective_cpus()
+    clip = F.synth_clip(w, h, n, depth=depth, seed=265)
+    yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
+    lib = ref_lib(depth)
+    opts = [("pools", str(cores)), ("frame-threads", str(frame_threads)), ("crf", "28")] + cfg["opts"]
+    res = {"config": cfg["name"], "size": f"{w}x{h}", "depth": depth, "preset": cfg["preset"], "options": dict(opts), "pool_threads": cores,
+           "reference_build": "x265 3.5 C primitives (no asm: nasm is not in the image), g++ -O2"}
+    md5_c = None
+    for t in tables:
+        nf = n
+        filler, note = None, None
+        if t == "hip":
+            A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+            L = A.lib()
+            filler = ctypes.cast(L.x265hip_setup_primitives, ctypes.c_void_p)
+            calls0 = L.x265hip_table_calls()
+            c = res.get("c")
+            if c and budget_s:         # per-call stubs cost ~20 us per primitive call: shorten the clip so the leg fits the budget
+                est_calls = c.get("est_primitive_calls_per_frame", 0)
+                # measured on the first frames below; start from 2 frames, never less
+                nf = max(2, min(n, int(budget_s / max(1e-9, est_calls * 20e-6 / max(1, min(cores, 8)))))) if est_calls else min(n, 2)
+        elif t == "seam":
+            seam = importlib.import_module("tools.seam_driver") if os.path.exists(os.path.join(ROOT, "tools", "seam_driver.py")) else None
+            if seam is None:
+                continue
+            filler, note = seam.install(lib, depth, w, h, dict(opts))
+        t0 = time.perf_counter()
+        md5, nbytes, sec, filled = encode(lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
+        wall = time.perf_counter() - t0
+        r = {"frames": nf, "seconds": round(sec, 3), "fps": round(nf / sec, 4), "bytes": nbytes, "md5": md5, "slots_replaced": filled,
+             "wall_seconds_with_open_close": round(wall, 3)}
+        if t == "c":
+            md5_c = {nf: md5}
+            # SURVEY section 6 call-rate probe (counting thunks, 1080p): medium ~3.0 M, slow ~3.4 M primitive calls per frame; scale by area
+            per_1080p = {"ultrafast": 1.2e6, "medium": 3.0e6, "slow": 3.4e6, "slower": 6e6}.get(cfg["preset"], 3e6)
+            r["est_primitive_calls_per_frame"] = int(per_1080p * (w * h) / (1920 * 1080))
+        else:
+            if nf not in md5_c:      # the C table on the same shortened clip, for the md5 comparison
+                md5_c[nf] = encode(lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, None)[0]
+            r["md5_equal_to_c_table"] = md5 == md5_c[nf]
+            if t == "hip":
+                r["primitive_calls_through_gpu"] = int(L.x265hip_table_calls() - calls0)
+                r["us_per_primitive_call"] = round(1e6 * sec / max(1, r["primitive_calls_through_gpu"]), 2)
+            if note:
+                r["seam"] = note() if callable(note) else note
+        res[t] = r
+        print(f"[encoder] {key} {t}: {json.dumps(r)}", file=log, flush=True)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="cfg1,cfg2,cfg3")
+    ap.add_argument("--tables", default="c,hip")
+    ap.add_argument("--frames", type=int, default=0)
+    ap.add_argument("--frame-threads", type=int, default=1)
+    ap.add_argument("--budget-s", type=float, default=240.0, help="target seconds for one per-call-stub (hip) leg; the clip is shortened to fit")
+    args = ap.parse_args()
+    out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s) for k in args.configs.split(",")}
+    print(json.dumps({"encoder": out}))
+
+
+if __name__ == "__main__":
+    main()
