@@ -484,6 +484,13 @@ typedef struct x265hip_sao_apply_params
     int ctu_width, ctu_height;     /* as in x265hip_sao_stats_params */
 } x265hip_sao_apply_params;
 int x265hip_sao_apply(const x265hip_sao_apply_params* p, void* stream);
+/* x265hip_sao_decide: the parameters between the two passes for a pipeline that never leaves the device - for every CTU
+ * SAO::saoStatsInitialOffset (sao.cpp:1378-1433, exact) and a DISTORTION-ONLY choice of the type (smallest sum of estSaoDist,
+ * sao.cpp:56-59, over EO_0..EO_3 and the best four-band window of BO; off when nothing gains).  A documented stand-in for the
+ * entropy-coder-driven rdoSaoUnitCu (sao.cpp:1225-1605: rate terms, offset iteration, merge candidates), which stays host work.
+ *   count / offset_org : DEVICE int32 [nctu][5][32] from x265hip_sao_stats;  init_offset : optional DEVICE int32 [nctu][5][32]
+ *   (SAO::m_offset);  ctu_params : DEVICE int32 [nctu][7] in x265hip_sao_apply's format. */
+int x265hip_sao_decide(int depth, const int32_t* count, const int32_t* offset_org, int nctu, int32_t* init_offset, int32_t* ctu_params, void* stream);
 
 /* ------------------------------------------------------------------ generic job-list entry points
  * Every remaining family evaluates `njobs` independent blocks of one size per launch.  An operand
@@ -593,6 +600,60 @@ enum x265hip_lf_kind
 };
 int x265hip_loopfilter_batch(int kind, int depth, const x265hip_plane planes[4], const x265hip_job* jobs, int njobs,
                              uint32_t* result, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Frame-granular CONSUMER of the exhaustive search (csrc/me_cache.hip): host planes in, SAD surfaces in pinned host memory
+ * out, one launch per (source picture, reference picture); the encoder's sad / sad_x3 / sad_x4 stubs look the results up
+ * (SURVEY.md section 7 step 6).  Serves the call sites motion.cpp:228-328, :397-604, :1069-1083, :1397-1445 without touching
+ * the decision code; a lookup that cannot be served (row not there yet, displacement outside the window, PU not a union of
+ * 8x8 blocks) falls back to the host's own primitive - identical values either way.
+ *   width, height : whole CTUs (multiples of 64);  stride / margin_x / margin_y : the PicYuv geometry (picyuv.cpp:87-114),
+ *                   buffers handed to submit are the WHOLE allocated planes: stride * (height + 2 * margin_y) samples
+ *   range         : surfaces cover displacements [-range, range]^2 around each CTU's own position
+ *   slots         : number of (source, reference) pairs resident in host memory at once */
+typedef struct x265hip_me_cache x265hip_me_cache;
+typedef struct x265hip_me_cache_params
+{
+    int depth;
+    int width, height;
+    intptr_t stride;
+    int margin_x, margin_y;
+    int range;
+    int surf_format;                /* X265HIP_SURF_PACKED (8-bit) or X265HIP_SURF_I32 */
+    int slots;
+} x265hip_me_cache_params;
+typedef struct x265hip_me_cache_stats_t
+{
+    uint64_t fills, failed;
+    uint64_t us_upload, us_kernel, us_download;     /* summed over the fills, worker-thread wall time */
+    uint64_t bytes_downloaded, surface_bytes;
+} x265hip_me_cache_stats_t;
+int  x265hip_me_cache_create(x265hip_me_cache** out, const x265hip_me_cache_params* p);
+void x265hip_me_cache_destroy(x265hip_me_cache* c);
+/* copies both planes, queues upload + search + row-streamed download on the cache's worker thread, returns the slot's new
+ * GENERATION (> 0) at once, or a negative error */
+int  x265hip_me_cache_submit(x265hip_me_cache* c, int slot, const void* fenc_buf, uint64_t fenc_key, const void* ref_buf);
+const void* x265hip_me_cache_surface(x265hip_me_cache* c, int slot);
+/* int [height / 64]: CTU row r of the slot is complete when ready[r] == the generation submit returned */
+const volatile int* x265hip_me_cache_ready(x265hip_me_cache* c, int slot);
+int  x265hip_me_cache_stats(x265hip_me_cache* c, x265hip_me_cache_stats_t* st);
+
+/* Address arithmetic of a surface record (both formats), usable from any host language: the SAD of square PU `z` (z-order
+ * index inside its level; level 0..3 = 8x8, 16x16, 32x32, 64x64) of CTU `ctu` at displacement (dx, dy), |dx|, |dy| <= range. */
+static inline int32_t x265hip_surf_lookup(const void* surf, int surf_format, int range, int ctu, int level, int z, int dx, int dy)
+{
+    const int nc = 2 * range + 1, ng = (nc + 3) >> 2, col = dx + range;
+    const size_t gb = surf_format == X265HIP_SURF_PACKED ? X265HIP_SURF_GROUP_BYTES_PACKED : X265HIP_SURF_GROUP_BYTES_I32;
+    const unsigned char* g = (const unsigned char*)surf + (((size_t)ctu * nc + (size_t)(dy + range)) * ng + (size_t)(col >> 2)) * gb;
+    if (surf_format == X265HIP_SURF_PACKED)
+    {
+        if (level < 2) return ((const uint16_t*)(g + (level ? 512 : 0)))[z * 4 + (col & 3)];
+        return ((const int32_t*)(g + (level == 2 ? 640 : 704)))[z * 4 + (col & 3)];
+    }
+    static const int base[4] = { 0, 64, 80, 84 };
+    return ((const int32_t*)g)[(base[level] + z) * 4 + (col & 3)];
+}
 
 #ifdef __cplusplus
 }

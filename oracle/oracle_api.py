@@ -375,6 +375,19 @@ def sao_stats(depth, fenc, rec, stride, org, width, height, nthreads=0, avx2=Fal
     return cnt, off
 
 
+def sao_decide(depth, count, offset_org, avx2=False):
+    """CPU restatement of SAO::saoStatsInitialOffset (sao.cpp:1378-1433) + the distortion-only type choice (see x265hip_sao_decide).
+    count / offset_org int32 [numCtu, 5, 32].  Returns (initial offsets int32 [numCtu, 5, 32], params int32 [numCtu, 7])."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_sao_decide_d{depth}")
+    c = np.ascontiguousarray(count, dtype=np.int32).reshape(-1, 160)
+    o = np.ascontiguousarray(offset_org, dtype=np.int32).reshape(-1, 160)
+    init, params = np.zeros((c.shape[0], 5, 32), np.int32), np.zeros((c.shape[0], 7), np.int32)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert fn(c.ctypes.data, o.ctypes.data, c.shape[0], init.ctypes.data, params.ctypes.data) == 0
+    return init, params
+
+
 def sao_apply(depth, src, stride, org, width, height, params, nthreads=0, avx2=False, ctu=(64, 64)):
     """CPU restatement of SAO::generateLumaOffsets / applyPixelOffsets (sao.cpp:572-630, 274-570) for every CTU; params int32
     [numCtu, 7] = typeIdx, bandPos, offset[4], mergeLeft.  Returns the offset picture (a copy of src outside the picture area)."""

@@ -29,7 +29,9 @@ struct SaoProbe : public SAO
     using SAO::m_count;
     using SAO::m_offsetOrg;
     using SAO::m_tmpU;
+    using SAO::m_offset;
 };
+std::vector<int32_t> g_lastInitialOffsets;      /* SAO::m_offset[0] after saoStatsInitialOffset(addr, 0), per CTU of the last x265ref_sao call */
 }
 
 extern "C" {
@@ -109,6 +111,9 @@ int x265ref_sao(const void* fencPlane, void* recPlane, int width, int height, co
         sao.calcSaoStatsCTU(a, 0);
         memcpy(count + (size_t)a * 5 * 32, sao.m_count[0], sizeof(int32_t) * 5 * 32);
         memcpy(offsetOrg + (size_t)a * 5 * 32, sao.m_offsetOrg[0], sizeof(int32_t) * 5 * 32);
+        sao.saoStatsInitialOffset(a, 0);                       /* sao.cpp:1378-1433 */
+        g_lastInitialOffsets.resize((size_t)numCtu * 5 * 32);
+        memcpy(g_lastInitialOffsets.data() + (size_t)a * 5 * 32, sao.m_offset[0], sizeof(int32_t) * 5 * 32);
     }
 
     /* apply: the above-row reference comes from the picture before any offset was applied */
@@ -266,3 +271,10 @@ int x265ref_sao_chroma(const void* const* fencC, void* const* recC, int width, i
 }
 
 } // extern "C"
+
+extern "C" int x265ref_sao_last_initial_offsets(int32_t* out, int numCtu)
+{
+    if ((size_t)numCtu * 160 != g_lastInitialOffsets.size()) return -1;
+    memcpy(out, g_lastInitialOffsets.data(), sizeof(int32_t) * g_lastInitialOffsets.size());
+    return 0;
+}

@@ -1,0 +1,370 @@
+/* oracle/ref_seam.cpp - TEST INFRASTRUCTURE: the REFERENCE-SIDE BINDING of the stage-level seam, i.e.
+ * what a maintainer of the reference would add to consume libx265hip's frame-granular motion-search results.  Never part of the
+ * product path; compiled by oracle/Makefile together with the reference's own sources into oracle/_ref/libx265ref<depth>_seam.so.
+ *
+ * Mechanism (no reference source is modified or copied):
+ *   * oracle/Makefile renames the symbol of MotionEstimate::motionEstimate in the reference's compiled encoder/motion.o to
+ *     x265ref_orig_motionEstimate (objcopy --redefine-sym) and this file supplies MotionEstimate::motionEstimate: a wrapper that
+ *     identifies (source picture, reference picture, CTU, PU) for the calling worker thread, makes sure the pair's SAD surfaces
+ *     have been requested from the provider (ONE exhaustive-search launch per pair, x265hip_me_cache_submit), publishes a
+ *     thread-local lookup context and then runs the reference's own, untouched search (all --me methods, all its quirks).
+ *   * the table filler x265ref_seam_fill_table() replaces pu[].sad / sad_x3 / sad_x4 (primitives.h:247-249) of the partitions
+ *     that are unions of 8x8 blocks with LOOKUP stubs: inside a wrapped search they translate the reference pointer into a
+ *     displacement and read the SAD from the surfaces (summing the square sub-blocks of rectangular / asymmetric partitions);
+ *     anything else - other callers, a CTU row whose surfaces have not arrived, displacements outside the window - goes to the
+ *     host's original primitive.  Both routes return the same integers, so the bitstream cannot change; with
+ *     X265REF_SEAM_VERIFY=1 every lookup is checked against the original primitive on the spot.
+ * Requires --frame-threads 1 (a reference picture must be complete when the first PU of the next picture searches it; the
+ * reference's row-lagged frame parallelism would need per-row submits) and unweighted references; otherwise it stays out of the way.
+ *
+ * The provider is a table of C function pointers with the signatures of x265hip_me_cache_submit / _surface / _ready
+ * (include/x265hip.h), so the GPU library plugs in directly; the CPU-only tests plug in the oracle's exhaustive search instead. */
+#include "common.h"
+#include "primitives.h"
+#include "constants.h"
+#include "picyuv.h"
+#include "frame.h"
+#include "framedata.h"
+#include "slice.h"
+#include "search.h"
+#include "motion.h"
+#include "reference.h"
+
+#include <atomic>
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+using namespace X265_NS;
+
+extern "C" int x265ref_orig_motionEstimate(MotionEstimate* self, ReferencePlanes* ref, const MV* mvmin, const MV* mvmax, const MV* qmvp,
+                                           int numCandidates, const MV* mvc, int merange, MV* outQMv, uint32_t maxSlices, pixel* srcReferencePlane);
+
+namespace {
+
+enum { SURF_I32 = 0, SURF_PACKED = 1, GROUP_I32 = 1360, GROUP_PACKED = 720, MAX_PARTS = 6, MAX_SLOTS = 64 };
+
+struct Provider
+{
+    void* ctx;
+    int (*submit)(void* ctx, int slot, const void* fenc_buf, uint64_t fenc_key, const void* ref_buf);
+    const void* (*surface)(void* ctx, int slot);
+    const volatile int* (*ready)(void* ctx, int slot);
+    int range, surf_format, slots;
+    int width, height;            /* whole CTUs */
+    intptr_t stride;
+    int margin_x, margin_y;
+    int min_pu;                   /* serve partitions whose smaller side is >= min_pu (8, 16, 32 or 64) */
+};
+
+struct Pair { int fencPoc; const PicYuv* rec; int recPoc; int slot; int gen; bool used; };
+
+struct Seam
+{
+    bool enabled = false, verify = false;
+    Provider p;
+    int nc, ng, groupBytes, ctusW;
+    size_t ctuBytes;
+    std::mutex mu;
+    Pair pairs[MAX_SLOTS];
+    std::atomic<int> epoch{0};          /* bumped on every (re)assignment of a slot: invalidates the thread-local pair caches */
+    pixelcmp_t sad[NUM_PU_SIZES];
+    pixelcmp_x3_t sad_x3[NUM_PU_SIZES];
+    pixelcmp_x4_t sad_x4[NUM_PU_SIZES];
+    std::atomic<uint64_t> hits{0}, outside{0}, notReady{0}, meCalls{0}, meServed{0}, submits{0}, mismatches{0}, noSlot{0}, foreign{0};
+} g;
+
+struct Part { uint16_t off; uint16_t wide; };      /* byte offset of entry [z][0] inside a group record; wide = int32 entries */
+
+struct Ctx
+{
+    bool valid;
+    int part;                 /* LumaPU enum of the PU being searched */
+    const pixel* fenc;
+    const pixel* fref0;       /* reference pointer of displacement (0,0) */
+    intptr_t stride;
+    ptrdiff_t bias;           /* range * stride + range */
+    const uint8_t* ctuBase;   /* surfaces of this CTU */
+    const volatile int* ready;
+    int ctuRow, gen, nparts;
+    Part parts[MAX_PARTS];
+    uint64_t hits, outside, notReady;
+};
+thread_local Ctx t_ctx;
+struct TlsPair { const PicYuv* rec; int recPoc; int slot; int gen; };
+thread_local struct { int fencPoc; int epoch; int n; TlsPair e[8]; } t_pairs = { -0x7fffffff, -1, 0, {} };
+
+/* width / height per LumaPU enum (primitives.h:41-55); the reference never sets MotionEstimate::blockheight (motion.cpp:178,217) */
+const int PU_DIMS[NUM_PU_SIZES][2] = { {4,4},{8,8},{16,16},{32,32},{64,64},{8,4},{4,8},{16,8},{8,16},{32,16},{16,32},{64,32},{32,64},
+                                       {16,12},{12,16},{16,4},{4,16},{32,24},{24,32},{32,8},{8,32},{64,48},{48,64},{64,16},{16,64} };
+
+/* decompose the PU rectangle (CTU-relative, multiples of 8) into the squares the surfaces hold, quadtree order */
+bool decompose(int px, int py, int w, int h, int bx, int by, int size, Ctx& c)
+{
+    const int x0 = bx > px ? bx : px, x1 = (bx + size < px + w) ? bx + size : px + w;
+    const int y0 = by > py ? by : py, y1 = (by + size < py + h) ? by + size : py + h;
+    if (x0 >= x1 || y0 >= y1) return true;                                 /* no overlap */
+    if (x1 - x0 == size && y1 - y0 == size)                                /* fully inside */
+    {
+        if (c.nparts == MAX_PARTS) return false;
+        const int level = size == 8 ? 0 : size == 16 ? 1 : size == 32 ? 2 : 3;
+        const int ux = bx / size, uy = by / size;
+        int z = 0;
+        for (int b = 0; b < 3; b++) z |= ((ux >> b) & 1) << (2 * b) | ((uy >> b) & 1) << (2 * b + 1);
+        Part& q = c.parts[c.nparts++];
+        if (g.p.surf_format == SURF_PACKED)
+        {
+            static const int base[4] = { 0, 512, 640, 704 };
+            q.wide = level >= 2;
+            q.off = (uint16_t)(base[level] + z * (q.wide ? 16 : 8));
+        }
+        else
+        {
+            static const int base[4] = { 0, 64, 80, 84 };
+            q.wide = 1;
+            q.off = (uint16_t)((base[level] + z) * 16);
+        }
+        return true;
+    }
+    if (size == 8) return false;                                           /* a partial 8x8 block: not derivable */
+    const int hs = size >> 1;
+    return decompose(px, py, w, h, bx, by, hs, c) && decompose(px, py, w, h, bx + hs, by, hs, c) &&
+           decompose(px, py, w, h, bx, by + hs, hs, c) && decompose(px, py, w, h, bx + hs, by + hs, hs, c);
+}
+
+inline bool lookup(Ctx& c, const pixel* fref, int& out)
+{
+    const ptrdiff_t t = (fref - c.fref0) + c.bias;
+    if (t < 0) { c.outside++; return false; }
+    const uint64_t row = (uint64_t)t / (uint64_t)c.stride, col = (uint64_t)t - row * (uint64_t)c.stride;
+    const uint64_t span = 2 * (uint64_t)g.p.range;
+    if (row > span || col > span) { c.outside++; return false; }
+    if (c.ready[c.ctuRow] != c.gen) { c.notReady++; return false; }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const uint8_t* rec = c.ctuBase + (row * g.ng + (col >> 2)) * g.groupBytes;
+    const int k = (int)(col & 3);
+    int sum = 0;
+    for (int i = 0; i < c.nparts; i++)
+        sum += c.parts[i].wide ? ((const int32_t*)(rec + c.parts[i].off))[k] : ((const uint16_t*)(rec + c.parts[i].off))[k];
+    c.hits++;
+    out = sum;
+    return true;
+}
+
+void verify_fail(int part, int got, int want)
+{
+    g.mismatches++;
+    fprintf(stderr, "ref_seam: VERIFY MISMATCH partition %d: surface %d, primitive %d\n", part, got, want);
+    abort();
+}
+
+template <int P> int sad_seam(const pixel* fenc, intptr_t fstride, const pixel* fref, intptr_t rstride)
+{
+    Ctx& c = t_ctx;
+    int v;
+    if (c.valid && c.part == P && fenc == c.fenc && rstride == c.stride && lookup(c, fref, v))
+    {
+        if (g.verify) { const int w = g.sad[P](fenc, fstride, fref, rstride); if (w != v) verify_fail(P, v, w); }
+        return v;
+    }
+    return g.sad[P](fenc, fstride, fref, rstride);
+}
+
+template <int P, int N> inline void sad_xn_seam(const pixel* fenc, const pixel* const* r, intptr_t rstride, int32_t* res)
+{
+    Ctx& c = t_ctx;
+    for (int i = 0; i < N; i++)
+    {
+        int v;
+        if (lookup(c, r[i], v))
+        {
+            if (g.verify) { const int w = g.sad[P](fenc, FENC_STRIDE, r[i], rstride); if (w != v) verify_fail(P, v, w); }
+            res[i] = v;
+        }
+        else
+            res[i] = g.sad[P](fenc, FENC_STRIDE, r[i], rstride);      /* sad_x3 / sad_x4 are N independent SADs (pixel.cpp:74-119) */
+    }
+}
+template <int P> void sad_x3_seam(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, intptr_t rstride, int32_t* res)
+{
+    Ctx& c = t_ctx;
+    if (c.valid && c.part == P && fenc == c.fenc && rstride == c.stride) { const pixel* r[3] = { r0, r1, r2 }; sad_xn_seam<P, 3>(fenc, r, rstride, res); }
+    else g.sad_x3[P](fenc, r0, r1, r2, rstride, res);
+}
+template <int P> void sad_x4_seam(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rstride, int32_t* res)
+{
+    Ctx& c = t_ctx;
+    if (c.valid && c.part == P && fenc == c.fenc && rstride == c.stride) { const pixel* r[4] = { r0, r1, r2, r3 }; sad_xn_seam<P, 4>(fenc, r, rstride, res); }
+    else g.sad_x4[P](fenc, r0, r1, r2, r3, rstride, res);
+}
+
+template <int P> struct Install
+{
+    static void run(EncoderPrimitives& t, int& n)
+    {
+        const int w = PU_DIMS[P][0], h = PU_DIMS[P][1];
+        g.sad[P] = t.pu[P].sad; g.sad_x3[P] = t.pu[P].sad_x3; g.sad_x4[P] = t.pu[P].sad_x4;
+        if (!(w & 7) && !(h & 7) && (w < h ? w : h) >= g.p.min_pu && t.pu[P].sad)
+        {
+            t.pu[P].sad = sad_seam<P>; t.pu[P].sad_x3 = sad_x3_seam<P>; t.pu[P].sad_x4 = sad_x4_seam<P>;
+            n += 3;
+        }
+        Install<P + 1>::run(t, n);
+    }
+};
+template <> struct Install<NUM_PU_SIZES> { static void run(EncoderPrimitives&, int&) {} };
+
+/* slot of (source picture poc, reference picture), requesting the surfaces when the pair is new; -1 when none can be had */
+int pair_slot(int fencPoc, const PicYuv* fencPic, const PicYuv* rec, int recPoc, int& gen)
+{
+    const int epoch = g.epoch.load(std::memory_order_acquire);
+    if (t_pairs.fencPoc != fencPoc || t_pairs.epoch != epoch) { t_pairs.fencPoc = fencPoc; t_pairs.epoch = epoch; t_pairs.n = 0; }
+    for (int i = 0; i < t_pairs.n; i++)
+        if (t_pairs.e[i].rec == rec && t_pairs.e[i].recPoc == recPoc) { gen = t_pairs.e[i].gen; return t_pairs.e[i].slot; }
+    int slot = -1;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        int freeSlot = -1;
+        for (int i = 0; i < g.p.slots; i++)
+        {
+            Pair& q = g.pairs[i];
+            if (q.used && q.fencPoc == fencPoc && q.rec == rec && q.recPoc == recPoc) { slot = i; gen = q.gen; break; }
+            if (freeSlot < 0 && (!q.used || q.fencPoc != fencPoc)) freeSlot = i;     /* surfaces of an earlier picture: its encode is over (-F 1) */
+        }
+        if (slot < 0 && freeSlot >= 0)
+        {
+            const int rc = g.p.submit(g.p.ctx, freeSlot, fencPic->m_picBuf[0], (uint64_t)(uint32_t)fencPoc, rec->m_picBuf[0]);
+            if (rc > 0)
+            {
+                Pair& q = g.pairs[freeSlot];
+                q.used = true; q.fencPoc = fencPoc; q.rec = rec; q.recPoc = recPoc; q.slot = freeSlot; q.gen = rc;
+                slot = freeSlot; gen = rc;
+                g.submits++;
+                g.epoch.fetch_add(1, std::memory_order_release);
+                t_pairs.epoch = g.epoch.load(); t_pairs.n = 0;
+            }
+        }
+    }
+    if (slot < 0) { g.noSlot++; return -1; }
+    if (t_pairs.n < 8) { TlsPair& e = t_pairs.e[t_pairs.n++]; e.rec = rec; e.recPoc = recPoc; e.slot = slot; e.gen = gen; }
+    return slot;
+}
+
+} // namespace
+
+/* the seam: same signature, same symbol as the reference's function (whose compiled body now answers to x265ref_orig_motionEstimate) */
+int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const MV& mvmax, const MV& qmvp, int numCandidates, const MV* mvc,
+                                   int merange, MV& outQMv, uint32_t maxSlices, pixel* srcReferencePlane)
+{
+    Ctx& c = t_ctx;
+    c.valid = false;
+    if (g.enabled)
+    {
+        g.meCalls.fetch_add(1, std::memory_order_relaxed);
+        if (ctuAddr >= 0 && !srcReferencePlane && !ref->isLowres && !ref->isWeighted && ref->reconPic && partEnum >= 0 && partEnum < NUM_PU_SIZES &&
+            PU_DIMS[partEnum][0] == blockwidth && !(blockwidth & 7) && !(PU_DIMS[partEnum][1] & 7))
+        {
+            /* a MotionEstimate with ctuAddr >= 0 is the m_me member of a Search (search.h:257; the lookahead's instances use the other
+             * setSourcePU overload, ctuAddr -1) */
+            const Search* s = reinterpret_cast<const Search*>(reinterpret_cast<const char*>(this) - offsetof(Search, m_me));
+            const Frame* frame = s->m_frame;
+            const PicYuv* rec = ref->reconPic;
+            const PicYuv* src = frame ? frame->m_fencPic : NULL;
+            if (src && s->m_param->frameNumThreads == 1 && ref->fpelPlane[0] == rec->m_picOrg[0] &&
+                rec->m_stride == g.p.stride && src->m_stride == g.p.stride && (int)rec->m_lumaMarginX == g.p.margin_x && (int)rec->m_lumaMarginY == g.p.margin_y &&
+                (int)src->m_lumaMarginX == g.p.margin_x && (int)src->m_lumaMarginY == g.p.margin_y && s->m_param->maxCUSize == 64)
+            {
+                /* which reference picture: ref points into slice->m_mref[list][idx] (slice.h:337) */
+                const Slice* slice = s->m_slice;
+                const ptrdiff_t idx = static_cast<const MotionReference*>(ref) - &slice->m_mref[0][0];
+                int recPoc = -0x7fffffff;
+                if (idx >= 0 && idx < 2 * (MAX_NUM_REF + 1))
+                    recPoc = slice->m_refPOCList[idx / (MAX_NUM_REF + 1)][idx % (MAX_NUM_REF + 1)];
+                int gen = 0;
+                const int slot = recPoc == -0x7fffffff ? -1 : pair_slot(frame->m_poc, src, rec, recPoc, gen);
+                if (slot >= 0)
+                {
+                    c.nparts = 0;
+                    const int px = g_zscanToPelX[absPartIdx], py = g_zscanToPelY[absPartIdx];
+                    if (decompose(px, py, blockwidth, PU_DIMS[partEnum][1], 0, 0, 64, c) && c.nparts)
+                    {
+                        c.part = partEnum;
+                        c.fenc = fencPUYuv.m_buf[0];
+                        const intptr_t off = rec->getLumaAddr(ctuAddr, absPartIdx) - rec->getLumaAddr(0);
+                        c.fref0 = ref->fpelPlane[0] + off;
+                        c.stride = ref->lumaStride;
+                        c.bias = (ptrdiff_t)g.p.range * c.stride + g.p.range;
+                        c.ctuBase = (const uint8_t*)g.p.surface(g.p.ctx, slot) + (size_t)ctuAddr * g.ctuBytes;
+                        c.ready = g.p.ready(g.p.ctx, slot);
+                        c.ctuRow = ctuAddr / g.ctusW;
+                        c.gen = gen;
+                        c.hits = c.outside = c.notReady = 0;
+                        c.valid = true;
+                    }
+                }
+            }
+            else
+                g.foreign.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
+    const int cost = x265ref_orig_motionEstimate(this, ref, &mvmin, &mvmax, &qmvp, numCandidates, mvc, merange, &outQMv, maxSlices, srcReferencePlane);
+    if (c.valid)
+    {
+        c.valid = false;
+        g.meServed.fetch_add(1, std::memory_order_relaxed);
+        g.hits.fetch_add(c.hits, std::memory_order_relaxed);
+        g.outside.fetch_add(c.outside, std::memory_order_relaxed);
+        g.notReady.fetch_add(c.notReady, std::memory_order_relaxed);
+    }
+    return cost;
+}
+
+extern "C" {
+
+/* provider: see the header comment; geometry = the PicYuv layout of the encode about to start.  Call before x265ref_encode. */
+int x265ref_seam_configure(void* ctx, void* submit, void* surface, void* ready, int range, int surf_format, int slots,
+                           int width, int height, intptr_t stride, int margin_x, int margin_y, int min_pu, int verify)
+{
+    if (slots < 1 || slots > MAX_SLOTS || range < 1 || (width & 63) || (height & 63)) return -1;
+    if (surf_format == SURF_PACKED && X265_DEPTH != 8) return -2;
+    g.p.ctx = ctx;
+    g.p.submit = (int (*)(void*, int, const void*, uint64_t, const void*))submit;
+    g.p.surface = (const void* (*)(void*, int))surface;
+    g.p.ready = (const volatile int* (*)(void*, int))ready;
+    g.p.range = range; g.p.surf_format = surf_format; g.p.slots = slots;
+    g.p.width = width; g.p.height = height; g.p.stride = stride; g.p.margin_x = margin_x; g.p.margin_y = margin_y;
+    g.p.min_pu = min_pu < 8 ? 8 : min_pu;
+    g.nc = 2 * range + 1; g.ng = (g.nc + 3) >> 2;
+    g.groupBytes = surf_format == SURF_PACKED ? GROUP_PACKED : GROUP_I32;
+    g.ctusW = width / 64;
+    g.ctuBytes = (size_t)g.nc * g.ng * g.groupBytes;
+    memset(g.pairs, 0, sizeof(g.pairs));
+    g.verify = verify != 0 || (getenv("X265REF_SEAM_VERIFY") && atoi(getenv("X265REF_SEAM_VERIFY")));
+    g.hits = g.outside = g.notReady = g.meCalls = g.meServed = g.submits = g.mismatches = g.noSlot = g.foreign = 0;
+    g.epoch.fetch_add(1);
+    g.enabled = true;
+    return 0;
+}
+
+void x265ref_seam_disable(void) { g.enabled = false; }
+
+/* table filler with the x265hip_setup_primitives signature: installs the lookup stubs over the host's own sad family */
+int x265ref_seam_fill_table(void* table, size_t bytes, int depth)
+{
+    if (!table || bytes != sizeof(EncoderPrimitives) || depth != X265_DEPTH || !g.enabled) return -1;
+    int n = 0;
+    Install<0>::run(*static_cast<EncoderPrimitives*>(table), n);
+    return n;
+}
+
+/* out[10]: lookups served, outside the window, row not ready, motionEstimate calls, calls with a lookup context, pair submits,
+ * verify mismatches, calls without a free slot, calls on foreign geometry / frame threads, verify flag */
+void x265ref_seam_stats(uint64_t* out)
+{
+    out[0] = g.hits; out[1] = g.outside; out[2] = g.notReady; out[3] = g.meCalls; out[4] = g.meServed; out[5] = g.submits;
+    out[6] = g.mismatches; out[7] = g.noSlot; out[8] = g.foreign; out[9] = g.verify;
+}
+
+} // extern "C"

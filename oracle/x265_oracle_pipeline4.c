@@ -410,3 +410,56 @@ int EXPORT(x265oracle_sao_apply_plane)(const pixel* src, pixel* dst, intptr_t st
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * SAO parameters on the device's side of the seam: SAO::saoStatsInitialOffset (sao.cpp:1378-1433, exact: roundIBDI (:34-37) of
+ * offsetOrg / count, clipped to +-(OFFSET_THRESH - 1) with OFFSET_THRESH = 1 << min(depth - 5, 5), the sign constraint of the edge
+ * classes) followed by a DISTORTION-ONLY choice of the type: the type (EO_0..EO_3, then BO with its best window of four
+ * consecutive bands, first minimum wins) whose initial offsets give the smallest sum of estSaoDist (:56-59), off when no sum is
+ * negative.  That choice is a documented stand-in for rdoSaoUnitCu / saoLumaComponentParamDist (:1225-1605), which iterate the
+ * offsets against CABAC bit counts and try the merge candidates - entropy-coder work that stays with the host.
+ *   initOffset: optional int32 [nctu][5][32] = SAO::m_offset[plane] after saoStatsInitialOffset;  params: int32 [nctu][7] */
+int EXPORT(x265oracle_sao_decide)(const int32_t* count, const int32_t* offsetOrg, int nctu, int32_t* initOffset, int32_t* params)
+{
+    const int thresh = 1 << ((DEPTH - 5) < 5 ? (DEPTH - 5) : 5);
+    for (int a = 0; a < nctu; a++)
+    {
+        const int32_t* cnt = count + (size_t)a * 160;
+        const int32_t* org = offsetOrg + (size_t)a * 160;
+        int32_t off[5][32];
+        memset(off, 0, sizeof(off));
+        for (int t = 0; t < 5; t++)
+        {
+            const int c0 = t < 4 ? 1 : 0, c1 = t < 4 ? 5 : 32;
+            for (int c = c0; c < c1; c++)
+            {
+                const int32_t n = cnt[t * 32 + c], e = org[t * 32 + c];
+                if (!n) continue;
+                int o = e >= 0 ? (e * 2 + n) / (n * 2) : -((-e * 2 + n) / (n * 2));
+                o = clip3(-thresh + 1, thresh - 1, o);
+                if (t < 4) o = c < 3 ? (o > 0 ? o : 0) : (o < 0 ? o : 0);
+                off[t][c] = o;
+            }
+        }
+        if (initOffset) memcpy(initOffset + (size_t)a * 160, off, sizeof(off));
+        int64_t best = 0;
+        int32_t* p = params + (size_t)a * 7;
+        p[0] = -1; p[1] = 0; p[2] = p[3] = p[4] = p[5] = 0; p[6] = 0;
+        for (int t = 0; t < 4; t++)
+        {
+            int64_t d = 0;
+            for (int c = 1; c < 5; c++) d += ((int64_t)cnt[t * 32 + c] * off[t][c] - (int64_t)org[t * 32 + c] * 2) * off[t][c];
+            if (d < best) { best = d; p[0] = t; p[1] = 0; for (int i = 0; i < 4; i++) p[2 + i] = off[t][1 + i]; }
+        }
+        int64_t db[32];
+        for (int b = 0; b < 32; b++) db[b] = ((int64_t)cnt[128 + b] * off[4][b] - (int64_t)org[128 + b] * 2) * off[4][b];
+        int64_t bo = 0; int start = -1;
+        for (int s = 0; s <= 28; s++)
+        {
+            const int64_t d = db[s] + db[s + 1] + db[s + 2] + db[s + 3];
+            if (start < 0 || d < bo) { bo = d; start = s; }
+        }
+        if (bo < best) { best = bo; p[0] = 4; p[1] = start; for (int i = 0; i < 4; i++) p[2 + i] = off[4][start + i]; }
+    }
+    return 0;
+}

@@ -100,7 +100,7 @@ def test_whole_4k_frame_every_stage_equals_oracle_chain(depth):
     _, cpu_out = B.oracle_chain(F, clip, 57, 3, 2, qp, depth, pipe.ms.nctu, B.effective_cpus(), O.host_has_avx2())
     res = B.compare_outputs(dev_out, cpu_out)
     assert res["ok"], res["stages"]
-    assert res["values_compared"] > 30_000_000
+    assert res["values_compared"] > 25_000_000
     assert int(dev_out["num_sig"].sum()) > 0 and len(np.unique(dev_out["subpel_mv"][:, 1])) > 8      # not a degenerate frame
 
 

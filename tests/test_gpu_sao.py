@@ -89,3 +89,53 @@ def test_sao_apply_refuses_in_place():
     par = torch.zeros(7, dtype=torch.int32, device=dev)
     with pytest.raises(RuntimeError):
         H.sao_apply(8, t, 256, 0, t, 256, 0, 64, 64, par)
+
+
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (10, 192, 136), (8, 1920, 1080), (12, 200, 150)])
+def test_sao_decide_matches_oracle_and_closes_the_loop(depth, width, height):
+    """x265hip_sao_decide (saoStatsInitialOffset + the distortion-only type choice) on the device's own statistics equals the oracle
+    (whose initial offsets are pinned against the real SAO class), also on random statistics incl. empty classes and huge sums; the
+    chosen parameters then go through x265hip_sao_apply and must lower the distortion against the source."""
+    import torch
+    dev = torch.device("cuda:0")
+    y, rec, _ = _case(depth, width, height, 8)
+    fenc, stride, org, w64, h64 = F.pad_plane(y)
+    recp = F.pad_plane(rec)[0]
+    nctu = ((width + 63) // 64) * ((height + 63) // 64)
+    d_f = torch.from_numpy(fenc.view(np.uint8).reshape(-1)).to(dev)
+    d_r = torch.from_numpy(recp.view(np.uint8).reshape(-1)).to(dev)
+    d_cnt = torch.zeros(nctu * 160, dtype=torch.int32, device=dev)
+    d_off = torch.zeros(nctu * 160, dtype=torch.int32, device=dev)
+    H.sao_stats(depth, d_f, stride, org, d_r, stride, org, width, height, d_cnt, d_off)
+    d_par = torch.full((nctu * 7,), 99, dtype=torch.int32, device=dev)
+    d_init = torch.full((nctu * 160,), 99, dtype=torch.int32, device=dev)
+    H.sao_decide(depth, d_cnt, d_off, nctu, d_par, init_offset=d_init)
+    d_out = d_r.clone()
+    H.sao_apply(depth, d_r, stride, org, d_out, stride, org, width, height, d_par)
+    torch.cuda.synchronize()
+    O = _oracle()
+    init, params = O.sao_decide(depth, d_cnt.cpu().numpy(), d_off.cpu().numpy())
+    assert np.array_equal(d_par.cpu().numpy().reshape(nctu, 7), params)
+    assert np.array_equal(d_init.cpu().numpy().reshape(nctu, 5, 32), init)
+    assert (params[:, 0] >= 0).any()
+    out = O.sao_apply(depth, recp, stride, org, width, height, params)
+    gout = d_out.cpu().numpy().view(y.dtype).reshape(out.shape)
+    assert np.array_equal(gout, out)
+    r0 = org // stride
+    a = fenc[r0:r0 + height, org % stride:org % stride + width].astype(np.int64)
+    sse = lambda p: int(((p.reshape(fenc.shape)[r0:r0 + height, org % stride:org % stride + width].astype(np.int64) - a) ** 2).sum())
+    assert sse(out) < sse(recp), "the chosen offsets must lower the distortion"
+    # random statistics: empty classes, negative / large sums
+    rng = np.random.default_rng([9, depth, width])
+    n = 300
+    cnt = rng.integers(0, 4097, size=(n, 5, 32)).astype(np.int32)
+    cnt[rng.random(cnt.shape) < 0.3] = 0
+    off = (rng.integers(-40, 41, size=(n, 5, 32)) * cnt * rng.random((n, 5, 32))).astype(np.int32)
+    off[::7] *= 3
+    g_par = torch.zeros(n * 7, dtype=torch.int32, device=dev)
+    g_init = torch.zeros(n * 160, dtype=torch.int32, device=dev)
+    H.sao_decide(depth, torch.from_numpy(cnt.reshape(-1)).to(dev), torch.from_numpy(off.reshape(-1)).to(dev), n, g_par, init_offset=g_init)
+    torch.cuda.synchronize()
+    init, params = O.sao_decide(depth, cnt, off)
+    assert np.array_equal(g_par.cpu().numpy().reshape(n, 7), params) and np.array_equal(g_init.cpu().numpy().reshape(n, 5, 32), init)
+    assert len(set(params[:, 0].tolist())) >= 4

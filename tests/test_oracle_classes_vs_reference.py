@@ -658,6 +658,13 @@ def test_sao_restatement_equals_reference_class(depth, width, height):
     cnt, off = O.sao_stats(depth, fenc, recp, stride, org, width, height)
     assert np.array_equal(cnt, rcnt), f"count differs in CTU/type {np.argwhere((cnt != rcnt).any(axis=2))[:6].tolist()}"
     assert np.array_equal(off, roff), f"offsetOrg differs in CTU/type {np.argwhere((off != roff).any(axis=2))[:6].tolist()}"
+    if hasattr(lib, "x265ref_sao_last_initial_offsets"):          # SAO::saoStatsInitialOffset (sao.cpp:1378-1433) on the same statistics
+        rinit = np.zeros((nctu, 5, 32), np.int32)
+        lib.x265ref_sao_last_initial_offsets.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        assert lib.x265ref_sao_last_initial_offsets(rinit.ctypes.data, nctu) == 0
+        init, chosen = O.sao_decide(depth, cnt, off)
+        assert np.array_equal(init[:, :4, 1:5], rinit[:, :4, 1:5]) and np.array_equal(init[:, 4, :], rinit[:, 4, :]), "initial offsets differ"
+        assert (chosen[:, 0] >= 0).any() and (init != 0).any()
     out = O.sao_apply(depth, recp, stride, org, width, height, params)
     rows = out.size // stride
     a = out.reshape(rows, stride)[org // stride: org // stride + height, org % stride: org % stride + width]

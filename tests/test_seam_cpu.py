@@ -1,0 +1,71 @@
+"""The stage-level seam (oracle/ref_seam.cpp + tools/seam_driver.py) on the CPU: the REAL reference encoder whose
+MotionEstimate::motionEstimate runs its integer search on looked-up SAD surfaces must write the same bitstream as the pristine
+reference build, with every lookup verified against the original primitive on the spot (X265REF_SEAM_VERIFY semantics).
+Here the surfaces come from the oracle's exhaustive search (OracleProvider); tests/test_gpu_seam.py plugs in libx265hip.so."""
+import ctypes
+import hashlib
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+
+
+def _tools():
+    from tools import encoder_bench, seam_driver
+    return encoder_bench, seam_driver
+
+
+def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41):
+    EB, SD = _tools()
+    try:
+        plain = EB.ref_lib(depth)
+        SD.seam_lib(depth)
+    except (SystemExit, FileNotFoundError):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    clip = F.synth_clip(w, h, nframes, depth=depth, seed=seed)
+    yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
+    base = EB.encode(plain, yuv, w, h, nframes, preset, opts)
+    lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=8, min_pu=min_pu, verify=verify)
+    try:
+        got = EB.encode(lib, yuv, w, h, nframes, preset, opts, filler)
+        rep = report()
+    finally:
+        close()
+    return base, got, rep
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("depth,preset,extra", [(8, "medium", []), (8, "slow", [("me", "star")]), (8, "slower", []), (8, "medium", [("me", "umh")]),
+                                                (8, "medium", [("me", "full"), ("merange", "12")]), (10, "medium", []), (8, "fast", [("me", "dia")])])
+def test_seam_encode_is_byte_identical_and_every_lookup_verified(depth, preset, extra):
+    opts = [("pools", "4"), ("frame-threads", "1"), ("crf", "24"), ("no-weightp", None), ("no-weightb", None)] + extra
+    base, got, rep = run_pair(depth, 256, 192, 5, preset, opts, "oracle", rng=20)
+    assert got[0] == base[0], f"seam changed the bitstream: {rep}"
+    assert rep["verify"] == 1 and rep["verify_mismatches"] == 0
+    assert rep["lookups_served"] > 1500 and rep["calls_with_lookup_context"] > 100, rep
+    assert rep["pair_submits"] >= 4                                       # one per (picture, reference)
+    assert rep["foreign_geometry"] == 0
+
+
+@pytest.mark.reference
+def test_seam_stays_out_of_the_way_with_frame_threads():
+    """--frame-threads 2: reference rows arrive while the next picture is searched; the seam must not engage."""
+    opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24")]
+    base, got, rep = run_pair(8, 256, 192, 5, "medium", opts, "oracle", rng=20)
+    assert got[0] == base[0]
+    assert rep["lookups_served"] == 0 and rep["pair_submits"] == 0
+
+
+@pytest.mark.reference
+def test_seam_with_weighted_prediction_defaults():
+    """preset defaults keep --weightp on: weighted references are bypassed, unweighted ones served."""
+    opts = [("pools", "4"), ("frame-threads", "1"), ("crf", "24")]
+    base, got, rep = run_pair(8, 256, 192, 6, "slow", opts, "oracle", rng=16, min_pu=16)
+    assert got[0] == base[0] and rep["verify_mismatches"] == 0
+    assert rep["lookups_served"] > 1000

@@ -79,7 +79,8 @@ def effective_cpus():
     return n
 
 
-def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sys.stderr):
+def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sys.stderr, seam=None):
+    seam = seam or {"range": 32, "slots": 8, "min_pu": 8, "verify": False}
     F = importlib.import_module("x265-yuuki-asuna_amd.frames")
     cfg = CONFIGS[key]
     w, h, depth = cfg["width"], cfg["height"], cfg["depth"]
@@ -90,11 +91,11 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
     lib = ref_lib(depth)
     opts = [("pools", str(cores)), ("frame-threads", str(frame_threads)), ("crf", "28")] + cfg["opts"]
     res = {"config": cfg["name"], "size": f"{w}x{h}", "depth": depth, "preset": cfg["preset"], "options": dict(opts), "pool_threads": cores,
-           "reference_build": "x265 3.5 C primitives (no asm: nasm is not in the image), g++ -O2"}
+           "reference_build": "x265 3.5 C primitives (no asm: nasm is not in the image), g++ -O3"}
     md5_c = None
     for t in tables:
         nf = n
-        filler, note = None, None
+        filler, note, closer, enc_lib = None, None, None, lib
         if t == "hip":
             A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
             L = A.lib()
@@ -106,12 +107,13 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
                 # measured on the first frames below; start from 2 frames, never less
                 nf = max(2, min(n, int(budget_s / max(1e-9, est_calls * 20e-6 / max(1, min(cores, 8)))))) if est_calls else min(n, 2)
         elif t == "seam":
-            seam = importlib.import_module("tools.seam_driver") if os.path.exists(os.path.join(ROOT, "tools", "seam_driver.py")) else None
-            if seam is None:
+            if cfg["preset"] == "ultrafast":       # --ctu 32 and, in cfg1, no inter pictures at all: nothing for the seam to serve
                 continue
-            filler, note = seam.install(lib, depth, w, h, dict(opts))
+            from tools import seam_driver as SD
+            enc_lib, filler, note, closer, _ = SD.install(depth, w, h, provider="gpu", rng=seam["range"], slots=seam["slots"], min_pu=seam["min_pu"],
+                                                          verify=seam["verify"])
         t0 = time.perf_counter()
-        md5, nbytes, sec, filled = encode(lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
+        md5, nbytes, sec, filled = encode(enc_lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
         wall = time.perf_counter() - t0
         r = {"frames": nf, "seconds": round(sec, 3), "fps": round(nf / sec, 4), "bytes": nbytes, "md5": md5, "slots_replaced": filled,
              "wall_seconds_with_open_close": round(wall, 3)}
@@ -128,7 +130,9 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
                 r["primitive_calls_through_gpu"] = int(L.x265hip_table_calls() - calls0)
                 r["us_per_primitive_call"] = round(1e6 * sec / max(1, r["primitive_calls_through_gpu"]), 2)
             if note:
-                r["seam"] = note() if callable(note) else note
+                r["seam"] = note()
+            if closer:
+                closer()
         res[t] = r
         print(f"[encoder] {key} {t}: {json.dumps(r)}", file=log, flush=True)
     return res
@@ -141,8 +145,13 @@ def main():
     ap.add_argument("--frames", type=int, default=0)
     ap.add_argument("--frame-threads", type=int, default=1)
     ap.add_argument("--budget-s", type=float, default=240.0, help="target seconds for one per-call-stub (hip) leg; the clip is shortened to fit")
+    ap.add_argument("--seam-range", type=int, default=32, help="displacements the SAD surfaces cover (lookups outside fall back to the C primitive)")
+    ap.add_argument("--seam-slots", type=int, default=8, help="(picture, reference) pairs resident in pinned host memory")
+    ap.add_argument("--seam-min-pu", type=int, default=8, help="serve partitions whose smaller side is at least this")
+    ap.add_argument("--seam-verify", action="store_true", help="check every lookup against the C primitive in flight (slow)")
     args = ap.parse_args()
-    out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s) for k in args.configs.split(",")}
+    seam = {"range": args.seam_range, "slots": args.seam_slots, "min_pu": args.seam_min_pu, "verify": args.seam_verify}
+    out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s, seam=seam) for k in args.configs.split(",")}
     print(json.dumps({"encoder": out}))
 
 

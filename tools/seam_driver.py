@@ -1,0 +1,181 @@
+"""Driver of the stage-level seam (tier T3 with a batch-layer consumer): configures oracle/_ref/libx265ref<depth>_seam.so
+(oracle/ref_seam.cpp - the reference-side binding) with a SAD-surface provider and hands back the table filler for
+x265ref_encode.  Two providers with the same three entry points (x265hip_me_cache_submit / _surface / _ready signatures):
+
+  GpuProvider     libx265hip.so's frame-granular cache (csrc/me_cache.hip): one exhaustive-search launch per (picture, reference),
+                  surfaces streamed to pinned host memory CTU row by CTU row                          -> the product path
+  OracleProvider  the oracle's exhaustive search on the CPU, synchronous (tests in the GPU-less container: proves the binding, the
+                  lookup arithmetic and the partition decomposition against the real encoder)        -> checker only
+
+Test infrastructure; the product is what GpuProvider calls."""
+import ctypes
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SUBMIT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p)
+SURFACE = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
+READY = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
+SURF_I32, SURF_PACKED = 0, 1
+
+
+def geometry(width, height):
+    """PicYuv layout for --ctu 64 (common/picyuv.cpp:87-114): whole CTUs, margins ctu + 32 / ctu + 16."""
+    w64, h64 = (width + 63) // 64 * 64, (height + 63) // 64 * 64
+    mx, my = 64 + 32, 64 + 16
+    return dict(width=w64, height=h64, stride=w64 + 2 * mx, margin_x=mx, margin_y=my)
+
+
+def seam_lib(depth):
+    path = os.path.join(ROOT, "oracle", "_ref", f"libx265ref{depth}_seam.so")
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    lib = ctypes.CDLL(path)
+    lib.x265ref_encode.restype = ctypes.c_long
+    lib.x265ref_encode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
+                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long,
+                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    lib.x265ref_seam_configure.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_ssize_t] + [ctypes.c_int] * 4
+    lib.x265ref_seam_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    return lib
+
+
+STAT_NAMES = ("lookups_served", "outside_window", "row_not_ready", "motion_estimate_calls", "calls_with_lookup_context", "pair_submits",
+              "verify_mismatches", "no_free_slot", "foreign_geometry", "verify")
+
+
+def stats(lib):
+    out = (ctypes.c_uint64 * 10)()
+    lib.x265ref_seam_stats(out)
+    d = dict(zip(STAT_NAMES, [int(v) for v in out]))
+    tot = d["lookups_served"] + d["outside_window"] + d["row_not_ready"]
+    d["lookup_hit_rate"] = round(d["lookups_served"] / tot, 4) if tot else None
+    return d
+
+
+class OracleProvider:
+    """CPU stand-in for x265hip_me_cache (checker only): surfaces from oracle/x265_oracle_pipeline.c, int32 records."""
+
+    def __init__(self, depth, geo, rng, slots):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_api
+        self.O, self.depth, self.geo, self.range, self.slots = oracle_api, depth, geo, rng, slots
+        self.es = 1 if depth == 8 else 2
+        self.nctu = (geo["width"] // 64) * (geo["height"] // 64)
+        nc = 2 * rng + 1
+        self.words = self.nctu * nc * ((nc + 3) // 4) * 340
+        self.surf = [np.zeros(self.words, np.int32) for _ in range(slots)]
+        self.flags = [np.zeros(geo["height"] // 64, np.int32) for _ in range(slots)]
+        self.gen = [0] * slots
+        self.plane_elems = geo["stride"] * (geo["height"] + 2 * geo["margin_y"])
+        self.org = geo["margin_y"] * geo["stride"] + geo["margin_x"]
+        self.fills = 0
+        self.format = SURF_I32
+        self._cb = (SUBMIT(self._submit), SURFACE(self._surface), READY(self._ready))
+
+    def _plane(self, ptr):
+        dt = np.uint8 if self.depth == 8 else np.uint16
+        raw = (ctypes.c_uint8 * (self.plane_elems * self.es)).from_address(ptr)
+        return np.frombuffer(raw, dtype=dt)
+
+    def _submit(self, ctx, slot, fenc, key, ref):
+        g = self.geo
+        zero = np.zeros(2 * self.range + 1, np.uint16)
+        surf, _ = self.O.me_fullsearch(self.depth, self._plane(fenc), g["stride"], self.org, self._plane(ref), g["stride"], self.org,
+                                       g["width"], g["height"], self.range, 0, self.nctu, zero, zero, want_surf=True, want_best=False)
+        self.surf[slot][:] = surf
+        self.gen[slot] += 1
+        self.flags[slot][:] = self.gen[slot]
+        self.fills += 1
+        return self.gen[slot]
+
+    def _surface(self, ctx, slot):
+        return self.surf[slot].ctypes.data
+
+    def _ready(self, ctx, slot):
+        return self.flags[slot].ctypes.data
+
+    def pointers(self):
+        return None, *(ctypes.cast(c, ctypes.c_void_p) for c in self._cb)
+
+    def report(self):
+        return {"provider": "oracle (CPU checker)", "fills": self.fills}
+
+    def close(self):
+        pass
+
+
+class CacheParams(ctypes.Structure):
+    """x265hip_me_cache_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int), ("stride", ctypes.c_ssize_t),
+                ("margin_x", ctypes.c_int), ("margin_y", ctypes.c_int), ("range", ctypes.c_int), ("surf_format", ctypes.c_int), ("slots", ctypes.c_int)]
+
+
+class CacheStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("fills", "failed", "us_upload", "us_kernel", "us_download", "bytes_downloaded", "surface_bytes")]
+
+
+class GpuProvider:
+    """libx265hip.so's x265hip_me_cache: the product path."""
+
+    def __init__(self, depth, geo, rng, slots):
+        A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+        self.A, self.L = A, A.lib()
+        self.format = SURF_PACKED if depth == 8 else SURF_I32
+        p = CacheParams(depth, geo["width"], geo["height"], geo["stride"], geo["margin_x"], geo["margin_y"], rng, self.format, slots)
+        self.handle = ctypes.c_void_p()
+        self.L.x265hip_me_cache_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(CacheParams)]
+        A.check(self.L.x265hip_me_cache_create(ctypes.byref(self.handle), ctypes.byref(p)), "x265hip_me_cache_create")
+        self.L.x265hip_me_cache_destroy.argtypes = [ctypes.c_void_p]
+        self.L.x265hip_me_cache_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(CacheStats)]
+
+    def pointers(self):
+        L = self.L
+        return (self.handle, ctypes.cast(L.x265hip_me_cache_submit, ctypes.c_void_p), ctypes.cast(L.x265hip_me_cache_surface, ctypes.c_void_p),
+                ctypes.cast(L.x265hip_me_cache_ready, ctypes.c_void_p))
+
+    def report(self):
+        st = CacheStats()
+        self.L.x265hip_me_cache_stats(self.handle, ctypes.byref(st))
+        n = max(1, st.fills)
+        return {"provider": "x265hip_me_cache (one x265hip_me_fullsearch launch per (picture, reference))", "fills": int(st.fills), "failed": int(st.failed),
+                "ms_per_fill": {"upload": round(st.us_upload / n / 1e3, 3), "kernel": round(st.us_kernel / n / 1e3, 3),
+                                "download": round(st.us_download / n / 1e3, 3)},
+                "surface_mbytes_per_pair": round(st.surface_bytes / 1e6, 1),
+                "download_gbytes_per_s": round(st.bytes_downloaded / max(1, st.us_download) / 1e3, 2)}
+
+    def close(self):
+        if self.handle:
+            self.L.x265hip_me_cache_destroy(self.handle)
+            self.handle = None
+
+
+def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False):
+    """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) using
+    --frame-threads 1 and --ctu 64."""
+    lib = seam_lib(depth)
+    geo = geometry(width, height)
+    prov = (GpuProvider if provider == "gpu" else OracleProvider)(depth, geo, rng, slots)
+    ctx, submit, surface, ready = prov.pointers()
+    rc = lib.x265ref_seam_configure(ctx, submit, surface, ready, rng, prov.format, slots, geo["width"], geo["height"], geo["stride"],
+                                    geo["margin_x"], geo["margin_y"], min_pu, int(bool(verify)))
+    if rc:
+        raise RuntimeError(f"x265ref_seam_configure failed ({rc})")
+    filler = ctypes.cast(lib.x265ref_seam_fill_table, ctypes.c_void_p)
+
+    def report():
+        d = stats(lib)
+        d.update(prov.report())
+        d.update({"range": rng, "slots": slots, "min_pu": min_pu})
+        return d
+
+    def close():
+        lib.x265ref_seam_disable()
+        prov.close()
+    return lib, filler, report, close, prov

@@ -223,6 +223,65 @@ __global__ void __launch_bounds__(256) sao_apply_kernel(SaoApplyArgs a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// SAO parameters without leaving the device: SAO::saoStatsInitialOffset (sao.cpp:1378-1433: roundIBDI of offsetOrg / count,
+// clip to +-(OFFSET_THRESH - 1), sign constraint of the edge classes) + a distortion-only choice of the type by estSaoDist
+// (sao.cpp:56-59) - the documented stand-in for the entropy-coder-driven rdoSaoUnitCu that lets the closed-loop pipeline hand the
+// next picture a reference that went through SAO.  One thread per CTU (160 statistics each).
+struct SaoDecideArgs { const int32_t* count; const int32_t* offsetOrg; int nctu, depth; int32_t* initOffset; int32_t* params; };
+
+__global__ void __launch_bounds__(64) sao_decide_kernel(SaoDecideArgs a)
+{
+    const int ctu = blockIdx.x * 64 + threadIdx.x;
+    if (ctu >= a.nctu) return;
+    const int32_t* cnt = a.count + (size_t)ctu * 160;
+    const int32_t* org = a.offsetOrg + (size_t)ctu * 160;
+    const int thresh = 1 << (a.depth - 5 < 5 ? a.depth - 5 : 5);
+    auto initial = [&](const int t, const int c) -> int
+    {
+        const int n = cnt[t * 32 + c], e = org[t * 32 + c];
+        if (!n) return 0;
+        int o = e >= 0 ? (e * 2 + n) / (n * 2) : -((-e * 2 + n) / (n * 2));
+        o = clip3(-thresh + 1, thresh - 1, o);
+        if (t < 4) o = c < 3 ? max(o, 0) : min(o, 0);
+        return o;
+    };
+    auto dist = [&](const int t, const int c, const int o) -> long long
+    { return ((long long)cnt[t * 32 + c] * o - (long long)org[t * 32 + c] * 2) * o; };
+    if (a.initOffset)
+    {
+        int32_t* io = a.initOffset + (size_t)ctu * 160;
+        for (int t = 0; t < 5; t++)
+            for (int c = 0; c < 32; c++) io[t * 32 + c] = (t < 4 && (c < 1 || c > 4)) ? 0 : initial(t, c);
+    }
+    long long best = 0;
+    int type = -1, band = 0, o4[4] = { 0, 0, 0, 0 };
+    for (int t = 0; t < 4; t++)
+    {
+        int o[4]; long long d = 0;
+        for (int c = 1; c < 5; c++) { o[c - 1] = initial(t, c); d += dist(t, c, o[c - 1]); }
+        if (d < best) { best = d; type = t; band = 0; for (int i = 0; i < 4; i++) o4[i] = o[i]; }
+    }
+    // band offset: sliding window of four bands
+    long long w = 0, bo = 0; int start = -1;
+    long long d3[3] = { 0, 0, 0 };
+    for (int b = 0; b < 32; b++)
+    {
+        const long long d = dist(4, b, initial(4, b));
+        w += d;
+        if (b >= 3)
+        {
+            if (start < 0 || w < bo) { bo = w; start = b - 3; }
+            w -= d3[0];
+        }
+        d3[0] = d3[1]; d3[1] = d3[2]; d3[2] = d;
+    }
+    if (bo < best) { type = 4; band = start; for (int i = 0; i < 4; i++) o4[i] = initial(4, start + i); }
+    int32_t* p = a.params + (size_t)ctu * 7;
+    p[0] = type; p[1] = band; p[2] = o4[0]; p[3] = o4[1]; p[4] = o4[2]; p[5] = o4[3]; p[6] = 0;
+}
+
 } // namespace x265hip
 
 using namespace x265hip;
@@ -271,6 +330,19 @@ extern "C" int x265hip_sao_apply(const x265hip_sao_apply_params* p, void* stream
     hipStream_t s = (hipStream_t)stream;
     if (bpp == 1) hipLaunchKernelGGL(sao_apply_kernel<uint8_t>, dim3(nctu), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(sao_apply_kernel<uint16_t>, dim3(nctu), dim3(256), 0, s, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x265hip_sao_decide(int depth, const int32_t* count, const int32_t* offset_org, int nctu, int32_t* init_offset, int32_t* ctu_params, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!count || !offset_org || !ctu_params) { set_error("sao_decide: NULL operand"); return X265HIP_EINVAL; }
+    if (depth != 8 && depth != 10 && depth != 12) { set_error("sao_decide: depth %d", depth); return X265HIP_EINVAL; }
+    if (nctu <= 0) { set_error("sao_decide: nctu %d", nctu); return X265HIP_EINVAL; }
+    SaoDecideArgs a = { count, offset_org, nctu, depth, init_offset, ctu_params };
+    hipLaunchKernelGGL(sao_decide_kernel, dim3((nctu + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
     X265HIP_TRY(hipGetLastError());
     return 0;
 }

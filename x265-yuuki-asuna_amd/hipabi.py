@@ -161,7 +161,9 @@ def exported_symbols():
     """Names include/x265hip.h declares; used by the CPU-only ABI test."""
     import re
     hdr = os.path.join(os.path.dirname(_HERE), "include", "x265hip.h")
-    return sorted(set(re.findall(r"\b(x265hip_[a-z0-9_]+)\s*\(", open(hdr).read())))
+    text = open(hdr).read()
+    inline = set(re.findall(r"static inline [^\n(]*\b(x265hip_[a-z0-9_]+)\s*\(", text))      # header-only helpers are not exports
+    return sorted(set(re.findall(r"\b(x265hip_[a-z0-9_]+)\s*\(", text)) - inline)
 
 
 def current_stream() -> int:
@@ -531,6 +533,14 @@ class SaoStatsParams(ctypes.Structure):
                 ("rec", ctypes.c_void_p), ("rec_stride", ctypes.c_ssize_t), ("width", ctypes.c_int), ("height", ctypes.c_int),
                 ("count", ctypes.c_void_p), ("offset_org", ctypes.c_void_p),
                 ("ctu_width", ctypes.c_int), ("ctu_height", ctypes.c_int), ("plane_offset", ctypes.c_int)]
+
+
+def sao_decide(depth, count, offset_org, nctu, params, init_offset=None, stream=None):
+    """x265hip_sao_decide: saoStatsInitialOffset + distortion-only type choice per CTU; params int32 [nctu * 7] (device)."""
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_sao_decide
+    f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    check(f(depth, count.data_ptr(), offset_org.data_ptr(), nctu, _p(init_offset), params.data_ptr(), s), "x265hip_sao_decide")
 
 
 class SaoApplyParams(ctypes.Structure):
