@@ -45,14 +45,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2):
-    """The oracle's restatement (CPU; checker + cpu_baseline leg only) of one frame of the pipeline - clip[1] searched in
-    clip[0] - on the first n CTUs.  n == all CTUs also runs the per-picture stages (lookahead, deblocking, SAO statistics)
+def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_planes=None, cur_index=1):
+    """The oracle's restatement (CPU; checker + cpu_baseline leg only) of one frame of the pipeline - clip[cur_index] searched in
+    clip[cur_index - 1] (or in ref_planes = padded Y, Cb, Cr of a reconstruction) - on the first n CTUs.  n == all CTUs also runs the per-picture stages (lookahead, deblocking, SAO statistics)
     and returns every stage output for the bit-exact comparison with the device pipeline.  Returns (seconds, outputs)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_api as O          # cpu_baseline / bit-exact checker leg only
-    cur, stride, org, w64, h64 = F.pad_plane(clip[1][0])
-    ref = F.pad_plane(clip[0][0])[0]
+    cur, stride, org, w64, h64 = F.pad_plane(clip[cur_index][0])
+    src_prev = F.pad_plane(clip[cur_index - 1][0])[0]              # the lookahead scores SOURCE pictures
+    # the picture searched / predicted from: the previous source frame, or (closed loop) the padded Y / Cb / Cr planes handed in
+    ref = src_prev if ref_planes is None else ref_planes[0]
     cost = F.mv_cost_table(rng_r)
     cq, qoff = F.qpel_cost_table(rng_r)
     nctu = (w64 // 64) * (h64 // 64)
@@ -66,7 +68,7 @@ def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2):
         ic, im, lc = O.lowres_intra(depth, lp[0], lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lw // 8, lh // 8, 5, nthreads=cores, avx2=avx2)
         # the frame cost estimate against the previous picture is serial per picture (the reference spreads pictures over threads)
         lq, lqoff = F.qpel_cost_table(16, lam=1.0 if depth == 8 else 16.0, qmax=4 * (max(lw, lh) + 64))
-        lpr = O.lowres_init(depth, ref, stride, org, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lh + 2 * F.MARGIN_Y, lw, lh,
+        lpr = O.lowres_init(depth, src_prev, stride, org, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lh + 2 * F.MARGIN_Y, lw, lh,
                             F.MARGIN_X, F.MARGIN_Y, avx2=avx2)
         O.lowres_cost(depth, lp[0], lpr, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lw // 8, lh // 8, lq, lqoff, ic, avx2=avx2)
         out.update({"lowres_plane%d" % i: lp[i] for i in range(4)})
@@ -78,14 +80,37 @@ def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2):
     rec, lev, ns, dist = O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp, ctu_begin=0, ctu_end=n,
                                        nthreads=cores, avx2=avx2)
     if n == nctu:       # per-picture stages, single-threaded in the restatement
+        S = importlib.import_module("x265-yuuki-asuna_amd.stages")
+        cuqp = max(qp - 6 * (depth - 8), 0)
         bv, bh = O.deblock_bs_inter(depth, w64, h64, level, mv, ns, avx2=avx2)
-        dbk = O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, max(qp - 6 * (depth - 8), 0), avx2=avx2)
+        dbk = O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, cuqp, avx2=avx2)
         cnt, off = O.sao_stats(depth, cur.reshape(-1), dbk.reshape(-1), stride, org, w64, h64, nthreads=cores, avx2=avx2)
+        _, par = O.sao_decide(depth, cnt, off, avx2=avx2)
+        fin = O.sao_apply(depth, dbk.reshape(-1), stride, org, w64, h64, par, nthreads=cores, avx2=avx2).reshape(rec.shape)
+        # chroma planes: prediction + residual round trip with the luma mvs, chroma edge filter (Bs 2 only), SAO on 32x32 footprints
+        cpl = [(F.pad_chroma(clip[cur_index][c], w64, h64),
+                F.pad_chroma(clip[cur_index - 1][c], w64, h64) if ref_planes is None else (ref_planes[c],)) for c in (1, 2)]
+        sc, oc = cpl[0][0][1], cpl[0][0][2]
+        qpc = S.chroma_quant_qp(qp, depth)
+        crec = [O.inter_recon_chroma(depth, cpl[i][0][0].reshape(-1), cpl[i][1][0].reshape(-1), sc, oc, w64, h64, level, mv, qpc, nthreads=cores, avx2=avx2)
+                for i in range(2)]
+        cdb = O.deblock_chroma(depth, crec[0][0], crec[1][0], sc, oc, w64, h64, bv, bh, cuqp, avx2=avx2)
+        cfin = []
+        for i in range(2):
+            ccnt, coff = O.sao_stats(depth, cpl[i][0][0].reshape(-1), cdb[i].reshape(-1), sc, oc, w64 // 2, h64 // 2, nthreads=cores, avx2=avx2,
+                                     ctu=(32, 32), plane_offset=2)
+            _, cpar = O.sao_decide(depth, ccnt, coff, avx2=avx2)
+            cf = O.sao_apply(depth, cdb[i].reshape(-1), sc, oc, w64 // 2, h64 // 2, cpar, nthreads=cores, avx2=avx2, ctu=(32, 32))
+            out["sao_params_c%d" % i], out["levels_c%d" % i], out["sao_count_c%d" % i] = cpar, crec[i][1], ccnt
+            cfin.append(cf)
         dt = time.perf_counter() - t
-        dbk = dbk.reshape(rec.shape)
-        inner = dbk[F.MARGIN_Y:F.MARGIN_Y + h64, F.MARGIN_X:F.MARGIN_X + w64]
+        inner = fin[F.MARGIN_Y:F.MARGIN_Y + h64, F.MARGIN_X:F.MARGIN_X + w64]
         out.update({"me_best": best, "subpel_mv": mv, "levels": lev, "num_sig": ns, "dist": dist, "sao_count": cnt, "sao_offset_org": off,
+                    "sao_params": par,
                     "recon": np.pad(inner, ((F.MARGIN_Y, F.MARGIN_Y), (F.MARGIN_X, F.MARGIN_X)), mode="edge")})   # extendPicBorder
+        for i in range(2):
+            ci = cfin[i].reshape(-1, sc)[F.CHROMA_MARGIN_Y:F.CHROMA_MARGIN_Y + h64 // 2, F.CHROMA_MARGIN_X:F.CHROMA_MARGIN_X + w64 // 2]
+            out["recon_c%d" % i] = np.pad(ci, ((F.CHROMA_MARGIN_Y, F.CHROMA_MARGIN_Y), (F.CHROMA_MARGIN_X, F.CHROMA_MARGIN_X)), mode="edge")
         return dt, out
     return time.perf_counter() - t, out
 
@@ -102,7 +127,13 @@ def device_outputs(pipe, cur, ref):
                 "me_best": pipe.ms.best.cpu().numpy().view(np.uint64), "subpel_mv": pipe.sp.out.cpu().numpy().reshape(-1, 2),
                 "levels": pipe.rc.levels.cpu().numpy(), "num_sig": pipe.rc.num_sig.cpu().numpy(), "dist": pipe.rc.dist.cpu().numpy(),
                 "sao_count": pipe.sao.count.cpu().numpy(), "sao_offset_org": pipe.sao.offset_org.cpu().numpy(),
+                "sao_params": pipe.sao.params.cpu().numpy(),
                 "recon": rec.cpu().numpy().view(dt).reshape(cur.host.shape)})
+    for i in range(2):
+        out["sao_params_c%d" % i] = pipe.sao_c[i].params.cpu().numpy()
+        out["sao_count_c%d" % i] = pipe.sao_c[i].count.cpu().numpy()
+        out["levels_c%d" % i] = pipe.rc_c[i].levels.cpu().numpy()
+        out["recon_c%d" % i] = pipe.final_c[i].cpu().numpy().view(dt)
     return out
 
 
@@ -145,8 +176,8 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0, dev_o
         bit_exact = compare_outputs(dev_out, cpu_out)
         bit_exact["ctus"] = nctu
         bit_exact["what"] = ("device pipeline == oracle chain (C restatement, pinned against the real reference) for one whole frame "
-                             "searched in the previous source frame: lookahead planes / intra costs, integer mvs, sub-pel mvs, levels, "
-                             "numSig, SSE, deblocked + border-extended reconstruction, SAO statistics")
+                             "searched in the previous source frame: lookahead planes / intra costs, integer mvs, sub-pel mvs, luma + chroma levels, "
+                             "numSig, SSE, SAO statistics and parameters, and the deblocked + SAO-filtered + border-extended Y / Cb / Cr reconstruction")
     else:
         probe = min(nctu, max(cores, 8))
         t_probe, _ = run(probe)
@@ -250,20 +281,19 @@ def main():
 
     nclip = 4
     clip = F.synth_clip(args.width, args.height, nclip, depth=args.depth, seed=265 + rank)
-    pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
+    pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
                            qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed" and args.depth == 8,
-                           lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True, lookahead_cost_batch=args.lookahead_batch)
-    ref_pic = P.DevicePicture.__new__(P.DevicePicture)
-    ref_pic.__dict__.update(pics[0].__dict__)
-    ref_pic.t = pics[0].t.clone()                    # the reference every rank searches in (starts as frame 0)
+                           lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True, lookahead_cost_batch=args.lookahead_batch,
+                           chroma=True, sao_apply=True)
+    ref_pic = pics[0].like([p.clone() for p in pics[0].planes()])     # the reference every rank searches in (starts as frame 0): Y, Cb, Cr
     fp = P.FrameParallel(rank, world)
 
     def step(i):
         cur = pics[1 + i % (nclip - 1)]
-        rec = pipe.run(cur, ref_pic)
-        # frame-parallel hand-off: the last rank's reconstruction becomes everyone's next reference
-        fp.exchange(ref_pic.t, rec)
+        pipe.run(cur, ref_pic)
+        # frame-parallel hand-off: the last rank's filtered reconstruction (Y, Cb, Cr) becomes everyone's next reference
+        fp.exchange(ref_pic.planes(), pipe.final_planes())
 
     for i in range(args.warmup):
         step(i)
@@ -287,45 +317,23 @@ def main():
         dt = float(tt.item())
     csum = pipe.checksum()
 
-    # ---- untimed pass: HIP-event time of every stage (events on the stream the kernels are launched on) ----
-    ms, sp, rc = pipe.ms, pipe.sp, pipe.rc
+    # ---- untimed pass: HIP-event time of every stage (events on the stream the kernels are launched on, recorded by the
+    # pipeline's own stage hook, so exactly the launches of the timed loop are measured) ----
+    ms = pipe.ms
     cur = pics[1]
-    names = ["lookahead", "me", "subpel", "recon", "deblock", "sao_stats", "border"]
-    acc = {k: [] for k in names}
+    acc = {}
     for _ in range(5):
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
-        lk, lk2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        lk.record()
-        pipe.la.run(cur)                          # half-resolution planes + intra cost estimate of the source picture
-        lk2.record()
-        if pipe.ps is not None:
-            marks[0].record()
-            pipe.ps.run(cur, ref_pic)             # pattern search + sub-pel for every PU, one launch
-            marks[1].record()
-            marks[2].record()
-            mv_out = pipe.ps.out
-        else:
-            A.me_best_reset(ms.best)                  # 4 us fill, outside the timed kernel
-            marks[0].record()
-            A.me_fullsearch(args.depth, ms.w64, ms.h64, ms.range, cur.t, cur.stride, ref_pic.t, ref_pic.stride, surf=ms.surf, best=ms.best,
-                            cost_x=ms.cost_x, cost_y=ms.cost_y, fenc_off=cur.org, fref_off=ref_pic.org,
-                            surf_format=A.SURF_PACKED if ms.packed else A.SURF_I32)                      # ONE fused launch
-            marks[1].record()
-            sp.run(cur, ref_pic)
-            marks[2].record()
-            mv_out = sp.out
-        rc.run(cur, ref_pic, pipe.recon, mv_out)
-        marks[3].record()
-        pipe.db.run(pipe.recon, cur, mv_out, rc.num_sig)      # boundary strengths + vertical / horizontal edge passes
-        marks[4].record()
-        pipe.sao.stats(cur, pipe.recon, cur.stride, cur.org)
-        marks[5].record()
-        S.extend_border(pipe.recon, cur)
-        marks[6].record()
+        evs = [("start", torch.cuda.Event(enable_timing=True))]
+        evs[0][1].record()
+
+        def mark(name):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append((name, e))
+        pipe.run(cur, ref_pic, mark=mark)
         torch.cuda.synchronize()
-        acc["lookahead"].append(lk.elapsed_time(lk2))
-        for j, k in enumerate(names[1:]):
-            acc[k].append(marks[j].elapsed_time(marks[j + 1]))
+        for (_, e0), (name, e1) in zip(evs[:-1], evs[1:]):
+            acc.setdefault(name, []).append(e0.elapsed_time(e1))
     stages = {k: round(float(np.median(v)), 4) for k, v in acc.items()}
     if pipe.lcb:
         # the lookahead's cost estimate: one launch scores `lookahead_batch` pictures on its own stream, overlapped with the stages above
@@ -358,8 +366,10 @@ def main():
                                    (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + ('packed' if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
                                     f"sub-pel subme={args.subme} -> " if args.search == "full" else
                                     f"{args.search} search driver (motionEstimate, merange {args.range}, subme {args.subme}, predictor 0) for all 85 PUs/CTU -> ") +
-                                   f"{8 << args.level}x{8 << args.level} prediction + DCT/quant/recon qp {args.qp} -> luma deblocking -> SAO statistics -> "
-                                   f"border extension -> next reference; pipeline throughput, not HEVC encoded fps",
+                                   f"{8 << args.level}x{8 << args.level} luma + 4:2:0 chroma prediction + DCT/quant/recon qp {args.qp} -> luma + chroma deblocking -> "
+                                   f"SAO statistics -> SAO parameters (saoStatsInitialOffset + distortion-only choice, on device) -> SAO apply (Y, Cb, Cr) -> "
+                                   f"border extension -> next reference (Y, Cb, Cr); pipeline throughput (tier T2), not HEVC encoded fps - the real "
+                                   f"encoder's fps (tier T3) is `bench.py --encoder` / profiles/r02_encoder_*.txt",
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world}",
                        "ctus_per_frame": ms.nctu, "checksum": csum},
             "stages_ms": stages,

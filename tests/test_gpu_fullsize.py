@@ -86,22 +86,24 @@ def test_me_10bit_full_size_properties(width, height):
 @pytest.mark.parametrize("depth", [8, 10])
 def test_whole_4k_frame_every_stage_equals_oracle_chain(depth):
     """configs[2] (8-bit) / configs[3] (10-bit) at full size with the bench's own settings (merange 57, subme 3, 32x32 blocks):
-    lookahead, integer mvs, sub-pel mvs, levels, numSig, SSE, deblocked + extended reconstruction, SAO statistics - all CTUs."""
+    lookahead, integer mvs, sub-pel mvs, luma + chroma levels, numSig, SSE, SAO statistics + parameters, and the deblocked + SAO-filtered
+    + border-extended Y / Cb / Cr reconstruction - all CTUs."""
     import torch
     B = _bench()
     O = _oracle()
     dev = torch.device("cuda:0")
     w, h, qp = 3840, 2160, 27 + 12 * (depth == 10)
     clip = F.synth_clip(w, h, 2, depth=depth, seed=265)
-    pics = [P.DevicePicture(y, dev) for (y, _, _) in clip]
+    pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=57, subme=3, level=2, qp=qp, want_surf=True, packed=depth == 8,
-                           lookahead=(w, h), deblock=True, sao=True)
+                           lookahead=(w, h), deblock=True, sao=True, chroma=True, sao_apply=True)
     dev_out = B.device_outputs(pipe, pics[1], pics[0])
     _, cpu_out = B.oracle_chain(F, clip, 57, 3, 2, qp, depth, pipe.ms.nctu, B.effective_cpus(), O.host_has_avx2())
     res = B.compare_outputs(dev_out, cpu_out)
     assert res["ok"], res["stages"]
     assert res["values_compared"] > 25_000_000
     assert int(dev_out["num_sig"].sum()) > 0 and len(np.unique(dev_out["subpel_mv"][:, 1])) > 8      # not a degenerate frame
+    assert (dev_out["sao_params"].reshape(-1, 7)[:, 0] >= 0).any()                                   # SAO switched on somewhere
 
 
 def test_8k_10bit_ctu_samples_and_whole_picture_loop_filters():

@@ -109,3 +109,32 @@ def test_lookahead_costs_run_ahead_in_batches(depth):
     planes.append(([p.cpu().numpy().view(dt).copy() for p in fp.la.planes], fp.la.intra_cost.cpu().numpy().copy()))
     mvs, mvc, lcost, rows, frame = expect(7)
     assert np.array_equal(fp.lc[0].mvs.cpu().numpy().reshape(-1, 2), mvs) and np.array_equal(fp.lc[0].frame.cpu().numpy()[:3], frame)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_closed_loop_with_chroma_and_sao_in_the_loop(depth):
+    """The default bench pipeline (luma + 4:2:0 chroma reconstruction, luma + chroma deblocking, SAO statistics -> on-device parameters
+    -> SAO apply on Y / Cb / Cr, border extension) over three frames, each searched in and predicted from the previous frame's
+    FILTERED reconstruction; every stage output of every frame against the oracle chain (bench.py's bit_exact code path)."""
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench as B
+    O = _oracle()
+    dev = torch.device("cuda:0")
+    W, Hh, R, subme, level, qp = 256, 192, 12, 3, 2, 30 + 12 * (depth == 10)
+    clip = F.synth_clip(W, Hh, 4, depth=depth, seed=67)
+    pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
+    pipe = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=R, subme=subme, level=level, qp=qp, want_surf=False, lookahead=(W, Hh),
+                           deblock=True, sao=True, chroma=True, sao_apply=True)
+    ref_dev = pics[0].like([p.clone() for p in pics[0].planes()])
+    ref_host = None                                                    # frame 1 searches the source frame 0
+    types = set()
+    for k in (1, 2, 3):
+        dev_out = B.device_outputs(pipe, pics[k], ref_dev)
+        _, cpu_out = B.oracle_chain(F, clip, R, subme, level, qp, depth, pipe.ms.nctu, 4, False, ref_planes=ref_host, cur_index=k)
+        res = B.compare_outputs(dev_out, cpu_out)
+        assert res["ok"], f"frame {k}: {res['stages']}"
+        types |= set(cpu_out["sao_params"][:, 0].tolist()) | set(cpu_out["sao_params_c0"][:, 0].tolist())
+        ref_host = (cpu_out["recon"], cpu_out["recon_c0"].reshape(-1), cpu_out["recon_c1"].reshape(-1))
+        ref_dev = pics[k].like([p.clone() for p in pipe.final_planes()])
+    assert any(t >= 0 for t in types), "SAO never switched on: the loop was not exercised"

@@ -36,6 +36,20 @@ def pad_plane(img: np.ndarray):
     return np.ascontiguousarray(buf), stride, org, w64, h64
 
 
+CHROMA_MARGIN_X = MARGIN_X          # picyuv.cpp:97-98: the chroma margin keeps the luma margin's width ...
+CHROMA_MARGIN_Y = MARGIN_Y >> 1     # ... and halves its height (4:2:0)
+
+
+def pad_chroma(img: np.ndarray, w64: int, h64: int):
+    """4:2:0 chroma picture -> padded plane of the reference's PicYuv geometry (m_strideC = w64 / 2 + 2 * margin).
+    Returns (buf, stride, org)."""
+    cw, ch = w64 // 2, h64 // 2
+    h, w = img.shape
+    buf = np.pad(img, ((CHROMA_MARGIN_Y, CHROMA_MARGIN_Y + ch - h), (CHROMA_MARGIN_X, CHROMA_MARGIN_X + cw - w)), mode="edge")
+    stride = cw + 2 * CHROMA_MARGIN_X
+    return np.ascontiguousarray(buf), stride, CHROMA_MARGIN_Y * stride + CHROMA_MARGIN_X
+
+
 def _box5(a):
     k = np.ones(5) / 5.0
     a = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, a)

@@ -26,15 +26,35 @@ PUS_PER_CTU = 85
 class DevicePicture:
     """A padded picture plane in HBM (layout: frames.padded_dims)."""
 
-    def __init__(self, img: np.ndarray, device):
+    def __init__(self, img: np.ndarray, device, cb: np.ndarray = None, cr: np.ndarray = None):
         import torch
         buf, self.stride, self.org, self.w64, self.h64 = F.pad_plane(img)
         self.depth = 8 if img.dtype == np.uint8 else 10
-        if img.dtype == np.uint8:
-            self.t = torch.from_numpy(buf).to(device)
-        else:
-            self.t = torch.from_numpy(buf.view(np.int16)).to(device)   # torch has no uint16 arithmetic; raw bits only
+
+        def up(b):
+            return torch.from_numpy(b if b.dtype == np.uint8 else b.view(np.int16)).to(device)   # torch has no uint16 arithmetic; raw bits only
+        self.t = up(buf)
         self.host = buf
+        # optional 4:2:0 chroma planes (flat tensors, PicYuv chroma geometry)
+        self.c, self.c_host, self.stride_c, self.org_c = None, None, 0, 0
+        if cb is not None:
+            pads = [F.pad_chroma(p, self.w64, self.h64) for p in (cb, cr)]
+            self.stride_c, self.org_c = pads[0][1], pads[0][2]
+            self.c_host = [p[0] for p in pads]
+            self.c = [up(p[0]).reshape(-1) for p in pads]
+
+    def planes(self):
+        """[luma, cb, cr] device tensors (luma only without chroma)."""
+        return [self.t] + (self.c or [])
+
+    def like(self, planes):
+        """A picture of the same geometry over other device planes (e.g. a reconstruction that becomes a reference)."""
+        o = DevicePicture.__new__(DevicePicture)
+        o.__dict__.update(self.__dict__)
+        o.t = planes[0]
+        o.c = list(planes[1:3]) if len(planes) >= 3 else None
+        o.host, o.c_host = None, None
+        return o
 
 
 class MotionSearch:
@@ -81,9 +101,16 @@ class MotionSearch:
         out += self.best.numel() * 8 if self.best is not None else 0
         return pix + out
 
-    def run(self, cur: DevicePicture, ref: DevicePicture):
+    def reset(self):
         if self.best is not None:
             hipabi.me_best_reset(self.best)
+
+    def run(self, cur: DevicePicture, ref: DevicePicture):
+        self.reset()
+        self.search(cur, ref)
+
+    def search(self, cur: DevicePicture, ref: DevicePicture):
+        """The one exhaustive-search launch (best[] must have been reset)."""
         hipabi.me_fullsearch(self.depth, self.w64, self.h64, self.range,
                              cur.t, cur.stride, ref.t, ref.stride,
                              surf=self.surf, best=self.best, cost_x=self.cost_x, cost_y=self.cost_y,
@@ -161,7 +188,12 @@ class FrameParallel:
         return self.world - 1
 
     def exchange(self, ref_plane, newest_plane):
-        """ref_plane <- the reference owner's newest picture (in place on every rank)."""
+        """ref_plane <- the reference owner's newest picture (in place on every rank).  Either one plane each or equally long
+        lists of planes (luma, Cb, Cr)."""
+        if isinstance(ref_plane, (list, tuple)):
+            for r, n in zip(ref_plane, newest_plane):
+                self.exchange(r, n)
+            return
         if self.world == 1:
             ref_plane.copy_(newest_plane)
             return

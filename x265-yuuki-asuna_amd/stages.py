@@ -115,15 +115,32 @@ class InterReconChroma:
         hipabi.check(f(ctypes.byref(p), s), "x265hip_inter_recon_chroma")
 
 
-def extend_border(plane, pic: DevicePicture, stream=None):
-    """Replicate the picture edges into the margins of `plane` (same geometry as `pic`), on device."""
+def extend_border(plane, pic: DevicePicture, stream=None, chroma=False):
+    """Replicate the picture edges into the margins of `plane` (same geometry as `pic`; chroma: one of its 4:2:0 planes), on device."""
     from . import frames as F
     es = 1 if pic.depth == 8 else 2
     s = hipabi.current_stream() if stream is None else stream
     f = hipabi.lib().x265hip_extend_border
     f.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    if chroma:
+        hipabi.check(f(plane.data_ptr() + pic.org_c * es, pic.stride_c, pic.w64 // 2, pic.h64 // 2, F.CHROMA_MARGIN_X, F.CHROMA_MARGIN_Y, pic.depth, s),
+                     "x265hip_extend_border")
+        return
     hipabi.check(f(plane.data_ptr() + pic.org * es, pic.stride, pic.w64, pic.h64, F.MARGIN_X, F.MARGIN_Y, pic.depth, s),
                  "x265hip_extend_border")
+
+
+# g_chromaScale (constants.cpp:346-350) as Quant::setChromaQP applies it to 4:2:0 pictures (quant.cpp:233-244)
+_CHROMA_SCALE = list(range(30)) + [29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37] + list(range(38, 52)) + [51] * 12
+
+
+def chroma_quant_qp(qp, depth, offset=0):
+    """The chroma quantiser's QP for a CU whose luma quantiser runs at `qp` (= CU QP + QP_BD_OFFSET)."""
+    bd = 6 * (depth - 8)
+    q = min(max(qp - bd + offset, -bd), 57)
+    if q >= 30:
+        q = _CHROMA_SCALE[q]
+    return q + bd
 
 
 class Deblock:
@@ -147,18 +164,31 @@ class Sao:
     :274-570).  The parameter choice between them (rdoSaoUnitCu, entropy-coder bit counts) is host work: `stats()` fills
     count / offset_org [numCtu, 5, 32]; `apply(params)` takes int32 [numCtu, 7] = typeIdx, bandPos, offset[4], mergeLeft."""
 
-    def __init__(self, width, height, depth, device):
+    def __init__(self, width, height, depth, device, ctu=(64, 64), plane_offset=0):
+        """width / height: the PLANE's size; ctu: the CTU's footprint in it (4:2:0 chroma: (32, 32) with plane_offset 2)."""
         import torch
-        self.width, self.height, self.depth = width, height, depth
-        self.nctu = ((width + 63) // 64) * ((height + 63) // 64)
+        self.width, self.height, self.depth, self.ctu, self.plane_offset = width, height, depth, ctu, plane_offset
+        self.nctu = ((width + ctu[0] - 1) // ctu[0]) * ((height + ctu[1] - 1) // ctu[1])
         self.count = torch.zeros(self.nctu * 160, dtype=torch.int32, device=device)
         self.offset_org = torch.zeros(self.nctu * 160, dtype=torch.int32, device=device)
+        self.params = torch.zeros(self.nctu * 7, dtype=torch.int32, device=device)
 
-    def stats(self, src: DevicePicture, rec, rec_stride, rec_org):
-        hipabi.sao_stats(self.depth, src.t, src.stride, src.org, rec, rec_stride, rec_org, self.width, self.height, self.count, self.offset_org)
+    def stats(self, src, rec, rec_stride, rec_org, src_plane=None):
+        """src: a DevicePicture (its luma plane) or, with src_plane, any plane of the same stride / origin as the reconstruction."""
+        if src_plane is not None:
+            hipabi.sao_stats(self.depth, src_plane, rec_stride, rec_org, rec, rec_stride, rec_org, self.width, self.height, self.count, self.offset_org,
+                             ctu=self.ctu, plane_offset=self.plane_offset)
+            return
+        hipabi.sao_stats(self.depth, src.t, src.stride, src.org, rec, rec_stride, rec_org, self.width, self.height, self.count, self.offset_org,
+                         ctu=self.ctu, plane_offset=self.plane_offset)
 
-    def apply(self, rec, rec_stride, rec_org, out, params):
-        hipabi.sao_apply(self.depth, rec, rec_stride, rec_org, out, rec_stride, rec_org, self.width, self.height, params)
+    def decide(self):
+        """saoStatsInitialOffset + the distortion-only type choice of x265hip_sao_decide -> self.params (stays on the device)."""
+        hipabi.sao_decide(self.depth, self.count, self.offset_org, self.nctu, self.params)
+
+    def apply(self, rec, rec_stride, rec_org, out, params=None):
+        hipabi.sao_apply(self.depth, rec, rec_stride, rec_org, out, rec_stride, rec_org, self.width, self.height,
+                         self.params if params is None else params, ctu=self.ctu)
 
 
 class Lookahead:
@@ -402,7 +432,7 @@ class FramePipeline:
     cost estimate per 8x8 block), which only depends on the source."""
 
     def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False, lookahead=None,
-                 search="full", deblock=False, sao=False, lookahead_cost_batch=0):
+                 search="full", deblock=False, sao=False, lookahead_cost_batch=0, chroma=False, sao_apply=False):
         import torch
         from .pipeline import MotionSearch, SubpelRefine
         self.depth = depth
@@ -436,10 +466,24 @@ class FramePipeline:
         # SAO statistics of the deblocked reconstruction (what rdoSaoUnitCu reads); the offsets themselves are the host's decision
         self.sao = Sao(w64, h64, depth, device) if sao else None
         self.recon = None
+        # 4:2:0 chroma through the same closed loop (predInterChromaPixel + residual round trip, edgeFilterChroma, SAO on 32x32 footprints)
+        self.chroma = chroma
+        self.qp = qp
+        self.recon_c, self.out, self.out_c = None, None, None
+        if chroma:
+            qpc = chroma_quant_qp(qp, depth)
+            self.rc_c = [InterReconChroma(self.ms.nctu, w64, h64, depth, level, qpc, device) for _ in range(2)]
+            self.sao_c = [Sao(w64 // 2, h64 // 2, depth, device, ctu=(32, 32), plane_offset=2) for _ in range(2)] if sao else None
+        # SAO applied in the loop: the parameters come from x265hip_sao_decide (initial offsets + distortion-only choice), so the
+        # picture handed to the next frame is deblocked AND offset like a decoder's
+        self.sao_apply = bool(sao and sao_apply)
 
-    def run(self, cur: DevicePicture, ref: DevicePicture):
-        """ref.t is the current reference plane (extended borders); returns the plane holding the new reconstruction."""
+    def run(self, cur: DevicePicture, ref: DevicePicture, mark=None):
+        """ref: the current reference picture (extended borders; with chroma=True also its Cb / Cr planes); returns the luma plane of
+        the picture for the next frame's reference list (final_planes() has all three).  mark(name), if given, is called after every
+        stage (bench.py records an event there)."""
         import torch
+        mark = mark or (lambda name: None)
         if self.recon is None:
             self.recon = torch.zeros_like(cur.t)
         if self.lcb:
@@ -455,20 +499,64 @@ class FramePipeline:
                 self.launch_lookahead_costs()
         elif self.la is not None:
             self.la.run(cur)
+        if self.ps is None:
+            self.ms.reset()                                  # 4 us fill of best[]: kept out of the search kernel's interval
+        mark("lookahead")
         if self.ps is not None:
             self.ps.run(cur, ref)
             mv = self.ps.out
+            mark("me")
         else:
-            self.ms.run(cur, ref)
+            self.ms.search(cur, ref)                         # ONE fused launch: SAD surfaces + best mv
+            mark("me")
             self.sp.run(cur, ref)
             mv = self.sp.out
+        mark("subpel")
         self.rc.run(cur, ref, self.recon, mv)
+        mark("recon")
+        if self.chroma:
+            if self.recon_c is None:
+                self.recon_c = [torch.zeros_like(p) for p in cur.c]
+            for i in range(2):
+                self.rc_c[i].run(cur.c[i], ref.c[i], self.recon_c[i], cur.stride_c, cur.org_c, mv)
+            mark("recon_chroma")
         if self.db is not None:
             self.db.run(self.recon, cur, mv, self.rc.num_sig)
+            if self.chroma:                  # Bs 2 edges only (intra CUs): none in an all-inter picture, the pass still runs like the reference's
+                hipabi.deblock_chroma(self.depth, self.recon_c[0], self.recon_c[1], cur.stride_c, cur.org_c, cur.w64, cur.h64,
+                                      self.db.bs_ver, self.db.bs_hor, self.db.qp)
+            mark("deblock")
+        final, final_c = self.recon, self.recon_c
         if self.sao is not None:
             self.sao.stats(cur, self.recon, cur.stride, cur.org)
-        extend_border(self.recon, cur)
-        return self.recon
+            if self.chroma:
+                for i in range(2):
+                    self.sao_c[i].stats(None, self.recon_c[i], cur.stride_c, cur.org_c, src_plane=cur.c[i])
+            mark("sao_stats")
+            if self.sao_apply:
+                if self.out is None:
+                    self.out = torch.zeros_like(cur.t)
+                    self.out_c = [torch.zeros_like(p) for p in cur.c] if self.chroma else None
+                self.sao.decide()
+                self.sao.apply(self.recon, cur.stride, cur.org, self.out)
+                final = self.out
+                if self.chroma:
+                    for i in range(2):
+                        self.sao_c[i].decide()
+                        self.sao_c[i].apply(self.recon_c[i], cur.stride_c, cur.org_c, self.out_c[i])
+                    final_c = self.out_c
+                mark("sao_apply")
+        extend_border(final, cur)
+        if self.chroma:
+            for i in range(2):
+                extend_border(final_c[i], cur, chroma=True)
+        mark("border")
+        self.final, self.final_c = final, final_c
+        return final
+
+    def final_planes(self):
+        """[luma, cb, cr] of the picture the last run() produced for the next frame's reference list."""
+        return [self.final] + (list(self.final_c) if self.chroma else [])
 
     def _table(self, key):
         if key not in self.tables:
@@ -506,5 +594,11 @@ class FramePipeline:
         if self.sao is not None:
             out["sao_count"] = int(self.sao.count.sum(dtype=torch.int64).item())
             out["sao_offset_org"] = int(self.sao.offset_org.sum(dtype=torch.int64).item())
-        out["recon"] = int(self.recon.view(torch.uint8).to(torch.int64).sum().item())
+        out["recon"] = int(self.final.view(torch.uint8).to(torch.int64).sum().item())
+        if self.chroma:
+            out["recon_cb"] = int(self.final_c[0].view(torch.uint8).to(torch.int64).sum().item())
+            out["recon_cr"] = int(self.final_c[1].view(torch.uint8).to(torch.int64).sum().item())
+            out["levels_c"] = int(sum(r.levels.to(torch.int64).sum().item() for r in self.rc_c))
+        if self.sao_apply:
+            out["sao_types"] = int((self.sao.params.view(-1, 7)[:, 0] >= 0).sum().item())
         return out
