@@ -135,14 +135,20 @@ int x265hip_subpel_refine(const x265hip_subpel_params* p, void* stream);
 
 /* Fused inter prediction + residual coding round trip of every NxN block (N = 8 << level, level 0..2), the
  * caller sequence of SURVEY section 8(f) item 2: Predict::predInterLumaPixel (predict.cpp:245-265),
- * calcresidual, Quant::transformNxN without RDOQ / sign hiding (quant.cpp:397-480, flat scaling lists),
+ * calcresidual, Quant::transformNxN without RDOQ (quant.cpp:397-480, flat scaling lists; sign-bit hiding optional),
  * Quant::invtransformNxN incl. the DC-only shortcut (quant.cpp:543-605), add_ps / copy_pp, sse_pp.
  *   mv      : int32 [ctu*85][2] from x265hip_subpel_refine ({cost, qmvx | qmvy << 16}); block z of the level uses
  *             entry base(level) + z (base = 0, 64, 80)
- *   qp      : scaled luma QP (per = qp / 6, rem = qp % 6); intra_slice selects the 171/85 rounding offset
+ *   qp      : scaled luma QP (per = qp / 6, rem = qp % 6)
+ *   intra_slice : flag bits - X265HIP_TU_INTRA_SLICE selects the I-slice rounding offset (171 instead of 85, quant.cpp:466),
+ *             X265HIP_TU_SIGN_HIDE runs Quant::signBitHidingHDQ after the quantiser (quant.cpp:247-395, 471-476: the x265 default,
+ *             pps.bSignHideEnabled; up-right diagonal scan for inter TUs, the mode-dependent scan for 4x4 / luma 8x8 intra TUs).
+ *             Scaling lists, the denoiser and RDOQ (the host's rows a8 / a9) are not part of the fused stages.
  *   recon   : reconstructed luma plane, same geometry as fenc (margins are not written)
  *   levels  : int16 [ctu][blocks][N*N] quantised coefficients   num_sig : uint32 [ctu][blocks]
  *   dist    : uint64 [ctu][blocks] sse_pp(fenc, recon) */
+#define X265HIP_TU_INTRA_SLICE 1
+#define X265HIP_TU_SIGN_HIDE   2
 typedef struct x265hip_recon_params
 {
     int depth;
@@ -511,7 +517,7 @@ typedef struct x265hip_intra_recon_params
     const void* fenc;  intptr_t fenc_stride;
     const void* nb;
     void* recon;       intptr_t recon_stride;
-    int qp, intra_slice;
+    int qp, intra_slice;           /* intra_slice: X265HIP_TU_* flag bits, as in x265hip_recon_params */
     const x265hip_job* jobs;  int njobs;
     int16_t* levels; uint32_t* num_sig; uint64_t* dist;
     /* non-zero: the 4:2:0 chroma flavour (Search::codeIntraChromaQt's pixel work, search.cpp:899-930) - Predict::predIntraChromaAng
@@ -625,8 +631,8 @@ typedef struct x265hip_me_cache_params
 } x265hip_me_cache_params;
 typedef struct x265hip_me_cache_stats_t
 {
-    uint64_t fills, failed;
-    uint64_t us_upload, us_kernel, us_download;     /* summed over the fills, worker-thread wall time */
+    uint64_t fills, failed, batches;
+    uint64_t us_upload, us_kernel, us_download;     /* summed over the batches, worker-thread wall time (us_kernel includes the uploads) */
     uint64_t bytes_downloaded, surface_bytes;
 } x265hip_me_cache_stats_t;
 int  x265hip_me_cache_create(x265hip_me_cache** out, const x265hip_me_cache_params* p);
@@ -634,6 +640,10 @@ void x265hip_me_cache_destroy(x265hip_me_cache* c);
 /* copies both planes, queues upload + search + row-streamed download on the cache's worker thread, returns the slot's new
  * GENERATION (> 0) at once, or a negative error */
 int  x265hip_me_cache_submit(x265hip_me_cache* c, int slot, const void* fenc_buf, uint64_t fenc_key, const void* ref_buf);
+/* the references of one source picture as ONE batch: searched back to back, surfaces downloaded row-interleaved across the pairs
+ * (row 0 of every pair first - the order a wavefront-parallel encoder needs them); generations[i] = slot i's new generation */
+int  x265hip_me_cache_submit_batch(x265hip_me_cache* c, int n, const int* slots, const void* fenc_buf, uint64_t fenc_key,
+                                   const void* const* ref_bufs, int* generations);
 const void* x265hip_me_cache_surface(x265hip_me_cache* c, int slot);
 /* int [height / 64]: CTU row r of the slot is complete when ready[r] == the generation submit returned */
 const volatile int* x265hip_me_cache_ready(x265hip_me_cache* c, int slot);

@@ -14,6 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _libs = {}
 
 
+TU_INTRA_SLICE, TU_SIGN_HIDE = 1, 2       # flag bits of the TU stages' `intra_slice` argument (x265hip.h: X265HIP_TU_*)
+
+
 def host_has_avx2() -> bool:
     try:
         return " avx2 " in open("/proc/cpuinfo").read().replace("\n", " ")

@@ -31,7 +31,16 @@ extern "C" {
  * Outputs: levels int16 [njobs][n*n], numSig uint32 [njobs], resiOut int16 [njobs][n*n] (zero when numSig == 0, as the callers
  * skip the inverse transform then).  Returns 0 on success. */
 static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intraCU, int intraSlice, int njobs,
-                             int16_t* levels, uint32_t* numSig, int16_t* resiOut, TextType ttype);
+                             int16_t* levels, uint32_t* numSig, int16_t* resiOut, TextType ttype, int signHide = 0, int intraDir = 1);
+
+/* the x265 default: pps.bSignHideEnabled = 1 (Quant::signBitHidingHDQ after the quantiser, quant.cpp:471-476).  intraDir is the
+ * intra direction the TU's scan order depends on (CUData::getTUEntropyCodingParameters, cudata.cpp:2067-2089); chroma != 0 runs
+ * TEXT_CHROMA_U blocks of a 4:2:0 picture (mode-dependent scans for the 4x4 TU only). */
+int x265ref_tu_roundtrip_ex(const int16_t* resi, int n, int qpScaled, int intraCU, int intraSlice, int signHide, int intraDir, int chroma,
+                            int njobs, int16_t* levels, uint32_t* numSig, int16_t* resiOut)
+{
+    return tu_roundtrip_core(resi, n, qpScaled, intraCU, intraSlice, njobs, levels, numSig, resiOut, chroma ? TEXT_CHROMA_U : TEXT_LUMA, signHide, intraDir);
+}
 
 int x265ref_tu_roundtrip(const int16_t* resi, int n, int qpScaled, int intraCU, int intraSlice, int njobs,
                          int16_t* levels, uint32_t* numSig, int16_t* resiOut)
@@ -48,7 +57,7 @@ int x265ref_tu_roundtrip_chroma(const int16_t* resi, int n, int qpScaled, int in
 }
 
 static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intraCU, int intraSlice, int njobs,
-                             int16_t* levels, uint32_t* numSig, int16_t* resiOut, TextType ttype)
+                             int16_t* levels, uint32_t* numSig, int16_t* resiOut, TextType ttype, int signHide, int intraDir)
 {
     static bool tableReady = false;
     if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
@@ -58,7 +67,7 @@ static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intra
     x265_param_default(param);
     param->sourceWidth = 64;
     param->sourceHeight = 64;
-    param->internalCsp = X265_CSP_I400;
+    param->internalCsp = (signHide && ttype != TEXT_LUMA) ? X265_CSP_I420 : X265_CSP_I400;   /* the chroma scan rule reads m_hChromaShift */
     param->maxCUSize = 64;
     param->minCUSize = 8;
     param->maxLog2CUSize = 6;
@@ -74,7 +83,7 @@ static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intra
     sps.quadtreeTULog2MaxSize = 5;
     PPS pps;
     memset((void*)&pps, 0, sizeof(pps));
-    pps.bSignHideEnabled = 0;
+    pps.bSignHideEnabled = signHide != 0;
     Frame frame;
     frame.m_param = param;
     FrameData encData;
@@ -92,7 +101,12 @@ static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intra
     if (!pool.create(0, param->internalCsp, 1, *param)) return -2;
     ctu.initialize(pool, 0, *param, 0);
     ctu.initCTU(frame, 0, qpScaled - QP_BD_OFFSET, 1, 1, 1);
-    for (int p = 0; p < 256; p++) ctu.m_predMode[p] = intraCU ? MODE_INTRA : MODE_INTER;
+    for (int p = 0; p < 256; p++)
+    {
+        ctu.m_predMode[p] = intraCU ? MODE_INTRA : MODE_INTER;
+        ctu.m_lumaIntraDir[p] = (uint8_t)intraDir;
+        if (param->internalCsp != X265_CSP_I400) ctu.m_chromaIntraDir[p] = (uint8_t)intraDir;
+    }
 
     ScalingList scalingList;
     if (!scalingList.init()) return -3;

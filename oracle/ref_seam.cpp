@@ -50,6 +50,7 @@ struct Provider
 {
     void* ctx;
     int (*submit)(void* ctx, int slot, const void* fenc_buf, uint64_t fenc_key, const void* ref_buf);
+    int (*submit_batch)(void* ctx, int n, const int* slots, const void* fenc_buf, uint64_t fenc_key, const void* const* ref_bufs, int* generations);
     const void* (*surface)(void* ctx, int slot);
     const volatile int* (*ready)(void* ctx, int slot);
     int range, surf_format, slots;
@@ -216,8 +217,10 @@ template <int P> struct Install
 };
 template <> struct Install<NUM_PU_SIZES> { static void run(EncoderPrimitives&, int&) {} };
 
-/* slot of (source picture poc, reference picture), requesting the surfaces when the pair is new; -1 when none can be had */
-int pair_slot(int fencPoc, const PicYuv* fencPic, const PicYuv* rec, int recPoc, int& gen)
+/* slot of (source picture poc, reference picture); -1 when none can be had.  The first query for a new source picture requests the
+ * surfaces of ALL its unweighted references as one batch (x265hip_me_cache_submit_batch: searched back to back, downloaded
+ * row-interleaved), so the top CTU rows of every reference arrive first. */
+int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicYuv* rec, int recPoc, int& gen)
 {
     const int epoch = g.epoch.load(std::memory_order_acquire);
     if (t_pairs.fencPoc != fencPoc || t_pairs.epoch != epoch) { t_pairs.fencPoc = fencPoc; t_pairs.epoch = epoch; t_pairs.n = 0; }
@@ -226,22 +229,62 @@ int pair_slot(int fencPoc, const PicYuv* fencPic, const PicYuv* rec, int recPoc,
     int slot = -1;
     {
         std::lock_guard<std::mutex> lk(g.mu);
-        int freeSlot = -1;
+        bool known = false;
         for (int i = 0; i < g.p.slots; i++)
         {
             Pair& q = g.pairs[i];
-            if (q.used && q.fencPoc == fencPoc && q.rec == rec && q.recPoc == recPoc) { slot = i; gen = q.gen; break; }
-            if (freeSlot < 0 && (!q.used || q.fencPoc != fencPoc)) freeSlot = i;     /* surfaces of an earlier picture: its encode is over (-F 1) */
+            if (q.used && q.fencPoc == fencPoc) known = true;
+            if (q.used && q.fencPoc == fencPoc && q.rec == rec && q.recPoc == recPoc) { slot = i; gen = q.gen; }
         }
-        if (slot < 0 && freeSlot >= 0)
+        if (slot < 0)
         {
-            const int rc = g.p.submit(g.p.ctx, freeSlot, fencPic->m_picBuf[0], (uint64_t)(uint32_t)fencPoc, rec->m_picBuf[0]);
-            if (rc > 0)
+            /* candidates: a new source picture -> every reference of the slice; otherwise just the one asked for */
+            const PicYuv* want[2 * (MAX_NUM_REF + 1)]; int wantPoc[2 * (MAX_NUM_REF + 1)]; int nwant = 0;
+            want[nwant] = rec; wantPoc[nwant++] = recPoc;
+            if (!known)
+                for (int l = 0; l < 2; l++)
+                    for (int r = 0; r < slice->m_numRefIdx[l]; r++)
+                    {
+                        const MotionReference& mr = slice->m_mref[l][r];
+                        if (!mr.reconPic || mr.isWeighted || mr.fpelPlane[0] != mr.reconPic->m_picOrg[0] || mr.reconPic->m_stride != g.p.stride) continue;
+                        bool dup = false;
+                        for (int k = 0; k < nwant; k++) dup |= want[k] == mr.reconPic && wantPoc[k] == slice->m_refPOCList[l][r];
+                        if (!dup) { want[nwant] = mr.reconPic; wantPoc[nwant++] = slice->m_refPOCList[l][r]; }
+                    }
+            int slots[2 * (MAX_NUM_REF + 1)], gens[2 * (MAX_NUM_REF + 1)]; const void* bufs[2 * (MAX_NUM_REF + 1)]; int n = 0;
+            for (int k = 0; k < nwant; k++)
             {
-                Pair& q = g.pairs[freeSlot];
-                q.used = true; q.fencPoc = fencPoc; q.rec = rec; q.recPoc = recPoc; q.slot = freeSlot; q.gen = rc;
-                slot = freeSlot; gen = rc;
-                g.submits++;
+                int freeSlot = -1;
+                for (int i = 0; i < g.p.slots && freeSlot < 0; i++)
+                {
+                    bool taken = false;
+                    for (int j = 0; j < n; j++) taken |= slots[j] == i;
+                    if (!taken && (!g.pairs[i].used || g.pairs[i].fencPoc != fencPoc)) freeSlot = i;      /* an earlier picture's surfaces: its encode is over (-F 1) */
+                }
+                if (freeSlot < 0) break;
+                slots[n] = freeSlot; bufs[n] = want[k]->m_picBuf[0]; n++;
+            }
+            int rc = -1;
+            if (n > 0 && g.p.submit_batch)
+                rc = g.p.submit_batch(g.p.ctx, n, slots, fencPic->m_picBuf[0], (uint64_t)(uint32_t)fencPoc, bufs, gens);
+            else if (n > 0)
+            {
+                rc = 0;
+                for (int k = 0; k < n && rc == 0; k++)
+                {
+                    gens[k] = g.p.submit(g.p.ctx, slots[k], fencPic->m_picBuf[0], (uint64_t)(uint32_t)fencPoc, bufs[k]);
+                    if (gens[k] <= 0) rc = -1;
+                }
+            }
+            if (rc == 0)
+            {
+                for (int k = 0; k < n; k++)
+                {
+                    Pair& q = g.pairs[slots[k]];
+                    q.used = true; q.fencPoc = fencPoc; q.rec = want[k]; q.recPoc = wantPoc[k]; q.slot = slots[k]; q.gen = gens[k];
+                    g.submits++;
+                }
+                slot = slots[0]; gen = gens[0];            /* want[0] is the pair that was asked for */
                 g.epoch.fetch_add(1, std::memory_order_release);
                 t_pairs.epoch = g.epoch.load(); t_pairs.n = 0;
             }
@@ -283,7 +326,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
                 if (idx >= 0 && idx < 2 * (MAX_NUM_REF + 1))
                     recPoc = slice->m_refPOCList[idx / (MAX_NUM_REF + 1)][idx % (MAX_NUM_REF + 1)];
                 int gen = 0;
-                const int slot = recPoc == -0x7fffffff ? -1 : pair_slot(frame->m_poc, src, rec, recPoc, gen);
+                const int slot = recPoc == -0x7fffffff ? -1 : pair_slot(frame->m_poc, src, slice, rec, recPoc, gen);
                 if (slot >= 0)
                 {
                     c.nparts = 0;
@@ -324,13 +367,14 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
 extern "C" {
 
 /* provider: see the header comment; geometry = the PicYuv layout of the encode about to start.  Call before x265ref_encode. */
-int x265ref_seam_configure(void* ctx, void* submit, void* surface, void* ready, int range, int surf_format, int slots,
+int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* surface, void* ready, int range, int surf_format, int slots,
                            int width, int height, intptr_t stride, int margin_x, int margin_y, int min_pu, int verify)
 {
     if (slots < 1 || slots > MAX_SLOTS || range < 1 || (width & 63) || (height & 63)) return -1;
     if (surf_format == SURF_PACKED && X265_DEPTH != 8) return -2;
     g.p.ctx = ctx;
     g.p.submit = (int (*)(void*, int, const void*, uint64_t, const void*))submit;
+    g.p.submit_batch = (int (*)(void*, int, const int*, const void*, uint64_t, const void* const*, int*))submit_batch;      /* may be NULL */
     g.p.surface = (const void* (*)(void*, int))surface;
     g.p.ready = (const volatile int* (*)(void*, int))ready;
     g.p.range = range; g.p.surf_format = surf_format; g.p.slots = slots;

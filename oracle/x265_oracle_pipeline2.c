@@ -45,9 +45,94 @@ static void zxy(int z, int* x, int* y)
 /* level: 0..2 -> 8x8, 16x16, 32x32 blocks.  mv: int32 [ctu*85][2] = {cost, qx | qy << 16} from the sub-pel stage.
  * Outputs: recon plane (same geometry as fenc), levels int16 [ctu][npu][n*n], numSig uint32 [ctu][npu],
  * dist uint64 [ctu][npu]. */
+/* ---- sign-bit hiding of the non-RDOQ quantiser: Quant::signBitHidingHDQ (quant.cpp:247-395), called by transformNxN when
+ * numSig >= 2 and pps.bSignHideEnabled (quant.cpp:471-476) - the x265 default.  Per 4x4 coefficient group in scan order whose first
+ * and last non-zero level lie >= SBH_THRESHOLD (4, common.h:281) positions apart, the sign of the first non-zero level is inferred
+ * from the parity of the group's sum; when the parity is wrong, the level whose change costs least (deltaU from the quantiser,
+ * dct.cpp:664-686) moves by one towards / away from zero.  Scan orders: the up-right diagonal / horizontal / vertical scans of the
+ * standard (6.5.3-6.5.5) over 4x4 groups; equal to the reference's g_scanOrder (checked in tests/test_oracle_classes_vs_reference.py). */
+enum { ORACLE_SCAN_DIAG = 0, ORACLE_SCAN_HOR = 1, ORACLE_SCAN_VER = 2 };
+#define TU_FLAG_INTRA_SLICE 1
+#define TU_FLAG_SIGN_HIDE   2
+
+static void scan_xy(int type, int n, int idx, int* x, int* y)      /* idx-th position of an n x n grid in scan `type` */
+{
+    if (type == ORACLE_SCAN_HOR) { *x = idx % n; *y = idx / n; return; }
+    if (type == ORACLE_SCAN_VER) { *x = idx / n; *y = idx % n; return; }
+    int k = 0;
+    for (int d = 0; d < 2 * n - 1; d++)
+        for (int yy = d < n - 1 ? d : n - 1; yy >= 0; yy--)
+        {
+            const int xx = d - yy;
+            if (xx >= n) break;
+            if (k++ == idx) { *x = xx; *y = yy; return; }
+        }
+    *x = *y = 0;
+}
+
+void EXPORT(x265oracle_scan_order)(int type, int log2n, uint16_t* out)
+{
+    const int n = 1 << log2n, g = n >> 2;
+    if (log2n > 3) type = ORACLE_SCAN_DIAG;                               /* mode-dependent scans exist for 4x4 and 8x8 only */
+    for (int cg = 0; cg < g * g; cg++)
+    {
+        int cx, cy;
+        scan_xy(type, g, cg, &cx, &cy);
+        for (int i = 0; i < 16; i++)
+        {
+            int ix, iy;
+            scan_xy(type, 4, i, &ix, &iy);
+            out[cg * 16 + i] = (uint16_t)((cy * 4 + iy) * n + cx * 4 + ix);
+        }
+    }
+}
+
+/* CUData::getTUEntropyCodingParameters' scan choice (cudata.cpp:2067-2089) for an intra TU of a 4:2:0 picture */
+static int intra_scan_type(int mode, int n, int chroma)
+{
+    if (!(n == 4 || (!chroma && n == 8))) return ORACLE_SCAN_DIAG;
+    return mode >= 22 && mode <= 30 ? ORACLE_SCAN_HOR : (mode >= 6 && mode <= 14 ? ORACLE_SCAN_VER : ORACLE_SCAN_DIAG);
+}
+
+static uint32_t sign_hide(int16_t* level, const int32_t* deltaU, const int16_t* dct, uint32_t numSig, int scanType, int log2n)
+{
+    uint16_t scan[32 * 32];
+    EXPORT(x265oracle_scan_order)(scanType, log2n, scan);
+    const int ncg = 1 << (2 * log2n - 4);
+    int cgLast = -1;
+    for (int i = (ncg << 4) - 1; i >= 0 && cgLast < 0; i--) if (level[scan[i]]) cgLast = i >> 4;
+    for (int cg = cgLast; cg >= 0; cg--)
+    {
+        const uint16_t* sc = scan + cg * 16;
+        int first = -1, last = -1, sum = 0;
+        for (int i = 0; i < 16; i++) if (level[sc[i]]) { if (first < 0) first = i; last = i; sum += level[sc[i]]; }
+        if (first < 0 || last - first < 4) continue;
+        const int signbit = level[sc[first]] > 0 ? 0 : 1;
+        if (signbit == (sum & 1)) continue;
+        int minCost = 0x7fffffff, minPos = -1, change = 0;
+        for (int i = cg == cgLast ? last : 15; i >= 0; i--)
+        {
+            const int pos = sc[i];
+            int cost = 0x7fffffff, ch = 0;
+            if (level[pos])
+            {
+                if (deltaU[pos] > 0) { cost = -deltaU[pos]; ch = 1; }
+                else if (!(i == first && (level[pos] == 1 || level[pos] == -1))) { cost = deltaU[pos]; ch = -1; }
+            }
+            else if (i > first || (dct[pos] >= 0 ? 0 : 1) == signbit) { cost = -deltaU[pos]; ch = 1; }
+            if (cost < minCost) { minCost = cost; minPos = pos; change = ch; }
+        }
+        if (level[minPos] == 32767 || level[minPos] == -32768) change = -1;
+        if (!level[minPos]) numSig++;
+        else if (change == -1 && (level[minPos] == 1 || level[minPos] == -1)) numSig--;
+        level[minPos] = (int16_t)(level[minPos] + (dct[minPos] < 0 ? -change : change));
+    }
+    return numSig;
+}
+
 int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const pixel* fref, intptr_t frefStride,
                                    pixel* recon, intptr_t reconStride, int width, int height, int level,
-                                   const int32_t* mv, int qp, int isIntraSlice,
+                                   const int32_t* mv, int qp, int flags,
                                    int16_t* levels, uint32_t* numSigOut, uint64_t* distOut,
                                    int ctuBegin, int ctuEnd, int nthreads)
 {
@@ -62,7 +147,7 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
     const int per = qp / 6, rem = qp % 6;
     const int transformShift = 15 - X265HIP_DEPTH - log2n;
     const int qbits = 14 + per + transformShift;
-    const int add = (isIntraSlice ? 171 : 85) << (qbits - 9);
+    const int add = ((flags & TU_FLAG_INTRA_SLICE) ? 171 : 85) << (qbits - 9);
     const int dqShift = 20 - 14 - transformShift;
     const int dqScale = kInvQuantScales[rem] << per;
     (void)height;
@@ -99,7 +184,8 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
             cu->sub_ps(resi, 64, fe, pred, fencStride, 64);
             cu->dct(resi, coef, 64);
             int16_t* q = levels + ((size_t)ctu * npu + z) * n * n;
-            const uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
+            uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
+            if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, ORACLE_SCAN_DIAG, log2n);
             numSigOut[(size_t)ctu * npu + z] = numSig;
             if (numSig)
             {
@@ -129,7 +215,7 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
  * records in the sub-pel stage's format; dir: uint8 [ctu][npu] or NULL (all 3). */
 int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, const pixel* fref0, const pixel* fref1, intptr_t frefStride,
                                       pixel* recon, intptr_t reconStride, int width, int height, int level,
-                                      const int32_t* mv0, const int32_t* mv1, const uint8_t* dir, int qp, int isIntraSlice,
+                                      const int32_t* mv0, const int32_t* mv1, const uint8_t* dir, int qp, int flags,
                                       int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads)
 {
     static x265hip_EncoderPrimitives prim;
@@ -143,7 +229,7 @@ int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, co
     const int per = qp / 6, rem = qp % 6;
     const int transformShift = 15 - X265HIP_DEPTH - log2n;
     const int qbits = 14 + per + transformShift;
-    const int add = (isIntraSlice ? 171 : 85) << (qbits - 9);
+    const int add = ((flags & TU_FLAG_INTRA_SLICE) ? 171 : 85) << (qbits - 9);
     const int dqShift = 20 - 14 - transformShift;
     const int dqScale = kInvQuantScales[rem] << per;
 #ifdef _OPENMP
@@ -201,7 +287,8 @@ int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, co
             cu->sub_ps(resi, 64, fe, pred, fencStride, 64);
             cu->dct(resi, coef, 64);
             int16_t* q = levels + ((size_t)ctu * npu + z) * n * n;
-            const uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
+            uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
+            if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, ORACLE_SCAN_DIAG, log2n);
             numSigOut[(size_t)ctu * npu + z] = numSig;
             if (numSig)
             {
@@ -231,7 +318,7 @@ int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, co
  * caller, + QP_BD_OFFSET).  Outputs as x265oracle_inter_recon with (n/2)^2 levels per block. */
 int EXPORT(x265oracle_inter_recon_chroma)(const pixel* fenc, intptr_t fencStride, const pixel* fref, intptr_t frefStride,
                                           pixel* recon, intptr_t reconStride, int width, int height, int level,
-                                          const int32_t* mv, int qp, int isIntraSlice,
+                                          const int32_t* mv, int qp, int flags,
                                           int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads)
 {
     static x265hip_EncoderPrimitives prim;
@@ -245,7 +332,7 @@ int EXPORT(x265oracle_inter_recon_chroma)(const pixel* fenc, intptr_t fencStride
     const int per = qp / 6, rem = qp % 6;
     const int transformShift = 15 - X265HIP_DEPTH - log2nc;
     const int qbits = 14 + per + transformShift;
-    const int add = (isIntraSlice ? 171 : 85) << (qbits - 9);
+    const int add = ((flags & TU_FLAG_INTRA_SLICE) ? 171 : 85) << (qbits - 9);
     const int dqShift = 20 - 14 - transformShift;
     const int dqScale = kInvQuantScales[rem] << per;
 #ifdef _OPENMP
@@ -284,7 +371,8 @@ int EXPORT(x265oracle_inter_recon_chroma)(const pixel* fenc, intptr_t fencStride
             cu->sub_ps(resi, 32, fe, pred, fencStride, 32);
             cu->dct(resi, coef, 32);
             int16_t* q = levels + ((size_t)ctu * npu + z) * nc * nc;
-            const uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, nc * nc);
+            uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, nc * nc);
+            if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, ORACLE_SCAN_DIAG, log2nc);
             numSigOut[(size_t)ctu * npu + z] = numSig;
             if (numSig)
             {
@@ -323,14 +411,14 @@ static const uint8_t kIntraFilterFlags[35] = {
     0x38 };
 
 static int intra_recon_core(const pixel* fenc, intptr_t fencStride, const pixel* nb, pixel* recon, intptr_t reconStride,
-                            int n, int qp, int isIntraSlice, const intra_job* jobs, int njobs,
+                            int n, int qp, int flags, const intra_job* jobs, int njobs,
                             int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads, int chroma);
 
 int EXPORT(x265oracle_intra_recon)(const pixel* fenc, intptr_t fencStride, const pixel* nb, pixel* recon, intptr_t reconStride,
-                                   int n, int qp, int isIntraSlice, const intra_job* jobs, int njobs,
+                                   int n, int qp, int flags, const intra_job* jobs, int njobs,
                                    int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads)
 {
-    return intra_recon_core(fenc, fencStride, nb, recon, reconStride, n, qp, isIntraSlice, jobs, njobs, levels, numSigOut, distOut, nthreads, 0);
+    return intra_recon_core(fenc, fencStride, nb, recon, reconStride, n, qp, flags, jobs, njobs, levels, numSigOut, distOut, nthreads, 0);
 }
 
 /* The chroma flavour for 4:2:0 (Search::codeIntraChromaQt's pixel work, search.cpp:899-930): Predict::predIntraChromaAng
@@ -338,14 +426,14 @@ int EXPORT(x265oracle_intra_recon)(const pixel* fenc, intptr_t fencStride, const
  * smoothing), and the 4x4 TU uses the DCT (useDST needs TEXT_LUMA, quant.cpp:426,583).  qp = the chroma QP the host mapped
  * (Quant::setChromaQP, + QP_BD_OFFSET); fenc / nb / recon are the chroma plane's. */
 int EXPORT(x265oracle_intra_recon_chroma)(const pixel* fenc, intptr_t fencStride, const pixel* nb, pixel* recon, intptr_t reconStride,
-                                          int n, int qp, int isIntraSlice, const intra_job* jobs, int njobs,
+                                          int n, int qp, int flags, const intra_job* jobs, int njobs,
                                           int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads)
 {
-    return intra_recon_core(fenc, fencStride, nb, recon, reconStride, n, qp, isIntraSlice, jobs, njobs, levels, numSigOut, distOut, nthreads, 1);
+    return intra_recon_core(fenc, fencStride, nb, recon, reconStride, n, qp, flags, jobs, njobs, levels, numSigOut, distOut, nthreads, 1);
 }
 
 static int intra_recon_core(const pixel* fenc, intptr_t fencStride, const pixel* nb, pixel* recon, intptr_t reconStride,
-                            int n, int qp, int isIntraSlice, const intra_job* jobs, int njobs,
+                            int n, int qp, int flags, const intra_job* jobs, int njobs,
                             int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads, int chroma)
 {
     static x265hip_EncoderPrimitives prim;
@@ -358,7 +446,7 @@ static int intra_recon_core(const pixel* fenc, intptr_t fencStride, const pixel*
     const int per = qp / 6, rem = qp % 6;
     const int transformShift = 15 - X265HIP_DEPTH - log2n;
     const int qbits = 14 + per + transformShift;
-    const int add = (isIntraSlice ? 171 : 85) << (qbits - 9);
+    const int add = ((flags & TU_FLAG_INTRA_SLICE) ? 171 : 85) << (qbits - 9);
     const int dqShift = 20 - 14 - transformShift;
     const int dqScale = kInvQuantScales[rem] << per;
 #ifdef _OPENMP
@@ -385,7 +473,8 @@ static int intra_recon_core(const pixel* fenc, intptr_t fencStride, const pixel*
         if (useDST) prim.dst4x4(resi, coef, n);
         else cu->dct(resi, coef, n);
         int16_t* q = levels + (size_t)j * n * n;
-        const uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
+        uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
+        if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, intra_scan_type(mode, n, chroma), log2n);
         numSigOut[j] = numSig;
         if (numSig)
         {

@@ -1060,3 +1060,94 @@ def test_search_driver_with_extra_candidates_equals_reference(depth):
                      -57, -57, 57, 57, jb, n, 1, mvc.ctypes.data, num.ctypes.data) == 0
             for a, b in zip(ja, jb):
                 assert (a.out_cost, a.out_qmvx, a.out_qmvy) == (b.out_cost, b.out_qmvx, b.out_qmvy)
+
+
+# ------------------------------------------------------------------------------------------------ sign-bit hiding (the x265 default)
+def test_scan_orders_equal_reference_tables():
+    """The oracle generates the up-right diagonal / horizontal / vertical coefficient scans from the standard's definition; the
+    reference ships them as tables (g_scanOrder, constants.cpp)."""
+    import oracle_api as O
+    lib = _ref(8)
+    tab = (ctypes.c_void_p * 12).in_dll(lib, "_ZN4x26511g_scanOrderE")
+    L = O.lib()
+    for t in range(3):
+        for s in range(4):
+            n = 16 << (2 * s)
+            want = np.ctypeslib.as_array((ctypes.c_uint16 * n).from_address(tab[t * 4 + s]))
+            got = np.zeros(n, np.uint16)
+            L.x265oracle_scan_order_d8.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+            L.x265oracle_scan_order_d8(t, s + 2, got.ctypes.data)
+            assert np.array_equal(got, want), f"scan type {t}, log2 size {s + 2}"
+
+
+@pytest.mark.parametrize("chroma", [False, True])
+@pytest.mark.parametrize("depth,n,qp,islice", [(8, 4, 24, 1), (8, 8, 27, 0), (8, 16, 30, 1), (8, 32, 22, 0), (8, 32, 38, 1), (10, 8, 36, 1), (10, 16, 40, 0), (12, 8, 50, 1)])
+def test_intra_tu_sign_hiding_equals_reference_quant_class(depth, n, qp, islice, chroma):
+    """pps.bSignHideEnabled = 1 (x265's default): Quant::transformNxN runs signBitHidingHDQ (quant.cpp:247-395, 471-476) after the
+    quantiser.  Flat neighbours make every mode's prediction a constant, so DC (diagonal scan), mode 26 (horizontal scan for 4x4 / luma
+    8x8) and mode 10 (vertical scan) can each be compared block by block with the real class."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_tu_roundtrip_ex"):
+        pytest.skip("oracle/_ref predates x265ref_tu_roundtrip_ex")
+    rng = np.random.default_rng([35, depth, n, qp])
+    dt = np.uint8 if depth == 8 else np.uint16
+    pmax, v = (1 << depth) - 1, 1 << (depth - 1)
+    ntu = 48
+    W = n * ntu
+    yy, xx = np.mgrid[0:n, 0:W]
+    amp = np.repeat(rng.choice([0.0, 0.03, 0.2, 0.45], size=ntu), n)[None, :]
+    src = np.clip(np.rint(v + amp * pmax * np.sin(xx / 2.3 + yy / 1.7) + rng.normal(0, 2.5 * (1 << (depth - 8)), (n, W))), 0, pmax).astype(dt)
+    nbw = 4 * n + 1
+    nb = np.full(2 * nbw, v, dtype=dt)
+    changed = 0
+    for mode in (1, 26, 10):
+        jobs = np.zeros(ntu, dtype=np.dtype([("off", "<i8", 4), ("arg", "<i4", 4)]))
+        for t in range(ntu):
+            jobs["off"][t] = (t * n, 0, nbw, t * n * n)
+            jobs["arg"][t, 0] = mode
+        rec, lev, ns, _ = O.intra_recon(depth, n, src.reshape(-1), W, nb, ntu * n * n, n, qp, islice | O.TU_SIGN_HIDE, jobs, chroma=chroma)
+        plain = O.intra_recon(depth, n, src.reshape(-1), W, nb, ntu * n * n, n, qp, islice, jobs, chroma=chroma)[1]
+        resi = np.stack([src[:, t * n:(t + 1) * n].astype(np.int16) - v for t in range(ntu)]).reshape(-1)
+        rlev, rns, rout = np.zeros(ntu * n * n, np.int16), np.zeros(ntu, np.uint32), np.zeros(ntu * n * n, np.int16)
+        fn = lib.x265ref_tu_roundtrip_ex
+        fn.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p] * 3
+        assert fn(resi.ctypes.data, n, qp, 1, islice, 1, mode, int(chroma), ntu, rlev.ctypes.data, rns.ctypes.data, rout.ctypes.data) == 0
+        assert np.array_equal(lev, rlev), f"mode {mode}: levels differ in TUs {np.unique(np.nonzero(lev != rlev)[0] // (n * n))[:8]}"
+        assert np.array_equal(ns, rns)
+        assert np.array_equal(rec.astype(np.int32), np.clip(v + rout.astype(np.int32), 0, pmax))
+        changed += int(np.count_nonzero(plain != lev))
+    assert changed > 0, "sign hiding never changed a level: the case does not exercise it"
+
+
+@pytest.mark.parametrize("depth,level,qp", [(8, 2, 30), (8, 0, 24), (8, 1, 27), (10, 1, 38), (12, 1, 50)])
+def test_inter_tu_sign_hiding_equals_reference_quant_class(depth, level, qp):
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_tu_roundtrip_ex"):
+        pytest.skip("oracle/_ref predates x265ref_tu_roundtrip_ex")
+    clip = F.synth_clip(128, 64, 2, depth=depth, seed=83)
+    cur, stride, org, w64, h64 = F.pad_plane(clip[1][0])
+    ref = F.pad_plane(clip[0][0])[0]
+    nctu = (w64 // 64) * (h64 // 64)
+    n = 8 << level
+    nblk = (64 // n) ** 2
+    mv = np.zeros((nctu * 85, 2), np.int32)
+    rec, lev, ns, dist = O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp, intra_slice=O.TU_SIGN_HIDE)
+    plain = O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp)[1]
+    r0, c0 = org // stride, org % stride
+    blocks = []
+    for ctu in range(nctu):
+        cx, cy = (ctu % (w64 // 64)) * 64, (ctu // (w64 // 64)) * 64
+        for z in range(nblk):
+            bx, by = _zxy(z)
+            y0, x0 = r0 + cy + by * n, c0 + cx + bx * n
+            blocks.append((cur[y0:y0 + n, x0:x0 + n].astype(np.int16) - ref[y0:y0 + n, x0:x0 + n].astype(np.int16)).reshape(-1))
+    resi = np.concatenate(blocks)
+    nj = len(blocks)
+    rlev, rns, rout = np.zeros(nj * n * n, np.int16), np.zeros(nj, np.uint32), np.zeros(nj * n * n, np.int16)
+    fn = lib.x265ref_tu_roundtrip_ex
+    fn.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p] * 3
+    assert fn(resi.ctypes.data, n, qp, 0, 0, 1, 1, 0, nj, rlev.ctypes.data, rns.ctypes.data, rout.ctypes.data) == 0
+    assert np.array_equal(lev, rlev) and np.array_equal(ns, rns)
+    assert np.count_nonzero(plain != lev) > 0

@@ -92,7 +92,7 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
     opts = [("pools", str(cores)), ("frame-threads", str(frame_threads)), ("crf", "28")] + cfg["opts"]
     res = {"config": cfg["name"], "size": f"{w}x{h}", "depth": depth, "preset": cfg["preset"], "options": dict(opts), "pool_threads": cores,
            "reference_build": "x265 3.5 C primitives (no asm: nasm is not in the image), g++ -O3"}
-    md5_c = None
+    md5_c = {}
     for t in tables:
         nf = n
         filler, note, closer, enc_lib = None, None, None, lib
@@ -118,7 +118,7 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
         r = {"frames": nf, "seconds": round(sec, 3), "fps": round(nf / sec, 4), "bytes": nbytes, "md5": md5, "slots_replaced": filled,
              "wall_seconds_with_open_close": round(wall, 3)}
         if t == "c":
-            md5_c = {nf: md5}
+            md5_c[nf] = md5
             # SURVEY section 6 call-rate probe (counting thunks, 1080p): medium ~3.0 M, slow ~3.4 M primitive calls per frame; scale by area
             per_1080p = {"ultrafast": 1.2e6, "medium": 3.0e6, "slow": 3.4e6, "slower": 6e6}.get(cfg["preset"], 3e6)
             r["est_primitive_calls_per_frame"] = int(per_1080p * (w * h) / (1920 * 1080))

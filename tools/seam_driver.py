@@ -41,7 +41,7 @@ def seam_lib(depth):
     lib.x265ref_encode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long,
                                    ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
-    lib.x265ref_seam_configure.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_ssize_t] + [ctypes.c_int] * 4
+    lib.x265ref_seam_configure.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_ssize_t] + [ctypes.c_int] * 4
     lib.x265ref_seam_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     return lib
 
@@ -102,7 +102,8 @@ class OracleProvider:
         return self.flags[slot].ctypes.data
 
     def pointers(self):
-        return None, *(ctypes.cast(c, ctypes.c_void_p) for c in self._cb)
+        sub, surf, rdy = (ctypes.cast(c, ctypes.c_void_p) for c in self._cb)
+        return None, sub, None, surf, rdy          # no batch entry: the binding falls back to single submits
 
     def report(self):
         return {"provider": "oracle (CPU checker)", "fills": self.fills}
@@ -118,7 +119,7 @@ class CacheParams(ctypes.Structure):
 
 
 class CacheStats(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_uint64) for n in ("fills", "failed", "us_upload", "us_kernel", "us_download", "bytes_downloaded", "surface_bytes")]
+    _fields_ = [(n, ctypes.c_uint64) for n in ("fills", "failed", "batches", "us_upload", "us_kernel", "us_download", "bytes_downloaded", "surface_bytes")]
 
 
 class GpuProvider:
@@ -137,16 +138,16 @@ class GpuProvider:
 
     def pointers(self):
         L = self.L
-        return (self.handle, ctypes.cast(L.x265hip_me_cache_submit, ctypes.c_void_p), ctypes.cast(L.x265hip_me_cache_surface, ctypes.c_void_p),
-                ctypes.cast(L.x265hip_me_cache_ready, ctypes.c_void_p))
+        return (self.handle, ctypes.cast(L.x265hip_me_cache_submit, ctypes.c_void_p), ctypes.cast(L.x265hip_me_cache_submit_batch, ctypes.c_void_p),
+                ctypes.cast(L.x265hip_me_cache_surface, ctypes.c_void_p), ctypes.cast(L.x265hip_me_cache_ready, ctypes.c_void_p))
 
     def report(self):
         st = CacheStats()
         self.L.x265hip_me_cache_stats(self.handle, ctypes.byref(st))
-        n = max(1, st.fills)
-        return {"provider": "x265hip_me_cache (one x265hip_me_fullsearch launch per (picture, reference))", "fills": int(st.fills), "failed": int(st.failed),
-                "ms_per_fill": {"upload": round(st.us_upload / n / 1e3, 3), "kernel": round(st.us_kernel / n / 1e3, 3),
-                                "download": round(st.us_download / n / 1e3, 3)},
+        n = max(1, st.batches)
+        return {"provider": "x265hip_me_cache (one x265hip_me_fullsearch launch per (picture, reference); a picture's references as one batch, "
+                            "surfaces downloaded row-interleaved)", "fills": int(st.fills), "failed": int(st.failed), "batches": int(st.batches),
+                "ms_per_batch": {"uploads_and_kernels": round(st.us_kernel / n / 1e3, 3), "download": round(st.us_download / n / 1e3, 3)},
                 "surface_mbytes_per_pair": round(st.surface_bytes / 1e6, 1),
                 "download_gbytes_per_s": round(st.bytes_downloaded / max(1, st.us_download) / 1e3, 2)}
 
@@ -162,8 +163,8 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     lib = seam_lib(depth)
     geo = geometry(width, height)
     prov = (GpuProvider if provider == "gpu" else OracleProvider)(depth, geo, rng, slots)
-    ctx, submit, surface, ready = prov.pointers()
-    rc = lib.x265ref_seam_configure(ctx, submit, surface, ready, rng, prov.format, slots, geo["width"], geo["height"], geo["stride"],
+    ctx, submit, submit_batch, surface, ready = prov.pointers()
+    rc = lib.x265ref_seam_configure(ctx, submit, submit_batch, surface, ready, rng, prov.format, slots, geo["width"], geo["height"], geo["stride"],
                                     geo["margin_x"], geo["margin_y"], min_pu, int(bool(verify)))
     if rc:
         raise RuntimeError(f"x265ref_seam_configure failed ({rc})")

@@ -29,15 +29,19 @@ struct x265hip_me_cache
     x265hip_me_cache_params prm;
     int bpp, ctusW, ctusH, nc, ng, groupBytes, device;
     size_t planeBytes, surfBytes, rowBytes, orgOffset;     // orgOffset: bytes from the buffer start to sample (0,0)
-    void* dFenc = nullptr; void* dRef = nullptr; void* dSurf = nullptr;
+    void* dFenc = nullptr; void* dRef = nullptr;
     uint64_t fencKeyOnDevice = ~0ull;
     hipStream_t stream = nullptr;
-    std::vector<hipEvent_t> rowEvents;
+    uint8_t* stageFenc = nullptr;          // pinned copy of the last submitted source picture (shared by the pairs of a picture)
+    uint64_t stageFencKey = ~0ull;
+    std::mutex stageMu;
     struct Slot
     {
         uint8_t* surf = nullptr;           // pinned host surfaces
-        uint8_t* stageFenc = nullptr;      // pinned copies of the submitted planes (taken inside submit: the caller's buffers
-        uint8_t* stageRef = nullptr;       //   need not outlive the call)
+        void* dSurf = nullptr;             // device surfaces: every pair of a batch keeps its own, the rows are downloaded interleaved
+        uint8_t* stageRef = nullptr;       // pinned copy of the submitted reference plane (taken inside submit: the caller's buffer
+                                           //   need not outlive the call)
+        std::vector<hipEvent_t> rowEvents;
         std::atomic<int>* ready = nullptr; // per CTU row
         uint64_t fencKey = 0;
         std::atomic<int> generation{0};
@@ -50,7 +54,7 @@ struct x265hip_me_cache
     bool stop = false;
     std::thread worker;
     // statistics
-    std::atomic<uint64_t> fills{0}, failed{0};
+    std::atomic<uint64_t> fills{0}, failed{0}, batches{0};
     std::atomic<uint64_t> usUpload{0}, usKernel{0}, usDownload{0}, bytesDown{0};
     char workerError[256] = "";
 };
@@ -62,47 +66,57 @@ double now_us()
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// one (source, reference) pair: upload -> one launch -> row-streamed download
-int run_job(x265hip_me_cache* c, int slotIdx, int generation)
+// A batch = the (source, reference) pairs that were queued together (normally all references of one picture): every pair is
+// uploaded and searched (one launch each), then the surfaces come down CTU ROW BY CTU ROW ACROSS THE PAIRS - row 0 of every pair,
+// row 1 of every pair, ... - the order in which the reference's wavefront rows need them, with a flag raised per (pair, row).
+int run_batch(x265hip_me_cache* c, const std::vector<x265hip_me_cache::Job>& batch)
 {
-    x265hip_me_cache::Slot& s = c->slots[slotIdx];
     X265HIP_TRY(hipSetDevice(c->device));
     const double t0 = now_us();
-    if (c->fencKeyOnDevice != s.fencKey)
+    for (const auto& job : batch)
     {
-        X265HIP_TRY(hipMemcpyAsync(c->dFenc, s.stageFenc, c->planeBytes, hipMemcpyHostToDevice, c->stream));
-        c->fencKeyOnDevice = s.fencKey;
+        x265hip_me_cache::Slot& s = c->slots[job.slot];
+        if (c->fencKeyOnDevice != s.fencKey)
+        {
+            std::lock_guard<std::mutex> lk(c->stageMu);
+            X265HIP_TRY(hipMemcpyAsync(c->dFenc, c->stageFenc, c->planeBytes, hipMemcpyHostToDevice, c->stream));
+            X265HIP_TRY(hipStreamSynchronize(c->stream));          // the staging copy may be replaced once this returns
+            c->fencKeyOnDevice = s.fencKey;
+        }
+        X265HIP_TRY(hipMemcpyAsync(c->dRef, s.stageRef, c->planeBytes, hipMemcpyHostToDevice, c->stream));
+        x265hip_me_params p;
+        memset(&p, 0, sizeof(p));
+        p.depth = c->prm.depth; p.width = c->prm.width; p.height = c->prm.height; p.range = c->prm.range;
+        p.fenc = (const uint8_t*)c->dFenc + c->orgOffset; p.fenc_stride = c->prm.stride;
+        p.fref = (const uint8_t*)c->dRef + c->orgOffset;  p.fref_stride = c->prm.stride;
+        p.surf = (int32_t*)s.dSurf; p.surf_format = c->prm.surf_format;
+        int rc = x265hip_me_fullsearch(&p, c->stream);          // stream order: the next pair's upload waits for this launch
+        if (rc) return rc;
     }
-    X265HIP_TRY(hipMemcpyAsync(c->dRef, s.stageRef, c->planeBytes, hipMemcpyHostToDevice, c->stream));
     X265HIP_TRY(hipStreamSynchronize(c->stream));
     const double t1 = now_us();
-    x265hip_me_params p;
-    memset(&p, 0, sizeof(p));
-    p.depth = c->prm.depth; p.width = c->prm.width; p.height = c->prm.height; p.range = c->prm.range;
-    p.fenc = (const uint8_t*)c->dFenc + c->orgOffset; p.fenc_stride = c->prm.stride;
-    p.fref = (const uint8_t*)c->dRef + c->orgOffset;  p.fref_stride = c->prm.stride;
-    p.surf = (int32_t*)c->dSurf; p.surf_format = c->prm.surf_format;
-    int rc = x265hip_me_fullsearch(&p, c->stream);
-    if (rc) return rc;
-    X265HIP_TRY(hipStreamSynchronize(c->stream));
-    const double t2 = now_us();
     // all row copies are queued at once (the PCIe pipe stays full), each followed by an event; flags are raised as they complete
     for (int r = 0; r < c->ctusH; r++)
-    {
-        X265HIP_TRY(hipMemcpyAsync(s.surf + (size_t)r * c->rowBytes, (const uint8_t*)c->dSurf + (size_t)r * c->rowBytes, c->rowBytes,
-                                   hipMemcpyDeviceToHost, c->stream));
-        X265HIP_TRY(hipEventRecord(c->rowEvents[r], c->stream));
-    }
+        for (const auto& job : batch)
+        {
+            x265hip_me_cache::Slot& s = c->slots[job.slot];
+            X265HIP_TRY(hipMemcpyAsync(s.surf + (size_t)r * c->rowBytes, (const uint8_t*)s.dSurf + (size_t)r * c->rowBytes, c->rowBytes,
+                                       hipMemcpyDeviceToHost, c->stream));
+            X265HIP_TRY(hipEventRecord(s.rowEvents[r], c->stream));
+        }
     for (int r = 0; r < c->ctusH; r++)
-    {
-        X265HIP_TRY(hipEventSynchronize(c->rowEvents[r]));
-        if (s.generation.load(std::memory_order_acquire) == generation)      // a newer submit owns the flags otherwise
-            s.ready[r].store(generation, std::memory_order_release);
-    }
-    const double t3 = now_us();
-    c->usUpload += (uint64_t)(t1 - t0); c->usKernel += (uint64_t)(t2 - t1); c->usDownload += (uint64_t)(t3 - t2);
-    c->bytesDown += c->surfBytes;
-    c->fills++;
+        for (const auto& job : batch)
+        {
+            x265hip_me_cache::Slot& s = c->slots[job.slot];
+            X265HIP_TRY(hipEventSynchronize(s.rowEvents[r]));
+            if (s.generation.load(std::memory_order_acquire) == job.generation)      // a newer submit owns the flags otherwise
+                s.ready[r].store(job.generation, std::memory_order_release);
+        }
+    const double t2 = now_us();
+    c->usKernel += (uint64_t)(t1 - t0); c->usDownload += (uint64_t)(t2 - t1);
+    c->bytesDown += c->surfBytes * batch.size();
+    c->fills += batch.size();
+    c->batches++;
     return 0;
 }
 
@@ -110,19 +124,22 @@ void worker_main(x265hip_me_cache* c)
 {
     for (;;)
     {
-        x265hip_me_cache::Job job;
+        std::vector<x265hip_me_cache::Job> batch;
         {
             std::unique_lock<std::mutex> lk(c->mu);
             c->cv.wait(lk, [c] { return c->stop || !c->queue.empty(); });
             if (c->stop) return;
-            job = c->queue.front();
-            c->queue.pop_front();
+            while (!c->queue.empty())                   // everything queued so far is one batch
+            {
+                const x265hip_me_cache::Job job = c->queue.front();
+                c->queue.pop_front();
+                if (c->slots[job.slot].generation.load() == job.generation)      // else: superseded before it ran
+                    batch.push_back(job);
+            }
         }
-        if (c->slots[job.slot].generation.load() != job.generation)
-            continue;                                   // superseded before it ran
-        if (run_job(c, job.slot, job.generation))
+        if (!batch.empty() && run_batch(c, batch))
         {
-            c->failed++;
+            c->failed += batch.size();
             snprintf(c->workerError, sizeof(c->workerError), "%s", x265hip_last_error());
         }
     }
@@ -133,14 +150,14 @@ void free_all(x265hip_me_cache* c)
     for (auto& s : c->slots)
     {
         if (s.surf) (void)hipHostFree(s.surf);
-        if (s.stageFenc) (void)hipHostFree(s.stageFenc);
+        if (s.dSurf) (void)hipFree(s.dSurf);
         if (s.stageRef) (void)hipHostFree(s.stageRef);
+        for (hipEvent_t e : s.rowEvents) if (e) (void)hipEventDestroy(e);
         delete[] s.ready;
     }
-    for (hipEvent_t e : c->rowEvents) (void)hipEventDestroy(e);
+    if (c->stageFenc) (void)hipHostFree(c->stageFenc);
     if (c->dFenc) (void)hipFree(c->dFenc);
     if (c->dRef) (void)hipFree(c->dRef);
-    if (c->dSurf) (void)hipFree(c->dSurf);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -181,15 +198,15 @@ int x265hip_me_cache_create(x265hip_me_cache** out, const x265hip_me_cache_param
     MC_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     MC_TRY(hipMalloc(&c->dFenc, c->planeBytes));
     MC_TRY(hipMalloc(&c->dRef, c->planeBytes));
-    MC_TRY(hipMalloc(&c->dSurf, c->surfBytes));
-    c->rowEvents.resize(c->ctusH);
-    for (int r = 0; r < c->ctusH; r++) { c->rowEvents[r] = nullptr; MC_TRY(hipEventCreateWithFlags(&c->rowEvents[r], hipEventDisableTiming)); }
+    MC_TRY(hipHostMalloc((void**)&c->stageFenc, c->planeBytes, hipHostMallocDefault));
     c->slots = std::vector<x265hip_me_cache::Slot>(p->slots);
     for (auto& s : c->slots)
     {
         MC_TRY(hipHostMalloc((void**)&s.surf, c->surfBytes, hipHostMallocDefault));
-        MC_TRY(hipHostMalloc((void**)&s.stageFenc, c->planeBytes, hipHostMallocDefault));
+        MC_TRY(hipMalloc(&s.dSurf, c->surfBytes));
         MC_TRY(hipHostMalloc((void**)&s.stageRef, c->planeBytes, hipHostMallocDefault));
+        s.rowEvents.assign(c->ctusH, nullptr);
+        for (int r = 0; r < c->ctusH; r++) MC_TRY(hipEventCreateWithFlags(&s.rowEvents[r], hipEventDisableTiming));
         s.ready = new std::atomic<int>[c->ctusH];
         for (int r = 0; r < c->ctusH; r++) s.ready[r].store(0);
     }
@@ -212,22 +229,46 @@ void x265hip_me_cache_destroy(x265hip_me_cache* c)
     delete c;
 }
 
-/* Copies the two planes (whole allocated buffers, margins included) and queues the search; returns at once.  fenc_key names the
- * source picture (e.g. its POC): consecutive submits with the same key upload the source once. */
-int x265hip_me_cache_submit(x265hip_me_cache* c, int slot, const void* fenc_buf, uint64_t fenc_key, const void* ref_buf)
+/* Copies the planes (whole allocated buffers, margins included) and queues the searches as ONE batch; returns at once.  fenc_key names
+ * the source picture (e.g. its POC): it is copied / uploaded once per key.  generations[i] receives slot i's new generation. */
+int x265hip_me_cache_submit_batch(x265hip_me_cache* c, int n, const int* slots, const void* fenc_buf, uint64_t fenc_key, const void* const* ref_bufs,
+                                  int* generations)
 {
-    if (!c || !fenc_buf || !ref_buf || slot < 0 || slot >= (int)c->slots.size()) { set_error("me_cache_submit: bad argument"); return X265HIP_EINVAL; }
-    x265hip_me_cache::Slot& s = c->slots[slot];
-    const int gen = s.generation.fetch_add(1) + 1;          // readers compare ready[row] with the generation they were handed
-    memcpy(s.stageFenc, fenc_buf, c->planeBytes);
-    memcpy(s.stageRef, ref_buf, c->planeBytes);
-    s.fencKey = fenc_key;
+    if (!c || n < 1 || !slots || !fenc_buf || !ref_bufs || !generations) { set_error("me_cache_submit_batch: bad argument"); return X265HIP_EINVAL; }
+    for (int i = 0; i < n; i++)
+        if (slots[i] < 0 || slots[i] >= (int)c->slots.size() || !ref_bufs[i]) { set_error("me_cache_submit_batch: bad slot / plane %d", i); return X265HIP_EINVAL; }
+    {
+        std::lock_guard<std::mutex> lk(c->stageMu);
+        if (c->stageFencKey != fenc_key)
+        {
+            memcpy(c->stageFenc, fenc_buf, c->planeBytes);
+            c->stageFencKey = fenc_key;
+        }
+    }
+    std::vector<x265hip_me_cache::Job> jobs;
+    for (int i = 0; i < n; i++)
+    {
+        x265hip_me_cache::Slot& s = c->slots[slots[i]];
+        const int gen = s.generation.fetch_add(1) + 1;          // readers compare ready[row] with the generation they were handed
+        memcpy(s.stageRef, ref_bufs[i], c->planeBytes);
+        s.fencKey = fenc_key;
+        generations[i] = gen;
+        jobs.push_back({ slots[i], gen });
+    }
     {
         std::lock_guard<std::mutex> lk(c->mu);
-        c->queue.push_back({ slot, gen });
+        for (const auto& j : jobs) c->queue.push_back(j);
     }
     c->cv.notify_one();
-    return gen;
+    return 0;
+}
+
+/* one pair: returns the slot's new GENERATION (> 0) or a negative error */
+int x265hip_me_cache_submit(x265hip_me_cache* c, int slot, const void* fenc_buf, uint64_t fenc_key, const void* ref_buf)
+{
+    int gen = 0;
+    const int rc = x265hip_me_cache_submit_batch(c, 1, &slot, fenc_buf, fenc_key, &ref_buf, &gen);
+    return rc ? rc : gen;
 }
 
 const void* x265hip_me_cache_surface(x265hip_me_cache* c, int slot)
@@ -244,7 +285,7 @@ const volatile int* x265hip_me_cache_ready(x265hip_me_cache* c, int slot)
 int x265hip_me_cache_stats(x265hip_me_cache* c, x265hip_me_cache_stats_t* st)
 {
     if (!c || !st) { set_error("me_cache_stats: NULL"); return X265HIP_EINVAL; }
-    st->fills = c->fills; st->failed = c->failed; st->us_upload = c->usUpload; st->us_kernel = c->usKernel;
+    st->fills = c->fills; st->failed = c->failed; st->batches = c->batches; st->us_upload = c->usUpload; st->us_kernel = c->usKernel;
     st->us_download = c->usDownload; st->bytes_downloaded = c->bytesDown; st->surface_bytes = c->surfBytes;
     if (c->failed) set_error("me_cache worker: %s", c->workerError);
     return 0;

@@ -53,7 +53,7 @@ struct TuArgs
     uint8_t* recon; long reconStrideB;
     int ctusW, depth, level;
     const int2* mv;                 // [ctu*85] {cost, qx | qy << 16}
-    int qp, intraSlice;
+    int qp, intraSlice;          // intraSlice: the X265HIP_TU_* flag bits
     int16_t* levels; uint32_t* numSig; unsigned long long* dist;
 };
 
@@ -82,10 +82,79 @@ template <int N> struct TuOps<N, true>
 };
 template <int N, bool DST> using TuOpsFor = TuOps<N, (N >= 16 && !DST)>;
 
+// ---- sign-bit hiding (Quant::signBitHidingHDQ, quant.cpp:247-395; on by default in x265: pps.bSignHideEnabled) -------------------
+// Coefficient scans of the standard (6.5.3-6.5.5) over 4x4 coefficient groups: up-right diagonal everywhere, horizontal / vertical
+// for 4x4 and 8x8 intra TUs whose direction asks for it (CUData::getTUEntropyCodingParameters, cudata.cpp:2067-2089).  The tables
+// hold x | y << 3 of the k-th position of an n x n up-right diagonal scan.
+__constant__ uint8_t kTuDiag2[4] = { 0, 8, 1, 9 };
+__constant__ uint8_t kTuDiag4[16] = { 0, 8, 1, 16, 9, 2, 24, 17, 10, 3, 25, 18, 11, 26, 19, 27 };
+__constant__ uint8_t kTuDiag8[64] = { 0, 8, 1, 16, 9, 2, 24, 17, 10, 3, 32, 25, 18, 11, 4, 40, 33, 26, 19, 12, 5, 48, 41, 34, 27, 20, 13, 6, 56, 49, 42, 35,
+                                      28, 21, 14, 7, 57, 50, 43, 36, 29, 22, 15, 58, 51, 44, 37, 30, 23, 59, 52, 45, 38, 31, 60, 53, 46, 39, 61, 54, 47, 62, 55, 63 };
+enum { TU_SCAN_DIAG = 0, TU_SCAN_HOR = 1, TU_SCAN_VER = 2, TU_FLAG_INTRA_SLICE = 1, TU_FLAG_SIGN_HIDE = 2 };
+
+// raster position inside the N x N block of scan position i (0..15) of coefficient group cg
+template <int N> __device__ __forceinline__ int tu_scan_pos(int scanType, int cg, int i)
+{
+    constexpr int G = N / 4;
+    int cx, cy, ix, iy;
+    if (scanType == TU_SCAN_DIAG || N > 8)
+    {
+        const int c = G == 1 ? 0 : (G == 2 ? kTuDiag2[cg] : (G == 4 ? kTuDiag4[cg] : kTuDiag8[cg]));
+        cx = c & 7; cy = c >> 3;
+        const int q = kTuDiag4[i];
+        ix = q & 7; iy = q >> 3;
+    }
+    else if (scanType == TU_SCAN_HOR) { cx = cg % G; cy = cg / G; ix = i & 3; iy = i >> 2; }
+    else { cx = cg / G; cy = cg % G; ix = i >> 2; iy = i & 3; }
+    return (cy * 4 + iy) * N + cx * 4 + ix;
+}
+
+// One lane per coefficient group (NN / 16 <= 64 groups, lanes of wavefront 0).  lev: the quantised levels (LDS, updated in place),
+// aux: per coefficient (deltaU << 1) | (dct coefficient < 0) as the quantiser left it; returns the change of numSig of this lane's group.
+template <int N> __device__ __forceinline__ int tu_sign_hide_group(int16_t* lev, const int16_t* aux, int16_t* lvOut, int scanType, int cg, int cgLast)
+{
+    int first = -1, last = -1, sum = 0;
+    int pos[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+    {
+        pos[i] = tu_scan_pos<N>(scanType, cg, i);
+        const int l = lev[pos[i]];
+        if (l) { if (first < 0) first = i; last = i; sum += l; }
+    }
+    if (first < 0 || last - first < 4) return 0;
+    const int signbit = lev[pos[first]] > 0 ? 0 : 1;
+    if (signbit == (sum & 1)) return 0;
+    int minCost = 0x7fffffff, minPos = -1, change = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; i--)
+    {
+        if (cg == cgLast && i > last) continue;
+        const int p = pos[i], l = lev[p], a = aux[p], du = a >> 1;
+        int cost = 0x7fffffff, ch = 0;
+        if (l)
+        {
+            if (du > 0) { cost = -du; ch = 1; }
+            else if (!(i == first && (l == 1 || l == -1))) { cost = du; ch = -1; }
+        }
+        else if (i > first || (a & 1) == signbit) { cost = -du; ch = 1; }
+        if (cost < minCost) { minCost = cost; minPos = p; change = ch; }
+    }
+    const int l = lev[minPos];
+    if (l == 32767 || l == -32768) change = -1;
+    int dn = 0;
+    if (!l) dn = 1;
+    else if (change == -1 && (l == 1 || l == -1)) dn = -1;
+    const int nl = l + ((aux[minPos] & 1) ? -change : change);
+    lev[minPos] = (int16_t)nl;
+    lvOut[minPos] = (int16_t)nl;
+    return dn;
+}
+
 template <typename Px, int N, bool DST>
 __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int16_t* pred, const int16_t* fe, int16_t* A, int16_t* B, unsigned long long* red, int& sNumSig,
-                                         int depth, int qp, int intraSlice, int16_t* lvOut, uint32_t* numSigOut, unsigned long long* distOut,
-                                         Px* rec, long cst)
+                                         int depth, int qp, int flags, int16_t* lvOut, uint32_t* numSigOut, unsigned long long* distOut,
+                                         Px* rec, long cst, int scanType = TU_SCAN_DIAG)
 {
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -97,7 +166,9 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
     const int per = qp / 6, rem = qp - per * 6;
     const int transformShift = 15 - depth - LOG2N;
     const int qbits = 14 + per + transformShift;
-    const int qadd = (intraSlice ? 171 : 85) << (qbits - 9);
+    const int qadd = ((flags & TU_FLAG_INTRA_SLICE) ? 171 : 85) << (qbits - 9);
+    const bool signHide = (flags & TU_FLAG_SIGN_HIDE) != 0;
+    const int qbits8 = qbits - 8;
     const int qscale = kTuQuantScales[rem];
     int16_t* lv = lvOut;
     int nz = 0;
@@ -141,6 +212,9 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
                 const int c = (int16_t)((p[r] + (1 << (sh2 - 1))) >> sh2);
                 const int t = abs(c) * qscale;
                 int level = (t + qadd) >> qbits;
+                // B's pass-1 values were consumed by the products above (one wavefront, LDS operations in order): it now keeps what
+                // sign hiding needs per coefficient - deltaU (dct.cpp:679, within +-256) and the sign of the transform coefficient
+                if (signHide) B[e] = (int16_t)((((t - (level << qbits)) >> qbits8) << 1) | (c < 0));
                 nz += level != 0;
                 if (c < 0) level = -level;
                 level = tu_sat16(level);
@@ -151,6 +225,7 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
     }
     else
     {
+    int auxReg = 0;
     for (int e = tid; e < NN; e += nth)
     {
         const int k = e >> LOG2N, j = e & (N - 1);
@@ -170,16 +245,42 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
         const int c = (int16_t)((acc + (1 << (sh2 - 1))) >> sh2);
         const int t = abs(c) * qscale;
         int level = (t + qadd) >> qbits;
+        auxReg = (((t - (level << qbits)) >> qbits8) << 1) | (c < 0);
         nz += level != 0;
         if (c < 0) level = -level;
         level = tu_sat16(level);
         A[e] = (int16_t)level;            // A is free again: quantised levels
         lv[e] = (int16_t)level;
     }
+    if (signHide)
+    {   // NN <= 64 <= blockDim here: a thread owns at most one coefficient; B may be rewritten once every thread is through reading it
+        __syncthreads();
+        if (tid < NN) B[tid] = (int16_t)auxReg;
+    }
     }
     nz = group_sum<64>(nz);
     if ((tid & 63) == 0 && nz) atomicAdd(&sNumSig, nz);
     __syncthreads();
+    if (signHide && sNumSig >= 2)
+    {   // Quant::signBitHidingHDQ: one lane per 4x4 coefficient group, the groups are independent of each other
+        if (tid < 64)
+        {
+            constexpr int NCG = NN / 16;
+            bool any = false;
+            if (tid < NCG)
+            {
+#pragma unroll
+                for (int i = 0; i < 16; i++) any |= A[tu_scan_pos<N>(scanType, tid, i)] != 0;
+            }
+            const unsigned long long mask = __ballot(any);
+            const int cgLast = 63 - __builtin_clzll(mask | 1ull);             // numSig >= 2: at least one group is populated
+            int dn = 0;
+            if (tid < NCG && any) dn = tu_sign_hide_group<N>(A, B, lv, scanType, tid, cgLast);
+            dn = group_sum<64>(dn);
+            if (tid == 0 && dn) sNumSig += dn;
+        }
+        __syncthreads();
+    }
     const int numSig = sNumSig;
     if (tid == 0) *numSigOut = (uint32_t)numSig;
 
@@ -565,7 +666,10 @@ __global__ void __launch_bounds__(N <= 8 ? 256 : 64) intra_recon_kernel(IntraTuA
         __syncthreads();
         tu_chain<Px, N, DST>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
                              a.levels + (size_t)job * NN, &a.numSig[job], &a.dist[job],
-                             reinterpret_cast<Px*>(a.recon) + jb.off[3], a.reconStrideB / BPP);
+                             reinterpret_cast<Px*>(a.recon) + jb.off[3], a.reconStrideB / BPP,
+                             // the scan sign hiding walks: mode-dependent for 4x4 TUs and 8x8 luma TUs (cudata.cpp:2083-2084)
+                             (N == 4 || (!a.chroma && N == 8)) ? (mode >= 22 && mode <= 30 ? TU_SCAN_HOR : (mode >= 6 && mode <= 14 ? TU_SCAN_VER : TU_SCAN_DIAG))
+                                                               : TU_SCAN_DIAG);
         __syncthreads();
     };
     // 4 / 8: one candidate per workgroup; 16 / 32: persistent, the MFMA operands above are reused
