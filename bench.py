@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_planes=None, cur_index=1):
+def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_planes=None, cur_index=1, tu_flags=2):
     """The oracle's restatement (CPU; checker + cpu_baseline leg only) of one frame of the pipeline - clip[cur_index] searched in
     clip[cur_index - 1] (or in ref_planes = padded Y, Cb, Cr of a reconstruction) - on the first n CTUs.  n == all CTUs also runs the per-picture stages (lookahead, deblocking, SAO statistics)
     and returns every stage output for the bit-exact comparison with the device pipeline.  Returns (seconds, outputs)."""
@@ -78,7 +78,7 @@ def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_pl
     mv = O.subpel_refine(depth, cur, stride, org, ref, stride, org, w64, h64, rng_r, 0, n, best, cq, qoff, subme,
                          nthreads=cores, avx2=avx2)
     rec, lev, ns, dist = O.inter_recon(depth, cur, stride, org, ref, stride, org, w64, h64, level, mv, qp, ctu_begin=0, ctu_end=n,
-                                       nthreads=cores, avx2=avx2)
+                                       nthreads=cores, avx2=avx2, intra_slice=tu_flags)         # tu_flags 2 = sign-bit hiding (the x265 default)
     if n == nctu:       # per-picture stages, single-threaded in the restatement
         S = importlib.import_module("x265-yuuki-asuna_amd.stages")
         cuqp = max(qp - 6 * (depth - 8), 0)
@@ -92,7 +92,8 @@ def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_pl
                 F.pad_chroma(clip[cur_index - 1][c], w64, h64) if ref_planes is None else (ref_planes[c],)) for c in (1, 2)]
         sc, oc = cpl[0][0][1], cpl[0][0][2]
         qpc = S.chroma_quant_qp(qp, depth)
-        crec = [O.inter_recon_chroma(depth, cpl[i][0][0].reshape(-1), cpl[i][1][0].reshape(-1), sc, oc, w64, h64, level, mv, qpc, nthreads=cores, avx2=avx2)
+        crec = [O.inter_recon_chroma(depth, cpl[i][0][0].reshape(-1), cpl[i][1][0].reshape(-1), sc, oc, w64, h64, level, mv, qpc, nthreads=cores, avx2=avx2,
+                                      intra_slice=tu_flags)
                 for i in range(2)]
         cdb = O.deblock_chroma(depth, crec[0][0], crec[1][0], sc, oc, w64, h64, bv, bh, cuqp, avx2=avx2)
         cfin = []
@@ -285,7 +286,7 @@ def main():
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
                            qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed" and args.depth == 8,
                            lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True, lookahead_cost_batch=args.lookahead_batch,
-                           chroma=True, sao_apply=True)
+                           chroma=True, sao_apply=True, sign_hide=True)
     ref_pic = pics[0].like([p.clone() for p in pics[0].planes()])     # the reference every rank searches in (starts as frame 0): Y, Cb, Cr
     fp = P.FrameParallel(rank, world)
 
@@ -366,7 +367,7 @@ def main():
                                    (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + ('packed' if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
                                     f"sub-pel subme={args.subme} -> " if args.search == "full" else
                                     f"{args.search} search driver (motionEstimate, merange {args.range}, subme {args.subme}, predictor 0) for all 85 PUs/CTU -> ") +
-                                   f"{8 << args.level}x{8 << args.level} luma + 4:2:0 chroma prediction + DCT/quant/recon qp {args.qp} -> luma + chroma deblocking -> "
+                                   f"{8 << args.level}x{8 << args.level} luma + 4:2:0 chroma prediction + DCT/quant (sign-bit hiding on)/recon qp {args.qp} -> luma + chroma deblocking -> "
                                    f"SAO statistics -> SAO parameters (saoStatsInitialOffset + distortion-only choice, on device) -> SAO apply (Y, Cb, Cr) -> "
                                    f"border extension -> next reference (Y, Cb, Cr); pipeline throughput (tier T2), not HEVC encoded fps - the real "
                                    f"encoder's fps (tier T3) is `bench.py --encoder` / profiles/r02_encoder_*.txt",

@@ -36,7 +36,11 @@ def _smooth(a):
 
 @pytest.mark.parametrize("depth,n,qp,islice", [(8, 4, 22, 1), (8, 8, 27, 1), (8, 16, 32, 0), (8, 32, 22, 1), (8, 32, 44, 0),
                                                (10, 4, 30, 0), (10, 8, 12, 1), (10, 16, 24, 1), (10, 32, 37, 1), (8, 16, 0, 1),
-                                               (12, 4, 40, 1), (12, 16, 33, 0), (12, 32, 50, 1)])
+                                               (12, 4, 40, 1), (12, 16, 33, 0), (12, 32, 50, 1),
+                                               # islice >= 2: X265HIP_TU_SIGN_HIDE (Quant::signBitHidingHDQ after the quantiser; all 35 modes, so
+                                               # the horizontal / vertical scans of the 4x4 and luma 8x8 TUs are walked as well)
+                                               (8, 4, 22, 3), (8, 8, 27, 2), (8, 16, 30, 3), (8, 32, 22, 2), (8, 32, 36, 3), (10, 4, 30, 2), (10, 8, 24, 3),
+                                               (10, 32, 30, 2), (12, 16, 33, 3)])
 @pytest.mark.parametrize("chroma", [False, True])
 def test_intra_recon_matches_oracle(depth, n, qp, islice, chroma):
     """chroma: the 4:2:0 chroma flavour (predIntraChromaAng: unfiltered neighbours, bFilter 0; DCT for 4x4 - the oracle side of both
@@ -96,6 +100,9 @@ def test_intra_recon_matches_oracle(depth, n, qp, islice, chroma):
         assert (ens > 1).any()
     if qp == 44:
         assert (ens == 0).any()
+    if islice & 2:                                              # sign hiding really changed levels
+        plain = O.intra_recon(depth, n, fenc.reshape(-1), fenc_stride, nb.reshape(-1), recon_len, recon_stride, qp, islice & 1, jobs, chroma=chroma)[1]
+        assert np.count_nonzero(plain != elev) > 0
     if chroma and n <= 16:                                      # the two flavours really differ (edge smoothing / filtered neighbours / DST)
         other = O.intra_recon(depth, n, fenc.reshape(-1), fenc_stride, nb.reshape(-1), recon_len, recon_stride, qp, islice, jobs)[0]
         assert not np.array_equal(other, erec)

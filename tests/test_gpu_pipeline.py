@@ -125,7 +125,7 @@ def test_closed_loop_with_chroma_and_sao_in_the_loop(depth):
     clip = F.synth_clip(W, Hh, 4, depth=depth, seed=67)
     pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=R, subme=subme, level=level, qp=qp, want_surf=False, lookahead=(W, Hh),
-                           deblock=True, sao=True, chroma=True, sao_apply=True)
+                           deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True)
     ref_dev = pics[0].like([p.clone() for p in pics[0].planes()])
     ref_host = None                                                    # frame 1 searches the source frame 0
     types = set()

@@ -20,8 +20,9 @@ def _oracle():
     return oracle_api
 
 
+@pytest.mark.parametrize("flags", [0, 2, 3])          # X265HIP_TU_SIGN_HIDE = 2 (the x265 default), | X265HIP_TU_INTRA_SLICE
 @pytest.mark.parametrize("depth,level,qp", [(8, 2, 22), (8, 1, 30), (8, 0, 12), (8, 2, 45), (10, 2, 34), (10, 1, 20), (8, 2, 0), (12, 2, 40), (12, 0, 30)])
-def test_inter_recon_matches_oracle(depth, level, qp):
+def test_inter_recon_matches_oracle(depth, level, qp, flags):
     import torch
     dev = torch.device("cuda:0")
     rng = np.random.default_rng([51, depth, level, qp])
@@ -34,14 +35,17 @@ def test_inter_recon_matches_oracle(depth, level, qp):
     ms.run(cur, ref)
     sp = P.SubpelRefine(ms, 2, dev)
     sp.run(cur, ref)
-    st = S.InterRecon(ms.nctu, cur.w64, cur.h64, depth, level, qp, dev)
+    st = S.InterRecon(ms.nctu, cur.w64, cur.h64, depth, level, qp, dev, intra_slice=flags)
     recon = torch.zeros_like(cur.t)
     st.run(cur, ref, recon, sp.out)
     torch.cuda.synchronize()
     O = _oracle()
     mv = sp.out.cpu().numpy().reshape(-1, 2)
     erec, elev, ens, edist = O.inter_recon(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org,
-                                           cur.w64, cur.h64, level, mv, qp)
+                                           cur.w64, cur.h64, level, mv, qp, intra_slice=flags)
+    if flags & 2 and qp in (12, 20, 22, 30):              # sign hiding really changed levels
+        plain = O.inter_recon(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, level, mv, qp, intra_slice=flags & 1)[1]
+        assert np.count_nonzero(plain != elev) > 0
     assert np.array_equal(st.num_sig.cpu().numpy().view(np.uint32), ens), "numSig differs"
     assert np.array_equal(st.levels.cpu().numpy(), elev), "quantised levels differ"
     grec = recon.cpu().numpy().view(cur.host.dtype).reshape(cur.host.shape)
@@ -91,13 +95,14 @@ def test_inter_recon_chroma_matches_oracle(depth, level, qp):
             body[:src.shape[0], :src.shape[1]] = src
             planes.append(np.ascontiguousarray(np.pad(body, margin, mode="edge")).reshape(-1))
         fenc_h, fref_h = planes
-        st = S.InterReconChroma(ms.nctu, cur.w64, cur.h64, depth, level, qp, dev)
+        flags = 2 if (level == 1 or depth == 10) else 0        # X265HIP_TU_SIGN_HIDE on some of the cases
+        st = S.InterReconChroma(ms.nctu, cur.w64, cur.h64, depth, level, qp, dev, intra_slice=flags)
         d_f = torch.from_numpy(fenc_h.view(np.uint8)).to(dev)
         d_r = torch.from_numpy(fref_h.view(np.uint8)).to(dev)
         d_o = torch.zeros_like(d_f)
         st.run(d_f, d_r, d_o, stride, org, d_mv)
         torch.cuda.synchronize()
-        erec, elev, ens, edist = O.inter_recon_chroma(depth, fenc_h, fref_h, stride, org, cur.w64, cur.h64, level, mv, qp)
+        erec, elev, ens, edist = O.inter_recon_chroma(depth, fenc_h, fref_h, stride, org, cur.w64, cur.h64, level, mv, qp, intra_slice=flags)
         assert np.array_equal(st.num_sig.cpu().numpy().view(np.uint32), ens), f"plane {c}: numSig differs"
         assert np.array_equal(st.levels.cpu().numpy(), elev), f"plane {c}: levels differ"
         assert np.array_equal(d_o.cpu().numpy().view(dt), erec), f"plane {c}: reconstruction differs"
@@ -123,14 +128,15 @@ def test_inter_recon_bi_matches_oracle(depth, level, qp):
         mvs.append(m)
     nblk = (64 >> (3 + level)) ** 2
     dirs = rng.integers(1, 4, size=nctu * nblk).astype(np.uint8)
-    st = S.InterReconBi(nctu, cur.w64, cur.h64, depth, level, qp, dev)
+    flags = 2 if level == 1 else 0                          # X265HIP_TU_SIGN_HIDE on some of the cases
+    st = S.InterReconBi(nctu, cur.w64, cur.h64, depth, level, qp, dev, intra_slice=flags)
     recon = torch.zeros_like(cur.t)
     st.run(cur, r0, r1, recon, torch.from_numpy(mvs[0].reshape(-1)).to(dev), torch.from_numpy(mvs[1].reshape(-1)).to(dev),
            dir_flags=torch.from_numpy(dirs).to(dev))
     torch.cuda.synchronize()
     O = _oracle()
     erec, elev, ens, edist = O.inter_recon_bi(depth, cur.host.reshape(-1), cur.stride, cur.org, r0.host.reshape(-1), r1.host.reshape(-1),
-                                              cur.w64, cur.h64, level, mvs[0], mvs[1], qp, dir_flags=dirs)
+                                              cur.w64, cur.h64, level, mvs[0], mvs[1], qp, dir_flags=dirs, intra_slice=flags)
     assert np.array_equal(st.num_sig.cpu().numpy().view(np.uint32), ens), "numSig differs"
     assert np.array_equal(st.levels.cpu().numpy(), elev), "levels differ"
     assert np.array_equal(recon.cpu().numpy().view(cur.host.dtype).reshape(-1), erec.reshape(-1)), "reconstruction differs"

@@ -432,7 +432,7 @@ class FramePipeline:
     cost estimate per 8x8 block), which only depends on the source."""
 
     def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False, lookahead=None,
-                 search="full", deblock=False, sao=False, lookahead_cost_batch=0, chroma=False, sao_apply=False):
+                 search="full", deblock=False, sao=False, lookahead_cost_batch=0, chroma=False, sao_apply=False, sign_hide=False):
         import torch
         from .pipeline import MotionSearch, SubpelRefine
         self.depth = depth
@@ -443,7 +443,9 @@ class FramePipeline:
         if search != "full":
             method = {"dia": hipabi.ME_DIA, "hex": hipabi.ME_HEX, "umh": hipabi.ME_UMH, "star": hipabi.ME_STAR, "sea": hipabi.ME_SEA}[search]
             self.ps = PatternSearch(w64, h64, depth, method, subme, rng, device)
-        self.rc = InterRecon(self.ms.nctu, w64, h64, depth, level, qp, device)
+        # sign_hide: Quant::signBitHidingHDQ after the quantiser (pps.bSignHideEnabled, the x265 default)
+        self.tu_flags = hipabi.TU_SIGN_HIDE if sign_hide else 0
+        self.rc = InterRecon(self.ms.nctu, w64, h64, depth, level, qp, device, intra_slice=self.tu_flags)
         self.la = Lookahead(lookahead[0], lookahead[1], depth, device) if lookahead else None
         # The lookahead's P-frame cost estimate runs AHEAD of the encode like the reference's lookahead thread: every
         # `lookahead_cost_batch` frames one launch on a side stream scores that many (picture, previous picture) pairs.  The
@@ -472,7 +474,7 @@ class FramePipeline:
         self.recon_c, self.out, self.out_c = None, None, None
         if chroma:
             qpc = chroma_quant_qp(qp, depth)
-            self.rc_c = [InterReconChroma(self.ms.nctu, w64, h64, depth, level, qpc, device) for _ in range(2)]
+            self.rc_c = [InterReconChroma(self.ms.nctu, w64, h64, depth, level, qpc, device, intra_slice=self.tu_flags) for _ in range(2)]
             self.sao_c = [Sao(w64 // 2, h64 // 2, depth, device, ctu=(32, 32), plane_offset=2) for _ in range(2)] if sao else None
         # SAO applied in the loop: the parameters come from x265hip_sao_decide (initial offsets + distortion-only choice), so the
         # picture handed to the next frame is deblocked AND offset like a decoder's
