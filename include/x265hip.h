@@ -51,6 +51,8 @@ int         x265hip_init(int device);          /* device >= 0: validate (gfx950)
 int x265hip_setup_primitives(void* table, size_t table_bytes, int depth);
 /* Number of table calls served by the GPU since init (to prove stubs really ran). */
 uint64_t x265hip_table_calls(void);
+/* the table layer keeps a stream + pinned / device staging per calling host thread, released when that thread exits */
+void        x265hip_table_stage_counts(uint64_t* created, uint64_t* released);
 
 /* ------------------------------------------------------------------ 2. batch layer */
 /* pixel-compare family (reference pixel.cpp:40-55 sad, :210-297 satd, :299-377 sa8d, :167-186 sse,

@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <time.h>
 
 using namespace X265_NS;
 
@@ -64,7 +65,7 @@ struct Pair { int fencPoc; const PicYuv* rec; int recPoc; int slot; int gen; boo
 
 struct Seam
 {
-    bool enabled = false, verify = false;
+    bool enabled = false, verify = false, wait = false;
     Provider p;
     int nc, ng, groupBytes, ctusW;
     size_t ctuBytes;
@@ -142,7 +143,20 @@ inline bool lookup(Ctx& c, const pixel* fref, int& out)
     const uint64_t row = (uint64_t)t / (uint64_t)c.stride, col = (uint64_t)t - row * (uint64_t)c.stride;
     const uint64_t span = 2 * (uint64_t)g.p.range;
     if (row > span || col > span) { c.outside++; return false; }
-    if (c.ready[c.ctuRow] != c.gen) { c.notReady++; return false; }
+    if (c.ready[c.ctuRow] != c.gen)
+    {
+        /* default: never wait, the host primitive answers instead.  Test mode (wait): give the transfer up to 2 s, so that small
+         * pictures - encoded faster than their surfaces travel - still exercise the lookups */
+        bool arrived = false;
+        if (g.wait)
+            for (int spin = 0; spin < 20000 && !arrived; spin++)
+            {
+                struct timespec ts = { 0, 100000 };
+                nanosleep(&ts, NULL);
+                arrived = c.ready[c.ctuRow] == c.gen;
+            }
+        if (!arrived) { c.notReady++; return false; }
+    }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const uint8_t* rec = c.ctuBase + (row * g.ng + (col >> 2)) * g.groupBytes;
     const int k = (int)(col & 3);
@@ -385,7 +399,8 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
     g.ctusW = width / 64;
     g.ctuBytes = (size_t)g.nc * g.ng * g.groupBytes;
     memset(g.pairs, 0, sizeof(g.pairs));
-    g.verify = verify != 0 || (getenv("X265REF_SEAM_VERIFY") && atoi(getenv("X265REF_SEAM_VERIFY")));
+    g.verify = (verify & 1) != 0 || (getenv("X265REF_SEAM_VERIFY") && atoi(getenv("X265REF_SEAM_VERIFY")));
+    g.wait = (verify & 2) != 0;
     g.hits = g.outside = g.notReady = g.meCalls = g.meServed = g.submits = g.mismatches = g.noSlot = g.foreign = 0;
     g.epoch.fetch_add(1);
     g.enabled = true;

@@ -156,7 +156,7 @@ def test_8k_10bit_ctu_samples_and_whole_picture_loop_filters():
     bv, bh = O.deblock_bs_inter(depth, cur.w64, cur.h64, level, g_mv, g_ns.astype(np.uint32))
     assert np.array_equal(db.bs_ver.cpu().numpy(), bv.reshape(-1)) and np.array_equal(db.bs_hor.cpu().numpy(), bh.reshape(-1))
     edbk = O.deblock_luma(depth, pre.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64, bv, bh, max(qp - 6 * (depth - 8), 0))
-    gdbk = recon.cpu().numpy().view(np.uint16)
+    gdbk = recon.cpu().numpy().view(np.uint16).reshape(-1)
     bad = np.nonzero(gdbk != edbk.reshape(-1))[0]
     assert bad.size == 0, (f"8K deblocked picture differs at {bad.size} samples; first (row, col) relative to sample (0,0): "
                            f"{[((int(b) - cur.org) // cur.stride, (int(b) - cur.org) % cur.stride) for b in bad[:6]]}, device {gdbk[bad[:6]].tolist()}, "

@@ -81,8 +81,18 @@ def test_me_cache_surfaces_equal_oracle(depth, width, height, rng):
 def test_seam_encode_on_gpu_surfaces_is_byte_identical(depth, preset, extra):
     import test_seam_cpu as T
     opts = [("pools", "4"), ("frame-threads", "1"), ("crf", "24"), ("no-weightp", None), ("no-weightb", None)] + extra
-    base, got, rep = T.run_pair(depth, 256, 192, 5, preset, opts, "gpu", rng=20, verify=True)
+    # wait=True: a 256x192 picture is encoded faster than its surfaces travel; the test mode lets the lookups wait for their rows
+    base, got, rep = T.run_pair(depth, 256, 192, 5, preset, opts, "gpu", rng=20, verify=True, wait=True)
     assert got[0] == base[0], f"seam changed the bitstream: {rep}"
     assert rep["verify"] == 1 and rep["verify_mismatches"] == 0 and rep["failed"] == 0
-    assert rep["fills"] == rep["pair_submits"] >= 4
-    assert rep["lookups_served"] > 500, rep        # rows that had not arrived yet fall back to the C primitive; most must be served
+    assert 1 <= rep["fills"] <= rep["pair_submits"] and rep["pair_submits"] >= 4      # a pair superseded before its turn is skipped
+    assert rep["lookups_served"] > 1500, rep
+
+
+def test_seam_never_waits_by_default():
+    """Production mode: a row that has not arrived is answered by the host primitive at once; the bitstream is the same either way."""
+    import test_seam_cpu as T
+    opts = [("pools", "4"), ("frame-threads", "1"), ("crf", "24"), ("no-weightp", None), ("no-weightb", None)]
+    base, got, rep = T.run_pair(8, 256, 192, 5, "medium", opts, "gpu", rng=20, verify=True)
+    assert got[0] == base[0] and rep["verify_mismatches"] == 0 and rep["failed"] == 0
+    assert rep["lookups_served"] + rep["row_not_ready"] + rep["outside_window"] > 1000

@@ -21,7 +21,7 @@ def _tools():
     return encoder_bench, seam_driver
 
 
-def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41):
+def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False):
     EB, SD = _tools()
     try:
         plain = EB.ref_lib(depth)
@@ -31,7 +31,7 @@ def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify
     clip = F.synth_clip(w, h, nframes, depth=depth, seed=seed)
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
     base = EB.encode(plain, yuv, w, h, nframes, preset, opts)
-    lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=8, min_pu=min_pu, verify=verify)
+    lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=8, min_pu=min_pu, verify=verify, wait=wait)
     try:
         got = EB.encode(lib, yuv, w, h, nframes, preset, opts, filler)
         rep = report()

@@ -157,7 +157,7 @@ class GpuProvider:
             self.handle = None
 
 
-def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False):
+def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False):
     """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) using
     --frame-threads 1 and --ctu 64."""
     lib = seam_lib(depth)
@@ -165,7 +165,7 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     prov = (GpuProvider if provider == "gpu" else OracleProvider)(depth, geo, rng, slots)
     ctx, submit, submit_batch, surface, ready = prov.pointers()
     rc = lib.x265ref_seam_configure(ctx, submit, submit_batch, surface, ready, rng, prov.format, slots, geo["width"], geo["height"], geo["stride"],
-                                    geo["margin_x"], geo["margin_y"], min_pu, int(bool(verify)))
+                                    geo["margin_x"], geo["margin_y"], min_pu, int(bool(verify)) | (2 if wait else 0))
     if rc:
         raise RuntimeError(f"x265ref_seam_configure failed ({rc})")
     filler = ctypes.cast(lib.x265ref_seam_fill_table, ctypes.c_void_p)

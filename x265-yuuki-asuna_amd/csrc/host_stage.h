@@ -16,6 +16,7 @@
 namespace x265hip {
 
 extern std::atomic<uint64_t> g_tableCalls;
+extern std::atomic<uint64_t> g_stagesCreated, g_stagesReleased;
 
 struct ThreadStage
 {
@@ -25,6 +26,22 @@ struct ThreadStage
     size_t cap = 0;
     size_t used = 0;              // bytes packed so far (inputs first, then outputs)
     size_t inBytes = 0;
+
+    // a pool worker that exits (the reference tears its thread pools down in x265_encoder_close) gives its stream and staging back;
+    // errors are ignored: at process exit the runtime may already be shutting down
+    ~ThreadStage()
+    {
+        if (!stream) return;
+        (void)hipStreamSynchronize(stream);
+        if (host) (void)hipHostFree(host);
+        if (dev) (void)hipFree(dev);
+        (void)hipStreamDestroy(stream);
+        stream = nullptr; host = nullptr; dev = nullptr; cap = 0;
+        g_stagesReleased.fetch_add(1, std::memory_order_relaxed);
+    }
+    ThreadStage() = default;
+    ThreadStage(const ThreadStage&) = delete;
+    ThreadStage& operator=(const ThreadStage&) = delete;
 
     static void die(const char* what, hipError_t e)
     {
@@ -38,6 +55,7 @@ struct ThreadStage
             if (ensure_device()) { fprintf(stderr, "libx265hip: %s\n", x265hip_last_error()); abort(); }
             hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
             if (e != hipSuccess) die("hipStreamCreate", e);
+            g_stagesCreated.fetch_add(1, std::memory_order_relaxed);
         }
         if (need <= cap) return;
         size_t ncap = cap ? cap : (size_t)1 << 20;

@@ -6,6 +6,7 @@ struct x265hip_EncoderPrimitives;
 namespace x265hip {
 
 std::atomic<uint64_t> g_tableCalls{0};
+std::atomic<uint64_t> g_stagesCreated{0}, g_stagesReleased{0};
 
 ThreadStage& thread_stage()
 {
@@ -42,3 +43,9 @@ extern "C" int x265hip_setup_primitives(void* table, size_t table_bytes, int dep
 }
 
 extern "C" uint64_t x265hip_table_calls(void) { return g_tableCalls.load(); }
+/* per-thread staging (stream + pinned + device buffer) of the table layer: how many host threads created one / gave it back at thread exit */
+extern "C" void x265hip_table_stage_counts(uint64_t* created, uint64_t* released)
+{
+    if (created) *created = g_stagesCreated.load();
+    if (released) *released = g_stagesReleased.load();
+}
