@@ -243,6 +243,12 @@ def main():
                     help="pictures per launch of the lookahead's P-frame cost estimate, which runs ahead on a side stream (0 = stage off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the bit-exact comparison of one whole frame with the oracle chain")
+    ap.add_argument("--no-encoder", action="store_true",
+                    help="skip the encoder-level leg (tier T3): the REAL reference encoder (oracle/_ref) on BASELINE configs[2] - 4K, preset slow, "
+                         "--me star - with its own C table and with the stage-level seam on x265hip_me_cache surfaces; fps + bitstream md5")
+    ap.add_argument("--encoder", default="cfg3", help="configurations of the encoder-level leg (tools/encoder_bench.py: cfg1,cfg2,cfg3,cfg4)")
+    ap.add_argument("--encoder-frames", type=int, default=6)
+    ap.add_argument("--encoder-tables", default="c,seam", help="c = reference C table, seam = + x265hip_me_cache lookups, hip = per-call stubs (slow)")
     ap.add_argument("--prims", action="store_true",
                     help="instead of the pipeline line, print the per-family table of the batch-layer kernels with the CPU paths timed beside "
                          "them (tools/bench_prims.py: bench.py's cpu_baseline leg at primitive level)")
@@ -390,6 +396,24 @@ def main():
             if bit_exact is not None:
                 out["bit_exact"] = bit_exact["ok"]
                 out["bit_exact_detail"] = bit_exact
+        if world == 1 and not args.no_encoder and not args.no_cpu_baseline:
+            # tier T3: the real reference encoder on the host cores, C table vs the seam; test infrastructure drives it,
+            # the timed product part is x265hip_me_cache.  Never fatal for the bench line.
+            try:
+                sys.path.insert(0, ROOT)
+                from tools import encoder_bench as EB
+                enc = {}
+                for key in args.encoder.split(","):
+                    enc[key] = EB.run_config(key, args.encoder_tables.split(","), args.encoder_frames, 1, 120.0, log=sys.stderr,
+                                             seam={"range": 24, "slots": 8, "min_pu": 8, "verify": False})
+                out["encoder"] = enc
+                c3 = enc.get("cfg3", {})
+                if "c" in c3:
+                    out["encoder_summary"] = {"workload": c3["config"], "reference_c_table_fps": c3["c"]["fps"], "cores": c3["pool_threads"],
+                                              "seam_fps": c3.get("seam", {}).get("fps"), "seam_md5_equal": c3.get("seam", {}).get("md5_equal_to_c_table"),
+                                              "kind": "reference (x265 3.5 C primitives, no asm: nasm is not in the image)"}
+            except BaseException as e:       # incl. SystemExit from a missing oracle/_ref
+                out["encoder"] = {"error": repr(e)}
         print(json.dumps(out))
         if bit_exact is not None and not bit_exact["ok"]:
             sys.stderr.write("bench.py: device pipeline differs from the oracle chain: %s\n" % json.dumps(bit_exact["stages"]))

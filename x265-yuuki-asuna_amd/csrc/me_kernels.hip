@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
                 cxk4[k] = ((4 * g + k < NC ? (uint32_t)a.costX[4 * g + k] : (1u << 20)) << 2) | (uint32_t)k;
             cxL = 4 * g + kcol < NC ? (uint32_t)a.costX[4 * g + kcol] : (1u << 23);
         }
+        const uint32_t cxL8 = cxL << 8;
         u64 acc[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) acc[i] = 0;
@@ -350,7 +351,8 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
                 for (int j = 0; j < 8; j++)
                 {
                     if (FIRST && j > p) continue;
-                    u64 v = acc[(p - j) & 7];
+                    // j == 0 opens a fresh ring slot (the one emitted a row ago): start from the constant 0 instead of clearing registers
+                    u64 v = j == 0 ? 0ull : acc[(p - j) & 7];
                     v = __builtin_amdgcn_qsad_pk_u16_u8(w0, F[j][0], v);
                     v = __builtin_amdgcn_qsad_pk_u16_u8(w1, F[j][1], v);
                     acc[(p - j) & 7] = v;
@@ -359,8 +361,7 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
                 {
                     const int m = t0 + p - 7;
                     const int slot = (p + 1) & 7;
-                    const u64 A = acc[slot];
-                    acc[slot] = 0;
+                    const u64 A = acc[slot];                                          // the slot is reopened by the next row's j == 0 step
                     const uint32_t lo = (uint32_t)A, hi = (uint32_t)(A >> 32);      // columns {0,1} and {2,3}, u16 each
                     // 16x16 = quad sums, still packed (<= 65280 per half: no carry between the halves)
                     const uint32_t qlo = (uint32_t)quad_sum((int)lo), qhi = (uint32_t)quad_sum((int)hi);
@@ -410,10 +411,11 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
                             key = (key & ~3u) | (kmin & 3u);                             // | k  (v_bfi)
                             r8 = key < r8 ? key : r8;
                         }
-                        const uint32_t cxy = cxL + cy_;
-                        const uint32_t k16 = (((uint32_t)v16 + cxy) << 8) | (uint32_t)m;
-                        const uint32_t k32 = (((uint32_t)v32 + cxy) << 8) | (uint32_t)m;
-                        const uint32_t k64 = (((uint32_t)v64 + cxy) << 8) | (uint32_t)m;
+                        // (v + cxL + cy) << 8 | m  ==  (v << 8) + base with base = (cxL << 8) + ((cy << 8) | m): one v_lshl_add_u32 per level
+                        const uint32_t base = cxL8 + ((cy_ << 8) | (uint32_t)m);
+                        const uint32_t k16 = ((uint32_t)v16 << 8) + base;
+                        const uint32_t k32 = ((uint32_t)v32 << 8) + base;
+                        const uint32_t k64 = ((uint32_t)v64 << 8) + base;
                         r16 = k16 < r16 ? k16 : r16;
                         r32 = k32 < r32 ? k32 : r32;
                         r64 = k64 < r64 ? k64 : r64;

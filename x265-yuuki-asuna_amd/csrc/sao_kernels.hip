@@ -228,58 +228,60 @@ __global__ void __launch_bounds__(256) sao_apply_kernel(SaoApplyArgs a)
 // SAO parameters without leaving the device: SAO::saoStatsInitialOffset (sao.cpp:1378-1433: roundIBDI of offsetOrg / count,
 // clip to +-(OFFSET_THRESH - 1), sign constraint of the edge classes) + a distortion-only choice of the type by estSaoDist
 // (sao.cpp:56-59) - the documented stand-in for the entropy-coder-driven rdoSaoUnitCu that lets the closed-loop pipeline hand the
-// next picture a reference that went through SAO.  One thread per CTU (160 statistics each).
+// next picture a reference that went through SAO.
 struct SaoDecideArgs { const int32_t* count; const int32_t* offsetOrg; int nctu, depth; int32_t* initOffset; int32_t* params; };
 
+// one wavefront per CTU: lanes 0..15 take the (edge type, class) pairs, lanes 32..63 the 32 bands - the divisions of the initial offsets
+// run side by side - and lane 0 makes the small serial choice from LDS
 __global__ void __launch_bounds__(64) sao_decide_kernel(SaoDecideArgs a)
 {
-    const int ctu = blockIdx.x * 64 + threadIdx.x;
-    if (ctu >= a.nctu) return;
+    __shared__ int sOff[5][32];
+    __shared__ long long sDist[5][32];
+    const int ctu = blockIdx.x, lane = threadIdx.x;
     const int32_t* cnt = a.count + (size_t)ctu * 160;
     const int32_t* org = a.offsetOrg + (size_t)ctu * 160;
     const int thresh = 1 << (a.depth - 5 < 5 ? a.depth - 5 : 5);
-    auto initial = [&](const int t, const int c) -> int
+    int t = -1, c = 0;
+    if (lane < 16) { t = lane >> 2; c = 1 + (lane & 3); }
+    else if (lane >= 32) { t = 4; c = lane - 32; }
+    for (int i = lane; i < 160; i += 64) { sOff[i >> 5][i & 31] = 0; sDist[i >> 5][i & 31] = 0; }
+    __syncthreads();
+    if (t >= 0)
     {
         const int n = cnt[t * 32 + c], e = org[t * 32 + c];
-        if (!n) return 0;
-        int o = e >= 0 ? (e * 2 + n) / (n * 2) : -((-e * 2 + n) / (n * 2));
-        o = clip3(-thresh + 1, thresh - 1, o);
-        if (t < 4) o = c < 3 ? max(o, 0) : min(o, 0);
-        return o;
-    };
-    auto dist = [&](const int t, const int c, const int o) -> long long
-    { return ((long long)cnt[t * 32 + c] * o - (long long)org[t * 32 + c] * 2) * o; };
-    if (a.initOffset)
-    {
-        int32_t* io = a.initOffset + (size_t)ctu * 160;
-        for (int t = 0; t < 5; t++)
-            for (int c = 0; c < 32; c++) io[t * 32 + c] = (t < 4 && (c < 1 || c > 4)) ? 0 : initial(t, c);
-    }
-    long long best = 0;
-    int type = -1, band = 0, o4[4] = { 0, 0, 0, 0 };
-    for (int t = 0; t < 4; t++)
-    {
-        int o[4]; long long d = 0;
-        for (int c = 1; c < 5; c++) { o[c - 1] = initial(t, c); d += dist(t, c, o[c - 1]); }
-        if (d < best) { best = d; type = t; band = 0; for (int i = 0; i < 4; i++) o4[i] = o[i]; }
-    }
-    // band offset: sliding window of four bands
-    long long w = 0, bo = 0; int start = -1;
-    long long d3[3] = { 0, 0, 0 };
-    for (int b = 0; b < 32; b++)
-    {
-        const long long d = dist(4, b, initial(4, b));
-        w += d;
-        if (b >= 3)
+        int o = 0;
+        if (n)
         {
-            if (start < 0 || w < bo) { bo = w; start = b - 3; }
-            w -= d3[0];
+            o = e >= 0 ? (e * 2 + n) / (n * 2) : -((-e * 2 + n) / (n * 2));          // roundIBDI (sao.cpp:34-37)
+            o = clip3(-thresh + 1, thresh - 1, o);
+            if (t < 4) o = c < 3 ? max(o, 0) : min(o, 0);
         }
-        d3[0] = d3[1]; d3[1] = d3[2]; d3[2] = d;
+        sOff[t][c] = o;
+        sDist[t][c] = ((long long)n * o - (long long)e * 2) * o;                       // estSaoDist (sao.cpp:56-59)
     }
-    if (bo < best) { type = 4; band = start; for (int i = 0; i < 4; i++) o4[i] = initial(4, start + i); }
-    int32_t* p = a.params + (size_t)ctu * 7;
-    p[0] = type; p[1] = band; p[2] = o4[0]; p[3] = o4[1]; p[4] = o4[2]; p[5] = o4[3]; p[6] = 0;
+    __syncthreads();
+    if (a.initOffset)
+        for (int i = lane; i < 160; i += 64) a.initOffset[(size_t)ctu * 160 + i] = sOff[i >> 5][i & 31];
+    if (lane == 0)
+    {
+        long long best = 0;
+        int type = -1, band = 0;
+        for (int ty = 0; ty < 4; ty++)
+        {
+            const long long d = sDist[ty][1] + sDist[ty][2] + sDist[ty][3] + sDist[ty][4];
+            if (d < best) { best = d; type = ty; }
+        }
+        long long bo = 0; int start = -1;
+        for (int sidx = 0; sidx <= 28; sidx++)
+        {
+            const long long d = sDist[4][sidx] + sDist[4][sidx + 1] + sDist[4][sidx + 2] + sDist[4][sidx + 3];
+            if (start < 0 || d < bo) { bo = d; start = sidx; }
+        }
+        if (bo < best) { type = 4; band = start; }
+        int32_t* p = a.params + (size_t)ctu * 7;
+        p[0] = type; p[1] = band; p[6] = 0;
+        for (int i = 0; i < 4; i++) p[2 + i] = type < 0 ? 0 : (type == 4 ? sOff[4][band + i] : sOff[type][1 + i]);
+    }
 }
 
 } // namespace x265hip
@@ -342,7 +344,7 @@ extern "C" int x265hip_sao_decide(int depth, const int32_t* count, const int32_t
     if (depth != 8 && depth != 10 && depth != 12) { set_error("sao_decide: depth %d", depth); return X265HIP_EINVAL; }
     if (nctu <= 0) { set_error("sao_decide: nctu %d", nctu); return X265HIP_EINVAL; }
     SaoDecideArgs a = { count, offset_org, nctu, depth, init_offset, ctu_params };
-    hipLaunchKernelGGL(sao_decide_kernel, dim3((nctu + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(sao_decide_kernel, dim3(nctu), dim3(64), 0, (hipStream_t)stream, a);
     X265HIP_TRY(hipGetLastError());
     return 0;
 }
