@@ -281,6 +281,36 @@ typedef struct x265hip_lowres_cost_params
 } x265hip_lowres_cost_params;
 int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* stream);
 
+/* The same estimate behind host pointers, shaped like the loop it replaces (csrc/lookahead_host.hip): ONE call = the estimateCUCost
+ * loop of CostEstimateGroup::estimateFrameCost (slicetype.cpp:3178-3196 over :3216-3388) for one (p0, b, p1) triple whose Lowres
+ * planes and per-block arrays live in HOST memory; synchronous, re-entrant (per-thread stream + device scratch).
+ *   cur, ref[], ref1[], ref_bi[] : sample (0,0) of host planes that start margin_y rows / margin_x samples earlier and hold
+ *                 lines + 2 * margin_y rows of `stride` samples (Lowres::create, lowres.cpp:50-72); ref1 all NULL = P picture;
+ *                 ref_bi: the unweighted list-0 planes when ref[] is weighted on a B picture (see the pair structure above), else all NULL
+ *   cost_q      : the CENTRE of the mv-difference cost table (BitCost::m_cost, bitcost.h:45), valid for [-cost_q_half, cost_q_half]
+ *   mvs / mv_costs : lowresMvs[l][dist] (int32 [n][2], 8-byte aligned) / lowresMvCosts[l][dist]: outputs for do_search[l] != 0,
+ *                 inputs otherwise (a list searched earlier is reused, slicetype.cpp:3126-3127, 3256-3260)
+ *   lowres_costs uint16 [n], row_satds int32 [height_in_cu], frame int64 [4] = { costEst sum, costEstAq sum, intraMbs, score } */
+typedef struct x265hip_lowres_cost_host_params
+{
+    int depth;
+    intptr_t stride;
+    int width_in_cu, height_in_cu;
+    int lines, margin_x, margin_y;
+    const void* cur;
+    const void* ref[4];
+    const void* ref1[4];
+    const void* ref_bi[4];
+    const int32_t* intra_cost;
+    const int32_t* inv_qscale;                      /* optional */
+    const uint16_t* cost_q;  int cost_q_half;
+    int bframe_bias;
+    int do_search[2];
+    int32_t* mvs[2];  int32_t* mv_costs[2];
+    uint16_t* lowres_costs;  int32_t* row_satds;  int64_t* frame;
+} x265hip_lowres_cost_host_params;
+int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p);
+
 /* ---- in-loop deblocking of a device-resident luma reconstruction (deblocking half) ----
  * x265hip_deblock_bs_inter = Deblock::getBoundaryStrength (deblock.cpp:191-215) for a P picture with one reference cut into
  *   square inter blocks of 8 << level samples: inputs are the sub-pel stage's mv array (int32 [ctu*85][2], z-order) and the

@@ -29,6 +29,8 @@
 #include "search.h"
 #include "motion.h"
 #include "reference.h"
+#include "lowres.h"
+#include "slicetype.h"
 
 #include <atomic>
 #include <cstddef>
@@ -43,7 +45,45 @@ using namespace X265_NS;
 extern "C" int x265ref_orig_motionEstimate(MotionEstimate* self, ReferencePlanes* ref, const MV* mvmin, const MV* mvmax, const MV* qmvp,
                                            int numCandidates, const MV* mvc, int merange, MV* outQMv, uint32_t maxSlices, pixel* srcReferencePlane);
 
+extern "C" int64_t x265ref_orig_estimateFrameCost(CostEstimateGroup* self, LookaheadTLD* tld, int p0, int p1, int b, bool bIntraPenalty);
+
 namespace {
+
+/* ---- the lookahead seam: CostEstimateGroup::estimateFrameCost's estimateCUCost loop as ONE call of the provider ------------------
+ * x265hip_lowres_cost_host_params (include/x265hip.h), mirrored field by field */
+struct LaHostParams
+{
+    int depth;
+    intptr_t stride;
+    int width_in_cu, height_in_cu;
+    int lines, margin_x, margin_y;
+    const void* cur;
+    const void* ref[4];
+    const void* ref1[4];
+    const void* ref_bi[4];
+    const int32_t* intra_cost;
+    const int32_t* inv_qscale;
+    const uint16_t* cost_q;  int cost_q_half;
+    int bframe_bias;
+    int do_search[2];
+    int32_t* mvs[2];  int32_t* mv_costs[2];
+    uint16_t* lowres_costs;  int32_t* row_satds;  int64_t* frame;
+};
+typedef int (*la_host_fn)(const LaHostParams*);
+/* the oracle's CPU restatement (x265oracle_lowres_cost_wp_d<depth>): the checker-only provider of the GPU-less tests */
+typedef int (*la_oracle_fn)(const pixel* cur, const pixel* const* refs0, const pixel* const* refs1, intptr_t stride, int widthInCU, int heightInCU,
+                            const uint16_t* cost, int qoff, const int32_t* intraCost, const int32_t* invQscale, const int* doSearch, int bFrameBias,
+                            int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1, uint16_t* lowresCosts, int32_t* rowSatds,
+                            int64_t* frame, const pixel* const* refs0Bi);
+struct LookaheadSeam
+{
+    bool enabled = false;
+    la_host_fn host = NULL;
+    la_oracle_fn oracle = NULL;
+    std::atomic<uint64_t> served{0}, passed{0}, failed{0};
+} gla;
+
+struct MeCostProbe : public MotionEstimate { const uint16_t* costCentre() const { return m_cost; } };
 
 enum { SURF_I32 = 0, SURF_PACKED = 1, GROUP_I32 = 1360, GROUP_PACKED = 720, MAX_PARTS = 6, MAX_SLOTS = 64 };
 
@@ -378,6 +418,93 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     return cost;
 }
 
+/* The lookahead seam: same signature, same symbol as the reference's function.  oracle/Makefile makes the compiled original weak and
+ * reachable as x265ref_orig_estimateFrameCost; this definition wins at link time for every caller (singleCost, the batch tasks).
+ * Only the compute path is taken over - the bookkeeping around the block loop is restated from slicetype.cpp:3121-3146 / 3199-3211,
+ * the loop itself (:3178-3196 over estimateCUCost) becomes one provider call.  Cached triples, HME and cooperative slices go to
+ * the original: run with --lookahead-slices 1, where the reference walks the picture in one piece too (sliced walks reset the
+ * row predictors at every slice boundary, a different - equally valid - estimate). */
+int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, int b, bool bIntraPenalty)
+{
+    Lowres* fenc = m_frames[b];
+    x265_param* param = m_lookahead.m_param;
+    const bool cached = fenc->costEst[b - p0][p1 - b] >= 0 && fenc->rowSatds[b - p0][p1 - b][0] != -1;
+    if (!gla.enabled || cached || param->bEnableHME || (!m_batchMode && m_lookahead.m_numCoopSlices > 1) || param->rc.qgSize == 8)
+    {
+        if (gla.enabled && !cached) gla.passed.fetch_add(1, std::memory_order_relaxed);
+        return x265ref_orig_estimateFrameCost(this, &tld, p0, p1, b, bIntraPenalty);
+    }
+    bool bDoSearch[2];
+    bDoSearch[0] = fenc->lowresMvs[0][b - p0][0].x == 0x7FFF;
+    bDoSearch[1] = p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF;
+    fenc->weightedRef[b - p0].isWeighted = false;
+    if (param->bEnableWeightedPred && bDoSearch[0])
+        tld.weightsAnalyse(*m_frames[b], *m_frames[p0]);
+    fenc->costEst[b - p0][p1 - b] = 0;
+    fenc->costEstAq[b - p0][p1 - b] = 0;
+
+    Lowres* fref0 = m_frames[p0];
+    Lowres* fref1 = m_frames[p1];
+    const bool bidir = b < p1;
+    const ReferencePlanes* wfref0 = fenc->weightedRef[b - p0].isWeighted ? &fenc->weightedRef[b - p0] : fref0;
+    const ptrdiff_t pad = fenc->lowresPlane[0] - fenc->buffer[0];
+    int64_t frame[4] = { 0, 0, 0, 0 };
+    const int half = 4 * (fenc->width > fenc->lines ? fenc->width : fenc->lines) + 4 * 256;      /* mv differences stay far inside */
+    int rc;
+    if (gla.host)
+    {
+        LaHostParams q;
+        memset(&q, 0, sizeof(q));
+        q.depth = X265_DEPTH; q.stride = fenc->lumaStride;
+        q.width_in_cu = m_lookahead.m_8x8Width; q.height_in_cu = m_lookahead.m_8x8Height;
+        q.lines = fenc->lines; q.margin_y = (int)(pad / fenc->lumaStride); q.margin_x = (int)(pad % fenc->lumaStride);
+        q.cur = fenc->lowresPlane[0];
+        for (int i = 0; i < 4; i++)
+        {
+            q.ref[i] = wfref0->lowresPlane[i];
+            q.ref1[i] = bidir ? fref1->lowresPlane[i] : NULL;
+            q.ref_bi[i] = (bidir && wfref0 != fref0) ? fref0->lowresPlane[i] : NULL;
+        }
+        q.intra_cost = fenc->intraCost; q.inv_qscale = fenc->invQscaleFactor;
+        q.cost_q = static_cast<const MeCostProbe&>(tld.me).costCentre(); q.cost_q_half = half;
+        q.bframe_bias = param->bFrameBias;
+        q.do_search[0] = bDoSearch[0]; q.do_search[1] = bDoSearch[1];
+        q.mvs[0] = &fenc->lowresMvs[0][b - p0][0].x; q.mv_costs[0] = fenc->lowresMvCosts[0][b - p0];
+        q.mvs[1] = bidir ? &fenc->lowresMvs[1][p1 - b][0].x : NULL; q.mv_costs[1] = bidir ? fenc->lowresMvCosts[1][p1 - b] : NULL;
+        q.lowres_costs = fenc->lowresCosts[b - p0][p1 - b]; q.row_satds = fenc->rowSatds[b - p0][p1 - b]; q.frame = frame;
+        rc = gla.host(&q);
+    }
+    else
+    {
+        const pixel* r0[4]; const pixel* r1[4]; const pixel* rb[4];
+        for (int i = 0; i < 4; i++) { r0[i] = wfref0->lowresPlane[i]; r1[i] = fref1->lowresPlane[i]; rb[i] = fref0->lowresPlane[i]; }
+        const int ds[2] = { bDoSearch[0], bDoSearch[1] };
+        rc = gla.oracle(fenc->lowresPlane[0], r0, bidir ? r1 : NULL, fenc->lumaStride, m_lookahead.m_8x8Width, m_lookahead.m_8x8Height,
+                        static_cast<const MeCostProbe&>(tld.me).costCentre(), 0, fenc->intraCost, fenc->invQscaleFactor, ds, param->bFrameBias,
+                        &fenc->lowresMvs[0][b - p0][0].x, fenc->lowresMvCosts[0][b - p0],
+                        bidir ? &fenc->lowresMvs[1][p1 - b][0].x : NULL, bidir ? fenc->lowresMvCosts[1][p1 - b] : NULL,
+                        fenc->lowresCosts[b - p0][p1 - b], fenc->rowSatds[b - p0][p1 - b], frame, (bidir && wfref0 != fref0) ? rb : NULL);
+    }
+    if (rc)
+    {
+        /* provider failure: loud, and the reference's own loop takes over for this triple (its state is as the original expects it) */
+        gla.failed.fetch_add(1, std::memory_order_relaxed);
+        fprintf(stderr, "ref_seam: lookahead provider failed (%d) for (%d, %d, %d); the reference's loop runs instead\n", rc, p0, b, p1);
+        fenc->costEst[b - p0][p1 - b] = -1;
+        return x265ref_orig_estimateFrameCost(this, &tld, p0, p1, b, bIntraPenalty);
+    }
+    gla.served.fetch_add(1, std::memory_order_relaxed);
+    fenc->costEstAq[b - p0][p1 - b] = frame[1];
+    if (p1 == b) fenc->intraMbs[b - p0] += (int)frame[2];
+    int64_t score = frame[0];
+    if (b != p1)
+        score = score * 100 / (130 + param->bFrameBias);
+    fenc->costEst[b - p0][p1 - b] = score;
+    if (bIntraPenalty)
+        score += score * fenc->intraMbs[b - p0] / (tld.ncu * 8);
+    return score;
+}
+
 extern "C" {
 
 /* provider: see the header comment; geometry = the PicYuv layout of the encode about to start.  Call before x265ref_encode. */
@@ -407,7 +534,21 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
     return 0;
 }
 
-void x265ref_seam_disable(void) { g.enabled = false; }
+void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; }
+
+/* lookahead seam: host_fn = x265hip_lowres_cost_host (the product) or NULL; oracle_fn = x265oracle_lowres_cost_wp_d<depth> (CPU checker,
+ * tests only) or NULL.  Both NULL switches the seam off. */
+int x265ref_lookahead_seam_configure(void* host_fn, void* oracle_fn)
+{
+    gla.host = (la_host_fn)host_fn;
+    gla.oracle = (la_oracle_fn)oracle_fn;
+    gla.served = 0; gla.passed = 0; gla.failed = 0;
+    gla.enabled = host_fn || oracle_fn;
+    return 0;
+}
+
+/* out[3]: frame cost estimates served by the provider, passed to the reference's loop (HME / cooperative slices / qg 8), failed */
+void x265ref_lookahead_seam_stats(uint64_t* out) { out[0] = gla.served; out[1] = gla.passed; out[2] = gla.failed; }
 
 /* table filler with the x265hip_setup_primitives signature: installs the lookup stubs over the host's own sad family */
 int x265ref_seam_fill_table(void* table, size_t bytes, int depth)

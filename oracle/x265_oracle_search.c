@@ -819,9 +819,16 @@ int EXPORT(x265oracle_lowres_cost_wp)(const pixel* cur, const pixel* const* refs
                                       uint16_t* lowresCosts, int32_t* rowSatds, int64_t* frame, const pixel* const* refs0Bi)
 {
     if (!refs0Bi) refs0Bi = refs0;
+    /* the seam tests call this from several encoder threads at once: the table is filled exactly once */
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
-    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    if (!__atomic_load_n(&ready, __ATOMIC_ACQUIRE))
+    {
+        static int lock = 0;
+        while (__atomic_exchange_n(&lock, 1, __ATOMIC_ACQUIRE)) { }
+        if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); __atomic_store_n(&ready, 1, __ATOMIC_RELEASE); }
+        __atomic_store_n(&lock, 0, __ATOMIC_RELEASE);
+    }
     int part = -1;
     for (int k = 0; k < 25; k++) if (kPuDims[k][0] == 8 && kPuDims[k][1] == 8) part = k;
     const int bBidir = refs1 != NULL;

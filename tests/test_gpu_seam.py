@@ -96,3 +96,75 @@ def test_seam_never_waits_by_default():
     base, got, rep = T.run_pair(8, 256, 192, 5, "medium", opts, "gpu", rng=20, verify=True)
     assert got[0] == base[0] and rep["verify_mismatches"] == 0 and rep["failed"] == 0
     assert rep["lookups_served"] + rep["row_not_ready"] + rep["outside_window"] > 1000
+
+
+@pytest.mark.parametrize("depth,preset,extra", [(8, "medium", []), (8, "slow", []), (10, "medium", []), (8, "medium", [("bframes", "0")])])
+def test_lookahead_seam_on_gpu_is_byte_identical(depth, preset, extra):
+    """CostEstimateGroup::estimateFrameCost's block loop served by x265hip_lowres_cost_host inside the real encoder (P and B pictures,
+    list reuse, weighted references, AQ weights): same slice decisions, same bitstream."""
+    import test_seam_cpu as T
+    opts = [("pools", "4"), ("frame-threads", "1"), ("crf", "24"), ("lookahead-slices", "1")] + extra
+    base, got, rep = T.run_pair(depth, 320, 192, 12, preset, opts, "gpu", rng=16, verify=True, wait=True, lookahead="gpu")
+    assert got[0] == base[0], f"lookahead seam changed the bitstream: {rep}"
+    la = rep["lookahead_seam"]
+    assert la["frame_cost_estimates_served"] >= 10 and la["failed"] == 0, la
+    assert rep["verify_mismatches"] == 0 and rep["failed"] == 0
+
+
+def test_lowres_cost_host_entry_equals_oracle():
+    """x265hip_lowres_cost_host through plain host pointers (what the seam passes) against the oracle, P and B, both lists searched."""
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_api as O
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    depth, W, Hh = 8, 416, 240
+    clip = F.synth_clip(W, Hh, 3, depth=depth, seed=57)
+    lw, lh = ((W // 2 + 7) >> 3) * 8, ((Hh // 2 + 7) >> 3) * 8
+    stride = (lw + 2 * F.MARGIN_X + 31) & ~31
+    org = stride * F.MARGIN_Y + F.MARGIN_X
+    rows = lh + 2 * F.MARGIN_Y
+    planes = []
+    for y, _, _ in clip:
+        buf, st, og, _, _ = F.pad_plane(y)
+        planes.append(O.lowres_init(depth, buf, st, og, stride, org, rows, lw, lh, F.MARGIN_X, F.MARGIN_Y))
+    wcu, hcu = lw // 8, lh // 8
+    n = wcu * hcu
+    icost, _, _ = O.lowres_intra(depth, planes[1][0], stride, org, wcu, hcu, 5)
+    half = 4 * max(lw, lh) + 1024
+    cq, qoff = F.qpel_cost_table(16, lam=1.0, qmax=half)
+    assert qoff == half
+
+    class HP(ctypes.Structure):
+        _fields_ = [("depth", ctypes.c_int), ("stride", ctypes.c_ssize_t), ("width_in_cu", ctypes.c_int), ("height_in_cu", ctypes.c_int),
+                    ("lines", ctypes.c_int), ("margin_x", ctypes.c_int), ("margin_y", ctypes.c_int), ("cur", ctypes.c_void_p),
+                    ("ref", ctypes.c_void_p * 4), ("ref1", ctypes.c_void_p * 4), ("ref_bi", ctypes.c_void_p * 4),
+                    ("intra_cost", ctypes.c_void_p), ("inv_qscale", ctypes.c_void_p), ("cost_q", ctypes.c_void_p), ("cost_q_half", ctypes.c_int),
+                    ("bframe_bias", ctypes.c_int), ("do_search", ctypes.c_int * 2), ("mvs", ctypes.c_void_p * 2), ("mv_costs", ctypes.c_void_p * 2),
+                    ("lowres_costs", ctypes.c_void_p), ("row_satds", ctypes.c_void_p), ("frame", ctypes.c_void_p)]
+    for bidir in (False, True):
+        mvs = [np.zeros((n, 2), np.int32), np.zeros((n, 2), np.int32)]
+        mvc = [np.zeros(n, np.int32), np.zeros(n, np.int32)]
+        lc, rws, frame = np.zeros(n, np.uint16), np.zeros(hcu, np.int32), np.zeros(4, np.int64)
+        q = HP()
+        q.depth, q.stride, q.width_in_cu, q.height_in_cu, q.lines, q.margin_x, q.margin_y = depth, stride, wcu, hcu, lh, F.MARGIN_X, F.MARGIN_Y
+        q.cur = planes[1][0].ctypes.data + org
+        for i in range(4):
+            q.ref[i] = planes[0][i].ctypes.data + org
+            q.ref1[i] = planes[2][i].ctypes.data + org if bidir else None
+        q.intra_cost, q.inv_qscale = icost.ctypes.data, None
+        q.cost_q, q.cost_q_half, q.bframe_bias = cq.ctypes.data + 2 * qoff, half, 0
+        q.do_search[0], q.do_search[1] = 1, int(bidir)
+        for l in range(2):
+            q.mvs[l], q.mv_costs[l] = mvs[l].ctypes.data, mvc[l].ctypes.data
+        q.lowres_costs, q.row_satds, q.frame = lc.ctypes.data, rws.ctypes.data, frame.ctypes.data
+        f = A.lib().x265hip_lowres_cost_host
+        f.argtypes = [ctypes.POINTER(HP)]
+        A.check(f(ctypes.byref(q)), "x265hip_lowres_cost_host")
+        exp = O.lowres_cost(depth, planes[1][0], planes[0], stride, org, wcu, hcu, cq, qoff, icost, ref1_planes=planes[2] if bidir else None)
+        if bidir:
+            (e0, e1), (c0, c1), elc, erows, eframe = exp
+            assert np.array_equal(mvs[1], e1) and np.array_equal(mvc[1], c1)
+        else:
+            e0, c0, elc, erows, eframe = exp
+        assert np.array_equal(mvs[0], e0) and np.array_equal(mvc[0], c0) and np.array_equal(lc, elc) and np.array_equal(rws, erows)
+        assert np.array_equal(frame[:len(eframe)], eframe)

@@ -21,7 +21,7 @@ def _tools():
     return encoder_bench, seam_driver
 
 
-def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False):
+def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False, lookahead=None):
     EB, SD = _tools()
     try:
         plain = EB.ref_lib(depth)
@@ -31,7 +31,7 @@ def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify
     clip = F.synth_clip(w, h, nframes, depth=depth, seed=seed)
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
     base = EB.encode(plain, yuv, w, h, nframes, preset, opts)
-    lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=8, min_pu=min_pu, verify=verify, wait=wait)
+    lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=8, min_pu=min_pu, verify=verify, wait=wait, lookahead=lookahead)
     try:
         got = EB.encode(lib, yuv, w, h, nframes, preset, opts, filler)
         rep = report()
@@ -69,3 +69,19 @@ def test_seam_with_weighted_prediction_defaults():
     base, got, rep = run_pair(8, 256, 192, 6, "slow", opts, "oracle", rng=16, min_pu=16)
     assert got[0] == base[0] and rep["verify_mismatches"] == 0
     assert rep["lookups_served"] > 1000
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("depth,preset,extra", [(8, "medium", []), (8, "slow", []), (8, "slower", []), (10, "medium", []),
+                                                (8, "medium", [("no-weightp", None)]), (8, "fast", [("b-adapt", "1")]), (8, "medium", [("bframes", "0")]),
+                                                (8, "medium", [("aq-mode", "0"), ("no-cutree", None)])])
+def test_lookahead_seam_encode_is_byte_identical(depth, preset, extra):
+    """The lookahead seam: CostEstimateGroup::estimateFrameCost's block loop served by ONE provider call per (p0, b, p1) triple
+    (here the oracle's restatement; tests/test_gpu_seam.py plugs in x265hip_lowres_cost_host) - P and B pictures, list reuse, weighted
+    references, AQ weights - inside the real encoder: slice types, cuTree and therefore the bitstream must not change."""
+    opts = [("pools", "4"), ("frame-threads", "1"), ("crf", "24"), ("lookahead-slices", "1")] + extra
+    base, got, rep = run_pair(depth, 320, 192, 12, preset, opts, "oracle", rng=16, verify=True, lookahead="oracle")
+    assert got[0] == base[0], f"lookahead seam changed the bitstream: {rep}"
+    la = rep["lookahead_seam"]
+    assert la["frame_cost_estimates_served"] >= 10 and la["failed"] == 0, la
+    assert rep["verify_mismatches"] == 0

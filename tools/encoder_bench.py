@@ -80,7 +80,7 @@ def effective_cpus():
 
 
 def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sys.stderr, seam=None):
-    seam = seam or {"range": 32, "slots": 8, "min_pu": 8, "verify": False}
+    seam = seam or {"range": 32, "slots": 8, "min_pu": 8, "verify": False, "lookahead": False}
     F = importlib.import_module("x265-yuuki-asuna_amd.frames")
     cfg = CONFIGS[key]
     w, h, depth = cfg["width"], cfg["height"], cfg["depth"]
@@ -90,6 +90,8 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
     lib = ref_lib(depth)
     opts = [("pools", str(cores)), ("frame-threads", str(frame_threads)), ("crf", "28")] + cfg["opts"]
+    if seam.get("lookahead"):        # the lookahead seam serves unsliced frame cost estimates: every leg of this run walks the lowres picture in one piece
+        opts.append(("lookahead-slices", "1"))
     res = {"config": cfg["name"], "size": f"{w}x{h}", "depth": depth, "preset": cfg["preset"], "options": dict(opts), "pool_threads": cores,
            "reference_build": "x265 3.5 C primitives (no asm: nasm is not in the image), g++ -O3"}
     md5_c = {}
@@ -111,7 +113,7 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
                 continue
             from tools import seam_driver as SD
             enc_lib, filler, note, closer, _ = SD.install(depth, w, h, provider="gpu", rng=seam["range"], slots=seam["slots"], min_pu=seam["min_pu"],
-                                                          verify=seam["verify"])
+                                                          verify=seam["verify"], lookahead="gpu" if seam.get("lookahead") else None)
         t0 = time.perf_counter()
         md5, nbytes, sec, filled = encode(enc_lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
         wall = time.perf_counter() - t0
@@ -149,8 +151,10 @@ def main():
     ap.add_argument("--seam-slots", type=int, default=8, help="(picture, reference) pairs resident in pinned host memory")
     ap.add_argument("--seam-min-pu", type=int, default=8, help="serve partitions whose smaller side is at least this")
     ap.add_argument("--seam-verify", action="store_true", help="check every lookup against the C primitive in flight (slow)")
+    ap.add_argument("--seam-lookahead", action="store_true",
+                    help="also serve CostEstimateGroup::estimateFrameCost's block loop from x265hip_lowres_cost_host (adds --lookahead-slices 1 to every leg)")
     args = ap.parse_args()
-    seam = {"range": args.seam_range, "slots": args.seam_slots, "min_pu": args.seam_min_pu, "verify": args.seam_verify}
+    seam = {"range": args.seam_range, "slots": args.seam_slots, "min_pu": args.seam_min_pu, "verify": args.seam_verify, "lookahead": args.seam_lookahead}
     out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s, seam=seam) for k in args.configs.split(",")}
     print(json.dumps({"encoder": out}))
 

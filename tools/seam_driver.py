@@ -157,7 +157,7 @@ class GpuProvider:
             self.handle = None
 
 
-def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False):
+def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None):
     """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) using
     --frame-threads 1 and --ctu 64."""
     lib = seam_lib(depth)
@@ -169,14 +169,30 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     if rc:
         raise RuntimeError(f"x265ref_seam_configure failed ({rc})")
     filler = ctypes.cast(lib.x265ref_seam_fill_table, ctypes.c_void_p)
+    # the lookahead seam (CostEstimateGroup::estimateFrameCost's block loop as one provider call): "gpu" = x265hip_lowres_cost_host,
+    # "oracle" = the CPU restatement (checker; GPU-less tests), None = off.  Needs --lookahead-slices 1.
+    lib.x265ref_lookahead_seam_configure.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    keep = None
+    if lookahead == "gpu":
+        A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+        lib.x265ref_lookahead_seam_configure(ctypes.cast(A.lib().x265hip_lowres_cost_host, ctypes.c_void_p), None)
+    elif lookahead == "oracle":
+        keep = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libx265oracle.so"))
+        lib.x265ref_lookahead_seam_configure(None, ctypes.cast(getattr(keep, f"x265oracle_lowres_cost_wp_d{depth}"), ctypes.c_void_p))
+    else:
+        lib.x265ref_lookahead_seam_configure(None, None)
 
     def report():
         d = stats(lib)
         d.update(prov.report())
         d.update({"range": rng, "slots": slots, "min_pu": min_pu})
+        la = (ctypes.c_uint64 * 3)()
+        lib.x265ref_lookahead_seam_stats(la)
+        d["lookahead_seam"] = {"provider": lookahead, "frame_cost_estimates_served": int(la[0]), "passed_to_reference_loop": int(la[1]), "failed": int(la[2])}
         return d
 
     def close():
         lib.x265ref_seam_disable()
         prov.close()
+    close.keep = keep            # the oracle library must outlive the encode
     return lib, filler, report, close, prov

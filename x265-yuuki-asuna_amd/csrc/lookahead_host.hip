@@ -1,0 +1,134 @@
+// lookahead_host.hip - the CONSUMER side of the lookahead's frame cost estimate: a host-pointer, frame-granular entry on top of
+// x265hip_lowres_cost, shaped like the loop it replaces.  CostEstimateGroup::estimateFrameCost (encoder/slicetype.cpp:3115-3213)
+// spends its time in the estimateCUCost loop over every 8x8 block of the half-resolution picture (:3216-3388: predictor candidates,
+// the lowres motionEstimate, bi-directional candidates, intra competition, the frame / row sums); a host encoder whose Lowres
+// planes live in host memory hands the (p0, b, p1) triple's planes and per-block arrays over, one launch walks the whole picture
+// (the wavefront of dependent rows runs in one workgroup, csrc/lowres_cost_kernels.hip) and the per-block results land in the
+// caller's Lowres arrays - lowresMvs, lowresMvCosts, lowresCosts, rowSatds - plus the frame sums.  Stateless and re-entrant: every
+// calling thread (the reference scores several triples at once from its pool, slicetype.cpp:2389-2436 batch mode) owns a stream
+// and grow-only device scratch, released at thread exit.  Same integers as the loop it replaces (tests: device == oracle == the real
+// CostEstimateGroup::singleCost), so the slice-type decisions and the bitstream cannot change.
+#include "common.h"
+
+#include <cstring>
+#include <vector>
+
+using namespace x265hip;
+
+namespace {
+
+struct LaThread
+{
+    hipStream_t stream = nullptr;
+    uint8_t* dev = nullptr;
+    size_t cap = 0;
+    ~LaThread()
+    {
+        if (!stream) return;
+        (void)hipStreamSynchronize(stream);
+        if (dev) (void)hipFree(dev);
+        (void)hipStreamDestroy(stream);
+    }
+    int ensure(size_t need)
+    {
+        if (!stream) X265HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (need <= cap) return 0;
+        if (dev) X265HIP_TRY(hipFree(dev));
+        dev = nullptr; cap = 0;
+        size_t n = (size_t)1 << 22;
+        while (n < need) n <<= 1;
+        X265HIP_TRY(hipMalloc((void**)&dev, n));
+        cap = n;
+        return 0;
+    }
+};
+
+LaThread& la_thread()
+{
+    static thread_local LaThread t;
+    return t;
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+} // namespace
+
+extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->cur || !p->intra_cost || !p->cost_q || !p->mvs[0] || !p->mv_costs[0] || !p->lowres_costs || !p->row_satds || !p->frame)
+    { set_error("lowres_cost_host: NULL operand"); return X265HIP_EINVAL; }
+    for (int k = 0; k < 4; k++) if (!p->ref[k]) { set_error("lowres_cost_host: NULL list-0 plane %d", k); return X265HIP_EINVAL; }
+    const bool bidir = p->ref1[0] != nullptr;
+    if (bidir) for (int k = 0; k < 4; k++) if (!p->ref1[k]) { set_error("lowres_cost_host: NULL list-1 plane %d", k); return X265HIP_EINVAL; }
+    const bool wbi = p->ref_bi[0] != nullptr;
+    if (wbi && !bidir) { set_error("lowres_cost_host: ref_bi needs a B picture"); return X265HIP_EINVAL; }
+    if (bidir && (!p->mvs[1] || !p->mv_costs[1])) { set_error("lowres_cost_host: NULL list-1 output"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("lowres_cost_host: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->width_in_cu <= 0 || p->height_in_cu <= 0 || p->lines <= 0 || p->margin_x < 32 || p->margin_y < 32 || p->stride < p->width_in_cu * 8 + 2 * p->margin_x)
+    { set_error("lowres_cost_host: geometry %d x %d blocks, %d lines, margins %d / %d, stride %ld", p->width_in_cu, p->height_in_cu, p->lines, p->margin_x, p->margin_y, (long)p->stride); return X265HIP_EINVAL; }
+    if (p->cost_q_half < 64) { set_error("lowres_cost_host: cost_q_half %d", p->cost_q_half); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    const int n = p->width_in_cu * p->height_in_cu;
+    // a plane as the caller holds it: (0,0) sits margin_y rows and margin_x samples into a buffer of lines + 2 * margin_y rows
+    const size_t org = ((size_t)p->margin_y * p->stride + p->margin_x) * bpp;
+    const size_t planeBytes = (size_t)p->stride * (p->lines + 2 * p->margin_y) * bpp;
+    const int nplanes = 1 + 4 + (bidir ? 4 : 0) + (wbi ? 4 : 0);
+    const size_t costBytes = (size_t)(2 * p->cost_q_half + 1) * 2;
+    // device layout
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align256(off + bytes); return o; };
+    size_t oPlane[13];
+    for (int i = 0; i < nplanes; i++) oPlane[i] = take(planeBytes + 64);
+    const size_t oCost = take(costBytes), oIntra = take((size_t)n * 4), oInvq = take((size_t)n * 4);
+    const size_t oMv0 = take((size_t)n * 8), oMc0 = take((size_t)n * 4), oMv1 = take((size_t)n * 8), oMc1 = take((size_t)n * 4);
+    const size_t oLc = take((size_t)n * 2), oRows = take((size_t)p->height_in_cu * 4), oFrame = take(32);
+    LaThread& t = la_thread();
+    rc = t.ensure(off);
+    if (rc) return rc;
+    hipStream_t s = t.stream;
+    uint8_t* d = t.dev;
+    auto up = [&](size_t o, const void* src, size_t bytes) { return check_hip(hipMemcpyAsync(d + o, src, bytes, hipMemcpyHostToDevice, s), "lowres_cost_host upload"); };
+    // planes: the caller passes sample (0,0); the allocation starts `org` bytes before it
+    const void* planes[13];
+    int k = 0;
+    planes[k++] = p->cur;
+    for (int i = 0; i < 4; i++) planes[k++] = p->ref[i];
+    if (bidir) for (int i = 0; i < 4; i++) planes[k++] = p->ref1[i];
+    if (wbi) for (int i = 0; i < 4; i++) planes[k++] = p->ref_bi[i];
+    for (int i = 0; i < nplanes; i++)
+        if (up(oPlane[i], (const uint8_t*)planes[i] - org, planeBytes)) return X265HIP_ENODEV;
+    if (up(oCost, p->cost_q - p->cost_q_half, costBytes)) return X265HIP_ENODEV;
+    if (up(oIntra, p->intra_cost, (size_t)n * 4)) return X265HIP_ENODEV;
+    if (p->inv_qscale && up(oInvq, p->inv_qscale, (size_t)n * 4)) return X265HIP_ENODEV;
+    // a list that is not searched again keeps the mvs / costs it was given (estimateFrameCost's bDoSearch)
+    if (!p->do_search[0]) { if (up(oMv0, p->mvs[0], (size_t)n * 8) || up(oMc0, p->mv_costs[0], (size_t)n * 4)) return X265HIP_ENODEV; }
+    if (bidir && !p->do_search[1]) { if (up(oMv1, p->mvs[1], (size_t)n * 8) || up(oMc1, p->mv_costs[1], (size_t)n * 4)) return X265HIP_ENODEV; }
+
+    x265hip_lowres_cost_pair pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.cur = d + oPlane[0] + org;
+    for (int i = 0; i < 4; i++) pr.ref[i] = d + oPlane[1 + i] + org;
+    if (bidir) for (int i = 0; i < 4; i++) pr.ref1[i] = d + oPlane[5 + i] + org;
+    if (wbi) for (int i = 0; i < 4; i++) pr.ref_bi[i] = d + oPlane[9 + i] + org;
+    pr.intra_cost = (const int32_t*)(d + oIntra);
+    pr.inv_qscale = p->inv_qscale ? (const int32_t*)(d + oInvq) : nullptr;
+    pr.mvs = (int32_t*)(d + oMv0); pr.mv_costs = (int32_t*)(d + oMc0);
+    pr.mvs1 = bidir ? (int32_t*)(d + oMv1) : nullptr; pr.mv_costs1 = bidir ? (int32_t*)(d + oMc1) : nullptr;
+    pr.do_search[0] = p->do_search[0]; pr.do_search[1] = p->do_search[1];
+    pr.lowres_costs = (uint16_t*)(d + oLc); pr.row_satds = (int32_t*)(d + oRows); pr.frame = (int64_t*)(d + oFrame);
+    x265hip_lowres_cost_params q;
+    memset(&q, 0, sizeof(q));
+    q.depth = p->depth; q.stride = p->stride; q.width_in_cu = p->width_in_cu; q.height_in_cu = p->height_in_cu;
+    q.cost_q = (const uint16_t*)(d + oCost); q.qoff = p->cost_q_half; q.bframe_bias = p->bframe_bias;
+    q.pairs = &pr; q.npairs = 1; q.pairs_on_device = 0;
+    rc = x265hip_lowres_cost(&q, s);
+    if (rc) return rc;
+    auto down = [&](void* dst, size_t o, size_t bytes) { return check_hip(hipMemcpyAsync(dst, d + o, bytes, hipMemcpyDeviceToHost, s), "lowres_cost_host download"); };
+    if (p->do_search[0]) { if (down(p->mvs[0], oMv0, (size_t)n * 8) || down(p->mv_costs[0], oMc0, (size_t)n * 4)) return X265HIP_ENODEV; }
+    if (bidir && p->do_search[1]) { if (down(p->mvs[1], oMv1, (size_t)n * 8) || down(p->mv_costs[1], oMc1, (size_t)n * 4)) return X265HIP_ENODEV; }
+    if (down(p->lowres_costs, oLc, (size_t)n * 2) || down(p->row_satds, oRows, (size_t)p->height_in_cu * 4) || down(p->frame, oFrame, 32)) return X265HIP_ENODEV;
+    X265HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
