@@ -308,6 +308,10 @@ typedef struct x265hip_lowres_cost_host_params
     int do_search[2];
     int32_t* mvs[2];  int32_t* mv_costs[2];
     uint16_t* lowres_costs;  int32_t* row_satds;  int64_t* frame;
+    /* optional content keys (0 = upload on every call): a non-zero key vouches that the plane set at these host addresses does not
+     * change while the key stays the same (e.g. Lowres::frameNum + 1), so the library keeps ONE device copy across the many triples
+     * that involve the picture.  cur / ref / ref1 / ref_bi planes respectively; weighted scratch planes must pass 0. */
+    uint64_t plane_key_cur, plane_key_ref, plane_key_ref1, plane_key_ref_bi;
 } x265hip_lowres_cost_host_params;
 int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p);
 

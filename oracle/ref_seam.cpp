@@ -68,6 +68,7 @@ struct LaHostParams
     int do_search[2];
     int32_t* mvs[2];  int32_t* mv_costs[2];
     uint16_t* lowres_costs;  int32_t* row_satds;  int64_t* frame;
+    uint64_t plane_key_cur, plane_key_ref, plane_key_ref1, plane_key_ref_bi;
 };
 typedef int (*la_host_fn)(const LaHostParams*);
 /* the oracle's CPU restatement (x265oracle_lowres_cost_wp_d<depth>): the checker-only provider of the GPU-less tests */
@@ -472,6 +473,12 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
         q.mvs[0] = &fenc->lowresMvs[0][b - p0][0].x; q.mv_costs[0] = fenc->lowresMvCosts[0][b - p0];
         q.mvs[1] = bidir ? &fenc->lowresMvs[1][p1 - b][0].x : NULL; q.mv_costs[1] = bidir ? fenc->lowresMvCosts[1][p1 - b] : NULL;
         q.lowres_costs = fenc->lowresCosts[b - p0][p1 - b]; q.row_satds = fenc->rowSatds[b - p0][p1 - b]; q.frame = frame;
+        /* a Lowres' planes are written once per picture (Lowres::init): its frame number names their content; weighted planes live in
+         * the thread's scratch (tld.wbuffer) and are uploaded every time */
+        q.plane_key_cur = (uint64_t)fenc->frameNum + 1;
+        q.plane_key_ref = wfref0 == fref0 ? (uint64_t)fref0->frameNum + 1 : 0;
+        q.plane_key_ref1 = bidir ? (uint64_t)fref1->frameNum + 1 : 0;
+        q.plane_key_ref_bi = (bidir && wfref0 != fref0) ? (uint64_t)fref0->frameNum + 1 : 0;
         rc = gla.host(&q);
     }
     else

@@ -140,7 +140,8 @@ def test_lowres_cost_host_entry_equals_oracle():
                     ("ref", ctypes.c_void_p * 4), ("ref1", ctypes.c_void_p * 4), ("ref_bi", ctypes.c_void_p * 4),
                     ("intra_cost", ctypes.c_void_p), ("inv_qscale", ctypes.c_void_p), ("cost_q", ctypes.c_void_p), ("cost_q_half", ctypes.c_int),
                     ("bframe_bias", ctypes.c_int), ("do_search", ctypes.c_int * 2), ("mvs", ctypes.c_void_p * 2), ("mv_costs", ctypes.c_void_p * 2),
-                    ("lowres_costs", ctypes.c_void_p), ("row_satds", ctypes.c_void_p), ("frame", ctypes.c_void_p)]
+                    ("lowres_costs", ctypes.c_void_p), ("row_satds", ctypes.c_void_p), ("frame", ctypes.c_void_p),
+                    ("plane_key_cur", ctypes.c_uint64), ("plane_key_ref", ctypes.c_uint64), ("plane_key_ref1", ctypes.c_uint64), ("plane_key_ref_bi", ctypes.c_uint64)]
     for bidir in (False, True):
         mvs = [np.zeros((n, 2), np.int32), np.zeros((n, 2), np.int32)]
         mvc = [np.zeros(n, np.int32), np.zeros(n, np.int32)]
@@ -157,6 +158,7 @@ def test_lowres_cost_host_entry_equals_oracle():
         for l in range(2):
             q.mvs[l], q.mv_costs[l] = mvs[l].ctypes.data, mvc[l].ctypes.data
         q.lowres_costs, q.row_satds, q.frame = lc.ctypes.data, rws.ctypes.data, frame.ctypes.data
+        q.plane_key_cur, q.plane_key_ref, q.plane_key_ref1 = (2, 1, 3) if bidir else (0, 0, 0)      # second pass: through the shared plane cache
         f = A.lib().x265hip_lowres_cost_host
         f.argtypes = [ctypes.POINTER(HP)]
         A.check(f(ctypes.byref(q)), "x265hip_lowres_cost_host")

@@ -2,7 +2,7 @@
 # Round-2 GPU visit E: the lookahead seam (x265hip_lowres_cost_host behind CostEstimateGroup::estimateFrameCost) - parity tests + encoder legs.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r2e
+OUT=$ROOT/gpurun_out/${1:-r2e}
 mkdir -p "$OUT"
 cd "$ROOT"
 ( time timeout 1500 python -m pytest tests -m gpu -q --durations=5 ) > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest.log"

@@ -11,6 +11,7 @@
 #include "common.h"
 
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 using namespace x265hip;
@@ -51,6 +52,44 @@ LaThread& la_thread()
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// Device copies of host planes the caller vouches for: plane_key != 0 names the CONTENT of a plane set (a picture's four lowres planes
+// do not change while its frame number stays the same), so the dozens of (p0, b, p1) triples the lookahead scores around a picture
+// upload each plane once.  Shared by all calling threads; entries are only read by kernels after their upload was synchronised.
+struct CachedPlane { const void* host; uint64_t key; size_t bytes; void* dev; uint64_t stamp; };
+std::mutex g_planeMu;
+std::vector<CachedPlane> g_planes;
+uint64_t g_planeClock = 0;
+size_t g_planeBytes = 0;
+constexpr size_t PLANE_CACHE_LIMIT = (size_t)6 << 30;          // 6 GiB of HBM at most
+
+// returns the device copy of the host plane (allocation start `host`, `bytes` long), uploading it on `s` when it is not cached yet
+int cached_plane(const void* host, uint64_t key, size_t bytes, hipStream_t s, void** out)
+{
+    std::lock_guard<std::mutex> lk(g_planeMu);
+    for (auto& e : g_planes)
+        if (e.host == host && e.key == key && e.bytes == bytes) { e.stamp = ++g_planeClock; *out = e.dev; return 0; }
+    // evict: same host buffer with an older key (the picture was replaced), then least recently used beyond the limit
+    for (size_t i = 0; i < g_planes.size();)
+    {
+        if (g_planes[i].host == host) { (void)hipFree(g_planes[i].dev); g_planeBytes -= g_planes[i].bytes; g_planes.erase(g_planes.begin() + i); }
+        else i++;
+    }
+    while (g_planeBytes + bytes > PLANE_CACHE_LIMIT && !g_planes.empty())
+    {
+        size_t lru = 0;
+        for (size_t i = 1; i < g_planes.size(); i++) if (g_planes[i].stamp < g_planes[lru].stamp) lru = i;
+        (void)hipFree(g_planes[lru].dev); g_planeBytes -= g_planes[lru].bytes; g_planes.erase(g_planes.begin() + lru);
+    }
+    void* d = nullptr;
+    X265HIP_TRY(hipMalloc(&d, bytes + 64));
+    X265HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s));
+    X265HIP_TRY(hipStreamSynchronize(s));                       // other threads may use the entry as soon as the lock is released
+    g_planes.push_back({ host, key, bytes, d, ++g_planeClock });
+    g_planeBytes += bytes;
+    *out = d;
+    return 0;
+}
+
 } // namespace
 
 extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p)
@@ -79,8 +118,18 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
     // device layout
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = align256(off + bytes); return o; };
+    // which planes may come from the shared cache: cur (key_cur), the list-0 / list-1 references when they are the pictures' own planes
+    uint64_t pkey[13];
+    {
+        int k = 0;
+        pkey[k++] = p->plane_key_cur;
+        for (int i = 0; i < 4; i++) pkey[k++] = p->plane_key_ref;
+        if (bidir) for (int i = 0; i < 4; i++) pkey[k++] = p->plane_key_ref1;
+        if (wbi) for (int i = 0; i < 4; i++) pkey[k++] = p->plane_key_ref_bi;
+    }
     size_t oPlane[13];
-    for (int i = 0; i < nplanes; i++) oPlane[i] = take(planeBytes + 64);
+    for (int i = 0; i < nplanes; i++) oPlane[i] = pkey[i] ? 0 : take(planeBytes + 64);
+    const size_t oPair = take(sizeof(x265hip_lowres_cost_pair));
     const size_t oCost = take(costBytes), oIntra = take((size_t)n * 4), oInvq = take((size_t)n * 4);
     const size_t oMv0 = take((size_t)n * 8), oMc0 = take((size_t)n * 4), oMv1 = take((size_t)n * 8), oMc1 = take((size_t)n * 4);
     const size_t oLc = take((size_t)n * 2), oRows = take((size_t)p->height_in_cu * 4), oFrame = take(32);
@@ -97,8 +146,22 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
     for (int i = 0; i < 4; i++) planes[k++] = p->ref[i];
     if (bidir) for (int i = 0; i < 4; i++) planes[k++] = p->ref1[i];
     if (wbi) for (int i = 0; i < 4; i++) planes[k++] = p->ref_bi[i];
+    uint8_t* dPlane[13];
     for (int i = 0; i < nplanes; i++)
-        if (up(oPlane[i], (const uint8_t*)planes[i] - org, planeBytes)) return X265HIP_ENODEV;
+    {
+        if (pkey[i])
+        {
+            void* cp = nullptr;
+            rc = cached_plane((const uint8_t*)planes[i] - org, pkey[i], planeBytes, s, &cp);
+            if (rc) return rc;
+            dPlane[i] = (uint8_t*)cp;
+        }
+        else
+        {
+            if (up(oPlane[i], (const uint8_t*)planes[i] - org, planeBytes)) return X265HIP_ENODEV;
+            dPlane[i] = d + oPlane[i];
+        }
+    }
     if (up(oCost, p->cost_q - p->cost_q_half, costBytes)) return X265HIP_ENODEV;
     if (up(oIntra, p->intra_cost, (size_t)n * 4)) return X265HIP_ENODEV;
     if (p->inv_qscale && up(oInvq, p->inv_qscale, (size_t)n * 4)) return X265HIP_ENODEV;
@@ -108,10 +171,10 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
 
     x265hip_lowres_cost_pair pr;
     memset(&pr, 0, sizeof(pr));
-    pr.cur = d + oPlane[0] + org;
-    for (int i = 0; i < 4; i++) pr.ref[i] = d + oPlane[1 + i] + org;
-    if (bidir) for (int i = 0; i < 4; i++) pr.ref1[i] = d + oPlane[5 + i] + org;
-    if (wbi) for (int i = 0; i < 4; i++) pr.ref_bi[i] = d + oPlane[9 + i] + org;
+    pr.cur = dPlane[0] + org;
+    for (int i = 0; i < 4; i++) pr.ref[i] = dPlane[1 + i] + org;
+    if (bidir) for (int i = 0; i < 4; i++) pr.ref1[i] = dPlane[5 + i] + org;
+    if (wbi) for (int i = 0; i < 4; i++) pr.ref_bi[i] = dPlane[9 + i] + org;
     pr.intra_cost = (const int32_t*)(d + oIntra);
     pr.inv_qscale = p->inv_qscale ? (const int32_t*)(d + oInvq) : nullptr;
     pr.mvs = (int32_t*)(d + oMv0); pr.mv_costs = (int32_t*)(d + oMc0);
@@ -122,7 +185,9 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
     memset(&q, 0, sizeof(q));
     q.depth = p->depth; q.stride = p->stride; q.width_in_cu = p->width_in_cu; q.height_in_cu = p->height_in_cu;
     q.cost_q = (const uint16_t*)(d + oCost); q.qoff = p->cost_q_half; q.bframe_bias = p->bframe_bias;
-    q.pairs = &pr; q.npairs = 1; q.pairs_on_device = 0;
+    // the pair record travels in this thread's own scratch: no stream-ordered allocation per call
+    if (up(oPair, &pr, sizeof(pr))) return X265HIP_ENODEV;
+    q.pairs = (const x265hip_lowres_cost_pair*)(d + oPair); q.npairs = 1; q.pairs_on_device = bidir ? 2 : 1;
     rc = x265hip_lowres_cost(&q, s);
     if (rc) return rc;
     auto down = [&](void* dst, size_t o, size_t bytes) { return check_hip(hipMemcpyAsync(dst, d + o, bytes, hipMemcpyDeviceToHost, s), "lowres_cost_host download"); };
