@@ -245,7 +245,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the bit-exact comparison of one whole frame with the oracle chain")
     ap.add_argument("--no-encoder", action="store_true",
                     help="skip the encoder-level leg (tier T3): the REAL reference encoder (oracle/_ref) on BASELINE configs[2] - 4K, preset slow, "
-                         "--me star - with its own C table and with the stage-level seam on x265hip_me_cache surfaces; fps + bitstream md5")
+                         "--me star - with its own C table and with the stage-level seams (integer-search SADs from x265hip_me_cache surfaces, the "
+                         "lookahead's frame cost / intra estimates from x265hip_lowres_cost_host / x265hip_lowres_intra_host); fps + bitstream md5")
     ap.add_argument("--encoder", default="cfg3", help="configurations of the encoder-level leg (tools/encoder_bench.py: cfg1,cfg2,cfg3,cfg4)")
     ap.add_argument("--encoder-frames", type=int, default=6)
     ap.add_argument("--encoder-tables", default="c,seam", help="c = reference C table, seam = + x265hip_me_cache lookups, hip = per-call stubs (slow)")
@@ -405,7 +406,7 @@ def main():
                 enc = {}
                 for key in args.encoder.split(","):
                     enc[key] = EB.run_config(key, args.encoder_tables.split(","), args.encoder_frames, 1, 120.0, log=sys.stderr,
-                                             seam={"range": 24, "slots": 8, "min_pu": 8, "verify": False})
+                                             seam={"range": 24, "slots": 8, "min_pu": 8, "verify": False, "lookahead": True})
                 out["encoder"] = enc
                 c3 = enc.get("cfg3", {})
                 if "c" in c3:

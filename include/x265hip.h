@@ -314,6 +314,21 @@ typedef struct x265hip_lowres_cost_host_params
     uint64_t plane_key_cur, plane_key_ref, plane_key_ref1, plane_key_ref_bi;
 } x265hip_lowres_cost_host_params;
 int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p);
+/* the intra half the same way: LookaheadTLD::lowresIntraEstimate's per-block work (slicetype.cpp:696-772) for one picture whose lowres
+ * plane 0 is in host memory (geometry and plane_key as above); intra_cost int32 [n], intra_mode uint8 [n], lowres_costs uint16 [n] are
+ * HOST outputs; the AQ weighting and the row / frame sums of :779-803 stay with the caller. */
+typedef struct x265hip_lowres_intra_host_params
+{
+    int depth;
+    intptr_t stride;
+    int width_in_cu, height_in_cu;
+    int lines, margin_x, margin_y;
+    const void* plane;
+    int intra_penalty;
+    int32_t* intra_cost; uint8_t* intra_mode; uint16_t* lowres_costs;
+    uint64_t plane_key;
+} x265hip_lowres_intra_host_params;
+int x265hip_lowres_intra_host(const x265hip_lowres_intra_host_params* p);
 
 /* ---- in-loop deblocking of a device-resident luma reconstruction (deblocking half) ----
  * x265hip_deblock_bs_inter = Deblock::getBoundaryStrength (deblock.cpp:191-215) for a P picture with one reference cut into

@@ -46,6 +46,7 @@ extern "C" int x265ref_orig_motionEstimate(MotionEstimate* self, ReferencePlanes
                                            int numCandidates, const MV* mvc, int merange, MV* outQMv, uint32_t maxSlices, pixel* srcReferencePlane);
 
 extern "C" int64_t x265ref_orig_estimateFrameCost(CostEstimateGroup* self, LookaheadTLD* tld, int p0, int p1, int b, bool bIntraPenalty);
+extern "C" void x265ref_orig_lowresIntraEstimate(LookaheadTLD* self, Lowres* fenc, uint32_t qgSize);
 
 namespace {
 
@@ -76,12 +77,28 @@ typedef int (*la_oracle_fn)(const pixel* cur, const pixel* const* refs0, const p
                             const uint16_t* cost, int qoff, const int32_t* intraCost, const int32_t* invQscale, const int* doSearch, int bFrameBias,
                             int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1, uint16_t* lowresCosts, int32_t* rowSatds,
                             int64_t* frame, const pixel* const* refs0Bi);
+struct LaIntraHostParams          /* x265hip_lowres_intra_host_params */
+{
+    int depth;
+    intptr_t stride;
+    int width_in_cu, height_in_cu;
+    int lines, margin_x, margin_y;
+    const void* plane;
+    int intra_penalty;
+    int32_t* intra_cost; uint8_t* intra_mode; uint16_t* lowres_costs;
+    uint64_t plane_key;
+};
+typedef int (*la_intra_host_fn)(const LaIntraHostParams*);
+typedef void (*la_intra_oracle_fn)(const pixel* plane, intptr_t stride, int widthInCU, int heightInCU, int intraPenalty,
+                                   int32_t* intraCost, uint8_t* intraMode, uint16_t* lowresCosts, int nthreads);
 struct LookaheadSeam
 {
     bool enabled = false;
     la_host_fn host = NULL;
     la_oracle_fn oracle = NULL;
-    std::atomic<uint64_t> served{0}, passed{0}, failed{0};
+    la_intra_host_fn intraHost = NULL;
+    la_intra_oracle_fn intraOracle = NULL;
+    std::atomic<uint64_t> served{0}, passed{0}, failed{0}, intraServed{0};
 } gla;
 
 struct MeCostProbe : public MotionEstimate { const uint16_t* costCentre() const { return m_cost; } };
@@ -512,6 +529,54 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
     return score;
 }
 
+/* The intra half of the lookahead: the per-block work of LookaheadTLD::lowresIntraEstimate (slicetype.cpp:716-777: DC, planar and the
+ * angular scan of every 8x8 block) as one provider call; the AQ weighting and the sums are the reference's own lines :779-803. */
+void LookaheadTLD::lowresIntraEstimate(Lowres& fenc, uint32_t qgSize)
+{
+    if (!gla.enabled || (!gla.intraHost && !gla.intraOracle)) { x265ref_orig_lowresIntraEstimate(this, &fenc, qgSize); return; }
+    const int intraPenalty = 5 * (int)x265_lambda_tab[X265_LOOKAHEAD_QP];
+    int rc = 0;
+    if (gla.intraHost)
+    {
+        const ptrdiff_t pad = fenc.lowresPlane[0] - fenc.buffer[0];
+        LaIntraHostParams q;
+        memset(&q, 0, sizeof(q));
+        q.depth = X265_DEPTH; q.stride = fenc.lumaStride; q.width_in_cu = widthInCU; q.height_in_cu = heightInCU;
+        q.lines = fenc.lines; q.margin_y = (int)(pad / fenc.lumaStride); q.margin_x = (int)(pad % fenc.lumaStride);
+        q.plane = fenc.lowresPlane[0]; q.intra_penalty = intraPenalty;
+        q.intra_cost = fenc.intraCost; q.intra_mode = fenc.intraMode; q.lowres_costs = fenc.lowresCosts[0][0];
+        q.plane_key = (uint64_t)fenc.frameNum + 1;
+        rc = gla.intraHost(&q);
+    }
+    else
+        gla.intraOracle(fenc.lowresPlane[0], fenc.lumaStride, widthInCU, heightInCU, intraPenalty, fenc.intraCost, fenc.intraMode, fenc.lowresCosts[0][0], 1);
+    if (rc)
+    {
+        gla.failed.fetch_add(1, std::memory_order_relaxed);
+        fprintf(stderr, "ref_seam: lookahead intra provider failed (%d); the reference's loop runs instead\n", rc);
+        x265ref_orig_lowresIntraEstimate(this, &fenc, qgSize);
+        return;
+    }
+    gla.intraServed.fetch_add(1, std::memory_order_relaxed);
+    int costEst = 0, costEstAq = 0;
+    for (int cuY = 0; cuY < heightInCU; cuY++)
+    {
+        fenc.rowSatds[0][0][cuY] = 0;
+        for (int cuX = 0; cuX < widthInCU; cuX++)
+        {
+            const int cuXY = cuX + cuY * widthInCU;
+            const int icost = fenc.intraCost[cuXY];
+            const bool bFrameScoreCU = (cuX > 0 && cuX < widthInCU - 1 && cuY > 0 && cuY < heightInCU - 1) || widthInCU <= 2 || heightInCU <= 2;
+            const int* scale = qgSize == 8 ? fenc.invQscaleFactor8x8 : fenc.invQscaleFactor;
+            const int icostAq = (bFrameScoreCU && fenc.invQscaleFactor) ? ((icost * scale[cuXY] + 128) >> 8) : icost;
+            if (bFrameScoreCU) { costEst += icost; costEstAq += icostAq; }
+            fenc.rowSatds[0][0][cuY] += icostAq;
+        }
+    }
+    fenc.costEst[0][0] = costEst;
+    fenc.costEstAq[0][0] = costEstAq;
+}
+
 extern "C" {
 
 /* provider: see the header comment; geometry = the PicYuv layout of the encode about to start.  Call before x265ref_encode. */
@@ -545,17 +610,20 @@ void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; }
 
 /* lookahead seam: host_fn = x265hip_lowres_cost_host (the product) or NULL; oracle_fn = x265oracle_lowres_cost_wp_d<depth> (CPU checker,
  * tests only) or NULL.  Both NULL switches the seam off. */
-int x265ref_lookahead_seam_configure(void* host_fn, void* oracle_fn)
+int x265ref_lookahead_seam_configure(void* host_fn, void* oracle_fn, void* intra_host_fn, void* intra_oracle_fn)
 {
     gla.host = (la_host_fn)host_fn;
     gla.oracle = (la_oracle_fn)oracle_fn;
-    gla.served = 0; gla.passed = 0; gla.failed = 0;
+    gla.intraHost = (la_intra_host_fn)intra_host_fn;
+    gla.intraOracle = (la_intra_oracle_fn)intra_oracle_fn;
+    gla.served = 0; gla.passed = 0; gla.failed = 0; gla.intraServed = 0;
     gla.enabled = host_fn || oracle_fn;
     return 0;
 }
 
-/* out[3]: frame cost estimates served by the provider, passed to the reference's loop (HME / cooperative slices / qg 8), failed */
-void x265ref_lookahead_seam_stats(uint64_t* out) { out[0] = gla.served; out[1] = gla.passed; out[2] = gla.failed; }
+/* out[4]: frame cost estimates served by the provider, passed to the reference's loop (HME / cooperative slices / qg 8), failed,
+ * intra estimates served */
+void x265ref_lookahead_seam_stats(uint64_t* out) { out[0] = gla.served; out[1] = gla.passed; out[2] = gla.failed; out[3] = gla.intraServed; }
 
 /* table filler with the x265hip_setup_primitives signature: installs the lookup stubs over the host's own sad family */
 int x265ref_seam_fill_table(void* table, size_t bytes, int depth)

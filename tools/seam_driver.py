@@ -171,24 +171,27 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     filler = ctypes.cast(lib.x265ref_seam_fill_table, ctypes.c_void_p)
     # the lookahead seam (CostEstimateGroup::estimateFrameCost's block loop as one provider call): "gpu" = x265hip_lowres_cost_host,
     # "oracle" = the CPU restatement (checker; GPU-less tests), None = off.  Needs --lookahead-slices 1.
-    lib.x265ref_lookahead_seam_configure.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.x265ref_lookahead_seam_configure.argtypes = [ctypes.c_void_p] * 4
     keep = None
     if lookahead == "gpu":
         A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
-        lib.x265ref_lookahead_seam_configure(ctypes.cast(A.lib().x265hip_lowres_cost_host, ctypes.c_void_p), None)
+        lib.x265ref_lookahead_seam_configure(ctypes.cast(A.lib().x265hip_lowres_cost_host, ctypes.c_void_p), None,
+                                             ctypes.cast(A.lib().x265hip_lowres_intra_host, ctypes.c_void_p), None)
     elif lookahead == "oracle":
         keep = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libx265oracle.so"))
-        lib.x265ref_lookahead_seam_configure(None, ctypes.cast(getattr(keep, f"x265oracle_lowres_cost_wp_d{depth}"), ctypes.c_void_p))
+        lib.x265ref_lookahead_seam_configure(None, ctypes.cast(getattr(keep, f"x265oracle_lowres_cost_wp_d{depth}"), ctypes.c_void_p),
+                                             None, ctypes.cast(getattr(keep, f"x265oracle_lowres_intra_d{depth}"), ctypes.c_void_p))
     else:
-        lib.x265ref_lookahead_seam_configure(None, None)
+        lib.x265ref_lookahead_seam_configure(None, None, None, None)
 
     def report():
         d = stats(lib)
         d.update(prov.report())
         d.update({"range": rng, "slots": slots, "min_pu": min_pu})
-        la = (ctypes.c_uint64 * 3)()
+        la = (ctypes.c_uint64 * 4)()
         lib.x265ref_lookahead_seam_stats(la)
-        d["lookahead_seam"] = {"provider": lookahead, "frame_cost_estimates_served": int(la[0]), "passed_to_reference_loop": int(la[1]), "failed": int(la[2])}
+        d["lookahead_seam"] = {"provider": lookahead, "frame_cost_estimates_served": int(la[0]), "passed_to_reference_loop": int(la[1]), "failed": int(la[2]),
+                               "intra_estimates_served": int(la[3])}
         return d
 
     def close():

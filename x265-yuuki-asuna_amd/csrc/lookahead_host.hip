@@ -197,3 +197,51 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
     X265HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
+
+// The intra half of the lookahead behind host pointers: the per-block work of LookaheadTLD::lowresIntraEstimate (slicetype.cpp:696-772)
+// for one picture whose lowres plane 0 lives in host memory; the AQ weighting and the row / frame sums of :779-803 stay with the caller
+// (they read its invQscaleFactor arrays).  plane_key as in x265hip_lowres_cost_host: the upload is shared with the frame cost estimates.
+extern "C" int x265hip_lowres_intra_host(const x265hip_lowres_intra_host_params* p)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->plane || !p->intra_cost || !p->intra_mode || !p->lowres_costs) { set_error("lowres_intra_host: NULL operand"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("lowres_intra_host: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->width_in_cu <= 0 || p->height_in_cu <= 0 || p->lines <= 0 || p->margin_x < 8 || p->margin_y < 8 || p->stride < p->width_in_cu * 8 + 2 * p->margin_x)
+    { set_error("lowres_intra_host: geometry"); return X265HIP_EINVAL; }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    const int n = p->width_in_cu * p->height_in_cu;
+    const size_t org = ((size_t)p->margin_y * p->stride + p->margin_x) * bpp;
+    const size_t planeBytes = (size_t)p->stride * (p->lines + 2 * p->margin_y) * bpp;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align256(off + bytes); return o; };
+    const size_t oPlane = p->plane_key ? 0 : take(planeBytes + 64);
+    const size_t oCost = take((size_t)n * 4), oMode = take((size_t)n), oLc = take((size_t)n * 2);
+    LaThread& t = la_thread();
+    rc = t.ensure(off);
+    if (rc) return rc;
+    hipStream_t s = t.stream;
+    uint8_t* d = t.dev;
+    uint8_t* dPlane = d + oPlane;
+    if (p->plane_key)
+    {
+        void* cp = nullptr;
+        rc = cached_plane((const uint8_t*)p->plane - org, p->plane_key, planeBytes, s, &cp);
+        if (rc) return rc;
+        dPlane = (uint8_t*)cp;
+    }
+    else
+        X265HIP_TRY(hipMemcpyAsync(dPlane, (const uint8_t*)p->plane - org, planeBytes, hipMemcpyHostToDevice, s));
+    x265hip_lowres_intra_params q;
+    memset(&q, 0, sizeof(q));
+    q.depth = p->depth; q.plane = dPlane + org; q.stride = p->stride; q.width_in_cu = p->width_in_cu; q.height_in_cu = p->height_in_cu;
+    q.intra_penalty = p->intra_penalty;
+    q.intra_cost = (int32_t*)(d + oCost); q.intra_mode = d + oMode; q.lowres_costs = (uint16_t*)(d + oLc);
+    rc = x265hip_lowres_intra(&q, s);
+    if (rc) return rc;
+    X265HIP_TRY(hipMemcpyAsync(p->intra_cost, d + oCost, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    X265HIP_TRY(hipMemcpyAsync(p->intra_mode, d + oMode, (size_t)n, hipMemcpyDeviceToHost, s));
+    X265HIP_TRY(hipMemcpyAsync(p->lowres_costs, d + oLc, (size_t)n * 2, hipMemcpyDeviceToHost, s));
+    X265HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
