@@ -45,13 +45,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_planes=None, cur_index=1, tu_flags=2):
+def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_planes=None, cur_index=1, tu_flags=2, band=None):
     """The oracle's restatement (CPU; checker + cpu_baseline leg only) of one frame of the pipeline - clip[cur_index] searched in
     clip[cur_index - 1] (or in ref_planes = padded Y, Cb, Cr of a reconstruction) - on the first n CTUs.  n == all CTUs also runs the per-picture stages (lookahead, deblocking, SAO statistics)
     and returns every stage output for the bit-exact comparison with the device pipeline.  Returns (seconds, outputs)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_api as O          # cpu_baseline / bit-exact checker leg only
     cur, stride, org, w64, h64 = F.pad_plane(clip[cur_index][0])
+    row0, first_band, last_band, h64_full = 0, True, True, h64
+    if band is not None:          # (first CTU row, CTU rows): the band is a slice of its own (stages.BandedFramePipeline); n counts the band's CTUs
+        row0, nrows = band
+        first_band, last_band = row0 == 0, (row0 + nrows) * 64 == h64
+        org += row0 * 64 * stride
+        h64 = nrows * 64
     src_prev = F.pad_plane(clip[cur_index - 1][0])[0]              # the lookahead scores SOURCE pictures
     # the picture searched / predicted from: the previous source frame, or (closed loop) the padded Y / Cb / Cr planes handed in
     ref = src_prev if ref_planes is None else ref_planes[0]
@@ -62,7 +68,7 @@ def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_pl
     lstride = (lw + 2 * F.MARGIN_X + 31) & ~31
     out = {}
     t = time.perf_counter()
-    if n == nctu:       # the lookahead stage is per picture: include it with whole-frame samples
+    if n == nctu and band is None:       # the lookahead stage is per picture: include it with whole-frame samples
         lp = O.lowres_init(depth, cur, stride, org, lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lh + 2 * F.MARGIN_Y, lw, lh,
                            F.MARGIN_X, F.MARGIN_Y, avx2=avx2)
         ic, im, lc = O.lowres_intra(depth, lp[0], lstride, lstride * F.MARGIN_Y + F.MARGIN_X, lw // 8, lh // 8, 5, nthreads=cores, avx2=avx2)
@@ -88,9 +94,9 @@ def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_pl
         _, par = O.sao_decide(depth, cnt, off, avx2=avx2)
         fin = O.sao_apply(depth, dbk.reshape(-1), stride, org, w64, h64, par, nthreads=cores, avx2=avx2).reshape(rec.shape)
         # chroma planes: prediction + residual round trip with the luma mvs, chroma edge filter (Bs 2 only), SAO on 32x32 footprints
-        cpl = [(F.pad_chroma(clip[cur_index][c], w64, h64),
-                F.pad_chroma(clip[cur_index - 1][c], w64, h64) if ref_planes is None else (ref_planes[c],)) for c in (1, 2)]
-        sc, oc = cpl[0][0][1], cpl[0][0][2]
+        cpl = [(F.pad_chroma(clip[cur_index][c], w64, h64_full),
+                F.pad_chroma(clip[cur_index - 1][c], w64, h64_full) if ref_planes is None else (ref_planes[c],)) for c in (1, 2)]
+        sc, oc = cpl[0][0][1], cpl[0][0][2] + row0 * 32 * cpl[0][0][1]
         qpc = S.chroma_quant_qp(qp, depth)
         crec = [O.inter_recon_chroma(depth, cpl[i][0][0].reshape(-1), cpl[i][1][0].reshape(-1), sc, oc, w64, h64, level, mv, qpc, nthreads=cores, avx2=avx2,
                                       intra_slice=tu_flags)
@@ -105,13 +111,16 @@ def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_pl
             out["sao_params_c%d" % i], out["levels_c%d" % i], out["sao_count_c%d" % i] = cpar, crec[i][1], ccnt
             cfin.append(cf)
         dt = time.perf_counter() - t
-        inner = fin[F.MARGIN_Y:F.MARGIN_Y + h64, F.MARGIN_X:F.MARGIN_X + w64]
+        # extendPicBorder; a band gets its side margins, the picture's top margin when it is the first band, the bottom margin when the last
+        y0 = F.MARGIN_Y + row0 * 64
+        inner = fin[y0:y0 + h64, F.MARGIN_X:F.MARGIN_X + w64]
         out.update({"me_best": best, "subpel_mv": mv, "levels": lev, "num_sig": ns, "dist": dist, "sao_count": cnt, "sao_offset_org": off,
                     "sao_params": par,
-                    "recon": np.pad(inner, ((F.MARGIN_Y, F.MARGIN_Y), (F.MARGIN_X, F.MARGIN_X)), mode="edge")})   # extendPicBorder
+                    "recon": np.pad(inner, ((F.MARGIN_Y * first_band, F.MARGIN_Y * last_band), (F.MARGIN_X, F.MARGIN_X)), mode="edge")})
         for i in range(2):
-            ci = cfin[i].reshape(-1, sc)[F.CHROMA_MARGIN_Y:F.CHROMA_MARGIN_Y + h64 // 2, F.CHROMA_MARGIN_X:F.CHROMA_MARGIN_X + w64 // 2]
-            out["recon_c%d" % i] = np.pad(ci, ((F.CHROMA_MARGIN_Y, F.CHROMA_MARGIN_Y), (F.CHROMA_MARGIN_X, F.CHROMA_MARGIN_X)), mode="edge")
+            yc = F.CHROMA_MARGIN_Y + row0 * 32
+            ci = cfin[i].reshape(-1, sc)[yc:yc + h64 // 2, F.CHROMA_MARGIN_X:F.CHROMA_MARGIN_X + w64 // 2]
+            out["recon_c%d" % i] = np.pad(ci, ((F.CHROMA_MARGIN_Y * first_band, F.CHROMA_MARGIN_Y * last_band), (F.CHROMA_MARGIN_X, F.CHROMA_MARGIN_X)), mode="edge")
         return dt, out
     return time.perf_counter() - t, out
 
@@ -241,6 +250,10 @@ def main():
                          "searches run by the device-side search driver (x265hip_me_search), predictor (0,0)")
     ap.add_argument("--lookahead-batch", type=int, default=0,
                     help="pictures per launch of the lookahead's P-frame cost estimate, which runs ahead on a side stream (0 = stage off)")
+    ap.add_argument("--band-rows", type=int, default=4,
+                    help="CTU rows per band of the frame-parallel ring (N > 1, or --banded): a band is searched / reconstructed / filtered as a slice "
+                         "of its own (the reference's --slices) and handed to the next rank as soon as it is final")
+    ap.add_argument("--banded", action="store_true", help="run the banded pipeline on one GPU too (measures what the band granularity costs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the bit-exact comparison of one whole frame with the oracle chain")
     ap.add_argument("--no-encoder", action="store_true",
@@ -296,9 +309,26 @@ def main():
                            chroma=True, sao_apply=True, sign_hide=True)
     ref_pic = pics[0].like([p.clone() for p in pics[0].planes()])     # the reference every rank searches in (starts as frame 0): Y, Cb, Cr
     fp = P.FrameParallel(rank, world)
+    banded = world > 1 or args.banded
+    if banded:
+        # N > 1: the reference's real frame-parallel dependency - frame f (rank f % N) searches frame f - 1, band by band (pipeline.FrameParallelRing)
+        bp = S.BandedFramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, band_rows=args.band_rows, rng=args.range, subme=args.subme, level=args.level,
+                                   qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed" and args.depth == 8,
+                                   lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True)
+        ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16)      # search window + 8-tap interpolation + sub-pel drift
+        ring.make_groups()
+        geom = (pics[0].stride, F.MARGIN_Y, pics[0].stride_c, F.CHROMA_MARGIN_Y)
+        total_frames = (args.warmup + args.steps) * world
+        bp.begin_frame(pics[1])                         # allocates the output planes
 
     def step(i):
         cur = pics[1 + i % (nclip - 1)]
+        if banded:
+            bp.begin_frame(cur)
+            ring.run_frame(i, geom, ref_pic.planes(), bp.final_planes(), lambda b, row0, n: bp.run_band(b, cur, ref_pic), total_frames=total_frames)
+            if world == 1:
+                fp.exchange(ref_pic.planes(), bp.final_planes())
+            return
         pipe.run(cur, ref_pic)
         # frame-parallel hand-off: the last rank's filtered reconstruction (Y, Cb, Cr) becomes everyone's next reference
         fp.exchange(ref_pic.planes(), pipe.final_planes())
@@ -312,7 +342,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(args.warmup + i)
+    if banded:
+        ring.finish()
     pipe.launch_lookahead_costs()                    # flush the incomplete batch: all K pictures are scored inside the timed region
     torch.cuda.synchronize()
     if world > 1:
@@ -323,7 +355,10 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    csum = pipe.checksum()
+    if banded:
+        csum = {"recon_%s" % n: int(p.view(torch.uint8).to(torch.int64).sum().item()) for n, p in zip(("y", "cb", "cr"), bp.final_planes())}
+    else:
+        csum = pipe.checksum()
 
     # ---- untimed pass: HIP-event time of every stage (events on the stream the kernels are launched on, recorded by the
     # pipeline's own stage hook, so exactly the launches of the timed loop are measured) ----
@@ -378,7 +413,9 @@ def main():
                                    f"SAO statistics -> SAO parameters (saoStatsInitialOffset + distortion-only choice, on device) -> SAO apply (Y, Cb, Cr) -> "
                                    f"border extension -> next reference (Y, Cb, Cr); pipeline throughput (tier T2), not HEVC encoded fps - the real "
                                    f"encoder's fps (tier T3) is `bench.py --encoder` / profiles/r02_encoder_*.txt",
-                       "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world}",
+                       "frames_per_step_per_gpu": 1, "parallelism": (f"frame-parallel x{world}" if not banded else
+                                       f"frame-parallel ring x{world}: frame f on rank f % {world} searches frame f - 1, handed on in bands of {args.band_rows} CTU rows "
+                                       f"(each band a slice of its own, like the reference's --slices)"),
                        "ctus_per_frame": ms.nctu, "checksum": csum},
             "stages_ms": stages,
             "roofline": {"bound": "hbm", "kernel": "me_search_kernel" if args.search != "full" else

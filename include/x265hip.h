@@ -185,6 +185,10 @@ int x265hip_inter_recon_bi(const x265hip_recon_bi_params* p, void* stream);
  * ipfilter.cpp:59-77, + top/bottom row replication): `pic` points at pixel (0,0) of a plane that has
  * margin_x columns / margin_y rows of padding on every side. */
 int x265hip_extend_border(void* pic, intptr_t stride, int width, int height, int margin_x, int margin_y, int depth, void* stream);
+/* the row-wise form FrameFilter uses (framefilter.cpp:346-436): `band` = first sample of a band of `height` rows; left / right margins of
+ * those rows, margin_top rows above (first band of a picture) and margin_bottom rows below (last band), either may be 0 */
+int x265hip_extend_border_rows(void* band, intptr_t stride, int width, int height, int margin_x, int margin_top, int margin_bottom,
+                               int depth, void* stream);
 
 /* ---- motion search drivers: MotionEstimate::motionEstimate for a list of PUs ----
  * One job = one prediction unit of one reference picture: position, size (any of the reference's 24 inter partitions,
@@ -715,6 +719,29 @@ static inline int32_t x265hip_surf_lookup(const void* surf, int surf_format, int
     static const int base[4] = { 0, 64, 80, 84 };
     return ((const int32_t*)g)[(base[level] + z) * 4 + (col & 3)];
 }
+
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Multi-GPU seam (csrc/recon_publish.hip): hand a finished band of reconstructed CTU rows - Y, Cb, Cr with their margins - from the
+ * GPU that produced it to the GPU(s) whose in-flight pictures reference it, where the reference raises m_reconRowFlag
+ * (encoder/framefilter.cpp:664; consumers wait in encoder/frameencoder.cpp:852-868).  One process per GPU; `comm` is the host's
+ * ncclComm_t (RCCL, resolved at run time).  Every rank of the communicator (peer < 0: broadcast from `root`) or the two ranks
+ * involved (peer >= 0: ncclSend on `root`, ncclRecv on `peer`) make the same call with their own plane pointers; the three planes
+ * travel in one RCCL group on `stream` - give it a copy stream so the next band's kernels overlap.
+ *   plane[]  : ALLOCATION STARTS of the padded planes (PicYuv layout); plane[1] / plane[2] NULL = luma only
+ *   height   : picture height in luma samples (whole CTUs); the first band also carries the top margin rows, the last band the bottom ones */
+typedef struct x265hip_recon_publish_params
+{
+    void* comm;                     /* ncclComm_t */
+    int rank, root, peer;           /* this process' rank; the producer; the one consumer, or -1 = everyone (broadcast) */
+    int depth;
+    void* plane[3];
+    intptr_t stride, stride_c;
+    int margin_y, margin_y_c;
+    int height;
+    int ctu_row0, ctu_rows;
+} x265hip_recon_publish_params;
+int x265hip_recon_publish_rows(const x265hip_recon_publish_params* p, void* stream);
 
 #ifdef __cplusplus
 }

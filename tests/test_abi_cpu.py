@@ -86,3 +86,31 @@ def test_ctypes_structures_match_the_c_header(repo_root, tmp_path):
         assert int(val) == expect, f"{cname}.{fname}: C says {val}, ctypes says {expect}"
         seen += 1
     assert seen > 150
+
+
+def test_library_has_no_unresolved_symbols_of_its_own():
+    """Every x265hip / x265hip:: symbol the library references must be defined inside it (a shared library links with undefined symbols)."""
+    import subprocess
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "x265-yuuki-asuna_amd", "libx265hip.so")
+    out = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
+    bad = [l for l in out.splitlines() if "x265hip" in l]
+    assert not bad, bad
+
+
+def test_recon_publish_rows_validates_before_touching_a_device():
+    """The multi-GPU seam's C entry rejects bad geometry without a device or RCCL (argument checks come first)."""
+    import ctypes
+
+    class PP(ctypes.Structure):
+        _fields_ = [("comm", ctypes.c_void_p), ("rank", ctypes.c_int), ("root", ctypes.c_int), ("peer", ctypes.c_int), ("depth", ctypes.c_int),
+                    ("plane", ctypes.c_void_p * 3), ("stride", ctypes.c_ssize_t), ("stride_c", ctypes.c_ssize_t), ("margin_y", ctypes.c_int),
+                    ("margin_y_c", ctypes.c_int), ("height", ctypes.c_int), ("ctu_row0", ctypes.c_int), ("ctu_rows", ctypes.c_int)]
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    f = A.lib().x265hip_recon_publish_rows
+    f.argtypes = [ctypes.POINTER(PP), ctypes.c_void_p]
+    p = PP()
+    assert f(ctypes.byref(p), None) == -2                       # NULL communicator
+    p.comm, p.depth, p.height, p.ctu_row0, p.ctu_rows, p.stride, p.margin_y = 1, 8, 128, 1, 2, 320, 80
+    p.plane[0] = 4096
+    assert f(ctypes.byref(p), None) == -2                       # rows 1..3 of a 2-row picture
+    assert b"rows" in A.lib().x265hip_last_error()

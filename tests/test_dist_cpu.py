@@ -49,3 +49,101 @@ def test_single_rank_is_a_plain_copy():
     a, b = torch.zeros(8, dtype=torch.uint8), torch.arange(8, dtype=torch.uint8)
     fp.exchange(a, b)
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ the frame k -> k - 1 ring, band by band
+def _ring_geometry(w64, h64):
+    F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+    stride, sc = w64 + 2 * F.MARGIN_X, w64 // 2 + 2 * F.CHROMA_MARGIN_X
+    return (stride, F.MARGIN_Y, sc, F.CHROMA_MARGIN_Y), (h64 + 2 * F.MARGIN_Y) * stride, (h64 // 2 + 2 * F.CHROMA_MARGIN_Y) * sc
+
+
+def _fake_band(frame, planes_ref, planes_out, geom, w64, h64, row0, nrows, lag, first, last):
+    """A stand-in for the banded pipeline with the same data footprint: every output row of the band mixes the frame's own pattern with
+    reference rows up to `lag` luma rows above and below it (the search window + interpolation taps), then the band's side margins and -
+    for the first / last band - the picture's top / bottom margins are extended.  A band started before those reference rows arrived
+    produces a different picture than the serial run."""
+    st, my, sc, myc = geom
+    for pi, (p_ref, p_out) in enumerate(zip(planes_ref, planes_out)):
+        s_, m_, sh = (st, my, 0) if pi == 0 else (sc, myc, 1)
+        R = p_ref.reshape(-1, s_).to(torch.int64)
+        O = p_out.reshape(-1, s_)
+        rows = torch.arange(m_ + (row0 * 64 >> sh), m_ + ((row0 + nrows) * 64 >> sh))
+        up = (rows - (lag >> sh)).clamp(0, R.shape[0] - 1)
+        dn = (rows + (lag >> sh)).clamp(0, R.shape[0] - 1)
+        pat = ((rows[:, None] * 7 + torch.arange(s_)[None, :] * 3 + frame * 11 + pi * 5) & 255)
+        val = (pat + R[up] + 2 * R[dn] + R[rows]) & 255
+        O[rows] = val.to(torch.uint8)
+        lo, hi = m_ + (row0 * 64 >> sh), m_ + ((row0 + nrows) * 64 >> sh)
+        if first:
+            O[:lo] = O[lo]
+        if last:
+            O[hi:] = O[hi - 1]
+
+
+def _ring_serial(nframes, w64, h64, bands, lag):
+    geom, ny, nc = _ring_geometry(w64, h64)
+    ref = [torch.full((ny,), 17, dtype=torch.uint8), torch.full((nc,), 29, dtype=torch.uint8), torch.full((nc,), 31, dtype=torch.uint8)]
+    outs = []
+    for f in range(nframes):
+        out = [torch.zeros_like(p) for p in ref]
+        for b, (row0, n) in enumerate(bands):
+            _fake_band(f, ref, out, geom, w64, h64, row0, n, lag, b == 0, b == len(bands) - 1)
+        outs.append(out)
+        ref = out
+    return outs
+
+
+def _ring_worker(rank, world, port, steps, out):
+    sys.path.insert(0, ROOT)
+    P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w64, h64, lag = 128, 448, 72                     # 7 CTU rows, bands of 2: (0,2) (2,2) (4,2) (6,1); a window of 57 + 8 + taps < 72 rows
+    bands = [(r, min(2, 7 - r)) for r in range(0, 7, 2)]
+    geom, ny, nc = _ring_geometry(w64, h64)
+    ring = P.FrameParallelRing(rank, world, bands, lag)
+    ring.make_groups()
+    assert [ring.bands_needed(b) for b in range(4)] == [1, 2, 3, 3]
+    ref = [torch.full((ny,), 17, dtype=torch.uint8), torch.full((nc,), 29, dtype=torch.uint8), torch.full((nc,), 31, dtype=torch.uint8)]
+    bufs = [[torch.zeros_like(p) for p in ref] for _ in range(2)]           # a frame's output stays untouched while its sends drain
+    total = steps * world
+    mine, order = {}, []
+    for step in range(steps):
+        f = ring.frame_index(step)
+        o = bufs[step & 1]
+
+        def band(b, row0, n, f=f, o=o):
+            order.append((f, b))
+            _fake_band(f, ref, o, geom, w64, h64, row0, n, lag, b == 0, b == len(bands) - 1)
+        ring.run_frame(step, geom, ref, o, band, total_frames=total)
+        mine[f] = [p.clone() for p in o]
+        if world == 1:
+            ref = [p.clone() for p in o]
+    ring.finish()
+    expect = _ring_serial(total, w64, h64, bands, lag)
+    ok = all(all(torch.equal(a, e) for a, e in zip(mine[f], expect[f])) for f in mine)
+    out[rank] = (ok, sorted(mine), order[:5])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_ring(world, steps):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29600 + (os.getpid() % 300) + world
+    mp.spawn(_ring_worker, args=(world, port, steps, out), nprocs=world, join=True)
+    return out
+
+
+def test_ring_two_ranks_follow_the_frame_chain_band_by_band():
+    out = _run_ring(2, 3)
+    assert out[0][0] and out[1][0], "a rank's frames differ from the serial chain: a band ran before its reference rows arrived"
+    assert out[0][1] == [0, 2, 4] and out[1][1] == [1, 3, 5]
+
+
+def test_ring_three_ranks():
+    out = _run_ring(3, 2)
+    assert all(out[r][0] for r in range(3))
+    assert out[2][1] == [2, 5]

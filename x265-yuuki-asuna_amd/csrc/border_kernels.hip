@@ -14,7 +14,8 @@ struct BorderArgs
 {
     void* pic[4];                     // up to four planes of one geometry (blockIdx.y selects)
     long stride;
-    int width, height, marginX, marginY;
+    int width, height, marginX, marginY;   // marginY: rows above
+    int marginBottom;                      // rows below (the whole-picture entry passes marginY again)
 };
 
 // Only the margin is walked: first the bands above and below the picture (full padded width), then the left / right bands of the
@@ -25,7 +26,7 @@ __global__ void __launch_bounds__(256) extend_border_kernel(BorderArgs a)
     Px* pic = reinterpret_cast<Px*>(a.pic[blockIdx.y]);
     const int width = a.width, height = a.height, marginX = a.marginX, marginY = a.marginY;
     const int pw = width + 2 * marginX, sideW = 2 * marginX;
-    const long nBands = (long)pw * 2 * marginY, nSides = (long)height * sideW;
+    const long nBands = (long)pw * (marginY + a.marginBottom), nSides = (long)height * sideW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nBands + nSides; i += (long)gridDim.x * blockDim.x)
     {
         int x, y;
@@ -48,12 +49,14 @@ __global__ void __launch_bounds__(256) extend_border_kernel(BorderArgs a)
 }
 
 // nplanes planes of one geometry in one launch (the four lookahead planes)
-int extend_borders(void* const* pics, int nplanes, intptr_t stride, int width, int height, int margin_x, int margin_y, int depth, hipStream_t s)
+int extend_borders_tb(void* const* pics, int nplanes, intptr_t stride, int width, int height, int margin_x, int margin_y, int depth, hipStream_t s,
+                      int margin_bottom)
 {
     BorderArgs a;
     for (int i = 0; i < 4; i++) a.pic[i] = i < nplanes ? pics[i] : nullptr;
     a.stride = (long)stride; a.width = width; a.height = height; a.marginX = margin_x; a.marginY = margin_y;
-    const long total = (long)(width + 2 * margin_x) * 2 * margin_y + (long)height * 2 * margin_x;
+    a.marginBottom = margin_bottom < 0 ? margin_y : margin_bottom;
+    const long total = (long)(width + 2 * margin_x) * (margin_y + a.marginBottom) + (long)height * 2 * margin_x;
     if (total <= 0) return 0;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -61,6 +64,11 @@ int extend_borders(void* const* pics, int nplanes, intptr_t stride, int width, i
     else hipLaunchKernelGGL(extend_border_kernel<uint16_t>, dim3(blocks, nplanes), dim3(256), 0, s, a);
     X265HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int extend_borders(void* const* pics, int nplanes, intptr_t stride, int width, int height, int margin_x, int margin_y, int depth, hipStream_t s)
+{
+    return extend_borders_tb(pics, nplanes, stride, width, height, margin_x, margin_y, depth, s, -1);
 }
 
 } // namespace x265hip
@@ -75,4 +83,19 @@ extern "C" int x265hip_extend_border(void* pic, intptr_t stride, int width, int 
     if (depth != 8 && depth != 10 && depth != 12) { set_error("extend_border: depth %d", depth); return X265HIP_EINVAL; }
     void* pics[1] = { pic };
     return extend_borders(pics, 1, stride, width, height, margin_x, margin_y, depth, (hipStream_t)stream);
+}
+
+/* A band of rows of a picture: (0,0) = the first sample of the band's first row; the left / right margins of its `height` rows are
+ * filled, plus margin_top rows above (the picture's first band) and margin_bottom rows below (its last band) - FrameFilter's
+ * row-wise form of the same extension (framefilter.cpp:346-436: extendRowBorder per CTU row, the top / bottom rows replicated for the
+ * first / last row). */
+extern "C" int x265hip_extend_border_rows(void* band, intptr_t stride, int width, int height, int margin_x, int margin_top, int margin_bottom,
+                                          int depth, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!band || width <= 0 || height <= 0 || margin_x < 0 || margin_top < 0 || margin_bottom < 0) { set_error("extend_border_rows: bad argument"); return X265HIP_EINVAL; }
+    if (depth != 8 && depth != 10 && depth != 12) { set_error("extend_border_rows: depth %d", depth); return X265HIP_EINVAL; }
+    void* pics[1] = { band };
+    return extend_borders_tb(pics, 1, stride, width, height, margin_x, margin_top, depth, (hipStream_t)stream, margin_bottom);
 }

@@ -47,6 +47,18 @@ class DevicePicture:
         """[luma, cb, cr] device tensors (luma only without chroma)."""
         return [self.t] + (self.c or [])
 
+    def band_view(self, ctu_row0, ctu_rows):
+        """The same planes seen as a band of `ctu_rows` CTU rows starting at CTU row `ctu_row0`: sample (0,0) moves to the band's first
+        row (luma and chroma), h64 shrinks to the band.  Stages called with a band view treat the band like a picture of its own -
+        exactly what the reference does with a slice (--slices: loop filters stop at the slice boundary, cudata.cpp:319, sao.cpp:286-287)
+        - while search windows and prediction keep reading the whole reference plane around it."""
+        o = DevicePicture.__new__(DevicePicture)
+        o.__dict__.update(self.__dict__)
+        o.org = self.org + ctu_row0 * 64 * self.stride
+        o.org_c = self.org_c + ctu_row0 * 32 * self.stride_c
+        o.h64 = ctu_rows * 64
+        return o
+
     def like(self, planes):
         """A picture of the same geometry over other device planes (e.g. a reconstruction that becomes a reference)."""
         o = DevicePicture.__new__(DevicePicture)
@@ -201,3 +213,97 @@ class FrameParallel:
         if self.rank == self.reference_owner():
             ref_plane.copy_(newest_plane)
         dist.broadcast(ref_plane, src=self.reference_owner())
+
+
+class FrameParallelRing:
+    """Frame-parallel encoding with the reference's REAL dependency: frame f is encoded by rank f % world and
+    searches / predicts from frame f - 1, which rank (f - 1) % world is producing at the same time - band by band.  A band of CTU
+    rows is handed on as soon as it is final (filtered, side margins extended): the point where the reference raises
+    m_reconRowFlag (encoder/framefilter.cpp:664), and the consumer starts a band once the reference rows its search window and
+    interpolation taps can touch have arrived - the wait of encoder/frameencoder.cpp:852-868 with m_refLagRows.  Every plane's rows
+    (Y, Cb, Cr incl. the side margins, plus the top / bottom margin with the first / last band) travel as one contiguous slice of the
+    padded plane, point to point to the one rank that needs them next (xGMI is point to point; with several reference pictures the
+    same slices would go to the next ranks as well).  Works on any torch.distributed backend: RCCL on GPUs, gloo in the CPU tests.
+
+    bands: [(first CTU row, CTU rows)], row_bytes-free: slices are computed from the plane geometry handed to run_frame."""
+
+    def __init__(self, rank: int, world: int, bands, lag_rows_luma: int):
+        self.rank, self.world, self.bands = rank, world, list(bands)
+        self.lag = lag_rows_luma            # luma rows below a band's last row that its search / interpolation may read
+        self.prev, self.next = (rank - 1) % world, (rank + 1) % world
+        self._sends = []
+
+    def frame_index(self, step: int) -> int:
+        return step * self.world + self.rank
+
+    @staticmethod
+    def _rows(geom, row0, nrows, first, last):
+        """(start, stop) element ranges of the band's rows in the three flat planes; geom = (stride, margin_y, stride_c, margin_y_c)."""
+        st, my, sc, myc = geom
+        y0 = my + row0 * 64 - (my if first else 0)
+        y1 = my + (row0 + nrows) * 64 + (my if last else 0)
+        c0 = myc + row0 * 32 - (myc if first else 0)
+        c1 = myc + (row0 + nrows) * 32 + (myc if last else 0)
+        return [(y0 * st, y1 * st), (c0 * sc, c1 * sc), (c0 * sc, c1 * sc)]
+
+    def bands_needed(self, b):
+        """Index of the last reference band that must have arrived before band b may start."""
+        row_end = (self.bands[b][0] + self.bands[b][1]) * 64 + self.lag
+        need = b
+        while need + 1 < len(self.bands) and self.bands[need + 1][0] * 64 < row_end:
+            need += 1
+        return need
+
+    def make_groups(self):
+        """Two process groups so that the traffic towards the next rank never queues behind the traffic from the previous one (with a
+        backend that serialises the operations of one communicator - NCCL / RCCL - and world == 2, both directions share one peer pair):
+        the hand-off rank r -> r + 1 uses group r % 2.  Collective call: every rank makes it once, after init_process_group."""
+        import torch.distributed as dist
+        self.groups = [dist.new_group(list(range(self.world))) for _ in range(2)] if self.world > 1 else [None, None]
+        return self.groups
+
+    def run_frame(self, step, geom, ref_planes, out_planes, process_band, total_frames=None, first_frame_is_local=True):
+        """One frame of this rank.  ref_planes: the flat Y / Cb / Cr tensors the previous frame's bands are received into (for the very
+        first frame of the job they already hold the start picture); out_planes: where process_band(b, row0, nrows) leaves this frame's
+        finished bands (not reused before the next call returns them: the sends of a frame are only waited for at the start of this
+        rank's next frame, or by finish()).  total_frames: frames of the whole job - the last frame has no consumer and is not sent."""
+        import torch.distributed as dist
+        f = self.frame_index(step)
+        nb = len(self.bands)
+        flat = lambda t: t.reshape(-1)
+        groups = getattr(self, "groups", [None, None])
+        g_in, g_out = groups[self.prev % 2], groups[self.rank % 2]
+        recv_from_peer = self.world > 1 and not (f == 0 and first_frame_is_local)
+        send_to_peer = self.world > 1 and (total_frames is None or f + 1 < total_frames)
+        self.finish()                                       # the previous frame's sends must be through before out_planes is rewritten
+        posted, arrived = -1, -1
+        pending = {}
+        for b, (row0, n) in enumerate(self.bands):
+            need = self.bands_needed(b) if recv_from_peer else -1
+            while posted < need:                            # receives are posted in band order, just ahead of the band that needs them
+                posted += 1
+                r0, rn = self.bands[posted]
+                pending[posted] = [dist.irecv(flat(p)[a:z], src=self.prev, group=g_in)
+                                   for p, (a, z) in zip(ref_planes, self._rows(geom, r0, rn, posted == 0, posted == nb - 1))]
+            while arrived < need:
+                arrived += 1
+                for w in pending.pop(arrived):
+                    w.wait()
+            process_band(b, row0, n)
+            if send_to_peer:
+                self._sends += [dist.isend(flat(p)[a:z], dst=self.next, group=g_out)
+                                for p, (a, z) in zip(out_planes, self._rows(geom, row0, n, b == 0, b == nb - 1))]
+        if recv_from_peer:                                  # bands below the last search window still belong to the reference picture
+            while posted < nb - 1:
+                posted += 1
+                r0, rn = self.bands[posted]
+                pending[posted] = [dist.irecv(flat(p)[a:z], src=self.prev, group=g_in)
+                                   for p, (a, z) in zip(ref_planes, self._rows(geom, r0, rn, posted == 0, posted == nb - 1))]
+            for b in sorted(pending):
+                for w in pending[b]:
+                    w.wait()
+
+    def finish(self):
+        for w in self._sends:
+            w.wait()
+        self._sends = []

@@ -115,6 +115,24 @@ class InterReconChroma:
         hipabi.check(f(ctypes.byref(p), s), "x265hip_inter_recon_chroma")
 
 
+def extend_border_rows(plane, pic: DevicePicture, top: bool, bottom: bool, stream=None, chroma=False):
+    """Row-wise border extension of the band `pic` is a view of (x265hip_extend_border_rows): left / right margins of the band's rows, the
+    picture's top margin when the band is its first, the bottom margin when it is its last."""
+    from . import frames as F
+    es = 1 if pic.depth == 8 else 2
+    s = hipabi.current_stream() if stream is None else stream
+    f = hipabi.lib().x265hip_extend_border_rows
+    f.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t] + [ctypes.c_int] * 6 + [ctypes.c_void_p]
+    if chroma:
+        my = F.CHROMA_MARGIN_Y
+        hipabi.check(f(plane.data_ptr() + pic.org_c * es, pic.stride_c, pic.w64 // 2, pic.h64 // 2, F.CHROMA_MARGIN_X, my if top else 0, my if bottom else 0,
+                       pic.depth, s), "x265hip_extend_border_rows")
+        return
+    my = F.MARGIN_Y
+    hipabi.check(f(plane.data_ptr() + pic.org * es, pic.stride, pic.w64, pic.h64, F.MARGIN_X, my if top else 0, my if bottom else 0, pic.depth, s),
+                 "x265hip_extend_border_rows")
+
+
 def extend_border(plane, pic: DevicePicture, stream=None, chroma=False):
     """Replicate the picture edges into the margins of `plane` (same geometry as `pic`; chroma: one of its 4:2:0 planes), on device."""
     from . import frames as F
@@ -479,6 +497,8 @@ class FramePipeline:
         # SAO applied in the loop: the parameters come from x265hip_sao_decide (initial offsets + distortion-only choice), so the
         # picture handed to the next frame is deblocked AND offset like a decoder's
         self.sao_apply = bool(sao and sao_apply)
+        # band mode (BandedFramePipeline): (is_first_band, is_last_band) -> row-wise border extension instead of the whole-picture one
+        self.band_border = None
 
     def run(self, cur: DevicePicture, ref: DevicePicture, mark=None):
         """ref: the current reference picture (extended borders; with chroma=True also its Cb / Cr planes); returns the luma plane of
@@ -548,10 +568,17 @@ class FramePipeline:
                         self.sao_c[i].apply(self.recon_c[i], cur.stride_c, cur.org_c, self.out_c[i])
                     final_c = self.out_c
                 mark("sao_apply")
-        extend_border(final, cur)
-        if self.chroma:
-            for i in range(2):
-                extend_border(final_c[i], cur, chroma=True)
+        if self.band_border is not None:
+            top, bottom = self.band_border
+            extend_border_rows(final, cur, top, bottom)
+            if self.chroma:
+                for i in range(2):
+                    extend_border_rows(final_c[i], cur, top, bottom, chroma=True)
+        else:
+            extend_border(final, cur)
+            if self.chroma:
+                for i in range(2):
+                    extend_border(final_c[i], cur, chroma=True)
         mark("border")
         self.final, self.final_c = final, final_c
         return final
@@ -604,3 +631,61 @@ class FramePipeline:
         if self.sao_apply:
             out["sao_types"] = int((self.sao.params.view(-1, 7)[:, 0] >= 0).sum().item())
         return out
+
+
+class BandedFramePipeline:
+    """The frame pipeline band by band - the reference's `--slices` picture: bands of `band_rows` CTU rows, each searched, reconstructed
+    and loop-filtered as a slice of its own (deblocking and SAO stop at the band boundary like the reference's slices: m_cuAbove is NULL
+    for the first row of a slice, cudata.cpp:319; SAO's firstRowInSlice / lastRowInSlice, sao.cpp:286-287), while the exhaustive search,
+    sub-pel refinement and prediction read the whole reference picture around the band.  A finished band (filtered, side margins
+    extended) can be handed to the rank that searches it next while the following bands are still in flight - the granularity of the
+    reference's m_reconRowFlag (framefilter.cpp:664).  band_ready(b, row0, rows), if given, is called after band b's launches."""
+
+    def __init__(self, w64, h64, depth, device, band_rows=4, lookahead=None, **kw):
+        self.w64, self.h64, self.depth, self.device = w64, h64, depth, device
+        rows = h64 // 64
+        self.bands = [(r, min(band_rows, rows - r)) for r in range(0, rows, band_rows)]
+        kw.pop("lookahead_cost_batch", None)
+        self.pipes = {n: FramePipeline(w64, n * 64, depth, device, lookahead=None, **kw) for n in sorted({n for _, n in self.bands})}
+        self.la = Lookahead(lookahead[0], lookahead[1], depth, device) if lookahead else None
+        self.planes = None          # [Y, Cb, Cr] the bands are written into: reconstruction and filtered picture
+        self.chroma = bool(kw.get("chroma"))
+        self.sao_apply = bool(kw.get("sao") and kw.get("sao_apply"))
+
+    def _alloc(self, cur):
+        import torch
+        if self.planes is None:
+            self.recon = [torch.zeros_like(p) for p in cur.planes()]
+            self.final = [torch.zeros_like(p) for p in cur.planes()] if self.sao_apply else self.recon
+        for pipe in self.pipes.values():
+            pipe.recon = self.recon[0]
+            pipe.recon_c = self.recon[1:3] if self.chroma else None
+            if self.sao_apply:
+                pipe.out = self.final[0]
+                pipe.out_c = self.final[1:3] if self.chroma else None
+        self.planes = self.final
+
+    def begin_frame(self, cur):
+        """Per-frame work that does not depend on the reference: output planes, the lookahead stage of the source picture."""
+        self._alloc(cur)
+        if self.la is not None:
+            self.la.run(cur)
+
+    def run_band(self, b, cur, ref):
+        row0, n = self.bands[b]
+        pipe = self.pipes[n]
+        pipe.band_border = (b == 0, b == len(self.bands) - 1)
+        pipe.run(cur.band_view(row0, n), ref.band_view(row0, n))
+
+    def run(self, cur, ref, band_ready=None, before_band=None):
+        self.begin_frame(cur)
+        for b, (row0, n) in enumerate(self.bands):
+            if before_band is not None:
+                before_band(b, row0, n)                     # e.g. wait until the reference rows this band reads have arrived
+            self.run_band(b, cur, ref)
+            if band_ready is not None:
+                band_ready(b, row0, n)
+        return self.planes[0]
+
+    def final_planes(self):
+        return list(self.planes)
