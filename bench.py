@@ -233,8 +233,8 @@ def load_traffic(width, height, rng_r, fmt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)       # ~0.5 s of timed region at 4K (round 1 timed 46 ms: too short for the driver's sampler)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=3840)      # BASELINE metric: "4K preset=slow" = configs[2]
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--range", type=int, default=57)          # reference default merange (param.cpp:198)
