@@ -293,7 +293,9 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        import datetime
+        # a hand-off that never completes must fail the run within minutes, not hold the node until the driver's limit
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=240))
 
     F = importlib.import_module("x265-yuuki-asuna_amd.frames")
     P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")

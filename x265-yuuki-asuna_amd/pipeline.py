@@ -259,7 +259,9 @@ class FrameParallelRing:
         backend that serialises the operations of one communicator - NCCL / RCCL - and world == 2, both directions share one peer pair):
         the hand-off rank r -> r + 1 uses group r % 2.  Collective call: every rank makes it once, after init_process_group."""
         import torch.distributed as dist
-        self.groups = [dist.new_group(list(range(self.world))) for _ in range(2)] if self.world > 1 else [None, None]
+        import datetime
+        self.groups = ([dist.new_group(list(range(self.world)), timeout=datetime.timedelta(seconds=240)) for _ in range(2)]
+                       if self.world > 1 else [None, None])
         return self.groups
 
     def run_frame(self, step, geom, ref_planes, out_planes, process_band, total_frames=None, first_frame_is_local=True):
