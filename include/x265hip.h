@@ -51,6 +51,15 @@ int         x265hip_init(int device);          /* device >= 0: validate (gfx950)
 int x265hip_setup_primitives(void* table, size_t table_bytes, int depth);
 /* Number of table calls served by the GPU since init (to prove stubs really ran). */
 uint64_t x265hip_table_calls(void);
+/* Error policy of the table layer (the reference's slot signatures cannot report an error).  X265HIP_ON_ERROR_ABORT (default): a HIP
+ * failure inside a stub aborts loudly.  X265HIP_ON_ERROR_RESTORE_HOST: the first failure is reported once on stderr, that call and every
+ * later call of every GPU-backed slot are answered by the function the HOST had in the slot before x265hip_setup_primitives (its own
+ * C / asm primitive, never code of this library); x265hip_table_failures() counts the failed calls. */
+#define X265HIP_ON_ERROR_ABORT        0
+#define X265HIP_ON_ERROR_RESTORE_HOST 1
+int         x265hip_set_error_policy(int policy);
+uint64_t    x265hip_table_failures(void);
+void        x265hip_table_inject_failure(long n);   /* test hook: the n-th stub call from now fails */
 /* the table layer keeps a stream + pinned / device staging per calling host thread, released when that thread exits */
 void        x265hip_table_stage_counts(uint64_t* created, uint64_t* released);
 

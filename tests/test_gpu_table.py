@@ -79,3 +79,37 @@ def test_whole_plane_weight_pp_on_a_fresh_thread(depth, repo_root):
         t.start(); t.join()
     assert not errs and len(outs) == 2
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_error_policy_restore_host_hands_the_slots_back(repo_root):
+    """X265HIP_ON_ERROR_RESTORE_HOST: a failing stub (test hook: the 3rd call) is reported, that call and every later one are answered
+    by the function the HOST had in the slot (here a sentinel table whose sad returns a recognisable value), nothing aborts; the
+    default policy stays 'abort'."""
+    import numpy as np
+    L = A.lib()
+    L.x265hip_table_failures.restype = ctypes.c_uint64
+    L.x265hip_table_inject_failure.argtypes = [ctypes.c_long]
+    orc = H.load_oracle(8, repo_root)
+    hip, _ = load_hip_table(8, base=orc)                      # the host's own table first, GPU slots on top
+    rng = np.random.default_rng(5)
+    a, b = H.pixels(rng, "random", 8, 16, 16, 64), H.pixels(rng, "random", 8, 16, 16, 48)
+    want = orc.fn("pu[2].sad")(a.p, a.stride, b.p, b.stride)
+    f = hip.fn("pu[2].sad")
+    assert f(a.p, a.stride, b.p, b.stride) == want            # through the GPU
+    try:
+        assert L.x265hip_set_error_policy(1) == 0
+        fails0, calls0 = L.x265hip_table_failures(), L.x265hip_table_calls()
+        L.x265hip_table_inject_failure(3)
+        got = [f(a.p, a.stride, b.p, b.stride) for _ in range(6)]
+        assert got == [want] * 6                              # identical answers: GPU, GPU, host (failed call), host, host, host
+        assert L.x265hip_table_failures() == fails0 + 1
+        assert L.x265hip_table_calls() == calls0 + 3          # calls 4..6 never reached a stub
+        sx = hip.fn("pu[2].sad_x3")                           # every other GPU-backed slot is handed back as well
+        res = (ctypes.c_int32 * 3)()
+        sx(a.p, b.p, b.p + 1, b.p + 2, b.stride, res)
+        assert res[0] == want and L.x265hip_table_calls() == calls0 + 3
+    finally:
+        L.x265hip_table_inject_failure(0)                     # clears the failed state
+        L.x265hip_set_error_policy(0)
+    assert f(a.p, a.stride, b.p, b.stride) == want and L.x265hip_table_calls() > calls0 + 3
+    assert L.x265hip_set_error_policy(7) < 0

@@ -3,7 +3,8 @@
 // (SURVEY.md section 8b "Threading"), so each host thread owns a stream, a pinned host buffer and a
 // device buffer with the same layout: operands are packed into the pinned buffer, shipped with one
 // H2D copy, the batch-layer kernel runs on them (batch of one), results come back with one D2H copy.
-// No error can be returned through the reference's signatures: any HIP failure aborts loudly.
+// No error can be returned through the reference's signatures: any HIP failure aborts loudly - or, if the host opted in, hands the
+// slots back to the host's own functions (see the error policy below).
 #pragma once
 
 #include "common.h"
@@ -17,6 +18,17 @@ namespace x265hip {
 
 extern std::atomic<uint64_t> g_tableCalls;
 extern std::atomic<uint64_t> g_stagesCreated, g_stagesReleased;
+
+// Error policy of the table layer.  The reference's slot signatures cannot return an error, so by default any HIP failure inside a stub
+// aborts loudly.  A host may opt in to X265HIP_ON_ERROR_RESTORE_HOST (x265hip_set_error_policy): the first failure is reported loudly
+// once, the failing call and every later call of every GPU-backed slot are answered by the function the HOST had in that slot before
+// x265hip_setup_primitives overwrote it (its own C / asm primitive - never code of this library), and x265hip_table_failures() counts.
+extern std::atomic<int> g_errorPolicy;          // X265HIP_ON_ERROR_*
+extern std::atomic<bool> g_tableFailed;
+extern std::atomic<uint64_t> g_tableFailures;
+extern std::atomic<long> g_injectFailureAt;     // test hook: the n-th stub call from now fails (0 = off)
+struct StubFailure { };
+[[noreturn]] void stub_failure(const char* what, const char* detail);
 
 struct ThreadStage
 {
@@ -43,16 +55,12 @@ struct ThreadStage
     ThreadStage(const ThreadStage&) = delete;
     ThreadStage& operator=(const ThreadStage&) = delete;
 
-    static void die(const char* what, hipError_t e)
-    {
-        fprintf(stderr, "libx265hip: fatal in primitive stub: %s: %s (no CPU fallback)\n", what, hipGetErrorString(e));
-        abort();
-    }
+    static void die(const char* what, hipError_t e) { stub_failure(what, hipGetErrorString(e)); }
     void ensure(size_t need)
     {
         if (!stream)
         {
-            if (ensure_device()) { fprintf(stderr, "libx265hip: %s\n", x265hip_last_error()); abort(); }
+            if (ensure_device()) stub_failure("device", x265hip_last_error());
             hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
             if (e != hipSuccess) die("hipStreamCreate", e);
             g_stagesCreated.fetch_add(1, std::memory_order_relaxed);
@@ -70,7 +78,14 @@ struct ThreadStage
         if (dev) (void)hipFree(dev);
         host = nh; dev = nd; cap = ncap;
     }
-    void begin() { used = 0; inBytes = 0; g_tableCalls.fetch_add(1, std::memory_order_relaxed); ensure(1 << 16); }
+    void begin()
+    {
+        used = 0; inBytes = 0;
+        g_tableCalls.fetch_add(1, std::memory_order_relaxed);
+        if (g_injectFailureAt.load(std::memory_order_relaxed) > 0 && g_injectFailureAt.fetch_sub(1) == 1)
+            stub_failure("injected", "test hook x265hip_table_inject_failure");
+        ensure(1 << 16);
+    }
     size_t alloc(size_t bytes)
     {
         size_t off = (used + 63) & ~(size_t)63;
@@ -121,7 +136,7 @@ struct ThreadStage
     template <typename T> T* hptr(size_t off) const { return reinterpret_cast<T*>(host + off); }
     void require(int rc, const char* what)
     {
-        if (rc) { fprintf(stderr, "libx265hip: fatal in primitive stub %s: %s\n", what, x265hip_last_error()); abort(); }
+        if (rc) stub_failure(what, x265hip_last_error());
     }
 };
 

@@ -7,6 +7,23 @@ namespace x265hip {
 
 std::atomic<uint64_t> g_tableCalls{0};
 std::atomic<uint64_t> g_stagesCreated{0}, g_stagesReleased{0};
+std::atomic<int> g_errorPolicy{X265HIP_ON_ERROR_ABORT};
+std::atomic<bool> g_tableFailed{false};
+std::atomic<uint64_t> g_tableFailures{0};
+std::atomic<long> g_injectFailureAt{0};
+
+[[noreturn]] void stub_failure(const char* what, const char* detail)
+{
+    if (g_errorPolicy.load() == X265HIP_ON_ERROR_RESTORE_HOST)
+    {
+        if (!g_tableFailed.exchange(true))
+            fprintf(stderr, "libx265hip: primitive stub failed (%s: %s); every GPU-backed slot is handed back to the host's own primitives\n", what, detail);
+        g_tableFailures.fetch_add(1, std::memory_order_relaxed);
+        throw StubFailure();
+    }
+    fprintf(stderr, "libx265hip: fatal in primitive stub: %s: %s (no CPU fallback)\n", what, detail);
+    abort();
+}
 
 ThreadStage& thread_stage()
 {
@@ -43,6 +60,15 @@ extern "C" int x265hip_setup_primitives(void* table, size_t table_bytes, int dep
 }
 
 extern "C" uint64_t x265hip_table_calls(void) { return g_tableCalls.load(); }
+extern "C" int x265hip_set_error_policy(int policy)
+{
+    if (policy != X265HIP_ON_ERROR_ABORT && policy != X265HIP_ON_ERROR_RESTORE_HOST) { set_error("set_error_policy: %d", policy); return X265HIP_EINVAL; }
+    g_errorPolicy.store(policy);
+    return 0;
+}
+extern "C" uint64_t x265hip_table_failures(void) { return g_tableFailures.load(); }
+/* test hook: the n-th stub call from now behaves as if HIP had failed (n <= 0 switches it off); also clears the failed state */
+extern "C" void x265hip_table_inject_failure(long n) { g_tableFailed.store(false); g_injectFailureAt.store(n > 0 ? n : 0); }
 /* per-thread staging (stream + pinned + device buffer) of the table layer: how many host threads created one / gave it back at thread exit */
 extern "C" void x265hip_table_stage_counts(uint64_t* created, uint64_t* released)
 {

@@ -615,6 +615,25 @@ template <int W, int H> struct AdsN { static constexpr int v = 4; };
 ADSN(4,4,1) ADSN(8,8,1) ADSN(8,4,2) ADSN(4,8,2) ADSN(16,8,2) ADSN(8,16,2) ADSN(16,12,1) ADSN(12,16,1) ADSN(16,4,1) ADSN(4,16,1)
 ADSN(32,16,2) ADSN(16,32,2) ADSN(64,32,2) ADSN(32,64,2)
 
+// Every stub goes into the table behind a guard that remembers what the host had in the slot: under X265HIP_ON_ERROR_RESTORE_HOST a
+// failed stub (and, from then on, every stub) answers with the host's own function.  A slot the host left NULL has nothing to restore
+// to: its guard aborts like the default policy.
+template <auto Stub> struct Guard;
+template <typename R, typename... A, R (*Stub)(A...)> struct Guard<Stub>
+{
+    static inline R (*host)(A...) = nullptr;
+    static R call(A... a)
+    {
+        if (g_tableFailed.load(std::memory_order_relaxed) && host) return host(a...);
+        try { return Stub(a...); }
+        catch (const StubFailure&)
+        {
+            if (!host) { fprintf(stderr, "libx265hip: fatal: the failed slot has no host function to restore\n"); abort(); }
+            return host(a...);
+        }
+    }
+};
+
 } // namespace
 
 #define CAT_(a, b) a##b
@@ -623,7 +642,7 @@ ADSN(32,16,2) ADSN(16,32,2) ADSN(64,32,2) ADSN(32,64,2)
 int CAT(setup_primitives_d, X265HIP_DEPTH)(x265hip_EncoderPrimitives* p)
 {
     int n = 0;
-#define SET(slot, fn) do { (slot) = (fn); n++; } while (0)
+#define SET(slot, fn) do { typedef Guard<&fn> G_; if ((slot) != &G_::call) G_::host = (slot); (slot) = &G_::call; n++; } while (0)
 #define SET2(slot, fn) do { SET((slot)[0], fn); SET((slot)[1], fn); } while (0)
 
 #define SET_PU(W, H) { auto& u = p->pu[X265HIP_LUMA_##W##x##H]; \
