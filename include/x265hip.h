@@ -154,12 +154,24 @@ int x265hip_subpel_refine(const x265hip_subpel_params* p, void* stream);
  *   intra_slice : flag bits - X265HIP_TU_INTRA_SLICE selects the I-slice rounding offset (171 instead of 85, quant.cpp:466),
  *             X265HIP_TU_SIGN_HIDE runs Quant::signBitHidingHDQ after the quantiser (quant.cpp:247-395, 471-476: the x265 default,
  *             pps.bSignHideEnabled; up-right diagonal scan for inter TUs, the mode-dependent scan for 4x4 / luma 8x8 intra TUs).
- *             Scaling lists, the denoiser and RDOQ (the host's rows a8 / a9) are not part of the fused stages.
+ *             Scaling lists and the denoiser come in through `tables`; RDOQ (the host's row a9) is not part of the fused stages.
  *   recon   : reconstructed luma plane, same geometry as fenc (margins are not written)
  *   levels  : int16 [ctu][blocks][N*N] quantised coefficients   num_sig : uint32 [ctu][blocks]
  *   dist    : uint64 [ctu][blocks] sse_pp(fenc, recon) */
 #define X265HIP_TU_INTRA_SLICE 1
 #define X265HIP_TU_SIGN_HIDE   2
+/* Optional per-coefficient tables of a TU stage launch (DEVICE pointers, n * n entries of the launch's transform size in raster order;
+ * any of them NULL = not used): the scaling list's quantiser / dequantiser coefficients the host selected for (size, list type, qp % 6)
+ * - ScalingList::m_quantCoef / m_dequantCoef, used by quant.cpp:463 and dequant_scaling (dct.cpp:612-662, quant.cpp:562-567) - and the
+ * denoiser's offsets with its running residual sums for the TU category (primitives.denoiseDct before the quantiser, quant.cpp:444-451,
+ * dct.cpp:744-755: nr_residual_sum[i] += |coef|, atomically).  A NULL `tables` pointer = flat lists, no denoising (the x265 defaults). */
+typedef struct x265hip_tu_tables
+{
+    const int32_t* quant_coeff;
+    const int32_t* dequant_coeff;
+    const uint16_t* nr_offset;
+    uint32_t* nr_residual_sum;
+} x265hip_tu_tables;
 typedef struct x265hip_recon_params
 {
     int depth;
@@ -171,6 +183,7 @@ typedef struct x265hip_recon_params
     void* recon;       intptr_t recon_stride;
     const void* mv;
     int16_t* levels; uint32_t* num_sig; uint64_t* dist;
+    const x265hip_tu_tables* tables;            /* HOST pointer to the table record, or NULL */
 } x265hip_recon_params;
 int x265hip_inter_recon(const x265hip_recon_params* p, void* stream);
 /* One chroma plane of the same stage for 4:2:0 pictures (Predict::predInterChromaPixel, predict.cpp:304-351, + the same residual
@@ -589,6 +602,7 @@ typedef struct x265hip_intra_recon_params
      * (useDST needs TEXT_LUMA, quant.cpp:426,583); fenc / nb / recon are the chroma plane's, n = 4..32, qp = the chroma QP the
      * host mapped (Quant::setChromaQP) + QP_BD_OFFSET */
     int chroma;
+    const x265hip_tu_tables* tables;            /* HOST pointer to the table record, or NULL */
 } x265hip_intra_recon_params;
 int x265hip_intra_recon_batch(const x265hip_intra_recon_params* p, void* stream);
 

@@ -17,6 +17,14 @@ _libs = {}
 TU_INTRA_SLICE, TU_SIGN_HIDE = 1, 2       # flag bits of the TU stages' `intra_slice` argument (x265hip.h: X265HIP_TU_*)
 
 
+def set_tu_tables(depth, quant_coeff=None, dequant_coeff=None, nr_offset=None, nr_sum=None, avx2=False):
+    """Scaling-list coefficients / denoiser tables for the oracle's TU stages (numpy arrays or None; kept alive by the caller).  Call with
+    no tables to switch back to flat lists."""
+    fn = getattr(lib(avx2), f"x265oracle_set_tu_tables_d{depth}")
+    fn.argtypes = [ctypes.c_void_p] * 4
+    fn(*[None if a is None else a.ctypes.data for a in (quant_coeff, dequant_coeff, nr_offset, nr_sum)])
+
+
 def host_has_avx2() -> bool:
     try:
         return " avx2 " in open("/proc/cpuinfo").read().replace("\n", " ")

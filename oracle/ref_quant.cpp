@@ -30,8 +30,26 @@ extern "C" {
  * device stages take).  intraCU: the CU's prediction mode (4x4 intra luma uses DST-VII); intraSlice: I slice (rounding 171 vs 85).
  * Outputs: levels int16 [njobs][n*n], numSig uint32 [njobs], resiOut int16 [njobs][n*n] (zero when numSig == 0, as the callers
  * skip the inverse transform then).  Returns 0 on success. */
+struct TuExtras          /* scaling lists / denoiser of the extended entry; all optional */
+{
+    int useScalingList;              /* HEVC default lists (ScalingList::setDefaultScalingList), m_bEnabled = true */
+    const uint16_t* nrOffset;        /* denoiser offsets for this TU category, n * n */
+    int32_t* quantCoefOut;           /* out: m_quantCoef[size][list][rem], n * n */
+    int32_t* dequantCoefOut;         /* out: m_dequantCoef[size][list][rem], n * n */
+    uint32_t* nrSumOut;              /* out: the category's residual sums after the jobs, n * n */
+};
 static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intraCU, int intraSlice, int njobs,
-                             int16_t* levels, uint32_t* numSig, int16_t* resiOut, TextType ttype, int signHide = 0, int intraDir = 1);
+                             int16_t* levels, uint32_t* numSig, int16_t* resiOut, TextType ttype, int signHide = 0, int intraDir = 1,
+                             const TuExtras* ex = NULL);
+
+/* + scaling lists (Quant::transformNxN :463 / invtransformNxN :562-567 with dequant_scaling) and the denoiser (:444-451) */
+int x265ref_tu_roundtrip_ex2(const int16_t* resi, int n, int qpScaled, int intraCU, int intraSlice, int signHide, int intraDir, int chroma,
+                             int useScalingList, const uint16_t* nrOffset, int njobs, int16_t* levels, uint32_t* numSig, int16_t* resiOut,
+                             int32_t* quantCoefOut, int32_t* dequantCoefOut, uint32_t* nrSumOut)
+{
+    TuExtras ex = { useScalingList, nrOffset, quantCoefOut, dequantCoefOut, nrSumOut };
+    return tu_roundtrip_core(resi, n, qpScaled, intraCU, intraSlice, njobs, levels, numSig, resiOut, chroma ? TEXT_CHROMA_U : TEXT_LUMA, signHide, intraDir, &ex);
+}
 
 /* the x265 default: pps.bSignHideEnabled = 1 (Quant::signBitHidingHDQ after the quantiser, quant.cpp:471-476).  intraDir is the
  * intra direction the TU's scan order depends on (CUData::getTUEntropyCodingParameters, cudata.cpp:2067-2089); chroma != 0 runs
@@ -57,7 +75,7 @@ int x265ref_tu_roundtrip_chroma(const int16_t* resi, int n, int qpScaled, int in
 }
 
 static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intraCU, int intraSlice, int njobs,
-                             int16_t* levels, uint32_t* numSig, int16_t* resiOut, TextType ttype, int signHide, int intraDir)
+                             int16_t* levels, uint32_t* numSig, int16_t* resiOut, TextType ttype, int signHide, int intraDir, const TuExtras* ex)
 {
     static bool tableReady = false;
     if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
@@ -67,7 +85,8 @@ static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intra
     x265_param_default(param);
     param->sourceWidth = 64;
     param->sourceHeight = 64;
-    param->internalCsp = (signHide && ttype != TEXT_LUMA) ? X265_CSP_I420 : X265_CSP_I400;   /* the chroma scan rule reads m_hChromaShift */
+    param->internalCsp = ((signHide || ex) && ttype != TEXT_LUMA) ? X265_CSP_I420 : X265_CSP_I400;   /* the chroma scan rule reads m_hChromaShift */
+    param->frameNumThreads = 1;                     /* Quant::init allocates one NoiseReduction per frame encoder */
     param->maxCUSize = 64;
     param->minCUSize = 8;
     param->maxLog2CUSize = 6;
@@ -93,6 +112,7 @@ static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intra
     slice.m_param = param;
     slice.m_sliceType = intraSlice ? I_SLICE : P_SLICE;
     encData.m_param = param;
+    encData.m_frameEncoderID = 0;
     encData.m_slice = &slice;
     CUData ctu;
     encData.m_picCTU = &ctu;
@@ -111,14 +131,33 @@ static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intra
     ScalingList scalingList;
     if (!scalingList.init()) return -3;
     scalingList.m_bEnabled = false;
+    if (ex && ex->useScalingList)
+    {
+        scalingList.setDefaultScalingList();
+        scalingList.m_bEnabled = true;
+    }
     scalingList.setupQuantMatrices(param->internalCsp);
     Entropy entropy;
     QuantProbe quant;
     if (!quant.init(0.0, scalingList, entropy)) return -4;
+    if (ex && ex->nrOffset && !quant.allocNoiseReduction(*param)) return -5;
     quant.setQPforQuant(ctu, qpScaled - QP_BD_OFFSET);
     if (ttype != TEXT_LUMA)          /* the I400 CTU above leaves the chroma QPs unset; chFmt 4:4:4 = no mapping table: the caller passes the mapped QP */
         quant.setChromaQP(qpScaled - QP_BD_OFFSET, ttype, X265_CSP_I444);
 
+    const int sizeIdx = log2n - 2, listType = (intraCU ? 0 : 3) + (int)ttype, rem = qpScaled % 6;
+    const int cat = sizeIdx + 4 * (ttype != TEXT_LUMA) + 8 * !intraCU;              /* quant.cpp:447 */
+    if (ex)
+    {
+        if (ex->quantCoefOut) memcpy(ex->quantCoefOut, scalingList.m_quantCoef[sizeIdx][listType][rem], sizeof(int32_t) * n * n);
+        if (ex->dequantCoefOut) memcpy(ex->dequantCoefOut, scalingList.m_dequantCoef[sizeIdx][listType][rem], sizeof(int32_t) * n * n);
+        if (ex->nrOffset && quant.m_nr)
+        {
+            NoiseReduction* nr = quant.m_nr;
+            nr->offset = nr->nrOffsetDenoise; nr->residualSum = nr->nrResidualSum; nr->count = nr->nrCount;
+            memcpy(nr->nrOffsetDenoise[cat], ex->nrOffset, sizeof(uint16_t) * n * n);
+        }
+    }
     std::vector<pixel> fencDummy(n * n, 0);
     for (int j = 0; j < njobs; j++)
     {
@@ -129,6 +168,7 @@ static int tu_roundtrip_core(const int16_t* resi, int n, int qpScaled, int intra
         memset(out, 0, sizeof(int16_t) * n * n);
         if (ns) quant.invtransformNxN(ctu, out, n, lv, log2n, ttype, !!intraCU, false, ns);
     }
+    if (ex && ex->nrSumOut && ex->nrOffset && quant.m_nr) memcpy(ex->nrSumOut, quant.m_nr->nrResidualSum[cat], sizeof(uint32_t) * n * n);
     frame.m_encData = NULL;
     encData.m_picCTU = NULL; encData.m_slice = NULL;
     pool.destroy();

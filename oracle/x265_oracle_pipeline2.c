@@ -130,6 +130,33 @@ static uint32_t sign_hide(int16_t* level, const int32_t* deltaU, const int16_t* 
     return numSig;
 }
 
+/* ---- optional per-coefficient tables of the TU stages (x265hip_tu_tables): the scaling list's quantiser / dequantiser coefficients
+ * (quant.cpp:463, :562-567 with dequant_scaling, dct.cpp:612-662) and the denoiser (primitives.denoiseDct before the quantiser,
+ * quant.cpp:444-451, dct.cpp:744-755).  Test infrastructure: set once per test, read by the four recon functions below. */
+static const int32_t* g_tabQuant; static const int32_t* g_tabDequant; static const uint16_t* g_tabNrOffset; static uint32_t* g_tabNrSum;
+void EXPORT(x265oracle_set_tu_tables)(const int32_t* quantCoeff, const int32_t* dequantCoeff, const uint16_t* nrOffset, uint32_t* nrSum)
+{
+    g_tabQuant = quantCoeff; g_tabDequant = dequantCoeff; g_tabNrOffset = nrOffset; g_tabNrSum = nrSum;
+}
+static void tab_denoise(int16_t* coef, int num)          /* denoiseDct with the sums added atomically (the callers run CTUs in parallel) */
+{
+    if (!g_tabNrOffset) return;
+    for (int i = 0; i < num; i++)
+    {
+        int level = coef[i];
+        const int sign = level >> 31;
+        level = (level + sign) ^ sign;
+        __atomic_fetch_add(&g_tabNrSum[i], (uint32_t)level, __ATOMIC_RELAXED);
+        level -= g_tabNrOffset[i];
+        coef[i] = (int16_t)(level < 0 ? 0 : (level ^ sign) - sign);
+    }
+}
+static void tab_dequant(const x265hip_EncoderPrimitives* prim, const int16_t* q, int16_t* coef, int num, int per, int dqScale, int dqShift)
+{
+    if (g_tabDequant) prim->dequant_scaling(q, g_tabDequant, coef, num, per, dqShift);
+    else prim->dequant_normal(q, coef, num, dqScale, dqShift);
+}
+
 int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const pixel* fref, intptr_t frefStride,
                                    pixel* recon, intptr_t reconStride, int width, int height, int level,
                                    const int32_t* mv, int qp, int flags,
@@ -163,7 +190,7 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
         int16_t coef[32 * 32] __attribute__((aligned(64)));
         int32_t quantCoeff[32 * 32] __attribute__((aligned(64)));
         int32_t deltaU[32 * 32];
-        for (int i = 0; i < n * n; i++) quantCoeff[i] = kQuantScales[rem];
+        for (int i = 0; i < n * n; i++) quantCoeff[i] = g_tabQuant ? g_tabQuant[i] : kQuantScales[rem];
         for (int z = 0; z < npu; z++)
         {
             int bx, by;
@@ -183,13 +210,14 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
             /* residual, transform, quantisation */
             cu->sub_ps(resi, 64, fe, pred, fencStride, 64);
             cu->dct(resi, coef, 64);
+            tab_denoise(coef, n * n);
             int16_t* q = levels + ((size_t)ctu * npu + z) * n * n;
             uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
             if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, ORACLE_SCAN_DIAG, log2n);
             numSigOut[(size_t)ctu * npu + z] = numSig;
             if (numSig)
             {
-                prim.dequant_normal(q, coef, n * n, dqScale, dqShift);
+                tab_dequant(&prim, q, coef, n * n, per, dqScale, dqShift);
                 if (numSig == 1 && q[0] != 0)
                 {
                     const int shift_2nd = 12 - (X265HIP_DEPTH - 8) - 3;
@@ -246,7 +274,7 @@ int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, co
         int16_t coef[32 * 32] __attribute__((aligned(64)));
         int32_t quantCoeff[32 * 32] __attribute__((aligned(64)));
         int32_t deltaU[32 * 32];
-        for (int i = 0; i < n * n; i++) quantCoeff[i] = kQuantScales[rem];
+        for (int i = 0; i < n * n; i++) quantCoeff[i] = g_tabQuant ? g_tabQuant[i] : kQuantScales[rem];
         for (int z = 0; z < npu; z++)
         {
             int bx, by;
@@ -286,13 +314,14 @@ int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, co
             if (d == 3) pu->addAvg[0](ps[0], ps[1], pred, 64, 64, 64);
             cu->sub_ps(resi, 64, fe, pred, fencStride, 64);
             cu->dct(resi, coef, 64);
+            tab_denoise(coef, n * n);
             int16_t* q = levels + ((size_t)ctu * npu + z) * n * n;
             uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
             if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, ORACLE_SCAN_DIAG, log2n);
             numSigOut[(size_t)ctu * npu + z] = numSig;
             if (numSig)
             {
-                prim.dequant_normal(q, coef, n * n, dqScale, dqShift);
+                tab_dequant(&prim, q, coef, n * n, per, dqScale, dqShift);
                 if (numSig == 1 && q[0] != 0)
                 {
                     const int shift_2nd = 12 - (X265HIP_DEPTH - 8) - 3;
@@ -348,7 +377,7 @@ int EXPORT(x265oracle_inter_recon_chroma)(const pixel* fenc, intptr_t fencStride
         int16_t immed[32 * (32 + 3)] __attribute__((aligned(64)));
         int32_t quantCoeff[16 * 16] __attribute__((aligned(64)));
         int32_t deltaU[16 * 16];
-        for (int i = 0; i < nc * nc; i++) quantCoeff[i] = kQuantScales[rem];
+        for (int i = 0; i < nc * nc; i++) quantCoeff[i] = g_tabQuant ? g_tabQuant[i] : kQuantScales[rem];
         for (int z = 0; z < npu; z++)
         {
             int bx, by;
@@ -370,13 +399,14 @@ int EXPORT(x265oracle_inter_recon_chroma)(const pixel* fenc, intptr_t fencStride
             }
             cu->sub_ps(resi, 32, fe, pred, fencStride, 32);
             cu->dct(resi, coef, 32);
+            tab_denoise(coef, nc * nc);
             int16_t* q = levels + ((size_t)ctu * npu + z) * nc * nc;
             uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, nc * nc);
             if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, ORACLE_SCAN_DIAG, log2nc);
             numSigOut[(size_t)ctu * npu + z] = numSig;
             if (numSig)
             {
-                prim.dequant_normal(q, coef, nc * nc, dqScale, dqShift);
+                tab_dequant(&prim, q, coef, nc * nc, per, dqScale, dqShift);
                 if (numSig == 1 && q[0] != 0)
                 {
                     const int shift_2nd = 12 - (X265HIP_DEPTH - 8) - 3;
@@ -460,7 +490,7 @@ static int intra_recon_core(const pixel* fenc, intptr_t fencStride, const pixel*
         int16_t coef[32 * 32] __attribute__((aligned(64)));
         int32_t quantCoeff[32 * 32] __attribute__((aligned(64)));
         int32_t deltaU[32 * 32];
-        for (int i = 0; i < n * n; i++) quantCoeff[i] = kQuantScales[rem];
+        for (int i = 0; i < n * n; i++) quantCoeff[i] = g_tabQuant ? g_tabQuant[i] : kQuantScales[rem];
         const intra_job* jb = &jobs[j];
         const int mode = jb->arg[0];
         const pixel* fe = fenc + jb->off[0];
@@ -472,13 +502,14 @@ static int intra_recon_core(const pixel* fenc, intptr_t fencStride, const pixel*
             for (int x = 0; x < n; x++) resi[y * n + x] = (int16_t)((int)fe[y * fencStride + x] - (int)pred[y * n + x]);
         if (useDST) prim.dst4x4(resi, coef, n);
         else cu->dct(resi, coef, n);
+        tab_denoise(coef, n * n);
         int16_t* q = levels + (size_t)j * n * n;
         uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
         if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, intra_scan_type(mode, n, chroma), log2n);
         numSigOut[j] = numSig;
         if (numSig)
         {
-            prim.dequant_normal(q, coef, n * n, dqScale, dqShift);
+            tab_dequant(&prim, q, coef, n * n, per, dqScale, dqShift);
             if (numSig == 1 && q[0] != 0 && !useDST)
             {
                 const int shift_2nd = 12 - (X265HIP_DEPTH - 8) - 3;

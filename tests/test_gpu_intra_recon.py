@@ -43,6 +43,20 @@ def _smooth(a):
                                                (10, 32, 30, 2), (12, 16, 33, 3)])
 @pytest.mark.parametrize("chroma", [False, True])
 def test_intra_recon_matches_oracle(depth, n, qp, islice, chroma):
+    _run(depth, n, qp, islice, chroma, False)
+
+
+QUANT_SCALES, INV_QUANT_SCALES = (26214, 23302, 20560, 18396, 16384, 14564), (40, 45, 51, 57, 64, 72)      # scalinglist.cpp:129-130
+
+
+@pytest.mark.parametrize("depth,n,qp,islice", [(8, 4, 22, 3), (8, 8, 27, 2), (8, 16, 30, 1), (8, 32, 24, 3), (10, 8, 30, 2), (10, 32, 33, 3), (12, 16, 40, 2)])
+@pytest.mark.parametrize("chroma", [False, True])
+def test_intra_recon_with_scaling_lists_and_denoiser(depth, n, qp, islice, chroma):
+    """x265hip_tu_tables in the intra candidate stage (scaling-list coefficient tables + the denoiser's offsets and running sums)."""
+    _run(depth, n, qp, islice, chroma, True)
+
+
+def _run(depth, n, qp, islice, chroma, tabs):
     """chroma: the 4:2:0 chroma flavour (predIntraChromaAng: unfiltered neighbours, bFilter 0; DCT for 4x4 - the oracle side of both
     flavours is pinned against the real Quant / the table primitive in tests/test_oracle_classes_vs_reference.py)."""
     import torch
@@ -78,7 +92,19 @@ def test_intra_recon_matches_oracle(depth, n, qp, islice, chroma):
     njobs = len(jobs)
     recon_len = njobs * n * recon_stride
     O = _oracle()
-    erec, elev, ens, edist = O.intra_recon(depth, n, fenc.reshape(-1), fenc_stride, nb.reshape(-1), recon_len, recon_stride, qp, islice, jobs, chroma=chroma)
+    rec = d_sum = osum = None
+    if tabs:
+        m = rng.integers(8, 64, size=n * n)
+        qc, dqc = ((QUANT_SCALES[qp % 6] << 4) // m).astype(np.int32), (INV_QUANT_SCALES[qp % 6] * m).astype(np.int32)
+        off = rng.integers(0, 5 << (depth - 8), size=n * n).astype(np.uint16)
+        osum = np.zeros(n * n, np.uint32)
+        d_sum = torch.zeros(n * n, dtype=torch.int32, device=dev)
+        rec = H.tu_tables(torch.from_numpy(qc).to(dev), torch.from_numpy(dqc).to(dev), torch.from_numpy(off.view(np.int16)).to(dev), d_sum)
+        O.set_tu_tables(depth, qc, dqc, off, osum)
+    try:
+        erec, elev, ens, edist = O.intra_recon(depth, n, fenc.reshape(-1), fenc_stride, nb.reshape(-1), recon_len, recon_stride, qp, islice, jobs, chroma=chroma)
+    finally:
+        O.set_tu_tables(depth)
 
     d_fenc = torch.from_numpy(fenc.reshape(-1).view(np.uint8)).to(dev)
     d_nb = torch.from_numpy(nb.reshape(-1).view(np.uint8)).to(dev)
@@ -87,8 +113,12 @@ def test_intra_recon_matches_oracle(depth, n, qp, islice, chroma):
     d_lev = torch.full((njobs * n * n,), 0x5a5a, dtype=torch.int16, device=dev)
     d_ns = torch.zeros(njobs, dtype=torch.int32, device=dev)
     d_dist = torch.zeros(njobs, dtype=torch.int64, device=dev)
-    H.intra_recon_batch(depth, n, d_fenc, fenc_stride, d_nb, d_rec, recon_stride, qp, islice, d_jobs, njobs, d_lev, d_ns, d_dist, chroma=chroma)
+    H.intra_recon_batch(depth, n, d_fenc, fenc_stride, d_nb, d_rec, recon_stride, qp, islice, d_jobs, njobs, d_lev, d_ns, d_dist, chroma=chroma, tables=rec)
     torch.cuda.synchronize()
+    if tabs:
+        assert np.array_equal(d_sum.cpu().numpy().view(np.uint32), osum) and osum.sum() > 0, "denoiser residual sums differ"
+        flat = O.intra_recon(depth, n, fenc.reshape(-1), fenc_stride, nb.reshape(-1), recon_len, recon_stride, qp, islice, jobs, chroma=chroma)[1]
+        assert not np.array_equal(flat, elev), "the tables changed nothing"
     assert np.array_equal(d_ns.cpu().numpy().view(np.uint32), ens), "numSig differs"
     assert np.array_equal(d_lev.cpu().numpy(), elev), "quantised levels differ"
     grec = d_rec.cpu().numpy().view(dt)

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 F = importlib.import_module("x265-yuuki-asuna_amd.frames")
 P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
 S = importlib.import_module("x265-yuuki-asuna_amd.stages")
+A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
 
 
 def _oracle():
@@ -142,3 +143,80 @@ def test_inter_recon_bi_matches_oracle(depth, level, qp):
     assert np.array_equal(recon.cpu().numpy().view(cur.host.dtype).reshape(-1), erec.reshape(-1)), "reconstruction differs"
     assert np.array_equal(st.dist.cpu().numpy().view(np.uint64), edist), "SSE differs"
     assert (dirs == 3).any() and (dirs == 1).any() and (dirs == 2).any()
+
+
+QUANT_SCALES, INV_QUANT_SCALES = (26214, 23302, 20560, 18396, 16384, 14564), (40, 45, 51, 57, 64, 72)      # scalinglist.cpp:129-130
+
+
+def _tables(rng, n, qp, depth, dev, lists=True, nr=True):
+    """A scaling matrix of the kind ScalingList::setupQuantMatrices turns into coefficient tables (quantCoef = (scale << 4) / m,
+    dequantCoef = invScale * m, scalinglist.cpp) + denoiser offsets; returns (host arrays, device record, device residual sums)."""
+    import torch
+    rem = qp % 6
+    m = rng.integers(8, 64, size=n * n)
+    qc = ((QUANT_SCALES[rem] << 4) // m).astype(np.int32) if lists else None
+    dqc = (INV_QUANT_SCALES[rem] * m).astype(np.int32) if lists else None
+    off = rng.integers(0, 5 << (depth - 8), size=n * n).astype(np.uint16) if nr else None
+    d = lambda a: None if a is None else torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).to(dev)
+    d_sum = torch.zeros(n * n, dtype=torch.int32, device=dev) if nr else None
+    rec = A.tu_tables(d(qc), d(dqc), d(off), d_sum)
+    return (qc, dqc, off), rec, d_sum
+
+
+@pytest.mark.parametrize("depth,level,qp,lists,nr", [(8, 2, 24, True, True), (8, 1, 30, True, False), (8, 0, 20, False, True), (10, 2, 36, True, True), (12, 1, 44, True, True)])
+def test_inter_recon_with_scaling_lists_and_denoiser(depth, level, qp, lists, nr):
+    """x265hip_tu_tables: scaling-list quantiser / dequantiser coefficients and the denoiser (running residual sums) in the fused inter TU
+    stage, luma and both chroma planes, sign hiding on - against the oracle, whose table paths are pinned against the real Quant."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng([57, depth, level, qp])
+    clip = F.synth_clip(256, 128, 2, depth=depth, seed=70 + level)
+    cur, ref = P.DevicePicture(clip[1][0], dev, clip[1][1], clip[1][2]), P.DevicePicture(clip[0][0], dev, clip[0][1], clip[0][2])
+    ms = P.MotionSearch(cur.w64, cur.h64, 8, depth, dev, want_surf=False)
+    ms.run(cur, ref)
+    sp = P.SubpelRefine(ms, 3, dev)
+    sp.run(cur, ref)
+    torch.cuda.synchronize()
+    mv = sp.out.cpu().numpy().reshape(-1, 2)
+    O = _oracle()
+    flags = 2
+    # luma
+    n = 8 << level
+    (qc, dqc, off), rec, d_sum = _tables(rng, n, qp, depth, dev, lists, nr)
+    st = S.InterRecon(ms.nctu, cur.w64, cur.h64, depth, level, qp, dev, intra_slice=flags)
+    st.tables = rec
+    recon = torch.zeros_like(cur.t)
+    st.run(cur, ref, recon, sp.out)
+    torch.cuda.synchronize()
+    osum = np.zeros(n * n, np.uint32)
+    O.set_tu_tables(depth, qc, dqc, off, osum if nr else None)
+    try:
+        erec, elev, ens, edist = O.inter_recon(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, level, mv, qp, intra_slice=flags)
+    finally:
+        O.set_tu_tables(depth)
+    assert np.array_equal(st.levels.cpu().numpy(), elev), "luma levels differ"
+    assert np.array_equal(st.num_sig.cpu().numpy().view(np.uint32), ens) and np.array_equal(st.dist.cpu().numpy().view(np.uint64), edist)
+    assert np.array_equal(recon.cpu().numpy().view(cur.host.dtype).reshape(cur.host.shape), erec)
+    if nr:
+        assert np.array_equal(d_sum.cpu().numpy().view(np.uint32), osum) and osum.sum() > 0
+    plain = O.inter_recon(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, level, mv, qp, intra_slice=flags)[1]
+    assert not np.array_equal(plain, elev), "the tables changed nothing: the case does not exercise them"
+    # one chroma plane
+    nc = n // 2
+    (qc, dqc, off), rec, d_sum = _tables(rng, nc, qp, depth, dev, lists, nr)
+    stc = S.InterReconChroma(ms.nctu, cur.w64, cur.h64, depth, level, qp, dev, intra_slice=flags)
+    stc.tables = rec
+    out = torch.zeros_like(cur.c[0])
+    stc.run(cur.c[0], ref.c[0], out, cur.stride_c, cur.org_c, sp.out)
+    torch.cuda.synchronize()
+    osum = np.zeros(nc * nc, np.uint32)
+    O.set_tu_tables(depth, qc, dqc, off, osum if nr else None)
+    try:
+        erec, elev, ens, edist = O.inter_recon_chroma(depth, cur.c_host[0].reshape(-1), ref.c_host[0].reshape(-1), cur.stride_c, cur.org_c, cur.w64, cur.h64, level, mv, qp,
+                                                      intra_slice=flags)
+    finally:
+        O.set_tu_tables(depth)
+    assert np.array_equal(stc.levels.cpu().numpy(), elev) and np.array_equal(stc.num_sig.cpu().numpy().view(np.uint32), ens)
+    assert np.array_equal(out.cpu().numpy().view(cur.host.dtype), erec.reshape(-1))
+    if nr:
+        assert np.array_equal(d_sum.cpu().numpy().view(np.uint32), osum)

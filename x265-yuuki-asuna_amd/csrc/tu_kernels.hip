@@ -46,6 +46,11 @@ static __constant__ int16_t kTuChromaTaps[8][4] = {                             
 static __constant__ int kTuQuantScales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };   // scalinglist.cpp:129
 static __constant__ int kTuInvQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                  // scalinglist.cpp:130
 
+// optional per-coefficient tables of the launch's block size (all DEVICE pointers, N * N entries, raster order; NULL = not used):
+// scaling-list quantiser / dequantiser coefficients (ScalingList::m_quantCoef / m_dequantCoef [size][list][rem], quant.cpp:463,566) and
+// the denoiser's offsets with its running residual sums (NoiseReduction, quant.cpp:444-451, dct.cpp:744-755)
+struct TuTables { const int32_t* qc; const int32_t* dqc; const uint16_t* nrOff; uint32_t* nrSum; };
+
 struct TuArgs
 {
     const uint8_t* fenc; long fencStrideB;
@@ -55,6 +60,7 @@ struct TuArgs
     const int2* mv;                 // [ctu*85] {cost, qx | qy << 16}
     int qp, intraSlice;          // intraSlice: the X265HIP_TU_* flag bits
     int16_t* levels; uint32_t* numSig; unsigned long long* dist;
+    TuTables tab;
 };
 
 __device__ __forceinline__ int tu_clip16(int v, int maxVal) { const int16_t s = (int16_t)v; return s < 0 ? 0 : (s > maxVal ? maxVal : s); }
@@ -154,7 +160,7 @@ template <int N> __device__ __forceinline__ int tu_sign_hide_group(int16_t* lev,
 template <typename Px, int N, bool DST>
 __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int16_t* pred, const int16_t* fe, int16_t* A, int16_t* B, unsigned long long* red, int& sNumSig,
                                          int depth, int qp, int flags, int16_t* lvOut, uint32_t* numSigOut, unsigned long long* distOut,
-                                         Px* rec, long cst, int scanType = TU_SCAN_DIAG)
+                                         Px* rec, long cst, int scanType = TU_SCAN_DIAG, const TuTables tab = TuTables{ nullptr, nullptr, nullptr, nullptr })
 {
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -170,6 +176,21 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
     const bool signHide = (flags & TU_FLAG_SIGN_HIDE) != 0;
     const int qbits8 = qbits - 8;
     const int qscale = kTuQuantScales[rem];
+    // one transform coefficient -> (denoised coefficient, quantiser scale): primitives.denoiseDct before the quantiser (quant.cpp:444-451),
+    // the scaling list's coefficient instead of the flat scale (quant.cpp:463)
+    auto prepare = [&](const int e, int c, int& scale)
+    {
+        if (tab.nrOff)
+        {
+            const int sign = c >> 31;
+            int level = (c + sign) ^ sign;
+            atomicAdd(&tab.nrSum[e], (uint32_t)level);
+            level -= (int)tab.nrOff[e];
+            c = (int16_t)(level < 0 ? 0 : (level ^ sign) - sign);
+        }
+        scale = tab.qc ? tab.qc[e] : qscale;
+        return c;
+    };
     int16_t* lv = lvOut;
     int nz = 0;
     constexpr bool USE_MFMA = N >= 16 && !DST;           // the 16 / 32 point transforms are dense matrix products: matrix cores
@@ -209,8 +230,9 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
             for (int r = 0; r < MF::NACC; r++)
             {
                 const int e = MF::row(lane, r) * N + MF::col(lane);
-                const int c = (int16_t)((p[r] + (1 << (sh2 - 1))) >> sh2);
-                const int t = abs(c) * qscale;
+                int qs;
+                const int c = prepare(e, (int16_t)((p[r] + (1 << (sh2 - 1))) >> sh2), qs);
+                const int t = abs(c) * qs;
                 int level = (t + qadd) >> qbits;
                 // B's pass-1 values were consumed by the products above (one wavefront, LDS operations in order): it now keeps what
                 // sign hiding needs per coefficient - deltaU (dct.cpp:679, within +-256) and the sign of the transform coefficient
@@ -242,8 +264,9 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
         int acc = 0;
 #pragma unroll
         for (int i = 0; i < N; i++) acc += tu_mat<N, DST>(k, i) * (int)B[j * N + i];
-        const int c = (int16_t)((acc + (1 << (sh2 - 1))) >> sh2);
-        const int t = abs(c) * qscale;
+        int qs;
+        const int c = prepare(e, (int16_t)((acc + (1 << (sh2 - 1))) >> sh2), qs);
+        const int t = abs(c) * qs;
         int level = (t + qadd) >> qbits;
         auxReg = (((t - (level << qbits)) >> qbits8) << 1) | (c < 0);
         nz += level != 0;
@@ -290,10 +313,18 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
     {
         const int dqShift = 20 - 14 - transformShift, dqAdd = 1 << (dqShift - 1);
         const int dqScale = kTuInvQuantScales[rem] << per;
+        // dequant_normal (flat lists) or dequant_scaling with the list's coefficient (dct.cpp:612-662, quant.cpp:562-572)
+        auto dequant = [&](const int e, const int level)
+        {
+            if (!tab.dqc) return tu_sat16((level * dqScale + dqAdd) >> dqShift);
+            const int sh = dqShift + 4, prod = level * tab.dqc[e];
+            if (sh > per) return tu_sat16((prod + (1 << (sh - per - 1))) >> (sh - per));
+            return tu_sat16(tu_sat16(prod) << (per - sh));
+        };
         if (numSig == 1 && A[0] != 0 && !DST)
         {
             // DC-only shortcut (quant.cpp:586-598)
-            const int deq = tu_sat16(((int)A[0] * dqScale + dqAdd) >> dqShift);
+            const int deq = dequant(0, (int)A[0]);
             const int shift2 = 12 - (depth - 8) - 3;
             const int dc = (int16_t)(((((deq + 1) >> 1) * 8) + (1 << (shift2 - 1))) >> shift2);
             for (int i = tid; i < NN; i += nth)
@@ -307,7 +338,7 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
         }
         else
         {
-            for (int i = tid; i < NN; i += nth) B[i] = (int16_t)tu_sat16(((int)A[i] * dqScale + dqAdd) >> dqShift);
+            for (int i = tid; i < NN; i += nth) B[i] = (int16_t)dequant(i, (int)A[i]);
             __syncthreads();
             const int shI = 12 - (depth - 8);
             if constexpr (USE_MFMA)
@@ -480,7 +511,7 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs 
 
     tu_chain<Px, N, false>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
                            a.levels + ((size_t)ctu * npu + z) * NN, &a.numSig[(size_t)ctu * npu + z], &a.dist[(size_t)ctu * npu + z],
-                           reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP);
+                           reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP, TU_SCAN_DIAG, a.tab);
     __syncthreads();
     };
     if constexpr (N >= 16)
@@ -598,7 +629,7 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBi
         }
         tu_chain<Px, N, false>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
                                a.levels + ((size_t)ctu * npu + z) * NN, &a.numSig[(size_t)ctu * npu + z], &a.dist[(size_t)ctu * npu + z],
-                               reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP);
+                               reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP, TU_SCAN_DIAG, a.tab);
         __syncthreads();
     };
     if constexpr (N >= 16)
@@ -621,6 +652,7 @@ struct IntraTuArgs
     const x265hip_job* jobs; int njobs;
     int depth, qp, intraSlice;
     int16_t* levels; uint32_t* numSig; unsigned long long* dist;
+    TuTables tab;
     int chroma;             // predIntraChromaAng (predict.cpp:590-598): unfiltered neighbours, no edge smoothing
 };
 
@@ -669,7 +701,7 @@ __global__ void __launch_bounds__(N <= 8 ? 256 : 64) intra_recon_kernel(IntraTuA
                              reinterpret_cast<Px*>(a.recon) + jb.off[3], a.reconStrideB / BPP,
                              // the scan sign hiding walks: mode-dependent for 4x4 TUs and 8x8 luma TUs (cudata.cpp:2083-2084)
                              (N == 4 || (!a.chroma && N == 8)) ? (mode >= 22 && mode <= 30 ? TU_SCAN_HOR : (mode >= 6 && mode <= 14 ? TU_SCAN_VER : TU_SCAN_DIAG))
-                                                               : TU_SCAN_DIAG);
+                                                               : TU_SCAN_DIAG, a.tab);
         __syncthreads();
     };
     // 4 / 8: one candidate per workgroup; 16 / 32: persistent, the MFMA operands above are reused
@@ -681,6 +713,14 @@ __global__ void __launch_bounds__(N <= 8 ? 256 : 64) intra_recon_kernel(IntraTuA
 } // namespace x265hip
 
 using namespace x265hip;
+
+static TuTables tu_tables_of(const x265hip_tu_tables* t)
+{
+    TuTables r = { nullptr, nullptr, nullptr, nullptr };
+    if (t) { r.qc = t->quant_coeff; r.dqc = t->dequant_coeff; r.nrOff = t->nr_offset; r.nrSum = t->nr_residual_sum; }
+    return r;
+}
+#define TABLES_OF(p) ((p)->tables)
 
 extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
 {
@@ -700,6 +740,7 @@ extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
     a.ctusW = p->width / 64; a.depth = p->depth; a.level = p->level;
     a.mv = (const int2*)p->mv; a.qp = p->qp; a.intraSlice = p->intra_slice;
     a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
+    a.tab = tu_tables_of(TABLES_OF(p));
     const int nctu = a.ctusW * (p->height / 64);
     const int npu = 64 >> (2 * p->level);
     hipStream_t s = (hipStream_t)stream;
@@ -744,6 +785,7 @@ extern "C" int x265hip_inter_recon_bi(const x265hip_recon_bi_params* q, void* st
     a.ctusW = p->width / 64; a.depth = p->depth; a.level = p->level;
     a.mv = (const int2*)p->mv; a.qp = p->qp; a.intraSlice = p->intra_slice;
     a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
+    a.tab = tu_tables_of(TABLES_OF(p));
     b.fref1 = (const uint8_t*)q->fref1; b.mv1 = (const int2*)q->mv1; b.dir = q->dir;
     const int nblocks = a.ctusW * (p->height / 64) * (64 >> (2 * p->level));
     hipStream_t s = (hipStream_t)stream;
@@ -784,6 +826,7 @@ extern "C" int x265hip_inter_recon_chroma(const x265hip_recon_params* p, void* s
     a.ctusW = p->width / 64; a.depth = p->depth; a.level = p->level;
     a.mv = (const int2*)p->mv; a.qp = p->qp; a.intraSlice = p->intra_slice;
     a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
+    a.tab = tu_tables_of(TABLES_OF(p));
     const int nctu = a.ctusW * (p->height / 64);
     const int nblocks = nctu * (64 >> (2 * p->level));
     hipStream_t s = (hipStream_t)stream;
@@ -823,6 +866,7 @@ extern "C" int x265hip_intra_recon_batch(const x265hip_intra_recon_params* p, vo
     a.recon = (uint8_t*)p->recon; a.reconStrideB = (long)p->recon_stride * bpp;
     a.jobs = p->jobs; a.njobs = p->njobs; a.depth = p->depth; a.qp = p->qp; a.intraSlice = p->intra_slice; a.chroma = p->chroma != 0;
     a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
+    a.tab = tu_tables_of(TABLES_OF(p));
     hipStream_t s = (hipStream_t)stream;
     // 16 / 32: persistent single-wavefront workgroups, exactly one resident set (a second partial round would double the time);
     // 4 / 8: nothing to amortise, one workgroup per job

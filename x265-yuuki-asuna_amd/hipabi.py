@@ -630,6 +630,18 @@ def _planes(ps, n):
     return arr
 
 
+class TuTablesRec(ctypes.Structure):
+    """x265hip_tu_tables (include/x265hip.h): device pointers, any may be NULL."""
+    _fields_ = [("quant_coeff", ctypes.c_void_p), ("dequant_coeff", ctypes.c_void_p), ("nr_offset", ctypes.c_void_p), ("nr_residual_sum", ctypes.c_void_p)]
+
+
+def tu_tables(quant_coeff=None, dequant_coeff=None, nr_offset=None, nr_residual_sum=None):
+    """Device tensors -> the table record a TU stage takes through its `tables` field (keep the returned object alive during the launch)."""
+    r = TuTablesRec(_p(quant_coeff), _p(dequant_coeff), _p(nr_offset), _p(nr_residual_sum))
+    r._keep = (quant_coeff, dequant_coeff, nr_offset, nr_residual_sum)
+    return r
+
+
 class IntraReconParams(ctypes.Structure):
     """x265hip_intra_recon_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("n", ctypes.c_int),
@@ -638,14 +650,16 @@ class IntraReconParams(ctypes.Structure):
                 ("recon", ctypes.c_void_p), ("recon_stride", ctypes.c_ssize_t),
                 ("qp", ctypes.c_int), ("intra_slice", ctypes.c_int),
                 ("jobs", ctypes.c_void_p), ("njobs", ctypes.c_int),
-                ("levels", ctypes.c_void_p), ("num_sig", ctypes.c_void_p), ("dist", ctypes.c_void_p), ("chroma", ctypes.c_int)]
+                ("levels", ctypes.c_void_p), ("num_sig", ctypes.c_void_p), ("dist", ctypes.c_void_p), ("chroma", ctypes.c_int),
+                ("tables", ctypes.c_void_p)]
 
 
 def intra_recon_batch(depth, n, fenc, fenc_stride, nb, recon, recon_stride, qp, intra_slice, jobs, njobs,
-                      levels, num_sig, dist, stream=None, chroma=False):
+                      levels, num_sig, dist, stream=None, chroma=False, tables=None):
     """Intra TU candidate set (search.cpp:335-373): one (TU, mode) candidate per job, see include/x265hip.h.
-    chroma=True: the 4:2:0 chroma flavour (unfiltered neighbours, no edge smoothing, DCT for 4x4)."""
+    chroma=True: the 4:2:0 chroma flavour (unfiltered neighbours, no edge smoothing, DCT for 4x4).  tables: hipabi.tu_tables(...)"""
     p = IntraReconParams()
+    p.tables = ctypes.addressof(tables) if tables is not None else None
     p.depth, p.n, p.chroma = depth, n, int(bool(chroma))
     p.fenc, p.fenc_stride, p.nb = fenc.data_ptr(), fenc_stride, nb.data_ptr()
     p.recon, p.recon_stride = recon.data_ptr(), recon_stride

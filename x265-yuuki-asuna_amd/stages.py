@@ -21,6 +21,7 @@ class ReconParams(ctypes.Structure):
         ("fref", ctypes.c_void_p), ("fref_stride", ctypes.c_ssize_t),
         ("recon", ctypes.c_void_p), ("recon_stride", ctypes.c_ssize_t),
         ("mv", ctypes.c_void_p), ("levels", ctypes.c_void_p), ("num_sig", ctypes.c_void_p), ("dist", ctypes.c_void_p),
+        ("tables", ctypes.c_void_p),
     ]
 
 
@@ -36,6 +37,7 @@ class InterRecon:
         self.levels = torch.zeros(nctu * self.nblk * self.n * self.n, dtype=torch.int16, device=device)
         self.num_sig = torch.zeros(nctu * self.nblk, dtype=torch.int32, device=device)
         self.dist = torch.zeros(nctu * self.nblk, dtype=torch.int64, device=device)
+        self.tables = None          # hipabi.tu_tables(...): scaling-list coefficients / denoiser tables of this block size, or None
 
     def algorithmic_bytes(self, bpp=1):
         """per block: source N^2 + reference patch (N+7)^2 + recon N^2 pixels, levels 2*N^2, 16 B of results"""
@@ -50,6 +52,7 @@ class InterRecon:
         p.fref, p.fref_stride = ref.t.data_ptr() + ref.org * es, ref.stride
         p.recon, p.recon_stride = recon_plane.data_ptr() + cur.org * es, cur.stride
         p.mv, p.levels, p.num_sig, p.dist = mv.data_ptr(), self.levels.data_ptr(), self.num_sig.data_ptr(), self.dist.data_ptr()
+        p.tables = ctypes.addressof(self.tables) if self.tables is not None else None
         s = hipabi.current_stream() if stream is None else stream
         f = hipabi.lib().x265hip_inter_recon
         f.argtypes = [ctypes.POINTER(ReconParams), ctypes.c_void_p]
@@ -79,6 +82,7 @@ class InterReconBi(InterRecon):
         p.fref, p.fref_stride = ref0.t.data_ptr() + ref0.org * es, ref0.stride
         p.recon, p.recon_stride = recon_plane.data_ptr() + cur.org * es, cur.stride
         p.mv, p.levels, p.num_sig, p.dist = mv0.data_ptr(), self.levels.data_ptr(), self.num_sig.data_ptr(), self.dist.data_ptr()
+        p.tables = ctypes.addressof(self.tables) if self.tables is not None else None
         q.fref1, q.mv1 = ref1.t.data_ptr() + ref1.org * es, mv1.data_ptr()
         q.dir = None if dir_flags is None else dir_flags.data_ptr()
         s = hipabi.current_stream() if stream is None else stream
@@ -100,6 +104,7 @@ class InterReconChroma:
         self.levels = torch.zeros(nctu * self.nblk * self.n * self.n, dtype=torch.int16, device=device)
         self.num_sig = torch.zeros(nctu * self.nblk, dtype=torch.int32, device=device)
         self.dist = torch.zeros(nctu * self.nblk, dtype=torch.int64, device=device)
+        self.tables = None
 
     def run(self, fenc, fref, recon, stride, org, mv, stream=None):
         es = 1 if self.depth == 8 else 2
@@ -109,6 +114,7 @@ class InterReconChroma:
         p.fref, p.fref_stride = fref.data_ptr() + org * es, stride
         p.recon, p.recon_stride = recon.data_ptr() + org * es, stride
         p.mv, p.levels, p.num_sig, p.dist = mv.data_ptr(), self.levels.data_ptr(), self.num_sig.data_ptr(), self.dist.data_ptr()
+        p.tables = ctypes.addressof(self.tables) if self.tables is not None else None
         s = hipabi.current_stream() if stream is None else stream
         f = hipabi.lib().x265hip_inter_recon_chroma
         f.argtypes = [ctypes.POINTER(ReconParams), ctypes.c_void_p]
