@@ -445,7 +445,7 @@ def main():
                 enc = {}
                 for key in args.encoder.split(","):
                     enc[key] = EB.run_config(key, args.encoder_tables.split(","), args.encoder_frames, 1, 120.0, log=sys.stderr,
-                                             seam={"range": 24, "slots": 8, "min_pu": 8, "verify": False, "lookahead": True})
+                                             seam={"range": 24, "slots": 8, "min_pu": 8, "verify": False, "lookahead": True, "subpel": True, "subpel_slots": 6})
                 out["encoder"] = enc
                 c3 = enc.get("cfg3", {})
                 if "c" in c3:

@@ -745,6 +745,60 @@ static inline int32_t x265hip_surf_lookup(const void* surf, int surf_format, int
 
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Fractional-phase planes of a reference picture (csrc/phase_kernels.hip, csrc/phase_cache.hip): every sub-sample position an
+ * encoder can ask of a reference picture, interpolated ONCE per picture instead of once per candidate block.
+ *   luma   : 15 planes, phase = yFrac * 4 + xFrac (quarter samples), plane of phase p at dst + (p - 1) * plane_bytes; sample (x, y) of
+ *            a plane = what luma_hpp (yFrac 0) / luma_vpp (xFrac 0) / luma_hvpp (both) write for source position (x, y)
+ *            (ipfilter.cpp:79-118, :164-203, :362-369 - the calls of MotionEstimate::subpelCompare, motion.cpp:1593-1598, and of
+ *            Predict::predInterLumaPixel, predict.cpp:261-281)
+ *   chroma : 63 planes per chroma plane, phase = yFrac * 8 + xFrac (eighth samples, 4:2:0): filter_hpp / filter_vpp /
+ *            filter_hps(isRowExt) + filter_vsp (motion.cpp:1628-1657, predict.cpp:304-351)
+ * The planes have the geometry of the source plane (same pitch, same rows), so a block's address in a phase plane is its address in
+ * the source plane plus a constant; the interpolated block needs no copy, the comparison primitive reads it in place.
+ * Batch-layer entry (device pointers):
+ *   src  : the padded plane, `rows` rows of `stride` samples; at least 4 rows + 64 bytes of readable memory must precede it and
+ *          8 rows follow it (samples within 4 of the buffer edge depend on those guard bytes: no valid block lies there)
+ *   dst  : (chroma ? 63 : 15) planes of stride * rows samples */
+typedef struct x265hip_phase_planes_params
+{
+    int depth;
+    int chroma;                     /* 0: 8-tap luma set, quarter phases; 1: 4-tap chroma set, eighth phases */
+    const void* src;
+    void* dst;
+    intptr_t stride;                /* samples; stride * bytes-per-sample must be a multiple of 4 */
+    int rows;                       /* multiple of 4 */
+} x265hip_phase_planes_params;
+int x265hip_phase_planes(const x265hip_phase_planes_params* p, void* stream);
+
+/* Picture-granular CONSUMER: host planes in (the reference's PicYuv buffers, margins included), phase planes in pinned host memory
+ * out; a worker thread uploads, interpolates and downloads while the encoder goes on.  `ready` is int[2]: luma planes are complete when
+ * ready[0] == the generation submit returned, both chroma planes when ready[1] == it.  Until then (and for anything else) the host
+ * interpolates the block itself - same samples either way. */
+typedef struct x265hip_phase_cache x265hip_phase_cache;
+typedef struct x265hip_phase_cache_params
+{
+    int depth;
+    intptr_t stride;   int rows;       /* luma buffer: pitch in samples, allocated rows (height + 2 * margin) */
+    intptr_t stride_c; int rows_c;     /* each chroma buffer; rows_c = 0: luma only */
+    int slots;                         /* reference pictures resident in host memory at once */
+} x265hip_phase_cache_params;
+typedef struct x265hip_phase_cache_stats_t
+{
+    uint64_t fills, failed;
+    uint64_t us_upload_kernel, us_download;
+    uint64_t bytes_downloaded, bytes_per_picture;
+} x265hip_phase_cache_stats_t;
+int  x265hip_phase_cache_create(x265hip_phase_cache** out, const x265hip_phase_cache_params* p);
+void x265hip_phase_cache_destroy(x265hip_phase_cache* c);
+/* copies the three buffers (cb / cr may be NULL when rows_c = 0), queues the work, returns the slot's new GENERATION (> 0) or < 0 */
+int  x265hip_phase_cache_submit(x265hip_phase_cache* c, int slot, const void* luma_buf, const void* cb_buf, const void* cr_buf);
+/* plane = 0: the 15 luma planes, 1 / 2: the 63 Cb / Cr planes (pinned host memory, fixed for the life of the cache) */
+const void* x265hip_phase_cache_planes(x265hip_phase_cache* c, int slot, int plane);
+const volatile int* x265hip_phase_cache_ready(x265hip_phase_cache* c, int slot);
+int  x265hip_phase_cache_stats(x265hip_phase_cache* c, x265hip_phase_cache_stats_t* st);
+
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Multi-GPU seam (csrc/recon_publish.hip): hand a finished band of reconstructed CTU rows - Y, Cb, Cr with their margins - from the
  * GPU that produced it to the GPU(s) whose in-flight pictures reference it, where the reference raises m_reconRowFlag
  * (encoder/framefilter.cpp:664; consumers wait in encoder/frameencoder.cpp:852-868).  One process per GPU; `comm` is the host's

@@ -455,3 +455,16 @@ def inter_recon_bi(depth, fenc, stride, org, fref0, fref1, width, height, level,
               recon.ctypes.data + org * es, stride, width, height, level, m0.ctypes.data, m1.ctypes.data, None if d is None else d.ctypes.data,
               qp, intra_slice, levels.ctypes.data, num_sig.ctypes.data, dist.ctypes.data, nthreads) == 0
     return recon, levels, num_sig, dist
+
+
+def phase_planes(depth, src, stride, rows, chroma=False, avx2=False):
+    """CPU restatement of x265hip_phase_planes on top of the oracle's interpolation primitives: src = flat padded plane (stride * rows
+    samples).  Returns [15 or 63, rows, stride]; the 8-sample border of every plane is zero (undefined in the product)."""
+    fn = getattr(lib(avx2), f"x265oracle_phase_planes_d{depth}")
+    s = np.ascontiguousarray(src).reshape(-1)
+    assert s.size == stride * rows and stride % 8 == 0 and rows % 8 == 0
+    out = np.zeros((63 if chroma else 15, rows, stride), s.dtype)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    fn.restype = None
+    fn(s.ctypes.data, stride, rows, int(bool(chroma)), out.ctypes.data)
+    return out

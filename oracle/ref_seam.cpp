@@ -45,6 +45,7 @@ using namespace X265_NS;
 extern "C" int x265ref_orig_motionEstimate(MotionEstimate* self, ReferencePlanes* ref, const MV* mvmin, const MV* mvmax, const MV* qmvp,
                                            int numCandidates, const MV* mvc, int merange, MV* outQMv, uint32_t maxSlices, pixel* srcReferencePlane);
 
+extern "C" int x265ref_orig_subpelCompare(MotionEstimate* self, ReferencePlanes* ref, const MV* qmv, pixelcmp_t cmp);
 extern "C" int64_t x265ref_orig_estimateFrameCost(CostEstimateGroup* self, LookaheadTLD* tld, int p0, int p1, int b, bool bIntraPenalty);
 extern "C" void x265ref_orig_lowresIntraEstimate(LookaheadTLD* self, Lowres* fenc, uint32_t qgSize);
 
@@ -367,6 +368,142 @@ int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicY
     return slot;
 }
 
+/* ---- the sub-sample seam: MotionEstimate::subpelCompare compares the source block with a block of a precomputed PHASE PLANE of
+ * the reference picture (x265hip_phase_cache: every fractional phase interpolated once per picture) instead of interpolating the
+ * block per candidate.  Provider = C function pointers with the signatures of x265hip_phase_cache_submit / _planes / _ready. */
+struct PhaseProvider
+{
+    void* ctx;
+    int (*submit)(void* ctx, int slot, const void* luma, const void* cb, const void* cr);
+    const void* (*planes)(void* ctx, int slot, int plane);
+    const volatile int* (*ready)(void* ctx, int slot);
+    int slots;
+    intptr_t stride;  int rows;
+    intptr_t strideC; int rowsC;
+};
+struct PhaseEntry { const PicYuv* rec; int poc; int gen; bool used; uint64_t lastUse; };
+struct SubSeam
+{
+    bool enabled = false, verify = false, wait = false;
+    PhaseProvider p;
+    std::mutex mu;
+    PhaseEntry e[MAX_SLOTS];
+    uint64_t tick = 0;
+    std::atomic<int> epoch{0};
+    std::atomic<uint64_t> served{0}, notReady{0}, noContext{0}, submits{0}, mismatches{0}, noSlot{0};
+} gs;
+
+struct SubCtx
+{
+    bool valid;
+    const ReferencePlanes* ref;
+    const PicYuv* rec;
+    const pixel* luma; const pixel* cb; const pixel* cr;      /* phase 1 of each plane set, buffer coordinates */
+    size_t planeL, planeC;                                    /* samples per plane */
+    const volatile int* ready;
+    int gen;
+    bool arrived[2];
+};
+thread_local SubCtx t_sub;
+thread_local struct { int epoch; int n; struct { const PicYuv* rec; int poc; int slot; int gen; } e[8]; } t_phase = { -1, 0, {} };
+
+/* slot that holds (or will hold) the phase planes of reconstructed picture (rec, poc); -1 when none can be had.  A picture is
+ * submitted the first time a search refers to it; the least recently used slot whose picture the current slice does not
+ * reference is recycled (-F 1: earlier pictures' searches are over). */
+int phase_slot(const PicYuv* rec, int poc, const Slice* slice, int& gen)
+{
+    const int epoch = gs.epoch.load(std::memory_order_acquire);
+    if (t_phase.epoch != epoch) { t_phase.epoch = epoch; t_phase.n = 0; }
+    for (int i = 0; i < t_phase.n; i++)
+        if (t_phase.e[i].rec == rec && t_phase.e[i].poc == poc) { gen = t_phase.e[i].gen; return t_phase.e[i].slot; }
+    int slot = -1;
+    {
+        std::lock_guard<std::mutex> lk(gs.mu);
+        gs.tick++;
+        for (int i = 0; i < gs.p.slots; i++)
+            if (gs.e[i].used && gs.e[i].rec == rec && gs.e[i].poc == poc) { slot = i; gen = gs.e[i].gen; gs.e[i].lastUse = gs.tick; }
+        if (slot < 0)
+        {
+            int victim = -1;
+            for (int i = 0; i < gs.p.slots; i++)
+            {
+                if (!gs.e[i].used) { victim = i; break; }
+                bool live = false;
+                for (int l = 0; l < 2 && !live; l++)
+                    for (int r = 0; r < slice->m_numRefIdx[l] && !live; r++)
+                        live = slice->m_mref[l][r].reconPic == gs.e[i].rec && slice->m_refPOCList[l][r] == gs.e[i].poc;
+                if (!live && (victim < 0 || gs.e[i].lastUse < gs.e[victim].lastUse)) victim = i;
+            }
+            if (victim >= 0)
+            {
+                const int gnew = gs.p.submit(gs.p.ctx, victim, rec->m_picBuf[0], rec->m_picBuf[1], rec->m_picBuf[2]);
+                if (gnew > 0)
+                {
+                    PhaseEntry& q = gs.e[victim];
+                    q.used = true; q.rec = rec; q.poc = poc; q.gen = gnew; q.lastUse = gs.tick;
+                    slot = victim; gen = gnew;
+                    gs.submits++;
+                    gs.epoch.fetch_add(1, std::memory_order_release);
+                    t_phase.epoch = gs.epoch.load(); t_phase.n = 0;
+                }
+            }
+        }
+    }
+    if (slot < 0) { gs.noSlot++; return -1; }
+    if (t_phase.n < 8) { auto& e = t_phase.e[t_phase.n++]; e.rec = rec; e.poc = poc; e.slot = slot; e.gen = gen; }
+    return slot;
+}
+
+/* POC of the reference picture `ref` points at: ref is an element of slice->m_mref[list][idx] (slice.h:337) */
+int ref_poc(const Slice* slice, const ReferencePlanes* ref)
+{
+    const ptrdiff_t idx = static_cast<const MotionReference*>(ref) - &slice->m_mref[0][0];
+    if (idx < 0 || idx >= 2 * (MAX_NUM_REF + 1)) return -0x7fffffff;
+    return slice->m_refPOCList[idx / (MAX_NUM_REF + 1)][idx % (MAX_NUM_REF + 1)];
+}
+
+void sub_context(const Search* s, ReferencePlanes* ref)
+{
+    SubCtx& c = t_sub;
+    c.valid = false;
+    const PicYuv* rec = ref->reconPic;
+    if (!rec || ref->isWeighted || ref->isLowres || s->m_param->frameNumThreads != 1 || rec->m_picCsp != X265_CSP_I420 ||
+        ref->fpelPlane[0] != rec->m_picOrg[0] || ref->fpelPlane[1] != rec->m_picOrg[1] || ref->fpelPlane[2] != rec->m_picOrg[2] ||
+        rec->m_stride != gs.p.stride || rec->m_strideC != gs.p.strideC) { gs.noContext.fetch_add(1, std::memory_order_relaxed); return; }
+    const int maxH = (int)((rec->m_picHeight + s->m_param->maxCUSize - 1) / s->m_param->maxCUSize * s->m_param->maxCUSize);
+    if (maxH + 2 * (int)rec->m_lumaMarginY != gs.p.rows || (maxH >> 1) + 2 * (int)rec->m_chromaMarginY != gs.p.rowsC)
+    { gs.noContext.fetch_add(1, std::memory_order_relaxed); return; }
+    const int poc = ref_poc(s->m_slice, ref);
+    if (poc == -0x7fffffff) { gs.noContext.fetch_add(1, std::memory_order_relaxed); return; }
+    int gen = 0;
+    const int slot = phase_slot(rec, poc, s->m_slice, gen);
+    if (slot < 0) return;
+    c.ref = ref; c.rec = rec;
+    c.luma = (const pixel*)gs.p.planes(gs.p.ctx, slot, 0);
+    c.cb = (const pixel*)gs.p.planes(gs.p.ctx, slot, 1);
+    c.cr = (const pixel*)gs.p.planes(gs.p.ctx, slot, 2);
+    c.planeL = (size_t)gs.p.stride * gs.p.rows; c.planeC = (size_t)gs.p.strideC * gs.p.rowsC;
+    c.ready = gs.p.ready(gs.p.ctx, slot);
+    c.gen = gen;
+    c.arrived[0] = c.arrived[1] = false;
+    c.valid = c.luma && c.cb && c.cr && c.ready;
+}
+
+inline bool sub_arrived(SubCtx& c, int which)
+{
+    if (c.arrived[which]) return true;
+    bool ok = c.ready[which] == c.gen;
+    if (!ok && gs.wait)          /* test mode: small pictures are encoded faster than their planes travel */
+        for (int spin = 0; spin < 20000 && !ok; spin++)
+        {
+            struct timespec ts = { 0, 100000 };
+            nanosleep(&ts, NULL);
+            ok = c.ready[which] == c.gen;
+        }
+    if (ok) { __atomic_thread_fence(__ATOMIC_ACQUIRE); c.arrived[which] = true; }
+    return ok;
+}
+
 } // namespace
 
 /* the seam: same signature, same symbol as the reference's function (whose compiled body now answers to x265ref_orig_motionEstimate) */
@@ -424,7 +561,11 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
                 g.foreign.fetch_add(1, std::memory_order_relaxed);
         }
     }
+    t_sub.valid = false;
+    if (gs.enabled && ctuAddr >= 0 && !srcReferencePlane && !ref->isLowres)
+        sub_context(reinterpret_cast<const Search*>(reinterpret_cast<const char*>(this) - offsetof(Search, m_me)), ref);
     const int cost = x265ref_orig_motionEstimate(this, ref, &mvmin, &mvmax, &qmvp, numCandidates, mvc, merange, &outQMv, maxSlices, srcReferencePlane);
+    t_sub.valid = false;
     if (c.valid)
     {
         c.valid = false;
@@ -432,6 +573,54 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         g.hits.fetch_add(c.hits, std::memory_order_relaxed);
         g.outside.fetch_add(c.outside, std::memory_order_relaxed);
         g.notReady.fetch_add(c.notReady, std::memory_order_relaxed);
+    }
+    return cost;
+}
+
+/* The sub-sample seam: same signature, same symbol as the reference's function (motion.cpp:1571-1664; the compiled original is weak and
+ * also answers to x265ref_orig_subpelCompare).  Inside a wrapped search on an unweighted 4:2:0 reference whose phase planes have
+ * arrived, the block the reference would interpolate into subpelbuf (luma_hpp / luma_vpp / luma_hvpp; chroma filter_hpp / filter_vpp /
+ * filter_hps + filter_vsp) is read in place from the plane of that phase - same samples, so the same cost; everything else goes to
+ * the original. */
+int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_t cmp)
+{
+    SubCtx& c = t_sub;
+    if (!c.valid || c.ref != ref || !sub_arrived(c, 0) || (bChromaSATD && !sub_arrived(c, 1)))
+    {
+        if (c.valid && c.ref == ref) gs.notReady.fetch_add(1, std::memory_order_relaxed);
+        return x265ref_orig_subpelCompare(this, ref, &qmv, cmp);
+    }
+    const intptr_t stride = ref->lumaStride;
+    const ptrdiff_t pos = blockOffset + (qmv.x >> 2) + (qmv.y >> 2) * stride;            /* relative to fpelPlane[0] */
+    const int lph = (qmv.y & 3) * 4 + (qmv.x & 3);
+    const pixel* lp = lph ? c.luma + (size_t)(lph - 1) * c.planeL + ((ref->fpelPlane[0] - c.rec->m_picBuf[0]) + pos) : ref->fpelPlane[0] + pos;
+    int cost = cmp(fencPUYuv.m_buf[0], FENC_STRIDE, lp, stride);
+    if (bChromaSATD)
+    {
+        /* 4:2:0: the quarter-sample luma vector is an eighth-sample chroma vector */
+        const intptr_t strideC = c.rec->m_strideC;
+        const ptrdiff_t cpos = (qmv.x >> 3) + (qmv.y >> 3) * strideC;
+        const int cph = (qmv.y & 7) * 8 + (qmv.x & 7);
+        const pixel* cb = ref->getCbAddr(ctuAddr, absPartIdx) + cpos;
+        const pixel* cr = ref->getCrAddr(ctuAddr, absPartIdx) + cpos;
+        if (cph)
+        {
+            cb = c.cb + (size_t)(cph - 1) * c.planeC + (cb - c.rec->m_picBuf[1]);
+            cr = c.cr + (size_t)(cph - 1) * c.planeC + (cr - c.rec->m_picBuf[2]);
+        }
+        cost += chromaSatd(fencPUYuv.m_buf[1], fencPUYuv.m_csize, cb, strideC);
+        cost += chromaSatd(fencPUYuv.m_buf[2], fencPUYuv.m_csize, cr, strideC);
+    }
+    gs.served.fetch_add(1, std::memory_order_relaxed);
+    if (gs.verify)
+    {
+        const int want = x265ref_orig_subpelCompare(this, ref, &qmv, cmp);
+        if (want != cost)
+        {
+            gs.mismatches++;
+            fprintf(stderr, "ref_seam: SUBPEL VERIFY MISMATCH partition %d mv (%d,%d): planes %d, reference %d\n", partEnum, qmv.x, qmv.y, cost, want);
+            abort();
+        }
     }
     return cost;
 }
@@ -606,7 +795,34 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
     return 0;
 }
 
-void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; }
+void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; gs.enabled = false; }
+
+/* sub-sample seam: provider = x265hip_phase_cache_submit / _planes / _ready signatures (NULL submit = off); geometry = the PicYuv
+ * buffers of the encode about to start.  flags: 1 = verify every served call against the reference's own function, 2 = wait for planes */
+int x265ref_subpel_seam_configure(void* ctx, void* submit, void* planes, void* ready, int slots, intptr_t stride, int rows, intptr_t stride_c, int rows_c, int flags)
+{
+    gs.enabled = false;
+    if (!submit) return 0;
+    if (slots < 1 || slots > MAX_SLOTS || !planes || !ready) return -1;
+    gs.p.ctx = ctx;
+    gs.p.submit = (int (*)(void*, int, const void*, const void*, const void*))submit;
+    gs.p.planes = (const void* (*)(void*, int, int))planes;
+    gs.p.ready = (const volatile int* (*)(void*, int))ready;
+    gs.p.slots = slots; gs.p.stride = stride; gs.p.rows = rows; gs.p.strideC = stride_c; gs.p.rowsC = rows_c;
+    memset(gs.e, 0, sizeof(gs.e));
+    gs.verify = (flags & 1) != 0; gs.wait = (flags & 2) != 0;
+    gs.served = gs.notReady = gs.noContext = gs.submits = gs.mismatches = gs.noSlot = 0;
+    gs.epoch.fetch_add(1);
+    gs.enabled = true;
+    return 0;
+}
+
+/* out[6]: subpelCompare calls served from phase planes, passed on because the planes had not arrived, searches without a usable
+ * context (weighted / foreign geometry), pictures submitted, verify mismatches, searches without a free slot */
+void x265ref_subpel_seam_stats(uint64_t* out)
+{
+    out[0] = gs.served; out[1] = gs.notReady; out[2] = gs.noContext; out[3] = gs.submits; out[4] = gs.mismatches; out[5] = gs.noSlot;
+}
 
 /* lookahead seam: host_fn = x265hip_lowres_cost_host (the product) or NULL; oracle_fn = x265oracle_lowres_cost_wp_d<depth> (CPU checker,
  * tests only) or NULL.  Both NULL switches the seam off. */

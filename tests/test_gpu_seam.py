@@ -170,3 +170,16 @@ def test_lowres_cost_host_entry_equals_oracle():
             e0, c0, elc, erows, eframe = exp
         assert np.array_equal(mvs[0], e0) and np.array_equal(mvc[0], c0) and np.array_equal(lc, elc) and np.array_equal(rws, erows)
         assert np.array_equal(frame[:len(eframe)], eframe)
+
+
+@pytest.mark.parametrize("depth,preset,extra", [(8, "slow", [("me", "star")]), (8, "slower", []), (10, "slow", []), (8, "medium", [])])
+def test_subpel_seam_encode_on_gpu_phase_planes_is_byte_identical(depth, preset, extra):
+    """The sub-sample seam on the product path: x265hip_phase_cache's planes serve MotionEstimate::subpelCompare of the real encoder;
+    every served call is re-evaluated by the reference's own (interpolating) function in flight."""
+    import test_seam_cpu as T
+    opts = [("pools", "4"), ("frame-threads", "1"), ("crf", "24")] + extra
+    base, got, rep = T.run_pair(depth, 256, 192, 5, preset, opts, "gpu", rng=20, verify=True, wait=True, subpel="gpu")
+    sub = rep["subpel_seam"]
+    assert got[0] == base[0], f"seam changed the bitstream: {rep}"
+    assert sub["verify_mismatches"] == 0 and rep["verify_mismatches"] == 0 and sub["failed"] == 0
+    assert sub["subpel_compares_served"] > 500 and sub["fills"] >= 2, sub

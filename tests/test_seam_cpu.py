@@ -21,7 +21,7 @@ def _tools():
     return encoder_bench, seam_driver
 
 
-def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False, lookahead=None):
+def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False, lookahead=None, subpel=None):
     EB, SD = _tools()
     try:
         plain = EB.ref_lib(depth)
@@ -31,7 +31,8 @@ def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify
     clip = F.synth_clip(w, h, nframes, depth=depth, seed=seed)
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
     base = EB.encode(plain, yuv, w, h, nframes, preset, opts)
-    lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=8, min_pu=min_pu, verify=verify, wait=wait, lookahead=lookahead)
+    lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=8, min_pu=min_pu, verify=verify, wait=wait, lookahead=lookahead,
+                                                  subpel=subpel)
     try:
         got = EB.encode(lib, yuv, w, h, nframes, preset, opts, filler)
         rep = report()
@@ -85,3 +86,27 @@ def test_lookahead_seam_encode_is_byte_identical(depth, preset, extra):
     la = rep["lookahead_seam"]
     assert la["frame_cost_estimates_served"] >= 10 and la["intra_estimates_served"] >= 12 and la["failed"] == 0, la
     assert rep["verify_mismatches"] == 0
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("depth,preset,extra", [(8, "slow", [("me", "star")]), (8, "medium", []), (8, "slower", []), (10, "slow", []), (8, "veryfast", []),
+                                                (8, "slow", [("subme", "7")]), (8, "medium", [("no-weightp", None), ("bframes", "0")])])
+def test_subpel_seam_encode_is_byte_identical_and_every_compare_verified(depth, preset, extra):
+    """The sub-sample seam: MotionEstimate::subpelCompare reads blocks of precomputed phase planes (here the oracle's, computed from
+    its interpolation primitives; tests/test_gpu_seam.py plugs in x265hip_phase_cache) instead of interpolating per candidate; every
+    served call is re-evaluated by the reference's own function on the spot."""
+    opts = [("pools", "4"), ("frame-threads", "1"), ("crf", "24")] + extra
+    base, got, rep = run_pair(depth, 192, 128, 5, preset, opts, "oracle", rng=16, subpel="oracle")
+    sub = rep["subpel_seam"]
+    assert got[0] == base[0], f"seam changed the bitstream: {rep}"
+    assert sub["verify_mismatches"] == 0 and rep["verify_mismatches"] == 0
+    assert sub["subpel_compares_served"] > 500, sub
+    assert sub["pictures_submitted"] >= 2 and sub["passed_on_planes_not_arrived"] == 0
+
+
+@pytest.mark.reference
+def test_subpel_seam_stays_out_of_the_way_with_frame_threads():
+    opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24")]
+    base, got, rep = run_pair(8, 192, 128, 5, "medium", opts, "oracle", rng=16, subpel="oracle")
+    assert got[0] == base[0]
+    assert rep["subpel_seam"]["subpel_compares_served"] == 0 and rep["subpel_seam"]["pictures_submitted"] == 0

@@ -113,7 +113,8 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
                 continue
             from tools import seam_driver as SD
             enc_lib, filler, note, closer, _ = SD.install(depth, w, h, provider="gpu", rng=seam["range"], slots=seam["slots"], min_pu=seam["min_pu"],
-                                                          verify=seam["verify"], lookahead="gpu" if seam.get("lookahead") else None)
+                                                          verify=seam["verify"], lookahead="gpu" if seam.get("lookahead") else None,
+                                                          subpel="gpu" if seam.get("subpel") else None, subpel_slots=seam.get("subpel_slots", 6))
         t0 = time.perf_counter()
         md5, nbytes, sec, filled = encode(enc_lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
         wall = time.perf_counter() - t0
@@ -153,8 +154,12 @@ def main():
     ap.add_argument("--seam-verify", action="store_true", help="check every lookup against the C primitive in flight (slow)")
     ap.add_argument("--seam-lookahead", action="store_true",
                     help="also serve CostEstimateGroup::estimateFrameCost's block loop from x265hip_lowres_cost_host (adds --lookahead-slices 1 to every leg)")
+    ap.add_argument("--seam-subpel", action="store_true",
+                    help="also serve MotionEstimate::subpelCompare from x265hip_phase_cache (every fractional phase of a reference picture interpolated once)")
+    ap.add_argument("--seam-subpel-slots", type=int, default=6, help="reference pictures whose phase planes stay in pinned host memory (450 MB each at 4K 8-bit)")
     args = ap.parse_args()
-    seam = {"range": args.seam_range, "slots": args.seam_slots, "min_pu": args.seam_min_pu, "verify": args.seam_verify, "lookahead": args.seam_lookahead}
+    seam = {"range": args.seam_range, "slots": args.seam_slots, "min_pu": args.seam_min_pu, "verify": args.seam_verify, "lookahead": args.seam_lookahead,
+            "subpel": args.seam_subpel, "subpel_slots": args.seam_subpel_slots}
     out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s, seam=seam) for k in args.configs.split(",")}
     print(json.dumps({"encoder": out}))
 

@@ -1,0 +1,56 @@
+"""Where does the real x265 (C primitives) spend its worker time, per family of EncoderPrimitives slots?  Runs one encode of a
+tools/encoder_bench.py configuration with oracle/ref_profile.cpp's cycle-counting thunks in the table and prints each family's share
+of the process CPU time.  Test infrastructure (needs oracle/_ref); used to rank what to take off the CPU next."""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from tools import encoder_bench as EB          # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--frames", type=int, default=3)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the picture (the 8-vCPU container cannot do 4K in reasonable time)")
+    a = ap.parse_args()
+    F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+    cfg = EB.CONFIGS[a.config]
+    w, h, depth = int(cfg["width"] * a.scale) // 16 * 16, int(cfg["height"] * a.scale) // 16 * 16, cfg["depth"]
+    clip = F.synth_clip(w, h, a.frames, depth=depth, seed=265)
+    yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
+    lib = EB.ref_lib(depth)
+    cores = EB.effective_cpus()
+    opts = [("pools", str(cores)), ("frame-threads", "1"), ("crf", "28")] + cfg["opts"]
+    filler = ctypes.cast(lib.x265ref_profile_fill_table, ctypes.c_void_p)
+    lib.x265ref_profile_tsc.restype = ctypes.c_uint64
+    t0, c0, tsc0 = time.perf_counter(), time.process_time(), lib.x265ref_profile_tsc()
+    md5, nbytes, sec, filled = EB.encode(lib, yuv, w, h, a.frames, cfg["preset"], opts, filler)
+    wall, cpu, tsc = time.perf_counter() - t0, time.process_time() - c0, lib.x265ref_profile_tsc() - tsc0
+    hz = tsc / wall
+    cyc, cnt, names = (ctypes.c_uint64 * 32)(), (ctypes.c_uint64 * 32)(), (ctypes.c_char_p * 32)()
+    lib.x265ref_profile_report.argtypes = [ctypes.c_void_p] * 3
+    n = lib.x265ref_profile_report(cyc, cnt, names)
+    rows = sorted(((names[i].decode(), cyc[i] / hz, int(cnt[i])) for i in range(n)), key=lambda r: -r[1])
+    inside = sum(r[1] for r in rows)
+    print(f"# {a.config} {w}x{h} {depth}-bit preset {cfg['preset']} {dict(cfg['opts'])}, {a.frames} frames, {cores} pool threads: {a.frames / sec:.3f} fps, "
+          f"process CPU {cpu:.2f} s, wall {wall:.2f} s, {filled} slots wrapped (C primitives, -O3, no asm)")
+    print(f"# {'family':44s} {'CPU s':>8s} {'% of CPU':>9s} {'calls':>12s} {'ns/call':>9s}")
+    for name, s, c in rows:
+        if c:
+            print(f"  {name:44s} {s:8.3f} {100 * s / cpu:8.1f}% {c:12d} {1e9 * s / c:9.0f}")
+    print(f"  {'(all wrapped primitives)':44s} {inside:8.3f} {100 * inside / cpu:8.1f}%")
+    print(f"  {'(encoder code outside the table)':44s} {cpu - inside:8.3f} {100 * (cpu - inside) / cpu:8.1f}%")
+
+
+if __name__ == "__main__":
+    main()

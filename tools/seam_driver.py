@@ -29,7 +29,8 @@ def geometry(width, height):
     """PicYuv layout for --ctu 64 (common/picyuv.cpp:87-114): whole CTUs, margins ctu + 32 / ctu + 16."""
     w64, h64 = (width + 63) // 64 * 64, (height + 63) // 64 * 64
     mx, my = 64 + 32, 64 + 16
-    return dict(width=w64, height=h64, stride=w64 + 2 * mx, margin_x=mx, margin_y=my)
+    return dict(width=w64, height=h64, stride=w64 + 2 * mx, margin_x=mx, margin_y=my,
+                rows=h64 + 2 * my, stride_c=w64 // 2 + 2 * mx, rows_c=h64 // 2 + 2 * (my >> 1))
 
 
 def seam_lib(depth):
@@ -157,7 +158,103 @@ class GpuProvider:
             self.handle = None
 
 
-def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None):
+PH_SUBMIT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+PH_PLANES = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
+PH_READY = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
+SUB_STAT_NAMES = ("subpel_compares_served", "passed_on_planes_not_arrived", "searches_without_context", "pictures_submitted", "verify_mismatches",
+                  "searches_without_slot")
+
+
+class OraclePhaseProvider:
+    """CPU stand-in for x265hip_phase_cache (checker only): the oracle's phase planes, computed synchronously inside submit."""
+
+    def __init__(self, depth, geo, slots):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_api
+        self.O, self.depth, self.geo, self.slots = oracle_api, depth, geo, slots
+        self.dt = np.uint8 if depth == 8 else np.uint16
+        g = geo
+        self.out = [[np.zeros((15, g["rows"], g["stride"]), self.dt)] + [np.zeros((63, g["rows_c"], g["stride_c"]), self.dt) for _ in range(2)]
+                    for _ in range(slots)]
+        self.flags = [np.zeros(2, np.int32) for _ in range(slots)]
+        self.gen = [0] * slots
+        self.fills = 0
+        self._cb = (PH_SUBMIT(self._submit), PH_PLANES(self._planes), PH_READY(self._ready))
+
+    def _view(self, ptr, n):
+        raw = (ctypes.c_uint8 * (n * np.dtype(self.dt).itemsize)).from_address(ptr)
+        return np.frombuffer(raw, dtype=self.dt)
+
+    def _submit(self, ctx, slot, luma, cb, cr):
+        g = self.geo
+        self.out[slot][0][:] = self.O.phase_planes(self.depth, self._view(luma, g["stride"] * g["rows"]), g["stride"], g["rows"])
+        for k, ptr in ((1, cb), (2, cr)):
+            self.out[slot][k][:] = self.O.phase_planes(self.depth, self._view(ptr, g["stride_c"] * g["rows_c"]), g["stride_c"], g["rows_c"], chroma=True)
+        self.gen[slot] += 1
+        self.flags[slot][:] = self.gen[slot]
+        self.fills += 1
+        return self.gen[slot]
+
+    def _planes(self, ctx, slot, plane):
+        return self.out[slot][plane].ctypes.data
+
+    def _ready(self, ctx, slot):
+        return self.flags[slot].ctypes.data
+
+    def pointers(self):
+        return (None,) + tuple(ctypes.cast(c, ctypes.c_void_p) for c in self._cb)
+
+    def report(self):
+        return {"provider": "oracle (CPU checker)", "fills": self.fills}
+
+    def close(self):
+        pass
+
+
+class PhaseCacheParams(ctypes.Structure):
+    """x265hip_phase_cache_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("stride", ctypes.c_ssize_t), ("rows", ctypes.c_int), ("stride_c", ctypes.c_ssize_t), ("rows_c", ctypes.c_int),
+                ("slots", ctypes.c_int)]
+
+
+class PhaseCacheStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("fills", "failed", "us_upload_kernel", "us_download", "bytes_downloaded", "bytes_per_picture")]
+
+
+class GpuPhaseProvider:
+    """libx265hip.so's x265hip_phase_cache: the product path."""
+
+    def __init__(self, depth, geo, slots):
+        A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+        self.L = A.lib()
+        p = PhaseCacheParams(depth, geo["stride"], geo["rows"], geo["stride_c"], geo["rows_c"], slots)
+        self.handle = ctypes.c_void_p()
+        self.L.x265hip_phase_cache_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(PhaseCacheParams)]
+        A.check(self.L.x265hip_phase_cache_create(ctypes.byref(self.handle), ctypes.byref(p)), "x265hip_phase_cache_create")
+        self.L.x265hip_phase_cache_destroy.argtypes = [ctypes.c_void_p]
+        self.L.x265hip_phase_cache_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(PhaseCacheStats)]
+
+    def pointers(self):
+        L = self.L
+        return (self.handle, ctypes.cast(L.x265hip_phase_cache_submit, ctypes.c_void_p), ctypes.cast(L.x265hip_phase_cache_planes, ctypes.c_void_p),
+                ctypes.cast(L.x265hip_phase_cache_ready, ctypes.c_void_p))
+
+    def report(self):
+        st = PhaseCacheStats()
+        self.L.x265hip_phase_cache_stats(self.handle, ctypes.byref(st))
+        n = max(1, st.fills)
+        return {"provider": "x265hip_phase_cache (15 luma + 2 x 63 chroma phase planes per reference picture, one x265hip_phase_planes launch per plane)",
+                "fills": int(st.fills), "failed": int(st.failed), "mbytes_per_picture": round(st.bytes_per_picture / 1e6, 1),
+                "ms_per_picture": {"upload_and_kernels": round(st.us_upload_kernel / n / 1e3, 3), "download": round(st.us_download / n / 1e3, 3)},
+                "download_gbytes_per_s": round(st.bytes_downloaded / max(1, st.us_download) / 1e3, 2)}
+
+    def close(self):
+        if self.handle:
+            self.L.x265hip_phase_cache_destroy(self.handle)
+            self.handle = None
+
+
+def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6):
     """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) using
     --frame-threads 1 and --ctu 64."""
     lib = seam_lib(depth)
@@ -184,6 +281,20 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     else:
         lib.x265ref_lookahead_seam_configure(None, None, None, None)
 
+    # the sub-sample seam (MotionEstimate::subpelCompare reads precomputed phase planes): "gpu" = x265hip_phase_cache, "oracle" = CPU checker
+    lib.x265ref_subpel_seam_configure.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int]
+    lib.x265ref_subpel_seam_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    sub = None
+    if subpel:
+        sub = (GpuPhaseProvider if subpel == "gpu" else OraclePhaseProvider)(depth, geo, subpel_slots)
+        sctx, ssub, spl, srd = sub.pointers()
+        rc = lib.x265ref_subpel_seam_configure(sctx, ssub, spl, srd, subpel_slots, geo["stride"], geo["rows"], geo["stride_c"], geo["rows_c"],
+                                               int(bool(verify)) | (2 if wait else 0))
+        if rc:
+            raise RuntimeError(f"x265ref_subpel_seam_configure failed ({rc})")
+    else:
+        lib.x265ref_subpel_seam_configure(None, None, None, None, 0, 0, 0, 0, 0, 0)
+
     def report():
         d = stats(lib)
         d.update(prov.report())
@@ -192,10 +303,17 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
         lib.x265ref_lookahead_seam_stats(la)
         d["lookahead_seam"] = {"provider": lookahead, "frame_cost_estimates_served": int(la[0]), "passed_to_reference_loop": int(la[1]), "failed": int(la[2]),
                                "intra_estimates_served": int(la[3])}
+        if sub:
+            so = (ctypes.c_uint64 * 6)()
+            lib.x265ref_subpel_seam_stats(so)
+            d["subpel_seam"] = dict(zip(SUB_STAT_NAMES, [int(v) for v in so]))
+            d["subpel_seam"].update(sub.report())
         return d
 
     def close():
         lib.x265ref_seam_disable()
         prov.close()
+        if sub:
+            sub.close()
     close.keep = keep            # the oracle library must outlive the encode
     return lib, filler, report, close, prov

@@ -721,3 +721,19 @@ def pixelcmp_batch(kind, depth, w, h, a, a_stride, b, b_stride, njobs, out,
                                        a.data_ptr() + a_base * es, a_stride, _p(a_off), a_step,
                                        b.data_ptr() + b_base * es, b_stride, _p(b_off), b_step,
                                        njobs, out.data_ptr(), s), "x265hip_pixelcmp_batch")
+
+
+class PhasePlanesParams(ctypes.Structure):
+    """x265hip_phase_planes_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("chroma", ctypes.c_int), ("src", ctypes.c_void_p), ("dst", ctypes.c_void_p),
+                ("stride", ctypes.c_ssize_t), ("rows", ctypes.c_int)]
+
+
+def phase_planes(depth, src, src_off_bytes, dst, stride, rows, chroma=False, stream=None):
+    """x265hip_phase_planes: every fractional phase of one padded plane.  src: device byte tensor that holds the plane at byte
+    offset src_off_bytes with >= 4 rows + 64 B of readable memory before it and 8 rows after it; dst: 15 (luma) / 63 (chroma) planes."""
+    p = PhasePlanesParams(depth, int(bool(chroma)), src.data_ptr() + src_off_bytes, dst.data_ptr(), stride, rows)
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_phase_planes
+    f.argtypes = [ctypes.POINTER(PhasePlanesParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_phase_planes")
