@@ -243,8 +243,9 @@ def main():
     ap.add_argument("--qp", type=int, default=27)
     ap.add_argument("--depth", type=int, default=8, choices=[8, 10], help="10 = the Main10 configurations (configs[3], [4])")
     ap.add_argument("--no-surface", action="store_true", help="ME keeps only the best mv (no SAD surfaces)")
-    ap.add_argument("--surf-format", choices=["packed", "i32"], default="packed",
-                    help="SAD surface records: packed = u16 for the 8x8/16x16 levels (X265HIP_SURF_PACKED), i32 = all int32")
+    ap.add_argument("--surf-format", choices=["packed_t", "packed", "i32"], default="packed_t",
+                    help="SAD surface records: packed = u16 for the 8x8/16x16 levels (X265HIP_SURF_PACKED), packed_t = the same records chunk-major "
+                         "inside a motion-vector row (X265HIP_SURF_PACKED_T, the record-per-lane kernel), i32 = all int32")
     ap.add_argument("--search", choices=["full", "dia", "hex", "umh", "star", "sea"], default="full",
                     help="full = exhaustive search (SAD surfaces + best mv) + sub-pel stage; dia/hex/umh/star/sea = the reference's pattern "
                          "searches run by the device-side search driver (x265hip_me_search), predictor (0,0)")
@@ -306,7 +307,7 @@ def main():
     clip = F.synth_clip(args.width, args.height, nclip, depth=args.depth, seed=265 + rank)
     pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
-                           qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed" and args.depth == 8,
+                           qp=args.qp, want_surf=not args.no_surface, packed=({"packed": True, "packed_t": "t"}.get(args.surf_format, False) if args.depth == 8 else False),
                            lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True, lookahead_cost_batch=args.lookahead_batch,
                            chroma=True, sao_apply=True, sign_hide=True)
     ref_pic = pics[0].like([p.clone() for p in pics[0].planes()])     # the reference every rank searches in (starts as frame 0): Y, Cb, Cr
@@ -315,7 +316,7 @@ def main():
     if banded:
         # N > 1: the reference's real frame-parallel dependency - frame f (rank f % N) searches frame f - 1, band by band (pipeline.FrameParallelRing)
         bp = S.BandedFramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, band_rows=args.band_rows, rng=args.range, subme=args.subme, level=args.level,
-                                   qp=args.qp, want_surf=not args.no_surface, packed=args.surf_format == "packed" and args.depth == 8,
+                                   qp=args.qp, want_surf=not args.no_surface, packed=({"packed": True, "packed_t": "t"}.get(args.surf_format, False) if args.depth == 8 else False),
                                    lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True)
         ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16)      # search window + 8-tap interpolation + sub-pel drift
         ring.make_groups()
@@ -401,14 +402,14 @@ def main():
         dom = "me"
         alg_bytes = ms.algorithmic_bytes(bpp=1 if args.depth == 8 else 2)
         achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9
-        traffic, tsrc = load_traffic(args.width, args.height, args.range, ('packed' if ms.packed else 'i32') + ('' if args.depth == 8 else '_d10')) if surf_mode else (None, None)
+        traffic, tsrc = load_traffic(args.width, args.height, args.range, (('packed_t' if ms.tiled else 'packed') if ms.packed else 'i32') + ('' if args.depth == 8 else '_d10')) if surf_mode else (None, None)
         out = {
             "metric": "encoded fps + bit-exact check, 4K preset=slow, 1/2/4/8 MI355X vs host AVX2",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8" if args.depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": f"{args.width}x{args.height} {args.depth}-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: lookahead lowres planes + intra estimate (+ P-frame cost estimate vs the previous picture, " + (f"{args.lookahead_batch} pictures per launch on a side stream" if args.lookahead_batch else "off") + ") -> " +
-                                   (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + ('packed' if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
+                                   (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + (('packed chunk-major' if ms.tiled else 'packed') if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
                                     f"sub-pel subme={args.subme} -> " if args.search == "full" else
                                     f"{args.search} search driver (motionEstimate, merange {args.range}, subme {args.subme}, predictor 0) for all 85 PUs/CTU -> ") +
                                    f"{8 << args.level}x{8 << args.level} luma + 4:2:0 chroma prediction + DCT/quant (sign-bit hiding on)/recon qp {args.qp} -> luma + chroma deblocking -> "
@@ -421,7 +422,8 @@ def main():
                        "ctus_per_frame": ms.nctu, "checksum": csum},
             "stages_ms": stages,
             "roofline": {"bound": "hbm", "kernel": "me_search_kernel" if args.search != "full" else
-                                   ("me_ctu_q_kernel" if args.depth == 8 else "me_ctu_w_kernel") + ("<surf,best>" if surf_mode else "<best>"),
+                                   (("me_ctu_c_kernel" if surf_mode and args.surf_format == "packed_t" else "me_ctu_q_kernel") if args.depth == 8 else "me_ctu_w_kernel")
+                                   + ("<surf,best>" if surf_mode else "<best>"),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                          "algorithmic_bytes_per_launch": alg_bytes, "output_bytes_per_launch": ms.hbm_floor_bytes(1 if args.depth == 8 else 2),

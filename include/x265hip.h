@@ -97,6 +97,11 @@ int x265hip_pixelcmp_batch(int kind, int depth, int w, int h,
  *                X265HIP_SURF_PACKED (8-bit only): 720 bytes per (ctu, mvy, group) -
  *                uint16 [64][4] 8x8 SADs (<= 16320), uint16 [16][4] 16x16 SADs (<= 65280), int32 [4][4] 32x32,
  *                int32 [1][4] 64x64; same values, 47 % fewer bytes through HBM (the search is write-bound).
+ *                X265HIP_SURF_PACKED_T (8-bit only): the packed record cut into its 45 16-byte chunks and stored CHUNK-MAJOR inside
+ *                a motion-vector row: chunk c of group g at row + (c * groups + g) * 16, row = ((ctu * (2*range+1) + mvy) * groups) * 720.
+ *                Same bytes per row; the 4 x 4 = 16 horizontal displacements of 4 neighbouring groups of one PU pair share a
+ *                cache line (a search that walks in x stays in it), and the kernel that owns one record per lane
+ *                (csrc/me_cand_kernel.hip) stores 16 contiguous bytes per lane.
  *   best       : optional per-PU minimum of (sad + cost_x[mvx] + cost_y[mvy]), uint64 [ctu][85] (same
  *                PU order) = cost << 32 | (mvy_index * (2*range+1) + mvx_index); must be pre-set to
  *                all-ones by the caller (x265hip_me_best_reset).  Ties resolve to the smallest raster
@@ -116,7 +121,7 @@ typedef struct x265hip_me_params
     const uint16_t* cost_y;
     int surf_format;                /* X265HIP_SURF_* */
 } x265hip_me_params;
-enum { X265HIP_SURF_I32 = 0, X265HIP_SURF_PACKED = 1 };
+enum { X265HIP_SURF_I32 = 0, X265HIP_SURF_PACKED = 1, X265HIP_SURF_PACKED_T = 2 };
 #define X265HIP_SURF_GROUP_BYTES_I32    1360
 #define X265HIP_SURF_GROUP_BYTES_PACKED 720
 int x265hip_me_fullsearch(const x265hip_me_params* p, void* stream);
@@ -704,7 +709,7 @@ typedef struct x265hip_me_cache_params
     intptr_t stride;
     int margin_x, margin_y;
     int range;
-    int surf_format;                /* X265HIP_SURF_PACKED (8-bit) or X265HIP_SURF_I32 */
+    int surf_format;                /* X265HIP_SURF_PACKED / X265HIP_SURF_PACKED_T (8-bit) or X265HIP_SURF_I32 */
     int slots;
 } x265hip_me_cache_params;
 typedef struct x265hip_me_cache_stats_t
@@ -732,15 +737,19 @@ int  x265hip_me_cache_stats(x265hip_me_cache* c, x265hip_me_cache_stats_t* st);
 static inline int32_t x265hip_surf_lookup(const void* surf, int surf_format, int range, int ctu, int level, int z, int dx, int dy)
 {
     const int nc = 2 * range + 1, ng = (nc + 3) >> 2, col = dx + range;
-    const size_t gb = surf_format == X265HIP_SURF_PACKED ? X265HIP_SURF_GROUP_BYTES_PACKED : X265HIP_SURF_GROUP_BYTES_I32;
-    const unsigned char* g = (const unsigned char*)surf + (((size_t)ctu * nc + (size_t)(dy + range)) * ng + (size_t)(col >> 2)) * gb;
-    if (surf_format == X265HIP_SURF_PACKED)
+    if (surf_format == X265HIP_SURF_I32)
     {
-        if (level < 2) return ((const uint16_t*)(g + (level ? 512 : 0)))[z * 4 + (col & 3)];
-        return ((const int32_t*)(g + (level == 2 ? 640 : 704)))[z * 4 + (col & 3)];
+        static const int base[4] = { 0, 64, 80, 84 };
+        const unsigned char* g = (const unsigned char*)surf + (((size_t)ctu * nc + (size_t)(dy + range)) * ng + (size_t)(col >> 2)) * X265HIP_SURF_GROUP_BYTES_I32;
+        return ((const int32_t*)g)[(base[level] + z) * 4 + (col & 3)];
     }
-    static const int base[4] = { 0, 64, 80, 84 };
-    return ((const int32_t*)g)[(base[level] + z) * 4 + (col & 3)];
+    /* byte offset of the value inside the 720-byte packed record */
+    static const int pbase[4] = { 0, 512, 640, 704 };
+    const size_t o = (size_t)pbase[level] + (size_t)(z * 4 + (col & 3)) * (level < 2 ? 2 : 4);
+    const unsigned char* row = (const unsigned char*)surf + ((size_t)ctu * nc + (size_t)(dy + range)) * ng * X265HIP_SURF_GROUP_BYTES_PACKED;
+    const unsigned char* v = surf_format == X265HIP_SURF_PACKED_T ? row + ((o >> 4) * ng + (size_t)(col >> 2)) * 16 + (o & 15)
+                                                                   : row + (size_t)(col >> 2) * X265HIP_SURF_GROUP_BYTES_PACKED + o;
+    return level < 2 ? *(const uint16_t*)v : *(const int32_t*)v;
 }
 
 

@@ -104,7 +104,7 @@ struct LookaheadSeam
 
 struct MeCostProbe : public MotionEstimate { const uint16_t* costCentre() const { return m_cost; } };
 
-enum { SURF_I32 = 0, SURF_PACKED = 1, GROUP_I32 = 1360, GROUP_PACKED = 720, MAX_PARTS = 6, MAX_SLOTS = 64 };
+enum { SURF_I32 = 0, SURF_PACKED = 1, SURF_PACKED_T = 2, GROUP_I32 = 1360, GROUP_PACKED = 720, MAX_PARTS = 6, MAX_SLOTS = 64 };
 
 struct Provider
 {
@@ -175,11 +175,13 @@ bool decompose(int px, int py, int w, int h, int bx, int by, int size, Ctx& c)
         int z = 0;
         for (int b = 0; b < 3; b++) z |= ((ux >> b) & 1) << (2 * b) | ((uy >> b) & 1) << (2 * b + 1);
         Part& q = c.parts[c.nparts++];
-        if (g.p.surf_format == SURF_PACKED)
+        if (g.p.surf_format != SURF_I32)
         {
             static const int base[4] = { 0, 512, 640, 704 };
             q.wide = level >= 2;
-            q.off = (uint16_t)(base[level] + z * (q.wide ? 16 : 8));
+            const int o = base[level] + z * (q.wide ? 16 : 8);            /* byte offset inside the 720-byte packed record */
+            /* chunk-major rows (X265HIP_SURF_PACKED_T): 16-byte chunk c of group g sits at row + (c * groups + g) * 16 */
+            q.off = (uint16_t)(g.p.surf_format == SURF_PACKED_T ? (o >> 4) * g.ng * 16 + (o & 15) : o);
         }
         else
         {
@@ -217,7 +219,8 @@ inline bool lookup(Ctx& c, const pixel* fref, int& out)
         if (!arrived) { c.notReady++; return false; }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    const uint8_t* rec = c.ctuBase + (row * g.ng + (col >> 2)) * g.groupBytes;
+    const uint8_t* rec = g.p.surf_format == SURF_PACKED_T ? c.ctuBase + row * g.ng * g.groupBytes + (col >> 2) * 16
+                                                           : c.ctuBase + (row * g.ng + (col >> 2)) * g.groupBytes;
     const int k = (int)(col & 3);
     int sum = 0;
     for (int i = 0; i < c.nparts; i++)
@@ -773,7 +776,8 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
                            int width, int height, intptr_t stride, int margin_x, int margin_y, int min_pu, int verify)
 {
     if (slots < 1 || slots > MAX_SLOTS || range < 1 || (width & 63) || (height & 63)) return -1;
-    if (surf_format == SURF_PACKED && X265_DEPTH != 8) return -2;
+    if (surf_format != SURF_I32 && X265_DEPTH != 8) return -2;
+    if (surf_format == SURF_PACKED_T && 45 * ((2 * range + 4) / 4) * 16 > 65535) return -3;          /* Part::off is 16 bits */
     g.p.ctx = ctx;
     g.p.submit = (int (*)(void*, int, const void*, uint64_t, const void*))submit;
     g.p.submit_batch = (int (*)(void*, int, const int*, const void*, uint64_t, const void* const*, int*))submit_batch;      /* may be NULL */
@@ -783,7 +787,7 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
     g.p.width = width; g.p.height = height; g.p.stride = stride; g.p.margin_x = margin_x; g.p.margin_y = margin_y;
     g.p.min_pu = min_pu < 8 ? 8 : min_pu;
     g.nc = 2 * range + 1; g.ng = (g.nc + 3) >> 2;
-    g.groupBytes = surf_format == SURF_PACKED ? GROUP_PACKED : GROUP_I32;
+    g.groupBytes = surf_format == SURF_I32 ? GROUP_I32 : GROUP_PACKED;
     g.ctusW = width / 64;
     g.ctuBytes = (size_t)g.nc * g.ng * g.groupBytes;
     memset(g.pairs, 0, sizeof(g.pairs));

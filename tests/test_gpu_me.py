@@ -77,6 +77,41 @@ def test_me_packed_surface_format():
     _run(256, 64, 57, 8, seed=4, packed=True)
 
 
+@pytest.mark.parametrize("case", [(128, 128, 8, 1, None), (200, 136, 12, 2, None), (128, 64, 5, 3, "flat"), (256, 64, 57, 4, None), (128, 128, 24, 5, None),
+                                  (64, 64, 1, 6, None), (192, 64, 32, 7, None), (128, 128, 3, 8, "flat")])
+def test_me_chunk_major_packed_format_record_per_lane_kernel(case):
+    """X265HIP_SURF_PACKED_T: written by the record-per-lane kernel (csrc/me_cand_kernel.hip) - surfaces and minima against the oracle,
+    ranges from one candidate group (a single live lane group) to the default merange and beyond one LDS bank period."""
+    w, h, rng, seed, extreme = case
+    _run(w, h, rng, 8, seed=seed, extreme=extreme, packed="t")
+
+
+def test_me_record_per_lane_kernel_serves_the_other_formats(monkeypatch):
+    """X265HIP_ME_KERNEL=cand routes every 8-bit launch to the record-per-lane kernel: int32 and record-contiguous packed surfaces,
+    minima alone, surfaces alone."""
+    import torch
+    monkeypatch.setenv("X265HIP_ME_KERNEL", "cand")
+    _run(128, 128, 8, 8, seed=21)
+    _run(200, 136, 12, 8, seed=22, packed=True)
+    _run(256, 64, 57, 8, seed=23)
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(192, 128, 2, depth=8, seed=24)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    O = _oracle()
+    for kw in (dict(want_surf=False), dict(want_best=False, packed="t"), dict(want_best=False)):
+        ms = P.MotionSearch(cur.w64, cur.h64, 14, 8, dev, **kw)
+        ms.run(cur, ref)
+        torch.cuda.synchronize()
+        surf, best = O.me_fullsearch(8, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, 14, 0, ms.nctu, ms.cost_host, ms.cost_host)
+        if ms.best is not None:
+            assert np.array_equal(ms.best.cpu().numpy().view(np.uint64), best)
+        if ms.surf is not None:
+            e = _valid(surf, ms)
+            for level in range(4):
+                b, n = P.LEVEL_BASE[level], P.LEVEL_PUS[level]
+                assert np.array_equal(ms.level_view(level)[0].cpu().numpy(), e[:, :, b:b + n].reshape(-1, n)), f"{kw} level {level}"
+
+
 def test_me_packed_surface_rejected_for_high_bit_depth():
     import torch
     dev = torch.device("cuda:0")

@@ -26,12 +26,12 @@ def _oracle():
     return oracle_api
 
 
-@pytest.mark.parametrize("depth,width,height,rng", [(8, 256, 192, 20), (8, 200, 136, 57), (10, 256, 128, 16)])
-def test_me_cache_surfaces_equal_oracle(depth, width, height, rng):
+@pytest.mark.parametrize("depth,width,height,rng,fmt", [(8, 256, 192, 20, 1), (8, 200, 136, 57, 1), (10, 256, 128, 16, 0), (8, 256, 192, 20, 2), (8, 200, 136, 57, 2)])
+def test_me_cache_surfaces_equal_oracle(depth, width, height, rng, fmt):
     from tools import seam_driver as SD
     O = _oracle()
     geo = SD.geometry(width, height)
-    prov = SD.GpuProvider(depth, geo, rng, 2)
+    prov = SD.GpuProvider(depth, geo, rng, 2, fmt)
     try:
         clip = F.synth_clip(width, height, 3, depth=depth, seed=51)
         planes = [F.pad_plane(y)[0] for (y, _, _) in clip]
@@ -63,8 +63,11 @@ def test_me_cache_surfaces_equal_oracle(depth, width, height, rng):
             e = cols(surf.reshape(nctu, nc, ng, 85, 4))
             gb = 720 if depth == 8 else 1360
             raw = np.ctypeslib.as_array((ctypes.c_uint8 * (nctu * nc * ng * gb)).from_address(L.x265hip_me_cache_surface(prov.handle, slot)))
-            raw = raw.reshape(nctu, nc, ng, gb)
-            if depth == 8:      # X265HIP_SURF_PACKED
+            if fmt == 2:        # X265HIP_SURF_PACKED_T: [chunk 45][group][16 B] inside a motion-vector row -> record-contiguous
+                raw = raw.reshape(nctu, nc, 45, ng, 16).transpose(0, 1, 3, 2, 4).reshape(nctu, nc, ng, gb)
+            else:
+                raw = raw.reshape(nctu, nc, ng, gb)
+            if depth == 8:
                 g8 = raw[..., 0:512].copy().view(np.uint16).reshape(nctu, nc, ng, 64, 4)
                 g16 = raw[..., 512:640].copy().view(np.uint16).reshape(nctu, nc, ng, 16, 4)
                 g32 = raw[..., 640:720].copy().view(np.int32).reshape(nctu, nc, ng, 5, 4)
@@ -77,12 +80,14 @@ def test_me_cache_surfaces_equal_oracle(depth, width, height, rng):
         prov.close()
 
 
-@pytest.mark.parametrize("depth,preset,extra", [(8, "medium", []), (8, "slow", [("me", "star")]), (8, "slower", []), (10, "medium", [])])
-def test_seam_encode_on_gpu_surfaces_is_byte_identical(depth, preset, extra):
+@pytest.mark.parametrize("depth,preset,extra,fmt", [(8, "medium", [], None), (8, "slow", [("me", "star")], None), (8, "slower", [], None), (10, "medium", [], None),
+                                                    (8, "slow", [("me", "star")], 2), (8, "slower", [], 2)])
+def test_seam_encode_on_gpu_surfaces_is_byte_identical(depth, preset, extra, fmt):
+    """fmt 2 = X265HIP_SURF_PACKED_T: the lookups walk the chunk-major rows the record-per-lane kernel writes."""
     import test_seam_cpu as T
     opts = [("pools", "4"), ("frame-threads", "1"), ("crf", "24"), ("no-weightp", None), ("no-weightb", None)] + extra
     # wait=True: a 256x192 picture is encoded faster than its surfaces travel; the test mode lets the lookups wait for their rows
-    base, got, rep = T.run_pair(depth, 256, 192, 5, preset, opts, "gpu", rng=20, verify=True, wait=True)
+    base, got, rep = T.run_pair(depth, 256, 192, 5, preset, opts, "gpu", rng=20, verify=True, wait=True, surf_format=fmt)
     assert got[0] == base[0], f"seam changed the bitstream: {rep}"
     assert rep["verify"] == 1 and rep["verify_mismatches"] == 0 and rep["failed"] == 0
     assert 1 <= rep["fills"] <= rep["pair_submits"] and rep["pair_submits"] >= 4      # a pair superseded before its turn is skipped

@@ -21,7 +21,7 @@ def _tools():
     return encoder_bench, seam_driver
 
 
-def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False, lookahead=None, subpel=None):
+def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False, lookahead=None, subpel=None, surf_format=None):
     EB, SD = _tools()
     try:
         plain = EB.ref_lib(depth)
@@ -32,7 +32,7 @@ def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
     base = EB.encode(plain, yuv, w, h, nframes, preset, opts)
     lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=8, min_pu=min_pu, verify=verify, wait=wait, lookahead=lookahead,
-                                                  subpel=subpel)
+                                                  subpel=subpel, surf_format=surf_format)
     try:
         got = EB.encode(lib, yuv, w, h, nframes, preset, opts, filler)
         rep = report()

@@ -22,7 +22,7 @@ if ROOT not in sys.path:
 SUBMIT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p)
 SURFACE = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
 READY = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
-SURF_I32, SURF_PACKED = 0, 1
+SURF_I32, SURF_PACKED, SURF_PACKED_T = 0, 1, 2
 
 
 def geometry(width, height):
@@ -126,10 +126,12 @@ class CacheStats(ctypes.Structure):
 class GpuProvider:
     """libx265hip.so's x265hip_me_cache: the product path."""
 
-    def __init__(self, depth, geo, rng, slots):
+    def __init__(self, depth, geo, rng, slots, surf_format=None):
         A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
         self.A, self.L = A, A.lib()
-        self.format = SURF_PACKED if depth == 8 else SURF_I32
+        # 8-bit default: record-contiguous packed rows from the row-walking kernel (surfaces alone: 0.31 ms against 0.39 ms for the
+        # record-per-lane kernel's chunk-major rows at 4K +-24, profiles/r02_me_cand_ab.txt); SURF_PACKED_T on request
+        self.format = surf_format if surf_format is not None else (SURF_PACKED if depth == 8 else SURF_I32)
         p = CacheParams(depth, geo["width"], geo["height"], geo["stride"], geo["margin_x"], geo["margin_y"], rng, self.format, slots)
         self.handle = ctypes.c_void_p()
         self.L.x265hip_me_cache_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(CacheParams)]
@@ -254,12 +256,13 @@ class GpuPhaseProvider:
             self.handle = None
 
 
-def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6):
+def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
+            surf_format=None):
     """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) using
     --frame-threads 1 and --ctu 64."""
     lib = seam_lib(depth)
     geo = geometry(width, height)
-    prov = (GpuProvider if provider == "gpu" else OracleProvider)(depth, geo, rng, slots)
+    prov = GpuProvider(depth, geo, rng, slots, surf_format) if provider == "gpu" else OracleProvider(depth, geo, rng, slots)
     ctx, submit, submit_batch, surface, ready = prov.pointers()
     rc = lib.x265ref_seam_configure(ctx, submit, submit_batch, surface, ready, rng, prov.format, slots, geo["width"], geo["height"], geo["stride"],
                                     geo["margin_x"], geo["margin_y"], min_pu, int(bool(verify)) | (2 if wait else 0))

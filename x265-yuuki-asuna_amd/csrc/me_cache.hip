@@ -178,7 +178,7 @@ int x265hip_me_cache_create(x265hip_me_cache** out, const x265hip_me_cache_param
     { set_error("me_cache_create: range %d needs margins >= range + 12 (have %d / %d)", p->range, p->margin_x, p->margin_y); return X265HIP_EINVAL; }
     if (p->stride < p->width + 2 * p->margin_x) { set_error("me_cache_create: stride %ld < width + 2 * margin_x", (long)p->stride); return X265HIP_EINVAL; }
     if (p->slots < 1 || p->slots > 64) { set_error("me_cache_create: slots %d out of [1,64]", p->slots); return X265HIP_EINVAL; }
-    if (p->surf_format != X265HIP_SURF_I32 && !(p->surf_format == X265HIP_SURF_PACKED && p->depth == 8))
+    if (p->surf_format != X265HIP_SURF_I32 && !((p->surf_format == X265HIP_SURF_PACKED || p->surf_format == X265HIP_SURF_PACKED_T) && p->depth == 8))
     { set_error("me_cache_create: surf_format %d for depth %d", p->surf_format, p->depth); return X265HIP_EINVAL; }
     x265hip_me_cache* c = new (std::nothrow) x265hip_me_cache;
     if (!c) { set_error("me_cache_create: out of memory"); return X265HIP_EINVAL; }
@@ -186,7 +186,7 @@ int x265hip_me_cache_create(x265hip_me_cache** out, const x265hip_me_cache_param
     c->bpp = p->depth == 8 ? 1 : 2;
     c->ctusW = p->width / 64; c->ctusH = p->height / 64;
     c->nc = 2 * p->range + 1; c->ng = (c->nc + 3) / 4;
-    c->groupBytes = p->surf_format == X265HIP_SURF_PACKED ? X265HIP_SURF_GROUP_BYTES_PACKED : X265HIP_SURF_GROUP_BYTES_I32;
+    c->groupBytes = p->surf_format == X265HIP_SURF_I32 ? X265HIP_SURF_GROUP_BYTES_I32 : X265HIP_SURF_GROUP_BYTES_PACKED;
     c->planeBytes = (size_t)p->stride * (p->height + 2 * p->margin_y) * c->bpp;
     c->orgOffset = ((size_t)p->margin_y * p->stride + p->margin_x) * c->bpp;
     c->rowBytes = (size_t)c->ctusW * c->nc * c->ng * c->groupBytes;

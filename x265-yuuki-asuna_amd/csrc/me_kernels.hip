@@ -640,6 +640,8 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
 
 // wavefronts per workgroup: as many as the column count keeps busy (16 = 1024 threads max); the
 // columns are dealt round-robin, so the idle tail is at most one column per wavefront.
+int launch_me_cand(const x265hip_me_params* p, hipStream_t s);       // me_cand_kernel.hip: 0 = launched, 1 = not applicable, < 0 = error
+
 static int pick_waves(int ncols)
 {
     return ncols >= 16 ? 16 : (ncols < 4 ? 4 : ncols);
@@ -676,6 +678,20 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
         if (a.rowBytes == 256) LAUNCH_P(SF, BS, 256); else if (a.rowBytes == 512) LAUNCH_P(SF, BS, 512); \
         else if (a.rowBytes == 1024) LAUNCH_P(SF, BS, 1024); \
         else { set_error("me_fullsearch: range %d needs an LDS row pitch of %d bytes (unsupported)", p->range, a.rowBytes); return X265HIP_EINVAL; } } while (0)
+    // 8-bit: the record-per-lane kernel (me_cand_kernel.hip) owns the chunk-major surface format X265HIP_SURF_PACKED_T; for the
+    // record-contiguous formats and for minima alone the row-walking kernels below are faster (1.76 / 1.34 ms against 3.2 / 1.42 ms at
+    // 4K, profiles/r02_me_cand_ab.txt).  X265HIP_ME_KERNEL=cand forces it for every 8-bit launch (parity tests, A/B).
+    {
+        const char* which = getenv("X265HIP_ME_KERNEL");
+        const bool wantT = p->surf && p->surf_format == X265HIP_SURF_PACKED_T;
+        if (sizeof(Px) == 1 && !p_generic && (wantT || (which && which[0] == 'c')))
+        {
+            const int rc = launch_me_cand(p, s);
+            if (rc <= 0) return rc;
+        }
+        if (wantT)
+        { set_error("me_fullsearch: X265HIP_SURF_PACKED_T is written by the record-per-lane kernel only (depth 8, window within its LDS / step limits)"); return X265HIP_EINVAL; }
+    }
     if (sizeof(Px) == 1 && a.rowBytes == 256 && !p_generic)
     {
         // 8-bit fast path (v_qsad_pk_u16_u8); 2 * range + 75 bytes of window row must fit the 256-byte pitch
@@ -746,7 +762,7 @@ extern "C" int x265hip_me_fullsearch(const x265hip_me_params* p, void* stream)
     { set_error("me_fullsearch: plane strides must be multiples of 4 bytes and fenc 4-byte aligned"); return X265HIP_EINVAL; }
     const bool anyBest = p->best != nullptr;
     if (!p->surf && !p->best) { set_error("me_fullsearch: no output requested"); return X265HIP_EINVAL; }
-    if (p->surf_format != X265HIP_SURF_I32 && p->surf_format != X265HIP_SURF_PACKED) { set_error("me_fullsearch: surf_format %d", p->surf_format); return X265HIP_EINVAL; }
+    if (p->surf_format != X265HIP_SURF_I32 && p->surf_format != X265HIP_SURF_PACKED && p->surf_format != X265HIP_SURF_PACKED_T) { set_error("me_fullsearch: surf_format %d", p->surf_format); return X265HIP_EINVAL; }
     if (anyBest && (!p->cost_x || !p->cost_y)) { set_error("me_fullsearch: best[] needs cost_x / cost_y"); return X265HIP_EINVAL; }
     if (p->depth == 8) return launch_me<uint8_t>(p, (hipStream_t)stream);
     return launch_me<uint16_t>(p, (hipStream_t)stream);

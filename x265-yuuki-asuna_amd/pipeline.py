@@ -74,7 +74,9 @@ class MotionSearch:
 
     surf : int32 [ctu][mvy][mvx/4][85][4]  (85 = 64 8x8 + 16 16x16 + 4 32x32 + 1 64x64 PUs, z-order;
            mv columns in groups of 4, last group padded - the pad column holds unspecified values);
-           packed=True (8-bit): 720-byte groups, uint16 for the 8x8 / 16x16 levels (X265HIP_SURF_PACKED)
+           packed=True (8-bit): 720-byte groups, uint16 for the 8x8 / 16x16 levels (X265HIP_SURF_PACKED);
+           packed="t": the same records stored chunk-major inside a motion-vector row (X265HIP_SURF_PACKED_T, the layout of the
+           record-per-lane kernel)
     best : int64 [ctu][85]            cost << 32 | raster mv index
     """
 
@@ -85,7 +87,9 @@ class MotionSearch:
         self.nc = 2 * rng + 1
         self.ng = (self.nc + 3) // 4
         self.packed = bool(packed and want_surf)
+        self.tiled = self.packed and packed == "t"
         self.group_bytes = hipabi.SURF_GROUP_BYTES_PACKED if self.packed else hipabi.SURF_GROUP_BYTES_I32
+        self.surf_format = hipabi.SURF_PACKED_T if self.tiled else (hipabi.SURF_PACKED if self.packed else hipabi.SURF_I32)
         self.surf = torch.zeros(self.nctu * self.nc * self.ng * self.group_bytes // 4, dtype=torch.int32, device=device) if want_surf else None
         self.best = torch.empty(self.nctu * PUS_PER_CTU, dtype=torch.int64, device=device) if want_best else None
         cost = F.mv_cost_table(rng, lam)
@@ -127,7 +131,7 @@ class MotionSearch:
                              cur.t, cur.stride, ref.t, ref.stride,
                              surf=self.surf, best=self.best, cost_x=self.cost_x, cost_y=self.cost_y,
                              fenc_off=cur.org, fref_off=ref.org,
-                             surf_format=hipabi.SURF_PACKED if self.packed else hipabi.SURF_I32)
+                             surf_format=self.surf_format)
 
     def level_view(self, level):
         """(surface view [nmv, npu], best view [nctu, npu]) of one PU level."""
@@ -136,7 +140,10 @@ class MotionSearch:
         if self.surf is not None:      # [ctu*mvy, group, pu, col] -> [ctu*mvy, mvx, pu] with the pad column dropped
             if self.packed:
                 import torch
-                raw = self.surf.view(torch.uint8).view(self.nctu * self.nc, self.ng, self.group_bytes)
+                if self.tiled:         # [row][chunk 45][group][16 B] -> [row][group][720 B]
+                    raw = self.surf.view(torch.uint8).view(self.nctu * self.nc, 45, self.ng, 16).permute(0, 2, 1, 3).reshape(self.nctu * self.nc, self.ng, 720)
+                else:
+                    raw = self.surf.view(torch.uint8).view(self.nctu * self.nc, self.ng, self.group_bytes)
                 if level < 2:          # uint16 records at byte 0 (8x8) / 512 (16x16)
                     o = 0 if level == 0 else 512
                     g = raw[:, :, o:o + n * 8].contiguous().view(torch.int16).to(torch.int32) & 0xffff
