@@ -1243,3 +1243,20 @@ void EXPORT(x265oracle_setup_primitives)(x265hip_EncoderPrimitives* p)
 }
 
 int EXPORT(x265oracle_depth)(void) { return DEPTH; }
+
+
+/* Thread-safe lazy fill of a stage's private table: the stage restatements are called from several threads at once by the seam tests
+ * (an unguarded `if (!ready) { setup; ready = 1; }` lets a late thread re-fill the table under an early thread's feet).
+ * state: 0 = empty, 1 = being filled, 2 = ready. */
+void EXPORT(x265oracle_prims_once)(x265hip_EncoderPrimitives* p, int* state)
+{
+    if (__atomic_load_n(state, __ATOMIC_ACQUIRE) == 2) return;
+    int expected = 0;
+    if (__atomic_compare_exchange_n(state, &expected, 1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
+    {
+        EXPORT(x265oracle_setup_primitives)(p);
+        __atomic_store_n(state, 2, __ATOMIC_RELEASE);
+    }
+    else
+        while (__atomic_load_n(state, __ATOMIC_ACQUIRE) != 2) { }
+}

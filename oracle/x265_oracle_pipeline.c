@@ -31,6 +31,7 @@ typedef x265hip_pixel pixel;
 #define EXPORT(name) CAT(CAT(name, _d), X265HIP_DEPTH)
 
 void EXPORT(x265oracle_setup_primitives)(x265hip_EncoderPrimitives* p);
+void EXPORT(x265oracle_prims_once)(x265hip_EncoderPrimitives* p, int* state);
 
 /* z-order index -> (x, y) in units of the PU size inside the CTU */
 static void zorder_xy(int z, int* x, int* y)
@@ -55,7 +56,7 @@ int EXPORT(x265oracle_me_fullsearch)(const pixel* fenc, intptr_t fencStride, con
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
-    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    EXPORT(x265oracle_prims_once)(&prim, &ready);
     const int ctusW = width / 64;
     const int NC = 2 * range + 1;
     const int NG = (NC + 3) >> 2;
@@ -162,7 +163,7 @@ int EXPORT(x265oracle_subpel_refine)(const pixel* fenc, intptr_t fencStride, con
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
-    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    EXPORT(x265oracle_prims_once)(&prim, &ready);
     SubpelOut* out = (SubpelOut*)outv;
     const int ctusW = width / 64;
     const int NC = 2 * range + 1;

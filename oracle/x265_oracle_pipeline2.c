@@ -31,6 +31,7 @@ typedef x265hip_pixel pixel;
 #define EXPORT(name) CAT(CAT(name, _d), X265HIP_DEPTH)
 
 void EXPORT(x265oracle_setup_primitives)(x265hip_EncoderPrimitives* p);
+void EXPORT(x265oracle_prims_once)(x265hip_EncoderPrimitives* p, int* state);
 
 static const int kQuantScales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };   /* scalinglist.cpp:129 */
 static const int kInvQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                  /* scalinglist.cpp:130 */
@@ -165,7 +166,7 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
-    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    EXPORT(x265oracle_prims_once)(&prim, &ready);
     const int ctusW = width / 64;
     const int n = 8 << level, log2n = 3 + level, npu = (64 / n) * (64 / n);
     const int puIdx = level == 0 ? X265HIP_LUMA_8x8 : (level == 1 ? X265HIP_LUMA_16x16 : X265HIP_LUMA_32x32);
@@ -248,7 +249,7 @@ int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, co
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
-    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    EXPORT(x265oracle_prims_once)(&prim, &ready);
     const int ctusW = width / 64, nctu = ctusW * (height / 64);
     const int n = 8 << level, log2n = 3 + level, npu = (64 / n) * (64 / n);
     const int puIdx = level == 0 ? X265HIP_LUMA_8x8 : (level == 1 ? X265HIP_LUMA_16x16 : X265HIP_LUMA_32x32);
@@ -352,7 +353,7 @@ int EXPORT(x265oracle_inter_recon_chroma)(const pixel* fenc, intptr_t fencStride
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
-    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    EXPORT(x265oracle_prims_once)(&prim, &ready);
     const int ctusW = width / 64, nctu = ctusW * (height / 64);
     const int n = 8 << level, nc = n >> 1, log2nc = 2 + level, npu = (64 / n) * (64 / n);
     const int puIdx = level == 0 ? X265HIP_LUMA_8x8 : (level == 1 ? X265HIP_LUMA_16x16 : X265HIP_LUMA_32x32);
@@ -468,7 +469,7 @@ static int intra_recon_core(const pixel* fenc, intptr_t fencStride, const pixel*
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
-    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    EXPORT(x265oracle_prims_once)(&prim, &ready);
     const int log2n = n == 4 ? 2 : (n == 8 ? 3 : (n == 16 ? 4 : 5));
     if ((1 << log2n) != n) return -1;
     const struct x265hip_CU* cu = &prim.cu[log2n - 2];

@@ -38,12 +38,18 @@ void EXPORT(x265oracle_setup_host_primitives)(x265hip_EncoderPrimitives* p);
 
 static x265hip_EncoderPrimitives prim;
 static int ready;
-static void init(void)
+static void init(void)          /* thread-safe: 0 = empty, 1 = being filled, 2 = ready (the seam tests call in from several threads) */
 {
-    if (ready) return;
-    EXPORT(x265oracle_setup_primitives)(&prim);
-    EXPORT(x265oracle_setup_host_primitives)(&prim);
-    ready = 1;
+    if (__atomic_load_n(&ready, __ATOMIC_ACQUIRE) == 2) return;
+    int expected = 0;
+    if (__atomic_compare_exchange_n(&ready, &expected, 1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
+    {
+        EXPORT(x265oracle_setup_primitives)(&prim);
+        EXPORT(x265oracle_setup_host_primitives)(&prim);
+        __atomic_store_n(&ready, 2, __ATOMIC_RELEASE);
+    }
+    else
+        while (__atomic_load_n(&ready, __ATOMIC_ACQUIRE) != 2) { }
 }
 
 static const uint8_t kFilterFlags[35] = {        /* constants.cpp:561 g_intraFilterFlags */

@@ -29,6 +29,7 @@ typedef x265hip_pixel pixel;
 #define EXPORT(name) CAT(CAT(name, _d), X265HIP_DEPTH)
 
 void EXPORT(x265oracle_setup_primitives)(x265hip_EncoderPrimitives* p);
+void EXPORT(x265oracle_prims_once)(x265hip_EncoderPrimitives* p, int* state);
 
 static const uint8_t kTc[54] = {            /* H.265 table 8-12 (deblock.cpp:499-503) */
     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2,
@@ -138,7 +139,7 @@ void EXPORT(x265oracle_deblock_luma)(pixel* rec, intptr_t stride, int width, int
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
-    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    EXPORT(x265oracle_prims_once)(&prim, &ready);
     const int bo = betaOffsetDiv2 * 2, to = tcOffsetDiv2 * 2, w8 = width / 8;
     for (int ex = 1; ex < width / 8; ex++)                 /* EDGE_VER: offset 1, srcStep stride */
         for (int u = 0; u < height / 4; u++)
@@ -238,7 +239,7 @@ void EXPORT(x265oracle_deblock_chroma)(pixel* cb, pixel* cr, intptr_t strideC, i
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
-    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    EXPORT(x265oracle_prims_once)(&prim, &ready);
     pixel* planes[2] = { cb, cr };
     const int offs[2] = { cbQpOffset, crQpOffset };
     const int to = tcOffsetDiv2 * 2, w8 = width / 8;
@@ -300,7 +301,7 @@ int EXPORT(x265oracle_sao_stats_plane)(const pixel* fenc, const pixel* rec, intp
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
-    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    EXPORT(x265oracle_prims_once)(&prim, &ready);
     const int ctusW = (picWidth + ctuW - 1) / ctuW, ctusH = (picHeight + ctuH - 1) / ctuH;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);

@@ -24,18 +24,15 @@ typedef x265hip_pixel pixel;
 #define EXPORT(name) CAT(CAT(name, _d), X265HIP_DEPTH)
 
 void EXPORT(x265oracle_setup_primitives)(x265hip_EncoderPrimitives* p);
+void EXPORT(x265oracle_prims_once)(x265hip_EncoderPrimitives* p, int* state);
 
 /* src: stride x rows samples; dst: 15 (luma) or 63 (chroma) planes of the same geometry, zero-filled by the caller or not - the
  * interior is written, the border zeroed here */
 void EXPORT(x265oracle_phase_planes)(const pixel* src, intptr_t stride, int rows, int chroma, pixel* dst)
 {
     static x265hip_EncoderPrimitives prim;
-    static volatile int ready;
-    if (!ready)
-    {
-#pragma omp critical(phase_planes_init)
-        if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
-    }
+    static int ready;
+    EXPORT(x265oracle_prims_once)(&prim, &ready);
     const int nph = chroma ? 63 : 15, mask = chroma ? 7 : 3, sh = chroma ? 3 : 2;
     const size_t plane = (size_t)stride * rows;
     memset(dst, 0, plane * nph * sizeof(pixel));

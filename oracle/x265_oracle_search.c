@@ -28,6 +28,7 @@ typedef x265hip_pixel pixel;
 #define EXPORT(name) CAT(CAT(name, _d), X265HIP_DEPTH)
 
 void EXPORT(x265oracle_setup_primitives)(x265hip_EncoderPrimitives* p);
+void EXPORT(x265oracle_prims_once)(x265hip_EncoderPrimitives* p, int* state);
 
 enum { ME_DIA = 0, ME_HEX = 1, ME_UMH = 2, ME_STAR = 3, ME_SEA = 4, ME_FULL = 5 };     /* x265.h:492-497 */
 
@@ -733,7 +734,7 @@ int EXPORT(x265oracle_motion_estimate_mvc)(const pixel* fenc, const pixel* fref,
 {
     static x265hip_EncoderPrimitives prim;
     static int ready = 0;
-    if (!ready) { EXPORT(x265oracle_setup_primitives)(&prim); ready = 1; }
+    EXPORT(x265oracle_prims_once)(&prim, &ready);
     if (subme < 0 || subme > 7) return -1;
     int rc = 0;
 #ifdef _OPENMP
