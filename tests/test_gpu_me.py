@@ -157,15 +157,17 @@ def test_me_hierarchy_property_full_size():
     assert np.array_equal(ms.best[ctu * 85:(ctu + 1) * 85].cpu().numpy().view(np.uint64), best[ctu * 85:(ctu + 1) * 85])
 
 
-def test_me_4k_default_config_properties():
-    """BASELINE configs[2] size (3840x2160, merange 57, packed records), through size-independent properties:
+@pytest.mark.parametrize("packed", [True, "t"])
+def test_me_4k_default_config_properties(packed):
+    """BASELINE configs[2] size (3840x2160, merange 57, packed records - record-contiguous from the row-walking kernel, chunk-major
+    from the record-per-lane kernel), through size-independent properties:
     every parent SAD = sum of its four children at the same mv; best = min over the surface of (sad + mv cost, raster
     index) for every PU of every CTU; three CTUs spot-checked against the oracle at full picture size."""
     import torch
     dev = torch.device("cuda:0")
     clip = F.synth_clip(3840, 2160, 2, depth=8, seed=9)
     cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
-    ms = P.MotionSearch(cur.w64, cur.h64, 57, 8, dev, packed=True)
+    ms = P.MotionSearch(cur.w64, cur.h64, 57, 8, dev, packed=packed)
     ms.run(cur, ref)
     torch.cuda.synchronize()
     nmv = ms.nctu * ms.nc * ms.nc

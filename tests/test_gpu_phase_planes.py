@@ -103,3 +103,24 @@ def test_phase_cache_serves_host_planes(depth):
         assert L.x265hip_phase_cache_submit(h, 5, pics[0][0].ctypes.data, None, None) < 0          # bad slot / missing chroma: refused
     finally:
         L.x265hip_phase_cache_destroy(h)
+
+
+def test_phase_planes_at_4k():
+    """BASELINE configs[2] size: the 15 luma and 63 Cb phase planes of a 3840x2160 picture (4032 x 2336 / 2112 x 1168 buffers), whole
+    planes against the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    ybuf, stride, rows, cbuf, _, sc, rows_c = _planes(8, 77, w=3840, h=2160)
+    assert (stride, rows, sc, rows_c) == (4032, 2336, 2112, 1168)
+    for src, st, rw, chroma in ((ybuf, stride, rows, False), (cbuf, sc, rows_c, True)):
+        guard_lo, guard_hi = 4 * st + 64, 8 * st
+        d_src = torch.zeros(guard_lo + src.nbytes + guard_hi, dtype=torch.uint8, device=dev)
+        d_src[guard_lo:guard_lo + src.nbytes] = torch.from_numpy(src).to(dev)
+        nph = 63 if chroma else 15
+        d_dst = torch.zeros(nph * src.nbytes, dtype=torch.uint8, device=dev)
+        A.phase_planes(8, d_src, guard_lo, d_dst, st, rw, chroma=chroma)
+        torch.cuda.synchronize()
+        got = d_dst.cpu().numpy().reshape(nph, rw, st)
+        want = O.phase_planes(8, src, st, rw, chroma=chroma)
+        assert np.array_equal(_interior(got), _interior(want)), f"{'chroma' if chroma else 'luma'} planes differ at 4K"

@@ -140,16 +140,13 @@ class MotionSearch:
         if self.surf is not None:      # [ctu*mvy, group, pu, col] -> [ctu*mvy, mvx, pu] with the pad column dropped
             if self.packed:
                 import torch
-                if self.tiled:         # [row][chunk 45][group][16 B] -> [row][group][720 B]
-                    raw = self.surf.view(torch.uint8).view(self.nctu * self.nc, 45, self.ng, 16).permute(0, 2, 1, 3).reshape(self.nctu * self.nc, self.ng, 720)
+                o, nb = ((0, n * 8), (512, n * 8), (640, n * 16), (704, n * 16))[level]      # byte range of the level inside the 720-byte record
+                if self.tiled:         # [row][chunk 45][group][16 B]: the level's chunks -> [row][group][level bytes]
+                    lv = self.surf.view(torch.uint8).view(self.nctu * self.nc, 45, self.ng, 16)[:, o >> 4:(o + nb) >> 4].permute(0, 2, 1, 3) \
+                             .reshape(self.nctu * self.nc, self.ng, nb)
                 else:
-                    raw = self.surf.view(torch.uint8).view(self.nctu * self.nc, self.ng, self.group_bytes)
-                if level < 2:          # uint16 records at byte 0 (8x8) / 512 (16x16)
-                    o = 0 if level == 0 else 512
-                    g = raw[:, :, o:o + n * 8].contiguous().view(torch.int16).to(torch.int32) & 0xffff
-                else:                  # int32 records at byte 640 (32x32) / 704 (64x64)
-                    o = 640 if level == 2 else 704
-                    g = raw[:, :, o:o + n * 16].contiguous().view(torch.int32)
+                    lv = self.surf.view(torch.uint8).view(self.nctu * self.nc, self.ng, self.group_bytes)[:, :, o:o + nb].contiguous()
+                g = (lv.view(torch.int16).to(torch.int32) & 0xffff) if level < 2 else lv.view(torch.int32)      # uint16 / int32 records
                 g = g.view(self.nctu * self.nc, self.ng, n, 4)
             else:
                 g = self.surf.view(self.nctu * self.nc, self.ng, PUS_PER_CTU, 4)[:, :, b:b + n, :]
