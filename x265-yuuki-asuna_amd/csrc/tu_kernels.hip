@@ -157,7 +157,9 @@ template <int N> __device__ __forceinline__ int tu_sign_hide_group(int16_t* lev,
     return dn;
 }
 
-template <typename Px, int N, bool DST>
+// TAB: the launch carries scaling-list / denoiser tables (x265hip_tu_tables).  A separate instantiation: with the table branches compiled
+// into the default kernels the 32x32 inter stage crossed a register-count step and lost half of its resident workgroups (89 -> 183 us).
+template <typename Px, int N, bool DST, bool TAB = false>
 __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int16_t* pred, const int16_t* fe, int16_t* A, int16_t* B, unsigned long long* red, int& sNumSig,
                                          int depth, int qp, int flags, int16_t* lvOut, uint32_t* numSigOut, unsigned long long* distOut,
                                          Px* rec, long cst, int scanType = TU_SCAN_DIAG, const TuTables tab = TuTables{ nullptr, nullptr, nullptr, nullptr })
@@ -180,7 +182,7 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
     // the scaling list's coefficient instead of the flat scale (quant.cpp:463)
     auto prepare = [&](const int e, int c, int& scale)
     {
-        if (tab.nrOff)
+        if (TAB && tab.nrOff)
         {
             const int sign = c >> 31;
             int level = (c + sign) ^ sign;
@@ -188,7 +190,7 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
             level -= (int)tab.nrOff[e];
             c = (int16_t)(level < 0 ? 0 : (level ^ sign) - sign);
         }
-        scale = tab.qc ? tab.qc[e] : qscale;
+        scale = (TAB && tab.qc) ? tab.qc[e] : qscale;
         return c;
     };
     int16_t* lv = lvOut;
@@ -316,7 +318,7 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
         // dequant_normal (flat lists) or dequant_scaling with the list's coefficient (dct.cpp:612-662, quant.cpp:562-572)
         auto dequant = [&](const int e, const int level)
         {
-            if (!tab.dqc) return tu_sat16((level * dqScale + dqAdd) >> dqShift);
+            if (!TAB || !tab.dqc) return tu_sat16((level * dqScale + dqAdd) >> dqShift);
             const int sh = dqShift + 4, prod = level * tab.dqc[e];
             if (sh > per) return tu_sat16((prod + (1 << (sh - per - 1))) >> (sh - per));
             return tu_sat16(tu_sat16(prod) << (per - sh));
@@ -422,7 +424,7 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
 
 // CHROMA: one chroma plane of a 4:2:0 picture - N is the chroma block size (half the luma block), the mv counts 1/8 samples and
 // the filters are the 4-tap chroma set (Predict::predInterChromaPixel, predict.cpp:304-351)
-template <typename Px, int N, bool CHROMA>
+template <typename Px, int N, bool CHROMA, bool TAB = false>
 __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs a, int nblocks)
 {
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
@@ -509,7 +511,7 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs 
     }
     __syncthreads();
 
-    tu_chain<Px, N, false>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
+    tu_chain<Px, N, false, TAB>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
                            a.levels + ((size_t)ctu * npu + z) * NN, &a.numSig[(size_t)ctu * npu + z], &a.dist[(size_t)ctu * npu + z],
                            reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP, TU_SCAN_DIAG, a.tab);
     __syncthreads();
@@ -530,7 +532,7 @@ struct TuBiArgs
     const uint8_t* dir;                // [ctu][npu]: 1, 2 or 3; NULL = all 3
 };
 
-template <typename Px, int N>
+template <typename Px, int N, bool TAB = false>
 __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBiArgs b, int nblocks)
 {
     const TuArgs& a = b.t;
@@ -627,7 +629,7 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBi
             for (int i = tid; i < NN; i += nth) pred[i] = (int16_t)clip3(0, maxVal, ((int)ps0[i] + (int)pred[i] + offAvg) >> shiftAvg);
             __syncthreads();
         }
-        tu_chain<Px, N, false>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
+        tu_chain<Px, N, false, TAB>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
                                a.levels + ((size_t)ctu * npu + z) * NN, &a.numSig[(size_t)ctu * npu + z], &a.dist[(size_t)ctu * npu + z],
                                reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP, TU_SCAN_DIAG, a.tab);
         __syncthreads();
@@ -657,7 +659,7 @@ struct IntraTuArgs
 };
 
 // DST: the 4x4 intra LUMA TU (chroma 4x4 takes the DCT)
-template <typename Px, int N, bool DST>
+template <typename Px, int N, bool DST, bool TAB = false>
 __global__ void __launch_bounds__(N <= 8 ? 256 : 64) intra_recon_kernel(IntraTuArgs a)
 {
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
@@ -696,7 +698,7 @@ __global__ void __launch_bounds__(N <= 8 ? 256 : 64) intra_recon_kernel(IntraTuA
             pred[i] = (int16_t)intra_sample(nbS, N, LOG2N, mode, bFilter, dc, maxVal, x, y);
         }
         __syncthreads();
-        tu_chain<Px, N, DST>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
+        tu_chain<Px, N, DST, TAB>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
                              a.levels + (size_t)job * NN, &a.numSig[job], &a.dist[job],
                              reinterpret_cast<Px*>(a.recon) + jb.off[3], a.reconStrideB / BPP,
                              // the scan sign hiding walks: mode-dependent for 4x4 TUs and 8x8 luma TUs (cudata.cpp:2083-2084)
@@ -754,11 +756,13 @@ extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
         const long r = (long)cus * per;
         return (int)(nblocks < r ? nblocks : r);
     };
-#define GO(PX) do { \
-        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 8, false>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
-        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 16, false>), dim3(resident((const void*)inter_recon_kernel<PX, 16, false>)), dim3(64), 0, s, a, nblocks); \
-        else hipLaunchKernelGGL((inter_recon_kernel<PX, 32, false>), dim3(resident((const void*)inter_recon_kernel<PX, 32, false>)), dim3(64), 0, s, a, nblocks); } while (0)
+#define GO_T(PX, TB) do { \
+        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 8, false, TB>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 16, false, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 16, false, TB>)), dim3(64), 0, s, a, nblocks); \
+        else hipLaunchKernelGGL((inter_recon_kernel<PX, 32, false, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 32, false, TB>)), dim3(64), 0, s, a, nblocks); } while (0)
+#define GO(PX) do { if (p->tables) GO_T(PX, true); else GO_T(PX, false); } while (0)
     if (p->depth == 8) GO(uint8_t); else GO(uint16_t);
+#undef GO_T
 #undef GO
     X265HIP_TRY(hipGetLastError());
     return 0;
@@ -798,11 +802,13 @@ extern "C" int x265hip_inter_recon_bi(const x265hip_recon_bi_params* q, void* st
         const long r = (long)cus * per;
         return (int)(nblocks < r ? nblocks : r);
     };
-#define GOB(PX) do { \
-        if (p->level == 0) hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 8>), dim3(nblocks), dim3(64), 0, s, b, nblocks); \
-        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 16>), dim3(resident((const void*)inter_recon_bi_kernel<PX, 16>)), dim3(64), 0, s, b, nblocks); \
-        else hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 32>), dim3(resident((const void*)inter_recon_bi_kernel<PX, 32>)), dim3(64), 0, s, b, nblocks); } while (0)
+#define GOB_T(PX, TB) do { \
+        if (p->level == 0) hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 8, TB>), dim3(nblocks), dim3(64), 0, s, b, nblocks); \
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 16, TB>), dim3(resident((const void*)inter_recon_bi_kernel<PX, 16, TB>)), dim3(64), 0, s, b, nblocks); \
+        else hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 32, TB>), dim3(resident((const void*)inter_recon_bi_kernel<PX, 32, TB>)), dim3(64), 0, s, b, nblocks); } while (0)
+#define GOB(PX) do { if (p->tables) GOB_T(PX, true); else GOB_T(PX, false); } while (0)
     if (p->depth == 8) GOB(uint8_t); else GOB(uint16_t);
+#undef GOB_T
 #undef GOB
     X265HIP_TRY(hipGetLastError());
     return 0;
@@ -839,11 +845,13 @@ extern "C" int x265hip_inter_recon_chroma(const x265hip_recon_params* p, void* s
         const long r = (long)cus * per;
         return (int)(nblocks < r ? nblocks : r);
     };
-#define GOC(PX) do { \
-        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 4, true>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
-        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 8, true>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
-        else hipLaunchKernelGGL((inter_recon_kernel<PX, 16, true>), dim3(resident((const void*)inter_recon_kernel<PX, 16, true>)), dim3(64), 0, s, a, nblocks); } while (0)
+#define GOC_T(PX, TB) do { \
+        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 4, true, TB>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 8, true, TB>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
+        else hipLaunchKernelGGL((inter_recon_kernel<PX, 16, true, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 16, true, TB>)), dim3(64), 0, s, a, nblocks); } while (0)
+#define GOC(PX) do { if (p->tables) GOC_T(PX, true); else GOC_T(PX, false); } while (0)
     if (p->depth == 8) GOC(uint8_t); else GOC(uint16_t);
+#undef GOC_T
 #undef GOC
     X265HIP_TRY(hipGetLastError());
     return 0;
@@ -879,13 +887,15 @@ extern "C" int x265hip_intra_recon_batch(const x265hip_intra_recon_params* p, vo
         const long r = (long)cus * per;
         return (int)(p->njobs < r ? p->njobs : r);
     };
-#define GOI(PX) do { \
-        if (p->n == 4 && !p->chroma) hipLaunchKernelGGL((intra_recon_kernel<PX, 4, true>), dim3(p->njobs), dim3(64), 0, s, a); \
-        else if (p->n == 4) hipLaunchKernelGGL((intra_recon_kernel<PX, 4, false>), dim3(p->njobs), dim3(64), 0, s, a); \
-        else if (p->n == 8) hipLaunchKernelGGL((intra_recon_kernel<PX, 8, false>), dim3(p->njobs), dim3(64), 0, s, a); \
-        else if (p->n == 16) hipLaunchKernelGGL((intra_recon_kernel<PX, 16, false>), dim3(resident((const void*)intra_recon_kernel<PX, 16, false>)), dim3(64), 0, s, a); \
-        else hipLaunchKernelGGL((intra_recon_kernel<PX, 32, false>), dim3(resident((const void*)intra_recon_kernel<PX, 32, false>)), dim3(64), 0, s, a); } while (0)
+#define GOI_T(PX, TB) do { \
+        if (p->n == 4 && !p->chroma) hipLaunchKernelGGL((intra_recon_kernel<PX, 4, true, TB>), dim3(p->njobs), dim3(64), 0, s, a); \
+        else if (p->n == 4) hipLaunchKernelGGL((intra_recon_kernel<PX, 4, false, TB>), dim3(p->njobs), dim3(64), 0, s, a); \
+        else if (p->n == 8) hipLaunchKernelGGL((intra_recon_kernel<PX, 8, false, TB>), dim3(p->njobs), dim3(64), 0, s, a); \
+        else if (p->n == 16) hipLaunchKernelGGL((intra_recon_kernel<PX, 16, false, TB>), dim3(resident((const void*)intra_recon_kernel<PX, 16, false, TB>)), dim3(64), 0, s, a); \
+        else hipLaunchKernelGGL((intra_recon_kernel<PX, 32, false, TB>), dim3(resident((const void*)intra_recon_kernel<PX, 32, false, TB>)), dim3(64), 0, s, a); } while (0)
+#define GOI(PX) do { if (p->tables) GOI_T(PX, true); else GOI_T(PX, false); } while (0)
     if (p->depth == 8) GOI(uint8_t); else GOI(uint16_t);
+#undef GOI_T
 #undef GOI
     X265HIP_TRY(hipGetLastError());
     return 0;
