@@ -277,6 +277,11 @@ class FrameParallelRing:
         f = self.frame_index(step)
         nb = len(self.bands)
         flat = lambda t: t.reshape(-1)
+
+        def p2p(op, planes, ranges, peer, group):
+            """The three plane slices of one band as ONE grouped transfer (a single ncclGroup on RCCL: one launch per band and
+            direction instead of three)."""
+            return dist.batch_isend_irecv([dist.P2POp(op, flat(p)[a:z], peer, group) for p, (a, z) in zip(planes, ranges)])
         groups = getattr(self, "groups", [None, None])
         g_in, g_out = groups[self.prev % 2], groups[self.rank % 2]
         recv_from_peer = self.world > 1 and not (f == 0 and first_frame_is_local)
@@ -289,22 +294,19 @@ class FrameParallelRing:
             while posted < need:                            # receives are posted in band order, just ahead of the band that needs them
                 posted += 1
                 r0, rn = self.bands[posted]
-                pending[posted] = [dist.irecv(flat(p)[a:z], src=self.prev, group=g_in)
-                                   for p, (a, z) in zip(ref_planes, self._rows(geom, r0, rn, posted == 0, posted == nb - 1))]
+                pending[posted] = p2p(dist.irecv, ref_planes, self._rows(geom, r0, rn, posted == 0, posted == nb - 1), self.prev, g_in)
             while arrived < need:
                 arrived += 1
                 for w in pending.pop(arrived):
                     w.wait()
             process_band(b, row0, n)
             if send_to_peer:
-                self._sends += [dist.isend(flat(p)[a:z], dst=self.next, group=g_out)
-                                for p, (a, z) in zip(out_planes, self._rows(geom, row0, n, b == 0, b == nb - 1))]
+                self._sends += p2p(dist.isend, out_planes, self._rows(geom, row0, n, b == 0, b == nb - 1), self.next, g_out)
         if recv_from_peer:                                  # bands below the last search window still belong to the reference picture
             while posted < nb - 1:
                 posted += 1
                 r0, rn = self.bands[posted]
-                pending[posted] = [dist.irecv(flat(p)[a:z], src=self.prev, group=g_in)
-                                   for p, (a, z) in zip(ref_planes, self._rows(geom, r0, rn, posted == 0, posted == nb - 1))]
+                pending[posted] = p2p(dist.irecv, ref_planes, self._rows(geom, r0, rn, posted == 0, posted == nb - 1), self.prev, g_in)
             for b in sorted(pending):
                 for w in pending[b]:
                     w.wait()
