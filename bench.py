@@ -316,7 +316,10 @@ def main():
     if banded:
         # N > 1: the reference's real frame-parallel dependency - frame f (rank f % N) searches frame f - 1, band by band (pipeline.FrameParallelRing)
         bp = S.BandedFramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, band_rows=args.band_rows, rng=args.range, subme=args.subme, level=args.level,
-                                   qp=args.qp, want_surf=not args.no_surface, packed=({"packed": True, "packed_t": "t"}.get(args.surf_format, False) if args.depth == 8 else False),
+                                   qp=args.qp, want_surf=not args.no_surface,
+                                   # a band's grid (4 CTU rows = 240 workgroups) is too small for the record-per-lane kernel's 4-wavefront
+                                   # workgroups (one per CU): bands use the record-contiguous packed format of the row-walking kernel
+                                   packed=(args.surf_format != "i32" and args.depth == 8),
                                    lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True)
         ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16)      # search window + 8-tap interpolation + sub-pel drift
         ring.make_groups()
@@ -422,7 +425,7 @@ def main():
                        "ctus_per_frame": ms.nctu, "checksum": csum},
             "stages_ms": stages,
             "roofline": {"bound": "hbm", "kernel": "me_search_kernel" if args.search != "full" else
-                                   (("me_ctu_c_kernel" if surf_mode and args.surf_format == "packed_t" else "me_ctu_q_kernel") if args.depth == 8 else "me_ctu_w_kernel")
+                                   (("me_ctu_c_kernel" if surf_mode and ms.tiled else "me_ctu_q_kernel") if args.depth == 8 else "me_ctu_w_kernel")
                                    + ("<surf,best>" if surf_mode else "<best>"),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
