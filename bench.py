@@ -432,6 +432,9 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "output_bytes_per_launch": ms.hbm_floor_bytes(1 if args.depth == 8 else 2),
                          "launch_ms": stages[dom]},
         }
+        if banded:
+            out["roofline"]["note"] = ("stage times and roofline are whole-frame launches of rank 0 (untimed pass after the loop); the timed loop runs the "
+                                       f"same stages band by band ({args.band_rows} CTU rows per band, row-walking search kernel per band)")
         bit_exact = None
         if world == 1 and not args.no_cpu_baseline:
             dev_out = None
