@@ -176,6 +176,11 @@ typedef struct x265hip_tu_tables
     const int32_t* dequant_coeff;
     const uint16_t* nr_offset;
     uint32_t* nr_residual_sum;
+    /* capture for a host-side RDOQ pass (Quant::rdoQuant, quant.cpp:627+, stays on the host - SURVEY row a9 - but can run on
+     * device-produced transforms): the coefficients transformNxN hands to the quantiser (m_resiDctCoeff, after the denoiser when it is
+     * on) and the quantiser's deltaU (dct.cpp:679), both laid out like `levels`; NULL = not wanted */
+    int16_t* dct_coeff_out;
+    int32_t* delta_u_out;
 } x265hip_tu_tables;
 typedef struct x265hip_recon_params
 {

@@ -25,6 +25,14 @@ def set_tu_tables(depth, quant_coeff=None, dequant_coeff=None, nr_offset=None, n
     fn(*[None if a is None else a.ctypes.data for a in (quant_coeff, dequant_coeff, nr_offset, nr_sum)])
 
 
+def set_tu_capture(depth, dct_coeff=None, delta_u=None, avx2=False):
+    """Capture buffers of the oracle's TU stages (int16 / int32 numpy arrays shaped like the levels, or None): the coefficients handed
+    to the quantiser and the quantiser's deltaU."""
+    fn = getattr(lib(avx2), f"x265oracle_set_tu_capture_d{depth}")
+    fn.argtypes = [ctypes.c_void_p] * 2
+    fn(*[None if a is None else a.ctypes.data for a in (dct_coeff, delta_u)])
+
+
 def host_has_avx2() -> bool:
     try:
         return " avx2 " in open("/proc/cpuinfo").read().replace("\n", " ")

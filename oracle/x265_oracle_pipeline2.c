@@ -139,6 +139,14 @@ void EXPORT(x265oracle_set_tu_tables)(const int32_t* quantCoeff, const int32_t* 
 {
     g_tabQuant = quantCoeff; g_tabDequant = dequantCoeff; g_tabNrOffset = nrOffset; g_tabNrSum = nrSum;
 }
+/* capture of what a host-side RDOQ pass needs (x265hip_tu_tables.dct_coeff_out / delta_u_out): laid out like the levels */
+static int16_t* g_capDct; static int32_t* g_capDeltaU;
+void EXPORT(x265oracle_set_tu_capture)(int16_t* dctCoeff, int32_t* deltaU) { g_capDct = dctCoeff; g_capDeltaU = deltaU; }
+static void tab_capture(const int16_t* coef, const int32_t* deltaU, size_t elemOff, int num)
+{
+    if (g_capDct) memcpy(g_capDct + elemOff, coef, (size_t)num * sizeof(int16_t));
+    if (g_capDeltaU) memcpy(g_capDeltaU + elemOff, deltaU, (size_t)num * sizeof(int32_t));
+}
 static void tab_denoise(int16_t* coef, int num)          /* denoiseDct with the sums added atomically (the callers run CTUs in parallel) */
 {
     if (!g_tabNrOffset) return;
@@ -214,6 +222,7 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
             tab_denoise(coef, n * n);
             int16_t* q = levels + ((size_t)ctu * npu + z) * n * n;
             uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
+            tab_capture(coef, deltaU, (size_t)(q - levels), n * n);
             if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, ORACLE_SCAN_DIAG, log2n);
             numSigOut[(size_t)ctu * npu + z] = numSig;
             if (numSig)
@@ -318,6 +327,7 @@ int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, co
             tab_denoise(coef, n * n);
             int16_t* q = levels + ((size_t)ctu * npu + z) * n * n;
             uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
+            tab_capture(coef, deltaU, (size_t)(q - levels), n * n);
             if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, ORACLE_SCAN_DIAG, log2n);
             numSigOut[(size_t)ctu * npu + z] = numSig;
             if (numSig)
@@ -403,6 +413,7 @@ int EXPORT(x265oracle_inter_recon_chroma)(const pixel* fenc, intptr_t fencStride
             tab_denoise(coef, nc * nc);
             int16_t* q = levels + ((size_t)ctu * npu + z) * nc * nc;
             uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, nc * nc);
+            tab_capture(coef, deltaU, (size_t)(q - levels), nc * nc);
             if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, ORACLE_SCAN_DIAG, log2nc);
             numSigOut[(size_t)ctu * npu + z] = numSig;
             if (numSig)
@@ -506,6 +517,7 @@ static int intra_recon_core(const pixel* fenc, intptr_t fencStride, const pixel*
         tab_denoise(coef, n * n);
         int16_t* q = levels + (size_t)j * n * n;
         uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, n * n);
+        tab_capture(coef, deltaU, (size_t)(q - levels), n * n);
         if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, intra_scan_type(mode, n, chroma), log2n);
         numSigOut[j] = numSig;
         if (numSig)

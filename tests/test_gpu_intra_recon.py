@@ -99,12 +99,16 @@ def _run(depth, n, qp, islice, chroma, tabs):
         off = rng.integers(0, 5 << (depth - 8), size=n * n).astype(np.uint16)
         osum = np.zeros(n * n, np.uint32)
         d_sum = torch.zeros(n * n, dtype=torch.int32, device=dev)
-        rec = H.tu_tables(torch.from_numpy(qc).to(dev), torch.from_numpy(dqc).to(dev), torch.from_numpy(off.view(np.int16)).to(dev), d_sum)
+        d_cap = (torch.zeros(njobs * n * n, dtype=torch.int16, device=dev), torch.zeros(njobs * n * n, dtype=torch.int32, device=dev))
+        e_cap = (np.zeros(njobs * n * n, np.int16), np.zeros(njobs * n * n, np.int32))
+        rec = H.tu_tables(torch.from_numpy(qc).to(dev), torch.from_numpy(dqc).to(dev), torch.from_numpy(off.view(np.int16)).to(dev), d_sum, *d_cap)
         O.set_tu_tables(depth, qc, dqc, off, osum)
+        O.set_tu_capture(depth, *e_cap)
     try:
         erec, elev, ens, edist = O.intra_recon(depth, n, fenc.reshape(-1), fenc_stride, nb.reshape(-1), recon_len, recon_stride, qp, islice, jobs, chroma=chroma)
     finally:
         O.set_tu_tables(depth)
+        O.set_tu_capture(depth)
 
     d_fenc = torch.from_numpy(fenc.reshape(-1).view(np.uint8)).to(dev)
     d_nb = torch.from_numpy(nb.reshape(-1).view(np.uint8)).to(dev)
@@ -117,6 +121,8 @@ def _run(depth, n, qp, islice, chroma, tabs):
     torch.cuda.synchronize()
     if tabs:
         assert np.array_equal(d_sum.cpu().numpy().view(np.uint32), osum) and osum.sum() > 0, "denoiser residual sums differ"
+        assert np.array_equal(d_cap[0].cpu().numpy(), e_cap[0]), "captured transform coefficients differ"
+        assert np.array_equal(d_cap[1].cpu().numpy(), e_cap[1]), "captured deltaU differs"
         flat = O.intra_recon(depth, n, fenc.reshape(-1), fenc_stride, nb.reshape(-1), recon_len, recon_stride, qp, islice, jobs, chroma=chroma)[1]
         assert not np.array_equal(flat, elev), "the tables changed nothing"
     assert np.array_equal(d_ns.cpu().numpy().view(np.uint32), ens), "numSig differs"

@@ -163,6 +163,54 @@ def _tables(rng, n, qp, depth, dev, lists=True, nr=True):
     return (qc, dqc, off), rec, d_sum
 
 
+@pytest.mark.parametrize("depth,level,qp,with_tables", [(8, 2, 24, False), (8, 1, 30, True), (8, 0, 22, False), (10, 2, 34, True), (12, 1, 40, False)])
+def test_inter_recon_captures_transform_coefficients_and_delta_u(depth, level, qp, with_tables):
+    """x265hip_tu_tables.dct_coeff_out / delta_u_out: what Quant::transformNxN hands to the quantiser (m_resiDctCoeff, after the denoiser)
+    and primitives.quant's deltaU, for a host-side RDOQ pass on device-produced transforms - luma and one chroma plane."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng([58, depth, level, qp])
+    clip = F.synth_clip(192, 128, 2, depth=depth, seed=80 + level)
+    cur, ref = P.DevicePicture(clip[1][0], dev, clip[1][1], clip[1][2]), P.DevicePicture(clip[0][0], dev, clip[0][1], clip[0][2])
+    ms = P.MotionSearch(cur.w64, cur.h64, 8, depth, dev, want_surf=False)
+    ms.run(cur, ref)
+    sp = P.SubpelRefine(ms, 3, dev)
+    sp.run(cur, ref)
+    torch.cuda.synchronize()
+    mv = sp.out.cpu().numpy().reshape(-1, 2)
+    O = _oracle()
+    for chroma in (False, True):
+        n = (8 << level) >> (1 if chroma else 0)
+        (qc, dqc, off), rec0, d_sum = _tables(rng, n, qp, depth, dev, with_tables, with_tables)
+        st = (S.InterReconChroma if chroma else S.InterRecon)(ms.nctu, cur.w64, cur.h64, depth, level, qp, dev, intra_slice=2)
+        d_dct = torch.full_like(st.levels, 0x5a5a)
+        d_du = torch.full((st.levels.numel(),), 0x5a5a5a5a, dtype=torch.int32, device=dev)
+        t = lambda a: None if a is None else torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).to(dev)
+        st.tables = A.tu_tables(t(qc), t(dqc), t(off), d_sum, d_dct, d_du)
+        e_dct, e_du = np.zeros(st.levels.numel(), np.int16), np.zeros(st.levels.numel(), np.int32)
+        osum = np.zeros(n * n, np.uint32)
+        O.set_tu_tables(depth, qc, dqc, off, osum if with_tables else None)
+        O.set_tu_capture(depth, e_dct, e_du)
+        try:
+            if chroma:
+                out = torch.zeros_like(cur.c[0])
+                st.run(cur.c[0], ref.c[0], out, cur.stride_c, cur.org_c, sp.out)
+                elev = O.inter_recon_chroma(depth, cur.c_host[0].reshape(-1), ref.c_host[0].reshape(-1), cur.stride_c, cur.org_c, cur.w64, cur.h64, level, mv, qp,
+                                            intra_slice=2)[1]
+            else:
+                recon = torch.zeros_like(cur.t)
+                st.run(cur, ref, recon, sp.out)
+                elev = O.inter_recon(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, level, mv, qp, intra_slice=2)[1]
+        finally:
+            O.set_tu_tables(depth)
+            O.set_tu_capture(depth)
+        torch.cuda.synchronize()
+        assert np.array_equal(st.levels.cpu().numpy(), elev)
+        assert np.array_equal(d_dct.cpu().numpy(), e_dct), f"{'chroma' if chroma else 'luma'}: captured coefficients differ"
+        assert np.array_equal(d_du.cpu().numpy(), e_du), f"{'chroma' if chroma else 'luma'}: captured deltaU differs"
+        assert np.count_nonzero(e_dct) > 100
+
+
 @pytest.mark.parametrize("depth,level,qp,lists,nr", [(8, 2, 24, True, True), (8, 1, 30, True, False), (8, 0, 20, False, True), (10, 2, 36, True, True), (12, 1, 44, True, True)])
 def test_inter_recon_with_scaling_lists_and_denoiser(depth, level, qp, lists, nr):
     """x265hip_tu_tables: scaling-list quantiser / dequantiser coefficients and the denoiser (running residual sums) in the fused inter TU

@@ -49,7 +49,18 @@ static __constant__ int kTuInvQuantScales[6] = { 40, 45, 51, 57, 64, 72 };      
 // optional per-coefficient tables of the launch's block size (all DEVICE pointers, N * N entries, raster order; NULL = not used):
 // scaling-list quantiser / dequantiser coefficients (ScalingList::m_quantCoef / m_dequantCoef [size][list][rem], quant.cpp:463,566) and
 // the denoiser's offsets with its running residual sums (NoiseReduction, quant.cpp:444-451, dct.cpp:744-755)
-struct TuTables { const int32_t* qc; const int32_t* dqc; const uint16_t* nrOff; uint32_t* nrSum; };
+struct TuTables
+{
+    const int32_t* qc; const int32_t* dqc; const uint16_t* nrOff; uint32_t* nrSum;
+    int16_t* dctOut; int32_t* duOut;      // capture for a host-side RDOQ pass: transform coefficients / deltaU, laid out like the levels
+    __device__ __forceinline__ TuTables at(size_t elemOff) const
+    {
+        TuTables t = *this;
+        if (t.dctOut) t.dctOut += elemOff;
+        if (t.duOut) t.duOut += elemOff;
+        return t;
+    }
+};
 
 struct TuArgs
 {
@@ -162,7 +173,7 @@ template <int N> __device__ __forceinline__ int tu_sign_hide_group(int16_t* lev,
 template <typename Px, int N, bool DST, bool TAB = false>
 __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int16_t* pred, const int16_t* fe, int16_t* A, int16_t* B, unsigned long long* red, int& sNumSig,
                                          int depth, int qp, int flags, int16_t* lvOut, uint32_t* numSigOut, unsigned long long* distOut,
-                                         Px* rec, long cst, int scanType = TU_SCAN_DIAG, const TuTables tab = TuTables{ nullptr, nullptr, nullptr, nullptr })
+                                         Px* rec, long cst, int scanType = TU_SCAN_DIAG, const TuTables tab = TuTables{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr })
 {
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -239,6 +250,8 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
                 // B's pass-1 values were consumed by the products above (one wavefront, LDS operations in order): it now keeps what
                 // sign hiding needs per coefficient - deltaU (dct.cpp:679, within +-256) and the sign of the transform coefficient
                 if (signHide) B[e] = (int16_t)((((t - (level << qbits)) >> qbits8) << 1) | (c < 0));
+                if (TAB && tab.dctOut) tab.dctOut[e] = (int16_t)c;
+                if (TAB && tab.duOut) tab.duOut[e] = (t - (level << qbits)) >> qbits8;
                 nz += level != 0;
                 if (c < 0) level = -level;
                 level = tu_sat16(level);
@@ -271,6 +284,8 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
         const int t = abs(c) * qs;
         int level = (t + qadd) >> qbits;
         auxReg = (((t - (level << qbits)) >> qbits8) << 1) | (c < 0);
+        if (TAB && tab.dctOut) tab.dctOut[e] = (int16_t)c;
+        if (TAB && tab.duOut) tab.duOut[e] = (t - (level << qbits)) >> qbits8;
         nz += level != 0;
         if (c < 0) level = -level;
         level = tu_sat16(level);
@@ -513,7 +528,8 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs 
 
     tu_chain<Px, N, false, TAB>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
                            a.levels + ((size_t)ctu * npu + z) * NN, &a.numSig[(size_t)ctu * npu + z], &a.dist[(size_t)ctu * npu + z],
-                           reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP, TU_SCAN_DIAG, a.tab);
+                           reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP, TU_SCAN_DIAG,
+                           TAB ? a.tab.at(((size_t)ctu * npu + z) * NN) : a.tab);
     __syncthreads();
     };
     if constexpr (N >= 16)
@@ -631,7 +647,8 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBi
         }
         tu_chain<Px, N, false, TAB>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
                                a.levels + ((size_t)ctu * npu + z) * NN, &a.numSig[(size_t)ctu * npu + z], &a.dist[(size_t)ctu * npu + z],
-                               reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP, TU_SCAN_DIAG, a.tab);
+                               reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP, TU_SCAN_DIAG,
+                               TAB ? a.tab.at(((size_t)ctu * npu + z) * NN) : a.tab);
         __syncthreads();
     };
     if constexpr (N >= 16)
@@ -703,7 +720,7 @@ __global__ void __launch_bounds__(N <= 8 ? 256 : 64) intra_recon_kernel(IntraTuA
                              reinterpret_cast<Px*>(a.recon) + jb.off[3], a.reconStrideB / BPP,
                              // the scan sign hiding walks: mode-dependent for 4x4 TUs and 8x8 luma TUs (cudata.cpp:2083-2084)
                              (N == 4 || (!a.chroma && N == 8)) ? (mode >= 22 && mode <= 30 ? TU_SCAN_HOR : (mode >= 6 && mode <= 14 ? TU_SCAN_VER : TU_SCAN_DIAG))
-                                                               : TU_SCAN_DIAG, a.tab);
+                                                               : TU_SCAN_DIAG, TAB ? a.tab.at((size_t)job * NN) : a.tab);
         __syncthreads();
     };
     // 4 / 8: one candidate per workgroup; 16 / 32: persistent, the MFMA operands above are reused
@@ -718,8 +735,8 @@ using namespace x265hip;
 
 static TuTables tu_tables_of(const x265hip_tu_tables* t)
 {
-    TuTables r = { nullptr, nullptr, nullptr, nullptr };
-    if (t) { r.qc = t->quant_coeff; r.dqc = t->dequant_coeff; r.nrOff = t->nr_offset; r.nrSum = t->nr_residual_sum; }
+    TuTables r = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    if (t) { r.qc = t->quant_coeff; r.dqc = t->dequant_coeff; r.nrOff = t->nr_offset; r.nrSum = t->nr_residual_sum; r.dctOut = t->dct_coeff_out; r.duOut = t->delta_u_out; }
     return r;
 }
 #define TABLES_OF(p) ((p)->tables)

@@ -632,13 +632,15 @@ def _planes(ps, n):
 
 class TuTablesRec(ctypes.Structure):
     """x265hip_tu_tables (include/x265hip.h): device pointers, any may be NULL."""
-    _fields_ = [("quant_coeff", ctypes.c_void_p), ("dequant_coeff", ctypes.c_void_p), ("nr_offset", ctypes.c_void_p), ("nr_residual_sum", ctypes.c_void_p)]
+    _fields_ = [("quant_coeff", ctypes.c_void_p), ("dequant_coeff", ctypes.c_void_p), ("nr_offset", ctypes.c_void_p), ("nr_residual_sum", ctypes.c_void_p),
+                ("dct_coeff_out", ctypes.c_void_p), ("delta_u_out", ctypes.c_void_p)]
 
 
-def tu_tables(quant_coeff=None, dequant_coeff=None, nr_offset=None, nr_residual_sum=None):
-    """Device tensors -> the table record a TU stage takes through its `tables` field (keep the returned object alive during the launch)."""
-    r = TuTablesRec(_p(quant_coeff), _p(dequant_coeff), _p(nr_offset), _p(nr_residual_sum))
-    r._keep = (quant_coeff, dequant_coeff, nr_offset, nr_residual_sum)
+def tu_tables(quant_coeff=None, dequant_coeff=None, nr_offset=None, nr_residual_sum=None, dct_coeff_out=None, delta_u_out=None):
+    """Device tensors -> the table record a TU stage takes through its `tables` field (keep the returned object alive during the launch).
+    dct_coeff_out (int16) / delta_u_out (int32), shaped like the stage's levels: capture for a host-side RDOQ pass."""
+    r = TuTablesRec(_p(quant_coeff), _p(dequant_coeff), _p(nr_offset), _p(nr_residual_sum), _p(dct_coeff_out), _p(delta_u_out))
+    r._keep = (quant_coeff, dequant_coeff, nr_offset, nr_residual_sum, dct_coeff_out, delta_u_out)
     return r
 
 
