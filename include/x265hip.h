@@ -146,6 +146,10 @@ typedef struct x265hip_subpel_params
     const uint64_t* best_in;
     const uint16_t* cost_q;  int qoff;
     void* out;
+    /* optional: the 15 luma phase planes of the reference picture (x265hip_phase_planes) - phase_planes = sample (0,0) of phase 1,
+     * plane p at + (p - 1) * phase_plane_samples.  The candidates are then read from the planes instead of being interpolated per
+     * candidate (same samples, same result); NULL = interpolate */
+    const void* phase_planes;  intptr_t phase_plane_samples;
 } x265hip_subpel_params;
 int x265hip_subpel_refine(const x265hip_subpel_params* p, void* stream);
 
@@ -770,8 +774,8 @@ static inline int32_t x265hip_surf_lookup(const void* surf, int surf_format, int
  * The planes have the geometry of the source plane (same pitch, same rows), so a block's address in a phase plane is its address in
  * the source plane plus a constant; the interpolated block needs no copy, the comparison primitive reads it in place.
  * Batch-layer entry (device pointers):
- *   src  : the padded plane, `rows` rows of `stride` samples; at least 4 rows + 64 bytes of readable memory must precede it and
- *          8 rows follow it (samples within 4 of the buffer edge depend on those guard bytes: no valid block lies there)
+ *   src  : the padded plane, `rows` rows of `stride` samples (no guard memory needed: the first 4 and the last 8 rows of every phase
+ *          plane are not produced, and samples within 4 of a row end depend on the neighbouring rows - no valid block lies there)
  *   dst  : (chroma ? 63 : 15) planes of stride * rows samples */
 typedef struct x265hip_phase_planes_params
 {

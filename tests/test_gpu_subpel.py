@@ -19,8 +19,11 @@ def _oracle():
     return oracle_api
 
 
-@pytest.mark.parametrize("depth,subme", [(8, 2), (8, 0), (8, 1), (8, 3), (8, 5), (8, 7), (10, 2), (10, 7)])
-def test_subpel_refine_matches_oracle(depth, subme):
+@pytest.mark.parametrize("planes", [False, True])
+@pytest.mark.parametrize("depth,subme", [(8, 2), (8, 0), (8, 1), (8, 3), (8, 5), (8, 7), (10, 2), (10, 7), (12, 3)])
+def test_subpel_refine_matches_oracle(depth, subme, planes):
+    """planes: the candidates are read from the reference picture's phase planes (x265hip_phase_planes) instead of being interpolated
+    per candidate tile - the same decisions either way."""
     import torch
     dev = torch.device("cuda:0")
     # sub-pel motion: frame 1 is frame 0 shifted by a non-integer amount (bilinear mix) plus noise
@@ -32,7 +35,7 @@ def test_subpel_refine_matches_oracle(depth, subme):
     cur, ref = P.DevicePicture(y1, dev), P.DevicePicture(clip[0][0], dev)
     ms = P.MotionSearch(cur.w64, cur.h64, 8, depth, dev, want_surf=False)
     ms.run(cur, ref)
-    sp = P.SubpelRefine(ms, subme, dev)
+    sp = P.SubpelRefine(ms, subme, dev, phase_planes=planes)
     sp.run(cur, ref)
     torch.cuda.synchronize()
     O = _oracle()

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) phase_luma_kernel(PhaseArgs a)
 {
     constexpr int BPP = sizeof(Px);
     const int phase = blockIdx.x + 1, xf = phase & 3, yf = phase >> 2;
-    const int tx = blockIdx.y * 256 + threadIdx.x, ty = blockIdx.z;
+    const int tx = blockIdx.y * 256 + threadIdx.x, ty = blockIdx.z + 1;          // the first 4 and the last 8 rows are not produced
     if (tx >= a.tilesW) return;
     const long off = (long)(ty * 4) * a.strideB + (long)tx * 4 * BPP;
     int d[4][4];
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) phase_chroma_kernel(PhaseArgs a)
 {
     constexpr int BPP = sizeof(Px);
     const int phase = blockIdx.x + 1, xf = phase & 7, yf = phase >> 3;
-    const int tx = blockIdx.y * 256 + threadIdx.x, ty = blockIdx.z;
+    const int tx = blockIdx.y * 256 + threadIdx.x, ty = blockIdx.z + 1;
     if (tx >= a.tilesW) return;
     const long off = (long)(ty * 4) * a.strideB + (long)tx * 4 * BPP;
     const int maxVal = (1 << a.depth) - 1, headRoom = 14 - a.depth;
@@ -142,8 +142,10 @@ extern "C" int x265hip_phase_planes(const x265hip_phase_planes_params* p, void* 
     PhaseArgs a;
     a.src = (const uint8_t*)p->src; a.dst = (uint8_t*)p->dst; a.strideB = (long)p->stride * bpp; a.rows = p->rows;
     a.tilesW = (int)(p->stride / 4); a.depth = p->depth; a.planeBytes = (size_t)p->stride * p->rows * bpp;
-    if (p->rows / 4 > 65535) { set_error("phase_planes: %d rows", p->rows); return X265HIP_EINVAL; }
-    const dim3 grid(p->chroma ? 63 : 15, (a.tilesW + 255) / 256, p->rows / 4);
+    if (p->rows / 4 > 65535 || p->rows < 16) { set_error("phase_planes: %d rows", p->rows); return X265HIP_EINVAL; }
+    // tile rows 1 .. rows / 4 - 3: a tile reads 3 rows above and 7 below itself (and a few bytes of the neighbouring rows at the row
+    // ends), so every access stays inside the plane without any guard memory around it
+    const dim3 grid(p->chroma ? 63 : 15, (a.tilesW + 255) / 256, p->rows / 4 - 3);
     hipStream_t s = (hipStream_t)stream;
     if (p->chroma)
     {

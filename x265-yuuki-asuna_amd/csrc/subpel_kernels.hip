@@ -27,6 +27,7 @@ struct SubpelArgs
     const uint16_t* costQ; int qoff;
     int hpelIters, hpelDirs, qpelIters, qpelDirs, hpelSatd;
     int2* out;                       // {cost, qx | qy << 16} per PU, [ctu][85]
+    const uint8_t* planes; long planeBytes;      // phase planes of fref (x265hip_phase_planes), sample (0,0) of phase 1; NULL = interpolate
 };
 
 __constant__ int16_t kSpLumaTaps[4][8] = {
@@ -63,7 +64,10 @@ template <typename Px, int LEVEL> struct SpGeom
 // One workgroup = one (CTU, PU level): 256 threads, thread t owns 4x4 tile (t % NTILES) of PU (t / NTILES) for the
 // whole search, its 16 source pixels in registers.  Each pass of an evaluation round handles ONE candidate for
 // all PUs, so a wavefront mostly runs a single interpolation case.
-template <typename Px, int LEVEL>
+// PL: the candidates' samples are READ from the reference picture's phase planes (x265hip_phase_planes: the same luma_hpp / luma_vpp /
+// luma_hvpp samples, computed once per picture) instead of being interpolated per candidate tile: no LDS patches, four dword loads
+// per candidate tile.
+template <typename Px, int LEVEL, bool PL>
 __device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemRaw, SpShared& sh)
 {
     typedef SpGeom<Px, LEVEL> G;
@@ -100,6 +104,7 @@ __device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemR
             for (int x = 0; x < 4; x++) src[y][x] = fe[y * fst + x];
     }
     __syncthreads();
+    if (!PL)
     {   // stage every PU's reference patch, one (possibly unaligned) dword per item
         constexpr int ITEMS = NPU * PW * G::DWR;
         uint32_t* pdw = reinterpret_cast<uint32_t*>(smemRaw);
@@ -162,12 +167,34 @@ __device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemR
             }
         }
     };
+    // PL: byte address of the tile's sample (0,0) at integer mv (0,0), relative to fref / to a phase plane's sample (0,0)
+    const long tileOff = (long)(cy + byz * N + ty * 4) * a.frefStrideB + (long)(cx + bxz * N + tx * 4) * BPP;
     auto tile_cost = [&](const int qx, const int qy, const bool useSatd) -> int
     {
         const int ox = (qx >> 2) + pox, oy = (qy >> 2) + poy;
         const int xf = qx & 3, yf = qy & 3;
         int d[4][4];
-        if (!(xf | yf))
+        if (PL)
+        {
+            const int ph = yf * 4 + xf;
+            const uint8_t* base = (ph ? a.planes + (long)(ph - 1) * a.planeBytes : a.fref) + tileOff + (long)(qy >> 2) * a.frefStrideB + (long)(qx >> 2) * BPP;
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+            {
+                const uint8_t* rp = base + (long)y * a.frefStrideB;
+                if (BPP == 1)
+                {
+                    const uint32_t w = ld_u32(rp);
+                    d[y][0] = w & 0xff; d[y][1] = (w >> 8) & 0xff; d[y][2] = (w >> 16) & 0xff; d[y][3] = w >> 24;
+                }
+                else
+                {
+                    const uint32_t w0 = ld_u32(rp), w1 = ld_u32(rp + 4);
+                    d[y][0] = w0 & 0xffff; d[y][1] = w0 >> 16; d[y][2] = w1 & 0xffff; d[y][3] = w1 >> 16;
+                }
+            }
+        }
+        else if (!(xf | yf))
         {
 #pragma unroll
             for (int y = 0; y < 4; y++)
@@ -332,17 +359,17 @@ __device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemR
     }
 }
 
-template <typename Px>
+template <typename Px, bool PL = false>
 __global__ void __launch_bounds__(256) subpel_refine_kernel(SubpelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smemRaw[];
     __shared__ SpShared sh;
     switch (blockIdx.y)                                   // all four PU levels of a CTU run concurrently
     {
-    case 0: subpel_level<Px, 0>(a, smemRaw, sh); break;
-    case 1: subpel_level<Px, 1>(a, smemRaw, sh); break;
-    case 2: subpel_level<Px, 2>(a, smemRaw, sh); break;
-    default: subpel_level<Px, 3>(a, smemRaw, sh); break;
+    case 0: subpel_level<Px, 0, PL>(a, smemRaw, sh); break;
+    case 1: subpel_level<Px, 1, PL>(a, smemRaw, sh); break;
+    case 2: subpel_level<Px, 2, PL>(a, smemRaw, sh); break;
+    default: subpel_level<Px, 3, PL>(a, smemRaw, sh); break;
     }
 }
 
@@ -368,6 +395,8 @@ extern "C" int x265hip_subpel_refine(const x265hip_subpel_params* p, void* strea
     a.bestIn = (const unsigned long long*)p->best_in; a.costQ = p->cost_q; a.qoff = p->qoff;
     a.hpelIters = wl[p->subme][0]; a.hpelDirs = wl[p->subme][1]; a.qpelIters = wl[p->subme][2]; a.qpelDirs = wl[p->subme][3]; a.hpelSatd = wl[p->subme][4];
     a.out = (int2*)p->out;
+    a.planes = (const uint8_t*)p->phase_planes; a.planeBytes = (long)p->phase_plane_samples * bpp;
+    if (a.planes && p->phase_plane_samples <= 0) { set_error("subpel_refine: phase_plane_samples"); return X265HIP_EINVAL; }
     const int nctu = a.ctusW * (p->height / 64);
     hipStream_t s = (hipStream_t)stream;
     // one launch: grid.y = PU level; LDS sized for level 0 (64 patches of 23 rows), the largest
@@ -376,7 +405,12 @@ extern "C" int x265hip_subpel_refine(const x265hip_subpel_params* p, void* strea
                   && SpGeom<uint8_t, 0>::PSZ * 64 >= SpGeom<uint8_t, 3>::PSZ, "level 0 is the largest");
     static_assert(SpGeom<uint16_t, 0>::PSZ * 64 >= SpGeom<uint16_t, 1>::PSZ * 16 && SpGeom<uint16_t, 0>::PSZ * 64 >= SpGeom<uint16_t, 2>::PSZ * 4
                   && SpGeom<uint16_t, 0>::PSZ * 64 >= SpGeom<uint16_t, 3>::PSZ, "level 0 is the largest");
-    if (p->depth == 8)
+    if (a.planes)
+    {
+        if (p->depth == 8) hipLaunchKernelGGL((subpel_refine_kernel<uint8_t, true>), dim3(nctu, 4), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((subpel_refine_kernel<uint16_t, true>), dim3(nctu, 4), dim3(256), 0, s, a);
+    }
+    else if (p->depth == 8)
         hipLaunchKernelGGL(subpel_refine_kernel<uint8_t>, dim3(nctu, 4), dim3(256), lds, s, a);
     else
     {

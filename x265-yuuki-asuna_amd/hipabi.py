@@ -45,6 +45,7 @@ class SubpelParams(ctypes.Structure):
         ("fenc", ctypes.c_void_p), ("fenc_stride", ctypes.c_ssize_t),
         ("fref", ctypes.c_void_p), ("fref_stride", ctypes.c_ssize_t),
         ("best_in", ctypes.c_void_p), ("cost_q", ctypes.c_void_p), ("qoff", ctypes.c_int), ("out", ctypes.c_void_p),
+        ("phase_planes", ctypes.c_void_p), ("phase_plane_samples", ctypes.c_ssize_t),
     ]
 
 
@@ -193,13 +194,16 @@ def me_fullsearch(depth, width, height, rng, fenc, fenc_stride, fref, fref_strid
 
 
 def subpel_refine(depth, width, height, rng, subme, fenc, fenc_stride, fref, fref_stride, best_in, cost_q, qoff, out,
-                  fenc_off=0, fref_off=0, stream=None):
+                  fenc_off=0, fref_off=0, stream=None, phase_planes=None):
+    """phase_planes: byte tensor with the 15 luma phase planes of the fref buffer (x265hip_phase_planes, same geometry as fref's tensor)."""
     es = 1 if depth == 8 else 2
     p = SubpelParams()
     p.depth, p.width, p.height, p.range, p.subme = depth, width, height, rng, subme
     p.fenc, p.fenc_stride = fenc.data_ptr() + fenc_off * es, fenc_stride
     p.fref, p.fref_stride = fref.data_ptr() + fref_off * es, fref_stride
     p.best_in, p.cost_q, p.qoff, p.out = best_in.data_ptr(), cost_q.data_ptr(), qoff, out.data_ptr()
+    if phase_planes is not None:
+        p.phase_planes, p.phase_plane_samples = phase_planes.data_ptr() + fref_off * es, fref.numel() * fref.element_size() // es
     s = current_stream() if stream is None else stream
     f = lib().x265hip_subpel_refine
     f.argtypes = [ctypes.POINTER(SubpelParams), ctypes.c_void_p]
@@ -732,8 +736,8 @@ class PhasePlanesParams(ctypes.Structure):
 
 
 def phase_planes(depth, src, src_off_bytes, dst, stride, rows, chroma=False, stream=None):
-    """x265hip_phase_planes: every fractional phase of one padded plane.  src: device byte tensor that holds the plane at byte
-    offset src_off_bytes with >= 4 rows + 64 B of readable memory before it and 8 rows after it; dst: 15 (luma) / 63 (chroma) planes."""
+    """x265hip_phase_planes: every fractional phase of one padded plane.  src: device tensor that holds the plane at byte offset
+    src_off_bytes; dst: 15 (luma) / 63 (chroma) planes (their first 4 and last 8 rows are not produced)."""
     p = PhasePlanesParams(depth, int(bool(chroma)), src.data_ptr() + src_off_bytes, dst.data_ptr(), stride, rows)
     s = current_stream() if stream is None else stream
     f = lib().x265hip_phase_planes

@@ -170,18 +170,29 @@ class SubpelRefine:
     (x265hip_subpel_refine; reference caller motion.cpp:1448-1664).  Output int32 [ctu*85][2] =
     {cost, qmvx | qmvy << 16}."""
 
-    def __init__(self, ms: MotionSearch, subme: int, device, lam=4.0):
+    def __init__(self, ms: MotionSearch, subme: int, device, lam=4.0, phase_planes=False):
+        """phase_planes=True: the reference picture's 15 fractional-phase planes are computed first (x265hip_phase_planes, one launch)
+        and every candidate is READ from them instead of being interpolated per candidate tile - same samples, same result."""
         import torch
         self.ms, self.subme = ms, subme
+        self.use_planes, self.planes = bool(phase_planes), None
         cq, self.qoff = F.qpel_cost_table(ms.range, lam)
         self.cost_q_host = cq
         self.cost_q = torch.from_numpy(cq.view(np.int16)).to(device)
         self.out = torch.zeros(ms.nctu * PUS_PER_CTU * 2, dtype=torch.int32, device=device)
 
     def run(self, cur: DevicePicture, ref: DevicePicture):
+        import torch
         ms = self.ms
+        planes = None
+        if self.use_planes:
+            nb = ref.t.numel() * ref.t.element_size()
+            if self.planes is None or self.planes.numel() != 15 * nb:
+                self.planes = torch.empty(15 * nb, dtype=torch.uint8, device=ref.t.device)
+            hipabi.phase_planes(ms.depth, ref.t, 0, self.planes, ref.stride, nb // (ref.stride * (1 if ms.depth == 8 else 2)))
+            planes = self.planes
         hipabi.subpel_refine(ms.depth, ms.w64, ms.h64, ms.range, self.subme, cur.t, cur.stride, ref.t, ref.stride,
-                             ms.best, self.cost_q, self.qoff, self.out, fenc_off=cur.org, fref_off=ref.org)
+                             ms.best, self.cost_q, self.qoff, self.out, fenc_off=cur.org, fref_off=ref.org, phase_planes=planes)
 
     def checksum(self):
         return {"subpel": int(self.out.to(dtype=__import__("torch").int64).sum().item())}

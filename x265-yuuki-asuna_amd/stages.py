@@ -456,12 +456,14 @@ class FramePipeline:
     cost estimate per 8x8 block), which only depends on the source."""
 
     def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False, lookahead=None,
-                 search="full", deblock=False, sao=False, lookahead_cost_batch=0, chroma=False, sao_apply=False, sign_hide=False):
+                 search="full", deblock=False, sao=False, lookahead_cost_batch=0, chroma=False, sao_apply=False, sign_hide=False,
+                 subpel_planes=False):
         import torch
         from .pipeline import MotionSearch, SubpelRefine
         self.depth = depth
         self.ms = MotionSearch(w64, h64, rng, depth, device, want_surf=want_surf and search == "full", want_best=True, packed=packed)
-        self.sp = SubpelRefine(self.ms, subme, device)
+        # subpel_planes: sub-pel candidates read from the reference picture's phase planes (one x265hip_phase_planes launch per frame)
+        self.sp = SubpelRefine(self.ms, subme, device, phase_planes=subpel_planes)
         # search != "full": the pattern-search drivers replace the exhaustive search + sub-pel pair
         self.ps = None
         if search != "full":
