@@ -37,6 +37,8 @@ CONFIGS = {
                  name="configs[2]: 2160p 8-bit --preset slow --me star"),
     "cfg4": dict(width=3840, height=2160, depth=10, preset="slower", opts=[], frames=3,
                  name="configs[3]: 2160p 10-bit --preset slower (one GPU's share of the frame-parallel job)"),
+    "cfg5": dict(width=7680, height=4320, depth=10, preset="veryslow", opts=[("ctu", "64"), ("rd", "6")], frames=3,
+                 name="configs[4]: 4320p 10-bit --preset veryslow --ctu 64 --rd 6 (one GPU's share of the frame-parallel job)"),
 }
 FILL = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int)
 
