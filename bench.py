@@ -293,13 +293,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # X265HIP_BENCH_BACKEND=gloo: functional dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, the bands
+    # travel through host memory) - for checking the ring / band code on real kernels, never for numbers
+    backend = os.environ.get("X265HIP_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         # a hand-off that never completes must fail the run within minutes, not hold the node until the driver's limit
-        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=240))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=240))
+        else:
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=240))
 
     F = importlib.import_module("x265-yuuki-asuna_amd.frames")
     P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
@@ -324,7 +331,8 @@ def main():
                                    # workgroups (one per CU): bands use the record-contiguous packed format of the row-walking kernel
                                    packed=(args.surf_format != "i32" and args.depth == 8),
                                    lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True)
-        ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16)      # search window + 8-tap interpolation + sub-pel drift
+        ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16,      # search window + 8-tap interpolation + sub-pel drift
+                                   stage_through_host=backend != "nccl")
         ring.make_groups()
         geom = (pics[0].stride, F.MARGIN_Y, pics[0].stride_c, F.CHROMA_MARGIN_Y)
         total_frames = (args.warmup + args.steps) * world

@@ -94,7 +94,7 @@ def _ring_serial(nframes, w64, h64, bands, lag):
     return outs
 
 
-def _ring_worker(rank, world, port, steps, out):
+def _ring_worker(rank, world, port, steps, out, staged=False):
     sys.path.insert(0, ROOT)
     P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -103,7 +103,7 @@ def _ring_worker(rank, world, port, steps, out):
     w64, h64, lag = 128, 448, 72                     # 7 CTU rows, bands of 2: (0,2) (2,2) (4,2) (6,1); a window of 57 + 8 + taps < 72 rows
     bands = [(r, min(2, 7 - r)) for r in range(0, 7, 2)]
     geom, ny, nc = _ring_geometry(w64, h64)
-    ring = P.FrameParallelRing(rank, world, bands, lag)
+    ring = P.FrameParallelRing(rank, world, bands, lag, stage_through_host=staged)
     ring.make_groups()
     assert [ring.bands_needed(b) for b in range(4)] == [1, 2, 3, 3]
     ref = [torch.full((ny,), 17, dtype=torch.uint8), torch.full((nc,), 29, dtype=torch.uint8), torch.full((nc,), 31, dtype=torch.uint8)]
@@ -129,11 +129,11 @@ def _ring_worker(rank, world, port, steps, out):
     dist.destroy_process_group()
 
 
-def _run_ring(world, steps):
+def _run_ring(world, steps, staged=False):
     mgr = mp.Manager()
     out = mgr.dict()
-    port = 29600 + (os.getpid() % 300) + world
-    mp.spawn(_ring_worker, args=(world, port, steps, out), nprocs=world, join=True)
+    port = 29600 + (os.getpid() % 300) + world + (10 if staged else 0)
+    mp.spawn(_ring_worker, args=(world, port, steps, out, staged), nprocs=world, join=True)
     return out
 
 
@@ -147,3 +147,9 @@ def test_ring_three_ranks():
     out = _run_ring(3, 2)
     assert all(out[r][0] for r in range(3))
     assert out[2][1] == [2, 5]
+
+
+def test_ring_two_ranks_with_host_staged_transfers():
+    """The dry-run flavour bench.py uses when the backend has no device point-to-point transfers (X265HIP_BENCH_BACKEND=gloo)."""
+    out = _run_ring(2, 3, staged=True)
+    assert out[0][0] and out[1][0]

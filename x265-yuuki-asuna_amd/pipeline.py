@@ -242,8 +242,11 @@ class FrameParallelRing:
 
     bands: [(first CTU row, CTU rows)], row_bytes-free: slices are computed from the plane geometry handed to run_frame."""
 
-    def __init__(self, rank: int, world: int, bands, lag_rows_luma: int):
+    def __init__(self, rank: int, world: int, bands, lag_rows_luma: int, stage_through_host: bool = False):
+        """stage_through_host: device slices travel through host copies (a backend without device point-to-point transfers - the gloo
+        dry run of bench.py's N > 1 path on a box with fewer GPUs than ranks); never used with RCCL."""
         self.rank, self.world, self.bands = rank, world, list(bands)
+        self.stage = stage_through_host
         self.lag = lag_rows_luma            # luma rows below a band's last row that its search / interpolation may read
         self.prev, self.next = (rank - 1) % world, (rank + 1) % world
         self._sends = []
@@ -292,7 +295,19 @@ class FrameParallelRing:
         def p2p(op, planes, ranges, peer, group):
             """The three plane slices of one band as ONE grouped transfer (a single ncclGroup on RCCL: one launch per band and
             direction instead of three)."""
-            return dist.batch_isend_irecv([dist.P2POp(op, flat(p)[a:z], peer, group) for p, (a, z) in zip(planes, ranges)])
+            if not self.stage:
+                return dist.batch_isend_irecv([dist.P2POp(op, flat(p)[a:z], peer, group) for p, (a, z) in zip(planes, ranges)])
+            views = [flat(p)[a:z] for p, (a, z) in zip(planes, ranges)]
+            hosts = [v.cpu() if op is dist.isend else __import__("torch").empty(v.shape, dtype=v.dtype) for v in views]
+            works = dist.batch_isend_irecv([dist.P2POp(op, h, peer, group) for h in hosts])
+
+            class Staged:
+                def __init__(self, w, pairs): self.w, self.pairs = w, pairs
+                def wait(self):
+                    self.w.wait()
+                    for v, h in self.pairs:
+                        v.copy_(h)
+            return [Staged(w, ([(v, h)] if op is dist.irecv else [])) for w, v, h in zip(works, views, hosts)]
         groups = getattr(self, "groups", [None, None])
         g_in, g_out = groups[self.prev % 2], groups[self.rank % 2]
         recv_from_peer = self.world > 1 and not (f == 0 and first_frame_is_local)
