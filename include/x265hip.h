@@ -349,8 +349,11 @@ typedef struct x265hip_lowres_cost_host_params
     int32_t* mvs[2];  int32_t* mv_costs[2];
     uint16_t* lowres_costs;  int32_t* row_satds;  int64_t* frame;
     /* optional content keys (0 = upload on every call): a non-zero key vouches that the plane set at these host addresses does not
-     * change while the key stays the same (e.g. Lowres::frameNum + 1), so the library keeps ONE device copy across the many triples
-     * that involve the picture.  cur / ref / ref1 / ref_bi planes respectively; weighted scratch planes must pass 0. */
+     * change while the key stays the same, so the library keeps ONE device copy across the many triples that involve the picture.
+     * The key must name the CONTENT for as long as the process lives: a frame number alone repeats in the next encode of the same
+     * process (and the allocator hands out the same addresses again) - combine it with an encoder-instance number, e.g.
+     * instance << 32 | (Lowres::frameNum + 1), or call x265hip_lowres_planes_forget() when an encoder closes.
+     * cur / ref / ref1 / ref_bi planes respectively; weighted scratch planes must pass 0. */
     uint64_t plane_key_cur, plane_key_ref, plane_key_ref1, plane_key_ref_bi;
 } x265hip_lowres_cost_host_params;
 int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p);
@@ -369,6 +372,8 @@ typedef struct x265hip_lowres_intra_host_params
     uint64_t plane_key;
 } x265hip_lowres_intra_host_params;
 int x265hip_lowres_intra_host(const x265hip_lowres_intra_host_params* p);
+/* drops every device copy the two host entries above keep under plane keys (call between encodes, with no estimate in flight) */
+void x265hip_lowres_planes_forget(void);
 
 /* ---- in-loop deblocking of a device-resident luma reconstruction (deblocking half) ----
  * x265hip_deblock_bs_inter = Deblock::getBoundaryStrength (deblock.cpp:191-215) for a P picture with one reference cut into

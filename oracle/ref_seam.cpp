@@ -38,6 +38,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 #include <time.h>
 
 using namespace X265_NS;
@@ -99,7 +100,8 @@ struct LookaheadSeam
     la_oracle_fn oracle = NULL;
     la_intra_host_fn intraHost = NULL;
     la_intra_oracle_fn intraOracle = NULL;
-    std::atomic<uint64_t> served{0}, passed{0}, failed{0}, intraServed{0};
+    std::atomic<uint64_t> served{0}, passed{0}, failed{0}, intraServed{0}, mismatches{0};
+    uint64_t instance = 0;          /* bumped by every configure: a frame number names a picture's content only within one encode */
 } gla;
 
 struct MeCostProbe : public MotionEstimate { const uint16_t* costCentre() const { return m_cost; } };
@@ -684,11 +686,46 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
         q.lowres_costs = fenc->lowresCosts[b - p0][p1 - b]; q.row_satds = fenc->rowSatds[b - p0][p1 - b]; q.frame = frame;
         /* a Lowres' planes are written once per picture (Lowres::init): its frame number names their content; weighted planes live in
          * the thread's scratch (tld.wbuffer) and are uploaded every time */
-        q.plane_key_cur = (uint64_t)fenc->frameNum + 1;
-        q.plane_key_ref = wfref0 == fref0 ? (uint64_t)fref0->frameNum + 1 : 0;
-        q.plane_key_ref1 = bidir ? (uint64_t)fref1->frameNum + 1 : 0;
-        q.plane_key_ref_bi = (bidir && wfref0 != fref0) ? (uint64_t)fref0->frameNum + 1 : 0;
+        const uint64_t inst = gla.instance << 32;
+        q.plane_key_cur = inst | ((uint64_t)(uint32_t)fenc->frameNum + 1);
+        q.plane_key_ref = wfref0 == fref0 ? inst | ((uint64_t)(uint32_t)fref0->frameNum + 1) : 0;
+        q.plane_key_ref1 = bidir ? inst | ((uint64_t)(uint32_t)fref1->frameNum + 1) : 0;
+        q.plane_key_ref_bi = (bidir && wfref0 != fref0) ? inst | ((uint64_t)(uint32_t)fref0->frameNum + 1) : 0;
+        /* both providers configured = verify mode (tests): the oracle scores the same triple from the same inputs into scratch arrays */
+        std::vector<int32_t> vm0, vc0, vm1, vc1, vrs; std::vector<uint16_t> vlc; int64_t vframe[4] = { 0, 0, 0, 0 };
+        const int nblk = q.width_in_cu * q.height_in_cu;
+        if (gla.oracle)
+        {
+            vm0.assign(q.mvs[0], q.mvs[0] + 2 * nblk); vc0.assign(q.mv_costs[0], q.mv_costs[0] + nblk);
+            if (bidir) { vm1.assign(q.mvs[1], q.mvs[1] + 2 * nblk); vc1.assign(q.mv_costs[1], q.mv_costs[1] + nblk); }
+            vlc.assign(q.lowres_costs, q.lowres_costs + nblk); vrs.assign(q.row_satds, q.row_satds + q.height_in_cu);
+        }
         rc = gla.host(&q);
+        if (gla.oracle && !rc)
+        {
+            const pixel* r0[4]; const pixel* r1[4]; const pixel* rb[4];
+            for (int i = 0; i < 4; i++) { r0[i] = wfref0->lowresPlane[i]; r1[i] = fref1->lowresPlane[i]; rb[i] = fref0->lowresPlane[i]; }
+            const int ds[2] = { bDoSearch[0], bDoSearch[1] };
+            gla.oracle(fenc->lowresPlane[0], r0, bidir ? r1 : NULL, fenc->lumaStride, q.width_in_cu, q.height_in_cu,
+                       static_cast<const MeCostProbe&>(tld.me).costCentre(), 0, fenc->intraCost, fenc->invQscaleFactor, ds, param->bFrameBias,
+                       vm0.data(), vc0.data(), bidir ? vm1.data() : NULL, bidir ? vc1.data() : NULL, vlc.data(), vrs.data(), vframe,
+                       (bidir && wfref0 != fref0) ? rb : NULL);
+            int bad = 0;
+            auto cmp = [&](const char* what, const void* a, const void* bb, size_t bytes)
+            { if (memcmp(a, bb, bytes)) { bad++; fprintf(stderr, "ref_seam: LOOKAHEAD VERIFY MISMATCH (%d, %d, %d) %s\n", p0, b, p1, what); } };
+            cmp("mvs[0]", q.mvs[0], vm0.data(), (size_t)2 * nblk * 4); cmp("mv_costs[0]", q.mv_costs[0], vc0.data(), (size_t)nblk * 4);
+            if (bidir) { cmp("mvs[1]", q.mvs[1], vm1.data(), (size_t)2 * nblk * 4); cmp("mv_costs[1]", q.mv_costs[1], vc1.data(), (size_t)nblk * 4); }
+            cmp("lowres_costs", q.lowres_costs, vlc.data(), (size_t)nblk * 2); cmp("row_satds", q.row_satds, vrs.data(), (size_t)q.height_in_cu * 4);
+            cmp("frame totals", frame, vframe, sizeof(vframe));
+            if (bad)
+            {
+                fprintf(stderr, "ref_seam: do_search %d/%d weighted %d bidir %d keys %llu %llu %llu frame gpu %lld %lld %lld %lld oracle %lld %lld %lld %lld\n",
+                        bDoSearch[0], bDoSearch[1], wfref0 != fref0, bidir, (unsigned long long)q.plane_key_cur, (unsigned long long)q.plane_key_ref,
+                        (unsigned long long)q.plane_key_ref1, (long long)frame[0], (long long)frame[1], (long long)frame[2], (long long)frame[3],
+                        (long long)vframe[0], (long long)vframe[1], (long long)vframe[2], (long long)vframe[3]);
+                gla.mismatches.fetch_add(1, std::memory_order_relaxed);
+            }
+        }
     }
     else
     {
@@ -737,8 +774,19 @@ void LookaheadTLD::lowresIntraEstimate(Lowres& fenc, uint32_t qgSize)
         q.lines = fenc.lines; q.margin_y = (int)(pad / fenc.lumaStride); q.margin_x = (int)(pad % fenc.lumaStride);
         q.plane = fenc.lowresPlane[0]; q.intra_penalty = intraPenalty;
         q.intra_cost = fenc.intraCost; q.intra_mode = fenc.intraMode; q.lowres_costs = fenc.lowresCosts[0][0];
-        q.plane_key = (uint64_t)fenc.frameNum + 1;
+        q.plane_key = (gla.instance << 32) | ((uint64_t)(uint32_t)fenc.frameNum + 1);
         rc = gla.intraHost(&q);
+        if (gla.intraOracle && !rc)
+        {
+            const int nblk = widthInCU * heightInCU;
+            std::vector<int32_t> vc(nblk); std::vector<uint8_t> vmode(nblk); std::vector<uint16_t> vlc(fenc.lowresCosts[0][0], fenc.lowresCosts[0][0] + nblk);
+            gla.intraOracle(fenc.lowresPlane[0], fenc.lumaStride, widthInCU, heightInCU, intraPenalty, vc.data(), vmode.data(), vlc.data(), 1);
+            if (memcmp(vc.data(), fenc.intraCost, (size_t)nblk * 4) || memcmp(vmode.data(), fenc.intraMode, nblk))
+            {
+                fprintf(stderr, "ref_seam: LOOKAHEAD INTRA VERIFY MISMATCH frame %d\n", fenc.frameNum);
+                gla.mismatches.fetch_add(1, std::memory_order_relaxed);
+            }
+        }
     }
     else
         gla.intraOracle(fenc.lowresPlane[0], fenc.lumaStride, widthInCU, heightInCU, intraPenalty, fenc.intraCost, fenc.intraMode, fenc.lowresCosts[0][0], 1);
@@ -836,7 +884,8 @@ int x265ref_lookahead_seam_configure(void* host_fn, void* oracle_fn, void* intra
     gla.oracle = (la_oracle_fn)oracle_fn;
     gla.intraHost = (la_intra_host_fn)intra_host_fn;
     gla.intraOracle = (la_intra_oracle_fn)intra_oracle_fn;
-    gla.served = 0; gla.passed = 0; gla.failed = 0; gla.intraServed = 0;
+    gla.served = 0; gla.passed = 0; gla.failed = 0; gla.intraServed = 0; gla.mismatches = 0;
+    gla.instance++;
     gla.enabled = host_fn || oracle_fn;
     return 0;
 }
@@ -844,6 +893,7 @@ int x265ref_lookahead_seam_configure(void* host_fn, void* oracle_fn, void* intra
 /* out[4]: frame cost estimates served by the provider, passed to the reference's loop (HME / cooperative slices / qg 8), failed,
  * intra estimates served */
 void x265ref_lookahead_seam_stats(uint64_t* out) { out[0] = gla.served; out[1] = gla.passed; out[2] = gla.failed; out[3] = gla.intraServed; }
+uint64_t x265ref_lookahead_seam_mismatches(void) { return gla.mismatches; }
 
 /* table filler with the x265hip_setup_primitives signature: installs the lookup stubs over the host's own sad family */
 int x265ref_seam_fill_table(void* table, size_t bytes, int depth)

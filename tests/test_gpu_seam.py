@@ -109,11 +109,23 @@ def test_lookahead_seam_on_gpu_is_byte_identical(depth, preset, extra):
     list reuse, weighted references, AQ weights): same slice decisions, same bitstream."""
     import test_seam_cpu as T
     opts = [("pools", "4"), ("frame-threads", "1"), ("crf", "24"), ("lookahead-slices", "1")] + extra
-    base, got, rep = T.run_pair(depth, 320, 192, 12, preset, opts, "gpu", rng=16, verify=True, wait=True, lookahead="gpu")
-    assert got[0] == base[0], f"lookahead seam changed the bitstream: {rep}"
+    # gpu+verify: the oracle re-scores every (p0, b, p1) triple and every intra estimate from the same inputs, in flight
+    base, got, rep = T.run_pair(depth, 320, 192, 12, preset, opts, "gpu", rng=16, verify=True, wait=True, lookahead="gpu+verify")
     la = rep["lookahead_seam"]
+    assert la["verify_mismatches"] == 0, la
+    assert got[0] == base[0], f"lookahead seam changed the bitstream: {rep}"
     assert la["frame_cost_estimates_served"] >= 10 and la["intra_estimates_served"] >= 12 and la["failed"] == 0, la
     assert rep["verify_mismatches"] == 0 and rep["failed"] == 0
+
+
+def test_lookahead_seam_survives_a_second_encode_with_other_pictures_at_the_same_addresses():
+    """Two encodes in one process: the allocator hands the second one the first one's Lowres addresses and the frame numbers repeat;
+    the plane keys carry an encoder-instance number, so no device copy of the first clip is served to the second."""
+    import test_seam_cpu as T
+    opts = [("pools", "4"), ("frame-threads", "1"), ("crf", "24"), ("lookahead-slices", "1")]
+    for seed in (41, 42, 43, 41):
+        base, got, rep = T.run_pair(8, 320, 192, 12, "medium", opts, "gpu", rng=16, verify=False, wait=True, lookahead="gpu+verify", seed=seed)
+        assert rep["lookahead_seam"]["verify_mismatches"] == 0 and got[0] == base[0], (seed, rep["lookahead_seam"])
 
 
 def test_lowres_cost_host_entry_equals_oracle():

@@ -273,10 +273,15 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     # "oracle" = the CPU restatement (checker; GPU-less tests), None = off.  Needs --lookahead-slices 1.
     lib.x265ref_lookahead_seam_configure.argtypes = [ctypes.c_void_p] * 4
     keep = None
-    if lookahead == "gpu":
+    if lookahead in ("gpu", "gpu+verify"):
         A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
-        lib.x265ref_lookahead_seam_configure(ctypes.cast(A.lib().x265hip_lowres_cost_host, ctypes.c_void_p), None,
-                                             ctypes.cast(A.lib().x265hip_lowres_intra_host, ctypes.c_void_p), None)
+        ocost = ointra = None
+        if lookahead == "gpu+verify":          # the oracle re-scores every triple from the same inputs; mismatches are reported and counted
+            keep = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libx265oracle.so"))
+            ocost = ctypes.cast(getattr(keep, f"x265oracle_lowres_cost_wp_d{depth}"), ctypes.c_void_p)
+            ointra = ctypes.cast(getattr(keep, f"x265oracle_lowres_intra_d{depth}"), ctypes.c_void_p)
+        lib.x265ref_lookahead_seam_configure(ctypes.cast(A.lib().x265hip_lowres_cost_host, ctypes.c_void_p), ocost,
+                                             ctypes.cast(A.lib().x265hip_lowres_intra_host, ctypes.c_void_p), ointra)
     elif lookahead == "oracle":
         keep = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libx265oracle.so"))
         lib.x265ref_lookahead_seam_configure(None, ctypes.cast(getattr(keep, f"x265oracle_lowres_cost_wp_d{depth}"), ctypes.c_void_p),
@@ -304,8 +309,9 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
         d.update({"range": rng, "slots": slots, "min_pu": min_pu})
         la = (ctypes.c_uint64 * 4)()
         lib.x265ref_lookahead_seam_stats(la)
+        lib.x265ref_lookahead_seam_mismatches.restype = ctypes.c_uint64
         d["lookahead_seam"] = {"provider": lookahead, "frame_cost_estimates_served": int(la[0]), "passed_to_reference_loop": int(la[1]), "failed": int(la[2]),
-                               "intra_estimates_served": int(la[3])}
+                               "intra_estimates_served": int(la[3]), "verify_mismatches": int(lib.x265ref_lookahead_seam_mismatches())}
         if sub:
             so = (ctypes.c_uint64 * 6)()
             lib.x265ref_subpel_seam_stats(so)

@@ -92,6 +92,14 @@ int cached_plane(const void* host, uint64_t key, size_t bytes, hipStream_t s, vo
 
 } // namespace
 
+extern "C" void x265hip_lowres_planes_forget(void)
+{
+    std::lock_guard<std::mutex> lk(g_planeMu);
+    for (auto& e : g_planes) (void)hipFree(e.dev);
+    g_planes.clear();
+    g_planeBytes = 0;
+}
+
 extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p)
 {
     int rc = ensure_device();
