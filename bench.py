@@ -243,6 +243,9 @@ def main():
     ap.add_argument("--qp", type=int, default=27)
     ap.add_argument("--depth", type=int, default=8, choices=[8, 10], help="10 = the Main10 configurations (configs[3], [4])")
     ap.add_argument("--no-surface", action="store_true", help="ME keeps only the best mv (no SAD surfaces)")
+    ap.add_argument("--parallel-planes", type=int, default=1, choices=[0, 1],
+                    help="1 = after the sub-pel stage Y, Cb and Cr run their reconstruction -> deblocking -> SAO -> border chains on three HIP "
+                         "streams and the lookahead runs next to the search (same launches, same outputs); 0 = every launch on one stream")
     ap.add_argument("--subpel-planes", type=int, default=1, choices=[0, 1],
                     help="1 = the sub-pel stage reads its candidates from the reference picture's 15 phase planes (one x265hip_phase_planes launch "
                          "per frame, inside the timed step); 0 = it interpolates every candidate tile itself")
@@ -319,7 +322,8 @@ def main():
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
                            qp=args.qp, want_surf=not args.no_surface, packed=({"packed": True, "packed_t": "t"}.get(args.surf_format, False) if args.depth == 8 else False),
                            lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True, lookahead_cost_batch=args.lookahead_batch,
-                           chroma=True, sao_apply=True, sign_hide=True, subpel_planes=bool(args.subpel_planes))
+                           chroma=True, sao_apply=True, sign_hide=True, subpel_planes=bool(args.subpel_planes),
+                           parallel_planes=bool(args.parallel_planes))
     ref_pic = pics[0].like([p.clone() for p in pics[0].planes()])     # the reference every rank searches in (starts as frame 0): Y, Cb, Cr
     fp = P.FrameParallel(rank, world)
     banded = world > 1 or args.banded

@@ -111,11 +111,13 @@ def test_lookahead_costs_run_ahead_in_batches(depth):
     assert np.array_equal(fp.lc[0].mvs.cpu().numpy().reshape(-1, 2), mvs) and np.array_equal(fp.lc[0].frame.cpu().numpy()[:3], frame)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
-def test_closed_loop_with_chroma_and_sao_in_the_loop(depth):
+@pytest.mark.parametrize("depth,fast", [(8, False), (10, False), (8, True), (10, True)])
+def test_closed_loop_with_chroma_and_sao_in_the_loop(depth, fast):
     """The default bench pipeline (luma + 4:2:0 chroma reconstruction, luma + chroma deblocking, SAO statistics -> on-device parameters
     -> SAO apply on Y / Cb / Cr, border extension) over three frames, each searched in and predicted from the previous frame's
-    FILTERED reconstruction; every stage output of every frame against the oracle chain (bench.py's bit_exact code path)."""
+    FILTERED reconstruction; every stage output of every frame against the oracle chain (bench.py's bit_exact code path).
+    fast: bench.py's default launch structure - sub-pel candidates read from the reference's phase planes, the Cb / Cr chains and the
+    lookahead on their own HIP streams."""
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench as B
@@ -125,7 +127,7 @@ def test_closed_loop_with_chroma_and_sao_in_the_loop(depth):
     clip = F.synth_clip(W, Hh, 4, depth=depth, seed=67)
     pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=R, subme=subme, level=level, qp=qp, want_surf=False, lookahead=(W, Hh),
-                           deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True)
+                           deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True, subpel_planes=fast, parallel_planes=fast)
     ref_dev = pics[0].like([p.clone() for p in pics[0].planes()])
     ref_host = None                                                    # frame 1 searches the source frame 0
     types = set()

@@ -457,10 +457,15 @@ class FramePipeline:
 
     def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False, lookahead=None,
                  search="full", deblock=False, sao=False, lookahead_cost_batch=0, chroma=False, sao_apply=False, sign_hide=False,
-                 subpel_planes=False):
+                 subpel_planes=False, parallel_planes=False):
         import torch
         from .pipeline import MotionSearch, SubpelRefine
         self.depth = depth
+        # parallel_planes: after the sub-pel stage the three planes are independent chains (reconstruction -> deblocking -> SAO ->
+        # border) of small, latency-bound launches: Cb and Cr run on their own HIP streams next to Y, the lookahead (source picture
+        # only) next to the search; everything joins the caller's stream before run() returns
+        self.parallel = bool(parallel_planes)
+        self.pstreams = None
         self.ms = MotionSearch(w64, h64, rng, depth, device, want_surf=want_surf and search == "full", want_best=True, packed=packed)
         # subpel_planes: sub-pel candidates read from the reference picture's phase planes (one x265hip_phase_planes launch per frame)
         self.sp = SubpelRefine(self.ms, subme, device, phase_planes=subpel_planes)
@@ -513,6 +518,10 @@ class FramePipeline:
         the picture for the next frame's reference list (final_planes() has all three).  mark(name), if given, is called after every
         stage (bench.py records an event there)."""
         import torch
+        par = self.parallel and mark is None and self.chroma and not self.lcb and self.ps is None and self.db is not None and self.sao is not None \
+            and self.sao_apply and self.band_border is None
+        if par:
+            return self._run_parallel(cur, ref)
         mark = mark or (lambda name: None)
         if self.recon is None:
             self.recon = torch.zeros_like(cur.t)
@@ -590,6 +599,68 @@ class FramePipeline:
         mark("border")
         self.final, self.final_c = final, final_c
         return final
+
+    def _run_parallel(self, cur: DevicePicture, ref: DevicePicture):
+        """The same launches as run(), Y on the caller's stream, Cb / Cr on two side streams from the reconstruction on, the lookahead on
+        a third; all joined before returning (stage outputs are identical: no stage shares an output buffer with another plane)."""
+        import torch
+        main = torch.cuda.current_stream()
+        if self.pstreams is None:
+            self.pstreams = [torch.cuda.Stream() for _ in range(3)]
+        sCb, sCr, sLa = self.pstreams
+        if self.recon is None:
+            self.recon = torch.zeros_like(cur.t)
+        if self.recon_c is None:
+            self.recon_c = [torch.zeros_like(p) for p in cur.c]
+        if self.out is None:
+            self.out = torch.zeros_like(cur.t)
+            self.out_c = [torch.zeros_like(p) for p in cur.c]
+        start = torch.cuda.Event(); start.record(main)
+        if self.la is not None:
+            sLa.wait_event(start)
+            with torch.cuda.stream(sLa):
+                self.la.run(cur)
+        self.ms.reset()
+        self.ms.search(cur, ref)
+        self.sp.run(cur, ref)
+        mv = self.sp.out
+        ev_mv = torch.cuda.Event(); ev_mv.record(main)
+        # reconstruction: one plane per stream
+        self.rc.run(cur, ref, self.recon, mv)
+        ev_rec = []
+        for i, st in enumerate((sCb, sCr)):
+            st.wait_event(ev_mv)
+            with torch.cuda.stream(st):
+                self.rc_c[i].run(cur.c[i], ref.c[i], self.recon_c[i], cur.stride_c, cur.org_c, mv)
+                e = torch.cuda.Event(); e.record(st); ev_rec.append(e)
+        # deblocking: boundary strengths + luma on the caller's stream; the chroma pass (both planes, one entry point) on Cb's stream
+        self.db.run(self.recon, cur, mv, self.rc.num_sig)
+        ev_bs = torch.cuda.Event(); ev_bs.record(main)
+        sCb.wait_event(ev_bs); sCb.wait_event(ev_rec[1])
+        with torch.cuda.stream(sCb):
+            hipabi.deblock_chroma(self.depth, self.recon_c[0], self.recon_c[1], cur.stride_c, cur.org_c, cur.w64, cur.h64,
+                                  self.db.bs_ver, self.db.bs_hor, self.db.qp)
+            ev_dbc = torch.cuda.Event(); ev_dbc.record(sCb)
+        sCr.wait_event(ev_dbc)
+        # SAO + border extension per plane
+        self.sao.stats(cur, self.recon, cur.stride, cur.org)
+        self.sao.decide()
+        self.sao.apply(self.recon, cur.stride, cur.org, self.out)
+        extend_border(self.out, cur)
+        done = []
+        for i, st in enumerate((sCb, sCr)):
+            with torch.cuda.stream(st):
+                self.sao_c[i].stats(None, self.recon_c[i], cur.stride_c, cur.org_c, src_plane=cur.c[i])
+                self.sao_c[i].decide()
+                self.sao_c[i].apply(self.recon_c[i], cur.stride_c, cur.org_c, self.out_c[i])
+                extend_border(self.out_c[i], cur, chroma=True)
+                e = torch.cuda.Event(); e.record(st); done.append(e)
+        if self.la is not None:
+            e = torch.cuda.Event(); e.record(sLa); done.append(e)
+        for e in done:
+            main.wait_event(e)
+        self.final, self.final_c = self.out, self.out_c
+        return self.final
 
     def final_planes(self):
         """[luma, cb, cr] of the picture the last run() produced for the next frame's reference list."""
