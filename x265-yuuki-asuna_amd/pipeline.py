@@ -181,16 +181,21 @@ class SubpelRefine:
         self.cost_q = torch.from_numpy(cq.view(np.int16)).to(device)
         self.out = torch.zeros(ms.nctu * PUS_PER_CTU * 2, dtype=torch.int32, device=device)
 
-    def run(self, cur: DevicePicture, ref: DevicePicture):
+    def prepare(self, ref: DevicePicture):
+        """The reference picture's phase planes (needs only the reference: may run on another stream next to the integer search)."""
         import torch
+        if not self.use_planes:
+            return
+        nb = ref.t.numel() * ref.t.element_size()
+        if self.planes is None or self.planes.numel() != 15 * nb:
+            self.planes = torch.empty(15 * nb, dtype=torch.uint8, device=ref.t.device)
+        hipabi.phase_planes(self.ms.depth, ref.t, 0, self.planes, ref.stride, nb // (ref.stride * (1 if self.ms.depth == 8 else 2)))
+
+    def run(self, cur: DevicePicture, ref: DevicePicture, prepared=False):
         ms = self.ms
-        planes = None
-        if self.use_planes:
-            nb = ref.t.numel() * ref.t.element_size()
-            if self.planes is None or self.planes.numel() != 15 * nb:
-                self.planes = torch.empty(15 * nb, dtype=torch.uint8, device=ref.t.device)
-            hipabi.phase_planes(ms.depth, ref.t, 0, self.planes, ref.stride, nb // (ref.stride * (1 if ms.depth == 8 else 2)))
-            planes = self.planes
+        if not prepared:
+            self.prepare(ref)
+        planes = self.planes if self.use_planes else None
         hipabi.subpel_refine(ms.depth, ms.w64, ms.h64, ms.range, self.subme, cur.t, cur.stride, ref.t, ref.stride,
                              ms.best, self.cost_q, self.qoff, self.out, fenc_off=cur.org, fref_off=ref.org, phase_planes=planes)
 

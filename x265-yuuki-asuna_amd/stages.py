@@ -620,9 +620,15 @@ class FramePipeline:
             sLa.wait_event(start)
             with torch.cuda.stream(sLa):
                 self.la.run(cur)
+        # the reference's phase planes need only the reference: next to the search, on Cb's stream (idle until the reconstruction)
+        sCb.wait_event(start)
+        with torch.cuda.stream(sCb):
+            self.sp.prepare(ref)
+            ev_pl = torch.cuda.Event(); ev_pl.record(sCb)
         self.ms.reset()
         self.ms.search(cur, ref)
-        self.sp.run(cur, ref)
+        main.wait_event(ev_pl)
+        self.sp.run(cur, ref, prepared=True)
         mv = self.sp.out
         ev_mv = torch.cuda.Event(); ev_mv.record(main)
         # reconstruction: one plane per stream
