@@ -16,8 +16,9 @@ P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
 S = importlib.import_module("x265-yuuki-asuna_amd.stages")
 
 
-@pytest.mark.parametrize("depth,band_rows", [(8, 2), (8, 3), (10, 2)])
-def test_banded_pipeline_equals_oracle_band_by_band(depth, band_rows):
+@pytest.mark.parametrize("depth,band_rows,par", [(8, 2, False), (8, 3, False), (10, 2, False), (8, 2, True), (10, 3, True)])
+def test_banded_pipeline_equals_oracle_band_by_band(depth, band_rows, par):
+    """par: the Cb / Cr chains of every band on their own HIP streams (bench.py's launch structure)."""
     import torch
     sys.path.insert(0, ROOT)
     import bench as B
@@ -26,7 +27,7 @@ def test_banded_pipeline_equals_oracle_band_by_band(depth, band_rows):
     clip = F.synth_clip(W, Hh, 3, depth=depth, seed=71)
     pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
     bp = S.BandedFramePipeline(pics[0].w64, pics[0].h64, depth, dev, band_rows=band_rows, rng=R, subme=subme, level=level, qp=qp, want_surf=False,
-                               deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True)
+                               deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True, parallel_planes=par)
     assert [n for _, n in bp.bands] == ([2, 2, 1] if band_rows == 2 else [3, 2])
     ref_dev = pics[0].like([p.clone() for p in pics[0].planes()])
     ref_host = None

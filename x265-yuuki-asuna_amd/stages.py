@@ -520,7 +520,7 @@ class FramePipeline:
         stage (bench.py records an event there)."""
         import torch
         par = self.parallel and mark is None and self.chroma and not self.lcb and self.ps is None and self.db is not None and self.sao is not None \
-            and self.sao_apply and self.band_border is None
+            and self.sao_apply
         if par:
             return self._run_parallel(cur, ref)
         mark = mark or (lambda name: None)
@@ -657,14 +657,20 @@ class FramePipeline:
         self.sao.stats(cur, self.recon, cur.stride, cur.org)
         self.sao.decide()
         self.sao.apply(self.recon, cur.stride, cur.org, self.out)
-        extend_border(self.out, cur)
+
+        def border(plane, chroma):
+            if self.band_border is not None:              # a band of a picture: side margins, top / bottom margin only at the picture's edge
+                extend_border_rows(plane, cur, self.band_border[0], self.band_border[1], chroma=chroma)
+            else:
+                extend_border(plane, cur, chroma=chroma)
+        border(self.out, False)
         done = []
         for i, st in enumerate((sCb, sCr)):
             with torch.cuda.stream(st):
                 self.sao_c[i].stats(None, self.recon_c[i], cur.stride_c, cur.org_c, src_plane=cur.c[i])
                 self.sao_c[i].decide()
                 self.sao_c[i].apply(self.recon_c[i], cur.stride_c, cur.org_c, self.out_c[i])
-                extend_border(self.out_c[i], cur, chroma=True)
+                border(self.out_c[i], True)
                 e = torch.cuda.Event(); e.record(st); done.append(e)
         if self.la is not None:
             e = torch.cuda.Event(); e.record(sLa); done.append(e)
