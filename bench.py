@@ -334,8 +334,8 @@ def main():
                                    # a band's grid (4 CTU rows = 240 workgroups) is too small for the record-per-lane kernel's 4-wavefront
                                    # workgroups (one per CU): bands use the record-contiguous packed format of the row-walking kernel
                                    packed=(args.surf_format != "i32" and args.depth == 8),
-                                   lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True,
-                                   parallel_planes=bool(args.parallel_planes))
+                                   lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True)
+        # (bands keep every launch on one stream: side streams for the chroma chains change nothing at band size - 3.93 vs 3.97 ms at 4 rows)
         ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16,      # search window + 8-tap interpolation + sub-pel drift
                                    stage_through_host=backend != "nccl")
         ring.make_groups()
