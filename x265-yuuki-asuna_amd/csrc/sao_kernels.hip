@@ -148,7 +148,9 @@ __global__ void __launch_bounds__(256) sao_stats_kernel(SaoStatsArgs a)
         {
             const int cnt = (int)(acc[t][k] >> 20);
             const int sum = (int)(acc[t][k] & 0xfffffu) - cnt * bias;
-            const int cw = group_sum<64>(cnt), sw = group_sum<64>(sum);
+            // DPP row sums + four readlanes: no LDS round trips (the 40 butterfly reductions through ds_bpermute cost 8 us of the 44 us launch;
+            // halving the per-thread walk instead - 512 threads x 8 samples - changes nothing: the rest is the latency of one round of workgroups)
+            const int cw = wave_sum_of_rows(row_sum(cnt)), sw = wave_sum_of_rows(row_sum(sum));
             if ((tid & 63) == 0 && cw) { atomicAdd(&sEo[0][t * 5 + k], cw); atomicAdd(&sEo[1][t * 5 + k], sw); }
         }
     __syncthreads();
