@@ -680,13 +680,16 @@ int x265hip_intra_batch(int kind, int depth, int n, x265hip_plane src, x265hip_p
  *   TRANSPOSE: dst contiguous=p0 src=p1       WEIGHT_PP: dst=p0 src=p1 arg={w0, round, shift, offset}
  *   WEIGHT_SP: dst(pixel)=p0 src(int16)=p1 arg={w0, round, shift, offset}
  *   SCALE1D_128TO64: dst=p0 src=p1 (w=h=0)    SCALE2D_64TO32: dst=p0 src=p1
- *   SSE_SS (int16,int16), SSD_S (int16), VAR (pixel): reductions, result in `result` (uint64 per job) */
+ *   SSE_SS (int16,int16), SSD_S (int16), VAR (pixel): reductions, result in `result` (uint64 per job)
+ *   SSIM_DIST: cu[].ssimDist (pixel.cpp:958-981): fenc=p0 recon=p1 arg[0]=shift; result[2 job] = sum (fenc - recon)^2, result[2 job + 1] =
+ *              sum (fenc >> shift)^2      NORM_FACT: cu[].normFact (:983-995): src=p0 arg[0]=shift; result[job] = sum (src >> shift)^2 */
 enum x265hip_blockop_kind
 {
     X265HIP_OP_COPY_PP = 0, X265HIP_OP_COPY_PS, X265HIP_OP_COPY_SP, X265HIP_OP_COPY_SS, X265HIP_OP_SUB_PS, X265HIP_OP_ADD_PS,
     X265HIP_OP_ADDAVG, X265HIP_OP_PIXELAVG, X265HIP_OP_BLOCKFILL, X265HIP_OP_CPY2DTO1D_SHL, X265HIP_OP_CPY2DTO1D_SHR,
     X265HIP_OP_CPY1DTO2D_SHL, X265HIP_OP_CPY1DTO2D_SHR, X265HIP_OP_TRANSPOSE, X265HIP_OP_WEIGHT_PP, X265HIP_OP_WEIGHT_SP,
-    X265HIP_OP_SCALE1D_128TO64, X265HIP_OP_SCALE2D_64TO32, X265HIP_OP_SSE_SS, X265HIP_OP_SSD_S, X265HIP_OP_VAR
+    X265HIP_OP_SCALE1D_128TO64, X265HIP_OP_SCALE2D_64TO32, X265HIP_OP_SSE_SS, X265HIP_OP_SSD_S, X265HIP_OP_VAR,
+    X265HIP_OP_SSIM_DIST, X265HIP_OP_NORM_FACT
 };
 int x265hip_blockop_batch(int op, int depth, int w, int h, const x265hip_plane planes[3],
                           const x265hip_job* jobs, int njobs, uint64_t* result, void* stream);

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) blockop_kernel(OpArgs a)
     const int w = a.w, h = a.h, depth = a.depth;
     const int maxVal = (1 << depth) - 1;
     const long s0 = a.p[0].stride, s1 = a.p[1].stride, s2 = a.p[2].stride;
-    unsigned long long red = 0;
+    unsigned long long red = 0, red2 = 0;
 
     if (OP == X265HIP_OP_SCALE1D_128TO64)
     {
@@ -269,10 +269,32 @@ __global__ void __launch_bounds__(256) blockop_kernel(OpArgs a)
             red += (unsigned long long)v + ((unsigned long long)(v * v) << 32);   // low word sum, high word sum of squares
             break;
         }
+        case X265HIP_OP_SSIM_DIST:                                                // ssimDist_c (pixel.cpp:958-981): two 64-bit sums
+        {
+            const int f = ((const Px*)a.p[0].base + jb.off[0])[y * s0 + x];
+            const int d = f - (int)((const Px*)a.p[1].base + jb.off[1])[y * s1 + x];
+            const unsigned t = (unsigned)f >> jb.arg[0];
+            red += (unsigned long long)(long long)(d * d);
+            red2 += (unsigned long long)(t * t);
+            break;
+        }
+        case X265HIP_OP_NORM_FACT:                                                // normFact_c (pixel.cpp:983-995)
+        {
+            const unsigned t = (unsigned)((const Px*)a.p[0].base + jb.off[0])[y * s0 + x] >> jb.arg[0];
+            red += (unsigned long long)(t * t);
+            break;
+        }
         default: break;
         }
     }
-    if (OP == X265HIP_OP_SSE_SS || OP == X265HIP_OP_SSD_S || OP == X265HIP_OP_VAR)
+    if (OP == X265HIP_OP_SSIM_DIST)
+    {
+        __shared__ unsigned long long scratch3[4];
+        const unsigned long long ss = block_sum<unsigned long long>(red, scratch);
+        const unsigned long long ac = block_sum<unsigned long long>(red2, scratch3);
+        if (tid == 0) { a.result[2 * blockIdx.x] = ss; a.result[2 * blockIdx.x + 1] = ac; }
+    }
+    if (OP == X265HIP_OP_SSE_SS || OP == X265HIP_OP_SSD_S || OP == X265HIP_OP_VAR || OP == X265HIP_OP_NORM_FACT)
     {
         // VAR packs two independent 32-bit accumulators; carries out of the low word must not leak
         // into the high word (the reference keeps two uint32_t), so reduce the halves separately.
@@ -428,6 +450,7 @@ template <typename Px> static int launch_op(int op, const OpArgs& a, int njobs, 
         CASE(X265HIP_OP_CPY2DTO1D_SHL) CASE(X265HIP_OP_CPY2DTO1D_SHR) CASE(X265HIP_OP_CPY1DTO2D_SHL) CASE(X265HIP_OP_CPY1DTO2D_SHR)
         CASE(X265HIP_OP_TRANSPOSE) CASE(X265HIP_OP_WEIGHT_PP) CASE(X265HIP_OP_WEIGHT_SP) CASE(X265HIP_OP_SCALE1D_128TO64)
         CASE(X265HIP_OP_SCALE2D_64TO32) CASE(X265HIP_OP_SSE_SS) CASE(X265HIP_OP_SSD_S) CASE(X265HIP_OP_VAR)
+        CASE(X265HIP_OP_SSIM_DIST) CASE(X265HIP_OP_NORM_FACT)
     default: set_error("blockop_batch: unknown op %d", op); return X265HIP_EINVAL;
     }
 #undef CASE
@@ -472,7 +495,7 @@ extern "C" int x265hip_blockop_batch(int op, int depth, int w, int h, const x265
     if (depth != 8 && depth != 10 && depth != 12) { set_error("blockop_batch: depth %d", depth); return X265HIP_EINVAL; }
     const bool fixedSize = op == X265HIP_OP_SCALE1D_128TO64 || op == X265HIP_OP_SCALE2D_64TO32;
     if (!fixedSize && (w < 1 || h < 1 || w > 64 * 64 || h > 4096)) { set_error("blockop_batch: block %dx%d unsupported", w, h); return X265HIP_EINVAL; }
-    if ((op == X265HIP_OP_SSE_SS || op == X265HIP_OP_SSD_S || op == X265HIP_OP_VAR) && !result) { set_error("blockop_batch: reduction needs result"); return X265HIP_EINVAL; }
+    if ((op == X265HIP_OP_SSE_SS || op == X265HIP_OP_SSD_S || op == X265HIP_OP_VAR || op == X265HIP_OP_SSIM_DIST || op == X265HIP_OP_NORM_FACT) && !result) { set_error("blockop_batch: reduction needs result"); return X265HIP_EINVAL; }
     OpArgs a;
     for (int i = 0; i < 3; i++) a.p[i] = planes[i];
     a.jobs = jobs; a.result = (unsigned long long*)result; a.w = w; a.h = h; a.depth = depth;

@@ -380,6 +380,40 @@ template <typename T> static uint64_t reduce_core(int op, int n, const T* a, int
 template <int N> static sse_t sse_ss_stub(const int16_t* a, intptr_t sa, const int16_t* b, intptr_t sb) { return (sse_t)reduce_core<int16_t>(X265HIP_OP_SSE_SS, N, a, sa, b, sb); }
 template <int N> static sse_t ssd_s_stub(const int16_t* a, intptr_t sa) { return (sse_t)reduce_core<int16_t>(X265HIP_OP_SSD_S, N, a, sa, nullptr, 0); }
 template <int N> static uint64_t var_stub(const pixel* p, intptr_t s) { return reduce_core<pixel>(X265HIP_OP_VAR, N, p, s, nullptr, 0); }
+// ssimDist / normFact (pixel.cpp:958-995): 64-bit sums handed back through pointers
+template <int N> static void ssim_dist_stub(const pixel* fenc, uint32_t fstride, const pixel* recon, intptr_t rstride, uint64_t* ssBlock, int shift, uint64_t* ac_k)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in2d(fenc, (intptr_t)fstride, N, N, sizeof(pixel));
+    const size_t o1 = st.in2d(recon, rstride, N, N, sizeof(pixel));
+    x265hip_job jb = {};
+    jb.arg[0] = shift;
+    const JobRef dj = put_job(st, jb);
+    const size_t orr = st.alloc(16);
+    st.upload();
+    const x265hip_plane pl[3] = { plane(st, o0, N), plane(st, o1, N), plane(st, o1, N) };
+    st.require(x265hip_blockop_batch(X265HIP_OP_SSIM_DIST, D, N, N, pl, dj, 1, st.dptr<uint64_t>(orr), st.stream), "ssimDist");
+    st.download(orr, 16);
+    *ssBlock = st.hptr<uint64_t>(orr)[0];
+    *ac_k = st.hptr<uint64_t>(orr)[1];
+}
+static void norm_fact_stub(const pixel* src, uint32_t blockSize, int shift, uint64_t* z_k)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const int n = (int)blockSize;
+    const size_t o0 = st.in2d(src, n, n, n, sizeof(pixel));
+    x265hip_job jb = {};
+    jb.arg[0] = shift;
+    const JobRef dj = put_job(st, jb);
+    const size_t orr = st.alloc(8);
+    st.upload();
+    const x265hip_plane pl[3] = { plane(st, o0, n), plane(st, o0, n), plane(st, o0, n) };
+    st.require(x265hip_blockop_batch(X265HIP_OP_NORM_FACT, D, n, n, pl, dj, 1, st.dptr<uint64_t>(orr), st.stream), "normFact");
+    st.download(orr, 8);
+    *z_k = *st.hptr<uint64_t>(orr);
+}
 
 // ---------------------------------------------------------------- loop filter family
 static constexpr size_t NO_RESULT = ~(size_t)0;
@@ -660,8 +694,10 @@ int CAT(setup_primitives_d, X265HIP_DEPTH)(x265hip_EncoderPrimitives* p)
     SET2(c.cpy1Dto2D_shl, (cpy1d2d_shl_stub<N>)); SET(c.cpy1Dto2D_shr, (cpy1d2d_shr_stub<N>)); \
     SET(c.copy_sp, (copy_sp_stub<N, N>)); SET(c.copy_ps, (copy_ps_stub<N, N>)); SET(c.copy_ss, (copy_ss_stub<N, N>)); SET(c.copy_pp, (copy_pp_stub<N, N>)); \
     SET(c.var, (var_stub<N>)); SET(c.sse_pp, (sse_stub<N, N>)); SET(c.sse_ss, (sse_ss_stub<N>)); SET(c.psy_cost_pp, (cmp_stub<X265HIP_CMP_PSY_COST, N, N>)); \
-    SET2(c.ssd_s, (ssd_s_stub<N>)); SET(c.sa8d, (cmp_stub<X265HIP_CMP_SA8D, N, N>)); SET(c.transpose, (transpose_stub<N>)); }
+    SET2(c.ssd_s, (ssd_s_stub<N>)); SET(c.sa8d, (cmp_stub<X265HIP_CMP_SA8D, N, N>)); SET(c.transpose, (transpose_stub<N>)); \
+    SET(c.ssimDist, (ssim_dist_stub<N>)); }
     SET_CU(0, 4) SET_CU(1, 8) SET_CU(2, 16) SET_CU(3, 32) SET_CU(4, 64)
+    for (int i = 1; i < 5; i++) SET(p->cu[i].normFact, norm_fact_stub);          // the reference leaves cu[BLOCK_4x4].normFact NULL (pixel.cpp:1354-1357)
 
 #define SET_TU(I, N) { auto& c = p->cu[I]; \
     SET(c.dct, (fwd_tr_stub<X265HIP_TR_DCT, N>)); SET(c.idct, (inv_tr_stub<X265HIP_TR_IDCT, N>)); \

@@ -138,6 +138,12 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise X265HipError(f"{LIB_PATH} not built - run `python -c 'import __graft_entry__ as g; g.build()'`; "
                                "there is no CPU fallback for the product path")
+        # One HIP runtime per process: torch bundles its own libamdhip64 / libhsa-runtime64 and whichever copy is loaded first serves
+        # both.  If this library pulled in /opt/rocm's copies before torch was imported, torch's later initialisation found "No HIP GPUs".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         L.x265hip_version.restype = ctypes.c_char_p
         L.x265hip_last_error.restype = ctypes.c_char_p
