@@ -700,7 +700,7 @@ int CAT(setup_primitives_d, X265HIP_DEPTH)(x265hip_EncoderPrimitives* p)
     for (int i = 1; i < 5; i++) SET(p->cu[i].normFact, norm_fact_stub);          // the reference leaves cu[BLOCK_4x4].normFact NULL (pixel.cpp:1354-1357)
 
 #define SET_TU(I, N) { auto& c = p->cu[I]; \
-    SET(c.dct, (fwd_tr_stub<X265HIP_TR_DCT, N>)); SET(c.idct, (inv_tr_stub<X265HIP_TR_IDCT, N>)); \
+    SET(c.dct, (fwd_tr_stub<X265HIP_TR_DCT, N>)); SET(c.standard_dct, (fwd_tr_stub<X265HIP_TR_DCT, N>)); SET(c.idct, (inv_tr_stub<X265HIP_TR_IDCT, N>)); \
     SET(c.copy_cnt, (copy_cnt_stub<N>)); SET(c.count_nonzero, (count_nonzero_stub<N>)); \
     SET(c.intra_filter, (intra_filter_stub<N>)); SET(c.intra_pred_allangs, (intra_allangs_stub<N>)); \
     SET(c.intra_pred[0], (intra_pred_stub<N, 0>)); SET(c.intra_pred[1], (intra_pred_stub<N, 1>)); \
