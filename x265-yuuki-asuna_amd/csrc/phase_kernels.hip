@@ -8,8 +8,8 @@
 // Arithmetic (exact, int32 sums, the reference's int16 narrowing and clipping): ipfilter.cpp:79-118 (horizontal pp), :164-203
 // (vertical pp), :362-369 = :120-162 (horizontal ps with row extension) + :241-282 (vertical sp); taps constants.cpp:250-268.
 //
-// Bound: HBM writes (15 + 2 * 63 / 4 = 46.5 output bytes per luma source byte at 4:2:0); the source tile and its apron are re-read
-// through L2 by the phases of the same tile, which are adjacent in the grid (phase = fastest workgroup index).
+// Bound: HBM writes (15 + 2 * 63 / 4 = 46.5 output bytes per luma source byte at 4:2:0).  A thread owns a 4x4 tile and produces EVERY
+// phase of it: the source samples are loaded once and each horizontally filtered column set is shared by its vertical phases.
 #include "common.h"
 #include "tile_interp.h"
 
@@ -44,33 +44,94 @@ template <typename Px> __device__ __forceinline__ void phase_store(uint8_t* out,
     }
 }
 
-// grid: x = phase - 1 (15), y = blocks of 256 tiles along the rows' tiles, z = tile row.  One 4x4 tile per lane.
+// grid: x = blocks of 256 tiles along a tile row, y = tile row.  One 4x4 tile per lane, ALL 15 phases of it: the three horizontally
+// filtered 11-row columns (xf = 1, 2, 3) are formed once and shared by their four vertical phases (a phase-per-thread kernel filtered
+// 111 rows per tile horizontally, this one 33).
 template <typename Px>
 __global__ void __launch_bounds__(256) phase_luma_kernel(PhaseArgs a)
 {
     constexpr int BPP = sizeof(Px);
-    const int phase = blockIdx.x + 1, xf = phase & 3, yf = phase >> 2;
-    const int tx = blockIdx.y * 256 + threadIdx.x, ty = blockIdx.z + 1;          // the first 4 and the last 8 rows are not produced
+    const int tx = blockIdx.x * 256 + threadIdx.x, ty = blockIdx.y + 1;          // the first 4 and the last 8 rows are not produced
     if (tx >= a.tilesW) return;
     const long off = (long)(ty * 4) * a.strideB + (long)tx * 4 * BPP;
-    int d[4][4];
-    tile_predict<BPP>(a.src + off, a.strideB, xf, yf, a.depth, d);
-    phase_store<Px>(a.dst + (size_t)(phase - 1) * a.planeBytes + off, a.strideB, d);
+    const uint8_t* org = a.src + off;
+    const int maxVal = (1 << a.depth) - 1, headRoom = 14 - a.depth;
+    const int shiftPS = 6 - headRoom, offPS = -(8192 << shiftPS);
+    const int shiftSP = 6 + headRoom, offSP = (1 << (shiftSP - 1)) + (8192 << 6);
+    auto vtaps = [](const int yf, uint32_t (&cv)[4])
+    {
+        cv[0] = tile_sel3(yf, 0x0004ffffu, 0x0004ffffu, 0x00010000u); cv[1] = tile_sel3(yf, 0x003afff6u, 0x0028fff5u, 0x0011fffbu);
+        cv[2] = tile_sel3(yf, 0xfffb0011u, 0xfff50028u, 0xfff6003au); cv[3] = tile_sel3(yf, 0x00000001u, 0xffff0004u, 0xffff0004u);
+    };
+#pragma unroll
+    for (int xf = 0; xf < 4; xf++)
+    {
+        // column data of the tile's 4 columns, rows -3 .. +7: raw samples (xf = 0) or the horizontal sums (no rounding yet)
+        int col[11][4];
+#pragma unroll
+        for (int t = 0; t < 11; t++)
+        {
+            const uint8_t* rp = org + (long)(t - 3) * a.strideB;
+            if (xf == 0)
+            {
+                if (BPP == 1) { const uint32_t w = ld_u32(rp); col[t][0] = w & 0xff; col[t][1] = (w >> 8) & 0xff; col[t][2] = (w >> 16) & 0xff; col[t][3] = w >> 24; }
+                else { const uint32_t w0 = ld_u32(rp), w1 = ld_u32(rp + 4); col[t][0] = w0 & 0xffff; col[t][1] = w0 >> 16; col[t][2] = w1 & 0xffff; col[t][3] = w1 >> 16; }
+            }
+            else
+                tile_hrow<BPP>(rp - 3 * BPP, xf, col[t]);
+        }
+        int d[4][4];
+        if (xf)
+        {   // yf = 0: luma_hpp
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) d[y][x] = tile_clip16((col[y + 3][x] + 32) >> 6, maxVal);
+            phase_store<Px>(a.dst + (size_t)(xf - 1) * a.planeBytes + off, a.strideB, d);
+        }
+        // (row r, row r + 1) pairs of what the vertical filter reads: samples (luma_vpp) or the 16-bit intermediates of luma_hps
+        uint32_t pairs[10][4];
+#pragma unroll
+        for (int t = 0; t < 10; t++)
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                const uint32_t lo = xf ? (uint32_t)((col[t][x] + offPS) >> shiftPS) : (uint32_t)col[t][x];
+                const uint32_t hi = xf ? (uint32_t)((col[t + 1][x] + offPS) >> shiftPS) : (uint32_t)col[t + 1][x];
+                pairs[t][x] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+            }
+#pragma unroll
+        for (int yf = 1; yf < 4; yf++)
+        {
+            uint32_t cv[4];
+            vtaps(yf, cv);
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    int sum = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sum = tile_dot2(pairs[y + 2 * j][x], cv[j], sum);
+                    d[y][x] = xf ? tile_clip16((sum + offSP) >> shiftSP, maxVal) : tile_clip16((sum + 32) >> 6, maxVal);
+                }
+            phase_store<Px>(a.dst + (size_t)(yf * 4 + xf - 1) * a.planeBytes + off, a.strideB, d);
+        }
+    }
 }
 
-// 4-tap chroma set, eighth-sample phases: phase = yf * 8 + xf
+// 4-tap chroma set, eighth-sample phases: phase = yf * 8 + xf.  Same structure: one 4x4 tile per lane, the 7 x 7 source samples loaded
+// once, the horizontally filtered columns of an xf shared by its eight vertical phases.
 template <typename Px>
 __global__ void __launch_bounds__(256) phase_chroma_kernel(PhaseArgs a)
 {
     constexpr int BPP = sizeof(Px);
-    const int phase = blockIdx.x + 1, xf = phase & 7, yf = phase >> 3;
-    const int tx = blockIdx.y * 256 + threadIdx.x, ty = blockIdx.z + 1;
+    const int tx = blockIdx.x * 256 + threadIdx.x, ty = blockIdx.y + 1;
     if (tx >= a.tilesW) return;
     const long off = (long)(ty * 4) * a.strideB + (long)tx * 4 * BPP;
     const int maxVal = (1 << a.depth) - 1, headRoom = 14 - a.depth;
-    const int cx0 = kPhaseChromaTaps[xf][0], cx1 = kPhaseChromaTaps[xf][1], cx2 = kPhaseChromaTaps[xf][2], cx3 = kPhaseChromaTaps[xf][3];
-    const int cy0 = kPhaseChromaTaps[yf][0], cy1 = kPhaseChromaTaps[yf][1], cy2 = kPhaseChromaTaps[yf][2], cy3 = kPhaseChromaTaps[yf][3];
-    int d[4][4];
+    const int shiftPS = 6 - headRoom, offPS = -(8192 << shiftPS);
+    const int shiftSP = 6 + headRoom, offSP = (1 << (shiftSP - 1)) + (8192 << 6);
     // rows -1 .. +5, columns -1 .. +5 of the tile
     int s[7][7];
 #pragma unroll
@@ -90,39 +151,44 @@ __global__ void __launch_bounds__(256) phase_chroma_kernel(PhaseArgs a)
             s[r][4] = w2 & 0xffff; s[r][5] = w2 >> 16; s[r][6] = w3 & 0xffff;
         }
     }
-    if (!yf)
+#pragma unroll 1
+    for (int xf = 0; xf < 8; xf++)
     {
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-                d[y][x] = tile_clip16((cx0 * s[y + 1][x] + cx1 * s[y + 1][x + 1] + cx2 * s[y + 1][x + 2] + cx3 * s[y + 1][x + 3] + 32) >> 6, maxVal);
-    }
-    else if (!xf)
-    {
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-                d[y][x] = tile_clip16((cy0 * s[y][x + 1] + cy1 * s[y + 1][x + 1] + cy2 * s[y + 2][x + 1] + cy3 * s[y + 3][x + 1] + 32) >> 6, maxVal);
-    }
-    else
-    {
-        const int shiftPS = 6 - headRoom, offPS = -(8192 << shiftPS);
-        const int shiftSP = 6 + headRoom, offSP = (1 << (shiftSP - 1)) + (8192 << 6);
-        int im[7][4];
+        const int cx0 = kPhaseChromaTaps[xf][0], cx1 = kPhaseChromaTaps[xf][1], cx2 = kPhaseChromaTaps[xf][2], cx3 = kPhaseChromaTaps[xf][3];
+        int col[7][4];                       // xf = 0: the samples of columns 0..3; else the horizontal sums (no rounding yet)
 #pragma unroll
         for (int r = 0; r < 7; r++)
 #pragma unroll
             for (int x = 0; x < 4; x++)
-                im[r][x] = (int16_t)((cx0 * s[r][x] + cx1 * s[r][x + 1] + cx2 * s[r][x + 2] + cx3 * s[r][x + 3] + offPS) >> shiftPS);
+                col[r][x] = xf ? cx0 * s[r][x] + cx1 * s[r][x + 1] + cx2 * s[r][x + 2] + cx3 * s[r][x + 3] : s[r][x + 1];
+        int d[4][4];
+        if (xf)
+        {   // yf = 0: filter_hpp
 #pragma unroll
-        for (int y = 0; y < 4; y++)
+            for (int y = 0; y < 4; y++)
 #pragma unroll
-            for (int x = 0; x < 4; x++)
-                d[y][x] = tile_clip16((cy0 * im[y][x] + cy1 * im[y + 1][x] + cy2 * im[y + 2][x] + cy3 * im[y + 3][x] + offSP) >> shiftSP, maxVal);
+                for (int x = 0; x < 4; x++) d[y][x] = tile_clip16((col[y + 1][x] + 32) >> 6, maxVal);
+            phase_store<Px>(a.dst + (size_t)(xf - 1) * a.planeBytes + off, a.strideB, d);
+#pragma unroll
+            for (int r = 0; r < 7; r++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) col[r][x] = (int16_t)((col[r][x] + offPS) >> shiftPS);          // filter_hps output (int16)
+        }
+#pragma unroll 1
+        for (int yf = 1; yf < 8; yf++)
+        {
+            const int cy0 = kPhaseChromaTaps[yf][0], cy1 = kPhaseChromaTaps[yf][1], cy2 = kPhaseChromaTaps[yf][2], cy3 = kPhaseChromaTaps[yf][3];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    const int sum = cy0 * col[y][x] + cy1 * col[y + 1][x] + cy2 * col[y + 2][x] + cy3 * col[y + 3][x];
+                    d[y][x] = xf ? tile_clip16((sum + offSP) >> shiftSP, maxVal) : tile_clip16((sum + 32) >> 6, maxVal);
+                }
+            phase_store<Px>(a.dst + (size_t)(yf * 8 + xf - 1) * a.planeBytes + off, a.strideB, d);
+        }
     }
-    phase_store<Px>(a.dst + (size_t)(phase - 1) * a.planeBytes + off, a.strideB, d);
 }
 
 } // namespace x265hip
@@ -145,17 +211,17 @@ extern "C" int x265hip_phase_planes(const x265hip_phase_planes_params* p, void* 
     if (p->rows / 4 > 65535 || p->rows < 16) { set_error("phase_planes: %d rows", p->rows); return X265HIP_EINVAL; }
     // tile rows 1 .. rows / 4 - 3: a tile reads 3 rows above and 7 below itself (and a few bytes of the neighbouring rows at the row
     // ends), so every access stays inside the plane without any guard memory around it
-    const dim3 grid(p->chroma ? 63 : 15, (a.tilesW + 255) / 256, p->rows / 4 - 3);
+    const dim3 gridL((a.tilesW + 255) / 256, p->rows / 4 - 3);               // a thread produces every phase of its tile
     hipStream_t s = (hipStream_t)stream;
     if (p->chroma)
     {
-        if (bpp == 1) hipLaunchKernelGGL(phase_chroma_kernel<uint8_t>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(phase_chroma_kernel<uint16_t>, grid, dim3(256), 0, s, a);
+        if (bpp == 1) hipLaunchKernelGGL(phase_chroma_kernel<uint8_t>, gridL, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(phase_chroma_kernel<uint16_t>, gridL, dim3(256), 0, s, a);
     }
     else
     {
-        if (bpp == 1) hipLaunchKernelGGL(phase_luma_kernel<uint8_t>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(phase_luma_kernel<uint16_t>, grid, dim3(256), 0, s, a);
+        if (bpp == 1) hipLaunchKernelGGL(phase_luma_kernel<uint8_t>, gridL, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(phase_luma_kernel<uint16_t>, gridL, dim3(256), 0, s, a);
     }
     return check_hip(hipGetLastError(), "phase_planes launch");
 }
