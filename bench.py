@@ -338,7 +338,7 @@ def main():
         # (bands keep every launch on one stream: side streams for the chroma chains change nothing at band size - 3.93 vs 3.97 ms at 4 rows)
         ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16,      # search window + 8-tap interpolation + sub-pel drift
                                    stage_through_host=backend != "nccl")
-        ring.make_groups()
+        ring.make_groups(device=dev)
         geom = (pics[0].stride, F.MARGIN_Y, pics[0].stride_c, F.CHROMA_MARGIN_Y)
         total_frames = (args.warmup + args.steps) * world
         bp.begin_frame(pics[1])                         # allocates the output planes

@@ -277,7 +277,7 @@ class FrameParallelRing:
             need += 1
         return need
 
-    def make_groups(self):
+    def make_groups(self, device=None):
         """Two process groups so that the traffic towards the next rank never queues behind the traffic from the previous one (with a
         backend that serialises the operations of one communicator - NCCL / RCCL - and world == 2, both directions share one peer pair):
         the hand-off rank r -> r + 1 uses group r % 2.  Collective call: every rank makes it once, after init_process_group."""
@@ -285,6 +285,13 @@ class FrameParallelRing:
         import datetime
         self.groups = ([dist.new_group(list(range(self.world)), timeout=datetime.timedelta(seconds=240)) for _ in range(2)]
                        if self.world > 1 else [None, None])
+        if self.world > 1:
+            # one collective per group, made by every rank: the communicators exist before the first point-to-point transfer (RCCL creates
+            # them lazily, and a first use by only two of the ranks must not turn into a collective the others never join)
+            import torch
+            for g in self.groups:
+                t = torch.zeros(1, device=device if device is not None else "cpu")
+                dist.all_reduce(t, group=g)
         return self.groups
 
     def run_frame(self, step, geom, ref_planes, out_planes, process_band, total_frames=None, first_frame_is_local=True):
