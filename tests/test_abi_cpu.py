@@ -3,6 +3,7 @@ include/x265hip.h declares (no compute calls without a GPU), and the product nev
 import ctypes
 import importlib
 import os
+import sys
 import re
 
 A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
@@ -62,7 +63,11 @@ def test_ctypes_structures_match_the_c_header(repo_root, tmp_path):
              "x265hip_cutree_propagate_params": A.CuTreePropagateParams, "x265hip_cutree_finish_params": A.CuTreeFinishParams, "x265hip_frame_cost_recalculate_params": A.FrameCostRecalculateParams,
              "x265hip_lowres_weight_cost_params": A.LowresWeightCostParams, "x265hip_lowres_weight_apply_params": A.LowresWeightApplyParams,
              "x265hip_sao_stats_params": A.SaoStatsParams, "x265hip_sao_apply_params": A.SaoApplyParams, "x265hip_plane": A.Plane,
-             "x265hip_intra_recon_params": A.IntraReconParams}
+             "x265hip_intra_recon_params": A.IntraReconParams, "x265hip_tu_tables": A.TuTablesRec, "x265hip_phase_planes_params": A.PhasePlanesParams}
+    sys.path.insert(0, repo_root)
+    from tools import seam_driver as SD          # the consumer-layer records the seam tools mirror
+    pairs.update({"x265hip_me_cache_params": SD.CacheParams, "x265hip_me_cache_stats_t": SD.CacheStats,
+                  "x265hip_phase_cache_params": SD.PhaseCacheParams, "x265hip_phase_cache_stats_t": SD.PhaseCacheStats})
     for extra, cname in (("ReconParams", "x265hip_recon_params"), ("ReconBiParams", "x265hip_recon_bi_params")):
         cls = getattr(A, extra, None) or getattr(S, extra, None)
         if cls is not None and isinstance(cls, type) and issubclass(cls, ctypes.Structure):
@@ -114,3 +119,25 @@ def test_recon_publish_rows_validates_before_touching_a_device():
     p.plane[0] = 4096
     assert f(ctypes.byref(p), None) == -2                       # rows 1..3 of a 2-row picture
     assert b"rows" in A.lib().x265hip_last_error()
+
+
+def test_phase_plane_entries_validate_before_touching_a_device():
+    """x265hip_phase_planes / x265hip_phase_cache_create reject bad geometry without a device."""
+    import ctypes
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    L = A.lib()
+    f = L.x265hip_phase_planes
+    f.argtypes = [ctypes.POINTER(A.PhasePlanesParams), ctypes.c_void_p]
+    assert f(None, None) == -2
+    assert f(ctypes.byref(A.PhasePlanesParams(8, 0, 4096, 8192, 130, 64)), None) == -2          # stride not a multiple of 4
+    assert f(ctypes.byref(A.PhasePlanesParams(8, 0, 4096, 8192, 128, 62)), None) == -2          # rows not a multiple of 4
+    assert f(ctypes.byref(A.PhasePlanesParams(9, 0, 4096, 8192, 128, 64)), None) == -2          # depth
+    assert f(ctypes.byref(A.PhasePlanesParams(8, 1, 4096, 8192, 128, 12)), None) == -2          # too few rows to produce any
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import seam_driver as SD
+    g = L.x265hip_phase_cache_create
+    g.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(SD.PhaseCacheParams)]
+    h = ctypes.c_void_p()
+    assert g(ctypes.byref(h), ctypes.byref(SD.PhaseCacheParams(8, 130, 64, 0, 0, 2))) == -2 and not h
+    assert g(ctypes.byref(h), ctypes.byref(SD.PhaseCacheParams(8, 128, 64, 64, 30, 2))) == -2   # chroma rows not a multiple of 4
+    assert g(ctypes.byref(h), ctypes.byref(SD.PhaseCacheParams(8, 128, 64, 0, 0, 0))) == -2     # no slots

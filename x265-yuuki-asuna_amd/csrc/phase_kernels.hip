@@ -203,12 +203,12 @@ extern "C" int x265hip_phase_planes(const x265hip_phase_planes_params* p, void* 
     if (p->stride <= 0 || p->rows <= 0 || (p->rows & 3) || ((p->stride * bpp) & 3) || (p->stride & 3))
     { set_error("phase_planes: stride %ld / rows %d must be positive multiples of 4", (long)p->stride, p->rows); return X265HIP_EINVAL; }
     if ((uintptr_t)p->dst & 3) { set_error("phase_planes: dst must be 4-byte aligned"); return X265HIP_EINVAL; }
+    if (p->rows / 4 > 65535 || p->rows < 16) { set_error("phase_planes: %d rows", p->rows); return X265HIP_EINVAL; }
     int rc = ensure_device();
     if (rc) return rc;
     PhaseArgs a;
     a.src = (const uint8_t*)p->src; a.dst = (uint8_t*)p->dst; a.strideB = (long)p->stride * bpp; a.rows = p->rows;
     a.tilesW = (int)(p->stride / 4); a.depth = p->depth; a.planeBytes = (size_t)p->stride * p->rows * bpp;
-    if (p->rows / 4 > 65535 || p->rows < 16) { set_error("phase_planes: %d rows", p->rows); return X265HIP_EINVAL; }
     // tile rows 1 .. rows / 4 - 3: a tile reads 3 rows above and 7 below itself (and a few bytes of the neighbouring rows at the row
     // ends), so every access stays inside the plane without any guard memory around it
     const dim3 gridL((a.tilesW + 255) / 256, p->rows / 4 - 3);               // a thread produces every phase of its tile
