@@ -1,5 +1,6 @@
 """GPU parity: CTU-tiled exhaustive motion search (x265hip_me_fullsearch) vs the oracle's
 restatement of the reference full search (motion.cpp:1397-1445 over pu[].sad / sad_x4)."""
+import ctypes
 import importlib
 import os
 import sys
@@ -110,6 +111,23 @@ def test_me_record_per_lane_kernel_serves_the_other_formats(monkeypatch):
             for level in range(4):
                 b, n = P.LEVEL_BASE[level], P.LEVEL_PUS[level]
                 assert np.array_equal(ms.level_view(level)[0].cpu().numpy(), e[:, :, b:b + n].reshape(-1, n)), f"{kw} level {level}"
+
+
+def test_me_chunk_major_format_refused_when_the_window_does_not_fit():
+    """A window the record-per-lane kernel cannot hold in LDS: X265HIP_SURF_PACKED_T is refused with an error, nothing is written."""
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(64, 64, 2, depth=8, seed=8)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    A.lib().x265hip_me_fullsearch.restype = ctypes.c_int
+    p = A.MEParams()
+    p.depth, p.width, p.height, p.range = 8, 64, 64, 130
+    p.fenc = p.fref = cur.t.data_ptr() + cur.org
+    p.fenc_stride = p.fref_stride = cur.stride
+    surf = torch.zeros(1024, dtype=torch.int32, device=dev)
+    p.surf, p.surf_format = surf.data_ptr(), A.SURF_PACKED_T
+    assert A.lib().x265hip_me_fullsearch(ctypes.byref(p), None) < 0
+    assert b"PACKED_T" in A.lib().x265hip_last_error() and int(surf.abs().sum()) == 0
 
 
 def test_me_packed_surface_rejected_for_high_bit_depth():
