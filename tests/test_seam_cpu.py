@@ -110,3 +110,16 @@ def test_subpel_seam_stays_out_of_the_way_with_frame_threads():
     base, got, rep = run_pair(8, 192, 128, 5, "medium", opts, "oracle", rng=16, subpel="oracle")
     assert got[0] == base[0]
     assert rep["subpel_seam"]["subpel_compares_served"] == 0 and rep["subpel_seam"]["pictures_submitted"] == 0
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("ft", [2, 3])
+def test_lookahead_seam_holds_under_frame_threads(ft):
+    """--frame-threads > 1: the two search seams step aside (the reference picture is still being reconstructed when the next picture
+    starts), the lookahead seam does not depend on the frame encoders and keeps serving every estimate - same bitstream."""
+    opts = [("pools", "4"), ("frame-threads", str(ft)), ("crf", "24"), ("lookahead-slices", "1")]
+    base, got, rep = run_pair(8, 320, 192, 14, "medium", opts, "oracle", rng=16, verify=True, lookahead="oracle", subpel="oracle")
+    assert got[0] == base[0], f"seams changed the bitstream under {ft} frame threads: {rep}"
+    la = rep["lookahead_seam"]
+    assert la["frame_cost_estimates_served"] >= 10 and la["failed"] == 0, la
+    assert rep["lookups_served"] == 0 and rep["subpel_seam"]["subpel_compares_served"] == 0
