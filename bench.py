@@ -268,7 +268,10 @@ def main():
                          "--me star - with its own C table and with the stage-level seams (integer-search SADs from x265hip_me_cache surfaces, the "
                          "lookahead's frame cost / intra estimates from x265hip_lowres_cost_host / x265hip_lowres_intra_host); fps + bitstream md5")
     ap.add_argument("--encoder", default="cfg3", help="configurations of the encoder-level leg (tools/encoder_bench.py: cfg1,cfg2,cfg3,cfg4)")
-    ap.add_argument("--encoder-frames", type=int, default=6)
+    ap.add_argument("--encoder-frames", type=int, default=48, help="frames of the encoder-level leg: more than the 25-picture lookahead of preset slow, "
+                    "so that the lookahead runs ahead of the frame encoders the way it does in a real encode")
+    ap.add_argument("--encoder-frame-threads", type=int, default=5, help="--frame-threads of both encoder legs (5 = the reference's own choice for 16 "
+                    "cores; the two search seams need 1 and step aside otherwise, the lookahead seam serves at any value)")
     ap.add_argument("--encoder-tables", default="c,seam", help="c = reference C table, seam = + x265hip_me_cache lookups, hip = per-call stubs (slow)")
     ap.add_argument("--prims", action="store_true",
                     help="instead of the pipeline line, print the per-family table of the batch-layer kernels with the CPU paths timed beside "
@@ -468,12 +471,15 @@ def main():
                 from tools import encoder_bench as EB
                 enc = {}
                 for key in args.encoder.split(","):
-                    enc[key] = EB.run_config(key, args.encoder_tables.split(","), args.encoder_frames, 1, 120.0, log=sys.stderr,
-                                             seam={"range": 24, "slots": 8, "min_pu": 8, "verify": False, "lookahead": True, "subpel": True, "subpel_slots": 6})
+                    ft = args.encoder_frame_threads
+                    enc[key] = EB.run_config(key, args.encoder_tables.split(","), args.encoder_frames, ft, 120.0, log=sys.stderr,
+                                             seam={"range": 24, "slots": 8 if ft == 1 else 2, "min_pu": 8, "verify": False, "lookahead": True,
+                                                   "subpel": ft == 1, "subpel_slots": 6})
                 out["encoder"] = enc
                 c3 = enc.get("cfg3", {})
                 if "c" in c3:
-                    out["encoder_summary"] = {"workload": c3["config"], "reference_c_table_fps": c3["c"]["fps"], "cores": c3["pool_threads"],
+                    out["encoder_summary"] = {"workload": c3["config"], "frames": c3["c"]["frames"], "frame_threads": args.encoder_frame_threads,
+                                              "reference_c_table_fps": c3["c"]["fps"], "cores": c3["pool_threads"],
                                               "seam_fps": c3.get("seam", {}).get("fps"), "seam_md5_equal": c3.get("seam", {}).get("md5_equal_to_c_table"),
                                               "kind": "reference (x265 3.5 C primitives, no asm: nasm is not in the image)"}
             except BaseException as e:       # incl. SystemExit from a missing oracle/_ref
