@@ -248,6 +248,10 @@ def main():
     ap.add_argument("--qp", type=int, default=27)
     ap.add_argument("--depth", type=int, default=8, choices=[8, 10], help="10 = the Main10 configurations (configs[3], [4])")
     ap.add_argument("--no-surface", action="store_true", help="ME keeps only the best mv (no SAD surfaces)")
+    ap.add_argument("--sharding", choices=["ring", "gop"], default="ring",
+                    help="N > 1: ring = the reference's frame parallelism with its real dependency (frame f on rank f %% N searches frame f - 1, "
+                         "handed on band by band; DESIGN.md section 6); gop = every rank encodes its own closed group of pictures with its own "
+                         "reference chain (segment-parallel encoding: no data-path exchange at all, an upper bound, not what x265 -F does)")
     ap.add_argument("--parallel-planes", type=int, default=1, choices=[0, 1],
                     help="1 = after the sub-pel stage Y, Cb and Cr run their reconstruction -> deblocking -> SAO -> border chains on three HIP "
                          "streams and the lookahead runs next to the search (same launches, same outputs); 0 = every launch on one stream")
@@ -333,8 +337,9 @@ def main():
                            chroma=True, sao_apply=True, sign_hide=True, subpel_planes=bool(args.subpel_planes),
                            parallel_planes=bool(args.parallel_planes))
     ref_pic = pics[0].like([p.clone() for p in pics[0].planes()])     # the reference every rank searches in (starts as frame 0): Y, Cb, Cr
-    fp = P.FrameParallel(rank, world)
-    banded = world > 1 or args.banded
+    gop = world > 1 and args.sharding == "gop"
+    fp = P.FrameParallel(rank, 1 if gop else world)          # gop: the hand-off is this rank's own copy
+    banded = (world > 1 and not gop) or args.banded
     if banded:
         # N > 1: the reference's real frame-parallel dependency - frame f (rank f % N) searches frame f - 1, band by band (pipeline.FrameParallelRing)
         bp = S.BandedFramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, band_rows=args.band_rows, rng=args.range, subme=args.subme, level=args.level,
@@ -443,7 +448,8 @@ def main():
                                    f"SAO statistics -> SAO parameters (saoStatsInitialOffset + distortion-only choice, on device) -> SAO apply (Y, Cb, Cr) -> "
                                    f"border extension -> next reference (Y, Cb, Cr); pipeline throughput (tier T2), not HEVC encoded fps - the real "
                                    f"encoder's fps (tier T3) is `bench.py --encoder` / profiles/r02_encoder_*.txt",
-                       "frames_per_step_per_gpu": 1, "parallelism": (f"frame-parallel x{world}" if not banded else
+                       "frames_per_step_per_gpu": 1, "parallelism": ((f"segment-parallel x{world}: every rank encodes its own closed group of pictures, no exchange (--sharding gop)" if gop
+                                        else f"frame-parallel x{world}") if not banded else
                                        f"frame-parallel ring x{world}: frame f on rank f % {world} searches frame f - 1, handed on in bands of {args.band_rows} CTU rows "
                                        f"(each band a slice of its own, like the reference's --slices)"),
                        "ctus_per_frame": ms.nctu, "checksum": csum},
