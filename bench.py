@@ -269,6 +269,9 @@ def main():
     ap.add_argument("--band-rows", type=int, default=4,
                     help="CTU rows per band of the frame-parallel ring (N > 1, or --banded): a band is searched / reconstructed / filtered as a slice "
                          "of its own (the reference's --slices) and handed to the next rank as soon as it is final")
+    ap.add_argument("--band-streams", type=int, default=3, help="banded pipeline: band b runs on HIP stream b %% this, so a band's search overlaps the "
+                    "previous band's reconstruction / loop filters (1: every band on the caller's stream)")
+    ap.add_argument("--band-graphs", type=int, default=0, help="banded pipeline: replay each band's launches as one HIP graph (0: launch by launch)")
     ap.add_argument("--banded", action="store_true", help="run the banded pipeline on one GPU too (measures what the band granularity costs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the bit-exact comparison of one whole frame with the oracle chain")
@@ -347,7 +350,8 @@ def main():
                                    # a band's grid (4 CTU rows = 240 workgroups) is too small for the record-per-lane kernel's 4-wavefront
                                    # workgroups (one per CU): bands use the record-contiguous packed format of the row-walking kernel
                                    packed=(args.surf_format != "i32" and args.depth == 8),
-                                   lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True)
+                                   lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True,
+                                   graphs=bool(args.band_graphs), streams=args.band_streams)
         # (bands keep every launch on one stream: side streams for the chroma chains change nothing at band size - 3.93 vs 3.97 ms at 4 rows)
         ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16,      # search window + 8-tap interpolation + sub-pel drift
                                    stage_through_host=backend != "nccl")
@@ -355,12 +359,19 @@ def main():
         geom = (pics[0].stride, F.MARGIN_Y, pics[0].stride_c, F.CHROMA_MARGIN_Y)
         total_frames = (args.warmup + args.steps) * world
         bp.begin_frame(pics[1])                         # allocates the output planes
+        if args.band_graphs:                            # set-up: every (band, source picture) of the resident clip recorded as a HIP graph
+            for pc in pics[1:]:
+                bp.capture(pc, ref_pic)
+            torch.cuda.synchronize()
 
     def step(i):
         cur = pics[1 + i % (nclip - 1)]
         if banded:
+            ring.finish()                               # the previous picture's bands have left before its planes are rewritten
             bp.begin_frame(cur)
-            ring.run_frame(i, geom, ref_pic.planes(), bp.final_planes(), lambda b, row0, n: bp.run_band(b, cur, ref_pic), total_frames=total_frames)
+            ring.run_frame(i, geom, ref_pic.planes(), bp.final_planes(), lambda b, row0, n: bp.run_band(b, cur, ref_pic), total_frames=total_frames,
+                           band_context=bp.band_context)
+            bp.end_frame()
             if world == 1:
                 fp.exchange(ref_pic.planes(), bp.final_planes())
             return
@@ -372,6 +383,12 @@ def main():
         step(i)
     pipe.launch_lookahead_costs()                    # no lookahead work of the warm-up frames leaks into the timed region
     torch.cuda.synchronize()
+    # The interpreter's cycle collector is parked for the timed loop: one full collection over torch's object graph is a 30 - 60 ms
+    # pause of the launching thread (seen in the dispatch timeline, profiles/r02_band_timeline.txt: a single 38 ms hole in a 10-step
+    # run) - nothing the encoder-side caller of the C ABI would have, and with a few dozen steps it decides the average.
+    import gc
+    gc.collect()
+    gc.disable()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -390,6 +407,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    gc.enable()
     if banded:
         csum = {"recon_%s" % n: int(p.view(torch.uint8).to(torch.int64).sum().item()) for n, p in zip(("y", "cb", "cr"), bp.final_planes())}
     else:

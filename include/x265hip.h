@@ -593,6 +593,10 @@ int x265hip_sao_apply(const x265hip_sao_apply_params* p, void* stream);
  *   count / offset_org : DEVICE int32 [nctu][5][32] from x265hip_sao_stats;  init_offset : optional DEVICE int32 [nctu][5][32]
  *   (SAO::m_offset);  ctu_params : DEVICE int32 [nctu][7] in x265hip_sao_apply's format. */
 int x265hip_sao_decide(int depth, const int32_t* count, const int32_t* offset_org, int nctu, int32_t* init_offset, int32_t* ctu_params, void* stream);
+/* 1..3 planes of one picture (Y, Cb, Cr) through statistics -> parameters -> application with ONE launch per step (the steps are
+ * latency-bound rounds of workgroups: three planes in one launch cost one latency, not three).  stats[i] / apply[i] as the single-plane
+ * entries take them; apply[i].ctu_params (DEVICE, written) receives plane i's parameters; apply = NULL: statistics only. */
+int x265hip_sao_planes(int nplanes, const x265hip_sao_stats_params* stats, const x265hip_sao_apply_params* apply, void* stream);
 
 /* ------------------------------------------------------------------ generic job-list entry points
  * Every remaining family evaluates `njobs` independent blocks of one size per launch.  An operand

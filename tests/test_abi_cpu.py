@@ -141,3 +141,21 @@ def test_phase_plane_entries_validate_before_touching_a_device():
     assert g(ctypes.byref(h), ctypes.byref(SD.PhaseCacheParams(8, 130, 64, 0, 0, 2))) == -2 and not h
     assert g(ctypes.byref(h), ctypes.byref(SD.PhaseCacheParams(8, 128, 64, 64, 30, 2))) == -2   # chroma rows not a multiple of 4
     assert g(ctypes.byref(h), ctypes.byref(SD.PhaseCacheParams(8, 128, 64, 0, 0, 0))) == -2     # no slots
+
+
+def test_sao_planes_validates_before_touching_a_device():
+    """x265hip_sao_planes rejects a bad plane count / mixed bit depths / missing buffers without a device."""
+    import ctypes
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    L = A.lib()
+    f = L.x265hip_sao_planes
+    f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    st = (A.SaoStatsParams * 3)()
+    assert f(0, ctypes.cast(st, ctypes.c_void_p), None, None) == -2
+    assert f(4, ctypes.cast(st, ctypes.c_void_p), None, None) == -2
+    assert f(1, None, None, None) == -2
+    assert f(1, ctypes.cast(st, ctypes.c_void_p), None, None) == -2          # empty record: no planes, no geometry
+    for i in range(2):
+        st[i].depth, st[i].fenc, st[i].fenc_stride, st[i].rec, st[i].rec_stride = 8 + 2 * i, 4096, 256, 8192, 256
+        st[i].width, st[i].height, st[i].count, st[i].offset_org = 128, 64, 12288, 16384
+    assert f(2, ctypes.cast(st, ctypes.c_void_p), None, None) == -2          # 8-bit and 10-bit planes in one call

@@ -68,3 +68,37 @@ def test_banded_pipeline_equals_oracle_band_by_band(depth, band_rows, par):
         # the filtered picture becomes the next frame's reference on both sides
         ref_host = (next_host[0], next_host[1].reshape(-1), next_host[2].reshape(-1))
         ref_dev = pics[k].like([p.clone() for p in bp.final_planes()])
+
+
+@pytest.mark.parametrize("depth,packed", [(8, True), (10, False)])
+def test_banded_graph_replay_and_band_streams_equal_launch_by_launch(depth, packed):
+    """graphs=True: every band's launches recorded once per (band, source, reference) as a HIP graph and replayed - a closed loop of six
+    frames (the filtered picture is the next reference, buffers stay in place) gives the planes of the launch-by-launch pipeline."""
+    import torch
+    dev = torch.device("cuda:0")
+    W, Hh, R, subme, level, qp = 256, 320, 12, 3, 2, 30 + 12 * (depth == 10)
+    clip = F.synth_clip(W, Hh, 3, depth=depth, seed=72)
+    pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
+    kw = dict(band_rows=2, rng=R, subme=subme, level=level, qp=qp, want_surf=True, packed=packed, deblock=True, sao=True, chroma=True, sao_apply=True,
+              sign_hide=True, lookahead=(W, Hh))
+    eager = S.BandedFramePipeline(pics[0].w64, pics[0].h64, depth, dev, **kw)
+    graph = S.BandedFramePipeline(pics[0].w64, pics[0].h64, depth, dev, graphs=True, **kw)
+    # bands alternating between two HIP streams (each with its own stage buffers): the search of band b + 1 overlaps the filters of band b
+    two = S.BandedFramePipeline(pics[0].w64, pics[0].h64, depth, dev, streams=2, **kw)
+    refs = [pics[0].like([p.clone() for p in pics[0].planes()]) for _ in range(3)]
+    for pc in pics[1:]:
+        graph.capture(pc, refs[1])
+    assert len(graph.graphs) == 2 * len(graph.bands)              # capture() visits every band twice: a band that warmed its stage buffers up is recorded on the second visit
+    recorded = len(graph.graphs)
+    for f in range(6):
+        cur = pics[1 + f % 2]
+        for bp, ref in ((eager, refs[0]), (graph, refs[1]), (two, refs[2])):
+            bp.run(cur, ref)
+            for d, s in zip(ref.planes(), bp.final_planes()):
+                d.copy_(s)
+        torch.cuda.synchronize()
+        for i, (a, b, c) in enumerate(zip(refs[0].planes(), refs[1].planes(), refs[2].planes())):
+            assert torch.equal(a, b), f"frame {f}: plane {i} of the graph replay differs"
+            assert torch.equal(a, c), f"frame {f}: plane {i} of the two-stream bands differs"
+        assert torch.equal(eager.la.intra_cost, graph.la.intra_cost)
+    assert len(graph.graphs) == recorded                          # the loop only replayed

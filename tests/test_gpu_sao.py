@@ -139,3 +139,45 @@ def test_sao_decide_matches_oracle_and_closes_the_loop(depth, width, height):
     init, params = O.sao_decide(depth, cnt, off)
     assert np.array_equal(g_par.cpu().numpy().reshape(n, 7), params) and np.array_equal(g_init.cpu().numpy().reshape(n, 5, 32), init)
     assert len(set(params[:, 0].tolist())) >= 4
+
+
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 128), (10, 192, 136), (8, 1920, 1080), (8, 200, 152)])
+def test_sao_planes_fused_equals_the_single_plane_entries(depth, width, height):
+    """x265hip_sao_planes (Y + two half-size planes, one launch per SAO step) against the per-plane x265hip_sao_stats / _decide / _apply
+    the tests above pin on the oracle: statistics, parameters and filtered planes identical."""
+    import torch
+    dev = torch.device("cuda:0")
+    S = importlib.import_module("x265-yuuki-asuna_amd.stages")
+    geo = [(width, height, (64, 64), 0), (width // 2, height // 2, (32, 32), 2), (width // 2, height // 2, (32, 32), 2)]
+    fused, single, bufs = [], [], []
+    for i, (w, h, ctu, po) in enumerate(geo):
+        y, rec, _ = _case(depth, w, h, 11 + i)
+        fenc, stride, org, _, _ = F.pad_plane(y)
+        recp = F.pad_plane(rec)[0]
+        d_f = torch.from_numpy(fenc.view(np.uint8).reshape(-1)).to(dev)
+        d_r = torch.from_numpy(recp.view(np.uint8).reshape(-1)).to(dev)
+        a, b = S.Sao(w, h, depth, dev, ctu=ctu, plane_offset=po), S.Sao(w, h, depth, dev, ctu=ctu, plane_offset=po)
+        oa, ob = d_r.clone(), d_r.clone()
+        if depth > 8:
+            d_f, d_r, oa, ob = d_f.view(torch.int16), d_r.view(torch.int16), oa.view(torch.int16), ob.view(torch.int16)
+        fused.append(a.plane(d_f, stride, org, d_r, stride, org, oa))
+        single.append((b, d_f, d_r, stride, org, ob))
+        bufs.append((a, oa, b, ob))
+    H.sao_planes(depth, fused)
+    for b, d_f, d_r, stride, org, ob in single:
+        b.stats(None, d_r, stride, org, src_plane=d_f)
+        b.decide()
+        b.apply(d_r, stride, org, ob)
+    torch.cuda.synchronize()
+    for i, (a, oa, b, ob) in enumerate(bufs):
+        assert torch.equal(a.count, b.count) and torch.equal(a.offset_org, b.offset_org), f"plane {i}: statistics differ"
+        assert torch.equal(a.params, b.params), f"plane {i}: parameters differ"
+        assert torch.equal(oa, ob), f"plane {i}: filtered plane differs"
+        assert int((a.params.view(-1, 7)[:, 0] >= 0).sum()) > 0
+    # statistics only (no application records): the same counts
+    for a, _, _, _ in bufs:
+        a.count.fill_(-1)
+    H.sao_planes(depth, [dict(q, out=None) for q in fused])
+    torch.cuda.synchronize()
+    for i, (a, _, b, _) in enumerate(bufs):
+        assert torch.equal(a.count, b.count), f"plane {i}: statistics-only call differs"

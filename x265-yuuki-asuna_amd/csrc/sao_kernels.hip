@@ -21,14 +21,21 @@ struct SaoStatsArgs
     const uint8_t* rec; long recStrideB;
     int width, height, depth, ctusW;
     int ctuW, ctuH, planeOffset;      // the CTU's footprint in this plane (64x64 luma, 32x32 4:2:0 chroma) and the reference's plane_offset
+    int nctu;
     int32_t* count; int32_t* offsetOrg;
 };
 
 __device__ __forceinline__ int sao_sign(int x) { return max(-1, min(1, x)); }      // one v_med3_i32
 
+// Up to three planes per launch (grid.y = plane): the SAO passes of Y, Cb and Cr are independent, latency-bound launches of one round of
+// workgroups each - three of them cost three times the latency, one launch with three times the workgroups costs it once.
+struct SaoStatsArgs3 { SaoStatsArgs p[3]; };
+
 template <typename Px>
-__global__ void __launch_bounds__(256) sao_stats_kernel(SaoStatsArgs a)
+__global__ void __launch_bounds__(256) sao_stats_kernel(SaoStatsArgs3 aa)
 {
+    const SaoStatsArgs& a = aa.p[blockIdx.y];
+    if ((int)blockIdx.x >= a.nctu) return;
     constexpr int BPP = sizeof(Px);
     constexpr int LW = 68;                                   // LDS row pitch of the 66-wide neighbourhood
     __shared__ uint16_t sRec[66 * LW];
@@ -176,11 +183,15 @@ struct SaoApplyArgs
     uint8_t* dst; long dstStrideB;
     int width, height, depth, ctusW, ctuW, ctuH;
     const int32_t* params;
+    int nctu;
 };
+struct SaoApplyArgs3 { SaoApplyArgs p[3]; };
 
 template <typename Px>
-__global__ void __launch_bounds__(256) sao_apply_kernel(SaoApplyArgs a)
+__global__ void __launch_bounds__(256) sao_apply_kernel(SaoApplyArgs3 aa)
 {
+    const SaoApplyArgs& a = aa.p[blockIdx.y];
+    if ((int)blockIdx.x >= a.nctu) return;
     constexpr int BPP = sizeof(Px);
     const int tid = threadIdx.x, addr = blockIdx.x;
     const int lpelx = (addr % a.ctusW) * a.ctuW, tpely = (addr / a.ctusW) * a.ctuH;
@@ -232,11 +243,14 @@ __global__ void __launch_bounds__(256) sao_apply_kernel(SaoApplyArgs a)
 // (sao.cpp:56-59) - the documented stand-in for the entropy-coder-driven rdoSaoUnitCu that lets the closed-loop pipeline hand the
 // next picture a reference that went through SAO.
 struct SaoDecideArgs { const int32_t* count; const int32_t* offsetOrg; int nctu, depth; int32_t* initOffset; int32_t* params; };
+struct SaoDecideArgs3 { SaoDecideArgs p[3]; };
 
 // one wavefront per CTU: lanes 0..15 take the (edge type, class) pairs, lanes 32..63 the 32 bands - the divisions of the initial offsets
 // run side by side - and lane 0 makes the small serial choice from LDS
-__global__ void __launch_bounds__(64) sao_decide_kernel(SaoDecideArgs a)
+__global__ void __launch_bounds__(64) sao_decide_kernel(SaoDecideArgs3 aa)
 {
+    const SaoDecideArgs& a = aa.p[blockIdx.y];
+    if ((int)blockIdx.x >= a.nctu) return;
     __shared__ int sOff[5][32];
     __shared__ long long sDist[5][32];
     const int ctu = blockIdx.x, lane = threadIdx.x;
@@ -290,15 +304,12 @@ __global__ void __launch_bounds__(64) sao_decide_kernel(SaoDecideArgs a)
 
 using namespace x265hip;
 
-extern "C" int x265hip_sao_stats(const x265hip_sao_stats_params* p, void* stream)
+static int fill_stats(const x265hip_sao_stats_params* p, SaoStatsArgs& a)
 {
-    int rc = ensure_device();
-    if (rc) return rc;
     if (!p || !p->fenc || !p->rec || !p->count || !p->offset_org) { set_error("sao_stats: NULL operand"); return X265HIP_EINVAL; }
     if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("sao_stats: depth %d", p->depth); return X265HIP_EINVAL; }
     if (p->width <= 0 || p->height <= 0) { set_error("sao_stats: empty picture"); return X265HIP_EINVAL; }
     const int bpp = p->depth == 8 ? 1 : 2;
-    SaoStatsArgs a;
     a.fenc = (const uint8_t*)p->fenc; a.fencStrideB = (long)p->fenc_stride * bpp;
     a.rec = (const uint8_t*)p->rec; a.recStrideB = (long)p->rec_stride * bpp;
     a.ctuW = p->ctu_width ? p->ctu_width : 64; a.ctuH = p->ctu_height ? p->ctu_height : 64; a.planeOffset = p->plane_offset;
@@ -306,47 +317,105 @@ extern "C" int x265hip_sao_stats(const x265hip_sao_stats_params* p, void* stream
     { set_error("sao_stats: CTU footprint %d x %d / plane_offset %d", a.ctuW, a.ctuH, a.planeOffset); return X265HIP_EINVAL; }
     a.width = p->width; a.height = p->height; a.depth = p->depth; a.ctusW = (p->width + a.ctuW - 1) / a.ctuW;
     a.count = p->count; a.offsetOrg = p->offset_org;
-    const int nctu = a.ctusW * ((p->height + a.ctuH - 1) / a.ctuH);
-    hipStream_t s = (hipStream_t)stream;
-    if (bpp == 1) hipLaunchKernelGGL(sao_stats_kernel<uint8_t>, dim3(nctu), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(sao_stats_kernel<uint16_t>, dim3(nctu), dim3(256), 0, s, a);
-    X265HIP_TRY(hipGetLastError());
+    a.nctu = a.ctusW * ((p->height + a.ctuH - 1) / a.ctuH);
     return 0;
 }
 
-extern "C" int x265hip_sao_apply(const x265hip_sao_apply_params* p, void* stream)
+static int fill_apply(const x265hip_sao_apply_params* p, SaoApplyArgs& a)
 {
-    int rc = ensure_device();
-    if (rc) return rc;
     if (!p || !p->src || !p->dst || !p->ctu_params) { set_error("sao_apply: NULL operand"); return X265HIP_EINVAL; }
     if (p->src == p->dst) { set_error("sao_apply: the filter is out of place (a sample is classified against unfiltered neighbours)"); return X265HIP_EINVAL; }
     if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("sao_apply: depth %d", p->depth); return X265HIP_EINVAL; }
     if (p->width <= 0 || p->height <= 0) { set_error("sao_apply: empty picture"); return X265HIP_EINVAL; }
     const int bpp = p->depth == 8 ? 1 : 2;
-    SaoApplyArgs a;
     a.src = (const uint8_t*)p->src; a.srcStrideB = (long)p->src_stride * bpp;
     a.dst = (uint8_t*)p->dst; a.dstStrideB = (long)p->dst_stride * bpp;
     a.ctuW = p->ctu_width ? p->ctu_width : 64; a.ctuH = p->ctu_height ? p->ctu_height : 64;
     if (a.ctuW < 8 || a.ctuW > 64 || a.ctuH < 8 || a.ctuH > 64) { set_error("sao_apply: CTU footprint %d x %d", a.ctuW, a.ctuH); return X265HIP_EINVAL; }
     a.width = p->width; a.height = p->height; a.depth = p->depth; a.ctusW = (p->width + a.ctuW - 1) / a.ctuW;
     a.params = p->ctu_params;
-    const int nctu = a.ctusW * ((p->height + a.ctuH - 1) / a.ctuH);
-    hipStream_t s = (hipStream_t)stream;
-    if (bpp == 1) hipLaunchKernelGGL(sao_apply_kernel<uint8_t>, dim3(nctu), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(sao_apply_kernel<uint16_t>, dim3(nctu), dim3(256), 0, s, a);
-    X265HIP_TRY(hipGetLastError());
+    a.nctu = a.ctusW * ((p->height + a.ctuH - 1) / a.ctuH);
     return 0;
+}
+
+static int launch_stats(const SaoStatsArgs3& aa, int nplanes, int depth, hipStream_t s)
+{
+    int nmax = 0;
+    for (int i = 0; i < nplanes; i++) nmax = aa.p[i].nctu > nmax ? aa.p[i].nctu : nmax;
+    if (depth == 8) hipLaunchKernelGGL(sao_stats_kernel<uint8_t>, dim3(nmax, nplanes), dim3(256), 0, s, aa);
+    else hipLaunchKernelGGL(sao_stats_kernel<uint16_t>, dim3(nmax, nplanes), dim3(256), 0, s, aa);
+    return check_hip(hipGetLastError(), "sao_stats launch");
+}
+
+static int launch_apply(const SaoApplyArgs3& aa, int nplanes, int depth, hipStream_t s)
+{
+    int nmax = 0;
+    for (int i = 0; i < nplanes; i++) nmax = aa.p[i].nctu > nmax ? aa.p[i].nctu : nmax;
+    if (depth == 8) hipLaunchKernelGGL(sao_apply_kernel<uint8_t>, dim3(nmax, nplanes), dim3(256), 0, s, aa);
+    else hipLaunchKernelGGL(sao_apply_kernel<uint16_t>, dim3(nmax, nplanes), dim3(256), 0, s, aa);
+    return check_hip(hipGetLastError(), "sao_apply launch");
+}
+
+extern "C" int x265hip_sao_stats(const x265hip_sao_stats_params* p, void* stream)
+{
+    SaoStatsArgs3 aa = {};
+    int rc = fill_stats(p, aa.p[0]);
+    if (rc) return rc;
+    if ((rc = ensure_device())) return rc;
+    return launch_stats(aa, 1, p->depth, (hipStream_t)stream);
+}
+
+extern "C" int x265hip_sao_apply(const x265hip_sao_apply_params* p, void* stream)
+{
+    SaoApplyArgs3 aa = {};
+    int rc = fill_apply(p, aa.p[0]);
+    if (rc) return rc;
+    if ((rc = ensure_device())) return rc;
+    return launch_apply(aa, 1, p->depth, (hipStream_t)stream);
 }
 
 extern "C" int x265hip_sao_decide(int depth, const int32_t* count, const int32_t* offset_org, int nctu, int32_t* init_offset, int32_t* ctu_params, void* stream)
 {
-    int rc = ensure_device();
-    if (rc) return rc;
     if (!count || !offset_org || !ctu_params) { set_error("sao_decide: NULL operand"); return X265HIP_EINVAL; }
     if (depth != 8 && depth != 10 && depth != 12) { set_error("sao_decide: depth %d", depth); return X265HIP_EINVAL; }
     if (nctu <= 0) { set_error("sao_decide: nctu %d", nctu); return X265HIP_EINVAL; }
-    SaoDecideArgs a = { count, offset_org, nctu, depth, init_offset, ctu_params };
-    hipLaunchKernelGGL(sao_decide_kernel, dim3(nctu), dim3(64), 0, (hipStream_t)stream, a);
-    X265HIP_TRY(hipGetLastError());
-    return 0;
+    int rc = ensure_device();
+    if (rc) return rc;
+    SaoDecideArgs3 aa = {};
+    aa.p[0] = SaoDecideArgs{ count, offset_org, nctu, depth, init_offset, ctu_params };
+    hipLaunchKernelGGL(sao_decide_kernel, dim3(nctu, 1), dim3(64), 0, (hipStream_t)stream, aa);
+    return check_hip(hipGetLastError(), "sao_decide launch");
+}
+
+/* Y, Cb and Cr (or any 1..3 planes of one bit depth) through the three SAO steps with ONE launch per step instead of one per plane and
+ * step: statistics -> (when `apply` is given) parameters on the device -> application.  stats[i] / apply[i] describe plane i exactly as
+ * the single-plane entries take them; apply[i].ctu_params receives plane i's parameters. */
+extern "C" int x265hip_sao_planes(int nplanes, const x265hip_sao_stats_params* stats, const x265hip_sao_apply_params* apply, void* stream)
+{
+    if (nplanes < 1 || nplanes > 3 || !stats) { set_error("sao_planes: %d planes", nplanes); return X265HIP_EINVAL; }
+    SaoStatsArgs3 sa = {};
+    SaoApplyArgs3 ap = {};
+    SaoDecideArgs3 da = {};
+    int nmax = 0;
+    for (int i = 0; i < nplanes; i++)
+    {
+        int rc = fill_stats(&stats[i], sa.p[i]);
+        if (rc) return rc;
+        if (stats[i].depth != stats[0].depth) { set_error("sao_planes: planes of different bit depths"); return X265HIP_EINVAL; }
+        if (apply)
+        {
+            if ((rc = fill_apply(&apply[i], ap.p[i]))) return rc;
+            if (apply[i].depth != stats[0].depth || ap.p[i].nctu != sa.p[i].nctu) { set_error("sao_planes: statistics / application geometry of plane %d differ", i); return X265HIP_EINVAL; }
+            da.p[i] = SaoDecideArgs{ stats[i].count, stats[i].offset_org, sa.p[i].nctu, stats[i].depth, nullptr, const_cast<int32_t*>(apply[i].ctu_params) };
+        }
+        nmax = sa.p[i].nctu > nmax ? sa.p[i].nctu : nmax;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = launch_stats(sa, nplanes, stats[0].depth, s))) return rc;
+    if (!apply) return 0;
+    hipLaunchKernelGGL(sao_decide_kernel, dim3(nmax, nplanes), dim3(64), 0, s, da);
+    if ((rc = check_hip(hipGetLastError(), "sao_decide launch"))) return rc;
+    return launch_apply(ap, nplanes, stats[0].depth, s);
 }

@@ -590,6 +590,31 @@ def sao_apply(depth, src, src_stride, src_org, dst, dst_stride, dst_org, width, 
     check(f(ctypes.byref(p), s), "x265hip_sao_apply")
 
 
+def sao_planes(depth, planes, stream=None):
+    """x265hip_sao_planes: 1..3 planes through SAO statistics -> on-device parameters -> application with one launch per step.
+    planes: list of dicts with src / src_stride / src_org, rec / rec_stride / rec_org, out (None: statistics only - then for every
+    plane), width, height, count, offset_org, params, ctu, plane_offset."""
+    es = 1 if depth == 8 else 2
+    n = len(planes)
+    st = (SaoStatsParams * n)()
+    ap = (SaoApplyParams * n)()
+    with_apply = planes[0].get("out") is not None
+    for i, q in enumerate(planes):
+        st[i].depth, st[i].fenc, st[i].fenc_stride = depth, q["src"].data_ptr() + q["src_org"] * es, q["src_stride"]
+        st[i].rec, st[i].rec_stride, st[i].width, st[i].height = q["rec"].data_ptr() + q["rec_org"] * es, q["rec_stride"], q["width"], q["height"]
+        st[i].count, st[i].offset_org = q["count"].data_ptr(), q["offset_org"].data_ptr()
+        st[i].ctu_width, st[i].ctu_height, st[i].plane_offset = q["ctu"][0], q["ctu"][1], q["plane_offset"]
+        if with_apply:
+            ap[i].depth, ap[i].src, ap[i].src_stride = depth, st[i].rec, q["rec_stride"]
+            ap[i].dst, ap[i].dst_stride, ap[i].width, ap[i].height = q["out"].data_ptr() + q["rec_org"] * es, q["rec_stride"], q["width"], q["height"]
+            ap[i].ctu_params = q["params"].data_ptr()
+            ap[i].ctu_width, ap[i].ctu_height = q["ctu"]
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_sao_planes
+    f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    check(f(n, ctypes.cast(st, ctypes.c_void_p), ctypes.cast(ap, ctypes.c_void_p) if with_apply else None, s), "x265hip_sao_planes")
+
+
 def me_best_reset(best, stream=None):
     s = current_stream() if stream is None else stream
     check(lib().x265hip_me_best_reset(best.data_ptr(), best.numel(), s), "x265hip_me_best_reset")

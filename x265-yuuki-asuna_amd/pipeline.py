@@ -294,11 +294,15 @@ class FrameParallelRing:
                 dist.all_reduce(t, group=g)
         return self.groups
 
-    def run_frame(self, step, geom, ref_planes, out_planes, process_band, total_frames=None, first_frame_is_local=True):
+    def run_frame(self, step, geom, ref_planes, out_planes, process_band, total_frames=None, first_frame_is_local=True, band_context=None):
         """One frame of this rank.  ref_planes: the flat Y / Cb / Cr tensors the previous frame's bands are received into (for the very
         first frame of the job they already hold the start picture); out_planes: where process_band(b, row0, nrows) leaves this frame's
         finished bands (not reused before the next call returns them: the sends of a frame are only waited for at the start of this
-        rank's next frame, or by finish()).  total_frames: frames of the whole job - the last frame has no consumer and is not sent."""
+        rank's next frame, or by finish()).  total_frames: frames of the whole job - the last frame has no consumer and is not sent.
+        band_context(b): context manager under which band b is waited for, processed and sent (stages.BandedFramePipeline.band_context:
+        bands alternate between HIP streams, and a transfer orders itself against the stream that is current when it is issued / waited
+        for - so a band's arrival and departure only hold up that band's stream); the receives are posted outside it."""
+        import contextlib
         import torch.distributed as dist
         f = self.frame_index(step)
         nb = len(self.bands)
@@ -333,13 +337,14 @@ class FrameParallelRing:
                 posted += 1
                 r0, rn = self.bands[posted]
                 pending[posted] = p2p(dist.irecv, ref_planes, self._rows(geom, r0, rn, posted == 0, posted == nb - 1), self.prev, g_in)
-            while arrived < need:
-                arrived += 1
-                for w in pending.pop(arrived):
-                    w.wait()
-            process_band(b, row0, n)
-            if send_to_peer:
-                self._sends += p2p(dist.isend, out_planes, self._rows(geom, row0, n, b == 0, b == nb - 1), self.next, g_out)
+            with (band_context(b) if band_context is not None else contextlib.nullcontext()):
+                while arrived < need:
+                    arrived += 1
+                    for w in pending.pop(arrived):
+                        w.wait()
+                process_band(b, row0, n)
+                if send_to_peer:
+                    self._sends += p2p(dist.isend, out_planes, self._rows(geom, row0, n, b == 0, b == nb - 1), self.next, g_out)
         if recv_from_peer:                                  # bands below the last search window still belong to the reference picture
             while posted < nb - 1:
                 posted += 1

@@ -207,6 +207,11 @@ class Sao:
         hipabi.sao_stats(self.depth, src.t, src.stride, src.org, rec, rec_stride, rec_org, self.width, self.height, self.count, self.offset_org,
                          ctu=self.ctu, plane_offset=self.plane_offset)
 
+    def plane(self, src, src_stride, src_org, rec, rec_stride, rec_org, out=None):
+        """This plane's record for hipabi.sao_planes (several planes, one launch per SAO step)."""
+        return dict(src=src, src_stride=src_stride, src_org=src_org, rec=rec, rec_stride=rec_stride, rec_org=rec_org, out=out, width=self.width,
+                    height=self.height, count=self.count, offset_org=self.offset_org, params=self.params, ctu=self.ctu, plane_offset=self.plane_offset)
+
     def decide(self):
         """saoStatsInitialOffset + the distortion-only type choice of x265hip_sao_decide -> self.params (stays on the device)."""
         hipabi.sao_decide(self.depth, self.count, self.offset_org, self.nctu, self.params)
@@ -467,6 +472,10 @@ class FramePipeline:
         # only) next to the search; everything joins the caller's stream before run() returns
         self.parallel = bool(parallel_planes)
         self.pstreams = None
+        # the three planes' SAO passes as one launch per step: on by default where every launch is on one stream (0.144 vs 0.187 ms at 4K);
+        # with the planes' chains on side streams the per-plane passes already overlap and fusing them costs 0.07 ms ("2" forces it there too)
+        self.fuse_sao = os.environ.get("X265HIP_FUSE_SAO", "1") != "0"
+        self.fuse_sao_parallel = os.environ.get("X265HIP_FUSE_SAO", "1") == "2"
         self.ms = MotionSearch(w64, h64, rng, depth, device, want_surf=want_surf and search == "full", want_best=True, packed=packed)
         # subpel_planes: sub-pel candidates read from the reference picture's phase planes (one x265hip_phase_planes launch per frame)
         self.sp = SubpelRefine(self.ms, subme, device, phase_planes=subpel_planes)
@@ -567,7 +576,17 @@ class FramePipeline:
                                       self.db.bs_ver, self.db.bs_hor, self.db.qp)
             mark("deblock")
         final, final_c = self.recon, self.recon_c
-        if self.sao is not None:
+        if self.sao is not None and self.sao_apply and self.chroma and self.fuse_sao:
+            # Y, Cb, Cr through statistics -> parameters -> application with ONE launch per step (x265hip_sao_planes)
+            if self.out is None:
+                self.out = torch.zeros_like(cur.t)
+                self.out_c = [torch.zeros_like(p) for p in cur.c]
+            hipabi.sao_planes(self.depth, [self.sao.plane(cur.t, cur.stride, cur.org, self.recon, cur.stride, cur.org, self.out)] +
+                              [self.sao_c[i].plane(cur.c[i], cur.stride_c, cur.org_c, self.recon_c[i], cur.stride_c, cur.org_c, self.out_c[i]) for i in range(2)])
+            mark("sao_stats")
+            final, final_c = self.out, self.out_c
+            mark("sao_apply")
+        elif self.sao is not None:
             self.sao.stats(cur, self.recon, cur.stride, cur.org)
             if self.chroma:
                 for i in range(2):
@@ -653,10 +672,17 @@ class FramePipeline:
                                   self.db.bs_ver, self.db.bs_hor, self.db.qp)
             ev_dbc = torch.cuda.Event(); ev_dbc.record(sCb)
         sCr.wait_event(ev_dbc)
-        # SAO + border extension per plane
-        self.sao.stats(cur, self.recon, cur.stride, cur.org)
-        self.sao.decide()
-        self.sao.apply(self.recon, cur.stride, cur.org, self.out)
+        if self.fuse_sao_parallel:
+            # SAO of the three planes: one launch per step on the caller's stream; only the border extensions go back to the side streams
+            main.wait_event(ev_dbc)
+            hipabi.sao_planes(self.depth, [self.sao.plane(cur.t, cur.stride, cur.org, self.recon, cur.stride, cur.org, self.out)] +
+                              [self.sao_c[i].plane(cur.c[i], cur.stride_c, cur.org_c, self.recon_c[i], cur.stride_c, cur.org_c, self.out_c[i]) for i in range(2)])
+            ev_sao = torch.cuda.Event(); ev_sao.record(main)
+        else:
+            # SAO + border extension per plane
+            self.sao.stats(cur, self.recon, cur.stride, cur.org)
+            self.sao.decide()
+            self.sao.apply(self.recon, cur.stride, cur.org, self.out)
 
         def border(plane, chroma):
             if self.band_border is not None:              # a band of a picture: side margins, top / bottom margin only at the picture's edge
@@ -666,10 +692,13 @@ class FramePipeline:
         border(self.out, False)
         done = []
         for i, st in enumerate((sCb, sCr)):
+            if self.fuse_sao_parallel:
+                st.wait_event(ev_sao)
             with torch.cuda.stream(st):
-                self.sao_c[i].stats(None, self.recon_c[i], cur.stride_c, cur.org_c, src_plane=cur.c[i])
-                self.sao_c[i].decide()
-                self.sao_c[i].apply(self.recon_c[i], cur.stride_c, cur.org_c, self.out_c[i])
+                if not self.fuse_sao_parallel:
+                    self.sao_c[i].stats(None, self.recon_c[i], cur.stride_c, cur.org_c, src_plane=cur.c[i])
+                    self.sao_c[i].decide()
+                    self.sao_c[i].apply(self.recon_c[i], cur.stride_c, cur.org_c, self.out_c[i])
                 border(self.out_c[i], True)
                 e = torch.cuda.Event(); e.record(st); done.append(e)
         if self.la is not None:
@@ -737,12 +766,24 @@ class BandedFramePipeline:
     extended) can be handed to the rank that searches it next while the following bands are still in flight - the granularity of the
     reference's m_reconRowFlag (framefilter.cpp:664).  band_ready(b, row0, rows), if given, is called after band b's launches."""
 
-    def __init__(self, w64, h64, depth, device, band_rows=4, lookahead=None, **kw):
+    def __init__(self, w64, h64, depth, device, band_rows=4, lookahead=None, graphs=False, streams=1, **kw):
+        """graphs: a band's ~25 launches are captured once per (band, source picture, reference picture) into a HIP graph and replayed with
+        one launch - a band is 240 workgroups per kernel, so enqueueing its launches one by one from the host costs more than running them
+        (3.9 ms per 4K frame of 9 bands against 2.2 ms for the frame in one piece).  The buffers must then stay where they are between frames."""
         self.w64, self.h64, self.depth, self.device = w64, h64, depth, device
+        self.use_graphs, self.graphs, self.warm = bool(graphs), {}, set()
         rows = h64 // 64
         self.bands = [(r, min(band_rows, rows - r)) for r in range(0, rows, band_rows)]
         kw.pop("lookahead_cost_batch", None)
-        self.pipes = {n: FramePipeline(w64, n * 64, depth, device, lookahead=None, **kw) for n in sorted({n for _, n in self.bands})}
+        # streams > 1: band b runs on HIP stream b % streams with its own set of stage buffers.  The bands of one picture do not depend on
+        # each other (each is a slice), so the exhaustive search of band b + 1 - the one launch that fills the chip - overlaps the
+        # reconstruction / deblocking / SAO launches of band b, which at band size are a few dozen workgroups each and bound by their own
+        # latency.  begin_frame() forks the band streams from the caller's stream, end_frame() joins them.
+        self.nstreams = max(1, int(streams))
+        self.pipe_sets = [{n: FramePipeline(w64, n * 64, depth, device, lookahead=None, **kw) for n in sorted({n for _, n in self.bands})}
+                          for _ in range(self.nstreams)]
+        self.pipes = self.pipe_sets[0]
+        self.streams = None
         self.la = Lookahead(lookahead[0], lookahead[1], depth, device) if lookahead else None
         self.planes = None          # [Y, Cb, Cr] the bands are written into: reconstruction and filtered picture
         self.chroma = bool(kw.get("chroma"))
@@ -753,7 +794,7 @@ class BandedFramePipeline:
         if self.planes is None:
             self.recon = [torch.zeros_like(p) for p in cur.planes()]
             self.final = [torch.zeros_like(p) for p in cur.planes()] if self.sao_apply else self.recon
-        for pipe in self.pipes.values():
+        for pipe in [q for ps in self.pipe_sets for q in ps.values()]:
             pipe.recon = self.recon[0]
             pipe.recon_c = self.recon[1:3] if self.chroma else None
             if self.sao_apply:
@@ -764,23 +805,75 @@ class BandedFramePipeline:
     def begin_frame(self, cur):
         """Per-frame work that does not depend on the reference: output planes, the lookahead stage of the source picture."""
         self._alloc(cur)
+        if self.nstreams > 1:
+            import torch
+            if self.streams is None:
+                self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.nstreams)]
+            ev = torch.cuda.Event()
+            ev.record()
+            for st in self.streams:          # whatever the caller queued before (the hand-off of the previous picture) comes first
+                st.wait_event(ev)
         if self.la is not None:
             self.la.run(cur)
 
-    def run_band(self, b, cur, ref):
+    def band_context(self, b):
+        """Context manager under which band b's launches (and the transfers that wait for / follow them) are issued."""
+        import contextlib
+        if self.nstreams == 1 or self.streams is None:
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(self.streams[b % self.nstreams])
+
+    def end_frame(self):
+        """The caller's stream continues after every band of the picture."""
+        if self.nstreams > 1 and self.streams is not None:
+            import torch
+            main = torch.cuda.current_stream()
+            for st in self.streams:
+                main.wait_stream(st)
+
+    def _launch_band(self, b, cur, ref):
         row0, n = self.bands[b]
-        pipe = self.pipes[n]
+        pipe = self.pipe_sets[b % self.nstreams][n]
         pipe.band_border = (b == 0, b == len(self.bands) - 1)
         pipe.run(cur.band_view(row0, n), ref.band_view(row0, n))
+
+    def run_band(self, b, cur, ref):
+        if not self.use_graphs:
+            return self._launch_band(b, cur, ref)
+        import torch
+        n = (self.bands[b][1], b % self.nstreams)
+        if n not in self.warm:                     # the first band of this height runs launch by launch: lazy allocations, kernel attributes
+            self.warm.add(n)
+            return self._launch_band(b, cur, ref)
+        key = (b,) + tuple(p.data_ptr() for p in cur.planes()) + tuple(p.data_ptr() for p in ref.planes())
+        g = self.graphs.get(key)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):       # other threads (RCCL's watchdog) keep working during the capture
+                self._launch_band(b, cur, ref)
+            self.graphs[key] = g
+        g.replay()
+
+    def capture(self, cur, ref):
+        """Record every band of (cur, ref) ahead of time (set-up, outside any timed region).  Executes the bands once."""
+        self.begin_frame(cur)
+        for _ in range(2):
+            for b in range(len(self.bands)):
+                with self.band_context(b):
+                    self.run_band(b, cur, ref)
+        self.end_frame()
 
     def run(self, cur, ref, band_ready=None, before_band=None):
         self.begin_frame(cur)
         for b, (row0, n) in enumerate(self.bands):
-            if before_band is not None:
-                before_band(b, row0, n)                     # e.g. wait until the reference rows this band reads have arrived
-            self.run_band(b, cur, ref)
-            if band_ready is not None:
-                band_ready(b, row0, n)
+            with self.band_context(b):
+                if before_band is not None:
+                    before_band(b, row0, n)                 # e.g. wait until the reference rows this band reads have arrived
+                self.run_band(b, cur, ref)
+                if band_ready is not None:
+                    band_ready(b, row0, n)
+        self.end_frame()
         return self.planes[0]
 
     def final_planes(self):
