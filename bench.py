@@ -235,6 +235,27 @@ def load_traffic(width, height, rng_r, fmt):
         return None, None
 
 
+# One MI355X, 3840x2160 8-bit, three band streams (profiles/r02_band_size.txt): milliseconds per picture against the CTU rows per band.
+# Small bands cost launches whose grids no longer fill the chip; large bands make the next rank wait longer for its first reference rows.
+BANDED_STEP_MS = {1: 5.11, 2: 3.50, 3: 3.16, 4: 2.83, 6: 2.79, 8: 2.70, 12: 2.58, 17: 2.45}
+
+
+def pick_band_rows(world, ctu_rows=34, lag_rows_luma=73):
+    """Band size for a ring of `world` ranks: rank r + 1 may start band b once rank r has finished every band its search window and
+    interpolation taps reach (bands_needed: b plus the bands that begin inside the lag rows below it), so consecutive ranks run about
+    `lag` apart and a rank comes round again after world x lag - throughput is world pictures per max(step, world x lag).  The step
+    times are the measured ones above, a hand-over is taken as 0.1 ms."""
+    best = None
+    for rows, step in BANDED_STEP_MS.items():
+        nb = -(-ctu_rows // rows)
+        ahead = 1 + -(-lag_rows_luma // (rows * 64))            # band periods until the bands a start needs are final
+        lag = ahead * step / nb + 0.1
+        period = max(step, world * lag)
+        if best is None or period < best[0]:
+            best = (period, rows)
+    return best[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,9 +287,9 @@ def main():
                          "searches run by the device-side search driver (x265hip_me_search), predictor (0,0)")
     ap.add_argument("--lookahead-batch", type=int, default=0,
                     help="pictures per launch of the lookahead's P-frame cost estimate, which runs ahead on a side stream (0 = stage off)")
-    ap.add_argument("--band-rows", type=int, default=4,
+    ap.add_argument("--band-rows", type=int, default=0,
                     help="CTU rows per band of the frame-parallel ring (N > 1, or --banded): a band is searched / reconstructed / filtered as a slice "
-                         "of its own (the reference's --slices) and handed to the next rank as soon as it is final")
+                         "of its own and handed to the next rank as soon as it is final.  0 = chosen from the number of ranks (pick_band_rows)")
     ap.add_argument("--band-streams", type=int, default=3, help="banded pipeline: band b runs on HIP stream b %% this, so a band's search overlaps the "
                     "previous band's reconstruction / loop filters (1: every band on the caller's stream)")
     ap.add_argument("--band-graphs", type=int, default=0, help="banded pipeline: replay each band's launches as one HIP graph (0: launch by launch)")
@@ -343,6 +364,8 @@ def main():
     gop = world > 1 and args.sharding == "gop"
     fp = P.FrameParallel(rank, 1 if gop else world)          # gop: the hand-off is this rank's own copy
     banded = (world > 1 and not gop) or args.banded
+    if banded and not args.band_rows:
+        args.band_rows = pick_band_rows(world) if world > 1 else 4
     if banded:
         # N > 1: the reference's real frame-parallel dependency - frame f (rank f % N) searches frame f - 1, band by band (pipeline.FrameParallelRing)
         bp = S.BandedFramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, band_rows=args.band_rows, rng=args.range, subme=args.subme, level=args.level,
