@@ -273,6 +273,10 @@ def main():
                     help="N > 1: ring = the reference's frame parallelism with its real dependency (frame f on rank f %% N searches frame f - 1, "
                          "handed on band by band; DESIGN.md section 6); gop = every rank encodes its own closed group of pictures with its own "
                          "reference chain (segment-parallel encoding: no data-path exchange at all, an upper bound, not what x265 -F does)")
+    ap.add_argument("--split", type=int, default=1,
+                    help="search -> sub-pel refinement -> reconstruction in this many parts of whole CTU rows, part k refined / reconstructed on a side "
+                         "stream while part k + 1 is searched (same results; needs --parallel-planes 1; 1 = the picture in one piece - the default: "
+                         "next to other kernels the record-per-lane search loses more than the overlap hides, 2.94 against 2.29 ms at 4K)")
     ap.add_argument("--parallel-planes", type=int, default=1, choices=[0, 1],
                     help="1 = after the sub-pel stage Y, Cb and Cr run their reconstruction -> deblocking -> SAO -> border chains on three HIP "
                          "streams and the lookahead runs next to the search (same launches, same outputs); 0 = every launch on one stream")
@@ -359,7 +363,7 @@ def main():
                            qp=args.qp, want_surf=not args.no_surface, packed=({"packed": True, "packed_t": "t"}.get(args.surf_format, False) if args.depth == 8 else False),
                            lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True, lookahead_cost_batch=args.lookahead_batch,
                            chroma=True, sao_apply=True, sign_hide=True, subpel_planes=bool(args.subpel_planes),
-                           parallel_planes=bool(args.parallel_planes))
+                           parallel_planes=bool(args.parallel_planes), split=args.split)
     ref_pic = pics[0].like([p.clone() for p in pics[0].planes()])     # the reference every rank searches in (starts as frame 0): Y, Cb, Cr
     gop = world > 1 and args.sharding == "gop"
     fp = P.FrameParallel(rank, 1 if gop else world)          # gop: the hand-off is this rank's own copy

@@ -140,3 +140,34 @@ def test_closed_loop_with_chroma_and_sao_in_the_loop(depth, fast):
         ref_host = (cpu_out["recon"], cpu_out["recon_c0"].reshape(-1), cpu_out["recon_c1"].reshape(-1))
         ref_dev = pics[k].like([p.clone() for p in pipe.final_planes()])
     assert any(t >= 0 for t in types), "SAO never switched on: the loop was not exercised"
+
+
+@pytest.mark.parametrize("depth,split,packed", [(8, 2, "t"), (8, 3, True), (10, 2, False)])
+def test_search_to_reconstruction_in_parts_leaves_the_same_picture(depth, split, packed):
+    """FramePipeline(split=k): search -> refinement -> reconstruction in k parts of whole CTU rows, parts refined / reconstructed on a side
+    stream while the next one is searched (stage objects' part() views).  Every stage output and the filtered planes equal the picture
+    processed in one piece, over a closed loop of three frames."""
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(256, 320, 4, depth=depth, seed=64)
+    pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
+    kw = dict(rng=12, subme=3, level=2, qp=30 + 12 * (depth == 10), want_surf=True, packed=packed, lookahead=(256, 320), deblock=True, sao=True,
+              chroma=True, sao_apply=True, sign_hide=True, subpel_planes=True, parallel_planes=True)
+    whole = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, **kw)
+    parts = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, split=split, **kw)
+    refs = [pics[0].like([p.clone() for p in pics[0].planes()]) for _ in range(2)]
+    for k in (1, 2, 3):
+        for fp, ref in ((whole, refs[0]), (parts, refs[1])):
+            fp.run(pics[k], ref)
+            torch.cuda.synchronize()
+        assert parts.parts is not None and len(parts.parts) == split
+        for name in ("best", "surf"):
+            assert torch.equal(getattr(whole.ms, name), getattr(parts.ms, name)), f"frame {k}: search {name} differs"
+        assert torch.equal(whole.sp.out, parts.sp.out), f"frame {k}: refined vectors differ"
+        for a, b in [(whole.rc, parts.rc)] + list(zip(whole.rc_c, parts.rc_c)):
+            assert torch.equal(a.levels, b.levels) and torch.equal(a.num_sig, b.num_sig) and torch.equal(a.dist, b.dist), f"frame {k}: TU stage outputs differ"
+        for i, (a, b) in enumerate(zip(whole.final_planes(), parts.final_planes())):
+            assert torch.equal(a, b), f"frame {k}: filtered plane {i} differs"
+        for fp, ref in ((whole, refs[0]), (parts, refs[1])):
+            for d, s in zip(ref.planes(), fp.final_planes()):
+                d.copy_(s)

@@ -117,6 +117,21 @@ class MotionSearch:
         out += self.best.numel() * 8 if self.best is not None else 0
         return pix + out
 
+    def part(self, ctu_row0, ctu_rows):
+        """The same stage restricted to `ctu_rows` CTU rows from `ctu_row0`: a shallow copy whose outputs are the matching slices of this
+        object's tensors (both are CTU-major), to be run with DevicePicture.band_view(ctu_row0, ctu_rows) - every CTU's search is
+        independent of the others, so the parts together leave exactly what one whole-picture launch leaves."""
+        import copy
+        o = copy.copy(self)
+        cw = self.w64 // 64
+        c0, o.nctu, o.h64 = cw * ctu_row0, cw * ctu_rows, ctu_rows * 64
+        if self.best is not None:
+            o.best = self.best[c0 * PUS_PER_CTU:(c0 + o.nctu) * PUS_PER_CTU]
+        if self.surf is not None:
+            per = self.nc * self.ng * self.group_bytes // 4
+            o.surf = self.surf[c0 * per:(c0 + o.nctu) * per]
+        return o
+
     def reset(self):
         if self.best is not None:
             hipabi.me_best_reset(self.best)
@@ -181,6 +196,16 @@ class SubpelRefine:
         self.cost_q = torch.from_numpy(cq.view(np.int16)).to(device)
         self.out = torch.zeros(ms.nctu * PUS_PER_CTU * 2, dtype=torch.int32, device=device)
 
+    def part(self, ms_part, ctu_row0):
+        """This stage for the CTU rows of `ms_part` (MotionSearch.part): a shallow copy writing the matching slice of `out`.  The phase
+        planes stay the parent's: prepare() them there, run the part with prepared=True."""
+        import copy
+        o = copy.copy(self)
+        o.ms, o.parent = ms_part, self
+        c0 = (ms_part.w64 // 64) * ctu_row0
+        o.out = self.out[c0 * PUS_PER_CTU * 2:(c0 + ms_part.nctu) * PUS_PER_CTU * 2]
+        return o
+
     def prepare(self, ref: DevicePicture):
         """The reference picture's phase planes (needs only the reference: may run on another stream next to the integer search)."""
         import torch
@@ -195,7 +220,7 @@ class SubpelRefine:
         ms = self.ms
         if not prepared:
             self.prepare(ref)
-        planes = self.planes if self.use_planes else None
+        planes = getattr(self, "parent", self).planes if self.use_planes else None
         hipabi.subpel_refine(ms.depth, ms.w64, ms.h64, ms.range, self.subme, cur.t, cur.stride, ref.t, ref.stride,
                              ms.best, self.cost_q, self.qoff, self.out, fenc_off=cur.org, fref_off=ref.org, phase_planes=planes)
 

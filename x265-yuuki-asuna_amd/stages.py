@@ -26,6 +26,18 @@ class ReconParams(ctypes.Structure):
     ]
 
 
+def _tu_part(stage, ctu_row0, ctu_rows):
+    import copy
+    o = copy.copy(stage)
+    cw = stage.w64 // 64
+    c0, o.nctu, o.h64 = cw * ctu_row0, cw * ctu_rows, ctu_rows * 64
+    nb, nn = stage.nblk, stage.n * stage.n
+    o.levels = stage.levels[c0 * nb * nn:(c0 + o.nctu) * nb * nn]
+    o.num_sig = stage.num_sig[c0 * nb:(c0 + o.nctu) * nb]
+    o.dist = stage.dist[c0 * nb:(c0 + o.nctu) * nb]
+    return o
+
+
 class InterRecon:
     """Stage 3: for every NxN block (N = 8 << level) predict with the refined mv, transform / quantise the
     residual, reconstruct, measure SSE.  Outputs: recon plane, levels, num_sig, dist."""
@@ -39,6 +51,10 @@ class InterRecon:
         self.num_sig = torch.zeros(nctu * self.nblk, dtype=torch.int32, device=device)
         self.dist = torch.zeros(nctu * self.nblk, dtype=torch.int64, device=device)
         self.tables = None          # hipabi.tu_tables(...): scaling-list coefficients / denoiser tables of this block size, or None
+
+    def part(self, ctu_row0, ctu_rows):
+        """The stage for `ctu_rows` CTU rows from `ctu_row0` (outputs = the matching slices; see pipeline.MotionSearch.part)."""
+        return _tu_part(self, ctu_row0, ctu_rows)
 
     def algorithmic_bytes(self, bpp=1):
         """per block: source N^2 + reference patch (N+7)^2 + recon N^2 pixels, levels 2*N^2, 16 B of results"""
@@ -106,6 +122,9 @@ class InterReconChroma:
         self.num_sig = torch.zeros(nctu * self.nblk, dtype=torch.int32, device=device)
         self.dist = torch.zeros(nctu * self.nblk, dtype=torch.int64, device=device)
         self.tables = None
+
+    def part(self, ctu_row0, ctu_rows):
+        return _tu_part(self, ctu_row0, ctu_rows)
 
     def run(self, fenc, fref, recon, stride, org, mv, stream=None):
         es = 1 if self.depth == 8 else 2
@@ -463,7 +482,13 @@ class FramePipeline:
 
     def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False, lookahead=None,
                  search="full", deblock=False, sao=False, lookahead_cost_batch=0, chroma=False, sao_apply=False, sign_hide=False,
-                 subpel_planes=False, parallel_planes=False):
+                 subpel_planes=False, parallel_planes=False, split=1):
+        """split (with parallel_planes): the picture goes through search -> sub-pel refinement -> reconstruction in `split` parts of whole
+        CTU rows; while the search of part k + 1 runs on the caller's stream, part k is refined and reconstructed on a side stream.  No
+        CTU's result depends on another CTU before the loop filters, which still run on the whole picture: same outputs, and only the last
+        part's refinement + reconstruction stay behind the search on the critical path.  Measured at 4K 8-bit (profiles/r02_split.txt):
+        2.94 ms per picture with 2 parts against 2.29 ms in one piece - the record-per-lane search kernel wants every CU's LDS and both of
+        its workgroup slots, and workgroups of other kernels resident next to it cost it more than the overlap hides.  Off by default."""
         import torch
         from .pipeline import MotionSearch, SubpelRefine
         self.depth = depth
@@ -472,6 +497,8 @@ class FramePipeline:
         # only) next to the search; everything joins the caller's stream before run() returns
         self.parallel = bool(parallel_planes)
         self.pstreams = None
+        self.split = max(1, min(int(split), h64 // 64))
+        self.parts = None
         # the three planes' SAO passes as one launch per step: on by default where every launch is on one stream (0.144 vs 0.187 ms at 4K);
         # with the planes' chains on side streams the per-plane passes already overlap and fusing them costs 0.07 ms ("2" forces it there too)
         self.fuse_sao = os.environ.get("X265HIP_FUSE_SAO", "1") != "0"
@@ -626,8 +653,8 @@ class FramePipeline:
         import torch
         main = torch.cuda.current_stream()
         if self.pstreams is None:
-            self.pstreams = [torch.cuda.Stream() for _ in range(3)]
-        sCb, sCr, sLa = self.pstreams
+            self.pstreams = [torch.cuda.Stream() for _ in range(4)]
+        sCb, sCr, sLa = self.pstreams[:3]
         if self.recon is None:
             self.recon = torch.zeros_like(cur.t)
         if self.recon_c is None:
@@ -649,20 +676,23 @@ class FramePipeline:
                 self.sp.prepare(ref)
                 ev_pl = torch.cuda.Event(); ev_pl.record(sCb)
         self.ms.reset()
-        self.ms.search(cur, ref)
-        if overlap_prep:
-            main.wait_event(ev_pl)
-        self.sp.run(cur, ref, prepared=overlap_prep)
         mv = self.sp.out
-        ev_mv = torch.cuda.Event(); ev_mv.record(main)
-        # reconstruction: one plane per stream
-        self.rc.run(cur, ref, self.recon, mv)
-        ev_rec = []
-        for i, st in enumerate((sCb, sCr)):
-            st.wait_event(ev_mv)
-            with torch.cuda.stream(st):
-                self.rc_c[i].run(cur.c[i], ref.c[i], self.recon_c[i], cur.stride_c, cur.org_c, mv)
-                e = torch.cuda.Event(); e.record(st); ev_rec.append(e)
+        if self.split > 1:
+            ev_rec = self._search_to_recon_in_parts(cur, ref, main, sCb, sCr, start)
+        else:
+            self.ms.search(cur, ref)
+            if overlap_prep:
+                main.wait_event(ev_pl)
+            self.sp.run(cur, ref, prepared=overlap_prep)
+            ev_mv = torch.cuda.Event(); ev_mv.record(main)
+            # reconstruction: one plane per stream
+            self.rc.run(cur, ref, self.recon, mv)
+            ev_rec = []
+            for i, st in enumerate((sCb, sCr)):
+                st.wait_event(ev_mv)
+                with torch.cuda.stream(st):
+                    self.rc_c[i].run(cur.c[i], ref.c[i], self.recon_c[i], cur.stride_c, cur.org_c, mv)
+                    e = torch.cuda.Event(); e.record(st); ev_rec.append(e)
         # deblocking: boundary strengths + luma on the caller's stream; the chroma pass (both planes, one entry point) on Cb's stream
         self.db.run(self.recon, cur, mv, self.rc.num_sig)
         ev_bs = torch.cuda.Event(); ev_bs.record(main)
@@ -707,6 +737,45 @@ class FramePipeline:
             main.wait_event(e)
         self.final, self.final_c = self.out, self.out_c
         return self.final
+
+    def _search_to_recon_in_parts(self, cur, ref, main, sCb, sCr, start):
+        """Search on `main`, part after part; a part's sub-pel refinement + luma reconstruction follow on a fourth stream, its chroma
+        reconstructions on the Cb / Cr streams - except the last part's luma chain, which continues on `main` (the loop filters wait for it
+        there anyway).  Returns the events after which Cb / Cr are reconstructed; `main` has waited for every luma part."""
+        import torch
+        if self.parts is None:
+            rows = self.ms.h64 // 64
+            cuts = [rows * k // self.split for k in range(self.split + 1)]
+            self.parts = []
+            for r0, r1 in zip(cuts[:-1], cuts[1:]):
+                msp = self.ms.part(r0, r1 - r0)
+                self.parts.append((r0, r1 - r0, msp, self.sp.part(msp, r0), self.rc.part(r0, r1 - r0), [q.part(r0, r1 - r0) for q in self.rc_c]))
+        sY = self.pstreams[3]
+        sY.wait_event(start)
+        with torch.cuda.stream(sY):                       # the reference's phase planes: next to the first part's search
+            self.sp.prepare(ref)
+        last = len(self.parts) - 1
+        for k, (r0, n, msp, spp, rcp, rcc) in enumerate(self.parts):
+            c, r = cur.band_view(r0, n), ref.band_view(r0, n)
+            msp.search(c, r)
+            ev_me = torch.cuda.Event(); ev_me.record(main)
+            st = main if k == last else sY
+            if k == last:
+                main.wait_stream(sY)                      # the phase planes (and the earlier parts' luma chains)
+            else:
+                sY.wait_event(ev_me)
+            with torch.cuda.stream(st):
+                spp.run(c, r, prepared=True)
+                ev_mv = torch.cuda.Event(); ev_mv.record(st)
+                rcp.run(c, r, self.recon, spp.out)
+            for i, sc in enumerate((sCb, sCr)):
+                sc.wait_event(ev_mv)
+                with torch.cuda.stream(sc):
+                    rcc[i].run(cur.c[i], ref.c[i], self.recon_c[i], cur.stride_c, c.org_c, spp.out)
+        ev_rec = []
+        for sc in (sCb, sCr):
+            e = torch.cuda.Event(); e.record(sc); ev_rec.append(e)
+        return ev_rec
 
     def final_planes(self):
         """[luma, cb, cr] of the picture the last run() produced for the next frame's reference list."""
