@@ -610,9 +610,8 @@ class FramePipeline:
                 self.out_c = [torch.zeros_like(p) for p in cur.c]
             hipabi.sao_planes(self.depth, [self.sao.plane(cur.t, cur.stride, cur.org, self.recon, cur.stride, cur.org, self.out)] +
                               [self.sao_c[i].plane(cur.c[i], cur.stride_c, cur.org_c, self.recon_c[i], cur.stride_c, cur.org_c, self.out_c[i]) for i in range(2)])
-            mark("sao_stats")
             final, final_c = self.out, self.out_c
-            mark("sao_apply")
+            mark("sao")                      # statistics + parameters + application of the three planes: three launches
         elif self.sao is not None:
             self.sao.stats(cur, self.recon, cur.stride, cur.org)
             if self.chroma:
