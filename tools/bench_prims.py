@@ -168,6 +168,24 @@ def main():
             report(cpu, f"{name} {w}x{w}", n, t, 2 * w * w + 8, path, SIG_PIXELCMP, [(fenc_h, 64), (ref_h, st)],
                    jobs_np(n, (aoff, boff)), "random positions: each row of a block is its own DRAM sector" if w == 8 and name == "sad" else "")
 
+    # the same kernels on jobs in PICTURE ORDER (the block grid of a plane, candidates within +-8 samples of the block's own position - what a
+    # refinement pass over a picture issues): neighbouring jobs share DRAM lines, so the fetched bytes approach the algorithmic ones
+    if on("compare"):
+        src_h = rng.integers(0, 256, size=st * (Hh + 160), dtype=np.uint8)
+        src_d = to_dev(src_h, dev)
+        for kind, name in ((A.CMP_SAD, "sad"), (A.CMP_SATD, "satd")):
+            for w in (8, 16):
+                bw, bh = (W - 192) // w, (Hh - 160) // w
+                by, bx = np.divmod(np.arange(bw * bh, dtype=np.int64), bw)
+                n = bw * bh
+                aoff = (80 + by * w) * st + 96 + bx * w
+                boff = aoff + rng.integers(-8, 9, size=n) * st + rng.integers(-8, 9, size=n)
+                ao, bo = to_dev(aoff, dev), to_dev(boff, dev)
+                out = torch.zeros(n, dtype=torch.int64, device=dev)
+                t = timeit(lambda: A.pixelcmp_batch(kind, 8, w, w, src_d, st, ref_d, st, n, out, a_off=ao, b_off=bo))
+                report(cpu, f"{name} {w}x{w} picture order", n, t, 2 * w * w + 8, f"pu[{pu_index(w, w)}].{name}", SIG_PIXELCMP, [(src_h, st), (ref_h, st)],
+                       jobs_np(n, (aoff, boff)), "block grid of a 4K plane, candidates within +-8 samples")
+
     # ---- a11: interpolation ----
     def interp_case(kind, kname, slot, sig, w, taps, dst_dtype, src_short=False, bpj=None):
         n = 1 << 16 if w <= 16 else 1 << 14
