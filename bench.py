@@ -235,9 +235,10 @@ def load_traffic(width, height, rng_r, fmt):
         return None, None
 
 
-# One MI355X, 3840x2160 8-bit, three band streams (profiles/r02_band_size.txt): milliseconds per picture against the CTU rows per band.
+# One MI355X, 3840x2160 8-bit, three band streams (profiles/r02_band_size.txt; bands of 5 rows and more with the record-per-lane search
+# kernel): milliseconds per picture against the CTU rows per band.
 # Small bands cost launches whose grids no longer fill the chip; large bands make the next rank wait longer for its first reference rows.
-BANDED_STEP_MS = {1: 5.11, 2: 3.50, 3: 3.16, 4: 2.83, 6: 2.79, 8: 2.70, 12: 2.58, 17: 2.45}
+BANDED_STEP_MS = {1: 5.11, 2: 3.50, 3: 3.16, 4: 2.83, 5: 2.83, 6: 2.58, 8: 2.68, 12: 2.45, 17: 2.42}
 
 
 def pick_band_rows(world, ctu_rows=34, lag_rows_luma=73):
@@ -374,9 +375,11 @@ def main():
         # N > 1: the reference's real frame-parallel dependency - frame f (rank f % N) searches frame f - 1, band by band (pipeline.FrameParallelRing)
         bp = S.BandedFramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, band_rows=args.band_rows, rng=args.range, subme=args.subme, level=args.level,
                                    qp=args.qp, want_surf=not args.no_surface,
-                                   # a band's grid (4 CTU rows = 240 workgroups) is too small for the record-per-lane kernel's 4-wavefront
-                                   # workgroups (one per CU): bands use the record-contiguous packed format of the row-walking kernel
-                                   packed=(args.surf_format != "i32" and args.depth == 8),
+                                   # a small band's grid (4 CTU rows = 240 workgroups) is too small for the record-per-lane kernel's 4-wavefront
+                                   # workgroups (one per CU): such bands use the record-contiguous packed format of the row-walking kernel;
+                                   # from 5 rows on the record-per-lane kernel wins (6 rows: 2.58 against 2.81 ms per picture)
+                                   packed=(args.surf_format != "i32" and args.depth == 8) and
+                                          ("t" if args.band_rows >= int(os.environ.get("X265HIP_BAND_T_ROWS", "5")) and args.surf_format == "packed_t" else True),
                                    lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True,
                                    graphs=bool(args.band_graphs), streams=args.band_streams)
         # (bands keep every launch on one stream: side streams for the chroma chains change nothing at band size - 3.93 vs 3.97 ms at 4 rows)
