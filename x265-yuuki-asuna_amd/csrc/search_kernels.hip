@@ -7,7 +7,7 @@
 // raster refinement whose fourth candidate is priced with mvcost(tmv << 3), :1196) and FULL :1397-1445; predictor-vs-search
 // choice :1452-1458; zero-residual shortcut :1464-1469; sub-pel refinement :1508-1561 over subpelCompare :1571-1613
 // (luma_hpp / luma_vpp / luma_hvpp + sad / satd); UMH :946-1130.  mv costs come from the caller's table, indexed by the quarter-pel
-// difference to the predictor (bitcost.h:45).  SEA is not implemented (the entry point rejects it).
+// difference to the predictor (bitcost.h:45).  X265_SEA (:1241-1395) is sea_search() below, on the block-sum planes of x265hip_sea_integral.
 //
 // Mapping: a lane GROUP per PU - a DPP quad (4 lanes) for PUs of up to 8 tiles of 4x4 (8x8, 8x4, 16x8 ...), a 16-lane row up
 // to 32 tiles (16x16 ... 32x16), the whole wavefront above (32x32 ... 64x64: 4 tiles per lane).  The source tiles stay packed
