@@ -31,9 +31,9 @@ def _clip(F, P, dev, depth, nframes):
     return [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
 
 
-def _pipeline(S, pics, depth, dev, streams):
+def _pipeline(S, pics, depth, dev, streams, tiled=False):
     return S.BandedFramePipeline(pics[0].w64, pics[0].h64, depth, dev, band_rows=2, rng=R, subme=SUBME, level=LEVEL, qp=QP + 12 * (depth == 10),
-                                 want_surf=True, packed=(depth == 8), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True,
+                                 want_surf=True, packed=("t" if tiled else True) if depth == 8 else False, deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True,
                                  lookahead=(W, HH), streams=streams)
 
 
@@ -46,7 +46,7 @@ def _digest(planes):
     return h.hexdigest()
 
 
-def _worker(rank, world, port, depth, out):
+def _worker(rank, world, port, depth, tiled, out):
     import torch
     import torch.distributed as dist
     F, P, S, dev = _setup(depth, 3)
@@ -55,7 +55,7 @@ def _worker(rank, world, port, depth, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     total = STEPS * world
     pics = _clip(F, P, dev, depth, total)
-    bp = _pipeline(S, pics, depth, dev, 3)
+    bp = _pipeline(S, pics, depth, dev, 3, tiled)
     ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=R + 16, stage_through_host=True)
     ring.make_groups()
     geom = (pics[0].stride, F.MARGIN_Y, pics[0].stride_c, F.CHROMA_MARGIN_Y)
@@ -77,8 +77,9 @@ def _worker(rank, world, port, depth, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("depth,world", [(8, 2), (8, 3), (10, 2)])
-def test_ring_on_a_shared_device_equals_one_process(depth, world):
+@pytest.mark.parametrize("depth,world,tiled", [(8, 2, False), (8, 3, False), (10, 2, False), (8, 2, True)])
+def test_ring_on_a_shared_device_equals_one_process(depth, world, tiled):
+    """tiled: the ranks search with the record-per-lane kernel (chunk-major surfaces), the one-process encode with the row-walking one."""
     import torch
     import torch.multiprocessing as mp
     F, P, S, dev = _setup(depth, 1)
@@ -96,7 +97,7 @@ def test_ring_on_a_shared_device_equals_one_process(depth, world):
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29600 + (os.getpid() % 300)
-    mp.spawn(_worker, args=(world, port, depth, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, depth, tiled, out), nprocs=world, join=True)
     got = {}
     for r in range(world):
         assert sorted(out[r]) == [s * world + r for s in range(STEPS)]
