@@ -503,6 +503,9 @@ class FramePipeline:
         # with the planes' chains on side streams the per-plane passes already overlap and fusing them costs 0.07 ms ("2" forces it there too)
         self.fuse_sao = os.environ.get("X265HIP_FUSE_SAO", "1") != "0"
         self.fuse_sao_parallel = os.environ.get("X265HIP_FUSE_SAO", "1") == "2"
+        # experiment switches of the parallel-planes launch structure (read once): where the lookahead and the phase planes run
+        self.la_after_search = os.environ.get("X265HIP_LA_AFTER_ME", "1") == "1"
+        self.prep_next_to_search = os.environ.get("X265HIP_PREP_OVERLAP", "0") == "1"
         self.ms = MotionSearch(w64, h64, rng, depth, device, want_surf=want_surf and search == "full", want_best=True, packed=packed)
         # subpel_planes: sub-pel candidates read from the reference picture's phase planes (one x265hip_phase_planes launch per frame)
         self.sp = SubpelRefine(self.ms, subme, device, phase_planes=subpel_planes)
@@ -665,14 +668,14 @@ class FramePipeline:
         # The lookahead of the source picture only depends on the source, but it does not run next to the search: the record-per-lane search
         # kernel loses more to any co-resident kernel than that kernel takes (see split below); next to the latency-bound stages behind the
         # search it is free - 2.20 against 2.25 ms per 4K picture (X265HIP_LA_AFTER_ME=0: the old placement)
-        la_after_me = self.la is not None and self.split == 1 and os.environ.get("X265HIP_LA_AFTER_ME", "1") == "1"
+        la_after_me = self.la is not None and self.split == 1 and self.la_after_search
         if self.la is not None and not la_after_me:
             sLa.wait_event(start)
             with torch.cuda.stream(sLa):
                 self.la.run(cur)
         # the reference's phase planes need only the reference and could run next to the search (X265HIP_PREP_OVERLAP=1), but their 141 MB
         # of plane writes compete with the search's record stream: measured 2.34 ms per step against 2.30 with the planes after the search
-        overlap_prep = os.environ.get("X265HIP_PREP_OVERLAP", "0") == "1"
+        overlap_prep = self.prep_next_to_search
         if overlap_prep:
             sCb.wait_event(start)
             with torch.cuda.stream(sCb):
