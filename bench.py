@@ -238,7 +238,7 @@ def load_traffic(width, height, rng_r, fmt):
 # One MI355X, 3840x2160 8-bit, three band streams (profiles/r02_band_size.txt; bands of 5 rows and more with the record-per-lane search
 # kernel): milliseconds per picture against the CTU rows per band.
 # Small bands cost launches whose grids no longer fill the chip; large bands make the next rank wait longer for its first reference rows.
-BANDED_STEP_MS = {1: 5.11, 2: 3.50, 3: 3.16, 4: 2.83, 5: 2.83, 6: 2.58, 8: 2.68, 12: 2.45, 17: 2.42}
+BANDED_STEP_MS = {1: 5.11, 2: 3.37, 3: 3.16, 4: 2.78, 5: 2.83, 6: 2.58, 8: 2.68, 12: 2.45, 17: 2.42}
 
 
 def pick_band_rows(world, ctu_rows=34, lag_rows_luma=73):

@@ -205,6 +205,9 @@ int x265hip_inter_recon(const x265hip_recon_params* p, void* stream);
  * strides, width / height = LUMA size, mv = the luma stage's records, qp = the plane's quantiser QP (chroma QP mapping and PPS /
  * slice offsets applied by the caller, + QP_BD_OFFSET); levels hold (n/2)^2 entries per block. */
 int x265hip_inter_recon_chroma(const x265hip_recon_params* p, void* stream);
+/* Cb and Cr of one picture in ONE launch: same geometry, bit depth, block size and use of `tables`; each record carries its own planes,
+ * QP and outputs.  Results are those of two x265hip_inter_recon_chroma calls. */
+int x265hip_inter_recon_chroma_pair(const x265hip_recon_params* cb, const x265hip_recon_params* cr, void* stream);
 /* Bi-predictive flavour (B pictures, luma): Predict::motionCompensation without weighted prediction (predict.cpp:168-243).  base =
  * the uni-directional parameters with fref / mv = list 0 (both references share fref_stride); dir = uint8 [ctu][blocks]: 1 = list 0
  * only, 2 = list 1 only, 3 = predInterLumaShort of both lists combined by addAvg; NULL = all 3. */

@@ -159,3 +159,12 @@ def test_sao_planes_validates_before_touching_a_device():
         st[i].depth, st[i].fenc, st[i].fenc_stride, st[i].rec, st[i].rec_stride = 8 + 2 * i, 4096, 256, 8192, 256
         st[i].width, st[i].height, st[i].count, st[i].offset_org = 128, 64, 12288, 16384
     assert f(2, ctypes.cast(st, ctypes.c_void_p), None, None) == -2          # 8-bit and 10-bit planes in one call
+
+
+def test_chroma_pair_validates_before_touching_a_device():
+    """x265hip_inter_recon_chroma_pair needs two complete records of one geometry (checked after the device: only the NULL case here)."""
+    import ctypes
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    f = A.lib().x265hip_inter_recon_chroma_pair
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    assert f(None, None, None) == -2

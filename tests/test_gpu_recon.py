@@ -268,3 +268,30 @@ def test_inter_recon_with_scaling_lists_and_denoiser(depth, level, qp, lists, nr
     assert np.array_equal(out.cpu().numpy().view(cur.host.dtype), erec.reshape(-1))
     if nr:
         assert np.array_equal(d_sum.cpu().numpy().view(np.uint32), osum)
+
+
+@pytest.mark.parametrize("depth,level,qp", [(8, 2, 24), (8, 0, 20), (10, 2, 36), (10, 1, 30)])
+def test_inter_recon_chroma_pair_equals_two_single_plane_calls(depth, level, qp):
+    """x265hip_inter_recon_chroma_pair: Cb and Cr in ONE launch, each plane with its own QP / flags / outputs, against the single-plane
+    entry the test above pins on the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(256, 192, 2, depth=depth, seed=66 + level)
+    cur, ref = P.DevicePicture(clip[1][0], dev, clip[1][1], clip[1][2]), P.DevicePicture(clip[0][0], dev, clip[0][1], clip[0][2])
+    ms = P.MotionSearch(cur.w64, cur.h64, 8, depth, dev, want_surf=False)
+    ms.run(cur, ref)
+    sp = P.SubpelRefine(ms, 3, dev)
+    sp.run(cur, ref)
+    single = [S.InterReconChroma(ms.nctu, cur.w64, cur.h64, depth, level, qp - 2 * i, dev, intra_slice=2 * i) for i in range(2)]
+    pair = [S.InterReconChroma(ms.nctu, cur.w64, cur.h64, depth, level, qp - 2 * i, dev, intra_slice=2 * i) for i in range(2)]
+    rec_single = [torch.zeros_like(cur.c[0]) for _ in range(2)]
+    rec_pair = [torch.zeros_like(cur.c[0]) for _ in range(2)]
+    for i in range(2):
+        single[i].run(cur.c[i], ref.c[i], rec_single[i], cur.stride_c, cur.org_c, sp.out)
+    S.InterReconChroma.run_pair(pair, cur.c, ref.c, rec_pair, cur.stride_c, cur.org_c, sp.out)
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(rec_single[i], rec_pair[i]), f"plane {i}: reconstruction differs"
+        assert torch.equal(single[i].levels, pair[i].levels) and torch.equal(single[i].num_sig, pair[i].num_sig) and torch.equal(single[i].dist, pair[i].dist), f"plane {i}"
+        assert int(pair[i].num_sig.sum()) > 0
+    assert not torch.equal(pair[0].levels, pair[1].levels)

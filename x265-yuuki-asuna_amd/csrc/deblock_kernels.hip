@@ -184,10 +184,10 @@ __global__ void __launch_bounds__(256) deblock_luma_kernel(DbArgs a)
 // a thread per 4-line chroma unit of an edge on the 8-sample chroma grid (luma multiples of 16); only Bs 2 units are filtered.
 struct DbChromaArgs
 {
-    uint8_t* plane; long strideB;
+    uint8_t* plane[2]; long strideB;           // Cb, Cr: one launch per direction filters both (grid.y = plane)
     int width, height, depth;                  // LUMA size
     const uint8_t* bs; const int8_t* qpMap;
-    int qp, qpOffset, tcOffset;
+    int qp, qpOffset[2], tcOffset;
 };
 
 __constant__ uint8_t kDbChromaScale[70] = {
@@ -209,12 +209,12 @@ __global__ void __launch_bounds__(256) deblock_chroma_kernel(DbChromaArgs a)
     if (a.qpMap)
         qp = DIR == 0 ? (a.qpMap[cu * w8 + 2 * e - 1] + a.qpMap[cu * w8 + 2 * e] + 1) >> 1
                       : (a.qpMap[(2 * e - 1) * w8 + cu] + a.qpMap[(2 * e) * w8 + cu] + 1) >> 1;
-    qp += a.qpOffset;
+    qp += a.qpOffset[blockIdx.y];
     if (qp >= 30) qp = kDbChromaScale[qp];
     const int tc = (int)kDbTc[clip3(0, 53, qp + 2 + a.tcOffset)] << (a.depth - 8);
     const int maxVal = (1 << a.depth) - 1;
     const long st = a.strideB / (long)sizeof(Px);
-    Px* src = reinterpret_cast<Px*>(a.plane) + (DIR == 0 ? (long)(4 * cu) * st + 8 * e : (long)(8 * e) * st + 4 * cu);
+    Px* src = reinterpret_cast<Px*>(a.plane[blockIdx.y]) + (DIR == 0 ? (long)(4 * cu) * st + 8 * e : (long)(8 * e) * st + 4 * cu);
     const long offset = DIR == 0 ? 1 : st, srcStep = DIR == 0 ? st : 1;
 #pragma unroll
     for (int l = 0; l < 4; l++)
@@ -294,18 +294,17 @@ extern "C" int x265hip_deblock_chroma(const x265hip_deblock_chroma_params* p, vo
     a.width = p->width; a.height = p->height; a.depth = p->depth;
     a.qpMap = p->qp_map; a.qp = p->qp; a.tcOffset = p->tc_offset_div2 * 2;
     const int nv = (p->width >> 4) * (p->height >> 3), nh = (p->height >> 4) * (p->width >> 3);
+    a.plane[0] = (uint8_t*)p->cb; a.plane[1] = (uint8_t*)p->cr;
+    a.qpOffset[0] = p->cb_qp_offset; a.qpOffset[1] = p->cr_qp_offset;
     for (int dir = 0; dir < 2; dir++)
-        for (int c = 0; c < 2; c++)
-        {
-            a.plane = (uint8_t*)(c ? p->cr : p->cb);
-            a.qpOffset = c ? p->cr_qp_offset : p->cb_qp_offset;
-            a.bs = dir ? p->bs_hor : p->bs_ver;
-            const int n = dir ? nh : nv;
-            if (bpp == 1 && dir == 0) hipLaunchKernelGGL((deblock_chroma_kernel<uint8_t, 0>), dim3((n + 255) / 256), dim3(256), 0, s, a);
-            else if (bpp == 1) hipLaunchKernelGGL((deblock_chroma_kernel<uint8_t, 1>), dim3((n + 255) / 256), dim3(256), 0, s, a);
-            else if (dir == 0) hipLaunchKernelGGL((deblock_chroma_kernel<uint16_t, 0>), dim3((n + 255) / 256), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((deblock_chroma_kernel<uint16_t, 1>), dim3((n + 255) / 256), dim3(256), 0, s, a);
-        }
+    {
+        a.bs = dir ? p->bs_hor : p->bs_ver;
+        const dim3 grid(((dir ? nh : nv) + 255) / 256, 2);
+        if (bpp == 1 && dir == 0) hipLaunchKernelGGL((deblock_chroma_kernel<uint8_t, 0>), grid, dim3(256), 0, s, a);
+        else if (bpp == 1) hipLaunchKernelGGL((deblock_chroma_kernel<uint8_t, 1>), grid, dim3(256), 0, s, a);
+        else if (dir == 0) hipLaunchKernelGGL((deblock_chroma_kernel<uint16_t, 0>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((deblock_chroma_kernel<uint16_t, 1>), grid, dim3(256), 0, s, a);
+    }
     X265HIP_TRY(hipGetLastError());
     return 0;
 }

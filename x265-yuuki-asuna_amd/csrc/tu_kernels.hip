@@ -74,6 +74,8 @@ struct TuArgs
     TuTables tab;
 };
 
+struct TuArgs2 { TuArgs p[2]; };
+
 __device__ __forceinline__ int tu_clip16(int v, int maxVal) { const int16_t s = (int16_t)v; return s < 0 ? 0 : (s > maxVal ? maxVal : s); }
 __device__ __forceinline__ int tu_sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 
@@ -440,8 +442,9 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
 // CHROMA: one chroma plane of a 4:2:0 picture - N is the chroma block size (half the luma block), the mv counts 1/8 samples and
 // the filters are the 4-tap chroma set (Predict::predInterChromaPixel, predict.cpp:304-351)
 template <typename Px, int N, bool CHROMA, bool TAB = false>
-__global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs a, int nblocks)
+__global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs2 aa, int nblocks)
 {
+    const TuArgs& a = aa.p[blockIdx.y];          // grid.y = plane: Cb and Cr of a picture (or of a band of it) share one launch
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
     constexpr int TAPS = CHROMA ? 4 : 8, APRON = TAPS / 2 - 1, PW = N + TAPS - 1, PP = PW + 1;
     constexpr int NL = CHROMA ? 2 * N : N, CTU = CHROMA ? 32 : 64, MVSH = CHROMA ? 3 : 2, MVMASK = CHROMA ? 7 : 3;
@@ -760,6 +763,8 @@ extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
     a.mv = (const int2*)p->mv; a.qp = p->qp; a.intraSlice = p->intra_slice;
     a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
     a.tab = tu_tables_of(TABLES_OF(p));
+    TuArgs2 aa = {};
+    aa.p[0] = a;
     const int nctu = a.ctusW * (p->height / 64);
     const int npu = 64 >> (2 * p->level);
     hipStream_t s = (hipStream_t)stream;
@@ -774,9 +779,9 @@ extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
         return (int)(nblocks < r ? nblocks : r);
     };
 #define GO_T(PX, TB) do { \
-        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 8, false, TB>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
-        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 16, false, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 16, false, TB>)), dim3(64), 0, s, a, nblocks); \
-        else hipLaunchKernelGGL((inter_recon_kernel<PX, 32, false, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 32, false, TB>)), dim3(64), 0, s, a, nblocks); } while (0)
+        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 8, false, TB>), dim3(nblocks), dim3(64), 0, s, aa, nblocks); \
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 16, false, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 16, false, TB>)), dim3(64), 0, s, aa, nblocks); \
+        else hipLaunchKernelGGL((inter_recon_kernel<PX, 32, false, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 32, false, TB>)), dim3(64), 0, s, aa, nblocks); } while (0)
 #define GO(PX) do { if (p->tables) GO_T(PX, true); else GO_T(PX, false); } while (0)
     if (p->depth == 8) GO(uint8_t); else GO(uint16_t);
 #undef GO_T
@@ -831,26 +836,35 @@ extern "C" int x265hip_inter_recon_bi(const x265hip_recon_bi_params* q, void* st
     return 0;
 }
 
-extern "C" int x265hip_inter_recon_chroma(const x265hip_recon_params* p, void* stream)
+// One or both chroma planes of a picture: the same kernel, grid.y = plane.
+static int inter_recon_chroma_planes(const x265hip_recon_params* const* pp, int nplanes, void* stream)
 {
     int rc = ensure_device();
     if (rc) return rc;
-    if (!p || !p->fenc || !p->fref || !p->recon || !p->mv || !p->levels || !p->num_sig || !p->dist)
-    { set_error("inter_recon_chroma: NULL operand"); return X265HIP_EINVAL; }
-    if ((p->width & 63) || (p->height & 63) || p->width <= 0 || p->height <= 0) { set_error("inter_recon_chroma: width/height (luma) must be multiples of 64"); return X265HIP_EINVAL; }
-    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("inter_recon_chroma: depth %d", p->depth); return X265HIP_EINVAL; }
-    if (p->level < 0 || p->level > 2) { set_error("inter_recon_chroma: level %d (0..2 = 8x8, 16x16, 32x32 luma blocks)", p->level); return X265HIP_EINVAL; }
-    if (p->qp < 0 || p->qp > 51 + 6 * (p->depth - 8)) { set_error("inter_recon_chroma: qp %d out of range", p->qp); return X265HIP_EINVAL; }
-    const int bpp = p->depth == 8 ? 1 : 2;
-    TuArgs a;
-    a.fenc = (const uint8_t*)p->fenc; a.fencStrideB = (long)p->fenc_stride * bpp;
-    a.fref = (const uint8_t*)p->fref; a.frefStrideB = (long)p->fref_stride * bpp;
-    a.recon = (uint8_t*)p->recon; a.reconStrideB = (long)p->recon_stride * bpp;
-    a.ctusW = p->width / 64; a.depth = p->depth; a.level = p->level;
-    a.mv = (const int2*)p->mv; a.qp = p->qp; a.intraSlice = p->intra_slice;
-    a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
-    a.tab = tu_tables_of(TABLES_OF(p));
-    const int nctu = a.ctusW * (p->height / 64);
+    TuArgs2 aa = {};
+    const x265hip_recon_params* p = pp[0];
+    for (int i = 0; i < nplanes; i++)
+    {
+        const x265hip_recon_params* q = pp[i];
+        if (!q || !q->fenc || !q->fref || !q->recon || !q->mv || !q->levels || !q->num_sig || !q->dist)
+        { set_error("inter_recon_chroma: NULL operand"); return X265HIP_EINVAL; }
+        if ((q->width & 63) || (q->height & 63) || q->width <= 0 || q->height <= 0) { set_error("inter_recon_chroma: width/height (luma) must be multiples of 64"); return X265HIP_EINVAL; }
+        if (q->depth != 8 && q->depth != 10 && q->depth != 12) { set_error("inter_recon_chroma: depth %d", q->depth); return X265HIP_EINVAL; }
+        if (q->level < 0 || q->level > 2) { set_error("inter_recon_chroma: level %d (0..2 = 8x8, 16x16, 32x32 luma blocks)", q->level); return X265HIP_EINVAL; }
+        if (q->qp < 0 || q->qp > 51 + 6 * (q->depth - 8)) { set_error("inter_recon_chroma: qp %d out of range", q->qp); return X265HIP_EINVAL; }
+        if (q->width != p->width || q->height != p->height || q->depth != p->depth || q->level != p->level || !q->tables != !p->tables)
+        { set_error("inter_recon_chroma: the two planes differ in geometry / depth / level / use of tables"); return X265HIP_EINVAL; }
+        const int bpp = q->depth == 8 ? 1 : 2;
+        TuArgs& a = aa.p[i];
+        a.fenc = (const uint8_t*)q->fenc; a.fencStrideB = (long)q->fenc_stride * bpp;
+        a.fref = (const uint8_t*)q->fref; a.frefStrideB = (long)q->fref_stride * bpp;
+        a.recon = (uint8_t*)q->recon; a.reconStrideB = (long)q->recon_stride * bpp;
+        a.ctusW = q->width / 64; a.depth = q->depth; a.level = q->level;
+        a.mv = (const int2*)q->mv; a.qp = q->qp; a.intraSlice = q->intra_slice;
+        a.levels = q->levels; a.numSig = q->num_sig; a.dist = (unsigned long long*)q->dist;
+        a.tab = tu_tables_of(TABLES_OF(q));
+    }
+    const int nctu = aa.p[0].ctusW * (p->height / 64);
     const int nblocks = nctu * (64 >> (2 * p->level));
     hipStream_t s = (hipStream_t)stream;
     auto resident = [&](const void* fn)
@@ -859,19 +873,33 @@ extern "C" int x265hip_inter_recon_chroma(const x265hip_recon_params* p, void* s
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, 64, 0) != hipSuccess || per < 1) per = 8;
-        const long r = (long)cus * per;
-        return (int)(nblocks < r ? nblocks : r);
+        const long r = (long)cus * per / nplanes;
+        return (int)(nblocks < r ? nblocks : (r < 1 ? 1 : r));
     };
 #define GOC_T(PX, TB) do { \
-        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 4, true, TB>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
-        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 8, true, TB>), dim3(nblocks), dim3(64), 0, s, a, nblocks); \
-        else hipLaunchKernelGGL((inter_recon_kernel<PX, 16, true, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 16, true, TB>)), dim3(64), 0, s, a, nblocks); } while (0)
+        if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 4, true, TB>), dim3(nblocks, nplanes), dim3(64), 0, s, aa, nblocks); \
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 8, true, TB>), dim3(nblocks, nplanes), dim3(64), 0, s, aa, nblocks); \
+        else hipLaunchKernelGGL((inter_recon_kernel<PX, 16, true, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 16, true, TB>), nplanes), dim3(64), 0, s, aa, nblocks); } while (0)
 #define GOC(PX) do { if (p->tables) GOC_T(PX, true); else GOC_T(PX, false); } while (0)
     if (p->depth == 8) GOC(uint8_t); else GOC(uint16_t);
 #undef GOC_T
 #undef GOC
     X265HIP_TRY(hipGetLastError());
     return 0;
+}
+
+extern "C" int x265hip_inter_recon_chroma(const x265hip_recon_params* p, void* stream)
+{
+    if (!p) { set_error("inter_recon_chroma: NULL operand"); return X265HIP_EINVAL; }
+    return inter_recon_chroma_planes(&p, 1, stream);
+}
+
+/* Cb and Cr of one picture (same geometry, bit depth, block size; each with its own planes, QP and outputs) in ONE launch. */
+extern "C" int x265hip_inter_recon_chroma_pair(const x265hip_recon_params* cb, const x265hip_recon_params* cr, void* stream)
+{
+    if (!cb || !cr) { set_error("inter_recon_chroma_pair: NULL operand"); return X265HIP_EINVAL; }
+    const x265hip_recon_params* pp[2] = { cb, cr };
+    return inter_recon_chroma_planes(pp, 2, stream);
 }
 
 extern "C" int x265hip_intra_recon_batch(const x265hip_intra_recon_params* p, void* stream)

@@ -126,7 +126,7 @@ class InterReconChroma:
     def part(self, ctu_row0, ctu_rows):
         return _tu_part(self, ctu_row0, ctu_rows)
 
-    def run(self, fenc, fref, recon, stride, org, mv, stream=None):
+    def params(self, fenc, fref, recon, stride, org, mv):
         es = 1 if self.depth == 8 else 2
         p = ReconParams()
         p.depth, p.width, p.height, p.level, p.qp, p.intra_slice = self.depth, self.w64, self.h64, self.level, self.qp, self.intra
@@ -135,10 +135,23 @@ class InterReconChroma:
         p.recon, p.recon_stride = recon.data_ptr() + org * es, stride
         p.mv, p.levels, p.num_sig, p.dist = mv.data_ptr(), self.levels.data_ptr(), self.num_sig.data_ptr(), self.dist.data_ptr()
         p.tables = ctypes.addressof(self.tables) if self.tables is not None else None
+        return p
+
+    def run(self, fenc, fref, recon, stride, org, mv, stream=None):
+        p = self.params(fenc, fref, recon, stride, org, mv)
         s = hipabi.current_stream() if stream is None else stream
         f = hipabi.lib().x265hip_inter_recon_chroma
         f.argtypes = [ctypes.POINTER(ReconParams), ctypes.c_void_p]
         hipabi.check(f(ctypes.byref(p), s), "x265hip_inter_recon_chroma")
+
+    @staticmethod
+    def run_pair(stages, fencs, frefs, recons, stride, org, mv, stream=None):
+        """Cb and Cr (stages = the two planes' InterReconChroma objects) in one launch: x265hip_inter_recon_chroma_pair."""
+        ps = [st.params(fenc, fref, recon, stride, org, mv) for st, fenc, fref, recon in zip(stages, fencs, frefs, recons)]
+        s = hipabi.current_stream() if stream is None else stream
+        f = hipabi.lib().x265hip_inter_recon_chroma_pair
+        f.argtypes = [ctypes.POINTER(ReconParams), ctypes.POINTER(ReconParams), ctypes.c_void_p]
+        hipabi.check(f(ctypes.byref(ps[0]), ctypes.byref(ps[1]), s), "x265hip_inter_recon_chroma_pair")
 
 
 def extend_border_rows(plane, pic: DevicePicture, top: bool, bottom: bool, stream=None, chroma=False):
@@ -596,8 +609,11 @@ class FramePipeline:
         if self.chroma:
             if self.recon_c is None:
                 self.recon_c = [torch.zeros_like(p) for p in cur.c]
-            for i in range(2):
-                self.rc_c[i].run(cur.c[i], ref.c[i], self.recon_c[i], cur.stride_c, cur.org_c, mv)
+            if self.rc_c[0].tables is None and self.rc_c[1].tables is None:
+                InterReconChroma.run_pair(self.rc_c, cur.c, ref.c, self.recon_c, cur.stride_c, cur.org_c, mv)      # Cb + Cr: one launch
+            else:
+                for i in range(2):
+                    self.rc_c[i].run(cur.c[i], ref.c[i], self.recon_c[i], cur.stride_c, cur.org_c, mv)
             mark("recon_chroma")
         if self.db is not None:
             self.db.run(self.recon, cur, mv, self.rc.num_sig)
