@@ -2,7 +2,7 @@
 # Round-2 closing GPU visit (second): full parity suite, smoke, default bench line, rocprofv3 kernel stats of the same command
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r2y
+OUT=$ROOT/gpurun_out/r2w
 mkdir -p "$OUT"
 cd "$ROOT"
 ( time timeout 1700 python -m pytest tests -m gpu -q --durations=8 ) > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest.log"
