@@ -370,7 +370,7 @@ def main():
     fp = P.FrameParallel(rank, 1 if gop else world)          # gop: the hand-off is this rank's own copy
     banded = (world > 1 and not gop) or args.banded
     if banded and not args.band_rows:
-        args.band_rows = pick_band_rows(world) if world > 1 else 4
+        args.band_rows = pick_band_rows(world, ctu_rows=(args.height + 63) // 64, lag_rows_luma=args.range + 16) if world > 1 else 4
     if banded:
         # N > 1: the reference's real frame-parallel dependency - frame f (rank f % N) searches frame f - 1, band by band (pipeline.FrameParallelRing)
         bp = S.BandedFramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, band_rows=args.band_rows, rng=args.range, subme=args.subme, level=args.level,
