@@ -206,6 +206,42 @@ def aq_frame(depth, y, stride, org, width, height, cb=None, cr=None, stride_c=0,
     return energy, qp, inv, sm, ssd
 
 
+AQ_LAYER_DEPTH = {64: (1, 0, 1, 0), 32: (1, 1, 1, 0), 16: (1, 1, 1, 0), 8: (1, 1, 1, 1)}      # lowres.h:123-129, 64x64 CTUs, by qgSize
+
+
+def aq_hevc_quadrants(depth, y, stride, org, width, height, part, avx2=False):
+    """The integer half of LookaheadTLD::xPreanalyze: uint64 [partitions, 4 quadrants, (sum, sum of squares)]."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_aq_hevc_quadrants_d{depth}")
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t] + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    n = ((width + part - 1) // part) * ((height + part - 1) // part)
+    sums = np.zeros((n, 4, 2), np.uint64)
+    fn(y.ctypes.data + org * y.itemsize, stride, width, height, part, sums.ctypes.data)
+    return sums
+
+
+def aq_hevc_frame(depth, y, stride, org, width, height, cb=None, cr=None, stride_c=0, org_c=0, qg_size=16, qp_adaptation_range=1.0, weightp=True,
+                  avx2=False):
+    """CPU restatement of calcAdaptiveQuantFrame with rc.hevcAq (xPreanalyze / xPreanalyzeQp).  Returns (layer_parts int32 [4],
+    activity, qp_offset float64 [sum of the enabled layers' partitions], avg_activity float64 [4], inv_qscale int32 [deepest layer's
+    partitions], wp_sum, wp_ssd uint64 [3])."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_aq_hevc_frame_d{depth}")
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_ssize_t] * 2 + [ctypes.c_int] * 4 + [ctypes.c_double, ctypes.c_int] + [ctypes.c_void_p] * 7
+    total = sum(((width + (64 >> d) - 1) // (64 >> d)) * ((height + (64 >> d) - 1) // (64 >> d)) for d in range(4) if AQ_LAYER_DEPTH[qg_size][d])
+    parts, act, qp, avg = np.zeros(4, np.int32), np.zeros(total, np.float64), np.zeros(total, np.float64), np.zeros(4, np.float64)
+    inv = np.zeros(total, np.int32)
+    sm, ssd = np.zeros(3, np.uint64), np.zeros(3, np.uint64)
+    es = y.itemsize
+    fn(y.ctypes.data + org * es, None if cb is None else cb.ctypes.data + org_c * es, None if cr is None else cr.ctypes.data + org_c * es,
+       stride, stride_c, width, height, 64, qg_size, float(qp_adaptation_range), int(bool(weightp)),
+       parts.ctypes.data, act.ctypes.data, qp.ctypes.data, avg.ctypes.data, inv.ctypes.data, sm.ctypes.data, ssd.ctypes.data)
+    deepest = max(d for d in range(4) if parts[d])
+    return parts, act, qp, avg, inv[:parts[deepest]], sm, ssd
+
+
 def lowres_weight_cost(depth, fenc, ref, stride, org, width, lines, intra_cost, weight, avx2=False):
     """CPU restatement of LookaheadTLD::weightCostLuma: weight = None (unweighted) or (scale, denom, offset)."""
     L = lib(avx2)

@@ -379,6 +379,89 @@ int x265ref_aq_frame(const void* yPlane, const void* cb, const void* cr, int wid
 }
 
 
+/* The REAL calcAdaptiveQuantFrame with rc.hevcAq (LookaheadTLD::xPreanalyze / xPreanalyzeQp, slicetype.cpp:293-441) on one picture:
+ * planes as in x265ref_aq_frame.  Outputs: layerParts[4] (numAQPartInWidth * numAQPartInHeight of every enabled layer, 0 = off),
+ * the enabled layers' dActivity / dQpOffset one after the other, dAvgActivity[4], invQscaleFactor over the deepest layer's partitions,
+ * wp_sum / wp_ssd [3]. */
+int x265ref_aq_hevc_frame(const void* yPlane, const void* cb, const void* cr, int width, int height, int qgSize, double qpAdaptationRange,
+                          int weightp, int32_t* layerParts, double* activity, double* qpOffset, double* avgActivity, int32_t* invQscale,
+                          uint64_t* wpSum, uint64_t* wpSsd)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width;
+    param->sourceHeight = height;
+    param->internalCsp = cb ? X265_CSP_I420 : X265_CSP_I400;
+    param->maxCUSize = 64;
+    param->rc.aqMode = 2;
+    param->rc.aqStrength = 1.0;
+    param->rc.hevcAq = 1;
+    param->rc.qpAdaptationRange = qpAdaptationRange;
+    param->rc.qgSize = qgSize;
+    param->rc.cuTree = 0;
+    param->rc.bStatRead = 0;
+    param->bAQMotion = 0;
+    param->bEnableHME = 0;
+    param->bHDR10Opt = 0;
+    param->bDynamicRefine = 0;
+    param->bEnableFades = 0;
+    param->bEnableWeightedPred = weightp;
+    param->bEnableWeightedBiPred = 0;
+    PicYuv pic;
+    pic.m_param = param;
+    if (!pic.create(param, true)) return -1;
+    const int h64 = (height + 63) / 64 * 64;
+    memcpy(pic.m_picOrg[0] - pic.m_lumaMarginY * pic.m_stride - pic.m_lumaMarginX, yPlane,
+           sizeof(pixel) * pic.m_stride * (h64 + 2 * pic.m_lumaMarginY));
+    if (cb)
+    {
+        const void* cs[2] = { cb, cr };
+        for (int c = 0; c < 2; c++)
+            for (int y = 0; y < height / 2; y++)
+                memcpy(pic.m_picOrg[1 + c] + (intptr_t)y * pic.m_strideC, (const pixel*)cs[c] + (size_t)y * (width / 2), sizeof(pixel) * (width / 2));
+    }
+    int rc = 0;
+    {
+        Frame frame;
+        frame.m_param = param;
+        frame.m_fencPic = &pic;
+        frame.m_quantOffsets = NULL;
+        memset((void*)&frame.m_lowres, 0, sizeof(Lowres));
+        if (!frame.m_lowres.create(param, &pic, qgSize)) rc = -2;
+        else
+        {
+            LookaheadTLD tld;
+            tld.init(frame.m_lowres.maxBlocksInRow, frame.m_lowres.maxBlocksInCol, frame.m_lowres.maxBlocksInRow * frame.m_lowres.maxBlocksInCol);
+            tld.calcAdaptiveQuantFrame(&frame, param);
+            size_t at = 0;
+            int deepest = -1;
+            for (int d = 0; d < 4; d++)
+            {
+                layerParts[d] = 0; avgActivity[d] = 0;
+                if (!aqLayerDepth[0][6 - (qgSize == 64 ? 6 : qgSize == 32 ? 5 : qgSize == 16 ? 4 : 3)][d]) continue;
+                PicQPAdaptationLayer& L = frame.m_lowres.pAQLayer[d];
+                const int n = L.numAQPartInWidth * L.numAQPartInHeight;
+                memcpy(activity + at, L.dActivity, sizeof(double) * n);
+                memcpy(qpOffset + at, L.dQpOffset, sizeof(double) * n);
+                avgActivity[d] = L.dAvgActivity;
+                layerParts[d] = n; at += n; deepest = d;
+            }
+            if (deepest >= 0)
+                for (int i = 0; i < layerParts[deepest]; i++) invQscale[i] = frame.m_lowres.invQscaleFactor[i];
+            if ((int)frame.m_lowres.pAQLayer->minAQDepth != deepest) rc = -3;
+            for (int i = 0; i < 3; i++) { wpSum[i] = frame.m_lowres.wp_sum[i]; wpSsd[i] = frame.m_lowres.wp_ssd[i]; }
+            frame.m_lowres.destroy();
+        }
+        frame.m_fencPic = NULL;
+    }
+    pic.destroy();
+    x265_param_free(param);
+    return rc;
+}
+
+
 namespace { struct LookaheadProbe : public Lookahead
 {
     LookaheadProbe(x265_param* p, ThreadPool* t) : Lookahead(p, t) {}

@@ -330,6 +330,119 @@ void EXPORT(x265oracle_aq_frame)(const pixel* y, const pixel* cb, const pixel* c
     }
 }
 
+/* ================================================================ --hevc-aq: the adaptive-quantisation pass on quadrant variances
+ * LookaheadTLD::xPreanalyze + xPreanalyzeQp (slicetype.cpp:293-441), what calcAdaptiveQuantFrame runs instead of the AQ modes when
+ * rc.hevcAq is set (:507-511).  For every enabled layer d (aqLayerDepth[ctu size][log2 ctu - log2 qg][d], lowres.h:123-142; partitions of
+ * (maxCUSize >> d)^2 samples, clipped at the picture's right / bottom edge): sum and sum of squares of the partition's four quadrants
+ * - split at HALF THE CLIPPED size, every quadrant divided by (cw / 2) * (ch / 2) whatever it really holds (:339-389) -, activity =
+ * 1 + the smallest quadrant variance, the layer's average activity over ceil(w / P) * ceil(h / P) partitions, then per partition
+ * dQpOffset = log2((maxQScale * act + avg) / (act + maxQScale * avg)) * 6 with maxQScale = 2^(qpAdaptationRange / 6).  The deepest
+ * enabled layer feeds invQscaleFactor = x265_exp2fix8(dQpOffset), written SEQUENTIALLY in partition order (:432-441), and the same loop
+ * gathers the wp_sum / wp_ssd statistics through acEnergyCu.  qpAqOffset / qpCuTreeOffset are not written by this path.
+ * layerParts[d] receives the partition count of layer d (0: layer off); activity / qpOffset hold the enabled layers one after the other. */
+static const uint8_t kAqLayerDepth[3][4][4] = {
+    { { 1, 0, 1, 0 }, { 1, 1, 1, 0 }, { 1, 1, 1, 0 }, { 1, 1, 1, 1 } },      /* ctu 64: qg 64, 32, 16, 8 */
+    { { 1, 1, 0, 0 }, { 1, 1, 0, 0 }, { 1, 1, 1, 0 }, { 0, 0, 0, 0 } },      /* ctu 32 */
+    { { 1, 0, 0, 0 }, { 1, 1, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } } };    /* ctu 16 */
+
+void EXPORT(x265oracle_aq_hevc_quadrants)(const pixel* y, intptr_t stride, int width, int height, int part, uint64_t* sums)
+{
+    /* sums[partition][quadrant][0 = sum, 1 = sum of squares] - the integer half of xPreanalyze, what the device kernel produces */
+    for (int py = 0, i = 0; py < height; py += part)
+        for (int px = 0; px < width; px += part, i++)
+        {
+            const int cw = part < width - px ? part : width - px, ch = part < height - py ? part : height - py;
+            uint64_t* q = sums + (size_t)i * 8;
+            for (int k = 0; k < 8; k++) q[k] = 0;
+            for (int by = 0; by < ch; by++)
+                for (int bx = 0; bx < cw; bx++)
+                {
+                    const uint64_t v = y[(intptr_t)(py + by) * stride + px + bx];
+                    const int quad = (by >= (ch >> 1)) * 2 + (bx >= (cw >> 1));
+                    q[2 * quad] += v; q[2 * quad + 1] += v * v;
+                }
+        }
+}
+
+void EXPORT(x265oracle_aq_hevc_offsets)(int width, int height, int part, double qpAdaptationRange, const uint64_t* sums,
+                                        double* activity, double* qpOffset, double* avgActivity)
+{
+    const int pw = (width + part - 1) / part, ph = (height + part - 1) / part;
+    double dSumAct = 0.0;
+    for (int py = 0, i = 0; py < height; py += part)
+        for (int px = 0; px < width; px += part, i++)
+        {
+            const int cw = part < width - px ? part : width - px, ch = part < height - py ? part : height - py;
+            const uint32_t numPix = (uint32_t)(cw >> 1) * (uint32_t)(ch >> 1);
+            double dMinVar = 1.7976931348623158e+308;
+            if (numPix)
+                for (int k = 0; k < 4; k++)
+                {
+                    const double dAverage = (double)sums[(size_t)i * 8 + 2 * k] / numPix;
+                    const double dVariance = (double)sums[(size_t)i * 8 + 2 * k + 1] / numPix - dAverage * dAverage;
+                    dMinVar = dMinVar < dVariance ? dMinVar : dVariance;
+                }
+            else
+                dMinVar = 0.0;
+            activity[i] = 1.0 + dMinVar;
+            dSumAct += activity[i];
+        }
+    const double dAvgAct = dSumAct / ((double)pw * ph == 0 ? 1 : (uint32_t)(pw * ph));
+    *avgActivity = dAvgAct;
+    for (int i = 0; i < pw * ph; i++)
+    {
+        const double dMaxQScale = pow(2.0, qpAdaptationRange / 6.0);
+        const double dNormAct = (dMaxQScale * activity[i] + dAvgAct) / (activity[i] + dMaxQScale * dAvgAct);
+        qpOffset[i] = (log2(dNormAct) / log2(2.0)) * 6.0;
+    }
+}
+
+void EXPORT(x265oracle_aq_hevc_frame)(const pixel* y, const pixel* cb, const pixel* cr, intptr_t stride, intptr_t strideC, int width, int height,
+                                      int maxCUSize, int qgSize, double qpAdaptationRange, int weightp,
+                                      int32_t* layerParts, double* activity, double* qpOffset, double* avgActivity, int32_t* invQscale,
+                                      uint64_t* wpSum, uint64_t* wpSsd)
+{
+    int lc = 0, lq = 0;
+    while ((1 << lc) < maxCUSize) lc++;
+    while ((1 << lq) < qgSize) lq++;
+    const int ctuIdx = 6 - lc, aqDepth = lc - lq;
+    size_t at = 0, deepestAt = 0;
+    int deepest = -1;
+    for (int i = 0; i < 3; i++) wpSum[i] = wpSsd[i] = 0;
+    for (int d = 0; d < 4; d++)
+    {
+        layerParts[d] = 0; avgActivity[d] = 0;
+        if (ctuIdx < 0 || ctuIdx > 2 || aqDepth < 0 || aqDepth > 3 || !kAqLayerDepth[ctuIdx][aqDepth][d]) continue;
+        const int part = maxCUSize >> d, n = ((width + part - 1) / part) * ((height + part - 1) / part);
+        uint64_t* sums = (uint64_t*)malloc(sizeof(uint64_t) * 8 * (size_t)n);
+        EXPORT(x265oracle_aq_hevc_quadrants)(y, stride, width, height, part, sums);
+        EXPORT(x265oracle_aq_hevc_offsets)(width, height, part, qpAdaptationRange, sums, activity + at, qpOffset + at, &avgActivity[d]);
+        free(sums);
+        layerParts[d] = n; deepest = d; deepestAt = at; at += (size_t)n;
+    }
+    if (deepest < 0) return;
+    const int part = maxCUSize >> deepest, lshift = qgSize == 8 ? 6 : 8, cshift = qgSize == 8 ? 4 : 6, inc = qgSize == 8 ? 8 : 16;
+    for (int py = 0, i = 0; py < height; py += part)
+        for (int px = 0; px < width; px += part, i++)
+        {
+            invQscale[i] = exp2fix8(qpOffset[deepestAt + i]);
+            /* acEnergyCu(curFrame, x, y, csp, qgSize): the block is qgSize-driven (8x8 or 16x16), the position the partition's */
+            (void)aq_block_energy(y + px + (intptr_t)py * stride, stride, inc, lshift, &wpSum[0], &wpSsd[0]);
+            if (cb)
+            {
+                (void)aq_block_energy(cb + (px >> 1) + (intptr_t)(py >> 1) * strideC, strideC, inc >> 1, cshift, &wpSum[1], &wpSsd[1]);
+                (void)aq_block_energy(cr + (px >> 1) + (intptr_t)(py >> 1) * strideC, strideC, inc >> 1, cshift, &wpSum[2], &wpSsd[2]);
+            }
+        }
+    if (weightp)
+    {
+        const int maxCol = ((width + 8) >> 4) << 4, maxRow = ((height + 8) >> 4) << 4;
+        const int w[3] = { maxCol, maxCol >> 1, maxCol >> 1 }, h[3] = { maxRow, maxRow >> 1, maxRow >> 1 };
+        for (int i = 0; i < 3; i++)
+            wpSsd[i] = wpSsd[i] - (wpSum[i] * wpSum[i] + (uint64_t)(w[i] * h[i]) / 2) / (uint64_t)(w[i] * h[i]);
+    }
+}
+
 /* ================================================================ cuTree: one propagation step
  * Lookahead::estimateCUPropagate (slicetype.cpp:2641-2753) with primitives.propagateCost (pixel.cpp:914-940): every 8x8 lowres block
  * of picture b passes on  (propagateIn + intraCost * invQscale * fpsFactor / 256) * (intraCost - min(intraCost, interCost)) / intraCost

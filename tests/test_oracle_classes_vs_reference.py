@@ -453,6 +453,44 @@ def test_adaptive_quant_pass_equals_reference_class(depth, width, height, qg, mo
         assert len(np.unique(inv)) > 4
 
 
+@pytest.mark.parametrize("depth,width,height,qg,rng,chroma", [(8, 256, 128, 16, 1.0, True), (8, 208, 144, 32, 2.5, True), (8, 250, 138, 64, 1.0, False),
+                                                              (8, 192, 136, 8, 6.0, True), (10, 192, 128, 16, 1.0, True), (10, 232, 120, 8, 3.0, False),
+                                                              (12, 128, 80, 32, 1.0, True), (12, 136, 72, 64, 2.0, False)])
+def test_hevc_aq_pass_equals_reference_class(depth, width, height, qg, rng, chroma, seed=101):
+    """--hevc-aq: LookaheadTLD::xPreanalyze / xPreanalyzeQp inside calcAdaptiveQuantFrame (slicetype.cpp:293-441, 507-511) - quadrant
+    variances of every enabled layer's partitions (clipped at the picture edge), activities, the layers' QP offsets, invQscaleFactor from
+    the deepest layer and the wp statistics gathered on the way - restatement against the real class.  Pictures whose sizes are not
+    multiples of the partitions exercise the clipped quadrants."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_aq_hevc_frame"):
+        pytest.skip("oracle/_ref predates x265ref_aq_hevc_frame")
+    clip = F.synth_clip(width, height, 1, depth=depth, seed=seed)
+    yimg, cbimg, crimg = clip[0]
+    yp, stride, org, w64, h64 = F.pad_plane(yimg)
+    cpad = [pad_any(np.ascontiguousarray(c), margin=16) for c in (cbimg, crimg)] if chroma else None
+    if chroma:
+        parts, act, qp, avg, inv, sm, ssd = O.aq_hevc_frame(depth, yp, stride, org, width, height, cpad[0][0], cpad[1][0], cpad[0][1], cpad[0][2], qg, rng, True)
+    else:
+        parts, act, qp, avg, inv, sm, ssd = O.aq_hevc_frame(depth, yp, stride, org, width, height, qg_size=qg, qp_adaptation_range=rng, weightp=True)
+    total = int(parts.sum())
+    rparts, ract, rqp, ravg = np.zeros(4, np.int32), np.zeros(total + 64, np.float64), np.zeros(total + 64, np.float64), np.zeros(4, np.float64)
+    rinv, rsum, rssd = np.zeros(total + 64, np.int32), np.zeros(3, np.uint64), np.zeros(3, np.uint64)
+    lib.x265ref_aq_hevc_frame.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_double, ctypes.c_int] + [ctypes.c_void_p] * 7
+    cbc, crc = (np.ascontiguousarray(cbimg), np.ascontiguousarray(crimg)) if chroma else (None, None)
+    assert lib.x265ref_aq_hevc_frame(yp.ctypes.data, None if cbc is None else cbc.ctypes.data, None if crc is None else crc.ctypes.data, width, height,
+                                     qg, rng, 1, rparts.ctypes.data, ract.ctypes.data, rqp.ctypes.data, ravg.ctypes.data, rinv.ctypes.data,
+                                     rsum.ctypes.data, rssd.ctypes.data) == 0
+    assert np.array_equal(parts, rparts), f"layers {parts} vs {rparts}"
+    assert [bool(v) for v in parts] == [bool(v) for v in O.AQ_LAYER_DEPTH[qg]]
+    assert np.array_equal(act, ract[:total]), f"{np.count_nonzero(act != ract[:total])} activities differ"
+    assert np.array_equal(avg, ravg), f"average activities {avg} vs {ravg}"
+    assert np.array_equal(qp, rqp[:total]), f"{np.count_nonzero(qp != rqp[:total])} QP offsets differ (max {np.abs(qp - rqp[:total]).max()})"
+    assert np.array_equal(inv, rinv[:inv.size]) and len(np.unique(inv)) > 3
+    assert np.array_equal(sm, rsum) and np.array_equal(ssd, rssd), f"wp statistics: {sm} {ssd} vs {rsum} {rssd}"
+    assert qp.min() < 0 < qp.max()
+
+
 @pytest.mark.parametrize("depth,width,height,gain,lift", [(8, 256, 128, 0.8, 8), (8, 208, 144, 0.7, 10), (10, 192, 128, 0.7, 12)])
 def test_weighted_b_frame_cost_equals_reference_classes(depth, width, height, gain, lift):
     """--weightp on a B picture: the list-0 search (predictor candidates, skip cost, motionEstimate) sees the weighted list-0 planes,
