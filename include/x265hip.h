@@ -504,6 +504,34 @@ typedef struct x265hip_aq_offsets_params
     int32_t* inv_qscale;             /* HOST int32 [nblocks] */
 } x265hip_aq_offsets_params;
 int x265hip_aq_offsets(const x265hip_aq_offsets_params* p);
+/* --hevc-aq (rc.hevcAq): what calcAdaptiveQuantFrame runs instead of the AQ modes - LookaheadTLD::xPreanalyze / xPreanalyzeQp
+ *   (encoder/slicetype.cpp:293-441, 507-511).  x265hip_aq_hevc_quadrants = its pixel work for ONE layer: per partition of part x part
+ *   samples (part = maxCUSize >> d for the layers aqLayerDepth enables, lowres.h:123-142; clipped at the right / bottom edge) the sum
+ *   and the sum of squares of the four quadrants, split at half the clipped size.  sums: DEVICE uint64 [partitions][4][2], partitions
+ *   row-major, ceil(width / part) per row.  x265hip_aq_hevc_offsets - HOST-side companion (host pointers, no device work): activity =
+ *   1 + the smallest quadrant variance (every quadrant divided by (cw / 2) * (ch / 2) as the reference does), the layer's average
+ *   activity, dQpOffset = log2((s * act + avg) / (act + s * avg)) * 6 with s = 2^(qp_adaptation_range / 6), and - for the deepest
+ *   enabled layer, whose partitions invQscaleFactor is indexed by - x265_exp2fix8(dQpOffset).  The wp_sum / wp_ssd statistics the
+ *   reference gathers in the same loop are those of x265hip_aq_energy. */
+typedef struct x265hip_aq_hevc_params
+{
+    int depth;
+    const void* y; intptr_t stride;         /* sample (0,0) of the source luma plane */
+    int width, height, part;
+    uint64_t* sums;
+} x265hip_aq_hevc_params;
+int x265hip_aq_hevc_quadrants(const x265hip_aq_hevc_params* p, void* stream);
+typedef struct x265hip_aq_hevc_offsets_params
+{
+    int width, height, part;
+    double qp_adaptation_range;             /* rc.qpAdaptationRange, 1.0 .. 6.0 */
+    const uint64_t* sums;                   /* HOST uint64 [partitions][4][2] */
+    double* activity;                       /* HOST double [partitions]: dActivity */
+    double* qp_offset;                      /* HOST double [partitions]: dQpOffset (= dCuTreeOffset) */
+    double* avg_activity;                   /* HOST double [1] or NULL: dAvgActivity */
+    int32_t* inv_qscale;                    /* HOST int32 [partitions] or NULL */
+} x265hip_aq_hevc_offsets_params;
+int x265hip_aq_hevc_offsets(const x265hip_aq_hevc_offsets_params* p);
 /* x265hip_cutree_propagate = one cuTree propagation step, Lookahead::estimateCUPropagate (encoder/slicetype.cpp:2641-2753) with
  *   primitives.propagateCost (pixel.cpp:914-940): every 8x8 lowres block of picture b passes on
  *   (propagate_in + intra_cost * inv_qscale * fps_factor / 256) * (intra - min(intra, inter)) / intra   (double arithmetic, exactly as

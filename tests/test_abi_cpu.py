@@ -6,6 +6,8 @@ import os
 import sys
 import re
 
+import numpy as np
+
 A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
 
 
@@ -63,7 +65,8 @@ def test_ctypes_structures_match_the_c_header(repo_root, tmp_path):
              "x265hip_cutree_propagate_params": A.CuTreePropagateParams, "x265hip_cutree_finish_params": A.CuTreeFinishParams, "x265hip_frame_cost_recalculate_params": A.FrameCostRecalculateParams,
              "x265hip_lowres_weight_cost_params": A.LowresWeightCostParams, "x265hip_lowres_weight_apply_params": A.LowresWeightApplyParams,
              "x265hip_sao_stats_params": A.SaoStatsParams, "x265hip_sao_apply_params": A.SaoApplyParams, "x265hip_plane": A.Plane,
-             "x265hip_intra_recon_params": A.IntraReconParams, "x265hip_tu_tables": A.TuTablesRec, "x265hip_phase_planes_params": A.PhasePlanesParams}
+             "x265hip_intra_recon_params": A.IntraReconParams, "x265hip_tu_tables": A.TuTablesRec, "x265hip_phase_planes_params": A.PhasePlanesParams,
+             "x265hip_aq_hevc_params": A.AqHevcParams, "x265hip_aq_hevc_offsets_params": A.AqHevcOffsetsParams}
     sys.path.insert(0, repo_root)
     from tools import seam_driver as SD          # the consumer-layer records the seam tools mirror
     pairs.update({"x265hip_me_cache_params": SD.CacheParams, "x265hip_me_cache_stats_t": SD.CacheStats,
@@ -168,3 +171,33 @@ def test_chroma_pair_validates_before_touching_a_device():
     f = A.lib().x265hip_inter_recon_chroma_pair
     f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     assert f(None, None, None) == -2
+
+
+def test_hevc_aq_host_side_matches_the_oracle_without_a_device():
+    """x265hip_aq_hevc_offsets is host code: the double-precision half of --hevc-aq from the oracle's quadrant sums equals the oracle's
+    (reference-pinned) restatement bit for bit, incl. clipped partitions; the device entry refuses bad geometry before touching a device."""
+    import ctypes
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_api as O
+    for depth, width, height, qg, rng in ((8, 250, 138, 16, 1.0), (10, 232, 120, 8, 3.0), (8, 208, 144, 64, 6.0)):
+        y = F.synth_clip(width, height, 1, depth=depth, seed=7)[0][0]
+        yp, stride, org, _, _ = F.pad_plane(y)
+        parts, act, qp, avg, inv, _, _ = O.aq_hevc_frame(depth, yp, stride, org, width, height, qg_size=qg, qp_adaptation_range=rng)
+        at = 0
+        for d in range(4):
+            if not parts[d]:
+                continue
+            part = 64 >> d
+            sums = O.aq_hevc_quadrants(depth, yp, stride, org, width, height, part)
+            a, q, g, iv = A.aq_hevc_offsets(width, height, part, rng, sums)
+            assert np.array_equal(a, act[at:at + parts[d]]) and np.array_equal(q, qp[at:at + parts[d]]) and g == avg[d]
+            if d == max(k for k in range(4) if parts[k]):
+                assert np.array_equal(iv, inv)
+            at += parts[d]
+    f = A.lib().x265hip_aq_hevc_quadrants
+    f.argtypes = [ctypes.POINTER(A.AqHevcParams), ctypes.c_void_p]
+    assert f(None, None) == -2
+    assert f(ctypes.byref(A.AqHevcParams(8, 4096, 256, 128, 64, 24, 8192)), None) == -2        # partition size
+    assert f(ctypes.byref(A.AqHevcParams(8, 4096, 256, 127, 64, 16, 8192)), None) == -2        # odd width

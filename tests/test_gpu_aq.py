@@ -64,3 +64,50 @@ def test_aq_energy_rejects_bad_arguments():
         A.aq_energy(8, pic.t, pic.stride, pic.org, 64, 64, 32, energy, wp)
     with pytest.raises(A.X265HipError):
         A.aq_energy(8, pic.t, pic.stride, pic.org, 64, 64, 16, energy, wp, cb=pic.t)
+
+
+@pytest.mark.parametrize("depth,width,height,qg,rng,chroma", [(8, 640, 360, 16, 1.0, True), (8, 416, 240, 32, 2.5, True), (8, 250, 138, 64, 1.0, False),
+                                                              (8, 640, 352, 8, 6.0, True), (10, 384, 256, 16, 1.0, True), (10, 232, 120, 8, 3.0, False),
+                                                              (8, 3840, 2160, 16, 1.0, True), (10, 3840, 2160, 8, 2.0, False), (12, 136, 72, 64, 2.0, False)])
+def test_hevc_aq_pass_matches_oracle(depth, width, height, qg, rng, chroma, seed=103):
+    """--hevc-aq (stages.HevcAq: x265hip_aq_hevc_quadrants per layer + the host-side x265hip_aq_hevc_offsets + the wp statistics of
+    x265hip_aq_energy) vs the oracle's restatement of xPreanalyze / xPreanalyzeQp, pinned against the real class on the CPU."""
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    yimg, cbimg, crimg = F.synth_clip(width, height, 1, depth=depth, seed=seed)[0]
+    pic = P.DevicePicture(yimg, dev)
+    kw, okw = {}, {}
+    if chroma:
+        cpad = [_pad(np.ascontiguousarray(c)) for c in (cbimg, crimg)]
+        to_dev = lambda a: torch.from_numpy(a.view(np.uint8) if depth == 8 else a.view(np.int16)).to(dev)
+        kw = dict(cb=to_dev(cpad[0][0]), cr=to_dev(cpad[1][0]), stride_c=cpad[0][1], org_c=cpad[0][2])
+        okw = dict(cb=cpad[0][0], cr=cpad[1][0], stride_c=cpad[0][1], org_c=cpad[0][2])
+    aq = S.HevcAq(width, height, depth, dev, qg_size=qg, qp_adaptation_range=rng, weightp=True)
+    layers, inv, wp_sum, wp_ssd = aq.run(pic, **kw)
+    parts, act, qp, avg, einv, esum, essd = O.aq_hevc_frame(depth, pic.host.reshape(-1), pic.stride, pic.org, width, height, qg_size=qg,
+                                                            qp_adaptation_range=rng, weightp=True, **okw)
+    at = 0
+    for d in range(4):
+        if not parts[d]:
+            assert (64 >> d) not in layers
+            continue
+        part = 64 >> d
+        sums = aq.sums[aq.parts.index(part)].cpu().numpy().view(np.uint64).reshape(-1, 4, 2)
+        assert np.array_equal(sums, O.aq_hevc_quadrants(depth, pic.host.reshape(-1), pic.stride, pic.org, width, height, part)), f"layer {d}: quadrant sums differ"
+        a, q, g = layers[part]
+        assert np.array_equal(a, act[at:at + parts[d]]) and np.array_equal(q, qp[at:at + parts[d]]) and g == avg[d], f"layer {d}: activities / offsets differ"
+        at += parts[d]
+    assert np.array_equal(inv, einv) and len(np.unique(inv)) > 3
+    assert wp_sum == [int(v) for v in esum] and wp_ssd == [int(v) for v in essd], "wp statistics differ"
+
+
+def test_hevc_aq_rejects_bad_arguments():
+    import torch
+    dev = torch.device("cuda:0")
+    pic = P.DevicePicture(F.synth_clip(64, 64, 1, depth=8, seed=1)[0][0], dev)
+    sums = torch.zeros(64, dtype=torch.int64, device=dev)
+    with pytest.raises(A.X265HipError):
+        A.aq_hevc_quadrants(8, pic.t, pic.stride, pic.org, 64, 64, 24, sums)
+    with pytest.raises(A.X265HipError):
+        A.aq_hevc_offsets(64, 64, 16, 0.5, np.zeros((16, 4, 2), np.uint64))

@@ -634,6 +634,119 @@ extern "C" int x265hip_aq_offsets(const x265hip_aq_offsets_params* p)
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- --hevc-aq: quadrant sums
+// The integer half of LookaheadTLD::xPreanalyze (slicetype.cpp:329-404): per partition of part x part samples (clipped at the right /
+// bottom edge of the picture) the sum and the sum of squares of its four quadrants, split at half the CLIPPED size.  One wavefront per
+// partition: lanes walk its samples in raster order (unit-stride loads), four (sum, sum of squares) pairs per lane, DPP reduction.
+struct AqHevcArgs
+{
+    const uint8_t* y; long strideB;
+    int width, height, part, partsW, nparts;
+    unsigned long long* sums;
+};
+
+template <typename Px>
+__global__ void __launch_bounds__(256) aq_hevc_quadrants_kernel(AqHevcArgs a)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= a.nparts) return;
+    const int px = (wave % a.partsW) * a.part, py = (wave / a.partsW) * a.part;
+    const int cw = min(a.part, a.width - px), ch = min(a.part, a.height - py);
+    const int hw = cw >> 1, hh = ch >> 1;
+    unsigned long long acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const Px* src = reinterpret_cast<const Px*>(a.y + (long)py * a.strideB) + px;
+    const long st = a.strideB / (long)sizeof(Px);
+    for (int i = lane; i < cw * ch; i += 64)
+    {
+        const int by = i / cw, bx = i - by * cw;
+        const unsigned v = src[by * st + bx];
+        const int quad = (by >= hh) * 2 + (bx >= hw);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            acc[2 * k] += quad == k ? v : 0u;
+            acc[2 * k + 1] += quad == k ? (unsigned long long)v * v : 0ull;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+    {
+        unsigned long long t = acc[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+        acc[k] = t;
+    }
+    if (lane < 8)
+    {
+        unsigned long long out = acc[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) out = lane == k ? acc[k] : out;
+        a.sums[(size_t)wave * 8 + lane] = out;
+    }
+}
+
+extern "C" int x265hip_aq_hevc_quadrants(const x265hip_aq_hevc_params* p, void* stream)
+{
+    if (!p || !p->y || !p->sums) { set_error("aq_hevc_quadrants: NULL operand"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("aq_hevc_quadrants: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->part != 64 && p->part != 32 && p->part != 16 && p->part != 8) { set_error("aq_hevc_quadrants: partition size %d (64, 32, 16, 8)", p->part); return X265HIP_EINVAL; }
+    if (p->width <= 0 || p->height <= 0 || (p->width & 1) || (p->height & 1)) { set_error("aq_hevc_quadrants: width / height must be positive and even"); return X265HIP_EINVAL; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    AqHevcArgs a;
+    const int bpp = p->depth == 8 ? 1 : 2;
+    a.y = (const uint8_t*)p->y; a.strideB = (long)p->stride * bpp;
+    a.width = p->width; a.height = p->height; a.part = p->part;
+    a.partsW = (p->width + p->part - 1) / p->part;
+    a.nparts = a.partsW * ((p->height + p->part - 1) / p->part);
+    a.sums = (unsigned long long*)p->sums;
+    const int blocks = (a.nparts + 3) / 4;
+    if (bpp == 1) hipLaunchKernelGGL(aq_hevc_quadrants_kernel<uint8_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(aq_hevc_quadrants_kernel<uint16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The double-precision half (host pointers, no device work): activity = 1 + the smallest quadrant variance, the layer's average, and
+// xPreanalyzeQp's offset (slicetype.cpp:293-327, 389-404) through the C library's pow / log2 like the reference.
+extern "C" int x265hip_aq_hevc_offsets(const x265hip_aq_hevc_offsets_params* p)
+{
+    if (!p || !p->sums || !p->activity || !p->qp_offset) { set_error("aq_hevc_offsets: NULL operand"); return X265HIP_EINVAL; }
+    if (p->part != 64 && p->part != 32 && p->part != 16 && p->part != 8) { set_error("aq_hevc_offsets: partition size %d", p->part); return X265HIP_EINVAL; }
+    if (p->width <= 0 || p->height <= 0) { set_error("aq_hevc_offsets: picture size"); return X265HIP_EINVAL; }
+    if (p->qp_adaptation_range < 1.0 || p->qp_adaptation_range > 6.0) { set_error("aq_hevc_offsets: qp_adaptation_range %g out of [1, 6] (param.cpp:1700)", p->qp_adaptation_range); return X265HIP_EINVAL; }
+    const int part = p->part, pw = (p->width + part - 1) / part, ph = (p->height + part - 1) / part;
+    double dSumAct = 0.0;
+    for (int py = 0, i = 0; py < p->height; py += part)
+        for (int px = 0; px < p->width; px += part, i++)
+        {
+            const int cw = std::min(part, p->width - px), ch = std::min(part, p->height - py);
+            const uint32_t numPix = (uint32_t)(cw >> 1) * (uint32_t)(ch >> 1);
+            double dMinVar = 1.7976931348623158e+308;
+            if (numPix)
+                for (int k = 0; k < 4; k++)
+                {
+                    const double dAverage = double(p->sums[(size_t)i * 8 + 2 * k]) / numPix;
+                    const double dVariance = double(p->sums[(size_t)i * 8 + 2 * k + 1]) / numPix - dAverage * dAverage;
+                    dMinVar = std::min(dMinVar, dVariance);
+                }
+            else
+                dMinVar = 0.0;
+            p->activity[i] = 1.0 + dMinVar;
+            dSumAct += p->activity[i];
+        }
+    const double dAvgAct = dSumAct / (uint32_t)(pw * ph);
+    if (p->avg_activity) *p->avg_activity = dAvgAct;
+    for (int i = 0; i < pw * ph; i++)
+    {
+        const double dMaxQScale = std::pow(2.0, p->qp_adaptation_range / 6.0);
+        const double dNormAct = (dMaxQScale * p->activity[i] + dAvgAct) / (p->activity[i] + dMaxQScale * dAvgAct);
+        p->qp_offset[i] = (std::log2(dNormAct) / std::log2(2.0)) * 6.0;
+        if (p->inv_qscale) p->inv_qscale[i] = aq_exp2fix8(p->qp_offset[i]);
+    }
+    return 0;
+}
+
 extern "C" int x265hip_cutree_propagate(const x265hip_cutree_propagate_params* p, void* stream)
 {
     int rc = ensure_device();

@@ -365,6 +365,46 @@ def aq_offsets(depth, qg_size, aq_mode, aq_strength, energy):
     return qp, inv
 
 
+class AqHevcParams(ctypes.Structure):
+    """x265hip_aq_hevc_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("y", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),
+                ("width", ctypes.c_int), ("height", ctypes.c_int), ("part", ctypes.c_int), ("sums", ctypes.c_void_p)]
+
+
+class AqHevcOffsetsParams(ctypes.Structure):
+    """x265hip_aq_hevc_offsets_params (include/x265hip.h)."""
+    _fields_ = [("width", ctypes.c_int), ("height", ctypes.c_int), ("part", ctypes.c_int), ("qp_adaptation_range", ctypes.c_double),
+                ("sums", ctypes.c_void_p), ("activity", ctypes.c_void_p), ("qp_offset", ctypes.c_void_p), ("avg_activity", ctypes.c_void_p),
+                ("inv_qscale", ctypes.c_void_p)]
+
+
+def aq_hevc_quadrants(depth, y, stride, org, width, height, part, sums, stream=None):
+    """x265hip_aq_hevc_quadrants: sums = device int64 tensor [partitions * 8] (uint64 bits)."""
+    es = 1 if depth == 8 else 2
+    p = AqHevcParams()
+    p.depth, p.y, p.stride, p.width, p.height, p.part, p.sums = depth, y.data_ptr() + org * es, stride, width, height, part, sums.data_ptr()
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_aq_hevc_quadrants
+    f.argtypes = [ctypes.POINTER(AqHevcParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_aq_hevc_quadrants")
+
+
+def aq_hevc_offsets(width, height, part, qp_adaptation_range, sums):
+    """Host side of --hevc-aq for one layer (x265hip_aq_hevc_offsets): sums = numpy uint64 [partitions, 4, 2]; returns (activity, qp_offset
+    float64 [partitions], avg_activity float, inv_qscale int32 [partitions])."""
+    import numpy as np
+    sm = np.ascontiguousarray(sums, dtype=np.uint64)
+    n = ((width + part - 1) // part) * ((height + part - 1) // part)
+    act, qp, avg, inv = np.zeros(n, np.float64), np.zeros(n, np.float64), np.zeros(1, np.float64), np.zeros(n, np.int32)
+    p = AqHevcOffsetsParams()
+    p.width, p.height, p.part, p.qp_adaptation_range = width, height, part, float(qp_adaptation_range)
+    p.sums, p.activity, p.qp_offset, p.avg_activity, p.inv_qscale = sm.ctypes.data, act.ctypes.data, qp.ctypes.data, avg.ctypes.data, inv.ctypes.data
+    f = lib().x265hip_aq_hevc_offsets
+    f.argtypes = [ctypes.POINTER(AqHevcOffsetsParams)]
+    check(f(ctypes.byref(p)), "x265hip_aq_hevc_offsets")
+    return act, qp, float(avg[0]), inv
+
+
 class CuTreePropagateParams(ctypes.Structure):
     """x265hip_cutree_propagate_params (include/x265hip.h)."""
     _fields_ = [("width_in_cu", ctypes.c_int), ("height_in_cu", ctypes.c_int),

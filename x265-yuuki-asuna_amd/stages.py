@@ -319,6 +319,33 @@ class AdaptiveQuant:
         return qp, inv, wp_sum, wp_ssd
 
 
+class HevcAq:
+    """--hevc-aq: the pass calcAdaptiveQuantFrame runs instead of the AQ modes - LookaheadTLD::xPreanalyze / xPreanalyzeQp
+    (slicetype.cpp:293-441).  Per enabled layer (lowres.h:123-129, 64x64 CTUs) one launch produces the quadrant sums of every partition
+    (x265hip_aq_hevc_quadrants); activities, the layer's average and the QP offsets are the reference's double-precision expressions in
+    the library's host-side x265hip_aq_hevc_offsets; the wp_sum / wp_ssd statistics of the same loop come from x265hip_aq_energy."""
+    LAYERS = {64: (1, 0, 1, 0), 32: (1, 1, 1, 0), 16: (1, 1, 1, 0), 8: (1, 1, 1, 1)}
+
+    def __init__(self, width, height, depth, device, qg_size=16, qp_adaptation_range=1.0, weightp=True):
+        import torch
+        self.width, self.height, self.depth, self.qg, self.range = width, height, depth, qg_size, float(qp_adaptation_range)
+        self.parts = [64 >> d for d in range(4) if self.LAYERS[qg_size][d]]
+        self.sums = [torch.zeros(8 * ((width + p - 1) // p) * ((height + p - 1) // p), dtype=torch.int64, device=device) for p in self.parts]
+        self.wp_pass = AdaptiveQuant(width, height, depth, device, qg_size=8 if qg_size == 8 else 16, aq_mode=0, weightp=weightp)
+
+    def run(self, y: DevicePicture, cb=None, cr=None, stride_c=0, org_c=0):
+        """Returns ({partition size: (activity, qp_offset, avg_activity)}, inv_qscale of the deepest layer, wp_sum [3], wp_ssd [3])."""
+        import numpy as np
+        for p, sm in zip(self.parts, self.sums):
+            hipabi.aq_hevc_quadrants(self.depth, y.t, y.stride, y.org, self.width, self.height, p, sm)
+        _, _, wp_sum, wp_ssd = self.wp_pass.run(y, cb, cr, stride_c, org_c)
+        layers, inv = {}, None
+        for p, sm in zip(self.parts, self.sums):
+            act, qp, avg, inv = hipabi.aq_hevc_offsets(self.width, self.height, p, self.range, sm.cpu().numpy().view(np.uint64).reshape(-1, 4, 2))
+            layers[p] = (act, qp, avg)
+        return layers, inv, wp_sum, wp_ssd
+
+
 class WeightAnalysis:
     """Weighted-reference analysis of a prepared picture against a prepared reference - LookaheadTLD::weightsAnalyse
     (slicetype.cpp:860-957).  The pixel work runs on the device (x265hip_lowres_weight_cost scores the unweighted reference and the
