@@ -208,15 +208,28 @@ int x265hip_inter_recon_chroma(const x265hip_recon_params* p, void* stream);
 /* Cb and Cr of one picture in ONE launch: same geometry, bit depth, block size and use of `tables`; each record carries its own planes,
  * QP and outputs.  Results are those of two x265hip_inter_recon_chroma calls. */
 int x265hip_inter_recon_chroma_pair(const x265hip_recon_params* cb, const x265hip_recon_params* cr, void* stream);
-/* Bi-predictive flavour (B pictures, luma): Predict::motionCompensation without weighted prediction (predict.cpp:168-243).  base =
- * the uni-directional parameters with fref / mv = list 0 (both references share fref_stride); dir = uint8 [ctu][blocks]: 1 = list 0
- * only, 2 = list 1 only, 3 = predInterLumaShort of both lists combined by addAvg; NULL = all 3. */
+/* Bi-predictive flavour (B pictures - and P pictures with explicit weights -, luma): Predict::motionCompensation (predict.cpp:77-243).
+ * base = the uni-directional parameters with fref / mv = list 0 (both references share fref_stride); dir = uint8 [ctu][blocks]: 1 =
+ * list 0 only, 2 = list 1 only, 3 = predInterLumaShort of both lists combined by addAvg; NULL = all 3.
+ * weight0 / weight1 (HOST pointers, read at the call): the luma WeightParam of the list-0 / list-1 reference, NULL = the list has no
+ * table (pps.bUseWeightPred / bUseWeightedBiPred off).  A block predicted from one list whose table is `present` takes
+ * predInterLumaShort + addWeightUni (weight_sp, predict.cpp:525-545); a block predicted from both takes addWeightBi (:411-456) when
+ * both tables exist and at least one is present - with list 0's denominator for both, as the reference does - and addAvg otherwise. */
+typedef struct x265hip_pred_weight
+{
+    int present;          /* WeightParam::wtPresent */
+    int weight;           /* inputWeight */
+    int offset;           /* inputOffset (8-bit domain; scaled by 1 << (depth - 8) inside) */
+    int log2_denom;       /* log2WeightDenom */
+} x265hip_pred_weight;
 typedef struct x265hip_recon_bi_params
 {
     x265hip_recon_params base;
     const void* fref1;
     const int32_t* mv1;
     const uint8_t* dir;
+    const x265hip_pred_weight* weight0;
+    const x265hip_pred_weight* weight1;
 } x265hip_recon_bi_params;
 int x265hip_inter_recon_bi(const x265hip_recon_bi_params* p, void* stream);
 

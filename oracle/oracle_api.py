@@ -478,10 +478,17 @@ def inter_recon_chroma(depth, fenc, fref, stride, org, width, height, level, mv,
     return recon, levels, num_sig, dist
 
 
-def inter_recon_bi(depth, fenc, stride, org, fref0, fref1, width, height, level, mv0, mv1, qp, dir_flags=None, intra_slice=0, nthreads=0, avx2=False):
-    """CPU restatement of the bi-predictive inter TU stage (all planes share stride / org).  Returns (recon, levels, num_sig, dist)."""
+def inter_recon_bi(depth, fenc, stride, org, fref0, fref1, width, height, level, mv0, mv1, qp, dir_flags=None, intra_slice=0, nthreads=0, avx2=False,
+                   weights=None):
+    """CPU restatement of the bi-predictive inter TU stage (all planes share stride / org).  Returns (recon, levels, num_sig, dist).
+    weights: (list 0, list 1), each None (no table) or (present, weight, offset, log2_denom) - explicit weighted prediction."""
     L = lib(avx2)
     fn = getattr(L, f"x265oracle_inter_recon_bi_d{depth}")
+    setw = getattr(L, f"x265oracle_set_pred_weights_d{depth}")
+    setw.restype = None
+    setw.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    wrec = [None if (weights is None or w is None) else np.asarray(w, dtype=np.int32) for w in (weights or (None, None))]
+    setw(*[None if w is None else w.ctypes.data for w in wrec])
     nctu = (width // 64) * (height // 64)
     n = 8 << level
     nblk = (64 // n) ** 2
@@ -498,6 +505,7 @@ def inter_recon_bi(depth, fenc, stride, org, fref0, fref1, width, height, level,
     assert fn(fenc.ctypes.data + org * es, stride, fref0.ctypes.data + org * es, fref1.ctypes.data + org * es, stride,
               recon.ctypes.data + org * es, stride, width, height, level, m0.ctypes.data, m1.ctypes.data, None if d is None else d.ctypes.data,
               qp, intra_slice, levels.ctypes.data, num_sig.ctypes.data, dist.ctypes.data, nthreads) == 0
+    setw(None, None)
     return recon, levels, num_sig, dist
 
 

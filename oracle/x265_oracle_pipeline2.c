@@ -251,6 +251,15 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
  * predInterLumaShort of each list (:267-304: convert_p2s / luma_hps / luma_vps / luma_hps with row extension + luma_vss) and
  * combine them with addAvg (pixel.cpp: (a + b + offset) >> shift at 14-bit intermediate precision).  mv0 / mv1: the two lists'
  * records in the sub-pel stage's format; dir: uint8 [ctu][npu] or NULL (all 3). */
+/* Explicit weighted prediction of the bi-predictive stage (x265hip_recon_bi_params.weight0 / weight1): the two lists' WeightParam of
+ * the luma plane as { wtPresent, inputWeight, inputOffset, log2WeightDenom }, NULL = that list has no table (P slices without
+ * pps.bUseWeightPred, B slices without pps.bUseWeightedBiPred).  Predict::motionCompensation (predict.cpp:77-243): a block predicted
+ * from one list whose table is present takes predInterLumaShort + addWeightUni (weight_sp, :525-545); a block predicted from both
+ * takes addWeightBi (:411-456, weightBidir :52-55) when both tables exist and one is present, otherwise addAvg.  Test infrastructure:
+ * set per test. */
+static const int32_t* g_predW[2];
+void EXPORT(x265oracle_set_pred_weights)(const int32_t* w0, const int32_t* w1) { g_predW[0] = w0; g_predW[1] = w1; }
+
 int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, const pixel* fref0, const pixel* fref1, intptr_t frefStride,
                                       pixel* recon, intptr_t reconStride, int width, int height, int level,
                                       const int32_t* mv0, const int32_t* mv1, const uint8_t* dir, int qp, int flags,
@@ -300,7 +309,8 @@ int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, co
                 const int qx = (int16_t)(packed & 0xffff), qy = (int16_t)(packed >> 16);
                 const pixel* src = (l ? fref1 : fref0) + (intptr_t)(py + (qy >> 2)) * frefStride + px + (qx >> 2);
                 const int xf = qx & 3, yf = qy & 3;
-                if (d != 3)
+                const int32_t* wl = g_predW[l];
+                if (d != 3 && !(wl && wl[0]))
                 {
                     /* predInterLumaPixel */
                     if (!(xf | yf)) pu->copy_pp(pred, 64, src, frefStride);
@@ -321,7 +331,36 @@ int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, co
                     }
                 }
             }
-            if (d == 3) pu->addAvg[0](ps[0], ps[1], pred, 64, 64, 64);
+            const int shiftNum = 14 - X265HIP_DEPTH;
+            if (d == 3)
+            {
+                const int32_t* w0 = g_predW[0]; const int32_t* w1 = g_predW[1];
+                if (w0 && w1 && (w0[0] || w1[0]))
+                {
+                    /* addWeightBi: wv.o = inputOffset << (depth - 8), the shift and the rounding of list 0's denominator for both */
+                    const int offset = w0[2] * (1 << (X265HIP_DEPTH - 8)) + w1[2] * (1 << (X265HIP_DEPTH - 8));
+                    const int shift = w0[3] + shiftNum + 1, round = shift ? (1 << (shift - 1)) : 0;
+                    const int maxVal = (1 << X265HIP_DEPTH) - 1;
+                    for (int y = 0; y < n; y++)
+                        for (int x = 0; x < n; x++)
+                        {
+                            const int v = (w0[1] * (ps[0][y * 64 + x] + 8192) + w1[1] * (ps[1][y * 64 + x] + 8192) + round + (offset * (1 << (shift - 1)))) >> shift;
+                            pred[y * 64 + x] = (pixel)(v < 0 ? 0 : (v > maxVal ? maxVal : v));
+                        }
+                }
+                else
+                    pu->addAvg[0](ps[0], ps[1], pred, 64, 64, 64);
+            }
+            else
+            {
+                const int l = d == 2;
+                const int32_t* wl = g_predW[l];
+                if (wl && wl[0])                           /* addWeightUni through the weight_sp primitive */
+                {
+                    const int shift = wl[3] + shiftNum, round = shift ? (1 << (shift - 1)) : 0;
+                    prim.weight_sp(ps[l], pred, 64, 64, n, n, wl[1], round, shift, wl[2] * (1 << (X265HIP_DEPTH - 8)));
+                }
+            }
             cu->sub_ps(resi, 64, fe, pred, fencStride, 64);
             cu->dct(resi, coef, 64);
             tab_denoise(coef, n * n);

@@ -71,7 +71,7 @@ def test_ctypes_structures_match_the_c_header(repo_root, tmp_path):
     from tools import seam_driver as SD          # the consumer-layer records the seam tools mirror
     pairs.update({"x265hip_me_cache_params": SD.CacheParams, "x265hip_me_cache_stats_t": SD.CacheStats,
                   "x265hip_phase_cache_params": SD.PhaseCacheParams, "x265hip_phase_cache_stats_t": SD.PhaseCacheStats})
-    for extra, cname in (("ReconParams", "x265hip_recon_params"), ("ReconBiParams", "x265hip_recon_bi_params")):
+    for extra, cname in (("ReconParams", "x265hip_recon_params"), ("ReconBiParams", "x265hip_recon_bi_params"), ("PredWeight", "x265hip_pred_weight")):
         cls = getattr(A, extra, None) or getattr(S, extra, None)
         if cls is not None and isinstance(cls, type) and issubclass(cls, ctypes.Structure):
             pairs[cname] = cls

@@ -145,6 +145,58 @@ def test_inter_recon_bi_matches_oracle(depth, level, qp):
     assert (dirs == 3).any() and (dirs == 1).any() and (dirs == 2).any()
 
 
+@pytest.mark.parametrize("depth,level,qp,w0,w1", [(8, 2, 26, (1, 45, 6, 6), (1, 70, -9, 6)), (8, 1, 30, (1, 120, 20, 7), (0, 64, 0, 7)),
+                                                  (8, 0, 22, (0, 32, 0, 5), (1, 29, -3, 5)), (10, 2, 38, (1, 61, 4, 6), None),
+                                                  (10, 1, 34, None, (1, 127, -128, 7)), (12, 1, 46, (1, -20, 100, 4), (1, 90, 7, 3)),
+                                                  (8, 2, 28, (1, 1, 0, 0), (1, 3, 1, 0))])
+def test_inter_recon_bi_with_explicit_weights_matches_oracle(depth, level, qp, w0, w1):
+    """Explicit weighted prediction in the B / weighted-P stage: blocks of one list -> predInterLumaShort + addWeightUni (weight_sp),
+    blocks of both -> addWeightBi when both lists carry a table and one is present (list 0's denominator for both), else addAvg; a list
+    without a table (None) or with wtPresent 0 keeps the unweighted paths."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng([57, depth, level])
+    clip = F.synth_clip(256, 128, 3, depth=depth, seed=68 + level)
+    cur, r0, r1 = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev), P.DevicePicture(clip[2][0], dev)
+    nctu = (cur.w64 // 64) * (cur.h64 // 64)
+    mvs = []
+    for _ in range(2):
+        qx, qy = rng.integers(-30, 31, size=nctu * 85), rng.integers(-30, 31, size=nctu * 85)
+        qx[::4] &= ~3; qy[::3] &= ~3
+        m = np.zeros((nctu * 85, 2), np.int32)
+        m[:, 1] = (qx & 0xffff) | (qy << 16)
+        mvs.append(m)
+    nblk = (64 >> (3 + level)) ** 2
+    dirs = rng.integers(1, 4, size=nctu * nblk).astype(np.uint8)
+    st = S.InterReconBi(nctu, cur.w64, cur.h64, depth, level, qp, dev, intra_slice=2)
+    plain = S.InterReconBi(nctu, cur.w64, cur.h64, depth, level, qp, dev, intra_slice=2)
+    recon, recon_plain = torch.zeros_like(cur.t), torch.zeros_like(cur.t)
+    d_mv = [torch.from_numpy(m.reshape(-1)).to(dev) for m in mvs]
+    d_dir = torch.from_numpy(dirs).to(dev)
+    st.run(cur, r0, r1, recon, d_mv[0], d_mv[1], dir_flags=d_dir, weights=(w0, w1))
+    plain.run(cur, r0, r1, recon_plain, d_mv[0], d_mv[1], dir_flags=d_dir)
+    torch.cuda.synchronize()
+    O = _oracle()
+    erec, elev, ens, edist = O.inter_recon_bi(depth, cur.host.reshape(-1), cur.stride, cur.org, r0.host.reshape(-1), r1.host.reshape(-1),
+                                              cur.w64, cur.h64, level, mvs[0], mvs[1], qp, dir_flags=dirs, intra_slice=2, weights=(w0, w1))
+    assert np.array_equal(st.num_sig.cpu().numpy().view(np.uint32), ens), "numSig differs"
+    assert np.array_equal(st.levels.cpu().numpy(), elev), "levels differ"
+    assert np.array_equal(recon.cpu().numpy().view(cur.host.dtype).reshape(-1), erec.reshape(-1)), "reconstruction differs"
+    assert np.array_equal(st.dist.cpu().numpy().view(np.uint64), edist), "SSE differs"
+    assert not torch.equal(st.levels, plain.levels), "the weights changed nothing"
+
+
+def test_inter_recon_bi_rejects_bad_weights():
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(128, 64, 2, depth=8, seed=3)
+    cur, r0 = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    st = S.InterReconBi(2, cur.w64, cur.h64, 8, 2, 26, dev)
+    mv = torch.zeros(2 * 85 * 2, dtype=torch.int32, device=dev)
+    with pytest.raises(A.X265HipError):
+        st.run(cur, r0, r0, torch.zeros_like(cur.t), mv, mv, weights=((1, 64, 0, 9), None))
+
+
 QUANT_SCALES, INV_QUANT_SCALES = (26214, 23302, 20560, 18396, 16384, 14564), (40, 45, 51, 57, 64, 72)      # scalinglist.cpp:129-130
 
 

@@ -549,6 +549,7 @@ struct TuBiArgs
     TuArgs t;                          // t.fref / t.mv = list 0
     const uint8_t* fref1; const int2* mv1;
     const uint8_t* dir;                // [ctu][npu]: 1, 2 or 3; NULL = all 3
+    int wHave[2], wPresent[2], w[2], wOff[2], wDenom, wDenomUni[2];   // explicit weights of the two lists (wOff scaled to the bit depth; wDenom = list 0's)
 };
 
 template <typename Px, int N, bool TAB = false>
@@ -595,7 +596,8 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBi
             }
             __syncthreads();
             int16_t* out = (d == 3 && l == 0) ? ps0 : pred;            // list 0's short prediction waits in ps0
-            const bool shortOut = d == 3;
+            // addWeightUni works on the short (14-bit) prediction like the bi-directional combination
+            const bool shortOut = d == 3 || (b.wHave[l] && b.wPresent[l]);
             const int shiftPS = 6 - headRoom, offPS = -(8192 << shiftPS);
             if (xf && yf)
             {
@@ -644,8 +646,26 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBi
         __syncthreads();
         if (d == 3)
         {
-            const int shiftAvg = 15 - a.depth, offAvg = (1 << (shiftAvg - 1)) + 2 * 8192;                              // addAvg
-            for (int i = tid; i < NN; i += nth) pred[i] = (int16_t)clip3(0, maxVal, ((int)ps0[i] + (int)pred[i] + offAvg) >> shiftAvg);
+            if (b.wHave[0] && b.wHave[1] && (b.wPresent[0] || b.wPresent[1]))
+            {
+                // addWeightBi (predict.cpp:411-456, weightBidir :52-55): list 0's denominator for both lists
+                const int shift = b.wDenom + headRoom + 1, round = 1 << (shift - 1), offset = (b.wOff[0] + b.wOff[1]) * (1 << (shift - 1));
+                for (int i = tid; i < NN; i += nth)
+                    pred[i] = (int16_t)clip3(0, maxVal, (b.w[0] * ((int)ps0[i] + 8192) + b.w[1] * ((int)pred[i] + 8192) + round + offset) >> shift);
+            }
+            else
+            {
+                const int shiftAvg = 15 - a.depth, offAvg = (1 << (shiftAvg - 1)) + 2 * 8192;                          // addAvg
+                for (int i = tid; i < NN; i += nth) pred[i] = (int16_t)clip3(0, maxVal, ((int)ps0[i] + (int)pred[i] + offAvg) >> shiftAvg);
+            }
+            __syncthreads();
+        }
+        else if (b.wHave[d == 2] && b.wPresent[d == 2])
+        {
+            // addWeightUni = weight_sp (pixel.cpp:493-515) on the short prediction of the one list used
+            const int l = d == 2, shift = b.wDenomUni[l] + headRoom, round = shift ? 1 << (shift - 1) : 0;
+            for (int i = tid; i < NN; i += nth)
+                pred[i] = (int16_t)clip3(0, maxVal, ((b.w[l] * ((int)pred[i] + 8192) + round) >> shift) + b.wOff[l]);
             __syncthreads();
         }
         tu_chain<Px, N, false, TAB>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
@@ -813,6 +833,18 @@ extern "C" int x265hip_inter_recon_bi(const x265hip_recon_bi_params* q, void* st
     a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
     a.tab = tu_tables_of(TABLES_OF(p));
     b.fref1 = (const uint8_t*)q->fref1; b.mv1 = (const int2*)q->mv1; b.dir = q->dir;
+    {
+        const x265hip_pred_weight* ws[2] = { q->weight0, q->weight1 };
+        for (int l = 0; l < 2; l++)
+        {
+            b.wHave[l] = ws[l] != nullptr; b.wPresent[l] = 0; b.w[l] = 0; b.wOff[l] = 0; b.wDenomUni[l] = 0;
+            if (!ws[l]) continue;
+            if (ws[l]->log2_denom < 0 || ws[l]->log2_denom > 7 || ws[l]->weight < -128 || ws[l]->weight > 127 || ws[l]->offset < -128 || ws[l]->offset > 127)
+            { set_error("inter_recon_bi: weight %d / offset %d / log2_denom %d of list %d out of range", ws[l]->weight, ws[l]->offset, ws[l]->log2_denom, l); return X265HIP_EINVAL; }
+            b.wPresent[l] = ws[l]->present != 0; b.w[l] = ws[l]->weight; b.wOff[l] = ws[l]->offset * (1 << (p->depth - 8)); b.wDenomUni[l] = ws[l]->log2_denom;
+        }
+        b.wDenom = b.wDenomUni[0];
+    }
     const int nblocks = a.ctusW * (p->height / 64) * (64 >> (2 * p->level));
     hipStream_t s = (hipStream_t)stream;
     auto resident = [&](const void* fn)

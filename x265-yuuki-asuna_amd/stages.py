@@ -81,18 +81,31 @@ class InterRecon:
                 "dist": int(self.dist.sum().item())}
 
 
+class PredWeight(ctypes.Structure):
+    """x265hip_pred_weight (include/x265hip.h)."""
+    _fields_ = [("present", ctypes.c_int), ("weight", ctypes.c_int), ("offset", ctypes.c_int), ("log2_denom", ctypes.c_int)]
+
+
 class ReconBiParams(ctypes.Structure):
     """x265hip_recon_bi_params (include/x265hip.h)."""
-    _fields_ = [("base", ReconParams), ("fref1", ctypes.c_void_p), ("mv1", ctypes.c_void_p), ("dir", ctypes.c_void_p)]
+    _fields_ = [("base", ReconParams), ("fref1", ctypes.c_void_p), ("mv1", ctypes.c_void_p), ("dir", ctypes.c_void_p),
+                ("weight0", ctypes.POINTER(PredWeight)), ("weight1", ctypes.POINTER(PredWeight))]
 
 
 class InterReconBi(InterRecon):
     """The inter TU stage for B pictures (x265hip_inter_recon_bi): per block list 0, list 1 or the average of both
     (predInterLumaShort + addAvg, predict.cpp:168-304)."""
 
-    def run(self, cur: DevicePicture, ref0: DevicePicture, ref1: DevicePicture, recon_plane, mv0, mv1, dir_flags=None, stream=None):
+    def run(self, cur: DevicePicture, ref0: DevicePicture, ref1: DevicePicture, recon_plane, mv0, mv1, dir_flags=None, stream=None, weights=None):
+        """weights: (list 0, list 1), each None (the list has no weight table) or (present, weight, offset, log2_denom) - explicit
+        weighted prediction (addWeightUni / addWeightBi); a P picture with weights is `dir` all 1 with ref1 = ref0."""
         es = 1 if self.depth == 8 else 2
         q = ReconBiParams()
+        keep = []
+        for name, w in zip(("weight0", "weight1"), weights or (None, None)):
+            if w is not None:
+                keep.append(PredWeight(*[int(v) for v in w]))
+                setattr(q, name, ctypes.pointer(keep[-1]))
         p = q.base
         p.depth, p.width, p.height, p.level, p.qp, p.intra_slice = self.depth, self.w64, self.h64, self.level, self.qp, self.intra
         p.fenc, p.fenc_stride = cur.t.data_ptr() + cur.org * es, cur.stride
