@@ -232,6 +232,10 @@ typedef struct x265hip_recon_bi_params
     const x265hip_pred_weight* weight1;
 } x265hip_recon_bi_params;
 int x265hip_inter_recon_bi(const x265hip_recon_bi_params* p, void* stream);
+/* One chroma plane of a 4:2:0 picture through the same stage - predInterChromaPixel / predInterChromaShort (predict.cpp:304-409), the
+ * plane's own weights (WeightParam of Cb or Cr) - with the conventions of x265hip_inter_recon_chroma: planes and strides of the chroma
+ * plane, width / height = LUMA size, mv / mv1 = the luma stage's records, (n/2)^2 levels per block. */
+int x265hip_inter_recon_chroma_bi(const x265hip_recon_bi_params* p, void* stream);
 
 /* Picture border extension (reference extendPicBorder, pixel.cpp:1027-1041 = extendRowBorder slot,
  * ipfilter.cpp:59-77, + top/bottom row replication): `pic` points at pixel (0,0) of a plane that has

@@ -509,6 +509,37 @@ def inter_recon_bi(depth, fenc, stride, org, fref0, fref1, width, height, level,
     return recon, levels, num_sig, dist
 
 
+def inter_recon_chroma_bi(depth, fenc, fref0, fref1, stride, org, width, height, level, mv0, mv1, qp, dir_flags=None, intra_slice=0, nthreads=0,
+                          avx2=False, weights=None):
+    """CPU restatement of one chroma plane of the bi-predictive / weighted inter TU stage (planes share stride / org; width / height =
+    luma size).  Returns (recon, levels, num_sig, dist)."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_inter_recon_chroma_bi_d{depth}")
+    setw = getattr(L, f"x265oracle_set_pred_weights_d{depth}")
+    setw.restype = None
+    setw.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    wrec = [None if (weights is None or w is None) else np.asarray(w, dtype=np.int32) for w in (weights or (None, None))]
+    setw(*[None if w is None else w.ctypes.data for w in wrec])
+    nctu = (width // 64) * (height // 64)
+    n = 4 << level
+    nblk = (32 // n) ** 2
+    recon = np.zeros_like(fenc)
+    levels = np.zeros(nctu * nblk * n * n, dtype=np.int16)
+    num_sig = np.zeros(nctu * nblk, dtype=np.uint32)
+    dist = np.zeros(nctu * nblk, dtype=np.uint64)
+    es = fenc.itemsize
+    m0, m1 = np.ascontiguousarray(mv0, dtype=np.int32), np.ascontiguousarray(mv1, dtype=np.int32)
+    d = None if dir_flags is None else np.ascontiguousarray(dir_flags, dtype=np.uint8)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_void_p, ctypes.c_ssize_t,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    assert fn(fenc.ctypes.data + org * es, stride, fref0.ctypes.data + org * es, fref1.ctypes.data + org * es, stride,
+              recon.ctypes.data + org * es, stride, width, height, level, m0.ctypes.data, m1.ctypes.data, None if d is None else d.ctypes.data,
+              qp, intra_slice, levels.ctypes.data, num_sig.ctypes.data, dist.ctypes.data, nthreads) == 0
+    setw(None, None)
+    return recon, levels, num_sig, dist
+
+
 def phase_planes(depth, src, stride, rows, chroma=False, avx2=False):
     """CPU restatement of x265hip_phase_planes on top of the oracle's interpolation primitives: src = flat padded plane (stride * rows
     samples).  Returns [15 or 63, rows, stride]; the 8-sample border of every plane is zero (undefined in the product)."""

@@ -476,6 +476,141 @@ int EXPORT(x265oracle_inter_recon_chroma)(const pixel* fenc, intptr_t fencStride
     return 0;
 }
 
+/* One chroma plane of the bi-predictive stage (B pictures, and weighted P pictures): Predict::motionCompensation's chroma half
+ * (predict.cpp:77-243) - a block of one list predInterChromaPixel (:304-351), or with a present weight table predInterChromaShort
+ * (:355-409: p2s / filter_hps / filter_vps / filter_hps with row extension + filter_vss) + addWeightUni (:547-576); a block of both
+ * lists the two short predictions combined by addAvg or, with tables, addWeightBi (:458-520).  The plane's own weights come from
+ * x265oracle_set_pred_weights.  Block geometry and outputs as x265oracle_inter_recon_chroma. */
+int EXPORT(x265oracle_inter_recon_chroma_bi)(const pixel* fenc, intptr_t fencStride, const pixel* fref0, const pixel* fref1, intptr_t frefStride,
+                                             pixel* recon, intptr_t reconStride, int width, int height, int level,
+                                             const int32_t* mv0, const int32_t* mv1, const uint8_t* dir, int qp, int flags,
+                                             int16_t* levels, uint32_t* numSigOut, uint64_t* distOut, int nthreads)
+{
+    static x265hip_EncoderPrimitives prim;
+    static int ready = 0;
+    EXPORT(x265oracle_prims_once)(&prim, &ready);
+    const int ctusW = width / 64, nctu = ctusW * (height / 64);
+    const int n = 8 << level, nc = n >> 1, log2nc = 2 + level, npu = (64 / n) * (64 / n);
+    const int puIdx = level == 0 ? X265HIP_LUMA_8x8 : (level == 1 ? X265HIP_LUMA_16x16 : X265HIP_LUMA_32x32);
+    const struct x265hip_PUChroma* pu = &prim.chroma[1].pu[puIdx];       /* X265_CSP_I420 */
+    const struct x265hip_CU* cu = &prim.cu[log2nc - 2];
+    const int per = qp / 6, rem = qp % 6;
+    const int transformShift = 15 - X265HIP_DEPTH - log2nc;
+    const int qbits = 14 + per + transformShift;
+    const int add = ((flags & TU_FLAG_INTRA_SLICE) ? 171 : 85) << (qbits - 9);
+    const int dqShift = 20 - 14 - transformShift;
+    const int dqScale = kInvQuantScales[rem] << per;
+    const int shiftNum = 14 - X265HIP_DEPTH, maxVal = (1 << X265HIP_DEPTH) - 1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int ctu = 0; ctu < nctu; ctu++)
+    {
+        const int cx = (ctu % ctusW) * 32, cy = (ctu / ctusW) * 32;
+        pixel pred[32 * 32] __attribute__((aligned(64)));
+        int16_t ps[2][32 * 32] __attribute__((aligned(64)));
+        int16_t resi[32 * 32] __attribute__((aligned(64)));
+        int16_t coef[16 * 16] __attribute__((aligned(64)));
+        int16_t immed[32 * (32 + 3)] __attribute__((aligned(64)));
+        int32_t quantCoeff[16 * 16] __attribute__((aligned(64)));
+        int32_t deltaU[16 * 16];
+        for (int i = 0; i < nc * nc; i++) quantCoeff[i] = g_tabQuant ? g_tabQuant[i] : kQuantScales[rem];
+        for (int z = 0; z < npu; z++)
+        {
+            int bx, by;
+            zxy(z, &bx, &by);
+            const int px = cx + bx * nc, py = cy + by * nc;
+            const int d = dir ? dir[(size_t)ctu * npu + z] : 3;
+            const pixel* fe = fenc + (intptr_t)py * fencStride + px;
+            pixel* rec = recon + (intptr_t)py * reconStride + px;
+            for (int l = 0; l < 2; l++)
+            {
+                if (!(d & (1 << l))) continue;
+                const int32_t packed = (l ? mv1 : mv0)[((size_t)ctu * 85 + kLvlBase[level] + z) * 2 + 1];
+                const int qx = (int16_t)(packed & 0xffff), qy = (int16_t)(packed >> 16);       /* 1/4 luma = 1/8 chroma samples */
+                const pixel* src = (l ? fref1 : fref0) + (intptr_t)(py + (qy >> 3)) * frefStride + px + (qx >> 3);
+                const int xf = qx & 7, yf = qy & 7;
+                const int32_t* wl = g_predW[l];
+                if (d != 3 && !(wl && wl[0]))
+                {
+                    if (!(xf | yf)) pu->copy_pp(pred, 32, src, frefStride);
+                    else if (!yf) pu->filter_hpp(src, frefStride, pred, 32, xf);
+                    else if (!xf) pu->filter_vpp(src, frefStride, pred, 32, yf);
+                    else
+                    {
+                        pu->filter_hps(src, frefStride, immed, nc, xf, 1);
+                        pu->filter_vsp(immed + 1 * nc, nc, pred, 32, yf);
+                    }
+                }
+                else
+                {
+                    if (!(xf | yf)) pu->p2s[0](src, frefStride, ps[l], 32);
+                    else if (!yf) pu->filter_hps(src, frefStride, ps[l], 32, xf, 0);
+                    else if (!xf) pu->filter_vps(src, frefStride, ps[l], 32, yf);
+                    else
+                    {
+                        pu->filter_hps(src, frefStride, immed, nc, xf, 1);
+                        pu->filter_vss(immed + 1 * nc, nc, ps[l], 32, yf);
+                    }
+                }
+            }
+            if (d == 3)
+            {
+                const int32_t* w0 = g_predW[0]; const int32_t* w1 = g_predW[1];
+                if (w0 && w1 && (w0[0] || w1[0]))
+                {
+                    const int offset = w0[2] * (1 << (X265HIP_DEPTH - 8)) + w1[2] * (1 << (X265HIP_DEPTH - 8));
+                    const int shift = w0[3] + shiftNum + 1, round = shift ? (1 << (shift - 1)) : 0;
+                    for (int y = 0; y < nc; y++)
+                        for (int x = 0; x < nc; x++)
+                        {
+                            const int v = (w0[1] * (ps[0][y * 32 + x] + 8192) + w1[1] * (ps[1][y * 32 + x] + 8192) + round + (offset * (1 << (shift - 1)))) >> shift;
+                            pred[y * 32 + x] = (pixel)(v < 0 ? 0 : (v > maxVal ? maxVal : v));
+                        }
+                }
+                else
+                    pu->addAvg[0](ps[0], ps[1], pred, 32, 32, 32);
+            }
+            else
+            {
+                const int l = d == 2;
+                const int32_t* wl = g_predW[l];
+                if (wl && wl[0])
+                {
+                    const int shift = wl[3] + shiftNum, round = shift ? (1 << (shift - 1)) : 0;
+                    prim.weight_sp(ps[l], pred, 32, 32, nc, nc, wl[1], round, shift, wl[2] * (1 << (X265HIP_DEPTH - 8)));
+                }
+            }
+            cu->sub_ps(resi, 32, fe, pred, fencStride, 32);
+            cu->dct(resi, coef, 32);
+            tab_denoise(coef, nc * nc);
+            int16_t* q = levels + ((size_t)ctu * npu + z) * nc * nc;
+            uint32_t numSig = prim.quant(coef, quantCoeff, deltaU, q, qbits, add, nc * nc);
+            tab_capture(coef, deltaU, (size_t)(q - levels), nc * nc);
+            if ((flags & TU_FLAG_SIGN_HIDE) && numSig >= 2) numSig = sign_hide(q, deltaU, coef, numSig, ORACLE_SCAN_DIAG, log2nc);
+            numSigOut[(size_t)ctu * npu + z] = numSig;
+            if (numSig)
+            {
+                tab_dequant(&prim, q, coef, nc * nc, per, dqScale, dqShift);
+                if (numSig == 1 && q[0] != 0)
+                {
+                    const int shift_2nd = 12 - (X265HIP_DEPTH - 8) - 3;
+                    const int dc = ((((coef[0] * (64 >> 6) + 1) >> 1) * (64 >> 3)) + (1 << (shift_2nd - 1))) >> shift_2nd;
+                    cu->blockfill_s[0](resi, 32, (int16_t)dc);
+                }
+                else
+                    cu->idct(coef, resi, 32);
+                cu->add_ps[0](rec, reconStride, pred, resi, 32, 32);
+            }
+            else
+                cu->copy_pp(rec, reconStride, pred, 32);
+            distOut[(size_t)ctu * npu + z] = (uint64_t)cu->sse_pp(fe, fencStride, rec, reconStride);
+        }
+    }
+    return 0;
+}
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Intra TU candidate set: the pixel work of Search::codeIntraLumaQT for one (TU, mode) candidate
  * (source/encoder/search.cpp:335-373): Predict::predIntraLumaAng (predict.cpp:579-588: filtered neighbours per

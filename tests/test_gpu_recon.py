@@ -186,6 +186,52 @@ def test_inter_recon_bi_with_explicit_weights_matches_oracle(depth, level, qp, w
     assert not torch.equal(st.levels, plain.levels), "the weights changed nothing"
 
 
+@pytest.mark.parametrize("depth,level,qp,w0,w1", [(8, 2, 26, None, None), (8, 1, 30, (1, 45, 6, 6), (1, 70, -9, 6)), (8, 0, 22, (1, 120, 20, 7), (0, 64, 0, 7)),
+                                                  (10, 2, 38, (1, 61, 4, 6), None), (10, 0, 34, None, (1, 127, -128, 7)), (12, 1, 46, (1, -20, 100, 4), (1, 90, 7, 3))])
+def test_inter_recon_chroma_bi_matches_oracle(depth, level, qp, w0, w1):
+    """The chroma planes of a B picture (x265hip_inter_recon_chroma_bi): 1/8-sample 4-tap prediction of one list or both
+    (predInterChromaShort + addAvg), with and without explicit weights (addWeightUni / addWeightBi with the plane's own table)."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng([59, depth, level])
+    clip = F.synth_clip(256, 128, 3, depth=depth, seed=70 + level)
+    pics = [P.DevicePicture(c[0], dev, c[1], c[2]) for c in clip]
+    cur, r0, r1 = pics[1], pics[0], pics[2]
+    nctu = (cur.w64 // 64) * (cur.h64 // 64)
+    mvs = []
+    for _ in range(2):
+        qx, qy = rng.integers(-40, 41, size=nctu * 85), rng.integers(-40, 41, size=nctu * 85)
+        qx[::4] &= ~7; qy[::3] &= ~7                           # integer / h-only / v-only phases too
+        m = np.zeros((nctu * 85, 2), np.int32)
+        m[:, 1] = (qx & 0xffff) | (qy << 16)
+        mvs.append(m)
+    nblk = (64 >> (3 + level)) ** 2
+    dirs = rng.integers(1, 4, size=nctu * nblk).astype(np.uint8)
+    d_mv = [torch.from_numpy(m.reshape(-1)).to(dev) for m in mvs]
+    d_dir = torch.from_numpy(dirs).to(dev)
+    O = _oracle()
+    weights = None if (w0 is None and w1 is None) else (w0, w1)
+    for c in range(2):
+        st = S.InterReconChromaBi(nctu, cur.w64, cur.h64, depth, level, qp - c, dev, intra_slice=2)
+        recon = torch.zeros_like(cur.c[c])
+        st.run(cur.c[c], r0.c[c], r1.c[c], recon, cur.stride_c, cur.org_c, d_mv[0], d_mv[1], dir_flags=d_dir, weights=weights)
+        torch.cuda.synchronize()
+        erec, elev, ens, edist = O.inter_recon_chroma_bi(depth, cur.c_host[c].reshape(-1), r0.c_host[c].reshape(-1), r1.c_host[c].reshape(-1), cur.stride_c, cur.org_c,
+                                                         cur.w64, cur.h64, level, mvs[0], mvs[1], qp - c, dir_flags=dirs, intra_slice=2, weights=weights)
+        assert np.array_equal(st.num_sig.cpu().numpy().view(np.uint32), ens), f"plane {c}: numSig differs"
+        assert np.array_equal(st.levels.cpu().numpy(), elev), f"plane {c}: levels differ"
+        assert np.array_equal(recon.cpu().numpy().view(cur.host.dtype).reshape(-1), erec.reshape(-1)), f"plane {c}: reconstruction differs"
+        assert np.array_equal(st.dist.cpu().numpy().view(np.uint64), edist), f"plane {c}: SSE differs"
+        assert (ens > 0).any()
+        if weights is None:                                    # blocks of one list: exactly the uni-directional chroma stage
+            uni = S.InterReconChroma(nctu, cur.w64, cur.h64, depth, level, qp - c, dev, intra_slice=2)
+            rec_u = torch.zeros_like(cur.c[c])
+            uni.run(cur.c[c], r0.c[c], rec_u, cur.stride_c, cur.org_c, d_mv[0])
+            n = 4 << level
+            only0 = torch.from_numpy(np.repeat(dirs == 1, n * n)).to(dev)
+            assert torch.equal(uni.levels[only0], st.levels[only0])
+
+
 def test_inter_recon_bi_rejects_bad_weights():
     import torch
     dev = torch.device("cuda:0")

@@ -552,19 +552,24 @@ struct TuBiArgs
     int wHave[2], wPresent[2], w[2], wOff[2], wDenom, wDenomUni[2];   // explicit weights of the two lists (wOff scaled to the bit depth; wDenom = list 0's)
 };
 
-template <typename Px, int N, bool TAB = false>
+// CHROMA: one chroma plane of a 4:2:0 picture (N = the chroma block size, 1/8-sample mvs, the 4-tap filters; predInterChromaShort,
+// predict.cpp:355-409, for the short predictions)
+template <typename Px, int N, bool CHROMA, bool TAB = false>
 __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBiArgs b, int nblocks)
 {
     const TuArgs& a = b.t;
-    constexpr int NN = N * N, LOG2N = N == 8 ? 3 : (N == 16 ? 4 : 5), PW = N + 7, PP = N + 8;
+    constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
+    constexpr int TAPS = CHROMA ? 4 : 8, APRON = TAPS / 2 - 1, PW = N + TAPS - 1, PP = PW + 1;
+    constexpr int NL = CHROMA ? 2 * N : N, CTU = CHROMA ? 32 : 64, MVSH = CHROMA ? 3 : 2, MVMASK = CHROMA ? 7 : 3;
     constexpr int BPP = sizeof(Px);
+    auto tap = [](int f, int t) { return CHROMA ? (int)kTuChromaTaps[f][t] : (int)kTuTaps[f][t]; };
     __shared__ int16_t patch[PW * PP];
     __shared__ int16_t immed[PW * N];
     __shared__ int16_t pred[NN], ps0[NN], fe[NN], A[NN], B[NN];
     __shared__ unsigned long long red[4];
     __shared__ int sNumSig;
-    const int npu = (64 / N) * (64 / N);
-    const int lbase = N == 8 ? 0 : (N == 16 ? 64 : 80);
+    const int npu = (64 / NL) * (64 / NL);
+    const int lbase = NL == 8 ? 0 : (NL == 16 ? 64 : 80);
     const int tid = threadIdx.x, nth = blockDim.x;
     const int maxVal = (1 << a.depth) - 1, headRoom = 14 - a.depth;
     TuOpsFor<N, false> ops;
@@ -573,7 +578,7 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBi
     {
         const int ctu = blk / npu, z = blk - ctu * npu;
         const int bxz = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), byz = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
-        const int px = (ctu % a.ctusW) * 64 + bxz * N, py = (ctu / a.ctusW) * 64 + byz * N;
+        const int px = (ctu % a.ctusW) * CTU + bxz * N, py = (ctu / a.ctusW) * CTU + byz * N;
         const int d = b.dir ? b.dir[blk] : 3;
         {
             const Px* f = reinterpret_cast<const Px*>(a.fenc + (long)py * a.fencStrideB) + px;
@@ -586,11 +591,11 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBi
             if (!(d & (1 << l))) continue;                              // uniform over the workgroup
             const int packed = (l ? b.mv1 : a.mv)[(size_t)ctu * 85 + lbase + z].y;
             const int qx = (int16_t)(packed & 0xffff), qy = (int16_t)(packed >> 16);
-            const int xf = qx & 3, yf = qy & 3;
+            const int xf = qx & MVMASK, yf = qy & MVMASK;
             __syncthreads();                                            // the patch of the other list is no longer read
             {
                 const uint8_t* plane = l ? b.fref1 : a.fref;
-                const Px* r = reinterpret_cast<const Px*>(plane + (long)(py + (qy >> 2) - 3) * a.frefStrideB) + (px + (qx >> 2) - 3);
+                const Px* r = reinterpret_cast<const Px*>(plane + (long)(py + (qy >> MVSH) - APRON) * a.frefStrideB) + (px + (qx >> MVSH) - APRON);
                 const long rst = a.frefStrideB / BPP;
                 for (int i = tid; i < PW * PW; i += nth) { const int y = i / PW, x = i - y * PW; patch[y * PP + x] = (int16_t)r[y * rst + x]; }
             }
@@ -606,7 +611,7 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBi
                     const int y = i >> LOG2N, x = i & (N - 1);
                     int s = 0;
 #pragma unroll
-                    for (int t = 0; t < 8; t++) s += (int)patch[y * PP + x + t] * kTuTaps[xf][t];
+                    for (int t = 0; t < TAPS; t++) s += (int)patch[y * PP + x + t] * tap(xf, t);
                     immed[i] = (int16_t)((s + offPS) >> shiftPS);
                 }
                 __syncthreads();
@@ -616,7 +621,7 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBi
                     const int y = i >> LOG2N, x = i & (N - 1);
                     int s = 0;
 #pragma unroll
-                    for (int t = 0; t < 8; t++) s += (int)immed[(y + t) * N + x] * kTuTaps[yf][t];
+                    for (int t = 0; t < TAPS; t++) s += (int)immed[(y + t) * N + x] * tap(yf, t);
                     out[i] = shortOut ? (int16_t)(s >> 6) : (int16_t)tu_clip16((s + offSP) >> shiftSP, maxVal);      // luma_vss : luma_vsp
                 }
             }
@@ -628,15 +633,15 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBi
                     int v;
                     if (!(xf | yf))
                     {
-                        const int c = patch[(y + 3) * PP + x + 3];
+                        const int c = patch[(y + APRON) * PP + x + APRON];
                         v = shortOut ? (int16_t)((c << headRoom) - 8192) : c;                                         // convert_p2s : copy_pp
                     }
                     else
                     {
                         int s = 0;
 #pragma unroll
-                        for (int t = 0; t < 8; t++)
-                            s += (int)(xf ? patch[(y + 3) * PP + x + t] : patch[(y + t) * PP + x + 3]) * kTuTaps[xf ? xf : yf][t];
+                        for (int t = 0; t < TAPS; t++)
+                            s += (int)(xf ? patch[(y + APRON) * PP + x + t] : patch[(y + t) * PP + x + APRON]) * tap(xf ? xf : yf, t);
                         v = shortOut ? (int16_t)((s + offPS) >> shiftPS) : tu_clip16((s + 32) >> 6, maxVal);           // luma_hps / vps : hpp / vpp
                     }
                     out[i] = (int16_t)v;
@@ -810,7 +815,7 @@ extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
     return 0;
 }
 
-extern "C" int x265hip_inter_recon_bi(const x265hip_recon_bi_params* q, void* stream)
+static int inter_recon_bi_impl(const x265hip_recon_bi_params* q, void* stream, const bool chroma)
 {
     int rc = ensure_device();
     if (rc) return rc;
@@ -857,16 +862,26 @@ extern "C" int x265hip_inter_recon_bi(const x265hip_recon_bi_params* q, void* st
         return (int)(nblocks < r ? nblocks : r);
     };
 #define GOB_T(PX, TB) do { \
-        if (p->level == 0) hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 8, TB>), dim3(nblocks), dim3(64), 0, s, b, nblocks); \
-        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 16, TB>), dim3(resident((const void*)inter_recon_bi_kernel<PX, 16, TB>)), dim3(64), 0, s, b, nblocks); \
-        else hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 32, TB>), dim3(resident((const void*)inter_recon_bi_kernel<PX, 32, TB>)), dim3(64), 0, s, b, nblocks); } while (0)
-#define GOB(PX) do { if (p->tables) GOB_T(PX, true); else GOB_T(PX, false); } while (0)
+        if (p->level == 0) hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 8, false, TB>), dim3(nblocks), dim3(64), 0, s, b, nblocks); \
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 16, false, TB>), dim3(resident((const void*)inter_recon_bi_kernel<PX, 16, false, TB>)), dim3(64), 0, s, b, nblocks); \
+        else hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 32, false, TB>), dim3(resident((const void*)inter_recon_bi_kernel<PX, 32, false, TB>)), dim3(64), 0, s, b, nblocks); } while (0)
+#define GOBC_T(PX, TB) do { \
+        if (p->level == 0) hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 4, true, TB>), dim3(nblocks), dim3(64), 0, s, b, nblocks); \
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 8, true, TB>), dim3(nblocks), dim3(64), 0, s, b, nblocks); \
+        else hipLaunchKernelGGL((inter_recon_bi_kernel<PX, 16, true, TB>), dim3(resident((const void*)inter_recon_bi_kernel<PX, 16, true, TB>)), dim3(64), 0, s, b, nblocks); } while (0)
+#define GOB(PX) do { if (chroma) { if (p->tables) GOBC_T(PX, true); else GOBC_T(PX, false); } else { if (p->tables) GOB_T(PX, true); else GOB_T(PX, false); } } while (0)
     if (p->depth == 8) GOB(uint8_t); else GOB(uint16_t);
 #undef GOB_T
+#undef GOBC_T
 #undef GOB
     X265HIP_TRY(hipGetLastError());
     return 0;
 }
+
+extern "C" int x265hip_inter_recon_bi(const x265hip_recon_bi_params* q, void* stream) { return inter_recon_bi_impl(q, stream, false); }
+/* one chroma plane of a 4:2:0 picture through the same stage (width / height = LUMA size, the luma stage's mv records, the plane's own
+ * QP and weights) */
+extern "C" int x265hip_inter_recon_chroma_bi(const x265hip_recon_bi_params* q, void* stream) { return inter_recon_bi_impl(q, stream, true); }
 
 // One or both chroma planes of a picture: the same kernel, grid.y = plane.
 static int inter_recon_chroma_planes(const x265hip_recon_params* const* pp, int nplanes, void* stream)

@@ -167,6 +167,27 @@ class InterReconChroma:
         hipabi.check(f(ctypes.byref(ps[0]), ctypes.byref(ps[1]), s), "x265hip_inter_recon_chroma_pair")
 
 
+class InterReconChromaBi(InterReconChroma):
+    """One chroma plane of a B picture (or of a P picture with explicit weights): x265hip_inter_recon_chroma_bi - per block list 0,
+    list 1 or both, with the plane's own weights (Predict::motionCompensation's chroma half, predict.cpp:77-243, 304-409)."""
+
+    def run(self, fenc, fref0, fref1, recon, stride, org, mv0, mv1, dir_flags=None, stream=None, weights=None):
+        q = ReconBiParams()
+        q.base = self.params(fenc, fref0, recon, stride, org, mv0)          # copied into the record
+        es = 1 if self.depth == 8 else 2
+        q.fref1, q.mv1 = fref1.data_ptr() + org * es, mv1.data_ptr()
+        q.dir = None if dir_flags is None else dir_flags.data_ptr()
+        keep = []
+        for name, w in zip(("weight0", "weight1"), weights or (None, None)):
+            if w is not None:
+                keep.append(PredWeight(*[int(v) for v in w]))
+                setattr(q, name, ctypes.pointer(keep[-1]))
+        s = hipabi.current_stream() if stream is None else stream
+        f = hipabi.lib().x265hip_inter_recon_chroma_bi
+        f.argtypes = [ctypes.POINTER(ReconBiParams), ctypes.c_void_p]
+        hipabi.check(f(ctypes.byref(q), s), "x265hip_inter_recon_chroma_bi")
+
+
 def extend_border_rows(plane, pic: DevicePicture, top: bool, bottom: bool, stream=None, chroma=False):
     """Row-wise border extension of the band `pic` is a view of (x265hip_extend_border_rows): left / right margins of the band's rows, the
     picture's top margin when the band is its first, the bottom margin when it is its last."""
