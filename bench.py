@@ -500,7 +500,10 @@ def main():
                                         else f"frame-parallel x{world}") if not banded else
                                        f"frame-parallel ring x{world}: frame f on rank f % {world} searches frame f - 1, handed on in bands of {args.band_rows} CTU rows "
                                        f"(each band a slice of its own, like the reference's --slices)"),
-                       "ctus_per_frame": ms.nctu, "checksum": csum},
+                       "ctus_per_frame": ms.nctu, "checksum": csum,
+                       **({"band_rows": args.band_rows, "band_streams": args.band_streams,
+                           "ring_model": "N pictures per max(step, N x lag), lag = the band periods until the reference rows a band's search window "
+                                         "reaches are final + a hand-over (DESIGN.md section 6; band size chosen from N by pick_band_rows)"} if banded else {})},
             "stages_ms": stages,
             "roofline": {"bound": "hbm", "kernel": "me_search_kernel" if args.search != "full" else
                                    (("me_ctu_c_kernel" if surf_mode and ms.tiled else "me_ctu_q_kernel") if args.depth == 8 else "me_ctu_w_kernel")
