@@ -509,6 +509,24 @@ def inter_recon_bi(depth, fenc, stride, org, fref0, fref1, width, height, level,
     return recon, levels, num_sig, dist
 
 
+class pred_capture:
+    """Context manager: the inter stages called inside copy every block's PREDICTION into `plane` (unpadded 2-D array of the stage's
+    geometry: width x height for the luma stages, half of that for the chroma stages)."""
+
+    def __init__(self, depth, plane, avx2=False):
+        self.fn = getattr(lib(avx2), f"x265oracle_set_pred_capture_d{depth}")
+        self.fn.restype = None
+        self.fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t]
+        self.plane = plane
+
+    def __enter__(self):
+        self.fn(self.plane.ctypes.data, self.plane.shape[1])
+        return self.plane
+
+    def __exit__(self, *exc):
+        self.fn(None, 0)
+
+
 def inter_recon_chroma_bi(depth, fenc, fref0, fref1, stride, org, width, height, level, mv0, mv1, qp, dir_flags=None, intra_slice=0, nthreads=0,
                           avx2=False, weights=None):
     """CPU restatement of one chroma plane of the bi-predictive / weighted inter TU stage (planes share stride / org; width / height =

@@ -147,6 +147,15 @@ static void tab_capture(const int16_t* coef, const int32_t* deltaU, size_t elemO
     if (g_capDct) memcpy(g_capDct + elemOff, coef, (size_t)num * sizeof(int16_t));
     if (g_capDeltaU) memcpy(g_capDeltaU + elemOff, deltaU, (size_t)num * sizeof(int32_t));
 }
+/* capture of the PREDICTION of every block (before the residual round trip) into an unpadded plane of the stage's geometry - lets
+ * tests compare the prediction half of the inter stages with the real Predict::motionCompensation (oracle/ref_predict.cpp) */
+static pixel* g_capPred; static intptr_t g_capPredStride;
+void EXPORT(x265oracle_set_pred_capture)(pixel* plane, intptr_t stride) { g_capPred = plane; g_capPredStride = stride; }
+static void cap_pred(const pixel* pred, int predStride, int px, int py, int n)
+{
+    if (!g_capPred) return;
+    for (int y = 0; y < n; y++) memcpy(g_capPred + (intptr_t)(py + y) * g_capPredStride + px, pred + y * predStride, sizeof(pixel) * n);
+}
 static void tab_denoise(int16_t* coef, int num)          /* denoiseDct with the sums added atomically (the callers run CTUs in parallel) */
 {
     if (!g_tabNrOffset) return;
@@ -217,6 +226,7 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
             else if (!xf) pu->luma_vpp(src, frefStride, pred, 64, yf);
             else pu->luma_hvpp(src, frefStride, pred, 64, xf, yf);
             /* residual, transform, quantisation */
+            cap_pred(pred, 64, px, py, n);
             cu->sub_ps(resi, 64, fe, pred, fencStride, 64);
             cu->dct(resi, coef, 64);
             tab_denoise(coef, n * n);
@@ -361,6 +371,7 @@ int EXPORT(x265oracle_inter_recon_bi)(const pixel* fenc, intptr_t fencStride, co
                     prim.weight_sp(ps[l], pred, 64, 64, n, n, wl[1], round, shift, wl[2] * (1 << (X265HIP_DEPTH - 8)));
                 }
             }
+            cap_pred(pred, 64, px, py, n);
             cu->sub_ps(resi, 64, fe, pred, fencStride, 64);
             cu->dct(resi, coef, 64);
             tab_denoise(coef, n * n);
@@ -447,6 +458,7 @@ int EXPORT(x265oracle_inter_recon_chroma)(const pixel* fenc, intptr_t fencStride
                 pu->filter_hps(src, frefStride, immed, nc, xf, 1);
                 pu->filter_vsp(immed + 1 * nc, nc, pred, 32, yf);
             }
+            cap_pred(pred, 32, px, py, nc);
             cu->sub_ps(resi, 32, fe, pred, fencStride, 32);
             cu->dct(resi, coef, 32);
             tab_denoise(coef, nc * nc);
@@ -582,6 +594,7 @@ int EXPORT(x265oracle_inter_recon_chroma_bi)(const pixel* fenc, intptr_t fencStr
                     prim.weight_sp(ps[l], pred, 32, 32, nc, nc, wl[1], round, shift, wl[2] * (1 << (X265HIP_DEPTH - 8)));
                 }
             }
+            cap_pred(pred, 32, px, py, nc);
             cu->sub_ps(resi, 32, fe, pred, fencStride, 32);
             cu->dct(resi, coef, 32);
             tab_denoise(coef, nc * nc);

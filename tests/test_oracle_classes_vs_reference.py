@@ -1281,3 +1281,76 @@ def test_tu_scaling_lists_and_denoiser_equal_reference_quant_class(depth, n, qp,
             assert np.array_equal(osum, rsum) and rsum.sum() > 0
     finally:
         O.set_tu_tables(depth)
+
+
+@pytest.mark.parametrize("depth,level,slice_b,use_wp,use_wbp,wl0,wl1", [
+    (8, 2, 0, 0, 0, None, None),                                                                   # plain P picture
+    (8, 1, 0, 1, 0, [(1, 45, 6, 6), (1, 70, -9, 5), (1, 60, 3, 6)], None),                          # weighted P picture
+    (8, 0, 1, 0, 0, None, None),                                                                   # B picture, addAvg
+    (8, 2, 1, 0, 1, [(1, 45, 6, 6), (1, 70, -9, 6), (0, 64, 0, 6)], [(1, 70, -9, 6), (0, 64, 0, 6), (1, 50, 10, 6)]),   # weighted B
+    (10, 1, 1, 0, 1, [(0, 64, 0, 6), (0, 64, 0, 6), (0, 64, 0, 6)], [(1, 127, -128, 7), (1, 3, 1, 0), (1, -20, 100, 4)]),
+    (10, 2, 0, 1, 0, [(1, 120, 20, 7), (0, 64, 0, 6), (1, 1, 0, 0)], None),
+    (12, 1, 1, 0, 1, [(1, -20, 100, 4), (1, 90, 7, 3), (1, 33, -4, 5)], [(1, 90, 7, 3), (1, 61, 4, 6), (0, 1, 0, 0)])])
+def test_inter_stage_predictions_equal_the_real_motion_compensation(depth, level, slice_b, use_wp, use_wbp, wl0, wl1):
+    """The PREDICTION half of the oracle's inter TU stages - uni- and bi-directional, luma and both 4:2:0 chroma planes, explicit
+    weights per list and plane (addWeightUni / addWeightBi), every fractional phase - against the real Predict::motionCompensation
+    driven CU by CU (oracle/ref_predict.cpp): P slices with / without pps.bUseWeightPred, B slices with / without bUseWeightedBiPred."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_motion_compensation"):
+        pytest.skip("oracle/_ref predates x265ref_motion_compensation")
+    rng = np.random.default_rng([61, depth, level, slice_b])
+    width, height = 256, 128
+    clip = F.synth_clip(width, height, 3, depth=depth, seed=75 + level)
+    luma = [F.pad_plane(c[0]) for c in clip]
+    stride, org, w64, h64 = luma[0][1:5]
+    def edge_pad(img, margin=24):                          # (flat plane, stride, org) with replicated edges, like extendPicBorder
+        buf = np.ascontiguousarray(np.pad(img, margin, mode="edge"))
+        return buf.reshape(-1), img.shape[1] + 2 * margin, margin * (img.shape[1] + 2 * margin) + margin
+    chroma = [[edge_pad(np.ascontiguousarray(c[k])) for k in (1, 2)] for c in clip]
+    nctu = (w64 // 64) * (h64 // 64)
+    mvs = []
+    for _ in range(2):
+        qx, qy = rng.integers(-40, 41, size=nctu * 85), rng.integers(-40, 41, size=nctu * 85)
+        qx[::4] &= ~7; qy[::3] &= ~7; qx[1::5] &= ~3
+        m = np.zeros((nctu * 85, 2), np.int32)
+        m[:, 1] = (qx & 0xffff) | (qy << 16)
+        mvs.append(m)
+    nblk = (64 >> (3 + level)) ** 2
+    dirs = rng.integers(1, 4, size=nctu * nblk).astype(np.uint8) if slice_b else np.ones(nctu * nblk, np.uint8)
+    none3 = [(0, 1, 0, 0)] * 3
+    wtab = np.asarray([wl0 or none3, wl1 or none3], dtype=np.int32)
+    dt = clip[0][0].dtype
+    ry, rcb, rcr = np.zeros((height, width), dt), np.zeros((height // 2, width // 2), dt), np.zeros((height // 2, width // 2), dt)
+    compact = lambda a: np.ascontiguousarray(a)
+    lib.x265ref_motion_compensation.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
+    c0, c1 = [compact(clip[0][k]) for k in (1, 2)], [compact(clip[2][k]) for k in (1, 2)]
+    assert lib.x265ref_motion_compensation(luma[0][0].ctypes.data, c0[0].ctypes.data, c0[1].ctypes.data, luma[2][0].ctypes.data, c1[0].ctypes.data, c1[1].ctypes.data,
+                                           width, height, level, mvs[0].ctypes.data, mvs[1].ctypes.data, dirs.ctypes.data, slice_b, use_wp, use_wbp,
+                                           wtab.ctypes.data, ry.ctypes.data, rcb.ctypes.data, rcr.ctypes.data) == 0
+    # the oracle's view of the same picture: a list has a weight table iff the slice type's flag is on
+    have = (bool(use_wp), False) if not slice_b else (bool(use_wbp), bool(use_wbp))
+    def wplane(p):
+        return tuple(tuple(int(v) for v in wtab[l][p]) if have[l] else None for l in range(2))
+    cur = luma[1][0]
+    py = np.zeros((height, width), dt)
+    with O.pred_capture(depth, py):
+        O.inter_recon_bi(depth, cur.reshape(-1), stride, org, luma[0][0].reshape(-1), luma[2][0].reshape(-1), w64, h64, level, mvs[0], mvs[1], 30 + 6 * (depth - 8),
+                         dir_flags=dirs, weights=wplane(0))
+    assert np.array_equal(py, ry), f"luma: {np.count_nonzero(py != ry)} predicted samples differ from Predict::motionCompensation"
+    for k, rc in ((0, rcb), (1, rcr)):
+        pc = np.zeros((height // 2, width // 2), dt)
+        cst, corg = chroma[1][k][1], chroma[1][k][2]
+        with O.pred_capture(depth, pc):
+            O.inter_recon_chroma_bi(depth, chroma[1][k][0], chroma[0][k][0], chroma[2][k][0], cst, corg, w64, h64, level, mvs[0], mvs[1], 30 + 6 * (depth - 8),
+                                    dir_flags=dirs, weights=wplane(1 + k))
+        assert np.array_equal(pc, rc), f"chroma plane {k}: {np.count_nonzero(pc != rc)} predicted samples differ"
+    if not slice_b and not use_wp:                      # the uni-directional stages (x265hip_inter_recon / _chroma) predict the same picture
+        py2 = np.zeros((height, width), dt)
+        with O.pred_capture(depth, py2):
+            O.inter_recon(depth, cur.reshape(-1), stride, org, luma[0][0].reshape(-1), stride, org, w64, h64, level, mvs[0], 30 + 6 * (depth - 8))
+        assert np.array_equal(py2, ry)
+        pc2 = np.zeros((height // 2, width // 2), dt)
+        with O.pred_capture(depth, pc2):
+            O.inter_recon_chroma(depth, chroma[1][0][0], chroma[0][0][0], chroma[1][0][1], chroma[1][0][2], w64, h64, level, mvs[0], 30 + 6 * (depth - 8))
+        assert np.array_equal(pc2, rcb)
