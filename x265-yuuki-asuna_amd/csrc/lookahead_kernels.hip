@@ -739,7 +739,10 @@ extern "C" int x265hip_aq_hevc_offsets(const x265hip_aq_hevc_offsets_params* p)
     if (p->avg_activity) *p->avg_activity = dAvgAct;
     for (int i = 0; i < pw * ph; i++)
     {
-        const double dMaxQScale = std::pow(2.0, p->qp_adaptation_range / 6.0);
+        // the reference calls pow(2.0, x); a compiler that rewrites that into exp2(x) (LLVM does) is one ulp off for most x - the base is
+        // read through a volatile so that the C library's pow is what runs
+        static const volatile double kTwo = 2.0;
+        const double dMaxQScale = std::pow(kTwo, p->qp_adaptation_range / 6.0);
         const double dNormAct = (dMaxQScale * p->activity[i] + dAvgAct) / (p->activity[i] + dMaxQScale * dAvgAct);
         p->qp_offset[i] = (std::log2(dNormAct) / std::log2(2.0)) * 6.0;
         if (p->inv_qscale) p->inv_qscale[i] = aq_exp2fix8(p->qp_offset[i]);
