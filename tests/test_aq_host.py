@@ -34,3 +34,56 @@ def test_aq_offsets_reject_bad_arguments():
     for args in ((8, 32, 2, 1.0), (9, 16, 2, 1.0), (8, 16, 4, 1.0)):
         with pytest.raises(A.X265HipError):
             A.aq_offsets(*args, e)
+
+
+def test_host_side_double_math_equals_oracle_on_random_parameters():
+    """The library's host-side functions are compiled by another compiler (clang, inside the .hip files) than the oracle and the
+    reference (gcc): a libcall rewrite or a contraction there is a one-ulp difference that round parameter values hide (one such case:
+    pow(2.0, x) -> exp2(x) in the --hevc-aq offsets).  Random strengths / ranges / costs through x265hip_aq_offsets and
+    x265hip_aq_hevc_offsets against the oracle's (reference-pinned) restatements."""
+    import oracle_api as O
+    rng = np.random.default_rng(2027)
+    for it in range(24):
+        depth = int(rng.choice([8, 10, 12]))
+        w, h = 16 * int(rng.integers(4, 24)), 16 * int(rng.integers(3, 14))
+        y = F.synth_clip(w, h, 1, depth=depth, seed=int(rng.integers(1, 1 << 30)))[0][0]
+        yp, stride, org, _, _ = F.pad_plane(y)
+        mode, qg, strength = int(rng.integers(1, 4)), int(rng.choice([8, 16])), float(rng.uniform(0.05, 3.0))
+        energy, qp, inv, _, _ = O.aq_frame(depth, yp, stride, org, w, h, qg_size=qg, aq_mode=mode, aq_strength=strength, weightp=False)
+        got_qp, got_inv = A.aq_offsets(depth, qg, mode, strength, energy)
+        assert np.array_equal(got_qp, qp) and np.array_equal(got_inv, inv), f"aq_offsets: depth {depth} mode {mode} qg {qg} strength {strength!r}"
+        w2, h2, qg2, span = 2 * int(rng.integers(20, 160)), 2 * int(rng.integers(20, 120)), int(rng.choice([8, 16, 32, 64])), float(rng.uniform(1.0, 6.0))
+        y2 = F.synth_clip(w2, h2, 1, depth=depth, seed=int(rng.integers(1, 1 << 30)))[0][0]
+        yp2, stride2, org2, _, _ = F.pad_plane(y2)
+        parts, act, qpo, avg, einv, _, _ = O.aq_hevc_frame(depth, yp2, stride2, org2, w2, h2, qg_size=qg2, qp_adaptation_range=span, weightp=False)
+        at = 0
+        for d in range(4):
+            if not parts[d]:
+                continue
+            a, q, g, iv = A.aq_hevc_offsets(w2, h2, 64 >> d, span, O.aq_hevc_quadrants(depth, yp2, stride2, org2, w2, h2, 64 >> d))
+            assert np.array_equal(a, act[at:at + parts[d]]) and np.array_equal(q, qpo[at:at + parts[d]]) and g == avg[d], \
+                f"aq_hevc_offsets: {w2}x{h2} depth {depth} qg {qg2} layer {d} range {span!r}"
+            at += parts[d]
+
+
+def test_cutree_host_side_equals_oracle_on_random_parameters():
+    """x265hip_cutree_finish / x265hip_frame_cost_recalculate (host-side, clang-compiled) against the oracle on random costs, strengths,
+    weight deltas and frame-rate factors."""
+    import oracle_api as O
+    rng = np.random.default_rng(2028)
+    for it in range(40):
+        wcu, hcu = int(rng.integers(2, 40)), int(rng.integers(2, 30))
+        n = wcu * hcu
+        intra = rng.integers(0, 4000, size=n).astype(np.int32)
+        invq = rng.integers(1, 1024, size=n).astype(np.int32)
+        prop = rng.integers(0, 65536, size=n).astype(np.uint16)
+        qpaq = rng.uniform(-3, 3, size=n)
+        preset = rng.uniform(-5, 5, size=n)
+        fps_q8, wdelta, strength = int(rng.integers(1, 2000)), float(rng.uniform(0, 1)) * int(rng.integers(0, 2)), float(rng.uniform(0.1, 6.0))
+        want = O.cutree_finish(8, intra, invq, prop, qpaq, fps_q8, wdelta, strength, preset.copy())
+        got = A.cutree_finish(intra, invq, prop, qpaq, fps_q8, wdelta, strength, preset.copy())
+        assert np.array_equal(got, want), f"cutree_finish: {wcu}x{hcu} strength {strength!r} delta {wdelta!r}"
+        lc = rng.integers(0, 65536, size=n).astype(np.uint16)
+        score_w, rows_w = O.frame_cost_recalculate(8, wcu, hcu, lc, got)
+        score_g, rows_g = A.frame_cost_recalculate(wcu, hcu, lc, got)
+        assert score_g == score_w and np.array_equal(rows_g, rows_w), f"frame_cost_recalculate: {wcu}x{hcu}"
