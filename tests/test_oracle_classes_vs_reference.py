@@ -455,7 +455,7 @@ def test_adaptive_quant_pass_equals_reference_class(depth, width, height, qg, mo
 
 @pytest.mark.parametrize("depth,width,height,qg,rng,chroma", [(8, 256, 128, 16, 1.0, True), (8, 208, 144, 32, 2.5, True), (8, 250, 138, 64, 1.0, False),
                                                               (8, 192, 136, 8, 6.0, True), (10, 192, 128, 16, 1.0, True), (10, 232, 120, 8, 3.0, False),
-                                                              (12, 128, 80, 32, 1.0, True), (12, 136, 72, 64, 2.0, False)])
+                                                              (12, 128, 80, 32, 1.0, True), (12, 136, 72, 64, 2.0, False), (8, 304, 206, 16, 4.0762005658023845, False), (10, 202, 94, 8, 5.123456789, False)])
 def test_hevc_aq_pass_equals_reference_class(depth, width, height, qg, rng, chroma, seed=101):
     """--hevc-aq: LookaheadTLD::xPreanalyze / xPreanalyzeQp inside calcAdaptiveQuantFrame (slicetype.cpp:293-441, 507-511) - quadrant
     variances of every enabled layer's partitions (clipped at the picture edge), activities, the layers' QP offsets, invQscaleFactor from
