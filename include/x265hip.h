@@ -217,7 +217,9 @@ int x265hip_inter_recon_chroma_pair(const x265hip_recon_params* cb, const x265hi
  * both tables exist and at least one is present - with list 0's denominator for both, as the reference does - and addAvg otherwise. */
 typedef struct x265hip_pred_weight
 {
-    int present;          /* WeightParam::wtPresent */
+    int present;          /* WeightParam::wtPresent of the reference picture's LUMA entry - also for a chroma plane: the reference decides
+                           * weighted prediction for all three planes on the luma entry (pwp->wtPresent, predict.cpp:94, :187, :196) and
+                           * then takes weight / offset / denominator from the plane's own entry */
     int weight;           /* inputWeight */
     int offset;           /* inputOffset (8-bit domain; scaled by 1 << (depth - 8) inside) */
     int log2_denom;       /* log2WeightDenom */

@@ -262,7 +262,8 @@ int EXPORT(x265oracle_inter_recon)(const pixel* fenc, intptr_t fencStride, const
  * combine them with addAvg (pixel.cpp: (a + b + offset) >> shift at 14-bit intermediate precision).  mv0 / mv1: the two lists'
  * records in the sub-pel stage's format; dir: uint8 [ctu][npu] or NULL (all 3). */
 /* Explicit weighted prediction of the bi-predictive stage (x265hip_recon_bi_params.weight0 / weight1): the two lists' WeightParam of
- * the luma plane as { wtPresent, inputWeight, inputOffset, log2WeightDenom }, NULL = that list has no table (P slices without
+ * the plane as { wtPresent OF THE LUMA ENTRY (what the reference tests for every plane), inputWeight, inputOffset, log2WeightDenom },
+ * NULL = that list has no table (P slices without
  * pps.bUseWeightPred, B slices without pps.bUseWeightedBiPred).  Predict::motionCompensation (predict.cpp:77-243): a block predicted
  * from one list whose table is present takes predInterLumaShort + addWeightUni (weight_sp, :525-545); a block predicted from both
  * takes addWeightBi (:411-456, weightBidir :52-55) when both tables exist and one is present, otherwise addAvg.  Test infrastructure:

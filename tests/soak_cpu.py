@@ -37,7 +37,19 @@ def s_lowres(r):
     fn = T.test_lowres_b_frame_cost_restatement_equals_reference_classes if r.integers(0, 2) else T.test_lowres_frame_cost_restatement_equals_reference_classes
     fn(int(r.choice([8, 10])), int(r.choice([192, 208, 256])), int(r.choice([128, 144])), seed=int(r.integers(1, 1 << 30)), check_coverage=False)
 
-stages = [("search drivers (DIA / HEX / UMH / STAR)", s_search), ("lookahead frame cost (P / B)", s_lowres), ("SEA search", s_sea), ("cuTree step", s_cutree), ("weight analysis", s_weights), ("adaptive quantisation", s_aq), ("boundary strengths (B)", s_bs)]
+def s_hevc_aq(r):
+    chroma = bool(r.integers(0, 2))
+    qg = int(r.choice([8, 16, 32, 64]))
+    w, h = (16 * int(r.integers(6, 24)), 16 * int(r.integers(4, 14))) if chroma else (2 * int(r.integers(40, 180)), 2 * int(r.integers(30, 110)))
+    T.test_hevc_aq_pass_equals_reference_class(int(r.choice([8, 10, 12])), w, h, qg, float(r.uniform(1.0, 6.0)), chroma, seed=int(r.integers(1, 1 << 30)))
+def s_predict(r):
+    def table(): return [(int(r.integers(0, 2)), int(r.integers(-128, 128)), int(r.integers(-128, 128)), int(r.integers(0, 8))) for _ in range(3)]
+    slice_b = int(r.integers(0, 2))
+    flag = int(r.integers(0, 2))
+    T.test_inter_stage_predictions_equal_the_real_motion_compensation(int(r.choice([8, 10, 12])), int(r.integers(0, 3)), slice_b, flag if not slice_b else 0,
+                                                                      flag if slice_b else 0, table(), table(), seed=int(r.integers(1, 1 << 20)))
+
+stages = [("--hevc-aq pass", s_hevc_aq), ("inter prediction (uni / bi, weighted, luma + chroma)", s_predict), ("search drivers (DIA / HEX / UMH / STAR)", s_search), ("lookahead frame cost (P / B)", s_lowres), ("SEA search", s_sea), ("cuTree step", s_cutree), ("weight analysis", s_weights), ("adaptive quantisation", s_aq), ("boundary strengths (B)", s_bs)]
 counts = {n: 0 for n, _ in stages}
 t0, fail = time.time(), 0
 while time.time() - t0 < budget and not fail:

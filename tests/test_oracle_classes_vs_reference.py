@@ -1291,7 +1291,7 @@ def test_tu_scaling_lists_and_denoiser_equal_reference_quant_class(depth, n, qp,
     (10, 1, 1, 0, 1, [(0, 64, 0, 6), (0, 64, 0, 6), (0, 64, 0, 6)], [(1, 127, -128, 7), (1, 3, 1, 0), (1, -20, 100, 4)]),
     (10, 2, 0, 1, 0, [(1, 120, 20, 7), (0, 64, 0, 6), (1, 1, 0, 0)], None),
     (12, 1, 1, 0, 1, [(1, -20, 100, 4), (1, 90, 7, 3), (1, 33, -4, 5)], [(1, 90, 7, 3), (1, 61, 4, 6), (0, 1, 0, 0)])])
-def test_inter_stage_predictions_equal_the_real_motion_compensation(depth, level, slice_b, use_wp, use_wbp, wl0, wl1):
+def test_inter_stage_predictions_equal_the_real_motion_compensation(depth, level, slice_b, use_wp, use_wbp, wl0, wl1, seed=0):
     """The PREDICTION half of the oracle's inter TU stages - uni- and bi-directional, luma and both 4:2:0 chroma planes, explicit
     weights per list and plane (addWeightUni / addWeightBi), every fractional phase - against the real Predict::motionCompensation
     driven CU by CU (oracle/ref_predict.cpp): P slices with / without pps.bUseWeightPred, B slices with / without bUseWeightedBiPred."""
@@ -1299,9 +1299,9 @@ def test_inter_stage_predictions_equal_the_real_motion_compensation(depth, level
     lib = _ref(depth)
     if not hasattr(lib, "x265ref_motion_compensation"):
         pytest.skip("oracle/_ref predates x265ref_motion_compensation")
-    rng = np.random.default_rng([61, depth, level, slice_b])
+    rng = np.random.default_rng([61, depth, level, slice_b, seed])
     width, height = 256, 128
-    clip = F.synth_clip(width, height, 3, depth=depth, seed=75 + level)
+    clip = F.synth_clip(width, height, 3, depth=depth, seed=75 + level + seed)
     luma = [F.pad_plane(c[0]) for c in clip]
     stride, org, w64, h64 = luma[0][1:5]
     def edge_pad(img, margin=24):                          # (flat plane, stride, org) with replicated edges, like extendPicBorder
@@ -1330,8 +1330,8 @@ def test_inter_stage_predictions_equal_the_real_motion_compensation(depth, level
                                            wtab.ctypes.data, ry.ctypes.data, rcb.ctypes.data, rcr.ctypes.data) == 0
     # the oracle's view of the same picture: a list has a weight table iff the slice type's flag is on
     have = (bool(use_wp), False) if not slice_b else (bool(use_wbp), bool(use_wbp))
-    def wplane(p):
-        return tuple(tuple(int(v) for v in wtab[l][p]) if have[l] else None for l in range(2))
+    def wplane(p):             # the reference decides on the LUMA entry's wtPresent for every plane (pwp0->wtPresent, predict.cpp:94, :187, :196)
+        return tuple((int(wtab[l][0][0]),) + tuple(int(v) for v in wtab[l][p][1:]) if have[l] else None for l in range(2))
     cur = luma[1][0]
     py = np.zeros((height, width), dt)
     with O.pred_capture(depth, py):
