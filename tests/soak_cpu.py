@@ -49,8 +49,25 @@ def s_predict(r):
     T.test_inter_stage_predictions_equal_the_real_motion_compensation(int(r.choice([8, 10, 12])), int(r.integers(0, 3)), slice_b, flag if not slice_b else 0,
                                                                       flag if slice_b else 0, table(), table(), seed=int(r.integers(1, 1 << 20)))
 
-stages = [("--hevc-aq pass", s_hevc_aq), ("inter prediction (uni / bi, weighted, luma + chroma)", s_predict), ("search drivers (DIA / HEX / UMH / STAR)", s_search), ("lookahead frame cost (P / B)", s_lowres), ("SEA search", s_sea), ("cuTree step", s_cutree), ("weight analysis", s_weights), ("adaptive quantisation", s_aq), ("boundary strengths (B)", s_bs)]
+def _qp(r, depth): return int(r.integers(14, 36)) + 6 * (depth - 8)      # (above that the tests' own coverage assertions - some level non-zero - can fail)
+def s_tu(r):
+    depth = int(r.choice([8, 10, 12]))
+    which = int(r.integers(0, 4))
+    if which == 0: T.test_inter_tu_round_trip_equals_reference_quant_class(depth, int(r.integers(0, 3)), _qp(r, depth))
+    elif which == 1: T.test_chroma_inter_tu_round_trip_equals_reference_quant_class(depth, int(r.integers(0, 3)), _qp(r, depth))
+    elif which == 2: T.test_inter_tu_sign_hiding_equals_reference_quant_class(depth, int(r.integers(0, 3)), _qp(r, depth))
+    else: T.test_intra_tu_sign_hiding_equals_reference_quant_class(depth, int(r.choice([4, 8, 16, 32])), _qp(r, depth), int(r.integers(0, 2)), 0)
+def s_deblock(r):
+    depth = int(r.choice([8, 10, 12]))
+    T.test_deblock_restatement_equals_reference_class(depth, int(r.integers(0, 3)), min(51, int(r.integers(32, 46)) + 2 * (depth - 8)), (int(r.integers(-1, 4)), int(r.integers(-1, 4))))
+def s_sao(r):
+    fn = T.test_sao_restatement_equals_reference_class if r.integers(0, 2) else T.test_sao_chroma_restatement_equals_reference_class
+    fn(int(r.choice([8, 10])), 8 * int(r.integers(8, 40)), 8 * int(r.integers(8, 24)))
+
+stages = [("TU round trips against the real Quant (inter / chroma / sign hiding)", s_tu), ("luma deblocking against the real Deblock", s_deblock),
+          ("SAO statistics / application against the real SAO", s_sao), ("--hevc-aq pass", s_hevc_aq), ("inter prediction (uni / bi, weighted, luma + chroma)", s_predict), ("search drivers (DIA / HEX / UMH / STAR)", s_search), ("lookahead frame cost (P / B)", s_lowres), ("SEA search", s_sea), ("cuTree step", s_cutree), ("weight analysis", s_weights), ("adaptive quantisation", s_aq), ("boundary strengths (B)", s_bs)]
 counts = {n: 0 for n, _ in stages}
+shortfalls = {}
 t0, fail = time.time(), 0
 while time.time() - t0 < budget and not fail:
     for name, fn in stages:
@@ -59,10 +76,16 @@ while time.time() - t0 < budget and not fail:
             fn(np.random.default_rng(seed))
             counts[name] += 1
         except AssertionError as e:
-            print(f"MISMATCH in {name} (case seed {seed}): {str(e)[:400]}", flush=True)
+            import traceback
+            line = (traceback.extract_tb(e.__traceback__)[-1].line or "")
+            # the pin tests end with COVERAGE assertions (the case must filter / code something); random parameters may miss those
+            if "array_equal" not in line and " == " not in line and ("> 50" in line or ".any()" in line or "len(np.unique" in line or "min() <" in line):
+                shortfalls[name] = shortfalls.get(name, 0) + 1
+                continue
+            print(f"MISMATCH in {name} (case seed {seed}): {line.strip()[:200]} {str(e)[:400]}", flush=True)
             fail = 1
             break
 for n, c in counts.items():
-    print(f"{n}: {c} randomised cases matched the real reference class")
+    print(f"{n}: {c} randomised cases matched the real reference class" + (f" ({shortfalls[n]} more matched but missed the test's own coverage check)" if shortfalls.get(n) else ""))
 print(f"cpu soak {'FAILED' if fail else 'ok'} after {time.time() - t0:.0f} s")
 sys.exit(fail)
