@@ -597,6 +597,12 @@ typedef struct x265hip_frame_cost_recalculate_params
     int32_t* row_satds; int64_t* score;                                /* HOST outputs */
 } x265hip_frame_cost_recalculate_params;
 int x265hip_frame_cost_recalculate(const x265hip_frame_cost_recalculate_params* p);
+/* The --qg-size 8 branches of the two functions above (slicetype.cpp:2903-2921, 2990-3002): qp_aq_offset / qp_cutree_offset are the
+ * FULL-RESOLUTION 8x8 grids (2 * width_in_cu per row, two by two per lowres block), intra_cost / propagate_cost / lowres_costs stay on
+ * the lowres grid, inv_qscale is invQscaleFactor8x8 (the average calcAdaptiveQuantFrame leaves per lowres block); intra and propagated
+ * costs enter at a quarter; the recalculation averages the block's four offsets. */
+int x265hip_cutree_finish_qg8(const x265hip_cutree_finish_params* p, int width_in_cu, int height_in_cu);
+int x265hip_frame_cost_recalculate_qg8(const x265hip_frame_cost_recalculate_params* p);
 typedef struct x265hip_lowres_weight_apply_params
 {
     int depth;

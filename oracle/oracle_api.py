@@ -188,6 +188,28 @@ def frame_cost_recalculate(depth, width_in_cu, height_in_cu, lowres_costs, qp_cu
     return int(fn(width_in_cu, height_in_cu, lc.ctypes.data, qp.ctypes.data, rows.ctypes.data)), rows
 
 
+def cutree_finish_qg8(depth, width_in_cu, height_in_cu, intra_cost, inv_qscale8x8, propagate_cost, qp_aq_offset, fps_factor_q8, weight_delta, strength,
+                      qp_cutree_offset, avx2=False):
+    """The --qg-size 8 branch of cuTreeFinish: offsets on the full-resolution grid [2 * height_in_cu, 2 * width_in_cu]."""
+    fn = getattr(lib(avx2), f"x265oracle_cutree_finish_qg8_d{depth}")
+    fn.restype = None
+    fn.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+    ic, iq = np.ascontiguousarray(intra_cost, np.int32), np.ascontiguousarray(inv_qscale8x8, np.int32)
+    pc, qa = np.ascontiguousarray(propagate_cost, np.uint16), np.ascontiguousarray(qp_aq_offset, np.float64)
+    out = np.ascontiguousarray(qp_cutree_offset, np.float64).copy()
+    fn(width_in_cu, height_in_cu, ic.ctypes.data, iq.ctypes.data, pc.ctypes.data, qa.ctypes.data, int(fps_factor_q8), float(weight_delta), float(strength), out.ctypes.data)
+    return out
+
+
+def frame_cost_recalculate_qg8(depth, width_in_cu, height_in_cu, lowres_costs, qp_cutree_offset, avx2=False):
+    fn = getattr(lib(avx2), f"x265oracle_frame_cost_recalculate_qg8_d{depth}")
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lc, qp = np.ascontiguousarray(lowres_costs, np.uint16), np.ascontiguousarray(qp_cutree_offset, np.float64)
+    rows = np.zeros(height_in_cu, np.int32)
+    return int(fn(width_in_cu, height_in_cu, lc.ctypes.data, qp.ctypes.data, rows.ctypes.data)), rows
+
+
 def aq_frame(depth, y, stride, org, width, height, cb=None, cr=None, stride_c=0, org_c=0, qg_size=16, aq_mode=2, aq_strength=1.0, weightp=True,
              avx2=False):
     """CPU restatement of LookaheadTLD::calcAdaptiveQuantFrame.  y / cb / cr: padded planes (flat arrays, sample (0,0) at org / org_c).

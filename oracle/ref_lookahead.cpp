@@ -553,9 +553,27 @@ int x265ref_cutree_propagate(const void* curPlane, const void* ref0Plane, const 
 
 /* The REAL Lookahead::cuTreeFinish (encoder/slicetype.cpp:2889-2937) on caller-supplied per-block arrays of a width x height picture
  * (qgSize 32, hevcAq off): qpCuTreeOffset is preset to `preset` and updated in place. */
+static int cutree_finish_core(int qgSize, int width, int height, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* propagateCost,
+                              const double* qpAqOffset, int fpsNum, int fpsDenom, double averageDuration, double qCompress,
+                              int ref0Distance, double weightedCostDelta, double* qpCuTreeOffset);
 int x265ref_cutree_finish(int width, int height, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* propagateCost,
                           const double* qpAqOffset, int fpsNum, int fpsDenom, double averageDuration, double qCompress,
                           int ref0Distance, double weightedCostDelta, double* qpCuTreeOffset)
+{
+    return cutree_finish_core(32, width, height, intraCost, invQscale, propagateCost, qpAqOffset, fpsNum, fpsDenom, averageDuration, qCompress, ref0Distance,
+                              weightedCostDelta, qpCuTreeOffset);
+}
+/* --qg-size 8: invQscale = invQscaleFactor8x8 per lowres block, qpAqOffset / qpCuTreeOffset on the full-resolution grid (4 per block) */
+int x265ref_cutree_finish_qg8(int width, int height, const int32_t* intraCost, const int32_t* invQscale8x8, const uint16_t* propagateCost,
+                              const double* qpAqOffset, int fpsNum, int fpsDenom, double averageDuration, double qCompress,
+                              int ref0Distance, double weightedCostDelta, double* qpCuTreeOffset)
+{
+    return cutree_finish_core(8, width, height, intraCost, invQscale8x8, propagateCost, qpAqOffset, fpsNum, fpsDenom, averageDuration, qCompress, ref0Distance,
+                              weightedCostDelta, qpCuTreeOffset);
+}
+static int cutree_finish_core(int qgSize, int width, int height, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* propagateCost,
+                              const double* qpAqOffset, int fpsNum, int fpsDenom, double averageDuration, double qCompress,
+                              int ref0Distance, double weightedCostDelta, double* qpCuTreeOffset)
 {
     static bool tableReady = false;
     if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
@@ -567,7 +585,7 @@ int x265ref_cutree_finish(int width, int height, const int32_t* intraCost, const
     param->maxCUSize = 64;
     param->rc.aqMode = 2;
     param->rc.hevcAq = 0;
-    param->rc.qgSize = 32;
+    param->rc.qgSize = qgSize;
     param->rc.qCompress = qCompress;
     param->bEnableHME = 0;
     param->fpsNum = fpsNum;
@@ -577,7 +595,7 @@ int x265ref_cutree_finish(int width, int height, const int32_t* intraCost, const
     if (!pic.create(param, true)) return -1;
     Lowres lr;
     memset((void*)&lr, 0, sizeof(Lowres));
-    if (!lr.create(param, &pic, 32)) return -2;
+    if (!lr.create(param, &pic, qgSize)) return -2;
     const int ncu = lr.maxBlocksInRow * lr.maxBlocksInCol;
     int rc = 0;
     {
@@ -585,17 +603,17 @@ int x265ref_cutree_finish(int width, int height, const int32_t* intraCost, const
         if (!la.create()) rc = -3;
         else
         {
+            const int nq = qgSize == 8 ? 4 * ncu : ncu;
             for (int k = 0; k < ncu; k++)
             {
                 lr.intraCost[k] = intraCost[k];
-                lr.invQscaleFactor[k] = invQscale[k];
+                if (qgSize == 8) lr.invQscaleFactor8x8[k] = invQscale[k]; else lr.invQscaleFactor[k] = invQscale[k];
                 lr.propagateCost[k] = propagateCost[k];
-                lr.qpAqOffset[k] = qpAqOffset[k];
-                lr.qpCuTreeOffset[k] = qpCuTreeOffset[k];
             }
+            for (int k = 0; k < nq; k++) { lr.qpAqOffset[k] = qpAqOffset[k]; lr.qpCuTreeOffset[k] = qpCuTreeOffset[k]; }
             if (ref0Distance) lr.weightedCostDelta[ref0Distance - 1] = weightedCostDelta;
             la.cuTreeFinish(&lr, averageDuration, ref0Distance);
-            for (int k = 0; k < ncu; k++) qpCuTreeOffset[k] = lr.qpCuTreeOffset[k];
+            for (int k = 0; k < nq; k++) qpCuTreeOffset[k] = lr.qpCuTreeOffset[k];
             la.destroy();
         }
     }
@@ -609,7 +627,16 @@ int x265ref_cutree_finish(int width, int height, const int32_t* intraCost, const
 /* The REAL Lookahead::frameCostRecalculate(frames, 0, 1, 1) (encoder/slicetype.cpp:2941-3011) for a P picture of a width x height
  * source whose lowresCosts[1][0] and qpCuTreeOffset are supplied by the caller; rowSatds receives rowSatds[1][0].  Returns the score
  * through *score. */
+static int frame_cost_recalculate_core(int qgSize, int width, int height, const uint16_t* lowresCosts, const double* qpCuTreeOffset, int32_t* rowSatds, int64_t* score);
 int x265ref_frame_cost_recalculate(int width, int height, const uint16_t* lowresCosts, const double* qpCuTreeOffset, int32_t* rowSatds, int64_t* score)
+{
+    return frame_cost_recalculate_core(32, width, height, lowresCosts, qpCuTreeOffset, rowSatds, score);
+}
+int x265ref_frame_cost_recalculate_qg8(int width, int height, const uint16_t* lowresCosts, const double* qpCuTreeOffset, int32_t* rowSatds, int64_t* score)
+{
+    return frame_cost_recalculate_core(8, width, height, lowresCosts, qpCuTreeOffset, rowSatds, score);
+}
+static int frame_cost_recalculate_core(int qgSize, int width, int height, const uint16_t* lowresCosts, const double* qpCuTreeOffset, int32_t* rowSatds, int64_t* score)
 {
     static bool tableReady = false;
     if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
@@ -621,7 +648,7 @@ int x265ref_frame_cost_recalculate(int width, int height, const uint16_t* lowres
     param->maxCUSize = 64;
     param->rc.aqMode = 2;
     param->rc.hevcAq = 0;
-    param->rc.qgSize = 32;
+    param->rc.qgSize = qgSize;
     param->bEnableHME = 0;
     PicYuv pic;
     pic.m_param = param;
@@ -630,7 +657,7 @@ int x265ref_frame_cost_recalculate(int width, int height, const uint16_t* lowres
     for (int i = 0; i < 2; i++)
     {
         memset((void*)&lrs[i], 0, sizeof(Lowres));
-        if (!lrs[i].create(param, &pic, 32)) return -2;
+        if (!lrs[i].create(param, &pic, qgSize)) return -2;
     }
     Lowres& fenc = lrs[1];
     fenc.sliceType = X265_TYPE_P;
@@ -641,7 +668,8 @@ int x265ref_frame_cost_recalculate(int width, int height, const uint16_t* lowres
         if (!la.create()) rc = -3;
         else
         {
-            for (int k = 0; k < ncu; k++) { fenc.lowresCosts[1][0][k] = lowresCosts[k]; fenc.qpCuTreeOffset[k] = qpCuTreeOffset[k]; }
+            for (int k = 0; k < ncu; k++) fenc.lowresCosts[1][0][k] = lowresCosts[k];
+            for (int k = 0; k < (qgSize == 8 ? 4 * ncu : ncu); k++) fenc.qpCuTreeOffset[k] = qpCuTreeOffset[k];
             Lowres* frames[2] = { &lrs[0], &lrs[1] };
             *score = la.frameCostRecalculate(frames, 0, 1, 1);
             for (int y = 0; y < fenc.maxBlocksInCol; y++) rowSatds[y] = fenc.rowSatds[1][0][y];

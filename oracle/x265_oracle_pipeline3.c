@@ -514,6 +514,49 @@ void EXPORT(x265oracle_cutree_finish)(int n, const int32_t* intraCost, const int
     }
 }
 
+/* the --qg-size 8 branches (slicetype.cpp:2903-2921, 2990-3002): offsets on the full-resolution 8x8 grid, costs on the lowres grid */
+void EXPORT(x265oracle_cutree_finish_qg8)(int widthInCU, int heightInCU, const int32_t* intraCost, const int32_t* invQscale8x8, const uint16_t* propagateCost,
+                                          const double* qpAqOffset, int fpsFactorQ8, double weightDelta, double strength, double* qpCuTreeOffset)
+{
+    const int fullRow = 2 * widthInCU;
+    for (int cuY = 0; cuY < heightInCU; cuY++)
+        for (int cuX = 0; cuX < widthInCU; cuX++)
+        {
+            const int cuXY = cuX + cuY * widthInCU;
+            int intracost = ((intraCost[cuXY]) / 4 * invQscale8x8[cuXY] + 128) >> 8;
+            if (intracost)
+            {
+                int propagate = ((propagateCost[cuXY]) / 4 * fpsFactorQ8 + 128) >> 8;
+                double log2_ratio = log2((double)(intracost + propagate)) - log2((double)intracost) + weightDelta;
+                qpCuTreeOffset[cuX * 2 + cuY * widthInCU * 4] = qpAqOffset[cuX * 2 + cuY * widthInCU * 4] - strength * (log2_ratio);
+                qpCuTreeOffset[cuX * 2 + cuY * widthInCU * 4 + 1] = qpAqOffset[cuX * 2 + cuY * widthInCU * 4 + 1] - strength * (log2_ratio);
+                qpCuTreeOffset[cuX * 2 + cuY * widthInCU * 4 + fullRow] = qpAqOffset[cuX * 2 + cuY * widthInCU * 4 + fullRow] - strength * (log2_ratio);
+                qpCuTreeOffset[cuX * 2 + cuY * widthInCU * 4 + fullRow + 1] = qpAqOffset[cuX * 2 + cuY * widthInCU * 4 + fullRow + 1] - strength * (log2_ratio);
+            }
+        }
+}
+
+int64_t EXPORT(x265oracle_frame_cost_recalculate_qg8)(int widthInCU, int heightInCU, const uint16_t* lowresCosts, const double* qpCuTreeOffset,
+                                                      int32_t* rowSatds)
+{
+    const int fullRow = 2 * widthInCU;
+    int64_t score = 0;
+    for (int cuy = heightInCU - 1; cuy >= 0; cuy--)
+    {
+        rowSatds[cuy] = 0;
+        for (int cux = widthInCU - 1; cux >= 0; cux--)
+        {
+            int cuCost = lowresCosts[cux + cuy * widthInCU] & LOWRES_COST_MASK;
+            const double qp_adj = (qpCuTreeOffset[cux * 2 + cuy * widthInCU * 4] + qpCuTreeOffset[cux * 2 + cuy * widthInCU * 4 + 1] +
+                                   qpCuTreeOffset[cux * 2 + cuy * widthInCU * 4 + fullRow] + qpCuTreeOffset[cux * 2 + cuy * widthInCU * 4 + fullRow + 1]) / 4;
+            cuCost = (cuCost * exp2fix8(qp_adj) + 128) >> 8;
+            rowSatds[cuy] += cuCost;
+            if ((cuy > 0 && cuy < heightInCU - 1 && cux > 0 && cux < widthInCU - 1) || widthInCU <= 2 || heightInCU <= 2) score += cuCost;
+        }
+    }
+    return score;
+}
+
 /* Lookahead::frameCostRecalculate (slicetype.cpp:2941-3011; P pictures, quantisation groups of 16 or more, hevcAq off): the frame
  * cost after cuTree changed the quantisers - every block's lowres cost scaled by x265_exp2fix8(qpCuTreeOffset), summed per row into
  * rowSatds and over the interior blocks (all blocks when the picture is at most two blocks wide or high) into the returned score. */

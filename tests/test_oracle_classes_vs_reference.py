@@ -654,6 +654,53 @@ def test_frame_cost_recalculate_equals_reference_class(width, height):
     assert score2 == int(rscore[0]) and np.array_equal(rows2, rrows)
 
 
+@pytest.mark.parametrize("width,height,avg,qcomp,dist,wdelta", [(256, 128, 1 / 30, 0.6, 0, 0.0), (416, 240, 1 / 24, 0.6, 1, 0.4), (640, 360, 1 / 60, 0.5, 1, 1.0)])
+def test_cutree_finish_and_recalculation_qg8_equal_reference_class(width, height, avg, qcomp, dist, wdelta):
+    """--qg-size 8: the branches of Lookahead::cuTreeFinish / frameCostRecalculate that keep the offsets on the full-resolution 8x8 grid
+    (slicetype.cpp:2903-2921, 2990-3002) - restatement and the library's host-side entries against the real class."""
+    import importlib
+    import oracle_api as O
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    lib = _ref(8)
+    if not hasattr(lib, "x265ref_cutree_finish_qg8"):
+        pytest.skip("oracle/_ref predates x265ref_cutree_finish_qg8")
+    rng = np.random.default_rng([29, width, height])
+    wcu, hcu = (width // 2 + 7) >> 3, (height // 2 + 7) >> 3
+    n = wcu * hcu
+    intra = rng.integers(0, 9000, size=n).astype(np.int32)
+    intra[rng.random(n) < 0.05] = 0
+    intra[rng.random(n) < 0.05] = 3                                  # a quarter of it is 0
+    invq = rng.integers(64, 1024, size=n).astype(np.int32)
+    prop = rng.integers(0, 65536, size=n).astype(np.uint16)
+    prop[::5] = 65535
+    qpaq = rng.normal(0, 2, size=4 * n)
+    preset = rng.normal(0, 1, size=4 * n)
+    got = preset.copy()
+    lib.x265ref_cutree_finish_qg8.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                                                                                      ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
+    assert lib.x265ref_cutree_finish_qg8(width, height, intra.ctypes.data, invq.ctypes.data, prop.ctypes.data, qpaq.ctypes.data, 30, 1, avg, qcomp, dist, wdelta,
+                                         got.ctypes.data) == n
+    fps_q8 = int(clip_duration(avg) / clip_duration(1 / 30) * 256)
+    weight_delta = (1.0 - wdelta) if (dist and wdelta > 0) else 0.0
+    strength = 5.0 * (1.0 - qcomp)
+    exp = O.cutree_finish_qg8(8, wcu, hcu, intra, invq, prop, qpaq, fps_q8, weight_delta, strength, preset)
+    assert np.array_equal(exp, got), f"{np.count_nonzero(exp != got)} offsets differ from the real class"
+    mine = A.cutree_finish_qg8(wcu, hcu, intra, invq, prop, qpaq, fps_q8, weight_delta, strength, preset)
+    assert np.array_equal(mine, got), f"{np.count_nonzero(mine != got)} offsets of the library entry differ from the real class"
+    assert (got == preset).any() and (got != preset).any()
+    # the recalculation on those offsets
+    lc = (rng.integers(0, 16384, size=n) | (rng.integers(0, 4, size=n) << 14)).astype(np.uint16)
+    qp = got.copy()
+    qp[::11] = 60.0; qp[5::13] = -60.0
+    rrows, rscore = np.zeros(hcu, np.int32), np.zeros(1, np.int64)
+    lib.x265ref_frame_cost_recalculate_qg8.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4
+    assert lib.x265ref_frame_cost_recalculate_qg8(width, height, lc.ctypes.data, qp.ctypes.data, rrows.ctypes.data, rscore.ctypes.data) == n
+    score, rows = O.frame_cost_recalculate_qg8(8, wcu, hcu, lc, qp)
+    assert score == int(rscore[0]) and np.array_equal(rows, rrows)
+    score2, rows2 = A.frame_cost_recalculate_qg8(wcu, hcu, lc, qp)
+    assert score2 == int(rscore[0]) and np.array_equal(rows2, rrows)
+
+
 def sao_case(depth, width, height, seed):
     """Source / deblocked-like pair and random per-CTU SAO parameters (all five types, off, merge-left runs)."""
     rng = np.random.default_rng([21, depth, width, seed])

@@ -795,6 +795,51 @@ extern "C" int x265hip_cutree_finish(const x265hip_cutree_finish_params* p)
     return 0;
 }
 
+// --qg-size 8: the offsets live on the full-resolution 8x8 grid (two by two per lowres block, 2 * width_in_cu per row), costs and the
+// averaged invQscaleFactor8x8 on the lowres grid; intra and propagated costs enter at a quarter (slicetype.cpp:2903-2921)
+extern "C" int x265hip_cutree_finish_qg8(const x265hip_cutree_finish_params* p, int width_in_cu, int height_in_cu)
+{
+    if (!p || !p->intra_cost || !p->inv_qscale || !p->propagate_cost || !p->qp_aq_offset || !p->qp_cutree_offset) { set_error("cutree_finish_qg8: NULL operand"); return X265HIP_EINVAL; }
+    if (width_in_cu <= 0 || height_in_cu <= 0 || p->nblocks != width_in_cu * height_in_cu) { set_error("cutree_finish_qg8: nblocks %d for %d x %d blocks", p->nblocks, width_in_cu, height_in_cu); return X265HIP_EINVAL; }
+    const int w = width_in_cu, full = 2 * w;
+    for (int cuY = 0; cuY < height_in_cu; cuY++)
+        for (int cuX = 0; cuX < w; cuX++)
+        {
+            const int cuXY = cuX + cuY * w;
+            const int intracost = (p->intra_cost[cuXY] / 4 * p->inv_qscale[cuXY] + 128) >> 8;
+            if (!intracost) continue;
+            const int propagate = (p->propagate_cost[cuXY] / 4 * p->fps_factor_q8 + 128) >> 8;
+            const double log2_ratio = std::log2((double)(intracost + propagate)) - std::log2((double)intracost) + p->weight_delta;
+            const int at = cuX * 2 + cuY * w * 4;
+            const int idx[4] = { at, at + 1, at + full, at + full + 1 };
+            for (int k = 0; k < 4; k++) p->qp_cutree_offset[idx[k]] = p->qp_aq_offset[idx[k]] - p->strength * log2_ratio;
+        }
+    return 0;
+}
+
+extern "C" int x265hip_frame_cost_recalculate_qg8(const x265hip_frame_cost_recalculate_params* p)
+{
+    if (!p || !p->lowres_costs || !p->qp_cutree_offset || !p->row_satds || !p->score) { set_error("frame_cost_recalculate_qg8: NULL operand"); return X265HIP_EINVAL; }
+    if (p->width_in_cu <= 0 || p->height_in_cu <= 0) { set_error("frame_cost_recalculate_qg8: empty picture"); return X265HIP_EINVAL; }
+    const int w = p->width_in_cu, h = p->height_in_cu, full = 2 * w;
+    int64_t score = 0;
+    for (int cuy = h - 1; cuy >= 0; cuy--)
+    {
+        int row = 0;
+        for (int cux = w - 1; cux >= 0; cux--)
+        {
+            const int at = cux * 2 + cuy * w * 4;
+            const double qp_adj = (p->qp_cutree_offset[at] + p->qp_cutree_offset[at + 1] + p->qp_cutree_offset[at + full] + p->qp_cutree_offset[at + full + 1]) / 4;
+            const int cuCost = ((p->lowres_costs[cux + cuy * w] & 0x3fff) * aq_exp2fix8(qp_adj) + 128) >> 8;
+            row += cuCost;
+            if ((cuy > 0 && cuy < h - 1 && cux > 0 && cux < w - 1) || w <= 2 || h <= 2) score += cuCost;
+        }
+        p->row_satds[cuy] = row;
+    }
+    *p->score = score;
+    return 0;
+}
+
 extern "C" int x265hip_frame_cost_recalculate(const x265hip_frame_cost_recalculate_params* p)
 {
     if (!p || !p->lowres_costs || !p->qp_cutree_offset || !p->row_satds || !p->score) { set_error("frame_cost_recalculate: NULL operand"); return X265HIP_EINVAL; }

@@ -451,6 +451,22 @@ def cutree_finish(intra_cost, inv_qscale, propagate_cost, qp_aq_offset, fps_fact
     return out
 
 
+def cutree_finish_qg8(width_in_cu, height_in_cu, intra_cost, inv_qscale8x8, propagate_cost, qp_aq_offset, fps_factor_q8, weight_delta, strength, qp_cutree_offset):
+    """x265hip_cutree_finish_qg8: the --qg-size 8 branch (offsets on the full-resolution grid); returns the updated copy."""
+    import numpy as np
+    ic, iq = np.ascontiguousarray(intra_cost, np.int32), np.ascontiguousarray(inv_qscale8x8, np.int32)
+    pc, qa = np.ascontiguousarray(propagate_cost, np.uint16), np.ascontiguousarray(qp_aq_offset, np.float64)
+    out = np.ascontiguousarray(qp_cutree_offset, np.float64).copy()
+    p = CuTreeFinishParams()
+    p.nblocks, p.fps_factor_q8, p.weight_delta, p.strength = len(ic), int(fps_factor_q8), float(weight_delta), float(strength)
+    p.intra_cost, p.inv_qscale, p.propagate_cost, p.qp_aq_offset = ic.ctypes.data, iq.ctypes.data, pc.ctypes.data, qa.ctypes.data
+    p.qp_cutree_offset = out.ctypes.data
+    f = lib().x265hip_cutree_finish_qg8
+    f.argtypes = [ctypes.POINTER(CuTreeFinishParams), ctypes.c_int, ctypes.c_int]
+    check(f(ctypes.byref(p), width_in_cu, height_in_cu), "x265hip_cutree_finish_qg8")
+    return out
+
+
 class FrameCostRecalculateParams(ctypes.Structure):
     """x265hip_frame_cost_recalculate_params (include/x265hip.h)."""
     _fields_ = [("width_in_cu", ctypes.c_int), ("height_in_cu", ctypes.c_int), ("lowres_costs", ctypes.c_void_p), ("qp_cutree_offset", ctypes.c_void_p),
@@ -468,6 +484,20 @@ def frame_cost_recalculate(width_in_cu, height_in_cu, lowres_costs, qp_cutree_of
     f = lib().x265hip_frame_cost_recalculate
     f.argtypes = [ctypes.POINTER(FrameCostRecalculateParams)]
     check(f(ctypes.byref(p)), "x265hip_frame_cost_recalculate")
+    return int(score[0]), rows
+
+
+def frame_cost_recalculate_qg8(width_in_cu, height_in_cu, lowres_costs, qp_cutree_offset):
+    """x265hip_frame_cost_recalculate_qg8: qp_cutree_offset on the full-resolution grid; returns (score, row_satds)."""
+    import numpy as np
+    lc, qp = np.ascontiguousarray(lowres_costs, np.uint16), np.ascontiguousarray(qp_cutree_offset, np.float64)
+    rows, score = np.zeros(height_in_cu, np.int32), np.zeros(1, np.int64)
+    p = FrameCostRecalculateParams()
+    p.width_in_cu, p.height_in_cu = width_in_cu, height_in_cu
+    p.lowres_costs, p.qp_cutree_offset, p.row_satds, p.score = lc.ctypes.data, qp.ctypes.data, rows.ctypes.data, score.ctypes.data
+    f = lib().x265hip_frame_cost_recalculate_qg8
+    f.argtypes = [ctypes.POINTER(FrameCostRecalculateParams)]
+    check(f(ctypes.byref(p)), "x265hip_frame_cost_recalculate_qg8")
     return int(score[0]), rows
 
 
