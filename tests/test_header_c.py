@@ -78,3 +78,81 @@ def test_surf_lookup_in_plain_c(fmt, tmp_path):
     _write(fmt, rng, nctu).tofile(data)
     out = subprocess.check_output([str(exe), str(data), str(fmt), str(rng), str(nctu)]).decode().split()
     assert int(out[0]) == nctu * 85 * (2 * rng + 1) ** 2 and int(out[1]) == 0
+
+
+C_HOST = r"""
+/* A C host of libx265hip.so without Python in the call path: links the library, checks the version string, drives two host-side
+ * entries on data read from a file and prints their results (hex floats: bit-exact text), and confirms that a device entry fails
+ * loudly - X265HIP_ENODEV with a message - when no gfx950 device is there. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "x265hip.h"
+int main(int argc, char** argv)
+{
+    const char* ver = x265hip_version();
+    if (!ver || !strstr(ver, "x265hip")) return 2;
+    FILE* f = fopen(argv[1], "rb");
+    int hdr[4];                                   /* width, height, part, number of partitions */
+    if (fread(hdr, sizeof(int), 4, f) != 4) return 3;
+    double span;
+    if (fread(&span, sizeof(double), 1, f) != 1) return 3;
+    const int n = hdr[3];
+    uint64_t* sums = malloc(sizeof(uint64_t) * 8 * n);
+    if (fread(sums, sizeof(uint64_t), 8 * (size_t)n, f) != 8 * (size_t)n) return 3;
+    double* act = malloc(sizeof(double) * n); double* qp = malloc(sizeof(double) * n); int32_t* inv = malloc(sizeof(int32_t) * n);
+    double avg = 0;
+    x265hip_aq_hevc_offsets_params p;
+    memset(&p, 0, sizeof(p));
+    p.width = hdr[0]; p.height = hdr[1]; p.part = hdr[2]; p.qp_adaptation_range = span;
+    p.sums = sums; p.activity = act; p.qp_offset = qp; p.avg_activity = &avg; p.inv_qscale = inv;
+    if (x265hip_aq_hevc_offsets(&p) != 0) { fprintf(stderr, "%s\n", x265hip_last_error()); return 4; }
+    printf("%a\n", avg);
+    for (int i = 0; i < n; i++) printf("%a %a %d\n", act[i], qp[i], inv[i]);
+    p.qp_adaptation_range = 0.5;                  /* out of [1, 6]: refused with a message */
+    if (x265hip_aq_hevc_offsets(&p) != X265HIP_EINVAL || !strstr(x265hip_last_error(), "qp_adaptation_range")) return 5;
+    if (argc > 2 && !strcmp(argv[2], "nodevice"))
+    {
+        uint64_t best[85];
+        if (x265hip_me_best_reset(best, 85, NULL) != X265HIP_ENODEV || !x265hip_last_error()[0]) return 6;
+    }
+    return 0;
+}
+"""
+
+
+def test_a_c_host_links_the_library_and_calls_it(tmp_path):
+    """The drop-in boundary is a C ABI: a C99 program linked against libx265hip.so (no Python, no torch in the process) gets the same
+    --hevc-aq numbers as the reference-pinned oracle and the documented error behaviour."""
+    import importlib
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_api as O
+    F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    if not os.path.exists(A.LIB_PATH):
+        pytest.skip("libx265hip.so not built")
+    width, height, part, span, depth = 250, 138, 16, 3.3333333333333335, 8
+    y = F.synth_clip(width, height, 1, depth=depth, seed=9)[0][0]
+    yp, stride, org, _, _ = F.pad_plane(y)
+    sums = O.aq_hevc_quadrants(depth, yp, stride, org, width, height, part)
+    n = sums.shape[0]
+    blob = tmp_path / "sums.bin"
+    with open(blob, "wb") as f:
+        f.write(np.asarray([width, height, part, n], np.int32).tobytes())
+        f.write(np.asarray([span], np.float64).tobytes())
+        f.write(sums.tobytes())
+    src = tmp_path / "host.c"
+    src.write_text(C_HOST)
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(A.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir, "-lx265hip",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    import torch
+    nodev = [] if torch.cuda.is_available() else ["nodevice"]
+    out = subprocess.run([str(exe), str(blob)] + nodev, check=True, capture_output=True, text=True).stdout.split("\n")
+    parts, act, qp, avg, inv, _, _ = O.aq_hevc_frame(depth, yp, stride, org, width, height, qg_size=16, qp_adaptation_range=span, weightp=False)
+    at = int(parts[0] + parts[1])                                    # layer 2 = 16 x 16 partitions, the deepest for this quantisation group size
+    assert float.fromhex(out[0]) == avg[2]
+    for i in range(n):
+        a, q, v = out[1 + i].split()
+        assert float.fromhex(a) == act[at + i] and float.fromhex(q) == qp[at + i] and int(v) == inv[i], f"partition {i}"
