@@ -602,6 +602,23 @@ int x265hip_frame_cost_recalculate(const x265hip_frame_cost_recalculate_params* 
  * the lowres grid, inv_qscale is invQscaleFactor8x8 (the average calcAdaptiveQuantFrame leaves per lowres block); intra and propagated
  * costs enter at a quarter; the recalculation averages the block's four offsets. */
 int x265hip_cutree_finish_qg8(const x265hip_cutree_finish_params* p, int width_in_cu, int height_in_cu);
+/* cuTreeFinish with --hevc-aq (HOST-side): Lookahead::computeCUTreeQpOffset (slicetype.cpp:2749-2887), quantisation groups of 16 or more,
+ * one layer per call - dCuTreeOffset of every partition = its dQpOffset - strength * mean over the 16x16 blocks it covers (clipped at the
+ * picture edge) of log2(intra + propagate) - log2(intra) + weight_delta, with intra / propagate scaled as in x265hip_cutree_finish.
+ * A block whose scaled intra cost is 0 contributes +inf or NaN, as it does upstream.  The frame cost recalculation of such a picture is
+ * x265hip_frame_cost_recalculate on the deepest layer's offsets (16 x 16 partitions = the lowres grid). */
+typedef struct x265hip_cutree_finish_hevc_params
+{
+    int width, height;                    /* full-resolution picture size */
+    int part;                             /* the layer's partition size: 64, 32 or 16 */
+    int blocks_in_row;                    /* lowres blocks per row (Lowres::maxBlocksInRow) */
+    const int32_t* intra_cost; const int32_t* inv_qscale; const uint16_t* propagate_cost;      /* HOST, lowres grid */
+    int fps_factor_q8;
+    double weight_delta, strength;
+    const double* qp_offset;              /* HOST double [partitions]: the layer's dQpOffset */
+    double* cutree_offset;                /* HOST double [partitions]: the layer's dCuTreeOffset (out) */
+} x265hip_cutree_finish_hevc_params;
+int x265hip_cutree_finish_hevc_aq(const x265hip_cutree_finish_hevc_params* p);
 int x265hip_frame_cost_recalculate_qg8(const x265hip_frame_cost_recalculate_params* p);
 typedef struct x265hip_lowres_weight_apply_params
 {

@@ -188,6 +188,20 @@ def frame_cost_recalculate(depth, width_in_cu, height_in_cu, lowres_costs, qp_cu
     return int(fn(width_in_cu, height_in_cu, lc.ctypes.data, qp.ctypes.data, rows.ctypes.data)), rows
 
 
+def cutree_finish_hevc_aq(depth, width, height, part, blocks_in_row, intra_cost, inv_qscale, propagate_cost, fps_factor_q8, weight_delta, strength, qp_offset,
+                          avx2=False):
+    """CPU restatement of Lookahead::computeCUTreeQpOffset (qgSize >= 16) for one layer; returns dCuTreeOffset float64 [partitions]."""
+    fn = getattr(lib(avx2), f"x265oracle_cutree_finish_hevc_aq_d{depth}")
+    fn.restype = None
+    fn.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+    ic, iq, pc = np.ascontiguousarray(intra_cost, np.int32), np.ascontiguousarray(inv_qscale, np.int32), np.ascontiguousarray(propagate_cost, np.uint16)
+    qo = np.ascontiguousarray(qp_offset, np.float64)
+    out = np.zeros_like(qo)
+    fn(width, height, part, blocks_in_row, ic.ctypes.data, iq.ctypes.data, pc.ctypes.data, int(fps_factor_q8), float(weight_delta), float(strength), qo.ctypes.data,
+       out.ctypes.data)
+    return out
+
+
 def cutree_finish_qg8(depth, width_in_cu, height_in_cu, intra_cost, inv_qscale8x8, propagate_cost, qp_aq_offset, fps_factor_q8, weight_delta, strength,
                       qp_cutree_offset, avx2=False):
     """The --qg-size 8 branch of cuTreeFinish: offsets on the full-resolution grid [2 * height_in_cu, 2 * width_in_cu]."""

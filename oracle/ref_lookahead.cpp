@@ -627,6 +627,71 @@ static int cutree_finish_core(int qgSize, int width, int height, const int32_t* 
 /* The REAL Lookahead::frameCostRecalculate(frames, 0, 1, 1) (encoder/slicetype.cpp:2941-3011) for a P picture of a width x height
  * source whose lowresCosts[1][0] and qpCuTreeOffset are supplied by the caller; rowSatds receives rowSatds[1][0].  Returns the score
  * through *score. */
+/* The REAL Lookahead::cuTreeFinish with rc.hevcAq (computeCUTreeQpOffset, slicetype.cpp:2749-2887) on caller-supplied per-block arrays
+ * (qgSize 16 or 32): dQpOffset of every enabled layer is preset from qpOffsetIn (layers one after the other, as x265ref_aq_hevc_frame
+ * lays them out), the layers' dCuTreeOffset come back the same way.  layerParts[4] receives the partition counts. */
+int x265ref_cutree_finish_hevc_aq(int width, int height, int qgSize, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* propagateCost,
+                                  int fpsNum, int fpsDenom, double averageDuration, double qCompress, int ref0Distance, double weightedCostDelta,
+                                  const double* qpOffsetIn, double* cuTreeOffsetOut, int32_t* layerParts)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width;
+    param->sourceHeight = height;
+    param->internalCsp = X265_CSP_I400;
+    param->maxCUSize = 64;
+    param->rc.aqMode = 2;
+    param->rc.hevcAq = 1;
+    param->rc.qgSize = qgSize;
+    param->rc.qCompress = qCompress;
+    param->bEnableHME = 0;
+    param->fpsNum = fpsNum;
+    param->fpsDenom = fpsDenom;
+    PicYuv pic;
+    pic.m_param = param;
+    if (!pic.create(param, true)) return -1;
+    Lowres lr;
+    memset((void*)&lr, 0, sizeof(Lowres));
+    if (!lr.create(param, &pic, qgSize)) return -2;
+    const int ncu = lr.maxBlocksInRow * lr.maxBlocksInCol;
+    int rc = 0;
+    {
+        LookaheadProbe la(param, NULL);
+        if (!la.create()) rc = -3;
+        else
+        {
+            for (int k = 0; k < ncu; k++) { lr.intraCost[k] = intraCost[k]; lr.invQscaleFactor[k] = invQscale[k]; lr.propagateCost[k] = propagateCost[k]; }
+            const int aqDepth = 6 - (qgSize == 64 ? 6 : qgSize == 32 ? 5 : qgSize == 16 ? 4 : 3);
+            size_t at = 0;
+            for (int d = 0; d < 4; d++)
+            {
+                layerParts[d] = 0;
+                if (!aqLayerDepth[0][aqDepth][d]) continue;
+                PicQPAdaptationLayer& L = lr.pAQLayer[d];
+                const int n = L.numAQPartInWidth * L.numAQPartInHeight;
+                for (int k = 0; k < n; k++) L.dQpOffset[k] = qpOffsetIn[at + k];
+                layerParts[d] = n; at += n;
+            }
+            if (ref0Distance) lr.weightedCostDelta[ref0Distance - 1] = weightedCostDelta;
+            la.cuTreeFinish(&lr, averageDuration, ref0Distance);
+            at = 0;
+            for (int d = 0; d < 4; d++)
+            {
+                if (!layerParts[d]) continue;
+                memcpy(cuTreeOffsetOut + at, lr.pAQLayer[d].dCuTreeOffset, sizeof(double) * layerParts[d]);
+                at += layerParts[d];
+            }
+            la.destroy();
+        }
+    }
+    lr.destroy();
+    pic.destroy();
+    x265_param_free(param);
+    return rc ? rc : ncu;
+}
+
 static int frame_cost_recalculate_core(int qgSize, int width, int height, const uint16_t* lowresCosts, const double* qpCuTreeOffset, int32_t* rowSatds, int64_t* score);
 int x265ref_frame_cost_recalculate(int width, int height, const uint16_t* lowresCosts, const double* qpCuTreeOffset, int32_t* rowSatds, int64_t* score)
 {

@@ -514,6 +514,31 @@ void EXPORT(x265oracle_cutree_finish)(int n, const int32_t* intraCost, const int
     }
 }
 
+/* cuTreeFinish with --hevc-aq: Lookahead::computeCUTreeQpOffset (slicetype.cpp:2749-2887), the qgSize >= 16 branch, one layer */
+void EXPORT(x265oracle_cutree_finish_hevc_aq)(int width, int height, int part, int blocksInRow, const int32_t* intraCost, const int32_t* invQscale,
+                                              const uint16_t* propagateCost, int fpsFactorQ8, double weightDelta, double strength,
+                                              const double* qpOffset, double* cuTreeOffset)
+{
+    const unsigned loopIncr = 16, nw = (width + part - 1) / part, nh = (height + part - 1) / part;
+    for (unsigned y = 0, i = 0; y < nh; y++)
+        for (unsigned x = 0; x < nw; x++, i++)
+        {
+            const unsigned block_x = x * part, block_y = y * part;
+            unsigned blockXY = 0;
+            double log2_ratio = 0;
+            for (unsigned yy = block_y; yy < block_y + part && yy < (unsigned)height; yy += loopIncr)
+                for (unsigned xx = block_x; xx < block_x + part && xx < (unsigned)width; xx += loopIncr)
+                {
+                    const unsigned idx = ((yy / loopIncr) * blocksInRow) + (xx / loopIncr);
+                    int ic = (intraCost[idx] * invQscale[idx] + 128) >> 8;
+                    int pc = (propagateCost[idx] * fpsFactorQ8 + 128) >> 8;
+                    log2_ratio += (log2((double)(ic + pc)) - log2((double)ic) + weightDelta);
+                    blockXY++;
+                }
+            cuTreeOffset[i] = qpOffset[i] - (strength * log2_ratio) / blockXY;
+        }
+}
+
 /* the --qg-size 8 branches (slicetype.cpp:2903-2921, 2990-3002): offsets on the full-resolution 8x8 grid, costs on the lowres grid */
 void EXPORT(x265oracle_cutree_finish_qg8)(int widthInCU, int heightInCU, const int32_t* intraCost, const int32_t* invQscale8x8, const uint16_t* propagateCost,
                                           const double* qpAqOffset, int fpsFactorQ8, double weightDelta, double strength, double* qpCuTreeOffset)

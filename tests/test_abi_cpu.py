@@ -66,7 +66,8 @@ def test_ctypes_structures_match_the_c_header(repo_root, tmp_path):
              "x265hip_lowres_weight_cost_params": A.LowresWeightCostParams, "x265hip_lowres_weight_apply_params": A.LowresWeightApplyParams,
              "x265hip_sao_stats_params": A.SaoStatsParams, "x265hip_sao_apply_params": A.SaoApplyParams, "x265hip_plane": A.Plane,
              "x265hip_intra_recon_params": A.IntraReconParams, "x265hip_tu_tables": A.TuTablesRec, "x265hip_phase_planes_params": A.PhasePlanesParams,
-             "x265hip_aq_hevc_params": A.AqHevcParams, "x265hip_aq_hevc_offsets_params": A.AqHevcOffsetsParams}
+             "x265hip_aq_hevc_params": A.AqHevcParams, "x265hip_aq_hevc_offsets_params": A.AqHevcOffsetsParams,
+             "x265hip_cutree_finish_hevc_params": A.CuTreeFinishHevcParams}
     sys.path.insert(0, repo_root)
     from tools import seam_driver as SD          # the consumer-layer records the seam tools mirror
     pairs.update({"x265hip_me_cache_params": SD.CacheParams, "x265hip_me_cache_stats_t": SD.CacheStats,

@@ -701,6 +701,49 @@ def test_cutree_finish_and_recalculation_qg8_equal_reference_class(width, height
     assert score2 == int(rscore[0]) and np.array_equal(rows2, rrows)
 
 
+@pytest.mark.parametrize("width,height,qg,avg,qcomp,dist,wdelta", [(256, 128, 16, 1 / 30, 0.6, 0, 0.0), (416, 240, 32, 1 / 24, 0.6, 1, 0.4), (250, 138, 16, 1 / 60, 0.5, 1, 1.0),
+                                                                 (640, 360, 32, 0.2, 0.8, 2, 0.0)])
+def test_cutree_finish_with_hevc_aq_equals_reference_class(width, height, qg, avg, qcomp, dist, wdelta):
+    """cuTreeFinish with rc.hevcAq = Lookahead::computeCUTreeQpOffset (slicetype.cpp:2749-2887): every layer's dCuTreeOffset from its
+    dQpOffset and the block costs, strength 6 * (1 - qCompress); restatement and the library's host-side entry against the real class.
+    Blocks with a zero intra cost make their partition infinite / NaN upstream - kept (compared with NaN == NaN)."""
+    import importlib
+    import oracle_api as O
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    lib = _ref(8)
+    if not hasattr(lib, "x265ref_cutree_finish_hevc_aq"):
+        pytest.skip("oracle/_ref predates x265ref_cutree_finish_hevc_aq")
+    rng = np.random.default_rng([31, width, height])
+    wcu, hcu = (width // 2 + 7) >> 3, (height // 2 + 7) >> 3
+    n = wcu * hcu
+    intra = rng.integers(1, 9000, size=n).astype(np.int32)
+    intra[rng.random(n) < 0.01] = 0
+    invq = rng.integers(64, 1024, size=n).astype(np.int32)
+    prop = rng.integers(0, 65536, size=n).astype(np.uint16)
+    prop[::7] = 0
+    layers = [d for d in range(4) if O.AQ_LAYER_DEPTH[qg][d]]
+    counts = [((width + (64 >> d) - 1) // (64 >> d)) * ((height + (64 >> d) - 1) // (64 >> d)) for d in layers]
+    qp_in = rng.normal(0, 2, size=sum(counts))
+    got, parts = np.zeros(sum(counts)), np.zeros(4, np.int32)
+    lib.x265ref_cutree_finish_hevc_aq.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                                                                                             ctypes.c_double] + [ctypes.c_void_p] * 3
+    assert lib.x265ref_cutree_finish_hevc_aq(width, height, qg, intra.ctypes.data, invq.ctypes.data, prop.ctypes.data, 30, 1, avg, qcomp, dist, wdelta,
+                                             qp_in.ctypes.data, got.ctypes.data, parts.ctypes.data) == n
+    assert [int(parts[d]) for d in layers] == counts
+    fps_q8 = int(clip_duration(avg) / clip_duration(1 / 30) * 256)
+    weight_delta = (1.0 - wdelta) if (dist and wdelta > 0) else 0.0
+    strength = 6.0 * (1.0 - qcomp)
+    at = 0
+    for d, cnt in zip(layers, counts):
+        args = (width, height, 64 >> d, wcu, intra, invq, prop, fps_q8, weight_delta, strength, qp_in[at:at + cnt])
+        exp = O.cutree_finish_hevc_aq(8, *args)
+        assert np.array_equal(exp, got[at:at + cnt], equal_nan=True), f"layer {d}: {np.count_nonzero(exp != got[at:at + cnt])} offsets differ from the real class"
+        mine = A.cutree_finish_hevc_aq(*args)
+        assert np.array_equal(mine, got[at:at + cnt], equal_nan=True), f"layer {d}: the library entry differs from the real class"
+        assert np.isfinite(exp).sum() > cnt // 2
+        at += cnt
+
+
 def sao_case(depth, width, height, seed):
     """Source / deblocked-like pair and random per-CTU SAO parameters (all five types, off, merge-left runs)."""
     rng = np.random.default_rng([21, depth, width, seed])

@@ -840,6 +840,40 @@ extern "C" int x265hip_frame_cost_recalculate_qg8(const x265hip_frame_cost_recal
     return 0;
 }
 
+// cuTree with --hevc-aq (Lookahead::computeCUTreeQpOffset, slicetype.cpp:2749-2887, quantisation groups of 16 or more): per partition
+// of one layer the mean, over the 16x16 blocks it covers, of log2(intra + propagate) - log2(intra) + weight_delta, scaled by the cuTree
+// strength and taken off the layer's dQpOffset.  Blocks whose scaled intra cost is 0 are NOT skipped here (the reference does not
+// either): their term is +inf or NaN and so is the partition's offset.
+extern "C" int x265hip_cutree_finish_hevc_aq(const x265hip_cutree_finish_hevc_params* p)
+{
+    if (!p || !p->intra_cost || !p->inv_qscale || !p->propagate_cost || !p->qp_offset || !p->cutree_offset) { set_error("cutree_finish_hevc_aq: NULL operand"); return X265HIP_EINVAL; }
+    if (p->part != 64 && p->part != 32 && p->part != 16) { set_error("cutree_finish_hevc_aq: partition size %d (64, 32, 16)", p->part); return X265HIP_EINVAL; }
+    if (p->width <= 0 || p->height <= 0 || p->blocks_in_row <= 0) { set_error("cutree_finish_hevc_aq: picture size"); return X265HIP_EINVAL; }
+    const uint32_t part = (uint32_t)p->part, w = (uint32_t)p->width, h = (uint32_t)p->height, loopIncr = 16;
+    const uint32_t nw = (w + part - 1) / part, nh = (h + part - 1) / part;
+    const double* pcQP = p->qp_offset;
+    double* pcCuTree = p->cutree_offset;
+    for (uint32_t y = 0; y < nh; y++)
+        for (uint32_t x = 0; x < nw; x++, pcQP++, pcCuTree++)
+        {
+            const uint32_t block_x = x * part, block_y = y * part;
+            uint32_t blockXY = 0;
+            double log2_ratio = 0;
+            for (uint32_t yy = block_y; yy < block_y + part && yy < h; yy += loopIncr)
+                for (uint32_t xx = block_x; xx < block_x + part && xx < w; xx += loopIncr)
+                {
+                    const uint32_t idx = (yy / loopIncr) * (uint32_t)p->blocks_in_row + xx / loopIncr;
+                    const int intraCost = (p->intra_cost[idx] * p->inv_qscale[idx] + 128) >> 8;
+                    const int propagateCost = (p->propagate_cost[idx] * p->fps_factor_q8 + 128) >> 8;
+                    log2_ratio += (std::log2((double)(intraCost + propagateCost)) - std::log2((double)intraCost) + p->weight_delta);
+                    blockXY++;
+                }
+            const double qp_offset = (p->strength * log2_ratio) / blockXY;
+            *pcCuTree = *pcQP - qp_offset;
+        }
+    return 0;
+}
+
 extern "C" int x265hip_frame_cost_recalculate(const x265hip_frame_cost_recalculate_params* p)
 {
     if (!p || !p->lowres_costs || !p->qp_cutree_offset || !p->row_satds || !p->score) { set_error("frame_cost_recalculate: NULL operand"); return X265HIP_EINVAL; }

@@ -451,6 +451,31 @@ def cutree_finish(intra_cost, inv_qscale, propagate_cost, qp_aq_offset, fps_fact
     return out
 
 
+class CuTreeFinishHevcParams(ctypes.Structure):
+    """x265hip_cutree_finish_hevc_params (include/x265hip.h)."""
+    _fields_ = [("width", ctypes.c_int), ("height", ctypes.c_int), ("part", ctypes.c_int), ("blocks_in_row", ctypes.c_int),
+                ("intra_cost", ctypes.c_void_p), ("inv_qscale", ctypes.c_void_p), ("propagate_cost", ctypes.c_void_p),
+                ("fps_factor_q8", ctypes.c_int), ("weight_delta", ctypes.c_double), ("strength", ctypes.c_double),
+                ("qp_offset", ctypes.c_void_p), ("cutree_offset", ctypes.c_void_p)]
+
+
+def cutree_finish_hevc_aq(width, height, part, blocks_in_row, intra_cost, inv_qscale, propagate_cost, fps_factor_q8, weight_delta, strength, qp_offset):
+    """x265hip_cutree_finish_hevc_aq (host-side): one layer's dCuTreeOffset from its dQpOffset; numpy arrays in, float64 [partitions] out."""
+    import numpy as np
+    ic, iq, pc = np.ascontiguousarray(intra_cost, np.int32), np.ascontiguousarray(inv_qscale, np.int32), np.ascontiguousarray(propagate_cost, np.uint16)
+    qo = np.ascontiguousarray(qp_offset, np.float64)
+    out = np.zeros_like(qo)
+    p = CuTreeFinishHevcParams()
+    p.width, p.height, p.part, p.blocks_in_row = width, height, part, blocks_in_row
+    p.intra_cost, p.inv_qscale, p.propagate_cost = ic.ctypes.data, iq.ctypes.data, pc.ctypes.data
+    p.fps_factor_q8, p.weight_delta, p.strength = int(fps_factor_q8), float(weight_delta), float(strength)
+    p.qp_offset, p.cutree_offset = qo.ctypes.data, out.ctypes.data
+    f = lib().x265hip_cutree_finish_hevc_aq
+    f.argtypes = [ctypes.POINTER(CuTreeFinishHevcParams)]
+    check(f(ctypes.byref(p)), "x265hip_cutree_finish_hevc_aq")
+    return out
+
+
 def cutree_finish_qg8(width_in_cu, height_in_cu, intra_cost, inv_qscale8x8, propagate_cost, qp_aq_offset, fps_factor_q8, weight_delta, strength, qp_cutree_offset):
     """x265hip_cutree_finish_qg8: the --qg-size 8 branch (offsets on the full-resolution grid); returns the updated copy."""
     import numpy as np
