@@ -87,3 +87,31 @@ def test_cutree_host_side_equals_oracle_on_random_parameters():
         score_w, rows_w = O.frame_cost_recalculate(8, wcu, hcu, lc, got)
         score_g, rows_g = A.frame_cost_recalculate(wcu, hcu, lc, got)
         assert score_g == score_w and np.array_equal(rows_g, rows_w), f"frame_cost_recalculate: {wcu}x{hcu}"
+
+
+def test_cutree_qg8_and_hevc_aq_host_side_equal_oracle_on_random_parameters():
+    """The --qg-size 8 and --hevc-aq flavours of the cuTree host functions against the oracle, random costs / strengths / deltas / sizes."""
+    import oracle_api as O
+    rng = np.random.default_rng(2029)
+    for it in range(40):
+        wcu, hcu = int(rng.integers(2, 40)), int(rng.integers(2, 30))
+        n = wcu * hcu
+        intra = rng.integers(0, 4000, size=n).astype(np.int32)
+        invq = rng.integers(1, 1024, size=n).astype(np.int32)
+        prop = rng.integers(0, 65536, size=n).astype(np.uint16)
+        fps_q8, wdelta, strength = int(rng.integers(1, 2000)), float(rng.uniform(0, 1)) * int(rng.integers(0, 2)), float(rng.uniform(0.1, 6.0))
+        qpaq, preset = rng.uniform(-3, 3, size=4 * n), rng.uniform(-5, 5, size=4 * n)
+        want = O.cutree_finish_qg8(8, wcu, hcu, intra, invq, prop, qpaq, fps_q8, wdelta, strength, preset)
+        got = A.cutree_finish_qg8(wcu, hcu, intra, invq, prop, qpaq, fps_q8, wdelta, strength, preset)
+        assert np.array_equal(got, want), f"cutree_finish_qg8: {wcu}x{hcu} strength {strength!r}"
+        lc = rng.integers(0, 65536, size=n).astype(np.uint16)
+        sw, rw = O.frame_cost_recalculate_qg8(8, wcu, hcu, lc, got)
+        sg, rg = A.frame_cost_recalculate_qg8(wcu, hcu, lc, got)
+        assert sg == sw and np.array_equal(rg, rw)
+        part = int(rng.choice([16, 32, 64]))
+        width, height = 16 * wcu - int(rng.integers(0, 15)), 16 * hcu - int(rng.integers(0, 15))
+        cnt = ((width + part - 1) // part) * ((height + part - 1) // part)
+        qo = rng.uniform(-4, 4, size=cnt)
+        intra1 = np.maximum(intra, 1)
+        args = (width, height, part, wcu, intra1, np.maximum(invq, 256), prop, fps_q8, wdelta, strength, qo)
+        assert np.array_equal(A.cutree_finish_hevc_aq(*args), O.cutree_finish_hevc_aq(8, *args), equal_nan=True), f"cutree_finish_hevc_aq: {width}x{height} part {part}"
