@@ -94,7 +94,7 @@ def _ring_serial(nframes, w64, h64, bands, lag):
     return outs
 
 
-def _ring_worker(rank, world, port, steps, out, staged=False):
+def _ring_worker(rank, world, port, steps, out, staged=False, with_context=False):
     sys.path.insert(0, ROOT)
     P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -117,7 +117,26 @@ def _ring_worker(rank, world, port, steps, out, staged=False):
         def band(b, row0, n, f=f, o=o):
             order.append((f, b))
             _fake_band(f, ref, o, geom, w64, h64, row0, n, lag, b == 0, b == len(bands) - 1)
-        ring.run_frame(step, geom, ref, o, band, total_frames=total)
+        if with_context:
+            # the hook the banded pipeline's stream contexts plug into: band b is waited for / processed / sent INSIDE context b, one at a time
+            import contextlib
+            events = []
+
+            @contextlib.contextmanager
+            def ctx(b, events=events):
+                events.append(("enter", b))
+                try:
+                    yield
+                finally:
+                    events.append(("exit", b))
+
+            def band_in_ctx(b, row0, n, band=band, events=events):
+                assert events and events[-1] == ("enter", b), "the band function ran outside its context"
+                band(b, row0, n)
+            ring.run_frame(step, geom, ref, o, band_in_ctx, total_frames=total, band_context=ctx)
+            assert events == [e for b in range(len(bands)) for e in (("enter", b), ("exit", b))]
+        else:
+            ring.run_frame(step, geom, ref, o, band, total_frames=total)
         mine[f] = [p.clone() for p in o]
         if world == 1:
             ref = [p.clone() for p in o]
@@ -129,11 +148,11 @@ def _ring_worker(rank, world, port, steps, out, staged=False):
     dist.destroy_process_group()
 
 
-def _run_ring(world, steps, staged=False):
+def _run_ring(world, steps, staged=False, with_context=False):
     mgr = mp.Manager()
     out = mgr.dict()
-    port = 29600 + (os.getpid() % 300) + world + (10 if staged else 0)
-    mp.spawn(_ring_worker, args=(world, port, steps, out, staged), nprocs=world, join=True)
+    port = 29600 + (os.getpid() % 300) + world + (10 if staged else 0) + (20 if with_context else 0)
+    mp.spawn(_ring_worker, args=(world, port, steps, out, staged, with_context), nprocs=world, join=True)
     return out
 
 
@@ -153,3 +172,10 @@ def test_ring_two_ranks_with_host_staged_transfers():
     """The dry-run flavour bench.py uses when the backend has no device point-to-point transfers (X265HIP_BENCH_BACKEND=gloo)."""
     out = _run_ring(2, 3, staged=True)
     assert out[0][0] and out[1][0]
+
+
+def test_ring_two_ranks_with_band_contexts():
+    """run_frame(band_context=): every band is waited for, processed and sent inside its own context (the banded pipeline's HIP stream of
+    that band), in band order - and the frame chain still comes out as the serial one."""
+    out = _run_ring(2, 3, with_context=True)
+    assert out[0][0] and out[1][0], "a rank's frames differ from the serial chain"
