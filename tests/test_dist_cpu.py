@@ -179,3 +179,14 @@ def test_ring_two_ranks_with_band_contexts():
     that band), in band order - and the frame chain still comes out as the serial one."""
     out = _run_ring(2, 3, with_context=True)
     assert out[0][0] and out[1][0], "a rank's frames differ from the serial chain"
+
+
+def test_band_size_follows_the_rank_count():
+    """bench.py's pick_band_rows: the ring delivers N pictures per max(step, N x lag), so more ranks want smaller bands; the choice is one
+    of the measured sizes and never larger for more ranks."""
+    sys.path.insert(0, ROOT)
+    import bench as B
+    rows = [B.pick_band_rows(n) for n in (2, 3, 4, 6, 8, 16)]
+    assert all(r in B.BANDED_STEP_MS for r in rows)
+    assert rows == sorted(rows, reverse=True) and rows[0] > rows[-1]
+    assert B.pick_band_rows(8, ctu_rows=68) >= B.pick_band_rows(8, ctu_rows=34)          # an 8K picture has twice the bands per picture
