@@ -189,4 +189,19 @@ int x265ref_motion_compensation(const void* ref0, const void* ref0Cb, const void
     return rc;
 }
 
+/* The REAL Predict::predIntraLumaAng / predIntraChromaAng (predict.cpp:579-598) on caller-supplied neighbour arrays (the layout of
+ * Predict::intraNeighbourBuf: corner, 2N above, 2N left; [0] unfiltered, [1] filtered).  dst: n x n, stride n. */
+int x265ref_pred_intra(int mode, int log2Size, const void* unfiltered, const void* filtered, int chroma, void* dst)
+{
+    static bool tableReady = false;
+    if (!tableReady) { x265ref_encoder_table_reset_c(); tableReady = true; }
+    const int n = 1 << log2Size;
+    Predict pred;
+    memcpy(pred.intraNeighbourBuf[0], unfiltered, sizeof(pixel) * (4 * n + 1));
+    memcpy(pred.intraNeighbourBuf[1], filtered, sizeof(pixel) * (4 * n + 1));
+    if (chroma) pred.predIntraChromaAng((uint32_t)mode, (pixel*)dst, n, (uint32_t)log2Size);
+    else pred.predIntraLumaAng((uint32_t)mode, (pixel*)dst, n, (uint32_t)log2Size);
+    return 0;
+}
+
 } // extern "C"

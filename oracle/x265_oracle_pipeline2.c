@@ -697,6 +697,8 @@ static int intra_recon_core(const pixel* fenc, intptr_t fencStride, const pixel*
         pixel* rec = recon + jb->off[3];
         const int filter = !chroma && (kIntraFilterFlags[mode] & n);
         cu->intra_pred[mode](pred, n, nb + (filter ? jb->off[2] : jb->off[1]), mode, chroma ? 0 : log2n <= 4);
+        if (g_capPred)                    /* prediction capture (x265oracle_set_pred_capture): laid out like the candidates' reconstructions */
+            for (int y = 0; y < n; y++) memcpy(g_capPred + jb->off[3] + (intptr_t)y * g_capPredStride, pred + y * n, sizeof(pixel) * n);
         /* calcresidual assumes one stride for fenc / pred / residual (search.cpp:357); restate it for separate strides */
         for (int y = 0; y < n; y++)
             for (int x = 0; x < n; x++) resi[y * n + x] = (int16_t)((int)fe[y * fencStride + x] - (int)pred[y * n + x]);

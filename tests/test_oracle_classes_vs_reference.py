@@ -1444,3 +1444,40 @@ def test_inter_stage_predictions_equal_the_real_motion_compensation(depth, level
         with O.pred_capture(depth, pc2):
             O.inter_recon_chroma(depth, chroma[1][0][0], chroma[0][0][0], chroma[1][0][1], chroma[1][0][2], w64, h64, level, mvs[0], 30 + 6 * (depth - 8))
         assert np.array_equal(pc2, rcb)
+
+
+@pytest.mark.parametrize("depth,n,chroma", [(8, 4, False), (8, 8, False), (8, 16, False), (8, 32, False), (8, 4, True), (8, 16, True), (10, 8, False), (10, 32, False),
+                                            (10, 8, True), (12, 16, False)])
+def test_intra_stage_predictions_equal_the_real_predict_class(depth, n, chroma):
+    """The PREDICTION half of the intra TU stage - all 35 modes, the choice between the unfiltered and the filtered neighbours
+    (g_intraFilterFlags & size), edge smoothing up to 16x16, the chroma flavour's unfiltered / unsmoothed form - against the real
+    Predict::predIntraLumaAng / predIntraChromaAng (oracle/ref_predict.cpp) on random neighbour arrays."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_pred_intra"):
+        pytest.skip("oracle/_ref predates x265ref_pred_intra")
+    rng = np.random.default_rng([37, depth, n, int(chroma)])
+    dt = np.uint8 if depth == 8 else np.uint16
+    pmax = (1 << depth) - 1
+    nbw = 4 * n + 1
+    sets = 3
+    nb = rng.integers(0, pmax + 1, size=2 * nbw * sets).astype(dt)          # per set: unfiltered then "filtered" (any values: the choice is what is tested)
+    njobs = 35 * sets
+    src = np.zeros((n, n * njobs), dt)
+    jobs = np.zeros(njobs, dtype=np.dtype([("off", "<i8", 4), ("arg", "<i4", 4)]))
+    for t in range(njobs):
+        s_, mode = divmod(t, 35)
+        jobs["off"][t] = (t * n, 2 * nbw * s_, 2 * nbw * s_ + nbw, t * n * n)
+        jobs["arg"][t, 0] = mode
+    pred = np.zeros((njobs * n, n), dt)
+    with O.pred_capture(depth, pred):
+        O.intra_recon(depth, n, src.reshape(-1), n * njobs, nb, njobs * n * n, n, 30 + 6 * (depth - 8), 0, jobs, chroma=chroma)
+    lib.x265ref_pred_intra.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    log2n = int(np.log2(n))
+    for t in range(njobs):
+        s_, mode = divmod(t, 35)
+        unf, fil = nb[2 * nbw * s_:2 * nbw * s_ + nbw], nb[2 * nbw * s_ + nbw:2 * nbw * (s_ + 1)]
+        want = np.zeros((n, n), dt)
+        assert lib.x265ref_pred_intra(mode, log2n, np.ascontiguousarray(unf).ctypes.data, np.ascontiguousarray(fil).ctypes.data, int(chroma), want.ctypes.data) == 0
+        got = pred[t * n:(t + 1) * n]
+        assert np.array_equal(got, want), f"mode {mode} (neighbour set {s_}): {np.count_nonzero(got != want)} predicted samples differ"
