@@ -113,3 +113,43 @@ def test_error_policy_restore_host_hands_the_slots_back(repo_root):
         L.x265hip_set_error_policy(0)
     assert f(a.p, a.stride, b.p, b.stride) == want and L.x265hip_table_calls() > calls0 + 3
     assert L.x265hip_set_error_policy(7) < 0
+
+
+def test_restore_host_answers_every_slot_with_that_slots_own_host_function(repo_root):
+    """One stub serves many slots ([0]/[1] pairs, dct / standard_dct, intra_pred[2..34], cu[1..4].normFact, the chroma tables'
+    aliases of luma sizes); an asm-enabled host has a DIFFERENT function in each.  After a failure every GPU-backed slot must be
+    answered by the function the host had in exactly that slot (round-2 advisor finding: the saved pointer was per stub).  The host
+    table here holds one distinguishable dummy per slot."""
+    L = A.lib()
+    L.x265hip_table_inject_failure.argtypes = [ctypes.c_long]
+    depth = 8
+    seen, keep = [], []
+    mem = (ctypes.c_void_p * spec.TABLE_PTRS)()
+
+    def dummy(idx, proto, has_ret):
+        def f(*_a):
+            seen.append(idx)
+            return (idx & 0x7fff) if has_ret else None
+        cb = proto(f)
+        keep.append(cb)
+        return ctypes.cast(cb, ctypes.c_void_p).value
+    for path, (td, idx) in spec.SLOTS.items():
+        mem[idx] = dummy(idx, spec.prototype(td, depth), spec.TYPEDEFS[td][0].strip() != "void")
+    host = spec.Table(ctypes.addressof(mem), depth, keep)
+    hip, nset = load_hip_table(depth, base=host)
+    gpu_paths = [p for p in spec.SLOTS if hip.ptr(p) != host.ptr(p)]
+    assert len(gpu_paths) == nset > 1800
+    try:
+        assert L.x265hip_set_error_policy(1) == 0
+        L.x265hip_table_inject_failure(1)                      # the very next stub call fails before it touches an operand
+        for path in gpu_paths:
+            td, idx = spec.SLOTS[path]
+            ret, args = spec.TYPEDEFS[td]
+            seen.clear()
+            got = hip.fn(path)(*[None if a.strip().endswith("*") else 0 for a in args])
+            assert seen == [idx], f"{path}: answered by the host function of slot {seen} instead of its own ({idx})"
+            if ret.strip() != "void":
+                assert got == (idx & 0x7fff), path
+    finally:
+        L.x265hip_table_inject_failure(0)
+        L.x265hip_set_error_policy(0)

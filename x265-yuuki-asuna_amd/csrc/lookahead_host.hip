@@ -55,49 +55,80 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // Device copies of host planes the caller vouches for: plane_key != 0 names the CONTENT of a plane set (a picture's four lowres planes
 // do not change while its frame number stays the same), so the dozens of (p0, b, p1) triples the lookahead scores around a picture
 // upload each plane once.  Shared by all calling threads; entries are only read by kernels after their upload was synchronised.
-struct CachedPlane { const void* host; uint64_t key; size_t bytes; void* dev; uint64_t stamp; };
+// An entry handed out is PINNED until the call that asked for it has synchronised its stream (PlanePins below): neither the
+// same-host-buffer replacement nor the LRU eviction may free a buffer another thread's - or this call's own, not yet launched -
+// kernel is about to read (round-2 advisor finding).  A replaced but still pinned entry is only retired (host = NULL: it matches
+// no later request) and freed by whoever evicts next after its last user let go.
+struct CachedPlane { const void* host; uint64_t key; size_t bytes; void* dev; uint64_t stamp; int pins; };
 std::mutex g_planeMu;
 std::vector<CachedPlane> g_planes;
 uint64_t g_planeClock = 0;
 size_t g_planeBytes = 0;
 constexpr size_t PLANE_CACHE_LIMIT = (size_t)6 << 30;          // 6 GiB of HBM at most
 
-// returns the device copy of the host plane (allocation start `host`, `bytes` long), uploading it on `s` when it is not cached yet
+// returns the device copy of the host plane (allocation start `host`, `bytes` long), uploading it on `s` when it is not cached yet;
+// the entry comes back pinned (release_planes)
 int cached_plane(const void* host, uint64_t key, size_t bytes, hipStream_t s, void** out)
 {
     std::lock_guard<std::mutex> lk(g_planeMu);
     for (auto& e : g_planes)
-        if (e.host == host && e.key == key && e.bytes == bytes) { e.stamp = ++g_planeClock; *out = e.dev; return 0; }
+        if (e.host == host && e.key == key && e.bytes == bytes) { e.stamp = ++g_planeClock; e.pins++; *out = e.dev; return 0; }
     // evict: same host buffer with an older key (the picture was replaced), then least recently used beyond the limit
     for (size_t i = 0; i < g_planes.size();)
     {
-        if (g_planes[i].host == host) { (void)hipFree(g_planes[i].dev); g_planeBytes -= g_planes[i].bytes; g_planes.erase(g_planes.begin() + i); }
+        if (g_planes[i].host == host || (!g_planes[i].host && !g_planes[i].pins))
+        {
+            if (g_planes[i].pins) { g_planes[i].host = nullptr; i++; continue; }             // retired, freed once unpinned
+            (void)hipFree(g_planes[i].dev); g_planeBytes -= g_planes[i].bytes; g_planes.erase(g_planes.begin() + i);
+        }
         else i++;
     }
-    while (g_planeBytes + bytes > PLANE_CACHE_LIMIT && !g_planes.empty())
+    while (g_planeBytes + bytes > PLANE_CACHE_LIMIT)
     {
-        size_t lru = 0;
-        for (size_t i = 1; i < g_planes.size(); i++) if (g_planes[i].stamp < g_planes[lru].stamp) lru = i;
+        size_t lru = g_planes.size();
+        for (size_t i = 0; i < g_planes.size(); i++)
+            if (!g_planes[i].pins && (lru == g_planes.size() || g_planes[i].stamp < g_planes[lru].stamp)) lru = i;
+        if (lru == g_planes.size()) break;                      // everything left is in use: exceed the soft limit rather than free it
         (void)hipFree(g_planes[lru].dev); g_planeBytes -= g_planes[lru].bytes; g_planes.erase(g_planes.begin() + lru);
     }
     void* d = nullptr;
     X265HIP_TRY(hipMalloc(&d, bytes + 64));
-    X265HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s));
-    X265HIP_TRY(hipStreamSynchronize(s));                       // other threads may use the entry as soon as the lock is released
-    g_planes.push_back({ host, key, bytes, d, ++g_planeClock });
+    hipError_t e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);           // other threads may use the entry as soon as the lock is released
+    if (e != hipSuccess) { (void)hipFree(d); X265HIP_TRY(e); }
+    g_planes.push_back({ host, key, bytes, d, ++g_planeClock, 1 });
     g_planeBytes += bytes;
     *out = d;
     return 0;
 }
+
+// the planes one call took from the cache; unpinned when the call leaves (after its final stream synchronisation, or on an error path)
+struct PlanePins
+{
+    void* dev[16]; int n = 0;
+    hipStream_t stream;
+    explicit PlanePins(hipStream_t s) : stream(s) {}
+    void add(void* d) { if (n < 16) dev[n++] = d; }
+    ~PlanePins()
+    {
+        if (!n) return;
+        (void)hipStreamSynchronize(stream);          // error paths leave with work queued; the normal path is already idle here
+        std::lock_guard<std::mutex> lk(g_planeMu);
+        for (int i = 0; i < n; i++)
+            for (auto& e : g_planes) if (e.dev == dev[i] && e.pins > 0) { e.pins--; break; }
+    }
+};
 
 } // namespace
 
 extern "C" void x265hip_lowres_planes_forget(void)
 {
     std::lock_guard<std::mutex> lk(g_planeMu);
-    for (auto& e : g_planes) (void)hipFree(e.dev);
-    g_planes.clear();
-    g_planeBytes = 0;
+    for (size_t i = 0; i < g_planes.size();)          // entries a running call still reads are retired, not freed
+    {
+        if (g_planes[i].pins) { g_planes[i].host = nullptr; i++; continue; }
+        (void)hipFree(g_planes[i].dev); g_planeBytes -= g_planes[i].bytes; g_planes.erase(g_planes.begin() + i);
+    }
 }
 
 extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p)
@@ -155,6 +186,7 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
     if (bidir) for (int i = 0; i < 4; i++) planes[k++] = p->ref1[i];
     if (wbi) for (int i = 0; i < 4; i++) planes[k++] = p->ref_bi[i];
     uint8_t* dPlane[13];
+    PlanePins pins(s);                    // released when this call returns: after the final synchronisation below
     for (int i = 0; i < nplanes; i++)
     {
         if (pkey[i])
@@ -162,6 +194,7 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
             void* cp = nullptr;
             rc = cached_plane((const uint8_t*)planes[i] - org, pkey[i], planeBytes, s, &cp);
             if (rc) return rc;
+            pins.add(cp);
             dPlane[i] = (uint8_t*)cp;
         }
         else
@@ -231,11 +264,13 @@ extern "C" int x265hip_lowres_intra_host(const x265hip_lowres_intra_host_params*
     hipStream_t s = t.stream;
     uint8_t* d = t.dev;
     uint8_t* dPlane = d + oPlane;
+    PlanePins pins(s);
     if (p->plane_key)
     {
         void* cp = nullptr;
         rc = cached_plane((const uint8_t*)p->plane - org, p->plane_key, planeBytes, s, &cp);
         if (rc) return rc;
+        pins.add(cp);
         dPlane = (uint8_t*)cp;
     }
     else

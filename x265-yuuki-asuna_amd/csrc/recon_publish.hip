@@ -63,7 +63,11 @@ extern "C" int x265hip_recon_publish_rows(const x265hip_recon_publish_params* p,
     if (rc) return rc;
     std::call_once(g_rcclOnce, load_rccl);
     if (!g_rccl.lib || !g_rccl.bcast || !g_rccl.send || !g_rccl.recv || !g_rccl.groupStart || !g_rccl.groupEnd)
-    { set_error("recon_publish_rows: librccl.so (ncclBroadcast / ncclSend / ncclRecv) is not available: %s", dlerror() ? dlerror() : "symbols missing"); return X265HIP_ENODEV; }
+    {
+        const char* de = dlerror();          // ONE call: dlerror() clears the state it reports
+        set_error("recon_publish_rows: librccl.so (ncclBroadcast / ncclSend / ncclRecv) is not available: %s", de ? de : "symbols missing");
+        return X265HIP_ENODEV;
+    }
     const int bpp = p->depth == 8 ? 1 : 2;
     const bool first = p->ctu_row0 == 0, last = (p->ctu_row0 + p->ctu_rows) * 64 == p->height;
     // the band's rows as one contiguous slice of each padded plane: whole rows (side margins included), plus the top margin with the
@@ -82,6 +86,7 @@ extern "C" int x265hip_recon_publish_rows(const x265hip_recon_publish_params* p,
     }
     hipStream_t s = (hipStream_t)stream;
     int e = g_rccl.groupStart();
+    if (e) { set_error("recon_publish_rows: ncclGroupStart failed: %d (%s)", e, g_rccl.errStr ? g_rccl.errStr(e) : "?"); return X265HIP_ENODEV; }
     for (int i = 0; i < ns && !e; i++)
     {
         if (p->peer < 0) e = g_rccl.bcast(sl[i].ptr, sl[i].ptr, sl[i].bytes, NCCL_UINT8, p->root, p->comm, s);           // one-to-many

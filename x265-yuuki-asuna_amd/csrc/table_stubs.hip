@@ -649,11 +649,15 @@ template <int W, int H> struct AdsN { static constexpr int v = 4; };
 ADSN(4,4,1) ADSN(8,8,1) ADSN(8,4,2) ADSN(4,8,2) ADSN(16,8,2) ADSN(8,16,2) ADSN(16,12,1) ADSN(12,16,1) ADSN(16,4,1) ADSN(4,16,1)
 ADSN(32,16,2) ADSN(16,32,2) ADSN(64,32,2) ADSN(32,64,2)
 
-// Every stub goes into the table behind a guard that remembers what the host had in the slot: under X265HIP_ON_ERROR_RESTORE_HOST a
-// failed stub (and, from then on, every stub) answers with the host's own function.  A slot the host left NULL has nothing to restore
-// to: its guard aborts like the default policy.
-template <auto Stub> struct Guard;
-template <typename R, typename... A, R (*Stub)(A...)> struct Guard<Stub>
+// Every stub goes into the table behind a guard that remembers what the host had in THAT SLOT: under X265HIP_ON_ERROR_RESTORE_HOST a
+// failed stub (and, from then on, every stub) answers with the host's own function.  The guard is keyed by (stub, slot tag), not by
+// the stub alone: one stub serves many slots (the [0]/[1] alignment pairs, dct / standard_dct, the 33 angular intra slots, the
+// chroma tables' aliases of luma sizes) and an asm-enabled host has DIFFERENT functions there (pelFilterLumaStrong_V / _H,
+// saoCuOrgE2 / saoCuOrgE2_32, normFact8 / 16 / 32 / 64 ...) - each slot must be answered by its own (round-2 advisor finding).
+// A slot the host left NULL has nothing to restore to: its guard aborts like the default policy.  The saved pointers are
+// per-process statics like the reference's table itself (primitives.h:432): filling a second table re-points them at that table's host.
+template <auto Stub, int Tag> struct Guard;
+template <typename R, typename... A, R (*Stub)(A...), int Tag> struct Guard<Stub, Tag>
 {
     static inline R (*host)(A...) = nullptr;
     static R call(A... a)
@@ -667,6 +671,18 @@ template <typename R, typename... A, R (*Stub)(A...)> struct Guard<Stub>
         }
     }
 };
+template <auto Stub, int Tag, typename F> static inline void set_slot(F& slot, int& n)
+{
+    typedef Guard<Stub, Tag> G;
+    if (slot != &G::call) G::host = slot;
+    slot = &G::call;
+    n++;
+}
+// consecutive slots served by one stub (intra_pred[2..34]): a guard per slot all the same
+template <auto Stub, int Tag, typename F, size_t... M> static inline void set_slots(F* slots, int& n, std::index_sequence<M...>)
+{
+    (set_slot<Stub, 1000000 + Tag * 64 + (int)M>(slots[M], n), ...);
+}
 
 } // namespace
 
@@ -676,7 +692,7 @@ template <typename R, typename... A, R (*Stub)(A...)> struct Guard<Stub>
 int CAT(setup_primitives_d, X265HIP_DEPTH)(x265hip_EncoderPrimitives* p)
 {
     int n = 0;
-#define SET(slot, fn) do { typedef Guard<&fn> G_; if ((slot) != &G_::call) G_::host = (slot); (slot) = &G_::call; n++; } while (0)
+#define SET(slot, fn) set_slot<&fn, __COUNTER__>((slot), n)
 #define SET2(slot, fn) do { SET((slot)[0], fn); SET((slot)[1], fn); } while (0)
 
 #define SET_PU(W, H) { auto& u = p->pu[X265HIP_LUMA_##W##x##H]; \
@@ -697,14 +713,15 @@ int CAT(setup_primitives_d, X265HIP_DEPTH)(x265hip_EncoderPrimitives* p)
     SET2(c.ssd_s, (ssd_s_stub<N>)); SET(c.sa8d, (cmp_stub<X265HIP_CMP_SA8D, N, N>)); SET(c.transpose, (transpose_stub<N>)); \
     SET(c.ssimDist, (ssim_dist_stub<N>)); }
     SET_CU(0, 4) SET_CU(1, 8) SET_CU(2, 16) SET_CU(3, 32) SET_CU(4, 64)
-    for (int i = 1; i < 5; i++) SET(p->cu[i].normFact, norm_fact_stub);          // the reference leaves cu[BLOCK_4x4].normFact NULL (pixel.cpp:1354-1357)
+    SET(p->cu[1].normFact, norm_fact_stub); SET(p->cu[2].normFact, norm_fact_stub); SET(p->cu[3].normFact, norm_fact_stub);
+    SET(p->cu[4].normFact, norm_fact_stub);          // the reference leaves cu[BLOCK_4x4].normFact NULL (pixel.cpp:1354-1357)
 
 #define SET_TU(I, N) { auto& c = p->cu[I]; \
     SET(c.dct, (fwd_tr_stub<X265HIP_TR_DCT, N>)); SET(c.standard_dct, (fwd_tr_stub<X265HIP_TR_DCT, N>)); SET(c.idct, (inv_tr_stub<X265HIP_TR_IDCT, N>)); \
     SET(c.copy_cnt, (copy_cnt_stub<N>)); SET(c.count_nonzero, (count_nonzero_stub<N>)); \
     SET(c.intra_filter, (intra_filter_stub<N>)); SET(c.intra_pred_allangs, (intra_allangs_stub<N>)); \
     SET(c.intra_pred[0], (intra_pred_stub<N, 0>)); SET(c.intra_pred[1], (intra_pred_stub<N, 1>)); \
-    for (int m = 2; m < 35; m++) SET(c.intra_pred[m], (intra_pred_stub<N, 2>)); }
+    set_slots<&intra_pred_stub<N, 2>, __COUNTER__>(&c.intra_pred[2], n, std::make_index_sequence<33>()); }
     SET_TU(0, 4) SET_TU(1, 8) SET_TU(2, 16) SET_TU(3, 32)
     SET(p->cu[1].lowpass_dct, (fwd_tr_stub<X265HIP_TR_LOWPASS_DCT, 8>));
     SET(p->cu[2].lowpass_dct, (fwd_tr_stub<X265HIP_TR_LOWPASS_DCT, 16>));

@@ -932,6 +932,11 @@ class BandedFramePipeline:
         rows = h64 // 64
         self.bands = [(r, min(band_rows, rows - r)) for r in range(0, rows, band_rows)]
         kw.pop("lookahead_cost_batch", None)
+        # options that make a stage read or write WHOLE pictures per call have no banded meaning: every band would recompute the whole
+        # reference's phase planes, and in ring mode read reference rows that have not arrived yet (round-2 advisor finding)
+        for opt in ("subpel_planes", "parallel_planes", "split"):
+            if kw.get(opt):
+                raise ValueError(f"BandedFramePipeline: {opt} is a whole-picture option and cannot be forwarded to the band pipelines")
         # streams > 1: band b runs on HIP stream b % streams with its own set of stage buffers.  The bands of one picture do not depend on
         # each other (each is a slice), so the exhaustive search of band b + 1 - the one launch that fills the chip - overlaps the
         # reconstruction / deblocking / SAO launches of band b, which at band size are a few dozen workgroups each and bound by their own
