@@ -235,6 +235,22 @@ def load_traffic(width, height, rng_r, fmt):
         return None, None
 
 
+def load_stage_traffic(width, height, depth):
+    """Per-kernel HBM traffic and duration of the default step's launches from the committed PMC summary (profiles/stage_traffic.json,
+    made by tools/pmc_to_traffic.py from profiles/rNN_bench_pmc.txt + rNN_bench_kernel_stats.txt): the physical roofline fraction of
+    every stage kernel, weakest first.  Only valid for the configuration the profile was taken on (3840x2160 8-bit)."""
+    if (width, height, depth) != (3840, 2160, 8):
+        return None
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "stage_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    rows = [{"kernel": k, "hbm_bytes": v["fetch_bytes"] + v["write_bytes"], "avg_us": v["avg_us"], "gbytes_per_s": v["gbytes_per_s"],
+             "frac_traffic": v["frac_of_8tb"]} for k, v in t["kernels"].items()]
+    rows.sort(key=lambda r: r["frac_traffic"])
+    return {"source": t["source"], "peak_gbytes_per_s": HBM_PEAK_GBS, "kernels": rows}
+
+
 # One MI355X, 3840x2160 8-bit, three band streams (profiles/r02_band_size.txt; bands of 5 rows and more with the record-per-lane search
 # kernel): milliseconds per picture against the CTU rows per band.
 # Small bands cost launches whose grids no longer fill the chip; large bands make the next rank wait longer for its first reference rows.
@@ -510,9 +526,16 @@ def main():
                                    + ("<surf,best>" if surf_mode else "<best>"),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                         # the PHYSICAL fraction beside the contractual one: HBM bytes the counters saw / the live launch time / peak.
+                         # `frac` prices SURVEY 8(d)'s algorithmic bytes (window re-reads that LDS serves, 4 B per candidate where the
+                         # packed records hold 2.14) - it is the contract's number, this one is what the memory system really carries
+                         "frac_traffic": round(traffic / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "output_bytes_per_launch": ms.hbm_floor_bytes(1 if args.depth == 8 else 2),
                          "launch_ms": stages[dom]},
         }
+        sr = load_stage_traffic(args.width, args.height, args.depth)
+        if sr:
+            out["stages_roofline"] = sr
         if banded:
             out["roofline"]["note"] = ("stage times and roofline are whole-frame launches of rank 0 (untimed pass after the loop); the timed loop runs the "
                                        f"same stages band by band ({args.band_rows} CTU rows per band, row-walking search kernel per band)")

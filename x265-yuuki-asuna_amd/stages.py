@@ -934,7 +934,8 @@ class BandedFramePipeline:
         kw.pop("lookahead_cost_batch", None)
         # options that make a stage read or write WHOLE pictures per call have no banded meaning: every band would recompute the whole
         # reference's phase planes, and in ring mode read reference rows that have not arrived yet (round-2 advisor finding)
-        for opt in ("subpel_planes", "parallel_planes", "split"):
+        # (parallel_planes - the Cb / Cr chains of a band on their own streams - IS a per-band option: tests/test_gpu_banded.py)
+        for opt in ("subpel_planes", "split"):
             if kw.get(opt):
                 raise ValueError(f"BandedFramePipeline: {opt} is a whole-picture option and cannot be forwarded to the band pipelines")
         # streams > 1: band b runs on HIP stream b % streams with its own set of stage buffers.  The bands of one picture do not depend on
