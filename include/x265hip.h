@@ -37,6 +37,7 @@ extern "C" {
 #define X265HIP_ENODEV       -1   /* no HIP device / runtime error (see x265hip_last_error) */
 #define X265HIP_EINVAL       -2   /* bad argument (size, depth, alignment, NULL) */
 #define X265HIP_EUNSUPPORTED -3   /* valid in the reference, not implemented on the GPU path */
+#define X265HIP_EBUSY        -4   /* every entry of a bounded pool is in use; retry later or create the object with a larger pool */
 
 const char* x265hip_version(void);
 const char* x265hip_last_error(void);          /* thread-local text of the last failure */
@@ -826,6 +827,57 @@ const void* x265hip_me_cache_surface(x265hip_me_cache* c, int slot);
 const volatile int* x265hip_me_cache_ready(x265hip_me_cache* c, int slot);
 int  x265hip_me_cache_stats(x265hip_me_cache* c, x265hip_me_cache_stats_t* st);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * ROW-GRANULAR consumer of the exhaustive search (csrc/me_stream.hip) for hosts that encode several pictures at once - the reference's
+ * frame threads.  Picture k + 1 starts while picture k is still being reconstructed; the reference publishes every finished CTU row of a
+ * reconstructed picture through Frame::m_reconRowFlag (encoder/framefilter.cpp:664) and consumers wait row by row
+ * (encoder/frameencoder.cpp:852-868).  The host hands rows over where it raises that flag (x265hip_me_stream_picture_rows), opens a
+ * (source, reference) pair when the first search of the pair is about to run (x265hip_me_stream_pair_open), and the service searches
+ * every CTU row of every open pair as soon as the reference rows its window reaches - row + (63 + range) / 64 - are on the device,
+ * raising ready[row] as the band's surfaces land in pinned host memory.  The host's own consumers wait for row + 3 (m_refLagRows with
+ * the sub-pel taps, frameencoder.cpp:161-164), so the device is two reference rows ahead of the first lookup of a row.
+ *   surf_format : record-contiguous formats only - X265HIP_SURF_PACKED (8-bit) or X265HIP_SURF_I32
+ *   min_level   : 0 = whole records; 1 = the 16x16 / 32x32 / 64x64 levels only: the LAST X265HIP_SURF_TAIL_BYTES_* bytes of every record
+ *                 (packed: uint16 [16][4] + int32 [5][4] = 208 bytes; int32: [21][4] = 336 bytes), same group order
+ *   slots       : (source, reference) pairs resident in host memory at once;  pictures : pictures resident on the device at once
+ *   band_rows   : most CTU rows searched by one launch (0 = 8)
+ * Keys name picture CONTENT (e.g. POC * 2 + is-reconstruction); a key may be reused once no open pair refers to it.
+ * Readers: a row of a slot is valid while ready[row] == the generation pair_open returned - check it before AND after reading (a
+ * reopened slot has its flags cleared before any row is rewritten).  Anything else is the host primitive's to answer. */
+#define X265HIP_SURF_TAIL_BYTES_PACKED 208
+#define X265HIP_SURF_TAIL_BYTES_I32    336
+typedef struct x265hip_me_stream x265hip_me_stream;
+typedef struct x265hip_me_stream_params
+{
+    int depth;
+    int width, height;
+    intptr_t stride;
+    int margin_x, margin_y;
+    int range;
+    int surf_format;
+    int min_level;
+    int slots;
+    int pictures;
+    int band_rows;
+} x265hip_me_stream_params;
+typedef struct x265hip_me_stream_stats_t
+{
+    uint64_t pairs_opened, pairs_completed, bands, rows_searched, rows_uploaded, failed, stale_pairs;
+    uint64_t us_busy;                        /* worker-thread wall time inside uploads / launches / downloads */
+    uint64_t bytes_downloaded, bytes_uploaded, surface_bytes;
+} x265hip_me_stream_stats_t;
+int  x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_params* p);
+void x265hip_me_stream_destroy(x265hip_me_stream* s);
+/* CTU rows [ctu_row0, ctu_row0 + ctu_rows) of picture `key` are final in `buf` = the whole allocated plane (the top margin travels with
+ * row 0, the bottom margin with the last row); the rows are copied before the call returns.  X265HIP_EBUSY: no picture entry free. */
+int  x265hip_me_stream_picture_rows(x265hip_me_stream* s, uint64_t key, const void* buf, int ctu_row0, int ctu_rows);
+/* returns the slot's new GENERATION (> 0) or a negative error; the pictures' rows may arrive before or after */
+int  x265hip_me_stream_pair_open(x265hip_me_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key);
+const void* x265hip_me_stream_surface(x265hip_me_stream* s, int slot);
+const volatile int* x265hip_me_stream_ready(x265hip_me_stream* s, int slot);      /* int [height / 64] */
+int  x265hip_me_stream_record_bytes(x265hip_me_stream* s);
+int  x265hip_me_stream_stats(x265hip_me_stream* s, x265hip_me_stream_stats_t* st);
+
 /* Address arithmetic of a surface record (both formats), usable from any host language: the SAD of square PU `z` (z-order
  * index inside its level; level 0..3 = 8x8, 16x16, 32x32, 64x64) of CTU `ctu` at displacement (dx, dy), |dx|, |dy| <= range. */
 static inline int32_t x265hip_surf_lookup(const void* surf, int surf_format, int range, int ctu, int level, int z, int dx, int dy)
@@ -899,6 +951,37 @@ int  x265hip_phase_cache_submit(x265hip_phase_cache* c, int slot, const void* lu
 const void* x265hip_phase_cache_planes(x265hip_phase_cache* c, int slot, int plane);
 const volatile int* x265hip_phase_cache_ready(x265hip_phase_cache* c, int slot);
 int  x265hip_phase_cache_stats(x265hip_phase_cache* c, x265hip_phase_cache_stats_t* st);
+
+
+/* ROW-GRANULAR flavour (csrc/phase_stream.hip) for hosts that encode several pictures at once - the reference's frame threads: the
+ * producer side opens a slot for a reconstructed picture and hands its CTU rows over as they become final (where the reference raises
+ * Frame::m_reconRowFlag, encoder/framefilter.cpp:664); the phase planes grow line by line behind it.
+ *   progress : uint64 [2] per slot, [0] luma planes, [1] both chroma plane sets: generation << 32 | lines finished, counted from the top
+ *              of the buffer (lines [4, finished) of every phase plane are valid).  A reader checks it before AND after reading a block.
+ *   4:2:0 only when rows_c > 0: a CTU row is 64 luma / 32 chroma lines; rows = ctu_rows * 64 + 2 * margin_y, rows_c likewise with 32. */
+typedef struct x265hip_phase_stream x265hip_phase_stream;
+typedef struct x265hip_phase_stream_params
+{
+    int depth;
+    intptr_t stride;   int rows;   int margin_y;        /* luma buffer: pitch in samples, allocated rows, rows above sample (0,0) */
+    intptr_t stride_c; int rows_c; int margin_y_c;      /* each chroma buffer; rows_c = 0: luma only */
+    int ctu_rows;
+    int slots;                                          /* reference pictures resident (device + pinned host memory) at once */
+} x265hip_phase_stream_params;
+typedef struct x265hip_phase_stream_stats_t
+{
+    uint64_t opened, completed, bands, failed;
+    uint64_t us_busy;
+    uint64_t bytes_downloaded, bytes_uploaded, bytes_per_picture;
+} x265hip_phase_stream_stats_t;
+int  x265hip_phase_stream_create(x265hip_phase_stream** out, const x265hip_phase_stream_params* p);
+void x265hip_phase_stream_destroy(x265hip_phase_stream* s);
+int  x265hip_phase_stream_open(x265hip_phase_stream* s, int slot);                       /* -> the slot's new GENERATION (> 0) */
+int  x265hip_phase_stream_rows(x265hip_phase_stream* s, int slot, int generation, const void* luma_buf, const void* cb_buf, const void* cr_buf,
+                               int ctu_row0, int ctu_rows);
+const void* x265hip_phase_stream_planes(x265hip_phase_stream* s, int slot, int plane);   /* 0: 15 luma planes, 1 / 2: 63 Cb / Cr planes */
+const volatile uint64_t* x265hip_phase_stream_progress(x265hip_phase_stream* s, int slot);
+int  x265hip_phase_stream_stats(x265hip_phase_stream* s, x265hip_phase_stream_stats_t* st);
 
 
 /* ---------------------------------------------------------------------------------------------------------------

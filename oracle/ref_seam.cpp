@@ -14,8 +14,13 @@
  *     anything else - other callers, a CTU row whose surfaces have not arrived, displacements outside the window - goes to the
  *     host's original primitive.  Both routes return the same integers, so the bitstream cannot change; with
  *     X265REF_SEAM_VERIFY=1 every lookup is checked against the original primitive on the spot.
- * Requires --frame-threads 1 (a reference picture must be complete when the first PU of the next picture searches it; the
- * reference's row-lagged frame parallelism would need per-row submits) and unweighted references; otherwise it stays out of the way.
+ * Two provider flavours.  PICTURE-GRANULAR (x265hip_me_cache / x265hip_phase_cache): a reference picture must be complete when the
+ * first PU of the next picture searches it, i.e. --frame-threads 1; with more frame threads these seams step aside.
+ * ROW-GRANULAR (x265hip_me_stream / x265hip_phase_stream, round 3): this file also takes over FrameFilter::processPostRow - the
+ * function that raises Frame::m_reconRowFlag[row] (framefilter.cpp:664) - and hands every finished CTU row of a reconstructed picture
+ * to the providers right after the reference's own body; pairs are opened by the first search of a (picture, reference) and searched
+ * on the device row by row behind the producer, so the seams serve under the reference's own frame threads (-F 5 on 16 cores).
+ * Unweighted references only; otherwise the seams stay out of the way.
  *
  * The provider is a table of C function pointers with the signatures of x265hip_me_cache_submit / _surface / _ready
  * (include/x265hip.h), so the GPU library plugs in directly; the CPU-only tests plug in the oracle's exhaustive search instead. */
@@ -31,6 +36,7 @@
 #include "reference.h"
 #include "lowres.h"
 #include "slicetype.h"
+#include "framefilter.h"
 
 #include <atomic>
 #include <cstddef>
@@ -46,6 +52,7 @@ using namespace X265_NS;
 extern "C" int x265ref_orig_motionEstimate(MotionEstimate* self, ReferencePlanes* ref, const MV* mvmin, const MV* mvmax, const MV* qmvp,
                                            int numCandidates, const MV* mvc, int merange, MV* outQMv, uint32_t maxSlices, pixel* srcReferencePlane);
 
+extern "C" void x265ref_orig_processPostRow(FrameFilter* self, int row);
 extern "C" int x265ref_orig_subpelCompare(MotionEstimate* self, ReferencePlanes* ref, const MV* qmv, pixelcmp_t cmp);
 extern "C" int64_t x265ref_orig_estimateFrameCost(CostEstimateGroup* self, LookaheadTLD* tld, int p0, int p1, int b, bool bIntraPenalty);
 extern "C" void x265ref_orig_lowresIntraEstimate(LookaheadTLD* self, Lowres* fenc, uint32_t qgSize);
@@ -115,6 +122,11 @@ struct Provider
     int (*submit_batch)(void* ctx, int n, const int* slots, const void* fenc_buf, uint64_t fenc_key, const void* const* ref_bufs, int* generations);
     const void* (*surface)(void* ctx, int slot);
     const volatile int* (*ready)(void* ctx, int slot);
+    /* row-granular flavour (x265hip_me_stream_picture_rows / _pair_open signatures); streamed = both are set */
+    int (*picture_rows)(void* ctx, uint64_t key, const void* buf, int ctu_row0, int ctu_rows);
+    int (*pair_open)(void* ctx, int slot, uint64_t fenc_key, uint64_t ref_key);
+    bool streamed;
+    int min_level;                /* 1: records hold the 16x16 / 32x32 / 64x64 levels only (X265HIP_SURF_TAIL_BYTES_*) */
     int range, surf_format, slots;
     int width, height;            /* whole CTUs */
     intptr_t stride;
@@ -122,7 +134,8 @@ struct Provider
     int min_pu;                   /* serve partitions whose smaller side is >= min_pu (8, 16, 32 or 64) */
 };
 
-struct Pair { int fencPoc; const PicYuv* rec; int recPoc; int slot; int gen; bool used; };
+struct Pair { int fencPoc; const PicYuv* rec; int recPoc; int slot; int gen; bool used; int encodeOrder; };
+struct FencStaged { int poc; int encodeOrder; bool used; };
 
 struct Seam
 {
@@ -132,12 +145,17 @@ struct Seam
     size_t ctuBytes;
     std::mutex mu;
     Pair pairs[MAX_SLOTS];
+    FencStaged fencs[32];               /* streamed: source pictures already handed to the provider */
+    uint64_t instance = 0;              /* bumped by every configure: a POC names a picture's content only within one encode */
     std::atomic<int> epoch{0};          /* bumped on every (re)assignment of a slot: invalidates the thread-local pair caches */
     pixelcmp_t sad[NUM_PU_SIZES];
     pixelcmp_x3_t sad_x3[NUM_PU_SIZES];
     pixelcmp_x4_t sad_x4[NUM_PU_SIZES];
     std::atomic<uint64_t> hits{0}, outside{0}, notReady{0}, meCalls{0}, meServed{0}, submits{0}, mismatches{0}, noSlot{0}, foreign{0};
+    std::atomic<uint64_t> rowsPublished{0}, rowsRefused{0}, torn{0};
 } g;
+enum { MAX_SLOTS_STREAMED = 64 };
+inline uint64_t pic_key(uint64_t instance, int poc, int isRecon) { return (instance << 40) | ((uint64_t)(uint32_t)poc << 1) | (uint64_t)isRecon; }
 
 struct Part { uint16_t off; uint16_t wide; };      /* byte offset of entry [z][0] inside a group record; wide = int32 entries */
 
@@ -173,6 +191,7 @@ bool decompose(int px, int py, int w, int h, int bx, int by, int size, Ctx& c)
     {
         if (c.nparts == MAX_PARTS) return false;
         const int level = size == 8 ? 0 : size == 16 ? 1 : size == 32 ? 2 : 3;
+        if (g.p.min_level && level == 0) return false;                     /* the 8x8 level was not downloaded */
         const int ux = bx / size, uy = by / size;
         int z = 0;
         for (int b = 0; b < 3; b++) z |= ((ux >> b) & 1) << (2 * b) | ((uy >> b) & 1) << (2 * b + 1);
@@ -181,7 +200,7 @@ bool decompose(int px, int py, int w, int h, int bx, int by, int size, Ctx& c)
         {
             static const int base[4] = { 0, 512, 640, 704 };
             q.wide = level >= 2;
-            const int o = base[level] + z * (q.wide ? 16 : 8);            /* byte offset inside the 720-byte packed record */
+            const int o = base[level] + z * (q.wide ? 16 : 8) - (g.p.min_level ? 512 : 0);      /* byte offset inside the 720-byte packed record (208-byte tail) */
             /* chunk-major rows (X265HIP_SURF_PACKED_T): 16-byte chunk c of group g sits at row + (c * groups + g) * 16 */
             q.off = (uint16_t)(g.p.surf_format == SURF_PACKED_T ? (o >> 4) * g.ng * 16 + (o & 15) : o);
         }
@@ -189,7 +208,7 @@ bool decompose(int px, int py, int w, int h, int bx, int by, int size, Ctx& c)
         {
             static const int base[4] = { 0, 64, 80, 84 };
             q.wide = 1;
-            q.off = (uint16_t)((base[level] + z) * 16);
+            q.off = (uint16_t)((base[level] + z) * 16 - (g.p.min_level ? 1024 : 0));
         }
         return true;
     }
@@ -227,6 +246,9 @@ inline bool lookup(Ctx& c, const pixel* fref, int& out)
     int sum = 0;
     for (int i = 0; i < c.nparts; i++)
         sum += c.parts[i].wide ? ((const int32_t*)(rec + c.parts[i].off))[k] : ((const uint16_t*)(rec + c.parts[i].off))[k];
+    /* the row must STILL be this generation's after the read: a reopened slot has its flags cleared before any row is rewritten */
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (c.ready[c.ctuRow] != c.gen) { g.torn.fetch_add(1, std::memory_order_relaxed); return false; }
     c.hits++;
     out = sum;
     return true;
@@ -298,7 +320,7 @@ template <> struct Install<NUM_PU_SIZES> { static void run(EncoderPrimitives&, i
 /* slot of (source picture poc, reference picture); -1 when none can be had.  The first query for a new source picture requests the
  * surfaces of ALL its unweighted references as one batch (x265hip_me_cache_submit_batch: searched back to back, downloaded
  * row-interleaved), so the top CTU rows of every reference arrive first. */
-int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicYuv* rec, int recPoc, int& gen)
+int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicYuv* rec, int recPoc, int& gen, int encodeOrder, int frameThreads)
 {
     const int epoch = g.epoch.load(std::memory_order_acquire);
     if (t_pairs.fencPoc != fencPoc || t_pairs.epoch != epoch) { t_pairs.fencPoc = fencPoc; t_pairs.epoch = epoch; t_pairs.n = 0; }
@@ -337,13 +359,41 @@ int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicY
                 {
                     bool taken = false;
                     for (int j = 0; j < n; j++) taken |= slots[j] == i;
-                    if (!taken && (!g.pairs[i].used || g.pairs[i].fencPoc != fencPoc)) freeSlot = i;      /* an earlier picture's surfaces: its encode is over (-F 1) */
+                    /* picture-granular: an earlier picture's surfaces - its encode is over (-F 1).  Row-granular: frame encoders take the
+                     * pictures round robin in encode order and finish one before they start the next (encoder.cpp:1988-1989, :2394), so while
+                     * picture e is being encoded every picture of encode order <= e - frameThreads is done */
+                    const bool dead = !g.pairs[i].used || (g.p.streamed ? g.pairs[i].encodeOrder <= encodeOrder - frameThreads : g.pairs[i].fencPoc != fencPoc);
+                    if (!taken && dead) freeSlot = i;
                 }
                 if (freeSlot < 0) break;
                 slots[n] = freeSlot; bufs[n] = want[k]->m_picBuf[0]; n++;
             }
             int rc = -1;
-            if (n > 0 && g.p.submit_batch)
+            if (n > 0 && g.p.streamed)
+            {
+                /* the source picture travels once (whole: it is complete before its encode starts), then every pair is opened; the
+                 * reference pictures' rows arrive from the producer hook (FrameFilter::processPostRow below), before or after */
+                const uint64_t fkey = pic_key(g.instance, fencPoc, 0);
+                bool staged = false;
+                int freeF = -1;
+                for (int i = 0; i < 32; i++)
+                {
+                    if (g.fencs[i].used && g.fencs[i].poc == fencPoc) staged = true;
+                    if (!g.fencs[i].used || g.fencs[i].encodeOrder <= encodeOrder - frameThreads) freeF = i;
+                }
+                rc = 0;
+                if (!staged)
+                {
+                    rc = freeF < 0 ? -1 : g.p.picture_rows(g.p.ctx, fkey, fencPic->m_picBuf[0], 0, g.p.height / 64);
+                    if (!rc) { g.fencs[freeF].used = true; g.fencs[freeF].poc = fencPoc; g.fencs[freeF].encodeOrder = encodeOrder; }
+                }
+                for (int k = 0; k < n && rc == 0; k++)
+                {
+                    gens[k] = g.p.pair_open(g.p.ctx, slots[k], fkey, pic_key(g.instance, wantPoc[k], 1));
+                    if (gens[k] <= 0) rc = -1;
+                }
+            }
+            else if (n > 0 && g.p.submit_batch)
                 rc = g.p.submit_batch(g.p.ctx, n, slots, fencPic->m_picBuf[0], (uint64_t)(uint32_t)fencPoc, bufs, gens);
             else if (n > 0)
             {
@@ -360,6 +410,7 @@ int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicY
                 {
                     Pair& q = g.pairs[slots[k]];
                     q.used = true; q.fencPoc = fencPoc; q.rec = want[k]; q.recPoc = wantPoc[k]; q.slot = slots[k]; q.gen = gens[k];
+                    q.encodeOrder = encodeOrder;
                     g.submits++;
                 }
                 slot = slots[0]; gen = gens[0];            /* want[0] is the pair that was asked for */
@@ -382,6 +433,12 @@ struct PhaseProvider
     int (*submit)(void* ctx, int slot, const void* luma, const void* cb, const void* cr);
     const void* (*planes)(void* ctx, int slot, int plane);
     const volatile int* (*ready)(void* ctx, int slot);
+    /* row-granular flavour (x265hip_phase_stream_open / _rows / _progress signatures); streamed = all three are set */
+    int (*open)(void* ctx, int slot);
+    int (*rows_fn)(void* ctx, int slot, int gen, const void* luma, const void* cb, const void* cr, int ctu_row0, int ctu_rows);
+    const volatile uint64_t* (*progress)(void* ctx, int slot);
+    bool streamed;
+    int ctuRows;
     int slots;
     intptr_t stride;  int rows;
     intptr_t strideC; int rowsC;
@@ -395,7 +452,7 @@ struct SubSeam
     PhaseEntry e[MAX_SLOTS];
     uint64_t tick = 0;
     std::atomic<int> epoch{0};
-    std::atomic<uint64_t> served{0}, notReady{0}, noContext{0}, submits{0}, mismatches{0}, noSlot{0};
+    std::atomic<uint64_t> served{0}, notReady{0}, noContext{0}, submits{0}, mismatches{0}, noSlot{0}, rowsPublished{0}, torn{0};
 } gs;
 
 struct SubCtx
@@ -406,6 +463,7 @@ struct SubCtx
     const pixel* luma; const pixel* cb; const pixel* cr;      /* phase 1 of each plane set, buffer coordinates */
     size_t planeL, planeC;                                    /* samples per plane */
     const volatile int* ready;
+    const volatile uint64_t* progress;                        /* streamed: generation << 32 | lines finished, [0] luma [1] chroma */
     int gen;
     bool arrived[2];
 };
@@ -427,7 +485,7 @@ int phase_slot(const PicYuv* rec, int poc, const Slice* slice, int& gen)
         gs.tick++;
         for (int i = 0; i < gs.p.slots; i++)
             if (gs.e[i].used && gs.e[i].rec == rec && gs.e[i].poc == poc) { slot = i; gen = gs.e[i].gen; gs.e[i].lastUse = gs.tick; }
-        if (slot < 0)
+        if (slot < 0 && !gs.p.streamed)
         {
             int victim = -1;
             for (int i = 0; i < gs.p.slots; i++)
@@ -459,6 +517,30 @@ int phase_slot(const PicYuv* rec, int poc, const Slice* slice, int& gen)
     return slot;
 }
 
+/* producer side of the row-granular flavour: the slot that holds reconstructed picture (rec, poc), opened the first time one of its
+ * rows is published (least recently used slot: with more slots than the DPB holds pictures that one is long out of use) */
+int phase_slot_produce(const PicYuv* rec, int poc, int& gen)
+{
+    std::lock_guard<std::mutex> lk(gs.mu);
+    gs.tick++;
+    for (int i = 0; i < gs.p.slots; i++)
+        if (gs.e[i].used && gs.e[i].rec == rec && gs.e[i].poc == poc) { gen = gs.e[i].gen; gs.e[i].lastUse = gs.tick; return i; }
+    int victim = 0;
+    for (int i = 0; i < gs.p.slots; i++)
+    {
+        if (!gs.e[i].used) { victim = i; break; }
+        if (gs.e[i].lastUse < gs.e[victim].lastUse) victim = i;
+    }
+    const int gnew = gs.p.open(gs.p.ctx, victim);
+    if (gnew <= 0) return -1;
+    PhaseEntry& q = gs.e[victim];
+    q.used = true; q.rec = rec; q.poc = poc; q.gen = gnew; q.lastUse = gs.tick;
+    gen = gnew;
+    gs.submits++;
+    gs.epoch.fetch_add(1, std::memory_order_release);
+    return victim;
+}
+
 /* POC of the reference picture `ref` points at: ref is an element of slice->m_mref[list][idx] (slice.h:337) */
 int ref_poc(const Slice* slice, const ReferencePlanes* ref)
 {
@@ -472,7 +554,7 @@ void sub_context(const Search* s, ReferencePlanes* ref)
     SubCtx& c = t_sub;
     c.valid = false;
     const PicYuv* rec = ref->reconPic;
-    if (!rec || ref->isWeighted || ref->isLowres || s->m_param->frameNumThreads != 1 || rec->m_picCsp != X265_CSP_I420 ||
+    if (!rec || ref->isWeighted || ref->isLowres || (s->m_param->frameNumThreads != 1 && !gs.p.streamed) || rec->m_picCsp != X265_CSP_I420 ||
         ref->fpelPlane[0] != rec->m_picOrg[0] || ref->fpelPlane[1] != rec->m_picOrg[1] || ref->fpelPlane[2] != rec->m_picOrg[2] ||
         rec->m_stride != gs.p.stride || rec->m_strideC != gs.p.strideC) { gs.noContext.fetch_add(1, std::memory_order_relaxed); return; }
     const int maxH = (int)((rec->m_picHeight + s->m_param->maxCUSize - 1) / s->m_param->maxCUSize * s->m_param->maxCUSize);
@@ -488,10 +570,29 @@ void sub_context(const Search* s, ReferencePlanes* ref)
     c.cb = (const pixel*)gs.p.planes(gs.p.ctx, slot, 1);
     c.cr = (const pixel*)gs.p.planes(gs.p.ctx, slot, 2);
     c.planeL = (size_t)gs.p.stride * gs.p.rows; c.planeC = (size_t)gs.p.strideC * gs.p.rowsC;
-    c.ready = gs.p.ready(gs.p.ctx, slot);
+    c.ready = gs.p.streamed ? NULL : gs.p.ready(gs.p.ctx, slot);
+    c.progress = gs.p.streamed ? gs.p.progress(gs.p.ctx, slot) : NULL;
     c.gen = gen;
     c.arrived[0] = c.arrived[1] = false;
-    c.valid = c.luma && c.cb && c.cr && c.ready;
+    c.valid = c.luma && c.cb && c.cr && (c.ready || c.progress);
+}
+
+/* streamed: are buffer lines [line0, line1) of plane kind `which` (0 luma, 1 chroma) finished for this context's generation? */
+inline bool sub_lines(SubCtx& c, int which, long line0, long line1)
+{
+    if (line0 < 4) return false;
+    uint64_t v = c.progress[which];
+    if (gs.wait)
+        for (int spin = 0; spin < 20000 && ((int)(v >> 32) != c.gen || (long)(uint32_t)v < line1); spin++)
+        {
+            if ((int)(v >> 32) > c.gen) break;                  /* the slot went to another picture: never */
+            struct timespec ts = { 0, 100000 };
+            nanosleep(&ts, NULL);
+            v = c.progress[which];
+        }
+    if ((int)(v >> 32) != c.gen || (long)(uint32_t)v < line1) return false;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return true;
 }
 
 inline bool sub_arrived(SubCtx& c, int which)
@@ -520,7 +621,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     if (g.enabled)
     {
         g.meCalls.fetch_add(1, std::memory_order_relaxed);
-        if (ctuAddr >= 0 && !srcReferencePlane && !ref->isLowres && !ref->isWeighted && ref->reconPic && partEnum >= 0 && partEnum < NUM_PU_SIZES &&
+        if (g.p.min_pu <= 64 && ctuAddr >= 0 && !srcReferencePlane && !ref->isLowres && !ref->isWeighted && ref->reconPic && partEnum >= 0 && partEnum < NUM_PU_SIZES &&
             PU_DIMS[partEnum][0] == blockwidth && !(blockwidth & 7) && !(PU_DIMS[partEnum][1] & 7))
         {
             /* a MotionEstimate with ctuAddr >= 0 is the m_me member of a Search (search.h:257; the lookahead's instances use the other
@@ -529,7 +630,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
             const Frame* frame = s->m_frame;
             const PicYuv* rec = ref->reconPic;
             const PicYuv* src = frame ? frame->m_fencPic : NULL;
-            if (src && s->m_param->frameNumThreads == 1 && ref->fpelPlane[0] == rec->m_picOrg[0] &&
+            if (src && (s->m_param->frameNumThreads == 1 || g.p.streamed) && ref->fpelPlane[0] == rec->m_picOrg[0] &&
                 rec->m_stride == g.p.stride && src->m_stride == g.p.stride && (int)rec->m_lumaMarginX == g.p.margin_x && (int)rec->m_lumaMarginY == g.p.margin_y &&
                 (int)src->m_lumaMarginX == g.p.margin_x && (int)src->m_lumaMarginY == g.p.margin_y && s->m_param->maxCUSize == 64)
             {
@@ -540,7 +641,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
                 if (idx >= 0 && idx < 2 * (MAX_NUM_REF + 1))
                     recPoc = slice->m_refPOCList[idx / (MAX_NUM_REF + 1)][idx % (MAX_NUM_REF + 1)];
                 int gen = 0;
-                const int slot = recPoc == -0x7fffffff ? -1 : pair_slot(frame->m_poc, src, slice, rec, recPoc, gen);
+                const int slot = recPoc == -0x7fffffff ? -1 : pair_slot(frame->m_poc, src, slice, rec, recPoc, gen, frame->m_encodeOrder, s->m_param->frameNumThreads);
                 if (slot >= 0)
                 {
                     c.nparts = 0;
@@ -590,7 +691,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
 int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_t cmp)
 {
     SubCtx& c = t_sub;
-    if (!c.valid || c.ref != ref || !sub_arrived(c, 0) || (bChromaSATD && !sub_arrived(c, 1)))
+    if (!c.valid || c.ref != ref || (!c.progress && (!sub_arrived(c, 0) || (bChromaSATD && !sub_arrived(c, 1)))))
     {
         if (c.valid && c.ref == ref) gs.notReady.fetch_add(1, std::memory_order_relaxed);
         return x265ref_orig_subpelCompare(this, ref, &qmv, cmp);
@@ -598,16 +699,32 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
     const intptr_t stride = ref->lumaStride;
     const ptrdiff_t pos = blockOffset + (qmv.x >> 2) + (qmv.y >> 2) * stride;            /* relative to fpelPlane[0] */
     const int lph = (qmv.y & 3) * 4 + (qmv.x & 3);
-    const pixel* lp = lph ? c.luma + (size_t)(lph - 1) * c.planeL + ((ref->fpelPlane[0] - c.rec->m_picBuf[0]) + pos) : ref->fpelPlane[0] + pos;
+    const ptrdiff_t lbuf = (ref->fpelPlane[0] - c.rec->m_picBuf[0]) + pos;               /* relative to the buffer start */
+    const intptr_t strideC = c.rec->m_strideC;
+    const ptrdiff_t cpos = (qmv.x >> 3) + (qmv.y >> 3) * strideC;                        /* 4:2:0: the quarter-sample luma vector is an eighth-sample chroma vector */
+    const int cph = (qmv.y & 7) * 8 + (qmv.x & 7);
+    const pixel* cb = bChromaSATD ? ref->getCbAddr(ctuAddr, absPartIdx) + cpos : NULL;
+    const pixel* cr = bChromaSATD ? ref->getCrAddr(ctuAddr, absPartIdx) + cpos : NULL;
+    if (c.progress)
+    {
+        /* row-granular planes: the block's lines must be finished (the picture may still be growing under the producer) */
+        const int bh = PU_DIMS[partEnum][1];
+        bool ok = !lph || sub_lines(c, 0, lbuf / stride, lbuf / stride + bh);
+        if (ok && bChromaSATD && cph)
+        {
+            const long l0 = (long)((cb - c.rec->m_picBuf[1]) / strideC);
+            ok = sub_lines(c, 1, l0, l0 + (bh >> 1));
+        }
+        if (!ok)
+        {
+            gs.notReady.fetch_add(1, std::memory_order_relaxed);
+            return x265ref_orig_subpelCompare(this, ref, &qmv, cmp);
+        }
+    }
+    const pixel* lp = lph ? c.luma + (size_t)(lph - 1) * c.planeL + lbuf : ref->fpelPlane[0] + pos;
     int cost = cmp(fencPUYuv.m_buf[0], FENC_STRIDE, lp, stride);
     if (bChromaSATD)
     {
-        /* 4:2:0: the quarter-sample luma vector is an eighth-sample chroma vector */
-        const intptr_t strideC = c.rec->m_strideC;
-        const ptrdiff_t cpos = (qmv.x >> 3) + (qmv.y >> 3) * strideC;
-        const int cph = (qmv.y & 7) * 8 + (qmv.x & 7);
-        const pixel* cb = ref->getCbAddr(ctuAddr, absPartIdx) + cpos;
-        const pixel* cr = ref->getCrAddr(ctuAddr, absPartIdx) + cpos;
         if (cph)
         {
             cb = c.cb + (size_t)(cph - 1) * c.planeC + (cb - c.rec->m_picBuf[1]);
@@ -615,6 +732,16 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
         }
         cost += chromaSatd(fencPUYuv.m_buf[1], fencPUYuv.m_csize, cb, strideC);
         cost += chromaSatd(fencPUYuv.m_buf[2], fencPUYuv.m_csize, cr, strideC);
+    }
+    if (c.progress)
+    {
+        /* the slot must STILL hold this picture after the read (open() clears the progress before a slot's planes are rewritten) */
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if ((int)(c.progress[0] >> 32) != c.gen || (bChromaSATD && (int)(c.progress[1] >> 32) != c.gen))
+        {
+            gs.torn.fetch_add(1, std::memory_order_relaxed);
+            return x265ref_orig_subpelCompare(this, ref, &qmv, cmp);
+        }
     }
     gs.served.fetch_add(1, std::memory_order_relaxed);
     if (gs.verify)
@@ -628,6 +755,36 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
         }
     }
     return cost;
+}
+
+/* The PRODUCER hook of the row-granular providers: same signature, same symbol as the reference's function (framefilter.cpp:657-719;
+ * oracle/Makefile makes the compiled original weak and reachable as x265ref_orig_processPostRow).  The reference's body raises
+ * m_frame->m_reconRowFlag[row] (:664) - the row is final, borders extended - and from then on any frame encoder may search it; right
+ * after it the row is handed to the providers: copied into their pinned staging inside the calls, so nothing here outlives the row. */
+void FrameFilter::processPostRow(int row)
+{
+    x265ref_orig_processPostRow(this, row);
+    const bool sad = g.enabled && g.p.streamed && g.p.min_pu <= 64, sub = gs.enabled && gs.p.streamed;        /* min_pu > 64: no SAD stub is installed */
+    if (!sad && !sub) return;
+    const Frame* frame = m_frame;
+    const PicYuv* rec = frame ? frame->m_reconPic : NULL;
+    if (!rec || !IS_REFERENCED(frame) || m_param->maxCUSize != 64) return;            /* nobody will search an unreferenced B picture */
+    if (sad && rec->m_stride == g.p.stride && (int)rec->m_lumaMarginX == g.p.margin_x && (int)rec->m_lumaMarginY == g.p.margin_y &&
+        m_numRows == g.p.height / 64 && row < m_numRows)
+    {
+        if (g.p.picture_rows(g.p.ctx, pic_key(g.instance, frame->m_poc, 1), rec->m_picBuf[0], row, 1) == 0)
+            g.rowsPublished.fetch_add(1, std::memory_order_relaxed);
+        else
+            g.rowsRefused.fetch_add(1, std::memory_order_relaxed);
+    }
+    if (sub && rec->m_picCsp == X265_CSP_I420 && rec->m_stride == gs.p.stride && rec->m_strideC == gs.p.strideC && m_numRows == gs.p.ctuRows &&
+        m_numRows * 64 + 2 * (int)rec->m_lumaMarginY == gs.p.rows && m_numRows * 32 + 2 * (int)rec->m_chromaMarginY == gs.p.rowsC)
+    {
+        int gen = 0;
+        const int slot = phase_slot_produce(rec, frame->m_poc, gen);
+        if (slot >= 0 && gs.p.rows_fn(gs.p.ctx, slot, gen, rec->m_picBuf[0], rec->m_picBuf[1], rec->m_picBuf[2], row, 1) == 0)
+            gs.rowsPublished.fetch_add(1, std::memory_order_relaxed);
+    }
 }
 
 /* The lookahead seam: same signature, same symbol as the reference's function.  oracle/Makefile makes the compiled original weak and
@@ -831,6 +988,10 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
     g.p.submit_batch = (int (*)(void*, int, const int*, const void*, uint64_t, const void* const*, int*))submit_batch;      /* may be NULL */
     g.p.surface = (const void* (*)(void*, int))surface;
     g.p.ready = (const volatile int* (*)(void*, int))ready;
+    g.p.picture_rows = NULL; g.p.pair_open = NULL; g.p.streamed = false; g.p.min_level = 0;
+    memset(g.fencs, 0, sizeof(g.fencs));
+    g.instance++;
+    g.rowsPublished = 0; g.rowsRefused = 0; g.torn = 0;
     g.p.range = range; g.p.surf_format = surf_format; g.p.slots = slots;
     g.p.width = width; g.p.height = height; g.p.stride = stride; g.p.margin_x = margin_x; g.p.margin_y = margin_y;
     g.p.min_pu = min_pu < 8 ? 8 : min_pu;
@@ -847,6 +1008,27 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
     return 0;
 }
 
+/* row-granular provider (x265hip_me_stream_picture_rows / _pair_open / _surface / _ready signatures): serves under any --frame-threads.
+ * record_bytes = x265hip_me_stream_record_bytes (the whole record, or its 16x16-and-up tail with min_level 1). */
+int x265ref_seam_configure_streamed(void* ctx, void* picture_rows, void* pair_open, void* surface, void* ready, int range, int surf_format, int min_level,
+                                    int slots, int width, int height, intptr_t stride, int margin_x, int margin_y, int min_pu, int verify)
+{
+    if (!picture_rows || !pair_open || surf_format == SURF_PACKED_T || min_level < 0 || min_level > 1) return -4;
+    const int rc = x265ref_seam_configure(ctx, NULL, NULL, surface, ready, range, surf_format, slots, width, height, stride, margin_x, margin_y,
+                                          min_level && min_pu < 16 ? 16 : min_pu, verify);
+    if (rc) return rc;
+    g.p.picture_rows = (int (*)(void*, uint64_t, const void*, int, int))picture_rows;
+    g.p.pair_open = (int (*)(void*, int, uint64_t, uint64_t))pair_open;
+    g.p.min_level = min_level;
+    g.p.streamed = true;
+    if (min_level)
+    {
+        g.groupBytes = surf_format == SURF_I32 ? 336 : 208;          /* X265HIP_SURF_TAIL_BYTES_I32 / _PACKED */
+        g.ctuBytes = (size_t)g.nc * g.ng * g.groupBytes;
+    }
+    return 0;
+}
+
 void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; gs.enabled = false; }
 
 /* sub-sample seam: provider = x265hip_phase_cache_submit / _planes / _ready signatures (NULL submit = off); geometry = the PicYuv
@@ -860,13 +1042,45 @@ int x265ref_subpel_seam_configure(void* ctx, void* submit, void* planes, void* r
     gs.p.submit = (int (*)(void*, int, const void*, const void*, const void*))submit;
     gs.p.planes = (const void* (*)(void*, int, int))planes;
     gs.p.ready = (const volatile int* (*)(void*, int))ready;
+    gs.p.open = NULL; gs.p.rows_fn = NULL; gs.p.progress = NULL; gs.p.streamed = false; gs.p.ctuRows = 0;
     gs.p.slots = slots; gs.p.stride = stride; gs.p.rows = rows; gs.p.strideC = stride_c; gs.p.rowsC = rows_c;
     memset(gs.e, 0, sizeof(gs.e));
     gs.verify = (flags & 1) != 0; gs.wait = (flags & 2) != 0;
-    gs.served = gs.notReady = gs.noContext = gs.submits = gs.mismatches = gs.noSlot = 0;
+    gs.served = gs.notReady = gs.noContext = gs.submits = gs.mismatches = gs.noSlot = 0; gs.rowsPublished = 0; gs.torn = 0;
     gs.epoch.fetch_add(1);
     gs.enabled = true;
     return 0;
+}
+
+/* row-granular provider (x265hip_phase_stream_open / _rows / _planes / _progress signatures): the producer hook feeds it, serves under
+ * any --frame-threads */
+int x265ref_subpel_seam_configure_streamed(void* ctx, void* open, void* rows_fn, void* planes, void* progress, int slots, intptr_t stride, int rows,
+                                           intptr_t stride_c, int rows_c, int ctu_rows, int flags)
+{
+    gs.enabled = false;
+    if (!open) return 0;
+    if (slots < 1 || slots > MAX_SLOTS || !rows_fn || !planes || !progress || rows_c <= 0) return -1;
+    gs.p.ctx = ctx;
+    gs.p.submit = NULL; gs.p.ready = NULL;
+    gs.p.open = (int (*)(void*, int))open;
+    gs.p.rows_fn = (int (*)(void*, int, int, const void*, const void*, const void*, int, int))rows_fn;
+    gs.p.planes = (const void* (*)(void*, int, int))planes;
+    gs.p.progress = (const volatile uint64_t* (*)(void*, int))progress;
+    gs.p.streamed = true; gs.p.ctuRows = ctu_rows;
+    gs.p.slots = slots; gs.p.stride = stride; gs.p.rows = rows; gs.p.strideC = stride_c; gs.p.rowsC = rows_c;
+    memset(gs.e, 0, sizeof(gs.e));
+    gs.verify = (flags & 1) != 0; gs.wait = (flags & 2) != 0;
+    gs.served = gs.notReady = gs.noContext = gs.submits = gs.mismatches = gs.noSlot = 0; gs.rowsPublished = 0; gs.torn = 0;
+    gs.epoch.fetch_add(1);
+    gs.enabled = true;
+    return 0;
+}
+
+/* out[4]: rows of reconstructed pictures handed to the SAD provider / refused by it, rows handed to the phase provider, lookups dropped
+ * because their slot was reopened under the read (SAD + sub-sample) */
+void x265ref_seam_stream_stats(uint64_t* out)
+{
+    out[0] = g.rowsPublished; out[1] = g.rowsRefused; out[2] = gs.rowsPublished; out[3] = g.torn + gs.torn;
 }
 
 /* out[6]: subpelCompare calls served from phase planes, passed on because the planes had not arrived, searches without a usable

@@ -200,3 +200,153 @@ def test_subpel_seam_encode_on_gpu_phase_planes_is_byte_identical(depth, preset,
     assert got[0] == base[0], f"seam changed the bitstream: {rep}"
     assert sub["verify_mismatches"] == 0 and rep["verify_mismatches"] == 0 and sub["failed"] == 0
     assert sub["subpel_compares_served"] > 500 and sub["fills"] >= 2, sub
+
+
+# ---- round 3: the ROW-GRANULAR services (csrc/me_stream.hip, csrc/phase_stream.hip) -------------------------------------------------
+@pytest.mark.parametrize("depth,width,height,rng,min_level,band_rows", [(8, 256, 320, 20, 0, 2), (8, 256, 320, 20, 1, 8), (10, 192, 256, 16, 1, 3),
+                                                                        (8, 200, 264, 57, 1, 1), (12, 128, 192, 12, 0, 8)])
+def test_me_stream_surfaces_equal_oracle_whatever_order_the_rows_arrive_in(depth, width, height, rng, min_level, band_rows):
+    """Rows of the reference picture handed over one by one (and out of order), the pair opened in the middle: every CTU row's records
+    - whole, or the 16x16-and-up tail - must equal the oracle's exhaustive search, and a row may only be flagged once the rows its
+    window reaches have been handed over."""
+    from tools import seam_driver as SD
+    O = _oracle()
+    geo = SD.geometry(width, height)
+    clip = F.synth_clip(geo["width"], geo["height"], 3, depth=depth, seed=7)
+    dt = np.uint8 if depth == 8 else np.uint16
+    def padded(y):      # the PicYuv layout: edges replicated into the margins
+        return np.ascontiguousarray(np.pad(y.reshape(geo["height"], geo["width"]).astype(dt), ((geo["margin_y"],) * 2, (geo["margin_x"],) * 2), mode="edge")).reshape(-1)
+    planes = [padded(fr[0]) for fr in clip]
+    prov = SD.StreamGpuProvider(depth, geo, rng, slots=3, min_level=min_level, pictures=6, band_rows=band_rows)
+    L = prov.L
+    L.x265hip_me_stream_picture_rows.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.x265hip_me_stream_pair_open.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64]
+    L.x265hip_me_stream_surface.restype = ctypes.c_void_p
+    L.x265hip_me_stream_surface.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.x265hip_me_stream_ready.restype = ctypes.c_void_p
+    L.x265hip_me_stream_ready.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.x265hip_me_stream_record_bytes.argtypes = [ctypes.c_void_p]
+    try:
+        ctus_w, ctus_h = geo["width"] // 64, geo["height"] // 64
+        nc = 2 * rng + 1
+        ng = (nc + 3) // 4
+        rec = L.x265hip_me_stream_record_bytes(prov.handle)
+        full = 720 if depth == 8 else 1360
+        assert rec == (full if not min_level else 208 if depth == 8 else 336)
+        lag = (63 + rng) // 64
+        org = geo["margin_y"] * geo["stride"] + geo["margin_x"]
+        zero = np.zeros(nc, np.uint16)
+        for slot, (fi, ri, order) in enumerate([(1, 0, list(range(ctus_h))), (2, 1, [1, 0] + list(range(2, ctus_h))), (2, 0, list(range(ctus_h))[::-1])]):
+            fkey, rkey = 100 + 10 * slot + fi, 200 + 10 * slot + ri
+            assert L.x265hip_me_stream_picture_rows(prov.handle, fkey, planes[fi].ctypes.data, 0, ctus_h) == 0
+            ready = np.ctypeslib.as_array((ctypes.c_int32 * ctus_h).from_address(L.x265hip_me_stream_ready(prov.handle, slot)))
+            gen = None
+            given = set()
+            for i, r in enumerate(order):
+                if i == 1:                  # the pair is opened after the first row of the reference is already there
+                    gen = L.x265hip_me_stream_pair_open(prov.handle, slot, fkey, rkey)
+                    assert gen > 0
+                assert L.x265hip_me_stream_picture_rows(prov.handle, rkey, planes[ri].ctypes.data, r, 1) == 0
+                given.add(r)
+                time.sleep(0.02)
+                if gen:
+                    for q in range(ctus_h):     # no row is flagged before the rows its window reaches were handed over
+                        if ready[q] == gen:
+                            assert all(k in given for k in range(max(0, q - lag), min(ctus_h, q + lag + 1))), (q, sorted(given))
+            if gen is None:
+                gen = L.x265hip_me_stream_pair_open(prov.handle, slot, fkey, rkey)
+            t0 = time.time()
+            while not all(ready[q] == gen for q in range(ctus_h)) and time.time() - t0 < 20:
+                time.sleep(0.01)
+            assert all(ready[q] == gen for q in range(ctus_h)), (list(ready), gen, prov.report())
+            surf, _ = O.me_fullsearch(depth, planes[fi], geo["stride"], org, planes[ri], geo["stride"], org, geo["width"], geo["height"], rng,
+                                      0, ctus_w * ctus_h, zero, zero, want_surf=True, want_best=False)
+            e = surf.reshape(-1, 85, 4)
+            nrec = e.shape[0]
+            raw = np.ctypeslib.as_array((ctypes.c_uint8 * (nrec * rec)).from_address(L.x265hip_me_stream_surface(prov.handle, slot))).reshape(nrec, rec)
+            def cols(v):        # [record, pu, 4] -> [motion-vector row, dx, pu]; the pad columns of a row's last group hold don't-care values
+                v = v.reshape(-1, ng, v.shape[1], 4)
+                return v.transpose(0, 1, 3, 2).reshape(v.shape[0], ng * 4, v.shape[2])[:, :nc]
+            if depth == 8:
+                tail = raw if min_level else raw[:, 512:]
+                g16 = tail[:, 0:128].copy().view(np.uint16).reshape(nrec, 16, 4)
+                g32 = tail[:, 128:208].copy().view(np.int32).reshape(nrec, 5, 4)
+                assert np.array_equal(cols(g16), cols(e[:, 64:80])) and np.array_equal(cols(g32), cols(e[:, 80:85]))
+                if not min_level:
+                    assert np.array_equal(cols(raw[:, 0:512].copy().view(np.uint16).reshape(nrec, 64, 4)), cols(e[:, 0:64]))
+            else:
+                got = raw.copy().view(np.int32).reshape(nrec, -1, 4)
+                assert np.array_equal(cols(got), cols(e[:, 64:] if min_level else e))
+        rep = prov.report()
+        assert rep["failed"] == 0 and rep["pairs_completed"] == 3 and rep["rows_searched"] == 3 * ctus_h, rep
+    finally:
+        prov.close()
+
+
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 320), (10, 192, 192), (12, 128, 128)])
+def test_phase_stream_planes_equal_the_picture_granular_planes(depth, width, height):
+    """Rows handed over one by one: progress only ever covers finished lines, and the finished planes equal x265hip_phase_planes run
+    on the whole picture (itself pinned on the oracle's interpolation primitives, test_gpu_phase_planes.py)."""
+    import torch
+    from tools import seam_driver as SD
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    geo = SD.geometry(width, height)
+    dt = np.uint8 if depth == 8 else np.uint16
+    rng = np.random.default_rng(3 + depth)
+    src = [rng.integers(0, 1 << depth, (geo["rows"], geo["stride"])).astype(dt), rng.integers(0, 1 << depth, (geo["rows_c"], geo["stride_c"])).astype(dt),
+           rng.integers(0, 1 << depth, (geo["rows_c"], geo["stride_c"])).astype(dt)]
+    prov = SD.StreamGpuPhaseProvider(depth, geo, slots=2)
+    L = prov.L
+    L.x265hip_phase_stream_open.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.x265hip_phase_stream_rows.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.x265hip_phase_stream_planes.restype = ctypes.c_void_p
+    L.x265hip_phase_stream_planes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.x265hip_phase_stream_progress.restype = ctypes.c_void_p
+    L.x265hip_phase_stream_progress.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    try:
+        ctu_rows = geo["height"] // 64
+        for slot in (1, 0):
+            gen = L.x265hip_phase_stream_open(prov.handle, slot)
+            assert gen > 0
+            prog = np.ctypeslib.as_array((ctypes.c_uint64 * 2).from_address(L.x265hip_phase_stream_progress(prov.handle, slot)))
+            for r in range(ctu_rows):
+                assert L.x265hip_phase_stream_rows(prov.handle, slot, gen, src[0].ctypes.data, src[1].ctypes.data, src[2].ctypes.data, r, 1) == 0
+                time.sleep(0.02)
+                have = geo["rows"] if r == ctu_rows - 1 else geo["margin_y"] + (r + 1) * 64
+                assert int(prog[0]) >> 32 in (0, gen) and (int(prog[0]) & 0xffffffff) <= have - 8
+            t0 = time.time()
+            want = [(gen << 32) | (geo["rows"] - 8), (gen << 32) | (geo["rows_c"] - 8)]
+            while (int(prog[0]) != want[0] or int(prog[1]) != want[1]) and time.time() - t0 < 20:
+                time.sleep(0.01)
+            assert [int(prog[0]), int(prog[1])] == want, prov.report()
+            for pl in range(3):
+                k = min(pl, 1)
+                rows, stride, nph = (geo["rows"], geo["stride"], 15) if k == 0 else (geo["rows_c"], geo["stride_c"], 63)
+                n = nph * rows * stride
+                got = np.ctypeslib.as_array((ctypes.c_uint8 * (n * dt().itemsize)).from_address(L.x265hip_phase_stream_planes(prov.handle, slot, pl))).view(dt).reshape(nph, rows, stride)
+                dev = torch.device("cuda:0")
+                tsrc = torch.from_numpy(src[pl].view(np.int16 if depth > 8 else np.uint8)).to(dev)
+                tdst = torch.zeros(n, dtype=tsrc.dtype, device=dev)
+                A.phase_planes(depth, tsrc, 0, tdst, stride, rows, chroma=bool(k))
+                torch.cuda.synchronize()
+                exp = tdst.cpu().numpy().view(dt).reshape(nph, rows, stride)
+                assert np.array_equal(got[:, 4:rows - 8, 8:stride - 8], exp[:, 4:rows - 8, 8:stride - 8]), (slot, pl)
+        rep = prov.report()
+        assert rep["failed"] == 0 and rep["completed"] == 2, rep
+    finally:
+        prov.close()
+
+
+@pytest.mark.parametrize("depth,preset,ft,min_level,extra", [(8, "medium", 3, 0, []), (8, "slow", 3, 1, [("me", "star")]), (8, "slower", 2, 1, []), (10, "medium", 3, 1, [])])
+def test_row_granular_seams_on_the_gpu_serve_under_frame_threads(depth, preset, ft, min_level, extra):
+    """The real encoder at --frame-threads > 1 on x265hip_me_stream + x265hip_phase_stream: byte-identical, every SAD lookup and every
+    sub-sample comparison verified in flight against the reference's own functions."""
+    import test_seam_cpu as T
+    opts = [("pools", "4"), ("frame-threads", str(ft)), ("crf", "24"), ("no-weightp", None), ("no-weightb", None)] + extra
+    base, got, rep = T.run_pair(depth, 256, 192, 8, preset, opts, "gpu", rng=20, verify=True, wait=True, streamed=True, min_level=min_level, subpel="gpu",
+                                slots=24, subpel_slots=12)
+    assert got[0] == base[0], f"seam changed the bitstream: {rep}"
+    sub = rep["subpel_seam"]
+    assert rep["verify_mismatches"] == 0 and sub["verify_mismatches"] == 0 and rep["failed"] == 0 and sub["failed"] == 0
+    assert rep["lookups_served"] > (300 if min_level else 1500) and sub["subpel_compares_served"] > 1000, rep
+    assert rep["row_stream"]["recon_rows_refused"] == 0 and rep["stale_pairs"] == 0

@@ -21,7 +21,8 @@ def _tools():
     return encoder_bench, seam_driver
 
 
-def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False, lookahead=None, subpel=None, surf_format=None):
+def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False, lookahead=None, subpel=None, surf_format=None,
+             streamed=False, min_level=0, slots=8, subpel_slots=6):
     EB, SD = _tools()
     try:
         plain = EB.ref_lib(depth)
@@ -31,8 +32,8 @@ def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify
     clip = F.synth_clip(w, h, nframes, depth=depth, seed=seed)
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
     base = EB.encode(plain, yuv, w, h, nframes, preset, opts)
-    lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=8, min_pu=min_pu, verify=verify, wait=wait, lookahead=lookahead,
-                                                  subpel=subpel, surf_format=surf_format)
+    lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=slots, min_pu=min_pu, verify=verify, wait=wait, lookahead=lookahead,
+                                                  subpel=subpel, surf_format=surf_format, streamed=streamed, min_level=min_level, subpel_slots=subpel_slots)
     try:
         got = EB.encode(lib, yuv, w, h, nframes, preset, opts, filler)
         rep = report()
@@ -123,3 +124,48 @@ def test_lookahead_seam_holds_under_frame_threads(ft):
     la = rep["lookahead_seam"]
     assert la["frame_cost_estimates_served"] >= 10 and la["failed"] == 0, la
     assert rep["lookups_served"] == 0 and rep["subpel_seam"]["subpel_compares_served"] == 0
+
+
+# ---- round 3: the ROW-GRANULAR providers serve under the reference's own frame threads -------------------------------------------
+@pytest.mark.reference
+@pytest.mark.parametrize("depth,preset,ft,min_level,extra", [(8, "medium", 3, 0, []), (8, "slow", 3, 1, [("me", "star")]), (8, "slower", 2, 0, []),
+                                                             (10, "medium", 3, 1, []), (8, "medium", 1, 0, []), (8, "medium", 4, 1, [("bframes", "0")])])
+def test_row_granular_seam_serves_under_frame_threads(depth, preset, ft, min_level, extra):
+    """FrameFilter::processPostRow hands every reconstructed CTU row to the provider where the reference raises m_reconRowFlag; pairs are
+    searched row by row behind the producer.  --frame-threads > 1: byte-identical bitstream, every lookup verified against the
+    primitive, and the lookups ARE served (the picture-granular seam steps aside here)."""
+    opts = [("pools", "4"), ("frame-threads", str(ft)), ("crf", "24"), ("no-weightp", None), ("no-weightb", None)] + extra
+    base, got, rep = run_pair(depth, 256, 192, 8, preset, opts, "oracle", rng=20, streamed=True, min_level=min_level, slots=24)
+    assert got[0] == base[0], f"seam changed the bitstream: {rep}"
+    assert rep["verify"] == 1 and rep["verify_mismatches"] == 0
+    assert rep["row_granular"] and rep["row_stream"]["recon_rows_to_sad_provider"] >= 3 * 3      # 3 CTU rows per referenced picture (I / P / B-ref)
+    assert rep["row_stream"]["recon_rows_refused"] == 0
+    assert rep["lookups_served"] > (300 if min_level else 1500) and rep["calls_with_lookup_context"] > 50, rep
+    assert rep["foreign_geometry"] == 0 and rep["no_free_slot"] == 0, rep
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("depth,preset,ft,extra", [(8, "medium", 3, []), (8, "slow", 3, []), (10, "medium", 2, []), (8, "slower", 3, [("subme", "7")])])
+def test_row_granular_subpel_seam_serves_under_frame_threads(depth, preset, ft, extra):
+    """The sub-sample seam on phase planes that grow line by line behind the reconstruction: every served subpelCompare is re-evaluated
+    by the reference's own interpolating function (verify), the bitstream is byte-identical, --frame-threads > 1."""
+    opts = [("pools", "4"), ("frame-threads", str(ft)), ("crf", "24"), ("no-weightp", None), ("no-weightb", None)] + extra
+    base, got, rep = run_pair(depth, 256, 192, 8, preset, opts, "oracle", rng=20, streamed=True, subpel="oracle", slots=24, subpel_slots=12)
+    assert got[0] == base[0], f"seam changed the bitstream: {rep}"
+    ss = rep["subpel_seam"]
+    assert ss["verify_mismatches"] == 0 and rep["verify_mismatches"] == 0
+    assert ss["subpel_compares_served"] > 2000, rep
+    assert rep["row_stream"]["recon_rows_to_phase_provider"] >= 3 * 3
+    assert rep["lookups_served"] > 1500
+
+
+@pytest.mark.reference
+def test_row_granular_seams_with_all_defaults_and_the_lookahead_seam():
+    """Preset defaults (weightp / weightb on, B pyramid), all three seams, --frame-threads 3."""
+    opts = [("pools", "4"), ("frame-threads", "3"), ("crf", "24"), ("lookahead-slices", "1")]
+    base, got, rep = run_pair(8, 256, 192, 10, "slow", opts, "oracle", rng=16, streamed=True, min_level=1, subpel="oracle", lookahead="oracle", slots=24,
+                              subpel_slots=12)
+    assert got[0] == base[0], f"seam changed the bitstream: {rep}"
+    assert rep["verify_mismatches"] == 0 and rep["subpel_seam"]["verify_mismatches"] == 0
+    assert rep["lookups_served"] > 300 and rep["subpel_seam"]["subpel_compares_served"] > 1000
+    assert rep["lookahead_seam"]["frame_cost_estimates_served"] > 10

@@ -114,9 +114,12 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
             if cfg["preset"] == "ultrafast":       # --ctu 32 and, in cfg1, no inter pictures at all: nothing for the seam to serve
                 continue
             from tools import seam_driver as SD
-            enc_lib, filler, note, closer, _ = SD.install(depth, w, h, provider="gpu", rng=seam["range"], slots=seam["slots"], min_pu=seam["min_pu"],
+            enc_lib, filler, note, closer, _ = SD.install(depth, w, h, provider="gpu", rng=seam["range"], slots=seam["slots"],
+                                                          min_pu=128 if seam.get("no_sad") else seam["min_pu"],
                                                           verify=seam["verify"], lookahead="gpu" if seam.get("lookahead") else None,
-                                                          subpel="gpu" if seam.get("subpel") else None, subpel_slots=seam.get("subpel_slots", 6))
+                                                          subpel="gpu" if seam.get("subpel") else None, subpel_slots=seam.get("subpel_slots", 6),
+                                                          streamed=bool(seam.get("streamed")), min_level=seam.get("min_level", 0),
+                                                          pictures=seam.get("pictures", 24), band_rows=seam.get("band_rows", 0))
         t0 = time.perf_counter()
         md5, nbytes, sec, filled = encode(enc_lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
         wall = time.perf_counter() - t0
@@ -158,10 +161,17 @@ def main():
                     help="also serve CostEstimateGroup::estimateFrameCost's block loop from x265hip_lowres_cost_host (adds --lookahead-slices 1 to every leg)")
     ap.add_argument("--seam-subpel", action="store_true",
                     help="also serve MotionEstimate::subpelCompare from x265hip_phase_cache (every fractional phase of a reference picture interpolated once)")
+    ap.add_argument("--seam-streamed", action="store_true",
+                    help="row-granular providers (x265hip_me_stream / x265hip_phase_stream fed by the FrameFilter::processPostRow hook): serve under --frame-threads > 1")
+    ap.add_argument("--seam-min-level", type=int, default=1, help="row-granular SAD provider: 1 = download only the 16x16-and-up tail of every record")
+    ap.add_argument("--seam-pictures", type=int, default=24, help="row-granular SAD provider: pictures resident on the device")
+    ap.add_argument("--seam-band-rows", type=int, default=0, help="row-granular SAD provider: most CTU rows per search launch (0 = 8)")
+    ap.add_argument("--seam-no-sad", action="store_true", help="install no SAD lookup stubs (sub-sample / lookahead seams only)")
     ap.add_argument("--seam-subpel-slots", type=int, default=6, help="reference pictures whose phase planes stay in pinned host memory (450 MB each at 4K 8-bit)")
     args = ap.parse_args()
     seam = {"range": args.seam_range, "slots": args.seam_slots, "min_pu": args.seam_min_pu, "verify": args.seam_verify, "lookahead": args.seam_lookahead,
-            "subpel": args.seam_subpel, "subpel_slots": args.seam_subpel_slots}
+            "subpel": args.seam_subpel, "subpel_slots": args.seam_subpel_slots, "streamed": args.seam_streamed, "min_level": args.seam_min_level,
+            "pictures": args.seam_pictures, "band_rows": args.seam_band_rows, "no_sad": args.seam_no_sad}
     out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s, seam=seam) for k in args.configs.split(",")}
     print(json.dumps({"encoder": out}))
 

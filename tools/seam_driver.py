@@ -256,16 +256,308 @@ class GpuPhaseProvider:
             self.handle = None
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# ROW-GRANULAR providers (round 3): x265hip_me_stream / x265hip_phase_stream and their CPU stand-ins.  The binding's producer hook
+# (FrameFilter::processPostRow) feeds them reconstructed CTU rows, so they serve under any --frame-threads.
+PIC_ROWS = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
+PAIR_OPEN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64)
+PS_OPEN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
+PS_ROWS = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
+PS_PROGRESS = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
+STREAM_STAT_NAMES = ("recon_rows_to_sad_provider", "recon_rows_refused", "recon_rows_to_phase_provider", "lookups_dropped_slot_reopened")
+
+
+class StreamOracleProvider:
+    """CPU stand-in for x265hip_me_stream (checker only): pictures arrive row by row, every open pair's CTU rows are searched with the
+    oracle as soon as the reference rows their windows reach are there - synchronously inside the calls.  int32 records; min_level 1
+    keeps the 21 PUs of 16x16 and up like the product."""
+
+    def __init__(self, depth, geo, rng, slots, min_level=0):
+        import threading
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_api
+        self.O, self.depth, self.geo, self.range, self.slots, self.min_level = oracle_api, depth, geo, rng, slots, min_level
+        self.dt = np.uint8 if depth == 8 else np.uint16
+        self.ctus_w, self.ctus_h = geo["width"] // 64, geo["height"] // 64
+        nc = 2 * rng + 1
+        self.nc, self.ng = nc, (nc + 3) // 4
+        self.rec_words = (21 if min_level else 85) * 4
+        self.row_words = self.ctus_w * nc * self.ng * self.rec_words
+        self.surf = [np.zeros(self.row_words * self.ctus_h, np.int32) for _ in range(slots)]
+        self.flags = [np.zeros(self.ctus_h, np.int32) for _ in range(slots)]
+        self.pair = [None] * slots               # dict(f, r, gen, next)
+        self.gen = [0] * slots
+        self.pics = {}                           # key -> dict(plane, rows)
+        self.plane_elems = geo["stride"] * geo["rows"]
+        self.org = geo["margin_y"] * geo["stride"] + geo["margin_x"]
+        self.lag = (63 + rng) // 64
+        self.format = SURF_I32
+        self.bands = self.rows_in = 0
+        self.lock = threading.Lock()
+        self._cb = (PIC_ROWS(self._picture_rows), PAIR_OPEN(self._pair_open), SURFACE(self._surface), READY(self._ready))
+
+    def _lines(self, r0, n):
+        g = self.geo
+        y0 = 0 if r0 == 0 else g["margin_y"] + r0 * 64
+        y1 = g["rows"] if r0 + n == self.ctus_h else g["margin_y"] + (r0 + n) * 64
+        return y0, y1
+
+    def _picture_rows(self, ctx, key, buf, r0, n):
+        with self.lock:
+            g = self.geo
+            pic = self.pics.setdefault(int(key), {"plane": np.zeros(self.plane_elems, self.dt), "rows": set()})
+            if len(self.pics) > 64:              # drop the oldest pictures nobody refers to
+                live = {q[k] for q in self.pair if q for k in ("f", "r")} | {int(key)}
+                for k in list(self.pics):
+                    if k not in live and len(self.pics) > 48:
+                        del self.pics[k]
+            y0, y1 = self._lines(r0, n)
+            es = np.dtype(self.dt).itemsize
+            raw = (ctypes.c_uint8 * ((y1 - y0) * g["stride"] * es)).from_address(buf + y0 * g["stride"] * es)
+            pic["plane"][y0 * g["stride"]:y1 * g["stride"]] = np.frombuffer(raw, dtype=self.dt)
+            pic["rows"].update(range(r0, r0 + n))
+            self.rows_in += n
+            self._advance()
+        return 0
+
+    def _pair_open(self, ctx, slot, fkey, rkey):
+        with self.lock:
+            self.gen[slot] += 1
+            self.flags[slot][:] = 0
+            self.pair[slot] = {"f": int(fkey), "r": int(rkey), "gen": self.gen[slot], "next": 0}
+            self._advance()
+            return self.gen[slot]
+
+    def _advance(self):
+        g = self.geo
+        zero = np.zeros(self.nc, np.uint16)
+        for slot, q in enumerate(self.pair):
+            if not q or q["next"] >= self.ctus_h or q["f"] not in self.pics or q["r"] not in self.pics:
+                continue
+            pf, pr = self.pics[q["f"]], self.pics[q["r"]]
+            r0 = r1 = q["next"]
+            while r1 < self.ctus_h and r1 in pf["rows"] and all(k in pr["rows"] for k in range(max(0, r1 - self.lag), min(self.ctus_h, r1 + self.lag + 1))):
+                r1 += 1
+            if r1 == r0:
+                continue
+            n = r1 - r0
+            off = self.org + r0 * 64 * g["stride"]
+            surf, _ = self.O.me_fullsearch(self.depth, pf["plane"], g["stride"], off, pr["plane"], g["stride"], off, g["width"], n * 64, self.range,
+                                           0, self.ctus_w * n, zero, zero, want_surf=True, want_best=False)
+            recs = surf.reshape(-1, 85, 4)
+            if self.min_level:
+                recs = recs[:, 64:, :]
+            self.surf[slot][r0 * self.row_words:r1 * self.row_words] = recs.reshape(-1)
+            self.flags[slot][r0:r1] = q["gen"]
+            q["next"] = r1
+            self.bands += 1
+
+    def _surface(self, ctx, slot):
+        return self.surf[slot].ctypes.data
+
+    def _ready(self, ctx, slot):
+        return self.flags[slot].ctypes.data
+
+    def pointers(self):
+        return (None,) + tuple(ctypes.cast(c, ctypes.c_void_p) for c in self._cb)
+
+    def report(self):
+        return {"provider": "oracle, row-granular (CPU checker)", "bands": self.bands, "rows_in": self.rows_in}
+
+    def close(self):
+        pass
+
+
+class StreamParams(ctypes.Structure):
+    """x265hip_me_stream_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int), ("stride", ctypes.c_ssize_t),
+                ("margin_x", ctypes.c_int), ("margin_y", ctypes.c_int), ("range", ctypes.c_int), ("surf_format", ctypes.c_int), ("min_level", ctypes.c_int),
+                ("slots", ctypes.c_int), ("pictures", ctypes.c_int), ("band_rows", ctypes.c_int)]
+
+
+class StreamStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("pairs_opened", "pairs_completed", "bands", "rows_searched", "rows_uploaded", "failed", "stale_pairs",
+                                               "us_busy", "bytes_downloaded", "bytes_uploaded", "surface_bytes")]
+
+
+class StreamGpuProvider:
+    """libx265hip.so's x265hip_me_stream: the product path under frame threads."""
+
+    def __init__(self, depth, geo, rng, slots, min_level=1, pictures=24, band_rows=0):
+        A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+        self.A, self.L = A, A.lib()
+        self.format = SURF_PACKED if depth == 8 else SURF_I32
+        self.min_level = min_level
+        p = StreamParams(depth, geo["width"], geo["height"], geo["stride"], geo["margin_x"], geo["margin_y"], rng, self.format, min_level, slots, pictures, band_rows)
+        self.handle = ctypes.c_void_p()
+        L = self.L
+        L.x265hip_me_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(StreamParams)]
+        A.check(L.x265hip_me_stream_create(ctypes.byref(self.handle), ctypes.byref(p)), "x265hip_me_stream_create")
+        L.x265hip_me_stream_destroy.argtypes = [ctypes.c_void_p]
+        L.x265hip_me_stream_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(StreamStats)]
+
+    def pointers(self):
+        L = self.L
+        return (self.handle,) + tuple(ctypes.cast(f, ctypes.c_void_p) for f in (L.x265hip_me_stream_picture_rows, L.x265hip_me_stream_pair_open,
+                                                                                  L.x265hip_me_stream_surface, L.x265hip_me_stream_ready))
+
+    def report(self):
+        st = StreamStats()
+        self.L.x265hip_me_stream_stats(self.handle, ctypes.byref(st))
+        d = {n: int(getattr(st, n)) for n, _ in StreamStats._fields_}
+        d["provider"] = ("x265hip_me_stream (reconstructed CTU rows in as the reference publishes them; every open (picture, reference) pair searched "
+                         "row by row behind the producer; " + ("16x16-and-up record tails" if self.min_level else "whole records") + " downloaded per band)")
+        d["surface_mbytes_per_pair"] = round(st.surface_bytes / 1e6, 1)
+        d["worker_busy_ms"] = round(st.us_busy / 1e3, 1)
+        return d
+
+    def close(self):
+        if self.handle:
+            self.L.x265hip_me_stream_destroy(self.handle)
+            self.handle = None
+
+
+class StreamOraclePhaseProvider:
+    """CPU stand-in for x265hip_phase_stream (checker only): the oracle's phase planes, grown line by line as rows arrive."""
+
+    def __init__(self, depth, geo, slots):
+        import threading
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_api
+        self.O, self.depth, self.geo, self.slots = oracle_api, depth, geo, slots
+        self.dt = np.uint8 if depth == 8 else np.uint16
+        g = geo
+        self.ctu_rows = g["height"] // 64
+        self.dims = [(g["rows"], g["stride"], g["margin_y"], 64, 15), (g["rows_c"], g["stride_c"], g["margin_y"] >> 1, 32, 63)]
+        self.src = [[np.zeros((self.dims[min(k, 1)][0], self.dims[min(k, 1)][1]), self.dt) for k in range(3)] for _ in range(slots)]
+        self.out = [[np.zeros((self.dims[min(k, 1)][4], self.dims[min(k, 1)][0], self.dims[min(k, 1)][1]), self.dt) for k in range(3)] for _ in range(slots)]
+        self.progress = [np.zeros(2, np.uint64) for _ in range(slots)]
+        self.state = [None] * slots
+        self.gen = [0] * slots
+        self.opened = self.bands = 0
+        self.lock = threading.Lock()
+        self._cb = (PS_OPEN(self._open), PS_ROWS(self._rows), PH_PLANES(self._planes), PS_PROGRESS(self._progress))
+
+    def _open(self, ctx, slot):
+        with self.lock:
+            self.gen[slot] += 1
+            self.progress[slot][:] = 0
+            self.state[slot] = {"staged": set(), "next": 0, "done": [8, 8]}
+            self.opened += 1
+            return self.gen[slot]
+
+    def _rows(self, ctx, slot, gen, luma, cb, cr, r0, n):
+        with self.lock:
+            if gen != self.gen[slot]:
+                return -4
+            st = self.state[slot]
+            es = np.dtype(self.dt).itemsize
+            for pl, ptr in enumerate((luma, cb, cr)):
+                rows, stride, margin, cl, _ = self.dims[min(pl, 1)]
+                y0 = 0 if r0 == 0 else margin + r0 * cl
+                y1 = rows if r0 + n == self.ctu_rows else margin + (r0 + n) * cl
+                raw = (ctypes.c_uint8 * ((y1 - y0) * stride * es)).from_address(ptr + y0 * stride * es)
+                self.src[slot][pl][y0:y1] = np.frombuffer(raw, dtype=self.dt).reshape(y1 - y0, stride)
+            st["staged"].update(range(r0, r0 + n))
+            r1 = st["next"]
+            while r1 in st["staged"]:
+                r1 += 1
+            if r1 == st["next"]:
+                return 0
+            st["next"] = r1
+            for k in range(2):
+                rows, stride, margin, cl, nph = self.dims[k]
+                y1 = rows if r1 == self.ctu_rows else margin + r1 * cl
+                b0, b1 = st["done"][k], y1 - 8
+                if b1 - b0 < 8:
+                    continue
+                for pl in ((0,) if k == 0 else (1, 2)):
+                    band = self.src[slot][pl][b0 - 8:b1 + 8]
+                    ph = self.O.phase_planes(self.depth, band, stride, band.shape[0], chroma=bool(k))
+                    self.out[slot][pl][:, b0:b1] = ph[:, 8:band.shape[0] - 8]
+                st["done"][k] = b1
+                self.progress[slot][k] = (self.gen[slot] << 32) | b1
+            self.bands += 1
+        return 0
+
+    def _planes(self, ctx, slot, plane):
+        return self.out[slot][plane].ctypes.data
+
+    def _progress(self, ctx, slot):
+        return self.progress[slot].ctypes.data
+
+    def pointers(self):
+        return (None,) + tuple(ctypes.cast(c, ctypes.c_void_p) for c in self._cb)
+
+    def report(self):
+        return {"provider": "oracle, row-granular (CPU checker)", "pictures_opened": self.opened, "bands": self.bands}
+
+    def close(self):
+        pass
+
+
+class PhaseStreamParams(ctypes.Structure):
+    """x265hip_phase_stream_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("stride", ctypes.c_ssize_t), ("rows", ctypes.c_int), ("margin_y", ctypes.c_int),
+                ("stride_c", ctypes.c_ssize_t), ("rows_c", ctypes.c_int), ("margin_y_c", ctypes.c_int), ("ctu_rows", ctypes.c_int), ("slots", ctypes.c_int)]
+
+
+class PhaseStreamStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("opened", "completed", "bands", "failed", "us_busy", "bytes_downloaded", "bytes_uploaded", "bytes_per_picture")]
+
+
+class StreamGpuPhaseProvider:
+    """libx265hip.so's x265hip_phase_stream: the product path under frame threads."""
+
+    def __init__(self, depth, geo, slots):
+        A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+        self.L = L = A.lib()
+        p = PhaseStreamParams(depth, geo["stride"], geo["rows"], geo["margin_y"], geo["stride_c"], geo["rows_c"], geo["margin_y"] >> 1, geo["height"] // 64, slots)
+        self.handle = ctypes.c_void_p()
+        L.x265hip_phase_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(PhaseStreamParams)]
+        A.check(L.x265hip_phase_stream_create(ctypes.byref(self.handle), ctypes.byref(p)), "x265hip_phase_stream_create")
+        L.x265hip_phase_stream_destroy.argtypes = [ctypes.c_void_p]
+        L.x265hip_phase_stream_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(PhaseStreamStats)]
+
+    def pointers(self):
+        L = self.L
+        return (self.handle,) + tuple(ctypes.cast(f, ctypes.c_void_p) for f in (L.x265hip_phase_stream_open, L.x265hip_phase_stream_rows,
+                                                                                  L.x265hip_phase_stream_planes, L.x265hip_phase_stream_progress))
+
+    def report(self):
+        st = PhaseStreamStats()
+        self.L.x265hip_phase_stream_stats(self.handle, ctypes.byref(st))
+        d = {n: int(getattr(st, n)) for n, _ in PhaseStreamStats._fields_}
+        d["provider"] = "x265hip_phase_stream (phase planes grown line by line behind the reconstruction, one band per published CTU row)"
+        d["mbytes_per_picture"] = round(st.bytes_per_picture / 1e6, 1)
+        d["worker_busy_ms"] = round(st.us_busy / 1e3, 1)
+        d["download_gbytes_per_s_while_busy"] = round(st.bytes_downloaded / max(1, st.us_busy) / 1e3, 2)
+        return d
+
+    def close(self):
+        if self.handle:
+            self.L.x265hip_phase_stream_destroy(self.handle)
+            self.handle = None
+
+
 def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
-            surf_format=None):
-    """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) using
-    --frame-threads 1 and --ctu 64."""
+            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0):
+    """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
+    the picture-granular providers need --frame-threads 1, streamed=True (row-granular providers) serves under any --frame-threads."""
     lib = seam_lib(depth)
     geo = geometry(width, height)
-    prov = GpuProvider(depth, geo, rng, slots, surf_format) if provider == "gpu" else OracleProvider(depth, geo, rng, slots)
-    ctx, submit, submit_batch, surface, ready = prov.pointers()
-    rc = lib.x265ref_seam_configure(ctx, submit, submit_batch, surface, ready, rng, prov.format, slots, geo["width"], geo["height"], geo["stride"],
-                                    geo["margin_x"], geo["margin_y"], min_pu, int(bool(verify)) | (2 if wait else 0))
+    if streamed:
+        prov = (StreamGpuProvider(depth, geo, rng, slots, min_level, pictures, band_rows) if provider == "gpu"
+                else StreamOracleProvider(depth, geo, rng, slots, min_level))
+        ctx, pic_rows, pair_open, surface, ready = prov.pointers()
+        lib.x265ref_seam_configure_streamed.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_ssize_t] + [ctypes.c_int] * 4
+        rc = lib.x265ref_seam_configure_streamed(ctx, pic_rows, pair_open, surface, ready, rng, prov.format, min_level, slots, geo["width"], geo["height"],
+                                                 geo["stride"], geo["margin_x"], geo["margin_y"], min_pu, int(bool(verify)) | (2 if wait else 0))
+    else:
+        prov = GpuProvider(depth, geo, rng, slots, surf_format) if provider == "gpu" else OracleProvider(depth, geo, rng, slots)
+        ctx, submit, submit_batch, surface, ready = prov.pointers()
+        rc = lib.x265ref_seam_configure(ctx, submit, submit_batch, surface, ready, rng, prov.format, slots, geo["width"], geo["height"], geo["stride"],
+                                        geo["margin_x"], geo["margin_y"], min_pu, int(bool(verify)) | (2 if wait else 0))
     if rc:
         raise RuntimeError(f"x265ref_seam_configure failed ({rc})")
     filler = ctypes.cast(lib.x265ref_seam_fill_table, ctypes.c_void_p)
@@ -293,7 +585,16 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     lib.x265ref_subpel_seam_configure.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int]
     lib.x265ref_subpel_seam_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     sub = None
-    if subpel:
+    if subpel and streamed:
+        sub = (StreamGpuPhaseProvider if subpel == "gpu" else StreamOraclePhaseProvider)(depth, geo, subpel_slots)
+        sctx, sopen, srows, spl, sprog = sub.pointers()
+        lib.x265ref_subpel_seam_configure_streamed.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_ssize_t,
+                                                                                       ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        rc = lib.x265ref_subpel_seam_configure_streamed(sctx, sopen, srows, spl, sprog, subpel_slots, geo["stride"], geo["rows"], geo["stride_c"], geo["rows_c"],
+                                                        geo["height"] // 64, int(bool(verify)) | (2 if wait else 0))
+        if rc:
+            raise RuntimeError(f"x265ref_subpel_seam_configure_streamed failed ({rc})")
+    elif subpel:
         sub = (GpuPhaseProvider if subpel == "gpu" else OraclePhaseProvider)(depth, geo, subpel_slots)
         sctx, ssub, spl, srd = sub.pointers()
         rc = lib.x265ref_subpel_seam_configure(sctx, ssub, spl, srd, subpel_slots, geo["stride"], geo["rows"], geo["stride_c"], geo["rows_c"],
@@ -306,7 +607,12 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     def report():
         d = stats(lib)
         d.update(prov.report())
-        d.update({"range": rng, "slots": slots, "min_pu": min_pu})
+        d.update({"range": rng, "slots": slots, "min_pu": min_pu, "row_granular": bool(streamed)})
+        if streamed:
+            so4 = (ctypes.c_uint64 * 4)()
+            lib.x265ref_seam_stream_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+            lib.x265ref_seam_stream_stats(so4)
+            d["row_stream"] = dict(zip(STREAM_STAT_NAMES, [int(v) for v in so4]))
         la = (ctypes.c_uint64 * 4)()
         lib.x265ref_lookahead_seam_stats(la)
         lib.x265ref_lookahead_seam_mismatches.restype = ctypes.c_uint64

@@ -25,6 +25,9 @@ void set_error(const char* fmt, ...);
 int  check_hip(hipError_t e, const char* what);   // 0 or X265HIP_ENODEV with last-error text
 int  ensure_device();                             // lazy x265hip_init(-1): validates the calling thread's current device
 
+// csrc/phase_kernels.hip: the launch behind x265hip_phase_planes with the distance between phase planes as a parameter (bands)
+int  phase_planes_launch(int depth, int chroma, const void* src, void* dst, intptr_t stride, int rows, size_t plane_bytes, hipStream_t s);
+
 #define X265HIP_TRY(expr) do { int _rc = ::x265hip::check_hip((expr), #expr); if (_rc) return _rc; } while (0)
 
 #ifdef __HIPCC__

@@ -1,0 +1,414 @@
+// me_stream.hip - the ROW-GRANULAR consumer of the exhaustive search, for hosts that encode several pictures at once.
+//
+// x265hip_me_cache (csrc/me_cache.hip) takes whole pictures: a reference picture must be complete when the next picture starts, which
+// is --frame-threads 1.  The reference's own parallelism is frame threads (5 on 16 cores): picture k + 1 starts while picture k is
+// still being reconstructed, CTU row by CTU row, each row published through Frame::m_reconRowFlag (encoder/framefilter.cpp:664) and
+// awaited row by row by the consumers (encoder/frameencoder.cpp:852-868, m_refLagRows :161-164).  This service follows that protocol:
+//
+//   * a host thread hands over CTU ROWS of a picture as they become final (x265hip_me_stream_picture_rows: the rows are copied into
+//     pinned staging inside the call - the hook sits right after m_reconRowFlag[row].set(1)); a source picture arrives in one piece;
+//   * a (source, reference) pair is OPENED when the first search of that pair is about to run (x265hip_me_stream_pair_open);
+//   * the worker thread uploads rows as they arrive and searches every CTU row of every open pair as soon as the rows of the
+//     reference its window reaches (row + (63 + range) / 64) are on the device - bands of up to `band_rows` CTU rows per launch of
+//     x265hip_me_fullsearch - then downloads the band's SAD surfaces on a copy stream and raises one flag per (pair, CTU row).
+//     The window needs 1 row below the CTU row at merange <= 64; the host itself waits for 3 (motion.cpp's sub-pel lag), so the
+//     device runs two reference rows ahead of the first host lookup of a row.
+//   * min_level = 1 keeps only the 16x16 / 32x32 / 64x64 levels of a record (720 -> 208 bytes packed, 1360 -> 336 bytes int32): a
+//     compaction kernel between search and download.  An 8x8 SAD on cached pixels costs a host less than a cache-missing lookup;
+//     with the 8x8 level gone a 4K pair at +-32 is 0.47 GB of pinned host memory instead of 1.6 GB.
+//
+// Readers never wait and never lock: surface rows are valid when ready[row] == the pair's generation, checked BEFORE and AFTER the
+// read (a slot that was reopened in between has its flags cleared before any of its rows can be rewritten).  Everything a lookup
+// cannot serve is answered by the host's own primitive with identical values, so the bitstream cannot change.
+#include "common.h"
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+using namespace x265hip;
+
+namespace {
+
+// records of `rec16` 16-byte chunks -> their last `tail16` chunks, contiguous
+__global__ void surf_tail_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t nrec, int rec16, int tail16)
+{
+    const size_t n = nrec * (size_t)tail16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    {
+        const size_t r = i / (size_t)tail16;
+        const int c = (int)(i - r * (size_t)tail16);
+        out[i] = in[r * (size_t)rec16 + (size_t)(rec16 - tail16 + c)];
+    }
+}
+
+double ms_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+enum { ROW_NONE = 0, ROW_STAGED = 1, ROW_ON_DEVICE = 2 };
+
+} // namespace
+
+struct x265hip_me_stream
+{
+    x265hip_me_stream_params prm;
+    int bpp, ctusW, ctusH, nc, ng, fullRec, rec, device, bandRows, lagRows;
+    size_t planeBytes, rowBytes, fullRowBytes, surfBytes, linePitch;
+    hipStream_t compute = nullptr, copy = nullptr;
+    uint8_t* dScratch = nullptr;            // full records of one band (min_level > 0)
+    struct Pic
+    {
+        uint64_t key = 0; bool used = false; uint32_t epoch = 0; uint64_t stamp = 0; int busy = 0;
+        uint8_t* stage = nullptr;           // pinned copy, rows staged by the host threads
+        uint8_t* dev = nullptr;
+        std::vector<uint8_t> rows;          // per CTU row: ROW_*
+    };
+    struct Slot
+    {
+        uint8_t* surf = nullptr; uint8_t* dSurf = nullptr;
+        std::atomic<int>* ready = nullptr;
+        int generation = 0;
+        int fenc = -1, ref = -1; uint32_t fencEpoch = 0, refEpoch = 0;
+        int nextRow = 0; bool active = false;
+        hipEvent_t evSearched = nullptr, evDown = nullptr;
+    };
+    std::vector<Pic> pics;
+    std::vector<Slot> slots;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool stop = false, dirty = false;
+    uint64_t clock = 0;
+    std::thread worker;
+    std::atomic<uint64_t> bands{0}, rowsSearched{0}, rowsUploaded{0}, pairsOpened{0}, pairsCompleted{0}, failed{0}, noPicture{0};
+    std::atomic<uint64_t> usBusy{0}, bytesDown{0}, bytesUp{0};
+    char workerError[256] = "";
+};
+
+namespace {
+
+typedef x265hip_me_stream S;
+
+// first / one-past-last buffer line of CTU rows [r0, r0 + n): the margins travel with the first / last row
+inline void row_lines(const S* s, int r0, int n, long& y0, long& y1)
+{
+    y0 = r0 == 0 ? 0 : s->prm.margin_y + (long)r0 * 64;
+    y1 = r0 + n == s->ctusH ? (long)s->prm.height + 2 * s->prm.margin_y : s->prm.margin_y + (long)(r0 + n) * 64;
+}
+
+struct Band { int slot, gen, r0, r1; };
+struct Upload { int pic, r0, n; };
+
+int run_round(S* s, const std::vector<Upload>& ups, const std::vector<Band>& bands)
+{
+    X265HIP_TRY(hipSetDevice(s->device));
+    for (const Upload& u : ups)
+    {
+        long y0, y1;
+        row_lines(s, u.r0, u.n, y0, y1);
+        const size_t off = (size_t)y0 * s->linePitch, bytes = (size_t)(y1 - y0) * s->linePitch;
+        X265HIP_TRY(hipMemcpyAsync(s->pics[u.pic].dev + off, s->pics[u.pic].stage + off, bytes, hipMemcpyHostToDevice, s->compute));
+        s->bytesUp += bytes; s->rowsUploaded += u.n;
+    }
+    const size_t org = ((size_t)s->prm.margin_y * s->prm.stride + s->prm.margin_x) * s->bpp;
+    for (const Band& b : bands)
+    {
+        S::Slot& sl = s->slots[b.slot];
+        const int n = b.r1 - b.r0 + 1;
+        const size_t bandOff = (size_t)b.r0 * 64 * s->linePitch;
+        x265hip_me_params p;
+        memset(&p, 0, sizeof(p));
+        p.depth = s->prm.depth; p.width = s->prm.width; p.height = n * 64; p.range = s->prm.range;
+        p.fenc = s->pics[sl.fenc].dev + org + bandOff; p.fenc_stride = s->prm.stride;
+        p.fref = s->pics[sl.ref].dev + org + bandOff;  p.fref_stride = s->prm.stride;
+        p.surf_format = s->prm.surf_format;
+        uint8_t* dst = sl.dSurf + (size_t)b.r0 * s->rowBytes;
+        p.surf = (int32_t*)(s->prm.min_level ? s->dScratch : dst);
+        int rc = x265hip_me_fullsearch(&p, s->compute);
+        if (rc) return rc;
+        if (s->prm.min_level)
+        {
+            const size_t nrec = (size_t)n * s->ctusW * s->nc * s->ng;
+            const int rec16 = s->fullRec / 16, tail16 = s->rec / 16;
+            size_t blocks = (nrec * tail16 + 255) / 256;
+            if (blocks > 16384) blocks = 16384;
+            hipLaunchKernelGGL(surf_tail_kernel, dim3((unsigned)blocks), dim3(256), 0, s->compute, (const uint4*)s->dScratch, (uint4*)dst, nrec, rec16, tail16);
+            X265HIP_TRY(hipGetLastError());
+        }
+        X265HIP_TRY(hipEventRecord(sl.evSearched, s->compute));
+        X265HIP_TRY(hipStreamWaitEvent(s->copy, sl.evSearched, 0));
+        X265HIP_TRY(hipMemcpyAsync(sl.surf + (size_t)b.r0 * s->rowBytes, dst, (size_t)n * s->rowBytes, hipMemcpyDeviceToHost, s->copy));
+        X265HIP_TRY(hipEventRecord(sl.evDown, s->copy));
+        s->bytesDown += (size_t)n * s->rowBytes;
+    }
+    for (const Band& b : bands)
+    {
+        S::Slot& sl = s->slots[b.slot];
+        X265HIP_TRY(hipEventSynchronize(sl.evDown));
+        std::lock_guard<std::mutex> lk(s->mu);                    // against pair_open: a reopened slot keeps its cleared flags
+        if (sl.generation == b.gen)
+        {
+            for (int r = b.r0; r <= b.r1; r++) sl.ready[r].store(b.gen, std::memory_order_release);
+            if (b.r1 == s->ctusH - 1) s->pairsCompleted++;
+        }
+        s->bands++; s->rowsSearched += b.r1 - b.r0 + 1;
+    }
+    return 0;
+}
+
+void worker_main(S* s)
+{
+    for (;;)
+    {
+        std::vector<Upload> ups;
+        std::vector<Band> bands;
+        {
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv.wait(lk, [s] { return s->stop || s->dirty; });
+            if (s->stop) return;
+            s->dirty = false;
+            for (int i = 0; i < (int)s->pics.size(); i++)
+            {
+                S::Pic& pc = s->pics[i];
+                if (!pc.used) continue;
+                for (int r = 0; r < s->ctusH;)
+                {
+                    if (pc.rows[r] != ROW_STAGED) { r++; continue; }
+                    int e = r;
+                    while (e < s->ctusH && pc.rows[e] == ROW_STAGED) pc.rows[e++] = ROW_ON_DEVICE;      // stream order: every later launch sees them
+                    ups.push_back({ i, r, e - r });
+                    r = e;
+                }
+            }
+            for (int i = 0; i < (int)s->slots.size(); i++)
+            {
+                S::Slot& sl = s->slots[i];
+                if (!sl.active) continue;
+                const S::Pic& pf = s->pics[sl.fenc]; const S::Pic& pr = s->pics[sl.ref];
+                if (!pf.used || !pr.used || pf.epoch != sl.fencEpoch || pr.epoch != sl.refEpoch) { sl.active = false; s->noPicture++; continue; }
+                int r1 = sl.nextRow - 1;
+                while (r1 + 1 < s->ctusH && r1 + 1 - sl.nextRow < s->bandRows)
+                {
+                    const int r = r1 + 1;
+                    const int lo = r - s->lagRows < 0 ? 0 : r - s->lagRows, hi = r + s->lagRows >= s->ctusH ? s->ctusH - 1 : r + s->lagRows;
+                    bool ok = pf.rows[r] == ROW_ON_DEVICE;
+                    for (int k = lo; k <= hi && ok; k++) ok = pr.rows[k] == ROW_ON_DEVICE;
+                    if (!ok) break;
+                    r1 = r;
+                }
+                if (r1 < sl.nextRow) continue;
+                bands.push_back({ i, sl.generation, sl.nextRow, r1 });
+                sl.nextRow = r1 + 1;
+                if (sl.nextRow == s->ctusH) sl.active = false;
+                else s->dirty = true;                                   // more rows may be searchable at once: come round again
+            }
+        }
+        if (ups.empty() && bands.empty()) continue;
+        const double t0 = ms_now_us();
+        if (run_round(s, ups, bands))
+        {
+            s->failed += bands.size() + 1;
+            snprintf(s->workerError, sizeof(s->workerError), "%s", x265hip_last_error());
+        }
+        s->usBusy += (uint64_t)(ms_now_us() - t0);
+    }
+}
+
+void free_all(S* s)
+{
+    for (auto& p : s->pics) { if (p.stage) (void)hipHostFree(p.stage); if (p.dev) (void)hipFree(p.dev); }
+    for (auto& sl : s->slots)
+    {
+        if (sl.surf) (void)hipHostFree(sl.surf);
+        if (sl.dSurf) (void)hipFree(sl.dSurf);
+        if (sl.evSearched) (void)hipEventDestroy(sl.evSearched);
+        if (sl.evDown) (void)hipEventDestroy(sl.evDown);
+        delete[] sl.ready;
+    }
+    if (s->dScratch) (void)hipFree(s->dScratch);
+    if (s->compute) (void)hipStreamDestroy(s->compute);
+    if (s->copy) (void)hipStreamDestroy(s->copy);
+}
+
+// index of the picture named `key`, created when it is new (least recently used entry that no open pair reads); -1 when every entry is held
+int find_or_make_picture(S* s, uint64_t key)
+{
+    for (int i = 0; i < (int)s->pics.size(); i++)
+        if (s->pics[i].used && s->pics[i].key == key) { s->pics[i].stamp = ++s->clock; return i; }
+    int victim = -1;
+    for (int i = 0; i < (int)s->pics.size(); i++)
+    {
+        S::Pic& p = s->pics[i];
+        if (!p.used) { victim = i; break; }
+        if (p.busy) continue;
+        bool held = false;
+        for (const auto& sl : s->slots)
+            held |= sl.active && ((sl.fenc == i && sl.fencEpoch == p.epoch) || (sl.ref == i && sl.refEpoch == p.epoch));
+        if (!held && (victim < 0 || p.stamp < s->pics[victim].stamp)) victim = i;
+    }
+    if (victim < 0) return -1;
+    S::Pic& p = s->pics[victim];
+    p.used = true; p.key = key; p.epoch++; p.stamp = ++s->clock; p.busy = 0;
+    std::fill(p.rows.begin(), p.rows.end(), (uint8_t)ROW_NONE);
+    return victim;
+}
+
+} // namespace
+
+extern "C" {
+
+int x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_params* p)
+{
+    if (!out || !p) { set_error("me_stream_create: NULL argument"); return X265HIP_EINVAL; }
+    *out = nullptr;
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("me_stream_create: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->width <= 0 || p->height <= 0 || (p->width & 63) || (p->height & 63))
+    { set_error("me_stream_create: width/height must be whole CTUs (got %dx%d)", p->width, p->height); return X265HIP_EINVAL; }
+    if (p->range < 1 || p->range > 256 || p->margin_x < p->range + 12 || p->margin_y < p->range + 12)
+    { set_error("me_stream_create: range %d needs margins >= range + 12 (have %d / %d)", p->range, p->margin_x, p->margin_y); return X265HIP_EINVAL; }
+    if (p->stride < p->width + 2 * p->margin_x) { set_error("me_stream_create: stride %ld < width + 2 * margin_x", (long)p->stride); return X265HIP_EINVAL; }
+    if (p->slots < 1 || p->slots > 256 || p->pictures < 2 || p->pictures > 256) { set_error("me_stream_create: slots %d / pictures %d", p->slots, p->pictures); return X265HIP_EINVAL; }
+    if (p->surf_format != X265HIP_SURF_I32 && !(p->surf_format == X265HIP_SURF_PACKED && p->depth == 8))
+    { set_error("me_stream_create: surf_format %d for depth %d (record-contiguous formats only: X265HIP_SURF_PACKED at 8 bits, X265HIP_SURF_I32)", p->surf_format, p->depth); return X265HIP_EINVAL; }
+    if (p->min_level < 0 || p->min_level > 1 || p->band_rows < 0) { set_error("me_stream_create: min_level %d / band_rows %d", p->min_level, p->band_rows); return X265HIP_EINVAL; }
+    S* s = new (std::nothrow) S;
+    if (!s) { set_error("me_stream_create: out of memory"); return X265HIP_EINVAL; }
+    s->prm = *p;
+    s->bpp = p->depth == 8 ? 1 : 2;
+    s->ctusW = p->width / 64; s->ctusH = p->height / 64;
+    s->nc = 2 * p->range + 1; s->ng = (s->nc + 3) / 4;
+    s->fullRec = p->surf_format == X265HIP_SURF_I32 ? X265HIP_SURF_GROUP_BYTES_I32 : X265HIP_SURF_GROUP_BYTES_PACKED;
+    s->rec = !p->min_level ? s->fullRec : p->surf_format == X265HIP_SURF_I32 ? X265HIP_SURF_TAIL_BYTES_I32 : X265HIP_SURF_TAIL_BYTES_PACKED;
+    s->linePitch = (size_t)p->stride * s->bpp;
+    s->planeBytes = s->linePitch * (p->height + 2 * p->margin_y);
+    s->rowBytes = (size_t)s->ctusW * s->nc * s->ng * s->rec;
+    s->fullRowBytes = (size_t)s->ctusW * s->nc * s->ng * s->fullRec;
+    s->surfBytes = s->rowBytes * s->ctusH;
+    s->bandRows = p->band_rows ? p->band_rows : 8;
+    if (s->bandRows > s->ctusH) s->bandRows = s->ctusH;
+    s->lagRows = (63 + p->range) / 64;                    // CTU rows of the reference a CTU row's window reaches below (and above) itself
+    if ((s->linePitch & 3) || ((((size_t)p->margin_y * p->stride + p->margin_x) * s->bpp) & 3))
+    { set_error("me_stream_create: sample (0,0) and the row pitch must be 4-byte aligned"); delete s; return X265HIP_EINVAL; }
+    if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;
+#define MS_TRY(expr) do { if (check_hip((expr), #expr)) { free_all(s); delete s; return X265HIP_ENODEV; } } while (0)
+    MS_TRY(hipStreamCreateWithFlags(&s->compute, hipStreamNonBlocking));
+    MS_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
+    if (p->min_level) MS_TRY(hipMalloc((void**)&s->dScratch, s->fullRowBytes * s->bandRows));
+    s->pics = std::vector<S::Pic>(p->pictures);
+    for (auto& pc : s->pics)
+    {
+        MS_TRY(hipHostMalloc((void**)&pc.stage, s->planeBytes, hipHostMallocDefault));
+        MS_TRY(hipMalloc((void**)&pc.dev, s->planeBytes + 256));
+        pc.rows.assign(s->ctusH, (uint8_t)ROW_NONE);
+    }
+    s->slots = std::vector<S::Slot>(p->slots);
+    for (auto& sl : s->slots)
+    {
+        MS_TRY(hipHostMalloc((void**)&sl.surf, s->surfBytes, hipHostMallocDefault));
+        MS_TRY(hipMalloc((void**)&sl.dSurf, s->surfBytes));
+        MS_TRY(hipEventCreateWithFlags(&sl.evSearched, hipEventDisableTiming));
+        MS_TRY(hipEventCreateWithFlags(&sl.evDown, hipEventDisableTiming));
+        sl.ready = new std::atomic<int>[s->ctusH];
+        for (int r = 0; r < s->ctusH; r++) sl.ready[r].store(0);
+    }
+#undef MS_TRY
+    s->worker = std::thread(worker_main, s);
+    *out = s;
+    return 0;
+}
+
+void x265hip_me_stream_destroy(x265hip_me_stream* s)
+{
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->stop = true;
+    }
+    s->cv.notify_all();
+    if (s->worker.joinable()) s->worker.join();
+    (void)hipStreamSynchronize(s->compute);
+    (void)hipStreamSynchronize(s->copy);
+    free_all(s);
+    delete s;
+}
+
+/* CTU rows [ctu_row0, ctu_row0 + ctu_rows) of the picture named `key` are final in `buf` (the whole allocated plane: stride * (height +
+ * 2 * margin_y) samples; the top margin belongs to row 0, the bottom margin to the last row): copied before the call returns. */
+int x265hip_me_stream_picture_rows(x265hip_me_stream* s, uint64_t key, const void* buf, int ctu_row0, int ctu_rows)
+{
+    if (!s || !buf || ctu_row0 < 0 || ctu_rows < 1 || ctu_row0 + ctu_rows > s->ctusH) { set_error("me_stream_picture_rows: bad argument"); return X265HIP_EINVAL; }
+    int idx;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        idx = find_or_make_picture(s, key);
+        if (idx < 0) { set_error("me_stream_picture_rows: every picture entry is held by an open pair (pictures = %d)", s->prm.pictures); return X265HIP_EBUSY; }
+        s->pics[idx].busy++;
+    }
+    long y0, y1;
+    row_lines(s, ctu_row0, ctu_rows, y0, y1);
+    memcpy(s->pics[idx].stage + (size_t)y0 * s->linePitch, (const uint8_t*)buf + (size_t)y0 * s->linePitch, (size_t)(y1 - y0) * s->linePitch);
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        S::Pic& p = s->pics[idx];
+        p.busy--;
+        if (p.used && p.key == key)
+            for (int r = ctu_row0; r < ctu_row0 + ctu_rows; r++) p.rows[r] = ROW_STAGED;
+        s->dirty = true;
+    }
+    s->cv.notify_one();
+    return 0;
+}
+
+/* Opens pair (source picture fenc_key, reference picture ref_key) in `slot`: its CTU rows are searched as the two pictures' rows
+ * arrive (before or after this call).  Returns the slot's new GENERATION (> 0) or a negative error. */
+int x265hip_me_stream_pair_open(x265hip_me_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key)
+{
+    if (!s || slot < 0 || slot >= (int)s->slots.size()) { set_error("me_stream_pair_open: bad slot"); return X265HIP_EINVAL; }
+    int gen;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        S::Slot& sl = s->slots[slot];
+        sl.active = false;                                   // the slot's previous pair no longer holds its pictures
+        const int f = find_or_make_picture(s, fenc_key);
+        const int r = f < 0 ? -1 : find_or_make_picture(s, ref_key);
+        if (f < 0 || r < 0 || f == r) { set_error("me_stream_pair_open: no picture entry free (pictures = %d)", s->prm.pictures); return X265HIP_EBUSY; }
+        gen = ++sl.generation;
+        if (gen <= 0) gen = sl.generation = 1;
+        for (int k = 0; k < s->ctusH; k++) sl.ready[k].store(0, std::memory_order_release);      // before any row of the slot can be rewritten
+        sl.fenc = f; sl.ref = r; sl.fencEpoch = s->pics[f].epoch; sl.refEpoch = s->pics[r].epoch;
+        sl.nextRow = 0; sl.active = true;
+        s->dirty = true;
+        s->pairsOpened++;
+    }
+    s->cv.notify_one();
+    return gen;
+}
+
+const void* x265hip_me_stream_surface(x265hip_me_stream* s, int slot)
+{
+    return (s && slot >= 0 && slot < (int)s->slots.size()) ? s->slots[slot].surf : nullptr;
+}
+
+const volatile int* x265hip_me_stream_ready(x265hip_me_stream* s, int slot)
+{
+    return (s && slot >= 0 && slot < (int)s->slots.size()) ? reinterpret_cast<const volatile int*>(s->slots[slot].ready) : nullptr;
+}
+
+int x265hip_me_stream_record_bytes(x265hip_me_stream* s) { return s ? s->rec : 0; }
+
+int x265hip_me_stream_stats(x265hip_me_stream* s, x265hip_me_stream_stats_t* st)
+{
+    if (!s || !st) { set_error("me_stream_stats: NULL"); return X265HIP_EINVAL; }
+    st->pairs_opened = s->pairsOpened; st->pairs_completed = s->pairsCompleted; st->bands = s->bands; st->rows_searched = s->rowsSearched;
+    st->rows_uploaded = s->rowsUploaded; st->failed = s->failed; st->stale_pairs = s->noPicture; st->us_busy = s->usBusy;
+    st->bytes_downloaded = s->bytesDown; st->bytes_uploaded = s->bytesUp; st->surface_bytes = s->surfBytes;
+    if (s->failed) set_error("me_stream worker: %s", s->workerError);
+    return 0;
+}
+
+} // extern "C"

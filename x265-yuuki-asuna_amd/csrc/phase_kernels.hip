@@ -195,6 +195,31 @@ __global__ void __launch_bounds__(256) phase_chroma_kernel(PhaseArgs a)
 
 using namespace x265hip;
 
+// rows of the source (multiple of 4, >= 16) -> lines [4, rows - 8) of every phase plane; plane_bytes = distance between consecutive phase
+// planes of dst (the whole plane for a band of a larger picture: csrc/phase_stream.hip runs bands with src / dst moved to the band's
+// first line - 4 and the planes' own pitch)
+int x265hip::phase_planes_launch(int depth, int chroma, const void* src, void* dst, intptr_t stride, int rows, size_t plane_bytes, hipStream_t s)
+{
+    const int bpp = depth == 8 ? 1 : 2;
+    PhaseArgs a;
+    a.src = (const uint8_t*)src; a.dst = (uint8_t*)dst; a.strideB = (long)stride * bpp; a.rows = rows;
+    a.tilesW = (int)(stride / 4); a.depth = depth; a.planeBytes = plane_bytes;
+    // tile rows 1 .. rows / 4 - 3: a tile reads 3 rows above and 7 below itself (and a few bytes of the neighbouring rows at the row
+    // ends), so every access stays inside the plane without any guard memory around it
+    const dim3 gridL((a.tilesW + 255) / 256, rows / 4 - 3);               // a thread produces every phase of its tile
+    if (chroma)
+    {
+        if (bpp == 1) hipLaunchKernelGGL(phase_chroma_kernel<uint8_t>, gridL, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(phase_chroma_kernel<uint16_t>, gridL, dim3(256), 0, s, a);
+    }
+    else
+    {
+        if (bpp == 1) hipLaunchKernelGGL(phase_luma_kernel<uint8_t>, gridL, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(phase_luma_kernel<uint16_t>, gridL, dim3(256), 0, s, a);
+    }
+    return check_hip(hipGetLastError(), "phase_planes launch");
+}
+
 extern "C" int x265hip_phase_planes(const x265hip_phase_planes_params* p, void* stream)
 {
     if (!p || !p->src || !p->dst) { set_error("phase_planes: NULL argument"); return X265HIP_EINVAL; }
@@ -206,22 +231,5 @@ extern "C" int x265hip_phase_planes(const x265hip_phase_planes_params* p, void* 
     if (p->rows / 4 > 65535 || p->rows < 16) { set_error("phase_planes: %d rows", p->rows); return X265HIP_EINVAL; }
     int rc = ensure_device();
     if (rc) return rc;
-    PhaseArgs a;
-    a.src = (const uint8_t*)p->src; a.dst = (uint8_t*)p->dst; a.strideB = (long)p->stride * bpp; a.rows = p->rows;
-    a.tilesW = (int)(p->stride / 4); a.depth = p->depth; a.planeBytes = (size_t)p->stride * p->rows * bpp;
-    // tile rows 1 .. rows / 4 - 3: a tile reads 3 rows above and 7 below itself (and a few bytes of the neighbouring rows at the row
-    // ends), so every access stays inside the plane without any guard memory around it
-    const dim3 gridL((a.tilesW + 255) / 256, p->rows / 4 - 3);               // a thread produces every phase of its tile
-    hipStream_t s = (hipStream_t)stream;
-    if (p->chroma)
-    {
-        if (bpp == 1) hipLaunchKernelGGL(phase_chroma_kernel<uint8_t>, gridL, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(phase_chroma_kernel<uint16_t>, gridL, dim3(256), 0, s, a);
-    }
-    else
-    {
-        if (bpp == 1) hipLaunchKernelGGL(phase_luma_kernel<uint8_t>, gridL, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(phase_luma_kernel<uint16_t>, gridL, dim3(256), 0, s, a);
-    }
-    return check_hip(hipGetLastError(), "phase_planes launch");
+    return phase_planes_launch(p->depth, p->chroma, p->src, p->dst, p->stride, p->rows, (size_t)p->stride * p->rows * bpp, (hipStream_t)stream);
 }
