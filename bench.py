@@ -47,6 +47,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+CFG_DEPTH = {"cfg1": 8, "cfg2": 8, "cfg3": 8, "cfg4": 10, "cfg5": 10}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -557,15 +558,23 @@ def main():
                 enc = {}
                 for key in args.encoder.split(","):
                     ft = args.encoder_frame_threads
+                    # round 3: the row-granular providers (x265hip_me_stream / x265hip_phase_stream, fed where the reference raises
+                    # m_reconRowFlag) serve the SAD lookups and the sub-sample comparisons under the reference's own frame threads
                     enc[key] = EB.run_config(key, args.encoder_tables.split(","), args.encoder_frames, ft, 120.0, log=sys.stderr,
-                                             seam={"range": 24, "slots": 8 if ft == 1 else 2, "min_pu": 8, "verify": False, "lookahead": True,
-                                                   "subpel": ft == 1, "subpel_slots": 6})
+                                             seam={"range": 24, "slots": 24 if CFG_DEPTH.get(key, 8) == 8 else 40, "min_pu": 16, "verify": False, "lookahead": True,
+                                                   "subpel": True, "subpel_slots": 12, "streamed": True, "min_level": 1, "pictures": 24})
                 out["encoder"] = enc
                 c3 = enc.get("cfg3", {})
                 if "c" in c3:
                     out["encoder_summary"] = {"workload": c3["config"], "frames": c3["c"]["frames"], "frame_threads": args.encoder_frame_threads,
                                               "reference_c_table_fps": c3["c"]["fps"], "cores": c3["pool_threads"],
                                               "seam_fps": c3.get("seam", {}).get("fps"), "seam_md5_equal": c3.get("seam", {}).get("md5_equal_to_c_table"),
+                                              **{k: c3.get("seam", {}).get("seam", {}).get(k) for k in ("motion_estimate_calls", "calls_with_lookup_context", "lookups_served",
+                                                                                                       "lookup_hit_rate")},
+                                              "subpel_compares_served": c3.get("seam", {}).get("seam", {}).get("subpel_seam", {}).get("subpel_compares_served"),
+                                              "frame_cost_estimates_served": c3.get("seam", {}).get("seam", {}).get("lookahead_seam", {}).get("frame_cost_estimates_served"),
+                                              "seams": "row-granular SAD lookups (x265hip_me_stream) + sub-sample comparisons (x265hip_phase_stream) + lookahead frame costs "
+                                                       "(x265hip_lowres_cost_host), all under the reference's own frame threads",
                                               "kind": "reference (x265 3.5 C primitives, no asm: nasm is not in the image)"}
             except BaseException as e:       # incl. SystemExit from a missing oracle/_ref
                 out["encoder"] = {"error": repr(e)}

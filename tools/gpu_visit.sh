@@ -2,7 +2,7 @@
 # ONE parametrised GPU-box visit (replaces the round-2 tools/gpu_r2_*.sh one-offs).  Run from the repo root on the GPU box:
 #   gpurun --timeout 900 -- 'bash tools/gpu_visit.sh <tag> <step> [<step> ...]'
 # Steps (each writes under gpurun_out/<tag>/ and prints a short tail):
-#   tests[:<pytest args>]   python -m pytest tests -m gpu -q [args]           -> pytest.log
+#   tests[:<pytest args>]   python -m pytest tests -m gpu -q [args]           -> pytest_N.log
 #   smoke                   __graft_entry__.smoke()                             -> smoke.log
 #   bench[:<args>]          python bench.py [args]                             -> bench[_N].json / .err
 #   stats[:<args>]          rocprofv3 --kernel-trace --stats of bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-encoder [args]
@@ -26,8 +26,8 @@ for step in "$@"; do
     echo "=== [$n] $step"
     case $kind in
     tests)
-        ( time timeout 1700 python -m pytest tests -m gpu -q --durations=6 $arg ) > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest.log"
-        grep -E "^(FAILED|ERROR)|passed|failed|^real" "$OUT/pytest.log" | tail -30 ;;
+        ( time timeout 1700 python -m pytest tests -m gpu -q --durations=6 $arg ) > "$OUT/pytest_$n.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest_$n.log"
+        grep -E "^(FAILED|ERROR)|passed|failed|^real" "$OUT/pytest_$n.log" | tail -30 ;;
     smoke)
         timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > "$OUT/smoke.log" 2>&1; tail -1 "$OUT/smoke.log" ;;
     bench)
