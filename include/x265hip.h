@@ -186,6 +186,28 @@ typedef struct x265hip_tu_tables
      * on) and the quantiser's deltaU (dct.cpp:679), both laid out like `levels`; NULL = not wanted */
     int16_t* dct_coeff_out;
     int32_t* delta_u_out;
+    /* The data-parallel half of Quant::rdoQuant (quant.cpp:609+; every preset from `slow` up runs rdoqLevel 2, param.cpp:489-553), produced
+     * next to the transform instead of per coefficient group on the host (round 3; all optional, NULL = not wanted):
+     *   rdoq_levels / rdoq_num_sig : primitives.nquant (dct.cpp:688-713: rounding 1/2, ABSOLUTE levels) - what rdoQuant starts from
+     *                                (quant.cpp:626); laid out like `levels` / `num_sig`
+     *   rdoq_cost_uncoded          : int64 per coefficient, laid out like `levels`: what the pre-pass slots cu[].nonPsyRdoQuant (psy_scale 0)
+     *                                or cu[].psyRdoQuant = psyRdoQuant_1p + psyRdoQuant_2p (dct.cpp:986-1069) write into costUncoded[] for
+     *                                every 4x4 coefficient group of the block
+     *   rdoq_cg_cost               : int64 [blocks][n * n / 16][2]: what a slot call adds to *totalUncodedCost and *totalRdCost for coefficient
+     *                                group g = (blkPos / (4 n)) * (n / 4) + (blkPos % n) / 4 (raster order of the groups): [0] = sum of
+     *                                coef^2 << scaleBits (nonPsyRdoQuant, psyRdoQuant_1p), [1] = sum of the finished costUncoded (psyRdoQuant,
+     *                                psyRdoQuant_2p; = [0] without psy).  A host without AVX-512 calls _1p AND _2p on the same totals
+     *                                (quant.cpp:716-717, 803-808), i.e. adds [0] + [1]
+     *   psy_scale                  : Quant::m_psyRdoqScale * lambda (quant.cpp:634); != 0 selects the psy pre-pass, which needs the SOURCE
+     *                                block's transform (m_fencDctCoeff, quant.cpp:436-441: copy_ps + dct of fenc - always the DCT)
+     *   fenc_dct_out               : that transform, laid out like `levels`
+     * The CABAC-coupled rest of rdoQuant (bit costs from the entropy coder's context state, the serial level decisions) stays host work. */
+    int64_t* rdoq_cost_uncoded;
+    int64_t* rdoq_cg_cost;
+    int16_t* rdoq_levels;
+    uint32_t* rdoq_num_sig;
+    int16_t* fenc_dct_out;
+    int64_t psy_scale;
 } x265hip_tu_tables;
 typedef struct x265hip_recon_params
 {

@@ -53,11 +53,18 @@ struct TuTables
 {
     const int32_t* qc; const int32_t* dqc; const uint16_t* nrOff; uint32_t* nrSum;
     int16_t* dctOut; int32_t* duOut;      // capture for a host-side RDOQ pass: transform coefficients / deltaU, laid out like the levels
+    // the data-parallel half of Quant::rdoQuant (round 3): nquant's levels + count (quant.cpp:626, dct.cpp:688-713) and what the pre-pass
+    // slots nonPsyRdoQuant / psyRdoQuant (= _1p + _2p) write per coefficient and add per 4x4 coefficient group (dct.cpp:986-1069)
+    long long* rdoqCost; long long* rdoqCg; int16_t* rdoqLevels; uint32_t* rdoqNumSig; int16_t* fencDct; long long psyScale;
     __device__ __forceinline__ TuTables at(size_t elemOff) const
     {
         TuTables t = *this;
         if (t.dctOut) t.dctOut += elemOff;
         if (t.duOut) t.duOut += elemOff;
+        if (t.rdoqCost) t.rdoqCost += elemOff;
+        if (t.rdoqCg) t.rdoqCg += elemOff >> 3;
+        if (t.rdoqLevels) t.rdoqLevels += elemOff;
+        if (t.fencDct) t.fencDct += elemOff;
         return t;
     }
 };
@@ -175,7 +182,8 @@ template <int N> __device__ __forceinline__ int tu_sign_hide_group(int16_t* lev,
 template <typename Px, int N, bool DST, bool TAB = false>
 __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int16_t* pred, const int16_t* fe, int16_t* A, int16_t* B, unsigned long long* red, int& sNumSig,
                                          int depth, int qp, int flags, int16_t* lvOut, uint32_t* numSigOut, unsigned long long* distOut,
-                                         Px* rec, long cst, int scanType = TU_SCAN_DIAG, const TuTables tab = TuTables{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr })
+                                         Px* rec, long cst, int scanType = TU_SCAN_DIAG, const TuTables tab = TuTables{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0 },
+                                         const size_t blockIndex = 0)
 {
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -210,6 +218,40 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
     int nz = 0;
     constexpr bool USE_MFMA = N >= 16 && !DST;           // the 16 / 32 point transforms are dense matrix products: matrix cores
     const int lane = tid & 63, wave = tid >> 6;
+    // ---- RDOQ pre-passes (TAB launches that ask for them): Quant::rdoQuant (quant.cpp:609+) starts from primitives.nquant - the
+    // quantiser with rounding 1/2, absolute levels (dct.cpp:688-713) - and needs, per coefficient, the cost of NOT coding it:
+    // nonPsyRdoQuant (dct.cpp:986-1005) costUncoded = coef^2 << scaleBits; psyRdoQuant = _1p + _2p (:1006-1069) additionally
+    // - ((psyScale * (fencDct - coef)) >> max(0, 2 * transformShift + 1)) with the SOURCE block's transform (m_fencDctCoeff, quant.cpp:436-441).
+    // Every slot call adds 16 values of one 4x4 group to totalUncodedCost / totalRdCost: rdoqCg holds, per group (raster order), [0] the sum
+    // of coef^2 << scaleBits (what nonPsyRdoQuant and psyRdoQuant_1p add) and [1] the sum of the finished costUncoded (what psyRdoQuant
+    // and psyRdoQuant_2p add) - hosts without AVX-512 call _1p AND _2p on the same totals (quant.cpp:716-717), i.e. add [0] + [1].
+    const bool rdoq = TAB && tab.rdoqCost != nullptr;
+    const bool rdoqPsy = rdoq && tab.psyScale != 0;
+    const int rdoqScaleBits = 15 - 2 * transformShift, rdoqPsyShift = 2 * transformShift + 1 > 0 ? 2 * transformShift + 1 : 0;
+    const int nqAdd = 1 << (qbits - 1);
+    __shared__ unsigned long long sCg[TAB ? NN / 8 : 1];
+    __shared__ int sNq;
+    if (rdoq)
+    {
+        for (int i = tid; i < NN / 8; i += nth) sCg[i] = 0;
+        if (tid == 0) sNq = 0;
+    }
+    int nq = 0;
+    // c = the coefficient the quantiser sees (after the denoiser), fd = the source block's coefficient at the same position
+    auto rdoq_emit = [&](const int e, const int c, const int qs, const int fd)
+    {
+        long long cost = ((long long)c * c) << rdoqScaleBits;
+        const int g = ((e >> LOG2N) >> 2) * (N >> 2) + ((e & (N - 1)) >> 2);
+        atomicAdd(&sCg[2 * g], (unsigned long long)cost);
+        if (rdoqPsy) cost -= (tab.psyScale * (long long)(fd - c)) >> rdoqPsyShift;
+        tab.rdoqCost[e] = cost;
+        atomicAdd(&sCg[2 * g + 1], (unsigned long long)cost);
+        int level = (abs(c) * qs + nqAdd) >> qbits;
+        nq += level != 0;
+        if (c < 0) level = -level;
+        level = abs(level < -32768 ? -32768 : (level > 32767 ? 32767 : level));
+        if (tab.rdoqLevels) tab.rdoqLevels[e] = (int16_t)level;
+    };
     // 16 consecutive int16 of an LDS row (forward operands) / 16 samples down a column (inverse operands)
     auto lds_row16 = [&](const int16_t* base, uint32_t (&d)[8])
     {
@@ -231,6 +273,27 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
             const int kb = MF::kbase(lane), rn = MF::mn(lane);
             uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
             int p[MF::NACC];
+            int fdReg[MF::NACC];
+            if (rdoqPsy)
+            {   // the source block's transform (quant.cpp:436-441: copy_ps + dct of fenc), same two passes; B is free until the residual's pass 1
+                if (fw.kvalid) lds_row16(fe + rn * N + kb, d);
+                fw.product(d, p);
+#pragma unroll
+                for (int r = 0; r < MF::NACC; r++) B[MF::row(lane, r) * N + MF::col(lane)] = (int16_t)((p[r] + (1 << (sh1 - 1))) >> sh1);
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                if (fw.kvalid) lds_row16(B + rn * N + kb, d);
+                fw.product(d, p);
+#pragma unroll
+                for (int r = 0; r < MF::NACC; r++)
+                {
+                    fdReg[r] = (int16_t)((p[r] + (1 << (sh2 - 1))) >> sh2);
+                    if (tab.fencDct) tab.fencDct[MF::row(lane, r) * N + MF::col(lane)] = (int16_t)fdReg[r];
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 8; k++) d[k] = 0;
+            }
             // pass 1: P[k][j] = sum_i M[k][i] * resid[j][i]
             if (fw.kvalid) lds_row16(A + rn * N + kb, d);
             fw.product(d, p);
@@ -254,6 +317,7 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
                 if (signHide) B[e] = (int16_t)((((t - (level << qbits)) >> qbits8) << 1) | (c < 0));
                 if (TAB && tab.dctOut) tab.dctOut[e] = (int16_t)c;
                 if (TAB && tab.duOut) tab.duOut[e] = (t - (level << qbits)) >> qbits8;
+                if (rdoq) rdoq_emit(e, c, qs, rdoqPsy ? fdReg[r] : 0);
                 nz += level != 0;
                 if (c < 0) level = -level;
                 level = tu_sat16(level);
@@ -265,6 +329,30 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
     else
     {
     int auxReg = 0;
+    int fdOne = 0;
+    if (rdoqPsy)
+    {   // the source block's transform - always the DCT, also where the residual takes the DST (quant.cpp:436-441) - NN <= 64 <= blockDim:
+        // a thread owns at most one coefficient
+        for (int e = tid; e < NN; e += nth)
+        {
+            const int k = e >> LOG2N, j = e & (N - 1);
+            int acc = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) acc += tu_mat<N, false>(k, i) * (int)fe[j * N + i];
+            B[k * N + j] = (int16_t)((acc + (1 << (sh1 - 1))) >> sh1);
+        }
+        __syncthreads();
+        for (int e = tid; e < NN; e += nth)
+        {
+            const int k = e >> LOG2N, j = e & (N - 1);
+            int acc = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) acc += tu_mat<N, false>(k, i) * (int)B[j * N + i];
+            fdOne = (int16_t)((acc + (1 << (sh2 - 1))) >> sh2);
+            if (tab.fencDct) tab.fencDct[e] = (int16_t)fdOne;
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < NN; e += nth)
     {
         const int k = e >> LOG2N, j = e & (N - 1);
@@ -288,6 +376,7 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
         auxReg = (((t - (level << qbits)) >> qbits8) << 1) | (c < 0);
         if (TAB && tab.dctOut) tab.dctOut[e] = (int16_t)c;
         if (TAB && tab.duOut) tab.duOut[e] = (t - (level << qbits)) >> qbits8;
+        if (rdoq) rdoq_emit(e, c, qs, fdOne);
         nz += level != 0;
         if (c < 0) level = -level;
         level = tu_sat16(level);
@@ -302,7 +391,17 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
     }
     nz = group_sum<64>(nz);
     if ((tid & 63) == 0 && nz) atomicAdd(&sNumSig, nz);
+    if (rdoq)
+    {
+        nq = group_sum<64>(nq);
+        if ((tid & 63) == 0 && nq) atomicAdd(&sNq, nq);
+    }
     __syncthreads();
+    if (rdoq)
+    {
+        if (tab.rdoqCg) for (int i = tid; i < NN / 8; i += nth) tab.rdoqCg[i] = (long long)sCg[i];
+        if (tid == 0 && tab.rdoqNumSig) tab.rdoqNumSig[blockIndex] = (uint32_t)sNq;
+    }
     if (signHide && sNumSig >= 2)
     {   // Quant::signBitHidingHDQ: one lane per 4x4 coefficient group, the groups are independent of each other
         if (tid < 64)
@@ -532,7 +631,7 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs2
     tu_chain<Px, N, false, TAB>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
                            a.levels + ((size_t)ctu * npu + z) * NN, &a.numSig[(size_t)ctu * npu + z], &a.dist[(size_t)ctu * npu + z],
                            reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP, TU_SCAN_DIAG,
-                           TAB ? a.tab.at(((size_t)ctu * npu + z) * NN) : a.tab);
+                           TAB ? a.tab.at(((size_t)ctu * npu + z) * NN) : a.tab, (size_t)ctu * npu + z);
     __syncthreads();
     };
     if constexpr (N >= 16)
@@ -676,7 +775,7 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBi
         tu_chain<Px, N, false, TAB>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
                                a.levels + ((size_t)ctu * npu + z) * NN, &a.numSig[(size_t)ctu * npu + z], &a.dist[(size_t)ctu * npu + z],
                                reinterpret_cast<Px*>(a.recon + (long)py * a.reconStrideB) + px, a.reconStrideB / BPP, TU_SCAN_DIAG,
-                               TAB ? a.tab.at(((size_t)ctu * npu + z) * NN) : a.tab);
+                               TAB ? a.tab.at(((size_t)ctu * npu + z) * NN) : a.tab, (size_t)ctu * npu + z);
         __syncthreads();
     };
     if constexpr (N >= 16)
@@ -748,7 +847,7 @@ __global__ void __launch_bounds__(N <= 8 ? 256 : 64) intra_recon_kernel(IntraTuA
                              reinterpret_cast<Px*>(a.recon) + jb.off[3], a.reconStrideB / BPP,
                              // the scan sign hiding walks: mode-dependent for 4x4 TUs and 8x8 luma TUs (cudata.cpp:2083-2084)
                              (N == 4 || (!a.chroma && N == 8)) ? (mode >= 22 && mode <= 30 ? TU_SCAN_HOR : (mode >= 6 && mode <= 14 ? TU_SCAN_VER : TU_SCAN_DIAG))
-                                                               : TU_SCAN_DIAG, TAB ? a.tab.at((size_t)job * NN) : a.tab);
+                                                               : TU_SCAN_DIAG, TAB ? a.tab.at((size_t)job * NN) : a.tab, (size_t)job);
         __syncthreads();
     };
     // 4 / 8: one candidate per workgroup; 16 / 32: persistent, the MFMA operands above are reused
@@ -763,8 +862,13 @@ using namespace x265hip;
 
 static TuTables tu_tables_of(const x265hip_tu_tables* t)
 {
-    TuTables r = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    if (t) { r.qc = t->quant_coeff; r.dqc = t->dequant_coeff; r.nrOff = t->nr_offset; r.nrSum = t->nr_residual_sum; r.dctOut = t->dct_coeff_out; r.duOut = t->delta_u_out; }
+    TuTables r = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0 };
+    if (t)
+    {
+        r.qc = t->quant_coeff; r.dqc = t->dequant_coeff; r.nrOff = t->nr_offset; r.nrSum = t->nr_residual_sum; r.dctOut = t->dct_coeff_out; r.duOut = t->delta_u_out;
+        r.rdoqCost = (long long*)t->rdoq_cost_uncoded; r.rdoqCg = (long long*)t->rdoq_cg_cost; r.rdoqLevels = t->rdoq_levels; r.rdoqNumSig = t->rdoq_num_sig;
+        r.fencDct = t->fenc_dct_out; r.psyScale = t->psy_scale;
+    }
     return r;
 }
 #define TABLES_OF(p) ((p)->tables)

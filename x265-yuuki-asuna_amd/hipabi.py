@@ -763,14 +763,21 @@ def _planes(ps, n):
 class TuTablesRec(ctypes.Structure):
     """x265hip_tu_tables (include/x265hip.h): device pointers, any may be NULL."""
     _fields_ = [("quant_coeff", ctypes.c_void_p), ("dequant_coeff", ctypes.c_void_p), ("nr_offset", ctypes.c_void_p), ("nr_residual_sum", ctypes.c_void_p),
-                ("dct_coeff_out", ctypes.c_void_p), ("delta_u_out", ctypes.c_void_p)]
+                ("dct_coeff_out", ctypes.c_void_p), ("delta_u_out", ctypes.c_void_p),
+                ("rdoq_cost_uncoded", ctypes.c_void_p), ("rdoq_cg_cost", ctypes.c_void_p), ("rdoq_levels", ctypes.c_void_p), ("rdoq_num_sig", ctypes.c_void_p),
+                ("fenc_dct_out", ctypes.c_void_p), ("psy_scale", ctypes.c_int64)]
 
 
-def tu_tables(quant_coeff=None, dequant_coeff=None, nr_offset=None, nr_residual_sum=None, dct_coeff_out=None, delta_u_out=None):
+def tu_tables(quant_coeff=None, dequant_coeff=None, nr_offset=None, nr_residual_sum=None, dct_coeff_out=None, delta_u_out=None,
+              rdoq_cost_uncoded=None, rdoq_cg_cost=None, rdoq_levels=None, rdoq_num_sig=None, fenc_dct_out=None, psy_scale=0):
     """Device tensors -> the table record a TU stage takes through its `tables` field (keep the returned object alive during the launch).
-    dct_coeff_out (int16) / delta_u_out (int32), shaped like the stage's levels: capture for a host-side RDOQ pass."""
-    r = TuTablesRec(_p(quant_coeff), _p(dequant_coeff), _p(nr_offset), _p(nr_residual_sum), _p(dct_coeff_out), _p(delta_u_out))
-    r._keep = (quant_coeff, dequant_coeff, nr_offset, nr_residual_sum, dct_coeff_out, delta_u_out)
+    dct_coeff_out (int16) / delta_u_out (int32), shaped like the stage's levels: capture for a host-side RDOQ pass.
+    rdoq_*: the data-parallel half of Quant::rdoQuant - nquant's levels / count, costUncoded per coefficient (int64) and per 4x4 group;
+    psy_scale != 0 = the psy pre-pass (fenc_dct_out: the source block's transform)."""
+    r = TuTablesRec(_p(quant_coeff), _p(dequant_coeff), _p(nr_offset), _p(nr_residual_sum), _p(dct_coeff_out), _p(delta_u_out),
+                    _p(rdoq_cost_uncoded), _p(rdoq_cg_cost), _p(rdoq_levels), _p(rdoq_num_sig), _p(fenc_dct_out), int(psy_scale))
+    r._keep = (quant_coeff, dequant_coeff, nr_offset, nr_residual_sum, dct_coeff_out, delta_u_out, rdoq_cost_uncoded, rdoq_cg_cost, rdoq_levels, rdoq_num_sig,
+               fenc_dct_out)
     return r
 
 
