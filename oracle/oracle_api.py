@@ -479,6 +479,31 @@ def sao_decide(depth, count, offset_org, avx2=False):
     return init, params
 
 
+def sao_rdo(depth, counts, offset_orgs, ctus_w, ctus_h, lambda_ctu, ctx_merge, ctx_type, entropy_bits, sao_flag=(1, 1), avx2=False):
+    """CPU restatement of SAO::rdoSaoUnitCu over a picture (oracle/x265_oracle_pipeline6.c; sao.cpp:1225-1760): counts / offset_orgs =
+    lists (1 or 3 planes) of int32 [numCtu, 5, 32]; lambda_ctu int64 [numCtu, 2]; ctx_* = the slice's initial context states;
+    entropy_bits = the host's 128 per-state bit costs.  Returns (params: list of int32 [numCtu, 7] = typeIdx, bandPos, offset[4],
+    mergeMode (0 none / 1 left / 2 up), numNoSao int32 [2])."""
+    fn = getattr(lib(avx2), f"x265oracle_sao_rdo_d{depth}")
+    planes = len(counts)
+    nctu = ctus_w * ctus_h
+    cs = [np.ascontiguousarray(c, dtype=np.int32).reshape(nctu, 160) for c in counts]
+    os_ = [np.ascontiguousarray(o, dtype=np.int32).reshape(nctu, 160) for o in offset_orgs]
+    lam = np.ascontiguousarray(lambda_ctu, dtype=np.int64).reshape(nctu, 2)
+    bits = np.ascontiguousarray(entropy_bits, dtype=np.uint32)
+    assert bits.size == 128
+    params = [np.zeros((nctu, 7), np.int32) for _ in range(planes)]
+    nos = np.zeros(2, np.int32)
+    P3 = ctypes.c_void_p * planes
+    flag = (ctypes.c_int * 2)(*[int(f) for f in sao_flag])
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rc = fn(P3(*[c.ctypes.data for c in cs]), P3(*[o.ctypes.data for o in os_]), planes, ctus_w, ctus_h, lam.ctypes.data, int(ctx_merge), int(ctx_type),
+            bits.ctypes.data, flag, P3(*[p.ctypes.data for p in params]), nos.ctypes.data)
+    assert rc == 0
+    return params, nos
+
+
 def sao_apply(depth, src, stride, org, width, height, params, nthreads=0, avx2=False, ctu=(64, 64)):
     """CPU restatement of SAO::generateLumaOffsets / applyPixelOffsets (sao.cpp:572-630, 274-570) for every CTU; params int32
     [numCtu, 7] = typeIdx, bandPos, offset[4], mergeLeft.  Returns the offset picture (a copy of src outside the picture area)."""

@@ -1481,3 +1481,81 @@ def test_intra_stage_predictions_equal_the_real_predict_class(depth, n, chroma):
         assert lib.x265ref_pred_intra(mode, log2n, np.ascontiguousarray(unf).ctypes.data, np.ascontiguousarray(fil).ctypes.data, int(chroma), want.ctypes.data) == 0
         got = pred[t * n:(t + 1) * n]
         assert np.array_equal(got, want), f"mode {mode} (neighbour set {s_}): {np.count_nonzero(got != want)} predicted samples differ"
+
+
+def sao_rdo_case(depth, width, height, seed, noise):
+    """Source / deblocked-like Y, Cb, Cr of a 4:2:0 picture in the PicYuv layout; `noise` steers how much SAO can gain."""
+    rng = np.random.default_rng([29, depth, width, seed])
+    clip = F.synth_clip(width, height, 1, depth=depth, seed=seed)[0]
+    planes_src, planes_rec = [], []
+    for c in range(3):
+        y = clip[c]
+        sm = (y.astype(np.int32) * 2 + np.roll(y, 1, axis=1) + np.roll(y, 1, axis=0) + 2) >> 2
+        r = np.clip(sm + (rng.integers(-noise, noise + 1, size=y.shape) << (depth - 8)), 0, (1 << depth) - 1).astype(y.dtype)
+        h, w = y.shape
+        r[: h // 4, : w // 4] = y[: h // 4, : w // 4]                 # zero differences: SAO off is the best choice there
+        r[h // 2:, w // 2:] = np.clip(y[h // 2:, w // 2:].astype(np.int32) + (3 << (depth - 8)), 0, (1 << depth) - 1)      # a constant shift: band offsets
+        planes_src.append(np.ascontiguousarray(y)); planes_rec.append(np.ascontiguousarray(r))
+    return planes_src, planes_rec
+
+
+@pytest.mark.parametrize("depth,width,height,slice_type,qp,csp400", [(8, 256, 192, 1, 27, 0), (8, 200, 150, 2, 22, 0), (8, 320, 128, 0, 37, 0), (10, 192, 136, 1, 30, 0),
+                                                                      (12, 192, 136, 2, 14, 0), (8, 256, 128, 1, 32, 1), (10, 128, 128, 0, 24, 1)])
+def test_sao_rdo_restatement_equals_the_real_class(depth, width, height, slice_type, qp, csp400):
+    """oracle/x265_oracle_pipeline6.c against the real SAO::rdoSaoUnitCu (oracle/ref_sao.cpp::x265ref_sao_rdo) driven row by row like
+    FrameFilter does: type, band position, offsets and merge mode of every CTU and plane, and the count of CTUs left without SAO; B / P /
+    I slices (the context initialisation differs), per-CTU QPs, 4:2:0 and 4:0:0."""
+    import oracle_api as O
+    lib = _ref(depth)
+    if not hasattr(lib, "x265ref_sao_rdo"):
+        pytest.skip("oracle/_ref predates x265ref_sao_rdo")
+    rng = np.random.default_rng([31, depth, width, qp])
+    src, rec = sao_rdo_case(depth, width, height, 11, 2 + qp // 12)
+    fenc, stride, org, w64, h64 = F.pad_plane(src[0])
+    recp = F.pad_plane(rec[0])[0]
+    ctus_w, ctus_h = w64 // 64, h64 // 64
+    nctu = ctus_w * ctus_h
+    planes = 1 if csp400 else 3
+    bufs_src, bufs_rec = [fenc], [recp]
+    cgeo = None
+    if not csp400:
+        for c in (1, 2):
+            b, st, og = F.pad_chroma(src[c], w64, h64)
+            bufs_src.append(b); bufs_rec.append(F.pad_chroma(rec[c], w64, h64)[0])
+            cgeo = (st, og)
+    ctu_qp = np.clip(qp + rng.integers(-3, 4, size=nctu), 0, 51).astype(np.int32)
+    rparams = [np.zeros((nctu, 7), np.int32) for _ in range(3)]
+    info = np.zeros(8, np.int64)
+    P3 = ctypes.c_void_p * 3
+    lib.x265ref_sao_rdo.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    pad3 = lambda xs: P3(*([x.ctypes.data for x in xs] + [None] * (3 - len(xs))))
+    assert lib.x265ref_sao_rdo(pad3(bufs_src), pad3(bufs_rec), width, height, csp400, slice_type, qp, ctu_qp.ctypes.data, 0, P3(*[p.ctypes.data for p in rparams]),
+                               info.ctypes.data) == 0
+    # the host's tables: per-state bit costs and the lambdas of every CTU's QP
+    lib.x265ref_entropy_bits_table.restype = ctypes.POINTER(ctypes.c_uint32)
+    bits = np.ctypeslib.as_array(lib.x265ref_entropy_bits_table(), shape=(128,)).copy()
+    lam2 = (ctypes.c_double * 70).in_dll(lib, "_ZN4x26516x265_lambda2_tabE")
+    cscale = (ctypes.c_uint8 * 70).in_dll(lib, "_ZN4x26513g_chromaScaleE")
+    lam = np.zeros((nctu, 2), np.int64)
+    for a in range(nctu):
+        q = int(ctu_qp[a])
+        qc = q if csp400 else int(cscale[min(max(q, 0), 69)])
+        lam[a] = (int(np.floor(256.0 * lam2[q])), int(np.floor(256.0 * lam2[qc])))
+    assert (lam[0] == info[0:2]).all()
+    counts, orgs = [], []
+    c0, o0 = O.sao_stats(depth, fenc, recp, stride, org, width, height)
+    counts.append(c0); orgs.append(o0)
+    if not csp400:
+        for c in (1, 2):
+            cc, oo = O.sao_stats(depth, bufs_src[c], bufs_rec[c], cgeo[0], cgeo[1], width // 2, height // 2, ctu=(32, 32), plane_offset=2)
+            counts.append(cc); orgs.append(oo)
+    params, nos = O.sao_rdo(depth, counts, orgs, ctus_w, ctus_h, lam, int(info[2]), int(info[3]), bits, sao_flag=(1, 0 if csp400 else 1))
+    for pl in range(planes):
+        bad = np.argwhere((params[pl] != rparams[pl]).any(axis=1))[:5].reshape(-1).tolist()
+        assert np.array_equal(params[pl], rparams[pl]), f"plane {pl}: CTUs {bad}: oracle {params[pl][bad].tolist()} reference {rparams[pl][bad].tolist()}"
+    assert int(nos[0]) == int(info[4]) and (csp400 or int(nos[1]) == int(info[5]))
+    # the case set exercises every outcome
+    t = rparams[0][:, 0]
+    assert (t >= 0).any(), "no CTU took SAO"
+    if nctu >= 6:
+        assert (rparams[0][:, 6] > 0).any(), "no CTU took a merge candidate"
