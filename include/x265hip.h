@@ -684,11 +684,48 @@ typedef struct x265hip_sao_apply_params
 int x265hip_sao_apply(const x265hip_sao_apply_params* p, void* stream);
 /* x265hip_sao_decide: the parameters between the two passes for a pipeline that never leaves the device - for every CTU
  * SAO::saoStatsInitialOffset (sao.cpp:1378-1433, exact) and a DISTORTION-ONLY choice of the type (smallest sum of estSaoDist,
- * sao.cpp:56-59, over EO_0..EO_3 and the best four-band window of BO; off when nothing gains).  A documented stand-in for the
- * entropy-coder-driven rdoSaoUnitCu (sao.cpp:1225-1605: rate terms, offset iteration, merge candidates), which stays host work.
+ * sao.cpp:56-59, over EO_0..EO_3 and the best four-band window of BO; off when nothing gains).  A cheap stand-in kept for A/B runs;
+ * the reference's own decision is x265hip_sao_rdo below.
  *   count / offset_org : DEVICE int32 [nctu][5][32] from x265hip_sao_stats;  init_offset : optional DEVICE int32 [nctu][5][32]
  *   (SAO::m_offset);  ctu_params : DEVICE int32 [nctu][7] in x265hip_sao_apply's format. */
 int x265hip_sao_decide(int depth, const int32_t* count, const int32_t* offset_org, int nctu, int32_t* init_offset, int32_t* ctu_params, void* stream);
+/* x265hip_sao_rdo (round 3): the REAL rate-distortion decision of the parameters on the device - SAO::rdoSaoUnitCu (sao.cpp:1225-1376) with
+ * saoStatsInitialOffset, estIterOffset, saoLumaComponentParamDist / saoChromaComponentParamDist (:1378-1760) and the entropy coder's bit
+ * counts for the SAO syntax (entropy.cpp:1221-1292, :2198-2214), for bLimitSAO = 0 / bSaoNonDeblocked = 0 (the x265 defaults).  Every CTU
+ * row carries its own context state from the slice's initial state (sao.cpp:245-247), the merge-up candidate reads the row above: two
+ * launches, a neighbour-independent one (a workgroup per CTU) and the serial one (a lane per CTU row, rows staggered by a column).
+ *   count / offset_org : DEVICE int32 [nctu][5][32] per plane from x265hip_sao_stats (planes = 1: luma only, 4:0:0; 3: Y, Cb, Cr of 4:2:0)
+ *   lambda             : floor(256 * x265_lambda2_tab[qp]) for luma and for chroma at the Cb QP (sao.cpp:1229-1238), the HOST's tables;
+ *   lambda_ctu         : optional DEVICE int64 [nctu][2] when cu->m_qp[0] varies over the picture (replaces lambda[])
+ *   ctx_merge/ctx_type : the slice's initial context states of sao_merge_left/up_flag and sao_type_idx (sbacInit of the slice QP,
+ *                        entropy.cpp:1297-1308, 196-208);  frac_bits : Entropy::m_fracBits & 32767 of that state (0 after resetEntropy)
+ *   entropy_bits       : HOST pointer to the host's 128 per-state bit costs (g_entropyBits, entropy.cpp:2611) - host-built tables are
+ *                        handed in, never recomputed here
+ *   sao_flag           : saoParam->bSaoFlag[luma, chroma] (sao.cpp:257-270)
+ *   scratch            : DEVICE, x265hip_sao_rdo_scratch_bytes(ctus_w, ctus_h)
+ *   ctu_params         : DEVICE int32 [nctu][7] per plane = { typeIdx (-1 off, 0..3 EO, 4 BO), bandPos, offset[4], mergeMode (0 none, 1 left,
+ *                        2 up: merged CTUs carry the source's values) } - x265hip_sao_apply's format;  num_no_sao : optional DEVICE int32 [2] */
+typedef struct x265hip_sao_rdo_params
+{
+    int depth;
+    int planes;
+    int ctus_w, ctus_h;
+    const int32_t* count[3];
+    const int32_t* offset_org[3];
+    int64_t lambda[2];
+    const int64_t* lambda_ctu;
+    int ctx_merge, ctx_type;
+    uint32_t frac_bits;
+    const uint32_t* entropy_bits;
+    int sao_flag[2];
+    void* scratch;
+    int32_t* ctu_params[3];
+    int32_t* num_no_sao;
+} x265hip_sao_rdo_params;
+/* the application of 1..3 planes as one launch (the step after x265hip_sao_rdo) */
+int x265hip_sao_apply_planes(int nplanes, const x265hip_sao_apply_params* apply, void* stream);
+size_t x265hip_sao_rdo_scratch_bytes(int ctus_w, int ctus_h);
+int x265hip_sao_rdo(const x265hip_sao_rdo_params* p, void* stream);
 /* 1..3 planes of one picture (Y, Cb, Cr) through statistics -> parameters -> application with ONE launch per step (the steps are
  * latency-bound rounds of workgroups: three planes in one launch cost one latency, not three).  stats[i] / apply[i] as the single-plane
  * entries take them; apply[i].ctu_params (DEVICE, written) receives plane i's parameters; apply = NULL: statistics only. */

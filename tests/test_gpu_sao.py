@@ -181,3 +181,55 @@ def test_sao_planes_fused_equals_the_single_plane_entries(depth, width, height):
     torch.cuda.synchronize()
     for i, (a, _, b, _) in enumerate(bufs):
         assert torch.equal(a.count, b.count), f"plane {i}: statistics-only call differs"
+
+
+# ---- round 3: the real rate-distortion decision of the parameters on the device (x265hip_sao_rdo) ----------------------------------
+@pytest.mark.parametrize("depth,width,height,slice_type,qp,planes", [(8, 256, 192, 1, 27, 3), (8, 200, 150, 2, 22, 3), (8, 1920, 1080, 1, 30, 3), (10, 192, 136, 0, 30, 3),
+                                                                     (12, 192, 136, 2, 14, 3), (8, 256, 128, 1, 32, 1), (8, 128, 4352, 1, 27, 3),
+                                                                     (8, 3840, 2160, 1, 27, 3)])
+def test_sao_rdo_matches_oracle(depth, width, height, slice_type, qp, planes):
+    """x265hip_sao_rdo on the device's own statistics == the oracle's restatement of SAO::rdoSaoUnitCu (pinned against the real class,
+    tests/test_oracle_classes_vs_reference.py) on the same statistics: type, band position, offsets and merge mode of every CTU and plane,
+    and the count of CTUs left without SAO.  B / P / I context initialisation, 4:2:0 and luma-only, per-CTU lambdas, a 68-row picture
+    (two wavefronts of rows, the 8K case) and a whole 4K picture."""
+    import torch
+    HT = importlib.import_module("x265-yuuki-asuna_amd.host_tables")
+    P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+    S = importlib.import_module("x265-yuuki-asuna_amd.stages")
+    A = H
+    from test_oracle_classes_vs_reference import sao_rdo_case
+    O = _oracle()
+    dev = torch.device("cuda:0")
+    tabs = HT.load()
+    rng = np.random.default_rng([37, depth, width, qp])
+    src, rec = sao_rdo_case(depth, width, height, 11, 2 + qp // 12)
+    cur = P.DevicePicture(src[0], dev, src[1], src[2])
+    dbl = P.DevicePicture(rec[0], dev, rec[1], rec[2])
+    ctus_w, ctus_h = cur.w64 // 64, cur.h64 // 64
+    nctu = ctus_w * ctus_h
+    stages = [S.Sao(width, height, depth, dev)] + ([S.Sao(width // 2, height // 2, depth, dev, ctu=(32, 32), plane_offset=2) for _ in range(2)] if planes == 3 else [])
+    stages[0].stats(cur, dbl.t, cur.stride, cur.org)
+    for i in range(planes - 1):
+        stages[1 + i].stats(None, dbl.c[i], cur.stride_c, cur.org_c, src_plane=cur.c[i])
+    per_ctu = width <= 256                              # per-CTU QPs on the small cases, one QP on the large ones
+    ctu_qp = np.clip(qp + rng.integers(-3, 4, size=nctu), 0, 51) if per_ctu else np.full(nctu, qp)
+    lam = np.array([HT.sao_lambdas(tabs, int(q), csp400=planes == 1) for q in ctu_qp], dtype=np.int64)
+    ctx_m, ctx_t = HT.sao_contexts(slice_type, qp)
+    scratch = torch.zeros(A.sao_rdo_scratch_bytes(ctus_w, ctus_h), dtype=torch.uint8, device=dev)
+    nos = torch.full((2,), -1, dtype=torch.int32, device=dev)
+    for st in stages:
+        st.params.fill_(0x5a5a5a5a)
+    A.sao_rdo(depth, [st.count for st in stages], [st.offset_org for st in stages], ctus_w, ctus_h, lam[0], ctx_m, ctx_t, tabs["entropy_bits"],
+              [st.params for st in stages], scratch, lambda_ctu=torch.from_numpy(lam).to(dev) if per_ctu else None, sao_flag=(1, 1 if planes == 3 else 0), num_no_sao=nos)
+    torch.cuda.synchronize()
+    eparams, enos = O.sao_rdo(depth, [st.count.cpu().numpy() for st in stages], [st.offset_org.cpu().numpy() for st in stages], ctus_w, ctus_h, lam, ctx_m, ctx_t,
+                              tabs["entropy_bits"], sao_flag=(1, 1 if planes == 3 else 0))
+    for pl in range(planes):
+        got = stages[pl].params.cpu().numpy().reshape(nctu, 7)
+        bad = np.argwhere((got != eparams[pl]).any(axis=1))[:5].reshape(-1).tolist()
+        assert np.array_equal(got, eparams[pl]), f"plane {pl}: CTUs {bad}: device {got[bad].tolist()} oracle {eparams[pl][bad].tolist()}"
+    gn = nos.cpu().numpy()
+    assert int(gn[0]) == int(enos[0]) and (planes == 1 or int(gn[1]) == int(enos[1]))
+    assert (eparams[0][:, 0] >= 0).any()
+    if nctu >= 12:
+        assert (eparams[0][:, 6] > 0).any()

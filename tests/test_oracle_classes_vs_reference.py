@@ -1500,7 +1500,8 @@ def sao_rdo_case(depth, width, height, seed, noise):
 
 
 @pytest.mark.parametrize("depth,width,height,slice_type,qp,csp400", [(8, 256, 192, 1, 27, 0), (8, 200, 150, 2, 22, 0), (8, 320, 128, 0, 37, 0), (10, 192, 136, 1, 30, 0),
-                                                                      (12, 192, 136, 2, 14, 0), (8, 256, 128, 1, 32, 1), (10, 128, 128, 0, 24, 1)])
+                                                                      (12, 192, 136, 2, 14, 0), (8, 256, 128, 1, 32, 1), (10, 128, 128, 0, 24, 1),
+                                                                      (8, 2560, 192, 1, 27, 0), (8, 1920, 1080, 0, 30, 0)])
 def test_sao_rdo_restatement_equals_the_real_class(depth, width, height, slice_type, qp, csp400):
     """oracle/x265_oracle_pipeline6.c against the real SAO::rdoSaoUnitCu (oracle/ref_sao.cpp::x265ref_sao_rdo) driven row by row like
     FrameFilter does: type, band position, offsets and merge mode of every CTU and plane, and the count of CTUs left without SAO; B / P /

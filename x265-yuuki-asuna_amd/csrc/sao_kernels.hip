@@ -374,6 +374,22 @@ extern "C" int x265hip_sao_apply(const x265hip_sao_apply_params* p, void* stream
     return launch_apply(aa, 1, p->depth, (hipStream_t)stream);
 }
 
+/* the application of 1..3 planes (Y, Cb, Cr) as ONE launch: what follows x265hip_sao_rdo, whose decision needs all planes' statistics first */
+extern "C" int x265hip_sao_apply_planes(int nplanes, const x265hip_sao_apply_params* apply, void* stream)
+{
+    if (nplanes < 1 || nplanes > 3 || !apply) { set_error("sao_apply_planes: %d planes", nplanes); return X265HIP_EINVAL; }
+    SaoApplyArgs3 ap = {};
+    for (int i = 0; i < nplanes; i++)
+    {
+        int rc = fill_apply(&apply[i], ap.p[i]);
+        if (rc) return rc;
+        if (apply[i].depth != apply[0].depth) { set_error("sao_apply_planes: planes of different bit depths"); return X265HIP_EINVAL; }
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    return launch_apply(ap, nplanes, apply[0].depth, (hipStream_t)stream);
+}
+
 extern "C" int x265hip_sao_decide(int depth, const int32_t* count, const int32_t* offset_org, int nctu, int32_t* init_offset, int32_t* ctu_params, void* stream)
 {
     if (!count || !offset_org || !ctu_params) { set_error("sao_decide: NULL operand"); return X265HIP_EINVAL; }

@@ -710,6 +710,60 @@ def sao_planes(depth, planes, stream=None):
     check(f(n, ctypes.cast(st, ctypes.c_void_p), ctypes.cast(ap, ctypes.c_void_p) if with_apply else None, s), "x265hip_sao_planes")
 
 
+def sao_apply_planes(depth, planes, stream=None):
+    """x265hip_sao_apply_planes: the application of 1..3 planes as one launch; planes as in sao_planes (with out)."""
+    es = 1 if depth == 8 else 2
+    n = len(planes)
+    ap = (SaoApplyParams * n)()
+    for i, q in enumerate(planes):
+        ap[i].depth, ap[i].src, ap[i].src_stride = depth, q["rec"].data_ptr() + q["rec_org"] * es, q["rec_stride"]
+        ap[i].dst, ap[i].dst_stride, ap[i].width, ap[i].height = q["out"].data_ptr() + q["rec_org"] * es, q["rec_stride"], q["width"], q["height"]
+        ap[i].ctu_params = q["params"].data_ptr()
+        ap[i].ctu_width, ap[i].ctu_height = q["ctu"]
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_sao_apply_planes
+    f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    check(f(n, ctypes.cast(ap, ctypes.c_void_p), s), "x265hip_sao_apply_planes")
+
+
+class SaoRdoParams(ctypes.Structure):
+    """x265hip_sao_rdo_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("planes", ctypes.c_int), ("ctus_w", ctypes.c_int), ("ctus_h", ctypes.c_int),
+                ("count", ctypes.c_void_p * 3), ("offset_org", ctypes.c_void_p * 3), ("lambda_", ctypes.c_int64 * 2), ("lambda_ctu", ctypes.c_void_p),
+                ("ctx_merge", ctypes.c_int), ("ctx_type", ctypes.c_int), ("frac_bits", ctypes.c_uint32), ("entropy_bits", ctypes.c_void_p),
+                ("sao_flag", ctypes.c_int * 2), ("scratch", ctypes.c_void_p), ("ctu_params", ctypes.c_void_p * 3), ("num_no_sao", ctypes.c_void_p)]
+
+
+def sao_rdo_scratch_bytes(ctus_w, ctus_h):
+    f = lib().x265hip_sao_rdo_scratch_bytes
+    f.restype, f.argtypes = ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]
+    return int(f(ctus_w, ctus_h))
+
+
+def sao_rdo(depth, counts, offset_orgs, ctus_w, ctus_h, lambdas, ctx_merge, ctx_type, entropy_bits, params, scratch, lambda_ctu=None, sao_flag=(1, 1),
+            num_no_sao=None, frac_bits=0, stream=None):
+    """x265hip_sao_rdo: SAO::rdoSaoUnitCu over a picture.  counts / offset_orgs / params: lists (1 or 3 planes) of device tensors;
+    entropy_bits: HOST numpy uint32 [128] (the host's per-state bit costs); lambdas: (luma, chroma) ints; scratch: device tensor of
+    sao_rdo_scratch_bytes(ctus_w, ctus_h) bytes."""
+    import numpy as np
+    p = SaoRdoParams()
+    p.depth, p.planes, p.ctus_w, p.ctus_h = depth, len(counts), ctus_w, ctus_h
+    for i in range(len(counts)):
+        p.count[i], p.offset_org[i], p.ctu_params[i] = counts[i].data_ptr(), offset_orgs[i].data_ptr(), params[i].data_ptr()
+    p.lambda_[0], p.lambda_[1] = int(lambdas[0]), int(lambdas[1])
+    p.lambda_ctu = _p(lambda_ctu)
+    p.ctx_merge, p.ctx_type, p.frac_bits = int(ctx_merge), int(ctx_type), int(frac_bits)
+    bits = np.ascontiguousarray(entropy_bits, dtype=np.uint32)
+    assert bits.size == 128
+    p.entropy_bits = bits.ctypes.data
+    p.sao_flag[0], p.sao_flag[1] = int(sao_flag[0]), int(sao_flag[1])
+    p.scratch, p.num_no_sao = scratch.data_ptr(), _p(num_no_sao)
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_sao_rdo
+    f.argtypes = [ctypes.POINTER(SaoRdoParams), ctypes.c_void_p]
+    check(f(ctypes.byref(p), s), "x265hip_sao_rdo")
+
+
 def me_best_reset(best, stream=None):
     s = current_stream() if stream is None else stream
     check(lib().x265hip_me_best_reset(best.data_ptr(), best.numel(), s), "x265hip_me_best_reset")
