@@ -51,7 +51,7 @@ CFG_DEPTH = {"cfg1": 8, "cfg2": 8, "cfg3": 8, "cfg4": 10, "cfg5": 10}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_planes=None, cur_index=1, tu_flags=2, band=None):
+def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_planes=None, cur_index=1, tu_flags=2, band=None, sao_rdo=None):
     """The oracle's restatement (CPU; checker + cpu_baseline leg only) of one frame of the pipeline - clip[cur_index] searched in
     clip[cur_index - 1] (or in ref_planes = padded Y, Cb, Cr of a reconstruction) - on the first n CTUs.  n == all CTUs also runs the per-picture stages (lookahead, deblocking, SAO statistics)
     and returns every stage output for the bit-exact comparison with the device pipeline.  Returns (seconds, outputs)."""
@@ -97,8 +97,6 @@ def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_pl
         bv, bh = O.deblock_bs_inter(depth, w64, h64, level, mv, ns, avx2=avx2)
         dbk = O.deblock_luma(depth, rec.reshape(-1), stride, org, w64, h64, bv, bh, cuqp, avx2=avx2)
         cnt, off = O.sao_stats(depth, cur.reshape(-1), dbk.reshape(-1), stride, org, w64, h64, nthreads=cores, avx2=avx2)
-        _, par = O.sao_decide(depth, cnt, off, avx2=avx2)
-        fin = O.sao_apply(depth, dbk.reshape(-1), stride, org, w64, h64, par, nthreads=cores, avx2=avx2).reshape(rec.shape)
         # chroma planes: prediction + residual round trip with the luma mvs, chroma edge filter (Bs 2 only), SAO on 32x32 footprints
         cpl = [(F.pad_chroma(clip[cur_index][c], w64, h64_full),
                 F.pad_chroma(clip[cur_index - 1][c], w64, h64_full) if ref_planes is None else (ref_planes[c],)) for c in (1, 2)]
@@ -108,13 +106,22 @@ def oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, cores, avx2, ref_pl
                                       intra_slice=tu_flags)
                 for i in range(2)]
         cdb = O.deblock_chroma(depth, crec[0][0], crec[1][0], sc, oc, w64, h64, bv, bh, cuqp, avx2=avx2)
+        cstat = [O.sao_stats(depth, cpl[i][0][0].reshape(-1), cdb[i].reshape(-1), sc, oc, w64 // 2, h64 // 2, nthreads=cores, avx2=avx2, ctu=(32, 32), plane_offset=2)
+                 for i in range(2)]
+        if sao_rdo is not None:
+            # the reference's own decision: SAO::rdoSaoUnitCu over the picture on all planes' statistics (oracle/x265_oracle_pipeline6.c)
+            lam = np.tile(np.array(sao_rdo["lambdas"], np.int64), (nctu, 1))
+            pars, _ = O.sao_rdo(depth, [cnt, cstat[0][0], cstat[1][0]], [off, cstat[0][1], cstat[1][1]], w64 // 64, h64 // 64, lam, sao_rdo["ctx_merge"], sao_rdo["ctx_type"],
+                                sao_rdo["entropy_bits"], avx2=avx2)
+            par, cpars = pars[0].reshape(-1), [pars[1].reshape(-1), pars[2].reshape(-1)]
+        else:
+            _, par = O.sao_decide(depth, cnt, off, avx2=avx2)
+            cpars = [O.sao_decide(depth, cstat[i][0], cstat[i][1], avx2=avx2)[1] for i in range(2)]
+        fin = O.sao_apply(depth, dbk.reshape(-1), stride, org, w64, h64, par, nthreads=cores, avx2=avx2).reshape(rec.shape)
         cfin = []
         for i in range(2):
-            ccnt, coff = O.sao_stats(depth, cpl[i][0][0].reshape(-1), cdb[i].reshape(-1), sc, oc, w64 // 2, h64 // 2, nthreads=cores, avx2=avx2,
-                                     ctu=(32, 32), plane_offset=2)
-            _, cpar = O.sao_decide(depth, ccnt, coff, avx2=avx2)
-            cf = O.sao_apply(depth, cdb[i].reshape(-1), sc, oc, w64 // 2, h64 // 2, cpar, nthreads=cores, avx2=avx2, ctu=(32, 32))
-            out["sao_params_c%d" % i], out["levels_c%d" % i], out["sao_count_c%d" % i] = cpar, crec[i][1], ccnt
+            cf = O.sao_apply(depth, cdb[i].reshape(-1), sc, oc, w64 // 2, h64 // 2, cpars[i], nthreads=cores, avx2=avx2, ctu=(32, 32))
+            out["sao_params_c%d" % i], out["levels_c%d" % i], out["sao_count_c%d" % i] = cpars[i], crec[i][1], cstat[i][0]
             cfin.append(cf)
         dt = time.perf_counter() - t
         # extendPicBorder; a band gets its side margins, the picture's top margin when it is the first band, the bottom margin when the last
@@ -169,7 +176,7 @@ def compare_outputs(dev_out, cpu_out):
     return {"ok": ok, "stages": stages, "values_compared": int(sum(np.asarray(v).size for v in cpu_out.values()))}
 
 
-def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0, dev_out=None):
+def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0, dev_out=None, sao_rdo=None):
     """The oracle chain (CPU restatement, AVX2 build when the host has AVX2) for one frame, all host cores via OpenMP:
     lookahead -> exhaustive search (best mv) -> sub-pel -> prediction/residual round trip -> deblocking -> SAO statistics.
     Timed on whole frames when one fits the budget, else on a bounded CTU sample; with dev_out (the device pipeline's outputs
@@ -182,7 +189,7 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0, dev_o
     cores = effective_cpus()
 
     def run(n, c=cores):
-        return oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, c, avx2)
+        return oracle_chain(F, clip, rng_r, subme, level, qp, depth, n, c, avx2, sao_rdo=sao_rdo)
 
     bit_exact = None
     reps, t, n = 0, 0.0, nctu
@@ -318,6 +325,10 @@ def main():
     ap.add_argument("--banded", action="store_true", help="run the banded pipeline on one GPU too (measures what the band granularity costs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the bit-exact comparison of one whole frame with the oracle chain")
+    ap.add_argument("--sao-decision", default="rdo", choices=["rdo", "standin"],
+                    help="rdo (default): the reference's own rate-distortion decision of the SAO parameters on the device (x265hip_sao_rdo = "
+                         "SAO::rdoSaoUnitCu: offset iteration, CABAC bit counts, merge candidates; ~0.3 ms of serial CTU-row walk at 4K); standin: round 2's "
+                         "distortion-only choice (x265hip_sao_decide, 0.01 ms) - not what x265 decides")
     ap.add_argument("--no-encoder", action="store_true",
                     help="skip the encoder-level leg (tier T3): the REAL reference encoder (oracle/_ref) on BASELINE configs[2] - 4K, preset slow, "
                          "--me star - with its own C table and with the stage-level seams (integer-search SADs from x265hip_me_cache surfaces, the "
@@ -374,6 +385,13 @@ def main():
     S = importlib.import_module("x265-yuuki-asuna_amd.stages")
     A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
 
+    sao_rdo = None
+    if args.sao_decision == "rdo":
+        HT = importlib.import_module("x265-yuuki-asuna_amd.host_tables")
+        tabs = HT.load()                                   # host-built tables (entropy bit costs, lambda): handed to the stage, never recomputed there
+        cu_qp = max(args.qp - 6 * (args.depth - 8), 0)     # --qp is the quantiser's QP (+ QP_BD_OFFSET); SAO prices bits at the CU's own QP
+        cm, ct = HT.sao_contexts(HT.SLICE_P, cu_qp)
+        sao_rdo = {"lambdas": HT.sao_lambdas(tabs, cu_qp), "ctx_merge": cm, "ctx_type": ct, "entropy_bits": tabs["entropy_bits"]}
     nclip = 4
     clip = F.synth_clip(args.width, args.height, nclip, depth=args.depth, seed=265 + rank)
     pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
@@ -381,7 +399,7 @@ def main():
                            qp=args.qp, want_surf=not args.no_surface, packed=({"packed": True, "packed_t": "t"}.get(args.surf_format, False) if args.depth == 8 else False),
                            lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True, lookahead_cost_batch=args.lookahead_batch,
                            chroma=True, sao_apply=True, sign_hide=True, subpel_planes=bool(args.subpel_planes),
-                           parallel_planes=bool(args.parallel_planes), split=args.split)
+                           parallel_planes=bool(args.parallel_planes), split=args.split, sao_rdo=sao_rdo)
     ref_pic = pics[0].like([p.clone() for p in pics[0].planes()])     # the reference every rank searches in (starts as frame 0): Y, Cb, Cr
     gop = world > 1 and args.sharding == "gop"
     fp = P.FrameParallel(rank, 1 if gop else world)          # gop: the hand-off is this rank's own copy
@@ -398,7 +416,7 @@ def main():
                                    packed=(args.surf_format != "i32" and args.depth == 8) and
                                           ("t" if args.band_rows >= int(os.environ.get("X265HIP_BAND_T_ROWS", "5")) and args.surf_format == "packed_t" else True),
                                    lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True,
-                                   graphs=bool(args.band_graphs), streams=args.band_streams)
+                                   graphs=bool(args.band_graphs), streams=args.band_streams, sao_rdo=sao_rdo)
         # (bands keep every launch on one stream: side streams for the chroma chains change nothing at band size - 3.93 vs 3.97 ms at 4 rows)
         ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16,      # search window + 8-tap interpolation + sub-pel drift
                                    stage_through_host=backend != "nccl")
@@ -510,7 +528,8 @@ def main():
                                     f"sub-pel subme={args.subme} -> " if args.search == "full" else
                                     f"{args.search} search driver (motionEstimate, merange {args.range}, subme {args.subme}, predictor 0) for all 85 PUs/CTU -> ") +
                                    f"{8 << args.level}x{8 << args.level} luma + 4:2:0 chroma prediction + DCT/quant (sign-bit hiding on)/recon qp {args.qp} -> luma + chroma deblocking -> "
-                                   f"SAO statistics -> SAO parameters (saoStatsInitialOffset + distortion-only choice, on device) -> SAO apply (Y, Cb, Cr) -> "
+                                   f"SAO statistics -> SAO parameters (" + ("the reference's rate-distortion decision SAO::rdoSaoUnitCu on the device: offset iteration, CABAC bit "
+                                   "counts with per-row contexts, merge candidates" if sao_rdo else "saoStatsInitialOffset + distortion-only stand-in, on device") + ") -> SAO apply (Y, Cb, Cr) -> "
                                    f"border extension -> next reference (Y, Cb, Cr); pipeline throughput (tier T2), not HEVC encoded fps - the real "
                                    f"encoder's fps (tier T3) is `bench.py --encoder` / profiles/r02_encoder_*.txt",
                        "frames_per_step_per_gpu": 1, "parallelism": ((f"segment-parallel x{world}: every rank encodes its own closed group of pictures, no exchange (--sharding gop)" if gop
@@ -545,7 +564,7 @@ def main():
             dev_out = None
             if args.search == "full" and not args.no_verify:      # one more (untimed) frame: clip[1] searched in the SOURCE clip[0]
                 dev_out = device_outputs(pipe, pics[1], pics[0])
-            out["cpu_baseline"], bit_exact = cpu_baseline(F, clip, args.range, args.subme, args.level, args.qp, depth=args.depth, dev_out=dev_out)
+            out["cpu_baseline"], bit_exact = cpu_baseline(F, clip, args.range, args.subme, args.level, args.qp, depth=args.depth, dev_out=dev_out, sao_rdo=sao_rdo)
             if bit_exact is not None:
                 out["bit_exact"] = bit_exact["ok"]
                 out["bit_exact_detail"] = bit_exact

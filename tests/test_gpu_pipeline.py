@@ -111,13 +111,23 @@ def test_lookahead_costs_run_ahead_in_batches(depth):
     assert np.array_equal(fp.lc[0].mvs.cpu().numpy().reshape(-1, 2), mvs) and np.array_equal(fp.lc[0].frame.cpu().numpy()[:3], frame)
 
 
-@pytest.mark.parametrize("depth,fast", [(8, False), (10, False), (8, True), (10, True)])
-def test_closed_loop_with_chroma_and_sao_in_the_loop(depth, fast):
+def _sao_rdo_inputs(depth, qp):
+    """The host-side inputs of x265hip_sao_rdo for a P picture at quantiser QP `qp` (bench.py builds the same record)."""
+    HT = importlib.import_module("x265-yuuki-asuna_amd.host_tables")
+    tabs = HT.load()
+    cu_qp = max(qp - 6 * (depth - 8), 0)
+    cm, ct = HT.sao_contexts(HT.SLICE_P, cu_qp)
+    return {"lambdas": HT.sao_lambdas(tabs, cu_qp), "ctx_merge": cm, "ctx_type": ct, "entropy_bits": tabs["entropy_bits"]}
+
+
+@pytest.mark.parametrize("depth,fast,rdo", [(8, False, False), (10, False, False), (8, True, False), (10, True, False), (8, False, True), (8, True, True), (10, True, True)])
+def test_closed_loop_with_chroma_and_sao_in_the_loop(depth, fast, rdo):
     """The default bench pipeline (luma + 4:2:0 chroma reconstruction, luma + chroma deblocking, SAO statistics -> on-device parameters
     -> SAO apply on Y / Cb / Cr, border extension) over three frames, each searched in and predicted from the previous frame's
     FILTERED reconstruction; every stage output of every frame against the oracle chain (bench.py's bit_exact code path).
     fast: bench.py's default launch structure - sub-pel candidates read from the reference's phase planes, the Cb / Cr chains and the
-    lookahead on their own HIP streams."""
+    lookahead on their own HIP streams.  rdo: the SAO parameters from x265hip_sao_rdo (the reference's rate-distortion decision, bench.py's
+    default) instead of the distortion-only stand-in."""
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench as B
@@ -126,17 +136,18 @@ def test_closed_loop_with_chroma_and_sao_in_the_loop(depth, fast):
     W, Hh, R, subme, level, qp = 256, 192, 12, 3, 2, 30 + 12 * (depth == 10)
     clip = F.synth_clip(W, Hh, 4, depth=depth, seed=67)
     pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
+    srdo = _sao_rdo_inputs(depth, qp) if rdo else None
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=R, subme=subme, level=level, qp=qp, want_surf=False, lookahead=(W, Hh),
-                           deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True, subpel_planes=fast, parallel_planes=fast)
+                           deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True, subpel_planes=fast, parallel_planes=fast, sao_rdo=srdo)
     ref_dev = pics[0].like([p.clone() for p in pics[0].planes()])
     ref_host = None                                                    # frame 1 searches the source frame 0
     types = set()
     for k in (1, 2, 3):
         dev_out = B.device_outputs(pipe, pics[k], ref_dev)
-        _, cpu_out = B.oracle_chain(F, clip, R, subme, level, qp, depth, pipe.ms.nctu, 4, False, ref_planes=ref_host, cur_index=k)
+        _, cpu_out = B.oracle_chain(F, clip, R, subme, level, qp, depth, pipe.ms.nctu, 4, False, ref_planes=ref_host, cur_index=k, sao_rdo=srdo)
         res = B.compare_outputs(dev_out, cpu_out)
         assert res["ok"], f"frame {k}: {res['stages']}"
-        types |= set(cpu_out["sao_params"][:, 0].tolist()) | set(cpu_out["sao_params_c0"][:, 0].tolist())
+        types |= set(np.asarray(cpu_out["sao_params"]).reshape(-1, 7)[:, 0].tolist()) | set(np.asarray(cpu_out["sao_params_c0"]).reshape(-1, 7)[:, 0].tolist())
         ref_host = (cpu_out["recon"], cpu_out["recon_c0"].reshape(-1), cpu_out["recon_c1"].reshape(-1))
         ref_dev = pics[k].like([p.clone() for p in pipe.final_planes()])
     assert any(t >= 0 for t in types), "SAO never switched on: the loop was not exercised"

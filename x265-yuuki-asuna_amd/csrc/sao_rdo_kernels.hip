@@ -19,6 +19,8 @@
 // mv cost tables it is never recomputed here), bypass bins 32768; the state-transition table is derived from H.265 table 9-46.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace x265hip {
 
 enum { SAO_BO_T = 4 };
@@ -33,11 +35,15 @@ struct SaoCtuCand
     long long dist[3][5];         // EO_0..EO_3, BO: sum of the classes' distClasses
     long long quotY[5];           // (dist[0][k] << 8) / lambda luma
     long long quotC[5];           // ((dist[1][k] + dist[2][k]) << 8) / lambda chroma
+    long long binsLambdaY[5];     // (all bypass bins of luma candidate k) * lambda luma: the serial pass adds the context-coded bin's share
+    long long binsLambdaC[5];     // (all bypass bins of chroma candidate k, Cb + Cr) * lambda chroma
     int off[3][5][4];             // the candidate's four offsets (EO: classes 1..4; BO: the bands of the best window)
     int bins[3][5];               // bypass bins of the offsets (truncated unary + BO signs and band position)
     int boPos[3];
+    int nbY[5], nbC[5];           // all bypass bins of candidate k: 1 (edge / band) + offsets (+ 2 bits of the edge class) - luma; Cb + Cr
+    int pad[2];
 };
-static_assert(sizeof(SaoCtuCand) == 512, "the rows kernel copies candidate records in 16-byte pieces");
+static_assert(sizeof(SaoCtuCand) == 640, "the rows kernel copies candidate records in 16-byte pieces");
 
 struct SaoRdoArgs
 {
@@ -47,6 +53,7 @@ struct SaoRdoArgs
     const long long* lambdaCtu;   // optional [nctu][2]
     int ctxMerge, ctxType, saoFlag[2];
     uint32_t frac;
+    int dbg;                      // timing experiments only (X265HIP_SAO_RDO_DEBUG): 1 skip the merge lanes, 2 skip the copies, 4 skip the decision, 8 skip the prep launch
     SaoCtuCand* cand;
     int32_t* params[3];
     int32_t* numNoSao;
@@ -62,6 +69,7 @@ __global__ void __launch_bounds__(192) sao_rdo_prep_kernel(SaoRdoArgs a)
     __shared__ int sDist[3][5][32];
     __shared__ long long sCost[3][32];        // BO classes only: the window search needs them
     __shared__ long long sSum[3][5];
+    __shared__ int sBinsL[3][5];
     const int ctu = blockIdx.x, pl = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int thresh = 1 << (a.depth - 5 < 5 ? a.depth - 5 : 5);
     const long long lamY = a.lambdaCtu ? a.lambdaCtu[2 * ctu] : a.lambda[0], lamC = a.lambdaCtu ? a.lambdaCtu[2 * ctu + 1] : a.lambda[1];
@@ -109,7 +117,7 @@ __global__ void __launch_bounds__(192) sao_rdo_prep_kernel(SaoRdoArgs a)
                 bins += sao_uvlc_bins(k < 2 ? o : -o, thresh - 1);
             }
             rec.dist[pl][lane] = d; rec.bins[pl][lane] = bins;
-            sSum[pl][lane] = d;
+            sSum[pl][lane] = d; sBinsL[pl][lane] = bins;
         }
         if (lane == 32)
         {   // best window of four consecutive bands: first minimum of the summed class costs (sao.cpp:1552-1570, :1693-1716)
@@ -129,47 +137,113 @@ __global__ void __launch_bounds__(192) sao_rdo_prep_kernel(SaoRdoArgs a)
                 bins += sao_uvlc_bins(abs(o), thresh - 1) + (o != 0);
             }
             rec.dist[pl][SAO_BO_T] = d; rec.bins[pl][SAO_BO_T] = bins; rec.boPos[pl] = pos;
-            sSum[pl][SAO_BO_T] = d;
+            sSum[pl][SAO_BO_T] = d; sBinsL[pl][SAO_BO_T] = bins;
         }
     }
     __syncthreads();
-    if (threadIdx.x < 5) rec.quotY[threadIdx.x] = (sSum[0][threadIdx.x] << 8) / lamY;                                                     // sao.cpp:1597
-    else if (threadIdx.x < 10 && a.planes == 3) rec.quotC[threadIdx.x - 5] = ((sSum[1][threadIdx.x - 5] + sSum[2][threadIdx.x - 5]) << 8) / lamC;   // :1742
+    if (threadIdx.x < 5)
+    {
+        const int k = threadIdx.x;
+        rec.quotY[k] = (sSum[0][k] << 8) / lamY;                                                     // sao.cpp:1597
+        // codeSaoOffsetEO / BO (entropy.cpp:1258-1292) = Entropy::codeSaoOffset of the same parameters (:1221-1256): after the context-coded
+        // type bin, 1 bypass bin (edge / band), the offsets' bins and, for an edge type, 2 bits of its class
+        const int nb = 1 + sBinsL[0][k] + (k < 4 ? 2 : 0);
+        rec.nbY[k] = nb; rec.binsLambdaY[k] = (long long)nb * lamY;
+    }
+    else if (threadIdx.x < 10 && a.planes == 3)
+    {
+        const int k = threadIdx.x - 5;
+        rec.quotC[k] = ((sSum[1][k] + sSum[2][k]) << 8) / lamC;                                      // :1742
+        const int nb = 1 + sBinsL[1][k] + (k < 4 ? 2 : 0) + sBinsL[2][k];                             // Cr carries no type / class bins
+        rec.nbC[k] = nb; rec.binsLambdaC[k] = (long long)nb * lamC;
+    }
 }
 
 struct SaoEnt { int ctxMerge, ctxType; uint32_t frac; };
-struct SaoP { int type, band, off[4], merge; };
+struct SaoP { int type, band, off[4], merge, pad; };       // 32 bytes: two 16-byte LDS accesses
 
-__global__ void __launch_bounds__(256) sao_rdo_rows_kernel(SaoRdoArgs a)
+// exact truncating n / d for d > 0 and |n| < 2^52 (here: sums of four int distortions << 8) from the reciprocal in double precision: the
+// estimate is within one of the quotient, one multiply-subtract repairs it.  The compiler's 64-bit division is ~150 dependent instructions,
+// and six of them sat on the serial path of every step.
+__device__ __forceinline__ long long sao_div(long long n, long long d, double rd)
+{
+    long long q = (long long)((double)n * rd);
+    long long r = n - q * d;
+    if (n >= 0) { if (r < 0) q--; else if (r >= d) q++; }
+    else { if (r > 0) q++; else if (r <= -d) q--; }
+    return q;
+}
+
+// PLANES is a template parameter so that every per-plane array is indexed by constants and stays in registers (the first version kept
+// the parameter sets in dynamically indexed private arrays: 192 bytes of scratch, 79 scratch accesses on the serial path, 11.5 us per step).
+//
+// Roles (round-3 tuning: 1086 -> 764 us at 4K without scratch, then the step was cut into concurrent pieces): the wavefronts of the
+// workgroup split into DECISION lanes (a lane per CTU row: the type decision of luma and chroma, the final comparison with the merge
+// candidates), MERGE-LEFT and MERGE-UP lanes (a lane per row each: the neighbour's parameters on this CTU's statistics - 24 scattered loads
+// and three divisions that do not depend on this CTU's own decision) and four COPY wavefronts that stage the next anti-diagonal's candidate
+// records in LDS.  Two barriers per step: merge distortions ready -> decision final.
+template <int PLANES>
+__global__ void __launch_bounds__(1024) sao_rdo_rows_kernel(SaoRdoArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    // [2][rows] candidate records (prefetched one step ahead) | [2][rows][3] neighbour parameters | bit costs
+    // [2][rows] candidate records (prefetched one step ahead) | [2][rows][3] finished parameters (the row below / the next column read them)
+    // | [rows][2] merge distortions of the step
     SaoCtuCand* sCand = reinterpret_cast<SaoCtuCand*>(smem);
-    SaoP* sUp = reinterpret_cast<SaoP*>(sCand + 2 * a.ctusH);
+    SaoP* sPar = reinterpret_cast<SaoP*>(sCand + 2 * a.ctusH);
+    long long* sMerge = reinterpret_cast<long long*>(sPar + 2 * a.ctusH * 3);
     __shared__ uint32_t sBits[128];
+    __shared__ uint8_t sNext[256];
     __shared__ int sNo[2];
-    const int tid = threadIdx.x, nth = blockDim.x, row = tid;
-    const int W = a.ctusW, H = a.ctusH, planes = a.planes, thresh = 1 << (a.depth - 5 < 5 ? a.depth - 5 : 5);
-    for (int i = tid; i < 128; i += nth) sBits[i] = a.bits[i];          // the block may be a single wavefront
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int W = a.ctusW, H = a.ctusH, thresh = 1 << (a.depth - 5 < 5 ? a.depth - 5 : 5);
+    const int RW = (H + 63) >> 6;                              // wavefronts per role
+    const int wave = tid >> 6, role = wave / RW < 3 ? wave / RW : 3;        // 0 decision, 1 merge-left, 2 merge-up, 3 copy (every further wavefront)
+    const int row = (wave - role * RW) * 64 + (tid & 63);
+    const int ncopy = nth - 3 * RW * 64, ctid = tid - 3 * RW * 64;
+    for (int i = tid; i < 128; i += nth) sBits[i] = a.bits[i];
+    for (int i = tid; i < 256; i += nth)
+    {   // context byte = pStateIdx << 1 | valMps (contexts.h:116 sbacNext); transIdxMps = min(p + 1, 62)
+        const int st = i >> 1, bin = i & 1, p = st >> 1, mps = st & 1;
+        sNext[i] = (uint8_t)(bin == mps ? ((p < 62 ? p + 1 : p) << 1) | mps : ((int)kSaoTransIdxLps[p] << 1) | (p == 0 ? 1 - mps : mps));
+    }
     if (tid < 2) sNo[tid] = 0;
     // the candidate records of the CTUs on anti-diagonal t: row r works on column t - r
-    auto prefetch = [&](int t)
+    auto prefetch = [&](int t, int id, int n)
     {
-        constexpr int Q = sizeof(SaoCtuCand) / 16;
-        for (int i = tid; i < H * Q; i += nth)
+        constexpr int Q = sizeof(SaoCtuCand) / 16, B = 6;       // batches of 6: every load of a batch is in flight before the first LDS store
+        for (int base = id; base < H * Q; base += n * B)
         {
-            const int r = i / Q, q = i - r * Q, x = t - r;
-            if (x >= 0 && x < W)
-                reinterpret_cast<uint4*>(sCand + (t & 1) * H + r)[q] = reinterpret_cast<const uint4*>(a.cand + (size_t)r * W + x)[q];
+            uint4 v[B];
+            bool ok[B];
+#pragma unroll
+            for (int j = 0; j < B; j++)
+            {
+                const int i = base + j * n, r = i / Q, q = i - r * Q, x = t - r;
+                ok[j] = i < H * Q && x >= 0 && x < W;
+                if (ok[j]) v[j] = reinterpret_cast<const uint4*>(a.cand + (size_t)r * W + x)[q];
+            }
+#pragma unroll
+            for (int j = 0; j < B; j++)
+            {
+                const int i = base + j * n, r = i / Q, q = i - r * Q;
+                if (ok[j]) reinterpret_cast<uint4*>(sCand + (t & 1) * H + r)[q] = v[j];
+            }
         }
     };
-    prefetch(0);
-    auto next_state = [](int s, int bin)
+    // the parameters the decision lanes left in LDS at step t -> ctu_params in global memory (kept off the decision lanes: a barrier waits
+    // for a wavefront's outstanding stores, and theirs would sit on the serial path)
+    auto flush = [&](int t, int id, int n)
     {
-        const int p = s >> 1, mps = s & 1;
-        if (bin == mps) return ((p < 62 ? p + 1 : p) << 1) | mps;
-        return ((int)kSaoTransIdxLps[p] << 1) | (p == 0 ? 1 - mps : mps);
+        for (int i = id; i < H * PLANES * 7; i += n)
+        {
+            const int r = i / (PLANES * 7), k = i - r * (PLANES * 7), pl = k / 7, f = k - pl * 7, x = t - r;
+            if (x >= 0 && x < W)
+                a.params[pl][((size_t)r * W + x) * 7 + f] = reinterpret_cast<const int*>(sPar + ((t & 1) * H + r) * 3 + pl)[f];
+        }
     };
+    prefetch(0, tid, nth);
+    // the state-transition table in LDS (a lookup in the __constant__ table is a vector memory load on the serial path)
+    auto next_state = [&](int s, int bin) { return (int)sNext[s * 2 + bin]; };
     auto bin_ctx = [&](SaoEnt& e, int& ctx, int bin) { e.frac += sBits[ctx ^ bin]; ctx = next_state(ctx, bin); };
     // Entropy::codeSaoOffset (entropy.cpp:1221-1256): the bins of a finished parameter set
     auto code_param = [&](SaoEnt& e, const SaoP& p, int plane)
@@ -183,6 +257,7 @@ __global__ void __launch_bounds__(256) sao_rdo_rows_kernel(SaoRdoArgs a)
         int bins = 0;
         if (p.type == SAO_BO_T)
         {
+#pragma unroll
             for (int i = 0; i < 4; i++) bins += sao_uvlc_bins(abs(p.off[i]), thresh - 1) + (p.off[i] != 0);
             bins += 5;
         }
@@ -193,122 +268,166 @@ __global__ void __launch_bounds__(256) sao_rdo_rows_kernel(SaoRdoArgs a)
         }
         e.frac += 32768u * (uint32_t)bins;
     };
+    auto lds_param = [&](int buf, int r, int pl)
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(sPar + (buf * H + r) * 3 + pl);
+        const uint4 v0 = q[0], v1 = q[1];
+        SaoP p;
+        p.type = (int)v0.x; p.band = (int)v0.y; p.off[0] = (int)v0.z; p.off[1] = (int)v0.w; p.off[2] = (int)v1.x; p.off[3] = (int)v1.y; p.merge = (int)v1.z; p.pad = 0;
+        return p;
+    };
     SaoEnt cur = { a.ctxMerge, a.ctxType, a.frac };          // m_rdContexts.cur.load(initState) (sao.cpp:247): every row starts from the slice's state
-    SaoP left[3];
-    int noSao[2] = { 0, 0 };
+    int noSao0 = 0, noSao1 = 0;
     __syncthreads();
     for (int t = 0; t < W + H - 1; t++)
     {
-        if (t + 1 < W + H - 1) prefetch(t + 1);
         const int col = t - row;
-        const bool live = row < H && col >= 0 && col < W;
-        SaoP mine[3];
-        if (live)
+        const bool live = role < 3 && row < H && col >= 0 && col < W;
+        const int addr = row * W + col;
+        const int pb = (t + 1) & 1;                            // the buffer the previous step wrote: left neighbour = my row, up neighbour = row - 1
+        const bool allowL = col != 0, allowU = row != 0;
+        long long lamY = a.lambda[0], lamC = a.lambda[1];
+        if (live && a.lambdaCtu) { lamY = a.lambdaCtu[2 * addr]; lamC = a.lambdaCtu[2 * addr + 1]; }
+        SaoP mine[PLANES];
+        SaoEnt temp = cur;
+        long long bestCost = 0;
+        if (role == 3)
         {
-            const int addr = row * W + col;
+            if (!(a.dbg & 2)) { if (t + 1 < W + H - 1) prefetch(t + 1, ctid, ncopy);
+            if (t > 0) flush(t - 1, ctid, ncopy); }
+        }
+        else if (role && live && !(a.dbg & 1))
+        {   // ---- a merge candidate's distortion (sao.cpp:1314-1335): the neighbour's parameters on THIS CTU's statistics ----
+            const int m = role - 1;
+            long long mergeDist = 0;
+            if (m ? allowU : allowL)
+            {
+                const double rdY = 1.0 / (double)lamY, rdC = 1.0 / (double)lamC;
+                SaoP nb[PLANES];
+                int mc[PLANES][4], mo[PLANES][4];
+#pragma unroll
+                for (int pl = 0; pl < PLANES; pl++)
+                {
+                    nb[pl] = lds_param(pb, m ? row - 1 : row, pl);
+                    const int ty = nb[pl].type < 0 ? 0 : (nb[pl].type > SAO_BO_T ? SAO_BO_T : nb[pl].type);
+                    const int bandPos = nb[pl].type == SAO_BO_T ? min(nb[pl].band & 31, 28) : 1;       // (always in range: clamped so that no state can form a wild address)
+                    const int32_t* cnt = a.count[pl] + (size_t)addr * 160 + ty * 32 + bandPos;
+                    const int32_t* org = a.offsetOrg[pl] + (size_t)addr * 160 + ty * 32 + bandPos;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { mc[pl][c] = cnt[c]; mo[pl][c] = org[c]; }        // unconditional (always a valid address): all loads in flight together
+                }
+#pragma unroll
+                for (int pl = 0; pl < PLANES; pl++)
+                    if (nb[pl].type >= 0)
+                    {
+                        long long estDist = 0;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) estDist += (long long)(int)((mc[pl][c] * nb[pl].off[c] - mo[pl][c] * 2) * nb[pl].off[c]);
+                        mergeDist += sao_div(estDist << 8, pl ? lamC : lamY, pl ? rdC : rdY);
+                    }
+            }
+            sMerge[row * 2 + m] = mergeDist;
+        }
+        else if (live && !(a.dbg & 4))
+        {   // ---- the type decision, everything up to the comparison with the merge candidates ----
             const SaoCtuCand& cd = sCand[(t & 1) * H + row];
-            const long long lamY = a.lambdaCtu ? a.lambdaCtu[2 * addr] : a.lambda[0], lamC = a.lambdaCtu ? a.lambdaCtu[2 * addr + 1] : a.lambda[1];
-            const bool allowL = col != 0, allowU = row != 0;
-            for (int pl = 0; pl < 3; pl++) { mine[pl].type = -1; mine[pl].band = 0; mine[pl].merge = 0; for (int i = 0; i < 4; i++) mine[pl].off[i] = 0; }
-            SaoEnt e = cur, temp;
+#pragma unroll
+            for (int pl = 0; pl < PLANES; pl++) mine[pl] = SaoP{ -1, 0, { 0, 0, 0, 0 }, 0, 0 };
+            SaoEnt e = cur;
             e.frac &= 32767;                                   // resetBits (entropy.cpp:2442-2451)
             if (allowL) bin_ctx(e, e.ctxMerge, 0);
             if (allowU) bin_ctx(e, e.ctxMerge, 0);
             temp = e;
-            long long bestCost = 0, rateDist = 0;
-            // a candidate's rate: the context-coded first bin of sao_type_idx + its bypass bins on top of temp's fractional bits
-            auto rate_of = [&](int ctxBin, int epBins) { return (uint32_t)(((temp.frac & 32767) + sBits[temp.ctxType ^ ctxBin] + 32768u * (uint32_t)epBins) >> 15); };
-            if (a.saoFlag[0])
-            {   // saoLumaComponentParamDist (sao.cpp:1484-1610)
-                long long costBest = sao_rd_cost(0, rate_of(0, 0), lamY);
-                int bestK = -1;
+            long long rateDist = 0;
+            // A candidate's rate = (F + 32768 * bypassBins) >> 15 = bypassBins + (F >> 15), F = the fractional bits carried in + the cost of the
+            // context-coded sao_type_idx bin: its lambda share is precomputed per candidate (binsLambda), only (F >> 15) * lambda is added here.
+            // The chosen candidate then costs exactly its candidate's bins again (codeSaoOffset writes the same syntax, sao.cpp:1598-1600).
+            auto decide = [&](const long long* dist0, const long long* dist1, const long long* binsLambda, const int* nb, long long lambda, int& bestK)
+            {
+                const uint32_t F = temp.frac & 32767, f0 = F + sBits[temp.ctxType], f1 = F + sBits[temp.ctxType ^ 1];
+                long long costBest = ((long long)(f0 >> 15) * lambda + 128) >> 8;          // sao_type_idx = 0 (sao.cpp:1491-1494)
+                const long long carry = (long long)(f1 >> 15) * lambda + 128;
+                bestK = -1;
+#pragma unroll
                 for (int k = 0; k < 5; k++)
                 {
-                    // EO: type bin + 1 bypass (edge / band) + offsets + 2 bits of the class; BO: type bin + 1 bypass + offsets, signs, band position
-                    const long long cost = sao_rd_cost(cd.dist[0][k], rate_of(1, 1 + cd.bins[0][k] + (k < 4 ? 2 : 0)), lamY);
+                    const long long cost = dist0[k] + (dist1 ? dist1[k] : 0) + ((binsLambda[k] + carry) >> 8);
                     if (cost < costBest) { costBest = cost; bestK = k; }
                 }
+                // Entropy::codeSaoOffset of the winner on top of temp, no resetBits (sao.cpp:1598-1600, :1743-1750)
+                temp.frac += bestK < 0 ? sBits[temp.ctxType] : sBits[temp.ctxType ^ 1] + 32768u * (uint32_t)nb[bestK];
+                temp.ctxType = next_state(temp.ctxType, bestK >= 0);
+            };
+            if (a.saoFlag[0])
+            {   // saoLumaComponentParamDist (sao.cpp:1484-1610)
+                int bestK;
+                decide(cd.dist[0], nullptr, cd.binsLambdaY, cd.nbY, lamY, bestK);
                 if (bestK >= 0)
                 {
                     mine[0].type = bestK; mine[0].band = bestK == SAO_BO_T ? cd.boPos[0] : 0;
+#pragma unroll
                     for (int i = 0; i < 4; i++) mine[0].off[i] = cd.off[0][bestK][i];
                     rateDist = cd.quotY[bestK];
                 }
-                e = temp; code_param(e, mine[0], 0); temp = e;         // no resetBits: the merge flags' bits stay counted (sao.cpp:1598-1600)
-                if (planes == 1) bestCost = rateDist + (e.frac >> 15);
+                if (PLANES == 1) bestCost = rateDist + (temp.frac >> 15);
             }
-            if (planes == 3 && a.saoFlag[1])
+            if (PLANES == 3 && a.saoFlag[1])
             {   // saoChromaComponentParamDist (sao.cpp:1611-1760): Cb and Cr share the type, the rate counts both planes' syntax
-                long long costBest = sao_rd_cost(0, rate_of(0, 0), lamC);
-                int bestK = -1;
-                for (int k = 0; k < 5; k++)
-                {
-                    const long long cost = sao_rd_cost(cd.dist[1][k] + cd.dist[2][k], rate_of(1, 1 + cd.bins[1][k] + (k < 4 ? 2 : 0) + cd.bins[2][k]), lamC);
-                    if (cost < costBest) { costBest = cost; bestK = k; }
-                }
+                int bestK;
+                decide(cd.dist[1], cd.dist[2], cd.binsLambdaC, cd.nbC, lamC, bestK);
                 if (bestK >= 0)
                 {
-                    for (int pl = 1; pl < 3; pl++)
+#pragma unroll
+                    for (int pl = 1; pl < PLANES; pl++)
                     {
                         mine[pl].type = bestK; mine[pl].band = bestK == SAO_BO_T ? cd.boPos[pl] : 0;
+#pragma unroll
                         for (int i = 0; i < 4; i++) mine[pl].off[i] = cd.off[pl][bestK][i];
                     }
                     rateDist += cd.quotC[bestK];
                 }
-                e = temp; code_param(e, mine[1], 1); code_param(e, mine[2], 2); temp = e;
-                bestCost = rateDist + (e.frac >> 15);
+                bestCost = rateDist + (temp.frac >> 15);
             }
+        }
+        __syncthreads();                                       // the merge distortions of this step are in LDS
+        if (role == 0 && live)
+        {
             if (a.saoFlag[0] || a.saoFlag[1])
-            {   // the merge candidates (sao.cpp:1314-1373): the neighbour's parameters on THIS CTU's statistics
+            {   // the merge candidates against the best new parameters (sao.cpp:1336-1373)
+#pragma unroll
                 for (int m = 0; m < 2; m++)
                 {
                     if (!(m ? allowU : allowL)) continue;
-                    long long mergeDist = 0;
-                    for (int pl = 0; pl < planes; pl++)
-                    {
-                        const SaoP src = m ? sUp[((t + 1) & 1) * H * 3 + (row - 1) * 3 + pl] : left[pl];
-                        long long estDist = 0;
-                        if (src.type >= 0)
-                        {
-                            const int bandPos = src.type == SAO_BO_T ? src.band : 1;
-                            const int32_t* cnt = a.count[pl] + (size_t)addr * 160 + src.type * 32 + bandPos;
-                            const int32_t* org = a.offsetOrg[pl] + (size_t)addr * 160 + src.type * 32 + bandPos;
-                            for (int c = 0; c < 4; c++) estDist += (long long)(int)((cnt[c] * src.off[c] - org[c] * 2) * src.off[c]);
-                        }
-                        mergeDist += (estDist << 8) / (pl ? lamC : lamY);
-                    }
-                    e = cur; e.frac &= 32767;
+                    SaoEnt e = cur; e.frac &= 32767;
                     if (allowL) bin_ctx(e, e.ctxMerge, 1 - m);
                     if (allowU && m == 1) bin_ctx(e, e.ctxMerge, 1);
-                    const long long mergeCost = mergeDist + (e.frac >> 15);
+                    const long long mergeCost = sMerge[row * 2 + m] + (e.frac >> 15);
                     if (mergeCost < bestCost)
                     {
                         bestCost = mergeCost;
                         temp = e;
-                        for (int pl = 0; pl < planes; pl++)
-                            if (a.saoFlag[pl > 0])
-                            {
-                                const SaoP src = m ? sUp[((t + 1) & 1) * H * 3 + (row - 1) * 3 + pl] : left[pl];
-                                mine[pl] = src; mine[pl].merge = m ? 2 : 1;
-                            }
+#pragma unroll
+                        for (int pl = 0; pl < PLANES; pl++)
+                            if (a.saoFlag[pl > 0]) { mine[pl] = lds_param(pb, m ? row - 1 : row, pl); mine[pl].merge = m ? 2 : 1; }
                     }
                 }
-                noSao[0] += mine[0].type < 0;
-                if (planes == 3) noSao[1] += mine[1].type < 0;
+                noSao0 += mine[0].type < 0;
+                if (PLANES == 3) noSao1 += mine[1].type < 0;
                 cur = temp;
             }
-            for (int pl = 0; pl < planes; pl++)
+#pragma unroll
+            for (int pl = 0; pl < PLANES; pl++)
             {
-                int32_t* o = a.params[pl] + (size_t)addr * 7;
-                o[0] = mine[pl].type; o[1] = mine[pl].band; o[6] = mine[pl].merge;
-                for (int i = 0; i < 4; i++) o[2 + i] = mine[pl].off[i];
-                left[pl] = mine[pl];
-                sUp[(t & 1) * H * 3 + row * 3 + pl] = mine[pl];            // the row below reads it at the next step (same column)
+                const uint4 v0 = make_uint4((uint32_t)mine[pl].type, (uint32_t)mine[pl].band, (uint32_t)mine[pl].off[0], (uint32_t)mine[pl].off[1]);
+                const uint4 v1 = make_uint4((uint32_t)mine[pl].off[2], (uint32_t)mine[pl].off[3], (uint32_t)mine[pl].merge, 0u);
+                uint4* q = reinterpret_cast<uint4*>(sPar + ((t & 1) * H + row) * 3 + pl);         // the row below and my next column read it at the next step;
+                q[0] = v0; q[1] = v1;                                                              // the copy wavefronts write it to global memory then
             }
         }
-        __syncthreads();
+        __syncthreads();                                       // the decisions of this step are in LDS
     }
-    if (row < H) { if (noSao[0]) atomicAdd(&sNo[0], noSao[0]); if (noSao[1]) atomicAdd(&sNo[1], noSao[1]); }
+    flush(W + H - 2, tid, nth);
+    if (role == 0 && row < H) { if (noSao0) atomicAdd(&sNo[0], noSao0); if (noSao1) atomicAdd(&sNo[1], noSao1); }
     __syncthreads();
     if (tid < 2 && a.numNoSao) a.numNoSao[tid] = sNo[tid];
 }
@@ -327,7 +446,7 @@ extern "C" int x265hip_sao_rdo(const x265hip_sao_rdo_params* p, void* stream)
     if (!p || !p->entropy_bits || !p->scratch || !p->count[0] || !p->offset_org[0] || !p->ctu_params[0]) { set_error("sao_rdo: NULL operand"); return X265HIP_EINVAL; }
     if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("sao_rdo: depth %d", p->depth); return X265HIP_EINVAL; }
     if (p->planes != 1 && p->planes != 3) { set_error("sao_rdo: planes %d (1 = luma only, 3 = 4:2:0)", p->planes); return X265HIP_EINVAL; }
-    if (p->ctus_w < 1 || p->ctus_h < 1 || p->ctus_h > 256) { set_error("sao_rdo: %d x %d CTUs (at most 256 CTU rows)", p->ctus_w, p->ctus_h); return X265HIP_EINVAL; }
+    if (p->ctus_w < 1 || p->ctus_h < 1 || p->ctus_h > 128) { set_error("sao_rdo: %d x %d CTUs (at most 128 CTU rows)", p->ctus_w, p->ctus_h); return X265HIP_EINVAL; }
     for (int i = 1; i < p->planes; i++)
         if (!p->count[i] || !p->offset_org[i] || !p->ctu_params[i]) { set_error("sao_rdo: NULL operand of plane %d", i); return X265HIP_EINVAL; }
     if ((!p->lambda_ctu && (p->lambda[0] <= 0 || (p->planes == 3 && p->lambda[1] <= 0))) || p->ctx_merge < 0 || p->ctx_merge > 125 || p->ctx_type < 0 || p->ctx_type > 125 ||
@@ -341,21 +460,24 @@ extern "C" int x265hip_sao_rdo(const x265hip_sao_rdo_params* p, void* stream)
     a.lambda[0] = p->lambda[0]; a.lambda[1] = p->lambda[1]; a.lambdaCtu = (const long long*)p->lambda_ctu;
     a.ctxMerge = p->ctx_merge; a.ctxType = p->ctx_type; a.saoFlag[0] = p->sao_flag[0] != 0; a.saoFlag[1] = p->sao_flag[1] != 0 && p->planes == 3;
     a.frac = p->frac_bits;
+    a.dbg = getenv("X265HIP_SAO_RDO_DEBUG") ? atoi(getenv("X265HIP_SAO_RDO_DEBUG")) : 0;
     a.cand = (SaoCtuCand*)p->scratch; a.numNoSao = p->num_no_sao;
     for (int i = 0; i < 128; i++) a.bits[i] = p->entropy_bits[i];
     hipStream_t s = (hipStream_t)stream;
     const int nctu = p->ctus_w * p->ctus_h;
-    hipLaunchKernelGGL(sao_rdo_prep_kernel, dim3(nctu), dim3(192), 0, s, a);
+    if (!(a.dbg & 8)) hipLaunchKernelGGL(sao_rdo_prep_kernel, dim3(nctu), dim3(192), 0, s, a);
     if ((rc = check_hip(hipGetLastError(), "sao_rdo prep launch"))) return rc;
-    const int threads = (p->ctus_h + 63) / 64 * 64;
-    const size_t lds = (size_t)2 * p->ctus_h * sizeof(SaoCtuCand) + (size_t)2 * p->ctus_h * 3 * sizeof(SaoP);
+    const int threads = ((p->ctus_h + 63) / 64 * 3 + 4) * 64;          // decision / merge-left / merge-up lanes per CTU row + four copy wavefronts
+    const size_t lds = (size_t)2 * p->ctus_h * sizeof(SaoCtuCand) + (size_t)2 * p->ctus_h * 3 * sizeof(SaoP) + (size_t)p->ctus_h * 2 * sizeof(long long);
     if (lds > 150 * 1024) { set_error("sao_rdo: %d CTU rows need %zu bytes of LDS", p->ctus_h, lds); return X265HIP_EUNSUPPORTED; }
     static bool ldsRaised = false;
     if (lds > 48 * 1024 && !ldsRaised)
     {
-        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         ldsRaised = true;
     }
-    hipLaunchKernelGGL(sao_rdo_rows_kernel, dim3(1), dim3(threads < 64 ? 64 : threads), lds, s, a);
+    if (p->planes == 3) hipLaunchKernelGGL(sao_rdo_rows_kernel<3>, dim3(1), dim3(threads), lds, s, a);
+    else hipLaunchKernelGGL(sao_rdo_rows_kernel<1>, dim3(1), dim3(threads), lds, s, a);
     return check_hip(hipGetLastError(), "sao_rdo rows launch");
 }

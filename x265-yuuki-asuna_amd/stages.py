@@ -556,7 +556,7 @@ class FramePipeline:
 
     def __init__(self, w64, h64, depth, device, rng=57, subme=2, level=2, qp=27, want_surf=True, packed=False, lookahead=None,
                  search="full", deblock=False, sao=False, lookahead_cost_batch=0, chroma=False, sao_apply=False, sign_hide=False,
-                 subpel_planes=False, parallel_planes=False, split=1):
+                 subpel_planes=False, parallel_planes=False, split=1, sao_rdo=None):
         """split (with parallel_planes): the picture goes through search -> sub-pel refinement -> reconstruction in `split` parts of whole
         CTU rows; while the search of part k + 1 runs on the caller's stream, part k is refined and reconstructed on a side stream.  No
         CTU's result depends on another CTU before the loop filters, which still run on the whole picture: same outputs, and only the last
@@ -624,8 +624,25 @@ class FramePipeline:
         # SAO applied in the loop: the parameters come from x265hip_sao_decide (initial offsets + distortion-only choice), so the
         # picture handed to the next frame is deblocked AND offset like a decoder's
         self.sao_apply = bool(sao and sao_apply)
+        # sao_rdo: dict(lambdas=(luma, chroma), ctx_merge, ctx_type, entropy_bits) - the parameters come from x265hip_sao_rdo, the
+        # reference's own rate-distortion decision (SAO::rdoSaoUnitCu) on all planes' statistics, instead of the distortion-only stand-in
+        self.sao_rdo = sao_rdo if (sao and sao_apply) else None
+        if self.sao_rdo is not None:
+            self.sao_scratch = torch.zeros(hipabi.sao_rdo_scratch_bytes(w64 // 64, h64 // 64), dtype=torch.uint8, device=device)
+            self.sao_no = torch.zeros(2, dtype=torch.int32, device=device)
         # band mode (BandedFramePipeline): (is_first_band, is_last_band) -> row-wise border extension instead of the whole-picture one
         self.band_border = None
+
+    def _sao_rdo(self):
+        """x265hip_sao_rdo on the statistics of all planes -> every plane's Sao.params."""
+        st = [self.sao] + (list(self.sao_c) if self.chroma else [])
+        q = self.sao_rdo
+        hipabi.sao_rdo(self.depth, [x.count for x in st], [x.offset_org for x in st], self.ms.w64 // 64, self.ms.h64 // 64, q["lambdas"], q["ctx_merge"], q["ctx_type"],
+                       q["entropy_bits"], [x.params for x in st], self.sao_scratch, sao_flag=(1, 1 if self.chroma else 0), num_no_sao=self.sao_no)
+
+    def _sao_planes(self, cur):
+        return [self.sao.plane(cur.t, cur.stride, cur.org, self.recon, cur.stride, cur.org, self.out)] + \
+               ([self.sao_c[i].plane(cur.c[i], cur.stride_c, cur.org_c, self.recon_c[i], cur.stride_c, cur.org_c, self.out_c[i]) for i in range(2)] if self.chroma else [])
 
     def run(self, cur: DevicePicture, ref: DevicePicture, mark=None):
         """ref: the current reference picture (extended borders; with chroma=True also its Cb / Cr planes); returns the luma plane of
@@ -683,7 +700,21 @@ class FramePipeline:
                                       self.db.bs_ver, self.db.bs_hor, self.db.qp)
             mark("deblock")
         final, final_c = self.recon, self.recon_c
-        if self.sao is not None and self.sao_apply and self.chroma and self.fuse_sao:
+        if self.sao_rdo is not None:
+            # statistics of all planes (one launch) -> the reference's rate-distortion decision (x265hip_sao_rdo: it needs every plane's
+            # statistics, Cb / Cr share a type) -> application of all planes (one launch)
+            if self.out is None:
+                self.out = torch.zeros_like(cur.t)
+                self.out_c = [torch.zeros_like(p) for p in cur.c] if self.chroma else None
+            planes = self._sao_planes(cur)
+            hipabi.sao_planes(self.depth, [dict(q, out=None) for q in planes])
+            mark("sao_stats")
+            self._sao_rdo()
+            mark("sao_rdo")
+            hipabi.sao_apply_planes(self.depth, planes)
+            final, final_c = self.out, self.out_c
+            mark("sao_apply")
+        elif self.sao is not None and self.sao_apply and self.chroma and self.fuse_sao:
             # Y, Cb, Cr through statistics -> parameters -> application with ONE launch per step (x265hip_sao_planes)
             if self.out is None:
                 self.out = torch.zeros_like(cur.t)
@@ -790,7 +821,21 @@ class FramePipeline:
                                   self.db.bs_ver, self.db.bs_hor, self.db.qp)
             ev_dbc = torch.cuda.Event(); ev_dbc.record(sCb)
         sCr.wait_event(ev_dbc)
-        if self.fuse_sao_parallel:
+        if self.sao_rdo is not None:
+            # the decision couples the planes: statistics of Y on the caller's stream and of Cb / Cr on theirs, the decision + the application
+            # of all three on the caller's stream, the border extensions back on the side streams
+            self.sao.stats(cur, self.recon, cur.stride, cur.org)
+            evs = []
+            for i, st in enumerate((sCb, sCr)):
+                with torch.cuda.stream(st):
+                    self.sao_c[i].stats(None, self.recon_c[i], cur.stride_c, cur.org_c, src_plane=cur.c[i])
+                    e = torch.cuda.Event(); e.record(st); evs.append(e)
+            for e in evs:
+                main.wait_event(e)
+            self._sao_rdo()
+            hipabi.sao_apply_planes(self.depth, self._sao_planes(cur))
+            ev_sao = torch.cuda.Event(); ev_sao.record(main)
+        elif self.fuse_sao_parallel:
             # SAO of the three planes: one launch per step on the caller's stream; only the border extensions go back to the side streams
             main.wait_event(ev_dbc)
             hipabi.sao_planes(self.depth, [self.sao.plane(cur.t, cur.stride, cur.org, self.recon, cur.stride, cur.org, self.out)] +
@@ -810,10 +855,10 @@ class FramePipeline:
         border(self.out, False)
         done = []
         for i, st in enumerate((sCb, sCr)):
-            if self.fuse_sao_parallel:
+            if self.fuse_sao_parallel or self.sao_rdo is not None:
                 st.wait_event(ev_sao)
             with torch.cuda.stream(st):
-                if not self.fuse_sao_parallel:
+                if not self.fuse_sao_parallel and self.sao_rdo is None:
                     self.sao_c[i].stats(None, self.recon_c[i], cur.stride_c, cur.org_c, src_plane=cur.c[i])
                     self.sao_c[i].decide()
                     self.sao_c[i].apply(self.recon_c[i], cur.stride_c, cur.org_c, self.out_c[i])
