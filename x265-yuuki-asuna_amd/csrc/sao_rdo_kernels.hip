@@ -30,20 +30,26 @@ __constant__ uint8_t kSaoTransIdxLps[64] = {          // ITU-T H.265 table 9-46
     24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63 };
 
 // one CTU's neighbour-independent candidates (all three planes)
+// One CTU's neighbour-independent results (all three planes), as the serial pass needs them.  A candidate's rate is
+// (F + 32768 * bypassBins) >> 15 = bypassBins + (F >> 15) with F = the fractional bits carried in + the cost of the context-coded
+// sao_type_idx bin: the ONLY thing the serial state contributes to the type decision is the small integer c = F >> 15 (0 .. 15 for any
+// table whose costs stay below 15 bits of 32768ths, checked at the entry).  So the winner among the five candidates - first minimum of
+// dist_k + ((bins_k + c) * lambda + 128 >> 8), the reference's loop order and strict '<' - is tabulated per c here, in parallel, and the
+// serial pass only compares it with the cost of switching SAO off.
+enum { SAO_C = 16 };
 struct SaoCtuCand
 {
-    long long dist[3][5];         // EO_0..EO_3, BO: sum of the classes' distClasses
-    long long quotY[5];           // (dist[0][k] << 8) / lambda luma
-    long long quotC[5];           // ((dist[1][k] + dist[2][k]) << 8) / lambda chroma
-    long long binsLambdaY[5];     // (all bypass bins of luma candidate k) * lambda luma: the serial pass adds the context-coded bin's share
-    long long binsLambdaC[5];     // (all bypass bins of chroma candidate k, Cb + Cr) * lambda chroma
-    int off[3][5][4];             // the candidate's four offsets (EO: classes 1..4; BO: the bands of the best window)
-    int bins[3][5];               // bypass bins of the offsets (truncated unary + BO signs and band position)
-    int boPos[3];
-    int nbY[5], nbC[5];           // all bypass bins of candidate k: 1 (edge / band) + offsets (+ 2 bits of the edge class) - luma; Cb + Cr
-    int pad[2];
+    long long minCostY[SAO_C];    // luma: the best candidate's cost for c = 0 .. 15
+    long long minCostC[SAO_C];    // chroma (Cb + Cr share the type, the rate counts both planes' syntax)
+    long long quotY[5];           // (dist[0][k] << 8) / lambda luma                       (rateDist of the winner, sao.cpp:1597)
+    long long quotC[5];           // ((dist[1][k] + dist[2][k]) << 8) / lambda chroma      (:1742)
+    int nbY[5], nbC[5];           // all bypass bins of candidate k: 1 (edge / band) + offsets (+ 2 bits of the edge class); Cb + Cr for chroma
+    uint8_t minKY[SAO_C], minKC[SAO_C];
+    int8_t off[3][5][4];          // the candidate's four offsets (EO: classes 1..4; BO: the bands of the best window)
+    uint8_t boPos[3];
+    uint8_t pad[9];
 };
-static_assert(sizeof(SaoCtuCand) == 640, "the rows kernel copies candidate records in 16-byte pieces");
+static_assert(sizeof(SaoCtuCand) == 480 && sizeof(SaoCtuCand) % 16 == 0, "the rows kernel copies candidate records in 16-byte pieces");
 
 struct SaoRdoArgs
 {
@@ -70,6 +76,7 @@ __global__ void __launch_bounds__(192) sao_rdo_prep_kernel(SaoRdoArgs a)
     __shared__ long long sCost[3][32];        // BO classes only: the window search needs them
     __shared__ long long sSum[3][5];
     __shared__ int sBinsL[3][5];
+    __shared__ long long sBL[2][5];          // (all bypass bins of candidate k) * lambda: luma, chroma
     const int ctu = blockIdx.x, pl = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int thresh = 1 << (a.depth - 5 < 5 ? a.depth - 5 : 5);
     const long long lamY = a.lambdaCtu ? a.lambdaCtu[2 * ctu] : a.lambda[0], lamC = a.lambdaCtu ? a.lambdaCtu[2 * ctu + 1] : a.lambda[1];
@@ -113,10 +120,9 @@ __global__ void __launch_bounds__(192) sao_rdo_prep_kernel(SaoRdoArgs a)
             {
                 const int o = sOff[pl][lane][1 + k];
                 d += sDist[pl][lane][1 + k];
-                rec.off[pl][lane][k] = o;
+                rec.off[pl][lane][k] = (int8_t)o;
                 bins += sao_uvlc_bins(k < 2 ? o : -o, thresh - 1);
             }
-            rec.dist[pl][lane] = d; rec.bins[pl][lane] = bins;
             sSum[pl][lane] = d; sBinsL[pl][lane] = bins;
         }
         if (lane == 32)
@@ -133,10 +139,10 @@ __global__ void __launch_bounds__(192) sao_rdo_prep_kernel(SaoRdoArgs a)
             {
                 const int o = sOff[pl][SAO_BO_T][pos + k];
                 d += sDist[pl][SAO_BO_T][pos + k];
-                rec.off[pl][SAO_BO_T][k] = o;
+                rec.off[pl][SAO_BO_T][k] = (int8_t)o;
                 bins += sao_uvlc_bins(abs(o), thresh - 1) + (o != 0);
             }
-            rec.dist[pl][SAO_BO_T] = d; rec.bins[pl][SAO_BO_T] = bins; rec.boPos[pl] = pos;
+            rec.boPos[pl] = (uint8_t)pos;
             sSum[pl][SAO_BO_T] = d; sBinsL[pl][SAO_BO_T] = bins;
         }
     }
@@ -148,14 +154,31 @@ __global__ void __launch_bounds__(192) sao_rdo_prep_kernel(SaoRdoArgs a)
         // codeSaoOffsetEO / BO (entropy.cpp:1258-1292) = Entropy::codeSaoOffset of the same parameters (:1221-1256): after the context-coded
         // type bin, 1 bypass bin (edge / band), the offsets' bins and, for an edge type, 2 bits of its class
         const int nb = 1 + sBinsL[0][k] + (k < 4 ? 2 : 0);
-        rec.nbY[k] = nb; rec.binsLambdaY[k] = (long long)nb * lamY;
+        rec.nbY[k] = nb; sBL[0][k] = (long long)nb * lamY;
     }
     else if (threadIdx.x < 10 && a.planes == 3)
     {
         const int k = threadIdx.x - 5;
         rec.quotC[k] = ((sSum[1][k] + sSum[2][k]) << 8) / lamC;                                      // :1742
         const int nb = 1 + sBinsL[1][k] + (k < 4 ? 2 : 0) + sBinsL[2][k];                             // Cr carries no type / class bins
-        rec.nbC[k] = nb; rec.binsLambdaC[k] = (long long)nb * lamC;
+        rec.nbC[k] = nb; sBL[1][k] = (long long)nb * lamC;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * SAO_C)
+    {   // the winner among the five candidates for every carry c (sao.cpp:1505-1530 / :1636-1660 + the BO comparison :1576-1590 / :1718-1735)
+        const int g = threadIdx.x / SAO_C, c = threadIdx.x - g * SAO_C;
+        if (g == 0 || a.planes == 3)
+        {
+            const long long carry = (long long)c * (g ? lamC : lamY) + 128;
+            long long best = 0; int bestK = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+            {
+                const long long cost = (g ? sSum[1][k] + sSum[2][k] : sSum[0][k]) + ((sBL[g][k] + carry) >> 8);
+                if (k == 0 || cost < best) { best = cost; bestK = k; }
+            }
+            if (g) { rec.minCostC[c] = best; rec.minKC[c] = (uint8_t)bestK; } else { rec.minCostY[c] = best; rec.minKY[c] = (uint8_t)bestK; }
+        }
     }
 }
 
@@ -208,40 +231,85 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows_kernel(SaoRdoArgs a)
     }
     if (tid < 2) sNo[tid] = 0;
     // the candidate records of the CTUs on anti-diagonal t: row r works on column t - r
-    auto prefetch = [&](int t, int id, int n)
+    // The candidate records travel global memory -> registers -> LDS in two steps of the walk: a copy lane LOADS the pieces of
+    // anti-diagonal t + 2 while step t runs and STORES them to LDS during step t + 1, so the barrier at the end of a step never waits for a
+    // load that was issued in that step (a barrier waits for the LDS stores, and those wait for their loads).
+    // A copy lane owns up to B fixed pieces (row r, 16-byte piece q of the record): per step only the column moves, so the global address
+    // advances by one record and the LDS buffer toggles - a handful of instructions per piece (the first version recomputed row / piece /
+    // address from the piece index every step, and the copy wavefronts crowded the decision lanes out of their SIMDs' issue slots).
+    constexpr int Q = sizeof(SaoCtuCand) / 16, B = 6;
+    uint4 stagev[B];
+    bool stageok[B];
+    int pieceRow[B], pieceLds[B];
+    const uint4* piecePtr[B];
+#pragma unroll
+    for (int j = 0; j < B; j++)
     {
-        constexpr int Q = sizeof(SaoCtuCand) / 16, B = 6;       // batches of 6: every load of a batch is in flight before the first LDS store
-        for (int base = id; base < H * Q; base += n * B)
+        const int i = ctid + j * ncopy, r = i / Q, q = i - r * Q;
+        pieceRow[j] = (role == 3 && i < H * Q) ? r : -0x10000;                       // column of step t: t - r
+        pieceLds[j] = r * Q + q;
+        piecePtr[j] = reinterpret_cast<const uint4*>(a.cand + (size_t)(r < H ? r : 0) * W) + q;       // + column * Q
+    }
+    auto stage_load = [&](int t)
+    {
+#pragma unroll
+        for (int j = 0; j < B; j++)
         {
-            uint4 v[B];
-            bool ok[B];
+            const int x = t - pieceRow[j];
+            stageok[j] = x >= 0 && x < W;
+            if (stageok[j]) stagev[j] = piecePtr[j][(size_t)x * Q];
+        }
+    };
+    auto stage_store = [&](int t)
+    {
+        uint4* buf = reinterpret_cast<uint4*>(sCand + (t & 1) * H);
 #pragma unroll
-            for (int j = 0; j < B; j++)
-            {
-                const int i = base + j * n, r = i / Q, q = i - r * Q, x = t - r;
-                ok[j] = i < H * Q && x >= 0 && x < W;
-                if (ok[j]) v[j] = reinterpret_cast<const uint4*>(a.cand + (size_t)r * W + x)[q];
-            }
-#pragma unroll
-            for (int j = 0; j < B; j++)
-            {
-                const int i = base + j * n, r = i / Q, q = i - r * Q;
-                if (ok[j]) reinterpret_cast<uint4*>(sCand + (t & 1) * H + r)[q] = v[j];
-            }
+        for (int j = 0; j < B; j++)
+            if (stageok[j]) buf[pieceLds[j]] = stagev[j];
+    };
+    // (more than B pieces per copy lane - pictures of more than ~38 CTU rows - take the direct route for the rest)
+    auto prefetch_rest = [&](int t, int id, int n)
+    {
+        for (int i = id + B * n; i < H * Q; i += n)
+        {
+            const int r = i / Q, q = i - r * Q, x = t - r;
+            if (x >= 0 && x < W)
+                reinterpret_cast<uint4*>(sCand + (t & 1) * H + r)[q] = reinterpret_cast<const uint4*>(a.cand + (size_t)r * W + x)[q];
         }
     };
     // the parameters the decision lanes left in LDS at step t -> ctu_params in global memory (kept off the decision lanes: a barrier waits
     // for a wavefront's outstanding stores, and theirs would sit on the serial path)
+    constexpr int FB = 4;                                       // parameter ints per copy lane and step: rows * PLANES * 7 / copy lanes, rounded up
+    int flRow[FB], flLds[FB], flOut[FB], flPl[FB];
+#pragma unroll
+    for (int j = 0; j < FB; j++)
+    {
+        const int i = ctid + j * ncopy, r = i / (PLANES * 7), k = i - r * (PLANES * 7), pl = k / 7, f = k - pl * 7;
+        flRow[j] = (role == 3 && i < H * PLANES * 7) ? r : -0x10000;
+        flLds[j] = (r * 3 + pl) * 8 + f;                        // int index inside one parameter buffer (SaoP = 8 ints)
+        flOut[j] = r * W * 7 + f;                               // + column * 7
+        flPl[j] = pl;
+    }
     auto flush = [&](int t, int id, int n)
     {
-        for (int i = id; i < H * PLANES * 7; i += n)
+        const int* buf = reinterpret_cast<const int*>(sPar + (t & 1) * H * 3);
+#pragma unroll
+        for (int j = 0; j < FB; j++)
+        {
+            const int x = t - flRow[j];
+            if (x >= 0 && x < W) a.params[flPl[j]][flOut[j] + x * 7] = buf[flLds[j]];
+        }
+        for (int i = id + FB * n; i < H * PLANES * 7; i += n)          // (pictures of more than ~48 CTU rows)
         {
             const int r = i / (PLANES * 7), k = i - r * (PLANES * 7), pl = k / 7, f = k - pl * 7, x = t - r;
-            if (x >= 0 && x < W)
-                a.params[pl][((size_t)r * W + x) * 7 + f] = reinterpret_cast<const int*>(sPar + ((t & 1) * H + r) * 3 + pl)[f];
+            if (x >= 0 && x < W) a.params[pl][((size_t)r * W + x) * 7 + f] = buf[(r * 3 + pl) * 8 + f];
         }
     };
-    prefetch(0, tid, nth);
+    if (role == 3)
+    {
+        stage_load(0); stage_store(0); prefetch_rest(0, ctid, ncopy);
+        stage_load(1);
+    }
     // the state-transition table in LDS (a lookup in the __constant__ table is a vector memory load on the serial path)
     auto next_state = [&](int s, int bin) { return (int)sNext[s * 2 + bin]; };
     auto bin_ctx = [&](SaoEnt& e, int& ctx, int bin) { e.frac += sBits[ctx ^ bin]; ctx = next_state(ctx, bin); };
@@ -293,8 +361,12 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows_kernel(SaoRdoArgs a)
         long long bestCost = 0;
         if (role == 3)
         {
-            if (!(a.dbg & 2)) { if (t + 1 < W + H - 1) prefetch(t + 1, ctid, ncopy);
-            if (t > 0) flush(t - 1, ctid, ncopy); }
+            if (!(a.dbg & 2))
+            {
+                if (t + 1 < W + H - 1) { stage_store(t + 1); prefetch_rest(t + 1, ctid, ncopy); }
+                if (t + 2 < W + H - 1) stage_load(t + 2);
+                if (t > 0) flush(t - 1, ctid, ncopy);
+            }
         }
         else if (role && live && !(a.dbg & 1))
         {   // ---- a merge candidate's distortion (sao.cpp:1314-1335): the neighbour's parameters on THIS CTU's statistics ----
@@ -339,52 +411,40 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows_kernel(SaoRdoArgs a)
             if (allowU) bin_ctx(e, e.ctxMerge, 0);
             temp = e;
             long long rateDist = 0;
-            // A candidate's rate = (F + 32768 * bypassBins) >> 15 = bypassBins + (F >> 15), F = the fractional bits carried in + the cost of the
-            // context-coded sao_type_idx bin: its lambda share is precomputed per candidate (binsLambda), only (F >> 15) * lambda is added here.
-            // The chosen candidate then costs exactly its candidate's bins again (codeSaoOffset writes the same syntax, sao.cpp:1598-1600).
-            auto decide = [&](const long long* dist0, const long long* dist1, const long long* binsLambda, const int* nb, long long lambda, int& bestK)
+            // the type decision from the tables (see SaoCtuCand): c0 / c1 = the carries with the context-coded bin 0 / 1; SAO off costs
+            // (c0 * lambda + 128) >> 8 (sao.cpp:1491-1494), the tabulated winner takes over when it is cheaper; then Entropy::codeSaoOffset of
+            // the outcome on top of temp, no resetBits (:1598-1600, :1743-1750)
+            auto decide = [&](const long long* minCost, const uint8_t* minK, const int* nb, long long lambda)
             {
-                const uint32_t F = temp.frac & 32767, f0 = F + sBits[temp.ctxType], f1 = F + sBits[temp.ctxType ^ 1];
-                long long costBest = ((long long)(f0 >> 15) * lambda + 128) >> 8;          // sao_type_idx = 0 (sao.cpp:1491-1494)
-                const long long carry = (long long)(f1 >> 15) * lambda + 128;
-                bestK = -1;
-#pragma unroll
-                for (int k = 0; k < 5; k++)
-                {
-                    const long long cost = dist0[k] + (dist1 ? dist1[k] : 0) + ((binsLambda[k] + carry) >> 8);
-                    if (cost < costBest) { costBest = cost; bestK = k; }
-                }
-                // Entropy::codeSaoOffset of the winner on top of temp, no resetBits (sao.cpp:1598-1600, :1743-1750)
-                temp.frac += bestK < 0 ? sBits[temp.ctxType] : sBits[temp.ctxType ^ 1] + 32768u * (uint32_t)nb[bestK];
-                temp.ctxType = next_state(temp.ctxType, bestK >= 0);
+                const uint32_t F = temp.frac & 32767, b0 = sBits[temp.ctxType], b1 = sBits[temp.ctxType ^ 1];
+                const uint32_t c0 = (F + b0) >> 15, c1 = (F + b1) >> 15;
+                const long long costOff = ((long long)c0 * lambda + 128) >> 8;
+                int k = minK[c1];
+                if (!(minCost[c1] < costOff)) k = -1;
+                temp.frac += k < 0 ? b0 : b1 + 32768u * (uint32_t)nb[k];
+                temp.ctxType = next_state(temp.ctxType, k >= 0);
+                return k;
+            };
+            auto take = [&](SaoP& p, int pl, int k)
+            {
+                p.type = k; p.band = k == SAO_BO_T ? cd.boPos[pl] : 0;
+                const uint32_t w = *reinterpret_cast<const uint32_t*>(cd.off[pl][k]);
+                p.off[0] = (int8_t)(w & 0xff); p.off[1] = (int8_t)((w >> 8) & 0xff); p.off[2] = (int8_t)((w >> 16) & 0xff); p.off[3] = (int8_t)(w >> 24);
             };
             if (a.saoFlag[0])
             {   // saoLumaComponentParamDist (sao.cpp:1484-1610)
-                int bestK;
-                decide(cd.dist[0], nullptr, cd.binsLambdaY, cd.nbY, lamY, bestK);
-                if (bestK >= 0)
-                {
-                    mine[0].type = bestK; mine[0].band = bestK == SAO_BO_T ? cd.boPos[0] : 0;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) mine[0].off[i] = cd.off[0][bestK][i];
-                    rateDist = cd.quotY[bestK];
-                }
+                const int k = decide(cd.minCostY, cd.minKY, cd.nbY, lamY);
+                if (k >= 0) { take(mine[0], 0, k); rateDist = cd.quotY[k]; }
                 if (PLANES == 1) bestCost = rateDist + (temp.frac >> 15);
             }
             if (PLANES == 3 && a.saoFlag[1])
-            {   // saoChromaComponentParamDist (sao.cpp:1611-1760): Cb and Cr share the type, the rate counts both planes' syntax
-                int bestK;
-                decide(cd.dist[1], cd.dist[2], cd.binsLambdaC, cd.nbC, lamC, bestK);
-                if (bestK >= 0)
+            {   // saoChromaComponentParamDist (sao.cpp:1611-1760)
+                const int k = decide(cd.minCostC, cd.minKC, cd.nbC, lamC);
+                if (k >= 0)
                 {
 #pragma unroll
-                    for (int pl = 1; pl < PLANES; pl++)
-                    {
-                        mine[pl].type = bestK; mine[pl].band = bestK == SAO_BO_T ? cd.boPos[pl] : 0;
-#pragma unroll
-                        for (int i = 0; i < 4; i++) mine[pl].off[i] = cd.off[pl][bestK][i];
-                    }
-                    rateDist += cd.quotC[bestK];
+                    for (int pl = 1; pl < PLANES; pl++) take(mine[pl], pl, k);
+                    rateDist += cd.quotC[k];
                 }
                 bestCost = rateDist + (temp.frac >> 15);
             }
@@ -426,7 +486,7 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows_kernel(SaoRdoArgs a)
         }
         __syncthreads();                                       // the decisions of this step are in LDS
     }
-    flush(W + H - 2, tid, nth);
+    if (role == 3) flush(W + H - 2, ctid, ncopy);
     if (role == 0 && row < H) { if (noSao0) atomicAdd(&sNo[0], noSao0); if (noSao1) atomicAdd(&sNo[1], noSao1); }
     __syncthreads();
     if (tid < 2 && a.numNoSao) a.numNoSao[tid] = sNo[tid];
@@ -462,7 +522,11 @@ extern "C" int x265hip_sao_rdo(const x265hip_sao_rdo_params* p, void* stream)
     a.frac = p->frac_bits;
     a.dbg = getenv("X265HIP_SAO_RDO_DEBUG") ? atoi(getenv("X265HIP_SAO_RDO_DEBUG")) : 0;
     a.cand = (SaoCtuCand*)p->scratch; a.numNoSao = p->num_no_sao;
-    for (int i = 0; i < 128; i++) a.bits[i] = p->entropy_bits[i];
+    for (int i = 0; i < 128; i++)
+    {
+        a.bits[i] = p->entropy_bits[i];
+        if (a.bits[i] >= (uint32_t)(SAO_C - 1) * 32768u) { set_error("sao_rdo: entropy_bits[%d] = %u: more than %d bits for one bin", i, a.bits[i], SAO_C - 1); return X265HIP_EINVAL; }
+    }
     hipStream_t s = (hipStream_t)stream;
     const int nctu = p->ctus_w * p->ctus_h;
     if (!(a.dbg & 8)) hipLaunchKernelGGL(sao_rdo_prep_kernel, dim3(nctu), dim3(192), 0, s, a);
@@ -477,6 +541,7 @@ extern "C" int x265hip_sao_rdo(const x265hip_sao_rdo_params* p, void* stream)
         X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         ldsRaised = true;
     }
+    if (a.dbg & 16) return 0;
     if (p->planes == 3) hipLaunchKernelGGL(sao_rdo_rows_kernel<3>, dim3(1), dim3(threads), lds, s, a);
     else hipLaunchKernelGGL(sao_rdo_rows_kernel<1>, dim3(1), dim3(threads), lds, s, a);
     return check_hip(hipGetLastError(), "sao_rdo rows launch");
