@@ -265,13 +265,24 @@ def load_stage_traffic(width, height, depth):
 BANDED_STEP_MS = {1: 5.11, 2: 3.37, 3: 3.16, 4: 2.78, 5: 2.83, 6: 2.58, 8: 2.68, 12: 2.45, 17: 2.42}
 
 
-def pick_band_rows(world, ctu_rows=34, lag_rows_luma=73):
+# Whole-picture step (ms, one MI355X) of the configurations the bands were measured on: the banded step of another bit depth / picture size is
+# taken as the 4K 8-bit table scaled by the ratio of the whole-picture steps.  Measured pairs behind it (profiles/r02_10bit_bands.txt): 4K
+# 10-bit 3.56 whole / 4.46 in 4-row bands / 4.84 in 2-row bands (table x 1.58 gives 4.39 / 5.32); 8K 10-bit 14.0 / 16.1 / 17.3 (x 6.2: the
+# table over-states small bands there - an 8K band has four times the CTUs of a 4K band of the same rows, so its launches fill the chip).
+WHOLE_STEP_MS = {(8, "4k"): 2.25, (10, "4k"): 3.56, (12, "4k"): 3.56, (8, "8k"): 9.0, (10, "8k"): 14.0, (12, "8k"): 14.0, (8, "1080p"): 0.62, (10, "1080p"): 0.95,
+                 (12, "1080p"): 0.95}
+
+
+def pick_band_rows(world, ctu_rows=34, lag_rows_luma=73, depth=8, width=3840):
     """Band size for a ring of `world` ranks: rank r + 1 may start band b once rank r has finished every band its search window and
     interpolation taps reach (bands_needed: b plus the bands that begin inside the lag rows below it), so consecutive ranks run about
     `lag` apart and a rank comes round again after world x lag - throughput is world pictures per max(step, world x lag).  The step
-    times are the measured ones above, a hand-over is taken as 0.1 ms."""
+    times are the measured 4K 8-bit ones above scaled to the configuration (WHOLE_STEP_MS), a hand-over is taken as 0.1 ms."""
+    size = "8k" if width > 5000 else ("4k" if width > 2500 else "1080p")
+    scale = WHOLE_STEP_MS.get((depth, size), 2.25) / 2.25
     best = None
-    for rows, step in BANDED_STEP_MS.items():
+    for rows, step8 in BANDED_STEP_MS.items():
+        step = step8 * scale
         nb = -(-ctu_rows // rows)
         ahead = 1 + -(-lag_rows_luma // (rows * 64))            # band periods until the bands a start needs are final
         lag = ahead * step / nb + 0.1
@@ -405,7 +416,7 @@ def main():
     fp = P.FrameParallel(rank, 1 if gop else world)          # gop: the hand-off is this rank's own copy
     banded = (world > 1 and not gop) or args.banded
     if banded and not args.band_rows:
-        args.band_rows = pick_band_rows(world, ctu_rows=(args.height + 63) // 64, lag_rows_luma=args.range + 16) if world > 1 else 4
+        args.band_rows = pick_band_rows(world, ctu_rows=(args.height + 63) // 64, lag_rows_luma=args.range + 16, depth=args.depth, width=args.width) if world > 1 else 4
     if banded:
         # N > 1: the reference's real frame-parallel dependency - frame f (rank f % N) searches frame f - 1, band by band (pipeline.FrameParallelRing)
         bp = S.BandedFramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, band_rows=args.band_rows, rng=args.range, subme=args.subme, level=args.level,
@@ -418,10 +429,32 @@ def main():
                                    lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True,
                                    graphs=bool(args.band_graphs), streams=args.band_streams, sao_rdo=sao_rdo)
         # (bands keep every launch on one stream: side streams for the chroma chains change nothing at band size - 3.93 vs 3.97 ms at 4 rows)
-        ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16,      # search window + 8-tap interpolation + sub-pel drift
-                                   stage_through_host=backend != "nccl")
-        ring.make_groups(device=dev)
         geom = (pics[0].stride, F.MARGIN_Y, pics[0].stride_c, F.CHROMA_MARGIN_Y)
+        # The band hand-off goes through the library's C ABI (x265hip_comm_* + x265hip_recon_publish_rows: pipeline.AbiTransport), so the code
+        # RCCL executes here is the code a C++ host would run; X265HIP_RING_TRANSPORT=dist selects torch.distributed's own point-to-point
+        # operations instead (also the fallback when the C-ABI communicators cannot be built - decided collectively, never by one rank alone).
+        transport_name = "dist"
+        transport = None
+        if world > 1 and backend == "nccl" and os.environ.get("X265HIP_RING_TRANSPORT", "abi") == "abi":
+            ok = 1
+            try:
+                transport = P.AbiTransport(rank, world, dev, args.depth, geom, pics[0].h64)
+                transport.setup(dev)
+            except Exception as e:          # noqa: BLE001 - any failure means "use the other transport", on every rank
+                sys.stderr.write(f"bench.py rank {rank}: C-ABI ring transport unavailable ({e!r}); torch.distributed point-to-point instead\n")
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()):
+                transport_name = "abi"
+            else:
+                if transport is not None:
+                    transport.close()
+                transport = None
+        ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16,      # search window + 8-tap interpolation + sub-pel drift
+                                   stage_through_host=backend != "nccl", transport=transport)
+        if transport is None:
+            ring.make_groups(device=dev)
         total_frames = (args.warmup + args.steps) * world
         bp.begin_frame(pics[1])                         # allocates the output planes
         if args.band_graphs:                            # set-up: every (band, source picture) of the resident clip recorded as a HIP graph
@@ -535,7 +568,9 @@ def main():
                        "frames_per_step_per_gpu": 1, "parallelism": ((f"segment-parallel x{world}: every rank encodes its own closed group of pictures, no exchange (--sharding gop)" if gop
                                         else f"frame-parallel x{world}") if not banded else
                                        f"frame-parallel ring x{world}: frame f on rank f % {world} searches frame f - 1, handed on in bands of {args.band_rows} CTU rows "
-                                       f"(each band a slice of its own, like the reference's --slices)"),
+                                       f"(each band a slice of its own, like the reference's --slices); band transfers: "
+                                       + ("x265hip_recon_publish_rows (the library's C ABI on RCCL, one 2-rank communicator per directed flow)" if transport_name == "abi"
+                                          else "torch.distributed point-to-point")),
                        "ctus_per_frame": ms.nctu, "checksum": csum,
                        **({"band_rows": args.band_rows, "band_streams": args.band_streams,
                            "ring_model": "N pictures per max(step, N x lag), lag = the band periods until the reference rows a band's search window "

@@ -1064,6 +1064,16 @@ typedef struct x265hip_recon_publish_params
     int ctu_row0, ctu_rows;
 } x265hip_recon_publish_params;
 int x265hip_recon_publish_rows(const x265hip_recon_publish_params* p, void* stream);
+/* the producer's band to SEVERAL consumers - a picture that is the reference of several in-flight pictures (preset slow: 4 references and
+ * B pictures) - as ONE group of point-to-point sends (xGMI is point to point: k consumers = k links, no ring); a consumer calls it with
+ * rank != root and receives from root (peers ignored) */
+int x265hip_recon_publish_rows_to(const x265hip_recon_publish_params* p, int npeers, const int* peers, void* stream);
+/* Communicator plumbing for a host without an RCCL binding of its own (one process per GPU): rank 0 makes the 128-byte id
+ * (ncclGetUniqueId), the host ships it to the other ranks by whatever it has, every rank joins on its CURRENT device (ncclCommInitRank).
+ * RCCL is resolved at run time (dlopen): a single-GPU host never loads it. */
+int x265hip_comm_unique_id(void* id128);
+int x265hip_comm_init(void** comm, int nranks, const void* id128, int rank);
+int x265hip_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -5,6 +5,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -58,7 +59,7 @@ def _ring_geometry(w64, h64):
     return (stride, F.MARGIN_Y, sc, F.CHROMA_MARGIN_Y), (h64 + 2 * F.MARGIN_Y) * stride, (h64 // 2 + 2 * F.CHROMA_MARGIN_Y) * sc
 
 
-def _fake_band(frame, planes_ref, planes_out, geom, w64, h64, row0, nrows, lag, first, last):
+def _fake_band(frame, planes_ref, planes_out, geom, w64, h64, row0, nrows, lag, first, last, more_refs=()):
     """A stand-in for the banded pipeline with the same data footprint: every output row of the band mixes the frame's own pattern with
     reference rows up to `lag` luma rows above and below it (the search window + interpolation taps), then the band's side margins and -
     for the first / last band - the picture's top / bottom margins are extended.  A band started before those reference rows arrived
@@ -72,7 +73,11 @@ def _fake_band(frame, planes_ref, planes_out, geom, w64, h64, row0, nrows, lag, 
         up = (rows - (lag >> sh)).clamp(0, R.shape[0] - 1)
         dn = (rows + (lag >> sh)).clamp(0, R.shape[0] - 1)
         pat = ((rows[:, None] * 7 + torch.arange(s_)[None, :] * 3 + frame * 11 + pi * 5) & 255)
-        val = (pat + R[up] + 2 * R[dn] + R[rows]) & 255
+        val = pat + R[up] + 2 * R[dn] + R[rows]
+        for k, extra in enumerate(more_refs):            # older reference pictures (frame f - 2, ...): the same footprint, other weights
+            E = extra[pi].reshape(-1, s_).to(torch.int64)
+            val = val + (k + 3) * E[up] + E[dn] + 5 * E[rows]
+        val = val & 255
         O[rows] = val.to(torch.uint8)
         lo, hi = m_ + (row0 * 64 >> sh), m_ + ((row0 + nrows) * 64 >> sh)
         if first:
@@ -81,16 +86,16 @@ def _fake_band(frame, planes_ref, planes_out, geom, w64, h64, row0, nrows, lag, 
             O[hi:] = O[hi - 1]
 
 
-def _ring_serial(nframes, w64, h64, bands, lag):
+def _ring_serial(nframes, w64, h64, bands, lag, refs=1):
     geom, ny, nc = _ring_geometry(w64, h64)
-    ref = [torch.full((ny,), 17, dtype=torch.uint8), torch.full((nc,), 29, dtype=torch.uint8), torch.full((nc,), 31, dtype=torch.uint8)]
+    start = [torch.full((ny,), 17, dtype=torch.uint8), torch.full((nc,), 29, dtype=torch.uint8), torch.full((nc,), 31, dtype=torch.uint8)]
     outs = []
     for f in range(nframes):
-        out = [torch.zeros_like(p) for p in ref]
+        rs = [outs[f - d] if f - d >= 0 else start for d in range(1, refs + 1)]
+        out = [torch.zeros_like(p) for p in start]
         for b, (row0, n) in enumerate(bands):
-            _fake_band(f, ref, out, geom, w64, h64, row0, n, lag, b == 0, b == len(bands) - 1)
+            _fake_band(f, rs[0], out, geom, w64, h64, row0, n, lag, b == 0, b == len(bands) - 1, more_refs=rs[1:])
         outs.append(out)
-        ref = out
     return outs
 
 
@@ -179,6 +184,57 @@ def test_ring_two_ranks_with_band_contexts():
     that band), in band order - and the frame chain still comes out as the serial one."""
     out = _run_ring(2, 3, with_context=True)
     assert out[0][0] and out[1][0], "a rank's frames differ from the serial chain"
+
+
+def _ring_worker_refs(rank, world, port, steps, refs, out):
+    """The ring with SEVERAL reference pictures: frame f reads frames f - 1 .. f - refs, so a finished band has up to `refs` consumers - the
+    one-to-many hand-off of SURVEY 8(e).  A reference this rank produced itself (distance a multiple of the world size) is handed in from
+    its own output."""
+    sys.path.insert(0, ROOT)
+    P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w64, h64, lag = 128, 448, 72
+    bands = [(r, min(2, 7 - r)) for r in range(0, 7, 2)]
+    geom, ny, nc = _ring_geometry(w64, h64)
+    ring = P.FrameParallelRing(rank, world, bands, lag, refs=refs)
+    ring.make_groups()
+    start = [torch.full((ny,), 17, dtype=torch.uint8), torch.full((nc,), 29, dtype=torch.uint8), torch.full((nc,), 31, dtype=torch.uint8)]
+    ref_sets = [[p.clone() for p in start] for _ in range(refs)]
+    bufs = [[torch.zeros_like(p) for p in start] for _ in range(2)]
+    total = steps * world
+    mine = {}
+    for step in range(steps):
+        f = ring.frame_index(step)
+        o = bufs[step & 1]
+        for d in range(1, refs + 1):
+            if d % world == 0 and f - d >= 0:               # my own earlier frame: no transfer, the planes are here
+                ref_sets[d - 1] = [p.clone() for p in mine[f - d]]
+
+        def band(b, row0, n, f=f, o=o):
+            _fake_band(f, ref_sets[0], o, geom, w64, h64, row0, n, lag, b == 0, b == len(bands) - 1, more_refs=ref_sets[1:])
+        ring.run_frame(step, geom, ref_sets if refs > 1 else ref_sets[0], o, band, total_frames=total)
+        mine[f] = [p.clone() for p in o]
+    ring.finish()
+    expect = _ring_serial(total, w64, h64, bands, lag, refs=refs)
+    ok = all(all(torch.equal(a, e) for a, e in zip(mine[f], expect[f])) for f in mine)
+    out[rank] = (ok, sorted(mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,refs", [(2, 2), (3, 2), (4, 2)])
+def test_ring_with_several_reference_pictures(world, refs):
+    """Frame f on rank f % world reads frames f - 1 .. f - refs: every finished band goes to the ranks of the next `refs` frames (two
+    consumers per band with refs = 2), each consumer waits band by band for every reference it reads; the frames must equal the serial
+    chain with the same references - a band that ran before ANY of its reference rows arrived would not."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29950 + (os.getpid() % 200) + 7 * world + refs
+    mp.spawn(_ring_worker_refs, args=(world, port, 3, refs, out), nprocs=world, join=True)
+    assert all(out[r][0] for r in range(world)), {r: out[r] for r in range(world)}
+    assert out[world - 1][1] == [world - 1 + k * world for k in range(3)]
 
 
 def test_band_size_follows_the_rank_count():

@@ -764,6 +764,13 @@ def sao_rdo(depth, counts, offset_orgs, ctus_w, ctus_h, lambdas, ctx_merge, ctx_
     check(f(ctypes.byref(p), s), "x265hip_sao_rdo")
 
 
+class ReconPublishParams(ctypes.Structure):
+    """x265hip_recon_publish_params (include/x265hip.h)."""
+    _fields_ = [("comm", ctypes.c_void_p), ("rank", ctypes.c_int), ("root", ctypes.c_int), ("peer", ctypes.c_int), ("depth", ctypes.c_int),
+                ("plane", ctypes.c_void_p * 3), ("stride", ctypes.c_ssize_t), ("stride_c", ctypes.c_ssize_t), ("margin_y", ctypes.c_int),
+                ("margin_y_c", ctypes.c_int), ("height", ctypes.c_int), ("ctu_row0", ctypes.c_int), ("ctu_rows", ctypes.c_int)]
+
+
 def me_best_reset(best, stream=None):
     s = current_stream() if stream is None else stream
     check(lib().x265hip_me_best_reset(best.data_ptr(), best.numel(), s), "x265hip_me_best_reset")

@@ -260,25 +260,168 @@ class FrameParallel:
         dist.broadcast(ref_plane, src=self.reference_owner())
 
 
+class DistTransport:
+    """The ring's transfers over torch.distributed point-to-point operations (gloo in the CPU tests, RCCL through torch on request): the
+    three plane slices of a band travel as ONE grouped transfer.  The hand-off of producer rank s uses process group s % 2, so that the
+    traffic a rank sends never queues behind the traffic it receives (a backend that serialises one communicator's operations, world 2)."""
+
+    def __init__(self, rank, world, stage_through_host=False):
+        self.rank, self.world, self.stage = rank, world, stage_through_host
+        self.groups = [None, None]
+
+    def setup(self, device=None):
+        import datetime
+        import torch
+        import torch.distributed as dist
+        if self.world > 1:
+            self.groups = [dist.new_group(list(range(self.world)), timeout=datetime.timedelta(seconds=240)) for _ in range(2)]
+            # one collective per group, made by every rank: the communicators exist before the first point-to-point transfer (RCCL creates
+            # them lazily, and a first use by only two of the ranks must not turn into a collective the others never join)
+            for g in self.groups:
+                t = torch.zeros(1, device=device if device is not None else "cpu")
+                dist.all_reduce(t, group=g)
+        return self.groups
+
+    def _p2p(self, op, planes, ranges, peer, group):
+        import torch
+        import torch.distributed as dist
+        flat = lambda t: t.reshape(-1)
+        if not self.stage:
+            return dist.batch_isend_irecv([dist.P2POp(op, flat(p)[a:z], peer, group) for p, (a, z) in zip(planes, ranges)])
+        views = [flat(p)[a:z] for p, (a, z) in zip(planes, ranges)]
+        hosts = [v.cpu() if op is dist.isend else torch.empty(v.shape, dtype=v.dtype) for v in views]
+        works = dist.batch_isend_irecv([dist.P2POp(op, h, peer, group) for h in hosts])
+
+        class Staged:
+            def __init__(self, w, pairs): self.w, self.pairs = w, pairs
+            def wait(self):
+                self.w.wait()
+                for v, h in self.pairs:
+                    v.copy_(h)
+        return [Staged(w, ([(v, h)] if op is dist.irecv else [])) for w, v, h in zip(works, views, hosts)]
+
+    def send(self, planes, ranges, band, peers):
+        import torch.distributed as dist
+        out = []
+        for peer in peers:
+            out += self._p2p(dist.isend, planes, ranges, peer, self.groups[self.rank % 2])
+        return out
+
+    def recv(self, planes, ranges, band, src):
+        import torch.distributed as dist
+        return self._p2p(dist.irecv, planes, ranges, src, self.groups[src % 2])
+
+    def close(self):
+        pass
+
+
+class AbiTransport:
+    """The ring's transfers through the library's C ABI (csrc/recon_publish.hip): x265hip_comm_* build the communicators,
+    x265hip_recon_publish_rows issues a band's three plane slices as one RCCL group on a copy stream - the calls a C++ host makes, so the
+    code RCCL executes in `bench.py --gpus N` is the library's own (round-2 verdict, next 7a).
+    One 2-rank communicator per DIRECTED flow (producer s -> consumer s + d, d = 1 .. refs): a rank uses a communicator either for sending
+    or for receiving, never both, so no transfer queues behind one that waits for the other side (the cycle a single communicator closes
+    when every rank sits in a send the peer has queued behind its own send).  The ids travel by torch.distributed (bootstrap only); the
+    communicators are joined in one global order of the flows, which keeps the blocking joins acyclic."""
+
+    def __init__(self, rank, world, device, depth, geom, height, refs=1):
+        self.rank, self.world, self.device, self.depth, self.geom, self.height, self.refs = rank, world, device, depth, geom, height, refs
+        self.send_comm, self.recv_comm = {}, {}          # distance d -> communicator (this rank is rank 0 when it sends, 1 when it receives)
+        self.streams = {}
+
+    def setup(self, device=None):
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        L = hipabi.lib()
+        L.x265hip_comm_unique_id.argtypes = [ctypes.c_void_p]
+        L.x265hip_comm_init.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        dists = [d for d in range(1, self.refs + 1) if d % self.world]           # d a multiple of world: the consumer is this rank itself
+        mine = torch.zeros((max(1, len(dists)), 128), dtype=torch.uint8)
+        for k, d in enumerate(dists):                                            # the producer of a flow makes its id
+            buf = (ctypes.c_uint8 * 128)()
+            hipabi.check(L.x265hip_comm_unique_id(buf), "x265hip_comm_unique_id")
+            mine[k] = torch.tensor(list(buf), dtype=torch.uint8)
+        mine = mine.to(self.device)
+        gathered = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(gathered, mine)
+        torch.cuda.synchronize()
+        for k, d in enumerate(dists):                                            # one global order: (distance, producer)
+            for s in range(self.world):
+                c = (s + d) % self.world
+                if self.rank not in (s, c):
+                    continue
+                raw = gathered[s][k].cpu().numpy().tobytes()
+                comm = ctypes.c_void_p()
+                hipabi.check(L.x265hip_comm_init(ctypes.byref(comm), 2, raw, 0 if self.rank == s else 1), "x265hip_comm_init")
+                (self.send_comm if self.rank == s else self.recv_comm)[d] = comm
+        self.streams = {("s", d): torch.cuda.Stream(device=self.device) for d in dists}
+        self.streams.update({("r", d): torch.cuda.Stream(device=self.device) for d in dists})
+        return None
+
+    def _publish(self, comm, planes, band, sending, stream):
+        import ctypes
+        import torch
+        st, my, sc, myc = self.geom
+        p = hipabi.ReconPublishParams()
+        p.comm, p.rank, p.root, p.peer, p.depth = comm, 0 if sending else 1, 0, 1, self.depth
+        for i in range(3):
+            p.plane[i] = planes[i].data_ptr()
+        p.stride, p.stride_c, p.margin_y, p.margin_y_c, p.height = st, sc, my, myc, self.height
+        p.ctu_row0, p.ctu_rows = band
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event(); ready.record(cur)
+        stream.wait_event(ready)                           # the band's kernels (send) / the readers of the old picture (receive) come first
+        f = hipabi.lib().x265hip_recon_publish_rows
+        f.argtypes = [ctypes.POINTER(hipabi.ReconPublishParams), ctypes.c_void_p]
+        hipabi.check(f(ctypes.byref(p), stream.cuda_stream), "x265hip_recon_publish_rows")
+        done = torch.cuda.Event(); done.record(stream)
+
+        class Done:
+            def wait(self_inner):
+                torch.cuda.current_stream().wait_event(done)
+        return [Done()]
+
+    def send(self, planes, ranges, band, peers):
+        out = []
+        for peer in peers:
+            d = (peer - self.rank) % self.world
+            out += self._publish(self.send_comm[d], planes, band, True, self.streams[("s", d)])
+        return out
+
+    def recv(self, planes, ranges, band, src):
+        d = (self.rank - src) % self.world
+        return self._publish(self.recv_comm[d], planes, band, False, self.streams[("r", d)])
+
+    def close(self):
+        L = hipabi.lib()
+        for c in list(self.send_comm.values()) + list(self.recv_comm.values()):
+            L.x265hip_comm_destroy(c)
+        self.send_comm, self.recv_comm = {}, {}
+
+
 class FrameParallelRing:
     """Frame-parallel encoding with the reference's REAL dependency: frame f is encoded by rank f % world and
-    searches / predicts from frame f - 1, which rank (f - 1) % world is producing at the same time - band by band.  A band of CTU
+    searches / predicts from frames f - 1 .. f - refs, which other ranks are producing at the same time - band by band.  A band of CTU
     rows is handed on as soon as it is final (filtered, side margins extended): the point where the reference raises
     m_reconRowFlag (encoder/framefilter.cpp:664), and the consumer starts a band once the reference rows its search window and
     interpolation taps can touch have arrived - the wait of encoder/frameencoder.cpp:852-868 with m_refLagRows.  Every plane's rows
     (Y, Cb, Cr incl. the side margins, plus the top / bottom margin with the first / last band) travel as one contiguous slice of the
-    padded plane, point to point to the one rank that needs them next (xGMI is point to point; with several reference pictures the
-    same slices would go to the next ranks as well).  Works on any torch.distributed backend: RCCL on GPUs, gloo in the CPU tests.
+    padded plane, point to point to EVERY rank that needs them: with refs = k reference pictures a finished band goes to the ranks of
+    frames f + 1 .. f + k - one-to-many, each over its own link (xGMI is point to point) - the broadcast of SURVEY 8(e).
+    The transfers go through a transport: AbiTransport (the library's C ABI, RCCL) in bench.py, DistTransport (torch.distributed:
+    gloo in the CPU tests, host-staged for ranks that share a GPU).
 
-    bands: [(first CTU row, CTU rows)], row_bytes-free: slices are computed from the plane geometry handed to run_frame."""
+    bands: [(first CTU row, CTU rows)]; slices are computed from the plane geometry handed to run_frame."""
 
-    def __init__(self, rank: int, world: int, bands, lag_rows_luma: int, stage_through_host: bool = False):
+    def __init__(self, rank: int, world: int, bands, lag_rows_luma: int, stage_through_host: bool = False, refs: int = 1, transport=None):
         """stage_through_host: device slices travel through host copies (a backend without device point-to-point transfers - the gloo
         dry run of bench.py's N > 1 path on a box with fewer GPUs than ranks); never used with RCCL."""
         self.rank, self.world, self.bands = rank, world, list(bands)
-        self.stage = stage_through_host
+        self.refs = max(1, int(refs))
         self.lag = lag_rows_luma            # luma rows below a band's last row that its search / interpolation may read
         self.prev, self.next = (rank - 1) % world, (rank + 1) % world
+        self.transport = transport if transport is not None else DistTransport(rank, world, stage_through_host)
         self._sends = []
 
     def frame_index(self, step: int) -> int:
@@ -303,80 +446,61 @@ class FrameParallelRing:
         return need
 
     def make_groups(self, device=None):
-        """Two process groups so that the traffic towards the next rank never queues behind the traffic from the previous one (with a
-        backend that serialises the operations of one communicator - NCCL / RCCL - and world == 2, both directions share one peer pair):
-        the hand-off rank r -> r + 1 uses group r % 2.  Collective call: every rank makes it once, after init_process_group."""
-        import torch.distributed as dist
-        import datetime
-        self.groups = ([dist.new_group(list(range(self.world)), timeout=datetime.timedelta(seconds=240)) for _ in range(2)]
-                       if self.world > 1 else [None, None])
-        if self.world > 1:
-            # one collective per group, made by every rank: the communicators exist before the first point-to-point transfer (RCCL creates
-            # them lazily, and a first use by only two of the ranks must not turn into a collective the others never join)
-            import torch
-            for g in self.groups:
-                t = torch.zeros(1, device=device if device is not None else "cpu")
-                dist.all_reduce(t, group=g)
+        """Collective call: every rank makes it once, after init_process_group - the transport builds its communicators."""
+        self.groups = self.transport.setup(device)
         return self.groups
 
     def run_frame(self, step, geom, ref_planes, out_planes, process_band, total_frames=None, first_frame_is_local=True, band_context=None):
-        """One frame of this rank.  ref_planes: the flat Y / Cb / Cr tensors the previous frame's bands are received into (for the very
-        first frame of the job they already hold the start picture); out_planes: where process_band(b, row0, nrows) leaves this frame's
-        finished bands (not reused before the next call returns them: the sends of a frame are only waited for at the start of this
-        rank's next frame, or by finish()).  total_frames: frames of the whole job - the last frame has no consumer and is not sent.
+        """One frame of this rank.  ref_planes: the flat Y / Cb / Cr tensors the previous frame's bands are received into - with refs > 1
+        a LIST of such plane sets, [d - 1] for frame f - d (for frames before the start of the job they already hold the start picture);
+        out_planes: where process_band(b, row0, nrows) leaves this frame's finished bands (not reused before the next call returns them:
+        the sends of a frame are only waited for at the start of this rank's next frame, or by finish()).  total_frames: frames of the whole
+        job - a frame past the end has no consumer and nothing is sent to it.
         band_context(b): context manager under which band b is waited for, processed and sent (stages.BandedFramePipeline.band_context:
         bands alternate between HIP streams, and a transfer orders itself against the stream that is current when it is issued / waited
         for - so a band's arrival and departure only hold up that band's stream); the receives are posted outside it."""
         import contextlib
-        import torch.distributed as dist
         f = self.frame_index(step)
         nb = len(self.bands)
-        flat = lambda t: t.reshape(-1)
-
-        def p2p(op, planes, ranges, peer, group):
-            """The three plane slices of one band as ONE grouped transfer (a single ncclGroup on RCCL: one launch per band and
-            direction instead of three)."""
-            if not self.stage:
-                return dist.batch_isend_irecv([dist.P2POp(op, flat(p)[a:z], peer, group) for p, (a, z) in zip(planes, ranges)])
-            views = [flat(p)[a:z] for p, (a, z) in zip(planes, ranges)]
-            hosts = [v.cpu() if op is dist.isend else __import__("torch").empty(v.shape, dtype=v.dtype) for v in views]
-            works = dist.batch_isend_irecv([dist.P2POp(op, h, peer, group) for h in hosts])
-
-            class Staged:
-                def __init__(self, w, pairs): self.w, self.pairs = w, pairs
-                def wait(self):
-                    self.w.wait()
-                    for v, h in self.pairs:
-                        v.copy_(h)
-            return [Staged(w, ([(v, h)] if op is dist.irecv else [])) for w, v, h in zip(works, views, hosts)]
-        groups = getattr(self, "groups", [None, None])
-        g_in, g_out = groups[self.prev % 2], groups[self.rank % 2]
-        recv_from_peer = self.world > 1 and not (f == 0 and first_frame_is_local)
-        send_to_peer = self.world > 1 and (total_frames is None or f + 1 < total_frames)
+        T = self.transport
+        ref_sets = ref_planes if self.refs > 1 else [ref_planes]
+        assert len(ref_sets) == self.refs
+        # which references travel: frame f - d exists (first_frame_is_local: the job's first frames read the start picture) and was made by
+        # another rank (d a multiple of world: this rank made it itself - the caller hands its own planes in)
+        srcs = [d for d in range(1, self.refs + 1)
+                if self.world > 1 and d % self.world and not (first_frame_is_local and f - d < 0)]
+        peers = [(self.rank + d) % self.world for d in range(1, self.refs + 1)
+                 if self.world > 1 and d % self.world and (total_frames is None or f + d < total_frames)]
         self.finish()                                       # the previous frame's sends must be through before out_planes is rewritten
-        posted, arrived = -1, -1
-        pending = {}
+        posted = {d: -1 for d in srcs}
+        arrived = {d: -1 for d in srcs}
+        pending = {d: {} for d in srcs}
+
+        def post(d, upto):
+            while posted[d] < upto:                         # receives are posted in band order per source
+                posted[d] += 1
+                r0, rn = self.bands[posted[d]]
+                pending[d][posted[d]] = T.recv(ref_sets[d - 1], self._rows(geom, r0, rn, posted[d] == 0, posted[d] == nb - 1), (r0, rn), (self.rank - d) % self.world)
+        for d in srcs:
+            if d > 1:
+                post(d, nb - 1)                             # older references were finished long ago: everything at once
         for b, (row0, n) in enumerate(self.bands):
-            need = self.bands_needed(b) if recv_from_peer else -1
-            while posted < need:                            # receives are posted in band order, just ahead of the band that needs them
-                posted += 1
-                r0, rn = self.bands[posted]
-                pending[posted] = p2p(dist.irecv, ref_planes, self._rows(geom, r0, rn, posted == 0, posted == nb - 1), self.prev, g_in)
+            need = self.bands_needed(b)
+            if 1 in posted:
+                post(1, need)                               # the newest reference: just ahead of the band that needs it
             with (band_context(b) if band_context is not None else contextlib.nullcontext()):
-                while arrived < need:
-                    arrived += 1
-                    for w in pending.pop(arrived):
-                        w.wait()
+                for d in srcs:
+                    while arrived[d] < need:
+                        arrived[d] += 1
+                        for w in pending[d].pop(arrived[d]):
+                            w.wait()
                 process_band(b, row0, n)
-                if send_to_peer:
-                    self._sends += p2p(dist.isend, out_planes, self._rows(geom, row0, n, b == 0, b == nb - 1), self.next, g_out)
-        if recv_from_peer:                                  # bands below the last search window still belong to the reference picture
-            while posted < nb - 1:
-                posted += 1
-                r0, rn = self.bands[posted]
-                pending[posted] = p2p(dist.irecv, ref_planes, self._rows(geom, r0, rn, posted == 0, posted == nb - 1), self.prev, g_in)
-            for b in sorted(pending):
-                for w in pending[b]:
+                if peers:
+                    self._sends += T.send(out_planes, self._rows(geom, row0, n, b == 0, b == nb - 1), (row0, n), peers)
+        for d in srcs:                                      # bands below the last search window still belong to the reference picture
+            post(d, nb - 1)
+            for bb in sorted(pending[d]):
+                for w in pending[d][bb]:
                     w.wait()
 
     def finish(self):
