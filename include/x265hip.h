@@ -869,13 +869,15 @@ typedef struct x265hip_me_cache_params
 typedef struct x265hip_me_cache_stats_t
 {
     uint64_t fills, failed, batches;
-    uint64_t us_upload, us_kernel, us_download;     /* summed over the batches, worker-thread wall time (us_kernel includes the uploads) */
+    uint64_t us_upload, us_kernel, us_download;     /* summed over the batches, worker-thread wall time: us_upload = the source pictures' uploads, us_kernel = uploads + searches */
     uint64_t bytes_downloaded, surface_bytes;
 } x265hip_me_cache_stats_t;
 int  x265hip_me_cache_create(x265hip_me_cache** out, const x265hip_me_cache_params* p);
 void x265hip_me_cache_destroy(x265hip_me_cache* c);
 /* copies both planes, queues upload + search + row-streamed download on the cache's worker thread, returns the slot's new
- * GENERATION (> 0) at once, or a negative error */
+ * GENERATION (> 0) at once, or a negative error.  fenc_key names the source picture: it is copied once per key, and every queued pair
+ * keeps ITS source until the worker has searched it - pairs of several source pictures may be queued back to back without waiting
+ * (frame threads); X265HIP_EBUSY only when 64 source pictures are waiting for the worker */
 int  x265hip_me_cache_submit(x265hip_me_cache* c, int slot, const void* fenc_buf, uint64_t fenc_key, const void* ref_buf);
 /* the references of one source picture as ONE batch: searched back to back, surfaces downloaded row-interleaved across the pairs
  * (row 0 of every pair first - the order a wavefront-parallel encoder needs them); generations[i] = slot i's new generation */

@@ -80,6 +80,53 @@ def test_me_cache_surfaces_equal_oracle(depth, width, height, rng, fmt):
         prov.close()
 
 
+def test_me_cache_pairs_of_two_source_pictures_queued_back_to_back_keep_their_own_source():
+    """Round-2 advice: submits of the NEXT source picture must not replace the samples a queued pair of the previous one still has to upload.
+    Four pairs of three source pictures go in without waiting for any of them; each surface must be the one of ITS (source, reference)."""
+    from tools import seam_driver as SD
+    O = _oracle()
+    depth, width, height, rng = 8, 256, 192, 12
+    geo = SD.geometry(width, height)
+    prov = SD.GpuProvider(depth, geo, rng, 4, 1)
+    try:
+        clip = F.synth_clip(width, height, 5, depth=depth, seed=57)
+        planes = [F.pad_plane(y)[0] for (y, _, _) in clip]
+        org = geo["margin_y"] * geo["stride"] + geo["margin_x"]
+        L = prov.L
+        L.x265hip_me_cache_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        L.x265hip_me_cache_surface.restype = ctypes.c_void_p
+        L.x265hip_me_cache_surface.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.x265hip_me_cache_ready.restype = ctypes.c_void_p
+        L.x265hip_me_cache_ready.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        nctu, rows, nc = (geo["width"] // 64) * (geo["height"] // 64), geo["height"] // 64, 2 * rng + 1
+        ng = (nc + 3) // 4
+        pairs = [(1, 0), (2, 1), (2, 0), (3, 2)]                 # (source, reference): three source pictures, the middle one twice
+        gens = []
+        for slot, (cur, ref) in enumerate(pairs):                # a fresh copy per call: the caller's buffers need not outlive it
+            a, b = planes[cur].copy(), planes[ref].copy()
+            gens.append(L.x265hip_me_cache_submit(prov.handle, slot, a.ctypes.data, 100 + cur, b.ctypes.data))
+            a[:] = 0; b[:] = 0
+        assert all(g > 0 for g in gens)
+        zero = np.zeros(nc, np.uint16)
+        for slot, (cur, ref) in enumerate(pairs):
+            flags = np.ctypeslib.as_array((ctypes.c_int * rows).from_address(L.x265hip_me_cache_ready(prov.handle, slot)))
+            t0 = time.time()
+            while not (flags == gens[slot]).all():
+                assert time.time() - t0 < 60, "surfaces never arrived"
+                time.sleep(0.002)
+            surf, _ = O.me_fullsearch(depth, planes[cur], geo["stride"], org, planes[ref], geo["stride"], org, geo["width"], geo["height"], rng,
+                                      0, nctu, zero, zero, want_surf=True, want_best=False)
+            e = surf.reshape(nctu, nc, ng, 85, 4).transpose(0, 1, 2, 4, 3).reshape(nctu, nc, ng * 4, 85)[:, :, :nc, :]
+            raw = np.ctypeslib.as_array((ctypes.c_uint8 * (nctu * nc * ng * 720)).from_address(L.x265hip_me_cache_surface(prov.handle, slot))).reshape(nctu, nc, ng, 720)
+            g8 = raw[..., 0:512].copy().view(np.uint16).reshape(nctu, nc, ng, 64, 4).transpose(0, 1, 2, 4, 3).reshape(nctu, nc, ng * 4, 64)[:, :, :nc, :]
+            g32 = raw[..., 640:720].copy().view(np.int32).reshape(nctu, nc, ng, 5, 4).transpose(0, 1, 2, 4, 3).reshape(nctu, nc, ng * 4, 5)[:, :, :nc, :]
+            assert np.array_equal(g8, e[..., 0:64]) and np.array_equal(g32, e[..., 80:85]), f"pair {slot}: surfaces of another source picture"
+        rep = prov.report()
+        assert rep["fills"] == 4 and rep["failed"] == 0
+    finally:
+        prov.close()
+
+
 @pytest.mark.parametrize("depth,preset,extra,fmt", [(8, "medium", [], None), (8, "slow", [("me", "star")], None), (8, "slower", [], None), (10, "medium", [], None),
                                                     (8, "slow", [("me", "star")], 2), (8, "slower", [], 2)])
 def test_seam_encode_on_gpu_surfaces_is_byte_identical(depth, preset, extra, fmt):

@@ -32,8 +32,11 @@ struct x265hip_me_cache
     void* dFenc = nullptr; void* dRef = nullptr;
     uint64_t fencKeyOnDevice = ~0ull;
     hipStream_t stream = nullptr;
-    uint8_t* stageFenc = nullptr;          // pinned copy of the last submitted source picture (shared by the pairs of a picture)
-    uint64_t stageFencKey = ~0ull;
+    // Pinned copies of the submitted SOURCE pictures: one per source picture that still has queued pairs (shared by the pairs of a picture,
+    // counted by them), so that a submit of the next picture never replaces samples a queued pair has yet to upload.  Grown on demand.
+    struct FencStage { uint8_t* buf = nullptr; uint64_t key = ~0ull; int users = 0; uint64_t stamp = 0; };
+    std::vector<FencStage> fencStages;
+    uint64_t fencStamp = 0;
     std::mutex stageMu;
     struct Slot
     {
@@ -43,11 +46,10 @@ struct x265hip_me_cache
                                            //   need not outlive the call)
         std::vector<hipEvent_t> rowEvents;
         std::atomic<int>* ready = nullptr; // per CTU row
-        uint64_t fencKey = 0;
         std::atomic<int> generation{0};
     };
     std::vector<Slot> slots;
-    struct Job { int slot; int generation; };
+    struct Job { int slot; int generation; int fencStage; uint64_t fencKey; };      // the source travels WITH the job (copied under mu)
     std::deque<Job> queue;
     std::mutex mu;
     std::condition_variable cv;
@@ -76,12 +78,15 @@ int run_batch(x265hip_me_cache* c, const std::vector<x265hip_me_cache::Job>& bat
     for (const auto& job : batch)
     {
         x265hip_me_cache::Slot& s = c->slots[job.slot];
-        if (c->fencKeyOnDevice != s.fencKey)
+        if (c->fencKeyOnDevice != job.fencKey)
         {
-            std::lock_guard<std::mutex> lk(c->stageMu);
-            X265HIP_TRY(hipMemcpyAsync(c->dFenc, c->stageFenc, c->planeBytes, hipMemcpyHostToDevice, c->stream));
-            X265HIP_TRY(hipStreamSynchronize(c->stream));          // the staging copy may be replaced once this returns
-            c->fencKeyOnDevice = s.fencKey;
+            const uint8_t* src;
+            { std::lock_guard<std::mutex> lk(c->stageMu); src = c->fencStages[job.fencStage].buf; }      // the vector may grow under a submit
+            const double u0 = now_us();
+            X265HIP_TRY(hipMemcpyAsync(c->dFenc, src, c->planeBytes, hipMemcpyHostToDevice, c->stream));    // stream order: after the searches
+            X265HIP_TRY(hipStreamSynchronize(c->stream));                                                   //   that still read the old source
+            c->usUpload += (uint64_t)(now_us() - u0);
+            c->fencKeyOnDevice = job.fencKey;
         }
         X265HIP_TRY(hipMemcpyAsync(c->dRef, s.stageRef, c->planeBytes, hipMemcpyHostToDevice, c->stream));
         x265hip_me_params p;
@@ -124,7 +129,7 @@ void worker_main(x265hip_me_cache* c)
 {
     for (;;)
     {
-        std::vector<x265hip_me_cache::Job> batch;
+        std::vector<x265hip_me_cache::Job> batch, dropped;
         {
             std::unique_lock<std::mutex> lk(c->mu);
             c->cv.wait(lk, [c] { return c->stop || !c->queue.empty(); });
@@ -133,14 +138,20 @@ void worker_main(x265hip_me_cache* c)
             {
                 const x265hip_me_cache::Job job = c->queue.front();
                 c->queue.pop_front();
-                if (c->slots[job.slot].generation.load() == job.generation)      // else: superseded before it ran
-                    batch.push_back(job);
+                if (c->slots[job.slot].generation.load() == job.generation) batch.push_back(job);
+                else dropped.push_back(job);                                          // superseded before it ran
             }
         }
         if (!batch.empty() && run_batch(c, batch))
         {
             c->failed += batch.size();
             snprintf(c->workerError, sizeof(c->workerError), "%s", x265hip_last_error());
+        }
+        if (!batch.empty() || !dropped.empty())
+        {
+            std::lock_guard<std::mutex> lk(c->stageMu);          // the pairs are done with (or never needed) their source picture's staging copy
+            for (const auto& j : batch) c->fencStages[j.fencStage].users--;
+            for (const auto& j : dropped) c->fencStages[j.fencStage].users--;
         }
     }
 }
@@ -155,7 +166,7 @@ void free_all(x265hip_me_cache* c)
         for (hipEvent_t e : s.rowEvents) if (e) (void)hipEventDestroy(e);
         delete[] s.ready;
     }
-    if (c->stageFenc) (void)hipHostFree(c->stageFenc);
+    for (auto& f : c->fencStages) if (f.buf) (void)hipHostFree(f.buf);
     if (c->dFenc) (void)hipFree(c->dFenc);
     if (c->dRef) (void)hipFree(c->dRef);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -198,7 +209,8 @@ int x265hip_me_cache_create(x265hip_me_cache** out, const x265hip_me_cache_param
     MC_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     MC_TRY(hipMalloc(&c->dFenc, c->planeBytes));
     MC_TRY(hipMalloc(&c->dRef, c->planeBytes));
-    MC_TRY(hipHostMalloc((void**)&c->stageFenc, c->planeBytes, hipHostMallocDefault));
+    c->fencStages.resize(2);
+    for (auto& f : c->fencStages) MC_TRY(hipHostMalloc((void**)&f.buf, c->planeBytes, hipHostMallocDefault));
     c->slots = std::vector<x265hip_me_cache::Slot>(p->slots);
     for (auto& s : c->slots)
     {
@@ -237,13 +249,30 @@ int x265hip_me_cache_submit_batch(x265hip_me_cache* c, int n, const int* slots, 
     if (!c || n < 1 || !slots || !fenc_buf || !ref_bufs || !generations) { set_error("me_cache_submit_batch: bad argument"); return X265HIP_EINVAL; }
     for (int i = 0; i < n; i++)
         if (slots[i] < 0 || slots[i] >= (int)c->slots.size() || !ref_bufs[i]) { set_error("me_cache_submit_batch: bad slot / plane %d", i); return X265HIP_EINVAL; }
+    int stage = -1;
     {
+        // the source picture's staging copy: the one that already holds this key, else the least recently used copy no queued pair counts
+        // on, else a new one (two source pictures in flight is the normal case under frame threads; more only when the worker is behind)
         std::lock_guard<std::mutex> lk(c->stageMu);
-        if (c->stageFencKey != fenc_key)
+        for (size_t k = 0; k < c->fencStages.size(); k++)
+            if (c->fencStages[k].key == fenc_key) stage = (int)k;
+        if (stage < 0)
         {
-            memcpy(c->stageFenc, fenc_buf, c->planeBytes);
-            c->stageFencKey = fenc_key;
+            for (size_t k = 0; k < c->fencStages.size(); k++)
+                if (c->fencStages[k].users == 0 && (stage < 0 || c->fencStages[k].stamp < c->fencStages[stage].stamp)) stage = (int)k;
+            if (stage < 0)
+            {
+                if (c->fencStages.size() >= 64) { set_error("me_cache_submit_batch: 64 source pictures are waiting for the worker"); return X265HIP_EBUSY; }
+                x265hip_me_cache::FencStage f;
+                if (ensure_device() || check_hip(hipHostMalloc((void**)&f.buf, c->planeBytes, hipHostMallocDefault), "hipHostMalloc(source staging)")) return X265HIP_ENODEV;
+                c->fencStages.push_back(f);
+                stage = (int)c->fencStages.size() - 1;
+            }
+            memcpy(c->fencStages[stage].buf, fenc_buf, c->planeBytes);
+            c->fencStages[stage].key = fenc_key;
         }
+        c->fencStages[stage].users += n;
+        c->fencStages[stage].stamp = ++c->fencStamp;
     }
     std::vector<x265hip_me_cache::Job> jobs;
     for (int i = 0; i < n; i++)
@@ -251,9 +280,8 @@ int x265hip_me_cache_submit_batch(x265hip_me_cache* c, int n, const int* slots, 
         x265hip_me_cache::Slot& s = c->slots[slots[i]];
         const int gen = s.generation.fetch_add(1) + 1;          // readers compare ready[row] with the generation they were handed
         memcpy(s.stageRef, ref_bufs[i], c->planeBytes);
-        s.fencKey = fenc_key;
         generations[i] = gen;
-        jobs.push_back({ slots[i], gen });
+        jobs.push_back({ slots[i], gen, stage, fenc_key });
     }
     {
         std::lock_guard<std::mutex> lk(c->mu);
