@@ -144,15 +144,27 @@ __device__ __forceinline__ int la_sample(const Px* nb, int mode, int dc, int max
     return ((32 - frac) * p0 + frac * ref(off + c + 1) + 16) >> 5;
 }
 
+// LookaheadTLD::lowresIntraEstimate (slicetype.cpp:718-805) for the 8x8 blocks of the half-resolution picture.  The reference walks
+// twelve modes one after the other (DC, planar, angular 5 .. 30 in steps of 5, then +-2 and +-1 around the best angular mode); here the
+// modes of a block are evaluated SIDE BY SIDE: a block has 32 lanes = 8 mode slots x the 4 tiles (4x4) of the block, and two rounds -
+//   round 1: DC, planar and the six coarse angular modes, one per slot;
+//   round 2: the six modes a - 3 .. a + 3 (a = the coarse winner) the two refinement steps can ever look at (the +-1 step starts from
+//            a - 2, a or a + 2), one per slot, two slots idle;
+// the winners are then picked in the reference's order with its strict-less comparisons, so ties fall the same way.  Fourteen mode costs
+// instead of twelve, but a dependent chain of two instead of twelve and eight times the lanes: the sequential organisation (one lane
+// per tile, 507 workgroups at 4K) ran 110 us with two wavefronts per SIMD waiting on each other's LDS reads
+// (profiles/r02_bench_final_pmc.txt), this one is in profiles/r03_*.
 template <typename Px>
 __global__ void __launch_bounds__(256) lowres_intra_kernel(LowresIntraArgs a)
 {
     constexpr int BPP = sizeof(Px);
-    __shared__ Px nbS[64][36], nbF[64][36];
+    __shared__ Px nbS[8][36], nbF[8][36];
+    __shared__ int16_t extS[8][8][28];
     const int tid = threadIdx.x;
-    const int bw = tid >> 2, tile = tid & 3;                         // block within the workgroup, 4x4 tile within the block
+    const int tile = tid & 3, slot = (tid >> 2) & 7, bw = tid >> 5;      // 4x4 tile within the block, mode slot, block within the workgroup
+    const int l32 = tid & 31;
     const int ncu = a.widthInCU * a.heightInCU;
-    const int cuXY = blockIdx.x * 64 + bw;
+    const int cuXY = blockIdx.x * 8 + bw;
     const bool live = cuXY < ncu;
     const int cuX = live ? cuXY % a.widthInCU : 0, cuY = live ? cuXY / a.widthInCU : 0;
     const Px* pix = reinterpret_cast<const Px*>(a.plane + (long)(8 * cuY) * a.strideB) + 8 * cuX;
@@ -160,11 +172,10 @@ __global__ void __launch_bounds__(256) lowres_intra_kernel(LowresIntraArgs a)
     const int maxVal = (1 << a.depth) - 1;
 
     // neighbours: [0] corner, [1..16] above + above-right, [17..32] left + below-left (slicetype.cpp:725-729)
-    for (int k = tile; k < 33; k += 4)
+    for (int k = l32; k < 33; k += 32)
         nbS[bw][k] = k <= 16 ? pix[-st - 1 + k] : pix[-1 + (long)(k - 17) * st];
-    __builtin_amdgcn_wave_barrier();
     __syncthreads();
-    for (int i = tile; i < 33; i += 4)                              // intra_filter, intrapred.cpp:31-51
+    for (int i = l32; i < 33; i += 32)                              // intra_filter, intrapred.cpp:31-51
     {
         const Px* s = nbS[bw];
         int v;
@@ -182,19 +193,32 @@ __global__ void __launch_bounds__(256) lowres_intra_kernel(LowresIntraArgs a)
     int src[4][4];
 #pragma unroll
     for (int y = 0; y < 4; y++)
-#pragma unroll
-        for (int x = 0; x < 4; x++) src[y][x] = pix[(long)(ty + y) * st + tx + x];
+    {
+        if (BPP == 1)
+        {
+            const uint32_t w = *reinterpret_cast<const u32_unaligned*>(pix + (long)(ty + y) * st + tx);
+            src[y][0] = w & 255; src[y][1] = (w >> 8) & 255; src[y][2] = (w >> 16) & 255; src[y][3] = w >> 24;
+        }
+        else
+        {
+            const uint32_t w0 = reinterpret_cast<const u32_unaligned*>(pix + (long)(ty + y) * st + tx)[0], w1 = reinterpret_cast<const u32_unaligned*>(pix + (long)(ty + y) * st + tx)[1];
+            src[y][0] = w0 & 0xffff; src[y][1] = w0 >> 16; src[y][2] = w1 & 0xffff; src[y][3] = w1 >> 16;
+        }
+    }
     int dcSum = 8;
     for (int i = 0; i < 8; i++) dcSum += nbS[bw][1 + i] + nbS[bw][17 + i];
     const int dc = dcSum / 16;
 
-    auto mode_cost = [&](const int mode, const Px* nb) -> int
+    // One mode's SATD of this lane's 4x4 tile.  The angular modes (intrapred.cpp:104-214 in closed form, as la_sample states it per
+    // sample) are evaluated the way the reference builds them: the 25 reference samples ref(-8) .. ref(16) of the mode - the main side, the
+    // corner, and for negative angles the side samples projected through the inverse angle - are laid out once per (block, mode slot) in
+    // LDS by the slot's four lanes; a line of the tile (a row of a vertical mode, a column of a horizontal one - the transposed tile has
+    // the same SATD) then has ONE position / fraction and reads five neighbouring samples for its four predictions.  ~190 instructions
+    // per tile and mode instead of ~130 per SAMPLE of the generic per-sample function (what the first mode-parallel version still did:
+    // 103 us at 4K, issue-bound, profiles/r03_tail_kernels.txt).
+    int16_t* ext = extS[bw][slot];
+    auto satd4 = [&](const int (&d)[4][4]) -> int
     {
-        int d[4][4];
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++) d[y][x] = src[y][x] - la_sample<Px>(nb, mode, dc, maxVal, tx + x, ty + y);
         int t4[4][4], acc = 0;
 #pragma unroll
         for (int y = 0; y < 4; y++)
@@ -210,30 +234,97 @@ __global__ void __launch_bounds__(256) lowres_intra_kernel(LowresIntraArgs a)
         }
         return quad_sum(acc >> 1);                                   // every 4x4 abs-sum is even; 8x8 satd = sum of its four tiles
     };
-    auto nb_for = [&](const int mode) -> const Px* { return (kLaFilterFlags[mode] & 8) ? nbF[bw] : nbS[bw]; };
+    auto mode_cost = [&](const int mode) -> int
+    {
+        int d[4][4];
+        if (mode < 2)
+        {   // DC (unfiltered neighbours, edge filter: bFilter = cuSize <= 16) and planar (filtered neighbours)
+            const Px* nb = mode ? nbS[bw] : nbF[bw];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) d[y][x] = src[y][x] - la_sample<Px>(nb, mode, dc, maxVal, tx + x, ty + y);
+            return satd4(d);
+        }
+        const Px* nb = (kLaFilterFlags[mode] & 8) ? nbF[bw] : nbS[bw];          // modes 2, 18, 34 of an 8x8 block read the filtered set
+        const bool hor = mode < 18;
+        const int mainBase = hor ? 16 : 0, sideBase = hor ? 0 : 16;
+        const int aoff = hor ? 10 - mode : mode - 26;
+        const int angle = kLaAngle[8 + aoff];
+        const int inv = angle < 0 ? kLaInvAngle[-aoff - 1] : 0;
+        for (int e = tile; e < 25; e += 4)
+        {
+            const int k = e - 8;
+            int idx = (128 + (-1 - k) * inv) >> 8;                   // (entries no line of this mode reaches hold a clamped, unused sample)
+            idx = idx > 16 ? 16 : idx;
+            ext[e] = (int16_t)(k >= 0 ? nb[mainBase + 1 + k] : (k == -1 ? nb[0] : nb[sideBase + idx]));
+        }
+        __builtin_amdgcn_wave_barrier();                              // the slot's four lanes sit in one wavefront: LDS operations are in order
+        const int r0 = hor ? tx : ty, c0 = hor ? ty : tx;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int pos = (r0 + i + 1) * angle, off = pos >> 5, frac = pos & 31;
+            const int16_t* q = ext + 8 + off + c0;
+            int e5[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) e5[j] = q[j];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const int pr = ((32 - frac) * e5[j] + frac * e5[j + 1] + 16) >> 5;       // frac == 0: exactly e5[j]
+                d[i][j] = (hor ? src[j][i] : src[i][j]) - pr;
+            }
+        }
+        if (angle == 0 && c0 == 0)
+        {   // the pure horizontal / vertical mode's edge filter on the first line across the prediction direction (intrapred.cpp:190-203)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const int16_t t = (int16_t)((int)nb[mainBase + 1] + (((int)nb[sideBase + 1 + r0 + i] - (int)nb[0]) >> 1));
+                const int v = t < 0 ? 0 : (t > maxVal ? maxVal : t);
+                d[i][0] = (hor ? src[0][i] : src[i][0]) - v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                              // round 2 rewrites the slot's line after every lane has read it
+        return satd4(d);
+    };
+    // the cost slot `sl` of this lane's block holds (the block's 32 lanes sit in one half of the wavefront)
+    const int lane = tid & 63, half = lane & 32;
+    auto from_slot = [&](const int v, const int sl) -> int { return __shfl(v, half | (sl << 2) | tile, 64); };
 
+    // round 1: slot 0 DC, slot 1 planar (the filtered neighbours: kLaFilterFlags[0] & 8), slots 2 .. 7 angular 5 .. 30
+    const int c1 = mode_cost(slot == 0 ? 1 : (slot == 1 ? 0 : 5 * (slot - 1)));
     int icost = 1 << 28, ilow = 0;
-    int cost = mode_cost(1, nbS[bw]);
+    int cost = from_slot(c1, 0);
     if (cost < icost) { icost = cost; ilow = 1; }
-    cost = mode_cost(0, nbF[bw]);                                    // planar uses the filtered set when cuSize >= 8
+    cost = from_slot(c1, 1);
     if (cost < icost) { icost = cost; ilow = 0; }
     int acost = 1 << 28, alow = 4;
-    for (int mode = 5; mode < 35; mode += 5)
+#pragma unroll
+    for (int k = 2; k < 8; k++)
     {
-        cost = mode_cost(mode, nb_for(mode));
-        if (cost < acost) { acost = cost; alow = mode; }
+        cost = from_slot(c1, k);
+        if (cost < acost) { acost = cost; alow = 5 * (k - 1); }
     }
-    for (int dist = 2; dist >= 1; dist--)
+    // round 2: slots 0 .. 5 = a - 3, a - 2, a - 1, a + 1, a + 2, a + 3 (slots 6, 7 repeat a + 3)
+    const int a0 = alow;
+    const int o2 = slot < 3 ? slot - 3 : (slot < 6 ? slot - 2 : 3);
+    const int c2 = mode_cost(a0 + o2);
+    auto at = [&](const int off) -> int { return from_slot(c2, off < 0 ? off + 3 : off + 2); };
+    const int cm3 = at(-3), cm2 = at(-2), cm1 = at(-1), cp1 = at(1), cp2 = at(2), cp3 = at(3);
+    if (cm2 < acost) { acost = cm2; alow = a0 - 2; }
+    if (cp2 < acost) { acost = cp2; alow = a0 + 2; }
     {
-        const int minusmode = alow - dist, plusmode = alow + dist;
-        cost = mode_cost(minusmode, nb_for(minusmode));
-        if (cost < acost) { acost = cost; alow = minusmode; }
-        cost = mode_cost(plusmode, nb_for(plusmode));
-        if (cost < acost) { acost = cost; alow = plusmode; }
+        const int b = alow - a0;                                     // -2, 0, 2
+        const int minus = b < 0 ? cm3 : (b == 0 ? cm1 : cp1), plus = b < 0 ? cm1 : (b == 0 ? cp1 : cp3);
+        const int base = alow;
+        if (minus < acost) { acost = minus; alow = base - 1; }
+        if (plus < acost) { acost = plus; alow = base + 1; }
     }
     if (acost < icost) { icost = acost; ilow = alow; }
     icost += a.intraPenalty + 4;
-    if (live && tile == 0)
+    if (live && tile == 0 && slot == 0)
     {
         a.intraCost[cuXY] = icost;
         a.intraMode[cuXY] = (uint8_t)ilow;
@@ -486,8 +577,8 @@ extern "C" int x265hip_lowres_intra(const x265hip_lowres_intra_params* p, void* 
     a.intraCost = p->intra_cost; a.intraMode = p->intra_mode; a.lowresCosts = p->lowres_costs;
     const int ncu = p->width_in_cu * p->height_in_cu;
     hipStream_t s = (hipStream_t)stream;
-    if (bpp == 1) hipLaunchKernelGGL(lowres_intra_kernel<uint8_t>, dim3((ncu + 63) / 64), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(lowres_intra_kernel<uint16_t>, dim3((ncu + 63) / 64), dim3(256), 0, s, a);
+    if (bpp == 1) hipLaunchKernelGGL(lowres_intra_kernel<uint8_t>, dim3((ncu + 7) / 8), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lowres_intra_kernel<uint16_t>, dim3((ncu + 7) / 8), dim3(256), 0, s, a);
     X265HIP_TRY(hipGetLastError());
     return 0;
 }

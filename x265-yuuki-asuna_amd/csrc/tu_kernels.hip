@@ -235,6 +235,7 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
     {
         for (int i = tid; i < NN / 8; i += nth) sCg[i] = 0;
         if (tid == 0) sNq = 0;
+        if (nth > 64) __syncthreads();          // the emitting wavefront may not be the one that cleared a slot (uniform condition)
     }
     int nq = 0;
     // c = the coefficient the quantiser sees (after the denoiser), fd = the source block's coefficient at the same position
@@ -540,17 +541,22 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
 
 // CHROMA: one chroma plane of a 4:2:0 picture - N is the chroma block size (half the luma block), the mv counts 1/8 samples and
 // the filters are the 4-tap chroma set (Predict::predInterChromaPixel, predict.cpp:304-351)
+// threads per block of the uni-predictive inter stage.  16x16 and 32x32 blocks stay on ONE wavefront: four wavefronts per 32x32 block
+// (real barriers, three of them idle through the matrix-core transforms) ran 241 us per 4K picture against 99 us (profiles/r03_tail_kernels.txt) -
+// the stage is bound by the instructions it issues, not by the latency of one block's chain.
+template <int N> struct InterReconThreads { static constexpr int value = N >= 16 ? 64 : 256; };
+
 template <typename Px, int N, bool CHROMA, bool TAB = false>
-__global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs2 aa, int nblocks)
+__global__ void __launch_bounds__(InterReconThreads<N>::value) inter_recon_kernel(TuArgs2 aa, int nblocks)
 {
     const TuArgs& a = aa.p[blockIdx.y];          // grid.y = plane: Cb and Cr of a picture (or of a band of it) share one launch
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
     constexpr int TAPS = CHROMA ? 4 : 8, APRON = TAPS / 2 - 1, PW = N + TAPS - 1, PP = PW + 1;
     constexpr int NL = CHROMA ? 2 * N : N, CTU = CHROMA ? 32 : 64, MVSH = CHROMA ? 3 : 2, MVMASK = CHROMA ? 7 : 3;
     constexpr int BPP = sizeof(Px);
-    __shared__ int16_t patch[PW * PP];
+    __shared__ __attribute__((aligned(16))) int16_t patch[PW * PP];
     __shared__ int16_t immed[PW * N];
-    __shared__ int16_t pred[NN], fe[NN], A[NN], B[NN];
+    __shared__ __attribute__((aligned(16))) int16_t pred[NN], fe[NN], A[NN], B[NN];
     __shared__ unsigned long long red[4];
     __shared__ int sNumSig;
 
@@ -577,10 +583,44 @@ __global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_kernel(TuArgs2
     {
         const Px* f = reinterpret_cast<const Px*>(a.fenc + (long)py * a.fencStrideB) + px;
         const long fst = a.fencStrideB / BPP;
-        for (int i = tid; i < NN; i += nth) { const int y = i >> LOG2N, x = i & (N - 1); fe[i] = (int16_t)f[y * fst + x]; }
         const Px* r = reinterpret_cast<const Px*>(a.fref + (long)(py + (qy >> MVSH) - APRON) * a.frefStrideB) + (px + (qx >> MVSH) - APRON);
         const long rst = a.frefStrideB / BPP;
-        for (int i = tid; i < PW * PW; i += nth) { const int y = i / PW, x = i - y * PW; patch[y * PP + x] = (int16_t)r[y * rst + x]; }
+        if constexpr (N >= 16)
+        {   // dword loads (4 / 2 samples), all issued before the first one is waited for (the rolled per-sample loop paid the memory latency
+            // once per trip: 16 + 24 trips for a 32x32 block), widened to int16 pairs on the way into LDS.  A patch row is read to the next
+            // dword boundary (one sample beyond the 2 * apron + N needed: still inside the padded plane, and inside the row's LDS pitch).
+            constexpr int NT = InterReconThreads<N>::value, SPD = 4 / BPP, FD = N / SPD, PWD = (PW + SPD - 1) / SPD;
+            constexpr int FI = (N * FD) / NT, PI = (PW * PWD + NT - 1) / NT;
+            static_assert(PWD * SPD <= PP && (N * FD) % NT == 0, "patch pitch / source block size");
+            uint32_t fv[FI], pv[PI];
+#pragma unroll
+            for (int k = 0; k < FI; k++) { const int i = tid + k * NT, y = i / FD, c = i - y * FD; fv[k] = ld_u32(reinterpret_cast<const uint8_t*>(f + y * fst) + 4 * c); }
+#pragma unroll
+            for (int k = 0; k < PI; k++)
+            {
+                const int i = tid + k * NT, y = i / PWD, c = i - y * PWD;
+                pv[k] = i < PW * PWD ? ld_u32(reinterpret_cast<const uint8_t*>(r + y * rst) + 4 * c) : 0u;
+            }
+            auto put = [&](int16_t* dst, const uint32_t w)
+            {
+                if (BPP == 1)
+                {
+                    uint2 v;
+                    v.x = (w & 0xffu) | ((w & 0xff00u) << 8); v.y = ((w >> 16) & 0xffu) | ((w >> 8) & 0xff0000u);
+                    *reinterpret_cast<uint2*>(dst) = v;
+                }
+                else *reinterpret_cast<uint32_t*>(dst) = w;
+            };
+#pragma unroll
+            for (int k = 0; k < FI; k++) { const int i = tid + k * NT; put(fe + i * SPD, fv[k]); }
+#pragma unroll
+            for (int k = 0; k < PI; k++) { const int i = tid + k * NT, y = i / PWD, c = i - y * PWD; if (i < PW * PWD) put(patch + y * PP + c * SPD, pv[k]); }
+        }
+        else
+        {
+            for (int i = tid; i < NN; i += nth) { const int y = i >> LOG2N, x = i & (N - 1); fe[i] = (int16_t)f[y * fst + x]; }
+            for (int i = tid; i < PW * PW; i += nth) { const int y = i / PW, x = i - y * PW; patch[y * PP + x] = (int16_t)r[y * rst + x]; }
+        }
         if (tid == 0) sNumSig = 0;
     }
     __syncthreads();
@@ -898,19 +938,19 @@ extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
     const int npu = 64 >> (2 * p->level);
     hipStream_t s = (hipStream_t)stream;
     const int nblocks = nctu * npu;
-    auto resident = [&](const void* fn)
+    auto resident = [&](const void* fn, const int threads)
     {
         int dev = 0, cus = 256, per = 8;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, 64, 0) != hipSuccess || per < 1) per = 8;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, threads, 0) != hipSuccess || per < 1) per = 8;
         const long r = (long)cus * per;
         return (int)(nblocks < r ? nblocks : r);
     };
 #define GO_T(PX, TB) do { \
         if (p->level == 0) hipLaunchKernelGGL((inter_recon_kernel<PX, 8, false, TB>), dim3(nblocks), dim3(64), 0, s, aa, nblocks); \
-        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 16, false, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 16, false, TB>)), dim3(64), 0, s, aa, nblocks); \
-        else hipLaunchKernelGGL((inter_recon_kernel<PX, 32, false, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 32, false, TB>)), dim3(64), 0, s, aa, nblocks); } while (0)
+        else if (p->level == 1) hipLaunchKernelGGL((inter_recon_kernel<PX, 16, false, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 16, false, TB>, 64)), dim3(64), 0, s, aa, nblocks); \
+        else hipLaunchKernelGGL((inter_recon_kernel<PX, 32, false, TB>), dim3(resident((const void*)inter_recon_kernel<PX, 32, false, TB>, 64)), dim3(64), 0, s, aa, nblocks); } while (0)
 #define GO(PX) do { if (p->tables) GO_T(PX, true); else GO_T(PX, false); } while (0)
     if (p->depth == 8) GO(uint8_t); else GO(uint16_t);
 #undef GO_T
