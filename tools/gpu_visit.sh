@@ -23,6 +23,7 @@ BENCH_PROF="--steps 10 --warmup 2 --no-cpu-baseline --no-encoder"
 for step in "$@"; do
     n=$((n + 1))
     kind=${step%%:*}; arg=""; [ "$step" != "$kind" ] && arg=${step#*:}
+    case $kind in tests|bench|stats|pmc) arg=${arg//:/ } ;; esac          # ':' separates arguments (bench:--no-encoder:--steps:20)
     echo "=== [$n] $step"
     case $kind in
     tests)

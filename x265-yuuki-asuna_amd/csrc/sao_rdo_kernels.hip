@@ -492,6 +492,313 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows_kernel(SaoRdoArgs a)
     if (tid < 2 && a.numNoSao) a.numNoSao[tid] = sNo[tid];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The serial pass, second organisation (round 3): ONE barrier per step and nothing but the decision lane's own chain on the serial path.
+//
+// sao_rdo_rows_kernel above runs a step as  [merge distortions of the step || type decision] -> barrier -> [comparison with the merge
+// candidates] -> barrier:  the merge lanes wait for the neighbours' FINAL parameters of the previous step, fetch 24 statistics from
+// global memory and divide three times, and the comparison waits for them - 3.3 us per step, 310 us for the 93 steps of a 4K picture.
+// A neighbour's final parameters, however, can only be one of three sets that are known a step earlier: its own new decision N, or -
+// if it merged - the final parameters P of ITS left / upper neighbour.  So for the CTU X = (r, c) of anti-diagonal s the merge lanes
+// compute, during step s, the distortions of FIVE sets on X's statistics:
+//      0: N(r, c-1)   1: P(r, c-2)   2: P(r-1, c-1)   3: N(r-1, c)   4: P(r-2, c)
+// (left neighbour = 0 / 1 / 2 by its choice new / merged left / merged up; upper neighbour = 3 / 2 / 4), all of them published before
+// step s begins, and the decision lane - a lane per CTU row as before - does, in step s + 1, the comparison for X with the two that
+// apply, then at once the type decision of its next CTU: the entropy state never leaves its registers, the merge lanes have a whole
+// step for their loads, and a step is one barrier.
+template <int PLANES>
+__global__ void __launch_bounds__(768) sao_rdo_rows2_kernel(SaoRdoArgs a)          // 12 wavefronts: up to 76 CTU rows; 168 registers, nothing spilled
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    // [2][rows] candidate records (staged one step ahead) | [2][rows][3] final parameters P by diagonal parity | [2][rows][3] new decisions N
+    // by diagonal parity | [2][rows][8] speculative merge distortions by diagonal parity
+    SaoCtuCand* sCand = reinterpret_cast<SaoCtuCand*>(smem);
+    SaoP* sPar = reinterpret_cast<SaoP*>(sCand + 2 * a.ctusH);
+    SaoP* sNew = sPar + 2 * a.ctusH * 3;
+    long long* sD = reinterpret_cast<long long*>(sNew + 2 * a.ctusH * 3);
+    __shared__ uint32_t sBits[128];
+    __shared__ uint8_t sNext[256];
+    __shared__ int sNo[2];
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int W = a.ctusW, H = a.ctusH, thresh = 1 << (a.depth - 5 < 5 ? a.depth - 5 : 5);
+    const int RW = (H + 63) >> 6, MW = (5 * H + 63) >> 6;       // wavefronts of decision lanes / of merge lanes (a lane per row and candidate set)
+    const int wave = tid >> 6;
+    const int role = wave < RW ? 0 : (wave < RW + MW ? 1 : 2);     // 0 decision, 1 merge, 2 copy
+    const int row = role == 0 ? tid : 0;
+    const int mid = tid - RW * 64, mrow = mid / 5, mj = mid - mrow * 5;       // merge lane: row, candidate set
+    const int ncopy = nth - (RW + MW) * 64, ctid = tid - (RW + MW) * 64;
+    const int NS = W + H - 1;                                  // anti-diagonals
+    for (int i = tid; i < 128; i += nth) sBits[i] = a.bits[i];
+    for (int i = tid; i < 256; i += nth)
+    {   // context byte = pStateIdx << 1 | valMps (contexts.h:116 sbacNext); transIdxMps = min(p + 1, 62)
+        const int st = i >> 1, bin = i & 1, p = st >> 1, mps = st & 1;
+        sNext[i] = (uint8_t)(bin == mps ? ((p < 62 ? p + 1 : p) << 1) | mps : ((int)kSaoTransIdxLps[p] << 1) | (p == 0 ? 1 - mps : mps));
+    }
+    if (tid < 2) sNo[tid] = 0;
+    // candidate records: global -> registers -> LDS over two steps, as in sao_rdo_rows_kernel
+    constexpr int Q = sizeof(SaoCtuCand) / 16, B = 6;
+    uint4 stagev[B];
+    bool stageok[B];
+    int pieceRow[B], pieceLds[B];
+    const uint4* piecePtr[B];
+#pragma unroll
+    for (int j = 0; j < B; j++)
+    {
+        const int i = ctid + j * ncopy, r = i / Q, q = i - r * Q;
+        pieceRow[j] = (role == 2 && i < H * Q) ? r : -0x10000;
+        pieceLds[j] = r * Q + q;
+        piecePtr[j] = reinterpret_cast<const uint4*>(a.cand + (size_t)(r < H ? r : 0) * W) + q;
+    }
+    auto stage_load = [&](int t)
+    {
+#pragma unroll
+        for (int j = 0; j < B; j++)
+        {
+            const int x = t - pieceRow[j];
+            stageok[j] = x >= 0 && x < W;
+            if (stageok[j]) stagev[j] = piecePtr[j][(size_t)x * Q];
+        }
+    };
+    auto stage_store = [&](int t)
+    {
+        uint4* buf = reinterpret_cast<uint4*>(sCand + (t & 1) * H);
+#pragma unroll
+        for (int j = 0; j < B; j++)
+            if (stageok[j]) buf[pieceLds[j]] = stagev[j];
+    };
+    auto prefetch_rest = [&](int t, int id, int n)
+    {
+        for (int i = id + B * n; i < H * Q; i += n)
+        {
+            const int r = i / Q, q = i - r * Q, x = t - r;
+            if (x >= 0 && x < W)
+                reinterpret_cast<uint4*>(sCand + (t & 1) * H + r)[q] = reinterpret_cast<const uint4*>(a.cand + (size_t)r * W + x)[q];
+        }
+    };
+    constexpr int FB = 4;
+    int flRow[FB], flLds[FB], flOut[FB], flPl[FB];
+#pragma unroll
+    for (int j = 0; j < FB; j++)
+    {
+        const int i = ctid + j * ncopy, r = i / (PLANES * 7), k = i - r * (PLANES * 7), pl = k / 7, f = k - pl * 7;
+        flRow[j] = (role == 2 && i < H * PLANES * 7) ? r : -0x10000;
+        flLds[j] = (r * 3 + pl) * 8 + f;
+        flOut[j] = r * W * 7 + f;
+        flPl[j] = pl;
+    }
+    // the final parameters of anti-diagonal d (written during step d + 1) -> ctu_params
+    auto flush = [&](int d, int id, int n)
+    {
+        const int* buf = reinterpret_cast<const int*>(sPar + (d & 1) * H * 3);
+#pragma unroll
+        for (int j = 0; j < FB; j++)
+        {
+            const int x = d - flRow[j];
+            if (x >= 0 && x < W) a.params[flPl[j]][flOut[j] + x * 7] = buf[flLds[j]];
+        }
+        for (int i = id + FB * n; i < H * PLANES * 7; i += n)
+        {
+            const int r = i / (PLANES * 7), k = i - r * (PLANES * 7), pl = k / 7, f = k - pl * 7, x = d - r;
+            if (x >= 0 && x < W) a.params[pl][((size_t)r * W + x) * 7 + f] = buf[(r * 3 + pl) * 8 + f];
+        }
+    };
+    if (role == 2)
+    {
+        stage_load(0); stage_store(0); prefetch_rest(0, ctid, ncopy);
+        stage_load(1);
+    }
+    auto next_state = [&](int s, int bin) { return (int)sNext[s * 2 + bin]; };
+    auto bin_ctx = [&](SaoEnt& e, int& ctx, int bin) { e.frac += sBits[ctx ^ bin]; ctx = next_state(ctx, bin); };
+    auto lds_param = [&](const SaoP* base, int r, int pl)
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(base + r * 3 + pl);
+        const uint4 v0 = q[0], v1 = q[1];
+        SaoP p;
+        p.type = (int)v0.x; p.band = (int)v0.y; p.off[0] = (int)v0.z; p.off[1] = (int)v0.w; p.off[2] = (int)v1.x; p.off[3] = (int)v1.y; p.merge = (int)v1.z; p.pad = (int)v1.w;
+        return p;
+    };
+    auto put_param = [&](SaoP* base, int r, int pl, const SaoP& p)
+    {
+        uint4* q = reinterpret_cast<uint4*>(base + r * 3 + pl);
+        q[0] = make_uint4((uint32_t)p.type, (uint32_t)p.band, (uint32_t)p.off[0], (uint32_t)p.off[1]);
+        q[1] = make_uint4((uint32_t)p.off[2], (uint32_t)p.off[3], (uint32_t)p.merge, (uint32_t)p.pad);
+    };
+    // decision-lane state that lives across steps
+    SaoEnt cur = { a.ctxMerge, a.ctxType, a.frac };          // m_rdContexts.cur.load(initState) (sao.cpp:247): every row starts from the slice's state
+    SaoEnt tempN = cur;                                      // the entropy state after coding the new decision of the CTU whose comparison is pending
+    SaoP newP[PLANES], prevP[PLANES];                        // that CTU's new decision; the row's previous final parameters (the left neighbour's)
+    long long bestN = 0;
+    int prevChoice = 0;                                      // how the left neighbour ended: 0 new, 1 merged left, 2 merged up
+    int noSao0 = 0, noSao1 = 0;
+#pragma unroll
+    for (int pl = 0; pl < PLANES; pl++) { newP[pl] = SaoP{ -1, 0, { 0, 0, 0, 0 }, 0, 0 }; prevP[pl] = newP[pl]; }
+    __syncthreads();
+    for (int s = 0; s <= NS; s++)
+    {
+        const SaoP* parOld = sPar + (s & 1) * H * 3;         // P of anti-diagonal s - 2
+        SaoP* parOut = sPar + ((s + 1) & 1) * H * 3;         // P of anti-diagonal s - 1 (written in this step)
+        const SaoP* newOld = sNew + ((s + 1) & 1) * H * 3;   // N of anti-diagonal s - 1
+        SaoP* newOut = sNew + (s & 1) * H * 3;               // N of anti-diagonal s (written in this step)
+        if (role == 2)
+        {
+            if (a.dbg & 2) {} else
+            {
+            if (s + 1 < NS) { stage_store(s + 1); prefetch_rest(s + 1, ctid, ncopy); }
+            if (s + 2 < NS) stage_load(s + 2);
+            if (s >= 2) flush(s - 2, ctid, ncopy);
+            }
+        }
+        else if (role == 1)
+        {   // ---- the five candidate sets on the statistics of (mrow, s - mrow)  (sao.cpp:1314-1335 for each) ----
+            const int col = s - mrow;
+            if (mrow < H && col >= 0 && col < W && !(a.dbg & 1))
+            {
+                const bool fromNew = mj == 0 || mj == 3;
+                const int srow = mj == 0 || mj == 1 ? mrow : (mj == 4 ? mrow - 2 : mrow - 1);
+                const bool valid = mj == 0 ? col >= 1 : (mj == 1 ? col >= 2 : (mj == 2 ? mrow >= 1 && col >= 1 : (mj == 3 ? mrow >= 1 : mrow >= 2)));
+                long long mergeDist = 0;
+                if (valid)
+                {
+                    const int addr = mrow * W + col;
+                    long long lamY = a.lambda[0], lamC = a.lambda[1];
+                    if (a.lambdaCtu) { lamY = a.lambdaCtu[2 * addr]; lamC = a.lambdaCtu[2 * addr + 1]; }
+                    const double rdY = 1.0 / (double)lamY, rdC = 1.0 / (double)lamC;
+                    SaoP nb[PLANES];
+                    int mc[PLANES][4], mo[PLANES][4];
+#pragma unroll
+                    for (int pl = 0; pl < PLANES; pl++)
+                    {
+                        nb[pl] = lds_param(fromNew ? newOld : parOld, srow, pl);
+                        const int ty = nb[pl].type < 0 ? 0 : (nb[pl].type > SAO_BO_T ? SAO_BO_T : nb[pl].type);
+                        const int bandPos = nb[pl].type == SAO_BO_T ? min(nb[pl].band & 31, 28) : 1;       // (clamped: no state can form a wild address)
+                        const int32_t* cnt = a.count[pl] + (size_t)addr * 160 + ty * 32 + bandPos;
+                        const int32_t* org = a.offsetOrg[pl] + (size_t)addr * 160 + ty * 32 + bandPos;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) { mc[pl][c] = cnt[c]; mo[pl][c] = org[c]; }
+                    }
+#pragma unroll
+                    for (int pl = 0; pl < PLANES; pl++)
+                        if (nb[pl].type >= 0)
+                        {
+                            long long estDist = 0;
+#pragma unroll
+                            for (int c = 0; c < 4; c++) estDist += (long long)(int)((mc[pl][c] * nb[pl].off[c] - mo[pl][c] * 2) * nb[pl].off[c]);
+                            mergeDist += sao_div(estDist << 8, pl ? lamC : lamY, pl ? rdC : rdY);
+                        }
+                }
+                sD[((s & 1) * H + mrow) * 8 + mj] = mergeDist;
+            }
+        }
+        else if (row < H && !(a.dbg & 4))
+        {
+            // ---- the comparison for the CTU of the previous step (sao.cpp:1336-1373) ----
+            const int colF = s - 1 - row;
+            if (colF >= 0 && colF < W)
+            {
+                const bool allowL = colF != 0, allowU = row != 0;
+                SaoP mine[PLANES];
+#pragma unroll
+                for (int pl = 0; pl < PLANES; pl++) mine[pl] = newP[pl];
+                SaoEnt temp = tempN;
+                long long bestCost = bestN;
+                int choice = 0;
+                if (a.saoFlag[0] || a.saoFlag[1])
+                {
+                    const long long* D = sD + (((s + 1) & 1) * H + row) * 8;
+                    const int upChoice = allowU ? parOld[(row - 1) * 3].pad : 0;
+                    const long long dL = D[prevChoice], dU = D[upChoice == 0 ? 3 : (upChoice == 1 ? 2 : 4)];
+#pragma unroll
+                    for (int m = 0; m < 2; m++)
+                    {
+                        if (!(m ? allowU : allowL)) continue;
+                        SaoEnt e = cur; e.frac &= 32767;
+                        if (allowL) bin_ctx(e, e.ctxMerge, 1 - m);
+                        if (allowU && m == 1) bin_ctx(e, e.ctxMerge, 1);
+                        const long long mergeCost = (m ? dU : dL) + (e.frac >> 15);
+                        if (mergeCost < bestCost)
+                        {
+                            bestCost = mergeCost;
+                            temp = e;
+                            choice = m + 1;
+#pragma unroll
+                            for (int pl = 0; pl < PLANES; pl++)
+                                if (a.saoFlag[pl > 0]) { mine[pl] = m ? lds_param(parOld, row - 1, pl) : prevP[pl]; mine[pl].merge = m ? 2 : 1; }
+                        }
+                    }
+                    noSao0 += mine[0].type < 0;
+                    if (PLANES == 3) noSao1 += mine[1].type < 0;
+                    cur = temp;
+                }
+                mine[0].pad = choice;
+#pragma unroll
+                for (int pl = 0; pl < PLANES; pl++) { put_param(parOut, row, pl, mine[pl]); prevP[pl] = mine[pl]; }
+                prevChoice = choice;
+            }
+            // ---- the type decision of this step's CTU, everything up to the comparison with the merge candidates ----
+            const int col = s - row;
+            if (col >= 0 && col < W)
+            {
+                const bool allowL = col != 0, allowU = row != 0;
+                const int addr = row * W + col;
+                long long lamY = a.lambda[0], lamC = a.lambda[1];
+                if (a.lambdaCtu) { lamY = a.lambdaCtu[2 * addr]; lamC = a.lambdaCtu[2 * addr + 1]; }
+                const SaoCtuCand& cd = sCand[(s & 1) * H + row];
+#pragma unroll
+                for (int pl = 0; pl < PLANES; pl++) newP[pl] = SaoP{ -1, 0, { 0, 0, 0, 0 }, 0, 0 };
+                SaoEnt temp = cur;
+                temp.frac &= 32767;                                // resetBits (entropy.cpp:2442-2451)
+                if (allowL) bin_ctx(temp, temp.ctxMerge, 0);
+                if (allowU) bin_ctx(temp, temp.ctxMerge, 0);
+                long long rateDist = 0;
+                bestN = 0;
+                auto decide = [&](const long long* minCost, const uint8_t* minK, const int* nb, long long lambda)
+                {
+                    const uint32_t F = temp.frac & 32767, b0 = sBits[temp.ctxType], b1 = sBits[temp.ctxType ^ 1];
+                    const uint32_t c0 = (F + b0) >> 15, c1 = (F + b1) >> 15;
+                    const long long costOff = ((long long)c0 * lambda + 128) >> 8;
+                    int k = minK[c1];
+                    if (!(minCost[c1] < costOff)) k = -1;
+                    temp.frac += k < 0 ? b0 : b1 + 32768u * (uint32_t)nb[k];
+                    temp.ctxType = next_state(temp.ctxType, k >= 0);
+                    return k;
+                };
+                auto take = [&](SaoP& p, int pl, int k)
+                {
+                    p.type = k; p.band = k == SAO_BO_T ? cd.boPos[pl] : 0;
+                    const uint32_t w = *reinterpret_cast<const uint32_t*>(cd.off[pl][k]);
+                    p.off[0] = (int8_t)(w & 0xff); p.off[1] = (int8_t)((w >> 8) & 0xff); p.off[2] = (int8_t)((w >> 16) & 0xff); p.off[3] = (int8_t)(w >> 24);
+                };
+                if (a.saoFlag[0])
+                {   // saoLumaComponentParamDist (sao.cpp:1484-1610)
+                    const int k = decide(cd.minCostY, cd.minKY, cd.nbY, lamY);
+                    if (k >= 0) { take(newP[0], 0, k); rateDist = cd.quotY[k]; }
+                    if (PLANES == 1) bestN = rateDist + (temp.frac >> 15);
+                }
+                if (PLANES == 3 && a.saoFlag[1])
+                {   // saoChromaComponentParamDist (sao.cpp:1611-1760)
+                    const int k = decide(cd.minCostC, cd.minKC, cd.nbC, lamC);
+                    if (k >= 0)
+                    {
+#pragma unroll
+                        for (int pl = 1; pl < PLANES; pl++) take(newP[pl], pl, k);
+                        rateDist += cd.quotC[k];
+                    }
+                    bestN = rateDist + (temp.frac >> 15);
+                }
+                tempN = temp;
+#pragma unroll
+                for (int pl = 0; pl < PLANES; pl++) put_param(newOut, row, pl, newP[pl]);
+            }
+        }
+        __syncthreads();
+    }
+    if (role == 2) { if (NS >= 2) flush(NS - 2, ctid, ncopy); flush(NS - 1, ctid, ncopy); }
+    if (role == 0 && row < H) { if (noSao0) atomicAdd(&sNo[0], noSao0); if (noSao1) atomicAdd(&sNo[1], noSao1); }
+    __syncthreads();
+    if (tid < 2 && a.numNoSao) a.numNoSao[tid] = sNo[tid];
+}
+
 } // namespace x265hip
 
 using namespace x265hip;
@@ -531,18 +838,30 @@ extern "C" int x265hip_sao_rdo(const x265hip_sao_rdo_params* p, void* stream)
     const int nctu = p->ctus_w * p->ctus_h;
     if (!(a.dbg & 8)) hipLaunchKernelGGL(sao_rdo_prep_kernel, dim3(nctu), dim3(192), 0, s, a);
     if ((rc = check_hip(hipGetLastError(), "sao_rdo prep launch"))) return rc;
-    const int threads = ((p->ctus_h + 63) / 64 * 3 + 4) * 64;          // decision / merge-left / merge-up lanes per CTU row + four copy wavefronts
-    const size_t lds = (size_t)2 * p->ctus_h * sizeof(SaoCtuCand) + (size_t)2 * p->ctus_h * 3 * sizeof(SaoP) + (size_t)p->ctus_h * 2 * sizeof(long long);
+    // the serial pass: the one-barrier organisation (sao_rdo_rows2_kernel) where its LDS fits, X265HIP_SAO_RDO_KERNEL=1 forces the first one (A/B tests)
+    static const int forced = getenv("X265HIP_SAO_RDO_KERNEL") ? atoi(getenv("X265HIP_SAO_RDO_KERNEL")) : 0;
+    const size_t lds2 = (size_t)2 * p->ctus_h * sizeof(SaoCtuCand) + (size_t)4 * p->ctus_h * 3 * sizeof(SaoP) + (size_t)2 * p->ctus_h * 8 * sizeof(long long);
+    const int threads2 = ((p->ctus_h + 63) / 64 + (5 * p->ctus_h + 63) / 64 + 4) * 64;
+    const bool second = forced != 1 && lds2 <= 150 * 1024 && threads2 <= 768;
+    const int threads = second ? threads2 : ((p->ctus_h + 63) / 64 * 3 + 4) * 64;          // decision / merge-left / merge-up lanes per CTU row + four copy wavefronts
+    const size_t lds = second ? lds2 : (size_t)2 * p->ctus_h * sizeof(SaoCtuCand) + (size_t)2 * p->ctus_h * 3 * sizeof(SaoP) + (size_t)p->ctus_h * 2 * sizeof(long long);
     if (lds > 150 * 1024) { set_error("sao_rdo: %d CTU rows need %zu bytes of LDS", p->ctus_h, lds); return X265HIP_EUNSUPPORTED; }
     static bool ldsRaised = false;
     if (lds > 48 * 1024 && !ldsRaised)
     {
         X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         ldsRaised = true;
     }
     if (a.dbg & 16) return 0;
-    if (p->planes == 3) hipLaunchKernelGGL(sao_rdo_rows_kernel<3>, dim3(1), dim3(threads), lds, s, a);
+    if (second)
+    {
+        if (p->planes == 3) hipLaunchKernelGGL(sao_rdo_rows2_kernel<3>, dim3(1), dim3(threads), lds, s, a);
+        else hipLaunchKernelGGL(sao_rdo_rows2_kernel<1>, dim3(1), dim3(threads), lds, s, a);
+    }
+    else if (p->planes == 3) hipLaunchKernelGGL(sao_rdo_rows_kernel<3>, dim3(1), dim3(threads), lds, s, a);
     else hipLaunchKernelGGL(sao_rdo_rows_kernel<1>, dim3(1), dim3(threads), lds, s, a);
     return check_hip(hipGetLastError(), "sao_rdo rows launch");
 }
