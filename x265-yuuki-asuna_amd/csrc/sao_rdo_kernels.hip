@@ -20,6 +20,8 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace x265hip {
 
@@ -181,6 +183,12 @@ __global__ void __launch_bounds__(192) sao_rdo_prep_kernel(SaoRdoArgs a)
         }
     }
 }
+
+// a loop over compile-time indices: every array access inside has a CONSTANT index from the start, so the arrays become registers (the
+// copy lanes' staging arrays, indexed by an unrolled loop variable, were left in scratch memory: global load -> scratch -> LDS, with the
+// wait for the load inside the step that issued it - the copy wavefronts alone took 2.1 us per step)
+template <typename F, int... Is> __device__ __forceinline__ void sao_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void sao_static_for(F&& f) { sao_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct SaoEnt { int ctxMerge, ctxType; uint32_t frac; };
 struct SaoP { int type, band, off[4], merge, pad; };       // 32 bytes: two 16-byte LDS accesses
@@ -507,8 +515,9 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows_kernel(SaoRdoArgs a)
 // step s begins, and the decision lane - a lane per CTU row as before - does, in step s + 1, the comparison for X with the two that
 // apply, then at once the type decision of its next CTU: the entropy state never leaves its registers, the merge lanes have a whole
 // step for their loads, and a step is one barrier.
-template <int PLANES>
-__global__ void __launch_bounds__(768) sao_rdo_rows2_kernel(SaoRdoArgs a)          // 12 wavefronts: up to 76 CTU rows; 168 registers, nothing spilled
+// MAXT = 512 (8 wavefronts: up to 38 CTU rows, 256 registers - nothing spilled) or 768 (12 wavefronts: up to 76 rows)
+template <int PLANES, int MAXT>
+__global__ void __launch_bounds__(MAXT) sao_rdo_rows2_kernel(SaoRdoArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     // [2][rows] candidate records (staged one step ahead) | [2][rows][3] final parameters P by diagonal parity | [2][rows][3] new decisions N
@@ -542,30 +551,33 @@ __global__ void __launch_bounds__(768) sao_rdo_rows2_kernel(SaoRdoArgs a)       
     bool stageok[B];
     int pieceRow[B], pieceLds[B];
     const uint4* piecePtr[B];
-#pragma unroll
-    for (int j = 0; j < B; j++)
+    sao_static_for<B>([&](auto jc)
     {
+        constexpr int j = decltype(jc)::value;
         const int i = ctid + j * ncopy, r = i / Q, q = i - r * Q;
         pieceRow[j] = (role == 2 && i < H * Q) ? r : -0x10000;
         pieceLds[j] = r * Q + q;
         piecePtr[j] = reinterpret_cast<const uint4*>(a.cand + (size_t)(r < H ? r : 0) * W) + q;
-    }
+        stagev[j] = make_uint4(0, 0, 0, 0); stageok[j] = false;
+    });
     auto stage_load = [&](int t)
     {
-#pragma unroll
-        for (int j = 0; j < B; j++)
+        sao_static_for<B>([&](auto jc)
         {
+            constexpr int j = decltype(jc)::value;
             const int x = t - pieceRow[j];
             stageok[j] = x >= 0 && x < W;
             if (stageok[j]) stagev[j] = piecePtr[j][(size_t)x * Q];
-        }
+        });
     };
     auto stage_store = [&](int t)
     {
         uint4* buf = reinterpret_cast<uint4*>(sCand + (t & 1) * H);
-#pragma unroll
-        for (int j = 0; j < B; j++)
+        sao_static_for<B>([&](auto jc)
+        {
+            constexpr int j = decltype(jc)::value;
             if (stageok[j]) buf[pieceLds[j]] = stagev[j];
+        });
     };
     auto prefetch_rest = [&](int t, int id, int n)
     {
@@ -578,25 +590,25 @@ __global__ void __launch_bounds__(768) sao_rdo_rows2_kernel(SaoRdoArgs a)       
     };
     constexpr int FB = 4;
     int flRow[FB], flLds[FB], flOut[FB], flPl[FB];
-#pragma unroll
-    for (int j = 0; j < FB; j++)
+    sao_static_for<FB>([&](auto jc)
     {
+        constexpr int j = decltype(jc)::value;
         const int i = ctid + j * ncopy, r = i / (PLANES * 7), k = i - r * (PLANES * 7), pl = k / 7, f = k - pl * 7;
         flRow[j] = (role == 2 && i < H * PLANES * 7) ? r : -0x10000;
         flLds[j] = (r * 3 + pl) * 8 + f;
         flOut[j] = r * W * 7 + f;
         flPl[j] = pl;
-    }
+    });
     // the final parameters of anti-diagonal d (written during step d + 1) -> ctu_params
     auto flush = [&](int d, int id, int n)
     {
         const int* buf = reinterpret_cast<const int*>(sPar + (d & 1) * H * 3);
-#pragma unroll
-        for (int j = 0; j < FB; j++)
+        sao_static_for<FB>([&](auto jc)
         {
+            constexpr int j = decltype(jc)::value;
             const int x = d - flRow[j];
             if (x >= 0 && x < W) a.params[flPl[j]][flOut[j] + x * 7] = buf[flLds[j]];
-        }
+        });
         for (int i = id + FB * n; i < H * PLANES * 7; i += n)
         {
             const int r = i / (PLANES * 7), k = i - r * (PLANES * 7), pl = k / 7, f = k - pl * 7, x = d - r;
@@ -634,13 +646,12 @@ __global__ void __launch_bounds__(768) sao_rdo_rows2_kernel(SaoRdoArgs a)       
 #pragma unroll
     for (int pl = 0; pl < PLANES; pl++) { newP[pl] = SaoP{ -1, 0, { 0, 0, 0, 0 }, 0, 0 }; prevP[pl] = newP[pl]; }
     __syncthreads();
-    for (int s = 0; s <= NS; s++)
+    // One loop PER ROLE (the wavefronts of a role run their own loop; every loop has the same NS + 1 barriers): the compiler schedules each
+    // role's step on its own - in one shared loop body the three roles' code, registers and wait counters were one problem.
+    if (role == 2)
     {
-        const SaoP* parOld = sPar + (s & 1) * H * 3;         // P of anti-diagonal s - 2
-        SaoP* parOut = sPar + ((s + 1) & 1) * H * 3;         // P of anti-diagonal s - 1 (written in this step)
-        const SaoP* newOld = sNew + ((s + 1) & 1) * H * 3;   // N of anti-diagonal s - 1
-        SaoP* newOut = sNew + (s & 1) * H * 3;               // N of anti-diagonal s (written in this step)
-        if (role == 2)
+        for (int s = 0; s <= NS; s++)
+        {
         {
             if (a.dbg & 2) {} else
             {
@@ -649,7 +660,15 @@ __global__ void __launch_bounds__(768) sao_rdo_rows2_kernel(SaoRdoArgs a)       
             if (s >= 2) flush(s - 2, ctid, ncopy);
             }
         }
-        else if (role == 1)
+            __syncthreads();
+        }
+    }
+    else if (role == 1)
+    {
+        for (int s = 0; s <= NS; s++)
+        {
+            const SaoP* parOld = sPar + (s & 1) * H * 3;         // P of anti-diagonal s - 2
+            const SaoP* newOld = sNew + ((s + 1) & 1) * H * 3;   // N of anti-diagonal s - 1
         {   // ---- the five candidate sets on the statistics of (mrow, s - mrow)  (sao.cpp:1314-1335 for each) ----
             const int col = s - mrow;
             if (mrow < H && col >= 0 && col < W && !(a.dbg & 1))
@@ -690,7 +709,17 @@ __global__ void __launch_bounds__(768) sao_rdo_rows2_kernel(SaoRdoArgs a)       
                 sD[((s & 1) * H + mrow) * 8 + mj] = mergeDist;
             }
         }
-        else if (row < H && !(a.dbg & 4))
+            __syncthreads();
+        }
+    }
+    else
+    {
+        for (int s = 0; s <= NS; s++)
+        {
+            const SaoP* parOld = sPar + (s & 1) * H * 3;         // P of anti-diagonal s - 2
+            SaoP* parOut = sPar + ((s + 1) & 1) * H * 3;         // P of anti-diagonal s - 1 (written in this step)
+            SaoP* newOut = sNew + (s & 1) * H * 3;               // N of anti-diagonal s (written in this step)
+        if (row < H && !(a.dbg & 4))
         {
             // ---- the comparison for the CTU of the previous step (sao.cpp:1336-1373) ----
             const int colF = s - 1 - row;
@@ -791,7 +820,8 @@ __global__ void __launch_bounds__(768) sao_rdo_rows2_kernel(SaoRdoArgs a)       
                 for (int pl = 0; pl < PLANES; pl++) put_param(newOut, row, pl, newP[pl]);
             }
         }
-        __syncthreads();
+            __syncthreads();
+        }
     }
     if (role == 2) { if (NS >= 2) flush(NS - 2, ctid, ncopy); flush(NS - 1, ctid, ncopy); }
     if (role == 0 && row < H) { if (noSao0) atomicAdd(&sNo[0], noSao0); if (noSao1) atomicAdd(&sNo[1], noSao1); }
@@ -851,15 +881,22 @@ extern "C" int x265hip_sao_rdo(const x265hip_sao_rdo_params* p, void* stream)
     {
         X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<3, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<1, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<3, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         ldsRaised = true;
     }
     if (a.dbg & 16) return 0;
     if (second)
     {
-        if (p->planes == 3) hipLaunchKernelGGL(sao_rdo_rows2_kernel<3>, dim3(1), dim3(threads), lds, s, a);
-        else hipLaunchKernelGGL(sao_rdo_rows2_kernel<1>, dim3(1), dim3(threads), lds, s, a);
+        if (threads <= 512)
+        {
+            if (p->planes == 3) hipLaunchKernelGGL((sao_rdo_rows2_kernel<3, 512>), dim3(1), dim3(threads), lds, s, a);
+            else hipLaunchKernelGGL((sao_rdo_rows2_kernel<1, 512>), dim3(1), dim3(threads), lds, s, a);
+        }
+        else if (p->planes == 3) hipLaunchKernelGGL((sao_rdo_rows2_kernel<3, 768>), dim3(1), dim3(threads), lds, s, a);
+        else hipLaunchKernelGGL((sao_rdo_rows2_kernel<1, 768>), dim3(1), dim3(threads), lds, s, a);
     }
     else if (p->planes == 3) hipLaunchKernelGGL(sao_rdo_rows_kernel<3>, dim3(1), dim3(threads), lds, s, a);
     else hipLaunchKernelGGL(sao_rdo_rows_kernel<1>, dim3(1), dim3(threads), lds, s, a);
