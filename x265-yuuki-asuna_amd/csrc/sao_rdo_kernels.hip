@@ -515,9 +515,9 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows_kernel(SaoRdoArgs a)
 // step s begins, and the decision lane - a lane per CTU row as before - does, in step s + 1, the comparison for X with the two that
 // apply, then at once the type decision of its next CTU: the entropy state never leaves its registers, the merge lanes have a whole
 // step for their loads, and a step is one barrier.
-// MAXT = 512 (8 wavefronts: up to 38 CTU rows, 256 registers - nothing spilled) or 768 (12 wavefronts: up to 76 rows)
-template <int PLANES, int MAXT>
-__global__ void __launch_bounds__(MAXT) sao_rdo_rows2_kernel(SaoRdoArgs a)
+// decision + merge + EIGHT copy wavefronts: 1 + 3 + 8 for a 4K picture, 2 + 6 + 8 = 1024 threads for the 68 rows of an 8K one
+template <int PLANES>
+__global__ void __launch_bounds__(1024) sao_rdo_rows2_kernel(SaoRdoArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     // [2][rows] candidate records (staged one step ahead) | [2][rows][3] final parameters P by diagonal parity | [2][rows][3] new decisions N
@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(MAXT) sao_rdo_rows2_kernel(SaoRdoArgs a)
     }
     if (tid < 2) sNo[tid] = 0;
     // candidate records: global -> registers -> LDS over two steps, as in sao_rdo_rows_kernel
-    constexpr int Q = sizeof(SaoCtuCand) / 16, B = 6;
+    constexpr int Q = sizeof(SaoCtuCand) / 16, B = 4;               // pieces per copy lane: eight copy wavefronts (a role's step is bound by the instructions ONE wavefront issues)
     uint4 stagev[B];
     bool stageok[B];
     int pieceRow[B], pieceLds[B];
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(MAXT) sao_rdo_rows2_kernel(SaoRdoArgs a)
                 reinterpret_cast<uint4*>(sCand + (t & 1) * H + r)[q] = reinterpret_cast<const uint4*>(a.cand + (size_t)r * W + x)[q];
         }
     };
-    constexpr int FB = 4;
+    constexpr int FB = 3;
     int flRow[FB], flLds[FB], flOut[FB], flPl[FB];
     sao_static_for<FB>([&](auto jc)
     {
@@ -665,6 +665,7 @@ __global__ void __launch_bounds__(MAXT) sao_rdo_rows2_kernel(SaoRdoArgs a)
     }
     else if (role == 1)
     {
+        const double rdY0 = a.lambdaCtu ? 1.0 : 1.0 / (double)a.lambda[0], rdC0 = a.lambdaCtu || PLANES == 1 ? 1.0 : 1.0 / (double)a.lambda[1];
         for (int s = 0; s <= NS; s++)
         {
             const SaoP* parOld = sPar + (s & 1) * H * 3;         // P of anti-diagonal s - 2
@@ -681,8 +682,8 @@ __global__ void __launch_bounds__(MAXT) sao_rdo_rows2_kernel(SaoRdoArgs a)
                 {
                     const int addr = mrow * W + col;
                     long long lamY = a.lambda[0], lamC = a.lambda[1];
-                    if (a.lambdaCtu) { lamY = a.lambdaCtu[2 * addr]; lamC = a.lambdaCtu[2 * addr + 1]; }
-                    const double rdY = 1.0 / (double)lamY, rdC = 1.0 / (double)lamC;
+                    double rdY = rdY0, rdC = rdC0;
+                    if (a.lambdaCtu) { lamY = a.lambdaCtu[2 * addr]; lamC = a.lambdaCtu[2 * addr + 1]; rdY = 1.0 / (double)lamY; rdC = 1.0 / (double)lamC; }
                     SaoP nb[PLANES];
                     int mc[PLANES][4], mo[PLANES][4];
 #pragma unroll
@@ -871,8 +872,8 @@ extern "C" int x265hip_sao_rdo(const x265hip_sao_rdo_params* p, void* stream)
     // the serial pass: the one-barrier organisation (sao_rdo_rows2_kernel) where its LDS fits, X265HIP_SAO_RDO_KERNEL=1 forces the first one (A/B tests)
     static const int forced = getenv("X265HIP_SAO_RDO_KERNEL") ? atoi(getenv("X265HIP_SAO_RDO_KERNEL")) : 0;
     const size_t lds2 = (size_t)2 * p->ctus_h * sizeof(SaoCtuCand) + (size_t)4 * p->ctus_h * 3 * sizeof(SaoP) + (size_t)2 * p->ctus_h * 8 * sizeof(long long);
-    const int threads2 = ((p->ctus_h + 63) / 64 + (5 * p->ctus_h + 63) / 64 + 4) * 64;
-    const bool second = forced != 1 && lds2 <= 150 * 1024 && threads2 <= 768;
+    const int threads2 = ((p->ctus_h + 63) / 64 + (5 * p->ctus_h + 63) / 64 + 8) * 64;     // decision + merge + copy wavefronts
+    const bool second = forced != 1 && lds2 <= 150 * 1024 && threads2 <= 1024;
     const int threads = second ? threads2 : ((p->ctus_h + 63) / 64 * 3 + 4) * 64;          // decision / merge-left / merge-up lanes per CTU row + four copy wavefronts
     const size_t lds = second ? lds2 : (size_t)2 * p->ctus_h * sizeof(SaoCtuCand) + (size_t)2 * p->ctus_h * 3 * sizeof(SaoP) + (size_t)p->ctus_h * 2 * sizeof(long long);
     if (lds > 150 * 1024) { set_error("sao_rdo: %d CTU rows need %zu bytes of LDS", p->ctus_h, lds); return X265HIP_EUNSUPPORTED; }
@@ -881,22 +882,15 @@ extern "C" int x265hip_sao_rdo(const x265hip_sao_rdo_params* p, void* stream)
     {
         X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<3, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<1, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<3, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         ldsRaised = true;
     }
     if (a.dbg & 16) return 0;
     if (second)
     {
-        if (threads <= 512)
-        {
-            if (p->planes == 3) hipLaunchKernelGGL((sao_rdo_rows2_kernel<3, 512>), dim3(1), dim3(threads), lds, s, a);
-            else hipLaunchKernelGGL((sao_rdo_rows2_kernel<1, 512>), dim3(1), dim3(threads), lds, s, a);
-        }
-        else if (p->planes == 3) hipLaunchKernelGGL((sao_rdo_rows2_kernel<3, 768>), dim3(1), dim3(threads), lds, s, a);
-        else hipLaunchKernelGGL((sao_rdo_rows2_kernel<1, 768>), dim3(1), dim3(threads), lds, s, a);
+        if (p->planes == 3) hipLaunchKernelGGL(sao_rdo_rows2_kernel<3>, dim3(1), dim3(threads), lds, s, a);
+        else hipLaunchKernelGGL(sao_rdo_rows2_kernel<1>, dim3(1), dim3(threads), lds, s, a);
     }
     else if (p->planes == 3) hipLaunchKernelGGL(sao_rdo_rows_kernel<3>, dim3(1), dim3(threads), lds, s, a);
     else hipLaunchKernelGGL(sao_rdo_rows_kernel<1>, dim3(1), dim3(threads), lds, s, a);
