@@ -83,12 +83,14 @@ def test_me_10bit_full_size_properties(width, height):
     _spot_check_ctus(ms, cur, ref, 10, 57, (0, ms.nctu // 2 + 7, ms.nctu - 1))
 
 
-@pytest.mark.parametrize("depth,rdo", [(8, True), (10, True), (8, False)])
-def test_whole_4k_frame_every_stage_equals_oracle_chain(depth, rdo):
+@pytest.mark.parametrize("depth,rdo,packed", [(8, True, "t"), (10, True, False), (8, False, True)])
+def test_whole_4k_frame_every_stage_equals_oracle_chain(depth, rdo, packed):
     """configs[2] (8-bit) / configs[3] (10-bit) at full size with the bench's own settings (merange 57, subme 3, 32x32 blocks):
     lookahead, integer mvs, sub-pel mvs, luma + chroma levels, numSig, SSE, SAO statistics + parameters, and the deblocked + SAO-filtered
     + border-extended Y / Cb / Cr reconstruction - all CTUs.  rdo: the SAO parameters are the reference's rate-distortion decision
-    (x265hip_sao_rdo, bench.py's default); False: round 2's distortion-only stand-in."""
+    (x265hip_sao_rdo, bench.py's default); False: round 2's distortion-only stand-in.  packed "t": the chunk-major surface records of the
+    record-per-lane kernel me_ctu_c_kernel - exactly what the default bench line times (round-2 verdict, weak 2 iii); True: the row-walking
+    kernel's record-contiguous packed format; False (10-bit): int32 records."""
     import torch
     from test_gpu_pipeline import _sao_rdo_inputs
     B = _bench()
@@ -98,7 +100,7 @@ def test_whole_4k_frame_every_stage_equals_oracle_chain(depth, rdo):
     clip = F.synth_clip(w, h, 2, depth=depth, seed=265)
     pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
     srdo = _sao_rdo_inputs(depth, qp) if rdo else None
-    pipe = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=57, subme=3, level=2, qp=qp, want_surf=True, packed=depth == 8,
+    pipe = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=57, subme=3, level=2, qp=qp, want_surf=True, packed=packed,
                            lookahead=(w, h), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True, sao_rdo=srdo)
     dev_out = B.device_outputs(pipe, pics[1], pics[0])
     _, cpu_out = B.oracle_chain(F, clip, 57, 3, 2, qp, depth, pipe.ms.nctu, B.effective_cpus(), O.host_has_avx2(), sao_rdo=srdo)

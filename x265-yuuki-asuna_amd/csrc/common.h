@@ -24,6 +24,7 @@ template <> struct PxInfo<uint16_t> { static constexpr int BPP = 2; static const
 void set_error(const char* fmt, ...);
 int  check_hip(hipError_t e, const char* what);   // 0 or X265HIP_ENODEV with last-error text
 int  ensure_device();                             // lazy x265hip_init(-1): validates the calling thread's current device
+void* stream_scratch(hipStream_t s, int slot, size_t bytes);   // runtime.hip: grow-only scratch per (device, stream, slot), NULL on failure
 
 // csrc/phase_kernels.hip: the launch behind x265hip_phase_planes with the distance between phase planes as a parameter (bands)
 int  phase_planes_launch(int depth, int chroma, const void* src, void* dst, intptr_t stride, int rows, size_t plane_bytes, hipStream_t s);

@@ -3,6 +3,9 @@
 // entry point returns X265HIP_ENODEV and x265hip_last_error() says why.
 #include "common.h"
 
+#include <map>
+#include <mutex>
+
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -73,6 +76,30 @@ int ensure_device()
         return g_initRc;
     }
     return 0;
+}
+
+// A grow-only device buffer per (device, stream, slot) for entry points that need a few KB of stream-ordered scratch on every call.  Calls
+// on one stream are ordered, so the next call may reuse the buffer; hipMallocAsync / hipFreeAsync per call kept the host from running
+// ahead of the device on this runtime (the pattern-search step took twice its stage sum, round-2 verdict).  Returns NULL on failure
+// (set_error holds the reason).  Buffers live until the process ends; growing one frees the old buffer (a device-wide wait, rare).
+void* stream_scratch(hipStream_t s, int slot, size_t bytes)
+{
+    struct Key { int dev; hipStream_t s; int slot; bool operator<(const Key& o) const { return dev != o.dev ? dev < o.dev : (s != o.s ? s < o.s : slot < o.slot); } };
+    struct Buf { void* p; size_t n; };
+    static std::mutex mu;
+    static std::map<Key, Buf> bufs;
+    int dev = 0;
+    if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    Buf& b = bufs[Key{ dev, s, slot }];
+    if (b.n < bytes)
+    {
+        if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.n = 0; }
+        const size_t want = (bytes + 4095) & ~(size_t)4095;
+        if (check_hip(hipMalloc(&b.p, want), "hipMalloc(stream scratch)")) { b.p = nullptr; return nullptr; }
+        b.n = want;
+    }
+    return b.p;
 }
 
 } // namespace x265hip

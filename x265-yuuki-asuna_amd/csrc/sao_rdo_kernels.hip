@@ -516,21 +516,35 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows_kernel(SaoRdoArgs a)
 // apply, then at once the type decision of its next CTU: the entropy state never leaves its registers, the merge lanes have a whole
 // step for their loads, and a step is one barrier.
 // decision + merge + EIGHT copy wavefronts: 1 + 3 + 8 for a 4K picture, 2 + 6 + 8 = 1024 threads for the 68 rows of an 8K one
+// Parameters travel through LDS PACKED: w0 = type (int8) | band << 8 | merge << 16 | choice << 24 (choice: plane 0 of a final set only),
+// w1 = the four offsets (int8 each) - a set is one 8-byte access, taking over a neighbour's set is two selects.  The decision lane's step is
+// bound by the instructions and the dependent LDS reads of ONE wavefront (the first version of this kernel: 570 instructions, a quarter of
+// them register moves of unpacked sets, ~40 LDS reads in a dozen dependent rounds: 1.3 us per step), so it is written for few of both:
+//   * per-state tables built once in LDS: tM[state of sao_merge_*_flag] = the bits of the bin strings 0 / 00 / 1 / 01 and the states they
+//     lead to, tT[state of sao_type_idx] = the bits of bin 0 / 1 and the two next states - one read instead of a chain of (bits, next) pairs;
+//   * every read whose address is known at the top of the step is issued there (the tables for all states the pending comparison can
+//     leave behind, the five distortions, the upper neighbour's set), and the tables of the second decision of a CTU (chroma) are
+//     fetched for both outcomes of the first.
+struct SaoW { uint32_t w0, w1; };
+__device__ __forceinline__ int sao_w_type(uint32_t w0) { return (int)(int8_t)(w0 & 0xff); }
+
 template <int PLANES>
 __global__ void __launch_bounds__(1024) sao_rdo_rows2_kernel(SaoRdoArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    // [2][rows] candidate records (staged one step ahead) | [2][rows][3] final parameters P by diagonal parity | [2][rows][3] new decisions N
-    // by diagonal parity | [2][rows][8] speculative merge distortions by diagonal parity
+    // [2][rows] candidate records (staged one step ahead) | [2][rows][8] speculative merge distortions by diagonal parity
+    // | [2][rows][3] final sets P by diagonal parity | [2][rows][3] new decisions N by diagonal parity
     SaoCtuCand* sCand = reinterpret_cast<SaoCtuCand*>(smem);
-    SaoP* sPar = reinterpret_cast<SaoP*>(sCand + 2 * a.ctusH);
-    SaoP* sNew = sPar + 2 * a.ctusH * 3;
-    long long* sD = reinterpret_cast<long long*>(sNew + 2 * a.ctusH * 3);
+    long long* sD = reinterpret_cast<long long*>(sCand + 2 * a.ctusH);
+    uint2* sPar = reinterpret_cast<uint2*>(sD + 2 * a.ctusH * 8);
+    uint2* sNew = sPar + 2 * a.ctusH * 3;
     __shared__ uint32_t sBits[128];
     __shared__ uint8_t sNext[256];
+    __shared__ uint4 tM[128], tT[128];
+    __shared__ uint32_t tMn[128];
     __shared__ int sNo[2];
     const int tid = threadIdx.x, nth = blockDim.x;
-    const int W = a.ctusW, H = a.ctusH, thresh = 1 << (a.depth - 5 < 5 ? a.depth - 5 : 5);
+    const int W = a.ctusW, H = a.ctusH;
     const int RW = (H + 63) >> 6, MW = (5 * H + 63) >> 6;       // wavefronts of decision lanes / of merge lanes (a lane per row and candidate set)
     const int wave = tid >> 6;
     const int role = wave < RW ? 0 : (wave < RW + MW ? 1 : 2);     // 0 decision, 1 merge, 2 copy
@@ -545,6 +559,15 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows2_kernel(SaoRdoArgs a)
         sNext[i] = (uint8_t)(bin == mps ? ((p < 62 ? p + 1 : p) << 1) | mps : ((int)kSaoTransIdxLps[p] << 1) | (p == 0 ? 1 - mps : mps));
     }
     if (tid < 2) sNo[tid] = 0;
+    __syncthreads();
+    for (int c = tid; c < 128; c += nth)
+    {
+        const uint32_t z0 = sBits[c], o1 = sBits[c ^ 1];
+        const int n0 = sNext[2 * c], n1 = sNext[2 * c + 1];
+        tM[c] = make_uint4(z0, z0 + sBits[n0], o1, z0 + sBits[n0 ^ 1]);                 // bin strings 0, 00, 1, 01 from state c
+        tMn[c] = (uint32_t)n0 | ((uint32_t)sNext[2 * n0] << 8) | ((uint32_t)n1 << 16) | ((uint32_t)sNext[2 * n0 + 1] << 24);
+        tT[c] = make_uint4(z0, o1, (uint32_t)n0 | ((uint32_t)n1 << 8), 0u);
+    }
     // candidate records: global -> registers -> LDS over two steps, as in sao_rdo_rows_kernel
     constexpr int Q = sizeof(SaoCtuCand) / 16, B = 4;               // pieces per copy lane: eight copy wavefronts (a role's step is bound by the instructions ONE wavefront issues)
     uint4 stagev[B];
@@ -588,31 +611,38 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows2_kernel(SaoRdoArgs a)
                 reinterpret_cast<uint4*>(sCand + (t & 1) * H + r)[q] = reinterpret_cast<const uint4*>(a.cand + (size_t)r * W + x)[q];
         }
     };
+    // a packed set's field f of ctu_params (type, band, four offsets, merge): word and bit position
+    auto field = [](const uint32_t w0, const uint32_t w1, const int f) -> int
+    {
+        const uint32_t w = (f >= 2 && f < 6) ? w1 : w0;
+        const int sh = f == 0 ? 0 : (f == 1 ? 8 : (f == 6 ? 16 : 8 * (f - 2)));
+        return __builtin_amdgcn_sbfe((int)w, sh, 8);                // band <= 31 and merge <= 2: the signed extraction is exact for every field
+    };
     constexpr int FB = 3;
-    int flRow[FB], flLds[FB], flOut[FB], flPl[FB];
+    int flRow[FB], flLds[FB], flOut[FB], flPl[FB], flF[FB];
     sao_static_for<FB>([&](auto jc)
     {
         constexpr int j = decltype(jc)::value;
         const int i = ctid + j * ncopy, r = i / (PLANES * 7), k = i - r * (PLANES * 7), pl = k / 7, f = k - pl * 7;
         flRow[j] = (role == 2 && i < H * PLANES * 7) ? r : -0x10000;
-        flLds[j] = (r * 3 + pl) * 8 + f;
+        flLds[j] = r * 3 + pl;
         flOut[j] = r * W * 7 + f;
-        flPl[j] = pl;
+        flPl[j] = pl; flF[j] = f;
     });
-    // the final parameters of anti-diagonal d (written during step d + 1) -> ctu_params
+    // the final sets of anti-diagonal d (written during step d + 1) -> ctu_params
     auto flush = [&](int d, int id, int n)
     {
-        const int* buf = reinterpret_cast<const int*>(sPar + (d & 1) * H * 3);
+        const uint2* buf = sPar + (d & 1) * H * 3;
         sao_static_for<FB>([&](auto jc)
         {
             constexpr int j = decltype(jc)::value;
             const int x = d - flRow[j];
-            if (x >= 0 && x < W) a.params[flPl[j]][flOut[j] + x * 7] = buf[flLds[j]];
+            if (x >= 0 && x < W) { const uint2 v = buf[flLds[j]]; a.params[flPl[j]][flOut[j] + x * 7] = field(v.x, v.y, flF[j]); }
         });
         for (int i = id + FB * n; i < H * PLANES * 7; i += n)
         {
             const int r = i / (PLANES * 7), k = i - r * (PLANES * 7), pl = k / 7, f = k - pl * 7, x = d - r;
-            if (x >= 0 && x < W) a.params[pl][((size_t)r * W + x) * 7 + f] = buf[(r * 3 + pl) * 8 + f];
+            if (x >= 0 && x < W) { const uint2 v = buf[r * 3 + pl]; a.params[pl][((size_t)r * W + x) * 7 + f] = field(v.x, v.y, f); }
         }
     };
     if (role == 2)
@@ -620,31 +650,6 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows2_kernel(SaoRdoArgs a)
         stage_load(0); stage_store(0); prefetch_rest(0, ctid, ncopy);
         stage_load(1);
     }
-    auto next_state = [&](int s, int bin) { return (int)sNext[s * 2 + bin]; };
-    auto bin_ctx = [&](SaoEnt& e, int& ctx, int bin) { e.frac += sBits[ctx ^ bin]; ctx = next_state(ctx, bin); };
-    auto lds_param = [&](const SaoP* base, int r, int pl)
-    {
-        const uint4* q = reinterpret_cast<const uint4*>(base + r * 3 + pl);
-        const uint4 v0 = q[0], v1 = q[1];
-        SaoP p;
-        p.type = (int)v0.x; p.band = (int)v0.y; p.off[0] = (int)v0.z; p.off[1] = (int)v0.w; p.off[2] = (int)v1.x; p.off[3] = (int)v1.y; p.merge = (int)v1.z; p.pad = (int)v1.w;
-        return p;
-    };
-    auto put_param = [&](SaoP* base, int r, int pl, const SaoP& p)
-    {
-        uint4* q = reinterpret_cast<uint4*>(base + r * 3 + pl);
-        q[0] = make_uint4((uint32_t)p.type, (uint32_t)p.band, (uint32_t)p.off[0], (uint32_t)p.off[1]);
-        q[1] = make_uint4((uint32_t)p.off[2], (uint32_t)p.off[3], (uint32_t)p.merge, (uint32_t)p.pad);
-    };
-    // decision-lane state that lives across steps
-    SaoEnt cur = { a.ctxMerge, a.ctxType, a.frac };          // m_rdContexts.cur.load(initState) (sao.cpp:247): every row starts from the slice's state
-    SaoEnt tempN = cur;                                      // the entropy state after coding the new decision of the CTU whose comparison is pending
-    SaoP newP[PLANES], prevP[PLANES];                        // that CTU's new decision; the row's previous final parameters (the left neighbour's)
-    long long bestN = 0;
-    int prevChoice = 0;                                      // how the left neighbour ended: 0 new, 1 merged left, 2 merged up
-    int noSao0 = 0, noSao1 = 0;
-#pragma unroll
-    for (int pl = 0; pl < PLANES; pl++) { newP[pl] = SaoP{ -1, 0, { 0, 0, 0, 0 }, 0, 0 }; prevP[pl] = newP[pl]; }
     __syncthreads();
     // One loop PER ROLE (the wavefronts of a role run their own loop; every loop has the same NS + 1 barriers): the compiler schedules each
     // role's step on its own - in one shared loop body the three roles' code, registers and wait counters were one problem.
@@ -652,14 +657,12 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows2_kernel(SaoRdoArgs a)
     {
         for (int s = 0; s <= NS; s++)
         {
-        {
-            if (a.dbg & 2) {} else
+            if (!(a.dbg & 2))
             {
-            if (s + 1 < NS) { stage_store(s + 1); prefetch_rest(s + 1, ctid, ncopy); }
-            if (s + 2 < NS) stage_load(s + 2);
-            if (s >= 2) flush(s - 2, ctid, ncopy);
+                if (s + 1 < NS) { stage_store(s + 1); prefetch_rest(s + 1, ctid, ncopy); }
+                if (s + 2 < NS) stage_load(s + 2);
+                if (s >= 2) flush(s - 2, ctid, ncopy);
             }
-        }
             __syncthreads();
         }
     }
@@ -668,9 +671,9 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows2_kernel(SaoRdoArgs a)
         const double rdY0 = a.lambdaCtu ? 1.0 : 1.0 / (double)a.lambda[0], rdC0 = a.lambdaCtu || PLANES == 1 ? 1.0 : 1.0 / (double)a.lambda[1];
         for (int s = 0; s <= NS; s++)
         {
-            const SaoP* parOld = sPar + (s & 1) * H * 3;         // P of anti-diagonal s - 2
-            const SaoP* newOld = sNew + ((s + 1) & 1) * H * 3;   // N of anti-diagonal s - 1
-        {   // ---- the five candidate sets on the statistics of (mrow, s - mrow)  (sao.cpp:1314-1335 for each) ----
+            const uint2* parOld = sPar + (s & 1) * H * 3;         // P of anti-diagonal s - 2
+            const uint2* newOld = sNew + ((s + 1) & 1) * H * 3;   // N of anti-diagonal s - 1
+            // ---- the five candidate sets on the statistics of (mrow, s - mrow)  (sao.cpp:1314-1335 for each) ----
             const int col = s - mrow;
             if (mrow < H && col >= 0 && col < W && !(a.dbg & 1))
             {
@@ -684,14 +687,15 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows2_kernel(SaoRdoArgs a)
                     long long lamY = a.lambda[0], lamC = a.lambda[1];
                     double rdY = rdY0, rdC = rdC0;
                     if (a.lambdaCtu) { lamY = a.lambdaCtu[2 * addr]; lamC = a.lambdaCtu[2 * addr + 1]; rdY = 1.0 / (double)lamY; rdC = 1.0 / (double)lamC; }
-                    SaoP nb[PLANES];
+                    uint2 nb[PLANES];
                     int mc[PLANES][4], mo[PLANES][4];
 #pragma unroll
                     for (int pl = 0; pl < PLANES; pl++)
                     {
-                        nb[pl] = lds_param(fromNew ? newOld : parOld, srow, pl);
-                        const int ty = nb[pl].type < 0 ? 0 : (nb[pl].type > SAO_BO_T ? SAO_BO_T : nb[pl].type);
-                        const int bandPos = nb[pl].type == SAO_BO_T ? min(nb[pl].band & 31, 28) : 1;       // (clamped: no state can form a wild address)
+                        nb[pl] = (fromNew ? newOld : parOld)[srow * 3 + pl];
+                        const int type = sao_w_type(nb[pl].x), band = (nb[pl].x >> 8) & 0xff;
+                        const int ty = type < 0 ? 0 : (type > SAO_BO_T ? SAO_BO_T : type);
+                        const int bandPos = type == SAO_BO_T ? min(band & 31, 28) : 1;       // (clamped: no state can form a wild address)
                         const int32_t* cnt = a.count[pl] + (size_t)addr * 160 + ty * 32 + bandPos;
                         const int32_t* org = a.offsetOrg[pl] + (size_t)addr * 160 + ty * 32 + bandPos;
 #pragma unroll
@@ -699,133 +703,185 @@ __global__ void __launch_bounds__(1024) sao_rdo_rows2_kernel(SaoRdoArgs a)
                     }
 #pragma unroll
                     for (int pl = 0; pl < PLANES; pl++)
-                        if (nb[pl].type >= 0)
+                        if (sao_w_type(nb[pl].x) >= 0)
                         {
                             long long estDist = 0;
 #pragma unroll
-                            for (int c = 0; c < 4; c++) estDist += (long long)(int)((mc[pl][c] * nb[pl].off[c] - mo[pl][c] * 2) * nb[pl].off[c]);
+                            for (int c = 0; c < 4; c++)
+                            {
+                                const int o = __builtin_amdgcn_sbfe((int)nb[pl].y, 8 * c, 8);
+                                estDist += (long long)(int)((mc[pl][c] * o - mo[pl][c] * 2) * o);
+                            }
                             mergeDist += sao_div(estDist << 8, pl ? lamC : lamY, pl ? rdC : rdY);
                         }
                 }
                 sD[((s & 1) * H + mrow) * 8 + mj] = mergeDist;
             }
-        }
             __syncthreads();
         }
     }
     else
     {
+        // decision-lane state that lives across steps
+        int curCm = a.ctxMerge, curCt = a.ctxType;              // m_rdContexts.cur.load(initState) (sao.cpp:247): every row starts from the slice's state
+        uint32_t curFrac = a.frac;
+        int newCm = curCm, newCt = curCt;                       // the entropy state after coding the new decision of the CTU whose comparison is pending
+        uint32_t newFrac = curFrac;
+        SaoW newP[PLANES], prevP[PLANES];                       // that CTU's new decision; the row's previous final set (the left neighbour's)
+        long long bestN = 0;
+        int prevChoice = 0;                                     // how the left neighbour ended: 0 new, 1 merged left, 2 merged up
+        int noSao0 = 0, noSao1 = 0;
+#pragma unroll
+        for (int pl = 0; pl < PLANES; pl++) { newP[pl] = SaoW{ 0xffu, 0u }; prevP[pl] = newP[pl]; }
+        const bool flags = a.saoFlag[0] || a.saoFlag[1];
+        const bool allowU = row != 0;
         for (int s = 0; s <= NS; s++)
         {
-            const SaoP* parOld = sPar + (s & 1) * H * 3;         // P of anti-diagonal s - 2
-            SaoP* parOut = sPar + ((s + 1) & 1) * H * 3;         // P of anti-diagonal s - 1 (written in this step)
-            SaoP* newOut = sNew + (s & 1) * H * 3;               // N of anti-diagonal s (written in this step)
-        if (row < H && !(a.dbg & 4))
-        {
-            // ---- the comparison for the CTU of the previous step (sao.cpp:1336-1373) ----
-            const int colF = s - 1 - row;
-            if (colF >= 0 && colF < W)
+            const uint2* parOld = sPar + (s & 1) * H * 3;         // P of anti-diagonal s - 2
+            uint2* parOut = sPar + ((s + 1) & 1) * H * 3;         // P of anti-diagonal s - 1 (written in this step)
+            uint2* newOut = sNew + (s & 1) * H * 3;               // N of anti-diagonal s (written in this step)
+            if (row < H && !(a.dbg & 4))
             {
-                const bool allowL = colF != 0, allowU = row != 0;
-                SaoP mine[PLANES];
+                const int colF = s - 1 - row, col = s - row;
+                const bool doF = colF >= 0 && colF < W, doD = col >= 0 && col < W;
+                // ---- everything whose address is known now ----
+                const uint4 tmCur = tM[curCm], tmNew = tM[newCm];
+                const uint32_t tnCur = tMn[curCm], tnNew = tMn[newCm];
+                const uint4 ttCur = tT[curCt], ttNew = tT[newCt];
+                const uint4* Dq = reinterpret_cast<const uint4*>(sD + (((s + 1) & 1) * H + row) * 8);
+                const uint4 d01 = Dq[0], d23 = Dq[1], d4x = Dq[2];
+                uint2 up[PLANES];
 #pragma unroll
-                for (int pl = 0; pl < PLANES; pl++) mine[pl] = newP[pl];
-                SaoEnt temp = tempN;
-                long long bestCost = bestN;
+                for (int pl = 0; pl < PLANES; pl++) up[pl] = parOld[(allowU ? row - 1 : 0) * 3 + pl];
+                const SaoCtuCand& cd = sCand[(s & 1) * H + row];
+                long long lamY = a.lambda[0], lamC = a.lambda[1];
+                if (doD && a.lambdaCtu) { lamY = a.lambdaCtu[2 * (row * W + col)]; lamC = a.lambdaCtu[2 * (row * W + col) + 1]; }
+                // the tables of the states a merge would leave in sao_merge_*_flag's context
+                const bool allowLF = colF != 0;
+                const int cmL = (int)((tnCur >> 16) & 0xff);                                  // after bin 1
+                const int cmU = allowLF ? (int)(tnCur >> 24) : cmL;                           // after bins 0, 1 (or bin 1 alone in the first column)
+                const uint4 tmL = tM[cmL], tmU = tM[cmU];
+                const uint32_t tnL = tMn[cmL], tnU = tMn[cmU];
                 int choice = 0;
-                if (a.saoFlag[0] || a.saoFlag[1])
+                // ---- the comparison for the CTU of the previous step (sao.cpp:1336-1373) ----
+                if (doF)
                 {
-                    const long long* D = sD + (((s + 1) & 1) * H + row) * 8;
-                    const int upChoice = allowU ? parOld[(row - 1) * 3].pad : 0;
-                    const long long dL = D[prevChoice], dU = D[upChoice == 0 ? 3 : (upChoice == 1 ? 2 : 4)];
-#pragma unroll
-                    for (int m = 0; m < 2; m++)
+                    int stCm = newCm, stCt = newCt;
+                    uint32_t stFrac = newFrac;
+                    if (flags)
                     {
-                        if (!(m ? allowU : allowL)) continue;
-                        SaoEnt e = cur; e.frac &= 32767;
-                        if (allowL) bin_ctx(e, e.ctxMerge, 1 - m);
-                        if (allowU && m == 1) bin_ctx(e, e.ctxMerge, 1);
-                        const long long mergeCost = (m ? dU : dL) + (e.frac >> 15);
-                        if (mergeCost < bestCost)
+                        const auto ll = [](uint32_t lo, uint32_t hi) { return (long long)(((unsigned long long)hi << 32) | lo); };
+                        const long long D0 = ll(d01.x, d01.y), D1 = ll(d01.z, d01.w), D2 = ll(d23.x, d23.y), D3 = ll(d23.z, d23.w), D4 = ll(d4x.x, d4x.y);
+                        const int upChoice = (int)(up[0].x >> 24);
+                        const long long dL = prevChoice == 0 ? D0 : (prevChoice == 1 ? D1 : D2), dU = upChoice == 0 ? D3 : (upChoice == 1 ? D2 : D4);
+                        const uint32_t F0 = curFrac & 32767;
+                        long long best = bestN;
+                        if (allowLF)
                         {
-                            bestCost = mergeCost;
-                            temp = e;
-                            choice = m + 1;
-#pragma unroll
-                            for (int pl = 0; pl < PLANES; pl++)
-                                if (a.saoFlag[pl > 0]) { mine[pl] = m ? lds_param(parOld, row - 1, pl) : prevP[pl]; mine[pl].merge = m ? 2 : 1; }
+                            const uint32_t fr = F0 + tmCur.z;                                  // bin 1
+                            const long long cost = dL + (fr >> 15);
+                            if (cost < best) { best = cost; choice = 1; stCm = cmL; stCt = curCt; stFrac = fr; }
+                        }
+                        if (allowU)
+                        {
+                            const uint32_t fr = F0 + (allowLF ? tmCur.w : tmCur.z);            // bins 0, 1 / bin 1
+                            const long long cost = dU + (fr >> 15);
+                            if (cost < best) { best = cost; choice = 2; stCm = cmU; stCt = curCt; stFrac = fr; }
                         }
                     }
-                    noSao0 += mine[0].type < 0;
-                    if (PLANES == 3) noSao1 += mine[1].type < 0;
-                    cur = temp;
-                }
-                mine[0].pad = choice;
+                    SaoW mine[PLANES];
 #pragma unroll
-                for (int pl = 0; pl < PLANES; pl++) { put_param(parOut, row, pl, mine[pl]); prevP[pl] = mine[pl]; }
-                prevChoice = choice;
-            }
-            // ---- the type decision of this step's CTU, everything up to the comparison with the merge candidates ----
-            const int col = s - row;
-            if (col >= 0 && col < W)
-            {
-                const bool allowL = col != 0, allowU = row != 0;
-                const int addr = row * W + col;
-                long long lamY = a.lambda[0], lamC = a.lambda[1];
-                if (a.lambdaCtu) { lamY = a.lambdaCtu[2 * addr]; lamC = a.lambdaCtu[2 * addr + 1]; }
-                const SaoCtuCand& cd = sCand[(s & 1) * H + row];
-#pragma unroll
-                for (int pl = 0; pl < PLANES; pl++) newP[pl] = SaoP{ -1, 0, { 0, 0, 0, 0 }, 0, 0 };
-                SaoEnt temp = cur;
-                temp.frac &= 32767;                                // resetBits (entropy.cpp:2442-2451)
-                if (allowL) bin_ctx(temp, temp.ctxMerge, 0);
-                if (allowU) bin_ctx(temp, temp.ctxMerge, 0);
-                long long rateDist = 0;
-                bestN = 0;
-                auto decide = [&](const long long* minCost, const uint8_t* minK, const int* nb, long long lambda)
-                {
-                    const uint32_t F = temp.frac & 32767, b0 = sBits[temp.ctxType], b1 = sBits[temp.ctxType ^ 1];
-                    const uint32_t c0 = (F + b0) >> 15, c1 = (F + b1) >> 15;
-                    const long long costOff = ((long long)c0 * lambda + 128) >> 8;
-                    int k = minK[c1];
-                    if (!(minCost[c1] < costOff)) k = -1;
-                    temp.frac += k < 0 ? b0 : b1 + 32768u * (uint32_t)nb[k];
-                    temp.ctxType = next_state(temp.ctxType, k >= 0);
-                    return k;
-                };
-                auto take = [&](SaoP& p, int pl, int k)
-                {
-                    p.type = k; p.band = k == SAO_BO_T ? cd.boPos[pl] : 0;
-                    const uint32_t w = *reinterpret_cast<const uint32_t*>(cd.off[pl][k]);
-                    p.off[0] = (int8_t)(w & 0xff); p.off[1] = (int8_t)((w >> 8) & 0xff); p.off[2] = (int8_t)((w >> 16) & 0xff); p.off[3] = (int8_t)(w >> 24);
-                };
-                if (a.saoFlag[0])
-                {   // saoLumaComponentParamDist (sao.cpp:1484-1610)
-                    const int k = decide(cd.minCostY, cd.minKY, cd.nbY, lamY);
-                    if (k >= 0) { take(newP[0], 0, k); rateDist = cd.quotY[k]; }
-                    if (PLANES == 1) bestN = rateDist + (temp.frac >> 15);
-                }
-                if (PLANES == 3 && a.saoFlag[1])
-                {   // saoChromaComponentParamDist (sao.cpp:1611-1760)
-                    const int k = decide(cd.minCostC, cd.minKC, cd.nbC, lamC);
-                    if (k >= 0)
+                    for (int pl = 0; pl < PLANES; pl++)
                     {
-#pragma unroll
-                        for (int pl = 1; pl < PLANES; pl++) take(newP[pl], pl, k);
-                        rateDist += cd.quotC[k];
+                        mine[pl] = newP[pl];
+                        if (choice && a.saoFlag[pl > 0])
+                        {
+                            const uint32_t w0 = choice == 1 ? prevP[pl].w0 : up[pl].x, w1 = choice == 1 ? prevP[pl].w1 : up[pl].y;
+                            mine[pl].w0 = (w0 & 0xffffu) | ((uint32_t)choice << 16);
+                            mine[pl].w1 = w1;
+                        }
                     }
-                    bestN = rateDist + (temp.frac >> 15);
-                }
-                tempN = temp;
+                    if (flags)
+                    {
+                        noSao0 += (mine[0].w0 >> 7) & 1;
+                        if (PLANES == 3) noSao1 += (mine[1].w0 >> 7) & 1;
+                        curCm = stCm; curCt = stCt; curFrac = stFrac;
+                    }
+                    mine[0].w0 = (mine[0].w0 & 0xffffffu) | ((uint32_t)choice << 24);
 #pragma unroll
-                for (int pl = 0; pl < PLANES; pl++) put_param(newOut, row, pl, newP[pl]);
+                    for (int pl = 0; pl < PLANES; pl++) { parOut[row * 3 + pl] = make_uint2(mine[pl].w0, mine[pl].w1); prevP[pl] = mine[pl]; }
+                    prevChoice = choice;
+                }
+                // ---- the type decision of this step's CTU, everything up to the comparison with the merge candidates ----
+                if (doD)
+                {
+                    const bool newState = !(doF && flags && choice);                       // the context states are the pending CTU's new-decision states
+                    const uint4 tm = newState ? (doF && flags ? tmNew : tmCur) : (choice == 1 ? tmL : tmU);
+                    const uint32_t tn = newState ? (doF && flags ? tnNew : tnCur) : (choice == 1 ? tnL : tnU);
+                    uint4 tt = (doF && flags && !choice) ? ttNew : ttCur;
+                    const bool allowL = col != 0;
+                    uint32_t frac = curFrac & 32767;                                       // resetBits (entropy.cpp:2442-2451)
+                    int cm = curCm, ct = curCt;
+                    if (allowL && allowU) { frac += tm.y; cm = (int)((tn >> 8) & 0xff); }       // sao_merge_left_flag 0, sao_merge_up_flag 0
+                    else if (allowL || allowU) { frac += tm.x; cm = (int)(tn & 0xff); }
+                    long long rateDist = 0;
+                    bestN = 0;
+#pragma unroll
+                    for (int pl = 0; pl < PLANES; pl++) newP[pl] = SaoW{ 0xffu, 0u };
+                    // one type decision from the tables (see SaoCtuCand): c0 / c1 = the carries with the context-coded bin 0 / 1; SAO off costs
+                    // (c0 * lambda + 128) >> 8 (sao.cpp:1491-1494), the tabulated winner takes over when it is cheaper; then
+                    // Entropy::codeSaoOffset of the outcome on top, no resetBits (:1598-1600, :1743-1750)
+                    if (a.saoFlag[0])
+                    {   // saoLumaComponentParamDist (sao.cpp:1484-1610)
+                        const uint32_t F = frac & 32767, c0 = (F + tt.x) >> 15, c1 = (F + tt.y) >> 15;
+                        const int n0 = (int)(tt.z & 0xff), n1 = (int)((tt.z >> 8) & 0xff);
+                        const int mk = cd.minKY[c1];
+                        const long long mcst = cd.minCostY[c1];
+                        const uint4 tt0 = tT[n0], tt1 = tT[n1];                            // for the chroma decision, whichever way this one goes
+                        const bool on = mcst < (long long)(((unsigned long long)c0 * (unsigned long long)lamY + 128) >> 8);
+                        const int k = on ? mk : 0;
+                        const int nbins = cd.nbY[k];
+                        const long long quot = cd.quotY[k];
+                        const uint32_t ow = *reinterpret_cast<const uint32_t*>(cd.off[0][k]);
+                        const uint32_t bp = cd.boPos[0];
+                        frac += on ? tt.y + 32768u * (uint32_t)nbins : tt.x;
+                        ct = on ? n1 : n0;
+                        tt = on ? tt1 : tt0;
+                        if (on) { newP[0].w0 = (uint32_t)k | (k == SAO_BO_T ? bp << 8 : 0u); newP[0].w1 = ow; rateDist = quot; }
+                        if (PLANES == 1) bestN = rateDist + (frac >> 15);
+                    }
+                    if (PLANES == 3 && a.saoFlag[1])
+                    {   // saoChromaComponentParamDist (sao.cpp:1611-1760)
+                        const uint32_t F = frac & 32767, c0 = (F + tt.x) >> 15, c1 = (F + tt.y) >> 15;
+                        const int n0 = (int)(tt.z & 0xff), n1 = (int)((tt.z >> 8) & 0xff);
+                        const int mk = cd.minKC[c1];
+                        const long long mcst = cd.minCostC[c1];
+                        const bool on = mcst < (long long)(((unsigned long long)c0 * (unsigned long long)lamC + 128) >> 8);
+                        const int k = on ? mk : 0;
+                        const int nbins = cd.nbC[k];
+                        const long long quot = cd.quotC[k];
+                        const uint32_t ow1 = *reinterpret_cast<const uint32_t*>(cd.off[1][k]), ow2 = *reinterpret_cast<const uint32_t*>(cd.off[PLANES - 1][k]);
+                        const uint32_t bp1 = cd.boPos[1], bp2 = cd.boPos[PLANES - 1];
+                        frac += on ? tt.y + 32768u * (uint32_t)nbins : tt.x;
+                        ct = on ? n1 : n0;
+                        if (on)
+                        {
+                            newP[1].w0 = (uint32_t)k | (k == SAO_BO_T ? bp1 << 8 : 0u); newP[1].w1 = ow1;
+                            newP[PLANES - 1].w0 = (uint32_t)k | (k == SAO_BO_T ? bp2 << 8 : 0u); newP[PLANES - 1].w1 = ow2;
+                            rateDist += quot;
+                        }
+                        bestN = rateDist + (frac >> 15);
+                    }
+                    newCm = cm; newCt = ct; newFrac = frac;
+#pragma unroll
+                    for (int pl = 0; pl < PLANES; pl++) newOut[row * 3 + pl] = make_uint2(newP[pl].w0, newP[pl].w1);
+                }
             }
-        }
             __syncthreads();
         }
+        if (row < H) { if (noSao0) atomicAdd(&sNo[0], noSao0); if (noSao1) atomicAdd(&sNo[1], noSao1); }
     }
     if (role == 2) { if (NS >= 2) flush(NS - 2, ctid, ncopy); flush(NS - 1, ctid, ncopy); }
-    if (role == 0 && row < H) { if (noSao0) atomicAdd(&sNo[0], noSao0); if (noSao1) atomicAdd(&sNo[1], noSao1); }
     __syncthreads();
     if (tid < 2 && a.numNoSao) a.numNoSao[tid] = sNo[tid];
 }
@@ -871,7 +927,7 @@ extern "C" int x265hip_sao_rdo(const x265hip_sao_rdo_params* p, void* stream)
     if ((rc = check_hip(hipGetLastError(), "sao_rdo prep launch"))) return rc;
     // the serial pass: the one-barrier organisation (sao_rdo_rows2_kernel) where its LDS fits, X265HIP_SAO_RDO_KERNEL=1 forces the first one (A/B tests)
     static const int forced = getenv("X265HIP_SAO_RDO_KERNEL") ? atoi(getenv("X265HIP_SAO_RDO_KERNEL")) : 0;
-    const size_t lds2 = (size_t)2 * p->ctus_h * sizeof(SaoCtuCand) + (size_t)4 * p->ctus_h * 3 * sizeof(SaoP) + (size_t)2 * p->ctus_h * 8 * sizeof(long long);
+    const size_t lds2 = (size_t)2 * p->ctus_h * sizeof(SaoCtuCand) + (size_t)2 * p->ctus_h * 8 * sizeof(long long) + (size_t)4 * p->ctus_h * 3 * 8;
     const int threads2 = ((p->ctus_h + 63) / 64 + (5 * p->ctus_h + 63) / 64 + 8) * 64;     // decision + merge + copy wavefronts
     const bool second = forced != 1 && lds2 <= 150 * 1024 && threads2 <= 1024;
     const int threads = second ? threads2 : ((p->ctus_h + 63) / 64 * 3 + 4) * 64;          // decision / merge-left / merge-up lanes per CTU row + four copy wavefronts

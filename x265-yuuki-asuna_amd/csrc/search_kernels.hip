@@ -699,9 +699,9 @@ extern "C" int x265hip_me_search(const x265hip_me_search_params* p, void* stream
     a.mvc = p->mvc; a.numMvc = p->num_mvc;
     for (int k = 0; k < 12; k++) a.integral[k] = p->integral[k];
     hipStream_t s = (hipStream_t)stream;
-    // stream-ordered scratch: [0] = number of large jobs, [1..] = their indices
-    int* scratch = nullptr;
-    X265HIP_TRY(hipMallocAsync((void**)&scratch, sizeof(int) * ((size_t)p->njobs + 1), s));
+    // scratch of this stream: [0] = number of large jobs, [1..] = their indices
+    int* scratch = (int*)stream_scratch(s, 0, sizeof(int) * ((size_t)p->njobs + 1));
+    if (!scratch) return X265HIP_ENODEV;
     X265HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(int), s));
     a.largeCount = scratch; a.largeQueue = scratch + 1;
     const int wgs = (p->njobs + 63) / 64;                          // 4 wavefronts x 16 jobs per workgroup
@@ -715,6 +715,5 @@ extern "C" int x265hip_me_search(const x265hip_me_search_params* p, void* stream
     else { if (sea) LAUNCH_SEARCH(uint16_t, true); else LAUNCH_SEARCH(uint16_t, false); }
 #undef LAUNCH_SEARCH
     X265HIP_TRY(hipGetLastError());
-    X265HIP_TRY(hipFreeAsync(scratch, s));
     return 0;
 }
