@@ -545,9 +545,15 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
 // (real barriers, three of them idle through the matrix-core transforms) ran 241 us per 4K picture against 99 us (profiles/r03_tail_kernels.txt) -
 // the stage is bound by the instructions it issues, not by the latency of one block's chain.
 template <int N> struct InterReconThreads { static constexpr int value = N >= 16 ? 64 : 256; };
+// Wavefronts per SIMD the single-wavefront 16 / 32 point kernels are compiled for.  Left to itself the compiler took 284 - 401 registers
+// for the 32x32 kernels (a 64-thread workgroup may have 512): ONE resident wavefront per SIMD, every LDS and memory wait of a block's
+// chain exposed - 103 us per 4K picture for luma.  Two wavefronts (256 registers, nothing spilled): 73 us.  Three (170 registers, 86
+// spilled) lose again: 109 us; the 16x16 kernels sit at ~190 registers = two wavefronts by themselves, and forcing three or four
+// (spills) made the chroma pair slower, 81 -> 93 / 85 us (profiles/r03_tail_kernels.txt).
+template <int N> struct TuWavesPerSimd { static constexpr int value = N == 32 ? 2 : (N == 16 ? 2 : 1); };
 
 template <typename Px, int N, bool CHROMA, bool TAB = false>
-__global__ void __launch_bounds__(InterReconThreads<N>::value) inter_recon_kernel(TuArgs2 aa, int nblocks)
+__global__ void __launch_bounds__(InterReconThreads<N>::value, TuWavesPerSimd<N>::value) inter_recon_kernel(TuArgs2 aa, int nblocks)
 {
     const TuArgs& a = aa.p[blockIdx.y];          // grid.y = plane: Cb and Cr of a picture (or of a band of it) share one launch
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
@@ -694,7 +700,7 @@ struct TuBiArgs
 // CHROMA: one chroma plane of a 4:2:0 picture (N = the chroma block size, 1/8-sample mvs, the 4-tap filters; predInterChromaShort,
 // predict.cpp:355-409, for the short predictions)
 template <typename Px, int N, bool CHROMA, bool TAB = false>
-__global__ void __launch_bounds__(N >= 16 ? 64 : 256) inter_recon_bi_kernel(TuBiArgs b, int nblocks)
+__global__ void __launch_bounds__(N >= 16 ? 64 : 256, TuWavesPerSimd<N>::value) inter_recon_bi_kernel(TuBiArgs b, int nblocks)
 {
     const TuArgs& a = b.t;
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
@@ -844,7 +850,7 @@ struct IntraTuArgs
 
 // DST: the 4x4 intra LUMA TU (chroma 4x4 takes the DCT)
 template <typename Px, int N, bool DST, bool TAB = false>
-__global__ void __launch_bounds__(N <= 8 ? 256 : 64) intra_recon_kernel(IntraTuArgs a)
+__global__ void __launch_bounds__(N <= 8 ? 256 : 64, TuWavesPerSimd<N>::value) intra_recon_kernel(IntraTuArgs a)
 {
     constexpr int NN = N * N, LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
     constexpr int BPP = sizeof(Px);
