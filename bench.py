@@ -529,6 +529,12 @@ def main():
         for (_, e0), (name, e1) in zip(evs[:-1], evs[1:]):
             acc.setdefault(name, []).append(e0.elapsed_time(e1))
     stages = {k: round(float(np.median(v)), 4) for k, v in acc.items()}
+    # The pattern searches are data-dependent (early exits, STAR's raster refinement): stages_ms is the median of five runs of ONE frame pair
+    # (frame 1 searched in the last reference), ms_per_step the average over the closed loop including the synthetic clip's wrap-around
+    # pairs - for --search star the two differ by 2x, and that is GPU time of the search launches, not a host stall
+    # (profiles/r03_search_star_stats.txt).  The exhaustive search (the default) does the same work for every pair.
+    stages_note = None if args.search == "full" else ("data-dependent search: stages_ms is one frame pair (frame 1 vs the last reference), "
+                                                      "ms_per_step averages the closed loop incl. the clip's wrap-around pairs")
     if pipe.lcb:
         # the lookahead's cost estimate: one launch scores `lookahead_batch` pictures on its own stream, overlapped with the stages above
         b = pipe.lcb
@@ -576,6 +582,7 @@ def main():
                            "ring_model": "N pictures per max(step, N x lag), lag = the band periods until the reference rows a band's search window "
                                          "reaches are final + a hand-over (DESIGN.md section 6; band size chosen from N by pick_band_rows)"} if banded else {})},
             "stages_ms": stages,
+            **({"stages_note": stages_note} if stages_note else {}),
             "roofline": {"bound": "hbm", "kernel": "me_search_kernel" if args.search != "full" else
                                    (("me_ctu_c_kernel" if surf_mode and ms.tiled else "me_ctu_q_kernel") if args.depth == 8 else "me_ctu_w_kernel")
                                    + ("<surf,best>" if surf_mode else "<best>"),
