@@ -340,6 +340,9 @@ def main():
                     help="rdo (default): the reference's own rate-distortion decision of the SAO parameters on the device (x265hip_sao_rdo = "
                          "SAO::rdoSaoUnitCu: offset iteration, CABAC bit counts, merge candidates; ~0.3 ms of serial CTU-row walk at 4K); standin: round 2's "
                          "distortion-only choice (x265hip_sao_decide, 0.01 ms) - not what x265 decides")
+    ap.add_argument("--ref-handoff", choices=["swap", "copy"], default="swap",
+                    help="one GPU: how the picture a step produced becomes the next step's reference - swap = the decoded-picture buffer "
+                         "ping-pongs (no copy), copy = three plane copies per step (rounds 1-2)")
     ap.add_argument("--no-encoder", action="store_true",
                     help="skip the encoder-level leg (tier T3): the REAL reference encoder (oracle/_ref) on BASELINE configs[2] - 4K, preset slow, "
                          "--me star - with its own C table and with the stage-level seams (integer-search SADs from x265hip_me_cache surfaces, the "
@@ -474,8 +477,15 @@ def main():
                 fp.exchange(ref_pic.planes(), bp.final_planes())
             return
         pipe.run(cur, ref_pic)
-        # frame-parallel hand-off: the last rank's filtered reconstruction (Y, Cb, Cr) becomes everyone's next reference
-        fp.exchange(ref_pic.planes(), pipe.final_planes())
+        # the filtered reconstruction (Y, Cb, Cr) becomes the next reference.  One GPU: the decoded-picture buffer ping-pongs - the planes the
+        # step wrote ARE the next reference and the replaced reference's planes receive the next picture (three plane copies and the gaps
+        # around them were 50 - 70 us of the step, profiles/r03_step_timeline.txt; --ref-handoff copy keeps them).  N > 1: the frame-parallel
+        # hand-off, the last rank's picture becomes everyone's reference.
+        new = pipe.swap_output(ref_pic.planes()) if (world == 1 and args.ref_handoff == "swap") else None
+        if new is not None:
+            ref_pic.t, ref_pic.c = new[0], (list(new[1:3]) if len(new) >= 3 else None)
+        else:
+            fp.exchange(ref_pic.planes(), pipe.final_planes())
 
     for i in range(args.warmup):
         step(i)

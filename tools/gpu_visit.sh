@@ -7,6 +7,7 @@
 #   bench[:<args>]          python bench.py [args]                             -> bench[_N].json / .err
 #   stats[:<args>]          rocprofv3 --kernel-trace --stats of bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-encoder [args]
 #                                                                                -> kernel_stats[_N].txt
+#   timeline[:<args>]       rocprofv3 --kernel-trace of the same command -> the dispatches of ONE steady-state step with start / end / idle gaps -> timeline_N.txt
 #   pmc[:<args>]            two PMC passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of the same command -> pmc[_N].txt
 #   variants                the bench variants table (10-bit, 1080p, 8K 10-bit, star / hex, no surfaces, banded) -> variants.txt
 #   py:<script> [args]      python <script> args (':'-separated), e.g. py:tools/phase_probe.py:--depth:10      -> py_N.log
@@ -23,7 +24,7 @@ BENCH_PROF="--steps 10 --warmup 2 --no-cpu-baseline --no-encoder"
 for step in "$@"; do
     n=$((n + 1))
     kind=${step%%:*}; arg=""; [ "$step" != "$kind" ] && arg=${step#*:}
-    case $kind in tests|bench|stats|pmc) arg=${arg//:/ } ;; esac          # ':' separates arguments (bench:--no-encoder:--steps:20)
+    case $kind in tests|bench|stats|pmc|timeline) arg=${arg//:/ } ;; esac          # ':' separates arguments (bench:--no-encoder:--steps:20)
     echo "=== [$n] $step"
     case $kind in
     tests)
@@ -48,6 +49,11 @@ PY
         python tools/rocprof_summary.py kernel-trace $(find "$OUT/stats_$n" -name '*.db' | head -1) > "$OUT/kernel_stats_$n.txt" 2>&1 || true
         find "$OUT/stats_$n" -name '*.db' -delete
         grep -v "at::native\|rocclr" "$OUT/kernel_stats_$n.txt" | head -40 ;;
+    timeline)
+        ( cd /tmp && timeout 900 rocprofv3 --kernel-trace -d "$OUT/tl_$n" -o bench -- python "$ROOT/bench.py" $BENCH_PROF $arg > /dev/null 2> "$OUT/tl_$n.err" )
+        python tools/rocprof_summary.py timeline $(find "$OUT/tl_$n" -name '*.db' | head -1) > "$OUT/timeline_$n.txt" 2>&1 || true
+        find "$OUT/tl_$n" -name '*.db' -delete
+        cat "$OUT/timeline_$n.txt" ;;
     pmc)
         for c in FETCH_SIZE WRITE_SIZE; do
             ( cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace -d "$OUT/pmc_${c}_$n" -o bench -- python "$ROOT/bench.py" $BENCH_PROF $arg > /dev/null 2> "$OUT/pmc_${c}_$n.err" )

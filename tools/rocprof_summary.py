@@ -33,8 +33,36 @@ def pmc(paths):
             print(f"{short(k):92s} {c:>12s} {n:4d} {a:16.2f} {mn:16.2f} {mx:16.2f} {d:12.0f}")
 
 
+def timeline(path, anchor="me_ctu"):
+    """Dispatch timeline of ONE steady-state step: every kernel between the start of the last-but-one launch whose name contains `anchor`
+    and the start of the last one - start / end relative to the anchor's start, queue, and the device idle time before each dispatch."""
+    c = sqlite3.connect(path)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    cols = [r[1] for r in c.execute(f"pragma table_info({kd})")]
+    q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    rows = c.execute(f"select d.start, d.end, s.kernel_name, d.{q} from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
+    anchors = [i for i, r in enumerate(rows) if anchor in r[2]]
+    if len(anchors) < 3:
+        print(f"fewer than three launches of {anchor}"); return
+    # the middle of the run: bench.py's timed loop (the first launches are warm-up, the last ones its one-stream stage-timing pass)
+    a0, a1 = anchors[len(anchors) // 2 - 1], anchors[len(anchors) // 2]
+    t0 = rows[a0][0]
+    print(f"# one step of {path}: from the start of one {anchor} launch to the start of the next = {(rows[a1][0] - t0) / 1e3:.1f} us")
+    print(f"{'start_us':>9s} {'end_us':>9s} {'dur_us':>8s} {'idle_before_us':>14s} {'queue':>6s}  kernel")
+    busy_until = t0
+    for s_, e_, n, qq in rows[a0:a1 + 1]:
+        idle = max(0, s_ - busy_until)
+        name = n.split("(")[0].replace("void ", "").replace("x265hip::", "")
+        print(f"{(s_ - t0) / 1e3:9.1f} {(e_ - t0) / 1e3:9.1f} {(e_ - s_) / 1e3:8.1f} {idle / 1e3:14.1f} {str(qq):>6s}  {short(name, 80)}")
+        busy_until = max(busy_until, e_)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "kernel-trace":
         kernel_trace(sys.argv[2])
+    elif sys.argv[1] == "timeline":
+        timeline(*sys.argv[2:4])
     else:
         pmc(sys.argv[2:])

@@ -136,6 +136,19 @@ class MotionSearch:
         if self.best is not None:
             hipabi.me_best_reset(self.best)
 
+    def reset_spare(self, stream=None):
+        """Double-buffered minima: clears the buffer the NEXT picture's search will merge into (on `stream`, next to this picture's
+        stages) - the 8 us fill and the gap in front of it leave the chain between two searches.  swap_best() makes it current."""
+        import torch
+        if self.best is None:
+            return
+        if getattr(self, "best_spare", None) is None:
+            self.best_spare = torch.empty_like(self.best)
+        hipabi.me_best_reset(self.best_spare, stream=stream)
+
+    def swap_best(self):
+        self.best, self.best_spare = self.best_spare, self.best
+
     def run(self, cur: DevicePicture, ref: DevicePicture):
         self.reset()
         self.search(cur, ref)

@@ -571,6 +571,8 @@ class FramePipeline:
         # only) next to the search; everything joins the caller's stream before run() returns
         self.parallel = bool(parallel_planes)
         self.pstreams = None
+        self._spare_ready = None
+        self.schedule2 = os.environ.get("X265HIP_PAR_SCHEDULE", "2") != "1"          # 1: the round-2 schedule (A/B runs)
         self.split = max(1, min(int(split), h64 // 64))
         self.parts = None
         # the three planes' SAO passes as one launch per step: on by default where every launch is on one stream (0.144 vs 0.187 ms at 4K);
@@ -772,6 +774,8 @@ class FramePipeline:
         if self.out is None:
             self.out = torch.zeros_like(cur.t)
             self.out_c = [torch.zeros_like(p) for p in cur.c]
+        if self.sao_rdo is not None and self.split == 1 and not self.prep_next_to_search and self.la_after_search and self.schedule2 and self.band_border is None:
+            return self._run_parallel2(cur, ref, main, sCb, sLa)
         start = torch.cuda.Event(); start.record(main)
         # The lookahead of the source picture only depends on the source, but it does not run next to the search: the record-per-lane search
         # kernel loses more to any co-resident kernel than that kernel takes (see split below); next to the latency-bound stages behind the
@@ -870,6 +874,78 @@ class FramePipeline:
             main.wait_event(e)
         self.final, self.final_c = self.out, self.out_c
         return self.final
+
+    def _run_parallel2(self, cur, ref, main, sC, sLa):
+        """The launch schedule of the default bench step since round 3, read off the dispatch timeline of one step
+        (tools/gpu_visit.sh timeline, profiles/r03_step_timeline.txt).  Same launches and outputs as run(); what moved:
+          * Cb + Cr are ONE chain of pair launches on one side stream (reconstruction pair, deblocking of both planes, statistics of both
+            planes): two chains of half-size launches next to the luma chain each ran 1.8x their stand-alone time and ended 50 us after it;
+          * the lookahead of the source picture starts when the luma statistics are done, i.e. next to the SAO decision - a serial pass
+            on ONE compute unit (115 us with the other 255 idle) - instead of next to the phase planes / sub-pel refinement, which it slowed;
+          * the minima of the NEXT picture's search are cleared on the side stream (MotionSearch.reset_spare): the fill and the launch gap
+            in front of it no longer sit between two searches."""
+        import torch
+        ms = self.ms
+        if self._spare_ready is not None:                 # cleared next to the previous picture's stages
+            main.wait_event(self._spare_ready)
+            ms.swap_best()
+        else:
+            ms.reset()
+        ms.search(cur, ref)
+        self.sp.run(cur, ref)
+        mv = self.sp.out
+        ev_mv = torch.cuda.Event(); ev_mv.record(main)
+        self.rc.run(cur, ref, self.recon, mv)
+        sC.wait_event(ev_mv)
+        with torch.cuda.stream(sC):
+            InterReconChroma.run_pair(self.rc_c, cur.c, ref.c, self.recon_c, cur.stride_c, cur.org_c, mv)
+        sLa.wait_event(ev_mv)                             # the sub-pel stage has read this picture's minima: the other buffer may be cleared
+        with torch.cuda.stream(sLa):
+            ms.reset_spare()
+            self._spare_ready = torch.cuda.Event(); self._spare_ready.record(sLa)
+        self.db.run(self.recon, cur, mv, self.rc.num_sig)
+        ev_bs = torch.cuda.Event(); ev_bs.record(main)
+        planes = self._sao_planes(cur)
+        sC.wait_event(ev_bs)
+        with torch.cuda.stream(sC):
+            hipabi.deblock_chroma(self.depth, self.recon_c[0], self.recon_c[1], cur.stride_c, cur.org_c, cur.w64, cur.h64,
+                                  self.db.bs_ver, self.db.bs_hor, self.db.qp)
+            hipabi.sao_planes(self.depth, [dict(q, out=None) for q in planes[1:3]])
+            ev_cstats = torch.cuda.Event(); ev_cstats.record(sC)
+        hipabi.sao_planes(self.depth, [dict(planes[0], out=None)])
+        if self.la is not None:
+            ev_y = torch.cuda.Event(); ev_y.record(main)
+            sLa.wait_event(ev_y)
+            with torch.cuda.stream(sLa):
+                self.la.run(cur)
+        main.wait_event(ev_cstats)
+        self._sao_rdo()
+        hipabi.sao_apply_planes(self.depth, planes)
+        ev_sao = torch.cuda.Event(); ev_sao.record(main)
+        extend_border(self.out, cur)
+        sC.wait_event(ev_sao)
+        with torch.cuda.stream(sC):
+            for i in range(2):
+                extend_border(self.out_c[i], cur, chroma=True)
+            ev_c = torch.cuda.Event(); ev_c.record(sC)
+        main.wait_event(ev_c)
+        if self.la is not None:
+            e = torch.cuda.Event(); e.record(sLa)
+            main.wait_event(e)
+        self.final, self.final_c = self.out, self.out_c
+        return self.final
+
+    def swap_output(self, spare):
+        """Ping-pong of the decoded picture: hands out the planes the last run() wrote (the next reference) and takes `spare` - [Y, Cb, Cr]
+        planes the host no longer needs, e.g. the reference that has just been replaced - as the destination of the next run().  What a
+        decoded-picture buffer does instead of copying a picture per frame.  None when the last output is not a plane set of its own."""
+        if self.final is not self.out or self.out is None or (self.chroma and self.final_c is not self.out_c):
+            return None
+        outs = self.final_planes()
+        self.out = spare[0]
+        if self.chroma:
+            self.out_c = list(spare[1:3])
+        return outs
 
     def _search_to_recon_in_parts(self, cur, ref, main, sCb, sCr, start):
         """Search on `main`, part after part; a part's sub-pel refinement + luma reconstruction follow on a fourth stream, its chroma
