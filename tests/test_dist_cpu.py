@@ -246,3 +246,42 @@ def test_band_size_follows_the_rank_count():
     assert all(r in B.BANDED_STEP_MS for r in rows)
     assert rows == sorted(rows, reverse=True) and rows[0] > rows[-1]
     assert B.pick_band_rows(8, ctu_rows=68) >= B.pick_band_rows(8, ctu_rows=34)          # an 8K picture has twice the bands per picture
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 5, 8])
+@pytest.mark.parametrize("refs", [1, 2, 3, 4])
+def test_abi_transport_joins_its_communicators_without_a_waiting_cycle(world, refs):
+    """pipeline.AbiTransport (what `bench.py --gpus N` uses) makes one 2-rank RCCL communicator per directed flow producer s -> consumer
+    s + d with BLOCKING joins (ncclCommInitRank returns when both ranks have called it).  The joins of every rank are simulated here: a join
+    completes when it is at the head of both participants' lists; the simulation must drain every list (no cycle of ranks waiting for each
+    other), every flow must be joined exactly once by its producer as rank 0 and once by its consumer as rank 1, and the communicator a
+    sender picks for a peer must be the one that peer receives on."""
+    P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+    lists = {r: [(d, s, role) for (_, d, s, role) in P.AbiTransport.joins(r, world, refs)] for r in range(world)}
+    seen = {}
+    for r, joins in lists.items():
+        for d, s, role in joins:
+            assert (r == s) == (role == 0) and (role == 0 or r == (s + d) % world)
+            seen.setdefault((d, s), []).append(role)
+    dists = [d for d in range(1, refs + 1) if d % world]
+    assert sorted(seen) == sorted((d, s) for d in dists for s in range(world)) and all(sorted(v) == [0, 1] for v in seen.values())
+    heads = {r: 0 for r in range(world)}
+    progressed = True
+    while progressed:
+        progressed = False
+        for r in range(world):
+            if heads[r] >= len(lists[r]):
+                continue
+            d, s, role = lists[r][heads[r]]
+            other = (s + d) % world if role == 0 else s
+            if heads[other] < len(lists[other]) and lists[other][heads[other]][:2] == (d, s):
+                heads[r] += 1
+                heads[other] += 1
+                progressed = True
+    assert all(heads[r] == len(lists[r]) for r in range(world)), f"ranks wait for each other: {heads}"
+    # a sender addresses peer p over the communicator of distance (p - rank) % world, the receiver of source s over (rank - s) % world
+    for r in range(world):
+        for d in dists:
+            p = (r + d) % world
+            assert (p - r) % world == (d % world) and (d, r, 0) in lists[r] and (d, r, 1) in lists[p]
+

@@ -359,18 +359,31 @@ class AbiTransport:
         gathered = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(gathered, mine)
         torch.cuda.synchronize()
-        for k, d in enumerate(dists):                                            # one global order: (distance, producer)
-            for s in range(self.world):
-                c = (s + d) % self.world
-                if self.rank not in (s, c):
-                    continue
-                raw = gathered[s][k].cpu().numpy().tobytes()
-                comm = ctypes.c_void_p()
-                hipabi.check(L.x265hip_comm_init(ctypes.byref(comm), 2, raw, 0 if self.rank == s else 1), "x265hip_comm_init")
-                (self.send_comm if self.rank == s else self.recv_comm)[d] = comm
+        for k, d, s, role in self.joins(self.rank, self.world, self.refs):         # one global order: (distance, producer)
+            raw = gathered[s][k].cpu().numpy().tobytes()
+            comm = ctypes.c_void_p()
+            hipabi.check(L.x265hip_comm_init(ctypes.byref(comm), 2, raw, role), "x265hip_comm_init")
+            (self.recv_comm if role else self.send_comm)[d] = comm
         self.streams = {("s", d): torch.cuda.Stream(device=self.device) for d in dists}
         self.streams.update({("r", d): torch.cuda.Stream(device=self.device) for d in dists})
         return None
+
+    @staticmethod
+    def joins(rank, world, refs):
+        """The blocking 2-rank communicator joins of `rank`, in the order it makes them: (index of the flow's id in the producer's id list,
+        distance d, producer s, role) with role 0 = this rank produces the flow (rank 0 of the communicator), 1 = it consumes it.  Every rank
+        walks the SAME global order of flows (distance, then producer) and skips the flows it is not part of, so two ranks always meet in
+        the flow that is first for both of them: no cycle of waiting joins can form (tests/test_dist_cpu.py simulates it for worlds 2 .. 8)."""
+        out = []
+        dists = [d for d in range(1, refs + 1) if d % world]
+        for k, d in enumerate(dists):
+            for s in range(world):
+                c = (s + d) % world
+                if rank == s:
+                    out.append((k, d, s, 0))
+                elif rank == c:
+                    out.append((k, d, s, 1))
+        return out
 
     def _publish(self, comm, planes, band, sending, stream):
         import ctypes
