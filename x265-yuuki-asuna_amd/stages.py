@@ -880,14 +880,14 @@ class FramePipeline:
         (tools/gpu_visit.sh timeline, profiles/r03_step_timeline.txt).  Same launches and outputs as run(); what moved:
           * Cb + Cr are ONE chain of pair launches on one side stream (reconstruction pair, deblocking of both planes, statistics of both
             planes): two chains of half-size launches next to the luma chain each ran 1.8x their stand-alone time and ended 50 us after it;
-          * the lookahead of the source picture starts when the luma statistics are done, i.e. next to the SAO decision - a serial pass
-            on ONE compute unit (115 us with the other 255 idle) - instead of next to the phase planes / sub-pel refinement, which it slowed;
-          * the minima of the NEXT picture's search are cleared on the side stream (MotionSearch.reset_spare): the fill and the launch gap
-            in front of it no longer sit between two searches."""
+          * the lookahead of the source picture runs on that stream BEHIND the chroma statistics, i.e. next to the SAO decision - a serial
+            pass on ONE compute unit (115 us with the other 255 idle) - instead of next to the phase planes / sub-pel refinement, which it
+            slowed; the minima of the NEXT picture's search are cleared there too (MotionSearch.reset_spare);
+          * ONE side stream: every cross-stream dependency costs the waiting stream ~8 us on this runtime, and a step on three side streams
+            had eight of them on the caller's stream - now three records and two waits."""
         import torch
         ms = self.ms
-        if self._spare_ready is not None:                 # cleared next to the previous picture's stages
-            main.wait_event(self._spare_ready)
+        if self._spare_ready:                             # cleared next to the previous picture's stages, on the stream the caller joined last
             ms.swap_best()
         else:
             ms.reset()
@@ -899,10 +899,6 @@ class FramePipeline:
         sC.wait_event(ev_mv)
         with torch.cuda.stream(sC):
             InterReconChroma.run_pair(self.rc_c, cur.c, ref.c, self.recon_c, cur.stride_c, cur.org_c, mv)
-        sLa.wait_event(ev_mv)                             # the sub-pel stage has read this picture's minima: the other buffer may be cleared
-        with torch.cuda.stream(sLa):
-            ms.reset_spare()
-            self._spare_ready = torch.cuda.Event(); self._spare_ready.record(sLa)
         self.db.run(self.recon, cur, mv, self.rc.num_sig)
         ev_bs = torch.cuda.Event(); ev_bs.record(main)
         planes = self._sao_planes(cur)
@@ -912,12 +908,11 @@ class FramePipeline:
                                   self.db.bs_ver, self.db.bs_hor, self.db.qp)
             hipabi.sao_planes(self.depth, [dict(q, out=None) for q in planes[1:3]])
             ev_cstats = torch.cuda.Event(); ev_cstats.record(sC)
-        hipabi.sao_planes(self.depth, [dict(planes[0], out=None)])
-        if self.la is not None:
-            ev_y = torch.cuda.Event(); ev_y.record(main)
-            sLa.wait_event(ev_y)
-            with torch.cuda.stream(sLa):
+            ms.reset_spare()                              # the sub-pel stage has long read this picture's minima: the other buffer may be cleared
+            self._spare_ready = True
+            if self.la is not None:
                 self.la.run(cur)
+        hipabi.sao_planes(self.depth, [dict(planes[0], out=None)])
         main.wait_event(ev_cstats)
         self._sao_rdo()
         hipabi.sao_apply_planes(self.depth, planes)
@@ -928,10 +923,7 @@ class FramePipeline:
             for i in range(2):
                 extend_border(self.out_c[i], cur, chroma=True)
             ev_c = torch.cuda.Event(); ev_c.record(sC)
-        main.wait_event(ev_c)
-        if self.la is not None:
-            e = torch.cuda.Event(); e.record(sLa)
-            main.wait_event(e)
+        main.wait_event(ev_c)                             # also covers the lookahead and the cleared minima (same stream, issued before)
         self.final, self.final_c = self.out, self.out_c
         return self.final
 
