@@ -92,6 +92,7 @@ class MotionSearch:
         self.surf_format = hipabi.SURF_PACKED_T if self.tiled else (hipabi.SURF_PACKED if self.packed else hipabi.SURF_I32)
         self.surf = torch.zeros(self.nctu * self.nc * self.ng * self.group_bytes // 4, dtype=torch.int32, device=device) if want_surf else None
         self.best = torch.empty(self.nctu * PUS_PER_CTU, dtype=torch.int64, device=device) if want_best else None
+        self.best_spare = None          # second buffer of the minima (reset_spare / swap_best), allocated on first use
         cost = F.mv_cost_table(rng, lam)
         self.cost_host = cost
         self.cost_x = torch.from_numpy(cost.view(np.int16)).to(device)
@@ -142,12 +143,13 @@ class MotionSearch:
         import torch
         if self.best is None:
             return
-        if getattr(self, "best_spare", None) is None:
+        if self.best_spare is None:
             self.best_spare = torch.empty_like(self.best)
         hipabi.me_best_reset(self.best_spare, stream=stream)
 
     def swap_best(self):
-        self.best, self.best_spare = self.best_spare, self.best
+        if self.best_spare is not None:
+            self.best, self.best_spare = self.best_spare, self.best
 
     def run(self, cur: DevicePicture, ref: DevicePicture):
         self.reset()
