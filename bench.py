@@ -319,9 +319,10 @@ def main():
     ap.add_argument("--subpel-planes", type=int, default=1, choices=[0, 1],
                     help="1 = the sub-pel stage reads its candidates from the reference picture's 15 phase planes (one x265hip_phase_planes launch "
                          "per frame, inside the timed step); 0 = it interpolates every candidate tile itself")
-    ap.add_argument("--surf-format", choices=["packed_t", "packed", "i32"], default="packed_t",
+    ap.add_argument("--surf-format", choices=["packed_b", "packed_t", "packed", "i32"], default="packed_b",
                     help="SAD surface records: packed = u16 for the 8x8/16x16 levels (X265HIP_SURF_PACKED), packed_t = the same records chunk-major "
-                         "inside a motion-vector row (X265HIP_SURF_PACKED_T, the record-per-lane kernel), i32 = all int32")
+                         "inside a motion-vector row (X265HIP_SURF_PACKED_T), packed_b = the same records in contiguous blocks of 64 "
+                         "(X265HIP_SURF_PACKED_B: one block per wavefront step of the record-per-lane kernel), i32 = all int32")
     ap.add_argument("--search", choices=["full", "dia", "hex", "umh", "star", "sea"], default="full",
                     help="full = exhaustive search (SAD surfaces + best mv) + sub-pel stage; dia/hex/umh/star/sea = the reference's pattern "
                          "searches run by the device-side search driver (x265hip_me_search), predictor (0,0)")
@@ -410,7 +411,7 @@ def main():
     clip = F.synth_clip(args.width, args.height, nclip, depth=args.depth, seed=265 + rank)
     pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
-                           qp=args.qp, want_surf=not args.no_surface, packed=({"packed": True, "packed_t": "t"}.get(args.surf_format, False) if args.depth == 8 else False),
+                           qp=args.qp, want_surf=not args.no_surface, packed=({"packed": True, "packed_t": "t", "packed_b": "b"}.get(args.surf_format, False) if args.depth == 8 else False),
                            lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True, lookahead_cost_batch=args.lookahead_batch,
                            chroma=True, sao_apply=True, sign_hide=True, subpel_planes=bool(args.subpel_planes),
                            parallel_planes=bool(args.parallel_planes), split=args.split, sao_rdo=sao_rdo)
@@ -428,7 +429,7 @@ def main():
                                    # workgroups (one per CU): such bands use the record-contiguous packed format of the row-walking kernel;
                                    # from 5 rows on the record-per-lane kernel wins (6 rows: 2.58 against 2.81 ms per picture)
                                    packed=(args.surf_format != "i32" and args.depth == 8) and
-                                          ("t" if args.band_rows >= int(os.environ.get("X265HIP_BAND_T_ROWS", "5")) and args.surf_format == "packed_t" else True),
+                                          (("b" if args.surf_format == "packed_b" else "t") if args.band_rows >= int(os.environ.get("X265HIP_BAND_T_ROWS", "5")) and args.surf_format in ("packed_t", "packed_b") else True),
                                    lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True,
                                    graphs=bool(args.band_graphs), streams=args.band_streams, sao_rdo=sao_rdo)
         # (bands keep every launch on one stream: side streams for the chroma chains change nothing at band size - 3.93 vs 3.97 ms at 4 rows)
@@ -566,14 +567,14 @@ def main():
         dom = "me"
         alg_bytes = ms.algorithmic_bytes(bpp=1 if args.depth == 8 else 2)
         achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9
-        traffic, tsrc = load_traffic(args.width, args.height, args.range, (('packed_t' if ms.tiled else 'packed') if ms.packed else 'i32') + ('' if args.depth == 8 else '_d10')) if surf_mode else (None, None)
+        traffic, tsrc = load_traffic(args.width, args.height, args.range, (('packed_b' if ms.blocked else ('packed_t' if ms.tiled else 'packed')) if ms.packed else 'i32') + ('' if args.depth == 8 else '_d10')) if surf_mode else (None, None)
         out = {
             "metric": "encoded fps + bit-exact check, 4K preset=slow, 1/2/4/8 MI355X vs host AVX2",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8" if args.depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": f"{args.width}x{args.height} {args.depth}-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: lookahead lowres planes + intra estimate (+ P-frame cost estimate vs the previous picture, " + (f"{args.lookahead_batch} pictures per launch on a side stream" if args.lookahead_batch else "off") + ") -> " +
-                                   (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + (('packed chunk-major' if ms.tiled else 'packed') if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
+                                   (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + (('packed, blocks of 64 records' if ms.blocked else ('packed chunk-major' if ms.tiled else 'packed')) if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
                                     f"sub-pel subme={args.subme} -> " if args.search == "full" else
                                     f"{args.search} search driver (motionEstimate, merange {args.range}, subme {args.subme}, predictor 0) for all 85 PUs/CTU -> ") +
                                    f"{8 << args.level}x{8 << args.level} luma + 4:2:0 chroma prediction + DCT/quant (sign-bit hiding on)/recon qp {args.qp} -> luma + chroma deblocking -> "
@@ -594,7 +595,7 @@ def main():
             "stages_ms": stages,
             **({"stages_note": stages_note} if stages_note else {}),
             "roofline": {"bound": "hbm", "kernel": "me_search_kernel" if args.search != "full" else
-                                   (("me_ctu_c_kernel" if surf_mode and ms.tiled else "me_ctu_q_kernel") if args.depth == 8 else "me_ctu_w_kernel")
+                                   (("me_ctu_c_kernel" if surf_mode and (ms.tiled or ms.blocked) else "me_ctu_q_kernel") if args.depth == 8 else "me_ctu_w_kernel")
                                    + ("<surf,best>" if surf_mode else "<best>"),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,

@@ -45,7 +45,7 @@ def _run(width, height, rng, depth, seed, extreme=None, packed=False):
                                  cur.w64, cur.h64, rng, 0, nctu, ms.cost_host, ms.cost_host)
     e = _valid(surf, ms)
     if packed:      # X265HIP_SURF_PACKED: same values, u16 records for the 8x8 / 16x16 levels
-        assert ms.surf.numel() * 4 == nctu * ms.nc * ms.ng * 720
+        assert ms.surf.numel() * 4 == (nctu * ((ms.nc * ms.ng + 63) // 64) * 46080 if packed == "b" else nctu * ms.nc * ms.ng * 720)      # x265hip_surf_ctu_bytes
         for level in range(4):
             b, n = P.LEVEL_BASE[level], P.LEVEL_PUS[level]
             g = ms.level_view(level)[0].cpu().numpy()
@@ -87,6 +87,15 @@ def test_me_chunk_major_packed_format_record_per_lane_kernel(case):
     _run(w, h, rng, 8, seed=seed, extreme=extreme, packed="t")
 
 
+@pytest.mark.parametrize("case", [(128, 128, 8, 11, None), (200, 136, 12, 12, None), (128, 64, 5, 13, "flat"), (256, 64, 57, 14, None), (128, 128, 24, 15, None),
+                                  (64, 64, 1, 16, None), (192, 64, 32, 17, None), (256, 128, 15, 18, None)])
+def test_me_block_major_packed_format_record_per_lane_kernel(case):
+    """X265HIP_SURF_PACKED_B (round 3): the records of a CTU in blocks of 64, chunk-major inside a block - what the default bench line times.
+    Ranges whose record count is a multiple of 64 (+-15: 31 x 8 = 248 is not, +-8: 17 x 5 = 85 ...), one record group, the default merange."""
+    w, h, rng, seed, extreme = case
+    _run(w, h, rng, 8, seed=seed, extreme=extreme, packed="b")
+
+
 def test_me_record_per_lane_kernel_serves_the_other_formats(monkeypatch):
     """X265HIP_ME_KERNEL=cand routes every 8-bit launch to the record-per-lane kernel: int32 and record-contiguous packed surfaces,
     minima alone, surfaces alone."""
@@ -99,7 +108,7 @@ def test_me_record_per_lane_kernel_serves_the_other_formats(monkeypatch):
     clip = F.synth_clip(192, 128, 2, depth=8, seed=24)
     cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
     O = _oracle()
-    for kw in (dict(want_surf=False), dict(want_best=False, packed="t"), dict(want_best=False)):
+    for kw in (dict(want_surf=False), dict(want_best=False, packed="t"), dict(want_best=False, packed="b"), dict(want_best=False)):
         ms = P.MotionSearch(cur.w64, cur.h64, 14, 8, dev, **kw)
         ms.run(cur, ref)
         torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 """include/x265hip.h as plain C: the header compiles with gcc -std=c99 and the header-only x265hip_surf_lookup finds every value of a
-synthetic surface set in all three record formats (the layouts are written here from the header's prose, independently of the
+synthetic surface set in all four record formats (the layouts are written here from the header's prose, independently of the
 function)."""
 import os
 import subprocess
@@ -46,7 +46,8 @@ def _write(fmt, rng, nctu):
     npu = (64, 16, 4, 1)
     pbase = (0, 512, 640, 704)
     gb = 1360 if fmt == 0 else 720
-    buf = np.zeros(nctu * nc * ng * gb, np.uint8)
+    ctu_bytes = ((nc * ng + 63) // 64) * 64 * 720 if fmt == 3 else nc * ng * gb
+    buf = np.zeros(nctu * ctu_bytes, np.uint8)
     for ctu in range(nctu):
         for level in range(4):
             for z in range(npu[level]):
@@ -63,13 +64,16 @@ def _write(fmt, rng, nctu):
                             o = pbase[level] + (z * 4 + k) * size          # byte inside the 720-byte record
                             if fmt == 1:      # record-contiguous
                                 a = (row + g) * 720 + o
-                            else:             # chunk c of group g at row + (c * groups + g) * 16
+                            elif fmt == 2:    # chunk c of group g at row + (c * groups + g) * 16
                                 a = row * 720 + ((o >> 4) * ng + g) * 16 + (o & 15)
+                            else:             # blocks of 64 records (raster order m * groups + g), chunk c of slot l at block + (c * 64 + l) * 16
+                                r = m * ng + g
+                                a = ctu * ctu_bytes + (r >> 6) * 46080 + ((o >> 4) * 64 + (r & 63)) * 16 + (o & 15)
                             buf[a:a + size] = np.frombuffer((np.uint16(v) if size == 2 else np.int32(v)).tobytes(), np.uint8)
     return buf
 
 
-@pytest.mark.parametrize("fmt", [0, 1, 2])
+@pytest.mark.parametrize("fmt", [0, 1, 2, 3])
 def test_surf_lookup_in_plain_c(fmt, tmp_path):
     src, exe, data = tmp_path / "t.c", tmp_path / "t", tmp_path / "surf.bin"
     src.write_text(C_SRC)

@@ -46,8 +46,8 @@ def test_hot_kernels_keep_the_occupancy_they_were_tuned_for():
     for name in ("inter_recon_kernel<unsigned char, 32, false, false>", "inter_recon_kernel<unsigned char, 16, true, false>"):
         assert waves(name) >= 2 and k[name]["vspill"] == 0 and k[name]["scratch"] == 0, (name, k[name])
     # the exhaustive search the bench times: two workgroups of four wavefronts per CU by design (194 registers), no spills
-    me = "me_ctu_c_kernel<true, true, 2, 3>"
-    assert waves(me) == 2 and k[me]["vspill"] == 0 and k[me]["scratch"] == 0, k[me]
+    for me in ("me_ctu_c_kernel<true, true, 3, 3>", "me_ctu_c_kernel<true, true, 2, 3>"):          # block-major (the default) / chunk-major records
+        assert waves(me) == 2 and k[me]["vspill"] == 0 and k[me]["scratch"] == 0, (me, k[me])
     # the serial pass of the SAO decision: one wavefront's chain IS the step - no scratch, no spills
     for name in ("sao_rdo_rows2_kernel<3>", "sao_rdo_rows2_kernel<1>"):
         assert k[name]["vspill"] == 0 and k[name]["scratch"] == 0 and k[name]["vgpr"] <= 128, (name, k[name])

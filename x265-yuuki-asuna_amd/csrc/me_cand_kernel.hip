@@ -114,7 +114,8 @@ __device__ __forceinline__ uint32_t mc_wave_min(uint32_t v)
     return sw.x < sw.y ? sw.x : sw.y;
 }
 
-// FMT: X265HIP_SURF_I32 / _PACKED / _PACKED_T (include/x265hip.h).  PACKED_T is this kernel's native layout: a lane's 16-byte chunk c goes
+// FMT: X265HIP_SURF_I32 / _PACKED / _PACKED_T / _PACKED_B (include/x265hip.h).  PACKED_B (round 3) is this kernel's native layout - the 64 records of
+// a step form one contiguous block, a store instruction writes one aligned KiB; PACKED_T was it in round 2: a lane's 16-byte chunk c goes
 // to row + (c * NG + g) * 16, so the lanes of a store instruction (consecutive g) write consecutive 16-byte pieces; with the
 // record-contiguous formats the same instruction scatters 64 pieces 720 / 1360 bytes apart (measured: 3.2 / 6.0 ms instead of 1.5).
 // VAR (A/B switches, X265HIP_ME_CAND_VARIANT): bit 0 - the source CTU sits in LDS and a row is read with 4 broadcast ds_read_b128
@@ -191,14 +192,16 @@ __global__ void __launch_bounds__(256, 2) me_ctu_c_kernel(MECandArgs a)
             }
         }
         uint8_t* recp = nullptr;
-        if (SURF)
+        if (SURF && FMT != X265HIP_SURF_PACKED_B)
             recp = FMT == X265HIP_SURF_PACKED_T ? a.surf + (size_t)((long)ctu * NC + m) * NG * GB + (size_t)g * 16
                                                 : a.surf + ((size_t)((long)ctu * NC + m) * NG + g) * GB;
-        const int chunkStride = NG * 16;
+        if (SURF && FMT == X265HIP_SURF_PACKED_B)          // the step's 64 records = one block: chunk c of lane l at block + (c * 64 + l) * 16
+            recp = a.surf + ((size_t)ctu * nsteps + S) * (64 * GB) + (size_t)lane * 16;
+        const int chunkStride = FMT == X265HIP_SURF_PACKED_B ? 1024 : NG * 16;
         // 16 bytes at byte offset `off` (a multiple of 16) of the lane's record
         auto put = [&](const int off, const mc_v4u32 v)
         {
-            mc_v4u32* dst = reinterpret_cast<mc_v4u32*>(FMT == X265HIP_SURF_PACKED_T ? recp + (off >> 4) * chunkStride : recp + off);
+            mc_v4u32* dst = reinterpret_cast<mc_v4u32*>((FMT == X265HIP_SURF_PACKED_T || FMT == X265HIP_SURF_PACKED_B) ? recp + (off >> 4) * chunkStride : recp + off);
             if (a.ntStores) __builtin_nontemporal_store(v, dst); else *dst = v;
         };
 
@@ -438,7 +441,8 @@ int launch_me_cand(const x265hip_me_params* p, hipStream_t s)
         if (var == 0) MC_LAUNCH_V(SF, BS, FM, 0); else if (var == 1) MC_LAUNCH_V(SF, BS, FM, 1); \
         else if (var == 2) MC_LAUNCH_V(SF, BS, FM, 2); else MC_LAUNCH_V(SF, BS, FM, 3); } while (0)
 #define MC_FMT(SF, BS) do { \
-        if (fmt == X265HIP_SURF_PACKED_T) MC_LAUNCH(SF, BS, X265HIP_SURF_PACKED_T); \
+        if (fmt == X265HIP_SURF_PACKED_B) MC_LAUNCH(SF, BS, X265HIP_SURF_PACKED_B); \
+        else if (fmt == X265HIP_SURF_PACKED_T) MC_LAUNCH(SF, BS, X265HIP_SURF_PACKED_T); \
         else if (fmt == X265HIP_SURF_PACKED) MC_LAUNCH(SF, BS, X265HIP_SURF_PACKED); \
         else MC_LAUNCH(SF, BS, X265HIP_SURF_I32); } while (0)
     if (anySurf && anyBest) MC_FMT(true, true);

@@ -683,14 +683,14 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     // 4K, profiles/r02_me_cand_ab.txt).  X265HIP_ME_KERNEL=cand forces it for every 8-bit launch (parity tests, A/B).
     {
         const char* which = getenv("X265HIP_ME_KERNEL");
-        const bool wantT = p->surf && p->surf_format == X265HIP_SURF_PACKED_T;
+        const bool wantT = p->surf && (p->surf_format == X265HIP_SURF_PACKED_T || p->surf_format == X265HIP_SURF_PACKED_B);
         if (sizeof(Px) == 1 && !p_generic && (wantT || (which && which[0] == 'c')))
         {
             const int rc = launch_me_cand(p, s);
             if (rc <= 0) return rc;
         }
         if (wantT)
-        { set_error("me_fullsearch: X265HIP_SURF_PACKED_T is written by the record-per-lane kernel only (depth 8, window within its LDS / step limits)"); return X265HIP_EINVAL; }
+        { set_error("me_fullsearch: X265HIP_SURF_PACKED_T / _PACKED_B are written by the record-per-lane kernel only (depth 8, window within its LDS / step limits)"); return X265HIP_EINVAL; }
     }
     if (sizeof(Px) == 1 && a.rowBytes == 256 && !p_generic)
     {
@@ -762,7 +762,7 @@ extern "C" int x265hip_me_fullsearch(const x265hip_me_params* p, void* stream)
     { set_error("me_fullsearch: plane strides must be multiples of 4 bytes and fenc 4-byte aligned"); return X265HIP_EINVAL; }
     const bool anyBest = p->best != nullptr;
     if (!p->surf && !p->best) { set_error("me_fullsearch: no output requested"); return X265HIP_EINVAL; }
-    if (p->surf_format != X265HIP_SURF_I32 && p->surf_format != X265HIP_SURF_PACKED && p->surf_format != X265HIP_SURF_PACKED_T) { set_error("me_fullsearch: surf_format %d", p->surf_format); return X265HIP_EINVAL; }
+    if (p->surf_format != X265HIP_SURF_I32 && p->surf_format != X265HIP_SURF_PACKED && p->surf_format != X265HIP_SURF_PACKED_T && p->surf_format != X265HIP_SURF_PACKED_B) { set_error("me_fullsearch: surf_format %d", p->surf_format); return X265HIP_EINVAL; }
     if (anyBest && (!p->cost_x || !p->cost_y)) { set_error("me_fullsearch: best[] needs cost_x / cost_y"); return X265HIP_EINVAL; }
     if (p->depth == 8) return launch_me<uint8_t>(p, (hipStream_t)stream);
     return launch_me<uint16_t>(p, (hipStream_t)stream);

@@ -34,7 +34,7 @@ class MEParams(ctypes.Structure):
 
 
 TU_INTRA_SLICE, TU_SIGN_HIDE = 1, 2        # X265HIP_TU_* flag bits of the TU stages' intra_slice field
-SURF_I32, SURF_PACKED, SURF_PACKED_T = 0, 1, 2
+SURF_I32, SURF_PACKED, SURF_PACKED_T, SURF_PACKED_B = 0, 1, 2, 3
 SURF_GROUP_BYTES_I32, SURF_GROUP_BYTES_PACKED = 1360, 720
 
 

@@ -12,6 +12,8 @@ Stages implemented so far
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import frames as F
@@ -75,6 +77,8 @@ class MotionSearch:
     surf : int32 [ctu][mvy][mvx/4][85][4]  (85 = 64 8x8 + 16 16x16 + 4 32x32 + 1 64x64 PUs, z-order;
            mv columns in groups of 4, last group padded - the pad column holds unspecified values);
            packed=True (8-bit): 720-byte groups, uint16 for the 8x8 / 16x16 levels (X265HIP_SURF_PACKED);
+           packed="b": the same records in blocks of 64, chunk-major inside a block (X265HIP_SURF_PACKED_B: the record-per-lane kernel's native
+           layout since round 3, one contiguous block per wavefront step);
            packed="t": the same records stored chunk-major inside a motion-vector row (X265HIP_SURF_PACKED_T, the layout of the
            record-per-lane kernel)
     best : int64 [ctu][85]            cost << 32 | raster mv index
@@ -88,9 +92,12 @@ class MotionSearch:
         self.ng = (self.nc + 3) // 4
         self.packed = bool(packed and want_surf)
         self.tiled = self.packed and packed == "t"
+        self.blocked = self.packed and packed == "b"
         self.group_bytes = hipabi.SURF_GROUP_BYTES_PACKED if self.packed else hipabi.SURF_GROUP_BYTES_I32
-        self.surf_format = hipabi.SURF_PACKED_T if self.tiled else (hipabi.SURF_PACKED if self.packed else hipabi.SURF_I32)
-        self.surf = torch.zeros(self.nctu * self.nc * self.ng * self.group_bytes // 4, dtype=torch.int32, device=device) if want_surf else None
+        self.surf_format = hipabi.SURF_PACKED_B if self.blocked else (hipabi.SURF_PACKED_T if self.tiled else (hipabi.SURF_PACKED if self.packed else hipabi.SURF_I32))
+        self.nblk = (self.nc * self.ng + 63) // 64                 # X265HIP_SURF_PACKED_B: blocks of 64 records per CTU (the last one allocated whole)
+        ctu_bytes = self.nblk * 64 * self.group_bytes if self.blocked else self.nc * self.ng * self.group_bytes
+        self.surf = torch.zeros(self.nctu * ctu_bytes // 4, dtype=torch.int32, device=device) if want_surf else None
         self.best = torch.empty(self.nctu * PUS_PER_CTU, dtype=torch.int64, device=device) if want_best else None
         self.best_spare = None          # second buffer of the minima (reset_spare / swap_best), allocated on first use
         cost = F.mv_cost_table(rng, lam)
@@ -129,7 +136,7 @@ class MotionSearch:
         if self.best is not None:
             o.best = self.best[c0 * PUS_PER_CTU:(c0 + o.nctu) * PUS_PER_CTU]
         if self.surf is not None:
-            per = self.nc * self.ng * self.group_bytes // 4
+            per = (self.nblk * 64 if self.blocked else self.nc * self.ng) * self.group_bytes // 4
             o.surf = self.surf[c0 * per:(c0 + o.nctu) * per]
         return o
 
@@ -171,7 +178,10 @@ class MotionSearch:
             if self.packed:
                 import torch
                 o, nb = ((0, n * 8), (512, n * 8), (640, n * 16), (704, n * 16))[level]      # byte range of the level inside the 720-byte record
-                if self.tiled:         # [row][chunk 45][group][16 B]: the level's chunks -> [row][group][level bytes]
+                if self.blocked:       # [ctu][block][chunk 45][slot 64][16 B]: the level's chunks -> [ctu][record][level bytes] -> the first nc * ng records
+                    lv = self.surf.view(torch.uint8).view(self.nctu, self.nblk, 45, 64, 16)[:, :, o >> 4:(o + nb) >> 4].permute(0, 1, 3, 2, 4) \
+                             .reshape(self.nctu, self.nblk * 64, nb)[:, :self.nc * self.ng].reshape(self.nctu * self.nc, self.ng, nb)
+                elif self.tiled:       # [row][chunk 45][group][16 B]: the level's chunks -> [row][group][level bytes]
                     lv = self.surf.view(torch.uint8).view(self.nctu * self.nc, 45, self.ng, 16)[:, o >> 4:(o + nb) >> 4].permute(0, 2, 1, 3) \
                              .reshape(self.nctu * self.nc, self.ng, nb)
                 else:
