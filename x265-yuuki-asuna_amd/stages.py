@@ -776,7 +776,7 @@ class FramePipeline:
         if self.out is None:
             self.out = torch.zeros_like(cur.t)
             self.out_c = [torch.zeros_like(p) for p in cur.c]
-        if self.sao_rdo is not None and self.split == 1 and not self.prep_next_to_search and self.la_after_search and self.schedule2 and self.band_border is None:
+        if self.sao_rdo is not None and self.split == 1 and self.la_after_search and self.schedule2 and self.band_border is None:
             return self._run_parallel2(cur, ref, main, sCb, sLa)
         start = torch.cuda.Event(); start.record(main)
         # The lookahead of the source picture only depends on the source, but it does not run next to the search: the record-per-lane search
@@ -893,8 +893,16 @@ class FramePipeline:
             ms.swap_best()
         else:
             ms.reset()
+        if self.prep_next_to_search:                      # X265HIP_PREP_OVERLAP=1 (experiment): the reference's phase planes next to the search, late in it
+            ev0 = torch.cuda.Event(); ev0.record(main)
+            sC.wait_event(ev0)
+            with torch.cuda.stream(sC):
+                self.sp.prepare(ref)
+                ev_pl = torch.cuda.Event(); ev_pl.record(sC)
         ms.search(cur, ref)
-        self.sp.run(cur, ref)
+        if self.prep_next_to_search:
+            main.wait_event(ev_pl)
+        self.sp.run(cur, ref, prepared=self.prep_next_to_search)
         mv = self.sp.out
         ev_mv = torch.cuda.Event(); ev_mv.record(main)
         self.rc.run(cur, ref, self.recon, mv)
