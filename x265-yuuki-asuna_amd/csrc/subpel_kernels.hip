@@ -103,6 +103,20 @@ __device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemR
 #pragma unroll
             for (int x = 0; x < 4; x++) src[y][x] = fe[y * fst + x];
     }
+    // The tile's rows as two packed int16 pairs each - columns (0, 2) / (1, 3) for 8-bit samples (what two masks make of a loaded dword),
+    // (0, 1) / (2, 3) for 16-bit ones (the dwords as loaded): the difference, the 4x4 Hadamard and the absolute sums below run on
+    // packed pairs (v_pk_add_i16 / v_pk_sub_i16 / v_pk_max_i16).  A 4-point Hadamard's absolute sum does not depend on the order of its
+    // inputs (its three non-constant rows are the three ways of splitting four items two and two), so any pairing gives the reference's
+    // value; every intermediate fits int16 up to 12-bit samples (8 * 4095 = 32760).  The kernel is VALU-bound (profiles/r03_inst_counters.txt).
+    typedef short sp_v2s __attribute__((ext_vector_type(2)));
+    auto pk = [](const int lo, const int hi) -> sp_v2s { return __builtin_bit_cast(sp_v2s, ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16)); };
+    sp_v2s srcP[4], srcQ[4];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        srcP[y] = BPP == 1 ? pk(src[y][0], src[y][2]) : pk(src[y][0], src[y][1]);
+        srcQ[y] = BPP == 1 ? pk(src[y][1], src[y][3]) : pk(src[y][2], src[y][3]);
+    }
     __syncthreads();
     if (!PL)
     {   // stage every PU's reference patch, one (possibly unaligned) dword per item
@@ -174,6 +188,7 @@ __device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemR
         const int ox = (qx >> 2) + pox, oy = (qy >> 2) + poy;
         const int xf = qx & 3, yf = qy & 3;
         int d[4][4];
+        sp_v2s dP[4], dQ[4];                                 // the prediction's rows (then the differences) as packed pairs
         if (PL)
         {
             const int ph = yf * 4 + xf;
@@ -185,12 +200,13 @@ __device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemR
                 if (BPP == 1)
                 {
                     const uint32_t w = ld_u32(rp);
-                    d[y][0] = w & 0xff; d[y][1] = (w >> 8) & 0xff; d[y][2] = (w >> 16) & 0xff; d[y][3] = w >> 24;
+                    dP[y] = __builtin_bit_cast(sp_v2s, w & 0x00ff00ffu);
+                    dQ[y] = __builtin_bit_cast(sp_v2s, (w >> 8) & 0x00ff00ffu);
                 }
                 else
                 {
-                    const uint32_t w0 = ld_u32(rp), w1 = ld_u32(rp + 4);
-                    d[y][0] = w0 & 0xffff; d[y][1] = w0 >> 16; d[y][2] = w1 & 0xffff; d[y][3] = w1 >> 16;
+                    dP[y] = __builtin_bit_cast(sp_v2s, ld_u32(rp));
+                    dQ[y] = __builtin_bit_cast(sp_v2s, ld_u32(rp + 4));
                 }
             }
         }
@@ -263,33 +279,42 @@ __device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemR
                     d[y][x] = xf ? sp_clip16((sum + offSP) >> shiftSP, maxVal) : sp_clip16((sum + 32) >> 6, maxVal);
                 }
         }
+        if (!PL)
+        {
 #pragma unroll
-        for (int y = 0; y < 4; y++)
+            for (int y = 0; y < 4; y++)
+            {
+                dP[y] = BPP == 1 ? pk(d[y][0], d[y][2]) : pk(d[y][0], d[y][1]);
+                dQ[y] = BPP == 1 ? pk(d[y][1], d[y][3]) : pk(d[y][2], d[y][3]);
+            }
+        }
 #pragma unroll
-            for (int x = 0; x < 4; x++) d[y][x] = src[y][x] - d[y][x];
+        for (int y = 0; y < 4; y++) { dP[y] = srcP[y] - dP[y]; dQ[y] = srcQ[y] - dQ[y]; }
+        // |lo| + |hi| of a packed pair / max(|lo|, |hi|)
+        auto pabs = [](const sp_v2s v) -> sp_v2s { return __builtin_elementwise_max(v, (sp_v2s)(-v)); };
+        auto lo_plus_hi = [](const sp_v2s v) -> int { const uint32_t u = __builtin_bit_cast(uint32_t, v); return (int)((u & 0xffffu) + (u >> 16)); };
+        auto lo_max_hi = [](const sp_v2s v) -> int { const uint32_t u = __builtin_bit_cast(uint32_t, v); const uint32_t l = u & 0xffffu, h = u >> 16; return (int)(l > h ? l : h); };
         int acc = 0;
         if (!useSatd)
         {
 #pragma unroll
-            for (int y = 0; y < 4; y++)
-#pragma unroll
-                for (int x = 0; x < 4; x++) acc += abs(d[y][x]);
+            for (int y = 0; y < 4; y++) acc += lo_plus_hi(pabs(dP[y])) + lo_plus_hi(pabs(dQ[y]));
             return acc;
         }
-        int t4[4][4];
-#pragma unroll
-        for (int y = 0; y < 4; y++)
+        // vertical 4-point Hadamard of both pair columns (packed adds), then per transformed row k: s = P + Q, t = P - Q hold the two
+        // half-sums of the horizontal transform and |a + b| + |a - b| = 2 max(|a|, |b|): the row's four absolute values sum to
+        // 2 (max(|s.lo|, |s.hi|) + max(|t.lo|, |t.hi|)) - the reference's (sum >> 1) is the sum of those maxima
+        sp_v2s pv[4], qv[4];
         {
-            const int s0 = d[y][0] + d[y][1], s1 = d[y][0] - d[y][1], s2 = d[y][2] + d[y][3], s3 = d[y][2] - d[y][3];
-            t4[y][0] = s0 + s2; t4[y][1] = s1 + s3; t4[y][2] = s0 - s2; t4[y][3] = s1 - s3;
+            const sp_v2s a0 = dP[0] + dP[1], b0 = dP[0] - dP[1], c0 = dP[2] + dP[3], e0 = dP[2] - dP[3];
+            pv[0] = a0 + c0; pv[1] = b0 + e0; pv[2] = a0 - c0; pv[3] = b0 - e0;
+            const sp_v2s a1 = dQ[0] + dQ[1], b1 = dQ[0] - dQ[1], c1 = dQ[2] + dQ[3], e1 = dQ[2] - dQ[3];
+            qv[0] = a1 + c1; qv[1] = b1 + e1; qv[2] = a1 - c1; qv[3] = b1 - e1;
         }
 #pragma unroll
-        for (int x = 0; x < 4; x++)
-        {
-            const int s0 = t4[0][x] + t4[1][x], s1 = t4[0][x] - t4[1][x], s2 = t4[2][x] + t4[3][x], s3 = t4[2][x] - t4[3][x];
-            acc += abs(s0 + s2) + abs(s1 + s3) + abs(s0 - s2) + abs(s1 - s3);
-        }
-        return acc >> 1;
+        for (int k = 0; k < 4; k++)
+            acc += lo_max_hi(pabs(pv[k] + qv[k])) + lo_max_hi(pabs(pv[k] - qv[k]));
+        return acc;
     };
 
     auto mvcost = [&](const int qx, const int qy) { return (int)a.costQ[qx + a.qoff] + (int)a.costQ[qy + a.qoff]; };
