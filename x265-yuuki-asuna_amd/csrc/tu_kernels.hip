@@ -575,62 +575,62 @@ __global__ void __launch_bounds__(InterReconThreads<N>::value, TuWavesPerSimd<N>
     // transforms built once (its barriers are wave-local); 8: one block per workgroup
     TuOpsFor<N, false> ops;
     ops.init(tid & 63);
-    auto do_block = [&](const int blk)
+    // geometry of block `blk` given its packed quarter-sample motion vector
+    struct Geo { int ctu, z, px, py, qx, qy, xf, yf; };
+    auto geom = [&](const int blk, const int packed) -> Geo
     {
-    const int ctu = blk / npu, z = blk - ctu * npu;
-    const int bxz = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), byz = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
-    const int px = (ctu % a.ctusW) * CTU + bxz * N, py = (ctu / a.ctusW) * CTU + byz * N;
-
-    const int packed = a.mv[(size_t)ctu * 85 + lbase + z].y;
-    const int qx = (int16_t)(packed & 0xffff), qy = (int16_t)(packed >> 16);
-    const int xf = qx & MVMASK, yf = qy & MVMASK;
-
-    // ---- stage source block + reference patch (TAPS/2 - 1 left/top, TAPS/2 right/bottom apron) --------------------
+        Geo g;
+        g.ctu = blk / npu; g.z = blk - g.ctu * npu;
+        const int bxz = (g.z & 1) | ((g.z >> 1) & 2) | ((g.z >> 2) & 4), byz = ((g.z >> 1) & 1) | ((g.z >> 2) & 2) | ((g.z >> 3) & 4);
+        g.px = (g.ctu % a.ctusW) * CTU + bxz * N; g.py = (g.ctu / a.ctusW) * CTU + byz * N;
+        g.qx = (int16_t)(packed & 0xffff); g.qy = (int16_t)(packed >> 16);
+        g.xf = g.qx & MVMASK; g.yf = g.qy & MVMASK;
+        return g;
+    };
+    auto mv_of = [&](const int blk) -> int { const int ctu = blk / npu; return a.mv[(size_t)ctu * 85 + lbase + (blk - ctu * npu)].y; };
+    // 16 / 32: dword loads (4 / 2 samples) of the source block and the reference patch into REGISTERS, all issued before the first one is
+    // waited for; they go into LDS (widened to int16 pairs) at the top of the block's turn.  A patch row is read to the next dword boundary
+    // (one sample beyond the 2 * apron + N needed: still inside the padded plane, and inside the row's LDS pitch).
+    constexpr int NT = InterReconThreads<N>::value, SPD = 4 / BPP, FD = N / SPD, PWD = (PW + SPD - 1) / SPD;
+    constexpr int FI = N >= 16 ? (N * FD) / NT : 1, PI = N >= 16 ? (PW * PWD + NT - 1) / NT : 1;
+    static_assert(N < 16 || (PWD * SPD <= PP && (N * FD) % NT == 0), "patch pitch / source block size");
+    auto load_regs = [&](const Geo& g, uint32_t (&fv)[FI], uint32_t (&pv)[PI])
     {
-        const Px* f = reinterpret_cast<const Px*>(a.fenc + (long)py * a.fencStrideB) + px;
+        const Px* f = reinterpret_cast<const Px*>(a.fenc + (long)g.py * a.fencStrideB) + g.px;
         const long fst = a.fencStrideB / BPP;
-        const Px* r = reinterpret_cast<const Px*>(a.fref + (long)(py + (qy >> MVSH) - APRON) * a.frefStrideB) + (px + (qx >> MVSH) - APRON);
+        const Px* r = reinterpret_cast<const Px*>(a.fref + (long)(g.py + (g.qy >> MVSH) - APRON) * a.frefStrideB) + (g.px + (g.qx >> MVSH) - APRON);
         const long rst = a.frefStrideB / BPP;
-        if constexpr (N >= 16)
-        {   // dword loads (4 / 2 samples), all issued before the first one is waited for (the rolled per-sample loop paid the memory latency
-            // once per trip: 16 + 24 trips for a 32x32 block), widened to int16 pairs on the way into LDS.  A patch row is read to the next
-            // dword boundary (one sample beyond the 2 * apron + N needed: still inside the padded plane, and inside the row's LDS pitch).
-            constexpr int NT = InterReconThreads<N>::value, SPD = 4 / BPP, FD = N / SPD, PWD = (PW + SPD - 1) / SPD;
-            constexpr int FI = (N * FD) / NT, PI = (PW * PWD + NT - 1) / NT;
-            static_assert(PWD * SPD <= PP && (N * FD) % NT == 0, "patch pitch / source block size");
-            uint32_t fv[FI], pv[PI];
 #pragma unroll
-            for (int k = 0; k < FI; k++) { const int i = tid + k * NT, y = i / FD, c = i - y * FD; fv[k] = ld_u32(reinterpret_cast<const uint8_t*>(f + y * fst) + 4 * c); }
+        for (int k = 0; k < FI; k++) { const int i = tid + k * NT, y = i / FD, c = i - y * FD; fv[k] = ld_u32(reinterpret_cast<const uint8_t*>(f + y * fst) + 4 * c); }
 #pragma unroll
-            for (int k = 0; k < PI; k++)
-            {
-                const int i = tid + k * NT, y = i / PWD, c = i - y * PWD;
-                pv[k] = i < PW * PWD ? ld_u32(reinterpret_cast<const uint8_t*>(r + y * rst) + 4 * c) : 0u;
-            }
-            auto put = [&](int16_t* dst, const uint32_t w)
-            {
-                if (BPP == 1)
-                {
-                    uint2 v;
-                    v.x = (w & 0xffu) | ((w & 0xff00u) << 8); v.y = ((w >> 16) & 0xffu) | ((w >> 8) & 0xff0000u);
-                    *reinterpret_cast<uint2*>(dst) = v;
-                }
-                else *reinterpret_cast<uint32_t*>(dst) = w;
-            };
-#pragma unroll
-            for (int k = 0; k < FI; k++) { const int i = tid + k * NT; put(fe + i * SPD, fv[k]); }
-#pragma unroll
-            for (int k = 0; k < PI; k++) { const int i = tid + k * NT, y = i / PWD, c = i - y * PWD; if (i < PW * PWD) put(patch + y * PP + c * SPD, pv[k]); }
-        }
-        else
+        for (int k = 0; k < PI; k++)
         {
-            for (int i = tid; i < NN; i += nth) { const int y = i >> LOG2N, x = i & (N - 1); fe[i] = (int16_t)f[y * fst + x]; }
-            for (int i = tid; i < PW * PW; i += nth) { const int y = i / PW, x = i - y * PW; patch[y * PP + x] = (int16_t)r[y * rst + x]; }
+            const int i = tid + k * NT, y = i / PWD, c = i - y * PWD;
+            pv[k] = i < PW * PWD ? ld_u32(reinterpret_cast<const uint8_t*>(r + y * rst) + 4 * c) : 0u;
         }
-        if (tid == 0) sNumSig = 0;
-    }
-    __syncthreads();
-
+    };
+    auto store_regs = [&](const uint32_t (&fv)[FI], const uint32_t (&pv)[PI])
+    {
+        auto put = [&](int16_t* dst, const uint32_t w)
+        {
+            if (BPP == 1)
+            {
+                uint2 v;
+                v.x = (w & 0xffu) | ((w & 0xff00u) << 8); v.y = ((w >> 16) & 0xffu) | ((w >> 8) & 0xff0000u);
+                *reinterpret_cast<uint2*>(dst) = v;
+            }
+            else *reinterpret_cast<uint32_t*>(dst) = w;
+        };
+#pragma unroll
+        for (int k = 0; k < FI; k++) { const int i = tid + k * NT; put(fe + i * SPD, fv[k]); }
+#pragma unroll
+        for (int k = 0; k < PI; k++) { const int i = tid + k * NT, y = i / PWD, c = i - y * PWD; if (i < PW * PWD) put(patch + y * PP + c * SPD, pv[k]); }
+    };
+    // everything behind the staging: prediction from the patch in LDS; `between` runs after the prediction (the next block's loads are issued
+    // there: its motion vector has arrived by then and the loads have the whole transform chain to complete); then the transform chain
+    auto do_rest = [&](const Geo& g, auto&& between)
+    {
+    const int ctu = g.ctu, z = g.z, px = g.px, py = g.py, xf = g.xf, yf = g.yf;
     // ---- predInterLumaPixel ----------------------------------------------------------------------------
     if (xf && yf)
     {
@@ -673,6 +673,7 @@ __global__ void __launch_bounds__(InterReconThreads<N>::value, TuWavesPerSimd<N>
         }
     }
     __syncthreads();
+    between();
 
     tu_chain<Px, N, false, TAB>(ops, pred, fe, A, B, red, sNumSig, a.depth, a.qp, a.intraSlice,
                            a.levels + ((size_t)ctu * npu + z) * NN, &a.numSig[(size_t)ctu * npu + z], &a.dist[(size_t)ctu * npu + z],
@@ -681,9 +682,63 @@ __global__ void __launch_bounds__(InterReconThreads<N>::value, TuWavesPerSimd<N>
     __syncthreads();
     };
     if constexpr (N >= 16)
-        for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) do_block(blk);
+    {
+        // A persistent wavefront walks blocks blockIdx.x, + gridDim.x, ...  Per block it used to pay two dependent trips to memory before any
+        // work - the motion vector, then the source block / reference patch the vector points at - ~3 us of a 10 us (16x16) / 17 us (32x32)
+        // block at one instruction per ~28 cycles (profiles/r03_inst_counters.txt).  Now the NEXT block's vector is requested at the top of a
+        // block and its samples right after the prediction, into registers; they wait there until the block's turn.
+        // (32x32: only the vector travels ahead - the 11 sample registers on top of its 252 made the compiler spill 261)
+        constexpr bool AHEAD = N == 16;
+        uint32_t fvC[FI], pvC[PI], fvN[AHEAD ? FI : 1], pvN[AHEAD ? PI : 1];
+        int blk = blockIdx.x;
+        if (blk < nblocks)
+        {
+            Geo g = geom(blk, mv_of(blk));
+            if constexpr (AHEAD) load_regs(g, fvC, pvC);
+            for (; blk < nblocks; blk += gridDim.x)
+            {
+                const int nb = blk + gridDim.x;
+                const bool has = nb < nblocks;
+                int packedN = 0;
+                if (has) packedN = mv_of(nb);
+                if constexpr (!AHEAD) load_regs(g, fvC, pvC);
+                store_regs(fvC, pvC);
+                if (tid == 0) sNumSig = 0;
+                __syncthreads();
+                Geo gn = g;
+                if constexpr (AHEAD)
+                {
+                    do_rest(g, [&]() { if (has) { gn = geom(nb, packedN); load_regs(gn, fvN, pvN); } });
+#pragma unroll
+                    for (int k = 0; k < FI; k++) fvC[k] = fvN[k];
+#pragma unroll
+                    for (int k = 0; k < PI; k++) pvC[k] = pvN[k];
+                }
+                else
+                {
+                    do_rest(g, []() {});
+                    if (has) gn = geom(nb, packedN);
+                }
+                g = gn;
+            }
+        }
+    }
     else
-        do_block(blockIdx.x);
+    {
+        const int blk = blockIdx.x;
+        const Geo g = geom(blk, mv_of(blk));
+        {
+            const Px* f = reinterpret_cast<const Px*>(a.fenc + (long)g.py * a.fencStrideB) + g.px;
+            const long fst = a.fencStrideB / BPP;
+            const Px* r = reinterpret_cast<const Px*>(a.fref + (long)(g.py + (g.qy >> MVSH) - APRON) * a.frefStrideB) + (g.px + (g.qx >> MVSH) - APRON);
+            const long rst = a.frefStrideB / BPP;
+            for (int i = tid; i < NN; i += nth) { const int y = i >> LOG2N, x = i & (N - 1); fe[i] = (int16_t)f[y * fst + x]; }
+            for (int i = tid; i < PW * PW; i += nth) { const int y = i / PW, x = i - y * PW; patch[y * PP + x] = (int16_t)r[y * rst + x]; }
+            if (tid == 0) sNumSig = 0;
+        }
+        __syncthreads();
+        do_rest(g, []() {});
+    }
 }
 
 // Bi-predictive flavour of the inter stage (B pictures; Predict::motionCompensation, predict.cpp:168-243 without weighted prediction):
