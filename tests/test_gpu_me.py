@@ -62,6 +62,13 @@ def test_me_small_range(depth):
     _run(128, 128, 8, depth, seed=1)
 
 
+@pytest.mark.parametrize("rng", [12, 13, 14])
+def test_me_10bit_ranges_around_an_lds_pitch_step(rng):
+    """+-13 at 16-bit samples: the generic kernel's window row + skew is exactly 64 dwords, the column-group kernel's one more - the
+    launch used to fail with an "internal" error there (found by tools/r3_soak.py); its neighbours on either side of the pitch step."""
+    _run(128, 64, rng, 10, seed=30 + rng)
+
+
 def test_me_non_ctu_multiple_picture():
     _run(200, 136, 12, 8, seed=2)       # padded to 256x192 like the reference's whole-CTU allocation
 

@@ -1,4 +1,4 @@
-"""Randomised soak of the two kernels rewritten in round 3 whose results hang on tie-breaking: the serial pass of the SAO decision
+"""Randomised soak of the kernels rewritten in round 3 (the exhaustive search with block-major records + the packed sub-pel arithmetic, and) the two whose results hang on tie-breaking: the serial pass of the SAO decision
 (x265hip_sao_rdo, second organisation) and the mode-parallel lowres intra estimate - device against oracle, fresh random cases for a
 time budget.  SAO: random / run-copied / sparse / extreme statistics (copied runs make the merge candidates tie with the new parameters),
 1..40 x 1..70 CTUs (one and two wavefronts of rows; the fall-back to the first organisation beyond 76 rows), 8/10/12-bit, luma-only and
@@ -88,6 +88,50 @@ def la_case(rng, torch):
     return None
 
 
+def me_case(rng, torch):
+    """Exhaustive search with block-major records (X265HIP_SURF_PACKED_B) and the sub-pel stage with packed arithmetic on its minima - random
+    sizes, ranges, depths (the packed record formats are 8-bit), subme levels, both sub-pel flavours - against the oracle."""
+    import importlib
+    F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+    P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+    import oracle_api as O
+    dev = torch.device("cuda:0")
+    depth = int(rng.choice([8, 8, 8, 10, 12]))
+    w, h = int(rng.integers(1, 5)) * 64, int(rng.integers(1, 4)) * 64
+    r = int(rng.integers(1, 41))
+    subme = int(rng.integers(0, 8))
+    planes = bool(rng.integers(0, 2))
+    seed = int(rng.integers(0, 1 << 30))
+    clip = F.synth_clip(w, h, 2, depth=depth, seed=seed)
+    y0 = clip[0][0].astype(np.float32)
+    sh = np.roll(y0, (int(rng.integers(-2, 3)), int(rng.integers(-3, 4))), axis=(0, 1))
+    mix = float(rng.uniform(0.2, 0.8))
+    y1 = np.clip(np.rint(mix * y0 + (1 - mix) * sh + rng.normal(0, 1.0, size=y0.shape)), 0, (1 << depth) - 1).astype(clip[0][0].dtype)
+    cur, ref = P.DevicePicture(y1, dev), P.DevicePicture(clip[0][0], dev)
+    fmt = "b" if depth == 8 else False
+    ms = P.MotionSearch(cur.w64, cur.h64, r, depth, dev, packed=fmt)
+    ms.run(cur, ref)
+    sp = P.SubpelRefine(ms, subme, dev, phase_planes=planes)
+    sp.run(cur, ref)
+    torch.cuda.synchronize()
+    desc = f"me {w}x{h} depth {depth} range {r} subme {subme} planes {planes} seed {seed}"
+    surf, best = O.me_fullsearch(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, r, 0, ms.nctu, ms.cost_host, ms.cost_host)
+    gb = ms.best.cpu().numpy().view(np.uint64)
+    if not np.array_equal(gb, best):
+        return f"{desc}: best differs ({np.count_nonzero(gb != best)})"
+    e = surf.reshape(ms.nctu * ms.nc, ms.ng, 85, 4).transpose(0, 1, 3, 2).reshape(ms.nctu * ms.nc, ms.ng * 4, 85)[:, :ms.nc, :]
+    for level in range(4):
+        b, n = P.LEVEL_BASE[level], P.LEVEL_PUS[level]
+        g = ms.level_view(level)[0].cpu().numpy()
+        if not np.array_equal(g, e[:, :, b:b + n].reshape(-1, n)):
+            return f"{desc}: surface level {level} differs"
+    exp = O.subpel_refine(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, r, 0, ms.nctu, best, sp.cost_q_host, sp.qoff, subme)
+    got = sp.out.cpu().numpy().reshape(-1, 2)
+    if not np.array_equal(got, exp):
+        return f"{desc}: sub-pel output differs for {int((got != exp).any(axis=1).sum())} PUs"
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60)
@@ -100,18 +144,21 @@ def main():
     tabs = HT.load()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(args.seed)
-    n = {"sao": 0, "lookahead": 0}
+    n = {"sao": 0, "lookahead": 0, "me": 0}
     fails = []
     t0 = time.time()
     while time.time() - t0 < args.seconds and len(fails) < 5:
-        if rng.random() < 0.75:
+        u = rng.random()
+        if u < 0.55:
             r = sao_case(rng, A, HT, O, tabs, dev, torch); n["sao"] += 1
-        else:
+        elif u < 0.75:
             r = la_case(rng, torch); n["lookahead"] += 1
+        else:
+            r = me_case(rng, torch); n["me"] += 1
         if r:
             fails.append(r)
             print("MISMATCH", r, flush=True)
-    print(f"r3_soak seed {args.seed}: {n['sao']} SAO decisions + {n['lookahead']} lowres intra estimates in {time.time() - t0:.0f} s, {len(fails)} mismatches")
+    print(f"r3_soak seed {args.seed}: {n['sao']} SAO decisions + {n['lookahead']} lowres intra estimates + {n['me']} search / sub-pel pictures in {time.time() - t0:.0f} s, {len(fails)} mismatches")
     return 1 if fails else 0
 
 

@@ -659,8 +659,12 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     a.range = p->range;
     const int payload = (3 + (56 + 2 * p->range) * BPP + 4 * MECfg<Px>::NLD + 3) >> 2;   // dwords actually read per row
     a.payloadDw = payload;
+    // the 10-bit column-group kernel reads 6 dwords per window row, one more than the generic kernel: the pitch must hold ITS payload (at
+    // +-13 and +-77 the generic payload + skew is exactly a power of two and the fast path refused with an "internal" error: found by
+    // tools/r3_soak.py, round 3)
+    const int payloadW = sizeof(Px) == 2 ? (3 + (56 + 2 * p->range) * 2 + 4 * 6 + 3) >> 2 : payload;
     int pitchDw = 64;                                          // power-of-two pitch >= payload + max skew (17 dwords)
-    while (pitchDw < payload + 17) pitchDw <<= 1;
+    while (pitchDw < (payloadW > payload ? payloadW : payload) + 17) pitchDw <<= 1;
     a.rowBytes = pitchDw * 4;
     a.surf = p->surf; a.best = (unsigned long long*)p->best;
     const bool anySurf = p->surf != nullptr, anyBest = p->best != nullptr;
