@@ -132,6 +132,44 @@ def me_case(rng, torch):
     return None
 
 
+def pipe_case(rng, torch):
+    """The whole frame pipeline as bench.py runs it - lookahead, exhaustive search, sub-pel stage, luma + chroma TU stages with sign hiding,
+    deblocking, SAO statistics, the reference's SAO decision, application, borders - on a random small picture, with the round-3 launch
+    schedule (parallel_planes) or on one stream, every stage output against the oracle chain (bench.py's own bit_exact comparison)."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    import bench as B
+    from test_gpu_pipeline import _sao_rdo_inputs
+    F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+    P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+    S = importlib.import_module("x265-yuuki-asuna_amd.stages")
+    import oracle_api as O
+    dev = torch.device("cuda:0")
+    depth = int(rng.choice([8, 8, 10]))
+    w, h = int(rng.integers(2, 7)) * 64 - int(rng.choice([0, 0, 24])), int(rng.integers(1, 5)) * 64 - int(rng.choice([0, 0, 16]))
+    R, subme = int(rng.integers(4, 21)), int(rng.integers(0, 8))
+    qp = int(rng.integers(16, 42)) + 12 * (depth == 10)
+    par = bool(rng.integers(0, 2))
+    fmt = [True, "t", "b"][int(rng.integers(0, 3))] if depth == 8 else False
+    seed = int(rng.integers(0, 1 << 30))
+    clip = F.synth_clip(w, h, 2, depth=depth, seed=seed)
+    pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
+    srdo = _sao_rdo_inputs(depth, qp)
+    pipe = S.FramePipeline(pics[0].w64, pics[0].h64, depth, dev, rng=R, subme=subme, level=2, qp=qp, want_surf=True, packed=fmt, lookahead=(w, h),
+                           deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True, sao_rdo=srdo, subpel_planes=bool(rng.integers(0, 2)),
+                           parallel_planes=par)
+    dev_out = B.device_outputs(pipe, pics[1], pics[0])
+    if par:                                            # a second frame through the same pipeline object: the double-buffered minima, the ping-pong
+        new = pipe.swap_output([p.clone() for p in pics[0].planes()])
+        dev_out = B.device_outputs(pipe, pics[1], pics[0])
+    _, cpu_out = B.oracle_chain(F, clip, R, subme, 2, qp, depth, pipe.ms.nctu, B.effective_cpus(), O.host_has_avx2(), sao_rdo=srdo)
+    res = B.compare_outputs(dev_out, cpu_out)
+    if not res["ok"]:
+        bad = {k: v for k, v in res["stages"].items() if v != "equal"}
+        return f"pipeline {w}x{h} depth {depth} range {R} subme {subme} qp {qp} parallel {par} format {fmt} seed {seed}: {bad}"
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60)
@@ -144,7 +182,7 @@ def main():
     tabs = HT.load()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(args.seed)
-    n = {"sao": 0, "lookahead": 0, "me": 0}
+    n = {"sao": 0, "lookahead": 0, "me": 0, "pipe": 0}
     fails = []
     t0 = time.time()
     while time.time() - t0 < args.seconds and len(fails) < 5:
@@ -153,12 +191,14 @@ def main():
             r = sao_case(rng, A, HT, O, tabs, dev, torch); n["sao"] += 1
         elif u < 0.75:
             r = la_case(rng, torch); n["lookahead"] += 1
-        else:
+        elif u < 0.9:
             r = me_case(rng, torch); n["me"] += 1
+        else:
+            r = pipe_case(rng, torch); n["pipe"] += 1
         if r:
             fails.append(r)
             print("MISMATCH", r, flush=True)
-    print(f"r3_soak seed {args.seed}: {n['sao']} SAO decisions + {n['lookahead']} lowres intra estimates + {n['me']} search / sub-pel pictures in {time.time() - t0:.0f} s, {len(fails)} mismatches")
+    print(f"r3_soak seed {args.seed}: {n['sao']} SAO decisions + {n['lookahead']} lowres intra estimates + {n['me']} search / sub-pel pictures + {n['pipe']} whole-pipeline frames in {time.time() - t0:.0f} s, {len(fails)} mismatches")
     return 1 if fails else 0
 
 
