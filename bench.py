@@ -574,14 +574,17 @@ def main():
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8" if args.depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": f"{args.width}x{args.height} {args.depth}-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: lookahead lowres planes + intra estimate (+ P-frame cost estimate vs the previous picture, " + (f"{args.lookahead_batch} pictures per launch on a side stream" if args.lookahead_batch else "off") + ") -> " +
-                                   (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + (('packed, blocks of 64 records' if ms.blocked else ('packed chunk-major' if ms.tiled else 'packed')) if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
+                                   (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + (('packed, in blocks of 64' if ms.blocked else ('packed chunk-major' if ms.tiled else 'packed')) if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
                                     f"sub-pel subme={args.subme} -> " if args.search == "full" else
                                     f"{args.search} search driver (motionEstimate, merange {args.range}, subme {args.subme}, predictor 0) for all 85 PUs/CTU -> ") +
                                    f"{8 << args.level}x{8 << args.level} luma + 4:2:0 chroma prediction + DCT/quant (sign-bit hiding on)/recon qp {args.qp} -> luma + chroma deblocking -> "
                                    f"SAO statistics -> SAO parameters (" + ("the reference's rate-distortion decision SAO::rdoSaoUnitCu on the device: offset iteration, CABAC bit "
                                    "counts with per-row contexts, merge candidates" if sao_rdo else "saoStatsInitialOffset + distortion-only stand-in, on device") + ") -> SAO apply (Y, Cb, Cr) -> "
-                                   f"border extension -> next reference (Y, Cb, Cr); pipeline throughput (tier T2), not HEVC encoded fps - the real "
-                                   f"encoder's fps (tier T3) is `bench.py --encoder` / profiles/r02_encoder_*.txt",
+                                   f"border extension -> next reference (Y, Cb, Cr"
+                                   + ("; one GPU: the decoded picture ping-pongs - the planes a step wrote are the next step's reference, no copy"
+                                      if world == 1 and args.ref_handoff == "swap" and not banded else "") +
+                                   f"); pipeline throughput (tier T2), not HEVC encoded fps - the real "
+                                   f"encoder's fps (tier T3) is the `encoder` object of this line / profiles/r03_encoder_*.txt",
                        "frames_per_step_per_gpu": 1, "parallelism": ((f"segment-parallel x{world}: every rank encodes its own closed group of pictures, no exchange (--sharding gop)" if gop
                                         else f"frame-parallel x{world}") if not banded else
                                        f"frame-parallel ring x{world}: frame f on rank f % {world} searches frame f - 1, handed on in bands of {args.band_rows} CTU rows "
