@@ -12,8 +12,6 @@ Stages implemented so far
 """
 from __future__ import annotations
 
-import os
-
 import numpy as np
 
 from . import frames as F

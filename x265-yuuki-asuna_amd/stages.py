@@ -777,7 +777,7 @@ class FramePipeline:
             self.out = torch.zeros_like(cur.t)
             self.out_c = [torch.zeros_like(p) for p in cur.c]
         if self.sao_rdo is not None and self.split == 1 and self.la_after_search and self.schedule2 and self.band_border is None:
-            return self._run_parallel2(cur, ref, main, sCb, sLa)
+            return self._run_parallel2(cur, ref, main, sCb)
         start = torch.cuda.Event(); start.record(main)
         # The lookahead of the source picture only depends on the source, but it does not run next to the search: the record-per-lane search
         # kernel loses more to any co-resident kernel than that kernel takes (see split below); next to the latency-bound stages behind the
@@ -877,7 +877,7 @@ class FramePipeline:
         self.final, self.final_c = self.out, self.out_c
         return self.final
 
-    def _run_parallel2(self, cur, ref, main, sC, sLa):
+    def _run_parallel2(self, cur, ref, main, sC):
         """The launch schedule of the default bench step since round 3, read off the dispatch timeline of one step
         (tools/gpu_visit.sh timeline, profiles/r03_step_timeline.txt).  Same launches and outputs as run(); what moved:
           * Cb + Cr are ONE chain of pair launches on one side stream (reconstruction pair, deblocking of both planes, statistics of both
