@@ -425,7 +425,8 @@ template <typename Px, int N>
 static int launch_ip(int kind, const IPArgs& a, int njobs, hipStream_t s)
 {
     const int threads = a.w * a.h <= 256 ? 64 : 256;
-    const bool strip = (a.w & 3) == 0 && kind != X265HIP_IP_P2S && !getenv("X265HIP_INTERP_GENERIC");
+    static const bool forceGeneric = getenv("X265HIP_INTERP_GENERIC") != nullptr;    // A/B switch, read once: this launcher sits under every table stub
+    const bool strip = (a.w & 3) == 0 && kind != X265HIP_IP_P2S && !forceGeneric;
 #define CASE(K) case K: if (strip && K != X265HIP_IP_P2S) launch_strip<Px, K == X265HIP_IP_P2S ? X265HIP_IP_HPP : K, N>(a, njobs, s); \
                         else hipLaunchKernelGGL((interp_kernel<Px, K, N>), dim3(njobs), dim3(threads), 0, s, a); break;
     switch (kind)

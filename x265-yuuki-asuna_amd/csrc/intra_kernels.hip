@@ -362,7 +362,7 @@ extern "C" int x265hip_intra_batch(int kind, int depth, int n, x265hip_plane src
     // neighbours of up to 64 / 16 / 16 / 4 candidates)
     const int qpt = n >= 16 ? 4 : 1;
     const int log2tpj = 2 * a.log2n - 2 - (qpt == 4 ? 2 : 0), jpw = 256 >> log2tpj, wgs = (njobs + jpw - 1) / jpw;
-    const bool generic = getenv("X265HIP_INTRA_GENERIC") != nullptr;                 // A/B switch: one workgroup per candidate
+    static const bool generic = getenv("X265HIP_INTRA_GENERIC") != nullptr;          // A/B switch (read once): one workgroup per candidate
 #define GO(PX) do { switch (kind) { \
         case X265HIP_INTRA_PRED:    if (generic) hipLaunchKernelGGL((intra_kernel<PX, X265HIP_INTRA_PRED>), dim3(njobs), dim3(threads), 0, s, a); \
                                     else hipLaunchKernelGGL((intra_quad_kernel<PX, X265HIP_INTRA_PRED>), dim3(wgs), dim3(256), 0, s, a, njobs, log2tpj, qpt); break; \

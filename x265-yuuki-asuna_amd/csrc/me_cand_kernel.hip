@@ -426,7 +426,7 @@ int launch_me_cand(const x265hip_me_params* p, hipStream_t s)
     a.costX = p->cost_x; a.costY = p->cost_y;
     const int nsteps = (NC * NG + 63) / 64;
     a.stepsPerWave = (nsteps + 3) / 4;
-    const char* vs = getenv("X265HIP_ME_CAND_VARIANT");
+    static const char* const vs = getenv("X265HIP_ME_CAND_VARIANT");          // A/B switch, read once
     const int var = vs ? atoi(vs) & 3 : 3;            // default: source CTU in LDS, odd pairs shuffled (the fastest of the four, profiles/r02_me_cand_ab.txt)
     a.ntStores = vs ? (atoi(vs) >> 2) & 1 : 0;
     const size_t lds = (size_t)rows * a.pitchB + (p->best ? (size_t)4 * a.stepsPerWave * 256 + 16 * NG : 0) + ((var & 1) ? 4096 + 16 : 0);

@@ -650,7 +650,8 @@ static int pick_waves(int ncols)
 template <typename Px>
 static int launch_me(const x265hip_me_params* p, hipStream_t s)
 {
-    const bool p_generic = getenv("X265HIP_ME_GENERIC") != nullptr;   // force the generic (v_sad) kernel, for A/B tests
+    static const bool p_split = getenv("X265HIP_ME_SPLIT") != nullptr;       // surfaces-then-minima pair of launches instead of the fused one (A/B runs)
+    static const bool p_generic = getenv("X265HIP_ME_GENERIC") != nullptr;   // force the generic (v_sad) kernel (A/B runs); both read once
     constexpr int BPP = PxInfo<Px>::BPP;
     MEArgs a;
     a.fenc = (const uint8_t*)p->fenc;  a.fencStrideB = (long)p->fenc_stride * BPP;
@@ -705,7 +706,7 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
         // Both outputs: ONE fused launch.  It needs ~170 VGPRs, so its workgroup is 8 wavefronts (2 per SIMD,
         // 256-VGPR budget) instead of 16; the qsad chains carry enough ILP to keep the VALU busy at that occupancy.
         // X265HIP_ME_SPLIT forces the older surfaces-then-minima pair of launches (A/B measurements).
-        if (anySurf && anyBest && !getenv("X265HIP_ME_SPLIT")) LAUNCH_Q(true, true, 12);
+        if (anySurf && anyBest && !p_split) LAUNCH_Q(true, true, 12);
         else
         {
             if (anySurf) LAUNCH_Q(true, false, 16);
@@ -725,7 +726,7 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
         else { \
             if (lds > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_w_kernel<SF, BS, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL((me_ctu_w_kernel<SF, BS, 512>), grid, dim3(nwq * 64), lds, s, a); } } while (0)
-        if (anySurf && anyBest && !getenv("X265HIP_ME_SPLIT")) LAUNCH_W(true, true, 12);
+        if (anySurf && anyBest && !p_split) LAUNCH_W(true, true, 12);
         else
         {
             if (anySurf) LAUNCH_W(true, false, 16);

@@ -431,7 +431,8 @@ template <typename Px, int OP> static void launch_quad(const OpArgs& a, int njob
 template <typename Px> static int launch_op(int op, const OpArgs& a, int njobs, hipStream_t s)
 {
     const int threads = (a.w * a.h <= 256 && op < X265HIP_OP_SCALE1D_128TO64) ? 64 : 256;
-    if ((a.w & 3) == 0 && !getenv("X265HIP_BLOCKOP_GENERIC"))
+    static const bool forceGeneric = getenv("X265HIP_BLOCKOP_GENERIC") != nullptr;   // A/B switch, read once
+    if ((a.w & 3) == 0 && !forceGeneric)
     {
 #define QUAD(K) case K: launch_quad<Px, K>(a, njobs, s); X265HIP_TRY(hipGetLastError()); return 0;
         switch (op)

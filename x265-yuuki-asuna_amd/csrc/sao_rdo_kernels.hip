@@ -914,7 +914,8 @@ extern "C" int x265hip_sao_rdo(const x265hip_sao_rdo_params* p, void* stream)
     a.lambda[0] = p->lambda[0]; a.lambda[1] = p->lambda[1]; a.lambdaCtu = (const long long*)p->lambda_ctu;
     a.ctxMerge = p->ctx_merge; a.ctxType = p->ctx_type; a.saoFlag[0] = p->sao_flag[0] != 0; a.saoFlag[1] = p->sao_flag[1] != 0 && p->planes == 3;
     a.frac = p->frac_bits;
-    a.dbg = getenv("X265HIP_SAO_RDO_DEBUG") ? atoi(getenv("X265HIP_SAO_RDO_DEBUG")) : 0;
+    static const int dbg = getenv("X265HIP_SAO_RDO_DEBUG") ? atoi(getenv("X265HIP_SAO_RDO_DEBUG")) : 0;      // timing aid (tools/sao_rdo_ab.sh): switches roles OFF, results are then wrong
+    a.dbg = dbg;
     a.cand = (SaoCtuCand*)p->scratch; a.numNoSao = p->num_no_sao;
     for (int i = 0; i < 128; i++)
     {

@@ -447,7 +447,8 @@ __global__ void __launch_bounds__(256) transform_mfma_stream_kernel(TrArgs a)
 
 template <int N, int KIND> static int launch_mfma(const TrArgs& a, hipStream_t s)
 {
-    if (getenv("X265HIP_MFMA_SIMPLE"))                              // A/B switch: one wavefront + one workgroup per TU
+    static const bool simple = getenv("X265HIP_MFMA_SIMPLE") != nullptr;   // A/B switch (read once): one wavefront + one workgroup per TU
+    if (simple)
         hipLaunchKernelGGL((transform_mfma_kernel<N, KIND>), dim3(a.njobs), dim3(64), 0, s, a);
     else
     {
