@@ -41,9 +41,12 @@ std::once_flag g_rcclOnce;
 
 void load_rccl()
 {
-    const char* names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" };
+    // The SONAME first: a process that already holds an RCCL (a torch host: torch/lib/librccl.so, SONAME librccl.so.1) gets THAT copy back -
+    // one RCCL instance with several communicators, the arrangement RCCL is used in everywhere - instead of a second copy from the
+    // library path next to it.  RTLD_LOCAL: every entry is taken with dlsym from the handle, nothing is offered for interposition.
+    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so" };
     for (const char* n : names)
-        if ((g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL)))
+        if ((g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
             break;
     if (!g_rccl.lib) return;
     g_rccl.bcast = (nccl_bcast_t)dlsym(g_rccl.lib, "ncclBroadcast");
