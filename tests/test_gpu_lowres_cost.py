@@ -120,3 +120,38 @@ def test_lowres_cost_rejects_bad_geometry():
     with pytest.raises(RuntimeError):
         # 600 blocks per row cannot be walked by the 16 rows in flight of a 2-row picture
         H.lowres_cost(8, 64, 600, 2, i32, 0, [H.lowres_cost_pair(8, 0, t, [t] * 4, i32, i32, i32, i32, i32, i32)])
+
+
+@pytest.mark.parametrize("depth,width,height,bidir", [(8, 208, 144, False), (8, 640, 360, True), (10, 1280, 720, False), (8, 1920, 1080, True)])
+def test_lowres_cost_split_into_bands_equals_one_workgroup(monkeypatch, depth, width, height, bidir):
+    """One estimate alone is walked by several workgroups (bands of block rows, mvs of a band's top row handed up through L2): every band
+    count must give the integers of the one-workgroup walk, which the tests above hold against the oracle (and at 720p / 1080p those tests
+    run the split form themselves: it is the default from 32 block rows up)."""
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(width, height, 3, depth=depth, seed=93)
+    y1 = np.roll(clip[0][0], (2, -3), axis=(0, 1)).copy()
+    y1[: height // 3] = clip[1][0][: height // 3]
+    pics = [P.DevicePicture(y, dev) for y in (y1, clip[0][0], clip[2][0])]
+    las = [S.Lookahead(width, height, depth, dev, intra_penalty=5 if depth == 8 else 80) for _ in range(3)]
+    for la, pic in zip(las, pics):
+        la.run(pic)
+    lc, l0, l1 = las
+
+    def run(bands):
+        monkeypatch.setenv("X265HIP_LOWRES_COST_SPLIT", str(bands))
+        st = S.LookaheadCost(lc, dev, bidir=bidir)
+        if bidir:
+            st.run(lc, l0, l1, bframe_bias=10)
+        else:
+            st.run(lc, l0)
+        torch.cuda.synchronize()
+        out = [st.mvs, st.mv_costs, st.lowres_costs, st.row_satds, st.frame] + ([st.mvs1, st.mv_costs1] if bidir else [])
+        return [o.cpu().numpy().copy() for o in out]
+
+    one = run(1)
+    assert (one[0] != 0).any()
+    for bands in (2, 3, 5, 16):
+        got = run(bands)
+        for k, (a, b) in enumerate(zip(one, got)):
+            assert np.array_equal(a, b), f"{bands} bands: output {k} differs from the one-workgroup walk"

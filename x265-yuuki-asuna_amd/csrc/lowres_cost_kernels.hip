@@ -10,6 +10,15 @@
 // (lane = one 4x4 tile of the block), one barrier per step, mvs exchanged through the output array with workgroup-scope accesses.
 // The step time is the latency of one HEX search, so a single picture cannot fill the chip: callers batch independent pictures
 // (frame-parallel encoding has them) on separate streams.
+//
+// SPLIT (round 3): one estimate alone - the lookahead seam's case, a pool thread waits for it - is bound by the ONE compute unit its workgroup
+// sits on: 69 % of a wavefront's time is s_waitcnt, ~21 k cache-line reads per step go through that CU's L1 (profiles/r03_lowres_cost_counters.txt).
+// The split form gives a picture K workgroups, each a band of R consecutive block rows on a CU of its own.  Inside a band nothing changes
+// (lockstep steps, one barrier per step); a band's bottom row takes the three finished mvs of the row below from the band below through L2:
+// the producer's top row publishes every finished mv as ONE tagged 64-bit word (agent-scope store), the consumer's bottom-row quad spins on
+// the three words it needs (agent-scope loads).  Band k only ever waits for band k - 1, which has the lower workgroup index and is dispatched
+// first, so the wait cannot starve (the ordering decoupled look-back scans rely on).  The frame sums meet in agent-scope accumulators; the
+// last band to arrive writes them out.  Same integers as the one-workgroup walk, which stays in charge of batches.
 #include "pu_eval.h"
 
 namespace x265hip {
@@ -19,7 +28,12 @@ struct LowresCostArgs
     const x265hip_lowres_cost_pair* pairs;     // device copy, one per workgroup
     int strideB, W, H, depth, bFrameBias;
     const uint16_t* cost;
+    int K, R;                                  // SPLIT: workgroups per picture, block rows per workgroup
+    unsigned long long* sync;                  // SPLIT: per picture [2 lists][K][W] tagged boundary mvs + 3 frame sums + arrival count, zeroed before the launch
 };
+
+constexpr unsigned kSplitTag = 0xA5C3u;        // upper 16 bits of a published word (the buffer starts as zeros)
+__host__ __device__ inline size_t split_sync_words(int K, int W) { return (size_t)2 * K * W + 4; }
 
 // the four phase planes, biased like PuEval::base; passed by value so that they stay in registers
 struct PhasePlanes { const uint8_t *p0, *p1, *p2, *p3; };
@@ -168,10 +182,12 @@ __device__ __forceinline__ int lowres_motion_estimate(const LowresPu<Px>& L, con
     return bcost;
 }
 
-template <typename Px, bool BIDIR>
-__global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
+template <typename Px, bool BIDIR, bool SPLIT>
+__global__ void __launch_bounds__(SPLIT ? 512 : 1024) lowres_cost_kernel(LowresCostArgs g)
 {
-    const x265hip_lowres_cost_pair pr = g.pairs[blockIdx.x];
+    const int pairIdx = SPLIT ? (int)blockIdx.x / g.K : (int)blockIdx.x;
+    const int wk = SPLIT ? (int)blockIdx.x - pairIdx * g.K : 0;                  // this workgroup's band (0 = the bottom rows)
+    const x265hip_lowres_cost_pair pr = g.pairs[pairIdx];
     const uint8_t* cur = (const uint8_t*)pr.cur;
     unsigned long long* mvsL[2] = { (unsigned long long*)pr.mvs, (unsigned long long*)pr.mvs1 };
     int32_t* mvCostsL[2] = { pr.mv_costs, pr.mv_costs1 };
@@ -182,7 +198,10 @@ __global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
     const int q = threadIdx.x >> 2, l = threadIdx.x & 3;
     const int tx = l & 1, ty = l >> 1;
     const int W = g.W, H = g.H;
-    const int steps = W + 2 * (H - 1);
+    const int row0 = SPLIT ? wk * g.R : 0;                                       // first block row (from the bottom) of this band
+    const int rowsHere = SPLIT ? (g.R < H - row0 ? g.R : H - row0) : H;
+    const int tBegin = 2 * row0, tEnd = SPLIT ? 2 * (row0 + rowsHere - 1) + W : W + 2 * (H - 1);
+    unsigned long long* const syncP = SPLIT ? g.sync + (size_t)pairIdx * split_sync_words(g.K, W) : nullptr;
     __shared__ long long sFrame[3];
     if (threadIdx.x < 3) sFrame[threadIdx.x] = 0;
     __syncthreads();
@@ -196,11 +215,17 @@ __global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
     const PhasePlanes ppB = (BIDIR && pr.ref_bi[0]) ? PhasePlanes{ (const uint8_t*)pr.ref_bi[0] - kBias, (const uint8_t*)pr.ref_bi[1] - kBias, (const uint8_t*)pr.ref_bi[2] - kBias, (const uint8_t*)pr.ref_bi[3] - kBias } : pp0;
     L.c.strideB = g.strideB; L.c.depth = g.depth; L.c.cost = g.cost;
     L.c.have[0] = true;
-    for (int t = 0; t < steps; t++)
+    for (int t = tBegin; t < tEnd; t++)
     {
         // quad q walks rows q, q + Q, q + 2Q ... (counted from the bottom); W <= 2Q keeps at most one of them active per step
+        // (SPLIT: quad q owns row row0 + q of its band)
         int ry = -1, cuX = 0;
-        if (t >= 2 * q)
+        if (SPLIT)
+        {
+            const int r = row0 + q, dx = t - 2 * r;
+            if (q < rowsHere && dx >= 0 && dx < W) { ry = r; cuX = W - 1 - dx; }
+        }
+        else if (t >= 2 * q)
         {
             const int k = (t - 2 * q) / (2 * Q), r = q + k * Q, dx = t - 2 * r;
             if (r < H && dx < W) { ry = r; cuX = W - 1 - dx; }
@@ -240,6 +265,23 @@ __global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
                     const bool vR = cuX < W - 1, vB = ry > 0, vBL = vB && cuX > 0, vBR = vB && cuX < W - 1;
                     auto finished = [&](bool valid, int idx, int& mx, int& my)
                     {
+                        if (SPLIT && q == 0 && wk > 0)
+                        {
+                            // the row below is the top row of the band below: wait for its published word (qx, qy in 24 bits each under the tag)
+                            mx = my = 0;
+                            if (valid)
+                            {
+                                const unsigned long long* w = syncP + ((size_t)(li * g.K + wk - 1) * W + (idx - (cuXY + W) + cuX));
+                                unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                while ((unsigned)(v >> 48) != kSplitTag)
+                                {
+                                    __builtin_amdgcn_s_sleep(1);
+                                    v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                                mx = ((int)((uint32_t)v << 8)) >> 8; my = ((int)((uint32_t)(v >> 24) << 8)) >> 8;
+                            }
+                            return;
+                        }
                         const unsigned long long v = __hip_atomic_load(&mvA[valid ? idx : cuXY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         mx = valid ? (int)(uint32_t)v : 0; my = valid ? (int)(uint32_t)(v >> 32) : 0;
                     };
@@ -269,6 +311,10 @@ __global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
                         __hip_atomic_store(&mvA[cuXY], (unsigned long long)(uint32_t)qx | ((unsigned long long)(uint32_t)qy << 32),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         mvCostsL[li][cuXY] = fencCost;
+                        if (SPLIT && q == rowsHere - 1 && wk < g.K - 1)                      // the band above reads this row through L2
+                            __hip_atomic_store(syncP + ((size_t)(li * g.K + wk) * W + cuX),
+                                               ((unsigned long long)kSplitTag << 48) | ((unsigned long long)((uint32_t)qy & 0xffffffu) << 24) | (unsigned long long)((uint32_t)qx & 0xffffffu),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
                 lmx[li] = qx; lmy[li] = qy;
@@ -324,6 +370,24 @@ __global__ void __launch_bounds__(1024) lowres_cost_kernel(LowresCostArgs g)
         atomicAdd((unsigned long long*)&sFrame[2], (unsigned long long)intraMbs);
     }
     __syncthreads();
+    if (SPLIT)
+    {
+        // every band adds its sums; the band that arrives last holds all of them and writes the picture's totals
+        if (threadIdx.x == 0)
+        {
+            unsigned long long* acc = syncP + (size_t)2 * g.K * W;
+            for (int i = 0; i < 3; i++) __hip_atomic_fetch_add(&acc[i], (unsigned long long)sFrame[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long before = __hip_atomic_fetch_add(&acc[3], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == (unsigned long long)(g.K - 1))
+            {
+                long long f[3];
+                for (int i = 0; i < 3; i++) f[i] = (long long)__hip_atomic_load(&acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < 3; i++) pr.frame[i] = f[i];
+                pr.frame[3] = BIDIR ? f[0] * 100 / (130 + g.bFrameBias) : f[0];
+            }
+        }
+        return;
+    }
     if (threadIdx.x < 3) pr.frame[threadIdx.x] = sFrame[threadIdx.x];
     if (threadIdx.x == 0) pr.frame[3] = BIDIR ? sFrame[0] * 100 / (130 + g.bFrameBias) : sFrame[0];      // estimateFrameCost's score (:3201-3204)
 }
@@ -356,9 +420,25 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
         if (q.ref_bi[0] && (!b || !q.ref_bi[1] || !q.ref_bi[2] || !q.ref_bi[3])) { set_error("lowres_cost: ref_bi needs a B picture and four planes (pair %d)", i); return X265HIP_EINVAL; }
         if ((((uintptr_t)q.mvs) & 7) || (b && (((uintptr_t)q.mvs1) & 7))) { set_error("lowres_cost: mvs of pair %d must be 8-byte aligned", i); return X265HIP_EINVAL; }
     }
-    int quads = (p->height_in_cu + 15) & ~15;
+    // One estimate on its own (the lookahead seam) is split into bands of ~8 block rows (at most 16 bands: 4K 8.9 -> 5.3 ms with 16, 5.8 with 9; 1080p 3.27 ->
+    // 2.78 ms with 8, 2.88 with 5 - profiles/r03_lowres_cost_counters.txt), a workgroup = a compute unit each; batches keep one
+    // workgroup per picture (the chip is full anyway).  X265HIP_LOWRES_COST_SPLIT=<bands> forces the number (1 = never split; tests, A/B runs).
+    int K = 1;
+    {
+        const char* e = getenv("X265HIP_LOWRES_COST_SPLIT");
+        if (e) K = atoi(e);
+        else if (p->height_in_cu >= 32 && p->npairs <= 4) K = (p->height_in_cu + 7) / 8;
+        if (K > 16) K = 16;
+        if (K > p->height_in_cu) K = p->height_in_cu;
+        if (K < 1) K = 1;
+        if (K > 1 && (p->height_in_cu + K - 1) / K > 128) K = (p->height_in_cu + 127) / 128;      // a band is at most 128 rows = 512 threads
+    }
+    const int R = (p->height_in_cu + K - 1) / K;
+    K = (p->height_in_cu + R - 1) / R;                                 // no empty band
+    const bool split = K > 1;
+    int quads = ((split ? R : p->height_in_cu) + 15) & ~15;
     if (quads > 256) quads = 256;
-    if (p->width_in_cu > 2 * quads) { set_error("lowres_cost: %d blocks per row need more than %d rows in flight", p->width_in_cu, quads); return X265HIP_EINVAL; }
+    if (!split && p->width_in_cu > 2 * quads) { set_error("lowres_cost: %d blocks per row need more than %d rows in flight", p->width_in_cu, quads); return X265HIP_EINVAL; }
     const int bpp = p->depth == 8 ? 1 : 2;
     hipStream_t s = (hipStream_t)stream;
     // the pair table travels in stream order: allocated, filled, used and released on `s`
@@ -376,10 +456,22 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     a.W = p->width_in_cu; a.H = p->height_in_cu; a.depth = p->depth;
     a.cost = p->cost_q + p->qoff;
     a.bFrameBias = p->bframe_bias;
-    if (bpp == 1 && !bidir) hipLaunchKernelGGL((lowres_cost_kernel<uint8_t, false>), dim3(p->npairs), dim3(quads * 4), 0, s, a);
-    else if (bpp == 1) hipLaunchKernelGGL((lowres_cost_kernel<uint8_t, true>), dim3(p->npairs), dim3(quads * 4), 0, s, a);
-    else if (!bidir) hipLaunchKernelGGL((lowres_cost_kernel<uint16_t, false>), dim3(p->npairs), dim3(quads * 4), 0, s, a);
-    else hipLaunchKernelGGL((lowres_cost_kernel<uint16_t, true>), dim3(p->npairs), dim3(quads * 4), 0, s, a);
+    a.K = K; a.R = R; a.sync = nullptr;
+    if (split)
+    {
+        const size_t sb = split_sync_words(K, p->width_in_cu) * 8 * (size_t)p->npairs;
+        a.sync = (unsigned long long*)stream_scratch(s, 1, sb);
+        if (!a.sync) return X265HIP_ENODEV;
+        X265HIP_TRY(hipMemsetAsync(a.sync, 0, sb, s));
+    }
+    const dim3 grid(p->npairs * K), block(quads * 4);
+#define LRC_GO(PX, BI) do { if (split) hipLaunchKernelGGL((lowres_cost_kernel<PX, BI, true>), grid, block, 0, s, a); \
+                            else hipLaunchKernelGGL((lowres_cost_kernel<PX, BI, false>), grid, block, 0, s, a); } while (0)
+    if (bpp == 1 && !bidir) LRC_GO(uint8_t, false);
+    else if (bpp == 1) LRC_GO(uint8_t, true);
+    else if (!bidir) LRC_GO(uint16_t, false);
+    else LRC_GO(uint16_t, true);
+#undef LRC_GO
     X265HIP_TRY(hipGetLastError());
     if (!p->pairs_on_device) X265HIP_TRY(hipFreeAsync(dpairs, s));
     return 0;
