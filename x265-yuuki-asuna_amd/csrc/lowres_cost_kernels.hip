@@ -123,7 +123,8 @@ __device__ __forceinline__ int lowres_motion_estimate(const LowresPu<Px>& L, con
     SMv bmv = { (pmvx + 2) >> 2, (pmvy + 2) >> 2 };
     const int bprecost = L.qpel_cost(pp, pmvx, pmvy, false);
     const int roundedCost = c.cost_mv(bmv.x, bmv.y);
-    const int zeroCost = c.sad_at(0, 0) + c.mvcost_q(0, 0);
+    int zeroCost = c.sad_at(0, 0) + c.mvcost_q(0, 0);
+    pin_value(zeroCost);
     int bcost = bprecost;
     if ((pmvx | pmvy) & 3) bcost = roundedCost;
     if (pmvx | pmvy)
@@ -150,33 +151,37 @@ __device__ __forceinline__ int lowres_motion_estimate(const LowresPu<Px>& L, con
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
-            const int qx = bx + kSSquare1[i + 1].x * 2, qy = by + kSSquare1[i + 1].y * 2;
+            const int qx = bx + sSquare1(i + 1).x * 2, qy = by + sSquare1(i + 1).y * 2;
             cs[i] = L.qpel_cost(pp, qx, qy, false) + c.mvcost_q(qx, qy);
         }
 #pragma unroll
+        for (int i = 0; i < 4; i++) pin_value(cs[i]);
+#pragma unroll
         for (int i = 0; i < 4; i++)
         {
-            const int qy = by + kSSquare1[i + 1].y * 2;
+            const int qy = by + sSquare1(i + 1).y * 2;
             if ((qy < qminy) | (qy > qmaxy)) continue;
             if (cs[i] < bcost) { bcost = cs[i]; bdir = i + 1; }
         }
-        bx += kSSquare1[bdir].x * 2; by += kSSquare1[bdir].y * 2;
+        bx += sSquare1(bdir).x * 2; by += sSquare1(bdir).y * 2;
         bcost = L.qpel_cost(pp, bx, by, true) + c.mvcost_q(bx, by);
         bdir = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
-            const int qx = bx + kSSquare1[i + 1].x, qy = by + kSSquare1[i + 1].y;
+            const int qx = bx + sSquare1(i + 1).x, qy = by + sSquare1(i + 1).y;
             cs[i] = L.qpel_cost(pp, qx, qy, true) + c.mvcost_q(qx, qy);
         }
 #pragma unroll
+        for (int i = 0; i < 4; i++) pin_value(cs[i]);
+#pragma unroll
         for (int i = 0; i < 4; i++)
         {
-            const int qy = by + kSSquare1[i + 1].y;
+            const int qy = by + sSquare1(i + 1).y;
             if ((qy < qminy) | (qy > qmaxy)) continue;
             if (cs[i] < bcost) { bcost = cs[i]; bdir = i + 1; }
         }
-        bx += kSSquare1[bdir].x; by += kSSquare1[bdir].y;
+        bx += sSquare1(bdir).x; by += sSquare1(bdir).y;
     }
     outx = bx; outy = by;
     return bcost;
@@ -292,6 +297,8 @@ __global__ void __launch_bounds__(SPLIT ? 512 : 1024) lowres_cost_kernel(LowresC
                     finished(vBR, cuXY + W + 1, cx[3], cy[3]);
 #pragma unroll
                     for (int i = 0; i < 4; i++) cc[i] = L.qpel_cost(pp, cx[i], cy[i], true);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) pin_value(cc[i]);
                     const bool cv[4] = { vR, vB, vBL, vBR };
                     int mvpx = 0, mvpy = 0, mvpcost = 1 << 28, skipCost = 0x7fffffff;
 #pragma unroll

@@ -7,13 +7,32 @@ namespace x265hip {
 
 struct SMv { int x, y; };
 
-static __constant__ SMv kSHex2[8] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
-static __constant__ unsigned char kSMod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
-static __constant__ SMv kSSquare1[9] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+// The small direction tables of encoder/motion.cpp:64-66 (hex2, mod6m1, square1) as packed immediates.  They are indexed by the direction a
+// lane group has just decided; a __constant__ array indexed per lane is a vector load from memory - one more dependent round trip in every
+// round of a search whose time IS its chain of round trips (profiles/r03_lowres_cost_counters.txt).  Four bits per entry, value + 2.
+constexpr uint64_t pk_nib(int a0, int a1, int a2, int a3, int a4, int a5, int a6, int a7, int a8 = 0)
+{
+    return (uint64_t)a0 | (uint64_t)a1 << 4 | (uint64_t)a2 << 8 | (uint64_t)a3 << 12 | (uint64_t)a4 << 16 | (uint64_t)a5 << 20 | (uint64_t)a6 << 24 |
+           (uint64_t)a7 << 28 | (uint64_t)a8 << 32;
+}
+__device__ __forceinline__ SMv sHex2(int i)
+{
+    constexpr uint32_t X = (uint32_t)pk_nib(-1 + 2, -2 + 2, -1 + 2, 1 + 2, 2 + 2, 1 + 2, -1 + 2, -2 + 2), Y = (uint32_t)pk_nib(-2 + 2, 0 + 2, 2 + 2, 2 + 2, 0 + 2, -2 + 2, -2 + 2, 0 + 2);
+    return { (int)((X >> (4 * i)) & 15) - 2, (int)((Y >> (4 * i)) & 15) - 2 };
+}
+__device__ __forceinline__ int sMod6m1(int i) { return (int)(((uint32_t)pk_nib(5, 0, 1, 2, 3, 4, 5, 0) >> (4 * i)) & 15); }      // (x - 1) % 6
+__device__ __forceinline__ SMv sSquare1(int i)
+{
+    constexpr uint64_t X = pk_nib(0 + 2, 0 + 2, 0 + 2, -1 + 2, 1 + 2, -1 + 2, -1 + 2, 1 + 2, 1 + 2), Y = pk_nib(0 + 2, -1 + 2, 1 + 2, 0 + 2, 0 + 2, -1 + 2, 1 + 2, -1 + 2, 1 + 2);
+    return { (int)((X >> (4 * i)) & 15) - 2, (int)((Y >> (4 * i)) & 15) - 2 };
+}
 static __constant__ SMv kSOffsets[16] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
                                    { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
 static __constant__ int kSWorkload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
                                       { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+
+// keeps a value (and the loads behind it) where it is computed: an empty asm that reads and writes the register
+__device__ __forceinline__ void pin_value(int& v) { asm volatile("" : "+v"(v)); }
 
 // sum over the G lanes of a group, result in every lane of the group
 template <int G> __device__ __forceinline__ int group_total(int v)
@@ -92,8 +111,10 @@ struct PuEval
     __device__ __forceinline__ void cost_mv_n(const int (&mx)[N], const int (&my)[N], int (&out)[N]) const
     {
         uint32_t acc[N];
+        int mc[N];
+        // the mv costs first: their table loads travel with the reference loads (one round trip), not behind the reduction
 #pragma unroll
-        for (int n = 0; n < N; n++) acc[n] = 0;
+        for (int n = 0; n < N; n++) { acc[n] = 0; mc[n] = mvcost_q(mx[n] * 4, my[n] * 4); }
 #pragma unroll
         for (int k = 0; k < T; k++)
         {
@@ -111,7 +132,11 @@ struct PuEval
             if (N * T * 4 * DW > 64) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int n = 0; n < N; n++) out[n] = group_total<G>((int)acc[n]) + mvcost_q(mx[n] * 4, my[n] * 4);
+        for (int n = 0; n < N; n++) out[n] = group_total<G>((int)acc[n]) + mc[n];
+        // every score of the group exists HERE: without the pin the compiler sinks a candidate's table load and sum into the branch that
+        // reads it - a memory round trip per decision instead of one per group
+#pragma unroll
+        for (int n = 0; n < N; n++) pin_value(out[n]);
     }
 
     // subpelCompare: SAD or SATD of the PU at quarter-pel displacement (qx, qy)
@@ -175,20 +200,20 @@ __device__ __forceinline__ void hex_search(const PuEval<Px, G, T>& c, SMv& bmv, 
         if (bcost & 7)
         {
             int dir = (bcost & 7) - 2;
-            if (YOK(kSHex2[dir + 1].y))
+            if (YOK(sHex2(dir + 1).y))
             {
-                bmv.x += kSHex2[dir + 1].x; bmv.y += kSHex2[dir + 1].y;
+                bmv.x += sHex2(dir + 1).x; bmv.y += sHex2(dir + 1).y;
                 for (int i = (merange >> 1) - 1; i > 0 && c.in_range(bmv.x, bmv.y); i--)
                 {
-                    X3(kSHex2[dir + 0].x, kSHex2[dir + 0].y, kSHex2[dir + 1].x, kSHex2[dir + 1].y, kSHex2[dir + 2].x, kSHex2[dir + 2].y);
+                    X3(sHex2(dir + 0).x, sHex2(dir + 0).y, sHex2(dir + 1).x, sHex2(dir + 1).y, sHex2(dir + 2).x, sHex2(dir + 2).y);
                     bcost &= ~7;
-                    if (YOK(kSHex2[dir + 0].y)) LT((costs[0] << 3) + 1);
-                    if (YOK(kSHex2[dir + 1].y)) LT((costs[1] << 3) + 2);
-                    if (YOK(kSHex2[dir + 2].y)) LT((costs[2] << 3) + 3);
+                    if (YOK(sHex2(dir + 0).y)) LT((costs[0] << 3) + 1);
+                    if (YOK(sHex2(dir + 1).y)) LT((costs[1] << 3) + 2);
+                    if (YOK(sHex2(dir + 2).y)) LT((costs[2] << 3) + 3);
                     if (!(bcost & 7)) break;
                     dir += (bcost & 7) - 2;
-                    dir = kSMod6m1[dir + 1];
-                    bmv.x += kSHex2[dir + 1].x; bmv.y += kSHex2[dir + 1].y;
+                    dir = sMod6m1(dir + 1);
+                    bmv.x += sHex2(dir + 1).x; bmv.y += sHex2(dir + 1).y;
                 }
             }
         }
@@ -209,7 +234,7 @@ __device__ __forceinline__ void hex_search(const PuEval<Px, G, T>& c, SMv& bmv, 
             if (YOK(-1) && cs8[6] < bcost) { bcost = cs8[6]; dir = 7; }
             if (YOK(1) && cs8[7] < bcost) { bcost = cs8[7]; dir = 8; }
         }
-        bmv.x += kSSquare1[dir].x; bmv.y += kSSquare1[dir].y;
+        bmv.x += sSquare1(dir).x; bmv.y += sSquare1(dir).y;
 #undef X3
 #undef YOK
 #undef LT

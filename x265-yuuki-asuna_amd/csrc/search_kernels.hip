@@ -579,12 +579,12 @@ __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
             int bdir = 0;
             for (int i = 1; i <= hpelDirs; i++)
             {
-                const int qx = bx + kSSquare1[i].x * 2, qy = by + kSSquare1[i].y * 2;
+                const int qx = bx + sSquare1(i).x * 2, qy = by + sSquare1(i).y * 2;
                 if ((qy < qminy) | (qy > qmaxy)) continue;
                 const int cost = c.cmp_q(qx, qy, hpelSatd) + c.mvcost_q(qx, qy);
                 if (cost < bcost) { bcost = cost; bdir = i; }
             }
-            if (bdir) { bx += kSSquare1[bdir].x * 2; by += kSSquare1[bdir].y * 2; }
+            if (bdir) { bx += sSquare1(bdir).x * 2; by += sSquare1(bdir).y * 2; }
             else break;
         }
         if (!hpelSatd) bcost = c.cmp_q(bx, by, true) + c.mvcost_q(bx, by);
@@ -593,12 +593,12 @@ __device__ __forceinline__ void search_job(const SearchArgs& a, const int job)
             int bdir = 0;
             for (int i = 1; i <= qpelDirs; i++)
             {
-                const int qx = bx + kSSquare1[i].x, qy = by + kSSquare1[i].y;
+                const int qx = bx + sSquare1(i).x, qy = by + sSquare1(i).y;
                 if ((qy < qminy) | (qy > qmaxy)) continue;
                 const int cost = c.cmp_q(qx, qy, true) + c.mvcost_q(qx, qy);
                 if (cost < bcost) { bcost = cost; bdir = i; }
             }
-            if (bdir) { bx += kSSquare1[bdir].x; by += kSSquare1[bdir].y; }
+            if (bdir) { bx += sSquare1(bdir).x; by += sSquare1(bdir).y; }
             else break;
         }
     }
