@@ -381,7 +381,7 @@ typedef struct x265hip_lowres_cost_params
 } x265hip_lowres_cost_params;
 /* One workgroup walks a picture (a wavefront of dependent block rows); a call of up to four pictures of 32 or more block rows - the
  * latency case: a host thread waits for one estimate - gives every picture several workgroups, one per band of block rows, the
- * boundary mvs handed upward through L2 (same integers; 4K: 8.9 -> 5.4 ms per estimate).  Uses a few KB of per-stream scratch. */
+ * boundary mvs handed upward through L2 (same integers; 4K: 8.9 -> 5.2 ms per estimate).  Uses a few KB of per-stream scratch. */
 int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* stream);
 
 /* The same estimate behind host pointers, shaped like the loop it replaces (csrc/lookahead_host.hip): ONE call = the estimateCUCost
