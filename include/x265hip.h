@@ -944,6 +944,7 @@ typedef struct x265hip_me_stream_stats_t
     uint64_t pairs_opened, pairs_completed, bands, rows_searched, rows_uploaded, failed, stale_pairs;
     uint64_t us_busy;                        /* worker-thread wall time inside uploads / launches / downloads */
     uint64_t bytes_downloaded, bytes_uploaded, surface_bytes;
+    uint64_t rows_weighted, weighted_pairs;  /* CTU rows weighted on the device; pairs opened on a weighted reference */
 } x265hip_me_stream_stats_t;
 int  x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_params* p);
 void x265hip_me_stream_destroy(x265hip_me_stream* s);
@@ -952,6 +953,15 @@ void x265hip_me_stream_destroy(x265hip_me_stream* s);
 int  x265hip_me_stream_picture_rows(x265hip_me_stream* s, uint64_t key, const void* buf, int ctu_row0, int ctu_rows);
 /* returns the slot's new GENERATION (> 0) or a negative error; the pictures' rows may arrive before or after */
 int  x265hip_me_stream_pair_open(x265hip_me_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key);
+/* The same on a WEIGHTED reference (x265's default --weightp: MotionReference::applyWeight materialises primitives.weight_pp of every
+ * finished reconstructed row into a second plane and the search reads that plane, encoder/reference.cpp:119-178,
+ * encoder/frameencoder.cpp:865-866).  w = the arguments of weight_pp (common/pixel.cpp:518-543):
+ *     dst = clip(((w0 * (src << (14 - depth)) + round) >> shift) + offset)      i.e. round and shift INCLUDE the 14 - depth correction
+ * The service weights the rows of picture ref_key on the device as they arrive (margins included: a replicated border sample weights
+ * to the replicated weighted sample, so the result is the host's plane sample for sample) and searches that plane; pairs with the
+ * same (ref_key, w) share it.  w = NULL is x265hip_me_stream_pair_open. */
+typedef struct x265hip_weight { int w0, round, shift, offset; } x265hip_weight;
+int  x265hip_me_stream_pair_open_weighted(x265hip_me_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key, const x265hip_weight* w);
 const void* x265hip_me_stream_surface(x265hip_me_stream* s, int slot);
 const volatile int* x265hip_me_stream_ready(x265hip_me_stream* s, int slot);      /* int [height / 64] */
 int  x265hip_me_stream_record_bytes(x265hip_me_stream* s);
@@ -1039,9 +1049,12 @@ const volatile int* x265hip_phase_cache_ready(x265hip_phase_cache* c, int slot);
 int  x265hip_phase_cache_stats(x265hip_phase_cache* c, x265hip_phase_cache_stats_t* st);
 
 
-/* ROW-GRANULAR flavour (csrc/phase_stream.hip) for hosts that encode several pictures at once - the reference's frame threads: the
- * producer side opens a slot for a reconstructed picture and hands its CTU rows over as they become final (where the reference raises
- * Frame::m_reconRowFlag, encoder/framefilter.cpp:664); the phase planes grow line by line behind it.
+/* ROW-GRANULAR flavour (csrc/phase_stream.hip) for hosts that encode several pictures at once - the reference's frame threads.
+ * PICTURES are named by a key; the producer hands their CTU rows over as they become final (where the reference raises
+ * Frame::m_reconRowFlag, encoder/framefilter.cpp:664: x265hip_phase_stream_picture_rows).  A slot holds a VIEW of one picture - its
+ * fractional-phase planes, growing line by line behind the rows - opened by the consumer the first time a search refers to it
+ * (x265hip_phase_stream_view_open); a WEIGHTED reference (x265's default --weightp: the search reads primitives.weight_pp of the
+ * reconstruction, encoder/reference.cpp:119-178) is a view of its own, weighted on the device before the interpolation.
  *   progress : uint64 [2] per slot, [0] luma planes, [1] both chroma plane sets: generation << 32 | lines finished, counted from the top
  *              of the buffer (lines [4, finished) of every phase plane are valid).  A reader checks it before AND after reading a block.
  *   4:2:0 only when rows_c > 0: a CTU row is 64 luma / 32 chroma lines; rows = ctu_rows * 64 + 2 * margin_y, rows_c likewise with 32. */
@@ -1052,16 +1065,26 @@ typedef struct x265hip_phase_stream_params
     intptr_t stride;   int rows;   int margin_y;        /* luma buffer: pitch in samples, allocated rows, rows above sample (0,0) */
     intptr_t stride_c; int rows_c; int margin_y_c;      /* each chroma buffer; rows_c = 0: luma only */
     int ctu_rows;
-    int slots;                                          /* reference pictures resident (device + pinned host memory) at once */
+    int slots;                                          /* views resident (device + pinned host memory) at once */
+    int pictures;                                       /* source pictures resident at once (0 = slots) */
 } x265hip_phase_stream_params;
 typedef struct x265hip_phase_stream_stats_t
 {
     uint64_t opened, completed, bands, failed;
     uint64_t us_busy;
     uint64_t bytes_downloaded, bytes_uploaded, bytes_per_picture;
+    uint64_t weighted_views, lines_weighted;
 } x265hip_phase_stream_stats_t;
 int  x265hip_phase_stream_create(x265hip_phase_stream** out, const x265hip_phase_stream_params* p);
 void x265hip_phase_stream_destroy(x265hip_phase_stream* s);
+/* CTU rows [ctu_row0, ctu_row0 + ctu_rows) of picture `key` are final in the three whole-plane buffers (cb / cr NULL when rows_c = 0);
+ * copied before the call returns.  X265HIP_EBUSY: every picture entry still feeds a view. */
+int  x265hip_phase_stream_picture_rows(x265hip_phase_stream* s, uint64_t key, const void* luma_buf, const void* cb_buf, const void* cr_buf,
+                                       int ctu_row0, int ctu_rows);
+/* `slot` becomes the view of picture `key`; w = NULL: as reconstructed, else plane c (0 Y, 1 Cb, 2 Cr) is weighted with w[c] (the
+ * arguments of primitives.weight_pp, see x265hip_weight) where bit c of planes_weighted is set.  -> the slot's new GENERATION (> 0) */
+int  x265hip_phase_stream_view_open(x265hip_phase_stream* s, int slot, uint64_t key, const x265hip_weight* w, unsigned planes_weighted);
+/* round-3 entries, kept: the producer opens a slot for an (anonymous) picture and feeds the slot */
 int  x265hip_phase_stream_open(x265hip_phase_stream* s, int slot);                       /* -> the slot's new GENERATION (> 0) */
 int  x265hip_phase_stream_rows(x265hip_phase_stream* s, int slot, int generation, const void* luma_buf, const void* cb_buf, const void* cr_buf,
                                int ctu_row0, int ctu_rows);

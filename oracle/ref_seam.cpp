@@ -20,7 +20,10 @@
  * function that raises Frame::m_reconRowFlag[row] (framefilter.cpp:664) - and hands every finished CTU row of a reconstructed picture
  * to the providers right after the reference's own body; pairs are opened by the first search of a (picture, reference) and searched
  * on the device row by row behind the producer, so the seams serve under the reference's own frame threads (-F 5 on 16 cores).
- * Unweighted references only; otherwise the seams stay out of the way.
+ * WEIGHTED references (x265's default --weightp / --weightb: MotionReference::applyWeight materialises primitives.weight_pp of every
+ * finished reconstructed row, reference.cpp:119-178, frameencoder.cpp:865-866) are served by the row-granular providers too (round 4):
+ * the weighted plane is the reconstructed plane weighted sample by sample, margins included, so the provider gets the weight_pp
+ * arguments with the pair / view and weights the rows it already holds on the device; the picture-granular providers still step aside.
  *
  * The provider is a table of C function pointers with the signatures of x265hip_me_cache_submit / _surface / _ready
  * (include/x265hip.h), so the GPU library plugs in directly; the CPU-only tests plug in the oracle's exhaustive search instead. */
@@ -46,6 +49,7 @@
 #include <mutex>
 #include <vector>
 #include <time.h>
+#include <x86intrin.h>
 
 using namespace X265_NS;
 
@@ -56,6 +60,7 @@ extern "C" void x265ref_orig_processPostRow(FrameFilter* self, int row);
 extern "C" int x265ref_orig_subpelCompare(MotionEstimate* self, ReferencePlanes* ref, const MV* qmv, pixelcmp_t cmp);
 extern "C" int64_t x265ref_orig_estimateFrameCost(CostEstimateGroup* self, LookaheadTLD* tld, int p0, int p1, int b, bool bIntraPenalty);
 extern "C" void x265ref_orig_lowresIntraEstimate(LookaheadTLD* self, Lowres* fenc, uint32_t qgSize);
+extern "C" int x265ref_profile_fill_table(void* table, size_t bytes, int depth);          /* oracle/ref_profile.cpp: cycle-counting thunks */
 
 namespace {
 
@@ -111,6 +116,19 @@ struct LookaheadSeam
     uint64_t instance = 0;          /* bumped by every configure: a frame number names a picture's content only within one encode */
 } gla;
 
+/* measurement aid (tools/encoder_profile.py --seams): cycles inside the wrapped stages, next to ref_profile.cpp's per-family thunks */
+struct SeamProf
+{
+    bool on = false;
+    std::atomic<uint64_t> meCyc{0}, meCalls{0}, subCyc{0}, subCalls{0}, laCyc{0}, laCalls{0}, rowCyc{0}, rows{0};
+} gp;
+struct ProfScope
+{
+    std::atomic<uint64_t>& cyc; std::atomic<uint64_t>& n; uint64_t t0;
+    ProfScope(std::atomic<uint64_t>& c, std::atomic<uint64_t>& k) : cyc(c), n(k), t0(gp.on ? __rdtsc() : 0) {}
+    ~ProfScope() { if (gp.on) { cyc.fetch_add(__rdtsc() - t0, std::memory_order_relaxed); n.fetch_add(1, std::memory_order_relaxed); } }
+};
+
 struct MeCostProbe : public MotionEstimate { const uint16_t* costCentre() const { return m_cost; } };
 
 enum { SURF_I32 = 0, SURF_PACKED = 1, SURF_PACKED_T = 2, GROUP_I32 = 1360, GROUP_PACKED = 720, MAX_PARTS = 6, MAX_SLOTS = 64 };
@@ -125,6 +143,7 @@ struct Provider
     /* row-granular flavour (x265hip_me_stream_picture_rows / _pair_open signatures); streamed = both are set */
     int (*picture_rows)(void* ctx, uint64_t key, const void* buf, int ctu_row0, int ctu_rows);
     int (*pair_open)(void* ctx, int slot, uint64_t fenc_key, uint64_t ref_key);
+    int (*pair_open_w)(void* ctx, int slot, uint64_t fenc_key, uint64_t ref_key, const void* weight);      /* x265hip_me_stream_pair_open_weighted; NULL: weighted references pass */
     bool streamed;
     int min_level;                /* 1: records hold the 16x16 / 32x32 / 64x64 levels only (X265HIP_SURF_TAIL_BYTES_*) */
     int range, surf_format, slots;
@@ -134,7 +153,20 @@ struct Provider
     int min_pu;                   /* serve partitions whose smaller side is >= min_pu (8, 16, 32 or 64) */
 };
 
-struct Pair { int fencPoc; const PicYuv* rec; int recPoc; int slot; int gen; bool used; int encodeOrder; };
+/* the arguments of primitives.weight_pp as reference.cpp:154 passes them = x265hip_weight; present = 0: the plane as reconstructed */
+struct Wt { int w0, round, shift, offset; int present; };
+inline bool same_wt(const Wt& a, const Wt& b) { return a.present == b.present && (!a.present || (a.w0 == b.w0 && a.round == b.round && a.shift == b.shift && a.offset == b.offset)); }
+inline Wt plane_weight(const ReferencePlanes* ref, int c)
+{
+    Wt w = { 0, 0, 0, 0, 0 };
+    if (ref->isWeighted && ref->reconPic && ref->fpelPlane[c] != ref->reconPic->m_picOrg[c])
+    {
+        const int correction = IF_INTERNAL_PREC - X265_DEPTH;
+        w.w0 = ref->w[c].weight; w.round = ref->w[c].round << correction; w.shift = ref->w[c].shift + correction; w.offset = ref->w[c].offset; w.present = 1;
+    }
+    return w;
+}
+struct Pair { int fencPoc; const PicYuv* rec; int recPoc; int slot; int gen; bool used; int encodeOrder; Wt wt; };
 struct FencStaged { int poc; int encodeOrder; bool used; };
 
 struct Seam
@@ -152,7 +184,7 @@ struct Seam
     pixelcmp_x3_t sad_x3[NUM_PU_SIZES];
     pixelcmp_x4_t sad_x4[NUM_PU_SIZES];
     std::atomic<uint64_t> hits{0}, outside{0}, notReady{0}, meCalls{0}, meServed{0}, submits{0}, mismatches{0}, noSlot{0}, foreign{0};
-    std::atomic<uint64_t> rowsPublished{0}, rowsRefused{0}, torn{0};
+    std::atomic<uint64_t> rowsPublished{0}, rowsRefused{0}, torn{0}, weightedPairs{0}, weightedHits{0}, weightedCalls{0};
 } g;
 enum { MAX_SLOTS_STREAMED = 64 };
 inline uint64_t pic_key(uint64_t instance, int poc, int isRecon) { return (instance << 40) | ((uint64_t)(uint32_t)poc << 1) | (uint64_t)isRecon; }
@@ -170,11 +202,12 @@ struct Ctx
     const uint8_t* ctuBase;   /* surfaces of this CTU */
     const volatile int* ready;
     int ctuRow, gen, nparts;
+    bool weighted;
     Part parts[MAX_PARTS];
     uint64_t hits, outside, notReady;
 };
 thread_local Ctx t_ctx;
-struct TlsPair { const PicYuv* rec; int recPoc; int slot; int gen; };
+struct TlsPair { const PicYuv* rec; int recPoc; int slot; int gen; Wt wt; };
 thread_local struct { int fencPoc; int epoch; int n; TlsPair e[8]; } t_pairs = { -0x7fffffff, -1, 0, {} };
 
 /* width / height per LumaPU enum (primitives.h:41-55); the reference never sets MotionEstimate::blockheight (motion.cpp:178,217) */
@@ -320,12 +353,12 @@ template <> struct Install<NUM_PU_SIZES> { static void run(EncoderPrimitives&, i
 /* slot of (source picture poc, reference picture); -1 when none can be had.  The first query for a new source picture requests the
  * surfaces of ALL its unweighted references as one batch (x265hip_me_cache_submit_batch: searched back to back, downloaded
  * row-interleaved), so the top CTU rows of every reference arrive first. */
-int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicYuv* rec, int recPoc, int& gen, int encodeOrder, int frameThreads)
+int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicYuv* rec, int recPoc, const Wt& wt, int& gen, int encodeOrder, int frameThreads)
 {
     const int epoch = g.epoch.load(std::memory_order_acquire);
     if (t_pairs.fencPoc != fencPoc || t_pairs.epoch != epoch) { t_pairs.fencPoc = fencPoc; t_pairs.epoch = epoch; t_pairs.n = 0; }
     for (int i = 0; i < t_pairs.n; i++)
-        if (t_pairs.e[i].rec == rec && t_pairs.e[i].recPoc == recPoc) { gen = t_pairs.e[i].gen; return t_pairs.e[i].slot; }
+        if (t_pairs.e[i].rec == rec && t_pairs.e[i].recPoc == recPoc && same_wt(t_pairs.e[i].wt, wt)) { gen = t_pairs.e[i].gen; return t_pairs.e[i].slot; }
     int slot = -1;
     {
         std::lock_guard<std::mutex> lk(g.mu);
@@ -334,24 +367,26 @@ int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicY
         {
             Pair& q = g.pairs[i];
             if (q.used && q.fencPoc == fencPoc) known = true;
-            if (q.used && q.fencPoc == fencPoc && q.rec == rec && q.recPoc == recPoc) { slot = i; gen = q.gen; }
+            if (q.used && q.fencPoc == fencPoc && q.rec == rec && q.recPoc == recPoc && same_wt(q.wt, wt)) { slot = i; gen = q.gen; }
         }
         if (slot < 0)
         {
             /* candidates: a new source picture -> every reference of the slice; otherwise just the one asked for */
-            const PicYuv* want[2 * (MAX_NUM_REF + 1)]; int wantPoc[2 * (MAX_NUM_REF + 1)]; int nwant = 0;
-            want[nwant] = rec; wantPoc[nwant++] = recPoc;
+            const PicYuv* want[2 * (MAX_NUM_REF + 1) + 1]; int wantPoc[2 * (MAX_NUM_REF + 1) + 1]; Wt wantWt[2 * (MAX_NUM_REF + 1) + 1]; int nwant = 0;
+            want[nwant] = rec; wantPoc[nwant] = recPoc; wantWt[nwant++] = wt;
             if (!known)
                 for (int l = 0; l < 2; l++)
                     for (int r = 0; r < slice->m_numRefIdx[l]; r++)
                     {
                         const MotionReference& mr = slice->m_mref[l][r];
-                        if (!mr.reconPic || mr.isWeighted || mr.fpelPlane[0] != mr.reconPic->m_picOrg[0] || mr.reconPic->m_stride != g.p.stride) continue;
+                        if (!mr.reconPic || mr.reconPic->m_stride != g.p.stride) continue;
+                        const Wt mw = plane_weight(&mr, 0);
+                        if (mw.present ? !(g.p.streamed && g.p.pair_open_w) : mr.isWeighted) continue;       /* isWeighted without a weighted luma plane does not occur (reference.cpp:73) */
                         bool dup = false;
-                        for (int k = 0; k < nwant; k++) dup |= want[k] == mr.reconPic && wantPoc[k] == slice->m_refPOCList[l][r];
-                        if (!dup) { want[nwant] = mr.reconPic; wantPoc[nwant++] = slice->m_refPOCList[l][r]; }
+                        for (int k = 0; k < nwant; k++) dup |= want[k] == mr.reconPic && wantPoc[k] == slice->m_refPOCList[l][r] && same_wt(wantWt[k], mw);
+                        if (!dup) { want[nwant] = mr.reconPic; wantPoc[nwant] = slice->m_refPOCList[l][r]; wantWt[nwant++] = mw; }
                     }
-            int slots[2 * (MAX_NUM_REF + 1)], gens[2 * (MAX_NUM_REF + 1)]; const void* bufs[2 * (MAX_NUM_REF + 1)]; int n = 0;
+            int slots[2 * (MAX_NUM_REF + 1) + 1], gens[2 * (MAX_NUM_REF + 1) + 1]; const void* bufs[2 * (MAX_NUM_REF + 1) + 1]; int n = 0;
             for (int k = 0; k < nwant; k++)
             {
                 int freeSlot = -1;
@@ -389,7 +424,8 @@ int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicY
                 }
                 for (int k = 0; k < n && rc == 0; k++)
                 {
-                    gens[k] = g.p.pair_open(g.p.ctx, slots[k], fkey, pic_key(g.instance, wantPoc[k], 1));
+                    gens[k] = wantWt[k].present ? g.p.pair_open_w(g.p.ctx, slots[k], fkey, pic_key(g.instance, wantPoc[k], 1), &wantWt[k])
+                                                : g.p.pair_open(g.p.ctx, slots[k], fkey, pic_key(g.instance, wantPoc[k], 1));
                     if (gens[k] <= 0) rc = -1;
                 }
             }
@@ -410,8 +446,9 @@ int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicY
                 {
                     Pair& q = g.pairs[slots[k]];
                     q.used = true; q.fencPoc = fencPoc; q.rec = want[k]; q.recPoc = wantPoc[k]; q.slot = slots[k]; q.gen = gens[k];
-                    q.encodeOrder = encodeOrder;
+                    q.encodeOrder = encodeOrder; q.wt = wantWt[k];
                     g.submits++;
+                    if (wantWt[k].present) g.weightedPairs++;
                 }
                 slot = slots[0]; gen = gens[0];            /* want[0] is the pair that was asked for */
                 g.epoch.fetch_add(1, std::memory_order_release);
@@ -420,7 +457,7 @@ int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicY
         }
     }
     if (slot < 0) { g.noSlot++; return -1; }
-    if (t_pairs.n < 8) { TlsPair& e = t_pairs.e[t_pairs.n++]; e.rec = rec; e.recPoc = recPoc; e.slot = slot; e.gen = gen; }
+    if (t_pairs.n < 8) { TlsPair& e = t_pairs.e[t_pairs.n++]; e.rec = rec; e.recPoc = recPoc; e.slot = slot; e.gen = gen; e.wt = wt; }
     return slot;
 }
 
@@ -433,9 +470,9 @@ struct PhaseProvider
     int (*submit)(void* ctx, int slot, const void* luma, const void* cb, const void* cr);
     const void* (*planes)(void* ctx, int slot, int plane);
     const volatile int* (*ready)(void* ctx, int slot);
-    /* row-granular flavour (x265hip_phase_stream_open / _rows / _progress signatures); streamed = all three are set */
-    int (*open)(void* ctx, int slot);
-    int (*rows_fn)(void* ctx, int slot, int gen, const void* luma, const void* cb, const void* cr, int ctu_row0, int ctu_rows);
+    /* row-granular flavour (x265hip_phase_stream_view_open / _picture_rows / _progress signatures); streamed = all three are set */
+    int (*open)(void* ctx, int slot, uint64_t key, const void* weights, unsigned planes_weighted);
+    int (*rows_fn)(void* ctx, uint64_t key, const void* luma, const void* cb, const void* cr, int ctu_row0, int ctu_rows);
     const volatile uint64_t* (*progress)(void* ctx, int slot);
     bool streamed;
     int ctuRows;
@@ -443,7 +480,8 @@ struct PhaseProvider
     intptr_t stride;  int rows;
     intptr_t strideC; int rowsC;
 };
-struct PhaseEntry { const PicYuv* rec; int poc; int gen; bool used; uint64_t lastUse; };
+struct PhaseEntry { const PicYuv* rec; int poc; int gen; bool used; uint64_t lastUse; Wt wt[3]; };
+inline bool same_wt3(const Wt* a, const Wt* b) { return same_wt(a[0], b[0]) && same_wt(a[1], b[1]) && same_wt(a[2], b[2]); }
 struct SubSeam
 {
     bool enabled = false, verify = false, wait = false;
@@ -451,8 +489,9 @@ struct SubSeam
     std::mutex mu;
     PhaseEntry e[MAX_SLOTS];
     uint64_t tick = 0;
+    uint64_t instance = 0;               /* bumped by every configure: a POC names a picture's content only within one encode */
     std::atomic<int> epoch{0};
-    std::atomic<uint64_t> served{0}, notReady{0}, noContext{0}, submits{0}, mismatches{0}, noSlot{0}, rowsPublished{0}, torn{0};
+    std::atomic<uint64_t> served{0}, notReady{0}, noContext{0}, submits{0}, mismatches{0}, noSlot{0}, rowsPublished{0}, torn{0}, weightedViews{0}, weightedServed{0};
 } gs;
 
 struct SubCtx
@@ -461,6 +500,8 @@ struct SubCtx
     const ReferencePlanes* ref;
     const PicYuv* rec;
     const pixel* luma; const pixel* cb; const pixel* cr;      /* phase 1 of each plane set, buffer coordinates */
+    const pixel* base[3];                                     /* allocation start of the plane the reference reads: PicYuv::m_picBuf or MotionReference::weightBuffer */
+    bool weighted;
     size_t planeL, planeC;                                    /* samples per plane */
     const volatile int* ready;
     const volatile uint64_t* progress;                        /* streamed: generation << 32 | lines finished, [0] luma [1] chroma */
@@ -468,42 +509,55 @@ struct SubCtx
     bool arrived[2];
 };
 thread_local SubCtx t_sub;
-thread_local struct { int epoch; int n; struct { const PicYuv* rec; int poc; int slot; int gen; } e[8]; } t_phase = { -1, 0, {} };
+thread_local struct { int epoch; int n; struct { const PicYuv* rec; int poc; int slot; int gen; Wt wt[3]; } e[8]; } t_phase = { -1, 0, {} };
 
-/* slot that holds (or will hold) the phase planes of reconstructed picture (rec, poc); -1 when none can be had.  A picture is
- * submitted the first time a search refers to it; the least recently used slot whose picture the current slice does not
- * reference is recycled (-F 1: earlier pictures' searches are over). */
-int phase_slot(const PicYuv* rec, int poc, const Slice* slice, int& gen)
+/* slot that holds (or will hold) the phase planes of reconstructed picture (rec, poc) seen through the weights wt[3]; -1 when none can
+ * be had.  A view is submitted / opened the first time a search refers to it.  Picture-granular: the least recently used slot whose
+ * picture the current slice does not reference is recycled (-F 1: earlier pictures' searches are over).  Row-granular: the least
+ * recently used slot (more slots than views in use at once; a reader of a recycled slot sees the generation change and passes). */
+int phase_slot(const PicYuv* rec, int poc, const Slice* slice, const Wt* wt, int& gen)
 {
     const int epoch = gs.epoch.load(std::memory_order_acquire);
     if (t_phase.epoch != epoch) { t_phase.epoch = epoch; t_phase.n = 0; }
     for (int i = 0; i < t_phase.n; i++)
-        if (t_phase.e[i].rec == rec && t_phase.e[i].poc == poc) { gen = t_phase.e[i].gen; return t_phase.e[i].slot; }
+        if (t_phase.e[i].rec == rec && t_phase.e[i].poc == poc && same_wt3(t_phase.e[i].wt, wt)) { gen = t_phase.e[i].gen; return t_phase.e[i].slot; }
     int slot = -1;
     {
         std::lock_guard<std::mutex> lk(gs.mu);
         gs.tick++;
         for (int i = 0; i < gs.p.slots; i++)
-            if (gs.e[i].used && gs.e[i].rec == rec && gs.e[i].poc == poc) { slot = i; gen = gs.e[i].gen; gs.e[i].lastUse = gs.tick; }
-        if (slot < 0 && !gs.p.streamed)
+            if (gs.e[i].used && gs.e[i].rec == rec && gs.e[i].poc == poc && same_wt3(gs.e[i].wt, wt)) { slot = i; gen = gs.e[i].gen; gs.e[i].lastUse = gs.tick; }
+        if (slot < 0)
         {
             int victim = -1;
             for (int i = 0; i < gs.p.slots; i++)
             {
                 if (!gs.e[i].used) { victim = i; break; }
                 bool live = false;
-                for (int l = 0; l < 2 && !live; l++)
-                    for (int r = 0; r < slice->m_numRefIdx[l] && !live; r++)
-                        live = slice->m_mref[l][r].reconPic == gs.e[i].rec && slice->m_refPOCList[l][r] == gs.e[i].poc;
+                if (!gs.p.streamed)
+                    for (int l = 0; l < 2 && !live; l++)
+                        for (int r = 0; r < slice->m_numRefIdx[l] && !live; r++)
+                            live = slice->m_mref[l][r].reconPic == gs.e[i].rec && slice->m_refPOCList[l][r] == gs.e[i].poc;
                 if (!live && (victim < 0 || gs.e[i].lastUse < gs.e[victim].lastUse)) victim = i;
             }
             if (victim >= 0)
             {
-                const int gnew = gs.p.submit(gs.p.ctx, victim, rec->m_picBuf[0], rec->m_picBuf[1], rec->m_picBuf[2]);
+                int gnew;
+                if (gs.p.streamed)
+                {
+                    const unsigned mask = (wt[0].present ? 1u : 0u) | (wt[1].present ? 2u : 0u) | (wt[2].present ? 4u : 0u);
+                    struct { int w0, round, shift, offset; } w3[3];
+                    for (int c = 0; c < 3; c++) { w3[c].w0 = wt[c].w0; w3[c].round = wt[c].round; w3[c].shift = wt[c].shift; w3[c].offset = wt[c].offset; }
+                    gnew = gs.p.open(gs.p.ctx, victim, pic_key(gs.instance, poc, 1), mask ? w3 : NULL, mask);
+                    if (gnew > 0 && mask) gs.weightedViews++;
+                }
+                else
+                    gnew = gs.p.submit(gs.p.ctx, victim, rec->m_picBuf[0], rec->m_picBuf[1], rec->m_picBuf[2]);
                 if (gnew > 0)
                 {
                     PhaseEntry& q = gs.e[victim];
                     q.used = true; q.rec = rec; q.poc = poc; q.gen = gnew; q.lastUse = gs.tick;
+                    q.wt[0] = wt[0]; q.wt[1] = wt[1]; q.wt[2] = wt[2];
                     slot = victim; gen = gnew;
                     gs.submits++;
                     gs.epoch.fetch_add(1, std::memory_order_release);
@@ -513,32 +567,8 @@ int phase_slot(const PicYuv* rec, int poc, const Slice* slice, int& gen)
         }
     }
     if (slot < 0) { gs.noSlot++; return -1; }
-    if (t_phase.n < 8) { auto& e = t_phase.e[t_phase.n++]; e.rec = rec; e.poc = poc; e.slot = slot; e.gen = gen; }
+    if (t_phase.n < 8) { auto& e = t_phase.e[t_phase.n++]; e.rec = rec; e.poc = poc; e.slot = slot; e.gen = gen; e.wt[0] = wt[0]; e.wt[1] = wt[1]; e.wt[2] = wt[2]; }
     return slot;
-}
-
-/* producer side of the row-granular flavour: the slot that holds reconstructed picture (rec, poc), opened the first time one of its
- * rows is published (least recently used slot: with more slots than the DPB holds pictures that one is long out of use) */
-int phase_slot_produce(const PicYuv* rec, int poc, int& gen)
-{
-    std::lock_guard<std::mutex> lk(gs.mu);
-    gs.tick++;
-    for (int i = 0; i < gs.p.slots; i++)
-        if (gs.e[i].used && gs.e[i].rec == rec && gs.e[i].poc == poc) { gen = gs.e[i].gen; gs.e[i].lastUse = gs.tick; return i; }
-    int victim = 0;
-    for (int i = 0; i < gs.p.slots; i++)
-    {
-        if (!gs.e[i].used) { victim = i; break; }
-        if (gs.e[i].lastUse < gs.e[victim].lastUse) victim = i;
-    }
-    const int gnew = gs.p.open(gs.p.ctx, victim);
-    if (gnew <= 0) return -1;
-    PhaseEntry& q = gs.e[victim];
-    q.used = true; q.rec = rec; q.poc = poc; q.gen = gnew; q.lastUse = gs.tick;
-    gen = gnew;
-    gs.submits++;
-    gs.epoch.fetch_add(1, std::memory_order_release);
-    return victim;
 }
 
 /* POC of the reference picture `ref` points at: ref is an element of slice->m_mref[list][idx] (slice.h:337) */
@@ -554,18 +584,26 @@ void sub_context(const Search* s, ReferencePlanes* ref)
     SubCtx& c = t_sub;
     c.valid = false;
     const PicYuv* rec = ref->reconPic;
-    if (!rec || ref->isWeighted || ref->isLowres || (s->m_param->frameNumThreads != 1 && !gs.p.streamed) || rec->m_picCsp != X265_CSP_I420 ||
-        ref->fpelPlane[0] != rec->m_picOrg[0] || ref->fpelPlane[1] != rec->m_picOrg[1] || ref->fpelPlane[2] != rec->m_picOrg[2] ||
+    if (!rec || ref->isLowres || (s->m_param->frameNumThreads != 1 && !gs.p.streamed) || (ref->isWeighted && !gs.p.streamed) || rec->m_picCsp != X265_CSP_I420 ||
         rec->m_stride != gs.p.stride || rec->m_strideC != gs.p.strideC) { gs.noContext.fetch_add(1, std::memory_order_relaxed); return; }
+    /* the planes the reference reads: the reconstruction, or - plane by plane - MotionReference::weightBuffer at the same pad (reference.cpp:103) */
+    Wt wt[3];
+    for (int k = 0; k < 3; k++)
+    {
+        wt[k] = plane_weight(ref, k);
+        c.base[k] = wt[k].present ? static_cast<const MotionReference*>(ref)->weightBuffer[k] : rec->m_picBuf[k];
+        if (!c.base[k] || ref->fpelPlane[k] - c.base[k] != rec->m_picOrg[k] - rec->m_picBuf[k]) { gs.noContext.fetch_add(1, std::memory_order_relaxed); return; }
+    }
     const int maxH = (int)((rec->m_picHeight + s->m_param->maxCUSize - 1) / s->m_param->maxCUSize * s->m_param->maxCUSize);
     if (maxH + 2 * (int)rec->m_lumaMarginY != gs.p.rows || (maxH >> 1) + 2 * (int)rec->m_chromaMarginY != gs.p.rowsC)
     { gs.noContext.fetch_add(1, std::memory_order_relaxed); return; }
     const int poc = ref_poc(s->m_slice, ref);
     if (poc == -0x7fffffff) { gs.noContext.fetch_add(1, std::memory_order_relaxed); return; }
     int gen = 0;
-    const int slot = phase_slot(rec, poc, s->m_slice, gen);
+    const int slot = phase_slot(rec, poc, s->m_slice, wt, gen);
     if (slot < 0) return;
     c.ref = ref; c.rec = rec;
+    c.weighted = wt[0].present || wt[1].present || wt[2].present;
     c.luma = (const pixel*)gs.p.planes(gs.p.ctx, slot, 0);
     c.cb = (const pixel*)gs.p.planes(gs.p.ctx, slot, 1);
     c.cr = (const pixel*)gs.p.planes(gs.p.ctx, slot, 2);
@@ -616,12 +654,16 @@ inline bool sub_arrived(SubCtx& c, int which)
 int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const MV& mvmax, const MV& qmvp, int numCandidates, const MV* mvc,
                                    int merange, MV& outQMv, uint32_t maxSlices, pixel* srcReferencePlane)
 {
+    ProfScope prof(gp.meCyc, gp.meCalls);
     Ctx& c = t_ctx;
     c.valid = false;
     if (g.enabled)
     {
         g.meCalls.fetch_add(1, std::memory_order_relaxed);
-        if (g.p.min_pu <= 64 && ctuAddr >= 0 && !srcReferencePlane && !ref->isLowres && !ref->isWeighted && ref->reconPic && partEnum >= 0 && partEnum < NUM_PU_SIZES &&
+        const Wt wt = (ref->isLowres || !ref->reconPic) ? Wt{ 0, 0, 0, 0, 0 } : plane_weight(ref, 0);
+        /* a weighted reference (fpelPlane[0] = MotionReference::weightBuffer[0] + the PicYuv pad, reference.cpp:103) needs the row-granular provider */
+        const bool wtOk = wt.present ? (g.p.streamed && g.p.pair_open_w != NULL) : !ref->isWeighted;
+        if (g.p.min_pu <= 64 && ctuAddr >= 0 && !srcReferencePlane && !ref->isLowres && wtOk && ref->reconPic && partEnum >= 0 && partEnum < NUM_PU_SIZES &&
             PU_DIMS[partEnum][0] == blockwidth && !(blockwidth & 7) && !(PU_DIMS[partEnum][1] & 7))
         {
             /* a MotionEstimate with ctuAddr >= 0 is the m_me member of a Search (search.h:257; the lookahead's instances use the other
@@ -630,7 +672,8 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
             const Frame* frame = s->m_frame;
             const PicYuv* rec = ref->reconPic;
             const PicYuv* src = frame ? frame->m_fencPic : NULL;
-            if (src && (s->m_param->frameNumThreads == 1 || g.p.streamed) && ref->fpelPlane[0] == rec->m_picOrg[0] &&
+            const pixel* lumaOrg = wt.present ? static_cast<const MotionReference*>(ref)->weightBuffer[0] + (rec->m_picOrg[0] - rec->m_picBuf[0]) : rec->m_picOrg[0];
+            if (src && (s->m_param->frameNumThreads == 1 || g.p.streamed) && ref->fpelPlane[0] == lumaOrg &&
                 rec->m_stride == g.p.stride && src->m_stride == g.p.stride && (int)rec->m_lumaMarginX == g.p.margin_x && (int)rec->m_lumaMarginY == g.p.margin_y &&
                 (int)src->m_lumaMarginX == g.p.margin_x && (int)src->m_lumaMarginY == g.p.margin_y && s->m_param->maxCUSize == 64)
             {
@@ -641,7 +684,8 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
                 if (idx >= 0 && idx < 2 * (MAX_NUM_REF + 1))
                     recPoc = slice->m_refPOCList[idx / (MAX_NUM_REF + 1)][idx % (MAX_NUM_REF + 1)];
                 int gen = 0;
-                const int slot = recPoc == -0x7fffffff ? -1 : pair_slot(frame->m_poc, src, slice, rec, recPoc, gen, frame->m_encodeOrder, s->m_param->frameNumThreads);
+                const int slot = recPoc == -0x7fffffff ? -1 : pair_slot(frame->m_poc, src, slice, rec, recPoc, wt, gen, frame->m_encodeOrder, s->m_param->frameNumThreads);
+                if (wt.present) g.weightedCalls.fetch_add(1, std::memory_order_relaxed);
                 if (slot >= 0)
                 {
                     c.nparts = 0;
@@ -658,6 +702,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
                         c.ready = g.p.ready(g.p.ctx, slot);
                         c.ctuRow = ctuAddr / g.ctusW;
                         c.gen = gen;
+                        c.weighted = wt.present != 0;
                         c.hits = c.outside = c.notReady = 0;
                         c.valid = true;
                     }
@@ -677,6 +722,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         c.valid = false;
         g.meServed.fetch_add(1, std::memory_order_relaxed);
         g.hits.fetch_add(c.hits, std::memory_order_relaxed);
+        if (c.weighted) g.weightedHits.fetch_add(c.hits, std::memory_order_relaxed);
         g.outside.fetch_add(c.outside, std::memory_order_relaxed);
         g.notReady.fetch_add(c.notReady, std::memory_order_relaxed);
     }
@@ -690,6 +736,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
  * the original. */
 int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_t cmp)
 {
+    ProfScope prof(gp.subCyc, gp.subCalls);
     SubCtx& c = t_sub;
     if (!c.valid || c.ref != ref || (!c.progress && (!sub_arrived(c, 0) || (bChromaSATD && !sub_arrived(c, 1)))))
     {
@@ -699,7 +746,7 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
     const intptr_t stride = ref->lumaStride;
     const ptrdiff_t pos = blockOffset + (qmv.x >> 2) + (qmv.y >> 2) * stride;            /* relative to fpelPlane[0] */
     const int lph = (qmv.y & 3) * 4 + (qmv.x & 3);
-    const ptrdiff_t lbuf = (ref->fpelPlane[0] - c.rec->m_picBuf[0]) + pos;               /* relative to the buffer start */
+    const ptrdiff_t lbuf = (ref->fpelPlane[0] - c.base[0]) + pos;                        /* relative to the buffer start */
     const intptr_t strideC = c.rec->m_strideC;
     const ptrdiff_t cpos = (qmv.x >> 3) + (qmv.y >> 3) * strideC;                        /* 4:2:0: the quarter-sample luma vector is an eighth-sample chroma vector */
     const int cph = (qmv.y & 7) * 8 + (qmv.x & 7);
@@ -712,7 +759,7 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
         bool ok = !lph || sub_lines(c, 0, lbuf / stride, lbuf / stride + bh);
         if (ok && bChromaSATD && cph)
         {
-            const long l0 = (long)((cb - c.rec->m_picBuf[1]) / strideC);
+            const long l0 = (long)((cb - c.base[1]) / strideC);
             ok = sub_lines(c, 1, l0, l0 + (bh >> 1));
         }
         if (!ok)
@@ -727,8 +774,8 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
     {
         if (cph)
         {
-            cb = c.cb + (size_t)(cph - 1) * c.planeC + (cb - c.rec->m_picBuf[1]);
-            cr = c.cr + (size_t)(cph - 1) * c.planeC + (cr - c.rec->m_picBuf[2]);
+            cb = c.cb + (size_t)(cph - 1) * c.planeC + (cb - c.base[1]);
+            cr = c.cr + (size_t)(cph - 1) * c.planeC + (cr - c.base[2]);
         }
         cost += chromaSatd(fencPUYuv.m_buf[1], fencPUYuv.m_csize, cb, strideC);
         cost += chromaSatd(fencPUYuv.m_buf[2], fencPUYuv.m_csize, cr, strideC);
@@ -744,6 +791,7 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
         }
     }
     gs.served.fetch_add(1, std::memory_order_relaxed);
+    if (c.weighted) gs.weightedServed.fetch_add(1, std::memory_order_relaxed);
     if (gs.verify)
     {
         const int want = x265ref_orig_subpelCompare(this, ref, &qmv, cmp);
@@ -764,6 +812,7 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
 void FrameFilter::processPostRow(int row)
 {
     x265ref_orig_processPostRow(this, row);
+    ProfScope prof(gp.rowCyc, gp.rows);
     const bool sad = g.enabled && g.p.streamed && g.p.min_pu <= 64, sub = gs.enabled && gs.p.streamed;        /* min_pu > 64: no SAD stub is installed */
     if (!sad && !sub) return;
     const Frame* frame = m_frame;
@@ -780,9 +829,7 @@ void FrameFilter::processPostRow(int row)
     if (sub && rec->m_picCsp == X265_CSP_I420 && rec->m_stride == gs.p.stride && rec->m_strideC == gs.p.strideC && m_numRows == gs.p.ctuRows &&
         m_numRows * 64 + 2 * (int)rec->m_lumaMarginY == gs.p.rows && m_numRows * 32 + 2 * (int)rec->m_chromaMarginY == gs.p.rowsC)
     {
-        int gen = 0;
-        const int slot = phase_slot_produce(rec, frame->m_poc, gen);
-        if (slot >= 0 && gs.p.rows_fn(gs.p.ctx, slot, gen, rec->m_picBuf[0], rec->m_picBuf[1], rec->m_picBuf[2], row, 1) == 0)
+        if (gs.p.rows_fn(gs.p.ctx, pic_key(gs.instance, frame->m_poc, 1), rec->m_picBuf[0], rec->m_picBuf[1], rec->m_picBuf[2], row, 1) == 0)
             gs.rowsPublished.fetch_add(1, std::memory_order_relaxed);
     }
 }
@@ -795,6 +842,7 @@ void FrameFilter::processPostRow(int row)
  * row predictors at every slice boundary, a different - equally valid - estimate). */
 int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, int b, bool bIntraPenalty)
 {
+    ProfScope prof(gp.laCyc, gp.laCalls);
     Lowres* fenc = m_frames[b];
     x265_param* param = m_lookahead.m_param;
     const bool cached = fenc->costEst[b - p0][p1 - b] >= 0 && fenc->rowSatds[b - p0][p1 - b][0] != -1;
@@ -988,7 +1036,8 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
     g.p.submit_batch = (int (*)(void*, int, const int*, const void*, uint64_t, const void* const*, int*))submit_batch;      /* may be NULL */
     g.p.surface = (const void* (*)(void*, int))surface;
     g.p.ready = (const volatile int* (*)(void*, int))ready;
-    g.p.picture_rows = NULL; g.p.pair_open = NULL; g.p.streamed = false; g.p.min_level = 0;
+    g.p.picture_rows = NULL; g.p.pair_open = NULL; g.p.pair_open_w = NULL; g.p.streamed = false; g.p.min_level = 0;
+    g.weightedPairs = 0; g.weightedHits = 0; g.weightedCalls = 0;
     memset(g.fencs, 0, sizeof(g.fencs));
     g.instance++;
     g.rowsPublished = 0; g.rowsRefused = 0; g.torn = 0;
@@ -1010,8 +1059,8 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
 
 /* row-granular provider (x265hip_me_stream_picture_rows / _pair_open / _surface / _ready signatures): serves under any --frame-threads.
  * record_bytes = x265hip_me_stream_record_bytes (the whole record, or its 16x16-and-up tail with min_level 1). */
-int x265ref_seam_configure_streamed(void* ctx, void* picture_rows, void* pair_open, void* surface, void* ready, int range, int surf_format, int min_level,
-                                    int slots, int width, int height, intptr_t stride, int margin_x, int margin_y, int min_pu, int verify)
+int x265ref_seam_configure_streamed(void* ctx, void* picture_rows, void* pair_open, void* pair_open_weighted, void* surface, void* ready, int range, int surf_format,
+                                    int min_level, int slots, int width, int height, intptr_t stride, int margin_x, int margin_y, int min_pu, int verify)
 {
     if (!picture_rows || !pair_open || surf_format == SURF_PACKED_T || min_level < 0 || min_level > 1) return -4;
     const int rc = x265ref_seam_configure(ctx, NULL, NULL, surface, ready, range, surf_format, slots, width, height, stride, margin_x, margin_y,
@@ -1019,6 +1068,7 @@ int x265ref_seam_configure_streamed(void* ctx, void* picture_rows, void* pair_op
     if (rc) return rc;
     g.p.picture_rows = (int (*)(void*, uint64_t, const void*, int, int))picture_rows;
     g.p.pair_open = (int (*)(void*, int, uint64_t, uint64_t))pair_open;
+    g.p.pair_open_w = (int (*)(void*, int, uint64_t, uint64_t, const void*))pair_open_weighted;      /* NULL: weighted references pass */
     g.p.min_level = min_level;
     g.p.streamed = true;
     if (min_level)
@@ -1047,13 +1097,14 @@ int x265ref_subpel_seam_configure(void* ctx, void* submit, void* planes, void* r
     memset(gs.e, 0, sizeof(gs.e));
     gs.verify = (flags & 1) != 0; gs.wait = (flags & 2) != 0;
     gs.served = gs.notReady = gs.noContext = gs.submits = gs.mismatches = gs.noSlot = 0; gs.rowsPublished = 0; gs.torn = 0;
+    gs.weightedViews = 0; gs.weightedServed = 0;
     gs.epoch.fetch_add(1);
     gs.enabled = true;
     return 0;
 }
 
-/* row-granular provider (x265hip_phase_stream_open / _rows / _planes / _progress signatures): the producer hook feeds it, serves under
- * any --frame-threads */
+/* row-granular provider (x265hip_phase_stream_view_open / _picture_rows / _planes / _progress signatures): the producer hook feeds it
+ * pictures, searches open views (weighted or not); serves under any --frame-threads */
 int x265ref_subpel_seam_configure_streamed(void* ctx, void* open, void* rows_fn, void* planes, void* progress, int slots, intptr_t stride, int rows,
                                            intptr_t stride_c, int rows_c, int ctu_rows, int flags)
 {
@@ -1062,8 +1113,9 @@ int x265ref_subpel_seam_configure_streamed(void* ctx, void* open, void* rows_fn,
     if (slots < 1 || slots > MAX_SLOTS || !rows_fn || !planes || !progress || rows_c <= 0) return -1;
     gs.p.ctx = ctx;
     gs.p.submit = NULL; gs.p.ready = NULL;
-    gs.p.open = (int (*)(void*, int))open;
-    gs.p.rows_fn = (int (*)(void*, int, int, const void*, const void*, const void*, int, int))rows_fn;
+    gs.p.open = (int (*)(void*, int, uint64_t, const void*, unsigned))open;
+    gs.p.rows_fn = (int (*)(void*, uint64_t, const void*, const void*, const void*, int, int))rows_fn;
+    gs.instance++;
     gs.p.planes = (const void* (*)(void*, int, int))planes;
     gs.p.progress = (const volatile uint64_t* (*)(void*, int))progress;
     gs.p.streamed = true; gs.p.ctuRows = ctu_rows;
@@ -1071,6 +1123,7 @@ int x265ref_subpel_seam_configure_streamed(void* ctx, void* open, void* rows_fn,
     memset(gs.e, 0, sizeof(gs.e));
     gs.verify = (flags & 1) != 0; gs.wait = (flags & 2) != 0;
     gs.served = gs.notReady = gs.noContext = gs.submits = gs.mismatches = gs.noSlot = 0; gs.rowsPublished = 0; gs.torn = 0;
+    gs.weightedViews = 0; gs.weightedServed = 0;
     gs.epoch.fetch_add(1);
     gs.enabled = true;
     return 0;
@@ -1081,6 +1134,13 @@ int x265ref_subpel_seam_configure_streamed(void* ctx, void* open, void* rows_fn,
 void x265ref_seam_stream_stats(uint64_t* out)
 {
     out[0] = g.rowsPublished; out[1] = g.rowsRefused; out[2] = gs.rowsPublished; out[3] = g.torn + gs.torn;
+}
+
+/* out[5]: pairs opened on a weighted reference, motionEstimate calls on weighted references that got a lookup context, lookups served on
+ * weighted references, phase-plane views opened on weighted references, subpelCompare calls served from weighted views */
+void x265ref_seam_weighted_stats(uint64_t* out)
+{
+    out[0] = g.weightedPairs; out[1] = g.weightedCalls; out[2] = g.weightedHits; out[3] = gs.weightedViews; out[4] = gs.weightedServed;
 }
 
 /* out[6]: subpelCompare calls served from phase planes, passed on because the planes had not arrived, searches without a usable
@@ -1116,6 +1176,25 @@ int x265ref_seam_fill_table(void* table, size_t bytes, int depth)
     int n = 0;
     Install<0>::run(*static_cast<EncoderPrimitives*>(table), n);
     return n;
+}
+
+/* the seam's lookup stubs over ref_profile.cpp's cycle-counting thunks (the stubs' fall-backs then count as host sad time), and the
+ * stage timers of this file switched on: where the encode's time goes WITH the seams in place (tools/encoder_profile.py --seams) */
+int x265ref_seam_fill_table_profiled(void* table, size_t bytes, int depth)
+{
+    const int a = x265ref_profile_fill_table(table, bytes, depth);
+    if (a < 0) return a;
+    gp.meCyc = gp.meCalls = gp.subCyc = gp.subCalls = gp.laCyc = gp.laCalls = gp.rowCyc = gp.rows = 0;
+    gp.on = true;
+    const int b = g.enabled ? x265ref_seam_fill_table(table, bytes, depth) : 0;
+    return b < 0 ? b : a + b;
+}
+/* out[8]: cycles / calls of MotionEstimate::motionEstimate (whole, wrapper included), subpelCompare, CostEstimateGroup::estimateFrameCost,
+ * the row hand-over inside FrameFilter::processPostRow */
+void x265ref_seam_profile_report(uint64_t* out)
+{
+    out[0] = gp.meCyc; out[1] = gp.meCalls; out[2] = gp.subCyc; out[3] = gp.subCalls; out[4] = gp.laCyc; out[5] = gp.laCalls; out[6] = gp.rowCyc; out[7] = gp.rows;
+    gp.on = false;
 }
 
 /* out[10]: lookups served, outside the window, row not ready, motionEstimate calls, calls with a lookup context, pair submits,

@@ -250,6 +250,45 @@ def test_subpel_seam_encode_on_gpu_phase_planes_is_byte_identical(depth, preset,
 
 
 # ---- round 3: the ROW-GRANULAR services (csrc/me_stream.hip, csrc/phase_stream.hip) -------------------------------------------------
+def _stream_entries(L):
+    L.x265hip_me_stream_picture_rows.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.x265hip_me_stream_pair_open.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64]
+    L.x265hip_me_stream_pair_open_weighted.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    L.x265hip_me_stream_surface.restype = ctypes.c_void_p
+    L.x265hip_me_stream_surface.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.x265hip_me_stream_ready.restype = ctypes.c_void_p
+    L.x265hip_me_stream_ready.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.x265hip_me_stream_record_bytes.argtypes = [ctypes.c_void_p]
+
+
+def _check_stream_surfaces(O, L, prov, slot, depth, geo, rng, min_level, fenc_plane, ref_plane):
+    """slot's downloaded records (whole, or the 16x16-and-up tails) == the oracle's exhaustive search of fenc_plane in ref_plane"""
+    ctus_w, ctus_h = geo["width"] // 64, geo["height"] // 64
+    nc = 2 * rng + 1
+    ng = (nc + 3) // 4
+    rec = L.x265hip_me_stream_record_bytes(prov.handle)
+    org = geo["margin_y"] * geo["stride"] + geo["margin_x"]
+    zero = np.zeros(nc, np.uint16)
+    surf, _ = O.me_fullsearch(depth, fenc_plane, geo["stride"], org, ref_plane, geo["stride"], org, geo["width"], geo["height"], rng,
+                              0, ctus_w * ctus_h, zero, zero, want_surf=True, want_best=False)
+    e = surf.reshape(-1, 85, 4)
+    nrec = e.shape[0]
+    raw = np.ctypeslib.as_array((ctypes.c_uint8 * (nrec * rec)).from_address(L.x265hip_me_stream_surface(prov.handle, slot))).reshape(nrec, rec)
+    def cols(v):        # [record, pu, 4] -> [motion-vector row, dx, pu]; the pad columns of a row's last group hold don't-care values
+        v = v.reshape(-1, ng, v.shape[1], 4)
+        return v.transpose(0, 1, 3, 2).reshape(v.shape[0], ng * 4, v.shape[2])[:, :nc]
+    if depth == 8:
+        tail = raw if min_level else raw[:, 512:]
+        g16 = tail[:, 0:128].copy().view(np.uint16).reshape(nrec, 16, 4)
+        g32 = tail[:, 128:208].copy().view(np.int32).reshape(nrec, 5, 4)
+        assert np.array_equal(cols(g16), cols(e[:, 64:80])) and np.array_equal(cols(g32), cols(e[:, 80:85]))
+        if not min_level:
+            assert np.array_equal(cols(raw[:, 0:512].copy().view(np.uint16).reshape(nrec, 64, 4)), cols(e[:, 0:64]))
+    else:
+        got = raw.copy().view(np.int32).reshape(nrec, -1, 4)
+        assert np.array_equal(cols(got), cols(e[:, 64:] if min_level else e))
+
+
 @pytest.mark.parametrize("depth,width,height,rng,min_level,band_rows", [(8, 256, 320, 20, 0, 2), (8, 256, 320, 20, 1, 8), (10, 192, 256, 16, 1, 3),
                                                                         (8, 200, 264, 57, 1, 1), (12, 128, 192, 12, 0, 8)])
 def test_me_stream_surfaces_equal_oracle_whatever_order_the_rows_arrive_in(depth, width, height, rng, min_level, band_rows):
@@ -266,23 +305,13 @@ def test_me_stream_surfaces_equal_oracle_whatever_order_the_rows_arrive_in(depth
     planes = [padded(fr[0]) for fr in clip]
     prov = SD.StreamGpuProvider(depth, geo, rng, slots=3, min_level=min_level, pictures=6, band_rows=band_rows)
     L = prov.L
-    L.x265hip_me_stream_picture_rows.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-    L.x265hip_me_stream_pair_open.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64]
-    L.x265hip_me_stream_surface.restype = ctypes.c_void_p
-    L.x265hip_me_stream_surface.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    L.x265hip_me_stream_ready.restype = ctypes.c_void_p
-    L.x265hip_me_stream_ready.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    L.x265hip_me_stream_record_bytes.argtypes = [ctypes.c_void_p]
+    _stream_entries(L)
     try:
         ctus_w, ctus_h = geo["width"] // 64, geo["height"] // 64
-        nc = 2 * rng + 1
-        ng = (nc + 3) // 4
         rec = L.x265hip_me_stream_record_bytes(prov.handle)
         full = 720 if depth == 8 else 1360
         assert rec == (full if not min_level else 208 if depth == 8 else 336)
         lag = (63 + rng) // 64
-        org = geo["margin_y"] * geo["stride"] + geo["margin_x"]
-        zero = np.zeros(nc, np.uint16)
         for slot, (fi, ri, order) in enumerate([(1, 0, list(range(ctus_h))), (2, 1, [1, 0] + list(range(2, ctus_h))), (2, 0, list(range(ctus_h))[::-1])]):
             fkey, rkey = 100 + 10 * slot + fi, 200 + 10 * slot + ri
             assert L.x265hip_me_stream_picture_rows(prov.handle, fkey, planes[fi].ctypes.data, 0, ctus_h) == 0
@@ -306,24 +335,7 @@ def test_me_stream_surfaces_equal_oracle_whatever_order_the_rows_arrive_in(depth
             while not all(ready[q] == gen for q in range(ctus_h)) and time.time() - t0 < 20:
                 time.sleep(0.01)
             assert all(ready[q] == gen for q in range(ctus_h)), (list(ready), gen, prov.report())
-            surf, _ = O.me_fullsearch(depth, planes[fi], geo["stride"], org, planes[ri], geo["stride"], org, geo["width"], geo["height"], rng,
-                                      0, ctus_w * ctus_h, zero, zero, want_surf=True, want_best=False)
-            e = surf.reshape(-1, 85, 4)
-            nrec = e.shape[0]
-            raw = np.ctypeslib.as_array((ctypes.c_uint8 * (nrec * rec)).from_address(L.x265hip_me_stream_surface(prov.handle, slot))).reshape(nrec, rec)
-            def cols(v):        # [record, pu, 4] -> [motion-vector row, dx, pu]; the pad columns of a row's last group hold don't-care values
-                v = v.reshape(-1, ng, v.shape[1], 4)
-                return v.transpose(0, 1, 3, 2).reshape(v.shape[0], ng * 4, v.shape[2])[:, :nc]
-            if depth == 8:
-                tail = raw if min_level else raw[:, 512:]
-                g16 = tail[:, 0:128].copy().view(np.uint16).reshape(nrec, 16, 4)
-                g32 = tail[:, 128:208].copy().view(np.int32).reshape(nrec, 5, 4)
-                assert np.array_equal(cols(g16), cols(e[:, 64:80])) and np.array_equal(cols(g32), cols(e[:, 80:85]))
-                if not min_level:
-                    assert np.array_equal(cols(raw[:, 0:512].copy().view(np.uint16).reshape(nrec, 64, 4)), cols(e[:, 0:64]))
-            else:
-                got = raw.copy().view(np.int32).reshape(nrec, -1, 4)
-                assert np.array_equal(cols(got), cols(e[:, 64:] if min_level else e))
+            _check_stream_surfaces(O, L, prov, slot, depth, geo, rng, min_level, planes[fi], planes[ri])
         rep = prov.report()
         assert rep["failed"] == 0 and rep["pairs_completed"] == 3 and rep["rows_searched"] == 3 * ctus_h, rep
     finally:
@@ -397,3 +409,126 @@ def test_row_granular_seams_on_the_gpu_serve_under_frame_threads(depth, preset, 
     assert rep["verify_mismatches"] == 0 and sub["verify_mismatches"] == 0 and rep["failed"] == 0 and sub["failed"] == 0
     assert rep["lookups_served"] > (300 if min_level else 1500) and sub["subpel_compares_served"] > 1000, rep
     assert rep["row_stream"]["recon_rows_refused"] == 0 and rep["stale_pairs"] == 0
+
+
+# ---- round 4: WEIGHTED references through the row-granular services ----------------------------------------------------------------
+@pytest.mark.parametrize("depth,width,height,rng,min_level", [(8, 256, 256, 20, 1), (8, 192, 192, 16, 0), (10, 192, 256, 16, 1), (12, 128, 192, 12, 0)])
+def test_me_stream_weighted_pairs_search_the_plane_the_host_would_weight(depth, width, height, rng, min_level):
+    """x265hip_me_stream_pair_open_weighted: the reference picture's rows are weighted on the device with the weight_pp arguments
+    (pixel.cpp:518-543; reference.cpp:119-178 builds that plane on the host) - the pair's surfaces must equal the oracle's exhaustive
+    search in the plane weighted on the CPU, an unweighted pair of the same pictures stays what it was, and two weights of one
+    reference are two planes."""
+    from tools import seam_driver as SD
+    O = _oracle()
+    geo = SD.geometry(width, height)
+    clip = F.synth_clip(geo["width"], geo["height"], 2, depth=depth, seed=11, fade=(1.0, 0.6))
+    dt = np.uint8 if depth == 8 else np.uint16
+    def padded(y):
+        return np.ascontiguousarray(np.pad(y.reshape(geo["height"], geo["width"]).astype(dt), ((geo["margin_y"],) * 2, (geo["margin_x"],) * 2), mode="edge")).reshape(-1)
+    planes = [padded(fr[0]) for fr in clip]
+    prov = SD.StreamGpuProvider(depth, geo, rng, slots=3, min_level=min_level, pictures=6, band_rows=2)
+    L = prov.L
+    _stream_entries(L)
+    try:
+        ctus_h = geo["height"] // 64
+        corr = 14 - depth
+        weights = [(38, (1 << 5) << corr, 6 + corr, 6 << (depth - 8)), (90, (1 << 6) << corr, 7 + corr, -(3 << (depth - 8)))]
+        assert L.x265hip_me_stream_picture_rows(prov.handle, 1, planes[1].ctypes.data, 0, ctus_h) == 0
+        gens = []
+        for slot, w in enumerate([weights[0], None, weights[1]]):
+            wbuf = (ctypes.c_int * 4)(*w) if w else None
+            gens.append(L.x265hip_me_stream_pair_open_weighted(prov.handle, slot, 1, 2, wbuf))
+            assert gens[-1] > 0
+        for r in list(range(ctus_h))[::-1]:          # rows of the reference arrive after the pairs were opened, bottom up
+            assert L.x265hip_me_stream_picture_rows(prov.handle, 2, planes[0].ctypes.data, r, 1) == 0
+        for slot, w in enumerate([weights[0], None, weights[1]]):
+            ready = np.ctypeslib.as_array((ctypes.c_int32 * ctus_h).from_address(L.x265hip_me_stream_ready(prov.handle, slot)))
+            t0 = time.time()
+            while not all(ready[q] == gens[slot] for q in range(ctus_h)) and time.time() - t0 < 20:
+                time.sleep(0.01)
+            assert all(ready[q] == gens[slot] for q in range(ctus_h)), (list(ready), prov.report())
+            ref_plane = planes[0] if w is None else SD.weight_plane(planes[0], depth, w)
+            _check_stream_surfaces(O, L, prov, slot, depth, geo, rng, min_level, planes[1], ref_plane)
+        rep = prov.report()
+        assert rep["failed"] == 0 and rep["weighted_pairs"] == 2 and rep["rows_weighted"] == 2 * ctus_h and rep["rows_uploaded"] == 2 * ctus_h, rep
+        # bad arguments are refused: the same key twice, a shift without the 14 - depth correction
+        assert L.x265hip_me_stream_pair_open_weighted(prov.handle, 0, 5, 5, None) < 0
+        assert L.x265hip_me_stream_pair_open_weighted(prov.handle, 0, 1, 2, (ctypes.c_int * 4)(64, 0, corr - 1, 0)) < 0
+    finally:
+        prov.close()
+
+
+@pytest.mark.parametrize("depth,width,height", [(8, 256, 256), (10, 192, 192)])
+def test_phase_stream_weighted_view_equals_the_phase_planes_of_the_weighted_picture(depth, width, height):
+    """x265hip_phase_stream_view_open with weights: a view opened BEFORE the rows arrive and one opened after them, luma and Cb weighted,
+    Cr as reconstructed - every plane equals x265hip_phase_planes of the plane weighted on the CPU; an unweighted view of the same
+    picture beside them is untouched."""
+    import torch
+    from tools import seam_driver as SD
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    geo = SD.geometry(width, height)
+    dt = np.uint8 if depth == 8 else np.uint16
+    rng = np.random.default_rng(13 + depth)
+    src = [rng.integers(0, 1 << depth, (geo["rows"], geo["stride"])).astype(dt), rng.integers(0, 1 << depth, (geo["rows_c"], geo["stride_c"])).astype(dt),
+           rng.integers(0, 1 << depth, (geo["rows_c"], geo["stride_c"])).astype(dt)]
+    prov = SD.StreamGpuPhaseProvider(depth, geo, slots=3, pictures=2)
+    L = prov.L
+    L.x265hip_phase_stream_view_open.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint]
+    L.x265hip_phase_stream_picture_rows.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.x265hip_phase_stream_planes.restype = ctypes.c_void_p
+    L.x265hip_phase_stream_planes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.x265hip_phase_stream_progress.restype = ctypes.c_void_p
+    L.x265hip_phase_stream_progress.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    try:
+        ctu_rows = geo["height"] // 64
+        corr = 14 - depth
+        w3 = [(45, (1 << 5) << corr, 6 + corr, 4 << (depth - 8)), (70, (1 << 5) << corr, 6 + corr, -(2 << (depth - 8))), (64, 0, corr, 0)]
+        wbuf = (ctypes.c_int * 12)(*[v for w in w3 for v in w])
+        gens = {0: L.x265hip_phase_stream_view_open(prov.handle, 0, 77, wbuf, 3), 1: L.x265hip_phase_stream_view_open(prov.handle, 1, 77, None, 0)}
+        for r in range(ctu_rows):
+            assert L.x265hip_phase_stream_picture_rows(prov.handle, 77, src[0].ctypes.data, src[1].ctypes.data, src[2].ctypes.data, r, 1) == 0
+            time.sleep(0.01)
+        gens[2] = L.x265hip_phase_stream_view_open(prov.handle, 2, 77, wbuf, 1)          # after the fact, luma only
+        assert all(g > 0 for g in gens.values())
+        masks = {0: 3, 1: 0, 2: 1}
+        for slot in (0, 1, 2):
+            prog = np.ctypeslib.as_array((ctypes.c_uint64 * 2).from_address(L.x265hip_phase_stream_progress(prov.handle, slot)))
+            want = [(gens[slot] << 32) | (geo["rows"] - 8), (gens[slot] << 32) | (geo["rows_c"] - 8)]
+            t0 = time.time()
+            while (int(prog[0]) != want[0] or int(prog[1]) != want[1]) and time.time() - t0 < 20:
+                time.sleep(0.01)
+            assert [int(prog[0]), int(prog[1])] == want, prov.report()
+            for pl in range(3):
+                k = min(pl, 1)
+                rows, stride, nph = (geo["rows"], geo["stride"], 15) if k == 0 else (geo["rows_c"], geo["stride_c"], 63)
+                n = nph * rows * stride
+                got = np.ctypeslib.as_array((ctypes.c_uint8 * (n * dt().itemsize)).from_address(L.x265hip_phase_stream_planes(prov.handle, slot, pl))).view(dt).reshape(nph, rows, stride)
+                plane = SD.weight_plane(src[pl], depth, w3[pl]) if (masks[slot] >> pl) & 1 else src[pl]
+                dev = torch.device("cuda:0")
+                tsrc = torch.from_numpy(np.ascontiguousarray(plane).view(np.int16 if depth > 8 else np.uint8)).to(dev)
+                tdst = torch.zeros(n, dtype=tsrc.dtype, device=dev)
+                A.phase_planes(depth, tsrc, 0, tdst, stride, rows, chroma=bool(k))
+                torch.cuda.synchronize()
+                exp = tdst.cpu().numpy().view(dt).reshape(nph, rows, stride)
+                assert np.array_equal(got[:, 4:rows - 8, 8:stride - 8], exp[:, 4:rows - 8, 8:stride - 8]), (slot, pl)
+        rep = prov.report()
+        assert rep["failed"] == 0 and rep["completed"] == 3 and rep["weighted_views"] == 2, rep
+    finally:
+        prov.close()
+
+
+@pytest.mark.parametrize("depth,preset,ft,min_level,extra", [(8, "slow", 3, 1, [("me", "star"), ("bframes", "0")]), (8, "medium", 3, 0, [("weightb", None)]),
+                                                             (10, "medium", 2, 1, [("bframes", "0")]), (8, "slower", 2, 1, [])])
+def test_row_granular_seams_on_the_gpu_serve_weighted_references_on_a_fade(depth, preset, ft, min_level, extra):
+    """The real encoder with --weightp / --weightb at their defaults on a luma fade, x265hip_me_stream + x265hip_phase_stream weighting the
+    reconstructed rows on the device: byte-identical, every SAD lookup and sub-sample comparison on a weighted reference re-evaluated
+    in flight by the reference's own function on the host's weighted plane (round-3 verdict, next 1)."""
+    import test_seam_cpu as T
+    opts = [("pools", "4"), ("frame-threads", str(ft)), ("crf", "24")] + extra
+    base, got, rep = T.run_fade_pair(depth, 256, 192, 10, preset, opts, "gpu", rng=20, wait=True, min_level=min_level, subpel="gpu", slots=32, subpel_slots=16)
+    assert got[0] == base[0], f"seam changed the bitstream: {rep}"
+    sub, wr = rep["subpel_seam"], rep["weighted_references"]
+    assert rep["verify"] == 1 and rep["verify_mismatches"] == 0 and sub["verify_mismatches"] == 0 and rep["failed"] == 0 and sub["failed"] == 0
+    assert wr["pairs_opened_on_weighted_references"] >= 1 and wr["lookups_served_on_weighted_references"] > 200, rep
+    assert wr["phase_views_opened_on_weighted_references"] >= 1 and wr["subpel_compares_served_from_weighted_views"] > 500, rep
+    assert rep["weighted_pairs"] >= 1 and rep["rows_weighted"] >= 3 and sub["weighted_views"] >= 1, rep

@@ -169,3 +169,75 @@ def test_row_granular_seams_with_all_defaults_and_the_lookahead_seam():
     assert rep["verify_mismatches"] == 0 and rep["subpel_seam"]["verify_mismatches"] == 0
     assert rep["lookups_served"] > 300 and rep["subpel_seam"]["subpel_compares_served"] > 1000
     assert rep["lookahead_seam"]["frame_cost_estimates_served"] > 10
+
+
+# ---- round 4: WEIGHTED references through the row-granular providers (x265's default --weightp / --weightb) ------------------------
+def run_fade_pair(depth, w, h, nframes, preset, opts, provider, rng, fade=(1.0, 0.35), **kw):
+    EB, SD = _tools()
+    try:
+        plain = EB.ref_lib(depth)
+        SD.seam_lib(depth)
+    except (SystemExit, FileNotFoundError):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    clip = F.synth_clip(w, h, nframes, depth=depth, seed=41, fade=fade)
+    yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
+    base = EB.encode(plain, yuv, w, h, nframes, preset, opts)
+    lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, verify=True, streamed=True, **kw)
+    try:
+        got = EB.encode(lib, yuv, w, h, nframes, preset, opts, filler)
+        rep = report()
+    finally:
+        close()
+    return base, got, rep
+
+
+@pytest.mark.reference
+def test_weight_plane_twin_equals_the_reference_weight_pp():
+    """tools/seam_driver.weight_plane (the CPU providers' weighting) against the real primitives.weight_pp of oracle/_ref."""
+    _, SD = _tools()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as H
+    rng = np.random.default_rng(5)
+    for depth in (8, 10, 12):
+        try:
+            ref = H.load_reference(depth, ROOT)
+        except Exception:
+            ref = None
+        if ref is None:
+            pytest.skip("oracle/_ref not built (needs /root/reference)")
+        w, h, st = 64, 16, 80
+        src = H.pixels(rng, "random", depth, w, h, st)
+        for w0, denom, off in ((37, 6, -3), (64, 6, 0), (90, 7, 5), (1, 0, -20), (127, 5, 12)):
+            corr = 14 - depth
+            args = (w0, (1 << (denom - 1) if denom else 0) << corr, denom + corr, off * (1 << (depth - 8)))
+            d = H.out2d(w, h, st, H.pix_dtype(depth), 0x33)
+            ref.fn("weight_pp")(src.p, d.p, st, w, h, *args)
+            blk = lambda b: b.data[b.org:b.org + h * st].reshape(h, st)[:, :w]
+            assert np.array_equal(SD.weight_plane(blk(src), depth, args), blk(d)), (depth, w0, denom, off)
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("depth,preset,ft,min_level,extra", [(8, "slow", 3, 1, [("me", "star"), ("bframes", "0")]), (8, "medium", 3, 0, [("weightb", None)]),
+                                                             (10, "medium", 2, 1, [("bframes", "0")]), (8, "slower", 2, 0, [("weightb", None)]),
+                                                             (8, "medium", 1, 0, [("bframes", "0")]), (8, "slow", 3, 1, [("me", "star")])])
+def test_row_granular_seams_serve_weighted_references_on_a_fade(depth, preset, ft, min_level, extra):
+    """A luma fade with --weightp / --weightb at their defaults (ON): the slices search MotionReference's weighted planes
+    (reference.cpp:119-178).  The providers weight the reconstructed rows themselves; every SAD lookup and every sub-sample comparison
+    on a weighted reference is re-evaluated by the reference's own function on the host's weighted plane (verify), byte-identical."""
+    opts = [("pools", "4"), ("frame-threads", str(ft)), ("crf", "24")] + extra
+    base, got, rep = run_fade_pair(depth, 256, 192, 10, preset, opts, "oracle", rng=20, min_level=min_level, slots=32, subpel="oracle", subpel_slots=16)
+    assert got[0] == base[0], f"seam changed the bitstream: {rep}"
+    wr = rep["weighted_references"]
+    assert rep["verify"] == 1 and rep["verify_mismatches"] == 0 and rep["subpel_seam"]["verify_mismatches"] == 0
+    assert wr["pairs_opened_on_weighted_references"] >= 1 and wr["lookups_served_on_weighted_references"] > 200, rep
+    assert wr["phase_views_opened_on_weighted_references"] >= 1 and wr["subpel_compares_served_from_weighted_views"] > 500, rep
+    assert rep["foreign_geometry"] == 0
+
+
+@pytest.mark.reference
+def test_weighted_references_pass_when_the_provider_has_no_weighted_entry():
+    """weighted=False (a provider without x265hip_me_stream_pair_open_weighted): weighted references go to the host, the rest is served."""
+    opts = [("pools", "4"), ("frame-threads", "3"), ("crf", "24")]
+    base, got, rep = run_fade_pair(8, 256, 192, 8, "medium", opts, "oracle", rng=20, slots=32, weighted=False)
+    assert got[0] == base[0]
+    assert rep["weighted_references"]["pairs_opened_on_weighted_references"] == 0 and rep["verify_mismatches"] == 0

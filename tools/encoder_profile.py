@@ -22,16 +22,33 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the picture (the 8-vCPU container cannot do 4K in reasonable time)")
+    ap.add_argument("--frame-threads", type=int, default=1)
+    ap.add_argument("--seams", action="store_true", help="profile the encode WITH the row-granular seams in place (libx265hip.so providers: needs the GPU): "
+                    "the lookup stubs sit over the counting thunks, so what the families show is the host work that REMAINS")
+    ap.add_argument("--seam-range", type=int, default=24)
+    ap.add_argument("--seam-min-level", type=int, default=1)
+    ap.add_argument("--seam-min-pu", type=int, default=16)
+    ap.add_argument("--no-lookahead-seam", action="store_true")
+    ap.add_argument("--provider", default="gpu", choices=["gpu", "oracle"], help="oracle = the CPU checker providers (plumbing test of this tool without a GPU)")
     a = ap.parse_args()
     F = importlib.import_module("x265-yuuki-asuna_amd.frames")
     cfg = EB.CONFIGS[a.config]
     w, h, depth = int(cfg["width"] * a.scale) // 16 * 16, int(cfg["height"] * a.scale) // 16 * 16, cfg["depth"]
-    clip = F.synth_clip(w, h, a.frames, depth=depth, seed=265)
+    clip = F.synth_clip(w, h, a.frames, depth=depth, seed=265, fade=cfg.get("fade"))
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
     lib = EB.ref_lib(depth)
     cores = EB.effective_cpus()
-    opts = [("pools", str(cores)), ("frame-threads", "1"), ("crf", "28")] + cfg["opts"]
+    opts = [("pools", str(cores)), ("frame-threads", str(a.frame_threads)), ("crf", "28")] + cfg["opts"]
     filler = ctypes.cast(lib.x265ref_profile_fill_table, ctypes.c_void_p)
+    note = closer = None
+    if a.seams:
+        from tools import seam_driver as SD
+        if not a.no_lookahead_seam:
+            opts.append(("lookahead-slices", "1"))
+        lib, _, note, closer, _ = SD.install(depth, w, h, provider=a.provider, rng=a.seam_range, slots=24 if depth == 8 else 40, min_pu=a.seam_min_pu, verify=False,
+                                             lookahead=None if a.no_lookahead_seam else a.provider, subpel=a.provider, subpel_slots=12, streamed=True,
+                                             min_level=a.seam_min_level, pictures=24)
+        filler = ctypes.cast(lib.x265ref_seam_fill_table_profiled, ctypes.c_void_p)
     lib.x265ref_profile_tsc.restype = ctypes.c_uint64
     t0, c0, tsc0 = time.perf_counter(), time.process_time(), lib.x265ref_profile_tsc()
     md5, nbytes, sec, filled = EB.encode(lib, yuv, w, h, a.frames, cfg["preset"], opts, filler)
@@ -50,6 +67,18 @@ def main():
             print(f"  {name:44s} {s:8.3f} {100 * s / cpu:8.1f}% {c:12d} {1e9 * s / c:9.0f}")
     print(f"  {'(all wrapped primitives)':44s} {inside:8.3f} {100 * inside / cpu:8.1f}%")
     print(f"  {'(encoder code outside the table)':44s} {cpu - inside:8.3f} {100 * (cpu - inside) / cpu:8.1f}%")
+    if a.seams:
+        st = (ctypes.c_uint64 * 8)()
+        lib.x265ref_seam_profile_report.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+        lib.x265ref_seam_profile_report(st)
+        print("# stages of oracle/ref_seam.cpp, whole (the primitives they call are ALSO in the families above; process CPU includes the providers' worker threads)")
+        for i, name in enumerate(("MotionEstimate::motionEstimate (integer search on lookups + sub-sample refinement)", "MotionEstimate::subpelCompare (inside motionEstimate)",
+                                  "CostEstimateGroup::estimateFrameCost (waits for x265hip_lowres_cost_host)", "row hand-over in FrameFilter::processPostRow (memcpy into pinned staging)")):
+            s_, c_ = st[2 * i] / hz, int(st[2 * i + 1])
+            if c_:
+                print(f"  {name:100s} {s_:8.3f} s {100 * s_ / cpu:6.1f}% of CPU {c_:10d} calls {1e9 * s_ / c_:9.0f} ns/call")
+        print("# seam report: " + json.dumps(note()))
+        closer()
 
 
 if __name__ == "__main__":

@@ -261,8 +261,25 @@ class GpuPhaseProvider:
 # (FrameFilter::processPostRow) feeds them reconstructed CTU rows, so they serve under any --frame-threads.
 PIC_ROWS = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
 PAIR_OPEN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64)
-PS_OPEN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
-PS_ROWS = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
+PAIR_OPEN_W = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p)
+PS_OPEN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint)
+PS_ROWS = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
+WEIGHTED_STAT_NAMES = ("pairs_opened_on_weighted_references", "motion_estimate_calls_with_context_on_weighted_references", "lookups_served_on_weighted_references",
+                       "phase_views_opened_on_weighted_references", "subpel_compares_served_from_weighted_views")
+
+
+def weight_plane(plane, depth, w):
+    """primitives.weight_pp (common/pixel.cpp:518-543) sample by sample; w = (w0, round, shift, offset) with the 14 - depth correction
+    already in round and shift - what reference.cpp:154 passes.  Checker-side twin of the providers' device kernels."""
+    w0, rnd, shift, off = w
+    val = (plane.astype(np.int32) << (14 - depth)).astype(np.int16).astype(np.int32)
+    return np.clip(((w0 * val + rnd) >> shift) + off, 0, (1 << depth) - 1).astype(plane.dtype)
+
+
+def read_weights(ptr, n):
+    """n x265hip_weight structs at ptr -> list of (w0, round, shift, offset)"""
+    raw = (ctypes.c_int * (4 * n)).from_address(ptr)
+    return [tuple(int(raw[4 * i + k]) for k in range(4)) for i in range(n)]
 PS_PROGRESS = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
 STREAM_STAT_NAMES = ("recon_rows_to_sad_provider", "recon_rows_refused", "recon_rows_to_phase_provider", "lookups_dropped_slot_reopened")
 
@@ -294,7 +311,8 @@ class StreamOracleProvider:
         self.format = SURF_I32
         self.bands = self.rows_in = 0
         self.lock = threading.Lock()
-        self._cb = (PIC_ROWS(self._picture_rows), PAIR_OPEN(self._pair_open), SURFACE(self._surface), READY(self._ready))
+        self.weighted_pairs = 0
+        self._cb = (PIC_ROWS(self._picture_rows), PAIR_OPEN(self._pair_open), PAIR_OPEN_W(self._pair_open_w), SURFACE(self._surface), READY(self._ready))
 
     def _lines(self, r0, n):
         g = self.geo
@@ -321,10 +339,14 @@ class StreamOracleProvider:
         return 0
 
     def _pair_open(self, ctx, slot, fkey, rkey):
+        return self._pair_open_w(ctx, slot, fkey, rkey, None)
+
+    def _pair_open_w(self, ctx, slot, fkey, rkey, wptr):
         with self.lock:
             self.gen[slot] += 1
             self.flags[slot][:] = 0
-            self.pair[slot] = {"f": int(fkey), "r": int(rkey), "gen": self.gen[slot], "next": 0}
+            self.pair[slot] = {"f": int(fkey), "r": int(rkey), "gen": self.gen[slot], "next": 0, "w": read_weights(wptr, 1)[0] if wptr else None}
+            self.weighted_pairs += bool(wptr)
             self._advance()
             return self.gen[slot]
 
@@ -342,7 +364,8 @@ class StreamOracleProvider:
                 continue
             n = r1 - r0
             off = self.org + r0 * 64 * g["stride"]
-            surf, _ = self.O.me_fullsearch(self.depth, pf["plane"], g["stride"], off, pr["plane"], g["stride"], off, g["width"], n * 64, self.range,
+            ref_plane = pr["plane"] if q["w"] is None else weight_plane(pr["plane"], self.depth, q["w"])      # rows not there yet weight to garbage nobody reads
+            surf, _ = self.O.me_fullsearch(self.depth, pf["plane"], g["stride"], off, ref_plane, g["stride"], off, g["width"], n * 64, self.range,
                                            0, self.ctus_w * n, zero, zero, want_surf=True, want_best=False)
             recs = surf.reshape(-1, 85, 4)
             if self.min_level:
@@ -362,7 +385,7 @@ class StreamOracleProvider:
         return (None,) + tuple(ctypes.cast(c, ctypes.c_void_p) for c in self._cb)
 
     def report(self):
-        return {"provider": "oracle, row-granular (CPU checker)", "bands": self.bands, "rows_in": self.rows_in}
+        return {"provider": "oracle, row-granular (CPU checker)", "bands": self.bands, "rows_in": self.rows_in, "weighted_pairs": self.weighted_pairs}
 
     def close(self):
         pass
@@ -377,7 +400,7 @@ class StreamParams(ctypes.Structure):
 
 class StreamStats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in ("pairs_opened", "pairs_completed", "bands", "rows_searched", "rows_uploaded", "failed", "stale_pairs",
-                                               "us_busy", "bytes_downloaded", "bytes_uploaded", "surface_bytes")]
+                                               "us_busy", "bytes_downloaded", "bytes_uploaded", "surface_bytes", "rows_weighted", "weighted_pairs")]
 
 
 class StreamGpuProvider:
@@ -399,7 +422,8 @@ class StreamGpuProvider:
     def pointers(self):
         L = self.L
         return (self.handle,) + tuple(ctypes.cast(f, ctypes.c_void_p) for f in (L.x265hip_me_stream_picture_rows, L.x265hip_me_stream_pair_open,
-                                                                                  L.x265hip_me_stream_surface, L.x265hip_me_stream_ready))
+                                                                                  L.x265hip_me_stream_pair_open_weighted, L.x265hip_me_stream_surface,
+                                                                                  L.x265hip_me_stream_ready))
 
     def report(self):
         st = StreamStats()
@@ -418,7 +442,8 @@ class StreamGpuProvider:
 
 
 class StreamOraclePhaseProvider:
-    """CPU stand-in for x265hip_phase_stream (checker only): the oracle's phase planes, grown line by line as rows arrive."""
+    """CPU stand-in for x265hip_phase_stream (checker only): pictures arrive row by row under a key; a slot is a VIEW of one picture,
+    optionally weighted plane by plane before the interpolation; the oracle's phase planes grow line by line as rows arrive."""
 
     def __init__(self, depth, geo, slots):
         import threading
@@ -429,56 +454,77 @@ class StreamOraclePhaseProvider:
         g = geo
         self.ctu_rows = g["height"] // 64
         self.dims = [(g["rows"], g["stride"], g["margin_y"], 64, 15), (g["rows_c"], g["stride_c"], g["margin_y"] >> 1, 32, 63)]
-        self.src = [[np.zeros((self.dims[min(k, 1)][0], self.dims[min(k, 1)][1]), self.dt) for k in range(3)] for _ in range(slots)]
+        self.pics = {}                           # key -> dict(src [3 planes], staged, next)
         self.out = [[np.zeros((self.dims[min(k, 1)][4], self.dims[min(k, 1)][0], self.dims[min(k, 1)][1]), self.dt) for k in range(3)] for _ in range(slots)]
         self.progress = [np.zeros(2, np.uint64) for _ in range(slots)]
-        self.state = [None] * slots
+        self.view = [None] * slots               # dict(key, gen, w [3] or None per plane, seen, done)
         self.gen = [0] * slots
-        self.opened = self.bands = 0
+        self.opened = self.bands = self.weighted_views = 0
         self.lock = threading.Lock()
         self._cb = (PS_OPEN(self._open), PS_ROWS(self._rows), PH_PLANES(self._planes), PS_PROGRESS(self._progress))
 
-    def _open(self, ctx, slot):
+    def _pic(self, key):
+        if key not in self.pics:
+            if len(self.pics) > 48:              # drop the oldest pictures no view is fed from
+                live = {v["key"] for v in self.view if v} | {key}
+                for k in list(self.pics):
+                    if k not in live and len(self.pics) > 32:
+                        del self.pics[k]
+            self.pics[key] = {"src": [np.zeros((self.dims[min(k, 1)][0], self.dims[min(k, 1)][1]), self.dt) for k in range(3)], "staged": set(), "next": 0}
+        return self.pics[key]
+
+    def _open(self, ctx, slot, key, wptr, mask):
         with self.lock:
             self.gen[slot] += 1
             self.progress[slot][:] = 0
-            self.state[slot] = {"staged": set(), "next": 0, "done": [8, 8]}
+            w3 = read_weights(wptr, 3) if wptr and mask else [None] * 3
+            self.view[slot] = {"key": int(key), "w": [w3[c] if (mask >> c) & 1 else None for c in range(3)], "seen": 0, "done": [8, 8]}
             self.opened += 1
+            self.weighted_views += bool(wptr and mask)
+            self._pic(int(key))
+            self._advance()
             return self.gen[slot]
 
-    def _rows(self, ctx, slot, gen, luma, cb, cr, r0, n):
+    def _rows(self, ctx, key, luma, cb, cr, r0, n):
         with self.lock:
-            if gen != self.gen[slot]:
-                return -4
-            st = self.state[slot]
+            pic = self._pic(int(key))
             es = np.dtype(self.dt).itemsize
             for pl, ptr in enumerate((luma, cb, cr)):
                 rows, stride, margin, cl, _ = self.dims[min(pl, 1)]
                 y0 = 0 if r0 == 0 else margin + r0 * cl
                 y1 = rows if r0 + n == self.ctu_rows else margin + (r0 + n) * cl
                 raw = (ctypes.c_uint8 * ((y1 - y0) * stride * es)).from_address(ptr + y0 * stride * es)
-                self.src[slot][pl][y0:y1] = np.frombuffer(raw, dtype=self.dt).reshape(y1 - y0, stride)
-            st["staged"].update(range(r0, r0 + n))
-            r1 = st["next"]
-            while r1 in st["staged"]:
-                r1 += 1
-            if r1 == st["next"]:
-                return 0
-            st["next"] = r1
+                pic["src"][pl][y0:y1] = np.frombuffer(raw, dtype=self.dt).reshape(y1 - y0, stride)
+            pic["staged"].update(range(r0, r0 + n))
+            while pic["next"] in pic["staged"]:
+                pic["next"] += 1
+            self._advance()
+        return 0
+
+    def _advance(self):
+        for slot, v in enumerate(self.view):
+            if not v or v["key"] not in self.pics:
+                continue
+            pic = self.pics[v["key"]]
+            r1 = pic["next"]
+            if r1 <= v["seen"]:
+                continue
+            v["seen"] = r1
             for k in range(2):
                 rows, stride, margin, cl, nph = self.dims[k]
                 y1 = rows if r1 == self.ctu_rows else margin + r1 * cl
-                b0, b1 = st["done"][k], y1 - 8
+                b0, b1 = v["done"][k], y1 - 8
                 if b1 - b0 < 8:
                     continue
                 for pl in ((0,) if k == 0 else (1, 2)):
-                    band = self.src[slot][pl][b0 - 8:b1 + 8]
-                    ph = self.O.phase_planes(self.depth, band, stride, band.shape[0], chroma=bool(k))
+                    band = pic["src"][pl][b0 - 8:b1 + 8]
+                    if v["w"][pl] is not None:
+                        band = weight_plane(band, self.depth, v["w"][pl])
+                    ph = self.O.phase_planes(self.depth, np.ascontiguousarray(band), stride, band.shape[0], chroma=bool(k))
                     self.out[slot][pl][:, b0:b1] = ph[:, 8:band.shape[0] - 8]
-                st["done"][k] = b1
+                v["done"][k] = b1
                 self.progress[slot][k] = (self.gen[slot] << 32) | b1
             self.bands += 1
-        return 0
 
     def _planes(self, ctx, slot, plane):
         return self.out[slot][plane].ctypes.data
@@ -490,7 +536,7 @@ class StreamOraclePhaseProvider:
         return (None,) + tuple(ctypes.cast(c, ctypes.c_void_p) for c in self._cb)
 
     def report(self):
-        return {"provider": "oracle, row-granular (CPU checker)", "pictures_opened": self.opened, "bands": self.bands}
+        return {"provider": "oracle, row-granular (CPU checker)", "views_opened": self.opened, "bands": self.bands, "weighted_views": self.weighted_views}
 
     def close(self):
         pass
@@ -499,20 +545,23 @@ class StreamOraclePhaseProvider:
 class PhaseStreamParams(ctypes.Structure):
     """x265hip_phase_stream_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("stride", ctypes.c_ssize_t), ("rows", ctypes.c_int), ("margin_y", ctypes.c_int),
-                ("stride_c", ctypes.c_ssize_t), ("rows_c", ctypes.c_int), ("margin_y_c", ctypes.c_int), ("ctu_rows", ctypes.c_int), ("slots", ctypes.c_int)]
+                ("stride_c", ctypes.c_ssize_t), ("rows_c", ctypes.c_int), ("margin_y_c", ctypes.c_int), ("ctu_rows", ctypes.c_int), ("slots", ctypes.c_int),
+                ("pictures", ctypes.c_int)]
 
 
 class PhaseStreamStats(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_uint64) for n in ("opened", "completed", "bands", "failed", "us_busy", "bytes_downloaded", "bytes_uploaded", "bytes_per_picture")]
+    _fields_ = [(n, ctypes.c_uint64) for n in ("opened", "completed", "bands", "failed", "us_busy", "bytes_downloaded", "bytes_uploaded", "bytes_per_picture",
+                                               "weighted_views", "lines_weighted")]
 
 
 class StreamGpuPhaseProvider:
     """libx265hip.so's x265hip_phase_stream: the product path under frame threads."""
 
-    def __init__(self, depth, geo, slots):
+    def __init__(self, depth, geo, slots, pictures=0):
         A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
         self.L = L = A.lib()
-        p = PhaseStreamParams(depth, geo["stride"], geo["rows"], geo["margin_y"], geo["stride_c"], geo["rows_c"], geo["margin_y"] >> 1, geo["height"] // 64, slots)
+        p = PhaseStreamParams(depth, geo["stride"], geo["rows"], geo["margin_y"], geo["stride_c"], geo["rows_c"], geo["margin_y"] >> 1, geo["height"] // 64, slots,
+                              pictures)
         self.handle = ctypes.c_void_p()
         L.x265hip_phase_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(PhaseStreamParams)]
         A.check(L.x265hip_phase_stream_create(ctypes.byref(self.handle), ctypes.byref(p)), "x265hip_phase_stream_create")
@@ -521,14 +570,15 @@ class StreamGpuPhaseProvider:
 
     def pointers(self):
         L = self.L
-        return (self.handle,) + tuple(ctypes.cast(f, ctypes.c_void_p) for f in (L.x265hip_phase_stream_open, L.x265hip_phase_stream_rows,
+        return (self.handle,) + tuple(ctypes.cast(f, ctypes.c_void_p) for f in (L.x265hip_phase_stream_view_open, L.x265hip_phase_stream_picture_rows,
                                                                                   L.x265hip_phase_stream_planes, L.x265hip_phase_stream_progress))
 
     def report(self):
         st = PhaseStreamStats()
         self.L.x265hip_phase_stream_stats(self.handle, ctypes.byref(st))
         d = {n: int(getattr(st, n)) for n, _ in PhaseStreamStats._fields_}
-        d["provider"] = "x265hip_phase_stream (phase planes grown line by line behind the reconstruction, one band per published CTU row)"
+        d["provider"] = ("x265hip_phase_stream (a view per (reference picture, weights) opened by the first search that refers to it; its phase planes grow "
+                         "line by line behind the reconstruction)")
         d["mbytes_per_picture"] = round(st.bytes_per_picture / 1e6, 1)
         d["worker_busy_ms"] = round(st.us_busy / 1e3, 1)
         d["download_gbytes_per_s_while_busy"] = round(st.bytes_downloaded / max(1, st.us_busy) / 1e3, 2)
@@ -541,7 +591,7 @@ class StreamGpuPhaseProvider:
 
 
 def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
-            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0):
+            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True):
     """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
     the picture-granular providers need --frame-threads 1, streamed=True (row-granular providers) serves under any --frame-threads."""
     lib = seam_lib(depth)
@@ -549,9 +599,10 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     if streamed:
         prov = (StreamGpuProvider(depth, geo, rng, slots, min_level, pictures, band_rows) if provider == "gpu"
                 else StreamOracleProvider(depth, geo, rng, slots, min_level))
-        ctx, pic_rows, pair_open, surface, ready = prov.pointers()
-        lib.x265ref_seam_configure_streamed.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_ssize_t] + [ctypes.c_int] * 4
-        rc = lib.x265ref_seam_configure_streamed(ctx, pic_rows, pair_open, surface, ready, rng, prov.format, min_level, slots, geo["width"], geo["height"],
+        ctx, pic_rows, pair_open, pair_open_w, surface, ready = prov.pointers()
+        lib.x265ref_seam_configure_streamed.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 6 + [ctypes.c_ssize_t] + [ctypes.c_int] * 4
+        rc = lib.x265ref_seam_configure_streamed(ctx, pic_rows, pair_open, pair_open_w if weighted else None, surface, ready, rng, prov.format, min_level, slots,
+                                                 geo["width"], geo["height"],
                                                  geo["stride"], geo["margin_x"], geo["margin_y"], min_pu, int(bool(verify)) | (2 if wait else 0))
     else:
         prov = GpuProvider(depth, geo, rng, slots, surf_format) if provider == "gpu" else OracleProvider(depth, geo, rng, slots)
@@ -613,6 +664,10 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
             lib.x265ref_seam_stream_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
             lib.x265ref_seam_stream_stats(so4)
             d["row_stream"] = dict(zip(STREAM_STAT_NAMES, [int(v) for v in so4]))
+            so5 = (ctypes.c_uint64 * 5)()
+            lib.x265ref_seam_weighted_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+            lib.x265ref_seam_weighted_stats(so5)
+            d["weighted_references"] = dict(zip(WEIGHTED_STAT_NAMES, [int(v) for v in so5]))
         la = (ctypes.c_uint64 * 4)()
         lib.x265ref_lookahead_seam_stats(la)
         lib.x265ref_lookahead_seam_mismatches.restype = ctypes.c_uint64

@@ -47,6 +47,29 @@ __global__ void surf_tail_kernel(const uint4* __restrict__ in, uint4* __restrict
     }
 }
 
+// primitives.weight_pp (common/pixel.cpp:518-543) over whole buffer lines, margins included: the plane MotionReference::applyWeight
+// builds row by row (encoder/reference.cpp:119-178: weight_pp on the picture, then the borders replicated) is the reconstructed
+// plane weighted sample by sample - a replicated border sample weights to the replicated weighted sample.
+template <typename Px>
+__global__ void __launch_bounds__(256) weight_lines_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t ndw, int w0, int round, int shift, int offset,
+                                                           int correction, int maxVal)
+{
+    constexpr int PER = 4 / (int)sizeof(Px), BITS = 8 * (int)sizeof(Px);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndw; i += (size_t)gridDim.x * blockDim.x)
+    {
+        const uint32_t v = src[i];
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++)
+        {
+            const int px = (int)((v >> (k * BITS)) & ((1u << BITS) - 1));
+            const int val = (int)(int16_t)(px << correction);                       // "simulating pixel to short conversion" (pixel.cpp:535)
+            o |= (uint32_t)clip3(0, maxVal, ((w0 * val + round) >> shift) + offset) << (k * BITS);
+        }
+        dst[i] = o;
+    }
+}
+
 double ms_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 enum { ROW_NONE = 0, ROW_STAGED = 1, ROW_ON_DEVICE = 2 };
@@ -66,6 +89,8 @@ struct x265hip_me_stream
         uint8_t* stage = nullptr;           // pinned copy, rows staged by the host threads
         uint8_t* dev = nullptr;
         std::vector<uint8_t> rows;          // per CTU row: ROW_*
+        // a DERIVED picture = picture `parent` weighted on the device (x265hip_me_stream_pair_open_weighted): no key, no staging use
+        bool derived = false; int parent = -1; uint32_t parentEpoch = 0; x265hip_weight w = { 0, 0, 0, 0 };
     };
     struct Slot
     {
@@ -84,7 +109,7 @@ struct x265hip_me_stream
     uint64_t clock = 0;
     std::thread worker;
     std::atomic<uint64_t> bands{0}, rowsSearched{0}, rowsUploaded{0}, pairsOpened{0}, pairsCompleted{0}, failed{0}, noPicture{0};
-    std::atomic<uint64_t> usBusy{0}, bytesDown{0}, bytesUp{0};
+    std::atomic<uint64_t> usBusy{0}, bytesDown{0}, bytesUp{0}, rowsWeighted{0}, weightedPairs{0};
     char workerError[256] = "";
 };
 
@@ -101,8 +126,9 @@ inline void row_lines(const S* s, int r0, int n, long& y0, long& y1)
 
 struct Band { int slot, gen, r0, r1; };
 struct Upload { int pic, r0, n; };
+struct Weigh { int pic, parent, r0, n; };
 
-int run_round(S* s, const std::vector<Upload>& ups, const std::vector<Band>& bands)
+int run_round(S* s, const std::vector<Upload>& ups, const std::vector<Weigh>& weighs, const std::vector<Band>& bands)
 {
     X265HIP_TRY(hipSetDevice(s->device));
     for (const Upload& u : ups)
@@ -112,6 +138,22 @@ int run_round(S* s, const std::vector<Upload>& ups, const std::vector<Band>& ban
         const size_t off = (size_t)y0 * s->linePitch, bytes = (size_t)(y1 - y0) * s->linePitch;
         X265HIP_TRY(hipMemcpyAsync(s->pics[u.pic].dev + off, s->pics[u.pic].stage + off, bytes, hipMemcpyHostToDevice, s->compute));
         s->bytesUp += bytes; s->rowsUploaded += u.n;
+    }
+    for (const Weigh& q : weighs)
+    {
+        long y0, y1;
+        row_lines(s, q.r0, q.n, y0, y1);
+        const size_t off = (size_t)y0 * s->linePitch, ndw = (size_t)(y1 - y0) * s->linePitch / 4;
+        const x265hip_weight& w = s->pics[q.pic].w;
+        const int correction = 14 - s->prm.depth, maxVal = (1 << s->prm.depth) - 1;
+        size_t blocks = (ndw + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        const uint32_t* src = (const uint32_t*)(s->pics[q.parent].dev + off);
+        uint32_t* dst = (uint32_t*)(s->pics[q.pic].dev + off);
+        if (s->bpp == 1) hipLaunchKernelGGL(weight_lines_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, s->compute, src, dst, ndw, w.w0, w.round, w.shift, w.offset, correction, maxVal);
+        else hipLaunchKernelGGL(weight_lines_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s->compute, src, dst, ndw, w.w0, w.round, w.shift, w.offset, correction, maxVal);
+        X265HIP_TRY(hipGetLastError());
+        s->rowsWeighted += q.n;
     }
     const size_t org = ((size_t)s->prm.margin_y * s->prm.stride + s->prm.margin_x) * s->bpp;
     for (const Band& b : bands)
@@ -164,6 +206,7 @@ void worker_main(S* s)
     for (;;)
     {
         std::vector<Upload> ups;
+        std::vector<Weigh> weighs;
         std::vector<Band> bands;
         {
             std::unique_lock<std::mutex> lk(s->mu);
@@ -183,12 +226,33 @@ void worker_main(S* s)
                     r = e;
                 }
             }
+            // derived pictures an open pair reads: weight the rows of their parent that are on the device (or on their way: stream order)
+            for (int i = 0; i < (int)s->pics.size(); i++)
+            {
+                S::Pic& pd = s->pics[i];
+                if (!pd.used || !pd.derived) continue;
+                const S::Pic& pp = s->pics[pd.parent];
+                if (!pp.used || pp.epoch != pd.parentEpoch) continue;                     // the parent went away: pairs on pd go stale below
+                bool wanted = false;
+                for (const auto& sl : s->slots) wanted |= sl.active && sl.ref == i && sl.refEpoch == pd.epoch;
+                if (!wanted) continue;
+                for (int r = 0; r < s->ctusH;)
+                {
+                    if (pd.rows[r] == ROW_ON_DEVICE || pp.rows[r] != ROW_ON_DEVICE) { r++; continue; }
+                    int e = r;
+                    while (e < s->ctusH && pd.rows[e] != ROW_ON_DEVICE && pp.rows[e] == ROW_ON_DEVICE) pd.rows[e++] = ROW_ON_DEVICE;
+                    weighs.push_back({ i, pd.parent, r, e - r });
+                    r = e;
+                }
+            }
             for (int i = 0; i < (int)s->slots.size(); i++)
             {
                 S::Slot& sl = s->slots[i];
                 if (!sl.active) continue;
                 const S::Pic& pf = s->pics[sl.fenc]; const S::Pic& pr = s->pics[sl.ref];
-                if (!pf.used || !pr.used || pf.epoch != sl.fencEpoch || pr.epoch != sl.refEpoch) { sl.active = false; s->noPicture++; continue; }
+                bool gone = !pf.used || !pr.used || pf.epoch != sl.fencEpoch || pr.epoch != sl.refEpoch;
+                if (!gone && pr.derived) gone = !s->pics[pr.parent].used || s->pics[pr.parent].epoch != pr.parentEpoch;
+                if (gone) { sl.active = false; s->noPicture++; continue; }
                 int r1 = sl.nextRow - 1;
                 while (r1 + 1 < s->ctusH && r1 + 1 - sl.nextRow < s->bandRows)
                 {
@@ -206,9 +270,9 @@ void worker_main(S* s)
                 else s->dirty = true;                                   // more rows may be searchable at once: come round again
             }
         }
-        if (ups.empty() && bands.empty()) continue;
+        if (ups.empty() && weighs.empty() && bands.empty()) continue;
         const double t0 = ms_now_us();
-        if (run_round(s, ups, bands))
+        if (run_round(s, ups, weighs, bands))
         {
             s->failed += bands.size() + 1;
             snprintf(s->workerError, sizeof(s->workerError), "%s", x265hip_last_error());
@@ -234,24 +298,62 @@ void free_all(S* s)
 }
 
 // index of the picture named `key`, created when it is new (least recently used entry that no open pair reads); -1 when every entry is held
-int find_or_make_picture(S* s, uint64_t key)
+bool pair_reads(const S* s, int i)
 {
-    for (int i = 0; i < (int)s->pics.size(); i++)
-        if (s->pics[i].used && s->pics[i].key == key) { s->pics[i].stamp = ++s->clock; return i; }
+    const S::Pic& p = s->pics[i];
+    for (const auto& sl : s->slots)
+        if (sl.active && ((sl.fenc == i && sl.fencEpoch == p.epoch) || (sl.ref == i && sl.refEpoch == p.epoch))) return true;
+    return false;
+}
+
+// an entry nobody needs: least recently used one that no open pair reads - directly or as the parent of a derived picture a pair reads
+int pick_victim(S* s)
+{
     int victim = -1;
     for (int i = 0; i < (int)s->pics.size(); i++)
     {
         S::Pic& p = s->pics[i];
-        if (!p.used) { victim = i; break; }
+        if (!p.used) return i;
         if (p.busy) continue;
-        bool held = false;
-        for (const auto& sl : s->slots)
-            held |= sl.active && ((sl.fenc == i && sl.fencEpoch == p.epoch) || (sl.ref == i && sl.refEpoch == p.epoch));
+        bool held = pair_reads(s, i);
+        for (int d = 0; d < (int)s->pics.size() && !held; d++)
+        {
+            const S::Pic& pd = s->pics[d];
+            held = pd.used && pd.derived && pd.parent == i && pd.parentEpoch == p.epoch && pair_reads(s, d);
+        }
         if (!held && (victim < 0 || p.stamp < s->pics[victim].stamp)) victim = i;
     }
+    return victim;
+}
+
+int find_or_make_picture(S* s, uint64_t key)
+{
+    for (int i = 0; i < (int)s->pics.size(); i++)
+        if (s->pics[i].used && !s->pics[i].derived && s->pics[i].key == key) { s->pics[i].stamp = ++s->clock; return i; }
+    const int victim = pick_victim(s);
     if (victim < 0) return -1;
     S::Pic& p = s->pics[victim];
     p.used = true; p.key = key; p.epoch++; p.stamp = ++s->clock; p.busy = 0;
+    p.derived = false; p.parent = -1;
+    std::fill(p.rows.begin(), p.rows.end(), (uint8_t)ROW_NONE);
+    return victim;
+}
+
+// picture `parent` weighted with w: found among the derived entries or created (its rows are produced by the worker)
+int find_or_make_derived(S* s, int parent, const x265hip_weight& w)
+{
+    const uint32_t pe = s->pics[parent].epoch;
+    for (int i = 0; i < (int)s->pics.size(); i++)
+    {
+        S::Pic& p = s->pics[i];
+        if (p.used && p.derived && p.parent == parent && p.parentEpoch == pe && p.w.w0 == w.w0 && p.w.round == w.round && p.w.shift == w.shift && p.w.offset == w.offset)
+        { p.stamp = ++s->clock; return i; }
+    }
+    const int victim = pick_victim(s);
+    if (victim < 0) return -1;
+    S::Pic& p = s->pics[victim];
+    p.used = true; p.key = 0; p.epoch++; p.stamp = ++s->clock; p.busy = 0;
+    p.derived = true; p.parent = parent; p.parentEpoch = pe; p.w = w;
     std::fill(p.rows.begin(), p.rows.end(), (uint8_t)ROW_NONE);
     return victim;
 }
@@ -365,18 +467,34 @@ int x265hip_me_stream_picture_rows(x265hip_me_stream* s, uint64_t key, const voi
 }
 
 /* Opens pair (source picture fenc_key, reference picture ref_key) in `slot`: its CTU rows are searched as the two pictures' rows
- * arrive (before or after this call).  Returns the slot's new GENERATION (> 0) or a negative error. */
-int x265hip_me_stream_pair_open(x265hip_me_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key)
+ * arrive (before or after this call).  w != NULL: the pair searches the reference picture WEIGHTED on the device with the arguments
+ * of primitives.weight_pp (the plane MotionReference::applyWeight materialises on the host, encoder/reference.cpp:119-178).
+ * Returns the slot's new GENERATION (> 0) or a negative error. */
+int x265hip_me_stream_pair_open_weighted(x265hip_me_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key, const x265hip_weight* w)
 {
     if (!s || slot < 0 || slot >= (int)s->slots.size()) { set_error("me_stream_pair_open: bad slot"); return X265HIP_EINVAL; }
+    if (fenc_key == ref_key) { set_error("me_stream_pair_open: source and reference picture carry the same key"); return X265HIP_EINVAL; }
+    if (w && (w->shift < 14 - s->prm.depth || w->shift > 31 || w->w0 < -128 * 64 || w->w0 > 128 * 64))
+    { set_error("me_stream_pair_open: weight (w0 %d, shift %d) out of range (shift includes the 14 - depth correction of weight_pp)", w->w0, w->shift); return X265HIP_EINVAL; }
     int gen;
     {
         std::lock_guard<std::mutex> lk(s->mu);
         S::Slot& sl = s->slots[slot];
-        sl.active = false;                                   // the slot's previous pair no longer holds its pictures
+        // every entry this pair needs is looked up (and pinned with busy) before the slot lets go of its previous pair: a failed open
+        // changes nothing, and the entry returned for the source can never be the victim chosen for the reference (round-3 advisor)
         const int f = find_or_make_picture(s, fenc_key);
-        const int r = f < 0 ? -1 : find_or_make_picture(s, ref_key);
-        if (f < 0 || r < 0 || f == r) { set_error("me_stream_pair_open: no picture entry free (pictures = %d)", s->prm.pictures); return X265HIP_EBUSY; }
+        if (f >= 0) s->pics[f].busy++;
+        int r = f < 0 ? -1 : find_or_make_picture(s, ref_key);
+        if (r >= 0 && w)
+        {
+            s->pics[r].busy++;
+            const int d = find_or_make_derived(s, r, *w);
+            s->pics[r].busy--;
+            r = d;
+        }
+        if (f >= 0) s->pics[f].busy--;
+        if (f < 0 || r < 0) { set_error("me_stream_pair_open: no picture entry free (pictures = %d)", s->prm.pictures); return X265HIP_EBUSY; }
+        sl.active = false;                                   // the slot's previous pair no longer holds its pictures
         gen = ++sl.generation;
         if (gen <= 0) gen = sl.generation = 1;
         for (int k = 0; k < s->ctusH; k++) sl.ready[k].store(0, std::memory_order_release);      // before any row of the slot can be rewritten
@@ -384,9 +502,15 @@ int x265hip_me_stream_pair_open(x265hip_me_stream* s, int slot, uint64_t fenc_ke
         sl.nextRow = 0; sl.active = true;
         s->dirty = true;
         s->pairsOpened++;
+        if (w) s->weightedPairs++;
     }
     s->cv.notify_one();
     return gen;
+}
+
+int x265hip_me_stream_pair_open(x265hip_me_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key)
+{
+    return x265hip_me_stream_pair_open_weighted(s, slot, fenc_key, ref_key, nullptr);
 }
 
 const void* x265hip_me_stream_surface(x265hip_me_stream* s, int slot)
@@ -407,6 +531,7 @@ int x265hip_me_stream_stats(x265hip_me_stream* s, x265hip_me_stream_stats_t* st)
     st->pairs_opened = s->pairsOpened; st->pairs_completed = s->pairsCompleted; st->bands = s->bands; st->rows_searched = s->rowsSearched;
     st->rows_uploaded = s->rowsUploaded; st->failed = s->failed; st->stale_pairs = s->noPicture; st->us_busy = s->usBusy;
     st->bytes_downloaded = s->bytesDown; st->bytes_uploaded = s->bytesUp; st->surface_bytes = s->surfBytes;
+    st->rows_weighted = s->rowsWeighted; st->weighted_pairs = s->weightedPairs;
     if (s->failed) set_error("me_stream worker: %s", s->workerError);
     return 0;
 }

@@ -56,8 +56,11 @@ def _box5(a):
     return np.apply_along_axis(lambda c: np.convolve(c, k, mode="same"), 0, a)
 
 
-def synth_clip(width: int, height: int, nframes: int, depth: int = 8, seed: int = 265):
-    """Return list of (Y, U, V) numpy planes (4:2:0), dtype uint8 (depth 8) or uint16."""
+def synth_clip(width: int, height: int, nframes: int, depth: int = 8, seed: int = 265, fade=None):
+    """Return list of (Y, U, V) numpy planes (4:2:0), dtype uint8 (depth 8) or uint16.
+    fade = (gain of the first picture, gain of the last one): a linear luma fade towards black level 16 - the content x265's default
+    --weightp exists for (weightAnalyse picks a weight per reference, encoder/weightPrediction.cpp:222+); None = constant brightness
+    (the same pictures as before the parameter existed)."""
     rng = np.random.default_rng(seed)
     tw, th = width + 3 * nframes + 8, height + 2 * nframes + 8
     yy, xx = np.mgrid[0:th, 0:tw].astype(np.float32)
@@ -76,6 +79,9 @@ def synth_clip(width: int, height: int, nframes: int, depth: int = 8, seed: int 
     for n in range(nframes):
         crop = tex[2 * n:2 * n + height, 3 * n:3 * n + width]
         y = crop * scale + rng.normal(0.0, 3.0 * scale, size=crop.shape).astype(np.float32)
+        if fade is not None:
+            gain = fade[0] + (fade[1] - fade[0]) * (n / max(1, nframes - 1))
+            y = (y - 16.0 * scale) * np.float32(gain) + 16.0 * scale
         y = np.clip(np.rint(y), 0, maxv).astype(dt)
         sub = y[::2, ::2].astype(np.int32)
         u = np.clip(sub // 2 + 64 * scale, 0, maxv).astype(dt)
