@@ -127,6 +127,10 @@ typedef struct x265hip_me_params
     const uint16_t* cost_x;
     const uint16_t* cost_y;
     int surf_format;                /* X265HIP_SURF_* */
+    /* optional (round 4), DEVICE int16 [ctu][2]: the window of CTU c covers displacements centres[2c] +- range x centres[2c+1] +- range
+     * instead of (0, 0) +- range (record / raster index i still means centre + (i - range)); the caller keeps every window inside the
+     * margins: |centre| + range + 12 <= margin.  NULL = windows centred on (0, 0) */
+    const int16_t* centres;
 } x265hip_me_params;
 enum { X265HIP_SURF_I32 = 0, X265HIP_SURF_PACKED = 1, X265HIP_SURF_PACKED_T = 2, X265HIP_SURF_PACKED_B = 3 };
 #define X265HIP_SURF_GROUP_BYTES_I32    1360
@@ -938,7 +942,34 @@ typedef struct x265hip_me_stream_params
     int slots;
     int pictures;
     int band_rows;
+    int layout;                              /* X265HIP_STREAM_RECORDS (0) or X265HIP_STREAM_PLANES */
+    int centre_range;                        /* 0: windows centred on (0, 0); R' >= range: on each CTU's own displacement (see below) */
 } x265hip_me_stream_params;
+/* layout X265HIP_STREAM_PLANES (round 4) - what a host search wants to read: PU-MAJOR.  Per CTU (x265hip_me_stream_ctu_bytes apart),
+ * for every square PU from the first served level on (min_level 0: 64 8x8, then 16 16x16, 4 32x32, 1 64x64, z-order per level) one
+ * raster of (2 range + 1) rows x pitch = 4 * ((2 range + 4) / 4) entries: entry [dy + range][dx + range] = the PU's SAD at
+ * displacement centre + (dx, dy).  8x8 and 16x16 rasters are uint16 and SATURATE: 65535 = "not representable" (only possible above
+ * 8 bits) - the host computes that one itself; 32x32 and 64x64 rasters are uint32.  One search walks one PU over neighbouring
+ * displacements, so its probes share a few cache lines of a 2 - 10 KB raster instead of missing once per probe.
+ * centre_range = R' > 0: before a band's surfaces are computed, a minima-only exhaustive search of +-R' (SAD alone) finds where each
+ * CTU's 64x64 block went; the CTU's window is centred there (clamped to |c| <= margin - range - 12 so it stays inside the picture
+ * margins).  x265hip_me_stream_centres(slot)[2 ctu], [2 ctu + 1] = that displacement, valid with the row's ready flag. */
+enum { X265HIP_STREAM_RECORDS = 0, X265HIP_STREAM_PLANES = 1 };
+static inline size_t x265hip_stream_planes_ctu_bytes(int range, int min_level)
+{
+    const size_t nc = (size_t)(2 * range + 1), pitch = 4 * ((nc + 3) >> 2);
+    return nc * pitch * ((min_level ? 0 : 64 * 2) + 16 * 2 + 5 * 4);
+}
+/* byte offset of square PU (level 0..3, z-order index z) inside a CTU's planes, and its entry size (2 or 4) */
+static inline size_t x265hip_stream_planes_pu_offset(int range, int min_level, int level, int z, int* entry_bytes)
+{
+    const size_t nc = (size_t)(2 * range + 1), pitch = 4 * ((nc + 3) >> 2), ps = nc * pitch * 2, pw = nc * pitch * 4;
+    const size_t n0 = min_level ? 0 : 64;
+    if (entry_bytes) *entry_bytes = level < 2 ? 2 : 4;
+    if (level == 0) return (size_t)z * ps;
+    if (level == 1) return (n0 + (size_t)z) * ps;
+    return (n0 + 16) * ps + (size_t)(level == 2 ? z : 4) * pw;
+}
 typedef struct x265hip_me_stream_stats_t
 {
     uint64_t pairs_opened, pairs_completed, bands, rows_searched, rows_uploaded, failed, stale_pairs;
@@ -964,7 +995,9 @@ typedef struct x265hip_weight { int w0, round, shift, offset; } x265hip_weight;
 int  x265hip_me_stream_pair_open_weighted(x265hip_me_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key, const x265hip_weight* w);
 const void* x265hip_me_stream_surface(x265hip_me_stream* s, int slot);
 const volatile int* x265hip_me_stream_ready(x265hip_me_stream* s, int slot);      /* int [height / 64] */
-int  x265hip_me_stream_record_bytes(x265hip_me_stream* s);
+int  x265hip_me_stream_record_bytes(x265hip_me_stream* s);           /* X265HIP_STREAM_RECORDS; 0 in the planes layout */
+size_t x265hip_me_stream_ctu_bytes(x265hip_me_stream* s);            /* bytes of one CTU's surfaces in the slot buffers, either layout */
+const int16_t* x265hip_me_stream_centres(x265hip_me_stream* s, int slot);
 int  x265hip_me_stream_stats(x265hip_me_stream* s, x265hip_me_stream_stats_t* st);
 
 /* Address arithmetic of a surface record (every format), usable from any host language: the SAD of square PU `z` (z-order

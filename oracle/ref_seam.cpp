@@ -120,7 +120,7 @@ struct LookaheadSeam
 struct SeamProf
 {
     bool on = false;
-    std::atomic<uint64_t> meCyc{0}, meCalls{0}, subCyc{0}, subCalls{0}, laCyc{0}, laCalls{0}, rowCyc{0}, rows{0};
+    std::atomic<uint64_t> meCyc{0}, meCalls{0}, subCyc{0}, subCalls{0}, laCyc{0}, laCalls{0}, rowCyc{0}, rows{0}, lookCyc{0}, lookups{0}, ctxCyc{0};
 } gp;
 struct ProfScope
 {
@@ -144,7 +144,9 @@ struct Provider
     int (*picture_rows)(void* ctx, uint64_t key, const void* buf, int ctu_row0, int ctu_rows);
     int (*pair_open)(void* ctx, int slot, uint64_t fenc_key, uint64_t ref_key);
     int (*pair_open_w)(void* ctx, int slot, uint64_t fenc_key, uint64_t ref_key, const void* weight);      /* x265hip_me_stream_pair_open_weighted; NULL: weighted references pass */
+    const int16_t* (*centres)(void* ctx, int slot);      /* x265hip_me_stream_centres; NULL or a NULL result: windows centred on (0, 0) */
     bool streamed;
+    int layout;                   /* 0: records; 1: PU-major planes (X265HIP_STREAM_PLANES) */
     int min_level;                /* 1: records hold the 16x16 / 32x32 / 64x64 levels only (X265HIP_SURF_TAIL_BYTES_*) */
     int range, surf_format, slots;
     int width, height;            /* whole CTUs */
@@ -173,7 +175,8 @@ struct Seam
 {
     bool enabled = false, verify = false, wait = false;
     Provider p;
-    int nc, ng, groupBytes, ctusW;
+    int nc, ng, groupBytes, ctusW, pitch;
+    uint64_t strideMagic;               /* ceil(2^40 / stride): row = (t * magic) >> 40 for every offset a lookup can see */
     size_t ctuBytes;
     std::mutex mu;
     Pair pairs[MAX_SLOTS];
@@ -184,19 +187,21 @@ struct Seam
     pixelcmp_x3_t sad_x3[NUM_PU_SIZES];
     pixelcmp_x4_t sad_x4[NUM_PU_SIZES];
     std::atomic<uint64_t> hits{0}, outside{0}, notReady{0}, meCalls{0}, meServed{0}, submits{0}, mismatches{0}, noSlot{0}, foreign{0};
-    std::atomic<uint64_t> rowsPublished{0}, rowsRefused{0}, torn{0}, weightedPairs{0}, weightedHits{0}, weightedCalls{0};
+    std::atomic<uint64_t> rowsPublished{0}, rowsRefused{0}, torn{0}, weightedPairs{0}, weightedHits{0}, weightedCalls{0}, saturated{0};
 } g;
 enum { MAX_SLOTS_STREAMED = 64 };
 inline uint64_t pic_key(uint64_t instance, int poc, int isRecon) { return (instance << 40) | ((uint64_t)(uint32_t)poc << 1) | (uint64_t)isRecon; }
 
-struct Part { uint16_t off; uint16_t wide; };      /* byte offset of entry [z][0] inside a group record; wide = int32 entries */
+struct Part { uint32_t off; uint32_t wide; };      /* records: byte offset of entry [z][0] inside a group record; planes: of the PU's raster inside the CTU; wide = 32-bit entries */
 
 struct Ctx
 {
     bool valid;
     int part;                 /* LumaPU enum of the PU being searched */
     const pixel* fenc;
-    const pixel* fref0;       /* reference pointer of displacement (0,0) */
+    const pixel* fref0;       /* reference pointer of the window's centre displacement ((0,0) until the row's centre is known) */
+    const int16_t* centre;    /* this CTU's entry of the slot's centres, or NULL */
+    bool centred;
     intptr_t stride;
     ptrdiff_t bias;           /* range * stride + range */
     const uint8_t* ctuBase;   /* surfaces of this CTU */
@@ -204,7 +209,7 @@ struct Ctx
     int ctuRow, gen, nparts;
     bool weighted;
     Part parts[MAX_PARTS];
-    uint64_t hits, outside, notReady;
+    uint64_t hits, outside, notReady, saturated, cyc;
 };
 thread_local Ctx t_ctx;
 struct TlsPair { const PicYuv* rec; int recPoc; int slot; int gen; Wt wt; };
@@ -229,19 +234,26 @@ bool decompose(int px, int py, int w, int h, int bx, int by, int size, Ctx& c)
         int z = 0;
         for (int b = 0; b < 3; b++) z |= ((ux >> b) & 1) << (2 * b) | ((uy >> b) & 1) << (2 * b + 1);
         Part& q = c.parts[c.nparts++];
-        if (g.p.surf_format != SURF_I32)
+        if (g.p.layout)
+        {
+            /* x265hip_stream_planes_pu_offset: uint16 rasters of the 8x8 (min_level 0) and 16x16 PUs, then uint32 rasters of 32x32 and 64x64 */
+            const size_t ps = (size_t)g.nc * g.pitch * 2, pw = (size_t)g.nc * g.pitch * 4, n0 = g.p.min_level ? 0 : 64;
+            q.wide = level >= 2;
+            q.off = (uint32_t)(level == 0 ? z * ps : level == 1 ? (n0 + z) * ps : (n0 + 16) * ps + (level == 2 ? z : 4) * pw);
+        }
+        else if (g.p.surf_format != SURF_I32)
         {
             static const int base[4] = { 0, 512, 640, 704 };
             q.wide = level >= 2;
             const int o = base[level] + z * (q.wide ? 16 : 8) - (g.p.min_level ? 512 : 0);      /* byte offset inside the 720-byte packed record (208-byte tail) */
             /* chunk-major rows (X265HIP_SURF_PACKED_T): 16-byte chunk c of group g sits at row + (c * groups + g) * 16 */
-            q.off = (uint16_t)(g.p.surf_format == SURF_PACKED_T ? (o >> 4) * g.ng * 16 + (o & 15) : o);
+            q.off = (uint32_t)(g.p.surf_format == SURF_PACKED_T ? (o >> 4) * g.ng * 16 + (o & 15) : o);
         }
         else
         {
             static const int base[4] = { 0, 64, 80, 84 };
             q.wide = 1;
-            q.off = (uint16_t)((base[level] + z) * 16 - (g.p.min_level ? 1024 : 0));
+            q.off = (uint32_t)((base[level] + z) * 16 - (g.p.min_level ? 1024 : 0));
         }
         return true;
     }
@@ -251,13 +263,8 @@ bool decompose(int px, int py, int w, int h, int bx, int by, int size, Ctx& c)
            decompose(px, py, w, h, bx, by + hs, hs, c) && decompose(px, py, w, h, bx + hs, by + hs, hs, c);
 }
 
-inline bool lookup(Ctx& c, const pixel* fref, int& out)
+inline bool lookup_raw(Ctx& c, const pixel* fref, int& out)
 {
-    const ptrdiff_t t = (fref - c.fref0) + c.bias;
-    if (t < 0) { c.outside++; return false; }
-    const uint64_t row = (uint64_t)t / (uint64_t)c.stride, col = (uint64_t)t - row * (uint64_t)c.stride;
-    const uint64_t span = 2 * (uint64_t)g.p.range;
-    if (row > span || col > span) { c.outside++; return false; }
     if (c.ready[c.ctuRow] != c.gen)
     {
         /* default: never wait, the host primitive answers instead.  Test mode (wait): give the transfer up to 2 s, so that small
@@ -273,18 +280,54 @@ inline bool lookup(Ctx& c, const pixel* fref, int& out)
         if (!arrived) { c.notReady++; return false; }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    const uint8_t* rec = g.p.surf_format == SURF_PACKED_T ? c.ctuBase + row * g.ng * g.groupBytes + (col >> 2) * 16
-                                                           : c.ctuBase + (row * g.ng + (col >> 2)) * g.groupBytes;
-    const int k = (int)(col & 3);
+    if (!c.centred)
+    {
+        /* the window of this CTU is centred on the displacement the provider found for it; its centre arrived with the row's flag */
+        if (c.centre) c.fref0 += (ptrdiff_t)c.centre[1] * c.stride + c.centre[0];
+        c.centred = true;
+    }
+    const ptrdiff_t t = (fref - c.fref0) + c.bias;
+    if (t < 0 || t >= ((ptrdiff_t)1 << 27)) { c.outside++; return false; }
+    const uint64_t row = ((uint64_t)t * g.strideMagic) >> 40, col = (uint64_t)t - row * (uint64_t)c.stride;
+    const uint64_t span = 2 * (uint64_t)g.p.range;
+    if (row > span || col > span) { c.outside++; return false; }
     int sum = 0;
-    for (int i = 0; i < c.nparts; i++)
-        sum += c.parts[i].wide ? ((const int32_t*)(rec + c.parts[i].off))[k] : ((const uint16_t*)(rec + c.parts[i].off))[k];
+    if (g.p.layout)
+    {
+        const size_t idx = (size_t)row * g.pitch + col;
+        for (int i = 0; i < c.nparts; i++)
+        {
+            if (c.parts[i].wide) sum += (int)((const uint32_t*)(c.ctuBase + c.parts[i].off))[idx];
+            else
+            {
+                const unsigned v = ((const uint16_t*)(c.ctuBase + c.parts[i].off))[idx];
+                if (v == 65535u) { c.saturated++; return false; }              /* not representable in 16 bits (above 8 bits only): the host's to compute */
+                sum += (int)v;
+            }
+        }
+    }
+    else
+    {
+        const uint8_t* rec = g.p.surf_format == SURF_PACKED_T ? c.ctuBase + row * g.ng * g.groupBytes + (col >> 2) * 16
+                                                               : c.ctuBase + (row * g.ng + (col >> 2)) * g.groupBytes;
+        const int k = (int)(col & 3);
+        for (int i = 0; i < c.nparts; i++)
+            sum += c.parts[i].wide ? ((const int32_t*)(rec + c.parts[i].off))[k] : ((const uint16_t*)(rec + c.parts[i].off))[k];
+    }
     /* the row must STILL be this generation's after the read: a reopened slot has its flags cleared before any row is rewritten */
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     if (c.ready[c.ctuRow] != c.gen) { g.torn.fetch_add(1, std::memory_order_relaxed); return false; }
     c.hits++;
     out = sum;
     return true;
+}
+inline bool lookup(Ctx& c, const pixel* fref, int& out)
+{
+    if (!gp.on) return lookup_raw(c, fref, out);
+    const uint64_t t0 = __rdtsc();
+    const bool ok = lookup_raw(c, fref, out);
+    c.cyc += __rdtsc() - t0;
+    return ok;
 }
 
 void verify_fail(int part, int got, int want)
@@ -507,6 +550,7 @@ struct SubCtx
     const volatile uint64_t* progress;                        /* streamed: generation << 32 | lines finished, [0] luma [1] chroma */
     int gen;
     bool arrived[2];
+    uint64_t nServed, nWeighted, nNotReady, nTorn;           /* per search, added to the shared counters once at its end (16 threads x 13 M compares) */
 };
 thread_local SubCtx t_sub;
 thread_local struct { int epoch; int n; struct { const PicYuv* rec; int poc; int slot; int gen; Wt wt[3]; } e[8]; } t_phase = { -1, 0, {} };
@@ -612,6 +656,7 @@ void sub_context(const Search* s, ReferencePlanes* ref)
     c.progress = gs.p.streamed ? gs.p.progress(gs.p.ctx, slot) : NULL;
     c.gen = gen;
     c.arrived[0] = c.arrived[1] = false;
+    c.nServed = c.nWeighted = c.nNotReady = c.nTorn = 0;
     c.valid = c.luma && c.cb && c.cr && (c.ready || c.progress);
 }
 
@@ -657,6 +702,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     ProfScope prof(gp.meCyc, gp.meCalls);
     Ctx& c = t_ctx;
     c.valid = false;
+    const uint64_t tctx = gp.on ? __rdtsc() : 0;
     if (g.enabled)
     {
         g.meCalls.fetch_add(1, std::memory_order_relaxed);
@@ -696,6 +742,9 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
                         c.fenc = fencPUYuv.m_buf[0];
                         const intptr_t off = rec->getLumaAddr(ctuAddr, absPartIdx) - rec->getLumaAddr(0);
                         c.fref0 = ref->fpelPlane[0] + off;
+                        const int16_t* cen = g.p.centres ? g.p.centres(g.p.ctx, slot) : NULL;
+                        c.centre = cen ? cen + 2 * (size_t)ctuAddr : NULL;
+                        c.centred = false;
                         c.stride = ref->lumaStride;
                         c.bias = (ptrdiff_t)g.p.range * c.stride + g.p.range;
                         c.ctuBase = (const uint8_t*)g.p.surface(g.p.ctx, slot) + (size_t)ctuAddr * g.ctuBytes;
@@ -703,7 +752,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
                         c.ctuRow = ctuAddr / g.ctusW;
                         c.gen = gen;
                         c.weighted = wt.present != 0;
-                        c.hits = c.outside = c.notReady = 0;
+                        c.hits = c.outside = c.notReady = c.saturated = c.cyc = 0;
                         c.valid = true;
                     }
                 }
@@ -715,7 +764,16 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     t_sub.valid = false;
     if (gs.enabled && ctuAddr >= 0 && !srcReferencePlane && !ref->isLowres)
         sub_context(reinterpret_cast<const Search*>(reinterpret_cast<const char*>(this) - offsetof(Search, m_me)), ref);
+    if (gp.on) gp.ctxCyc.fetch_add(__rdtsc() - tctx, std::memory_order_relaxed);
     const int cost = x265ref_orig_motionEstimate(this, ref, &mvmin, &mvmax, &qmvp, numCandidates, mvc, merange, &outQMv, maxSlices, srcReferencePlane);
+    if (t_sub.valid)
+    {
+        SubCtx& sc = t_sub;
+        if (sc.nServed) gs.served.fetch_add(sc.nServed, std::memory_order_relaxed);
+        if (sc.nWeighted) gs.weightedServed.fetch_add(sc.nWeighted, std::memory_order_relaxed);
+        if (sc.nNotReady) gs.notReady.fetch_add(sc.nNotReady, std::memory_order_relaxed);
+        if (sc.nTorn) gs.torn.fetch_add(sc.nTorn, std::memory_order_relaxed);
+    }
     t_sub.valid = false;
     if (c.valid)
     {
@@ -725,6 +783,8 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         if (c.weighted) g.weightedHits.fetch_add(c.hits, std::memory_order_relaxed);
         g.outside.fetch_add(c.outside, std::memory_order_relaxed);
         g.notReady.fetch_add(c.notReady, std::memory_order_relaxed);
+        if (c.saturated) g.saturated.fetch_add(c.saturated, std::memory_order_relaxed);
+        if (gp.on) { gp.lookCyc.fetch_add(c.cyc, std::memory_order_relaxed); gp.lookups.fetch_add(c.hits + c.outside + c.notReady + c.saturated, std::memory_order_relaxed); }
     }
     return cost;
 }
@@ -740,7 +800,7 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
     SubCtx& c = t_sub;
     if (!c.valid || c.ref != ref || (!c.progress && (!sub_arrived(c, 0) || (bChromaSATD && !sub_arrived(c, 1)))))
     {
-        if (c.valid && c.ref == ref) gs.notReady.fetch_add(1, std::memory_order_relaxed);
+        if (c.valid && c.ref == ref) c.nNotReady++;
         return x265ref_orig_subpelCompare(this, ref, &qmv, cmp);
     }
     const intptr_t stride = ref->lumaStride;
@@ -764,7 +824,7 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
         }
         if (!ok)
         {
-            gs.notReady.fetch_add(1, std::memory_order_relaxed);
+            c.nNotReady++;
             return x265ref_orig_subpelCompare(this, ref, &qmv, cmp);
         }
     }
@@ -786,12 +846,12 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         if ((int)(c.progress[0] >> 32) != c.gen || (bChromaSATD && (int)(c.progress[1] >> 32) != c.gen))
         {
-            gs.torn.fetch_add(1, std::memory_order_relaxed);
+            c.nTorn++;
             return x265ref_orig_subpelCompare(this, ref, &qmv, cmp);
         }
     }
-    gs.served.fetch_add(1, std::memory_order_relaxed);
-    if (c.weighted) gs.weightedServed.fetch_add(1, std::memory_order_relaxed);
+    c.nServed++;
+    if (c.weighted) c.nWeighted++;
     if (gs.verify)
     {
         const int want = x265ref_orig_subpelCompare(this, ref, &qmv, cmp);
@@ -1036,7 +1096,8 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
     g.p.submit_batch = (int (*)(void*, int, const int*, const void*, uint64_t, const void* const*, int*))submit_batch;      /* may be NULL */
     g.p.surface = (const void* (*)(void*, int))surface;
     g.p.ready = (const volatile int* (*)(void*, int))ready;
-    g.p.picture_rows = NULL; g.p.pair_open = NULL; g.p.pair_open_w = NULL; g.p.streamed = false; g.p.min_level = 0;
+    g.p.picture_rows = NULL; g.p.pair_open = NULL; g.p.pair_open_w = NULL; g.p.centres = NULL; g.p.streamed = false; g.p.min_level = 0; g.p.layout = 0;
+    g.saturated = 0;
     g.weightedPairs = 0; g.weightedHits = 0; g.weightedCalls = 0;
     memset(g.fencs, 0, sizeof(g.fencs));
     g.instance++;
@@ -1044,7 +1105,8 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
     g.p.range = range; g.p.surf_format = surf_format; g.p.slots = slots;
     g.p.width = width; g.p.height = height; g.p.stride = stride; g.p.margin_x = margin_x; g.p.margin_y = margin_y;
     g.p.min_pu = min_pu < 8 ? 8 : min_pu;
-    g.nc = 2 * range + 1; g.ng = (g.nc + 3) >> 2;
+    g.nc = 2 * range + 1; g.ng = (g.nc + 3) >> 2; g.pitch = 4 * g.ng;
+    g.strideMagic = (((uint64_t)1 << 40) + (uint64_t)stride - 1) / (uint64_t)stride;
     g.groupBytes = surf_format == SURF_I32 ? GROUP_I32 : GROUP_PACKED;
     g.ctusW = width / 64;
     g.ctuBytes = (size_t)g.nc * g.ng * g.groupBytes;
@@ -1059,19 +1121,24 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
 
 /* row-granular provider (x265hip_me_stream_picture_rows / _pair_open / _surface / _ready signatures): serves under any --frame-threads.
  * record_bytes = x265hip_me_stream_record_bytes (the whole record, or its 16x16-and-up tail with min_level 1). */
-int x265ref_seam_configure_streamed(void* ctx, void* picture_rows, void* pair_open, void* pair_open_weighted, void* surface, void* ready, int range, int surf_format,
-                                    int min_level, int slots, int width, int height, intptr_t stride, int margin_x, int margin_y, int min_pu, int verify)
+int x265ref_seam_configure_streamed(void* ctx, void* picture_rows, void* pair_open, void* pair_open_weighted, void* surface, void* ready, void* centres, int layout,
+                                    int range, int surf_format, int min_level, int slots, int width, int height, intptr_t stride, int margin_x, int margin_y,
+                                    int min_pu, int verify)
 {
-    if (!picture_rows || !pair_open || surf_format == SURF_PACKED_T || min_level < 0 || min_level > 1) return -4;
+    if (!picture_rows || !pair_open || surf_format == SURF_PACKED_T || min_level < 0 || min_level > 1 || layout < 0 || layout > 1) return -4;
     const int rc = x265ref_seam_configure(ctx, NULL, NULL, surface, ready, range, surf_format, slots, width, height, stride, margin_x, margin_y,
                                           min_level && min_pu < 16 ? 16 : min_pu, verify);
     if (rc) return rc;
     g.p.picture_rows = (int (*)(void*, uint64_t, const void*, int, int))picture_rows;
     g.p.pair_open = (int (*)(void*, int, uint64_t, uint64_t))pair_open;
     g.p.pair_open_w = (int (*)(void*, int, uint64_t, uint64_t, const void*))pair_open_weighted;      /* NULL: weighted references pass */
+    g.p.centres = (const int16_t* (*)(void*, int))centres;      /* NULL: windows centred on (0, 0) */
+    g.p.layout = layout;
     g.p.min_level = min_level;
     g.p.streamed = true;
-    if (min_level)
+    if (layout)
+        g.ctuBytes = (size_t)g.nc * g.pitch * ((min_level ? 0 : 64 * 2) + 16 * 2 + 5 * 4);          /* x265hip_stream_planes_ctu_bytes */
+    else if (min_level)
     {
         g.groupBytes = surf_format == SURF_I32 ? 336 : 208;          /* X265HIP_SURF_TAIL_BYTES_I32 / _PACKED */
         g.ctuBytes = (size_t)g.nc * g.ng * g.groupBytes;
@@ -1136,11 +1203,13 @@ void x265ref_seam_stream_stats(uint64_t* out)
     out[0] = g.rowsPublished; out[1] = g.rowsRefused; out[2] = gs.rowsPublished; out[3] = g.torn + gs.torn;
 }
 
-/* out[5]: pairs opened on a weighted reference, motionEstimate calls on weighted references that got a lookup context, lookups served on
- * weighted references, phase-plane views opened on weighted references, subpelCompare calls served from weighted views */
+/* out[6]: pairs opened on a weighted reference, motionEstimate calls on weighted references that got a lookup context, lookups served on
+ * weighted references, phase-plane views opened on weighted references, subpelCompare calls served from weighted views; lookups that
+ * met a saturated 16-bit entry of the planes layout (answered by the host) */
 void x265ref_seam_weighted_stats(uint64_t* out)
 {
     out[0] = g.weightedPairs; out[1] = g.weightedCalls; out[2] = g.weightedHits; out[3] = gs.weightedViews; out[4] = gs.weightedServed;
+    out[5] = g.saturated;
 }
 
 /* out[6]: subpelCompare calls served from phase planes, passed on because the planes had not arrived, searches without a usable
@@ -1184,16 +1253,17 @@ int x265ref_seam_fill_table_profiled(void* table, size_t bytes, int depth)
 {
     const int a = x265ref_profile_fill_table(table, bytes, depth);
     if (a < 0) return a;
-    gp.meCyc = gp.meCalls = gp.subCyc = gp.subCalls = gp.laCyc = gp.laCalls = gp.rowCyc = gp.rows = 0;
+    gp.meCyc = gp.meCalls = gp.subCyc = gp.subCalls = gp.laCyc = gp.laCalls = gp.rowCyc = gp.rows = 0; gp.lookCyc = gp.lookups = gp.ctxCyc = 0;
     gp.on = true;
     const int b = g.enabled ? x265ref_seam_fill_table(table, bytes, depth) : 0;
     return b < 0 ? b : a + b;
 }
-/* out[8]: cycles / calls of MotionEstimate::motionEstimate (whole, wrapper included), subpelCompare, CostEstimateGroup::estimateFrameCost,
- * the row hand-over inside FrameFilter::processPostRow */
+/* out[12]: cycles / calls of MotionEstimate::motionEstimate (whole, wrapper included), subpelCompare, CostEstimateGroup::estimateFrameCost,
+ * the row hand-over inside FrameFilter::processPostRow, the SAD lookups themselves (served or not), the context set-up of the wrapper */
 void x265ref_seam_profile_report(uint64_t* out)
 {
     out[0] = gp.meCyc; out[1] = gp.meCalls; out[2] = gp.subCyc; out[3] = gp.subCalls; out[4] = gp.laCyc; out[5] = gp.laCalls; out[6] = gp.rowCyc; out[7] = gp.rows;
+    out[8] = gp.lookCyc; out[9] = gp.lookups; out[10] = gp.ctxCyc; out[11] = gp.meCalls;
     gp.on = false;
 }
 

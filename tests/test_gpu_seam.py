@@ -532,3 +532,101 @@ def test_row_granular_seams_on_the_gpu_serve_weighted_references_on_a_fade(depth
     assert wr["pairs_opened_on_weighted_references"] >= 1 and wr["lookups_served_on_weighted_references"] > 200, rep
     assert wr["phase_views_opened_on_weighted_references"] >= 1 and wr["subpel_compares_served_from_weighted_views"] > 500, rep
     assert rep["weighted_pairs"] >= 1 and rep["rows_weighted"] >= 3 and sub["weighted_views"] >= 1, rep
+
+
+# ---- round 4: PU-major planes and windows centred on each CTU's displacement ---------------------------------------------------------
+@pytest.mark.parametrize("depth,width,height,rng,min_level,centre,band_rows", [(8, 256, 256, 12, 1, 0, 2), (8, 256, 256, 12, 0, 40, 8), (10, 192, 256, 10, 1, 32, 3),
+                                                                               (12, 128, 192, 8, 0, 24, 1), (8, 320, 192, 16, 1, 57, 2)])
+def test_me_stream_planes_layout_and_centres_equal_the_oracle(depth, width, height, rng, min_level, centre, band_rows):
+    """X265HIP_STREAM_PLANES: the slot buffer holds one raster per PU (uint16 saturating / uint32) - compared byte for byte with the
+    oracle's records transposed by the checker's twin; centre_range: centres = the clamped displacement of each CTU's 64x64 minimum in
+    the oracle's +-centre_range search, and every CTU's rasters are the oracle's search of the window around ITS centre."""
+    from tools import seam_driver as SD
+    O = _oracle()
+    geo = SD.geometry(width, height)
+    clip = F.synth_clip(geo["width"], geo["height"], 4, depth=depth, seed=17)
+    dt = np.uint8 if depth == 8 else np.uint16
+    def padded(y):
+        return np.ascontiguousarray(np.pad(y.reshape(geo["height"], geo["width"]).astype(dt), ((geo["margin_y"],) * 2, (geo["margin_x"],) * 2), mode="edge")).reshape(-1)
+    planes = [padded(fr[0]) for fr in clip]
+    prov = SD.StreamGpuProvider(depth, geo, rng, slots=2, min_level=min_level, pictures=6, band_rows=band_rows, layout=SD.LAYOUT_PLANES, centre_range=centre)
+    L = prov.L
+    _stream_entries(L)
+    L.x265hip_me_stream_centres.restype = ctypes.c_void_p
+    L.x265hip_me_stream_centres.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.x265hip_me_stream_ctu_bytes.restype = ctypes.c_size_t
+    L.x265hip_me_stream_ctu_bytes.argtypes = [ctypes.c_void_p]
+    try:
+        ctus_w, ctus_h = geo["width"] // 64, geo["height"] // 64
+        nctu = ctus_w * ctus_h
+        cb = SD.planes_ctu_bytes(rng, min_level)
+        assert L.x265hip_me_stream_ctu_bytes(prov.handle) == cb and L.x265hip_me_stream_record_bytes(prov.handle) == 0
+        org = geo["margin_y"] * geo["stride"] + geo["margin_x"]
+        zero = np.zeros(2 * rng + 1, np.uint16)
+        for slot, (fi, ri) in enumerate([(3, 0), (1, 0)]):             # three pictures / one picture apart: (9, 6) and (3, 2) of global motion
+            assert L.x265hip_me_stream_picture_rows(prov.handle, 10 + fi, planes[fi].ctypes.data, 0, ctus_h) == 0
+            gen = L.x265hip_me_stream_pair_open(prov.handle, slot, 10 + fi, 20 + ri + 5 * slot)
+            assert gen > 0
+            for r in range(ctus_h):
+                assert L.x265hip_me_stream_picture_rows(prov.handle, 20 + ri + 5 * slot, planes[ri].ctypes.data, r, 1) == 0
+            ready = np.ctypeslib.as_array((ctypes.c_int32 * ctus_h).from_address(L.x265hip_me_stream_ready(prov.handle, slot)))
+            t0 = time.time()
+            while not all(ready[q] == gen for q in range(ctus_h)) and time.time() - t0 < 20:
+                time.sleep(0.01)
+            assert all(ready[q] == gen for q in range(ctus_h)), prov.report()
+            cen = np.zeros((nctu, 2), np.int16)
+            cptr = L.x265hip_me_stream_centres(prov.handle, slot)
+            if centre:
+                zc = np.zeros(2 * centre + 1, np.uint16)
+                _, best = O.me_fullsearch(depth, planes[fi], geo["stride"], org, planes[ri], geo["stride"], org, geo["width"], geo["height"], centre, 0, nctu, zc, zc,
+                                          want_surf=False, want_best=True)
+                idx = (best.reshape(-1, 85)[:, 84] & 0xffffffff).astype(np.int64)
+                ncb = 2 * centre + 1
+                mx, my = min(centre, geo["margin_x"] - rng - 12), min(centre, geo["margin_y"] - rng - 12)
+                cen = np.stack([np.clip(idx % ncb - centre, -mx, mx), np.clip(idx // ncb - centre, -my, my)], axis=1).astype(np.int16)
+                got_c = np.ctypeslib.as_array((ctypes.c_int16 * (2 * nctu)).from_address(cptr)).reshape(nctu, 2)
+                assert np.array_equal(got_c, cen), (got_c[:6], cen[:6])
+                assert np.abs(cen).max() > 0                                 # the clip moves: a centre of (0, 0) everywhere would test nothing
+            else:
+                assert not cptr
+            parts = []
+            for c in range(nctu):
+                o = org + (c // ctus_w) * 64 * geo["stride"] + (c % ctus_w) * 64
+                sc, _ = O.me_fullsearch(depth, planes[fi], geo["stride"], o, planes[ri], geo["stride"], o + int(cen[c, 1]) * geo["stride"] + int(cen[c, 0]),
+                                        64, 64, rng, 0, 1, zero, zero, want_surf=True, want_best=False)
+                parts.append(sc)
+            exp = SD.records_to_planes(np.concatenate(parts).reshape(-1, 85, 4), nctu, rng, min_level)
+            got = np.ctypeslib.as_array((ctypes.c_uint8 * (nctu * cb)).from_address(L.x265hip_me_stream_surface(prov.handle, slot))).reshape(nctu, cb)
+            nc, pitch = 2 * rng + 1, 4 * ((2 * rng + 4) // 4)
+            def valid(b):       # the pad columns of a raster row hold don't-care values
+                lo = b[:, :nc * pitch * 2 * ((0 if min_level else 64) + 16)].copy().view(np.uint16).reshape(nctu, -1, nc, pitch)[..., :nc]
+                hi = b[:, nc * pitch * 2 * ((0 if min_level else 64) + 16):].copy().view(np.uint32).reshape(nctu, 5, nc, pitch)[..., :nc]
+                return lo, hi
+            (gl, gh), (el, eh) = valid(got), valid(exp)
+            assert np.array_equal(gl, el) and np.array_equal(gh, eh), slot
+        rep = prov.report()
+        assert rep["failed"] == 0 and rep["pairs_completed"] == 2, rep
+    finally:
+        prov.close()
+
+
+@pytest.mark.parametrize("depth,preset,ft,min_level,centre,extra", [(8, "slow", 3, 1, 57, [("me", "star")]), (8, "medium", 3, 0, 0, []), (10, "slower", 2, 1, 40, []),
+                                                                    (8, "slow", 3, 1, 40, [("me", "star"), ("bframes", "0")])])
+def test_row_granular_seams_on_the_gpu_with_planes_and_centred_windows(depth, preset, ft, min_level, centre, extra):
+    """The real encoder on the planes layout (and centred windows) of x265hip_me_stream, weighted references included (the last case
+    runs on a fade with --weightp on): byte-identical, every lookup verified in flight."""
+    import test_seam_cpu as T
+    from tools import seam_driver as SD
+    fade = any(k == "bframes" for k, _ in extra)
+    opts = [("pools", "4"), ("frame-threads", str(ft)), ("crf", "24")] + ([] if fade else [("no-weightp", None), ("no-weightb", None)]) + extra
+    kw = dict(rng=12, wait=True, min_level=min_level, subpel="gpu", slots=32, subpel_slots=16, layout=SD.LAYOUT_PLANES, centre_range=centre)
+    if fade:
+        base, got, rep = T.run_fade_pair(depth, 256, 192, 10, preset, opts, "gpu", **kw)
+    else:
+        base, got, rep = T.run_pair(depth, 256, 192, 8, preset, opts, "gpu", verify=True, streamed=True, **kw)
+    assert got[0] == base[0], f"seam changed the bitstream: {rep}"
+    sub = rep["subpel_seam"]
+    assert rep["verify"] == 1 and rep["verify_mismatches"] == 0 and sub["verify_mismatches"] == 0 and rep["failed"] == 0 and sub["failed"] == 0
+    assert rep["lookups_served"] > (300 if min_level else 1500) and sub["subpel_compares_served"] > 1000, rep
+    if fade:
+        assert rep["weighted_references"]["lookups_served_on_weighted_references"] > 100, rep

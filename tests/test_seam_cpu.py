@@ -22,7 +22,7 @@ def _tools():
 
 
 def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False, lookahead=None, subpel=None, surf_format=None,
-             streamed=False, min_level=0, slots=8, subpel_slots=6):
+             streamed=False, min_level=0, slots=8, subpel_slots=6, layout=0, centre_range=0):
     EB, SD = _tools()
     try:
         plain = EB.ref_lib(depth)
@@ -33,7 +33,8 @@ def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
     base = EB.encode(plain, yuv, w, h, nframes, preset, opts)
     lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=slots, min_pu=min_pu, verify=verify, wait=wait, lookahead=lookahead,
-                                                  subpel=subpel, surf_format=surf_format, streamed=streamed, min_level=min_level, subpel_slots=subpel_slots)
+                                                  subpel=subpel, surf_format=surf_format, streamed=streamed, min_level=min_level, subpel_slots=subpel_slots,
+                                                  layout=layout, centre_range=centre_range)
     try:
         got = EB.encode(lib, yuv, w, h, nframes, preset, opts, filler)
         rep = report()
@@ -241,3 +242,61 @@ def test_weighted_references_pass_when_the_provider_has_no_weighted_entry():
     base, got, rep = run_fade_pair(8, 256, 192, 8, "medium", opts, "oracle", rng=20, slots=32, weighted=False)
     assert got[0] == base[0]
     assert rep["weighted_references"]["pairs_opened_on_weighted_references"] == 0 and rep["verify_mismatches"] == 0
+
+
+# ---- round 4: PU-major planes + windows centred on each CTU's own displacement ------------------------------------------------------
+@pytest.mark.reference
+@pytest.mark.parametrize("depth,preset,ft,min_level,centre,extra", [(8, "slow", 3, 1, 0, [("me", "star")]), (8, "medium", 3, 0, 40, []), (10, "medium", 2, 1, 40, []),
+                                                                    (8, "slower", 2, 0, 0, []), (8, "slow", 3, 1, 57, [("me", "star")]), (10, "slow", 3, 0, 24, [])])
+def test_planes_layout_and_centred_windows_serve_the_same_values(depth, preset, ft, min_level, centre, extra):
+    """X265HIP_STREAM_PLANES (one raster per PU, 16-bit entries saturating) with and without centre_range: every lookup verified against
+    the host primitive, byte-identical bitstream, and the centred +-12 window serves what a +-12 window around (0, 0) cannot on a clip
+    that moves (3, 2) per picture."""
+    EB, SD = _tools()
+    opts = [("pools", "4"), ("frame-threads", str(ft)), ("crf", "24"), ("no-weightp", None), ("no-weightb", None)] + extra
+    base, got, rep = run_pair(depth, 256, 192, 8, preset, opts, "oracle", rng=12, streamed=True, min_level=min_level, slots=32,
+                              layout=SD.LAYOUT_PLANES, centre_range=centre)
+    assert got[0] == base[0], f"seam changed the bitstream: {rep}"
+    assert rep["verify"] == 1 and rep["verify_mismatches"] == 0 and rep["layout"] == "planes" and rep["centre_range"] == centre
+    assert rep["lookups_served"] > (300 if min_level else 1500), rep
+    if depth == 8:
+        assert rep["weighted_references"]["lookups_on_saturated_16_bit_entries"] == 0
+
+
+@pytest.mark.reference
+def test_centred_windows_raise_the_hit_rate_at_equal_window_size():
+    EB, SD = _tools()
+    opts = [("pools", "4"), ("frame-threads", "3"), ("crf", "24"), ("no-weightp", None), ("no-weightb", None), ("me", "star")]
+    rates = {}
+    for centre in (0, 48):
+        base, got, rep = run_pair(8, 256, 192, 8, "slow", opts, "oracle", rng=10, streamed=True, min_level=1, slots=32, layout=SD.LAYOUT_PLANES, centre_range=centre)
+        assert got[0] == base[0] and rep["verify_mismatches"] == 0
+        rates[centre] = rep["lookup_hit_rate"]
+    assert rates[48] > rates[0] + 0.05, rates
+
+
+def test_records_to_planes_twin_layout():
+    """tools/seam_driver.records_to_planes against x265hip_stream_planes_pu_offset's arithmetic (include/x265hip.h) on labelled records."""
+    _, SD = _tools()
+    rng_r, nctu = 5, 2
+    nc = 2 * rng_r + 1
+    ng = (nc + 3) // 4
+    recs = np.zeros((nctu * nc * ng, 85, 4), np.int32)
+    for r in range(recs.shape[0]):
+        for pu in range(85):
+            recs[r, pu] = [(r * 85 + pu) * 4 + k for k in range(4)]
+    recs[3, 70, 2] = 70000                         # saturates
+    for min_level in (0, 1):
+        out = SD.records_to_planes(recs, nctu, rng_r, min_level)
+        assert out.shape == (nctu, SD.planes_ctu_bytes(rng_r, min_level))
+        pitch, n0 = 4 * ng, (0 if min_level else 64)
+        ps, pw = nc * pitch * 2, nc * pitch * 4
+        for ctu, level, z, dy, dx in [(0, 1, 0, 0, 0), (1, 1, 15, 10, 10), (0, 2, 3, 4, 7), (1, 3, 0, 9, 2), (0, 0, 63, 5, 5), (0, 1, 6, 0, 14)]:
+            if level == 0 and min_level:
+                continue
+            pu = [0, 64, 80, 84][level] + z
+            off = z * ps if level == 0 else (n0 + z) * ps if level == 1 else (n0 + 16) * ps + (z if level == 2 else 4) * pw
+            es = 2 if level < 2 else 4
+            got = int(out[ctu, off + (dy * pitch + dx) * es:off + (dy * pitch + dx) * es + es].view(np.uint16 if es == 2 else np.uint32)[0])
+            want = int(recs[(ctu * nc + dy) * ng + dx // 4, pu, dx % 4])
+            assert got == min(want, 65535) if es == 2 else got == want, (min_level, ctu, level, z, dy, dx)

@@ -124,7 +124,7 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
                                                           subpel="gpu" if seam.get("subpel") else None, subpel_slots=seam.get("subpel_slots", 6),
                                                           streamed=bool(seam.get("streamed")), min_level=seam.get("min_level", 0),
                                                           pictures=seam.get("pictures", 24), band_rows=seam.get("band_rows", 0),
-                                                          weighted=seam.get("weighted", True))
+                                                          weighted=seam.get("weighted", True), layout=seam.get("layout", 0), centre_range=seam.get("centre_range", 0))
         t0 = time.perf_counter()
         md5, nbytes, sec, filled = encode(enc_lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
         wall = time.perf_counter() - t0
@@ -172,12 +172,16 @@ def main():
     ap.add_argument("--seam-pictures", type=int, default=24, help="row-granular SAD provider: pictures resident on the device")
     ap.add_argument("--seam-band-rows", type=int, default=0, help="row-granular SAD provider: most CTU rows per search launch (0 = 8)")
     ap.add_argument("--seam-no-sad", action="store_true", help="install no SAD lookup stubs (sub-sample / lookahead seams only)")
+    ap.add_argument("--seam-layout", default="records", choices=["records", "planes"], help="row-granular SAD provider: what lands in host memory - records "
+                    "(all PUs of a displacement together) or PU-major planes (X265HIP_STREAM_PLANES)")
+    ap.add_argument("--seam-centre-range", type=int, default=0, help="row-granular SAD provider: centre every CTU's window on its own displacement, found within +-this (0 = off)")
     ap.add_argument("--seam-no-weighted", action="store_true", help="weighted references pass to the host (the round-3 behaviour), for A/B on a fade")
     ap.add_argument("--seam-subpel-slots", type=int, default=6, help="reference pictures whose phase planes stay in pinned host memory (450 MB each at 4K 8-bit)")
     args = ap.parse_args()
     seam = {"range": args.seam_range, "slots": args.seam_slots, "min_pu": args.seam_min_pu, "verify": args.seam_verify, "lookahead": args.seam_lookahead,
             "subpel": args.seam_subpel, "subpel_slots": args.seam_subpel_slots, "streamed": args.seam_streamed, "min_level": args.seam_min_level,
-            "pictures": args.seam_pictures, "band_rows": args.seam_band_rows, "no_sad": args.seam_no_sad, "weighted": not args.seam_no_weighted}
+            "pictures": args.seam_pictures, "band_rows": args.seam_band_rows, "no_sad": args.seam_no_sad, "weighted": not args.seam_no_weighted,
+            "layout": 1 if args.seam_layout == "planes" else 0, "centre_range": args.seam_centre_range}
     out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s, seam=seam) for k in args.configs.split(",")}
     print(json.dumps({"encoder": out}))
 

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--seam-min-level", type=int, default=1)
     ap.add_argument("--seam-min-pu", type=int, default=16)
     ap.add_argument("--no-lookahead-seam", action="store_true")
+    ap.add_argument("--seam-layout", default="records", choices=["records", "planes"])
+    ap.add_argument("--seam-centre-range", type=int, default=0)
     ap.add_argument("--provider", default="gpu", choices=["gpu", "oracle"], help="oracle = the CPU checker providers (plumbing test of this tool without a GPU)")
     a = ap.parse_args()
     F = importlib.import_module("x265-yuuki-asuna_amd.frames")
@@ -47,7 +49,7 @@ def main():
             opts.append(("lookahead-slices", "1"))
         lib, _, note, closer, _ = SD.install(depth, w, h, provider=a.provider, rng=a.seam_range, slots=24 if depth == 8 else 40, min_pu=a.seam_min_pu, verify=False,
                                              lookahead=None if a.no_lookahead_seam else a.provider, subpel=a.provider, subpel_slots=12, streamed=True,
-                                             min_level=a.seam_min_level, pictures=24)
+                                             min_level=a.seam_min_level, pictures=24, layout=1 if a.seam_layout == "planes" else 0, centre_range=a.seam_centre_range)
         filler = ctypes.cast(lib.x265ref_seam_fill_table_profiled, ctypes.c_void_p)
     lib.x265ref_profile_tsc.restype = ctypes.c_uint64
     t0, c0, tsc0 = time.perf_counter(), time.process_time(), lib.x265ref_profile_tsc()
@@ -68,12 +70,13 @@ def main():
     print(f"  {'(all wrapped primitives)':44s} {inside:8.3f} {100 * inside / cpu:8.1f}%")
     print(f"  {'(encoder code outside the table)':44s} {cpu - inside:8.3f} {100 * (cpu - inside) / cpu:8.1f}%")
     if a.seams:
-        st = (ctypes.c_uint64 * 8)()
+        st = (ctypes.c_uint64 * 12)()
         lib.x265ref_seam_profile_report.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
         lib.x265ref_seam_profile_report(st)
         print("# stages of oracle/ref_seam.cpp, whole (the primitives they call are ALSO in the families above; process CPU includes the providers' worker threads)")
         for i, name in enumerate(("MotionEstimate::motionEstimate (integer search on lookups + sub-sample refinement)", "MotionEstimate::subpelCompare (inside motionEstimate)",
-                                  "CostEstimateGroup::estimateFrameCost (waits for x265hip_lowres_cost_host)", "row hand-over in FrameFilter::processPostRow (memcpy into pinned staging)")):
+                                  "CostEstimateGroup::estimateFrameCost (waits for x265hip_lowres_cost_host)", "row hand-over in FrameFilter::processPostRow (memcpy into pinned staging)",
+                                  "SAD lookups of the integer search (served or passed on; inside motionEstimate)", "context set-up of the motionEstimate wrapper (pair / view look-up)")):
             s_, c_ = st[2 * i] / hz, int(st[2 * i + 1])
             if c_:
                 print(f"  {name:100s} {s_:8.3f} s {100 * s_ / cpu:6.1f}% of CPU {c_:10d} calls {1e9 * s_ / c_:9.0f} ns/call")

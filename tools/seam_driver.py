@@ -265,7 +265,26 @@ PAIR_OPEN_W = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctyp
 PS_OPEN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint)
 PS_ROWS = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
 WEIGHTED_STAT_NAMES = ("pairs_opened_on_weighted_references", "motion_estimate_calls_with_context_on_weighted_references", "lookups_served_on_weighted_references",
-                       "phase_views_opened_on_weighted_references", "subpel_compares_served_from_weighted_views")
+                       "phase_views_opened_on_weighted_references", "subpel_compares_served_from_weighted_views", "lookups_on_saturated_16_bit_entries")
+CENTRES = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
+LAYOUT_RECORDS, LAYOUT_PLANES = 0, 1
+
+
+def planes_ctu_bytes(rng, min_level):
+    """x265hip_stream_planes_ctu_bytes (include/x265hip.h)"""
+    nc = 2 * rng + 1
+    return nc * 4 * ((nc + 3) // 4) * ((0 if min_level else 128) + 32 + 20)
+
+
+def records_to_planes(recs, nctu, rng, min_level):
+    """int32 records [nctu * nc * ng][85][4] -> the PU-major planes layout (X265HIP_STREAM_PLANES) as bytes [nctu][ctu_bytes]: uint16
+    (saturating) rasters of the 8x8 / 16x16 PUs, uint32 rasters of 32x32 / 64x64 - the checker-side twin of csrc/me_stream.hip's kernel"""
+    nc = 2 * rng + 1
+    ng = (nc + 3) // 4
+    v = recs.reshape(nctu, nc, ng, 85, 4).transpose(0, 3, 1, 2, 4).reshape(nctu, 85, nc * ng * 4)
+    lo = np.minimum(v[:, (64 if min_level else 0):80], 65535).astype(np.uint16)
+    hi = v[:, 80:85].astype(np.uint32)
+    return np.concatenate([lo.reshape(nctu, -1).view(np.uint8), hi.reshape(nctu, -1).view(np.uint8)], axis=1)
 
 
 def weight_plane(plane, depth, w):
@@ -289,7 +308,7 @@ class StreamOracleProvider:
     oracle as soon as the reference rows their windows reach are there - synchronously inside the calls.  int32 records; min_level 1
     keeps the 21 PUs of 16x16 and up like the product."""
 
-    def __init__(self, depth, geo, rng, slots, min_level=0):
+    def __init__(self, depth, geo, rng, slots, min_level=0, layout=LAYOUT_RECORDS, centre_range=0):
         import threading
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_api
@@ -299,8 +318,11 @@ class StreamOracleProvider:
         nc = 2 * rng + 1
         self.nc, self.ng = nc, (nc + 3) // 4
         self.rec_words = (21 if min_level else 85) * 4
-        self.row_words = self.ctus_w * nc * self.ng * self.rec_words
+        self.layout, self.centre_range = layout, centre_range
+        self.row_words = self.ctus_w * (planes_ctu_bytes(rng, min_level) // 4 if layout else nc * self.ng * self.rec_words)
         self.surf = [np.zeros(self.row_words * self.ctus_h, np.int32) for _ in range(slots)]
+        self.centres = [np.zeros((self.ctus_w * self.ctus_h, 2), np.int16) for _ in range(slots)] if centre_range else None
+        self.max_c = (min(centre_range, geo["margin_x"] - rng - 12), min(centre_range, geo["margin_y"] - rng - 12))
         self.flags = [np.zeros(self.ctus_h, np.int32) for _ in range(slots)]
         self.pair = [None] * slots               # dict(f, r, gen, next)
         self.gen = [0] * slots
@@ -312,7 +334,8 @@ class StreamOracleProvider:
         self.bands = self.rows_in = 0
         self.lock = threading.Lock()
         self.weighted_pairs = 0
-        self._cb = (PIC_ROWS(self._picture_rows), PAIR_OPEN(self._pair_open), PAIR_OPEN_W(self._pair_open_w), SURFACE(self._surface), READY(self._ready))
+        self._cb = (PIC_ROWS(self._picture_rows), PAIR_OPEN(self._pair_open), PAIR_OPEN_W(self._pair_open_w), SURFACE(self._surface), READY(self._ready),
+                    CENTRES(self._centres))
 
     def _lines(self, r0, n):
         g = self.geo
@@ -365,12 +388,33 @@ class StreamOracleProvider:
             n = r1 - r0
             off = self.org + r0 * 64 * g["stride"]
             ref_plane = pr["plane"] if q["w"] is None else weight_plane(pr["plane"], self.depth, q["w"])      # rows not there yet weight to garbage nobody reads
-            surf, _ = self.O.me_fullsearch(self.depth, pf["plane"], g["stride"], off, ref_plane, g["stride"], off, g["width"], n * 64, self.range,
-                                           0, self.ctus_w * n, zero, zero, want_surf=True, want_best=False)
+            if self.centre_range:
+                # where each CTU's 64x64 block went (minimum SAD of +-centre_range, ties to the first in raster order), clamped: the window's centre
+                zc = np.zeros(2 * self.centre_range + 1, np.uint16)
+                _, best = self.O.me_fullsearch(self.depth, pf["plane"], g["stride"], off, ref_plane, g["stride"], off, g["width"], n * 64, self.centre_range,
+                                               0, self.ctus_w * n, zc, zc, want_surf=False, want_best=True)
+                idx = (best.reshape(-1, 85)[:, 84] & 0xffffffff).astype(np.int64)
+                ncb = 2 * self.centre_range + 1
+                cen = np.stack([np.clip(idx % ncb - self.centre_range, -self.max_c[0], self.max_c[0]),
+                                np.clip(idx // ncb - self.centre_range, -self.max_c[1], self.max_c[1])], axis=1).astype(np.int16)
+                self.centres[slot][r0 * self.ctus_w:r1 * self.ctus_w] = cen
+                parts = []
+                for c in range(self.ctus_w * n):           # one CTU at a time: each has its own window
+                    o = off + (c // self.ctus_w) * 64 * g["stride"] + (c % self.ctus_w) * 64
+                    sc, _ = self.O.me_fullsearch(self.depth, pf["plane"], g["stride"], o, ref_plane, g["stride"], o + int(cen[c, 1]) * g["stride"] + int(cen[c, 0]),
+                                                 64, 64, self.range, 0, 1, zero, zero, want_surf=True, want_best=False)
+                    parts.append(sc)
+                surf = np.concatenate(parts)
+            else:
+                surf, _ = self.O.me_fullsearch(self.depth, pf["plane"], g["stride"], off, ref_plane, g["stride"], off, g["width"], n * 64, self.range,
+                                               0, self.ctus_w * n, zero, zero, want_surf=True, want_best=False)
             recs = surf.reshape(-1, 85, 4)
-            if self.min_level:
-                recs = recs[:, 64:, :]
-            self.surf[slot][r0 * self.row_words:r1 * self.row_words] = recs.reshape(-1)
+            if self.layout:
+                self.surf[slot][r0 * self.row_words:r1 * self.row_words] = records_to_planes(recs, self.ctus_w * n, self.range, self.min_level).reshape(-1).view(np.int32)
+            else:
+                if self.min_level:
+                    recs = recs[:, 64:, :]
+                self.surf[slot][r0 * self.row_words:r1 * self.row_words] = recs.reshape(-1)
             self.flags[slot][r0:r1] = q["gen"]
             q["next"] = r1
             self.bands += 1
@@ -380,6 +424,9 @@ class StreamOracleProvider:
 
     def _ready(self, ctx, slot):
         return self.flags[slot].ctypes.data
+
+    def _centres(self, ctx, slot):
+        return self.centres[slot].ctypes.data if self.centres else None
 
     def pointers(self):
         return (None,) + tuple(ctypes.cast(c, ctypes.c_void_p) for c in self._cb)
@@ -395,7 +442,7 @@ class StreamParams(ctypes.Structure):
     """x265hip_me_stream_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int), ("stride", ctypes.c_ssize_t),
                 ("margin_x", ctypes.c_int), ("margin_y", ctypes.c_int), ("range", ctypes.c_int), ("surf_format", ctypes.c_int), ("min_level", ctypes.c_int),
-                ("slots", ctypes.c_int), ("pictures", ctypes.c_int), ("band_rows", ctypes.c_int)]
+                ("slots", ctypes.c_int), ("pictures", ctypes.c_int), ("band_rows", ctypes.c_int), ("layout", ctypes.c_int), ("centre_range", ctypes.c_int)]
 
 
 class StreamStats(ctypes.Structure):
@@ -406,12 +453,13 @@ class StreamStats(ctypes.Structure):
 class StreamGpuProvider:
     """libx265hip.so's x265hip_me_stream: the product path under frame threads."""
 
-    def __init__(self, depth, geo, rng, slots, min_level=1, pictures=24, band_rows=0):
+    def __init__(self, depth, geo, rng, slots, min_level=1, pictures=24, band_rows=0, layout=LAYOUT_RECORDS, centre_range=0):
         A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
         self.A, self.L = A, A.lib()
         self.format = SURF_PACKED if depth == 8 else SURF_I32
-        self.min_level = min_level
-        p = StreamParams(depth, geo["width"], geo["height"], geo["stride"], geo["margin_x"], geo["margin_y"], rng, self.format, min_level, slots, pictures, band_rows)
+        self.min_level, self.layout, self.centre_range = min_level, layout, centre_range
+        p = StreamParams(depth, geo["width"], geo["height"], geo["stride"], geo["margin_x"], geo["margin_y"], rng, self.format, min_level, slots, pictures, band_rows,
+                         layout, centre_range)
         self.handle = ctypes.c_void_p()
         L = self.L
         L.x265hip_me_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(StreamParams)]
@@ -423,14 +471,16 @@ class StreamGpuProvider:
         L = self.L
         return (self.handle,) + tuple(ctypes.cast(f, ctypes.c_void_p) for f in (L.x265hip_me_stream_picture_rows, L.x265hip_me_stream_pair_open,
                                                                                   L.x265hip_me_stream_pair_open_weighted, L.x265hip_me_stream_surface,
-                                                                                  L.x265hip_me_stream_ready))
+                                                                                  L.x265hip_me_stream_ready, L.x265hip_me_stream_centres))
 
     def report(self):
         st = StreamStats()
         self.L.x265hip_me_stream_stats(self.handle, ctypes.byref(st))
         d = {n: int(getattr(st, n)) for n, _ in StreamStats._fields_}
         d["provider"] = ("x265hip_me_stream (reconstructed CTU rows in as the reference publishes them; every open (picture, reference) pair searched "
-                         "row by row behind the producer; " + ("16x16-and-up record tails" if self.min_level else "whole records") + " downloaded per band)")
+                         "row by row behind the producer; " + ("16x16-and-up " if self.min_level else "all ") +
+                         ("PU-major planes" if self.layout else "records") + " downloaded per band" +
+                         (f"; windows centred on each CTU's displacement within +-{self.centre_range}" if self.centre_range else "") + ")")
         d["surface_mbytes_per_pair"] = round(st.surface_bytes / 1e6, 1)
         d["worker_busy_ms"] = round(st.us_busy / 1e3, 1)
         return d
@@ -591,18 +641,18 @@ class StreamGpuPhaseProvider:
 
 
 def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
-            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True):
+            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0):
     """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
     the picture-granular providers need --frame-threads 1, streamed=True (row-granular providers) serves under any --frame-threads."""
     lib = seam_lib(depth)
     geo = geometry(width, height)
     if streamed:
-        prov = (StreamGpuProvider(depth, geo, rng, slots, min_level, pictures, band_rows) if provider == "gpu"
-                else StreamOracleProvider(depth, geo, rng, slots, min_level))
-        ctx, pic_rows, pair_open, pair_open_w, surface, ready = prov.pointers()
-        lib.x265ref_seam_configure_streamed.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 6 + [ctypes.c_ssize_t] + [ctypes.c_int] * 4
-        rc = lib.x265ref_seam_configure_streamed(ctx, pic_rows, pair_open, pair_open_w if weighted else None, surface, ready, rng, prov.format, min_level, slots,
-                                                 geo["width"], geo["height"],
+        prov = (StreamGpuProvider(depth, geo, rng, slots, min_level, pictures, band_rows, layout, centre_range) if provider == "gpu"
+                else StreamOracleProvider(depth, geo, rng, slots, min_level, layout, centre_range))
+        ctx, pic_rows, pair_open, pair_open_w, surface, ready, centres = prov.pointers()
+        lib.x265ref_seam_configure_streamed.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int] * 7 + [ctypes.c_ssize_t] + [ctypes.c_int] * 4
+        rc = lib.x265ref_seam_configure_streamed(ctx, pic_rows, pair_open, pair_open_w if weighted else None, surface, ready, centres if centre_range else None, layout,
+                                                 rng, prov.format, min_level, slots, geo["width"], geo["height"],
                                                  geo["stride"], geo["margin_x"], geo["margin_y"], min_pu, int(bool(verify)) | (2 if wait else 0))
     else:
         prov = GpuProvider(depth, geo, rng, slots, surf_format) if provider == "gpu" else OracleProvider(depth, geo, rng, slots)
@@ -658,13 +708,13 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     def report():
         d = stats(lib)
         d.update(prov.report())
-        d.update({"range": rng, "slots": slots, "min_pu": min_pu, "row_granular": bool(streamed)})
+        d.update({"range": rng, "slots": slots, "min_pu": min_pu, "row_granular": bool(streamed), "layout": "planes" if layout else "records", "centre_range": centre_range})
         if streamed:
             so4 = (ctypes.c_uint64 * 4)()
             lib.x265ref_seam_stream_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
             lib.x265ref_seam_stream_stats(so4)
             d["row_stream"] = dict(zip(STREAM_STAT_NAMES, [int(v) for v in so4]))
-            so5 = (ctypes.c_uint64 * 5)()
+            so5 = (ctypes.c_uint64 * 6)()
             lib.x265ref_seam_weighted_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
             lib.x265ref_seam_weighted_stats(so5)
             d["weighted_references"] = dict(zip(WEIGHTED_STAT_NAMES, [int(v) for v in so5]))

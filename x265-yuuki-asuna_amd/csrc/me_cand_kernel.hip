@@ -33,6 +33,7 @@ struct MECandArgs
     unsigned long long* best;
     const uint16_t* costX;
     const uint16_t* costY;
+    const int16_t* centres;      // optional [ctu][2], see MEArgs
 };
 
 typedef unsigned long long mc_u64;
@@ -153,7 +154,8 @@ __global__ void __launch_bounds__(256, 2) me_ctu_c_kernel(MECandArgs a)
         for (int i = threadIdx.x; i < 1024; i += blockDim.x)
             srcL[i] = ld_u32(fencCtu + (long)(i >> 4) * a.fencStrideB + 4 * (i & 15));
     {
-        const uint8_t* g0 = a.fref + (long)(cy - R) * a.frefStrideB + (long)(cx - R);
+        const int ccx = a.centres ? a.centres[2 * ctu] : 0, ccy = a.centres ? a.centres[2 * ctu + 1] : 0;
+        const uint8_t* g0 = a.fref + (long)(cy + ccy - R) * a.frefStrideB + (long)(cx + ccx - R);
         for (int r = wave; r < rows; r += nwaves)
         {
             const uint8_t* src = g0 + (long)r * a.frefStrideB;
@@ -424,6 +426,7 @@ int launch_me_cand(const x265hip_me_params* p, hipStream_t s)
     a.pitchB = pitchDw * 4;
     a.surf = (uint8_t*)p->surf; a.best = (unsigned long long*)p->best;
     a.costX = p->cost_x; a.costY = p->cost_y;
+    a.centres = p->centres;
     const int nsteps = (NC * NG + 63) / 64;
     a.stepsPerWave = (nsteps + 3) / 4;
     static const char* const vs = getenv("X265HIP_ME_CAND_VARIANT");          // A/B switch, read once

@@ -36,6 +36,7 @@ struct MEArgs
     unsigned long long* best;     // [ctu][85]
     const uint16_t* costX;
     const uint16_t* costY;
+    const int16_t* centres;      // optional [ctu][2]: the window of CTU c is centred on displacement (centres[2c], centres[2c+1]) instead of (0, 0)
 };
 
 // lane -> 8x8 block coordinates inside the CTU, z-order (quad = one 16x16, 16 lanes = one 32x32)
@@ -84,7 +85,8 @@ __global__ void __launch_bounds__(1024, SURF ? 4 : 8) me_ctu_kernel(MEArgs a)
     constexpr int pitch = PITCH;
 
     // ---- stage the search window: aligned dword copy of each row -------------------------------
-    const uint8_t* g0 = a.fref + (long)(cy - R) * a.frefStrideB + (long)(cx - R) * BPP;
+    const int ccx = a.centres ? a.centres[2 * ctu] : 0, ccy = a.centres ? a.centres[2 * ctu + 1] : 0;
+    const uint8_t* g0 = a.fref + (long)(cy + ccy - R) * a.frefStrideB + (long)(cx + ccx - R) * BPP;
     const int adj = (int)((uintptr_t)g0 & 3);           // identical for every row (stride % 4 == 0)
     const uint8_t* g0a = g0 - adj;
     const int rowDw = a.payloadDw;
@@ -265,7 +267,8 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
     const int nwaves = blockDim.x >> 6;
     constexpr int pitch = PITCH;
 
-    const uint8_t* g0 = a.fref + (long)(cy - R) * a.frefStrideB + (long)(cx - R);
+    const int ccx = a.centres ? a.centres[2 * ctu] : 0, ccy = a.centres ? a.centres[2 * ctu + 1] : 0;
+    const uint8_t* g0 = a.fref + (long)(cy + ccy - R) * a.frefStrideB + (long)(cx + ccx - R);
     const int rowDw = a.payloadDw;
     for (int r = wave; r < rows; r += nwaves)
     {
@@ -489,7 +492,8 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
     const int nwaves = blockDim.x >> 6;
     constexpr int pitch = PITCH;
 
-    const uint8_t* g0 = a.fref + (long)(cy - R) * a.frefStrideB + (long)(cx - R) * 2;
+    const int ccx = a.centres ? a.centres[2 * ctu] : 0, ccy = a.centres ? a.centres[2 * ctu + 1] : 0;
+    const uint8_t* g0 = a.fref + (long)(cy + ccy - R) * a.frefStrideB + (long)(cx + ccx - R) * 2;
     const int rowDw = a.payloadDw;
     for (int r = wave; r < rows; r += nwaves)
     {
@@ -671,6 +675,7 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     const bool anySurf = p->surf != nullptr, anyBest = p->best != nullptr;
     const bool packed = anySurf && p->surf_format == X265HIP_SURF_PACKED;
     a.costX = p->cost_x; a.costY = p->cost_y;
+    a.centres = p->centres;
     const int nctu = a.ctusW * (p->height / 64);
     const size_t lds = (size_t)a.rowBytes * (64 + 2 * p->range + 2);     // + 2 rows the pipeline may prefetch past the window
     if (lds > 160 * 1024) { set_error("me_fullsearch: range %d needs %zu B of LDS (> 160 KiB)", p->range, lds); return X265HIP_EINVAL; }

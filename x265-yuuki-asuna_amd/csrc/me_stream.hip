@@ -17,6 +17,16 @@
 //     compaction kernel between search and download.  An 8x8 SAD on cached pixels costs a host less than a cache-missing lookup;
 //     with the 8x8 level gone a 4K pair at +-32 is 0.47 GB of pinned host memory instead of 1.6 GB.
 //
+//   * layout = X265HIP_STREAM_PLANES (round 4): what lands in host memory is PU-MAJOR - per CTU, one (2R+1) x pitch raster of SADs per
+//     square PU (uint16 for 8x8 / 16x16, saturating; uint32 for 32x32 / 64x64) instead of records that interleave all PUs per
+//     displacement.  A search walks ONE PU over neighbouring displacements: in the record layout every probe is a cache and TLB miss of
+//     its own (1 us per lookup measured inside the real encoder, profiles/r04_encoder_family_profile_seams.txt), in a PU's own raster the
+//     probes of one search share a few lines of a 2 - 5 KB plane.  The transposition runs on the device between search and download.
+//   * centre_range > 0: every CTU's window is centred on the displacement an exhaustive minima-only search of +-centre_range finds for
+//     its 64x64 block (clamped so the window stays inside the margins): a +-R window around where the picture moved covers what a
+//     +-24 window around (0, 0) covered with a fraction of the bytes.  centres[ctu] travels with the row's flag.
+//   * surfaces and flags live in pinned memory backed by transparent huge pages (aligned_alloc + MADV_HUGEPAGE + hipHostRegister).
+//
 // Readers never wait and never lock: surface rows are valid when ready[row] == the pair's generation, checked BEFORE and AFTER the
 // read (a slot that was reopened in between has its flags cleared before any of its rows can be rewritten).  Everything a lookup
 // cannot serve is answered by the host's own primitive with identical values, so the bitstream cannot change.
@@ -30,6 +40,8 @@
 #include <new>
 #include <thread>
 #include <vector>
+#include <cstdlib>
+#include <sys/mman.h>
 
 using namespace x265hip;
 
@@ -46,6 +58,69 @@ __global__ void surf_tail_kernel(const uint4* __restrict__ in, uint4* __restrict
         out[i] = in[r * (size_t)rec16 + (size_t)(rec16 - tail16 + c)];
     }
 }
+
+// records -> PU-major planes (X265HIP_STREAM_PLANES).  in: the band's records [ctu][row][group] of recBytes (packed 720: u16 [80][4] +
+// i32 [5][4]; int32 1360: i32 [85][4]); out: per CTU (ctuBytes apart, the band's first CTU at out) the planes of PUs pu0 .. 84 in
+// order, each nc rows of `pitch` = 4 * ng entries: uint16 (saturating) below PU 80, uint32 from there.  One thread moves the 4
+// displacements of one (CTU, PU, row, group); the group index runs fastest so that the stores of a plane row are contiguous.
+__global__ void __launch_bounds__(256) surf_planes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int nctu, int nc, int ng, int recBytes, int packed, int pu0,
+                                                          size_t ctuBytes)
+{
+    const int npu = 85 - pu0, pitch = 4 * ng;
+    const size_t total = (size_t)nctu * nc * npu * ng;
+    const size_t planeS = (size_t)nc * pitch * 2, planeW = (size_t)nc * pitch * 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    {
+        const int g = (int)(i % ng);
+        size_t t = i / ng;
+        const int pu = pu0 + (int)(t % npu); t /= npu;
+        const int row = (int)(t % nc);
+        const int ctu = (int)(t / nc);
+        const uint8_t* rec = in + (((size_t)ctu * nc + row) * ng + g) * recBytes;
+        uint32_t v[4];
+        if (packed && pu < 80) { const ushort4 q = *reinterpret_cast<const ushort4*>(rec + pu * 8); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+        else
+        {
+            const uint4 q = *reinterpret_cast<const uint4*>(rec + (packed ? 640 + (pu - 80) * 16 : pu * 16));
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        }
+        uint8_t* base = out + (size_t)ctu * ctuBytes;
+        if (pu < 80)
+        {
+            ushort4 o;
+            o.x = (unsigned short)min(v[0], 65535u); o.y = (unsigned short)min(v[1], 65535u); o.z = (unsigned short)min(v[2], 65535u); o.w = (unsigned short)min(v[3], 65535u);
+            *reinterpret_cast<ushort4*>(base + (size_t)(pu - pu0) * planeS + ((size_t)row * pitch + 4 * g) * 2) = o;
+        }
+        else
+            *reinterpret_cast<uint4*>(base + (size_t)(80 - pu0) * planeS + (size_t)(pu - 80) * planeW + ((size_t)row * pitch + 4 * g) * 4) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// centre of every CTU's window = the displacement of its 64x64 block's minimum SAD in the +-big search, clamped to +-maxX / +-maxY
+__global__ void centre_kernel(const unsigned long long* __restrict__ best, int16_t* __restrict__ centres, int nctu, int big, int maxX, int maxY)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nctu) return;
+    const uint32_t idx = (uint32_t)best[(size_t)i * 85 + 84];
+    const int ncb = 2 * big + 1;
+    const int mx = (int)(idx % ncb) - big, my = (int)(idx / ncb) - big;
+    centres[2 * i] = (int16_t)clip3(-maxX, maxX, mx);
+    centres[2 * i + 1] = (int16_t)clip3(-maxY, maxY, my);
+}
+
+// pinned host memory on transparent huge pages: a search's lookups are random reads in hundreds of MB - with 4 KiB pages every one of
+// them also misses the TLB
+void* pinned_huge_alloc(size_t bytes)
+{
+    const size_t n = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+    void* p = aligned_alloc(2u << 20, n);
+    if (!p) return nullptr;
+    (void)madvise(p, n, MADV_HUGEPAGE);
+    memset(p, 0, n);
+    if (hipHostRegister(p, n, hipHostRegisterDefault) != hipSuccess) { free(p); return nullptr; }
+    return p;
+}
+void pinned_huge_free(void* p) { if (p) { (void)hipHostUnregister(p); free(p); } }
 
 // primitives.weight_pp (common/pixel.cpp:518-543) over whole buffer lines, margins included: the plane MotionReference::applyWeight
 // builds row by row (encoder/reference.cpp:119-178: weight_pp on the picture, then the borders replicated) is the reconstructed
@@ -79,10 +154,12 @@ enum { ROW_NONE = 0, ROW_STAGED = 1, ROW_ON_DEVICE = 2 };
 struct x265hip_me_stream
 {
     x265hip_me_stream_params prm;
-    int bpp, ctusW, ctusH, nc, ng, fullRec, rec, device, bandRows, lagRows;
-    size_t planeBytes, rowBytes, fullRowBytes, surfBytes, linePitch;
+    int bpp, ctusW, ctusH, nc, ng, fullRec, rec, device, bandRows, lagRows, planes, centreRange, maxCx, maxCy;
+    size_t planeBytes, rowBytes, fullRowBytes, surfBytes, linePitch, ctuBytes;
     hipStream_t compute = nullptr, copy = nullptr;
-    uint8_t* dScratch = nullptr;            // full records of one band (min_level > 0)
+    uint8_t* dScratch = nullptr;            // full records of one band (min_level > 0 or planes)
+    unsigned long long* dBest = nullptr;    // centre_range: minima of one band's +-centre_range search
+    uint16_t* dZeroCost = nullptr;          // ... searched on SAD alone
     struct Pic
     {
         uint64_t key = 0; bool used = false; uint32_t epoch = 0; uint64_t stamp = 0; int busy = 0;
@@ -95,6 +172,7 @@ struct x265hip_me_stream
     struct Slot
     {
         uint8_t* surf = nullptr; uint8_t* dSurf = nullptr;
+        int16_t* centres = nullptr; int16_t* dCentres = nullptr;      // [ctu][2] (centre_range > 0)
         std::atomic<int>* ready = nullptr;
         int generation = 0;
         int fenc = -1, ref = -1; uint32_t fencEpoch = 0, refEpoch = 0;
@@ -163,15 +241,41 @@ int run_round(S* s, const std::vector<Upload>& ups, const std::vector<Weigh>& we
         const size_t bandOff = (size_t)b.r0 * 64 * s->linePitch;
         x265hip_me_params p;
         memset(&p, 0, sizeof(p));
-        p.depth = s->prm.depth; p.width = s->prm.width; p.height = n * 64; p.range = s->prm.range;
+        p.depth = s->prm.depth; p.width = s->prm.width; p.height = n * 64;
         p.fenc = s->pics[sl.fenc].dev + org + bandOff; p.fenc_stride = s->prm.stride;
         p.fref = s->pics[sl.ref].dev + org + bandOff;  p.fref_stride = s->prm.stride;
+        const int nctuBand = n * s->ctusW;
+        if (s->centreRange)
+        {
+            // where did each CTU go?  minima of the +-centre_range search on SAD alone, the 64x64 block's displacement = the window's centre
+            int rc = x265hip_me_best_reset((uint64_t*)s->dBest, (size_t)nctuBand * 85, s->compute);
+            if (rc) return rc;
+            p.range = s->centreRange; p.best = (uint64_t*)s->dBest; p.cost_x = p.cost_y = s->dZeroCost;
+            rc = x265hip_me_fullsearch(&p, s->compute);
+            if (rc) return rc;
+            hipLaunchKernelGGL(centre_kernel, dim3((nctuBand + 63) / 64), dim3(64), 0, s->compute, (const unsigned long long*)s->dBest,
+                               sl.dCentres + (size_t)b.r0 * s->ctusW * 2, nctuBand, s->centreRange, s->maxCx, s->maxCy);
+            X265HIP_TRY(hipGetLastError());
+            p.best = nullptr; p.cost_x = p.cost_y = nullptr;
+            p.centres = sl.dCentres + (size_t)b.r0 * s->ctusW * 2;
+        }
+        p.range = s->prm.range;
         p.surf_format = s->prm.surf_format;
         uint8_t* dst = sl.dSurf + (size_t)b.r0 * s->rowBytes;
-        p.surf = (int32_t*)(s->prm.min_level ? s->dScratch : dst);
+        const bool staged = s->prm.min_level || s->planes;
+        p.surf = (int32_t*)(staged ? s->dScratch : dst);
         int rc = x265hip_me_fullsearch(&p, s->compute);
         if (rc) return rc;
-        if (s->prm.min_level)
+        if (s->planes)
+        {
+            const size_t total = (size_t)nctuBand * s->nc * (s->prm.min_level ? 21 : 85) * s->ng;
+            size_t blocks = (total + 255) / 256;
+            if (blocks > 16384) blocks = 16384;
+            hipLaunchKernelGGL(surf_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s->compute, (const uint8_t*)s->dScratch, dst, nctuBand, s->nc, s->ng, s->fullRec,
+                               s->prm.surf_format == X265HIP_SURF_PACKED ? 1 : 0, s->prm.min_level ? 64 : 0, s->ctuBytes);
+            X265HIP_TRY(hipGetLastError());
+        }
+        else if (s->prm.min_level)
         {
             const size_t nrec = (size_t)n * s->ctusW * s->nc * s->ng;
             const int rec16 = s->fullRec / 16, tail16 = s->rec / 16;
@@ -183,6 +287,8 @@ int run_round(S* s, const std::vector<Upload>& ups, const std::vector<Weigh>& we
         X265HIP_TRY(hipEventRecord(sl.evSearched, s->compute));
         X265HIP_TRY(hipStreamWaitEvent(s->copy, sl.evSearched, 0));
         X265HIP_TRY(hipMemcpyAsync(sl.surf + (size_t)b.r0 * s->rowBytes, dst, (size_t)n * s->rowBytes, hipMemcpyDeviceToHost, s->copy));
+        if (s->centreRange)
+            X265HIP_TRY(hipMemcpyAsync(sl.centres + (size_t)b.r0 * s->ctusW * 2, sl.dCentres + (size_t)b.r0 * s->ctusW * 2, (size_t)nctuBand * 4, hipMemcpyDeviceToHost, s->copy));
         X265HIP_TRY(hipEventRecord(sl.evDown, s->copy));
         s->bytesDown += (size_t)n * s->rowBytes;
     }
@@ -286,13 +392,17 @@ void free_all(S* s)
     for (auto& p : s->pics) { if (p.stage) (void)hipHostFree(p.stage); if (p.dev) (void)hipFree(p.dev); }
     for (auto& sl : s->slots)
     {
-        if (sl.surf) (void)hipHostFree(sl.surf);
+        pinned_huge_free(sl.surf);
         if (sl.dSurf) (void)hipFree(sl.dSurf);
+        if (sl.centres) (void)hipHostFree(sl.centres);
+        if (sl.dCentres) (void)hipFree(sl.dCentres);
         if (sl.evSearched) (void)hipEventDestroy(sl.evSearched);
         if (sl.evDown) (void)hipEventDestroy(sl.evDown);
         delete[] sl.ready;
     }
     if (s->dScratch) (void)hipFree(s->dScratch);
+    if (s->dBest) (void)hipFree(s->dBest);
+    if (s->dZeroCost) (void)hipFree(s->dZeroCost);
     if (s->compute) (void)hipStreamDestroy(s->compute);
     if (s->copy) (void)hipStreamDestroy(s->copy);
 }
@@ -378,6 +488,9 @@ int x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_pa
     if (p->surf_format != X265HIP_SURF_I32 && !(p->surf_format == X265HIP_SURF_PACKED && p->depth == 8))
     { set_error("me_stream_create: surf_format %d for depth %d (record-contiguous formats only: X265HIP_SURF_PACKED at 8 bits, X265HIP_SURF_I32)", p->surf_format, p->depth); return X265HIP_EINVAL; }
     if (p->min_level < 0 || p->min_level > 1 || p->band_rows < 0) { set_error("me_stream_create: min_level %d / band_rows %d", p->min_level, p->band_rows); return X265HIP_EINVAL; }
+    if (p->layout != X265HIP_STREAM_RECORDS && p->layout != X265HIP_STREAM_PLANES) { set_error("me_stream_create: layout %d", p->layout); return X265HIP_EINVAL; }
+    if (p->centre_range < 0 || (p->centre_range && (p->centre_range < p->range || p->centre_range > 128 || p->margin_x < p->centre_range + 12 || p->margin_y < p->centre_range + 12)))
+    { set_error("me_stream_create: centre_range %d (0, or range .. 128 with margins >= centre_range + 12)", p->centre_range); return X265HIP_EINVAL; }
     S* s = new (std::nothrow) S;
     if (!s) { set_error("me_stream_create: out of memory"); return X265HIP_EINVAL; }
     s->prm = *p;
@@ -388,7 +501,17 @@ int x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_pa
     s->rec = !p->min_level ? s->fullRec : p->surf_format == X265HIP_SURF_I32 ? X265HIP_SURF_TAIL_BYTES_I32 : X265HIP_SURF_TAIL_BYTES_PACKED;
     s->linePitch = (size_t)p->stride * s->bpp;
     s->planeBytes = s->linePitch * (p->height + 2 * p->margin_y);
-    s->rowBytes = (size_t)s->ctusW * s->nc * s->ng * s->rec;
+    s->planes = p->layout == X265HIP_STREAM_PLANES;
+    s->ctuBytes = (size_t)s->nc * s->ng * s->rec;
+    if (s->planes)
+    {
+        s->ctuBytes = x265hip_stream_planes_ctu_bytes(p->range, p->min_level);
+        s->rec = 0;                                           // no records in this layout
+    }
+    s->rowBytes = (size_t)s->ctusW * s->ctuBytes;
+    s->centreRange = p->centre_range;
+    s->maxCx = p->centre_range ? (p->margin_x - p->range - 12 < p->centre_range ? p->margin_x - p->range - 12 : p->centre_range) : 0;
+    s->maxCy = p->centre_range ? (p->margin_y - p->range - 12 < p->centre_range ? p->margin_y - p->range - 12 : p->centre_range) : 0;
     s->fullRowBytes = (size_t)s->ctusW * s->nc * s->ng * s->fullRec;
     s->surfBytes = s->rowBytes * s->ctusH;
     s->bandRows = p->band_rows ? p->band_rows : 8;
@@ -400,7 +523,13 @@ int x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_pa
 #define MS_TRY(expr) do { if (check_hip((expr), #expr)) { free_all(s); delete s; return X265HIP_ENODEV; } } while (0)
     MS_TRY(hipStreamCreateWithFlags(&s->compute, hipStreamNonBlocking));
     MS_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
-    if (p->min_level) MS_TRY(hipMalloc((void**)&s->dScratch, s->fullRowBytes * s->bandRows));
+    if (p->min_level || s->planes) MS_TRY(hipMalloc((void**)&s->dScratch, s->fullRowBytes * s->bandRows));
+    if (s->centreRange)
+    {
+        MS_TRY(hipMalloc((void**)&s->dBest, (size_t)s->bandRows * s->ctusW * 85 * 8));
+        MS_TRY(hipMalloc((void**)&s->dZeroCost, (size_t)(2 * s->centreRange + 8) * 2));
+        MS_TRY(hipMemset(s->dZeroCost, 0, (size_t)(2 * s->centreRange + 8) * 2));
+    }
     s->pics = std::vector<S::Pic>(p->pictures);
     for (auto& pc : s->pics)
     {
@@ -411,8 +540,15 @@ int x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_pa
     s->slots = std::vector<S::Slot>(p->slots);
     for (auto& sl : s->slots)
     {
-        MS_TRY(hipHostMalloc((void**)&sl.surf, s->surfBytes, hipHostMallocDefault));
+        sl.surf = (uint8_t*)pinned_huge_alloc(s->surfBytes);
+        if (!sl.surf) { set_error("me_stream_create: %zu bytes of pinned host memory per slot", s->surfBytes); free_all(s); delete s; return X265HIP_ENODEV; }
         MS_TRY(hipMalloc((void**)&sl.dSurf, s->surfBytes));
+        if (s->centreRange)
+        {
+            MS_TRY(hipHostMalloc((void**)&sl.centres, (size_t)s->ctusW * s->ctusH * 4, hipHostMallocDefault));
+            MS_TRY(hipMalloc((void**)&sl.dCentres, (size_t)s->ctusW * s->ctusH * 4));
+            memset(sl.centres, 0, (size_t)s->ctusW * s->ctusH * 4);
+        }
         MS_TRY(hipEventCreateWithFlags(&sl.evSearched, hipEventDisableTiming));
         MS_TRY(hipEventCreateWithFlags(&sl.evDown, hipEventDisableTiming));
         sl.ready = new std::atomic<int>[s->ctusH];
@@ -524,6 +660,15 @@ const volatile int* x265hip_me_stream_ready(x265hip_me_stream* s, int slot)
 }
 
 int x265hip_me_stream_record_bytes(x265hip_me_stream* s) { return s ? s->rec : 0; }
+
+/* int16 [ctu][2] of the slot: the displacement each CTU's window is centred on (centre_range > 0; NULL otherwise); row r's entries are
+ * valid while ready[r] == the pair's generation, like its surfaces */
+const int16_t* x265hip_me_stream_centres(x265hip_me_stream* s, int slot)
+{
+    return (s && slot >= 0 && slot < (int)s->slots.size()) ? s->slots[slot].centres : nullptr;
+}
+
+size_t x265hip_me_stream_ctu_bytes(x265hip_me_stream* s) { return s ? s->ctuBytes : 0; }
 
 int x265hip_me_stream_stats(x265hip_me_stream* s, x265hip_me_stream_stats_t* st)
 {

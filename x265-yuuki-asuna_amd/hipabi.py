@@ -30,6 +30,7 @@ class MEParams(ctypes.Structure):
         ("surf", ctypes.c_void_p), ("best", ctypes.c_void_p),
         ("cost_x", ctypes.c_void_p), ("cost_y", ctypes.c_void_p),
         ("surf_format", ctypes.c_int),
+        ("centres", ctypes.c_void_p),
     ]
 
 
@@ -185,7 +186,7 @@ def _p(t):
 
 def me_fullsearch(depth, width, height, rng, fenc, fenc_stride, fref, fref_stride,
                   surf=None, best=None, cost_x=None, cost_y=None,
-                  fenc_off=0, fref_off=0, stream=None, surf_format=SURF_I32):
+                  fenc_off=0, fref_off=0, stream=None, surf_format=SURF_I32, centres=None):
     """fenc/fref: torch tensors holding the planes; *_off = element offset of pixel (0,0)."""
     es = 1 if depth == 8 else 2
     p = MEParams()
@@ -195,6 +196,7 @@ def me_fullsearch(depth, width, height, rng, fenc, fenc_stride, fref, fref_strid
     p.fref, p.fref_stride = fref.data_ptr() + fref_off * es, fref_stride
     p.surf, p.best = _p(surf), _p(best)
     p.cost_x, p.cost_y = _p(cost_x), _p(cost_y)
+    p.centres = _p(centres)
     s = current_stream() if stream is None else stream
     check(lib().x265hip_me_fullsearch(ctypes.byref(p), s), "x265hip_me_fullsearch")
 
