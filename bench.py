@@ -348,11 +348,12 @@ def main():
                     help="skip the encoder-level leg (tier T3): the REAL reference encoder (oracle/_ref) on BASELINE configs[2] - 4K, preset slow, "
                          "--me star - with its own C table and with the stage-level seams (integer-search SADs from x265hip_me_cache surfaces, the "
                          "lookahead's frame cost / intra estimates from x265hip_lowres_cost_host / x265hip_lowres_intra_host); fps + bitstream md5")
-    ap.add_argument("--encoder", default="cfg3", help="configurations of the encoder-level leg (tools/encoder_bench.py: cfg1,cfg2,cfg3,cfg4)")
-    ap.add_argument("--encoder-frames", type=int, default=48, help="frames of the encoder-level leg: more than the 25-picture lookahead of preset slow, "
-                    "so that the lookahead runs ahead of the frame encoders the way it does in a real encode")
-    ap.add_argument("--encoder-frame-threads", type=int, default=5, help="--frame-threads of both encoder legs (5 = the reference's own choice for 16 "
-                    "cores; the two search seams need 1 and step aside otherwise, the lookahead seam serves at any value)")
+    ap.add_argument("--encoder", default="cfg3,cfg3f,cfg4,cfg2", help="configurations of the encoder-level leg (tools/encoder_bench.py: cfg1,cfg2,cfg3,cfg3f,cfg4); the "
+                    "default shows BASELINE configs[2] (the metric's), the same on a fade (weighted references), configs[3] (10-bit) and configs[1] (1080p)")
+    ap.add_argument("--encoder-frames", type=int, default=0, help="frames of every encoder-level leg (0 = per configuration: 48 for cfg3 - more than the "
+                    "25-picture lookahead of preset slow, so that the lookahead runs ahead of the frame encoders the way it does in a real encode - 24 for cfg3f / cfg4, 96 for cfg2)")
+    ap.add_argument("--encoder-frame-threads", type=int, default=0, help="--frame-threads of the encoder legs (0 = what x265 picks itself for 16 cores at that "
+                    "picture size: 5 at 4K, 3 at 1080p; the row-granular seams serve at any value)")
     ap.add_argument("--encoder-tables", default="c,seam", help="c = reference C table, seam = + x265hip_me_cache lookups, hip = per-call stubs (slow)")
     ap.add_argument("--prims", action="store_true",
                     help="instead of the pipeline line, print the per-family table of the batch-layer kernels with the CPU paths timed beside "
@@ -631,26 +632,42 @@ def main():
                 sys.path.insert(0, ROOT)
                 from tools import encoder_bench as EB
                 enc = {}
+                ENC_DEFAULTS = {"cfg3": (48, 5), "cfg3f": (24, 5), "cfg4": (24, 5), "cfg2": (96, 3), "cfg1": (8, 1), "cfg5": (3, 5)}       # frames, --frame-threads
                 for key in args.encoder.split(","):
-                    ft = args.encoder_frame_threads
-                    # round 3: the row-granular providers (x265hip_me_stream / x265hip_phase_stream, fed where the reference raises
-                    # m_reconRowFlag) serve the SAD lookups and the sub-sample comparisons under the reference's own frame threads
-                    enc[key] = EB.run_config(key, args.encoder_tables.split(","), args.encoder_frames, ft, 120.0, log=sys.stderr,
-                                             seam={"range": 24, "slots": 24 if CFG_DEPTH.get(key, 8) == 8 else 40, "min_pu": 16, "verify": False, "lookahead": True,
-                                                   "subpel": True, "subpel_slots": 12, "streamed": True, "min_level": 1, "pictures": 24})
+                    nf, ft = ENC_DEFAULTS.get(key, (24, 5))
+                    nf, ft = args.encoder_frames or nf, args.encoder_frame_threads or ft
+                    # round 3: the row-granular providers (x265hip_me_stream / x265hip_phase_stream, fed where the reference raises m_reconRowFlag) serve
+                    # the SAD lookups and the sub-sample comparisons under the reference's own frame threads.  Round 4: PU-major planes, windows of
+                    # +-12 centred on each CTU's own displacement (found within +-57 = the reference's merange), weighted references served, the
+                    # lookahead seam gated by picture size inside the binding (4K and up)
+                    enc[key] = EB.run_config(key, args.encoder_tables.split(","), nf, ft, 120.0, log=sys.stderr,
+                                             seam={"range": 12, "centre_range": 57, "layout": 1, "slots": 24 if CFG_DEPTH.get(key, 8) == 8 else 40, "min_pu": 16, "verify": False,
+                                                   "lookahead": True, "subpel": True, "subpel_slots": 12, "streamed": True, "min_level": 1, "pictures": 24})
                 out["encoder"] = enc
-                c3 = enc.get("cfg3", {})
-                if "c" in c3:
-                    out["encoder_summary"] = {"workload": c3["config"], "frames": c3["c"]["frames"], "frame_threads": args.encoder_frame_threads,
-                                              "reference_c_table_fps": c3["c"]["fps"], "cores": c3["pool_threads"],
-                                              "seam_fps": c3.get("seam", {}).get("fps"), "seam_md5_equal": c3.get("seam", {}).get("md5_equal_to_c_table"),
-                                              **{k: c3.get("seam", {}).get("seam", {}).get(k) for k in ("motion_estimate_calls", "calls_with_lookup_context", "lookups_served",
-                                                                                                       "lookup_hit_rate")},
-                                              "subpel_compares_served": c3.get("seam", {}).get("seam", {}).get("subpel_seam", {}).get("subpel_compares_served"),
-                                              "frame_cost_estimates_served": c3.get("seam", {}).get("seam", {}).get("lookahead_seam", {}).get("frame_cost_estimates_served"),
-                                              "seams": "row-granular SAD lookups (x265hip_me_stream) + sub-sample comparisons (x265hip_phase_stream) + lookahead frame costs "
-                                                       "(x265hip_lowres_cost_host), all under the reference's own frame threads",
-                                              "kind": "reference (x265 3.5 C primitives, no asm: nasm is not in the image)"}
+
+                def leg(key):
+                    c = enc.get(key, {})
+                    if "c" not in c:
+                        return None
+                    sm = c.get("seam", {})
+                    rep = sm.get("seam", {})
+                    return {"workload": c["config"], "frames": c["c"]["frames"], "frame_threads": int(c["options"]["frame-threads"]), "cores": c["pool_threads"],
+                            "reference_c_table_fps": c["c"]["fps"], "seam_fps": sm.get("fps"), "seam_md5_equal": sm.get("md5_equal_to_c_table"),
+                            "gain": round(sm["fps"] / c["c"]["fps"], 3) if sm.get("fps") else None,
+                            **{k: rep.get(k) for k in ("motion_estimate_calls", "calls_with_lookup_context", "lookups_served", "lookup_hit_rate", "bytes_downloaded")},
+                            "subpel_compares_served": rep.get("subpel_seam", {}).get("subpel_compares_served"),
+                            "phase_bytes_downloaded": rep.get("subpel_seam", {}).get("bytes_downloaded"),
+                            "frame_cost_estimates_served": rep.get("lookahead_seam", {}).get("frame_cost_estimates_served"),
+                            "frame_cost_estimates_left_to_the_reference_by_the_size_gate": rep.get("lookahead_seam", {}).get("left_to_the_reference_by_the_size_gate"),
+                            "weighted_references": rep.get("weighted_references")}
+                c3 = leg("cfg3")
+                if c3:
+                    out["encoder_summary"] = {**c3,
+                                              "seams": "row-granular SAD lookups (x265hip_me_stream: PU-major planes, +-12 windows centred on each CTU's displacement) + sub-sample "
+                                                       "comparisons (x265hip_phase_stream views, weighted references included) + lookahead frame costs (x265hip_lowres_cost_host, "
+                                                       "4K and up), all under the reference's own frame threads",
+                                              "kind": "reference (x265 3.5 C primitives, no asm: nasm is not in the image)",
+                                              "other_configs": {k: leg(k) for k in enc if k != "cfg3" and leg(k)}}
             except BaseException as e:       # incl. SystemExit from a missing oracle/_ref
                 out["encoder"] = {"error": repr(e)}
         print(json.dumps(out))

@@ -114,6 +114,11 @@ struct LookaheadSeam
     la_intra_oracle_fn intraOracle = NULL;
     std::atomic<uint64_t> served{0}, passed{0}, failed{0}, intraServed{0}, mismatches{0};
     uint64_t instance = 0;          /* bumped by every configure: a frame number names a picture's content only within one encode */
+    /* A frame cost estimate is one latency-bound walk on the device (1.3 ms at 4K against 49 ms of one host thread; 2.9 ms against a few ms
+     * at 1080p, where the seam LOSES 10 %, profiles/r03_encoder_other_configs.txt): pictures with fewer 8x8 lowres blocks than this go to
+     * the reference's own loop.  16384 lies between 1080p (8160) and 4K (32400); x265ref_lookahead_seam_min_blocks overrides (tests: 0). */
+    int minBlocks = 16384;
+    std::atomic<uint64_t> gated{0};
 } gla;
 
 /* measurement aid (tools/encoder_profile.py --seams): cycles inside the wrapped stages, next to ref_profile.cpp's per-family thunks */
@@ -906,9 +911,10 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
     Lowres* fenc = m_frames[b];
     x265_param* param = m_lookahead.m_param;
     const bool cached = fenc->costEst[b - p0][p1 - b] >= 0 && fenc->rowSatds[b - p0][p1 - b][0] != -1;
-    if (!gla.enabled || cached || param->bEnableHME || (!m_batchMode && m_lookahead.m_numCoopSlices > 1) || param->rc.qgSize == 8)
+    const bool small = m_lookahead.m_8x8Width * m_lookahead.m_8x8Height < gla.minBlocks;
+    if (!gla.enabled || cached || small || param->bEnableHME || (!m_batchMode && m_lookahead.m_numCoopSlices > 1) || param->rc.qgSize == 8)
     {
-        if (gla.enabled && !cached) gla.passed.fetch_add(1, std::memory_order_relaxed);
+        if (gla.enabled && !cached) (small ? gla.gated : gla.passed).fetch_add(1, std::memory_order_relaxed);
         return x265ref_orig_estimateFrameCost(this, &tld, p0, p1, b, bIntraPenalty);
     }
     bool bDoSearch[2];
@@ -1027,7 +1033,7 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
  * angular scan of every 8x8 block) as one provider call; the AQ weighting and the sums are the reference's own lines :779-803. */
 void LookaheadTLD::lowresIntraEstimate(Lowres& fenc, uint32_t qgSize)
 {
-    if (!gla.enabled || (!gla.intraHost && !gla.intraOracle)) { x265ref_orig_lowresIntraEstimate(this, &fenc, qgSize); return; }
+    if (!gla.enabled || (!gla.intraHost && !gla.intraOracle) || widthInCU * heightInCU < gla.minBlocks) { x265ref_orig_lowresIntraEstimate(this, &fenc, qgSize); return; }
     const int intraPenalty = 5 * (int)x265_lambda_tab[X265_LOOKAHEAD_QP];
     int rc = 0;
     if (gla.intraHost)
@@ -1227,7 +1233,7 @@ int x265ref_lookahead_seam_configure(void* host_fn, void* oracle_fn, void* intra
     gla.oracle = (la_oracle_fn)oracle_fn;
     gla.intraHost = (la_intra_host_fn)intra_host_fn;
     gla.intraOracle = (la_intra_oracle_fn)intra_oracle_fn;
-    gla.served = 0; gla.passed = 0; gla.failed = 0; gla.intraServed = 0; gla.mismatches = 0;
+    gla.served = 0; gla.passed = 0; gla.failed = 0; gla.intraServed = 0; gla.mismatches = 0; gla.gated = 0;
     gla.instance++;
     gla.enabled = host_fn || oracle_fn;
     return 0;
@@ -1236,6 +1242,9 @@ int x265ref_lookahead_seam_configure(void* host_fn, void* oracle_fn, void* intra
 /* out[4]: frame cost estimates served by the provider, passed to the reference's loop (HME / cooperative slices / qg 8), failed,
  * intra estimates served */
 void x265ref_lookahead_seam_stats(uint64_t* out) { out[0] = gla.served; out[1] = gla.passed; out[2] = gla.failed; out[3] = gla.intraServed; }
+/* pictures with fewer lowres 8x8 blocks than this keep the reference's own loop (default 16384: the seam serves from 4K up); returns the
+ * number of estimates the gate has sent there since the last configure */
+uint64_t x265ref_lookahead_seam_min_blocks(int min_blocks) { if (min_blocks >= 0) gla.minBlocks = min_blocks; return gla.gated; }
 uint64_t x265ref_lookahead_seam_mismatches(void) { return gla.mismatches; }
 
 /* table filler with the x265hip_setup_primitives signature: installs the lookup stubs over the host's own sad family */

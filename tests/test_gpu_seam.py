@@ -630,3 +630,37 @@ def test_row_granular_seams_on_the_gpu_with_planes_and_centred_windows(depth, pr
     assert rep["lookups_served"] > (300 if min_level else 1500) and sub["subpel_compares_served"] > 1000, rep
     if fade:
         assert rep["weighted_references"]["lookups_served_on_weighted_references"] > 100, rep
+
+
+def test_4k_preset_slow_star_frame_threads_5_every_served_value_verified_in_flight():
+    """The size and options the metric is quoted on (BASELINE configs[2]: 3840x2160, --preset slow --me star, the reference's own
+    --frame-threads 5), all three seams as bench.py's encoder leg configures them - and every served SAD, every served sub-sample
+    comparison and every frame cost estimate re-evaluated in flight by the host's own function (the reference's contract
+    check(ref.slot, opt.slot), test/testbench.cpp:181-233, at full size; round-3 verdict, next 3).  The timed leg runs unverified: an
+    md5 alone would also pass with a provider that silently served nothing."""
+    import test_seam_cpu as T
+    from tools import encoder_bench as EB, seam_driver as SD
+    try:
+        plain = EB.ref_lib(8)
+        SD.seam_lib(8)
+    except (SystemExit, FileNotFoundError):
+        pytest.skip("oracle/_ref not built (it travels to the GPU box with the snapshot)")
+    w, h, n = 3840, 2160, 8
+    clip = F.synth_clip(w, h, n, depth=8, seed=265)
+    yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
+    opts = [("pools", str(EB.effective_cpus())), ("frame-threads", "5"), ("crf", "28"), ("me", "star"), ("lookahead-slices", "1")]
+    base = EB.encode(plain, yuv, w, h, n, "slow", opts)
+    lib, filler, report, close, prov = SD.install(8, w, h, provider="gpu", rng=12, slots=24, min_pu=16, verify=True, lookahead="gpu+verify", subpel="gpu", subpel_slots=12,
+                                                  streamed=True, min_level=1, pictures=24, layout=SD.LAYOUT_PLANES, centre_range=57, lookahead_min_blocks=None)
+    try:
+        got = EB.encode(lib, yuv, w, h, n, "slow", opts, filler)
+        rep = report()
+    finally:
+        close()
+    assert got[0] == base[0], f"seams changed the bitstream: {rep}"
+    sub, la = rep["subpel_seam"], rep["lookahead_seam"]
+    assert rep["verify"] == 1 and rep["verify_mismatches"] == 0 and sub["verify_mismatches"] == 0 and la["verify_mismatches"] == 0, rep
+    assert rep["failed"] == 0 and sub["failed"] == 0 and la["failed"] == 0
+    assert rep["lookups_served"] > 1_000_000 and sub["subpel_compares_served"] > 500_000 and la["frame_cost_estimates_served"] >= 20, rep
+    assert la["left_to_the_reference_by_the_size_gate"] == 0          # 4K is above the binding's size gate
+    assert rep["lookup_hit_rate"] > 0.85, rep

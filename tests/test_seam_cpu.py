@@ -300,3 +300,27 @@ def test_records_to_planes_twin_layout():
             got = int(out[ctu, off + (dy * pitch + dx) * es:off + (dy * pitch + dx) * es + es].view(np.uint16 if es == 2 else np.uint32)[0])
             want = int(recs[(ctu * nc + dy) * ng + dx // 4, pu, dx % 4])
             assert got == min(want, 65535) if es == 2 else got == want, (min_level, ctu, level, z, dy, dx)
+
+
+@pytest.mark.reference
+def test_lookahead_seam_size_gate_leaves_small_pictures_to_the_reference():
+    """The binding's own gate (16384 lowres blocks: the seam pays from 4K up): a 256x192 encode configured WITHOUT an explicit
+    threshold must serve no frame cost estimate - and count what the gate passed on."""
+    opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24"), ("lookahead-slices", "1")]
+    EB, SD = _tools()
+    try:
+        plain = EB.ref_lib(8)
+        SD.seam_lib(8)
+    except (SystemExit, FileNotFoundError):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    clip = F.synth_clip(256, 192, 6, depth=8, seed=41)
+    yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
+    base = EB.encode(plain, yuv, 256, 192, 6, "medium", opts)
+    lib, filler, report, close, prov = SD.install(8, 256, 192, provider="oracle", rng=16, slots=16, verify=True, streamed=True, lookahead="oracle", lookahead_min_blocks=None)
+    try:
+        got = EB.encode(lib, yuv, 256, 192, 6, "medium", opts, filler)
+        rep = report()
+    finally:
+        close()
+    la = rep["lookahead_seam"]
+    assert got[0] == base[0] and la["frame_cost_estimates_served"] == 0 and la["intra_estimates_served"] == 0 and la["left_to_the_reference_by_the_size_gate"] > 5, la

@@ -641,7 +641,7 @@ class StreamGpuPhaseProvider:
 
 
 def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
-            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0):
+            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0):
     """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
     the picture-granular providers need --frame-threads 1, streamed=True (row-granular providers) serves under any --frame-threads."""
     lib = seam_lib(depth)
@@ -665,6 +665,10 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     # the lookahead seam (CostEstimateGroup::estimateFrameCost's block loop as one provider call): "gpu" = x265hip_lowres_cost_host,
     # "oracle" = the CPU restatement (checker; GPU-less tests), None = off.  Needs --lookahead-slices 1.
     lib.x265ref_lookahead_seam_configure.argtypes = [ctypes.c_void_p] * 4
+    lib.x265ref_lookahead_seam_min_blocks.argtypes = [ctypes.c_int]
+    lib.x265ref_lookahead_seam_min_blocks.restype = ctypes.c_uint64
+    # the binding's own gate (16384 lowres blocks: serve from 4K up) unless the caller names a threshold; tests on small pictures pass 0
+    lib.x265ref_lookahead_seam_min_blocks(16384 if lookahead_min_blocks is None else lookahead_min_blocks)
     keep = None
     if lookahead in ("gpu", "gpu+verify"):
         A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
@@ -722,7 +726,8 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
         lib.x265ref_lookahead_seam_stats(la)
         lib.x265ref_lookahead_seam_mismatches.restype = ctypes.c_uint64
         d["lookahead_seam"] = {"provider": lookahead, "frame_cost_estimates_served": int(la[0]), "passed_to_reference_loop": int(la[1]), "failed": int(la[2]),
-                               "intra_estimates_served": int(la[3]), "verify_mismatches": int(lib.x265ref_lookahead_seam_mismatches())}
+                               "intra_estimates_served": int(la[3]), "verify_mismatches": int(lib.x265ref_lookahead_seam_mismatches()),
+                               "left_to_the_reference_by_the_size_gate": int(lib.x265ref_lookahead_seam_min_blocks(-1))}
         if sub:
             so = (ctypes.c_uint64 * 6)()
             lib.x265ref_subpel_seam_stats(so)
