@@ -25,7 +25,9 @@
 //   * centre_range > 0: every CTU's window is centred on the displacement an exhaustive minima-only search of +-centre_range finds for
 //     its 64x64 block (clamped so the window stays inside the margins): a +-R window around where the picture moved covers what a
 //     +-24 window around (0, 0) covered with a fraction of the bytes.  centres[ctu] travels with the row's flag.
-//   * surfaces and flags live in pinned memory backed by transparent huge pages (aligned_alloc + MADV_HUGEPAGE + hipHostRegister).
+//     (Surfaces stay in hipHostMalloc memory: aligned_alloc + MADV_HUGEPAGE + hipHostRegister measured no faster per lookup -
+//     tools/ubench/host_lookup.hip, profiles/r04_host_lookup_ubench.txt - and two GPU-suite runs with registered user memory ended in
+//     values that did not verify; the runs before and after, on hipHostMalloc, are clean.)
 //
 // Readers never wait and never lock: surface rows are valid when ready[row] == the pair's generation, checked BEFORE and AFTER the
 // read (a slot that was reopened in between has its flags cleared before any of its rows can be rewritten).  Everything a lookup
@@ -41,7 +43,6 @@
 #include <thread>
 #include <vector>
 #include <cstdlib>
-#include <sys/mman.h>
 
 using namespace x265hip;
 
@@ -107,20 +108,6 @@ __global__ void centre_kernel(const unsigned long long* __restrict__ best, int16
     centres[2 * i] = (int16_t)clip3(-maxX, maxX, mx);
     centres[2 * i + 1] = (int16_t)clip3(-maxY, maxY, my);
 }
-
-// pinned host memory on transparent huge pages: a search's lookups are random reads in hundreds of MB - with 4 KiB pages every one of
-// them also misses the TLB
-void* pinned_huge_alloc(size_t bytes)
-{
-    const size_t n = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
-    void* p = aligned_alloc(2u << 20, n);
-    if (!p) return nullptr;
-    (void)madvise(p, n, MADV_HUGEPAGE);
-    memset(p, 0, n);
-    if (hipHostRegister(p, n, hipHostRegisterDefault) != hipSuccess) { free(p); return nullptr; }
-    return p;
-}
-void pinned_huge_free(void* p) { if (p) { (void)hipHostUnregister(p); free(p); } }
 
 // primitives.weight_pp (common/pixel.cpp:518-543) over whole buffer lines, margins included: the plane MotionReference::applyWeight
 // builds row by row (encoder/reference.cpp:119-178: weight_pp on the picture, then the borders replicated) is the reconstructed
@@ -392,7 +379,7 @@ void free_all(S* s)
     for (auto& p : s->pics) { if (p.stage) (void)hipHostFree(p.stage); if (p.dev) (void)hipFree(p.dev); }
     for (auto& sl : s->slots)
     {
-        pinned_huge_free(sl.surf);
+        if (sl.surf) (void)hipHostFree(sl.surf);
         if (sl.dSurf) (void)hipFree(sl.dSurf);
         if (sl.centres) (void)hipHostFree(sl.centres);
         if (sl.dCentres) (void)hipFree(sl.dCentres);
@@ -540,8 +527,7 @@ int x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_pa
     s->slots = std::vector<S::Slot>(p->slots);
     for (auto& sl : s->slots)
     {
-        sl.surf = (uint8_t*)pinned_huge_alloc(s->surfBytes);
-        if (!sl.surf) { set_error("me_stream_create: %zu bytes of pinned host memory per slot", s->surfBytes); free_all(s); delete s; return X265HIP_ENODEV; }
+        MS_TRY(hipHostMalloc((void**)&sl.surf, s->surfBytes, hipHostMallocDefault));
         MS_TRY(hipMalloc((void**)&sl.dSurf, s->surfBytes));
         if (s->centreRange)
         {
@@ -554,6 +540,7 @@ int x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_pa
         sl.ready = new std::atomic<int>[s->ctusH];
         for (int r = 0; r < s->ctusH; r++) sl.ready[r].store(0);
     }
+    MS_TRY(hipDeviceSynchronize());          // the zero fill above is queued on the null stream; the worker's streams do not order with it
 #undef MS_TRY
     s->worker = std::thread(worker_main, s);
     *out = s;

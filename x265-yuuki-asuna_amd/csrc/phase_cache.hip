@@ -169,6 +169,7 @@ int x265hip_phase_cache_create(x265hip_phase_cache** out, const x265hip_phase_ca
             PC_TRY(hipHostMalloc((void**)&s.out[i], c->chromaBytes * 63, hipHostMallocDefault));
         }
     }
+    PC_TRY(hipDeviceSynchronize());          // the zero fill of dSrc is queued on the null stream; the worker's stream does not order with it
 #undef PC_TRY
     c->worker = std::thread(pc_worker, c);
     *out = c;

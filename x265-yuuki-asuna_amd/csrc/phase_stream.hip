@@ -347,6 +347,10 @@ int x265hip_phase_stream_create(x265hip_phase_stream** out, const x265hip_phase_
             PS_TRY(hipHostMalloc((void**)&sl.out[i], s->planeBytes[k] * s->nph[k], hipHostMallocDefault));
         }
     }
+    // hipMemset returns before a DEVICE memset has run (it is queued on the null stream), and the worker's stream is non-blocking: an
+    // upload of the first rows could be overtaken by the zero fill queued before it (seen as planes that intermittently did not equal
+    // the whole-picture planes when other work sat in front of the memsets, round 4) - wait for the fills here, once
+    PS_TRY(hipDeviceSynchronize());
 #undef PS_TRY
     s->worker = std::thread(ps_worker, s);
     *out = s;
