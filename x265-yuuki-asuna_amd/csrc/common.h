@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <mutex>
 
 #include "x265hip.h"
 
@@ -25,6 +26,7 @@ void set_error(const char* fmt, ...);
 int  check_hip(hipError_t e, const char* what);   // 0 or X265HIP_ENODEV with last-error text
 int  ensure_device();                             // lazy x265hip_init(-1): validates the calling thread's current device
 void* stream_scratch(hipStream_t s, int slot, size_t bytes);   // runtime.hip: grow-only scratch per (device, stream, slot), NULL on failure
+std::unique_lock<std::mutex> stream_sequence_lock(hipStream_t s);   // runtime.hip: hold it while enqueuing a clear-then-launch sequence that uses stream_scratch
 
 // csrc/phase_kernels.hip: the launch behind x265hip_phase_planes with the distance between phase planes as a parameter (bands)
 int  phase_planes_launch(int depth, int chroma, const void* src, void* dst, intptr_t stride, int rows, size_t plane_bytes, hipStream_t s);

@@ -20,6 +20,7 @@
 // first, so the wait cannot starve (the ordering decoupled look-back scans rely on).  The frame sums meet in agent-scope accumulators; the
 // last band to arrive writes them out.  Same integers as the one-workgroup walk, which stays in charge of batches.
 #include "pu_eval.h"
+#include <atomic>
 
 namespace x265hip {
 
@@ -431,10 +432,21 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     // 2.78 ms with 8, 2.88 with 5 - profiles/r03_lowres_cost_counters.txt), a workgroup = a compute unit each; batches keep one
     // workgroup per picture (the chip is full anyway).  X265HIP_LOWRES_COST_SPLIT=<bands> forces the number (1 = never split; tests, A/B runs).
     int K = 1;
+    // A split launch's bands SPIN on the band below them (tagged words through L2); forward progress rests on the lower bands being
+    // dispatched first, which an ordinary launch does not promise once the chip is full of other spinners.  At most kMaxSplitInFlight split
+    // launches are in flight per process (counted at enqueue, released by a host callback behind the launch); above that an estimate runs
+    // as one workgroup per picture - slower, never stuck (round-3 advisor).  The A/B switch is read once.
+    static const char* const splitEnv = getenv("X265HIP_LOWRES_COST_SPLIT");
+    static std::atomic<int> splitInFlight{0};
+    constexpr int kMaxSplitInFlight = 8;                                // 8 x 16 bands = half the CUs at most wait on a neighbour
+    bool counted = false;
     {
-        const char* e = getenv("X265HIP_LOWRES_COST_SPLIT");
-        if (e) K = atoi(e);
-        else if (p->height_in_cu >= 32 && p->npairs <= 4) K = (p->height_in_cu + 7) / 8;
+        if (splitEnv) K = atoi(splitEnv);
+        else if (p->height_in_cu >= 32 && p->npairs <= 4)
+        {
+            if (splitInFlight.fetch_add(1) < kMaxSplitInFlight) { K = (p->height_in_cu + 7) / 8; counted = true; }
+            else splitInFlight.fetch_sub(1);
+        }
         if (K > 16) K = 16;
         if (K > p->height_in_cu) K = p->height_in_cu;
         if (K < 1) K = 1;
@@ -464,8 +476,10 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     a.cost = p->cost_q + p->qoff;
     a.bFrameBias = p->bframe_bias;
     a.K = K; a.R = R; a.sync = nullptr;
+    std::unique_lock<std::mutex> seq;                 // split: clear + launch are one sequence per stream (round-3 advisor)
     if (split)
     {
+        seq = stream_sequence_lock(s);
         const size_t sb = split_sync_words(K, p->width_in_cu) * 8 * (size_t)p->npairs;
         a.sync = (unsigned long long*)stream_scratch(s, 1, sb);
         if (!a.sync) return X265HIP_ENODEV;
@@ -479,6 +493,11 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     else if (!bidir) LRC_GO(uint16_t, false);
     else LRC_GO(uint16_t, true);
 #undef LRC_GO
+    if (counted)
+    {
+        if (split && hipLaunchHostFunc(s, [](void* c) { static_cast<std::atomic<int>*>(c)->fetch_sub(1); }, &splitInFlight) == hipSuccess) counted = false;
+        if (counted) splitInFlight.fetch_sub(1);                       // not split after all (or no callback could be queued): nothing to wait for
+    }
     X265HIP_TRY(hipGetLastError());
     if (!p->pairs_on_device) X265HIP_TRY(hipFreeAsync(dpairs, s));
     return 0;

@@ -73,7 +73,8 @@ enum { NCCL_UINT8 = 1 };      // ncclUint8 / ncclChar family: rccl.h ncclDataTyp
 
 } // namespace
 
-static int publish(const x265hip_recon_publish_params* p, int npeers, const int* peers, void* stream)
+// mode: 0 = broadcast over the whole communicator, 1 = point to point (the producer sends to peers[0 .. npeers), anyone else receives from root)
+static int publish(const x265hip_recon_publish_params* p, int mode, int npeers, const int* peers, void* stream)
 {
     if (!p || !p->comm || !p->plane[0]) { set_error("recon_publish_rows: NULL communicator / plane"); return X265HIP_EINVAL; }
     if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("recon_publish_rows: depth %d", p->depth); return X265HIP_EINVAL; }
@@ -106,7 +107,7 @@ static int publish(const x265hip_recon_publish_params* p, int npeers, const int*
     if (e) { set_error("recon_publish_rows: ncclGroupStart failed: %d (%s)", e, g_rccl.errStr ? g_rccl.errStr(e) : "?"); return X265HIP_ENODEV; }
     for (int i = 0; i < ns && !e; i++)
     {
-        if (npeers == 0) e = g_rccl.bcast(sl[i].ptr, sl[i].ptr, sl[i].bytes, NCCL_UINT8, p->root, p->comm, s);            // one-to-many over the whole communicator
+        if (mode == 0) e = g_rccl.bcast(sl[i].ptr, sl[i].ptr, sl[i].bytes, NCCL_UINT8, p->root, p->comm, s);            // one-to-many over the whole communicator
         else if (p->rank == p->root)                                                                                          // producer -> each of its consumers: xGMI is point to point,
             for (int k = 0; k < npeers && !e; k++) e = g_rccl.send(sl[i].ptr, sl[i].bytes, NCCL_UINT8, peers[k], p->comm, s); //   a picture with k consumers needs k links, all in one group
         else e = g_rccl.recv(sl[i].ptr, sl[i].bytes, NCCL_UINT8, p->root, p->comm, s);                                       // a consumer's side
@@ -122,17 +123,23 @@ static int publish(const x265hip_recon_publish_params* p, int npeers, const int*
 
 extern "C" int x265hip_recon_publish_rows(const x265hip_recon_publish_params* p, void* stream)
 {
-    if (p && p->peer >= 0) { const int peer = p->peer; return publish(p, 1, &peer, stream); }
-    return publish(p, 0, nullptr, stream);
+    if (p && p->peer >= 0) { const int peer = p->peer; return publish(p, 1, 1, &peer, stream); }
+    return publish(p, 0, 0, nullptr, stream);
 }
 
 /* the producer's band to SEVERAL consumers (a picture that is the reference of several in-flight pictures: preset slow has 4 references
  * and B pictures) as one group of point-to-point sends; a consumer calls it with rank != root and receives from root (peers ignored) */
 extern "C" int x265hip_recon_publish_rows_to(const x265hip_recon_publish_params* p, int npeers, const int* peers, void* stream)
 {
-    if (npeers < 1 || npeers > 16 || !peers) { set_error("recon_publish_rows_to: %d peers", npeers); return X265HIP_EINVAL; }
-    for (int k = 0; k < npeers; k++) if (peers[k] < 0) { set_error("recon_publish_rows_to: peer %d", peers[k]); return X265HIP_EINVAL; }
-    return publish(p, npeers, peers, stream);
+    // only the producer's peer list means anything; a consumer may pass (0, NULL) as documented and is routed to the receive branch, never
+    // to the broadcast one (round-3 advisor)
+    const bool producer = p && p->rank == p->root;
+    if (producer)
+    {
+        if (npeers < 1 || npeers > 16 || !peers) { set_error("recon_publish_rows_to: %d peers", npeers); return X265HIP_EINVAL; }
+        for (int k = 0; k < npeers; k++) if (peers[k] < 0) { set_error("recon_publish_rows_to: peer %d", peers[k]); return X265HIP_EINVAL; }
+    }
+    return publish(p, 1, producer ? npeers : 0, producer ? peers : nullptr, stream);
 }
 
 /* Communicator plumbing for a host that has no RCCL binding of its own (one process per GPU): rank 0 makes the 128-byte id, the host

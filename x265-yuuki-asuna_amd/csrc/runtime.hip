@@ -4,6 +4,7 @@
 #include "common.h"
 
 #include <map>
+#include <vector>
 #include <mutex>
 
 #include <atomic>
@@ -81,24 +82,68 @@ int ensure_device()
 // A grow-only device buffer per (device, stream, slot) for entry points that need a few KB of stream-ordered scratch on every call.  Calls
 // on one stream are ordered, so the next call may reuse the buffer; hipMallocAsync / hipFreeAsync per call kept the host from running
 // ahead of the device on this runtime (the pattern-search step took twice its stage sum, round-2 verdict).  Returns NULL on failure
-// (set_error holds the reason).  Buffers live until the process ends; growing one frees the old buffer (a device-wide wait, rare).
+// (set_error holds the reason).  Round 4 (round-3 advisor):
+//   * the ENQUEUE SEQUENCE of such an entry (clear the scratch, launch the kernels that use it) must not interleave with another
+//     thread's sequence on the same stream - two threads on the NULL stream could queue memset A, memset B, kernel A, kernel B.  The
+//     entries hold stream_sequence_lock(stream) while they enqueue; stream order then serialises the users of the buffer.
+//   * a buffer that was handed out is never freed: growing retires the old one (it may be baked into a captured graph);
+//   * a stream that is CAPTURING (torch.cuda.graph captures on a stream of its own, and allocation is prohibited there) adopts a spare
+//     buffer: every allocation made outside capture leaves one spare of its size behind, so the launch-by-launch warm-up that precedes a
+//     capture provides it.  No spare = an error that says so, not an allocation inside the capture.
+namespace {
+struct ScratchKey { int dev; hipStream_t s; int slot; bool operator<(const ScratchKey& o) const { return dev != o.dev ? dev < o.dev : (s != o.s ? s < o.s : slot < o.slot); } };
+struct ScratchBuf { void* p; size_t n; };
+std::mutex g_scratchMu;
+std::map<ScratchKey, ScratchBuf> g_scratch;
+std::map<std::pair<int, int>, std::vector<ScratchBuf>> g_scratchSpare;      // (device, slot) -> buffers no stream owns yet
+std::map<std::pair<int, hipStream_t>, std::mutex> g_seqMu;
+}
+
+std::unique_lock<std::mutex> stream_sequence_lock(hipStream_t s)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::mutex* m;
+    {
+        std::lock_guard<std::mutex> lk(g_scratchMu);
+        m = &g_seqMu[std::make_pair(dev, s)];              // std::map never moves its nodes
+    }
+    return std::unique_lock<std::mutex>(*m);
+}
+
 void* stream_scratch(hipStream_t s, int slot, size_t bytes)
 {
-    struct Key { int dev; hipStream_t s; int slot; bool operator<(const Key& o) const { return dev != o.dev ? dev < o.dev : (s != o.s ? s < o.s : slot < o.slot); } };
-    struct Buf { void* p; size_t n; };
-    static std::mutex mu;
-    static std::map<Key, Buf> bufs;
     int dev = 0;
     if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    Buf& b = bufs[Key{ dev, s, slot }];
-    if (b.n < bytes)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s) (void)hipStreamIsCapturing(s, &cap);
+    const bool capturing = cap == hipStreamCaptureStatusActive;
+    std::lock_guard<std::mutex> lk(g_scratchMu);
+    ScratchBuf& b = g_scratch[ScratchKey{ dev, s, slot }];
+    if (b.n >= bytes) return b.p;
+    const size_t want = (bytes + 4095) & ~(size_t)4095;
+    std::vector<ScratchBuf>& spare = g_scratchSpare[std::make_pair(dev, slot)];
+    for (size_t i = 0; i < spare.size(); i++)
+        if (spare[i].n >= want)
+        {
+            b = spare[i];                                    // the old buffer of this key (if any) stays allocated: graphs may hold it
+            spare.erase(spare.begin() + i);
+            if (!capturing)
+            {
+                ScratchBuf extra = { nullptr, b.n };         // leave a spare behind for the next stream that starts inside a capture
+                if (hipMalloc(&extra.p, extra.n) == hipSuccess) spare.push_back(extra);
+            }
+            return b.p;
+        }
+    if (capturing)
     {
-        if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.n = 0; }
-        const size_t want = (bytes + 4095) & ~(size_t)4095;
-        if (check_hip(hipMalloc(&b.p, want), "hipMalloc(stream scratch)")) { b.p = nullptr; return nullptr; }
-        b.n = want;
+        set_error("stream scratch: the stream is capturing and no buffer of %zu bytes was prepared - run the entry once outside the capture first (a warm-up on any stream leaves a spare)", want);
+        return nullptr;
     }
+    ScratchBuf fresh = { nullptr, want }, extra = { nullptr, want };
+    if (check_hip(hipMalloc(&fresh.p, want), "hipMalloc(stream scratch)")) return nullptr;
+    if (hipMalloc(&extra.p, want) == hipSuccess) spare.push_back(extra);
+    b = fresh;                                               // a smaller buffer this key held before is retired, not freed
     return b.p;
 }
 

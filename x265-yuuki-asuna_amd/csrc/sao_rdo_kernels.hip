@@ -18,6 +18,7 @@
 // Entropy::resetBits keeps (entropy.cpp:2442-2451); context bins cost the HOST's per-state table (g_entropyBits, handed in - like the
 // mv cost tables it is never recomputed here), bypass bins 32768; the state-transition table is derived from H.265 table 9-46.
 #include "common.h"
+#include <atomic>
 
 #include <cstdlib>
 #include <type_traits>
@@ -934,8 +935,12 @@ extern "C" int x265hip_sao_rdo(const x265hip_sao_rdo_params* p, void* stream)
     const int threads = second ? threads2 : ((p->ctus_h + 63) / 64 * 3 + 4) * 64;          // decision / merge-left / merge-up lanes per CTU row + four copy wavefronts
     const size_t lds = second ? lds2 : (size_t)2 * p->ctus_h * sizeof(SaoCtuCand) + (size_t)2 * p->ctus_h * 3 * sizeof(SaoP) + (size_t)p->ctus_h * 2 * sizeof(long long);
     if (lds > 150 * 1024) { set_error("sao_rdo: %d CTU rows need %zu bytes of LDS", p->ctus_h, lds); return X265HIP_EUNSUPPORTED; }
-    static bool ldsRaised = false;
-    if (lds > 48 * 1024 && !ldsRaised)
+    // the attribute takes effect per DEVICE: one flag per device ordinal (a process may drive several GPUs; round-3 advisor)
+    static std::atomic<bool> ldsRaisedDev[64];
+    int devOrd = 0;
+    (void)hipGetDevice(&devOrd);
+    std::atomic<bool>& ldsRaised = ldsRaisedDev[devOrd & 63];
+    if (lds > 48 * 1024 && !ldsRaised.load())
     {
         X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         X265HIP_TRY(hipFuncSetAttribute((const void*)sao_rdo_rows_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

@@ -699,7 +699,9 @@ extern "C" int x265hip_me_search(const x265hip_me_search_params* p, void* stream
     a.mvc = p->mvc; a.numMvc = p->num_mvc;
     for (int k = 0; k < 12; k++) a.integral[k] = p->integral[k];
     hipStream_t s = (hipStream_t)stream;
-    // scratch of this stream: [0] = number of large jobs, [1..] = their indices
+    // scratch of this stream: [0] = number of large jobs, [1..] = their indices.  Another thread on the same stream must not queue its clear between
+    // this call's clear and kernels: the sequence is enqueued under the stream's sequence lock (round-3 advisor)
+    const std::unique_lock<std::mutex> seq = stream_sequence_lock(s);
     int* scratch = (int*)stream_scratch(s, 0, sizeof(int) * ((size_t)p->njobs + 1));
     if (!scratch) return X265HIP_ENODEV;
     X265HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(int), s));
