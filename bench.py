@@ -244,19 +244,40 @@ def load_traffic(width, height, rng_r, fmt):
 
 
 def load_stage_traffic(width, height, depth):
-    """Per-kernel HBM traffic and duration of the default step's launches from the committed PMC summary (profiles/stage_traffic.json,
-    made by tools/pmc_to_traffic.py from profiles/rNN_bench_pmc.txt + rNN_bench_kernel_stats.txt): the physical roofline fraction of
-    every stage kernel, weakest first.  Only valid for the configuration the profile was taken on (3840x2160 8-bit)."""
-    if (width, height, depth) != (3840, 2160, 8):
-        return None
+    """Per-kernel HBM traffic, duration and matrix-core occupancy of the default step's launches from the committed PMC summaries
+    (profiles/stage_traffic.json, made by tools/pmc_to_traffic.py from profiles/rNN_bench_pmc*.txt + rNN_bench_kernel_stats*.txt): the
+    physical roofline fraction of every stage kernel, weakest first.  One entry per (picture size, bit depth) a profile was taken on
+    (round 4: 4K 8-bit, 4K 10-bit, 8K 10-bit - BASELINE configs[2], [3], [4]); None for any other configuration."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "stage_traffic.json")))
     except (OSError, ValueError):
         return None
+    t = t.get("configs", {}).get(f"{width}x{height}_d{depth}") if "configs" in t else (t if (width, height, depth) == (3840, 2160, 8) else None)
+    if not t:
+        return None
     rows = [{"kernel": k, "hbm_bytes": v["fetch_bytes"] + v["write_bytes"], "avg_us": v["avg_us"], "gbytes_per_s": v["gbytes_per_s"],
-             "frac_traffic": v["frac_of_8tb"]} for k, v in t["kernels"].items()]
+             "frac_traffic": v["frac_of_8tb"], **({"mfma_busy_frac": v["mfma_busy_frac"]} if v.get("mfma_busy_frac") is not None else {})}
+            for k, v in t["kernels"].items()]
     rows.sort(key=lambda r: r["frac_traffic"])
-    return {"source": t["source"], "peak_gbytes_per_s": HBM_PEAK_GBS, "kernels": rows}
+    return {"source": t["source"], "peak_gbytes_per_s": HBM_PEAK_GBS, "kernels": rows,
+            "mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 1024 SIMDs): the share of the matrix cores' issue capacity the kernel's int8-limb "
+                              "DCT / iDCT products occupy (north_star: DCT MFMA utilisation)"}
+
+
+def valu_bound(nctu, rng_r, depth, launch_ms):
+    """The search kernels are bound by VALU issue, not by HBM (round-3 verdict, weak 2): the SAD instruction stream alone - one
+    v_qsad_pk_u16_u8 per 16 pixel-candidates per lane at 8 bits, one v_sad_u16 per 2 at 16 bits - priced at the issue cost the
+    microbenchmark measures for that instruction ALONE (tools/ubench/valu_rates.hip, OPs 17 - 19; profiles/valu_rates.json), on 1024 SIMDs."""
+    try:
+        v = json.load(open(os.path.join(ROOT, "profiles", "valu_rates.json")))
+    except (OSError, ValueError):
+        return None
+    nc = 2 * rng_r + 1
+    cand = nctu * 4096 * nc * (4 * ((nc + 3) // 4))            # pixel-candidates (motion-vector columns come in groups of four)
+    per, ns, name = (16, v["v_qsad_pk_u16_u8_ns"], "v_qsad_pk_u16_u8") if depth == 8 else (2, v["v_sad_u16_ns"], "v_sad_u16")
+    floor_ms = cand / per / 64 / 1024 * ns * 1e-6
+    return {"bound": "valu", "instruction": name, "pixel_candidates": cand, "ns_per_wave_instruction_per_simd": ns, "floor_ms": round(floor_ms, 4),
+            "frac": round(floor_ms / launch_ms, 4), "source": v.get("source")}
 
 
 # One MI355X, 3840x2160 8-bit, three band streams (profiles/r02_band_size.txt; bands of 5 rows and more with the record-per-lane search
@@ -304,7 +325,12 @@ def main():
     ap.add_argument("--level", type=int, default=2)           # 32x32 blocks in the reconstruction stage
     ap.add_argument("--qp", type=int, default=27)
     ap.add_argument("--depth", type=int, default=8, choices=[8, 10], help="10 = the Main10 configurations (configs[3], [4])")
-    ap.add_argument("--no-surface", action="store_true", help="ME keeps only the best mv (no SAD surfaces)")
+    ap.add_argument("--surface", action="store_true",
+                    help="the search launch also WRITES the SAD surfaces of all 85 PUs (11.9 GB algorithmic / 4.9 GB physical per 4K picture, rounds 1 - 3's default). "
+                         "Nothing in this closed loop reads them - its stages consume the per-PU minima - so since round 4 the default search keeps the minima only "
+                         "(round-3 verdict, next 6: stop writing bytes nobody reads); the surfaces are the product of the consumer services (x265hip_me_stream), "
+                         "measured in the encoder leg")
+    ap.add_argument("--no-surface", action="store_true", help="(the default since round 4; kept so that older command lines still parse)")
     ap.add_argument("--sharding", choices=["ring", "gop"], default="ring",
                     help="N > 1: ring = the reference's frame parallelism with its real dependency (frame f on rank f %% N searches frame f - 1, "
                          "handed on band by band; DESIGN.md section 6); gop = every rank encodes its own closed group of pictures with its own "
@@ -412,7 +438,7 @@ def main():
     clip = F.synth_clip(args.width, args.height, nclip, depth=args.depth, seed=265 + rank)
     pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
     pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
-                           qp=args.qp, want_surf=not args.no_surface, packed=({"packed": True, "packed_t": "t", "packed_b": "b"}.get(args.surf_format, False) if args.depth == 8 else False),
+                           qp=args.qp, want_surf=args.surface, packed=({"packed": True, "packed_t": "t", "packed_b": "b"}.get(args.surf_format, False) if args.depth == 8 else False),
                            lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True, lookahead_cost_batch=args.lookahead_batch,
                            chroma=True, sao_apply=True, sign_hide=True, subpel_planes=bool(args.subpel_planes),
                            parallel_planes=bool(args.parallel_planes), split=args.split, sao_rdo=sao_rdo)
@@ -425,7 +451,7 @@ def main():
     if banded:
         # N > 1: the reference's real frame-parallel dependency - frame f (rank f % N) searches frame f - 1, band by band (pipeline.FrameParallelRing)
         bp = S.BandedFramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, band_rows=args.band_rows, rng=args.range, subme=args.subme, level=args.level,
-                                   qp=args.qp, want_surf=not args.no_surface,
+                                   qp=args.qp, want_surf=args.surface,
                                    # a small band's grid (4 CTU rows = 240 workgroups) is too small for the record-per-lane kernel's 4-wavefront
                                    # workgroups (one per CU): such bands use the record-contiguous packed format of the row-walking kernel;
                                    # from 5 rows on the record-per-lane kernel wins (6 rows: 2.58 against 2.81 ms per picture)
@@ -461,6 +487,12 @@ def main():
         if transport is None:
             ring.make_groups(device=dev)
         total_frames = (args.warmup + args.steps) * world
+        ranks_seen = 1
+        if world > 1:
+            # diagnostics for the first hardware runs (round-3 verdict, next 8): how many ranks does the collective layer really see?
+            seen = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(seen)
+            ranks_seen = int(seen.item())
         bp.begin_frame(pics[1])                         # allocates the output planes
         if args.band_graphs:                            # set-up: every (band, source picture) of the resident clip recorded as a HIP graph
             for pc in pics[1:]:
@@ -491,6 +523,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if banded and world > 1:
+        ring.time_waits()                            # two device events per band: how long its stream waits for the reference rows it reads
     pipe.launch_lookahead_costs()                    # no lookahead work of the warm-up frames leaks into the timed region
     torch.cuda.synchronize()
     # The interpreter's cycle collector is parked for the timed loop: one full collection over torch's object graph is a 30 - 60 ms
@@ -518,6 +552,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     gc.enable()
+    ring_wait = None
+    if banded and world > 1:                         # every rank: the maximum over ranks is a collective
+        wms, _ = ring.wait_ms()
+        wt = torch.tensor([wms / max(1, args.steps)], dtype=torch.float64, device=dev)
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        ring_wait = round(float(wt.item()), 4)
     if banded:
         csum = {"recon_%s" % n: int(p.view(torch.uint8).to(torch.int64).sum().item()) for n, p in zip(("y", "cb", "cr"), bp.final_planes())}
     else:
@@ -568,6 +608,10 @@ def main():
         dom = "me"
         alg_bytes = ms.algorithmic_bytes(bpp=1 if args.depth == 8 else 2)
         achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9
+        if args.search != "full":
+            # a pattern search visits a data-dependent handful of the window's candidates: the exhaustive search's algorithmic bytes do not
+            # describe it and no per-launch figure of its own exists - no fraction is printed (round-3 verdict, weak 6 ii)
+            alg_bytes = achieved = None
         traffic, tsrc = load_traffic(args.width, args.height, args.range, (('packed_b' if ms.blocked else ('packed_t' if ms.tiled else 'packed')) if ms.packed else 'i32') + ('' if args.depth == 8 else '_d10')) if surf_mode else (None, None)
         out = {
             "metric": "encoded fps + bit-exact check, 4K preset=slow, 1/2/4/8 MI355X vs host AVX2",
@@ -601,15 +645,26 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "me_search_kernel" if args.search != "full" else
                                    (("me_ctu_c_kernel" if surf_mode and (ms.tiled or ms.blocked) else "me_ctu_q_kernel") if args.depth == 8 else "me_ctu_w_kernel")
                                    + ("<surf,best>" if surf_mode else "<best>"),
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                         "achieved": round(achieved, 2) if achieved is not None else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved is not None else None, "traffic": traffic, "traffic_source": tsrc,
                          # the PHYSICAL fraction beside the contractual one: HBM bytes the counters saw / the live launch time / peak.
                          # `frac` prices SURVEY 8(d)'s algorithmic bytes (window re-reads that LDS serves, 4 B per candidate where the
                          # packed records hold 2.14) - it is the contract's number, this one is what the memory system really carries
                          "frac_traffic": round(traffic / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "output_bytes_per_launch": ms.hbm_floor_bytes(1 if args.depth == 8 else 2),
-                         "launch_ms": stages[dom]},
+                         "launch_ms": stages[dom],
+                         # what really bounds the kernel: the issue rate of its SAD instructions (the contract's `bound` can only say hbm | mfma)
+                         "valu": valu_bound(ms.nctu, args.range, args.depth, stages[dom]) if args.search == "full" else None,
+                         **({"note": "the launch keeps the per-PU minima only (default since round 4): its algorithmic bytes are the window reads + 8 bytes per PU; "
+                                     "rounds 1 - 3 quoted 0.90 - 0.92 on a launch that also wrote 11.9 GB (algorithmic) of SAD surfaces nothing in the loop read "
+                                     "(--surface brings it back)"} if args.search == "full" and not surf_mode else {})},
         }
+        if ring_wait is not None:
+            out["config"]["ring"] = {"ranks_seen": ranks_seen, "transport": transport_name, "bands_per_frame": len(bp.bands), "refs": 1,
+                                     "communicators": world if transport_name == "abi" else 0,
+                                     "band_wait_ms_per_frame_max_over_ranks": ring_wait,
+                                     "note": "band_wait = device time the bands' streams spent waiting for the reference rows they read (two events per band); "
+                                             "ranks_seen = all-reduce of ones over the job's process group"}
         sr = load_stage_traffic(args.width, args.height, args.depth)
         if sr:
             out["stages_roofline"] = sr

@@ -19,6 +19,7 @@ def _worker(rank, world, port, out):
     F = importlib.import_module("x265-yuuki-asuna_amd.frames")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     fp = P.FrameParallel(rank, world)
     clip = F.synth_clip(128, 64, 6, seed=77)            # same clip on every rank
@@ -104,6 +105,7 @@ def _ring_worker(rank, world, port, steps, out, staged=False, with_context=False
     P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     w64, h64, lag = 128, 448, 72                     # 7 CTU rows, bands of 2: (0,2) (2,2) (4,2) (6,1); a window of 57 + 8 + taps < 72 rows
     bands = [(r, min(2, 7 - r)) for r in range(0, 7, 2)]
@@ -194,6 +196,7 @@ def _ring_worker_refs(rank, world, port, steps, refs, out):
     P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)                    # `world` processes share this box's cores: no intra-op thread pools on top of them
     dist.init_process_group("gloo", rank=rank, world_size=world)
     w64, h64, lag = 128, 448, 72
     bands = [(r, min(2, 7 - r)) for r in range(0, 7, 2)]
@@ -224,7 +227,7 @@ def _ring_worker_refs(rank, world, port, steps, refs, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,refs", [(2, 2), (3, 2), (4, 2)])
+@pytest.mark.parametrize("world,refs", [(2, 2), (3, 2), (4, 2), (8, 2)])
 def test_ring_with_several_reference_pictures(world, refs):
     """Frame f on rank f % world reads frames f - 1 .. f - refs: every finished band goes to the ranks of the next `refs` frames (two
     consumers per band with refs = 2), each consumer waits band by band for every reference it reads; the frames must equal the serial
@@ -232,9 +235,10 @@ def test_ring_with_several_reference_pictures(world, refs):
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29950 + (os.getpid() % 200) + 7 * world + refs
-    mp.spawn(_ring_worker_refs, args=(world, port, 3, refs, out), nprocs=world, join=True)
+    steps = 3 if world < 8 else 2               # every rank also computes the serial chain it is compared with: world^2 frames of Python
+    mp.spawn(_ring_worker_refs, args=(world, port, steps, refs, out), nprocs=world, join=True)
     assert all(out[r][0] for r in range(world)), {r: out[r] for r in range(world)}
-    assert out[world - 1][1] == [world - 1 + k * world for k in range(3)]
+    assert out[world - 1][1] == [world - 1 + k * world for k in range(steps)]
 
 
 def test_band_size_follows_the_rank_count():

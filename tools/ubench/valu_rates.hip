@@ -1,3 +1,7 @@
+// (round 4) OPs 17 - 19 repeat the three SAD instructions WITHOUT the `| 1` on an operand: rounds 1 - 3 read "8.8 cycles per v_sad_u8 / u16, 25.3 per
+// v_qsad_pk_u16_u8" off OPs 0 - 2, but every one of those iterations also issues the v_or_b32 (two for the 64-bit quad-SAD operand), i.e. the plain-VALU
+// cost of 4.4 cycles on top.  The 10-bit search ran FASTER than the "floor" computed from 8.8 (2.67 ms against 2.89 ms, profiles/r04_bench_variants.txt),
+// which is how the mistake was found.
 // Micro-benchmark: issue rate of the packed-SAD VALU instructions on gfx950 (cycles per wave-instruction
 // per SIMD), to size the motion-search kernels.  One workgroup of 256 threads per CU (1 wave / SIMD)
 // and 4 waves / SIMD variants.  Build: hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates
@@ -43,6 +47,9 @@ __global__ void k(uint32_t* out, uint32_t seed)
                                 a[i] = __builtin_bit_cast(uint32_t, (v2s)(x * y + z)); }                  // v_pk_mad_i16
                 if (OP == 15) a[i] = __builtin_amdgcn_udot4(a[(i + 1) & 7], b, a[i], false);
                 if (OP == 16) a[i] = a[i] + a[(i + 1) & 7] + b;                                          // v_add3_u32
+                if (OP == 17) a[i] = __builtin_amdgcn_sad_u8(a[(i + 1) & 7], b, a[i]);
+                if (OP == 18) a[i] = __builtin_amdgcn_sad_u16(a[(i + 1) & 7], b, a[i]);
+                if (OP == 19) q[i] = __builtin_amdgcn_qsad_pk_u16_u8(q[(i + 1) & 7], b, q[i]);
             }
     }
     long long t1 = __builtin_readcyclecounter();
@@ -79,11 +86,13 @@ int main()
             run<4>("v_alignbit", 256); run<5>("v_sad_hi_u8", 256); run<6>("v_msad_u8", 256); run<7>("dpp add", 256);
             run<8>("v_dot4_i32_i8", 256); run<9>("v_dot2_i32_i16", 256); run<10>("v_mad_i32_i24", 256); run<11>("v_alignbyte", 256);
             run<12>("v_perm_b32", 256); run<13>("mul_lo_u32 + add", 256); run<14>("v_pk_mad_i16", 256); run<15>("v_dot4_u32_u8", 256); run<16>("v_add3_u32", 256);
+            run<17>("v_sad_u8 alone", 256); run<18>("v_sad_u16 alone", 256); run<19>("v_qsad_pk_u16_u8 alone", 256);
         } else {
             run<0>("v_sad_u8", 1024); run<1>("v_sad_u16", 1024); run<2>("v_qsad_pk_u16_u8", 1024); run<3>("v_add+xor (2 ops)", 1024);
             run<4>("v_alignbit", 1024); run<5>("v_sad_hi_u8", 1024); run<6>("v_msad_u8", 1024); run<7>("dpp add", 1024);
             run<8>("v_dot4_i32_i8", 1024); run<9>("v_dot2_i32_i16", 1024); run<10>("v_mad_i32_i24", 1024); run<11>("v_alignbyte", 1024);
             run<12>("v_perm_b32", 1024); run<13>("mul_lo_u32 + add", 1024); run<14>("v_pk_mad_i16", 1024); run<15>("v_dot4_u32_u8", 1024); run<16>("v_add3_u32", 1024);
+            run<17>("v_sad_u8 alone", 1024); run<18>("v_sad_u16 alone", 1024); run<19>("v_qsad_pk_u16_u8 alone", 1024);
         }
     }
     return 0;

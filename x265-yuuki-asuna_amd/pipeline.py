@@ -459,6 +459,20 @@ class FrameParallelRing:
         self.prev, self.next = (rank - 1) % world, (rank + 1) % world
         self.transport = transport if transport is not None else DistTransport(rank, world, stage_through_host)
         self._sends = []
+        self.wait_events = None             # time_waits(): (before, after) device events around every band's wait for its reference rows
+
+    def time_waits(self, on=True):
+        """Diagnostics for the first hardware runs (round-3 verdict, next 8): how long does a band's stream sit waiting for the reference
+        rows it needs?  Two device events per band on the band's own stream; wait_ms() sums them."""
+        self.wait_events = [] if on else None
+
+    def wait_ms(self):
+        """(total ms the bands' streams waited for reference rows since time_waits(), number of bands timed)"""
+        import torch
+        if not self.wait_events:
+            return 0.0, 0
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in self.wait_events)), len(self.wait_events)
 
     def frame_index(self, step: int) -> int:
         return step * self.world + self.rank
@@ -525,11 +539,19 @@ class FrameParallelRing:
             if 1 in posted:
                 post(1, need)                               # the newest reference: just ahead of the band that needs it
             with (band_context(b) if band_context is not None else contextlib.nullcontext()):
+                timed = self.wait_events is not None and srcs
+                if timed:
+                    import torch
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 for d in srcs:
                     while arrived[d] < need:
                         arrived[d] += 1
                         for w in pending[d].pop(arrived[d]):
                             w.wait()
+                if timed:
+                    e1.record()
+                    self.wait_events.append((e0, e1))
                 process_band(b, row0, n)
                 if peers:
                     self._sends += T.send(out_planes, self._rows(geom, row0, n, b == 0, b == nb - 1), (row0, n), peers)
