@@ -280,17 +280,18 @@ def valu_bound(nctu, rng_r, depth, launch_ms):
             "frac": round(floor_ms / launch_ms, 4), "source": v.get("source")}
 
 
-# One MI355X, 3840x2160 8-bit, three band streams (profiles/r02_band_size.txt; bands of 5 rows and more with the record-per-lane search
-# kernel): milliseconds per picture against the CTU rows per band.
-# Small bands cost launches whose grids no longer fill the chip; large bands make the next rank wait longer for its first reference rows.
-BANDED_STEP_MS = {1: 5.11, 2: 3.37, 3: 3.16, 4: 2.78, 5: 2.83, 6: 2.58, 8: 2.68, 12: 2.45, 17: 2.42}
-
-
-# Whole-picture step (ms, one MI355X) of the configurations the bands were measured on: the banded step of another bit depth / picture size is
-# taken as the 4K 8-bit table scaled by the ratio of the whole-picture steps.  Measured pairs behind it (profiles/r02_10bit_bands.txt): 4K
-# 10-bit 3.56 whole / 4.46 in 4-row bands / 4.84 in 2-row bands (table x 1.58 gives 4.39 / 5.32); 8K 10-bit 14.0 / 16.1 / 17.3 (x 6.2: the
-# table over-states small bands there - an 8K band has four times the CTUs of a 4K band of the same rows, so its launches fill the chip).
-WHOLE_STEP_MS = {(8, "4k"): 2.25, (10, "4k"): 3.56, (12, "4k"): 3.56, (8, "8k"): 9.0, (10, "8k"): 14.0, (12, "8k"): 14.0, (8, "1080p"): 0.62, (10, "1080p"): 0.95,
+# Milliseconds per picture of the BANDED step against the CTU rows per band, one MI355X, MEASURED per (bit depth, picture size) - round-3
+# verdict, next 8: rounds 2 - 3 scaled one 4K 8-bit table by the ratio of the whole-picture steps.  profiles/r04_band_tables.txt
+# (tools/r4_band_tables.sh, minima-only search = the default step of round 4).  Small bands cost launches whose grids no longer fill the
+# chip; large bands make the next rank wait longer for its first reference rows.
+BANDED_STEP_MS = {
+    (8, "4k"): {1: 6.10, 2: 3.37, 3: 2.98, 4: 2.57, 5: 2.67, 6: 2.45, 8: 2.42, 12: 2.22, 17: 2.13},
+    (10, "4k"): {2: 4.86, 3: 4.39, 4: 4.16, 6: 4.04, 8: 3.97, 12: 3.68, 17: 3.61},
+    (10, "8k"): {4: 14.51, 6: 14.13, 8: 13.79, 12: 13.88, 17: 14.03, 34: 13.75},
+    (8, "1080p"): {1: 2.93, 2: 1.62, 3: 1.13, 5: 1.11, 9: 0.86},
+}
+# configurations without a table of their own borrow the nearest one, scaled by the whole-picture steps (ms, same visit)
+WHOLE_STEP_MS = {(8, "4k"): 1.86, (10, "4k"): 3.26, (12, "4k"): 3.26, (8, "8k"): 7.4, (10, "8k"): 12.75, (12, "8k"): 12.75, (8, "1080p"): 0.60, (10, "1080p"): 0.95,
                  (12, "1080p"): 0.95}
 
 
@@ -300,9 +301,16 @@ def pick_band_rows(world, ctu_rows=34, lag_rows_luma=73, depth=8, width=3840):
     `lag` apart and a rank comes round again after world x lag - throughput is world pictures per max(step, world x lag).  The step
     times are the measured 4K 8-bit ones above scaled to the configuration (WHOLE_STEP_MS), a hand-over is taken as 0.1 ms."""
     size = "8k" if width > 5000 else ("4k" if width > 2500 else "1080p")
-    scale = WHOLE_STEP_MS.get((depth, size), 2.25) / 2.25
+    key = (10 if depth > 8 else 8, size)
+    if key in BANDED_STEP_MS:
+        table, scale = BANDED_STEP_MS[key], 1.0
+    else:
+        near = (10, "8k") if size == "8k" else ((8, "1080p") if size == "1080p" else (8, "4k"))
+        table, scale = BANDED_STEP_MS[near], WHOLE_STEP_MS.get((depth, size), WHOLE_STEP_MS[near]) / WHOLE_STEP_MS[near]
     best = None
-    for rows, step8 in BANDED_STEP_MS.items():
+    for rows, step8 in table.items():
+        if rows > ctu_rows:
+            continue
         step = step8 * scale
         nb = -(-ctu_rows // rows)
         ahead = 1 + -(-lag_rows_luma // (rows * 64))            # band periods until the bands a start needs are final
@@ -612,7 +620,10 @@ def main():
             # a pattern search visits a data-dependent handful of the window's candidates: the exhaustive search's algorithmic bytes do not
             # describe it and no per-launch figure of its own exists - no fraction is printed (round-3 verdict, weak 6 ii)
             alg_bytes = achieved = None
-        traffic, tsrc = load_traffic(args.width, args.height, args.range, (('packed_b' if ms.blocked else ('packed_t' if ms.tiled else 'packed')) if ms.packed else 'i32') + ('' if args.depth == 8 else '_d10')) if surf_mode else (None, None)
+        traffic, tsrc = load_traffic(args.width, args.height, args.range,
+                                     ((('packed_b' if ms.blocked else ('packed_t' if ms.tiled else 'packed')) if ms.packed else 'i32') if surf_mode else 'best') + ('' if args.depth == 8 else '_d10'))
+        if args.search != "full":
+            traffic, tsrc = None, None
         out = {
             "metric": "encoded fps + bit-exact check, 4K preset=slow, 1/2/4/8 MI355X vs host AVX2",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

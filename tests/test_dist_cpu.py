@@ -247,9 +247,13 @@ def test_band_size_follows_the_rank_count():
     sys.path.insert(0, ROOT)
     import bench as B
     rows = [B.pick_band_rows(n) for n in (2, 3, 4, 6, 8, 16)]
-    assert all(r in B.BANDED_STEP_MS for r in rows)
+    assert all(r in B.BANDED_STEP_MS[(8, "4k")] for r in rows)
     assert rows == sorted(rows, reverse=True) and rows[0] > rows[-1]
-    assert B.pick_band_rows(8, ctu_rows=68) >= B.pick_band_rows(8, ctu_rows=34)          # an 8K picture has twice the bands per picture
+    # every BASELINE configuration has a table of its own (round 4: measured per bit depth and picture size, not scaled from 4K 8-bit)
+    for depth, width, ctu_rows in ((10, 3840, 34), (10, 7680, 68), (8, 1920, 17)):
+        picks = [B.pick_band_rows(n, ctu_rows=ctu_rows, depth=depth, width=width) for n in (2, 4, 8)]
+        assert picks == sorted(picks, reverse=True) and all(1 <= r <= ctu_rows for r in picks), (depth, width, picks)
+    assert B.pick_band_rows(8, ctu_rows=68, depth=10, width=7680) >= B.pick_band_rows(8, ctu_rows=34, depth=10)      # an 8K picture has twice the rows
 
 
 @pytest.mark.parametrize("world", [2, 3, 4, 5, 8])

@@ -126,11 +126,11 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
                                                           pictures=seam.get("pictures", 24), band_rows=seam.get("band_rows", 0),
                                                           weighted=seam.get("weighted", True), layout=seam.get("layout", 0), centre_range=seam.get("centre_range", 0),
                                                           lookahead_min_blocks=seam.get("lookahead_min_blocks"))      # None: the binding's own size gate
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.process_time()
         md5, nbytes, sec, filled = encode(enc_lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
-        wall = time.perf_counter() - t0
+        wall, cpu = time.perf_counter() - t0, time.process_time() - c0
         r = {"frames": nf, "seconds": round(sec, 3), "fps": round(nf / sec, 4), "bytes": nbytes, "md5": md5, "slots_replaced": filled,
-             "wall_seconds_with_open_close": round(wall, 3)}
+             "wall_seconds_with_open_close": round(wall, 3), "process_cpu_seconds": round(cpu, 2)}
         if t == "c":
             md5_c[nf] = md5
             # SURVEY section 6 call-rate probe (counting thunks, 1080p): medium ~3.0 M, slow ~3.4 M primitive calls per frame; scale by area
@@ -153,6 +153,8 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
 
 
 def main():
+    if os.environ.get("X265HIP_BLOCKING_SYNC"):        # A/B: do the providers' waits burn host cores?  (hipDeviceScheduleBlockingSync = 4, before the first HIP call)
+        print("hipSetDeviceFlags(blocking sync) ->", ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(4), file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="cfg1,cfg2,cfg3")
     ap.add_argument("--tables", default="c,hip")
