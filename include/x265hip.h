@@ -944,6 +944,8 @@ typedef struct x265hip_me_stream_params
     int band_rows;
     int layout;                              /* X265HIP_STREAM_RECORDS (0) or X265HIP_STREAM_PLANES */
     int centre_range;                        /* 0: windows centred on (0, 0); R' >= range: on each CTU's own displacement (see below) */
+    int device_plus_1;                       /* 0: the calling thread's current device; d + 1: device d - one instance per GPU, e.g. one per frame-encoder
+                                              * pool of a host that spreads its FrameEncoders over the GPUs of a node (encoder/encoder.cpp:304-321) */
 } x265hip_me_stream_params;
 /* layout X265HIP_STREAM_PLANES (round 4) - what a host search wants to read: PU-MAJOR.  Per CTU (x265hip_me_stream_ctu_bytes apart),
  * for every square PU from the first served level on (min_level 0: 64 8x8, then 16 16x16, 4 32x32, 1 64x64, z-order per level) one
@@ -1100,6 +1102,7 @@ typedef struct x265hip_phase_stream_params
     int ctu_rows;
     int slots;                                          /* views resident (device + pinned host memory) at once */
     int pictures;                                       /* source pictures resident at once (0 = slots) */
+    int device_plus_1;                                  /* 0: the calling thread's current device; d + 1: device d (see x265hip_me_stream_params) */
 } x265hip_phase_stream_params;
 typedef struct x265hip_phase_stream_stats_t
 {

@@ -664,3 +664,20 @@ def test_4k_preset_slow_star_frame_threads_5_every_served_value_verified_in_flig
     assert rep["lookups_served"] > 1_000_000 and sub["subpel_compares_served"] > 500_000 and la["frame_cost_estimates_served"] >= 20, rep
     assert la["left_to_the_reference_by_the_size_gate"] == 0          # 4K is above the binding's size gate
     assert rep["lookup_hit_rate"] > 0.85, rep
+
+
+def test_stream_services_can_be_pinned_to_a_device():
+    """device_plus_1 of x265hip_me_stream_params / x265hip_phase_stream_params: an instance per GPU for a host that spreads its frame
+    encoders over a node (encoder/encoder.cpp:304-321).  Device 0 named explicitly works like the default; a device the box does not
+    have is refused with X265HIP_ENODEV and a message."""
+    from tools import seam_driver as SD
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    geo = SD.geometry(128, 128)
+    prov = SD.StreamGpuProvider(8, geo, 8, slots=1, min_level=1, pictures=2, layout=SD.LAYOUT_PLANES, device=0)
+    ph = SD.StreamGpuPhaseProvider(8, geo, slots=1, device=0)
+    prov.close(); ph.close()
+    n = A.lib().x265hip_device_count()
+    for cls, args in ((SD.StreamGpuProvider, (8, geo, 8, 1)), (SD.StreamGpuPhaseProvider, (8, geo, 1))):
+        with pytest.raises(A.X265HipError) as e:
+            cls(*args, device=n)
+        assert "device" in str(e.value)

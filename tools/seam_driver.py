@@ -442,7 +442,8 @@ class StreamParams(ctypes.Structure):
     """x265hip_me_stream_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int), ("stride", ctypes.c_ssize_t),
                 ("margin_x", ctypes.c_int), ("margin_y", ctypes.c_int), ("range", ctypes.c_int), ("surf_format", ctypes.c_int), ("min_level", ctypes.c_int),
-                ("slots", ctypes.c_int), ("pictures", ctypes.c_int), ("band_rows", ctypes.c_int), ("layout", ctypes.c_int), ("centre_range", ctypes.c_int)]
+                ("slots", ctypes.c_int), ("pictures", ctypes.c_int), ("band_rows", ctypes.c_int), ("layout", ctypes.c_int), ("centre_range", ctypes.c_int),
+                ("device_plus_1", ctypes.c_int)]
 
 
 class StreamStats(ctypes.Structure):
@@ -453,13 +454,13 @@ class StreamStats(ctypes.Structure):
 class StreamGpuProvider:
     """libx265hip.so's x265hip_me_stream: the product path under frame threads."""
 
-    def __init__(self, depth, geo, rng, slots, min_level=1, pictures=24, band_rows=0, layout=LAYOUT_RECORDS, centre_range=0):
+    def __init__(self, depth, geo, rng, slots, min_level=1, pictures=24, band_rows=0, layout=LAYOUT_RECORDS, centre_range=0, device=None):
         A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
         self.A, self.L = A, A.lib()
         self.format = SURF_PACKED if depth == 8 else SURF_I32
         self.min_level, self.layout, self.centre_range = min_level, layout, centre_range
         p = StreamParams(depth, geo["width"], geo["height"], geo["stride"], geo["margin_x"], geo["margin_y"], rng, self.format, min_level, slots, pictures, band_rows,
-                         layout, centre_range)
+                         layout, centre_range, 0 if device is None else device + 1)
         self.handle = ctypes.c_void_p()
         L = self.L
         L.x265hip_me_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(StreamParams)]
@@ -596,7 +597,7 @@ class PhaseStreamParams(ctypes.Structure):
     """x265hip_phase_stream_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("stride", ctypes.c_ssize_t), ("rows", ctypes.c_int), ("margin_y", ctypes.c_int),
                 ("stride_c", ctypes.c_ssize_t), ("rows_c", ctypes.c_int), ("margin_y_c", ctypes.c_int), ("ctu_rows", ctypes.c_int), ("slots", ctypes.c_int),
-                ("pictures", ctypes.c_int)]
+                ("pictures", ctypes.c_int), ("device_plus_1", ctypes.c_int)]
 
 
 class PhaseStreamStats(ctypes.Structure):
@@ -607,11 +608,11 @@ class PhaseStreamStats(ctypes.Structure):
 class StreamGpuPhaseProvider:
     """libx265hip.so's x265hip_phase_stream: the product path under frame threads."""
 
-    def __init__(self, depth, geo, slots, pictures=0):
+    def __init__(self, depth, geo, slots, pictures=0, device=None):
         A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
         self.L = L = A.lib()
         p = PhaseStreamParams(depth, geo["stride"], geo["rows"], geo["margin_y"], geo["stride_c"], geo["rows_c"], geo["margin_y"] >> 1, geo["height"] // 64, slots,
-                              pictures)
+                              pictures, 0 if device is None else device + 1)
         self.handle = ctypes.c_void_p()
         L.x265hip_phase_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(PhaseStreamParams)]
         A.check(L.x265hip_phase_stream_create(ctypes.byref(self.handle), ctypes.byref(p)), "x265hip_phase_stream_create")

@@ -476,6 +476,7 @@ int x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_pa
     { set_error("me_stream_create: surf_format %d for depth %d (record-contiguous formats only: X265HIP_SURF_PACKED at 8 bits, X265HIP_SURF_I32)", p->surf_format, p->depth); return X265HIP_EINVAL; }
     if (p->min_level < 0 || p->min_level > 1 || p->band_rows < 0) { set_error("me_stream_create: min_level %d / band_rows %d", p->min_level, p->band_rows); return X265HIP_EINVAL; }
     if (p->layout != X265HIP_STREAM_RECORDS && p->layout != X265HIP_STREAM_PLANES) { set_error("me_stream_create: layout %d", p->layout); return X265HIP_EINVAL; }
+    if (p->device_plus_1 < 0 || p->device_plus_1 > x265hip_device_count()) { set_error("me_stream_create: device %d of %d", p->device_plus_1 - 1, x265hip_device_count()); return X265HIP_ENODEV; }
     if (p->centre_range < 0 || (p->centre_range && (p->centre_range < p->range || p->centre_range > 128 || p->margin_x < p->centre_range + 12 || p->margin_y < p->centre_range + 12)))
     { set_error("me_stream_create: centre_range %d (0, or range .. 128 with margins >= centre_range + 12)", p->centre_range); return X265HIP_EINVAL; }
     S* s = new (std::nothrow) S;
@@ -506,7 +507,14 @@ int x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_pa
     s->lagRows = (63 + p->range) / 64;                    // CTU rows of the reference a CTU row's window reaches below (and above) itself
     if ((s->linePitch & 3) || ((((size_t)p->margin_y * p->stride + p->margin_x) * s->bpp) & 3))
     { set_error("me_stream_create: sample (0,0) and the row pitch must be 4-byte aligned"); delete s; return X265HIP_EINVAL; }
-    if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;
+    if (p->device_plus_1 > 0)
+    {
+        // an instance pinned to a GPU: validated as gfx950 and made current for this (creating) thread; the worker selects it for itself
+        rc = x265hip_init(p->device_plus_1 - 1);
+        if (rc) { delete s; return rc; }
+        s->device = p->device_plus_1 - 1;
+    }
+    else if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;
 #define MS_TRY(expr) do { if (check_hip((expr), #expr)) { free_all(s); delete s; return X265HIP_ENODEV; } } while (0)
     MS_TRY(hipStreamCreateWithFlags(&s->compute, hipStreamNonBlocking));
     MS_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));

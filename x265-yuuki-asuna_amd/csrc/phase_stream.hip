@@ -307,6 +307,8 @@ int x265hip_phase_stream_create(x265hip_phase_stream** out, const x265hip_phase_
     if (p->slots < 1 || p->slots > 64 || p->pictures < 0 || p->pictures > 256) { set_error("phase_stream_create: slots %d out of [1,64] / pictures %d out of [0,256]", p->slots, p->pictures); return X265HIP_EINVAL; }
     int rc = ensure_device();
     if (rc) return rc;
+    if (p->device_plus_1 < 0 || p->device_plus_1 > x265hip_device_count()) { set_error("phase_stream_create: device %d of %d", p->device_plus_1 - 1, x265hip_device_count()); return X265HIP_ENODEV; }
+    if (p->device_plus_1 > 0 && (rc = x265hip_init(p->device_plus_1 - 1))) return rc;       // pinned to a GPU: current for the creating thread from here on
     PS* s = new (std::nothrow) PS;
     if (!s) { set_error("phase_stream_create: out of memory"); return X265HIP_EINVAL; }
     s->prm = *p;
