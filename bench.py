@@ -725,7 +725,8 @@ def main():
                             "phase_bytes_downloaded": rep.get("subpel_seam", {}).get("bytes_downloaded"),
                             "frame_cost_estimates_served": rep.get("lookahead_seam", {}).get("frame_cost_estimates_served"),
                             "frame_cost_estimates_left_to_the_reference_by_the_size_gate": rep.get("lookahead_seam", {}).get("left_to_the_reference_by_the_size_gate"),
-                            "weighted_references": rep.get("weighted_references")}
+                            "weighted_references": rep.get("weighted_references"),
+                            "search_seams_left_off_by_the_size_gate": rep.get("search_seams_left_off_by_the_size_gate")}
                 c3 = leg("cfg3")
                 if c3:
                     out["encoder_summary"] = {**c3,

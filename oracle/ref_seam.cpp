@@ -195,6 +195,12 @@ struct Seam
     std::atomic<uint64_t> rowsPublished{0}, rowsRefused{0}, torn{0}, weightedPairs{0}, weightedHits{0}, weightedCalls{0}, saturated{0};
 } g;
 enum { MAX_SLOTS_STREAMED = 64 };
+/* The search seams move whole surfaces / phase planes per (picture, reference) to serve a search that, on small pictures and fast presets,
+ * asks for little: at 1080p --preset medium they cost 4 - 5 % (profiles/r04_encoder_legs.txt) where 4K gains 42 - 90 %.  Pictures of fewer
+ * CTUs than this are left alone by BOTH search seams (the lookahead seam has its own gate, gla.minBlocks); 1000 lies between 1080p (510)
+ * and 4K (2040).  x265ref_seam_min_ctus overrides (tests on small pictures: 0). */
+int g_minCtus = 1000;
+bool g_gated = false;
 inline uint64_t pic_key(uint64_t instance, int poc, int isRecon) { return (instance << 40) | ((uint64_t)(uint32_t)poc << 1) | (uint64_t)isRecon; }
 
 struct Part { uint32_t off; uint32_t wide; };      /* records: byte offset of entry [z][0] inside a group record; planes: of the PU's raster inside the CTU; wide = 32-bit entries */
@@ -1096,6 +1102,7 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
 {
     if (slots < 1 || slots > MAX_SLOTS || range < 1 || (width & 63) || (height & 63)) return -1;
     if (surf_format != SURF_I32 && X265_DEPTH != 8) return -2;
+    g_gated = (width / 64) * (height / 64) < g_minCtus;
     if (surf_format == SURF_PACKED_T && 45 * ((2 * range + 4) / 4) * 16 > 65535) return -3;          /* Part::off is 16 bits */
     g.p.ctx = ctx;
     g.p.submit = (int (*)(void*, int, const void*, uint64_t, const void*))submit;
@@ -1121,7 +1128,7 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
     g.wait = (verify & 2) != 0;
     g.hits = g.outside = g.notReady = g.meCalls = g.meServed = g.submits = g.mismatches = g.noSlot = g.foreign = 0;
     g.epoch.fetch_add(1);
-    g.enabled = true;
+    g.enabled = !g_gated;
     return 0;
 }
 
@@ -1198,9 +1205,13 @@ int x265ref_subpel_seam_configure_streamed(void* ctx, void* open, void* rows_fn,
     gs.served = gs.notReady = gs.noContext = gs.submits = gs.mismatches = gs.noSlot = 0; gs.rowsPublished = 0; gs.torn = 0;
     gs.weightedViews = 0; gs.weightedServed = 0;
     gs.epoch.fetch_add(1);
-    gs.enabled = true;
+    gs.enabled = !g_gated;          /* the size gate of the SAD seam's configure (made first) holds for this seam too */
     return 0;
 }
+
+/* pictures of fewer CTUs than this keep the reference's own search untouched (default 1000: the search seams serve from 4K up); call it
+ * BEFORE the configure calls.  Returns whether the last configure was gated. */
+int x265ref_seam_min_ctus(int min_ctus) { if (min_ctus >= 0) g_minCtus = min_ctus; return g_gated ? 1 : 0; }
 
 /* out[4]: rows of reconstructed pictures handed to the SAD provider / refused by it, rows handed to the phase provider, lookups dropped
  * because their slot was reopened under the read (SAD + sub-sample) */
@@ -1250,7 +1261,9 @@ uint64_t x265ref_lookahead_seam_mismatches(void) { return gla.mismatches; }
 /* table filler with the x265hip_setup_primitives signature: installs the lookup stubs over the host's own sad family */
 int x265ref_seam_fill_table(void* table, size_t bytes, int depth)
 {
-    if (!table || bytes != sizeof(EncoderPrimitives) || depth != X265_DEPTH || !g.enabled) return -1;
+    if (!table || bytes != sizeof(EncoderPrimitives) || depth != X265_DEPTH) return -1;
+    if (g_gated) return 0;          /* a picture below the size gate: nothing is installed, the encode is the reference's own */
+    if (!g.enabled) return -1;
     int n = 0;
     Install<0>::run(*static_cast<EncoderPrimitives*>(table), n);
     return n;

@@ -324,3 +324,13 @@ def test_lookahead_seam_size_gate_leaves_small_pictures_to_the_reference():
         close()
     la = rep["lookahead_seam"]
     assert got[0] == base[0] and la["frame_cost_estimates_served"] == 0 and la["intra_estimates_served"] == 0 and la["left_to_the_reference_by_the_size_gate"] > 5, la
+    assert rep["lookups_served"] > 100 and not rep["search_seams_left_off_by_the_size_gate"]      # min_ctus=0 here: the search seams did serve
+    # ... and the search seams' own gate (1000 CTUs): nothing installed, nothing handed over, the reference's own encode
+    lib, filler, report, close, prov = SD.install(8, 256, 192, provider="oracle", rng=16, slots=16, verify=True, streamed=True, subpel="oracle", min_ctus=None)
+    try:
+        got = EB.encode(lib, yuv, 256, 192, 6, "medium", opts, filler)
+        rep = report()
+    finally:
+        close()
+    assert got[0] == base[0] and got[3] == 0 and rep["search_seams_left_off_by_the_size_gate"], rep
+    assert rep["lookups_served"] == 0 and rep["pair_submits"] == 0 and rep["row_stream"]["recon_rows_to_sad_provider"] == 0 and rep["row_stream"]["recon_rows_to_phase_provider"] == 0, rep

@@ -125,7 +125,8 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
                                                           streamed=bool(seam.get("streamed")), min_level=seam.get("min_level", 0),
                                                           pictures=seam.get("pictures", 24), band_rows=seam.get("band_rows", 0),
                                                           weighted=seam.get("weighted", True), layout=seam.get("layout", 0), centre_range=seam.get("centre_range", 0),
-                                                          lookahead_min_blocks=seam.get("lookahead_min_blocks"))      # None: the binding's own size gate
+                                                          lookahead_min_blocks=seam.get("lookahead_min_blocks"),      # None: the binding's own size gates
+                                                          min_ctus=seam.get("min_ctus"))
         t0, c0 = time.perf_counter(), time.process_time()
         md5, nbytes, sec, filled = encode(enc_lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
         wall, cpu = time.perf_counter() - t0, time.process_time() - c0

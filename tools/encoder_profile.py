@@ -50,7 +50,7 @@ def main():
         lib, _, note, closer, _ = SD.install(depth, w, h, provider=a.provider, rng=a.seam_range, slots=24 if depth == 8 else 40, min_pu=a.seam_min_pu, verify=False,
                                              lookahead=None if a.no_lookahead_seam else a.provider, subpel=a.provider, subpel_slots=12, streamed=True,
                                              min_level=a.seam_min_level, pictures=24, layout=1 if a.seam_layout == "planes" else 0, centre_range=a.seam_centre_range,
-                                             lookahead_min_blocks=None)
+                                             lookahead_min_blocks=None, min_ctus=None)
         filler = ctypes.cast(lib.x265ref_seam_fill_table_profiled, ctypes.c_void_p)
     lib.x265ref_profile_tsc.restype = ctypes.c_uint64
     t0, c0, tsc0 = time.perf_counter(), time.process_time(), lib.x265ref_profile_tsc()

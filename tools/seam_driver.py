@@ -642,11 +642,14 @@ class StreamGpuPhaseProvider:
 
 
 def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
-            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0):
+            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0, min_ctus=0):
     """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
     the picture-granular providers need --frame-threads 1, streamed=True (row-granular providers) serves under any --frame-threads."""
     lib = seam_lib(depth)
     geo = geometry(width, height)
+    # the binding's own size gate of the two search seams (1000 CTUs: serve from 4K up) unless the caller names a threshold; tests on small pictures pass 0
+    lib.x265ref_seam_min_ctus.argtypes = [ctypes.c_int]
+    lib.x265ref_seam_min_ctus(1000 if min_ctus is None else min_ctus)
     if streamed:
         prov = (StreamGpuProvider(depth, geo, rng, slots, min_level, pictures, band_rows, layout, centre_range) if provider == "gpu"
                 else StreamOracleProvider(depth, geo, rng, slots, min_level, layout, centre_range))
@@ -713,7 +716,8 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     def report():
         d = stats(lib)
         d.update(prov.report())
-        d.update({"range": rng, "slots": slots, "min_pu": min_pu, "row_granular": bool(streamed), "layout": "planes" if layout else "records", "centre_range": centre_range})
+        d.update({"range": rng, "slots": slots, "min_pu": min_pu, "row_granular": bool(streamed), "layout": "planes" if layout else "records", "centre_range": centre_range,
+                  "search_seams_left_off_by_the_size_gate": bool(lib.x265ref_seam_min_ctus(-1))})
         if streamed:
             so4 = (ctypes.c_uint64 * 4)()
             lib.x265ref_seam_stream_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
