@@ -709,6 +709,19 @@ def main():
                     enc[key] = EB.run_config(key, args.encoder_tables.split(","), nf, ft, 120.0, log=sys.stderr,
                                              seam={"range": 12, "centre_range": 57, "layout": 1, "slots": 24 if CFG_DEPTH.get(key, 8) == 8 else 40, "min_pu": 16, "verify": False,
                                                    "lookahead": True, "subpel": True, "subpel_slots": 12, "streamed": True, "min_level": 1, "pictures": 24})
+                # "vs host AVX2" (BASELINE metric): the hand-written NASM AVX2 / AVX-512 kernels cannot be assembled here (no nasm); the closest
+                # buildable thing is the reference's own C path with AVX2 code generation (g++ -O3 -march=x86-64-v3, oracle/Makefile refv3: the
+                # SAD loops become vpsadbw) - timed beside the plain build for the metric's configuration and the 10-bit one, same seams on top
+                SEAM = {"range": 12, "centre_range": 57, "layout": 1, "min_pu": 16, "verify": False, "lookahead": True, "subpel": True, "subpel_slots": 12, "streamed": True,
+                        "min_level": 1, "pictures": 24}
+                for key in [k for k in ("cfg3", "cfg4") if k in enc]:
+                    nf, ft = ENC_DEFAULTS[key]
+                    nf, ft = args.encoder_frames or nf, args.encoder_frame_threads or ft
+                    try:
+                        enc[key + "_v3"] = EB.run_config(key, args.encoder_tables.split(","), nf, ft, 120.0, log=sys.stderr, build="v3",
+                                                         seam={**SEAM, "slots": 24 if CFG_DEPTH.get(key, 8) == 8 else 40})
+                    except BaseException as e:       # a missing libx265ref<depth>v3.so: the plain legs above stand
+                        enc[key + "_v3"] = {"error": repr(e)}
                 out["encoder"] = enc
 
                 def leg(key):
@@ -734,7 +747,14 @@ def main():
                                                        "comparisons (x265hip_phase_stream views, weighted references included) + lookahead frame costs (x265hip_lowres_cost_host, "
                                                        "4K and up), all under the reference's own frame threads",
                                               "kind": "reference (x265 3.5 C primitives, no asm: nasm is not in the image)",
-                                              "other_configs": {k: leg(k) for k in enc if k != "cfg3" and leg(k)}}
+                                              "other_configs": {k: leg(k) for k in enc if k != "cfg3" and not k.endswith("_v3") and leg(k)},
+                                              "host_avx2_autovectorised": {
+                                                  "build": "the reference's C path, g++ -O3 -march=x86-64-v3 -ffp-contract=off (AVX2 auto-vectorised; the hand-written NASM "
+                                                           "AVX2 / AVX-512 kernels need nasm, which the image lacks) - same seams on top, same bitstream as the plain build",
+                                                  **{k[:-3]: {**{f: v for f, v in (leg(k) or {}).items() if f in ("reference_c_table_fps", "seam_fps", "gain", "seam_md5_equal", "frames",
+                                                                                                                  "frame_threads")},
+                                                              "md5_equal_to_the_plain_build": enc[k].get("c", {}).get("md5") == enc[k[:-3]].get("c", {}).get("md5")}
+                                                     for k in enc if k.endswith("_v3") and "c" in enc[k]}}}
             except BaseException as e:       # incl. SystemExit from a missing oracle/_ref
                 out["encoder"] = {"error": repr(e)}
         print(json.dumps(out))

@@ -47,8 +47,10 @@ CONFIGS = {
 FILL = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int)
 
 
-def ref_lib(depth):
-    path = os.path.join(ROOT, "oracle", "_ref", f"libx265ref{depth}.so")
+def ref_lib(depth, build=""):
+    """build: "" = g++ -O3 (x86-64 baseline, what every parity test uses); "v3" = the same sources with -march=x86-64-v3 (AVX2 auto-vectorised
+    C primitives, 8-bit only: oracle/Makefile `refv3`)"""
+    path = os.path.join(ROOT, "oracle", "_ref", f"libx265ref{depth}{build}.so")
     if not os.path.exists(path):
         raise SystemExit(f"{path} missing: the real-reference build (make -C oracle ref) only exists where /root/reference does; "
                          "the built .so travels to the GPU box with the snapshot")
@@ -85,7 +87,7 @@ def effective_cpus():
     return n
 
 
-def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sys.stderr, seam=None):
+def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sys.stderr, seam=None, build=""):
     seam = seam or {"range": 32, "slots": 8, "min_pu": 8, "verify": False, "lookahead": False}
     F = importlib.import_module("x265-yuuki-asuna_amd.frames")
     cfg = CONFIGS[key]
@@ -94,12 +96,13 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
     cores = effective_cpus()
     clip = F.synth_clip(w, h, n, depth=depth, seed=265, fade=cfg.get("fade"))
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
-    lib = ref_lib(depth)
+    lib = ref_lib(depth, build)
     opts = [("pools", str(cores)), ("frame-threads", str(frame_threads)), ("crf", "28")] + cfg["opts"]
     if seam.get("lookahead"):        # the lookahead seam serves unsliced frame cost estimates: every leg of this run walks the lowres picture in one piece
         opts.append(("lookahead-slices", "1"))
     res = {"config": cfg["name"], "size": f"{w}x{h}", "depth": depth, "preset": cfg["preset"], "options": dict(opts), "pool_threads": cores,
-           "reference_build": "x265 3.5 C primitives (no asm: nasm is not in the image), g++ -O3"}
+           "reference_build": "x265 3.5 C primitives (no asm: nasm is not in the image), g++ -O3" +
+                              (" -march=x86-64-v3 -ffp-contract=off (AVX2 auto-vectorised; the hand-written NASM AVX2 path cannot be assembled here)" if build == "v3" else "")}
     md5_c = {}
     for t in tables:
         nf = n
@@ -126,7 +129,7 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
                                                           pictures=seam.get("pictures", 24), band_rows=seam.get("band_rows", 0),
                                                           weighted=seam.get("weighted", True), layout=seam.get("layout", 0), centre_range=seam.get("centre_range", 0),
                                                           lookahead_min_blocks=seam.get("lookahead_min_blocks"),      # None: the binding's own size gates
-                                                          min_ctus=seam.get("min_ctus"))
+                                                          min_ctus=seam.get("min_ctus"), build=build)
         t0, c0 = time.perf_counter(), time.process_time()
         md5, nbytes, sec, filled = encode(enc_lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
         wall, cpu = time.perf_counter() - t0, time.process_time() - c0
@@ -179,6 +182,7 @@ def main():
     ap.add_argument("--seam-layout", default="records", choices=["records", "planes"], help="row-granular SAD provider: what lands in host memory - records "
                     "(all PUs of a displacement together) or PU-major planes (X265HIP_STREAM_PLANES)")
     ap.add_argument("--seam-centre-range", type=int, default=0, help="row-granular SAD provider: centre every CTU's window on its own displacement, found within +-this (0 = off)")
+    ap.add_argument("--ref-build", default="", choices=["", "v3"], help="reference build flavour of every leg: '' = g++ -O3, v3 = + -march=x86-64-v3 (AVX2 auto-vectorised C)")
     ap.add_argument("--seam-no-weighted", action="store_true", help="weighted references pass to the host (the round-3 behaviour), for A/B on a fade")
     ap.add_argument("--seam-subpel-slots", type=int, default=6, help="reference pictures whose phase planes stay in pinned host memory (450 MB each at 4K 8-bit)")
     args = ap.parse_args()
@@ -186,7 +190,7 @@ def main():
             "subpel": args.seam_subpel, "subpel_slots": args.seam_subpel_slots, "streamed": args.seam_streamed, "min_level": args.seam_min_level,
             "pictures": args.seam_pictures, "band_rows": args.seam_band_rows, "no_sad": args.seam_no_sad, "weighted": not args.seam_no_weighted,
             "layout": 1 if args.seam_layout == "planes" else 0, "centre_range": args.seam_centre_range}
-    out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s, seam=seam) for k in args.configs.split(",")}
+    out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s, seam=seam, build=args.ref_build) for k in args.configs.split(",")}
     print(json.dumps({"encoder": out}))
 
 

@@ -33,8 +33,8 @@ def geometry(width, height):
                 rows=h64 + 2 * my, stride_c=w64 // 2 + 2 * mx, rows_c=h64 // 2 + 2 * (my >> 1))
 
 
-def seam_lib(depth):
-    path = os.path.join(ROOT, "oracle", "_ref", f"libx265ref{depth}_seam.so")
+def seam_lib(depth, build=""):
+    path = os.path.join(ROOT, "oracle", "_ref", f"libx265ref{depth}{build}_seam.so")
     if not os.path.exists(path):
         raise FileNotFoundError(path)
     lib = ctypes.CDLL(path)
@@ -642,10 +642,10 @@ class StreamGpuPhaseProvider:
 
 
 def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
-            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0, min_ctus=0):
+            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0, min_ctus=0, build=""):
     """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
     the picture-granular providers need --frame-threads 1, streamed=True (row-granular providers) serves under any --frame-threads."""
-    lib = seam_lib(depth)
+    lib = seam_lib(depth, build)
     geo = geometry(width, height)
     # the binding's own size gate of the two search seams (1000 CTUs: serve from 4K up) unless the caller names a threshold; tests on small pictures pass 0
     lib.x265ref_seam_min_ctus.argtypes = [ctypes.c_int]
