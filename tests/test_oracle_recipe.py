@@ -22,7 +22,7 @@ def test_makefile_has_a_compile_command_for_every_shim():
     shims = sorted(f[:-4] for f in os.listdir(os.path.join(ROOT, "oracle")) if f.startswith("ref_") and f.endswith(".cpp"))
     assert shims, "no shims found"
     for s in shims:
-        assert f"obj$(1)/{s}.o" in mk, f"{s}.o is linked into no library"
+        assert f"obj$(3)/{s}.o" in mk, f"{s}.o is linked into no library"          # $(3) = the build tag (8, 10, 12, 8v3, 10v3)
     out = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-n", "-B", "ref8", "OUT=/tmp/_x265hip_recipe_dry"],
                          capture_output=True, text=True, check=True).stdout
     for s in shims:
