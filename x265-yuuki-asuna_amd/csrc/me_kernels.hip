@@ -524,8 +524,14 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
     for (int g = wave; g < NG; g += nwaves)
     {
         const uint8_t* colBase = win + (by * 8) * pitch + (bx * 8 + 4 * g) * 2;
+        // (round 4) the 8x8 level keeps one running minimum PER COLUMN of `(sad + costY) << 8 | m`: a column's costX is the same for every row of the
+        // group, so it joins once, at the end of the group - 8 instead of 12 instructions per row for the level, 18 -> 12 spilled registers; 4K 2.67 -> 2.62 ms,
+        // 8K 10.32 -> 10.05 ms.  The same change made the 8-bit kernel SLOWER (1.43 -> 1.50 ms with v_mad_u32_u16 keys - a quarter-rate instruction on
+        // gfx950 - and 1.55 ms with and / shift-add keys, 17 % fewer instructions either way): there the key arithmetic was independent filler between the
+        // dependent DPP / permlane steps of the level sums, and without it their latency shows (profiles/r04_me_minima_ab.txt).  Left as it was.
         uint32_t cxk4[4] = { 0, 0, 0, 0 }, cxL = 0;
-        uint32_t r8 = 0xffffffffu, r16 = 0xffffffffu, r32 = 0xffffffffu, r64 = 0xffffffffu;
+        uint32_t r8c[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
+        uint32_t r16 = 0xffffffffu, r32 = 0xffffffffu, r64 = 0xffffffffu;
         if (BEST)
         {
 #pragma unroll
@@ -533,6 +539,7 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
                 cxk4[k] = ((4 * g + k < NC ? (uint32_t)a.costX[4 * g + k] : (1u << 20)) << 2) | (uint32_t)k;
             cxL = 4 * g + kcol < NC ? (uint32_t)a.costX[4 * g + kcol] : (1u << 23);
         }
+        const uint32_t cxL8 = cxL << 8;
         uint32_t acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; i++)
@@ -590,22 +597,17 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
                 }
                 if (BEST)
                 {
-                    const uint32_t cy_ = a.costY[m];
+                    const uint32_t rb = ((uint32_t)a.costY[m] << 8) | (uint32_t)m;          // the row's share of every key: costY << 8 | m
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
                     {
-                        const uint32_t k0 = ((uint32_t)s8[0] << 2) + cxk4[0], k1 = ((uint32_t)s8[1] << 2) + cxk4[1];
-                        const uint32_t k2 = ((uint32_t)s8[2] << 2) + cxk4[2], k3 = ((uint32_t)s8[3] << 2) + cxk4[3];
-                        uint32_t kmin = k0 < k1 ? k0 : k1;
-                        kmin = k2 < kmin ? k2 : kmin;
-                        kmin = k3 < kmin ? k3 : kmin;
-                        const uint32_t rowc = (cy_ << 10) | ((uint32_t)m << 2);
-                        uint32_t key = ((kmin & ~3u) << 8) + rowc;
-                        key = (key & ~3u) | (kmin & 3u);
-                        r8 = key < r8 ? key : r8;
+                        const uint32_t kk = ((uint32_t)s8[k] << 8) + rb;                     // (sad + costY) << 8 | m (an 8x8 SAD of 12-bit samples is < 2^18)
+                        r8c[k] = kk < r8c[k] ? kk : r8c[k];
                     }
-                    const uint32_t cxy = cxL + cy_;
-                    const uint32_t k16 = (((uint32_t)v16 + cxy) << 8) | (uint32_t)m;
-                    const uint32_t k32 = (((uint32_t)v32 + cxy) << 8) | (uint32_t)m;
-                    const uint32_t k64 = (((uint32_t)v64 + cxy) << 8) | (uint32_t)m;
+                    const uint32_t base = cxL8 + rb;
+                    const uint32_t k16 = ((uint32_t)v16 << 8) + base;
+                    const uint32_t k32 = ((uint32_t)v32 << 8) + base;
+                    const uint32_t k64 = ((uint32_t)v64 << 8) + base;
                     r16 = k16 < r16 ? k16 : r16;
                     r32 = k32 < r32 ? k32 : r32;
                     r64 = k64 < r64 ? k64 : r64;
@@ -623,6 +625,14 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
         }
         if (BEST)
         {
+            uint32_t r8 = 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const uint32_t kc = ((r8c[k] >> 8) << 2) + cxk4[k];                      // (sad + costY + costX) << 2 | k
+                const uint32_t key = ((kc & ~3u) << 8) | ((r8c[k] & 255u) << 2) | (kc & 3u);
+                r8 = key < r8 ? key : r8;
+            }
             const u64 w8 = ((u64)(r8 >> 10) << 32) | (uint32_t)(((r8 >> 2) & 255u) * NC + 4 * g + (r8 & 3u));
             bk8 = w8 < bk8 ? w8 : bk8;
             auto widen = [&](const uint32_t r) { return ((u64)(r >> 8) << 32) | (uint32_t)((r & 255u) * NC + 4 * g + kcol); };
