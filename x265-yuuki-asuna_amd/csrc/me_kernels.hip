@@ -249,7 +249,9 @@ __global__ void __launch_bounds__(1024, SURF ? 4 : 8) me_ctu_kernel(MEArgs a)
 // GROUP of 4 mv columns; the 8-deep ring holds 4 packed u16 SADs per slot (an 8x8 SAD is <= 16320).
 // The window is staged so that LDS byte 0 of a row is window column 0 (unaligned global dword loads),
 // which makes column group g start on LDS dword 2*bx + g for every CTU.
-template <bool SURF, bool BEST, int PITCH, bool PACKED = false>
+// VAR (minima-only launches, A/B: X265HIP_ME_BEST_VARIANT): bit 0 = the 8x8 level keeps one running minimum PER COLUMN of `(sad + costY) << 8 | m` and adds a
+// column's costX once per group (fewer instructions per row); bit 1 = no scheduling fence between rows.  profiles/r04_me_minima_ab.txt has the timings.
+template <bool SURF, bool BEST, int PITCH, bool PACKED = false, int VAR = 0>
 __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 4) me_ctu_q_kernel(MEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t win[];
@@ -319,6 +321,7 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
         // Pad columns (>= 2R+1) get a cost offset no real candidate reaches.
         uint32_t cxk4[4] = { 0, 0, 0, 0 }, cxL = 0;      // (costX << 2 | k) per column; this lane's own column cost
         uint32_t r8 = 0xffffffffu, r16 = 0xffffffffu, r32 = 0xffffffffu, r64 = 0xffffffffu;
+        uint32_t r8c[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };      // VAR & 1
         if (BEST)
         {
 #pragma unroll
@@ -400,7 +403,24 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
                             if (uMask) *reinterpret_cast<int*>(grp + (uint32_t)(uOffDw * 4)) = is64 ? v64 : v32;
                         }
                     }
-                    if (BEST)
+                    if (BEST && (VAR & 1))
+                    {
+                        const uint32_t rb = ((uint32_t)a.costY[m] << 8) | (uint32_t)m;      // the row's share of every key: costY << 8 | m
+                        const uint32_t k0 = ((lo & 0xffffu) << 8) + rb, k1 = ((lo >> 16) << 8) + rb;
+                        const uint32_t k2 = ((hi & 0xffffu) << 8) + rb, k3 = ((hi >> 16) << 8) + rb;
+                        r8c[0] = k0 < r8c[0] ? k0 : r8c[0];
+                        r8c[1] = k1 < r8c[1] ? k1 : r8c[1];
+                        r8c[2] = k2 < r8c[2] ? k2 : r8c[2];
+                        r8c[3] = k3 < r8c[3] ? k3 : r8c[3];
+                        const uint32_t base = cxL8 + rb;
+                        const uint32_t k16 = ((uint32_t)v16 << 8) + base;
+                        const uint32_t k32 = ((uint32_t)v32 << 8) + base;
+                        const uint32_t k64 = ((uint32_t)v64 << 8) + base;
+                        r16 = k16 < r16 ? k16 : r16;
+                        r32 = k32 < r32 ? k32 : r32;
+                        r64 = k64 < r64 ? k64 : r64;
+                    }
+                    else if (BEST)
                     {
                         const uint32_t cy_ = a.costY[m];
                         {   // 8x8: min over the 4 columns of (sad << 2) + (costX << 2 | k); costY is common to the row
@@ -431,7 +451,7 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
                 }
                 // keep the scheduler from interleaving the emission code of different rows (it would keep
                 // several rows' worth of unpacked sums alive and spill)
-                __builtin_amdgcn_sched_barrier(0);
+                if (!(VAR & 2)) __builtin_amdgcn_sched_barrier(0);
             }
         };
         using I8 = std::integral_constant<int, 8>;
@@ -448,6 +468,16 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
         }
         if (BEST)
         {   // widen the group's row-local keys to cost << 32 | raster index and merge
+            if (VAR & 1)
+            {   // each column's minimum over the rows gets its costX now; `cost << 10 | m << 2 | k` orders the four like (cost, raster index)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const uint32_t kc = ((r8c[k] >> 8) << 2) + cxk4[k];
+                    const uint32_t key = ((kc & ~3u) << 8) | ((r8c[k] & 255u) << 2) | (kc & 3u);
+                    r8 = key < r8 ? key : r8;
+                }
+            }
             const u64 w8 = ((u64)(r8 >> 10) << 32) | (uint32_t)(((r8 >> 2) & 255u) * NC + 4 * g + (r8 & 3u));
             bk8 = w8 < bk8 ? w8 : bk8;
             auto widen = [&](const uint32_t r) { return ((u64)(r >> 8) << 32) | (uint32_t)((r & 255u) * NC + 4 * g + kcol); };
@@ -475,7 +505,7 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
 // v_alignbit 16) feeding 8 ring slots x 4 columns x 4 dwords = 128 v_sad_u16; the emission (transposed upper levels,
 // 16-byte group stores, row-local 32-bit keys) is the 8-bit kernel's.  Key widths hold for depth <= 10
 // (64x64 SAD + mv cost < 2^23); 12-bit pictures use the generic kernel.
-template <bool SURF, bool BEST, int PITCH>
+template <bool SURF, bool BEST, int PITCH, int VAR = 1>
 __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 4) me_ctu_w_kernel(MEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t win[];
@@ -531,7 +561,7 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
         // dependent DPP / permlane steps of the level sums, and without it their latency shows (profiles/r04_me_minima_ab.txt).  Left as it was.
         uint32_t cxk4[4] = { 0, 0, 0, 0 }, cxL = 0;
         uint32_t r8c[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
-        uint32_t r16 = 0xffffffffu, r32 = 0xffffffffu, r64 = 0xffffffffu;
+        uint32_t r8 = 0xffffffffu, r16 = 0xffffffffu, r32 = 0xffffffffu, r64 = 0xffffffffu;
         if (BEST)
         {
 #pragma unroll
@@ -595,7 +625,29 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
                     *reinterpret_cast<int*>(grp + (uint32_t)(1024 + lane * 4)) = v16;
                     if (uMask) *reinterpret_cast<int*>(grp + (uint32_t)(uOffDw * 4)) = is64 ? v64 : v32;
                 }
-                if (BEST)
+                if (BEST && !(VAR & 1))
+                {   // round 3's scheme: one key per row
+                    const uint32_t cy_ = a.costY[m];
+                    {
+                        const uint32_t k0 = ((uint32_t)s8[0] << 2) + cxk4[0], k1 = ((uint32_t)s8[1] << 2) + cxk4[1];
+                        const uint32_t k2 = ((uint32_t)s8[2] << 2) + cxk4[2], k3 = ((uint32_t)s8[3] << 2) + cxk4[3];
+                        uint32_t kmin = k0 < k1 ? k0 : k1;
+                        kmin = k2 < kmin ? k2 : kmin;
+                        kmin = k3 < kmin ? k3 : kmin;
+                        const uint32_t rowc = (cy_ << 10) | ((uint32_t)m << 2);
+                        uint32_t key = ((kmin & ~3u) << 8) + rowc;
+                        key = (key & ~3u) | (kmin & 3u);
+                        r8 = key < r8 ? key : r8;
+                    }
+                    const uint32_t cxy = cxL + cy_;
+                    const uint32_t k16 = (((uint32_t)v16 + cxy) << 8) | (uint32_t)m;
+                    const uint32_t k32 = (((uint32_t)v32 + cxy) << 8) | (uint32_t)m;
+                    const uint32_t k64 = (((uint32_t)v64 + cxy) << 8) | (uint32_t)m;
+                    r16 = k16 < r16 ? k16 : r16;
+                    r32 = k32 < r32 ? k32 : r32;
+                    r64 = k64 < r64 ? k64 : r64;
+                }
+                else if (BEST)
                 {
                     const uint32_t rb = ((uint32_t)a.costY[m] << 8) | (uint32_t)m;          // the row's share of every key: costY << 8 | m
 #pragma unroll
@@ -613,7 +665,7 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
                     r64 = k64 < r64 ? k64 : r64;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (!(VAR & 2)) __builtin_amdgcn_sched_barrier(0);
         };
 #pragma unroll
         for (int p = 0; p < 8; p++) row_step(std::true_type{}, 0, p);
@@ -625,7 +677,7 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
         }
         if (BEST)
         {
-            uint32_t r8 = 0xffffffffu;
+            if (VAR & 1)
 #pragma unroll
             for (int k = 0; k < 4; k++)
             {
@@ -715,6 +767,9 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     if (sizeof(Px) == 1 && a.rowBytes == 256 && !p_generic)
     {
         // 8-bit fast path (v_qsad_pk_u16_u8); 2 * range + 75 bytes of window row must fit the 256-byte pitch
+        static const int bestVar = getenv("X265HIP_ME_BEST_VARIANT") ? atoi(getenv("X265HIP_ME_BEST_VARIANT")) & 3 : -1;       // A/B, read once
+#define LAUNCH_QV(V) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; \
+        hipLaunchKernelGGL((me_ctu_q_kernel<false, true, 256, false, V>), grid, dim3(nwq * 64), lds, s, a); } while (0)
 #define LAUNCH_Q(SF, BS, MAXW) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > (MAXW)) nwq = (MAXW); \
         if (packed) hipLaunchKernelGGL((me_ctu_q_kernel<SF, BS, 256, SF>), grid, dim3(nwq * 64), lds, s, a); \
         else hipLaunchKernelGGL((me_ctu_q_kernel<SF, BS, 256, false>), grid, dim3(nwq * 64), lds, s, a); } while (0)
@@ -725,9 +780,13 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
         else
         {
             if (anySurf) LAUNCH_Q(true, false, 16);
-            if (anyBest) LAUNCH_Q(false, true, 16);
+            if (anyBest)
+            {
+                if (bestVar == 1) LAUNCH_QV(1); else if (bestVar == 2) LAUNCH_QV(2); else if (bestVar == 3) LAUNCH_QV(3); else LAUNCH_QV(0);
+            }
         }
 #undef LAUNCH_Q
+#undef LAUNCH_QV
     }
     else if (packed) { set_error("me_fullsearch: X265HIP_SURF_PACKED needs depth 8 and 2 * range + 75 <= 256"); return X265HIP_EINVAL; }
     else if (sizeof(Px) == 2 && p->depth <= 10 && (a.rowBytes == 512 || a.rowBytes == 256) && !p_generic)
@@ -736,6 +795,12 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
         const int plw = (3 + (56 + 2 * p->range) * 2 + 4 * 6 + 3) >> 2;                 // the group kernel reads 6 dwords per row
         a.payloadDw = plw > a.payloadDw ? plw : a.payloadDw;
         if (a.payloadDw + 17 > a.rowBytes / 4) { set_error("me_fullsearch: internal: window row does not fit the LDS pitch"); return X265HIP_EINVAL; }
+        static const int bestVarW = getenv("X265HIP_ME_BEST_VARIANT") ? atoi(getenv("X265HIP_ME_BEST_VARIANT")) & 3 : -1;      // A/B, read once
+#define LAUNCH_WV(V) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; \
+        if (a.rowBytes == 256) hipLaunchKernelGGL((me_ctu_w_kernel<false, true, 256, V>), grid, dim3(nwq * 64), lds, s, a); \
+        else { \
+            if (lds > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_w_kernel<false, true, 512, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((me_ctu_w_kernel<false, true, 512, V>), grid, dim3(nwq * 64), lds, s, a); } } while (0)
 #define LAUNCH_W(SF, BS, MAXW) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > (MAXW)) nwq = (MAXW); \
         if (a.rowBytes == 256) hipLaunchKernelGGL((me_ctu_w_kernel<SF, BS, 256>), grid, dim3(nwq * 64), lds, s, a); \
         else { \
@@ -745,9 +810,13 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
         else
         {
             if (anySurf) LAUNCH_W(true, false, 16);
-            if (anyBest) LAUNCH_W(false, true, 16);
+            if (anyBest)
+            {
+                if (bestVarW == 0) LAUNCH_WV(0); else if (bestVarW == 2) LAUNCH_WV(2); else if (bestVarW == 3) LAUNCH_WV(3); else LAUNCH_WV(1);
+            }
         }
 #undef LAUNCH_W
+#undef LAUNCH_WV
     }
     else if (anySurf && anyBest) LAUNCH(true, true);
     else if (anySurf) LAUNCH(true, false);
