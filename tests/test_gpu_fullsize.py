@@ -169,3 +169,52 @@ def test_8k_10bit_ctu_samples_and_whole_picture_loop_filters():
     ecnt, eoff = O.sao_stats(depth, cur.host.reshape(-1), edbk.reshape(-1), cur.stride, cur.org, cur.w64, cur.h64, nthreads=nthreads)
     assert np.array_equal(sao.count.cpu().numpy().reshape(ecnt.shape), ecnt) and np.array_equal(sao.offset_org.cpu().numpy().reshape(eoff.shape), eoff)
     assert int(np.count_nonzero(edbk.reshape(-1) != pre.reshape(-1))) > 1000          # the filter really ran
+
+
+@pytest.mark.parametrize("depth,weights", [(8, None), (10, ((1, 45, 6, 6), (1, 70, -9, 6)))])
+def test_4k_b_picture_two_references_every_tu_size(depth, weights):
+    """What distinguishes BASELINE's slower presets from the closed loop of bench.py - B pictures, two reference lists, explicit weights,
+    TU sizes 8 / 16 / 32 (TU depth 3) - through the HIP path at 3840x2160 in one kept test (round-3 verdict, weak 1 ii): picture 1 of a
+    clip searched in pictures 0 AND 2 (exhaustive, minima), refined to quarter samples in both, then predicted bi-directionally
+    (per block: list 0, list 1 or both; with weights: addWeightBi / addWeightUni) and coded at every luma TU size plus 4:2:0 chroma -
+    motion vectors, levels, reconstruction and SSE of the WHOLE picture against the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    clip = F.synth_clip(3840, 2160, 3, depth=depth, seed=21)
+    cur, r0, r1 = (P.DevicePicture(clip[i][0], dev, clip[i][1], clip[i][2]) for i in (1, 0, 2))
+    rng_r, qp = 12, 30
+    ms = P.MotionSearch(cur.w64, cur.h64, rng_r, depth, dev, want_surf=False)
+    sp = P.SubpelRefine(ms, 3, dev)
+    mvs = []
+    for ref in (r0, r1):
+        ms.reset()
+        ms.run(cur, ref)
+        sp.run(cur, ref)
+        torch.cuda.synchronize()
+        _, best = O.me_fullsearch(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, rng_r, 0, ms.nctu, ms.cost_host, ms.cost_host,
+                                  want_surf=False)
+        assert np.array_equal(ms.best.cpu().numpy().view(np.uint64), best), "integer search differs"
+        want = O.subpel_refine(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, rng_r, 0, ms.nctu, best, sp.cost_q_host, sp.qoff, 3)
+        got = sp.out.cpu().numpy().reshape(-1, 2)
+        assert np.array_equal(got, want), "sub-sample refinement differs"
+        mvs.append(got.copy())
+    assert (mvs[0][:, 1] != mvs[1][:, 1]).any()                      # the two references are searched for different motion
+    rs = np.random.default_rng([31, depth])
+    kw = {"weights": weights} if weights else {}
+    okw = kw
+    for level in (0, 1, 2):
+        nblk = (64 >> (3 + level)) ** 2
+        dirs = rs.integers(1, 4, size=ms.nctu * nblk).astype(np.uint8)
+        st = S.InterReconBi(ms.nctu, cur.w64, cur.h64, depth, level, qp, dev, intra_slice=2)        # X265HIP_TU_SIGN_HIDE: the x265 default
+        recon = torch.zeros_like(cur.t)
+        st.run(cur, r0, r1, recon, torch.from_numpy(mvs[0].reshape(-1)).to(dev), torch.from_numpy(mvs[1].reshape(-1)).to(dev),
+               dir_flags=torch.from_numpy(dirs).to(dev), **kw)
+        torch.cuda.synchronize()
+        erec, elev, ens, edist = O.inter_recon_bi(depth, cur.host.reshape(-1), cur.stride, cur.org, r0.host.reshape(-1), r1.host.reshape(-1),
+                                                  cur.w64, cur.h64, level, mvs[0], mvs[1], qp, dir_flags=dirs, intra_slice=2, **okw)
+        assert np.array_equal(st.num_sig.cpu().numpy().view(np.uint32), ens), f"level {level}: numSig differs"
+        assert np.array_equal(st.levels.cpu().numpy(), elev), f"level {level}: levels differ"
+        assert np.array_equal(recon.cpu().numpy().view(cur.host.dtype).reshape(-1), erec.reshape(-1)), f"level {level}: reconstruction differs"
+        assert np.array_equal(st.dist.cpu().numpy().view(np.uint64), edist), f"level {level}: SSE differs"
+        assert (ens > 0).any() and all((dirs == d).any() for d in (1, 2, 3))
