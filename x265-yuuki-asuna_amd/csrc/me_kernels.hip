@@ -768,7 +768,11 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     {
         // 8-bit fast path (v_qsad_pk_u16_u8); 2 * range + 75 bytes of window row must fit the 256-byte pitch
         static const int bestVar = getenv("X265HIP_ME_BEST_VARIANT") ? atoi(getenv("X265HIP_ME_BEST_VARIANT")) & 3 : -1;       // A/B, read once
-#define LAUNCH_QV(V) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; \
+        static const int bestWaves = getenv("X265HIP_ME_BEST_WAVES") ? atoi(getenv("X265HIP_ME_BEST_WAVES")) : 0;       // A/B: wavefronts per workgroup of the minima-only launch
+        // 4K and up: 12 wavefronts per workgroup instead of 16 - step 1.875 -> 1.823 ms at 4K on one box, three interleaved rounds (8 does the same, 10 and 6 lose;
+        // at 1080p 16 stays best): profiles/r04_me_minima_ab.txt
+#define LAUNCH_QV(V) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 12) nwq = 12; \
+        if (bestWaves >= 4 && bestWaves <= 16 && bestWaves < pick_waves((2 * p->range + 4) / 4) + 1) nwq = bestWaves; \
         hipLaunchKernelGGL((me_ctu_q_kernel<false, true, 256, false, V>), grid, dim3(nwq * 64), lds, s, a); } while (0)
 #define LAUNCH_Q(SF, BS, MAXW) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > (MAXW)) nwq = (MAXW); \
         if (packed) hipLaunchKernelGGL((me_ctu_q_kernel<SF, BS, 256, SF>), grid, dim3(nwq * 64), lds, s, a); \
