@@ -4,6 +4,6 @@ run() { timeout 300 python bench.py --no-cpu-baseline --no-encoder --no-verify -
 import json,sys,os
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('waves', os.environ.get('X265HIP_ME_BEST_WAVES'), sys.argv[1:], 'step', d['ms_per_step'], 'me', d['stages_ms']['me'])" "$@"; }
 for round in 1 2 3; do
-  for w in 16 12 10 8 6; do X265HIP_ME_BEST_WAVES=$w run; done
+  for w in 16 12 10 8; do X265HIP_ME_BEST_WAVES=$w run --depth 10; done
 done
-for w in 16 10 8; do X265HIP_ME_BEST_WAVES=$w run --width 1920 --height 1080; done
+for w in 16 12 8; do X265HIP_ME_BEST_WAVES=$w run --depth 10 --width 7680 --height 4320 --steps 6; done

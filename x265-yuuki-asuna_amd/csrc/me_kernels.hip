@@ -800,7 +800,9 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
         a.payloadDw = plw > a.payloadDw ? plw : a.payloadDw;
         if (a.payloadDw + 17 > a.rowBytes / 4) { set_error("me_fullsearch: internal: window row does not fit the LDS pitch"); return X265HIP_EINVAL; }
         static const int bestVarW = getenv("X265HIP_ME_BEST_VARIANT") ? atoi(getenv("X265HIP_ME_BEST_VARIANT")) & 3 : -1;      // A/B, read once
-#define LAUNCH_WV(V) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; \
+        static const int bestWavesW = getenv("X265HIP_ME_BEST_WAVES") ? atoi(getenv("X265HIP_ME_BEST_WAVES")) : 0;
+#define LAUNCH_WV(V) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 12) nwq = 12;      /* 4K: step 3.20 -> 3.18 ms, 8K 12.61 -> 12.53 */ \
+        if (bestWavesW >= 4 && bestWavesW <= 16) nwq = bestWavesW; \
         if (a.rowBytes == 256) hipLaunchKernelGGL((me_ctu_w_kernel<false, true, 256, V>), grid, dim3(nwq * 64), lds, s, a); \
         else { \
             if (lds > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_w_kernel<false, true, 512, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
