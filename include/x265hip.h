@@ -920,7 +920,8 @@ int  x265hip_me_cache_stats(x265hip_me_cache* c, x265hip_me_cache_stats_t* st);
  * raising ready[row] as the band's surfaces land in pinned host memory.  The host's own consumers wait for row + 3 (m_refLagRows with
  * the sub-pel taps, frameencoder.cpp:161-164), so the device is two reference rows ahead of the first lookup of a row.
  *   surf_format : record-contiguous formats only - X265HIP_SURF_PACKED (8-bit) or X265HIP_SURF_I32
- *   min_level   : 0 = whole records; 1 = the 16x16 / 32x32 / 64x64 levels only: the LAST X265HIP_SURF_TAIL_BYTES_* bytes of every record
+ *   min_level   : 0 = whole records; 2 (X265HIP_STREAM_PLANES only) = the 32x32 / 64x64 rasters only - in the real encoder the 16x16-level lookups are
+ *                 fps-neutral (a lookup costs what the host's own 16x16 SAD costs, profiles/r04_encoder_legs.txt) and 62 % of the bytes; 1 = the 16x16 / 32x32 / 64x64 levels only: the LAST X265HIP_SURF_TAIL_BYTES_* bytes of every record
  *                 (packed: uint16 [16][4] + int32 [5][4] = 208 bytes; int32: [21][4] = 336 bytes), same group order
  *   slots       : (source, reference) pairs resident in host memory at once;  pictures : pictures resident on the device at once
  *   band_rows   : most CTU rows searched by one launch (0 = 8)
@@ -960,17 +961,17 @@ enum { X265HIP_STREAM_RECORDS = 0, X265HIP_STREAM_PLANES = 1 };
 static inline size_t x265hip_stream_planes_ctu_bytes(int range, int min_level)
 {
     const size_t nc = (size_t)(2 * range + 1), pitch = 4 * ((nc + 3) >> 2);
-    return nc * pitch * ((min_level ? 0 : 64 * 2) + 16 * 2 + 5 * 4);
+    return nc * pitch * ((min_level ? 0 : 64 * 2) + (min_level > 1 ? 0 : 16 * 2) + 5 * 4);
 }
 /* byte offset of square PU (level 0..3, z-order index z) inside a CTU's planes, and its entry size (2 or 4) */
 static inline size_t x265hip_stream_planes_pu_offset(int range, int min_level, int level, int z, int* entry_bytes)
 {
     const size_t nc = (size_t)(2 * range + 1), pitch = 4 * ((nc + 3) >> 2), ps = nc * pitch * 2, pw = nc * pitch * 4;
-    const size_t n0 = min_level ? 0 : 64;
+    const size_t n0 = min_level ? 0 : 64, n1 = min_level > 1 ? 0 : 16;     /* a level below min_level has no rasters: do not ask for it */
     if (entry_bytes) *entry_bytes = level < 2 ? 2 : 4;
     if (level == 0) return (size_t)z * ps;
     if (level == 1) return (n0 + (size_t)z) * ps;
-    return (n0 + 16) * ps + (size_t)(level == 2 ? z : 4) * pw;
+    return (n0 + n1) * ps + (size_t)(level == 2 ? z : 4) * pw;
 }
 typedef struct x265hip_me_stream_stats_t
 {

@@ -240,7 +240,7 @@ bool decompose(int px, int py, int w, int h, int bx, int by, int size, Ctx& c)
     {
         if (c.nparts == MAX_PARTS) return false;
         const int level = size == 8 ? 0 : size == 16 ? 1 : size == 32 ? 2 : 3;
-        if (g.p.min_level && level == 0) return false;                     /* the 8x8 level was not downloaded */
+        if (level < g.p.min_level) return false;                           /* that level was not downloaded (min_level 1: no 8x8 rasters; 2: no 16x16 ones either) */
         const int ux = bx / size, uy = by / size;
         int z = 0;
         for (int b = 0; b < 3; b++) z |= ((ux >> b) & 1) << (2 * b) | ((uy >> b) & 1) << (2 * b + 1);
@@ -248,9 +248,9 @@ bool decompose(int px, int py, int w, int h, int bx, int by, int size, Ctx& c)
         if (g.p.layout)
         {
             /* x265hip_stream_planes_pu_offset: uint16 rasters of the 8x8 (min_level 0) and 16x16 PUs, then uint32 rasters of 32x32 and 64x64 */
-            const size_t ps = (size_t)g.nc * g.pitch * 2, pw = (size_t)g.nc * g.pitch * 4, n0 = g.p.min_level ? 0 : 64;
+            const size_t ps = (size_t)g.nc * g.pitch * 2, pw = (size_t)g.nc * g.pitch * 4, n0 = g.p.min_level ? 0 : 64, n1 = g.p.min_level > 1 ? 0 : 16;
             q.wide = level >= 2;
-            q.off = (uint32_t)(level == 0 ? z * ps : level == 1 ? (n0 + z) * ps : (n0 + 16) * ps + (level == 2 ? z : 4) * pw);
+            q.off = (uint32_t)(level == 0 ? z * ps : level == 1 ? (n0 + z) * ps : (n0 + n1) * ps + (level == 2 ? z : 4) * pw);
         }
         else if (g.p.surf_format != SURF_I32)
         {
@@ -1138,9 +1138,9 @@ int x265ref_seam_configure_streamed(void* ctx, void* picture_rows, void* pair_op
                                     int range, int surf_format, int min_level, int slots, int width, int height, intptr_t stride, int margin_x, int margin_y,
                                     int min_pu, int verify)
 {
-    if (!picture_rows || !pair_open || surf_format == SURF_PACKED_T || min_level < 0 || min_level > 1 || layout < 0 || layout > 1) return -4;
+    if (!picture_rows || !pair_open || surf_format == SURF_PACKED_T || min_level < 0 || min_level > (layout ? 2 : 1) || layout < 0 || layout > 1) return -4;
     const int rc = x265ref_seam_configure(ctx, NULL, NULL, surface, ready, range, surf_format, slots, width, height, stride, margin_x, margin_y,
-                                          min_level && min_pu < 16 ? 16 : min_pu, verify);
+                                          min_level > 1 && min_pu < 32 ? 32 : (min_level && min_pu < 16 ? 16 : min_pu), verify);
     if (rc) return rc;
     g.p.picture_rows = (int (*)(void*, uint64_t, const void*, int, int))picture_rows;
     g.p.pair_open = (int (*)(void*, int, uint64_t, uint64_t))pair_open;
@@ -1150,7 +1150,7 @@ int x265ref_seam_configure_streamed(void* ctx, void* picture_rows, void* pair_op
     g.p.min_level = min_level;
     g.p.streamed = true;
     if (layout)
-        g.ctuBytes = (size_t)g.nc * g.pitch * ((min_level ? 0 : 64 * 2) + 16 * 2 + 5 * 4);          /* x265hip_stream_planes_ctu_bytes */
+        g.ctuBytes = (size_t)g.nc * g.pitch * ((min_level ? 0 : 64 * 2) + (min_level > 1 ? 0 : 16 * 2) + 5 * 4);          /* x265hip_stream_planes_ctu_bytes */
     else if (min_level)
     {
         g.groupBytes = surf_format == SURF_I32 ? 336 : 208;          /* X265HIP_SURF_TAIL_BYTES_I32 / _PACKED */

@@ -536,7 +536,8 @@ def test_row_granular_seams_on_the_gpu_serve_weighted_references_on_a_fade(depth
 
 # ---- round 4: PU-major planes and windows centred on each CTU's displacement ---------------------------------------------------------
 @pytest.mark.parametrize("depth,width,height,rng,min_level,centre,band_rows", [(8, 256, 256, 12, 1, 0, 2), (8, 256, 256, 12, 0, 40, 8), (10, 192, 256, 10, 1, 32, 3),
-                                                                               (12, 128, 192, 8, 0, 24, 1), (8, 320, 192, 16, 1, 57, 2)])
+                                                                               (12, 128, 192, 8, 0, 24, 1), (8, 320, 192, 16, 1, 57, 2), (8, 256, 256, 12, 2, 40, 2),
+                                                                               (10, 192, 256, 10, 2, 0, 3)])
 def test_me_stream_planes_layout_and_centres_equal_the_oracle(depth, width, height, rng, min_level, centre, band_rows):
     """X265HIP_STREAM_PLANES: the slot buffer holds one raster per PU (uint16 saturating / uint32) - compared byte for byte with the
     oracle's records transposed by the checker's twin; centre_range: centres = the clamped displacement of each CTU's 64x64 minimum in
@@ -599,8 +600,9 @@ def test_me_stream_planes_layout_and_centres_equal_the_oracle(depth, width, heig
             got = np.ctypeslib.as_array((ctypes.c_uint8 * (nctu * cb)).from_address(L.x265hip_me_stream_surface(prov.handle, slot))).reshape(nctu, cb)
             nc, pitch = 2 * rng + 1, 4 * ((2 * rng + 4) // 4)
             def valid(b):       # the pad columns of a raster row hold don't-care values
-                lo = b[:, :nc * pitch * 2 * ((0 if min_level else 64) + 16)].copy().view(np.uint16).reshape(nctu, -1, nc, pitch)[..., :nc]
-                hi = b[:, nc * pitch * 2 * ((0 if min_level else 64) + 16):].copy().view(np.uint32).reshape(nctu, 5, nc, pitch)[..., :nc]
+                nlo = (0 if min_level else 64) + (0 if min_level > 1 else 16)      # min_level 2: the 32x32 / 64x64 rasters only
+                lo = b[:, :nc * pitch * 2 * nlo].copy().view(np.uint16).reshape(nctu, nlo, nc, pitch)[..., :nc]
+                hi = b[:, nc * pitch * 2 * nlo:].copy().view(np.uint32).reshape(nctu, 5, nc, pitch)[..., :nc]
                 return lo, hi
             (gl, gh), (el, eh) = valid(got), valid(exp)
             assert np.array_equal(gl, el) and np.array_equal(gh, eh), slot
@@ -611,7 +613,7 @@ def test_me_stream_planes_layout_and_centres_equal_the_oracle(depth, width, heig
 
 
 @pytest.mark.parametrize("depth,preset,ft,min_level,centre,extra", [(8, "slow", 3, 1, 57, [("me", "star")]), (8, "medium", 3, 0, 0, []), (10, "slower", 2, 1, 40, []),
-                                                                    (8, "slow", 3, 1, 40, [("me", "star"), ("bframes", "0")])])
+                                                                    (8, "slow", 3, 1, 40, [("me", "star"), ("bframes", "0")]), (8, "slow", 3, 2, 57, [("me", "star")])])
 def test_row_granular_seams_on_the_gpu_with_planes_and_centred_windows(depth, preset, ft, min_level, centre, extra):
     """The real encoder on the planes layout (and centred windows) of x265hip_me_stream, weighted references included (the last case
     runs on a fade with --weightp on): byte-identical, every lookup verified in flight."""
@@ -627,7 +629,7 @@ def test_row_granular_seams_on_the_gpu_with_planes_and_centred_windows(depth, pr
     assert got[0] == base[0], f"seam changed the bitstream: {rep}"
     sub = rep["subpel_seam"]
     assert rep["verify"] == 1 and rep["verify_mismatches"] == 0 and sub["verify_mismatches"] == 0 and rep["failed"] == 0 and sub["failed"] == 0
-    assert rep["lookups_served"] > (300 if min_level else 1500) and sub["subpel_compares_served"] > 1000, rep
+    assert rep["lookups_served"] > (60 if min_level > 1 else 300 if min_level else 1500) and sub["subpel_compares_served"] > 1000, rep
     if fade:
         assert rep["weighted_references"]["lookups_served_on_weighted_references"] > 100, rep
 

@@ -273,7 +273,7 @@ LAYOUT_RECORDS, LAYOUT_PLANES = 0, 1
 def planes_ctu_bytes(rng, min_level):
     """x265hip_stream_planes_ctu_bytes (include/x265hip.h)"""
     nc = 2 * rng + 1
-    return nc * 4 * ((nc + 3) // 4) * ((0 if min_level else 128) + 32 + 20)
+    return nc * 4 * ((nc + 3) // 4) * ((0 if min_level else 128) + (0 if min_level > 1 else 32) + 20)
 
 
 def records_to_planes(recs, nctu, rng, min_level):
@@ -282,7 +282,7 @@ def records_to_planes(recs, nctu, rng, min_level):
     nc = 2 * rng + 1
     ng = (nc + 3) // 4
     v = recs.reshape(nctu, nc, ng, 85, 4).transpose(0, 3, 1, 2, 4).reshape(nctu, 85, nc * ng * 4)
-    lo = np.minimum(v[:, (64 if min_level else 0):80], 65535).astype(np.uint16)
+    lo = np.minimum(v[:, (80 if min_level > 1 else 64 if min_level else 0):80], 65535).astype(np.uint16)
     hi = v[:, 80:85].astype(np.uint32)
     return np.concatenate([lo.reshape(nctu, -1).view(np.uint8), hi.reshape(nctu, -1).view(np.uint8)], axis=1)
 
@@ -479,7 +479,7 @@ class StreamGpuProvider:
         self.L.x265hip_me_stream_stats(self.handle, ctypes.byref(st))
         d = {n: int(getattr(st, n)) for n, _ in StreamStats._fields_}
         d["provider"] = ("x265hip_me_stream (reconstructed CTU rows in as the reference publishes them; every open (picture, reference) pair searched "
-                         "row by row behind the producer; " + ("16x16-and-up " if self.min_level else "all ") +
+                         "row by row behind the producer; " + ("32x32-and-up " if self.min_level > 1 else "16x16-and-up " if self.min_level else "all ") +
                          ("PU-major planes" if self.layout else "records") + " downloaded per band" +
                          (f"; windows centred on each CTU's displacement within +-{self.centre_range}" if self.centre_range else "") + ")")
         d["surface_mbytes_per_pair"] = round(st.surface_bytes / 1e6, 1)

@@ -255,11 +255,12 @@ int run_round(S* s, const std::vector<Upload>& ups, const std::vector<Weigh>& we
         if (rc) return rc;
         if (s->planes)
         {
-            const size_t total = (size_t)nctuBand * s->nc * (s->prm.min_level ? 21 : 85) * s->ng;
+            const int pu0 = s->prm.min_level > 1 ? 80 : s->prm.min_level ? 64 : 0;
+            const size_t total = (size_t)nctuBand * s->nc * (85 - pu0) * s->ng;
             size_t blocks = (total + 255) / 256;
             if (blocks > 16384) blocks = 16384;
             hipLaunchKernelGGL(surf_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s->compute, (const uint8_t*)s->dScratch, dst, nctuBand, s->nc, s->ng, s->fullRec,
-                               s->prm.surf_format == X265HIP_SURF_PACKED ? 1 : 0, s->prm.min_level ? 64 : 0, s->ctuBytes);
+                               s->prm.surf_format == X265HIP_SURF_PACKED ? 1 : 0, pu0, s->ctuBytes);
             X265HIP_TRY(hipGetLastError());
         }
         else if (s->prm.min_level)
@@ -474,7 +475,7 @@ int x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_pa
     if (p->slots < 1 || p->slots > 256 || p->pictures < 2 || p->pictures > 256) { set_error("me_stream_create: slots %d / pictures %d", p->slots, p->pictures); return X265HIP_EINVAL; }
     if (p->surf_format != X265HIP_SURF_I32 && !(p->surf_format == X265HIP_SURF_PACKED && p->depth == 8))
     { set_error("me_stream_create: surf_format %d for depth %d (record-contiguous formats only: X265HIP_SURF_PACKED at 8 bits, X265HIP_SURF_I32)", p->surf_format, p->depth); return X265HIP_EINVAL; }
-    if (p->min_level < 0 || p->min_level > 1 || p->band_rows < 0) { set_error("me_stream_create: min_level %d / band_rows %d", p->min_level, p->band_rows); return X265HIP_EINVAL; }
+    if (p->min_level < 0 || p->min_level > (p->layout == X265HIP_STREAM_PLANES ? 2 : 1) || p->band_rows < 0) { set_error("me_stream_create: min_level %d / band_rows %d", p->min_level, p->band_rows); return X265HIP_EINVAL; }
     if (p->layout != X265HIP_STREAM_RECORDS && p->layout != X265HIP_STREAM_PLANES) { set_error("me_stream_create: layout %d", p->layout); return X265HIP_EINVAL; }
     if (p->device_plus_1 < 0 || p->device_plus_1 > x265hip_device_count()) { set_error("me_stream_create: device %d of %d", p->device_plus_1 - 1, x265hip_device_count()); return X265HIP_ENODEV; }
     if (p->centre_range < 0 || (p->centre_range && (p->centre_range < p->range || p->centre_range > 128 || p->margin_x < p->centre_range + 12 || p->margin_y < p->centre_range + 12)))
