@@ -441,6 +441,34 @@ typedef struct x265hip_lowres_intra_host_params
 int x265hip_lowres_intra_host(const x265hip_lowres_intra_host_params* p);
 /* drops every device copy the two host entries above keep under plane keys (call between encodes, with no estimate in flight) */
 void x265hip_lowres_planes_forget(void);
+/* LookaheadTLD::calcAdaptiveQuantFrame (encoder/slicetype.cpp:444-694, called once per source picture from PreLookaheadGroup::processTasks,
+ * :1395) behind host pointers, for the AQ modes x265hip_aq_offsets covers (1 - 3, strength > 0; 4:2:0 or 4:0:0): ONE call uploads the
+ * source picture's planes (the blocks' footprint: width / height rounded up to qg_size, which lies inside PicYuv's padding as it does
+ * for the reference's own loop), runs x265hip_aq_energy, downloads the block energies and the six totals, and finishes on the calling
+ * thread with x265hip_aq_offsets - outputs straight into the caller's Lowres arrays:
+ *   qp_aq_offset, qp_cutree_offset : HOST double [blocks]  (Lowres::qpAqOffset / qpCuTreeOffset, both the same values, :617-618)
+ *   inv_qscale                     : HOST int32  [blocks]  (Lowres::invQscaleFactor = x265_exp2fix8, :619)
+ *   inv_qscale_8x8                 : HOST int32  [width_in_cu * height_in_cu] or NULL; qg_size 8 only: the 2x2 averages of :626-640
+ *   energy                         : HOST uint32 [blocks] or NULL (what acEnergyCu returned per block; Lowres::blockVariance under --fades)
+ *   wp_sum / wp_ssd                : HOST uint64 [3]: Lowres::wp_sum, and wp_ssd - raw totals, or with normalise_wp != 0 the
+ *                                    ssd - (sum^2 + n / 2) / n of :662-675 (n = the plane's ((dim + 8) >> 4) << 4 area) that
+ *                                    --weightp / --weightb ask for.
+ * blocks = ceil(width / qg_size) * ceil(height / qg_size), row-major.  Stateless and re-entrant like x265hip_lowres_cost_host (a stream
+ * and grow-only scratch per calling thread).  quantOffsets, --hdr10-opt, --hevc-aq, the edge mode and the 2-pass cuTree reuse are the
+ * caller's to keep on its own loop. */
+typedef struct x265hip_aq_frame_host_params
+{
+    int depth;
+    const void* y; const void* cb; const void* cr;          /* HOST: sample (0,0) of the picture's planes (PicYuv::m_picOrg[]); cb = cr = NULL: 4:0:0 */
+    intptr_t stride, stride_c;                              /* in samples */
+    int width, height, qg_size, aq_mode;
+    double aq_strength;
+    int width_in_cu, height_in_cu;                          /* the lowres 8x8 grid (inv_qscale_8x8 only) */
+    int normalise_wp;
+    double* qp_aq_offset; double* qp_cutree_offset; int32_t* inv_qscale; int32_t* inv_qscale_8x8; uint32_t* energy;
+    uint64_t* wp_sum; uint64_t* wp_ssd;
+} x265hip_aq_frame_host_params;
+int x265hip_aq_frame_host(const x265hip_aq_frame_host_params* p);
 
 /* ---- in-loop deblocking of a device-resident luma reconstruction (deblocking half) ----
  * x265hip_deblock_bs_inter = Deblock::getBoundaryStrength (deblock.cpp:191-215) for a P picture with one reference cut into

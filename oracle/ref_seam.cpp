@@ -60,6 +60,7 @@ extern "C" void x265ref_orig_processPostRow(FrameFilter* self, int row);
 extern "C" int x265ref_orig_subpelCompare(MotionEstimate* self, ReferencePlanes* ref, const MV* qmv, pixelcmp_t cmp);
 extern "C" int64_t x265ref_orig_estimateFrameCost(CostEstimateGroup* self, LookaheadTLD* tld, int p0, int p1, int b, bool bIntraPenalty);
 extern "C" void x265ref_orig_lowresIntraEstimate(LookaheadTLD* self, Lowres* fenc, uint32_t qgSize);
+extern "C" void x265ref_orig_calcAdaptiveQuantFrame(LookaheadTLD* self, Frame* curFrame, x265_param* param);
 extern "C" int x265ref_profile_fill_table(void* table, size_t bytes, int depth);          /* oracle/ref_profile.cpp: cycle-counting thunks */
 
 namespace {
@@ -120,6 +121,32 @@ struct LookaheadSeam
     int minBlocks = 16384;
     std::atomic<uint64_t> gated{0};
 } gla;
+
+/* x265hip_aq_frame_host_params (include/x265hip.h), mirrored field by field */
+struct AqFrameHostParams
+{
+    int depth;
+    const void* y; const void* cb; const void* cr;
+    intptr_t stride, stride_c;
+    int width, height, qg_size, aq_mode;
+    double aq_strength;
+    int width_in_cu, height_in_cu;
+    int normalise_wp;
+    double* qp_aq_offset; double* qp_cutree_offset; int32_t* inv_qscale; int32_t* inv_qscale_8x8; uint32_t* energy;
+    uint64_t* wp_sum; uint64_t* wp_ssd;
+};
+typedef int (*aq_host_fn)(const AqFrameHostParams*);
+/* x265oracle_aq_frame_d<depth> (oracle/x265_oracle_pipeline3.c) */
+typedef void (*aq_oracle_fn)(const pixel* y, const pixel* cb, const pixel* cr, intptr_t stride, intptr_t strideC, int width, int height, int qgSize, int aqMode,
+                             double aqStrength, int weightp, uint32_t* energy, double* qpAqOffset, int32_t* invQscale, uint64_t* wpSum, uint64_t* wpSsd);
+struct AqSeam
+{
+    bool enabled = false, verify = false;
+    aq_host_fn host = NULL;
+    aq_oracle_fn oracle = NULL;
+    int minBlocks = 0;
+    std::atomic<uint64_t> served{0}, passed{0}, failed{0}, mismatches{0}, gated{0};
+} gaq;
 
 /* measurement aid (tools/encoder_profile.py --seams): cycles inside the wrapped stages, next to ref_profile.cpp's per-family thunks */
 struct SeamProf
@@ -1035,6 +1062,85 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
     return score;
 }
 
+/* LookaheadTLD::calcAdaptiveQuantFrame (slicetype.cpp:444-694; once per source picture from PreLookaheadGroup::processTasks, :1395): the
+ * acEnergyCu loop over every quantisation group of the picture - the pixel work - and the double-precision offsets as ONE provider call
+ * (x265hip_aq_frame_host) that writes straight into the Lowres arrays.  The AQ modes 1 - 3 of 4:2:0 / 4:0:0 pictures; everything the
+ * service does not restate (quantOffsets, --hdr10-opt, --hevc-aq, the edge mode, the 2-pass cuTree reuse, --dynamic-refine / --fades'
+ * blockVariance pass) keeps the reference's own body, as do pictures below the size gate. */
+void LookaheadTLD::calcAdaptiveQuantFrame(Frame* curFrame, x265_param* param)
+{
+    const PicYuv* pic = curFrame->m_fencPic;
+    Lowres& lr = curFrame->m_lowres;
+    const int q = param->rc.qgSize == 8 ? 8 : 16;
+    const int bw = (pic->m_picWidth + q - 1) / q, bh = (pic->m_picHeight + q - 1) / q;
+    const int blockCount = q == 8 ? (int)(lr.maxBlocksInRowFullRes * lr.maxBlocksInColFullRes) : widthInCU * heightInCU;
+    const bool mono = param->internalCsp == X265_CSP_I400 || pic->m_picCsp == X265_CSP_I400;
+    const bool covered = gaq.enabled && param->rc.aqMode >= X265_AQ_VARIANCE && param->rc.aqMode <= X265_AQ_AUTO_VARIANCE_BIASED && param->rc.aqStrength > 0 &&
+                         !param->rc.hevcAq && !(param->rc.bStatRead && param->rc.cuTree && IS_REFERENCED(curFrame)) && !param->bHDR10Opt && !curFrame->m_quantOffsets &&
+                         !param->bDynamicRefine && !param->bEnableFades && (mono || (param->internalCsp == X265_CSP_I420 && pic->m_picCsp == X265_CSP_I420)) &&
+                         bw * bh == blockCount && (q == 16 || bw == (int)lr.maxBlocksInRowFullRes);
+    if (!covered || blockCount < gaq.minBlocks)
+    {
+        if (gaq.enabled) (covered ? gaq.gated : gaq.passed).fetch_add(1, std::memory_order_relaxed);
+        x265ref_orig_calcAdaptiveQuantFrame(this, curFrame, param);
+        return;
+    }
+    const int weightp = param->bEnableWeightedPred || param->bEnableWeightedBiPred;
+    int rc = 0;
+    if (gaq.host)
+    {
+        AqFrameHostParams a;
+        memset(&a, 0, sizeof(a));
+        a.depth = X265_DEPTH; a.y = pic->m_picOrg[0]; a.stride = pic->m_stride;
+        if (!mono) { a.cb = pic->m_picOrg[1]; a.cr = pic->m_picOrg[2]; a.stride_c = pic->m_strideC; }
+        a.width = pic->m_picWidth; a.height = pic->m_picHeight; a.qg_size = q; a.aq_mode = param->rc.aqMode; a.aq_strength = param->rc.aqStrength;
+        a.width_in_cu = widthInCU; a.height_in_cu = heightInCU; a.normalise_wp = weightp;
+        a.qp_aq_offset = lr.qpAqOffset; a.qp_cutree_offset = lr.qpCuTreeOffset; a.inv_qscale = lr.invQscaleFactor;
+        a.inv_qscale_8x8 = q == 8 ? lr.invQscaleFactor8x8 : NULL;
+        a.wp_sum = lr.wp_sum; a.wp_ssd = lr.wp_ssd;
+        rc = gaq.host(&a);
+    }
+    else
+    {
+        std::vector<uint32_t> energy(blockCount);
+        gaq.oracle(pic->m_picOrg[0], mono ? NULL : pic->m_picOrg[1], mono ? NULL : pic->m_picOrg[2], pic->m_stride, pic->m_strideC, pic->m_picWidth, pic->m_picHeight,
+                   q, param->rc.aqMode, param->rc.aqStrength, weightp, energy.data(), lr.qpAqOffset, lr.invQscaleFactor, lr.wp_sum, lr.wp_ssd);
+        memcpy(lr.qpCuTreeOffset, lr.qpAqOffset, (size_t)blockCount * sizeof(double));
+        if (q == 8)
+            for (int cy = 0; cy < heightInCU; cy++)
+                for (int cx = 0; cx < widthInCU; cx++)
+                {
+                    const int* f = lr.invQscaleFactor + cx * 2 + cy * widthInCU * 4;
+                    lr.invQscaleFactor8x8[cx + cy * widthInCU] = (f[0] + f[1] + f[bw] + f[bw + 1]) / 4;
+                }
+    }
+    if (rc)
+    {
+        gaq.failed.fetch_add(1, std::memory_order_relaxed);
+        fprintf(stderr, "ref_seam: adaptive-quantisation provider failed (%d); the reference's loop runs instead\n", rc);
+        x265ref_orig_calcAdaptiveQuantFrame(this, curFrame, param);
+        return;
+    }
+    gaq.served.fetch_add(1, std::memory_order_relaxed);
+    if (gaq.verify)
+    {
+        const std::vector<double> aq(lr.qpAqOffset, lr.qpAqOffset + blockCount), ct(lr.qpCuTreeOffset, lr.qpCuTreeOffset + blockCount);
+        const std::vector<int> inv(lr.invQscaleFactor, lr.invQscaleFactor + blockCount);
+        std::vector<int> inv8;
+        if (q == 8) inv8.assign(lr.invQscaleFactor8x8, lr.invQscaleFactor8x8 + widthInCU * heightInCU);
+        uint64_t sum[3], ssd[3];
+        memcpy(sum, lr.wp_sum, sizeof(sum)); memcpy(ssd, lr.wp_ssd, sizeof(ssd));
+        x265ref_orig_calcAdaptiveQuantFrame(this, curFrame, param);
+        if (memcmp(aq.data(), lr.qpAqOffset, (size_t)blockCount * sizeof(double)) || memcmp(ct.data(), lr.qpCuTreeOffset, (size_t)blockCount * sizeof(double)) ||
+            memcmp(inv.data(), lr.invQscaleFactor, (size_t)blockCount * sizeof(int)) || memcmp(sum, lr.wp_sum, sizeof(sum)) || memcmp(ssd, lr.wp_ssd, sizeof(ssd)) ||
+            (q == 8 && memcmp(inv8.data(), lr.invQscaleFactor8x8, inv8.size() * sizeof(int))))
+        {
+            fprintf(stderr, "ref_seam: ADAPTIVE QUANTISATION VERIFY MISMATCH poc %d\n", curFrame->m_poc);
+            gaq.mismatches.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
+}
+
 /* The intra half of the lookahead: the per-block work of LookaheadTLD::lowresIntraEstimate (slicetype.cpp:716-777: DC, planar and the
  * angular scan of every 8x8 block) as one provider call; the AQ weighting and the sums are the reference's own lines :779-803. */
 void LookaheadTLD::lowresIntraEstimate(Lowres& fenc, uint32_t qgSize)
@@ -1159,7 +1265,7 @@ int x265ref_seam_configure_streamed(void* ctx, void* picture_rows, void* pair_op
     return 0;
 }
 
-void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; gs.enabled = false; }
+void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; gs.enabled = false; gaq.enabled = false; }
 
 /* sub-sample seam: provider = x265hip_phase_cache_submit / _planes / _ready signatures (NULL submit = off); geometry = the PicYuv
  * buffers of the encode about to start.  flags: 1 = verify every served call against the reference's own function, 2 = wait for planes */
@@ -1257,6 +1363,22 @@ void x265ref_lookahead_seam_stats(uint64_t* out) { out[0] = gla.served; out[1] =
  * number of estimates the gate has sent there since the last configure */
 uint64_t x265ref_lookahead_seam_min_blocks(int min_blocks) { if (min_blocks >= 0) gla.minBlocks = min_blocks; return gla.gated; }
 uint64_t x265ref_lookahead_seam_mismatches(void) { return gla.mismatches; }
+
+/* AQ seam: host_fn = x265hip_aq_frame_host (the product) or NULL; oracle_fn = x265oracle_aq_frame_d<depth> (CPU checker, GPU-less tests) or
+ * NULL; both NULL: off.  verify: the reference's own calcAdaptiveQuantFrame runs after every served picture and its arrays are compared
+ * with the served ones bit for bit.  min_blocks: pictures with fewer quantisation groups keep the reference's loop. */
+int x265ref_aq_seam_configure(void* host_fn, void* oracle_fn, int verify, int min_blocks)
+{
+    gaq.host = (aq_host_fn)host_fn;
+    gaq.oracle = (aq_oracle_fn)oracle_fn;
+    gaq.verify = verify != 0;
+    gaq.minBlocks = min_blocks < 0 ? 0 : min_blocks;
+    gaq.served = 0; gaq.passed = 0; gaq.failed = 0; gaq.mismatches = 0; gaq.gated = 0;
+    gaq.enabled = host_fn || oracle_fn;
+    return 0;
+}
+/* out[5]: pictures served, passed to the reference's loop (a mode / option the service does not cover), failed, verify mismatches, gated by size */
+void x265ref_aq_seam_stats(uint64_t* out) { out[0] = gaq.served; out[1] = gaq.passed; out[2] = gaq.failed; out[3] = gaq.mismatches; out[4] = gaq.gated; }
 
 /* table filler with the x265hip_setup_primitives signature: installs the lookup stubs over the host's own sad family */
 int x265ref_seam_fill_table(void* table, size_t bytes, int depth)

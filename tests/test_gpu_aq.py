@@ -111,3 +111,45 @@ def test_hevc_aq_rejects_bad_arguments():
         A.aq_hevc_quadrants(8, pic.t, pic.stride, pic.org, 64, 64, 24, sums)
     with pytest.raises(A.X265HipError):
         A.aq_hevc_offsets(64, 64, 16, 0.5, np.zeros((16, 4, 2), np.uint64))
+
+
+# ---- round 4: the same pass behind host pointers, as the pre-lookahead calls it ------------------------------------------------------------
+@pytest.mark.parametrize("depth,width,height,qg,mode,strength,chroma,weightp", [(8, 640, 360, 16, 2, 1.0, True, True), (8, 416, 240, 16, 1, 1.0, True, False),
+                                                                            (8, 640, 352, 8, 3, 1.3, True, True), (8, 250, 138, 16, 2, 1.0, False, True),
+                                                                            (10, 384, 256, 8, 2, 0.6, True, True), (12, 256, 128, 16, 3, 1.0, True, True),
+                                                                            (8, 3840, 2160, 16, 2, 1.0, True, True), (10, 3840, 2160, 16, 2, 1.0, True, True)])
+def test_aq_frame_host_fills_the_lowres_arrays_like_the_reference_loop(depth, width, height, qg, mode, strength, chroma, weightp, seed=202):
+    """x265hip_aq_frame_host: planes in host memory in (strided, padded, as PicYuv holds them), the Lowres arrays out - block energies, both QP offset
+    arrays, x265_exp2fix8 factors, the 2x2 averages of --qg-size 8, wp_sum and the normalised (or raw) wp_ssd - against the oracle's
+    calcAdaptiveQuantFrame, which tests/test_oracle_classes_vs_reference.py pins to the real class."""
+    O = _oracle()
+    yimg, cbimg, crimg = F.synth_clip(width, height, 1, depth=depth, seed=seed)[0]
+    ypad = _pad(np.ascontiguousarray(yimg), 32)
+    kw = {}
+    if chroma:
+        cpad = [_pad(np.ascontiguousarray(c)) for c in (cbimg, crimg)]
+        kw = dict(cb=cpad[0][0], cr=cpad[1][0], stride_c=cpad[0][1], org_c=cpad[0][2])
+    grid = (((width // 2) + 7) // 8, ((height // 2) + 7) // 8)
+    use8 = qg == 8 and 2 * grid[0] <= (width + 7) // 8 and 2 * grid[1] <= (height + 7) // 8
+    got = A.aq_frame_host(depth, ypad[0], ypad[1], ypad[2], width, height, qg, mode, strength, normalise_wp=weightp, lowres_grid=grid if use8 else None, **kw)
+    energy, eqp, einv, esum, essd = O.aq_frame(depth, ypad[0], ypad[1], ypad[2], width, height, qg_size=qg, aq_mode=mode, aq_strength=strength, weightp=weightp, **kw)
+    assert np.array_equal(got["energy"], energy), "block energies differ"
+    assert np.array_equal(got["wp_sum"], esum) and np.array_equal(got["wp_ssd"], essd), (got["wp_sum"], esum, got["wp_ssd"], essd)
+    assert np.array_equal(got["qp_aq_offset"], eqp) and np.array_equal(got["qp_cutree_offset"], eqp), f"{np.count_nonzero(got['qp_aq_offset'] != eqp)} QP offsets differ"
+    assert np.array_equal(got["inv_qscale"], einv) and len(np.unique(einv)) > 4
+    if use8:
+        bw = (width + 7) // 8
+        f = einv.reshape(-1, bw)
+        want = (f[0:2 * grid[1]:2, 0:2 * grid[0]:2] + f[0:2 * grid[1]:2, 1:2 * grid[0]:2] + f[1:2 * grid[1]:2, 0:2 * grid[0]:2] + f[1:2 * grid[1]:2, 1:2 * grid[0]:2]) // 4
+        assert np.array_equal(got["inv_qscale_8x8"].reshape(grid[1], grid[0]), want)
+
+
+def test_aq_frame_host_rejects_what_it_does_not_cover():
+    y = np.zeros(64 * 64, np.uint8)
+    for bad in (dict(qg_size=32), dict(aq_mode=0), dict(aq_mode=4), dict(aq_strength=0.0), dict(depth=9)):
+        kw = dict(depth=8, qg_size=16, aq_mode=2, aq_strength=1.0)
+        kw.update(bad)
+        with pytest.raises(A.X265HipError):
+            A.aq_frame_host(kw["depth"], y, 64, 0, 64, 64, kw["qg_size"], kw["aq_mode"], kw["aq_strength"])
+    with pytest.raises(A.X265HipError):
+        A.aq_frame_host(8, y, 64, 0, 64, 64, 16, 2, 1.0, cb=y)          # cb without cr

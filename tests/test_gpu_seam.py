@@ -683,3 +683,18 @@ def test_stream_services_can_be_pinned_to_a_device():
         with pytest.raises(A.X265HipError) as e:
             cls(*args, device=n)
         assert "device" in str(e.value)
+
+
+# ---- round 4: the pre-lookahead's adaptive-quantisation pass from x265hip_aq_frame_host ------------------------------------------------
+@pytest.mark.parametrize("depth,w,h,extra", [(8, 256, 192, []), (8, 256, 192, [("aq-mode", "3"), ("aq-strength", "1.4")]), (8, 256, 192, [("qg-size", "8")]),
+                                             (10, 192, 128, [("aq-mode", "1")]), (8, 256, 192, [("no-weightp", None), ("no-weightb", None)])])
+def test_aq_seam_on_the_gpu_fills_the_arrays_the_reference_loop_would(depth, w, h, extra):
+    """The real encoder with LookaheadTLD::calcAdaptiveQuantFrame served by x265hip_aq_frame_host for every source picture; after each one the
+    reference's own function recomputes qpAqOffset / qpCuTreeOffset / invQscaleFactor (+ 8x8) / wp_sum / wp_ssd and the binding compares bit for
+    bit.  Byte-identical bitstream."""
+    import test_seam_cpu as T
+    opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24")] + extra
+    base, got, rep = T.run_pair(depth, w, h, 6, "medium", opts, "gpu", rng=8, streamed=True, min_level=1, slots=16, aq="gpu")
+    a = rep["aq_seam"]
+    assert got[0] == base[0], f"seam changed the bitstream: {a}"
+    assert a["pictures_served"] == 6 and a["verify_mismatches"] == 0 and a["failed"] == 0 and a["passed_to_reference_loop"] == 0, a

@@ -22,7 +22,7 @@ def _tools():
 
 
 def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False, lookahead=None, subpel=None, surf_format=None,
-             streamed=False, min_level=0, slots=8, subpel_slots=6, layout=0, centre_range=0):
+             streamed=False, min_level=0, slots=8, subpel_slots=6, layout=0, centre_range=0, aq=None, width_clip=None):
     EB, SD = _tools()
     try:
         plain = EB.ref_lib(depth)
@@ -34,13 +34,38 @@ def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify
     base = EB.encode(plain, yuv, w, h, nframes, preset, opts)
     lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=slots, min_pu=min_pu, verify=verify, wait=wait, lookahead=lookahead,
                                                   subpel=subpel, surf_format=surf_format, streamed=streamed, min_level=min_level, subpel_slots=subpel_slots,
-                                                  layout=layout, centre_range=centre_range)
+                                                  layout=layout, centre_range=centre_range, aq=aq)
     try:
         got = EB.encode(lib, yuv, w, h, nframes, preset, opts, filler)
         rep = report()
     finally:
         close()
     return base, got, rep
+
+
+# ---- round 4: the adaptive-quantisation pass of the pre-lookahead behind one provider call --------------------------------------------
+@pytest.mark.reference
+@pytest.mark.parametrize("depth,w,h,extra,served", [(8, 256, 192, [], True), (8, 256, 192, [("aq-mode", "1")], True), (8, 256, 192, [("aq-mode", "3"), ("aq-strength", "1.4")], True),
+                                                    (8, 256, 192, [("qg-size", "8"), ("ctu", "64")], True), (10, 192, 128, [("aq-mode", "3")], True),
+                                                    (8, 200, 136, [("qg-size", "8")], None), (8, 256, 192, [("no-weightp", None), ("no-weightb", None)], True),
+                                                    (8, 256, 192, [("aq-mode", "4")], False), (8, 256, 192, [("hevc-aq", None)], False), (8, 256, 192, [("aq-mode", "0")], False)])
+def test_aq_seam_serves_the_same_offsets_as_the_reference_loop(depth, w, h, extra, served):
+    """LookaheadTLD::calcAdaptiveQuantFrame through ref_seam's replacement: the provider (here the CPU restatement) fills qpAqOffset /
+    qpCuTreeOffset / invQscaleFactor (+ the 8x8 averages at --qg-size 8) / wp_sum / wp_ssd, then - verify on - the reference's own function
+    recomputes them and every array is compared bit for bit; modes the service does not cover (edge AQ, --hevc-aq, AQ off) stay with the
+    reference.  The bitstream cannot change."""
+    opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24")] + extra
+    base, got, rep = run_pair(depth, w, h, 6, "medium", opts, "oracle", rng=8, streamed=True, min_level=1, slots=16, aq="oracle")
+    a = rep["aq_seam"]
+    if ("aq-mode", "4") not in extra:        # the reference's own edge mode encodes the same input differently on every run (three runs, three md5s): nothing to compare
+        assert got[0] == base[0], f"seam changed the bitstream: {a}"
+    assert a["verify_mismatches"] == 0 and a["failed"] == 0, a
+    if served is True:
+        assert a["pictures_served"] == 6 and a["passed_to_reference_loop"] == 0, a
+    elif served is False:
+        assert a["pictures_served"] == 0 and a["passed_to_reference_loop"] == 6, a
+    else:
+        assert a["pictures_served"] + a["passed_to_reference_loop"] == 6, a          # a grid the qg-8 arrays index differently: whichever, no mismatch
 
 
 @pytest.mark.reference

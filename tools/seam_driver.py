@@ -642,7 +642,7 @@ class StreamGpuPhaseProvider:
 
 
 def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
-            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0, min_ctus=0, build=""):
+            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0, min_ctus=0, build="", aq=None, aq_min_blocks=0):
     """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
     the picture-granular providers need --frame-threads 1, streamed=True (row-granular providers) serves under any --frame-threads."""
     lib = seam_lib(depth, build)
@@ -690,6 +690,20 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     else:
         lib.x265ref_lookahead_seam_configure(None, None, None, None)
 
+    # the adaptive-quantisation seam (LookaheadTLD::calcAdaptiveQuantFrame as one provider call per source picture): "gpu" = x265hip_aq_frame_host,
+    # "oracle" = the CPU restatement, None = off; verify = the reference's own function runs after every served picture, arrays compared bit for bit.
+    # aq_min_blocks None = 16384 quantisation groups (serve from 4K up at qg 16, like the lookahead seam's gate)
+    lib.x265ref_aq_seam_configure.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    if aq == "gpu":
+        A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+        lib.x265ref_aq_seam_configure(ctypes.cast(A.lib().x265hip_aq_frame_host, ctypes.c_void_p), None, int(bool(verify)), 16384 if aq_min_blocks is None else aq_min_blocks)
+    elif aq == "oracle":
+        keep_aq = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libx265oracle.so"))
+        lib.x265ref_aq_seam_configure(None, ctypes.cast(getattr(keep_aq, f"x265oracle_aq_frame_d{depth}"), ctypes.c_void_p), int(bool(verify)),
+                                      16384 if aq_min_blocks is None else aq_min_blocks)
+    else:
+        lib.x265ref_aq_seam_configure(None, None, 0, 0)
+
     # the sub-sample seam (MotionEstimate::subpelCompare reads precomputed phase planes): "gpu" = x265hip_phase_cache, "oracle" = CPU checker
     lib.x265ref_subpel_seam_configure.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int]
     lib.x265ref_subpel_seam_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
@@ -733,6 +747,10 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
         d["lookahead_seam"] = {"provider": lookahead, "frame_cost_estimates_served": int(la[0]), "passed_to_reference_loop": int(la[1]), "failed": int(la[2]),
                                "intra_estimates_served": int(la[3]), "verify_mismatches": int(lib.x265ref_lookahead_seam_mismatches()),
                                "left_to_the_reference_by_the_size_gate": int(lib.x265ref_lookahead_seam_min_blocks(-1))}
+        aqs = (ctypes.c_uint64 * 5)()
+        lib.x265ref_aq_seam_stats(aqs)
+        d["aq_seam"] = {"provider": aq, "pictures_served": int(aqs[0]), "passed_to_reference_loop": int(aqs[1]), "failed": int(aqs[2]), "verify_mismatches": int(aqs[3]),
+                        "left_to_the_reference_by_the_size_gate": int(aqs[4])}
         if sub:
             so = (ctypes.c_uint64 * 6)()
             lib.x265ref_subpel_seam_stats(so)
@@ -742,6 +760,7 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
 
     def close():
         lib.x265ref_seam_disable()
+        lib.x265ref_aq_seam_configure(None, None, 0, 0)
         prov.close()
         if sub:
             sub.close()

@@ -288,3 +288,81 @@ extern "C" int x265hip_lowres_intra_host(const x265hip_lowres_intra_host_params*
     X265HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
+
+// ---- LookaheadTLD::calcAdaptiveQuantFrame behind host pointers (encoder/slicetype.cpp:444-694) --------------------------------------
+// The pixel work (acEnergyCu of every block: 1.5 samples read per luma sample) is one launch of x265hip_aq_energy over a device copy
+// of the picture; what is left on the calling thread is the reference's own double-precision pass over the block energies.
+extern "C" int x265hip_aq_frame_host(const x265hip_aq_frame_host_params* p)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->y || !p->qp_aq_offset || !p->qp_cutree_offset || !p->inv_qscale || !p->wp_sum || !p->wp_ssd) { set_error("aq_frame_host: NULL operand"); return X265HIP_EINVAL; }
+    if ((p->cb == NULL) != (p->cr == NULL)) { set_error("aq_frame_host: cb and cr go together"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("aq_frame_host: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->qg_size != 16 && p->qg_size != 8) { set_error("aq_frame_host: qg_size %d", p->qg_size); return X265HIP_EINVAL; }
+    if (p->aq_mode < 1 || p->aq_mode > 3 || !(p->aq_strength > 0)) { set_error("aq_frame_host: aq_mode %d strength %g (modes 1..3 with a strength)", p->aq_mode, p->aq_strength); return X265HIP_EINVAL; }
+    if (p->width <= 0 || p->height <= 0 || p->stride < p->width || (p->cb && p->stride_c < p->width / 2)) { set_error("aq_frame_host: geometry"); return X265HIP_EINVAL; }
+    if (p->inv_qscale_8x8 && (p->qg_size != 8 || p->width_in_cu <= 0 || p->height_in_cu <= 0)) { set_error("aq_frame_host: inv_qscale_8x8 goes with qg_size 8 and the lowres grid"); return X265HIP_EINVAL; }
+    const int q = p->qg_size, bpp = p->depth == 8 ? 1 : 2;
+    const int bw = (p->width + q - 1) / q, bh = (p->height + q - 1) / q, nblk = bw * bh;
+    if (p->inv_qscale_8x8 && (2 * p->width_in_cu > bw || 2 * p->height_in_cu > bh)) { set_error("aq_frame_host: the lowres grid reaches past the qg-8 blocks"); return X265HIP_EINVAL; }
+    // the blocks' footprint, and the chroma one (4:2:0: half of it)
+    const size_t lw = (size_t)bw * q * bpp, lh = (size_t)bh * q, cw = lw / 2, ch = lh / 2;
+    const size_t pitchY = align256(lw), pitchC = align256(cw);
+    const size_t offCb = align256(pitchY * lh), offCr = offCb + (p->cb ? align256(pitchC * ch) : 0), offE = offCr + (p->cb ? align256(pitchC * ch) : 0);
+    const size_t offWp = offE + align256((size_t)nblk * 4), total = offWp + 256;
+    LaThread& t = la_thread();
+    rc = t.ensure(total);
+    if (rc) return rc;
+    hipStream_t s = t.stream;
+    X265HIP_TRY(hipMemcpy2DAsync(t.dev, pitchY, p->y, (size_t)p->stride * bpp, lw, lh, hipMemcpyHostToDevice, s));
+    if (p->cb)
+    {
+        X265HIP_TRY(hipMemcpy2DAsync(t.dev + offCb, pitchC, p->cb, (size_t)p->stride_c * bpp, cw, ch, hipMemcpyHostToDevice, s));
+        X265HIP_TRY(hipMemcpy2DAsync(t.dev + offCr, pitchC, p->cr, (size_t)p->stride_c * bpp, cw, ch, hipMemcpyHostToDevice, s));
+    }
+    x265hip_aq_energy_params e;
+    memset(&e, 0, sizeof(e));
+    e.depth = p->depth; e.y = t.dev; e.stride = (intptr_t)(pitchY / bpp);
+    if (p->cb) { e.cb = t.dev + offCb; e.cr = t.dev + offCr; e.stride_c = (intptr_t)(pitchC / bpp); }
+    e.width = p->width; e.height = p->height; e.qg_size = q;
+    e.energy = (uint32_t*)(t.dev + offE); e.wp = (uint64_t*)(t.dev + offWp);
+    rc = x265hip_aq_energy(&e, s);
+    if (rc) return rc;
+    std::vector<uint32_t> own;
+    uint32_t* energy = p->energy;
+    if (!energy) { own.resize(nblk); energy = own.data(); }
+    uint64_t wp[6];
+    X265HIP_TRY(hipMemcpyAsync(energy, t.dev + offE, (size_t)nblk * 4, hipMemcpyDeviceToHost, s));
+    X265HIP_TRY(hipMemcpyAsync(wp, t.dev + offWp, sizeof(wp), hipMemcpyDeviceToHost, s));
+    X265HIP_TRY(hipStreamSynchronize(s));
+    x265hip_aq_offsets_params o;
+    memset(&o, 0, sizeof(o));
+    o.depth = p->depth; o.qg_size = q; o.aq_mode = p->aq_mode; o.aq_strength = p->aq_strength; o.nblocks = nblk;
+    o.energy = energy; o.qp_aq_offset = p->qp_aq_offset; o.inv_qscale = p->inv_qscale;
+    rc = x265hip_aq_offsets(&o);
+    if (rc) return rc;
+    if (p->qp_cutree_offset != p->qp_aq_offset) memcpy(p->qp_cutree_offset, p->qp_aq_offset, (size_t)nblk * sizeof(double));
+    if (p->inv_qscale_8x8)                                     // slicetype.cpp:626-640: the four qg-8 factors under a lowres block, averaged
+        for (int cy = 0; cy < p->height_in_cu; cy++)
+            for (int cx = 0; cx < p->width_in_cu; cx++)
+            {
+                const int32_t* f = p->inv_qscale + cx * 2 + cy * p->width_in_cu * 4;
+                p->inv_qscale_8x8[cx + cy * p->width_in_cu] = (f[0] + f[1] + f[bw] + f[bw + 1]) / 4;
+            }
+    // :662-675 (the reference rounds the picture to 16s here whatever the quantisation group)
+    const int w16 = ((p->width + 8) >> 4) << 4, h16 = ((p->height + 8) >> 4) << 4;
+    for (int i = 0; i < 3; i++)
+    {
+        const uint64_t sum = (i && !p->cb) ? 0 : wp[i], ssd = (i && !p->cb) ? 0 : wp[3 + i];
+        p->wp_sum[i] = sum;
+        if (p->normalise_wp)
+        {
+            const int wi = i ? w16 >> 1 : w16, hi = i ? h16 >> 1 : h16;          // int arithmetic as the reference's width[i] * height[i]
+            p->wp_ssd[i] = ssd - (sum * sum + (wi * hi) / 2) / (wi * hi);
+        }
+        else
+            p->wp_ssd[i] = ssd;
+    }
+    return 0;
+}

@@ -367,6 +367,42 @@ def aq_offsets(depth, qg_size, aq_mode, aq_strength, energy):
     return qp, inv
 
 
+class AqFrameHostParams(ctypes.Structure):
+    """x265hip_aq_frame_host_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("y", ctypes.c_void_p), ("cb", ctypes.c_void_p), ("cr", ctypes.c_void_p),
+                ("stride", ctypes.c_ssize_t), ("stride_c", ctypes.c_ssize_t),
+                ("width", ctypes.c_int), ("height", ctypes.c_int), ("qg_size", ctypes.c_int), ("aq_mode", ctypes.c_int), ("aq_strength", ctypes.c_double),
+                ("width_in_cu", ctypes.c_int), ("height_in_cu", ctypes.c_int), ("normalise_wp", ctypes.c_int),
+                ("qp_aq_offset", ctypes.c_void_p), ("qp_cutree_offset", ctypes.c_void_p), ("inv_qscale", ctypes.c_void_p), ("inv_qscale_8x8", ctypes.c_void_p),
+                ("energy", ctypes.c_void_p), ("wp_sum", ctypes.c_void_p), ("wp_ssd", ctypes.c_void_p)]
+
+
+def aq_frame_host(depth, y, stride, org, width, height, qg_size, aq_mode, aq_strength, cb=None, cr=None, stride_c=0, org_c=0, normalise_wp=True, lowres_grid=None):
+    """LookaheadTLD::calcAdaptiveQuantFrame behind host pointers (x265hip_aq_frame_host): y / cb / cr = numpy planes in HOST memory, sample
+    (0,0) at org / org_c.  Returns dict(energy, qp_aq_offset, qp_cutree_offset, inv_qscale, inv_qscale_8x8 or None, wp_sum, wp_ssd)."""
+    import numpy as np
+    n = ((width + qg_size - 1) // qg_size) * ((height + qg_size - 1) // qg_size)
+    out = {"energy": np.zeros(n, np.uint32), "qp_aq_offset": np.zeros(n, np.float64), "qp_cutree_offset": np.zeros(n, np.float64), "inv_qscale": np.zeros(n, np.int32),
+           "inv_qscale_8x8": None, "wp_sum": np.zeros(3, np.uint64), "wp_ssd": np.zeros(3, np.uint64)}
+    es = y.itemsize
+    p = AqFrameHostParams()
+    p.depth, p.stride, p.stride_c, p.width, p.height, p.qg_size, p.aq_mode, p.aq_strength = depth, stride, stride_c, width, height, qg_size, aq_mode, float(aq_strength)
+    p.y = y.ctypes.data + org * es
+    p.cb = None if cb is None else cb.ctypes.data + org_c * es
+    p.cr = None if cr is None else cr.ctypes.data + org_c * es
+    p.normalise_wp = int(bool(normalise_wp))
+    if lowres_grid:
+        p.width_in_cu, p.height_in_cu = lowres_grid
+        out["inv_qscale_8x8"] = np.zeros(lowres_grid[0] * lowres_grid[1], np.int32)
+        p.inv_qscale_8x8 = out["inv_qscale_8x8"].ctypes.data
+    for k in ("energy", "qp_aq_offset", "qp_cutree_offset", "inv_qscale", "wp_sum", "wp_ssd"):
+        setattr(p, k, out[k].ctypes.data)
+    f = lib().x265hip_aq_frame_host
+    f.argtypes = [ctypes.POINTER(AqFrameHostParams)]
+    check(f(ctypes.byref(p)), "x265hip_aq_frame_host")
+    return out
+
+
 class AqHevcParams(ctypes.Structure):
     """x265hip_aq_hevc_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("y", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),
