@@ -469,6 +469,50 @@ typedef struct x265hip_aq_frame_host_params
     uint64_t* wp_sum; uint64_t* wp_ssd;
 } x265hip_aq_frame_host_params;
 int x265hip_aq_frame_host(const x265hip_aq_frame_host_params* p);
+/* weightAnalyse (encoder/weightPrediction.cpp:222-497; once per P / B slice from FrameEncoder::compressFrame when --weightp / --weightb
+ * are on) behind host pointers, 4:2:0: per list the float guess from the pictures' wp_ssd / wp_sum, and - unless the early exits take the
+ * plane - a motion-compensated copy of the reference plane from the lookahead's lowres vectors (mcLuma :59-92 through Lowres::lowresMC,
+ * mcChroma :96-166 with the 4-tap filters), then weightCost (:172-217: weight_pp + the 8x8 SATD sum, luma blocks capped by the intra
+ * cost) for the unweighted plane and EVERY (scale, offset) pair the reference's scan could visit (<= 9 x 5) in one launch; the scan's
+ * own order and early break, sliceHeaderCost, the denominator reduction and the 0.998 acceptance are replayed on the calling thread from
+ * the downloaded scores.  Same weights as the reference's loop, which spends 2 x (weight_pp + SATD) of a whole plane per pair visited.
+ *   lowres / ref[].lowres[4] : HOST, sample (0,0) of lowres planes (Lowres::lowresPlane) of one geometry: lowres_stride, lowres_width x
+ *                              lowres_lines (multiples of 8), margins as allocated (the compensated blocks reach 8 + 1 samples outside)
+ *   cb / cr, ref[].cb / cr   : HOST, sample (0,0) of the SOURCE pictures' chroma planes (PicYuv::m_picOrg[1 / 2]); the references' with
+ *                              their borders extended (weightPrediction.cpp:333-343), margin_xc / margin_yc >= 16 samples of it are read
+ *   ref[].mvs                : HOST int32 [lowres blocks][2] (Lowres::lowresMvs[list][distance]) when the lookahead searched that
+ *                              distance (distance <= bframes + 1 and mvs[0].x != 0x7FFF), else NULL: no compensation
+ *   intra_cost               : HOST int32 [lowres blocks] (Lowres::intraCost)
+ *   wp_ssd / wp_sum          : the pictures' Lowres::wp_ssd / wp_sum (x265hip_aq_frame_host fills them)
+ *   plane_key / ref[].plane_key : as x265hip_lowres_cost_host's keys (0 = upload on every call): the lowres planes of a picture keep one
+ *                              device copy across calls, shared with the frame cost estimates
+ *   weights                  : HOST int32 [2][3][4] out = { wtPresent, inputWeight, log2WeightDenom, inputOffset } of reference 0 per
+ *                              (list, plane); denoms: HOST int32 [2][2] out = lumaDenom, chromaDenom after each list (:468-474: what the
+ *                              list's other references are reset to) */
+typedef struct x265hip_weight_analyse_ref
+{
+    const void* lowres[4];
+    const void* cb; const void* cr;
+    const int32_t* mvs;
+    uint64_t wp_ssd[3], wp_sum[3];
+    uint64_t plane_key;
+} x265hip_weight_analyse_ref;
+typedef struct x265hip_weight_analyse_host_params
+{
+    int depth;
+    const void* lowres; intptr_t lowres_stride;
+    int lowres_width, lowres_lines, lowres_margin_x, lowres_margin_y;
+    const void* cb; const void* cr; intptr_t stride_c;
+    int margin_xc, margin_yc;
+    int pic_width, pic_height;
+    const int32_t* intra_cost;
+    uint64_t wp_ssd[3], wp_sum[3];
+    uint64_t plane_key;
+    int nlists;
+    x265hip_weight_analyse_ref ref[2];
+    int32_t* weights; int32_t* denoms;
+} x265hip_weight_analyse_host_params;
+int x265hip_weight_analyse_host(const x265hip_weight_analyse_host_params* p);
 
 /* ---- in-loop deblocking of a device-resident luma reconstruction (deblocking half) ----
  * x265hip_deblock_bs_inter = Deblock::getBoundaryStrength (deblock.cpp:191-215) for a P picture with one reference cut into

@@ -630,3 +630,42 @@ def phase_planes(depth, src, stride, rows, chroma=False, avx2=False):
     fn.restype = None
     fn(s.ctypes.data, stride, rows, int(bool(chroma)), out.ctypes.data)
     return out
+
+
+class WaList(ctypes.Structure):
+    """x265oracle_wa_list (oracle/x265_oracle_pipeline7.c)."""
+    _fields_ = [("lowres", ctypes.c_void_p * 4), ("cb", ctypes.c_void_p), ("cr", ctypes.c_void_p), ("mvs", ctypes.c_void_p),
+                ("wp_ssd", ctypes.c_uint64 * 3), ("wp_sum", ctypes.c_uint64 * 3)]
+
+
+def weight_analyse(depth, cur, refs, pic_width, pic_height, intra_cost, avx2=False):
+    """CPU restatement of weightAnalyse (encoder/weightPrediction.cpp:222-497), 4:2:0.  cur = dict(lowres=(array, org), lowres_stride, lowres_width,
+    lowres_lines, cb=(array, org), cr=(array, org), stride_c, wp_ssd[3], wp_sum[3]); refs = 1 or 2 dicts(lowres=[(array, org)] * 4, cb, cr, mvs =
+    int32 [blocks, 2] or None, wp_ssd, wp_sum).  Returns (weights int32 [2, 3, 4] = present / weight / denom / offset, denoms int32 [2, 2])."""
+    L = lib(avx2)
+    fn = getattr(L, f"x265oracle_weight_analyse_d{depth}")
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    es = cur["lowres"][0].itemsize
+    at = lambda pair: pair[0].ctypes.data + pair[1] * es
+    lists = (WaList * 2)()
+    keep = []
+    for i, r in enumerate(refs):
+        for k in range(4):
+            lists[i].lowres[k] = at(r["lowres"][k])
+        lists[i].cb, lists[i].cr = at(r["cb"]), at(r["cr"])
+        if r.get("mvs") is not None:
+            m = np.ascontiguousarray(r["mvs"], np.int32)
+            keep.append(m)
+            lists[i].mvs = m.ctypes.data
+        for k in range(3):
+            lists[i].wp_ssd[k], lists[i].wp_sum[k] = int(r["wp_ssd"][k]), int(r["wp_sum"][k])
+    ssd, sm = np.asarray(cur["wp_ssd"], np.uint64), np.asarray(cur["wp_sum"], np.uint64)
+    ic = np.ascontiguousarray(intra_cost, np.int32)
+    half = max(cur["lowres_stride"] * cur["lowres_lines"], cur["stride_c"] * (pic_height // 2)) + 64
+    scratch = np.zeros(2 * half, cur["lowres"][0].dtype)
+    out, den = np.zeros((2, 3, 4), np.int32), np.zeros((2, 2), np.int32)
+    fn(at(cur["lowres"]), cur["lowres_stride"], cur["lowres_width"], cur["lowres_lines"], at(cur["cb"]), at(cur["cr"]), cur["stride_c"], pic_width, pic_height,
+       ic.ctypes.data, ssd.ctypes.data, sm.ctypes.data, len(refs), ctypes.addressof(lists), scratch.ctypes.data, half, out.ctypes.data, den.ctypes.data)
+    return out, den

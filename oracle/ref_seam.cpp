@@ -61,6 +61,7 @@ extern "C" int x265ref_orig_subpelCompare(MotionEstimate* self, ReferencePlanes*
 extern "C" int64_t x265ref_orig_estimateFrameCost(CostEstimateGroup* self, LookaheadTLD* tld, int p0, int p1, int b, bool bIntraPenalty);
 extern "C" void x265ref_orig_lowresIntraEstimate(LookaheadTLD* self, Lowres* fenc, uint32_t qgSize);
 extern "C" void x265ref_orig_calcAdaptiveQuantFrame(LookaheadTLD* self, Frame* curFrame, x265_param* param);
+extern "C" void x265ref_orig_weightAnalyse(Slice* slice, Frame* frame, x265_param* param);          /* references are pointers at the ABI level */
 extern "C" int x265ref_profile_fill_table(void* table, size_t bytes, int depth);          /* oracle/ref_profile.cpp: cycle-counting thunks */
 
 namespace {
@@ -147,6 +148,38 @@ struct AqSeam
     int minBlocks = 0;
     std::atomic<uint64_t> served{0}, passed{0}, failed{0}, mismatches{0}, gated{0};
 } gaq;
+
+/* x265hip_weight_analyse_ref / x265hip_weight_analyse_host_params (include/x265hip.h), mirrored field by field */
+struct WaRef { const void* lowres[4]; const void* cb; const void* cr; const int32_t* mvs; uint64_t wp_ssd[3], wp_sum[3]; uint64_t plane_key; };
+struct WaHostParams
+{
+    int depth;
+    const void* lowres; intptr_t lowres_stride;
+    int lowres_width, lowres_lines, lowres_margin_x, lowres_margin_y;
+    const void* cb; const void* cr; intptr_t stride_c;
+    int margin_xc, margin_yc;
+    int pic_width, pic_height;
+    const int32_t* intra_cost;
+    uint64_t wp_ssd[3], wp_sum[3];
+    uint64_t plane_key;
+    int nlists;
+    WaRef ref[2];
+    int32_t* weights; int32_t* denoms;
+};
+typedef int (*wa_host_fn)(const WaHostParams*);
+/* x265oracle_wa_list / x265oracle_weight_analyse_d<depth> (oracle/x265_oracle_pipeline7.c) */
+struct WaOracleList { const pixel* lowres[4]; const pixel* cb; const pixel* cr; const int32_t* mvs; uint64_t wp_ssd[3], wp_sum[3]; };
+typedef void (*wa_oracle_fn)(const pixel* fencLowres, intptr_t lowresStride, int lowresWidth, int lowresLines, const pixel* fencCb, const pixel* fencCr, intptr_t strideC,
+                             int picWidth, int picHeight, const int32_t* intraCost, const uint64_t* fencSsd, const uint64_t* fencSum, int nlists, const WaOracleList* lists,
+                             pixel* scratch, size_t scratchHalf, int32_t* out, int32_t* denoms);
+struct WaSeam
+{
+    bool enabled = false, verify = false;
+    wa_host_fn host = NULL;
+    wa_oracle_fn oracle = NULL;
+    int minBlocks = 0;
+    std::atomic<uint64_t> served{0}, passed{0}, failed{0}, mismatches{0}, gated{0}, weighted{0};
+} gwa;
 
 /* measurement aid (tools/encoder_profile.py --seams): cycles inside the wrapped stages, next to ref_profile.cpp's per-family thunks */
 struct SeamProf
@@ -1141,6 +1174,140 @@ void LookaheadTLD::calcAdaptiveQuantFrame(Frame* curFrame, x265_param* param)
     }
 }
 
+/* weightAnalyse (weightPrediction.cpp:222-520; FrameEncoder::compressFrame calls it for every P / B slice with --weightp / --weightb on): the
+ * compensated reference planes, weightCost of every (scale, offset) pair and the decision logic as ONE provider call
+ * (x265hip_weight_analyse_host) that returns reference 0's weights per (list, plane) and the denominators the other references are reset to;
+ * this wrapper does what stays host-side in the reference - the lazy border extension of the references' source chroma (:333-343) before,
+ * the table assembly (:468-479) after.  4:2:0 pictures whose lowres planes are a multiple of 8 wide and high (otherwise the reference's loop
+ * reads rows weight_pp never wrote, :180-184 against :196). */
+namespace X265_NS {
+void weightAnalyse(Slice& slice, Frame& frame, x265_param& param)
+{
+    PicYuv* pic = frame.m_fencPic;
+    Lowres& fenc = frame.m_lowres;
+    const int numPredDir = slice.isInterP() ? 1 : 2;
+    const bool covered = gwa.enabled && param.internalCsp == X265_CSP_I420 && pic->m_picCsp == X265_CSP_I420 && !(fenc.width & 7) && !(fenc.lines & 7) &&
+                         pic->m_picWidth >= 16 && pic->m_picHeight >= 16;
+    if (!covered || (fenc.width >> 3) * (fenc.lines >> 3) < gwa.minBlocks)
+    {
+        if (gwa.enabled) (covered ? gwa.gated : gwa.passed).fetch_add(1, std::memory_order_relaxed);
+        x265ref_orig_weightAnalyse(&slice, &frame, &param);
+        return;
+    }
+    const int hshift = 1, vshift = 1;
+    const int32_t* mvs[2] = { NULL, NULL };
+    for (int list = 0; list < numPredDir; list++)
+    {
+        Frame* refFrame = slice.m_refFrameList[list][0];
+        const int diffPoc = abs(slice.m_poc - refFrame->m_poc);
+        if (diffPoc <= param.bframes + 1 && fenc.lowresMvs[list][diffPoc][0].x != 0x7FFF)
+        {
+            mvs[list] = (const int32_t*)fenc.lowresMvs[list][diffPoc];
+            if (!refFrame->m_bChromaExtended)                              /* :333-343 */
+            {
+                refFrame->m_bChromaExtended = true;
+                PicYuv* refPic = refFrame->m_fencPic;
+                const int width = refPic->m_picWidth >> hshift, height = refPic->m_picHeight >> vshift;
+                extendPicBorder(refPic->m_picOrg[1], refPic->m_strideC, width, height, refPic->m_chromaMarginX, refPic->m_chromaMarginY);
+                extendPicBorder(refPic->m_picOrg[2], refPic->m_strideC, width, height, refPic->m_chromaMarginX, refPic->m_chromaMarginY);
+            }
+        }
+    }
+    int32_t out[2][3][4], denoms[2][2];
+    int rc = 0;
+    const ptrdiff_t pad = fenc.lowresPlane[0] - fenc.buffer[0];
+    if (gwa.host)
+    {
+        WaHostParams a;
+        memset(&a, 0, sizeof(a));
+        a.depth = X265_DEPTH; a.lowres = fenc.lowresPlane[0]; a.lowres_stride = fenc.lumaStride; a.lowres_width = fenc.width; a.lowres_lines = fenc.lines;
+        a.lowres_margin_y = (int)(pad / fenc.lumaStride); a.lowres_margin_x = (int)(pad % fenc.lumaStride);
+        a.cb = pic->m_picOrg[1]; a.cr = pic->m_picOrg[2]; a.stride_c = pic->m_strideC; a.margin_xc = pic->m_chromaMarginX; a.margin_yc = pic->m_chromaMarginY;
+        a.pic_width = pic->m_picWidth; a.pic_height = pic->m_picHeight; a.intra_cost = fenc.intraCost;
+        memcpy(a.wp_ssd, fenc.wp_ssd, sizeof(a.wp_ssd)); memcpy(a.wp_sum, fenc.wp_sum, sizeof(a.wp_sum));
+        const bool keyed = gla.enabled && gla.host;                        /* the lookahead seam's device copies of the same planes, same keys */
+        a.plane_key = keyed ? (gla.instance << 32) | ((uint64_t)(uint32_t)fenc.frameNum + 1) : 0;
+        a.nlists = numPredDir;
+        for (int list = 0; list < numPredDir; list++)
+        {
+            Frame* refFrame = slice.m_refFrameList[list][0];
+            Lowres& r = refFrame->m_lowres;
+            for (int k = 0; k < 4; k++) a.ref[list].lowres[k] = r.lowresPlane[k];
+            a.ref[list].cb = refFrame->m_fencPic->m_picOrg[1]; a.ref[list].cr = refFrame->m_fencPic->m_picOrg[2];
+            a.ref[list].mvs = mvs[list];
+            memcpy(a.ref[list].wp_ssd, r.wp_ssd, sizeof(r.wp_ssd)); memcpy(a.ref[list].wp_sum, r.wp_sum, sizeof(r.wp_sum));
+            a.ref[list].plane_key = keyed ? (gla.instance << 32) | ((uint64_t)(uint32_t)r.frameNum + 1) : 0;
+        }
+        a.weights = &out[0][0][0]; a.denoms = &denoms[0][0];
+        rc = gwa.host(&a);
+    }
+    else
+    {
+        WaOracleList lists[2];
+        memset(lists, 0, sizeof(lists));
+        for (int list = 0; list < numPredDir; list++)
+        {
+            Frame* refFrame = slice.m_refFrameList[list][0];
+            Lowres& r = refFrame->m_lowres;
+            for (int k = 0; k < 4; k++) lists[list].lowres[k] = r.lowresPlane[k];
+            lists[list].cb = refFrame->m_fencPic->m_picOrg[1]; lists[list].cr = refFrame->m_fencPic->m_picOrg[2];
+            lists[list].mvs = mvs[list];
+            memcpy(lists[list].wp_ssd, r.wp_ssd, sizeof(r.wp_ssd)); memcpy(lists[list].wp_sum, r.wp_sum, sizeof(r.wp_sum));
+        }
+        const size_t half = (size_t)pic->m_stride * pic->m_picHeight;
+        std::vector<pixel> scratch(2 * half + 64);
+        gwa.oracle(fenc.lowresPlane[0], fenc.lumaStride, fenc.width, fenc.lines, pic->m_picOrg[1], pic->m_picOrg[2], pic->m_strideC, pic->m_picWidth, pic->m_picHeight,
+                   fenc.intraCost, fenc.wp_ssd, fenc.wp_sum, numPredDir, lists, scratch.data(), half, &out[0][0][0], &denoms[0][0]);
+    }
+    if (rc)
+    {
+        gwa.failed.fetch_add(1, std::memory_order_relaxed);
+        fprintf(stderr, "ref_seam: weightAnalyse provider failed (%d); the reference's loop runs instead\n", rc);
+        x265ref_orig_weightAnalyse(&slice, &frame, &param);
+        return;
+    }
+    gwa.served.fetch_add(1, std::memory_order_relaxed);
+    WeightParam wp[2][MAX_NUM_REF][3];
+    memset(wp, 0, sizeof(wp));
+    bool any = false;
+    for (int list = 0; list < numPredDir; list++)
+    {
+        for (int plane = 0; plane < 3; plane++)
+        {
+            SET_WEIGHT(wp[list][0][plane], out[list][plane][0] != 0, out[list][plane][1], (uint32_t)out[list][plane][2], out[list][plane][3]);
+            any |= out[list][plane][0] != 0;
+        }
+        for (int ref = 1; ref < slice.m_numRefIdx[list]; ref++)          /* :468-474 */
+        {
+            SET_WEIGHT(wp[list][ref][0], false, 1 << denoms[list][0], (uint32_t)denoms[list][0], 0);
+            SET_WEIGHT(wp[list][ref][1], false, 1 << denoms[list][1], (uint32_t)denoms[list][1], 0);
+            SET_WEIGHT(wp[list][ref][2], false, 1 << denoms[list][1], (uint32_t)denoms[list][1], 0);
+        }
+    }
+    if (any) gwa.weighted.fetch_add(1, std::memory_order_relaxed);
+    memcpy(slice.m_weightPredTable, wp, sizeof(wp));
+    if (gwa.verify)
+    {
+        x265ref_orig_weightAnalyse(&slice, &frame, &param);
+        bool same = true;
+        for (int list = 0; list < numPredDir; list++)                    /* the reference leaves the entries past numRefIdx uninitialised */
+            for (int ref = 0; ref < slice.m_numRefIdx[list]; ref++)
+                for (int plane = 0; plane < 3; plane++)
+                {
+                    const WeightParam& x = wp[list][ref][plane]; const WeightParam& y = slice.m_weightPredTable[list][ref][plane];
+                    same &= x.log2WeightDenom == y.log2WeightDenom && x.inputWeight == y.inputWeight && x.inputOffset == y.inputOffset && !x.wtPresent == !y.wtPresent;
+                }
+        if (!same)
+        {
+            fprintf(stderr, "ref_seam: WEIGHT ANALYSE VERIFY MISMATCH poc %d: served luma (%d %d %u %d), reference (%d %d %u %d)\n", slice.m_poc,
+                    wp[0][0][0].wtPresent, wp[0][0][0].inputWeight, wp[0][0][0].log2WeightDenom, wp[0][0][0].inputOffset, slice.m_weightPredTable[0][0][0].wtPresent,
+                    slice.m_weightPredTable[0][0][0].inputWeight, slice.m_weightPredTable[0][0][0].log2WeightDenom, slice.m_weightPredTable[0][0][0].inputOffset);
+            gwa.mismatches.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
+}
+}
+
 /* The intra half of the lookahead: the per-block work of LookaheadTLD::lowresIntraEstimate (slicetype.cpp:716-777: DC, planar and the
  * angular scan of every 8x8 block) as one provider call; the AQ weighting and the sums are the reference's own lines :779-803. */
 void LookaheadTLD::lowresIntraEstimate(Lowres& fenc, uint32_t qgSize)
@@ -1265,7 +1432,7 @@ int x265ref_seam_configure_streamed(void* ctx, void* picture_rows, void* pair_op
     return 0;
 }
 
-void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; gs.enabled = false; gaq.enabled = false; }
+void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; gs.enabled = false; gaq.enabled = false; gwa.enabled = false; }
 
 /* sub-sample seam: provider = x265hip_phase_cache_submit / _planes / _ready signatures (NULL submit = off); geometry = the PicYuv
  * buffers of the encode about to start.  flags: 1 = verify every served call against the reference's own function, 2 = wait for planes */
@@ -1363,6 +1530,26 @@ void x265ref_lookahead_seam_stats(uint64_t* out) { out[0] = gla.served; out[1] =
  * number of estimates the gate has sent there since the last configure */
 uint64_t x265ref_lookahead_seam_min_blocks(int min_blocks) { if (min_blocks >= 0) gla.minBlocks = min_blocks; return gla.gated; }
 uint64_t x265ref_lookahead_seam_mismatches(void) { return gla.mismatches; }
+
+/* weightAnalyse seam: host_fn = x265hip_weight_analyse_host (the product) or NULL; oracle_fn = x265oracle_weight_analyse_d<depth> (CPU checker)
+ * or NULL; both NULL: off.  verify: the reference's own weightAnalyse runs after every served slice and the weight tables are compared.
+ * min_blocks: pictures with fewer lowres 8x8 blocks keep the reference's loop. */
+int x265ref_weight_seam_configure(void* host_fn, void* oracle_fn, int verify, int min_blocks)
+{
+    gwa.host = (wa_host_fn)host_fn;
+    gwa.oracle = (wa_oracle_fn)oracle_fn;
+    gwa.verify = verify != 0;
+    gwa.minBlocks = min_blocks < 0 ? 0 : min_blocks;
+    gwa.served = 0; gwa.passed = 0; gwa.failed = 0; gwa.mismatches = 0; gwa.gated = 0; gwa.weighted = 0;
+    gwa.enabled = host_fn || oracle_fn;
+    return 0;
+}
+/* out[6]: slices served, passed to the reference's loop (not 4:2:0 / lowres size not a multiple of 8), failed, verify mismatches, gated by size,
+ * served slices that came back with at least one weight present */
+void x265ref_weight_seam_stats(uint64_t* out)
+{
+    out[0] = gwa.served; out[1] = gwa.passed; out[2] = gwa.failed; out[3] = gwa.mismatches; out[4] = gwa.gated; out[5] = gwa.weighted;
+}
 
 /* AQ seam: host_fn = x265hip_aq_frame_host (the product) or NULL; oracle_fn = x265oracle_aq_frame_d<depth> (CPU checker, GPU-less tests) or
  * NULL; both NULL: off.  verify: the reference's own calcAdaptiveQuantFrame runs after every served picture and its arrays are compared

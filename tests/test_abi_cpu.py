@@ -62,6 +62,7 @@ def test_ctypes_structures_match_the_c_header(repo_root, tmp_path):
              "x265hip_sea_integral_params": A.SeaIntegralParams, "x265hip_deblock_bs_params": A.DeblockBsParams,
              "x265hip_deblock_chroma_params": A.DeblockChromaParams, "x265hip_deblock_params": A.DeblockParams,
              "x265hip_aq_energy_params": A.AqEnergyParams, "x265hip_aq_offsets_params": A.AqOffsetsParams, "x265hip_aq_frame_host_params": A.AqFrameHostParams,
+             "x265hip_weight_analyse_ref": A.WeightAnalyseRef, "x265hip_weight_analyse_host_params": A.WeightAnalyseHostParams,
              "x265hip_cutree_propagate_params": A.CuTreePropagateParams, "x265hip_cutree_finish_params": A.CuTreeFinishParams, "x265hip_frame_cost_recalculate_params": A.FrameCostRecalculateParams,
              "x265hip_lowres_weight_cost_params": A.LowresWeightCostParams, "x265hip_lowres_weight_apply_params": A.LowresWeightApplyParams,
              "x265hip_sao_stats_params": A.SaoStatsParams, "x265hip_sao_apply_params": A.SaoApplyParams, "x265hip_plane": A.Plane,

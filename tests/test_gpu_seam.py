@@ -698,3 +698,22 @@ def test_aq_seam_on_the_gpu_fills_the_arrays_the_reference_loop_would(depth, w, 
     a = rep["aq_seam"]
     assert got[0] == base[0], f"seam changed the bitstream: {a}"
     assert a["pictures_served"] == 6 and a["verify_mismatches"] == 0 and a["failed"] == 0 and a["passed_to_reference_loop"] == 0, a
+
+
+# ---- round 4: the frame encoder's weightAnalyse from x265hip_weight_analyse_host ------------------------------------------------------------
+@pytest.mark.parametrize("depth,preset,fade,extra", [(8, "slow", (1.0, 0.35), [("bframes", "0")]), (8, "medium", (0.4, 1.0), [("weightb", None), ("bframes", "3")]),
+                                                     (10, "medium", (1.0, 0.35), [("weightb", None)])])
+def test_weight_analyse_seam_on_the_gpu_chooses_the_reference_weights(depth, preset, fade, extra):
+    """The real encoder on a fading clip with weightAnalyse served by x265hip_weight_analyse_host (and calcAdaptiveQuantFrame, whose wp_ssd / wp_sum it
+    reads, by x265hip_aq_frame_host); after every served slice the reference's own weightAnalyse runs and the weight tables are compared.  The
+    weighted references it chooses then go through the row-granular search services as in the tests above.  Byte-identical."""
+    import test_seam_cpu as T
+    opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24")] + extra
+    base, got, rep = T.run_fade_pair(depth, 256, 192, 10, preset, opts, "gpu", rng=8, fade=fade, min_level=1, slots=24, subpel="gpu", subpel_slots=12, lookahead="gpu",
+                                     weight_analyse="gpu", aq="gpu")
+    w = rep["weight_analyse_seam"]
+    assert got[0] == base[0], f"seam changed the bitstream: {w}"
+    assert w["verify_mismatches"] == 0 and w["failed"] == 0 and w["passed_to_reference_loop"] == 0 and w["slices_served"] >= 2, w
+    assert w["served_slices_with_a_weight"] > 0, w
+    assert rep["aq_seam"]["verify_mismatches"] == 0 and rep["aq_seam"]["pictures_served"] == 10
+    assert rep["verify_mismatches"] == 0 and rep["weighted_references"]["lookups_served_on_weighted_references"] > 0, rep

@@ -217,6 +217,25 @@ def run_fade_pair(depth, w, h, nframes, preset, opts, provider, rng, fade=(1.0, 
     return base, got, rep
 
 
+# ---- round 4: the frame encoder's weightAnalyse behind one provider call ----------------------------------------------------------------------
+@pytest.mark.reference
+@pytest.mark.parametrize("depth,preset,fade,extra,expect_weights", [(8, "slow", (1.0, 0.35), [("bframes", "0")], True), (8, "medium", (1.0, 0.35), [("weightb", None)], True),
+                                                                    (8, "medium", (0.4, 1.0), [("weightb", None), ("bframes", "3")], True), (10, "medium", (1.0, 0.35), [], True),
+                                                                    (8, "medium", (1.0, 1.0), [("weightb", None)], False), (8, "slow", (1.0, 0.1), [("bframes", "1"), ("weightb", None)], True)])
+def test_weight_analyse_seam_chooses_the_weights_the_reference_loop_chooses(depth, preset, fade, extra, expect_weights):
+    """weightAnalyse through ref_seam's replacement on fading clips (and one of constant brightness: the early exits): the provider (here the
+    CPU restatement, oracle/x265_oracle_pipeline7.c) returns the weight table; verify on, the reference's own weightAnalyse then runs on the same
+    slice and every entry it defines is compared.  This is what pins the restatement; the bitstream cannot change."""
+    opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24")] + extra
+    base, got, rep = run_fade_pair(depth, 256, 192, 10, preset, opts, "oracle", rng=8, fade=fade, min_level=1, slots=24, weight_analyse="oracle", aq="oracle")
+    w = rep["weight_analyse_seam"]
+    assert got[0] == base[0], f"seam changed the bitstream: {w}"
+    assert w["verify_mismatches"] == 0 and w["failed"] == 0 and w["passed_to_reference_loop"] == 0, w
+    assert w["slices_served"] >= 2, w                    # P slices only unless --weightb
+    assert (w["served_slices_with_a_weight"] > 0) == expect_weights, w
+    assert rep["aq_seam"]["verify_mismatches"] == 0 and rep["aq_seam"]["pictures_served"] == 10
+
+
 @pytest.mark.reference
 def test_weight_plane_twin_equals_the_reference_weight_pp():
     """tools/seam_driver.weight_plane (the CPU providers' weighting) against the real primitives.weight_pp of oracle/_ref."""

@@ -642,7 +642,8 @@ class StreamGpuPhaseProvider:
 
 
 def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
-            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0, min_ctus=0, build="", aq=None, aq_min_blocks=0):
+            surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0, min_ctus=0, build="", aq=None, aq_min_blocks=0,
+            weight_analyse=None, weight_min_blocks=0):
     """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
     the picture-granular providers need --frame-threads 1, streamed=True (row-granular providers) serves under any --frame-threads."""
     lib = seam_lib(depth, build)
@@ -704,6 +705,20 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     else:
         lib.x265ref_aq_seam_configure(None, None, 0, 0)
 
+    # the weightAnalyse seam (the frame encoder's weighted-prediction analysis as one provider call per P / B slice): "gpu" =
+    # x265hip_weight_analyse_host, "oracle" = the CPU restatement, None = off; verify = the reference's own function runs after every served slice
+    lib.x265ref_weight_seam_configure.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    if weight_analyse == "gpu":
+        A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+        lib.x265ref_weight_seam_configure(ctypes.cast(A.lib().x265hip_weight_analyse_host, ctypes.c_void_p), None, int(bool(verify)),
+                                          16384 if weight_min_blocks is None else weight_min_blocks)
+    elif weight_analyse == "oracle":
+        keep_wa = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libx265oracle.so"))
+        lib.x265ref_weight_seam_configure(None, ctypes.cast(getattr(keep_wa, f"x265oracle_weight_analyse_d{depth}"), ctypes.c_void_p), int(bool(verify)),
+                                          16384 if weight_min_blocks is None else weight_min_blocks)
+    else:
+        lib.x265ref_weight_seam_configure(None, None, 0, 0)
+
     # the sub-sample seam (MotionEstimate::subpelCompare reads precomputed phase planes): "gpu" = x265hip_phase_cache, "oracle" = CPU checker
     lib.x265ref_subpel_seam_configure.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int]
     lib.x265ref_subpel_seam_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
@@ -751,6 +766,10 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
         lib.x265ref_aq_seam_stats(aqs)
         d["aq_seam"] = {"provider": aq, "pictures_served": int(aqs[0]), "passed_to_reference_loop": int(aqs[1]), "failed": int(aqs[2]), "verify_mismatches": int(aqs[3]),
                         "left_to_the_reference_by_the_size_gate": int(aqs[4])}
+        was = (ctypes.c_uint64 * 6)()
+        lib.x265ref_weight_seam_stats(was)
+        d["weight_analyse_seam"] = {"provider": weight_analyse, "slices_served": int(was[0]), "passed_to_reference_loop": int(was[1]), "failed": int(was[2]),
+                                    "verify_mismatches": int(was[3]), "left_to_the_reference_by_the_size_gate": int(was[4]), "served_slices_with_a_weight": int(was[5])}
         if sub:
             so = (ctypes.c_uint64 * 6)()
             lib.x265ref_subpel_seam_stats(so)
@@ -761,6 +780,7 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     def close():
         lib.x265ref_seam_disable()
         lib.x265ref_aq_seam_configure(None, None, 0, 0)
+        lib.x265ref_weight_seam_configure(None, None, 0, 0)
         prov.close()
         if sub:
             sub.close()

@@ -366,3 +366,417 @@ extern "C" int x265hip_aq_frame_host(const x265hip_aq_frame_host_params* p)
     }
     return 0;
 }
+
+// ---- weightAnalyse behind host pointers (encoder/weightPrediction.cpp:222-497) ---------------------------------------------------------
+// Pixel work on the device - the motion-compensated copies (mcLuma / mcChroma) and weightCost for the unweighted plane plus every
+// (scale, offset) pair the scan could visit, one launch per plane - and the reference's own decision logic replayed on the calling
+// thread from the downloaded scores.
+#include "tile_interp.h"
+#include <cmath>
+
+namespace {
+
+struct WaMcLumaArgs { const uint8_t* plane[4]; uint8_t* out; long strideB; int width, lines; const int32_t* mvs; };
+
+// mcLuma (:59-92): one thread per sample of an 8x8 block; Lowres::lowresMC (lowres.h:67-92) - a half-sample plane at the integer part of
+// the clipped quarter-sample vector, or the rounded average of two such planes when either component is odd
+template <typename Px>
+__global__ void __launch_bounds__(256) wa_mc_luma_kernel(WaMcLumaArgs a)
+{
+    const int bw = a.width >> 3;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)bw * (a.lines >> 3) * 64;
+    if (i >= total) return;
+    const int cu = (int)(i >> 6), px = (int)(i & 7), py = (int)((i >> 3) & 7);
+    const int by = cu / bw, bx = cu - by * bw, x = bx * 8, y = by * 8;
+    const int mx = clip3((-x - 8) * 4, (a.width - x - 1 + 8) * 4, a.mvs[2 * cu]), my = clip3((-y - 8) * 4, (a.lines - y - 1 + 8) * 4, a.mvs[2 * cu + 1]);
+    const long st = a.strideB / (long)sizeof(Px);
+    const long at = (long)(y + py) * st + x + px;
+    const int hpelA = (my & 2) | ((mx & 2) >> 1);
+    int v = (int)reinterpret_cast<const Px*>(a.plane[hpelA])[at + (mx >> 2) + (long)(my >> 2) * st];
+    if ((mx | my) & 1)
+    {
+        const int qx = mx + (mx & 1), qy = my + (my & 1);
+        const int hpelB = (qy & 2) | ((qx & 2) >> 1);
+        v = (v + (int)reinterpret_cast<const Px*>(a.plane[hpelB])[at + (qx >> 2) + (long)(qy >> 2) * st] + 1) >> 1;      // pixelavg_pp, pixel.cpp:385-397
+    }
+    reinterpret_cast<Px*>(a.out)[at] = (Px)v;
+}
+
+struct WaMcChromaArgs { const uint8_t* src; uint8_t* out; long strideB; int width, height, lowresWidthInCU, lowresHeightInCU, depth; const int32_t* mvs; };
+
+__constant__ int8_t kWaChromaFilter[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 }, { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+
+// mcChroma (:96-166), 4:2:0: 8x8 chroma blocks.  The reference tests the block's SAMPLE position against the lowres CU counts (:121) and
+// indexes the vectors with y * lowresWidthInCU + x / 8 (:113,118); the vector is the lowres one (mv << 1 >> 1), its integer part taken with
+// >> 2 and its fraction with & 7 (:134-137) - all kept.  Filters: interp_horiz_pp_c / interp_vert_pp_c / interp_horiz_ps_c (row extension) +
+// interp_vert_sp_c (ipfilter.cpp), 4 taps.
+template <typename Px>
+__global__ void __launch_bounds__(256) wa_mc_chroma_kernel(WaMcChromaArgs a)
+{
+    const int bw = a.width >> 3;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)bw * (a.height >> 3) * 64;
+    if (i >= total) return;
+    const int blk = (int)(i >> 6), px = (int)(i & 7), py = (int)((i >> 3) & 7);
+    const int by = blk / bw, bx = blk - by * bw, x = bx * 8, y = by * 8;
+    const long st = a.strideB / (long)sizeof(Px);
+    const Px* src = reinterpret_cast<const Px*>(a.src);
+    const long at = (long)(y + py) * st + x + px;
+    int v;
+    if (x < a.lowresWidthInCU && y < a.lowresHeightInCU)
+    {
+        const int cu = y * a.lowresWidthInCU + bx;
+        const int mx = clip3((-x - 8) * 4, (a.width - x - 1 + 8) * 4, a.mvs[2 * cu]), my = clip3((-y - 8) * 4, (a.height - y - 1 + 8) * 4, a.mvs[2 * cu + 1]);
+        const Px* t = src + at + (long)(my >> 2) * st + (mx >> 2);
+        const int xf = mx & 7, yf = my & 7, maxVal = (1 << a.depth) - 1;
+        if (!(xf | yf)) v = (int)t[0];
+        else if (!yf)
+        {
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s += (int)t[k - 1] * kWaChromaFilter[xf][k];
+            v = clip3(0, maxVal, (s + 32) >> 6);
+        }
+        else if (!xf)
+        {
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s += (int)t[(long)(k - 1) * st] * kWaChromaFilter[yf][k];
+            v = clip3(0, maxVal, (s + 32) >> 6);
+        }
+        else
+        {
+            const int headRoom = 14 - a.depth, shiftH = 6 - headRoom, offH = -(1 << 13) << shiftH;
+            const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + ((1 << 13) << 6);
+            int s = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+            {
+                int h = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) h += (int)t[(long)(r - 1) * st + k - 1] * kWaChromaFilter[xf][k];
+                s += (int)(int16_t)((h + offH) >> shiftH) * kWaChromaFilter[yf][r];
+            }
+            v = clip3(0, maxVal, (s + offV) >> shiftV);
+        }
+    }
+    else
+        v = (int)src[at];
+    reinterpret_cast<Px*>(a.out)[at] = (Px)v;
+}
+
+struct WaCostArgs { const uint8_t* fenc; const uint8_t* ref; long strideB; int width, height, depth; const int32_t* intraCost; const int32_t* cand; uint32_t* cost; };
+
+// weightCost (:172-217): one thread per 8x8 block, blockIdx.y = candidate { present, scale, denom, offset }; weight_pp's arithmetic per
+// sample (pixel.cpp:518-543), four 4x4 Hadamards (satd 8x8), luma blocks capped by the intra cost; uint32 sums wrap as the reference's
+template <typename Px>
+__global__ void __launch_bounds__(256) wa_cost_kernel(WaCostArgs a)
+{
+    const int bw = a.width >> 3, nblk = bw * (a.height >> 3);
+    const int mb = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    uint32_t v = 0;
+    if (mb < nblk)
+    {
+        const int by = mb / bw, bx = mb - by * bw;
+        const int present = a.cand[4 * c], scale = a.cand[4 * c + 1], denom = a.cand[4 * c + 2];
+        const int correction = 14 - a.depth, maxVal = (1 << a.depth) - 1;
+        const int offset = a.cand[4 * c + 3] << (a.depth - 8), round = (denom ? 1 << (denom - 1) : 0) << correction, shift = denom + correction;
+        const long st = a.strideB / (long)sizeof(Px);
+        const Px* f = reinterpret_cast<const Px*>(a.fenc) + (long)(by * 8) * st + bx * 8;
+        const Px* r = reinterpret_cast<const Px*>(a.ref) + (long)(by * 8) * st + bx * 8;
+        int satd = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+        {
+            int d[4][4];
+            const int ox = (t & 1) * 4, oy = (t >> 1) * 4;
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    int rv = (int)r[(oy + y) * st + ox + x];
+                    if (present) rv = clip3(0, maxVal, ((scale * (int)(int16_t)(rv << correction) + round) >> shift) + offset);
+                    d[y][x] = rv - (int)f[(oy + y) * st + ox + x];
+                }
+            satd += x265hip::tile_satd4(d);
+        }
+        v = (uint32_t)(a.intraCost ? min(satd, a.intraCost[mb]) : satd);
+    }
+    v = (uint32_t)group_sum<64>((int)v);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&a.cost[c], v);
+}
+
+struct WaWeight { int present, weight, denom, offset; };
+inline int wa_bit_size(unsigned v) { if (!v) return 1; int n = 0; while (v >> (n + 1)) n++; return 2 * n + 1; }      // bitstream.h:94-112
+inline int wa_size_se(int val) { int tmp = 1 - val * 2; if (tmp < 0) tmp = val * 2; return tmp < 256 ? wa_bit_size((unsigned)tmp) : wa_bit_size((unsigned)tmp >> 8) + 16; }
+inline int wa_slice_header_cost(const WaWeight& w, int lambda, int bChroma)                                                // weightPrediction.cpp:49-56
+{
+    if (bChroma) lambda *= 4;
+    const int denomCost = wa_bit_size((unsigned)w.denom + 1) * (2 - bChroma);
+    return lambda * (10 + denomCost + 2 * (wa_size_se(w.weight) + wa_size_se(w.offset)));
+}
+
+} // namespace
+
+extern "C" int x265hip_weight_analyse_host(const x265hip_weight_analyse_host_params* p)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!p || !p->lowres || !p->cb || !p->cr || !p->intra_cost || !p->weights || !p->denoms) { set_error("weight_analyse_host: NULL operand (4:2:0 pictures only)"); return X265HIP_EINVAL; }
+    if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("weight_analyse_host: depth %d", p->depth); return X265HIP_EINVAL; }
+    if (p->nlists < 1 || p->nlists > 2) { set_error("weight_analyse_host: nlists %d", p->nlists); return X265HIP_EINVAL; }
+    if (p->lowres_width <= 0 || p->lowres_lines <= 0 || (p->lowres_width & 7) || (p->lowres_lines & 7) || p->lowres_margin_x < 16 || p->lowres_margin_y < 16 ||
+        p->lowres_stride < p->lowres_width + 2 * p->lowres_margin_x)
+    { set_error("weight_analyse_host: lowres geometry %d x %d, margins %d / %d, stride %ld (multiples of 8, margins >= 16)", p->lowres_width, p->lowres_lines, p->lowres_margin_x, p->lowres_margin_y, (long)p->lowres_stride); return X265HIP_EINVAL; }
+    const int cw = ((p->pic_width >> 4) << 4) >> 1, chh = ((p->pic_height >> 4) << 4) >> 1;          // :377-378: the chroma area weightCost measures
+    if (p->pic_width < 16 || p->pic_height < 16 || p->margin_xc < 24 || p->margin_yc < 24 || p->stride_c < cw + 2 * p->margin_xc)
+    { set_error("weight_analyse_host: picture %d x %d, chroma margins %d / %d, stride %ld (margins >= 24)", p->pic_width, p->pic_height, p->margin_xc, p->margin_yc, (long)p->stride_c); return X265HIP_EINVAL; }
+    for (int l = 0; l < p->nlists; l++)
+    {
+        for (int k = 0; k < 4; k++) if (!p->ref[l].lowres[k]) { set_error("weight_analyse_host: NULL lowres plane %d of list %d", k, l); return X265HIP_EINVAL; }
+        if (!p->ref[l].cb || !p->ref[l].cr) { set_error("weight_analyse_host: NULL chroma plane of list %d", l); return X265HIP_EINVAL; }
+    }
+    const int bpp = p->depth == 8 ? 1 : 2;
+    const int lw = p->lowres_width, lh = p->lowres_lines, n = (lw >> 3) * (lh >> 3);
+    const size_t lorg = ((size_t)p->lowres_margin_y * p->lowres_stride + p->lowres_margin_x) * bpp;
+    const size_t lplaneBytes = (size_t)p->lowres_stride * (lh + 2 * p->lowres_margin_y) * bpp;
+    const int CM = 24;                                                                                 // chroma rows / samples around the measured area that compensation may read
+    const size_t corg = ((size_t)CM * p->stride_c + CM) * bpp;
+    const size_t cplaneBytes = ((size_t)p->stride_c * (chh + 2 * CM) + 2 * CM) * bpp;
+    const size_t mcBytes = std::max((size_t)p->lowres_stride * lh, (size_t)p->stride_c * chh) * bpp;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align256(off + bytes); return o; };
+    const size_t oCur = p->plane_key ? 0 : take(lplaneBytes + 64);
+    size_t oRef[2][4] = {}, oRefC[2][2] = {}, oMvs[2] = {};
+    for (int l = 0; l < p->nlists; l++)
+    {
+        for (int k = 0; k < 4; k++) oRef[l][k] = p->ref[l].plane_key ? 0 : take(lplaneBytes + 64);
+        oRefC[l][0] = take(cplaneBytes + 64); oRefC[l][1] = take(cplaneBytes + 64);
+        oMvs[l] = take((size_t)n * 8);
+    }
+    const size_t oCb = take(cplaneBytes), oCr = take(cplaneBytes), oIntra = take((size_t)n * 4), oMc = take(mcBytes + 64);
+    const size_t oCand = take(64 * 16), oCost = take(64 * 4);
+    LaThread& t = la_thread();
+    rc = t.ensure(off);
+    if (rc) return rc;
+    hipStream_t s = t.stream;
+    uint8_t* d = t.dev;
+    auto up = [&](size_t o, const void* src, size_t bytes) { return check_hip(hipMemcpyAsync(d + o, src, bytes, hipMemcpyHostToDevice, s), "weight_analyse_host upload"); };
+    PlanePins pins(s);
+    auto lowres_plane = [&](const void* host, uint64_t key, size_t o, uint8_t** out) -> int
+    {
+        if (key)
+        {
+            void* cp = nullptr;
+            const int r = cached_plane((const uint8_t*)host - lorg, key, lplaneBytes, s, &cp);
+            if (r) return r;
+            pins.add(cp);
+            *out = (uint8_t*)cp + lorg;
+            return 0;
+        }
+        if (up(o, (const uint8_t*)host - lorg, lplaneBytes)) return X265HIP_ENODEV;
+        *out = d + o + lorg;
+        return 0;
+    };
+    // nothing is uploaded before a plane gets past the early exits (a picture without a brightness change costs no transfer at all)
+    uint8_t* dCur = nullptr;
+    bool curChromaUp[2] = { false, false };
+
+    const int lambdaTab[3] = { 1, 16, 256 };                       // (int)x265_lambda_tab[X265_LOOKAHEAD_QP], constants.cpp
+    const int lambda = lambdaTab[(p->depth - 8) / 2];
+    const float epsilon = 1.f / 128.f;
+    int chromaDenom = 7, lumaDenom = 7, denom;
+    int numpixels[3];
+    const int w16 = ((p->pic_width + 15) >> 4) << 4, h16 = ((p->pic_height + 15) >> 4) << 4;
+    numpixels[0] = w16 * h16;
+    numpixels[1] = numpixels[2] = numpixels[0] >> 2;
+    memset(p->weights, 0, 2 * 3 * 4 * sizeof(int32_t));
+    memset(p->denoms, 0, 4 * sizeof(int32_t));
+
+    for (int list = 0; list < p->nlists; list++)
+    {
+        const x265hip_weight_analyse_ref& R = p->ref[list];
+        WaWeight weights[3];
+        float guessScale[3], fencMean[3], refMean[3];
+        for (int plane = 0; plane < 3; plane++)
+        {
+            weights[plane] = { 0, 1, 0, 0 };
+            const uint64_t fencVar = p->wp_ssd[plane] + !R.wp_ssd[plane];
+            const uint64_t refVar = R.wp_ssd[plane] + !R.wp_ssd[plane];
+            guessScale[plane] = std::sqrt((float)fencVar / refVar);
+            fencMean[plane] = (float)p->wp_sum[plane] / (numpixels[plane]) / (1 << (p->depth - 8));
+            refMean[plane] = (float)R.wp_sum[plane] / (numpixels[plane]) / (1 << (p->depth - 8));
+        }
+        while (!list && chromaDenom > 0)
+        {
+            const float thresh = 127.f / (1 << chromaDenom);
+            if (guessScale[1] < thresh && guessScale[2] < thresh) break;
+            chromaDenom--;
+        }
+        weights[1] = { 0, 1 << chromaDenom, chromaDenom, 0 };
+        weights[2] = { 0, 1 << chromaDenom, chromaDenom, 0 };
+
+        bool refUp = false;
+        uint8_t* dRef[4] = {};
+        const int32_t* mvs = nullptr;
+        for (int plane = 0; plane < 3; plane++)
+        {
+            denom = plane ? chromaDenom : lumaDenom;
+            if (plane && !weights[0].present) break;
+            if (std::fabs(refMean[plane] - fencMean[plane]) < 0.5f && std::fabs(1.f - guessScale[plane]) < epsilon) { weights[plane] = { 0, 1 << denom, denom, 0 }; continue; }
+            if (plane)
+            {
+                const int scale = std::min(255, std::max(0, (int)(guessScale[plane] * (1 << denom) + 0.5f)));
+                if (scale > 127) continue;
+                weights[plane].weight = scale;
+            }
+            else
+            {
+                weights[0].offset = 0; weights[0].denom = denom; weights[0].weight = (int)(guessScale[0] * (1 << denom) + 0.5f);       // setFromWeightAndOffset, slice.h:304-316
+                while (!list && weights[0].denom > 0 && weights[0].weight > 127) { weights[0].denom--; weights[0].weight >>= 1; }
+                weights[0].weight = std::min(weights[0].weight, 127);
+            }
+            int mindenom = weights[plane].denom, minscale = weights[plane].weight, minoff = 0;
+            if (!plane) mvs = R.mvs;
+
+            // ---- the plane pair on the device
+            const uint8_t* dOrig; const uint8_t* dFref; long strideB; int width, height;
+            if (!plane)
+            {
+                if (!dCur)
+                {
+                    rc = lowres_plane(p->lowres, p->plane_key, oCur, &dCur);
+                    if (rc) return rc;
+                    if (up(oIntra, p->intra_cost, (size_t)n * 4)) return X265HIP_ENODEV;
+                }
+                if (!refUp)
+                {
+                    for (int k = 0; k < (mvs ? 4 : 1); k++) { rc = lowres_plane(R.lowres[k], R.plane_key, oRef[list][k], &dRef[k]); if (rc) return rc; }
+                    if (mvs && up(oMvs[list], mvs, (size_t)n * 8)) return X265HIP_ENODEV;
+                    refUp = true;
+                }
+                dOrig = dCur; dFref = dRef[0]; strideB = (long)p->lowres_stride * bpp; width = lw; height = lh;
+                if (mvs)
+                {
+                    WaMcLumaArgs m;
+                    for (int k = 0; k < 4; k++) m.plane[k] = dRef[k];
+                    m.out = d + oMc; m.strideB = strideB; m.width = lw; m.lines = lh; m.mvs = (const int32_t*)(d + oMvs[list]);
+                    const unsigned g = (unsigned)(((long)n * 64 + 255) / 256);
+                    if (bpp == 1) hipLaunchKernelGGL(wa_mc_luma_kernel<uint8_t>, dim3(g), dim3(256), 0, s, m);
+                    else hipLaunchKernelGGL(wa_mc_luma_kernel<uint16_t>, dim3(g), dim3(256), 0, s, m);
+                    dFref = d + oMc;
+                }
+            }
+            else
+            {
+                const void* hsrc = plane == 1 ? R.cb : R.cr;
+                const size_t o = oRefC[list][plane - 1];
+                if (up(o, (const uint8_t*)hsrc - corg, cplaneBytes)) return X265HIP_ENODEV;
+                if (!curChromaUp[plane - 1])                     // the current picture's chroma: only the measured area is read
+                {
+                    if (up(plane == 1 ? oCb : oCr, plane == 1 ? p->cb : p->cr, (size_t)p->stride_c * chh * bpp)) return X265HIP_ENODEV;
+                    curChromaUp[plane - 1] = true;
+                }
+                dOrig = d + (plane == 1 ? oCb : oCr); dFref = d + o + corg; strideB = (long)p->stride_c * bpp; width = cw; height = chh;
+                if (mvs)
+                {
+                    WaMcChromaArgs m;
+                    m.src = dFref; m.out = d + oMc; m.strideB = strideB; m.width = cw; m.height = chh; m.lowresWidthInCU = lw >> 3; m.lowresHeightInCU = lh >> 3;
+                    m.depth = p->depth; m.mvs = (const int32_t*)(d + oMvs[list]);
+                    const unsigned g = (unsigned)(((long)(cw >> 3) * (chh >> 3) * 64 + 255) / 256);
+                    if (bpp == 1) hipLaunchKernelGGL(wa_mc_chroma_kernel<uint8_t>, dim3(g), dim3(256), 0, s, m);
+                    else hipLaunchKernelGGL(wa_mc_chroma_kernel<uint16_t>, dim3(g), dim3(256), 0, s, m);
+                    dFref = d + oMc;
+                }
+            }
+            // ---- every pair the scan of :409-446 could visit (its early break only skips pairs), plus the unweighted plane
+            int32_t cand[64][4];
+            int ncand = 0;
+            cand[ncand][0] = 0; cand[ncand][1] = 1; cand[ncand][2] = 0; cand[ncand][3] = 0; ncand++;
+            auto cand_index = [&](int scale, int offv) -> int
+            {
+                for (int i = 1; i < ncand; i++) if (cand[i][1] == scale && cand[i][3] == offv) return i;
+                cand[ncand][0] = 1; cand[ncand][1] = scale; cand[ncand][2] = mindenom; cand[ncand][3] = offv;
+                return ncand++;
+            };
+            const int scaleDist = 4, offsetDist = 2;
+            const int startScale = std::min(127, std::max(0, minscale - scaleDist)), endScale = std::min(127, std::max(0, minscale + scaleDist));
+            struct Step { int curScale, startOffset, endOffset; };
+            Step steps[16]; int nsteps = 0;
+            for (int scale = startScale; scale <= endScale; scale++)
+            {
+                const int deltaWeight = scale - (1 << mindenom);
+                if (deltaWeight > 127 || deltaWeight <= -128) continue;
+                int curScale = scale;
+                int curOffset = (int)(fencMean[plane] - refMean[plane] * curScale / (1 << mindenom) + 0.5f);
+                if (curOffset < -128 || curOffset > 127)
+                {
+                    curOffset = std::min(127, std::max(-128, curOffset));
+                    curScale = (int)((1 << mindenom) * (fencMean[plane] - curOffset) / refMean[plane] + 0.5f);
+                    curScale = std::min(127, std::max(0, curScale));
+                }
+                const int startOffset = std::min(127, std::max(-128, curOffset - offsetDist)), endOffset = std::min(127, std::max(-128, curOffset + offsetDist));
+                steps[nsteps++] = { curScale, startOffset, endOffset };
+                for (int o2 = startOffset; o2 <= endOffset; o2++) cand_index(curScale, o2);
+            }
+            if (up(oCand, cand, (size_t)ncand * 16)) return X265HIP_ENODEV;
+            X265HIP_TRY(hipMemsetAsync(d + oCost, 0, 64 * 4, s));
+            WaCostArgs c;
+            c.fenc = dOrig; c.ref = dFref; c.strideB = strideB; c.width = width; c.height = height; c.depth = p->depth;
+            c.intraCost = plane ? nullptr : (const int32_t*)(d + oIntra); c.cand = (const int32_t*)(d + oCand); c.cost = (uint32_t*)(d + oCost);
+            const int nblk = (width >> 3) * (height >> 3);
+            const dim3 grid((unsigned)((nblk + 255) / 256), (unsigned)ncand);
+            if (bpp == 1) hipLaunchKernelGGL(wa_cost_kernel<uint8_t>, grid, dim3(256), 0, s, c);
+            else hipLaunchKernelGGL(wa_cost_kernel<uint16_t>, grid, dim3(256), 0, s, c);
+            X265HIP_TRY(hipGetLastError());
+            uint32_t cost[64];
+            X265HIP_TRY(hipMemcpyAsync(cost, d + oCost, (size_t)ncand * 4, hipMemcpyDeviceToHost, s));
+            X265HIP_TRY(hipStreamSynchronize(s));
+
+            // ---- the reference's scan, replayed on the scores
+            const uint32_t origscore = cost[0];
+            if (!origscore) { weights[plane] = { 0, 1 << denom, denom, 0 }; continue; }
+            uint32_t minscore = origscore;
+            bool bFound = false;
+            for (int k = 0; k < nsteps; k++)
+            {
+                const Step& st = steps[k];
+                for (int o2 = st.startOffset; o2 <= st.endOffset; o2++)
+                {
+                    const WaWeight wsp = { 1, st.curScale, mindenom, o2 };
+                    const uint32_t sc = cost[cand_index(st.curScale, o2)] + (uint32_t)wa_slice_header_cost(wsp, lambda, !!plane);
+                    if (sc < minscore) { minscore = sc; minscale = st.curScale; minoff = o2; bFound = true; }
+                    if (minoff == st.startOffset && o2 != st.startOffset) break;
+                }
+            }
+            if (!(plane || list))
+            {
+                if (mindenom > 0 && !(minscale & 1))
+                {
+                    const int idx = minscale ? __builtin_ctz((unsigned)minscale) : 32;
+                    const int shift = std::min(idx, mindenom);
+                    mindenom -= shift;
+                    minscale >>= shift;
+                }
+            }
+            if (!bFound || (minscale == (1 << mindenom) && minoff == 0) || (float)minscore / origscore > 0.998f) weights[plane] = { 0, 1 << denom, denom, 0 };
+            else weights[plane] = { 1, minscale, mindenom, minoff };
+        }
+        if (weights[0].present && weights[1].present != weights[2].present)
+        {
+            if (weights[1].present) weights[2] = weights[1];
+            else weights[1] = weights[2];
+        }
+        lumaDenom = weights[0].denom;
+        chromaDenom = weights[1].denom;
+        for (int plane = 0; plane < 3; plane++)
+        {
+            int32_t* o = p->weights + (list * 3 + plane) * 4;
+            o[0] = weights[plane].present; o[1] = weights[plane].weight; o[2] = weights[plane].denom; o[3] = weights[plane].offset;
+        }
+        p->denoms[list * 2] = lumaDenom; p->denoms[list * 2 + 1] = chromaDenom;
+    }
+    return 0;
+}

@@ -403,6 +403,59 @@ def aq_frame_host(depth, y, stride, org, width, height, qg_size, aq_mode, aq_str
     return out
 
 
+class WeightAnalyseRef(ctypes.Structure):
+    """x265hip_weight_analyse_ref (include/x265hip.h)."""
+    _fields_ = [("lowres", ctypes.c_void_p * 4), ("cb", ctypes.c_void_p), ("cr", ctypes.c_void_p), ("mvs", ctypes.c_void_p),
+                ("wp_ssd", ctypes.c_uint64 * 3), ("wp_sum", ctypes.c_uint64 * 3), ("plane_key", ctypes.c_uint64)]
+
+
+class WeightAnalyseHostParams(ctypes.Structure):
+    """x265hip_weight_analyse_host_params (include/x265hip.h)."""
+    _fields_ = [("depth", ctypes.c_int), ("lowres", ctypes.c_void_p), ("lowres_stride", ctypes.c_ssize_t),
+                ("lowres_width", ctypes.c_int), ("lowres_lines", ctypes.c_int), ("lowres_margin_x", ctypes.c_int), ("lowres_margin_y", ctypes.c_int),
+                ("cb", ctypes.c_void_p), ("cr", ctypes.c_void_p), ("stride_c", ctypes.c_ssize_t), ("margin_xc", ctypes.c_int), ("margin_yc", ctypes.c_int),
+                ("pic_width", ctypes.c_int), ("pic_height", ctypes.c_int), ("intra_cost", ctypes.c_void_p),
+                ("wp_ssd", ctypes.c_uint64 * 3), ("wp_sum", ctypes.c_uint64 * 3), ("plane_key", ctypes.c_uint64), ("nlists", ctypes.c_int),
+                ("ref", WeightAnalyseRef * 2), ("weights", ctypes.c_void_p), ("denoms", ctypes.c_void_p)]
+
+
+def weight_analyse_host(depth, cur, refs, pic_width, pic_height, intra_cost, lowres_margin, chroma_margin, plane_keys=None):
+    """weightAnalyse behind host pointers (x265hip_weight_analyse_host); cur = dict(lowres, lowres_stride, lowres_width, lowres_lines, cb, cr, stride_c, wp_ssd, wp_sum), refs = dicts(lowres[4], cb, cr, mvs, wp_ssd, wp_sum) (numpy planes in HOST
+    memory, (array, org) pairs).  Returns (weights int32 [2, 3, 4], denoms int32 [2, 2])."""
+    import numpy as np
+    es = cur["lowres"][0].itemsize
+    at = lambda pair: pair[0].ctypes.data + pair[1] * es
+    p = WeightAnalyseHostParams()
+    p.depth, p.lowres, p.lowres_stride = depth, at(cur["lowres"]), cur["lowres_stride"]
+    p.lowres_width, p.lowres_lines, p.lowres_margin_x, p.lowres_margin_y = cur["lowres_width"], cur["lowres_lines"], lowres_margin[0], lowres_margin[1]
+    p.cb, p.cr, p.stride_c, p.margin_xc, p.margin_yc = at(cur["cb"]), at(cur["cr"]), cur["stride_c"], chroma_margin[0], chroma_margin[1]
+    p.pic_width, p.pic_height = pic_width, pic_height
+    ic = np.ascontiguousarray(intra_cost, np.int32)
+    p.intra_cost = ic.ctypes.data
+    keep = []
+    for k in range(3):
+        p.wp_ssd[k], p.wp_sum[k] = int(cur["wp_ssd"][k]), int(cur["wp_sum"][k])
+    p.plane_key = plane_keys[0] if plane_keys else 0
+    p.nlists = len(refs)
+    for i, r in enumerate(refs):
+        for k in range(4):
+            p.ref[i].lowres[k] = at(r["lowres"][k])
+        p.ref[i].cb, p.ref[i].cr = at(r["cb"]), at(r["cr"])
+        if r.get("mvs") is not None:
+            m = np.ascontiguousarray(r["mvs"], np.int32)
+            keep.append(m)
+            p.ref[i].mvs = m.ctypes.data
+        for k in range(3):
+            p.ref[i].wp_ssd[k], p.ref[i].wp_sum[k] = int(r["wp_ssd"][k]), int(r["wp_sum"][k])
+        p.ref[i].plane_key = plane_keys[1 + i] if plane_keys else 0
+    out, den = np.zeros((2, 3, 4), np.int32), np.zeros((2, 2), np.int32)
+    p.weights, p.denoms = out.ctypes.data, den.ctypes.data
+    f = lib().x265hip_weight_analyse_host
+    f.argtypes = [ctypes.POINTER(WeightAnalyseHostParams)]
+    check(f(ctypes.byref(p)), "x265hip_weight_analyse_host")
+    return out, den
+
+
 class AqHevcParams(ctypes.Structure):
     """x265hip_aq_hevc_params (include/x265hip.h)."""
     _fields_ = [("depth", ctypes.c_int), ("y", ctypes.c_void_p), ("stride", ctypes.c_ssize_t),
