@@ -379,3 +379,21 @@ def test_lookahead_seam_size_gate_leaves_small_pictures_to_the_reference():
         close()
     assert got[0] == base[0] and got[3] == 0 and rep["search_seams_left_off_by_the_size_gate"], rep
     assert rep["lookups_served"] == 0 and rep["pair_submits"] == 0 and rep["row_stream"]["recon_rows_to_sad_provider"] == 0 and rep["row_stream"]["recon_rows_to_phase_provider"] == 0, rep
+
+
+@pytest.mark.reference
+def test_every_built_seam_library_exports_what_the_driver_binds():
+    """A seam library of one build flavour left behind by an older recipe (make ref without make refv3) fails at install time on the GPU box,
+    inside a bench leg: every libx265ref*_seam.so present must export the whole binding."""
+    import ctypes
+    import glob
+    libs = sorted(glob.glob(os.path.join(ROOT, "oracle", "_ref", "libx265ref*_seam.so")))
+    if not libs:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    need = ["x265ref_seam_configure", "x265ref_seam_configure_streamed", "x265ref_subpel_seam_configure_streamed", "x265ref_lookahead_seam_configure",
+            "x265ref_aq_seam_configure", "x265ref_aq_seam_stats", "x265ref_weight_seam_configure", "x265ref_weight_seam_stats", "x265ref_seam_fill_table",
+            "x265ref_seam_min_ctus", "x265ref_lookahead_seam_min_blocks", "x265ref_seam_weighted_stats", "x265ref_seam_disable", "x265ref_encode"]
+    for path in libs:
+        L = ctypes.CDLL(path)
+        missing = [n for n in need if not hasattr(L, n)]
+        assert not missing, f"{os.path.basename(path)} lacks {missing}: rebuild with make -C oracle ref refv3"
