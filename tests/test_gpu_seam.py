@@ -668,6 +668,40 @@ def test_4k_preset_slow_star_frame_threads_5_every_served_value_verified_in_flig
     assert rep["lookup_hit_rate"] > 0.85, rep
 
 
+def test_4k_fade_every_seam_on_weighted_references_and_both_host_services_verified_in_flight():
+    """The same size on a FADE with x265's default --weightp: weightAnalyse (x265hip_weight_analyse_host) picks the weights, the weighted references go
+    through the row-granular search services, calcAdaptiveQuantFrame (x265hip_aq_frame_host) feeds the statistics - all above the binding's size gates,
+    every served SAD / comparison / frame cost re-evaluated by the host's function and both host services re-run by the reference's own functions."""
+    import test_seam_cpu as T
+    from tools import encoder_bench as EB, seam_driver as SD
+    try:
+        plain = EB.ref_lib(8)
+        SD.seam_lib(8)
+    except (SystemExit, FileNotFoundError):
+        pytest.skip("oracle/_ref not built (it travels to the GPU box with the snapshot)")
+    w, h, n = 3840, 2160, 8
+    clip = F.synth_clip(w, h, n, depth=8, seed=265, fade=(1.0, 0.4))
+    yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
+    opts = [("pools", str(EB.effective_cpus())), ("frame-threads", "5"), ("crf", "28"), ("me", "star"), ("lookahead-slices", "1")]
+    base = EB.encode(plain, yuv, w, h, n, "slow", opts)
+    lib, filler, report, close, prov = SD.install(8, w, h, provider="gpu", rng=12, slots=24, min_pu=16, verify=True, lookahead="gpu+verify", subpel="gpu", subpel_slots=12,
+                                                  streamed=True, min_level=1, pictures=24, layout=SD.LAYOUT_PLANES, centre_range=57, lookahead_min_blocks=None, min_ctus=None,
+                                                  aq="gpu", aq_min_blocks=None, weight_analyse="gpu", weight_min_blocks=None)
+    try:
+        got = EB.encode(lib, yuv, w, h, n, "slow", opts, filler)
+        rep = report()
+    finally:
+        close()
+    assert got[0] == base[0], f"seams changed the bitstream: {rep}"
+    sub, la, aq, wa = rep["subpel_seam"], rep["lookahead_seam"], rep["aq_seam"], rep["weight_analyse_seam"]
+    assert rep["verify_mismatches"] == 0 and sub["verify_mismatches"] == 0 and la["verify_mismatches"] == 0 and aq["verify_mismatches"] == 0 and wa["verify_mismatches"] == 0, rep
+    assert rep["failed"] == 0 and sub["failed"] == 0 and la["failed"] == 0 and aq["failed"] == 0 and wa["failed"] == 0
+    assert aq["pictures_served"] == n and aq["left_to_the_reference_by_the_size_gate"] == 0, aq
+    assert wa["slices_served"] >= 2 and wa["served_slices_with_a_weight"] >= 1 and wa["left_to_the_reference_by_the_size_gate"] == 0, wa
+    assert rep["weighted_references"]["lookups_served_on_weighted_references"] > 100_000, rep["weighted_references"]
+    assert rep["weighted_references"]["subpel_compares_served_from_weighted_views"] > 10_000, rep["weighted_references"]
+
+
 def test_stream_services_can_be_pinned_to_a_device():
     """device_plus_1 of x265hip_me_stream_params / x265hip_phase_stream_params: an instance per GPU for a host that spreads its frame
     encoders over a node (encoder/encoder.cpp:304-321).  Device 0 named explicitly works like the default; a device the box does not
