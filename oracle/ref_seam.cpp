@@ -423,13 +423,24 @@ template <int P> int sad_seam(const pixel* fenc, intptr_t fstride, const pixel* 
 template <int P, int N> inline void sad_xn_seam(const pixel* fenc, const pixel* const* r, intptr_t rstride, int32_t* res)
 {
     Ctx& c = t_ctx;
+    int v[N];
+    unsigned hit = 0;
+    for (int i = 0; i < N; i++)
+        if (lookup(c, r[i], v[i])) hit |= 1u << i;
+    if (!hit)
+    {
+        /* none of the candidates lies in the window (a search that wanders - unweighted references on a fade - asks for hundreds of millions of
+         * those): the host's own batched primitive, one call, as if the seam were not there */
+        if (N == 3) g.sad_x3[P](fenc, r[0], r[1], r[2], rstride, res);
+        else g.sad_x4[P](fenc, r[0], r[1], r[2], r[3], rstride, res);
+        return;
+    }
     for (int i = 0; i < N; i++)
     {
-        int v;
-        if (lookup(c, r[i], v))
+        if (hit >> i & 1)
         {
-            if (g.verify) { const int w = g.sad[P](fenc, FENC_STRIDE, r[i], rstride); if (w != v) verify_fail(P, v, w); }
-            res[i] = v;
+            if (g.verify) { const int w = g.sad[P](fenc, FENC_STRIDE, r[i], rstride); if (w != v[i]) verify_fail(P, v[i], w); }
+            res[i] = v[i];
         }
         else
             res[i] = g.sad[P](fenc, FENC_STRIDE, r[i], rstride);      /* sad_x3 / sad_x4 are N independent SADs (pixel.cpp:74-119) */
