@@ -239,6 +239,7 @@ struct FencStaged { int poc; int encodeOrder; bool used; };
 struct Seam
 {
     bool enabled = false, verify = false, wait = false;
+    bool batchMisses = true;      /* X265REF_SEAM_NO_BATCH_MISS=1 (A/B): a sad_x3 / sad_x4 without a hit goes back to N single SADs */
     Provider p;
     int nc, ng, groupBytes, ctusW, pitch;
     uint64_t strideMagic;               /* ceil(2^40 / stride): row = (t * magic) >> 40 for every offset a lookup can see */
@@ -427,7 +428,7 @@ template <int P, int N> inline void sad_xn_seam(const pixel* fenc, const pixel* 
     unsigned hit = 0;
     for (int i = 0; i < N; i++)
         if (lookup(c, r[i], v[i])) hit |= 1u << i;
-    if (!hit)
+    if (!hit && g.batchMisses)
     {
         /* none of the candidates lies in the window (a search that wanders - unweighted references on a fade - asks for hundreds of millions of
          * those): the host's own batched primitive, one call, as if the seam were not there */
@@ -1402,6 +1403,7 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
     g.p.range = range; g.p.surf_format = surf_format; g.p.slots = slots;
     g.p.width = width; g.p.height = height; g.p.stride = stride; g.p.margin_x = margin_x; g.p.margin_y = margin_y;
     g.p.min_pu = min_pu < 8 ? 8 : min_pu;
+    g.batchMisses = !getenv("X265REF_SEAM_NO_BATCH_MISS");
     g.nc = 2 * range + 1; g.ng = (g.nc + 3) >> 2; g.pitch = 4 * g.ng;
     g.strideMagic = (((uint64_t)1 << 40) + (uint64_t)stride - 1) / (uint64_t)stride;
     g.groupBytes = surf_format == SURF_I32 ? GROUP_I32 : GROUP_PACKED;
