@@ -388,7 +388,10 @@ def main():
                     "25-picture lookahead of preset slow, so that the lookahead runs ahead of the frame encoders the way it does in a real encode - 24 for cfg3f / cfg4, 96 for cfg2)")
     ap.add_argument("--encoder-frame-threads", type=int, default=0, help="--frame-threads of the encoder legs (0 = what x265 picks itself for 16 cores at that "
                     "picture size: 5 at 4K, 3 at 1080p; the row-granular seams serve at any value)")
-    ap.add_argument("--encoder-tables", default="c,seam", help="c = reference C table, seam = + x265hip_me_cache lookups, hip = per-call stubs (slow)")
+    ap.add_argument("--encoder-tables", default="c,csplit,seam",
+                    help="c = reference C table; csplit = HOST-ONLY control: the C table with sad_x3 / sad_x4 answered by N calls of its own sad (what the seam stubs do "
+                         "for a candidate they cannot serve - g++ vectorises the single-reference loop and not the multi-reference ones, so this alone is faster); "
+                         "seam = the services behind the stage-level seams; hip = per-call stubs (slow)")
     ap.add_argument("--prims", action="store_true",
                     help="instead of the pipeline line, print the per-family table of the batch-layer kernels with the CPU paths timed beside "
                          "them (tools/bench_prims.py: bench.py's cpu_baseline leg at primitive level)")
@@ -736,6 +739,9 @@ def main():
                     return {"workload": c["config"], "frames": c["c"]["frames"], "frame_threads": int(c["options"]["frame-threads"]), "cores": c["pool_threads"],
                             "reference_c_table_fps": c["c"]["fps"], "seam_fps": sm.get("fps"), "seam_md5_equal": sm.get("md5_equal_to_c_table"),
                             "gain": round(sm["fps"] / c["c"]["fps"], 3) if sm.get("fps") else None,
+                            # how much of that is the stubs' HOST path: the C table with sad_x3 / sad_x4 split into single SADs, no GPU involved
+                            "host_only_split_sad_control_fps": c.get("csplit", {}).get("fps"),
+                            "gain_over_host_only_control": round(sm["fps"] / c["csplit"]["fps"], 3) if sm.get("fps") and c.get("csplit", {}).get("fps") else None,
                             **{k: rep.get(k) for k in ("motion_estimate_calls", "calls_with_lookup_context", "lookups_served", "lookup_hit_rate", "bytes_downloaded")},
                             "subpel_compares_served": rep.get("subpel_seam", {}).get("subpel_compares_served"),
                             "phase_bytes_downloaded": rep.get("subpel_seam", {}).get("bytes_downloaded"),
@@ -759,7 +765,8 @@ def main():
                                                   "build": "the reference's C path, g++ -O3 -march=x86-64-v3 -ffp-contract=off (AVX2 auto-vectorised; the hand-written NASM "
                                                            "AVX2 / AVX-512 kernels need nasm, which the image lacks) - same seams on top, same bitstream as the plain build",
                                                   **{k[:-3]: {**{f: v for f, v in (leg(k) or {}).items() if f in ("reference_c_table_fps", "seam_fps", "gain", "seam_md5_equal", "frames",
-                                                                                                                  "frame_threads")},
+                                                                                                                  "frame_threads", "host_only_split_sad_control_fps",
+                                                                                                                  "gain_over_host_only_control")},
                                                               "md5_equal_to_the_plain_build": enc[k].get("c", {}).get("md5") == enc[k[:-3]].get("c", {}).get("md5")}
                                                      for k in enc if k.endswith("_v3") and "c" in enc[k]}}}
             except BaseException as e:       # incl. SystemExit from a missing oracle/_ref

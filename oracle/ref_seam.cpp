@@ -476,6 +476,28 @@ template <int P> struct Install
 };
 template <> struct Install<NUM_PU_SIZES> { static void run(EncoderPrimitives&, int&) {} };
 
+/* the host-only control table (x265ref_split_fill_table below) */
+pixelcmp_t g_splitSad[NUM_PU_SIZES];
+template <int P> void split_x3(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, intptr_t rstride, int32_t* res)
+{
+    res[0] = g_splitSad[P](fenc, FENC_STRIDE, r0, rstride); res[1] = g_splitSad[P](fenc, FENC_STRIDE, r1, rstride); res[2] = g_splitSad[P](fenc, FENC_STRIDE, r2, rstride);
+}
+template <int P> void split_x4(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rstride, int32_t* res)
+{
+    res[0] = g_splitSad[P](fenc, FENC_STRIDE, r0, rstride); res[1] = g_splitSad[P](fenc, FENC_STRIDE, r1, rstride);
+    res[2] = g_splitSad[P](fenc, FENC_STRIDE, r2, rstride); res[3] = g_splitSad[P](fenc, FENC_STRIDE, r3, rstride);
+}
+template <int P> struct InstallSplit
+{
+    static void run(EncoderPrimitives& t, int& n)
+    {
+        g_splitSad[P] = t.pu[P].sad;
+        if (t.pu[P].sad) { t.pu[P].sad_x3 = split_x3<P>; t.pu[P].sad_x4 = split_x4<P>; n += 2; }
+        InstallSplit<P + 1>::run(t, n);
+    }
+};
+template <> struct InstallSplit<NUM_PU_SIZES> { static void run(EncoderPrimitives&, int&) {} };
+
 /* slot of (source picture poc, reference picture); -1 when none can be had.  The first query for a new source picture requests the
  * surfaces of ALL its unweighted references as one batch (x265hip_me_cache_submit_batch: searched back to back, downloaded
  * row-interleaved), so the top CTU rows of every reference arrive first. */
@@ -1579,6 +1601,18 @@ int x265ref_aq_seam_configure(void* host_fn, void* oracle_fn, int verify, int mi
 }
 /* out[5]: pictures served, passed to the reference's loop (a mode / option the service does not cover), failed, verify mismatches, gated by size */
 void x265ref_aq_seam_stats(uint64_t* out) { out[0] = gaq.served; out[1] = gaq.passed; out[2] = gaq.failed; out[3] = gaq.mismatches; out[4] = gaq.gated; }
+
+/* HOST-ONLY control (no provider, no GPU): sad_x3 / sad_x4 of every partition answered by N calls of the table's own `sad` - what the lookup stubs do for
+ * candidates they cannot serve.  g++ -O3 turns the reference's single-reference SAD loop (pixel.cpp:60-72) into psadbw but leaves the three- / four-reference
+ * loops (pixel.cpp:74-119) scalar, so this table alone is faster than the C table; an encode with it next to the C table and the seams separates what the
+ * services contribute from what the stubs' host path contributes (tools/encoder_bench.py --tables c,csplit,seam). */
+int x265ref_split_fill_table(void* table, size_t bytes, int depth)
+{
+    if (!table || bytes != sizeof(EncoderPrimitives) || depth != X265_DEPTH) return -1;
+    int n = 0;
+    InstallSplit<0>::run(*(EncoderPrimitives*)table, n);
+    return n;
+}
 
 /* table filler with the x265hip_setup_primitives signature: installs the lookup stubs over the host's own sad family */
 int x265ref_seam_fill_table(void* table, size_t bytes, int depth)

@@ -107,6 +107,11 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
     for t in tables:
         nf = n
         filler, note, closer, enc_lib = None, None, None, lib
+        if t == "csplit":          # host-only control: the C table with sad_x3 / sad_x4 answered by N calls of its own sad (what the seam stubs do on a miss)
+            from tools import seam_driver as SD
+            enc_lib = SD.seam_lib(depth, build)
+            enc_lib.x265ref_seam_disable()
+            filler = ctypes.cast(enc_lib.x265ref_split_fill_table, ctypes.c_void_p)
         if t == "hip":
             A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
             L = A.lib()
