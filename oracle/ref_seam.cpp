@@ -239,7 +239,7 @@ struct FencStaged { int poc; int encodeOrder; bool used; };
 struct Seam
 {
     bool enabled = false, verify = false, wait = false;
-    bool batchMisses = true;      /* X265REF_SEAM_NO_BATCH_MISS=1 (A/B): a sad_x3 / sad_x4 without a hit goes back to N single SADs */
+    bool batchMisses = false;     /* X265REF_SEAM_BATCH_MISS=1 (A/B): a sad_x3 / sad_x4 without a hit goes to the table's own batched primitive */
     Provider p;
     int nc, ng, groupBytes, ctusW, pitch;
     uint64_t strideMagic;               /* ceil(2^40 / stride): row = (t * magic) >> 40 for every offset a lookup can see */
@@ -430,8 +430,10 @@ template <int P, int N> inline void sad_xn_seam(const pixel* fenc, const pixel* 
         if (lookup(c, r[i], v[i])) hit |= 1u << i;
     if (!hit && g.batchMisses)
     {
-        /* none of the candidates lies in the window (a search that wanders - unweighted references on a fade - asks for hundreds of millions of
-         * those): the host's own batched primitive, one call, as if the seam were not there */
+        /* A/B only (off by default): none of the candidates lies in the window - the host's own batched primitive, one call, as if the seam were not
+         * there.  It LOSES a third of the fps on the fade (2.23 against 3.40, profiles/r04_encoder_legs.txt): g++ -O3 vectorises the reference's
+         * single-reference SAD loop and not its three- / four-reference loops, so N calls of `sad` beat one call of sad_x4 - which also means that part of
+         * what the seams gain over the C table is this host path and not the services (the csplit control table measures it) */
         if (N == 3) g.sad_x3[P](fenc, r[0], r[1], r[2], rstride, res);
         else g.sad_x4[P](fenc, r[0], r[1], r[2], r[3], rstride, res);
         return;
@@ -1425,7 +1427,7 @@ int x265ref_seam_configure(void* ctx, void* submit, void* submit_batch, void* su
     g.p.range = range; g.p.surf_format = surf_format; g.p.slots = slots;
     g.p.width = width; g.p.height = height; g.p.stride = stride; g.p.margin_x = margin_x; g.p.margin_y = margin_y;
     g.p.min_pu = min_pu < 8 ? 8 : min_pu;
-    g.batchMisses = !getenv("X265REF_SEAM_NO_BATCH_MISS");
+    g.batchMisses = getenv("X265REF_SEAM_BATCH_MISS") != NULL;
     g.nc = 2 * range + 1; g.ng = (g.nc + 3) >> 2; g.pitch = 4 * g.ng;
     g.strideMagic = (((uint64_t)1 << 40) + (uint64_t)stride - 1) / (uint64_t)stride;
     g.groupBytes = surf_format == SURF_I32 ? GROUP_I32 : GROUP_PACKED;
