@@ -392,8 +392,29 @@ def test_every_built_seam_library_exports_what_the_driver_binds():
         pytest.skip("oracle/_ref not built (needs /root/reference)")
     need = ["x265ref_seam_configure", "x265ref_seam_configure_streamed", "x265ref_subpel_seam_configure_streamed", "x265ref_lookahead_seam_configure",
             "x265ref_aq_seam_configure", "x265ref_aq_seam_stats", "x265ref_weight_seam_configure", "x265ref_weight_seam_stats", "x265ref_seam_fill_table",
-            "x265ref_seam_min_ctus", "x265ref_lookahead_seam_min_blocks", "x265ref_seam_weighted_stats", "x265ref_seam_disable", "x265ref_encode"]
+            "x265ref_seam_min_ctus", "x265ref_split_fill_table", "x265ref_lookahead_seam_min_blocks", "x265ref_seam_weighted_stats", "x265ref_seam_disable", "x265ref_encode"]
     for path in libs:
         L = ctypes.CDLL(path)
         missing = [n for n in need if not hasattr(L, n)]
         assert not missing, f"{os.path.basename(path)} lacks {missing}: rebuild with make -C oracle ref refv3"
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("depth,preset,extra", [(8, "medium", []), (8, "slow", [("me", "star")]), (10, "medium", [("me", "umh")])])
+def test_host_only_control_table_keeps_the_bitstream(depth, preset, extra):
+    """x265ref_split_fill_table - the encoder legs' host-only control: sad_x3 / sad_x4 of all 25 partitions answered by N calls of the table's own sad.
+    Same values, so the same bitstream; 50 slots replaced."""
+    import ctypes
+    EB, SD = _tools()
+    try:
+        plain = EB.ref_lib(depth)
+        lib = SD.seam_lib(depth)
+    except (SystemExit, FileNotFoundError):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    clip = F.synth_clip(256, 192, 5, depth=depth, seed=41)
+    yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
+    opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24")] + extra
+    base = EB.encode(plain, yuv, 256, 192, 5, preset, opts)
+    lib.x265ref_seam_disable()
+    got = EB.encode(lib, yuv, 256, 192, 5, preset, opts, ctypes.cast(lib.x265ref_split_fill_table, ctypes.c_void_p))
+    assert got[0] == base[0] and got[3] == 50, got
