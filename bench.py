@@ -714,12 +714,15 @@ def main():
                                                    "lookahead": True, "subpel": True, "subpel_slots": 12, "streamed": True, "min_level": 1, "pictures": 24,
                                                    # calcAdaptiveQuantFrame / weightAnalyse from x265hip_aq_frame_host / x265hip_weight_analyse_host (gated to 4K and up by
                                                    # the binding): +5 % on the fade, neutral at constant brightness (profiles/r04_encoder_legs.txt)
-                                                   "aq": True, "weight_analyse": True})
+                                                   "aq": True, "weight_analyse": True,
+                                                   # everything the services do not answer takes the host-only control's split SADs, so that seam_fps against
+                                                   # host_only_split_sad_control_fps is the services' contribution alone
+                                                   "split_rest": True})
                 # "vs host AVX2" (BASELINE metric): the hand-written NASM AVX2 / AVX-512 kernels cannot be assembled here (no nasm); the closest
                 # buildable thing is the reference's own C path with AVX2 code generation (g++ -O3 -march=x86-64-v3, oracle/Makefile refv3: the
                 # SAD loops become vpsadbw) - timed beside the plain build for the metric's configuration and the 10-bit one, same seams on top
                 SEAM = {"range": 12, "centre_range": 57, "layout": 1, "min_pu": 16, "verify": False, "lookahead": True, "subpel": True, "subpel_slots": 12, "streamed": True,
-                        "min_level": 1, "pictures": 24, "aq": True, "weight_analyse": True}
+                        "min_level": 1, "pictures": 24, "aq": True, "weight_analyse": True, "split_rest": True}
                 for key in [k for k in ("cfg3", "cfg4") if k in enc]:
                     nf, ft = ENC_DEFAULTS[key]
                     nf, ft = args.encoder_frames or nf, args.encoder_frame_threads or ft
@@ -758,7 +761,9 @@ def main():
                                               "seams": "row-granular SAD lookups (x265hip_me_stream: PU-major planes, +-12 windows centred on each CTU's displacement) + sub-sample "
                                                        "comparisons (x265hip_phase_stream views, weighted references included) + lookahead frame costs (x265hip_lowres_cost_host), "
                                                        "the pre-lookahead's adaptive-quantisation pass (x265hip_aq_frame_host) and the frame encoder's weightAnalyse "
-                                                       "(x265hip_weight_analyse_host) - the last three 4K and up - all under the reference's own frame threads",
+                                                       "(x265hip_weight_analyse_host) - the last three 4K and up - all under the reference's own frame threads; candidates / partitions the "
+                                                       "services do not answer take the host-only control's split SADs (csplit), so seam_fps against "
+                                                       "host_only_split_sad_control_fps is the services' contribution alone",
                                               "kind": "reference (x265 3.5 C primitives, no asm: nasm is not in the image)",
                                               "other_configs": {k: leg(k) for k in enc if k != "cfg3" and not k.endswith("_v3") and leg(k)},
                                               "host_avx2_autovectorised": {

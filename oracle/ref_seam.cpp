@@ -1620,9 +1620,16 @@ int x265ref_split_fill_table(void* table, size_t bytes, int depth)
 int x265ref_seam_fill_table(void* table, size_t bytes, int depth)
 {
     if (!table || bytes != sizeof(EncoderPrimitives) || depth != X265_DEPTH) return -1;
-    if (g_gated) return 0;          /* a picture below the size gate: nothing is installed, the encode is the reference's own */
-    if (!g.enabled) return -1;
     int n = 0;
+    if (g_gated)                    /* a picture below the size gate: no lookup stub is installed, the encode is the reference's own (or the host-only control's) */
+    {
+        if (getenv("X265REF_SEAM_SPLIT_REST")) InstallSplit<0>::run(*static_cast<EncoderPrimitives*>(table), n);
+        return n;
+    }
+    if (!g.enabled) return -1;
+    /* X265REF_SEAM_SPLIT_REST=1: everything the services do NOT answer - partitions below min_pu, searches without a context - goes through the host-only control's
+     * split sad_x3 / sad_x4 as well, so that an encode with the seams and an encode with the control table differ by the services alone */
+    if (getenv("X265REF_SEAM_SPLIT_REST")) InstallSplit<0>::run(*static_cast<EncoderPrimitives*>(table), n);
     Install<0>::run(*static_cast<EncoderPrimitives*>(table), n);
     return n;
 }

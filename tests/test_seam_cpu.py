@@ -22,7 +22,7 @@ def _tools():
 
 
 def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False, lookahead=None, subpel=None, surf_format=None,
-             streamed=False, min_level=0, slots=8, subpel_slots=6, layout=0, centre_range=0, aq=None, width_clip=None):
+             streamed=False, min_level=0, slots=8, subpel_slots=6, layout=0, centre_range=0, aq=None, width_clip=None, split_rest=False):
     EB, SD = _tools()
     try:
         plain = EB.ref_lib(depth)
@@ -34,7 +34,7 @@ def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify
     base = EB.encode(plain, yuv, w, h, nframes, preset, opts)
     lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=slots, min_pu=min_pu, verify=verify, wait=wait, lookahead=lookahead,
                                                   subpel=subpel, surf_format=surf_format, streamed=streamed, min_level=min_level, subpel_slots=subpel_slots,
-                                                  layout=layout, centre_range=centre_range, aq=aq)
+                                                  layout=layout, centre_range=centre_range, aq=aq, split_rest=split_rest)
     try:
         got = EB.encode(lib, yuv, w, h, nframes, preset, opts, filler)
         rep = report()
@@ -418,3 +418,16 @@ def test_host_only_control_table_keeps_the_bitstream(depth, preset, extra):
     lib.x265ref_seam_disable()
     got = EB.encode(lib, yuv, 256, 192, 5, preset, opts, ctypes.cast(lib.x265ref_split_fill_table, ctypes.c_void_p))
     assert got[0] == base[0] and got[3] == 50, got
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("depth,preset,min_pu,extra", [(8, "slow", 16, [("me", "star")]), (8, "medium", 32, []), (10, "medium", 16, [])])
+def test_seams_with_the_host_only_split_for_everything_they_do_not_answer(depth, preset, min_pu, extra):
+    """split_rest (bench.py's seam legs): the lookup stubs on the partitions the services serve, the host-only control's split sad_x3 / sad_x4 on all 25 - the
+    small partitions included - so that seams and control differ by the services alone.  Byte-identical, every lookup verified, more table slots replaced."""
+    opts = [("pools", "4"), ("frame-threads", "3"), ("crf", "24"), ("no-weightp", None), ("no-weightb", None)] + extra
+    base, got, rep = run_pair(depth, 256, 192, 8, preset, opts, "oracle", rng=12, min_pu=min_pu, streamed=True, min_level=1, slots=32, layout=1, centre_range=40, split_rest=True)
+    _, plain_seam, _ = run_pair(depth, 256, 192, 8, preset, opts, "oracle", rng=12, min_pu=min_pu, streamed=True, min_level=1, slots=32, layout=1, centre_range=40)
+    assert got[0] == base[0] == plain_seam[0], f"bitstream changed: {rep}"
+    assert rep["verify_mismatches"] == 0 and rep["lookups_served"] > 300, rep
+    assert got[3] > plain_seam[3] and got[3] >= 50, (got[3], plain_seam[3])

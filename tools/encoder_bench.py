@@ -136,7 +136,7 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
                                                           lookahead_min_blocks=seam.get("lookahead_min_blocks"),      # None: the binding's own size gates
                                                           min_ctus=seam.get("min_ctus"), build=build, aq="gpu" if seam.get("aq") else None,
                                                           aq_min_blocks=seam.get("aq_min_blocks"), weight_analyse="gpu" if seam.get("weight_analyse") else None,
-                                                          weight_min_blocks=seam.get("weight_min_blocks"))
+                                                          weight_min_blocks=seam.get("weight_min_blocks"), split_rest=bool(seam.get("split_rest")))
         t0, c0 = time.perf_counter(), time.process_time()
         md5, nbytes, sec, filled = encode(enc_lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
         wall, cpu = time.perf_counter() - t0, time.process_time() - c0
@@ -182,6 +182,8 @@ def main():
                     help="also serve LookaheadTLD::calcAdaptiveQuantFrame (every quantisation group's AC energy + the QP offsets) from x265hip_aq_frame_host")
     ap.add_argument("--seam-weight-analyse", action="store_true",
                     help="also serve the frame encoder's weightAnalyse (compensated planes, weightCost of every scale / offset pair) from x265hip_weight_analyse_host")
+    ap.add_argument("--seam-split-rest", action="store_true",
+                    help="whatever the services do not answer uses the host-only control's split sad_x3 / sad_x4 (compare with --tables csplit: the difference is the services alone)")
     ap.add_argument("--seam-subpel", action="store_true",
                     help="also serve MotionEstimate::subpelCompare from x265hip_phase_cache (every fractional phase of a reference picture interpolated once)")
     ap.add_argument("--seam-streamed", action="store_true",
@@ -200,7 +202,7 @@ def main():
     seam = {"range": args.seam_range, "slots": args.seam_slots, "min_pu": args.seam_min_pu, "verify": args.seam_verify, "lookahead": args.seam_lookahead,
             "subpel": args.seam_subpel, "subpel_slots": args.seam_subpel_slots, "streamed": args.seam_streamed, "min_level": args.seam_min_level,
             "pictures": args.seam_pictures, "band_rows": args.seam_band_rows, "no_sad": args.seam_no_sad, "weighted": not args.seam_no_weighted,
-            "layout": 1 if args.seam_layout == "planes" else 0, "centre_range": args.seam_centre_range, "aq": args.seam_aq, "weight_analyse": args.seam_weight_analyse}
+            "layout": 1 if args.seam_layout == "planes" else 0, "centre_range": args.seam_centre_range, "aq": args.seam_aq, "weight_analyse": args.seam_weight_analyse, "split_rest": args.seam_split_rest}
     out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s, seam=seam, build=args.ref_build) for k in args.configs.split(",")}
     print(json.dumps({"encoder": out}))
 

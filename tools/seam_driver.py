@@ -643,11 +643,17 @@ class StreamGpuPhaseProvider:
 
 def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
             surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0, min_ctus=0, build="", aq=None, aq_min_blocks=0,
-            weight_analyse=None, weight_min_blocks=0):
+            weight_analyse=None, weight_min_blocks=0, split_rest=False):
     """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
     the picture-granular providers need --frame-threads 1, streamed=True (row-granular providers) serves under any --frame-threads."""
     lib = seam_lib(depth, build)
     geo = geometry(width, height)
+    # split_rest: whatever the services do not answer (partitions below min_pu, searches without a context, pictures below the size gates) uses the host-only
+    # control's split sad_x3 / sad_x4 too (x265ref_split_fill_table) - an encode with the seams then differs from the control table by the services alone
+    if split_rest:
+        os.environ["X265REF_SEAM_SPLIT_REST"] = "1"
+    else:
+        os.environ.pop("X265REF_SEAM_SPLIT_REST", None)
     # the binding's own size gate of the two search seams (1000 CTUs: serve from 4K up) unless the caller names a threshold; tests on small pictures pass 0
     lib.x265ref_seam_min_ctus.argtypes = [ctypes.c_int]
     lib.x265ref_seam_min_ctus(1000 if min_ctus is None else min_ctus)
