@@ -1210,6 +1210,15 @@ void LookaheadTLD::calcAdaptiveQuantFrame(Frame* curFrame, x265_param* param)
     }
 }
 
+/* fixture generation (tools/gen_weight_golden.py): X265REF_WA_DUMP=<dir> + verify writes, per served slice, everything x265hip_weight_analyse_host is
+ * handed and what the REFERENCE's own weightAnalyse answered, as (name, element size, count, bytes) records */
+static void wa_dump_arr(FILE* f, const char* name, int elem, size_t count, const void* data)
+{
+    const uint32_t n = (uint32_t)strlen(name), e = (uint32_t)elem;
+    const uint64_t c = count;
+    fwrite(&n, 4, 1, f); fwrite(name, 1, n, f); fwrite(&e, 4, 1, f); fwrite(&c, 8, 1, f); fwrite(data, (size_t)elem, count, f);
+}
+
 /* weightAnalyse (weightPrediction.cpp:222-520; FrameEncoder::compressFrame calls it for every P / B slice with --weightp / --weightb on): the
  * compensated reference planes, weightCost of every (scale, offset) pair and the decision logic as ONE provider call
  * (x265hip_weight_analyse_host) that returns reference 0's weights per (list, plane) and the denominators the other references are reset to;
@@ -1333,6 +1342,48 @@ void weightAnalyse(Slice& slice, Frame& frame, x265_param& param)
                     const WeightParam& x = wp[list][ref][plane]; const WeightParam& y = slice.m_weightPredTable[list][ref][plane];
                     same &= x.log2WeightDenom == y.log2WeightDenom && x.inputWeight == y.inputWeight && x.inputOffset == y.inputOffset && !x.wtPresent == !y.wtPresent;
                 }
+        if (const char* dir = getenv("X265REF_WA_DUMP"))
+        {
+            static std::atomic<int> serial{0};
+            char path[1024];
+            snprintf(path, sizeof(path), "%s/wa_%03d_poc%d.bin", dir, serial.fetch_add(1), slice.m_poc);
+            if (FILE* f = fopen(path, "wb"))
+            {
+                const int marginY = (int)(pad / fenc.lumaStride), marginX = (int)(pad % fenc.lumaStride);
+                const size_t lplane = (size_t)fenc.lumaStride * (fenc.lines + 2 * marginY);
+                const int chh = pic->m_picHeight >> 1;
+                const size_t cplane = (size_t)pic->m_strideC * (chh + 2 * pic->m_chromaMarginY);
+                const size_t corg = (size_t)pic->m_chromaMarginY * pic->m_strideC + pic->m_chromaMarginX;
+                const int32_t geo[12] = { X265_DEPTH, (int32_t)fenc.lumaStride, fenc.width, fenc.lines, marginX, marginY, (int32_t)pic->m_strideC, (int32_t)pic->m_chromaMarginX,
+                                          (int32_t)pic->m_chromaMarginY, pic->m_picWidth, pic->m_picHeight, numPredDir };
+                wa_dump_arr(f, "geo", 4, 12, geo);
+                wa_dump_arr(f, "cur_lowres", sizeof(pixel), lplane, fenc.buffer[0]);
+                wa_dump_arr(f, "cur_cb", sizeof(pixel), cplane, pic->m_picOrg[1] - corg);
+                wa_dump_arr(f, "cur_cr", sizeof(pixel), cplane, pic->m_picOrg[2] - corg);
+                wa_dump_arr(f, "intra_cost", 4, (size_t)(fenc.width >> 3) * (fenc.lines >> 3), fenc.intraCost);
+                wa_dump_arr(f, "cur_wp_ssd", 8, 3, fenc.wp_ssd); wa_dump_arr(f, "cur_wp_sum", 8, 3, fenc.wp_sum);
+                for (int list = 0; list < numPredDir; list++)
+                {
+                    Frame* refFrame = slice.m_refFrameList[list][0];
+                    Lowres& r = refFrame->m_lowres;
+                    char nm[64];
+                    for (int k = 0; k < 4; k++) { snprintf(nm, sizeof(nm), "ref%d_lowres%d", list, k); wa_dump_arr(f, nm, sizeof(pixel), lplane, r.buffer[k]); }
+                    snprintf(nm, sizeof(nm), "ref%d_cb", list); wa_dump_arr(f, nm, sizeof(pixel), cplane, refFrame->m_fencPic->m_picOrg[1] - corg);
+                    snprintf(nm, sizeof(nm), "ref%d_cr", list); wa_dump_arr(f, nm, sizeof(pixel), cplane, refFrame->m_fencPic->m_picOrg[2] - corg);
+                    snprintf(nm, sizeof(nm), "ref%d_mvs", list); wa_dump_arr(f, nm, 4, mvs[list] ? (size_t)2 * (fenc.width >> 3) * (fenc.lines >> 3) : 0, mvs[list]);
+                    snprintf(nm, sizeof(nm), "ref%d_wp_ssd", list); wa_dump_arr(f, nm, 8, 3, r.wp_ssd);
+                    snprintf(nm, sizeof(nm), "ref%d_wp_sum", list); wa_dump_arr(f, nm, 8, 3, r.wp_sum);
+                    int32_t want[3][4];                                   /* what the REFERENCE's function left in the slice for reference 0 of this list */
+                    for (int plane = 0; plane < 3; plane++)
+                    {
+                        const WeightParam& y = slice.m_weightPredTable[list][0][plane];
+                        want[plane][0] = y.wtPresent != 0; want[plane][1] = y.inputWeight; want[plane][2] = (int32_t)y.log2WeightDenom; want[plane][3] = y.inputOffset;
+                    }
+                    snprintf(nm, sizeof(nm), "ref%d_expected", list); wa_dump_arr(f, nm, 4, 12, want);
+                }
+                fclose(f);
+            }
+        }
         if (!same)
         {
             fprintf(stderr, "ref_seam: WEIGHT ANALYSE VERIFY MISMATCH poc %d: served luma (%d %d %u %d), reference (%d %d %u %d)\n", slice.m_poc,

@@ -1,6 +1,7 @@
 """Golden vectors: reference outputs recorded from the real reference build (tools/gen_golden.py,
 committed under tests/golden/) replayed on the oracle table (CPU) and on the HIP table (GPU)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -37,3 +38,18 @@ def test_hip_table_reproduces_golden_vectors(depth, repo_root):
     for case in G.cases(depth):
         fails += G.run_case(hip, case, store, record=False)
     assert not fails, "\n".join(fails[:30])
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_weight_analyse_reproduces_the_weights_the_reference_chose(depth):
+    """tests/golden/weight_analyse_d*.npz: slices of real encodes of fading clips - what x265's own weightAnalyse (encoder/weightPrediction.cpp:222) was handed and what
+    it answered (tools/gen_weight_golden.py).  The oracle's restatement must choose the same weights; needs neither the reference nor a GPU."""
+    import weight_fixture as WF
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_api as O
+    cs = WF.cases(depth)
+    assert len(cs) >= 5 and any(c["nlists"] == 2 for c in cs) and any(c["expected"][0, 0, 0] for c in cs) and any(not c["expected"][0, 0, 0] for c in cs)
+    for i, c in enumerate(cs):
+        got, den = O.weight_analyse(depth, c["cur"], c["refs"], c["pic"][0], c["pic"][1], c["intra"])
+        assert np.array_equal(got[:c["nlists"]], c["expected"][:c["nlists"]]), (i, got.tolist(), c["expected"].tolist())
+        assert [int(den[l, 0]) for l in range(c["nlists"])] == [int(c["expected"][l, 0, 2]) for l in range(c["nlists"])]

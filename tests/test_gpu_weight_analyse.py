@@ -120,3 +120,14 @@ def test_weight_analyse_host_rejects_bad_geometry():
         A.weight_analyse_host(8, bad, refs, 256, 192, intra, lm, cm)
     with pytest.raises(A.X265HipError):
         A.weight_analyse_host(9, cur, refs, 256, 192, intra, lm, cm)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_weight_analyse_host_reproduces_the_weights_the_reference_chose(depth):
+    """tests/golden/weight_analyse_d*.npz: what x265's own weightAnalyse was handed inside real encodes of fading clips and what it answered (tools/gen_weight_golden.py;
+    weighted P slices, two-list B slices, slices that keep weight 1).  The service must choose the same weights - no oracle in between."""
+    import weight_fixture as WF
+    for i, c in enumerate(WF.cases(depth)):
+        got, den = A.weight_analyse_host(depth, c["cur"], c["refs"], c["pic"][0], c["pic"][1], c["intra"], c["lowres_margin"], c["chroma_margin"])
+        assert np.array_equal(got[:c["nlists"]], c["expected"][:c["nlists"]]), (i, got.tolist(), c["expected"].tolist())
+        assert [int(den[l, 0]) for l in range(c["nlists"])] == [int(c["expected"][l, 0, 2]) for l in range(c["nlists"])]
