@@ -1,4 +1,6 @@
-// lookahead_host.hip - the CONSUMER side of the lookahead's frame cost estimate: a host-pointer, frame-granular entry on top of
+// lookahead_host.hip - whole host functions behind host pointers: the lookahead's frame cost / intra estimates (rounds 2 - 3) and, at the end of the
+// file, LookaheadTLD::calcAdaptiveQuantFrame (x265hip_aq_frame_host) and the frame encoder's weightAnalyse (x265hip_weight_analyse_host, with its
+// compensation / weightCost kernels) - round 4.  First: the CONSUMER side of the lookahead's frame cost estimate: a host-pointer, frame-granular entry on top of
 // x265hip_lowres_cost, shaped like the loop it replaces.  CostEstimateGroup::estimateFrameCost (encoder/slicetype.cpp:3115-3213)
 // spends its time in the estimateCUCost loop over every 8x8 block of the half-resolution picture (:3216-3388: predictor candidates,
 // the lowres motionEstimate, bi-directional candidates, intra competition, the frame / row sums); a host encoder whose Lowres
@@ -9,7 +11,10 @@
 // and grow-only device scratch, released at thread exit.  Same integers as the loop it replaces (tests: device == oracle == the real
 // CostEstimateGroup::singleCost), so the slice-type decisions and the bitstream cannot change.
 #include "common.h"
+#include "tile_interp.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -371,9 +376,6 @@ extern "C" int x265hip_aq_frame_host(const x265hip_aq_frame_host_params* p)
 // Pixel work on the device - the motion-compensated copies (mcLuma / mcChroma) and weightCost for the unweighted plane plus every
 // (scale, offset) pair the scan could visit, one launch per plane - and the reference's own decision logic replayed on the calling
 // thread from the downloaded scores.
-#include "tile_interp.h"
-#include <cmath>
-
 namespace {
 
 struct WaMcLumaArgs { const uint8_t* plane[4]; uint8_t* out; long strideB; int width, lines; const int32_t* mvs; };
