@@ -1131,6 +1131,15 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
     return score;
 }
 
+/* fixture generation (tools/gen_weight_golden.py): X265REF_WA_DUMP=<dir> + verify writes, per served slice, everything x265hip_weight_analyse_host is
+ * handed and what the REFERENCE's own weightAnalyse answered, as (name, element size, count, bytes) records */
+static void wa_dump_arr(FILE* f, const char* name, int elem, size_t count, const void* data)
+{
+    const uint32_t n = (uint32_t)strlen(name), e = (uint32_t)elem;
+    const uint64_t c = count;
+    fwrite(&n, 4, 1, f); fwrite(name, 1, n, f); fwrite(&e, 4, 1, f); fwrite(&c, 8, 1, f); fwrite(data, (size_t)elem, count, f);
+}
+
 /* LookaheadTLD::calcAdaptiveQuantFrame (slicetype.cpp:444-694; once per source picture from PreLookaheadGroup::processTasks, :1395): the
  * acEnergyCu loop over every quantisation group of the picture - the pixel work - and the double-precision offsets as ONE provider call
  * (x265hip_aq_frame_host) that writes straight into the Lowres arrays.  The AQ modes 1 - 3 of 4:2:0 / 4:0:0 pictures; everything the
@@ -1207,16 +1216,34 @@ void LookaheadTLD::calcAdaptiveQuantFrame(Frame* curFrame, x265_param* param)
             fprintf(stderr, "ref_seam: ADAPTIVE QUANTISATION VERIFY MISMATCH poc %d\n", curFrame->m_poc);
             gaq.mismatches.fetch_add(1, std::memory_order_relaxed);
         }
+        if (const char* dir = getenv("X265REF_AQ_DUMP"))          /* fixture generation (tools/gen_weight_golden.py): the picture and what the REFERENCE's function left in Lowres */
+        {
+            static std::atomic<int> serial{0};
+            char path[1024];
+            snprintf(path, sizeof(path), "%s/aq_%03d_poc%d.bin", dir, serial.fetch_add(1), curFrame->m_poc);
+            if (FILE* f = fopen(path, "wb"))
+            {
+                const int chh = pic->m_picHeight >> 1;
+                const size_t yplane = (size_t)pic->m_stride * (pic->m_picHeight + 2 * pic->m_lumaMarginY), yorg = (size_t)pic->m_lumaMarginY * pic->m_stride + pic->m_lumaMarginX;
+                const size_t cplane = (size_t)pic->m_strideC * (chh + 2 * pic->m_chromaMarginY), corg = (size_t)pic->m_chromaMarginY * pic->m_strideC + pic->m_chromaMarginX;
+                const int32_t geo[12] = { X265_DEPTH, (int32_t)pic->m_stride, (int32_t)pic->m_lumaMarginX, (int32_t)pic->m_lumaMarginY, (int32_t)pic->m_strideC, (int32_t)pic->m_chromaMarginX,
+                                          (int32_t)pic->m_chromaMarginY, pic->m_picWidth, pic->m_picHeight, q, param->rc.aqMode, weightp };
+                const double strength = param->rc.aqStrength;
+                wa_dump_arr(f, "geo", 4, 12, geo);
+                wa_dump_arr(f, "strength", 8, 1, &strength);
+                const int32_t grid[2] = { widthInCU, heightInCU };
+                wa_dump_arr(f, "grid", 4, 2, grid);
+                wa_dump_arr(f, "y", sizeof(pixel), yplane, pic->m_picOrg[0] - yorg);
+                if (!mono) { wa_dump_arr(f, "cb", sizeof(pixel), cplane, pic->m_picOrg[1] - corg); wa_dump_arr(f, "cr", sizeof(pixel), cplane, pic->m_picOrg[2] - corg); }
+                wa_dump_arr(f, "qp_aq_offset", 8, blockCount, lr.qpAqOffset);
+                wa_dump_arr(f, "qp_cutree_offset", 8, blockCount, lr.qpCuTreeOffset);
+                wa_dump_arr(f, "inv_qscale", 4, blockCount, lr.invQscaleFactor);
+                if (q == 8) wa_dump_arr(f, "inv_qscale_8x8", 4, (size_t)widthInCU * heightInCU, lr.invQscaleFactor8x8);
+                wa_dump_arr(f, "wp_sum", 8, 3, lr.wp_sum); wa_dump_arr(f, "wp_ssd", 8, 3, lr.wp_ssd);
+                fclose(f);
+            }
+        }
     }
-}
-
-/* fixture generation (tools/gen_weight_golden.py): X265REF_WA_DUMP=<dir> + verify writes, per served slice, everything x265hip_weight_analyse_host is
- * handed and what the REFERENCE's own weightAnalyse answered, as (name, element size, count, bytes) records */
-static void wa_dump_arr(FILE* f, const char* name, int elem, size_t count, const void* data)
-{
-    const uint32_t n = (uint32_t)strlen(name), e = (uint32_t)elem;
-    const uint64_t c = count;
-    fwrite(&n, 4, 1, f); fwrite(name, 1, n, f); fwrite(&e, 4, 1, f); fwrite(&c, 8, 1, f); fwrite(data, (size_t)elem, count, f);
 }
 
 /* weightAnalyse (weightPrediction.cpp:222-520; FrameEncoder::compressFrame calls it for every P / B slice with --weightp / --weightb on): the

@@ -53,3 +53,19 @@ def test_oracle_weight_analyse_reproduces_the_weights_the_reference_chose(depth)
         got, den = O.weight_analyse(depth, c["cur"], c["refs"], c["pic"][0], c["pic"][1], c["intra"])
         assert np.array_equal(got[:c["nlists"]], c["expected"][:c["nlists"]]), (i, got.tolist(), c["expected"].tolist())
         assert [int(den[l, 0]) for l in range(c["nlists"])] == [int(c["expected"][l, 0, 2]) for l in range(c["nlists"])]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_aq_frame_reproduces_what_the_reference_left_in_lowres(depth):
+    """tests/golden/aq_frame_d*.npz: the source picture x265's own calcAdaptiveQuantFrame was handed inside a real encode and the arrays it filled (AQ modes 1 - 3,
+    qg 16 / 8, weightp on / off; tools/gen_weight_golden.py).  Doubles compared bit for bit."""
+    import weight_fixture as WF
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_api as O
+    cs = WF.aq_cases(depth)
+    assert len(cs) == 5 and {c["mode"] for c in cs} == {1, 2, 3} and {c["qg"] for c in cs} == {16, 8}
+    for i, c in enumerate(cs):
+        energy, qp, inv, sm, ssd = O.aq_frame(depth, c["y"], c["stride"], c["org"], c["width"], c["height"], cb=c["cb"], cr=c["cr"], stride_c=c["stride_c"], org_c=c["org_c"],
+                                              qg_size=c["qg"], aq_mode=c["mode"], aq_strength=c["strength"], weightp=c["weightp"])
+        assert np.array_equal(qp, c["qp_aq_offset"]) and np.array_equal(qp, c["qp_cutree_offset"]), i
+        assert np.array_equal(inv, c["inv_qscale"]) and np.array_equal(sm, c["wp_sum"]) and np.array_equal(ssd, c["wp_ssd"]), i

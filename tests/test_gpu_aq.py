@@ -153,3 +153,18 @@ def test_aq_frame_host_rejects_what_it_does_not_cover():
             A.aq_frame_host(kw["depth"], y, 64, 0, 64, 64, kw["qg_size"], kw["aq_mode"], kw["aq_strength"])
     with pytest.raises(A.X265HipError):
         A.aq_frame_host(8, y, 64, 0, 64, 64, 16, 2, 1.0, cb=y)          # cb without cr
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_aq_frame_host_reproduces_what_the_reference_left_in_lowres(depth):
+    """tests/golden/aq_frame_d*.npz: the picture x265's own calcAdaptiveQuantFrame was handed in a real encode and the arrays IT filled (tools/gen_weight_golden.py);
+    the service against them directly, doubles bit for bit - no oracle in between."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import weight_fixture as WF
+    for i, c in enumerate(WF.aq_cases(depth)):
+        got = A.aq_frame_host(depth, c["y"], c["stride"], c["org"], c["width"], c["height"], c["qg"], c["mode"], c["strength"], cb=c["cb"], cr=c["cr"], stride_c=c["stride_c"],
+                              org_c=c["org_c"], normalise_wp=c["weightp"], lowres_grid=c["grid"] if c["qg"] == 8 else None)
+        assert np.array_equal(got["qp_aq_offset"], c["qp_aq_offset"]) and np.array_equal(got["qp_cutree_offset"], c["qp_cutree_offset"]), i
+        assert np.array_equal(got["inv_qscale"], c["inv_qscale"]) and np.array_equal(got["wp_sum"], c["wp_sum"]) and np.array_equal(got["wp_ssd"], c["wp_ssd"]), i
+        if c["qg"] == 8:
+            assert np.array_equal(got["inv_qscale_8x8"], c["inv_qscale_8x8"]), i

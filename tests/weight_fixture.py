@@ -25,3 +25,18 @@ def cases(depth):
             expected[l] = g(f"ref{l}_expected").reshape(3, 4)
         out.append(dict(cur=cur, refs=refs, pic=(pw, ph), intra=g("intra_cost"), lowres_margin=(mx, my), chroma_margin=(cmx, cmy), nlists=nlists, expected=expected))
     return out
+
+
+def aq_cases(depth):
+    """tests/golden/aq_frame_d{8,10}.npz: the source picture calcAdaptiveQuantFrame was handed in a real encode and the Lowres arrays the REFERENCE's function filled."""
+    z = np.load(os.path.join(GOLDEN, f"aq_frame_d{depth}.npz"))
+    out = []
+    for i in range(int(z["count"][0])):
+        g = lambda k: z[f"s{i}_{k}"]
+        d, stride, mx, my, cstride, cmx, cmy, w, h, qg, mode, weightp = [int(v) for v in g("geo")]
+        assert d == depth
+        out.append(dict(y=g("y"), stride=stride, org=my * stride + mx, cb=g("cb"), cr=g("cr"), stride_c=cstride, org_c=cmy * cstride + cmx, width=w, height=h, qg=qg, mode=mode,
+                        strength=float(g("strength")[0]), weightp=bool(weightp), grid=tuple(int(v) for v in g("grid")),
+                        qp_aq_offset=g("qp_aq_offset"), qp_cutree_offset=g("qp_cutree_offset"), inv_qscale=g("inv_qscale"),
+                        inv_qscale_8x8=z[f"s{i}_inv_qscale_8x8"] if f"s{i}_inv_qscale_8x8" in z.files else None, wp_sum=g("wp_sum"), wp_ssd=g("wp_ssd")))
+    return out

@@ -73,5 +73,38 @@ def main():
               [(int(r["geo"][11]), r["ref0_expected"].reshape(3, 4)[:, 0].tolist(), r["ref0_mvs"].size > 0) for r in kept])
 
 
+def main_aq():
+    """tests/golden/aq_frame_d{8,10}.npz the same way: the source picture x265's calcAdaptiveQuantFrame (slicetype.cpp:444) was handed and the Lowres arrays IT filled
+    (X265REF_AQ_DUMP in the AQ seam), for AQ modes 1 - 3 and both quantisation-group sizes."""
+    from tools import encoder_bench as EB, seam_driver as SD
+    F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+    w, h, n = 160, 128, 2
+    for depth in (8, 10):
+        kept = []
+        for extra in ([("aq-mode", "1")], [("aq-mode", "2")], [("aq-mode", "3"), ("aq-strength", "1.4")], [("aq-mode", "2"), ("qg-size", "8")], [("aq-mode", "2"), ("no-weightp", None)]):
+            with tempfile.TemporaryDirectory() as d:
+                os.environ["X265REF_AQ_DUMP"] = d
+                clip = F.synth_clip(w, h, n, depth=depth, seed=43)
+                yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
+                opts = [("pools", "1"), ("frame-threads", "1"), ("crf", "24")] + extra
+                lib, filler, report, close, prov = SD.install(depth, w, h, provider="oracle", rng=4, slots=8, min_pu=128, verify=True, streamed=True, min_level=1, aq="oracle")
+                try:
+                    EB.encode(lib, yuv, w, h, n, "medium", opts, filler)
+                    rep = report()
+                finally:
+                    close()
+                    os.environ.pop("X265REF_AQ_DUMP", None)
+                assert rep["aq_seam"]["verify_mismatches"] == 0 and rep["aq_seam"]["pictures_served"] == n, rep["aq_seam"]
+                kept.append(read_dump(sorted(glob.glob(os.path.join(d, "aq_*.bin")))[0]))
+        arrays = {"count": np.array([len(kept)], np.int32)}
+        for i, r in enumerate(kept):
+            for k, v in r.items():
+                arrays[f"s{i}_{k}"] = v.view(np.float64) if k in ("strength", "qp_aq_offset", "qp_cutree_offset") else v
+        path = os.path.join(ROOT, "tests", "golden", f"aq_frame_d{depth}.npz")
+        np.savez_compressed(path, **arrays)
+        print(path, len(kept), "pictures", os.path.getsize(path), "bytes;", [(int(r["geo"][9]), int(r["geo"][10]), int(r["geo"][11])) for r in kept])
+
+
 if __name__ == "__main__":
     main()
+    main_aq()
