@@ -28,7 +28,8 @@ for step in "$@"; do
     echo "=== [$n] $step"
     case $kind in
     tests)
-        ( time timeout 1700 python -m pytest tests -m gpu -q --durations=6 $arg ) > "$OUT/pytest_$n.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest_$n.log"
+        case "$arg" in *tests/*) where="" ;; *) where="tests" ;; esac          # explicit test files replace the whole-suite default (use -k:<one_word> for filters: ':' splits arguments)
+        ( time timeout 1700 python -m pytest $where -m gpu -q --durations=6 $arg ) > "$OUT/pytest_$n.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest_$n.log"
         grep -E "^(FAILED|ERROR)|passed|failed|^real" "$OUT/pytest_$n.log" | tail -30 ;;
     smoke)
         timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > "$OUT/smoke.log" 2>&1; tail -1 "$OUT/smoke.log" ;;
