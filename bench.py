@@ -643,7 +643,7 @@ def main():
                                    + ("; one GPU: the decoded picture ping-pongs - the planes a step wrote are the next step's reference, no copy"
                                       if world == 1 and args.ref_handoff == "swap" and not banded else "") +
                                    f"); pipeline throughput (tier T2), not HEVC encoded fps - the real "
-                                   f"encoder's fps (tier T3) is the `encoder` object of this line / profiles/r03_encoder_*.txt",
+                                   f"encoder's fps (tier T3) is the `encoder` object of this line / profiles/r04_encoder_legs.txt",
                        "frames_per_step_per_gpu": 1, "parallelism": ((f"segment-parallel x{world}: every rank encodes its own closed group of pictures, no exchange (--sharding gop)" if gop
                                         else f"frame-parallel x{world}") if not banded else
                                        f"frame-parallel ring x{world}: frame f on rank f % {world} searches frame f - 1, handed on in bands of {args.band_rows} CTU rows "
