@@ -46,7 +46,8 @@ def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify
 # ---- round 4: the adaptive-quantisation pass of the pre-lookahead behind one provider call --------------------------------------------
 @pytest.mark.reference
 @pytest.mark.parametrize("depth,w,h,extra,served", [(8, 256, 192, [], True), (8, 256, 192, [("aq-mode", "1")], True), (8, 256, 192, [("aq-mode", "3"), ("aq-strength", "1.4")], True),
-                                                    (8, 256, 192, [("qg-size", "8"), ("ctu", "64")], True), (10, 192, 128, [("aq-mode", "3")], True),
+                                                    (8, 256, 192, [("qg-size", "8"), ("ctu", "64")], True), (10, 192, 128, [("aq-mode", "3")], True), (12, 192, 128, [("aq-mode", "1")], True),
+                                                    (12, 128, 128, [("qg-size", "8")], True),
                                                     (8, 200, 136, [("qg-size", "8")], None), (8, 256, 192, [("no-weightp", None), ("no-weightb", None)], True),
                                                     (8, 256, 192, [("aq-mode", "4")], False), (8, 256, 192, [("hevc-aq", None)], False), (8, 256, 192, [("aq-mode", "0")], False)])
 def test_aq_seam_serves_the_same_offsets_as_the_reference_loop(depth, w, h, extra, served):
@@ -221,7 +222,8 @@ def run_fade_pair(depth, w, h, nframes, preset, opts, provider, rng, fade=(1.0, 
 @pytest.mark.reference
 @pytest.mark.parametrize("depth,preset,fade,extra,expect_weights", [(8, "slow", (1.0, 0.35), [("bframes", "0")], True), (8, "medium", (1.0, 0.35), [("weightb", None)], True),
                                                                     (8, "medium", (0.4, 1.0), [("weightb", None), ("bframes", "3")], True), (10, "medium", (1.0, 0.35), [], True),
-                                                                    (8, "medium", (1.0, 1.0), [("weightb", None)], False), (8, "slow", (1.0, 0.1), [("bframes", "1"), ("weightb", None)], True)])
+                                                                    (8, "medium", (1.0, 1.0), [("weightb", None)], False), (8, "slow", (1.0, 0.1), [("bframes", "1"), ("weightb", None)], True),
+                                                                    (12, "medium", (1.0, 0.35), [("weightb", None)], True), (12, "medium", (0.5, 1.0), [("bframes", "0")], True)])
 def test_weight_analyse_seam_chooses_the_weights_the_reference_loop_chooses(depth, preset, fade, extra, expect_weights):
     """weightAnalyse through ref_seam's replacement on fading clips (and one of constant brightness: the early exits): the provider (here the
     CPU restatement, oracle/x265_oracle_pipeline7.c) returns the weight table; verify on, the reference's own weightAnalyse then runs on the same
