@@ -1694,6 +1694,15 @@ int x265ref_split_fill_table(void* table, size_t bytes, int depth)
     return n;
 }
 
+/* the control under tools/encoder_profile.py: counting thunks first, the split on top (its single SADs are then counted in the `sad` family) */
+int x265ref_split_fill_table_profiled(void* table, size_t bytes, int depth)
+{
+    const int a = x265ref_profile_fill_table(table, bytes, depth);
+    if (a < 0) return a;
+    const int b = x265ref_split_fill_table(table, bytes, depth);
+    return b < 0 ? b : a + b;
+}
+
 /* table filler with the x265hip_setup_primitives signature: installs the lookup stubs over the host's own sad family */
 int x265ref_seam_fill_table(void* table, size_t bytes, int depth)
 {

@@ -31,6 +31,11 @@ def main():
     ap.add_argument("--no-lookahead-seam", action="store_true")
     ap.add_argument("--seam-layout", default="records", choices=["records", "planes"])
     ap.add_argument("--seam-centre-range", type=int, default=0)
+    ap.add_argument("--control", action="store_true", help="profile the HOST-ONLY control instead of the C table: sad_x3 / sad_x4 split into single SADs (x265ref_split_fill_table), no GPU")
+    ap.add_argument("--seam-split-rest", action="store_true", help="with --seams: whatever the services do not answer takes the control's split SADs (bench.py's seam legs)")
+    ap.add_argument("--seam-no-sad", action="store_true", help="with --seams: no SAD lookup stubs (sub-sample / lookahead / AQ / weightAnalyse services only)")
+    ap.add_argument("--seam-aq", action="store_true")
+    ap.add_argument("--seam-weight-analyse", action="store_true")
     ap.add_argument("--provider", default="gpu", choices=["gpu", "oracle"], help="oracle = the CPU checker providers (plumbing test of this tool without a GPU)")
     a = ap.parse_args()
     F = importlib.import_module("x265-yuuki-asuna_amd.frames")
@@ -43,14 +48,20 @@ def main():
     opts = [("pools", str(cores)), ("frame-threads", str(a.frame_threads)), ("crf", "28")] + cfg["opts"]
     filler = ctypes.cast(lib.x265ref_profile_fill_table, ctypes.c_void_p)
     note = closer = None
+    if a.control and not a.seams:
+        from tools import seam_driver as SD
+        lib = SD.seam_lib(depth)
+        lib.x265ref_seam_disable()
+        filler = ctypes.cast(lib.x265ref_split_fill_table_profiled, ctypes.c_void_p)
     if a.seams:
         from tools import seam_driver as SD
         if not a.no_lookahead_seam:
             opts.append(("lookahead-slices", "1"))
-        lib, _, note, closer, _ = SD.install(depth, w, h, provider=a.provider, rng=a.seam_range, slots=24 if depth == 8 else 40, min_pu=a.seam_min_pu, verify=False,
+        lib, _, note, closer, _ = SD.install(depth, w, h, provider=a.provider, rng=a.seam_range, slots=24 if depth == 8 else 40, min_pu=128 if a.seam_no_sad else a.seam_min_pu, verify=False,
                                              lookahead=None if a.no_lookahead_seam else a.provider, subpel=a.provider, subpel_slots=12, streamed=True,
                                              min_level=a.seam_min_level, pictures=24, layout=1 if a.seam_layout == "planes" else 0, centre_range=a.seam_centre_range,
-                                             lookahead_min_blocks=None, min_ctus=None)
+                                             lookahead_min_blocks=None, min_ctus=None, split_rest=a.seam_split_rest, aq=a.provider if a.seam_aq else None, aq_min_blocks=None,
+                                             weight_analyse=a.provider if a.seam_weight_analyse else None, weight_min_blocks=None)
         filler = ctypes.cast(lib.x265ref_seam_fill_table_profiled, ctypes.c_void_p)
     lib.x265ref_profile_tsc.restype = ctypes.c_uint64
     t0, c0, tsc0 = time.perf_counter(), time.process_time(), lib.x265ref_profile_tsc()
