@@ -394,7 +394,7 @@ def test_every_built_seam_library_exports_what_the_driver_binds():
         pytest.skip("oracle/_ref not built (needs /root/reference)")
     need = ["x265ref_seam_configure", "x265ref_seam_configure_streamed", "x265ref_subpel_seam_configure_streamed", "x265ref_lookahead_seam_configure",
             "x265ref_aq_seam_configure", "x265ref_aq_seam_stats", "x265ref_weight_seam_configure", "x265ref_weight_seam_stats", "x265ref_seam_fill_table",
-            "x265ref_seam_min_ctus", "x265ref_split_fill_table", "x265ref_lookahead_seam_min_blocks", "x265ref_seam_weighted_stats", "x265ref_seam_disable", "x265ref_encode"]
+            "x265ref_seam_min_ctus", "x265ref_split_fill_table", "x265ref_split_fill_table_profiled", "x265ref_lookahead_seam_min_blocks", "x265ref_seam_weighted_stats", "x265ref_seam_disable", "x265ref_encode"]
     for path in libs:
         L = ctypes.CDLL(path)
         missing = [n for n in need if not hasattr(L, n)]
