@@ -24,6 +24,13 @@
  * finished reconstructed row, reference.cpp:119-178, frameencoder.cpp:865-866) are served by the row-granular providers too (round 4):
  * the weighted plane is the reconstructed plane weighted sample by sample, margins included, so the provider gets the weight_pp
  * arguments with the pair / view and weights the rows it already holds on the device; the picture-granular providers still step aside.
+ * WHOLE FUNCTIONS (end of round 4): LookaheadTLD::calcAdaptiveQuantFrame and the frame encoder's weightAnalyse are defined here too (the reference's
+ * bodies answer to x265ref_orig_*), each one provider call (x265hip_aq_frame_host / x265hip_weight_analyse_host or the oracle's restatements) whose
+ * results - with verify - are compared with what the reference's own function then computes for the same picture / slice; X265REF_AQ_DUMP /
+ * X265REF_WA_DUMP write the inputs and the reference's answers for tools/gen_weight_golden.py.
+ * HOST-ONLY CONTROL: x265ref_split_fill_table = the C table with sad_x3 / sad_x4 answered by N single SADs (what the lookup stubs do on a miss): g++
+ * vectorises the reference's single-reference SAD loop and not the multi-reference ones, so this alone is faster than the C table, and encoder legs
+ * must be compared with it to see what the services contribute.
  *
  * The provider is a table of C function pointers with the signatures of x265hip_me_cache_submit / _surface / _ready
  * (include/x265hip.h), so the GPU library plugs in directly; the CPU-only tests plug in the oracle's exhaustive search instead. */
