@@ -213,7 +213,8 @@ def cpu_baseline(F, clip, rng_r, subme, level, qp, depth=8, target_s=15.0, dev_o
     t1, _ = run(n1, 1)
     base = {"value": round(reps * (n / nctu) / t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "one_thread_value": round((n1 / nctu) / t1, 5),
-            "sample": f"{reps} x {n} of {nctu} CTUs of the same {clip[0][0].shape[1]}x{clip[0][0].shape[0]} frame through the same stages (search keeps only the best mv), "
+            "sample": f"{reps} x {n} of {nctu} CTUs of one {clip[0][0].shape[1]}x{clip[0][0].shape[0]} frame, same stages, oracle C + OpenMP on {cores} threads, {t:.1f} s",
+            "sample_detail": f"{reps} x {n} of {nctu} CTUs of the same {clip[0][0].shape[1]}x{clip[0][0].shape[0]} frame through the same stages (search keeps only the best mv), "
                       f"oracle C ({'-march=x86-64-v3' if avx2 else 'generic x86-64'}) with OpenMP over CTUs on {cores} threads "
                       f"(the container's CPU quota; {os.cpu_count()} hardware threads visible), {t:.1f} s; an EXHAUSTIVE +-{rng_r} search on the CPU is "
                       f"not what x265 runs at preset slow - the real reference encoder is timed by `bench.py --encoder` (profiles/)"}
@@ -321,6 +322,158 @@ def pick_band_rows(world, ctu_rows=34, lag_rows_luma=73, depth=8, width=3840):
     return best[1]
 
 
+MAX_LINE_BYTES = 4096      # the driver keeps a bounded tail of stdout: the one JSON line stays far below it (round-4 verdict: a 37 KB line was never parsed)
+
+# encoder-level legs (tier T3): configuration -> (frames, --frame-threads).  48 frames at cfg3 = more than preset slow's 25-picture lookahead, so the
+# lookahead runs ahead of the frame encoders the way it does in a real encode; cfg5 (8K veryslow) is 3 frames - about a minute per leg on 16 cores
+ENC_DEFAULTS = {"cfg3": (48, 5), "cfg3f": (24, 5), "cfg4": (24, 5), "cfg2": (96, 3), "cfg1": (8, 1), "cfg5": (3, 5)}
+
+
+def seam_config(key):
+    """How the encoder legs configure the consumer services for BASELINE configuration `key` - chosen by what was MEASURED
+    (profiles/r05_seam_matrix.txt), not by how many lookups get served: row-granular SAD planes of +-12 centred on each CTU's own
+    displacement (found within +-57 = the reference's merange), the 32x32-and-up levels only at 8 bits (`min_level` 2: the same fps as
+    level 1 at 40 % of the download), sub-sample comparisons, lookahead frame costs, AQ and weightAnalyse from the device;
+    everything the services do not answer takes the host-only control's split SADs."""
+    depth = CFG_DEPTH.get(key, 8)
+    return {"range": 12, "centre_range": 57, "layout": 1, "slots": 24 if depth == 8 else 40, "min_pu": 16, "verify": False, "lookahead": True,
+            "subpel": True, "subpel_slots": 12, "streamed": True, "min_level": int(os.environ.get("X265HIP_SEAM_MIN_LEVEL", "2" if depth == 8 else "1")),
+            "pictures": 24, "aq": True, "weight_analyse": True, "split_rest": True}
+
+
+def encoder_plan(args):
+    """The legs of the encoder-level measurement: every configuration of --encoder with the plain reference build, then the metric's
+    configuration and the 10-bit one again on the AVX2 auto-vectorised build ("vs host AVX2": the hand-written NASM kernels cannot be
+    assembled here - no nasm - so g++ -O3 -march=x86-64-v3 of the reference's C path is the closest thing that can be timed)."""
+    keys = [k for k in args.encoder.split(",") if k]
+    plan = []
+    for key in keys:
+        nf, ft = ENC_DEFAULTS.get(key, (24, 5))
+        plan.append({"name": key, "key": key, "tables": args.encoder_tables.split(","), "frames": args.encoder_frames or nf,
+                     "frame_threads": args.encoder_frame_threads or ft, "seam": seam_config(key), "build": ""})
+    for key in [k for k in ("cfg3", "cfg4") if k in keys]:
+        nf, ft = ENC_DEFAULTS[key]
+        plan.append({"name": key + "_v3", "key": key, "tables": args.encoder_tables.split(","), "frames": args.encoder_frames or nf,
+                     "frame_threads": args.encoder_frame_threads or ft, "seam": seam_config(key), "build": "v3"})
+    return plan
+
+
+def encoder_leg(args, timeout_s=None):
+    """Tier T3: the real reference encoder on the host cores - its C table, the host-only control, the seams - in a
+    CHILD process (tools/encoder_bench.py --plan): a crash or a hang of a leg costs that leg, never the headline of this line.  The child
+    writes its result file after every leg; whatever is there when it ends (or is stopped) is reported.  Returns {"encoder": ..,
+    "encoder_summary": ..}."""
+    import subprocess
+    import tempfile
+    timeout_s = timeout_s or float(os.environ.get("X265HIP_ENCODER_TIMEOUT_S", "1200"))
+    fd, path = tempfile.mkstemp(prefix="x265hip_encoder_", suffix=".json")
+    os.close(fd)
+    enc, err = {}, None
+    try:
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "encoder_bench.py"), "--plan", json.dumps(encoder_plan(args)), "--out", path]
+        try:
+            rc = subprocess.run(cmd, stdout=sys.stderr, stderr=sys.stderr, timeout=timeout_s, cwd=ROOT).returncode
+            if rc != 0:
+                err = f"encoder legs exited with status {rc}"
+        except subprocess.TimeoutExpired:
+            err = f"encoder legs stopped after {timeout_s:.0f} s"
+        try:
+            enc = json.load(open(path)).get("encoder", {})
+        except (OSError, ValueError):
+            pass
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    if err:
+        enc["error"] = err
+    return {"encoder": enc, "encoder_summary": encoder_summary(enc)}
+
+
+def encoder_leg_numbers(c):
+    """One leg (tools/encoder_bench.run_config result) as numbers only."""
+    if not isinstance(c, dict) or "c" not in c:
+        return None
+    sm, cs = c.get("seam", {}), c.get("csplit", {})
+    rep = sm.get("seam", {})
+    r = {"frames": c["c"]["frames"], "F": int(c["options"]["frame-threads"]), "cores": c["pool_threads"], "c_fps": c["c"]["fps"],
+         "control_fps": cs.get("fps"), "seam_fps": sm.get("fps"), "md5_equal": sm.get("md5_equal_to_c_table"),
+         "x_c": round(sm["fps"] / c["c"]["fps"], 3) if sm.get("fps") else None,
+         "x_control": round(sm["fps"] / cs["fps"], 3) if sm.get("fps") and cs.get("fps") else None,
+         "hit_rate": rep.get("lookup_hit_rate"),
+         "gb_down": round(((rep.get("bytes_downloaded") or 0) + (rep.get("subpel_seam", {}).get("bytes_downloaded") or 0)) / 1e9, 2) if rep else None}
+    sat = rep.get("subpel_seam", {}).get("satd_lookups_served")
+    if sat is not None:
+        r["satd_served"] = sat
+    return r
+
+
+def encoder_summary(enc):
+    """Numbers only (the per-leg diagnostics stay in bench_detail.json): per configuration the reference's C table, the host-only control
+    (C table with split sad_x3 / sad_x4, no GPU) and the seams, frames/s; md5 equality of the bitstreams; hit rate; GB downloaded."""
+    legs = {k: encoder_leg_numbers(v) for k, v in enc.items() if k != "error"}
+    s = {"kind": "reference x265 3.5, C primitives (no nasm in the image); *_v3 = g++ -march=x86-64-v3", **{k: v for k, v in legs.items() if v}}
+    if "error" in enc:
+        s["error"] = str(enc["error"])[:160]
+    return s
+
+
+def write_detail(out, args):
+    """Everything the one-line record leaves out - per-leg encoder diagnostics, the stage-by-stage comparison, per-kernel rooflines,
+    checksums, prose - as a file (bench_detail.json beside bench.py and, on a GPU visit, under gpurun_out/) and on stderr."""
+    text = json.dumps(out, indent=1, sort_keys=False)
+    paths = [os.environ.get("X265HIP_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                f.write(text + "\n")
+        except OSError:
+            pass
+    sys.stderr.write("bench.py detail (also in %s):\n%s\n" % (paths[0], json.dumps(out)))
+    sys.stderr.flush()
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(out, minimal=False):
+    """The ONE line rank 0 prints: the contract's fields plus `roofline`, `cpu_baseline`, `bit_exact` and the encoder summary, numbers
+    and short labels only - below MAX_LINE_BYTES by construction (tests/test_bench_line.py).  `minimal` drops the optional objects."""
+    cfg = out.get("config", {})
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    c = {"workload": str(cfg.get("workload", ""))[:200], "parallelism": str(cfg.get("parallelism", ""))[:120]}
+    c.update(_pick(cfg, ("ctus_per_frame", "band_rows", "sharding")))
+    if "ring" in cfg:
+        c["ring"] = _pick(cfg["ring"], ("ranks_seen", "transport", "communicators", "bands_per_frame", "refs", "band_wait_ms_per_frame_max_over_ranks", "comm_init_s"))
+    line["config"] = c
+    if "replicas" in out:
+        line["replicas"] = _pick(out["replicas"], ("value", "ms_per_step", "unit"))
+    r = out.get("roofline") or {}
+    rl = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "launch_ms"))
+    if isinstance(r.get("valu"), dict):
+        rl["valu"] = _pick(r["valu"], ("floor_ms", "frac"))
+    line["roofline"] = rl
+    if "cpu_baseline" in out:
+        cb = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "one_thread_value"))
+        cb["sample"] = str(out["cpu_baseline"].get("sample", ""))[:160]
+        line["cpu_baseline"] = cb
+    if "bit_exact" in out:
+        line["bit_exact"] = out["bit_exact"]
+        if isinstance(out.get("bit_exact_detail"), dict):
+            line["bit_exact_values"] = out["bit_exact_detail"].get("values_compared")
+    if not minimal:
+        if isinstance(out.get("stages_ms"), dict):
+            line["stages_ms"] = {k[:24]: v for k, v in list(out["stages_ms"].items())[:16]}
+        if "encoder_summary" in out:
+            line["encoder_summary"] = out["encoder_summary"]
+        line["detail"] = "bench_detail.json"
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -370,6 +523,7 @@ def main():
     ap.add_argument("--band-graphs", type=int, default=0, help="banded pipeline: replay each band's launches as one HIP graph (0: launch by launch)")
     ap.add_argument("--banded", action="store_true", help="run the banded pipeline on one GPU too (measures what the band granularity costs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-replicas", action="store_true", help="N > 1, ring: skip the second timed pass without exchange (`replicas` of the line)")
     ap.add_argument("--no-verify", action="store_true", help="skip the bit-exact comparison of one whole frame with the oracle chain")
     ap.add_argument("--sao-decision", default="rdo", choices=["rdo", "standin"],
                     help="rdo (default): the reference's own rate-distortion decision of the SAO parameters on the device (x265hip_sao_rdo = "
@@ -382,8 +536,8 @@ def main():
                     help="skip the encoder-level leg (tier T3): the REAL reference encoder (oracle/_ref) on BASELINE configs[2] - 4K, preset slow, "
                          "--me star - with its own C table and with the stage-level seams (integer-search SADs from x265hip_me_cache surfaces, the "
                          "lookahead's frame cost / intra estimates from x265hip_lowres_cost_host / x265hip_lowres_intra_host); fps + bitstream md5")
-    ap.add_argument("--encoder", default="cfg3,cfg3f,cfg4,cfg2", help="configurations of the encoder-level leg (tools/encoder_bench.py: cfg1,cfg2,cfg3,cfg3f,cfg4); the "
-                    "default shows BASELINE configs[2] (the metric's), the same on a fade (weighted references), configs[3] (10-bit) and configs[1] (1080p)")
+    ap.add_argument("--encoder", default="cfg3,cfg3f,cfg4,cfg5,cfg2", help="configurations of the encoder-level leg (tools/encoder_bench.py: cfg1,cfg2,cfg3,cfg3f,cfg4,cfg5); the "
+                    "default shows BASELINE configs[2] (the metric's), the same on a fade (weighted references), configs[3] (4K 10-bit), configs[4] (8K 10-bit, 3 frames) and configs[1] (1080p)")
     ap.add_argument("--encoder-frames", type=int, default=0, help="frames of every encoder-level leg (0 = per configuration: 48 for cfg3 - more than the "
                     "25-picture lookahead of preset slow, so that the lookahead runs ahead of the frame encoders the way it does in a real encode - 24 for cfg3f / cfg4, 96 for cfg2)")
     ap.add_argument("--encoder-frame-threads", type=int, default=0, help="--frame-threads of the encoder legs (0 = what x265 picks itself for 16 cores at that "
@@ -477,8 +631,10 @@ def main():
         # operations instead (also the fallback when the C-ABI communicators cannot be built - decided collectively, never by one rank alone).
         transport_name = "dist"
         transport = None
+        comm_init_s = None
         if world > 1 and backend == "nccl" and os.environ.get("X265HIP_RING_TRANSPORT", "abi") == "abi":
             ok = 1
+            t_comm = time.perf_counter()
             try:
                 transport = P.AbiTransport(rank, world, dev, args.depth, geom, pics[0].h64)
                 transport.setup(dev)
@@ -487,6 +643,7 @@ def main():
                 ok = 0
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            comm_init_s = time.perf_counter() - t_comm       # unique ids + ncclCommInitRank of every directed flow (+ the agreement all-reduce)
             if int(flag.item()):
                 transport_name = "abi"
             else:
@@ -562,6 +719,35 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    replicas = None
+    if world > 1 and not gop and not args.no_replicas:
+        # the comparison line beside the ring (round-4 verdict, next 6): the same K steps with NO exchange - every rank its own closed
+        # group of pictures (what --sharding gop times) - so the first hardware record shows ring and replicas side by side
+        rp = [p.clone() for p in ref_pic.planes()]
+        rpic = pics[0].like(rp)
+
+        def rstep(i):
+            pipe.run(pics[1 + i % (nclip - 1)], rpic)
+            new = pipe.swap_output(rpic.planes())
+            if new is not None:
+                rpic.t, rpic.c = new[0], (list(new[1:3]) if len(new) >= 3 else None)
+        for i in range(min(args.warmup, 3)):
+            rstep(i)
+        pipe.launch_lookahead_costs()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tr = time.perf_counter()
+        for i in range(args.steps):
+            rstep(i)
+        pipe.launch_lookahead_costs()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        rt = torch.tensor([time.perf_counter() - tr], dtype=torch.float64, device=dev)
+        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+        replicas = {"value": round(world * args.steps / float(rt.item()), 3), "unit": "frames/s", "ms_per_step": round(1000.0 * float(rt.item()) / args.steps, 4),
+                    "what": "--sharding gop: every rank its own closed group of pictures, no exchange - the upper bound the ring is compared with"}
     gc.enable()
     ring_wait = None
     if banded and world > 1:                         # every rank: the maximum over ranks is a collective
@@ -632,7 +818,10 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8" if args.depth == 8 else "u16", "data": "synthetic",
-            "config": {"workload": f"{args.width}x{args.height} {args.depth}-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: lookahead lowres planes + intra estimate (+ P-frame cost estimate vs the previous picture, " + (f"{args.lookahead_batch} pictures per launch on a side stream" if args.lookahead_batch else "off") + ") -> " +
+            "config": {"workload": (f"{args.width}x{args.height} {args.depth}-bit closed-loop frame pipeline (tier T2): lookahead -> "
+                                    + (f"exhaustive +-{args.range} ME, 85 PUs/CTU -> subme {args.subme}" if args.search == "full" else f"{args.search} search, merange {args.range}, subme {args.subme}")
+                                    + f" -> MC + DCT/quant/recon qp {args.qp} -> deblock -> SAO ({'rdo' if sao_rdo else 'stand-in'}) -> border -> next reference"),
+                       "workload_detail": f"{args.width}x{args.height} {args.depth}-bit ({'BASELINE configs[2]: 4K, preset slow search depth' if args.width == 3840 else 'BASELINE configs[1] picture size' if args.width == 1920 else 'custom size'}) closed-loop frame pipeline: lookahead lowres planes + intra estimate (+ P-frame cost estimate vs the previous picture, " + (f"{args.lookahead_batch} pictures per launch on a side stream" if args.lookahead_batch else "off") + ") -> " +
                                    (f"ME exhaustive +-{args.range} for all 85 PUs/CTU ({('SAD surfaces (' + (('packed, in blocks of 64' if ms.blocked else ('packed chunk-major' if ms.tiled else 'packed')) if ms.packed else 'i32') + ' records) + ') if surf_mode else ''}best mv) -> "
                                     f"sub-pel subme={args.subme} -> " if args.search == "full" else
                                     f"{args.search} search driver (motionEstimate, merange {args.range}, subme {args.subme}, predictor 0) for all 85 PUs/CTU -> ") +
@@ -643,13 +832,17 @@ def main():
                                    + ("; one GPU: the decoded picture ping-pongs - the planes a step wrote are the next step's reference, no copy"
                                       if world == 1 and args.ref_handoff == "swap" and not banded else "") +
                                    f"); pipeline throughput (tier T2), not HEVC encoded fps - the real "
-                                   f"encoder's fps (tier T3) is the `encoder` object of this line / profiles/r04_encoder_legs.txt",
-                       "frames_per_step_per_gpu": 1, "parallelism": ((f"segment-parallel x{world}: every rank encodes its own closed group of pictures, no exchange (--sharding gop)" if gop
+                                   f"encoder's fps (tier T3) is the `encoder_summary` object of this line / bench_detail.json",
+                       "frames_per_step_per_gpu": 1,
+                       "parallelism": ("none (1 GPU)" if world == 1 and not banded else f"gop x{world}: replicas, no exchange" if gop else
+                                       f"frame-parallel ring x{world}, bands of {args.band_rows} CTU rows, transport {transport_name if world > 1 else 'none'}"),
+                       "parallelism_detail": ((f"segment-parallel x{world}: every rank encodes its own closed group of pictures, no exchange (--sharding gop)" if gop
                                         else f"frame-parallel x{world}") if not banded else
                                        f"frame-parallel ring x{world}: frame f on rank f % {world} searches frame f - 1, handed on in bands of {args.band_rows} CTU rows "
                                        f"(each band a slice of its own, like the reference's --slices); band transfers: "
                                        + ("x265hip_recon_publish_rows (the library's C ABI on RCCL, one 2-rank communicator per directed flow)" if transport_name == "abi"
                                           else "torch.distributed point-to-point")),
+                       "sharding": ("gop" if gop else "ring") if world > 1 else "none",
                        "ctus_per_frame": ms.nctu, "checksum": csum,
                        **({"band_rows": args.band_rows, "band_streams": args.band_streams,
                            "ring_model": "N pictures per max(step, N x lag), lag = the band periods until the reference rows a band's search window "
@@ -676,9 +869,12 @@ def main():
         if ring_wait is not None:
             out["config"]["ring"] = {"ranks_seen": ranks_seen, "transport": transport_name, "bands_per_frame": len(bp.bands), "refs": 1,
                                      "communicators": world if transport_name == "abi" else 0,
+                                     "comm_init_s": round(comm_init_s, 3) if comm_init_s is not None else None,
                                      "band_wait_ms_per_frame_max_over_ranks": ring_wait,
                                      "note": "band_wait = device time the bands' streams spent waiting for the reference rows they read (two events per band); "
                                              "ranks_seen = all-reduce of ones over the job's process group"}
+        if replicas is not None:
+            out["replicas"] = replicas
         sr = load_stage_traffic(args.width, args.height, args.depth)
         if sr:
             out["stages_roofline"] = sr
@@ -695,88 +891,14 @@ def main():
                 out["bit_exact"] = bit_exact["ok"]
                 out["bit_exact_detail"] = bit_exact
         if world == 1 and not args.no_encoder and not args.no_cpu_baseline:
-            # tier T3: the real reference encoder on the host cores, C table vs the seam; test infrastructure drives it,
-            # the timed product part is x265hip_me_cache.  Never fatal for the bench line.
-            try:
-                sys.path.insert(0, ROOT)
-                from tools import encoder_bench as EB
-                enc = {}
-                ENC_DEFAULTS = {"cfg3": (48, 5), "cfg3f": (24, 5), "cfg4": (24, 5), "cfg2": (96, 3), "cfg1": (8, 1), "cfg5": (3, 5)}       # frames, --frame-threads
-                for key in args.encoder.split(","):
-                    nf, ft = ENC_DEFAULTS.get(key, (24, 5))
-                    nf, ft = args.encoder_frames or nf, args.encoder_frame_threads or ft
-                    # round 3: the row-granular providers (x265hip_me_stream / x265hip_phase_stream, fed where the reference raises m_reconRowFlag) serve
-                    # the SAD lookups and the sub-sample comparisons under the reference's own frame threads.  Round 4: PU-major planes, windows of
-                    # +-12 centred on each CTU's own displacement (found within +-57 = the reference's merange), weighted references served, the
-                    # lookahead seam gated by picture size inside the binding (4K and up)
-                    enc[key] = EB.run_config(key, args.encoder_tables.split(","), nf, ft, 120.0, log=sys.stderr,
-                                             seam={"range": 12, "centre_range": 57, "layout": 1, "slots": 24 if CFG_DEPTH.get(key, 8) == 8 else 40, "min_pu": 16, "verify": False,
-                                                   "lookahead": True, "subpel": True, "subpel_slots": 12, "streamed": True, "min_level": 1, "pictures": 24,
-                                                   # calcAdaptiveQuantFrame / weightAnalyse from x265hip_aq_frame_host / x265hip_weight_analyse_host (gated to 4K and up by
-                                                   # the binding): +5 % on the fade, neutral at constant brightness (profiles/r04_encoder_legs.txt)
-                                                   "aq": True, "weight_analyse": True,
-                                                   # everything the services do not answer takes the host-only control's split SADs, so that seam_fps against
-                                                   # host_only_split_sad_control_fps is the services' contribution alone
-                                                   "split_rest": True})
-                # "vs host AVX2" (BASELINE metric): the hand-written NASM AVX2 / AVX-512 kernels cannot be assembled here (no nasm); the closest
-                # buildable thing is the reference's own C path with AVX2 code generation (g++ -O3 -march=x86-64-v3, oracle/Makefile refv3: the
-                # SAD loops become vpsadbw) - timed beside the plain build for the metric's configuration and the 10-bit one, same seams on top
-                SEAM = {"range": 12, "centre_range": 57, "layout": 1, "min_pu": 16, "verify": False, "lookahead": True, "subpel": True, "subpel_slots": 12, "streamed": True,
-                        "min_level": 1, "pictures": 24, "aq": True, "weight_analyse": True, "split_rest": True}
-                for key in [k for k in ("cfg3", "cfg4") if k in enc]:
-                    nf, ft = ENC_DEFAULTS[key]
-                    nf, ft = args.encoder_frames or nf, args.encoder_frame_threads or ft
-                    try:
-                        enc[key + "_v3"] = EB.run_config(key, args.encoder_tables.split(","), nf, ft, 120.0, log=sys.stderr, build="v3",
-                                                         seam={**SEAM, "slots": 24 if CFG_DEPTH.get(key, 8) == 8 else 40})
-                    except BaseException as e:       # a missing libx265ref<depth>v3.so: the plain legs above stand
-                        enc[key + "_v3"] = {"error": repr(e)}
-                out["encoder"] = enc
-
-                def leg(key):
-                    c = enc.get(key, {})
-                    if "c" not in c:
-                        return None
-                    sm = c.get("seam", {})
-                    rep = sm.get("seam", {})
-                    return {"workload": c["config"], "frames": c["c"]["frames"], "frame_threads": int(c["options"]["frame-threads"]), "cores": c["pool_threads"],
-                            "reference_c_table_fps": c["c"]["fps"], "seam_fps": sm.get("fps"), "seam_md5_equal": sm.get("md5_equal_to_c_table"),
-                            "gain": round(sm["fps"] / c["c"]["fps"], 3) if sm.get("fps") else None,
-                            # how much of that is the stubs' HOST path: the C table with sad_x3 / sad_x4 split into single SADs, no GPU involved
-                            "host_only_split_sad_control_fps": c.get("csplit", {}).get("fps"),
-                            "gain_over_host_only_control": round(sm["fps"] / c["csplit"]["fps"], 3) if sm.get("fps") and c.get("csplit", {}).get("fps") else None,
-                            **{k: rep.get(k) for k in ("motion_estimate_calls", "calls_with_lookup_context", "lookups_served", "lookup_hit_rate", "bytes_downloaded")},
-                            "subpel_compares_served": rep.get("subpel_seam", {}).get("subpel_compares_served"),
-                            "phase_bytes_downloaded": rep.get("subpel_seam", {}).get("bytes_downloaded"),
-                            "frame_cost_estimates_served": rep.get("lookahead_seam", {}).get("frame_cost_estimates_served"),
-                            "frame_cost_estimates_left_to_the_reference_by_the_size_gate": rep.get("lookahead_seam", {}).get("left_to_the_reference_by_the_size_gate"),
-                            "weighted_references": rep.get("weighted_references"),
-                            "aq_pictures_served": rep.get("aq_seam", {}).get("pictures_served"),
-                            "weight_analyse_slices_served": rep.get("weight_analyse_seam", {}).get("slices_served"),
-                            "weight_analyse_slices_with_a_weight": rep.get("weight_analyse_seam", {}).get("served_slices_with_a_weight"),
-                            "search_seams_left_off_by_the_size_gate": rep.get("search_seams_left_off_by_the_size_gate")}
-                c3 = leg("cfg3")
-                if c3:
-                    out["encoder_summary"] = {**c3,
-                                              "seams": "row-granular SAD lookups (x265hip_me_stream: PU-major planes, +-12 windows centred on each CTU's displacement) + sub-sample "
-                                                       "comparisons (x265hip_phase_stream views, weighted references included) + lookahead frame costs (x265hip_lowres_cost_host), "
-                                                       "the pre-lookahead's adaptive-quantisation pass (x265hip_aq_frame_host) and the frame encoder's weightAnalyse "
-                                                       "(x265hip_weight_analyse_host) - the last three 4K and up - all under the reference's own frame threads; candidates / partitions the "
-                                                       "services do not answer take the host-only control's split SADs (csplit), so seam_fps against "
-                                                       "host_only_split_sad_control_fps is the services' contribution alone",
-                                              "kind": "reference (x265 3.5 C primitives, no asm: nasm is not in the image)",
-                                              "other_configs": {k: leg(k) for k in enc if k != "cfg3" and not k.endswith("_v3") and leg(k)},
-                                              "host_avx2_autovectorised": {
-                                                  "build": "the reference's C path, g++ -O3 -march=x86-64-v3 -ffp-contract=off (AVX2 auto-vectorised; the hand-written NASM "
-                                                           "AVX2 / AVX-512 kernels need nasm, which the image lacks) - same seams on top, same bitstream as the plain build",
-                                                  **{k[:-3]: {**{f: v for f, v in (leg(k) or {}).items() if f in ("reference_c_table_fps", "seam_fps", "gain", "seam_md5_equal", "frames",
-                                                                                                                  "frame_threads", "host_only_split_sad_control_fps",
-                                                                                                                  "gain_over_host_only_control")},
-                                                              "md5_equal_to_the_plain_build": enc[k].get("c", {}).get("md5") == enc[k[:-3]].get("c", {}).get("md5")}
-                                                     for k in enc if k.endswith("_v3") and "c" in enc[k]}}}
-            except BaseException as e:       # incl. SystemExit from a missing oracle/_ref
-                out["encoder"] = {"error": repr(e)}
-        print(json.dumps(out))
+            write_detail(out, args)              # the headline is on disk before the long encoder legs start
+            out.update(encoder_leg(args))
+        write_detail(out, args)
+        line = json.dumps(compact_line(out), separators=(",", ":"))
+        if len(line) >= MAX_LINE_BYTES:          # never again a line the driver cannot parse (round-4 verdict): drop the optional objects, keep the contract
+            line = json.dumps(compact_line(out, minimal=True), separators=(",", ":"))
+        sys.stdout.flush()
+        print(line, flush=True)
         if bit_exact is not None and not bit_exact["ok"]:
             sys.stderr.write("bench.py: device pipeline differs from the oracle chain: %s\n" % json.dumps(bit_exact["stages"]))
             sys.exit(3)

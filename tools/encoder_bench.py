@@ -197,8 +197,25 @@ def main():
     ap.add_argument("--seam-centre-range", type=int, default=0, help="row-granular SAD provider: centre every CTU's window on its own displacement, found within +-this (0 = off)")
     ap.add_argument("--ref-build", default="", choices=["", "v3"], help="reference build flavour of every leg: '' = g++ -O3, v3 = + -march=x86-64-v3 (AVX2 auto-vectorised C)")
     ap.add_argument("--seam-no-weighted", action="store_true", help="weighted references pass to the host (the round-3 behaviour), for A/B on a fade")
+    ap.add_argument("--plan", default="", help="bench.py's child-process mode: a JSON list of legs {name, key, tables, frames, frame_threads, seam, build}; the other options are ignored")
+    ap.add_argument("--out", default="", help="--plan: write {\"encoder\": {name: result}} to this file after EVERY leg (what is there survives a crash or a timeout of a later leg)")
     ap.add_argument("--seam-subpel-slots", type=int, default=6, help="reference pictures whose phase planes stay in pinned host memory (450 MB each at 4K 8-bit)")
     args = ap.parse_args()
+    if args.plan:
+        out = {}
+        for leg in json.loads(args.plan):
+            try:
+                out[leg["name"]] = run_config(leg["key"], leg["tables"], leg.get("frames") or None, leg.get("frame_threads", 1), args.budget_s, seam=leg.get("seam"),
+                                              build=leg.get("build", ""))
+            except BaseException as e:       # noqa: BLE001 - incl. SystemExit from a missing oracle/_ref build: the other legs stand
+                out[leg["name"]] = {"error": repr(e)}
+            if args.out:
+                with open(args.out + ".tmp", "w") as f:
+                    json.dump({"encoder": out}, f)
+                os.replace(args.out + ".tmp", args.out)
+        if not args.out:
+            print(json.dumps({"encoder": out}))
+        return
     seam = {"range": args.seam_range, "slots": args.seam_slots, "min_pu": args.seam_min_pu, "verify": args.seam_verify, "lookahead": args.seam_lookahead,
             "subpel": args.seam_subpel, "subpel_slots": args.seam_subpel_slots, "streamed": args.seam_streamed, "min_level": args.seam_min_level,
             "pictures": args.seam_pictures, "band_rows": args.seam_band_rows, "no_sad": args.seam_no_sad, "weighted": not args.seam_no_weighted,
