@@ -612,6 +612,89 @@ def test_me_stream_planes_layout_and_centres_equal_the_oracle(depth, width, heig
         prov.close()
 
 
+@pytest.mark.parametrize("depth,shift", [(8, 56), (10, -56)])
+def test_me_stream_centred_windows_wait_for_every_reference_row_they_reach(depth, shift):
+    """Round-4 advisor (high): with centre_range the window of a CTU row reaches 63 + max(centre_range, max |cy| + range) lines past the row's
+    first line - at range 12, centre_range 57, margin 80 that is 131 lines = TWO CTU rows - and the service used to launch a row once
+    rows r - 1 .. r + 1 were on the device.  The reference here is the source moved 56 lines (so every centre is (0, +-56)), its rows arrive
+    one at a time into a recycled picture entry: no row may be flagged before every row its searches read was handed over, and the
+    rasters must equal the oracle's search of the complete picture."""
+    from tools import seam_driver as SD
+    O = _oracle()
+    rng, centre = 12, 57
+    geo = SD.geometry(192, 448)
+    clip = F.synth_clip(geo["width"], geo["height"], 2, depth=depth, seed=23)
+    dt = np.uint8 if depth == 8 else np.uint16
+    def padded(y):
+        return np.ascontiguousarray(np.pad(y.reshape(geo["height"], geo["width"]).astype(dt), ((geo["margin_y"],) * 2, (geo["margin_x"],) * 2), mode="edge")).reshape(-1)
+    cur = clip[1][0].reshape(geo["height"], geo["width"])
+    moved = np.roll(cur, shift, axis=0)                      # what sits at line y of the source sits at line y + shift of the reference
+    planes = [padded(moved), padded(cur)]
+    stale = padded(clip[0][0])                               # what a recycled entry still holds
+    prov = SD.StreamGpuProvider(depth, geo, rng, slots=1, min_level=1, pictures=2, band_rows=8, layout=SD.LAYOUT_PLANES, centre_range=centre)
+    L = prov.L
+    _stream_entries(L)
+    L.x265hip_me_stream_centres.restype = ctypes.c_void_p
+    L.x265hip_me_stream_centres.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    try:
+        ctus_w, ctus_h = geo["width"] // 64, geo["height"] // 64
+        nctu = ctus_w * ctus_h
+        my = min(centre, geo["margin_y"] - rng - 12)
+        lag = (63 + max(centre, my + rng)) // 64
+        assert lag == 2 and abs(shift) + rng + 63 >= 128
+        # fill both picture entries with other content first: the entries the test's pictures get are recycled ones
+        assert L.x265hip_me_stream_picture_rows(prov.handle, 1, stale.ctypes.data, 0, ctus_h) == 0
+        assert L.x265hip_me_stream_picture_rows(prov.handle, 2, stale.ctypes.data, 0, ctus_h) == 0
+        time.sleep(0.2)
+        assert L.x265hip_me_stream_picture_rows(prov.handle, 11, planes[1].ctypes.data, 0, ctus_h) == 0
+        gen = L.x265hip_me_stream_pair_open(prov.handle, 0, 11, 12)
+        assert gen > 0
+        ready = np.ctypeslib.as_array((ctypes.c_int32 * ctus_h).from_address(L.x265hip_me_stream_ready(prov.handle, 0)))
+        given = set()
+        for r in (range(ctus_h) if shift > 0 else reversed(range(ctus_h))):        # the rows the windows reach arrive LAST: below (shift > 0) / above
+            assert L.x265hip_me_stream_picture_rows(prov.handle, 12, planes[0].ctypes.data, r, 1) == 0
+            given.add(r)
+            time.sleep(0.15)                                 # long enough for the worker to search whatever it believes is searchable
+            for q in range(ctus_h):
+                if ready[q] == gen:
+                    assert all(k in given for k in range(max(0, q - lag), min(ctus_h, q + lag + 1))), (q, sorted(given))
+        t0 = time.time()
+        while not all(ready[q] == gen for q in range(ctus_h)) and time.time() - t0 < 20:
+            time.sleep(0.01)
+        assert all(ready[q] == gen for q in range(ctus_h)), prov.report()
+        org = geo["margin_y"] * geo["stride"] + geo["margin_x"]
+        zc, zero = np.zeros(2 * centre + 1, np.uint16), np.zeros(2 * rng + 1, np.uint16)
+        _, best = O.me_fullsearch(depth, planes[1], geo["stride"], org, planes[0], geo["stride"], org, geo["width"], geo["height"], centre, 0, nctu, zc, zc,
+                                  want_surf=False, want_best=True)
+        idx = (best.reshape(-1, 85)[:, 84] & 0xffffffff).astype(np.int64)
+        ncb = 2 * centre + 1
+        mx = min(centre, geo["margin_x"] - rng - 12)
+        cen = np.stack([np.clip(idx % ncb - centre, -mx, mx), np.clip(idx // ncb - centre, -my, my)], axis=1).astype(np.int16)
+        got_c = np.ctypeslib.as_array((ctypes.c_int16 * (2 * nctu)).from_address(L.x265hip_me_stream_centres(prov.handle, 0))).reshape(nctu, 2)
+        assert np.array_equal(got_c, cen), (got_c, cen)
+        inner = cen[ctus_w:(ctus_h - 1) * ctus_w] if shift > 0 else cen[2 * ctus_w:]
+        assert np.all(inner[:, 1] == shift), cen             # the windows really sit two CTU rows' reach away
+        parts = []
+        for c in range(nctu):
+            o = org + (c // ctus_w) * 64 * geo["stride"] + (c % ctus_w) * 64
+            sc, _ = O.me_fullsearch(depth, planes[1], geo["stride"], o, planes[0], geo["stride"], o + int(cen[c, 1]) * geo["stride"] + int(cen[c, 0]),
+                                    64, 64, rng, 0, 1, zero, zero, want_surf=True, want_best=False)
+            parts.append(sc)
+        cb = SD.planes_ctu_bytes(rng, 1)
+        exp = SD.records_to_planes(np.concatenate(parts).reshape(-1, 85, 4), nctu, rng, 1)
+        got = np.ctypeslib.as_array((ctypes.c_uint8 * (nctu * cb)).from_address(L.x265hip_me_stream_surface(prov.handle, 0))).reshape(nctu, cb)
+        nc, pitch = 2 * rng + 1, 4 * ((2 * rng + 4) // 4)
+        def valid(b):
+            lo = b[:, :nc * pitch * 2 * 16].copy().view(np.uint16).reshape(nctu, 16, nc, pitch)[..., :nc]
+            hi = b[:, nc * pitch * 2 * 16:].copy().view(np.uint32).reshape(nctu, 5, nc, pitch)[..., :nc]
+            return lo, hi
+        (gl, gh), (el, eh) = valid(got), valid(exp)
+        assert np.array_equal(gl, el) and np.array_equal(gh, eh)
+        assert prov.report()["failed"] == 0
+    finally:
+        prov.close()
+
+
 @pytest.mark.parametrize("depth,preset,ft,min_level,centre,extra", [(8, "slow", 3, 1, 57, [("me", "star")]), (8, "medium", 3, 0, 0, []), (10, "slower", 2, 1, 40, []),
                                                                     (8, "slow", 3, 1, 40, [("me", "star"), ("bframes", "0")]), (8, "slow", 3, 2, 57, [("me", "star")])])
 def test_row_granular_seams_on_the_gpu_with_planes_and_centred_windows(depth, preset, ft, min_level, centre, extra):

@@ -329,7 +329,9 @@ class StreamOracleProvider:
         self.pics = {}                           # key -> dict(plane, rows)
         self.plane_elems = geo["stride"] * geo["rows"]
         self.org = geo["margin_y"] * geo["stride"] + geo["margin_x"]
-        self.lag = (63 + rng) // 64
+        # CTU rows of the reference a CTU row's searches reach: the centre search 63 + centre_range lines, the window round a centre another
+        # max |cy| + range (the product's lagRows, me_stream.hip - round-4 advisor: both ignored centre_range)
+        self.lag = (63 + (max(centre_range, self.max_c[1] + rng) if centre_range else rng)) // 64
         self.format = SURF_I32
         self.bands = self.rows_in = 0
         self.lock = threading.Lock()

@@ -189,7 +189,7 @@ inline void row_lines(const S* s, int r0, int n, long& y0, long& y1)
     y1 = r0 + n == s->ctusH ? (long)s->prm.height + 2 * s->prm.margin_y : s->prm.margin_y + (long)(r0 + n) * 64;
 }
 
-struct Band { int slot, gen, r0, r1; };
+struct Band { int slot, gen, r0, r1, fenc, ref; };
 struct Upload { int pic, r0, n; };
 struct Weigh { int pic, parent, r0, n; };
 
@@ -229,8 +229,8 @@ int run_round(S* s, const std::vector<Upload>& ups, const std::vector<Weigh>& we
         x265hip_me_params p;
         memset(&p, 0, sizeof(p));
         p.depth = s->prm.depth; p.width = s->prm.width; p.height = n * 64;
-        p.fenc = s->pics[sl.fenc].dev + org + bandOff; p.fenc_stride = s->prm.stride;
-        p.fref = s->pics[sl.ref].dev + org + bandOff;  p.fref_stride = s->prm.stride;
+        p.fenc = s->pics[b.fenc].dev + org + bandOff; p.fenc_stride = s->prm.stride;
+        p.fref = s->pics[b.ref].dev + org + bandOff;  p.fref_stride = s->prm.stride;
         const int nctuBand = n * s->ctusW;
         if (s->centreRange)
         {
@@ -317,6 +317,7 @@ void worker_main(S* s)
                     int e = r;
                     while (e < s->ctusH && pc.rows[e] == ROW_STAGED) pc.rows[e++] = ROW_ON_DEVICE;      // stream order: every later launch sees them
                     ups.push_back({ i, r, e - r });
+                    pc.busy++;                              // pinned until the round is synchronised (see the end of the round)
                     r = e;
                 }
             }
@@ -336,6 +337,7 @@ void worker_main(S* s)
                     int e = r;
                     while (e < s->ctusH && pd.rows[e] != ROW_ON_DEVICE && pp.rows[e] == ROW_ON_DEVICE) pd.rows[e++] = ROW_ON_DEVICE;
                     weighs.push_back({ i, pd.parent, r, e - r });
+                    pd.busy++; s->pics[pd.parent].busy++;
                     r = e;
                 }
             }
@@ -358,7 +360,10 @@ void worker_main(S* s)
                     r1 = r;
                 }
                 if (r1 < sl.nextRow) continue;
-                bands.push_back({ i, sl.generation, sl.nextRow, r1 });
+                bands.push_back({ i, sl.generation, sl.nextRow, r1, sl.fenc, sl.ref });
+                // a pair that closes with this band (active = false below) no longer holds its pictures: pin them until the launches that
+                // read them have run, or a host thread staging a new picture could take the entry while uploads / searches are queued on it
+                s->pics[sl.fenc].busy++; s->pics[sl.ref].busy++;
                 sl.nextRow = r1 + 1;
                 if (sl.nextRow == s->ctusH) sl.active = false;
                 else s->dirty = true;                                   // more rows may be searchable at once: come round again
@@ -370,6 +375,15 @@ void worker_main(S* s)
         {
             s->failed += bands.size() + 1;
             snprintf(s->workerError, sizeof(s->workerError), "%s", x265hip_last_error());
+        }
+        // bands end with a wait for their downloads (everything queued before them on the compute stream has run by then); a round without
+        // bands waits for its uploads / weighted rows here - then the pins go
+        if (bands.empty()) (void)hipStreamSynchronize(s->compute);
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            for (const Upload& u : ups) s->pics[u.pic].busy--;
+            for (const Weigh& q : weighs) { s->pics[q.pic].busy--; s->pics[q.parent].busy--; }
+            for (const Band& b : bands) { s->pics[b.fenc].busy--; s->pics[b.ref].busy--; }
         }
         s->usBusy += (uint64_t)(ms_now_us() - t0);
     }
@@ -505,7 +519,13 @@ int x265hip_me_stream_create(x265hip_me_stream** out, const x265hip_me_stream_pa
     s->surfBytes = s->rowBytes * s->ctusH;
     s->bandRows = p->band_rows ? p->band_rows : 8;
     if (s->bandRows > s->ctusH) s->bandRows = s->ctusH;
-    s->lagRows = (63 + p->range) / 64;                    // CTU rows of the reference a CTU row's window reaches below (and above) itself
+    // CTU rows of the reference a CTU row's launches reach below (and above) itself: the centre search reads 63 + centre_range lines past the
+    // row's first line, the window around a centre |cy| <= maxCy another maxCy + range (round-4 advisor: (63 + range) / 64 ignored both, so
+    // with progressively arriving rows a band could be searched against stale lines of a recycled picture entry)
+    {
+        const int reach = s->centreRange ? (s->centreRange > s->maxCy + p->range ? s->centreRange : s->maxCy + p->range) : p->range;
+        s->lagRows = (63 + reach) / 64;
+    }
     if ((s->linePitch & 3) || ((((size_t)p->margin_y * p->stride + p->margin_x) * s->bpp) & 3))
     { set_error("me_stream_create: sample (0,0) and the row pitch must be 4-byte aligned"); delete s; return X265HIP_EINVAL; }
     if (p->device_plus_1 > 0)

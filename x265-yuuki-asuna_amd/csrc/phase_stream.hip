@@ -204,7 +204,9 @@ void ps_worker(PS* s)
                 if (!pc.used) continue;
                 int r1 = pc.nextRow;
                 while (r1 < s->ctuRows && pc.staged[r1]) r1++;          // rows are interpolated top to bottom: only a contiguous prefix is useful
-                if (r1 > pc.nextRow) { ups.push_back({ i, pc.nextRow, r1 }); pc.nextRow = r1; }
+                // busy: the entry stays this picture's until the round is synchronised - a view that closes with its last rows (below) no longer
+                // holds it, and a host thread staging a NEW picture into the same pinned memory would race the upload still reading it
+                if (r1 > pc.nextRow) { ups.push_back({ i, pc.nextRow, r1 }); pc.nextRow = r1; pc.busy++; }
             }
             for (int i = 0; i < (int)s->slots.size(); i++)
             {
@@ -216,6 +218,7 @@ void ps_worker(PS* s)
                 {
                     ViewJob job = { i, sl.generation, sl.pic, sl.rowsSeen, pc.nextRow, { sl.done[0], sl.done[1] }, sl.mask, { sl.w[0], sl.w[1], sl.w[2] } };
                     jobs.push_back(job);
+                    s->pics[sl.pic].busy++;
                     sl.rowsSeen = pc.nextRow;
                     if (sl.rowsSeen == s->ctuRows) sl.active = false;
                 }
@@ -227,6 +230,12 @@ void ps_worker(PS* s)
         {
             s->failed++;
             snprintf(s->workerError, sizeof(s->workerError), "%s", x265hip_last_error());
+        }
+        {
+            // the round has been synchronised (or has failed): its pictures may be recycled again
+            std::lock_guard<std::mutex> lk(s->mu);
+            for (const Upload& u : ups) s->pics[u.pic].busy--;
+            for (const ViewJob& j : jobs) s->pics[j.pic].busy--;
         }
         s->usBusy += (uint64_t)(ps_now_us() - t0);
     }
