@@ -225,3 +225,45 @@ def test_me_4k_default_config_properties(packed):
         _, best = O.me_fullsearch(8, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org,
                                   cur.w64, cur.h64, 57, ctu, ctu + 1, ms.cost_host, ms.cost_host, want_surf=False)
         assert np.array_equal(ms.best[ctu * 85:(ctu + 1) * 85].cpu().numpy().view(np.uint64), best[ctu * 85:(ctu + 1) * 85])
+
+
+@pytest.mark.parametrize("variant", ["", "0", "1", "5"])
+@pytest.mark.parametrize("case", [(192, 128, 57, 4.0, None), (128, 128, 8, 0.0, None), (256, 64, 90, 16.0, None), (128, 64, 5, 4.0, "flat"), (192, 192, 12, 2.0, "centres"),
+                                  (128, 128, 123, 1.0, None)])
+def test_me_minima_only_launch_every_kernel_variant(case, variant, monkeypatch):
+    """The launch the closed loop times: per-PU minima only (no surfaces), 8-bit - round 5's kernel (default; X265HIP_ME_BEST_VARIANT 5 = its
+    per-column 8x8 minima) and round 4's (0 / 1) against the oracle: zero motion-vector cost (every tie decided by raster order alone), a flat
+    picture (every candidate ties), the widest window the 256-byte LDS pitch holds (+-90), the widest the row index byte holds (+-123), windows centred per CTU."""
+    import torch
+    width, height, rng, lam, special = case
+    if variant:
+        monkeypatch.setenv("X265HIP_ME_BEST_VARIANT", variant)
+    else:
+        monkeypatch.delenv("X265HIP_ME_BEST_VARIANT", raising=False)
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(width, height, 2, depth=8, seed=40 + rng)
+    y0, y1 = clip[0][0], clip[1][0]
+    if special == "flat":
+        y0 = np.zeros_like(y0); y1 = np.full_like(y1, 255)
+    cur, ref = P.DevicePicture(y1, dev), P.DevicePicture(y0, dev)
+    ms = P.MotionSearch(cur.w64, cur.h64, rng, 8, dev, want_surf=False, lam=lam)
+    O = _oracle()
+    if special == "centres":
+        r = np.random.default_rng(5)
+        cen = r.integers(-20, 21, size=(ms.nctu, 2)).astype(np.int16)
+        ms.run(cur, ref, centres=torch.from_numpy(cen).to(dev))
+        torch.cuda.synchronize()
+        gb = ms.best.cpu().numpy().view(np.uint64).reshape(ms.nctu, 85)
+        cw = cur.w64 // 64
+        for c in range(ms.nctu):
+            o = cur.org + (c // cw) * 64 * cur.stride + (c % cw) * 64
+            _, best = O.me_fullsearch(8, cur.host, cur.stride, o, ref.host, ref.stride, o + int(cen[c, 1]) * ref.stride + int(cen[c, 0]), 64, 64, rng, 0, 1,
+                                      ms.cost_host, ms.cost_host, want_surf=False, want_best=True)
+            assert np.array_equal(gb[c], best.reshape(-1)), (c, variant)
+        return
+    ms.run(cur, ref)
+    torch.cuda.synchronize()
+    _, best = O.me_fullsearch(8, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, rng, 0, ms.nctu, ms.cost_host, ms.cost_host,
+                              want_surf=False, want_best=True)
+    gb = ms.best.cpu().numpy().view(np.uint64)
+    assert np.array_equal(gb, best), f"variant {variant!r}: {np.count_nonzero(gb != best)} of {gb.size} minima differ"

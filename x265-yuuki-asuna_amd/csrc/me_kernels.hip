@@ -499,6 +499,237 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 5: the minima-only 8-bit launch with the OTHER half of its instruction stream cut down (round-4 verdict, weak 2: 44 level-sum / key /
+// minimum instructions per window row beside 16 quad-SADs; SQ_WAIT_INST_ANY 1.7 x SQ_ACTIVE).  Same walk, same ring of packed accumulators,
+// same keys - what changes:
+//   * the row's motion-vector cost no longer comes from a global_load_ushort per row (a vector load and a vmcnt(0) wait inside every row's
+//     dependency chain, then five vector instructions to shift / combine a value that is uniform): the workgroup builds `costY[m] << 8 | m`
+//     once in LDS, a block of 8 rows fetches its 8 entries with ONE ds_read and every row takes its entry with v_readlane -> the row
+//     constants live in SGPRs and the key arithmetic uses them as scalar operands;
+//   * the window bytes 0..7 / 4..11 of a row are read as two 4-byte-aligned 64-bit LDS loads (ds_read2_b32 each) into the aligned register
+//     pairs v_qsad_pk_u16_u8 wants - the three-dword load needed a copy per row (gfx950 wants even-aligned 64-bit operands) and a
+//     register shuffle per pair of rows;
+//   * the column's costX is added to the 16x16 / 32x32 / 64x64 running minima ONCE per column group (it is constant for a lane inside a
+//     group and min(x + c) = min(x) + c), not to every row's keys;
+//   * the 64x64 level is reduced for TWO window rows at a time: v_permlane16_swap exchanges the odd 16-lane rows of row A's 32x32 sums with
+//     the even rows of row B's, one add, v_permlane32_swap of the sum with itself, one add -> lanes of rows 0 / 2 hold A's 64x64 total,
+//     rows 1 / 3 hold B's (5 instructions per PAIR of rows where two separate reductions took 14); the per-lane `costY << 8 | m` of the
+//     row a lane ended up with comes from the LDS table with a per-lane address.
+// Results are identical (the keys order candidates exactly as before; tests/test_gpu_me.py runs every variant against the oracle).
+// COLMIN: the 8x8 level keeps one running minimum PER COLUMN of `(sad << 8) + (costY << 8 | m)` (an extract, a shift-add and half a
+// v_min3 per column and row) and gives each column its costX once per group, instead of folding the four columns into one key per row.
+template <int PITCH, bool COLMIN>
+__global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOff)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t win[];
+    typedef unsigned long long u64;
+    typedef u64 __attribute__((aligned(4))) u64a4;
+    const int R = a.range;
+    const int NC = 2 * R + 1;
+    const int NG = (NC + 3) >> 2;
+    const int rows = 64 + 2 * R;
+    const int ctu = blockIdx.x;
+    const int cx = (ctu % a.ctusW) * 64, cy = (ctu / a.ctusW) * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    constexpr int pitch = PITCH;
+
+    const int ccx = a.centres ? a.centres[2 * ctu] : 0, ccy = a.centres ? a.centres[2 * ctu + 1] : 0;
+    const uint8_t* g0 = a.fref + (long)(cy + ccy - R) * a.frefStrideB + (long)(cx + ccx - R);
+    const int rowDw = a.payloadDw;
+    for (int r = wave; r < rows; r += nwaves)
+    {
+        const uint8_t* src = g0 + (long)r * a.frefStrideB;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(win + lds_row_off(r, pitch));
+        for (int c = lane; c < rowDw; c += 64)
+            dst[c] = ld_u32(src + 4 * c);
+    }
+    // the rows' share of every key: costY[m] << 8 | m (8 entries of slack: a block's fetch may run past the last row)
+    uint32_t* ctab = reinterpret_cast<uint32_t*>(win + ctabOff);
+    for (int i = threadIdx.x; i < NC + 8; i += blockDim.x)
+        ctab[i] = i < NC ? ((uint32_t)a.costY[i] << 8) | (uint32_t)i : 0xffffff00u;
+    int bx, by;
+    zorder_xy(lane, bx, by);
+    uint32_t F[8][2];
+    {
+        const uint8_t* fe = a.fenc + (long)(cy + by * 8) * a.fencStrideB + (long)(cx + bx * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { F[j][0] = ld_u32(fe + (long)j * a.fencStrideB); F[j][1] = ld_u32(fe + (long)j * a.fencStrideB + 4); }
+    }
+    __syncthreads();
+
+    u64 bk8 = ~0ull, bk16 = ~0ull, bk32 = ~0ull, bk64 = ~0ull;
+    const int kcol = lane & 3;
+    const uint32_t selK = 0x0c0c0000u | (uint32_t)((2 * kcol + 1) << 8) | (uint32_t)(2 * kcol);   // v_perm: u16 #kcol of {qhi, qlo}
+    const int oddRow = (lane >> 4) & 1;                     // after the paired 64x64 reduction: 0 = this lane holds row A's total, 1 = row B's
+
+    const int T = 2 * R + 8;
+    for (int g = wave; g < NG; g += nwaves)
+    {
+        const uint32_t colOff = (uint32_t)((by * 8) * pitch + bx * 8 + 4 * g);
+        // LDS byte address of window row t0 of this lane's block column.  Kept opaque: ds_read2_b32 reaches 255 dwords past its address
+        // register, so a block of 8 rows is read from THREE address registers (rows 0 - 3, rows 4 - 7, the next block's rows 0 - 1)
+        // instead of one register per load
+        auto block_off = [&](const int t0) { uint32_t o = colOff + (uint32_t)(t0 * pitch + lds_skew_bytes(by + (t0 >> 3))); asm volatile("" : "+v"(o)); return o; };
+        // two window rows: bytes 0..7 and 4..11 of each, every 64-bit value in an aligned register pair of its own
+        auto ldpair = [&](u64 (&d)[2][2], const uint32_t off, const int p)
+        {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+            {
+                d[q][0] = *reinterpret_cast<const u64a4*>(win + off + (p + q) * pitch);
+                d[q][1] = *reinterpret_cast<const u64a4*>(win + off + (p + q) * pitch + 4);
+            }
+        };
+        uint32_t cxk4[4], cxL;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            cxk4[k] = ((4 * g + k < NC ? (uint32_t)a.costX[4 * g + k] : (1u << 20)) << 2) | (uint32_t)k;
+        cxL = 4 * g + kcol < NC ? (uint32_t)a.costX[4 * g + kcol] : (1u << 23);
+        uint32_t r8 = 0xffffffffu, r16 = 0xffffffffu, r32 = 0xffffffffu, r64 = 0xffffffffu;
+        uint32_t r8c[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
+        u64 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = 0;
+        u64 buf[2][2][2];                                   // [pipeline slot][row of the pair][bytes 0..7 / 4..11]; slot parity returns after 8 rows
+        ldpair(buf[0], block_off(0), 0);
+
+        auto rows8 = [&](auto firstTag, auto nrowsTag, const int t0)
+        {
+            constexpr bool FIRST = decltype(firstTag)::value;
+            constexpr int NROWS = decltype(nrowsTag)::value;
+            const uint32_t bb = block_off(t0), bn = block_off(t0 + 8);
+            uint32_t bb4 = bb + 4 * pitch;
+            asm volatile("" : "+v"(bb4));
+            // this block's row constants: lane l < 8 fetches the entry of window row t0 + l (m = t0 + l - 7; the first block only completes m = 0)
+            const int mb = t0 - 7;
+            const uint32_t cb = ctab[mb + (lane & 7) < 0 ? 0 : mb + (lane & 7)];
+            uint32_t v32even = 0;
+#pragma unroll
+            for (int p = 0; p < NROWS; p++)
+            {
+                if ((p & 1) == 0)
+                {
+                    if (p + 2 < 4) ldpair(buf[((p >> 1) + 1) & 1], bb, p + 2);
+                    else if (p + 2 < 8) ldpair(buf[((p >> 1) + 1) & 1], bb4, p + 2 - 4);
+                    else ldpair(buf[((p >> 1) + 1) & 1], bn, 0);
+                }
+                const u64 w0 = buf[(p >> 1) & 1][p & 1][0], w1 = buf[(p >> 1) & 1][p & 1][1];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                {
+                    if (FIRST && j > p) continue;
+                    u64 v = j == 0 ? 0ull : acc[(p - j) & 7];
+                    v = __builtin_amdgcn_qsad_pk_u16_u8(w0, F[j][0], v);
+                    v = __builtin_amdgcn_qsad_pk_u16_u8(w1, F[j][1], v);
+                    acc[(p - j) & 7] = v;
+                }
+                if (!FIRST || p == 7)
+                {
+                    const int slot = (p + 1) & 7;
+                    const u64 A = acc[slot];
+                    const uint32_t lo = (uint32_t)A, hi = (uint32_t)(A >> 32);
+                    const uint32_t qlo = (uint32_t)quad_sum((int)lo), qhi = (uint32_t)quad_sum((int)hi);
+                    // (opaque masks keep the compiler from turning `(x & 0xffff) << n` into shift + mask + add: mask, then one v_lshl_add_u32)
+                    uint32_t s80, s82;
+                    asm("v_and_b32 %0, 0xffff, %1" : "=v"(s80) : "v"(lo));
+                    asm("v_and_b32 %0, 0xffff, %1" : "=v"(s82) : "v"(hi));
+                    const uint32_t s81 = lo >> 16, s83 = hi >> 16;
+                    const uint32_t v16 = __builtin_amdgcn_perm(qhi, qlo, selK);
+                    const uint32_t v32 = (uint32_t)row_sum_of_quads((int)v16);
+                    const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)cb, p);      // costY[m] << 8 | m, in an SGPR
+                    if (COLMIN)
+                    {
+                        const uint32_t k0 = (s80 << 8) + sb, k1 = (s81 << 8) + sb, k2 = (s82 << 8) + sb, k3 = (s83 << 8) + sb;
+                        r8c[0] = k0 < r8c[0] ? k0 : r8c[0];
+                        r8c[1] = k1 < r8c[1] ? k1 : r8c[1];
+                        r8c[2] = k2 < r8c[2] ? k2 : r8c[2];
+                        r8c[3] = k3 < r8c[3] ? k3 : r8c[3];
+                    }
+                    else
+                    {
+                        const uint32_t k0 = (s80 << 2) + cxk4[0], k1 = (s81 << 2) + cxk4[1];
+                        const uint32_t k2 = (s82 << 2) + cxk4[2], k3 = (s83 << 2) + cxk4[3];
+                        uint32_t kmin = k0 < k1 ? k0 : k1;
+                        kmin = k2 < kmin ? k2 : kmin;
+                        kmin = k3 < kmin ? k3 : kmin;
+                        uint32_t key = ((kmin & ~3u) << 8) + (sb << 2);              // cost << 10 | m << 2
+                        key = (key & ~3u) | (kmin & 3u);                             // | k
+                        r8 = key < r8 ? key : r8;
+                    }
+                    const uint32_t k16 = (v16 << 8) + sb, k32 = (v32 << 8) + sb;     // costX joins once per group
+                    r16 = k16 < r16 ? k16 : r16;
+                    r32 = k32 < r32 ? k32 : r32;
+                    if (FIRST)
+                    {   // the first block completes a single row (m = 0): reduce it on its own
+                        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                        v2u sw = __builtin_amdgcn_permlane16_swap(v32, v32, false, false);
+                        const unsigned h64 = sw.x + sw.y;
+                        sw = __builtin_amdgcn_permlane32_swap(h64, h64, false, false);
+                        const uint32_t k64 = ((sw.x + sw.y) << 8) + sb;
+                        r64 = k64 < r64 ? k64 : r64;
+                    }
+                    else if ((p & 1) == 0)
+                        v32even = v32;
+                    else
+                    {
+                        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                        // rows A (p - 1) and B (p): {A0,B0,A2,B2} + {A1,B1,A3,B3}, then the two halves of that sum
+                        v2u sw = __builtin_amdgcn_permlane16_swap(v32even, v32, false, false);
+                        const unsigned h64 = sw.x + sw.y;
+                        sw = __builtin_amdgcn_permlane32_swap(h64, h64, false, false);
+                        const uint32_t tot = sw.x + sw.y;                            // 16-lane rows 0 / 2: A's 64x64 total, rows 1 / 3: B's
+                        const uint32_t mine = ctab[mb + p - 1 + oddRow];             // costY << 8 | m of the row this lane holds
+                        const uint32_t k64 = (tot << 8) + mine;
+                        r64 = k64 < r64 ? k64 : r64;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        using I8 = std::integral_constant<int, 8>;
+        rows8(std::true_type{}, I8{}, 0);
+        int t0 = 8;
+        for (; t0 + 8 <= T; t0 += 8)
+            rows8(std::false_type{}, I8{}, t0);
+        switch (T - t0)
+        {
+        case 2: rows8(std::false_type{}, std::integral_constant<int, 2>{}, t0); break;
+        case 4: rows8(std::false_type{}, std::integral_constant<int, 4>{}, t0); break;
+        case 6: rows8(std::false_type{}, std::integral_constant<int, 6>{}, t0); break;
+        default: break;
+        }
+        {   // widen the group's row-local keys to cost << 32 | raster index and merge; the column's costX joins the upper levels here
+            if (COLMIN)
+            {   // each column's minimum over the rows gets its costX now; `cost << 10 | m << 2 | k` orders the four like (cost, raster index)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const uint32_t kc = ((r8c[k] >> 8) << 2) + cxk4[k];
+                    const uint32_t key = ((kc & ~3u) << 8) | ((r8c[k] & 255u) << 2) | (kc & 3u);
+                    r8 = key < r8 ? key : r8;
+                }
+            }
+            const u64 w8 = ((u64)(r8 >> 10) << 32) | (uint32_t)(((r8 >> 2) & 255u) * NC + 4 * g + (r8 & 3u));
+            bk8 = w8 < bk8 ? w8 : bk8;
+            const uint32_t cxL8 = cxL << 8;
+            auto widen = [&](const uint32_t r) { const uint32_t rc = r + cxL8; return ((u64)(rc >> 8) << 32) | (uint32_t)((rc & 255u) * NC + 4 * g + kcol); };
+            const u64 w16 = widen(r16), w32 = widen(r32), w64 = widen(r64);
+            bk16 = w16 < bk16 ? w16 : bk16;
+            bk32 = w32 < bk32 ? w32 : bk32;
+            bk64 = w64 < bk64 ? w64 : bk64;
+        }
+    }
+
+    u64* rec = a.best + (size_t)ctu * 85;
+    atomicMin(&rec[lane], bk8);
+    atomicMin(&rec[64 + (lane >> 2)], bk16);
+    if ((lane & 15) < 4) atomicMin(&rec[80 + (lane >> 4)], bk32);
+    if ((lane & 0x2f) < 4) atomicMin(&rec[84], bk64);          // lanes 0..3 saw the even window rows of their column, lanes 16..19 the odd ones
+}
+
+// ------------------------------------------------------------------------------------------------
 // 10-bit fast path: the column-group organisation of me_ctu_q_kernel for 16-bit pixels.  There is no packed
 // multi-displacement SAD for 16-bit samples, so the core is v_sad_u16 (2 pixels, 8.8 cycles): a wavefront owns 4 mv
 // columns, each window row is 6 dwords (12 pixels: even columns read pixel pairs as stored, odd columns through
@@ -767,7 +998,8 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     if (sizeof(Px) == 1 && a.rowBytes == 256 && !p_generic)
     {
         // 8-bit fast path (v_qsad_pk_u16_u8); 2 * range + 75 bytes of window row must fit the 256-byte pitch
-        static const int bestVar = getenv("X265HIP_ME_BEST_VARIANT") ? atoi(getenv("X265HIP_ME_BEST_VARIANT")) & 3 : -1;       // A/B, read once
+        const char* bestVarEnv = getenv("X265HIP_ME_BEST_VARIANT");       // A/B and the parity test of every variant: read per launch
+        const int bestVar = bestVarEnv ? atoi(bestVarEnv) & 7 : -1;
         static const int bestWaves = getenv("X265HIP_ME_BEST_WAVES") ? atoi(getenv("X265HIP_ME_BEST_WAVES")) : 0;       // A/B: wavefronts per workgroup of the minima-only launch
         // 4K and up: 12 wavefronts per workgroup instead of 16 - step 1.875 -> 1.823 ms at 4K on one box, three interleaved rounds (8 does the same, 10 and 6 lose;
         // at 1080p 16 stays best): profiles/r04_me_minima_ab.txt
@@ -786,7 +1018,24 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
             if (anySurf) LAUNCH_Q(true, false, 16);
             if (anyBest)
             {
-                if (bestVar == 1) LAUNCH_QV(1); else if (bestVar == 2) LAUNCH_QV(2); else if (bestVar == 3) LAUNCH_QV(3); else LAUNCH_QV(0);
+                if (bestVar == 1) LAUNCH_QV(1); else if (bestVar == 2) LAUNCH_QV(2); else if (bestVar == 3) LAUNCH_QV(3);
+                else if (bestVar == 0 || p->range > 123) LAUNCH_QV(0);          // 0 = round 4's kernel (A/B)          // (the row index shares a byte with nothing else: m <= 2 * range < 256 either way)
+                else
+                {   // round 5's minima-only kernel (the default): the same launch geometry + the row-constant table behind the window
+                    int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 12) nwq = 12;
+                    if (bestWaves >= 4 && bestWaves <= 16 && bestWaves < pick_waves((2 * p->range + 4) / 4) + 1) nwq = bestWaves;
+                    const size_t lds2 = lds + (size_t)(2 * p->range + 1 + 8) * 4;
+                    if (bestVar == 5)
+                    {   // 5 = per-column 8x8 minima (A/B)
+                        if (lds2 > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_q2_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                        hipLaunchKernelGGL((me_ctu_q2_kernel<256, true>), grid, dim3(nwq * 64), lds2, s, a, (int)lds);
+                    }
+                    else
+                    {
+                        if (lds2 > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_q2_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                        hipLaunchKernelGGL((me_ctu_q2_kernel<256, false>), grid, dim3(nwq * 64), lds2, s, a, (int)lds);
+                    }
+                }
             }
         }
 #undef LAUNCH_Q

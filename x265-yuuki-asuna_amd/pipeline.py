@@ -156,17 +156,18 @@ class MotionSearch:
         if self.best_spare is not None:
             self.best, self.best_spare = self.best_spare, self.best
 
-    def run(self, cur: DevicePicture, ref: DevicePicture):
+    def run(self, cur: DevicePicture, ref: DevicePicture, centres=None):
         self.reset()
-        self.search(cur, ref)
+        self.search(cur, ref, centres=centres)
 
-    def search(self, cur: DevicePicture, ref: DevicePicture):
-        """The one exhaustive-search launch (best[] must have been reset)."""
+    def search(self, cur: DevicePicture, ref: DevicePicture, centres=None):
+        """The one exhaustive-search launch (best[] must have been reset).  centres: optional int16 [ctu][2] device tensor - every CTU's window is
+        centred on its own displacement (x265hip_me_params.centres)."""
         hipabi.me_fullsearch(self.depth, self.w64, self.h64, self.range,
                              cur.t, cur.stride, ref.t, ref.stride,
                              surf=self.surf, best=self.best, cost_x=self.cost_x, cost_y=self.cost_y,
                              fenc_off=cur.org, fref_off=ref.org,
-                             surf_format=self.surf_format)
+                             surf_format=self.surf_format, centres=centres)
 
     def level_view(self, level):
         """(surface view [nmv, npu], best view [nctu, npu]) of one PU level."""
