@@ -336,6 +336,9 @@ def seam_config(key):
     level 1 at 40 % of the download), sub-sample comparisons, lookahead frame costs, AQ and weightAnalyse from the device;
     everything the services do not answer takes the host-only control's split SADs."""
     depth = CFG_DEPTH.get(key, 8)
+    if key == "cfg5":       # 8K: a reference picture's phase planes are 3.4 GB of pinned memory, three frames need few resident pairs / views
+        return {"range": 12, "centre_range": 57, "layout": 1, "slots": 12, "min_pu": 16, "verify": False, "lookahead": True, "subpel": True, "subpel_slots": 4,
+                "streamed": True, "min_level": 1, "pictures": 8, "aq": True, "weight_analyse": True, "split_rest": True}
     return {"range": 12, "centre_range": 57, "layout": 1, "slots": 24 if depth == 8 else 40, "min_pu": 16, "verify": False, "lookahead": True,
             "subpel": True, "subpel_slots": 12, "streamed": True, "min_level": int(os.environ.get("X265HIP_SEAM_MIN_LEVEL", "2" if depth == 8 else "1")),
             "pictures": 24, "aq": True, "weight_analyse": True, "split_rest": True}

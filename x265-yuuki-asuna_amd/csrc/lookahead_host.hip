@@ -510,15 +510,88 @@ __global__ void __launch_bounds__(256) wa_cost_kernel(WaCostArgs a)
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&a.cost[c], v);
 }
 
-struct WaWeight { int present, weight, denom, offset; };
-inline int wa_bit_size(unsigned v) { if (!v) return 1; int n = 0; while (v >> (n + 1)) n++; return 2 * n + 1; }      // bitstream.h:94-112
-inline int wa_size_se(int val) { int tmp = 1 - val * 2; if (tmp < 0) tmp = val * 2; return tmp < 256 ? wa_bit_size((unsigned)tmp) : wa_bit_size((unsigned)tmp >> 8) + 16; }
-inline int wa_slice_header_cost(const WaWeight& w, int lambda, int bChroma)                                                // weightPrediction.cpp:49-56
+// ---- the decision half of x265hip_weight_analyse_host --------------------------------------------------------------------------------------
+// What the reference decides in weightAnalyse (encoder/weightPrediction.cpp:248-492), organised for a device that scores every trial of a
+// plane in ONE launch: the brightness statistics of a plane pair (:268-277) -> a seed gain (:300-330) -> a table of trials around the seed
+// (:403-446 visits them one weightCost call at a time; here the table is built first, scored as a batch, then walked in the reference's
+// order) -> the verdict (:448-470).  The float expressions are the reference's, operation for operation - the result must be bit-identical.
+struct Gain { int on, mul, log2d, add; };                  // sample' = clip(((mul * sample + round) >> log2d) + add); on = signalled in the slice header
+inline Gain unity(int log2d) { return { 0, 1 << log2d, log2d, 0 }; }
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct Brightness                                           // of one colour plane of a (picture, reference) pair
 {
-    if (bChroma) lambda *= 4;
-    const int denomCost = wa_bit_size((unsigned)w.denom + 1) * (2 - bChroma);
-    return lambda * (10 + denomCost + 2 * (wa_size_se(w.weight) + wa_size_se(w.offset)));
+    float ratio, meanCur, meanRef;                          // sqrt of the AC-energy ratio; mean sample values at 8-bit scale
+    void measure(uint64_t ssdCur, uint64_t ssdRef, uint64_t sumCur, uint64_t sumRef, int samples, int depth)
+    {
+        const uint64_t guard = !ssdRef;                     // :272-273: both energies get + 1 when the REFERENCE's is zero
+        ratio = std::sqrt((float)(ssdCur + guard) / (ssdRef + guard));
+        meanCur = (float)sumCur / (samples) / (1 << (depth - 8));
+        meanRef = (float)sumRef / (samples) / (1 << (depth - 8));
+    }
+    bool flat() const { return std::fabs(meanRef - meanCur) < 0.5f && std::fabs(1.f - ratio) < 1.f / 128.f; }      // :303-309: nothing to gain
+};
+
+// Exp-Golomb code lengths (common/bitstream.h:94-112) and the slice-header price of signalling a gain (weightPrediction.cpp:49-56)
+inline int ue_bits(unsigned v) { if (!v) return 1; int n = 0; while (v >> (n + 1)) n++; return 2 * n + 1; }
+inline int se_bits(int v) { int t = 1 - v * 2; if (t < 0) t = v * 2; return t < 256 ? ue_bits((unsigned)t) : ue_bits((unsigned)t >> 8) + 16; }
+inline int header_price(const Gain& g, int lambda, bool chroma)
+{
+    return (chroma ? 4 * lambda : lambda) * (10 + ue_bits((unsigned)g.log2d + 1) * (chroma ? 1 : 2) + 2 * (se_bits(g.mul) + se_bits(g.add)));
 }
+
+// The trials around a seed multiplier: one ROW per multiplier within +-4 of the seed whose distance from unity fits the header's signed byte;
+// a row carries the five offsets around the offset that multiplier implies for the two means (re-deriving the multiplier when that offset
+// does not fit a signed byte, :421-431).  Distinct (mul, add) pairs get one slot each in the launch's candidate list; slot 0 is the
+// unweighted plane.
+struct TrialTable
+{
+    struct Row { int mul, addLo, addHi; };
+    Row row[16];
+    int nrows = 0, ncand = 1, log2d = 0;
+    int32_t cand[64][4];                                    // { weighted?, mul, log2d, add } per slot: what wa_cost_kernel reads
+    int slot(int mul, int add)
+    {
+        for (int i = 1; i < ncand; i++) if (cand[i][1] == mul && cand[i][3] == add) return i;
+        cand[ncand][0] = 1; cand[ncand][1] = mul; cand[ncand][2] = log2d; cand[ncand][3] = add;
+        return ncand++;
+    }
+    void build(int seedMul, int d, const Brightness& b)
+    {
+        log2d = d;
+        cand[0][0] = 0; cand[0][1] = 1; cand[0][2] = 0; cand[0][3] = 0;
+        for (int m0 = clampi(seedMul - 4, 0, 127); m0 <= clampi(seedMul + 4, 0, 127); m0++)
+        {
+            const int fromUnity = m0 - (1 << d);
+            if (fromUnity > 127 || fromUnity <= -128) continue;
+            int m = m0;
+            int a = (int)(b.meanCur - b.meanRef * m / (1 << d) + 0.5f);
+            if (a < -128 || a > 127)
+            {
+                a = clampi(a, -128, 127);
+                m = clampi((int)((1 << d) * (b.meanCur - a) / b.meanRef + 0.5f), 0, 127);
+            }
+            Row& r = row[nrows++];
+            r.mul = m; r.addLo = clampi(a - 2, -128, 127); r.addHi = clampi(a + 2, -128, 127);
+            for (int k = r.addLo; k <= r.addHi; k++) slot(m, k);
+        }
+    }
+    // The reference's walk over the scored table: rows in order, offsets ascending, strict improvement only; a row is left as soon as the
+    // best offset so far is its first one and a later one has been looked at (:440-441 - the offsets are unimodal in practice).
+    bool walk(const uint32_t* score, int lambda, bool chroma, int& mul, int& add, uint32_t& best)
+    {
+        bool improved = false;
+        for (int k = 0; k < nrows; k++)
+            for (int a = row[k].addLo; a <= row[k].addHi; a++)
+            {
+                const Gain g = { 1, row[k].mul, log2d, a };
+                const uint32_t sc = score[slot(row[k].mul, a)] + (uint32_t)header_price(g, lambda, chroma);
+                if (sc < best) { best = sc; mul = row[k].mul; add = a; improved = true; }
+                if (add == row[k].addLo && a != row[k].addLo) break;
+            }
+        return improved;
+    }
+};
 
 } // namespace
 
@@ -586,199 +659,152 @@ extern "C" int x265hip_weight_analyse_host(const x265hip_weight_analyse_host_par
     uint8_t* dCur = nullptr;
     bool curChromaUp[2] = { false, false };
 
-    const int lambdaTab[3] = { 1, 16, 256 };                       // (int)x265_lambda_tab[X265_LOOKAHEAD_QP], constants.cpp
-    const int lambda = lambdaTab[(p->depth - 8) / 2];
-    const float epsilon = 1.f / 128.f;
-    int chromaDenom = 7, lumaDenom = 7, denom;
-    int numpixels[3];
-    const int w16 = ((p->pic_width + 15) >> 4) << 4, h16 = ((p->pic_height + 15) >> 4) << 4;
-    numpixels[0] = w16 * h16;
-    numpixels[1] = numpixels[2] = numpixels[0] >> 2;
+    const int lookaheadLambda[3] = { 1, 16, 256 };                 // (int)x265_lambda_tab[X265_LOOKAHEAD_QP] at 8 / 10 / 12 bits (constants.cpp)
+    const int lambda = lookaheadLambda[(p->depth - 8) / 2];
+    const int lumaSamples = (((p->pic_width + 15) >> 4) << 4) * (((p->pic_height + 15) >> 4) << 4);
+    const int samples[3] = { lumaSamples, lumaSamples >> 2, lumaSamples >> 2 };
+    int log2dLuma = 7, log2dChroma = 7;                            // the denominators carry over from list 0 to list 1 (:253, :487-488)
     memset(p->weights, 0, 2 * 3 * 4 * sizeof(int32_t));
     memset(p->denoms, 0, 4 * sizeof(int32_t));
 
     for (int list = 0; list < p->nlists; list++)
     {
         const x265hip_weight_analyse_ref& R = p->ref[list];
-        WaWeight weights[3];
-        float guessScale[3], fencMean[3], refMean[3];
-        for (int plane = 0; plane < 3; plane++)
-        {
-            weights[plane] = { 0, 1, 0, 0 };
-            const uint64_t fencVar = p->wp_ssd[plane] + !R.wp_ssd[plane];
-            const uint64_t refVar = R.wp_ssd[plane] + !R.wp_ssd[plane];
-            guessScale[plane] = std::sqrt((float)fencVar / refVar);
-            fencMean[plane] = (float)p->wp_sum[plane] / (numpixels[plane]) / (1 << (p->depth - 8));
-            refMean[plane] = (float)R.wp_sum[plane] / (numpixels[plane]) / (1 << (p->depth - 8));
-        }
-        while (!list && chromaDenom > 0)
-        {
-            const float thresh = 127.f / (1 << chromaDenom);
-            if (guessScale[1] < thresh && guessScale[2] < thresh) break;
-            chromaDenom--;
-        }
-        weights[1] = { 0, 1 << chromaDenom, chromaDenom, 0 };
-        weights[2] = { 0, 1 << chromaDenom, chromaDenom, 0 };
+        Brightness b[3];
+        for (int c = 0; c < 3; c++) b[c].measure(p->wp_ssd[c], R.wp_ssd[c], p->wp_sum[c], R.wp_sum[c], samples[c], p->depth);
+        if (!list)      // the chroma denominator both chroma ratios fit 7 bits with (:280-286)
+            while (log2dChroma > 0 && !(b[1].ratio < 127.f / (1 << log2dChroma) && b[2].ratio < 127.f / (1 << log2dChroma))) log2dChroma--;
+        Gain g[3] = { { 0, 1, 0, 0 }, unity(log2dChroma), unity(log2dChroma) };
 
-        bool refUp = false;
+        bool refOnDevice = false;
         uint8_t* dRef[4] = {};
         const int32_t* mvs = nullptr;
-        for (int plane = 0; plane < 3; plane++)
-        {
-            denom = plane ? chromaDenom : lumaDenom;
-            if (plane && !weights[0].present) break;
-            if (std::fabs(refMean[plane] - fencMean[plane]) < 0.5f && std::fabs(1.f - guessScale[plane]) < epsilon) { weights[plane] = { 0, 1 << denom, denom, 0 }; continue; }
-            if (plane)
-            {
-                const int scale = std::min(255, std::max(0, (int)(guessScale[plane] * (1 << denom) + 0.5f)));
-                if (scale > 127) continue;
-                weights[plane].weight = scale;
-            }
-            else
-            {
-                weights[0].offset = 0; weights[0].denom = denom; weights[0].weight = (int)(guessScale[0] * (1 << denom) + 0.5f);       // setFromWeightAndOffset, slice.h:304-316
-                while (!list && weights[0].denom > 0 && weights[0].weight > 127) { weights[0].denom--; weights[0].weight >>= 1; }
-                weights[0].weight = std::min(weights[0].weight, 127);
-            }
-            int mindenom = weights[plane].denom, minscale = weights[plane].weight, minoff = 0;
-            if (!plane) mvs = R.mvs;
 
-            // ---- the plane pair on the device
-            const uint8_t* dOrig; const uint8_t* dFref; long strideB; int width, height;
-            if (!plane)
+        // the plane pair of colour plane c on the device - the reference's plane motion-compensated with the lookahead's vectors when it has them
+        // (:336-400) - as (source, prediction, byte pitch, measured width / height)
+        struct PlanePair { const uint8_t* cur; const uint8_t* pred; long pitchB; int w, h; };
+        auto stage = [&](int c, PlanePair& pp) -> int
+        {
+            if (!c)
             {
                 if (!dCur)
                 {
-                    rc = lowres_plane(p->lowres, p->plane_key, oCur, &dCur);
-                    if (rc) return rc;
+                    int r = lowres_plane(p->lowres, p->plane_key, oCur, &dCur);
+                    if (r) return r;
                     if (up(oIntra, p->intra_cost, (size_t)n * 4)) return X265HIP_ENODEV;
                 }
-                if (!refUp)
+                if (!refOnDevice)
                 {
-                    for (int k = 0; k < (mvs ? 4 : 1); k++) { rc = lowres_plane(R.lowres[k], R.plane_key, oRef[list][k], &dRef[k]); if (rc) return rc; }
+                    for (int k = 0; k < (mvs ? 4 : 1); k++) { int r = lowres_plane(R.lowres[k], R.plane_key, oRef[list][k], &dRef[k]); if (r) return r; }
                     if (mvs && up(oMvs[list], mvs, (size_t)n * 8)) return X265HIP_ENODEV;
-                    refUp = true;
+                    refOnDevice = true;
                 }
-                dOrig = dCur; dFref = dRef[0]; strideB = (long)p->lowres_stride * bpp; width = lw; height = lh;
+                pp = { dCur, dRef[0], (long)p->lowres_stride * bpp, lw, lh };
                 if (mvs)
                 {
                     WaMcLumaArgs m;
                     for (int k = 0; k < 4; k++) m.plane[k] = dRef[k];
-                    m.out = d + oMc; m.strideB = strideB; m.width = lw; m.lines = lh; m.mvs = (const int32_t*)(d + oMvs[list]);
-                    const unsigned g = (unsigned)(((long)n * 64 + 255) / 256);
-                    if (bpp == 1) hipLaunchKernelGGL(wa_mc_luma_kernel<uint8_t>, dim3(g), dim3(256), 0, s, m);
-                    else hipLaunchKernelGGL(wa_mc_luma_kernel<uint16_t>, dim3(g), dim3(256), 0, s, m);
-                    dFref = d + oMc;
+                    m.out = d + oMc; m.strideB = pp.pitchB; m.width = lw; m.lines = lh; m.mvs = (const int32_t*)(d + oMvs[list]);
+                    const unsigned grid = (unsigned)(((long)n * 64 + 255) / 256);
+                    if (bpp == 1) hipLaunchKernelGGL(wa_mc_luma_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, m);
+                    else hipLaunchKernelGGL(wa_mc_luma_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, m);
+                    pp.pred = d + oMc;
                 }
+                return 0;
+            }
+            const size_t o = oRefC[list][c - 1];
+            if (up(o, (const uint8_t*)(c == 1 ? R.cb : R.cr) - corg, cplaneBytes)) return X265HIP_ENODEV;
+            if (!curChromaUp[c - 1])                                // the current picture's chroma: only the measured area is read
+            {
+                if (up(c == 1 ? oCb : oCr, c == 1 ? p->cb : p->cr, (size_t)p->stride_c * chh * bpp)) return X265HIP_ENODEV;
+                curChromaUp[c - 1] = true;
+            }
+            pp = { d + (c == 1 ? oCb : oCr), d + o + corg, (long)p->stride_c * bpp, cw, chh };
+            if (mvs)
+            {
+                WaMcChromaArgs m;
+                m.src = pp.pred; m.out = d + oMc; m.strideB = pp.pitchB; m.width = cw; m.height = chh; m.lowresWidthInCU = lw >> 3; m.lowresHeightInCU = lh >> 3;
+                m.depth = p->depth; m.mvs = (const int32_t*)(d + oMvs[list]);
+                const unsigned grid = (unsigned)(((long)(cw >> 3) * (chh >> 3) * 64 + 255) / 256);
+                if (bpp == 1) hipLaunchKernelGGL(wa_mc_chroma_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, m);
+                else hipLaunchKernelGGL(wa_mc_chroma_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, m);
+                pp.pred = d + oMc;
+            }
+            return 0;
+        };
+
+        for (int c = 0; c < 3; c++)
+        {
+            if (c && !g[0].on) break;                               // chroma is only weighted beside a weighted luma (:296-298)
+            const int log2dPlane = c ? log2dChroma : log2dLuma;
+            if (b[c].flat()) { g[c] = unity(log2dPlane); continue; }
+
+            // the seed: the energy ratio as a multiplier (:311-330)
+            int seedMul, seedLog2d = log2dPlane;
+            if (c)
+            {
+                seedMul = clampi((int)(b[c].ratio * (1 << log2dPlane) + 0.5f), 0, 255);
+                if (seedMul > 127) continue;                        // does not fit the header: the plane keeps unity
+                g[c].mul = seedMul;                                 // (what a later copy between the chroma planes would carry, :473-480)
             }
             else
             {
-                const void* hsrc = plane == 1 ? R.cb : R.cr;
-                const size_t o = oRefC[list][plane - 1];
-                if (up(o, (const uint8_t*)hsrc - corg, cplaneBytes)) return X265HIP_ENODEV;
-                if (!curChromaUp[plane - 1])                     // the current picture's chroma: only the measured area is read
-                {
-                    if (up(plane == 1 ? oCb : oCr, plane == 1 ? p->cb : p->cr, (size_t)p->stride_c * chh * bpp)) return X265HIP_ENODEV;
-                    curChromaUp[plane - 1] = true;
-                }
-                dOrig = d + (plane == 1 ? oCb : oCr); dFref = d + o + corg; strideB = (long)p->stride_c * bpp; width = cw; height = chh;
-                if (mvs)
-                {
-                    WaMcChromaArgs m;
-                    m.src = dFref; m.out = d + oMc; m.strideB = strideB; m.width = cw; m.height = chh; m.lowresWidthInCU = lw >> 3; m.lowresHeightInCU = lh >> 3;
-                    m.depth = p->depth; m.mvs = (const int32_t*)(d + oMvs[list]);
-                    const unsigned g = (unsigned)(((long)(cw >> 3) * (chh >> 3) * 64 + 255) / 256);
-                    if (bpp == 1) hipLaunchKernelGGL(wa_mc_chroma_kernel<uint8_t>, dim3(g), dim3(256), 0, s, m);
-                    else hipLaunchKernelGGL(wa_mc_chroma_kernel<uint16_t>, dim3(g), dim3(256), 0, s, m);
-                    dFref = d + oMc;
-                }
+                seedMul = (int)(b[0].ratio * (1 << log2dPlane) + 0.5f);                     // WeightParam::setFromWeightAndOffset, slice.h:304-316
+                while (!list && seedLog2d > 0 && seedMul > 127) { seedLog2d--; seedMul >>= 1; }
+                seedMul = seedMul < 127 ? seedMul : 127;
+                g[0] = { g[0].on, seedMul, seedLog2d, 0 };
+                mvs = R.mvs;                                        // from the luma plane on, the list's lookahead vectors compensate the reference (:332-334)
             }
-            // ---- every pair the scan of :409-446 could visit (its early break only skips pairs), plus the unweighted plane
-            int32_t cand[64][4];
-            int ncand = 0;
-            cand[ncand][0] = 0; cand[ncand][1] = 1; cand[ncand][2] = 0; cand[ncand][3] = 0; ncand++;
-            auto cand_index = [&](int scale, int offv) -> int
-            {
-                for (int i = 1; i < ncand; i++) if (cand[i][1] == scale && cand[i][3] == offv) return i;
-                cand[ncand][0] = 1; cand[ncand][1] = scale; cand[ncand][2] = mindenom; cand[ncand][3] = offv;
-                return ncand++;
-            };
-            const int scaleDist = 4, offsetDist = 2;
-            const int startScale = std::min(127, std::max(0, minscale - scaleDist)), endScale = std::min(127, std::max(0, minscale + scaleDist));
-            struct Step { int curScale, startOffset, endOffset; };
-            Step steps[16]; int nsteps = 0;
-            for (int scale = startScale; scale <= endScale; scale++)
-            {
-                const int deltaWeight = scale - (1 << mindenom);
-                if (deltaWeight > 127 || deltaWeight <= -128) continue;
-                int curScale = scale;
-                int curOffset = (int)(fencMean[plane] - refMean[plane] * curScale / (1 << mindenom) + 0.5f);
-                if (curOffset < -128 || curOffset > 127)
-                {
-                    curOffset = std::min(127, std::max(-128, curOffset));
-                    curScale = (int)((1 << mindenom) * (fencMean[plane] - curOffset) / refMean[plane] + 0.5f);
-                    curScale = std::min(127, std::max(0, curScale));
-                }
-                const int startOffset = std::min(127, std::max(-128, curOffset - offsetDist)), endOffset = std::min(127, std::max(-128, curOffset + offsetDist));
-                steps[nsteps++] = { curScale, startOffset, endOffset };
-                for (int o2 = startOffset; o2 <= endOffset; o2++) cand_index(curScale, o2);
-            }
-            if (up(oCand, cand, (size_t)ncand * 16)) return X265HIP_ENODEV;
+
+            PlanePair pp;
+            rc = stage(c, pp);
+            if (rc) return rc;
+
+            // every trial the walk could visit + the unweighted plane, scored by one launch (weightCost, :172-217, per candidate)
+            TrialTable trials;
+            trials.build(seedMul, seedLog2d, b[c]);
+            if (up(oCand, trials.cand, (size_t)trials.ncand * 16)) return X265HIP_ENODEV;
             X265HIP_TRY(hipMemsetAsync(d + oCost, 0, 64 * 4, s));
-            WaCostArgs c;
-            c.fenc = dOrig; c.ref = dFref; c.strideB = strideB; c.width = width; c.height = height; c.depth = p->depth;
-            c.intraCost = plane ? nullptr : (const int32_t*)(d + oIntra); c.cand = (const int32_t*)(d + oCand); c.cost = (uint32_t*)(d + oCost);
-            const int nblk = (width >> 3) * (height >> 3);
-            const dim3 grid((unsigned)((nblk + 255) / 256), (unsigned)ncand);
-            if (bpp == 1) hipLaunchKernelGGL(wa_cost_kernel<uint8_t>, grid, dim3(256), 0, s, c);
-            else hipLaunchKernelGGL(wa_cost_kernel<uint16_t>, grid, dim3(256), 0, s, c);
+            WaCostArgs ca;
+            ca.fenc = pp.cur; ca.ref = pp.pred; ca.strideB = pp.pitchB; ca.width = pp.w; ca.height = pp.h; ca.depth = p->depth;
+            ca.intraCost = c ? nullptr : (const int32_t*)(d + oIntra); ca.cand = (const int32_t*)(d + oCand); ca.cost = (uint32_t*)(d + oCost);
+            const dim3 grid((unsigned)(((pp.w >> 3) * (pp.h >> 3) + 255) / 256), (unsigned)trials.ncand);
+            if (bpp == 1) hipLaunchKernelGGL(wa_cost_kernel<uint8_t>, grid, dim3(256), 0, s, ca);
+            else hipLaunchKernelGGL(wa_cost_kernel<uint16_t>, grid, dim3(256), 0, s, ca);
             X265HIP_TRY(hipGetLastError());
-            uint32_t cost[64];
-            X265HIP_TRY(hipMemcpyAsync(cost, d + oCost, (size_t)ncand * 4, hipMemcpyDeviceToHost, s));
+            uint32_t score[64];
+            X265HIP_TRY(hipMemcpyAsync(score, d + oCost, (size_t)trials.ncand * 4, hipMemcpyDeviceToHost, s));
             X265HIP_TRY(hipStreamSynchronize(s));
 
-            // ---- the reference's scan, replayed on the scores
-            const uint32_t origscore = cost[0];
-            if (!origscore) { weights[plane] = { 0, 1 << denom, denom, 0 }; continue; }
-            uint32_t minscore = origscore;
-            bool bFound = false;
-            for (int k = 0; k < nsteps; k++)
-            {
-                const Step& st = steps[k];
-                for (int o2 = st.startOffset; o2 <= st.endOffset; o2++)
-                {
-                    const WaWeight wsp = { 1, st.curScale, mindenom, o2 };
-                    const uint32_t sc = cost[cand_index(st.curScale, o2)] + (uint32_t)wa_slice_header_cost(wsp, lambda, !!plane);
-                    if (sc < minscore) { minscore = sc; minscale = st.curScale; minoff = o2; bFound = true; }
-                    if (minoff == st.startOffset && o2 != st.startOffset) break;
-                }
+            // the verdict (:448-470)
+            const uint32_t plain = score[0];
+            if (!plain) { g[c] = unity(log2dPlane); continue; }     // a perfect prediction already
+            int mul = seedMul, add = 0, log2d = seedLog2d;
+            uint32_t best = plain;
+            const bool improved = trials.walk(score, lambda, c != 0, mul, add, best);
+            if (!c && !list && log2d > 0 && !(mul & 1))
+            {   // list 0's luma gain in lowest terms: common factors of two leave the multiplier and the denominator (:452-460)
+                const int twos = mul ? __builtin_ctz((unsigned)mul) : 32;
+                const int drop = twos < log2d ? twos : log2d;
+                log2d -= drop;
+                mul >>= drop;
             }
-            if (!(plane || list))
-            {
-                if (mindenom > 0 && !(minscale & 1))
-                {
-                    const int idx = minscale ? __builtin_ctz((unsigned)minscale) : 32;
-                    const int shift = std::min(idx, mindenom);
-                    mindenom -= shift;
-                    minscale >>= shift;
-                }
-            }
-            if (!bFound || (minscale == (1 << mindenom) && minoff == 0) || (float)minscore / origscore > 0.998f) weights[plane] = { 0, 1 << denom, denom, 0 };
-            else weights[plane] = { 1, minscale, mindenom, minoff };
+            const bool worthIt = improved && !(mul == (1 << log2d) && add == 0) && !((float)best / plain > 0.998f);
+            g[c] = worthIt ? Gain{ 1, mul, log2d, add } : unity(log2dPlane);
         }
-        if (weights[0].present && weights[1].present != weights[2].present)
+        if (g[0].on && g[1].on != g[2].on)                          // 4:2:0 signals the two chroma planes together (:472-481)
         {
-            if (weights[1].present) weights[2] = weights[1];
-            else weights[1] = weights[2];
+            if (g[1].on) g[2] = g[1];
+            else g[1] = g[2];
         }
-        lumaDenom = weights[0].denom;
-        chromaDenom = weights[1].denom;
-        for (int plane = 0; plane < 3; plane++)
+        log2dLuma = g[0].log2d;
+        log2dChroma = g[1].log2d;
+        for (int c = 0; c < 3; c++)
         {
-            int32_t* o = p->weights + (list * 3 + plane) * 4;
-            o[0] = weights[plane].present; o[1] = weights[plane].weight; o[2] = weights[plane].denom; o[3] = weights[plane].offset;
+            int32_t* o = p->weights + (list * 3 + c) * 4;
+            o[0] = g[c].on; o[1] = g[c].mul; o[2] = g[c].log2d; o[3] = g[c].add;
         }
-        p->denoms[list * 2] = lumaDenom; p->denoms[list * 2 + 1] = chromaDenom;
+        p->denoms[list * 2] = log2dLuma; p->denoms[list * 2 + 1] = log2dChroma;
     }
     return 0;
 }

@@ -674,6 +674,49 @@ static int aq_exp2fix8(double x)
     return (lut[i & 63] + 256) << (i >> 6) >> 8;
 }
 
+// Energy -> QP offset, the host half of the adaptive-quantisation pass.  x265 has two families (encoder/slicetype.cpp:540-633):
+//   * the fixed curve of --aq-mode 1: a group's offset is proportional to log2 of its AC energy measured from a pivot that depends on the group
+//     size and the bit depth (:606-610);
+//   * the picture-adaptive curves of --aq-mode 2 / 3: every group gets the tenth root of its depth-normalised energy, the picture's first and
+//     second moment of those roots place the curve (:566-583), mode 3 adds a bias towards dark / flat groups (:590-594).
+// Each family is a small object with the pass(es) it needs; the arithmetic keeps the reference's types (float constants inside double
+// expressions, sums in block order) because the offsets must come out bit-identical.
+namespace {
+
+struct FixedLogCurve                    // --aq-mode 1
+{
+    double gain; float pivot;
+    FixedLogCurve(double aqStrength, int qgSize, int depth) : gain(aqStrength * 1.0397f), pivot((qgSize == 8 ? 11.427f : 14.427f) + 2 * (depth - 8)) {}
+    double offset(uint32_t energy) const { return gain * (std::log2((double)(energy > 1 ? energy : 1)) - pivot); }
+};
+
+struct PictureAdaptiveCurve             // --aq-mode 2 (biased = false) / 3 (biased = true)
+{
+    double depthScale, gain = 0, centre = 0, bias = 0;
+    float knee;
+    bool biased;
+    PictureAdaptiveCurve(int qgSize, int depth, bool withBias) : depthScale(1.f / (1 << (2 * (depth - 8)))), knee(qgSize == 8 ? 8.f : 11.f), biased(withBias) {}
+    // first pass: the roots themselves (left in `root`), their two moments -> where the curve sits for this picture
+    void place(const uint32_t* energy, double* root, int n, double aqStrength)
+    {
+        double sum = 0, sumSq = 0;
+        for (int i = 0; i < n; i++)
+        {
+            const double r = std::pow(energy[i] * depthScale + 1, 0.1);
+            root[i] = r;
+            sum += r;
+            sumSq += r * r;
+        }
+        const double mean = sum / n, meanSq = sumSq / n;
+        gain = aqStrength * mean;
+        centre = mean - 0.5f * (meanSq - knee) / mean;
+        bias = aqStrength;
+    }
+    double offset(double r) const { return biased ? gain * (r - centre) + bias * (1.f - knee / (r * r)) : gain * (r - centre); }
+};
+
+} // namespace
+
 extern "C" int x265hip_aq_offsets(const x265hip_aq_offsets_params* p)
 {
     if (!p || !p->energy || !p->qp_aq_offset || !p->inv_qscale) { set_error("aq_offsets: NULL operand"); return X265HIP_EINVAL; }
@@ -682,46 +725,24 @@ extern "C" int x265hip_aq_offsets(const x265hip_aq_offsets_params* p)
     if (p->aq_mode < 0 || p->aq_mode > 3) { set_error("aq_offsets: aq_mode %d (0..3; the edge mode and hevcAq are not covered)", p->aq_mode); return X265HIP_EINVAL; }
     if (p->nblocks <= 0) { set_error("aq_offsets: nblocks %d", p->nblocks); return X265HIP_EINVAL; }
     const int n = p->nblocks;
-    double* qp = p->qp_aq_offset;
+    double* out = p->qp_aq_offset;
     if (p->aq_mode == 0 || p->aq_strength == 0)
-    {
-        for (int i = 0; i < n; i++) { qp[i] = 0; p->inv_qscale[i] = 256; }
+    {   // adaptive quantisation off: neutral offsets, unit scale factors (:517-537)
+        for (int i = 0; i < n; i++) { out[i] = 0; p->inv_qscale[i] = 256; }
         return 0;
     }
-    const float modeOneConst = p->qg_size == 8 ? 11.427f : 14.427f, modeTwoConst = p->qg_size == 8 ? 8.f : 11.f;
-    double avg_adj_pow2 = 0, avg_adj = 0, qp_adj = 0, bias_strength = 0.f, strength = 0.f;
-    if (p->aq_mode == 2 || p->aq_mode == 3)
+    if (p->aq_mode == 1)
     {
-        const double bit_depth_correction = 1.f / (1 << (2 * (p->depth - 8)));
-        for (int i = 0; i < n; i++)
-        {
-            qp_adj = std::pow(p->energy[i] * bit_depth_correction + 1, 0.1);
-            qp[i] = qp_adj;
-            avg_adj += qp_adj;
-            avg_adj_pow2 += qp_adj * qp_adj;
-        }
-        avg_adj /= n;
-        avg_adj_pow2 /= n;
-        strength = p->aq_strength * avg_adj;
-        avg_adj = avg_adj - 0.5f * (avg_adj_pow2 - modeTwoConst) / avg_adj;
-        bias_strength = p->aq_strength;
+        const FixedLogCurve curve(p->aq_strength, p->qg_size, p->depth);
+        for (int i = 0; i < n; i++) out[i] = curve.offset(p->energy[i]);
     }
     else
-        strength = p->aq_strength * 1.0397f;
-    for (int i = 0; i < n; i++)
     {
-        if (p->aq_mode == 3)
-        {
-            qp_adj = qp[i];
-            qp_adj = strength * (qp_adj - avg_adj) + bias_strength * (1.f - modeTwoConst / (qp_adj * qp_adj));
-        }
-        else if (p->aq_mode == 2)
-            qp_adj = strength * (qp[i] - avg_adj);
-        else
-            qp_adj = strength * (std::log2((double)(p->energy[i] > 1 ? p->energy[i] : 1)) - (modeOneConst + 2 * (p->depth - 8)));
-        qp[i] = qp_adj;
-        p->inv_qscale[i] = aq_exp2fix8(qp_adj);
+        PictureAdaptiveCurve curve(p->qg_size, p->depth, p->aq_mode == 3);
+        curve.place(p->energy, out, n, p->aq_strength);
+        for (int i = 0; i < n; i++) out[i] = curve.offset(out[i]);
     }
+    for (int i = 0; i < n; i++) p->inv_qscale[i] = aq_exp2fix8(out[i]);
     return 0;
 }
 
