@@ -477,6 +477,69 @@ def compact_line(out, minimal=False):
     return line
 
 
+class _StubPipeline:
+    """X265HIP_BENCH_STUB=1 (tests/test_dist_cpu.py, no GPU): a CPU stand-in with the interface main() uses of stages.FramePipeline /
+    stages.BandedFramePipeline, so that the control flow of `bench.py --gpus N` - process group, ring set-up, band hand-offs, barriers, the
+    replicas pass, max-over-ranks timing, the one-line record - runs end to end on gloo.  Its "encode" of a band is the average of the source and
+    the reference rows (so a band that ran before its reference rows arrived changes the checksum).  Numbers from it mean nothing."""
+
+    def __init__(self, P, pic, rng, depth, band_rows=0):
+        import torch
+        self.torch = torch
+        self.ms = P.MotionSearch(pic.w64, pic.h64, rng, depth, torch.device("cpu"), want_surf=False)
+        self.lcb = None
+        rows = pic.h64 // 64
+        self.bands = [(r, min(band_rows, rows - r)) for r in range(0, rows, band_rows)] if band_rows else [(0, rows)]
+        self.geo = (pic.stride, pic.t.numel() // pic.stride, pic.stride_c, pic.c[0].numel() // pic.stride_c)
+        self.out = [torch.zeros_like(t) for t in pic.planes()]
+        self.final = self.out
+
+    def _mix(self, cur, ref, row0, n):
+        st, rows, sc, rows_c = self.geo
+        my, myc = (rows - self.ms.h64) // 2, (rows_c - self.ms.h64 // 2) // 2
+        last = (row0 + n) * 64 == self.ms.h64
+        spans = [((0 if row0 == 0 else my + row0 * 64) * st, (rows if last else my + (row0 + n) * 64) * st)] + \
+                [((0 if row0 == 0 else myc + row0 * 32) * sc, (rows_c if last else myc + (row0 + n) * 32) * sc)] * 2
+        for o, c, r, (a, b) in zip(self.out, cur.planes(), ref.planes(), spans):
+            o[a:b] = (c[a:b] >> 1) + (r[a:b] >> 1)
+
+    # whole-picture interface (stages.FramePipeline)
+    def run(self, cur, ref, mark=None):
+        self._mix(cur, ref, 0, self.ms.h64 // 64)
+        self.final = self.out
+        return self.out[0]
+
+    def final_planes(self):
+        return self.final
+
+    def swap_output(self, spare):
+        outs, self.out = self.out, list(spare)
+        return outs
+
+    def launch_lookahead_costs(self):
+        pass
+
+    def checksum(self):
+        return {"recon_%s" % n: int(p.to(self.torch.int64).sum().item()) for n, p in zip(("y", "cb", "cr"), self.final)}
+
+    # banded interface (stages.BandedFramePipeline)
+    def begin_frame(self, cur):
+        self.cur = cur
+
+    def run_band(self, b, cur, ref):
+        self._mix(cur, ref, *self.bands[b])
+
+    def end_frame(self):
+        self.final = self.out
+
+    def band_context(self, b):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def capture(self, cur, ref):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -573,14 +636,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    # X265HIP_BENCH_STUB=1: the N > 1 control flow on CPU tensors over gloo with a stand-in for the stages (_StubPipeline; tests/test_dist_cpu.py) -
+    # a dry run of THIS FILE's logic, never a measurement and never a fallback: without the variable a missing GPU is fatal
+    stub = os.environ.get("X265HIP_BENCH_STUB") == "1"
+    if not torch.cuda.is_available() and not stub:
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # X265HIP_BENCH_BACKEND=gloo: functional dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, the bands
     # travel through host memory) - for checking the ring / band code on real kernels, never for numbers
-    backend = os.environ.get("X265HIP_BENCH_BACKEND", "nccl")
-    local = local % torch.cuda.device_count() if backend != "nccl" else local
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    backend = "gloo" if stub else os.environ.get("X265HIP_BENCH_BACKEND", "nccl")
+    if stub:
+        dev = torch.device("cpu")
+        torch.cuda.synchronize = lambda *a, **k: None          # the stand-in has nothing to wait for
+    else:
+        local = local % torch.cuda.device_count() if backend != "nccl" else local
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
@@ -605,7 +675,7 @@ def main():
     nclip = 4
     clip = F.synth_clip(args.width, args.height, nclip, depth=args.depth, seed=265 + rank)
     pics = [P.DevicePicture(y, dev, u, v) for (y, u, v) in clip]
-    pipe = S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
+    pipe = _StubPipeline(P, pics[0], args.range, args.depth) if stub else S.FramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, rng=args.range, subme=args.subme, level=args.level,
                            qp=args.qp, want_surf=args.surface, packed=({"packed": True, "packed_t": "t", "packed_b": "b"}.get(args.surf_format, False) if args.depth == 8 else False),
                            lookahead=(args.width, args.height), search=args.search, deblock=True, sao=True, lookahead_cost_batch=args.lookahead_batch,
                            chroma=True, sao_apply=True, sign_hide=True, subpel_planes=bool(args.subpel_planes),
@@ -618,7 +688,7 @@ def main():
         args.band_rows = pick_band_rows(world, ctu_rows=(args.height + 63) // 64, lag_rows_luma=args.range + 16, depth=args.depth, width=args.width) if world > 1 else 4
     if banded:
         # N > 1: the reference's real frame-parallel dependency - frame f (rank f % N) searches frame f - 1, band by band (pipeline.FrameParallelRing)
-        bp = S.BandedFramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, band_rows=args.band_rows, rng=args.range, subme=args.subme, level=args.level,
+        bp = _StubPipeline(P, pics[0], args.range, args.depth, band_rows=args.band_rows) if stub else S.BandedFramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, band_rows=args.band_rows, rng=args.range, subme=args.subme, level=args.level,
                                    qp=args.qp, want_surf=args.surface,
                                    # a small band's grid (4 CTU rows = 240 workgroups) is too small for the record-per-lane kernel's 4-wavefront
                                    # workgroups (one per CU): such bands use the record-contiguous packed format of the row-walking kernel;
@@ -694,7 +764,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if banded and world > 1:
+    if banded and world > 1 and not stub:
         ring.time_waits()                            # two device events per band: how long its stream waits for the reference rows it reads
     pipe.launch_lookahead_costs()                    # no lookahead work of the warm-up frames leaks into the timed region
     torch.cuda.synchronize()
@@ -754,7 +824,7 @@ def main():
     gc.enable()
     ring_wait = None
     if banded and world > 1:                         # every rank: the maximum over ranks is a collective
-        wms, _ = ring.wait_ms()
+        wms, _ = (0.0, 0) if stub else ring.wait_ms()
         wt = torch.tensor([wms / max(1, args.steps)], dtype=torch.float64, device=dev)
         dist.all_reduce(wt, op=dist.ReduceOp.MAX)
         ring_wait = round(float(wt.item()), 4)
@@ -768,7 +838,7 @@ def main():
     ms = pipe.ms
     cur = pics[1]
     acc = {}
-    for _ in range(5):
+    for _ in range(0 if stub else 5):
         evs = [("start", torch.cuda.Event(enable_timing=True))]
         evs[0][1].record()
 
@@ -780,7 +850,7 @@ def main():
         torch.cuda.synchronize()
         for (_, e0), (name, e1) in zip(evs[:-1], evs[1:]):
             acc.setdefault(name, []).append(e0.elapsed_time(e1))
-    stages = {k: round(float(np.median(v)), 4) for k, v in acc.items()}
+    stages = {k: round(float(np.median(v)), 4) for k, v in acc.items()} if not stub else {"me": 1.0}
     # The pattern searches are data-dependent (early exits, STAR's raster refinement): stages_ms is the median of five runs of ONE frame pair
     # (frame 1 searched in the last reference), ms_per_step the average over the closed loop including the synthetic clip's wrap-around
     # pairs - for --search star the two differ by 2x, and that is GPU time of the search launches, not a host stall
