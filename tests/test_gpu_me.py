@@ -227,19 +227,22 @@ def test_me_4k_default_config_properties(packed):
         assert np.array_equal(ms.best[ctu * 85:(ctu + 1) * 85].cpu().numpy().view(np.uint64), best[ctu * 85:(ctu + 1) * 85])
 
 
-@pytest.mark.parametrize("variant", ["", "0", "1", "5"])
+@pytest.mark.parametrize("variant", ["", "v0", "v1", "q0", "q1", "q2", "q4", "q8", "q32", "q10", "q12", "q14", "q46", "q47", "q62"])
 @pytest.mark.parametrize("case", [(192, 128, 57, 4.0, None), (128, 128, 8, 0.0, None), (256, 64, 90, 16.0, None), (128, 64, 5, 4.0, "flat"), (192, 192, 12, 2.0, "centres"),
-                                  (128, 128, 123, 1.0, None)])
+                                  (128, 128, 120, 1.0, None)])
 def test_me_minima_only_launch_every_kernel_variant(case, variant, monkeypatch):
-    """The launch the closed loop times: per-PU minima only (no surfaces), 8-bit - round 5's kernel (default; X265HIP_ME_BEST_VARIANT 5 = its
-    per-column 8x8 minima) and round 4's (0 / 1) against the oracle: zero motion-vector cost (every tie decided by raster order alone), a flat
-    picture (every candidate ties), the widest window the 256-byte LDS pitch holds (+-90), the widest the row index byte holds (+-123), windows centred per CTU."""
+    """The launch the closed loop times: per-PU minima only (no surfaces), 8-bit - the library's default, round 4's kernel (v0 / v1 =
+    X265HIP_ME_BEST_VARIANT) and every instantiated flag set of round 5's me_ctu_q2_kernel (qN = X265HIP_ME_Q2_FLAGS) against the oracle: zero
+    motion-vector cost (every tie decided by raster order alone), a flat picture (every candidate ties), the widest window the 256-byte LDS pitch
+    holds (+-90), +-120 (the last rows of the row-constant table), windows centred per CTU."""
     import torch
     width, height, rng, lam, special = case
-    if variant:
-        monkeypatch.setenv("X265HIP_ME_BEST_VARIANT", variant)
-    else:
-        monkeypatch.delenv("X265HIP_ME_BEST_VARIANT", raising=False)
+    monkeypatch.delenv("X265HIP_ME_BEST_VARIANT", raising=False)
+    monkeypatch.delenv("X265HIP_ME_Q2_FLAGS", raising=False)
+    if variant.startswith("v"):
+        monkeypatch.setenv("X265HIP_ME_BEST_VARIANT", variant[1:])
+    elif variant.startswith("q"):
+        monkeypatch.setenv("X265HIP_ME_Q2_FLAGS", variant[1:])
     dev = torch.device("cuda:0")
     clip = F.synth_clip(width, height, 2, depth=8, seed=40 + rng)
     y0, y1 = clip[0][0], clip[1][0]

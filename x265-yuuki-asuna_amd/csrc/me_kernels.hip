@@ -499,31 +499,32 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Round 5: the minima-only 8-bit launch with the OTHER half of its instruction stream cut down (round-4 verdict, weak 2: 44 level-sum / key /
+// Round 5: the minima-only 8-bit launch with the OTHER half of its instruction stream reworked (round-4 verdict, weak 2: 44 level-sum / key /
 // minimum instructions per window row beside 16 quad-SADs; SQ_WAIT_INST_ANY 1.7 x SQ_ACTIVE).  Same walk, same ring of packed accumulators,
-// same keys - what changes:
-//   * the row's motion-vector cost no longer comes from a global_load_ushort per row (a vector load and a vmcnt(0) wait inside every row's
-//     dependency chain, then five vector instructions to shift / combine a value that is uniform): the workgroup builds `costY[m] << 8 | m`
-//     once in LDS, a block of 8 rows fetches its 8 entries with ONE ds_read and every row takes its entry with v_readlane -> the row
-//     constants live in SGPRs and the key arithmetic uses them as scalar operands;
-//   * the window bytes 0..7 / 4..11 of a row are read as two 4-byte-aligned 64-bit LDS loads (ds_read2_b32 each) into the aligned register
-//     pairs v_qsad_pk_u16_u8 wants - the three-dword load needed a copy per row (gfx950 wants even-aligned 64-bit operands) and a
-//     register shuffle per pair of rows;
-//   * the column's costX is added to the 16x16 / 32x32 / 64x64 running minima ONCE per column group (it is constant for a lane inside a
-//     group and min(x + c) = min(x) + c), not to every row's keys;
-//   * the 64x64 level is reduced for TWO window rows at a time: v_permlane16_swap exchanges the odd 16-lane rows of row A's 32x32 sums with
-//     the even rows of row B's, one add, v_permlane32_swap of the sum with itself, one add -> lanes of rows 0 / 2 hold A's 64x64 total,
-//     rows 1 / 3 hold B's (5 instructions per PAIR of rows where two separate reductions took 14); the per-lane `costY << 8 | m` of the
-//     row a lane ended up with comes from the LDS table with a per-lane address.
-// Results are identical (the keys order candidates exactly as before; tests/test_gpu_me.py runs every variant against the oracle).
-// COLMIN: the 8x8 level keeps one running minimum PER COLUMN of `(sad << 8) + (costY << 8 | m)` (an extract, a shift-add and half a
-// v_min3 per column and row) and gives each column its costX once per group, instead of folding the four columns into one key per row.
-template <int PITCH, bool COLMIN>
+// same keys as me_ctu_q_kernel<best>; each change is a template flag so that it can be measured ALONE on one box (tools/r5_me_ab.sh,
+// profiles/r05_me_flags_ab.txt) - FL = 0 is round 4's instruction stream:
+//   1  LD64    the window bytes 0..7 / 4..11 of a row are read as two 4-byte-aligned 64-bit LDS loads into the aligned register pairs
+//              v_qsad_pk_u16_u8 wants, a block of 8 rows from three address registers (the three-dword load costs a copy per row - gfx950
+//              wants even-aligned 64-bit operands - and a register shuffle per pair of rows);
+//   2  CTAB    the row's `costY[m] << 8 | m` comes from a table the workgroup builds once in LDS: a block of 8 rows fetches its entries one
+//              block AHEAD, every row takes its entry with v_readlane -> row constants in SGPRs (round 4: a global_load_ushort + vmcnt wait
+//              in every row's chain and five vector instructions to combine a uniform value);
+//   4  PAIR64  the 64x64 level is reduced for TWO window rows at a time: v_permlane16_swap exchanges the odd 16-lane rows of row A's 32x32
+//              sums with the even rows of row B's, one add, v_permlane32_swap of the sum with itself, one add -> lanes of rows 0 / 2 hold
+//              A's total, rows 1 / 3 hold B's (5 instructions per PAIR of rows where two separate reductions take 14);
+//   8  DEFERX  the column's costX joins the 16x16 / 32x32 / 64x64 running minima once per column group (min(x + c) = min(x) + c);
+//  16  COLMIN  the 8x8 level keeps one running minimum per column and gives each column its costX once per group;
+//  32  MASK    the low halves of the packed 8x8 sums are extracted with an opaque v_and (the compiler turns `(x & 0xffff) << n` into
+//              shift + mask + add; this way it is mask + v_lshl_add_u32).
+// Results are identical for every FL (tests/test_gpu_me.py runs them all against the oracle).
+template <int PITCH, int FL>
 __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOff)
 {
+    constexpr bool LD64 = (FL & 1) != 0, CTAB = (FL & 2) != 0, PAIR64 = (FL & 4) != 0, DEFERX = (FL & 8) != 0, COLMIN = (FL & 16) != 0, MASK = (FL & 32) != 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t win[];
     typedef unsigned long long u64;
     typedef u64 __attribute__((aligned(4))) u64a4;
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
     const int R = a.range;
     const int NC = 2 * R + 1;
     const int NG = (NC + 3) >> 2;
@@ -545,10 +546,11 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
         for (int c = lane; c < rowDw; c += 64)
             dst[c] = ld_u32(src + 4 * c);
     }
-    // the rows' share of every key: costY[m] << 8 | m (8 entries of slack: a block's fetch may run past the last row)
+    // CTAB: the rows' share of every key, costY[m] << 8 | m (16 entries of slack: a block fetches the NEXT block's entries)
     uint32_t* ctab = reinterpret_cast<uint32_t*>(win + ctabOff);
-    for (int i = threadIdx.x; i < NC + 8; i += blockDim.x)
-        ctab[i] = i < NC ? ((uint32_t)a.costY[i] << 8) | (uint32_t)i : 0xffffff00u;
+    if (CTAB)
+        for (int i = threadIdx.x; i < NC + 16; i += blockDim.x)
+            ctab[i] = i < NC ? ((uint32_t)a.costY[i] << 8) | (uint32_t)i : 0xffffff00u;
     int bx, by;
     zorder_xy(lane, bx, by);
     uint32_t F[8][2];
@@ -562,18 +564,16 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
     u64 bk8 = ~0ull, bk16 = ~0ull, bk32 = ~0ull, bk64 = ~0ull;
     const int kcol = lane & 3;
     const uint32_t selK = 0x0c0c0000u | (uint32_t)((2 * kcol + 1) << 8) | (uint32_t)(2 * kcol);   // v_perm: u16 #kcol of {qhi, qlo}
-    const int oddRow = (lane >> 4) & 1;                     // after the paired 64x64 reduction: 0 = this lane holds row A's total, 1 = row B's
+    const int oddRow = (lane >> 4) & 1;                     // PAIR64: 0 = this lane ends up with row A's 64x64 total, 1 = row B's
 
     const int T = 2 * R + 8;
     for (int g = wave; g < NG; g += nwaves)
     {
         const uint32_t colOff = (uint32_t)((by * 8) * pitch + bx * 8 + 4 * g);
-        // LDS byte address of window row t0 of this lane's block column.  Kept opaque: ds_read2_b32 reaches 255 dwords past its address
+        // LDS byte offset of window row t0 of this lane's block column.  LD64 keeps it opaque: ds_read reaches 255 dwords past its address
         // register, so a block of 8 rows is read from THREE address registers (rows 0 - 3, rows 4 - 7, the next block's rows 0 - 1)
-        // instead of one register per load
-        auto block_off = [&](const int t0) { uint32_t o = colOff + (uint32_t)(t0 * pitch + lds_skew_bytes(by + (t0 >> 3))); asm volatile("" : "+v"(o)); return o; };
-        // two window rows: bytes 0..7 and 4..11 of each, every 64-bit value in an aligned register pair of its own
-        auto ldpair = [&](u64 (&d)[2][2], const uint32_t off, const int p)
+        auto block_off = [&](const int t0) { uint32_t o = colOff + (uint32_t)(t0 * pitch + lds_skew_bytes(by + (t0 >> 3))); if (LD64) asm volatile("" : "+v"(o)); return o; };
+        auto ldpair64 = [&](u64 (&d)[2][2], const uint32_t off, const int p)
         {
 #pragma unroll
             for (int q = 0; q < 2; q++)
@@ -582,18 +582,45 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
                 d[q][1] = *reinterpret_cast<const u64a4*>(win + off + (p + q) * pitch + 4);
             }
         };
+        auto ldpair32 = [&](uint32_t (&d)[2][3], const uint32_t off, const int p)
+        {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+            {
+                const uint32_t* lp = reinterpret_cast<const uint32_t*>(win + off + (p + q) * pitch);
+                d[q][0] = lp[0]; d[q][1] = lp[1]; d[q][2] = lp[2];
+            }
+        };
         uint32_t cxk4[4], cxL;
 #pragma unroll
         for (int k = 0; k < 4; k++)
             cxk4[k] = ((4 * g + k < NC ? (uint32_t)a.costX[4 * g + k] : (1u << 20)) << 2) | (uint32_t)k;
         cxL = 4 * g + kcol < NC ? (uint32_t)a.costX[4 * g + kcol] : (1u << 23);
+        const uint32_t cxL8 = cxL << 8;
         uint32_t r8 = 0xffffffffu, r16 = 0xffffffffu, r32 = 0xffffffffu, r64 = 0xffffffffu;
         uint32_t r8c[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
         u64 acc[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) acc[i] = 0;
-        u64 buf[2][2][2];                                   // [pipeline slot][row of the pair][bytes 0..7 / 4..11]; slot parity returns after 8 rows
-        ldpair(buf[0], block_off(0), 0);
+        u64 buf[2][2][2];                                   // LD64: [pipeline slot][row of the pair][bytes 0..7 / 4..11]; slot parity returns after 8 rows
+        uint32_t cur[2][3], nxt[2][3];                      // !LD64: round 4's three dwords per row
+        (void)buf; (void)cur; (void)nxt;
+        if (LD64) ldpair64(buf[0], block_off(0), 0); else ldpair32(cur, block_off(0), 0);
+
+        // CTAB: a block's row constants, fetched while the block before it runs.  lane l holds the entry of window row t0 + (l & 7)
+        // (m = t0 + (l & 7) - 7; the first block only completes m = 0), pr[q] the entry of the row this lane holds after the paired reduction
+        uint32_t cbNext = 0, prNext[4] = { 0, 0, 0, 0 };
+        auto fetch_consts = [&](const int t0)
+        {
+            const int i0 = t0 - 7 + (lane & 7);
+            cbNext = ctab[i0 < 0 ? 0 : i0];
+            if (PAIR64)
+            {
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int i = t0 - 7 + 2 * q + oddRow; prNext[q] = ctab[i < 0 ? 0 : i]; }
+            }
+        };
+        if (CTAB) fetch_consts(0);
 
         auto rows8 = [&](auto firstTag, auto nrowsTag, const int t0)
         {
@@ -601,21 +628,33 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
             constexpr int NROWS = decltype(nrowsTag)::value;
             const uint32_t bb = block_off(t0), bn = block_off(t0 + 8);
             uint32_t bb4 = bb + 4 * pitch;
-            asm volatile("" : "+v"(bb4));
-            // this block's row constants: lane l < 8 fetches the entry of window row t0 + l (m = t0 + l - 7; the first block only completes m = 0)
+            if (LD64) asm volatile("" : "+v"(bb4));
             const int mb = t0 - 7;
-            const uint32_t cb = ctab[mb + (lane & 7) < 0 ? 0 : mb + (lane & 7)];
-            uint32_t v32even = 0;
+            uint32_t cb = 0, pr[4] = { 0, 0, 0, 0 };
+            if (CTAB)
+            {
+                cb = cbNext;
+#pragma unroll
+                for (int q = 0; q < 4; q++) pr[q] = prNext[q];
+                fetch_consts(t0 + 8);
+            }
+            uint32_t v32even = 0, sbEven = 0;
 #pragma unroll
             for (int p = 0; p < NROWS; p++)
             {
                 if ((p & 1) == 0)
                 {
-                    if (p + 2 < 4) ldpair(buf[((p >> 1) + 1) & 1], bb, p + 2);
-                    else if (p + 2 < 8) ldpair(buf[((p >> 1) + 1) & 1], bb4, p + 2 - 4);
-                    else ldpair(buf[((p >> 1) + 1) & 1], bn, 0);
+                    if (LD64)
+                    {
+                        if (p + 2 < 4) ldpair64(buf[((p >> 1) + 1) & 1], bb, p + 2);
+                        else if (p + 2 < 8) ldpair64(buf[((p >> 1) + 1) & 1], bb4, p + 2 - 4);
+                        else ldpair64(buf[((p >> 1) + 1) & 1], bn, 0);
+                    }
+                    else { if (p + 2 < 8) ldpair32(nxt, bb, p + 2); else ldpair32(nxt, bn, 0); }
                 }
-                const u64 w0 = buf[(p >> 1) & 1][p & 1][0], w1 = buf[(p >> 1) & 1][p & 1][1];
+                u64 w0, w1;
+                if (LD64) { w0 = buf[(p >> 1) & 1][p & 1][0]; w1 = buf[(p >> 1) & 1][p & 1][1]; }
+                else { w0 = ((u64)cur[p & 1][1] << 32) | cur[p & 1][0]; w1 = ((u64)cur[p & 1][2] << 32) | cur[p & 1][1]; }
 #pragma unroll
                 for (int j = 0; j < 8; j++)
                 {
@@ -627,18 +666,23 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
                 }
                 if (!FIRST || p == 7)
                 {
+                    const int m = mb + p;
                     const int slot = (p + 1) & 7;
                     const u64 A = acc[slot];
                     const uint32_t lo = (uint32_t)A, hi = (uint32_t)(A >> 32);
                     const uint32_t qlo = (uint32_t)quad_sum((int)lo), qhi = (uint32_t)quad_sum((int)hi);
-                    // (opaque masks keep the compiler from turning `(x & 0xffff) << n` into shift + mask + add: mask, then one v_lshl_add_u32)
                     uint32_t s80, s82;
-                    asm("v_and_b32 %0, 0xffff, %1" : "=v"(s80) : "v"(lo));
-                    asm("v_and_b32 %0, 0xffff, %1" : "=v"(s82) : "v"(hi));
+                    if (MASK)
+                    {
+                        asm("v_and_b32 %0, 0xffff, %1" : "=v"(s80) : "v"(lo));
+                        asm("v_and_b32 %0, 0xffff, %1" : "=v"(s82) : "v"(hi));
+                    }
+                    else { s80 = lo & 0xffffu; s82 = hi & 0xffffu; }
                     const uint32_t s81 = lo >> 16, s83 = hi >> 16;
                     const uint32_t v16 = __builtin_amdgcn_perm(qhi, qlo, selK);
                     const uint32_t v32 = (uint32_t)row_sum_of_quads((int)v16);
-                    const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)cb, p);      // costY[m] << 8 | m, in an SGPR
+                    // costY[m] << 8 | m: an SGPR from the block's table entries, or built from round 4's per-row load
+                    const uint32_t sb = CTAB ? (uint32_t)__builtin_amdgcn_readlane((int)cb, p) : (((uint32_t)a.costY[m] << 8) | (uint32_t)m);
                     if (COLMIN)
                     {
                         const uint32_t k0 = (s80 << 8) + sb, k1 = (s81 << 8) + sb, k2 = (s82 << 8) + sb, k3 = (s83 << 8) + sb;
@@ -658,32 +702,36 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
                         key = (key & ~3u) | (kmin & 3u);                             // | k
                         r8 = key < r8 ? key : r8;
                     }
-                    const uint32_t k16 = (v16 << 8) + sb, k32 = (v32 << 8) + sb;     // costX joins once per group
+                    const uint32_t base = DEFERX ? sb : cxL8 + sb;
+                    const uint32_t k16 = (v16 << 8) + base, k32 = (v32 << 8) + base;
                     r16 = k16 < r16 ? k16 : r16;
                     r32 = k32 < r32 ? k32 : r32;
-                    if (FIRST)
-                    {   // the first block completes a single row (m = 0): reduce it on its own
-                        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    if (!PAIR64 || FIRST)
+                    {   // one row on its own (PAIR64: the first block completes a single row, m = 0)
                         v2u sw = __builtin_amdgcn_permlane16_swap(v32, v32, false, false);
                         const unsigned h64 = sw.x + sw.y;
                         sw = __builtin_amdgcn_permlane32_swap(h64, h64, false, false);
-                        const uint32_t k64 = ((sw.x + sw.y) << 8) + sb;
+                        const uint32_t k64 = ((sw.x + sw.y) << 8) + base;
                         r64 = k64 < r64 ? k64 : r64;
                     }
-                    else if ((p & 1) == 0)
-                        v32even = v32;
+                    else if ((p & 1) == 0) { v32even = v32; sbEven = sb; }
                     else
                     {
-                        typedef unsigned v2u __attribute__((ext_vector_type(2)));
                         // rows A (p - 1) and B (p): {A0,B0,A2,B2} + {A1,B1,A3,B3}, then the two halves of that sum
                         v2u sw = __builtin_amdgcn_permlane16_swap(v32even, v32, false, false);
                         const unsigned h64 = sw.x + sw.y;
                         sw = __builtin_amdgcn_permlane32_swap(h64, h64, false, false);
                         const uint32_t tot = sw.x + sw.y;                            // 16-lane rows 0 / 2: A's 64x64 total, rows 1 / 3: B's
-                        const uint32_t mine = ctab[mb + p - 1 + oddRow];             // costY << 8 | m of the row this lane holds
+                        uint32_t mine = CTAB ? pr[p >> 1] : (oddRow ? sb : sbEven);  // costY << 8 | m of the row this lane holds
+                        if (!DEFERX) mine += cxL8;
                         const uint32_t k64 = (tot << 8) + mine;
                         r64 = k64 < r64 ? k64 : r64;
                     }
+                }
+                if (!LD64 && (p & 1))
+                {
+#pragma unroll
+                    for (int q = 0; q < 2; q++) { cur[q][0] = nxt[q][0]; cur[q][1] = nxt[q][1]; cur[q][2] = nxt[q][2]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -700,7 +748,7 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
         case 6: rows8(std::false_type{}, std::integral_constant<int, 6>{}, t0); break;
         default: break;
         }
-        {   // widen the group's row-local keys to cost << 32 | raster index and merge; the column's costX joins the upper levels here
+        {   // widen the group's row-local keys to cost << 32 | raster index and merge
             if (COLMIN)
             {   // each column's minimum over the rows gets its costX now; `cost << 10 | m << 2 | k` orders the four like (cost, raster index)
 #pragma unroll
@@ -713,8 +761,7 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
             }
             const u64 w8 = ((u64)(r8 >> 10) << 32) | (uint32_t)(((r8 >> 2) & 255u) * NC + 4 * g + (r8 & 3u));
             bk8 = w8 < bk8 ? w8 : bk8;
-            const uint32_t cxL8 = cxL << 8;
-            auto widen = [&](const uint32_t r) { const uint32_t rc = r + cxL8; return ((u64)(rc >> 8) << 32) | (uint32_t)((rc & 255u) * NC + 4 * g + kcol); };
+            auto widen = [&](const uint32_t r) { const uint32_t rc = DEFERX ? r + cxL8 : r; return ((u64)(rc >> 8) << 32) | (uint32_t)((rc & 255u) * NC + 4 * g + kcol); };
             const u64 w16 = widen(r16), w32 = widen(r32), w64 = widen(r64);
             bk16 = w16 < bk16 ? w16 : bk16;
             bk32 = w32 < bk32 ? w32 : bk32;
@@ -726,7 +773,7 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
     atomicMin(&rec[lane], bk8);
     atomicMin(&rec[64 + (lane >> 2)], bk16);
     if ((lane & 15) < 4) atomicMin(&rec[80 + (lane >> 4)], bk32);
-    if ((lane & 0x2f) < 4) atomicMin(&rec[84], bk64);          // lanes 0..3 saw the even window rows of their column, lanes 16..19 the odd ones
+    if ((lane & (PAIR64 ? 0x2f : 0x3f)) < 4) atomicMin(&rec[84], bk64);    // PAIR64: lanes 0..3 saw the even window rows of their column, lanes 16..19 the odd ones
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -939,6 +986,9 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
 // columns are dealt round-robin, so the idle tail is at most one column per wavefront.
 int launch_me_cand(const x265hip_me_params* p, hipStream_t s);       // me_cand_kernel.hip: 0 = launched, 1 = not applicable, < 0 = error
 
+// the flag set the minima-only 8-bit launch uses by default (-1 = round 4's kernel): what measured fastest on one box, profiles/r05_me_flags_ab.txt
+static const int Q2_DEFAULT_FLAGS = -1;
+
 static int pick_waves(int ncols)
 {
     return ncols >= 16 ? 16 : (ncols < 4 ? 4 : ncols);
@@ -999,7 +1049,9 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     {
         // 8-bit fast path (v_qsad_pk_u16_u8); 2 * range + 75 bytes of window row must fit the 256-byte pitch
         const char* bestVarEnv = getenv("X265HIP_ME_BEST_VARIANT");       // A/B and the parity test of every variant: read per launch
-        const int bestVar = bestVarEnv ? atoi(bestVarEnv) & 7 : -1;
+        const int bestVar = bestVarEnv ? atoi(bestVarEnv) & 3 : -1;
+        const char* q2Env = getenv("X265HIP_ME_Q2_FLAGS");               // round 5's flagged kernel (me_ctu_q2_kernel<256, FL>): A/B and parity tests; unset = the default below
+        const int q2Flags = q2Env ? atoi(q2Env) : (bestVarEnv ? -1 : Q2_DEFAULT_FLAGS);
         static const int bestWaves = getenv("X265HIP_ME_BEST_WAVES") ? atoi(getenv("X265HIP_ME_BEST_WAVES")) : 0;       // A/B: wavefronts per workgroup of the minima-only launch
         // 4K and up: 12 wavefronts per workgroup instead of 16 - step 1.875 -> 1.823 ms at 4K on one box, three interleaved rounds (8 does the same, 10 and 6 lose;
         // at 1080p 16 stays best): profiles/r04_me_minima_ab.txt
@@ -1019,22 +1071,21 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
             if (anyBest)
             {
                 if (bestVar == 1) LAUNCH_QV(1); else if (bestVar == 2) LAUNCH_QV(2); else if (bestVar == 3) LAUNCH_QV(3);
-                else if (bestVar == 0 || p->range > 123) LAUNCH_QV(0);          // 0 = round 4's kernel (A/B)          // (the row index shares a byte with nothing else: m <= 2 * range < 256 either way)
+                else if (q2Flags < 0 || p->range > 120) LAUNCH_QV(0);          // round 4's kernel
                 else
-                {   // round 5's minima-only kernel (the default): the same launch geometry + the row-constant table behind the window
+                {   // round 5's flagged kernel: the same launch geometry + the row-constant table behind the window
                     int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 12) nwq = 12;
                     if (bestWaves >= 4 && bestWaves <= 16 && bestWaves < pick_waves((2 * p->range + 4) / 4) + 1) nwq = bestWaves;
-                    const size_t lds2 = lds + (size_t)(2 * p->range + 1 + 8) * 4;
-                    if (bestVar == 5)
-                    {   // 5 = per-column 8x8 minima (A/B)
-                        if (lds2 > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_q2_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-                        hipLaunchKernelGGL((me_ctu_q2_kernel<256, true>), grid, dim3(nwq * 64), lds2, s, a, (int)lds);
-                    }
-                    else
+                    const size_t lds2 = lds + (size_t)(2 * p->range + 1 + 16) * 4;
+#define LAUNCH_Q2(FLV) case FLV: \
+                        if (lds2 > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_q2_kernel<256, FLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
+                        hipLaunchKernelGGL((me_ctu_q2_kernel<256, FLV>), grid, dim3(nwq * 64), lds2, s, a, (int)lds); break;
+                    switch (q2Flags)
                     {
-                        if (lds2 > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_q2_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-                        hipLaunchKernelGGL((me_ctu_q2_kernel<256, false>), grid, dim3(nwq * 64), lds2, s, a, (int)lds);
+                    LAUNCH_Q2(0) LAUNCH_Q2(1) LAUNCH_Q2(2) LAUNCH_Q2(4) LAUNCH_Q2(8) LAUNCH_Q2(32) LAUNCH_Q2(14) LAUNCH_Q2(46) LAUNCH_Q2(47) LAUNCH_Q2(62) LAUNCH_Q2(10) LAUNCH_Q2(12)
+                    default: set_error("me_fullsearch: X265HIP_ME_Q2_FLAGS %d is not an instantiated combination", q2Flags); return X265HIP_EINVAL;
                     }
+#undef LAUNCH_Q2
                 }
             }
         }
