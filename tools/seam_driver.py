@@ -643,10 +643,113 @@ class StreamGpuPhaseProvider:
             self.handle = None
 
 
+class MultiDeviceStreamProvider:
+    """One x265hip_me_stream instance PER GPU behind the binding's single provider interface - the mapping a host that spreads its frame encoders
+    over the GPUs of a node would use (encoder/encoder.cpp:304-321: frame encoder i -> pool i % numPools): slot s of the binding lives on instance
+    s % n (its local slot s // n), every reconstructed CTU row is handed to EVERY instance (the one-to-many hand-over of SURVEY 8(e): any instance's
+    pairs may refer to the picture).  devices = the device index of each instance; naming one device twice runs the same mapping on a one-GPU box."""
+
+    def __init__(self, depth, geo, rng, slots, min_level, pictures, band_rows, layout, centre_range, devices):
+        self.n = len(devices)
+        per = -(-slots // self.n)
+        self.inst = [StreamGpuProvider(depth, geo, rng, per, min_level, pictures, band_rows, layout, centre_range, device=d) for d in devices]
+        self.format = self.inst[0].format
+        L = self.L = self.inst[0].L
+        L.x265hip_me_stream_picture_rows.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.x265hip_me_stream_pair_open.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64]
+        L.x265hip_me_stream_pair_open_weighted.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        for f in (L.x265hip_me_stream_surface, L.x265hip_me_stream_ready, L.x265hip_me_stream_centres):
+            f.restype, f.argtypes = ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]
+        self._cb = (PIC_ROWS(self._rows), PAIR_OPEN(self._open), PAIR_OPEN_W(self._open_w), SURFACE(self._surface), READY(self._ready), CENTRES(self._centres))
+
+    def _at(self, slot):
+        return self.inst[slot % self.n].handle, slot // self.n
+
+    def _rows(self, ctx, key, buf, r0, n):
+        rc = 0
+        for i in self.inst:
+            rc = rc or self.L.x265hip_me_stream_picture_rows(i.handle, key, buf, r0, n)
+        return rc
+
+    def _open(self, ctx, slot, fkey, rkey):
+        h, s = self._at(slot)
+        return self.L.x265hip_me_stream_pair_open(h, s, fkey, rkey)
+
+    def _open_w(self, ctx, slot, fkey, rkey, wptr):
+        h, s = self._at(slot)
+        return self.L.x265hip_me_stream_pair_open_weighted(h, s, fkey, rkey, wptr)
+
+    def _surface(self, ctx, slot):
+        return self.L.x265hip_me_stream_surface(*self._at(slot))
+
+    def _ready(self, ctx, slot):
+        return self.L.x265hip_me_stream_ready(*self._at(slot))
+
+    def _centres(self, ctx, slot):
+        return self.L.x265hip_me_stream_centres(*self._at(slot))
+
+    def pointers(self):
+        return (None,) + tuple(ctypes.cast(f, ctypes.c_void_p) for f in self._cb)
+
+    def report(self):
+        reps = [i.report() for i in self.inst]
+        d = {k: (sum(r[k] for r in reps) if isinstance(reps[0][k], int) and k != "surface_bytes" else reps[0][k]) for k in reps[0]}
+        d["instances"] = [{k: r[k] for k in ("pairs_opened", "pairs_completed", "rows_searched", "rows_uploaded", "failed")} for r in reps]
+        return d
+
+    def close(self):
+        for i in self.inst:
+            i.close()
+
+
+class MultiDevicePhaseProvider:
+    """The same mapping for x265hip_phase_stream: view slot s on instance s % n, every reconstructed row to every instance."""
+
+    def __init__(self, depth, geo, slots, devices):
+        self.n = len(devices)
+        per = -(-slots // self.n)
+        self.inst = [StreamGpuPhaseProvider(depth, geo, per, device=d) for d in devices]
+        L = self.L = self.inst[0].L
+        L.x265hip_phase_stream_view_open.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint]
+        L.x265hip_phase_stream_picture_rows.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.x265hip_phase_stream_planes.restype, L.x265hip_phase_stream_planes.argtypes = ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.x265hip_phase_stream_progress.restype, L.x265hip_phase_stream_progress.argtypes = ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]
+        self._cb = (PS_OPEN(self._open), PS_ROWS(self._rows), PH_PLANES(self._planes), PS_PROGRESS(self._progress))
+
+    def _open(self, ctx, slot, key, wptr, mask):
+        return self.L.x265hip_phase_stream_view_open(self.inst[slot % self.n].handle, slot // self.n, key, wptr, mask)
+
+    def _rows(self, ctx, key, y, cb, cr, r0, n):
+        rc = 0
+        for i in self.inst:
+            rc = rc or self.L.x265hip_phase_stream_picture_rows(i.handle, key, y, cb, cr, r0, n)
+        return rc
+
+    def _planes(self, ctx, slot, plane):
+        return self.L.x265hip_phase_stream_planes(self.inst[slot % self.n].handle, slot // self.n, plane)
+
+    def _progress(self, ctx, slot):
+        return self.L.x265hip_phase_stream_progress(self.inst[slot % self.n].handle, slot // self.n)
+
+    def pointers(self):
+        return (None,) + tuple(ctypes.cast(f, ctypes.c_void_p) for f in self._cb)
+
+    def report(self):
+        reps = [i.report() for i in self.inst]
+        d = {k: (sum(r[k] for r in reps) if isinstance(reps[0][k], int) and k != "bytes_per_picture" else reps[0][k]) for k in reps[0]}
+        d["instances"] = [{k: r[k] for k in ("opened", "completed", "bands", "failed")} for r in reps]
+        return d
+
+    def close(self):
+        for i in self.inst:
+            i.close()
+
+
 def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
             surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0, min_ctus=0, build="", aq=None, aq_min_blocks=0,
-            weight_analyse=None, weight_min_blocks=0, split_rest=False):
-    """Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
+            weight_analyse=None, weight_min_blocks=0, split_rest=False, devices=None):
+    """devices: [device index, ...] = one instance of each row-granular service PER entry (MultiDeviceStreamProvider / MultiDevicePhaseProvider).
+    Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
     the picture-granular providers need --frame-threads 1, streamed=True (row-granular providers) serves under any --frame-threads."""
     lib = seam_lib(depth, build)
     geo = geometry(width, height)
@@ -660,7 +763,8 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     lib.x265ref_seam_min_ctus.argtypes = [ctypes.c_int]
     lib.x265ref_seam_min_ctus(1000 if min_ctus is None else min_ctus)
     if streamed:
-        prov = (StreamGpuProvider(depth, geo, rng, slots, min_level, pictures, band_rows, layout, centre_range) if provider == "gpu"
+        prov = (MultiDeviceStreamProvider(depth, geo, rng, slots, min_level, pictures, band_rows, layout, centre_range, devices) if provider == "gpu" and devices
+                else StreamGpuProvider(depth, geo, rng, slots, min_level, pictures, band_rows, layout, centre_range) if provider == "gpu"
                 else StreamOracleProvider(depth, geo, rng, slots, min_level, layout, centre_range))
         ctx, pic_rows, pair_open, pair_open_w, surface, ready, centres = prov.pointers()
         lib.x265ref_seam_configure_streamed.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int] * 7 + [ctypes.c_ssize_t] + [ctypes.c_int] * 4
@@ -732,7 +836,8 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     lib.x265ref_subpel_seam_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     sub = None
     if subpel and streamed:
-        sub = (StreamGpuPhaseProvider if subpel == "gpu" else StreamOraclePhaseProvider)(depth, geo, subpel_slots)
+        sub = (MultiDevicePhaseProvider(depth, geo, subpel_slots, devices) if subpel == "gpu" and devices
+               else (StreamGpuPhaseProvider if subpel == "gpu" else StreamOraclePhaseProvider)(depth, geo, subpel_slots))
         sctx, sopen, srows, spl, sprog = sub.pointers()
         lib.x265ref_subpel_seam_configure_streamed.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_ssize_t,
                                                                                        ctypes.c_int, ctypes.c_int, ctypes.c_int]
