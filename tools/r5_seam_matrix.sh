@@ -1,22 +1,26 @@
 #!/bin/bash
-# FIRST THING for the next round (left unmeasured when round 4's GPU budget ran out): every seam alone and together against the HOST-ONLY control (csplit), not against
-# the C table - one box, interleaved.  cfg3 (8-bit) and cfg4 (10-bit); ~6 min of GPU time.
-#   bash tools/r5_seam_matrix.sh [frames3] [frames4]
-F3=${1:-48}; F4=${2:-24}
-BASE="--frame-threads 5 --seam-streamed --seam-layout planes --seam-centre-range 57 --seam-range 12 --seam-min-level 1 --seam-min-pu 16 --seam-subpel-slots 12 --seam-split-rest"
-run() { python tools/encoder_bench.py "$@" 2>&1 | grep "^\[encoder\]" | python -c "
-import sys,json
+# Round 5: how should the encoder legs configure the SAD seam?  (round-4 verdict, next 4: by what was measured, not by how many lookups get served.)
+# ONE box, interleaved rounds, everything against the HOST-ONLY control (csplit): per configuration
+#   control      C table with split sad_x3 / sad_x4, no GPU
+#   all_l1       every seam, SAD planes of the 16x16-and-up levels        (round 4's legs)
+#   all_l2       every seam, SAD planes of the 32x32 / 64x64 levels only  (40 % of the download)
+#   no_sad       every seam but the SAD lookups
+#   bash tools/r5_seam_matrix.sh [rounds] [configs]
+ROUNDS=${1:-2}; CFGS=${2:-"cfg3 cfg3f cfg4"}
+export ENCODER_BENCH_NO_MD5=1          # the bench legs hold the md5 check; here every leg would pay a C-table encode for it
+COMMON="--frame-threads 5 --seam-streamed --seam-layout planes --seam-centre-range 57 --seam-range 12 --seam-min-pu 16 --seam-subpel-slots 12 --seam-split-rest --seam-subpel --seam-lookahead --seam-aq --seam-weight-analyse"
+run() { tag=$1; shift; python tools/encoder_bench.py "$@" 2>&1 | grep "^\[encoder\]" | TAG=$tag python -c "
+import sys,json,os
 for l in sys.stdin:
-    tag=l.split(':')[0]; d=json.loads(l.split(': ',1)[1]); s=d.get('seam',{})
-    print(tag, 'fps', d['fps'], 'cpu', d.get('process_cpu_seconds'), 'served', s.get('lookups_served'), 'subpel', s.get('subpel_seam',{}).get('subpel_compares_served'), 'la', s.get('lookahead_seam',{}).get('frame_cost_estimates_served'), 'MB', round(s.get('bytes_downloaded',0)/1e6), 'md5', d.get('md5','')[:8])"; }
-for cfg in cfg3 cfg4; do
-  [ $cfg = cfg3 ] && NF=$F3 SLOTS=24 || NF=$F4 SLOTS=40
-  echo "== $cfg: C table and host-only control (the legs below add --lookahead-slices 1 only when the lookahead seam is on: compare md5s within a group)"
-  run --configs $cfg --tables c,csplit --frames $NF --frame-threads 5
-  echo "== $cfg: SAD seam alone (16x16 and up)";              run --configs $cfg --tables seam --frames $NF --seam-slots $SLOTS $BASE
-  echo "== $cfg: SAD seam alone, 32x32 and up (min_level 2)";  run --configs $cfg --tables seam --frames $NF --seam-slots $SLOTS ${BASE/--seam-min-level 1 --seam-min-pu 16/--seam-min-level 2 --seam-min-pu 32}
-  echo "== $cfg: sub-sample seam alone";                       run --configs $cfg --tables seam --frames $NF --seam-slots $SLOTS $BASE --seam-no-sad --seam-subpel
-  echo "== $cfg: lookahead + AQ + weightAnalyse alone";        run --configs $cfg --tables c,csplit,seam --frames $NF --seam-slots $SLOTS $BASE --seam-no-sad --seam-lookahead --seam-aq --seam-weight-analyse
-  echo "== $cfg: everything but the SAD seam";                 run --configs $cfg --tables seam --frames $NF --seam-slots $SLOTS $BASE --seam-no-sad --seam-subpel --seam-lookahead --seam-aq --seam-weight-analyse
-  echo "== $cfg: everything";                                  run --configs $cfg --tables seam --frames $NF --seam-slots $SLOTS $BASE --seam-subpel --seam-lookahead --seam-aq --seam-weight-analyse
+    leg=l.split(':')[0].split()[-1]; d=json.loads(l.split(': ',1)[1]); s=d.get('seam',{})
+    if leg == 'c': continue
+    print(os.environ['TAG'], leg, 'fps', d['fps'], 'cpu_s', d.get('process_cpu_seconds'), 'hit', s.get('lookup_hit_rate'), 'served', s.get('lookups_served'), 'GB_down', round((s.get('bytes_downloaded',0)+s.get('subpel_seam',{}).get('bytes_downloaded',0))/1e9,2), 'md5_equal', d.get('md5_equal_to_c_table'))"; }
+for r in $(seq 1 $ROUNDS); do
+  for cfg in $CFGS; do
+    case $cfg in cfg3) NF=48 SLOTS=24 ;; cfg3f) NF=24 SLOTS=24 ;; *) NF=24 SLOTS=40 ;; esac
+    run "$cfg r$r control" --configs $cfg --tables csplit --frames $NF --frame-threads 5 --seam-lookahead
+    run "$cfg r$r all_l1 " --configs $cfg --tables seam --frames $NF --seam-slots $SLOTS $COMMON --seam-min-level 1
+    run "$cfg r$r all_l2 " --configs $cfg --tables seam --frames $NF --seam-slots $SLOTS $COMMON --seam-min-level 2
+    run "$cfg r$r no_sad " --configs $cfg --tables seam --frames $NF --seam-slots $SLOTS $COMMON --seam-min-level 1 --seam-no-sad
+  done
 done

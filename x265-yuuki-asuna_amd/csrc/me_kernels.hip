@@ -514,6 +514,10 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
 //              A's total, rows 1 / 3 hold B's (5 instructions per PAIR of rows where two separate reductions take 14);
 //   8  DEFERX  the column's costX joins the 16x16 / 32x32 / 64x64 running minima once per column group (min(x + c) = min(x) + c);
 //  16  COLMIN  the 8x8 level keeps one running minimum per column and gives each column its costX once per group;
+//  64  RING    the three-dword loads of round 4 without their copies: two pairs of rows in flight in registers whose role alternates (the unrolled
+//              rows index them with constants), a block of 8 rows read from three address registers;
+// 128  QUAD64  PAIR64 for FOUR rows: two pair sums {A01,B01,A23,B23} / {C01,D01,C23,D23} change halves in one v_permlane32_swap -> 16-lane row r
+//              holds the 64x64 total of the quad's row r (6 instructions and one key per four rows);
 //  32  MASK    the low halves of the packed 8x8 sums are extracted with an opaque v_and (the compiler turns `(x & 0xffff) << n` into
 //              shift + mask + add; this way it is mask + v_lshl_add_u32).
 // Results are identical for every FL (tests/test_gpu_me.py runs them all against the oracle).
@@ -521,6 +525,9 @@ template <int PITCH, int FL>
 __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOff)
 {
     constexpr bool LD64 = (FL & 1) != 0, CTAB = (FL & 2) != 0, PAIR64 = (FL & 4) != 0, DEFERX = (FL & 8) != 0, COLMIN = (FL & 16) != 0, MASK = (FL & 32) != 0;
+    constexpr bool RING = (FL & 64) != 0, QUAD64 = (FL & 128) != 0;
+    static_assert(!QUAD64 || (PAIR64 && CTAB), "QUAD64 extends PAIR64 and takes its per-lane row constants from the table");
+    static_assert(!(RING && LD64), "RING is the three-dword load path without its copies");
     extern __shared__ __attribute__((aligned(16))) uint8_t win[];
     typedef unsigned long long u64;
     typedef u64 __attribute__((aligned(4))) u64a4;
@@ -572,7 +579,7 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
         const uint32_t colOff = (uint32_t)((by * 8) * pitch + bx * 8 + 4 * g);
         // LDS byte offset of window row t0 of this lane's block column.  LD64 keeps it opaque: ds_read reaches 255 dwords past its address
         // register, so a block of 8 rows is read from THREE address registers (rows 0 - 3, rows 4 - 7, the next block's rows 0 - 1)
-        auto block_off = [&](const int t0) { uint32_t o = colOff + (uint32_t)(t0 * pitch + lds_skew_bytes(by + (t0 >> 3))); if (LD64) asm volatile("" : "+v"(o)); return o; };
+        auto block_off = [&](const int t0) { uint32_t o = colOff + (uint32_t)(t0 * pitch + lds_skew_bytes(by + (t0 >> 3))); if (LD64 || RING) asm volatile("" : "+v"(o)); return o; };
         auto ldpair64 = [&](u64 (&d)[2][2], const uint32_t off, const int p)
         {
 #pragma unroll
@@ -604,17 +611,25 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
         for (int i = 0; i < 8; i++) acc[i] = 0;
         u64 buf[2][2][2];                                   // LD64: [pipeline slot][row of the pair][bytes 0..7 / 4..11]; slot parity returns after 8 rows
         uint32_t cur[2][3], nxt[2][3];                      // !LD64: round 4's three dwords per row
-        (void)buf; (void)cur; (void)nxt;
-        if (LD64) ldpair64(buf[0], block_off(0), 0); else ldpair32(cur, block_off(0), 0);
+        uint32_t d3[2][2][3];                               // RING: the same three dwords, two pairs of rows in flight, no copies (slot parity as above)
+        (void)buf; (void)cur; (void)nxt; (void)d3;
+        if (LD64) ldpair64(buf[0], block_off(0), 0); else if (RING) ldpair32(d3[0], block_off(0), 0); else ldpair32(cur, block_off(0), 0);
 
         // CTAB: a block's row constants, fetched while the block before it runs.  lane l holds the entry of window row t0 + (l & 7)
         // (m = t0 + (l & 7) - 7; the first block only completes m = 0), pr[q] the entry of the row this lane holds after the paired reduction
+        // QUAD64: pr[0] / pr[1] = the entries of window rows 0..3 / 4..7 by the lane's 16-lane row, pr[2] / pr[3] = those of a tail pair (rows 0,1 / 4,5)
         uint32_t cbNext = 0, prNext[4] = { 0, 0, 0, 0 };
         auto fetch_consts = [&](const int t0)
         {
             const int i0 = t0 - 7 + (lane & 7);
             cbNext = ctab[i0 < 0 ? 0 : i0];
-            if (PAIR64)
+            if (QUAD64)
+            {
+                const int a0 = t0 - 7 + (lane >> 4), a1 = t0 - 7 + oddRow;
+                prNext[0] = ctab[a0 < 0 ? 0 : a0]; prNext[1] = ctab[a0 + 4 < 0 ? 0 : a0 + 4];
+                prNext[2] = ctab[a1 < 0 ? 0 : a1]; prNext[3] = ctab[a1 + 4 < 0 ? 0 : a1 + 4];
+            }
+            else if (PAIR64)
             {
 #pragma unroll
                 for (int q = 0; q < 4; q++) { const int i = t0 - 7 + 2 * q + oddRow; prNext[q] = ctab[i < 0 ? 0 : i]; }
@@ -628,7 +643,7 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
             constexpr int NROWS = decltype(nrowsTag)::value;
             const uint32_t bb = block_off(t0), bn = block_off(t0 + 8);
             uint32_t bb4 = bb + 4 * pitch;
-            if (LD64) asm volatile("" : "+v"(bb4));
+            if (LD64 || RING) asm volatile("" : "+v"(bb4));
             const int mb = t0 - 7;
             uint32_t cb = 0, pr[4] = { 0, 0, 0, 0 };
             if (CTAB)
@@ -638,7 +653,7 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
                 for (int q = 0; q < 4; q++) pr[q] = prNext[q];
                 fetch_consts(t0 + 8);
             }
-            uint32_t v32even = 0, sbEven = 0;
+            uint32_t v32even = 0, sbEven = 0, pairSum = 0;
 #pragma unroll
             for (int p = 0; p < NROWS; p++)
             {
@@ -650,10 +665,21 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
                         else if (p + 2 < 8) ldpair64(buf[((p >> 1) + 1) & 1], bb4, p + 2 - 4);
                         else ldpair64(buf[((p >> 1) + 1) & 1], bn, 0);
                     }
+                    else if (RING)
+                    {
+                        if (p + 2 < 4) ldpair32(d3[((p >> 1) + 1) & 1], bb, p + 2);
+                        else if (p + 2 < 8) ldpair32(d3[((p >> 1) + 1) & 1], bb4, p + 2 - 4);
+                        else ldpair32(d3[((p >> 1) + 1) & 1], bn, 0);
+                    }
                     else { if (p + 2 < 8) ldpair32(nxt, bb, p + 2); else ldpair32(nxt, bn, 0); }
                 }
                 u64 w0, w1;
                 if (LD64) { w0 = buf[(p >> 1) & 1][p & 1][0]; w1 = buf[(p >> 1) & 1][p & 1][1]; }
+                else if (RING)
+                {
+                    const uint32_t (&dd)[3] = d3[(p >> 1) & 1][p & 1];
+                    w0 = ((u64)dd[1] << 32) | dd[0]; w1 = ((u64)dd[2] << 32) | dd[1];
+                }
                 else { w0 = ((u64)cur[p & 1][1] << 32) | cur[p & 1][0]; w1 = ((u64)cur[p & 1][2] << 32) | cur[p & 1][1]; }
 #pragma unroll
                 for (int j = 0; j < 8; j++)
@@ -715,6 +741,30 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
                         r64 = k64 < r64 ? k64 : r64;
                     }
                     else if ((p & 1) == 0) { v32even = v32; sbEven = sb; }
+                    else if (QUAD64)
+                    {
+                        // rows A (p - 1) and B (p): {A0,B0,A2,B2} + {A1,B1,A3,B3} = {A01, B01, A23, B23}
+                        v2u sw = __builtin_amdgcn_permlane16_swap(v32even, v32, false, false);
+                        const unsigned h64 = sw.x + sw.y;
+                        const bool quadEnd = (p & 3) == 3, tailPair = (p & 3) == 1 && p + 2 >= NROWS;       // constants once the row loop is unrolled
+                        if (quadEnd)
+                        {   // with the pair before it {C01, D01, C23, D23}: the halves change places -> 16-lane row r holds the total of the quad's row r
+                            sw = __builtin_amdgcn_permlane32_swap(pairSum, h64, false, false);
+                            uint32_t mine = pr[p >> 2];
+                            if (!DEFERX) mine += cxL8;
+                            const uint32_t k64 = ((sw.x + sw.y) << 8) + mine;
+                            r64 = k64 < r64 ? k64 : r64;
+                        }
+                        else if (tailPair)
+                        {   // the block ends with this pair (2 or 6 rows left): finished on its own, rows 0 / 2 hold A's total, rows 1 / 3 B's
+                            sw = __builtin_amdgcn_permlane32_swap(h64, h64, false, false);
+                            uint32_t mine = pr[2 + (p >> 2)];
+                            if (!DEFERX) mine += cxL8;
+                            const uint32_t k64 = ((sw.x + sw.y) << 8) + mine;
+                            r64 = k64 < r64 ? k64 : r64;
+                        }
+                        else pairSum = h64;
+                    }
                     else
                     {
                         // rows A (p - 1) and B (p): {A0,B0,A2,B2} + {A1,B1,A3,B3}, then the two halves of that sum
@@ -728,7 +778,7 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
                         r64 = k64 < r64 ? k64 : r64;
                     }
                 }
-                if (!LD64 && (p & 1))
+                if (!LD64 && !RING && (p & 1))
                 {
 #pragma unroll
                     for (int q = 0; q < 2; q++) { cur[q][0] = nxt[q][0]; cur[q][1] = nxt[q][1]; cur[q][2] = nxt[q][2]; }
@@ -773,7 +823,8 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
     atomicMin(&rec[lane], bk8);
     atomicMin(&rec[64 + (lane >> 2)], bk16);
     if ((lane & 15) < 4) atomicMin(&rec[80 + (lane >> 4)], bk32);
-    if ((lane & (PAIR64 ? 0x2f : 0x3f)) < 4) atomicMin(&rec[84], bk64);    // PAIR64: lanes 0..3 saw the even window rows of their column, lanes 16..19 the odd ones
+    // PAIR64: lanes 0..3 saw the even window rows of their column, lanes 16..19 the odd ones; QUAD64: every 16-lane row saw its own rows
+    if ((lane & (QUAD64 ? 0x0f : PAIR64 ? 0x2f : 0x3f)) < 4) atomicMin(&rec[84], bk64);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1082,7 +1133,7 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
                         hipLaunchKernelGGL((me_ctu_q2_kernel<256, FLV>), grid, dim3(nwq * 64), lds2, s, a, (int)lds); break;
                     switch (q2Flags)
                     {
-                    LAUNCH_Q2(0) LAUNCH_Q2(1) LAUNCH_Q2(2) LAUNCH_Q2(4) LAUNCH_Q2(8) LAUNCH_Q2(32) LAUNCH_Q2(14) LAUNCH_Q2(46) LAUNCH_Q2(47) LAUNCH_Q2(62) LAUNCH_Q2(10) LAUNCH_Q2(12)
+                    LAUNCH_Q2(0) LAUNCH_Q2(1) LAUNCH_Q2(2) LAUNCH_Q2(4) LAUNCH_Q2(8) LAUNCH_Q2(32) LAUNCH_Q2(14) LAUNCH_Q2(46) LAUNCH_Q2(62) LAUNCH_Q2(64) LAUNCH_Q2(126) LAUNCH_Q2(190) LAUNCH_Q2(254) LAUNCH_Q2(238)
                     default: set_error("me_fullsearch: X265HIP_ME_Q2_FLAGS %d is not an instantiated combination", q2Flags); return X265HIP_EINVAL;
                     }
 #undef LAUNCH_Q2
