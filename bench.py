@@ -356,7 +356,7 @@ def encoder_plan(args):
                      "frame_threads": args.encoder_frame_threads or ft, "seam": seam_config(key), "build": ""})
     for key in [k for k in ("cfg3", "cfg4") if k in keys]:
         nf, ft = ENC_DEFAULTS[key]
-        plan.append({"name": key + "_v3", "key": key, "tables": args.encoder_tables.split(","), "frames": args.encoder_frames or nf,
+        plan.append({"name": key + "_v3", "key": key, "tables": ["c", "csse"] + [t for t in args.encoder_tables.split(",") if t != "c"], "frames": args.encoder_frames or nf,
                      "frame_threads": args.encoder_frame_threads or ft, "seam": seam_config(key), "build": "v3"})
     return plan
 
@@ -409,6 +409,9 @@ def encoder_leg_numbers(c):
     sat = rep.get("subpel_seam", {}).get("satd_lookups_served")
     if sat is not None:
         r["satd_served"] = sat
+    if "csse" in c:          # v3 legs: the C table + the reference's SSE intrinsic transforms (common/vec), the strongest host table that can be built here
+        r["c_sse_fps"] = c["csse"].get("fps")
+        r["sse_md5_equal"] = c["csse"].get("md5_equal_to_c_table")
     return r
 
 

@@ -71,4 +71,26 @@ void x265ref_encoder_table_reset_c(void)
     g_cprimReady = false;   /* lowpass statics now point at `primitives`; rebuild g_cprim on next use */
 }
 
+/* A stronger host baseline that CAN be built here (round-4 verdict, optional 9): the reference's own SSE3 / SSSE3 / SSE4.1 intrinsic transforms
+ * (common/vec/*.cpp - what x265_setup_primitives installs under ENABLE_ASSEMBLY before the NASM kernels, primitives.cpp:261-264) over the C table.
+ * Only in the flavours built with them (oracle/Makefile refv3: -DX265REF_WITH_VEC); a table filler like x265hip_setup_primitives. */
+int x265ref_sse_fill_table(void* table, size_t bytes, int depth)
+{
+#if X265REF_WITH_VEC
+    if (!table || bytes != sizeof(EncoderPrimitives) || depth != X265_DEPTH) return -1;
+    EncoderPrimitives& t = *(EncoderPrimitives*)table;
+    EncoderPrimitives before = t;
+    setupInstrinsicPrimitives(t, X265_CPU_SSE2 | X265_CPU_SSE3 | X265_CPU_SSSE3 | X265_CPU_SSE4);
+    for (int i = 0; i < NUM_TR_SIZE; i++)
+        t.cu[i].standard_dct = t.cu[i].dct;
+    int n = 0;
+    const void* const* a = (const void* const*)&before; const void* const* b = (const void* const*)&t;
+    for (size_t i = 0; i < sizeof(EncoderPrimitives) / sizeof(void*); i++) n += a[i] != b[i];
+    return n;
+#else
+    (void)table; (void)bytes; (void)depth;
+    return -1;
+#endif
+}
+
 } // extern "C"

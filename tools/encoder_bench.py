@@ -4,6 +4,7 @@ x265 3.5 compiled from /root/reference by oracle/Makefile, C primitives, no asm 
 each BASELINE.json configuration, once per primitive-table flavour:
 
     c      the reference's own C table (setupCPrimitives + aliases)            -> the host-CPU baseline, kind "reference"
+    csse   (v3 build only) c + the reference's SSE intrinsic DCT / iDCT / dequant_scaling (common/vec/*.cpp) -> the strongest host table this image can build
     hip    1816 slots served by libx265hip.so's per-call stubs (table layer)   -> drop-in, byte-identical, launch-bound
     seam   C table + the stage-level seam (oracle/ref_seam.cpp): MotionEstimate::motionEstimate replays its integer search on the
            SAD surfaces one x265hip_me_fullsearch launch per (picture, reference) produced (batch layer)
@@ -112,6 +113,10 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
             enc_lib = SD.seam_lib(depth, build)
             enc_lib.x265ref_seam_disable()
             filler = ctypes.cast(enc_lib.x265ref_split_fill_table, ctypes.c_void_p)
+        if t == "csse":            # the C table + the reference's own SSE3 / SSSE3 / SSE4.1 intrinsic transforms (common/vec/*.cpp): only in the v3 flavour (oracle/Makefile)
+            if not hasattr(lib, "x265ref_sse_fill_table") or build != "v3":
+                continue
+            filler = ctypes.cast(lib.x265ref_sse_fill_table, ctypes.c_void_p)
         if t == "hip":
             A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
             L = A.lib()

@@ -441,7 +441,12 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     constexpr int kMaxSplitInFlight = 8;                                // 8 x 16 bands = half the CUs at most wait on a neighbour
     bool counted = false;
     {
+        // a launch recorded into a HIP graph is replayed without passing here again: the release callback would run once per replay against ONE
+        // increment and the cap below would stop meaning anything (round-4 advisor) - under capture the estimate is not split
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (stream) (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
         if (splitEnv) K = atoi(splitEnv);
+        else if (cap == hipStreamCaptureStatusActive) K = 1;
         else if (p->height_in_cu >= 32 && p->npairs <= 4)
         {
             if (splitInFlight.fetch_add(1) < kMaxSplitInFlight) { K = (p->height_in_cu + 7) / 8; counted = true; }
