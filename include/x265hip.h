@@ -146,6 +146,9 @@ static inline size_t x265hip_surf_ctu_bytes(int surf_format, int range)
 }
 int x265hip_me_fullsearch(const x265hip_me_params* p, void* stream);
 int x265hip_me_best_reset(uint64_t* best, size_t count, void* stream);
+/* Name of the kernel a minima-only launch (surf == NULL) of x265hip_me_fullsearch runs at this depth and range - what a profile of the caller lists as its
+ * dominant kernel (bench.py prints it as roofline.kernel); honours the A/B switches X265HIP_ME_BEST_VARIANT / X265HIP_ME_Q2_FLAGS like the launch itself. */
+const char* x265hip_me_minima_kernel_name(int depth, int range);
 
 /* Sub-pel refinement of every PU's integer motion vector (the caller loop of SURVEY section 8(f) item 1,
  * reference MotionEstimate::motionEstimate, motion.cpp:1448-1561 + subpelCompare :1571-1664, luma):

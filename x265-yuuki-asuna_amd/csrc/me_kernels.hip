@@ -1194,6 +1194,19 @@ __global__ void fill_u64_kernel(unsigned long long* p, size_t n, unsigned long l
 
 using namespace x265hip;
 
+extern "C" const char* x265hip_me_minima_kernel_name(int depth, int range)
+{
+    static thread_local char name[64];
+    if (depth != 8) return "me_ctu_w_kernel<best>";
+    if (2 * range + 75 > 256) return "me_ctu_kernel<u8,best>";
+    const char* bestVarEnv = getenv("X265HIP_ME_BEST_VARIANT");
+    const char* q2Env = getenv("X265HIP_ME_Q2_FLAGS");
+    const int q2Flags = q2Env ? atoi(q2Env) : (bestVarEnv ? -1 : Q2_DEFAULT_FLAGS);
+    if (q2Flags < 0 || range > 120 || (bestVarEnv && (atoi(bestVarEnv) & 3))) return "me_ctu_q_kernel<best>";
+    snprintf(name, sizeof(name), "me_ctu_q2_kernel<256,%d>", q2Flags);
+    return name;
+}
+
 extern "C" int x265hip_me_fullsearch(const x265hip_me_params* p, void* stream)
 {
     int rc = ensure_device();
