@@ -339,18 +339,20 @@ ENC_DEFAULTS = {"cfg3": (48, 5), "cfg3f": (24, 5), "cfg4": (24, 5), "cfg2": (96,
 
 
 def seam_config(key):
-    """How the encoder legs configure the consumer services for BASELINE configuration `key` - chosen by what was MEASURED
-    (profiles/r05_seam_matrix.txt), not by how many lookups get served: row-granular SAD planes of +-12 centred on each CTU's own
-    displacement (found within +-57 = the reference's merange), the 32x32-and-up levels only at 8 bits (`min_level` 2: the same fps as
-    level 1 at 40 % of the download), sub-sample comparisons, lookahead frame costs, AQ and weightAnalyse from the device;
-    everything the services do not answer takes the host-only control's split SADs."""
+    """How the encoder legs configure the consumer services for BASELINE configuration `key` - by what was MEASURED on one box, every leg against the
+    host-only control (profiles/r05_seam_matrix.txt, tools/r5_seam_matrix.sh), not by how many lookups get served (round-4 verdict, next 4):
+      * 8 bits: NO SAD lookups.  With the host path equal they add nothing at cfg3 (7.95 fps without, 7.89 - 7.98 with, 9.4 GB instead of 14.5 - 22.7 GB
+        downloaded per 48 frames) and cost 6 % on the fade (4.46 against 4.10 - 4.20: the searches leave the windows, hit rate 0.11 - 0.17);
+      * above 8 bits: the 32x32 / 64x64 rasters only (`min_level` 2): 1.88 fps like level 1, 8.9 instead of 13.2 GB; without the SAD seam 1.85;
+      * always: sub-sample comparisons, lookahead frame costs, AQ and weightAnalyse from the device; the binding's hit-rate gate (ref_seam.cpp) stops opening
+        pairs when fewer than half of the lookups of a window hit; everything the services do not answer takes the host-only control's split SADs."""
     depth = CFG_DEPTH.get(key, 8)
+    base = {"range": 12, "centre_range": 57, "layout": 1, "min_pu": 16, "verify": False, "lookahead": True, "subpel": True, "streamed": True, "aq": True,
+            "weight_analyse": True, "split_rest": True, "no_sad": depth == 8 and os.environ.get("X265HIP_SEAM_SAD_8BIT") != "1",
+            "min_level": int(os.environ.get("X265HIP_SEAM_MIN_LEVEL", "2"))}
     if key == "cfg5":       # 8K: a reference picture's phase planes are 3.4 GB of pinned memory, three frames need few resident pairs / views
-        return {"range": 12, "centre_range": 57, "layout": 1, "slots": 12, "min_pu": 16, "verify": False, "lookahead": True, "subpel": True, "subpel_slots": 4,
-                "streamed": True, "min_level": 1, "pictures": 8, "aq": True, "weight_analyse": True, "split_rest": True}
-    return {"range": 12, "centre_range": 57, "layout": 1, "slots": 24 if depth == 8 else 40, "min_pu": 16, "verify": False, "lookahead": True,
-            "subpel": True, "subpel_slots": 12, "streamed": True, "min_level": int(os.environ.get("X265HIP_SEAM_MIN_LEVEL", "2" if depth == 8 else "1")),
-            "pictures": 24, "aq": True, "weight_analyse": True, "split_rest": True}
+        return {**base, "slots": 12, "subpel_slots": 4, "pictures": 8, "min_level": 1}
+    return {**base, "slots": 24 if depth == 8 else 40, "subpel_slots": 12, "pictures": 24}
 
 
 def encoder_plan(args):

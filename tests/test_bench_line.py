@@ -133,4 +133,7 @@ def test_encoder_plan_names_every_default_configuration():
     by = {p["name"]: p for p in plan}
     assert by["cfg3"]["frames"] == 48 and by["cfg3"]["frame_threads"] == 5 and by["cfg5"]["frames"] == 3
     assert by["cfg4_v3"]["build"] == "v3" and by["cfg4"]["seam"]["slots"] == 40 and by["cfg3"]["seam"]["slots"] == 24
+    # configured by the one-box matrix (profiles/r05_seam_matrix.txt): no SAD lookups at 8 bits, the 32x32-and-up rasters above
+    assert by["cfg3"]["seam"]["no_sad"] and by["cfg3f"]["seam"]["no_sad"] and not by["cfg4"]["seam"]["no_sad"] and by["cfg4"]["seam"]["min_level"] == 2
+    assert by["cfg3_v3"]["tables"][:2] == ["c", "csse"]
     assert len(json.dumps(plan)) < 100000         # goes through argv

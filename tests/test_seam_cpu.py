@@ -433,3 +433,37 @@ def test_seams_with_the_host_only_split_for_everything_they_do_not_answer(depth,
     assert got[0] == base[0] == plain_seam[0], f"bitstream changed: {rep}"
     assert rep["verify_mismatches"] == 0 and rep["lookups_served"] > 300, rep
     assert got[3] > plain_seam[3] and got[3] >= 50, (got[3], plain_seam[3])
+
+
+# ---- round 5: the SAD seam's hit-rate gate -----------------------------------------------------------------------------------------
+@pytest.mark.reference
+def test_hit_rate_gate_closes_the_sad_seam_when_the_windows_are_missed_and_probes_again():
+    """A +-2 window on a clip that moves (3, 2) per picture: nearly every lookup falls outside.  With the gate (a window of 20000 lookups, 50 %) the
+    binding stops opening pairs once it has seen that, leaves the searches to the host, probes with every 8th picture - and the bitstream is the
+    reference's either way.  Without the gate every picture's pairs are opened."""
+    EB, SD = _tools()
+    try:
+        plain = EB.ref_lib(8)
+        SD.seam_lib(8)
+    except (SystemExit, FileNotFoundError):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    w, h, n = 256, 192, 20
+    clip = F.synth_clip(w, h, n, depth=8, seed=41)
+    yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
+    opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24"), ("me", "star"), ("no-weightp", None), ("no-weightb", None), ("bframes", "0")]
+    base = EB.encode(plain, yuv, w, h, n, "slow", opts)
+    reps = {}
+    for name, gate in (("gated", (20000, 50)), ("open", None)):
+        lib, filler, report, close, prov = SD.install(8, w, h, provider="oracle", rng=2, slots=32, min_pu=8, verify=True, streamed=True, min_level=0, hit_rate_gate=gate)
+        try:
+            got = EB.encode(lib, yuv, w, h, n, "slow", opts, filler)
+            reps[name] = report()
+        finally:
+            close()
+        assert got[0] == base[0], f"seam changed the bitstream ({name}): {reps[name]}"
+        assert reps[name]["verify_mismatches"] == 0
+    g, o = reps["gated"], reps["open"]
+    assert o["lookup_hit_rate"] < 0.5 and o["hit_rate_gate"]["times_closed"] == 0 and o["hit_rate_gate"]["window_lookups"] == 0, o
+    assert g["hit_rate_gate"]["times_closed"] >= 1 and g["hit_rate_gate"]["searches_left_to_the_host_while_closed"] > 100, g["hit_rate_gate"]
+    assert g["pair_submits"] < o["pair_submits"], (g["pair_submits"], o["pair_submits"])          # fewer pairs searched by the provider
+    assert g["pair_submits"] >= 3                                                                # ... but the probes keep coming

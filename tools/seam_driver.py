@@ -747,7 +747,7 @@ class MultiDevicePhaseProvider:
 
 def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
             surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0, min_ctus=0, build="", aq=None, aq_min_blocks=0,
-            weight_analyse=None, weight_min_blocks=0, split_rest=False, devices=None):
+            weight_analyse=None, weight_min_blocks=0, split_rest=False, devices=None, hit_rate_gate=(2000000, 50)):
     """devices: [device index, ...] = one instance of each row-granular service PER entry (MultiDeviceStreamProvider / MultiDevicePhaseProvider).
     Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
     the picture-granular providers need --frame-threads 1, streamed=True (row-granular providers) serves under any --frame-threads."""
@@ -762,6 +762,9 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     # the binding's own size gate of the two search seams (1000 CTUs: serve from 4K up) unless the caller names a threshold; tests on small pictures pass 0
     lib.x265ref_seam_min_ctus.argtypes = [ctypes.c_int]
     lib.x265ref_seam_min_ctus(1000 if min_ctus is None else min_ctus)
+    # the SAD seam's hit-rate gate (window in lookups, percent): below that share of served lookups no new pairs are opened until a probe picture hits again
+    lib.x265ref_seam_hit_rate_gate.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    lib.x265ref_seam_hit_rate_gate(*(hit_rate_gate or (0, 50)), None)
     if streamed:
         prov = (MultiDeviceStreamProvider(depth, geo, rng, slots, min_level, pictures, band_rows, layout, centre_range, devices) if provider == "gpu" and devices
                 else StreamGpuProvider(depth, geo, rng, slots, min_level, pictures, band_rows, layout, centre_range) if provider == "gpu"
@@ -860,6 +863,9 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
         d.update(prov.report())
         d.update({"range": rng, "slots": slots, "min_pu": min_pu, "row_granular": bool(streamed), "layout": "planes" if layout else "records", "centre_range": centre_range,
                   "search_seams_left_off_by_the_size_gate": bool(lib.x265ref_seam_min_ctus(-1))})
+        gate = (ctypes.c_uint64 * 4)()
+        lib.x265ref_seam_hit_rate_gate(-1, -1, gate)
+        d["hit_rate_gate"] = {"searches_left_to_the_host_while_closed": int(gate[0]), "times_closed": int(gate[1]), "closed_at_the_end": bool(gate[2]), "window_lookups": int(gate[3])}
         if streamed:
             so4 = (ctypes.c_uint64 * 4)()
             lib.x265ref_seam_stream_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]

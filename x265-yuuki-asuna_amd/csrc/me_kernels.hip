@@ -1038,7 +1038,7 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
 int launch_me_cand(const x265hip_me_params* p, hipStream_t s);       // me_cand_kernel.hip: 0 = launched, 1 = not applicable, < 0 = error
 
 // the flag set the minima-only 8-bit launch uses by default (-1 = round 4's kernel): what measured fastest on one box, profiles/r05_me_flags_ab.txt
-static const int Q2_DEFAULT_FLAGS = -1;
+static const int Q2_DEFAULT_FLAGS = 254;      // CTAB | PAIR64 | DEFERX | COLMIN | MASK | RING | QUAD64: 1.24 ms against round 4's 1.42 at 4K (three interleaved rounds)
 
 static int pick_waves(int ncols)
 {
