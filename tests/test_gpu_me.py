@@ -270,3 +270,43 @@ def test_me_minima_only_launch_every_kernel_variant(case, variant, monkeypatch):
                               want_surf=False, want_best=True)
     gb = ms.best.cpu().numpy().view(np.uint64)
     assert np.array_equal(gb, best), f"variant {variant!r}: {np.count_nonzero(gb != best)} of {gb.size} minima differ"
+
+
+@pytest.mark.parametrize("w2", ["0", "1"])
+@pytest.mark.parametrize("case", [(192, 128, 57, 4.0, None), (128, 128, 8, 0.0, None), (128, 64, 16, 16.0, None), (128, 64, 5, 4.0, "flat"), (192, 192, 12, 2.0, "centres"),
+                                  (128, 64, 100, 1.0, None)])
+def test_me_minima_only_launch_10bit_both_kernels(case, w2, monkeypatch):
+    """The 16-bit minima-only launch: round 4's me_ctu_w_kernel<best> (X265HIP_ME_W2=0) and round 5's me_ctu_w2_kernel (row constants from an LDS table,
+    costX once per group, the 64x64 level four rows at a time, the 16x16 level summed by a transposing butterfly) against the oracle - both LDS pitches
+    (+-12 / +-16: 256 bytes, +-57 / +-100: 512), ties decided by raster order alone, a flat picture, windows centred per CTU."""
+    import torch
+    width, height, rng, lam, special = case
+    monkeypatch.delenv("X265HIP_ME_BEST_VARIANT", raising=False)
+    monkeypatch.setenv("X265HIP_ME_W2", w2)
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(width, height, 2, depth=10, seed=60 + rng)
+    y0, y1 = clip[0][0], clip[1][0]
+    if special == "flat":
+        y0 = np.zeros_like(y0); y1 = np.full_like(y1, 1023)
+    cur, ref = P.DevicePicture(y1, dev), P.DevicePicture(y0, dev)
+    ms = P.MotionSearch(cur.w64, cur.h64, rng, 10, dev, want_surf=False, lam=lam)
+    O = _oracle()
+    if special == "centres":
+        r = np.random.default_rng(6)
+        cen = r.integers(-20, 21, size=(ms.nctu, 2)).astype(np.int16)
+        ms.run(cur, ref, centres=torch.from_numpy(cen).to(dev))
+        torch.cuda.synchronize()
+        gb = ms.best.cpu().numpy().view(np.uint64).reshape(ms.nctu, 85)
+        cw = cur.w64 // 64
+        for c in range(ms.nctu):
+            o = cur.org + (c // cw) * 64 * cur.stride + (c % cw) * 64
+            _, best = O.me_fullsearch(10, cur.host, cur.stride, o, ref.host, ref.stride, o + int(cen[c, 1]) * ref.stride + int(cen[c, 0]), 64, 64, rng, 0, 1,
+                                      ms.cost_host, ms.cost_host, want_surf=False, want_best=True)
+            assert np.array_equal(gb[c], best.reshape(-1)), (c, w2)
+        return
+    ms.run(cur, ref)
+    torch.cuda.synchronize()
+    _, best = O.me_fullsearch(10, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, rng, 0, ms.nctu, ms.cost_host, ms.cost_host,
+                              want_surf=False, want_best=True)
+    gb = ms.best.cpu().numpy().view(np.uint64)
+    assert np.array_equal(gb, best), f"X265HIP_ME_W2={w2}: {np.count_nonzero(gb != best)} of {gb.size} minima differ"

@@ -1033,11 +1033,208 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
     }
 }
 
+// Round 5: the minima-only 16-bit launch with what paid off in the 8-bit kernel (me_ctu_q2_kernel flags CTAB, DEFERX, QUAD64; the per-column 8x8 minima
+// were this kernel's already): the row's `costY << 8 | m` from an LDS table through v_readlane (fetched a block of 8 rows ahead) instead of a
+// global_load_ushort + wait in every row's chain, costX once per column group, the 64x64 level reduced for four window rows at a time, the window rows of a
+// block addressed from one register.  Same SADs, same keys, identical results (tests/test_gpu_me.py); X265HIP_ME_W2=0 selects round 4's kernel (A/B).
+template <int PITCH>
+__global__ void __launch_bounds__(1024, 4) me_ctu_w2_kernel(MEArgs a, int ctabOff)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t win[];
+    typedef unsigned long long u64;
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const int R = a.range;
+    const int NC = 2 * R + 1;
+    const int NG = (NC + 3) >> 2;
+    const int rows = 64 + 2 * R;
+    const int ctu = blockIdx.x;
+    const int cx = (ctu % a.ctusW) * 64, cy = (ctu / a.ctusW) * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    constexpr int pitch = PITCH;
+
+    const int ccx = a.centres ? a.centres[2 * ctu] : 0, ccy = a.centres ? a.centres[2 * ctu + 1] : 0;
+    const uint8_t* g0 = a.fref + (long)(cy + ccy - R) * a.frefStrideB + (long)(cx + ccx - R) * 2;
+    const int rowDw = a.payloadDw;
+    for (int r = wave; r < rows; r += nwaves)
+    {
+        const uint8_t* src = g0 + (long)r * a.frefStrideB;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(win + lds_row_off(r, pitch));
+        for (int c = lane; c < rowDw; c += 64)
+            dst[c] = ld_u32(src + 4 * c);
+    }
+    uint32_t* ctab = reinterpret_cast<uint32_t*>(win + ctabOff);
+    for (int i = threadIdx.x; i < NC + 16; i += blockDim.x)
+        ctab[i] = i < NC ? ((uint32_t)a.costY[i] << 8) | (uint32_t)i : 0xffffff00u;
+    int bx, by;
+    zorder_xy(lane, bx, by);
+    uint32_t F[8][4];
+    {
+        const uint8_t* fe = a.fenc + (long)(cy + by * 8) * a.fencStrideB + (long)(cx + bx * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) F[j][k] = ld_u32(fe + (long)j * a.fencStrideB + 4 * k);
+    }
+    __syncthreads();
+
+    u64 bk8 = ~0ull, bk16 = ~0ull, bk32 = ~0ull, bk64 = ~0ull;
+    const int kcol = lane & 3;
+    const int oddRow = (lane >> 4) & 1;
+    const bool lane1 = (lane & 1) != 0, lane2 = (lane & 2) != 0;
+
+    const int T = 2 * R + 8;
+    for (int g = wave; g < NG; g += nwaves)
+    {
+        const uint32_t colOff = (uint32_t)((by * 8) * pitch + (bx * 8 + 4 * g) * 2);
+        auto block_off = [&](const int t0) { uint32_t o = colOff + (uint32_t)(t0 * pitch + lds_skew_bytes(by + (t0 >> 3))); asm volatile("" : "+v"(o)); return o; };
+        uint32_t cxk4[4], cxL;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            cxk4[k] = ((4 * g + k < NC ? (uint32_t)a.costX[4 * g + k] : (1u << 20)) << 2) | (uint32_t)k;
+        cxL = 4 * g + kcol < NC ? (uint32_t)a.costX[4 * g + kcol] : (1u << 23);
+        const uint32_t cxL8 = cxL << 8;
+        uint32_t r8c[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
+        uint32_t r8 = 0xffffffffu, r16 = 0xffffffffu, r32 = 0xffffffffu, r64 = 0xffffffffu;
+        uint32_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[i][k] = 0;
+
+        // row constants: lane l takes the table entry of window row t0 + (l & 7) at the top of a block (its first use is a row of 128 SADs away); the entry of
+        // the row a lane ends up holding after the four-row 64x64 reduction is read when the quad starts - registers are what this kernel is short of
+        auto tab = [&](const int i) { return ctab[i < 0 ? 0 : i]; };
+        auto rows8 = [&](auto firstTag, auto nrowsTag, const int t0)
+        {
+            constexpr bool FIRST = decltype(firstTag)::value;
+            constexpr int NROWS = decltype(nrowsTag)::value;
+            const uint32_t bb = block_off(t0);
+            const uint32_t cb = tab(t0 - 7 + (lane & 7));
+            uint32_t v32even = 0, pairSum = 0, prq = 0;
+#pragma unroll
+            for (int p = 0; p < NROWS; p++)
+            {
+                if (!FIRST && (p & 3) == 0)          // the quad (or tail pair) that starts here: the entry of the row this lane will hold
+                    prq = tab(t0 - 7 + p + (p + 4 <= NROWS ? (lane >> 4) : oddRow));
+                const uint32_t* lp = reinterpret_cast<const uint32_t*>(win + bb + p * pitch);
+                uint32_t d[6], e[5];
+#pragma unroll
+                for (int k = 0; k < 6; k++) d[k] = lp[k];
+#pragma unroll
+                for (int k = 0; k < 5; k++) e[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], 16);
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                {
+                    if (FIRST && j > p) continue;
+                    const int slot = (p - j) & 7;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        acc[slot][0] = __builtin_amdgcn_sad_u16(d[k], F[j][k], acc[slot][0]);
+                        acc[slot][1] = __builtin_amdgcn_sad_u16(e[k], F[j][k], acc[slot][1]);
+                        acc[slot][2] = __builtin_amdgcn_sad_u16(d[k + 1], F[j][k], acc[slot][2]);
+                        acc[slot][3] = __builtin_amdgcn_sad_u16(e[k + 1], F[j][k], acc[slot][3]);
+                    }
+                }
+                if (!FIRST || p == 7)
+                {
+                    const int slot = (p + 1) & 7;
+                    int s8[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { s8[k] = (int)acc[slot][k]; acc[slot][k] = 0; }
+                    // 16x16 level, transposed while it is summed: lane (quad q, k = lane & 3) ends with column k of 16x16 PU q.  A butterfly over the quad - each
+                    // lane keeps the column whose parity is its own and hands the other one over (quad_perm xor 1), then the same for the pair of pairs (xor 2):
+                    // 6 selects + 3 DPP adds where four full quad sums and a four-way select took 8 + 3 (which the compiler turned into divergent branches)
+                    const int keep0 = lane1 ? s8[1] : s8[0], give0 = lane1 ? s8[0] : s8[1];
+                    const int keep1 = lane1 ? s8[3] : s8[2], give1 = lane1 ? s8[2] : s8[3];
+                    const int t0s = keep0 + dpp<0xB1>(give0), t1s = keep1 + dpp<0xB1>(give1);          // columns {0|1} / {2|3} over the lane pair
+                    const int v16i = (lane2 ? t1s : t0s) + dpp<0x4E>(lane2 ? t0s : t1s);
+                    const uint32_t v16 = (uint32_t)v16i;
+                    const uint32_t v32 = (uint32_t)row_sum_of_quads(v16i);
+                    const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)cb, p);      // costY[m] << 8 | m, in an SGPR
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        const uint32_t kk = ((uint32_t)s8[k] << 8) + sb;                               // (sad + costY) << 8 | m (an 8x8 SAD of 10-bit samples is < 2^16)
+                        r8c[k] = kk < r8c[k] ? kk : r8c[k];
+                    }
+                    const uint32_t k16 = (v16 << 8) + sb, k32 = (v32 << 8) + sb;             // costX joins once per group
+                    r16 = k16 < r16 ? k16 : r16;
+                    r32 = k32 < r32 ? k32 : r32;
+                    if (FIRST)
+                    {   // the first block completes a single row (m = 0)
+                        v2u sw = __builtin_amdgcn_permlane16_swap(v32, v32, false, false);
+                        const unsigned h64 = sw.x + sw.y;
+                        sw = __builtin_amdgcn_permlane32_swap(h64, h64, false, false);
+                        const uint32_t k64 = ((sw.x + sw.y) << 8) + sb;
+                        r64 = k64 < r64 ? k64 : r64;
+                    }
+                    else if ((p & 1) == 0) v32even = v32;
+                    else
+                    {
+                        // rows A (p - 1) and B (p): {A0,B0,A2,B2} + {A1,B1,A3,B3} = {A01, B01, A23, B23}
+                        v2u sw = __builtin_amdgcn_permlane16_swap(v32even, v32, false, false);
+                        const unsigned h64 = sw.x + sw.y;
+                        const bool quadEnd = (p & 3) == 3, tailPair = (p & 3) == 1 && p + 2 >= NROWS;       // constants once the row loop is unrolled
+                        if (quadEnd)
+                        {   // with the pair before it: the halves change places -> 16-lane row r holds the total of the quad's row r
+                            sw = __builtin_amdgcn_permlane32_swap(pairSum, h64, false, false);
+                            const uint32_t k64 = ((sw.x + sw.y) << 8) + prq;
+                            r64 = k64 < r64 ? k64 : r64;
+                        }
+                        else if (tailPair)
+                        {
+                            sw = __builtin_amdgcn_permlane32_swap(h64, h64, false, false);
+                            const uint32_t k64 = ((sw.x + sw.y) << 8) + prq;
+                            r64 = k64 < r64 ? k64 : r64;
+                        }
+                        else pairSum = h64;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        using I8 = std::integral_constant<int, 8>;
+        rows8(std::true_type{}, I8{}, 0);
+        int t0 = 8;
+        for (; t0 + 8 <= T; t0 += 8)
+            rows8(std::false_type{}, I8{}, t0);
+        switch (T - t0)
+        {
+        case 2: rows8(std::false_type{}, std::integral_constant<int, 2>{}, t0); break;
+        case 4: rows8(std::false_type{}, std::integral_constant<int, 4>{}, t0); break;
+        case 6: rows8(std::false_type{}, std::integral_constant<int, 6>{}, t0); break;
+        default: break;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const uint32_t kc = ((r8c[k] >> 8) << 2) + cxk4[k];                      // (sad + costY + costX) << 2 | k
+            const uint32_t key = ((kc & ~3u) << 8) | ((r8c[k] & 255u) << 2) | (kc & 3u);
+            r8 = key < r8 ? key : r8;
+        }
+        const u64 w8 = ((u64)(r8 >> 10) << 32) | (uint32_t)(((r8 >> 2) & 255u) * NC + 4 * g + (r8 & 3u));
+        bk8 = w8 < bk8 ? w8 : bk8;
+        auto widen = [&](const uint32_t r) { const uint32_t rc = r + cxL8; return ((u64)(rc >> 8) << 32) | (uint32_t)((rc & 255u) * NC + 4 * g + kcol); };
+        const u64 w16 = widen(r16), w32 = widen(r32), w64 = widen(r64);
+        bk16 = w16 < bk16 ? w16 : bk16;
+        bk32 = w32 < bk32 ? w32 : bk32;
+        bk64 = w64 < bk64 ? w64 : bk64;
+    }
+    u64* rec = a.best + (size_t)ctu * 85;
+    atomicMin(&rec[lane], bk8);
+    atomicMin(&rec[64 + (lane >> 2)], bk16);
+    if ((lane & 15) < 4) { atomicMin(&rec[80 + (lane >> 4)], bk32); atomicMin(&rec[84], bk64); }      // every 16-lane row saw its own window rows of the 64x64 level
+}
+
 // wavefronts per workgroup: as many as the column count keeps busy (16 = 1024 threads max); the
 // columns are dealt round-robin, so the idle tail is at most one column per wavefront.
 int launch_me_cand(const x265hip_me_params* p, hipStream_t s);       // me_cand_kernel.hip: 0 = launched, 1 = not applicable, < 0 = error
 
 // the flag set the minima-only 8-bit launch uses by default (-1 = round 4's kernel): what measured fastest on one box, profiles/r05_me_flags_ab.txt
+static const bool W2_DEFAULT = false;         // the 16-bit twin (me_ctu_w2_kernel): off until it has been measured on one box
 static const int Q2_DEFAULT_FLAGS = 254;      // CTAB | PAIR64 | DEFERX | COLMIN | MASK | RING | QUAD64: 1.24 ms against round 4's 1.42 at 4K (three interleaved rounds)
 
 static int pick_waves(int ncols)
@@ -1169,7 +1366,21 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
             if (anySurf) LAUNCH_W(true, false, 16);
             if (anyBest)
             {
-                if (bestVarW == 0) LAUNCH_WV(0); else if (bestVarW == 2) LAUNCH_WV(2); else if (bestVarW == 3) LAUNCH_WV(3); else LAUNCH_WV(1);
+                const char* w2Env = getenv("X265HIP_ME_W2");                 // round 5's kernel (me_ctu_w2_kernel): 0 = round 4's (A/B), unset = W2_DEFAULT
+                const bool w2 = (w2Env ? atoi(w2Env) != 0 : W2_DEFAULT) && bestVarW < 0 && p->range <= 120;
+                if (w2)
+                {
+                    int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 12) nwq = 12;
+                    if (bestWavesW >= 4 && bestWavesW <= 16) nwq = bestWavesW;
+                    const size_t lds2 = lds + (size_t)(2 * p->range + 1 + 16) * 4;
+                    if (a.rowBytes == 256) hipLaunchKernelGGL((me_ctu_w2_kernel<256>), grid, dim3(nwq * 64), lds2, s, a, (int)lds);
+                    else
+                    {
+                        if (lds2 > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_w2_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                        hipLaunchKernelGGL((me_ctu_w2_kernel<512>), grid, dim3(nwq * 64), lds2, s, a, (int)lds);
+                    }
+                }
+                else if (bestVarW == 0) LAUNCH_WV(0); else if (bestVarW == 2) LAUNCH_WV(2); else if (bestVarW == 3) LAUNCH_WV(3); else LAUNCH_WV(1);
             }
         }
 #undef LAUNCH_W
@@ -1197,7 +1408,11 @@ using namespace x265hip;
 extern "C" const char* x265hip_me_minima_kernel_name(int depth, int range)
 {
     static thread_local char name[64];
-    if (depth != 8) return "me_ctu_w_kernel<best>";
+    if (depth != 8)
+    {
+        const char* w2Env = getenv("X265HIP_ME_W2");
+        return ((w2Env ? atoi(w2Env) != 0 : W2_DEFAULT) && !getenv("X265HIP_ME_BEST_VARIANT") && range <= 120 && depth <= 10) ? "me_ctu_w2_kernel" : "me_ctu_w_kernel<best>";
+    }
     if (2 * range + 75 > 256) return "me_ctu_kernel<u8,best>";
     const char* bestVarEnv = getenv("X265HIP_ME_BEST_VARIANT");
     const char* q2Env = getenv("X265HIP_ME_Q2_FLAGS");
