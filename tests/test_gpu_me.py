@@ -274,11 +274,11 @@ def test_me_minima_only_launch_every_kernel_variant(case, variant, monkeypatch):
 
 @pytest.mark.parametrize("w2", ["0", "1"])
 @pytest.mark.parametrize("case", [(192, 128, 57, 4.0, None), (128, 128, 8, 0.0, None), (128, 64, 16, 16.0, None), (128, 64, 5, 4.0, "flat"), (192, 192, 12, 2.0, "centres"),
-                                  (128, 64, 100, 1.0, None)])
+                                  (128, 64, 72, 1.0, None)])
 def test_me_minima_only_launch_10bit_both_kernels(case, w2, monkeypatch):
     """The 16-bit minima-only launch: round 4's me_ctu_w_kernel<best> (X265HIP_ME_W2=0) and round 5's me_ctu_w2_kernel (row constants from an LDS table,
     costX once per group, the 64x64 level four rows at a time, the 16x16 level summed by a transposing butterfly) against the oracle - both LDS pitches
-    (+-12 / +-16: 256 bytes, +-57 / +-100: 512), ties decided by raster order alone, a flat picture, windows centred per CTU."""
+    (+-5 .. +-16: 256 bytes, +-57 / +-72: 512 - +-75 is the widest window the 16-bit fast path stages), ties decided by raster order alone, a flat picture, windows centred per CTU."""
     import torch
     width, height, rng, lam, special = case
     monkeypatch.delenv("X265HIP_ME_BEST_VARIANT", raising=False)

@@ -1234,7 +1234,7 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_w2_kernel(MEArgs a, int ctabOf
 int launch_me_cand(const x265hip_me_params* p, hipStream_t s);       // me_cand_kernel.hip: 0 = launched, 1 = not applicable, < 0 = error
 
 // the flag set the minima-only 8-bit launch uses by default (-1 = round 4's kernel): what measured fastest on one box, profiles/r05_me_flags_ab.txt
-static const bool W2_DEFAULT = false;         // the 16-bit twin (me_ctu_w2_kernel): off until it has been measured on one box
+static const bool W2_DEFAULT = true;          // the 16-bit twin (me_ctu_w2_kernel): 2.60 -> 2.35 ms at 4K, 9.95 -> 8.95 ms at 8K (one box, interleaved: profiles/r05_me10_ab.txt)
 static const int Q2_DEFAULT_FLAGS = 254;      // CTAB | PAIR64 | DEFERX | COLMIN | MASK | RING | QUAD64: 1.24 ms against round 4's 1.42 at 4K (three interleaved rounds)
 
 static int pick_waves(int ncols)
