@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Randomised soak of round 5's minima-only search kernels (me_ctu_q2_kernel<256, 254> at 8 bits, me_ctu_w2_kernel at 10) against the oracle: random picture sizes,
+window ranges over everything the fast paths stage (8-bit 1..90, 10-bit 1..75; beyond that the generic kernel answers - also compared), motion-vector cost scales from 0
+(every tie decided by raster order) to steep, flat / extreme / textured content, windows centred per CTU or not.  GPU box only; measurement aid, not part of the suite.
+
+  python tools/r5_me_minima_soak.py --seconds 90 [--seed 1]"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=90.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import torch
+    import oracle_api as O
+    F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+    P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+    A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+    name = A.lib().x265hip_me_minima_kernel_name
+    import ctypes
+    name.restype, name.argtypes = ctypes.c_char_p, [ctypes.c_int, ctypes.c_int]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(args.seed)
+    t0, n, kernels = time.time(), 0, {}
+    while time.time() - t0 < args.seconds:
+        depth = int(rng.choice([8, 8, 10]))
+        w, h = int(rng.integers(1, 5)) * 64, int(rng.integers(1, 4)) * 64
+        r = int(rng.choice([1, 2, 3, 5, 8, 12, 16, 24, 31, 57, 60, 75, 76, 90, 91, 100][: 16 if depth == 8 else 13]))
+        if (64 + 2 * r + 2) * (256 if (depth == 8 and 2 * r + 75 <= 256) or (depth > 8 and r <= 12) else 512 if r <= (90 if depth == 8 else 75) else 1024) > 160 * 1024:
+            continue
+        lam = float(rng.choice([0.0, 0.5, 4.0, 64.0]))
+        mode = int(rng.integers(0, 4))
+        clip = F.synth_clip(w, h, 2, depth=depth, seed=int(rng.integers(1, 1 << 30)))
+        y0, y1 = clip[0][0], clip[1][0]
+        maxv = (1 << depth) - 1
+        if mode == 1:
+            y0 = np.zeros_like(y0); y1 = np.full_like(y1, maxv)
+        elif mode == 2:
+            y0 = rng.integers(0, maxv + 1, y0.shape).astype(y0.dtype); y1 = rng.integers(0, maxv + 1, y1.shape).astype(y1.dtype)
+        cur, ref = P.DevicePicture(y1, dev), P.DevicePicture(y0, dev)
+        try:
+            ms = P.MotionSearch(cur.w64, cur.h64, r, depth, dev, want_surf=False, lam=lam)
+        except Exception as e:      # noqa: BLE001
+            print("skip", depth, w, h, r, e)
+            continue
+        centred = bool(rng.integers(0, 2)) and r <= 40
+        kernels[name(depth, r).decode()] = kernels.get(name(depth, r).decode(), 0) + 1
+        if centred:
+            cen = rng.integers(-24, 25, size=(ms.nctu, 2)).astype(np.int16)
+            ms.run(cur, ref, centres=torch.from_numpy(cen).to(dev))
+            torch.cuda.synchronize()
+            gb = ms.best.cpu().numpy().view(np.uint64).reshape(ms.nctu, 85)
+            cw = cur.w64 // 64
+            for c in range(ms.nctu):
+                o = cur.org + (c // cw) * 64 * cur.stride + (c % cw) * 64
+                _, best = O.me_fullsearch(depth, cur.host, cur.stride, o, ref.host, ref.stride, o + int(cen[c, 1]) * ref.stride + int(cen[c, 0]), 64, 64, r, 0, 1,
+                                          ms.cost_host, ms.cost_host, want_surf=False, want_best=True)
+                if not np.array_equal(gb[c], best.reshape(-1)):
+                    print("MISMATCH (centred)", depth, w, h, r, lam, mode, "ctu", c)
+                    sys.exit(1)
+        else:
+            ms.run(cur, ref)
+            torch.cuda.synchronize()
+            _, best = O.me_fullsearch(depth, cur.host, cur.stride, cur.org, ref.host, ref.stride, ref.org, cur.w64, cur.h64, r, 0, ms.nctu, ms.cost_host, ms.cost_host,
+                                      want_surf=False, want_best=True)
+            gb = ms.best.cpu().numpy().view(np.uint64)
+            if not np.array_equal(gb, best):
+                print("MISMATCH", depth, w, h, r, lam, mode, int(np.count_nonzero(gb != best)), "of", gb.size)
+                sys.exit(1)
+        n += 1
+    print(f"soak ok: {n} random cases in {time.time() - t0:.0f} s, kernels exercised: {kernels}")
+
+
+if __name__ == "__main__":
+    main()
