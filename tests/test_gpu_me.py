@@ -227,7 +227,7 @@ def test_me_4k_default_config_properties(packed):
         assert np.array_equal(ms.best[ctu * 85:(ctu + 1) * 85].cpu().numpy().view(np.uint64), best[ctu * 85:(ctu + 1) * 85])
 
 
-@pytest.mark.parametrize("variant", ["", "v0", "v1", "q0", "q1", "q2", "q4", "q8", "q32", "q14", "q46", "q62", "q64", "q126", "q190", "q254", "q238"])
+@pytest.mark.parametrize("variant", ["", "v0", "v1", "q0", "q1", "q2", "q4", "q8", "q32", "q14", "q46", "q62", "q64", "q126", "q190", "q254", "q238", "q256", "q446"])
 @pytest.mark.parametrize("case", [(192, 128, 57, 4.0, None), (128, 128, 8, 0.0, None), (256, 64, 90, 16.0, None), (128, 64, 5, 4.0, "flat"), (192, 192, 12, 2.0, "centres"),
                                   (128, 128, 120, 1.0, None)])
 def test_me_minima_only_launch_every_kernel_variant(case, variant, monkeypatch):
@@ -243,6 +243,8 @@ def test_me_minima_only_launch_every_kernel_variant(case, variant, monkeypatch):
         monkeypatch.setenv("X265HIP_ME_BEST_VARIANT", variant[1:])
     elif variant.startswith("q"):
         monkeypatch.setenv("X265HIP_ME_Q2_FLAGS", variant[1:])
+        if int(variant[1:]) & 256 and rng > 59:
+            pytest.skip("two window copies (flag 256) hold +-59 at most")
     dev = torch.device("cuda:0")
     clip = F.synth_clip(width, height, 2, depth=8, seed=40 + rng)
     y0, y1 = clip[0][0], clip[1][0]

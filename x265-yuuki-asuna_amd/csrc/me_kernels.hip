@@ -516,6 +516,8 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
 //  16  COLMIN  the 8x8 level keeps one running minimum per column and gives each column its costX once per group;
 //  64  RING    the three-dword loads of round 4 without their copies: two pairs of rows in flight in registers whose role alternates (the unrolled
 //              rows index them with constants), a block of 8 rows read from three address registers;
+// 256  LDA     the window staged twice (the second copy four bytes on), row groups skewed by {0, 16} dwords: both 64-bit values of a row are 8-byte-aligned
+//              ds_read_b64 from one copy or the other - LD64 without misaligned loads (ranges up to +-59);
 // 128  QUAD64  PAIR64 for FOUR rows: two pair sums {A01,B01,A23,B23} / {C01,D01,C23,D23} change halves in one v_permlane32_swap -> 16-lane row r
 //              holds the 64x64 total of the quad's row r (6 instructions and one key per four rows);
 //  32  MASK    the low halves of the packed 8x8 sums are extracted with an opaque v_and (the compiler turns `(x & 0xffff) << n` into
@@ -525,7 +527,8 @@ template <int PITCH, int FL>
 __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOff)
 {
     constexpr bool LD64 = (FL & 1) != 0, CTAB = (FL & 2) != 0, PAIR64 = (FL & 4) != 0, DEFERX = (FL & 8) != 0, COLMIN = (FL & 16) != 0, MASK = (FL & 32) != 0;
-    constexpr bool RING = (FL & 64) != 0, QUAD64 = (FL & 128) != 0;
+    constexpr bool RING = (FL & 64) != 0, QUAD64 = (FL & 128) != 0, LDA = (FL & 256) != 0;
+    static_assert(!LDA || (!LD64 && !RING), "LDA is a window-load scheme of its own");
     static_assert(!QUAD64 || (PAIR64 && CTAB), "QUAD64 extends PAIR64 and takes its per-lane row constants from the table");
     static_assert(!(RING && LD64), "RING is the three-dword load path without its copies");
     extern __shared__ __attribute__((aligned(16))) uint8_t win[];
@@ -546,12 +549,19 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
     const int ccx = a.centres ? a.centres[2 * ctu] : 0, ccy = a.centres ? a.centres[2 * ctu + 1] : 0;
     const uint8_t* g0 = a.fref + (long)(cy + ccy - R) * a.frefStrideB + (long)(cx + ccx - R);
     const int rowDw = a.payloadDw;
+    // LDA: the window is staged TWICE - copy B is copy A moved on by four bytes - and the groups of 8 rows are skewed by {0, 16} dwords only, so that both 64-bit
+    // values of a row (window bytes 0..7 and 4..11 of a block column) are 8-byte-ALIGNED loads from one copy or the other: for an even column group w0 comes from A and
+    // w1 from B, for an odd one the other way round.  (2 x 46 KB of LDS at +-57; the skew leaves room for +-59 at most: the host only selects LDA there.)
+    const int ldaB = LDA ? (rows + 2) * pitch : 0;
     for (int r = wave; r < rows; r += nwaves)
     {
         const uint8_t* src = g0 + (long)r * a.frefStrideB;
-        uint32_t* dst = reinterpret_cast<uint32_t*>(win + lds_row_off(r, pitch));
+        uint32_t* dst = reinterpret_cast<uint32_t*>(win + (LDA ? r * pitch + ((r >> 3) & 1) * 64 : lds_row_off(r, pitch)));
         for (int c = lane; c < rowDw; c += 64)
+        {
             dst[c] = ld_u32(src + 4 * c);
+            if (LDA) dst[c + ldaB / 4] = ld_u32(src + 4 * c + 4);
+        }
     }
     // CTAB: the rows' share of every key, costY[m] << 8 | m (16 entries of slack: a block fetches the NEXT block's entries)
     uint32_t* ctab = reinterpret_cast<uint32_t*>(win + ctabOff);
@@ -579,7 +589,24 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
         const uint32_t colOff = (uint32_t)((by * 8) * pitch + bx * 8 + 4 * g);
         // LDS byte offset of window row t0 of this lane's block column.  LD64 keeps it opaque: ds_read reaches 255 dwords past its address
         // register, so a block of 8 rows is read from THREE address registers (rows 0 - 3, rows 4 - 7, the next block's rows 0 - 1)
-        auto block_off = [&](const int t0) { uint32_t o = colOff + (uint32_t)(t0 * pitch + lds_skew_bytes(by + (t0 >> 3))); if (LD64 || RING) asm volatile("" : "+v"(o)); return o; };
+        auto block_off = [&](const int t0)
+        {
+            uint32_t o = colOff + (uint32_t)(t0 * pitch + (LDA ? ((by + (t0 >> 3)) & 1) * 64 : lds_skew_bytes(by + (t0 >> 3))));
+            if (LD64 || RING || LDA) asm volatile("" : "+v"(o));
+            return o;
+        };
+        // LDA: where this group's w0 / w1 live relative to block_off (which points at copy A, column 4 g): an even group reads w0 = A[4 g], w1 = B[4 g];
+        // an odd one w0 = B[4 (g - 1)] (= A[4 g]), w1 = A[4 (g + 1)] - every address a multiple of 8
+        const int ldaW0 = LDA ? ((g & 1) ? ldaB - 4 : 0) : 0, ldaW1 = LDA ? ((g & 1) ? 4 : ldaB) : 0;
+        auto ldpairA = [&](u64 (&d)[2][2], const uint32_t off, const int p)
+        {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+            {
+                d[q][0] = *reinterpret_cast<const u64*>(win + off + ldaW0 + (p + q) * pitch);
+                d[q][1] = *reinterpret_cast<const u64*>(win + off + ldaW1 + (p + q) * pitch);
+            }
+        };
         auto ldpair64 = [&](u64 (&d)[2][2], const uint32_t off, const int p)
         {
 #pragma unroll
@@ -613,7 +640,7 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
         uint32_t cur[2][3], nxt[2][3];                      // !LD64: round 4's three dwords per row
         uint32_t d3[2][2][3];                               // RING: the same three dwords, two pairs of rows in flight, no copies (slot parity as above)
         (void)buf; (void)cur; (void)nxt; (void)d3;
-        if (LD64) ldpair64(buf[0], block_off(0), 0); else if (RING) ldpair32(d3[0], block_off(0), 0); else ldpair32(cur, block_off(0), 0);
+        if (LDA) ldpairA(buf[0], block_off(0), 0); else if (LD64) ldpair64(buf[0], block_off(0), 0); else if (RING) ldpair32(d3[0], block_off(0), 0); else ldpair32(cur, block_off(0), 0);
 
         // CTAB: a block's row constants, fetched while the block before it runs.  lane l holds the entry of window row t0 + (l & 7)
         // (m = t0 + (l & 7) - 7; the first block only completes m = 0), pr[q] the entry of the row this lane holds after the paired reduction
@@ -659,7 +686,8 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
             {
                 if ((p & 1) == 0)
                 {
-                    if (LD64)
+                    if (LDA) { if (p + 2 < 8) ldpairA(buf[((p >> 1) + 1) & 1], bb, p + 2); else ldpairA(buf[((p >> 1) + 1) & 1], bn, 0); }
+                    else if (LD64)
                     {
                         if (p + 2 < 4) ldpair64(buf[((p >> 1) + 1) & 1], bb, p + 2);
                         else if (p + 2 < 8) ldpair64(buf[((p >> 1) + 1) & 1], bb4, p + 2 - 4);
@@ -674,7 +702,7 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
                     else { if (p + 2 < 8) ldpair32(nxt, bb, p + 2); else ldpair32(nxt, bn, 0); }
                 }
                 u64 w0, w1;
-                if (LD64) { w0 = buf[(p >> 1) & 1][p & 1][0]; w1 = buf[(p >> 1) & 1][p & 1][1]; }
+                if (LD64 || LDA) { w0 = buf[(p >> 1) & 1][p & 1][0]; w1 = buf[(p >> 1) & 1][p & 1][1]; }
                 else if (RING)
                 {
                     const uint32_t (&dd)[3] = d3[(p >> 1) & 1][p & 1];
@@ -778,7 +806,7 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
                         r64 = k64 < r64 ? k64 : r64;
                     }
                 }
-                if (!LD64 && !RING && (p & 1))
+                if (!LD64 && !RING && !LDA && (p & 1))
                 {
 #pragma unroll
                     for (int q = 0; q < 2; q++) { cur[q][0] = nxt[q][0]; cur[q][1] = nxt[q][1]; cur[q][2] = nxt[q][2]; }
@@ -1324,13 +1352,15 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
                 {   // round 5's flagged kernel: the same launch geometry + the row-constant table behind the window
                     int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 12) nwq = 12;
                     if (bestWaves >= 4 && bestWaves <= 16 && bestWaves < pick_waves((2 * p->range + 4) / 4) + 1) nwq = bestWaves;
-                    const size_t lds2 = lds + (size_t)(2 * p->range + 1 + 16) * 4;
+                    if ((q2Flags & 256) && a.payloadDw + 16 > 64) { set_error("me_fullsearch: X265HIP_ME_Q2_FLAGS bit 256 (two window copies) holds +-59 at most"); return X265HIP_EINVAL; }
+                    const size_t ctabAt = (q2Flags & 256) ? 2 * lds : lds;
+                    const size_t lds2 = ctabAt + (size_t)(2 * p->range + 1 + 16) * 4;
 #define LAUNCH_Q2(FLV) case FLV: \
                         if (lds2 > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_q2_kernel<256, FLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
-                        hipLaunchKernelGGL((me_ctu_q2_kernel<256, FLV>), grid, dim3(nwq * 64), lds2, s, a, (int)lds); break;
+                        hipLaunchKernelGGL((me_ctu_q2_kernel<256, FLV>), grid, dim3(nwq * 64), lds2, s, a, (int)ctabAt); break;
                     switch (q2Flags)
                     {
-                    LAUNCH_Q2(0) LAUNCH_Q2(1) LAUNCH_Q2(2) LAUNCH_Q2(4) LAUNCH_Q2(8) LAUNCH_Q2(32) LAUNCH_Q2(14) LAUNCH_Q2(46) LAUNCH_Q2(62) LAUNCH_Q2(64) LAUNCH_Q2(126) LAUNCH_Q2(190) LAUNCH_Q2(254) LAUNCH_Q2(238)
+                    LAUNCH_Q2(0) LAUNCH_Q2(1) LAUNCH_Q2(2) LAUNCH_Q2(4) LAUNCH_Q2(8) LAUNCH_Q2(32) LAUNCH_Q2(14) LAUNCH_Q2(46) LAUNCH_Q2(62) LAUNCH_Q2(64) LAUNCH_Q2(126) LAUNCH_Q2(190) LAUNCH_Q2(254) LAUNCH_Q2(238) LAUNCH_Q2(446) LAUNCH_Q2(256)
                     default: set_error("me_fullsearch: X265HIP_ME_Q2_FLAGS %d is not an instantiated combination", q2Flags); return X265HIP_EINVAL;
                     }
 #undef LAUNCH_Q2
