@@ -1347,10 +1347,11 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
             if (anyBest)
             {
                 if (bestVar == 1) LAUNCH_QV(1); else if (bestVar == 2) LAUNCH_QV(2); else if (bestVar == 3) LAUNCH_QV(3);
-                else if (q2Flags < 0 || p->range > 120) LAUNCH_QV(0);          // round 4's kernel
+                else if (q2Flags < 0) LAUNCH_QV(0);          // round 4's kernel
                 else
-                {   // round 5's flagged kernel: the same launch geometry + the row-constant table behind the window
-                    int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 12) nwq = 12;
+                {   // round 5's flagged kernel: the same launch geometry + the row-constant table behind the window; from 4K up 8 wavefronts per workgroup (two
+                    // workgroups per CU) are 0.8 % ahead of 12: 1.217 - 1.219 against 1.228 - 1.239 ms, one box, two interleaved rounds (profiles/r05_me_flags_ab.txt)
+                    int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 8) nwq = 8;
                     if (bestWaves >= 4 && bestWaves <= 16 && bestWaves < pick_waves((2 * p->range + 4) / 4) + 1) nwq = bestWaves;
                     if ((q2Flags & 256) && a.payloadDw + 16 > 64) { set_error("me_fullsearch: X265HIP_ME_Q2_FLAGS bit 256 (two window copies) holds +-59 at most"); return X265HIP_EINVAL; }
                     const size_t ctabAt = (q2Flags & 256) ? 2 * lds : lds;
@@ -1443,7 +1444,7 @@ extern "C" const char* x265hip_me_minima_kernel_name(int depth, int range)
         const char* w2Env = getenv("X265HIP_ME_W2");
         return ((w2Env ? atoi(w2Env) != 0 : W2_DEFAULT) && !getenv("X265HIP_ME_BEST_VARIANT") && range <= 120 && depth <= 10) ? "me_ctu_w2_kernel" : "me_ctu_w_kernel<best>";
     }
-    if (2 * range + 75 > 256) return "me_ctu_kernel<u8,best>";
+    if (((74 + 2 * range) >> 2) + 17 > 64) return "me_ctu_kernel<u8,best>";       // the window row + the largest skew must fit the 256-byte LDS pitch: +-58
     const char* bestVarEnv = getenv("X265HIP_ME_BEST_VARIANT");
     const char* q2Env = getenv("X265HIP_ME_Q2_FLAGS");
     const int q2Flags = q2Env ? atoi(q2Env) : (bestVarEnv ? -1 : Q2_DEFAULT_FLAGS);
