@@ -298,6 +298,10 @@ struct Ctx
     uint64_t hits, outside, notReady, saturated, cyc;
 };
 thread_local Ctx t_ctx;
+/* MEASUREMENT MODE (x265ref_predict_probe, off by default): how well would a device-side table of sub-sample costs "around the integer vector the
+ * device predicts" be addressed?  At the first sub-sample comparison of a search - the integer vector the host's search ended on - the rank of that vector among the
+ * window's SADs alone (what the device knows: no motion-vector cost, no predictors) is taken from the rasters the SAD seam already holds. */
+struct { bool on = false; std::atomic<uint64_t> total{0}, noCtx{0}, outside{0}, top1{0}, top2{0}, top4{0}, top8{0}; } gpp;
 struct TlsPair { const PicYuv* rec; int recPoc; int slot; int gen; Wt wt; };
 thread_local struct { int fencPoc; int epoch; int n; TlsPair e[8]; } t_pairs = { -0x7fffffff, -1, 0, {} };
 
@@ -930,6 +934,45 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
 int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_t cmp)
 {
     ProfScope prof(gp.subCyc, gp.subCalls);
+    if (gpp.on && !((qmv.x | qmv.y) & 3) && cmp == primitives.pu[partEnum].satd)
+    {
+        /* the refinement starts here: qmv is the integer vector the search ended on (motion.cpp:1515-1519) */
+        Ctx& k = t_ctx;
+        gpp.total++;
+        if (!k.valid || !k.centred || !g.p.layout || k.part != partEnum || k.ready[k.ctuRow] != k.gen) gpp.noCtx++;
+        else
+        {
+            const pixel* at = ref->fpelPlane[0] + blockOffset + (qmv.x >> 2) + (qmv.y >> 2) * k.stride;
+            const ptrdiff_t t = (at - k.fref0) + k.bias;
+            const uint64_t span = 2 * (uint64_t)g.p.range;
+            const uint64_t row = t < 0 ? ~0ull : (uint64_t)t / (uint64_t)k.stride, col = t < 0 ? ~0ull : (uint64_t)t - row * (uint64_t)k.stride;
+            if (t < 0 || row > span || col > span) gpp.outside++;
+            else
+            {
+                auto sad_at = [&](size_t idx)
+                {
+                    unsigned s = 0;
+                    for (int i = 0; i < k.nparts; i++)
+                        s += k.parts[i].wide ? ((const uint32_t*)(k.ctuBase + k.parts[i].off))[idx] : ((const uint16_t*)(k.ctuBase + k.parts[i].off))[idx];
+                    return s;
+                };
+                const size_t here = (size_t)row * g.pitch + col;
+                const unsigned mine = sad_at(here);
+                unsigned better = 0;                                    /* candidates the device would rank before this one: smaller SAD, or equal and earlier in raster order */
+                for (uint64_t y = 0; y <= span && better < 8; y++)
+                    for (uint64_t x = 0; x <= span; x++)
+                    {
+                        const size_t idx = (size_t)y * g.pitch + x;
+                        const unsigned v = sad_at(idx);
+                        better += v < mine || (v == mine && idx < here);
+                    }
+                if (better < 1) gpp.top1++;
+                if (better < 2) gpp.top2++;
+                if (better < 4) gpp.top4++;
+                if (better < 8) gpp.top8++;
+            }
+        }
+    }
     SubCtx& c = t_sub;
     if (!c.valid || c.ref != ref || (!c.progress && (!sub_arrived(c, 0) || (bChromaSATD && !sub_arrived(c, 1)))))
     {
@@ -1627,6 +1670,14 @@ int x265ref_subpel_seam_configure_streamed(void* ctx, void* open, void* rows_fn,
 /* pictures of fewer CTUs than this keep the reference's own search untouched (default 1000: the search seams serve from 4K up); call it
  * BEFORE the configure calls.  Returns whether the last configure was gated. */
 int x265ref_seam_min_ctus(int min_ctus) { if (min_ctus >= 0) g_minCtus = min_ctus; return g_gated ? 1 : 0; }
+
+/* measurement mode of the integer-vector predictor (see gpp): on = 1 / 0 (< 0: leave); out[7] (may be NULL): refinements seen, without a usable SAD context, ended outside the
+ * window, and - of those inside - ended on the window's SAD minimum / among its 2 / 4 / 8 smallest SADs */
+void x265ref_predict_probe(int on, uint64_t* out)
+{
+    if (on >= 0) { gpp.on = on != 0; gpp.total = 0; gpp.noCtx = 0; gpp.outside = 0; gpp.top1 = 0; gpp.top2 = 0; gpp.top4 = 0; gpp.top8 = 0; }
+    if (out) { out[0] = gpp.total; out[1] = gpp.noCtx; out[2] = gpp.outside; out[3] = gpp.top1; out[4] = gpp.top2; out[5] = gpp.top4; out[6] = gpp.top8; }
+}
 
 /* the hit-rate gate: window = lookups per decision (0 = gate off, < 0 = leave), pct = the share of served lookups below which no new pairs are opened.
  * out[3] (may be NULL): searches that went to the host because the gate was closed, times the gate closed, whether it is closed now, window */

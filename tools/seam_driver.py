@@ -765,6 +765,9 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     # the SAD seam's hit-rate gate (window in lookups, percent): below that share of served lookups no new pairs are opened until a probe picture hits again
     lib.x265ref_seam_hit_rate_gate.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     lib.x265ref_seam_hit_rate_gate(*(hit_rate_gate or (0, 50)), None)
+    # measurement mode (X265REF_PREDICT_PROBE=1): where does the host's integer search end, ranked by the window's SADs alone?  
+    lib.x265ref_predict_probe.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    lib.x265ref_predict_probe(1 if os.environ.get("X265REF_PREDICT_PROBE") == "1" else 0, None)
     if streamed:
         prov = (MultiDeviceStreamProvider(depth, geo, rng, slots, min_level, pictures, band_rows, layout, centre_range, devices) if provider == "gpu" and devices
                 else StreamGpuProvider(depth, geo, rng, slots, min_level, pictures, band_rows, layout, centre_range) if provider == "gpu"
@@ -866,6 +869,14 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
         gate = (ctypes.c_uint64 * 4)()
         lib.x265ref_seam_hit_rate_gate(-1, -1, gate)
         d["hit_rate_gate"] = {"searches_left_to_the_host_while_closed": int(gate[0]), "times_closed": int(gate[1]), "closed_at_the_end": bool(gate[2]), "window_lookups": int(gate[3])}
+        if os.environ.get("X265REF_PREDICT_PROBE") == "1":
+            pp = (ctypes.c_uint64 * 7)()
+            lib.x265ref_predict_probe(-1, pp)
+            inside = max(1, int(pp[0]) - int(pp[1]) - int(pp[2]))
+            d["integer_vector_predictor_probe"] = {"refinements": int(pp[0]), "without_sad_context": int(pp[1]), "ended_outside_the_window": int(pp[2]),
+                                                   "ended_on_the_sad_minimum": int(pp[3]), "among_2_smallest": int(pp[4]), "among_4": int(pp[5]), "among_8": int(pp[6]),
+                                                   "share_top1_of_inside": round(int(pp[3]) / inside, 4), "share_top4_of_inside": round(int(pp[5]) / inside, 4),
+                                                   "share_top1_of_all": round(int(pp[3]) / max(1, int(pp[0])), 4)}
         if streamed:
             so4 = (ctypes.c_uint64 * 4)()
             lib.x265ref_seam_stream_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
