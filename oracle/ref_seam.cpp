@@ -547,7 +547,14 @@ int pair_slot(int fencPoc, const PicYuv* fencPic, const Slice* slice, const PicY
                 g_gate.closed = low;
                 g_gate.h0 = h; g_gate.o0 = o;
             }
-            if (g_gate.closed && (encodeOrder & 7) != 0) { g_gate.skipped++; return -1; }      /* (the lock guard releases; the host's own search runs) */
+            if (g_gate.closed && (encodeOrder & 7) != 0)
+            {
+                /* the host's own search runs (the lock guard releases); remembered per thread, so that the other searches of this picture on this reference do not come
+                 * back to the mutex for the same answer */
+                g_gate.skipped++;
+                if (t_pairs.n < 8) { TlsPair& e = t_pairs.e[t_pairs.n++]; e.rec = rec; e.recPoc = recPoc; e.slot = -1; e.gen = 0; e.wt = wt; }
+                return -1;
+            }
         }
         if (slot < 0)
         {

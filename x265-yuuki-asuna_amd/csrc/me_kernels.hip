@@ -1361,7 +1361,8 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
                         hipLaunchKernelGGL((me_ctu_q2_kernel<256, FLV>), grid, dim3(nwq * 64), lds2, s, a, (int)ctabAt); break;
                     switch (q2Flags)
                     {
-                    LAUNCH_Q2(0) LAUNCH_Q2(1) LAUNCH_Q2(2) LAUNCH_Q2(4) LAUNCH_Q2(8) LAUNCH_Q2(32) LAUNCH_Q2(14) LAUNCH_Q2(46) LAUNCH_Q2(62) LAUNCH_Q2(64) LAUNCH_Q2(126) LAUNCH_Q2(190) LAUNCH_Q2(254) LAUNCH_Q2(238) LAUNCH_Q2(446) LAUNCH_Q2(256)
+                    /* the single flags, the sets the profile tables name, the default (profiles/r05_me_flags_ab.txt lists more combinations: they were instantiated for the A/B visits) */
+                    LAUNCH_Q2(0) LAUNCH_Q2(1) LAUNCH_Q2(2) LAUNCH_Q2(4) LAUNCH_Q2(8) LAUNCH_Q2(32) LAUNCH_Q2(62) LAUNCH_Q2(254) LAUNCH_Q2(446) LAUNCH_Q2(256)
                     default: set_error("me_fullsearch: X265HIP_ME_Q2_FLAGS %d is not an instantiated combination", q2Flags); return X265HIP_EINVAL;
                     }
 #undef LAUNCH_Q2
