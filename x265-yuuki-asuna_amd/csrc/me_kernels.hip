@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
 //              shift + mask + add; this way it is mask + v_lshl_add_u32).
 // Results are identical for every FL (tests/test_gpu_me.py runs them all against the oracle).
 template <int PITCH, int FL>
-__global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOff)
+__global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOff, int groupsPerWg)
 {
     constexpr bool LD64 = (FL & 1) != 0, CTAB = (FL & 2) != 0, PAIR64 = (FL & 4) != 0, DEFERX = (FL & 8) != 0, COLMIN = (FL & 16) != 0, MASK = (FL & 32) != 0;
     constexpr bool RING = (FL & 64) != 0, QUAD64 = (FL & 128) != 0, LDA = (FL & 256) != 0;
@@ -584,7 +584,11 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
     const int oddRow = (lane >> 4) & 1;                     // PAIR64: 0 = this lane ends up with row A's 64x64 total, 1 = row B's
 
     const int T = 2 * R + 8;
-    for (int g = wave; g < NG; g += nwaves)
+    // a launch of few CTUs (a band of the frame-parallel ring, a small picture) deals a CTU's column groups over blockIdx.y workgroups - each stages the window for
+    // itself, the 64-bit atomic minima merge them like they merge the wavefronts of one workgroup - so that the chip is filled (groupsPerWg = 0: one workgroup per CTU)
+    const int gPer = groupsPerWg > 0 ? groupsPerWg : NG;
+    const int gFirst = (int)blockIdx.y * gPer, gEnd = gFirst + gPer < NG ? gFirst + gPer : NG;
+    for (int g = gFirst + wave; g < gEnd; g += nwaves)
     {
         const uint32_t colOff = (uint32_t)((by * 8) * pitch + bx * 8 + 4 * g);
         // LDS byte offset of window row t0 of this lane's block column.  LD64 keeps it opaque: ds_read reaches 255 dwords past its address
@@ -1066,7 +1070,7 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
 // global_load_ushort + wait in every row's chain, costX once per column group, the 64x64 level reduced for four window rows at a time, the window rows of a
 // block addressed from one register.  Same SADs, same keys, identical results (tests/test_gpu_me.py); X265HIP_ME_W2=0 selects round 4's kernel (A/B).
 template <int PITCH>
-__global__ void __launch_bounds__(1024, 4) me_ctu_w2_kernel(MEArgs a, int ctabOff)
+__global__ void __launch_bounds__(1024, 4) me_ctu_w2_kernel(MEArgs a, int ctabOff, int groupsPerWg)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t win[];
     typedef unsigned long long u64;
@@ -1113,7 +1117,9 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_w2_kernel(MEArgs a, int ctabOf
     const bool lane1 = (lane & 1) != 0, lane2 = (lane & 2) != 0;
 
     const int T = 2 * R + 8;
-    for (int g = wave; g < NG; g += nwaves)
+    const int gPer = groupsPerWg > 0 ? groupsPerWg : NG;          // (see me_ctu_q2_kernel: a CTU's column groups dealt over blockIdx.y workgroups when the launch has few CTUs)
+    const int gFirst = (int)blockIdx.y * gPer, gEnd = gFirst + gPer < NG ? gFirst + gPer : NG;
+    for (int g = gFirst + wave; g < gEnd; g += nwaves)
     {
         const uint32_t colOff = (uint32_t)((by * 8) * pitch + (bx * 8 + 4 * g) * 2);
         auto block_off = [&](const int t0) { uint32_t o = colOff + (uint32_t)(t0 * pitch + lds_skew_bytes(by + (t0 >> 3))); asm volatile("" : "+v"(o)); return o; };
@@ -1353,12 +1359,19 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
                     // workgroups per CU) are 0.8 % ahead of 12: 1.217 - 1.219 against 1.228 - 1.239 ms, one box, two interleaved rounds (profiles/r05_me_flags_ab.txt)
                     int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 8) nwq = 8;
                     if (bestWaves >= 4 && bestWaves <= 16 && bestWaves < pick_waves((2 * p->range + 4) / 4) + 1) nwq = bestWaves;
+                    // few CTUs (a band of the ring: 2 CTU rows of a 4K picture = 120; a small picture): one workgroup per CTU would leave most of the 256 CUs idle -
+                    // 8 column groups per workgroup of 8 wavefronts instead, ceil(groups / 8) workgroups per CTU (X265HIP_ME_SPLIT_GROUPS=0: off, A/B)
+                    static const bool splitGroups = !(getenv("X265HIP_ME_SPLIT_GROUPS") && atoi(getenv("X265HIP_ME_SPLIT_GROUPS")) == 0);
+                    const int ngroups = (2 * p->range + 4) / 4;
+                    int gPer = 0;
+                    dim3 grid2 = grid;
+                    if (splitGroups && nctu < 192 && ngroups > 8) { nwq = 8; gPer = 8; grid2 = dim3(nctu, (ngroups + 7) / 8); }
                     if ((q2Flags & 256) && a.payloadDw + 16 > 64) { set_error("me_fullsearch: X265HIP_ME_Q2_FLAGS bit 256 (two window copies) holds +-59 at most"); return X265HIP_EINVAL; }
                     const size_t ctabAt = (q2Flags & 256) ? 2 * lds : lds;
                     const size_t lds2 = ctabAt + (size_t)(2 * p->range + 1 + 16) * 4;
 #define LAUNCH_Q2(FLV) case FLV: \
                         if (lds2 > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_q2_kernel<256, FLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
-                        hipLaunchKernelGGL((me_ctu_q2_kernel<256, FLV>), grid, dim3(nwq * 64), lds2, s, a, (int)ctabAt); break;
+                        hipLaunchKernelGGL((me_ctu_q2_kernel<256, FLV>), grid2, dim3(nwq * 64), lds2, s, a, (int)ctabAt, gPer); break;
                     switch (q2Flags)
                     {
                     /* the single flags, the sets the profile tables name, the default (profiles/r05_me_flags_ab.txt lists more combinations: they were instantiated for the A/B visits) */
@@ -1404,12 +1417,17 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
                 {
                     int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 12) nwq = 12;
                     if (bestWavesW >= 4 && bestWavesW <= 16) nwq = bestWavesW;
+                    static const bool splitGroupsW = !(getenv("X265HIP_ME_SPLIT_GROUPS") && atoi(getenv("X265HIP_ME_SPLIT_GROUPS")) == 0);
+                    const int ngroups = (2 * p->range + 4) / 4;
+                    int gPer = 0;
+                    dim3 grid2 = grid;
+                    if (splitGroupsW && nctu < 192 && ngroups > 8) { nwq = 8; gPer = 8; grid2 = dim3(nctu, (ngroups + 7) / 8); }      // few CTUs: see the 8-bit launch
                     const size_t lds2 = lds + (size_t)(2 * p->range + 1 + 16) * 4;
-                    if (a.rowBytes == 256) hipLaunchKernelGGL((me_ctu_w2_kernel<256>), grid, dim3(nwq * 64), lds2, s, a, (int)lds);
+                    if (a.rowBytes == 256) hipLaunchKernelGGL((me_ctu_w2_kernel<256>), grid2, dim3(nwq * 64), lds2, s, a, (int)lds, gPer);
                     else
                     {
                         if (lds2 > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_w2_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-                        hipLaunchKernelGGL((me_ctu_w2_kernel<512>), grid, dim3(nwq * 64), lds2, s, a, (int)lds);
+                        hipLaunchKernelGGL((me_ctu_w2_kernel<512>), grid2, dim3(nwq * 64), lds2, s, a, (int)lds, gPer);
                     }
                 }
                 else if (bestVarW == 0) LAUNCH_WV(0); else if (bestVarW == 2) LAUNCH_WV(2); else if (bestVarW == 3) LAUNCH_WV(3); else LAUNCH_WV(1);
