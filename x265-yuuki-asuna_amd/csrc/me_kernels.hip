@@ -1360,7 +1360,8 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
                     int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 8) nwq = 8;
                     if (bestWaves >= 4 && bestWaves <= 16 && bestWaves < pick_waves((2 * p->range + 4) / 4) + 1) nwq = bestWaves;
                     // few CTUs (a band of the ring: 2 CTU rows of a 4K picture = 120; a small picture): one workgroup per CTU would leave most of the 256 CUs idle -
-                    // 8 column groups per workgroup of 8 wavefronts instead, ceil(groups / 8) workgroups per CTU (X265HIP_ME_SPLIT_GROUPS=0: off, A/B)
+                    // 8 column groups per workgroup of 8 wavefronts instead, ceil(groups / 8) workgroups per CTU (X265HIP_ME_SPLIT_GROUPS=0: off, A/B).  Banded 4K 8-bit steps
+                    // (2 / 3 / 4 CTU rows per band): 3.11 / 2.72 / 2.43 -> 2.95 / 2.49 / 2.38 ms, one box, interleaved (profiles/r05_band_tables.txt)
                     static const bool splitGroups = !(getenv("X265HIP_ME_SPLIT_GROUPS") && atoi(getenv("X265HIP_ME_SPLIT_GROUPS")) == 0);
                     const int ngroups = (2 * p->range + 4) / 4;
                     int gPer = 0;
@@ -1417,7 +1418,9 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
                 {
                     int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 12) nwq = 12;
                     if (bestWavesW >= 4 && bestWavesW <= 16) nwq = bestWavesW;
-                    static const bool splitGroupsW = !(getenv("X265HIP_ME_SPLIT_GROUPS") && atoi(getenv("X265HIP_ME_SPLIT_GROUPS")) == 0);
+                    // off by default at 16 bits: the 92 KB window leaves room for ONE workgroup per CU, so four small workgroups per CTU run in two rounds at half the
+                    // occupancy - banded 4K 10-bit steps 4.45 / 4.05 / 3.80 ms (2 / 3 / 4 CTU rows per band) became 4.50 / 4.25 / 3.80 (profiles/r05_band_tables.txt); 1 = on (A/B)
+                    static const bool splitGroupsW = getenv("X265HIP_ME_SPLIT_GROUPS") && atoi(getenv("X265HIP_ME_SPLIT_GROUPS")) == 1;
                     const int ngroups = (2 * p->range + 4) / 4;
                     int gPer = 0;
                     dim3 grid2 = grid;
