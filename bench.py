@@ -291,17 +291,17 @@ def valu_bound(nctu, rng_r, depth, launch_ms):
 
 
 # Milliseconds per picture of the BANDED step against the CTU rows per band, one MI355X, MEASURED per (bit depth, picture size) - round-3
-# verdict, next 8: rounds 2 - 3 scaled one 4K 8-bit table by the ratio of the whole-picture steps.  profiles/r04_band_tables.txt
-# (tools/r4_band_tables.sh, minima-only search = the default step of round 4).  Small bands cost launches whose grids no longer fill the
+# verdict, next 8: rounds 2 - 3 scaled one 4K 8-bit table by the ratio of the whole-picture steps.  Round 5's values (the search kernels of round 5, column groups of a small
+# launch dealt over several workgroups at 8 bits): profiles/r05_band_tables.txt (tools/r4_band_tables.sh; round 4's: profiles/r04_band_tables.txt).  Small bands cost launches whose grids no longer fill the
 # chip; large bands make the next rank wait longer for its first reference rows.
 BANDED_STEP_MS = {
-    (8, "4k"): {1: 6.10, 2: 3.37, 3: 2.98, 4: 2.57, 5: 2.67, 6: 2.45, 8: 2.42, 12: 2.22, 17: 2.13},
-    (10, "4k"): {2: 4.86, 3: 4.39, 4: 4.16, 6: 4.04, 8: 3.97, 12: 3.68, 17: 3.61},
-    (10, "8k"): {4: 14.51, 6: 14.13, 8: 13.79, 12: 13.88, 17: 14.03, 34: 13.75},
-    (8, "1080p"): {1: 2.93, 2: 1.62, 3: 1.13, 5: 1.11, 9: 0.86},
+    (8, "4k"): {1: 5.54, 2: 2.94, 3: 2.48, 4: 2.38, 5: 2.52, 6: 2.31, 8: 2.24, 12: 2.12, 17: 2.03},
+    (10, "4k"): {2: 4.38, 3: 3.99, 4: 3.78, 6: 3.62, 8: 3.59, 12: 3.31, 17: 3.25},
+    (10, "8k"): {4: 13.13, 6: 12.72, 8: 12.58, 12: 12.34, 17: 12.51, 34: 12.23},
+    (8, "1080p"): {1: 2.82, 2: 1.73, 3: 1.17, 5: 0.90, 9: 0.82},
 }
-# configurations without a table of their own borrow the nearest one, scaled by the whole-picture steps (ms, same visit)
-WHOLE_STEP_MS = {(8, "4k"): 1.86, (10, "4k"): 3.26, (12, "4k"): 3.26, (8, "8k"): 7.4, (10, "8k"): 12.75, (12, "8k"): 12.75, (8, "1080p"): 0.60, (10, "1080p"): 0.95,
+# configurations without a table of their own borrow the nearest one, scaled by the whole-picture steps (ms, same round)
+WHOLE_STEP_MS = {(8, "4k"): 1.64, (10, "4k"): 2.92, (12, "4k"): 2.92, (8, "8k"): 6.6, (10, "8k"): 11.45, (12, "8k"): 11.45, (8, "1080p"): 0.60, (10, "1080p"): 0.95,
                  (12, "1080p"): 0.95}
 
 
