@@ -549,14 +549,15 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
     const int ccx = a.centres ? a.centres[2 * ctu] : 0, ccy = a.centres ? a.centres[2 * ctu + 1] : 0;
     const uint8_t* g0 = a.fref + (long)(cy + ccy - R) * a.frefStrideB + (long)(cx + ccx - R);
     const int rowDw = a.payloadDw;
-    // LDA: the window is staged TWICE - copy B is copy A moved on by four bytes - and the groups of 8 rows are skewed by {0, 16} dwords only, so that both 64-bit
-    // values of a row (window bytes 0..7 and 4..11 of a block column) are 8-byte-ALIGNED loads from one copy or the other: for an even column group w0 comes from A and
-    // w1 from B, for an odd one the other way round.  (2 x 46 KB of LDS at +-57; the skew leaves room for +-59 at most: the host only selects LDA there.)
+    // LDA: the window is staged TWICE - copy B is copy A moved on by four bytes - so that both 64-bit values of a row (window bytes 0..7 and 4..11 of a block column) are
+    // 8-byte-ALIGNED loads from one copy or the other: for an even column group w0 comes from A and w1 from B, for an odd one the other way round.  The row pitch is 320
+    // bytes (not a power of two) and groups of 8 rows are skewed by {0, 8, 16, 24} dwords: the LDS serves a 64-bit load 16 lanes at a time - 4 block columns x 4 block rows -
+    // and the four block rows then land on four disjoint sets of 8 banks (a first version skewed by {0, 16} and lost 5.8e7 cycles per launch to bank conflicts).
     const int ldaB = LDA ? (rows + 2) * pitch : 0;
     for (int r = wave; r < rows; r += nwaves)
     {
         const uint8_t* src = g0 + (long)r * a.frefStrideB;
-        uint32_t* dst = reinterpret_cast<uint32_t*>(win + (LDA ? r * pitch + ((r >> 3) & 1) * 64 : lds_row_off(r, pitch)));
+        uint32_t* dst = reinterpret_cast<uint32_t*>(win + (LDA ? r * pitch + ((r >> 3) & 3) * 32 : lds_row_off(r, pitch)));
         for (int c = lane; c < rowDw; c += 64)
         {
             dst[c] = ld_u32(src + 4 * c);
@@ -595,7 +596,7 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
         // register, so a block of 8 rows is read from THREE address registers (rows 0 - 3, rows 4 - 7, the next block's rows 0 - 1)
         auto block_off = [&](const int t0)
         {
-            uint32_t o = colOff + (uint32_t)(t0 * pitch + (LDA ? ((by + (t0 >> 3)) & 1) * 64 : lds_skew_bytes(by + (t0 >> 3))));
+            uint32_t o = colOff + (uint32_t)(t0 * pitch + (LDA ? ((by + (t0 >> 3)) & 3) * 32 : lds_skew_bytes(by + (t0 >> 3))));
             if (LD64 || RING || LDA) asm volatile("" : "+v"(o));
             return o;
         };
@@ -1367,19 +1368,22 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
                     int gPer = 0;
                     dim3 grid2 = grid;
                     if (splitGroups && nctu < 192 && ngroups > 8) { nwq = 8; gPer = 8; grid2 = dim3(nctu, (ngroups + 7) / 8); }
-                    if ((q2Flags & 256) && a.payloadDw + 16 > 64) { set_error("me_fullsearch: X265HIP_ME_Q2_FLAGS bit 256 (two window copies) holds +-59 at most"); return X265HIP_EINVAL; }
-                    const size_t ctabAt = (q2Flags & 256) ? 2 * lds : lds;
+                    const size_t ldsA = (size_t)320 * (64 + 2 * p->range + 2);            // flag 256: two copies of the window at a 320-byte pitch
+                    if ((q2Flags & 256) && (a.payloadDw + 24 > 80 || 2 * ldsA > 150 * 1024)) { set_error("me_fullsearch: X265HIP_ME_Q2_FLAGS bit 256 (two window copies) holds +-75 at most"); return X265HIP_EINVAL; }
+                    const size_t ctabAt = (q2Flags & 256) ? 2 * ldsA : lds;
                     const size_t lds2 = ctabAt + (size_t)(2 * p->range + 1 + 16) * 4;
-#define LAUNCH_Q2(FLV) case FLV: \
-                        if (lds2 > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_q2_kernel<256, FLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
-                        hipLaunchKernelGGL((me_ctu_q2_kernel<256, FLV>), grid2, dim3(nwq * 64), lds2, s, a, (int)ctabAt, gPer); break;
+#define LAUNCH_Q2P(PT, FLV) case FLV: \
+                        if (lds2 > 64 * 1024) X265HIP_TRY(hipFuncSetAttribute((const void*)me_ctu_q2_kernel<PT, FLV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
+                        hipLaunchKernelGGL((me_ctu_q2_kernel<PT, FLV>), grid2, dim3(nwq * 64), lds2, s, a, (int)ctabAt, gPer); break;
+#define LAUNCH_Q2(FLV) LAUNCH_Q2P(256, FLV)
                     switch (q2Flags)
                     {
                     /* the single flags, the sets the profile tables name, the default (profiles/r05_me_flags_ab.txt lists more combinations: they were instantiated for the A/B visits) */
-                    LAUNCH_Q2(0) LAUNCH_Q2(1) LAUNCH_Q2(2) LAUNCH_Q2(4) LAUNCH_Q2(8) LAUNCH_Q2(32) LAUNCH_Q2(62) LAUNCH_Q2(254) LAUNCH_Q2(446) LAUNCH_Q2(256)
+                    LAUNCH_Q2(0) LAUNCH_Q2(1) LAUNCH_Q2(2) LAUNCH_Q2(4) LAUNCH_Q2(8) LAUNCH_Q2(32) LAUNCH_Q2(62) LAUNCH_Q2(254) LAUNCH_Q2P(320, 446) LAUNCH_Q2P(320, 256)
                     default: set_error("me_fullsearch: X265HIP_ME_Q2_FLAGS %d is not an instantiated combination", q2Flags); return X265HIP_EINVAL;
                     }
 #undef LAUNCH_Q2
+#undef LAUNCH_Q2P
                 }
             }
         }
