@@ -40,6 +40,10 @@ extern "C" {
 #define X265HIP_EBUSY        -4   /* every entry of a bounded pool is in use; retry later or create the object with a larger pool */
 
 const char* x265hip_version(void);
+/* Before a host destroys a stream it has passed to this library: the per-stream scratch buffers (x265hip_me_search, split x265hip_lowres_cost) return to a pool the next
+ * stream adopts from, the stream's enqueue lock is dropped.  Stream idle, no HIP graph captured on it still in use.  Returns the number of buffers pooled (>= 0),
+ * X265HIP_EBUSY while another thread is enqueuing on the stream.  Optional: a process with a fixed set of streams never needs it. */
+int x265hip_stream_release(void* stream);
 const char* x265hip_last_error(void);          /* thread-local text of the last failure */
 int         x265hip_device_count(void);
 int         x265hip_init(int device);          /* device >= 0: validate (gfx950) and hipSetDevice() it for the calling thread; -1: validate the thread's current device and keep it */

@@ -194,3 +194,34 @@ def test_search_with_extra_candidates(depth):
         got = jd.cpu().numpy().view(A.me_search_job_dtype())
         for f in ("out_cost", "out_qmvx", "out_qmvy"):
             assert np.array_equal(got[f], exp[f]), f"{method}: {f} differs with extra candidates"
+
+
+def test_stream_release_pools_the_scratch_of_a_stream_the_host_destroys():
+    """x265hip_stream_release (round-4 advisor, low): the search driver keeps a scratch buffer per (device, stream); a host that creates and destroys streams hands
+    each one back before destroying it - its buffer goes to the pool the next stream adopts from (nothing is freed: a captured graph might hold it), results on the
+    next stream are still exact, a second release of the same stream finds nothing."""
+    import ctypes
+    import torch
+    dev = torch.device("cuda:0")
+    O = _oracle()
+    L = A.lib()
+    L.x265hip_stream_release.argtypes = [ctypes.c_void_p]
+    clip = F.synth_clip(256, 192, 2, depth=8, seed=77)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    rng = np.random.default_rng(5)
+    cq, qoff = F.qpel_cost_table(57, qmax=8 * 64 + 300)
+    cq_d = torch.from_numpy(cq.view(np.int16)).to(dev)
+    for round_ in range(3):
+        s = torch.cuda.Stream()
+        jobs = _jobs(rng, 48, 256, 192)
+        exp = O.motion_estimate(8, cur.host, ref.host, cur.stride, cur.org, METHODS["hex"], 2, 16, cq, qoff, (-57, -57), (57, 57), jobs)
+        jd = torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy()).to(dev)
+        torch.cuda.synchronize()
+        A.me_search(8, cur.t, cur.stride, cur.org, ref.t, ref.stride, ref.org, METHODS["hex"], 2, 16, cq_d, qoff, (-57, -57), (57, 57), jd, 48, stream=s.cuda_stream)
+        s.synchronize()
+        got = jd.cpu().numpy().view(A.me_search_job_dtype())
+        for f in ("out_cost", "out_qmvx", "out_qmvy"):
+            assert np.array_equal(got[f], exp[f]), (round_, f)
+        assert L.x265hip_stream_release(s.cuda_stream) >= 1          # the stream's scratch went back to the pool
+        assert L.x265hip_stream_release(s.cuda_stream) == 0          # nothing left under this stream
+        del s
