@@ -128,9 +128,10 @@ void* stream_scratch(hipStream_t s, int slot, size_t bytes)
         {
             b = spare[i];                                    // the old buffer of this key (if any) stays allocated: graphs may hold it
             spare.erase(spare.begin() + i);
-            if (!capturing)
+            if (!capturing && spare.empty())
             {
-                ScratchBuf extra = { nullptr, b.n };         // leave a spare behind for the next stream that starts inside a capture
+                ScratchBuf extra = { nullptr, b.n };         // leave a spare behind for the next stream that starts inside a capture (only when the pool ran dry:
+                                                             // streams handed back with x265hip_stream_release refill it, so the footprint stays bounded)
                 if (hipMalloc(&extra.p, extra.n) == hipSuccess) spare.push_back(extra);
             }
             return b.p;
