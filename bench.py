@@ -776,18 +776,20 @@ def main():
         else:
             fp.exchange(ref_pic.planes(), pipe.final_planes())
 
+    # The interpreter's cycle collector is parked for the warm-up AND the timed loop: one full collection over torch's object graph is a 30 - 60 ms
+    # pause of the launching thread (seen in the dispatch timeline, profiles/r02_band_timeline.txt: a single 38 ms hole in a 10-step
+    # run) - nothing the encoder-side caller of the C ABI would have, and with a few dozen steps it decides the average.  It runs BEFORE the
+    # warm-up steps (round 5): collecting between warm-up and timed loop left the GPU idle for those 30 - 60 ms and the first timed steps ran on a
+    # device that had clocked down - 1.69 ms per step over the driver's 20 steps against 1.63 over 200.
+    import gc
+    gc.collect()
+    gc.disable()
     for i in range(args.warmup):
         step(i)
     if banded and world > 1 and not stub:
         ring.time_waits()                            # two device events per band: how long its stream waits for the reference rows it reads
     pipe.launch_lookahead_costs()                    # no lookahead work of the warm-up frames leaks into the timed region
     torch.cuda.synchronize()
-    # The interpreter's cycle collector is parked for the timed loop: one full collection over torch's object graph is a 30 - 60 ms
-    # pause of the launching thread (seen in the dispatch timeline, profiles/r02_band_timeline.txt: a single 38 ms hole in a 10-step
-    # run) - nothing the encoder-side caller of the C ABI would have, and with a few dozen steps it decides the average.
-    import gc
-    gc.collect()
-    gc.disable()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
