@@ -12,6 +12,7 @@ import time
 
 import numpy as np
 import pytest
+from conftest import missing_reference_build
 
 pytestmark = pytest.mark.gpu
 
@@ -729,7 +730,7 @@ def test_4k_preset_slow_star_frame_threads_5_every_served_value_verified_in_flig
         plain = EB.ref_lib(8)
         SD.seam_lib(8)
     except (SystemExit, FileNotFoundError):
-        pytest.skip("oracle/_ref not built (it travels to the GPU box with the snapshot)")
+        missing_reference_build()
     w, h, n = 3840, 2160, 8
     clip = F.synth_clip(w, h, n, depth=8, seed=265)
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
@@ -761,7 +762,7 @@ def test_4k_fade_every_seam_on_weighted_references_and_both_host_services_verifi
         plain = EB.ref_lib(8)
         SD.seam_lib(8)
     except (SystemExit, FileNotFoundError):
-        pytest.skip("oracle/_ref not built (it travels to the GPU box with the snapshot)")
+        missing_reference_build()
     w, h, n = 3840, 2160, 8
     clip = F.synth_clip(w, h, n, depth=8, seed=265, fade=(1.0, 0.4))
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
@@ -795,7 +796,7 @@ def _verified_encode(depth, w, h, n, preset, extra, clip=None, slots=40, subpel_
         plain = EB.ref_lib(depth)
         SD.seam_lib(depth)
     except (SystemExit, FileNotFoundError):
-        pytest.skip("oracle/_ref not built (it travels to the GPU box with the snapshot)")
+        missing_reference_build()
     if clip is None:
         clip = F.synth_clip(w, h, n, depth=depth, seed=265)
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
@@ -888,7 +889,7 @@ def test_two_service_instances_serve_one_encode_frame_encoders_spread_over_devic
         plain = EB.ref_lib(depth)
         SD.seam_lib(depth)
     except (SystemExit, FileNotFoundError):
-        pytest.skip("oracle/_ref not built (it travels to the GPU box with the snapshot)")
+        missing_reference_build()
     w, h, n = 320, 256, 9
     clip = F.synth_clip(w, h, n, depth=depth, seed=31)
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])

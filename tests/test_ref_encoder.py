@@ -15,6 +15,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import missing_reference_build
 
 import harness as H
 
@@ -25,7 +26,7 @@ spec = H.spec
 def ref_lib(depth, root):
     path = os.path.join(root, "oracle", "_ref", f"libx265ref{depth}.so")
     if not os.path.exists(path):
-        pytest.skip("oracle/_ref not built (needs /root/reference)")
+        missing_reference_build("oracle/_ref not built (needs /root/reference)")
     lib = ctypes.CDLL(path)
     lib.x265ref_encode.restype = ctypes.c_long
     lib.x265ref_encode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
@@ -109,8 +110,8 @@ def test_hip_table_at_full_size_gives_reference_bitstream(repo_root):
     wall clock: some 12 M synchronous primitive calls at 5-6 us each (profiles/r02_encoder_c_vs_hipstubs.txt is the 6-frame run)."""
     A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
     lib = ref_lib(8, repo_root)
-    w, h, n = 1920, 1080, 2
-    clip = F.synth_clip(w, h, n, depth=8, seed=33)
+    w, h, n = 1920, 256, 2          # round-5 verdict, next 8: a FOUR-CTU-ROW sample of the 1080p picture (full width: the whole-plane weight_pp, the 64x64 PUs and
+    clip = F.synth_clip(w, h, n, depth=8, seed=33)          # the staging regrowth are all still there) - 2 full frames were 31.6 M calls = 363 s of the suite's 506 s
     opts = [("pools", "8"), ("frame-threads", "2"), ("crf", "22"), ("weightp", None)]
     base, t_c, _ = encode(lib, clip, w, h, "medium", opts)
     L = A.lib()
@@ -119,5 +120,5 @@ def test_hip_table_at_full_size_gives_reference_bitstream(repo_root):
     calls = L.x265hip_table_calls() - calls0
     print(f"\n[T3 full size] 1080p medium, {n} frames: {filled} slots on HIP, {calls} primitive calls through the GPU "
           f"({1e6 * t_g / max(calls, 1):.2f} us each), C table {t_c:.2f}s vs HIP stubs {t_g:.2f}s, {len(base)} bytes, md5 {hashlib.md5(base).hexdigest()}")
-    assert filled > 1700 and calls > 2_000_000
+    assert filled > 1700 and calls > 400_000
     assert hashlib.md5(got).hexdigest() == hashlib.md5(base).hexdigest(), "HIP table changed the 1080p bitstream"

@@ -19,6 +19,8 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 export TMPDIR=/tmp
+# the reference build under oracle/_ref travels with the snapshot (git-ignored, not gpurun-ignored): tests that need it FAIL instead of skipping when it is lost
+export X265HIP_EXPECT_REF=${X265HIP_EXPECT_REF:-1}
 n=0
 BENCH_PROF="--steps 10 --warmup 2 --no-cpu-baseline --no-encoder"
 for step in "$@"; do
