@@ -1210,6 +1210,99 @@ int  x265hip_phase_stream_stats(x265hip_phase_stream* s, x265hip_phase_stream_st
 
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * SUB-SAMPLE COST TABLES (round 6, csrc/cost_stream.hip): the sub-sample half of MotionEstimate::motionEstimate served as VALUES.
+ * After its integer search the reference refines every PU's vector with SATD comparisons at half- and quarter-sample positions
+ * (motion.cpp:1456-1561: the SubpelWorkload rows of :48-58; each comparison = MotionEstimate::subpelCompare, :1571-1664 - luma_hpp /
+ * luma_vpp / luma_hvpp into a scratch block, pu[].satd against the source block and, from --subme 3 on (bChromaSATD, :212), the 4-tap
+ * chroma filters + chroma[].pu[].satd of Cb and Cr).  Every one of those costs is a pure function of (source block, reference plane,
+ * quarter-sample vector), and the positions a refinement can visit from an integer vector v form a small fixed set: square1 steps of
+ * the workload row - 49 positions for --subme 3, 85 for --subme 4 (x265hip_cost_positions).  So, per (source picture, reference view):
+ *   1. where did each CTU go?  the minima-only exhaustive search of +-centre_range on SAD alone (x265hip_me_fullsearch) -> the centre;
+ *   2. SAD rasters of +-window around the centre for the 85 square PUs (x265hip_me_fullsearch, surfaces);
+ *   3. x265hip_cost_candidates: for EVERY PU shape of the list (x265hip_cost_pu_rect: the squares, the 2NxN / Nx2N halves, the AMP
+ *      parts that are unions of 8x8 blocks - summed from the square rasters) the `candidates` displacements of smallest SAD;
+ *   4. x265hip_cost_tables: around each candidate the SATD (luma, or luma + Cb + Cr) of every position of the set, read from the
+ *      view's fractional-phase planes (x265hip_phase_planes: the same samples the three luma / four chroma filter calls produce).
+ * What travels to the host is one RECORD per (CTU, PU, candidate): { int16 mvx, mvy (integer displacement; mvx = -32768: no record);
+ * uint32 base; uint16 delta[positions] }, cost(position i) = base + delta[i], delta 65535 = not representable (the host computes
+ * that one itself); x265hip_cost_record_bytes() apart, PU-major, candidates of a PU adjacent; x265hip_cost_ctu_bytes() per CTU.
+ * A host stub of subpelCompare answers (cmp == satd, qmv - 4 * (mvx, mvy) inside the position set) from the record and everything
+ * else with the host's own primitives - the same integers either way, so the bitstream cannot change.
+ * The ROW-GRANULAR service follows the reference's frame threads like x265hip_me_stream / x265hip_phase_stream: pictures (source AND
+ * reconstructed, three planes) arrive by key, reconstructed ones CTU row by CTU row where the reference raises m_reconRowFlag
+ * (framefilter.cpp:664); a pair (source, reference[, weights]) is opened by the first search that refers to it; reference VIEWS
+ * (weighted planes + their 15 + 2 x 63 phase planes) live on the DEVICE only and are shared by the pairs on the same (picture,
+ * weights); CTU row r of a pair is computed when its source row and reference rows <= r + 2 are there (the host's own consumers
+ * wait for the same rows, frameencoder.cpp:161-164), and ready[r] carries the pair's generation once the row's records have landed
+ * in pinned host memory - check it before AND after reading. */
+int x265hip_cost_pu_count(int shapes);                              /* shapes 0: the 85 squares; 1: + 2NxN / Nx2N (169); 2: + AMP of the 32 / 64 CUs (209) */
+int x265hip_cost_pu_rect(int shapes, int pu, int rect[4]);         /* x, y, width, height in luma samples inside the CTU; PUs [0, 85) in the surfaces' order */
+int x265hip_cost_positions(int subme, int8_t* xy, int max_positions);   /* -> count; xy[2 i], xy[2 i + 1] = quarter-sample offset of position i, raster order (y, then x) */
+int x265hip_cost_record_bytes(int subme);
+size_t x265hip_cost_ctu_bytes(int subme, int shapes, int candidates);
+typedef struct x265hip_cost_candidates_params
+{
+    int nctu;
+    int window;                         /* the surfaces hold (2 window + 1)^2 displacements per CTU, X265HIP_SURF_I32 records */
+    const int32_t* surf;                /* DEVICE */
+    const int16_t* centres;             /* DEVICE int16 [ctu][2] the surfaces were centred on, or NULL = (0, 0) */
+    int shapes, candidates;             /* candidates: 1 or 2 displacements of smallest SAD per PU (ties: raster order, like the search) */
+    int16_t* cand;                      /* DEVICE out, int16 [ctu][pu][candidate][2] = absolute integer displacement */
+} x265hip_cost_candidates_params;
+int x265hip_cost_candidates(const x265hip_cost_candidates_params* p, void* stream);
+typedef struct x265hip_cost_tables_params
+{
+    int depth;
+    int width;                          /* luma samples, whole CTUs */
+    intptr_t stride;   int margin_x, margin_y;          /* PicYuv layout of every luma plane below */
+    intptr_t stride_c; int margin_y_c;                  /* 4:2:0 chroma planes (same margin_x); ignored when chroma = 0 */
+    int ctu_row0, ctu_rows;             /* the band */
+    const void* fenc[3];                /* DEVICE, allocation starts of the source picture's planes */
+    const void* ref[3];                 /* DEVICE, allocation starts of the reference's (weighted) planes */
+    const void* phases[3];              /* DEVICE, the 15 luma / 63 Cb / 63 Cr phase planes of ref (x265hip_phase_planes), plane_bytes[_c] apart */
+    size_t plane_bytes, plane_bytes_c;
+    int shapes, candidates, subme, chroma;
+    const int16_t* cand;                /* DEVICE, the band's first CTU first */
+    void* tables;                       /* DEVICE out, the band's first CTU first */
+} x265hip_cost_tables_params;
+int x265hip_cost_tables(const x265hip_cost_tables_params* p, void* stream);
+
+typedef struct x265hip_cost_stream x265hip_cost_stream;
+typedef struct x265hip_cost_stream_params
+{
+    int depth;
+    int width, height;                  /* luma samples, whole CTUs */
+    intptr_t stride;   int margin_x, margin_y;
+    intptr_t stride_c; int margin_y_c;  /* 4:2:0 chroma planes; stride_c = 0: luma only (chroma must be 0 then) */
+    int centre_range;                   /* step 1 (the host's merange; 0 = windows around (0, 0)) */
+    int window;                         /* step 2 */
+    int candidates, shapes, subme, chroma;
+    int slots;                          /* pairs resident in pinned host memory at once */
+    int pictures;                       /* pictures (source + reconstructed) resident on the device at once */
+    int views;                          /* reference views resident on the device at once (each 15 luma + 126 chroma planes) */
+    int band_rows;                      /* most CTU rows per launch chain (0 = 8) */
+    int device_plus_1;                  /* 0: the calling thread's current device; d + 1: device d */
+} x265hip_cost_stream_params;
+typedef struct x265hip_cost_stream_stats_t
+{
+    uint64_t pairs_opened, pairs_completed, bands, rows_served, rows_uploaded, failed, stale_pairs;
+    uint64_t views_opened, views_shared, lines_weighted;
+    uint64_t us_busy, bytes_downloaded, bytes_uploaded, table_bytes;
+} x265hip_cost_stream_stats_t;
+int  x265hip_cost_stream_create(x265hip_cost_stream** out, const x265hip_cost_stream_params* p);
+void x265hip_cost_stream_destroy(x265hip_cost_stream* s);
+/* CTU rows [ctu_row0, ctu_row0 + ctu_rows) of picture `key` are final in the three buffers (whole allocated planes; cb / cr NULL when
+ * stride_c = 0); copied before the call returns.  X265HIP_EBUSY: no picture entry free. */
+int  x265hip_cost_stream_picture_rows(x265hip_cost_stream* s, uint64_t key, const void* luma_buf, const void* cb_buf, const void* cr_buf, int ctu_row0, int ctu_rows);
+/* -> the slot's new GENERATION (> 0).  w = NULL: the reference as reconstructed; otherwise plane c is weighted with w[c] (weight_pp
+ * arguments, round / shift including the 14 - depth correction) when bit c of planes_weighted is set */
+int  x265hip_cost_stream_pair_open(x265hip_cost_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key, const x265hip_weight* w, unsigned planes_weighted);
+const void* x265hip_cost_stream_tables(x265hip_cost_stream* s, int slot);             /* pinned host memory, CTU-major */
+const volatile int* x265hip_cost_stream_ready(x265hip_cost_stream* s, int slot);      /* int [height / 64] */
+int  x265hip_cost_stream_stats(x265hip_cost_stream* s, x265hip_cost_stream_stats_t* st);
+
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Multi-GPU seam (csrc/recon_publish.hip): hand a finished band of reconstructed CTU rows - Y, Cb, Cr with their margins - from the
  * GPU that produced it to the GPU(s) whose in-flight pictures reference it, where the reference raises m_reconRowFlag
  * (encoder/framefilter.cpp:664; consumers wait in encoder/frameencoder.cpp:852-868).  One process per GPU; `comm` is the host's

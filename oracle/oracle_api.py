@@ -669,3 +669,61 @@ def weight_analyse(depth, cur, refs, pic_width, pic_height, intra_cost, avx2=Fal
     fn(at(cur["lowres"]), cur["lowres_stride"], cur["lowres_width"], cur["lowres_lines"], at(cur["cb"]), at(cur["cr"]), cur["stride_c"], pic_width, pic_height,
        ic.ctypes.data, ssd.ctypes.data, sm.ctypes.data, len(refs), ctypes.addressof(lists), scratch.ctypes.data, half, out.ctypes.data, den.ctypes.data)
     return out, den
+
+
+# ---- round 6: sub-sample cost tables (oracle/x265_oracle_pipeline8.c) -----------------------------------------------------------------
+def cost_pu_list(shapes, depth=8):
+    """[n, 5] x, y, w, h, LumaPU enum of the PU list (squares / + 2NxN, Nx2N / + AMP)."""
+    fn = getattr(lib(), f"x265oracle_cost_pu_list_d{depth}")
+    fn.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    fn.restype = ctypes.c_int
+    out = np.zeros((209, 5), np.int32)
+    n = fn(shapes, out.ctypes.data)
+    return out[:n].copy()
+
+
+def cost_positions(subme, depth=8):
+    """[n, 2] quarter-sample offsets a refinement of SubpelWorkload row `subme` can measure, raster order."""
+    fn = getattr(lib(), f"x265oracle_cost_positions_d{depth}")
+    fn.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    fn.restype = ctypes.c_int
+    out = np.zeros((169, 2), np.int8)
+    n = fn(subme, out.ctypes.data)
+    return out[:n].copy()
+
+
+def cost_record_bytes(subme):
+    return (8 + 2 * len(cost_positions(subme)) + 3) & ~3
+
+
+def cost_candidates(surf, centres, nctu, window, shapes, k, depth=8, avx2=False):
+    """surf: int32 SAD rasters of the 85 squares (me_fullsearch's surfaces, I32 records); centres int16 [nctu, 2] or None.
+    Returns int16 [nctu, npu, k, 2]."""
+    fn = getattr(lib(avx2), f"x265oracle_cost_candidates_d{depth}")
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    fn.restype = None
+    npu = len(cost_pu_list(shapes))
+    s = np.ascontiguousarray(surf, np.int32)
+    c = None if centres is None else np.ascontiguousarray(centres, np.int16)
+    out = np.zeros((nctu, npu, k, 2), np.int16)
+    fn(s.ctypes.data, None if c is None else c.ctypes.data, nctu, window, shapes, k, out.ctypes.data)
+    return out
+
+
+def cost_tables(depth, fenc, ref, stride, stride_c, margin_x, margin_y, margin_y_c, width, ctu_row0, ctu_rows, shapes, k, subme, chroma, cand, avx2=False):
+    """fenc / ref: three flat padded planes each (allocation starts; the chroma ones may be None when chroma = 0).  cand: int16
+    [ctu_rows * width / 64, npu, k, 2].  Returns uint8 [ctus, npu, k, record bytes]: the reference's own subpelCompare route per value."""
+    fn = getattr(lib(avx2), f"x265oracle_cost_tables_d{depth}")
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_ssize_t] + [ctypes.c_int] * 10 + [ctypes.c_void_p, ctypes.c_void_p]
+    fn.restype = None
+    f = [None if p is None else np.ascontiguousarray(p).reshape(-1) for p in fenc]
+    r = [None if p is None else np.ascontiguousarray(p).reshape(-1) for p in ref]
+    fp = (ctypes.c_void_p * 3)(*[None if p is None else p.ctypes.data for p in f])
+    rp = (ctypes.c_void_p * 3)(*[None if p is None else p.ctypes.data for p in r])
+    c = np.ascontiguousarray(cand, np.int16)
+    npu, rec = len(cost_pu_list(shapes)), cost_record_bytes(subme)
+    nctu = ctu_rows * (width // 64)
+    assert c.size == nctu * npu * k * 2
+    out = np.zeros((nctu, npu, k, rec), np.uint8)
+    fn(fp, rp, stride, stride_c, margin_x, margin_y, margin_y_c, width, ctu_row0, ctu_rows, shapes, k, subme, int(bool(chroma)), c.ctypes.data, out.ctypes.data)
+    return out

@@ -1,0 +1,90 @@
+"""Checker-side helpers of the sub-sample cost tables (tests only): the oracle's full chain - centre search, centred SAD rasters,
+candidates, tables - from whole pictures, the way csrc/cost_stream.hip chains x265hip_me_fullsearch / x265hip_cost_candidates /
+x265hip_cost_tables band by band."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = importlib.import_module("x265-yuuki-asuna_amd.frames")
+
+
+def oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_api
+    return oracle_api
+
+
+def picture(planes):
+    """(Y, Cb, Cr) -> dict of flat padded buffers + geometry (PicYuv layout, --ctu 64)."""
+    y, cb, cr = planes
+    ybuf, stride, org, w64, h64 = F.pad_plane(y)
+    (cbuf, sc, _), (rbuf, _, _) = F.pad_chroma(cb, w64, h64), F.pad_chroma(cr, w64, h64)
+    return dict(y=ybuf.reshape(-1), cb=cbuf.reshape(-1), cr=rbuf.reshape(-1), stride=stride, stride_c=sc, org=org, width=w64, height=h64,
+                rows=ybuf.shape[0], rows_c=cbuf.shape[0], margin_x=F.MARGIN_X, margin_y=F.MARGIN_Y, margin_y_c=F.CHROMA_MARGIN_Y)
+
+
+def centre_clamp(geo, window, centre_range, chroma_planes=True):
+    """(maxCx, maxCy) of x265hip_cost_stream_create."""
+    mx = geo["margin_x"] - window - 12
+    my = (min(geo["margin_y"], 2 * geo["margin_y_c"]) if chroma_planes else geo["margin_y"]) - window - 20
+    if centre_range:
+        mx, my = min(mx, centre_range), min(my, centre_range)
+    return mx, my
+
+
+def chain(depth, fenc, ref, centre_range, window, shapes, k, subme, chroma):
+    """fenc / ref: picture() dicts (ref already weighted where the search reads weighted planes).  Returns (centres, cand, tables)."""
+    O = oracle()
+    g = fenc
+    nctu = (g["width"] // 64) * (g["height"] // 64)
+    mcx, mcy = centre_clamp(g, window, centre_range)
+    centres = np.zeros((nctu, 2), np.int16)
+    if centre_range:
+        zero = np.zeros(2 * centre_range + 1, np.uint16)
+        _, best = O.me_fullsearch(depth, fenc["y"], g["stride"], g["org"], ref["y"], g["stride"], g["org"], g["width"], g["height"], centre_range, 0, nctu, zero, zero,
+                                  want_surf=False, want_best=True)
+        idx = (best.reshape(nctu, 85)[:, 84] & np.uint64(0xffffffff)).astype(np.int64)
+        ncb = 2 * centre_range + 1
+        centres[:, 0] = np.clip(idx % ncb - centre_range, -mcx, mcx)
+        centres[:, 1] = np.clip(idx // ncb - centre_range, -mcy, mcy)
+    rb = int(np.abs(centres).max()) + window
+    zero = np.zeros(2 * rb + 1, np.uint16)
+    big, _ = O.me_fullsearch(depth, fenc["y"], g["stride"], g["org"], ref["y"], g["stride"], g["org"], g["width"], g["height"], rb, 0, nctu, zero, zero,
+                             want_surf=True, want_best=False)
+    ncb, ngb = 2 * rb + 1, (2 * rb + 4) // 4
+    big = big.reshape(nctu, ncb, ngb, 85, 4).transpose(0, 1, 2, 4, 3).reshape(nctu, ncb, ngb * 4, 85)      # [ctu][row][col][pu]
+    nc, ng = 2 * window + 1, (2 * window + 4) // 4
+    surf = np.zeros((nctu, nc, ng * 4, 85), np.int32)
+    for c in range(nctu):
+        r0, c0 = int(centres[c, 1]) - window + rb, int(centres[c, 0]) - window + rb
+        surf[c, :, :nc] = big[c, r0:r0 + nc, c0:c0 + nc]
+    surf = surf.reshape(nctu, nc, ng, 4, 85).transpose(0, 1, 2, 4, 3)                                        # back to records [ctu][row][group][pu][4]
+    cand = O.cost_candidates(np.ascontiguousarray(surf), centres, nctu, window, shapes, k, depth=depth)
+    tables = O.cost_tables(depth, [fenc["y"], fenc["cb"], fenc["cr"]], [ref["y"], ref["cb"], ref["cr"]], g["stride"], g["stride_c"], g["margin_x"], g["margin_y"],
+                           g["margin_y_c"], g["width"], 0, g["height"] // 64, shapes, k, subme, chroma, cand)
+    return centres, cand, tables
+
+
+def weight_plane(plane, depth, w):
+    """primitives.weight_pp (pixel.cpp:518-543) on a whole buffer; w = (w0, round, shift, offset) incl. the 14 - depth correction."""
+    w0, rnd, shift, off = w
+    val = (plane.astype(np.int64) << (14 - depth)).astype(np.int16).astype(np.int64)
+    return np.clip(((w0 * val + rnd) >> shift) + off, 0, (1 << depth) - 1).astype(plane.dtype)
+
+
+def parse_records(tables, subme):
+    """uint8 [..., rec] -> (mv int16 [..., 2], cost uint32 [..., npos]; 0xffffffff where the delta saturated)."""
+    O = oracle()
+    npos = len(O.cost_positions(subme))
+    t = np.ascontiguousarray(tables)
+    lead = t.shape[:-1]
+    flat = t.reshape(-1, t.shape[-1])
+    mv = flat[:, :4].copy().view(np.int16).reshape(*lead, 2)
+    base = flat[:, 4:8].copy().view(np.uint32).reshape(-1)
+    delta = flat[:, 8:8 + 2 * npos].copy().view(np.uint16).astype(np.uint32)
+    cost = base[:, None] + delta
+    cost[delta == 65535] = 0xffffffff
+    return mv, cost.reshape(*lead, npos)

@@ -1028,3 +1028,95 @@ def phase_planes(depth, src, src_off_bytes, dst, stride, rows, chroma=False, str
     f = lib().x265hip_phase_planes
     f.argtypes = [ctypes.POINTER(PhasePlanesParams), ctypes.c_void_p]
     check(f(ctypes.byref(p), s), "x265hip_phase_planes")
+
+
+# ---- round 6: sub-sample cost tables (csrc/cost_kernels.hip, csrc/cost_stream.hip) ----------------------------------------------------
+class CostCandidatesParams(ctypes.Structure):
+    """x265hip_cost_candidates_params"""
+    _fields_ = [("nctu", ctypes.c_int), ("window", ctypes.c_int), ("surf", ctypes.c_void_p), ("centres", ctypes.c_void_p),
+                ("shapes", ctypes.c_int), ("candidates", ctypes.c_int), ("cand", ctypes.c_void_p)]
+
+
+class CostTablesParams(ctypes.Structure):
+    """x265hip_cost_tables_params"""
+    _fields_ = [("depth", ctypes.c_int), ("width", ctypes.c_int),
+                ("stride", ctypes.c_ssize_t), ("margin_x", ctypes.c_int), ("margin_y", ctypes.c_int),
+                ("stride_c", ctypes.c_ssize_t), ("margin_y_c", ctypes.c_int),
+                ("ctu_row0", ctypes.c_int), ("ctu_rows", ctypes.c_int),
+                ("fenc", ctypes.c_void_p * 3), ("ref", ctypes.c_void_p * 3), ("phases", ctypes.c_void_p * 3),
+                ("plane_bytes", ctypes.c_size_t), ("plane_bytes_c", ctypes.c_size_t),
+                ("shapes", ctypes.c_int), ("candidates", ctypes.c_int), ("subme", ctypes.c_int), ("chroma", ctypes.c_int),
+                ("cand", ctypes.c_void_p), ("tables", ctypes.c_void_p)]
+
+
+class CostStreamParams(ctypes.Structure):
+    """x265hip_cost_stream_params"""
+    _fields_ = [("depth", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int),
+                ("stride", ctypes.c_ssize_t), ("margin_x", ctypes.c_int), ("margin_y", ctypes.c_int),
+                ("stride_c", ctypes.c_ssize_t), ("margin_y_c", ctypes.c_int),
+                ("centre_range", ctypes.c_int), ("window", ctypes.c_int),
+                ("candidates", ctypes.c_int), ("shapes", ctypes.c_int), ("subme", ctypes.c_int), ("chroma", ctypes.c_int),
+                ("slots", ctypes.c_int), ("pictures", ctypes.c_int), ("views", ctypes.c_int), ("band_rows", ctypes.c_int), ("device_plus_1", ctypes.c_int)]
+
+
+class CostStreamStats(ctypes.Structure):
+    """x265hip_cost_stream_stats_t"""
+    _fields_ = [(n, ctypes.c_uint64) for n in ("pairs_opened", "pairs_completed", "bands", "rows_served", "rows_uploaded", "failed", "stale_pairs",
+                                               "views_opened", "views_shared", "lines_weighted", "us_busy", "bytes_downloaded", "bytes_uploaded", "table_bytes")]
+
+
+def cost_pu_list(shapes):
+    """[n, 4] x, y, w, h of the PU list (host-only: needs no device)."""
+    import numpy as np
+    L = lib()
+    L.x265hip_cost_pu_rect.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int * 4)]
+    n = L.x265hip_cost_pu_count(shapes)
+    out = np.zeros((n, 4), np.int32)
+    r = (ctypes.c_int * 4)()
+    for i in range(n):
+        check(L.x265hip_cost_pu_rect(shapes, i, ctypes.byref(r)), "x265hip_cost_pu_rect")
+        out[i] = list(r)
+    return out
+
+
+def cost_positions(subme):
+    """[n, 2] quarter-sample offsets of the position set (host-only)."""
+    import numpy as np
+    L = lib()
+    L.x265hip_cost_positions.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    out = np.zeros((169, 2), np.int8)
+    n = check(L.x265hip_cost_positions(subme, out.ctypes.data, 169), "x265hip_cost_positions")
+    return out[:n].copy()
+
+
+def cost_record_bytes(subme):
+    return lib().x265hip_cost_record_bytes(subme)
+
+
+def cost_ctu_bytes(subme, shapes, candidates):
+    L = lib()
+    L.x265hip_cost_ctu_bytes.restype = ctypes.c_size_t
+    return L.x265hip_cost_ctu_bytes(subme, shapes, candidates)
+
+
+def cost_candidates(surf, centres, nctu, window, shapes, candidates, cand, stream=None):
+    L = lib()
+    L.x265hip_cost_candidates.argtypes = [ctypes.POINTER(CostCandidatesParams), ctypes.c_void_p]
+    p = CostCandidatesParams(nctu, window, _p(surf), _p(centres), shapes, candidates, _p(cand))
+    check(L.x265hip_cost_candidates(ctypes.byref(p), current_stream() if stream is None else stream), "x265hip_cost_candidates")
+
+
+def cost_tables(depth, width, stride, margin_x, margin_y, stride_c, margin_y_c, ctu_row0, ctu_rows, fenc, ref, phases, plane_bytes, plane_bytes_c,
+                shapes, candidates, subme, chroma, cand, tables, stream=None):
+    """fenc / ref / phases: three device tensors each (allocation starts; chroma entries None when chroma = 0)."""
+    L = lib()
+    L.x265hip_cost_tables.argtypes = [ctypes.POINTER(CostTablesParams), ctypes.c_void_p]
+    p = CostTablesParams()
+    p.depth, p.width, p.stride, p.margin_x, p.margin_y, p.stride_c, p.margin_y_c = depth, width, stride, margin_x, margin_y, stride_c, margin_y_c
+    p.ctu_row0, p.ctu_rows = ctu_row0, ctu_rows
+    for i in range(3):
+        p.fenc[i], p.ref[i], p.phases[i] = _p(fenc[i]), _p(ref[i]), _p(phases[i])
+    p.plane_bytes, p.plane_bytes_c = plane_bytes, plane_bytes_c
+    p.shapes, p.candidates, p.subme, p.chroma = shapes, candidates, subme, int(bool(chroma))
+    p.cand, p.tables = _p(cand), _p(tables)
+    check(L.x265hip_cost_tables(ctypes.byref(p), current_stream() if stream is None else stream), "x265hip_cost_tables")
