@@ -837,6 +837,205 @@ inline bool sub_arrived(SubCtx& c, int which)
     return ok;
 }
 
+
+/* ---- the COST-TABLE seam (round 6): MotionEstimate::subpelCompare's SATD comparisons answered as VALUES from x265hip_cost_stream's records
+ * (include/x265hip.h, "SUB-SAMPLE COST TABLES").  Per (source picture, reference[, weights]) pair the service holds, for every PU made of 8x8 blocks,
+ * records { int16 mvx, mvy; uint32 base; uint16 delta[positions] } around the 1 - 2 integer displacements of smallest SAD: the refinement of
+ * motion.cpp:1456-1561 starts from the vector the integer search ended on and measures quarter-sample vectors of a fixed position set around it, so
+ * when that vector is a record's (mvx, mvy) every comparison of the refinement is one table read.  Everything else - another start vector, a
+ * position outside the set (a refinement that started from a fractional predictor), SAD comparisons (the predictor candidates of :773-812), a row
+ * whose records have not landed, a saturated delta - is the next seam's or the reference's own to compute: the same integer.
+ * Provider = C function pointers with the signatures of x265hip_cost_stream_picture_rows / _pair_open / _tables / _ready. */
+struct CostProvider
+{
+    void* ctx;
+    int (*picture_rows)(void* ctx, uint64_t key, const void* luma, const void* cb, const void* cr, int ctu_row0, int ctu_rows);
+    int (*pair_open)(void* ctx, int slot, uint64_t fenc_key, uint64_t ref_key, const void* weights, unsigned planes_weighted);
+    const void* (*tables)(void* ctx, int slot);
+    const volatile int* (*ready)(void* ctx, int slot);
+    int slots;
+    intptr_t stride, strideC;
+    int width, height, marginX, marginY;
+    int K, subme, chroma, recBytes, npos, npu;
+    size_t ctuBytes;
+};
+struct CostPair { bool used; int fencPoc; const PicYuv* rec; int recPoc; Wt wt[3]; int gen; int encodeOrder; };
+struct CostSeam
+{
+    bool enabled = false, verify = false, wait = false;
+    CostProvider p;
+    int8_t posMap[13 * 13];             /* (dy + 6) * 13 + dx + 6 -> index into delta[], -1 = not a position of the set */
+    int16_t puIndex[8][8][8][8];        /* [w / 8 - 1][h / 8 - 1][y / 8][x / 8] -> PU of the service's list, -1 = not listed */
+    std::mutex mu;
+    CostPair pairs[MAX_SLOTS];
+    FencStaged fencs[32];
+    uint64_t instance = 0;
+    std::atomic<int> epoch{0};
+    std::atomic<uint64_t> served{0}, otherVector{0}, notReady{0}, saturated{0}, torn{0}, noContext{0}, contexts{0}, pairsOpened{0}, noSlot{0}, rowsPublished{0}, rowsRefused{0},
+                          mismatches{0}, weightedPairs{0};
+} gc;
+struct CostCtx
+{
+    bool valid;
+    const ReferencePlanes* ref;
+    const uint8_t* recs;                /* the PU's K records */
+    const volatile int* ready;
+    int row, gen;
+    uint64_t nServed, nOther, nNotReady, nSaturated, nTorn;      /* per search, added to the shared counters once at its end */
+};
+thread_local CostCtx t_cost;
+thread_local struct { int fencPoc; int epoch; int n; struct { const PicYuv* rec; int recPoc; Wt wt[3]; int slot; int gen; } e[8]; } t_cpairs = { -0x7fffffff, -1, 0, {} };
+
+/* slot of the pair (source picture fencPoc, reference picture, weights); -1 when none can be had.  The first query of a source picture hands its three
+ * planes to the provider (it is complete before its encode starts); the reference's rows arrive from the producer hook, before or after.  Slots are
+ * recycled like the SAD seam's: frame encoders take pictures round robin in encode order (encoder.cpp:1988-1989, :2394), so while picture e is being
+ * encoded every picture of encode order <= e - frameThreads is done. */
+int cost_slot(int fencPoc, const PicYuv* fencPic, const PicYuv* rec, int recPoc, const Wt* wt, int& gen, int encodeOrder, int frameThreads)
+{
+    const int epoch = gc.epoch.load(std::memory_order_acquire);
+    if (t_cpairs.fencPoc != fencPoc || t_cpairs.epoch != epoch) { t_cpairs.fencPoc = fencPoc; t_cpairs.epoch = epoch; t_cpairs.n = 0; }
+    for (int i = 0; i < t_cpairs.n; i++)
+        if (t_cpairs.e[i].rec == rec && t_cpairs.e[i].recPoc == recPoc && same_wt3(t_cpairs.e[i].wt, wt)) { gen = t_cpairs.e[i].gen; return t_cpairs.e[i].slot; }
+    int slot = -1;
+    {
+        std::lock_guard<std::mutex> lk(gc.mu);
+        for (int i = 0; i < gc.p.slots; i++)
+        {
+            CostPair& q = gc.pairs[i];
+            if (q.used && q.fencPoc == fencPoc && q.rec == rec && q.recPoc == recPoc && same_wt3(q.wt, wt)) { slot = i; gen = q.gen; }
+        }
+        if (slot < 0)
+        {
+            int freeSlot = -1;
+            for (int i = 0; i < gc.p.slots && freeSlot < 0; i++)
+                if (!gc.pairs[i].used || gc.pairs[i].encodeOrder <= encodeOrder - frameThreads) freeSlot = i;
+            const uint64_t fkey = pic_key(gc.instance, fencPoc, 0);
+            bool staged = false;
+            int freeF = -1;
+            for (int i = 0; i < 32; i++)
+            {
+                if (gc.fencs[i].used && gc.fencs[i].poc == fencPoc) staged = true;
+                if (!gc.fencs[i].used || gc.fencs[i].encodeOrder <= encodeOrder - frameThreads) freeF = i;
+            }
+            int rc = freeSlot < 0 ? -1 : 0;
+            if (!rc && !staged)
+            {
+                rc = freeF < 0 ? -1 : gc.p.picture_rows(gc.p.ctx, fkey, fencPic->m_picBuf[0], fencPic->m_picBuf[1], fencPic->m_picBuf[2], 0, gc.p.height / 64);
+                if (!rc) { gc.fencs[freeF].used = true; gc.fencs[freeF].poc = fencPoc; gc.fencs[freeF].encodeOrder = encodeOrder; }
+            }
+            if (!rc)
+            {
+                const unsigned mask = (wt[0].present ? 1u : 0u) | (wt[1].present ? 2u : 0u) | (wt[2].present ? 4u : 0u);
+                struct { int w0, round, shift, offset; } w3[3];
+                for (int c = 0; c < 3; c++) { w3[c].w0 = wt[c].w0; w3[c].round = wt[c].round; w3[c].shift = wt[c].shift; w3[c].offset = wt[c].offset; }
+                const int gnew = gc.p.pair_open(gc.p.ctx, freeSlot, fkey, pic_key(gc.instance, recPoc, 1), mask ? w3 : NULL, mask);
+                if (gnew > 0)
+                {
+                    CostPair& q = gc.pairs[freeSlot];
+                    q.used = true; q.fencPoc = fencPoc; q.rec = rec; q.recPoc = recPoc; q.wt[0] = wt[0]; q.wt[1] = wt[1]; q.wt[2] = wt[2]; q.gen = gnew; q.encodeOrder = encodeOrder;
+                    slot = freeSlot; gen = gnew;
+                    gc.pairsOpened++;
+                    if (mask) gc.weightedPairs++;
+                    gc.epoch.fetch_add(1, std::memory_order_release);
+                    t_cpairs.epoch = gc.epoch.load(); t_cpairs.n = 0;
+                }
+            }
+        }
+    }
+    if (slot < 0) gc.noSlot++;
+    /* remembered per thread either way: the other searches of this picture on this reference do not come back to the mutex for the same answer */
+    if (t_cpairs.n < 8) { auto& e = t_cpairs.e[t_cpairs.n++]; e.rec = rec; e.recPoc = recPoc; e.wt[0] = wt[0]; e.wt[1] = wt[1]; e.wt[2] = wt[2]; e.slot = slot; e.gen = gen; }
+    return slot;
+}
+
+/* the cost-table context of one motionEstimate call: which PU of which CTU on which pair */
+void cost_context(const Search* s, const MotionEstimate* me, ReferencePlanes* ref, int ctuAddr, int absPartIdx, int partEnum, int blockwidth, bool chromaSatd, int subme)
+{
+    CostCtx& c = t_cost;
+    const PicYuv* rec = ref->reconPic;
+    const Frame* frame = s->m_frame;
+    const PicYuv* src = frame ? frame->m_fencPic : NULL;
+    if (!rec || !src || rec->m_picCsp != X265_CSP_I420 || rec->m_stride != gc.p.stride || rec->m_strideC != gc.p.strideC || src->m_stride != gc.p.stride ||
+        (int)rec->m_lumaMarginX != gc.p.marginX || (int)rec->m_lumaMarginY != gc.p.marginY || s->m_param->maxCUSize != 64 ||
+        (int)chromaSatd != gc.p.chroma || subme != gc.p.subme || partEnum < 0 || partEnum >= NUM_PU_SIZES || PU_DIMS[partEnum][0] != blockwidth)
+    { gc.noContext.fetch_add(1, std::memory_order_relaxed); return; }
+    const int w = blockwidth, h = PU_DIMS[partEnum][1], px = g_zscanToPelX[absPartIdx], py = g_zscanToPelY[absPartIdx];
+    if ((w | h | px | py) & 7) { gc.noContext.fetch_add(1, std::memory_order_relaxed); return; }
+    const int pu = gc.puIndex[w / 8 - 1][h / 8 - 1][py / 8][px / 8];
+    if (pu < 0) { gc.noContext.fetch_add(1, std::memory_order_relaxed); return; }
+    /* the planes the reference reads: the reconstruction, or - plane by plane - MotionReference::weightBuffer at the same pad (reference.cpp:103) */
+    Wt wt[3];
+    for (int k = 0; k < 3; k++)
+    {
+        wt[k] = plane_weight(ref, k);
+        const pixel* base = wt[k].present ? static_cast<const MotionReference*>(ref)->weightBuffer[k] : rec->m_picBuf[k];
+        if (!base || ref->fpelPlane[k] - base != rec->m_picOrg[k] - rec->m_picBuf[k]) { gc.noContext.fetch_add(1, std::memory_order_relaxed); return; }
+    }
+    const int poc = ref_poc(s->m_slice, ref);
+    if (poc == -0x7fffffff) { gc.noContext.fetch_add(1, std::memory_order_relaxed); return; }
+    int gen = 0;
+    const int slot = cost_slot(frame->m_poc, src, rec, poc, wt, gen, frame->m_encodeOrder, s->m_param->frameNumThreads);
+    if (slot < 0) return;
+    const uint8_t* tab = (const uint8_t*)gc.p.tables(gc.p.ctx, slot);
+    c.ready = gc.p.ready(gc.p.ctx, slot);
+    if (!tab || !c.ready) return;
+    c.ref = ref;
+    c.recs = tab + (size_t)ctuAddr * gc.p.ctuBytes + (size_t)pu * gc.p.K * gc.p.recBytes;
+    c.row = ctuAddr / (gc.p.width / 64);
+    c.gen = gen;
+    c.nServed = c.nOther = c.nNotReady = c.nSaturated = c.nTorn = 0;
+    c.valid = true;
+    (void)me;
+}
+
+/* one comparison from the records; false = not this seam's */
+inline bool cost_lookup(CostCtx& c, const MV& qmv, int& out)
+{
+    if (c.ready[c.row] != c.gen)
+    {
+        bool arrived = false;
+        if (gc.wait)          /* test mode: small pictures are encoded faster than their records travel */
+            for (int spin = 0; spin < 20000 && !arrived; spin++)
+            {
+                struct timespec ts = { 0, 100000 };
+                nanosleep(&ts, NULL);
+                arrived = c.ready[c.row] == c.gen;
+            }
+        if (!arrived)
+        {
+            /* a row that does not come within 2 s will not come for the next lookup either: after a few timeouts the test mode stops waiting (and says so) */
+            static std::atomic<int> timeouts{0};
+            if (gc.wait && timeouts.fetch_add(1) < 8)
+                fprintf(stderr, "ref_seam: cost records of CTU row %d (generation %d, flag %d) did not arrive within 2 s\n", c.row, c.gen, (int)c.ready[c.row]);
+            if (gc.wait && timeouts.load() >= 8) gc.wait = false;
+            c.nNotReady++;
+            return false;
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int k = 0; k < gc.p.K; k++)
+    {
+        const uint8_t* rec = c.recs + (size_t)k * gc.p.recBytes;
+        const int mvx = ((const int16_t*)rec)[0], mvy = ((const int16_t*)rec)[1];
+        if (mvx == -32768) continue;
+        const int dx = qmv.x - 4 * mvx + 6, dy = qmv.y - 4 * mvy + 6;
+        if ((unsigned)dx > 12u || (unsigned)dy > 12u) continue;
+        const int idx = gc.posMap[dy * 13 + dx];
+        if (idx < 0) continue;
+        const unsigned delta = ((const uint16_t*)(rec + 8))[idx];
+        if (delta == 65535u) { c.nSaturated++; return false; }
+        const int cost = (int)(((const uint32_t*)rec)[1] + delta);
+        /* the row must STILL be this generation's after the read: a reopened slot has its flags cleared before any record is rewritten */
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (c.ready[c.row] != c.gen) { c.nTorn++; return false; }
+        c.nServed++;
+        out = cost;
+        return true;
+    }
+    c.nOther++;
+    return false;
+}
+
 } // namespace
 
 /* the seam: same signature, same symbol as the reference's function (whose compiled body now answers to x265ref_orig_motionEstimate) */
@@ -908,6 +1107,12 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     t_sub.valid = false;
     if (gs.enabled && ctuAddr >= 0 && !srcReferencePlane && !ref->isLowres)
         sub_context(reinterpret_cast<const Search*>(reinterpret_cast<const char*>(this) - offsetof(Search, m_me)), ref);
+    t_cost.valid = false;
+    if (gc.enabled && ctuAddr >= 0 && !srcReferencePlane && !ref->isLowres)
+    {
+        gc.contexts.fetch_add(1, std::memory_order_relaxed);
+        cost_context(reinterpret_cast<const Search*>(reinterpret_cast<const char*>(this) - offsetof(Search, m_me)), this, ref, ctuAddr, absPartIdx, partEnum, blockwidth, bChromaSATD, subpelRefine);
+    }
     if (gp.on) gp.ctxCyc.fetch_add(__rdtsc() - tctx, std::memory_order_relaxed);
     const int cost = x265ref_orig_motionEstimate(this, ref, &mvmin, &mvmax, &qmvp, numCandidates, mvc, merange, &outQMv, maxSlices, srcReferencePlane);
     if (t_sub.valid)
@@ -919,6 +1124,16 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         if (sc.nTorn) gs.torn.fetch_add(sc.nTorn, std::memory_order_relaxed);
     }
     t_sub.valid = false;
+    if (t_cost.valid)
+    {
+        CostCtx& cc = t_cost;
+        if (cc.nServed) gc.served.fetch_add(cc.nServed, std::memory_order_relaxed);
+        if (cc.nOther) gc.otherVector.fetch_add(cc.nOther, std::memory_order_relaxed);
+        if (cc.nNotReady) gc.notReady.fetch_add(cc.nNotReady, std::memory_order_relaxed);
+        if (cc.nSaturated) gc.saturated.fetch_add(cc.nSaturated, std::memory_order_relaxed);
+        if (cc.nTorn) gc.torn.fetch_add(cc.nTorn, std::memory_order_relaxed);
+    }
+    t_cost.valid = false;
     if (c.valid)
     {
         c.valid = false;
@@ -978,6 +1193,24 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
                 if (better < 4) gpp.top4++;
                 if (better < 8) gpp.top8++;
             }
+        }
+    }
+    if (t_cost.valid && t_cost.ref == ref && cmp == satd && sad != satd)
+    {
+        int cost;
+        if (cost_lookup(t_cost, qmv, cost))
+        {
+            if (gc.verify)
+            {
+                const int want = x265ref_orig_subpelCompare(this, ref, &qmv, cmp);
+                if (want != cost)
+                {
+                    gc.mismatches++;
+                    fprintf(stderr, "ref_seam: COST TABLE VERIFY MISMATCH partition %d mv (%d,%d): record %d, reference %d\n", partEnum, qmv.x, qmv.y, cost, want);
+                    abort();
+                }
+            }
+            return cost;
         }
     }
     SubCtx& c = t_sub;
@@ -1057,6 +1290,19 @@ void FrameFilter::processPostRow(int row)
     x265ref_orig_processPostRow(this, row);
     ProfScope prof(gp.rowCyc, gp.rows);
     const bool sad = g.enabled && g.p.streamed && g.p.min_pu <= 64, sub = gs.enabled && gs.p.streamed;        /* min_pu > 64: no SAD stub is installed */
+    if (gc.enabled)
+    {
+        const Frame* f = m_frame;
+        const PicYuv* r = f ? f->m_reconPic : NULL;
+        if (r && IS_REFERENCED(f) && m_param->maxCUSize == 64 && r->m_picCsp == X265_CSP_I420 && r->m_stride == gc.p.stride && r->m_strideC == gc.p.strideC &&
+            (int)r->m_lumaMarginX == gc.p.marginX && (int)r->m_lumaMarginY == gc.p.marginY && m_numRows == gc.p.height / 64 && row < m_numRows)
+        {
+            if (gc.p.picture_rows(gc.p.ctx, pic_key(gc.instance, f->m_poc, 1), r->m_picBuf[0], r->m_picBuf[1], r->m_picBuf[2], row, 1) == 0)
+                gc.rowsPublished.fetch_add(1, std::memory_order_relaxed);
+            else
+                gc.rowsRefused.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
     if (!sad && !sub) return;
     const Frame* frame = m_frame;
     const PicYuv* rec = frame ? frame->m_reconPic : NULL;
@@ -1624,7 +1870,59 @@ int x265ref_seam_configure_streamed(void* ctx, void* picture_rows, void* pair_op
     return 0;
 }
 
-void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; gs.enabled = false; gaq.enabled = false; gwa.enabled = false; }
+void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; gs.enabled = false; gaq.enabled = false; gwa.enabled = false; gc.enabled = false; }
+
+/* cost-table seam: provider = x265hip_cost_stream_picture_rows / _pair_open / _tables / _ready signatures (NULL pair_open = off); geometry = the PicYuv
+ * buffers of the encode about to start; pu_rects = int [npu][4] (x, y, w, h: x265hip_cost_pu_rect), positions = int8 [npos][2] (x265hip_cost_positions),
+ * record_bytes / ctu_bytes as the service lays the records out.  flags: 1 = verify every served value against the reference's own function, 2 = wait
+ * for records, 4 = ignore the size gate.  Needs the SAD seam's configure first when the size gate is to apply (it decides g_gated). */
+int x265ref_cost_seam_configure(void* ctx, void* picture_rows, void* pair_open, void* tables, void* ready, int slots, int width, int height, intptr_t stride, intptr_t stride_c,
+                                int margin_x, int margin_y, int candidates, int subme, int chroma, const int* pu_rects, int npu, const int8_t* positions, int npos,
+                                int record_bytes, size_t ctu_bytes, int flags)
+{
+    gc.enabled = false;
+    if (!pair_open) return 0;
+    if (slots < 1 || slots > MAX_SLOTS || !picture_rows || !tables || !ready || !pu_rects || !positions || npu < 1 || npos < 1 || npos > 169 || candidates < 1 || candidates > 2 ||
+        (width & 63) || (height & 63) || record_bytes < 8 + 2 * npos || ctu_bytes < (size_t)record_bytes * npu * candidates) return -1;
+    gc.p.ctx = ctx;
+    gc.p.picture_rows = (int (*)(void*, uint64_t, const void*, const void*, const void*, int, int))picture_rows;
+    gc.p.pair_open = (int (*)(void*, int, uint64_t, uint64_t, const void*, unsigned))pair_open;
+    gc.p.tables = (const void* (*)(void*, int))tables;
+    gc.p.ready = (const volatile int* (*)(void*, int))ready;
+    gc.p.slots = slots; gc.p.width = width; gc.p.height = height; gc.p.stride = stride; gc.p.strideC = stride_c; gc.p.marginX = margin_x; gc.p.marginY = margin_y;
+    gc.p.K = candidates; gc.p.subme = subme; gc.p.chroma = chroma; gc.p.recBytes = record_bytes; gc.p.npos = npos; gc.p.npu = npu; gc.p.ctuBytes = ctu_bytes;
+    memset(gc.posMap, -1, sizeof(gc.posMap));
+    for (int i = 0; i < npos; i++)
+    {
+        const int dx = positions[2 * i] + 6, dy = positions[2 * i + 1] + 6;
+        if ((unsigned)dx > 12u || (unsigned)dy > 12u) return -1;
+        gc.posMap[dy * 13 + dx] = (int8_t)i;
+    }
+    memset(gc.puIndex, -1, sizeof(gc.puIndex));
+    for (int i = 0; i < npu; i++)
+    {
+        const int x = pu_rects[4 * i], y = pu_rects[4 * i + 1], w = pu_rects[4 * i + 2], h = pu_rects[4 * i + 3];
+        if (((x | y | w | h) & 7) || w < 8 || h < 8 || x + w > 64 || y + h > 64) return -1;
+        gc.puIndex[w / 8 - 1][h / 8 - 1][y / 8][x / 8] = (int16_t)i;
+    }
+    gc.instance++;
+    memset(gc.pairs, 0, sizeof(gc.pairs)); memset(gc.fencs, 0, sizeof(gc.fencs));
+    gc.verify = (flags & 1) != 0; gc.wait = (flags & 2) != 0;
+    gc.served = 0; gc.otherVector = 0; gc.notReady = 0; gc.saturated = 0; gc.torn = 0; gc.noContext = 0; gc.contexts = 0; gc.pairsOpened = 0; gc.noSlot = 0;
+    gc.rowsPublished = 0; gc.rowsRefused = 0; gc.mismatches = 0; gc.weightedPairs = 0;
+    gc.epoch.fetch_add(1);
+    gc.enabled = (flags & 4) ? true : !g_gated;
+    return 0;
+}
+
+/* out[13]: comparisons served from records, passed on because the search did not end on a record's vector (or left the position set), because the row's records had
+ * not landed, because a delta was saturated, because the slot was reopened under the read; motionEstimate calls seen, of those without a usable context; pairs opened,
+ * pair requests without a free slot, rows of reconstructed pictures handed to the provider / refused by it, verify mismatches, pairs on weighted references */
+void x265ref_cost_seam_stats(uint64_t* out)
+{
+    out[0] = gc.served; out[1] = gc.otherVector; out[2] = gc.notReady; out[3] = gc.saturated; out[4] = gc.torn; out[5] = gc.contexts; out[6] = gc.noContext;
+    out[7] = gc.pairsOpened; out[8] = gc.noSlot; out[9] = gc.rowsPublished; out[10] = gc.rowsRefused; out[11] = gc.mismatches; out[12] = gc.weightedPairs;
+}
 
 /* sub-sample seam: provider = x265hip_phase_cache_submit / _planes / _ready signatures (NULL submit = off); geometry = the PicYuv
  * buffers of the encode about to start.  flags: 1 = verify every served call against the reference's own function, 2 = wait for planes */

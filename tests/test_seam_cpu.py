@@ -22,19 +22,19 @@ def _tools():
 
 
 def run_pair(depth, w, h, nframes, preset, opts, provider, rng, min_pu=8, verify=True, seed=41, wait=False, lookahead=None, subpel=None, surf_format=None,
-             streamed=False, min_level=0, slots=8, subpel_slots=6, layout=0, centre_range=0, aq=None, width_clip=None, split_rest=False):
+             streamed=False, min_level=0, slots=8, subpel_slots=6, layout=0, centre_range=0, aq=None, width_clip=None, split_rest=False, cost=None, cost_cfg=None, fade=None):
     EB, SD = _tools()
     try:
         plain = EB.ref_lib(depth)
         SD.seam_lib(depth)
     except (SystemExit, FileNotFoundError):
         pytest.skip("oracle/_ref not built (needs /root/reference)")
-    clip = F.synth_clip(w, h, nframes, depth=depth, seed=seed)
+    clip = F.synth_clip(w, h, nframes, depth=depth, seed=seed, fade=fade)
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
     base = EB.encode(plain, yuv, w, h, nframes, preset, opts)
     lib, filler, report, close, prov = SD.install(depth, w, h, provider=provider, rng=rng, slots=slots, min_pu=min_pu, verify=verify, wait=wait, lookahead=lookahead,
                                                   subpel=subpel, surf_format=surf_format, streamed=streamed, min_level=min_level, subpel_slots=subpel_slots,
-                                                  layout=layout, centre_range=centre_range, aq=aq, split_rest=split_rest)
+                                                  layout=layout, centre_range=centre_range, aq=aq, split_rest=split_rest, cost=cost, cost_cfg=cost_cfg)
     try:
         got = EB.encode(lib, yuv, w, h, nframes, preset, opts, filler)
         rep = report()
@@ -467,3 +467,31 @@ def test_hit_rate_gate_closes_the_sad_seam_when_the_windows_are_missed_and_probe
     assert g["hit_rate_gate"]["times_closed"] >= 1 and g["hit_rate_gate"]["searches_left_to_the_host_while_closed"] > 100, g["hit_rate_gate"]
     assert g["pair_submits"] < o["pair_submits"], (g["pair_submits"], o["pair_submits"])          # fewer pairs searched by the provider
     assert g["pair_submits"] >= 3                                                                # ... but the probes keep coming
+
+
+# ---- round 6: the cost-table seam - subpelCompare's SATD comparisons answered as values from the service's records ---------------------------------
+@pytest.mark.reference
+@pytest.mark.parametrize("depth,preset,extra,k,fade,min_share", [(8, "slow", [("me", "star")], 1, None, 0.6), (8, "slower", [], 2, None, 0.8), (10, "slow", [], 1, None, 0.6),
+                                                                 (8, "medium", [("subme", "3")], 2, None, 0.5), (8, "slow", [], 2, (1.0, 0.4), 0.08),
+                                                                 (8, "veryslow", [("frame-threads", "1")], 1, None, 0.6), (8, "medium", [], 2, None, 0.5)])
+def test_cost_seam_serves_the_refinement_with_the_references_own_values(depth, preset, extra, k, fade, min_share):
+    """The real encoder under --frame-threads 2 with MotionEstimate::subpelCompare answering its SATD comparisons from the records of the cost-table
+    provider (here the oracle's restatement; tests/test_gpu_seam.py plugs in x265hip_cost_stream): byte-identical bitstream, EVERY served value
+    re-evaluated by the reference's own subpelCompare on the spot (verify: luma_hpp / vpp / hvpp + satd, chroma filters + chroma satd), and the records are
+    really used - most of the SATD comparisons of the searches that have a context are served.  Presets: slow (subme 3: 49 positions, chroma SATD,
+    rectangles), slower / veryslow (subme 4: 85 positions, AMP), medium (subme 2: luma only) and medium with --subme 3; a fade (weighted references:
+    a pair per weight triple - and the UNWEIGHTED references of a fade, where the smallest SAD is a brightness accident and the host's search, pulled by
+    its vector cost, ends elsewhere: few comparisons served, all of them right)."""
+    EB, SD = _tools()
+    opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24")] + extra
+    cfg = SD.cost_config(preset, opts, centre_range=20, window=4, candidates=k, slots=40)
+    base, got, rep = run_pair(depth, 256, 192, 7, preset, opts, "oracle", rng=8, min_pu=128, streamed=True, min_level=1, slots=32, layout=1, centre_range=20, wait=True,
+                              cost="oracle", cost_cfg=cfg, fade=fade)
+    c = rep["cost_seam"]
+    assert got[0] == base[0], f"the cost-table seam changed the bitstream: {c}"
+    assert c["verify_mismatches"] == 0 and rep["verify"] == 1, c
+    assert c["comparisons_served_from_records"] > 3000 and c["pairs_opened"] >= 5, c
+    assert c["served_share_of_satd_comparisons_with_context"] > min_share, c
+    assert c["recon_rows_to_provider"] > 0 and c["recon_rows_refused"] == 0, c
+    if fade:
+        assert c["pairs_on_weighted_references"] > 0, c

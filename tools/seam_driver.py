@@ -643,6 +643,199 @@ class StreamGpuPhaseProvider:
             self.handle = None
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# COST-TABLE providers (round 6): x265hip_cost_stream and its CPU stand-in - the sub-sample half of motionEstimate served as values.
+CS_ROWS = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
+CS_OPEN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint)
+CS_TABLES = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
+CS_READY = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
+COST_STAT_NAMES = ("comparisons_served_from_records", "passed_on_other_vector_or_position", "passed_on_records_not_arrived", "passed_on_saturated_delta", "dropped_slot_reopened",
+                   "motion_estimate_calls_seen", "calls_without_context", "pairs_opened", "pair_requests_without_slot", "recon_rows_to_provider", "recon_rows_refused",
+                   "verify_mismatches", "pairs_on_weighted_references")
+PRESET_SUBME = {"ultrafast": 0, "superfast": 1, "veryfast": 1, "faster": 2, "fast": 2, "medium": 2, "slow": 3, "slower": 4, "veryslow": 4, "placebo": 5}      # common/param.cpp:397-539
+PRESET_SHAPES = {"slow": 1, "slower": 2, "veryslow": 2, "placebo": 2}                                                                                             # --rect from slow, --amp from slower
+
+
+def cost_config(preset, opts, centre_range=57, window=8, candidates=1, slots=24, pictures=40, views=12, band_rows=8):
+    """The cost-table service's parameters for an encode: the refinement's position set and the chroma flag follow --subme (bChromaSATD: subme > 2,
+    motion.cpp:212), the PU list follows --rect / --amp."""
+    o = dict((k, v) for k, v in opts)
+    subme = int(o.get("subme", PRESET_SUBME.get(preset, 2)))
+    shapes = PRESET_SHAPES.get(preset, 0)
+    if "rect" in o: shapes = max(shapes, 1)
+    if "amp" in o: shapes = 2
+    if "no-rect" in o: shapes = 0
+    elif "no-amp" in o: shapes = min(shapes, 1)
+    return dict(centre_range=centre_range, window=window, candidates=candidates, shapes=shapes, subme=subme, chroma=int(subme > 2), slots=slots, pictures=pictures, views=views,
+                band_rows=band_rows)
+
+
+class StreamGpuCostProvider:
+    """libx265hip.so's x265hip_cost_stream: the product path."""
+
+    def __init__(self, depth, geo, cfg, device=None):
+        A = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+        self.A, self.L, self.cfg = A, A.lib(), cfg
+        L = self.L
+        p = A.CostStreamParams(depth, geo["width"], geo["height"], geo["stride"], geo["margin_x"], geo["margin_y"], geo["stride_c"], geo["margin_y"] >> 1,
+                               cfg["centre_range"], cfg["window"], cfg["candidates"], cfg["shapes"], cfg["subme"], cfg["chroma"], cfg["slots"], cfg["pictures"], cfg["views"],
+                               cfg["band_rows"], 0 if device is None else device + 1)
+        self.handle = ctypes.c_void_p()
+        L.x265hip_cost_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(A.CostStreamParams)]
+        A.check(L.x265hip_cost_stream_create(ctypes.byref(self.handle), ctypes.byref(p)), "x265hip_cost_stream_create")
+        L.x265hip_cost_stream_destroy.argtypes = [ctypes.c_void_p]
+        L.x265hip_cost_stream_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(A.CostStreamStats)]
+        self.rects, self.positions = A.cost_pu_list(cfg["shapes"]), A.cost_positions(cfg["subme"])
+        self.record_bytes, self.ctu_bytes = A.cost_record_bytes(cfg["subme"]), A.cost_ctu_bytes(cfg["subme"], cfg["shapes"], cfg["candidates"])
+
+    def pointers(self):
+        L = self.L
+        return (self.handle,) + tuple(ctypes.cast(f, ctypes.c_void_p) for f in (L.x265hip_cost_stream_picture_rows, L.x265hip_cost_stream_pair_open,
+                                                                                  L.x265hip_cost_stream_tables, L.x265hip_cost_stream_ready))
+
+    def report(self):
+        st = self.A.CostStreamStats()
+        self.L.x265hip_cost_stream_stats(self.handle, ctypes.byref(st))
+        d = {n: int(getattr(st, n)) for n, _ in st._fields_}
+        d["provider"] = "x265hip_cost_stream (records of sub-sample SATD costs around each PU's best integer vectors; views and phase planes stay on the device)"
+        d["worker_busy_ms"] = round(st.us_busy / 1e3, 1)
+        d["config"] = dict(self.cfg)
+        return d
+
+    def close(self):
+        if self.handle:
+            self.L.x265hip_cost_stream_destroy(self.handle)
+            self.handle = None
+
+
+class StreamOracleCostProvider:
+    """CPU stand-in for x265hip_cost_stream (checker only): pictures arrive by key (a reconstructed one row by row), a pair's CTU row is computed - the
+    oracle's centre search, centred SAD rasters, candidates and tables (oracle/x265_oracle_pipeline8.c: the reference's own subpelCompare route per value) -
+    once the reference rows <= r + 2 have arrived."""
+
+    def __init__(self, depth, geo, cfg):
+        import threading
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_api
+        self.O, self.depth, self.geo, self.cfg = oracle_api, depth, geo, cfg
+        self.dt = np.uint8 if depth == 8 else np.uint16
+        g = geo
+        self.ctus_w, self.ctu_rows = g["width"] // 64, g["height"] // 64
+        self.nctu = self.ctus_w * self.ctu_rows
+        self.dims = [(g["rows"], g["stride"], g["margin_y"], 64), (g["rows_c"], g["stride_c"], g["margin_y"] >> 1, 32)]
+        self.rects, self.positions = oracle_api.cost_pu_list(cfg["shapes"])[:, :4].copy(), oracle_api.cost_positions(cfg["subme"])
+        self.record_bytes = oracle_api.cost_record_bytes(cfg["subme"])
+        self.ctu_bytes = self.record_bytes * len(self.rects) * cfg["candidates"]
+        self.pics = {}
+        self.tables = [np.zeros(self.nctu * self.ctu_bytes, np.uint8) for _ in range(cfg["slots"])]
+        self.flags = [np.zeros(self.ctu_rows, np.int32) for _ in range(cfg["slots"])]
+        self.pair = [None] * cfg["slots"]
+        self.gen = [0] * cfg["slots"]
+        self.opened = self.rows_served = self.weighted = 0
+        mx = g["margin_x"] - cfg["window"] - 12
+        my = min(g["margin_y"], 2 * (g["margin_y"] >> 1)) - cfg["window"] - 20
+        self.max_c = (min(mx, cfg["centre_range"]), min(my, cfg["centre_range"])) if cfg["centre_range"] else (mx, my)
+        self.lock = threading.Lock()
+        self._cb = (CS_ROWS(self._rows), CS_OPEN(self._open), CS_TABLES(self._tables), CS_READY(self._ready))
+
+    def _pic(self, key):
+        if key not in self.pics:
+            if len(self.pics) > 48:
+                live = {k for pr in self.pair if pr for k in (pr["fkey"], pr["rkey"])} | {key}
+                for k in list(self.pics):
+                    if k not in live and len(self.pics) > 32:
+                        del self.pics[k]
+            self.pics[key] = {"src": [np.zeros((self.dims[min(k, 1)][0], self.dims[min(k, 1)][1]), self.dt) for k in range(3)], "staged": set(), "next": 0}
+        return self.pics[key]
+
+    def _rows(self, ctx, key, luma, cb, cr, r0, n):
+        with self.lock:
+            pic = self._pic(int(key))
+            es = np.dtype(self.dt).itemsize
+            for pl, ptr in enumerate((luma, cb, cr)):
+                rows, stride, margin, cl = self.dims[min(pl, 1)]
+                y0 = 0 if r0 == 0 else margin + r0 * cl
+                y1 = rows if r0 + n == self.ctu_rows else margin + (r0 + n) * cl
+                raw = (ctypes.c_uint8 * ((y1 - y0) * stride * es)).from_address(ptr + y0 * stride * es)
+                pic["src"][pl][y0:y1] = np.frombuffer(raw, dtype=self.dt).reshape(y1 - y0, stride)
+            pic["staged"].update(range(r0, r0 + n))
+            while pic["next"] in pic["staged"]:
+                pic["next"] += 1
+            self._advance()
+        return 0
+
+    def _open(self, ctx, slot, fkey, rkey, wptr, mask):
+        with self.lock:
+            self.gen[slot] += 1
+            self.flags[slot][:] = 0
+            w3 = read_weights(wptr, 3) if wptr and mask else [None] * 3
+            self.pair[slot] = {"fkey": int(fkey), "rkey": int(rkey), "w": [w3[c] if (mask >> c) & 1 else None for c in range(3)], "next": 0}
+            self.opened += 1
+            self.weighted += bool(wptr and mask)
+            self._pic(int(fkey)); self._pic(int(rkey))
+            self._advance()
+            return self.gen[slot]
+
+    def _advance(self):
+        O, g, c = self.O, self.geo, self.cfg
+        for slot, pr in enumerate(self.pair):
+            if not pr or pr["next"] >= self.ctu_rows or pr["fkey"] not in self.pics or pr["rkey"] not in self.pics:
+                continue
+            pf, rf = self.pics[pr["fkey"]], self.pics[pr["rkey"]]
+            r1 = pr["next"] - 1
+            while r1 + 1 < self.ctu_rows and pf["next"] > r1 + 1 and rf["next"] >= min(self.ctu_rows, r1 + 4):
+                r1 += 1
+            if r1 < pr["next"]:
+                continue
+            r0 = pr["next"]
+            ref = [rf["src"][pl] if pr["w"][pl] is None else weight_plane(rf["src"][pl], self.depth, pr["w"][pl]) for pl in range(3)]
+            fy, ry = pf["src"][0].reshape(-1), np.ascontiguousarray(ref[0]).reshape(-1)
+            org = g["margin_y"] * g["stride"] + g["margin_x"]
+            b, e = r0 * self.ctus_w, (r1 + 1) * self.ctus_w
+            centres = np.zeros((self.nctu, 2), np.int16)
+            if c["centre_range"]:
+                zero = np.zeros(2 * c["centre_range"] + 1, np.uint16)
+                _, best = O.me_fullsearch(self.depth, fy, g["stride"], org, ry, g["stride"], org, g["width"], g["height"], c["centre_range"], b, e, zero, zero, want_surf=False, want_best=True)
+                idx = (best.reshape(self.nctu, 85)[b:e, 84] & np.uint64(0xffffffff)).astype(np.int64)
+                ncb = 2 * c["centre_range"] + 1
+                centres[b:e, 0] = np.clip(idx % ncb - c["centre_range"], -self.max_c[0], self.max_c[0])
+                centres[b:e, 1] = np.clip(idx // ncb - c["centre_range"], -self.max_c[1], self.max_c[1])
+            w = c["window"]
+            rb = int(np.abs(centres[b:e]).max()) + w
+            zero = np.zeros(2 * rb + 1, np.uint16)
+            big, _ = O.me_fullsearch(self.depth, fy, g["stride"], org, ry, g["stride"], org, g["width"], g["height"], rb, b, e, zero, zero, want_surf=True, want_best=False)
+            ncb, ngb = 2 * rb + 1, (2 * rb + 4) // 4
+            big = big.reshape(self.nctu, ncb, ngb, 85, 4)[b:e].transpose(0, 1, 2, 4, 3).reshape(e - b, ncb, ngb * 4, 85)
+            nc, ng = 2 * w + 1, (2 * w + 4) // 4
+            surf = np.zeros((e - b, nc, ng * 4, 85), np.int32)
+            for i in range(e - b):
+                y0, x0 = int(centres[b + i, 1]) - w + rb, int(centres[b + i, 0]) - w + rb
+                surf[i, :, :nc] = big[i, y0:y0 + nc, x0:x0 + nc]
+            surf = np.ascontiguousarray(surf.reshape(e - b, nc, ng, 4, 85).transpose(0, 1, 2, 4, 3))
+            cand = O.cost_candidates(surf, centres[b:e], e - b, w, c["shapes"], c["candidates"], depth=self.depth)
+            tab = O.cost_tables(self.depth, [pf["src"][0], pf["src"][1], pf["src"][2]], ref, g["stride"], g["stride_c"], g["margin_x"], g["margin_y"], g["margin_y"] >> 1,
+                                g["width"], r0, r1 - r0 + 1, c["shapes"], c["candidates"], c["subme"], c["chroma"], cand)
+            self.tables[slot][b * self.ctu_bytes:e * self.ctu_bytes] = tab.reshape(-1)
+            self.flags[slot][r0:r1 + 1] = self.gen[slot]
+            self.rows_served += r1 - r0 + 1
+            pr["next"] = r1 + 1
+
+    def _tables(self, ctx, slot):
+        return self.tables[slot].ctypes.data
+
+    def _ready(self, ctx, slot):
+        return self.flags[slot].ctypes.data
+
+    def pointers(self):
+        return (None,) + tuple(ctypes.cast(c, ctypes.c_void_p) for c in self._cb)
+
+    def report(self):
+        return {"provider": "oracle, row-granular (CPU checker)", "pairs_opened": self.opened, "rows_served": self.rows_served, "weighted_pairs": self.weighted, "config": dict(self.cfg)}
+
+    def close(self):
+        pass
+
+
 class MultiDeviceStreamProvider:
     """One x265hip_me_stream instance PER GPU behind the binding's single provider interface - the mapping a host that spreads its frame encoders
     over the GPUs of a node would use (encoder/encoder.cpp:304-321: frame encoder i -> pool i % numPools): slot s of the binding lives on instance
@@ -747,7 +940,7 @@ class MultiDevicePhaseProvider:
 
 def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, verify=False, wait=False, lookahead=None, subpel=None, subpel_slots=6,
             surf_format=None, streamed=False, min_level=0, pictures=24, band_rows=0, weighted=True, layout=LAYOUT_RECORDS, centre_range=0, lookahead_min_blocks=0, min_ctus=0, build="", aq=None, aq_min_blocks=0,
-            weight_analyse=None, weight_min_blocks=0, split_rest=False, devices=None, hit_rate_gate=(2000000, 50)):
+            weight_analyse=None, weight_min_blocks=0, split_rest=False, devices=None, hit_rate_gate=(2000000, 50), cost=None, cost_cfg=None):
     """devices: [device index, ...] = one instance of each row-granular service PER entry (MultiDeviceStreamProvider / MultiDevicePhaseProvider).
     Returns (seam library, table filler pointer, report(), close()).  Encode with lib.x265ref_encode(..., filler, ...) and --ctu 64;
     the picture-granular providers need --frame-threads 1, streamed=True (row-granular providers) serves under any --frame-threads."""
@@ -861,9 +1054,36 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     else:
         lib.x265ref_subpel_seam_configure(None, None, None, None, 0, 0, 0, 0, 0, 0)
 
+    # the cost-table seam (MotionEstimate::subpelCompare's SATD comparisons answered from x265hip_cost_stream's records): "gpu" = the service, "oracle" = CPU checker;
+    # cost_cfg = cost_config(preset, opts, ...) - the position set and the chroma flag must be the encode's --subme
+    lib.x265ref_cost_seam_configure.argtypes = ([ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_ssize_t] * 2 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int])
+    lib.x265ref_cost_seam_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    cst = None
+    if cost:
+        cfg = dict(cost_cfg or cost_config("slow", []))
+        cst = StreamGpuCostProvider(depth, geo, cfg) if cost == "gpu" else StreamOracleCostProvider(depth, geo, cfg)
+        cctx, crows, copen, ctab, crdy = cst.pointers()
+        rects = np.ascontiguousarray(cst.rects, np.int32)
+        posn = np.ascontiguousarray(cst.positions, np.int8)
+        rc = lib.x265ref_cost_seam_configure(cctx, crows, copen, ctab, crdy, cfg["slots"], geo["width"], geo["height"], geo["stride"], geo["stride_c"], geo["margin_x"], geo["margin_y"],
+                                             cfg["candidates"], cfg["subme"], cfg["chroma"], rects.ctypes.data, len(rects), posn.ctypes.data, len(posn), cst.record_bytes, cst.ctu_bytes,
+                                             int(bool(verify)) | (2 if wait else 0) | (4 if min_ctus == 0 else 0))
+        if rc:
+            raise RuntimeError(f"x265ref_cost_seam_configure failed ({rc})")
+    else:
+        lib.x265ref_cost_seam_configure(None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, 0, 0, 0, 0)
+
     def report():
         d = stats(lib)
         d.update(prov.report())
+        if cst:
+            co = (ctypes.c_uint64 * 13)()
+            lib.x265ref_cost_seam_stats(co)
+            d["cost_seam"] = dict(zip(COST_STAT_NAMES, [int(v) for v in co]))
+            asked = d["cost_seam"]["comparisons_served_from_records"] + sum(d["cost_seam"][k] for k in COST_STAT_NAMES[1:5])
+            d["cost_seam"]["served_share_of_satd_comparisons_with_context"] = round(d["cost_seam"]["comparisons_served_from_records"] / asked, 4) if asked else None
+            d["cost_seam"].update(cst.report())
         d.update({"range": rng, "slots": slots, "min_pu": min_pu, "row_granular": bool(streamed), "layout": "planes" if layout else "records", "centre_range": centre_range,
                   "search_seams_left_off_by_the_size_gate": bool(lib.x265ref_seam_min_ctus(-1))})
         gate = (ctypes.c_uint64 * 4)()
@@ -914,5 +1134,7 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
         prov.close()
         if sub:
             sub.close()
+        if cst:
+            cst.close()
     close.keep = keep            # the oracle library must outlive the encode
     return lib, filler, report, close, prov
