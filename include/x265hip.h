@@ -1246,8 +1246,12 @@ typedef struct x265hip_cost_candidates_params
     int window;                         /* the surfaces hold (2 window + 1)^2 displacements per CTU, X265HIP_SURF_I32 records */
     const int32_t* surf;                /* DEVICE */
     const int16_t* centres;             /* DEVICE int16 [ctu][2] the surfaces were centred on, or NULL = (0, 0) */
-    int shapes, candidates;             /* candidates: 1 or 2 displacements of smallest SAD per PU (ties: raster order, like the search) */
+    int shapes, candidates;             /* candidates: 1 or 2 displacements of smallest cost per PU (ties: raster order, like the search) */
     int16_t* cand;                      /* DEVICE out, int16 [ctu][pu][candidate][2] = absolute integer displacement */
+    /* optional, DEVICE uint16 [2 window + 1]: vector cost of a displacement component relative to the window's centre; the ranking key is
+     * sad + mv_cost[col] + mv_cost[row] - what the host's search minimises (SAD + mvcost(mv - mvp), motion.cpp:246-328) with the CTU's own
+     * displacement standing in for the predictor.  NULL = SAD alone */
+    const uint16_t* mv_cost;
 } x265hip_cost_candidates_params;
 int x265hip_cost_candidates(const x265hip_cost_candidates_params* p, void* stream);
 typedef struct x265hip_cost_tables_params
@@ -1295,8 +1299,12 @@ void x265hip_cost_stream_destroy(x265hip_cost_stream* s);
  * stride_c = 0); copied before the call returns.  X265HIP_EBUSY: no picture entry free. */
 int  x265hip_cost_stream_picture_rows(x265hip_cost_stream* s, uint64_t key, const void* luma_buf, const void* cb_buf, const void* cr_buf, int ctu_row0, int ctu_rows);
 /* -> the slot's new GENERATION (> 0).  w = NULL: the reference as reconstructed; otherwise plane c is weighted with w[c] (weight_pp
- * arguments, round / shift including the 14 - depth correction) when bit c of planes_weighted is set */
-int  x265hip_cost_stream_pair_open(x265hip_cost_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key, const x265hip_weight* w, unsigned planes_weighted);
+ * arguments, round / shift including the 14 - depth correction) when bit c of planes_weighted is set.
+ * mv_cost (HOST uint16 [2 window + 1], copied; NULL = rank by SAD alone): the host's vector cost of an integer displacement component
+ * i - window relative to its predictor (BitCost::mvcost's table at the slice's QP, bitcost.h:45: m_cost[4 (i - window)]) - the candidates
+ * are then the minima of SAD + cost, what the host's own search minimises, with each CTU's displacement standing in for the predictor */
+int  x265hip_cost_stream_pair_open(x265hip_cost_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key, const x265hip_weight* w, unsigned planes_weighted,
+                                   const uint16_t* mv_cost);
 const void* x265hip_cost_stream_tables(x265hip_cost_stream* s, int slot);             /* pinned host memory, CTU-major */
 const volatile int* x265hip_cost_stream_ready(x265hip_cost_stream* s, int slot);      /* int [height / 64] */
 int  x265hip_cost_stream_stats(x265hip_cost_stream* s, x265hip_cost_stream_stats_t* st);

@@ -696,17 +696,19 @@ def cost_record_bytes(subme):
     return (8 + 2 * len(cost_positions(subme)) + 3) & ~3
 
 
-def cost_candidates(surf, centres, nctu, window, shapes, k, depth=8, avx2=False):
+def cost_candidates(surf, centres, nctu, window, shapes, k, depth=8, avx2=False, mv_cost=None):
     """surf: int32 SAD rasters of the 85 squares (me_fullsearch's surfaces, I32 records); centres int16 [nctu, 2] or None.
     Returns int16 [nctu, npu, k, 2]."""
     fn = getattr(lib(avx2), f"x265oracle_cost_candidates_d{depth}")
-    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p]
     fn.restype = None
     npu = len(cost_pu_list(shapes))
+    mc = None if mv_cost is None else np.ascontiguousarray(mv_cost, np.uint16)
+    assert mc is None or mc.size == 2 * window + 1
     s = np.ascontiguousarray(surf, np.int32)
     c = None if centres is None else np.ascontiguousarray(centres, np.int16)
     out = np.zeros((nctu, npu, k, 2), np.int16)
-    fn(s.ctypes.data, None if c is None else c.ctypes.data, nctu, window, shapes, k, out.ctypes.data)
+    fn(s.ctypes.data, None if c is None else c.ctypes.data, nctu, window, shapes, k, out.ctypes.data, None if mc is None else mc.ctypes.data)
     return out
 
 

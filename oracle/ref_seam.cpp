@@ -850,21 +850,22 @@ struct CostProvider
 {
     void* ctx;
     int (*picture_rows)(void* ctx, uint64_t key, const void* luma, const void* cb, const void* cr, int ctu_row0, int ctu_rows);
-    int (*pair_open)(void* ctx, int slot, uint64_t fenc_key, uint64_t ref_key, const void* weights, unsigned planes_weighted);
+    int (*pair_open)(void* ctx, int slot, uint64_t fenc_key, uint64_t ref_key, const void* weights, unsigned planes_weighted, const uint16_t* mv_cost);
     const void* (*tables)(void* ctx, int slot);
     const volatile int* (*ready)(void* ctx, int slot);
     int slots;
     intptr_t stride, strideC;
     int width, height, marginX, marginY;
-    int K, subme, chroma, recBytes, npos, npu;
+    int K, subme, chroma, recBytes, npos, npu, window;
+    unsigned coverMask;                 /* bit s: the refinement of --subme s stays inside the service's position set when it starts on a record's vector */
     size_t ctuBytes;
 };
 struct CostPair { bool used; int fencPoc; const PicYuv* rec; int recPoc; Wt wt[3]; int gen; int encodeOrder; };
 struct CostSeam
 {
-    bool enabled = false, verify = false, wait = false;
+    bool enabled = false, verify = false, wait = false, useMvCost = true;
     CostProvider p;
-    int8_t posMap[13 * 13];             /* (dy + 6) * 13 + dx + 6 -> index into delta[], -1 = not a position of the set */
+    int16_t posMap[13 * 13];            /* (dy + 6) * 13 + dx + 6 -> index into delta[], -1 = not a position of the set */
     int16_t puIndex[8][8][8][8];        /* [w / 8 - 1][h / 8 - 1][y / 8][x / 8] -> PU of the service's list, -1 = not listed */
     std::mutex mu;
     CostPair pairs[MAX_SLOTS];
@@ -890,7 +891,7 @@ thread_local struct { int fencPoc; int epoch; int n; struct { const PicYuv* rec;
  * planes to the provider (it is complete before its encode starts); the reference's rows arrive from the producer hook, before or after.  Slots are
  * recycled like the SAD seam's: frame encoders take pictures round robin in encode order (encoder.cpp:1988-1989, :2394), so while picture e is being
  * encoded every picture of encode order <= e - frameThreads is done. */
-int cost_slot(int fencPoc, const PicYuv* fencPic, const PicYuv* rec, int recPoc, const Wt* wt, int& gen, int encodeOrder, int frameThreads)
+int cost_slot(int fencPoc, const PicYuv* fencPic, const PicYuv* rec, int recPoc, const Wt* wt, int& gen, int encodeOrder, int frameThreads, const uint16_t* mvCostQpel)
 {
     const int epoch = gc.epoch.load(std::memory_order_acquire);
     if (t_cpairs.fencPoc != fencPoc || t_cpairs.epoch != epoch) { t_cpairs.fencPoc = fencPoc; t_cpairs.epoch = epoch; t_cpairs.n = 0; }
@@ -928,7 +929,12 @@ int cost_slot(int fencPoc, const PicYuv* fencPic, const PicYuv* rec, int recPoc,
                 const unsigned mask = (wt[0].present ? 1u : 0u) | (wt[1].present ? 2u : 0u) | (wt[2].present ? 4u : 0u);
                 struct { int w0, round, shift, offset; } w3[3];
                 for (int c = 0; c < 3; c++) { w3[c].w0 = wt[c].w0; w3[c].round = wt[c].round; w3[c].shift = wt[c].shift; w3[c].offset = wt[c].offset; }
-                const int gnew = gc.p.pair_open(gc.p.ctx, freeSlot, fkey, pic_key(gc.instance, recPoc, 1), mask ? w3 : NULL, mask);
+                /* what the search minimises is SAD + mvcost(mv - mvp) (motion.cpp:246-328); the service ranks its candidates by the same sum with each CTU's own displacement
+                 * standing in for the predictor: the cost of an integer displacement component d = BitCost's table at 4 d quarter samples (bitcost.h:45), at the QP of
+                 * the first search of the pair */
+                uint16_t mvCost[2 * 32 + 1];
+                for (int i = 0; i <= 2 * gc.p.window; i++) mvCost[i] = mvCostQpel ? mvCostQpel[4 * (i - gc.p.window)] : 0;
+                const int gnew = gc.p.pair_open(gc.p.ctx, freeSlot, fkey, pic_key(gc.instance, recPoc, 1), mask ? w3 : NULL, mask, mvCostQpel ? mvCost : NULL);
                 if (gnew > 0)
                 {
                     CostPair& q = gc.pairs[freeSlot];
@@ -949,7 +955,7 @@ int cost_slot(int fencPoc, const PicYuv* fencPic, const PicYuv* rec, int recPoc,
 }
 
 /* the cost-table context of one motionEstimate call: which PU of which CTU on which pair */
-void cost_context(const Search* s, const MotionEstimate* me, ReferencePlanes* ref, int ctuAddr, int absPartIdx, int partEnum, int blockwidth, bool chromaSatd, int subme)
+void cost_context(const Search* s, const uint16_t* mvCostQpel, ReferencePlanes* ref, int ctuAddr, int absPartIdx, int partEnum, int blockwidth, bool chromaSatd, int subme)
 {
     CostCtx& c = t_cost;
     const PicYuv* rec = ref->reconPic;
@@ -957,7 +963,7 @@ void cost_context(const Search* s, const MotionEstimate* me, ReferencePlanes* re
     const PicYuv* src = frame ? frame->m_fencPic : NULL;
     if (!rec || !src || rec->m_picCsp != X265_CSP_I420 || rec->m_stride != gc.p.stride || rec->m_strideC != gc.p.strideC || src->m_stride != gc.p.stride ||
         (int)rec->m_lumaMarginX != gc.p.marginX || (int)rec->m_lumaMarginY != gc.p.marginY || s->m_param->maxCUSize != 64 ||
-        (int)chromaSatd != gc.p.chroma || subme != gc.p.subme || partEnum < 0 || partEnum >= NUM_PU_SIZES || PU_DIMS[partEnum][0] != blockwidth)
+        (int)chromaSatd != gc.p.chroma || subme < 0 || subme > 7 || !((gc.p.coverMask >> subme) & 1) || partEnum < 0 || partEnum >= NUM_PU_SIZES || PU_DIMS[partEnum][0] != blockwidth)
     { gc.noContext.fetch_add(1, std::memory_order_relaxed); return; }
     const int w = blockwidth, h = PU_DIMS[partEnum][1], px = g_zscanToPelX[absPartIdx], py = g_zscanToPelY[absPartIdx];
     if ((w | h | px | py) & 7) { gc.noContext.fetch_add(1, std::memory_order_relaxed); return; }
@@ -974,7 +980,7 @@ void cost_context(const Search* s, const MotionEstimate* me, ReferencePlanes* re
     const int poc = ref_poc(s->m_slice, ref);
     if (poc == -0x7fffffff) { gc.noContext.fetch_add(1, std::memory_order_relaxed); return; }
     int gen = 0;
-    const int slot = cost_slot(frame->m_poc, src, rec, poc, wt, gen, frame->m_encodeOrder, s->m_param->frameNumThreads);
+    const int slot = cost_slot(frame->m_poc, src, rec, poc, wt, gen, frame->m_encodeOrder, s->m_param->frameNumThreads, mvCostQpel);
     if (slot < 0) return;
     const uint8_t* tab = (const uint8_t*)gc.p.tables(gc.p.ctx, slot);
     c.ready = gc.p.ready(gc.p.ctx, slot);
@@ -985,7 +991,6 @@ void cost_context(const Search* s, const MotionEstimate* me, ReferencePlanes* re
     c.gen = gen;
     c.nServed = c.nOther = c.nNotReady = c.nSaturated = c.nTorn = 0;
     c.valid = true;
-    (void)me;
 }
 
 /* one comparison from the records; false = not this seam's */
@@ -1111,7 +1116,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     if (gc.enabled && ctuAddr >= 0 && !srcReferencePlane && !ref->isLowres)
     {
         gc.contexts.fetch_add(1, std::memory_order_relaxed);
-        cost_context(reinterpret_cast<const Search*>(reinterpret_cast<const char*>(this) - offsetof(Search, m_me)), this, ref, ctuAddr, absPartIdx, partEnum, blockwidth, bChromaSATD, subpelRefine);
+        cost_context(reinterpret_cast<const Search*>(reinterpret_cast<const char*>(this) - offsetof(Search, m_me)), gc.useMvCost ? m_cost : NULL, ref, ctuAddr, absPartIdx, partEnum, blockwidth, bChromaSATD, subpelRefine);
     }
     if (gp.on) gp.ctxCyc.fetch_add(__rdtsc() - tctx, std::memory_order_relaxed);
     const int cost = x265ref_orig_motionEstimate(this, ref, &mvmin, &mvmax, &qmvp, numCandidates, mvc, merange, &outQMv, maxSlices, srcReferencePlane);
@@ -1874,29 +1879,32 @@ void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; gs.ena
 
 /* cost-table seam: provider = x265hip_cost_stream_picture_rows / _pair_open / _tables / _ready signatures (NULL pair_open = off); geometry = the PicYuv
  * buffers of the encode about to start; pu_rects = int [npu][4] (x, y, w, h: x265hip_cost_pu_rect), positions = int8 [npos][2] (x265hip_cost_positions),
- * record_bytes / ctu_bytes as the service lays the records out.  flags: 1 = verify every served value against the reference's own function, 2 = wait
- * for records, 4 = ignore the size gate.  Needs the SAD seam's configure first when the size gate is to apply (it decides g_gated). */
+ * record_bytes / ctu_bytes as the service lays the records out, cover_mask bit s = the position set contains every position a --subme s refinement can reach from a record's
+ * vector (the service may hold a LARGER set than the encode's own --subme needs: refinements that start from a fractional predictor then stay inside it more often).  flags: 1 = verify every served value against the reference's own function, 2 = wait
+ * for records, 4 = ignore the size gate, 8 = rank the candidates by SAD alone (no vector-cost table travels with the pairs).  window = the service's (the table covers
+ * displacements of +-window around each CTU's centre).  Needs the SAD seam's configure first when the size gate is to apply (it decides g_gated). */
 int x265ref_cost_seam_configure(void* ctx, void* picture_rows, void* pair_open, void* tables, void* ready, int slots, int width, int height, intptr_t stride, intptr_t stride_c,
                                 int margin_x, int margin_y, int candidates, int subme, int chroma, const int* pu_rects, int npu, const int8_t* positions, int npos,
-                                int record_bytes, size_t ctu_bytes, int flags)
+                                int record_bytes, size_t ctu_bytes, int window, unsigned cover_mask, int flags)
 {
     gc.enabled = false;
     if (!pair_open) return 0;
     if (slots < 1 || slots > MAX_SLOTS || !picture_rows || !tables || !ready || !pu_rects || !positions || npu < 1 || npos < 1 || npos > 169 || candidates < 1 || candidates > 2 ||
-        (width & 63) || (height & 63) || record_bytes < 8 + 2 * npos || ctu_bytes < (size_t)record_bytes * npu * candidates) return -1;
+        (width & 63) || (height & 63) || record_bytes < 8 + 2 * npos || ctu_bytes < (size_t)record_bytes * npu * candidates || window < 0 || window > 32) return -1;
     gc.p.ctx = ctx;
     gc.p.picture_rows = (int (*)(void*, uint64_t, const void*, const void*, const void*, int, int))picture_rows;
-    gc.p.pair_open = (int (*)(void*, int, uint64_t, uint64_t, const void*, unsigned))pair_open;
+    gc.p.pair_open = (int (*)(void*, int, uint64_t, uint64_t, const void*, unsigned, const uint16_t*))pair_open;
+    gc.p.window = window; gc.p.coverMask = cover_mask;
     gc.p.tables = (const void* (*)(void*, int))tables;
     gc.p.ready = (const volatile int* (*)(void*, int))ready;
     gc.p.slots = slots; gc.p.width = width; gc.p.height = height; gc.p.stride = stride; gc.p.strideC = stride_c; gc.p.marginX = margin_x; gc.p.marginY = margin_y;
     gc.p.K = candidates; gc.p.subme = subme; gc.p.chroma = chroma; gc.p.recBytes = record_bytes; gc.p.npos = npos; gc.p.npu = npu; gc.p.ctuBytes = ctu_bytes;
-    memset(gc.posMap, -1, sizeof(gc.posMap));
+    for (int i = 0; i < 13 * 13; i++) gc.posMap[i] = -1;
     for (int i = 0; i < npos; i++)
     {
         const int dx = positions[2 * i] + 6, dy = positions[2 * i + 1] + 6;
         if ((unsigned)dx > 12u || (unsigned)dy > 12u) return -1;
-        gc.posMap[dy * 13 + dx] = (int8_t)i;
+        gc.posMap[dy * 13 + dx] = (int16_t)i;
     }
     memset(gc.puIndex, -1, sizeof(gc.puIndex));
     for (int i = 0; i < npu; i++)
@@ -1907,7 +1915,7 @@ int x265ref_cost_seam_configure(void* ctx, void* picture_rows, void* pair_open, 
     }
     gc.instance++;
     memset(gc.pairs, 0, sizeof(gc.pairs)); memset(gc.fencs, 0, sizeof(gc.fencs));
-    gc.verify = (flags & 1) != 0; gc.wait = (flags & 2) != 0;
+    gc.verify = (flags & 1) != 0; gc.wait = (flags & 2) != 0; gc.useMvCost = (flags & 8) == 0;
     gc.served = 0; gc.otherVector = 0; gc.notReady = 0; gc.saturated = 0; gc.torn = 0; gc.noContext = 0; gc.contexts = 0; gc.pairsOpened = 0; gc.noSlot = 0;
     gc.rowsPublished = 0; gc.rowsRefused = 0; gc.mismatches = 0; gc.weightedPairs = 0;
     gc.epoch.fetch_add(1);

@@ -113,8 +113,8 @@ int EXPORT(x265oracle_cost_positions)(int subme, int8_t* xy)
 }
 
 /* SAD rasters of the 85 squares (int32 [ctu][row][group][85][4], x265hip_me_fullsearch's X265HIP_SURF_I32) -> per PU the K displacements of
- * smallest SAD, ties to the earlier raster position (the full search's scan order and strict '<', motion.cpp:1395-1430) */
-void EXPORT(x265oracle_cost_candidates)(const int32_t* surf, const int16_t* centres, int nctu, int window, int shapes, int K, int16_t* cand)
+ * smallest SAD (+ the optional vector cost of the displacement relative to the window centre, uint16 [2 window + 1] per component), ties to the earlier raster position (the full search's scan order and strict '<', motion.cpp:1395-1430) */
+void EXPORT(x265oracle_cost_candidates)(const int32_t* surf, const int16_t* centres, int nctu, int window, int shapes, int K, int16_t* cand, const uint16_t* mvCost)
 {
     OraclePu pu[209];
     const int npu = pu_list(shapes, pu), nc = 2 * window + 1, ng = (nc + 3) >> 2;
@@ -135,6 +135,7 @@ void EXPORT(x265oracle_cost_candidates)(const int32_t* surf, const int16_t* cent
                             for (int b = 0; b < 3; b++) z |= ((bx >> b) & 1) << (2 * b) | ((by >> b) & 1) << (2 * b + 1);
                             sad += (uint32_t)rec[z * 4];
                         }
+                    if (mvCost) sad += (uint32_t)mvCost[col] + (uint32_t)mvCost[row];          /* the search's own objective: sad + mvcost(mv - predictor), motion.cpp:246-328 */
                     const uint64_t key = (uint64_t)sad << 32 | (uint32_t)(row * nc + col);
                     if (key < b1) { b2 = b1; b1 = key; } else if (key < b2) b2 = key;
                 }

@@ -27,20 +27,20 @@ def picture(planes):
 
 
 def centre_clamp(geo, window, centre_range, chroma_planes=True):
-    """(maxCx, maxCy) of x265hip_cost_stream_create."""
+    """(maxCx, maxCy, maxCyDown) of x265hip_cost_stream_create."""
     mx = geo["margin_x"] - window - 12
     my = (min(geo["margin_y"], 2 * geo["margin_y_c"]) if chroma_planes else geo["margin_y"]) - window - 20
     if centre_range:
         mx, my = min(mx, centre_range), min(my, centre_range)
-    return mx, my
+    return mx, my, min(my, (42 if chroma_planes else 54) - window)
 
 
-def chain(depth, fenc, ref, centre_range, window, shapes, k, subme, chroma):
+def chain(depth, fenc, ref, centre_range, window, shapes, k, subme, chroma, mv_cost=None):
     """fenc / ref: picture() dicts (ref already weighted where the search reads weighted planes).  Returns (centres, cand, tables)."""
     O = oracle()
     g = fenc
     nctu = (g["width"] // 64) * (g["height"] // 64)
-    mcx, mcy = centre_clamp(g, window, centre_range)
+    mcx, mcy, mdown = centre_clamp(g, window, centre_range)
     centres = np.zeros((nctu, 2), np.int16)
     if centre_range:
         zero = np.zeros(2 * centre_range + 1, np.uint16)
@@ -49,7 +49,7 @@ def chain(depth, fenc, ref, centre_range, window, shapes, k, subme, chroma):
         idx = (best.reshape(nctu, 85)[:, 84] & np.uint64(0xffffffff)).astype(np.int64)
         ncb = 2 * centre_range + 1
         centres[:, 0] = np.clip(idx % ncb - centre_range, -mcx, mcx)
-        centres[:, 1] = np.clip(idx // ncb - centre_range, -mcy, mcy)
+        centres[:, 1] = np.clip(idx // ncb - centre_range, -mcy, mdown)
     rb = int(np.abs(centres).max()) + window
     zero = np.zeros(2 * rb + 1, np.uint16)
     big, _ = O.me_fullsearch(depth, fenc["y"], g["stride"], g["org"], ref["y"], g["stride"], g["org"], g["width"], g["height"], rb, 0, nctu, zero, zero,
@@ -62,7 +62,7 @@ def chain(depth, fenc, ref, centre_range, window, shapes, k, subme, chroma):
         r0, c0 = int(centres[c, 1]) - window + rb, int(centres[c, 0]) - window + rb
         surf[c, :, :nc] = big[c, r0:r0 + nc, c0:c0 + nc]
     surf = surf.reshape(nctu, nc, ng, 4, 85).transpose(0, 1, 2, 4, 3)                                        # back to records [ctu][row][group][pu][4]
-    cand = O.cost_candidates(np.ascontiguousarray(surf), centres, nctu, window, shapes, k, depth=depth)
+    cand = O.cost_candidates(np.ascontiguousarray(surf), centres, nctu, window, shapes, k, depth=depth, mv_cost=mv_cost)
     tables = O.cost_tables(depth, [fenc["y"], fenc["cb"], fenc["cr"]], [ref["y"], ref["cb"], ref["cr"]], g["stride"], g["stride_c"], g["margin_x"], g["margin_y"],
                            g["margin_y_c"], g["width"], 0, g["height"] // 64, shapes, k, subme, chroma, cand)
     return centres, cand, tables

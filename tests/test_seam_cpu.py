@@ -471,7 +471,8 @@ def test_hit_rate_gate_closes_the_sad_seam_when_the_windows_are_missed_and_probe
 
 # ---- round 6: the cost-table seam - subpelCompare's SATD comparisons answered as values from the service's records ---------------------------------
 @pytest.mark.reference
-@pytest.mark.parametrize("depth,preset,extra,k,fade,min_share", [(8, "slow", [("me", "star")], 1, None, 0.6), (8, "slower", [], 2, None, 0.8), (10, "slow", [], 1, None, 0.6),
+@pytest.mark.parametrize("depth,preset,extra,k,fade,min_share", [(8, "slow", [("me", "star"), ("set-subme", "4")], 1, None, 0.85), (8, "slow", [("set-subme", "7")], 1, None, 0.85),
+                                                                 (8, "slow", [("me", "star")], 1, None, 0.6), (8, "slower", [], 2, None, 0.8), (10, "slow", [], 1, None, 0.6),
                                                                  (8, "medium", [("subme", "3")], 2, None, 0.5), (8, "slow", [], 2, (1.0, 0.4), 0.08),
                                                                  (8, "veryslow", [("frame-threads", "1")], 1, None, 0.6), (8, "medium", [], 2, None, 0.5)])
 def test_cost_seam_serves_the_refinement_with_the_references_own_values(depth, preset, extra, k, fade, min_share):
@@ -480,11 +481,13 @@ def test_cost_seam_serves_the_refinement_with_the_references_own_values(depth, p
     re-evaluated by the reference's own subpelCompare on the spot (verify: luma_hpp / vpp / hvpp + satd, chroma filters + chroma satd), and the records are
     really used - most of the SATD comparisons of the searches that have a context are served.  Presets: slow (subme 3: 49 positions, chroma SATD,
     rectangles), slower / veryslow (subme 4: 85 positions, AMP), medium (subme 2: luma only) and medium with --subme 3; a fade (weighted references:
-    a pair per weight triple - and the UNWEIGHTED references of a fade, where the smallest SAD is a brightness accident and the host's search, pulled by
+    a pair per weight triple; records with the position set of a higher --subme row than the encode's: a refinement that starts from a fractional predictor stays
+    inside the 85 positions of row 4 far more often than inside row 3's 49 - and the UNWEIGHTED references of a fade, where the smallest SAD is a brightness accident and the host's search, pulled by
     its vector cost, ends elsewhere: few comparisons served, all of them right)."""
     EB, SD = _tools()
-    opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24")] + extra
-    cfg = SD.cost_config(preset, opts, centre_range=20, window=4, candidates=k, slots=40)
+    set_subme = [int(v) for o, v in extra if o == "set-subme"]          # not an encoder option: the records hold a LARGER position set than the encode's --subme needs
+    opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24")] + [(o, v) for o, v in extra if o != "set-subme"]
+    cfg = SD.cost_config(preset, opts, centre_range=20, window=4, candidates=k, slots=40, set_subme=set_subme[0] if set_subme else None)
     base, got, rep = run_pair(depth, 256, 192, 7, preset, opts, "oracle", rng=8, min_pu=128, streamed=True, min_level=1, slots=32, layout=1, centre_range=20, wait=True,
                               cost="oracle", cost_cfg=cfg, fade=fade)
     c = rep["cost_seam"]

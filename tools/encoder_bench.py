@@ -141,7 +141,11 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
                                                           lookahead_min_blocks=seam.get("lookahead_min_blocks"),      # None: the binding's own size gates
                                                           min_ctus=seam.get("min_ctus"), build=build, aq="gpu" if seam.get("aq") else None,
                                                           aq_min_blocks=seam.get("aq_min_blocks"), weight_analyse="gpu" if seam.get("weight_analyse") else None,
-                                                          weight_min_blocks=seam.get("weight_min_blocks"), split_rest=bool(seam.get("split_rest")))
+                                                          weight_min_blocks=seam.get("weight_min_blocks"), split_rest=bool(seam.get("split_rest")),
+                                                          cost="gpu" if seam.get("cost") else None,
+                                                          cost_cfg=SD.cost_config(cfg["preset"], opts, centre_range=seam.get("cost_centre_range", 57), window=seam.get("cost_window", 8),
+                                                                                  candidates=seam.get("cost_candidates", 1), slots=seam.get("cost_slots", 24),
+                                                                                  pictures=seam.get("cost_pictures", 40), views=seam.get("cost_views", 12), set_subme=seam.get("cost_set_subme")) if seam.get("cost") else None)
         t0, c0 = time.perf_counter(), time.process_time()
         md5, nbytes, sec, filled = encode(enc_lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
         wall, cpu = time.perf_counter() - t0, time.process_time() - c0
@@ -204,6 +208,13 @@ def main():
     ap.add_argument("--seam-no-weighted", action="store_true", help="weighted references pass to the host (the round-3 behaviour), for A/B on a fade")
     ap.add_argument("--plan", default="", help="bench.py's child-process mode: a JSON list of legs {name, key, tables, frames, frame_threads, seam, build}; the other options are ignored")
     ap.add_argument("--out", default="", help="--plan: write {\"encoder\": {name: result}} to this file after EVERY leg (what is there survives a crash or a timeout of a later leg)")
+    ap.add_argument("--seam-cost", action="store_true",
+                    help="also answer MotionEstimate::subpelCompare's SATD comparisons from x265hip_cost_stream's records (sub-sample costs around each PU's best integer vectors)")
+    ap.add_argument("--seam-cost-candidates", type=int, default=1, help="cost tables: integer vectors per PU (1 or 2)")
+    ap.add_argument("--seam-cost-set-subme", type=int, default=0, help="cost tables: hold the position set of this --subme row when it is larger than the encode's own (4: 85 positions)")
+    ap.add_argument("--seam-cost-window", type=int, default=8, help="cost tables: the candidates are the smallest SADs within +-this of each CTU's own displacement")
+    ap.add_argument("--seam-cost-slots", type=int, default=24, help="cost tables: (picture, reference) pairs resident in pinned host memory (37 MB each at 4K preset slow)")
+    ap.add_argument("--seam-cost-views", type=int, default=12, help="cost tables: reference views (phase planes, 450 MB each at 4K 8-bit) resident on the device")
     ap.add_argument("--seam-subpel-slots", type=int, default=6, help="reference pictures whose phase planes stay in pinned host memory (450 MB each at 4K 8-bit)")
     args = ap.parse_args()
     if args.plan:
@@ -224,7 +235,9 @@ def main():
     seam = {"range": args.seam_range, "slots": args.seam_slots, "min_pu": args.seam_min_pu, "verify": args.seam_verify, "lookahead": args.seam_lookahead,
             "subpel": args.seam_subpel, "subpel_slots": args.seam_subpel_slots, "streamed": args.seam_streamed, "min_level": args.seam_min_level,
             "pictures": args.seam_pictures, "band_rows": args.seam_band_rows, "no_sad": args.seam_no_sad, "weighted": not args.seam_no_weighted,
-            "layout": 1 if args.seam_layout == "planes" else 0, "centre_range": args.seam_centre_range, "aq": args.seam_aq, "weight_analyse": args.seam_weight_analyse, "split_rest": args.seam_split_rest}
+            "layout": 1 if args.seam_layout == "planes" else 0, "centre_range": args.seam_centre_range, "aq": args.seam_aq, "weight_analyse": args.seam_weight_analyse, "split_rest": args.seam_split_rest,
+            "cost": args.seam_cost, "cost_candidates": args.seam_cost_candidates, "cost_window": args.seam_cost_window, "cost_slots": args.seam_cost_slots, "cost_views": args.seam_cost_views,
+            "cost_centre_range": args.seam_centre_range or 57, "cost_set_subme": args.seam_cost_set_subme or None}
     out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s, seam=seam, build=args.ref_build) for k in args.configs.split(",")}
     print(json.dumps({"encoder": out}))
 

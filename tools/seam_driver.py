@@ -646,7 +646,7 @@ class StreamGpuPhaseProvider:
 # ---------------------------------------------------------------------------------------------------------------------------------
 # COST-TABLE providers (round 6): x265hip_cost_stream and its CPU stand-in - the sub-sample half of motionEstimate served as values.
 CS_ROWS = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
-CS_OPEN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint)
+CS_OPEN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p)
 CS_TABLES = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
 CS_READY = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
 COST_STAT_NAMES = ("comparisons_served_from_records", "passed_on_other_vector_or_position", "passed_on_records_not_arrived", "passed_on_saturated_delta", "dropped_slot_reopened",
@@ -656,7 +656,7 @@ PRESET_SUBME = {"ultrafast": 0, "superfast": 1, "veryfast": 1, "faster": 2, "fas
 PRESET_SHAPES = {"slow": 1, "slower": 2, "veryslow": 2, "placebo": 2}                                                                                             # --rect from slow, --amp from slower
 
 
-def cost_config(preset, opts, centre_range=57, window=8, candidates=1, slots=24, pictures=40, views=12, band_rows=8):
+def cost_config(preset, opts, centre_range=57, window=8, candidates=1, slots=24, pictures=40, views=12, band_rows=8, mv_cost=True, set_subme=None):
     """The cost-table service's parameters for an encode: the refinement's position set and the chroma flag follow --subme (bChromaSATD: subme > 2,
     motion.cpp:212), the PU list follows --rect / --amp."""
     o = dict((k, v) for k, v in opts)
@@ -666,8 +666,10 @@ def cost_config(preset, opts, centre_range=57, window=8, candidates=1, slots=24,
     if "amp" in o: shapes = 2
     if "no-rect" in o: shapes = 0
     elif "no-amp" in o: shapes = min(shapes, 1)
-    return dict(centre_range=centre_range, window=window, candidates=candidates, shapes=shapes, subme=subme, chroma=int(subme > 2), slots=slots, pictures=pictures, views=views,
-                band_rows=band_rows)
+    # set_subme: the records may hold the position set of a HIGHER workload row than the encode's (a superset: refinements that start from a fractional predictor
+    # leave the --subme 3 set of 49 positions more often than --subme 4's 85); the chroma flag stays the encode's
+    return dict(centre_range=centre_range, window=window, candidates=candidates, shapes=shapes, subme=max(subme, set_subme or 0), host_subme=subme, chroma=int(subme > 2), slots=slots, pictures=pictures, views=views,
+                band_rows=band_rows, mv_cost=bool(mv_cost))
 
 
 class StreamGpuCostProvider:
@@ -735,6 +737,7 @@ class StreamOracleCostProvider:
         mx = g["margin_x"] - cfg["window"] - 12
         my = min(g["margin_y"], 2 * (g["margin_y"] >> 1)) - cfg["window"] - 20
         self.max_c = (min(mx, cfg["centre_range"]), min(my, cfg["centre_range"])) if cfg["centre_range"] else (mx, my)
+        self.max_down = min(self.max_c[1], 42 - cfg["window"])          # a row is computed from reference rows <= r + 1: x265hip_cost_stream_create
         self.lock = threading.Lock()
         self._cb = (CS_ROWS(self._rows), CS_OPEN(self._open), CS_TABLES(self._tables), CS_READY(self._ready))
 
@@ -764,12 +767,14 @@ class StreamOracleCostProvider:
             self._advance()
         return 0
 
-    def _open(self, ctx, slot, fkey, rkey, wptr, mask):
+    def _open(self, ctx, slot, fkey, rkey, wptr, mask, cptr):
         with self.lock:
             self.gen[slot] += 1
             self.flags[slot][:] = 0
             w3 = read_weights(wptr, 3) if wptr and mask else [None] * 3
-            self.pair[slot] = {"fkey": int(fkey), "rkey": int(rkey), "w": [w3[c] if (mask >> c) & 1 else None for c in range(3)], "next": 0}
+            n = 2 * self.cfg["window"] + 1
+            mvc = np.frombuffer((ctypes.c_uint16 * n).from_address(cptr), dtype=np.uint16).copy() if cptr else None
+            self.pair[slot] = {"fkey": int(fkey), "rkey": int(rkey), "w": [w3[c] if (mask >> c) & 1 else None for c in range(3)], "next": 0, "mv_cost": mvc}
             self.opened += 1
             self.weighted += bool(wptr and mask)
             self._pic(int(fkey)); self._pic(int(rkey))
@@ -783,7 +788,7 @@ class StreamOracleCostProvider:
                 continue
             pf, rf = self.pics[pr["fkey"]], self.pics[pr["rkey"]]
             r1 = pr["next"] - 1
-            while r1 + 1 < self.ctu_rows and pf["next"] > r1 + 1 and rf["next"] >= min(self.ctu_rows, r1 + 4):
+            while r1 + 1 < self.ctu_rows and pf["next"] > r1 + 1 and rf["next"] >= min(self.ctu_rows, r1 + 3):
                 r1 += 1
             if r1 < pr["next"]:
                 continue
@@ -799,7 +804,7 @@ class StreamOracleCostProvider:
                 idx = (best.reshape(self.nctu, 85)[b:e, 84] & np.uint64(0xffffffff)).astype(np.int64)
                 ncb = 2 * c["centre_range"] + 1
                 centres[b:e, 0] = np.clip(idx % ncb - c["centre_range"], -self.max_c[0], self.max_c[0])
-                centres[b:e, 1] = np.clip(idx // ncb - c["centre_range"], -self.max_c[1], self.max_c[1])
+                centres[b:e, 1] = np.clip(idx // ncb - c["centre_range"], -self.max_c[1], self.max_down)
             w = c["window"]
             rb = int(np.abs(centres[b:e]).max()) + w
             zero = np.zeros(2 * rb + 1, np.uint16)
@@ -812,7 +817,7 @@ class StreamOracleCostProvider:
                 y0, x0 = int(centres[b + i, 1]) - w + rb, int(centres[b + i, 0]) - w + rb
                 surf[i, :, :nc] = big[i, y0:y0 + nc, x0:x0 + nc]
             surf = np.ascontiguousarray(surf.reshape(e - b, nc, ng, 4, 85).transpose(0, 1, 2, 4, 3))
-            cand = O.cost_candidates(surf, centres[b:e], e - b, w, c["shapes"], c["candidates"], depth=self.depth)
+            cand = O.cost_candidates(surf, centres[b:e], e - b, w, c["shapes"], c["candidates"], depth=self.depth, mv_cost=pr["mv_cost"])
             tab = O.cost_tables(self.depth, [pf["src"][0], pf["src"][1], pf["src"][2]], ref, g["stride"], g["stride_c"], g["margin_x"], g["margin_y"], g["margin_y"] >> 1,
                                 g["width"], r0, r1 - r0 + 1, c["shapes"], c["candidates"], c["subme"], c["chroma"], cand)
             self.tables[slot][b * self.ctu_bytes:e * self.ctu_bytes] = tab.reshape(-1)
@@ -1057,7 +1062,7 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     # the cost-table seam (MotionEstimate::subpelCompare's SATD comparisons answered from x265hip_cost_stream's records): "gpu" = the service, "oracle" = CPU checker;
     # cost_cfg = cost_config(preset, opts, ...) - the position set and the chroma flag must be the encode's --subme
     lib.x265ref_cost_seam_configure.argtypes = ([ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_ssize_t] * 2 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                                                ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int])
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint, ctypes.c_int])
     lib.x265ref_cost_seam_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     cst = None
     if cost:
@@ -1066,13 +1071,18 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
         cctx, crows, copen, ctab, crdy = cst.pointers()
         rects = np.ascontiguousarray(cst.rects, np.int32)
         posn = np.ascontiguousarray(cst.positions, np.int8)
+        import sys as _sys
+        _sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_api as _O                     # the position lists only (host arithmetic); the GPU provider's own list is what the records are laid out by
+        have = {tuple(p) for p in posn.tolist()}
+        cover = sum(1 << sm for sm in range(8) if {tuple(p) for p in _O.cost_positions(sm).tolist()} <= have)
         rc = lib.x265ref_cost_seam_configure(cctx, crows, copen, ctab, crdy, cfg["slots"], geo["width"], geo["height"], geo["stride"], geo["stride_c"], geo["margin_x"], geo["margin_y"],
                                              cfg["candidates"], cfg["subme"], cfg["chroma"], rects.ctypes.data, len(rects), posn.ctypes.data, len(posn), cst.record_bytes, cst.ctu_bytes,
-                                             int(bool(verify)) | (2 if wait else 0) | (4 if min_ctus == 0 else 0))
+                                             cfg["window"], cover, int(bool(verify)) | (2 if wait else 0) | (4 if min_ctus == 0 else 0) | (0 if cfg.get("mv_cost", True) else 8))
         if rc:
             raise RuntimeError(f"x265ref_cost_seam_configure failed ({rc})")
     else:
-        lib.x265ref_cost_seam_configure(None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, 0, 0, 0, 0)
+        lib.x265ref_cost_seam_configure(None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, 0, 0, 0, 0, 0, 0)
 
     def report():
         d = stats(lib)

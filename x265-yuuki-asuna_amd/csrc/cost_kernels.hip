@@ -7,7 +7,7 @@
 //                             reference's pu[LUMA_64x32].sad returns on the same samples).  One wavefront per PU walks the raster,
 //                             64 displacements per step; the two smallest (sad << 32 | raster index) keys survive a shuffle reduction:
 //                             ties resolve to the smaller raster index, the reference's scan order with its strict '<'.
-//   x265hip_cost_tables       per (CTU, PU, candidate) one wavefront: for every position of the refinement's position set the SATD of the
+//   x265hip_cost_tables       (cost_tables_kernel; the shared-tile kernel below runs first) per (CTU, PU, candidate) one wavefront: for every position of the refinement's position set the SATD of the
 //                             source block against the block of the reference's fractional-phase plane the position selects
 //                             (x265hip_phase_planes holds exactly the samples luma_hpp / luma_vpp / luma_hvpp and the chroma filter_hpp /
 //                             filter_vpp / filter_hps + filter_vsp calls of subpelCompare would write), luma or luma + Cb + Cr.
@@ -20,13 +20,14 @@
 // (10 covering shapes with the rectangles), served by L2; the algorithmic bytes are the planes' CTU neighbourhoods + the records.
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
 
 namespace x265hip {
 
-enum { COST_MAX_PU = 209, COST_MAX_POS = 169, COST_MAX_PARTS = 8 };
+enum { COST_MAX_PU = 209, COST_MAX_POS = 169, COST_MAX_PARTS = 8, COST_WAVES_PER_CTU = 16 };
 
 struct CostPu { uint8_t x, y, w, h; uint8_t nparts; uint8_t part[COST_MAX_PARTS]; uint8_t pad[3]; };   // samples inside the CTU (w, h <= 64); parts = indices into the 85 squares
 
@@ -97,7 +98,7 @@ const PuList& pu_list()
 
 int pu_count(int shapes) { return shapes <= 0 ? 85 : shapes == 1 ? 169 : 209; }
 
-struct PosSet { int n, radius; int8_t xy[COST_MAX_POS][2]; int8_t map[13 * 13]; };
+struct PosSet { int n, radius; int8_t xy[COST_MAX_POS][2]; int16_t map[13 * 13]; };
 
 // the quarter-sample offsets a refinement of SubpelWorkload row `subme` (motion.cpp:48-58) can measure from its start vector: hpel_iters
 // rounds of square1[1 .. hpel_dirs] * 2 (each round moves to the best neighbour, :1518-1537), then qpel_iters rounds of square1[1 .. qpel_dirs]
@@ -134,7 +135,7 @@ bool positions(int subme, PosSet& P)
             P.map[y * 13 + x] = -1;
             if (!seen[y][x]) continue;
             if (P.n >= COST_MAX_POS) return false;
-            P.map[y * 13 + x] = (int8_t)P.n;
+            P.map[y * 13 + x] = (int16_t)P.n;
             P.xy[P.n][0] = (int8_t)(x - 6); P.xy[P.n][1] = (int8_t)(y - 6);
             const int r = abs(x - 6) > abs(y - 6) ? abs(x - 6) : abs(y - 6);
             if (r > P.radius) P.radius = r;
@@ -150,7 +151,7 @@ __constant__ CostPu kCostPu[COST_MAX_PU];
 
 struct CandArgs
 {
-    const int32_t* surf; const int16_t* centres; int16_t* cand;
+    const int32_t* surf; const int16_t* centres; int16_t* cand; const uint16_t* mvCost;
     int window, npu, K;
 };
 
@@ -171,6 +172,7 @@ __global__ void __launch_bounds__(256) cost_cand_kernel(CandArgs a)
             const int32_t* rec = base + ((size_t)(row * ng + (col >> 2)) * 85) * 4 + (col & 3);
             uint32_t sad = 0;
             for (int i = 0; i < P.nparts; i++) sad += (uint32_t)rec[P.part[i] * 4];
+            if (a.mvCost) sad += (uint32_t)a.mvCost[col] + (uint32_t)a.mvCost[row];
             const unsigned long long key = (unsigned long long)sad << 32 | (uint32_t)d;
             if (key < b1) { b2 = b1; b1 = key; } else if (key < b2) b2 = key;
         }
@@ -249,21 +251,27 @@ __device__ __forceinline__ int satd_tile(const uint8_t* f, long fStride, const u
 
 // one wavefront per (CTU of the band, PU, candidate)
 template <typename Px, bool CHROMA>
-__global__ void __launch_bounds__(64) cost_tables_kernel(TableArgs a)
+__global__ void __launch_bounds__(64) cost_tables_kernel(TableArgs a, const uint8_t* __restrict__ ctuFlags)
 {
     constexpr int BPP = sizeof(Px);
     __shared__ uint32_t acc[COST_MAX_POS];
     const int lane = threadIdx.x;
-    const int b = blockIdx.x, k = b % a.K, pu = (b / a.K) % a.npu, ctuB = b / (a.K * a.npu);
+    // COST_WAVES_PER_CTU single-wavefront workgroups per CTU, each walks the CTU's (PU, candidate) pairs with that stride: few enough workgroups that a launch in which
+    // the shared-tile kernel served (nearly) every CTU costs next to nothing, enough of them to fill the chip when it served none
+    const int ctuB = blockIdx.x / COST_WAVES_PER_CTU;
+    if (ctuFlags && !ctuFlags[ctuB]) return;                 // the shared-tile kernel wrote this CTU's records
     const int ctuX = ctuB % a.ctusW, ctuY = a.ctuRow0 + ctuB / a.ctusW;
-    const size_t recIdx = (size_t)(ctuB * a.npu + pu) * a.K + k;
+    for (int pc = blockIdx.x % COST_WAVES_PER_CTU; pc < a.npu * a.K; pc += COST_WAVES_PER_CTU)
+    {
+    const int pu = pc / a.K;
+    const size_t recIdx = (size_t)ctuB * a.npu * a.K + pc;
     uint8_t* rec = a.tables + recIdx * a.recBytes;
     const int mvx = a.cand[recIdx * 2], mvy = a.cand[recIdx * 2 + 1];
     if (mvx == -32768)
     {
         // "no record": the vector field says so, the rest of the record is zero
         for (int i = lane; i < a.recBytes / 4; i += 64) reinterpret_cast<uint32_t*>(rec)[i] = i ? 0u : 0x00008000u;
-        return;
+        continue;
     }
     for (int i = lane; i < a.npos; i += 64) acc[i] = 0;
     __syncthreads();
@@ -323,6 +331,129 @@ __global__ void __launch_bounds__(64) cost_tables_kernel(TableArgs a)
     }
     uint16_t* delta = reinterpret_cast<uint16_t*>(rec + 8);
     for (int i = lane; i < a.npos; i += 64) delta[i] = (uint16_t)min(acc[i] - lo, 65535u);
+    __syncthreads();                                         // acc is zeroed again for the next pair
+    }
+}
+
+// The same records with the tile work SHARED between the PUs of a CTU (round 6, after the first encoder measurements: the service was late for a fifth of the
+// comparisons at 4K preset slow - 12 - 21 ms of launches per pair).  Every listed PU is a union of 8x8 luma blocks, and in the content the service is built for most PUs of
+// a CTU sit on the same one or two vectors: per DISTINCT candidate vector of the CTU the workgroup fills one map [64 blocks][positions] of block costs (the block's four
+// luma tiles + its Cb and Cr tile, one lane per (tile, block, position) item, LDS atomics), then one wavefront per PU sums its blocks position by position - a tile is
+// evaluated once per vector instead of once per PU that covers it (10 covering shapes with the rectangles).  CTUs with more distinct vectors than `maxDistinct` are
+// flagged and left to cost_tables_kernel (a tile evaluated per PU is then the cheaper way).
+enum { COST_MAX_DISTINCT = 40 };
+template <typename Px, bool CHROMA>
+__global__ void __launch_bounds__(256) cost_tables_shared_kernel(TableArgs a, uint8_t* __restrict__ ctuFlags, int maxDistinct)
+{
+    constexpr int BPP = sizeof(Px), TPB = CHROMA ? 6 : 4;
+    __shared__ int16_t sCand[COST_MAX_PU * 2][2];
+    __shared__ int16_t sVec[COST_MAX_DISTINCT + 1][2];
+    __shared__ uint16_t sIdx[COST_MAX_PU * 2];
+    __shared__ int sNd;
+    extern __shared__ uint32_t sMap[];                       // [64 blocks][npos]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ctuB = blockIdx.x, n = a.npu * a.K, npos = a.npos;
+    const int ctuX = ctuB % a.ctusW, ctuY = a.ctuRow0 + ctuB / a.ctusW;
+    for (int i = tid; i < n; i += 256)
+    {
+        sCand[i][0] = a.cand[((size_t)ctuB * n + i) * 2];
+        sCand[i][1] = a.cand[((size_t)ctuB * n + i) * 2 + 1];
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        int nd = 0;
+        for (int i = 0; i < n && nd <= maxDistinct; i++)
+        {
+            const int x = sCand[i][0], y = sCand[i][1];
+            if (x == -32768) { sIdx[i] = 0xffff; continue; }
+            int k = 0;
+            while (k < nd && (sVec[k][0] != x || sVec[k][1] != y)) k++;
+            if (k == nd) { sVec[nd][0] = (int16_t)x; sVec[nd][1] = (int16_t)y; nd++; }
+            sIdx[i] = (uint16_t)k;
+        }
+        sNd = nd;
+        ctuFlags[ctuB] = nd > maxDistinct ? 1 : 0;
+    }
+    __syncthreads();
+    const int nd = sNd;
+    if (nd > maxDistinct) return;
+    for (int i = tid; i < n; i += 256)
+        if (sIdx[i] == 0xffff)
+        {
+            uint32_t* rec = reinterpret_cast<uint32_t*>(a.tables + ((size_t)ctuB * n + i) * a.recBytes);
+            for (int w = 0; w < a.recBytes / 4; w++) rec[w] = w ? 0u : 0x00008000u;
+        }
+    const int X0 = ctuX * 64, Y0 = ctuY * 64;
+    for (int d = 0; d < nd; d++)
+    {
+        for (int i = tid; i < 64 * npos; i += 256) sMap[i] = 0;
+        __syncthreads();
+        const int mvx = sVec[d][0], mvy = sVec[d][1];
+        const int items = npos * 64 * TPB;
+        for (int i = tid; i < items; i += 256)
+        {
+            const int rest = i / npos, pos = i - rest * npos, block = rest & 63, tile = rest >> 6;
+            const int bx = block & 7, by = block >> 3;
+            const int qx = mvx * 4 + a.pos[pos][0], qy = mvy * 4 + a.pos[pos][1];
+            int v;
+            if (tile < 4)
+            {
+                const int X = X0 + bx * 8 + (tile & 1) * 4, Y = Y0 + by * 8 + (tile >> 1) * 4;
+                const int ph = (qy & 3) * 4 + (qx & 3);
+                const uint8_t* src = ph ? a.phases[0] + (size_t)(ph - 1) * a.planeBytes : a.ref[0];
+                const uint8_t* f = a.fenc[0] + (long)(a.marginY + Y) * a.strideB + (long)(a.marginX + X) * BPP;
+                const uint8_t* r = src + (long)(a.marginY + Y + (qy >> 2)) * a.strideB + (long)(a.marginX + X + (qx >> 2)) * BPP;
+                v = satd_tile<Px>(f, a.strideB, r, a.strideB);
+            }
+            else
+            {
+                const int comp = tile - 3;
+                const int X = (X0 >> 1) + bx * 4, Y = (Y0 >> 1) + by * 4;
+                const int ph = (qy & 7) * 8 + (qx & 7);
+                const uint8_t* src = ph ? a.phases[comp] + (size_t)(ph - 1) * a.planeBytesC : a.ref[comp];
+                const uint8_t* f = a.fenc[comp] + (long)(a.marginYC + Y) * a.strideCB + (long)(a.marginX + X) * BPP;
+                const uint8_t* r = src + (long)(a.marginYC + Y + (qy >> 3)) * a.strideCB + (long)(a.marginX + X + (qx >> 3)) * BPP;
+                v = satd_tile<Px>(f, a.strideCB, r, a.strideCB);
+            }
+            atomicAdd(&sMap[block * npos + pos], (uint32_t)v);
+        }
+        __syncthreads();
+        for (int pc = wave; pc < n; pc += 4)
+        {
+            if (sIdx[pc] != d) continue;
+            const CostPu& P = kCostPu[pc / a.K];
+            const int bx0 = P.x >> 3, by0 = P.y >> 3, bw = P.w >> 3, bh = P.h >> 3;
+            uint32_t c[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu };
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+            {
+                const int pos = j * 64 + lane;
+                if (pos >= npos) continue;
+                uint32_t sum = 0;
+                for (int y = 0; y < bh; y++)
+                    for (int x = 0; x < bw; x++) sum += sMap[((by0 + y) * 8 + bx0 + x) * npos + pos];
+                c[j] = sum;
+            }
+            uint32_t lo = min(c[0], min(c[1], c[2]));
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, m, 64));
+            uint8_t* rec = a.tables + ((size_t)ctuB * n + pc) * a.recBytes;
+            if (lane == 0)
+            {
+                reinterpret_cast<int16_t*>(rec)[0] = (int16_t)mvx; reinterpret_cast<int16_t*>(rec)[1] = (int16_t)mvy;
+                reinterpret_cast<uint32_t*>(rec)[1] = lo;
+            }
+            uint16_t* delta = reinterpret_cast<uint16_t*>(rec + 8);
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+            {
+                const int pos = j * 64 + lane;
+                if (pos < npos) delta[pos] = (uint16_t)min(c[j] - lo, 65535u);
+            }
+        }
+        __syncthreads();
+    }
 }
 
 namespace {
@@ -387,7 +518,7 @@ int x265hip_cost_candidates(const x265hip_cost_candidates_params* p, void* strea
     int rc = ensure_device();
     if (rc) return rc;
     if ((rc = upload_pu_list())) return rc;
-    CandArgs a = { p->surf, p->centres, p->cand, p->window, pu_count(p->shapes), p->candidates };
+    CandArgs a = { p->surf, p->centres, p->cand, p->mv_cost, p->window, pu_count(p->shapes), p->candidates };
     hipLaunchKernelGGL(cost_cand_kernel, dim3(p->nctu), dim3(256), 0, (hipStream_t)stream, a);
     return check_hip(hipGetLastError(), "cost_candidates launch");
 }
@@ -418,12 +549,30 @@ int x265hip_cost_tables(const x265hip_cost_tables_params* p, void* stream)
     a.recBytes = (8 + 2 * P.n + 3) & ~3; a.maxVal = (1 << p->depth) - 1;
     a.cand = p->cand; a.tables = (uint8_t*)p->tables;
     memcpy(a.pos, P.xy, sizeof(a.pos));
-    const size_t blocks = (size_t)p->ctu_rows * a.ctusW * a.npu * a.K;
+    const size_t blocks = (size_t)p->ctu_rows * a.ctusW * COST_WAVES_PER_CTU;
     if (blocks > 0x7fffffffull) { set_error("cost_tables: band too large"); return X265HIP_EINVAL; }
-    const dim3 grid((unsigned)blocks), block(64);
     hipStream_t s = (hipStream_t)stream;
-    if (bpp == 1) { if (p->chroma) hipLaunchKernelGGL((cost_tables_kernel<uint8_t, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((cost_tables_kernel<uint8_t, false>), grid, block, 0, s, a); }
-    else          { if (p->chroma) hipLaunchKernelGGL((cost_tables_kernel<uint16_t, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((cost_tables_kernel<uint16_t, false>), grid, block, 0, s, a); }
+    // X265HIP_COST_SHARED=0: the per-PU kernel alone (A/B, tests of both routes); otherwise the shared-tile kernel first, then the per-PU kernel for the CTUs it flagged
+    static const int shared = getenv("X265HIP_COST_SHARED") ? atoi(getenv("X265HIP_COST_SHARED")) : 1;
+    const int nctuBand = p->ctu_rows * a.ctusW;
+    uint8_t* flags = nullptr;
+    std::unique_lock<std::mutex> seq;
+    if (shared)
+    {
+        seq = stream_sequence_lock(s);                        // the flags live in the stream's scratch: written and read by this launch pair
+        flags = (uint8_t*)stream_scratch(s, 5, (size_t)nctuBand);
+        if (!flags) { set_error("cost_tables: no scratch for %d CTU flags", nctuBand); return X265HIP_ENODEV; }
+        const int maxDistinct = shared > 1 ? shared : (a.K == 1 ? 10 : 20);       // break-even: a tile evaluated once per vector against once per covering PU
+        const size_t lds = (size_t)64 * P.n * sizeof(uint32_t);
+        const dim3 g2((unsigned)nctuBand), b2(256);
+        const int md = maxDistinct > COST_MAX_DISTINCT ? COST_MAX_DISTINCT : maxDistinct;
+        if (bpp == 1) { if (p->chroma) hipLaunchKernelGGL((cost_tables_shared_kernel<uint8_t, true>), g2, b2, lds, s, a, flags, md); else hipLaunchKernelGGL((cost_tables_shared_kernel<uint8_t, false>), g2, b2, lds, s, a, flags, md); }
+        else          { if (p->chroma) hipLaunchKernelGGL((cost_tables_shared_kernel<uint16_t, true>), g2, b2, lds, s, a, flags, md); else hipLaunchKernelGGL((cost_tables_shared_kernel<uint16_t, false>), g2, b2, lds, s, a, flags, md); }
+        X265HIP_TRY(hipGetLastError());
+    }
+    const dim3 grid((unsigned)blocks), block(64);
+    if (bpp == 1) { if (p->chroma) hipLaunchKernelGGL((cost_tables_kernel<uint8_t, true>), grid, block, 0, s, a, (const uint8_t*)flags); else hipLaunchKernelGGL((cost_tables_kernel<uint8_t, false>), grid, block, 0, s, a, (const uint8_t*)flags); }
+    else          { if (p->chroma) hipLaunchKernelGGL((cost_tables_kernel<uint16_t, true>), grid, block, 0, s, a, (const uint8_t*)flags); else hipLaunchKernelGGL((cost_tables_kernel<uint16_t, false>), grid, block, 0, s, a, (const uint8_t*)flags); }
     return check_hip(hipGetLastError(), "cost_tables launch");
 }
 

@@ -49,8 +49,9 @@ __global__ void __launch_bounds__(256) cs_weight_lines_kernel(const uint32_t* __
     }
 }
 
-// centre of every CTU's window = the displacement of its 64x64 block's minimum SAD in the +-big search, clamped to +-maxX / +-maxY
-__global__ void cs_centre_kernel(const unsigned long long* __restrict__ best, int16_t* __restrict__ centres, int nctu, int big, int maxX, int maxY)
+// centre of every CTU's window = the displacement of its 64x64 block's minimum SAD in the +-big search, clamped to +-maxX / [-maxY, maxYDown] (downwards the
+// candidates must stay inside the reference rows that exist when the row is computed)
+__global__ void cs_centre_kernel(const unsigned long long* __restrict__ best, int16_t* __restrict__ centres, int nctu, int big, int maxX, int maxY, int maxYDown)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nctu) return;
@@ -58,7 +59,7 @@ __global__ void cs_centre_kernel(const unsigned long long* __restrict__ best, in
     const int ncb = 2 * big + 1;
     const int mx = (int)(idx % ncb) - big, my = (int)(idx / ncb) - big;
     centres[2 * i] = (int16_t)clip3(-maxX, maxX, mx);
-    centres[2 * i + 1] = (int16_t)clip3(-maxY, maxY, my);
+    centres[2 * i + 1] = (int16_t)clip3(-maxY, maxYDown, my);
 }
 
 double cs_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -68,7 +69,7 @@ double cs_now_us() { return std::chrono::duration<double, std::micro>(std::chron
 struct x265hip_cost_stream
 {
     x265hip_cost_stream_params prm;
-    int bpp, device, ctusW, ctuRows, nplanes, bandRows, npu, recBytes, maxCx, maxCy;
+    int bpp, device, ctusW, ctuRows, nplanes, bandRows, npu, recBytes, maxCx, maxCy, maxCyDown;
     size_t planeBytes[2], pitch[2], ctuBytes, rowBytes;
     int rows[2], margin[2], ctuLines[2], nph[2];
     hipStream_t stream = nullptr;
@@ -96,6 +97,8 @@ struct x265hip_cost_stream
         int generation = 0;
         int fenc = -1, view = -1; uint32_t fencEpoch = 0; uint64_t viewStamp = 0;
         int nextRow = 0; bool active = false;
+        int bandLimit = 1;                                      // rows of the pair's next band: 1, 2, 4 ... band_rows - the first rows of EVERY open pair land before anybody's last ones
+        uint16_t* hMvCost = nullptr; uint16_t* dMvCost = nullptr; bool hasCost = false;      // the pair's vector-cost table (pinned staging, device copy); !hasCost: rank by SAD alone
     };
     std::vector<Pic> pics;
     std::vector<View> views;
@@ -125,7 +128,7 @@ inline void cs_lines(const CS* s, int k, int r0, int n, int& y0, int& y1)
 
 struct Upload { int pic, r0, r1; };
 struct ViewJob { int view, pic, r0, r1; int done[2]; unsigned mask; x265hip_weight w[3]; };
-struct Band { int slot, gen, r0, r1, fenc, view; };
+struct Band { int slot, gen, r0, r1, fenc, view; bool hasCost; };
 
 int run_round(CS* s, const std::vector<Upload>& ups, const std::vector<ViewJob>& jobs, const std::vector<Band>& bands)
 {
@@ -195,7 +198,7 @@ int run_round(CS* s, const std::vector<Upload>& ups, const std::vector<ViewJob>&
             p.range = s->prm.centre_range; p.best = (uint64_t*)s->dBest; p.cost_x = p.cost_y = s->dZeroCost;
             if ((rc = x265hip_me_fullsearch(&p, s->stream))) return rc;
             hipLaunchKernelGGL(cs_centre_kernel, dim3((nctuBand + 63) / 64), dim3(64), 0, s->stream, (const unsigned long long*)s->dBest, s->dCentres, nctuBand,
-                               s->prm.centre_range, s->maxCx, s->maxCy);
+                               s->prm.centre_range, s->maxCx, s->maxCy, s->maxCyDown);
             X265HIP_TRY(hipGetLastError());
             p.best = nullptr; p.cost_x = p.cost_y = nullptr;
         }
@@ -204,7 +207,14 @@ int run_round(CS* s, const std::vector<Upload>& ups, const std::vector<ViewJob>&
         p.centres = s->dCentres;
         p.range = s->prm.window; p.surf_format = X265HIP_SURF_I32; p.surf = (int32_t*)s->dSurf;
         if ((rc = x265hip_me_fullsearch(&p, s->stream))) return rc;
-        x265hip_cost_candidates_params c = { nctuBand, s->prm.window, (const int32_t*)s->dSurf, s->dCentres, s->prm.shapes, s->prm.candidates, s->dCand };
+        const uint16_t* mvCost = nullptr;
+        if (b.hasCost)
+        {
+            // a slot reopened under this copy belongs to a stale generation: its band is discarded below
+            X265HIP_TRY(hipMemcpyAsync(sl.dMvCost, sl.hMvCost, (2 * (size_t)s->prm.window + 1) * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
+            mvCost = sl.dMvCost;
+        }
+        x265hip_cost_candidates_params c = { nctuBand, s->prm.window, (const int32_t*)s->dSurf, s->dCentres, s->prm.shapes, s->prm.candidates, s->dCand, mvCost };
         if ((rc = x265hip_cost_candidates(&c, s->stream))) return rc;
         x265hip_cost_tables_params t;
         memset(&t, 0, sizeof(t));
@@ -294,17 +304,18 @@ void cs_worker(CS* s)
                     (v.rowsSeen < s->ctuRows && (!s->pics[v.pic].used || s->pics[v.pic].epoch != v.picEpoch)))
                 { sl.active = false; s->stalePairs++; continue; }
                 int r1 = sl.nextRow - 1;
-                while (r1 + 1 < s->ctuRows && r1 + 1 - sl.nextRow < s->bandRows)
+                while (r1 + 1 < s->ctuRows && r1 + 1 - sl.nextRow < sl.bandLimit)
                 {
                     const int r = r1 + 1;
-                    const int need = r + 3 > s->ctuRows ? s->ctuRows : r + 3;          // the candidates of row r reach <= 62 luma lines below it
+                    const int need = r + 2 > s->ctuRows ? s->ctuRows : r + 2;          // the candidates of row r reach <= 44 luma lines below it (maxCyDown + window + 2)
                     if (pf.nextRow <= r || v.rowsSeen < need) break;
                     r1 = r;
                 }
                 if (r1 < sl.nextRow) continue;
-                bands.push_back({ i, sl.generation, sl.nextRow, r1, sl.fenc, sl.view });
+                bands.push_back({ i, sl.generation, sl.nextRow, r1, sl.fenc, sl.view, sl.hasCost });
                 s->pics[sl.fenc].busy++; s->pics[v.pic].busy++; s->views[sl.view].busy++;
                 sl.nextRow = r1 + 1;
+                sl.bandLimit = sl.bandLimit * 2 > s->bandRows ? s->bandRows : sl.bandLimit * 2;
                 if (sl.nextRow == s->ctuRows) sl.active = false;
                 else s->dirty = true;
             }
@@ -341,7 +352,7 @@ void cs_free(CS* s)
             if (v.dW[i]) (void)hipFree(v.dW[i]);
             if (v.dOut[i]) (void)hipFree(v.dOut[i]);
         }
-    for (auto& sl : s->slots) { if (sl.tables) (void)hipHostFree(sl.tables); delete[] sl.ready; }
+    for (auto& sl : s->slots) { if (sl.tables) (void)hipHostFree(sl.tables); if (sl.hMvCost) (void)hipHostFree(sl.hMvCost); if (sl.dMvCost) (void)hipFree(sl.dMvCost); delete[] sl.ready; }
     if (s->dSurf) (void)hipFree(s->dSurf);
     if (s->dBest) (void)hipFree(s->dBest);
     if (s->dZeroCost) (void)hipFree(s->dZeroCost);
@@ -443,9 +454,12 @@ int x265hip_cost_stream_create(x265hip_cost_stream** out, const x265hip_cost_str
     if (p->slots < 1 || p->slots > 256 || p->pictures < 2 || p->pictures > 256 || p->views < 1 || p->views > 64)
     { set_error("cost_stream_create: %d slots / %d pictures / %d views", p->slots, p->pictures, p->views); return X265HIP_EINVAL; }
     // the candidates of a CTU lie within centre +- window; the fractional positions reach 2 samples further, the phase planes' lines [4, rows - 8) are valid
-    // (chroma: the vector halves): |candidate| <= margin_y - 20 vertically, margin_x - 12 horizontally
+    // (chroma: the vector halves): |candidate| <= margin_y - 20 vertically, margin_x - 12 horizontally.  DOWNWARDS a row's candidates must stay inside the
+    // reference rows <= r + 1 (the row is computed one reference row before the host may start it): the view's lines end 8 above the last row's end, so a luma
+    // block may reach 64 - 8 - 2 = 54 lines, a chroma block 32 - 8 - 2 = 22 = luma 42: candidate <= 42 (luma only: 54)
     const int maxCx = p->margin_x - p->window - 12, maxCy = (hasC && p->margin_y_c * 2 < p->margin_y ? p->margin_y_c * 2 : p->margin_y) - p->window - 20;
-    if (maxCx < 0 || maxCy < 0) { set_error("cost_stream_create: margins %d / %d too small for a window of +-%d", p->margin_x, p->margin_y, p->window); return X265HIP_EINVAL; }
+    const int maxCyDownRaw = (hasC ? 42 : 54) - p->window;
+    if (maxCx < 0 || maxCy < 0 || maxCyDownRaw < 0) { set_error("cost_stream_create: margins %d / %d too small for a window of +-%d", p->margin_x, p->margin_y, p->window); return X265HIP_EINVAL; }
     int rc = ensure_device();
     if (rc) return rc;
     if (p->device_plus_1 < 0 || p->device_plus_1 > x265hip_device_count()) { set_error("cost_stream_create: device %d of %d", p->device_plus_1 - 1, x265hip_device_count()); return X265HIP_ENODEV; }
@@ -465,6 +479,7 @@ int x265hip_cost_stream_create(x265hip_cost_stream** out, const x265hip_cost_str
     s->maxCx = maxCx; s->maxCy = maxCy;
     if (p->centre_range && (s->maxCx > p->centre_range)) s->maxCx = p->centre_range;
     if (p->centre_range && (s->maxCy > p->centre_range)) s->maxCy = p->centre_range;
+    s->maxCyDown = maxCyDownRaw < s->maxCy ? maxCyDownRaw : s->maxCy;
     s->pitch[0] = (size_t)p->stride * s->bpp; s->pitch[1] = (size_t)p->stride_c * s->bpp;
     s->rows[0] = p->height + 2 * p->margin_y; s->rows[1] = hasC ? p->height / 2 + 2 * p->margin_y_c : 0;
     s->planeBytes[0] = s->pitch[0] * s->rows[0]; s->planeBytes[1] = s->pitch[1] * s->rows[1];
@@ -499,6 +514,8 @@ int x265hip_cost_stream_create(x265hip_cost_stream** out, const x265hip_cost_str
     for (auto& sl : s->slots)
     {
         CS_TRY(hipHostMalloc((void**)&sl.tables, s->rowBytes * s->ctuRows, hipHostMallocDefault));
+        CS_TRY(hipHostMalloc((void**)&sl.hMvCost, (2 * (size_t)p->window + 1) * sizeof(uint16_t), hipHostMallocDefault));
+        CS_TRY(hipMalloc((void**)&sl.dMvCost, (2 * (size_t)p->window + 1) * sizeof(uint16_t)));
         sl.ready = new (std::nothrow) std::atomic<int>[s->ctuRows];
         if (!sl.ready) { set_error("cost_stream_create: out of memory"); cs_free(s); delete s; return X265HIP_EINVAL; }
         for (int r = 0; r < s->ctuRows; r++) sl.ready[r].store(0);
@@ -511,6 +528,7 @@ int x265hip_cost_stream_create(x265hip_cost_stream** out, const x265hip_cost_str
     CS_TRY(hipMalloc((void**)&s->dCentres, nctuBand * 4));
     CS_TRY(hipMalloc((void**)&s->dCand, nctuBand * s->npu * p->candidates * 4));
     CS_TRY(hipMalloc((void**)&s->dTables, nctuBand * s->ctuBytes));
+
     // the device memsets are queued on the null stream and the worker's stream is non-blocking: wait for the fills here, once
     CS_TRY(hipDeviceSynchronize());
 #undef CS_TRY
@@ -564,7 +582,7 @@ int x265hip_cost_stream_picture_rows(x265hip_cost_stream* s, uint64_t key, const
     return 0;
 }
 
-int x265hip_cost_stream_pair_open(x265hip_cost_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key, const x265hip_weight* w, unsigned planes_weighted)
+int x265hip_cost_stream_pair_open(x265hip_cost_stream* s, int slot, uint64_t fenc_key, uint64_t ref_key, const x265hip_weight* w, unsigned planes_weighted, const uint16_t* mv_cost)
 {
     if (!s || slot < 0 || slot >= (int)s->slots.size()) { set_error("cost_stream_pair_open: bad slot"); return X265HIP_EINVAL; }
     unsigned mask = w ? planes_weighted & ((1u << s->nplanes) - 1) : 0;
@@ -591,7 +609,9 @@ int x265hip_cost_stream_pair_open(x265hip_cost_stream* s, int slot, uint64_t fen
         if (++sl.generation <= 0) sl.generation = 1;
         for (int r = 0; r < s->ctuRows; r++) sl.ready[r].store(0, std::memory_order_release);      // before anything is rewritten
         sl.fenc = fenc; sl.fencEpoch = s->pics[fenc].epoch; sl.view = view; sl.viewStamp = s->views[view].stamp;
-        sl.nextRow = 0; sl.active = true;
+        sl.nextRow = 0; sl.active = true; sl.bandLimit = 1;
+        sl.hasCost = mv_cost != nullptr;
+        if (mv_cost) memcpy(sl.hMvCost, mv_cost, (2 * (size_t)s->prm.window + 1) * sizeof(uint16_t));
         gen = sl.generation;
         s->pairsOpened++;
         s->dirty = true;

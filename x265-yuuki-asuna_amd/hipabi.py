@@ -1034,7 +1034,7 @@ def phase_planes(depth, src, src_off_bytes, dst, stride, rows, chroma=False, str
 class CostCandidatesParams(ctypes.Structure):
     """x265hip_cost_candidates_params"""
     _fields_ = [("nctu", ctypes.c_int), ("window", ctypes.c_int), ("surf", ctypes.c_void_p), ("centres", ctypes.c_void_p),
-                ("shapes", ctypes.c_int), ("candidates", ctypes.c_int), ("cand", ctypes.c_void_p)]
+                ("shapes", ctypes.c_int), ("candidates", ctypes.c_int), ("cand", ctypes.c_void_p), ("mv_cost", ctypes.c_void_p)]
 
 
 class CostTablesParams(ctypes.Structure):
@@ -1099,10 +1099,10 @@ def cost_ctu_bytes(subme, shapes, candidates):
     return L.x265hip_cost_ctu_bytes(subme, shapes, candidates)
 
 
-def cost_candidates(surf, centres, nctu, window, shapes, candidates, cand, stream=None):
+def cost_candidates(surf, centres, nctu, window, shapes, candidates, cand, stream=None, mv_cost=None):
     L = lib()
     L.x265hip_cost_candidates.argtypes = [ctypes.POINTER(CostCandidatesParams), ctypes.c_void_p]
-    p = CostCandidatesParams(nctu, window, _p(surf), _p(centres), shapes, candidates, _p(cand))
+    p = CostCandidatesParams(nctu, window, _p(surf), _p(centres), shapes, candidates, _p(cand), _p(mv_cost))
     check(L.x265hip_cost_candidates(ctypes.byref(p), current_stream() if stream is None else stream), "x265hip_cost_candidates")
 
 
