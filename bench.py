@@ -347,12 +347,19 @@ def seam_config(key):
       * always: sub-sample comparisons, lookahead frame costs, AQ and weightAnalyse from the device; the binding's hit-rate gate (ref_seam.cpp) stops opening
         pairs when fewer than half of the lookups of a window hit; everything the services do not answer takes the host-only control's split SADs."""
     depth = CFG_DEPTH.get(key, 8)
-    base = {"range": 12, "centre_range": 57, "layout": 1, "min_pu": 16, "verify": False, "lookahead": True, "subpel": True, "streamed": True, "aq": True,
+    # round 6: the SUB-SAMPLE COST TABLES (x265hip_cost_stream behind MotionEstimate::subpelCompare: records of the refinement's SATD costs around each PU's best integer
+    # vector, one candidate, the 85-position set of --subme 4 also under --subme 3) - one box, interleaved, against round 5's legs (tools/r6_cost_ab.sh,
+    # profiles/r06_cost_ab_*.txt): cfg3 7.87 -> 8.42 fps with tables + phase planes, 8.63 with the tables ALONE (11.1 instead of 9.4 + 11.1 GB downloaded: the phase planes'
+    # transfers cost more than the comparisons they still serve); cfg4 1.89 -> 2.21 with both (2.14 tables alone: at 10 bits the host's own 16-bit interpolation of what
+    # the tables miss is the dearer path).  So: 8 bits without a fade = tables alone; everything else = tables first, phase planes behind them.
+    base = {"range": 12, "centre_range": 57, "layout": 1, "min_pu": 16, "verify": False, "lookahead": True, "subpel": key != "cfg3" or os.environ.get("X265HIP_SEAM_PHASES") == "1",
+            "streamed": True, "aq": True,
             "weight_analyse": True, "split_rest": True, "no_sad": depth == 8 and os.environ.get("X265HIP_SEAM_SAD_8BIT") != "1",
-            "min_level": int(os.environ.get("X265HIP_SEAM_MIN_LEVEL", "2"))}
+            "min_level": int(os.environ.get("X265HIP_SEAM_MIN_LEVEL", "2")),
+            "cost": os.environ.get("X265HIP_SEAM_COST", "1") != "0", "cost_candidates": 1, "cost_window": 8, "cost_set_subme": 4, "cost_centre_range": 57}
     if key == "cfg5":       # 8K: a reference picture's phase planes are 3.4 GB of pinned memory, three frames need few resident pairs / views
-        return {**base, "slots": 12, "subpel_slots": 4, "pictures": 8, "min_level": 1}
-    return {**base, "slots": 24 if depth == 8 else 40, "subpel_slots": 12, "pictures": 24}
+        return {**base, "slots": 12, "subpel_slots": 4, "pictures": 8, "min_level": 1, "cost_slots": 12, "cost_pictures": 12, "cost_views": 6}
+    return {**base, "slots": 24 if depth == 8 else 40, "subpel_slots": 12, "pictures": 24, "cost_slots": 24 if depth == 8 else 40, "cost_pictures": 40, "cost_views": 12}
 
 
 def encoder_plan(args):
@@ -416,7 +423,9 @@ def encoder_leg_numbers(c):
          "x_c": round(sm["fps"] / c["c"]["fps"], 3) if sm.get("fps") else None,
          "x_control": round(sm["fps"] / cs["fps"], 3) if sm.get("fps") and cs.get("fps") else None,
          "hit_rate": rep.get("lookup_hit_rate"),
-         "gb_down": round(((rep.get("bytes_downloaded") or 0) + (rep.get("subpel_seam", {}).get("bytes_downloaded") or 0)) / 1e9, 2) if rep else None}
+         "gb_down": round(((rep.get("bytes_downloaded") or 0) + (rep.get("subpel_seam", {}).get("bytes_downloaded") or 0) +
+                           (rep.get("cost_seam", {}).get("bytes_downloaded") or 0)) / 1e9, 2) if rep else None,
+         "cost_share": rep.get("cost_seam", {}).get("served_share_of_satd_comparisons_with_context") if rep else None}
     sat = rep.get("subpel_seam", {}).get("satd_lookups_served")
     if sat is not None:
         r["satd_served"] = sat
