@@ -386,12 +386,13 @@ def encoder_leg(args, timeout_s=None):
     "encoder_summary": ..}."""
     import subprocess
     import tempfile
-    timeout_s = timeout_s or float(os.environ.get("X265HIP_ENCODER_TIMEOUT_S", "1200"))
+    timeout_s = timeout_s or float(os.environ.get("X265HIP_ENCODER_TIMEOUT_S", "900"))
     fd, path = tempfile.mkstemp(prefix="x265hip_encoder_", suffix=".json")
     os.close(fd)
     enc, err = {}, None
     try:
-        cmd = [sys.executable, os.path.join(ROOT, "tools", "encoder_bench.py"), "--plan", json.dumps(encoder_plan(args)), "--out", path]
+        # legs are not STARTED after 60 % of the limit (the longest leg is a fifth of the default plan): the child then ends by itself and the line is printed
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "encoder_bench.py"), "--plan", json.dumps(encoder_plan(args)), "--out", path, "--deadline-s", str(0.6 * timeout_s)]
         try:
             rc = subprocess.run(cmd, stdout=sys.stderr, stderr=sys.stderr, timeout=timeout_s, cwd=ROOT).returncode
             if rc != 0:
@@ -442,6 +443,9 @@ def encoder_summary(enc):
     s = {"kind": "reference x265 3.5, C primitives (no nasm in the image); *_v3 = g++ -march=x86-64-v3", **{k: v for k, v in legs.items() if v}}
     if "error" in enc:
         s["error"] = str(enc["error"])[:160]
+    skipped = [k for k, v in enc.items() if isinstance(v, dict) and "skipped" in v]
+    if skipped:
+        s["legs_not_started_deadline"] = skipped
     return s
 
 

@@ -151,8 +151,11 @@ static inline size_t x265hip_surf_ctu_bytes(int surf_format, int range)
 int x265hip_me_fullsearch(const x265hip_me_params* p, void* stream);
 int x265hip_me_best_reset(uint64_t* best, size_t count, void* stream);
 /* Name of the kernel a minima-only launch (surf == NULL) of x265hip_me_fullsearch runs at this depth and range - what a profile of the caller lists as its
- * dominant kernel (bench.py prints it as roofline.kernel); honours the A/B switches X265HIP_ME_BEST_VARIANT / X265HIP_ME_Q2_FLAGS like the launch itself. */
+ * dominant kernel (bench.py prints it as roofline.kernel); derived from the same switches and the same LDS-pitch function as the launch itself. */
 const char* x265hip_me_minima_kernel_name(int depth, int range);
+/* TEST-ONLY: the X265HIP_ME_* A/B switches are read once per process; parity tests and soaks that flip one between launches call this to have them read again
+ * (never while launches are in flight on other threads) */
+void x265hip_me_env_refresh(void);
 
 /* Sub-pel refinement of every PU's integer motion vector (the caller loop of SURVEY section 8(f) item 1,
  * reference MotionEstimate::motionEstimate, motion.cpp:1448-1561 + subpelCompare :1571-1664, luma):
@@ -1225,7 +1228,8 @@ int  x265hip_phase_stream_stats(x265hip_phase_stream* s, x265hip_phase_stream_st
  *      view's fractional-phase planes (x265hip_phase_planes: the same samples the three luma / four chroma filter calls produce).
  * What travels to the host is one RECORD per (CTU, PU, candidate): { int16 mvx, mvy (integer displacement; mvx = -32768: no record);
  * uint32 base; uint16 delta[positions] }, cost(position i) = base + delta[i], delta 65535 = not representable (the host computes
- * that one itself); x265hip_cost_record_bytes() apart, PU-major, candidates of a PU adjacent; x265hip_cost_ctu_bytes() per CTU.
+ * that one itself; sad_costs = 1 appends { uint32 base; uint16 delta[positions] } of the SAD-typed comparisons); x265hip_cost_record_bytes() apart, PU-major,
+ * candidates of a PU adjacent; x265hip_cost_ctu_bytes() per CTU.
  * A host stub of subpelCompare answers (cmp == satd, qmv - 4 * (mvx, mvy) inside the position set) from the record and everything
  * else with the host's own primitives - the same integers either way, so the bitstream cannot change.
  * The ROW-GRANULAR service follows the reference's frame threads like x265hip_me_stream / x265hip_phase_stream: pictures (source AND
@@ -1238,8 +1242,8 @@ int  x265hip_phase_stream_stats(x265hip_phase_stream* s, x265hip_phase_stream_st
 int x265hip_cost_pu_count(int shapes);                              /* shapes 0: the 85 squares; 1: + 2NxN / Nx2N (169); 2: + AMP of the 32 / 64 CUs (209) */
 int x265hip_cost_pu_rect(int shapes, int pu, int rect[4]);         /* x, y, width, height in luma samples inside the CTU; PUs [0, 85) in the surfaces' order */
 int x265hip_cost_positions(int subme, int8_t* xy, int max_positions);   /* -> count; xy[2 i], xy[2 i + 1] = quarter-sample offset of position i, raster order (y, then x) */
-int x265hip_cost_record_bytes(int subme);
-size_t x265hip_cost_ctu_bytes(int subme, int shapes, int candidates);
+int x265hip_cost_record_bytes(int subme, int sad_costs);
+size_t x265hip_cost_ctu_bytes(int subme, int shapes, int candidates, int sad_costs);
 typedef struct x265hip_cost_candidates_params
 {
     int nctu;
@@ -1268,6 +1272,9 @@ typedef struct x265hip_cost_tables_params
     int shapes, candidates, subme, chroma;
     const int16_t* cand;                /* DEVICE, the band's first CTU first */
     void* tables;                       /* DEVICE out, the band's first CTU first */
+    int sad_costs;                      /* 1: every record carries a second { uint32 base; uint16 delta[positions] } behind the first (4-byte aligned): the costs of the
+                                         * SAD-typed comparisons - subpelCompare(ref, mv, sad) of the search's predictor candidates, motion.cpp:773-812 - luma SAD + (chroma = 1)
+                                         * the SATD of Cb and Cr, which subpelCompare adds whatever the luma comparison is (:1601-1661) */
 } x265hip_cost_tables_params;
 int x265hip_cost_tables(const x265hip_cost_tables_params* p, void* stream);
 
@@ -1281,6 +1288,7 @@ typedef struct x265hip_cost_stream_params
     int centre_range;                   /* step 1 (the host's merange; 0 = windows around (0, 0)) */
     int window;                         /* step 2 */
     int candidates, shapes, subme, chroma;
+    int sad_costs;                      /* see x265hip_cost_tables_params */
     int slots;                          /* pairs resident in pinned host memory at once */
     int pictures;                       /* pictures (source + reconstructed) resident on the device at once */
     int views;                          /* reference views resident on the device at once (each 15 luma + 126 chroma planes) */

@@ -692,8 +692,9 @@ def cost_positions(subme, depth=8):
     return out[:n].copy()
 
 
-def cost_record_bytes(subme):
-    return (8 + 2 * len(cost_positions(subme)) + 3) & ~3
+def cost_record_bytes(subme, sad_costs=0):
+    n = len(cost_positions(subme))
+    return ((8 + 2 * n + 3) & ~3) + (((4 + 2 * n + 3) & ~3) if sad_costs else 0)
 
 
 def cost_candidates(surf, centres, nctu, window, shapes, k, depth=8, avx2=False, mv_cost=None):
@@ -712,20 +713,21 @@ def cost_candidates(surf, centres, nctu, window, shapes, k, depth=8, avx2=False,
     return out
 
 
-def cost_tables(depth, fenc, ref, stride, stride_c, margin_x, margin_y, margin_y_c, width, ctu_row0, ctu_rows, shapes, k, subme, chroma, cand, avx2=False):
+def cost_tables(depth, fenc, ref, stride, stride_c, margin_x, margin_y, margin_y_c, width, ctu_row0, ctu_rows, shapes, k, subme, chroma, cand, avx2=False, sad_costs=0):
     """fenc / ref: three flat padded planes each (allocation starts; the chroma ones may be None when chroma = 0).  cand: int16
-    [ctu_rows * width / 64, npu, k, 2].  Returns uint8 [ctus, npu, k, record bytes]: the reference's own subpelCompare route per value."""
+    [ctu_rows * width / 64, npu, k, 2].  Returns uint8 [ctus, npu, k, record bytes]: the reference's own subpelCompare route per value; sad_costs = 1 appends
+    the costs of the SAD-typed comparisons (cmp = the PU's sad) to every record."""
     fn = getattr(lib(avx2), f"x265oracle_cost_tables_d{depth}")
-    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_ssize_t] + [ctypes.c_int] * 10 + [ctypes.c_void_p, ctypes.c_void_p]
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_ssize_t] + [ctypes.c_int] * 10 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     fn.restype = None
     f = [None if p is None else np.ascontiguousarray(p).reshape(-1) for p in fenc]
     r = [None if p is None else np.ascontiguousarray(p).reshape(-1) for p in ref]
     fp = (ctypes.c_void_p * 3)(*[None if p is None else p.ctypes.data for p in f])
     rp = (ctypes.c_void_p * 3)(*[None if p is None else p.ctypes.data for p in r])
     c = np.ascontiguousarray(cand, np.int16)
-    npu, rec = len(cost_pu_list(shapes)), cost_record_bytes(subme)
+    npu, rec = len(cost_pu_list(shapes)), cost_record_bytes(subme, sad_costs)
     nctu = ctu_rows * (width // 64)
     assert c.size == nctu * npu * k * 2
     out = np.zeros((nctu, npu, k, rec), np.uint8)
-    fn(fp, rp, stride, stride_c, margin_x, margin_y, margin_y_c, width, ctu_row0, ctu_rows, shapes, k, subme, int(bool(chroma)), c.ctypes.data, out.ctypes.data)
+    fn(fp, rp, stride, stride_c, margin_x, margin_y, margin_y_c, width, ctu_row0, ctu_rows, shapes, k, subme, int(bool(chroma)), c.ctypes.data, out.ctypes.data, int(bool(sad_costs)))
     return out

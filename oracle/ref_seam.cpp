@@ -857,6 +857,7 @@ struct CostProvider
     intptr_t stride, strideC;
     int width, height, marginX, marginY;
     int K, subme, chroma, recBytes, npos, npu, window;
+    int rec2Off;                        /* > 0: every record carries the costs of the SAD-typed comparisons at this byte offset ({ uint32 base; uint16 delta[] }) */
     unsigned coverMask;                 /* bit s: the refinement of --subme s stays inside the service's position set when it starts on a record's vector */
     size_t ctuBytes;
 };
@@ -872,6 +873,7 @@ struct CostSeam
     FencStaged fencs[32];
     uint64_t instance = 0;
     std::atomic<int> epoch{0};
+    std::atomic<uint64_t> servedSad{0};
     std::atomic<uint64_t> served{0}, otherVector{0}, notReady{0}, saturated{0}, torn{0}, noContext{0}, contexts{0}, pairsOpened{0}, noSlot{0}, rowsPublished{0}, rowsRefused{0},
                           mismatches{0}, weightedPairs{0};
 } gc;
@@ -882,7 +884,7 @@ struct CostCtx
     const uint8_t* recs;                /* the PU's K records */
     const volatile int* ready;
     int row, gen;
-    uint64_t nServed, nOther, nNotReady, nSaturated, nTorn;      /* per search, added to the shared counters once at its end */
+    uint64_t nServed, nServedSad, nOther, nNotReady, nSaturated, nTorn;      /* per search, added to the shared counters once at its end */
 };
 thread_local CostCtx t_cost;
 thread_local struct { int fencPoc; int epoch; int n; struct { const PicYuv* rec; int recPoc; Wt wt[3]; int slot; int gen; } e[8]; } t_cpairs = { -0x7fffffff, -1, 0, {} };
@@ -989,12 +991,12 @@ void cost_context(const Search* s, const uint16_t* mvCostQpel, ReferencePlanes* 
     c.recs = tab + (size_t)ctuAddr * gc.p.ctuBytes + (size_t)pu * gc.p.K * gc.p.recBytes;
     c.row = ctuAddr / (gc.p.width / 64);
     c.gen = gen;
-    c.nServed = c.nOther = c.nNotReady = c.nSaturated = c.nTorn = 0;
+    c.nServed = c.nServedSad = c.nOther = c.nNotReady = c.nSaturated = c.nTorn = 0;
     c.valid = true;
 }
 
-/* one comparison from the records; false = not this seam's */
-inline bool cost_lookup(CostCtx& c, const MV& qmv, int& out)
+/* one comparison from the records (sadTyped: the SAD-typed costs behind the SATD ones); false = not this seam's */
+inline bool cost_lookup(CostCtx& c, const MV& qmv, int& out, bool sadTyped)
 {
     if (c.ready[c.row] != c.gen)
     {
@@ -1027,13 +1029,14 @@ inline bool cost_lookup(CostCtx& c, const MV& qmv, int& out)
         if ((unsigned)dx > 12u || (unsigned)dy > 12u) continue;
         const int idx = gc.posMap[dy * 13 + dx];
         if (idx < 0) continue;
-        const unsigned delta = ((const uint16_t*)(rec + 8))[idx];
+        const uint8_t* part = sadTyped ? rec + gc.p.rec2Off : rec + 4;
+        const unsigned delta = ((const uint16_t*)(part + 4))[idx];
         if (delta == 65535u) { c.nSaturated++; return false; }
-        const int cost = (int)(((const uint32_t*)rec)[1] + delta);
+        const int cost = (int)(*(const uint32_t*)part + delta);
         /* the row must STILL be this generation's after the read: a reopened slot has its flags cleared before any record is rewritten */
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         if (c.ready[c.row] != c.gen) { c.nTorn++; return false; }
-        c.nServed++;
+        if (sadTyped) c.nServedSad++; else c.nServed++;
         out = cost;
         return true;
     }
@@ -1133,6 +1136,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     {
         CostCtx& cc = t_cost;
         if (cc.nServed) gc.served.fetch_add(cc.nServed, std::memory_order_relaxed);
+        if (cc.nServedSad) gc.servedSad.fetch_add(cc.nServedSad, std::memory_order_relaxed);
         if (cc.nOther) gc.otherVector.fetch_add(cc.nOther, std::memory_order_relaxed);
         if (cc.nNotReady) gc.notReady.fetch_add(cc.nNotReady, std::memory_order_relaxed);
         if (cc.nSaturated) gc.saturated.fetch_add(cc.nSaturated, std::memory_order_relaxed);
@@ -1200,10 +1204,10 @@ int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_
             }
         }
     }
-    if (t_cost.valid && t_cost.ref == ref && cmp == satd && sad != satd)
+    if (t_cost.valid && t_cost.ref == ref && sad != satd && (cmp == satd || (cmp == sad && gc.p.rec2Off > 0)))
     {
         int cost;
-        if (cost_lookup(t_cost, qmv, cost))
+        if (cost_lookup(t_cost, qmv, cost, cmp == sad))
         {
             if (gc.verify)
             {
@@ -1880,21 +1884,21 @@ void x265ref_seam_disable(void) { g.enabled = false; gla.enabled = false; gs.ena
 /* cost-table seam: provider = x265hip_cost_stream_picture_rows / _pair_open / _tables / _ready signatures (NULL pair_open = off); geometry = the PicYuv
  * buffers of the encode about to start; pu_rects = int [npu][4] (x, y, w, h: x265hip_cost_pu_rect), positions = int8 [npos][2] (x265hip_cost_positions),
  * record_bytes / ctu_bytes as the service lays the records out, cover_mask bit s = the position set contains every position a --subme s refinement can reach from a record's
- * vector (the service may hold a LARGER set than the encode's own --subme needs: refinements that start from a fractional predictor then stay inside it more often).  flags: 1 = verify every served value against the reference's own function, 2 = wait
+ * vector, sad_costs_offset > 0 = the records also carry the SAD-typed costs at that byte offset (the service may hold a LARGER set than the encode's own --subme needs: refinements that start from a fractional predictor then stay inside it more often).  flags: 1 = verify every served value against the reference's own function, 2 = wait
  * for records, 4 = ignore the size gate, 8 = rank the candidates by SAD alone (no vector-cost table travels with the pairs).  window = the service's (the table covers
  * displacements of +-window around each CTU's centre).  Needs the SAD seam's configure first when the size gate is to apply (it decides g_gated). */
 int x265ref_cost_seam_configure(void* ctx, void* picture_rows, void* pair_open, void* tables, void* ready, int slots, int width, int height, intptr_t stride, intptr_t stride_c,
                                 int margin_x, int margin_y, int candidates, int subme, int chroma, const int* pu_rects, int npu, const int8_t* positions, int npos,
-                                int record_bytes, size_t ctu_bytes, int window, unsigned cover_mask, int flags)
+                                int record_bytes, size_t ctu_bytes, int window, unsigned cover_mask, int sad_costs_offset, int flags)
 {
     gc.enabled = false;
     if (!pair_open) return 0;
     if (slots < 1 || slots > MAX_SLOTS || !picture_rows || !tables || !ready || !pu_rects || !positions || npu < 1 || npos < 1 || npos > 169 || candidates < 1 || candidates > 2 ||
-        (width & 63) || (height & 63) || record_bytes < 8 + 2 * npos || ctu_bytes < (size_t)record_bytes * npu * candidates || window < 0 || window > 32) return -1;
+        (width & 63) || (height & 63) || record_bytes < 8 + 2 * npos || sad_costs_offset < 0 || (sad_costs_offset && (sad_costs_offset < 8 + 2 * npos || record_bytes < sad_costs_offset + 4 + 2 * npos)) || ctu_bytes < (size_t)record_bytes * npu * candidates || window < 0 || window > 32) return -1;
     gc.p.ctx = ctx;
     gc.p.picture_rows = (int (*)(void*, uint64_t, const void*, const void*, const void*, int, int))picture_rows;
     gc.p.pair_open = (int (*)(void*, int, uint64_t, uint64_t, const void*, unsigned, const uint16_t*))pair_open;
-    gc.p.window = window; gc.p.coverMask = cover_mask;
+    gc.p.window = window; gc.p.coverMask = cover_mask; gc.p.rec2Off = sad_costs_offset;
     gc.p.tables = (const void* (*)(void*, int))tables;
     gc.p.ready = (const volatile int* (*)(void*, int))ready;
     gc.p.slots = slots; gc.p.width = width; gc.p.height = height; gc.p.stride = stride; gc.p.strideC = stride_c; gc.p.marginX = margin_x; gc.p.marginY = margin_y;
@@ -1916,20 +1920,21 @@ int x265ref_cost_seam_configure(void* ctx, void* picture_rows, void* pair_open, 
     gc.instance++;
     memset(gc.pairs, 0, sizeof(gc.pairs)); memset(gc.fencs, 0, sizeof(gc.fencs));
     gc.verify = (flags & 1) != 0; gc.wait = (flags & 2) != 0; gc.useMvCost = (flags & 8) == 0;
-    gc.served = 0; gc.otherVector = 0; gc.notReady = 0; gc.saturated = 0; gc.torn = 0; gc.noContext = 0; gc.contexts = 0; gc.pairsOpened = 0; gc.noSlot = 0;
+    gc.served = 0; gc.servedSad = 0; gc.otherVector = 0; gc.notReady = 0; gc.saturated = 0; gc.torn = 0; gc.noContext = 0; gc.contexts = 0; gc.pairsOpened = 0; gc.noSlot = 0;
     gc.rowsPublished = 0; gc.rowsRefused = 0; gc.mismatches = 0; gc.weightedPairs = 0;
     gc.epoch.fetch_add(1);
     gc.enabled = (flags & 4) ? true : !g_gated;
     return 0;
 }
 
-/* out[13]: comparisons served from records, passed on because the search did not end on a record's vector (or left the position set), because the row's records had
+/* out[14]: SATD comparisons served from records, passed on because the search did not end on a record's vector (or left the position set), because the row's records had
  * not landed, because a delta was saturated, because the slot was reopened under the read; motionEstimate calls seen, of those without a usable context; pairs opened,
  * pair requests without a free slot, rows of reconstructed pictures handed to the provider / refused by it, verify mismatches, pairs on weighted references */
 void x265ref_cost_seam_stats(uint64_t* out)
 {
     out[0] = gc.served; out[1] = gc.otherVector; out[2] = gc.notReady; out[3] = gc.saturated; out[4] = gc.torn; out[5] = gc.contexts; out[6] = gc.noContext;
     out[7] = gc.pairsOpened; out[8] = gc.noSlot; out[9] = gc.rowsPublished; out[10] = gc.rowsRefused; out[11] = gc.mismatches; out[12] = gc.weightedPairs;
+    out[13] = gc.servedSad;          /* SAD-typed comparisons (the predictor candidates') served from records */
 }
 
 /* sub-sample seam: provider = x265hip_phase_cache_submit / _planes / _ready signatures (NULL submit = off); geometry = the PicYuv

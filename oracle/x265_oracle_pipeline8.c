@@ -153,14 +153,15 @@ void EXPORT(x265oracle_cost_candidates)(const int32_t* surf, const int16_t* cent
 
 /* planes: ALLOCATION STARTS (PicYuv layout); tables: the band's first CTU first, records of x265hip_cost_record_bytes */
 void EXPORT(x265oracle_cost_tables)(const pixel* const* fenc, const pixel* const* ref, intptr_t stride, intptr_t strideC, int marginX, int marginY, int marginYC,
-                                    int width, int ctuRow0, int ctuRows, int shapes, int K, int subme, int chroma, const int16_t* cand, uint8_t* tables)
+                                    int width, int ctuRow0, int ctuRows, int shapes, int K, int subme, int chroma, const int16_t* cand, uint8_t* tables, int sadCosts)
 {
     static x265hip_EncoderPrimitives prim;
     static int ready;
     EXPORT(x265oracle_prims_once)(&prim, &ready);
     OraclePu pu[209];
     int8_t pos[169 * 2];
-    const int npu = pu_list(shapes, pu), npos = EXPORT(x265oracle_cost_positions)(subme, pos), recBytes = (8 + 2 * npos + 3) & ~3, ctusW = width / 64;
+    const int npu = pu_list(shapes, pu), npos = EXPORT(x265oracle_cost_positions)(subme, pos), rec2Off = (8 + 2 * npos + 3) & ~3, ctusW = width / 64;
+    const int recBytes = sadCosts ? rec2Off + ((4 + 2 * npos + 3) & ~3) : rec2Off;
 #pragma omp parallel for schedule(dynamic)
     for (int job = 0; job < ctuRows * ctusW * npu; job++)
     {
@@ -181,6 +182,10 @@ void EXPORT(x265oracle_cost_tables)(const pixel* const* fenc, const pixel* const
             const int mvx = cand[recIdx * 2], mvy = cand[recIdx * 2 + 1];
             memset(rec, 0, recBytes);
             if (mvx == -32768) { ((int16_t*)rec)[0] = -32768; continue; }
+            for (int which = 0; which < (sadCosts ? 2 : 1); which++)
+            {
+            /* which = 0: cmp = the PU's satd (the refinement's comparisons); 1: cmp = its sad (the predictor candidates', motion.cpp:773-812) - the chroma part is
+             * chromaSatd either way (:1601-1661) */
             uint32_t cost[169], lo = ~0u;
             for (int i = 0; i < npos; i++)
             {
@@ -188,13 +193,14 @@ void EXPORT(x265oracle_cost_tables)(const pixel* const* fenc, const pixel* const
                 /* subpelCompare, luma (motion.cpp:1573-1599) */
                 const pixel* fref = ref[0] + (size_t)(marginY + Y0 + (qy >> 2)) * stride + marginX + X0 + (qx >> 2);
                 int xFrac = qx & 3, yFrac = qy & 3, c;
-                if (!(yFrac | xFrac)) c = prim.pu[P->part].satd(fencBuf[0], 64, fref, stride);
+                x265hip_pixelcmp_t cmp = which ? prim.pu[P->part].sad : prim.pu[P->part].satd;
+                if (!(yFrac | xFrac)) c = cmp(fencBuf[0], 64, fref, stride);
                 else
                 {
                     if (!yFrac) prim.pu[P->part].luma_hpp(fref, stride, subpelbuf, P->w, xFrac);
                     else if (!xFrac) prim.pu[P->part].luma_vpp(fref, stride, subpelbuf, P->w, yFrac);
                     else prim.pu[P->part].luma_hvpp(fref, stride, subpelbuf, P->w, xFrac, yFrac);
-                    c = prim.pu[P->part].satd(fencBuf[0], 64, subpelbuf, P->w);
+                    c = cmp(fencBuf[0], 64, subpelbuf, P->w);
                 }
                 if (chroma)
                 {
@@ -222,9 +228,11 @@ void EXPORT(x265oracle_cost_tables)(const pixel* const* fenc, const pixel* const
                 cost[i] = (uint32_t)c;
                 if (cost[i] < lo) lo = cost[i];
             }
+            uint8_t* part = which ? rec + rec2Off : rec + 4;
+            *(uint32_t*)part = lo;
+            for (int i = 0; i < npos; i++) ((uint16_t*)(part + 4))[i] = (uint16_t)(cost[i] - lo > 65535u ? 65535u : cost[i] - lo);
+            }
             ((int16_t*)rec)[0] = (int16_t)mvx; ((int16_t*)rec)[1] = (int16_t)mvy;
-            ((uint32_t*)rec)[1] = lo;
-            for (int i = 0; i < npos; i++) ((uint16_t*)(rec + 8))[i] = (uint16_t)(cost[i] - lo > 65535u ? 65535u : cost[i] - lo);
         }
     }
 }

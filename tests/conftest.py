@@ -26,3 +26,14 @@ def missing_reference_build(what="oracle/_ref not built (it travels to the GPU b
     if os.environ.get("X265HIP_EXPECT_REF") == "1":
         pytest.fail(what + " - and X265HIP_EXPECT_REF=1 says it must be there (python -c 'import __graft_entry__ as g; g.build()' builds it)")
     pytest.skip(what)
+
+
+@pytest.fixture(autouse=True)
+def _library_switches_follow_the_environment():
+    """libx265hip.so reads its X265HIP_ME_* A/B switches once per process; tests that flip one call x265hip_me_env_refresh() themselves, and after EVERY test -
+    once monkeypatch has restored the environment (autouse fixtures are set up first, torn down last) - they are read again, so no test inherits another's kernel."""
+    yield
+    mod = sys.modules.get("x265-yuuki-asuna_amd.hipabi")
+    lib = getattr(mod, "_lib", None) if mod else None
+    if lib is not None and hasattr(lib, "x265hip_me_env_refresh"):
+        lib.x265hip_me_env_refresh()

@@ -35,7 +35,7 @@ def centre_clamp(geo, window, centre_range, chroma_planes=True):
     return mx, my, min(my, (42 if chroma_planes else 54) - window)
 
 
-def chain(depth, fenc, ref, centre_range, window, shapes, k, subme, chroma, mv_cost=None):
+def chain(depth, fenc, ref, centre_range, window, shapes, k, subme, chroma, mv_cost=None, sad_costs=0):
     """fenc / ref: picture() dicts (ref already weighted where the search reads weighted planes).  Returns (centres, cand, tables)."""
     O = oracle()
     g = fenc
@@ -64,7 +64,7 @@ def chain(depth, fenc, ref, centre_range, window, shapes, k, subme, chroma, mv_c
     surf = surf.reshape(nctu, nc, ng, 4, 85).transpose(0, 1, 2, 4, 3)                                        # back to records [ctu][row][group][pu][4]
     cand = O.cost_candidates(np.ascontiguousarray(surf), centres, nctu, window, shapes, k, depth=depth, mv_cost=mv_cost)
     tables = O.cost_tables(depth, [fenc["y"], fenc["cb"], fenc["cr"]], [ref["y"], ref["cb"], ref["cr"]], g["stride"], g["stride_c"], g["margin_x"], g["margin_y"],
-                           g["margin_y_c"], g["width"], 0, g["height"] // 64, shapes, k, subme, chroma, cand)
+                           g["margin_y_c"], g["width"], 0, g["height"] // 64, shapes, k, subme, chroma, cand, sad_costs=sad_costs)
     return centres, cand, tables
 
 
@@ -75,16 +75,29 @@ def weight_plane(plane, depth, w):
     return np.clip(((w0 * val + rnd) >> shift) + off, 0, (1 << depth) - 1).astype(plane.dtype)
 
 
-def parse_records(tables, subme):
-    """uint8 [..., rec] -> (mv int16 [..., 2], cost uint32 [..., npos]; 0xffffffff where the delta saturated)."""
+def parse_records(tables, subme, sad_typed=False):
+    """uint8 [..., rec] -> (mv int16 [..., 2], cost uint32 [..., npos]; 0xffffffff where the delta saturated); sad_typed: the second part of every record."""
     O = oracle()
     npos = len(O.cost_positions(subme))
     t = np.ascontiguousarray(tables)
     lead = t.shape[:-1]
     flat = t.reshape(-1, t.shape[-1])
     mv = flat[:, :4].copy().view(np.int16).reshape(*lead, 2)
-    base = flat[:, 4:8].copy().view(np.uint32).reshape(-1)
-    delta = flat[:, 8:8 + 2 * npos].copy().view(np.uint16).astype(np.uint32)
+    off = ((8 + 2 * npos + 3) & ~3) if sad_typed else 4
+    base = flat[:, off:off + 4].copy().view(np.uint32).reshape(-1)
+    delta = flat[:, off + 4:off + 4 + 2 * npos].copy().view(np.uint16).astype(np.uint32)
     cost = base[:, None] + delta
     cost[delta == 65535] = 0xffffffff
     return mv, cost.reshape(*lead, npos)
+
+
+def used_mask(subme, sad_costs=0):
+    """bool [record bytes]: the bytes of a record that are defined (the padding behind each delta array is not written by the product)."""
+    O = oracle()
+    npos = len(O.cost_positions(subme))
+    m = np.zeros(O.cost_record_bytes(subme, sad_costs), bool)
+    m[:8 + 2 * npos] = True
+    if sad_costs:
+        off = (8 + 2 * npos + 3) & ~3
+        m[off:off + 4 + 2 * npos] = True
+    return m

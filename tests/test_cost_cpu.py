@@ -25,7 +25,8 @@ def test_product_lists_equal_the_oracle_lists():
         got = A.cost_positions(subme)
         assert len(got) == n and np.array_equal(got, O.cost_positions(subme))
         assert A.cost_record_bytes(subme) == (8 + 2 * n + 3) // 4 * 4 == O.cost_record_bytes(subme)
-    assert A.cost_ctu_bytes(3, 1, 1) == 169 * 108 and A.cost_ctu_bytes(4, 2, 2) == 209 * 2 * 180
+        assert A.cost_record_bytes(subme, 1) == (8 + 2 * n + 3) // 4 * 4 + (4 + 2 * n + 3) // 4 * 4 == O.cost_record_bytes(subme, 1)
+    assert A.cost_ctu_bytes(3, 1, 1) == 169 * 108 and A.cost_ctu_bytes(4, 2, 2) == 209 * 2 * 180 and A.cost_ctu_bytes(4, 2, 2, 1) == 209 * 2 * (180 + 176)
     assert A.lib().x265hip_cost_pu_count(3) == 0 and A.cost_ctu_bytes(9, 0, 1) == 0
 
 
@@ -74,8 +75,9 @@ def test_oracle_tables_equal_tilewise_satd_of_the_phase_planes(depth, chroma, su
     cand = rng.integers(-6, 7, (nctu, npu, k, 2)).astype(np.int16)
     cand[0, 3, 1, 0] = -32768
     tables = O.cost_tables(depth, [fenc["y"], fenc["cb"], fenc["cr"]], [ref["y"], ref["cb"], ref["cr"]], g["stride"], g["stride_c"], g["margin_x"], g["margin_y"],
-                           g["margin_y_c"], g["width"], 0, 1, shapes, k, subme, chroma, cand)
+                           g["margin_y_c"], g["width"], 0, 1, shapes, k, subme, chroma, cand, sad_costs=1)
     mv, cost = C.parse_records(tables, subme)
+    _, cost_sad = C.parse_records(tables, subme, sad_typed=True)
     assert mv[0, 3, 1, 0] == -32768
     ph = [O.phase_planes(depth, ref["y"], g["stride"], g["rows"]), O.phase_planes(depth, ref["cb"], g["stride_c"], g["rows_c"], chroma=True),
           O.phase_planes(depth, ref["cr"], g["stride_c"], g["rows_c"], chroma=True)]
@@ -92,14 +94,20 @@ def test_oracle_tables_equal_tilewise_satd_of_the_phase_planes(depth, chroma, su
             X, Y = g["margin_x"] + ctu * 64 + x, g["margin_y"] + y
             p = (qy & 3) * 4 + (qx & 3)
             plane = ph[0][p - 1] if p else src[0]
-            want = _hadamard_tiles(fsrc[0][Y:Y + h, X:X + w].astype(np.int64) - plane[Y + (qy >> 2):Y + (qy >> 2) + h, X + (qx >> 2):X + (qx >> 2) + w])
+            dl = fsrc[0][Y:Y + h, X:X + w].astype(np.int64) - plane[Y + (qy >> 2):Y + (qy >> 2) + h, X + (qx >> 2):X + (qx >> 2) + w]
+            want = _hadamard_tiles(dl)
+            want_sad = int(np.abs(dl).sum())
             if chroma:
                 Xc, Yc = g["margin_x"] + (ctu * 64 + x) // 2, g["margin_y_c"] + y // 2
                 p = (qy & 7) * 8 + (qx & 7)
                 for c in (1, 2):
                     plane = ph[c][p - 1] if p else src[c]
-                    want += _hadamard_tiles(fsrc[c][Yc:Yc + h // 2, Xc:Xc + w // 2].astype(np.int64) -
-                                            plane[Yc + (qy >> 3):Yc + (qy >> 3) + h // 2, Xc + (qx >> 3):Xc + (qx >> 3) + w // 2])
+                    ch = _hadamard_tiles(fsrc[c][Yc:Yc + h // 2, Xc:Xc + w // 2].astype(np.int64) -
+                                         plane[Yc + (qy >> 3):Yc + (qy >> 3) + h // 2, Xc + (qx >> 3):Xc + (qx >> 3) + w // 2])
+                    want += ch
+                    want_sad += ch          # subpelCompare adds chromaSatd whatever the luma comparison is (motion.cpp:1601-1661)
+            if cost_sad[ctu, pu, kk, i] != 0xffffffff:
+                assert cost_sad[ctu, pu, kk, i] == want_sad, (ctu, pu, kk, i, int(cost_sad[ctu, pu, kk, i]), want_sad)
             if cost[ctu, pu, kk, i] == 0xffffffff:          # a delta that does not fit 16 bits (random vectors on a 64x64 block at 10 bits): the host's to compute
                 assert want - int(cost[ctu, pu, kk].min()) >= 65535
                 continue

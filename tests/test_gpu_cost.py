@@ -73,8 +73,9 @@ def _device_phases(depth, d_planes, g, dev):
 
 
 @pytest.mark.parametrize("few", [0, 5], ids=["scattered", "few_vectors"])
-@pytest.mark.parametrize("depth,chroma,subme,shapes,k", [(8, 1, 3, 1, 1), (8, 1, 4, 2, 2), (10, 1, 4, 2, 2), (12, 1, 3, 2, 1), (8, 0, 2, 2, 2), (10, 0, 7, 0, 1), (8, 1, 5, 1, 2)])
-def test_tables_match_oracle(depth, chroma, subme, shapes, k, few):
+@pytest.mark.parametrize("depth,chroma,subme,shapes,k,sad", [(8, 1, 3, 1, 1, 0), (8, 1, 4, 2, 2, 1), (10, 1, 4, 2, 2, 1), (12, 1, 3, 2, 1, 0), (8, 0, 2, 2, 2, 1), (10, 0, 7, 0, 1, 1), (8, 1, 5, 1, 2, 0),
+                                                             (8, 1, 7, 1, 1, 1)])
+def test_tables_match_oracle(depth, chroma, subme, shapes, k, sad, few):
     """few_vectors: the PUs of a CTU sit on a handful of distinct vectors - the shared-tile kernel (a map of 8x8-block costs per vector, summed per PU) writes the
     records; scattered: (nearly) every PU-candidate has a vector of its own - those CTUs are flagged and left to the per-PU kernel.  Both against the same oracle."""
     import torch
@@ -95,22 +96,21 @@ def test_tables_match_oracle(depth, chroma, subme, shapes, k, few):
     cand[:, :, 0] = np.array([3, 2], np.int16)                                 # the clip's own motion: the small costs a real search ends on
     cand[1, 5, k - 1, 0] = -32768
     want = O.cost_tables(depth, [fenc["y"], fenc["cb"], fenc["cr"]], [ref["y"], ref["cb"], ref["cr"]], g["stride"], g["stride_c"], g["margin_x"], g["margin_y"],
-                         g["margin_y_c"], g["width"], 0, g["height"] // 64, shapes, k, subme, chroma, cand)
+                         g["margin_y_c"], g["width"], 0, g["height"] // 64, shapes, k, subme, chroma, cand, sad_costs=sad)
     d_f, d_r = _device_picture(fenc, dev), _device_picture(ref, dev)
     d_ph = _device_phases(depth, d_r, g, dev)
-    rec = A.cost_record_bytes(subme)
+    rec = A.cost_record_bytes(subme, sad)
     d_t = torch.full((nctu, npu, k, rec), 0xAB, dtype=torch.uint8, device=dev)
     es = 1 if depth == 8 else 2
     for r0, n in ((0, 1), (1, g["height"] // 64 - 1)):                         # two bands
         c0 = r0 * (g["width"] // 64)
         A.cost_tables(depth, g["width"], g["stride"], g["margin_x"], g["margin_y"], g["stride_c"], g["margin_y_c"], r0, n, d_f, d_r, d_ph,
                       g["stride"] * g["rows"] * es, g["stride_c"] * g["rows_c"] * es, shapes, k, subme, chroma,
-                      torch.from_numpy(cand[c0:c0 + n * (g["width"] // 64)].copy()).to(dev), d_t[c0:])
+                      torch.from_numpy(cand[c0:c0 + n * (g["width"] // 64)].copy()).to(dev), d_t[c0:], sad_costs=sad)
     torch.cuda.synchronize()
     got = d_t.cpu().numpy()
-    npos = len(A.cost_positions(subme))
-    used = 8 + 2 * npos                                                        # the padding bytes of a record are not written
-    bad = np.argwhere((got[..., :used] != want[..., :used]).any(axis=-1))
+    used = C.used_mask(subme, sad)                                             # the padding bytes of a record are not written
+    bad = np.argwhere((got[..., used] != want[..., used]).any(axis=-1))
     assert len(bad) == 0, f"{len(bad)} records differ, first (ctu, pu, candidate) {bad[0].tolist()}: got {got[tuple(bad[0])][:24].tolist()} want {want[tuple(bad[0])][:24].tolist()}"
     mv, cost = C.parse_records(got, subme)
     assert (cost[mv[..., 0] != -32768] != 0xffffffff).mean() > 0.5            # most deltas are representable (random far-off vectors may saturate)
@@ -119,11 +119,11 @@ def test_tables_match_oracle(depth, chroma, subme, shapes, k, few):
 class _Stream:
     """ctypes handle of x265hip_cost_stream for the tests."""
 
-    def __init__(self, depth, g, centre_range, window, k, shapes, subme, chroma, slots=4, pictures=6, views=3, band_rows=2):
+    def __init__(self, depth, g, centre_range, window, k, shapes, subme, chroma, slots=4, pictures=6, views=3, band_rows=2, sad_costs=0):
         L = A.lib()
         self.L, self.g, self.subme = L, g, subme
         p = A.CostStreamParams(depth, g["width"], g["height"], g["stride"], g["margin_x"], g["margin_y"], g["stride_c"], g["margin_y_c"], centre_range, window,
-                               k, shapes, subme, int(chroma), slots, pictures, views, band_rows, 0)
+                               k, shapes, subme, int(chroma), int(sad_costs), slots, pictures, views, band_rows, 0)
         self.h = ctypes.c_void_p()
         L.x265hip_cost_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(A.CostStreamParams)]
         A.check(L.x265hip_cost_stream_create(ctypes.byref(self.h), ctypes.byref(p)), "x265hip_cost_stream_create")
@@ -136,8 +136,9 @@ class _Stream:
         L.x265hip_cost_stream_ready.restype = ctypes.POINTER(ctypes.c_int)
         L.x265hip_cost_stream_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(A.CostStreamStats)]
         self.ctu_rows = g["height"] // 64
-        self.row_bytes = A.cost_ctu_bytes(subme, shapes, k) * (g["width"] // 64)
-        self.shape = ((g["width"] // 64) * self.ctu_rows, len(A.cost_pu_list(shapes)), k, A.cost_record_bytes(subme))
+        self.sad_costs = int(sad_costs)
+        self.row_bytes = A.cost_ctu_bytes(subme, shapes, k, sad_costs) * (g["width"] // 64)
+        self.shape = ((g["width"] // 64) * self.ctu_rows, len(A.cost_pu_list(shapes)), k, A.cost_record_bytes(subme, sad_costs))
 
     def rows(self, key, pic, r0, n):
         return self.L.x265hip_cost_stream_picture_rows(self.h, key, pic["y"].ctypes.data, pic["cb"].ctypes.data, pic["cr"].ctypes.data, r0, n)
@@ -170,9 +171,9 @@ class _Stream:
         self.L.x265hip_cost_stream_destroy(self.h)
 
 
-def _equal_records(got, want, subme):
-    used = 8 + 2 * len(A.cost_positions(subme))
-    return np.argwhere((got[..., :used] != want[..., :used]).any(axis=-1))
+def _equal_records(got, want, subme, sad_costs=0):
+    used = C.used_mask(subme, sad_costs)
+    return np.argwhere((got[..., used] != want[..., used]).any(axis=-1))
 
 
 @pytest.mark.parametrize("depth", [8, 10])
@@ -189,10 +190,11 @@ def test_cost_stream_follows_the_rows_and_serves_weighted_views(depth):
     wref = dict(ref)
     wref["y"] = C.weight_plane(ref["y"], depth, w3[0]); wref["cb"] = C.weight_plane(ref["cb"], depth, w3[1])
     mvc = (np.abs(np.arange(-window, window + 1)) * 37 + 5).astype(np.uint16)
-    want_plain = C.chain(depth, fenc, ref, cr, window, shapes, k, subme, chroma)
-    want_w = C.chain(depth, fenc, wref, cr, window, shapes, k, subme, chroma)
-    want_other = C.chain(depth, other, ref, cr, window, shapes, k, subme, chroma, mv_cost=mvc)
-    S = _Stream(depth, g, cr, window, k, shapes, subme, chroma)
+    sad = int(depth == 10)                                                     # the 10-bit run carries the SAD-typed costs too
+    want_plain = C.chain(depth, fenc, ref, cr, window, shapes, k, subme, chroma, sad_costs=sad)
+    want_w = C.chain(depth, fenc, wref, cr, window, shapes, k, subme, chroma, sad_costs=sad)
+    want_other = C.chain(depth, other, ref, cr, window, shapes, k, subme, chroma, mv_cost=mvc, sad_costs=sad)
+    S = _Stream(depth, g, cr, window, k, shapes, subme, chroma, sad_costs=sad)
     try:
         gen0 = S.open(0, 1001, 2000)                                           # before anything has arrived
         assert gen0 > 0
@@ -210,16 +212,16 @@ def test_cost_stream_follows_the_rows_and_serves_weighted_views(depth):
         for slot, gen in ((0, gen0), (1, gen1), (2, gen2)):
             assert S.wait(slot, gen) == [gen] * S.ctu_rows, f"slot {slot} never completed: {S.stats()}"
         for slot, want in ((0, want_plain), (1, want_w), (2, want_other)):
-            bad = _equal_records(S.tables(slot), want[2], subme)
+            bad = _equal_records(S.tables(slot), want[2], subme, sad)
             assert len(bad) == 0, f"slot {slot}: {len(bad)} records differ, first {bad[0].tolist()}"
-        assert len(_equal_records(want_other[2], C.chain(depth, other, ref, cr, window, shapes, k, subme, chroma)[2], subme)) > 0, "the vector cost changed no record"
+        assert len(_equal_records(want_other[2], C.chain(depth, other, ref, cr, window, shapes, k, subme, chroma, sad_costs=sad)[2], subme, sad)) > 0, "the vector cost changed no record"
         st = S.stats()
         assert st["failed"] == 0 and st["pairs_completed"] == 3 and st["views_opened"] == 2 and st["views_shared"] == 1 and st["lines_weighted"] > 0, st
         # reopening a slot clears its flags before anything is rewritten; the new pair is served again
         gen0b = S.open(0, 1002, 2000, w3, 3)
         assert gen0b == gen0 + 1
         assert S.wait(0, gen0b) == [gen0b] * S.ctu_rows
-        assert len(_equal_records(S.tables(0), C.chain(depth, other, wref, cr, window, shapes, k, subme, chroma)[2], subme)) == 0
+        assert len(_equal_records(S.tables(0), C.chain(depth, other, wref, cr, window, shapes, k, subme, chroma, sad_costs=sad)[2], subme, sad)) == 0
         assert S.open(9, 1, 2) < 0 and S.rows(5, fenc, 3, 4) < 0                # bad slot / rows past the picture: refused
     finally:
         S.close()

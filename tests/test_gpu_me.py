@@ -108,6 +108,7 @@ def test_me_record_per_lane_kernel_serves_the_other_formats(monkeypatch):
     minima alone, surfaces alone."""
     import torch
     monkeypatch.setenv("X265HIP_ME_KERNEL", "cand")
+    A.lib().x265hip_me_env_refresh()          # the switches are read once per process: this test flips one
     _run(128, 128, 8, 8, seed=21)
     _run(200, 136, 12, 8, seed=22, packed=True)
     _run(256, 64, 57, 8, seed=23)
@@ -246,6 +247,7 @@ def test_me_minima_only_launch_every_kernel_variant(case, variant, monkeypatch):
         monkeypatch.setenv("X265HIP_ME_Q2_FLAGS", variant[1:])
         if int(variant[1:]) & 256 and rng > 59:
             pytest.skip("two window copies (flag 256) hold +-59 at most")
+    A.lib().x265hip_me_env_refresh()          # the switches are read once per process: this test flips them (tests/conftest.py re-reads them after every test)
     dev = torch.device("cuda:0")
     clip = F.synth_clip(width, height, 2, depth=8, seed=40 + rng)
     y0, y1 = clip[0][0], clip[1][0]
@@ -289,6 +291,7 @@ def test_me_minima_only_launch_10bit_both_kernels(case, w2, monkeypatch):
     width, height, rng, lam, special = case
     monkeypatch.delenv("X265HIP_ME_BEST_VARIANT", raising=False)
     monkeypatch.setenv("X265HIP_ME_W2", w2)
+    A.lib().x265hip_me_env_refresh()
     dev = torch.device("cuda:0")
     clip = F.synth_clip(width, height, 2, depth=10, seed=60 + rng)
     y0, y1 = clip[0][0], clip[1][0]

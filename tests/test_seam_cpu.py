@@ -487,7 +487,7 @@ def test_cost_seam_serves_the_refinement_with_the_references_own_values(depth, p
     EB, SD = _tools()
     set_subme = [int(v) for o, v in extra if o == "set-subme"]          # not an encoder option: the records hold a LARGER position set than the encode's --subme needs
     opts = [("pools", "4"), ("frame-threads", "2"), ("crf", "24")] + [(o, v) for o, v in extra if o != "set-subme"]
-    cfg = SD.cost_config(preset, opts, centre_range=20, window=4, candidates=k, slots=40, set_subme=set_subme[0] if set_subme else None)
+    cfg = SD.cost_config(preset, opts, centre_range=20, window=4, candidates=k, slots=40, set_subme=set_subme[0] if set_subme else None, sad_costs=bool(set_subme) or depth == 10)
     base, got, rep = run_pair(depth, 256, 192, 7, preset, opts, "oracle", rng=8, min_pu=128, streamed=True, min_level=1, slots=32, layout=1, centre_range=20, wait=True,
                               cost="oracle", cost_cfg=cfg, fade=fade)
     c = rep["cost_seam"]
@@ -498,3 +498,5 @@ def test_cost_seam_serves_the_refinement_with_the_references_own_values(depth, p
     assert c["recon_rows_to_provider"] > 0 and c["recon_rows_refused"] == 0, c
     if fade:
         assert c["pairs_on_weighted_references"] > 0, c
+    if cfg["sad_costs"]:          # the predictor candidates' comparisons (cmp = sad, motion.cpp:773-812) come from the second half of the records
+        assert c["sad_typed_comparisons_served_from_records"] > 1000, c

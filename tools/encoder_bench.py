@@ -145,7 +145,7 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
                                                           cost="gpu" if seam.get("cost") else None,
                                                           cost_cfg=SD.cost_config(cfg["preset"], opts, centre_range=seam.get("cost_centre_range", 57), window=seam.get("cost_window", 8),
                                                                                   candidates=seam.get("cost_candidates", 1), slots=seam.get("cost_slots", 24),
-                                                                                  pictures=seam.get("cost_pictures", 40), views=seam.get("cost_views", 12), set_subme=seam.get("cost_set_subme")) if seam.get("cost") else None)
+                                                                                  pictures=seam.get("cost_pictures", 40), views=seam.get("cost_views", 12), set_subme=seam.get("cost_set_subme"), sad_costs=seam.get("cost_sad")) if seam.get("cost") else None)
         t0, c0 = time.perf_counter(), time.process_time()
         md5, nbytes, sec, filled = encode(enc_lib, yuv[: nf * (yuv.size // n)], w, h, nf, cfg["preset"], opts, filler)
         wall, cpu = time.perf_counter() - t0, time.process_time() - c0
@@ -207,11 +207,13 @@ def main():
     ap.add_argument("--ref-build", default="", choices=["", "v3"], help="reference build flavour of every leg: '' = g++ -O3, v3 = + -march=x86-64-v3 (AVX2 auto-vectorised C)")
     ap.add_argument("--seam-no-weighted", action="store_true", help="weighted references pass to the host (the round-3 behaviour), for A/B on a fade")
     ap.add_argument("--plan", default="", help="bench.py's child-process mode: a JSON list of legs {name, key, tables, frames, frame_threads, seam, build}; the other options are ignored")
+    ap.add_argument("--deadline-s", type=float, default=0.0, help="--plan: legs are not started once this many seconds have passed (0 = no deadline)")
     ap.add_argument("--out", default="", help="--plan: write {\"encoder\": {name: result}} to this file after EVERY leg (what is there survives a crash or a timeout of a later leg)")
     ap.add_argument("--seam-cost", action="store_true",
                     help="also answer MotionEstimate::subpelCompare's SATD comparisons from x265hip_cost_stream's records (sub-sample costs around each PU's best integer vectors)")
     ap.add_argument("--seam-cost-candidates", type=int, default=1, help="cost tables: integer vectors per PU (1 or 2)")
     ap.add_argument("--seam-cost-set-subme", type=int, default=0, help="cost tables: hold the position set of this --subme row when it is larger than the encode's own (4: 85 positions)")
+    ap.add_argument("--seam-cost-sad", action="store_true", help="cost tables: the records also carry the costs of the SAD-typed comparisons (the search's predictor candidates)")
     ap.add_argument("--seam-cost-window", type=int, default=8, help="cost tables: the candidates are the smallest SADs within +-this of each CTU's own displacement")
     ap.add_argument("--seam-cost-slots", type=int, default=24, help="cost tables: (picture, reference) pairs resident in pinned host memory (37 MB each at 4K preset slow)")
     ap.add_argument("--seam-cost-views", type=int, default=12, help="cost tables: reference views (phase planes, 450 MB each at 4K 8-bit) resident on the device")
@@ -219,7 +221,17 @@ def main():
     args = ap.parse_args()
     if args.plan:
         out = {}
+        t_start = time.perf_counter()
         for leg in json.loads(args.plan):
+            # every leg has a time budget of its own kind: a leg is not STARTED once the plan's deadline has passed (round-5 advisor: all legs in one child with one
+            # limit - a slow box lost every result that came after the limit, and the caller's line with them); what has been measured is already in --out
+            if args.deadline_s and time.perf_counter() - t_start > args.deadline_s:
+                out[leg["name"]] = {"skipped": f"not started: the plan's deadline of {args.deadline_s:.0f} s had passed"}
+                if args.out:
+                    with open(args.out + ".tmp", "w") as f:
+                        json.dump({"encoder": out}, f)
+                    os.replace(args.out + ".tmp", args.out)
+                continue
             try:
                 out[leg["name"]] = run_config(leg["key"], leg["tables"], leg.get("frames") or None, leg.get("frame_threads", 1), args.budget_s, seam=leg.get("seam"),
                                               build=leg.get("build", ""))
@@ -237,7 +249,7 @@ def main():
             "pictures": args.seam_pictures, "band_rows": args.seam_band_rows, "no_sad": args.seam_no_sad, "weighted": not args.seam_no_weighted,
             "layout": 1 if args.seam_layout == "planes" else 0, "centre_range": args.seam_centre_range, "aq": args.seam_aq, "weight_analyse": args.seam_weight_analyse, "split_rest": args.seam_split_rest,
             "cost": args.seam_cost, "cost_candidates": args.seam_cost_candidates, "cost_window": args.seam_cost_window, "cost_slots": args.seam_cost_slots, "cost_views": args.seam_cost_views,
-            "cost_centre_range": args.seam_centre_range or 57, "cost_set_subme": args.seam_cost_set_subme or None}
+            "cost_centre_range": args.seam_centre_range or 57, "cost_set_subme": args.seam_cost_set_subme or None, "cost_sad": args.seam_cost_sad}
     out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s, seam=seam, build=args.ref_build) for k in args.configs.split(",")}
     print(json.dumps({"encoder": out}))
 

@@ -24,6 +24,7 @@ def main():
             os.environ["X265HIP_ME_KERNEL"] = kernel
         else:
             os.environ.pop("X265HIP_ME_KERNEL", None)
+        T.A.lib().x265hip_me_env_refresh()          # the library reads its switches once per process; this soak flips one per iteration
         extreme = "flat" if rng.integers(0, 8) == 0 else None
         try:
             T._run(w, h, r, 8, seed=int(rng.integers(1, 1000)), extreme=extreme, packed=fmt)

@@ -20,7 +20,7 @@ for l in sys.stdin:
           'GB_down', round((s.get('bytes_downloaded',0)+sp.get('bytes_downloaded',0)+c.get('bytes_downloaded',0))/1e9,2),
           'cost_served', c.get('comparisons_served_from_records'), 'share', c.get('served_share_of_satd_comparisons_with_context'), 'other', c.get('passed_on_other_vector_or_position'),
           'late', c.get('passed_on_records_not_arrived'), 'no_ctx', c.get('calls_without_context'), 'of', c.get('motion_estimate_calls_seen'), 'pairs', c.get('pairs_opened'), 'stale', c.get('stale_pairs'),
-          'failed', c.get('failed'), 'busy_ms', c.get('worker_busy_ms'), 'phase_served', sp.get('subpel_compares_served'), 'mismatch', c.get('verify_mismatches'), flush=True)
+          'sad_served', c.get('sad_typed_comparisons_served_from_records'), 'failed', c.get('failed'), 'busy_ms', c.get('worker_busy_ms'), 'phase_served', sp.get('subpel_compares_served'), 'mismatch', c.get('verify_mismatches'), flush=True)
 "; }
 for r in $(seq 1 $ROUNDS); do
   for cfg in $CFGS; do
@@ -36,5 +36,8 @@ for r in $(seq 1 $ROUNDS); do
     run "$cfg r$r r5+cost1s4" --configs $cfg --tables seam --frames $NF --seam-slots $SLOTS $COMMON $SAD --seam-subpel --seam-cost --seam-cost-candidates 1 --seam-cost-set-subme 4
     run "$cfg r$r cost1s4 only" --configs $cfg --tables seam --frames $NF --seam-slots $SLOTS $COMMON $SAD --seam-cost --seam-cost-candidates 1 --seam-cost-set-subme 4
     fi
+    # ... and the SAD-typed comparisons (the predictor candidates of every search) from the same records
+    run "$cfg r$r cost1s4+sad only" --configs $cfg --tables seam --frames $NF --seam-slots $SLOTS $COMMON $SAD --seam-cost --seam-cost-candidates 1 --seam-cost-set-subme 4 --seam-cost-sad $V
+    run "$cfg r$r r5+cost1s4+sad" --configs $cfg --tables seam --frames $NF --seam-slots $SLOTS $COMMON $SAD --seam-subpel --seam-cost --seam-cost-candidates 1 --seam-cost-set-subme 4 --seam-cost-sad
   done
 done

@@ -651,12 +651,12 @@ CS_TABLES = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
 CS_READY = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
 COST_STAT_NAMES = ("comparisons_served_from_records", "passed_on_other_vector_or_position", "passed_on_records_not_arrived", "passed_on_saturated_delta", "dropped_slot_reopened",
                    "motion_estimate_calls_seen", "calls_without_context", "pairs_opened", "pair_requests_without_slot", "recon_rows_to_provider", "recon_rows_refused",
-                   "verify_mismatches", "pairs_on_weighted_references")
+                   "verify_mismatches", "pairs_on_weighted_references", "sad_typed_comparisons_served_from_records")
 PRESET_SUBME = {"ultrafast": 0, "superfast": 1, "veryfast": 1, "faster": 2, "fast": 2, "medium": 2, "slow": 3, "slower": 4, "veryslow": 4, "placebo": 5}      # common/param.cpp:397-539
 PRESET_SHAPES = {"slow": 1, "slower": 2, "veryslow": 2, "placebo": 2}                                                                                             # --rect from slow, --amp from slower
 
 
-def cost_config(preset, opts, centre_range=57, window=8, candidates=1, slots=24, pictures=40, views=12, band_rows=8, mv_cost=True, set_subme=None):
+def cost_config(preset, opts, centre_range=57, window=8, candidates=1, slots=24, pictures=40, views=12, band_rows=8, mv_cost=True, set_subme=None, sad_costs=False):
     """The cost-table service's parameters for an encode: the refinement's position set and the chroma flag follow --subme (bChromaSATD: subme > 2,
     motion.cpp:212), the PU list follows --rect / --amp."""
     o = dict((k, v) for k, v in opts)
@@ -669,7 +669,7 @@ def cost_config(preset, opts, centre_range=57, window=8, candidates=1, slots=24,
     # set_subme: the records may hold the position set of a HIGHER workload row than the encode's (a superset: refinements that start from a fractional predictor
     # leave the --subme 3 set of 49 positions more often than --subme 4's 85); the chroma flag stays the encode's
     return dict(centre_range=centre_range, window=window, candidates=candidates, shapes=shapes, subme=max(subme, set_subme or 0), host_subme=subme, chroma=int(subme > 2), slots=slots, pictures=pictures, views=views,
-                band_rows=band_rows, mv_cost=bool(mv_cost))
+                band_rows=band_rows, mv_cost=bool(mv_cost), sad_costs=int(bool(sad_costs)))
 
 
 class StreamGpuCostProvider:
@@ -680,7 +680,7 @@ class StreamGpuCostProvider:
         self.A, self.L, self.cfg = A, A.lib(), cfg
         L = self.L
         p = A.CostStreamParams(depth, geo["width"], geo["height"], geo["stride"], geo["margin_x"], geo["margin_y"], geo["stride_c"], geo["margin_y"] >> 1,
-                               cfg["centre_range"], cfg["window"], cfg["candidates"], cfg["shapes"], cfg["subme"], cfg["chroma"], cfg["slots"], cfg["pictures"], cfg["views"],
+                               cfg["centre_range"], cfg["window"], cfg["candidates"], cfg["shapes"], cfg["subme"], cfg["chroma"], cfg.get("sad_costs", 0), cfg["slots"], cfg["pictures"], cfg["views"],
                                cfg["band_rows"], 0 if device is None else device + 1)
         self.handle = ctypes.c_void_p()
         L.x265hip_cost_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(A.CostStreamParams)]
@@ -688,7 +688,8 @@ class StreamGpuCostProvider:
         L.x265hip_cost_stream_destroy.argtypes = [ctypes.c_void_p]
         L.x265hip_cost_stream_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(A.CostStreamStats)]
         self.rects, self.positions = A.cost_pu_list(cfg["shapes"]), A.cost_positions(cfg["subme"])
-        self.record_bytes, self.ctu_bytes = A.cost_record_bytes(cfg["subme"]), A.cost_ctu_bytes(cfg["subme"], cfg["shapes"], cfg["candidates"])
+        self.record_bytes = A.cost_record_bytes(cfg["subme"], cfg.get("sad_costs", 0))
+        self.ctu_bytes = A.cost_ctu_bytes(cfg["subme"], cfg["shapes"], cfg["candidates"], cfg.get("sad_costs", 0))
 
     def pointers(self):
         L = self.L
@@ -726,7 +727,7 @@ class StreamOracleCostProvider:
         self.nctu = self.ctus_w * self.ctu_rows
         self.dims = [(g["rows"], g["stride"], g["margin_y"], 64), (g["rows_c"], g["stride_c"], g["margin_y"] >> 1, 32)]
         self.rects, self.positions = oracle_api.cost_pu_list(cfg["shapes"])[:, :4].copy(), oracle_api.cost_positions(cfg["subme"])
-        self.record_bytes = oracle_api.cost_record_bytes(cfg["subme"])
+        self.record_bytes = oracle_api.cost_record_bytes(cfg["subme"], cfg.get("sad_costs", 0))
         self.ctu_bytes = self.record_bytes * len(self.rects) * cfg["candidates"]
         self.pics = {}
         self.tables = [np.zeros(self.nctu * self.ctu_bytes, np.uint8) for _ in range(cfg["slots"])]
@@ -819,7 +820,7 @@ class StreamOracleCostProvider:
             surf = np.ascontiguousarray(surf.reshape(e - b, nc, ng, 4, 85).transpose(0, 1, 2, 4, 3))
             cand = O.cost_candidates(surf, centres[b:e], e - b, w, c["shapes"], c["candidates"], depth=self.depth, mv_cost=pr["mv_cost"])
             tab = O.cost_tables(self.depth, [pf["src"][0], pf["src"][1], pf["src"][2]], ref, g["stride"], g["stride_c"], g["margin_x"], g["margin_y"], g["margin_y"] >> 1,
-                                g["width"], r0, r1 - r0 + 1, c["shapes"], c["candidates"], c["subme"], c["chroma"], cand)
+                                g["width"], r0, r1 - r0 + 1, c["shapes"], c["candidates"], c["subme"], c["chroma"], cand, sad_costs=c.get("sad_costs", 0))
             self.tables[slot][b * self.ctu_bytes:e * self.ctu_bytes] = tab.reshape(-1)
             self.flags[slot][r0:r1 + 1] = self.gen[slot]
             self.rows_served += r1 - r0 + 1
@@ -1062,7 +1063,7 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
     # the cost-table seam (MotionEstimate::subpelCompare's SATD comparisons answered from x265hip_cost_stream's records): "gpu" = the service, "oracle" = CPU checker;
     # cost_cfg = cost_config(preset, opts, ...) - the position set and the chroma flag must be the encode's --subme
     lib.x265ref_cost_seam_configure.argtypes = ([ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_ssize_t] * 2 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                                                ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint, ctypes.c_int])
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_int])
     lib.x265ref_cost_seam_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
     cst = None
     if cost:
@@ -1078,21 +1079,22 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
         cover = sum(1 << sm for sm in range(8) if {tuple(p) for p in _O.cost_positions(sm).tolist()} <= have)
         rc = lib.x265ref_cost_seam_configure(cctx, crows, copen, ctab, crdy, cfg["slots"], geo["width"], geo["height"], geo["stride"], geo["stride_c"], geo["margin_x"], geo["margin_y"],
                                              cfg["candidates"], cfg["subme"], cfg["chroma"], rects.ctypes.data, len(rects), posn.ctypes.data, len(posn), cst.record_bytes, cst.ctu_bytes,
-                                             cfg["window"], cover, int(bool(verify)) | (2 if wait else 0) | (4 if min_ctus == 0 else 0) | (0 if cfg.get("mv_cost", True) else 8))
+                                             cfg["window"], cover, ((8 + 2 * len(posn) + 3) & ~3) if cfg.get("sad_costs") else 0, int(bool(verify)) | (2 if wait else 0) | (4 if min_ctus == 0 else 0) | (0 if cfg.get("mv_cost", True) else 8))
         if rc:
             raise RuntimeError(f"x265ref_cost_seam_configure failed ({rc})")
     else:
-        lib.x265ref_cost_seam_configure(None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, 0, 0, 0, 0, 0, 0)
+        lib.x265ref_cost_seam_configure(None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None, 0, 0, 0, 0, 0, 0, 0)
 
     def report():
         d = stats(lib)
         d.update(prov.report())
         if cst:
-            co = (ctypes.c_uint64 * 13)()
+            co = (ctypes.c_uint64 * 14)()
             lib.x265ref_cost_seam_stats(co)
             d["cost_seam"] = dict(zip(COST_STAT_NAMES, [int(v) for v in co]))
-            asked = d["cost_seam"]["comparisons_served_from_records"] + sum(d["cost_seam"][k] for k in COST_STAT_NAMES[1:5])
-            d["cost_seam"]["served_share_of_satd_comparisons_with_context"] = round(d["cost_seam"]["comparisons_served_from_records"] / asked, 4) if asked else None
+            got = d["cost_seam"]["comparisons_served_from_records"] + d["cost_seam"]["sad_typed_comparisons_served_from_records"]
+            asked = got + sum(d["cost_seam"][k] for k in COST_STAT_NAMES[1:5])
+            d["cost_seam"]["served_share_of_satd_comparisons_with_context"] = round(got / asked, 4) if asked else None
             d["cost_seam"].update(cst.report())
         d.update({"range": rng, "slots": slots, "min_pu": min_pu, "row_granular": bool(streamed), "layout": "planes" if layout else "records", "centre_range": centre_range,
                   "search_seams_left_off_by_the_size_gate": bool(lib.x265ref_seam_min_ctus(-1))})

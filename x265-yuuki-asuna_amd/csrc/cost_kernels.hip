@@ -206,6 +206,7 @@ struct TableArgs
     long strideB, strideCB;
     int marginX, marginY, marginYC;
     int ctusW, ctuRow0, npu, K, npos, recBytes, maxVal;
+    int sadCosts, rec2Off;              // sadCosts: a second { base, delta[] } at rec2Off = the costs of the SAD-typed comparisons (luma SAD + chroma SATD)
     const int16_t* cand;
     uint8_t* tables;
     int8_t pos[COST_MAX_POS][2];
@@ -249,12 +250,32 @@ __device__ __forceinline__ int satd_tile(const uint8_t* f, long fStride, const u
     return sum >> 1;
 }
 
+// the same tile's SAD (sad<4,4>, pixel.cpp:40-55): what a SAD-typed subpelCompare measures on luma
+template <typename Px>
+__device__ __forceinline__ int sad_tile(const uint8_t* f, long fStride, const uint8_t* r, long rStride)
+{
+    uint32_t acc = 0;
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        if (sizeof(Px) == 1) acc = sad4_u8(*reinterpret_cast<const uint32_t*>(f + y * fStride), ld_u32(r + y * rStride), acc);
+        else
+        {
+            const uint2 a = *reinterpret_cast<const uint2*>(f + y * fStride);
+            acc = sad2_u16(a.x, *reinterpret_cast<const u32_align2*>(r + y * rStride), acc);
+            acc = sad2_u16(a.y, *reinterpret_cast<const u32_align2*>(r + y * rStride + 4), acc);
+        }
+    }
+    return (int)acc;
+}
+
 // one wavefront per (CTU of the band, PU, candidate)
 template <typename Px, bool CHROMA>
 __global__ void __launch_bounds__(64) cost_tables_kernel(TableArgs a, const uint8_t* __restrict__ ctuFlags)
 {
     constexpr int BPP = sizeof(Px);
     __shared__ uint32_t acc[COST_MAX_POS];
+    __shared__ uint32_t acc2[COST_MAX_POS];                   // sadCosts: luma SAD + chroma SATD per position
     const int lane = threadIdx.x;
     // COST_WAVES_PER_CTU single-wavefront workgroups per CTU, each walks the CTU's (PU, candidate) pairs with that stride: few enough workgroups that a launch in which
     // the shared-tile kernel served (nearly) every CTU costs next to nothing, enough of them to fill the chip when it served none
@@ -273,7 +294,7 @@ __global__ void __launch_bounds__(64) cost_tables_kernel(TableArgs a, const uint
         for (int i = lane; i < a.recBytes / 4; i += 64) reinterpret_cast<uint32_t*>(rec)[i] = i ? 0u : 0x00008000u;
         continue;
     }
-    for (int i = lane; i < a.npos; i += 64) acc[i] = 0;
+    for (int i = lane; i < a.npos; i += 64) { acc[i] = 0; acc2[i] = 0; }
     __syncthreads();
     const CostPu P = kCostPu[pu];
     const int tw = P.w >> 2, L = tw * (P.h >> 2), cw = P.w >> 3, C = CHROMA ? cw * (P.h >> 3) : 0, T = L + 2 * C;
@@ -283,7 +304,7 @@ __global__ void __launch_bounds__(64) cost_tables_kernel(TableArgs a, const uint
     for (int i0 = 0; i0 < total; i0 += 64)
     {
         const int i = i0 + lane;
-        int v = 0, pos = 0;
+        int v = 0, v2 = 0, pos = 0;
         if (i < total)
         {
             pos = i / T;
@@ -298,6 +319,7 @@ __global__ void __launch_bounds__(64) cost_tables_kernel(TableArgs a, const uint
                 const uint8_t* f = a.fenc[0] + (long)(a.marginY + Y) * a.strideB + (long)(a.marginX + X) * BPP;
                 const uint8_t* r = src + (long)(a.marginY + Y + (qy >> 2)) * a.strideB + (long)(a.marginX + X + (qx >> 2)) * BPP;
                 v = satd_tile<Px>(f, a.strideB, r, a.strideB);
+                if (a.sadCosts) v2 = sad_tile<Px>(f, a.strideB, r, a.strideB);
             }
             else if (CHROMA)
             {
@@ -309,15 +331,20 @@ __global__ void __launch_bounds__(64) cost_tables_kernel(TableArgs a, const uint
                 const uint8_t* f = a.fenc[comp] + (long)(a.marginYC + Y) * a.strideCB + (long)(a.marginX + X) * BPP;
                 const uint8_t* r = src + (long)(a.marginYC + Y + (qy >> 3)) * a.strideCB + (long)(a.marginX + X + (qx >> 3)) * BPP;
                 v = satd_tile<Px>(f, a.strideCB, r, a.strideCB);
+                v2 = v;                                                     // the chroma part of a SAD-typed comparison is SATD too (motion.cpp:1601-1661 adds chromaSatd whatever cmp is)
             }
         }
         if (whole)
         {
             v = group_sum<64>(v);
-            if (lane == 0) acc[i0 / T] += (uint32_t)v;
+            if (a.sadCosts) v2 = group_sum<64>(v2);
+            if (lane == 0) { acc[i0 / T] += (uint32_t)v; if (a.sadCosts) acc2[i0 / T] += (uint32_t)v2; }
         }
         else if (i < total)
+        {
             atomicAdd(&acc[pos], (uint32_t)v);
+            if (a.sadCosts) atomicAdd(&acc2[pos], (uint32_t)v2);
+        }
     }
     __syncthreads();
     uint32_t lo = 0xffffffffu;
@@ -331,6 +358,16 @@ __global__ void __launch_bounds__(64) cost_tables_kernel(TableArgs a, const uint
     }
     uint16_t* delta = reinterpret_cast<uint16_t*>(rec + 8);
     for (int i = lane; i < a.npos; i += 64) delta[i] = (uint16_t)min(acc[i] - lo, 65535u);
+    if (a.sadCosts)
+    {
+        uint32_t lo2 = 0xffffffffu;
+        for (int i = lane; i < a.npos; i += 64) lo2 = min(lo2, acc2[i]);
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) lo2 = min(lo2, (uint32_t)__shfl_xor((int)lo2, m, 64));
+        if (lane == 0) *reinterpret_cast<uint32_t*>(rec + a.rec2Off) = lo2;
+        uint16_t* delta2 = reinterpret_cast<uint16_t*>(rec + a.rec2Off + 4);
+        for (int i = lane; i < a.npos; i += 64) delta2[i] = (uint16_t)min(acc2[i] - lo2, 65535u);
+    }
     __syncthreads();                                         // acc is zeroed again for the next pair
     }
 }
@@ -350,7 +387,7 @@ __global__ void __launch_bounds__(256) cost_tables_shared_kernel(TableArgs a, ui
     __shared__ int16_t sVec[COST_MAX_DISTINCT + 1][2];
     __shared__ uint16_t sIdx[COST_MAX_PU * 2];
     __shared__ int sNd;
-    extern __shared__ uint32_t sMap[];                       // [64 blocks][npos]
+    extern __shared__ uint32_t sMap[];                       // [64 blocks][npos] SATD costs (+ a second map of the SAD-typed costs with sadCosts)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ctuB = blockIdx.x, n = a.npu * a.K, npos = a.npos;
     const int ctuX = ctuB % a.ctusW, ctuY = a.ctuRow0 + ctuB / a.ctusW;
@@ -387,7 +424,8 @@ __global__ void __launch_bounds__(256) cost_tables_shared_kernel(TableArgs a, ui
     const int X0 = ctuX * 64, Y0 = ctuY * 64;
     for (int d = 0; d < nd; d++)
     {
-        for (int i = tid; i < 64 * npos; i += 256) sMap[i] = 0;
+        uint32_t* sMap2 = sMap + 64 * npos;
+        for (int i = tid; i < (a.sadCosts ? 2 : 1) * 64 * npos; i += 256) sMap[i] = 0;
         __syncthreads();
         const int mvx = sVec[d][0], mvy = sVec[d][1];
         const int items = npos * 64 * TPB;
@@ -396,7 +434,7 @@ __global__ void __launch_bounds__(256) cost_tables_shared_kernel(TableArgs a, ui
             const int rest = i / npos, pos = i - rest * npos, block = rest & 63, tile = rest >> 6;
             const int bx = block & 7, by = block >> 3;
             const int qx = mvx * 4 + a.pos[pos][0], qy = mvy * 4 + a.pos[pos][1];
-            int v;
+            int v, v2;
             if (tile < 4)
             {
                 const int X = X0 + bx * 8 + (tile & 1) * 4, Y = Y0 + by * 8 + (tile >> 1) * 4;
@@ -405,6 +443,7 @@ __global__ void __launch_bounds__(256) cost_tables_shared_kernel(TableArgs a, ui
                 const uint8_t* f = a.fenc[0] + (long)(a.marginY + Y) * a.strideB + (long)(a.marginX + X) * BPP;
                 const uint8_t* r = src + (long)(a.marginY + Y + (qy >> 2)) * a.strideB + (long)(a.marginX + X + (qx >> 2)) * BPP;
                 v = satd_tile<Px>(f, a.strideB, r, a.strideB);
+                v2 = a.sadCosts ? sad_tile<Px>(f, a.strideB, r, a.strideB) : 0;
             }
             else
             {
@@ -415,8 +454,10 @@ __global__ void __launch_bounds__(256) cost_tables_shared_kernel(TableArgs a, ui
                 const uint8_t* f = a.fenc[comp] + (long)(a.marginYC + Y) * a.strideCB + (long)(a.marginX + X) * BPP;
                 const uint8_t* r = src + (long)(a.marginYC + Y + (qy >> 3)) * a.strideCB + (long)(a.marginX + X + (qx >> 3)) * BPP;
                 v = satd_tile<Px>(f, a.strideCB, r, a.strideCB);
+                v2 = v;
             }
             atomicAdd(&sMap[block * npos + pos], (uint32_t)v);
+            if (a.sadCosts) atomicAdd(&sMap2[block * npos + pos], (uint32_t)v2);
         }
         __syncthreads();
         for (int pc = wave; pc < n; pc += 4)
@@ -424,32 +465,37 @@ __global__ void __launch_bounds__(256) cost_tables_shared_kernel(TableArgs a, ui
             if (sIdx[pc] != d) continue;
             const CostPu& P = kCostPu[pc / a.K];
             const int bx0 = P.x >> 3, by0 = P.y >> 3, bw = P.w >> 3, bh = P.h >> 3;
-            uint32_t c[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu };
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-            {
-                const int pos = j * 64 + lane;
-                if (pos >= npos) continue;
-                uint32_t sum = 0;
-                for (int y = 0; y < bh; y++)
-                    for (int x = 0; x < bw; x++) sum += sMap[((by0 + y) * 8 + bx0 + x) * npos + pos];
-                c[j] = sum;
-            }
-            uint32_t lo = min(c[0], min(c[1], c[2]));
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, m, 64));
             uint8_t* rec = a.tables + ((size_t)ctuB * n + pc) * a.recBytes;
-            if (lane == 0)
+            for (int which = 0; which < (a.sadCosts ? 2 : 1); which++)
             {
-                reinterpret_cast<int16_t*>(rec)[0] = (int16_t)mvx; reinterpret_cast<int16_t*>(rec)[1] = (int16_t)mvy;
-                reinterpret_cast<uint32_t*>(rec)[1] = lo;
-            }
-            uint16_t* delta = reinterpret_cast<uint16_t*>(rec + 8);
+                const uint32_t* map = which ? sMap2 : sMap;
+                uint32_t c[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu };
 #pragma unroll
-            for (int j = 0; j < 3; j++)
-            {
-                const int pos = j * 64 + lane;
-                if (pos < npos) delta[pos] = (uint16_t)min(c[j] - lo, 65535u);
+                for (int j = 0; j < 3; j++)
+                {
+                    const int pos = j * 64 + lane;
+                    if (pos >= npos) continue;
+                    uint32_t sum = 0;
+                    for (int y = 0; y < bh; y++)
+                        for (int x = 0; x < bw; x++) sum += map[((by0 + y) * 8 + bx0 + x) * npos + pos];
+                    c[j] = sum;
+                }
+                uint32_t lo = min(c[0], min(c[1], c[2]));
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, m, 64));
+                uint8_t* part = which ? rec + a.rec2Off : rec + 4;
+                if (lane == 0)
+                {
+                    if (!which) { reinterpret_cast<int16_t*>(rec)[0] = (int16_t)mvx; reinterpret_cast<int16_t*>(rec)[1] = (int16_t)mvy; }
+                    *reinterpret_cast<uint32_t*>(part) = lo;
+                }
+                uint16_t* delta = reinterpret_cast<uint16_t*>(part + 4);
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                {
+                    const int pos = j * 64 + lane;
+                    if (pos < npos) delta[pos] = (uint16_t)min(c[j] - lo, 65535u);
+                }
             }
         }
         __syncthreads();
@@ -497,17 +543,18 @@ int x265hip_cost_positions(int subme, int8_t* xy, int max_positions)
     return P.n;
 }
 
-int x265hip_cost_record_bytes(int subme)
+int x265hip_cost_record_bytes(int subme, int sad_costs)
 {
     PosSet P;
     if (!positions(subme, P)) return 0;
-    return (8 + 2 * P.n + 3) & ~3;
+    const int one = (8 + 2 * P.n + 3) & ~3;
+    return sad_costs ? one + ((4 + 2 * P.n + 3) & ~3) : one;
 }
 
-size_t x265hip_cost_ctu_bytes(int subme, int shapes, int candidates)
+size_t x265hip_cost_ctu_bytes(int subme, int shapes, int candidates, int sad_costs)
 {
     if (shapes < 0 || shapes > 2 || candidates < 1 || candidates > 2) return 0;
-    return (size_t)x265hip_cost_record_bytes(subme) * pu_count(shapes) * candidates;
+    return (size_t)x265hip_cost_record_bytes(subme, sad_costs) * pu_count(shapes) * candidates;
 }
 
 int x265hip_cost_candidates(const x265hip_cost_candidates_params* p, void* stream)
@@ -546,7 +593,8 @@ int x265hip_cost_tables(const x265hip_cost_tables_params* p, void* stream)
     a.strideB = (long)p->stride * bpp; a.strideCB = (long)p->stride_c * bpp;
     a.marginX = p->margin_x; a.marginY = p->margin_y; a.marginYC = p->margin_y_c;
     a.ctusW = p->width / 64; a.ctuRow0 = p->ctu_row0; a.npu = pu_count(p->shapes); a.K = p->candidates; a.npos = P.n;
-    a.recBytes = (8 + 2 * P.n + 3) & ~3; a.maxVal = (1 << p->depth) - 1;
+    a.sadCosts = p->sad_costs ? 1 : 0; a.rec2Off = (8 + 2 * P.n + 3) & ~3;
+    a.recBytes = x265hip_cost_record_bytes(p->subme, a.sadCosts); a.maxVal = (1 << p->depth) - 1;
     a.cand = p->cand; a.tables = (uint8_t*)p->tables;
     memcpy(a.pos, P.xy, sizeof(a.pos));
     const size_t blocks = (size_t)p->ctu_rows * a.ctusW * COST_WAVES_PER_CTU;
@@ -563,9 +611,15 @@ int x265hip_cost_tables(const x265hip_cost_tables_params* p, void* stream)
         flags = (uint8_t*)stream_scratch(s, 5, (size_t)nctuBand);
         if (!flags) { set_error("cost_tables: no scratch for %d CTU flags", nctuBand); return X265HIP_ENODEV; }
         const int maxDistinct = shared > 1 ? shared : (a.K == 1 ? 10 : 20);       // break-even: a tile evaluated once per vector against once per covering PU
-        const size_t lds = (size_t)64 * P.n * sizeof(uint32_t);
+        const size_t lds = (size_t)(a.sadCosts ? 2 : 1) * 64 * P.n * sizeof(uint32_t);
         const dim3 g2((unsigned)nctuBand), b2(256);
         const int md = maxDistinct > COST_MAX_DISTINCT ? COST_MAX_DISTINCT : maxDistinct;
+        if (lds > 40 * 1024)
+        {
+            // beyond the default dynamic LDS limit (the statics take 4 KB): gfx950 has 160 KB per CU
+            if (bpp == 1) { if (p->chroma) X265HIP_TRY(hipFuncSetAttribute((const void*)cost_tables_shared_kernel<uint8_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); else X265HIP_TRY(hipFuncSetAttribute((const void*)cost_tables_shared_kernel<uint8_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
+            else          { if (p->chroma) X265HIP_TRY(hipFuncSetAttribute((const void*)cost_tables_shared_kernel<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); else X265HIP_TRY(hipFuncSetAttribute((const void*)cost_tables_shared_kernel<uint16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
+        }
         if (bpp == 1) { if (p->chroma) hipLaunchKernelGGL((cost_tables_shared_kernel<uint8_t, true>), g2, b2, lds, s, a, flags, md); else hipLaunchKernelGGL((cost_tables_shared_kernel<uint8_t, false>), g2, b2, lds, s, a, flags, md); }
         else          { if (p->chroma) hipLaunchKernelGGL((cost_tables_shared_kernel<uint16_t, true>), g2, b2, lds, s, a, flags, md); else hipLaunchKernelGGL((cost_tables_shared_kernel<uint16_t, false>), g2, b2, lds, s, a, flags, md); }
         X265HIP_TRY(hipGetLastError());

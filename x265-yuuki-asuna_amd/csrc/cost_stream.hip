@@ -227,7 +227,7 @@ int run_round(CS* s, const std::vector<Upload>& ups, const std::vector<ViewJob>&
             t.phases[pl] = v.dOut[pl];
         }
         t.plane_bytes = s->planeBytes[0]; t.plane_bytes_c = s->planeBytes[1];
-        t.shapes = s->prm.shapes; t.candidates = s->prm.candidates; t.subme = s->prm.subme; t.chroma = s->prm.chroma;
+        t.shapes = s->prm.shapes; t.candidates = s->prm.candidates; t.subme = s->prm.subme; t.chroma = s->prm.chroma; t.sad_costs = s->prm.sad_costs;
         t.cand = s->dCand; t.tables = s->dTables;
         if ((rc = x265hip_cost_tables(&t, s->stream))) return rc;
         X265HIP_TRY(hipMemcpyAsync(sl.tables + (size_t)b.r0 * s->rowBytes, s->dTables, (size_t)n * s->rowBytes, hipMemcpyDeviceToHost, s->stream));
@@ -449,7 +449,7 @@ int x265hip_cost_stream_create(x265hip_cost_stream** out, const x265hip_cost_str
     { set_error("cost_stream_create: chroma geometry pitch %ld margin %d", (long)p->stride_c, p->margin_y_c); return X265HIP_EINVAL; }
     if (p->chroma && !hasC) { set_error("cost_stream_create: chroma costs need the chroma planes"); return X265HIP_EINVAL; }
     if (p->window < 0 || p->window > 32 || p->centre_range < 0 || p->centre_range + 12 > p->margin_x || p->centre_range + 12 > p->margin_y || p->candidates < 1 || p->candidates > 2 || p->shapes < 0 || p->shapes > 2 ||
-        x265hip_cost_record_bytes(p->subme) == 0)
+        x265hip_cost_record_bytes(p->subme, 0) == 0)
     { set_error("cost_stream_create: window %d / centre range %d / %d candidates / shape set %d / subme %d", p->window, p->centre_range, p->candidates, p->shapes, p->subme); return X265HIP_EINVAL; }
     if (p->slots < 1 || p->slots > 256 || p->pictures < 2 || p->pictures > 256 || p->views < 1 || p->views > 64)
     { set_error("cost_stream_create: %d slots / %d pictures / %d views", p->slots, p->pictures, p->views); return X265HIP_EINVAL; }
@@ -473,8 +473,8 @@ int x265hip_cost_stream_create(x265hip_cost_stream** out, const x265hip_cost_str
     s->bandRows = p->band_rows > 0 ? p->band_rows : 8;
     if (s->bandRows > s->ctuRows) s->bandRows = s->ctuRows;
     s->npu = x265hip_cost_pu_count(p->shapes);
-    s->recBytes = x265hip_cost_record_bytes(p->subme);
-    s->ctuBytes = x265hip_cost_ctu_bytes(p->subme, p->shapes, p->candidates);
+    s->recBytes = x265hip_cost_record_bytes(p->subme, p->sad_costs);
+    s->ctuBytes = x265hip_cost_ctu_bytes(p->subme, p->shapes, p->candidates, p->sad_costs);
     s->rowBytes = s->ctuBytes * s->ctusW;
     s->maxCx = maxCx; s->maxCy = maxCy;
     if (p->centre_range && (s->maxCx > p->centre_range)) s->maxCx = p->centre_range;

@@ -18,6 +18,7 @@
 //     ([ctu][mvy][mvx][64 + 16 + 4 + 1]) so a wavefront stores 340 contiguous bytes, and/or folded into a per-PU running minimum of
 //     (cost << 32 | raster index) that is merged across wavefronts with one 64-bit atomicMin.
 #include "common.h"
+#include <mutex>
 
 #include <cstdlib>
 #include <type_traits>
@@ -1272,6 +1273,55 @@ int launch_me_cand(const x265hip_me_params* p, hipStream_t s);       // me_cand_
 static const bool W2_DEFAULT = true;          // the 16-bit twin (me_ctu_w2_kernel): 2.60 -> 2.35 ms at 4K, 9.95 -> 8.95 ms at 8K (one box, interleaved: profiles/r05_me10_ab.txt)
 static const int Q2_DEFAULT_FLAGS = 254;      // CTAB | PAIR64 | DEFERX | COLMIN | MASK | RING | QUAD64: 1.24 ms against round 4's 1.42 at 4K (three interleaved rounds)
 
+// Every A/B switch of the search launches, read ONCE (round-5 advisor: some were read per launch - getenv in a hot path, not thread-safe against setenv in the host
+// process - and x265hip_me_minima_kernel_name re-derived the selection on its own and could disagree with the launch).  x265hip_me_env_refresh() re-reads them: a
+// TEST-ONLY hook for the parity tests and soaks that flip a switch between launches of one process.
+struct MeEnv
+{
+    bool split, generic, cand;
+    int bestVar;            // X265HIP_ME_BEST_VARIANT & 3, -1 = unset
+    int q2Flags;            // X265HIP_ME_Q2_FLAGS, or the default / -1 that follows from bestVar
+    int bestWaves;
+    bool splitGroups8, splitGroups16;
+    bool w2;
+};
+static MeEnv g_meEnv;
+static std::once_flag g_meEnvOnce;
+static void me_env_read()
+{
+    MeEnv e;
+    e.split = getenv("X265HIP_ME_SPLIT") != nullptr;
+    e.generic = getenv("X265HIP_ME_GENERIC") != nullptr;
+    const char* which = getenv("X265HIP_ME_KERNEL");
+    e.cand = which && which[0] == 'c';
+    const char* bv = getenv("X265HIP_ME_BEST_VARIANT");
+    e.bestVar = bv ? atoi(bv) & 3 : -1;
+    const char* q2 = getenv("X265HIP_ME_Q2_FLAGS");
+    e.q2Flags = q2 ? atoi(q2) : (bv ? -1 : Q2_DEFAULT_FLAGS);
+    e.bestWaves = getenv("X265HIP_ME_BEST_WAVES") ? atoi(getenv("X265HIP_ME_BEST_WAVES")) : 0;
+    const char* sg = getenv("X265HIP_ME_SPLIT_GROUPS");
+    e.splitGroups8 = !(sg && atoi(sg) == 0);
+    e.splitGroups16 = sg && atoi(sg) == 1;
+    const char* w2 = getenv("X265HIP_ME_W2");
+    e.w2 = w2 ? atoi(w2) != 0 : W2_DEFAULT;
+    g_meEnv = e;
+}
+static const MeEnv& me_env()
+{
+    std::call_once(g_meEnvOnce, me_env_read);
+    return g_meEnv;
+}
+// LDS row pitch (bytes) of a launch: the power of two that holds the widest payload of the kernels of that sample size + the largest skew (17 dwords)
+static int me_pitch_bytes(int bpp, int range)
+{
+    const int nld = bpp == 1 ? MECfg<uint8_t>::NLD : MECfg<uint16_t>::NLD;
+    const int payload = (3 + (56 + 2 * range) * bpp + 4 * nld + 3) >> 2;
+    const int payloadW = bpp == 2 ? (3 + (56 + 2 * range) * 2 + 4 * 6 + 3) >> 2 : payload;
+    int pitchDw = 64;
+    while (pitchDw < (payloadW > payload ? payloadW : payload) + 17) pitchDw <<= 1;
+    return pitchDw * 4;
+}
+
 static int pick_waves(int ncols)
 {
     return ncols >= 16 ? 16 : (ncols < 4 ? 4 : ncols);
@@ -1280,8 +1330,9 @@ static int pick_waves(int ncols)
 template <typename Px>
 static int launch_me(const x265hip_me_params* p, hipStream_t s)
 {
-    static const bool p_split = getenv("X265HIP_ME_SPLIT") != nullptr;       // surfaces-then-minima pair of launches instead of the fused one (A/B runs)
-    static const bool p_generic = getenv("X265HIP_ME_GENERIC") != nullptr;   // force the generic (v_sad) kernel (A/B runs); both read once
+    const MeEnv& env = me_env();
+    const bool p_split = env.split;         // surfaces-then-minima pair of launches instead of the fused one (A/B runs)
+    const bool p_generic = env.generic;     // force the generic (v_sad) kernel (A/B runs)
     constexpr int BPP = PxInfo<Px>::BPP;
     MEArgs a;
     a.fenc = (const uint8_t*)p->fenc;  a.fencStrideB = (long)p->fenc_stride * BPP;
@@ -1294,9 +1345,8 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     // +-13 and +-77 the generic payload + skew is exactly a power of two and the fast path refused with an "internal" error: found by
     // tools/r3_soak.py, round 3)
     const int payloadW = sizeof(Px) == 2 ? (3 + (56 + 2 * p->range) * 2 + 4 * 6 + 3) >> 2 : payload;
-    int pitchDw = 64;                                          // power-of-two pitch >= payload + max skew (17 dwords)
-    while (pitchDw < (payloadW > payload ? payloadW : payload) + 17) pitchDw <<= 1;
-    a.rowBytes = pitchDw * 4;
+    (void)payloadW;
+    a.rowBytes = me_pitch_bytes(BPP, p->range);                // power-of-two pitch >= payload + max skew (17 dwords): the same function names the kernel
     a.surf = p->surf; a.best = (unsigned long long*)p->best;
     const bool anySurf = p->surf != nullptr, anyBest = p->best != nullptr;
     const bool packed = anySurf && p->surf_format == X265HIP_SURF_PACKED;
@@ -1318,9 +1368,8 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     // record-contiguous formats and for minima alone the row-walking kernels below are faster (1.76 / 1.34 ms against 3.2 / 1.42 ms at
     // 4K, profiles/r02_me_cand_ab.txt).  X265HIP_ME_KERNEL=cand forces it for every 8-bit launch (parity tests, A/B).
     {
-        const char* which = getenv("X265HIP_ME_KERNEL");
         const bool wantT = p->surf && (p->surf_format == X265HIP_SURF_PACKED_T || p->surf_format == X265HIP_SURF_PACKED_B);
-        if (sizeof(Px) == 1 && !p_generic && (wantT || (which && which[0] == 'c')))
+        if (sizeof(Px) == 1 && !p_generic && (wantT || env.cand))
         {
             const int rc = launch_me_cand(p, s);
             if (rc <= 0) return rc;
@@ -1331,11 +1380,9 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     if (sizeof(Px) == 1 && a.rowBytes == 256 && !p_generic)
     {
         // 8-bit fast path (v_qsad_pk_u16_u8); 2 * range + 75 bytes of window row must fit the 256-byte pitch
-        const char* bestVarEnv = getenv("X265HIP_ME_BEST_VARIANT");       // A/B and the parity test of every variant: read per launch
-        const int bestVar = bestVarEnv ? atoi(bestVarEnv) & 3 : -1;
-        const char* q2Env = getenv("X265HIP_ME_Q2_FLAGS");               // round 5's flagged kernel (me_ctu_q2_kernel<256, FL>): A/B and parity tests; unset = the default below
-        const int q2Flags = q2Env ? atoi(q2Env) : (bestVarEnv ? -1 : Q2_DEFAULT_FLAGS);
-        static const int bestWaves = getenv("X265HIP_ME_BEST_WAVES") ? atoi(getenv("X265HIP_ME_BEST_WAVES")) : 0;       // A/B: wavefronts per workgroup of the minima-only launch
+        const int bestVar = env.bestVar;           // A/B and the parity test of every variant
+        const int q2Flags = env.q2Flags;           // round 5's flagged kernel (me_ctu_q2_kernel<256, FL>): A/B and parity tests; unset = the default
+        const int bestWaves = env.bestWaves;       // A/B: wavefronts per workgroup of the minima-only launch
         // 4K and up: 12 wavefronts per workgroup instead of 16 - step 1.875 -> 1.823 ms at 4K on one box, three interleaved rounds (8 does the same, 10 and 6 lose;
         // at 1080p 16 stays best): profiles/r04_me_minima_ab.txt
 #define LAUNCH_QV(V) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 12) nwq = 12; \
@@ -1363,7 +1410,7 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
                     // few CTUs (a band of the ring: 2 CTU rows of a 4K picture = 120; a small picture): one workgroup per CTU would leave most of the 256 CUs idle -
                     // 8 column groups per workgroup of 8 wavefronts instead, ceil(groups / 8) workgroups per CTU (X265HIP_ME_SPLIT_GROUPS=0: off, A/B).  Banded 4K 8-bit steps
                     // (2 / 3 / 4 CTU rows per band): 3.11 / 2.72 / 2.43 -> 2.95 / 2.49 / 2.38 ms, one box, interleaved (profiles/r05_band_tables.txt)
-                    static const bool splitGroups = !(getenv("X265HIP_ME_SPLIT_GROUPS") && atoi(getenv("X265HIP_ME_SPLIT_GROUPS")) == 0);
+                    const bool splitGroups = env.splitGroups8;
                     const int ngroups = (2 * p->range + 4) / 4;
                     int gPer = 0;
                     dim3 grid2 = grid;
@@ -1397,8 +1444,8 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
         const int plw = (3 + (56 + 2 * p->range) * 2 + 4 * 6 + 3) >> 2;                 // the group kernel reads 6 dwords per row
         a.payloadDw = plw > a.payloadDw ? plw : a.payloadDw;
         if (a.payloadDw + 17 > a.rowBytes / 4) { set_error("me_fullsearch: internal: window row does not fit the LDS pitch"); return X265HIP_EINVAL; }
-        static const int bestVarW = getenv("X265HIP_ME_BEST_VARIANT") ? atoi(getenv("X265HIP_ME_BEST_VARIANT")) & 3 : -1;      // A/B, read once
-        static const int bestWavesW = getenv("X265HIP_ME_BEST_WAVES") ? atoi(getenv("X265HIP_ME_BEST_WAVES")) : 0;
+        const int bestVarW = env.bestVar;      // A/B
+        const int bestWavesW = env.bestWaves;
 #define LAUNCH_WV(V) do { int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 12) nwq = 12;      /* 4K: step 3.20 -> 3.18 ms, 8K 12.61 -> 12.53 */ \
         if (bestWavesW >= 4 && bestWavesW <= 16) nwq = bestWavesW; \
         if (a.rowBytes == 256) hipLaunchKernelGGL((me_ctu_w_kernel<false, true, 256, V>), grid, dim3(nwq * 64), lds, s, a); \
@@ -1416,15 +1463,14 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
             if (anySurf) LAUNCH_W(true, false, 16);
             if (anyBest)
             {
-                const char* w2Env = getenv("X265HIP_ME_W2");                 // round 5's kernel (me_ctu_w2_kernel): 0 = round 4's (A/B), unset = W2_DEFAULT
-                const bool w2 = (w2Env ? atoi(w2Env) != 0 : W2_DEFAULT) && bestVarW < 0 && p->range <= 120;
+                const bool w2 = env.w2 && bestVarW < 0 && p->range <= 120;      // round 5's kernel (me_ctu_w2_kernel): X265HIP_ME_W2=0 = round 4's (A/B)
                 if (w2)
                 {
                     int nwq = pick_waves((2 * p->range + 4) / 4); if (nwq > 16) nwq = 16; if (nctu >= 1024 && nwq > 12) nwq = 12;
                     if (bestWavesW >= 4 && bestWavesW <= 16) nwq = bestWavesW;
                     // off by default at 16 bits: the 92 KB window leaves room for ONE workgroup per CU, so four small workgroups per CTU run in two rounds at half the
                     // occupancy - banded 4K 10-bit steps 4.45 / 4.05 / 3.80 ms (2 / 3 / 4 CTU rows per band) became 4.50 / 4.25 / 3.80 (profiles/r05_band_tables.txt); 1 = on (A/B)
-                    static const bool splitGroupsW = getenv("X265HIP_ME_SPLIT_GROUPS") && atoi(getenv("X265HIP_ME_SPLIT_GROUPS")) == 1;
+                    const bool splitGroupsW = env.splitGroups16;
                     const int ngroups = (2 * p->range + 4) / 4;
                     int gPer = 0;
                     dim3 grid2 = grid;
@@ -1464,19 +1510,27 @@ using namespace x265hip;
 
 extern "C" const char* x265hip_me_minima_kernel_name(int depth, int range)
 {
+    // the SAME switches and the SAME pitch function as launch_me: what this returns is what a minima-only launch runs
     static thread_local char name[64];
+    const MeEnv& env = me_env();
+    const int bpp = depth == 8 ? 1 : 2, pitch = me_pitch_bytes(bpp, range);
     if (depth != 8)
     {
-        const char* w2Env = getenv("X265HIP_ME_W2");
-        return ((w2Env ? atoi(w2Env) != 0 : W2_DEFAULT) && !getenv("X265HIP_ME_BEST_VARIANT") && range <= 120 && depth <= 10) ? "me_ctu_w2_kernel" : "me_ctu_w_kernel<best>";
+        if (env.generic || depth > 10 || pitch > 512) return "me_ctu_kernel<u16,best>";          // 12 bits, or a window row beyond the 512-byte pitch (+-76 and up at 16 bits)
+        return (env.w2 && env.bestVar < 0 && range <= 120) ? "me_ctu_w2_kernel" : "me_ctu_w_kernel<best>";
     }
-    if (((74 + 2 * range) >> 2) + 17 > 64) return "me_ctu_kernel<u8,best>";       // the window row + the largest skew must fit the 256-byte LDS pitch: +-58
-    const char* bestVarEnv = getenv("X265HIP_ME_BEST_VARIANT");
-    const char* q2Env = getenv("X265HIP_ME_Q2_FLAGS");
-    const int q2Flags = q2Env ? atoi(q2Env) : (bestVarEnv ? -1 : Q2_DEFAULT_FLAGS);
-    if (q2Flags < 0 || range > 120 || (bestVarEnv && (atoi(bestVarEnv) & 3))) return "me_ctu_q_kernel<best>";
-    snprintf(name, sizeof(name), "me_ctu_q2_kernel<256,%d>", q2Flags);
+    if (env.cand && !env.generic) return "me_ctu_c_kernel (record per lane)";
+    if (env.generic || pitch != 256) return "me_ctu_kernel<u8,best>";                            // the window row + the largest skew must fit the 256-byte LDS pitch: +-58
+    if (env.q2Flags < 0 || range > 120 || env.bestVar > 0) return "me_ctu_q_kernel<best>";
+    snprintf(name, sizeof(name), "me_ctu_q2_kernel<256,%d>", env.q2Flags);
     return name;
+}
+
+/* TEST-ONLY: re-read the X265HIP_ME_* switches (they are read once per process otherwise).  Not for use while launches are in flight on other threads. */
+extern "C" void x265hip_me_env_refresh(void)
+{
+    (void)me_env();
+    me_env_read();
 }
 
 extern "C" int x265hip_me_fullsearch(const x265hip_me_params* p, void* stream)

@@ -295,8 +295,13 @@ int run_round(S* s, const std::vector<Upload>& ups, const std::vector<Weigh>& we
     return 0;
 }
 
+struct PendingPins { hipEvent_t ev; std::vector<int> pics; };
+
 void worker_main(S* s)
 {
+    std::vector<PendingPins> pending;
+    std::vector<hipEvent_t> spareEvents;
+    (void)hipSetDevice(s->device);
     for (;;)
     {
         std::vector<Upload> ups;
@@ -304,8 +309,32 @@ void worker_main(S* s)
         std::vector<Band> bands;
         {
             std::unique_lock<std::mutex> lk(s->mu);
-            s->cv.wait(lk, [s] { return s->stop || s->dirty; });
-            if (s->stop) return;
+            // rounds without bands leave their pins to an event (round-5 advisor: a blocking wait there serialised upload and search scheduling while rows arrive one
+            // at a time): whatever has completed is unpinned here; while pins are outstanding the wait is bounded, so they never outlive their copies by much
+            auto reap = [&] {
+                for (size_t i = 0; i < pending.size();)
+                    if (hipEventQuery(pending[i].ev) != hipErrorNotReady)
+                    {
+                        for (int pic : pending[i].pics) s->pics[pic].busy--;
+                        spareEvents.push_back(pending[i].ev);
+                        pending.erase(pending.begin() + i);
+                    }
+                    else i++;
+            };
+            reap();
+            while (!s->stop && !s->dirty)
+            {
+                if (pending.empty()) s->cv.wait(lk, [s] { return s->stop || s->dirty; });
+                else { s->cv.wait_for(lk, std::chrono::milliseconds(1), [s] { return s->stop || s->dirty; }); reap(); }
+            }
+            if (s->stop)
+            {
+                lk.unlock();
+                (void)hipStreamSynchronize(s->compute);
+                for (auto& p : pending) (void)hipEventDestroy(p.ev);
+                for (auto& e : spareEvents) (void)hipEventDestroy(e);
+                return;
+            }
             s->dirty = false;
             for (int i = 0; i < (int)s->pics.size(); i++)
             {
@@ -371,14 +400,34 @@ void worker_main(S* s)
         }
         if (ups.empty() && weighs.empty() && bands.empty()) continue;
         const double t0 = ms_now_us();
+        bool failedRound = false;
         if (run_round(s, ups, weighs, bands))
         {
             s->failed += bands.size() + 1;
             snprintf(s->workerError, sizeof(s->workerError), "%s", x265hip_last_error());
+            failedRound = true;
         }
-        // bands end with a wait for their downloads (everything queued before them on the compute stream has run by then); a round without
-        // bands waits for its uploads / weighted rows here - then the pins go
-        if (bands.empty()) (void)hipStreamSynchronize(s->compute);
+        // Bands end with a wait for their downloads (everything queued before them on the compute stream has run by then).  A round without bands leaves its
+        // pins to an EVENT recorded behind its uploads / weighted rows and carries on; a round that FAILED may have stopped anywhere, e.g. before its bands'
+        // download wait: both streams are drained before its pins go (the uploads still queued would otherwise read an entry a host thread is staging anew).
+        bool deferred = false;
+        if (failedRound) { (void)hipStreamSynchronize(s->compute); (void)hipStreamSynchronize(s->copy); }
+        else if (bands.empty())
+        {
+            hipEvent_t ev = nullptr;
+            if (!spareEvents.empty()) { ev = spareEvents.back(); spareEvents.pop_back(); }
+            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+            if (ev && hipEventRecord(ev, s->compute) == hipSuccess)
+            {
+                PendingPins pp; pp.ev = ev;
+                for (const Upload& u : ups) pp.pics.push_back(u.pic);
+                for (const Weigh& q : weighs) { pp.pics.push_back(q.pic); pp.pics.push_back(q.parent); }
+                pending.push_back(pp);
+                deferred = true;
+            }
+            else (void)hipStreamSynchronize(s->compute);
+        }
+        if (!deferred)
         {
             std::lock_guard<std::mutex> lk(s->mu);
             for (const Upload& u : ups) s->pics[u.pic].busy--;

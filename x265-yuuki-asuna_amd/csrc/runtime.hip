@@ -160,27 +160,27 @@ const char* x265hip_last_error(void) { return t_err; }
 
 /* A host that destroys a stream tells the library first (round-4 advisor, low: per-stream state otherwise only ever grows).  The scratch buffers the stream's calls
  * used (x265hip_me_search, split x265hip_lowres_cost) go back to the spare pool - the next stream that needs one adopts it instead of allocating, so a process that
- * creates and destroys streams keeps a bounded footprint - and the stream's enqueue-sequence lock is dropped.  Buffers are never freed here: a HIP graph captured on
+ * creates and destroys streams keeps a bounded footprint (the stream's enqueue-sequence lock node stays: see below).  Buffers are never freed here: a HIP graph captured on
  * the stream may still hold them, which is also why a stream whose graphs are still replayed must NOT be released (its buffers would be handed to another stream).
  * Call it with the stream idle, before hipStreamDestroy.  Returns the number of buffers returned to the pool, X265HIP_EBUSY while another thread is enqueuing on it. */
 int x265hip_stream_release(void* stream)
 {
-    int dev = 0;
-    if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return X265HIP_ENODEV;
     const hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_scratchMu);
-    auto m = g_seqMu.find(std::make_pair(dev, s));
-    if (m != g_seqMu.end())
-    {
-        if (!m->second.try_lock()) { set_error("stream_release: another thread is enqueuing on this stream"); return X265HIP_EBUSY; }
-        m->second.unlock();
-        g_seqMu.erase(m);
-    }
+    // The stream is looked up on EVERY device (round-5 advisor: keyed on the caller's current device, a stream of another device silently released nothing).
+    // Its sequence-lock node is KEPT: stream_sequence_lock() takes the node's address under g_scratchMu and locks it after dropping g_scratchMu, so a node erased
+    // here could be locked after its destruction; a mutex per (device, stream) ever seen is a few dozen bytes.  EBUSY while somebody holds it.
+    for (auto& m : g_seqMu)
+        if (m.first.second == s)
+        {
+            if (!m.second.try_lock()) { set_error("stream_release: another thread is enqueuing on this stream"); return X265HIP_EBUSY; }
+            m.second.unlock();
+        }
     int n = 0;
     for (auto it = g_scratch.begin(); it != g_scratch.end();)
-        if (it->first.dev == dev && it->first.s == s)
+        if (it->first.s == s)
         {
-            if (it->second.p) { g_scratchSpare[std::make_pair(dev, it->first.slot)].push_back(it->second); n++; }
+            if (it->second.p) { g_scratchSpare[std::make_pair(it->first.dev, it->first.slot)].push_back(it->second); n++; }
             it = g_scratch.erase(it);
         }
         else ++it;

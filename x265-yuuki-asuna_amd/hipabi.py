@@ -1046,7 +1046,7 @@ class CostTablesParams(ctypes.Structure):
                 ("fenc", ctypes.c_void_p * 3), ("ref", ctypes.c_void_p * 3), ("phases", ctypes.c_void_p * 3),
                 ("plane_bytes", ctypes.c_size_t), ("plane_bytes_c", ctypes.c_size_t),
                 ("shapes", ctypes.c_int), ("candidates", ctypes.c_int), ("subme", ctypes.c_int), ("chroma", ctypes.c_int),
-                ("cand", ctypes.c_void_p), ("tables", ctypes.c_void_p)]
+                ("cand", ctypes.c_void_p), ("tables", ctypes.c_void_p), ("sad_costs", ctypes.c_int)]
 
 
 class CostStreamParams(ctypes.Structure):
@@ -1055,7 +1055,7 @@ class CostStreamParams(ctypes.Structure):
                 ("stride", ctypes.c_ssize_t), ("margin_x", ctypes.c_int), ("margin_y", ctypes.c_int),
                 ("stride_c", ctypes.c_ssize_t), ("margin_y_c", ctypes.c_int),
                 ("centre_range", ctypes.c_int), ("window", ctypes.c_int),
-                ("candidates", ctypes.c_int), ("shapes", ctypes.c_int), ("subme", ctypes.c_int), ("chroma", ctypes.c_int),
+                ("candidates", ctypes.c_int), ("shapes", ctypes.c_int), ("subme", ctypes.c_int), ("chroma", ctypes.c_int), ("sad_costs", ctypes.c_int),
                 ("slots", ctypes.c_int), ("pictures", ctypes.c_int), ("views", ctypes.c_int), ("band_rows", ctypes.c_int), ("device_plus_1", ctypes.c_int)]
 
 
@@ -1089,14 +1089,14 @@ def cost_positions(subme):
     return out[:n].copy()
 
 
-def cost_record_bytes(subme):
-    return lib().x265hip_cost_record_bytes(subme)
+def cost_record_bytes(subme, sad_costs=0):
+    return lib().x265hip_cost_record_bytes(subme, int(bool(sad_costs)))
 
 
-def cost_ctu_bytes(subme, shapes, candidates):
+def cost_ctu_bytes(subme, shapes, candidates, sad_costs=0):
     L = lib()
     L.x265hip_cost_ctu_bytes.restype = ctypes.c_size_t
-    return L.x265hip_cost_ctu_bytes(subme, shapes, candidates)
+    return L.x265hip_cost_ctu_bytes(subme, shapes, candidates, int(bool(sad_costs)))
 
 
 def cost_candidates(surf, centres, nctu, window, shapes, candidates, cand, stream=None, mv_cost=None):
@@ -1107,7 +1107,7 @@ def cost_candidates(surf, centres, nctu, window, shapes, candidates, cand, strea
 
 
 def cost_tables(depth, width, stride, margin_x, margin_y, stride_c, margin_y_c, ctu_row0, ctu_rows, fenc, ref, phases, plane_bytes, plane_bytes_c,
-                shapes, candidates, subme, chroma, cand, tables, stream=None):
+                shapes, candidates, subme, chroma, cand, tables, stream=None, sad_costs=0):
     """fenc / ref / phases: three device tensors each (allocation starts; chroma entries None when chroma = 0)."""
     L = lib()
     L.x265hip_cost_tables.argtypes = [ctypes.POINTER(CostTablesParams), ctypes.c_void_p]
@@ -1118,5 +1118,5 @@ def cost_tables(depth, width, stride, margin_x, margin_y, stride_c, margin_y_c, 
         p.fenc[i], p.ref[i], p.phases[i] = _p(fenc[i]), _p(ref[i]), _p(phases[i])
     p.plane_bytes, p.plane_bytes_c = plane_bytes, plane_bytes_c
     p.shapes, p.candidates, p.subme, p.chroma = shapes, candidates, subme, int(bool(chroma))
-    p.cand, p.tables = _p(cand), _p(tables)
+    p.cand, p.tables, p.sad_costs = _p(cand), _p(tables), int(bool(sad_costs))
     check(L.x265hip_cost_tables(ctypes.byref(p), current_stream() if stream is None else stream), "x265hip_cost_tables")
