@@ -50,8 +50,10 @@ int         x265hip_init(int device);          /* device >= 0: validate (gfx950)
 
 /* ------------------------------------------------------------------ 1. table layer */
 /* Overwrite the GPU-backed slots of an EncoderPrimitives-layout table (18240 bytes, see
- * include/x265hip_table.h) for the given bit depth.  Slots the GPU path does not implement are
- * left untouched (the caller's C/asm entries stay).  `table_bytes` must equal the table size.
+ * include/x265hip_table.h) for the given bit depth: every slot the reference's C filler sets (primitives.cpp:250-282) is GPU-backed
+ * from round 6 on - the frame-level helpers and the RDOQ helpers (rows a16 / a9) included.  Two slots, costCoeffNxN and costC1C2Flag, price
+ * context-coded bins with the host's own per-state table: they are written only when x265hip_set_entropy_bits() was called before;
+ * otherwise the caller's C/asm entries stay.  `table_bytes` must equal the table size.
  * Returns the number of slots written, or a negative error. */
 int x265hip_setup_primitives(void* table, size_t table_bytes, int depth);
 /* Number of table calls served by the GPU since init (to prove stubs really ran). */
@@ -947,6 +949,60 @@ enum x265hip_lf_kind
 };
 int x265hip_loopfilter_batch(int kind, int depth, const x265hip_plane planes[4], const x265hip_job* jobs, int njobs,
                              uint32_t* result, void* stream);
+
+/* Frame-level helpers (csrc/frame_coeff_kernels.hip).  src = plane 0 (off[0]), dst = plane 1 (off[1]), offsets and
+ * strides in elements of the operand's own type; w x h is the size every job of the batch shares.
+ *   PLANECOPY_CP     : planecopy_cp (pixel.cpp:864-874), uint8 -> pixel;   arg = {shift}
+ *   PLANECOPY_SP     : planecopy_sp (:876-886), uint16 -> pixel;           arg = {shift, mask}      (src >> shift) & mask
+ *   PLANECOPY_SP_SHL : planecopy_sp_shl (:888-898), uint16 -> pixel;       arg = {shift, mask}      (src << shift) & mask
+ *   PLANECOPY_PP_SHR : planecopy_pp_shr (:900-910), pixel -> pixel;        arg = {shift}
+ *   PLANE_CLIP_MAX   : planeClipAndMax (:996-1016), plane 0 clamped IN PLACE to arg = {minPix, maxPix}; out uint64 [job][2] = {maximum, sum}
+ *   SSIM_CORE        : ssim_4x4x2_core (:631-657), pix1 = plane 0, pix2 = plane 1 (w, h unused); out int32 [job][2][4]
+ *   SSIM_END4        : ssim_end_4 (:659-701), sum0 = plane 0, sum1 = plane 1 (int32 [5][4] each); arg = {width 1..4}; out float [job]
+ *                      (integer moment arithmetic at depth 8, float above: the reference's HIGH_BIT_DEPTH split)
+ *   FIX8_PACK        : cuTreeFix8Pack (:945-950), double -> uint16, w = count (h unused)
+ *   FIX8_UNPACK      : cuTreeFix8Unpack (:952-958), uint16 -> double, w = count */
+enum x265hip_frame_kind
+{
+    X265HIP_FR_PLANECOPY_CP = 0, X265HIP_FR_PLANECOPY_SP, X265HIP_FR_PLANECOPY_SP_SHL, X265HIP_FR_PLANECOPY_PP_SHR, X265HIP_FR_PLANE_CLIP_MAX,
+    X265HIP_FR_SSIM_CORE, X265HIP_FR_SSIM_END4, X265HIP_FR_FIX8_PACK, X265HIP_FR_FIX8_UNPACK
+};
+int x265hip_frame_batch(int kind, int depth, int w, int h, const x265hip_plane planes[2], const x265hip_job* jobs, int njobs,
+                        void* out, void* stream);
+/* frameInitLowres / frameInitLowerRes (pixel.cpp:604-629) of any size: `src` is read up to row 2 * height and column 2 * width; DEVICE
+ * pointers.  (x265hip_lowres_init is the whole-picture form with the border extension fused.) */
+int x265hip_frame_init_lowres(int depth, const void* src, intptr_t src_stride, void* const dst[4], intptr_t dst_stride,
+                              int width, int height, void* stream);
+/* propagateCost = estimateCUPropagateCost (pixel.cpp:914-943) over `len` lowres blocks, DEVICE pointers; fps_factor as the slot takes it
+ * (divided by 256 inside).  (x265hip_cutree_propagate is the fused form with the scatter to the references.) */
+int x265hip_propagate_cost(int32_t* dst, const uint16_t* propagate_in, const int32_t* intra_costs, const uint16_t* inter_costs,
+                           const int32_t* inv_qscales, double fps_factor, int len, void* stream);
+
+/* RDOQ helpers of Quant::rdoQuant (reference dct.cpp:757-1069; call sites quant.cpp:683-830, 1301, entropy.cpp:1856-2112),
+ * batch forms: one call of the slot per job, thousands of coefficient groups per launch.  The CABAC state makes every call serial inside
+ * (a lane walks it); each job works on its OWN copy of the context bytes.  bufs[0..4] are DEVICE base pointers, off[k] the element offset
+ * of the job's operand in bufs[k]:
+ *   SCAN_POS_LAST        : scanPosLast.   bufs0 scan (uint16), bufs1 coeff (int16), out bufs2 coeffSign / bufs3 coeffFlag (uint16 [64]),
+ *                          bufs4 coeffNum (uint8 [64]); arg = {numSig, trSize}; result = the last scan position
+ *   FIND_POS_FIRST_LAST  : findPosFirstLast.  bufs0 scanTbl (uint16 [16]), bufs1 the group's first coefficient; arg = {trSize}; result = packed
+ *   COST_COEFF_NXN       : costCoeffNxN.  bufs0 scan (uint16 [16]), bufs1 the group's first coefficient, bufs2 absCoeff (uint16 out, the pointer the
+ *                          caller passes: the levels of the non-zeros in coding order from [0]), bufs3 tabSigCtx (uint8 [16]), bufs4 baseCtx (uint8, updated);
+ *                          arg = {trSize, scanFlagMask, offset, scanPosSigOff, subPosBase}; result = bits
+ *   COST_COEFF_REMAIN    : costCoeffRemain.  bufs2 absCoeff; arg = {numNonZero, idx}; result = bits
+ *   COST_C1C2            : costC1C2Flag.  bufs2 absCoeff, bufs4 baseCtxMod (updated); arg = {numC1Flag, ctxOffset}; result = packed
+ *   RDOQ_NONPSY / _PSY / _PSY_1P / _PSY_2P : cu[].nonPsyRdoQuant / psyRdoQuant / psyRdoQuant_1p / _2p of ONE coefficient group.  bufs0 fenc's
+ *                          transform, bufs1 the residual's transform (int16, block origin), bufs2 costUncoded (int64, block origin), bufs3
+ *                          {totalUncodedCost, totalRdCost} (int64 [2], added to), bufs4 psyScale (int64); arg = {blkPos, log2TrSize, row stride or 0 = 1 << log2TrSize}; no result
+ * costCoeffNxN / costC1C2Flag price bins with the HOST's per-state table: hand g_entropyBits (entropy.cpp:2611; x265_entropyStateBits is
+ * accepted as well, its top byte is ignored) to x265hip_set_entropy_bits once - the table is the encoder's data, not this library's. */
+enum x265hip_coeff_kind
+{
+    X265HIP_CF_SCAN_POS_LAST = 0, X265HIP_CF_FIND_POS_FIRST_LAST, X265HIP_CF_COST_COEFF_NXN, X265HIP_CF_COST_COEFF_REMAIN, X265HIP_CF_COST_C1C2,
+    X265HIP_CF_RDOQ_NONPSY, X265HIP_CF_RDOQ_PSY, X265HIP_CF_RDOQ_PSY_1P, X265HIP_CF_RDOQ_PSY_2P
+};
+typedef struct x265hip_coeff_job { int64_t off[5]; int32_t arg[5]; int32_t reserved; } x265hip_coeff_job;
+int x265hip_set_entropy_bits(const uint32_t* bits128);
+int x265hip_coeff_batch(int kind, int depth, void* const bufs[5], const x265hip_coeff_job* jobs, int njobs, uint32_t* result, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -896,9 +896,16 @@ def load_reference(depth, root):
     return spec.Table(lib.x265ref_table(), depth, lib)
 
 
+def host_tables(root):
+    import json
+    import os
+    return json.load(open(os.path.join(root, "tests", "golden", "host_tables.json")))
+
+
 def load_oracle(depth, root, avx2=False, host=False, entropy_from=None):
     """The C restatement's table.  host=True also fills the host-side slots (rows a9 / a16, oracle/x265_oracle_host.c);
-    their CABAC bit-cost table is handed in from `entropy_from` (the reference Table) - see that file's header."""
+    their CABAC bit-cost table is handed in from `entropy_from` (the reference Table) or, without one, from the committed fixture -
+    see that file's header."""
     import os
     path = os.path.join(root, "oracle", "_build", "libx265oracle_avx2.so" if avx2 else "libx265oracle.so")
     lib = ctypes.CDLL(path)
@@ -908,6 +915,8 @@ def load_oracle(depth, root, avx2=False, host=False, entropy_from=None):
         getattr(lib, f"x265oracle_setup_host_primitives_d{depth}")(ctypes.byref(mem))
         if entropy_from is not None:
             bits = (ctypes.c_uint32 * 128).in_dll(entropy_from._owner, "x265_entropyStateBits")
-            getattr(lib, f"x265oracle_set_entropy_bits_d{depth}")(bits)
+        else:           # the committed fixture of the same table (tools/gen_host_tables.py)
+            bits = (ctypes.c_uint32 * 128)(*host_tables(root)["entropy_state_bits"])
+        getattr(lib, f"x265oracle_set_entropy_bits_d{depth}")(bits)
     t = spec.Table(ctypes.addressof(mem), depth, (lib, mem))
     return t

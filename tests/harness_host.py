@@ -114,6 +114,8 @@ def _cmp_cost_coeff_nxn(fa, fb, path, depth, rng, case):
     scan, inner = block_scan(rng, tr, int(rng.integers(0, 3)))
     tab = rng.integers(0, 9, size=16).astype(np.uint8)
     coeff = sparse_coeffs(rng, "random" if case != "random" else case, tr * tr + 4 * tr)
+    if rng.integers(0, 2):            # dense blocks: every visited position of the group writes a level, up to the last entry of absCoeff
+        coeff = np.where(coeff == 0, rng.integers(-9, 10, size=coeff.size), coeff).astype(np.int16)
     ncg = tr * tr // 16
     cg = int(rng.integers(0, ncg))
     sub_base = cg * 16

@@ -7,6 +7,7 @@ import importlib
 import pytest
 
 import harness as H
+import harness_host  # noqa: F401  (registers the handlers of rows a9 / a16)
 
 pytestmark = pytest.mark.gpu
 
@@ -27,9 +28,11 @@ def load_hip_table(depth, base=None):
 
 @pytest.mark.parametrize("depth", [8, 10])
 def test_table_slots_match_oracle(depth, repo_root):
-    orc = H.load_oracle(depth, repo_root)
+    orc = H.load_oracle(depth, repo_root, host=True)          # rows a9 / a16 included: the table is complete
+    A.set_entropy_bits(H.host_tables(repo_root)["entropy_bits"])      # the host's CABAC bit costs (costCoeffNxN, costC1C2Flag)
     hip, nset = load_hip_table(depth)
     assert nset > 100
+    assert all(hip.ptr(p) for p in spec.SLOTS if orc.ptr(p)), [p for p in spec.SLOTS if orc.ptr(p) and not hip.ptr(p)][:10]   # no slot is left to the host
     calls0 = A.lib().x265hip_table_calls()
     paths = [p for p in spec.SLOTS if hip.ptr(p)]
     assert len(paths) == nset

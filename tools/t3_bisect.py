@@ -13,8 +13,10 @@ lib = T.ref_lib(depth, ROOT)
 clip = F.synth_clip(128, 64, 3, depth=depth, seed=32)
 base, _, _ = T.encode(lib, clip, 128, 64, preset, T.OPTS)
 L = A.lib()
+A.set_entropy_bits(list((ctypes.c_uint32 * 128).in_dll(lib, "x265_entropyStateBits")))
 L.x265hip_setup_primitives.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
 fields = sorted({H.field_of(p) for p in spec.SLOTS})
+only = sys.argv[3].split(",") if len(sys.argv) > 3 else fields          # optional: the fields to try one by one
 def run(selected):
     def fill(tab, nbytes, d):
         tmp = (ctypes.c_void_p * spec.TABLE_PTRS)()
@@ -30,7 +32,7 @@ def run(selected):
     return got == base, filled
 ok, n = run(set(fields)); print("all fields:", ok, n)
 bad = []
-for f in fields:
+for f in only:
     ok, n = run({f})
     if n and not ok:
         bad.append(f); print("MISMATCH with only", f, "(", n, "slots )")

@@ -141,5 +141,6 @@ struct ThreadStage
 };
 
 ThreadStage& thread_stage();
+bool entropy_bits_ready();          // frame_coeff_kernels.hip: did the host hand its CABAC bit costs in (x265hip_set_entropy_bits)?
 
 } // namespace x265hip

@@ -640,6 +640,262 @@ template <int LX, int NSUM> static int ads_stub(int* encDC, uint32_t* sums, int 
     return n;
 }
 
+// ---------------------------------------------------------------- frame-level helpers (pixel.cpp:604-701, 864-1016, ipfilter.cpp:59-77)
+template <int KIND, typename S> static void planecopy_run(const S* src, intptr_t srcStride, pixel* dst, intptr_t dstStride, int width, int height, int shift, int mask)
+{
+    if (width <= 0 || height <= 0) return;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in2d(src, srcStride, width, height, sizeof(S));
+    x265hip_job jb = {}; jb.arg[0] = shift; jb.arg[1] = mask;
+    const JobRef dj = put_job(st, jb);
+    const size_t o1 = st.alloc((size_t)width * height * ES);
+    st.upload();
+    const x265hip_plane pl[2] = { plane(st, o0, width), plane(st, o1, width) };
+    st.require(x265hip_frame_batch(KIND, D, width, height, pl, dj, 1, nullptr, st.stream), "planecopy");
+    st.download(o1, (size_t)width * height * ES);
+    st.out2d(o1, dst, dstStride, width, height, ES);
+}
+static void planecopy_cp_stub(const uint8_t* src, intptr_t srcStride, pixel* dst, intptr_t dstStride, int width, int height, int shift)
+{ planecopy_run<X265HIP_FR_PLANECOPY_CP>(src, srcStride, dst, dstStride, width, height, shift, 0); }
+static void planecopy_sp_stub(const uint16_t* src, intptr_t srcStride, pixel* dst, intptr_t dstStride, int width, int height, int shift, uint16_t mask)
+{ planecopy_run<X265HIP_FR_PLANECOPY_SP>(src, srcStride, dst, dstStride, width, height, shift, mask); }
+static void planecopy_sp_shl_stub(const uint16_t* src, intptr_t srcStride, pixel* dst, intptr_t dstStride, int width, int height, int shift, uint16_t mask)
+{ planecopy_run<X265HIP_FR_PLANECOPY_SP_SHL>(src, srcStride, dst, dstStride, width, height, shift, mask); }
+static void planecopy_pp_shr_stub(const pixel* src, intptr_t srcStride, pixel* dst, intptr_t dstStride, int width, int height, int shift)
+{ planecopy_run<X265HIP_FR_PLANECOPY_PP_SHR>(src, srcStride, dst, dstStride, width, height, shift, 0); }
+#if X265HIP_DEPTH > 8
+// the reference has this slot in its high-bit-depth builds only (pixel.cpp:996, 1345-1347)
+static pixel plane_clip_max_stub(pixel* src, intptr_t stride, int width, int height, uint64_t* outsum, const pixel minPix, const pixel maxPix)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in2d(src, stride, width, height, ES);
+    x265hip_job jb = {}; jb.arg[0] = minPix; jb.arg[1] = maxPix;
+    const JobRef dj = put_job(st, jb);
+    const size_t oo = st.alloc(16);
+    st.upload();
+    const x265hip_plane pl[2] = { plane(st, o0, width), plane(st, o0, width) };
+    st.require(x265hip_frame_batch(X265HIP_FR_PLANE_CLIP_MAX, D, width, height, pl, dj, 1, st.dptr<void>(oo), st.stream), "planeClipAndMax");
+    st.download(o0, oo + 16 - o0);
+    st.out2d(o0, src, stride, width, height, ES);
+    *outsum = st.hptr<uint64_t>(oo)[1];
+    return (pixel)st.hptr<uint64_t>(oo)[0];
+}
+#endif
+static void ssim_core_stub(const pixel* pix1, intptr_t stride1, const pixel* pix2, intptr_t stride2, int* sums)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in2d(pix1, stride1, 8, 4, ES), o1 = st.in2d(pix2, stride2, 8, 4, ES);
+    x265hip_job jb = {};
+    const JobRef dj = put_job(st, jb);
+    const size_t oo = st.alloc(32);
+    st.upload();
+    const x265hip_plane pl[2] = { plane(st, o0, 8), plane(st, o1, 8) };
+    st.require(x265hip_frame_batch(X265HIP_FR_SSIM_CORE, D, 8, 4, pl, dj, 1, st.dptr<void>(oo), st.stream), "ssim_4x4x2_core");
+    st.download(oo, 32);
+    memcpy(sums, st.hptr<void>(oo), 32);
+}
+static float ssim_end4_stub(int* sum0, int* sum1, int width)
+{
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(sum0, 80), o1 = st.in1d(sum1, 80);
+    x265hip_job jb = {}; jb.arg[0] = width;
+    const JobRef dj = put_job(st, jb);
+    const size_t oo = st.alloc(4);
+    st.upload();
+    const x265hip_plane pl[2] = { plane(st, o0, 0), plane(st, o1, 0) };
+    st.require(x265hip_frame_batch(X265HIP_FR_SSIM_END4, D, 0, 0, pl, dj, 1, st.dptr<void>(oo), st.stream), "ssim_end_4");
+    st.download(oo, 4);
+    return *st.hptr<float>(oo);
+}
+static void fix8_pack_stub(uint16_t* dst, double* src, int count)
+{
+    if (count <= 0) return;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(src, (size_t)count * 8);
+    x265hip_job jb = {};
+    const JobRef dj = put_job(st, jb);
+    const size_t o1 = st.alloc((size_t)count * 2);
+    st.upload();
+    const x265hip_plane pl[2] = { plane(st, o0, 0), plane(st, o1, 0) };
+    st.require(x265hip_frame_batch(X265HIP_FR_FIX8_PACK, D, count, 1, pl, dj, 1, nullptr, st.stream), "fix8Pack");
+    st.download(o1, (size_t)count * 2);
+    memcpy(dst, st.hptr<void>(o1), (size_t)count * 2);
+}
+static void fix8_unpack_stub(double* dst, uint16_t* src, int count)
+{
+    if (count <= 0) return;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(src, (size_t)count * 2);
+    x265hip_job jb = {};
+    const JobRef dj = put_job(st, jb);
+    const size_t o1 = st.alloc((size_t)count * 8);
+    st.upload();
+    const x265hip_plane pl[2] = { plane(st, o0, 0), plane(st, o1, 0) };
+    st.require(x265hip_frame_batch(X265HIP_FR_FIX8_UNPACK, D, count, 1, pl, dj, 1, nullptr, st.stream), "fix8Unpack");
+    st.download(o1, (size_t)count * 8);
+    memcpy(dst, st.hptr<void>(o1), (size_t)count * 8);
+}
+// frameInitLowres reads rows 0 .. 2 * height and columns 0 .. 2 * width of the source (pixel.cpp:604-629)
+static void lowres_stub(const pixel* src0, pixel* dst0, pixel* dsth, pixel* dstv, pixel* dstc, intptr_t srcStride, intptr_t dstStride, int width, int height)
+{
+    if (width <= 0 || height <= 0) return;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const int sw = 2 * width + 1, sh = 2 * height + 1;
+    const size_t o0 = st.in2d(src0, srcStride, sw, sh, ES);
+    const size_t plane_bytes = ((size_t)width * height * ES + 63) & ~(size_t)63;
+    const size_t o1 = st.alloc(4 * plane_bytes);
+    st.upload();
+    void* const d[4] = { st.dptr<uint8_t>(o1), st.dptr<uint8_t>(o1) + plane_bytes, st.dptr<uint8_t>(o1) + 2 * plane_bytes, st.dptr<uint8_t>(o1) + 3 * plane_bytes };
+    st.require(x265hip_frame_init_lowres(D, st.dptr<void>(o0), sw, d, width, width, height, st.stream), "frameInitLowres");
+    st.download(o1, 4 * plane_bytes);
+    pixel* const out[4] = { dst0, dsth, dstv, dstc };
+    for (int i = 0; i < 4; i++) st.out2d(o1 + i * plane_bytes, out[i], dstStride, width, height, ES);
+}
+static void propagate_cost_stub(int* dst, const uint16_t* propagateIn, const int32_t* intraCosts, const uint16_t* interCosts, const int32_t* invQscales,
+                                const double* fpsFactor, int len)
+{
+    if (len <= 0) return;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const size_t o0 = st.in1d(propagateIn, (size_t)len * 2), o1 = st.in1d(intraCosts, (size_t)len * 4), o2 = st.in1d(interCosts, (size_t)len * 2),
+                 o3 = st.in1d(invQscales, (size_t)len * 4);
+    const size_t oo = st.alloc((size_t)len * 4);
+    st.upload();
+    st.require(x265hip_propagate_cost(st.dptr<int32_t>(oo), st.dptr<uint16_t>(o0), st.dptr<int32_t>(o1), st.dptr<uint16_t>(o2), st.dptr<int32_t>(o3),
+                                      *fpsFactor, len, st.stream), "propagateCost");
+    st.download(oo, (size_t)len * 4);
+    memcpy(dst, st.hptr<void>(oo), (size_t)len * 4);
+}
+// extendCURowBorder (ipfilter.cpp:59-77): the first / last sample of every row replicated into marginX columns either side
+static void extend_row_border_stub(pixel* txt, intptr_t stride, int width, int height, int marginX)
+{
+    if (width <= 0 || height <= 0 || marginX <= 0) return;
+    ThreadStage& st = thread_stage();
+    st.begin();
+    const int fw = width + 2 * marginX;
+    const size_t o0 = st.in2d(txt - marginX, stride, fw, height, ES);
+    st.upload();
+    st.require(x265hip_extend_border_rows(st.dptr<pixel>(o0) + marginX, fw, width, height, marginX, 0, 0, D, st.stream), "extendRowBorder");
+    st.download(o0, (size_t)fw * height * ES);
+    st.out2d(o0, txt - marginX, stride, fw, height, ES);
+}
+
+// ---------------------------------------------------------------- RDOQ helpers (dct.cpp:757-1069): a batch of one call
+struct CoeffCall
+{
+    ThreadStage& st;
+    size_t o[5] = { 0, 0, 0, 0, 0 };
+    x265hip_coeff_job jb = {};
+    CoeffCall() : st(thread_stage()) { st.begin(); }
+    // inputs first (in1d / in2d), then run(): packs the job, allocates the result word, uploads, launches
+    size_t orr = 0;
+    void run(int kind, const char* what)
+    {
+        const size_t oj = st.in1d(&jb, sizeof(jb));
+        orr = st.alloc(4);
+        st.upload();
+        void* const bufs[5] = { st.dptr<void>(o[0]), st.dptr<void>(o[1]), st.dptr<void>(o[2]), st.dptr<void>(o[3]), st.dptr<void>(o[4]) };
+        st.require(x265hip_coeff_batch(kind, D, bufs, st.dptr<const x265hip_coeff_job>(oj), 1, st.dptr<uint32_t>(orr), st.stream), what);
+    }
+    uint32_t result() const { return *st.hptr<uint32_t>(orr); }
+};
+static int scan_pos_last_stub(const uint16_t* scan, const int16_t* coeff, uint16_t* coeffSign, uint16_t* coeffFlag, uint8_t* coeffNum, int numSig,
+                              const uint16_t* /* scanCG4x4 */, const int trSize)
+{
+    CoeffCall c;
+    const size_t n = (size_t)trSize * trSize;
+    c.o[0] = c.st.in1d(scan, n * 2); c.o[1] = c.st.in1d(coeff, n * 2);
+    // the three outputs live in the input half of the staging buffer (they are small): in1d of the caller's arrays keeps the layout simple
+    c.o[2] = c.st.in1d(coeffSign, 128); c.o[3] = c.st.in1d(coeffFlag, 128); c.o[4] = c.st.in1d(coeffNum, 64);
+    c.jb.arg[0] = numSig; c.jb.arg[1] = trSize;
+    c.run(X265HIP_CF_SCAN_POS_LAST, "scanPosLast");
+    c.st.download(c.o[2], c.orr + 4 - c.o[2]);
+    memcpy(coeffSign, c.st.hptr<void>(c.o[2]), 128); memcpy(coeffFlag, c.st.hptr<void>(c.o[3]), 128); memcpy(coeffNum, c.st.hptr<void>(c.o[4]), 64);
+    return (int)c.result();
+}
+static uint32_t find_pos_first_last_stub(const int16_t* dstCoeff, const intptr_t trSize, const uint16_t scanTbl[16])
+{
+    CoeffCall c;
+    c.o[0] = c.st.in1d(scanTbl, 32); c.o[1] = c.st.in2d(dstCoeff, trSize, 4, 4, 2);
+    c.jb.arg[0] = 4;
+    c.run(X265HIP_CF_FIND_POS_FIRST_LAST, "findPosFirstLast");
+    c.st.download(c.orr, 4);
+    return c.result();
+}
+static uint32_t cost_coeff_nxn_stub(const uint16_t* scan, const int16_t* coeff, intptr_t trSize, uint16_t* absCoeff, const uint8_t* tabSigCtx,
+                                    uint32_t scanFlagMask, uint8_t* baseCtx, int offset, int scanPosSigOff, int subPosBase)
+{
+    CoeffCall c;
+    int nctx = 1;                                         // context 0 (the DC position) .. the largest significance context of the group
+    for (int i = 0; i < 16; i++) nctx = nctx > tabSigCtx[i] + offset + 1 ? nctx : tabSigCtx[i] + offset + 1;
+    // the levels go to absCoeff[0 .. number of non-zeros): the function steps its pointer back by the "last position already known" slot and
+    // indexes from that slot on, i.e. it writes from the pointer it was given; at most one entry per visited position
+    const int nabs = scanPosSigOff + 1;
+    c.o[0] = c.st.in1d(scan, 32); c.o[1] = c.st.in2d(coeff, trSize, 4, 4, 2);
+    c.o[2] = c.st.in1d(absCoeff, (size_t)nabs * 2);
+    c.o[3] = c.st.in1d(tabSigCtx, 16); c.o[4] = c.st.in1d(baseCtx, (size_t)nctx);
+    c.jb.arg[0] = 4; c.jb.arg[1] = (int32_t)scanFlagMask; c.jb.arg[2] = offset; c.jb.arg[3] = scanPosSigOff; c.jb.arg[4] = subPosBase;
+    c.run(X265HIP_CF_COST_COEFF_NXN, "costCoeffNxN");
+    c.st.download(c.o[2], c.orr + 4 - c.o[2]);
+    memcpy(absCoeff, c.st.hptr<void>(c.o[2]), (size_t)nabs * 2);
+    memcpy(baseCtx, c.st.hptr<void>(c.o[4]), (size_t)nctx);
+    return c.result();
+}
+static uint32_t cost_coeff_remain_stub(uint16_t* absCoeff, int numNonZero, int idx)
+{
+    CoeffCall c;
+    const int n = numNonZero > idx + 1 ? numNonZero : idx + 1;
+    c.o[2] = c.st.in1d(absCoeff, (size_t)n * 2);
+    c.jb.arg[0] = numNonZero; c.jb.arg[1] = idx;
+    c.run(X265HIP_CF_COST_COEFF_REMAIN, "costCoeffRemain");
+    c.st.download(c.orr, 4);
+    return c.result();
+}
+static uint32_t cost_c1c2_stub(uint16_t* absCoeff, intptr_t numC1Flag, uint8_t* baseCtxMod, intptr_t ctxOffset)
+{
+    CoeffCall c;
+    const intptr_t lo = ctxOffset < 0 ? ctxOffset : 0, hi = ctxOffset + 1 > 4 ? ctxOffset + 1 : 4;
+    c.o[2] = c.st.in1d(absCoeff, (size_t)(numC1Flag > 1 ? numC1Flag : 1) * 2);
+    c.o[4] = c.st.in1d(baseCtxMod + lo, (size_t)(hi - lo));
+    c.jb.off[4] = -lo;
+    c.jb.arg[0] = (int32_t)numC1Flag; c.jb.arg[1] = (int32_t)ctxOffset;
+    c.run(X265HIP_CF_COST_C1C2, "costC1C2Flag");
+    c.st.download(c.o[4], c.orr + 4 - c.o[4]);
+    // only the greater-than-1 contexts 0..3 and the one greater-than-2 context can have moved
+    memcpy(baseCtxMod, c.st.hptr<uint8_t>(c.o[4]) - lo, 4);
+    baseCtxMod[ctxOffset] = c.st.hptr<uint8_t>(c.o[4])[ctxOffset - lo];
+    return c.result();
+}
+// one coefficient group of the uncoded-cost pre-passes: the 4x4 group is staged densely (row stride 4 through arg[2])
+template <int KIND, int LOG2> static void rdoq_run(int16_t* resi, int16_t* fenc, int64_t* costUncoded, int64_t* totalUncoded, int64_t* totalRd, int64_t* psyScale, uint32_t blkPos)
+{
+    CoeffCall c;
+    const intptr_t tr = (intptr_t)1 << LOG2;
+    const int64_t tot[2] = { *totalUncoded, *totalRd }, psy = psyScale ? *psyScale : 0;
+    c.o[0] = c.st.in2d((fenc ? fenc : resi) + blkPos, tr, 4, 4, 2); c.o[1] = c.st.in2d(resi + blkPos, tr, 4, 4, 2);
+    c.o[2] = c.st.in2d(costUncoded + blkPos, tr, 4, 4, 8); c.o[3] = c.st.in1d(tot, 16); c.o[4] = c.st.in1d(&psy, 8);
+    c.jb.arg[0] = 0; c.jb.arg[1] = LOG2; c.jb.arg[2] = 4;
+    c.run(KIND, "rdoQuant pre-pass");
+    c.st.download(c.o[2], c.o[3] + 16 - c.o[2]);
+    c.st.out2d(c.o[2], costUncoded + blkPos, tr, 4, 4, 8);
+    *totalUncoded = c.st.hptr<int64_t>(c.o[3])[0]; *totalRd = c.st.hptr<int64_t>(c.o[3])[1];
+}
+template <int LOG2> static void nonpsy_rdoq_stub(int16_t* resi, int64_t* cost, int64_t* tu, int64_t* trd, uint32_t blkPos)
+{ rdoq_run<X265HIP_CF_RDOQ_NONPSY, LOG2>(resi, nullptr, cost, tu, trd, nullptr, blkPos); }
+template <int LOG2> static void psy_rdoq_stub(int16_t* resi, int16_t* fenc, int64_t* cost, int64_t* tu, int64_t* trd, int64_t* psyScale, uint32_t blkPos)
+{ rdoq_run<X265HIP_CF_RDOQ_PSY, LOG2>(resi, fenc, cost, tu, trd, psyScale, blkPos); }
+template <int LOG2> static void psy1_rdoq_stub(int16_t* resi, int64_t* cost, int64_t* tu, int64_t* trd, uint32_t blkPos)
+{ rdoq_run<X265HIP_CF_RDOQ_PSY_1P, LOG2>(resi, nullptr, cost, tu, trd, nullptr, blkPos); }
+template <int LOG2> static void psy2_rdoq_stub(int16_t* resi, int16_t* fenc, int64_t* cost, int64_t* tu, int64_t* trd, int64_t* psyScale, uint32_t blkPos)
+{ rdoq_run<X265HIP_CF_RDOQ_PSY_2P, LOG2>(resi, fenc, cost, tu, trd, psyScale, blkPos); }
+
 #define PU_LIST(X) X(4,4) X(8,8) X(16,16) X(32,32) X(64,64) X(8,4) X(4,8) X(16,8) X(8,16) X(32,16) X(16,32) \
     X(64,32) X(32,64) X(16,12) X(12,16) X(16,4) X(4,16) X(32,24) X(24,32) X(32,8) X(8,32) X(64,48) X(48,64) X(64,16) X(16,64)
 
@@ -739,6 +995,23 @@ int CAT(setup_primitives_d, X265HIP_DEPTH)(x265hip_EncoderPrimitives* p)
     SET2(p->pelFilterLumaStrong, deblock_luma_stub); SET2(p->pelFilterChroma, deblock_chroma_stub);
 #define SET_INTEG(I, N) SET(p->integral_initv[I], (integral_v_stub<N>)); SET(p->integral_inith[I], (integral_h_stub<N>));
     SET_INTEG(0, 4) SET_INTEG(1, 8) SET_INTEG(2, 12) SET_INTEG(3, 16) SET_INTEG(4, 24) SET_INTEG(5, 32)
+
+    // ---- rows a16 / a9: the frame-level helpers and the RDOQ helpers (csrc/frame_coeff_kernels.hip) ----
+    SET(p->planecopy_cp, planecopy_cp_stub); SET(p->planecopy_sp, planecopy_sp_stub); SET(p->planecopy_sp_shl, planecopy_sp_shl_stub);
+    SET(p->planecopy_pp_shr, planecopy_pp_shr_stub);
+#if X265HIP_DEPTH > 8
+    SET(p->planeClipAndMax, plane_clip_max_stub);
+#endif
+    SET(p->ssim_4x4x2_core, ssim_core_stub); SET(p->ssim_end_4, ssim_end4_stub);
+    SET(p->fix8Pack, fix8_pack_stub); SET(p->fix8Unpack, fix8_unpack_stub);
+    SET(p->frameInitLowres, lowres_stub); SET(p->frameInitLowerRes, lowres_stub);
+    SET(p->propagateCost, propagate_cost_stub); SET(p->extendRowBorder, extend_row_border_stub);
+    SET(p->scanPosLast, scan_pos_last_stub); SET(p->findPosFirstLast, find_pos_first_last_stub); SET(p->costCoeffRemain, cost_coeff_remain_stub);
+    // the two estimators that price context-coded bins need the HOST's per-state table: without x265hip_set_entropy_bits they stay the host's
+    if (entropy_bits_ready()) { SET(p->costCoeffNxN, cost_coeff_nxn_stub); SET(p->costC1C2Flag, cost_c1c2_stub); }
+#define SET_RDOQ(I, L2) { auto& c = p->cu[I]; SET(c.nonPsyRdoQuant, (nonpsy_rdoq_stub<L2>)); SET(c.psyRdoQuant, (psy_rdoq_stub<L2>)); \
+    SET(c.psyRdoQuant_1p, (psy1_rdoq_stub<L2>)); SET(c.psyRdoQuant_2p, (psy2_rdoq_stub<L2>)); }
+    SET_RDOQ(0, 2) SET_RDOQ(1, 3) SET_RDOQ(2, 4) SET_RDOQ(3, 5)
 
     // ---- chroma tables (indexed by the LUMA enum; primitives.h:77-79,393-428) ----
     // satd only where the reference has a function (multiple of 4x4: pixel.cpp:1200-1226,1279-1305); 4:2:0 2x2 has

@@ -900,6 +900,18 @@ def make_jobs(entries, device):
     return torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(device)
 
 
+def make_coeff_jobs(entries, device):
+    """entries: iterable of (offsets[<=5], args[<=5]) -> device tensor of x265hip_coeff_job records (64 bytes each)."""
+    import numpy as np
+    import torch
+    entries = list(entries)
+    arr = np.zeros(len(entries), dtype=np.dtype([("off", "<i8", 5), ("arg", "<i4", 5), ("reserved", "<i4")]))
+    for i, (offs, args) in enumerate(entries):
+        arr["off"][i, :len(offs)] = offs
+        arr["arg"][i, :len(args)] = args
+    return torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(device)
+
+
 def plane(t, stride=0, elem_off=0, elem_size=None):
     es = t.element_size() if elem_size is None else elem_size
     return Plane(t.data_ptr() + elem_off * es if t is not None else None, stride)
@@ -1002,6 +1014,55 @@ def loopfilter_batch(kind, depth, planes, jobs, njobs, result=None, stream=None)
     f = lib().x265hip_loopfilter_batch
     f.argtypes = [ctypes.c_int] * 2 + [ctypes.POINTER(Plane), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     check(f(kind, depth, _planes(planes, 4), jobs.data_ptr(), njobs, _p(result), s), "x265hip_loopfilter_batch")
+
+
+# x265hip_frame_kind / x265hip_coeff_kind (include/x265hip.h)
+FR_PLANECOPY_CP, FR_PLANECOPY_SP, FR_PLANECOPY_SP_SHL, FR_PLANECOPY_PP_SHR, FR_PLANE_CLIP_MAX, FR_SSIM_CORE, FR_SSIM_END4, FR_FIX8_PACK, FR_FIX8_UNPACK = range(9)
+CF_SCAN_POS_LAST, CF_FIND_POS_FIRST_LAST, CF_COST_COEFF_NXN, CF_COST_COEFF_REMAIN, CF_COST_C1C2, CF_RDOQ_NONPSY, CF_RDOQ_PSY, CF_RDOQ_PSY_1P, CF_RDOQ_PSY_2P = range(9)
+
+
+def frame_batch(kind, depth, w, h, planes, jobs, njobs, out=None, stream=None):
+    """x265hip_frame_batch: the frame-level helpers (row a16); planes = two Plane records, jobs = device x265hip_job array."""
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_frame_batch
+    f.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(Plane), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    check(f(kind, depth, w, h, _planes(planes, 2), jobs.data_ptr(), njobs, _p(out), s), "x265hip_frame_batch")
+
+
+def frame_init_lowres(depth, src, src_off_bytes, src_stride, dsts, dst_stride, width, height, stream=None):
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_frame_init_lowres
+    f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_ssize_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    d = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in dsts])
+    check(f(depth, src.data_ptr() + src_off_bytes, src_stride, d, dst_stride, width, height, s), "x265hip_frame_init_lowres")
+
+
+def propagate_cost(dst, propagate_in, intra_costs, inter_costs, inv_qscales, fps_factor, length, stream=None):
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_propagate_cost
+    f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_double, ctypes.c_int, ctypes.c_void_p]
+    check(f(dst.data_ptr(), propagate_in.data_ptr(), intra_costs.data_ptr(), inter_costs.data_ptr(), inv_qscales.data_ptr(), float(fps_factor), length, s),
+          "x265hip_propagate_cost")
+
+
+def set_entropy_bits(bits128):
+    """x265hip_set_entropy_bits: the host's 128 per-state CABAC bit costs (g_entropyBits / x265_entropyStateBits)."""
+    import numpy as np
+    b = np.ascontiguousarray(bits128, dtype=np.uint32)
+    assert b.size == 128
+    f = lib().x265hip_set_entropy_bits
+    f.argtypes = [ctypes.c_void_p]
+    check(f(b.ctypes.data), "x265hip_set_entropy_bits")
+
+
+def coeff_batch(kind, depth, bufs, jobs, njobs, result=None, stream=None):
+    """x265hip_coeff_batch: the RDOQ helpers (row a9); bufs = five device tensors (or None), jobs = device array of
+    x265hip_coeff_job (int64 off[5], int32 arg[5], int32 reserved = 64 bytes)."""
+    s = current_stream() if stream is None else stream
+    f = lib().x265hip_coeff_batch
+    f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    b = (ctypes.c_void_p * 5)(*[_p(t) for t in bufs])
+    check(f(kind, depth, b, jobs.data_ptr(), njobs, _p(result), s), "x265hip_coeff_batch")
 
 
 def pixelcmp_batch(kind, depth, w, h, a, a_stride, b, b_stride, njobs, out,
