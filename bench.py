@@ -344,7 +344,7 @@ def seam_config(key):
       * 8 bits: NO SAD lookups.  With the host path equal they add nothing at cfg3 (7.95 fps without, 7.89 - 7.98 with, 9.4 GB instead of 14.5 - 22.7 GB
         downloaded per 48 frames) and cost 6 % on the fade (4.46 against 4.10 - 4.20: the searches leave the windows, hit rate 0.11 - 0.17);
       * above 8 bits: the 32x32 / 64x64 rasters only (`min_level` 2): 1.88 fps like level 1, 8.9 instead of 13.2 GB; without the SAD seam 1.85;
-      * always: sub-sample comparisons, lookahead frame costs, AQ and weightAnalyse from the device; the binding's hit-rate gate (ref_seam.cpp) stops opening
+      * always: sub-sample comparisons, lookahead frame costs, AQ and weightAnalyse from the device; the binding's hit-rate gate (binding/x265hip_x265_binding.cpp) stops opening
         pairs when fewer than half of the lookups of a window hit; everything the services do not answer takes the host-only control's split SADs."""
     depth = CFG_DEPTH.get(key, 8)
     # round 6: the SUB-SAMPLE COST TABLES (x265hip_cost_stream behind MotionEstimate::subpelCompare: records of the refinement's SATD costs around each PU's best integer

@@ -1,10 +1,22 @@
-/* oracle/ref_seam.cpp - TEST INFRASTRUCTURE: the REFERENCE-SIDE BINDING of the stage-level seam, i.e.
- * what a maintainer of the reference would add to consume libx265hip's frame-granular motion-search results.  Never part of the
- * product path; compiled by oracle/Makefile together with the reference's own sources into oracle/_ref/libx265ref<depth>_seam.so.
+/* binding/x265hip_x265_binding.cpp - the REFERENCE-SIDE BINDING of libx265hip's consumer services (INTEGRATION.md sections 3c - 3g, 4): what a
+ * maintainer of x265 3.5 adds to the encoder so that MotionEstimate::motionEstimate / subpelCompare, CostEstimateGroup::estimateFrameCost,
+ * LookaheadTLD::lowresIntraEstimate / calcAdaptiveQuantFrame, weightAnalyse and FrameFilter::processPostRow consume the device's results.  It is written
+ * against the reference's PUBLIC members only and compiled with the reference's own headers; it holds no reference source text.
  *
- * Mechanism (no reference source is modified or copied):
- *   * oracle/Makefile renames the symbol of MotionEstimate::motionEstimate in the reference's compiled encoder/motion.o to
- *     x265ref_orig_motionEstimate (objcopy --redefine-sym) and this file supplies MotionEstimate::motionEstimate: a wrapper that
+ * TWO WAYS TO ATTACH IT
+ *   (a) source patch: seven `#if ENABLE_HIP_PRIMITIVES` hooks - motion.cpp:739 / :1571, slicetype.cpp:3115 / :696 / :444,
+ *       framefilter.cpp:657, weightPrediction.cpp:222 - rename the reference's bodies and export them as the extern "C" x265ref_orig_* trampolines declared
+ *       below; this file then supplies the public symbols.  Build it with the encoder (X265HIP_BINDING_TEST_HOOKS unset = 0).
+ *   (b) this repository's TEST RIG (oracle/Makefile): no reference source is touched - objcopy renames / weakens the same seven symbols in the reference's
+ *       compiled objects (--redefine-sym / --weaken-symbol + --add-symbol x265ref_orig_*), and this file is compiled with -DX265HIP_BINDING_TEST_HOOKS=1
+ *       into oracle/_ref/libx265ref<depth>_seam.so.  tests/test_seam_cpu.py, tests/test_gpu_seam.py and bench.py's encoder legs run on that library.
+ * What X265HIP_BINDING_TEST_HOOKS adds is measurement and fixture code only (stage timers for tools/encoder_profile.py, the integer-vector predictor probe,
+ * the X265REF_AQ_DUMP / X265REF_WA_DUMP fixture writers, the *_profiled table fillers); the binding proper - lookup stubs, the thread-local search context, the
+ * size and hit-rate gates, slot bookkeeping, the providers' plumbing and the in-flight verification switch a maintainer wants while bringing it up - is the rest.
+ *
+ * Mechanism:
+ *   * the reference's MotionEstimate::motionEstimate answers to x265ref_orig_motionEstimate (hook (a) or objcopy (b)) and this file supplies
+ *     MotionEstimate::motionEstimate: a wrapper that
  *     identifies (source picture, reference picture, CTU, PU) for the calling worker thread, makes sure the pair's SAD surfaces
  *     have been requested from the provider (ONE exhaustive-search launch per pair, x265hip_me_cache_submit), publishes a
  *     thread-local lookup context and then runs the reference's own, untouched search (all --me methods, all its quirks).
@@ -60,6 +72,17 @@
 
 using namespace X265_NS;
 
+#ifndef X265HIP_BINDING_TEST_HOOKS
+#define X265HIP_BINDING_TEST_HOOKS 0          /* 1: the test rig's measurement / fixture code is compiled in (see the header) */
+#endif
+#if X265HIP_BINDING_TEST_HOOKS
+#define SEAM_PROF_ON (gp.on)                   /* stage timers of tools/encoder_profile.py --seams */
+#define SEAM_PROBE_ON (gpp.on)                 /* integer-vector predictor probe (x265ref_predict_probe) */
+#else
+#define SEAM_PROF_ON false
+#define SEAM_PROBE_ON false
+#endif
+
 extern "C" int x265ref_orig_motionEstimate(MotionEstimate* self, ReferencePlanes* ref, const MV* mvmin, const MV* mvmax, const MV* qmvp,
                                            int numCandidates, const MV* mvc, int merange, MV* outQMv, uint32_t maxSlices, pixel* srcReferencePlane);
 
@@ -69,7 +92,10 @@ extern "C" int64_t x265ref_orig_estimateFrameCost(CostEstimateGroup* self, Looka
 extern "C" void x265ref_orig_lowresIntraEstimate(LookaheadTLD* self, Lowres* fenc, uint32_t qgSize);
 extern "C" void x265ref_orig_calcAdaptiveQuantFrame(LookaheadTLD* self, Frame* curFrame, x265_param* param);
 extern "C" void x265ref_orig_weightAnalyse(Slice* slice, Frame* frame, x265_param* param);          /* references are pointers at the ABI level */
+#if X265HIP_BINDING_TEST_HOOKS
 extern "C" int x265ref_profile_fill_table(void* table, size_t bytes, int depth);          /* oracle/ref_profile.cpp: cycle-counting thunks */
+#endif
+
 
 namespace {
 
@@ -197,8 +223,8 @@ struct SeamProf
 struct ProfScope
 {
     std::atomic<uint64_t>& cyc; std::atomic<uint64_t>& n; uint64_t t0;
-    ProfScope(std::atomic<uint64_t>& c, std::atomic<uint64_t>& k) : cyc(c), n(k), t0(gp.on ? __rdtsc() : 0) {}
-    ~ProfScope() { if (gp.on) { cyc.fetch_add(__rdtsc() - t0, std::memory_order_relaxed); n.fetch_add(1, std::memory_order_relaxed); } }
+    ProfScope(std::atomic<uint64_t>& c, std::atomic<uint64_t>& k) : cyc(c), n(k), t0(SEAM_PROF_ON ? __rdtsc() : 0) {}
+    ~ProfScope() { if (SEAM_PROF_ON) { cyc.fetch_add(__rdtsc() - t0, std::memory_order_relaxed); n.fetch_add(1, std::memory_order_relaxed); } }
 };
 
 struct MeCostProbe : public MotionEstimate { const uint16_t* costCentre() const { return m_cost; } };
@@ -413,7 +439,7 @@ inline bool lookup_raw(Ctx& c, const pixel* fref, int& out)
 }
 inline bool lookup(Ctx& c, const pixel* fref, int& out)
 {
-    if (!gp.on) return lookup_raw(c, fref, out);
+    if (!SEAM_PROF_ON) return lookup_raw(c, fref, out);
     const uint64_t t0 = __rdtsc();
     const bool ok = lookup_raw(c, fref, out);
     c.cyc += __rdtsc() - t0;
@@ -1053,7 +1079,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     ProfScope prof(gp.meCyc, gp.meCalls);
     Ctx& c = t_ctx;
     c.valid = false;
-    const uint64_t tctx = gp.on ? __rdtsc() : 0;
+    const uint64_t tctx = SEAM_PROF_ON ? __rdtsc() : 0;
     if (g.enabled)
     {
         g.meCalls.fetch_add(1, std::memory_order_relaxed);
@@ -1121,7 +1147,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         gc.contexts.fetch_add(1, std::memory_order_relaxed);
         cost_context(reinterpret_cast<const Search*>(reinterpret_cast<const char*>(this) - offsetof(Search, m_me)), gc.useMvCost ? m_cost : NULL, ref, ctuAddr, absPartIdx, partEnum, blockwidth, bChromaSATD, subpelRefine);
     }
-    if (gp.on) gp.ctxCyc.fetch_add(__rdtsc() - tctx, std::memory_order_relaxed);
+    if (SEAM_PROF_ON) gp.ctxCyc.fetch_add(__rdtsc() - tctx, std::memory_order_relaxed);
     const int cost = x265ref_orig_motionEstimate(this, ref, &mvmin, &mvmax, &qmvp, numCandidates, mvc, merange, &outQMv, maxSlices, srcReferencePlane);
     if (t_sub.valid)
     {
@@ -1152,7 +1178,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         g.outside.fetch_add(c.outside, std::memory_order_relaxed);
         g.notReady.fetch_add(c.notReady, std::memory_order_relaxed);
         if (c.saturated) g.saturated.fetch_add(c.saturated, std::memory_order_relaxed);
-        if (gp.on) { gp.lookCyc.fetch_add(c.cyc, std::memory_order_relaxed); gp.lookups.fetch_add(c.hits + c.outside + c.notReady + c.saturated, std::memory_order_relaxed); }
+        if (SEAM_PROF_ON) { gp.lookCyc.fetch_add(c.cyc, std::memory_order_relaxed); gp.lookups.fetch_add(c.hits + c.outside + c.notReady + c.saturated, std::memory_order_relaxed); }
     }
     return cost;
 }
@@ -1165,7 +1191,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
 int MotionEstimate::subpelCompare(ReferencePlanes* ref, const MV& qmv, pixelcmp_t cmp)
 {
     ProfScope prof(gp.subCyc, gp.subCalls);
-    if (gpp.on && !((qmv.x | qmv.y) & 3) && cmp == primitives.pu[partEnum].satd)
+    if (SEAM_PROBE_ON && !((qmv.x | qmv.y) & 3) && cmp == primitives.pu[partEnum].satd)
     {
         /* the refinement starts here: qmv is the integer vector the search ended on (motion.cpp:1515-1519) */
         Ctx& k = t_ctx;
@@ -1462,6 +1488,7 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
     return score;
 }
 
+#if X265HIP_BINDING_TEST_HOOKS
 /* fixture generation (tools/gen_weight_golden.py): X265REF_WA_DUMP=<dir> + verify writes, per served slice, everything x265hip_weight_analyse_host is
  * handed and what the REFERENCE's own weightAnalyse answered, as (name, element size, count, bytes) records */
 static void wa_dump_arr(FILE* f, const char* name, int elem, size_t count, const void* data)
@@ -1470,6 +1497,8 @@ static void wa_dump_arr(FILE* f, const char* name, int elem, size_t count, const
     const uint64_t c = count;
     fwrite(&n, 4, 1, f); fwrite(name, 1, n, f); fwrite(&e, 4, 1, f); fwrite(&c, 8, 1, f); fwrite(data, (size_t)elem, count, f);
 }
+#endif
+
 
 /* LookaheadTLD::calcAdaptiveQuantFrame (slicetype.cpp:444-694; once per source picture from PreLookaheadGroup::processTasks, :1395): the
  * acEnergyCu loop over every quantisation group of the picture - the pixel work - and the double-precision offsets as ONE provider call
@@ -1547,6 +1576,7 @@ void LookaheadTLD::calcAdaptiveQuantFrame(Frame* curFrame, x265_param* param)
             fprintf(stderr, "ref_seam: ADAPTIVE QUANTISATION VERIFY MISMATCH poc %d\n", curFrame->m_poc);
             gaq.mismatches.fetch_add(1, std::memory_order_relaxed);
         }
+#if X265HIP_BINDING_TEST_HOOKS
         if (const char* dir = getenv("X265REF_AQ_DUMP"))          /* fixture generation (tools/gen_weight_golden.py): the picture and what the REFERENCE's function left in Lowres */
         {
             static std::atomic<int> serial{0};
@@ -1574,6 +1604,8 @@ void LookaheadTLD::calcAdaptiveQuantFrame(Frame* curFrame, x265_param* param)
                 fclose(f);
             }
         }
+#endif
+
     }
 }
 
@@ -1700,6 +1732,7 @@ void weightAnalyse(Slice& slice, Frame& frame, x265_param& param)
                     const WeightParam& x = wp[list][ref][plane]; const WeightParam& y = slice.m_weightPredTable[list][ref][plane];
                     same &= x.log2WeightDenom == y.log2WeightDenom && x.inputWeight == y.inputWeight && x.inputOffset == y.inputOffset && !x.wtPresent == !y.wtPresent;
                 }
+#if X265HIP_BINDING_TEST_HOOKS
         if (const char* dir = getenv("X265REF_WA_DUMP"))
         {
             static std::atomic<int> serial{0};
@@ -1742,6 +1775,8 @@ void weightAnalyse(Slice& slice, Frame& frame, x265_param& param)
                 fclose(f);
             }
         }
+#endif
+
         if (!same)
         {
             fprintf(stderr, "ref_seam: WEIGHT ANALYSE VERIFY MISMATCH poc %d: served luma (%d %d %u %d), reference (%d %d %u %d)\n", slice.m_poc,
@@ -1989,6 +2024,7 @@ int x265ref_subpel_seam_configure_streamed(void* ctx, void* open, void* rows_fn,
  * BEFORE the configure calls.  Returns whether the last configure was gated. */
 int x265ref_seam_min_ctus(int min_ctus) { if (min_ctus >= 0) g_minCtus = min_ctus; return g_gated ? 1 : 0; }
 
+#if X265HIP_BINDING_TEST_HOOKS
 /* measurement mode of the integer-vector predictor (see gpp): on = 1 / 0 (< 0: leave); out[7] (may be NULL): refinements seen, without a usable SAD context, ended outside the
  * window, and - of those inside - ended on the window's SAD minimum / among its 2 / 4 / 8 smallest SADs */
 void x265ref_predict_probe(int on, uint64_t* out)
@@ -1996,6 +2032,8 @@ void x265ref_predict_probe(int on, uint64_t* out)
     if (on >= 0) { gpp.on = on != 0; gpp.total = 0; gpp.noCtx = 0; gpp.outside = 0; gpp.top1 = 0; gpp.top2 = 0; gpp.top4 = 0; gpp.top8 = 0; }
     if (out) { out[0] = gpp.total; out[1] = gpp.noCtx; out[2] = gpp.outside; out[3] = gpp.top1; out[4] = gpp.top2; out[5] = gpp.top4; out[6] = gpp.top8; }
 }
+#endif
+
 
 /* the hit-rate gate: window = lookups per decision (0 = gate off, < 0 = leave), pct = the share of served lookups below which no new pairs are opened.
  * out[3] (may be NULL): searches that went to the host because the gate was closed, times the gate closed, whether it is closed now, window */
@@ -2099,6 +2137,7 @@ int x265ref_split_fill_table(void* table, size_t bytes, int depth)
     return n;
 }
 
+#if X265HIP_BINDING_TEST_HOOKS
 /* the control under tools/encoder_profile.py: counting thunks first, the split on top (its single SADs are then counted in the `sad` family) */
 int x265ref_split_fill_table_profiled(void* table, size_t bytes, int depth)
 {
@@ -2107,6 +2146,8 @@ int x265ref_split_fill_table_profiled(void* table, size_t bytes, int depth)
     const int b = x265ref_split_fill_table(table, bytes, depth);
     return b < 0 ? b : a + b;
 }
+#endif
+
 
 /* table filler with the x265hip_setup_primitives signature: installs the lookup stubs over the host's own sad family */
 int x265ref_seam_fill_table(void* table, size_t bytes, int depth)
@@ -2126,6 +2167,7 @@ int x265ref_seam_fill_table(void* table, size_t bytes, int depth)
     return n;
 }
 
+#if X265HIP_BINDING_TEST_HOOKS
 /* the seam's lookup stubs over ref_profile.cpp's cycle-counting thunks (the stubs' fall-backs then count as host sad time), and the
  * stage timers of this file switched on: where the encode's time goes WITH the seams in place (tools/encoder_profile.py --seams) */
 int x265ref_seam_fill_table_profiled(void* table, size_t bytes, int depth)
@@ -2145,6 +2187,8 @@ void x265ref_seam_profile_report(uint64_t* out)
     out[8] = gp.lookCyc; out[9] = gp.lookups; out[10] = gp.ctxCyc; out[11] = gp.meCalls;
     gp.on = false;
 }
+#endif
+
 
 /* out[10]: lookups served, outside the window, row not ready, motionEstimate calls, calls with a lookup context, pair submits,
  * verify mismatches, calls without a free slot, calls on foreign geometry / frame threads, verify flag */

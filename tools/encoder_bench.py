@@ -6,7 +6,7 @@ each BASELINE.json configuration, once per primitive-table flavour:
     c      the reference's own C table (setupCPrimitives + aliases)            -> the host-CPU baseline, kind "reference"
     csse   (v3 build only) c + the reference's SSE intrinsic DCT / iDCT / dequant_scaling (common/vec/*.cpp) -> the strongest host table this image can build
     hip    1816 slots served by libx265hip.so's per-call stubs (table layer)   -> drop-in, byte-identical, launch-bound
-    seam   C table + the stage-level seam (oracle/ref_seam.cpp): MotionEstimate::motionEstimate replays its integer search on the
+    seam   C table + the stage-level seam (binding/x265hip_x265_binding.cpp): MotionEstimate::motionEstimate replays its integer search on the
            SAD surfaces one x265hip_me_fullsearch launch per (picture, reference) produced (batch layer)
 
 fps = frames / seconds of the encode loop (what encoder.cpp:2708 prints), bitstreams compared by md5 (--no-info, CRF, fixed

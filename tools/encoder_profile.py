@@ -85,7 +85,7 @@ def main():
         st = (ctypes.c_uint64 * 12)()
         lib.x265ref_seam_profile_report.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
         lib.x265ref_seam_profile_report(st)
-        print("# stages of oracle/ref_seam.cpp, whole (the primitives they call are ALSO in the families above; process CPU includes the providers' worker threads)")
+        print("# stages of binding/x265hip_x265_binding.cpp, whole (the primitives they call are ALSO in the families above; process CPU includes the providers' worker threads)")
         for i, name in enumerate(("MotionEstimate::motionEstimate (integer search on lookups + sub-sample refinement)", "MotionEstimate::subpelCompare (inside motionEstimate)",
                                   "CostEstimateGroup::estimateFrameCost (waits for x265hip_lowres_cost_host)", "row hand-over in FrameFilter::processPostRow (memcpy into pinned staging)",
                                   "SAD lookups of the integer search (served or passed on; inside motionEstimate)", "context set-up of the motionEstimate wrapper (pair / view look-up)")):

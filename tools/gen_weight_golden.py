@@ -5,8 +5,8 @@ tests/test_golden.py (the oracle's restatement) and tests/test_gpu_weight_analys
 
   python tools/gen_weight_golden.py
 
-How: real encodes of 160x128 fades through oracle/ref_seam.cpp's weightAnalyse seam with verify on and X265REF_WA_DUMP set - the seam writes what the
-provider was handed and what x265's weightAnalyse then left in the slice (ref_seam.cpp, wa_dump_arr).  A few slices per depth are kept: weighted P slices,
+How: real encodes of 160x128 fades through binding/x265hip_x265_binding.cpp's weightAnalyse seam with verify on and X265REF_WA_DUMP set - the seam writes what the
+provider was handed and what x265's weightAnalyse then left in the slice (binding/x265hip_x265_binding.cpp, wa_dump_arr).  A few slices per depth are kept: weighted P slices,
 a B slice with two lists, a slice that keeps weight 1."""
 import glob
 import importlib

@@ -1,5 +1,5 @@
 """Driver of the stage-level seam (tier T3 with a batch-layer consumer): configures oracle/_ref/libx265ref<depth>_seam.so
-(oracle/ref_seam.cpp - the reference-side binding) with a SAD-surface provider and hands back the table filler for
+(binding/x265hip_x265_binding.cpp - the reference-side binding) with a SAD-surface provider and hands back the table filler for
 x265ref_encode.  Two providers with the same three entry points (x265hip_me_cache_submit / _surface / _ready signatures):
 
   GpuProvider     libx265hip.so's frame-granular cache (csrc/me_cache.hip): one exhaustive-search launch per (picture, reference),
