@@ -50,7 +50,11 @@ def one_config(src, key, fill_bytes):
         fetch = e.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
         write = e.get("WRITE_SIZE", 0.0) * 1024.0 * cal
         us = stats.get(k, sum(e["dur_ns"]) / len(e["dur_ns"]) / 1e3)
-        kernels[k] = {"fetch_bytes": int(fetch), "write_bytes": int(write), "avg_us": round(us, 3), "gbytes_per_s": round((fetch + write) / us / 1e3, 1),
+        # round 6: FETCH_SIZE calibrated per access pattern (profiles/r06_fetch_size_calibration.txt, tools/ubench/fetch_calibration.hip): the x2 holds for every CONTIGUOUS row a
+        # wavefront reads (16 / 4 / 1 byte per lane, 32-byte tile rows: 128-byte requests tallied as 64); single 64-byte lines fetched one request each (4x4 tiles at arbitrary
+        # positions) are counted at face value.  fetch_bytes keeps the x2 (exact for streaming kernels, an UPPER bound for kernels that gather tiles / halos),
+        # fetch_bytes_min is the counter at face value (the lower bound; what a pure gather like subpel_refine_kernel moves)
+        kernels[k] = {"fetch_bytes": int(fetch), "fetch_bytes_min": int(fetch / 2), "write_bytes": int(write), "avg_us": round(us, 3), "gbytes_per_s": round((fetch + write) / us / 1e3, 1),
                       "frac_of_8tb": round((fetch + write) / us / 1e3 / 8000.0, 4), "mfma_busy_frac": mf.get(k) if mf.get(k) else None}
     return {"source": f"profiles/{RND}_bench_pmc_{key}.txt + profiles/{RND}_bench_kernel_stats_{key}.txt + profiles/{RND}_bench_mfma_{key}.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / "
                       f"--pmc SQ_VALU_MFMA_BUSY_CYCLES (separate passes, --kernel-trace only), per-dispatch averages; KiB -> bytes, FETCH_SIZE x 2 (gfx950), WRITE_SIZE x {cal:.4f} "
@@ -97,6 +101,9 @@ def main():
         p = os.path.join(src, f"inst_{key}.txt")
         if os.path.exists(p):
             shutil.copy(p, os.path.join(prof, f"{RND}_inst_counters_{key}.txt"))
+    fc = os.path.join(src, "fetch_size_calibration.txt")
+    if os.path.exists(fc):
+        shutil.copy(fc, os.path.join(prof, f"{RND}_fetch_size_calibration.txt"))
     vr = os.path.join(src, "valu_rates.txt")
     if os.path.exists(vr):
         shutil.copy(vr, os.path.join(prof, f"{RND}_valu_rates_ubench.txt"))
