@@ -338,6 +338,44 @@ MAX_LINE_BYTES = 4096      # the driver keeps a bounded tail of stdout: the one 
 ENC_DEFAULTS = {"cfg3": (48, 5), "cfg3f": (24, 5), "cfg4": (24, 5), "cfg2": (96, 3), "cfg1": (8, 1), "cfg5": (3, 5)}
 
 
+def band_table(depth=8, width=3840):
+    """(ms per banded picture by band height, whole-picture ms) for a configuration: its own measured table or the nearest one scaled."""
+    size = "8k" if width >= 7000 else ("1080p" if width <= 2000 else "4k")
+    key = (depth, size)
+    if key in BANDED_STEP_MS:
+        return dict(BANDED_STEP_MS[key]), WHOLE_STEP_MS[key]
+    near = (10, "8k") if size == "8k" else ((8, "1080p") if size == "1080p" else (8, "4k"))
+    scale = WHOLE_STEP_MS.get((depth, size), WHOLE_STEP_MS[near]) / WHOLE_STEP_MS[near]
+    return {r: v * scale for r, v in BANDED_STEP_MS[near].items()}, WHOLE_STEP_MS.get((depth, size), WHOLE_STEP_MS[near])
+
+
+def ring_model(world, rows, gop=0, ctu_rows=34, lag_rows_luma=73, depth=8, width=3840, frames=2000):
+    """Pictures per ms the ring delivers by the band model - a discrete simulation instead of round 5's closed form, so that mini-GOPs fit in:
+    frame f on rank f % world, ranks work in frame order; a picture may start `lag` after the picture it READS started and cannot end earlier than
+    `lag` after that one ended; lag = the band periods until the rows a band's search window reaches are final + a hand-over.  gop = 0: every
+    picture reads the one before it (round 5's chain: N pictures per max(step, N x lag)); gop = G: every picture reads the newest multiple of G
+    before it (FrameParallelRing(gop=G))."""
+    table, _ = band_table(depth, width)
+    step = table[rows]
+    nb = -(-ctu_rows // rows)
+    lag = (1 + -(-lag_rows_luma // (rows * 64))) * step / nb + 0.1
+    free, start, end = [0.0] * world, {}, {}
+    for f in range(frames):
+        r = f % world
+        a = (f - 1 if not gop else ((f - 1) // gop) * gop) if f > 0 else None
+        s_ = max(free[r], start[a] + lag if a is not None else 0.0)
+        e_ = max(s_ + step, end[a] + lag if a is not None else 0.0)
+        start[f], end[f], free[r] = s_, e_, e_
+    return frames / end[frames - 1]
+
+
+def pick_band_rows_gop(world, gop, ctu_rows=34, lag_rows_luma=73, depth=8, width=3840):
+    """Band size for the mini-GOP ring: the measured size with the largest modelled throughput."""
+    table, _ = band_table(depth, width)
+    best = max((ring_model(world, rows, gop, ctu_rows, lag_rows_luma, depth, width), -rows) for rows in table if rows <= ctu_rows)
+    return -best[1]
+
+
 def seam_config(key):
     """How the encoder legs configure the consumer services for BASELINE configuration `key` - by what was MEASURED on one box, every leg against the
     host-only control (profiles/r05_seam_matrix.txt, tools/r5_seam_matrix.sh), not by how many lookups get served (round-4 verdict, next 4):
@@ -478,7 +516,7 @@ def compact_line(out, minimal=False):
     c = {"workload": str(cfg.get("workload", ""))[:200], "parallelism": str(cfg.get("parallelism", ""))[:120]}
     c.update(_pick(cfg, ("ctus_per_frame", "band_rows", "sharding")))
     if "ring" in cfg:
-        c["ring"] = _pick(cfg["ring"], ("ranks_seen", "transport", "communicators", "bands_per_frame", "refs", "band_wait_ms_per_frame_max_over_ranks", "comm_init_s"))
+        c["ring"] = _pick(cfg["ring"], ("ranks_seen", "transport", "communicators", "bands_per_frame", "refs", "gop", "model_x_one_gpu", "band_wait_ms_per_frame_max_over_ranks", "comm_init_s"))
     line["config"] = c
     if "replicas" in out:
         line["replicas"] = _pick(out["replicas"], ("value", "ms_per_step", "unit"))
@@ -589,6 +627,11 @@ def main():
                     help="N > 1: ring = the reference's frame parallelism with its real dependency (frame f on rank f %% N searches frame f - 1, "
                          "handed on band by band; DESIGN.md section 6); gop = every rank encodes its own closed group of pictures with its own "
                          "reference chain (segment-parallel encoding: no data-path exchange at all, an upper bound, not what x265 -F does)")
+    ap.add_argument("--ring-gop", type=int, default=5,
+                    help="N > 1, ring: mini-GOP length G (round 6).  Frames that are multiples of G are anchors (they read the anchor before them); the G - 1 "
+                         "pictures between two anchors are non-referenced and read the anchor before them, so their ranks are independent of each other and "
+                         "the chain that bounds the ring is the anchors' - x265's default structure, bframes 4 (common/param.cpp:166-168), with the dependents "
+                         "predicted from one side.  Every picture is the same step.  0 = round 5's P-only chain (frame f reads frame f - 1)")
     ap.add_argument("--split", type=int, default=1,
                     help="search -> sub-pel refinement -> reconstruction in this many parts of whole CTU rows, part k refined / reconstructed on a side "
                          "stream while part k + 1 is searched (same results; needs --parallel-planes 1; 1 = the picture in one piece - the default: "
@@ -711,8 +754,10 @@ def main():
     gop = world > 1 and args.sharding == "gop"
     fp = P.FrameParallel(rank, 1 if gop else world)          # gop: the hand-off is this rank's own copy
     banded = (world > 1 and not gop) or args.banded
+    ring_gop = max(0, args.ring_gop) if (world > 1 and not gop) else 0
     if banded and not args.band_rows:
-        args.band_rows = pick_band_rows(world, ctu_rows=(args.height + 63) // 64, lag_rows_luma=args.range + 16, depth=args.depth, width=args.width) if world > 1 else 4
+        kw = dict(ctu_rows=(args.height + 63) // 64, lag_rows_luma=args.range + 16, depth=args.depth, width=args.width)
+        args.band_rows = (pick_band_rows_gop(world, ring_gop, **kw) if ring_gop else pick_band_rows(world, **kw)) if world > 1 else 4
     if banded:
         # N > 1: the reference's real frame-parallel dependency - frame f (rank f % N) searches frame f - 1, band by band (pipeline.FrameParallelRing)
         bp = _StubPipeline(P, pics[0], args.range, args.depth, band_rows=args.band_rows) if stub else S.BandedFramePipeline(pics[0].w64, pics[0].h64, args.depth, dev, band_rows=args.band_rows, rng=args.range, subme=args.subme, level=args.level,
@@ -724,6 +769,7 @@ def main():
                                           (("b" if args.surf_format == "packed_b" else "t") if args.band_rows >= int(os.environ.get("X265HIP_BAND_T_ROWS", "5")) and args.surf_format in ("packed_t", "packed_b") else True),
                                    lookahead=(args.width, args.height), deblock=True, sao=True, chroma=True, sao_apply=True, sign_hide=True,
                                    graphs=bool(args.band_graphs), streams=args.band_streams, sao_rdo=sao_rdo)
+        # (a band's Cb / Cr chains on side streams next to Y, like the whole-picture step, LOSE at every band size: 17 rows 1.97 -> 2.79 ms, 4 rows 2.35 -> 5.90 ms, profiles/r06_band_ab.txt)
         # (bands keep every launch on one stream: side streams for the chroma chains change nothing at band size - 3.93 vs 3.97 ms at 4 rows)
         geom = (pics[0].stride, F.MARGIN_Y, pics[0].stride_c, F.CHROMA_MARGIN_Y)
         # The band hand-off goes through the library's C ABI (x265hip_comm_* + x265hip_recon_publish_rows: pipeline.AbiTransport), so the code
@@ -736,7 +782,8 @@ def main():
             ok = 1
             t_comm = time.perf_counter()
             try:
-                transport = P.AbiTransport(rank, world, dev, args.depth, geom, pics[0].h64)
+                # mini-GOPs: an anchor's bands go to every rank that encodes one of the next G pictures - flows of distance 1 .. min(G, N - 1)
+                transport = P.AbiTransport(rank, world, dev, args.depth, geom, pics[0].h64, refs=min(ring_gop, world - 1) if ring_gop else 1)
                 transport.setup(dev)
             except Exception as e:          # noqa: BLE001 - any failure means "use the other transport", on every rank
                 sys.stderr.write(f"bench.py rank {rank}: C-ABI ring transport unavailable ({e!r}); torch.distributed point-to-point instead\n")
@@ -751,7 +798,7 @@ def main():
                     transport.close()
                 transport = None
         ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16,      # search window + 8-tap interpolation + sub-pel drift
-                                   stage_through_host=backend != "nccl", transport=transport)
+                                   stage_through_host=backend != "nccl", transport=transport, gop=ring_gop)
         if transport is None:
             ring.make_groups(device=dev)
         total_frames = (args.warmup + args.steps) * world
@@ -940,7 +987,7 @@ def main():
                                        f"frame-parallel ring x{world}, bands of {args.band_rows} CTU rows, transport {transport_name if world > 1 else 'none'}"),
                        "parallelism_detail": ((f"segment-parallel x{world}: every rank encodes its own closed group of pictures, no exchange (--sharding gop)" if gop
                                         else f"frame-parallel x{world}") if not banded else
-                                       f"frame-parallel ring x{world}: frame f on rank f % {world} searches frame f - 1, handed on in bands of {args.band_rows} CTU rows "
+                                       f"frame-parallel ring x{world}: frame f on rank f % {world} searches " + (f"the newest anchor before it (mini-GOPs of {ring_gop}: anchors = multiples of {ring_gop}, the pictures between two anchors non-referenced)" if ring_gop else "frame f - 1") + f", handed on in bands of {args.band_rows} CTU rows "
                                        f"(each band a slice of its own, like the reference's --slices); band transfers: "
                                        + ("x265hip_recon_publish_rows (the library's C ABI on RCCL, one 2-rank communicator per directed flow)" if transport_name == "abi"
                                           else "torch.distributed point-to-point")),
@@ -969,8 +1016,13 @@ def main():
                                      "(--surface brings it back)"} if args.search == "full" and not surf_mode else {})},
         }
         if ring_wait is not None:
-            out["config"]["ring"] = {"ranks_seen": ranks_seen, "transport": transport_name, "bands_per_frame": len(bp.bands), "refs": 1,
-                                     "communicators": world if transport_name == "abi" else 0,
+            flows = min(ring_gop, world - 1) if ring_gop else 1
+            model_kw = dict(ctu_rows=(args.height + 63) // 64, lag_rows_luma=args.range + 16, depth=args.depth, width=args.width)
+            out["config"]["ring"] = {"ranks_seen": ranks_seen, "transport": transport_name, "bands_per_frame": len(bp.bands), "refs": 1, "gop": ring_gop,
+                                     "communicators": world * flows if transport_name == "abi" else 0,
+                                     # what the band model predicts for this ring, in units of one GPU's whole-picture step (the tables are measured on one GPU)
+                                     "model_x_one_gpu": (round(ring_model(world, args.band_rows, ring_gop, **model_kw) * band_table(args.depth, args.width)[1], 2)
+                                                         if args.band_rows in band_table(args.depth, args.width)[0] else None),
                                      "comm_init_s": round(comm_init_s, 3) if comm_init_s is not None else None,
                                      "band_wait_ms_per_frame_max_over_ranks": ring_wait,
                                      "note": "band_wait = device time the bands' streams spent waiting for the reference rows they read (two events per band); "

@@ -46,7 +46,7 @@ def _digest(planes):
     return h.hexdigest()
 
 
-def _worker(rank, world, port, depth, tiled, out):
+def _worker(rank, world, port, depth, tiled, out, gop=0):
     import torch
     import torch.distributed as dist
     F, P, S, dev = _setup(depth, 3)
@@ -56,7 +56,7 @@ def _worker(rank, world, port, depth, tiled, out):
     total = STEPS * world
     pics = _clip(F, P, dev, depth, total)
     bp = _pipeline(S, pics, depth, dev, 3, tiled)
-    ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=R + 16, stage_through_host=True)
+    ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=R + 16, stage_through_host=True, gop=gop)
     ring.make_groups()
     geom = (pics[0].stride, F.MARGIN_Y, pics[0].stride_c, F.CHROMA_MARGIN_Y)
     ref = pics[0].like([p.clone() for p in pics[0].planes()])
@@ -77,9 +77,10 @@ def _worker(rank, world, port, depth, tiled, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("depth,world,tiled", [(8, 2, False), (8, 3, False), (10, 2, False), (8, 2, True)])
-def test_ring_on_a_shared_device_equals_one_process(depth, world, tiled):
-    """tiled: the ranks search with the record-per-lane kernel (chunk-major surfaces), the one-process encode with the row-walking one."""
+@pytest.mark.parametrize("depth,world,tiled,gop", [(8, 2, False, 0), (8, 3, False, 0), (10, 2, False, 0), (8, 2, True, 0), (8, 2, False, 3), (8, 3, False, 2)])
+def test_ring_on_a_shared_device_equals_one_process(depth, world, tiled, gop):
+    """tiled: the ranks search with the record-per-lane kernel (chunk-major surfaces), the one-process encode with the row-walking one.
+    gop: mini-GOPs (round 6) - every picture reads the newest multiple of gop before it; the one-process encode keeps that anchor as its reference."""
     import torch
     import torch.multiprocessing as mp
     F, P, S, dev = _setup(depth, 1)
@@ -90,14 +91,15 @@ def test_ring_on_a_shared_device_equals_one_process(depth, world, tiled):
     expect = {}
     for f in range(total):
         bp.run(pics[1 + f], ref)
-        for d, s in zip(ref.planes(), bp.final_planes()):
-            d.copy_(s)
+        if not gop or f % gop == 0:                      # chain: every picture is the next one's reference; mini-GOPs: the anchors only
+            for d, s in zip(ref.planes(), bp.final_planes()):
+                d.copy_(s)
         expect[f] = _digest(bp.final_planes())
     assert len(set(expect.values())) == total
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29600 + (os.getpid() % 300)
-    mp.spawn(_worker, args=(world, port, depth, tiled, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, depth, tiled, out, gop), nprocs=world, join=True)
     got = {}
     for r in range(world):
         assert sorted(out[r]) == [s * world + r for s in range(STEPS)]

@@ -451,11 +451,20 @@ class FrameParallelRing:
 
     bands: [(first CTU row, CTU rows)]; slices are computed from the plane geometry handed to run_frame."""
 
-    def __init__(self, rank: int, world: int, bands, lag_rows_luma: int, stage_through_host: bool = False, refs: int = 1, transport=None):
+    def __init__(self, rank: int, world: int, bands, lag_rows_luma: int, stage_through_host: bool = False, refs: int = 1, transport=None, gop: int = 0):
         """stage_through_host: device slices travel through host copies (a backend without device point-to-point transfers - the gloo
-        dry run of bench.py's N > 1 path on a box with fewer GPUs than ranks); never used with RCCL."""
+        dry run of bench.py's N > 1 path on a box with fewer GPUs than ranks); never used with RCCL.
+        gop (round 6; round-5 verdict, next 6): 0 = the P-only chain above.  G > 0 = mini-GOPs of G pictures: frames that are multiples of G are
+        ANCHORS (they read the anchor before them and are the only pictures anybody reads), the G - 1 pictures between two anchors are
+        NON-REFERENCED and read the anchor before them - x265's default structure (bframes 4, common/param.cpp:166-168: four non-referenced
+        pictures between two anchors, G = 5) with the dependents predicted from ONE side (the step has no bi-predictive search).  The ranks of
+        the pictures between two anchors are independent of each other, the chain that bounds the ring is the anchors' (one hop per G pictures).
+        An anchor's finished bands go ONCE to every rank that encodes one of the next G pictures; a rank keeps the anchor for all its pictures
+        that read it (and its own anchors in the caller's reference planes), so one (producer, consumer) pair never has two copies of a band
+        in flight."""
         self.rank, self.world, self.bands = rank, world, list(bands)
-        self.refs = max(1, int(refs))
+        self.gop = max(0, int(gop))
+        self.refs = max(1, int(refs)) if not self.gop else 1
         self.lag = lag_rows_luma            # luma rows below a band's last row that its search / interpolation may read
         self.prev, self.next = (rank - 1) % world, (rank + 1) % world
         self.transport = transport if transport is not None else DistTransport(rank, world, stage_through_host)
@@ -514,14 +523,32 @@ class FrameParallelRing:
         f = self.frame_index(step)
         nb = len(self.bands)
         T = self.transport
-        ref_sets = ref_planes if self.refs > 1 else [ref_planes]
-        assert len(ref_sets) == self.refs
-        # which references travel: frame f - d exists (first_frame_is_local: the job's first frames read the start picture) and was made by
-        # another rank (d a multiple of world: this rank made it itself - the caller hands its own planes in)
-        srcs = [d for d in range(1, self.refs + 1)
-                if self.world > 1 and d % self.world and not (first_frame_is_local and f - d < 0)]
-        peers = [(self.rank + d) % self.world for d in range(1, self.refs + 1)
-                 if self.world > 1 and d % self.world and (total_frames is None or f + d < total_frames)]
+        keep_own_anchor = False
+        if self.gop:
+            G = self.gop
+            anchor = ((f - 1) // G) * G if f > 0 else -1   # the picture frame f reads (-1: the start picture, local on every rank)
+            d0 = f - anchor
+            ref_sets = {d0: ref_planes}
+            # the anchor travels to this rank once: with its FIRST picture after the anchor (a later one, f - world > anchor, finds it in
+            # ref_planes); an anchor this rank made itself was copied into ref_planes when it was finished
+            srcs = [d0] if (self.world > 1 and anchor >= 0 and d0 % self.world and f - self.world <= anchor) else []
+            peers = []
+            if f % G == 0 and self.world > 1:
+                last = f + G if total_frames is None else min(f + G, total_frames - 1)
+                ranks = {(self.rank + k) % self.world for k in range(1, last - f + 1)}
+                peers = sorted(ranks - {self.rank}, key=lambda r: (r - self.rank) % self.world)
+                keep_own_anchor = any(k % self.world == 0 for k in range(1, last - f + 1))
+            if self.world == 1:
+                keep_own_anchor = f % G == 0
+        else:
+            ref_sets = dict(enumerate(ref_planes if self.refs > 1 else [ref_planes], 1))
+            assert len(ref_sets) == self.refs
+            # which references travel: frame f - d exists (first_frame_is_local: the job's first frames read the start picture) and was made by
+            # another rank (d a multiple of world: this rank made it itself - the caller hands its own planes in)
+            srcs = [d for d in range(1, self.refs + 1)
+                    if self.world > 1 and d % self.world and not (first_frame_is_local and f - d < 0)]
+            peers = [(self.rank + d) % self.world for d in range(1, self.refs + 1)
+                     if self.world > 1 and d % self.world and (total_frames is None or f + d < total_frames)]
         self.finish()                                       # the previous frame's sends must be through before out_planes is rewritten
         posted = {d: -1 for d in srcs}
         arrived = {d: -1 for d in srcs}
@@ -531,7 +558,7 @@ class FrameParallelRing:
             while posted[d] < upto:                         # receives are posted in band order per source
                 posted[d] += 1
                 r0, rn = self.bands[posted[d]]
-                pending[d][posted[d]] = T.recv(ref_sets[d - 1], self._rows(geom, r0, rn, posted[d] == 0, posted[d] == nb - 1), (r0, rn), (self.rank - d) % self.world)
+                pending[d][posted[d]] = T.recv(ref_sets[d], self._rows(geom, r0, rn, posted[d] == 0, posted[d] == nb - 1), (r0, rn), (self.rank - d) % self.world)
         for d in srcs:
             if d > 1:
                 post(d, nb - 1)                             # older references were finished long ago: everything at once
@@ -561,6 +588,9 @@ class FrameParallelRing:
             for bb in sorted(pending[d]):
                 for w in pending[d][bb]:
                     w.wait()
+        if keep_own_anchor:                                 # this rank reads its own anchor later: the reference planes are where it looks for it
+            for r, o in zip(ref_planes, out_planes):
+                r.copy_(o)
 
     def finish(self):
         for w in self._sends:
