@@ -326,7 +326,7 @@ def test_band_size_follows_the_rank_count():
 
 
 @pytest.mark.parametrize("world", [2, 3, 4, 5, 8])
-@pytest.mark.parametrize("refs", [1, 2, 3, 4])
+@pytest.mark.parametrize("refs", [1, 2, 3, 4, 5, 7])          # 5 = the mini-GOP ring of bench.py on 8 ranks (flows of distance 1 .. min(G, N - 1))
 def test_abi_transport_joins_its_communicators_without_a_waiting_cycle(world, refs):
     """pipeline.AbiTransport (what `bench.py --gpus N` uses) makes one 2-rank RCCL communicator per directed flow producer s -> consumer
     s + d with BLOCKING joins (ncclCommInitRank returns when both ranks have called it).  The joins of every rank are simulated here: a join

@@ -165,7 +165,7 @@ def test_cabac_estimators_batch(repo_root, tables):
     assert np.array_equal(back(res, np.uint32), np.array(want, np.uint32))
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", [8, 10, 12])
 def test_rdoq_uncoded_cost_batch(depth, repo_root, tables):
     """Every coefficient group of 40 TUs per size through the four pre-pass slots, in place on the blocks (row stride = the TU's)."""
     import torch

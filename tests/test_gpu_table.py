@@ -26,7 +26,7 @@ def load_hip_table(depth, base=None):
     return spec.Table(ctypes.addressof(mem), depth, (L, mem)), n
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", [8, 10, 12])
 def test_table_slots_match_oracle(depth, repo_root):
     orc = H.load_oracle(depth, repo_root, host=True)          # rows a9 / a16 included: the table is complete
     A.set_entropy_bits(H.host_tables(repo_root)["entropy_bits"])      # the host's CABAC bit costs (costCoeffNxN, costC1C2Flag)
