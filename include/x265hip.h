@@ -47,6 +47,14 @@ int x265hip_stream_release(void* stream);
 const char* x265hip_last_error(void);          /* thread-local text of the last failure */
 int         x265hip_device_count(void);
 int         x265hip_init(int device);          /* device >= 0: validate (gfx950) and hipSetDevice() it for the calling thread; -1: validate the thread's current device and keep it */
+/* How host threads wait for the device (round 6).  The runtime's default SPINS: a thread waiting 200 ms for a kernel burns 200 ms of a core (tools/ubench/wait_cpu.hip);
+ * under hipDeviceScheduleBlockingSync it burns 1.5 ms, and a short launch + wait costs the same 31 us.  The consumer services wait in worker threads and inside the lookahead's /
+ * AQ's / weightAnalyse's callers: with X265HIP_WAIT_BLOCK the real encode needs 8 % fewer CPU seconds at the same fps (- 0 .. 3 %: DESIGN.md 5.1).  The flag is a per-device,
+ * process-wide runtime setting, so the library leaves it alone unless the host asks: this call (applies to the calling thread's current device and to every device the library
+ * is initialised on afterwards) or X265HIP_WAIT=block in the environment. */
+#define X265HIP_WAIT_BLOCK 0
+#define X265HIP_WAIT_SPIN  1
+int         x265hip_set_wait_policy(int policy);
 
 /* ------------------------------------------------------------------ 1. table layer */
 /* Overwrite the GPU-backed slots of an EncoderPrimitives-layout table (18240 bytes, see

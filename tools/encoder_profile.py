@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--seam-no-sad", action="store_true", help="with --seams: no SAD lookup stubs (sub-sample / lookahead / AQ / weightAnalyse services only)")
     ap.add_argument("--seam-aq", action="store_true")
     ap.add_argument("--seam-weight-analyse", action="store_true")
+    ap.add_argument("--seam-cost", action="store_true", help="with --seams: the sub-sample cost tables (x265hip_cost_stream) behind subpelCompare, bench.py's configuration (1 candidate, the 85-position set)")
+    ap.add_argument("--no-subpel-seam", action="store_true", help="with --seams: no phase-plane service (bench.py's cfg3 leg: cost tables alone)")
     ap.add_argument("--provider", default="gpu", choices=["gpu", "oracle"], help="oracle = the CPU checker providers (plumbing test of this tool without a GPU)")
     a = ap.parse_args()
     F = importlib.import_module("x265-yuuki-asuna_amd.frames")
@@ -58,7 +60,8 @@ def main():
         if not a.no_lookahead_seam:
             opts.append(("lookahead-slices", "1"))
         lib, _, note, closer, _ = SD.install(depth, w, h, provider=a.provider, rng=a.seam_range, slots=24 if depth == 8 else 40, min_pu=128 if a.seam_no_sad else a.seam_min_pu, verify=False,
-                                             lookahead=None if a.no_lookahead_seam else a.provider, subpel=a.provider, subpel_slots=12, streamed=True,
+                                             lookahead=None if a.no_lookahead_seam else a.provider, subpel=None if a.no_subpel_seam else a.provider, subpel_slots=12, streamed=True,
+                                             cost=a.provider if a.seam_cost else None, cost_cfg=SD.cost_config(cfg["preset"], opts, set_subme=4) if a.seam_cost else None,
                                              min_level=a.seam_min_level, pictures=24, layout=1 if a.seam_layout == "planes" else 0, centre_range=a.seam_centre_range,
                                              lookahead_min_blocks=None, min_ctus=None, split_rest=a.seam_split_rest, aq=a.provider if a.seam_aq else None, aq_min_blocks=None,
                                              weight_analyse=a.provider if a.seam_weight_analyse else None, weight_min_blocks=None)

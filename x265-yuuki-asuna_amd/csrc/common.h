@@ -25,6 +25,7 @@ template <> struct PxInfo<uint16_t> { static constexpr int BPP = 2; static const
 void set_error(const char* fmt, ...);
 int  check_hip(hipError_t e, const char* what);   // 0 or X265HIP_ENODEV with last-error text
 int  ensure_device();                             // lazy x265hip_init(-1): validates the calling thread's current device
+void apply_wait_policy(int device);               // runtime.hip: blocking host waits on `device` (once per device; see x265hip_set_wait_policy)
 void* stream_scratch(hipStream_t s, int slot, size_t bytes);   // runtime.hip: grow-only scratch per (device, stream, slot), NULL on failure
 std::unique_lock<std::mutex> stream_sequence_lock(hipStream_t s);   // runtime.hip: hold it while enqueuing a clear-then-launch sequence that uses stream_scratch
 

@@ -133,6 +133,7 @@ struct Band { int slot, gen, r0, r1, fenc, view; bool hasCost; };
 int run_round(CS* s, const std::vector<Upload>& ups, const std::vector<ViewJob>& jobs, const std::vector<Band>& bands)
 {
     X265HIP_TRY(hipSetDevice(s->device));
+    apply_wait_policy(s->device);
     for (const Upload& u : ups)
         for (int pl = 0; pl < s->nplanes; pl++)
         {

@@ -74,6 +74,7 @@ double now_us()
 int run_batch(x265hip_me_cache* c, const std::vector<x265hip_me_cache::Job>& batch)
 {
     X265HIP_TRY(hipSetDevice(c->device));
+    apply_wait_policy(c->device);
     const double t0 = now_us();
     for (const auto& job : batch)
     {

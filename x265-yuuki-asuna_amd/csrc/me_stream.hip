@@ -196,6 +196,7 @@ struct Weigh { int pic, parent, r0, n; };
 int run_round(S* s, const std::vector<Upload>& ups, const std::vector<Weigh>& weighs, const std::vector<Band>& bands)
 {
     X265HIP_TRY(hipSetDevice(s->device));
+    apply_wait_policy(s->device);
     for (const Upload& u : ups)
     {
         long y0, y1;

@@ -75,6 +75,7 @@ int run_plane(x265hip_phase_cache* c, x265hip_phase_cache::Slot& s, int plane, d
 int run_job(x265hip_phase_cache* c, const x265hip_phase_cache::Job& job)
 {
     X265HIP_TRY(hipSetDevice(c->device));
+    apply_wait_policy(c->device);
     x265hip_phase_cache::Slot& s = c->slots[job.slot];
     double usK = 0, usD = 0;
     int rc = run_plane(c, s, 0, usK, usD);

@@ -115,6 +115,7 @@ struct ViewJob { int slot, gen, pic, r0, r1; int done[2]; unsigned mask; x265hip
 int run_round(PS* s, const std::vector<Upload>& ups, const std::vector<ViewJob>& jobs)
 {
     X265HIP_TRY(hipSetDevice(s->device));
+    apply_wait_policy(s->device);
     for (const Upload& u : ups)
         for (int pl = 0; pl < s->nplanes; pl++)
         {

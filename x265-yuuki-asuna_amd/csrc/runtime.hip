@@ -36,6 +36,44 @@ int check_hip(hipError_t e, const char* what)
     return X265HIP_ENODEV;
 }
 
+// WAIT POLICY (round 6).  Every host-side wait of this runtime - hipStreamSynchronize, hipEventSynchronize, with or without hipEventBlockingSync - SPINS under the default
+// device flags: a thread that waits 200 ms for a kernel burns 200 ms of a core (tools/ubench/wait_cpu.hip, profiles/r06_wait_cpu.txt); with hipDeviceScheduleBlockingSync it
+// burns 1.5 ms and a SHORT wait (launch + 20 us kernel + wait) costs the same 31 - 32 us either way.  The consumer services wait in worker threads and in the lookahead's /
+// AQ's / weightAnalyse's callers.  Measured in the real encode (tools/r6_wait_ab.sh, one box, interleaved): blocking waits take 8 % off the process's CPU seconds
+// (cfg3 74.3 -> 68.3 s, cfg4 169 -> 159 s) and leave the fps where it was or a little below (8.46 -> 8.25, 2.08 -> 2.08): the encode is bound by its row dependencies, not by
+// free cores, and a worker that sleeps wakes a little later (more records arrive late).  So the library does NOT touch the process-wide flag by itself; a host that
+// shares the machine asks for it: X265HIP_WAIT=block in the environment (read once) or x265hip_set_wait_policy(X265HIP_WAIT_BLOCK).
+std::atomic<int> g_waitPolicy{-1};                 // -1: not decided yet (environment), else X265HIP_WAIT_*
+std::atomic<unsigned long long> g_waitApplied{0};  // bit d: the policy has been applied to device d
+std::atomic<bool> g_waitTouched{false};            // this library changed a device's scheduling flag at least once
+
+static int wait_policy()
+{
+    int p = g_waitPolicy.load(std::memory_order_relaxed);
+    if (p < 0)
+    {
+        const char* e = getenv("X265HIP_WAIT");
+        p = (e && !strcmp(e, "block")) ? X265HIP_WAIT_BLOCK : X265HIP_WAIT_SPIN;
+        g_waitPolicy.store(p, std::memory_order_relaxed);
+    }
+    return p;
+}
+
+void apply_wait_policy(int device)
+{
+    if (device < 0 || device >= 64) return;
+    const unsigned long long bit = 1ull << device;
+    if (g_waitApplied.fetch_or(bit, std::memory_order_relaxed) & bit) return;
+    if (wait_policy() == X265HIP_WAIT_SPIN && !g_waitTouched.load(std::memory_order_relaxed)) return;      // the runtime's default, never touched: leave the flags alone
+    g_waitTouched.store(true, std::memory_order_relaxed);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+    if (cur != device && hipSetDevice(device) != hipSuccess) return;
+    (void)hipSetDeviceFlags(wait_policy() == X265HIP_WAIT_BLOCK ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto);       // a runtime that refuses keeps its default: slower host, same results
+    (void)hipGetLastError();
+    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+}
+
 static void do_init(int device)
 {
     int n = 0;
@@ -65,6 +103,7 @@ static void do_init(int device)
     }
     g_device = device;
     g_initRc = 0;
+    apply_wait_policy(device);
 }
 
 int ensure_device()
@@ -217,7 +256,18 @@ int x265hip_init(int device)
             }
         }
         if (check_hip(hipSetDevice(device), "hipSetDevice")) return X265HIP_ENODEV;
+        apply_wait_policy(device);
     }
+    return 0;
+}
+
+extern "C" int x265hip_set_wait_policy(int policy)
+{
+    if (policy != X265HIP_WAIT_BLOCK && policy != X265HIP_WAIT_SPIN) { set_error("x265hip_set_wait_policy: policy %d", policy); return X265HIP_EINVAL; }
+    g_waitPolicy.store(policy, std::memory_order_relaxed);
+    g_waitApplied.store(0, std::memory_order_relaxed);          // devices are visited again
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess) apply_wait_policy(cur);
     return 0;
 }
 
