@@ -297,3 +297,43 @@ def test_ssim_rows_lowres_and_cutree_rows(depth, repo_root):
     A.frame_batch(A.FR_FIX8_UNPACK, depth, n, 1, [A.Plane(dq.data_ptr(), 0), A.Plane(du.data_ptr(), 0)], one, 1)
     torch.cuda.synchronize()
     assert np.array_equal(back(dq, np.uint16), wantq) and du.cpu().numpy().tobytes() == wantu.tobytes()
+
+
+def test_edges_empty_batches_bad_arguments_and_the_missing_bit_cost_table(repo_root):
+    """Empty batches are accepted and touch nothing; 1-sample-wide planes; bad kinds / depths / NULL operands are refused with a message; the two estimators
+    that price context-coded bins refuse to run before the host handed its table in (and the table filler then leaves those two slots to the host)."""
+    import torch
+    L = A.lib()
+    L.x265hip_last_error.restype = ctypes.c_char_p
+    one = A.make_jobs([([0, 0], [0, 255])], "cuda:0")
+    src = torch.arange(7, dtype=torch.uint8, device="cuda:0")
+    dst = torch.full((7,), 9, dtype=torch.uint8, device="cuda:0")
+    pl = [A.Plane(src.data_ptr(), 1), A.Plane(dst.data_ptr(), 1)]
+    A.frame_batch(A.FR_PLANECOPY_CP, 8, 1, 7, pl, one, 0)                      # njobs = 0
+    torch.cuda.synchronize()
+    assert dst.cpu().tolist() == [9] * 7
+    A.frame_batch(A.FR_PLANECOPY_CP, 8, 1, 7, pl, one, 1)                      # a column of 7 rows, stride 1
+    torch.cuda.synchronize()
+    assert dst.cpu().tolist() == list(range(7))
+    f = L.x265hip_frame_batch
+    f.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(A.Plane), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    arr = (A.Plane * 2)(*pl)
+    assert f(99, 8, 1, 7, arr, one.data_ptr(), 1, None, None) < 0 and b"kind" in L.x265hip_last_error()
+    assert f(A.FR_PLANECOPY_CP, 9, 1, 7, arr, one.data_ptr(), 1, None, None) < 0 and b"depth" in L.x265hip_last_error()
+    assert f(A.FR_PLANECOPY_CP, 8, 0, 7, arr, one.data_ptr(), 1, None, None) < 0
+    assert f(A.FR_PLANE_CLIP_MAX, 10, 4, 4, arr, one.data_ptr(), 1, None, None) < 0 and b"out" in L.x265hip_last_error()
+    assert f(A.FR_PLANECOPY_CP, 8, 1, 7, None, one.data_ptr(), 1, None, None) < 0
+    g = L.x265hip_coeff_batch
+    g.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    bufs = (ctypes.c_void_p * 5)(src.data_ptr(), src.data_ptr(), dst.data_ptr(), src.data_ptr(), dst.data_ptr())
+    cj = A.make_coeff_jobs([([0] * 5, [1, 0])], "cuda:0")
+    res = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    assert g(A.CF_COST_COEFF_REMAIN, 8, bufs, cj.data_ptr(), 0, res.data_ptr(), None) == 0          # empty
+    assert g(42, 8, bufs, cj.data_ptr(), 1, res.data_ptr(), None) < 0 and b"kind" in L.x265hip_last_error()
+    assert g(A.CF_COST_COEFF_REMAIN, 8, bufs, cj.data_ptr(), 1, None, None) < 0 and b"result" in L.x265hip_last_error()
+    assert g(A.CF_COST_COEFF_REMAIN, 8, None, cj.data_ptr(), 1, res.data_ptr(), None) < 0
+    L.x265hip_set_entropy_bits.argtypes = [ctypes.c_void_p]
+    assert L.x265hip_set_entropy_bits(None) < 0
+    # wait policy: accepted values only; spinning (the runtime's default) restored afterwards
+    assert L.x265hip_set_wait_policy(7) < 0
+    assert L.x265hip_set_wait_policy(0) == 0 and L.x265hip_set_wait_policy(1) == 0
