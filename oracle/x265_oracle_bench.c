@@ -119,3 +119,55 @@ double x265oracle_time_jobs(void* fn, int sig, const bplane* pl, const bjob* job
 }
 
 int x265oracle_max_threads(void) { return omp_get_max_threads(); }
+
+/* ---- the RDOQ helper slots (round 6): the same harness for x265hip_coeff_job lists (5 element offsets + 5 ints into five buffers, include/x265hip.h).
+ * kind = x265hip_coeff_kind; every job owns its context bytes, so passes may run in any order (the contexts drift from pass to pass - timing only). */
+typedef struct { int64_t off[5]; int32_t arg[5]; int32_t reserved; } cjob;
+
+double x265oracle_time_coeff_jobs(void* fn, int kind, void* const* bufs, const cjob* jobs, int njobs, int reps, int threads, uint64_t* sink)
+{
+    if (threads > 0) omp_set_num_threads(threads);
+    uint64_t acc = 0;
+    double t0 = 0.0;
+    for (int rep = -1; rep < reps; rep++)
+    {
+        if (rep == 0) t0 = now();
+#pragma omp parallel for schedule(static) reduction(+ : acc)
+        for (int j = 0; j < njobs; j++)
+        {
+            const cjob* jb = &jobs[j];
+            uint16_t* b0 = (uint16_t*)bufs[0] + jb->off[0]; int16_t* b1 = (int16_t*)bufs[1] + jb->off[1];
+            switch (kind)
+            {
+            case 0:   /* scanPosLast(scan, coeff, coeffSign, coeffFlag, coeffNum, numSig, scanCG4x4, trSize) */
+                acc += (uint64_t)((int (*)(const uint16_t*, const int16_t*, uint16_t*, uint16_t*, uint8_t*, int, const uint16_t*, int))fn)(
+                    b0, b1, (uint16_t*)bufs[2] + jb->off[2], (uint16_t*)bufs[3] + jb->off[3], (uint8_t*)bufs[4] + jb->off[4], jb->arg[0], b0, jb->arg[1]);
+                break;
+            case 1:   /* findPosFirstLast(dstCoeff, trSize, scanTbl) */
+                acc += ((uint32_t (*)(const int16_t*, intptr_t, const uint16_t*))fn)(b1, jb->arg[0], b0);
+                break;
+            case 2:   /* costCoeffNxN(scan, coeff, trSize, absCoeff, tabSigCtx, scanFlagMask, baseCtx, offset, scanPosSigOff, subPosBase) */
+                acc += ((uint32_t (*)(const uint16_t*, const int16_t*, intptr_t, uint16_t*, const uint8_t*, uint32_t, uint8_t*, int, int, int))fn)(
+                    b0, b1, jb->arg[0], (uint16_t*)bufs[2] + jb->off[2], (const uint8_t*)bufs[3] + jb->off[3], (uint32_t)jb->arg[1], (uint8_t*)bufs[4] + jb->off[4],
+                    jb->arg[2], jb->arg[3], jb->arg[4]);
+                break;
+            case 3:   /* costCoeffRemain(absCoeff, numNonZero, idx) */
+                acc += ((uint32_t (*)(uint16_t*, int, int))fn)((uint16_t*)bufs[2] + jb->off[2], jb->arg[0], jb->arg[1]);
+                break;
+            case 4:   /* costC1C2Flag(absCoeff, numC1Flag, baseCtxMod, ctxOffset) */
+                acc += ((uint32_t (*)(uint16_t*, intptr_t, uint8_t*, intptr_t))fn)((uint16_t*)bufs[2] + jb->off[2], jb->arg[0], (uint8_t*)bufs[4] + jb->off[4], jb->arg[1]);
+                break;
+            case 5: case 7:   /* nonPsyRdoQuant / psyRdoQuant_1p (resi, costUncoded, totalUncoded, totalRd, blkPos) */
+                ((void (*)(int16_t*, int64_t*, int64_t*, int64_t*, uint32_t))fn)(b1, (int64_t*)bufs[2] + jb->off[2], (int64_t*)bufs[3] + jb->off[3], (int64_t*)bufs[3] + jb->off[3] + 1,
+                                                                               (uint32_t)jb->arg[0]);
+                break;
+            default:  /* psyRdoQuant / psyRdoQuant_2p (resi, fenc, costUncoded, totalUncoded, totalRd, psyScale, blkPos) */
+                ((void (*)(int16_t*, int16_t*, int64_t*, int64_t*, int64_t*, int64_t*, uint32_t))fn)(b1, (int16_t*)b0, (int64_t*)bufs[2] + jb->off[2], (int64_t*)bufs[3] + jb->off[3],
+                                                                                                   (int64_t*)bufs[3] + jb->off[3] + 1, (int64_t*)bufs[4] + jb->off[4], (uint32_t)jb->arg[0]);
+                break;
+            }
+        }
+    }
+    if (sink) *sink = acc;
+    return (now() - t0) / (reps > 0 ? reps : 1);
+}

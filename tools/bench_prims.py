@@ -133,7 +133,7 @@ def main():
     import argparse
     import torch
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="", help="comma-separated families to run: compare,interp,transform,quant,intra,intratu,blockop,loopfilter,sao")
+    ap.add_argument("--only", default="", help="comma-separated families to run: compare,interp,transform,quant,intra,intratu,blockop,loopfilter,sao,frame,coeff")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU columns (profiling runs)")
     args = ap.parse_args()
     want = set(x for x in args.only.split(",") if x)
@@ -242,7 +242,7 @@ def main():
                        SIG_DCT, [(src_h, n_), (dst_h, n_)], jb, extra)
 
     # ---- a8: quant family, 32x32 ----
-    if not (on("quant") or on("intra") or on("intratu") or on("blockop") or on("loopfilter") or on("sao")):
+    if not (on("quant") or on("intra") or on("intratu") or on("blockop") or on("loopfilter") or on("sao") or on("frame") or on("coeff")):
         return
     nb, n2 = 1 << 15, 1024
     coef_h = rng.integers(-255, 256, size=nb * n2, dtype=np.int16)
@@ -350,6 +350,165 @@ def main():
     jd = jobs_dev(jb, dev)
     t = timeit(lambda: A.loopfilter_batch(A.LF_DEBLOCK_LUMA_STRONG, 8, [A.plane(ref_d, st)], jd, ne))
     report(cpu, "pelFilterLumaStrong (4 lines)", ne, t, 4 * 8 + 4 * 6, "pelFilterLumaStrong[0]", SIG_DEBLOCK_LUMA, [(ref_h, st)], jb)
+
+    # ---- a16 / a9 (round 6): frame-level helpers on 4K planes, RDOQ helpers over 2^17 coefficient groups.  CPU columns: the reference build's own slot (ref-C) and
+    # the oracle's AVX2 restatement (port) - whole planes are ONE call of the slot (single thread, as the reference calls them: picyuv.cpp, lowres.cpp, slicetype.cpp);
+    # the RDOQ helpers run over the same job list on all host threads (oracle/x265_oracle_bench.c: x265oracle_time_coeff_jobs)
+    if on("frame") or on("coeff"):
+        import time
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import harness_host as HH        # noqa: E402  (TEST INFRASTRUCTURE: scan tables / coefficient recipes of the reference's harnesses)
+        ref_h8 = H.load_reference(8, ROOT)
+        orc8 = H.load_oracle(8, ROOT, avx2=True, host=True)
+        tabs = [t for t in (ref_h8, orc8) if t is not None]
+
+        def cpu_cols(path, call, nbytes, reps=5, tables=None):
+            cols, best = [], None
+            for tab in (tables or (ref_h8, orc8)):
+                if tab is None or not tab.ptr(path):
+                    cols.append(f"{'-':>10s}"); continue
+                f_ = tab.fn(path)
+                call(f_)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    call(f_)
+                tc = (time.perf_counter() - t0) / reps
+                cols.append(f"{nbytes / tc / 1e9:10.2f}")
+                best = tc if best is None or tc < best else best
+            return cols, best
+    if on("frame"):
+        pw, ph, pst, NP = 3840, 2160, 3840 + 192, 24          # 24 planes per launch: 0.4 - 0.8 GB of traffic, past the 256 MiB Infinity Cache
+        src8 = rng.integers(0, 256, size=pst * ph, dtype=np.uint8)
+        src16 = rng.integers(0, 1024, size=pst * ph).astype(np.uint16)
+        d8, d16 = to_dev(np.tile(src8, NP), dev), to_dev(np.tile(src16, NP), dev)
+        o8, o16 = torch.zeros(NP * pst * ph, dtype=torch.uint8, device=dev), torch.zeros(NP * pst * ph, dtype=torch.int16, device=dev)
+        out8, out16 = np.zeros(pst * ph, np.uint8), np.zeros(pst * ph, np.uint16)
+        P2 = lambda a, b: [A.Plane(a.data_ptr(), pst), A.Plane(b.data_ptr(), pst)]
+        orc10 = H.load_oracle(10, ROOT, avx2=True, host=True)
+        ref10 = H.load_reference(10, ROOT)
+        for name, kind, depth, src_d, dst_d, path, call, bpp, args_, tabs10 in (
+                ("planecopy_cp 4K planes (u8 -> u8)", A.FR_PLANECOPY_CP, 8, d8, o8, "planecopy_cp", lambda f_: f_(H.ptr(src8), pst, H.ptr(out8), pst, pw, ph, 0), 2, (0, 0), False),
+                ("planecopy_sp 4K planes (u16 -> u8)", A.FR_PLANECOPY_SP, 8, d16, o8, "planecopy_sp", lambda f_: f_(H.ptr(src16), pst, H.ptr(out8), pst, pw, ph, 2, 255), 3, (2, 255), False),
+                ("planecopy_sp 4K planes (u16 -> 10 bit)", A.FR_PLANECOPY_SP, 10, d16, o16, "planecopy_sp", lambda f_: f_(H.ptr(src16), pst, H.ptr(out16), pst, pw, ph, 0, 1023), 4, (0, 1023), True),
+                ("planecopy_pp_shr 4K planes", A.FR_PLANECOPY_PP_SHR, 8, d8, o8, "planecopy_pp_shr", lambda f_: f_(H.ptr(src8), pst, H.ptr(out8), pst, pw, ph, 2), 2, (2, 0), False)):
+            jd = jobs_dev(jobs_np(NP, (np.arange(NP, dtype=np.int64) * pst * ph,) * 2, args_), dev)
+            t = timeit(lambda: A.frame_batch(kind, depth, pw, ph, P2(src_d, dst_d), jd, NP))
+            nbytes = bpp * pw * ph
+            cols, best = cpu_cols(path, call, nbytes, tables=(ref10, orc10) if tabs10 else None)
+            gbs = NP * nbytes / t / 1e9
+            print(f"{name:40s} {NP:8d} {t * 1e6:9.1f} {nbytes:7d} {gbs:9.1f} {gbs / HBM:6.3f} {cols[0]} {cols[1]} {NP * best / t if best else 0:8.1f}  planes; bytes = one read + one write; CPU = one call per plane, one thread", flush=True)
+        if orc10 is not None:          # planeClipAndMax exists in the high-bit-depth builds only
+            clip = to_dev(np.tile(src16, NP), dev)
+            outc = torch.zeros(2 * NP, dtype=torch.int64, device=dev)
+            jd = jobs_dev(jobs_np(NP, (np.arange(NP, dtype=np.int64) * pst * ph,), (64, 940)), dev)
+            t = timeit(lambda: A.frame_batch(A.FR_PLANE_CLIP_MAX, 10, pw, ph, P2(clip, clip), jd, NP, outc))
+            tot = np.zeros(1, np.uint64); work = src16.copy()
+            cols, best = cpu_cols("planeClipAndMax", lambda f_: f_(H.ptr(work), pst, pw, ph, H.ptr(tot), 64, 940), 4 * pw * ph, tables=(ref10, orc10))
+            gbs = NP * 4 * pw * ph / t / 1e9
+            print(f"{'planeClipAndMax 4K planes (10 bit)':40s} {NP:8d} {t * 1e6:9.1f} {4 * pw * ph:7d} {gbs:9.1f} {gbs / HBM:6.3f} {cols[0]} {cols[1]} {NP * best / t if best else 0:8.1f}  planes; clamp in place + maximum + sum", flush=True)
+        # frameInitLowres 4K -> four 1920 x 1080 planes
+        lw, lh, lst = 1920, 1080, 1920 + 64
+        lo = [torch.zeros(lst * lh, dtype=torch.uint8, device=dev) for _ in range(4)]
+        lo_h = [np.zeros(lst * lh, np.uint8) for _ in range(4)]
+        srcL = rng.integers(0, 256, size=pst * (ph + 2), dtype=np.uint8)
+        dL = to_dev(srcL, dev)
+        t = timeit(lambda: A.frame_init_lowres(8, dL, 0, pst, lo, lst, lw, lh))
+        nbytes = pw * ph + 4 * lw * lh
+        cols, best = cpu_cols("frameInitLowres", lambda f_: f_(H.ptr(srcL), *[H.ptr(x) for x in lo_h], pst, lst, lw, lh), nbytes)
+        gbs = nbytes / t / 1e9
+        print(f"{'frameInitLowres 4K -> 4 x 1080p':40s} {1:8d} {t * 1e6:9.1f} {nbytes:7d} {gbs:9.1f} {gbs / HBM:6.3f} {cols[0]} {cols[1]} {best / t if best else 0:8.1f}  plane; bytes = source once + four planes", flush=True)
+        # propagateCost over a 4K picture's 240 x 135 lowres blocks, ssim moments of a 4K plane
+        nblk = 240 * 135
+        pin, inter = rng.integers(0, 65536, size=nblk).astype(np.uint16), rng.integers(0, 65536, size=nblk).astype(np.uint16)
+        intra, invq = rng.integers(1, 1 << 15, size=nblk).astype(np.int32), rng.integers(1, 1 << 15, size=nblk).astype(np.int32)
+        fps = np.array([64.0]); outp = np.zeros(nblk, np.int32)
+        dp = [to_dev(x, dev) for x in (pin, intra, inter, invq)]
+        dd = torch.zeros(nblk, dtype=torch.int32, device=dev)
+        t = timeit(lambda: A.propagate_cost(dd, dp[0], dp[1], dp[2], dp[3], 64.0, nblk))
+        nbytes = nblk * 16
+        cols, best = cpu_cols("propagateCost", lambda f_: f_(H.ptr(outp), H.ptr(pin), H.ptr(intra), H.ptr(inter), H.ptr(invq), H.ptr(fps), nblk), nbytes, reps=20)
+        print(f"{'propagateCost 240 x 135 blocks':40s} {nblk:8d} {t * 1e6:9.1f} {16:7d} {nbytes / t / 1e9:9.1f} {nbytes / t / 1e9 / HBM:6.3f} {cols[0]} {cols[1]} {best / t if best else 0:8.1f}  launch-latency bound at this size", flush=True)
+        pairs = [(y, x) for y in range(ph // 4) for x in range(0, pw // 4 - 1, 2)]
+        jb = jobs_np(len(pairs), (np.array([4 * y * pst + 4 * x for y, x in pairs], np.int64),) * 2)
+        jd = jobs_dev(jb, dev)
+        osum = torch.zeros(len(pairs) * 8, dtype=torch.int32, device=dev)
+        d8b = to_dev(np.clip(src8.astype(np.int32) + 3, 0, 255).astype(np.uint8), dev)
+        t = timeit(lambda: A.frame_batch(A.FR_SSIM_CORE, 8, 8, 4, [A.Plane(d8.data_ptr(), pst), A.Plane(d8b.data_ptr(), pst)], jd, len(pairs), osum))
+        nbytes = len(pairs) * 64
+        print(f"{'ssim_4x4x2_core over a 4K plane':40s} {len(pairs):8d} {t * 1e6:9.1f} {64:7d} {nbytes / t / 1e9:9.1f} {nbytes / t / 1e9 / HBM:6.3f} {'-':>10s} {'-':>10s} {'-':>8s}  8x4 samples of two planes per job", flush=True)
+    if on("coeff"):
+        A.set_entropy_bits(H.host_tables(ROOT)["entropy_bits"])
+        blib = cpu.lib
+        blib.x265oracle_time_coeff_jobs.restype = ctypes.c_double
+        blib.x265oracle_time_coeff_jobs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        nj = 1 << 17
+        cdt = np.dtype([("off", "<i8", 5), ("arg", "<i4", 5), ("reserved", "<i4")])
+        scan16 = np.tile(HH.diag_scan(4), (nj, 1))
+        coeff = rng.integers(-300, 301, size=(nj, 16)).astype(np.int16)
+        coeff[rng.random((nj, 16)) < 0.6] = 0
+        coeff[:, 0] |= 1
+        tabc = rng.integers(0, 9, size=(nj, 16)).astype(np.uint8)
+        ctx = rng.integers(2, 125, size=(nj, 64)).astype(np.uint8)
+        absb = rng.integers(1, 40, size=(nj, 24)).astype(np.uint16)
+        masks = np.array([int("".join("1" if coeff[j, int(q)] else "0" for q in HH.diag_scan(4)), 2) for j in range(nj)], np.int64)
+        idx = np.arange(nj, dtype=np.int64)
+
+        def cj(offs, args):
+            a = np.zeros(nj, cdt)
+            for k, o in enumerate(offs): a["off"][:, k] = o
+            for k, v in enumerate(args): a["arg"][:, k] = v
+            return a
+        cases = [
+            ("costCoeffNxN (16 positions)", A.CF_COST_COEFF_NXN, "costCoeffNxN", cj((16 * idx, 16 * idx, 24 * idx, 16 * idx, 64 * idx), (4, masks, 12, 15, 16)), 128),
+            ("costC1C2Flag (8 flags)", A.CF_COST_C1C2, "costC1C2Flag", cj((0, 0, 24 * idx, 0, 64 * idx), (8, 24)), 32),
+            ("costCoeffRemain (16 levels)", A.CF_COST_COEFF_REMAIN, "costCoeffRemain", cj((0, 0, 24 * idx), (16, 0)), 32),
+            ("findPosFirstLast", A.CF_FIND_POS_FIRST_LAST, "findPosFirstLast", cj((16 * idx, 16 * idx), (4,)), 64),
+        ]
+        bufs_h = [scan16.reshape(-1), coeff.reshape(-1), absb.reshape(-1), tabc.reshape(-1), ctx.reshape(-1)]
+        bufs_d = [to_dev(b.copy(), dev) for b in bufs_h]
+        res = torch.zeros(nj, dtype=torch.int32, device=dev)
+        for name, kind, path, jobs, bpj in cases:
+            jd = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(dev)
+            t = timeit(lambda: A.coeff_batch(kind, 8, bufs_d, jd, nj, res))
+            cols, best = [], None
+            for tab in (ref_h8, orc8):
+                if tab is None or not tab.ptr(path):
+                    cols.append(f"{'-':>10s}"); continue
+                hb = [b.copy() for b in bufs_h]
+                ptrs = (ctypes.c_void_p * 5)(*[b.ctypes.data for b in hb])
+                jj = np.ascontiguousarray(jobs)
+                tc = blib.x265oracle_time_coeff_jobs(tab.ptr(path), kind, ptrs, jj.ctypes.data, nj, 5, cpu.threads, None)
+                cols.append(f"{nj * bpj / tc / 1e9:10.2f}")
+                best = tc if best is None or tc < best else best
+            gbs = nj * bpj / t / 1e9
+            print(f"{name:40s} {nj:8d} {t * 1e6:9.1f} {bpj:7d} {gbs:9.1f} {gbs / HBM:6.3f} {cols[0]} {cols[1]} {best / t if best else 0:8.1f}  calls; {nj / t / 1e6:.0f} M calls/s on the GPU, "
+                  f"{nj / best / 1e6 if best else 0:.0f} M calls/s on {cpu.threads} host threads; serial in the CABAC state per call", flush=True)
+        # scanPosLast: 2^13 32x32 TUs
+        nt = 1 << 13
+        scan32, inner = HH.block_scan(rng, 32, 0)
+        cf = rng.integers(-300, 301, size=(nt, 1024)).astype(np.int16)
+        cf[rng.random((nt, 1024)) < 0.9] = 0
+        cf[:, 5] = 7
+        nsig = np.count_nonzero(cf, axis=1)
+        a = np.zeros(nt, cdt)
+        ti = np.arange(nt, dtype=np.int64)
+        a["off"][:, 1], a["off"][:, 2], a["off"][:, 3], a["off"][:, 4] = 1024 * ti, 64 * ti, 64 * ti, 64 * ti
+        a["arg"][:, 0], a["arg"][:, 1] = nsig, 32
+        hb = [scan32.copy(), cf.reshape(-1), np.zeros(nt * 64, np.uint16), np.zeros(nt * 64, np.uint16), np.zeros(nt * 64, np.uint8)]
+        db = [to_dev(b.copy(), dev) for b in hb]
+        jd = torch.from_numpy(a.view(np.uint8).reshape(-1)).to(dev)
+        res = torch.zeros(nt, dtype=torch.int32, device=dev)
+        t = timeit(lambda: A.coeff_batch(A.CF_SCAN_POS_LAST, 8, db, jd, nt, res))
+        cols, best = [], None
+        for tab in (ref_h8, orc8):
+            if tab is None:
+                cols.append(f"{'-':>10s}"); continue
+            ptrs = (ctypes.c_void_p * 5)(*[b.ctypes.data for b in hb])
+            tc = blib.x265oracle_time_coeff_jobs(tab.ptr("scanPosLast"), 0, ptrs, a.ctypes.data, nt, 5, cpu.threads, None)
+            cols.append(f"{nt * 2368 / tc / 1e9:10.2f}")
+            best = tc if best is None or tc < best else best
+        gbs = nt * 2368 / t / 1e9
+        print(f"{'scanPosLast 32x32 TU (10 % non-zero)':40s} {nt:8d} {t * 1e6:9.1f} {2368:7d} {gbs:9.1f} {gbs / HBM:6.3f} {cols[0]} {cols[1]} {best / t if best else 0:8.1f}  TUs; bytes = coefficients + the three 64-entry outputs; a wavefront per TU", flush=True)
 
     # ---- (f)-4: frame-level SAO passes on a 4K picture (statistics for every CTU / type / class; offsets applied out of place) ----
     if on("loopfilter") or on("sao"):

@@ -8,8 +8,8 @@
 //  x265hip_coeff_batch      the RDOQ helpers of Quant::rdoQuant (quant.cpp:609-1300): scanPosLast, findPosFirstLast, costCoeffNxN,
 //                           costCoeffRemain, costC1C2Flag and the four uncoded-cost pre-passes (dct.cpp:757-1069)
 //
-// Mapping.  The plane kernels are HBM-bound byte / word moves: a thread owns four consecutive samples of a row, a row of the grid per
-// picture row, a grid layer per job, so that a wavefront reads and writes 256 (8-bit) or 512 (16-bit) contiguous bytes.  The coefficient
+// Mapping.  The plane kernels are HBM-bound byte / word moves: a thread owns 16 consecutive samples of a row (16-byte loads and stores when the row
+// pointers allow), a row of the grid per picture row, a grid layer per job, so that a wavefront reads and writes 1 (8-bit) or 2 KiB (16-bit) contiguous bytes.  The coefficient
 // helpers are serial in the CABAC context state BY DEFINITION (every bin's cost and next state depend on the previous bin of the same
 // context): what is parallel is the batch - thousands of coefficient groups of different TUs, each with its own copy of the contexts -
 // so a lane owns one call and walks its <= 16 steps; scanPosLast alone is parallel inside a call (a lane per coefficient group of the
@@ -41,45 +41,78 @@ __device__ __forceinline__ D convert_sample(S v, int shift, int mask)
     return (D)((int)v >> shift);                                                           // planecopy_pp_shr :900-910
 }
 
-// grid (ceil(w / 1024), h, njobs) x 256 threads
+// grid (ceil(w / 4096), h, njobs) x 256 threads: a thread owns 16 consecutive samples of a row - one or two 16-byte loads and stores when both row pointers are 16-byte
+// aligned (whole planes of the PicYuv layout are: strides are multiples of 64), sample by sample otherwise (arbitrary offsets, the row's tail)
 template <typename S, typename D, int KIND>
 __global__ void __launch_bounds__(256) planecopy_kernel(FrameArgs a)
 {
     const x265hip_job jb = a.jobs[blockIdx.z];
-    const int y = blockIdx.y, x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int y = blockIdx.y, x0 = (blockIdx.x * 256 + threadIdx.x) * 16;
     if (x0 >= a.w) return;
     const S* s = (const S*)a.p0.base + jb.off[0] + (intptr_t)y * a.p0.stride + x0;
     D* d = (D*)a.p1.base + jb.off[1] + (intptr_t)y * a.p1.stride + x0;
-    const int n = min(4, a.w - x0);
+    const int n = min(16, a.w - x0);
+    if (n == 16 && !(((uintptr_t)s | (uintptr_t)d) & 15))
+    {
+        S v[16]; D o[16];
+        __builtin_memcpy(v, __builtin_assume_aligned(s, 16), sizeof(v));
+#pragma unroll
+        for (int i = 0; i < 16; i++) o[i] = convert_sample<S, D, KIND>(v[i], jb.arg[0], jb.arg[1]);
+        __builtin_memcpy(__builtin_assume_aligned(d, 16), o, sizeof(o));
+        return;
+    }
     for (int i = 0; i < n; i++) d[i] = convert_sample<S, D, KIND>(s[i], jb.arg[0], jb.arg[1]);
 }
 
 // planeClipAndMax (pixel.cpp:996-1016): clamp in place, the plane's maximum and sum.  out[2 job] = max, out[2 job + 1] = sum (zeroed by
-// the launcher): a wavefront reduces its samples with DPP-free shuffles, one atomic pair per wavefront
+// the launcher).  A thread owns 16 samples of a row like the copies; a workgroup walks CLIP_ROWS rows, reduces through shuffles and LDS and issues ONE
+// atomic pair: with one pair per wavefront and row the 200 000 atomics of 24 planes on 48 addresses were the whole launch (2.26 ms -> see profiles/r06_prims_frame_coeff.txt)
+constexpr int CLIP_ROWS = 16;
 template <typename Px>
 __global__ void __launch_bounds__(256) plane_clip_max_kernel(FrameArgs a)
 {
+    __shared__ unsigned sMax[4], sSum[4];
     const x265hip_job jb = a.jobs[blockIdx.z];
-    const int y = blockIdx.y, x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 16;
+    const int lo = jb.arg[0], hi = jb.arg[1];
     unsigned mx = 0, sum = 0;
     if (x0 < a.w)
-    {
-        Px* p = (Px*)a.p0.base + jb.off[0] + (intptr_t)y * a.p0.stride + x0;
-        const int n = min(4, a.w - x0);
-        for (int i = 0; i < n; i++)
+        for (int y = blockIdx.y * CLIP_ROWS; y < min(a.h, (int)(blockIdx.y + 1) * CLIP_ROWS); y++)
         {
-            int v = p[i];
-            v = v < jb.arg[0] ? jb.arg[0] : (v > jb.arg[1] ? jb.arg[1] : v);
-            p[i] = (Px)v;
-            mx = max(mx, (unsigned)v); sum += (unsigned)v;
+            Px* p = (Px*)a.p0.base + jb.off[0] + (intptr_t)y * a.p0.stride + x0;
+            const int n = min(16, a.w - x0);
+            if (n == 16 && !((uintptr_t)p & 15))
+            {
+                Px v[16];
+                __builtin_memcpy(v, __builtin_assume_aligned(p, 16), sizeof(v));
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                {
+                    const int c = min(max((int)v[i], lo), hi);
+                    v[i] = (Px)c; mx = max(mx, (unsigned)c); sum += (unsigned)c;
+                }
+                __builtin_memcpy(__builtin_assume_aligned(p, 16), v, sizeof(v));
+            }
+            else
+                for (int i = 0; i < n; i++)
+                {
+                    const int c = min(max((int)p[i], lo), hi);
+                    p[i] = (Px)c; mx = max(mx, (unsigned)c); sum += (unsigned)c;
+                }
         }
-    }
+    // a thread's sum: 16 rows x 16 samples x 4095 < 2^21; a wavefront's < 2^27; the workgroup's < 2^29
     for (int o = 32; o; o >>= 1) { mx = max(mx, (unsigned)__shfl_xor((int)mx, o)); sum += (unsigned)__shfl_xor((int)sum, o); }
-    if ((threadIdx.x & 63) == 0 && (sum | mx))
+    if ((threadIdx.x & 63) == 0) { sMax[threadIdx.x >> 6] = mx; sSum[threadIdx.x >> 6] = sum; }
+    __syncthreads();
+    if (threadIdx.x == 0)
     {
-        unsigned long long* out = (unsigned long long*)a.out + 2 * blockIdx.z;
-        atomicMax(&out[0], (unsigned long long)mx);
-        atomicAdd(&out[1], (unsigned long long)sum);
+        mx = max(max(sMax[0], sMax[1]), max(sMax[2], sMax[3])); sum = sSum[0] + sSum[1] + sSum[2] + sSum[3];
+        if (sum | mx)
+        {
+            unsigned long long* out = (unsigned long long*)a.out + 2 * blockIdx.z;
+            atomicMax(&out[0], (unsigned long long)mx);
+            atomicAdd(&out[1], (unsigned long long)sum);
+        }
     }
 }
 
@@ -446,7 +479,7 @@ extern "C" int x265hip_frame_batch(int kind, int depth, int w, int h, const x265
     const bool hi = depth > 8;
     const bool plane_kind = kind >= X265HIP_FR_PLANECOPY_CP && kind <= X265HIP_FR_PLANE_CLIP_MAX;
     if (plane_kind && (w <= 0 || h <= 0 || h > 65535 || njobs > 65535)) { set_error("frame_batch: plane %dx%d x %d jobs", w, h, njobs); return X265HIP_EINVAL; }
-    const dim3 pg((unsigned)((w + 1023) / 1024), (unsigned)(h > 0 ? h : 1), (unsigned)njobs);
+    const dim3 pg((unsigned)((w + 4095) / 4096), (unsigned)(h > 0 ? h : 1), (unsigned)njobs);
     switch (kind)
     {
     case X265HIP_FR_PLANECOPY_CP:
@@ -468,8 +501,11 @@ extern "C" int x265hip_frame_batch(int kind, int depth, int w, int h, const x265
     case X265HIP_FR_PLANE_CLIP_MAX:
         if (!out) { set_error("frame_batch: planeClipAndMax needs out"); return X265HIP_EINVAL; }
         X265HIP_TRY(hipMemsetAsync(out, 0, (size_t)njobs * 16, s));
-        if (hi) hipLaunchKernelGGL(plane_clip_max_kernel<uint16_t>, pg, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(plane_clip_max_kernel<uint8_t>, pg, dim3(256), 0, s, a);
+        {
+            const dim3 cg(pg.x, (unsigned)((h + CLIP_ROWS - 1) / CLIP_ROWS), pg.z);
+            if (hi) hipLaunchKernelGGL(plane_clip_max_kernel<uint16_t>, cg, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(plane_clip_max_kernel<uint8_t>, cg, dim3(256), 0, s, a);
+        }
         break;
     case X265HIP_FR_SSIM_CORE:
         if (!out) { set_error("frame_batch: ssim core needs out"); return X265HIP_EINVAL; }
