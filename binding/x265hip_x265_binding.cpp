@@ -1431,6 +1431,12 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
             vlc.assign(q.lowres_costs, q.lowres_costs + nblk); vrs.assign(q.row_satds, q.row_satds + q.height_in_cu);
         }
         rc = gla.host(&q);
+#if X265HIP_BINDING_TEST_HOOKS
+        {   /* diagnostic (tools/r6_lookahead_bound_ab.sh): X265REF_LA_DELAY_US adds latency to every served estimate - does the encode's fps follow it? */
+            static const int delayUs = getenv("X265REF_LA_DELAY_US") ? atoi(getenv("X265REF_LA_DELAY_US")) : 0;
+            if (delayUs > 0) { struct timespec ts = { 0, (long)delayUs * 1000L }; nanosleep(&ts, NULL); }
+        }
+#endif
         if (gla.oracle && !rc)
         {
             const pixel* r0[4]; const pixel* r1[4]; const pixel* rb[4];

@@ -401,12 +401,17 @@ typedef struct x265hip_lowres_cost_params
     int bframe_bias;                                /* param->bFrameBias: B score = costEst * 100 / (130 + bias) */
     const x265hip_lowres_cost_pair* pairs;  int npairs;
     int pairs_on_device;                            /* 0: `pairs` is host memory (copied in stream order, may block the caller);
-                                                       1 / 2: `pairs` already is a device array of P (1) / B (2) pictures (no allocation, no copy, no validation) */
+                                                       1 / 2: `pairs` already is a device array of P (1) / B (2) pictures (no allocation, no copy, no validation);
+                                                       | 4 (round 6): none of those pairs needs a search (every do_search is 0) - the dependency-free launch may be used */
 } x265hip_lowres_cost_params;
 /* One workgroup walks a picture (a wavefront of dependent block rows); a call of up to four pictures of 32 or more block rows - the
  * latency case: a host thread waits for one estimate - gives every picture several workgroups, one per band of block rows, the
  * boundary mvs handed upward through L2 (same integers; 4K: 8.9 -> 5.2 ms per estimate).  Uses a few KB of per-stream scratch. */
 int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* stream);
+/* Round 6: a call none of whose pairs needs a search (do_search 0 / 0: both lists were searched by earlier estimates - a third of the triples of the slice-type decision) has no
+ * dependency between blocks and runs as ONE flat launch (a wavefront per block row) instead of the W + 2 H lock-steps.  Diagnostic: launches so far as
+ * { flat, one-workgroup walk, split walk } (process-wide). */
+void x265hip_lowres_cost_launch_counts(uint64_t out[3]);
 
 /* The same estimate behind host pointers, shaped like the loop it replaces (csrc/lookahead_host.hip): ONE call = the estimateCUCost
  * loop of CostEstimateGroup::estimateFrameCost (slicetype.cpp:3178-3196 over :3216-3388) for one (p0, b, p1) triple whose Lowres

@@ -109,6 +109,25 @@ def test_lowres_b_cost_matches_oracle(depth, width, height, bias):
                                                       bframe_bias=bias, do_search=(0, 1), mvs_in=(keep0, None), mv_costs_in=(keepc0, None))
     assert np.array_equal(st.mvs.cpu().numpy().reshape(-1, 2), keep0) and np.array_equal(st.mvs1.cpu().numpy().reshape(-1, 2), mvs2[1])
     assert np.array_equal(st.lowres_costs.cpu().numpy().view(np.uint16), lcost2) and np.array_equal(st.frame.cpu().numpy(), frame2)
+    # third estimate, NEITHER list searched again (a third of the slice-type decision's triples): the dependency-free launch (round 6) - the vectors are
+    # inputs, everything else must equal the oracle's answer and what the lock-step walk gives for the same request
+    keep1, keepc1 = st.mvs1.cpu().numpy().reshape(-1, 2).copy(), st.mv_costs1.cpu().numpy().copy()
+    st.lowres_costs.zero_(); st.row_satds.zero_(); st.frame.zero_()
+    st.run(lc, l0, l0, do_search=(0, 0), bframe_bias=bias)
+    torch.cuda.synchronize()
+    mvs3, mvc3, lcost3, rows3, frame3 = O.lowres_cost(depth, cp, r0, lc.stride, lc.org, lc.wcu, lc.hcu, cq, st.qoff, ic, ref1_planes=r0, bframe_bias=bias,
+                                                      do_search=(0, 0), mvs_in=(keep0, keep1), mv_costs_in=(keepc0, keepc1))
+    flat = (st.lowres_costs.cpu().numpy().view(np.uint16).copy(), st.row_satds.cpu().numpy().copy(), st.frame.cpu().numpy().copy())
+    assert np.array_equal(st.mvs.cpu().numpy().reshape(-1, 2), keep0) and np.array_equal(st.mvs1.cpu().numpy().reshape(-1, 2), keep1)
+    assert np.array_equal(flat[0], lcost3) and np.array_equal(flat[1], rows3) and np.array_equal(flat[2], frame3)
+    os.environ["X265HIP_LOWRES_COST_FLAT_OFF"] = "1"
+    try:
+        st.lowres_costs.zero_(); st.row_satds.zero_(); st.frame.zero_()
+        st.run(lc, l0, l0, do_search=(0, 0), bframe_bias=bias)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["X265HIP_LOWRES_COST_FLAT_OFF"]
+    assert np.array_equal(st.lowres_costs.cpu().numpy().view(np.uint16), flat[0]) and np.array_equal(st.row_satds.cpu().numpy(), flat[1]) and np.array_equal(st.frame.cpu().numpy(), flat[2])
 
 
 def test_lowres_cost_rejects_bad_geometry():

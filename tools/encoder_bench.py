@@ -99,6 +99,8 @@ def run_config(key, tables, frames=None, frame_threads=1, budget_s=240.0, log=sy
     yuv = np.concatenate([np.concatenate([p.reshape(-1) for p in fr]) for fr in clip])
     lib = ref_lib(depth, build)
     opts = [("pools", str(cores)), ("frame-threads", str(frame_threads)), ("crf", "28")] + cfg["opts"]
+    # diagnostic only (what bounds the encode?): ENCODER_BENCH_EXTRA_OPTS="b-adapt=0,rc-lookahead=10" appends x265 options to EVERY leg of the run
+    opts += [tuple(kv.split("=", 1)) if "=" in kv else (kv, None) for kv in os.environ.get("ENCODER_BENCH_EXTRA_OPTS", "").split(",") if kv]
     if seam.get("lookahead"):        # the lookahead seam serves unsliced frame cost estimates: every leg of this run walks the lowres picture in one piece
         opts.append(("lookahead-slices", "1"))
     res = {"config": cfg["name"], "size": f"{w}x{h}", "depth": depth, "preset": cfg["preset"], "options": dict(opts), "pool_threads": cores,

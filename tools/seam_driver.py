@@ -1124,6 +1124,14 @@ def install(depth, width, height, provider="gpu", rng=32, slots=8, min_pu=8, ver
         d["lookahead_seam"] = {"provider": lookahead, "frame_cost_estimates_served": int(la[0]), "passed_to_reference_loop": int(la[1]), "failed": int(la[2]),
                                "intra_estimates_served": int(la[3]), "verify_mismatches": int(lib.x265ref_lookahead_seam_mismatches()),
                                "left_to_the_reference_by_the_size_gate": int(lib.x265ref_lookahead_seam_min_blocks(-1))}
+        if lookahead == "gpu":
+            try:          # process-wide launch counts of x265hip_lowres_cost: { dependency-free flat launches (no list searched again), one-workgroup walks, split walks }
+                A_ = importlib.import_module("x265-yuuki-asuna_amd.hipabi")
+                cnt = (ctypes.c_uint64 * 3)()
+                A_.lib().x265hip_lowres_cost_launch_counts(cnt)
+                d["lookahead_seam"]["launches_flat_walk_split"] = [int(cnt[0]), int(cnt[1]), int(cnt[2])]
+            except (AttributeError, OSError):
+                pass
         aqs = (ctypes.c_uint64 * 5)()
         lib.x265ref_aq_seam_stats(aqs)
         d["aq_seam"] = {"provider": aq, "pictures_served": int(aqs[0]), "passed_to_reference_loop": int(aqs[1]), "failed": int(aqs[2]), "verify_mismatches": int(aqs[3]),

@@ -233,7 +233,8 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
     q.cost_q = (const uint16_t*)(d + oCost); q.qoff = p->cost_q_half; q.bframe_bias = p->bframe_bias;
     // the pair record travels in this thread's own scratch: no stream-ordered allocation per call
     if (up(oPair, &pr, sizeof(pr))) return X265HIP_ENODEV;
-    q.pairs = (const x265hip_lowres_cost_pair*)(d + oPair); q.npairs = 1; q.pairs_on_device = bidir ? 2 : 1;
+    q.pairs = (const x265hip_lowres_cost_pair*)(d + oPair); q.npairs = 1;
+    q.pairs_on_device = (bidir ? 2 : 1) | ((!p->do_search[0] && (!bidir || !p->do_search[1])) ? 4 : 0);          // | 4: no list is searched again - the dependency-free launch
     rc = x265hip_lowres_cost(&q, s);
     if (rc) return rc;
     auto down = [&](void* dst, size_t o, size_t bytes) { return check_hip(hipMemcpyAsync(dst, d + o, bytes, hipMemcpyDeviceToHost, s), "lowres_cost_host download"); };

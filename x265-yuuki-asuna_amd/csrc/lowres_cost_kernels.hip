@@ -400,9 +400,129 @@ __global__ void __launch_bounds__(SPLIT ? 512 : 1024) lowres_cost_kernel(LowresC
     if (threadIdx.x == 0) pr.frame[3] = BIDIR ? sFrame[0] * 100 / (130 + g.bFrameBias) : sFrame[0];      // estimateFrameCost's score (:3201-3204)
 }
 
+// FLAT (round 6).  An estimate whose lists were BOTH searched by earlier estimates (estimateFrameCost's bDoSearch false for every list it reads, slicetype.cpp:3126-3127:
+// a third of the triples the slice-type decision scores - every (p0, b, p1) after the first with the same (b, p0) and (b, p1)) has no dependency between blocks at all:
+// the vectors are inputs, what is left per block is the bi-directional candidates / the intra comparison, the AQ weighting and the sums.  The dependent walk still took its
+// W + 2 H lock-steps for it (4K: 510 steps, 5 ms on one estimate the lookahead WAITS for - the real encode's fps follows that latency, profiles/r06_lookahead_bound.txt).
+// Here a wavefront owns a block row, a quad a segment of ceil(W / 16) consecutive blocks; row sums meet by shuffles, frame sums in the split form's accumulators.
+template <typename Px, bool BIDIR>
+__global__ void __launch_bounds__(256) lowres_cost_flat_kernel(LowresCostArgs g)
+{
+    const int pairIdx = (int)blockIdx.y;
+    const x265hip_lowres_cost_pair pr = g.pairs[pairIdx];
+    const uint8_t* cur = (const uint8_t*)pr.cur;
+    const unsigned long long* mvsL[2] = { (const unsigned long long*)pr.mvs, (const unsigned long long*)pr.mvs1 };
+    const int32_t* mvCostsL[2] = { pr.mv_costs, pr.mv_costs1 };
+    constexpr int BPP = sizeof(Px);
+    constexpr uint32_t kBias = 1u << 30;
+    constexpr int NL = BIDIR ? 2 : 1;
+    const int lane = threadIdx.x & 63, q = lane >> 2, l = lane & 3;
+    const int tx = l & 1, ty = l >> 1;
+    const int W = g.W, H = g.H;
+    const int cuY = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int seg = (W + 15) >> 4, x0 = q * seg, x1 = min(W, x0 + seg);
+    unsigned long long* const acc = g.sync + (size_t)pairIdx * 4;
+    __shared__ long long sFrame[3];
+    if (threadIdx.x < 3) sFrame[threadIdx.x] = 0;
+    __syncthreads();
+    long long costEst = 0, costEstAq = 0;
+    int intraMbs = 0, rowSatd = 0;
+    LowresPu<Px> L;
+    const PhasePlanes pp0 = { (const uint8_t*)pr.ref[0] - kBias, (const uint8_t*)pr.ref[1] - kBias, (const uint8_t*)pr.ref[2] - kBias, (const uint8_t*)pr.ref[3] - kBias };
+    const PhasePlanes pp1 = BIDIR ? PhasePlanes{ (const uint8_t*)pr.ref1[0] - kBias, (const uint8_t*)pr.ref1[1] - kBias, (const uint8_t*)pr.ref1[2] - kBias, (const uint8_t*)pr.ref1[3] - kBias } : pp0;
+    const PhasePlanes ppB = (BIDIR && pr.ref_bi[0]) ? PhasePlanes{ (const uint8_t*)pr.ref_bi[0] - kBias, (const uint8_t*)pr.ref_bi[1] - kBias, (const uint8_t*)pr.ref_bi[2] - kBias, (const uint8_t*)pr.ref_bi[3] - kBias } : pp0;
+    L.c.strideB = g.strideB; L.c.depth = g.depth; L.c.cost = g.cost;
+    L.c.have[0] = true;
+    if (cuY < H)
+        for (int cuX = x1 - 1; cuX >= x0; cuX--)
+        {
+            const int cuXY = cuX + cuY * W;
+            const uint32_t pel = (uint32_t)((cuY * 8 + ty * 4) * g.strideB + (cuX * 8 + tx * 4) * BPP);
+            L.c.refOrg[0] = kBias + pel;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int d = 0; d < BPP; d++) L.c.src[0][r][d] = ld_u32(cur + (pel + (uint32_t)(r * g.strideB + 4 * d)));
+            L.c.mvmin.x = -cuX * 8 - 8; L.c.mvmin.y = -cuY * 8 - 8;
+            L.c.mvmax.x = (W - cuX - 1) * 8 + 8; L.c.mvmax.y = (H - cuY - 1) * 8 + 8;
+            int bcost = 1 << 28, listused = 0;
+            int lmx[2] = { 0, 0 }, lmy[2] = { 0, 0 };
+#pragma unroll
+            for (int li = 0; li < NL; li++)
+            {
+                const int fencCost = mvCostsL[li][cuXY];
+                const unsigned long long v = mvsL[li][cuXY];
+                lmx[li] = (int)(uint32_t)v; lmy[li] = (int)(uint32_t)(v >> 32);
+                if (fencCost < bcost) { bcost = fencCost; listused = li + 1; }
+            }
+            if (BIDIR)
+            {
+                int p0[4][4], p1[4][4];
+                L.predict(ppB, lmx[0], lmy[0], p0);
+                L.predict(pp1, lmx[1], lmy[1], p1);
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) p0[y][x] = (p0[y][x] + p1[y][x] + 1) >> 1;
+                int bicost = L.score(p0, true);
+                if (bicost < bcost) { bcost = bicost; listused = 3; }
+                L.predict(ppB, 0, 0, p0);
+                L.predict(pp1, 0, 0, p1);
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) p0[y][x] = (p0[y][x] + p1[y][x] + 1) >> 1;
+                bicost = L.score(p0, true);
+                if (bicost < bcost) { bcost = bicost; listused = 3; }
+                bcost += 4;
+            }
+            else
+            {
+                bcost += 4;
+                const int ic = pr.intra_cost[cuXY];
+                if (ic < bcost) { bcost = ic; listused = 0; }
+            }
+            const bool scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+            const int bcostAq = (scored && pr.inv_qscale) ? ((bcost * pr.inv_qscale[cuXY] + 128) >> 8) : bcost;
+            if (scored) { costEst += bcost; costEstAq += bcostAq; intraMbs += (!BIDIR && !listused); }
+            rowSatd += bcostAq;
+            if (l == 0) pr.lowres_costs[cuXY] = (uint16_t)((bcost < 0x3fff ? bcost : 0x3fff) | (listused << 14));
+        }
+    // the row's sum over its 16 quads (every lane of a quad holds the quad's value), then the frame sums of the workgroup's four rows
+    for (int o = 4; o < 64; o <<= 1) rowSatd += __shfl_xor(rowSatd, o);
+    if (lane == 0 && cuY < H) pr.row_satds[cuY] = rowSatd;
+    auto xor64 = [](long long v, int o) { return (long long)(((unsigned long long)(uint32_t)__shfl_xor((int)(v >> 32), o) << 32) | (uint32_t)__shfl_xor((int)v, o)); };
+    for (int o = 4; o < 64; o <<= 1) { costEst += xor64(costEst, o); costEstAq += xor64(costEstAq, o); intraMbs += __shfl_xor(intraMbs, o); }
+    if (lane == 0)
+    {
+        atomicAdd((unsigned long long*)&sFrame[0], (unsigned long long)costEst);
+        atomicAdd((unsigned long long*)&sFrame[1], (unsigned long long)costEstAq);
+        atomicAdd((unsigned long long*)&sFrame[2], (unsigned long long)intraMbs);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        for (int i = 0; i < 3; i++) __hip_atomic_fetch_add(&acc[i], (unsigned long long)sFrame[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long before = __hip_atomic_fetch_add(&acc[3], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == (unsigned long long)(gridDim.x - 1))
+        {
+            long long f[3];
+            for (int i = 0; i < 3; i++) f[i] = (long long)__hip_atomic_load(&acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < 3; i++) pr.frame[i] = f[i];
+            pr.frame[3] = BIDIR ? f[0] * 100 / (130 + g.bFrameBias) : f[0];
+        }
+    }
+}
+
 } // namespace x265hip
 
 using namespace x265hip;
+
+static std::atomic<uint64_t> g_lrcFlat{0}, g_lrcWalk{0}, g_lrcSplit{0};
+extern "C" void x265hip_lowres_cost_launch_counts(uint64_t out[3])
+{
+    out[0] = g_lrcFlat.load(); out[1] = g_lrcWalk.load(); out[2] = g_lrcSplit.load();
+}
 
 extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* stream)
 {
@@ -414,7 +534,7 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     if (p->depth != 8 && p->depth != 10 && p->depth != 12) { set_error("lowres_cost: depth %d", p->depth); return X265HIP_EINVAL; }
     if (p->width_in_cu <= 0 || p->height_in_cu <= 0) { set_error("lowres_cost: empty picture"); return X265HIP_EINVAL; }
     bool bidir = false;
-    if (p->pairs_on_device) bidir = p->pairs_on_device == 2;
+    if (p->pairs_on_device) bidir = (p->pairs_on_device & 3) == 2;
     else
     for (int i = 0; i < p->npairs; i++)
     {
@@ -427,6 +547,44 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
         if (b && (!q.ref1[1] || !q.ref1[2] || !q.ref1[3] || !q.mvs1 || !q.mv_costs1)) { set_error("lowres_cost: NULL list-1 operand in pair %d", i); return X265HIP_EINVAL; }
         if (q.ref_bi[0] && (!b || !q.ref_bi[1] || !q.ref_bi[2] || !q.ref_bi[3])) { set_error("lowres_cost: ref_bi needs a B picture and four planes (pair %d)", i); return X265HIP_EINVAL; }
         if ((((uintptr_t)q.mvs) & 7) || (b && (((uintptr_t)q.mvs1) & 7))) { set_error("lowres_cost: mvs of pair %d must be 8-byte aligned", i); return X265HIP_EINVAL; }
+    }
+    // FLAT: no list of any pair needs a search - no dependency, no lock-step walk.  Host pair tables are read here; a DEVICE table says so itself (pairs_on_device | 4)
+    bool flat = getenv("X265HIP_LOWRES_COST_FLAT_OFF") == nullptr;
+    if (flat && p->pairs_on_device) flat = (p->pairs_on_device & 4) != 0;
+    else if (flat)
+        for (int i = 0; i < p->npairs; i++)
+            flat &= !p->pairs[i].do_search[0] && (!bidir || !p->pairs[i].do_search[1]);
+    if (flat)
+    {
+        const int bppF = p->depth == 8 ? 1 : 2;
+        hipStream_t sF = (hipStream_t)stream;
+        x265hip_lowres_cost_pair* dp = nullptr;
+        const size_t nb = sizeof(x265hip_lowres_cost_pair) * (size_t)p->npairs;
+        if (p->pairs_on_device) dp = const_cast<x265hip_lowres_cost_pair*>(p->pairs);
+        else
+        {
+            X265HIP_TRY(hipMallocAsync((void**)&dp, nb, sF));
+            X265HIP_TRY(hipMemcpyAsync(dp, p->pairs, nb, hipMemcpyHostToDevice, sF));
+        }
+        LowresCostArgs a;
+        a.pairs = dp; a.strideB = (int)(p->stride * bppF); a.W = p->width_in_cu; a.H = p->height_in_cu; a.depth = p->depth;
+        a.cost = p->cost_q + p->qoff; a.bFrameBias = p->bframe_bias; a.K = 1; a.R = p->height_in_cu;
+        {
+            std::unique_lock<std::mutex> seqF = stream_sequence_lock(sF);          // clear + launch are one sequence per stream
+            const size_t sb = 4 * 8 * (size_t)p->npairs;
+            a.sync = (unsigned long long*)stream_scratch(sF, 1, sb);
+            if (!a.sync) return X265HIP_ENODEV;
+            X265HIP_TRY(hipMemsetAsync(a.sync, 0, sb, sF));
+            const dim3 gridF((p->height_in_cu + 3) / 4, p->npairs), blockF(256);
+            if (bppF == 1 && !bidir) hipLaunchKernelGGL((lowres_cost_flat_kernel<uint8_t, false>), gridF, blockF, 0, sF, a);
+            else if (bppF == 1) hipLaunchKernelGGL((lowres_cost_flat_kernel<uint8_t, true>), gridF, blockF, 0, sF, a);
+            else if (!bidir) hipLaunchKernelGGL((lowres_cost_flat_kernel<uint16_t, false>), gridF, blockF, 0, sF, a);
+            else hipLaunchKernelGGL((lowres_cost_flat_kernel<uint16_t, true>), gridF, blockF, 0, sF, a);
+        }
+        X265HIP_TRY(hipGetLastError());
+        if (!p->pairs_on_device) X265HIP_TRY(hipFreeAsync(dp, sF));
+        g_lrcFlat.fetch_add(1, std::memory_order_relaxed);
+        return 0;
     }
     // One estimate on its own (the lookahead seam) is split into bands of ~8 block rows (at most 16 bands: 4K 8.9 -> 5.3 ms with 16, 5.8 with 9; 1080p 3.27 ->
     // 2.78 ms with 8, 2.88 with 5 - profiles/r03_lowres_cost_counters.txt), a workgroup = a compute unit each; batches keep one
@@ -490,6 +648,7 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
         if (!a.sync) return X265HIP_ENODEV;
         X265HIP_TRY(hipMemsetAsync(a.sync, 0, sb, s));
     }
+    (split ? g_lrcSplit : g_lrcWalk).fetch_add(1, std::memory_order_relaxed);
     const dim3 grid(p->npairs * K), block(quads * 4);
 #define LRC_GO(PX, BI) do { if (split) hipLaunchKernelGGL((lowres_cost_kernel<PX, BI, true>), grid, block, 0, s, a); \
                             else hipLaunchKernelGGL((lowres_cost_kernel<PX, BI, false>), grid, block, 0, s, a); } while (0)
