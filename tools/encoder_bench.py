@@ -217,6 +217,7 @@ def main():
     ap.add_argument("--seam-cost-candidates", type=int, default=1, help="cost tables: integer vectors per PU (1 or 2)")
     ap.add_argument("--seam-cost-set-subme", type=int, default=0, help="cost tables: hold the position set of this --subme row when it is larger than the encode's own (4: 85 positions)")
     ap.add_argument("--seam-cost-sad", action="store_true", help="cost tables: the records also carry the costs of the SAD-typed comparisons (the search's predictor candidates)")
+    ap.add_argument("--seam-lookahead-min-blocks", type=int, default=-1, help="size gate of the lookahead seam in 8x8 lowres blocks (-1 = the binding's own 16384: serve from 4K up; 0 = any size)")
     ap.add_argument("--seam-min-ctus", type=int, default=-1, help="size gate of the search seams in CTUs (-1 = the binding's own 1000: serve from 4K up; 0 = serve any size)")
     ap.add_argument("--seam-cost-window", type=int, default=8, help="cost tables: the candidates are the smallest SADs within +-this of each CTU's own displacement")
     ap.add_argument("--seam-cost-slots", type=int, default=24, help="cost tables: (picture, reference) pairs resident in pinned host memory (37 MB each at 4K preset slow)")
@@ -253,7 +254,8 @@ def main():
             "pictures": args.seam_pictures, "band_rows": args.seam_band_rows, "no_sad": args.seam_no_sad, "weighted": not args.seam_no_weighted,
             "layout": 1 if args.seam_layout == "planes" else 0, "centre_range": args.seam_centre_range, "aq": args.seam_aq, "weight_analyse": args.seam_weight_analyse, "split_rest": args.seam_split_rest,
             "cost": args.seam_cost, "cost_candidates": args.seam_cost_candidates, "cost_window": args.seam_cost_window, "cost_slots": args.seam_cost_slots, "cost_views": args.seam_cost_views,
-            "cost_centre_range": args.seam_centre_range or 57, "cost_set_subme": args.seam_cost_set_subme or None, "cost_sad": args.seam_cost_sad, "min_ctus": None if args.seam_min_ctus < 0 else args.seam_min_ctus}
+            "cost_centre_range": args.seam_centre_range or 57, "cost_set_subme": args.seam_cost_set_subme or None, "cost_sad": args.seam_cost_sad, "min_ctus": None if args.seam_min_ctus < 0 else args.seam_min_ctus,
+            "lookahead_min_blocks": None if args.seam_lookahead_min_blocks < 0 else args.seam_lookahead_min_blocks}
     out = {k: run_config(k, args.tables.split(","), args.frames or None, args.frame_threads, args.budget_s, seam=seam, build=args.ref_build) for k in args.configs.split(",")}
     print(json.dumps({"encoder": out}))
 
