@@ -610,7 +610,7 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
             if (splitInFlight.fetch_add(1) < kMaxSplitInFlight) { K = (p->height_in_cu + 7) / 8; counted = true; }
             else splitInFlight.fetch_sub(1);
         }
-        if (K > 16) K = 16;
+        if (K > (splitEnv ? 64 : 16)) K = splitEnv ? 64 : 16;          // (the switch may ask for more bands than the library's own choice ever makes: A/B runs)
         if (K > p->height_in_cu) K = p->height_in_cu;
         if (K < 1) K = 1;
         if (K > 1 && (p->height_in_cu + K - 1) / K > 128) K = (p->height_in_cu + 127) / 128;      // a band is at most 128 rows = 512 threads
