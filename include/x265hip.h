@@ -402,7 +402,9 @@ typedef struct x265hip_lowres_cost_params
     const x265hip_lowres_cost_pair* pairs;  int npairs;
     int pairs_on_device;                            /* 0: `pairs` is host memory (copied in stream order, may block the caller);
                                                        1 / 2: `pairs` already is a device array of P (1) / B (2) pictures (no allocation, no copy, no validation);
-                                                       | 4 (round 6): none of those pairs needs a search (every do_search is 0) - the dependency-free launch may be used */
+                                                       | 4 (round 6): none of those pairs needs a search (every do_search is 0) - the dependency-free launch may be used
+                                                       | 8, | 16 (round 6): every pair searches list 0 / list 1 (do_search[0] / [1]) - a split B estimate may walk the two
+                                                       lists side by side; without them a device table of B pictures takes the one-walk form */
 } x265hip_lowres_cost_params;
 /* One workgroup walks a picture (a wavefront of dependent block rows); a call of up to four pictures of 32 or more block rows - the
  * latency case: a host thread waits for one estimate - gives every picture several workgroups, one per band of block rows, the
@@ -410,8 +412,12 @@ typedef struct x265hip_lowres_cost_params
 int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* stream);
 /* Round 6: a call none of whose pairs needs a search (do_search 0 / 0: both lists were searched by earlier estimates - a third of the triples of the slice-type decision) has no
  * dependency between blocks and runs as ONE flat launch (a wavefront per block row) instead of the W + 2 H lock-steps.  Diagnostic: launches so far as
- * { flat, one-workgroup walk, split walk } (process-wide). */
+ * { flat, one-workgroup walk, split walk } (process-wide).
+ * A split B estimate that searches (round 6, second half): its lists are independent of each other, so each searched list is walked by its own bands (one HEX search per
+ * lock-step instead of two searches + the bi-directional candidates) and the same flat launch finishes the estimate.  X265HIP_LOWRES_COST_SO_OFF=1 = the one-walk form. */
 void x265hip_lowres_cost_launch_counts(uint64_t out[3]);
+/* X265HIP_LOWRES_COST_SPLIT=<bands> / X265HIP_LOWRES_COST_SO_OFF=1 are read when the library is loaded; this reads them again (tests, A/B tools). */
+void x265hip_lowres_cost_env_refresh(void);
 
 /* The same estimate behind host pointers, shaped like the loop it replaces (csrc/lookahead_host.hip): ONE call = the estimateCUCost
  * loop of CostEstimateGroup::estimateFrameCost (slicetype.cpp:3178-3196 over :3216-3388) for one (p0, b, p1) triple whose Lowres
@@ -445,7 +451,12 @@ typedef struct x265hip_lowres_cost_host_params
      * The key must name the CONTENT for as long as the process lives: a frame number alone repeats in the next encode of the same
      * process (and the allocator hands out the same addresses again) - combine it with an encoder-instance number, e.g.
      * instance << 32 | (Lowres::frameNum + 1), or call x265hip_lowres_planes_forget() when an encoder closes.
-     * cur / ref / ref1 / ref_bi planes respectively; weighted scratch planes must pass 0. */
+     * cur / ref / ref1 / ref_bi planes respectively; weighted scratch planes must pass 0.
+     * Round 6: plane_key_cur != 0 also vouches for the picture's vector arrays: while the key stays the same, mvs[l] / mv_costs[l] at these addresses are written only by
+     * this function's own searches, or before the first call that reuses them (lowresMvs / lowresMvCosts: searched once per lifetime of a Lowres, reset by Lowres::init,
+     * lowres.cpp:283-284).  The library then keeps the device copy a search left behind (or uploads a reused list once) and the estimates that reuse the list -
+     * three quarters of the slice-type decision's - upload no vectors at all; whatever a call does transfer goes as ONE upload and ONE download through pinned staging
+     * (4K: 1.8 -> see DESIGN 5.1 ms per reusing estimate).  X265HIP_LA_RESIDENT_OFF=1 (read when the library loads) uploads reused lists every time, as before. */
     uint64_t plane_key_cur, plane_key_ref, plane_key_ref1, plane_key_ref_bi;
 } x265hip_lowres_cost_host_params;
 int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p);

@@ -243,7 +243,7 @@ def test_ring_with_several_reference_pictures(world, refs):
     assert out[world - 1][1] == [world - 1 + k * world for k in range(steps)]
 
 
-def _ring_worker_gop(rank, world, port, steps, gop, out):
+def _ring_worker_gop(rank, world, port, steps, gop, out, bcast=False):
     """The ring with MINI-GOPS (round-5 verdict, next 6): frames that are multiples of `gop` are anchors, every other picture is non-referenced and
     reads the anchor before it.  An anchor's bands go once to every rank that encodes one of the next `gop` pictures; a rank keeps the anchor for all
     its pictures that read it, its own anchors included."""
@@ -256,7 +256,7 @@ def _ring_worker_gop(rank, world, port, steps, gop, out):
     w64, h64, lag = 128, 448, 72
     bands = [(r, min(2, 7 - r)) for r in range(0, 7, 2)]
     geom, ny, nc = _ring_geometry(w64, h64)
-    ring = P.FrameParallelRing(rank, world, bands, lag, gop=gop)
+    ring = P.FrameParallelRing(rank, world, bands, lag, gop=gop, transport=P.DistBcastTransport(rank, world) if bcast else None)
     ring.make_groups()
     ref = [torch.full((ny,), 17, dtype=torch.uint8), torch.full((nc,), 29, dtype=torch.uint8), torch.full((nc,), 31, dtype=torch.uint8)]
     bufs = [[torch.zeros_like(p) for p in ref] for _ in range(2)]
@@ -270,6 +270,7 @@ def _ring_worker_gop(rank, world, port, steps, gop, out):
             _fake_band(f, ref, o, geom, w64, h64, row0, n, lag, b == 0, b == len(bands) - 1)
         ring.run_frame(step, geom, ref, o, band, total_frames=total)
         mine[f] = [p.clone() for p in o]
+    ring.drain(geom, ref, total)                 # a broadcast transport: the anchors this rank has not joined yet (a no-op for point-to-point flows)
     ring.finish()
     expect = _ring_serial(total, w64, h64, bands, lag, gop=gop)
     ok = all(all(torch.equal(a, e) for a, e in zip(mine[f], expect[f])) for f in mine)
@@ -291,6 +292,79 @@ def test_ring_with_mini_gops_of_non_referenced_pictures(world, gop):
     mp.spawn(_ring_worker_gop, args=(world, port, steps, gop, out), nprocs=world, join=True)
     assert all(out[r][0] for r in range(world)), {r: out[r] for r in range(world)}
     assert out[world - 1][1] == [world - 1 + k * world for k in range(steps)]
+
+
+@pytest.mark.parametrize("world,gop", [(2, 5), (3, 5), (4, 5), (8, 5), (4, 3), (8, 2), (5, 2)])
+def test_ring_with_mini_gops_over_the_broadcast_transport(world, gop):
+    """Round-5 verdict, next 6: the single-communicator broadcast `north_star` names as an A/B switch (pipeline.DistBcastTransport here, AbiBcastTransport = ncclBroadcast
+    through the C ABI in bench.py).  Every rank joins every anchor's broadcasts - the ranks that read the anchor into their reference planes, the others into a scratch
+    picture - and every frame must still equal the serial encode of the same structure."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 30900 + (os.getpid() % 200) + 11 * world + gop
+    steps = {2: 8, 3: 6, 4: 5, 5: 4, 8: 3}[world]
+    mp.spawn(_ring_worker_gop, args=(world, port, steps, gop, out, True), nprocs=world, join=True)
+    assert all(out[r][0] for r in range(world)), {r: out[r] for r in range(world)}
+    assert out[world - 1][1] == [world - 1 + k * world for k in range(steps)]
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 5, 8])
+@pytest.mark.parametrize("gop", [2, 3, 5])
+def test_broadcast_transport_joins_in_one_global_order(world, gop):
+    """The collectives of ONE communicator must be issued in the same order by every rank.  Each rank's ring is driven here with a transport that only records its
+    calls: the sequences of (root, band) must be identical on all ranks - anchor by anchor, band by band, the root being the anchor's rank - whoever joins as the
+    producer, as a consumer (into its reference planes) or as a bystander (into the scratch picture); and exactly the anchors somebody reads travel."""
+    sys.path.insert(0, ROOT)
+    P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+
+    class Recorder:
+        collective = True
+
+        def __init__(self):
+            self.calls = []
+
+        def setup(self, device=None):
+            return None
+
+        def send(self, planes, ranges, band, peers):
+            self.calls.append(("root", None, band, id(planes)))
+            return []
+
+        def recv(self, planes, ranges, band, src):
+            self.calls.append(("recv", src, band, id(planes)))
+            return []
+
+    w64, h64, lag = 128, 448, 72
+    bands = [(r, min(2, 7 - r)) for r in range(0, 7, 2)]
+    geom, ny, nc = _ring_geometry(w64, h64)
+    steps = 4
+    total = steps * world
+    seqs, dest = [], []
+    for rank in range(world):
+        rec = Recorder()
+        ring = P.FrameParallelRing(rank, world, bands, lag, gop=gop, transport=rec)
+        ref = [torch.zeros(ny, dtype=torch.uint8), torch.zeros(nc, dtype=torch.uint8), torch.zeros(nc, dtype=torch.uint8)]
+        o = [torch.zeros_like(p) for p in ref]
+        for step in range(steps):
+            ring.run_frame(step, geom, ref, o, lambda b, row0, n: None, total_frames=total)
+        ring.drain(geom, ref, total)
+        seqs.append([(rank if kind == "root" else src, band) for kind, src, band, _ in rec.calls])
+        # a consumer receives into the reference planes exactly the anchors one of its pictures reads
+        reads = {((f - 1) // gop) * gop for f in range(rank, total, world) if f > 0}
+        got = {}
+        it = iter(P.FrameParallelRing.broadcast_anchors(gop, total))
+        for k in range(0, len(rec.calls), len(bands)):
+            a = next(it)
+            kind, src, _, where = rec.calls[k]
+            got[a] = "root" if kind == "root" else ("ref" if where == id(ref) else "scratch")
+        for a, how in got.items():
+            assert how == ("root" if a % world == rank else ("ref" if a in reads else "scratch")), (rank, a, how)
+        dest.append(got)
+    anchors = P.FrameParallelRing.broadcast_anchors(gop, total)
+    expect = [(a % world, b) for a in anchors for b in bands]
+    for rank in range(world):
+        assert seqs[rank] == expect, (rank, seqs[rank][:12], expect[:12])
+    assert anchors == [a for a in range(0, total - 1, gop)]
 
 
 def test_band_model_mini_gops_lift_the_chain_ceiling():

@@ -157,8 +157,15 @@ def test_lowres_cost_split_into_bands_equals_one_workgroup(monkeypatch, depth, w
         la.run(pic)
     lc, l0, l1 = las
 
-    def run(bands):
+    refresh = importlib.import_module("x265-yuuki-asuna_amd.hipabi").lib().x265hip_lowres_cost_env_refresh      # the switches are read when the library loads
+
+    def run(bands, side_by_side=True):
         monkeypatch.setenv("X265HIP_LOWRES_COST_SPLIT", str(bands))
+        if side_by_side:
+            monkeypatch.delenv("X265HIP_LOWRES_COST_SO_OFF", raising=False)
+        else:
+            monkeypatch.setenv("X265HIP_LOWRES_COST_SO_OFF", "1")
+        refresh()
         st = S.LookaheadCost(lc, dev, bidir=bidir)
         if bidir:
             st.run(lc, l0, l1, bframe_bias=10)
@@ -168,9 +175,18 @@ def test_lowres_cost_split_into_bands_equals_one_workgroup(monkeypatch, depth, w
         out = [st.mvs, st.mv_costs, st.lowres_costs, st.row_satds, st.frame] + ([st.mvs1, st.mv_costs1] if bidir else [])
         return [o.cpu().numpy().copy() for o in out]
 
-    one = run(1)
-    assert (one[0] != 0).any()
-    for bands in (2, 3, 5, 16):
-        got = run(bands)
-        for k, (a, b) in enumerate(zip(one, got)):
-            assert np.array_equal(a, b), f"{bands} bands: output {k} differs from the one-workgroup walk"
+    try:
+        one = run(1)
+        assert (one[0] != 0).any()
+        for bands in (2, 3, 5, 16):
+            got = run(bands)
+            for k, (a, b) in enumerate(zip(one, got)):
+                assert np.array_equal(a, b), f"{bands} bands: output {k} differs from the one-workgroup walk"
+            if bidir:
+                # round 6: a split B estimate walks its two lists side by side and a flat launch finishes it (the default above); the one-walk split form stays as the A/B
+                got = run(bands, side_by_side=False)
+                for k, (a, b) in enumerate(zip(one, got)):
+                    assert np.array_equal(a, b), f"{bands} bands, lists in one walk: output {k} differs from the one-workgroup walk"
+    finally:
+        monkeypatch.undo()
+        refresh()

@@ -207,6 +207,7 @@ def test_lowres_cost_host_entry_equals_oracle():
                     ("bframe_bias", ctypes.c_int), ("do_search", ctypes.c_int * 2), ("mvs", ctypes.c_void_p * 2), ("mv_costs", ctypes.c_void_p * 2),
                     ("lowres_costs", ctypes.c_void_p), ("row_satds", ctypes.c_void_p), ("frame", ctypes.c_void_p),
                     ("plane_key_cur", ctypes.c_uint64), ("plane_key_ref", ctypes.c_uint64), ("plane_key_ref1", ctypes.c_uint64), ("plane_key_ref_bi", ctypes.c_uint64)]
+    A.lib().x265hip_lowres_planes_forget()          # keys 1..3 name THIS test's pictures
     for bidir in (False, True):
         mvs = [np.zeros((n, 2), np.int32), np.zeros((n, 2), np.int32)]
         mvc = [np.zeros(n, np.int32), np.zeros(n, np.int32)]
@@ -235,6 +236,31 @@ def test_lowres_cost_host_entry_equals_oracle():
             e0, c0, elc, erows, eframe = exp
         assert np.array_equal(mvs[0], e0) and np.array_equal(mvc[0], c0) and np.array_equal(lc, elc) and np.array_equal(rws, erows)
         assert np.array_equal(frame[:len(eframe)], eframe)
+        if not bidir:
+            continue
+        # round 6: the searched vectors stay on the device under the picture's key.  The same triple again with NEITHER list searched (the dependency-free launch reads
+        # the resident copies), then list 0 reused against another list-1 picture with arrays of its own: the oracle's answers for the same requests
+        lc[:], rws[:], frame[:] = 0, 0, 0
+        q.do_search[0], q.do_search[1] = 0, 0
+        A.check(f(ctypes.byref(q)), "x265hip_lowres_cost_host")
+        assert np.array_equal(mvs[0], e0) and np.array_equal(mvs[1], e1) and np.array_equal(lc, elc) and np.array_equal(rws, erows) and np.array_equal(frame[:len(eframe)], eframe)
+        mv1b, mc1b = np.zeros((n, 2), np.int32), np.zeros(n, np.int32)
+        q.mvs[1], q.mv_costs[1] = mv1b.ctypes.data, mc1b.ctypes.data
+        for i in range(4):
+            q.ref1[i] = planes[0][i].ctypes.data + org
+        q.plane_key_ref1 = 1
+        q.do_search[0], q.do_search[1] = 0, 1
+        lc[:], rws[:], frame[:] = 0, 0, 0
+        A.check(f(ctypes.byref(q)), "x265hip_lowres_cost_host")
+        (_, f1), (_, fc1), flc, frows, fframe = O.lowres_cost(depth, planes[1][0], planes[0], stride, org, wcu, hcu, cq, qoff, icost, ref1_planes=planes[0],
+                                                              do_search=(0, 1), mvs_in=(e0, None), mv_costs_in=(c0, None))
+        assert np.array_equal(mvs[0], e0) and np.array_equal(mv1b, f1) and np.array_equal(mc1b, fc1)
+        assert np.array_equal(lc, flc) and np.array_equal(rws, frows) and np.array_equal(frame[:len(fframe)], fframe)
+        q.do_search[0], q.do_search[1] = 0, 0
+        lc[:], rws[:], frame[:] = 0, 0, 0
+        A.check(f(ctypes.byref(q)), "x265hip_lowres_cost_host")
+        assert np.array_equal(lc, flc) and np.array_equal(rws, frows) and np.array_equal(frame[:len(fframe)], fframe)
+    A.lib().x265hip_lowres_planes_forget()
 
 
 @pytest.mark.parametrize("depth,preset,extra", [(8, "slow", [("me", "star")]), (8, "slower", []), (10, "slow", []), (8, "medium", [])])

@@ -11,6 +11,10 @@
 // and grow-only device scratch, released at thread exit.  Same integers as the loop it replaces (tests: device == oracle == the real
 // CostEstimateGroup::singleCost), so the slice-type decisions and the bitstream cannot change.
 #include "common.h"
+#include <chrono>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include "tile_interp.h"
 
 #include <algorithm>
@@ -28,16 +32,29 @@ struct LaThread
     hipStream_t stream = nullptr;
     uint8_t* dev = nullptr;
     size_t cap = 0;
+    uint8_t* pin = nullptr;                    // pinned staging: one upload and one download per call instead of a pageable copy per array
+    size_t pinCap = 0;
     ~LaThread()
     {
         if (!stream) return;
         (void)hipStreamSynchronize(stream);
         if (dev) (void)hipFree(dev);
+        if (pin) (void)hipHostFree(pin);
         (void)hipStreamDestroy(stream);
     }
     int ensure(size_t need)
     {
-        if (!stream) X265HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (!stream)
+        {
+            // X265HIP_LA_PRIORITY=1 (experiment): the highest stream priority the device offers.  A pool thread of the host WAITS for every call made here, while the
+            // services that share the device queue chip-filling searches nobody waits for row by row - yet at cfg3 it measured no gain (three interleaved pairs:
+            // 8.91 / 8.88 / 8.17 fps with, 9.06 / 9.10 / 8.92 without, profiles/r06_lookahead_resident.txt): plain streams stay the default.
+            int least = 0, greatest = 0;
+            if (!getenv("X265HIP_LA_PRIORITY") || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || greatest == least)
+                X265HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            else
+                X265HIP_TRY(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, greatest));
+        }
         if (need <= cap) return 0;
         if (dev) X265HIP_TRY(hipFree(dev));
         dev = nullptr; cap = 0;
@@ -45,6 +62,17 @@ struct LaThread
         while (n < need) n <<= 1;
         X265HIP_TRY(hipMalloc((void**)&dev, n));
         cap = n;
+        return 0;
+    }
+    int ensure_pin(size_t need)
+    {
+        if (need <= pinCap) return 0;
+        if (pin) X265HIP_TRY(hipHostFree(pin));
+        pin = nullptr; pinCap = 0;
+        size_t n = (size_t)1 << 20;
+        while (n < need) n <<= 1;
+        X265HIP_TRY(hipHostMalloc((void**)&pin, n, hipHostMallocDefault));
+        pinCap = n;
         return 0;
     }
 };
@@ -57,34 +85,49 @@ LaThread& la_thread()
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// Device copies of host planes the caller vouches for: plane_key != 0 names the CONTENT of a plane set (a picture's four lowres planes
+// Device copies of host arrays the caller vouches for: plane_key != 0 names the CONTENT of a plane set (a picture's four lowres planes
 // do not change while its frame number stays the same), so the dozens of (p0, b, p1) triples the lookahead scores around a picture
 // upload each plane once.  Shared by all calling threads; entries are only read by kernels after their upload was synchronised.
 // An entry handed out is PINNED until the call that asked for it has synchronised its stream (PlanePins below): neither the
 // same-host-buffer replacement nor the LRU eviction may free a buffer another thread's - or this call's own, not yet launched -
 // kernel is about to read (round-2 advisor finding).  A replaced but still pinned entry is only retired (host = NULL: it matches
 // no later request) and freed by whoever evicts next after its last user let go.
+// Round 6: (a) the vectors / vector costs a frame-cost estimate searched (lowresMvs[l][d], lowresMvCosts[l][d]: written once per lifetime of the
+// picture, Lowres::init resets them, lowres.cpp:283-284) live here too, keyed by the picture's key: the estimates that reuse a list - three quarters
+// of them - read the device copy the search left behind instead of uploading the host's arrays again.  (b) Buffers an entry gives up go to a pool
+// and are handed out again for the same size: hipFree waits for the whole device (every other thread's 5 ms walk) with the cache locked.
 struct CachedPlane { const void* host; uint64_t key; size_t bytes; void* dev; uint64_t stamp; int pins; };
 std::mutex g_planeMu;
 std::vector<CachedPlane> g_planes;
+struct PooledBuffer { size_t bytes; void* dev; };
+std::vector<PooledBuffer> g_bufferPool;
 uint64_t g_planeClock = 0;
 size_t g_planeBytes = 0;
 constexpr size_t PLANE_CACHE_LIMIT = (size_t)6 << 30;          // 6 GiB of HBM at most
+constexpr size_t BUFFER_POOL_LIMIT = 512;
 
-// returns the device copy of the host plane (allocation start `host`, `bytes` long), uploading it on `s` when it is not cached yet;
-// the entry comes back pinned (release_planes)
-int cached_plane(const void* host, uint64_t key, size_t bytes, hipStream_t s, void** out)
+// (g_planeMu held) a device buffer of `bytes` + 64: from the pool when one of that size waits there
+int pool_take(size_t bytes, void** out)
 {
-    std::lock_guard<std::mutex> lk(g_planeMu);
-    for (auto& e : g_planes)
-        if (e.host == host && e.key == key && e.bytes == bytes) { e.stamp = ++g_planeClock; e.pins++; *out = e.dev; return 0; }
-    // evict: same host buffer with an older key (the picture was replaced), then least recently used beyond the limit
+    for (size_t i = 0; i < g_bufferPool.size(); i++)
+        if (g_bufferPool[i].bytes == bytes) { *out = g_bufferPool[i].dev; g_bufferPool.erase(g_bufferPool.begin() + i); return 0; }
+    X265HIP_TRY(hipMalloc(out, bytes + 64));
+    return 0;
+}
+void pool_give(size_t bytes, void* dev)
+{
+    if (g_bufferPool.size() < BUFFER_POOL_LIMIT) g_bufferPool.push_back({ bytes, dev });
+    else (void)hipFree(dev);
+}
+// (g_planeMu held) make room for an entry of `host`: an older entry of the same host buffer goes (the picture was replaced), then the least recently used beyond the limit
+void cache_evict_for(const void* host, size_t bytes)
+{
     for (size_t i = 0; i < g_planes.size();)
     {
         if (g_planes[i].host == host || (!g_planes[i].host && !g_planes[i].pins))
         {
             if (g_planes[i].pins) { g_planes[i].host = nullptr; i++; continue; }             // retired, freed once unpinned
-            (void)hipFree(g_planes[i].dev); g_planeBytes -= g_planes[i].bytes; g_planes.erase(g_planes.begin() + i);
+            pool_give(g_planes[i].bytes, g_planes[i].dev); g_planeBytes -= g_planes[i].bytes; g_planes.erase(g_planes.begin() + i);
         }
         else i++;
     }
@@ -96,24 +139,54 @@ int cached_plane(const void* host, uint64_t key, size_t bytes, hipStream_t s, vo
         if (lru == g_planes.size()) break;                      // everything left is in use: exceed the soft limit rather than free it
         (void)hipFree(g_planes[lru].dev); g_planeBytes -= g_planes[lru].bytes; g_planes.erase(g_planes.begin() + lru);
     }
+}
+
+// returns the device copy of the host array (allocation start `host`, `bytes` long), uploading it on `s` when it is not cached yet;
+// the entry comes back pinned (PlanePins)
+int cached_plane(const void* host, uint64_t key, size_t bytes, hipStream_t s, void** out)
+{
+    std::lock_guard<std::mutex> lk(g_planeMu);
+    for (auto& e : g_planes)
+        if (e.host == host && e.key == key && e.bytes == bytes) { e.stamp = ++g_planeClock; e.pins++; *out = e.dev; return 0; }
+    cache_evict_for(host, bytes);
     void* d = nullptr;
-    X265HIP_TRY(hipMalloc(&d, bytes + 64));
+    int rc = pool_take(bytes, &d);
+    if (rc) return rc;
     hipError_t e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);           // other threads may use the entry as soon as the lock is released
-    if (e != hipSuccess) { (void)hipFree(d); X265HIP_TRY(e); }
+    if (e != hipSuccess) { pool_give(bytes, d); X265HIP_TRY(e); }
     g_planes.push_back({ host, key, bytes, d, ++g_planeClock, 1 });
     g_planeBytes += bytes;
     *out = d;
     return 0;
 }
 
-// the planes one call took from the cache; unpinned when the call leaves (after its final stream synchronisation, or on an error path)
+// a device buffer that will BECOME the cache's copy of `host` once the caller has filled it and synchronised (cached_adopt); until then it is the caller's alone
+int cached_reserve(size_t bytes, void** out)
+{
+    std::lock_guard<std::mutex> lk(g_planeMu);
+    return pool_take(bytes, out);
+}
+void cached_adopt(const void* host, uint64_t key, size_t bytes, void* dev)
+{
+    std::lock_guard<std::mutex> lk(g_planeMu);
+    cache_evict_for(host, bytes);
+    g_planes.push_back({ host, key, bytes, dev, ++g_planeClock, 0 });
+    g_planeBytes += bytes;
+}
+void cached_abandon(size_t bytes, void* dev)
+{
+    std::lock_guard<std::mutex> lk(g_planeMu);
+    pool_give(bytes, dev);
+}
+
+// the entries one call took from the cache; unpinned when the call leaves (after its final stream synchronisation, or on an error path)
 struct PlanePins
 {
-    void* dev[16]; int n = 0;
+    void* dev[24]; int n = 0;
     hipStream_t stream;
     explicit PlanePins(hipStream_t s) : stream(s) {}
-    void add(void* d) { if (n < 16) dev[n++] = d; }
+    void add(void* d) { if (n < 24) dev[n++] = d; }
     ~PlanePins()
     {
         if (!n) return;
@@ -134,12 +207,43 @@ extern "C" void x265hip_lowres_planes_forget(void)
         if (g_planes[i].pins) { g_planes[i].host = nullptr; i++; continue; }
         (void)hipFree(g_planes[i].dev); g_planeBytes -= g_planes[i].bytes; g_planes.erase(g_planes.begin() + i);
     }
+    for (auto& b : g_bufferPool) (void)hipFree(b.dev);
+    g_bufferPool.clear();
+}
+
+namespace {
+// diagnostic (X265HIP_LA_STATS=1: printed when the process ends): the estimates by what they had to search and the wall time of the calls
+struct LaKinds
+{
+    std::atomic<uint64_t> n[6], us[6];          // P: none / list 0;  B: none / list 0 only / list 1 only / both
+    ~LaKinds()
+    {
+        if (!getenv("X265HIP_LA_STATS")) return;
+        static const char* const name[6] = { "P, nothing searched", "P, list 0 searched", "B, nothing searched", "B, list 0 searched", "B, list 1 searched", "B, both lists searched" };
+        for (int i = 0; i < 6; i++)
+            if (n[i]) fprintf(stderr, "libx265hip: lowres_cost_host %-24s %8llu calls %10.3f ms each\n", name[i], (unsigned long long)n[i].load(), 1e-3 * us[i].load() / n[i].load());
+    }
+} g_laKinds;
+// X265HIP_LA_RESIDENT_OFF=1 (A/B): the searched vectors are not kept on the device, every array travels by itself from / to pageable memory as before round 6's second half
+const bool g_laResidentOff = getenv("X265HIP_LA_RESIDENT_OFF") != nullptr;
 }
 
 extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p)
 {
     int rc = ensure_device();
     if (rc) return rc;
+    struct KindTimer
+    {
+        int kind; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~KindTimer()
+        {
+            if (kind < 0) return;
+            g_laKinds.n[kind].fetch_add(1, std::memory_order_relaxed);
+            g_laKinds.us[kind].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+        }
+    } kindTimer{ -1 };
+    if (p && p->ref1[0]) kindTimer.kind = 2 + (p->do_search[0] ? 1 : 0) + (p->do_search[1] ? 2 : 0);
+    else if (p) kindTimer.kind = p->do_search[0] ? 1 : 0;
     if (!p || !p->cur || !p->intra_cost || !p->cost_q || !p->mvs[0] || !p->mv_costs[0] || !p->lowres_costs || !p->row_satds || !p->frame)
     { set_error("lowres_cost_host: NULL operand"); return X265HIP_EINVAL; }
     for (int k = 0; k < 4; k++) if (!p->ref[k]) { set_error("lowres_cost_host: NULL list-0 plane %d", k); return X265HIP_EINVAL; }
@@ -154,12 +258,18 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
     if (p->cost_q_half < 64) { set_error("lowres_cost_host: cost_q_half %d", p->cost_q_half); return X265HIP_EINVAL; }
     const int bpp = p->depth == 8 ? 1 : 2;
     const int n = p->width_in_cu * p->height_in_cu;
+    const int NL = bidir ? 2 : 1;
     // a plane as the caller holds it: (0,0) sits margin_y rows and margin_x samples into a buffer of lines + 2 * margin_y rows
     const size_t org = ((size_t)p->margin_y * p->stride + p->margin_x) * bpp;
     const size_t planeBytes = (size_t)p->stride * (p->lines + 2 * p->margin_y) * bpp;
     const int nplanes = 1 + 4 + (bidir ? 4 : 0) + (wbi ? 4 : 0);
     const size_t costBytes = (size_t)(2 * p->cost_q_half + 1) * 2;
-    // device layout
+    const bool searches = p->do_search[0] || (bidir && p->do_search[1]);
+    // what the kernels of this request read: the vector-cost table only when a list is searched, the intra costs only on a P picture
+    const bool needCost = searches, needIntra = !bidir;
+    // the vectors of a list: searched = an output; reused = the device copy the search left behind (keyed pictures), else uploaded
+    const uint64_t mvKey = g_laResidentOff ? 0 : p->plane_key_cur;
+    // device layout: [planes without a key] [UP: everything this call uploads, one copy] [DOWN: everything it downloads, one copy]
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = align256(off + bytes); return o; };
     // which planes may come from the shared cache: cur (key_cur), the list-0 / list-1 references when they are the pictures' own planes
@@ -173,16 +283,26 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
     }
     size_t oPlane[13];
     for (int i = 0; i < nplanes; i++) oPlane[i] = pkey[i] ? 0 : take(planeBytes + 64);
+    const size_t oUp = off;
     const size_t oPair = take(sizeof(x265hip_lowres_cost_pair));
-    const size_t oCost = take(costBytes), oIntra = take((size_t)n * 4), oInvq = take((size_t)n * 4);
-    const size_t oMv0 = take((size_t)n * 8), oMc0 = take((size_t)n * 4), oMv1 = take((size_t)n * 8), oMc1 = take((size_t)n * 4);
-    const size_t oLc = take((size_t)n * 2), oRows = take((size_t)p->height_in_cu * 4), oFrame = take(32);
+    const size_t oInvq = p->inv_qscale ? take((size_t)n * 4) : 0, oIntra = needIntra ? take((size_t)n * 4) : 0, oCost = needCost ? take(costBytes) : 0;
+    size_t oMv[2] = { 0, 0 }, oMc[2] = { 0, 0 };
+    for (int li = 0; li < NL; li++)
+        if (!p->do_search[li] && !mvKey) { oMv[li] = take((size_t)n * 8); oMc[li] = take((size_t)n * 4); }
+    const size_t upBytes = off - oUp;
+    const size_t oDown = off;
+    const size_t oFrame = take(32), oRows = take((size_t)p->height_in_cu * 4), oLc = take((size_t)n * 2);
+    for (int li = 0; li < NL; li++)
+        if (p->do_search[li]) { oMv[li] = take((size_t)n * 8); oMc[li] = take((size_t)n * 4); }
+    const size_t downBytes = off - oDown;
     LaThread& t = la_thread();
     rc = t.ensure(off);
+    if (!rc) rc = t.ensure_pin(upBytes + downBytes);
     if (rc) return rc;
     hipStream_t s = t.stream;
     uint8_t* d = t.dev;
-    auto up = [&](size_t o, const void* src, size_t bytes) { return check_hip(hipMemcpyAsync(d + o, src, bytes, hipMemcpyHostToDevice, s), "lowres_cost_host upload"); };
+    uint8_t* const pinUp = t.pin;
+    uint8_t* const pinDown = t.pin + upBytes;
     // planes: the caller passes sample (0,0); the allocation starts `org` bytes before it
     const void* planes[13];
     int k = 0;
@@ -204,16 +324,35 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
         }
         else
         {
-            if (up(oPlane[i], (const uint8_t*)planes[i] - org, planeBytes)) return X265HIP_ENODEV;
+            if (check_hip(hipMemcpyAsync(d + oPlane[i], (const uint8_t*)planes[i] - org, planeBytes, hipMemcpyHostToDevice, s), "lowres_cost_host upload")) return X265HIP_ENODEV;
             dPlane[i] = d + oPlane[i];
         }
     }
-    if (up(oCost, p->cost_q - p->cost_q_half, costBytes)) return X265HIP_ENODEV;
-    if (up(oIntra, p->intra_cost, (size_t)n * 4)) return X265HIP_ENODEV;
-    if (p->inv_qscale && up(oInvq, p->inv_qscale, (size_t)n * 4)) return X265HIP_ENODEV;
     // a list that is not searched again keeps the mvs / costs it was given (estimateFrameCost's bDoSearch)
-    if (!p->do_search[0]) { if (up(oMv0, p->mvs[0], (size_t)n * 8) || up(oMc0, p->mv_costs[0], (size_t)n * 4)) return X265HIP_ENODEV; }
-    if (bidir && !p->do_search[1]) { if (up(oMv1, p->mvs[1], (size_t)n * 8) || up(oMc1, p->mv_costs[1], (size_t)n * 4)) return X265HIP_ENODEV; }
+    int32_t* dMv[2] = { nullptr, nullptr };
+    int32_t* dMc[2] = { nullptr, nullptr };
+    for (int li = 0; li < NL; li++)
+    {
+        if (!p->do_search[li] && mvKey)
+        {
+            void *cv = nullptr, *cc = nullptr;
+            rc = cached_plane(p->mvs[li], mvKey, (size_t)n * 8, s, &cv);
+            if (rc) return rc;
+            pins.add(cv);
+            rc = cached_plane(p->mv_costs[li], mvKey, (size_t)n * 4, s, &cc);
+            if (rc) return rc;
+            pins.add(cc);
+            dMv[li] = (int32_t*)cv; dMc[li] = (int32_t*)cc;
+        }
+        else
+        {
+            dMv[li] = (int32_t*)(d + oMv[li]); dMc[li] = (int32_t*)(d + oMc[li]);
+            if (!p->do_search[li]) { memcpy(pinUp + (oMv[li] - oUp), p->mvs[li], (size_t)n * 8); memcpy(pinUp + (oMc[li] - oUp), p->mv_costs[li], (size_t)n * 4); }
+        }
+    }
+    if (needCost) memcpy(pinUp + (oCost - oUp), p->cost_q - p->cost_q_half, costBytes);
+    if (needIntra) memcpy(pinUp + (oIntra - oUp), p->intra_cost, (size_t)n * 4);
+    if (p->inv_qscale) memcpy(pinUp + (oInvq - oUp), p->inv_qscale, (size_t)n * 4);
 
     x265hip_lowres_cost_pair pr;
     memset(&pr, 0, sizeof(pr));
@@ -221,27 +360,52 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
     for (int i = 0; i < 4; i++) pr.ref[i] = dPlane[1 + i] + org;
     if (bidir) for (int i = 0; i < 4; i++) pr.ref1[i] = dPlane[5 + i] + org;
     if (wbi) for (int i = 0; i < 4; i++) pr.ref_bi[i] = dPlane[9 + i] + org;
-    pr.intra_cost = (const int32_t*)(d + oIntra);
+    pr.intra_cost = needIntra ? (const int32_t*)(d + oIntra) : (const int32_t*)(d + oLc);          // (a B picture's kernels never read it)
     pr.inv_qscale = p->inv_qscale ? (const int32_t*)(d + oInvq) : nullptr;
-    pr.mvs = (int32_t*)(d + oMv0); pr.mv_costs = (int32_t*)(d + oMc0);
-    pr.mvs1 = bidir ? (int32_t*)(d + oMv1) : nullptr; pr.mv_costs1 = bidir ? (int32_t*)(d + oMc1) : nullptr;
+    pr.mvs = dMv[0]; pr.mv_costs = dMc[0];
+    pr.mvs1 = bidir ? dMv[1] : nullptr; pr.mv_costs1 = bidir ? dMc[1] : nullptr;
     pr.do_search[0] = p->do_search[0]; pr.do_search[1] = p->do_search[1];
     pr.lowres_costs = (uint16_t*)(d + oLc); pr.row_satds = (int32_t*)(d + oRows); pr.frame = (int64_t*)(d + oFrame);
+    // the pair record travels in this thread's own scratch: no stream-ordered allocation per call
+    memcpy(pinUp + (oPair - oUp), &pr, sizeof(pr));
+    if (check_hip(hipMemcpyAsync(d + oUp, pinUp, upBytes, hipMemcpyHostToDevice, s), "lowres_cost_host upload")) return X265HIP_ENODEV;
     x265hip_lowres_cost_params q;
     memset(&q, 0, sizeof(q));
     q.depth = p->depth; q.stride = p->stride; q.width_in_cu = p->width_in_cu; q.height_in_cu = p->height_in_cu;
-    q.cost_q = (const uint16_t*)(d + oCost); q.qoff = p->cost_q_half; q.bframe_bias = p->bframe_bias;
-    // the pair record travels in this thread's own scratch: no stream-ordered allocation per call
-    if (up(oPair, &pr, sizeof(pr))) return X265HIP_ENODEV;
+    q.cost_q = needCost ? (const uint16_t*)(d + oCost) : (const uint16_t*)(d + oLc);              // (never read without a search)
+    q.qoff = p->cost_q_half; q.bframe_bias = p->bframe_bias;
     q.pairs = (const x265hip_lowres_cost_pair*)(d + oPair); q.npairs = 1;
-    q.pairs_on_device = (bidir ? 2 : 1) | ((!p->do_search[0] && (!bidir || !p->do_search[1])) ? 4 : 0);          // | 4: no list is searched again - the dependency-free launch
+    q.pairs_on_device = (bidir ? 2 : 1) | (!searches ? 4 : 0)                                    // | 4: no list is searched again - the dependency-free launch
+                      | (p->do_search[0] ? 8 : 0) | ((bidir && p->do_search[1]) ? 16 : 0);        // | 8, | 16: the lists that are (a B estimate walks them side by side)
     rc = x265hip_lowres_cost(&q, s);
     if (rc) return rc;
-    auto down = [&](void* dst, size_t o, size_t bytes) { return check_hip(hipMemcpyAsync(dst, d + o, bytes, hipMemcpyDeviceToHost, s), "lowres_cost_host download"); };
-    if (p->do_search[0]) { if (down(p->mvs[0], oMv0, (size_t)n * 8) || down(p->mv_costs[0], oMc0, (size_t)n * 4)) return X265HIP_ENODEV; }
-    if (bidir && p->do_search[1]) { if (down(p->mvs[1], oMv1, (size_t)n * 8) || down(p->mv_costs[1], oMc1, (size_t)n * 4)) return X265HIP_ENODEV; }
-    if (down(p->lowres_costs, oLc, (size_t)n * 2) || down(p->row_satds, oRows, (size_t)p->height_in_cu * 4) || down(p->frame, oFrame, 32)) return X265HIP_ENODEV;
-    X265HIP_TRY(hipStreamSynchronize(s));
+    if (check_hip(hipMemcpyAsync(pinDown, d + oDown, downBytes, hipMemcpyDeviceToHost, s), "lowres_cost_host download")) return X265HIP_ENODEV;
+    // the vectors just searched stay on the device for the estimates that reuse them
+    void* keep[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };
+    bool kept = true;
+    if (mvKey)
+        for (int li = 0; li < NL && kept; li++)
+            if (p->do_search[li])
+            {
+                if (cached_reserve((size_t)n * 8, &keep[li][0]) || cached_reserve((size_t)n * 4, &keep[li][1])) { kept = false; break; }
+                if (hipMemcpyAsync(keep[li][0], d + oMv[li], (size_t)n * 8, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+                    hipMemcpyAsync(keep[li][1], d + oMc[li], (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) kept = false;
+            }
+    const hipError_t es = hipStreamSynchronize(s);
+    if (es != hipSuccess || !kept)
+    {
+        for (int li = 0; li < 2; li++) { if (keep[li][0]) cached_abandon((size_t)n * 8, keep[li][0]); if (keep[li][1]) cached_abandon((size_t)n * 4, keep[li][1]); }
+        (void)hipGetLastError();
+        if (es != hipSuccess) X265HIP_TRY(es);
+    }
+    else
+        for (int li = 0; li < NL; li++)
+            if (keep[li][0]) { cached_adopt(p->mvs[li], mvKey, (size_t)n * 8, keep[li][0]); cached_adopt(p->mv_costs[li], mvKey, (size_t)n * 4, keep[li][1]); }
+    memcpy(p->frame, pinDown + (oFrame - oDown), 32);
+    memcpy(p->row_satds, pinDown + (oRows - oDown), (size_t)p->height_in_cu * 4);
+    memcpy(p->lowres_costs, pinDown + (oLc - oDown), (size_t)n * 2);
+    for (int li = 0; li < NL; li++)
+        if (p->do_search[li]) { memcpy(p->mvs[li], pinDown + (oMv[li] - oDown), (size_t)n * 8); memcpy(p->mv_costs[li], pinDown + (oMc[li] - oDown), (size_t)n * 4); }
     return 0;
 }
 

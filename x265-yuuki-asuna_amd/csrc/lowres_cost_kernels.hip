@@ -188,7 +188,11 @@ __device__ __forceinline__ int lowres_motion_estimate(const LowresPu<Px>& L, con
     return bcost;
 }
 
-template <typename Px, bool BIDIR, bool SPLIT>
+// SO (round 6, "search only"): a B picture's two lists are searched independently of each other (each list's predictors are that list's finished vectors), yet the walk above
+// ran them one after the other inside every lock-step, followed by the bi-directional candidates: a step of a (p0, b, p1) estimate that searches both lists cost two HEX
+// searches + four predictions + two SATDs.  The SO form walks ONE list (blockIdx.y names which of the searched lists) and writes only that list's vectors and costs; the
+// lists run side by side on their own compute units and the dependency-free kernel below finishes the estimate (candidates, AQ weighting, sums) in one short launch.
+template <typename Px, bool BIDIR, bool SPLIT, bool SO = false>
 __global__ void __launch_bounds__(SPLIT ? 512 : 1024) lowres_cost_kernel(LowresCostArgs g)
 {
     const int pairIdx = SPLIT ? (int)blockIdx.x / g.K : (int)blockIdx.x;
@@ -199,7 +203,9 @@ __global__ void __launch_bounds__(SPLIT ? 512 : 1024) lowres_cost_kernel(LowresC
     int32_t* mvCostsL[2] = { pr.mv_costs, pr.mv_costs1 };
     constexpr int BPP = sizeof(Px);
     constexpr uint32_t kBias = 1u << 30;
-    constexpr int NL = BIDIR ? 2 : 1;
+    constexpr int NL = SO ? 1 : (BIDIR ? 2 : 1);
+    // SO: the list this workgroup walks - the blockIdx.y-th of the lists the estimate searches
+    const int soList = SO ? ((pr.do_search[0] && blockIdx.y == 0) ? 0 : 1) : 0;
     const int Q = blockDim.x >> 2;                    // rows in flight: one quad each
     const int q = threadIdx.x >> 2, l = threadIdx.x & 3;
     const int tx = l & 1, ty = l >> 1;
@@ -250,15 +256,17 @@ __global__ void __launch_bounds__(SPLIT ? 512 : 1024) lowres_cost_kernel(LowresC
             int bcost = 1 << 28, listused = 0;                                     // MotionEstimate::COST_MAX
             int lmx[2] = { 0, 0 }, lmy[2] = { 0, 0 };
 #pragma unroll
-            for (int li = 0; li < NL; li++)
+            for (int lk = 0; lk < NL; lk++)
             {
+                const int li = SO ? soList : lk;
                 const PhasePlanes pp = li ? pp1 : pp0;
-                unsigned long long* mvA = mvsL[li];
+                unsigned long long* mvA = li ? mvsL[1] : mvsL[0];
+                int32_t* mcA = li ? mvCostsL[1] : mvCostsL[0];
                 int fencCost, qx, qy;
-                if (!pr.do_search[li])
+                if (!SO && !pr.do_search[li])
                 {
                     // estimateFrameCost's bDoSearch == false: this list was searched by an earlier estimate, its results stand
-                    fencCost = mvCostsL[li][cuXY];
+                    fencCost = mcA[cuXY];
                     const unsigned long long v = mvA[cuXY];
                     qx = (int)(uint32_t)v; qy = (int)(uint32_t)(v >> 32);
                 }
@@ -292,7 +300,7 @@ __global__ void __launch_bounds__(SPLIT ? 512 : 1024) lowres_cost_kernel(LowresC
                         mx = valid ? (int)(uint32_t)v : 0; my = valid ? (int)(uint32_t)(v >> 32) : 0;
                     };
                     int cx[4], cy[4], cc[4];
-                    cx[0] = vR ? rightx[li] : 0; cy[0] = vR ? righty[li] : 0;
+                    cx[0] = vR ? rightx[SO ? 0 : li] : 0; cy[0] = vR ? righty[SO ? 0 : li] : 0;
                     finished(vB, cuXY + W, cx[1], cy[1]);
                     finished(vBL, cuXY + W - 1, cx[2], cy[2]);
                     finished(vBR, cuXY + W + 1, cx[3], cy[3]);
@@ -313,22 +321,23 @@ __global__ void __launch_bounds__(SPLIT ? 512 : 1024) lowres_cost_kernel(LowresC
                     L.c.mvpx = mvpx; L.c.mvpy = mvpy;
                     fencCost = lowres_motion_estimate<Px>(L, pp, qx, qy);
                     if (BIDIR && skipCost < 64 && skipCost < fencCost) { fencCost = skipCost; qx = qy = 0; }       // :3311-3315
-                    rightx[li] = qx; righty[li] = qy;
+                    rightx[SO ? 0 : li] = qx; righty[SO ? 0 : li] = qy;
                     if (l == 0)
                     {
                         __hip_atomic_store(&mvA[cuXY], (unsigned long long)(uint32_t)qx | ((unsigned long long)(uint32_t)qy << 32),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        mvCostsL[li][cuXY] = fencCost;
+                        mcA[cuXY] = fencCost;
                         if (SPLIT && q == rowsHere - 1 && wk < g.K - 1)                      // the band above reads this row through L2
                             __hip_atomic_store(syncP + ((size_t)(li * g.K + wk) * W + cuX),
                                                ((unsigned long long)kSplitTag << 48) | ((unsigned long long)((uint32_t)qy & 0xffffffu) << 24) | (unsigned long long)((uint32_t)qx & 0xffffffu),
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                lmx[li] = qx; lmy[li] = qy;
+                lmx[SO ? 0 : li] = qx; lmy[SO ? 0 : li] = qy;
                 if (fencCost < bcost) { bcost = fencCost; listused = li + 1; }
             }
-            if (BIDIR)
+            if (SO) { }                                                            // the candidates and the sums are the flat kernel's
+            else if (BIDIR)
             {
                 // avg(l0-mv, l1-mv), then the co-located average (:3322-3343)
                 int p0[4][4], p1[4][4];
@@ -356,6 +365,8 @@ __global__ void __launch_bounds__(SPLIT ? 512 : 1024) lowres_cost_kernel(LowresC
                 const int ic = pr.intra_cost[cuXY];
                 if (ic < bcost) { bcost = ic; listused = 0; }
             }
+            if (!SO)
+            {
             const bool scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
             const int bcostAq = (scored && pr.inv_qscale) ? ((bcost * pr.inv_qscale[cuXY] + 128) >> 8) : bcost;
             if (scored) { costEst += bcost; costEstAq += bcostAq; intraMbs += (!BIDIR && !listused); }
@@ -366,11 +377,13 @@ __global__ void __launch_bounds__(SPLIT ? 512 : 1024) lowres_cost_kernel(LowresC
                 pr.lowres_costs[cuXY] = (uint16_t)((bcost < 0x3fff ? bcost : 0x3fff) | (listused << 14));
                 if (cuX == 0) pr.row_satds[cuY] = rowSatd;
             }
+            }
         }
         // the exchange stays inside one workgroup (one CU, one L1 / L2): the barrier's workgroup-scope fence is all it needs - an
         // agent-scope fence would write the L2 back every step
         __syncthreads();
     }
+    if (SO) return;
     if (l == 0)
     {
         atomicAdd((unsigned long long*)&sFrame[0], (unsigned long long)costEst);
@@ -518,7 +531,17 @@ __global__ void __launch_bounds__(256) lowres_cost_flat_kernel(LowresCostArgs g)
 
 using namespace x265hip;
 
-static std::atomic<uint64_t> g_lrcFlat{0}, g_lrcWalk{0}, g_lrcSplit{0};
+static std::atomic<uint64_t> g_lrcFlat{0}, g_lrcWalk{0}, g_lrcSplit{0}, g_lrcSo{0};          // (g_lrcSo: the split launches that walked their lists side by side)
+// the A/B switches, read once when the library is loaded; x265hip_lowres_cost_env_refresh() reads them again (tests and A/B tools that change them in a running process)
+static std::atomic<int> g_lrcEnvSplit{0}, g_lrcEnvSoOff{0};
+extern "C" void x265hip_lowres_cost_env_refresh(void)
+{
+    const char* e = getenv("X265HIP_LOWRES_COST_SPLIT");
+    int k = e ? atoi(e) : 0;
+    g_lrcEnvSplit.store(e ? (k < 1 ? 1 : k) : 0, std::memory_order_relaxed);
+    g_lrcEnvSoOff.store(getenv("X265HIP_LOWRES_COST_SO_OFF") ? 1 : 0, std::memory_order_relaxed);
+}
+namespace { struct LrcEnvInit { LrcEnvInit() { x265hip_lowres_cost_env_refresh(); } } g_lrcEnvInit; }
 extern "C" void x265hip_lowres_cost_launch_counts(uint64_t out[3])
 {
     out[0] = g_lrcFlat.load(); out[1] = g_lrcWalk.load(); out[2] = g_lrcSplit.load();
@@ -594,7 +617,8 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     // dispatched first, which an ordinary launch does not promise once the chip is full of other spinners.  At most kMaxSplitInFlight split
     // launches are in flight per process (counted at enqueue, released by a host callback behind the launch); above that an estimate runs
     // as one workgroup per picture - slower, never stuck (round-3 advisor).  The A/B switch is read once.
-    static const char* const splitEnv = getenv("X265HIP_LOWRES_COST_SPLIT");
+    const int splitEnvBands = g_lrcEnvSplit.load(std::memory_order_relaxed);          // 0: not set
+    const bool splitEnv = splitEnvBands != 0;
     static std::atomic<int> splitInFlight{0};
     constexpr int kMaxSplitInFlight = 8;                                // 8 x 16 bands = half the CUs at most wait on a neighbour
     bool counted = false;
@@ -603,7 +627,7 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
         // increment and the cap below would stop meaning anything (round-4 advisor) - under capture the estimate is not split
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (stream) (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
-        if (splitEnv) K = atoi(splitEnv);
+        if (splitEnv) K = splitEnvBands;
         else if (cap == hipStreamCaptureStatusActive) K = 1;
         else if (p->height_in_cu >= 32 && p->npairs <= 4)
         {
@@ -639,17 +663,48 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     a.cost = p->cost_q + p->qoff;
     a.bFrameBias = p->bframe_bias;
     a.K = K; a.R = R; a.sync = nullptr;
+    // SO: a split B estimate walks its searched lists side by side (one search per lock-step instead of two searches + the bi-directional candidates) and
+    // leaves the rest to the dependency-free kernel.  The lists an estimate searches: bits 8 / 16 of pairs_on_device, or the host table itself (all pairs alike).
+    int soLists = 0;
+    const bool soOff = g_lrcEnvSoOff.load(std::memory_order_relaxed) != 0;
+    if (split && bidir && !soOff)
+    {
+        if (p->pairs_on_device) soLists = (p->pairs_on_device >> 3) & 3;
+        else
+        {
+            soLists = (p->pairs[0].do_search[0] ? 1 : 0) | (p->pairs[0].do_search[1] ? 2 : 0);
+            for (int i = 1; i < p->npairs; i++)
+                if (soLists != ((p->pairs[i].do_search[0] ? 1 : 0) | (p->pairs[i].do_search[1] ? 2 : 0))) soLists = 0;
+        }
+    }
     std::unique_lock<std::mutex> seq;                 // split: clear + launch are one sequence per stream (round-3 advisor)
+    unsigned long long* flatAcc = nullptr;
     if (split)
     {
         seq = stream_sequence_lock(s);
-        const size_t sb = split_sync_words(K, p->width_in_cu) * 8 * (size_t)p->npairs;
+        const size_t words = split_sync_words(K, p->width_in_cu) * (size_t)p->npairs;
+        const size_t sb = (words + (soLists ? 4 * (size_t)p->npairs : 0)) * 8;
         a.sync = (unsigned long long*)stream_scratch(s, 1, sb);
         if (!a.sync) return X265HIP_ENODEV;
         X265HIP_TRY(hipMemsetAsync(a.sync, 0, sb, s));
+        flatAcc = a.sync + words;
     }
     (split ? g_lrcSplit : g_lrcWalk).fetch_add(1, std::memory_order_relaxed);
     const dim3 grid(p->npairs * K), block(quads * 4);
+    if (soLists)
+    {
+        const dim3 gridS(p->npairs * K, soLists == 3 ? 2 : 1);
+        if (bpp == 1) hipLaunchKernelGGL((lowres_cost_kernel<uint8_t, true, true, true>), gridS, block, 0, s, a);
+        else hipLaunchKernelGGL((lowres_cost_kernel<uint16_t, true, true, true>), gridS, block, 0, s, a);
+        LowresCostArgs f = a;
+        f.K = 1; f.R = p->height_in_cu; f.sync = flatAcc;
+        const dim3 gridF((p->height_in_cu + 3) / 4, p->npairs), blockF(256);
+        if (bpp == 1) hipLaunchKernelGGL((lowres_cost_flat_kernel<uint8_t, true>), gridF, blockF, 0, s, f);
+        else hipLaunchKernelGGL((lowres_cost_flat_kernel<uint16_t, true>), gridF, blockF, 0, s, f);
+        g_lrcSo.fetch_add(1, std::memory_order_relaxed);
+    }
+    else
+    {
 #define LRC_GO(PX, BI) do { if (split) hipLaunchKernelGGL((lowres_cost_kernel<PX, BI, true>), grid, block, 0, s, a); \
                             else hipLaunchKernelGGL((lowres_cost_kernel<PX, BI, false>), grid, block, 0, s, a); } while (0)
     if (bpp == 1 && !bidir) LRC_GO(uint8_t, false);
@@ -657,6 +712,7 @@ extern "C" int x265hip_lowres_cost(const x265hip_lowres_cost_params* p, void* st
     else if (!bidir) LRC_GO(uint16_t, false);
     else LRC_GO(uint16_t, true);
 #undef LRC_GO
+    }
     if (counted)
     {
         if (split && hipLaunchHostFunc(s, [](void* c) { static_cast<std::atomic<int>*>(c)->fetch_sub(1); }, &splitInFlight) == hipSuccess) counted = false;
