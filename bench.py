@@ -778,12 +778,18 @@ def main():
         transport_name = "dist"
         transport = None
         comm_init_s = None
-        if world > 1 and backend == "nccl" and os.environ.get("X265HIP_RING_TRANSPORT", "abi") == "abi":
+        # X265HIP_RING_TRANSPORT=bcast (round 6; needs mini-GOPs): ONE communicator over all ranks, an anchor's band = ncclBroadcast rooted at its rank (pipeline.AbiBcastTransport,
+        # x265hip_recon_publish_rows with peer = -1) - the transport `north_star` names, as an A/B switch next to the point-to-point flows; dist_bcast = its torch.distributed twin
+        want = os.environ.get("X265HIP_RING_TRANSPORT", "abi")
+        if want in ("bcast", "dist_bcast") and not ring_gop:
+            want = "abi" if want == "bcast" else "dist"
+        if world > 1 and backend == "nccl" and want in ("abi", "bcast"):
             ok = 1
             t_comm = time.perf_counter()
             try:
                 # mini-GOPs: an anchor's bands go to every rank that encodes one of the next G pictures - flows of distance 1 .. min(G, N - 1)
-                transport = P.AbiTransport(rank, world, dev, args.depth, geom, pics[0].h64, refs=min(ring_gop, world - 1) if ring_gop else 1)
+                transport = P.AbiBcastTransport(rank, world, dev, args.depth, geom, pics[0].h64) if want == "bcast" else \
+                    P.AbiTransport(rank, world, dev, args.depth, geom, pics[0].h64, refs=min(ring_gop, world - 1) if ring_gop else 1)
                 transport.setup(dev)
             except Exception as e:          # noqa: BLE001 - any failure means "use the other transport", on every rank
                 sys.stderr.write(f"bench.py rank {rank}: C-ABI ring transport unavailable ({e!r}); torch.distributed point-to-point instead\n")
@@ -792,14 +798,17 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             comm_init_s = time.perf_counter() - t_comm       # unique ids + ncclCommInitRank of every directed flow (+ the agreement all-reduce)
             if int(flag.item()):
-                transport_name = "abi"
+                transport_name = want
             else:
                 if transport is not None:
                     transport.close()
                 transport = None
+        if transport is None and world > 1 and want in ("bcast", "dist_bcast") and ring_gop:
+            transport = P.DistBcastTransport(rank, world, stage_through_host=backend != "nccl")
+            transport_name = "dist_bcast"
         ring = P.FrameParallelRing(rank, world, bp.bands, lag_rows_luma=args.range + 16,      # search window + 8-tap interpolation + sub-pel drift
                                    stage_through_host=backend != "nccl", transport=transport, gop=ring_gop)
-        if transport is None:
+        if transport is None or transport_name == "dist_bcast":
             ring.make_groups(device=dev)
         total_frames = (args.warmup + args.steps) * world
         ranks_seen = 1
@@ -857,6 +866,7 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     if banded:
+        ring.drain(geom, ref_pic.planes(), total_frames)     # a broadcast transport: the anchors this rank has not joined yet (nothing to do for point-to-point flows)
         ring.finish()
     pipe.launch_lookahead_costs()                    # flush the incomplete batch: all K pictures are scored inside the timed region
     torch.cuda.synchronize()
@@ -990,6 +1000,8 @@ def main():
                                        f"frame-parallel ring x{world}: frame f on rank f % {world} searches " + (f"the newest anchor before it (mini-GOPs of {ring_gop}: anchors = multiples of {ring_gop}, the pictures between two anchors non-referenced)" if ring_gop else "frame f - 1") + f", handed on in bands of {args.band_rows} CTU rows "
                                        f"(each band a slice of its own, like the reference's --slices); band transfers: "
                                        + ("x265hip_recon_publish_rows (the library's C ABI on RCCL, one 2-rank communicator per directed flow)" if transport_name == "abi"
+                                          else "x265hip_recon_publish_rows with peer = -1: ncclBroadcast over ONE communicator of all ranks, rooted at the anchor's rank (every rank joins every broadcast)" if transport_name == "bcast"
+                                          else "torch.distributed broadcast over one group of all ranks" if transport_name == "dist_bcast"
                                           else "torch.distributed point-to-point")),
                        "sharding": ("gop" if gop else "ring") if world > 1 else "none",
                        "ctus_per_frame": ms.nctu, "checksum": csum,
@@ -1019,7 +1031,7 @@ def main():
             flows = min(ring_gop, world - 1) if ring_gop else 1
             model_kw = dict(ctu_rows=(args.height + 63) // 64, lag_rows_luma=args.range + 16, depth=args.depth, width=args.width)
             out["config"]["ring"] = {"ranks_seen": ranks_seen, "transport": transport_name, "bands_per_frame": len(bp.bands), "refs": 1, "gop": ring_gop,
-                                     "communicators": world * flows if transport_name == "abi" else 0,
+                                     "communicators": world * flows if transport_name == "abi" else 1 if transport_name == "bcast" else 0,
                                      # what the band model predicts for this ring, in units of one GPU's whole-picture step (the tables are measured on one GPU)
                                      "model_x_one_gpu": (round(ring_model(world, args.band_rows, ring_gop, **model_kw) * band_table(args.depth, args.width)[1], 2)
                                                          if args.band_rows in band_table(args.depth, args.width)[0] else None),

@@ -438,7 +438,7 @@ def test_abi_transport_joins_its_communicators_without_a_waiting_cycle(world, re
 
 
 
-@pytest.mark.parametrize("world,sharding", [(2, "ring"), (2, "gop"), (3, "ring")])
+@pytest.mark.parametrize("world,sharding", [(2, "ring"), (2, "gop"), (3, "ring"), (3, "ring+bcast")])
 def test_bench_py_gpus_n_runs_end_to_end_on_gloo_with_the_stage_stand_in(world, sharding, tmp_path):
     """`bench.py --gpus N` as the driver launches it (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W),
     with X265HIP_BENCH_STUB=1: CPU tensors, gloo, a stand-in for the stages - everything else is main()'s own code: the process group, the ring of
@@ -450,6 +450,10 @@ def test_bench_py_gpus_n_runs_end_to_end_on_gloo_with_the_stage_stand_in(world, 
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, X265HIP_BENCH_STUB="1", X265HIP_BENCH_DETAIL=str(tmp_path / "detail.json"), OMP_NUM_THREADS="1")
+    bcast = sharding.endswith("+bcast")          # round 6: the one-communicator broadcast transport (its torch.distributed twin on gloo) as the A/B switch selects it
+    if bcast:
+        sharding = "ring"
+        env["X265HIP_RING_TRANSPORT"] = "bcast"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--width", "256", "--height", "256", "--range", "8",
            "--sharding", sharding]
@@ -465,7 +469,7 @@ def test_bench_py_gpus_n_runs_end_to_end_on_gloo_with_the_stage_stand_in(world, 
     assert {"bound", "kernel", "peak", "unit"} <= set(d["roofline"])
     if sharding == "ring":
         ring = d["config"]["ring"]
-        assert ring["ranks_seen"] == world and ring["transport"] == "dist" and ring["bands_per_frame"] >= 1
+        assert ring["ranks_seen"] == world and ring["transport"] == ("dist_bcast" if bcast else "dist") and ring["bands_per_frame"] >= 1
         assert ring["gop"] == 5 and ring["model_x_one_gpu"] > 0               # round 6: mini-GOPs of 5 by default, the band model's prediction printed beside the measurement
         assert "band_wait_ms_per_frame_max_over_ranks" in ring and "comm_init_s" in ring
         assert d["replicas"]["value"] > 0 and d["replicas"]["unit"] == "frames/s"                # ring and replicas side by side

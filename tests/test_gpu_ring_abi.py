@@ -62,3 +62,44 @@ def test_one_rank_communicator_and_a_published_band_through_the_c_abi():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))
     r = subprocess.run([sys.executable, "-c", CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and "RING-ABI-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+CHILD_BCAST = r'''
+import importlib, os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+P = importlib.import_module("x265-yuuki-asuna_amd.pipeline")
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+H, st, my, sc, myc = 256, 448, 80, 256, 40
+geom = (st, my, sc, myc)
+T = P.AbiBcastTransport(0, 1, dev, 8, geom, H)
+T.setup(dev)
+g = torch.Generator().manual_seed(5)
+planes = [torch.randint(0, 200, ((H + 2 * my) * st,), generator=g, dtype=torch.int32).to(torch.uint8).to(dev),
+          torch.randint(0, 200, ((H // 2 + 2 * myc) * sc,), generator=g, dtype=torch.int32).to(torch.uint8).to(dev),
+          torch.randint(0, 200, ((H // 2 + 2 * myc) * sc,), generator=g, dtype=torch.int32).to(torch.uint8).to(dev)]
+before = [p.clone() for p in planes]
+bands = [(0, 2), (2, 2)]
+works = []
+for b, (r0, rn) in enumerate(bands):
+    rows = P.FrameParallelRing._rows(geom, r0, rn, b == 0, b == len(bands) - 1)
+    works += T.send(planes, rows, (r0, rn), [])          # the root's side of the broadcast
+    works += T.recv(planes, rows, (r0, rn), 0)           # (one rank: the same call with root = itself)
+for w in works:
+    w.wait()
+torch.cuda.synchronize()
+assert all(torch.equal(a, b) for a, b in zip(planes, before))
+T.close()
+print("RING-BCAST-OK")
+'''
+
+
+def test_broadcast_transport_on_a_one_rank_communicator():
+    """pipeline.AbiBcastTransport (X265HIP_RING_TRANSPORT=bcast in bench.py): ONE communicator over all ranks, a band = a group of ncclBroadcast calls rooted at the
+    producer on one copy stream.  On a 1-GPU box: the communicator of one rank is built by the transport's own setup, bands are published as the ring would (root and
+    receiver side), the planes come back untouched.  The N-rank protocol - who joins what in which order - is covered on gloo (tests/test_dist_cpu.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))
+    r = subprocess.run([sys.executable, "-c", CHILD_BCAST], cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "RING-BCAST-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
