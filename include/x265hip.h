@@ -456,7 +456,7 @@ typedef struct x265hip_lowres_cost_host_params
      * this function's own searches, or before the first call that reuses them (lowresMvs / lowresMvCosts: searched once per lifetime of a Lowres, reset by Lowres::init,
      * lowres.cpp:283-284).  The library then keeps the device copy a search left behind (or uploads a reused list once) and the estimates that reuse the list -
      * three quarters of the slice-type decision's - upload no vectors at all; whatever a call does transfer goes as ONE upload and ONE download through pinned staging
-     * (4K: 1.8 -> see DESIGN 5.1 ms per reusing estimate).  X265HIP_LA_RESIDENT_OFF=1 (read when the library loads) uploads reused lists every time, as before. */
+     * (4K: 1.8 -> 0.3 - 0.5 ms per reusing estimate).  X265HIP_LA_RESIDENT_OFF=1 (read when the library loads) uploads reused lists every time, as before. */
     uint64_t plane_key_cur, plane_key_ref, plane_key_ref1, plane_key_ref_bi;
 } x265hip_lowres_cost_host_params;
 int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p);

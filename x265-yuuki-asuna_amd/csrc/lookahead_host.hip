@@ -215,13 +215,13 @@ namespace {
 // diagnostic (X265HIP_LA_STATS=1: printed when the process ends): the estimates by what they had to search and the wall time of the calls
 struct LaKinds
 {
-    std::atomic<uint64_t> n[6], us[6];          // P: none / list 0;  B: none / list 0 only / list 1 only / both
+    std::atomic<uint64_t> n[6], us[6], maxUs[6];          // P: none / list 0;  B: none / list 0 only / list 1 only / both
     ~LaKinds()
     {
         if (!getenv("X265HIP_LA_STATS")) return;
         static const char* const name[6] = { "P, nothing searched", "P, list 0 searched", "B, nothing searched", "B, list 0 searched", "B, list 1 searched", "B, both lists searched" };
         for (int i = 0; i < 6; i++)
-            if (n[i]) fprintf(stderr, "libx265hip: lowres_cost_host %-24s %8llu calls %10.3f ms each\n", name[i], (unsigned long long)n[i].load(), 1e-3 * us[i].load() / n[i].load());
+            if (n[i]) fprintf(stderr, "libx265hip: lowres_cost_host %-24s %8llu calls %10.3f ms each, longest %.3f ms\n", name[i], (unsigned long long)n[i].load(), 1e-3 * us[i].load() / n[i].load(), 1e-3 * maxUs[i].load());
     }
 } g_laKinds;
 // X265HIP_LA_RESIDENT_OFF=1 (A/B): the searched vectors are not kept on the device, every array travels by itself from / to pageable memory as before round 6's second half
@@ -239,7 +239,10 @@ extern "C" int x265hip_lowres_cost_host(const x265hip_lowres_cost_host_params* p
         {
             if (kind < 0) return;
             g_laKinds.n[kind].fetch_add(1, std::memory_order_relaxed);
-            g_laKinds.us[kind].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+            const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            g_laKinds.us[kind].fetch_add(us, std::memory_order_relaxed);
+            uint64_t m = g_laKinds.maxUs[kind].load(std::memory_order_relaxed);
+            while (us > m && !g_laKinds.maxUs[kind].compare_exchange_weak(m, us, std::memory_order_relaxed)) { }
         }
     } kindTimer{ -1 };
     if (p && p->ref1[0]) kindTimer.kind = 2 + (p->do_search[0] ? 1 : 0) + (p->do_search[1] ? 2 : 0);
