@@ -260,6 +260,16 @@ def test_lowres_cost_host_entry_equals_oracle():
         lc[:], rws[:], frame[:] = 0, 0, 0
         A.check(f(ctypes.byref(q)), "x265hip_lowres_cost_host")
         assert np.array_equal(lc, flc) and np.array_equal(rws, frows) and np.array_equal(frame[:len(fframe)], fframe)
+        # a NEW key for the current picture at the SAME addresses (the Lowres was recycled: other vectors in the same arrays): nothing resident may be served -
+        # the arrays' present content is what counts.  List 1 now holds the FIRST estimate's list-1 vectors (searched against planes[2]) next to planes[0].
+        mv1b[:], mc1b[:] = e1, c1
+        q.plane_key_cur = 9
+        lc[:], rws[:], frame[:] = 0, 0, 0
+        A.check(f(ctypes.byref(q)), "x265hip_lowres_cost_host")
+        _, _, glc, grows, gframe = O.lowres_cost(depth, planes[1][0], planes[0], stride, org, wcu, hcu, cq, qoff, icost, ref1_planes=planes[0],
+                                                 do_search=(0, 0), mvs_in=(e0, e1), mv_costs_in=(c0, c1))
+        assert not np.array_equal(glc, flc)
+        assert np.array_equal(lc, glc) and np.array_equal(rws, grows) and np.array_equal(frame[:len(gframe)], gframe)
     A.lib().x265hip_lowres_planes_forget()
 
 
