@@ -12,3 +12,6 @@ run 2ranks_gop5 2
 run 2ranks_gop2 2 --ring-gop 2
 run 2ranks_chain 2 --ring-gop 0
 run 3ranks_gop5 3
+# round 6, second half: the one-communicator broadcast transport's torch.distributed twin over the same real stages (X265HIP_RING_TRANSPORT=bcast falls to dist_bcast on gloo)
+X265HIP_RING_TRANSPORT=bcast run 3ranks_gop5_bcast 3
+X265HIP_RING_TRANSPORT=bcast run 2ranks_gop2_bcast 2 --ring-gop 2
