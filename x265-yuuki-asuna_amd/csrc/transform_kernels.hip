@@ -445,11 +445,153 @@ __global__ void __launch_bounds__(256) transform_mfma_stream_kernel(TrArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------ MFMA path, 16 point, FOUR TUs per instruction (round 6)
+// v_mfma_i32_16x16x64_i8 on a 16 x 16 block uses a quarter of its K range (the stream kernel above feeds zeros to K 16 .. 63: 48 of 64 lanes
+// supply nothing, 16 lanes load the whole block).  A 32 x 32 x 32 product whose matrix operand is BLOCK-DIAGONAL, diag(M16, M16), is four
+// independent 16 x 16 products: with the data operand B = [[X0, X1], [X2, X3]] the result is [[M X0, M X1], [M X2, M X3]].  So a wavefront takes
+// FOUR TUs per step: lane (h = lane >> 5, c = lane & 31) supplies row c & 15 of TU 2 h + (c >> 4) - every lane loads 32 bytes - and the accumulator
+// rows 0 .. 15 / 16 .. 31 of a lane belong to TUs (c >> 4) and 2 + (c >> 4).  Same limbs, biases and rounding as the kernels above (bit-exact by
+// construction: the zero blocks of the matrix operand add nothing); half of each instruction still multiplies zeros, none of its K range is idle.
+template <int KIND>
+__global__ void __launch_bounds__(256) transform_mfma_quad16_kernel(TrArgs a)
+{
+    typedef Mfma<32> MF;
+    constexpr int N = 16, NN = 256, LOG2N = 4;
+    constexpr bool INV = KIND == 1;
+    __shared__ __attribute__((aligned(16))) int16_t lds[4][4 * NN];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int16_t* T = lds[wave];
+    const int h = lane >> 5, c = lane & 31, b = c >> 4, j16 = c & 15;
+    const int tl = 2 * h + b;                                      // the TU whose operand row this lane supplies
+
+    v4i Afrag = { 0, 0, 0, 0 };                                    // diag(M, M)[row c][k 16 h .. 16 h + 15]: zero off the diagonal blocks
+    if (b == h)
+    {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            int v[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+            {
+                const int k = 4 * q + t;
+                v[t] = INV ? kT.m[k * 2][j16] : kT.m[j16 * 2][k];
+            }
+            Afrag[q] = pack4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    int bias[MF::NACC];
+#pragma unroll
+    for (int r = 0; r < MF::NACC; r++)
+    {
+        const int row = MF::row(lane, r) & 15;
+        int rs = 0;
+        if (INV) { for (int i = 0; i < N; i++) rs += kT.m[i * 2][row]; }
+        else rs = row == 0 ? 64 * N : 0;
+        bias[r] = 128 * rs;
+    }
+    const int shF1 = LOG2N - 1 + a.depth - 8, shF2 = LOG2N + 6, shI2 = 12 - (a.depth - 8);
+    auto product = [&](const uint32_t (&d)[8], int (&out)[MF::NACC])
+    {
+        v4i hi, lo;
+        split_limbs(d, hi, lo);
+        typename MF::Acc zero = {};
+        const typename MF::Acc ph = MF::run(Afrag, hi, zero);
+        const typename MF::Acc pl = MF::run(Afrag, lo, zero);
+#pragma unroll
+        for (int r = 0; r < MF::NACC; r++) out[r] = ph[r] * 256 + pl[r] + bias[r];
+    };
+    auto lds_row = [&](uint32_t (&d)[8])                            // T of TU tl, row j16: the operand row of the second pass
+    {
+        const u32x4* p = reinterpret_cast<const u32x4*>(T + tl * NN + j16 * N);
+        const u32x4 v0 = p[0], v1 = p[1];
+        d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+    };
+    const int nquads = (a.njobs + 3) >> 2;
+    const int nwaves = gridDim.x * 4;
+    for (int qd = blockIdx.x * 4 + wave; qd < nquads; qd += nwaves)
+    {
+        const int j0 = qd * 4;
+        // the TU this lane reads, and the two TUs its accumulator rows 0 .. 15 / 16 .. 31 belong to (a missing TU of the last quad: zeros in, nothing out)
+        const bool vl = j0 + tl < a.njobs, v0ok = j0 + b < a.njobs, v1ok = j0 + 2 + b < a.njobs;
+        const int16_t* src = a.src + (vl ? a.jobs[j0 + tl].off[0] : 0);
+        int16_t* dst0 = a.dst + (v0ok ? a.jobs[j0 + b].off[1] : 0);
+        int16_t* dst1 = a.dst + (v1ok ? a.jobs[j0 + 2 + b].off[1] : 0);
+        uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        int p[MF::NACC];
+        if (!INV)
+        {
+            if (vl)
+            {
+                const u32x4_a2* g = reinterpret_cast<const u32x4_a2*>(src + (long)j16 * a.srcStride);
+                const u32x4_a2 w0 = g[0], w1 = g[1];
+                d[0] = w0.x; d[1] = w0.y; d[2] = w0.z; d[3] = w0.w; d[4] = w1.x; d[5] = w1.y; d[6] = w1.z; d[7] = w1.w;
+            }
+            product(d, p);
+#pragma unroll
+            for (int r = 0; r < MF::NACC; r++)
+                T[(2 * (r >> 3) + b) * NN + (MF::row(lane, r) & 15) * N + j16] = (int16_t)((p[r] + (1 << (shF1 - 1))) >> shF1);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            lds_row(d);
+            product(d, p);
+#pragma unroll
+            for (int r = 0; r < MF::NACC; r++)
+            {
+                const int v = (int16_t)((p[r] + (1 << (shF2 - 1))) >> shF2);
+                if (r < 8) { if (v0ok) dst0[(MF::row(lane, r) & 15) * N + j16] = (int16_t)v; }
+                else if (v1ok) dst1[(MF::row(lane, r) & 15) * N + j16] = (int16_t)v;
+            }
+        }
+        else
+        {
+            if (vl)
+            {
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                {
+                    const uint32_t e0 = (uint16_t)src[(2 * q) * N + j16], e1 = (uint16_t)src[(2 * q + 1) * N + j16];
+                    d[q] = e0 | (e1 << 16);
+                }
+            }
+            product(d, p);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < MF::NACC; r++)
+                T[(2 * (r >> 3) + b) * NN + (MF::row(lane, r) & 15) * N + j16] = (int16_t)clip16((p[r] + 64) >> 7);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            lds_row(d);
+            product(d, p);
+#pragma unroll
+            for (int g = 0; g < MF::NACC / 4; g++)
+            {
+                int v[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = clip16((p[4 * g + t] + (1 << (shI2 - 1))) >> shI2);
+                if (g < 2 ? !v0ok : !v1ok) continue;
+                uint8_t* dp = reinterpret_cast<uint8_t*>((g < 2 ? dst0 : dst1) + (long)j16 * a.dstStride + (MF::row(lane, 4 * g) & 15));
+                reinterpret_cast<u32_unaligned*>(dp)[0] = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
+                reinterpret_cast<u32_unaligned*>(dp)[1] = ((uint32_t)v[2] & 0xffffu) | ((uint32_t)v[3] << 16);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int N, int KIND> static int launch_mfma(const TrArgs& a, hipStream_t s)
 {
     static const bool simple = getenv("X265HIP_MFMA_SIMPLE") != nullptr;   // A/B switch (read once): one wavefront + one workgroup per TU
+    static const bool quadOff = getenv("X265HIP_MFMA_QUAD16_OFF") != nullptr;   // A/B switch (read once): 16 point TUs one per 16x16x64 instruction, as before round 6
     if (simple)
         hipLaunchKernelGGL((transform_mfma_kernel<N, KIND>), dim3(a.njobs), dim3(64), 0, s, a);
+    else if (N == 16 && !quadOff)
+    {
+        int wgs = ((a.njobs + 3) / 4 + 3) / 4;
+        if (wgs > 256 * 8) wgs = 256 * 8;
+        hipLaunchKernelGGL((transform_mfma_quad16_kernel<KIND>), dim3(wgs), dim3(256), 0, s, a);
+    }
     else
     {
         int wgs = (a.njobs + 3) / 4;
