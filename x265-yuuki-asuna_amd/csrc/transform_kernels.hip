@@ -43,6 +43,18 @@ struct DctMat
     }
 };
 __constant__ DctMat kT = DctMat();
+// column sums of the N-point matrix (the data-independent bias of the inverse passes' accumulators): sum_i M_N[i][col]
+struct DctColSums
+{
+    int s16[16], s32[32];
+    constexpr DctColSums() : s16{}, s32{}
+    {
+        constexpr DctMat t = DctMat();
+        for (int c = 0; c < 32; c++) { int v = 0; for (int i = 0; i < 32; i++) v += t.m[i][c]; s32[c] = v; }
+        for (int c = 0; c < 16; c++) { int v = 0; for (int i = 0; i < 16; i++) v += t.m[2 * i][c]; s16[c] = v; }
+    }
+};
+__constant__ DctColSums kTColSum = DctColSums();
 __constant__ int8_t kDst[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };
 
 struct TrArgs
@@ -349,7 +361,7 @@ __global__ void __launch_bounds__(256) transform_mfma_stream_kernel(TrArgs a)
     {
         const int row = MF::row(lane, r);
         int rs = 0;
-        if (INV) { for (int i = 0; i < N; i++) rs += kT.m[i * (32 / N)][row]; }
+        if (INV) rs = N == 16 ? kTColSum.s16[row & 15] : kTColSum.s32[row];          // (a table: the sum itself was N loads per accumulator element and wavefront)
         else rs = row == 0 ? 64 * N : 0;
         bias[r] = 128 * rs;
     }
@@ -487,7 +499,7 @@ __global__ void __launch_bounds__(256) transform_mfma_quad16_kernel(TrArgs a)
     {
         const int row = MF::row(lane, r) & 15;
         int rs = 0;
-        if (INV) { for (int i = 0; i < N; i++) rs += kT.m[i * 2][row]; }
+        if (INV) rs = kTColSum.s16[row];
         else rs = row == 0 ? 64 * N : 0;
         bias[r] = 128 * rs;
     }
@@ -546,17 +558,27 @@ __global__ void __launch_bounds__(256) transform_mfma_quad16_kernel(TrArgs a)
         }
         else
         {
-            if (vl)
+            // pass 1 contracts down the COLUMNS of the coefficient block.  The stream kernel gathers a lane's column with 16 two-byte global loads; here the TU comes in
+            // row by row (every lane 32 contiguous bytes), goes through T as it is, and the lane takes its column from LDS - two global loads per lane instead of sixteen
             {
+                u32x4 w0 = { 0, 0, 0, 0 }, w1 = { 0, 0, 0, 0 };
+                if (vl)
+                {
+                    const u32x4_a2* g = reinterpret_cast<const u32x4_a2*>(src + j16 * N);
+                    const u32x4_a2 g0 = g[0], g1 = g[1];
+                    w0 = u32x4{ g0.x, g0.y, g0.z, g0.w }; w1 = u32x4{ g1.x, g1.y, g1.z, g1.w };
+                }
+                u32x4* tp = reinterpret_cast<u32x4*>(T + tl * NN + j16 * N);
+                tp[0] = w0; tp[1] = w1;
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                const int16_t* col = T + tl * NN + j16;
 #pragma unroll
                 for (int q = 0; q < 8; q++)
-                {
-                    const uint32_t e0 = (uint16_t)src[(2 * q) * N + j16], e1 = (uint16_t)src[(2 * q + 1) * N + j16];
-                    d[q] = e0 | (e1 << 16);
-                }
+                    d[q] = (uint32_t)(uint16_t)col[(2 * q) * N] | ((uint32_t)(uint16_t)col[(2 * q + 1) * N] << 16);
             }
             product(d, p);
-            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_wave_barrier();                        // (LDS operations of a wavefront execute in order: the column reads above are through)
 #pragma unroll
             for (int r = 0; r < MF::NACC; r++)
                 T[(2 * (r >> 3) + b) * NN + (MF::row(lane, r) & 15) * N + j16] = (int16_t)clip16((p[r] + 64) >> 7);
@@ -564,16 +586,28 @@ __global__ void __launch_bounds__(256) transform_mfma_quad16_kernel(TrArgs a)
             __builtin_amdgcn_s_waitcnt(0xc07f);
             lds_row(d);
             product(d, p);
+            // A lane holds rows 4 h .. 4 h + 3 and 8 + 4 h .. of output row j16 of BOTH its TUs; lane ^ 32 holds the other rows.  One v_permlane32_swap per
+            // dword hands the (2 + b) pieces of the lower half-wave to the upper one and the b pieces back: every lane then owns ONE whole output row
+            // (32 contiguous bytes, two 16-byte stores) instead of four 8-byte pieces of two rows.
+            uint32_t pk[8];
 #pragma unroll
-            for (int g = 0; g < MF::NACC / 4; g++)
+            for (int g = 0; g < 4; g++)
             {
                 int v[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) v[t] = clip16((p[4 * g + t] + (1 << (shI2 - 1))) >> shI2);
-                if (g < 2 ? !v0ok : !v1ok) continue;
-                uint8_t* dp = reinterpret_cast<uint8_t*>((g < 2 ? dst0 : dst1) + (long)j16 * a.dstStride + (MF::row(lane, 4 * g) & 15));
-                reinterpret_cast<u32_unaligned*>(dp)[0] = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
-                reinterpret_cast<u32_unaligned*>(dp)[1] = ((uint32_t)v[2] & 0xffffu) | ((uint32_t)v[3] << 16);
+                pk[2 * g] = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
+                pk[2 * g + 1] = ((uint32_t)v[2] & 0xffffu) | ((uint32_t)v[3] << 16);
+            }
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            v2u sw[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) sw[i] = __builtin_amdgcn_permlane32_swap(pk[i], pk[4 + i], false, false);
+            if (h ? v1ok : v0ok)
+            {
+                u32x4_a2* dp = reinterpret_cast<u32x4_a2*>((h ? dst1 : dst0) + (long)j16 * a.dstStride);
+                dp[0] = u32x4_a2{ sw[0].x, sw[1].x, sw[0].y, sw[1].y };
+                dp[1] = u32x4_a2{ sw[2].x, sw[3].x, sw[2].y, sw[3].y };
             }
         }
         __builtin_amdgcn_wave_barrier();
