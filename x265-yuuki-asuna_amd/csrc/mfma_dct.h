@@ -66,6 +66,12 @@ struct DctOperand
     template <typename MatF>
     __device__ __forceinline__ void init(int lane, MatF m)
     {
+        init(lane, m, [&](int col) { int rs = 0; for (int i = 0; i < N; i++) rs += m(i * (32 / N), col); return rs; });
+    }
+    // colsum(c) = sum_i M_N[i][c]: callers that hold the sums in a table spare every wavefront N loads per accumulator element
+    template <typename MatF, typename SumF>
+    __device__ __forceinline__ void init(int lane, MatF m, SumF colsum)
+    {
         const int kb = MF::kbase(lane), rn = MF::mn(lane);
         kvalid = kb < N;
         frag = v4i{ 0, 0, 0, 0 };
@@ -89,7 +95,7 @@ struct DctOperand
         {
             const int row = MF::row(lane, r);
             int rs = 0;
-            if (INV) { for (int i = 0; i < N; i++) rs += m(i * (32 / N), row); }
+            if (INV) rs = colsum(row);
             else rs = row == 0 ? 64 * N : 0;
             bias[r] = 128 * rs;
         }

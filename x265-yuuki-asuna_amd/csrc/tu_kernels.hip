@@ -37,6 +37,19 @@ struct DctMatrix
     }
 };
 static __constant__ DctMatrix kTu = DctMatrix();
+// column sums of the 16 / 32 point matrices: the data-independent bias of the inverse passes' accumulators (DctOperand::init summed N matrix entries per
+// accumulator element - 512 loads per lane at the start of every persistent wavefront of the 32 x 32 stage)
+struct DctMatrixColSums
+{
+    int s16[16], s32[32];
+    constexpr DctMatrixColSums() : s16{}, s32{}
+    {
+        constexpr DctMatrix t = DctMatrix();
+        for (int c = 0; c < 32; c++) { int v = 0; for (int i = 0; i < 32; i++) v += t.m[i][c]; s32[c] = v; }
+        for (int c = 0; c < 16; c++) { int v = 0; for (int i = 0; i < 16; i++) v += t.m[2 * i][c]; s16[c] = v; }
+    }
+};
+static __constant__ DctMatrixColSums kTuColSum = DctMatrixColSums();
 static __constant__ int8_t kTuDst[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };   // dct.cpp:43-81
 static __constant__ int16_t kTuTaps[4][8] = {
     { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
@@ -102,8 +115,9 @@ template <int N> struct TuOps<N, true>
     __device__ __forceinline__ void init(int lane)
     {
         auto matrix = [](int r, int c) { return (int)kTu.m[r][c]; };
-        fw.init(lane, matrix);
-        iv.init(lane, matrix);
+        auto colsum = [](int c) { return N == 16 ? kTuColSum.s16[c] : kTuColSum.s32[c]; };
+        fw.init(lane, matrix, colsum);
+        iv.init(lane, matrix, colsum);
     }
 };
 template <int N, bool DST> using TuOpsFor = TuOps<N, (N >= 16 && !DST)>;
