@@ -105,6 +105,13 @@ __device__ __forceinline__ int xcd_swizzle(int i, int n)
     return i < (per << 3) ? (i & 7) * per + (i >> 3) : i;
 }
 
+// the same for a 2-D grid whose rows share input with the rows above / below them (halo rows): every XCD gets a contiguous band of grid rows
+__device__ __forceinline__ void xcd_swizzle_2d(int& bx, int& by)
+{
+    const int t = xcd_swizzle((int)(blockIdx.x + blockIdx.y * gridDim.x), (int)(gridDim.x * gridDim.y));
+    bx = t % (int)gridDim.x; by = t / (int)gridDim.x;
+}
+
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 #endif  // __HIPCC__
 

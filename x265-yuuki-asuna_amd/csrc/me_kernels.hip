@@ -38,6 +38,7 @@ struct MEArgs
     const uint16_t* costX;
     const uint16_t* costY;
     const int16_t* centres;      // optional [ctu][2]: the window of CTU c is centred on displacement (centres[2c], centres[2c+1]) instead of (0, 0)
+    int xcdOrder;                // 1: a whole-picture launch maps workgroup -> CTU so that every XCD holds a contiguous band of CTUs (X265HIP_ME_XCD_OFF=1: raster order, A/B)
 };
 
 // lane -> 8x8 block coordinates inside the CTU, z-order (quad = one 16x16, 16 lanes = one 32x32)
@@ -78,7 +79,8 @@ __global__ void __launch_bounds__(1024, SURF ? 4 : 8) me_ctu_kernel(MEArgs a)
     const int NC = 2 * R + 1;                 // mv columns == mv rows
     const int NG = (NC + 3) >> 2;             // column groups of 4 in the surface layout
     const int rows = 64 + 2 * R;
-    const int ctu = blockIdx.x;
+    // XCD-aware order (round 6): a whole-picture launch hands every XCD a contiguous band of CTUs - the windows of neighbouring CTUs overlap by 2 R / (64 + 2 R) and meet in one L2
+    const int ctu = (gridDim.y == 1 && a.xcdOrder) ? xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int cx = (ctu % a.ctusW) * 64, cy = (ctu / a.ctusW) * 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -263,7 +265,8 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
     const int NC = 2 * R + 1;
     const int NG = (NC + 3) >> 2;
     const int rows = 64 + 2 * R;
-    const int ctu = blockIdx.x;
+    // XCD-aware order (round 6): a whole-picture launch hands every XCD a contiguous band of CTUs - the windows of neighbouring CTUs overlap by 2 R / (64 + 2 R) and meet in one L2
+    const int ctu = (gridDim.y == 1 && a.xcdOrder) ? xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int cx = (ctu % a.ctusW) * 64, cy = (ctu / a.ctusW) * 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -540,7 +543,8 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_q2_kernel(MEArgs a, int ctabOf
     const int NC = 2 * R + 1;
     const int NG = (NC + 3) >> 2;
     const int rows = 64 + 2 * R;
-    const int ctu = blockIdx.x;
+    // XCD-aware order (round 6): a whole-picture launch hands every XCD a contiguous band of CTUs - the windows of neighbouring CTUs overlap by 2 R / (64 + 2 R) and meet in one L2
+    const int ctu = (gridDim.y == 1 && a.xcdOrder) ? xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int cx = (ctu % a.ctusW) * 64, cy = (ctu / a.ctusW) * 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -878,7 +882,8 @@ __global__ void __launch_bounds__(SURF && BEST ? 768 : 1024, SURF && BEST ? 3 : 
     const int NC = 2 * R + 1;
     const int NG = (NC + 3) >> 2;
     const int rows = 64 + 2 * R;
-    const int ctu = blockIdx.x;
+    // XCD-aware order (round 6): a whole-picture launch hands every XCD a contiguous band of CTUs - the windows of neighbouring CTUs overlap by 2 R / (64 + 2 R) and meet in one L2
+    const int ctu = (gridDim.y == 1 && a.xcdOrder) ? xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int cx = (ctu % a.ctusW) * 64, cy = (ctu / a.ctusW) * 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1081,7 +1086,8 @@ __global__ void __launch_bounds__(1024, 4) me_ctu_w2_kernel(MEArgs a, int ctabOf
     const int NC = 2 * R + 1;
     const int NG = (NC + 3) >> 2;
     const int rows = 64 + 2 * R;
-    const int ctu = blockIdx.x;
+    // XCD-aware order (round 6): a whole-picture launch hands every XCD a contiguous band of CTUs - the windows of neighbouring CTUs overlap by 2 R / (64 + 2 R) and meet in one L2
+    const int ctu = (gridDim.y == 1 && a.xcdOrder) ? xcd_swizzle((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int cx = (ctu % a.ctusW) * 64, cy = (ctu / a.ctusW) * 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1284,6 +1290,7 @@ struct MeEnv
     int bestWaves;
     bool splitGroups8, splitGroups16;
     bool w2;
+    bool xcdOrder;
 };
 static MeEnv g_meEnv;
 static std::once_flag g_meEnvOnce;
@@ -1298,6 +1305,7 @@ static void me_env_read()
     e.bestVar = bv ? atoi(bv) & 3 : -1;
     const char* q2 = getenv("X265HIP_ME_Q2_FLAGS");
     e.q2Flags = q2 ? atoi(q2) : (bv ? -1 : Q2_DEFAULT_FLAGS);
+    e.xcdOrder = getenv("X265HIP_ME_XCD_OFF") == nullptr;
     e.bestWaves = getenv("X265HIP_ME_BEST_WAVES") ? atoi(getenv("X265HIP_ME_BEST_WAVES")) : 0;
     const char* sg = getenv("X265HIP_ME_SPLIT_GROUPS");
     e.splitGroups8 = !(sg && atoi(sg) == 0);
@@ -1352,6 +1360,7 @@ static int launch_me(const x265hip_me_params* p, hipStream_t s)
     const bool packed = anySurf && p->surf_format == X265HIP_SURF_PACKED;
     a.costX = p->cost_x; a.costY = p->cost_y;
     a.centres = p->centres;
+    a.xcdOrder = env.xcdOrder ? 1 : 0;
     const int nctu = a.ctusW * (p->height / 64);
     const size_t lds = (size_t)a.rowBytes * (64 + 2 * p->range + 2);     // + 2 rows the pipeline may prefetch past the window
     if (lds > 160 * 1024) { set_error("me_fullsearch: range %d needs %zu B of LDS (> 160 KiB)", p->range, lds); return X265HIP_EINVAL; }

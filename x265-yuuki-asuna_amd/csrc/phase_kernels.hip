@@ -53,7 +53,9 @@ template <typename Px>
 __global__ void __launch_bounds__(256) phase_luma_kernel(PhaseArgs a)
 {
     constexpr int BPP = sizeof(Px);
-    const int tx = blockIdx.x * 256 + threadIdx.x, ty = blockIdx.y + 1;          // the first 4 and the last 8 rows are not produced
+    int bx, by;
+    xcd_swizzle_2d(bx, by);                                                       // a tile row reads 11 sample rows for its 4: vertical neighbours on one XCD's L2
+    const int tx = bx * 256 + threadIdx.x, ty = by + 1;                           // the first 4 and the last 8 rows are not produced
     if (tx >= a.tilesW) return;
     const long off = (long)(ty * 4) * a.strideB + (long)tx * 4 * BPP;
     const uint8_t* org = a.src + off;
@@ -280,7 +282,9 @@ __device__ __forceinline__ void phase_luma_wide_body(const PhaseArgs& a)
 {
     constexpr int BPP = sizeof(Px), NW = BPP == 1 ? 3 : 6;
     const int lane = threadIdx.x & 63;
-    const int tx = blockIdx.x * 256 + threadIdx.x, ty = blockIdx.y + 1;          // the first 4 and the last 8 rows are not produced
+    int bx, by;
+    xcd_swizzle_2d(bx, by);                                                       // a tile row reads 11 sample rows for its 4: vertical neighbours on one XCD's L2
+    const int tx = bx * 256 + threadIdx.x, ty = by + 1;                           // the first 4 and the last 8 rows are not produced
     // whole quads only (tilesW % 4 == 0); lanes beyond the row repeat its last quad's loads and store nothing
     const bool live = tx < a.tilesW;
     const int txl = live ? tx : a.tilesW - 4 + (tx & 3);
@@ -308,7 +312,9 @@ template <typename Px>
 __global__ void __launch_bounds__(256) phase_chroma_kernel(PhaseArgs a)
 {
     constexpr int BPP = sizeof(Px);
-    const int tx = blockIdx.x * 256 + threadIdx.x, ty = blockIdx.y + 1;
+    int bx, by;
+    xcd_swizzle_2d(bx, by);
+    const int tx = bx * 256 + threadIdx.x, ty = by + 1;
     if (tx >= a.tilesW) return;
     const long off = (long)(ty * 4) * a.strideB + (long)tx * 4 * BPP;
     const int maxVal = (1 << a.depth) - 1, headRoom = 14 - a.depth;

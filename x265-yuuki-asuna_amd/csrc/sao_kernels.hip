@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) sao_stats_kernel(SaoStatsArgs3 aa)
     __shared__ int sBo[4][2][32];
     __shared__ int sEo[2][20];
     const int tid = threadIdx.x;
-    const int addr = blockIdx.x;
+    const int addr = xcd_swizzle(blockIdx.x, a.nctu);          // neighbouring CTUs (shared halo lines) on one XCD's L2
     const int lpelx = (addr % a.ctusW) * a.ctuW, tpely = (addr / a.ctusW) * a.ctuH;
     const int rpelx = min(lpelx + a.ctuW, a.width), bpely = min(tpely + a.ctuH, a.height);
     const int ctuW = rpelx - lpelx, ctuH = bpely - tpely;
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) sao_apply_kernel(SaoApplyArgs3 aa)
     const SaoApplyArgs& a = aa.p[blockIdx.y];
     if ((int)blockIdx.x >= a.nctu) return;
     constexpr int BPP = sizeof(Px);
-    const int tid = threadIdx.x, addr = blockIdx.x;
+    const int tid = threadIdx.x, addr = xcd_swizzle(blockIdx.x, a.nctu);
     const int lpelx = (addr % a.ctusW) * a.ctuW, tpely = (addr / a.ctusW) * a.ctuH;
     const int32_t* p = a.params + (size_t)addr * 7;
     const int typeIdx = p[0], bandPos = p[1];

@@ -704,15 +704,19 @@ __global__ void __launch_bounds__(InterReconThreads<N>::value, TuWavesPerSimd<N>
         // (32x32: only the vector travels ahead - the 11 sample registers on top of its 252 made the compiler spill 261)
         constexpr bool AHEAD = N == 16;
         uint32_t fvC[FI], pvC[PI], fvN[AHEAD ? FI : 1], pvN[AHEAD ? PI : 1];
-        int blk = blockIdx.x;
-        if (blk < nblocks)
+        // XCD-aware order (round 6): wavefront w sits on XCD w % 8 (observed placement, for speed only) and walks virtual indices w, w + gridDim.x, ...; the virtual index
+        // -> block map hands every XCD a contiguous eighth of the picture's blocks, so the TUs of a CTU and the CTUs of a row - whose 32-byte source rows and straddling
+        // reference rows share 64-byte lines - meet in ONE L2 instead of being fetched by up to four (inter_recon<32> fetched 2.3 - 4.6 x its planes, profiles/stage_traffic.json)
+        int v = blockIdx.x;
+        if (v < nblocks)
         {
+            int blk = xcd_swizzle(v, nblocks);
             Geo g = geom(blk, mv_of(blk));
             if constexpr (AHEAD) load_regs(g, fvC, pvC);
-            for (; blk < nblocks; blk += gridDim.x)
+            for (; v < nblocks; v += gridDim.x)
             {
-                const int nb = blk + gridDim.x;
-                const bool has = nb < nblocks;
+                const bool has = v + (int)gridDim.x < nblocks;
+                const int nb = has ? xcd_swizzle(v + (int)gridDim.x, nblocks) : 0;
                 int packedN = 0;
                 if (has) packedN = mv_of(nb);
                 if constexpr (!AHEAD) load_regs(g, fvC, pvC);
