@@ -89,7 +89,7 @@ struct TuArgs
     uint8_t* recon; long reconStrideB;
     int ctusW, depth, level;
     const int2* mv;                 // [ctu*85] {cost, qx | qy << 16}
-    int qp, intraSlice;          // intraSlice: the X265HIP_TU_* flag bits
+    int qp, intraSlice;          // intraSlice: the X265HIP_TU_* flag bits (+ TU_FLAG_RASTER_ORDER, set by the launcher alone)
     int16_t* levels; uint32_t* numSig; unsigned long long* dist;
     TuTables tab;
 };
@@ -130,7 +130,7 @@ __constant__ uint8_t kTuDiag2[4] = { 0, 8, 1, 9 };
 __constant__ uint8_t kTuDiag4[16] = { 0, 8, 1, 16, 9, 2, 24, 17, 10, 3, 25, 18, 11, 26, 19, 27 };
 __constant__ uint8_t kTuDiag8[64] = { 0, 8, 1, 16, 9, 2, 24, 17, 10, 3, 32, 25, 18, 11, 4, 40, 33, 26, 19, 12, 5, 48, 41, 34, 27, 20, 13, 6, 56, 49, 42, 35,
                                       28, 21, 14, 7, 57, 50, 43, 36, 29, 22, 15, 58, 51, 44, 37, 30, 23, 59, 52, 45, 38, 31, 60, 53, 46, 39, 61, 54, 47, 62, 55, 63 };
-enum { TU_SCAN_DIAG = 0, TU_SCAN_HOR = 1, TU_SCAN_VER = 2, TU_FLAG_INTRA_SLICE = 1, TU_FLAG_SIGN_HIDE = 2 };
+enum { TU_SCAN_DIAG = 0, TU_SCAN_HOR = 1, TU_SCAN_VER = 2, TU_FLAG_INTRA_SLICE = 1, TU_FLAG_SIGN_HIDE = 2, TU_FLAG_RASTER_ORDER = 1 << 30 };
 
 // raster position inside the N x N block of scan position i (0..15) of coefficient group cg
 template <int N> __device__ __forceinline__ int tu_scan_pos(int scanType, int cg, int i)
@@ -708,15 +708,17 @@ __global__ void __launch_bounds__(InterReconThreads<N>::value, TuWavesPerSimd<N>
         // -> block map hands every XCD a contiguous eighth of the picture's blocks, so the TUs of a CTU and the CTUs of a row - whose 32-byte source rows and straddling
         // reference rows share 64-byte lines - meet in ONE L2 instead of being fetched by up to four (inter_recon<32> fetched 2.3 - 4.6 x its planes, profiles/stage_traffic.json)
         int v = blockIdx.x;
+        const bool xcdOrder = !(a.intraSlice & TU_FLAG_RASTER_ORDER);
+        auto order = [&](const int i) { return xcdOrder ? xcd_swizzle(i, nblocks) : i; };
         if (v < nblocks)
         {
-            int blk = xcd_swizzle(v, nblocks);
+            int blk = order(v);
             Geo g = geom(blk, mv_of(blk));
             if constexpr (AHEAD) load_regs(g, fvC, pvC);
             for (; v < nblocks; v += gridDim.x)
             {
                 const bool has = v + (int)gridDim.x < nblocks;
-                const int nb = has ? xcd_swizzle(v + (int)gridDim.x, nblocks) : 0;
+                const int nb = has ? order(v + (int)gridDim.x) : 0;
                 int packedN = 0;
                 if (has) packedN = mv_of(nb);
                 if constexpr (!AHEAD) load_regs(g, fvC, pvC);
@@ -992,6 +994,14 @@ static TuTables tu_tables_of(const x265hip_tu_tables* t)
 }
 #define TABLES_OF(p) ((p)->tables)
 
+// A/B switch (read once): X265HIP_TU_XCD_OFF = 1 / luma / chroma - the persistent TU kernels walk the blocks in raster order instead of the XCD-aware one
+static bool tu_raster_order(const bool chroma)
+{
+    static const char* const e = getenv("X265HIP_TU_XCD_OFF");
+    if (!e) return false;
+    return e[0] == '1' || (chroma ? e[0] == 'c' : e[0] == 'l');
+}
+
 extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
 {
     int rc = ensure_device();
@@ -1008,7 +1018,7 @@ extern "C" int x265hip_inter_recon(const x265hip_recon_params* p, void* stream)
     a.fref = (const uint8_t*)p->fref; a.frefStrideB = (long)p->fref_stride * bpp;
     a.recon = (uint8_t*)p->recon; a.reconStrideB = (long)p->recon_stride * bpp;
     a.ctusW = p->width / 64; a.depth = p->depth; a.level = p->level;
-    a.mv = (const int2*)p->mv; a.qp = p->qp; a.intraSlice = p->intra_slice;
+    a.mv = (const int2*)p->mv; a.qp = p->qp; a.intraSlice = (p->intra_slice & ~TU_FLAG_RASTER_ORDER) | (tu_raster_order(false) ? TU_FLAG_RASTER_ORDER : 0);
     a.levels = p->levels; a.numSig = p->num_sig; a.dist = (unsigned long long*)p->dist;
     a.tab = tu_tables_of(TABLES_OF(p));
     TuArgs2 aa = {};
@@ -1130,7 +1140,7 @@ static int inter_recon_chroma_planes(const x265hip_recon_params* const* pp, int 
         a.fref = (const uint8_t*)q->fref; a.frefStrideB = (long)q->fref_stride * bpp;
         a.recon = (uint8_t*)q->recon; a.reconStrideB = (long)q->recon_stride * bpp;
         a.ctusW = q->width / 64; a.depth = q->depth; a.level = q->level;
-        a.mv = (const int2*)q->mv; a.qp = q->qp; a.intraSlice = q->intra_slice;
+        a.mv = (const int2*)q->mv; a.qp = q->qp; a.intraSlice = (q->intra_slice & ~TU_FLAG_RASTER_ORDER) | (tu_raster_order(true) ? TU_FLAG_RASTER_ORDER : 0);
         a.levels = q->levels; a.numSig = q->num_sig; a.dist = (unsigned long long*)q->dist;
         a.tab = tu_tables_of(TABLES_OF(q));
     }
