@@ -322,3 +322,36 @@ def test_me_minima_only_launch_10bit_both_kernels(case, w2, monkeypatch):
                               want_surf=False, want_best=True)
     gb = ms.best.cpu().numpy().view(np.uint64)
     assert np.array_equal(gb, best), f"X265HIP_ME_W2={w2}: {np.count_nonzero(gb != best)} of {gb.size} minima differ"
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_me_minima_xcd_aware_ctu_order_equals_raster_order_and_the_oracle(depth, monkeypatch):
+    """Round 6: a whole-picture search launch maps workgroup b to a CTU so that every XCD (b % 8) owns a contiguous band of CTUs (xcd_swizzle; the last
+    n % 8 workgroups keep their own index).  60 CTUs = 56 swizzled + 4 not, per-CTU centres included: the minima must equal the raster-order launch
+    (X265HIP_ME_XCD_OFF=1) and the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    width, height, rng = 640, 384, 24
+    clip = F.synth_clip(width, height, 2, depth=depth, seed=77)
+    cur, ref = P.DevicePicture(clip[1][0], dev), P.DevicePicture(clip[0][0], dev)
+    r = np.random.default_rng(6)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("X265HIP_ME_XCD_OFF", "1")
+        else:
+            monkeypatch.delenv("X265HIP_ME_XCD_OFF", raising=False)
+        A.lib().x265hip_me_env_refresh()
+        ms = P.MotionSearch(cur.w64, cur.h64, rng, depth, dev, want_surf=False, lam=4.0)
+        cen = np.random.default_rng(6).integers(-12, 13, size=(ms.nctu, 2)).astype(np.int16)
+        ms.run(cur, ref, centres=torch.from_numpy(cen).to(dev))
+        torch.cuda.synchronize()
+        outs.append(ms.best.cpu().numpy().view(np.uint64).reshape(ms.nctu, 85).copy())
+    assert ms.nctu == 60 and np.array_equal(outs[0], outs[1])
+    O = _oracle()
+    cw = cur.w64 // 64
+    for c in (0, 7, 8, 55, 56, 59):
+        o = cur.org + (c // cw) * 64 * cur.stride + (c % cw) * 64
+        _, best = O.me_fullsearch(depth, cur.host, cur.stride, o, ref.host, ref.stride, o + int(cen[c, 1]) * ref.stride + int(cen[c, 0]), 64, 64, rng, 0, 1,
+                                  ms.cost_host, ms.cost_host, want_surf=False, want_best=True)
+        assert np.array_equal(outs[0][c], best.reshape(-1)), c
