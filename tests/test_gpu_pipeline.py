@@ -182,3 +182,33 @@ def test_search_to_reconstruction_in_parts_leaves_the_same_picture(depth, split,
         for fp, ref in ((whole, refs[0]), (parts, refs[1])):
             for d, s in zip(ref.planes(), fp.final_planes()):
                 d.copy_(s)
+
+
+@pytest.mark.parametrize("depth,width,height", [(8, 192, 128), (10, 320, 192), (8, 64, 64)])
+def test_border_extension_of_a_pictures_planes_in_one_launch(depth, width, height):
+    """x265hip_extend_border_planes (round 6): Y, Cb and Cr of one picture - each with its own geometry - extended by ONE launch must equal the three
+    single-plane calls, which the closed-loop tests hold against the oracle (edge samples replicated into the margins, corners included)."""
+    import torch
+    dev = torch.device("cuda:0")
+    clip = F.synth_clip(width, height, 1, depth=depth, seed=19)
+    y, cb, cr = clip[0]
+    a = P.DevicePicture(y, dev, cb, cr)
+    b = P.DevicePicture(y, dev, cb, cr)
+    for pic in (a, b):              # garbage in the margins: the extension must overwrite every margin sample
+        for p in pic.planes():
+            p.view(torch.uint8).fill_(0x5a)
+    a2, b2 = P.DevicePicture(y, dev, cb, cr), P.DevicePicture(y, dev, cb, cr)
+    # keep the interiors of the fresh pictures, wipe the margins only: copy the interior rows into the garbage-filled planes
+    for dst, src in ((a, a2), (b, b2)):
+        for k, (pd, ps) in enumerate(zip(dst.planes(), src.planes())):
+            st, org, w, h = (dst.stride, dst.org, dst.w64, dst.h64) if k == 0 else (dst.stride_c, dst.org_c, dst.w64 // 2, dst.h64 // 2)
+            for r in range(h):
+                pd.view(-1)[org + r * st: org + r * st + w] = ps.view(-1)[org + r * st: org + r * st + w]
+    S.extend_border(a.t, a)
+    for i in range(2):
+        S.extend_border(a.c[i], a, chroma=True)
+    S.extend_border_picture(b.planes(), b)
+    torch.cuda.synchronize()
+    for pa, pb, pf in zip(a.planes(), b.planes(), a2.planes()):
+        assert torch.equal(pa, pb)
+        assert torch.equal(pa, pf)          # DevicePicture uploads planes whose margins the host already extended

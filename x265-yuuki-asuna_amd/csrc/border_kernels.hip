@@ -49,6 +49,39 @@ __global__ void __launch_bounds__(256) extend_border_kernel(BorderArgs a)
 }
 
 // nplanes planes of one geometry in one launch (the four lookahead planes)
+// the planes of one picture, each with a geometry of its own (blockIdx.y = plane)
+struct BorderArgs3 { void* pic[3]; long stride[3]; int width[3], height[3], marginX[3], marginY[3]; };
+
+template <typename Px>
+__global__ void __launch_bounds__(256) extend_border_planes_kernel(BorderArgs3 a)
+{
+    const int p = blockIdx.y;
+    Px* pic = reinterpret_cast<Px*>(a.pic[p]);
+    const int width = a.width[p], height = a.height[p], marginX = a.marginX[p], marginY = a.marginY[p];
+    const long stride = a.stride[p];
+    const int pw = width + 2 * marginX, sideW = 2 * marginX;
+    const long nBands = (long)pw * (2 * marginY), nSides = (long)height * sideW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nBands + nSides; i += (long)gridDim.x * blockDim.x)
+    {
+        int x, y;
+        if (i < nBands)
+        {
+            const int r = (int)(i / pw);
+            x = (int)(i - (long)r * pw) - marginX;
+            y = r < marginY ? r - marginY : height + (r - marginY);
+        }
+        else
+        {
+            const long j = i - nBands;
+            y = (int)(j / sideW);
+            const int k = (int)(j - (long)y * sideW);
+            x = k < marginX ? k - marginX : width + (k - marginX);
+        }
+        const int sx = x < 0 ? 0 : (x >= width ? width - 1 : x), sy = y < 0 ? 0 : (y >= height ? height - 1 : y);
+        pic[(long)y * stride + x] = pic[(long)sy * stride + sx];
+    }
+}
+
 int extend_borders_tb(void* const* pics, int nplanes, intptr_t stride, int width, int height, int margin_x, int margin_y, int depth, hipStream_t s,
                       int margin_bottom)
 {
@@ -83,6 +116,31 @@ extern "C" int x265hip_extend_border(void* pic, intptr_t stride, int width, int 
     if (depth != 8 && depth != 10 && depth != 12) { set_error("extend_border: depth %d", depth); return X265HIP_EINVAL; }
     void* pics[1] = { pic };
     return extend_borders(pics, 1, stride, width, height, margin_x, margin_y, depth, (hipStream_t)stream);
+}
+
+extern "C" int x265hip_extend_border_planes(const x265hip_border_plane* planes, int nplanes, int depth, void* stream)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!planes || nplanes < 1 || nplanes > 3) { set_error("extend_border_planes: %d planes", nplanes); return X265HIP_EINVAL; }
+    if (depth != 8 && depth != 10 && depth != 12) { set_error("extend_border_planes: depth %d", depth); return X265HIP_EINVAL; }
+    BorderArgs3 a = {};
+    long most = 0;
+    for (int i = 0; i < nplanes; i++)
+    {
+        const x265hip_border_plane& q = planes[i];
+        if (!q.pic || q.width <= 0 || q.height <= 0 || q.margin_x < 0 || q.margin_y < 0) { set_error("extend_border_planes: bad plane %d", i); return X265HIP_EINVAL; }
+        a.pic[i] = q.pic; a.stride[i] = (long)q.stride; a.width[i] = q.width; a.height[i] = q.height; a.marginX[i] = q.margin_x; a.marginY[i] = q.margin_y;
+        const long total = (long)(q.width + 2 * q.margin_x) * (2 * q.margin_y) + (long)q.height * 2 * q.margin_x;
+        most = total > most ? total : most;
+    }
+    if (most <= 0) return 0;
+    int blocks = (int)((most + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (depth == 8) hipLaunchKernelGGL(extend_border_planes_kernel<uint8_t>, dim3(blocks, nplanes), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(extend_border_planes_kernel<uint16_t>, dim3(blocks, nplanes), dim3(256), 0, (hipStream_t)stream, a);
+    X265HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 /* A band of rows of a picture: (0,0) = the first sample of the band's first row; the left / right margins of its `height` rows are

@@ -221,6 +221,24 @@ def extend_border(plane, pic: DevicePicture, stream=None, chroma=False):
                  "x265hip_extend_border")
 
 
+class BorderPlane(ctypes.Structure):
+    _fields_ = [("pic", ctypes.c_void_p), ("stride", ctypes.c_ssize_t), ("width", ctypes.c_int), ("height", ctypes.c_int), ("margin_x", ctypes.c_int), ("margin_y", ctypes.c_int)]
+
+
+def extend_border_picture(planes, pic: DevicePicture, stream=None):
+    """extend_border of [Y, Cb, Cr] (or [Y]) of one picture as ONE launch (x265hip_extend_border_planes)."""
+    from . import frames as F
+    es = 1 if pic.depth == 8 else 2
+    s = hipabi.current_stream() if stream is None else stream
+    arr = (BorderPlane * len(planes))()
+    arr[0] = BorderPlane(planes[0].data_ptr() + pic.org * es, pic.stride, pic.w64, pic.h64, F.MARGIN_X, F.MARGIN_Y)
+    for i in range(1, len(planes)):
+        arr[i] = BorderPlane(planes[i].data_ptr() + pic.org_c * es, pic.stride_c, pic.w64 // 2, pic.h64 // 2, F.CHROMA_MARGIN_X, F.CHROMA_MARGIN_Y)
+    f = hipabi.lib().x265hip_extend_border_planes
+    f.argtypes = [ctypes.POINTER(BorderPlane), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    hipabi.check(f(arr, len(planes), pic.depth, s), "x265hip_extend_border_planes")
+
+
 # g_chromaScale (constants.cpp:346-350) as Quant::setChromaQP applies it to 4:2:0 pictures (quant.cpp:233-244)
 _CHROMA_SCALE = list(range(30)) + [29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37] + list(range(38, 52)) + [51] * 12
 
@@ -927,9 +945,12 @@ class FramePipeline:
         main.wait_event(ev_cstats)
         self._sao_rdo()
         hipabi.sao_apply_planes(self.depth, planes)
-        extend_border(self.out, cur)
-        for i in range(2):                                # the three border launches back to back: 15 us, no hand-over
-            extend_border(self.out_c[i], cur, chroma=True)
+        if os.environ.get("X265HIP_BORDER_PLANES", "1") == "0":       # A/B: three launches back to back (15 us) instead of one
+            extend_border(self.out, cur)
+            for i in range(2):
+                extend_border(self.out_c[i], cur, chroma=True)
+        else:
+            extend_border_picture([self.out] + list(self.out_c), cur)
         main.wait_event(ev_side)                          # the lookahead and the cleared minima (long done: next to the SAO decision)
         self.final, self.final_c = self.out, self.out_c
         return self.final
