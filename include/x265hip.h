@@ -307,7 +307,7 @@ int x265hip_inter_recon_chroma_bi(const x265hip_recon_bi_params* p, void* stream
 int x265hip_extend_border(void* pic, intptr_t stride, int width, int height, int margin_x, int margin_y, int depth, void* stream);
 /* round 6: the planes of ONE picture (Y, Cb, Cr - each with its own geometry) in one launch: the three back-to-back launches of a 4:2:0 picture were 15 us of
  * the step for 2 MB of copies (PicYuv's planes after FrameFilter finished the picture, framefilter.cpp:346-436 / picyuv.cpp). */
-typedef struct x265hip_border_plane { void* pic; intptr_t stride; int width, height, margin_x, margin_y; } x265hip_border_plane;
+typedef struct x265hip_border_plane { void* pic; intptr_t stride; int width, height, margin_x, margin_top, margin_bottom; } x265hip_border_plane;   /* a whole picture: margin_top = margin_bottom = its margin; a band of rows: as x265hip_extend_border_rows (either may be 0) */
 int x265hip_extend_border_planes(const x265hip_border_plane* planes, int nplanes, int depth, void* stream);
 /* the row-wise form FrameFilter uses (framefilter.cpp:346-436): `band` = first sample of a band of `height` rows; left / right margins of
  * those rows, margin_top rows above (first band of a picture) and margin_bottom rows below (last band), either may be 0 */

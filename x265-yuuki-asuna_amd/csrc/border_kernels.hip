@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) extend_border_kernel(BorderArgs a)
 
 // nplanes planes of one geometry in one launch (the four lookahead planes)
 // the planes of one picture, each with a geometry of its own (blockIdx.y = plane)
-struct BorderArgs3 { void* pic[3]; long stride[3]; int width[3], height[3], marginX[3], marginY[3]; };
+struct BorderArgs3 { void* pic[3]; long stride[3]; int width[3], height[3], marginX[3], marginY[3], marginBottom[3]; };
 
 template <typename Px>
 __global__ void __launch_bounds__(256) extend_border_planes_kernel(BorderArgs3 a)
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) extend_border_planes_kernel(BorderArgs3 a
     const int width = a.width[p], height = a.height[p], marginX = a.marginX[p], marginY = a.marginY[p];
     const long stride = a.stride[p];
     const int pw = width + 2 * marginX, sideW = 2 * marginX;
-    const long nBands = (long)pw * (2 * marginY), nSides = (long)height * sideW;
+    const long nBands = (long)pw * (marginY + a.marginBottom[p]), nSides = (long)height * sideW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nBands + nSides; i += (long)gridDim.x * blockDim.x)
     {
         int x, y;
@@ -129,9 +129,9 @@ extern "C" int x265hip_extend_border_planes(const x265hip_border_plane* planes, 
     for (int i = 0; i < nplanes; i++)
     {
         const x265hip_border_plane& q = planes[i];
-        if (!q.pic || q.width <= 0 || q.height <= 0 || q.margin_x < 0 || q.margin_y < 0) { set_error("extend_border_planes: bad plane %d", i); return X265HIP_EINVAL; }
-        a.pic[i] = q.pic; a.stride[i] = (long)q.stride; a.width[i] = q.width; a.height[i] = q.height; a.marginX[i] = q.margin_x; a.marginY[i] = q.margin_y;
-        const long total = (long)(q.width + 2 * q.margin_x) * (2 * q.margin_y) + (long)q.height * 2 * q.margin_x;
+        if (!q.pic || q.width <= 0 || q.height <= 0 || q.margin_x < 0 || q.margin_top < 0 || q.margin_bottom < 0) { set_error("extend_border_planes: bad plane %d", i); return X265HIP_EINVAL; }
+        a.pic[i] = q.pic; a.stride[i] = (long)q.stride; a.width[i] = q.width; a.height[i] = q.height; a.marginX[i] = q.margin_x; a.marginY[i] = q.margin_top; a.marginBottom[i] = q.margin_bottom;
+        const long total = (long)(q.width + 2 * q.margin_x) * (q.margin_top + q.margin_bottom) + (long)q.height * 2 * q.margin_x;
         most = total > most ? total : most;
     }
     if (most <= 0) return 0;

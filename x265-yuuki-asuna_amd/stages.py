@@ -222,18 +222,21 @@ def extend_border(plane, pic: DevicePicture, stream=None, chroma=False):
 
 
 class BorderPlane(ctypes.Structure):
-    _fields_ = [("pic", ctypes.c_void_p), ("stride", ctypes.c_ssize_t), ("width", ctypes.c_int), ("height", ctypes.c_int), ("margin_x", ctypes.c_int), ("margin_y", ctypes.c_int)]
+    _fields_ = [("pic", ctypes.c_void_p), ("stride", ctypes.c_ssize_t), ("width", ctypes.c_int), ("height", ctypes.c_int), ("margin_x", ctypes.c_int),
+                ("margin_top", ctypes.c_int), ("margin_bottom", ctypes.c_int)]
 
 
-def extend_border_picture(planes, pic: DevicePicture, stream=None):
-    """extend_border of [Y, Cb, Cr] (or [Y]) of one picture as ONE launch (x265hip_extend_border_planes)."""
+def extend_border_picture(planes, pic: DevicePicture, stream=None, top=True, bottom=True):
+    """extend_border of [Y, Cb, Cr] (or [Y]) of one picture as ONE launch (x265hip_extend_border_planes); `pic` a band view with top / bottom =
+    whether it is the picture's first / last band: the row-wise form (extend_border_rows) of all planes at once."""
     from . import frames as F
     es = 1 if pic.depth == 8 else 2
     s = hipabi.current_stream() if stream is None else stream
     arr = (BorderPlane * len(planes))()
-    arr[0] = BorderPlane(planes[0].data_ptr() + pic.org * es, pic.stride, pic.w64, pic.h64, F.MARGIN_X, F.MARGIN_Y)
+    arr[0] = BorderPlane(planes[0].data_ptr() + pic.org * es, pic.stride, pic.w64, pic.h64, F.MARGIN_X, F.MARGIN_Y if top else 0, F.MARGIN_Y if bottom else 0)
     for i in range(1, len(planes)):
-        arr[i] = BorderPlane(planes[i].data_ptr() + pic.org_c * es, pic.stride_c, pic.w64 // 2, pic.h64 // 2, F.CHROMA_MARGIN_X, F.CHROMA_MARGIN_Y)
+        arr[i] = BorderPlane(planes[i].data_ptr() + pic.org_c * es, pic.stride_c, pic.w64 // 2, pic.h64 // 2, F.CHROMA_MARGIN_X,
+                             F.CHROMA_MARGIN_Y if top else 0, F.CHROMA_MARGIN_Y if bottom else 0)
     f = hipabi.lib().x265hip_extend_border_planes
     f.argtypes = [ctypes.POINTER(BorderPlane), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     hipabi.check(f(arr, len(planes), pic.depth, s), "x265hip_extend_border_planes")
@@ -762,12 +765,18 @@ class FramePipeline:
                         self.sao_c[i].apply(self.recon_c[i], cur.stride_c, cur.org_c, self.out_c[i])
                     final_c = self.out_c
                 mark("sao_apply")
+        one_launch = os.environ.get("X265HIP_BORDER_PLANES", "1") != "0"          # round 6: the picture's (band's) planes in one launch
         if self.band_border is not None:
             top, bottom = self.band_border
-            extend_border_rows(final, cur, top, bottom)
-            if self.chroma:
-                for i in range(2):
-                    extend_border_rows(final_c[i], cur, top, bottom, chroma=True)
+            if one_launch:
+                extend_border_picture([final] + (list(final_c) if self.chroma else []), cur, top=top, bottom=bottom)
+            else:
+                extend_border_rows(final, cur, top, bottom)
+                if self.chroma:
+                    for i in range(2):
+                        extend_border_rows(final_c[i], cur, top, bottom, chroma=True)
+        elif one_launch:
+            extend_border_picture([final] + (list(final_c) if self.chroma else []), cur)
         else:
             extend_border(final, cur)
             if self.chroma:
