@@ -295,14 +295,15 @@ def valu_bound(nctu, rng_r, depth, launch_ms):
 # launch dealt over several workgroups at 8 bits): profiles/r05_band_tables.txt (tools/r4_band_tables.sh; round 4's: profiles/r04_band_tables.txt).  Small bands cost launches whose grids no longer fill the
 # chip; large bands make the next rank wait longer for its first reference rows.
 BANDED_STEP_MS = {
-    (8, "4k"): {1: 5.54, 2: 2.94, 3: 2.48, 4: 2.38, 5: 2.52, 6: 2.31, 8: 2.24, 12: 2.12, 17: 2.03},
-    (10, "4k"): {2: 4.38, 3: 3.99, 4: 3.78, 6: 3.62, 8: 3.59, 12: 3.31, 17: 3.25},
-    (10, "8k"): {4: 13.13, 6: 12.72, 8: 12.58, 12: 12.34, 17: 12.51, 34: 12.23},
-    (8, "1080p"): {1: 2.82, 2: 1.73, 3: 1.17, 5: 0.90, 9: 0.82},
+    # (round 6 closing library, visit r9j: one border launch per band, XCD-ordered kernels; round 5's table: 4K 8-bit 4 rows 2.38, 1 row 5.54)
+    (8, "4k"): {1: 4.81, 2: 2.68, 3: 2.36, 4: 2.29, 5: 2.40, 6: 2.23, 8: 2.17, 12: 2.09, 17: 2.00},
+    (10, "4k"): {2: 4.37, 3: 4.00, 4: 3.74, 6: 3.61, 8: 3.50, 12: 3.26, 17: 3.19},
+    (10, "8k"): {4: 13.02, 6: 12.60, 8: 12.25, 12: 12.27, 17: 12.46, 34: 12.19},
+    (8, "1080p"): {1: 2.53, 2: 1.26, 3: 0.97, 5: 0.86, 9: 0.80},
 }
 # configurations without a table of their own borrow the nearest one, scaled by the whole-picture steps (ms, same round)
-WHOLE_STEP_MS = {(8, "4k"): 1.64, (10, "4k"): 2.92, (12, "4k"): 2.92, (8, "8k"): 6.6, (10, "8k"): 11.45, (12, "8k"): 11.45, (8, "1080p"): 0.60, (10, "1080p"): 0.95,
-                 (12, "1080p"): 0.95}
+WHOLE_STEP_MS = {(8, "4k"): 1.62, (10, "4k"): 2.87, (12, "4k"): 2.87, (8, "8k"): 6.5, (10, "8k"): 11.30, (12, "8k"): 11.30, (8, "1080p"): 0.56, (10, "1080p"): 0.93,
+                 (12, "1080p"): 0.93}
 
 
 def pick_band_rows(world, ctu_rows=34, lag_rows_luma=73, depth=8, width=3840):

@@ -9,7 +9,7 @@ import bench as B          # noqa: E402
 
 
 def main():
-    print("# bench.ring_model: x one GPU (whole-picture step) delivered by N ranks; band tables profiles/r05_band_tables.txt; chain = frame f reads f - 1, gop5 = every picture reads the")
+    print("# bench.ring_model: x one GPU (whole-picture step) delivered by N ranks; band tables profiles/r06_band_tables.txt (round 5: r05_band_tables.txt); chain = frame f reads f - 1, gop5 = every picture reads the")
     print("# newest multiple of 5 before it (FrameParallelRing(gop=5), bench.py --ring-gop 5).  The ceiling of the banded ring is N x whole / banded step (the banded step costs more")
     print("# than the whole-picture one: no phase planes, one stream per band); * = the band size bench.py picks")
     for name, depth, width, ctu_rows in (("4K 8-bit", 8, 3840, 34), ("4K 10-bit", 10, 3840, 34), ("8K 10-bit", 10, 7680, 68), ("1080p 8-bit", 8, 1920, 17)):
