@@ -202,37 +202,66 @@ __global__ void __launch_bounds__(256) sao_apply_kernel(SaoApplyArgs3 aa)
     const long sst = a.srcStrideB / BPP, dst_st = a.dstStrideB / BPP;
     const Px* src = reinterpret_cast<const Px*>(a.src);
     Px* dst = reinterpret_cast<Px*>(a.dst);
-    // a lane owns one column (unit-stride loads and stores across the wavefront), a wavefront every fourth row
-    const int x = lpelx + (tid & 63);
-    if ((tid & 63) >= a.ctuW || x >= a.width) return;
+    // round 6 (closing): a lane owns FOUR consecutive samples of a row - one dword (two for 16-bit samples) per load / store where the first version moved
+    // one sample per lane and instruction (three loads + one store per sample for an edge class); the neighbours of the four samples come as two more
+    // (unaligned) loads of four.  The planes are padded pictures: the sample beyond a picture edge that such a load touches exists, and is never used.
+    const int qpr = (a.ctuW + 3) >> 2, rowsPerPass = 256 / qpr;                 // quads per CTU row: 16 (64-wide CTUs) / 8 (32-wide chroma footprints)
+    const int xl = (tid % qpr) * 4, x = lpelx + xl;
+    if (x >= a.width) return;
     // neighbour step of the edge classes: EO_0 horizontal, EO_1 vertical, EO_2 135 degrees, EO_3 45 degrees
     const int dx = typeIdx == 1 ? 0 : (typeIdx == 3 ? -1 : 1), dy = typeIdx == 0 ? 0 : 1;
-    const bool okx = !dx || (x > 0 && x < a.width - 1);
-    for (int i = 0; i < 16; i++)
+    auto load4 = [&](const Px* q, int (&v)[4])
     {
-        const int yl = (tid >> 6) + 4 * i, y = tpely + yl;
-        if (yl >= a.ctuH || y >= a.height) break;
-        const bool oky = !dy || (y > 0 && y < a.height - 1);
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(q);
+        if (BPP == 1) { const uint32_t w = ld_u32(b); v[0] = w & 0xff; v[1] = (w >> 8) & 0xff; v[2] = (w >> 16) & 0xff; v[3] = w >> 24; }
+        else { const uint32_t w0 = ld_u32(b), w1 = ld_u32(b + 4); v[0] = w0 & 0xffff; v[1] = w0 >> 16; v[2] = w1 & 0xffff; v[3] = w1 >> 16; }
+    };
+    const bool whole = x + 3 < a.width;
+    for (int yl = tid / qpr; yl < a.ctuH; yl += rowsPerPass)
+    {
+        const int y = tpely + yl;
+        if (y >= a.height) break;
         const Px* c = src + x + (long)y * sst;
-        int v = *c;
+        int v[4];
+        load4(c, v);
         if (typeIdx == 4)
         {
-            const int k = ((v >> boShift) - bandPos) & 31;                  // offset[i] sits on band (bandPos + i) mod 32
-            const int off = k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : (k == 3 ? o3 : 0)));
-            v = clip3(0, maxVal, v + off);
-        }
-        else if (typeIdx >= 0)
-        {
-            if (okx && oky)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
             {
-                const int na = c[-dx - dy * sst], nb = c[dx + dy * sst];
-                const int e = sao_sign(v - na) + sao_sign(v - nb) + 2;
-                // offsetEo[e] = offset[s_eoTable[e]] with offset[] = { 0, o0, o1, o2, o3 }, s_eoTable = { 1, 2, 0, 3, 4 }
-                const int off = e == 0 ? o0 : (e == 1 ? o1 : (e == 2 ? 0 : (e == 3 ? o2 : o3)));
-                v = clip3(0, maxVal, v + off);
+                const int k = ((v[j] >> boShift) - bandPos) & 31;                  // offset[i] sits on band (bandPos + i) mod 32
+                const int off = k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : (k == 3 ? o3 : 0)));
+                v[j] = clip3(0, maxVal, v[j] + off);
             }
         }
-        dst[x + (long)y * dst_st] = (Px)v;
+        else if (typeIdx >= 0 && (!dy || (y > 0 && y < a.height - 1)))
+        {
+            int na[4], nb[4];
+            load4(c - dx - dy * sst, na);
+            load4(c + dx + dy * sst, nb);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                if (dx && !(x + j > 0 && x + j < a.width - 1)) continue;
+                const int e = sao_sign(v[j] - na[j]) + sao_sign(v[j] - nb[j]) + 2;
+                // offsetEo[e] = offset[s_eoTable[e]] with offset[] = { 0, o0, o1, o2, o3 }, s_eoTable = { 1, 2, 0, 3, 4 }
+                const int off = e == 0 ? o0 : (e == 1 ? o1 : (e == 2 ? 0 : (e == 3 ? o2 : o3)));
+                v[j] = clip3(0, maxVal, v[j] + off);
+            }
+        }
+        Px* d = dst + x + (long)y * dst_st;
+        if (whole)
+        {
+            uint8_t* b = reinterpret_cast<uint8_t*>(d);
+            if (BPP == 1) *reinterpret_cast<u32_unaligned*>(b) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+            else
+            {
+                reinterpret_cast<u32_unaligned*>(b)[0] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+                reinterpret_cast<u32_unaligned*>(b)[1] = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+            }
+        }
+        else
+            for (int j = 0; j < 4 && x + j < a.width; j++) d[j] = (Px)v[j];
     }
 }
 
