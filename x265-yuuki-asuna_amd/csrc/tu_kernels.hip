@@ -493,15 +493,29 @@ __device__ __forceinline__ void tu_chain(const TuOpsFor<N, DST>& ops, const int1
                     // pass 2: r[j][k] = sum_i M[i][k] * out1[i][j]
                     if (iv.kvalid) lds_col16(A + kb * N + rn, d);
                     iv.product(d, p);
+                    // a lane's accumulator rows come in runs of four consecutive k of output row j: one 4-byte (8-byte) store per run instead of four single-sample
+                    // stores (16 store instructions per 32 x 32 block, every one of them 64 scattered bytes)
+                    int vq[4];
 #pragma unroll
                     for (int r = 0; r < MF::NACC; r++)
                     {
                         const int j = MF::col(lane), k = MF::row(lane, r);
                         const int res = tu_sat16((p[r] + (1 << (shI - 1))) >> shI);
                         const int v = clip3(0, maxVal, (int)pred[j * N + k] + res);
-                        rec[j * cst + k] = (Px)v;
+                        vq[r & 3] = v;
                         const int dd = (int)fe[j * N + k] - v;
                         part += (unsigned)(dd * dd);
+                        if ((r & 3) == 3)
+                        {
+                            uint8_t* rp = reinterpret_cast<uint8_t*>(rec + j * cst + (k - 3));
+                            if (sizeof(Px) == 1)
+                                *reinterpret_cast<u32_unaligned*>(rp) = (uint32_t)vq[0] | ((uint32_t)vq[1] << 8) | ((uint32_t)vq[2] << 16) | ((uint32_t)vq[3] << 24);
+                            else
+                            {
+                                reinterpret_cast<u32_unaligned*>(rp)[0] = (uint32_t)vq[0] | ((uint32_t)vq[1] << 16);
+                                reinterpret_cast<u32_unaligned*>(rp)[1] = (uint32_t)vq[2] | ((uint32_t)vq[3] << 16);
+                            }
+                        }
                     }
                 }
             }
