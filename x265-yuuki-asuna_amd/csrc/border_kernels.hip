@@ -55,30 +55,55 @@ struct BorderArgs3 { void* pic[3]; long stride[3]; int width[3], height[3], marg
 template <typename Px>
 __global__ void __launch_bounds__(256) extend_border_planes_kernel(BorderArgs3 a)
 {
+    // a thread writes FOUR consecutive margin samples (one 4- / 8-byte store; the first version moved one sample per thread): the items are quads of the
+    // top / bottom margin rows (whole padded rows: copies of the first / last picture row, whose own side margins are the edge samples) and quads of the
+    // left / right margins of the picture's rows (the row's edge sample four times).  Widths and margins of x265's planes are multiples of 4.
     const int p = blockIdx.y;
     Px* pic = reinterpret_cast<Px*>(a.pic[p]);
     const int width = a.width[p], height = a.height[p], marginX = a.marginX[p], marginY = a.marginY[p];
     const long stride = a.stride[p];
     const int pw = width + 2 * marginX, sideW = 2 * marginX;
-    const long nBands = (long)pw * (marginY + a.marginBottom[p]), nSides = (long)height * sideW;
+    const bool quads = !((width | marginX) & 3);
+    const int Q = quads ? 4 : 1;
+    const long nBands = (long)(pw / Q) * (marginY + a.marginBottom[p]), nSides = (long)height * (sideW / Q);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nBands + nSides; i += (long)gridDim.x * blockDim.x)
     {
         int x, y;
         if (i < nBands)
         {
-            const int r = (int)(i / pw);
-            x = (int)(i - (long)r * pw) - marginX;
+            const int r = (int)(i / (pw / Q));
+            x = (int)(i - (long)r * (pw / Q)) * Q - marginX;
             y = r < marginY ? r - marginY : height + (r - marginY);
         }
         else
         {
             const long j = i - nBands;
-            y = (int)(j / sideW);
-            const int k = (int)(j - (long)y * sideW);
+            y = (int)(j / (sideW / Q));
+            const int k = (int)(j - (long)y * (sideW / Q)) * Q;
             x = k < marginX ? k - marginX : width + (k - marginX);
         }
-        const int sx = x < 0 ? 0 : (x >= width ? width - 1 : x), sy = y < 0 ? 0 : (y >= height ? height - 1 : y);
-        pic[(long)y * stride + x] = pic[(long)sy * stride + sx];
+        const int sy = y < 0 ? 0 : (y >= height ? height - 1 : y);
+        Px v[4];
+        const Px* srow = pic + (long)sy * stride;
+        if (quads && x >= 0 && x + 4 <= width)
+        {   // a quad never straddles the picture edge (x, width, marginX are multiples of 4): four samples of the first / last row
+            const uint8_t* b = reinterpret_cast<const uint8_t*>(srow + x);
+            if (sizeof(Px) == 1) { const uint32_t w = ld_u32(b); v[0] = (Px)(w & 0xff); v[1] = (Px)((w >> 8) & 0xff); v[2] = (Px)((w >> 16) & 0xff); v[3] = (Px)(w >> 24); }
+            else { const uint32_t w0 = ld_u32(b), w1 = ld_u32(b + 4); v[0] = (Px)(w0 & 0xffff); v[1] = (Px)(w0 >> 16); v[2] = (Px)(w1 & 0xffff); v[3] = (Px)(w1 >> 16); }
+        }
+        else
+        {
+            const Px e = srow[x < 0 ? 0 : (x >= width ? width - 1 : x)];
+            v[0] = v[1] = v[2] = v[3] = e;
+        }
+        Px* d = pic + (long)y * stride + x;
+        if (!quads) d[0] = v[0];
+        else if (sizeof(Px) == 1) *reinterpret_cast<u32_unaligned*>(d) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+        else
+        {
+            reinterpret_cast<u32_unaligned*>(d)[0] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+            reinterpret_cast<u32_unaligned*>(d)[1] = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+        }
     }
 }
 
@@ -131,7 +156,8 @@ extern "C" int x265hip_extend_border_planes(const x265hip_border_plane* planes, 
         const x265hip_border_plane& q = planes[i];
         if (!q.pic || q.width <= 0 || q.height <= 0 || q.margin_x < 0 || q.margin_top < 0 || q.margin_bottom < 0) { set_error("extend_border_planes: bad plane %d", i); return X265HIP_EINVAL; }
         a.pic[i] = q.pic; a.stride[i] = (long)q.stride; a.width[i] = q.width; a.height[i] = q.height; a.marginX[i] = q.margin_x; a.marginY[i] = q.margin_top; a.marginBottom[i] = q.margin_bottom;
-        const long total = (long)(q.width + 2 * q.margin_x) * (q.margin_top + q.margin_bottom) + (long)q.height * 2 * q.margin_x;
+        const int quad = ((q.width | q.margin_x) & 3) ? 1 : 4;
+        const long total = ((long)(q.width + 2 * q.margin_x) * (q.margin_top + q.margin_bottom) + (long)q.height * 2 * q.margin_x) / quad;
         most = total > most ? total : most;
     }
     if (most <= 0) return 0;

@@ -98,10 +98,14 @@ __device__ __forceinline__ void subpel_level(const SubpelArgs& a, uint8_t* smemR
     {
         const Px* fe = reinterpret_cast<const Px*>(a.fenc + (long)(cy + byz * N + ty * 4) * a.fencStrideB) + (cx + bxz * N + tx * 4);
         const long fst = a.fencStrideB / BPP;
+        // the tile's rows as one dword (two for 16-bit samples) each: sixteen single-sample loads were a quarter of the kernel's load instructions
 #pragma unroll
         for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++) src[y][x] = fe[y * fst + x];
+        {
+            const uint8_t* rp = reinterpret_cast<const uint8_t*>(fe + y * fst);
+            if (BPP == 1) { const uint32_t w = ld_u32(rp); src[y][0] = w & 0xff; src[y][1] = (w >> 8) & 0xff; src[y][2] = (w >> 16) & 0xff; src[y][3] = w >> 24; }
+            else { const uint32_t w0 = ld_u32(rp), w1 = ld_u32(rp + 4); src[y][0] = w0 & 0xffff; src[y][1] = w0 >> 16; src[y][2] = w1 & 0xffff; src[y][3] = w1 >> 16; }
+        }
     }
     // The tile's rows as two packed int16 pairs each - columns (0, 2) / (1, 3) for 8-bit samples (what two masks make of a loaded dword),
     // (0, 1) / (2, 3) for 16-bit ones (the dwords as loaded): the difference, the 4x4 Hadamard and the absolute sums below run on
